@@ -1,0 +1,159 @@
+/* ref_shim.cpp — TEST INFRASTRUCTURE ONLY.
+ *
+ * A thin extern "C" window onto the REAL x265 reference, linked together with the reference's own objects into
+ * oracle/_ref/libx265ref{8,10}.so by oracle/Makefile.  Nothing here re-implements anything: every entry point
+ * dispatches through the reference's C primitive table (setupCPrimitives + setupAliasPrimitives,
+ * common/primitives.cpp:63-73, :88-209) or drives the reference's MotionEstimate / BitCost classes
+ * (encoder/motion.cpp, encoder/bitcost.cpp).  It is how oracle/x265_oracle.c gets pinned to the reference.
+ *
+ * `part` = LumaPU enum (common/primitives.h:41-55), `cu` = LumaCU enum (:57-65, log2(size)-2).
+ * Pixel pointers are uint8_t* in the 8-bit build and uint16_t* in the 10-bit build (common/common.h:126-142).
+ */
+#include "common.h"
+#include "primitives.h"
+#include "bitcost.h"
+#include "motion.h"
+#include "lowres.h"
+#include "yuv.h"
+#include "x265.h"
+
+using namespace X265_NS;
+
+namespace {
+EncoderPrimitives& T()
+{
+    static bool done = false;
+    if (!done)
+    {
+        /* fill the GLOBAL table too: MotionEstimate and the hv filters read it */
+        setupCPrimitives(primitives);
+        setupAliasPrimitives(primitives);
+        done = true;
+    }
+    return primitives;
+}
+
+struct CostProbe : public BitCost
+{
+    const uint16_t* table() const { return m_cost; }
+};
+}
+
+extern "C" {
+
+int ref_depth() { return X265_DEPTH; }
+int ref_sizeof_pixel() { return (int)sizeof(pixel); }
+
+/* ---- pixel compare ---- */
+int ref_sad(int part, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { return T().pu[part].sad(a, sa, b, sb); }
+void ref_sad_x3(int part, const pixel* f, const pixel* r0, const pixel* r1, const pixel* r2, intptr_t rs, int32_t* res) { T().pu[part].sad_x3(f, r0, r1, r2, rs, res); }
+void ref_sad_x4(int part, const pixel* f, const pixel* r0, const pixel* r1, const pixel* r2, const pixel* r3, intptr_t rs, int32_t* res) { T().pu[part].sad_x4(f, r0, r1, r2, r3, rs, res); }
+int ref_satd(int part, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { return T().pu[part].satd(a, sa, b, sb); }
+int ref_sa8d(int cu, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { return T().cu[cu].sa8d(a, sa, b, sb); }
+int ref_chroma_satd(int part, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
+{
+    pixelcmp_t f = T().chroma[X265_CSP_I420].pu[part].satd;
+    return f ? f(a, sa, b, sb) : -1;
+}
+int ref_chroma_sa8d(int cu, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
+{
+    pixelcmp_t f = T().chroma[X265_CSP_I420].cu[cu].sa8d;
+    return f ? f(a, sa, b, sb) : -1;
+}
+uint64_t ref_sse_pp(int cu, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { return T().cu[cu].sse_pp(a, sa, b, sb); }
+uint64_t ref_sse_ss(int cu, const int16_t* a, intptr_t sa, const int16_t* b, intptr_t sb) { return T().cu[cu].sse_ss(a, sa, b, sb); }
+uint64_t ref_ssd_s(int cu, const int16_t* a, intptr_t sa) { return T().cu[cu].ssd_s[NONALIGNED](a, sa); }
+int ref_psy_cost_pp(int cu, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { return T().cu[cu].psy_cost_pp(a, sa, b, sb); }
+uint64_t ref_var(int cu, const pixel* a, intptr_t sa) { return T().cu[cu].var(a, sa); }
+
+/* ---- block arithmetic / copies ---- */
+void ref_sub_ps(int cu, int16_t* d, intptr_t ds, const pixel* a, const pixel* b, intptr_t sa, intptr_t sb) { T().cu[cu].sub_ps(d, ds, a, b, sa, sb); }
+void ref_add_ps(int cu, pixel* d, intptr_t ds, const pixel* a, const int16_t* r, intptr_t sa, intptr_t sr) { T().cu[cu].add_ps[NONALIGNED](d, ds, a, r, sa, sr); }
+void ref_calcresidual(int cu, const pixel* f, const pixel* p, int16_t* r, intptr_t s) { T().cu[cu].calcresidual[NONALIGNED](f, p, r, s); }
+void ref_addAvg(int part, const int16_t* a, const int16_t* b, pixel* d, intptr_t sa, intptr_t sb, intptr_t ds) { T().pu[part].addAvg[NONALIGNED](a, b, d, sa, sb, ds); }
+void ref_pixelavg_pp(int part, pixel* d, intptr_t ds, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { T().pu[part].pixelavg_pp[NONALIGNED](d, ds, a, sa, b, sb, 32); }
+void ref_copy_pp(int part, pixel* d, intptr_t ds, const pixel* s, intptr_t ss) { T().pu[part].copy_pp(d, ds, s, ss); }
+void ref_copy_sp(int cu, pixel* d, intptr_t ds, const int16_t* s, intptr_t ss) { T().cu[cu].copy_sp(d, ds, s, ss); }
+void ref_copy_ps(int cu, int16_t* d, intptr_t ds, const pixel* s, intptr_t ss) { T().cu[cu].copy_ps(d, ds, s, ss); }
+void ref_copy_ss(int cu, int16_t* d, intptr_t ds, const int16_t* s, intptr_t ss) { T().cu[cu].copy_ss(d, ds, s, ss); }
+void ref_blockfill_s(int cu, int16_t* d, intptr_t ds, int16_t v) { T().cu[cu].blockfill_s[NONALIGNED](d, ds, v); }
+void ref_cpy2Dto1D_shl(int cu, int16_t* d, const int16_t* s, intptr_t ss, int sh) { T().cu[cu].cpy2Dto1D_shl(d, s, ss, sh); }
+void ref_cpy2Dto1D_shr(int cu, int16_t* d, const int16_t* s, intptr_t ss, int sh) { T().cu[cu].cpy2Dto1D_shr(d, s, ss, sh); }
+void ref_cpy1Dto2D_shl(int cu, int16_t* d, const int16_t* s, intptr_t ds, int sh) { T().cu[cu].cpy1Dto2D_shl[NONALIGNED](d, s, ds, sh); }
+void ref_cpy1Dto2D_shr(int cu, int16_t* d, const int16_t* s, intptr_t ds, int sh) { T().cu[cu].cpy1Dto2D_shr(d, s, ds, sh); }
+uint32_t ref_copy_cnt(int cu, int16_t* c, const int16_t* r, intptr_t rs) { return T().cu[cu].copy_cnt(c, r, rs); }
+int ref_count_nonzero(int cu, const int16_t* q) { return T().cu[cu].count_nonzero(q); }
+
+/* ---- transforms ---- */
+void ref_dct(int cu, const int16_t* s, int16_t* d, intptr_t ss) { T().cu[cu].dct(s, d, ss); }
+void ref_idct(int cu, const int16_t* s, int16_t* d, intptr_t ds) { T().cu[cu].idct(s, d, ds); }
+void ref_dst4(const int16_t* s, int16_t* d, intptr_t ss) { T().dst4x4(s, d, ss); }
+void ref_idst4(const int16_t* s, int16_t* d, intptr_t ds) { T().idst4x4(s, d, ds); }
+uint32_t ref_quant(const int16_t* c, const int32_t* qc, int32_t* du, int16_t* q, int qBits, int add, int n) { return T().quant(c, qc, du, q, qBits, add, n); }
+uint32_t ref_nquant(const int16_t* c, const int32_t* qc, int16_t* q, int qBits, int add, int n) { return T().nquant(c, qc, q, qBits, add, n); }
+void ref_dequant_normal(const int16_t* q, int16_t* c, int n, int scale, int shift) { T().dequant_normal(q, c, n, scale, shift); }
+void ref_dequant_scaling(const int16_t* q, const int32_t* dq, int16_t* c, int n, int per, int shift) { T().dequant_scaling(q, dq, c, n, per, shift); }
+void ref_denoise_dct(int16_t* c, uint32_t* rs, const uint16_t* off, int n) { T().denoiseDct(c, rs, off, n); }
+void ref_nonpsy_rdoquant(int cu, int16_t* r, int64_t* cu_, int64_t* tu, int64_t* tr, uint32_t pos) { T().cu[cu].nonPsyRdoQuant(r, cu_, tu, tr, pos); }
+void ref_psy_rdoquant(int cu, int16_t* r, int16_t* f, int64_t* cu_, int64_t* tu, int64_t* tr, int64_t* ps, uint32_t pos) { T().cu[cu].psyRdoQuant(r, f, cu_, tu, tr, ps, pos); }
+void ref_psy_rdoquant_1p(int cu, int16_t* r, int64_t* cu_, int64_t* tu, int64_t* tr, uint32_t pos) { T().cu[cu].psyRdoQuant_1p(r, cu_, tu, tr, pos); }
+void ref_psy_rdoquant_2p(int cu, int16_t* r, int16_t* f, int64_t* cu_, int64_t* tu, int64_t* tr, int64_t* ps, uint32_t pos) { T().cu[cu].psyRdoQuant_2p(r, f, cu_, tu, tr, ps, pos); }
+
+/* ---- interpolation: chroma != 0 selects the 4:2:0 4-tap table entry of the same LumaPU index ---- */
+void ref_interp_hpp(int chroma, int part, const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int idx)
+{ (chroma ? T().chroma[X265_CSP_I420].pu[part].filter_hpp : T().pu[part].luma_hpp)(s, ss, d, ds, idx); }
+void ref_interp_hps(int chroma, int part, const pixel* s, intptr_t ss, int16_t* d, intptr_t ds, int idx, int ext)
+{ (chroma ? T().chroma[X265_CSP_I420].pu[part].filter_hps : T().pu[part].luma_hps)(s, ss, d, ds, idx, ext); }
+void ref_interp_vpp(int chroma, int part, const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int idx)
+{ (chroma ? T().chroma[X265_CSP_I420].pu[part].filter_vpp : T().pu[part].luma_vpp)(s, ss, d, ds, idx); }
+void ref_interp_vps(int chroma, int part, const pixel* s, intptr_t ss, int16_t* d, intptr_t ds, int idx)
+{ (chroma ? T().chroma[X265_CSP_I420].pu[part].filter_vps : T().pu[part].luma_vps)(s, ss, d, ds, idx); }
+void ref_interp_vsp(int chroma, int part, const int16_t* s, intptr_t ss, pixel* d, intptr_t ds, int idx)
+{ (chroma ? T().chroma[X265_CSP_I420].pu[part].filter_vsp : T().pu[part].luma_vsp)(s, ss, d, ds, idx); }
+void ref_interp_vss(int chroma, int part, const int16_t* s, intptr_t ss, int16_t* d, intptr_t ds, int idx)
+{ (chroma ? T().chroma[X265_CSP_I420].pu[part].filter_vss : T().pu[part].luma_vss)(s, ss, d, ds, idx); }
+void ref_interp_hvpp(int part, const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int ix, int iy) { T().pu[part].luma_hvpp(s, ss, d, ds, ix, iy); }
+void ref_p2s(int chroma, int part, const pixel* s, intptr_t ss, int16_t* d, intptr_t ds)
+{ (chroma ? T().chroma[X265_CSP_I420].pu[part].p2s[NONALIGNED] : T().pu[part].convert_p2s[NONALIGNED])(s, ss, d, ds); }
+
+/* ---- tables ---- */
+const int16_t* ref_dct_matrix(int log2n) { return log2n == 2 ? &g_t4[0][0] : log2n == 3 ? &g_t8[0][0] : log2n == 4 ? &g_t16[0][0] : &g_t32[0][0]; }
+const int16_t* ref_luma_filter(int i) { return g_lumaFilter[i]; }
+const int16_t* ref_chroma_filter(int i) { return g_chromaFilter[i]; }
+int ref_partition_from_sizes(int w, int h) { return partitionFromSizes(w, h); }
+/* BitCost::setQP (encoder/bitcost.cpp:32): copies the lambda-scaled MVD cost row, out[i + 65536], i in [-65536, 65536] */
+void ref_mvcost_table(int qp, uint16_t* out)
+{
+    CostProbe p;
+    p.setQP(qp);
+    memcpy(out, p.table() - 2 * 32768, (4 * 32768 + 1) * sizeof(uint16_t));
+}
+
+/* ---- the real MotionEstimate::motionEstimate (encoder/motion.cpp:739), lookahead-style entry (:167): the source
+ * PU is read from `fencPlane` at the same (bx,by)/stride as the reference plane. Returns bcost; outQMv = qpel MV. */
+int ref_motion_estimate(pixel* refPlane, pixel* fencPlane, intptr_t stride, int bx, int by, int w, int h,
+                        const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp, int numCand, const int32_t* mvc,
+                        int merange, int method, int subme, int qp, int32_t* outQMv)
+{
+    T();
+    MotionEstimate me;
+    me.init(X265_CSP_I400);
+    me.setQP(qp);
+    me.setSourcePU(fencPlane, stride, bx + (intptr_t)by * stride, w, h, method, method, method, subme);
+    ReferencePlanes ref;
+    ref.fpelPlane[0] = refPlane;
+    ref.lumaStride = stride;
+    ref.isLowres = false;
+    ref.isHMELowres = false;
+    MV cands[16];
+    for (int i = 0; i < numCand && i < 16; i++)
+        cands[i] = MV(mvc[2 * i], mvc[2 * i + 1]);
+    MV out(0, 0);
+    int cost = me.motionEstimate(&ref, MV(mvmin[0], mvmin[1]), MV(mvmax[0], mvmax[1]), MV(qmvp[0], qmvp[1]),
+                                 numCand, cands, merange, out, 1, 0);
+    outQMv[0] = out.x;
+    outQMv[1] = out.y;
+    return cost;
+}
+
+} // extern "C"

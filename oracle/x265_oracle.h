@@ -1,0 +1,150 @@
+/* x265_oracle.h — TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the x265 C reference primitives on the hot path
+ * plus MotionEstimate::motionEstimate.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library; the product path (x265_amd/, libx265hip.so) never does.
+ *
+ * Parity status: PINNED — every function here is checked bit-for-bit against the real reference
+ * (oracle/_ref/libx265ref{8,10}.so, compiled from /root/reference/source by oracle/Makefile) in
+ * tests/test_oracle_vs_ref.py, and against digests of reference outputs committed under tests/golden/.
+ *
+ * Conventions: strides are in ELEMENTS (as in x265). `depth` is the internal bit depth (8, 10 or 12);
+ * pixel storage is uint8_t when depth == 8 (functions suffixed _8) and uint16_t otherwise (_16).
+ * Each declaration cites the reference function it restates (paths relative to /root/reference/source).
+ */
+#ifndef X265_ORACLE_H
+#define X265_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_FENC_STRIDE 64 /* common/common.h:70 */
+
+/* ---- pixel comparisons -------------------------------------------------------------------------------- */
+#define ORC_DECL_PIXEL(P, SFX) \
+/* common/pixel.cpp:40 sad<lx,ly> */ \
+int orc_sad_##SFX(const P* a, intptr_t sa, const P* b, intptr_t sb, int w, int h); \
+/* common/pixel.cpp:74 sad_x3<lx,ly>: fenc stride fixed at FENC_STRIDE */ \
+void orc_sad_x3_##SFX(const P* fenc, const P* r0, const P* r1, const P* r2, intptr_t rs, int w, int h, int32_t* res); \
+/* common/pixel.cpp:96 sad_x4<lx,ly> */ \
+void orc_sad_x4_##SFX(const P* fenc, const P* r0, const P* r1, const P* r2, const P* r3, intptr_t rs, int w, int h, int32_t* res); \
+/* common/pixel.cpp:210 satd_4x4, :239 satd_8x4, :263-297 satd4/satd8 tilers, table :1131-1155 */ \
+int orc_satd_##SFX(const P* a, intptr_t sa, const P* b, intptr_t sb, int w, int h); \
+/* common/pixel.cpp:299-376: cu[].sa8d — 4x4=satd_4x4, 8x8=sa8d_8x8, >=16 sum of sa8d_16x16 (table :1163-1167) */ \
+int orc_sa8d_##SFX(const P* a, intptr_t sa, const P* b, intptr_t sb, int size); \
+/* common/pixel.cpp:352 sa8d8<w,h> (chroma tables :1258, :1343): each 8x8 rounded separately */ \
+int orc_sa8d8_##SFX(const P* a, intptr_t sa, const P* b, intptr_t sb, int w, int h); \
+/* common/pixel.cpp:167 sse<lx,ly,pixel,pixel> */ \
+uint64_t orc_sse_pp_##SFX(const P* a, intptr_t sa, const P* b, intptr_t sb, int w, int h); \
+/* common/pixel.cpp:726 psyCost_pp<size> (size = log2(dim)-2) */ \
+int orc_psy_cost_pp_##SFX(const P* src, intptr_t ss, const P* rec, intptr_t rs, int dim); \
+/* common/pixel.cpp:704 pixel_var<size> */ \
+uint64_t orc_var_##SFX(const P* p, intptr_t s, int size); \
+/* common/pixel.cpp:815 pixel_sub_ps_c */ \
+void orc_sub_ps_##SFX(int16_t* d, intptr_t ds, const P* a, const P* b, intptr_t sa, intptr_t sb, int w, int h); \
+/* common/pixel.cpp:829 pixel_add_ps_c */ \
+void orc_add_ps_##SFX(P* d, intptr_t ds, const P* a, const int16_t* r, intptr_t sa, intptr_t sr, int w, int h, int depth); \
+/* common/pixel.cpp:469 getResidual<blockSize>: one stride for all three */ \
+void orc_calcresidual_##SFX(const P* fenc, const P* pred, int16_t* resi, intptr_t stride, int size); \
+/* common/pixel.cpp:842 addAvg<bx,by> */ \
+void orc_addAvg_##SFX(const int16_t* a, const int16_t* b, P* d, intptr_t sa, intptr_t sb, intptr_t ds, int w, int h, int depth); \
+/* common/pixel.cpp:545 pixelavg_pp<lx,ly> */ \
+void orc_pixelavg_pp_##SFX(P* d, intptr_t ds, const P* a, intptr_t sa, const P* b, intptr_t sb, int w, int h); \
+/* common/pixel.cpp:759 blockcopy_pp_c, :785 blockcopy_sp_c, :802 blockcopy_ps_c */ \
+void orc_copy_pp_##SFX(P* d, intptr_t ds, const P* s, intptr_t ss, int w, int h); \
+void orc_copy_sp_##SFX(P* d, intptr_t ds, const int16_t* s, intptr_t ss, int w, int h); \
+void orc_copy_ps_##SFX(int16_t* d, intptr_t ds, const P* s, intptr_t ss, int w, int h); \
+/* ---- interpolation (N = 8 luma / 4 chroma taps) ---- */ \
+/* common/ipfilter.cpp:79 interp_horiz_pp_c */ \
+void orc_interp_horiz_pp_##SFX(int N, const P* src, intptr_t ss, P* dst, intptr_t ds, int w, int h, int coeffIdx, int depth); \
+/* common/ipfilter.cpp:120 interp_horiz_ps_c */ \
+void orc_interp_horiz_ps_##SFX(int N, const P* src, intptr_t ss, int16_t* dst, intptr_t ds, int w, int h, int coeffIdx, int isRowExt, int depth); \
+/* common/ipfilter.cpp:164 interp_vert_pp_c */ \
+void orc_interp_vert_pp_##SFX(int N, const P* src, intptr_t ss, P* dst, intptr_t ds, int w, int h, int coeffIdx, int depth); \
+/* common/ipfilter.cpp:205 interp_vert_ps_c */ \
+void orc_interp_vert_ps_##SFX(int N, const P* src, intptr_t ss, int16_t* dst, intptr_t ds, int w, int h, int coeffIdx, int depth); \
+/* common/ipfilter.cpp:241 interp_vert_sp_c */ \
+void orc_interp_vert_sp_##SFX(int N, const int16_t* src, intptr_t ss, P* dst, intptr_t ds, int w, int h, int coeffIdx, int depth); \
+/* common/ipfilter.cpp:362 interp_hv_pp_c (hps with row extension, then vertical sp) */ \
+void orc_interp_hv_pp_##SFX(int N, const P* src, intptr_t ss, P* dst, intptr_t ds, int w, int h, int idxX, int idxY, int depth); \
+/* common/ipfilter.cpp:40 filterPixelToShort_c */ \
+void orc_p2s_##SFX(const P* src, intptr_t ss, int16_t* dst, intptr_t ds, int w, int h, int depth); \
+/* ---- motion estimation: encoder/motion.cpp:739 MotionEstimate::motionEstimate (non-lowres, no chroma SATD) \
+ * plane/stride: full-pel reference luma plane (must have >= merange+8 valid margin around the block); \
+ * fenc: PU pixels at stride FENC_STRIDE; (bx,by): PU position in the plane; cost: u16 table centred on MVD 0 \
+ * (orc_mvcost_table); method: 0 DIA, 1 HEX, 2 UMH(unsupported), 3 STAR(unsupported), 5 FULL (x265.h X265_*_SEARCH). \
+ * Returns bcost, writes the quarter-pel MV. */ \
+int orc_motion_estimate_##SFX(const P* plane, intptr_t stride, int bx, int by, const P* fenc, int w, int h, \
+                              const int32_t mvmin[2], const int32_t mvmax[2], const int32_t qmvp[2], \
+                              int numCand, const int32_t* mvc, int merange, int method, int subme, \
+                              const uint16_t* cost, int depth, int32_t outQMv[2]); \
+/* encoder/motion.cpp:1571 MotionEstimate::subpelCompare (luma only); cmp: 0 = sad, 1 = satd */ \
+int orc_subpel_compare_##SFX(const P* plane, intptr_t stride, int bx, int by, const P* fenc, int w, int h, \
+                             int qmvx, int qmvy, int cmp, int depth);
+
+ORC_DECL_PIXEL(uint8_t, 8)
+ORC_DECL_PIXEL(uint16_t, 16)
+
+/* ---- int16 block helpers (pixel-type independent) ------------------------------------------------------ */
+/* common/pixel.cpp:167 sse<..,int16_t,int16_t> */
+uint64_t orc_sse_ss(const int16_t* a, intptr_t sa, const int16_t* b, intptr_t sb, int w, int h);
+/* common/pixel.cpp:379 pixel_ssd_s_c */
+uint64_t orc_ssd_s(const int16_t* a, intptr_t sa, int size);
+/* common/pixel.cpp:393 blockfill_s_c */
+void orc_blockfill_s(int16_t* d, intptr_t ds, int16_t val, int size);
+/* common/pixel.cpp:401-467 cpy2Dto1D_shl/shr, cpy1Dto2D_shl/shr */
+void orc_cpy2Dto1D_shl(int16_t* d, const int16_t* s, intptr_t ss, int shift, int size);
+void orc_cpy2Dto1D_shr(int16_t* d, const int16_t* s, intptr_t ss, int shift, int size);
+void orc_cpy1Dto2D_shl(int16_t* d, const int16_t* s, intptr_t ds, int shift, int size);
+void orc_cpy1Dto2D_shr(int16_t* d, const int16_t* s, intptr_t ds, int shift, int size);
+/* common/pixel.cpp:772 blockcopy_ss_c */
+void orc_copy_ss(int16_t* d, intptr_t ds, const int16_t* s, intptr_t ss, int w, int h);
+/* common/dct.cpp:714 count_nonzero_c, :728 copy_count */
+int orc_count_nonzero(const int16_t* q, int size);
+uint32_t orc_copy_cnt(int16_t* coeff, const int16_t* resi, intptr_t rs, int size);
+/* common/ipfilter.cpp:284 interp_vert_ss_c */
+void orc_interp_vert_ss(int N, const int16_t* src, intptr_t ss, int16_t* dst, intptr_t ds, int w, int h, int coeffIdx);
+
+/* ---- transforms ---------------------------------------------------------------------------------------- */
+/* common/dct.cpp:459-525 dct4_c..dct32_c (log2n = 2..5); src has stride, dst is contiguous N*N */
+void orc_dct(int log2n, const int16_t* src, int16_t* dst, intptr_t srcStride, int depth);
+/* common/dct.cpp:544-610 idct4_c..idct32_c; src contiguous N*N, dst has stride */
+void orc_idct(int log2n, const int16_t* src, int16_t* dst, intptr_t dstStride, int depth);
+/* common/dct.cpp:442 dst4_c / :527 idst4_c */
+void orc_dst4(const int16_t* src, int16_t* dst, intptr_t srcStride, int depth);
+void orc_idst4(const int16_t* src, int16_t* dst, intptr_t dstStride, int depth);
+/* common/dct.cpp:664 quant_c */
+uint32_t orc_quant(const int16_t* coef, const int32_t* quantCoeff, int32_t* deltaU, int16_t* qCoef, int qBits, int add, int numCoeff);
+/* common/dct.cpp:688 nquant_c */
+uint32_t orc_nquant(const int16_t* coef, const int32_t* quantCoeff, int16_t* qCoef, int qBits, int add, int numCoeff);
+/* common/dct.cpp:612 dequant_normal_c */
+void orc_dequant_normal(const int16_t* q, int16_t* coef, int num, int scale, int shift);
+/* common/dct.cpp:636 dequant_scaling_c */
+void orc_dequant_scaling(const int16_t* q, const int32_t* deQuantCoef, int16_t* coef, int num, int per, int shift);
+/* common/dct.cpp:743 denoiseDct_c */
+void orc_denoise_dct(int16_t* dctCoef, uint32_t* resSum, const uint16_t* offset, int numCoeff);
+/* common/dct.cpp:985 nonPsyRdoQuant_c, :1005 psyRdoQuant_c, :1030 psyRdoQuant_c_1, :1049 psyRdoQuant_c_2 */
+void orc_nonpsy_rdoquant(int log2n, const int16_t* resiDct, int64_t* costUncoded, int64_t* totalUncoded, int64_t* totalRd, uint32_t blkPos, int depth);
+void orc_psy_rdoquant(int log2n, const int16_t* resiDct, const int16_t* fencDct, int64_t* costUncoded, int64_t* totalUncoded, int64_t* totalRd, const int64_t* psyScale, uint32_t blkPos, int depth);
+void orc_psy_rdoquant_1p(int log2n, const int16_t* resiDct, int64_t* costUncoded, int64_t* totalUncoded, int64_t* totalRd, uint32_t blkPos, int depth);
+void orc_psy_rdoquant_2p(int log2n, const int16_t* resiDct, const int16_t* fencDct, int64_t* costUncoded, int64_t* totalUncoded, int64_t* totalRd, const int64_t* psyScale, uint32_t blkPos, int depth);
+
+/* ---- data tables ---------------------------------------------------------------------------------------- */
+/* common/constants.cpp:250 g_lumaFilter, :258 g_chromaFilter, :270-344 g_t4..g_t32 (regenerated, not pasted) */
+const int16_t* orc_luma_filter(int idx);     /* 8 taps */
+const int16_t* orc_chroma_filter(int idx);   /* 4 taps */
+const int16_t* orc_dct_matrix(int log2n);    /* N*N row-major */
+/* encoder/bitcost.cpp:32 BitCost::setQP + :108 CalculateLogs: table[i + 2*32768] = cost of MVD component i (qpel),
+ * i in [-65536, 65536]; lambda = x265_lambda_tab[qp] for the given depth (common/constants.cpp:34/74/114).
+ * `table` must hold 4*32768+1 entries. */
+void orc_mvcost_table(int qp, int depth, uint16_t* table);
+/* common/primitives.cpp lumaPartitionMapTable via partitionFromSizes (primitives.h:435): LumaPU enum or -1 */
+int orc_partition_from_sizes(int w, int h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

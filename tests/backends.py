@@ -1,0 +1,459 @@
+"""Uniform numpy-level front ends over the CPU checkers (tests only):
+
+  Orc(depth)  -> oracle/libx265oracle.so  (our plain-C restatement)
+  Ref(depth)  -> oracle/_ref/libx265ref{8,10}.so (the real reference C primitives + MotionEstimate)
+
+Both expose the same methods so a parity test is `assert same(Orc(d).f(*a), Ref(d).f(*a))`.
+Blocks are passed as C-contiguous 2-D numpy arrays plus an (y, x) origin; stride = array width.
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import pyoracle as po  # noqa: E402
+
+PU_SIZES = po.PU_SIZES
+CU_SIZES = [4, 8, 16, 32, 64]
+ptr = po.ptr
+
+
+def part_of(w, h):
+    return PU_SIZES.index((w, h))
+
+
+def cu_of(size):
+    return CU_SIZES.index(size)
+
+
+class _Base:
+    def __init__(self, depth):
+        self.depth = depth
+        self.pix = po.pix_dtype(depth)
+        self.pmax = (1 << depth) - 1
+
+
+class Orc(_Base):
+    name = "oracle"
+
+    def __init__(self, depth):
+        super().__init__(depth)
+        self.L = po.oracle()
+        self.s = po.sfx(depth)
+
+    def _f(self, name):
+        return getattr(self.L, "%s_%s" % (name, self.s))
+
+    # ---- pixel compare
+    def sad(self, w, h, a, ao, b, bo):
+        return self._f("orc_sad")(ptr(a, *ao), a.shape[1], ptr(b, *bo), b.shape[1], w, h)
+
+    def sad_xn(self, w, h, fenc, ref, offs):
+        res = np.zeros(len(offs), np.int32)
+        ps = [ptr(ref, *o) for o in offs]
+        if len(offs) == 3:
+            self._f("orc_sad_x3")(ptr(fenc), ps[0], ps[1], ps[2], ref.shape[1], w, h, ptr(res))
+        else:
+            self._f("orc_sad_x4")(ptr(fenc), ps[0], ps[1], ps[2], ps[3], ref.shape[1], w, h, ptr(res))
+        return res
+
+    def satd(self, w, h, a, ao, b, bo):
+        return self._f("orc_satd")(ptr(a, *ao), a.shape[1], ptr(b, *bo), b.shape[1], w, h)
+
+    def sa8d(self, size, a, ao, b, bo):
+        return self._f("orc_sa8d")(ptr(a, *ao), a.shape[1], ptr(b, *bo), b.shape[1], size)
+
+    def sse_pp(self, size, a, ao, b, bo):
+        return self._f("orc_sse_pp")(ptr(a, *ao), a.shape[1], ptr(b, *bo), b.shape[1], size, size)
+
+    def sse_ss(self, size, a, ao, b, bo):
+        return self.L.orc_sse_ss(ptr(a, *ao), a.shape[1], ptr(b, *bo), b.shape[1], size, size)
+
+    def ssd_s(self, size, a, ao):
+        return self.L.orc_ssd_s(ptr(a, *ao), a.shape[1], size)
+
+    def psy_cost_pp(self, size, a, ao, b, bo):
+        return self._f("orc_psy_cost_pp")(ptr(a, *ao), a.shape[1], ptr(b, *bo), b.shape[1], size)
+
+    def var(self, size, a, ao):
+        return self._f("orc_var")(ptr(a, *ao), a.shape[1], size)
+
+    # ---- block arithmetic (outputs returned as fresh dense arrays)
+    def sub_ps(self, size, a, ao, b, bo):
+        d = np.zeros((size, size), np.int16)
+        self._f("orc_sub_ps")(ptr(d), size, ptr(a, *ao), ptr(b, *bo), a.shape[1], b.shape[1], size, size)
+        return d
+
+    def add_ps(self, size, a, ao, r, ro):
+        d = np.zeros((size, size), self.pix)
+        self._f("orc_add_ps")(ptr(d), size, ptr(a, *ao), ptr(r, *ro), a.shape[1], r.shape[1], size, size, self.depth)
+        return d
+
+    def addAvg(self, w, h, a, ao, b, bo):
+        d = np.zeros((h, w), self.pix)
+        self._f("orc_addAvg")(ptr(a, *ao), ptr(b, *bo), ptr(d), a.shape[1], b.shape[1], w, w, h, self.depth)
+        return d
+
+    def pixelavg_pp(self, w, h, a, ao, b, bo):
+        d = np.zeros((h, w), self.pix)
+        self._f("orc_pixelavg_pp")(ptr(d), w, ptr(a, *ao), a.shape[1], ptr(b, *bo), b.shape[1], w, h)
+        return d
+
+    def p2s(self, w, h, a, ao):
+        d = np.zeros((h, w), np.int16)
+        self._f("orc_p2s")(ptr(a, *ao), a.shape[1], ptr(d), w, w, h, self.depth)
+        return d
+
+    def cpy2Dto1D_shl(self, size, a, ao, shift):
+        d = np.zeros(size * size, np.int16)
+        self.L.orc_cpy2Dto1D_shl(ptr(d), ptr(a, *ao), a.shape[1], shift, size)
+        return d
+
+    def cpy2Dto1D_shr(self, size, a, ao, shift):
+        d = np.zeros(size * size, np.int16)
+        self.L.orc_cpy2Dto1D_shr(ptr(d), ptr(a, *ao), a.shape[1], shift, size)
+        return d
+
+    def cpy1Dto2D_shl(self, size, a, shift):
+        d = np.zeros((size, size), np.int16)
+        self.L.orc_cpy1Dto2D_shl(ptr(d), ptr(a), size, shift, size)
+        return d
+
+    def cpy1Dto2D_shr(self, size, a, shift):
+        d = np.zeros((size, size), np.int16)
+        self.L.orc_cpy1Dto2D_shr(ptr(d), ptr(a), size, shift, size)
+        return d
+
+    def copy_cnt(self, size, a, ao):
+        d = np.zeros(size * size, np.int16)
+        n = self.L.orc_copy_cnt(ptr(d), ptr(a, *ao), a.shape[1], size)
+        return d, n
+
+    def count_nonzero(self, size, a):
+        return self.L.orc_count_nonzero(ptr(a), size)
+
+    # ---- transforms
+    def dct(self, size, a, ao):
+        d = np.zeros(size * size, np.int16)
+        self.L.orc_dct(size.bit_length() - 1, ptr(a, *ao), ptr(d), a.shape[1], self.depth)
+        return d
+
+    def idct(self, size, a):
+        d = np.zeros((size, size), np.int16)
+        self.L.orc_idct(size.bit_length() - 1, ptr(a), ptr(d), size, self.depth)
+        return d
+
+    def dst4(self, a, ao):
+        d = np.zeros(16, np.int16)
+        self.L.orc_dst4(ptr(a, *ao), ptr(d), a.shape[1], self.depth)
+        return d
+
+    def idst4(self, a):
+        d = np.zeros((4, 4), np.int16)
+        self.L.orc_idst4(ptr(a), ptr(d), 4, self.depth)
+        return d
+
+    def quant(self, coef, qc, qbits, add):
+        n = coef.size
+        du = np.zeros(n, np.int32)
+        q = np.zeros(n, np.int16)
+        ns = self.L.orc_quant(ptr(coef), ptr(qc), ptr(du), ptr(q), qbits, add, n)
+        return q, du, ns
+
+    def nquant(self, coef, qc, qbits, add):
+        n = coef.size
+        q = np.zeros(n, np.int16)
+        ns = self.L.orc_nquant(ptr(coef), ptr(qc), ptr(q), qbits, add, n)
+        return q, ns
+
+    def dequant_normal(self, q, scale, shift):
+        c = np.zeros(q.size, np.int16)
+        self.L.orc_dequant_normal(ptr(q), ptr(c), q.size, scale, shift)
+        return c
+
+    def dequant_scaling(self, q, dq, per, shift):
+        c = np.zeros(q.size, np.int16)
+        self.L.orc_dequant_scaling(ptr(q), ptr(dq), ptr(c), q.size, per, shift)
+        return c
+
+    def denoise_dct(self, coef, ressum, offset):
+        c, r = coef.copy(), ressum.copy()
+        self.L.orc_denoise_dct(ptr(c), ptr(r), ptr(offset), c.size)
+        return c, r
+
+    def rdoquant(self, kind, size, resi, fenc, psyscale, blkpos):
+        log2n = size.bit_length() - 1
+        cu_ = np.full(size * size, 7, np.int64)
+        tot = np.array([11, 13], np.int64)
+        ps = np.array([psyscale], np.int64)
+        tu, tr = po.vp(tot.ctypes.data), po.vp(tot.ctypes.data + 8)
+        if kind == "nonpsy":
+            self.L.orc_nonpsy_rdoquant(log2n, ptr(resi), ptr(cu_), tu, tr, blkpos, self.depth)
+        elif kind == "psy":
+            self.L.orc_psy_rdoquant(log2n, ptr(resi), ptr(fenc), ptr(cu_), tu, tr, ptr(ps), blkpos, self.depth)
+        elif kind == "psy1":
+            self.L.orc_psy_rdoquant_1p(log2n, ptr(resi), ptr(cu_), tu, tr, blkpos, self.depth)
+        else:
+            self.L.orc_psy_rdoquant_2p(log2n, ptr(resi), ptr(fenc), ptr(cu_), tu, tr, ptr(ps), blkpos, self.depth)
+        return cu_, tot
+
+    # ---- interpolation; src origin must leave >= 3 (luma) / 1 (chroma) pixels of margin before it
+    def interp(self, kind, chroma, w, h, src, so, idx, idy=0, ext=0):
+        N = 4 if chroma else 8
+        d = self.depth
+        if kind == "hpp":
+            out = np.zeros((h, w), self.pix)
+            self._f("orc_interp_horiz_pp")(N, ptr(src, *so), src.shape[1], ptr(out), w, w, h, idx, d)
+        elif kind == "hps":
+            rows = h + (N - 1 if ext else 0)
+            out = np.zeros((rows, w), np.int16)
+            self._f("orc_interp_horiz_ps")(N, ptr(src, *so), src.shape[1], ptr(out), w, w, h, idx, ext, d)
+        elif kind == "vpp":
+            out = np.zeros((h, w), self.pix)
+            self._f("orc_interp_vert_pp")(N, ptr(src, *so), src.shape[1], ptr(out), w, w, h, idx, d)
+        elif kind == "vps":
+            out = np.zeros((h, w), np.int16)
+            self._f("orc_interp_vert_ps")(N, ptr(src, *so), src.shape[1], ptr(out), w, w, h, idx, d)
+        elif kind == "vsp":
+            out = np.zeros((h, w), self.pix)
+            self._f("orc_interp_vert_sp")(N, ptr(src, *so), src.shape[1], ptr(out), w, w, h, idx, d)
+        elif kind == "vss":
+            out = np.zeros((h, w), np.int16)
+            self.L.orc_interp_vert_ss(N, ptr(src, *so), src.shape[1], ptr(out), w, w, h, idx)
+        elif kind == "hvpp":
+            out = np.zeros((h, w), self.pix)
+            self._f("orc_interp_hv_pp")(N, ptr(src, *so), src.shape[1], ptr(out), w, w, h, idx, idy, d)
+        else:
+            raise ValueError(kind)
+        return out
+
+    # ---- motion estimation
+    def mvcost_table(self, qp):
+        return po.mvcost_table(qp, self.depth)
+
+    def motion_estimate(self, refplane, fencplane, bx, by, w, h, mvmin, mvmax, qmvp, mvc, merange, method, subme, qp):
+        fenc = np.zeros((64, 64), self.pix)
+        fenc[:h, :w] = fencplane[by:by + h, bx:bx + w]
+        cost = self.mvcost_table(qp)
+        a = [np.array(v, np.int32) for v in (mvmin, mvmax, qmvp)]
+        cand = np.array(mvc, np.int32).reshape(-1)
+        out = np.zeros(2, np.int32)
+        c = self._f("orc_motion_estimate")(ptr(refplane), refplane.shape[1], bx, by, ptr(fenc), w, h,
+                                           ptr(a[0]), ptr(a[1]), ptr(a[2]), len(mvc), ptr(cand) if len(mvc) else None,
+                                           merange, method, subme,
+                                           po.vp(cost.ctypes.data + 2 * po.MVCOST_CENTRE), self.depth, ptr(out))
+        return c, (int(out[0]), int(out[1]))
+
+
+class Ref(_Base):
+    name = "reference"
+
+    def __init__(self, depth):
+        super().__init__(depth)
+        self.L = po.ref(depth)
+
+    def sad(self, w, h, a, ao, b, bo):
+        return self.L.ref_sad(part_of(w, h), ptr(a, *ao), a.shape[1], ptr(b, *bo), b.shape[1])
+
+    def sad_xn(self, w, h, fenc, ref, offs):
+        res = np.zeros(len(offs), np.int32)
+        ps = [ptr(ref, *o) for o in offs]
+        if len(offs) == 3:
+            self.L.ref_sad_x3(part_of(w, h), ptr(fenc), ps[0], ps[1], ps[2], ref.shape[1], ptr(res))
+        else:
+            self.L.ref_sad_x4(part_of(w, h), ptr(fenc), ps[0], ps[1], ps[2], ps[3], ref.shape[1], ptr(res))
+        return res
+
+    def satd(self, w, h, a, ao, b, bo):
+        return self.L.ref_satd(part_of(w, h), ptr(a, *ao), a.shape[1], ptr(b, *bo), b.shape[1])
+
+    def sa8d(self, size, a, ao, b, bo):
+        return self.L.ref_sa8d(cu_of(size), ptr(a, *ao), a.shape[1], ptr(b, *bo), b.shape[1])
+
+    def sse_pp(self, size, a, ao, b, bo):
+        return self.L.ref_sse_pp(cu_of(size), ptr(a, *ao), a.shape[1], ptr(b, *bo), b.shape[1])
+
+    def sse_ss(self, size, a, ao, b, bo):
+        return self.L.ref_sse_ss(cu_of(size), ptr(a, *ao), a.shape[1], ptr(b, *bo), b.shape[1])
+
+    def ssd_s(self, size, a, ao):
+        return self.L.ref_ssd_s(cu_of(size), ptr(a, *ao), a.shape[1])
+
+    def psy_cost_pp(self, size, a, ao, b, bo):
+        return self.L.ref_psy_cost_pp(cu_of(size), ptr(a, *ao), a.shape[1], ptr(b, *bo), b.shape[1])
+
+    def var(self, size, a, ao):
+        return self.L.ref_var(cu_of(size), ptr(a, *ao), a.shape[1])
+
+    def sub_ps(self, size, a, ao, b, bo):
+        d = np.zeros((size, size), np.int16)
+        self.L.ref_sub_ps(cu_of(size), ptr(d), size, ptr(a, *ao), ptr(b, *bo), a.shape[1], b.shape[1])
+        return d
+
+    def add_ps(self, size, a, ao, r, ro):
+        d = np.zeros((size, size), self.pix)
+        self.L.ref_add_ps(cu_of(size), ptr(d), size, ptr(a, *ao), ptr(r, *ro), a.shape[1], r.shape[1])
+        return d
+
+    def addAvg(self, w, h, a, ao, b, bo):
+        d = np.zeros((h, w), self.pix)
+        self.L.ref_addAvg(part_of(w, h), ptr(a, *ao), ptr(b, *bo), ptr(d), a.shape[1], b.shape[1], w)
+        return d
+
+    def pixelavg_pp(self, w, h, a, ao, b, bo):
+        d = np.zeros((h, w), self.pix)
+        self.L.ref_pixelavg_pp(part_of(w, h), ptr(d), w, ptr(a, *ao), a.shape[1], ptr(b, *bo), b.shape[1])
+        return d
+
+    def p2s(self, w, h, a, ao):
+        d = np.zeros((h, w), np.int16)
+        self.L.ref_p2s(0, part_of(w, h), ptr(a, *ao), a.shape[1], ptr(d), w)
+        return d
+
+    def cpy2Dto1D_shl(self, size, a, ao, shift):
+        d = np.zeros(size * size, np.int16)
+        self.L.ref_cpy2Dto1D_shl(cu_of(size), ptr(d), ptr(a, *ao), a.shape[1], shift)
+        return d
+
+    def cpy2Dto1D_shr(self, size, a, ao, shift):
+        d = np.zeros(size * size, np.int16)
+        self.L.ref_cpy2Dto1D_shr(cu_of(size), ptr(d), ptr(a, *ao), a.shape[1], shift)
+        return d
+
+    def cpy1Dto2D_shl(self, size, a, shift):
+        d = np.zeros((size, size), np.int16)
+        self.L.ref_cpy1Dto2D_shl(cu_of(size), ptr(d), ptr(a), size, shift)
+        return d
+
+    def cpy1Dto2D_shr(self, size, a, shift):
+        d = np.zeros((size, size), np.int16)
+        self.L.ref_cpy1Dto2D_shr(cu_of(size), ptr(d), ptr(a), size, shift)
+        return d
+
+    def copy_cnt(self, size, a, ao):
+        d = np.zeros(size * size, np.int16)
+        n = self.L.ref_copy_cnt(cu_of(size), ptr(d), ptr(a, *ao), a.shape[1])
+        return d, n
+
+    def count_nonzero(self, size, a):
+        return self.L.ref_count_nonzero(cu_of(size), ptr(a))
+
+    def dct(self, size, a, ao):
+        d = np.zeros(size * size, np.int16)
+        self.L.ref_dct(cu_of(size), ptr(a, *ao), ptr(d), a.shape[1])
+        return d
+
+    def idct(self, size, a):
+        d = np.zeros((size, size), np.int16)
+        self.L.ref_idct(cu_of(size), ptr(a), ptr(d), size)
+        return d
+
+    def dst4(self, a, ao):
+        d = np.zeros(16, np.int16)
+        self.L.ref_dst4(ptr(a, *ao), ptr(d), a.shape[1])
+        return d
+
+    def idst4(self, a):
+        d = np.zeros((4, 4), np.int16)
+        self.L.ref_idst4(ptr(a), ptr(d), 4)
+        return d
+
+    def quant(self, coef, qc, qbits, add):
+        n = coef.size
+        du = np.zeros(n, np.int32)
+        q = np.zeros(n, np.int16)
+        ns = self.L.ref_quant(ptr(coef), ptr(qc), ptr(du), ptr(q), qbits, add, n)
+        return q, du, ns
+
+    def nquant(self, coef, qc, qbits, add):
+        n = coef.size
+        q = np.zeros(n, np.int16)
+        ns = self.L.ref_nquant(ptr(coef), ptr(qc), ptr(q), qbits, add, n)
+        return q, ns
+
+    def dequant_normal(self, q, scale, shift):
+        c = np.zeros(q.size, np.int16)
+        self.L.ref_dequant_normal(ptr(q), ptr(c), q.size, scale, shift)
+        return c
+
+    def dequant_scaling(self, q, dq, per, shift):
+        c = np.zeros(q.size, np.int16)
+        self.L.ref_dequant_scaling(ptr(q), ptr(dq), ptr(c), q.size, per, shift)
+        return c
+
+    def denoise_dct(self, coef, ressum, offset):
+        c, r = coef.copy(), ressum.copy()
+        self.L.ref_denoise_dct(ptr(c), ptr(r), ptr(offset), c.size)
+        return c, r
+
+    def rdoquant(self, kind, size, resi, fenc, psyscale, blkpos):
+        cu = cu_of(size)
+        cu_ = np.full(size * size, 7, np.int64)
+        tot = np.array([11, 13], np.int64)
+        ps = np.array([psyscale], np.int64)
+        tu, tr = po.vp(tot.ctypes.data), po.vp(tot.ctypes.data + 8)
+        if kind == "nonpsy":
+            self.L.ref_nonpsy_rdoquant(cu, ptr(resi), ptr(cu_), tu, tr, blkpos)
+        elif kind == "psy":
+            self.L.ref_psy_rdoquant(cu, ptr(resi), ptr(fenc), ptr(cu_), tu, tr, ptr(ps), blkpos)
+        elif kind == "psy1":
+            self.L.ref_psy_rdoquant_1p(cu, ptr(resi), ptr(cu_), tu, tr, blkpos)
+        else:
+            self.L.ref_psy_rdoquant_2p(cu, ptr(resi), ptr(fenc), ptr(cu_), tu, tr, ptr(ps), blkpos)
+        return cu_, tot
+
+    def interp(self, kind, chroma, w, h, src, so, idx, idy=0, ext=0):
+        # chroma tables are indexed by the LUMA partition whose 4:2:0 chroma block is (w, h)
+        part = part_of(w * 2, h * 2) if chroma else part_of(w, h)
+        N = 4 if chroma else 8
+        c = 1 if chroma else 0
+        L = self.L
+        if kind == "hpp":
+            out = np.zeros((h, w), self.pix)
+            L.ref_interp_hpp(c, part, ptr(src, *so), src.shape[1], ptr(out), w, idx)
+        elif kind == "hps":
+            out = np.zeros((h + (N - 1 if ext else 0), w), np.int16)
+            L.ref_interp_hps(c, part, ptr(src, *so), src.shape[1], ptr(out), w, idx, ext)
+        elif kind == "vpp":
+            out = np.zeros((h, w), self.pix)
+            L.ref_interp_vpp(c, part, ptr(src, *so), src.shape[1], ptr(out), w, idx)
+        elif kind == "vps":
+            out = np.zeros((h, w), np.int16)
+            L.ref_interp_vps(c, part, ptr(src, *so), src.shape[1], ptr(out), w, idx)
+        elif kind == "vsp":
+            out = np.zeros((h, w), self.pix)
+            L.ref_interp_vsp(c, part, ptr(src, *so), src.shape[1], ptr(out), w, idx)
+        elif kind == "vss":
+            out = np.zeros((h, w), np.int16)
+            L.ref_interp_vss(c, part, ptr(src, *so), src.shape[1], ptr(out), w, idx)
+        elif kind == "hvpp":
+            out = np.zeros((h, w), self.pix)
+            L.ref_interp_hvpp(part, ptr(src, *so), src.shape[1], ptr(out), w, idx, idy)
+        else:
+            raise ValueError(kind)
+        return out
+
+    def mvcost_table(self, qp):
+        t = np.zeros(4 * 32768 + 1, np.uint16)
+        self.L.ref_mvcost_table(qp, ptr(t))
+        return t
+
+    def motion_estimate(self, refplane, fencplane, bx, by, w, h, mvmin, mvmax, qmvp, mvc, merange, method, subme, qp):
+        assert refplane.shape == fencplane.shape
+        a = [np.array(v, np.int32) for v in (mvmin, mvmax, qmvp)]
+        cand = np.array(mvc, np.int32).reshape(-1)
+        out = np.zeros(2, np.int32)
+        c = self.L.ref_motion_estimate(ptr(refplane), ptr(fencplane), refplane.shape[1], bx, by, w, h,
+                                       ptr(a[0]), ptr(a[1]), ptr(a[2]), len(mvc), ptr(cand) if len(mvc) else None,
+                                       merange, method, subme, qp, ptr(out))
+        return c, (int(out[0]), int(out[1]))
+
+
+def same(x, y):
+    """Bit-exact comparison of scalars / arrays / tuples thereof."""
+    if isinstance(x, tuple):
+        return len(x) == len(y) and all(same(a, b) for a, b in zip(x, y))
+    if isinstance(x, np.ndarray):
+        return x.dtype == y.dtype and x.shape == y.shape and np.array_equal(x, y)
+    return int(x) == int(y)

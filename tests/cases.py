@@ -1,0 +1,201 @@
+"""Seeded test-vector generator shared by the CPU pinning tests, the golden-digest fixtures and the GPU parity tests.
+
+Input distributions follow the reference TestBench: random / all-min / all-max pixel buffers
+(source/test/pixelharness.cpp:31-80), residuals in [-PIXEL_MAX, PIXEL_MAX] and full-range int16 for inverse
+transforms (source/test/mbdstharness.cpp:53-86), unaligned origins and strides (ipfilterharness.cpp:72-108) —
+but with FIXED seeds (the reference seeds from time(), testbench.cpp:142).
+"""
+import hashlib
+
+import numpy as np
+
+from backends import PU_SIZES, CU_SIZES
+
+TU_SIZES = [4, 8, 16, 32]
+# primitives.h:80-90, indexed by LumaPU; 2x2 has no filter entry in the reference (ipfilter.cpp:419-470)
+CHROMA_PU_420 = [(w // 2, h // 2) for (w, h) in PU_SIZES if (w, h) != (4, 4)]
+MODES = ["rand", "min", "max"]
+
+
+def pix_buf(rng, mode, shape, depth):
+    dt = np.uint8 if depth == 8 else np.uint16
+    pmax = (1 << depth) - 1
+    if mode == "rand":
+        return rng.integers(0, pmax + 1, size=shape, dtype=np.int64).astype(dt)
+    return np.full(shape, 0 if mode == "min" else pmax, dt)
+
+
+def short_buf(rng, mode, shape, lo, hi):
+    if mode == "rand":
+        return rng.integers(lo, hi + 1, size=shape, dtype=np.int64).astype(np.int16)
+    return np.full(shape, lo if mode == "min" else hi, np.int16)
+
+
+def gen_cases(depth, seed=1234, reps=2):
+    """Yield (label, method_name, args) tuples; args are ready for Orc/Ref methods of tests/backends.py."""
+    rng = np.random.default_rng(seed + depth)
+    pmax = (1 << depth) - 1
+    S = 96  # buffer stride, deliberately not a multiple of 64
+
+    def origin(margin=0, room=64):
+        return (int(rng.integers(margin, S - room - margin)), int(rng.integers(margin, S - room - margin)))
+
+    combos = [("rand", "rand")] * reps + [("min", "max"), ("max", "min"), ("max", "max")]
+    for (ma, mb) in combos:
+        a = pix_buf(rng, ma, (S + 80, S), depth)
+        b = pix_buf(rng, mb, (S + 80, S), depth)
+        fenc = np.zeros((64, 64), a.dtype)
+        fenc[:, :] = pix_buf(rng, ma, (64, 64), depth)
+        tag = "%s-%s" % (ma, mb)
+        for (w, h) in PU_SIZES:
+            ao, bo = origin(), origin()
+            yield ("sad %dx%d %s" % (w, h, tag), "sad", (w, h, a, ao, b, bo))
+            yield ("satd %dx%d %s" % (w, h, tag), "satd", (w, h, a, ao, b, bo))
+            offs = [origin() for _ in range(4)]
+            yield ("sad_x3 %dx%d %s" % (w, h, tag), "sad_xn", (w, h, fenc, b, offs[:3]))
+            yield ("sad_x4 %dx%d %s" % (w, h, tag), "sad_xn", (w, h, fenc, b, offs))
+            yield ("pixelavg %dx%d %s" % (w, h, tag), "pixelavg_pp", (w, h, a, ao, b, bo))
+            yield ("p2s %dx%d %s" % (w, h, tag), "p2s", (w, h, a, ao))
+        for size in CU_SIZES:
+            ao, bo = origin(), origin()
+            yield ("sa8d %d %s" % (size, tag), "sa8d", (size, a, ao, b, bo))
+            yield ("sse_pp %d %s" % (size, tag), "sse_pp", (size, a, ao, b, bo))
+            yield ("psy_cost %d %s" % (size, tag), "psy_cost_pp", (size, a, ao, b, bo))
+            yield ("var %d %s" % (size, tag), "var", (size, a, ao))
+            yield ("sub_ps %d %s" % (size, tag), "sub_ps", (size, a, ao, b, bo))
+
+    # int16 families
+    for mode in ["rand"] * reps + ["min", "max"]:
+        r = short_buf(rng, mode, (S + 80, S), -pmax, pmax)        # residual-range
+        r2 = short_buf(rng, mode, (S + 80, S), -pmax, pmax)
+        full = short_buf(rng, mode, (S + 80, S), -32768, 32767)   # full int16 range
+        p = pix_buf(rng, mode, (S + 80, S), depth)
+        avg = short_buf(rng, mode, (S + 80, S), -16384, 16383)    # addAvg operand range (pixelharness.cpp:41)
+        avg2 = short_buf(rng, "rand", (S + 80, S), -16384, 16383)
+        for size in CU_SIZES:
+            ao, bo = origin(), origin()
+            yield ("sse_ss %d %s" % (size, mode), "sse_ss", (size, r, ao, r2, bo))
+            yield ("ssd_s %d %s" % (size, mode), "ssd_s", (size, r, ao))
+            yield ("add_ps %d %s" % (size, mode), "add_ps", (size, p, ao, r, bo))
+        for (w, h) in PU_SIZES:
+            ao, bo = origin(), origin()
+            yield ("addAvg %dx%d %s" % (w, h, mode), "addAvg", (w, h, avg, ao, avg2, bo))
+        for size in TU_SIZES:
+            ao = origin()
+            yield ("dct %d %s" % (size, mode), "dct", (size, r, ao))
+            flat = np.ascontiguousarray(full[:size, :size]).reshape(-1).copy()
+            yield ("idct %d %s" % (size, mode), "idct", (size, flat))
+            lim = (1 << (depth + 4)) - 1                           # mbufidct range, mbdstharness.cpp:83
+            flat2 = short_buf(rng, "rand", (size * size,), -lim, lim)
+            yield ("idct-typ %d %s" % (size, mode), "idct", (size, flat2))
+            yield ("cpy2Dto1D_shl %d %s" % (size, mode), "cpy2Dto1D_shl", (size, r, ao, int(rng.integers(0, 4))))
+            yield ("cpy2Dto1D_shr %d %s" % (size, mode), "cpy2Dto1D_shr", (size, r, ao, int(rng.integers(1, 5))))
+            flat3 = np.ascontiguousarray(r[:size, :size]).reshape(-1).copy()
+            yield ("cpy1Dto2D_shl %d %s" % (size, mode), "cpy1Dto2D_shl", (size, flat3, int(rng.integers(0, 4))))
+            yield ("cpy1Dto2D_shr %d %s" % (size, mode), "cpy1Dto2D_shr", (size, flat3, int(rng.integers(1, 5))))
+            sparse = (flat3 * (rng.integers(0, 3, size=flat3.shape) == 0)).astype(np.int16)
+            yield ("count_nonzero %d %s" % (size, mode), "count_nonzero", (size, sparse))
+            sp2 = (r * (rng.integers(0, 3, size=r.shape) == 0)).astype(np.int16)
+            yield ("copy_cnt %d %s" % (size, mode), "copy_cnt", (size, sp2, ao))
+        ao = origin()
+        yield ("dst4 %s" % mode, "dst4", (r, ao))
+        yield ("idst4 %s" % mode, "idst4", (np.ascontiguousarray(full[:4, :4]).reshape(-1).copy(),))
+
+    # quant / dequant (parameter ranges from common/quant.cpp:465-466, :567, :621)
+    for rep in range(reps + 2):
+        for size in TU_SIZES:
+            n = size * size
+            log2n = size.bit_length() - 1
+            coef = short_buf(rng, "rand", (n,), -32768, 32767) if rep else short_buf(rng, "rand", (n,), -pmax * 8, pmax * 8)
+            qp = int(rng.integers(0, 52))
+            # quantCoeff = quantScales[qp%6] for flat lists (common/scalinglist.cpp:129) or arbitrary below 1<<15
+            qs = [26214, 23302, 20560, 18396, 16384, 14564][qp % 6]
+            qc = np.full(n, qs, np.int32) if rep % 2 == 0 else rng.integers(1, 1 << 15, size=n, dtype=np.int64).astype(np.int32)
+            qbits = 14 + qp // 6 + (15 - depth - log2n)
+            add = (171 if rep % 2 else 85) << (qbits - 9)
+            yield ("quant %d #%d" % (size, rep), "quant", (coef, qc, qbits, add))
+            yield ("nquant %d #%d" % (size, rep), "nquant", (coef, qc, qbits, 1 << (qbits - 1)))
+            q = short_buf(rng, "rand", (n,), -32768, 32767) if rep == 0 else short_buf(rng, "rand", (n,), -512, 512)
+            shift = 20 - 14 - (15 - depth - log2n)                 # QUANT_IQUANT_SHIFT - QUANT_SHIFT - transformShift
+            scale = [40, 45, 51, 57, 64, 72][qp % 6] << (qp // 6)
+            if shift >= 1 and scale < 32768:
+                yield ("dequant_normal %d #%d" % (size, rep), "dequant_normal", (q, scale, shift))
+            dq = rng.integers(1, 72 * 16 + 1, size=n, dtype=np.int64).astype(np.int32)
+            per = qp // 6
+            yield ("dequant_scaling %d #%d" % (size, rep), "dequant_scaling", (q, dq, per, max(shift, 0)))
+            rs = rng.integers(0, 1 << 20, size=n, dtype=np.int64).astype(np.uint32)
+            off = rng.integers(0, 1 << 10, size=n, dtype=np.int64).astype(np.uint16)
+            yield ("denoise %d #%d" % (size, rep), "denoise_dct", (coef, rs, off))
+            resi = short_buf(rng, "rand", (n,), -32768, 32767)
+            fe = short_buf(rng, "rand", (n,), -32768, 32767)
+            cgx, cgy = int(rng.integers(0, size // 4)), int(rng.integers(0, size // 4))
+            blk = cgy * 4 * size + cgx * 4
+            psy = int(rng.integers(0, 1 << 20))
+            for kind in ("nonpsy", "psy", "psy1", "psy2"):
+                yield ("rdoq-%s %d #%d" % (kind, size, rep), "rdoquant", (kind, size, resi, fe, psy, blk))
+
+    # interpolation: luma (8 tap) all PU sizes, chroma 4:2:0 (4 tap) for the chroma PU sizes
+    for mode in ["rand"] * reps + ["min", "max"]:
+        p = pix_buf(rng, mode, (S + 88, S), depth)
+        sh = short_buf(rng, mode, (S + 88, S), -8192, 8191 if depth == 8 else 8191)   # 14-bit intermediates
+        for chroma, sizes in ((0, PU_SIZES), (1, CHROMA_PU_420)):
+            nph = 8 if chroma else 4
+            for (w, h) in sizes:
+                so = origin(margin=8, room=72)
+                idx, idy = int(rng.integers(0 if chroma else 1, nph)), int(rng.integers(1, nph))
+                lab = "%s %dx%d %s" % ("chroma" if chroma else "luma", w, h, mode)
+                for kind in ("hpp", "vpp", "vps"):
+                    yield ("%s %s" % (kind, lab), "interp", (kind, chroma, w, h, p, so, idx))
+                yield ("hps %s" % lab, "interp", ("hps", chroma, w, h, p, so, idx, 0, 0))
+                yield ("hps-ext %s" % lab, "interp", ("hps", chroma, w, h, p, so, idx, 0, 1))
+                yield ("vsp %s" % lab, "interp", ("vsp", chroma, w, h, sh, so, idx))
+                yield ("vss %s" % lab, "interp", ("vss", chroma, w, h, sh, so, idx))
+                if not chroma:
+                    yield ("hvpp %s" % lab, "interp", ("hvpp", chroma, w, h, p, so, max(idx, 1), idy))
+
+
+def textured_frame(rng, h, w, depth, sigma=3.0):
+    """Low-pass random texture + noise: SADs then have a meaningful minimum (BASELINE.md §3 generator, scaled down)."""
+    pmax = (1 << depth) - 1
+    base = rng.random((h // 8 + 3, w // 8 + 3))
+    up = np.kron(base, np.ones((8, 8)))[:h + 16, :w + 16]
+    k = np.ones(9) / 9.0
+    up = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 1, up)
+    up = np.apply_along_axis(lambda c: np.convolve(c, k, mode="same"), 0, up)[8:8 + h, 8:8 + w]
+    up = (up - up.min()) / max(up.max() - up.min(), 1e-9)
+    img = up * pmax * 0.8 + pmax * 0.1 + rng.normal(0, sigma * (pmax / 255.0), (h, w))
+    return np.ascontiguousarray(np.clip(np.rint(img), 0, pmax).astype(np.uint8 if depth == 8 else np.uint16))
+
+
+def me_scene(depth, seed, H=160, W=192, margin=80):
+    """A padded reference plane and a source plane that is the reference shifted per 48x40 tile + noise."""
+    rng = np.random.default_rng(seed)
+    ref = textured_frame(rng, H + 2 * margin, W + 2 * margin, depth)
+    src = np.zeros_like(ref)
+    pmax = (1 << depth) - 1
+    th, tw = 40, 48                      # tile size: each tile moves by its own vector in [-9, 9]^2
+    for y0 in range(margin, margin + H, th):
+        for x0 in range(margin, margin + W, tw):
+            dy, dx = int(rng.integers(-9, 10)), int(rng.integers(-9, 10))
+            y1, x1 = min(y0 + th, margin + H), min(x0 + tw, margin + W)
+            src[y0:y1, x0:x1] = ref[y0 + dy:y1 + dy, x0 + dx:x1 + dx]
+    noise = rng.normal(0, 2.0 * (pmax / 255.0), src.shape)
+    src = np.clip(np.rint(src.astype(np.float64) + noise), 0, pmax).astype(ref.dtype)
+    return np.ascontiguousarray(ref), np.ascontiguousarray(src), margin
+
+
+def digest(result):
+    """sha256 over the canonical bytes of a scalar / array / tuple result."""
+    h = hashlib.sha256()
+
+    def feed(x):
+        if isinstance(x, tuple):
+            for e in x:
+                feed(e)
+        elif isinstance(x, np.ndarray):
+            h.update(str(x.dtype).encode() + str(x.shape).encode())
+            h.update(np.ascontiguousarray(x).tobytes())
+        else:
+            h.update(b"i" + str(int(x)).encode())
+    feed(result)
+    return h.hexdigest()[:16]

@@ -1,0 +1,63 @@
+"""Generate tests/golden/primitives_golden.json: sha256 digests of the REAL reference's outputs
+(oracle/_ref/libx265ref{8,10}.so, i.e. /root/reference/source compiled by oracle/Makefile) on the seeded cases of
+tests/cases.py.  Run here (where /root/reference exists): `python tests/golden/make_golden.py`.
+tests/test_oracle_golden.py then pins the oracle to these digests anywhere, with or without oracle/_ref."""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import numpy as np  # noqa: E402
+from backends import Ref  # noqa: E402
+from cases import gen_cases, me_scene, digest  # noqa: E402
+
+ME_CASES = [  # (method, subme, w, h, bx_off, by_off, merange, qmvp, mvc, qp)
+    (1, 2, 16, 16, 16, 24, 57, (5, -7), [(12, 8), (-20, 4)], 28),
+    (1, 2, 64, 64, 32, 32, 57, (0, 0), [], 28),
+    (1, 5, 8, 8, 40, 12, 32, (-13, 22), [(3, 3)], 22),
+    (1, 1, 32, 24, 8, 48, 57, (9, 1), [], 37),
+    (0, 2, 16, 8, 60, 60, 16, (2, 2), [(0, 8)], 28),
+    (5, 2, 8, 16, 20, 44, 12, (-4, 6), [], 28),
+    (5, 3, 32, 32, 64, 16, 10, (0, 0), [(16, -16)], 22),
+    (1, 7, 48, 64, 0, 0, 57, (31, -29), [(8, 8), (-8, -8), (40, 0)], 28),
+]
+
+
+def me_digests(backend_cls, depth):
+    b = backend_cls(depth)
+    refp, srcp, m = me_scene(depth, 99 + depth)
+    out = {}
+    for i, (method, subme, w, h, bx, by, mr, qmvp, mvc, qp) in enumerate(ME_CASES):
+        mvmin = ((qmvp[0] >> 2) - mr, (qmvp[1] >> 2) - mr)
+        mvmax = ((qmvp[0] >> 2) + mr, (qmvp[1] >> 2) + mr)
+        cost, mv = b.motion_estimate(refp, srcp, m + bx, m + by, w, h, mvmin, mvmax, qmvp, mvc, mr, method, subme, qp)
+        out["me#%d" % i] = [int(cost), int(mv[0]), int(mv[1])]
+    return out
+
+
+def prim_digests(backend_cls, depth):
+    b = backend_cls(depth)
+    out = {}
+    for label, fn, args in gen_cases(depth):
+        key = label
+        k = 0
+        while key in out:
+            k += 1
+            key = "%s~%d" % (label, k)
+        out[key] = digest(getattr(b, fn)(*args))
+    return out
+
+
+if __name__ == "__main__":
+    gold = {}
+    for depth in (8, 10):
+        gold[str(depth)] = {"prims": prim_digests(Ref, depth), "me": me_digests(Ref, depth),
+                            "mvcost": {str(qp): digest(Ref(depth).mvcost_table(qp)) for qp in (12, 28, 37, 51)}}
+    path = os.path.join(HERE, "primitives_golden.json")
+    with open(path, "w") as f:
+        json.dump({"source": "x265 3.4+28 C primitives ([noasm]), /root/reference/source via oracle/Makefile",
+                   "generator": "tests/golden/make_golden.py", "golden": gold}, f, indent=0, sort_keys=True)
+    print("wrote", path, {d: len(g["prims"]) for d, g in gold.items()})

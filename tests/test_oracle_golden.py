@@ -1,0 +1,38 @@
+"""Pin the oracle to the committed golden digests (generated from the real reference by tests/golden/make_golden.py).
+Runs anywhere: needs neither /root/reference nor oracle/_ref."""
+import json
+import os
+
+import pytest
+
+from backends import Orc
+from cases import digest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+import sys
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden  # noqa: E402
+
+with open(os.path.join(HERE, "golden", "primitives_golden.json")) as f:
+    GOLD = json.load(f)["golden"]
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_oracle_primitives_match_golden(depth):
+    got = make_golden.prim_digests(Orc, depth)
+    want = GOLD[str(depth)]["prims"]
+    assert set(got) == set(want)
+    bad = [k for k in want if got[k] != want[k]]
+    assert not bad, bad[:10]
+    assert len(want) > 2000
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_oracle_motion_estimate_matches_golden(depth):
+    assert make_golden.me_digests(Orc, depth) == GOLD[str(depth)]["me"]
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_oracle_mvcost_matches_golden(depth):
+    for qp, d in GOLD[str(depth)]["mvcost"].items():
+        assert digest(Orc(depth).mvcost_table(int(qp))) == d

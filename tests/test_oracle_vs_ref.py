@@ -1,0 +1,81 @@
+"""Pin oracle/x265_oracle.c to the REAL reference (oracle/_ref/libx265ref{8,10}.so, built from
+/root/reference/source by oracle/Makefile): every primitive, every PU/CU/TU size, TestBench input distributions,
+bit-exact.  Skipped only where oracle/_ref was never built (it travels to the GPU box as a prebuilt .so)."""
+import numpy as np
+import pytest
+
+from backends import Orc, Ref, same
+from cases import gen_cases, me_scene
+from oracle import pyoracle as po
+
+DEPTHS = [8, 10]
+
+
+def _need_ref(depth):
+    if not po.ref_available(depth):
+        pytest.skip("oracle/_ref/libx265ref%d.so not built (make -C oracle ref)" % depth)
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_tables_match_reference(depth):
+    _need_ref(depth)
+    o, r = po.oracle(), po.ref(depth)
+    for log2n in (2, 3, 4, 5):
+        n = 1 << (2 * log2n)
+        assert [o.orc_dct_matrix(log2n)[i] for i in range(n)] == [r.ref_dct_matrix(log2n)[i] for i in range(n)]
+    for i in range(4):
+        assert [o.orc_luma_filter(i)[k] for k in range(8)] == [r.ref_luma_filter(i)[k] for k in range(8)]
+    for i in range(8):
+        assert [o.orc_chroma_filter(i)[k] for k in range(4)] == [r.ref_chroma_filter(i)[k] for k in range(4)]
+    for (w, h) in po.PU_SIZES:
+        assert o.orc_partition_from_sizes(w, h) == r.ref_partition_from_sizes(w, h)
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_mvcost_table_matches_bitcost(depth):
+    _need_ref(depth)
+    for qp in (0, 12, 22, 28, 37, 51):
+        assert np.array_equal(Orc(depth).mvcost_table(qp), Ref(depth).mvcost_table(qp)), qp
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_every_primitive_matches_reference(depth):
+    _need_ref(depth)
+    o, r = Orc(depth), Ref(depth)
+    n = 0
+    for label, fn, args in gen_cases(depth):
+        a, b = getattr(o, fn)(*args), getattr(r, fn)(*args)
+        assert same(a, b), "%s (depth %d): oracle != reference" % (label, depth)
+        n += 1
+    assert n > 2000
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+@pytest.mark.parametrize("method", [0, 1, 5])     # DIA, HEX, FULL (x265.h X265_*_SEARCH)
+def test_motion_estimate_matches_reference(depth, method):
+    _need_ref(depth)
+    o, r = Orc(depth), Ref(depth)
+    rng = np.random.default_rng(77 + depth + method)
+    refp, srcp, m = me_scene(depth, 99 + depth)
+    H, W = refp.shape[0] - 2 * m, refp.shape[1] - 2 * m
+    sizes = [(8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 24), (12, 16), (64, 48), (16, 4), (8, 32)]
+    n = 0
+    for subme in (0, 1, 2, 3, 5, 7):
+        for (w, h) in sizes:
+            for _ in range(2 if method != 5 else 1):
+                bx = m + int(rng.integers(0, (W - w) // 4 + 1)) * 4
+                by = m + int(rng.integers(0, (H - h) // 4 + 1)) * 4
+                merange = 12 if method == 5 else int(rng.choice([16, 32, 57]))
+                qmvp = (int(rng.integers(-40, 41)), int(rng.integers(-40, 41)))
+                # search window as Search::setSearchRange does it (search.cpp:2724): mvp +- merange, full-pel
+                mvmin = ((qmvp[0] >> 2) - merange, (qmvp[1] >> 2) - merange)
+                mvmax = ((qmvp[0] >> 2) + merange, (qmvp[1] >> 2) + merange)
+                if rng.integers(0, 3) == 0:      # sometimes a tight vertical bound, as frame-parallel row lag makes
+                    mvmax = (mvmax[0], min(mvmax[1], int(rng.integers(0, 6))))
+                mvc = [(int(rng.integers(-60, 61)), int(rng.integers(-60, 61))) for _ in range(int(rng.integers(0, 5)))]
+                qp = int(rng.choice([22, 28, 37]))
+                a = o.motion_estimate(refp, srcp, bx, by, w, h, mvmin, mvmax, qmvp, mvc, merange, method, subme, qp)
+                b = r.motion_estimate(refp, srcp, bx, by, w, h, mvmin, mvmax, qmvp, mvc, merange, method, subme, qp)
+                assert a == b, (depth, method, subme, w, h, bx, by, qmvp, mvmin, mvmax, mvc, a, b)
+                n += 1
+    assert n >= 60
