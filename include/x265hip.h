@@ -1,0 +1,198 @@
+/* x265hip.h — C ABI of libx265hip.so: MI355X (gfx950) implementations of x265's data-parallel encode primitives.
+ *
+ * This is the drop-in boundary.  Every entry point is the BATCHED form of one (family of) slot(s) of x265's
+ * `EncoderPrimitives` function-pointer table (reference: source/common/primitives.h:237-429); the typedef each
+ * one replaces is cited next to it.  A slot call `p.pu[part].sad(fenc, s0, ref, s1)` becomes one job
+ * `{offA, offB}` of `x265hip_pixcmp_batch(X265HIP_CMP_SAD, depth, w, h, planeA, s0, planeB, s1, offA[], offB[], n, out[])`.
+ * The per-call shims that fill the reference's table (setupAssemblyPrimitives, primitives.h:470) live in
+ * x265_amd/host/x265_hip_primitives.cpp and only use the `x265hip_call_*` entry points at the end of this file.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes, no C++ / torch types.  Every function returns 0 on success or a negative
+ *    X265HIP_E* code; x265hip_last_error() gives the text.  Nothing here falls back to a CPU implementation:
+ *    without a usable GPU every call fails with X265HIP_ENODEV.
+ *  - `depth` is x265's internal bit depth (X265_DEPTH): 8 -> pixel = uint8_t; 10 or 12 -> pixel = uint16_t
+ *    (reference: source/common/common.h:126-142).
+ *  - planes, job arrays and outputs are DEVICE pointers unless the name says `host`.  Strides and offsets are in
+ *    ELEMENTS (as in x265), offsets are relative to the plane pointer and may be negative (picture margins).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are asynchronous on it.
+ *  - block sizes (w, h) must be one of x265's 25 luma PU shapes or their 4:2:0 chroma halves
+ *    (primitives.h:41-55, :80-90); transform sizes are 4, 8, 16, 32.
+ */
+#ifndef X265HIP_H
+#define X265HIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define X265HIP_OK        0
+#define X265HIP_EINVAL   -1   /* bad size / depth / argument */
+#define X265HIP_ENODEV   -2   /* no usable HIP device */
+#define X265HIP_EHIP     -3   /* a HIP runtime call failed (see x265hip_last_error) */
+#define X265HIP_ENOMEM   -4
+
+/* ---------------------------------------------------------------- runtime ---------------------------------- */
+int  x265hip_init(int device);                 /* select the device for the calling thread; 0 on success */
+int  x265hip_device_count(void);
+const char* x265hip_last_error(void);          /* thread-local text of the last failure */
+const char* x265hip_version(void);
+int  x265hip_malloc(void** dptr, size_t bytes);
+int  x265hip_free(void* dptr);
+int  x265hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
+int  x265hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int  x265hip_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+int  x265hip_memset(void* dst, int value, size_t bytes, void* stream);
+int  x265hip_stream_create(void** stream);
+int  x265hip_stream_destroy(void* stream);
+int  x265hip_stream_sync(void* stream);
+/* timing helper used by bench.py: HIP events on `stream` (torch.cuda.Event only sees torch's own stream) */
+int  x265hip_event_create(void** ev);
+int  x265hip_event_destroy(void* ev);
+int  x265hip_event_record(void* ev, void* stream);
+int  x265hip_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
+
+/* ---------------------------------------------------------------- pixel comparisons ------------------------- */
+/* pixelcmp_t  (primitives.h:133): pu[].sad, pu[].satd, cu[].sa8d, chroma sa8d; out[i] = cmp(A+offA[i], B+offB[i]) */
+#define X265HIP_CMP_SAD    0   /* pixel.cpp:40   sad<lx,ly>                                  */
+#define X265HIP_CMP_SATD   1   /* pixel.cpp:210-297 satd_4x4 / satd_8x4 tilers               */
+#define X265HIP_CMP_SA8D   2   /* pixel.cpp:336-376 cu[].sa8d: square 4..64, one rounding per 16x16 */
+#define X265HIP_CMP_SA8D8  3   /* pixel.cpp:352 sa8d8<w,h>: every 8x8 rounded (chroma tables) */
+#define X265HIP_CMP_PSY    4   /* pixelcmp_t-shaped psy_cost_pp (primitives.h:224, pixel.cpp:726), square 4..64 */
+int x265hip_pixcmp_batch(int op, int depth, int w, int h,
+                         const void* planeA, int64_t strideA, const void* planeB, int64_t strideB,
+                         const int32_t* offA, const int32_t* offB, int n, int32_t* out, void* stream);
+/* pixelcmp_x3_t / pixelcmp_x4_t (primitives.h:139-140, pixel.cpp:74-119): K = 3 or 4 reference candidates per
+ * fenc block; offRef is [n][K], out is [n][K].  (x265 fixes the fenc stride at FENC_STRIDE = 64; here it is free.) */
+int x265hip_sad_xn_batch(int K, int depth, int w, int h,
+                         const void* fenc, int64_t strideF, const void* ref, int64_t strideR,
+                         const int32_t* offF, const int32_t* offRef, int n, int32_t* out, void* stream);
+/* pixel_sse_t (primitives.h:135, pixel.cpp:167): out is sse_t widened to u64 */
+int x265hip_sse_pp_batch(int depth, int w, int h, const void* planeA, int64_t strideA, const void* planeB, int64_t strideB,
+                         const int32_t* offA, const int32_t* offB, int n, uint64_t* out, void* stream);
+/* pixel_sse_ss_t (primitives.h:136) on int16 planes; planeB == NULL gives pixel_ssd_s_t (primitives.h:137, pixel.cpp:379) */
+int x265hip_sse_ss_batch(int w, int h, const int16_t* planeA, int64_t strideA, const int16_t* planeB, int64_t strideB,
+                         const int32_t* offA, const int32_t* offB, int n, uint64_t* out, void* stream);
+
+/* ---------------------------------------------------------------- block arithmetic -------------------------- */
+/* pixel_sub_ps_t (primitives.h:147, pixel.cpp:815): resi = a - b */
+int x265hip_sub_ps_batch(int depth, int w, int h, int16_t* resi, int64_t strideD, const void* planeA, int64_t strideA,
+                         const void* planeB, int64_t strideB, const int32_t* offD, const int32_t* offA, const int32_t* offB,
+                         int n, void* stream);
+/* pixel_add_ps_t (primitives.h:148, pixel.cpp:829): recon = clip(pred + resi) */
+int x265hip_add_ps_batch(int depth, int w, int h, void* recon, int64_t strideD, const void* pred, int64_t strideA,
+                         const int16_t* resi, int64_t strideR, const int32_t* offD, const int32_t* offA, const int32_t* offR,
+                         int n, void* stream);
+/* addAvg_t (primitives.h:173, pixel.cpp:842) */
+int x265hip_addavg_batch(int depth, int w, int h, const int16_t* src0, int64_t stride0, const int16_t* src1, int64_t stride1,
+                         void* dst, int64_t strideD, const int32_t* off0, const int32_t* off1, const int32_t* offD,
+                         int n, void* stream);
+/* pixelavg_pp_t (primitives.h:149, pixel.cpp:545) */
+int x265hip_pixelavg_pp_batch(int depth, int w, int h, void* dst, int64_t strideD, const void* src0, int64_t stride0,
+                              const void* src1, int64_t stride1, const int32_t* offD, const int32_t* off0, const int32_t* off1,
+                              int n, void* stream);
+/* copy_pp_t / copy_sp_t / copy_ps_t / copy_ss_t (primitives.h:143-146, pixel.cpp:759-812): kind = "pp","sp","ps","ss" as 0..3 */
+int x265hip_copy_batch(int kind, int depth, int w, int h, void* dst, int64_t strideD, const void* src, int64_t strideS,
+                       const int32_t* offD, const int32_t* offS, int n, void* stream);
+/* filter_p2s_t (primitives.h:185, ipfilter.cpp:40) */
+int x265hip_p2s_batch(int depth, int w, int h, const void* src, int64_t strideS, int16_t* dst, int64_t strideD,
+                      const int32_t* offS, const int32_t* offD, int n, void* stream);
+
+/* ---------------------------------------------------------------- transforms -------------------------------- */
+/* dct_t (primitives.h:153; dct.cpp:442-525): src blocks of `size` x `size` int16 at src+offS[i] with row stride
+ * strideS -> dst + i*size*size (contiguous).  dst4 != 0 selects the 4x4 DST (cu[].dct vs dst4x4 slot). */
+int x265hip_dct_batch(int size, int dst4, int depth, const int16_t* src, int64_t strideS, const int32_t* offS,
+                      int16_t* dst, int n, void* stream);
+/* idct_t (primitives.h:154; dct.cpp:527-610): src + i*size*size (contiguous) -> dst+offD[i] with row stride strideD */
+int x265hip_idct_batch(int size, int dst4, int depth, const int16_t* src, int16_t* dst, int64_t strideD,
+                       const int32_t* offD, int n, void* stream);
+/* quant_t (primitives.h:159; dct.cpp:664): n TUs of numCoeff coefficients, all contiguous.  quantCoeff is
+ * numCoeff entries shared by every TU (x265: ScalingList::m_quantCoef[size][list][rem]).  deltaU may be NULL.
+ * numSig[i] receives the return value of the reference call. */
+int x265hip_quant_batch(const int16_t* coef, const int32_t* quantCoeff, int32_t* deltaU, int16_t* qCoef,
+                        int qBits, int add, int numCoeff, int n, uint32_t* numSig, void* stream);
+/* nquant_t (primitives.h:160; dct.cpp:688) */
+int x265hip_nquant_batch(const int16_t* coef, const int32_t* quantCoeff, int16_t* qCoef,
+                         int qBits, int add, int numCoeff, int n, uint32_t* numSig, void* stream);
+/* dequant_normal_t (primitives.h:162; dct.cpp:612): elementwise over `num` coefficients (any number of TUs) */
+int x265hip_dequant_normal(const int16_t* quantCoef, int16_t* coef, int64_t num, int scale, int shift, void* stream);
+/* dequant_scaling_t (primitives.h:161; dct.cpp:636): deQuantCoef has numCoeff entries shared by the n TUs */
+int x265hip_dequant_scaling_batch(const int16_t* quantCoef, const int32_t* deQuantCoef, int16_t* coef,
+                                  int numCoeff, int n, int per, int shift, void* stream);
+/* count_nonzero_t (primitives.h:163; dct.cpp:714) per TU */
+int x265hip_count_nonzero_batch(const int16_t* qCoef, int numCoeff, int n, uint32_t* out, void* stream);
+
+/* ---------------------------------------------------------------- interpolation ----------------------------- */
+/* filter_pp_t / filter_hps_t / filter_ps_t / filter_sp_t / filter_ss_t / filter_hv_pp_t (primitives.h:176-183;
+ * ipfilter.cpp:79-369).  taps = 8 (luma) or 4 (chroma).  One job = one W x H block:
+ *   src + offS[i] is the block origin in the source plane (the filter reads 3 (luma) / 1 (chroma) elements before
+ *   it and 4 / 2 after, horizontally and/or vertically, exactly as the reference does);
+ *   coeff[i] = coeffIdx; for HV: coeff[i] = idxX | (idxY << 4).
+ * src element type: pixel for HPP/HPS/VPP/VPS/HV, int16 for VSP/VSS; dst: pixel for *PP/VSP/HV, int16 for *PS/VSS. */
+#define X265HIP_IF_HPP 0
+#define X265HIP_IF_HPS 1   /* isRowExt = (flags & 1) : taps-1 extra rows starting taps/2-1 rows above */
+#define X265HIP_IF_VPP 2
+#define X265HIP_IF_VPS 3
+#define X265HIP_IF_VSP 4
+#define X265HIP_IF_VSS 5
+#define X265HIP_IF_HVPP 6
+int x265hip_interp_batch(int kind, int taps, int depth, int w, int h,
+                         const void* src, int64_t strideS, void* dst, int64_t strideD,
+                         const int32_t* offS, const int32_t* offD, const int32_t* coeff, int flags, int n, void* stream);
+
+/* ---------------------------------------------------------------- fused hot loops --------------------------- */
+/* MotionEstimate::motionEstimate (reference: source/encoder/motion.cpp:739-1569) for n PUs of one shape in one
+ * launch: predictor / zero / candidate tests, integer search (searchMethod X265_DIA_SEARCH 0, X265_HEX_SEARCH 1,
+ * X265_FULL_SEARCH 5; x265.h), then the sub-pel refine of workload[subme] (motion.cpp:48-58) with luma_hpp/vpp/hvpp
+ * + sad/satd (subpelCompare, motion.cpp:1571).  Luma only (bChromaSATD == false, i.e. subme <= 2 semantics for chroma).
+ *   fencPlane/refPlane: source and (padded) reconstructed reference luma planes; PU i sits at pu_xy[2i], pu_xy[2i+1]
+ *   in both planes' coordinates (same origin);  mvmin/mvmax: full-pel search bounds [n][2] (Search::setSearchRange,
+ *   search.cpp:2724);  qmvp: quarter-pel predictor [n][2];  numCand candidates per PU in mvc [n][numCand][2];
+ *   mvcost: the lambda-scaled u16 MVD cost row of BitCost::setQP (bitcost.cpp:32), pointer to the entry of MVD 0,
+ *   valid for indices [-mvcostHalf, mvcostHalf];  outMv [n][2] quarter-pel;  outCost [n]. */
+int x265hip_motion_estimate_batch(int depth, int w, int h,
+                                  const void* fencPlane, int64_t strideF, const void* refPlane, int64_t strideR,
+                                  const int32_t* pu_xy, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp,
+                                  int numCand, const int32_t* mvc, int merange, int searchMethod, int subme,
+                                  const uint16_t* mvcost, int mvcostHalf,
+                                  int n, int32_t* outMv, int32_t* outCost, void* stream);
+
+/* The residual chain of Search::estimateResidualQT for n TUs of one size (reference: search.cpp:3178-3330 ->
+ * quant.cpp:397 transformNxN, :543 invtransformNxN): resi = fenc - pred (sub_ps) -> dct -> quant (flat quantCoeff,
+ * add = rounding offset) -> numSig; if numSig: dequant_normal -> idct -> recon = clip(pred + resi') (add_ps)
+ * else recon = pred; dist = sse_pp(fenc, recon).  Every intermediate equals the corresponding primitive's output.
+ *   TU i: fenc block at fenc+offF[i], prediction at pred+offP[i], recon written at recon+offR[i];
+ *   level: [n][size*size] quantised coefficients (quant_t's qCoef); numSig[n]; dist[n]. */
+int x265hip_residual_chain_batch(int size, int depth,
+                                 const void* fenc, int64_t strideF, const void* pred, int64_t strideP,
+                                 void* recon, int64_t strideR,
+                                 const int32_t* offF, const int32_t* offP, const int32_t* offR,
+                                 const int32_t* quantCoeff, int qBits, int add, int dqScale, int dqShift,
+                                 int16_t* level, uint32_t* numSig, uint64_t* dist, int n, void* stream);
+
+/* ---------------------------------------------------------------- per-call entry points (host pointers) ----- */
+/* What the reference-side table shims bind (x265_amd/host/x265_hip_primitives.cpp).  Arguments are the slot's own
+ * arguments (HOST pointers, caller-owned, valid only during the call — primitives.h:133-234); each call stages the
+ * operands into pinned memory, launches the batched kernel with n = 1 on the calling thread's stream and waits.
+ * On any failure they return a negative code and leave the outputs untouched so the shim can call the C slot. */
+int x265hip_call_pixcmp(int op, int depth, int w, int h, const void* a, int64_t sa, const void* b, int64_t sb, int32_t* result);
+int x265hip_call_sad_xn(int K, int depth, int w, int h, const void* fenc, const void* const* refs, int64_t strideR, int32_t* res);
+int x265hip_call_sse_pp(int depth, int w, int h, const void* a, int64_t sa, const void* b, int64_t sb, uint64_t* result);
+int x265hip_call_sse_ss(int w, int h, const int16_t* a, int64_t sa, const int16_t* b, int64_t sb, uint64_t* result);
+int x265hip_call_dct(int size, int dst4, int depth, const int16_t* src, int16_t* dst, int64_t srcStride);
+int x265hip_call_idct(int size, int dst4, int depth, const int16_t* src, int16_t* dst, int64_t dstStride);
+int x265hip_call_quant(const int16_t* coef, const int32_t* quantCoeff, int32_t* deltaU, int16_t* qCoef,
+                       int qBits, int add, int numCoeff, uint32_t* numSig);
+int x265hip_call_nquant(const int16_t* coef, const int32_t* quantCoeff, int16_t* qCoef, int qBits, int add, int numCoeff,
+                        uint32_t* numSig);
+int x265hip_call_dequant_normal(const int16_t* quantCoef, int16_t* coef, int num, int scale, int shift);
+int x265hip_call_dequant_scaling(const int16_t* quantCoef, const int32_t* deQuantCoef, int16_t* coef, int num, int per, int shift);
+int x265hip_call_interp(int kind, int taps, int depth, int w, int h, const void* src, int64_t strideS,
+                        void* dst, int64_t strideD, int coeffIdx, int coeffIdy, int isRowExt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* X265HIP_H */

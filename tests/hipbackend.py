@@ -1,0 +1,230 @@
+"""Hip(depth): the same numpy-level front end as backends.Orc / backends.Ref, but every method goes through the
+C ABI of libx265hip.so (batched entry points with n = 1) on the GPU.  Used only by the -m gpu parity tests."""
+import ctypes as C
+
+import numpy as np
+
+from x265_amd import hipprim as hp
+from x265_amd.hipprim import DevBuf, check, dev_i32
+
+MVCOST_HALF = 2 * 32768
+
+
+def _off(a, o):
+    return int(o[0]) * a.shape[1] + int(o[1])
+
+
+_KEEP = []
+
+
+def _ip(values):
+    """device int32 array kept alive until _release() (a temporary DevBuf would be freed before the launch)"""
+    b = dev_i32(values)
+    _KEEP.append(b)
+    return b.ptr
+
+
+def _release():
+    del _KEEP[:]
+
+
+class Hip:
+    name = "hip"
+
+    def __init__(self, depth):
+        self.depth = depth
+        self.pix = hp.pix_dtype(depth)
+        self.L = hp.lib()
+        self._mvcost = {}
+
+    # ---- pixel compare
+    def _cmp(self, op, w, h, a, ao, b, bo):
+        da, db = DevBuf(a), DevBuf(b)
+        oa, ob = dev_i32([_off(a, ao)]), dev_i32([_off(b, bo)])
+        out = DevBuf.zeros((1,), np.int32)
+        check(self.L.x265hip_pixcmp_batch(op, self.depth, w, h, da.ptr, a.shape[1], db.ptr, b.shape[1], oa.ptr, ob.ptr, 1, out.ptr, None))
+        return int(out.get()[0])
+
+    def sad(self, w, h, a, ao, b, bo):
+        return self._cmp(hp.CMP_SAD, w, h, a, ao, b, bo)
+
+    def satd(self, w, h, a, ao, b, bo):
+        return self._cmp(hp.CMP_SATD, w, h, a, ao, b, bo)
+
+    def sa8d(self, size, a, ao, b, bo):
+        return self._cmp(hp.CMP_SA8D, size, size, a, ao, b, bo)
+
+    def sa8d8(self, w, h, a, ao, b, bo):
+        return self._cmp(hp.CMP_SA8D8, w, h, a, ao, b, bo)
+
+    def psy_cost_pp(self, size, a, ao, b, bo):
+        return self._cmp(hp.CMP_PSY, size, size, a, ao, b, bo)
+
+    def sad_xn(self, w, h, fenc, ref, offs):
+        K = len(offs)
+        df, dr = DevBuf(fenc), DevBuf(ref)
+        of, orf = dev_i32([0]), dev_i32([_off(ref, o) for o in offs])
+        out = DevBuf.zeros((K,), np.int32)
+        check(self.L.x265hip_sad_xn_batch(K, self.depth, w, h, df.ptr, fenc.shape[1], dr.ptr, ref.shape[1], of.ptr, orf.ptr, 1, out.ptr, None))
+        return out.get()
+
+    def sse_pp(self, size, a, ao, b, bo):
+        da, db = DevBuf(a), DevBuf(b)
+        oa, ob = dev_i32([_off(a, ao)]), dev_i32([_off(b, bo)])
+        out = DevBuf.zeros((1,), np.uint64)
+        check(self.L.x265hip_sse_pp_batch(self.depth, size, size, da.ptr, a.shape[1], db.ptr, b.shape[1], oa.ptr, ob.ptr, 1, out.ptr, None))
+        return int(out.get()[0])
+
+    def sse_ss(self, size, a, ao, b, bo):
+        da, db = DevBuf(a), DevBuf(b)
+        oa, ob = dev_i32([_off(a, ao)]), dev_i32([_off(b, bo)])
+        out = DevBuf.zeros((1,), np.uint64)
+        check(self.L.x265hip_sse_ss_batch(size, size, da.ptr, a.shape[1], db.ptr, b.shape[1], oa.ptr, ob.ptr, 1, out.ptr, None))
+        return int(out.get()[0])
+
+    def ssd_s(self, size, a, ao):
+        da = DevBuf(a)
+        oa = dev_i32([_off(a, ao)])
+        out = DevBuf.zeros((1,), np.uint64)
+        check(self.L.x265hip_sse_ss_batch(size, size, da.ptr, a.shape[1], None, 0, oa.ptr, None, 1, out.ptr, None))
+        return int(out.get()[0])
+
+    # ---- block arithmetic
+    def sub_ps(self, size, a, ao, b, bo):
+        da, db = DevBuf(a), DevBuf(b)
+        d = DevBuf.zeros((size, size), np.int16)
+        check(self.L.x265hip_sub_ps_batch(self.depth, size, size, d.ptr, size, da.ptr, a.shape[1], db.ptr, b.shape[1],
+                                          _ip([0]), _ip([_off(a, ao)]), _ip([_off(b, bo)]), 1, None))
+        return d.get()
+
+    def add_ps(self, size, a, ao, r, ro):
+        da, dr = DevBuf(a), DevBuf(r)
+        d = DevBuf.zeros((size, size), self.pix)
+        check(self.L.x265hip_add_ps_batch(self.depth, size, size, d.ptr, size, da.ptr, a.shape[1], dr.ptr, r.shape[1],
+                                          _ip([0]), _ip([_off(a, ao)]), _ip([_off(r, ro)]), 1, None))
+        return d.get()
+
+    def addAvg(self, w, h, a, ao, b, bo):
+        da, db = DevBuf(a), DevBuf(b)
+        d = DevBuf.zeros((h, w), self.pix)
+        check(self.L.x265hip_addavg_batch(self.depth, w, h, da.ptr, a.shape[1], db.ptr, b.shape[1], d.ptr, w,
+                                          _ip([_off(a, ao)]), _ip([_off(b, bo)]), _ip([0]), 1, None))
+        return d.get()
+
+    def pixelavg_pp(self, w, h, a, ao, b, bo):
+        da, db = DevBuf(a), DevBuf(b)
+        d = DevBuf.zeros((h, w), self.pix)
+        check(self.L.x265hip_pixelavg_pp_batch(self.depth, w, h, d.ptr, w, da.ptr, a.shape[1], db.ptr, b.shape[1],
+                                               _ip([0]), _ip([_off(a, ao)]), _ip([_off(b, bo)]), 1, None))
+        return d.get()
+
+    def p2s(self, w, h, a, ao):
+        da = DevBuf(a)
+        d = DevBuf.zeros((h, w), np.int16)
+        check(self.L.x265hip_p2s_batch(self.depth, w, h, da.ptr, a.shape[1], d.ptr, w, _ip([_off(a, ao)]), _ip([0]), 1, None))
+        return d.get()
+
+    def copy(self, kind, w, h, a, ao):
+        """kind 0 pp, 1 sp, 2 ps, 3 ss"""
+        da = DevBuf(a)
+        dt = [self.pix, self.pix, np.int16, np.int16][kind]
+        d = DevBuf.zeros((h, w), dt)
+        check(self.L.x265hip_copy_batch(kind, self.depth, w, h, d.ptr, w, da.ptr, a.shape[1], _ip([0]), _ip([_off(a, ao)]), 1, None))
+        return d.get()
+
+    # ---- transforms
+    def dct(self, size, a, ao):
+        da = DevBuf(a)
+        d = DevBuf.zeros((size * size,), np.int16)
+        check(self.L.x265hip_dct_batch(size, 0, self.depth, da.ptr, a.shape[1], _ip([_off(a, ao)]), d.ptr, 1, None))
+        return d.get()
+
+    def idct(self, size, a):
+        da = DevBuf(a)
+        d = DevBuf.zeros((size, size), np.int16)
+        check(self.L.x265hip_idct_batch(size, 0, self.depth, da.ptr, d.ptr, size, _ip([0]), 1, None))
+        return d.get()
+
+    def dst4(self, a, ao):
+        da = DevBuf(a)
+        d = DevBuf.zeros((16,), np.int16)
+        check(self.L.x265hip_dct_batch(4, 1, self.depth, da.ptr, a.shape[1], _ip([_off(a, ao)]), d.ptr, 1, None))
+        return d.get()
+
+    def idst4(self, a):
+        da = DevBuf(a)
+        d = DevBuf.zeros((4, 4), np.int16)
+        check(self.L.x265hip_idct_batch(4, 1, self.depth, da.ptr, d.ptr, 4, _ip([0]), 1, None))
+        return d.get()
+
+    def quant(self, coef, qc, qbits, add):
+        n = coef.size
+        dc, dq = DevBuf(coef), DevBuf(qc)
+        du, q, ns = DevBuf.zeros((n,), np.int32), DevBuf.zeros((n,), np.int16), DevBuf.zeros((1,), np.uint32)
+        check(self.L.x265hip_quant_batch(dc.ptr, dq.ptr, du.ptr, q.ptr, qbits, add, n, 1, ns.ptr, None))
+        return q.get(), du.get(), int(ns.get()[0])
+
+    def nquant(self, coef, qc, qbits, add):
+        n = coef.size
+        dc, dq = DevBuf(coef), DevBuf(qc)
+        q, ns = DevBuf.zeros((n,), np.int16), DevBuf.zeros((1,), np.uint32)
+        check(self.L.x265hip_nquant_batch(dc.ptr, dq.ptr, q.ptr, qbits, add, n, 1, ns.ptr, None))
+        return q.get(), int(ns.get()[0])
+
+    def dequant_normal(self, q, scale, shift):
+        dq = DevBuf(q)
+        c = DevBuf.zeros((q.size,), np.int16)
+        check(self.L.x265hip_dequant_normal(dq.ptr, c.ptr, q.size, scale, shift, None))
+        return c.get()
+
+    def dequant_scaling(self, q, dqc, per, shift):
+        dq, dd = DevBuf(q), DevBuf(dqc)
+        c = DevBuf.zeros((q.size,), np.int16)
+        check(self.L.x265hip_dequant_scaling_batch(dq.ptr, dd.ptr, c.ptr, q.size, 1, per, shift, None))
+        return c.get()
+
+    def count_nonzero(self, size, a):
+        da = DevBuf(a)
+        out = DevBuf.zeros((1,), np.uint32)
+        check(self.L.x265hip_count_nonzero_batch(da.ptr, size * size, 1, out.ptr, None))
+        return int(out.get()[0])
+
+    # ---- interpolation
+    def interp(self, kind, chroma, w, h, src, so, idx, idy=0, ext=0):
+        taps = 4 if chroma else 8
+        k = {"hpp": hp.IF_HPP, "hps": hp.IF_HPS, "vpp": hp.IF_VPP, "vps": hp.IF_VPS, "vsp": hp.IF_VSP,
+             "vss": hp.IF_VSS, "hvpp": hp.IF_HVPP}[kind]
+        rows = h + (taps - 1 if (kind == "hps" and ext) else 0)
+        odt = self.pix if kind in ("hpp", "vpp", "vsp", "hvpp") else np.int16
+        ds = DevBuf(src)
+        d = DevBuf.zeros((rows, w), odt)
+        coeff = idx | (idy << 4) if kind == "hvpp" else idx
+        check(self.L.x265hip_interp_batch(k, taps, self.depth, w, h, ds.ptr, src.shape[1], d.ptr, w,
+                                          _ip([_off(src, so)]), _ip([0]), _ip([coeff]),
+                                          1 if ext else 0, 1, None))
+        return d.get()
+
+    # ---- motion estimation
+    def set_mvcost_table(self, qp, table):
+        """table: the u16[4*32768+1] MVD cost row (host side builds it; BitCost::setQP is float host code, bitcost.cpp:32)"""
+        self._mvcost[qp] = DevBuf(table)
+
+    def motion_estimate_batch(self, refplane, fencplane, w, h, pu_xy, mvmin, mvmax, qmvp, mvc, merange, method, subme, qp):
+        n = len(pu_xy)
+        numCand = len(mvc[0]) if n and len(mvc) else 0
+        dr, df = DevBuf(refplane), DevBuf(fencplane)
+        tab = self._mvcost[qp]
+        outmv, outcost = DevBuf.zeros((n, 2), np.int32), DevBuf.zeros((n,), np.int32)
+        cand = dev_i32(np.asarray(mvc, np.int32).reshape(-1)) if numCand else None
+        check(self.L.x265hip_motion_estimate_batch(
+            self.depth, w, h, df.ptr, fencplane.shape[1], dr.ptr, refplane.shape[1],
+            _ip(np.asarray(pu_xy, np.int32)), _ip(np.asarray(mvmin, np.int32)),
+            _ip(np.asarray(mvmax, np.int32)), _ip(np.asarray(qmvp, np.int32)),
+            numCand, cand.ptr if cand else None, merange, method, subme,
+            tab.at(MVCOST_HALF), MVCOST_HALF, n, outmv.ptr, outcost.ptr, None))
+        return outcost.get(), outmv.get()
+
+    def motion_estimate(self, refplane, fencplane, bx, by, w, h, mvmin, mvmax, qmvp, mvc, merange, method, subme, qp):
+        cost, mv = self.motion_estimate_batch(refplane, fencplane, w, h, [(bx, by)], [mvmin], [mvmax], [qmvp],
+                                              [mvc] if len(mvc) else [], merange, method, subme, qp)
+        return int(cost[0]), (int(mv[0, 0]), int(mv[0, 1]))

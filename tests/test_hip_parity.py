@@ -1,0 +1,352 @@
+"""GPU parity: every HIP entry point of libx265hip.so (through the C ABI) against the pinned CPU oracle, bit-exact.
+
+The per-primitive sweep reuses the TestBench-shaped seeded cases of tests/cases.py (random / all-min / all-max
+buffers, unaligned origins, stride 96) — the same cases that pin the oracle to the real reference and to the golden
+digests — and reports EVERY mismatch (grouped), not just the first, so one GPU run tells the whole story."""
+import collections
+
+import numpy as np
+import pytest
+
+from backends import Orc, same, PU_SIZES
+from cases import gen_cases, me_scene, pix_buf, short_buf
+
+pytestmark = pytest.mark.gpu
+
+DEPTHS = [8, 10]
+NOT_ON_GPU = {"var", "cpy2Dto1D_shl", "cpy2Dto1D_shr", "cpy1Dto2D_shl", "cpy1Dto2D_shr", "copy_cnt", "denoise_dct", "rdoquant"}
+
+
+@pytest.fixture(scope="module")
+def hipmod():
+    import hipbackend
+    from x265_amd import hipprim as hp
+    assert hp.lib().x265hip_device_count() > 0, "no HIP device: the -m gpu tests need a real MI355X"
+    hp.check(hp.lib().x265hip_init(0))
+    return hipbackend
+
+
+def _report(bad, total):
+    if not bad:
+        return
+    groups = collections.Counter(" ".join(lbl.split()[:2]) for lbl in bad)
+    msg = "%d / %d mismatches; by (primitive size): %s; first: %s" % (len(bad), total, dict(groups.most_common(40)), bad[:6])
+    pytest.fail(msg)
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_every_primitive_matches_oracle(hipmod, depth):
+    o, g = Orc(depth), hipmod.Hip(depth)
+    bad, n = [], 0
+    for label, fn, args in gen_cases(depth):
+        if fn in NOT_ON_GPU:
+            continue
+        want = getattr(o, fn)(*args)
+        try:
+            got = getattr(g, fn)(*args)
+        except Exception as e:  # noqa: BLE001 - report and continue
+            bad.append("%s !! %s" % (label, str(e)[:80]))
+            hipmod._release()
+            continue
+        hipmod._release()
+        n += 1
+        if not same(got, want):
+            bad.append(label)
+    assert n > 1500
+    _report(bad, n)
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_chroma_sa8d8_and_copies(hipmod, depth):
+    o, g = Orc(depth), hipmod.Hip(depth)
+    rng = np.random.default_rng(5 + depth)
+    a, b = pix_buf(rng, "rand", (160, 96), depth), pix_buf(rng, "rand", (160, 96), depth)
+    s = short_buf(rng, "rand", (160, 96), -(1 << depth) + 1, (1 << depth) - 1)
+    bad = []
+    for (w, h) in [(8, 8), (16, 16), (32, 32), (8, 16), (16, 8), (16, 32), (32, 16), (8, 32), (32, 8), (24, 32), (32, 24), (16, 24)]:
+        if w % 8 or h % 8:
+            continue
+        want = o._f("orc_sa8d8")(o_ptr(a, 3, 5), 96, o_ptr(b, 7, 2), 96, w, h)
+        if g.sa8d8(w, h, a, (3, 5), b, (7, 2)) != want:
+            bad.append("sa8d8 %dx%d" % (w, h))
+    for (w, h) in PU_SIZES + [(2, 4), (6, 8), (2, 8), (8, 2), (8, 6), (4, 2)]:
+        for kind, src in ((0, a), (1, s), (2, a), (3, s)):
+            got = g.copy(kind, w, h, src, (9, 11))
+            hipmod._release()
+            blk = src[9:9 + h, 11:11 + w]
+            want = blk.astype(got.dtype)   # sp: truncating cast like (pixel)b[x]; ps/ss: widening / identity
+            if not np.array_equal(got, want):
+                bad.append("copy%d %dx%d" % (kind, w, h))
+    _report(bad, 1)
+
+
+def o_ptr(a, y, x):
+    from oracle import pyoracle as po
+    return po.ptr(a, y, x)
+
+
+# ---- batched launches: many jobs per call, ragged tails, all shapes ----------------------------------------------------
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_pixcmp_batches(hipmod, depth):
+    from x265_amd import hipprim as hp
+    from x265_amd.hipprim import DevBuf, check, dev_i32
+    o = Orc(depth)
+    rng = np.random.default_rng(100 + depth)
+    H, W = 200, 328
+    a, b = pix_buf(rng, "rand", (H, W), depth), pix_buf(rng, "rand", (H, W), depth)
+    da, db = DevBuf(a), DevBuf(b)
+    L = hp.lib()
+    bad = []
+    ops = [(hp.CMP_SAD, "orc_sad", None), (hp.CMP_SATD, "orc_satd", None), (hp.CMP_SA8D, "orc_sa8d", "sq"),
+           (hp.CMP_SA8D8, "orc_sa8d8", "m8"), (hp.CMP_PSY, "orc_psy_cost_pp", "sq")]
+    for (w, h) in PU_SIZES:
+        for op, fn, cons in ops:
+            if cons == "sq" and w != h:
+                continue
+            if cons == "m8" and (w % 8 or h % 8):
+                continue
+            n = 37 if w * h >= 1024 else 301            # ragged: not a multiple of the blocks-per-wave
+            ya, xa = rng.integers(0, H - h, n), rng.integers(0, W - w, n)
+            yb, xb = rng.integers(0, H - h, n), rng.integers(0, W - w, n)
+            oa, ob = dev_i32(ya * W + xa), dev_i32(yb * W + xb)
+            out = DevBuf.zeros((n,), np.int32)
+            check(L.x265hip_pixcmp_batch(op, depth, w, h, da.ptr, W, db.ptr, W, oa.ptr, ob.ptr, n, out.ptr, None))
+            got = out.get()
+            f = o._f(fn)
+            for i in range(n):
+                pa, pb = o_ptr(a, int(ya[i]), int(xa[i])), o_ptr(b, int(yb[i]), int(xb[i]))
+                want = f(pa, W, pb, W, w) if fn in ("orc_sa8d", "orc_psy_cost_pp") else f(pa, W, pb, W, w, h)
+                if int(got[i]) != want:
+                    bad.append("%s %dx%d job%d got %d want %d" % (fn[4:], w, h, i, got[i], want))
+                    break
+    _report(bad, 1)
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_transform_batches(hipmod, depth):
+    from x265_amd import hipprim as hp
+    from x265_amd.hipprim import DevBuf, check, dev_i32
+    from oracle import pyoracle as po
+    O = po.oracle()
+    L = hp.lib()
+    rng = np.random.default_rng(200 + depth)
+    pmax = (1 << depth) - 1
+    bad = []
+    for size in (4, 8, 16, 32):
+        for n in (1, 7, 67, 530):
+            log2n = size.bit_length() - 1
+            S = 1100                                             # residual plane stride
+            plane = short_buf(rng, "rand", (size * 2 + 40, S), -pmax, pmax)
+            ys, xs = rng.integers(0, 40, n), rng.integers(0, S - size, n)
+            offs = dev_i32(ys * S + xs)
+            dp = DevBuf(plane)
+            dst = DevBuf.zeros((n, size * size), np.int16)
+            check(L.x265hip_dct_batch(size, 0, depth, dp.ptr, S, offs.ptr, dst.ptr, n, None))
+            got = dst.get()
+            want = np.zeros_like(got)
+            for i in range(n):
+                O.orc_dct(log2n, po.ptr(plane, int(ys[i]), int(xs[i])), po.ptr(want, i, 0), S, depth)
+            if not np.array_equal(got, want):
+                bad.append("dct %d n=%d (%d TUs differ)" % (size, n, int((got != want).any(axis=1).sum())))
+            # inverse of the quantised-looking coefficients, scattered back into a plane
+            lim = (1 << (depth + 4)) - 1
+            coef = short_buf(rng, "rand", (n, size * size), -lim, lim)
+            coef[:: 3] = short_buf(rng, "rand", coef[:: 3].shape, -32768, 32767)
+            dc = DevBuf(coef)
+            gx = (np.arange(n) % 30) * 36
+            gy = (np.arange(n) // 30) * 33
+            S2 = 30 * 36 + 8
+            outp = DevBuf.zeros((int(gy.max()) + 40, S2), np.int16)
+            offd = dev_i32(gy * S2 + gx)
+            check(L.x265hip_idct_batch(size, 0, depth, dc.ptr, outp.ptr, S2, offd.ptr, n, None))
+            gotp = outp.get()
+            wantp = np.zeros_like(gotp)
+            for i in range(n):
+                O.orc_idct(log2n, po.ptr(coef, i, 0), po.ptr(wantp, int(gy[i]), int(gx[i])), S2, depth)
+            if not np.array_equal(gotp, wantp):
+                bad.append("idct %d n=%d" % (size, n))
+            # quant / nquant / dequant / count_nonzero on the forward output
+            nc = size * size
+            qp = int(rng.integers(10, 45))
+            qc = np.full(nc, [26214, 23302, 20560, 18396, 16384, 14564][qp % 6], np.int32)
+            qbits = 14 + qp // 6 + (15 - depth - log2n)
+            add = 171 << (qbits - 9)
+            dq = DevBuf(qc)
+            dcoef = DevBuf(want)
+            du, ql, ns = DevBuf.zeros((n, nc), np.int32), DevBuf.zeros((n, nc), np.int16), DevBuf.zeros((n,), np.uint32)
+            check(L.x265hip_quant_batch(dcoef.ptr, dq.ptr, du.ptr, ql.ptr, qbits, add, nc, n, ns.ptr, None))
+            gq, gdu, gns = ql.get(), du.get(), ns.get()
+            wq, wdu, wns = np.zeros_like(gq), np.zeros_like(gdu), np.zeros_like(gns)
+            for i in range(n):
+                wns[i] = O.orc_quant(po.ptr(want, i, 0), po.ptr(qc), po.ptr(wdu, i, 0), po.ptr(wq, i, 0), qbits, add, nc)
+            if not (np.array_equal(gq, wq) and np.array_equal(gdu, wdu) and np.array_equal(gns, wns)):
+                bad.append("quant %d n=%d" % (size, n))
+            cnt = DevBuf.zeros((n,), np.uint32)
+            check(L.x265hip_count_nonzero_batch(ql.ptr, nc, n, cnt.ptr, None))
+            if not np.array_equal(cnt.get(), (wq != 0).sum(axis=1).astype(np.uint32)):
+                bad.append("count_nonzero %d n=%d" % (size, n))
+            shift = 20 - 14 - (15 - depth - log2n)
+            scale = [40, 45, 51, 57, 64, 72][qp % 6] << (qp // 6)
+            if shift >= 1:
+                dd = DevBuf.zeros((n, nc), np.int16)
+                check(L.x265hip_dequant_normal(ql.ptr, dd.ptr, n * nc, scale, shift, None))
+                wd = np.zeros((n, nc), np.int16)
+                O.orc_dequant_normal(po.ptr(wq), po.ptr(wd), n * nc, scale, shift)
+                if not np.array_equal(dd.get(), wd):
+                    bad.append("dequant_normal %d n=%d" % (size, n))
+    _report(bad, 1)
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_residual_chain_equals_primitive_sequence(hipmod, depth):
+    """x265hip_residual_chain_batch == sub_ps -> dct -> quant -> dequant_normal -> idct -> add_ps -> sse_pp (oracle)."""
+    from x265_amd import hipprim as hp
+    from x265_amd.hipprim import DevBuf, check, dev_i32
+    from oracle import pyoracle as po
+    O = po.oracle()
+    o = Orc(depth)
+    L = hp.lib()
+    rng = np.random.default_rng(300 + depth)
+    bad = []
+    H, W = 136, 264
+    fenc = pix_buf(rng, "rand", (H, W), depth)
+    noise = rng.integers(-12, 13, size=(H, W))
+    pred = np.clip(fenc.astype(np.int64) + noise * (1 << (depth - 8)), 0, (1 << depth) - 1).astype(fenc.dtype)
+    pred[:40] = pix_buf(rng, "rand", (40, W), depth)         # a band of large residuals
+    df, dp = DevBuf(fenc), DevBuf(pred)
+    for size in (4, 8, 16, 32):
+        log2n = size.bit_length() - 1
+        nc = size * size
+        for qp in (22, 37):
+            tus = [(y, x) for y in range(0, H - size + 1, size) for x in range(0, W - size + 1, size)]
+            tus = tus[: len(tus) - 3]                              # ragged tail
+            n = len(tus)
+            offs = np.array([y * W + x for (y, x) in tus], np.int32)
+            do = dev_i32(offs)
+            qc = np.full(nc, [26214, 23302, 20560, 18396, 16384, 14564][qp % 6], np.int32)
+            qbits = 14 + qp // 6 + (15 - depth - log2n)
+            add = 85 << (qbits - 9)
+            shift = 20 - 14 - (15 - depth - log2n)
+            scale = [40, 45, 51, 57, 64, 72][qp % 6] << (qp // 6)
+            drec = DevBuf.zeros((H, W), fenc.dtype)
+            lvl, ns, dist = DevBuf.zeros((n, nc), np.int16), DevBuf.zeros((n,), np.uint32), DevBuf.zeros((n,), np.uint64)
+            check(L.x265hip_residual_chain_batch(size, depth, df.ptr, W, dp.ptr, W, drec.ptr, W, do.ptr, do.ptr, do.ptr,
+                                                 _keep(qc).ptr, qbits, add, scale, shift,
+                                                 lvl.ptr, ns.ptr, dist.ptr, n, None))
+            grec, glvl, gns, gdist = drec.get(), lvl.get(), ns.get(), dist.get()
+            wrec = np.zeros_like(grec)
+            for i, (y, x) in enumerate(tus):
+                resi = o.sub_ps(size, fenc, (y, x), pred, (y, x))
+                coef = np.zeros(nc, np.int16)
+                O.orc_dct(log2n, po.ptr(resi), po.ptr(coef), size, depth)
+                q, du = np.zeros(nc, np.int16), np.zeros(nc, np.int32)
+                nsig = O.orc_quant(po.ptr(coef), po.ptr(qc), po.ptr(du), po.ptr(q), qbits, add, nc)
+                dq = np.zeros(nc, np.int16)
+                O.orc_dequant_normal(po.ptr(q), po.ptr(dq), nc, scale, shift)
+                r2 = np.zeros((size, size), np.int16)
+                O.orc_idct(log2n, po.ptr(dq), po.ptr(r2), size, depth)
+                rec = o.add_ps(size, pred, (y, x), r2, (0, 0))
+                wrec[y:y + size, x:x + size] = rec
+                d = o._f("orc_sse_pp")(po.ptr(fenc, y, x), W, po.ptr(rec), size, size, size)
+                if not (np.array_equal(glvl[i], q) and gns[i] == nsig and int(gdist[i]) == d):
+                    bad.append("chain %d qp%d tu%d (level %s numSig %d/%d dist %d/%d)" % (
+                        size, qp, i, np.array_equal(glvl[i], q), gns[i], nsig, int(gdist[i]), d))
+                    break
+            mask = np.zeros((H, W), bool)
+            for (y, x) in tus:
+                mask[y:y + size, x:x + size] = True
+            if not np.array_equal(grec[mask], wrec[mask]):
+                bad.append("chain-recon %d qp%d" % (size, qp))
+            if grec[~mask].any():
+                bad.append("chain-recon-outside %d qp%d" % (size, qp))
+    _report(bad, 1)
+
+
+_KEEPALIVE = []
+
+
+def _keep(arr):
+    from x265_amd.hipprim import DevBuf
+    b = DevBuf(arr)
+    _KEEPALIVE.append(b)
+    return b
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_interp_batches(hipmod, depth):
+    from x265_amd import hipprim as hp
+    from x265_amd.hipprim import DevBuf, check, dev_i32
+    o = Orc(depth)
+    L = hp.lib()
+    rng = np.random.default_rng(400 + depth)
+    H, W = 180, 300
+    p = pix_buf(rng, "rand", (H, W), depth)
+    sh = short_buf(rng, "rand", (H, W), -8192, 8191)
+    dP, dS = DevBuf(p), DevBuf(sh)
+    bad = []
+    kinds = [("hpp", hp.IF_HPP), ("hps", hp.IF_HPS), ("vpp", hp.IF_VPP), ("vps", hp.IF_VPS), ("vsp", hp.IF_VSP), ("vss", hp.IF_VSS), ("hvpp", hp.IF_HVPP)]
+    for (w, h) in [(8, 8), (16, 16), (64, 64), (12, 16), (32, 24), (4, 8), (48, 64)]:
+        for name, k in kinds:
+            n = 23
+            src = sh if name in ("vsp", "vss") else p
+            dsrc = dS if name in ("vsp", "vss") else dP
+            ys, xs = rng.integers(8, H - h - 8, n), rng.integers(8, W - w - 8, n)
+            cx, cy = rng.integers(1, 4, n), rng.integers(1, 4, n)
+            coeff = (cx | (cy << 4)) if name == "hvpp" else cx
+            odt = p.dtype if name in ("hpp", "vpp", "vsp", "hvpp") else np.int16
+            out = DevBuf.zeros((n, h, w), odt)
+            check(L.x265hip_interp_batch(k, 8, depth, w, h, dsrc.ptr, W, out.ptr, w, dev_keep(ys * W + xs), dev_keep(np.arange(n) * w * h),
+                                         dev_keep(coeff), 0, n, None))
+            got = out.get()
+            for i in range(n):
+                want = o.interp(name, 0, w, h, src, (int(ys[i]), int(xs[i])), int(cx[i]), int(cy[i]))
+                if not np.array_equal(got[i], want):
+                    bad.append("%s %dx%d job%d" % (name, w, h, i))
+                    break
+    _report(bad, 1)
+
+
+def dev_keep(values):
+    from x265_amd.hipprim import dev_i32
+    b = dev_i32(values)
+    _KEEPALIVE.append(b)
+    return b.ptr
+
+
+# ---- motion estimation ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("depth", DEPTHS)
+@pytest.mark.parametrize("method", [0, 1, 5])
+def test_motion_estimate_matches_oracle(hipmod, depth, method):
+    o, g = Orc(depth), hipmod.Hip(depth)
+    rng = np.random.default_rng(77 + depth + method)
+    refp, srcp, m = me_scene(depth, 99 + depth)
+    H, W = refp.shape[0] - 2 * m, refp.shape[1] - 2 * m
+    sizes = [(8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 24), (12, 16), (64, 48), (16, 4), (8, 32), (4, 8), (8, 4), (24, 32), (48, 64)]
+    bad, total = [], 0
+    for qp in (22, 37):
+        g.set_mvcost_table(qp, o.mvcost_table(qp))
+    for subme in (0, 1, 2, 3, 5, 7):
+        for (w, h) in sizes:
+            npu = 3 if method == 5 else 12
+            merange = 10 if method == 5 else int(rng.choice([16, 32, 57]))
+            qp = int(rng.choice([22, 37]))
+            numCand = int(rng.integers(0, 4))
+            pus, mins, maxs, mvps, cands = [], [], [], [], []
+            for _ in range(npu):
+                bx = m + int(rng.integers(0, (W - w) // 4 + 1)) * 4
+                by = m + int(rng.integers(0, (H - h) // 4 + 1)) * 4
+                qmvp = (int(rng.integers(-40, 41)), int(rng.integers(-40, 41)))
+                mvmin = ((qmvp[0] >> 2) - merange, (qmvp[1] >> 2) - merange)
+                mvmax = ((qmvp[0] >> 2) + merange, (qmvp[1] >> 2) + merange)
+                if rng.integers(0, 3) == 0:
+                    mvmax = (mvmax[0], min(mvmax[1], int(rng.integers(0, 6))))
+                pus.append((bx, by)); mins.append(mvmin); maxs.append(mvmax); mvps.append(qmvp)
+                cands.append([(int(rng.integers(-60, 61)), int(rng.integers(-60, 61))) for _ in range(numCand)])
+            cost, mv = g.motion_estimate_batch(refp, srcp, w, h, pus, mins, maxs, mvps, cands if numCand else [], merange, method, subme, qp)
+            hipmod._release()
+            for i in range(npu):
+                want = o.motion_estimate(refp, srcp, pus[i][0], pus[i][1], w, h, mins[i], maxs[i], mvps[i], cands[i], merange, method, subme, qp)
+                total += 1
+                if (int(cost[i]), (int(mv[i, 0]), int(mv[i, 1]))) != want:
+                    bad.append("me%d %dx%d subme%d got %s want %s" % (method, w, h, subme, (int(cost[i]), tuple(mv[i])), want))
+    _report(bad, total)

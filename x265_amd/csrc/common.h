@@ -1,0 +1,134 @@
+// common.h — shared device/host helpers for the gfx950 kernels of libx265hip.
+// Wave size is 64 on CDNA4; every cross-lane idiom below is written for that and for nothing else.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "../../include/x265hip.h"
+
+namespace xh {
+
+constexpr int kWave = 64;
+
+// ---- error plumbing (host) ---------------------------------------------------------------------------------
+int set_error(int code, const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+int ensure_device();                       // lazy hipSetDevice + capability check; X265HIP_ENODEV when absent
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+bool valid_depth(int depth);
+bool valid_block(int w, int h);            // multiples of 2 up to 64 (luma PU shapes and their chroma halves)
+
+#define XH_CHECK_DEV()      do { int e_ = xh::ensure_device(); if (e_) return e_; } while (0)
+#define XH_LAUNCH_CHECK(nm) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return xh::check_hip(e_, nm); } while (0)
+
+// grid sizing for batch kernels: enough 256-thread workgroups to fill 256 CUs several times over, grid-stride beyond
+inline int grid_for(long long workgroups_needed, int cap = 256 * 16)
+{
+    if (workgroups_needed < 1) workgroups_needed = 1;
+    return (int)(workgroups_needed < cap ? workgroups_needed : cap);
+}
+
+// ---- unaligned loads ---------------------------------------------------------------------------------------
+// x265 block pointers carry no alignment promise (primitives.h:133; TestBench slides by odd offsets).  gfx950
+// global/LDS accesses are unaligned-capable, and memcpy lowers to one global_load_dword / dwordx2 / dwordx4.
+template <typename T, typename P>
+__device__ __forceinline__ T ld_unaligned(const P* p)
+{
+    T v;
+    __builtin_memcpy(&v, p, sizeof(T));
+    return v;
+}
+template <typename T, typename P>
+__device__ __forceinline__ void st_unaligned(P* p, T v)
+{
+    __builtin_memcpy(p, &v, sizeof(T));
+}
+
+// 4 horizontally adjacent pixels as ints
+__device__ __forceinline__ void load4(const uint8_t* p, int v[4])
+{
+    uint32_t x = ld_unaligned<uint32_t>(p);
+    v[0] = x & 255; v[1] = (x >> 8) & 255; v[2] = (x >> 16) & 255; v[3] = x >> 24;
+}
+__device__ __forceinline__ void load4(const uint16_t* p, int v[4])
+{
+    uint2 x = ld_unaligned<uint2>(p);
+    v[0] = x.x & 0xffff; v[1] = x.x >> 16; v[2] = x.y & 0xffff; v[3] = x.y >> 16;
+}
+__device__ __forceinline__ void load4(const int16_t* p, int v[4])
+{
+    uint2 x = ld_unaligned<uint2>(p);
+    v[0] = (int)(int16_t)(x.x & 0xffff); v[1] = (int)x.x >> 16; v[2] = (int)(int16_t)(x.y & 0xffff); v[3] = (int)x.y >> 16;
+}
+__device__ __forceinline__ void store4(uint8_t* p, const int v[4])
+{
+    st_unaligned<uint32_t>(p, (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24));
+}
+__device__ __forceinline__ void store4(uint16_t* p, const int v[4])
+{
+    uint2 x;
+    x.x = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+    x.y = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+    st_unaligned<uint2>(p, x);
+}
+__device__ __forceinline__ void store4(int16_t* p, const int v[4])
+{
+    uint2 x;
+    x.x = ((uint32_t)v[0] & 0xffff) | ((uint32_t)v[1] << 16);
+    x.y = ((uint32_t)v[2] & 0xffff) | ((uint32_t)v[3] << 16);
+    st_unaligned<uint2>(p, x);
+}
+// 2 adjacent elements (chroma 2xN / 6xN shapes)
+template <typename P>
+__device__ __forceinline__ void load2(const P* p, int v[2]) { v[0] = p[0]; v[1] = p[1]; }
+
+// ---- wave-level reductions ---------------------------------------------------------------------------------
+// DPP quad permutes: cross-lane inside aligned groups of 4 lanes without touching LDS.
+__device__ __forceinline__ int quad_xor1(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }  // [1,0,3,2]
+__device__ __forceinline__ int quad_xor2(int v) { return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true); }  // [2,3,0,1]
+__device__ __forceinline__ int quad_sum(int v) { v += quad_xor1(v); v += quad_xor2(v); return v; }
+
+// sum over aligned groups of `g` lanes (g = power of two, 1..64, wave-uniform); every lane of a group gets the sum
+__device__ __forceinline__ int group_sum(int v, int g)
+{
+    if (g > 1) v += quad_xor1(v);
+    if (g > 2) v += quad_xor2(v);
+    for (int o = 4; o < g; o <<= 1)
+        v += __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ unsigned long long group_sum64(unsigned long long v, int g)
+{
+    for (int o = 1; o < g; o <<= 1)
+        v += __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v) { return group_sum(v, kWave); }
+
+__device__ __forceinline__ int clip3i(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+
+// smallest power of two >= v (v in 1..64)
+__host__ __device__ inline int pow2_ceil(int v)
+{
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// ---- filter and transform tables (HEVC normative constants; reference copies: common/constants.cpp:250-344) ----
+// Luma 8-tap / chroma 4-tap DCT-IF coefficients.
+__device__ __constant__ const int8_t kLumaFilter[4][8] = {
+    { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 }, { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+__device__ __constant__ const int8_t kChromaFilter[8][4] = {
+    { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 }, { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
+
+// filter tap i of phase idx; NT = 8 (luma) or 4 (chroma)
+template <int NT>
+__device__ __forceinline__ int filter_tap(int idx, int i)
+{
+    if (NT == 8) return kLumaFilter[idx][i];
+    return kChromaFilter[idx][i];
+}
+
+} // namespace xh

@@ -1,0 +1,576 @@
+// motion.hip — MotionEstimate::motionEstimate for a whole batch of PUs in one launch (gfx950).
+//
+// Reference semantics (bit-exact MV and cost): source/encoder/motion.cpp — motionEstimate :739-1569 (predictor,
+// zero and candidate tests :761-812; DIA :831-852; HEX :855-944; FULL :1397-1441; bestpre/bmv merge :1449-1455;
+// sub-pel refine :1504-1561 driven by workload[] :48-58), subpelCompare :1571 (luma_hpp / luma_vpp / luma_hvpp +
+// sad / satd), COPY*_IF_LT tie-breaking (common.h:183-204), MV::clipped / checkRange (mv.h:88-100),
+// BitCost::mvcost (bitcost.h:42-45: u16 sum of two table entries).
+//
+// Mapping: ONE WAVE PER PU, 4 independent waves per workgroup.  The search is a serial chain of decisions, but every
+// decision variable (bmv, bcost, dir ...) is wave-uniform, so the wave runs the reference's control flow in lockstep
+// while the 64 lanes split the pixels of each SAD / interpolation / SATD:
+//   * the PU's source pixels live in LDS (loaded once per PU, coalesced);
+//   * integer-pel SADs read the reference plane straight from L1/L2 with unaligned packed loads + v_sad_u8/u16;
+//     small PUs (<= 16 quads) evaluate the 3 / 4 candidates of a sad_x3 / sad_x4 step in ONE pass, 16 (or fewer) lanes
+//     per candidate, the hex / square pattern costs come back through DPP + readlane;
+//   * sub-pel candidates are interpolated into an LDS block (hv through a 14-bit LDS intermediate) and compared there
+//     with the 4x4-tile Hadamard of tiles.h.
+// HBM traffic per PU is its source block once plus whatever part of the search window the pattern touches (L2 absorbs
+// the overlap between neighbouring PUs); results are 12 bytes.
+#include "common.h"
+#include "tiles.h"
+#include "filters.h"
+
+namespace xh {
+
+struct Mv { int x, y; };
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <typename P> struct Packed;
+template <> struct Packed<uint8_t>
+{
+    typedef uint32_t T;
+    static __device__ __forceinline__ unsigned sad(T a, T b, unsigned acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
+};
+template <> struct Packed<uint16_t>
+{
+    typedef uint2 T;
+    static __device__ __forceinline__ unsigned sad(T a, T b, unsigned acc)
+    {
+        acc = __builtin_amdgcn_sad_u16(a.x, b.x, acc);
+        return __builtin_amdgcn_sad_u16(a.y, b.y, acc);
+    }
+};
+
+template <typename P>
+struct MeCtx
+{
+    typedef typename Packed<P>::T Q;     // 4 packed pixels
+    const P* fref;                       // reference plane at the PU origin (full-pel mv (0,0))
+    int64_t stride;
+    P* fenc;                             // LDS, w x h, stride w
+    P* pred;                             // LDS, w x h, stride w (interpolated candidate)
+    int16_t* tmp;                        // LDS, (h + 7) x w, hv intermediate
+    const uint16_t* cost;                // mvcost row, entry of MVD 0
+    Mv qmvp;
+    int w, h, depth, lane;
+    int quadsX, quads;                   // quads = (w/4) * h groups of 4 horizontally adjacent pixels
+    int gs, ngroups;                     // lanes per candidate group, groups per wave
+
+    __device__ __forceinline__ int mvcost(int qx, int qy) const
+    {
+        return uni((int)(uint16_t)(cost[qx - qmvp.x] + cost[qy - qmvp.y]));
+    }
+
+    // SAD of the PU against the reference at full-pel (mx, my); whole wave on one candidate
+    __device__ __forceinline__ int sad_at(int mx, int my) const
+    {
+        const P* r = fref + (int64_t)my * stride + mx;
+        unsigned acc = 0;
+        for (int q = lane; q < quads; q += 64)
+        {
+            const int row = q / quadsX, c4 = (q - row * quadsX) * 4;
+            acc = Packed<P>::sad(ld_unaligned<Q>(r + (int64_t)row * stride + c4), *reinterpret_cast<const Q*>(fenc + row * w + c4), acc);
+        }
+        return uni(wave_sum((int)acc));
+    }
+
+    // K (<= 4) candidates; costs[k] = SAD only.  Small PUs run all candidates side by side in lane groups.
+    __device__ __forceinline__ void sad_multi(int K, const Mv* mvs, int* costs) const
+    {
+        if (ngroups == 1)
+        {
+            for (int k = 0; k < K; k++)
+                costs[k] = sad_at(mvs[k].x, mvs[k].y);
+            return;
+        }
+        const int g = lane / gs, s = lane - g * gs;
+        for (int k0 = 0; k0 < K; k0 += ngroups)
+        {
+            int k = k0 + g;
+            if (k >= K) k = K - 1;                     // idle groups recompute the last candidate; result unused
+            Mv m = mvs[0];
+#pragma unroll
+            for (int i = 1; i < 4; i++)
+                if (i == k) m = mvs[i];
+            const P* r = fref + (int64_t)m.y * stride + m.x;
+            unsigned acc = 0;
+            for (int q = s; q < quads; q += gs)
+            {
+                const int row = q / quadsX, c4 = (q - row * quadsX) * 4;
+                acc = Packed<P>::sad(ld_unaligned<Q>(r + (int64_t)row * stride + c4), *reinterpret_cast<const Q*>(fenc + row * w + c4), acc);
+            }
+            const int sum = group_sum((int)acc, gs);
+            for (int j = 0; j < ngroups && k0 + j < K; j++)
+                costs[k0 + j] = __builtin_amdgcn_readlane(sum, j * gs);
+        }
+    }
+
+    // ---- sub-pel candidate into `pred` (motion.cpp:1571-1600: hpp / vpp / hvpp or the plain block)
+    __device__ __forceinline__ void build_pred(int qx, int qy) const
+    {
+        const int xFrac = qx & 3, yFrac = qy & 3;
+        const P* r = fref + (int64_t)(qy >> 2) * stride + (qx >> 2);
+        if (!(xFrac | yFrac))
+        {
+            for (int q = lane; q < quads; q += 64)
+            {
+                const int row = q / quadsX, c4 = (q - row * quadsX) * 4;
+                *reinterpret_cast<Q*>(pred + row * w + c4) = ld_unaligned<Q>(r + (int64_t)row * stride + c4);
+            }
+        }
+        else if (!yFrac)
+        {
+            const Stage st = stage_for(IF_HPP, depth);
+            int c[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) c[i] = kLumaFilter[xFrac][i];
+            for (int q = lane; q < quads; q += 64)
+            {
+                const int row = q / quadsX, c4 = (q - row * quadsX) * 4;
+                int v[11], out[4];
+                load_span<11>(r + (int64_t)row * stride + c4 - 3, v);
+#pragma unroll
+                for (int o = 0; o < 4; o++)
+                {
+                    int sum = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) sum += v[o + i] * c[i];
+                    out[o] = finish(sum, st);
+                }
+                store4(pred + row * w + c4, out);
+            }
+        }
+        else if (!xFrac)
+        {
+            const Stage st = stage_for(IF_VPP, depth);
+            int c[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) c[i] = kLumaFilter[yFrac][i];
+            for (int q = lane; q < quads; q += 64)
+            {
+                const int row = q / quadsX, c4 = (q - row * quadsX) * 4;
+                int sum[4] = { 0, 0, 0, 0 }, out[4];
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                {
+                    int v[4];
+                    load4(r + (int64_t)(row + i - 3) * stride + c4, v);
+#pragma unroll
+                    for (int o = 0; o < 4; o++) sum[o] += v[o] * c[i];
+                }
+#pragma unroll
+                for (int o = 0; o < 4; o++) out[o] = finish(sum[o], st);
+                store4(pred + row * w + c4, out);
+            }
+        }
+        else
+        {
+            const Stage s1 = stage_for(IF_HPS, depth), s2 = stage_for(IF_VSP, depth);
+            int c1[8], c2[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { c1[i] = kLumaFilter[xFrac][i]; c2[i] = kLumaFilter[yFrac][i]; }
+            const int quads1 = quadsX * (h + 7);
+            for (int q = lane; q < quads1; q += 64)
+            {
+                const int row = q / quadsX, c4 = (q - row * quadsX) * 4;
+                int v[11], out[4];
+                load_span<11>(r + (int64_t)(row - 3) * stride + c4 - 3, v);
+#pragma unroll
+                for (int o = 0; o < 4; o++)
+                {
+                    int sum = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) sum += v[o + i] * c1[i];
+                    out[o] = finish(sum, s1);
+                }
+                store4(tmp + row * w + c4, out);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            for (int q = lane; q < quads; q += 64)
+            {
+                const int row = q / quadsX, c4 = (q - row * quadsX) * 4;
+                int sum[4] = { 0, 0, 0, 0 }, out[4];
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                {
+                    int v[4];
+                    load4(tmp + (row + i) * w + c4, v);
+#pragma unroll
+                    for (int o = 0; o < 4; o++) sum[o] += v[o] * c2[i];
+                }
+#pragma unroll
+                for (int o = 0; o < 4; o++) out[o] = finish(sum[o], s2);
+                store4(pred + row * w + c4, out);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    __device__ __forceinline__ int sad_pred() const
+    {
+        unsigned acc = 0;
+        for (int q = lane; q < quads; q += 64)
+            acc = Packed<P>::sad(*reinterpret_cast<const Q*>(pred + q * 4), *reinterpret_cast<const Q*>(fenc + q * 4), acc);
+        return uni(wave_sum((int)acc));
+    }
+
+    // pixel.cpp:263-297 satd tilers, see pixel.hip for the per-tile >> 1 argument
+    __device__ __forceinline__ int satd_pred() const
+    {
+        const int tilesX = w >> 2, tiles = tilesX * (h >> 2);
+        int acc = 0;
+        for (int t = lane; t < tiles; t += 64)
+        {
+            const int ty = t / tilesX, tx = t - ty * tilesX;
+            int m[16];
+            tile_diff(fenc + ty * 4 * w + tx * 4, (int64_t)w, pred + ty * 4 * w + tx * 4, (int64_t)w, m);
+            hadamard4x4(m);
+            acc += abs_sum16(m) >> 1;
+        }
+        return uni(wave_sum(acc));
+    }
+
+    // MotionEstimate::subpelCompare (luma): cmp 0 = sad, 1 = satd
+    __device__ __forceinline__ int subpel(Mv q, int cmp) const
+    {
+        if (!cmp && !((q.x | q.y) & 3))
+            return sad_at(q.x >> 2, q.y >> 2);
+        build_pred(q.x, q.y);
+        const int v = cmp ? satd_pred() : sad_pred();
+        __builtin_amdgcn_wave_barrier();
+        return v;
+    }
+};
+
+__device__ __forceinline__ Mv mv_clip(Mv v, Mv lo, Mv hi)
+{
+    Mv r = { v.x > hi.x ? hi.x : v.x, v.y > hi.y ? hi.y : v.y };
+    r.x = r.x < lo.x ? lo.x : r.x;
+    r.y = r.y < lo.y ? lo.y : r.y;
+    return r;
+}
+__device__ __forceinline__ bool mv_in_range(Mv v, Mv lo, Mv hi) { return v.x >= lo.x && v.x <= hi.x && v.y >= lo.y && v.y <= hi.y; }
+__device__ __forceinline__ int sext2(int v) { return (v & 2) ? (v | ~3) : v; }
+
+__device__ __constant__ const int8_t kHex2[8][2] = { {-1,-2}, {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2}, {-2,0} };   // motion.cpp:63
+__device__ __constant__ const uint8_t kMod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };                                             // motion.cpp:64
+__device__ __constant__ const int8_t kSquare1[9][2] = { {0,0}, {0,-1}, {0,1}, {-1,0}, {1,0}, {-1,-1}, {-1,1}, {1,-1}, {1,1} }; // motion.cpp:65
+// motion.cpp:48-58 workload[subme] = { hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd }
+__device__ __constant__ const uint8_t kWorkload[8][5] = { {1,4,0,4,0}, {1,4,1,4,0}, {1,4,1,4,1}, {2,4,1,4,1}, {2,4,2,4,1}, {1,8,1,8,1}, {2,8,1,8,1}, {2,8,2,8,1} };
+
+template <typename P>
+__global__ __launch_bounds__(256) void motion_kernel(const P* __restrict__ fencPlane, int64_t strideF,
+                                                     const P* __restrict__ refPlane, int64_t strideR,
+                                                     const int32_t* __restrict__ pu_xy, const int32_t* __restrict__ mvminA,
+                                                     const int32_t* __restrict__ mvmaxA, const int32_t* __restrict__ qmvpA,
+                                                     int numCand, const int32_t* __restrict__ mvcA, int merange, int method, int subme,
+                                                     const uint16_t* __restrict__ mvcost, int w, int h, int depth, int n,
+                                                     int perWaveBytes, int32_t* __restrict__ outMv, int32_t* __restrict__ outCost)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wv = threadIdx.x >> 6;
+    MeCtx<P> c;
+    c.lane = threadIdx.x & 63;
+    c.w = w; c.h = h; c.depth = depth;
+    c.quadsX = w >> 2; c.quads = c.quadsX * h;
+    c.gs = c.quads >= 64 ? 64 : pow2_ceil(c.quads);
+    c.ngroups = 64 / c.gs;
+    unsigned char* base = smem + (size_t)wv * perWaveBytes;
+    c.fenc = reinterpret_cast<P*>(base);
+    c.pred = reinterpret_cast<P*>(base + (size_t)w * h * sizeof(P));
+    c.tmp = reinterpret_cast<int16_t*>(base + 2 * (size_t)w * h * sizeof(P));
+    c.stride = strideR;
+    c.cost = mvcost;
+    typedef typename MeCtx<P>::Q Q;
+
+    const int wavesPerWg = blockDim.x >> 6;
+    const int wavesTotal = gridDim.x * wavesPerWg;
+    for (int pu = blockIdx.x * wavesPerWg + wv; pu < n; pu += wavesTotal)
+    {
+        const int bx = pu_xy[2 * pu], by = pu_xy[2 * pu + 1];
+        const Mv mvmin = { mvminA[2 * pu], mvminA[2 * pu + 1] }, mvmax = { mvmaxA[2 * pu], mvmaxA[2 * pu + 1] };
+        const Mv qmvp = { qmvpA[2 * pu], qmvpA[2 * pu + 1] };
+        const Mv qmvmin = { mvmin.x * 4, mvmin.y * 4 }, qmvmax = { mvmax.x * 4, mvmax.y * 4 };
+        c.qmvp = qmvp;
+        c.fref = refPlane + (int64_t)by * strideR + bx;
+        // source block -> LDS
+        {
+            const P* f = fencPlane + (int64_t)by * strideF + bx;
+            for (int q = c.lane; q < c.quads; q += 64)
+            {
+                const int row = q / c.quadsX, c4 = (q - row * c.quadsX) * 4;
+                *reinterpret_cast<Q*>(c.fenc + row * w + c4) = ld_unaligned<Q>(f + (int64_t)row * strideF + c4);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+
+#define YOK(yy) (((yy) >= mvmin.y) & ((yy) <= mvmax.y))
+#define LT1(v) do { const int v_ = (v); if (v_ < bcost) bcost = v_; } while (0)
+        // ---- predictor, zero and candidates (motion.cpp:761-812)
+        const Mv pmv = mv_clip(qmvp, qmvmin, qmvmax);
+        Mv bestpre = pmv;
+        int bprecost = c.subpel(pmv, 0);
+        Mv bmv = { (pmv.x + 2) >> 2, (pmv.y + 2) >> 2 };
+        int bcost = bprecost;
+        if ((pmv.x & 3) | (pmv.y & 3))
+            bcost = c.sad_at(bmv.x, bmv.y) + c.mvcost(bmv.x * 4, bmv.y * 4);
+        if (pmv.x | pmv.y)
+        {
+            const int cst = c.sad_at(0, 0) + c.mvcost(0, 0);
+            if (cst < bcost)
+            {
+                bcost = cst;
+                bmv.x = 0;
+                bmv.y = max(min(0, mvmax.y), mvmin.y);
+            }
+        }
+        for (int i = 0; i < numCand; i++)
+        {
+            const Mv raw = { mvcA[((int64_t)pu * numCand + i) * 2], mvcA[((int64_t)pu * numCand + i) * 2 + 1] };
+            const Mv m = mv_clip(raw, qmvmin, qmvmax);
+            if ((m.x | m.y) && !(m.x == pmv.x && m.y == pmv.y) && !(m.x == bestpre.x && m.y == bestpre.y))
+            {
+                const int cst = c.subpel(m, 0) + c.mvcost(m.x, m.y);
+                if (cst < bprecost)
+                {
+                    bprecost = cst;
+                    bestpre = m;
+                }
+            }
+        }
+
+        int costs[4];
+        Mv cand[4];
+#define DIRS3(ax, ay, bx_, by_, cx, cy) do { \
+            cand[0] = Mv{ bmv.x + (ax), bmv.y + (ay) }; cand[1] = Mv{ bmv.x + (bx_), bmv.y + (by_) }; cand[2] = Mv{ bmv.x + (cx), bmv.y + (cy) }; \
+            c.sad_multi(3, cand, costs); \
+            for (int k_ = 0; k_ < 3; k_++) costs[k_] += c.mvcost(cand[k_].x * 4, cand[k_].y * 4); } while (0)
+#define DIRS4(ax, ay, bx_, by_, cx, cy, dx, dy) do { \
+            cand[0] = Mv{ bmv.x + (ax), bmv.y + (ay) }; cand[1] = Mv{ bmv.x + (bx_), bmv.y + (by_) }; \
+            cand[2] = Mv{ bmv.x + (cx), bmv.y + (cy) }; cand[3] = Mv{ bmv.x + (dx), bmv.y + (dy) }; \
+            c.sad_multi(4, cand, costs); \
+            for (int k_ = 0; k_ < 4; k_++) costs[k_] += c.mvcost(cand[k_].x * 4, cand[k_].y * 4); } while (0)
+
+        if (method == 0)
+        {
+            // X265_DIA_SEARCH, motion.cpp:831-852
+            bcost <<= 4;
+            int i = merange;
+            do
+            {
+                DIRS4(0, -1, 0, 1, -1, 0, 1, 0);
+                if (YOK(bmv.y - 1)) LT1((costs[0] << 4) + 1);
+                if (YOK(bmv.y + 1)) LT1((costs[1] << 4) + 3);
+                LT1((costs[2] << 4) + 4);
+                LT1((costs[3] << 4) + 12);
+                if (!(bcost & 15))
+                    break;
+                bmv.x -= sext2((bcost >> 2) & 3);
+                bmv.y -= sext2(bcost & 3);
+                bcost &= ~15;
+            }
+            while (--i && mv_in_range(bmv, mvmin, mvmax));
+            bcost >>= 4;
+        }
+        else if (method == 1)
+        {
+            // X265_HEX_SEARCH, motion.cpp:855-944
+            DIRS3(-2, 0, -1, 2, 1, 2);
+            bcost <<= 3;
+            if (YOK(bmv.y)) LT1((costs[0] << 3) + 2);
+            if (YOK(bmv.y + 2))
+            {
+                LT1((costs[1] << 3) + 3);
+                LT1((costs[2] << 3) + 4);
+            }
+            DIRS3(2, 0, 1, -2, -1, -2);
+            if (YOK(bmv.y)) LT1((costs[0] << 3) + 5);
+            if (YOK(bmv.y - 2))
+            {
+                LT1((costs[1] << 3) + 6);
+                LT1((costs[2] << 3) + 7);
+            }
+            if (bcost & 7)
+            {
+                int dir = (bcost & 7) - 2;
+                if (YOK(bmv.y + kHex2[dir + 1][1]))
+                {
+                    bmv.x += kHex2[dir + 1][0];
+                    bmv.y += kHex2[dir + 1][1];
+                    for (int i = (merange >> 1) - 1; i > 0 && mv_in_range(bmv, mvmin, mvmax); i--)
+                    {
+                        DIRS3(kHex2[dir + 0][0], kHex2[dir + 0][1], kHex2[dir + 1][0], kHex2[dir + 1][1], kHex2[dir + 2][0], kHex2[dir + 2][1]);
+                        bcost &= ~7;
+                        if (YOK(bmv.y + kHex2[dir + 0][1])) LT1((costs[0] << 3) + 1);
+                        if (YOK(bmv.y + kHex2[dir + 1][1])) LT1((costs[1] << 3) + 2);
+                        if (YOK(bmv.y + kHex2[dir + 2][1])) LT1((costs[2] << 3) + 3);
+                        if (!(bcost & 7))
+                            break;
+                        dir += (bcost & 7) - 2;
+                        dir = kMod6m1[dir + 1];
+                        bmv.x += kHex2[dir + 1][0];
+                        bmv.y += kHex2[dir + 1][1];
+                    }
+                }
+            }
+            bcost >>= 3;
+            // square refine, motion.cpp:918-942
+            int dir = 0;
+            DIRS4(0, -1, 0, 1, -1, 0, 1, 0);
+            if (YOK(bmv.y - 1) && costs[0] < bcost) { bcost = costs[0]; dir = 1; }
+            if (YOK(bmv.y + 1) && costs[1] < bcost) { bcost = costs[1]; dir = 2; }
+            if (costs[2] < bcost) { bcost = costs[2]; dir = 3; }
+            if (costs[3] < bcost) { bcost = costs[3]; dir = 4; }
+            DIRS4(-1, -1, -1, 1, 1, -1, 1, 1);
+            if (YOK(bmv.y - 1) && costs[0] < bcost) { bcost = costs[0]; dir = 5; }
+            if (YOK(bmv.y + 1) && costs[1] < bcost) { bcost = costs[1]; dir = 6; }
+            if (YOK(bmv.y - 1) && costs[2] < bcost) { bcost = costs[2]; dir = 7; }
+            if (YOK(bmv.y + 1) && costs[3] < bcost) { bcost = costs[3]; dir = 8; }
+            bmv.x += kSquare1[dir][0];
+            bmv.y += kSquare1[dir][1];
+        }
+        else
+        {
+            // X265_FULL_SEARCH, motion.cpp:1397-1441: raster order, strict '<' keeps the first minimum
+            for (int ty = mvmin.y; ty <= mvmax.y; ty++)
+                for (int tx = mvmin.x; tx <= mvmax.x; tx += 4)
+                {
+                    const int K = min(4, mvmax.x - tx + 1);
+                    for (int k = 0; k < 4; k++)
+                        cand[k] = Mv{ tx + min(k, K - 1), ty };
+                    c.sad_multi(K, cand, costs);
+                    for (int k = 0; k < K; k++)
+                    {
+                        const int cst = costs[k] + c.mvcost((tx + k) * 4, ty * 4);
+                        if (cst < bcost)
+                        {
+                            bcost = cst;
+                            bmv.x = tx + k;
+                            bmv.y = ty;
+                        }
+                    }
+                }
+        }
+
+        // motion.cpp:1449-1455
+        if (bprecost < bcost)
+        {
+            bmv = bestpre;
+            bcost = bprecost;
+        }
+        else
+        {
+            bmv.x *= 4;
+            bmv.y *= 4;
+        }
+
+        if (!bcost)
+            bcost = c.mvcost(bmv.x, bmv.y);            // motion.cpp:1466-1471
+        else
+        {
+            // motion.cpp:1504-1561
+            const int hpelIters = kWorkload[subme][0], hpelDirs = kWorkload[subme][1];
+            const int qpelIters = kWorkload[subme][2], qpelDirs = kWorkload[subme][3], hpelSatd = kWorkload[subme][4];
+            int hpelcomp = 0;
+            if (hpelSatd)
+            {
+                bcost = c.subpel(bmv, 1) + c.mvcost(bmv.x, bmv.y);
+                hpelcomp = 1;
+            }
+            for (int iter = 0; iter < hpelIters; iter++)
+            {
+                int bdir = 0;
+                for (int i = 1; i <= hpelDirs; i++)
+                {
+                    const Mv q = { bmv.x + kSquare1[i][0] * 2, bmv.y + kSquare1[i][1] * 2 };
+                    if ((q.y < qmvmin.y) | (q.y > qmvmax.y))
+                        continue;
+                    const int cst = c.subpel(q, hpelcomp) + c.mvcost(q.x, q.y);
+                    if (cst < bcost) { bcost = cst; bdir = i; }
+                }
+                if (bdir)
+                {
+                    bmv.x += kSquare1[bdir][0] * 2;
+                    bmv.y += kSquare1[bdir][1] * 2;
+                }
+                else
+                    break;
+            }
+            if (!hpelSatd)
+                bcost = c.subpel(bmv, 1) + c.mvcost(bmv.x, bmv.y);
+            for (int iter = 0; iter < qpelIters; iter++)
+            {
+                int bdir = 0;
+                for (int i = 1; i <= qpelDirs; i++)
+                {
+                    const Mv q = { bmv.x + kSquare1[i][0], bmv.y + kSquare1[i][1] };
+                    if ((q.y < qmvmin.y) | (q.y > qmvmax.y))
+                        continue;
+                    const int cst = c.subpel(q, 1) + c.mvcost(q.x, q.y);
+                    if (cst < bcost) { bcost = cst; bdir = i; }
+                }
+                if (bdir)
+                {
+                    bmv.x += kSquare1[bdir][0];
+                    bmv.y += kSquare1[bdir][1];
+                }
+                else
+                    break;
+            }
+        }
+#undef YOK
+#undef LT1
+#undef DIRS3
+#undef DIRS4
+        if (c.lane == 0)
+        {
+            outMv[2 * pu] = bmv.x;
+            outMv[2 * pu + 1] = bmv.y;
+            outCost[pu] = bcost;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+} // namespace xh
+
+using namespace xh;
+
+extern "C" int x265hip_motion_estimate_batch(int depth, int w, int h, const void* fencPlane, int64_t strideF,
+                                             const void* refPlane, int64_t strideR, const int32_t* pu_xy,
+                                             const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp,
+                                             int numCand, const int32_t* mvc, int merange, int searchMethod, int subme,
+                                             const uint16_t* mvcost, int mvcostHalf, int n, int32_t* outMv,
+                                             int32_t* outCost, void* stream)
+{
+    XH_CHECK_DEV();
+    if (!valid_depth(depth) || !valid_block(w, h) || (w & 3) || (h & 3) || (w == 4 && h == 4) || n < 0)
+        return set_error(X265HIP_EINVAL, "motion_estimate: depth %d PU %dx%d n %d", depth, w, h, n);
+    if (searchMethod != 0 && searchMethod != 1 && searchMethod != 5)
+        return set_error(X265HIP_EINVAL, "motion_estimate: searchMethod %d not implemented (DIA 0, HEX 1, FULL 5)", searchMethod);
+    if (subme < 0 || subme > 7 || numCand < 0 || merange < 1 || mvcostHalf < 4 * (merange + 64))
+        return set_error(X265HIP_EINVAL, "motion_estimate: subme %d numCand %d merange %d mvcostHalf %d", subme, numCand, merange, mvcostHalf);
+    if (!n) return X265HIP_OK;
+    const int B = depth == 8 ? 1 : 2;
+    int perWave = 2 * w * h * B + (h + 7) * w * 2;
+    perWave = (perWave + 15) & ~15;
+    // dynamic LDS is kept under 64 KiB per workgroup: big PUs at 16-bit run 2 waves per workgroup instead of 4
+    const int wpg = perWave * 4 <= 65536 ? 4 : (perWave * 2 <= 65536 ? 2 : 1);
+    dim3 grid(grid_for((n + wpg - 1) / wpg, 256 * 8)), block(64 * wpg);
+    if (depth == 8)
+        hipLaunchKernelGGL((motion_kernel<uint8_t>), grid, block, wpg * perWave, as_stream(stream), (const uint8_t*)fencPlane, strideF,
+                           (const uint8_t*)refPlane, strideR, pu_xy, mvmin, mvmax, qmvp, numCand, mvc, merange, searchMethod, subme,
+                           mvcost, w, h, depth, n, perWave, outMv, outCost);
+    else
+        hipLaunchKernelGGL((motion_kernel<uint16_t>), grid, block, wpg * perWave, as_stream(stream), (const uint16_t*)fencPlane, strideF,
+                           (const uint16_t*)refPlane, strideR, pu_xy, mvmin, mvmax, qmvp, numCand, mvc, merange, searchMethod, subme,
+                           mvcost, w, h, depth, n, perWave, outMv, outCost);
+    XH_LAUNCH_CHECK("motion_kernel");
+    return X265HIP_OK;
+}

@@ -1,0 +1,185 @@
+// runtime.hip — device selection, memory/stream/event plumbing and error reporting of the C ABI (include/x265hip.h).
+// There is deliberately no CPU fallback anywhere in this library: without a gfx950-class device every entry point
+// returns X265HIP_ENODEV.
+#include "common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace xh {
+
+static thread_local char t_err[512] = "";
+static thread_local int t_dev_ready = 0;   // 0 = not tried, 1 = ok, -1 = failed
+static thread_local int t_device = 0;
+
+int set_error(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof(t_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_hip(hipError_t e, const char* what)
+{
+    if (e == hipSuccess)
+        return X265HIP_OK;
+    return set_error(e == hipErrorOutOfMemory ? X265HIP_ENOMEM : X265HIP_EHIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+static int init_device(int device)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+    {
+        t_dev_ready = -1;
+        (void)hipGetLastError();
+        return set_error(X265HIP_ENODEV, "libx265hip: no HIP device available (%s); there is no CPU fallback",
+                         e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    }
+    if (device < 0 || device >= count)
+        return set_error(X265HIP_EINVAL, "libx265hip: device %d out of range (have %d)", device, count);
+    e = hipSetDevice(device);
+    if (e != hipSuccess)
+    {
+        t_dev_ready = -1;
+        return check_hip(e, "hipSetDevice");
+    }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess)
+        return check_hip(e, "hipGetDeviceProperties");
+    if (prop.warpSize != kWave)
+    {
+        t_dev_ready = -1;
+        return set_error(X265HIP_ENODEV, "libx265hip: device %d (%s) has wavefront %d; kernels are built for wave64 gfx950",
+                         device, prop.gcnArchName, prop.warpSize);
+    }
+    t_device = device;
+    t_dev_ready = 1;
+    return X265HIP_OK;
+}
+
+int ensure_device()
+{
+    if (t_dev_ready == 1)
+        return X265HIP_OK;
+    if (t_dev_ready == -1)
+        return X265HIP_ENODEV;
+    // honour a device already chosen by the host framework (e.g. torch.cuda.set_device) on this thread
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess)
+        cur = 0;
+    return init_device(cur);
+}
+
+bool valid_depth(int depth) { return depth == 8 || depth == 10 || depth == 12; }
+bool valid_block(int w, int h) { return w >= 2 && h >= 2 && w <= 64 && h <= 64 && !(w & 1) && !(h & 1); }
+
+} // namespace xh
+
+using namespace xh;
+
+extern "C" {
+
+int x265hip_init(int device) { return init_device(device); }
+
+int x265hip_device_count(void)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return count;
+}
+
+const char* x265hip_last_error(void) { return t_err; }
+const char* x265hip_version(void) { return "x265hip 0.1 (gfx950)"; }
+
+int x265hip_malloc(void** dptr, size_t bytes)
+{
+    XH_CHECK_DEV();
+    if (!dptr) return set_error(X265HIP_EINVAL, "x265hip_malloc: null out pointer");
+    return check_hip(hipMalloc(dptr, bytes ? bytes : 1), "hipMalloc");
+}
+int x265hip_free(void* dptr)
+{
+    XH_CHECK_DEV();
+    return check_hip(hipFree(dptr), "hipFree");
+}
+int x265hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream)
+{
+    XH_CHECK_DEV();
+    if (!bytes) return X265HIP_OK;
+    return check_hip(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)), "hipMemcpyAsync(h2d)");
+}
+int x265hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream)
+{
+    XH_CHECK_DEV();
+    if (!bytes) return X265HIP_OK;
+    int e = check_hip(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)), "hipMemcpyAsync(d2h)");
+    if (e) return e;
+    return check_hip(hipStreamSynchronize(as_stream(stream)), "hipStreamSynchronize");
+}
+int x265hip_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream)
+{
+    XH_CHECK_DEV();
+    if (!bytes) return X265HIP_OK;
+    return check_hip(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)), "hipMemcpyAsync(d2d)");
+}
+int x265hip_memset(void* dst, int value, size_t bytes, void* stream)
+{
+    XH_CHECK_DEV();
+    if (!bytes) return X265HIP_OK;
+    return check_hip(hipMemsetAsync(dst, value, bytes, as_stream(stream)), "hipMemsetAsync");
+}
+int x265hip_stream_create(void** stream)
+{
+    XH_CHECK_DEV();
+    hipStream_t s;
+    int e = check_hip(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+    if (!e) *stream = s;
+    return e;
+}
+int x265hip_stream_destroy(void* stream)
+{
+    XH_CHECK_DEV();
+    return check_hip(hipStreamDestroy(as_stream(stream)), "hipStreamDestroy");
+}
+int x265hip_stream_sync(void* stream)
+{
+    XH_CHECK_DEV();
+    return check_hip(hipStreamSynchronize(as_stream(stream)), "hipStreamSynchronize");
+}
+int x265hip_event_create(void** ev)
+{
+    XH_CHECK_DEV();
+    hipEvent_t e;
+    int r = check_hip(hipEventCreate(&e), "hipEventCreate");
+    if (!r) *ev = e;
+    return r;
+}
+int x265hip_event_destroy(void* ev)
+{
+    XH_CHECK_DEV();
+    return check_hip(hipEventDestroy(reinterpret_cast<hipEvent_t>(ev)), "hipEventDestroy");
+}
+int x265hip_event_record(void* ev, void* stream)
+{
+    XH_CHECK_DEV();
+    return check_hip(hipEventRecord(reinterpret_cast<hipEvent_t>(ev), as_stream(stream)), "hipEventRecord");
+}
+int x265hip_event_elapsed_ms(void* start, void* stop, float* ms)
+{
+    XH_CHECK_DEV();
+    int r = check_hip(hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop)), "hipEventSynchronize");
+    if (r) return r;
+    return check_hip(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)),
+                     "hipEventElapsedTime");
+}
+
+} // extern "C"

@@ -1,0 +1,188 @@
+"""ctypes binding of libx265hip.so (the C ABI in include/x265hip.h) — plumbing only.
+
+The product is the HIP library; this module just loads it, declares the prototypes and offers small helpers to move
+numpy arrays to and from device memory.  There is NO fallback: if the library is missing, or no MI355X-class GPU is
+present when a compute entry point is called, an exception is raised.  Nothing here imports or calls oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libx265hip.so")
+
+vp, i32, i64, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32
+
+# name -> (restype, argtypes); mirrors include/x265hip.h one to one (tests/test_abi.py checks the header against this)
+PROTOTYPES = {
+    "x265hip_init": (i32, [i32]),
+    "x265hip_device_count": (i32, []),
+    "x265hip_last_error": (C.c_char_p, []),
+    "x265hip_version": (C.c_char_p, []),
+    "x265hip_malloc": (i32, [C.POINTER(vp), C.c_size_t]),
+    "x265hip_free": (i32, [vp]),
+    "x265hip_memcpy_h2d": (i32, [vp, vp, C.c_size_t, vp]),
+    "x265hip_memcpy_d2h": (i32, [vp, vp, C.c_size_t, vp]),
+    "x265hip_memcpy_d2d": (i32, [vp, vp, C.c_size_t, vp]),
+    "x265hip_memset": (i32, [vp, i32, C.c_size_t, vp]),
+    "x265hip_stream_create": (i32, [C.POINTER(vp)]),
+    "x265hip_stream_destroy": (i32, [vp]),
+    "x265hip_stream_sync": (i32, [vp]),
+    "x265hip_event_create": (i32, [C.POINTER(vp)]),
+    "x265hip_event_destroy": (i32, [vp]),
+    "x265hip_event_record": (i32, [vp, vp]),
+    "x265hip_event_elapsed_ms": (i32, [vp, vp, C.POINTER(C.c_float)]),
+    "x265hip_pixcmp_batch": (i32, [i32, i32, i32, i32, vp, i64, vp, i64, vp, vp, i32, vp, vp]),
+    "x265hip_sad_xn_batch": (i32, [i32, i32, i32, i32, vp, i64, vp, i64, vp, vp, i32, vp, vp]),
+    "x265hip_sse_pp_batch": (i32, [i32, i32, i32, vp, i64, vp, i64, vp, vp, i32, vp, vp]),
+    "x265hip_sse_ss_batch": (i32, [i32, i32, vp, i64, vp, i64, vp, vp, i32, vp, vp]),
+    "x265hip_sub_ps_batch": (i32, [i32, i32, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, i32, vp]),
+    "x265hip_add_ps_batch": (i32, [i32, i32, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, i32, vp]),
+    "x265hip_addavg_batch": (i32, [i32, i32, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, i32, vp]),
+    "x265hip_pixelavg_pp_batch": (i32, [i32, i32, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, i32, vp]),
+    "x265hip_copy_batch": (i32, [i32, i32, i32, i32, vp, i64, vp, i64, vp, vp, i32, vp]),
+    "x265hip_p2s_batch": (i32, [i32, i32, i32, vp, i64, vp, i64, vp, vp, i32, vp]),
+    "x265hip_dct_batch": (i32, [i32, i32, i32, vp, i64, vp, vp, i32, vp]),
+    "x265hip_idct_batch": (i32, [i32, i32, i32, vp, vp, i64, vp, i32, vp]),
+    "x265hip_quant_batch": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "x265hip_nquant_batch": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "x265hip_dequant_normal": (i32, [vp, vp, i64, i32, i32, vp]),
+    "x265hip_dequant_scaling_batch": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "x265hip_count_nonzero_batch": (i32, [vp, i32, i32, vp, vp]),
+    "x265hip_interp_batch": (i32, [i32, i32, i32, i32, i32, vp, i64, vp, i64, vp, vp, vp, i32, i32, vp]),
+    "x265hip_motion_estimate_batch": (i32, [i32, i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, i32, vp, i32, i32, i32,
+                                            vp, i32, i32, vp, vp, vp]),
+    "x265hip_residual_chain_batch": (i32, [i32, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32,
+                                           vp, vp, vp, i32, vp]),
+    "x265hip_call_pixcmp": (i32, [i32, i32, i32, i32, vp, i64, vp, i64, vp]),
+    "x265hip_call_sad_xn": (i32, [i32, i32, i32, i32, vp, vp, i64, vp]),
+    "x265hip_call_sse_pp": (i32, [i32, i32, i32, vp, i64, vp, i64, vp]),
+    "x265hip_call_sse_ss": (i32, [i32, i32, vp, i64, vp, i64, vp]),
+    "x265hip_call_dct": (i32, [i32, i32, i32, vp, vp, i64]),
+    "x265hip_call_idct": (i32, [i32, i32, i32, vp, vp, i64]),
+    "x265hip_call_quant": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "x265hip_call_nquant": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "x265hip_call_dequant_normal": (i32, [vp, vp, i32, i32, i32]),
+    "x265hip_call_dequant_scaling": (i32, [vp, vp, vp, i32, i32, i32]),
+    "x265hip_call_interp": (i32, [i32, i32, i32, i32, i32, vp, i64, vp, i64, i32, i32, i32]),
+}
+
+CMP_SAD, CMP_SATD, CMP_SA8D, CMP_SA8D8, CMP_PSY = 0, 1, 2, 3, 4
+IF_HPP, IF_HPS, IF_VPP, IF_VPS, IF_VSP, IF_VSS, IF_HVPP = range(7)
+DIA_SEARCH, HEX_SEARCH, FULL_SEARCH = 0, 1, 5      # x265.h X265_*_SEARCH
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libx265hip.so (built by __graft_entry__.build() / x265_amd/csrc/Makefile). Fails loudly when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipError("x265_amd/libx265hip.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != 0:
+        raise HipError("libx265hip error %d: %s" % (code, lib().x265hip_last_error().decode(errors="replace")))
+
+
+def pix_dtype(depth):
+    return np.uint8 if depth == 8 else np.uint16
+
+
+class DevBuf:
+    """A device allocation owned by libx265hip (hipMalloc); optionally initialised from a numpy array."""
+
+    def __init__(self, arr=None, nbytes=None, dtype=None, shape=None):
+        L = lib()
+        if arr is not None:
+            arr = np.ascontiguousarray(arr)
+            nbytes, dtype, shape = arr.nbytes, arr.dtype, arr.shape
+        self.nbytes, self.dtype, self.shape = int(nbytes), np.dtype(dtype) if dtype is not None else None, shape
+        p = vp()
+        check(L.x265hip_malloc(C.byref(p), max(self.nbytes, 1)))
+        self.ptr = p.value
+        if arr is not None and self.nbytes:
+            check(L.x265hip_memcpy_h2d(self.ptr, arr.ctypes.data, self.nbytes, None))
+            check(L.x265hip_stream_sync(None))
+
+    @classmethod
+    def empty(cls, shape, dtype):
+        shape = tuple(np.atleast_1d(shape).tolist()) if not isinstance(shape, tuple) else shape
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        return cls(nbytes=n, dtype=dtype, shape=shape)
+
+    @classmethod
+    def zeros(cls, shape, dtype):
+        b = cls.empty(shape, dtype)
+        check(lib().x265hip_memset(b.ptr, 0, b.nbytes, None))
+        return b
+
+    def at(self, elem_offset):
+        """Device address of element `elem_offset` (flat index)."""
+        return self.ptr + int(elem_offset) * self.dtype.itemsize
+
+    def get(self):
+        out = np.empty(self.shape, self.dtype)
+        if self.nbytes:
+            check(lib().x265hip_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes, None))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().x265hip_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def dev_i32(values):
+    return DevBuf(np.asarray(values, np.int32).reshape(-1))
+
+
+class Timer:
+    """HIP-event timer on a given stream handle (int / None)."""
+
+    def __init__(self, stream=None):
+        L = lib()
+        self.stream = stream
+        a, b = vp(), vp()
+        check(L.x265hip_event_create(C.byref(a)))
+        check(L.x265hip_event_create(C.byref(b)))
+        self.a, self.b = a.value, b.value
+
+    def start(self):
+        check(lib().x265hip_event_record(self.a, self.stream))
+
+    def stop_ms(self):
+        L = lib()
+        check(L.x265hip_event_record(self.b, self.stream))
+        ms = C.c_float()
+        check(L.x265hip_event_elapsed_ms(self.a, self.b, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            lib().x265hip_event_destroy(self.a)
+            lib().x265hip_event_destroy(self.b)
+        except Exception:
+            pass
