@@ -159,6 +159,26 @@ int x265hip_motion_estimate_batch(int depth, int w, int h,
                                   const uint16_t* mvcost, int mvcostHalf,
                                   int n, int32_t* outMv, int32_t* outCost, void* stream);
 
+/* Search::setSearchRange (reference: source/encoder/search.cpp:2724-2770) with CUData::clipMv (cudata.cpp:1915-1928) for n
+ * CUs at cu_xy [n][2]: qmvp[i] = mvSrc[srcIdx[i]] (quarter-pel; (0,0) when mvSrc is NULL or srcIdx[i] < 0), then
+ * [mvmin, mvmax] = clip(qmvp -/+ merange) >> 2 with the frame-parallel vertical bound refLagPixels (search.cpp:92).
+ * Intra-refresh and multi-slice restrictions are at their x265 defaults (off). */
+int x265hip_set_search_range_batch(int picW, int picH, int maxCUSize, int merange, int refLagPixels,
+                                   const int32_t* cu_xy, const int32_t* mvSrc, const int32_t* srcIdx, int n,
+                                   int32_t* qmvp, int32_t* mvmin, int32_t* mvmax, void* stream);
+/* Predict::predInterLumaPixel (reference: source/common/predict.cpp:245-266) for n PUs of one shape: the prediction
+ * of PU i (at pu_xy[i] in both planes) with quarter-pel vector qmv[i] is written into dst at the PU position:
+ * copy_pp / luma_hpp / luma_vpp / luma_hvpp selected by the fractional parts. */
+int x265hip_pred_inter_luma_batch(int depth, int w, int h, const void* refPlane, int64_t strideR, void* dst, int64_t strideD,
+                                  const int32_t* pu_xy, const int32_t* qmv, int n, void* stream);
+/* Picture border extension (reference: source/common/pixel.cpp:1027-1041 extendPicBorder, margins picyuv.cpp:87-115):
+ * replicates the edge pixels of the picW x picH picture at picOrigin into marginX / marginY pixels all around. */
+int x265hip_extend_border(int depth, void* picOrigin, int64_t stride, int picW, int picH, int marginX, int marginY, void* stream);
+/* BitCost::setQP (reference: source/encoder/bitcost.cpp:32-60, CalculateLogs :108-125): HOST function, fills the u16
+ * MVD cost row for `qp`: table[half + i] = table[half - i] = cost of |MVD| = i quarter-pels, i = 0..half (x265: half =
+ * 2 * BC_MAX_MV = 65536).  lambda = x265_lambda_tab[qp] of the given bit depth (constants.cpp:34-152). */
+int x265hip_mvcost_table(int qp, int depth, uint16_t* hostTable, int half);
+
 /* The residual chain of Search::estimateResidualQT for n TUs of one size (reference: search.cpp:3178-3330 ->
  * quant.cpp:397 transformNxN, :543 invtransformNxN): resi = fenc - pred (sub_ps) -> dct -> quant (flat quantCoeff,
  * add = rounding offset) -> numSig; if numSig: dequant_normal -> idct -> recon = clip(pred + resi') (add_ps)
@@ -171,6 +191,35 @@ int x265hip_residual_chain_batch(int size, int depth,
                                  const int32_t* offF, const int32_t* offP, const int32_t* offR,
                                  const int32_t* quantCoeff, int qBits, int add, int dqScale, int dqShift,
                                  int16_t* level, uint32_t* numSig, uint64_t* dist, int n, void* stream);
+
+/* ---------------------------------------------------------------- frame pass ------------------------------------ */
+/* One P-frame worth of the hot path as a fixed pipeline of the kernels above, all on one stream, no host round trip
+ * (what bench.py times).  For a width x height luma picture (multiples of 8):
+ *   1. motion search, top-down over CU sizes 64, 32, 16, 8 (every 2Nx2N PU that lies inside the picture): setSearchRange
+ *      + motionEstimate; the 64x64 level searches around (0,0), every smaller PU around its parent's result;
+ *   2. prediction of the picture from the 8x8 vectors (predInterLumaPixel);
+ *   3. the residual chain with 32x32 TUs over the 32-aligned area and 8x8 TUs over the rest -> levels, recon, SSE;
+ *   4. sa8d(src, pred) mode costs for every CU of the four sizes (analysis.cpp:3065);
+ *   5. border extension of the reconstructed picture so it can serve as the next frame's reference.
+ * Planes are passed by their picture ORIGIN pointer (pixel 0,0) with margins of at least maxCUSize + 32 = 96 pixels
+ * around them (PicYuv, picyuv.cpp:87-89). */
+typedef struct x265hip_framepass x265hip_framepass;
+int x265hip_framepass_create(int width, int height, int depth, int qp, int merange, int searchMethod, int subme,
+                             x265hip_framepass** out);
+int x265hip_framepass_destroy(x265hip_framepass* fp);
+int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t strideS, const void* ref, int64_t strideR,
+                          void* pred, int64_t strideP, void* recon, int64_t strideRec, int marginX, int marginY, void* stream);
+/* device pointers to the results of the last run (owned by fp).  `level`: 0..3 = CU size 64, 32, 16, 8 for the ME
+ * outputs; 0..1 = TU size 32, 8 for the transform outputs.  *count = number of PUs / TUs. */
+#define X265HIP_FP_PU_XY     0   /* int32 [n][2]                         */
+#define X265HIP_FP_MV        1   /* int32 [n][2] quarter-pel             */
+#define X265HIP_FP_MECOST    2   /* int32 [n]                            */
+#define X265HIP_FP_SA8D      3   /* int32 [n]   sa8d(src, pred) per CU   */
+#define X265HIP_FP_TU_OFF    4   /* int32 [n]   y*stride+x is NOT stored; (x, y) pairs: int32 [n][2] */
+#define X265HIP_FP_LEVEL     5   /* int16 [n][size*size]                 */
+#define X265HIP_FP_NUMSIG    6   /* uint32 [n]                           */
+#define X265HIP_FP_DIST      7   /* uint64 [n]                           */
+int x265hip_framepass_output(x265hip_framepass* fp, int which, int level, void** devPtr, int* count);
 
 /* ---------------------------------------------------------------- per-call entry points (host pointers) ----- */
 /* What the reference-side table shims bind (x265_amd/host/x265_hip_primitives.cpp).  Arguments are the slot's own

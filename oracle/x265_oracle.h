@@ -88,6 +88,23 @@ int orc_subpel_compare_##SFX(const P* plane, intptr_t stride, int bx, int by, co
 ORC_DECL_PIXEL(uint8_t, 8)
 ORC_DECL_PIXEL(uint16_t, 16)
 
+/* ---- frame pass (x265_oracle_frame.c): the pipeline libx265hip's x265hip_framepass_run executes, restated on the CPU
+ * from the pinned primitives above.  Checker for the GPU frame pass and bench.py's cpu_baseline ("port"). */
+/* encoder/search.cpp:2724 Search::setSearchRange + common/cudata.cpp:1915 CUData::clipMv */
+void orc_set_search_range(int picW, int picH, int maxCUSize, int merange, int refLagPixels, int cuX, int cuY,
+                          const int32_t qmvp[2], int32_t mvmin[2], int32_t mvmax[2]);
+#define ORC_DECL_FRAME(P, SFX) \
+/* common/predict.cpp:245 Predict::predInterLumaPixel */ \
+void orc_pred_inter_luma_##SFX(const P* ref, intptr_t rs, P* dst, intptr_t ds, int bx, int by, int w, int h, int qx, int qy, int depth); \
+/* common/pixel.cpp:1027 extendPicBorder */ \
+void orc_extend_border_##SFX(P* pic, intptr_t stride, int picW, int picH, int mx, int my); \
+void orc_frame_pass_##SFX(int width, int height, int depth, int qp, int merange, int method, int subme, \
+                          const P* src, intptr_t ss, const P* ref, intptr_t rs, P* pred, intptr_t ps, P* recon, intptr_t cs, \
+                          int marginX, int marginY, int32_t* mv[4], int32_t* mecost[4], int32_t* sa8d[4], \
+                          int16_t* level[2], uint32_t* numSig[2], uint64_t* dist[2]);
+ORC_DECL_FRAME(uint8_t, 8)
+ORC_DECL_FRAME(uint16_t, 16)
+
 /* ---- int16 block helpers (pixel-type independent) ------------------------------------------------------ */
 /* common/pixel.cpp:167 sse<..,int16_t,int16_t> */
 uint64_t orc_sse_ss(const int16_t* a, intptr_t sa, const int16_t* b, intptr_t sb, int w, int h);

@@ -1,0 +1,69 @@
+"""GPU parity of the frame pass (x265hip_framepass_*): every output bit-exact against the C restatement
+(oracle/x265_oracle_frame.c), from a 200x136 picture with 8x8 TU strips up to the BASELINE 1080p configuration, and a
+two-frame chain where the second frame searches the first frame's border-extended reconstruction."""
+import numpy as np
+import pytest
+
+from frame_oracle import make_scene, oracle_frame_pass, same_results
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fpmod():
+    from x265_amd import hipprim as hp, framepass
+    assert hp.lib().x265hip_device_count() > 0
+    hp.check(hp.lib().x265hip_init(0))
+    return framepass
+
+
+@pytest.mark.parametrize("depth,method,subme,qp", [(8, 1, 2, 28), (10, 1, 2, 30), (8, 0, 3, 22), (8, 1, 5, 35), (10, 1, 7, 24)])
+def test_small_frame_pass_is_bit_exact(fpmod, depth, method, subme, qp):
+    sc = make_scene(200, 136, depth=depth, seed=11 + qp, tile=48, sigma=3.0 * (1 if depth == 8 else 4))
+    fp = fpmod.FramePass(200, 136, depth=depth, qp=qp, merange=57, method=method, subme=subme)
+    got = fp.run_host(sc["src"], sc["ref"])
+    want = oracle_frame_pass(sc["src"], sc["ref"], depth=depth, qp=qp, merange=57, method=method, subme=subme)
+    assert same_results(got, want) == []
+    assert sum(int(x.sum()) for x in want["numSig"]) > 0          # the transform path was exercised
+
+
+def test_1080p_frame_pass_is_bit_exact(fpmod):
+    """BASELINE.json configs[1]: 1920x1080, --me hex, merange 57, subme 2 (preset medium)."""
+    sc = make_scene(1920, 1080, depth=8, seed=4321)
+    fp = fpmod.FramePass(1920, 1080, depth=8, qp=28)
+    got = fp.run_host(sc["src"], sc["ref"])
+    want = oracle_frame_pass(sc["src"], sc["ref"], depth=8, qp=28)
+    assert same_results(got, want) == []
+
+
+def test_two_frame_chain_uses_recon_as_reference(fpmod):
+    from x265_amd.framepass import Plane
+    w, h, depth, qp = 328, 200, 8, 26
+    a = make_scene(w, h, depth=depth, seed=5, tile=64)
+    b = make_scene(w, h, depth=depth, seed=6, tile=64)
+    fp = fpmod.FramePass(w, h, depth=depth, qp=qp)
+    s1, r0 = Plane(w, h, depth, a["src"]), Plane(w, h, depth, a["ref"])
+    s2 = Plane(w, h, depth, b["src"])
+    p, rec1, rec2 = Plane(w, h, depth), Plane(w, h, depth), Plane(w, h, depth)
+    fp.run(s1, r0, p, rec1)
+    fp.run(s2, rec1, p, rec2)                                     # frame 2 references frame 1's recon, all on device
+    got = fp.results()
+    got["pred"], got["recon"] = p.get(), rec2.get(with_margins=True)
+    o1 = oracle_frame_pass(a["src"], a["ref"], depth=depth, qp=qp)
+    m = 96
+    rec1_host = np.ascontiguousarray(o1["recon"][m:m + h, m:m + w])
+    # the oracle pads by edge replication, which is what extend_border produced on the device
+    assert np.array_equal(o1["recon"], np.pad(rec1_host, m, mode="edge"))
+    want = oracle_frame_pass(b["src"], rec1_host, depth=depth, qp=qp)
+    assert same_results(got, want) == []
+
+
+def test_mvcost_table_matches_oracle(fpmod):
+    """host BitCost::setQP restatement in the product == pinned oracle table (also covered on CPU in test_host_logic)."""
+    from x265_amd import hipprim as hp
+    from oracle import pyoracle as po
+    t = np.zeros(4 * 32768 + 1, np.uint16)
+    for qp in (0, 17, 28, 51):
+        for depth in (8, 10):
+            hp.check(hp.lib().x265hip_mvcost_table(qp, depth, t.ctypes.data, 2 * 32768))
+            assert np.array_equal(t, po.mvcost_table(qp, depth))

@@ -1,0 +1,105 @@
+"""Per-kernel micro-benchmarks on one GPU: frame-sized batches (SURVEY.md §8d shapes), HIP-event timing,
+achieved ALGORITHMIC GB/s (bytes per unit as defined in SURVEY.md §8d / DESIGN.md).  Not the contract bench (bench.py)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from x265_amd import hipprim as hp                      # noqa: E402
+from x265_amd.hipprim import DevBuf, check, dev_i32     # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    t = hp.Timer(None)
+    t.start()
+    for _ in range(iters):
+        fn()
+    return t.stop_ms() / iters
+
+
+def main():
+    L = hp.lib()
+    check(L.x265hip_init(0))
+    depth = int(os.environ.get("DEPTH", "8"))
+    B = 1 if depth == 8 else 2
+    W, H, M = 1920, 1080, 96
+    S = W + 2 * M
+    rng = np.random.default_rng(1)
+    dt = hp.pix_dtype(depth)
+    a = rng.integers(0, 1 << depth, size=(H + 2 * M, S)).astype(dt)
+    b = rng.integers(0, 1 << depth, size=(H + 2 * M, S)).astype(dt)
+    da, db = DevBuf(a), DevBuf(b)
+    res = []
+
+    def grid(bs, K=1, jitter=0):
+        ys, xs = np.meshgrid(np.arange(0, H - bs + 1, bs), np.arange(0, W - bs + 1, bs), indexing="ij")
+        off = ((ys + M) * S + xs + M).reshape(-1).astype(np.int64)
+        offb = np.repeat(off, K)
+        if jitter:
+            offb = offb + rng.integers(-jitter, jitter + 1, offb.size) * S + rng.integers(-jitter, jitter + 1, offb.size)
+        return off.astype(np.int32), offb.astype(np.int32)
+
+    for bs in (8, 16, 32, 64):
+        for K in (1, 16):
+            oa, ob = grid(bs, K, 8)
+            oaK = np.repeat(oa, K)
+            n = ob.size
+            d_oa, d_ob = dev_i32(oaK), dev_i32(ob)
+            out = DevBuf.zeros((n,), np.int32)
+            for op, name in ((hp.CMP_SAD, "sad"), (hp.CMP_SATD, "satd"), (hp.CMP_SA8D, "sa8d")):
+                ms = timeit(lambda: check(L.x265hip_pixcmp_batch(op, depth, bs, bs, da.ptr, S, db.ptr, S, d_oa.ptr, d_ob.ptr, n, out.ptr, None)))
+                byts = n * (2 * bs * bs * B + 4)
+                res.append({"kernel": "%s %dx%d K=%d" % (name, bs, bs, K), "n": n, "ms": ms, "GBps": byts / ms / 1e6})
+
+    # transforms: all TUs of a 1080p frame per size
+    for size in (4, 8, 16, 32):
+        n = (W // size) * (H // size)
+        resi = rng.integers(-255, 256, size=(n, size * size)).astype(np.int16)
+        dr = DevBuf(resi)
+        offs = dev_i32(np.arange(n) * size * size)
+        dst = DevBuf.zeros((n, size * size), np.int16)
+        ms = timeit(lambda: check(L.x265hip_dct_batch(size, 0, depth, dr.ptr, size, offs.ptr, dst.ptr, n, None)))
+        res.append({"kernel": "dct %d" % size, "n": n, "ms": ms, "GBps": n * 4 * size * size / ms / 1e6})
+        ms = timeit(lambda: check(L.x265hip_idct_batch(size, 0, depth, dst.ptr, dr.ptr, size, offs.ptr, n, None)))
+        res.append({"kernel": "idct %d" % size, "n": n, "ms": ms, "GBps": n * 4 * size * size / ms / 1e6})
+        # fused chain straight from the planes
+        oa, _ = grid(size)
+        n2 = oa.size
+        d_o = dev_i32(oa)
+        rec = DevBuf.zeros(a.shape, dt)
+        lvl, ns, dist = DevBuf.zeros((n2, size * size), np.int16), DevBuf.zeros((n2,), np.uint32), DevBuf.zeros((n2,), np.uint64)
+        log2n = size.bit_length() - 1
+        qp = 28
+        qc = DevBuf(np.full(size * size, [26214, 23302, 20560, 18396, 16384, 14564][qp % 6], np.int32))
+        qbits = 14 + qp // 6 + (15 - depth - log2n)
+        ms = timeit(lambda: check(L.x265hip_residual_chain_batch(size, depth, da.ptr, S, db.ptr, S, rec.ptr, S, d_o.ptr, d_o.ptr, d_o.ptr, qc.ptr,
+                                                                 qbits, 85 << (qbits - 9), [40, 45, 51, 57, 64, 72][qp % 6] << (qp // 6),
+                                                                 20 - 14 - (15 - depth - log2n), lvl.ptr, ns.ptr, dist.ptr, n2, None)))
+        res.append({"kernel": "chain %d" % size, "n": n2, "ms": ms, "GBps": n2 * size * size * (3 * B + 2) / ms / 1e6})
+
+    # interpolation: every 16x16 / 64x64 block of the frame
+    for bs in (16, 64):
+        oa, _ = grid(bs)
+        n = oa.size
+        d_o = dev_i32(oa)
+        d_od = dev_i32(np.arange(n) * bs * bs)
+        co = dev_i32(rng.integers(1, 4, n) | (rng.integers(1, 4, n) << 4))
+        out = DevBuf.zeros((n, bs, bs), dt)
+        for kind, name, ext in ((hp.IF_HPP, "hpp", (bs + 7) * bs), (hp.IF_VPP, "vpp", bs * (bs + 7)), (hp.IF_HVPP, "hvpp", (bs + 7) * (bs + 7))):
+            ms = timeit(lambda: check(L.x265hip_interp_batch(kind, 8, depth, bs, bs, da.ptr, S, out.ptr, bs, d_o.ptr, d_od.ptr, co.ptr, 0, n, None)))
+            res.append({"kernel": "luma_%s %dx%d" % (name, bs, bs), "n": n, "ms": ms, "GBps": n * (ext + bs * bs) * B / ms / 1e6})
+
+    for r in res:
+        print("%-22s n=%-7d %8.3f ms  %9.1f GB/s (algorithmic)" % (r["kernel"], r["n"], r["ms"], r["GBps"]))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "microbench_d%d.json" % depth), "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,265 @@
+// framepass.hip — host-side pipeline: one P-frame of the hot path as a fixed sequence of batched launches on one
+// stream (include/x265hip.h "frame pass").  Pure host C++ over the C ABI of this same library; also hosts
+// BitCost::setQP (bitcost.cpp:32-60) because the MVD cost table is float host math in the reference too.
+#include "common.h"
+#include <cmath>
+#include <vector>
+
+struct x265hip_framepass
+{
+    int width, height, depth, qp, merange, method, subme;
+    int nLevel[4];                 // PUs per CU size 64, 32, 16, 8
+    int32_t* puXY[4];              // device
+    int32_t* parent[4];            // device: index into the level above, -1 when that CU is not inside the picture
+    int32_t *qmvp[4], *mvmin[4], *mvmax[4], *mv[4], *cost[4], *sa8d[4];
+    int32_t* cuOff[4];             // y*stride+x offsets for sa8d launches are stride dependent -> rebuilt per run when strides change
+    int64_t cuOffStrideS, cuOffStrideP;
+    int32_t* cuOffP[4];
+    int nTu[2];                    // TU size 32, 8
+    int32_t* tuXY[2];              // device (x, y)
+    int32_t *tuOffF[2], *tuOffP[2], *tuOffR[2];
+    int64_t tuStrideF, tuStrideP, tuStrideR;
+    int16_t* level[2];
+    uint32_t* numSig[2];
+    uint64_t* dist[2];
+    uint16_t* mvcost;              // device, 4*32768+1 entries
+    int32_t* quantCoeff[2];        // flat scaling: quantScales[qp % 6] (scalinglist.cpp:129)
+    std::vector<int32_t> hCuXY[4], hTuXY[2];
+};
+
+namespace xh {
+
+static const int kCuSize[4] = { 64, 32, 16, 8 };
+static const int kTuSize[2] = { 32, 8 };
+static const int kMvHalf = 2 * 32768;
+
+template <typename T>
+static int dev_upload(T** d, const std::vector<T>& h)
+{
+    int e = check_hip(hipMalloc((void**)d, (h.size() ? h.size() : 1) * sizeof(T)), "hipMalloc(framepass)");
+    if (e) return e;
+    if (h.size())
+        e = check_hip(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy(framepass)");
+    return e;
+}
+template <typename T>
+static int dev_alloc(T** d, size_t n) { return check_hip(hipMalloc((void**)d, (n ? n : 1) * sizeof(T)), "hipMalloc(framepass)"); }
+
+static int upload_offsets(int32_t** d, const std::vector<int32_t>& xy, int64_t stride)
+{
+    std::vector<int32_t> off(xy.size() / 2);
+    for (size_t i = 0; i < off.size(); i++)
+        off[i] = (int32_t)((int64_t)xy[2 * i + 1] * stride + xy[2 * i]);
+    if (*d) (void)hipFree(*d);
+    *d = nullptr;
+    return dev_upload(d, off);
+}
+
+} // namespace xh
+
+using namespace xh;
+
+#define FP_TRY(x) do { int e_ = (x); if (e_) return e_; } while (0)
+
+extern "C" {
+
+int x265hip_mvcost_table(int qp, int depth, uint16_t* table, int half)
+{
+    if (qp < 0 || qp > 69 || !valid_depth(depth) || !table || half < 1)
+        return set_error(X265HIP_EINVAL, "mvcost_table: qp %d depth %d half %d", qp, depth, half);
+    // x265_lambda_tab[qp] = 2^(qp/6 - 2) * 2^(depth - 8)... stored as 4-decimal literals (constants.cpp:34-152)
+    const double e = (double)qp / 6.0 - 2.0 + (double)(depth - 8);
+    const double lambda = std::floor(std::pow(2.0, e) * 10000.0 + 0.5) / 10000.0;
+    // CalculateLogs (bitcost.cpp:108-125): float table, log() evaluated in double on a float argument
+    const float log2_2 = (float)(2.0f / std::log((double)2.0f));
+    for (int i = 0; i <= half; i++)
+    {
+        const float bits = i ? (float)(std::log((double)(float)(i + 1)) * log2_2 + 1.718f) : 0.718f;
+        const double v = bits * lambda + 0.5f;
+        const double cap = (double)((1 << 15) - 1);
+        const uint16_t c = (uint16_t)(v < cap ? v : cap);
+        table[half + i] = table[half - i] = c;
+    }
+    return X265HIP_OK;
+}
+
+int x265hip_framepass_create(int width, int height, int depth, int qp, int merange, int searchMethod, int subme,
+                             x265hip_framepass** out)
+{
+    XH_CHECK_DEV();
+    if (!out || width < 8 || height < 8 || (width & 7) || (height & 7) || !valid_depth(depth) || qp < 0 || qp > 51 ||
+        merange < 1 || merange > 256 || subme < 0 || subme > 7 || (searchMethod != 0 && searchMethod != 1 && searchMethod != 5))
+        return set_error(X265HIP_EINVAL, "framepass_create: %dx%d depth %d qp %d merange %d me %d subme %d", width, height, depth, qp,
+                         merange, searchMethod, subme);
+    x265hip_framepass* fp = new x265hip_framepass();
+    fp->width = width; fp->height = height; fp->depth = depth; fp->qp = qp;
+    fp->merange = merange; fp->method = searchMethod; fp->subme = subme;
+    fp->cuOffStrideS = fp->cuOffStrideP = fp->tuStrideF = fp->tuStrideP = fp->tuStrideR = -1;
+    for (int l = 0; l < 4; l++)
+    {
+        const int sz = kCuSize[l];
+        std::vector<int32_t> par;
+        for (int y = 0; y + sz <= height; y += sz)
+            for (int x = 0; x + sz <= width; x += sz)
+            {
+                fp->hCuXY[l].push_back(x);
+                fp->hCuXY[l].push_back(y);
+                int p = -1;
+                if (l > 0)
+                {
+                    const int ps = kCuSize[l - 1], pw = width / ps, ph = height / ps;     // parents fully inside
+                    const int px = x / ps, py = y / ps;
+                    if (px < pw && py < ph)
+                        p = py * pw + px;
+                }
+                par.push_back(p);
+            }
+        const int n = (int)par.size();
+        fp->nLevel[l] = n;
+        FP_TRY(dev_upload(&fp->puXY[l], fp->hCuXY[l]));
+        FP_TRY(dev_upload(&fp->parent[l], par));
+        FP_TRY(dev_alloc(&fp->qmvp[l], 2 * (size_t)n));
+        FP_TRY(dev_alloc(&fp->mvmin[l], 2 * (size_t)n));
+        FP_TRY(dev_alloc(&fp->mvmax[l], 2 * (size_t)n));
+        FP_TRY(dev_alloc(&fp->mv[l], 2 * (size_t)n));
+        FP_TRY(dev_alloc(&fp->cost[l], (size_t)n));
+        FP_TRY(dev_alloc(&fp->sa8d[l], (size_t)n));
+        fp->cuOff[l] = fp->cuOffP[l] = nullptr;
+    }
+    // TUs: 32x32 over the 32-aligned area, 8x8 over the remaining right / bottom strips
+    const int w32 = width & ~31, h32 = height & ~31;
+    for (int y = 0; y < h32; y += 32)
+        for (int x = 0; x < w32; x += 32) { fp->hTuXY[0].push_back(x); fp->hTuXY[0].push_back(y); }
+    for (int y = 0; y < height; y += 8)
+        for (int x = 0; x < width; x += 8)
+            if (x >= w32 || y >= h32) { fp->hTuXY[1].push_back(x); fp->hTuXY[1].push_back(y); }
+    static const int quantScales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };      // scalinglist.cpp:129 s_quantScales
+    for (int t = 0; t < 2; t++)
+    {
+        const int n = (int)fp->hTuXY[t].size() / 2, nc = kTuSize[t] * kTuSize[t];
+        fp->nTu[t] = n;
+        FP_TRY(dev_upload(&fp->tuXY[t], fp->hTuXY[t]));
+        FP_TRY(dev_alloc(&fp->level[t], (size_t)n * nc));
+        FP_TRY(dev_alloc(&fp->numSig[t], (size_t)n));
+        FP_TRY(dev_alloc(&fp->dist[t], (size_t)n));
+        std::vector<int32_t> qc(nc, quantScales[qp % 6]);
+        FP_TRY(dev_upload(&fp->quantCoeff[t], qc));
+        fp->tuOffF[t] = fp->tuOffP[t] = fp->tuOffR[t] = nullptr;
+    }
+    std::vector<uint16_t> tab(2 * kMvHalf + 1);
+    FP_TRY(x265hip_mvcost_table(qp, depth, tab.data(), kMvHalf));
+    FP_TRY(dev_upload(&fp->mvcost, tab));
+    *out = fp;
+    return X265HIP_OK;
+}
+
+int x265hip_framepass_destroy(x265hip_framepass* fp)
+{
+    if (!fp) return X265HIP_OK;
+    for (int l = 0; l < 4; l++)
+    {
+        void* ptrs[] = { fp->puXY[l], fp->parent[l], fp->qmvp[l], fp->mvmin[l], fp->mvmax[l], fp->mv[l], fp->cost[l], fp->sa8d[l], fp->cuOff[l], fp->cuOffP[l] };
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+    }
+    for (int t = 0; t < 2; t++)
+    {
+        void* ptrs[] = { fp->tuXY[t], fp->tuOffF[t], fp->tuOffP[t], fp->tuOffR[t], fp->level[t], fp->numSig[t], fp->dist[t], fp->quantCoeff[t] };
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+    }
+    if (fp->mvcost) (void)hipFree(fp->mvcost);
+    delete fp;
+    return X265HIP_OK;
+}
+
+int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t strideS, const void* ref, int64_t strideR,
+                          void* pred, int64_t strideP, void* recon, int64_t strideRec, int marginX, int marginY, void* stream)
+{
+    XH_CHECK_DEV();
+    if (!fp || !src || !ref || !pred || !recon)
+        return set_error(X265HIP_EINVAL, "framepass_run: null argument");
+    const int depth = fp->depth;
+    // offset tables depend on the caller's strides: (re)build them when the strides change (first run, normally once)
+    if (fp->cuOffStrideS != strideS || fp->cuOffStrideP != strideP)
+    {
+        FP_TRY(check_hip(hipStreamSynchronize(as_stream(stream)), "framepass sync"));
+        for (int l = 0; l < 4; l++)
+        {
+            FP_TRY(upload_offsets(&fp->cuOff[l], fp->hCuXY[l], strideS));
+            FP_TRY(upload_offsets(&fp->cuOffP[l], fp->hCuXY[l], strideP));
+        }
+        fp->cuOffStrideS = strideS; fp->cuOffStrideP = strideP;
+    }
+    if (fp->tuStrideF != strideS || fp->tuStrideP != strideP || fp->tuStrideR != strideRec)
+    {
+        FP_TRY(check_hip(hipStreamSynchronize(as_stream(stream)), "framepass sync"));
+        for (int t = 0; t < 2; t++)
+        {
+            FP_TRY(upload_offsets(&fp->tuOffF[t], fp->hTuXY[t], strideS));
+            FP_TRY(upload_offsets(&fp->tuOffP[t], fp->hTuXY[t], strideP));
+            FP_TRY(upload_offsets(&fp->tuOffR[t], fp->hTuXY[t], strideRec));
+        }
+        fp->tuStrideF = strideS; fp->tuStrideP = strideP; fp->tuStrideR = strideRec;
+    }
+    // 1. top-down motion search
+    for (int l = 0; l < 4; l++)
+    {
+        const int n = fp->nLevel[l], sz = kCuSize[l];
+        if (!n) continue;
+        FP_TRY(x265hip_set_search_range_batch(fp->width, fp->height, 64, fp->merange, fp->height /* -F1: m_refLagPixels = sourceHeight */,
+                                              fp->puXY[l], l ? fp->mv[l - 1] : nullptr, l ? fp->parent[l] : nullptr, n,
+                                              fp->qmvp[l], fp->mvmin[l], fp->mvmax[l], stream));
+        FP_TRY(x265hip_motion_estimate_batch(depth, sz, sz, src, strideS, ref, strideR, fp->puXY[l], fp->mvmin[l], fp->mvmax[l], fp->qmvp[l],
+                                             0, nullptr, fp->merange, fp->method, fp->subme, fp->mvcost + kMvHalf, kMvHalf, n,
+                                             fp->mv[l], fp->cost[l], stream));
+    }
+    // 2. prediction from the 8x8 vectors
+    FP_TRY(x265hip_pred_inter_luma_batch(depth, 8, 8, ref, strideR, pred, strideP, fp->puXY[3], fp->mv[3], fp->nLevel[3], stream));
+    // 3. residual chain
+    const int qp = fp->qp;
+    static const int invQuantScales[6] = { 40, 45, 51, 57, 64, 72 };                     // scalinglist.cpp:130
+    for (int t = 0; t < 2; t++)
+    {
+        if (!fp->nTu[t]) continue;
+        const int log2n = kTuSize[t] == 32 ? 5 : 3;
+        const int transformShift = 15 - depth - log2n;                                   // MAX_TR_DYNAMIC_RANGE - X265_DEPTH - log2TrSize (quant.cpp:408)
+        const int qBits = 14 + qp / 6 + transformShift;                                  // QUANT_SHIFT + per + transformShift (quant.cpp:465)
+        const int add = 85 << (qBits - 9);                                               // inter rounding (quant.cpp:466)
+        const int dqShift = 20 - 14 - transformShift;                                    // QUANT_IQUANT_SHIFT - QUANT_SHIFT - transformShift (quant.cpp:552)
+        const int dqScale = invQuantScales[qp % 6] << (qp / 6);                          // quant.cpp:567
+        FP_TRY(x265hip_residual_chain_batch(kTuSize[t], depth, src, strideS, pred, strideP, recon, strideRec, fp->tuOffF[t], fp->tuOffP[t],
+                                            fp->tuOffR[t], fp->quantCoeff[t], qBits, add, dqScale, dqShift, fp->level[t], fp->numSig[t],
+                                            fp->dist[t], fp->nTu[t], stream));
+    }
+    // 4. mode costs
+    for (int l = 0; l < 4; l++)
+        if (fp->nLevel[l])
+            FP_TRY(x265hip_pixcmp_batch(X265HIP_CMP_SA8D, depth, kCuSize[l], kCuSize[l], src, strideS, pred, strideP, fp->cuOff[l], fp->cuOffP[l],
+                                        fp->nLevel[l], fp->sa8d[l], stream));
+    // 5. the reconstructed picture becomes a reference
+    FP_TRY(x265hip_extend_border(depth, recon, strideRec, fp->width, fp->height, marginX, marginY, stream));
+    return X265HIP_OK;
+}
+
+int x265hip_framepass_output(x265hip_framepass* fp, int which, int level, void** devPtr, int* count)
+{
+    if (!fp || !devPtr || !count)
+        return set_error(X265HIP_EINVAL, "framepass_output: null argument");
+    const bool cuLevel = which <= X265HIP_FP_SA8D;
+    if (level < 0 || level >= (cuLevel ? 4 : 2))
+        return set_error(X265HIP_EINVAL, "framepass_output: level %d for output %d", level, which);
+    switch (which)
+    {
+    case X265HIP_FP_PU_XY:  *devPtr = fp->puXY[level]; *count = fp->nLevel[level]; break;
+    case X265HIP_FP_MV:     *devPtr = fp->mv[level]; *count = fp->nLevel[level]; break;
+    case X265HIP_FP_MECOST: *devPtr = fp->cost[level]; *count = fp->nLevel[level]; break;
+    case X265HIP_FP_SA8D:   *devPtr = fp->sa8d[level]; *count = fp->nLevel[level]; break;
+    case X265HIP_FP_TU_OFF: *devPtr = fp->tuXY[level]; *count = fp->nTu[level]; break;
+    case X265HIP_FP_LEVEL:  *devPtr = fp->level[level]; *count = fp->nTu[level]; break;
+    case X265HIP_FP_NUMSIG: *devPtr = fp->numSig[level]; *count = fp->nTu[level]; break;
+    case X265HIP_FP_DIST:   *devPtr = fp->dist[level]; *count = fp->nTu[level]; break;
+    default: return set_error(X265HIP_EINVAL, "framepass_output: unknown output %d", which);
+    }
+    return X265HIP_OK;
+}
+
+} // extern "C"

@@ -107,17 +107,17 @@ struct MeCtx
         }
     }
 
-    // ---- sub-pel candidate into `pred` (motion.cpp:1571-1600: hpp / vpp / hvpp or the plain block)
-    __device__ __forceinline__ void build_pred(int qx, int qy) const
+    // ---- W x H block at `r` (integer position in the reference plane) filtered to phase (xFrac, yFrac) into dst:
+    // copy / luma_hpp / luma_vpp / luma_hvpp exactly as subpelCompare (motion.cpp:1571-1600) and
+    // Predict::predInterLumaPixel (predict.cpp:245-266) select them.  dst may be LDS or global.
+    __device__ __forceinline__ void interp_block(const P* r, int xFrac, int yFrac, P* dst, int64_t ds) const
     {
-        const int xFrac = qx & 3, yFrac = qy & 3;
-        const P* r = fref + (int64_t)(qy >> 2) * stride + (qx >> 2);
         if (!(xFrac | yFrac))
         {
             for (int q = lane; q < quads; q += 64)
             {
                 const int row = q / quadsX, c4 = (q - row * quadsX) * 4;
-                *reinterpret_cast<Q*>(pred + row * w + c4) = ld_unaligned<Q>(r + (int64_t)row * stride + c4);
+                st_unaligned<Q>(dst + row * ds + c4, ld_unaligned<Q>(r + (int64_t)row * stride + c4));
             }
         }
         else if (!yFrac)
@@ -139,7 +139,7 @@ struct MeCtx
                     for (int i = 0; i < 8; i++) sum += v[o + i] * c[i];
                     out[o] = finish(sum, st);
                 }
-                store4(pred + row * w + c4, out);
+                store4(dst + row * ds + c4, out);
             }
         }
         else if (!xFrac)
@@ -162,7 +162,7 @@ struct MeCtx
                 }
 #pragma unroll
                 for (int o = 0; o < 4; o++) out[o] = finish(sum[o], st);
-                store4(pred + row * w + c4, out);
+                store4(dst + row * ds + c4, out);
             }
         }
         else
@@ -203,11 +203,16 @@ struct MeCtx
                 }
 #pragma unroll
                 for (int o = 0; o < 4; o++) out[o] = finish(sum[o], s2);
-                store4(pred + row * w + c4, out);
+                store4(dst + row * ds + c4, out);
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
+    }
+
+    __device__ __forceinline__ void build_pred(int qx, int qy) const
+    {
+        interp_block(fref + (int64_t)(qy >> 2) * stride + (qx >> 2), qx & 3, qy & 3, pred, (int64_t)w);
     }
 
     __device__ __forceinline__ int sad_pred() const
@@ -572,5 +577,105 @@ extern "C" int x265hip_motion_estimate_batch(int depth, int w, int h, const void
                            (const uint16_t*)refPlane, strideR, pu_xy, mvmin, mvmax, qmvp, numCand, mvc, merange, searchMethod, subme,
                            mvcost, w, h, depth, n, perWave, outMv, outCost);
     XH_LAUNCH_CHECK("motion_kernel");
+    return X265HIP_OK;
+}
+
+// ======================================================================================================================
+// Callers' helpers either side of motionEstimate: Search::setSearchRange and Predict::predInterLumaPixel
+// ======================================================================================================================
+namespace xh {
+
+// Search::setSearchRange (search.cpp:2724-2770) with CUData::clipMv (cudata.cpp:1915-1928); intra-refresh and slice
+// restrictions are off (their x265 defaults).  qmvp[i] = mvSrc[srcIdx[i]] (quarter-pel) or (0,0) when there is none.
+__global__ __launch_bounds__(256) void search_range_kernel(int picW, int picH, int maxCUSize, int merange, int refLagPixels,
+                                                           const int32_t* __restrict__ cu_xy, const int32_t* __restrict__ mvSrc,
+                                                           const int32_t* __restrict__ srcIdx, int n,
+                                                           int32_t* __restrict__ qmvp, int32_t* __restrict__ mvminO, int32_t* __restrict__ mvmaxO)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    {
+        int px = 0, py = 0;
+        if (mvSrc && srcIdx && srcIdx[i] >= 0)
+        {
+            px = mvSrc[2 * srcIdx[i]];
+            py = mvSrc[2 * srcIdx[i] + 1];
+        }
+        const int cx = cu_xy[2 * i], cy = cu_xy[2 * i + 1];
+        const int dist = merange << 2;
+        int minx = px - dist, miny = py - dist, maxx = px + dist, maxy = py + dist;
+        const int offset = 8;
+        const int xmax = (picW + offset - cx - 1) << 2, xmin = -((maxCUSize + offset + cx - 1) << 2);
+        const int ymax = (picH + offset - cy - 1) << 2, ymin = -((maxCUSize + offset + cy - 1) << 2);
+        minx = min(xmax, max(xmin, minx)); miny = min(ymax, max(ymin, miny));
+        maxx = min(xmax, max(xmin, maxx)); maxy = min(ymax, max(ymin, maxy));
+        const int maxMvLen = (1 << 15) - 1;
+        minx = max(minx, -maxMvLen); miny = max(miny, -maxMvLen);
+        maxx = min(maxx, maxMvLen); maxy = min(maxy, maxMvLen);
+        minx >>= 2; miny >>= 2; maxx >>= 2; maxy >>= 2;
+        miny = min(miny, refLagPixels);
+        maxy = min(maxy, refLagPixels);
+        maxy = max(maxy, miny);
+        qmvp[2 * i] = px; qmvp[2 * i + 1] = py;
+        mvminO[2 * i] = minx; mvminO[2 * i + 1] = miny;
+        mvmaxO[2 * i] = maxx; mvmaxO[2 * i + 1] = maxy;
+    }
+}
+
+// Predict::predInterLumaPixel (predict.cpp:245-266): one wave per PU, prediction written into the destination plane
+template <typename P>
+__global__ __launch_bounds__(256) void pred_inter_luma_kernel(const P* __restrict__ refPlane, int64_t strideR, P* __restrict__ dst, int64_t strideD,
+                                                              const int32_t* __restrict__ pu_xy, const int32_t* __restrict__ qmv,
+                                                              int w, int h, int depth, int n, int perWaveBytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wv = threadIdx.x >> 6;
+    MeCtx<P> c;
+    c.lane = threadIdx.x & 63;
+    c.w = w; c.h = h; c.depth = depth;
+    c.quadsX = w >> 2; c.quads = c.quadsX * h;
+    c.stride = strideR;
+    c.tmp = reinterpret_cast<int16_t*>(smem + (size_t)wv * perWaveBytes);
+    const int wavesPerWg = blockDim.x >> 6;
+    for (int pu = blockIdx.x * wavesPerWg + wv; pu < n; pu += gridDim.x * wavesPerWg)
+    {
+        const int bx = pu_xy[2 * pu], by = pu_xy[2 * pu + 1];
+        const int qx = qmv[2 * pu], qy = qmv[2 * pu + 1];
+        const P* r = refPlane + (int64_t)(by + (qy >> 2)) * strideR + bx + (qx >> 2);
+        c.interp_block(r, qx & 3, qy & 3, dst + (int64_t)by * strideD + bx, strideD);
+    }
+}
+
+} // namespace xh
+
+extern "C" int x265hip_set_search_range_batch(int picW, int picH, int maxCUSize, int merange, int refLagPixels,
+                                              const int32_t* cu_xy, const int32_t* mvSrc, const int32_t* srcIdx, int n,
+                                              int32_t* qmvp, int32_t* mvmin, int32_t* mvmax, void* stream)
+{
+    XH_CHECK_DEV();
+    if (picW < 8 || picH < 8 || maxCUSize < 8 || merange < 1 || n < 0)
+        return set_error(X265HIP_EINVAL, "set_search_range: pic %dx%d maxCU %d merange %d n %d", picW, picH, maxCUSize, merange, n);
+    if (!n) return X265HIP_OK;
+    hipLaunchKernelGGL(search_range_kernel, dim3(grid_for((n + 255) / 256)), dim3(256), 0, as_stream(stream), picW, picH, maxCUSize, merange,
+                       refLagPixels, cu_xy, mvSrc, srcIdx, n, qmvp, mvmin, mvmax);
+    XH_LAUNCH_CHECK("search_range_kernel");
+    return X265HIP_OK;
+}
+
+extern "C" int x265hip_pred_inter_luma_batch(int depth, int w, int h, const void* refPlane, int64_t strideR, void* dst, int64_t strideD,
+                                             const int32_t* pu_xy, const int32_t* qmv, int n, void* stream)
+{
+    XH_CHECK_DEV();
+    if (!valid_depth(depth) || !valid_block(w, h) || (w & 3) || n < 0)
+        return set_error(X265HIP_EINVAL, "pred_inter_luma: depth %d PU %dx%d n %d", depth, w, h, n);
+    if (!n) return X265HIP_OK;
+    int perWave = ((h + 7) * w * 2 + 15) & ~15;
+    dim3 grid(grid_for((n + 3) / 4)), block(256);
+    if (depth == 8)
+        hipLaunchKernelGGL((pred_inter_luma_kernel<uint8_t>), grid, block, 4 * perWave, as_stream(stream), (const uint8_t*)refPlane, strideR,
+                           (uint8_t*)dst, strideD, pu_xy, qmv, w, h, depth, n, perWave);
+    else
+        hipLaunchKernelGGL((pred_inter_luma_kernel<uint16_t>), grid, block, 4 * perWave, as_stream(stream), (const uint16_t*)refPlane, strideR,
+                           (uint16_t*)dst, strideD, pu_xy, qmv, w, h, depth, n, perWave);
+    XH_LAUNCH_CHECK("pred_inter_luma_kernel");
     return X265HIP_OK;
 }

@@ -444,3 +444,36 @@ int x265hip_p2s_batch(int depth, int w, int h, const void* src, int64_t strideS,
 }
 
 } // extern "C"
+
+// ---- picture border extension (reference: pixel.cpp:1027-1041 extendPicBorder / PicYuv margins picyuv.cpp:87-115) ----
+namespace xh {
+template <typename P>
+__global__ __launch_bounds__(256) void extend_border_kernel(P* __restrict__ pic, int64_t stride, int picW, int picH, int marginX, int marginY)
+{
+    const int fullW = picW + 2 * marginX, fullH = picH + 2 * marginY;
+    const long long total = (long long)fullW * fullH;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    {
+        const int y = (int)(i / fullW) - marginY, x = (int)(i % fullW) - marginX;
+        if (x >= 0 && x < picW && y >= 0 && y < picH)
+            continue;
+        const int sy = y < 0 ? 0 : (y >= picH ? picH - 1 : y), sx = x < 0 ? 0 : (x >= picW ? picW - 1 : x);
+        pic[(int64_t)y * stride + x] = pic[(int64_t)sy * stride + sx];
+    }
+}
+} // namespace xh
+
+extern "C" int x265hip_extend_border(int depth, void* picOrigin, int64_t stride, int picW, int picH, int marginX, int marginY, void* stream)
+{
+    XH_CHECK_DEV();
+    if (!valid_depth(depth) || picW < 1 || picH < 1 || marginX < 0 || marginY < 0)
+        return set_error(X265HIP_EINVAL, "extend_border: depth %d pic %dx%d margins %d,%d", depth, picW, picH, marginX, marginY);
+    const long long total = (long long)(picW + 2 * marginX) * (picH + 2 * marginY);
+    dim3 grid(grid_for((total + 255) / 256)), block(256);
+    if (depth == 8)
+        hipLaunchKernelGGL((extend_border_kernel<uint8_t>), grid, block, 0, as_stream(stream), (uint8_t*)picOrigin, stride, picW, picH, marginX, marginY);
+    else
+        hipLaunchKernelGGL((extend_border_kernel<uint16_t>), grid, block, 0, as_stream(stream), (uint16_t*)picOrigin, stride, picW, picH, marginX, marginY);
+    XH_LAUNCH_CHECK("extend_border_kernel");
+    return X265HIP_OK;
+}

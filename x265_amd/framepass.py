@@ -1,0 +1,139 @@
+"""Python handle on the C++ frame pass of libx265hip (x265hip_framepass_*, include/x265hip.h) — plumbing only.
+
+A frame pass = one P-frame of the hot path (top-down motion search, prediction, residual chain, mode costs, border
+extension) as a fixed pipeline of batched launches on one stream.  Planes live in device memory with PicYuv-style
+margins (reference: common/picyuv.cpp:87-89); `origin` pointers address pixel (0, 0)."""
+import ctypes as C
+
+import numpy as np
+
+from . import hipprim as hp
+from .hipprim import DevBuf, check
+
+MARGIN = 96                      # maxCUSize + 32 (picyuv.cpp:87-88)
+CU_SIZES = (64, 32, 16, 8)
+TU_SIZES = (32, 8)
+FP_PU_XY, FP_MV, FP_MECOST, FP_SA8D, FP_TU_XY, FP_LEVEL, FP_NUMSIG, FP_DIST = range(8)
+
+
+def padded(plane, margin=MARGIN):
+    """Edge-replicated copy of a 2-D picture with `margin` pixels all around (what extendPicBorder produces)."""
+    return np.ascontiguousarray(np.pad(plane, margin, mode="edge"))
+
+
+class Plane:
+    """A padded picture plane in device memory."""
+
+    def __init__(self, width, height, depth, host=None, margin=MARGIN):
+        self.width, self.height, self.depth, self.margin = width, height, depth, margin
+        self.stride = width + 2 * margin
+        self.rows = height + 2 * margin
+        dt = hp.pix_dtype(depth)
+        if host is not None:
+            assert host.shape == (height, width) and host.dtype == dt
+            self.buf = DevBuf(padded(host, margin))
+        else:
+            self.buf = DevBuf.zeros((self.rows, self.stride), dt)
+        self.origin = self.buf.at(margin * self.stride + margin)
+
+    def upload(self, host):
+        p = padded(host, self.margin)
+        check(hp.lib().x265hip_memcpy_h2d(self.buf.ptr, p.ctypes.data, p.nbytes, None))
+        check(hp.lib().x265hip_stream_sync(None))
+
+    def get(self, with_margins=False):
+        a = self.buf.get()
+        m = self.margin
+        return a if with_margins else np.ascontiguousarray(a[m:m + self.height, m:m + self.width])
+
+
+class FramePass:
+    def __init__(self, width, height, depth=8, qp=28, merange=57, method=hp.HEX_SEARCH, subme=2):
+        self.L = hp.lib()
+        self.width, self.height, self.depth, self.qp = width, height, depth, qp
+        self.merange, self.method, self.subme = merange, method, subme
+        h = C.c_void_p()
+        check(self.L.x265hip_framepass_create(width, height, depth, qp, merange, method, subme, C.byref(h)))
+        self.h = h
+
+    def run(self, src, ref, pred, recon, stream=None):
+        """src/ref/pred/recon: Plane objects (device).  Asynchronous on `stream`."""
+        check(self.L.x265hip_framepass_run(self.h, src.origin, src.stride, ref.origin, ref.stride, pred.origin, pred.stride,
+                                           recon.origin, recon.stride, recon.margin, recon.margin, stream))
+
+    def output(self, which, level):
+        p, n = C.c_void_p(), C.c_int()
+        check(self.L.x265hip_framepass_output(self.h, which, level, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def fetch(self, which, level):
+        ptr, n = self.output(which, level)
+        if which in (FP_PU_XY, FP_MV, FP_TU_XY):
+            shape, dt = (n, 2), np.int32
+        elif which in (FP_MECOST, FP_SA8D):
+            shape, dt = (n,), np.int32
+        elif which == FP_LEVEL:
+            shape, dt = (n, TU_SIZES[level] ** 2), np.int16
+        elif which == FP_NUMSIG:
+            shape, dt = (n,), np.uint32
+        else:
+            shape, dt = (n,), np.uint64
+        out = np.empty(shape, dt)
+        if out.nbytes:
+            check(self.L.x265hip_memcpy_d2h(out.ctypes.data, ptr, out.nbytes, None))
+        return out
+
+    def counts(self):
+        return [self.output(FP_MV, l)[1] for l in range(4)], [self.output(FP_NUMSIG, t)[1] for t in range(2)]
+
+    def results(self):
+        """All outputs of the last run as host arrays (synchronises)."""
+        check(self.L.x265hip_stream_sync(None))
+        r = {"mv": [self.fetch(FP_MV, l) for l in range(4)], "cost": [self.fetch(FP_MECOST, l) for l in range(4)],
+             "sa8d": [self.fetch(FP_SA8D, l) for l in range(4)], "level": [self.fetch(FP_LEVEL, t) for t in range(2)],
+             "numSig": [self.fetch(FP_NUMSIG, t) for t in range(2)], "dist": [self.fetch(FP_DIST, t) for t in range(2)]}
+        return r
+
+    def run_host(self, src, ref):
+        """Convenience for tests / smoke: host pictures in, every output (plus pred / recon with margins) out."""
+        ps, pr = Plane(self.width, self.height, self.depth, src), Plane(self.width, self.height, self.depth, ref)
+        pp, pc = Plane(self.width, self.height, self.depth), Plane(self.width, self.height, self.depth)
+        self.run(ps, pr, pp, pc)
+        r = self.results()
+        r["pred"] = pp.get()
+        r["recon"] = pc.get(with_margins=True)
+        return r
+
+    def close(self):
+        if self.h:
+            self.L.x265hip_framepass_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def algorithmic_bytes(width, height, depth, merange=57):
+    """ALGORITHMIC HBM bytes of one frame pass per kernel family (definitions: DESIGN.md §4)."""
+    B = 1 if depth == 8 else 2
+    R = 2 * merange + 1
+    out = {}
+    me = 0
+    for sz in CU_SIZES:
+        n = (width // sz) * (height // sz)
+        # exhaustive-window upper bound is NOT used: the hex pattern only touches a neighbourhood.  Count the source block
+        # once plus one (sz + 2*8 + 7)^2 reference neighbourhood per PU (±8 full-pel walk + 8-tap support), plus 12 B out.
+        me += n * (sz * sz * B + (sz + 23) * (sz + 23) * B + 12 + 24)
+    out["motion"] = me
+    n8 = (width // 8) * (height // 8)
+    out["pred"] = n8 * ((8 + 7) * (8 + 7) * B + 64 * B + 16)
+    w32, h32 = width & ~31, height & ~31
+    n32 = (w32 // 32) * (h32 // 32)
+    n8t = (width // 8) * (height // 8) - n32 * 16
+    out["chain"] = (n32 * 1024 + n8t * 64) * (3 * B + 2)
+    out["sa8d"] = sum((width // s) * (height // s) * (2 * s * s * B + 4) for s in CU_SIZES)
+    out["border"] = ((width + 2 * MARGIN) * (height + 2 * MARGIN) - width * height) * 2 * B
+    return out

@@ -55,6 +55,14 @@ PROTOTYPES = {
                                             vp, i32, i32, vp, vp, vp]),
     "x265hip_residual_chain_batch": (i32, [i32, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32,
                                            vp, vp, vp, i32, vp]),
+    "x265hip_set_search_range_batch": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "x265hip_pred_inter_luma_batch": (i32, [i32, i32, i32, vp, i64, vp, i64, vp, vp, i32, vp]),
+    "x265hip_extend_border": (i32, [i32, vp, i64, i32, i32, i32, i32, vp]),
+    "x265hip_mvcost_table": (i32, [i32, i32, vp, i32]),
+    "x265hip_framepass_create": (i32, [i32, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]),
+    "x265hip_framepass_destroy": (i32, [vp]),
+    "x265hip_framepass_run": (i32, [vp, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, vp]),
+    "x265hip_framepass_output": (i32, [vp, i32, i32, C.POINTER(vp), C.POINTER(i32)]),
     "x265hip_call_pixcmp": (i32, [i32, i32, i32, i32, vp, i64, vp, i64, vp]),
     "x265hip_call_sad_xn": (i32, [i32, i32, i32, i32, vp, vp, i64, vp]),
     "x265hip_call_sse_pp": (i32, [i32, i32, i32, vp, i64, vp, i64, vp]),
