@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — the contract bench.  One "step" = one frame pass (the P-frame hot path: top-down HEX motion search,
+prediction, residual chain, sa8d costs, border extension — include/x265hip.h "frame pass") over one 1920x1080 synthetic
+frame per GPU (BASELINE.json configs[1]: 1080p, --me hex, merange 57, subme 2, 8-bit).  Frames shard across ranks the way
+x265's frame threads do: rank g owns frames g, g+N, ...; after every step each rank sends its border-extended
+reconstruction to rank g+1 (RCCL send/recv ring shift) where it is the reference of that rank's next frame.
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see DESIGN.md §5 for every field)."""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, DEPTH, QP, MERANGE, SUBME = 1920, 1080, 8, 28, 57, 2
+HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+STAGES = ["me64", "me32", "me16", "me8", "pred8", "chain32", "chain8", "sa8d", "border"]
+
+
+def cpu_baseline(frames):
+    """The oracle's C restatement of the SAME frame pass, single thread, on `frames` 1080p frames (checker code used
+    here only as the reported CPU baseline)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from frame_oracle import oracle_frame_pass
+    from x265_amd.synth import make_scene
+    sc = make_scene(W, H, depth=DEPTH, seed=4321)
+    oracle_frame_pass(sc["src"][:136, :200].copy(), sc["ref"][:136, :200].copy(), depth=DEPTH, qp=QP)   # load + warm
+    t0 = time.perf_counter()
+    ref = sc["ref"]
+    for i in range(frames):
+        r = oracle_frame_pass(sc["src"], ref, depth=DEPTH, qp=QP, merange=MERANGE, method=1, subme=SUBME)
+        ref = r["recon"][96:96 + H, 96:96 + W]
+    dt = time.perf_counter() - t0
+    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frame passes of the same 1920x1080 workload (oracle/x265_oracle_frame.c, gcc -O2, 1 thread, %.1f s)" % (frames, dt)}
+
+
+def reference_encoder(frames=12):
+    """Context only: the REAL reference CLI ([noasm] C path, built into oracle/_ref by oracle/Makefile) encoding the same
+    kind of clip at 1080p preset medium --me hex on all host cores.  A full encoder, not the same workload."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "x265_8bit")
+    if not os.path.exists(exe):
+        return None
+    import numpy as np
+    from x265_amd.synth import make_clip
+    path = "/tmp/x265hip_bench_%d.yuv" % os.getpid()
+    try:
+        make_clip(path, W, H, frames, seed=4321)
+        cmd = [exe, "--input", path, "--input-res", "%dx%d" % (W, H), "--fps", "30", "--preset", "medium", "--me", "hex",
+               "--frames", str(frames), "-o", "/dev/null"]
+        t0 = time.perf_counter()
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        dt = time.perf_counter() - t0
+        fps = None
+        for line in (p.stderr + p.stdout).splitlines():
+            if "encoded" in line and "fps" in line:
+                fps = float(line.split("(")[1].split("fps")[0])
+        return {"fps": fps, "cores": os.cpu_count(), "frames": frames, "wall_s": round(dt, 1), "cmd": " ".join(cmd[3:]),
+                "note": "full x265 encoder, [noasm] C primitives (no nasm in the image); reported for context, not the same workload"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)[:200]}
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-ref-encoder", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from x265_amd import hipprim as hp
+    from x265_amd.framepass import FramePass, MARGIN, algorithmic_bytes
+    from x265_amd.synth import make_scene
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libx265hip has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    L = hp.lib()
+    hp.check(L.x265hip_init(local_rank))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream().cuda_stream or None
+
+    # ---- synthetic input resident in HBM: a pool of source frames per rank + the first reference
+    S, R = W + 2 * MARGIN, H + 2 * MARGIN
+    NPOOL = 4
+    pool, ref0 = [], None
+    for i in range(NPOOL):
+        sc = make_scene(W, H, depth=DEPTH, seed=4321 + 17 * rank + i)
+        pool.append(torch.from_numpy(np.ascontiguousarray(np.pad(sc["src"], MARGIN, mode="edge"))).to(dev))
+        if i == 0:
+            ref0 = torch.from_numpy(np.ascontiguousarray(np.pad(sc["ref"], MARGIN, mode="edge"))).to(dev)
+    refbuf = [ref0, torch.empty_like(ref0)]
+    pred = torch.zeros_like(ref0)
+    recon = [torch.empty_like(ref0), torch.empty_like(ref0)]
+    org = lambda t: t.data_ptr() + MARGIN * S + MARGIN            # noqa: E731  (8-bit: 1 byte per pixel)
+    fp = FramePass(W, H, depth=DEPTH, qp=QP, merange=MERANGE, method=hp.HEX_SEARCH, subme=SUBME)
+
+    state = {"ref": refbuf[0], "k": 0}
+
+    def step():
+        k = state["k"]
+        src, rec = pool[k % NPOOL], recon[k & 1]
+        hp.check(L.x265hip_framepass_run(fp.h, org(src), S, org(state["ref"]), S, org(pred), S, org(rec), S, MARGIN, MARGIN, stream))
+        if world > 1:
+            # reconstructed-reference exchange: my recon is the reference of the next frame, which lives on rank+1
+            nxt, prv = (rank + 1) % world, (rank - 1) % world
+            inbox = refbuf[1] if state["ref"] is refbuf[0] else refbuf[0]
+            ops = [dist.P2POp(dist.isend, rec, nxt), dist.P2POp(dist.irecv, inbox, prv)]
+            for r_ in dist.batch_isend_irecv(ops):
+                r_.wait()
+            state["ref"] = inbox
+        else:
+            state["ref"] = rec
+        state["k"] = k + 1
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt * 1e3 / args.steps
+    fps = world * args.steps / dt
+
+    # ---- roofline of the dominant kernel: same workload, same stream, HIP events at the stage boundaries
+    hp.check(L.x265hip_framepass_set_profiling(fp.h, 1))
+    acc = np.zeros(9)
+    nprof = max(10, min(args.steps, 50))
+    ms9 = (C.c_float * 9)()
+    for _ in range(nprof):
+        step()
+        hp.check(L.x265hip_framepass_stage_ms(fp.h, ms9))
+        acc += np.array(list(ms9))
+    hp.check(L.x265hip_framepass_set_profiling(fp.h, 0))
+    stage_ms = dict(zip(STAGES, (acc / nprof).round(5).tolist()))
+    fence()
+
+    if rank == 0:
+        ab = algorithmic_bytes(W, H, DEPTH, MERANGE)
+        dom = max(STAGES, key=lambda s: stage_ms[s])
+        # the dominant stage is a motion-search level: algorithmic bytes = source + reference picture once each (every
+        # PU of a level tiles the picture and the search windows overlap: compulsory traffic is the two pictures) + I/O arrays
+        n_by_stage = {"me64": 480, "me32": 1980, "me16": 8040, "me8": 32400}
+        if dom in n_by_stage:
+            n = n_by_stage[dom]
+            dom_bytes = W * H + (W + 2 * (MERANGE + 4)) * (H + 2 * (MERANGE + 4)) + n * (12 + 32)
+            kernel = "motion_kernel<uint8_t> (%s: %d PUs)" % (dom, n)
+        else:
+            dom_bytes = {"pred8": ab["pred"], "chain32": ab["chain"], "chain8": ab["chain"], "sa8d": ab["sa8d"], "border": ab["border"]}[dom]
+            kernel = dom
+        achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
+        out = {
+            "metric": "encode fps (1080p preset medium hot path: frame passes per second)", "value": round(fps, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "1920x1080 8-bit, --me hex --merange 57 --subme 2, qp 28: frame pass = top-down 2Nx2N motion search "
+                                   "(64/32/16/8) + predInterLuma + dct/quant/dequant/idct/recon/sse chain + sa8d + border extension; "
+                                   "one frame per GPU per step, recon exchanged to the next rank (RCCL send/recv) when N > 1",
+                       "frames_per_step": world, "pus_per_frame": 42900, "tus_per_frame": 2700},
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": stage_ms[dom]},
+            "stage_ms": stage_ms,
+        }
+        if world == 1 and args.cpu_frames > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_frames)
+            if not args.no_ref_encoder:
+                out["reference_encoder"] = reference_encoder()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -220,12 +220,19 @@ int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t stride
 #define X265HIP_FP_NUMSIG    6   /* uint32 [n]                           */
 #define X265HIP_FP_DIST      7   /* uint64 [n]                           */
 int x265hip_framepass_output(x265hip_framepass* fp, int which, int level, void** devPtr, int* count);
+/* Stage timing with HIP events on the run's own stream.  After set_profiling(fp, 1) every run records an event at each
+ * stage boundary; stage_ms() waits for the last run and returns the 9 stage durations in ms:
+ * [0..3] motion search of CU size 64/32/16/8 (setSearchRange + motionEstimate), [4] prediction, [5] 32x32 residual chain,
+ * [6] 8x8 residual chain, [7] the four sa8d launches, [8] border extension. */
+int x265hip_framepass_set_profiling(x265hip_framepass* fp, int enable);
+int x265hip_framepass_stage_ms(x265hip_framepass* fp, float* ms9);
 
 /* ---------------------------------------------------------------- per-call entry points (host pointers) ----- */
 /* What the reference-side table shims bind (x265_amd/host/x265_hip_primitives.cpp).  Arguments are the slot's own
  * arguments (HOST pointers, caller-owned, valid only during the call — primitives.h:133-234); each call stages the
  * operands into pinned memory, launches the batched kernel with n = 1 on the calling thread's stream and waits.
  * On any failure they return a negative code and leave the outputs untouched so the shim can call the C slot. */
+unsigned long long x265hip_call_count(void);   /* per-call launches served so far (process-wide) */
 int x265hip_call_pixcmp(int op, int depth, int w, int h, const void* a, int64_t sa, const void* b, int64_t sb, int32_t* result);
 int x265hip_call_sad_xn(int K, int depth, int w, int h, const void* fenc, const void* const* refs, int64_t strideR, int32_t* res);
 int x265hip_call_sse_pp(int depth, int w, int h, const void* a, int64_t sa, const void* b, int64_t sb, uint64_t* result);

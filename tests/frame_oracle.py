@@ -8,6 +8,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import pyoracle as po  # noqa: E402
+from x265_amd.synth import make_scene  # noqa: E402,F401  (seeded input generator, shared with bench.py)
 
 MARGIN = 96
 CU_SIZES = (64, 32, 16, 8)
@@ -19,33 +20,6 @@ def counts(width, height):
     n32 = ((width & ~31) // 32) * ((height & ~31) // 32)
     n8 = (width // 8) * (height // 8) - n32 * 16
     return ncu, [n32, n8]
-
-
-def make_scene(width, height, depth=8, seed=4321, tile=96, vmax=9, sigma=3.0):
-    """BASELINE.md §3 generator: low-pass random texture; the source frame is the reference moved per `tile` x `tile`
-    tile by its own vector in [-vmax, vmax]^2 plus Gaussian noise.  Returns dict(src=, ref=) of (height, width) arrays."""
-    rng = np.random.default_rng(seed)
-    pmax = (1 << depth) - 1
-    pad = vmax + 8
-    H, W = height + 2 * pad, width + 2 * pad
-    base = rng.random((H // 8 + 3, W // 8 + 3))
-    up = np.kron(base, np.ones((8, 8)))[:H + 16, :W + 16]
-    k = np.ones(9) / 9.0
-    up = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 1, up)
-    up = np.apply_along_axis(lambda c: np.convolve(c, k, mode="same"), 0, up)[8:8 + H, 8:8 + W]
-    up = (up - up.min()) / max(up.max() - up.min(), 1e-9)
-    fine = rng.normal(0, 6.0 * pmax / 255.0, (H, W))
-    big = np.clip(up * pmax * 0.8 + pmax * 0.1 + fine, 0, pmax)
-    ref = big[pad:pad + height, pad:pad + width]
-    src = np.empty_like(ref)
-    for y0 in range(0, height, tile):
-        for x0 in range(0, width, tile):
-            dy, dx = int(rng.integers(-vmax, vmax + 1)), int(rng.integers(-vmax, vmax + 1))
-            y1, x1 = min(y0 + tile, height), min(x0 + tile, width)
-            src[y0:y1, x0:x1] = big[pad + y0 + dy:pad + y1 + dy, pad + x0 + dx:pad + x1 + dx]
-    src = src + rng.normal(0, sigma * pmax / 255.0, src.shape)
-    dt = np.uint8 if depth == 8 else np.uint16
-    return {"src": np.clip(np.rint(src), 0, pmax).astype(dt), "ref": np.clip(np.rint(ref), 0, pmax).astype(dt)}
 
 
 def _proto(L, depth):

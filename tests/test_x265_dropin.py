@@ -1,0 +1,69 @@
+"""The drop-in proof on a real GPU: the REFERENCE's own binaries, linked with x265_amd/host/x265_hip_primitives.cpp
+(our setupAssemblyPrimitives) and libx265hip.so, built into oracle/_ref by `make -C oracle hip` where /root/reference
+exists (the binaries travel to the GPU box; the reference sources do not).
+
+ 1. the reference TestBench (source/test/testbench.cpp): C table vs our table on its own random / min / max inputs,
+    bit-exact or it aborts — run until its correctness phase ends;
+ 2. BASELINE.json configs[0]: QCIF all-intra ultrafast encode — the bitstream produced with the GPU primitives behind the
+    EncoderPrimitives table must be byte-identical to the C-primitive build's (the reference's regression criterion,
+    source/test/regression-tests.txt:3-7)."""
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+
+def _need(name):
+    p = os.path.join(REF, name)
+    if not os.path.exists(p):
+        pytest.skip("%s not built (needs /root/reference at build time: make -C oracle hip)" % name)
+    return p
+
+
+@pytest.mark.parametrize("bits", [8, 10])
+def test_reference_testbench_passes_with_gpu_primitives(bits):
+    exe = _need("TestBench_hip%d" % bits)
+    env = dict(os.environ, X265HIP_VERBOSE="1")
+    p = subprocess.Popen([exe, "--cpuid", "SSE2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+    lines, t0, done = [], time.time(), False
+    try:
+        for line in p.stdout:
+            lines.append(line.rstrip())
+            if "Test performance improvement" in line:
+                done = True
+                break
+            if time.time() - t0 > 400:
+                break
+    finally:
+        p.kill()
+    out = "\n".join(lines)
+    assert "has failed" not in out and "failed" not in out.lower(), out[-2000:]
+    assert done, "TestBench did not finish its correctness phase: " + out[-1500:]
+    assert out.count("Testing primitives:") >= 1
+
+
+def test_qcif_bitstream_identical_to_c_primitives(tmp_path):
+    c_exe, g_exe = _need("x265_8bit"), _need("x265_hip_8bit")
+    sys.path.insert(0, ROOT)
+    from x265_amd.synth import make_clip
+    yuv = str(tmp_path / "qcif.yuv")
+    make_clip(yuv, 176, 144, 8, seed=99, tile=48)
+    args = ["--input", yuv, "--input-res", "176x144", "--fps", "30", "--preset", "ultrafast", "--keyint", "1",
+            "--frames", "8", "--pools", "none", "-F", "1", "--hash", "1"]
+    outs = {}
+    for tag, exe in (("c", c_exe), ("gpu", g_exe)):
+        o = str(tmp_path / (tag + ".hevc"))
+        env = dict(os.environ, X265HIP_VERBOSE="1")
+        r = subprocess.run([exe] + args + ["-o", o], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-800:]
+        outs[tag] = (open(o, "rb").read(), r.stderr)
+    assert len(outs["c"][0]) > 1000
+    assert outs["c"][0] == outs["gpu"][0], "bitstreams differ"
+    served = [l for l in outs["gpu"][1].splitlines() if "primitive calls served by the GPU" in l]
+    assert served and int(served[0].split()[1]) > 1000, outs["gpu"][1][-600:]

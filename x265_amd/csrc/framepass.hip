@@ -25,6 +25,8 @@ struct x265hip_framepass
     uint16_t* mvcost;              // device, 4*32768+1 entries
     int32_t* quantCoeff[2];        // flat scaling: quantScales[qp % 6] (scalinglist.cpp:129)
     std::vector<int32_t> hCuXY[4], hTuXY[2];
+    bool profile;                  // record a HIP event at every stage boundary of run()
+    hipEvent_t ev[10];
 };
 
 namespace xh {
@@ -95,6 +97,9 @@ int x265hip_framepass_create(int width, int height, int depth, int qp, int meran
     fp->width = width; fp->height = height; fp->depth = depth; fp->qp = qp;
     fp->merange = merange; fp->method = searchMethod; fp->subme = subme;
     fp->cuOffStrideS = fp->cuOffStrideP = fp->tuStrideF = fp->tuStrideP = fp->tuStrideR = -1;
+    fp->profile = false;
+    for (int i = 0; i < 10; i++)
+        FP_TRY(check_hip(hipEventCreate(&fp->ev[i]), "hipEventCreate(framepass)"));
     for (int l = 0; l < 4; l++)
     {
         const int sz = kCuSize[l];
@@ -167,6 +172,7 @@ int x265hip_framepass_destroy(x265hip_framepass* fp)
         for (void* p : ptrs) if (p) (void)hipFree(p);
     }
     if (fp->mvcost) (void)hipFree(fp->mvcost);
+    for (int i = 0; i < 10; i++) (void)hipEventDestroy(fp->ev[i]);
     delete fp;
     return X265HIP_OK;
 }
@@ -200,10 +206,12 @@ int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t stride
         }
         fp->tuStrideF = strideS; fp->tuStrideP = strideP; fp->tuStrideR = strideRec;
     }
+#define FP_MARK(i) do { if (fp->profile) FP_TRY(check_hip(hipEventRecord(fp->ev[i], as_stream(stream)), "hipEventRecord")); } while (0)
     // 1. top-down motion search
     for (int l = 0; l < 4; l++)
     {
         const int n = fp->nLevel[l], sz = kCuSize[l];
+        FP_MARK(l);
         if (!n) continue;
         FP_TRY(x265hip_set_search_range_batch(fp->width, fp->height, 64, fp->merange, fp->height /* -F1: m_refLagPixels = sourceHeight */,
                                               fp->puXY[l], l ? fp->mv[l - 1] : nullptr, l ? fp->parent[l] : nullptr, n,
@@ -212,6 +220,7 @@ int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t stride
                                              0, nullptr, fp->merange, fp->method, fp->subme, fp->mvcost + kMvHalf, kMvHalf, n,
                                              fp->mv[l], fp->cost[l], stream));
     }
+    FP_MARK(4);
     // 2. prediction from the 8x8 vectors
     FP_TRY(x265hip_pred_inter_luma_batch(depth, 8, 8, ref, strideR, pred, strideP, fp->puXY[3], fp->mv[3], fp->nLevel[3], stream));
     // 3. residual chain
@@ -219,6 +228,7 @@ int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t stride
     static const int invQuantScales[6] = { 40, 45, 51, 57, 64, 72 };                     // scalinglist.cpp:130
     for (int t = 0; t < 2; t++)
     {
+        FP_MARK(5 + t);
         if (!fp->nTu[t]) continue;
         const int log2n = kTuSize[t] == 32 ? 5 : 3;
         const int transformShift = 15 - depth - log2n;                                   // MAX_TR_DYNAMIC_RANGE - X265_DEPTH - log2TrSize (quant.cpp:408)
@@ -230,13 +240,34 @@ int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t stride
                                             fp->tuOffR[t], fp->quantCoeff[t], qBits, add, dqScale, dqShift, fp->level[t], fp->numSig[t],
                                             fp->dist[t], fp->nTu[t], stream));
     }
+    FP_MARK(7);
     // 4. mode costs
     for (int l = 0; l < 4; l++)
         if (fp->nLevel[l])
             FP_TRY(x265hip_pixcmp_batch(X265HIP_CMP_SA8D, depth, kCuSize[l], kCuSize[l], src, strideS, pred, strideP, fp->cuOff[l], fp->cuOffP[l],
                                         fp->nLevel[l], fp->sa8d[l], stream));
+    FP_MARK(8);
     // 5. the reconstructed picture becomes a reference
     FP_TRY(x265hip_extend_border(depth, recon, strideRec, fp->width, fp->height, marginX, marginY, stream));
+    FP_MARK(9);
+#undef FP_MARK
+    return X265HIP_OK;
+}
+
+int x265hip_framepass_set_profiling(x265hip_framepass* fp, int enable)
+{
+    if (!fp) return set_error(X265HIP_EINVAL, "framepass_set_profiling: null handle");
+    fp->profile = enable != 0;
+    return X265HIP_OK;
+}
+
+int x265hip_framepass_stage_ms(x265hip_framepass* fp, float* ms9)
+{
+    if (!fp || !ms9 || !fp->profile)
+        return set_error(X265HIP_EINVAL, "framepass_stage_ms: profiling is off");
+    FP_TRY(check_hip(hipEventSynchronize(fp->ev[9]), "hipEventSynchronize"));
+    for (int i = 0; i < 9; i++)
+        FP_TRY(check_hip(hipEventElapsedTime(&ms9[i], fp->ev[i], fp->ev[i + 1]), "hipEventElapsedTime"));
     return X265HIP_OK;
 }
 

@@ -9,6 +9,7 @@
 // This path exists for drop-in correctness (TestBench, bit-exact encodes); throughput comes from the batched
 // entry points.  Any failure returns a negative code with outputs untouched; the shim then calls the C slot.
 #include "common.h"
+#include <atomic>
 #include <cstring>
 
 namespace xh {
@@ -22,6 +23,7 @@ struct Staging
     size_t used = 0;
 };
 static thread_local Staging t_st;
+static std::atomic<unsigned long long> g_calls{0};   // per-call launches served (diagnostics: proves the GPU path ran)
 
 static int staging_reserve(size_t bytes)
 {
@@ -71,6 +73,7 @@ static void unpack_rows(void* dst, int64_t dstStrideElems, const void* src, int 
 static int upload() { return check_hip(hipMemcpyAsync(t_st.dev, t_st.host, t_st.used, hipMemcpyHostToDevice, t_st.stream), "percall h2d"); }
 static int download(size_t off, size_t bytes)
 {
+    g_calls.fetch_add(1, std::memory_order_relaxed);
     int e = check_hip(hipMemcpyAsync(t_st.host + off, t_st.dev + off, bytes, hipMemcpyDeviceToHost, t_st.stream), "percall d2h");
     if (e) return e;
     return check_hip(hipStreamSynchronize(t_st.stream), "percall sync");
@@ -84,6 +87,8 @@ using namespace xh;
 #define PC_TRY(x) do { int e_ = (x); if (e_) return e_; } while (0)
 
 extern "C" {
+
+unsigned long long x265hip_call_count(void) { return g_calls.load(); }
 
 int x265hip_call_pixcmp(int op, int depth, int w, int h, const void* a, int64_t sa, const void* b, int64_t sb, int32_t* result)
 {

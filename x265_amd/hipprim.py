@@ -63,6 +63,9 @@ PROTOTYPES = {
     "x265hip_framepass_destroy": (i32, [vp]),
     "x265hip_framepass_run": (i32, [vp, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, vp]),
     "x265hip_framepass_output": (i32, [vp, i32, i32, C.POINTER(vp), C.POINTER(i32)]),
+    "x265hip_framepass_set_profiling": (i32, [vp, i32]),
+    "x265hip_framepass_stage_ms": (i32, [vp, C.POINTER(C.c_float)]),
+    "x265hip_call_count": (C.c_ulonglong, []),
     "x265hip_call_pixcmp": (i32, [i32, i32, i32, i32, vp, i64, vp, i64, vp]),
     "x265hip_call_sad_xn": (i32, [i32, i32, i32, i32, vp, vp, i64, vp]),
     "x265hip_call_sse_pp": (i32, [i32, i32, i32, vp, i64, vp, i64, vp]),

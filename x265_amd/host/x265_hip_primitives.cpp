@@ -1,0 +1,250 @@
+// x265_hip_primitives.cpp — the ONE translation unit a maintainer adds to an x265 build to run the hot-path slots of
+// `EncoderPrimitives` on an MI355X through libx265hip.so (C ABI: include/x265hip.h).
+//
+// It is compiled INSIDE the x265 tree (it includes x265's own common.h / primitives.h, so it always sees the exact
+// struct layout, pixel type and X265_NS of that build) and defines the two symbols x265 expects from its assembly
+// directory (reference: source/common/primitives.h:469-470, called from primitives.cpp:260-265 and from the TestBench,
+// test/testbench.cpp:191,211):
+//     void setupInstrinsicPrimitives(EncoderPrimitives& p, int cpuMask);     // (sic) — no-op here
+//     void setupAssemblyPrimitives(EncoderPrimitives& p, int cpuMask);       // overwrites the slots listed below
+// plus the cpu-a.asm helpers the ENABLE_ASSEMBLY x86 build references (primitives.cpp:288-303).
+//
+// Every shim is a synchronous call on caller-owned host memory, exactly the slot's signature; it forwards to the
+// per-call entry point x265hip_call_* and, if the GPU path reports an error, to the reference's own C implementation
+// (a private table filled by setupCPrimitives) — never garbage, never abort (SURVEY.md §8b "Errors").
+// `cpuMask` is ignored: the GPU path is selected by the environment variable X265HIP (default on, "0" disables).
+#include "common.h"
+#include "primitives.h"
+#include "x265hip.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace X265_NS {
+
+static EncoderPrimitives g_c;          // the C reference table, for fallback
+static bool g_cReady = false;
+
+static void ensure_c_table()
+{
+    if (!g_cReady)
+    {
+        memset(&g_c, 0, sizeof(g_c));
+        setupCPrimitives(g_c);
+        setupAliasPrimitives(g_c);
+        g_cReady = true;
+    }
+}
+
+#define D X265_DEPTH
+
+// ---- pixel comparisons (primitives.h:133-140) ----------------------------------------------------------------------
+template <int W, int H, int PART> static int sad_hip(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
+{
+    int32_t r;
+    if (x265hip_call_pixcmp(X265HIP_CMP_SAD, D, W, H, a, sa, b, sb, &r)) return g_c.pu[PART].sad(a, sa, b, sb);
+    return r;
+}
+template <int W, int H, int PART> static int satd_hip(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
+{
+    int32_t r;
+    if (x265hip_call_pixcmp(X265HIP_CMP_SATD, D, W, H, a, sa, b, sb, &r)) return g_c.pu[PART].satd(a, sa, b, sb);
+    return r;
+}
+template <int W, int H, int PART> static void sad_x3_hip(const pixel* f, const pixel* r0, const pixel* r1, const pixel* r2, intptr_t rs, int32_t* res)
+{
+    const void* refs[3] = { r0, r1, r2 };
+    if (x265hip_call_sad_xn(3, D, W, H, f, refs, rs, res)) g_c.pu[PART].sad_x3(f, r0, r1, r2, rs, res);
+}
+template <int W, int H, int PART> static void sad_x4_hip(const pixel* f, const pixel* r0, const pixel* r1, const pixel* r2, const pixel* r3, intptr_t rs, int32_t* res)
+{
+    const void* refs[4] = { r0, r1, r2, r3 };
+    if (x265hip_call_sad_xn(4, D, W, H, f, refs, rs, res)) g_c.pu[PART].sad_x4(f, r0, r1, r2, r3, rs, res);
+}
+template <int N, int CU> static int sa8d_hip(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
+{
+    int32_t r;
+    if (x265hip_call_pixcmp(X265HIP_CMP_SA8D, D, N, N, a, sa, b, sb, &r)) return g_c.cu[CU].sa8d(a, sa, b, sb);
+    return r;
+}
+template <int N, int CU> static int psy_hip(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
+{
+    int32_t r;
+    if (x265hip_call_pixcmp(X265HIP_CMP_PSY, D, N, N, a, sa, b, sb, &r)) return g_c.cu[CU].psy_cost_pp(a, sa, b, sb);
+    return r;
+}
+template <int N, int CU> static sse_t sse_pp_hip(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
+{
+    uint64_t r;
+    if (x265hip_call_sse_pp(D, N, N, a, sa, b, sb, &r)) return g_c.cu[CU].sse_pp(a, sa, b, sb);
+    return (sse_t)r;
+}
+template <int N, int CU> static sse_t sse_ss_hip(const int16_t* a, intptr_t sa, const int16_t* b, intptr_t sb)
+{
+    uint64_t r;
+    if (x265hip_call_sse_ss(N, N, a, sa, b, sb, &r)) return g_c.cu[CU].sse_ss(a, sa, b, sb);
+    return (sse_t)r;
+}
+template <int N, int CU> static sse_t ssd_s_hip(const int16_t* a, intptr_t sa)
+{
+    uint64_t r;
+    if (x265hip_call_sse_ss(N, N, a, sa, NULL, 0, &r)) return g_c.cu[CU].ssd_s[NONALIGNED](a, sa);
+    return (sse_t)r;
+}
+
+// ---- transforms (primitives.h:153-163) --------------------------------------------------------------------------------
+template <int N, int CU> static void dct_hip(const int16_t* src, int16_t* dst, intptr_t stride)
+{
+    if (x265hip_call_dct(N, 0, D, src, dst, stride)) g_c.cu[CU].dct(src, dst, stride);
+}
+template <int N, int CU> static void idct_hip(const int16_t* src, int16_t* dst, intptr_t stride)
+{
+    if (x265hip_call_idct(N, 0, D, src, dst, stride)) g_c.cu[CU].idct(src, dst, stride);
+}
+static void dst4_hip(const int16_t* src, int16_t* dst, intptr_t stride)
+{
+    if (x265hip_call_dct(4, 1, D, src, dst, stride)) g_c.dst4x4(src, dst, stride);
+}
+static void idst4_hip(const int16_t* src, int16_t* dst, intptr_t stride)
+{
+    if (x265hip_call_idct(4, 1, D, src, dst, stride)) g_c.idst4x4(src, dst, stride);
+}
+static bool tu_count(int n) { return n == 16 || n == 64 || n == 256 || n == 1024; }
+static uint32_t quant_hip(const int16_t* coef, const int32_t* quantCoeff, int32_t* deltaU, int16_t* qCoef, int qBits, int add, int numCoeff)
+{
+    uint32_t ns;
+    if (!tu_count(numCoeff) || x265hip_call_quant(coef, quantCoeff, deltaU, qCoef, qBits, add, numCoeff, &ns))
+        return g_c.quant(coef, quantCoeff, deltaU, qCoef, qBits, add, numCoeff);
+    return ns;
+}
+static uint32_t nquant_hip(const int16_t* coef, const int32_t* quantCoeff, int16_t* qCoef, int qBits, int add, int numCoeff)
+{
+    uint32_t ns;
+    if (!tu_count(numCoeff) || x265hip_call_nquant(coef, quantCoeff, qCoef, qBits, add, numCoeff, &ns))
+        return g_c.nquant(coef, quantCoeff, qCoef, qBits, add, numCoeff);
+    return ns;
+}
+static void dequant_normal_hip(const int16_t* q, int16_t* coef, int num, int scale, int shift)
+{
+    if ((num & 3) || x265hip_call_dequant_normal(q, coef, num, scale, shift)) g_c.dequant_normal(q, coef, num, scale, shift);
+}
+static void dequant_scaling_hip(const int16_t* q, const int32_t* dq, int16_t* coef, int num, int per, int shift)
+{
+    if (!tu_count(num) || x265hip_call_dequant_scaling(q, dq, coef, num, per, shift)) g_c.dequant_scaling(q, dq, coef, num, per, shift);
+}
+
+// ---- interpolation (primitives.h:176-183) -------------------------------------------------------------------------------
+template <int W, int H, int PART> static void hpp_hip(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int c)
+{
+    if (x265hip_call_interp(X265HIP_IF_HPP, 8, D, W, H, s, ss, d, ds, c, 0, 0)) g_c.pu[PART].luma_hpp(s, ss, d, ds, c);
+}
+template <int W, int H, int PART> static void hps_hip(const pixel* s, intptr_t ss, int16_t* d, intptr_t ds, int c, int ext)
+{
+    if (x265hip_call_interp(X265HIP_IF_HPS, 8, D, W, H, s, ss, d, ds, c, 0, ext)) g_c.pu[PART].luma_hps(s, ss, d, ds, c, ext);
+}
+template <int W, int H, int PART> static void vpp_hip(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int c)
+{
+    if (x265hip_call_interp(X265HIP_IF_VPP, 8, D, W, H, s, ss, d, ds, c, 0, 0)) g_c.pu[PART].luma_vpp(s, ss, d, ds, c);
+}
+template <int W, int H, int PART> static void vps_hip(const pixel* s, intptr_t ss, int16_t* d, intptr_t ds, int c)
+{
+    if (x265hip_call_interp(X265HIP_IF_VPS, 8, D, W, H, s, ss, d, ds, c, 0, 0)) g_c.pu[PART].luma_vps(s, ss, d, ds, c);
+}
+template <int W, int H, int PART> static void vsp_hip(const int16_t* s, intptr_t ss, pixel* d, intptr_t ds, int c)
+{
+    if (x265hip_call_interp(X265HIP_IF_VSP, 8, D, W, H, s, ss, d, ds, c, 0, 0)) g_c.pu[PART].luma_vsp(s, ss, d, ds, c);
+}
+template <int W, int H, int PART> static void vss_hip(const int16_t* s, intptr_t ss, int16_t* d, intptr_t ds, int c)
+{
+    if (x265hip_call_interp(X265HIP_IF_VSS, 8, D, W, H, s, ss, d, ds, c, 0, 0)) g_c.pu[PART].luma_vss(s, ss, d, ds, c);
+}
+template <int W, int H, int PART> static void hvpp_hip(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int cx, int cy)
+{
+    if (x265hip_call_interp(X265HIP_IF_HVPP, 8, D, W, H, s, ss, d, ds, cx, cy, 0)) g_c.pu[PART].luma_hvpp(s, ss, d, ds, cx, cy);
+}
+
+#undef D
+
+#define HIP_PU(W, H) do { \
+        const int part = LUMA_ ## W ## x ## H; \
+        p.pu[part].sad = sad_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.pu[part].sad_x3 = sad_x3_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.pu[part].sad_x4 = sad_x4_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.pu[part].satd = satd_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.pu[part].luma_hpp = hpp_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.pu[part].luma_hps = hps_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.pu[part].luma_vpp = vpp_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.pu[part].luma_vps = vps_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.pu[part].luma_vsp = vsp_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.pu[part].luma_vss = vss_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.pu[part].luma_hvpp = hvpp_hip<W, H, LUMA_ ## W ## x ## H>; \
+    } while (0)
+
+#define HIP_CU(N) do { \
+        const int cu = BLOCK_ ## N ## x ## N; \
+        p.cu[cu].sa8d = sa8d_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[cu].psy_cost_pp = psy_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[cu].sse_pp = sse_pp_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[cu].sse_ss = sse_ss_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[cu].ssd_s[NONALIGNED] = ssd_s_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[cu].ssd_s[ALIGNED] = ssd_s_hip<N, BLOCK_ ## N ## x ## N>; \
+    } while (0)
+
+#define HIP_TU(N) do { \
+        p.cu[BLOCK_ ## N ## x ## N].dct = dct_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[BLOCK_ ## N ## x ## N].idct = idct_hip<N, BLOCK_ ## N ## x ## N>; \
+    } while (0)
+
+static void report_calls()
+{
+    fprintf(stderr, "x265hip: %llu primitive calls served by the GPU\n", x265hip_call_count());
+}
+
+void setupInstrinsicPrimitives(EncoderPrimitives&, int) {}
+
+void setupAssemblyPrimitives(EncoderPrimitives& p, int /* cpuMask: CPU ISA bits, meaningless for a GPU path */)
+{
+    const char* env = getenv("X265HIP");
+    if (env && !strcmp(env, "0"))
+        return;
+    if (x265hip_device_count() < 1 || x265hip_init(0))
+        return;                                     // no usable GPU: leave the table alone (C path stays)
+    ensure_c_table();
+    static bool registered = false;
+    if (!registered && getenv("X265HIP_VERBOSE"))
+    {
+        registered = true;
+        atexit(report_calls);
+    }
+
+    HIP_PU(4, 4);   HIP_PU(8, 8);   HIP_PU(16, 16); HIP_PU(32, 32); HIP_PU(64, 64);
+    HIP_PU(8, 4);   HIP_PU(4, 8);   HIP_PU(16, 8);  HIP_PU(8, 16);  HIP_PU(32, 16); HIP_PU(16, 32);
+    HIP_PU(64, 32); HIP_PU(32, 64); HIP_PU(16, 12); HIP_PU(12, 16); HIP_PU(16, 4);  HIP_PU(4, 16);
+    HIP_PU(32, 24); HIP_PU(24, 32); HIP_PU(32, 8);  HIP_PU(8, 32);  HIP_PU(64, 48); HIP_PU(48, 64);
+    HIP_PU(64, 16); HIP_PU(16, 64);
+
+    HIP_CU(4); HIP_CU(8); HIP_CU(16); HIP_CU(32); HIP_CU(64);
+    HIP_TU(4); HIP_TU(8); HIP_TU(16); HIP_TU(32);
+    p.dst4x4 = dst4_hip;
+    p.idst4x4 = idst4_hip;
+    p.quant = quant_hip;
+    p.nquant = nquant_hip;
+    p.dequant_normal = dequant_normal_hip;
+    p.dequant_scaling = dequant_scaling_hip;
+}
+
+} // namespace X265_NS
+
+// cpu-a.asm stand-ins for an ENABLE_ASSEMBLY build without nasm (reference primitives.cpp:288-303 defines these only
+// in the non-assembly configuration)
+extern "C" {
+int PFX(cpu_cpuid_test)(void) { return 0; }
+void PFX(cpu_emms)(void) {}
+void PFX(cpu_cpuid)(uint32_t, uint32_t* eax, uint32_t* ebx, uint32_t* ecx, uint32_t* edx) { *eax = *ebx = *ecx = *edx = 0; }
+void PFX(cpu_xgetbv)(uint32_t, uint32_t* eax, uint32_t* edx) { *eax = *edx = 0; }
+#if X265_ARCH_ARM == 0
+void PFX(cpu_neon_test)(void) {}
+int PFX(cpu_fast_neon_mrc_test)(void) { return 0; }
+#endif
+}

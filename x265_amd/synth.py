@@ -1,0 +1,53 @@
+"""Seeded synthetic video generator (BASELINE.md §3 / SURVEY.md §8d): there are no clips in the tree or on the box."""
+import numpy as np
+
+
+def make_scene(width, height, depth=8, seed=4321, tile=96, vmax=9, sigma=3.0):
+    """BASELINE.md §3 generator: low-pass random texture; the source frame is the reference moved per `tile` x `tile`
+    tile by its own vector in [-vmax, vmax]^2 plus Gaussian noise.  Returns dict(src=, ref=) of (height, width) arrays."""
+    rng = np.random.default_rng(seed)
+    pmax = (1 << depth) - 1
+    pad = vmax + 8
+    H, W = height + 2 * pad, width + 2 * pad
+    base = rng.random((H // 8 + 3, W // 8 + 3))
+    up = np.kron(base, np.ones((8, 8)))[:H + 16, :W + 16]
+    k = np.ones(9) / 9.0
+    up = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 1, up)
+    up = np.apply_along_axis(lambda c: np.convolve(c, k, mode="same"), 0, up)[8:8 + H, 8:8 + W]
+    up = (up - up.min()) / max(up.max() - up.min(), 1e-9)
+    fine = rng.normal(0, 6.0 * pmax / 255.0, (H, W))
+    big = np.clip(up * pmax * 0.8 + pmax * 0.1 + fine, 0, pmax)
+    ref = big[pad:pad + height, pad:pad + width]
+    src = np.empty_like(ref)
+    for y0 in range(0, height, tile):
+        for x0 in range(0, width, tile):
+            dy, dx = int(rng.integers(-vmax, vmax + 1)), int(rng.integers(-vmax, vmax + 1))
+            y1, x1 = min(y0 + tile, height), min(x0 + tile, width)
+            src[y0:y1, x0:x1] = big[pad + y0 + dy:pad + y1 + dy, pad + x0 + dx:pad + x1 + dx]
+    src = src + rng.normal(0, sigma * pmax / 255.0, src.shape)
+    dt = np.uint8 if depth == 8 else np.uint16
+    return {"src": np.clip(np.rint(src), 0, pmax).astype(dt), "ref": np.clip(np.rint(ref), 0, pmax).astype(dt)}
+
+
+def make_clip(path, width, height, frames, seed=4321, tile=96, vmax=9, sigma=3.0):
+    """Write an 8-bit I420 clip: a textured background whose tiles keep moving with their own constant velocity
+    (half rate) + per-frame noise; chroma = 128 + 0.3 * (luma - 128) subsampled."""
+    rng = np.random.default_rng(seed)
+    pad = vmax * frames // 2 + 16
+    big = make_scene(width + 2 * pad, height + 2 * pad, 8, seed, tile, 0, 0.0)["ref"].astype(np.float64)
+    ty, tx = (height + tile - 1) // tile, (width + tile - 1) // tile
+    vel = rng.integers(-vmax, vmax + 1, size=(ty, tx, 2))
+    with open(path, "wb") as f:
+        for t in range(frames):
+            luma = np.empty((height, width))
+            for j in range(ty):
+                for i in range(tx):
+                    dy, dx = (vel[j, i] * t) // 2
+                    y0, x0 = j * tile, i * tile
+                    y1, x1 = min(y0 + tile, height), min(x0 + tile, width)
+                    luma[y0:y1, x0:x1] = big[pad + y0 + dy:pad + y1 + dy, pad + x0 + dx:pad + x1 + dx]
+            luma = np.clip(np.rint(luma + rng.normal(0, sigma, luma.shape)), 0, 255)
+            f.write(luma.astype(np.uint8).tobytes())
+            c = np.clip(np.rint(128 + 0.3 * (luma[::2, ::2] - 128)), 0, 255).astype(np.uint8)
+            f.write(c.tobytes())
+            f.write(c.tobytes())
