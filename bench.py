@@ -112,28 +112,22 @@ def main():
         pool.append(torch.from_numpy(np.ascontiguousarray(np.pad(sc["src"], MARGIN, mode="edge"))).to(dev))
         if i == 0:
             ref0 = torch.from_numpy(np.ascontiguousarray(np.pad(sc["ref"], MARGIN, mode="edge"))).to(dev)
-    refbuf = [ref0, torch.empty_like(ref0)]
+    from x265_amd.exchange import ReferenceRing
+    ring = ReferenceRing(ref0, torch.empty_like(ref0), rank, world)
     pred = torch.zeros_like(ref0)
     recon = [torch.empty_like(ref0), torch.empty_like(ref0)]
     org = lambda t: t.data_ptr() + MARGIN * S + MARGIN            # noqa: E731  (8-bit: 1 byte per pixel)
     fp = FramePass(W, H, depth=DEPTH, qp=QP, merange=MERANGE, method=hp.HEX_SEARCH, subme=SUBME)
 
-    state = {"ref": refbuf[0], "k": 0}
+    state = {"ref": ring.current, "k": 0}
 
     def step():
         k = state["k"]
         src, rec = pool[k % NPOOL], recon[k & 1]
         hp.check(L.x265hip_framepass_run(fp.h, org(src), S, org(state["ref"]), S, org(pred), S, org(rec), S, MARGIN, MARGIN, stream))
-        if world > 1:
-            # reconstructed-reference exchange: my recon is the reference of the next frame, which lives on rank+1
-            nxt, prv = (rank + 1) % world, (rank - 1) % world
-            inbox = refbuf[1] if state["ref"] is refbuf[0] else refbuf[0]
-            ops = [dist.P2POp(dist.isend, rec, nxt), dist.P2POp(dist.irecv, inbox, prv)]
-            for r_ in dist.batch_isend_irecv(ops):
-                r_.wait()
-            state["ref"] = inbox
-        else:
-            state["ref"] = rec
+        # reconstructed-reference exchange: my recon is the reference of the next frame, which lives on rank+1
+        # (RCCL send/recv ring shift; at N = 1 the recon simply becomes the next reference)
+        state["ref"] = ring.exchange(rec)
         state["k"] = k + 1
 
     def fence():
