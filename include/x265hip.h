@@ -159,6 +159,22 @@ int x265hip_motion_estimate_batch(int depth, int w, int h,
                                   const uint16_t* mvcost, int mvcostHalf,
                                   int n, int32_t* outMv, int32_t* outCost, void* stream);
 
+/* All 16 quarter-pel phases of a whole (padded) reference picture, computed once per reference: plane[yFrac*4 + xFrac](x,y)
+ * is exactly what luma_hpp / luma_vpp / luma_hvpp (ipfilter.cpp:79-369) produce for that pixel, plane 0 is the picture.
+ * planesOrigin addresses pixel (0,0) of plane 0; plane p starts planeElems elements later; same stride and margins as the
+ * reference.  Everything except the outermost 4 rows / columns of the padded area is written. */
+int x265hip_build_subpel_planes(int depth, const void* refOrigin, int64_t stride, int picW, int picH, int marginX, int marginY,
+                                void* planesOrigin, int64_t planeElems, void* stream);
+/* x265hip_motion_estimate_batch with the sub-pel candidates read from pre-filtered planes instead of being filtered per
+ * candidate (identical results; subpelPlanes == NULL falls back to filtering).  refPlane and subpelPlanes share strideR. */
+int x265hip_motion_estimate_planes_batch(int depth, int w, int h,
+                                         const void* fencPlane, int64_t strideF, const void* refPlane, int64_t strideR,
+                                         const void* subpelPlanes, int64_t planeElems,
+                                         const int32_t* pu_xy, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp,
+                                         int numCand, const int32_t* mvc, int merange, int searchMethod, int subme,
+                                         const uint16_t* mvcost, int mvcostHalf,
+                                         int n, int32_t* outMv, int32_t* outCost, void* stream);
+
 /* Search::setSearchRange (reference: source/encoder/search.cpp:2724-2770) with CUData::clipMv (cudata.cpp:1915-1928) for n
  * CUs at cu_xy [n][2]: qmvp[i] = mvSrc[srcIdx[i]] (quarter-pel; (0,0) when mvSrc is NULL or srcIdx[i] < 0), then
  * [mvmin, mvmax] = clip(qmvp -/+ merange) >> 2 with the frame-parallel vertical bound refLagPixels (search.cpp:92).

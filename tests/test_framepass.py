@@ -67,3 +67,43 @@ def test_mvcost_table_matches_oracle(fpmod):
         for depth in (8, 10):
             hp.check(hp.lib().x265hip_mvcost_table(qp, depth, t.ctypes.data, 2 * 32768))
             assert np.array_equal(t, po.mvcost_table(qp, depth))
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_subpel_planes_match_reference_filters(fpmod, depth):
+    """x265hip_build_subpel_planes: plane[yF*4+xF] == luma_hpp / luma_vpp / luma_hvpp of the oracle on the whole padded picture."""
+    from backends import Orc
+    from x265_amd import hipprim as hp
+    from x265_amd.hipprim import DevBuf, check
+    w, h, m = 136, 72, 96
+    rng = np.random.default_rng(9 + depth)
+    pic = rng.integers(0, 1 << depth, size=(h + 2 * m, w + 2 * m)).astype(hp.pix_dtype(depth))
+    S = w + 2 * m
+    d = DevBuf(pic)
+    planes = DevBuf.zeros((16, h + 2 * m, S), pic.dtype)
+    org = (m * S + m) * pic.itemsize
+    check(hp.lib().x265hip_build_subpel_planes(depth, d.ptr + org, S, w, h, m, m, planes.ptr + org, (h + 2 * m) * S, None))
+    got = planes.get()
+    o = Orc(depth)
+    lo = 4                                                   # computed region: everything but the outermost 4 rows / columns
+    H, W = h + 2 * m, w + 2 * m
+    bad = []
+    for yf in range(4):
+        for xf in range(4):
+            want = np.zeros((H, W), pic.dtype)
+            for y0 in range(lo, H - lo, 64):
+                for x0 in range(lo, W - lo, 64):
+                    bh, bw = min(64, H - lo - y0), min(64, W - lo - x0)
+                    bw -= bw % 4
+                    if not (xf | yf):
+                        blk = pic[y0:y0 + bh, x0:x0 + bw]
+                    elif not yf:
+                        blk = o.interp("hpp", 0, bw, bh, pic, (y0, x0), xf)
+                    elif not xf:
+                        blk = o.interp("vpp", 0, bw, bh, pic, (y0, x0), yf)
+                    else:
+                        blk = o.interp("hvpp", 0, bw, bh, pic, (y0, x0), xf, yf)
+                    want[y0:y0 + bh, x0:x0 + bw] = blk
+            if not np.array_equal(got[yf * 4 + xf][lo:H - lo, lo:W - lo], want[lo:H - lo, lo:W - lo]):
+                bad.append((xf, yf, int((got[yf * 4 + xf][lo:H - lo, lo:W - lo] != want[lo:H - lo, lo:W - lo]).sum())))
+    assert not bad, bad

@@ -25,6 +25,9 @@ struct x265hip_framepass
     uint16_t* mvcost;              // device, 4*32768+1 entries
     int32_t* quantCoeff[2];        // flat scaling: quantScales[qp % 6] (scalinglist.cpp:129)
     std::vector<int32_t> hCuXY[4], hTuXY[2];
+    void* planes;                  // 16 sub-pel planes of the current reference (device), sized on first run
+    int64_t planeElems, planeStride;
+    int planeMarginX, planeMarginY;
     bool profile;                  // record a HIP event at every stage boundary of run()
     hipEvent_t ev[10];
 };
@@ -98,6 +101,9 @@ int x265hip_framepass_create(int width, int height, int depth, int qp, int meran
     fp->merange = merange; fp->method = searchMethod; fp->subme = subme;
     fp->cuOffStrideS = fp->cuOffStrideP = fp->tuStrideF = fp->tuStrideP = fp->tuStrideR = -1;
     fp->profile = false;
+    fp->planes = nullptr;
+    fp->planeElems = fp->planeStride = 0;
+    fp->planeMarginX = fp->planeMarginY = 0;
     for (int i = 0; i < 10; i++)
         FP_TRY(check_hip(hipEventCreate(&fp->ev[i]), "hipEventCreate(framepass)"));
     for (int l = 0; l < 4; l++)
@@ -172,6 +178,7 @@ int x265hip_framepass_destroy(x265hip_framepass* fp)
         for (void* p : ptrs) if (p) (void)hipFree(p);
     }
     if (fp->mvcost) (void)hipFree(fp->mvcost);
+    if (fp->planes) (void)hipFree(fp->planes);
     for (int i = 0; i < 10; i++) (void)hipEventDestroy(fp->ev[i]);
     delete fp;
     return X265HIP_OK;
@@ -206,19 +213,36 @@ int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t stride
         }
         fp->tuStrideF = strideS; fp->tuStrideP = strideP; fp->tuStrideR = strideRec;
     }
+    // sub-pel planes of this reference (16 x padded picture, e.g. 43 MB at 1080p 8-bit): allocated once per geometry
+    if (!fp->planes || fp->planeStride != strideR || fp->planeMarginX != marginX || fp->planeMarginY != marginY)
+    {
+        FP_TRY(check_hip(hipStreamSynchronize(as_stream(stream)), "framepass sync"));
+        if (fp->planes) (void)hipFree(fp->planes);
+        fp->planes = nullptr;
+        fp->planeStride = strideR; fp->planeMarginX = marginX; fp->planeMarginY = marginY;
+        fp->planeElems = strideR * (int64_t)(fp->height + 2 * marginY);
+        const size_t B = depth == 8 ? 1 : 2;
+        FP_TRY(check_hip(hipMalloc(&fp->planes, (size_t)fp->planeElems * 16 * B), "hipMalloc(subpel planes)"));
+        FP_TRY(check_hip(hipMemsetAsync(fp->planes, 0, (size_t)fp->planeElems * 16 * B, as_stream(stream)), "hipMemset(subpel planes)"));
+    }
+    const size_t Bp = depth == 8 ? 1 : 2;
+    void* planesOrigin = (char*)fp->planes + ((int64_t)marginY * strideR + marginX) * Bp;
 #define FP_MARK(i) do { if (fp->profile) FP_TRY(check_hip(hipEventRecord(fp->ev[i], as_stream(stream)), "hipEventRecord")); } while (0)
+    // 0. (timed with the first search level) the 16 quarter-pel planes of this reference
+    FP_MARK(0);
+    FP_TRY(x265hip_build_subpel_planes(depth, ref, strideR, fp->width, fp->height, marginX, marginY, planesOrigin, fp->planeElems, stream));
     // 1. top-down motion search
     for (int l = 0; l < 4; l++)
     {
         const int n = fp->nLevel[l], sz = kCuSize[l];
-        FP_MARK(l);
+        if (l) FP_MARK(l);
         if (!n) continue;
         FP_TRY(x265hip_set_search_range_batch(fp->width, fp->height, 64, fp->merange, fp->height /* -F1: m_refLagPixels = sourceHeight */,
                                               fp->puXY[l], l ? fp->mv[l - 1] : nullptr, l ? fp->parent[l] : nullptr, n,
                                               fp->qmvp[l], fp->mvmin[l], fp->mvmax[l], stream));
-        FP_TRY(x265hip_motion_estimate_batch(depth, sz, sz, src, strideS, ref, strideR, fp->puXY[l], fp->mvmin[l], fp->mvmax[l], fp->qmvp[l],
-                                             0, nullptr, fp->merange, fp->method, fp->subme, fp->mvcost + kMvHalf, kMvHalf, n,
-                                             fp->mv[l], fp->cost[l], stream));
+        FP_TRY(x265hip_motion_estimate_planes_batch(depth, sz, sz, src, strideS, ref, strideR, planesOrigin, fp->planeElems, fp->puXY[l],
+                                                    fp->mvmin[l], fp->mvmax[l], fp->qmvp[l], 0, nullptr, fp->merange, fp->method, fp->subme,
+                                                    fp->mvcost + kMvHalf, kMvHalf, n, fp->mv[l], fp->cost[l], stream));
     }
     FP_MARK(4);
     // 2. prediction from the 8x8 vectors

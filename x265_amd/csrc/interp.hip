@@ -199,3 +199,137 @@ extern "C" int x265hip_interp_batch(int kind, int taps, int depth, int w, int h,
     return taps == 8 ? dispatch_interp<uint16_t, 8>(kind, depth, w, h, src, strideS, dst, strideD, offS, offD, coeff, flags, n, st)
                      : dispatch_interp<uint16_t, 4>(kind, depth, w, h, src, strideS, dst, strideD, offS, offD, coeff, flags, n, st);
 }
+
+// ======================================================================================================================
+// Sub-pel planes: all 16 quarter-pel phases of a whole reference picture, computed once per reference
+// ======================================================================================================================
+// MotionEstimate::subpelCompare (motion.cpp:1571-1600) filters a W x H block with luma_hpp / luma_vpp / luma_hvpp for every
+// sub-pel candidate.  Those filters are position-independent per-pixel functions of the reference picture, so a device with
+// 288 GB of HBM computes them ONCE per reference picture: plane[yFrac*4 + xFrac](x, y) = the value the reference's filter
+// produces for that pixel (plane 0 = the picture itself).  16 planes of a padded 1080p picture are 43 MB.  The motion search
+// then reads sub-pel candidates as plain blocks: no filtering in its serial chain at all.
+namespace xh {
+
+template <typename P>
+__global__ __launch_bounds__(256) void subpel_planes_kernel(const P* __restrict__ ref, int64_t stride, P* __restrict__ planes, int64_t planeElems,
+                                                            int x0, int y0, int x1, int y1, int depth)
+{
+    // buffer bounds: the computed region is inset by 4 from the padded buffer on every side (see the launcher)
+    const int xlo = x0 - 4, xhi = x1 + 4, ylo = y0 - 4, yhi = y1 + 4;
+    constexpr int TW = 64, TH = 16, IW = TW + 8, IH = TH + 7;          // IW padded to 72 (71 needed)
+    __shared__ __attribute__((aligned(16))) P in[IH][IW];
+    __shared__ __attribute__((aligned(16))) int16_t im[3][IH][TW];
+    const int tilesX = (x1 - x0 + TW - 1) / TW;
+    const int bx = x0 + (blockIdx.x % tilesX) * TW, by = y0 + (blockIdx.x / tilesX) * TH;
+    const int t = threadIdx.x;
+    const Stage sHpp = stage_for(IF_HPP, depth), sHps = stage_for(IF_HPS, depth), sVpp = stage_for(IF_VPP, depth), sVsp = stage_for(IF_VSP, depth);
+    // ---- stage the input tile: rows by-3 .. by+TH+3, cols bx-3 .. bx+TW+4 (quads of 4; 18 quads per row)
+    for (int i = t; i < IH * (IW / 4); i += 256)
+    {
+        const int r = i / (IW / 4), q = i % (IW / 4);
+        int v[4];
+        // tiles overhang the computed region at the right / bottom: clamp the READ position into the buffer (the clamped
+        // values only feed outputs that are masked out below)
+        const int yy = min(max(by - 3 + r, ylo), yhi - 1), xs = bx - 3 + 4 * q;
+        const P* row = ref + (int64_t)yy * stride;
+        if (xs >= xlo && xs + 3 < xhi)
+            load4(row + xs, v);
+        else
+        {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = (int)row[min(max(xs + e, xlo), xhi - 1)];
+        }
+        store4(&in[r][4 * q], v);
+    }
+    __syncthreads();
+    // ---- phase A: horizontal sums for xFrac = 1..3 on every staged row; hps intermediates to LDS, hpp planes out
+    for (int i = t; i < 3 * IH * (TW / 4); i += 256)
+    {
+        const int xf = 1 + i / (IH * (TW / 4)), rem = i % (IH * (TW / 4)), r = rem / (TW / 4), q = rem % (TW / 4);
+        int v[11], hps[4], hpp[4];
+        load_span<11>(&in[r][4 * q], v);                               // in[][c] holds column bx-3+c
+#pragma unroll
+        for (int o = 0; o < 4; o++)
+        {
+            int sum = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) sum += v[o + k] * kLumaFilter[xf][k];
+            hps[o] = finish(sum, sHps);
+            hpp[o] = finish(sum, sHpp);
+        }
+        store4(&im[xf - 1][r][4 * q], hps);
+        const int y = by + r - 3, x = bx + 4 * q;
+        if (r >= 3 && r < 3 + TH && y < y1 && x < x1)
+            store4(planes + (int64_t)xf * planeElems + (int64_t)y * stride + x, hpp);
+    }
+    __syncthreads();
+    // ---- phase B: plane 0, vertical-only planes and the nine hv planes for one output quad per thread
+    {
+        const int r = t / (TW / 4), q = t % (TW / 4);
+        const int y = by + r, x = bx + 4 * q;
+        if (y < y1 && x < x1)
+        {
+            int px[8][4];
+#pragma unroll
+            for (int k = 0; k < 8; k++) load4(&in[r + k][4 * q + 3], px[k]);      // rows y-3..y+4 at columns x..x+3
+            store4(planes + (int64_t)y * stride + x, px[3]);
+#pragma unroll
+            for (int yf = 1; yf < 4; yf++)
+            {
+                int out[4];
+#pragma unroll
+                for (int o = 0; o < 4; o++)
+                {
+                    int sum = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) sum += px[k][o] * kLumaFilter[yf][k];
+                    out[o] = finish(sum, sVpp);
+                }
+                store4(planes + (int64_t)(yf * 4) * planeElems + (int64_t)y * stride + x, out);
+            }
+#pragma unroll
+            for (int xf = 1; xf < 4; xf++)
+            {
+                int h[8][4];
+#pragma unroll
+                for (int k = 0; k < 8; k++) load4(&im[xf - 1][r + k][4 * q], h[k]);
+#pragma unroll
+                for (int yf = 1; yf < 4; yf++)
+                {
+                    int out[4];
+#pragma unroll
+                    for (int o = 0; o < 4; o++)
+                    {
+                        int sum = 0;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) sum += h[k][o] * kLumaFilter[yf][k];
+                        out[o] = finish(sum, sVsp);
+                    }
+                    store4(planes + (int64_t)(yf * 4 + xf) * planeElems + (int64_t)y * stride + x, out);
+                }
+            }
+        }
+    }
+}
+
+} // namespace xh
+
+extern "C" int x265hip_build_subpel_planes(int depth, const void* refOrigin, int64_t stride, int picW, int picH, int marginX, int marginY,
+                                           void* planesOrigin, int64_t planeElems, void* stream)
+{
+    XH_CHECK_DEV();
+    if (!valid_depth(depth) || picW < 8 || picH < 8 || marginX < 8 || marginY < 8 || (picW & 3) || (marginX & 3))
+        return set_error(X265HIP_EINVAL, "build_subpel_planes: depth %d pic %dx%d margins %d,%d", depth, picW, picH, marginX, marginY);
+    // the 8-tap support needs 3 / 4 pixels around every output: compute everything except the outermost 4 columns / rows
+    const int x0 = -marginX + 4, y0 = -marginY + 4, x1 = picW + marginX - 4, y1 = picH + marginY - 4;
+    const int tilesX = (x1 - x0 + 63) / 64, tilesY = (y1 - y0 + 15) / 16;
+    dim3 grid(tilesX * tilesY), block(256);
+    if (depth == 8)
+        hipLaunchKernelGGL((subpel_planes_kernel<uint8_t>), grid, block, 0, as_stream(stream), (const uint8_t*)refOrigin, stride,
+                           (uint8_t*)planesOrigin, planeElems, x0, y0, x1, y1, depth);
+    else
+        hipLaunchKernelGGL((subpel_planes_kernel<uint16_t>), grid, block, 0, as_stream(stream), (const uint16_t*)refOrigin, stride,
+                           (uint16_t*)planesOrigin, planeElems, x0, y0, x1, y1, depth);
+    XH_LAUNCH_CHECK("subpel_planes_kernel");
+    return X265HIP_OK;
+}

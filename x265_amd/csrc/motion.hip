@@ -20,6 +20,7 @@
 #include "common.h"
 #include "tiles.h"
 #include "filters.h"
+#include <cstdlib>
 
 namespace xh {
 
@@ -547,12 +548,30 @@ __global__ __launch_bounds__(256) void motion_kernel(const P* __restrict__ fencP
 
 using namespace xh;
 
+namespace xh {
+int motion2_dispatch(int depth, int w, int h, const void* fencPlane, int64_t strideF, const void* refPlane, int64_t strideR,
+                     const int32_t* pu_xy, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp, int numCand,
+                     const int32_t* mvc, int merange, int method, int subme, const uint16_t* mvcost, int n, const void* planes,
+                     int64_t planeElems, int32_t* outMv, int32_t* outCost, hipStream_t st, int* rc);
+}
+
 extern "C" int x265hip_motion_estimate_batch(int depth, int w, int h, const void* fencPlane, int64_t strideF,
                                              const void* refPlane, int64_t strideR, const int32_t* pu_xy,
                                              const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp,
                                              int numCand, const int32_t* mvc, int merange, int searchMethod, int subme,
                                              const uint16_t* mvcost, int mvcostHalf, int n, int32_t* outMv,
                                              int32_t* outCost, void* stream)
+{
+    return x265hip_motion_estimate_planes_batch(depth, w, h, fencPlane, strideF, refPlane, strideR, nullptr, 0, pu_xy, mvmin, mvmax, qmvp,
+                                                numCand, mvc, merange, searchMethod, subme, mvcost, mvcostHalf, n, outMv, outCost, stream);
+}
+
+extern "C" int x265hip_motion_estimate_planes_batch(int depth, int w, int h, const void* fencPlane, int64_t strideF,
+                                                    const void* refPlane, int64_t strideR, const void* subpelPlanes, int64_t planeElems,
+                                                    const int32_t* pu_xy, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp,
+                                                    int numCand, const int32_t* mvc, int merange, int searchMethod, int subme,
+                                                    const uint16_t* mvcost, int mvcostHalf, int n, int32_t* outMv,
+                                                    int32_t* outCost, void* stream)
 {
     XH_CHECK_DEV();
     if (!valid_depth(depth) || !valid_block(w, h) || (w & 3) || (h & 3) || (w == 4 && h == 4) || n < 0)
@@ -562,6 +581,12 @@ extern "C" int x265hip_motion_estimate_batch(int depth, int w, int h, const void
     if (subme < 0 || subme > 7 || numCand < 0 || merange < 1 || mvcostHalf < 4 * (merange + 64))
         return set_error(X265HIP_EINVAL, "motion_estimate: subme %d numCand %d merange %d mvcostHalf %d", subme, numCand, merange, mvcostHalf);
     if (!n) return X265HIP_OK;
+    // square 8..64 PUs run on the team kernel of motion2.hip; everything else (and X265HIP_ME_V1=1) on the generic one
+    static const bool forceV1 = getenv("X265HIP_ME_V1") != nullptr;
+    int rc2 = 0;
+    if (!forceV1 && motion2_dispatch(depth, w, h, fencPlane, strideF, refPlane, strideR, pu_xy, mvmin, mvmax, qmvp, numCand, mvc, merange,
+                                     searchMethod, subme, mvcost, n, subpelPlanes, planeElems, outMv, outCost, as_stream(stream), &rc2))
+        return rc2;
     const int B = depth == 8 ? 1 : 2;
     int perWave = 2 * w * h * B + (h + 7) * w * 2;
     perWave = (perWave + 15) & ~15;

@@ -1,0 +1,767 @@
+// motion2.hip — MotionEstimate::motionEstimate, second-generation kernel for the square PU sizes (8, 16, 32, 64).
+//
+// Same reference semantics as motion.hip (source/encoder/motion.cpp:739-1569, subpelCompare :1571) and the same bit-exact
+// outputs; what changes is how a PU's serial decision chain is executed, because that chain — not bandwidth — bounds the
+// kernel:
+//   * compile-time PU shape: every loop over pixels unrolls, all loads of a search step are in flight together;
+//   * a TEAM per PU: one wave for 8x8 / 16x16, four waves (one workgroup) for 32x32 / 64x64, so the small-count levels
+//     still fill the chip; team results meet in LDS with one barrier per step;
+//   * candidate-parallel evaluation everywhere: the 3 / 4 SADs of a sad_x3 / sad_x4 step AND the 4 (or 8) directions of a
+//     half/quarter-pel iteration are computed side by side (lane groups of 16 inside a wave, or one wave per candidate
+//     inside a workgroup); the reference's sequential "if (cost < bcost)" updates are then replayed in reference order —
+//     costs do not depend on bcost, so the result is identical;
+//   * sub-pel candidates are never materialised: each lane filters the 4x4 tiles it needs straight from the reference
+//     picture into registers (luma_hpp / luma_vpp / luma_hvpp arithmetic of ipfilter.cpp:79-369) and feeds the tile
+//     Hadamard; no LDS block, no barrier inside a candidate;
+//   * wave reductions use the DPP row_shr / row_bcast ladder (7 VALU ops) instead of ds_bpermute chains; the MVD cost of
+//     candidate k is fetched by lane k while the pixel loads are in flight;
+//   * the source block sits in registers for the SAD steps (same lane -> same quad for every candidate) and in LDS for the
+//     tile stage; candidate / cost arrays are registers (v1 spilt them: 4-8 MB of scratch writes per launch).
+#include "common.h"
+#include "tiles.h"
+#include "filters.h"
+
+#ifndef ME2_MIN_WAVES
+#define ME2_MIN_WAVES 2
+#endif
+namespace xh {
+
+struct Mv2 { int x, y; };
+
+__device__ __forceinline__ int uni2(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---- DPP reductions ---------------------------------------------------------------------------------------------------
+template <int CTRL, int ROWMASK, int BANKMASK>
+__device__ __forceinline__ int dpp0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, BANKMASK, false); }
+// sum over each row of 16 lanes; lane 15 of every row holds its row's total
+__device__ __forceinline__ int row16_sum(int v)
+{
+    int s = v + dpp0<0x111, 0xf, 0xf>(v) + dpp0<0x112, 0xf, 0xf>(v) + dpp0<0x113, 0xf, 0xf>(v);   // row_shr:1,2,3
+    s += dpp0<0x114, 0xf, 0xe>(s);                                                                   // row_shr:4, lanes 4..15
+    s += dpp0<0x118, 0xf, 0xc>(s);                                                                   // row_shr:8, lanes 8..15
+    return s;
+}
+// sum over aligned groups of 8 lanes; lanes 7 and 15 of every row hold their group's total
+__device__ __forceinline__ int row8_sum(int v)
+{
+    int s = v + dpp0<0x111, 0xf, 0xf>(v) + dpp0<0x112, 0xf, 0xf>(v) + dpp0<0x113, 0xf, 0xf>(v);
+    s += dpp0<0x114, 0xf, 0xa>(s);                                                                   // row_shr:4 into lanes 4..7 and 12..15
+    return s;
+}
+// sum over the wave; valid in lane 63
+__device__ __forceinline__ int wave64_sum_l63(int v)
+{
+    int s = row16_sum(v);
+    s += dpp0<0x142, 0xa, 0xf>(s);                                                                   // row_bcast:15 into rows 1,3
+    s += dpp0<0x143, 0xc, 0xf>(s);                                                                   // row_bcast:31 into rows 2,3
+    return s;
+}
+
+template <typename P> struct Pk;
+template <> struct Pk<uint8_t>
+{
+    typedef uint32_t T;
+    static __device__ __forceinline__ unsigned sad(T a, T b, unsigned acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
+};
+template <> struct Pk<uint16_t>
+{
+    typedef uint2 T;
+    static __device__ __forceinline__ unsigned sad(T a, T b, unsigned acc)
+    {
+        acc = __builtin_amdgcn_sad_u16(a.x, b.x, acc);
+        return __builtin_amdgcn_sad_u16(a.y, b.y, acc);
+    }
+};
+
+// ---- one 4x4 tile of the sub-pel prediction, in registers ----------------------------------------------------------------
+// r: reference picture at the tile's integer-pel origin.  Selects copy / luma_hpp / luma_vpp / luma_hvpp exactly as
+// subpelCompare (motion.cpp:1583-1597) does.
+template <typename P>
+__device__ __forceinline__ void tile_pred(const P* r, int64_t stride, int xFrac, int yFrac, int depth, int out[16])
+{
+    if (!(xFrac | yFrac))
+    {
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+            load4(r + y * stride, &out[4 * y]);
+    }
+    else if (!yFrac)
+    {
+        const Stage st = stage_for(IF_HPP, depth);
+        int c[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) c[i] = kLumaFilter[xFrac][i];
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+        {
+            int v[11];
+            load_span<11>(r + y * stride - 3, v);
+#pragma unroll
+            for (int o = 0; o < 4; o++)
+            {
+                int sum = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) sum += v[o + i] * c[i];
+                out[4 * y + o] = finish(sum, st);
+            }
+        }
+    }
+    else if (!xFrac)
+    {
+        const Stage st = stage_for(IF_VPP, depth);
+        int c[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) c[i] = kLumaFilter[yFrac][i];
+        int sum[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) sum[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 11; i++)
+        {
+            int v[4];
+            load4(r + (int64_t)(i - 3) * stride, v);
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+                if (i - y >= 0 && i - y < 8)
+                {
+#pragma unroll
+                    for (int o = 0; o < 4; o++) sum[4 * y + o] += v[o] * c[i - y];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) out[i] = finish(sum[i], st);
+    }
+    else
+    {
+        const Stage s1 = stage_for(IF_HPS, depth), s2 = stage_for(IF_VSP, depth);
+        int c1[8], c2[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { c1[i] = kLumaFilter[xFrac][i]; c2[i] = kLumaFilter[yFrac][i]; }
+        int sum[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) sum[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 11; i++)
+        {
+            int v[11], t[4];
+            load_span<11>(r + (int64_t)(i - 3) * stride - 3, v);
+#pragma unroll
+            for (int o = 0; o < 4; o++)
+            {
+                int s = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) s += v[o + k] * c1[k];
+                t[o] = finish(s, s1);
+            }
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+                if (i - y >= 0 && i - y < 8)
+                {
+#pragma unroll
+                    for (int o = 0; o < 4; o++) sum[4 * y + o] += t[o] * c2[i - y];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) out[i] = finish(sum[i], s2);
+    }
+}
+
+__device__ __forceinline__ Mv2 mv_clip2(Mv2 v, Mv2 lo, Mv2 hi)
+{
+    Mv2 r = { v.x > hi.x ? hi.x : v.x, v.y > hi.y ? hi.y : v.y };
+    r.x = r.x < lo.x ? lo.x : r.x;
+    r.y = r.y < lo.y ? lo.y : r.y;
+    return r;
+}
+__device__ __forceinline__ bool mv_in_range2(Mv2 v, Mv2 lo, Mv2 hi) { return v.x >= lo.x && v.x <= hi.x && v.y >= lo.y && v.y <= hi.y; }
+__device__ __forceinline__ int sext2b(int v) { return (v & 2) ? (v | ~3) : v; }
+
+__device__ __constant__ const int8_t kHexB[8][2] = { {-1,-2}, {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2}, {-2,0} };   // motion.cpp:63
+__device__ __constant__ const uint8_t kMod6m1B[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };                                            // motion.cpp:64
+__device__ __constant__ const int8_t kSquareB[9][2] = { {0,0}, {0,-1}, {0,1}, {-1,0}, {1,0}, {-1,-1}, {-1,1}, {1,-1}, {1,1} }; // motion.cpp:65
+__device__ __constant__ const uint8_t kWorkloadB[8][5] = { {1,4,0,4,0}, {1,4,1,4,0}, {1,4,1,4,1}, {2,4,1,4,1}, {2,4,2,4,1}, {1,8,1,8,1}, {2,8,1,8,1}, {2,8,2,8,1} }; // motion.cpp:48-58
+
+// ---- the team context ------------------------------------------------------------------------------------------------------
+template <typename P, int N, int WAVES, bool PLANES>
+struct Team
+{
+    typedef typename Pk<P>::T Q;
+    static constexpr int T = 64 * WAVES;
+    static constexpr int QX = N / 4, QUADS = QX * N;                 // 16, 64, 256, 1024
+    static constexpr int GS = (WAVES > 1 || QUADS >= 64) ? T : QUADS; // threads per integer-SAD candidate
+    static constexpr int NG = T / GS;                                // 4 for 8x8, else 1
+    static constexpr int IPT = QUADS / GS;                           // quads per thread per candidate
+    static constexpr int TX = N / 4, TILES = TX * TX;
+
+    const P* fref;
+    const P* plane0;                // sub-pel planes at the PU origin (plane p at plane0 + p * planeElems), or NULL
+    int64_t planeElems;
+    int64_t stride;
+    const uint16_t* cost;
+    Mv2 qmvp;
+    int depth, tid, lane, wv;
+    P* fencL;                       // LDS copy of the source block, stride N
+    int* part;                      // LDS [2][8][WAVES] team partial sums (WAVES > 1)
+    int phase;                      // alternates the partial buffer
+    Q fq[IPT];                      // this thread's quads of the source block
+
+    __device__ __forceinline__ void team_barrier() const { if (WAVES > 1) __syncthreads(); }
+
+    __device__ __forceinline__ int mvcost_lane(int qx, int qy) const { return (int)(uint16_t)(cost[qx - qmvp.x] + cost[qy - qmvp.y]); }
+    __device__ __forceinline__ int mvcost(int qx, int qy) const { return uni2(mvcost_lane(qx, qy)); }
+
+    // combine K per-wave values (valid in lane 63 of each wave) over the team; every thread gets the K totals
+    template <int K>
+    __device__ __forceinline__ void team_combine(int (&v)[K])
+    {
+        if (WAVES == 1)
+        {
+#pragma unroll
+            for (int k = 0; k < K; k++) v[k] = __builtin_amdgcn_readlane(v[k], 63);
+        }
+        else
+        {
+            int* p = part + phase * 8 * WAVES;
+            phase ^= 1;
+            if (lane == 63)
+            {
+#pragma unroll
+                for (int k = 0; k < K; k++) p[k * WAVES + wv] = v[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < K; k++)
+            {
+                int s = 0;
+#pragma unroll
+                for (int w = 0; w < WAVES; w++) s += p[k * WAVES + w];
+                v[k] = uni2(s);
+            }
+        }
+    }
+
+    // integer-pel SAD + MVD cost of K (<= 4) candidates (sad / sad_x3 / sad_x4 of the reference)
+    template <int K>
+    __device__ __forceinline__ void eval_sad(const Mv2 (&c)[K], int (&costs)[K])
+    {
+        // MVD cost of candidate k is fetched by lane k while the pixel loads fly
+        Mv2 mine = c[0];
+#pragma unroll
+        for (int k = 1; k < K; k++)
+            if (lane == k) mine = c[k];
+        const int mvc = mvcost_lane(mine.x * 4, mine.y * 4);
+        if (NG == 1)
+        {
+            unsigned acc[K];
+#pragma unroll
+            for (int k = 0; k < K; k++)
+            {
+                acc[k] = 0;
+                const P* r = fref + (int64_t)c[k].y * stride + c[k].x;
+#pragma unroll
+                for (int j = 0; j < IPT; j++)
+                {
+                    const int q = tid + j * GS, row = q / QX, c4 = (q % QX) * 4;
+                    acc[k] = Pk<P>::sad(ld_unaligned<Q>(r + (int64_t)row * stride + c4), fq[j], acc[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; k++) costs[k] = wave64_sum_l63((int)acc[k]);
+            team_combine<K>(costs);
+        }
+        else
+        {
+            // 8x8: four lane groups of 16, one candidate each per pass (idle groups redo the last candidate)
+            const int g = lane >> 4, s = lane & 15;
+            const int row = s / QX, c4 = (s % QX) * 4;
+            constexpr int PASSES = (K + 3) / 4;
+            unsigned a[PASSES];
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ps++)
+            {
+                Mv2 m = c[K - 1];
+#pragma unroll
+                for (int k = 4 * ps; k < K - 1 && k < 4 * ps + 4; k++)
+                    if (g == k - 4 * ps) m = c[k];
+                const P* r = fref + (int64_t)m.y * stride + m.x;
+                a[ps] = Pk<P>::sad(ld_unaligned<Q>(r + (int64_t)row * stride + c4), fq[0], 0u);
+            }
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ps++)
+            {
+                const int rs = row16_sum((int)a[ps]);
+#pragma unroll
+                for (int k = 4 * ps; k < K && k < 4 * ps + 4; k++) costs[k] = __builtin_amdgcn_readlane(rs, 16 * (k - 4 * ps) + 15);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) costs[k] += __builtin_amdgcn_readlane(mvc, k);
+    }
+
+    __device__ __forceinline__ int sad_one(int mx, int my)
+    {
+        const Mv2 c[1] = { { mx, my } };
+        int v[1];
+        eval_sad<1>(c, v);
+        return v[0];           // includes mvcost(mx*4, my*4)
+    }
+
+    // partial sub-pel cost of candidate q over tiles s, s+G, ... : sad (cmp 0) or satd (cmp 1) against the source block
+    template <int G>
+    __device__ __forceinline__ int subpel_partial(Mv2 q, int cmp, int s) const
+    {
+        const int xFrac = q.x & 3, yFrac = q.y & 3;
+        const P* r = fref + (int64_t)(q.y >> 2) * stride + (q.x >> 2);
+        int acc = 0;
+#pragma unroll 1
+        for (int t = s; t < TILES; t += G)
+        {
+            const int ty = t / TX, tx = t % TX;
+            int p[16], f[16];
+            if (PLANES)
+            {
+                // pre-filtered phase plane (x265hip_build_subpel_planes): the candidate is a plain block
+                const P* pp = plane0 + (int64_t)(yFrac * 4 + xFrac) * planeElems + (int64_t)((q.y >> 2) + ty * 4) * stride + (q.x >> 2) + tx * 4;
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+                    load4(pp + y * stride, &p[4 * y]);
+            }
+            else
+                tile_pred(r + (int64_t)(ty * 4) * stride + tx * 4, stride, xFrac, yFrac, depth, p);
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+                load4(fencL + (ty * 4 + y) * N + tx * 4, &f[4 * y]);
+            if (cmp)
+            {
+#pragma unroll
+                for (int i = 0; i < 16; i++) f[i] -= p[i];
+                hadamard4x4(f);
+                acc += abs_sum16(f) >> 1;
+            }
+            else
+            {
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc += iabs(f[i] - p[i]);
+            }
+        }
+        return acc;
+    }
+
+    // K (<= 4) sub-pel candidates side by side; costs[k] = subpelCompare + mvcost (only meaningful where ok[k])
+    template <int K>
+    __device__ __forceinline__ void eval_subpel(const Mv2 (&q)[K], const bool (&ok)[K], int cmp, int (&costs)[K])
+    {
+        Mv2 mine = q[0];
+#pragma unroll
+        for (int k = 1; k < K; k++)
+            if (lane == k) mine = q[k];
+        const int mvc = mvcost_lane(mine.x, mine.y);
+        if (WAVES == 1)
+        {
+            if (K == 1)
+            {
+                costs[0] = __builtin_amdgcn_readlane(wave64_sum_l63(subpel_partial<64>(q[0], cmp, lane)), 63);
+            }
+            else
+            {
+                constexpr int G = K > 4 ? 8 : 16;       // lanes per candidate
+                const int g = lane / G, s = lane % G;
+                Mv2 m = q[0];
+                bool live = false;                      // lane groups beyond K stay idle
+#pragma unroll
+                for (int k = 0; k < K; k++)
+                    if (g == k) { m = q[k]; live = ok[k]; }
+                int a = 0;
+                if (live)
+                    a = subpel_partial<G>(m, cmp, s);
+                const int rs = G == 8 ? row8_sum(a) : row16_sum(a);
+#pragma unroll
+                for (int k = 0; k < K; k++) costs[k] = __builtin_amdgcn_readlane(rs, G * k + G - 1);
+            }
+        }
+        else
+        {
+            // one wave per candidate (two rounds when K > WAVES)
+            int* p = part + phase * 8 * WAVES;
+            phase ^= 1;
+#pragma unroll
+            for (int k0 = 0; k0 < K; k0 += WAVES)
+            {
+                Mv2 m = q[0];
+                bool live = false;
+#pragma unroll
+                for (int k = k0; k < K && k < k0 + WAVES; k++)
+                    if (wv == k - k0) { m = q[k]; live = ok[k]; }
+                int a = 0;
+                if (live)
+                    a = subpel_partial<64>(m, cmp, lane);
+                a = wave64_sum_l63(a);
+                if (lane == 63) p[k0 + wv] = a;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < K; k++) costs[k] = uni2(p[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) costs[k] += __builtin_amdgcn_readlane(mvc, k);
+    }
+
+    __device__ __forceinline__ int subpel_one(Mv2 q, int cmp)
+    {
+        const Mv2 c[1] = { q };
+        const bool ok[1] = { true };
+        int v[1];
+        eval_subpel<1>(c, ok, cmp, v);
+        return v[0];           // includes mvcost(q)
+    }
+};
+
+template <typename P, int N, int WAVES, bool PLANES>
+__global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __restrict__ fencPlane, int64_t strideF,
+                                                             const P* __restrict__ refPlane, int64_t strideR,
+                                                             const int32_t* __restrict__ pu_xy, const int32_t* __restrict__ mvminA,
+                                                             const int32_t* __restrict__ mvmaxA, const int32_t* __restrict__ qmvpA,
+                                                             int numCand, const int32_t* __restrict__ mvcA, int merange, int method, int subme,
+                                                             const uint16_t* __restrict__ mvcostTab, int depth, int n,
+                                                             const P* __restrict__ planes, int64_t planeElems,
+                                                             int32_t* __restrict__ outMv, int32_t* __restrict__ outCost)
+{
+    typedef Team<P, N, WAVES, PLANES> TM;
+    typedef typename TM::Q Q;
+    constexpr int TPB = (WAVES > 1) ? 1 : 4;                           // teams per workgroup
+    __shared__ __attribute__((aligned(16))) P fencS[TPB][N * N];
+    __shared__ int partS[TPB][2 * 8 * WAVES];
+    const int team = (WAVES > 1) ? 0 : (threadIdx.x >> 6);
+    TM c;
+    c.tid = (WAVES > 1) ? threadIdx.x : (threadIdx.x & 63);
+    c.lane = threadIdx.x & 63;
+    c.wv = (WAVES > 1) ? (threadIdx.x >> 6) : 0;
+    c.depth = depth;
+    c.stride = strideR;
+    c.cost = mvcostTab;
+    c.fencL = fencS[team];
+    c.part = partS[team];
+    c.phase = 0;
+
+    const int teamsTotal = gridDim.x * TPB;
+    for (int pu = blockIdx.x * TPB + team; pu < n; pu += teamsTotal)
+    {
+        const int bx = pu_xy[2 * pu], by = pu_xy[2 * pu + 1];
+        const Mv2 mvmin = { mvminA[2 * pu], mvminA[2 * pu + 1] }, mvmax = { mvmaxA[2 * pu], mvmaxA[2 * pu + 1] };
+        const Mv2 qmvp = { qmvpA[2 * pu], qmvpA[2 * pu + 1] };
+        const Mv2 qmvmin = { mvmin.x * 4, mvmin.y * 4 }, qmvmax = { mvmax.x * 4, mvmax.y * 4 };
+        c.qmvp = qmvp;
+        c.fref = refPlane + (int64_t)by * strideR + bx;
+        c.plane0 = PLANES ? planes + (int64_t)by * strideR + bx : nullptr;
+        c.planeElems = planeElems;
+        // source block: registers (SAD mapping) + LDS (tile stage)
+        c.team_barrier();                                               // previous PU's tile reads are done
+        {
+            const P* f = fencPlane + (int64_t)by * strideF + bx;
+#pragma unroll
+            for (int j = 0; j < TM::IPT; j++)
+            {
+                const int q = (TM::NG == 1 ? c.tid : (c.lane & 15)) + j * TM::GS, row = q / TM::QX, c4 = (q % TM::QX) * 4;
+                c.fq[j] = ld_unaligned<Q>(f + (int64_t)row * strideF + c4);
+                if (TM::NG == 1 || c.lane < 16)
+                    *reinterpret_cast<Q*>(c.fencL + row * N + c4) = c.fq[j];
+            }
+        }
+        if (WAVES > 1)
+            __syncthreads();
+        else
+        {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+
+#define YOK(yy) (((yy) >= mvmin.y) & ((yy) <= mvmax.y))
+#define LT1(v) do { const int v_ = (v); if (v_ < bcost) bcost = v_; } while (0)
+        // ---- predictor, zero and candidates (motion.cpp:761-812)
+        const Mv2 pmv = mv_clip2(qmvp, qmvmin, qmvmax);
+        Mv2 bestpre = pmv;
+        // bprecost = subpelCompare(pmv, sad) WITHOUT mv cost (motion.cpp:771); subpel_one adds mvcost(pmv), take it out again
+        int bprecost = c.subpel_one(pmv, 0) - c.mvcost(pmv.x, pmv.y);
+        Mv2 bmv = { (pmv.x + 2) >> 2, (pmv.y + 2) >> 2 };
+        int bcost = bprecost;
+        if ((pmv.x & 3) | (pmv.y & 3))
+            bcost = c.sad_one(bmv.x, bmv.y);
+        if (pmv.x | pmv.y)
+        {
+            const int cst = c.sad_one(0, 0);
+            if (cst < bcost)
+            {
+                bcost = cst;
+                bmv.x = 0;
+                bmv.y = max(min(0, mvmax.y), mvmin.y);
+            }
+        }
+        for (int i = 0; i < numCand; i++)
+        {
+            const Mv2 raw = { mvcA[((int64_t)pu * numCand + i) * 2], mvcA[((int64_t)pu * numCand + i) * 2 + 1] };
+            const Mv2 m = mv_clip2(raw, qmvmin, qmvmax);
+            if ((m.x | m.y) && !(m.x == pmv.x && m.y == pmv.y) && !(m.x == bestpre.x && m.y == bestpre.y))
+            {
+                const int cst = c.subpel_one(m, 0);
+                if (cst < bprecost)
+                {
+                    bprecost = cst;
+                    bestpre = m;
+                }
+            }
+        }
+
+        if (method == 0)
+        {
+            // X265_DIA_SEARCH, motion.cpp:831-852
+            bcost <<= 4;
+            int i = merange;
+            do
+            {
+                const Mv2 cd[4] = { { bmv.x, bmv.y - 1 }, { bmv.x, bmv.y + 1 }, { bmv.x - 1, bmv.y }, { bmv.x + 1, bmv.y } };
+                int costs[4];
+                c.template eval_sad<4>(cd, costs);
+                if (YOK(bmv.y - 1)) LT1((costs[0] << 4) + 1);
+                if (YOK(bmv.y + 1)) LT1((costs[1] << 4) + 3);
+                LT1((costs[2] << 4) + 4);
+                LT1((costs[3] << 4) + 12);
+                if (!(bcost & 15))
+                    break;
+                bmv.x -= sext2b((bcost >> 2) & 3);
+                bmv.y -= sext2b(bcost & 3);
+                bcost &= ~15;
+            }
+            while (--i && mv_in_range2(bmv, mvmin, mvmax));
+            bcost >>= 4;
+        }
+        else if (method == 1)
+        {
+            // X265_HEX_SEARCH, motion.cpp:855-944
+            {
+                // the two sad_x3 calls of motion.cpp:857-873 are independent: one 6-wide evaluation, replayed in order
+                const Mv2 cd[6] = { { bmv.x - 2, bmv.y }, { bmv.x - 1, bmv.y + 2 }, { bmv.x + 1, bmv.y + 2 },
+                                    { bmv.x + 2, bmv.y }, { bmv.x + 1, bmv.y - 2 }, { bmv.x - 1, bmv.y - 2 } };
+                int cs[6];
+                c.template eval_sad<6>(cd, cs);
+                bcost <<= 3;
+                if (YOK(bmv.y)) LT1((cs[0] << 3) + 2);
+                if (YOK(bmv.y + 2))
+                {
+                    LT1((cs[1] << 3) + 3);
+                    LT1((cs[2] << 3) + 4);
+                }
+                if (YOK(bmv.y)) LT1((cs[3] << 3) + 5);
+                if (YOK(bmv.y - 2))
+                {
+                    LT1((cs[4] << 3) + 6);
+                    LT1((cs[5] << 3) + 7);
+                }
+            }
+            if (bcost & 7)
+            {
+                int dir = (bcost & 7) - 2;
+                if (YOK(bmv.y + kHexB[dir + 1][1]))
+                {
+                    bmv.x += kHexB[dir + 1][0];
+                    bmv.y += kHexB[dir + 1][1];
+                    for (int i = (merange >> 1) - 1; i > 0 && mv_in_range2(bmv, mvmin, mvmax); i--)
+                    {
+                        const Mv2 cd[3] = { { bmv.x + kHexB[dir + 0][0], bmv.y + kHexB[dir + 0][1] },
+                                            { bmv.x + kHexB[dir + 1][0], bmv.y + kHexB[dir + 1][1] },
+                                            { bmv.x + kHexB[dir + 2][0], bmv.y + kHexB[dir + 2][1] } };
+                        int cs[3];
+                        c.template eval_sad<3>(cd, cs);
+                        bcost &= ~7;
+                        if (YOK(cd[0].y)) LT1((cs[0] << 3) + 1);
+                        if (YOK(cd[1].y)) LT1((cs[1] << 3) + 2);
+                        if (YOK(cd[2].y)) LT1((cs[2] << 3) + 3);
+                        if (!(bcost & 7))
+                            break;
+                        dir += (bcost & 7) - 2;
+                        dir = kMod6m1B[dir + 1];
+                        bmv.x += kHexB[dir + 1][0];
+                        bmv.y += kHexB[dir + 1][1];
+                    }
+                }
+            }
+            bcost >>= 3;
+            // square refine, motion.cpp:918-942
+            int dir = 0;
+            {
+                // both sad_x4 calls (motion.cpp:920-937) are centred on the same bmv: one 8-wide evaluation
+                const Mv2 cd[8] = { { bmv.x, bmv.y - 1 }, { bmv.x, bmv.y + 1 }, { bmv.x - 1, bmv.y }, { bmv.x + 1, bmv.y },
+                                    { bmv.x - 1, bmv.y - 1 }, { bmv.x - 1, bmv.y + 1 }, { bmv.x + 1, bmv.y - 1 }, { bmv.x + 1, bmv.y + 1 } };
+                int costs[8];
+                c.template eval_sad<8>(cd, costs);
+                if (YOK(bmv.y - 1) && costs[0] < bcost) { bcost = costs[0]; dir = 1; }
+                if (YOK(bmv.y + 1) && costs[1] < bcost) { bcost = costs[1]; dir = 2; }
+                if (costs[2] < bcost) { bcost = costs[2]; dir = 3; }
+                if (costs[3] < bcost) { bcost = costs[3]; dir = 4; }
+                if (YOK(bmv.y - 1) && costs[4] < bcost) { bcost = costs[4]; dir = 5; }
+                if (YOK(bmv.y + 1) && costs[5] < bcost) { bcost = costs[5]; dir = 6; }
+                if (YOK(bmv.y - 1) && costs[6] < bcost) { bcost = costs[6]; dir = 7; }
+                if (YOK(bmv.y + 1) && costs[7] < bcost) { bcost = costs[7]; dir = 8; }
+            }
+            bmv.x += kSquareB[dir][0];
+            bmv.y += kSquareB[dir][1];
+        }
+        else
+        {
+            // X265_FULL_SEARCH, motion.cpp:1397-1441: raster order, strict '<' keeps the first minimum
+            for (int ty = mvmin.y; ty <= mvmax.y; ty++)
+                for (int tx = mvmin.x; tx <= mvmax.x; tx += 4)
+                {
+                    const int K = min(4, mvmax.x - tx + 1);
+                    const Mv2 cd[4] = { { tx, ty }, { tx + min(1, K - 1), ty }, { tx + min(2, K - 1), ty }, { tx + min(3, K - 1), ty } };
+                    int costs[4];
+                    c.template eval_sad<4>(cd, costs);
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (k < K && costs[k] < bcost)
+                        {
+                            bcost = costs[k];
+                            bmv.x = tx + k;
+                            bmv.y = ty;
+                        }
+                }
+        }
+
+        // motion.cpp:1449-1455
+        if (bprecost < bcost)
+        {
+            bmv = bestpre;
+            bcost = bprecost;
+        }
+        else
+        {
+            bmv.x *= 4;
+            bmv.y *= 4;
+        }
+
+        if (!bcost)
+            bcost = c.mvcost(bmv.x, bmv.y);            // motion.cpp:1466-1471
+        else
+        {
+            // motion.cpp:1504-1561; the directions of one iteration are evaluated together and replayed in order
+            const int hpelIters = kWorkloadB[subme][0], hpelDirs = kWorkloadB[subme][1];
+            const int qpelIters = kWorkloadB[subme][2], qpelDirs = kWorkloadB[subme][3], hpelSatd = kWorkloadB[subme][4];
+            int hpelcomp = 0;
+            bool firstDone = false;
+            if (hpelSatd)
+            {
+                hpelcomp = 1;
+                if (hpelDirs == 4)
+                {
+                    // bcost = satd(bmv) (motion.cpp:1507) and the first half-pel iteration are independent: 5-wide evaluation
+                    Mv2 q[5]; bool ok[5]; int cs[5];
+                    q[0] = bmv; ok[0] = true;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                    {
+                        q[k + 1] = Mv2{ bmv.x + kSquareB[1 + k][0] * 2, bmv.y + kSquareB[1 + k][1] * 2 };
+                        ok[k + 1] = !((q[k + 1].y < qmvmin.y) | (q[k + 1].y > qmvmax.y));
+                    }
+                    c.template eval_subpel<5>(q, ok, 1, cs);
+                    bcost = cs[0];
+                    int bdir = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (ok[k + 1] && cs[k + 1] < bcost) { bcost = cs[k + 1]; bdir = 1 + k; }
+                    if (bdir)
+                    {
+                        bmv.x += kSquareB[bdir][0] * 2;
+                        bmv.y += kSquareB[bdir][1] * 2;
+                    }
+                    firstDone = true;
+                    if (!bdir)
+                        hpelcomp = 3;                   // satd + "first iteration found nothing: stop half-pel iterations"
+                }
+                else
+                    bcost = c.subpel_one(bmv, 1);
+            }
+#define REFINE(ITERS, DIRS, STEP, CMP) \
+            for (int iter = 0; iter < (ITERS); iter++) \
+            { \
+                int bdir = 0; \
+                for (int d0 = 1; d0 <= (DIRS); d0 += 4) \
+                { \
+                    Mv2 q[4]; bool ok[4]; int cs[4]; \
+                    _Pragma("unroll") for (int k = 0; k < 4; k++) \
+                    { \
+                        q[k] = Mv2{ bmv.x + kSquareB[d0 + k][0] * (STEP), bmv.y + kSquareB[d0 + k][1] * (STEP) }; \
+                        ok[k] = !((q[k].y < qmvmin.y) | (q[k].y > qmvmax.y)); \
+                    } \
+                    c.template eval_subpel<4>(q, ok, (CMP), cs); \
+                    _Pragma("unroll") for (int k = 0; k < 4; k++) \
+                        if (ok[k] && cs[k] < bcost) { bcost = cs[k]; bdir = d0 + k; } \
+                } \
+                if (bdir) \
+                { \
+                    bmv.x += kSquareB[bdir][0] * (STEP); \
+                    bmv.y += kSquareB[bdir][1] * (STEP); \
+                } \
+                else \
+                    break; \
+            }
+            {
+                const int itersLeft = (hpelcomp == 3) ? 0 : hpelIters - (firstDone ? 1 : 0);
+                const int cmpH = hpelcomp ? 1 : 0;
+                REFINE(itersLeft, hpelDirs, 2, cmpH)
+            }
+            if (!hpelSatd)
+                bcost = c.subpel_one(bmv, 1);
+            REFINE(qpelIters, qpelDirs, 1, 1)
+#undef REFINE
+        }
+#undef YOK
+#undef LT1
+        if (threadIdx.x == ((WAVES > 1) ? 0 : (team << 6)))
+        {
+            outMv[2 * pu] = bmv.x;
+            outMv[2 * pu + 1] = bmv.y;
+            outCost[pu] = bcost;
+        }
+    }
+}
+
+template <typename P, int N, int WAVES>
+static int launch_motion2(const void* fencPlane, int64_t strideF, const void* refPlane, int64_t strideR, const int32_t* pu_xy,
+                          const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp, int numCand, const int32_t* mvc,
+                          int merange, int method, int subme, const uint16_t* mvcost, int depth, int n, const void* planes,
+                          int64_t planeElems, int32_t* outMv, int32_t* outCost, hipStream_t st)
+{
+    constexpr int TPB = (WAVES > 1) ? 1 : 4;
+    dim3 grid(grid_for((n + TPB - 1) / TPB, 256 * 32)), block(64 * (WAVES > 1 ? WAVES : 4));
+    if (planes)
+        hipLaunchKernelGGL((motion2_kernel<P, N, WAVES, true>), grid, block, 0, st, (const P*)fencPlane, strideF, (const P*)refPlane, strideR, pu_xy,
+                           mvmin, mvmax, qmvp, numCand, mvc, merange, method, subme, mvcost, depth, n, (const P*)planes, planeElems, outMv, outCost);
+    else
+        hipLaunchKernelGGL((motion2_kernel<P, N, WAVES, false>), grid, block, 0, st, (const P*)fencPlane, strideF, (const P*)refPlane, strideR, pu_xy,
+                           mvmin, mvmax, qmvp, numCand, mvc, merange, method, subme, mvcost, depth, n, (const P*)planes, planeElems, outMv, outCost);
+    XH_LAUNCH_CHECK("motion2_kernel");
+    return X265HIP_OK;
+}
+
+// returns 1 when the shape is handled here, 0 when the caller should use the generic kernel of motion.hip
+int motion2_dispatch(int depth, int w, int h, const void* fencPlane, int64_t strideF, const void* refPlane, int64_t strideR,
+                     const int32_t* pu_xy, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp, int numCand,
+                     const int32_t* mvc, int merange, int method, int subme, const uint16_t* mvcost, int n, const void* planes,
+                     int64_t planeElems, int32_t* outMv, int32_t* outCost, hipStream_t st, int* rc)
+{
+    if (w != h || !(w == 8 || w == 16 || w == 32 || w == 64))
+        return 0;
+#define M2(P, N, WV) *rc = launch_motion2<P, N, WV>(fencPlane, strideF, refPlane, strideR, pu_xy, mvmin, mvmax, qmvp, numCand, mvc, merange, \
+                                                    method, subme, mvcost, depth, n, planes, planeElems, outMv, outCost, st)
+    if (depth == 8)
+    {
+        if (w == 8) M2(uint8_t, 8, 1); else if (w == 16) M2(uint8_t, 16, 1); else if (w == 32) M2(uint8_t, 32, 4); else M2(uint8_t, 64, 4);
+    }
+    else
+    {
+        if (w == 8) M2(uint16_t, 8, 1); else if (w == 16) M2(uint16_t, 16, 1); else if (w == 32) M2(uint16_t, 32, 4); else M2(uint16_t, 64, 4);
+    }
+#undef M2
+    return 1;
+}
+
+} // namespace xh

@@ -53,6 +53,9 @@ PROTOTYPES = {
     "x265hip_interp_batch": (i32, [i32, i32, i32, i32, i32, vp, i64, vp, i64, vp, vp, vp, i32, i32, vp]),
     "x265hip_motion_estimate_batch": (i32, [i32, i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, i32, vp, i32, i32, i32,
                                             vp, i32, i32, vp, vp, vp]),
+    "x265hip_build_subpel_planes": (i32, [i32, vp, i64, i32, i32, i32, i32, vp, i64, vp]),
+    "x265hip_motion_estimate_planes_batch": (i32, [i32, i32, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, vp, i32, i32, i32,
+                                                   vp, i32, i32, vp, vp, vp]),
     "x265hip_residual_chain_batch": (i32, [i32, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32,
                                            vp, vp, vp, i32, vp]),
     "x265hip_set_search_range_batch": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
