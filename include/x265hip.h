@@ -124,6 +124,21 @@ int x265hip_dequant_scaling_batch(const int16_t* quantCoef, const int32_t* deQua
 /* count_nonzero_t (primitives.h:163; dct.cpp:714) per TU */
 int x265hip_count_nonzero_batch(const int16_t* qCoef, int numCoeff, int n, uint32_t* out, void* stream);
 
+/* cpy2Dto1D_shl_t / cpy2Dto1D_shr_t / cpy1Dto2D_shl_t / cpy1Dto2D_shr_t (primitives.h:147-150; pixel.cpp:401-467): kind 0..3 in
+ * that order.  The 2-D side is a block at plane + off[i] with row stride `stride`, the 1-D side is dense [i][size*size]. */
+int x265hip_cpy_shift_batch(int kind, int size, int16_t* dst, const int16_t* src, int64_t stride, const int32_t* off, int shift, int n, void* stream);
+/* copy_cnt_t (primitives.h:151; dct.cpp:728): coeff[i] = residual block i (dense), numSig[i] = its non-zero count */
+int x265hip_copy_cnt_batch(int size, int16_t* coeff, const int16_t* resi, int64_t stride, const int32_t* off, int n, uint32_t* numSig, void* stream);
+/* blockfill_s_t (primitives.h:141; pixel.cpp:393): block i at dst + off[i] filled with val[i] */
+int x265hip_blockfill_s_batch(int size, int16_t* dst, int64_t stride, const int32_t* off, const int16_t* val, int n, void* stream);
+/* denoiseDct_t (primitives.h:155; dct.cpp:743): in place on dctCoef [n][numCoeff]; resSum / offset [numCoeff] are shared */
+int x265hip_denoise_dct_batch(int16_t* dctCoef, uint32_t* resSum, const uint16_t* offset, int numCoeff, int n, void* stream);
+/* nonPsyRdoQuant_t / psyRdoQuant_t / psyRdoQuant_t1 / psyRdoQuant_t2 (primitives.h:229-232; dct.cpp:985-1069): kind 0..3.  Job i is
+ * the 4x4 coefficient group at blkPos[i] of TU tu[i] (resiDct / fencDct / costUncoded are dense [numTU][size*size]); cgUncoded[i]
+ * and cgRd[i] are what the reference adds to *totalUncodedCost and *totalRdCost for that group. */
+int x265hip_rdoq_cost_batch(int kind, int size, int depth, const int16_t* resiDct, const int16_t* fencDct, const int64_t* psyScale,
+                            const int32_t* tu, const int32_t* blkPos, int n, int64_t* costUncoded, int64_t* cgUncoded, int64_t* cgRd, void* stream);
+
 /* ---------------------------------------------------------------- interpolation ----------------------------- */
 /* filter_pp_t / filter_hps_t / filter_ps_t / filter_sp_t / filter_ss_t / filter_hv_pp_t (primitives.h:176-183;
  * ipfilter.cpp:79-369).  taps = 8 (luma) or 4 (chroma).  One job = one W x H block:

@@ -189,6 +189,49 @@ class Hip:
         check(self.L.x265hip_count_nonzero_batch(da.ptr, size * size, 1, out.ptr, None))
         return int(out.get()[0])
 
+    def cpy2Dto1D_shl(self, size, a, ao, shift):
+        return self._cpy(0, size, a, ao, shift)
+
+    def cpy2Dto1D_shr(self, size, a, ao, shift):
+        return self._cpy(1, size, a, ao, shift)
+
+    def cpy1Dto2D_shl(self, size, a, shift):
+        return self._cpy(2, size, a, None, shift)
+
+    def cpy1Dto2D_shr(self, size, a, shift):
+        return self._cpy(3, size, a, None, shift)
+
+    def _cpy(self, kind, size, a, ao, shift):
+        da = DevBuf(a)
+        if kind < 2:
+            d = DevBuf.zeros((size * size,), np.int16)
+            check(self.L.x265hip_cpy_shift_batch(kind, size, d.ptr, da.ptr, a.shape[1], _ip([_off(a, ao)]), shift, 1, None))
+        else:
+            d = DevBuf.zeros((size, size), np.int16)
+            check(self.L.x265hip_cpy_shift_batch(kind, size, d.ptr, da.ptr, size, _ip([0]), shift, 1, None))
+        return d.get()
+
+    def copy_cnt(self, size, a, ao):
+        da = DevBuf(a)
+        d, ns = DevBuf.zeros((size * size,), np.int16), DevBuf.zeros((1,), np.uint32)
+        check(self.L.x265hip_copy_cnt_batch(size, d.ptr, da.ptr, a.shape[1], _ip([_off(a, ao)]), 1, ns.ptr, None))
+        return d.get(), int(ns.get()[0])
+
+    def denoise_dct(self, coef, ressum, offset):
+        dc, dr, do = DevBuf(coef), DevBuf(ressum), DevBuf(offset)
+        check(self.L.x265hip_denoise_dct_batch(dc.ptr, dr.ptr, do.ptr, coef.size, 1, None))
+        return dc.get(), dr.get()
+
+    def rdoquant(self, kind, size, resi, fenc, psyscale, blkpos):
+        k = {"nonpsy": 0, "psy": 1, "psy1": 2, "psy2": 3}[kind]
+        cu_ = np.full(size * size, 7, np.int64)
+        dr, df, dcu = DevBuf(resi), DevBuf(fenc), DevBuf(cu_)
+        ps = DevBuf(np.array([psyscale], np.int64))
+        a, b = DevBuf.zeros((1,), np.int64), DevBuf.zeros((1,), np.int64)
+        check(self.L.x265hip_rdoq_cost_batch(k, size, self.depth, dr.ptr, df.ptr, ps.ptr, _ip([0]), _ip([blkpos]), 1, dcu.ptr, a.ptr, b.ptr, None))
+        tot = np.array([11 + int(a.get()[0]), 13 + int(b.get()[0])], np.int64)     # the reference adds into running totals
+        return dcu.get(), tot
+
     # ---- interpolation
     def interp(self, kind, chroma, w, h, src, so, idx, idy=0, ext=0):
         taps = 4 if chroma else 8

@@ -107,3 +107,38 @@ def test_subpel_planes_match_reference_filters(fpmod, depth):
             if not np.array_equal(got[yf * 4 + xf][lo:H - lo, lo:W - lo], want[lo:H - lo, lo:W - lo]):
                 bad.append((xf, yf, int((got[yf * 4 + xf][lo:H - lo, lo:W - lo] != want[lo:H - lo, lo:W - lo]).sum())))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("depth,qp", [(8, 30), (10, 32)])
+def test_4k_frame_pass_is_bit_exact(fpmod, depth, qp):
+    """BASELINE.json configs[2]/[3] picture size (3840x2160, 8-bit and Main10): every output against the CPU restatement."""
+    sc = make_scene(3840, 2160, depth=depth, seed=77 + depth, sigma=3.0 * (1 if depth == 8 else 4))
+    fp = fpmod.FramePass(3840, 2160, depth=depth, qp=qp)
+    got = fp.run_host(sc["src"], sc["ref"])
+    want = oracle_frame_pass(sc["src"], sc["ref"], depth=depth, qp=qp)
+    assert same_results(got, want) == []
+
+
+def test_8k_frame_pass_properties(fpmod):
+    """BASELINE.json configs[4] picture size (7680x4320): size-independent properties instead of the (slow) CPU pass:
+    a static scene gives zero vectors, zero levels and recon == reference; a globally shifted scene is found exactly; the
+    recon margins are edge replicas; running twice is deterministic."""
+    w, h, depth = 7680, 4320, 8
+    rng = np.random.default_rng(8)
+    base = make_scene(1920 + 64, 1080 + 64, depth=depth, seed=8, sigma=0.0)["ref"]
+    big = np.tile(base, (5, 5))[: h + 64, : w + 64]
+    ref = np.ascontiguousarray(big[32:32 + h, 32:32 + w])
+    fp = fpmod.FramePass(w, h, depth=depth, qp=28)
+    still = fp.run_host(ref, ref)
+    assert all(not x.any() for x in still["mv"]) and all(not x.any() for x in still["numSig"])
+    m = 96
+    assert np.array_equal(still["recon"][m:-m, m:-m], ref)
+    assert np.array_equal(still["recon"], np.pad(ref, m, mode="edge"))
+    # global shift by (+3, -2) full pels: every interior 16x16 PU must find (12, -8) quarter-pels with zero SAD residual cost
+    src = np.ascontiguousarray(big[32 - 2:32 - 2 + h, 32 + 3:32 + 3 + w])
+    a = fp.run_host(src, ref)
+    b = fp.run_host(src, ref)
+    assert all(np.array_equal(x, y) for x, y in zip(a["mv"], b["mv"])) and np.array_equal(a["recon"], b["recon"])
+    mv16 = a["mv"][2].reshape(h // 16, w // 16, 2)
+    inner = mv16[4:-4, 4:-4].reshape(-1, 2)
+    assert (inner == np.array([12, -8])).all(axis=1).mean() > 0.999

@@ -14,7 +14,7 @@ from cases import gen_cases, me_scene, pix_buf, short_buf
 pytestmark = pytest.mark.gpu
 
 DEPTHS = [8, 10]
-NOT_ON_GPU = {"var", "cpy2Dto1D_shl", "cpy2Dto1D_shr", "cpy1Dto2D_shl", "cpy1Dto2D_shr", "copy_cnt", "denoise_dct", "rdoquant"}
+NOT_ON_GPU = {"var"}     # pixel_var is lookahead / AQ material, not on the §8 path
 
 
 @pytest.fixture(scope="module")
@@ -52,7 +52,7 @@ def test_every_primitive_matches_oracle(hipmod, depth):
         n += 1
         if not same(got, want):
             bad.append(label)
-    assert n > 1500
+    assert n > 2500
     _report(bad, n)
 
 
@@ -350,3 +350,86 @@ def test_motion_estimate_matches_oracle(hipmod, depth, method):
                 if (int(cost[i]), (int(mv[i, 0]), int(mv[i, 1]))) != want:
                     bad.append("me%d %dx%d subme%d got %s want %s" % (method, w, h, subme, (int(cost[i]), tuple(mv[i])), want))
     _report(bad, total)
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_misc_batches(hipmod, depth):
+    """cpy shuffles, copy_cnt, blockfill, denoise and the RDOQ group costs with many jobs per launch."""
+    from x265_amd import hipprim as hp
+    from x265_amd.hipprim import DevBuf, check
+    from oracle import pyoracle as po
+    O = po.oracle()
+    L = hp.lib()
+    rng = np.random.default_rng(600 + depth)
+    bad = []
+    for size in (4, 8, 16, 32):
+        n, S = 211, 700
+        nc = size * size
+        log2n = size.bit_length() - 1
+        plane = short_buf(rng, "rand", (size + 60, S), -2000, 2000)
+        plane *= (rng.integers(0, 3, plane.shape) == 0)
+        ys, xs = rng.integers(0, 60, n), rng.integers(0, S - size, n)
+        dp, doff = DevBuf(plane), _keep(np.asarray(ys * S + xs, np.int32))
+        for kind, fn, shift in ((0, O.orc_cpy2Dto1D_shl, 2), (1, O.orc_cpy2Dto1D_shr, 3)):
+            d = DevBuf.zeros((n, nc), np.int16)
+            check(L.x265hip_cpy_shift_batch(kind, size, d.ptr, dp.ptr, S, doff.ptr, shift, n, None))
+            want = np.zeros((n, nc), np.int16)
+            for i in range(n):
+                fn(po.ptr(want, i, 0), po.ptr(plane, int(ys[i]), int(xs[i])), S, shift, size)
+            if not np.array_equal(d.get(), want):
+                bad.append("cpy2Dto1D kind%d %d" % (kind, size))
+        d, ns = DevBuf.zeros((n, nc), np.int16), DevBuf.zeros((n,), np.uint32)
+        check(L.x265hip_copy_cnt_batch(size, d.ptr, dp.ptr, S, doff.ptr, n, ns.ptr, None))
+        want, wns = np.zeros((n, nc), np.int16), np.zeros(n, np.uint32)
+        for i in range(n):
+            wns[i] = O.orc_copy_cnt(po.ptr(want, i, 0), po.ptr(plane, int(ys[i]), int(xs[i])), S, size)
+        if not (np.array_equal(d.get(), want) and np.array_equal(ns.get(), wns)):
+            bad.append("copy_cnt %d" % size)
+        # scatter back (1D -> 2D) on a disjoint grid, and blockfill
+        gx, gy = (np.arange(n) % 16) * 40, (np.arange(n) // 16) * 36
+        S2 = 16 * 40
+        goff = _keep(np.asarray(gy * S2 + gx, np.int32))
+        for kind, fn, shift in ((2, O.orc_cpy1Dto2D_shl, 1), (3, O.orc_cpy1Dto2D_shr, 2)):
+            out = DevBuf.zeros((int(gy.max()) + 36, S2), np.int16)
+            check(L.x265hip_cpy_shift_batch(kind, size, out.ptr, _keep(want).ptr, S2, goff.ptr, shift, n, None))
+            w2 = np.zeros(out.shape, np.int16)
+            for i in range(n):
+                fn(po.ptr(w2, int(gy[i]), int(gx[i])), po.ptr(want, i, 0), S2, shift, size)
+            if not np.array_equal(out.get(), w2):
+                bad.append("cpy1Dto2D kind%d %d" % (kind, size))
+        vals = rng.integers(-300, 300, n).astype(np.int16)
+        out = DevBuf.zeros((int(gy.max()) + 36, S2), np.int16)
+        check(L.x265hip_blockfill_s_batch(size, out.ptr, S2, goff.ptr, _keep(vals).ptr, n, None))
+        w2 = np.zeros(out.shape, np.int16)
+        for i in range(n):
+            w2[gy[i]:gy[i] + size, gx[i]:gx[i] + size] = vals[i]
+        if not np.array_equal(out.get(), w2):
+            bad.append("blockfill %d" % size)
+        # RDOQ costs: every coefficient group of every TU, psy and non-psy
+        resi = short_buf(rng, "rand", (n, nc), -32768, 32767)
+        fenc = short_buf(rng, "rand", (n, nc), -32768, 32767)
+        cgs = [(t, cy * 4 * size + cx * 4) for t in range(n) for cy in range(size // 4) for cx in range(size // 4)]
+        tu = _keep(np.array([c[0] for c in cgs], np.int32))
+        bp = _keep(np.array([c[1] for c in cgs], np.int32))
+        psy = np.array([int(rng.integers(1, 1 << 20))], np.int64)
+        for kind, name in ((0, "orc_nonpsy_rdoquant"), (1, "orc_psy_rdoquant")):
+            cu = DevBuf.zeros((n, nc), np.int64)
+            a, b = DevBuf.zeros((len(cgs),), np.int64), DevBuf.zeros((len(cgs),), np.int64)
+            check(L.x265hip_rdoq_cost_batch(kind, size, depth, _keep(resi).ptr, _keep(fenc).ptr, _keep(psy).ptr, tu.ptr, bp.ptr, len(cgs),
+                                            cu.ptr, a.ptr, b.ptr, None))
+            wcu = np.zeros((n, nc), np.int64)
+            wa = np.zeros(len(cgs), np.int64)
+            m = min(400, len(cgs))
+            for j, (t, p) in enumerate(cgs[:m]):
+                tot = np.zeros(2, np.int64)
+                if kind == 0:
+                    O.orc_nonpsy_rdoquant(log2n, po.ptr(resi, t, 0), po.ptr(wcu, t, 0), po.vp(tot.ctypes.data), po.vp(tot.ctypes.data + 8), p, depth)
+                else:
+                    O.orc_psy_rdoquant(log2n, po.ptr(resi, t, 0), po.ptr(fenc, t, 0), po.ptr(wcu, t, 0), po.vp(tot.ctypes.data),
+                                       po.vp(tot.ctypes.data + 8), po.ptr(psy), p, depth)
+                wa[j] = tot[0]
+            gcu, ga = cu.get(), a.get()
+            tmax = cgs[m - 1][0]
+            if not (np.array_equal(ga[:m], wa[:m]) and np.array_equal(gcu[:tmax], wcu[:tmax]) and np.array_equal(ga, b.get())):
+                bad.append("rdoq kind%d %d" % (kind, size))
+    _report(bad, 1)

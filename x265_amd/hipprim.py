@@ -50,6 +50,11 @@ PROTOTYPES = {
     "x265hip_dequant_normal": (i32, [vp, vp, i64, i32, i32, vp]),
     "x265hip_dequant_scaling_batch": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "x265hip_count_nonzero_batch": (i32, [vp, i32, i32, vp, vp]),
+    "x265hip_cpy_shift_batch": (i32, [i32, i32, vp, vp, i64, vp, i32, i32, vp]),
+    "x265hip_copy_cnt_batch": (i32, [i32, vp, vp, i64, vp, i32, vp, vp]),
+    "x265hip_blockfill_s_batch": (i32, [i32, vp, i64, vp, vp, i32, vp]),
+    "x265hip_denoise_dct_batch": (i32, [vp, vp, vp, i32, i32, vp]),
+    "x265hip_rdoq_cost_batch": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
     "x265hip_interp_batch": (i32, [i32, i32, i32, i32, i32, vp, i64, vp, i64, vp, vp, vp, i32, i32, vp]),
     "x265hip_motion_estimate_batch": (i32, [i32, i32, i32, vp, i64, vp, i64, vp, vp, vp, vp, i32, vp, i32, i32, i32,
                                             vp, i32, i32, vp, vp, vp]),
