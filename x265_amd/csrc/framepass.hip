@@ -2,6 +2,7 @@
 // stream (include/x265hip.h "frame pass").  Pure host C++ over the C ABI of this same library; also hosts
 // BitCost::setQP (bitcost.cpp:32-60) because the MVD cost table is float host math in the reference too.
 #include "common.h"
+#include "internal.h"
 #include <cmath>
 #include <vector>
 
@@ -237,16 +238,20 @@ int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t stride
         const int n = fp->nLevel[l], sz = kCuSize[l];
         if (l) FP_MARK(l);
         if (!n) continue;
-        FP_TRY(x265hip_set_search_range_batch(fp->width, fp->height, 64, fp->merange, fp->height /* -F1: m_refLagPixels = sourceHeight */,
-                                              fp->puXY[l], l ? fp->mv[l - 1] : nullptr, l ? fp->parent[l] : nullptr, n,
-                                              fp->qmvp[l], fp->mvmin[l], fp->mvmax[l], stream));
-        FP_TRY(x265hip_motion_estimate_planes_batch(depth, sz, sz, src, strideS, ref, strideR, planesOrigin, fp->planeElems, fp->puXY[l],
-                                                    fp->mvmin[l], fp->mvmax[l], fp->qmvp[l], 0, nullptr, fp->merange, fp->method, fp->subme,
-                                                    fp->mvcost + kMvHalf, kMvHalf, n, fp->mv[l], fp->cost[l], stream));
+        // setSearchRange + motionEstimate in one launch (searchrange.h); qmvp / mvmin / mvmax arrays are still produced
+        DeriveRange dr{};
+        dr.enable = 1;
+        dr.mvSrc = l ? fp->mv[l - 1] : nullptr;
+        dr.srcIdx = fp->parent[l];
+        dr.picW = fp->width; dr.picH = fp->height; dr.maxCUSize = 64;
+        dr.refLagPixels = fp->height;                     // -F1: m_refLagPixels = sourceHeight (search.cpp:92)
+        dr.qmvpO = fp->qmvp[l]; dr.mvminO = fp->mvmin[l]; dr.mvmaxO = fp->mvmax[l];
+        FP_TRY(motion_estimate_fused(depth, sz, src, strideS, ref, strideR, planesOrigin, fp->planeElems, fp->puXY[l], dr, fp->merange,
+                                     fp->method, fp->subme, fp->mvcost + kMvHalf, n, fp->mv[l], fp->cost[l], as_stream(stream)));
     }
     FP_MARK(4);
     // 2. prediction from the 8x8 vectors
-    FP_TRY(x265hip_pred_inter_luma_batch(depth, 8, 8, ref, strideR, pred, strideP, fp->puXY[3], fp->mv[3], fp->nLevel[3], stream));
+    FP_TRY(pred_from_planes(depth, 8, planesOrigin, fp->planeElems, strideR, pred, strideP, fp->puXY[3], fp->mv[3], fp->nLevel[3], as_stream(stream)));
     // 3. residual chain
     const int qp = fp->qp;
     static const int invQuantScales[6] = { 40, 45, 51, 57, 64, 72 };                     // scalinglist.cpp:130
@@ -266,10 +271,12 @@ int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t stride
     }
     FP_MARK(7);
     // 4. mode costs
-    for (int l = 0; l < 4; l++)
-        if (fp->nLevel[l])
-            FP_TRY(x265hip_pixcmp_batch(X265HIP_CMP_SA8D, depth, kCuSize[l], kCuSize[l], src, strideS, pred, strideP, fp->cuOff[l], fp->cuOffP[l],
-                                        fp->nLevel[l], fp->sa8d[l], stream));
+    {
+        Sa8dLevel lv[4];
+        for (int l = 0; l < 4; l++)
+            lv[l] = Sa8dLevel{ fp->cuOff[l], fp->cuOffP[l], fp->sa8d[l], fp->nLevel[l], kCuSize[l] };
+        FP_TRY(sa8d_levels(depth, src, strideS, pred, strideP, lv, 4, as_stream(stream)));
+    }
     FP_MARK(8);
     // 5. the reconstructed picture becomes a reference
     FP_TRY(x265hip_extend_border(depth, recon, strideRec, fp->width, fp->height, marginX, marginY, stream));

@@ -1,0 +1,17 @@
+// internal.h — cross-file helpers of libx265hip that are NOT part of the C ABI (used by the frame pass only).
+#pragma once
+#include "common.h"
+#include "searchrange.h"
+
+namespace xh {
+
+// sa8d(src, pred) of up to 4 CU sizes in ONE launch (the frame pass's mode costs; same arithmetic as pixcmp_kernel<SA8D>)
+struct Sa8dLevel { const int32_t* offA; const int32_t* offB; int32_t* out; int n; int size; };
+int sa8d_levels(int depth, const void* planeA, int64_t strideA, const void* planeB, int64_t strideB, const Sa8dLevel* levels, int nLevels,
+                hipStream_t st);
+
+// Predict::predInterLumaPixel for 8x8 PUs reading the pre-filtered quarter-pel planes (a phase-selected block copy)
+int pred_from_planes(int depth, int size, const void* planes, int64_t planeElems, int64_t strideR, void* dst, int64_t strideD,
+                     const int32_t* pu_xy, const int32_t* qmv, int n, hipStream_t st);
+
+} // namespace xh

@@ -9,6 +9,7 @@
 // separable hv filter keeps its 14-bit intermediate in LDS (one wave per block), never in HBM.
 #include "common.h"
 #include "filters.h"
+#include "internal.h"
 
 namespace xh {
 
@@ -333,3 +334,37 @@ extern "C" int x265hip_build_subpel_planes(int depth, const void* refOrigin, int
     XH_LAUNCH_CHECK("subpel_planes_kernel");
     return X265HIP_OK;
 }
+
+// ---- prediction out of the quarter-pel planes: predInterLumaPixel (predict.cpp:245-266) becomes a phase-selected block copy ----
+namespace xh {
+template <typename P>
+__global__ __launch_bounds__(256) void pred_from_planes_kernel(const P* __restrict__ planes, int64_t planeElems, int64_t sR, P* __restrict__ dst, int64_t sD,
+                                                               const int32_t* __restrict__ pu_xy, const int32_t* __restrict__ qmv, int size, int n)
+{
+    const int qx = size >> 2, per = qx * size;
+    const long long total = (long long)n * per;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x)
+    {
+        const int pu = (int)(idx / per), p = (int)(idx - (long long)pu * per), y = p / qx, x = (p - y * qx) * 4;
+        const int bx = pu_xy[2 * pu], by = pu_xy[2 * pu + 1], mx = qmv[2 * pu], my = qmv[2 * pu + 1];
+        const P* s = planes + (int64_t)((my & 3) * 4 + (mx & 3)) * planeElems + (int64_t)(by + (my >> 2) + y) * sR + bx + (mx >> 2) + x;
+        int v[4];
+        load4(s, v);
+        store4(dst + (int64_t)(by + y) * sD + bx + x, v);
+    }
+}
+
+int pred_from_planes(int depth, int size, const void* planes, int64_t planeElems, int64_t strideR, void* dst, int64_t strideD,
+                     const int32_t* pu_xy, const int32_t* qmv, int n, hipStream_t st)
+{
+    if (!n) return X265HIP_OK;
+    const long long total = (long long)n * (size / 4) * size;
+    dim3 grid(grid_for((total + 255) / 256)), block(256);
+    if (depth == 8)
+        hipLaunchKernelGGL((pred_from_planes_kernel<uint8_t>), grid, block, 0, st, (const uint8_t*)planes, planeElems, strideR, (uint8_t*)dst, strideD, pu_xy, qmv, size, n);
+    else
+        hipLaunchKernelGGL((pred_from_planes_kernel<uint16_t>), grid, block, 0, st, (const uint16_t*)planes, planeElems, strideR, (uint16_t*)dst, strideD, pu_xy, qmv, size, n);
+    XH_LAUNCH_CHECK("pred_from_planes_kernel");
+    return X265HIP_OK;
+}
+} // namespace xh

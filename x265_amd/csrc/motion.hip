@@ -20,6 +20,7 @@
 #include "common.h"
 #include "tiles.h"
 #include "filters.h"
+#include "searchrange.h"
 #include <cstdlib>
 
 namespace xh {
@@ -552,7 +553,7 @@ namespace xh {
 int motion2_dispatch(int depth, int w, int h, const void* fencPlane, int64_t strideF, const void* refPlane, int64_t strideR,
                      const int32_t* pu_xy, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp, int numCand,
                      const int32_t* mvc, int merange, int method, int subme, const uint16_t* mvcost, int n, const void* planes,
-                     int64_t planeElems, int32_t* outMv, int32_t* outCost, hipStream_t st, int* rc);
+                     int64_t planeElems, int32_t* outMv, int32_t* outCost, hipStream_t st, int* rc, const DeriveRange* drp = nullptr);
 }
 
 extern "C" int x265hip_motion_estimate_batch(int depth, int w, int h, const void* fencPlane, int64_t strideF,
@@ -625,21 +626,8 @@ __global__ __launch_bounds__(256) void search_range_kernel(int picW, int picH, i
             px = mvSrc[2 * srcIdx[i]];
             py = mvSrc[2 * srcIdx[i] + 1];
         }
-        const int cx = cu_xy[2 * i], cy = cu_xy[2 * i + 1];
-        const int dist = merange << 2;
-        int minx = px - dist, miny = py - dist, maxx = px + dist, maxy = py + dist;
-        const int offset = 8;
-        const int xmax = (picW + offset - cx - 1) << 2, xmin = -((maxCUSize + offset + cx - 1) << 2);
-        const int ymax = (picH + offset - cy - 1) << 2, ymin = -((maxCUSize + offset + cy - 1) << 2);
-        minx = min(xmax, max(xmin, minx)); miny = min(ymax, max(ymin, miny));
-        maxx = min(xmax, max(xmin, maxx)); maxy = min(ymax, max(ymin, maxy));
-        const int maxMvLen = (1 << 15) - 1;
-        minx = max(minx, -maxMvLen); miny = max(miny, -maxMvLen);
-        maxx = min(maxx, maxMvLen); maxy = min(maxy, maxMvLen);
-        minx >>= 2; miny >>= 2; maxx >>= 2; maxy >>= 2;
-        miny = min(miny, refLagPixels);
-        maxy = min(maxy, refLagPixels);
-        maxy = max(maxy, miny);
+        const SearchRange r = search_range(picW, picH, maxCUSize, merange, refLagPixels, cu_xy[2 * i], cu_xy[2 * i + 1], px, py);
+        const int minx = r.minx, miny = r.miny, maxx = r.maxx, maxy = r.maxy;
         qmvp[2 * i] = px; qmvp[2 * i + 1] = py;
         mvminO[2 * i] = minx; mvminO[2 * i + 1] = miny;
         mvmaxO[2 * i] = maxx; mvmaxO[2 * i + 1] = maxy;

@@ -20,6 +20,7 @@
 #include "common.h"
 #include "tiles.h"
 #include "filters.h"
+#include "searchrange.h"
 
 #ifndef ME2_MIN_WAVES
 #define ME2_MIN_WAVES 2
@@ -210,6 +211,14 @@ struct Team
     __device__ __forceinline__ int mvcost_lane(int qx, int qy) const { return (int)(uint16_t)(cost[qx - qmvp.x] + cost[qy - qmvp.y]); }
     __device__ __forceinline__ int mvcost(int qx, int qy) const { return uni2(mvcost_lane(qx, qy)); }
 
+    template <bool QPEL>
+    __device__ __forceinline__ const P* cand_ptr(Mv2 m) const
+    {
+        if (QPEL)
+            return plane0 + (int64_t)((m.y & 3) * 4 + (m.x & 3)) * planeElems + (int64_t)(m.y >> 2) * stride + (m.x >> 2);
+        return fref + (int64_t)m.y * stride + m.x;
+    }
+
     // combine K per-wave values (valid in lane 63 of each wave) over the team; every thread gets the K totals
     template <int K>
     __device__ __forceinline__ void team_combine(int (&v)[K])
@@ -241,7 +250,8 @@ struct Team
     }
 
     // integer-pel SAD + MVD cost of K (<= 4) candidates (sad / sad_x3 / sad_x4 of the reference)
-    template <int K>
+    // QPEL: candidates are quarter-pel vectors read from the pre-filtered planes (SAD of subpelCompare, motion.cpp:1571)
+    template <int K, bool QPEL = false>
     __device__ __forceinline__ void eval_sad(const Mv2 (&c)[K], int (&costs)[K])
     {
         // MVD cost of candidate k is fetched by lane k while the pixel loads fly
@@ -249,7 +259,7 @@ struct Team
 #pragma unroll
         for (int k = 1; k < K; k++)
             if (lane == k) mine = c[k];
-        const int mvc = mvcost_lane(mine.x * 4, mine.y * 4);
+        const int mvc = QPEL ? mvcost_lane(mine.x, mine.y) : mvcost_lane(mine.x * 4, mine.y * 4);
         if (NG == 1)
         {
             unsigned acc[K];
@@ -257,7 +267,7 @@ struct Team
             for (int k = 0; k < K; k++)
             {
                 acc[k] = 0;
-                const P* r = fref + (int64_t)c[k].y * stride + c[k].x;
+                const P* r = cand_ptr<QPEL>(c[k]);
 #pragma unroll
                 for (int j = 0; j < IPT; j++)
                 {
@@ -283,7 +293,7 @@ struct Team
 #pragma unroll
                 for (int k = 4 * ps; k < K - 1 && k < 4 * ps + 4; k++)
                     if (g == k - 4 * ps) m = c[k];
-                const P* r = fref + (int64_t)m.y * stride + m.x;
+                const P* r = cand_ptr<QPEL>(m);
                 a[ps] = Pk<P>::sad(ld_unaligned<Q>(r + (int64_t)row * stride + c4), fq[0], 0u);
             }
 #pragma unroll
@@ -423,7 +433,7 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
                                                              const int32_t* __restrict__ mvmaxA, const int32_t* __restrict__ qmvpA,
                                                              int numCand, const int32_t* __restrict__ mvcA, int merange, int method, int subme,
                                                              const uint16_t* __restrict__ mvcostTab, int depth, int n,
-                                                             const P* __restrict__ planes, int64_t planeElems,
+                                                             const P* __restrict__ planes, int64_t planeElems, DeriveRange dr,
                                                              int32_t* __restrict__ outMv, int32_t* __restrict__ outCost)
 {
     typedef Team<P, N, WAVES, PLANES> TM;
@@ -447,8 +457,29 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
     for (int pu = blockIdx.x * TPB + team; pu < n; pu += teamsTotal)
     {
         const int bx = pu_xy[2 * pu], by = pu_xy[2 * pu + 1];
-        const Mv2 mvmin = { mvminA[2 * pu], mvminA[2 * pu + 1] }, mvmax = { mvmaxA[2 * pu], mvmaxA[2 * pu + 1] };
-        const Mv2 qmvp = { qmvpA[2 * pu], qmvpA[2 * pu + 1] };
+        Mv2 mvmin, mvmax, qmvp;
+        if (dr.enable)
+        {
+            // Search::setSearchRange fused into the launch (searchrange.h); the arrays are still written for the caller
+            qmvp = Mv2{ 0, 0 };
+            if (dr.mvSrc && dr.srcIdx[pu] >= 0)
+                qmvp = Mv2{ dr.mvSrc[2 * dr.srcIdx[pu]], dr.mvSrc[2 * dr.srcIdx[pu] + 1] };
+            const SearchRange sr = search_range(dr.picW, dr.picH, dr.maxCUSize, merange, dr.refLagPixels, bx, by, qmvp.x, qmvp.y);
+            mvmin = Mv2{ sr.minx, sr.miny };
+            mvmax = Mv2{ sr.maxx, sr.maxy };
+            if (threadIdx.x == ((WAVES > 1) ? 0 : (team << 6)))
+            {
+                dr.qmvpO[2 * pu] = qmvp.x; dr.qmvpO[2 * pu + 1] = qmvp.y;
+                dr.mvminO[2 * pu] = mvmin.x; dr.mvminO[2 * pu + 1] = mvmin.y;
+                dr.mvmaxO[2 * pu] = mvmax.x; dr.mvmaxO[2 * pu + 1] = mvmax.y;
+            }
+        }
+        else
+        {
+            mvmin = Mv2{ mvminA[2 * pu], mvminA[2 * pu + 1] };
+            mvmax = Mv2{ mvmaxA[2 * pu], mvmaxA[2 * pu + 1] };
+            qmvp = Mv2{ qmvpA[2 * pu], qmvpA[2 * pu + 1] };
+        }
         const Mv2 qmvmin = { mvmin.x * 4, mvmin.y * 4 }, qmvmax = { mvmax.x * 4, mvmax.y * 4 };
         c.qmvp = qmvp;
         c.fref = refPlane + (int64_t)by * strideR + bx;
@@ -481,19 +512,40 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
         const Mv2 pmv = mv_clip2(qmvp, qmvmin, qmvmax);
         Mv2 bestpre = pmv;
         // bprecost = subpelCompare(pmv, sad) WITHOUT mv cost (motion.cpp:771); subpel_one adds mvcost(pmv), take it out again
-        int bprecost = c.subpel_one(pmv, 0) - c.mvcost(pmv.x, pmv.y);
+        int bprecost, bcost;
         Mv2 bmv = { (pmv.x + 2) >> 2, (pmv.y + 2) >> 2 };
-        int bcost = bprecost;
-        if ((pmv.x & 3) | (pmv.y & 3))
-            bcost = c.sad_one(bmv.x, bmv.y);
-        if (pmv.x | pmv.y)
+        if (PLANES)
         {
-            const int cst = c.sad_one(0, 0);
-            if (cst < bcost)
+            // the three opening measurements (predictor, its full-pel rounding, zero) are independent: one 3-wide step
+            const Mv2 q3[3] = { pmv, { bmv.x * 4, bmv.y * 4 }, { 0, 0 } };
+            int cs[3];
+            c.template eval_sad<3, true>(q3, cs);
+            bprecost = cs[0] - c.mvcost(pmv.x, pmv.y);
+            bcost = bprecost;
+            if ((pmv.x & 3) | (pmv.y & 3))
+                bcost = cs[1];
+            if ((pmv.x | pmv.y) && cs[2] < bcost)
             {
-                bcost = cst;
+                bcost = cs[2];
                 bmv.x = 0;
                 bmv.y = max(min(0, mvmax.y), mvmin.y);
+            }
+        }
+        else
+        {
+            bprecost = c.subpel_one(pmv, 0) - c.mvcost(pmv.x, pmv.y);
+            bcost = bprecost;
+            if ((pmv.x & 3) | (pmv.y & 3))
+                bcost = c.sad_one(bmv.x, bmv.y);
+            if (pmv.x | pmv.y)
+            {
+                const int cst = c.sad_one(0, 0);
+                if (cst < bcost)
+                {
+                    bcost = cst;
+                    bmv.x = 0;
+                    bmv.y = max(min(0, mvmax.y), mvmin.y);
+                }
             }
         }
         for (int i = 0; i < numCand; i++)
@@ -728,16 +780,16 @@ template <typename P, int N, int WAVES>
 static int launch_motion2(const void* fencPlane, int64_t strideF, const void* refPlane, int64_t strideR, const int32_t* pu_xy,
                           const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp, int numCand, const int32_t* mvc,
                           int merange, int method, int subme, const uint16_t* mvcost, int depth, int n, const void* planes,
-                          int64_t planeElems, int32_t* outMv, int32_t* outCost, hipStream_t st)
+                          int64_t planeElems, const DeriveRange& dr, int32_t* outMv, int32_t* outCost, hipStream_t st)
 {
     constexpr int TPB = (WAVES > 1) ? 1 : 4;
     dim3 grid(grid_for((n + TPB - 1) / TPB, 256 * 32)), block(64 * (WAVES > 1 ? WAVES : 4));
     if (planes)
         hipLaunchKernelGGL((motion2_kernel<P, N, WAVES, true>), grid, block, 0, st, (const P*)fencPlane, strideF, (const P*)refPlane, strideR, pu_xy,
-                           mvmin, mvmax, qmvp, numCand, mvc, merange, method, subme, mvcost, depth, n, (const P*)planes, planeElems, outMv, outCost);
+                           mvmin, mvmax, qmvp, numCand, mvc, merange, method, subme, mvcost, depth, n, (const P*)planes, planeElems, dr, outMv, outCost);
     else
         hipLaunchKernelGGL((motion2_kernel<P, N, WAVES, false>), grid, block, 0, st, (const P*)fencPlane, strideF, (const P*)refPlane, strideR, pu_xy,
-                           mvmin, mvmax, qmvp, numCand, mvc, merange, method, subme, mvcost, depth, n, (const P*)planes, planeElems, outMv, outCost);
+                           mvmin, mvmax, qmvp, numCand, mvc, merange, method, subme, mvcost, depth, n, (const P*)planes, planeElems, dr, outMv, outCost);
     XH_LAUNCH_CHECK("motion2_kernel");
     return X265HIP_OK;
 }
@@ -746,12 +798,14 @@ static int launch_motion2(const void* fencPlane, int64_t strideF, const void* re
 int motion2_dispatch(int depth, int w, int h, const void* fencPlane, int64_t strideF, const void* refPlane, int64_t strideR,
                      const int32_t* pu_xy, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp, int numCand,
                      const int32_t* mvc, int merange, int method, int subme, const uint16_t* mvcost, int n, const void* planes,
-                     int64_t planeElems, int32_t* outMv, int32_t* outCost, hipStream_t st, int* rc)
+                     int64_t planeElems, int32_t* outMv, int32_t* outCost, hipStream_t st, int* rc, const DeriveRange* drp = nullptr)
 {
+    DeriveRange dr{};
+    if (drp) dr = *drp;
     if (w != h || !(w == 8 || w == 16 || w == 32 || w == 64))
         return 0;
 #define M2(P, N, WV) *rc = launch_motion2<P, N, WV>(fencPlane, strideF, refPlane, strideR, pu_xy, mvmin, mvmax, qmvp, numCand, mvc, merange, \
-                                                    method, subme, mvcost, depth, n, planes, planeElems, outMv, outCost, st)
+                                                    method, subme, mvcost, depth, n, planes, planeElems, dr, outMv, outCost, st)
     if (depth == 8)
     {
         if (w == 8) M2(uint8_t, 8, 1); else if (w == 16) M2(uint8_t, 16, 1); else if (w == 32) M2(uint8_t, 32, 4); else M2(uint8_t, 64, 4);
@@ -762,6 +816,18 @@ int motion2_dispatch(int depth, int w, int h, const void* fencPlane, int64_t str
     }
 #undef M2
     return 1;
+}
+
+int motion_estimate_fused(int depth, int size, const void* fencPlane, int64_t strideF, const void* refPlane, int64_t strideR,
+                          const void* planes, int64_t planeElems, const int32_t* pu_xy, const DeriveRange& dr, int merange, int method,
+                          int subme, const uint16_t* mvcost, int n, int32_t* outMv, int32_t* outCost, hipStream_t st)
+{
+    int rc = X265HIP_OK;
+    if (!n) return rc;
+    if (!motion2_dispatch(depth, size, size, fencPlane, strideF, refPlane, strideR, pu_xy, dr.mvminO, dr.mvmaxO, dr.qmvpO, 0, nullptr, merange,
+                          method, subme, mvcost, n, planes, planeElems, outMv, outCost, st, &rc, &dr))
+        return set_error(X265HIP_EINVAL, "motion_estimate_fused: PU size %d is not a team-kernel shape", size);
+    return rc;
 }
 
 } // namespace xh

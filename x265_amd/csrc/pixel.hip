@@ -13,6 +13,7 @@
 // quadrant followed by a 2x2 butterfly ACROSS the quad (v_*_dpp quad_perm), no LDS involved.
 #include "common.h"
 #include "tiles.h"
+#include "internal.h"
 
 namespace xh {
 
@@ -477,3 +478,91 @@ extern "C" int x265hip_extend_border(int depth, void* picOrigin, int64_t stride,
     XH_LAUNCH_CHECK("extend_border_kernel");
     return X265HIP_OK;
 }
+
+// ---- sa8d of several CU sizes in one launch (frame pass step 4) -------------------------------------------------------------
+namespace xh {
+struct Sa8dLevels { Sa8dLevel l[4]; int firstBlock[5]; };
+
+template <typename P>
+__global__ __launch_bounds__(256) void sa8d_levels_kernel(const P* __restrict__ A, int64_t sA, const P* __restrict__ B, int64_t sB, Sa8dLevels lv)
+{
+    int li = 0;
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        if ((int)blockIdx.x >= lv.firstBlock[i]) li = i;
+    const Sa8dLevel L = lv.l[li];
+    const int w = L.size;
+    const int lane = threadIdx.x & 63;
+    const int tiles = (w >> 2) * (w >> 2);
+    const int T = tiles >= 64 ? 64 : tiles;                    // 4 (8x8), 16, 64, 64
+    const int bpw = 64 / T, iters = tiles / T, sub = lane & (T - 1);
+    const int wave = ((int)blockIdx.x - lv.firstBlock[li]) * 4 + (threadIdx.x >> 6);
+    const long long job = (long long)wave * bpw + lane / T;
+    const bool jobOk = job < L.n;
+    const long long jc = jobOk ? job : L.n - 1;
+    const P* a = A + L.offA[jc];
+    const P* b = B + L.offB[jc];
+    int acc = 0;
+    for (int it = 0; it < iters; it++)
+    {
+        const int t = sub + it * T;
+        int x, y;
+        const int n16x = w >= 16 ? (w >> 4) : 1;
+        const int b16 = t >> 4, b8 = (t >> 2) & 3, q = t & 3;
+        x = (b16 % n16x) * 16 + (b8 & 1) * 8 + (q & 1) * 4;
+        y = (b16 / n16x) * 16 + (b8 >> 1) * 8 + (q >> 1) * 4;
+        int m[16];
+        tile_diff(a + y * sA + x, sA, b + y * sB + x, sB, m);
+        if (!jobOk)
+        {
+#pragma unroll
+            for (int i = 0; i < 16; i++) m[i] = 0;
+        }
+        hadamard4x4(m);
+        const int raw8 = quad_sa8d_raw(m, lane);
+        if (w >= 16)
+        {
+            const int s16 = group_sum((lane & 3) == 0 ? raw8 : 0, 16);
+            acc += (lane & 15) == 0 ? ((s16 + 2) >> 2) : 0;
+        }
+        else
+            acc += (lane & 3) == 0 ? ((raw8 + 2) >> 2) : 0;
+    }
+    acc = group_sum(acc, T);
+    if (jobOk && sub == 0)
+        L.out[job] = acc;
+}
+
+int sa8d_levels(int depth, const void* planeA, int64_t strideA, const void* planeB, int64_t strideB, const Sa8dLevel* levels, int nLevels,
+                hipStream_t st)
+{
+    Sa8dLevels lv{};
+    int blocks = 0;
+    for (int i = 0; i < 4; i++)
+    {
+        lv.firstBlock[i] = blocks;
+        if (i < nLevels && levels[i].n > 0)
+        {
+            if (levels[i].size != 8 && levels[i].size != 16 && levels[i].size != 32 && levels[i].size != 64)
+                return set_error(X265HIP_EINVAL, "sa8d_levels: size %d", levels[i].size);
+            lv.l[i] = levels[i];
+            const int tiles = (levels[i].size / 4) * (levels[i].size / 4), T = tiles >= 64 ? 64 : tiles;
+            const long long waves = ((long long)levels[i].n + 64 / T - 1) / (64 / T);
+            blocks += (int)((waves + 3) / 4);
+        }
+        else
+            lv.l[i] = Sa8dLevel{ nullptr, nullptr, nullptr, 0, 8 };
+    }
+    lv.firstBlock[4] = blocks;
+    // levels with n == 0 own no blocks; give them an unreachable first block so the level lookup skips them
+    for (int i = 3; i >= 0; i--)
+        if (lv.l[i].n == 0) lv.firstBlock[i] = lv.firstBlock[i + 1];
+    if (!blocks) return X265HIP_OK;
+    if (depth == 8)
+        hipLaunchKernelGGL((sa8d_levels_kernel<uint8_t>), dim3(blocks), dim3(256), 0, st, (const uint8_t*)planeA, strideA, (const uint8_t*)planeB, strideB, lv);
+    else
+        hipLaunchKernelGGL((sa8d_levels_kernel<uint16_t>), dim3(blocks), dim3(256), 0, st, (const uint16_t*)planeA, strideA, (const uint16_t*)planeB, strideB, lv);
+    XH_LAUNCH_CHECK("sa8d_levels_kernel");
+    return X265HIP_OK;
+}
+} // namespace xh
