@@ -255,10 +255,15 @@ struct Team
     __device__ __forceinline__ void eval_sad(const Mv2 (&c)[K], int (&costs)[K])
     {
         // MVD cost of candidate k is fetched by lane k while the pixel loads fly
+        // lane k <- candidate k (a plain compare/select chain on the lane id gets "optimised" into a scratch-memory array)
         Mv2 mine = c[0];
 #pragma unroll
         for (int k = 1; k < K; k++)
-            if (lane == k) mine = c[k];
+        {
+            const int is = lane == k ? -1 : 0;          // arithmetic select: keeps the compiler from building a lane-indexed array
+            mine.x += is & (c[k].x - c[0].x);
+            mine.y += is & (c[k].y - c[0].y);
+        }
         const int mvc = QPEL ? mvcost_lane(mine.x, mine.y) : mvcost_lane(mine.x * 4, mine.y * 4);
         if (NG == 1)
         {
@@ -364,7 +369,11 @@ struct Team
         Mv2 mine = q[0];
 #pragma unroll
         for (int k = 1; k < K; k++)
-            if (lane == k) mine = q[k];
+        {
+            const int is = lane == k ? -1 : 0;          // arithmetic select: keeps the compiler from building a lane-indexed array
+            mine.x += is & (q[k].x - q[0].x);
+            mine.y += is & (q[k].y - q[0].y);
+        }
         const int mvc = mvcost_lane(mine.x, mine.y);
         if (WAVES == 1)
         {
@@ -391,22 +400,25 @@ struct Team
         }
         else
         {
-            // one wave per candidate (two rounds when K > WAVES)
+            // one wave per candidate (two rounds when K > WAVES).  Lane k of `mine` already holds candidate k (see above), so a
+            // wave picks its candidate with v_readlane on its (uniform) wave index — a register array indexed by wv would be
+            // demoted to scratch memory by the compiler.
+            int okmask = 0;
+#pragma unroll
+            for (int k = 0; k < K; k++) okmask |= (ok[k] ? 1 : 0) << k;
             int* p = part + phase * 8 * WAVES;
             phase ^= 1;
 #pragma unroll
             for (int k0 = 0; k0 < K; k0 += WAVES)
             {
-                Mv2 m = q[0];
-                bool live = false;
-#pragma unroll
-                for (int k = k0; k < K && k < k0 + WAVES; k++)
-                    if (wv == k - k0) { m = q[k]; live = ok[k]; }
+                const int sel = k0 + wv;
+                const Mv2 m = { __builtin_amdgcn_readlane(mine.x, sel & 63), __builtin_amdgcn_readlane(mine.y, sel & 63) };
+                const bool live = sel < K && ((okmask >> sel) & 1);
                 int a = 0;
                 if (live)
                     a = subpel_partial<64>(m, cmp, lane);
                 a = wave64_sum_l63(a);
-                if (lane == 63) p[k0 + wv] = a;
+                if (lane == 63 && sel < 8) p[sel] = a;
             }
             __syncthreads();
 #pragma unroll
@@ -453,8 +465,13 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
     c.part = partS[team];
     c.phase = 0;
 
+    // XCD-aware block order: hardware places workgroup b on XCD b % 8 (MI355X_MICROARCH.md), and each XCD has its own 4 MiB L2.
+    // PUs are listed in raster order, so giving XCD x the x-th contiguous eighth of the list keeps every XCD's reads inside one
+    // horizontal stripe of the reference picture / planes instead of spraying the whole 43 MB over all eight L2s.
+    const int chunk = gridDim.x >> 3;                       // the launcher pads the grid to a multiple of 8
+    const int lblock = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     const int teamsTotal = gridDim.x * TPB;
-    for (int pu = blockIdx.x * TPB + team; pu < n; pu += teamsTotal)
+    for (int pu = lblock * TPB + team; pu < n; pu += teamsTotal)
     {
         const int bx = pu_xy[2 * pu], by = pu_xy[2 * pu + 1];
         Mv2 mvmin, mvmax, qmvp;
@@ -783,7 +800,8 @@ static int launch_motion2(const void* fencPlane, int64_t strideF, const void* re
                           int64_t planeElems, const DeriveRange& dr, int32_t* outMv, int32_t* outCost, hipStream_t st)
 {
     constexpr int TPB = (WAVES > 1) ? 1 : 4;
-    dim3 grid(grid_for((n + TPB - 1) / TPB, 256 * 32)), block(64 * (WAVES > 1 ? WAVES : 4));
+    const int blocks = (grid_for((n + TPB - 1) / TPB, 256 * 32) + 7) & ~7;      // multiple of 8 for the XCD-aware order
+    dim3 grid(blocks), block(64 * (WAVES > 1 ? WAVES : 4));
     if (planes)
         hipLaunchKernelGGL((motion2_kernel<P, N, WAVES, true>), grid, block, 0, st, (const P*)fencPlane, strideF, (const P*)refPlane, strideR, pu_xy,
                            mvmin, mvmax, qmvp, numCand, mvc, merange, method, subme, mvcost, depth, n, (const P*)planes, planeElems, dr, outMv, outCost);
