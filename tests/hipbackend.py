@@ -252,15 +252,24 @@ class Hip:
         """table: the u16[4*32768+1] MVD cost row (host side builds it; BitCost::setQP is float host code, bitcost.cpp:32)"""
         self._mvcost[qp] = DevBuf(table)
 
-    def motion_estimate_batch(self, refplane, fencplane, w, h, pu_xy, mvmin, mvmax, qmvp, mvc, merange, method, subme, qp):
+    def motion_estimate_batch(self, refplane, fencplane, w, h, pu_xy, mvmin, mvmax, qmvp, mvc, merange, method, subme, qp, planes_margin=0):
+        """planes_margin > 0: also build the 16 quarter-pel planes (picture origin at (margin, margin)) and search on them."""
         n = len(pu_xy)
         numCand = len(mvc[0]) if n and len(mvc) else 0
         dr, df = DevBuf(refplane), DevBuf(fencplane)
         tab = self._mvcost[qp]
         outmv, outcost = DevBuf.zeros((n, 2), np.int32), DevBuf.zeros((n,), np.int32)
         cand = dev_i32(np.asarray(mvc, np.int32).reshape(-1)) if numCand else None
-        check(self.L.x265hip_motion_estimate_batch(
-            self.depth, w, h, df.ptr, fencplane.shape[1], dr.ptr, refplane.shape[1],
+        planes, pe = None, 0
+        if planes_margin:
+            m = planes_margin
+            H, S = refplane.shape
+            pe = H * S
+            planes = DevBuf.zeros((16, H, S), refplane.dtype)
+            org = (m * S + m) * refplane.itemsize
+            check(self.L.x265hip_build_subpel_planes(self.depth, dr.ptr + org, S, S - 2 * m, H - 2 * m, m, m, planes.ptr + org, pe, None))
+        check(self.L.x265hip_motion_estimate_planes_batch(
+            self.depth, w, h, df.ptr, fencplane.shape[1], dr.ptr, refplane.shape[1], planes.ptr if planes else None, pe,
             _ip(np.asarray(pu_xy, np.int32)), _ip(np.asarray(mvmin, np.int32)),
             _ip(np.asarray(mvmax, np.int32)), _ip(np.asarray(qmvp, np.int32)),
             numCand, cand.ptr if cand else None, merange, method, subme,

@@ -314,9 +314,10 @@ def dev_keep(values):
 
 
 # ---- motion estimation ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("planes", [0, 1], ids=["filter", "planes"])
 @pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("method", [0, 1, 5])
-def test_motion_estimate_matches_oracle(hipmod, depth, method):
+def test_motion_estimate_matches_oracle(hipmod, depth, method, planes):
     o, g = Orc(depth), hipmod.Hip(depth)
     rng = np.random.default_rng(77 + depth + method)
     refp, srcp, m = me_scene(depth, 99 + depth)
@@ -342,13 +343,14 @@ def test_motion_estimate_matches_oracle(hipmod, depth, method):
                     mvmax = (mvmax[0], min(mvmax[1], int(rng.integers(0, 6))))
                 pus.append((bx, by)); mins.append(mvmin); maxs.append(mvmax); mvps.append(qmvp)
                 cands.append([(int(rng.integers(-60, 61)), int(rng.integers(-60, 61))) for _ in range(numCand)])
-            cost, mv = g.motion_estimate_batch(refp, srcp, w, h, pus, mins, maxs, mvps, cands if numCand else [], merange, method, subme, qp)
+            cost, mv = g.motion_estimate_batch(refp, srcp, w, h, pus, mins, maxs, mvps, cands if numCand else [], merange, method, subme, qp,
+                                               planes_margin=m if planes else 0)
             hipmod._release()
             for i in range(npu):
                 want = o.motion_estimate(refp, srcp, pus[i][0], pus[i][1], w, h, mins[i], maxs[i], mvps[i], cands[i], merange, method, subme, qp)
                 total += 1
                 if (int(cost[i]), (int(mv[i, 0]), int(mv[i, 1]))) != want:
-                    bad.append("me%d %dx%d subme%d got %s want %s" % (method, w, h, subme, (int(cost[i]), tuple(mv[i])), want))
+                    bad.append("me%d %dx%d subme%d got %s want %s" % (method, w, h, subme, (int(cost[i]), tuple(int(v) for v in mv[i])), want))
     _report(bad, total)
 
 

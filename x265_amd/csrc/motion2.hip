@@ -21,6 +21,7 @@
 #include "tiles.h"
 #include "filters.h"
 #include "searchrange.h"
+#include <cstdlib>
 
 #ifndef ME2_MIN_WAVES
 #define ME2_MIN_WAVES 2
@@ -812,12 +813,22 @@ static int launch_motion2(const void* fencPlane, int64_t strideF, const void* re
     return X265HIP_OK;
 }
 
+int motion3_dispatch(int depth, int size, const void* fencPlane, int64_t strideF, int64_t strideR, const int32_t* pu_xy,
+                     const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp, int numCand, const int32_t* mvc, int merange,
+                     int method, int subme, const uint16_t* mvcost, int n, const void* planes, int64_t planeElems, const DeriveRange* drp,
+                     int32_t* outMv, int32_t* outCost, hipStream_t st, int* rc);
+
 // returns 1 when the shape is handled here, 0 when the caller should use the generic kernel of motion.hip
 int motion2_dispatch(int depth, int w, int h, const void* fencPlane, int64_t strideF, const void* refPlane, int64_t strideR,
                      const int32_t* pu_xy, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp, int numCand,
                      const int32_t* mvc, int merange, int method, int subme, const uint16_t* mvcost, int n, const void* planes,
                      int64_t planeElems, int32_t* outMv, int32_t* outCost, hipStream_t st, int* rc, const DeriveRange* drp = nullptr)
 {
+    // 8x8 / 16x16 with planes: four PUs per wave (motion3.hip) unless X265HIP_ME_TEAM=1 asks for the wave-per-PU kernel
+    static const bool forceTeam = getenv("X265HIP_ME_TEAM") != nullptr;
+    if (!forceTeam && w == h && motion3_dispatch(depth, w, fencPlane, strideF, strideR, pu_xy, mvmin, mvmax, qmvp, numCand, mvc, merange, method,
+                                                 subme, mvcost, n, planes, planeElems, drp, outMv, outCost, st, rc))
+        return 1;
     DeriveRange dr{};
     if (drp) dr = *drp;
     if (w != h || !(w == 8 || w == 16 || w == 32 || w == 64))

@@ -1,0 +1,431 @@
+// motion3.hip — MotionEstimate::motionEstimate for 8x8 and 16x16 PUs, "row team" kernel: FOUR PUs per wave.
+//
+// Same reference semantics and bit-exact outputs as motion.hip / motion2.hip (source/encoder/motion.cpp:739-1569).
+// For small PUs a whole wave per PU wastes lanes: the team kernel of motion2.hip spends ~1200 VALU instructions per 8x8 PU
+// with 4-20 useful lanes (profiles/r01_v2_pmc_sq.txt).  Here one PU is owned by one DPP ROW of 16 lanes, so a wave64
+// carries four independent searches in SIMT fashion:
+//   * every decision variable (bmv, bcost, dir ...) is an ordinary per-thread value, identical across the 16 lanes of a row;
+//     the four rows of a wave diverge freely (the hardware exec mask handles it);
+//   * a candidate costs each lane one packed quad load per 64 pixels of PU + v_sad_u8, then a 4-step `row_ror` DPP all-reduce
+//     leaves the block sum in all 16 lanes — no readlane, no LDS, no barrier;
+//   * lanes are tile-major (4 consecutive lanes = the 4 rows of one 4x4 tile), so the SATD's vertical Hadamard runs across
+//     DPP quads (tiles.h idea) and its horizontal one in registers;
+//   * every candidate, integer or sub-pel, is a block read from the pre-filtered quarter-pel planes
+//     (x265hip_build_subpel_planes; plane 0 is the picture), so the serial chain contains no filtering.
+#include "common.h"
+#include "searchrange.h"
+
+namespace xh {
+
+struct Mv3 { int x, y; };
+
+template <typename P> struct Pk3;
+template <> struct Pk3<uint8_t>
+{
+    typedef uint32_t T;
+    static __device__ __forceinline__ unsigned sad(T a, T b, unsigned acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
+    static __device__ __forceinline__ void unpack(T a, int v[4]) { v[0] = a & 255; v[1] = (a >> 8) & 255; v[2] = (a >> 16) & 255; v[3] = a >> 24; }
+};
+template <> struct Pk3<uint16_t>
+{
+    typedef uint2 T;
+    static __device__ __forceinline__ unsigned sad(T a, T b, unsigned acc)
+    {
+        acc = __builtin_amdgcn_sad_u16(a.x, b.x, acc);
+        return __builtin_amdgcn_sad_u16(a.y, b.y, acc);
+    }
+    static __device__ __forceinline__ void unpack(T a, int v[4]) { v[0] = a.x & 0xffff; v[1] = a.x >> 16; v[2] = a.y & 0xffff; v[3] = a.y >> 16; }
+};
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_all(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+// sum over the 16 lanes of a DPP row, result in every lane (row_ror:8,4,2,1)
+__device__ __forceinline__ int row_allsum(int v)
+{
+    v += dpp_all<0x128>(v);
+    v += dpp_all<0x124>(v);
+    v += dpp_all<0x122>(v);
+    v += dpp_all<0x121>(v);
+    return v;
+}
+
+__device__ __constant__ const int8_t kHexC[8][2] = { {-1,-2}, {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2}, {-2,0} };   // motion.cpp:63
+__device__ __constant__ const uint8_t kMod6m1C[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };                                            // motion.cpp:64
+__device__ __constant__ const int8_t kSquareC[9][2] = { {0,0}, {0,-1}, {0,1}, {-1,0}, {1,0}, {-1,-1}, {-1,1}, {1,-1}, {1,1} }; // motion.cpp:65
+__device__ __constant__ const uint8_t kWorkloadC[8][5] = { {1,4,0,4,0}, {1,4,1,4,0}, {1,4,1,4,1}, {2,4,1,4,1}, {2,4,2,4,1}, {1,8,1,8,1}, {2,8,1,8,1}, {2,8,2,8,1} }; // motion.cpp:48-58
+
+template <typename P, int N>
+struct RowTeam
+{
+    typedef typename Pk3<P>::T Q;
+    static constexpr int IPT = N * N / 64;             // quads per lane: 1 (8x8), 4 (16x16)
+    static constexpr int TX = N / 4;                   // tiles per row
+    const P* plane0;                                   // phase plane 0 at the PU origin
+    int64_t planeElems;
+    int stride;
+    const uint16_t* cost;
+    Mv3 qmvp;
+    int s;                                             // lane within the row (0..15)
+    int qoff[IPT];                                     // element offset of this lane's quads inside the PU (row * stride + col)
+    Q fq[IPT];
+    int fu[IPT][4];
+
+    __device__ __forceinline__ int mvcost(int qx, int qy) const { return (int)(uint16_t)(cost[qx - qmvp.x] + cost[qy - qmvp.y]); }
+
+    __device__ __forceinline__ const P* cand(Mv3 q) const
+    {
+        return plane0 + (int64_t)((q.y & 3) * 4 + (q.x & 3)) * planeElems + (q.y >> 2) * stride + (q.x >> 2);
+    }
+    // subpelCompare(..., sad) (motion.cpp:1571) / sad() of the block at quarter-pel vector q, WITHOUT mv cost
+    __device__ __forceinline__ int sad_q(Mv3 q) const
+    {
+        const P* r = cand(q);
+        unsigned acc = 0;
+#pragma unroll
+        for (int j = 0; j < IPT; j++)
+            acc = Pk3<P>::sad(ld_unaligned<Q>(r + qoff[j]), fq[j], acc);
+        return row_allsum((int)acc);
+    }
+    // subpelCompare(..., satd): 4x4 Hadamard tiles, rows of a tile in the 4 lanes of a DPP quad
+    __device__ __forceinline__ int satd_q(Mv3 q) const
+    {
+        const P* r = cand(q);
+        const bool hi1 = s & 1, hi2 = s & 2;
+        int acc = 0;
+#pragma unroll
+        for (int j = 0; j < IPT; j++)
+        {
+            int p[4];
+            Pk3<P>::unpack(ld_unaligned<Q>(r + qoff[j]), p);
+            const int d0 = fu[j][0] - p[0], d1 = fu[j][1] - p[1], d2 = fu[j][2] - p[2], d3 = fu[j][3] - p[3];
+            const int s01 = d0 + d1, e01 = d0 - d1, s23 = d2 + d3, e23 = d2 - d3;
+            int m[4] = { s01 + s23, s01 - s23, e01 + e23, e01 - e23 };
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                const int pr = __builtin_amdgcn_mov_dpp(m[i], 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+                m[i] = hi1 ? pr - m[i] : m[i] + pr;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                const int pr = __builtin_amdgcn_mov_dpp(m[i], 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
+                m[i] = hi2 ? pr - m[i] : m[i] + pr;
+            }
+            acc += iabs(m[0]) + iabs(m[1]) + iabs(m[2]) + iabs(m[3]);
+        }
+        // every tile's |H D H^T| sum is even (pixel.hip), so one >> 1 over the block equals the per-tile >> 1 of pixel.cpp:235
+        return row_allsum(acc) >> 1;
+    }
+    __device__ __forceinline__ int cmp_q(Mv3 q, int satd) const { return satd ? satd_q(q) : sad_q(q); }
+};
+
+__device__ __forceinline__ Mv3 mv_clip3(Mv3 v, Mv3 lo, Mv3 hi)
+{
+    Mv3 r = { v.x > hi.x ? hi.x : v.x, v.y > hi.y ? hi.y : v.y };
+    r.x = r.x < lo.x ? lo.x : r.x;
+    r.y = r.y < lo.y ? lo.y : r.y;
+    return r;
+}
+__device__ __forceinline__ bool mv_in3(Mv3 v, Mv3 lo, Mv3 hi) { return v.x >= lo.x && v.x <= hi.x && v.y >= lo.y && v.y <= hi.y; }
+__device__ __forceinline__ int sext2c(int v) { return (v & 2) ? (v | ~3) : v; }
+
+template <typename P, int N>
+__global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fencPlane, int64_t strideF, int64_t strideR,
+                                                      const int32_t* __restrict__ pu_xy, const int32_t* __restrict__ mvminA,
+                                                      const int32_t* __restrict__ mvmaxA, const int32_t* __restrict__ qmvpA,
+                                                      int numCand, const int32_t* __restrict__ mvcA, int merange, int method, int subme,
+                                                      const uint16_t* __restrict__ mvcostTab, int n,
+                                                      const P* __restrict__ planes, int64_t planeElems, DeriveRange dr,
+                                                      int32_t* __restrict__ outMv, int32_t* __restrict__ outCost)
+{
+    typedef RowTeam<P, N> RT;
+    typedef typename RT::Q Q;
+    RT c;
+    c.s = threadIdx.x & 15;
+    c.stride = (int)strideR;
+    c.planeElems = planeElems;
+    c.cost = mvcostTab;
+    // XCD-aware block order (see motion2.hip): XCD x works on the x-th contiguous eighth of the raster-ordered PU list
+    const int chunk = gridDim.x >> 3;
+    const int lblock = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    const int pu = lblock * 16 + (threadIdx.x >> 4);
+    if (pu >= n)
+        return;                                             // whole rows leave together
+
+    const int bx = pu_xy[2 * pu], by = pu_xy[2 * pu + 1];
+    Mv3 mvmin, mvmax, qmvp;
+    if (dr.enable)
+    {
+        qmvp = Mv3{ 0, 0 };
+        if (dr.mvSrc && dr.srcIdx[pu] >= 0)
+            qmvp = Mv3{ dr.mvSrc[2 * dr.srcIdx[pu]], dr.mvSrc[2 * dr.srcIdx[pu] + 1] };
+        const SearchRange sr = search_range(dr.picW, dr.picH, dr.maxCUSize, merange, dr.refLagPixels, bx, by, qmvp.x, qmvp.y);
+        mvmin = Mv3{ sr.minx, sr.miny };
+        mvmax = Mv3{ sr.maxx, sr.maxy };
+        if (c.s == 0)
+        {
+            dr.qmvpO[2 * pu] = qmvp.x; dr.qmvpO[2 * pu + 1] = qmvp.y;
+            dr.mvminO[2 * pu] = mvmin.x; dr.mvminO[2 * pu + 1] = mvmin.y;
+            dr.mvmaxO[2 * pu] = mvmax.x; dr.mvmaxO[2 * pu + 1] = mvmax.y;
+        }
+    }
+    else
+    {
+        mvmin = Mv3{ mvminA[2 * pu], mvminA[2 * pu + 1] };
+        mvmax = Mv3{ mvmaxA[2 * pu], mvmaxA[2 * pu + 1] };
+        qmvp = Mv3{ qmvpA[2 * pu], qmvpA[2 * pu + 1] };
+    }
+    const Mv3 qmvmin = { mvmin.x * 4, mvmin.y * 4 }, qmvmax = { mvmax.x * 4, mvmax.y * 4 };
+    c.qmvp = qmvp;
+    c.plane0 = planes + (int64_t)by * strideR + bx;
+    {
+        const P* f = fencPlane + (int64_t)by * strideF + bx;
+#pragma unroll
+        for (int j = 0; j < RT::IPT; j++)
+        {
+            const int t = j * 4 + (c.s >> 2), r = c.s & 3;              // tile-major: 4 consecutive lanes = the 4 rows of tile t
+            const int row = (t / RT::TX) * 4 + r, col = (t % RT::TX) * 4;
+            c.qoff[j] = row * (int)strideR + col;
+            c.fq[j] = ld_unaligned<Q>(f + (int64_t)row * strideF + col);
+            Pk3<P>::unpack(c.fq[j], c.fu[j]);
+        }
+    }
+
+#define YOK(yy) (((yy) >= mvmin.y) & ((yy) <= mvmax.y))
+#define LT1(v) do { const int v_ = (v); if (v_ < bcost) bcost = v_; } while (0)
+#define FULLPEL(mx, my) (c.sad_q(Mv3{ (mx) * 4, (my) * 4 }) + c.mvcost((mx) * 4, (my) * 4))
+    // ---- predictor, zero and candidates (motion.cpp:761-812)
+    const Mv3 pmv = mv_clip3(qmvp, qmvmin, qmvmax);
+    Mv3 bestpre = pmv;
+    int bprecost = c.sad_q(pmv);
+    Mv3 bmv = { (pmv.x + 2) >> 2, (pmv.y + 2) >> 2 };
+    int bcost = bprecost;
+    if ((pmv.x & 3) | (pmv.y & 3))
+        bcost = FULLPEL(bmv.x, bmv.y);
+    if (pmv.x | pmv.y)
+    {
+        const int cst = FULLPEL(0, 0);
+        if (cst < bcost)
+        {
+            bcost = cst;
+            bmv.x = 0;
+            bmv.y = max(min(0, mvmax.y), mvmin.y);
+        }
+    }
+    for (int i = 0; i < numCand; i++)
+    {
+        const Mv3 raw = { mvcA[((int64_t)pu * numCand + i) * 2], mvcA[((int64_t)pu * numCand + i) * 2 + 1] };
+        const Mv3 m = mv_clip3(raw, qmvmin, qmvmax);
+        if ((m.x | m.y) && !(m.x == pmv.x && m.y == pmv.y) && !(m.x == bestpre.x && m.y == bestpre.y))
+        {
+            const int cst = c.sad_q(m) + c.mvcost(m.x, m.y);
+            if (cst < bprecost)
+            {
+                bprecost = cst;
+                bestpre = m;
+            }
+        }
+    }
+
+    if (method == 0)
+    {
+        // X265_DIA_SEARCH, motion.cpp:831-852
+        bcost <<= 4;
+        int i = merange;
+        do
+        {
+            const int c0 = FULLPEL(bmv.x, bmv.y - 1), c1 = FULLPEL(bmv.x, bmv.y + 1), c2 = FULLPEL(bmv.x - 1, bmv.y), c3 = FULLPEL(bmv.x + 1, bmv.y);
+            if (YOK(bmv.y - 1)) LT1((c0 << 4) + 1);
+            if (YOK(bmv.y + 1)) LT1((c1 << 4) + 3);
+            LT1((c2 << 4) + 4);
+            LT1((c3 << 4) + 12);
+            if (!(bcost & 15))
+                break;
+            bmv.x -= sext2c((bcost >> 2) & 3);
+            bmv.y -= sext2c(bcost & 3);
+            bcost &= ~15;
+        }
+        while (--i && mv_in3(bmv, mvmin, mvmax));
+        bcost >>= 4;
+    }
+    else if (method == 1)
+    {
+        // X265_HEX_SEARCH, motion.cpp:855-944
+        {
+            const int c0 = FULLPEL(bmv.x - 2, bmv.y), c1 = FULLPEL(bmv.x - 1, bmv.y + 2), c2 = FULLPEL(bmv.x + 1, bmv.y + 2);
+            const int c3 = FULLPEL(bmv.x + 2, bmv.y), c4 = FULLPEL(bmv.x + 1, bmv.y - 2), c5 = FULLPEL(bmv.x - 1, bmv.y - 2);
+            bcost <<= 3;
+            if (YOK(bmv.y)) LT1((c0 << 3) + 2);
+            if (YOK(bmv.y + 2))
+            {
+                LT1((c1 << 3) + 3);
+                LT1((c2 << 3) + 4);
+            }
+            if (YOK(bmv.y)) LT1((c3 << 3) + 5);
+            if (YOK(bmv.y - 2))
+            {
+                LT1((c4 << 3) + 6);
+                LT1((c5 << 3) + 7);
+            }
+        }
+        if (bcost & 7)
+        {
+            int dir = (bcost & 7) - 2;
+            if (YOK(bmv.y + kHexC[dir + 1][1]))
+            {
+                bmv.x += kHexC[dir + 1][0];
+                bmv.y += kHexC[dir + 1][1];
+                for (int i = (merange >> 1) - 1; i > 0 && mv_in3(bmv, mvmin, mvmax); i--)
+                {
+                    const Mv3 a = { bmv.x + kHexC[dir + 0][0], bmv.y + kHexC[dir + 0][1] };
+                    const Mv3 b = { bmv.x + kHexC[dir + 1][0], bmv.y + kHexC[dir + 1][1] };
+                    const Mv3 d = { bmv.x + kHexC[dir + 2][0], bmv.y + kHexC[dir + 2][1] };
+                    const int c0 = FULLPEL(a.x, a.y), c1 = FULLPEL(b.x, b.y), c2 = FULLPEL(d.x, d.y);
+                    bcost &= ~7;
+                    if (YOK(a.y)) LT1((c0 << 3) + 1);
+                    if (YOK(b.y)) LT1((c1 << 3) + 2);
+                    if (YOK(d.y)) LT1((c2 << 3) + 3);
+                    if (!(bcost & 7))
+                        break;
+                    dir += (bcost & 7) - 2;
+                    dir = kMod6m1C[dir + 1];
+                    bmv.x += kHexC[dir + 1][0];
+                    bmv.y += kHexC[dir + 1][1];
+                }
+            }
+        }
+        bcost >>= 3;
+        // square refine, motion.cpp:918-942
+        int dir = 0;
+        {
+            const int c0 = FULLPEL(bmv.x, bmv.y - 1), c1 = FULLPEL(bmv.x, bmv.y + 1), c2 = FULLPEL(bmv.x - 1, bmv.y), c3 = FULLPEL(bmv.x + 1, bmv.y);
+            const int c4 = FULLPEL(bmv.x - 1, bmv.y - 1), c5 = FULLPEL(bmv.x - 1, bmv.y + 1), c6 = FULLPEL(bmv.x + 1, bmv.y - 1), c7 = FULLPEL(bmv.x + 1, bmv.y + 1);
+            if (YOK(bmv.y - 1) && c0 < bcost) { bcost = c0; dir = 1; }
+            if (YOK(bmv.y + 1) && c1 < bcost) { bcost = c1; dir = 2; }
+            if (c2 < bcost) { bcost = c2; dir = 3; }
+            if (c3 < bcost) { bcost = c3; dir = 4; }
+            if (YOK(bmv.y - 1) && c4 < bcost) { bcost = c4; dir = 5; }
+            if (YOK(bmv.y + 1) && c5 < bcost) { bcost = c5; dir = 6; }
+            if (YOK(bmv.y - 1) && c6 < bcost) { bcost = c6; dir = 7; }
+            if (YOK(bmv.y + 1) && c7 < bcost) { bcost = c7; dir = 8; }
+        }
+        bmv.x += kSquareC[dir][0];
+        bmv.y += kSquareC[dir][1];
+    }
+    else
+    {
+        // X265_FULL_SEARCH, motion.cpp:1397-1441: raster order, strict '<' keeps the first minimum
+        for (int ty = mvmin.y; ty <= mvmax.y; ty++)
+            for (int tx = mvmin.x; tx <= mvmax.x; tx++)
+            {
+                const int cst = FULLPEL(tx, ty);
+                if (cst < bcost)
+                {
+                    bcost = cst;
+                    bmv.x = tx;
+                    bmv.y = ty;
+                }
+            }
+    }
+
+    // motion.cpp:1449-1455
+    if (bprecost < bcost)
+    {
+        bmv = bestpre;
+        bcost = bprecost;
+    }
+    else
+    {
+        bmv.x *= 4;
+        bmv.y *= 4;
+    }
+
+    if (!bcost)
+        bcost = c.mvcost(bmv.x, bmv.y);                // motion.cpp:1466-1471
+    else
+    {
+        // motion.cpp:1504-1561
+        const int hpelIters = kWorkloadC[subme][0], hpelDirs = kWorkloadC[subme][1];
+        const int qpelIters = kWorkloadC[subme][2], qpelDirs = kWorkloadC[subme][3], hpelSatd = kWorkloadC[subme][4];
+        int hpelcomp = 0;
+        if (hpelSatd)
+        {
+            bcost = c.satd_q(bmv) + c.mvcost(bmv.x, bmv.y);
+            hpelcomp = 1;
+        }
+        for (int iter = 0; iter < hpelIters; iter++)
+        {
+            int bdir = 0;
+            for (int i = 1; i <= hpelDirs; i++)
+            {
+                const Mv3 q = { bmv.x + kSquareC[i][0] * 2, bmv.y + kSquareC[i][1] * 2 };
+                if ((q.y < qmvmin.y) | (q.y > qmvmax.y))
+                    continue;
+                const int cst = c.cmp_q(q, hpelcomp) + c.mvcost(q.x, q.y);
+                if (cst < bcost) { bcost = cst; bdir = i; }
+            }
+            if (bdir)
+            {
+                bmv.x += kSquareC[bdir][0] * 2;
+                bmv.y += kSquareC[bdir][1] * 2;
+            }
+            else
+                break;
+        }
+        if (!hpelSatd)
+            bcost = c.satd_q(bmv) + c.mvcost(bmv.x, bmv.y);
+        for (int iter = 0; iter < qpelIters; iter++)
+        {
+            int bdir = 0;
+            for (int i = 1; i <= qpelDirs; i++)
+            {
+                const Mv3 q = { bmv.x + kSquareC[i][0], bmv.y + kSquareC[i][1] };
+                if ((q.y < qmvmin.y) | (q.y > qmvmax.y))
+                    continue;
+                const int cst = c.satd_q(q) + c.mvcost(q.x, q.y);
+                if (cst < bcost) { bcost = cst; bdir = i; }
+            }
+            if (bdir)
+            {
+                bmv.x += kSquareC[bdir][0];
+                bmv.y += kSquareC[bdir][1];
+            }
+            else
+                break;
+        }
+    }
+#undef YOK
+#undef LT1
+#undef FULLPEL
+    if (c.s == 0)
+    {
+        outMv[2 * pu] = bmv.x;
+        outMv[2 * pu + 1] = bmv.y;
+        outCost[pu] = bcost;
+    }
+}
+
+// returns 1 when handled (8x8 / 16x16 with planes), 0 otherwise
+int motion3_dispatch(int depth, int size, const void* fencPlane, int64_t strideF, int64_t strideR, const int32_t* pu_xy,
+                     const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp, int numCand, const int32_t* mvc, int merange,
+                     int method, int subme, const uint16_t* mvcost, int n, const void* planes, int64_t planeElems, const DeriveRange* drp,
+                     int32_t* outMv, int32_t* outCost, hipStream_t st, int* rc)
+{
+    if (!planes || (size != 8 && size != 16) || strideR > 0x3fffffff)
+        return 0;
+    DeriveRange dr{};
+    if (drp) dr = *drp;
+    const int blocks = (((n + 15) / 16) + 7) & ~7;
+    dim3 grid(blocks), block(256);
+#define M3(P, N) hipLaunchKernelGGL((motion3_kernel<P, N>), grid, block, 0, st, (const P*)fencPlane, strideF, strideR, pu_xy, mvmin, mvmax, qmvp, \
+                                    numCand, mvc, merange, method, subme, mvcost, n, (const P*)planes, planeElems, dr, outMv, outCost)
+    if (depth == 8) { if (size == 8) M3(uint8_t, 8); else M3(uint8_t, 16); }
+    else            { if (size == 8) M3(uint16_t, 8); else M3(uint16_t, 16); }
+#undef M3
+    hipError_t e = hipGetLastError();
+    *rc = e == hipSuccess ? X265HIP_OK : check_hip(e, "motion3_kernel");
+    return 1;
+}
+
+} // namespace xh
