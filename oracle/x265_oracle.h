@@ -75,7 +75,7 @@ void orc_p2s_##SFX(const P* src, intptr_t ss, int16_t* dst, intptr_t ds, int w, 
 /* ---- motion estimation: encoder/motion.cpp:739 MotionEstimate::motionEstimate (non-lowres, no chroma SATD) \
  * plane/stride: full-pel reference luma plane (must have >= merange+8 valid margin around the block); \
  * fenc: PU pixels at stride FENC_STRIDE; (bx,by): PU position in the plane; cost: u16 table centred on MVD 0 \
- * (orc_mvcost_table); method: 0 DIA, 1 HEX, 2 UMH(unsupported), 3 STAR(unsupported), 5 FULL (x265.h X265_*_SEARCH). \
+ * (orc_mvcost_table); method: 0 DIA, 1 HEX, 2 UMH(unsupported), 3 STAR, 5 FULL (x265.h X265_*_SEARCH). \
  * Returns bcost, writes the quarter-pel MV. */ \
 int orc_motion_estimate_##SFX(const P* plane, intptr_t stride, int bx, int by, const P* fenc, int w, int h, \
                               const int32_t mvmin[2], const int32_t mvmax[2], const int32_t qmvp[2], \

@@ -23,6 +23,10 @@ ME_CASES = [  # (method, subme, w, h, bx_off, by_off, merange, qmvp, mvc, qp)
     (5, 2, 8, 16, 20, 44, 12, (-4, 6), [], 28),
     (5, 3, 32, 32, 64, 16, 10, (0, 0), [(16, -16)], 22),
     (1, 7, 48, 64, 0, 0, 57, (31, -29), [(8, 8), (-8, -8), (40, 0)], 28),
+    (3, 3, 16, 16, 16, 24, 57, (37, -41), [(12, 8)], 28),        # X265_STAR_SEARCH (BASELINE.json configs[2])
+    (3, 3, 64, 64, 32, 32, 57, (0, 0), [], 28),
+    (3, 2, 8, 8, 40, 12, 32, (-53, 22), [(3, 3)], 22),
+    (3, 4, 32, 32, 64, 16, 16, (60, 60), [], 37),
 ]
 
 

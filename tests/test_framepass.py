@@ -17,7 +17,7 @@ def fpmod():
     return framepass
 
 
-@pytest.mark.parametrize("depth,method,subme,qp", [(8, 1, 2, 28), (10, 1, 2, 30), (8, 0, 3, 22), (8, 1, 5, 35), (10, 1, 7, 24)])
+@pytest.mark.parametrize("depth,method,subme,qp", [(8, 1, 2, 28), (10, 1, 2, 30), (8, 0, 3, 22), (8, 1, 5, 35), (10, 1, 7, 24), (8, 3, 3, 28), (10, 3, 2, 26)])
 def test_small_frame_pass_is_bit_exact(fpmod, depth, method, subme, qp):
     sc = make_scene(200, 136, depth=depth, seed=11 + qp, tile=48, sigma=3.0 * (1 if depth == 8 else 4))
     fp = fpmod.FramePass(200, 136, depth=depth, qp=qp, merange=57, method=method, subme=subme)

@@ -316,7 +316,7 @@ def dev_keep(values):
 # ---- motion estimation ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("planes", [0, 1], ids=["filter", "planes"])
 @pytest.mark.parametrize("depth", DEPTHS)
-@pytest.mark.parametrize("method", [0, 1, 5])
+@pytest.mark.parametrize("method", [0, 1, 3, 5])
 def test_motion_estimate_matches_oracle(hipmod, depth, method, planes):
     o, g = Orc(depth), hipmod.Hip(depth)
     rng = np.random.default_rng(77 + depth + method)

@@ -51,7 +51,7 @@ def test_every_primitive_matches_reference(depth):
 
 
 @pytest.mark.parametrize("depth", DEPTHS)
-@pytest.mark.parametrize("method", [0, 1, 5])     # DIA, HEX, FULL (x265.h X265_*_SEARCH)
+@pytest.mark.parametrize("method", [0, 1, 3, 5])     # DIA, HEX, STAR, FULL (x265.h X265_*_SEARCH)
 def test_motion_estimate_matches_reference(depth, method):
     _need_ref(depth)
     o, r = Orc(depth), Ref(depth)

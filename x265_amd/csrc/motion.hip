@@ -21,6 +21,7 @@
 #include "tiles.h"
 #include "filters.h"
 #include "searchrange.h"
+#include "mestar.h"
 #include <cstdlib>
 
 namespace xh {
@@ -77,6 +78,9 @@ struct MeCtx
         }
         return uni(wave_sum((int)acc));
     }
+
+    // mestar.h contract
+    __device__ __forceinline__ int fullpel_cost(int mx, int my, int shift) const { return sad_at(mx, my) + mvcost(mx << shift, my << shift); }
 
     // K (<= 4) candidates; costs[k] = SAD only.  Small PUs run all candidates side by side in lane groups.
     __device__ __forceinline__ void sad_multi(int K, const Mv* mvs, int* costs) const
@@ -441,6 +445,8 @@ __global__ __launch_bounds__(256) void motion_kernel(const P* __restrict__ fencP
             bmv.x += kSquare1[dir][0];
             bmv.y += kSquare1[dir][1];
         }
+        else if (method == 3)
+            star_search(c, mvmin.x, mvmin.y, mvmax.x, mvmax.y, merange, bmv.x, bmv.y, bcost);  // X265_STAR_SEARCH (mestar.h)
         else
         {
             // X265_FULL_SEARCH, motion.cpp:1397-1441: raster order, strict '<' keeps the first minimum
@@ -577,8 +583,8 @@ extern "C" int x265hip_motion_estimate_planes_batch(int depth, int w, int h, con
     XH_CHECK_DEV();
     if (!valid_depth(depth) || !valid_block(w, h) || (w & 3) || (h & 3) || (w == 4 && h == 4) || n < 0)
         return set_error(X265HIP_EINVAL, "motion_estimate: depth %d PU %dx%d n %d", depth, w, h, n);
-    if (searchMethod != 0 && searchMethod != 1 && searchMethod != 5)
-        return set_error(X265HIP_EINVAL, "motion_estimate: searchMethod %d not implemented (DIA 0, HEX 1, FULL 5)", searchMethod);
+    if (searchMethod != 0 && searchMethod != 1 && searchMethod != 3 && searchMethod != 5)
+        return set_error(X265HIP_EINVAL, "motion_estimate: searchMethod %d not implemented (DIA 0, HEX 1, STAR 3, FULL 5)", searchMethod);
     if (subme < 0 || subme > 7 || numCand < 0 || merange < 1 || mvcostHalf < 4 * (merange + 64))
         return set_error(X265HIP_EINVAL, "motion_estimate: subme %d numCand %d merange %d mvcostHalf %d", subme, numCand, merange, mvcostHalf);
     if (!n) return X265HIP_OK;

@@ -21,6 +21,7 @@
 #include "tiles.h"
 #include "filters.h"
 #include "searchrange.h"
+#include "mestar.h"
 #include <cstdlib>
 
 #ifndef ME2_MIN_WAVES
@@ -314,6 +315,12 @@ struct Team
         for (int k = 0; k < K; k++) costs[k] += __builtin_amdgcn_readlane(mvc, k);
     }
 
+    // mestar.h contract: sad + mvcost((mx, my) << shift)
+    __device__ __forceinline__ int fullpel_cost(int mx, int my, int shift)
+    {
+        const int v = sad_one(mx, my);                       // sad + mvcost(<< 2)
+        return shift == 2 ? v : v - mvcost(mx * 4, my * 4) + mvcost(mx << shift, my << shift);
+    }
     __device__ __forceinline__ int sad_one(int mx, int my)
     {
         const Mv2 c[1] = { { mx, my } };
@@ -675,6 +682,8 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
             bmv.x += kSquareB[dir][0];
             bmv.y += kSquareB[dir][1];
         }
+        else if (method == 3)
+            star_search(c, mvmin.x, mvmin.y, mvmax.x, mvmax.y, merange, bmv.x, bmv.y, bcost);  // X265_STAR_SEARCH (mestar.h)
         else
         {
             // X265_FULL_SEARCH, motion.cpp:1397-1441: raster order, strict '<' keeps the first minimum

@@ -14,6 +14,7 @@
 //     (x265hip_build_subpel_planes; plane 0 is the picture), so the serial chain contains no filtering.
 #include "common.h"
 #include "searchrange.h"
+#include "mestar.h"
 
 namespace xh {
 
@@ -116,6 +117,11 @@ struct RowTeam
         }
         // every tile's |H D H^T| sum is even (pixel.hip), so one >> 1 over the block equals the per-tile >> 1 of pixel.cpp:235
         return row_allsum(acc) >> 1;
+    }
+    // mestar.h contract
+    __device__ __forceinline__ int fullpel_cost(int mx, int my, int shift) const
+    {
+        return sad_q(Mv3{ mx * 4, my * 4 }) + mvcost(mx << shift, my << shift);
     }
     __device__ __forceinline__ int cmp_q(Mv3 q, int satd) const { return satd ? satd_q(q) : sad_q(q); }
 };
@@ -313,6 +319,8 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
         bmv.x += kSquareC[dir][0];
         bmv.y += kSquareC[dir][1];
     }
+    else if (method == 3)
+        star_search(c, mvmin.x, mvmin.y, mvmax.x, mvmax.y, merange, bmv.x, bmv.y, bcost);      // X265_STAR_SEARCH (mestar.h)
     else
     {
         // X265_FULL_SEARCH, motion.cpp:1397-1441: raster order, strict '<' keeps the first minimum

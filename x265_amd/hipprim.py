@@ -89,7 +89,7 @@ PROTOTYPES = {
 
 CMP_SAD, CMP_SATD, CMP_SA8D, CMP_SA8D8, CMP_PSY = 0, 1, 2, 3, 4
 IF_HPP, IF_HPS, IF_VPP, IF_VPS, IF_VSP, IF_VSS, IF_HVPP = range(7)
-DIA_SEARCH, HEX_SEARCH, FULL_SEARCH = 0, 1, 5      # x265.h X265_*_SEARCH
+DIA_SEARCH, HEX_SEARCH, STAR_SEARCH, FULL_SEARCH = 0, 1, 3, 5      # x265.h X265_*_SEARCH
 
 
 class HipError(RuntimeError):
