@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-ref-encoder", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="independent frame passes per GPU per step, each on its own HIP stream (x265 --frame-threads inside one device)")
     args = ap.parse_args()
 
     import numpy as np
@@ -113,21 +115,46 @@ def main():
         if i == 0:
             ref0 = torch.from_numpy(np.ascontiguousarray(np.pad(sc["ref"], MARGIN, mode="edge"))).to(dev)
     from x265_amd.exchange import ReferenceRing
+    # F frame chains per GPU (x265 runs several frame encoders per device the same way): chain j of rank g encodes frames
+    # (step * N + g) * F + j; its reference is the reconstruction chain j-1 produced one step earlier (chain 0 takes the last
+    # chain of rank g-1 through the RCCL ring).  The F passes of a step are independent and run on F streams, so the small
+    # motion-search levels of one frame overlap the wide ones of another.
+    F = max(1, args.frames_in_flight)
     ring = ReferenceRing(ref0, torch.empty_like(ref0), rank, world)
-    pred = torch.zeros_like(ref0)
-    recon = [torch.empty_like(ref0), torch.empty_like(ref0)]
+    preds = [torch.zeros_like(ref0) for _ in range(F)]
+    recons = [[torch.empty_like(ref0), torch.empty_like(ref0)] for _ in range(F)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(F)] if F > 1 else [None]
     org = lambda t: t.data_ptr() + MARGIN * S + MARGIN            # noqa: E731  (8-bit: 1 byte per pixel)
-    fp = FramePass(W, H, depth=DEPTH, qp=QP, merange=MERANGE, method=hp.HEX_SEARCH, subme=SUBME)
+    fps_ = [FramePass(W, H, depth=DEPTH, qp=QP, merange=MERANGE, method=hp.HEX_SEARCH, subme=SUBME) for _ in range(F)]
+    fp = fps_[0]
 
-    state = {"ref": ring.current, "k": 0}
+    state = {"refs": [ring.current] + [ref0] * (F - 1), "k": 0}
 
     def step():
         k = state["k"]
-        src, rec = pool[k % NPOOL], recon[k & 1]
-        hp.check(L.x265hip_framepass_run(fp.h, org(src), S, org(state["ref"]), S, org(pred), S, org(rec), S, MARGIN, MARGIN, stream))
-        # reconstructed-reference exchange: my recon is the reference of the next frame, which lives on rank+1
-        # (RCCL send/recv ring shift; at N = 1 the recon simply becomes the next reference)
-        state["ref"] = ring.exchange(rec)
+        cur = torch.cuda.current_stream()
+        recs = []
+        for j in range(F):
+            src, rec = pool[(k + j) % NPOOL], recons[j][k & 1]
+            recs.append(rec)
+            if streams[j] is not None:
+                streams[j].wait_stream(cur)
+                sh = streams[j].cuda_stream
+            else:
+                sh = stream
+            hp.check(L.x265hip_framepass_run(fps_[j].h, org(src), S, org(state["refs"][j]), S, org(preds[j]), S, org(rec), S, MARGIN, MARGIN, sh))
+        for j in range(F):
+            if streams[j] is not None:
+                cur.wait_stream(streams[j])
+        # reconstructed-reference hand-over: chain j+1 takes chain j's recon (same device, pointer swap); the last chain's recon
+        # goes to chain 0 of rank+1 through the RCCL send/recv ring (at N = 1 it wraps around locally)
+        state["refs"] = [ring.exchange(recs[F - 1])] + recs[:F - 1]
+        state["k"] = k + 1
+
+    def profile_step():
+        k = state["k"]
+        rec = recons[0][k & 1]
+        hp.check(L.x265hip_framepass_run(fp.h, org(pool[k % NPOOL]), S, org(state["refs"][0]), S, org(preds[0]), S, org(rec), S, MARGIN, MARGIN, stream))
         state["k"] = k + 1
 
     def fence():
@@ -148,7 +175,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt * 1e3 / args.steps
-    fps = world * args.steps / dt
+    fps = world * F * args.steps / dt
 
     # ---- roofline of the dominant kernel: same workload, same stream, HIP events at the stage boundaries
     hp.check(L.x265hip_framepass_set_profiling(fp.h, 1))
@@ -156,7 +183,7 @@ def main():
     nprof = max(10, min(args.steps, 50))
     ms9 = (C.c_float * 9)()
     for _ in range(nprof):
-        step()
+        profile_step()
         hp.check(L.x265hip_framepass_stage_ms(fp.h, ms9))
         acc += np.array(list(ms9))
     hp.check(L.x265hip_framepass_set_profiling(fp.h, 0))
@@ -183,8 +210,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "1920x1080 8-bit, --me hex --merange 57 --subme 2, qp 28: frame pass = top-down 2Nx2N motion search "
                                    "(64/32/16/8) + predInterLuma + dct/quant/dequant/idct/recon/sse chain + sa8d + border extension; "
-                                   "one frame per GPU per step, recon exchanged to the next rank (RCCL send/recv) when N > 1",
-                       "frames_per_step": world, "pus_per_frame": 42900, "tus_per_frame": 2700},
+                                   "F independent frame passes per GPU per step on F streams (x265 frame threads), each referencing the previous chain's recon; "
+                                   "the last chain's recon goes to the next rank (RCCL send/recv) when N > 1",
+                       "frames_per_step": world * F, "frames_in_flight_per_gpu": F, "pus_per_frame": 42900, "tus_per_frame": 2700},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
                          "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": stage_ms[dom]},
