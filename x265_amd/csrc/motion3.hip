@@ -55,18 +55,29 @@ __device__ __constant__ const uint8_t kMod6m1C[8] = { 5, 0, 1, 2, 3, 4, 5, 0 }; 
 __device__ __constant__ const int8_t kSquareC[9][2] = { {0,0}, {0,-1}, {0,1}, {-1,0}, {1,0}, {-1,-1}, {-1,1}, {1,-1}, {1,1} }; // motion.cpp:65
 __device__ __constant__ const uint8_t kWorkloadC[8][5] = { {1,4,0,4,0}, {1,4,1,4,0}, {1,4,1,4,1}, {2,4,1,4,1}, {2,4,2,4,1}, {1,8,1,8,1}, {2,8,1,8,1}, {2,8,2,8,1} }; // motion.cpp:48-58
 
-template <typename P, int N>
+// sum over the team: a 16-lane row (DPP only) or the whole wave (row all-reduce + 4 readlanes; the wave is then one PU and
+// its control flow is uniform)
+template <int TEAM>
+__device__ __forceinline__ int team_allsum(int v)
+{
+    v = row_allsum(v);
+    if (TEAM == 64)
+        v = __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+    return v;
+}
+
+template <typename P, int N, int TEAM>
 struct RowTeam
 {
     typedef typename Pk3<P>::T Q;
-    static constexpr int IPT = N * N / 64;             // quads per lane: 1 (8x8), 4 (16x16)
+    static constexpr int IPT = N * N / 4 / TEAM;       // quads per lane: 1 (8x8), 4 (16x16 on 16 lanes, 32x32 on 64), 16 (64x64 on 64)
     static constexpr int TX = N / 4;                   // tiles per row
     const P* plane0;                                   // phase plane 0 at the PU origin
     int64_t planeElems;
     int stride;
     const uint16_t* cost;
     Mv3 qmvp;
-    int s;                                             // lane within the row (0..15)
+    int s;                                             // lane within the team (0..TEAM-1)
     int qoff[IPT];                                     // element offset of this lane's quads inside the PU (row * stride + col)
     Q fq[IPT];
     int fu[IPT][4];
@@ -85,7 +96,7 @@ struct RowTeam
 #pragma unroll
         for (int j = 0; j < IPT; j++)
             acc = Pk3<P>::sad(ld_unaligned<Q>(r + qoff[j]), fq[j], acc);
-        return row_allsum((int)acc);
+        return team_allsum<TEAM>((int)acc);
     }
     // subpelCompare(..., satd): 4x4 Hadamard tiles, rows of a tile in the 4 lanes of a DPP quad
     __device__ __forceinline__ int satd_q(Mv3 q) const
@@ -116,7 +127,7 @@ struct RowTeam
             acc += iabs(m[0]) + iabs(m[1]) + iabs(m[2]) + iabs(m[3]);
         }
         // every tile's |H D H^T| sum is even (pixel.hip), so one >> 1 over the block equals the per-tile >> 1 of pixel.cpp:235
-        return row_allsum(acc) >> 1;
+        return team_allsum<TEAM>(acc) >> 1;
     }
     // mestar.h contract
     __device__ __forceinline__ int fullpel_cost(int mx, int my, int shift) const
@@ -136,7 +147,7 @@ __device__ __forceinline__ Mv3 mv_clip3(Mv3 v, Mv3 lo, Mv3 hi)
 __device__ __forceinline__ bool mv_in3(Mv3 v, Mv3 lo, Mv3 hi) { return v.x >= lo.x && v.x <= hi.x && v.y >= lo.y && v.y <= hi.y; }
 __device__ __forceinline__ int sext2c(int v) { return (v & 2) ? (v | ~3) : v; }
 
-template <typename P, int N>
+template <typename P, int N, int TEAM>
 __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fencPlane, int64_t strideF, int64_t strideR,
                                                       const int32_t* __restrict__ pu_xy, const int32_t* __restrict__ mvminA,
                                                       const int32_t* __restrict__ mvmaxA, const int32_t* __restrict__ qmvpA,
@@ -145,17 +156,18 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
                                                       const P* __restrict__ planes, int64_t planeElems, DeriveRange dr,
                                                       int32_t* __restrict__ outMv, int32_t* __restrict__ outCost)
 {
-    typedef RowTeam<P, N> RT;
+    typedef RowTeam<P, N, TEAM> RT;
     typedef typename RT::Q Q;
+    constexpr int TPB = 256 / TEAM;                         // PUs per workgroup
     RT c;
-    c.s = threadIdx.x & 15;
+    c.s = threadIdx.x & (TEAM - 1);
     c.stride = (int)strideR;
     c.planeElems = planeElems;
     c.cost = mvcostTab;
     // XCD-aware block order (see motion2.hip): XCD x works on the x-th contiguous eighth of the raster-ordered PU list
     const int chunk = gridDim.x >> 3;
     const int lblock = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    const int pu = lblock * 16 + (threadIdx.x >> 4);
+    const int pu = lblock * TPB + threadIdx.x / TEAM;
     if (pu >= n)
         return;                                             // whole rows leave together
 
@@ -190,7 +202,7 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
 #pragma unroll
         for (int j = 0; j < RT::IPT; j++)
         {
-            const int t = j * 4 + (c.s >> 2), r = c.s & 3;              // tile-major: 4 consecutive lanes = the 4 rows of tile t
+            const int t = j * (TEAM / 4) + (c.s >> 2), r = c.s & 3;     // tile-major: 4 consecutive lanes = the 4 rows of tile t
             const int row = (t / RT::TX) * 4 + r, col = (t % RT::TX) * 4;
             c.qoff[j] = row * (int)strideR + col;
             c.fq[j] = ld_unaligned<Q>(f + (int64_t)row * strideF + col);
@@ -414,22 +426,24 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
     }
 }
 
-// returns 1 when handled (8x8 / 16x16 with planes), 0 otherwise
+// returns 1 when handled (square PUs with planes), 0 otherwise
 int motion3_dispatch(int depth, int size, const void* fencPlane, int64_t strideF, int64_t strideR, const int32_t* pu_xy,
                      const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp, int numCand, const int32_t* mvc, int merange,
                      int method, int subme, const uint16_t* mvcost, int n, const void* planes, int64_t planeElems, const DeriveRange* drp,
                      int32_t* outMv, int32_t* outCost, hipStream_t st, int* rc)
 {
-    if (!planes || (size != 8 && size != 16) || strideR > 0x3fffffff)
+    // 64x64 stays on the 4-wave team kernel of motion2.hip: one wave per 64x64 PU measured slower (58 vs 38 us per level)
+    if (!planes || (size != 8 && size != 16 && size != 32) || strideR > 0x3fffffff)
         return 0;
     DeriveRange dr{};
     if (drp) dr = *drp;
-    const int blocks = (((n + 15) / 16) + 7) & ~7;
+    const int tpb = size <= 16 ? 16 : 4;                     // 16-lane teams for 8x8 / 16x16, one wave per PU for 32x32 / 64x64
+    const int blocks = (((n + tpb - 1) / tpb) + 7) & ~7;
     dim3 grid(blocks), block(256);
-#define M3(P, N) hipLaunchKernelGGL((motion3_kernel<P, N>), grid, block, 0, st, (const P*)fencPlane, strideF, strideR, pu_xy, mvmin, mvmax, qmvp, \
+#define M3(P, N, TEAM) hipLaunchKernelGGL((motion3_kernel<P, N, TEAM>), grid, block, 0, st, (const P*)fencPlane, strideF, strideR, pu_xy, mvmin, mvmax, qmvp, \
                                     numCand, mvc, merange, method, subme, mvcost, n, (const P*)planes, planeElems, dr, outMv, outCost)
-    if (depth == 8) { if (size == 8) M3(uint8_t, 8); else M3(uint8_t, 16); }
-    else            { if (size == 8) M3(uint16_t, 8); else M3(uint16_t, 16); }
+    if (depth == 8) { if (size == 8) M3(uint8_t, 8, 16); else if (size == 16) M3(uint8_t, 16, 16); else if (size == 32) M3(uint8_t, 32, 64); else M3(uint8_t, 64, 64); }
+    else            { if (size == 8) M3(uint16_t, 8, 16); else if (size == 16) M3(uint16_t, 16, 16); else if (size == 32) M3(uint16_t, 32, 64); else M3(uint16_t, 64, 64); }
 #undef M3
     hipError_t e = hipGetLastError();
     *rc = e == hipSuccess ? X265HIP_OK : check_hip(e, "motion3_kernel");
