@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 
 W, H, DEPTH, QP, MERANGE, SUBME = 1920, 1080, 8, 28, 57, 2
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-STAGES = ["me64", "me32", "me16", "me8", "pred8", "chain32", "chain8", "sa8d", "border"]
+STAGES = ["planes", "me64", "me32", "me16", "me8", "pred8", "chain32", "chain8", "sa8d", "border"]
 
 
 def cpu_baseline(frames):
@@ -72,6 +72,28 @@ def reference_encoder(frames=12):
             os.remove(path)
 
 
+def pmc_traffic(stage):
+    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
+    in separate runs of this same command; FETCH doubled per the gfx950 correction of MI355X_MICROARCH.md).  None if absent."""
+    names = {"planes": "subpel_planes_kernel", "me64": "motion2_kernel<unsigned char, 64", "me32": "motion3_kernel<unsigned char, 32",
+             "me16": "motion3_kernel<unsigned char, 16", "me8": "motion3_kernel<unsigned char, 8", "pred8": "pred_from_planes_kernel",
+             "chain32": "residual_chain_kernel<unsigned char, 32", "chain8": "residual_chain_kernel<unsigned char, 8",
+             "sa8d": "sa8d_levels_kernel", "border": "extend_border_kernel"}
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_bytes.txt")))
+    if not files:
+        return None, None
+    for line in open(files[-1]):
+        if names[stage] in line:
+            cols = line.split()
+            try:
+                fetch2_kib, write_kib = float(cols[-2]), float(cols[-1])
+                return int((fetch2_kib + write_kib) * 1024), os.path.relpath(files[-1], ROOT)
+            except ValueError:
+                continue
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,11 +119,18 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libx265hip has no CPU fallback")
+    # X265HIP_BENCH_SAME_DEVICE=1 is a debugging aid for 1-GPU boxes: every rank uses cuda:0 and the exchange runs over gloo
+    same_dev = os.environ.get("X265HIP_BENCH_SAME_DEVICE") == "1"
+    if same_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     L = hp.lib()
     hp.check(L.x265hip_init(local_rank))
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if same_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream().cuda_stream or None
 
@@ -179,9 +208,9 @@ def main():
 
     # ---- roofline of the dominant kernel: same workload, same stream, HIP events at the stage boundaries
     hp.check(L.x265hip_framepass_set_profiling(fp.h, 1))
-    acc = np.zeros(9)
+    acc = np.zeros(10)
     nprof = max(10, min(args.steps, 50))
-    ms9 = (C.c_float * 9)()
+    ms9 = (C.c_float * 10)()
     for _ in range(nprof):
         profile_step()
         hp.check(L.x265hip_framepass_stage_ms(fp.h, ms9))
@@ -196,14 +225,21 @@ def main():
         # the dominant stage is a motion-search level: algorithmic bytes = source + reference picture once each (every
         # PU of a level tiles the picture and the search windows overlap: compulsory traffic is the two pictures) + I/O arrays
         n_by_stage = {"me64": 480, "me32": 1980, "me16": 8040, "me8": 32400}
+        S_, R_ = W + 2 * MARGIN, H + 2 * MARGIN
         if dom in n_by_stage:
             n = n_by_stage[dom]
             dom_bytes = W * H + (W + 2 * (MERANGE + 4)) * (H + 2 * (MERANGE + 4)) + n * (12 + 32)
-            kernel = "motion_kernel<uint8_t> (%s: %d PUs)" % (dom, n)
+            names = {"me64": "motion2_kernel<u8,64,4,planes>", "me32": "motion3_kernel<u8,32,64>", "me16": "motion3_kernel<u8,16,16>",
+                     "me8": "motion3_kernel<u8,8,16>"}
+            kernel = "%s (%s: %d PUs; compulsory bytes = source + reference window once + 44 B per PU)" % (names[dom], dom, n)
+        elif dom == "planes":
+            dom_bytes = 17 * S_ * R_                       # read the padded reference once, write 16 planes
+            kernel = "subpel_planes_kernel<u8> (16 quarter-pel planes of the padded reference)"
         else:
             dom_bytes = {"pred8": ab["pred"], "chain32": ab["chain"], "chain8": ab["chain"], "sa8d": ab["sa8d"], "border": ab["border"]}[dom]
             kernel = dom
         achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(dom)
         out = {
             "metric": "encode fps (1080p preset medium hot path: frame passes per second)", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -214,7 +250,7 @@ def main():
                                    "the last chain's recon goes to the next rank (RCCL send/recv) when N > 1",
                        "frames_per_step": world * F, "frames_in_flight_per_gpu": F, "pus_per_frame": 42900, "tus_per_frame": 2700},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": stage_ms[dom]},
             "stage_ms": stage_ms,
         }

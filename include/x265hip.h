@@ -252,11 +252,11 @@ int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t stride
 #define X265HIP_FP_DIST      7   /* uint64 [n]                           */
 int x265hip_framepass_output(x265hip_framepass* fp, int which, int level, void** devPtr, int* count);
 /* Stage timing with HIP events on the run's own stream.  After set_profiling(fp, 1) every run records an event at each
- * stage boundary; stage_ms() waits for the last run and returns the 9 stage durations in ms:
- * [0..3] motion search of CU size 64/32/16/8 (setSearchRange + motionEstimate), [4] prediction, [5] 32x32 residual chain,
- * [6] 8x8 residual chain, [7] the four sa8d launches, [8] border extension. */
+ * stage boundary; stage_ms() waits for the last run and returns the 10 stage durations in ms:
+ * [0] quarter-pel planes, [1..4] motion search of CU size 64/32/16/8 (setSearchRange + motionEstimate), [5] prediction,
+ * [6] 32x32 residual chain, [7] 8x8 residual chain, [8] sa8d of the four CU sizes, [9] border extension. */
 int x265hip_framepass_set_profiling(x265hip_framepass* fp, int enable);
-int x265hip_framepass_stage_ms(x265hip_framepass* fp, float* ms9);
+int x265hip_framepass_stage_ms(x265hip_framepass* fp, float* ms10);
 
 /* ---------------------------------------------------------------- per-call entry points (host pointers) ----- */
 /* What the reference-side table shims bind (x265_amd/host/x265_hip_primitives.cpp).  Arguments are the slot's own

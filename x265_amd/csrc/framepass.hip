@@ -30,7 +30,7 @@ struct x265hip_framepass
     int64_t planeElems, planeStride;
     int planeMarginX, planeMarginY;
     bool profile;                  // record a HIP event at every stage boundary of run()
-    hipEvent_t ev[10];
+    hipEvent_t ev[11];
 };
 
 namespace xh {
@@ -105,7 +105,7 @@ int x265hip_framepass_create(int width, int height, int depth, int qp, int meran
     fp->planes = nullptr;
     fp->planeElems = fp->planeStride = 0;
     fp->planeMarginX = fp->planeMarginY = 0;
-    for (int i = 0; i < 10; i++)
+    for (int i = 0; i < 11; i++)
         FP_TRY(check_hip(hipEventCreate(&fp->ev[i]), "hipEventCreate(framepass)"));
     for (int l = 0; l < 4; l++)
     {
@@ -180,7 +180,7 @@ int x265hip_framepass_destroy(x265hip_framepass* fp)
     }
     if (fp->mvcost) (void)hipFree(fp->mvcost);
     if (fp->planes) (void)hipFree(fp->planes);
-    for (int i = 0; i < 10; i++) (void)hipEventDestroy(fp->ev[i]);
+    for (int i = 0; i < 11; i++) (void)hipEventDestroy(fp->ev[i]);
     delete fp;
     return X265HIP_OK;
 }
@@ -229,14 +229,14 @@ int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t stride
     const size_t Bp = depth == 8 ? 1 : 2;
     void* planesOrigin = (char*)fp->planes + ((int64_t)marginY * strideR + marginX) * Bp;
 #define FP_MARK(i) do { if (fp->profile) FP_TRY(check_hip(hipEventRecord(fp->ev[i], as_stream(stream)), "hipEventRecord")); } while (0)
-    // 0. (timed with the first search level) the 16 quarter-pel planes of this reference
+    // 0. the 16 quarter-pel planes of this reference
     FP_MARK(0);
     FP_TRY(x265hip_build_subpel_planes(depth, ref, strideR, fp->width, fp->height, marginX, marginY, planesOrigin, fp->planeElems, stream));
     // 1. top-down motion search
     for (int l = 0; l < 4; l++)
     {
         const int n = fp->nLevel[l], sz = kCuSize[l];
-        if (l) FP_MARK(l);
+        FP_MARK(1 + l);
         if (!n) continue;
         // setSearchRange + motionEstimate in one launch (searchrange.h); qmvp / mvmin / mvmax arrays are still produced
         DeriveRange dr{};
@@ -249,7 +249,7 @@ int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t stride
         FP_TRY(motion_estimate_fused(depth, sz, src, strideS, ref, strideR, planesOrigin, fp->planeElems, fp->puXY[l], dr, fp->merange,
                                      fp->method, fp->subme, fp->mvcost + kMvHalf, n, fp->mv[l], fp->cost[l], as_stream(stream)));
     }
-    FP_MARK(4);
+    FP_MARK(5);
     // 2. prediction from the 8x8 vectors
     FP_TRY(pred_from_planes(depth, 8, planesOrigin, fp->planeElems, strideR, pred, strideP, fp->puXY[3], fp->mv[3], fp->nLevel[3], as_stream(stream)));
     // 3. residual chain
@@ -257,7 +257,7 @@ int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t stride
     static const int invQuantScales[6] = { 40, 45, 51, 57, 64, 72 };                     // scalinglist.cpp:130
     for (int t = 0; t < 2; t++)
     {
-        FP_MARK(5 + t);
+        FP_MARK(6 + t);
         if (!fp->nTu[t]) continue;
         const int log2n = kTuSize[t] == 32 ? 5 : 3;
         const int transformShift = 15 - depth - log2n;                                   // MAX_TR_DYNAMIC_RANGE - X265_DEPTH - log2TrSize (quant.cpp:408)
@@ -269,7 +269,7 @@ int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t stride
                                             fp->tuOffR[t], fp->quantCoeff[t], qBits, add, dqScale, dqShift, fp->level[t], fp->numSig[t],
                                             fp->dist[t], fp->nTu[t], stream));
     }
-    FP_MARK(7);
+    FP_MARK(8);
     // 4. mode costs
     {
         Sa8dLevel lv[4];
@@ -277,10 +277,10 @@ int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t stride
             lv[l] = Sa8dLevel{ fp->cuOff[l], fp->cuOffP[l], fp->sa8d[l], fp->nLevel[l], kCuSize[l] };
         FP_TRY(sa8d_levels(depth, src, strideS, pred, strideP, lv, 4, as_stream(stream)));
     }
-    FP_MARK(8);
+    FP_MARK(9);
     // 5. the reconstructed picture becomes a reference
     FP_TRY(x265hip_extend_border(depth, recon, strideRec, fp->width, fp->height, marginX, marginY, stream));
-    FP_MARK(9);
+    FP_MARK(10);
 #undef FP_MARK
     return X265HIP_OK;
 }
@@ -292,13 +292,13 @@ int x265hip_framepass_set_profiling(x265hip_framepass* fp, int enable)
     return X265HIP_OK;
 }
 
-int x265hip_framepass_stage_ms(x265hip_framepass* fp, float* ms9)
+int x265hip_framepass_stage_ms(x265hip_framepass* fp, float* ms10)
 {
-    if (!fp || !ms9 || !fp->profile)
+    if (!fp || !ms10 || !fp->profile)
         return set_error(X265HIP_EINVAL, "framepass_stage_ms: profiling is off");
-    FP_TRY(check_hip(hipEventSynchronize(fp->ev[9]), "hipEventSynchronize"));
-    for (int i = 0; i < 9; i++)
-        FP_TRY(check_hip(hipEventElapsedTime(&ms9[i], fp->ev[i], fp->ev[i + 1]), "hipEventElapsedTime"));
+    FP_TRY(check_hip(hipEventSynchronize(fp->ev[10]), "hipEventSynchronize"));
+    for (int i = 0; i < 10; i++)
+        FP_TRY(check_hip(hipEventElapsedTime(&ms10[i], fp->ev[i], fp->ev[i + 1]), "hipEventElapsedTime"));
     return X265HIP_OK;
 }
 

@@ -23,9 +23,13 @@ def ring_shift(send, recv, rank, world):
     if world == 1:
         recv.copy_(send)
         return
-    ops = [dist.P2POp(dist.isend, send, (rank + 1) % world), dist.P2POp(dist.irecv, recv, (rank - 1) % world)]
-    for r in dist.batch_isend_irecv(ops):
-        r.wait()
+    staged = send.is_cuda and dist.get_backend() == "gloo"      # debugging aid: gloo moves host memory only
+    s, r = (send.cpu(), recv.cpu()) if staged else (send, recv)
+    ops = [dist.P2POp(dist.isend, s, (rank + 1) % world), dist.P2POp(dist.irecv, r, (rank - 1) % world)]
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    if staged:
+        recv.copy_(r)
 
 
 class ReferenceRing:
