@@ -278,6 +278,19 @@ int x265hip_call_dequant_normal(const int16_t* quantCoef, int16_t* coef, int num
 int x265hip_call_dequant_scaling(const int16_t* quantCoef, const int32_t* deQuantCoef, int16_t* coef, int num, int per, int shift);
 int x265hip_call_interp(int kind, int taps, int depth, int w, int h, const void* src, int64_t strideS,
                         void* dst, int64_t strideD, int coeffIdx, int coeffIdy, int isRowExt);
+int x265hip_call_sub_ps(int depth, int w, int h, int16_t* dst, int64_t ds, const void* a, const void* b, int64_t sa, int64_t sb);
+int x265hip_call_add_ps(int depth, int w, int h, void* dst, int64_t ds, const void* a, const int16_t* r, int64_t sa, int64_t sr);
+int x265hip_call_addavg(int depth, int w, int h, const int16_t* s0, const int16_t* s1, void* dst, int64_t st0, int64_t st1, int64_t ds);
+int x265hip_call_pixelavg_pp(int depth, int w, int h, void* dst, int64_t ds, const void* s0, int64_t st0, const void* s1, int64_t st1);
+int x265hip_call_copy(int kind, int depth, int w, int h, void* dst, int64_t ds, const void* src, int64_t ss);
+int x265hip_call_p2s(int depth, int w, int h, const void* src, int64_t ss, int16_t* dst, int64_t ds);
+int x265hip_call_cpy_shift(int kind, int size, int16_t* dst, const int16_t* src, int64_t stride, int shift);
+int x265hip_call_copy_cnt(int size, int16_t* coeff, const int16_t* resi, int64_t stride, uint32_t* numSig);
+int x265hip_call_count_nonzero(int size, const int16_t* qCoef, int* count);
+int x265hip_call_blockfill_s(int size, int16_t* dst, int64_t ds, int16_t val);
+int x265hip_call_denoise_dct(int16_t* dctCoef, uint32_t* resSum, const uint16_t* offset, int numCoeff);
+int x265hip_call_rdoq_cost(int kind, int size, int depth, const int16_t* resiDct, const int16_t* fencDct, int64_t* costUncoded,
+                           int64_t* totalUncoded, int64_t* totalRd, const int64_t* psyScale, uint32_t blkPos);
 
 #ifdef __cplusplus
 }

@@ -273,3 +273,213 @@ int x265hip_call_interp(int kind, int taps, int depth, int w, int h, const void*
 }
 
 } // extern "C"
+
+// ---- block arithmetic / layout slots (rows a15 / a16 of SURVEY.md §8a) ------------------------------------------------------
+extern "C" {
+
+// pixel_sub_ps_t (primitives.h:147)
+int x265hip_call_sub_ps(int depth, int w, int h, int16_t* dst, int64_t ds, const void* a, const void* b, int64_t sa, int64_t sb)
+{
+    const int B = depth == 8 ? 1 : 2;
+    PC_BEGIN((size_t)w * h * (2 * B + 2));
+    const size_t oOff = carve(4 * sizeof(int32_t)), oA = carve((size_t)w * h * B), oB = carve((size_t)w * h * B), oD = carve((size_t)w * h * 2);
+    hostp<int32_t>(oOff)[0] = 0;
+    pack_rows(hostp<char>(oA), a, sa, w, h, B);
+    pack_rows(hostp<char>(oB), b, sb, w, h, B);
+    PC_TRY(upload());
+    PC_TRY(x265hip_sub_ps_batch(depth, w, h, devp<int16_t>(oD), w, devp<char>(oA), w, devp<char>(oB), w, devp<int32_t>(oOff), devp<int32_t>(oOff),
+                                devp<int32_t>(oOff), 1, t_st.stream));
+    PC_TRY(download(oD, (size_t)w * h * 2));
+    unpack_rows(dst, ds, hostp<char>(oD), w, h, 2);
+    return X265HIP_OK;
+}
+
+// pixel_add_ps_t (primitives.h:148)
+int x265hip_call_add_ps(int depth, int w, int h, void* dst, int64_t ds, const void* a, const int16_t* r, int64_t sa, int64_t sr)
+{
+    const int B = depth == 8 ? 1 : 2;
+    PC_BEGIN((size_t)w * h * (2 * B + 2));
+    const size_t oOff = carve(4 * sizeof(int32_t)), oA = carve((size_t)w * h * B), oR = carve((size_t)w * h * 2), oD = carve((size_t)w * h * B);
+    hostp<int32_t>(oOff)[0] = 0;
+    pack_rows(hostp<char>(oA), a, sa, w, h, B);
+    pack_rows(hostp<char>(oR), r, sr, w, h, 2);
+    PC_TRY(upload());
+    PC_TRY(x265hip_add_ps_batch(depth, w, h, devp<char>(oD), w, devp<char>(oA), w, devp<int16_t>(oR), w, devp<int32_t>(oOff), devp<int32_t>(oOff),
+                                devp<int32_t>(oOff), 1, t_st.stream));
+    PC_TRY(download(oD, (size_t)w * h * B));
+    unpack_rows(dst, ds, hostp<char>(oD), w, h, B);
+    return X265HIP_OK;
+}
+
+// addAvg_t (primitives.h:173)
+int x265hip_call_addavg(int depth, int w, int h, const int16_t* s0, const int16_t* s1, void* dst, int64_t st0, int64_t st1, int64_t ds)
+{
+    const int B = depth == 8 ? 1 : 2;
+    PC_BEGIN((size_t)w * h * (4 + B));
+    const size_t oOff = carve(4 * sizeof(int32_t)), o0 = carve((size_t)w * h * 2), o1 = carve((size_t)w * h * 2), oD = carve((size_t)w * h * B);
+    hostp<int32_t>(oOff)[0] = 0;
+    pack_rows(hostp<char>(o0), s0, st0, w, h, 2);
+    pack_rows(hostp<char>(o1), s1, st1, w, h, 2);
+    PC_TRY(upload());
+    PC_TRY(x265hip_addavg_batch(depth, w, h, devp<int16_t>(o0), w, devp<int16_t>(o1), w, devp<char>(oD), w, devp<int32_t>(oOff), devp<int32_t>(oOff),
+                                devp<int32_t>(oOff), 1, t_st.stream));
+    PC_TRY(download(oD, (size_t)w * h * B));
+    unpack_rows(dst, ds, hostp<char>(oD), w, h, B);
+    return X265HIP_OK;
+}
+
+// pixelavg_pp_t (primitives.h:149; the weight argument is always 32 in x265)
+int x265hip_call_pixelavg_pp(int depth, int w, int h, void* dst, int64_t ds, const void* s0, int64_t st0, const void* s1, int64_t st1)
+{
+    const int B = depth == 8 ? 1 : 2;
+    PC_BEGIN((size_t)w * h * 3 * B);
+    const size_t oOff = carve(4 * sizeof(int32_t)), o0 = carve((size_t)w * h * B), o1 = carve((size_t)w * h * B), oD = carve((size_t)w * h * B);
+    hostp<int32_t>(oOff)[0] = 0;
+    pack_rows(hostp<char>(o0), s0, st0, w, h, B);
+    pack_rows(hostp<char>(o1), s1, st1, w, h, B);
+    PC_TRY(upload());
+    PC_TRY(x265hip_pixelavg_pp_batch(depth, w, h, devp<char>(oD), w, devp<char>(o0), w, devp<char>(o1), w, devp<int32_t>(oOff), devp<int32_t>(oOff),
+                                     devp<int32_t>(oOff), 1, t_st.stream));
+    PC_TRY(download(oD, (size_t)w * h * B));
+    unpack_rows(dst, ds, hostp<char>(oD), w, h, B);
+    return X265HIP_OK;
+}
+
+// copy_pp_t / copy_sp_t / copy_ps_t / copy_ss_t (primitives.h:143-146): kind 0..3
+int x265hip_call_copy(int kind, int depth, int w, int h, void* dst, int64_t ds, const void* src, int64_t ss)
+{
+    const int B = depth == 8 ? 1 : 2;
+    const int es = (kind == 1 || kind == 3) ? 2 : B, ed = (kind == 2 || kind == 3) ? 2 : B;
+    PC_BEGIN((size_t)w * h * (es + ed));
+    const size_t oOff = carve(4 * sizeof(int32_t)), oS = carve((size_t)w * h * es), oD = carve((size_t)w * h * ed);
+    hostp<int32_t>(oOff)[0] = 0;
+    pack_rows(hostp<char>(oS), src, ss, w, h, es);
+    PC_TRY(upload());
+    PC_TRY(x265hip_copy_batch(kind, depth, w, h, devp<char>(oD), w, devp<char>(oS), w, devp<int32_t>(oOff), devp<int32_t>(oOff), 1, t_st.stream));
+    PC_TRY(download(oD, (size_t)w * h * ed));
+    unpack_rows(dst, ds, hostp<char>(oD), w, h, ed);
+    return X265HIP_OK;
+}
+
+// filter_p2s_t (primitives.h:185)
+int x265hip_call_p2s(int depth, int w, int h, const void* src, int64_t ss, int16_t* dst, int64_t ds)
+{
+    const int B = depth == 8 ? 1 : 2;
+    PC_BEGIN((size_t)w * h * (B + 2));
+    const size_t oOff = carve(4 * sizeof(int32_t)), oS = carve((size_t)w * h * B), oD = carve((size_t)w * h * 2);
+    hostp<int32_t>(oOff)[0] = 0;
+    pack_rows(hostp<char>(oS), src, ss, w, h, B);
+    PC_TRY(upload());
+    PC_TRY(x265hip_p2s_batch(depth, w, h, devp<char>(oS), w, devp<int16_t>(oD), w, devp<int32_t>(oOff), devp<int32_t>(oOff), 1, t_st.stream));
+    PC_TRY(download(oD, (size_t)w * h * 2));
+    unpack_rows(dst, ds, hostp<char>(oD), w, h, 2);
+    return X265HIP_OK;
+}
+
+// cpy2Dto1D_shl/shr, cpy1Dto2D_shl/shr (primitives.h:147-150): kind 0..3; `stride` is the 2-D side's
+int x265hip_call_cpy_shift(int kind, int size, int16_t* dst, const int16_t* src, int64_t stride, int shift)
+{
+    const size_t nb = (size_t)size * size * 2;
+    PC_BEGIN(2 * nb);
+    const size_t oOff = carve(4 * sizeof(int32_t)), oS = carve(nb), oD = carve(nb);
+    hostp<int32_t>(oOff)[0] = 0;
+    if (kind < 2) pack_rows(hostp<char>(oS), src, stride, size, size, 2); else memcpy(hostp<char>(oS), src, nb);
+    PC_TRY(upload());
+    PC_TRY(x265hip_cpy_shift_batch(kind, size, devp<int16_t>(oD), devp<int16_t>(oS), size, devp<int32_t>(oOff), shift, 1, t_st.stream));
+    PC_TRY(download(oD, nb));
+    if (kind < 2) memcpy(dst, hostp<char>(oD), nb); else unpack_rows(dst, stride, hostp<char>(oD), size, size, 2);
+    return X265HIP_OK;
+}
+
+// copy_cnt_t (primitives.h:151)
+int x265hip_call_copy_cnt(int size, int16_t* coeff, const int16_t* resi, int64_t stride, uint32_t* numSig)
+{
+    const size_t nb = (size_t)size * size * 2;
+    PC_BEGIN(2 * nb + 64);
+    const size_t oOff = carve(4 * sizeof(int32_t)), oS = carve(nb), oD = carve(nb + 16);
+    hostp<int32_t>(oOff)[0] = 0;
+    pack_rows(hostp<char>(oS), resi, stride, size, size, 2);
+    PC_TRY(upload());
+    PC_TRY(x265hip_copy_cnt_batch(size, devp<int16_t>(oD), devp<int16_t>(oS), size, devp<int32_t>(oOff), 1,
+                                  reinterpret_cast<uint32_t*>(devp<char>(oD) + nb), t_st.stream));
+    PC_TRY(download(oD, nb + 4));
+    memcpy(coeff, hostp<char>(oD), nb);
+    *numSig = *reinterpret_cast<uint32_t*>(hostp<char>(oD) + nb);
+    return X265HIP_OK;
+}
+
+// count_nonzero_t (primitives.h:163)
+int x265hip_call_count_nonzero(int size, const int16_t* qCoef, int* count)
+{
+    const size_t nb = (size_t)size * size * 2;
+    PC_BEGIN(nb + 64);
+    const size_t oS = carve(nb), oD = carve(16);
+    memcpy(hostp<char>(oS), qCoef, nb);
+    PC_TRY(upload());
+    PC_TRY(x265hip_count_nonzero_batch(devp<int16_t>(oS), size * size, 1, devp<uint32_t>(oD), t_st.stream));
+    PC_TRY(download(oD, 4));
+    *count = (int)*hostp<uint32_t>(oD);
+    return X265HIP_OK;
+}
+
+// blockfill_s_t (primitives.h:141)
+int x265hip_call_blockfill_s(int size, int16_t* dst, int64_t ds, int16_t val)
+{
+    const size_t nb = (size_t)size * size * 2;
+    PC_BEGIN(nb + 64);
+    const size_t oOff = carve(4 * sizeof(int32_t)), oV = carve(16), oD = carve(nb);
+    hostp<int32_t>(oOff)[0] = 0;
+    hostp<int16_t>(oV)[0] = val;
+    PC_TRY(upload());
+    PC_TRY(x265hip_blockfill_s_batch(size, devp<int16_t>(oD), size, devp<int32_t>(oOff), devp<int16_t>(oV), 1, t_st.stream));
+    PC_TRY(download(oD, nb));
+    unpack_rows(dst, ds, hostp<char>(oD), size, size, 2);
+    return X265HIP_OK;
+}
+
+// denoiseDct_t (primitives.h:155): in place on dctCoef and resSum
+int x265hip_call_denoise_dct(int16_t* dctCoef, uint32_t* resSum, const uint16_t* offset, int numCoeff)
+{
+    const size_t n = (size_t)numCoeff;
+    PC_BEGIN(n * 8);
+    const size_t oO = carve(n * 2), oC = carve(n * 2 + ((16 - (n * 2) % 16) % 16) + n * 4);
+    const size_t rsOff = (n * 2 + 15) & ~(size_t)15;
+    memcpy(hostp<char>(oO), offset, n * 2);
+    memcpy(hostp<char>(oC), dctCoef, n * 2);
+    memcpy(hostp<char>(oC) + rsOff, resSum, n * 4);
+    PC_TRY(upload());
+    PC_TRY(x265hip_denoise_dct_batch(devp<int16_t>(oC), reinterpret_cast<uint32_t*>(devp<char>(oC) + rsOff), devp<uint16_t>(oO), numCoeff, 1, t_st.stream));
+    PC_TRY(download(oC, rsOff + n * 4));
+    memcpy(dctCoef, hostp<char>(oC), n * 2);
+    memcpy(resSum, hostp<char>(oC) + rsOff, n * 4);
+    return X265HIP_OK;
+}
+
+// nonPsyRdoQuant_t / psyRdoQuant_t / psyRdoQuant_t1 / psyRdoQuant_t2 (primitives.h:229-232): kind 0..3; one coefficient group
+int x265hip_call_rdoq_cost(int kind, int size, int depth, const int16_t* resiDct, const int16_t* fencDct, int64_t* costUncoded,
+                           int64_t* totalUncoded, int64_t* totalRd, const int64_t* psyScale, uint32_t blkPos)
+{
+    // The slot only touches the 4x4 group at blkPos (row pitch = size) and blkPos is not bounded by size*size (the reference
+    // TestBench passes 1024 to the 4x4 slot), so stage just that window, rebased to position 0.
+    const size_t span = (size_t)3 * size + 4;                       // elements from the group's first to its last coefficient
+    PC_BEGIN(span * 12 + 256);
+    const size_t oOff = carve(4 * sizeof(int32_t)), oR = carve(span * 2), oF = carve(span * 2), oP = carve(16), oCU = carve(span * 8 + 32);
+    hostp<int32_t>(oOff)[0] = 0;
+    hostp<int32_t>(oOff)[1] = 0;
+    memcpy(hostp<char>(oR), resiDct + blkPos, span * 2);
+    if (fencDct) memcpy(hostp<char>(oF), fencDct + blkPos, span * 2); else memset(hostp<char>(oF), 0, span * 2);
+    hostp<int64_t>(oP)[0] = psyScale ? *psyScale : 0;
+    memcpy(hostp<char>(oCU), costUncoded + blkPos, span * 8);       // psy_2p reads the values stored by the _1p call
+    PC_TRY(upload());
+    int64_t* dCU = devp<int64_t>(oCU);
+    PC_TRY(x265hip_rdoq_cost_batch(kind, size, depth, devp<int16_t>(oR), devp<int16_t>(oF), devp<int64_t>(oP), devp<int32_t>(oOff), devp<int32_t>(oOff) + 1, 1,
+                                   dCU, dCU + span, dCU + span + 1, t_st.stream));
+    PC_TRY(download(oCU, span * 8 + 16));
+    for (int y = 0; y < 4; y++)
+        memcpy(costUncoded + blkPos + (size_t)y * size, hostp<int64_t>(oCU) + (size_t)y * size, 4 * sizeof(int64_t));
+    *totalUncoded += hostp<int64_t>(oCU)[span];
+    *totalRd += hostp<int64_t>(oCU)[span + 1];
+    return X265HIP_OK;
+}
+
+} // extern "C"

@@ -85,6 +85,18 @@ PROTOTYPES = {
     "x265hip_call_dequant_normal": (i32, [vp, vp, i32, i32, i32]),
     "x265hip_call_dequant_scaling": (i32, [vp, vp, vp, i32, i32, i32]),
     "x265hip_call_interp": (i32, [i32, i32, i32, i32, i32, vp, i64, vp, i64, i32, i32, i32]),
+    "x265hip_call_sub_ps": (i32, [i32, i32, i32, vp, i64, vp, vp, i64, i64]),
+    "x265hip_call_add_ps": (i32, [i32, i32, i32, vp, i64, vp, vp, i64, i64]),
+    "x265hip_call_addavg": (i32, [i32, i32, i32, vp, vp, vp, i64, i64, i64]),
+    "x265hip_call_pixelavg_pp": (i32, [i32, i32, i32, vp, i64, vp, i64, vp, i64]),
+    "x265hip_call_copy": (i32, [i32, i32, i32, i32, vp, i64, vp, i64]),
+    "x265hip_call_p2s": (i32, [i32, i32, i32, vp, i64, vp, i64]),
+    "x265hip_call_cpy_shift": (i32, [i32, i32, vp, vp, i64, i32]),
+    "x265hip_call_copy_cnt": (i32, [i32, vp, vp, i64, vp]),
+    "x265hip_call_count_nonzero": (i32, [i32, vp, vp]),
+    "x265hip_call_blockfill_s": (i32, [i32, vp, i64, C.c_int16]),
+    "x265hip_call_denoise_dct": (i32, [vp, vp, vp, i32]),
+    "x265hip_call_rdoq_cost": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, u32]),
 }
 
 CMP_SAD, CMP_SATD, CMP_SA8D, CMP_SA8D8, CMP_PSY = 0, 1, 2, 3, 4

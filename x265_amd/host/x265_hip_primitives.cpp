@@ -164,6 +164,122 @@ template <int W, int H, int PART> static void hvpp_hip(const pixel* s, intptr_t 
     if (x265hip_call_interp(X265HIP_IF_HVPP, 8, D, W, H, s, ss, d, ds, cx, cy, 0)) g_c.pu[PART].luma_hvpp(s, ss, d, ds, cx, cy);
 }
 
+// ---- block arithmetic / layout (primitives.h:141-151, :163, :173, :185) -------------------------------------------------------
+template <int W, int H, int PART> static void copy_pp_hip(pixel* d, intptr_t ds, const pixel* s, intptr_t ss)
+{
+    if (x265hip_call_copy(0, D, W, H, d, ds, s, ss)) g_c.pu[PART].copy_pp(d, ds, s, ss);
+}
+template <int W, int H, int PART> static void addAvg_hip(const int16_t* a, const int16_t* b, pixel* d, intptr_t sa, intptr_t sb, intptr_t ds)
+{
+    if (x265hip_call_addavg(D, W, H, a, b, d, sa, sb, ds)) g_c.pu[PART].addAvg[NONALIGNED](a, b, d, sa, sb, ds);
+}
+template <int W, int H, int PART> static void pixelavg_hip(pixel* d, intptr_t ds, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb, int w)
+{
+    if (x265hip_call_pixelavg_pp(D, W, H, d, ds, a, sa, b, sb)) g_c.pu[PART].pixelavg_pp[NONALIGNED](d, ds, a, sa, b, sb, w);
+}
+template <int W, int H, int PART> static void p2s_hip(const pixel* s, intptr_t ss, int16_t* d, intptr_t ds)
+{
+    if (x265hip_call_p2s(D, W, H, s, ss, d, ds)) g_c.pu[PART].convert_p2s[NONALIGNED](s, ss, d, ds);
+}
+template <int N, int CU> static void sub_ps_hip(int16_t* d, intptr_t ds, const pixel* a, const pixel* b, intptr_t sa, intptr_t sb)
+{
+    if (x265hip_call_sub_ps(D, N, N, d, ds, a, b, sa, sb)) g_c.cu[CU].sub_ps(d, ds, a, b, sa, sb);
+}
+template <int N, int CU> static void add_ps_hip(pixel* d, intptr_t ds, const pixel* a, const int16_t* r, intptr_t sa, intptr_t sr)
+{
+    if (x265hip_call_add_ps(D, N, N, d, ds, a, r, sa, sr)) g_c.cu[CU].add_ps[NONALIGNED](d, ds, a, r, sa, sr);
+}
+template <int N, int CU> static void copy_sp_hip(pixel* d, intptr_t ds, const int16_t* s, intptr_t ss)
+{
+    if (x265hip_call_copy(1, D, N, N, d, ds, s, ss)) g_c.cu[CU].copy_sp(d, ds, s, ss);
+}
+template <int N, int CU> static void copy_ps_hip(int16_t* d, intptr_t ds, const pixel* s, intptr_t ss)
+{
+    if (x265hip_call_copy(2, D, N, N, d, ds, s, ss)) g_c.cu[CU].copy_ps(d, ds, s, ss);
+}
+template <int N, int CU> static void copy_ss_hip(int16_t* d, intptr_t ds, const int16_t* s, intptr_t ss)
+{
+    if (x265hip_call_copy(3, D, N, N, d, ds, s, ss)) g_c.cu[CU].copy_ss(d, ds, s, ss);
+}
+template <int N, int CU> static void blockfill_hip(int16_t* d, intptr_t ds, int16_t v)
+{
+    if (x265hip_call_blockfill_s(N, d, ds, v)) g_c.cu[CU].blockfill_s[NONALIGNED](d, ds, v);
+}
+template <int N, int CU> static void cpy2Dto1D_shl_hip(int16_t* d, const int16_t* s, intptr_t ss, int shift)
+{
+    if (x265hip_call_cpy_shift(0, N, d, s, ss, shift)) g_c.cu[CU].cpy2Dto1D_shl(d, s, ss, shift);
+}
+template <int N, int CU> static void cpy2Dto1D_shr_hip(int16_t* d, const int16_t* s, intptr_t ss, int shift)
+{
+    if (shift < 1 || x265hip_call_cpy_shift(1, N, d, s, ss, shift)) g_c.cu[CU].cpy2Dto1D_shr(d, s, ss, shift);
+}
+template <int N, int CU> static void cpy1Dto2D_shl_hip(int16_t* d, const int16_t* s, intptr_t ds, int shift)
+{
+    if (x265hip_call_cpy_shift(2, N, d, s, ds, shift)) g_c.cu[CU].cpy1Dto2D_shl[NONALIGNED](d, s, ds, shift);
+}
+template <int N, int CU> static void cpy1Dto2D_shr_hip(int16_t* d, const int16_t* s, intptr_t ds, int shift)
+{
+    if (shift < 1 || x265hip_call_cpy_shift(3, N, d, s, ds, shift)) g_c.cu[CU].cpy1Dto2D_shr(d, s, ds, shift);
+}
+template <int N, int CU> static uint32_t copy_cnt_hip(int16_t* coeff, const int16_t* resi, intptr_t stride)
+{
+    uint32_t ns;
+    if (x265hip_call_copy_cnt(N, coeff, resi, stride, &ns)) return g_c.cu[CU].copy_cnt(coeff, resi, stride);
+    return ns;
+}
+template <int N, int CU> static int count_nonzero_hip(const int16_t* q)
+{
+    int c;
+    if (x265hip_call_count_nonzero(N, q, &c)) return g_c.cu[CU].count_nonzero(q);
+    return c;
+}
+template <int N, int CU> static void nonpsy_rdoq_hip(int16_t* resi, int64_t* cu_, int64_t* tu, int64_t* tr, uint32_t blkPos)
+{
+    if (x265hip_call_rdoq_cost(0, N, D, resi, NULL, cu_, tu, tr, NULL, blkPos)) g_c.cu[CU].nonPsyRdoQuant(resi, cu_, tu, tr, blkPos);
+}
+template <int N, int CU> static void psy_rdoq_hip(int16_t* resi, int16_t* fenc, int64_t* cu_, int64_t* tu, int64_t* tr, int64_t* psy, uint32_t blkPos)
+{
+    if (x265hip_call_rdoq_cost(1, N, D, resi, fenc, cu_, tu, tr, psy, blkPos)) g_c.cu[CU].psyRdoQuant(resi, fenc, cu_, tu, tr, psy, blkPos);
+}
+template <int N, int CU> static void psy_rdoq_1p_hip(int16_t* resi, int64_t* cu_, int64_t* tu, int64_t* tr, uint32_t blkPos)
+{
+    if (x265hip_call_rdoq_cost(2, N, D, resi, NULL, cu_, tu, tr, NULL, blkPos)) g_c.cu[CU].psyRdoQuant_1p(resi, cu_, tu, tr, blkPos);
+}
+template <int N, int CU> static void psy_rdoq_2p_hip(int16_t* resi, int16_t* fenc, int64_t* cu_, int64_t* tu, int64_t* tr, int64_t* psy, uint32_t blkPos)
+{
+    if (x265hip_call_rdoq_cost(3, N, D, resi, fenc, cu_, tu, tr, psy, blkPos)) g_c.cu[CU].psyRdoQuant_2p(resi, fenc, cu_, tu, tr, psy, blkPos);
+}
+static void denoise_hip(int16_t* coef, uint32_t* resSum, const uint16_t* offset, int numCoeff)
+{
+    if (x265hip_call_denoise_dct(coef, resSum, offset, numCoeff)) g_c.denoiseDct(coef, resSum, offset, numCoeff);
+}
+
+// ---- 4:2:0 chroma interpolation (primitives.h:399-404): chroma block of luma partition W x H is (W/2) x (H/2), 4 taps ----
+template <int W, int H, int PART> static void c_hpp_hip(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int c)
+{
+    if (x265hip_call_interp(X265HIP_IF_HPP, 4, D, W / 2, H / 2, s, ss, d, ds, c, 0, 0)) g_c.chroma[X265_CSP_I420].pu[PART].filter_hpp(s, ss, d, ds, c);
+}
+template <int W, int H, int PART> static void c_hps_hip(const pixel* s, intptr_t ss, int16_t* d, intptr_t ds, int c, int ext)
+{
+    if (x265hip_call_interp(X265HIP_IF_HPS, 4, D, W / 2, H / 2, s, ss, d, ds, c, 0, ext)) g_c.chroma[X265_CSP_I420].pu[PART].filter_hps(s, ss, d, ds, c, ext);
+}
+template <int W, int H, int PART> static void c_vpp_hip(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int c)
+{
+    if (x265hip_call_interp(X265HIP_IF_VPP, 4, D, W / 2, H / 2, s, ss, d, ds, c, 0, 0)) g_c.chroma[X265_CSP_I420].pu[PART].filter_vpp(s, ss, d, ds, c);
+}
+template <int W, int H, int PART> static void c_vps_hip(const pixel* s, intptr_t ss, int16_t* d, intptr_t ds, int c)
+{
+    if (x265hip_call_interp(X265HIP_IF_VPS, 4, D, W / 2, H / 2, s, ss, d, ds, c, 0, 0)) g_c.chroma[X265_CSP_I420].pu[PART].filter_vps(s, ss, d, ds, c);
+}
+template <int W, int H, int PART> static void c_vsp_hip(const int16_t* s, intptr_t ss, pixel* d, intptr_t ds, int c)
+{
+    if (x265hip_call_interp(X265HIP_IF_VSP, 4, D, W / 2, H / 2, s, ss, d, ds, c, 0, 0)) g_c.chroma[X265_CSP_I420].pu[PART].filter_vsp(s, ss, d, ds, c);
+}
+template <int W, int H, int PART> static void c_vss_hip(const int16_t* s, intptr_t ss, int16_t* d, intptr_t ds, int c)
+{
+    if (x265hip_call_interp(X265HIP_IF_VSS, 4, D, W / 2, H / 2, s, ss, d, ds, c, 0, 0)) g_c.chroma[X265_CSP_I420].pu[PART].filter_vss(s, ss, d, ds, c);
+}
+
 #undef D
 
 #define HIP_PU(W, H) do { \
@@ -179,6 +295,23 @@ template <int W, int H, int PART> static void hvpp_hip(const pixel* s, intptr_t 
         p.pu[part].luma_vsp = vsp_hip<W, H, LUMA_ ## W ## x ## H>; \
         p.pu[part].luma_vss = vss_hip<W, H, LUMA_ ## W ## x ## H>; \
         p.pu[part].luma_hvpp = hvpp_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.pu[part].copy_pp = copy_pp_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.pu[part].addAvg[NONALIGNED] = addAvg_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.pu[part].addAvg[ALIGNED] = addAvg_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.pu[part].pixelavg_pp[NONALIGNED] = pixelavg_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.pu[part].pixelavg_pp[ALIGNED] = pixelavg_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.pu[part].convert_p2s[NONALIGNED] = p2s_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.pu[part].convert_p2s[ALIGNED] = p2s_hip<W, H, LUMA_ ## W ## x ## H>; \
+    } while (0)
+
+#define HIP_CHROMA420(W, H) do { \
+        const int part = LUMA_ ## W ## x ## H; \
+        p.chroma[X265_CSP_I420].pu[part].filter_hpp = c_hpp_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.chroma[X265_CSP_I420].pu[part].filter_hps = c_hps_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.chroma[X265_CSP_I420].pu[part].filter_vpp = c_vpp_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.chroma[X265_CSP_I420].pu[part].filter_vps = c_vps_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.chroma[X265_CSP_I420].pu[part].filter_vsp = c_vsp_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.chroma[X265_CSP_I420].pu[part].filter_vss = c_vss_hip<W, H, LUMA_ ## W ## x ## H>; \
     } while (0)
 
 #define HIP_CU(N) do { \
@@ -189,11 +322,30 @@ template <int W, int H, int PART> static void hvpp_hip(const pixel* s, intptr_t 
         p.cu[cu].sse_ss = sse_ss_hip<N, BLOCK_ ## N ## x ## N>; \
         p.cu[cu].ssd_s[NONALIGNED] = ssd_s_hip<N, BLOCK_ ## N ## x ## N>; \
         p.cu[cu].ssd_s[ALIGNED] = ssd_s_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[cu].sub_ps = sub_ps_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[cu].add_ps[NONALIGNED] = add_ps_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[cu].add_ps[ALIGNED] = add_ps_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[cu].copy_sp = copy_sp_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[cu].copy_ps = copy_ps_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[cu].copy_ss = copy_ss_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[cu].blockfill_s[NONALIGNED] = blockfill_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[cu].blockfill_s[ALIGNED] = blockfill_hip<N, BLOCK_ ## N ## x ## N>; \
     } while (0)
 
 #define HIP_TU(N) do { \
         p.cu[BLOCK_ ## N ## x ## N].dct = dct_hip<N, BLOCK_ ## N ## x ## N>; \
         p.cu[BLOCK_ ## N ## x ## N].idct = idct_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[BLOCK_ ## N ## x ## N].cpy2Dto1D_shl = cpy2Dto1D_shl_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[BLOCK_ ## N ## x ## N].cpy2Dto1D_shr = cpy2Dto1D_shr_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[BLOCK_ ## N ## x ## N].cpy1Dto2D_shl[NONALIGNED] = cpy1Dto2D_shl_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[BLOCK_ ## N ## x ## N].cpy1Dto2D_shl[ALIGNED] = cpy1Dto2D_shl_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[BLOCK_ ## N ## x ## N].cpy1Dto2D_shr = cpy1Dto2D_shr_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[BLOCK_ ## N ## x ## N].copy_cnt = copy_cnt_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[BLOCK_ ## N ## x ## N].count_nonzero = count_nonzero_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[BLOCK_ ## N ## x ## N].nonPsyRdoQuant = nonpsy_rdoq_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[BLOCK_ ## N ## x ## N].psyRdoQuant = psy_rdoq_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[BLOCK_ ## N ## x ## N].psyRdoQuant_1p = psy_rdoq_1p_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[BLOCK_ ## N ## x ## N].psyRdoQuant_2p = psy_rdoq_2p_hip<N, BLOCK_ ## N ## x ## N>; \
     } while (0)
 
 static void report_calls()
@@ -224,6 +376,15 @@ void setupAssemblyPrimitives(EncoderPrimitives& p, int /* cpuMask: CPU ISA bits,
     HIP_PU(32, 24); HIP_PU(24, 32); HIP_PU(32, 8);  HIP_PU(8, 32);  HIP_PU(64, 48); HIP_PU(48, 64);
     HIP_PU(64, 16); HIP_PU(16, 64);
 
+    // 4:2:0 chroma filters for every luma partition whose chroma block is at least 4 wide and 2 high... the reference has no
+    // 2xN / Nx2 filter kernels worth a launch, keep those on the C path
+    HIP_CHROMA420(8, 8);   HIP_CHROMA420(16, 16); HIP_CHROMA420(32, 32); HIP_CHROMA420(64, 64);
+    HIP_CHROMA420(16, 8);  HIP_CHROMA420(8, 16);  HIP_CHROMA420(32, 16); HIP_CHROMA420(16, 32);
+    HIP_CHROMA420(64, 32); HIP_CHROMA420(32, 64); HIP_CHROMA420(32, 24); HIP_CHROMA420(24, 32);
+    HIP_CHROMA420(32, 8);  HIP_CHROMA420(8, 32);  HIP_CHROMA420(64, 48); HIP_CHROMA420(48, 64);
+    HIP_CHROMA420(64, 16); HIP_CHROMA420(16, 64); HIP_CHROMA420(16, 12); HIP_CHROMA420(12, 16);
+    HIP_CHROMA420(8, 4);   HIP_CHROMA420(4, 8);   HIP_CHROMA420(16, 4);  HIP_CHROMA420(4, 16);
+
     HIP_CU(4); HIP_CU(8); HIP_CU(16); HIP_CU(32); HIP_CU(64);
     HIP_TU(4); HIP_TU(8); HIP_TU(16); HIP_TU(32);
     p.dst4x4 = dst4_hip;
@@ -232,6 +393,7 @@ void setupAssemblyPrimitives(EncoderPrimitives& p, int /* cpuMask: CPU ISA bits,
     p.nquant = nquant_hip;
     p.dequant_normal = dequant_normal_hip;
     p.dequant_scaling = dequant_scaling_hip;
+    p.denoiseDct = denoise_hip;
 }
 
 } // namespace X265_NS
