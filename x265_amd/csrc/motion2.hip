@@ -179,10 +179,15 @@ __device__ __forceinline__ Mv2 mv_clip2(Mv2 v, Mv2 lo, Mv2 hi)
 __device__ __forceinline__ bool mv_in_range2(Mv2 v, Mv2 lo, Mv2 hi) { return v.x >= lo.x && v.x <= hi.x && v.y >= lo.y && v.y <= hi.y; }
 __device__ __forceinline__ int sext2b(int v) { return (v & 2) ? (v | ~3) : v; }
 
-__device__ __constant__ const int8_t kHexB[8][2] = { {-1,-2}, {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2}, {-2,0} };   // motion.cpp:63
-__device__ __constant__ const uint8_t kMod6m1B[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };                                            // motion.cpp:64
-__device__ __constant__ const int8_t kSquareB[9][2] = { {0,0}, {0,-1}, {0,1}, {-1,0}, {1,0}, {-1,-1}, {-1,1}, {1,-1}, {1,1} }; // motion.cpp:65
 __device__ __constant__ const uint8_t kWorkloadB[8][5] = { {1,4,0,4,0}, {1,4,1,4,0}, {1,4,1,4,1}, {2,4,1,4,1}, {2,4,2,4,1}, {1,8,1,8,1}, {2,8,1,8,1}, {2,8,2,8,1} }; // motion.cpp:48-58
+
+// The search-pattern tables of motion.cpp:63-65 as packed nibbles (value + 8): a lookup is two VALU ops on a literal instead of
+// a dependent constant-memory load sitting on the serial chain (per lane in the SIMT row-team kernel).
+__device__ __forceinline__ int hex2xB(int i) { return (int)((0x679A9767u >> (4 * i)) & 15) - 8; }      // {-1,-2,-1,1,2,1,-1,-2}
+__device__ __forceinline__ int hex2yB(int i) { return (int)((0x8668AA86u >> (4 * i)) & 15) - 8; }      // {-2,0,2,2,0,-2,-2,0}
+__device__ __forceinline__ int mod6m1B(int i) { return (int)((0x05432105u >> (4 * i)) & 15); }          // {5,0,1,2,3,4,5,0}
+__device__ __forceinline__ int sq1xB(int i) { return (int)((0x997797888ull >> (4 * i)) & 15) - 8; }     // {0,0,0,-1,1,-1,-1,1,1}
+__device__ __forceinline__ int sq1yB(int i) { return (int)((0x979788978ull >> (4 * i)) & 15) - 8; }     // {0,-1,1,0,0,-1,1,-1,1}
 
 // ---- the team context ------------------------------------------------------------------------------------------------------
 template <typename P, int N, int WAVES, bool PLANES>
@@ -637,15 +642,15 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
             if (bcost & 7)
             {
                 int dir = (bcost & 7) - 2;
-                if (YOK(bmv.y + kHexB[dir + 1][1]))
+                if (YOK(bmv.y + hex2yB(dir + 1)))
                 {
-                    bmv.x += kHexB[dir + 1][0];
-                    bmv.y += kHexB[dir + 1][1];
+                    bmv.x += hex2xB(dir + 1);
+                    bmv.y += hex2yB(dir + 1);
                     for (int i = (merange >> 1) - 1; i > 0 && mv_in_range2(bmv, mvmin, mvmax); i--)
                     {
-                        const Mv2 cd[3] = { { bmv.x + kHexB[dir + 0][0], bmv.y + kHexB[dir + 0][1] },
-                                            { bmv.x + kHexB[dir + 1][0], bmv.y + kHexB[dir + 1][1] },
-                                            { bmv.x + kHexB[dir + 2][0], bmv.y + kHexB[dir + 2][1] } };
+                        const Mv2 cd[3] = { { bmv.x + hex2xB(dir + 0), bmv.y + hex2yB(dir + 0) },
+                                            { bmv.x + hex2xB(dir + 1), bmv.y + hex2yB(dir + 1) },
+                                            { bmv.x + hex2xB(dir + 2), bmv.y + hex2yB(dir + 2) } };
                         int cs[3];
                         c.template eval_sad<3>(cd, cs);
                         bcost &= ~7;
@@ -655,9 +660,9 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
                         if (!(bcost & 7))
                             break;
                         dir += (bcost & 7) - 2;
-                        dir = kMod6m1B[dir + 1];
-                        bmv.x += kHexB[dir + 1][0];
-                        bmv.y += kHexB[dir + 1][1];
+                        dir = mod6m1B(dir + 1);
+                        bmv.x += hex2xB(dir + 1);
+                        bmv.y += hex2yB(dir + 1);
                     }
                 }
             }
@@ -679,8 +684,8 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
                 if (YOK(bmv.y - 1) && costs[6] < bcost) { bcost = costs[6]; dir = 7; }
                 if (YOK(bmv.y + 1) && costs[7] < bcost) { bcost = costs[7]; dir = 8; }
             }
-            bmv.x += kSquareB[dir][0];
-            bmv.y += kSquareB[dir][1];
+            bmv.x += sq1xB(dir);
+            bmv.y += sq1yB(dir);
         }
         else if (method == 3)
             star_search(c, mvmin.x, mvmin.y, mvmax.x, mvmax.y, merange, bmv.x, bmv.y, bcost);  // X265_STAR_SEARCH (mestar.h)
@@ -737,7 +742,7 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
 #pragma unroll
                     for (int k = 0; k < 4; k++)
                     {
-                        q[k + 1] = Mv2{ bmv.x + kSquareB[1 + k][0] * 2, bmv.y + kSquareB[1 + k][1] * 2 };
+                        q[k + 1] = Mv2{ bmv.x + sq1xB(1 + k) * 2, bmv.y + sq1yB(1 + k) * 2 };
                         ok[k + 1] = !((q[k + 1].y < qmvmin.y) | (q[k + 1].y > qmvmax.y));
                     }
                     c.template eval_subpel<5>(q, ok, 1, cs);
@@ -748,8 +753,8 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
                         if (ok[k + 1] && cs[k + 1] < bcost) { bcost = cs[k + 1]; bdir = 1 + k; }
                     if (bdir)
                     {
-                        bmv.x += kSquareB[bdir][0] * 2;
-                        bmv.y += kSquareB[bdir][1] * 2;
+                        bmv.x += sq1xB(bdir) * 2;
+                        bmv.y += sq1yB(bdir) * 2;
                     }
                     firstDone = true;
                     if (!bdir)
@@ -767,7 +772,7 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
                     Mv2 q[4]; bool ok[4]; int cs[4]; \
                     _Pragma("unroll") for (int k = 0; k < 4; k++) \
                     { \
-                        q[k] = Mv2{ bmv.x + kSquareB[d0 + k][0] * (STEP), bmv.y + kSquareB[d0 + k][1] * (STEP) }; \
+                        q[k] = Mv2{ bmv.x + sq1xB(d0 + k) * (STEP), bmv.y + sq1yB(d0 + k) * (STEP) }; \
                         ok[k] = !((q[k].y < qmvmin.y) | (q[k].y > qmvmax.y)); \
                     } \
                     c.template eval_subpel<4>(q, ok, (CMP), cs); \
@@ -776,8 +781,8 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
                 } \
                 if (bdir) \
                 { \
-                    bmv.x += kSquareB[bdir][0] * (STEP); \
-                    bmv.y += kSquareB[bdir][1] * (STEP); \
+                    bmv.x += sq1xB(bdir) * (STEP); \
+                    bmv.y += sq1yB(bdir) * (STEP); \
                 } \
                 else \
                     break; \

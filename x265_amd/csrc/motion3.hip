@@ -50,10 +50,15 @@ __device__ __forceinline__ int row_allsum(int v)
     return v;
 }
 
-__device__ __constant__ const int8_t kHexC[8][2] = { {-1,-2}, {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2}, {-2,0} };   // motion.cpp:63
-__device__ __constant__ const uint8_t kMod6m1C[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };                                            // motion.cpp:64
-__device__ __constant__ const int8_t kSquareC[9][2] = { {0,0}, {0,-1}, {0,1}, {-1,0}, {1,0}, {-1,-1}, {-1,1}, {1,-1}, {1,1} }; // motion.cpp:65
 __device__ __constant__ const uint8_t kWorkloadC[8][5] = { {1,4,0,4,0}, {1,4,1,4,0}, {1,4,1,4,1}, {2,4,1,4,1}, {2,4,2,4,1}, {1,8,1,8,1}, {2,8,1,8,1}, {2,8,2,8,1} }; // motion.cpp:48-58
+
+// The search-pattern tables of motion.cpp:63-65 as packed nibbles (value + 8): a lookup is two VALU ops on a literal instead of
+// a dependent constant-memory load sitting on the serial chain (per lane in the SIMT row-team kernel).
+__device__ __forceinline__ int hex2xC(int i) { return (int)((0x679A9767u >> (4 * i)) & 15) - 8; }      // {-1,-2,-1,1,2,1,-1,-2}
+__device__ __forceinline__ int hex2yC(int i) { return (int)((0x8668AA86u >> (4 * i)) & 15) - 8; }      // {-2,0,2,2,0,-2,-2,0}
+__device__ __forceinline__ int mod6m1C(int i) { return (int)((0x05432105u >> (4 * i)) & 15); }          // {5,0,1,2,3,4,5,0}
+__device__ __forceinline__ int sq1xC(int i) { return (int)((0x997797888ull >> (4 * i)) & 15) - 8; }     // {0,0,0,-1,1,-1,-1,1,1}
+__device__ __forceinline__ int sq1yC(int i) { return (int)((0x979788978ull >> (4 * i)) & 15) - 8; }     // {0,-1,1,0,0,-1,1,-1,1}
 
 // sum over the team: a 16-lane row (DPP only) or the whole wave (row all-reduce + 4 readlanes; the wave is then one PU and
 // its control flow is uniform)
@@ -290,15 +295,15 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
         if (bcost & 7)
         {
             int dir = (bcost & 7) - 2;
-            if (YOK(bmv.y + kHexC[dir + 1][1]))
+            if (YOK(bmv.y + hex2yC(dir + 1)))
             {
-                bmv.x += kHexC[dir + 1][0];
-                bmv.y += kHexC[dir + 1][1];
+                bmv.x += hex2xC(dir + 1);
+                bmv.y += hex2yC(dir + 1);
                 for (int i = (merange >> 1) - 1; i > 0 && mv_in3(bmv, mvmin, mvmax); i--)
                 {
-                    const Mv3 a = { bmv.x + kHexC[dir + 0][0], bmv.y + kHexC[dir + 0][1] };
-                    const Mv3 b = { bmv.x + kHexC[dir + 1][0], bmv.y + kHexC[dir + 1][1] };
-                    const Mv3 d = { bmv.x + kHexC[dir + 2][0], bmv.y + kHexC[dir + 2][1] };
+                    const Mv3 a = { bmv.x + hex2xC(dir + 0), bmv.y + hex2yC(dir + 0) };
+                    const Mv3 b = { bmv.x + hex2xC(dir + 1), bmv.y + hex2yC(dir + 1) };
+                    const Mv3 d = { bmv.x + hex2xC(dir + 2), bmv.y + hex2yC(dir + 2) };
                     const int c0 = FULLPEL(a.x, a.y), c1 = FULLPEL(b.x, b.y), c2 = FULLPEL(d.x, d.y);
                     bcost &= ~7;
                     if (YOK(a.y)) LT1((c0 << 3) + 1);
@@ -307,9 +312,9 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
                     if (!(bcost & 7))
                         break;
                     dir += (bcost & 7) - 2;
-                    dir = kMod6m1C[dir + 1];
-                    bmv.x += kHexC[dir + 1][0];
-                    bmv.y += kHexC[dir + 1][1];
+                    dir = mod6m1C(dir + 1);
+                    bmv.x += hex2xC(dir + 1);
+                    bmv.y += hex2yC(dir + 1);
                 }
             }
         }
@@ -328,8 +333,8 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
             if (YOK(bmv.y - 1) && c6 < bcost) { bcost = c6; dir = 7; }
             if (YOK(bmv.y + 1) && c7 < bcost) { bcost = c7; dir = 8; }
         }
-        bmv.x += kSquareC[dir][0];
-        bmv.y += kSquareC[dir][1];
+        bmv.x += sq1xC(dir);
+        bmv.y += sq1yC(dir);
     }
     else if (method == 3)
         star_search(c, mvmin.x, mvmin.y, mvmax.x, mvmax.y, merange, bmv.x, bmv.y, bcost);      // X265_STAR_SEARCH (mestar.h)
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
             int bdir = 0;
             for (int i = 1; i <= hpelDirs; i++)
             {
-                const Mv3 q = { bmv.x + kSquareC[i][0] * 2, bmv.y + kSquareC[i][1] * 2 };
+                const Mv3 q = { bmv.x + sq1xC(i) * 2, bmv.y + sq1yC(i) * 2 };
                 if ((q.y < qmvmin.y) | (q.y > qmvmax.y))
                     continue;
                 const int cst = c.cmp_q(q, hpelcomp) + c.mvcost(q.x, q.y);
@@ -387,8 +392,8 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
             }
             if (bdir)
             {
-                bmv.x += kSquareC[bdir][0] * 2;
-                bmv.y += kSquareC[bdir][1] * 2;
+                bmv.x += sq1xC(bdir) * 2;
+                bmv.y += sq1yC(bdir) * 2;
             }
             else
                 break;
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
             int bdir = 0;
             for (int i = 1; i <= qpelDirs; i++)
             {
-                const Mv3 q = { bmv.x + kSquareC[i][0], bmv.y + kSquareC[i][1] };
+                const Mv3 q = { bmv.x + sq1xC(i), bmv.y + sq1yC(i) };
                 if ((q.y < qmvmin.y) | (q.y > qmvmax.y))
                     continue;
                 const int cst = c.satd_q(q) + c.mvcost(q.x, q.y);
@@ -408,8 +413,8 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
             }
             if (bdir)
             {
-                bmv.x += kSquareC[bdir][0];
-                bmv.y += kSquareC[bdir][1];
+                bmv.x += sq1xC(bdir);
+                bmv.y += sq1yC(bdir);
             }
             else
                 break;
