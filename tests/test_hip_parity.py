@@ -435,3 +435,43 @@ def test_misc_batches(hipmod, depth):
             if not (np.array_equal(ga[:m], wa[:m]) and np.array_equal(gcu[:tmax], wcu[:tmax]) and np.array_equal(ga, b.get())):
                 bad.append("rdoq kind%d %d" % (kind, size))
     _report(bad, 1)
+
+
+def test_twelve_bit_primitives_match_oracle(hipmod):
+    """depth 12 (u16 pixels, the third X265_DEPTH): same sweep against the oracle restatement (the real-reference pin covers
+    8 and 10 bit; the 12-bit arithmetic differs only in the shift / clip constants the oracle derives from `depth`)."""
+    o, g = Orc(12), hipmod.Hip(12)
+    bad, n = [], 0
+    for label, fn, args in gen_cases(12, seed=777, reps=1):
+        if fn in NOT_ON_GPU:
+            continue
+        want = getattr(o, fn)(*args)
+        got = getattr(g, fn)(*args)
+        hipmod._release()
+        n += 1
+        if not same(got, want):
+            bad.append(label)
+    assert n > 1500
+    _report(bad, n)
+
+
+def test_empty_batches_and_bad_arguments(hipmod):
+    """n = 0 is a no-op that succeeds; impossible shapes / depths are rejected with X265HIP_EINVAL and a message."""
+    from x265_amd import hipprim as hp
+    L = hp.lib()
+    assert L.x265hip_pixcmp_batch(hp.CMP_SAD, 8, 8, 8, None, 0, None, 0, None, None, 0, None, None) == 0
+    assert L.x265hip_dct_batch(32, 0, 8, None, 32, None, None, 0, None) == 0
+    assert L.x265hip_quant_batch(None, None, None, None, 20, 1, 64, 0, None, None) == 0
+    assert L.x265hip_motion_estimate_batch(8, 16, 16, None, 0, None, 0, None, None, None, None, 0, None, 57, 1, 2, None, 65536, 0, None, None, None) == 0
+    assert L.x265hip_residual_chain_batch(32, 8, None, 0, None, 0, None, 0, None, None, None, None, 20, 1, 40, 1, None, None, None, 0, None) == 0
+    assert L.x265hip_pixcmp_batch(hp.CMP_SAD, 9, 8, 8, None, 0, None, 0, None, None, 1, None, None) == -1      # depth 9
+    assert b"depth" in L.x265hip_last_error()
+    assert L.x265hip_pixcmp_batch(hp.CMP_SA8D, 8, 16, 8, None, 0, None, 0, None, None, 1, None, None) == -1    # sa8d is square
+    assert L.x265hip_dct_batch(64, 0, 8, None, 64, None, None, 1, None) == -1                                  # no 64-point transform
+    assert L.x265hip_dct_batch(8, 1, 8, None, 8, None, None, 1, None) == -1                                    # DST is 4x4 only
+    assert L.x265hip_motion_estimate_batch(8, 4, 4, None, 0, None, 0, None, None, None, None, 0, None, 57, 1, 2, None, 65536, 1, None, None, None) == -1
+    assert L.x265hip_motion_estimate_batch(8, 8, 8, None, 0, None, 0, None, None, None, None, 0, None, 57, 2, 2, None, 65536, 1, None, None, None) == -1   # UMH
+    assert L.x265hip_interp_batch(hp.IF_HVPP, 4, 8, 8, 8, None, 0, None, 0, None, None, None, 0, 1, None) == -1          # hv_pp is a luma slot
+    from x265_amd.framepass import FramePass
+    with pytest.raises(hp.HipError):
+        FramePass(1921, 1080)                                                                                  # not a multiple of 8
