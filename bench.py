@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 
 W, H, DEPTH, QP, MERANGE, SUBME = 1920, 1080, 8, 28, 57, 2
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-STAGES = ["planes", "me64", "me32", "me16", "me8", "pred8", "chain32", "chain8", "sa8d", "border"]
+STAGES = ["planes", "me64", "me32", "me16", "me8", "pred8", "chain32", "chain8", "sa8d", "chroma", "border"]
 
 
 def cpu_baseline(frames):
@@ -78,7 +78,7 @@ def pmc_traffic(stage):
     names = {"planes": "subpel_planes_kernel", "me64": "motion2_kernel<unsigned char, 64", "me32": "motion3_kernel<unsigned char, 32",
              "me16": "motion3_kernel<unsigned char, 16", "me8": "motion3_kernel<unsigned char, 8", "pred8": "pred_from_planes_kernel",
              "chain32": "residual_chain_kernel<unsigned char, 32", "chain8": "residual_chain_kernel<unsigned char, 8",
-             "sa8d": "sa8d_levels_kernel", "border": "extend_border_kernel"}
+             "sa8d": "sa8d_levels_kernel", "border": "extend_border_kernel", "chroma": "pred_chroma_kernel"}
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_bytes.txt")))
     if not files:
@@ -110,8 +110,6 @@ def main():
     import torch.distributed as dist
     from x265_amd import hipprim as hp
     from x265_amd.framepass import FramePass, MARGIN, algorithmic_bytes
-    from x265_amd.synth import make_scene
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,15 +132,30 @@ def main():
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream().cuda_stream or None
 
-    # ---- synthetic input resident in HBM: a pool of source frames per rank + the first reference
+    # ---- synthetic 4:2:0 input resident in HBM: a pool of source pictures per rank + the first reference.  A picture is ONE flat
+    # u8 tensor [Y | Cb | Cr] (padded planes back to back) so the reference exchange is a single send/recv.
+    from x265_amd.framepass import YuvStruct
+    from x265_amd.synth import make_scene_yuv
     S, R = W + 2 * MARGIN, H + 2 * MARGIN
+    MC = MARGIN // 2
+    SC, RC = W // 2 + 2 * MC, H // 2 + 2 * MC
+    YB, CB = S * R, SC * RC
+
+    def flat(y, cb, cr):
+        parts = [np.pad(y, MARGIN, mode="edge"), np.pad(cb, MC, mode="edge"), np.pad(cr, MC, mode="edge")]
+        return torch.from_numpy(np.concatenate([np.ascontiguousarray(p).reshape(-1) for p in parts])).to(dev)
+
+    def yuv(t):
+        b = t.data_ptr()
+        return YuvStruct(b + MARGIN * S + MARGIN, b + YB + MC * SC + MC, b + YB + CB + MC * SC + MC, S, SC)
+
     NPOOL = 4
     pool, ref0 = [], None
     for i in range(NPOOL):
-        sc = make_scene(W, H, depth=DEPTH, seed=4321 + 17 * rank + i)
-        pool.append(torch.from_numpy(np.ascontiguousarray(np.pad(sc["src"], MARGIN, mode="edge"))).to(dev))
+        sc = make_scene_yuv(W, H, depth=DEPTH, seed=4321 + 17 * rank + i)
+        pool.append(flat(sc["src"], sc["src_cb"], sc["src_cr"]))
         if i == 0:
-            ref0 = torch.from_numpy(np.ascontiguousarray(np.pad(sc["ref"], MARGIN, mode="edge"))).to(dev)
+            ref0 = flat(sc["ref"], sc["ref_cb"], sc["ref_cr"])
     from x265_amd.exchange import ReferenceRing
     # F frame chains per GPU (x265 runs several frame encoders per device the same way): chain j of rank g encodes frames
     # (step * N + g) * F + j; its reference is the reconstruction chain j-1 produced one step earlier (chain 0 takes the last
@@ -153,11 +166,14 @@ def main():
     preds = [torch.zeros_like(ref0) for _ in range(F)]
     recons = [[torch.empty_like(ref0), torch.empty_like(ref0)] for _ in range(F)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(F)] if F > 1 else [None]
-    org = lambda t: t.data_ptr() + MARGIN * S + MARGIN            # noqa: E731  (8-bit: 1 byte per pixel)
     fps_ = [FramePass(W, H, depth=DEPTH, qp=QP, merange=MERANGE, method=hp.HEX_SEARCH, subme=SUBME) for _ in range(F)]
     fp = fps_[0]
 
     state = {"refs": [ring.current] + [ref0] * (F - 1), "k": 0}
+
+    def run_pass(h, src, ref, pred, rec, sh):
+        a, b, c, d = yuv(src), yuv(ref), yuv(pred), yuv(rec)
+        hp.check(L.x265hip_framepass_run_yuv(h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), MARGIN, MARGIN, sh))
 
     def step():
         k = state["k"]
@@ -171,7 +187,7 @@ def main():
                 sh = streams[j].cuda_stream
             else:
                 sh = stream
-            hp.check(L.x265hip_framepass_run(fps_[j].h, org(src), S, org(state["refs"][j]), S, org(preds[j]), S, org(rec), S, MARGIN, MARGIN, sh))
+            run_pass(fps_[j].h, src, state["refs"][j], preds[j], rec, sh)
         for j in range(F):
             if streams[j] is not None:
                 cur.wait_stream(streams[j])
@@ -182,8 +198,7 @@ def main():
 
     def profile_step():
         k = state["k"]
-        rec = recons[0][k & 1]
-        hp.check(L.x265hip_framepass_run(fp.h, org(pool[k % NPOOL]), S, org(state["refs"][0]), S, org(preds[0]), S, org(rec), S, MARGIN, MARGIN, stream))
+        run_pass(fp.h, pool[k % NPOOL], state["refs"][0], preds[0], recons[0][k & 1], stream)
         state["k"] = k + 1
 
     def fence():
@@ -208,9 +223,9 @@ def main():
 
     # ---- roofline of the dominant kernel: same workload, same stream, HIP events at the stage boundaries
     hp.check(L.x265hip_framepass_set_profiling(fp.h, 1))
-    acc = np.zeros(10)
+    acc = np.zeros(11)
     nprof = max(10, min(args.steps, 50))
-    ms9 = (C.c_float * 10)()
+    ms9 = (C.c_float * 11)()
     for _ in range(nprof):
         profile_step()
         hp.check(L.x265hip_framepass_stage_ms(fp.h, ms9))
@@ -236,7 +251,8 @@ def main():
             dom_bytes = 17 * S_ * R_                       # read the padded reference once, write 16 planes
             kernel = "subpel_planes_kernel<u8> (16 quarter-pel planes of the padded reference)"
         else:
-            dom_bytes = {"pred8": ab["pred"], "chain32": ab["chain"], "chain8": ab["chain"], "sa8d": ab["sa8d"], "border": ab["border"]}[dom]
+            dom_bytes = {"pred8": ab["pred"], "chain32": ab["chain"], "chain8": ab["chain"], "sa8d": ab["sa8d"], "border": ab["border"],
+                         "chroma": ab["chain"] // 2 + ab["pred"] // 2}[dom]
             kernel = dom
         achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(dom)
@@ -244,11 +260,11 @@ def main():
             "metric": "encode fps (1080p preset medium hot path: frame passes per second)", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "1920x1080 8-bit, --me hex --merange 57 --subme 2, qp 28: frame pass = top-down 2Nx2N motion search "
-                                   "(64/32/16/8) + predInterLuma + dct/quant/dequant/idct/recon/sse chain + sa8d + border extension; "
+            "config": {"workload": "1920x1080 8-bit 4:2:0, --me hex --merange 57 --subme 2, qp 28: frame pass = quarter-pel planes + top-down 2Nx2N "
+                                   "motion search (64/32/16/8) + luma/chroma prediction + dct/quant/dequant/idct/recon/sse chain (Y, Cb, Cr) + sa8d + borders; "
                                    "F independent frame passes per GPU per step on F streams (x265 frame threads), each referencing the previous chain's recon; "
                                    "the last chain's recon goes to the next rank (RCCL send/recv) when N > 1",
-                       "frames_per_step": world * F, "frames_in_flight_per_gpu": F, "pus_per_frame": 42900, "tus_per_frame": 2700},
+                       "frames_per_step": world * F, "frames_in_flight_per_gpu": F, "pus_per_frame": 42900, "tus_per_frame": 8100},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": stage_ms[dom]},

@@ -202,6 +202,12 @@ int x265hip_set_search_range_batch(int picW, int picH, int maxCUSize, int merang
  * copy_pp / luma_hpp / luma_vpp / luma_hvpp selected by the fractional parts. */
 int x265hip_pred_inter_luma_batch(int depth, int w, int h, const void* refPlane, int64_t strideR, void* dst, int64_t strideD,
                                   const int32_t* pu_xy, const int32_t* qmv, int n, void* stream);
+/* Predict::predInterChromaPixel (reference: source/common/predict.cpp:306-352) for n 4:2:0 PUs of luma size lumaW x lumaH (a
+ * multiple of 8 wide): Cb and Cr prediction of PU i (luma position pu_xy[i], quarter-pel vector qmv[i] = eighth-pel chroma
+ * vector) written at the PU's chroma position: copy / filter_hpp / filter_vpp / filter_hps + filter_vsp by the fractions. */
+int x265hip_pred_inter_chroma_batch(int depth, int lumaW, int lumaH, const void* refCb, const void* refCr, int64_t strideR,
+                                    void* dstCb, void* dstCr, int64_t strideD, const int32_t* pu_xy, const int32_t* qmv, int n,
+                                    void* stream);
 /* Picture border extension (reference: source/common/pixel.cpp:1027-1041 extendPicBorder, margins picyuv.cpp:87-115):
  * replicates the edge pixels of the picW x picH picture at picOrigin into marginX / marginY pixels all around. */
 int x265hip_extend_border(int depth, void* picOrigin, int64_t stride, int picW, int picH, int marginX, int marginY, void* stream);
@@ -240,8 +246,16 @@ int x265hip_framepass_create(int width, int height, int depth, int qp, int meran
 int x265hip_framepass_destroy(x265hip_framepass* fp);
 int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t strideS, const void* ref, int64_t strideR,
                           void* pred, int64_t strideP, void* recon, int64_t strideRec, int marginX, int marginY, void* stream);
+/* The same pass on a 4:2:0 picture: additionally Predict::predInterChromaPixel (predict.cpp:306-352) from the 8x8 vectors and
+ * the residual chain on Cb and Cr (16x16 TUs under the 32x32 luma TUs, 4x4 under the 8x8 ones) with the chroma QpParam of
+ * Quant::setChromaQP (quant.cpp:233-243), and border extension of the chroma reconstruction.  Plane pointers address pixel
+ * (0,0); chroma margins are marginX/2, marginY/2. */
+typedef struct x265hip_yuv { void* y; void* cb; void* cr; int64_t strideY; int64_t strideC; } x265hip_yuv;
+int x265hip_framepass_run_yuv(x265hip_framepass* fp, const x265hip_yuv* src, const x265hip_yuv* ref, const x265hip_yuv* pred,
+                              const x265hip_yuv* recon, int marginX, int marginY, void* stream);
 /* device pointers to the results of the last run (owned by fp).  `level`: 0..3 = CU size 64, 32, 16, 8 for the ME
- * outputs; 0..1 = TU size 32, 8 for the transform outputs.  *count = number of PUs / TUs. */
+ * outputs; for the transform outputs 0..1 = luma TU size 32, 8 and (after run_yuv) 2..3 = Cb 16x16, 4x4, 4..5 = Cr 16x16, 4x4.
+ * *count = number of PUs / TUs. */
 #define X265HIP_FP_PU_XY     0   /* int32 [n][2]                         */
 #define X265HIP_FP_MV        1   /* int32 [n][2] quarter-pel             */
 #define X265HIP_FP_MECOST    2   /* int32 [n]                            */
@@ -252,11 +266,12 @@ int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t stride
 #define X265HIP_FP_DIST      7   /* uint64 [n]                           */
 int x265hip_framepass_output(x265hip_framepass* fp, int which, int level, void** devPtr, int* count);
 /* Stage timing with HIP events on the run's own stream.  After set_profiling(fp, 1) every run records an event at each
- * stage boundary; stage_ms() waits for the last run and returns the 10 stage durations in ms:
- * [0] quarter-pel planes, [1..4] motion search of CU size 64/32/16/8 (setSearchRange + motionEstimate), [5] prediction,
- * [6] 32x32 residual chain, [7] 8x8 residual chain, [8] sa8d of the four CU sizes, [9] border extension. */
+ * stage boundary; stage_ms() waits for the last run and returns the 11 stage durations in ms:
+ * [0] quarter-pel planes, [1..4] motion search of CU size 64/32/16/8 (setSearchRange + motionEstimate), [5] luma prediction,
+ * [6] 32x32 residual chain, [7] 8x8 residual chain, [8] sa8d of the four CU sizes, [9] chroma prediction + chroma chains
+ * (0 for the luma-only pass), [10] border extension. */
 int x265hip_framepass_set_profiling(x265hip_framepass* fp, int enable);
-int x265hip_framepass_stage_ms(x265hip_framepass* fp, float* ms10);
+int x265hip_framepass_stage_ms(x265hip_framepass* fp, float* ms11);
 
 /* ---------------------------------------------------------------- per-call entry points (host pointers) ----- */
 /* What the reference-side table shims bind (x265_amd/host/x265_hip_primitives.cpp).  Arguments are the slot's own

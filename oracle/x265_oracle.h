@@ -101,7 +101,12 @@ void orc_extend_border_##SFX(P* pic, intptr_t stride, int picW, int picH, int mx
 void orc_frame_pass_##SFX(int width, int height, int depth, int qp, int merange, int method, int subme, \
                           const P* src, intptr_t ss, const P* ref, intptr_t rs, P* pred, intptr_t ps, P* recon, intptr_t cs, \
                           int marginX, int marginY, int32_t* mv[4], int32_t* mecost[4], int32_t* sa8d[4], \
-                          int16_t* level[2], uint32_t* numSig[2], uint64_t* dist[2]);
+                          int16_t* level[2], uint32_t* numSig[2], uint64_t* dist[2], \
+                          const P* const srcC[2], const P* const refC[2], P* const predC[2], P* const reconC[2], \
+                          intptr_t ssC, intptr_t rsC, intptr_t psC, intptr_t csC, \
+                          int16_t* clevel[4], uint32_t* cnumSig[4], uint64_t* cdist[4]); \
+/* common/predict.cpp:306 Predict::predInterChromaPixel (4:2:0) */ \
+void orc_pred_inter_chroma_##SFX(const P* ref, intptr_t rs, P* dst, intptr_t ds, int bx, int by, int lumaW, int lumaH, int qx, int qy, int depth);
 ORC_DECL_FRAME(uint8_t, 8)
 ORC_DECL_FRAME(uint16_t, 16)
 

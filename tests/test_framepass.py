@@ -4,7 +4,7 @@ two-frame chain where the second frame searches the first frame's border-extende
 import numpy as np
 import pytest
 
-from frame_oracle import make_scene, oracle_frame_pass, same_results
+from frame_oracle import make_scene, make_scene_yuv, oracle_frame_pass, same_results
 
 pytestmark = pytest.mark.gpu
 
@@ -142,3 +142,45 @@ def test_8k_frame_pass_properties(fpmod):
     mv16 = a["mv"][2].reshape(h // 16, w // 16, 2)
     inner = mv16[4:-4, 4:-4].reshape(-1, 2)
     assert (inner == np.array([12, -8])).all(axis=1).mean() > 0.999
+
+
+@pytest.mark.parametrize("w,h,depth,qp,subme", [(200, 136, 8, 28, 2), (200, 136, 10, 33, 3), (328, 200, 8, 40, 2), (1920, 1080, 8, 28, 2)])
+def test_yuv_frame_pass_is_bit_exact(fpmod, w, h, depth, qp, subme):
+    """4:2:0 pass: chroma prediction (predInterChromaPixel), chroma residual chain (16x16 / 4x4 TUs, chroma QpParam), chroma recon
+    borders — on top of the luma pass, every output against the C restatement."""
+    sc = make_scene_yuv(w, h, depth=depth, seed=21 + qp, tile=48 if w < 1000 else 96, sigma=3.0 * (1 if depth == 8 else 4))
+    fp = fpmod.FramePass(w, h, depth=depth, qp=qp, subme=subme)
+    got = fp.run_host_yuv(sc)
+    want = oracle_frame_pass(sc["src"], sc["ref"], depth=depth, qp=qp, subme=subme, src_c=(sc["src_cb"], sc["src_cr"]), ref_c=(sc["ref_cb"], sc["ref_cr"]))
+    assert same_results(got, want) == []
+    assert sum(int(x.sum()) for x in want["cnumSig"]) > 0
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_pred_inter_chroma_matches_oracle(fpmod, depth):
+    from oracle import pyoracle as po
+    from x265_amd import hipprim as hp
+    from x265_amd.hipprim import DevBuf, check, dev_i32
+    L, O = hp.lib(), po.oracle()
+    rng = np.random.default_rng(31 + depth)
+    H, W = 120, 160                                             # chroma plane incl. margins; luma coordinates are twice that
+    refs = [rng.integers(0, 1 << depth, size=(H, W)).astype(hp.pix_dtype(depth)) for _ in range(2)]
+    fn = getattr(O, "orc_pred_inter_chroma_%s" % po.sfx(depth))
+    fn.restype, fn.argtypes = None, [po.vp, po.ip, po.vp, po.ip] + [po.i32] * 7
+    for (lw, lh) in [(8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 24), (24, 32), (64, 48), (8, 32)]:
+        n = 19
+        bx = (rng.integers(12, W - 12 - lw // 2, n)) * 2
+        by = (rng.integers(12, H - 12 - lh // 2, n)) * 2
+        mv = rng.integers(-60, 61, size=(n, 2)).astype(np.int32)
+        bad = []
+        for i in range(n):
+            dref = [DevBuf(r) for r in refs]
+            dd = [DevBuf.zeros((H, W), refs[0].dtype) for _ in range(2)]
+            xy, q = dev_i32([int(bx[i]), int(by[i])]), dev_i32(mv[i])
+            check(L.x265hip_pred_inter_chroma_batch(depth, lw, lh, dref[0].ptr, dref[1].ptr, W, dd[0].ptr, dd[1].ptr, W, xy.ptr, q.ptr, 1, None))
+            for pl in range(2):
+                want = np.zeros((H, W), refs[0].dtype)
+                fn(po.ptr(refs[pl]), W, po.ptr(want), W, int(bx[i]), int(by[i]), lw, lh, int(mv[i, 0]), int(mv[i, 1]), depth)
+                if not np.array_equal(dd[pl].get(), want):
+                    bad.append((lw, lh, i, pl))
+        assert not bad, bad[:5]

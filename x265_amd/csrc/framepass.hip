@@ -26,17 +26,30 @@ struct x265hip_framepass
     uint16_t* mvcost;              // device, 4*32768+1 entries
     int32_t* quantCoeff[2];        // flat scaling: quantScales[qp % 6] (scalinglist.cpp:129)
     std::vector<int32_t> hCuXY[4], hTuXY[2];
+    // chroma (4:2:0) TU classes: 16x16 under every 32x32 luma TU, 4x4 under every 8x8 luma TU; one set of outputs per plane
+    int32_t *ctuOffF[2], *ctuOffP[2], *ctuOffR[2];       // [class][2n]: Cb TUs then Cr TUs, Cr addressed from the Cb base pointer
+    int64_t cStrideF, cStrideP, cStrideR, cDeltaF, cDeltaP, cDeltaR;
+    int16_t* clevel[2][2];         // [plane Cb/Cr][class]
+    uint32_t* cnumSig[2][2];
+    uint64_t* cdist[2][2];
+    int32_t* cquantCoeff[2];
+    std::vector<int32_t> hCtuXY[2];
     void* planes;                  // 16 sub-pel planes of the current reference (device), sized on first run
     int64_t planeElems, planeStride;
     int planeMarginX, planeMarginY;
     bool profile;                  // record a HIP event at every stage boundary of run()
-    hipEvent_t ev[11];
+    hipEvent_t ev[12];
 };
 
 namespace xh {
 
 static const int kCuSize[4] = { 64, 32, 16, 8 };
 static const int kTuSize[2] = { 32, 8 };
+static const int kCTuSize[2] = { 16, 4 };
+// g_chromaScale (reference: common/constants.cpp:346-350), 4:2:0 chroma QP mapping
+static const uint8_t kChromaScale[70] = {
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 33, 33, 34, 34, 35,
+    35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51, 51 };
 static const int kMvHalf = 2 * 32768;
 
 template <typename T>
@@ -105,7 +118,7 @@ int x265hip_framepass_create(int width, int height, int depth, int qp, int meran
     fp->planes = nullptr;
     fp->planeElems = fp->planeStride = 0;
     fp->planeMarginX = fp->planeMarginY = 0;
-    for (int i = 0; i < 11; i++)
+    for (int i = 0; i < 12; i++)
         FP_TRY(check_hip(hipEventCreate(&fp->ev[i]), "hipEventCreate(framepass)"));
     for (int l = 0; l < 4; l++)
     {
@@ -154,9 +167,34 @@ int x265hip_framepass_create(int width, int height, int depth, int qp, int meran
         FP_TRY(dev_alloc(&fp->level[t], (size_t)n * nc));
         FP_TRY(dev_alloc(&fp->numSig[t], (size_t)n));
         FP_TRY(dev_alloc(&fp->dist[t], (size_t)n));
-        std::vector<int32_t> qc(nc, quantScales[qp % 6]);
+        std::vector<int32_t> qc(nc, quantScales[(qp + 6 * (depth - 8)) % 6]);       // QpParam: qp + QP_BD_OFFSET (quant.cpp:224)
         FP_TRY(dev_upload(&fp->quantCoeff[t], qc));
         fp->tuOffF[t] = fp->tuOffP[t] = fp->tuOffR[t] = nullptr;
+    }
+    // chroma TUs mirror the luma TU lists at half resolution; QpParam of chroma: Quant::setChromaQP (quant.cpp:233-243)
+    {
+        const int bd = 6 * (depth - 8);
+        int qpc = qp < -bd ? -bd : (qp > 57 ? 57 : qp);
+        if (qpc >= 30) qpc = kChromaScale[qpc];
+        qpc += bd;
+        for (int t = 0; t < 2; t++)
+        {
+            for (size_t i = 0; i < fp->hTuXY[t].size(); i++)
+                fp->hCtuXY[t].push_back(fp->hTuXY[t][i] >> 1);
+            const int n = fp->nTu[t], nc = kCTuSize[t] * kCTuSize[t];
+            std::vector<int32_t> qc(nc, quantScales[qpc % 6]);
+            FP_TRY(dev_upload(&fp->cquantCoeff[t], qc));
+            // Cb and Cr outputs are one allocation each ([2n]: Cb then Cr) so both planes go through ONE chain launch
+            FP_TRY(dev_alloc(&fp->clevel[0][t], (size_t)2 * n * nc));
+            FP_TRY(dev_alloc(&fp->cnumSig[0][t], (size_t)2 * n));
+            FP_TRY(dev_alloc(&fp->cdist[0][t], (size_t)2 * n));
+            fp->clevel[1][t] = fp->clevel[0][t] + (size_t)n * nc;
+            fp->cnumSig[1][t] = fp->cnumSig[0][t] + n;
+            fp->cdist[1][t] = fp->cdist[0][t] + n;
+            fp->ctuOffF[t] = fp->ctuOffP[t] = fp->ctuOffR[t] = nullptr;
+        }
+        fp->cStrideF = fp->cStrideP = fp->cStrideR = -1;
+        fp->cDeltaF = fp->cDeltaP = fp->cDeltaR = 0;
     }
     std::vector<uint16_t> tab(2 * kMvHalf + 1);
     FP_TRY(x265hip_mvcost_table(qp, depth, tab.data(), kMvHalf));
@@ -178,15 +216,25 @@ int x265hip_framepass_destroy(x265hip_framepass* fp)
         void* ptrs[] = { fp->tuXY[t], fp->tuOffF[t], fp->tuOffP[t], fp->tuOffR[t], fp->level[t], fp->numSig[t], fp->dist[t], fp->quantCoeff[t] };
         for (void* p : ptrs) if (p) (void)hipFree(p);
     }
+    for (int t = 0; t < 2; t++)
+    {
+        void* ptrs[] = { fp->ctuOffF[t], fp->ctuOffP[t], fp->ctuOffR[t], fp->cquantCoeff[t], fp->clevel[0][t], fp->cnumSig[0][t], fp->cdist[0][t] };
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+    }
     if (fp->mvcost) (void)hipFree(fp->mvcost);
     if (fp->planes) (void)hipFree(fp->planes);
-    for (int i = 0; i < 11; i++) (void)hipEventDestroy(fp->ev[i]);
+    for (int i = 0; i < 12; i++) (void)hipEventDestroy(fp->ev[i]);
     delete fp;
     return X265HIP_OK;
 }
 
-int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t strideS, const void* ref, int64_t strideR,
-                          void* pred, int64_t strideP, void* recon, int64_t strideRec, int marginX, int marginY, void* stream)
+} // extern "C"
+
+struct ChromaArgs { const void *srcCb, *srcCr, *refCb, *refCr; void *predCb, *predCr, *recCb, *recCr; int64_t sS, sR, sP, sRec; };
+
+static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t strideS, const void* ref, int64_t strideR,
+                              void* pred, int64_t strideP, void* recon, int64_t strideRec, int marginX, int marginY, const ChromaArgs* ca,
+                              void* stream)
 {
     XH_CHECK_DEV();
     if (!fp || !src || !ref || !pred || !recon)
@@ -253,7 +301,7 @@ int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t stride
     // 2. prediction from the 8x8 vectors
     FP_TRY(pred_from_planes(depth, 8, planesOrigin, fp->planeElems, strideR, pred, strideP, fp->puXY[3], fp->mv[3], fp->nLevel[3], as_stream(stream)));
     // 3. residual chain
-    const int qp = fp->qp;
+    const int qp = fp->qp + 6 * (depth - 8);                                            // QpParam.qp = slice qp + QP_BD_OFFSET (quant.cpp:224)
     static const int invQuantScales[6] = { 40, 45, 51, 57, 64, 72 };                     // scalinglist.cpp:130
     for (int t = 0; t < 2; t++)
     {
@@ -278,11 +326,90 @@ int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t stride
         FP_TRY(sa8d_levels(depth, src, strideS, pred, strideP, lv, 4, as_stream(stream)));
     }
     FP_MARK(9);
+    // 4b. chroma (4:2:0), when the caller passed Cb / Cr planes: predInterChromaPixel from the 8x8 vectors, then the same residual
+    //     chain with 16x16 / 4x4 TUs and the chroma QpParam
+    if (ca)
+    {
+        const int64_t B = depth == 8 ? 1 : 2;
+        const int64_t dF = ((const char*)ca->srcCr - (const char*)ca->srcCb) / B, dP = ((const char*)ca->predCr - (const char*)ca->predCb) / B;
+        const int64_t dR = ((const char*)ca->recCr - (const char*)ca->recCb) / B;
+        const int64_t lim = 0x7fffffffLL - (int64_t)(fp->height / 2 + 8) * (ca->sS > ca->sRec ? ca->sS : ca->sRec);
+        if (dF > lim || dF < -lim || dP > lim || dP < -lim || dR > lim || dR < -lim)
+            return set_error(X265HIP_EINVAL, "framepass_run_yuv: Cb and Cr planes are more than 2^31 elements apart");
+        if (fp->cStrideF != ca->sS || fp->cStrideP != ca->sP || fp->cStrideR != ca->sRec || fp->cDeltaF != dF || fp->cDeltaP != dP || fp->cDeltaR != dR)
+        {
+            FP_TRY(check_hip(hipStreamSynchronize(as_stream(stream)), "framepass sync"));
+            for (int t = 0; t < 2; t++)
+            {
+                const int64_t strides[3] = { ca->sS, ca->sP, ca->sRec }, deltas[3] = { dF, dP, dR };
+                int32_t** dst[3] = { &fp->ctuOffF[t], &fp->ctuOffP[t], &fp->ctuOffR[t] };
+                for (int k = 0; k < 3; k++)
+                {
+                    const size_t n = fp->hCtuXY[t].size() / 2;
+                    std::vector<int32_t> off(2 * n);
+                    for (size_t i = 0; i < n; i++)
+                    {
+                        const int64_t o = (int64_t)fp->hCtuXY[t][2 * i + 1] * strides[k] + fp->hCtuXY[t][2 * i];
+                        off[i] = (int32_t)o;
+                        off[n + i] = (int32_t)(o + deltas[k]);
+                    }
+                    if (*dst[k]) (void)hipFree(*dst[k]);
+                    *dst[k] = nullptr;
+                    FP_TRY(dev_upload(dst[k], off));
+                }
+            }
+            fp->cStrideF = ca->sS; fp->cStrideP = ca->sP; fp->cStrideR = ca->sRec;
+            fp->cDeltaF = dF; fp->cDeltaP = dP; fp->cDeltaR = dR;
+        }
+        FP_TRY(x265hip_pred_inter_chroma_batch(depth, 8, 8, ca->refCb, ca->refCr, ca->sR, ca->predCb, ca->predCr, ca->sP, fp->puXY[3], fp->mv[3],
+                                               fp->nLevel[3], stream));
+        const int bd = 6 * (depth - 8);
+        int qpc = fp->qp < -bd ? -bd : (fp->qp > 57 ? 57 : fp->qp);
+        if (qpc >= 30) qpc = kChromaScale[qpc];
+        qpc += bd;
+        for (int t = 0; t < 2; t++)
+        {
+            if (!fp->nTu[t]) continue;
+            const int log2n = kCTuSize[t] == 16 ? 4 : 2;
+            const int transformShift = 15 - depth - log2n;
+            const int qBits = 14 + qpc / 6 + transformShift, add = 85 << (qBits - 9);
+            const int dqShift = 20 - 14 - transformShift, dqScale = invQuantScales[qpc % 6] << (qpc / 6);
+            // Cb and Cr in one launch: Cr TUs are addressed from the Cb base pointers (offset tables above)
+            FP_TRY(x265hip_residual_chain_batch(kCTuSize[t], depth, ca->srcCb, ca->sS, ca->predCb, ca->sP, ca->recCb, ca->sRec, fp->ctuOffF[t],
+                                                fp->ctuOffP[t], fp->ctuOffR[t], fp->cquantCoeff[t], qBits, add, dqScale, dqShift, fp->clevel[0][t],
+                                                fp->cnumSig[0][t], fp->cdist[0][t], 2 * fp->nTu[t], stream));
+        }
+    }
+    FP_MARK(10);
     // 5. the reconstructed picture becomes a reference
     FP_TRY(x265hip_extend_border(depth, recon, strideRec, fp->width, fp->height, marginX, marginY, stream));
-    FP_MARK(10);
+    if (ca)
+    {
+        FP_TRY(x265hip_extend_border(depth, ca->recCb, ca->sRec, fp->width / 2, fp->height / 2, marginX / 2, marginY / 2, stream));
+        FP_TRY(x265hip_extend_border(depth, ca->recCr, ca->sRec, fp->width / 2, fp->height / 2, marginX / 2, marginY / 2, stream));
+    }
+    FP_MARK(11);
 #undef FP_MARK
     return X265HIP_OK;
+}
+
+extern "C" {
+
+int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t strideS, const void* ref, int64_t strideR,
+                          void* pred, int64_t strideP, void* recon, int64_t strideRec, int marginX, int marginY, void* stream)
+{
+    return framepass_run_impl(fp, src, strideS, ref, strideR, pred, strideP, recon, strideRec, marginX, marginY, nullptr, stream);
+}
+
+int x265hip_framepass_run_yuv(x265hip_framepass* fp, const x265hip_yuv* src, const x265hip_yuv* ref, const x265hip_yuv* pred,
+                              const x265hip_yuv* recon, int marginX, int marginY, void* stream)
+{
+    if (!fp || !src || !ref || !pred || !recon || !src->cb || !src->cr || !ref->cb || !ref->cr || !pred->cb || !pred->cr || !recon->cb || !recon->cr)
+        return set_error(X265HIP_EINVAL, "framepass_run_yuv: null plane");
+    if ((marginX & 1) || (marginY & 1))
+        return set_error(X265HIP_EINVAL, "framepass_run_yuv: margins must be even (4:2:0)");
+    ChromaArgs ca = { src->cb, src->cr, ref->cb, ref->cr, pred->cb, pred->cr, recon->cb, recon->cr, src->strideC, ref->strideC, pred->strideC, recon->strideC };
+    return framepass_run_impl(fp, src->y, src->strideY, ref->y, ref->strideY, pred->y, pred->strideY, recon->y, recon->strideY, marginX, marginY, &ca, stream);
 }
 
 int x265hip_framepass_set_profiling(x265hip_framepass* fp, int enable)
@@ -292,13 +419,13 @@ int x265hip_framepass_set_profiling(x265hip_framepass* fp, int enable)
     return X265HIP_OK;
 }
 
-int x265hip_framepass_stage_ms(x265hip_framepass* fp, float* ms10)
+int x265hip_framepass_stage_ms(x265hip_framepass* fp, float* ms11)
 {
-    if (!fp || !ms10 || !fp->profile)
+    if (!fp || !ms11 || !fp->profile)
         return set_error(X265HIP_EINVAL, "framepass_stage_ms: profiling is off");
-    FP_TRY(check_hip(hipEventSynchronize(fp->ev[10]), "hipEventSynchronize"));
-    for (int i = 0; i < 10; i++)
-        FP_TRY(check_hip(hipEventElapsedTime(&ms10[i], fp->ev[i], fp->ev[i + 1]), "hipEventElapsedTime"));
+    FP_TRY(check_hip(hipEventSynchronize(fp->ev[11]), "hipEventSynchronize"));
+    for (int i = 0; i < 11; i++)
+        FP_TRY(check_hip(hipEventElapsedTime(&ms11[i], fp->ev[i], fp->ev[i + 1]), "hipEventElapsedTime"));
     return X265HIP_OK;
 }
 
@@ -307,8 +434,22 @@ int x265hip_framepass_output(x265hip_framepass* fp, int which, int level, void**
     if (!fp || !devPtr || !count)
         return set_error(X265HIP_EINVAL, "framepass_output: null argument");
     const bool cuLevel = which <= X265HIP_FP_SA8D;
-    if (level < 0 || level >= (cuLevel ? 4 : 2))
+    if (level < 0 || level >= (cuLevel ? 4 : 6))
         return set_error(X265HIP_EINVAL, "framepass_output: level %d for output %d", level, which);
+    if (!cuLevel && level >= 2)
+    {
+        // chroma: level 2/3 = Cb 16x16 / 4x4, 4/5 = Cr 16x16 / 4x4 (outputs of x265hip_framepass_run_yuv)
+        const int pl = (level - 2) >> 1, t = (level - 2) & 1;
+        *count = fp->nTu[t];
+        switch (which)
+        {
+        case X265HIP_FP_LEVEL:  *devPtr = fp->clevel[pl][t]; break;
+        case X265HIP_FP_NUMSIG: *devPtr = fp->cnumSig[pl][t]; break;
+        case X265HIP_FP_DIST:   *devPtr = fp->cdist[pl][t]; break;
+        default: return set_error(X265HIP_EINVAL, "framepass_output: output %d has no chroma form", which);
+        }
+        return X265HIP_OK;
+    }
     switch (which)
     {
     case X265HIP_FP_PU_XY:  *devPtr = fp->puXY[level]; *count = fp->nLevel[level]; break;

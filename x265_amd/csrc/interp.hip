@@ -368,3 +368,106 @@ int pred_from_planes(int depth, int size, const void* planes, int64_t planeElems
     return X265HIP_OK;
 }
 } // namespace xh
+
+// ======================================================================================================================
+// Predict::predInterChromaPixel (reference: source/common/predict.cpp:306-352), 4:2:0
+// ======================================================================================================================
+// One lane = one row quad of a chroma block; the four cases (copy / filter_hpp / filter_vpp / filter_hps(rowExt)+filter_vsp) are
+// selected per PU by the eighth-pel fraction of the chroma vector exactly as the reference does.  Cb and Cr in one launch.
+namespace xh {
+
+template <typename P>
+__global__ __launch_bounds__(256) void pred_chroma_kernel(const P* __restrict__ refCb, const P* __restrict__ refCr, int64_t sR,
+                                                          P* __restrict__ dstCb, P* __restrict__ dstCr, int64_t sD,
+                                                          const int32_t* __restrict__ pu_xy, const int32_t* __restrict__ qmv,
+                                                          int cw, int ch, int n, int depth)
+{
+    const int qx = cw >> 2, per = qx * ch;
+    const long long total = 2LL * n * per;
+    const Stage sHpp = stage_for(IF_HPP, depth), sHps = stage_for(IF_HPS, depth), sVpp = stage_for(IF_VPP, depth), sVsp = stage_for(IF_VSP, depth);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x)
+    {
+        const int plane = (int)(idx / ((long long)n * per));
+        const long long rem = idx - (long long)plane * n * per;
+        const int pu = (int)(rem / per), p = (int)(rem - (long long)pu * per), y = p / qx, x = (p - y * qx) * 4;
+        // chroma block origin = luma PU origin / 2; chroma vector (1/8 pel) = luma quarter-pel vector for 4:2:0 (predict.cpp:311-312)
+        const int bx = pu_xy[2 * pu] >> 1, by = pu_xy[2 * pu + 1] >> 1, mvx = qmv[2 * pu], mvy = qmv[2 * pu + 1];
+        const int xFrac = mvx & 7, yFrac = mvy & 7;
+        const P* s = (plane ? refCr : refCb) + (int64_t)(by + (mvy >> 3) + y) * sR + bx + (mvx >> 3) + x;
+        P* d = (plane ? dstCr : dstCb) + (int64_t)(by + y) * sD + bx + x;
+        int out[4];
+        if (!(xFrac | yFrac))
+            load4(s, out);
+        else if (!yFrac)
+        {
+            int v[7];
+            load_span<7>(s - 1, v);
+#pragma unroll
+            for (int o = 0; o < 4; o++)
+            {
+                int sum = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) sum += v[o + k] * kChromaFilter[xFrac][k];
+                out[o] = finish(sum, sHpp);
+            }
+        }
+        else if (!xFrac)
+        {
+            int sum[4] = { 0, 0, 0, 0 };
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                int v[4];
+                load4(s + (int64_t)(k - 1) * sR, v);
+#pragma unroll
+                for (int o = 0; o < 4; o++) sum[o] += v[o] * kChromaFilter[yFrac][k];
+            }
+#pragma unroll
+            for (int o = 0; o < 4; o++) out[o] = finish(sum[o], sVpp);
+        }
+        else
+        {
+            int sum[4] = { 0, 0, 0, 0 };
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                int v[7];
+                load_span<7>(s + (int64_t)(k - 1) * sR - 1, v);
+#pragma unroll
+                for (int o = 0; o < 4; o++)
+                {
+                    int hs = 0;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) hs += v[o + t] * kChromaFilter[xFrac][t];
+                    sum[o] += finish(hs, sHps) * kChromaFilter[yFrac][k];
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 4; o++) out[o] = finish(sum[o], sVsp);
+        }
+        store4(d, out);
+    }
+}
+
+} // namespace xh
+
+extern "C" int x265hip_pred_inter_chroma_batch(int depth, int lumaW, int lumaH, const void* refCb, const void* refCr, int64_t strideR,
+                                               void* dstCb, void* dstCr, int64_t strideD, const int32_t* pu_xy, const int32_t* qmv, int n,
+                                               void* stream)
+{
+    XH_CHECK_DEV();
+    if (!valid_depth(depth) || !valid_block(lumaW, lumaH) || (lumaW & 7) || (lumaH & 1) || n < 0)
+        return set_error(X265HIP_EINVAL, "pred_inter_chroma: depth %d luma PU %dx%d n %d (4:2:0 chroma blocks must be a multiple of 4 wide)", depth, lumaW, lumaH, n);
+    if (!n) return X265HIP_OK;
+    const int cw = lumaW >> 1, ch = lumaH >> 1;
+    const long long total = 2LL * n * (cw / 4) * ch;
+    dim3 grid(grid_for((total + 255) / 256)), block(256);
+    if (depth == 8)
+        hipLaunchKernelGGL((pred_chroma_kernel<uint8_t>), grid, block, 0, as_stream(stream), (const uint8_t*)refCb, (const uint8_t*)refCr, strideR,
+                           (uint8_t*)dstCb, (uint8_t*)dstCr, strideD, pu_xy, qmv, cw, ch, n, depth);
+    else
+        hipLaunchKernelGGL((pred_chroma_kernel<uint16_t>), grid, block, 0, as_stream(stream), (const uint16_t*)refCb, (const uint16_t*)refCr, strideR,
+                           (uint16_t*)dstCb, (uint16_t*)dstCr, strideD, pu_xy, qmv, cw, ch, n, depth);
+    XH_LAUNCH_CHECK("pred_chroma_kernel");
+    return X265HIP_OK;
+}

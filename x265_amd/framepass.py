@@ -47,6 +47,22 @@ class Plane:
         return a if with_margins else np.ascontiguousarray(a[m:m + self.height, m:m + self.width])
 
 
+class YuvStruct(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("cb", C.c_void_p), ("cr", C.c_void_p), ("strideY", C.c_int64), ("strideC", C.c_int64)]
+
+
+class Picture:
+    """A 4:2:0 picture in device memory: luma Plane + two chroma Planes (half size, half margins)."""
+
+    def __init__(self, width, height, depth, y=None, cb=None, cr=None, margin=MARGIN):
+        self.y = Plane(width, height, depth, y, margin)
+        self.cb = Plane(width // 2, height // 2, depth, cb, margin // 2)
+        self.cr = Plane(width // 2, height // 2, depth, cr, margin // 2)
+
+    def struct(self):
+        return YuvStruct(self.y.origin, self.cb.origin, self.cr.origin, self.y.stride, self.cb.stride)
+
+
 class FramePass:
     def __init__(self, width, height, depth=8, qp=28, merange=57, method=hp.HEX_SEARCH, subme=2):
         self.L = hp.lib()
@@ -61,6 +77,11 @@ class FramePass:
         check(self.L.x265hip_framepass_run(self.h, src.origin, src.stride, ref.origin, ref.stride, pred.origin, pred.stride,
                                            recon.origin, recon.stride, recon.margin, recon.margin, stream))
 
+    def run_yuv(self, src, ref, pred, recon, stream=None):
+        """src/ref/pred/recon: Picture objects (device, 4:2:0)."""
+        a, b, c, d = src.struct(), ref.struct(), pred.struct(), recon.struct()
+        check(self.L.x265hip_framepass_run_yuv(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), recon.y.margin, recon.y.margin, stream))
+
     def output(self, which, level):
         p, n = C.c_void_p(), C.c_int()
         check(self.L.x265hip_framepass_output(self.h, which, level, C.byref(p), C.byref(n)))
@@ -73,7 +94,8 @@ class FramePass:
         elif which in (FP_MECOST, FP_SA8D):
             shape, dt = (n,), np.int32
         elif which == FP_LEVEL:
-            shape, dt = (n, TU_SIZES[level] ** 2), np.int16
+            size = TU_SIZES[level] if level < 2 else TU_SIZES[(level - 2) & 1] // 2
+            shape, dt = (n, size ** 2), np.int16
         elif which == FP_NUMSIG:
             shape, dt = (n,), np.uint32
         else:
@@ -102,6 +124,22 @@ class FramePass:
         r = self.results()
         r["pred"] = pp.get()
         r["recon"] = pc.get(with_margins=True)
+        return r
+
+    def run_host_yuv(self, sc):
+        """sc: dict with src, ref, src_cb, src_cr, ref_cb, ref_cr host arrays (x265_amd.synth.make_scene_yuv)."""
+        w, h, d = self.width, self.height, self.depth
+        ps = Picture(w, h, d, sc["src"], sc["src_cb"], sc["src_cr"])
+        pr = Picture(w, h, d, sc["ref"], sc["ref_cb"], sc["ref_cr"])
+        pp, pc = Picture(w, h, d), Picture(w, h, d)
+        self.run_yuv(ps, pr, pp, pc)
+        r = self.results()
+        r["pred"], r["recon"] = pp.y.get(), pc.y.get(with_margins=True)
+        r["clevel"] = [self.fetch(FP_LEVEL, 2 + i) for i in range(4)]
+        r["cnumSig"] = [self.fetch(FP_NUMSIG, 2 + i) for i in range(4)]
+        r["cdist"] = [self.fetch(FP_DIST, 2 + i) for i in range(4)]
+        r["pred_c"] = [pp.cb.get(), pp.cr.get()]
+        r["recon_c"] = [pc.cb.get(with_margins=True), pc.cr.get(with_margins=True)]
         return r
 
     def close(self):

@@ -51,3 +51,25 @@ def make_clip(path, width, height, frames, seed=4321, tile=96, vmax=9, sigma=3.0
             c = np.clip(np.rint(128 + 0.3 * (luma[::2, ::2] - 128)), 0, 255).astype(np.uint8)
             f.write(c.tobytes())
             f.write(c.tobytes())
+
+
+def chroma_of(luma, depth, gain):
+    """4:2:0 chroma plane derived from luma: mid + gain * (2x2-mean(luma) - mid)."""
+    mid = 1 << (depth - 1)
+    h, w = luma.shape
+    m = luma.astype(np.float64).reshape(h // 2, 2, w // 2, 2).mean(axis=(1, 3))
+    dt = np.uint8 if depth == 8 else np.uint16
+    return np.clip(np.rint(mid + gain * (m - mid)), 0, (1 << depth) - 1).astype(dt)
+
+
+def make_scene_yuv(width, height, depth=8, seed=4321, **kw):
+    """make_scene plus Cb / Cr planes (half resolution) for source and reference."""
+    sc = make_scene(width, height, depth, seed, **kw)
+    rng = np.random.default_rng(seed + 99)
+    out = {"src": sc["src"], "ref": sc["ref"]}
+    for name, gain in (("cb", 0.3), ("cr", -0.2)):
+        for k in ("src", "ref"):
+            c = chroma_of(sc[k], depth, gain).astype(np.int64)
+            c += rng.integers(-2, 3, c.shape) * (1 << (depth - 8))
+            out[k + "_" + name] = np.clip(c, 0, (1 << depth) - 1).astype(sc[k].dtype)
+    return out
