@@ -26,18 +26,24 @@ STAGES = ["planes", "me64", "me32", "me16", "me8", "pred8", "chain32", "chain8",
 
 
 def cpu_baseline(frames):
+    import numpy as np
     """The oracle's C restatement of the SAME frame pass, single thread, on `frames` 1080p frames (checker code used
     here only as the reported CPU baseline)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from frame_oracle import oracle_frame_pass
-    from x265_amd.synth import make_scene
-    sc = make_scene(W, H, depth=DEPTH, seed=4321)
-    oracle_frame_pass(sc["src"][:136, :200].copy(), sc["ref"][:136, :200].copy(), depth=DEPTH, qp=QP)   # load + warm
+    from x265_amd.synth import make_scene_yuv
+    sc = make_scene_yuv(W, H, depth=DEPTH, seed=4321)
+    crop = lambda a, hh, ww: np.ascontiguousarray(a[:hh, :ww])  # noqa: E731
+    oracle_frame_pass(crop(sc["src"], 136, 200), crop(sc["ref"], 136, 200), depth=DEPTH, qp=QP,
+                      src_c=(crop(sc["src_cb"], 68, 100), crop(sc["src_cr"], 68, 100)),
+                      ref_c=(crop(sc["ref_cb"], 68, 100), crop(sc["ref_cr"], 68, 100)))   # load + warm
     t0 = time.perf_counter()
-    ref = sc["ref"]
+    ref, ref_c = sc["ref"], (sc["ref_cb"], sc["ref_cr"])
     for i in range(frames):
-        r = oracle_frame_pass(sc["src"], ref, depth=DEPTH, qp=QP, merange=MERANGE, method=1, subme=SUBME)
-        ref = r["recon"][96:96 + H, 96:96 + W]
+        r = oracle_frame_pass(sc["src"], ref, depth=DEPTH, qp=QP, merange=MERANGE, method=1, subme=SUBME,
+                              src_c=(sc["src_cb"], sc["src_cr"]), ref_c=ref_c)
+        ref = np.ascontiguousarray(r["recon"][96:96 + H, 96:96 + W])
+        ref_c = tuple(np.ascontiguousarray(p[48:48 + H // 2, 48:48 + W // 2]) for p in r["recon_c"])
     dt = time.perf_counter() - t0
     return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "%d frame passes of the same 1920x1080 workload (oracle/x265_oracle_frame.c, gcc -O2, 1 thread, %.1f s)" % (frames, dt)}
