@@ -181,25 +181,37 @@ def main():
         a, b, c, d = yuv(src), yuv(ref), yuv(pred), yuv(rec)
         hp.check(L.x265hip_framepass_run_yuv(h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), MARGIN, MARGIN, sh))
 
+    state["last"] = None                  # recon of the last chain of the previous step, still to be handed to the next rank
+
+    def launch(j, k, recs):
+        src, rec = pool[(k + j) % NPOOL], recons[j][k & 1]
+        recs[j] = rec
+        if streams[j] is not None:
+            streams[j].wait_stream(torch.cuda.current_stream())
+            sh = streams[j].cuda_stream
+        else:
+            sh = stream
+        run_pass(fps_[j].h, src, state["refs"][j], preds[j], rec, sh)
+
     def step():
+        # reconstructed-reference hand-over: chain j+1 takes chain j's recon of the previous step (same device, pointer swap); the
+        # last chain's recon goes to chain 0 of rank+1 through the RCCL send/recv ring (at N = 1 it wraps around locally).  The
+        # transfer is started first and only chain 0 waits for it: chains 1..F-1 run on their own streams meanwhile.
         k = state["k"]
         cur = torch.cuda.current_stream()
-        recs = []
-        for j in range(F):
-            src, rec = pool[(k + j) % NPOOL], recons[j][k & 1]
-            recs.append(rec)
-            if streams[j] is not None:
-                streams[j].wait_stream(cur)
-                sh = streams[j].cuda_stream
-            else:
-                sh = stream
-            run_pass(fps_[j].h, src, state["refs"][j], preds[j], rec, sh)
+        recs = [None] * F
+        if state["last"] is not None:
+            ring.begin(state["last"])
+        for j in range(1, F):
+            launch(j, k, recs)
+        if state["last"] is not None:
+            state["refs"][0] = ring.finish()
+        launch(0, k, recs)
         for j in range(F):
             if streams[j] is not None:
                 cur.wait_stream(streams[j])
-        # reconstructed-reference hand-over: chain j+1 takes chain j's recon (same device, pointer swap); the last chain's recon
-        # goes to chain 0 of rank+1 through the RCCL send/recv ring (at N = 1 it wraps around locally)
-        state["refs"] = [ring.exchange(recs[F - 1])] + recs[:F - 1]
+        state["refs"] = [state["refs"][0]] + recs[:F - 1]
+        state["last"] = recs[F - 1]
         state["k"] = k + 1
 
     def profile_step():

@@ -33,23 +33,45 @@ def ring_shift(send, recv, rank, world):
 
 
 class ReferenceRing:
-    """Double-buffered reference planes of one rank: `current` is what the next frame pass searches; `exchange(recon)`
-    publishes this rank's reconstruction and installs the incoming one as the new current reference."""
+    """Double-buffered reference planes of one rank: `current` is what the next frame pass searches.
+
+    `exchange(recon)` publishes this rank's reconstruction and installs the incoming one as the new current reference.
+    `begin(recon)` / `finish()` split that so the transfer overlaps the frame passes that do not need it (bench.py launches the
+    chains whose reference is local between the two calls; only chain 0 waits for the incoming picture)."""
 
     def __init__(self, first_reference, spare, rank, world):
         self.bufs = [first_reference, spare]
         self.cur = 0
         self.rank, self.world = rank, world
+        self._pending = None
 
     @property
     def current(self):
         return self.bufs[self.cur]
 
-    def exchange(self, recon):
+    def begin(self, recon):
+        assert self._pending is None
         if self.world == 1:
-            # single rank: the frame just reconstructed IS the next reference; no copy, just swap roles
-            return recon
+            self._pending = (recon, None, None)       # single rank: the frame just reconstructed IS the next reference
+            return
         inbox = self.bufs[self.cur ^ 1]
-        ring_shift(recon, inbox, self.rank, self.world)
+        staged = recon.is_cuda and dist.get_backend() == "gloo"      # debugging aid: gloo moves host memory only
+        s, r = (recon.cpu(), inbox.cpu()) if staged else (recon, inbox)
+        ops = [dist.P2POp(dist.isend, s, (self.rank + 1) % self.world), dist.P2POp(dist.irecv, r, (self.rank - 1) % self.world)]
+        self._pending = (inbox, dist.batch_isend_irecv(ops), r if staged else None)
+
+    def finish(self):
+        ref, works, staged = self._pending
+        self._pending = None
+        if works is None:
+            return ref
+        for w in works:
+            w.wait()
+        if staged is not None:
+            ref.copy_(staged)
         self.cur ^= 1
-        return inbox
+        return ref
+
+    def exchange(self, recon):
+        self.begin(recon)
+        return self.finish()
