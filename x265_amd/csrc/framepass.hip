@@ -382,11 +382,12 @@ static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t st
     }
     FP_MARK(10);
     // 5. the reconstructed picture becomes a reference
-    FP_TRY(x265hip_extend_border(depth, recon, strideRec, fp->width, fp->height, marginX, marginY, stream));
-    if (ca)
     {
-        FP_TRY(x265hip_extend_border(depth, ca->recCb, ca->sRec, fp->width / 2, fp->height / 2, marginX / 2, marginY / 2, stream));
-        FP_TRY(x265hip_extend_border(depth, ca->recCr, ca->sRec, fp->width / 2, fp->height / 2, marginX / 2, marginY / 2, stream));
+        void* pics[3] = { recon, ca ? ca->recCb : nullptr, ca ? ca->recCr : nullptr };
+        const int64_t strides[3] = { strideRec, ca ? ca->sRec : 0, ca ? ca->sRec : 0 };
+        const int ws[3] = { fp->width, fp->width / 2, fp->width / 2 }, hs[3] = { fp->height, fp->height / 2, fp->height / 2 };
+        const int mxs[3] = { marginX, marginX / 2, marginX / 2 }, mys[3] = { marginY, marginY / 2, marginY / 2 };
+        FP_TRY(extend_border_planes(depth, ca ? 3 : 1, pics, strides, ws, hs, mxs, mys, as_stream(stream)));
     }
     FP_MARK(11);
 #undef FP_MARK

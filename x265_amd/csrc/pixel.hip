@@ -451,13 +451,25 @@ namespace xh {
 template <typename P>
 __global__ __launch_bounds__(256) void extend_border_kernel(P* __restrict__ pic, int64_t stride, int picW, int picH, int marginX, int marginY)
 {
-    const int fullW = picW + 2 * marginX, fullH = picH + 2 * marginY;
-    const long long total = (long long)fullW * fullH;
+    // only the margin pixels are visited: two full-width bands above / below, then the left / right strips of the picture rows
+    const int fullW = picW + 2 * marginX;
+    const long long bands = 2LL * marginY * fullW, total = bands + 2LL * marginX * picH;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
     {
-        const int y = (int)(i / fullW) - marginY, x = (int)(i % fullW) - marginX;
-        if (x >= 0 && x < picW && y >= 0 && y < picH)
-            continue;
+        int x, y;
+        if (i < bands)
+        {
+            const int row = (int)(i / fullW);
+            y = row < marginY ? row - marginY : picH + (row - marginY);
+            x = (int)(i % fullW) - marginX;
+        }
+        else
+        {
+            const long long k = i - bands;
+            const int xx = (int)(k % (2 * marginX));
+            y = (int)(k / (2 * marginX));
+            x = xx < marginX ? xx - marginX : picW + (xx - marginX);
+        }
         const int sy = y < 0 ? 0 : (y >= picH ? picH - 1 : y), sx = x < 0 ? 0 : (x >= picW ? picW - 1 : x);
         pic[(int64_t)y * stride + x] = pic[(int64_t)sy * stride + sx];
     }
@@ -469,7 +481,8 @@ extern "C" int x265hip_extend_border(int depth, void* picOrigin, int64_t stride,
     XH_CHECK_DEV();
     if (!valid_depth(depth) || picW < 1 || picH < 1 || marginX < 0 || marginY < 0)
         return set_error(X265HIP_EINVAL, "extend_border: depth %d pic %dx%d margins %d,%d", depth, picW, picH, marginX, marginY);
-    const long long total = (long long)(picW + 2 * marginX) * (picH + 2 * marginY);
+    const long long total = 2LL * marginY * (picW + 2 * marginX) + 2LL * marginX * picH;
+    if (total <= 0) return X265HIP_OK;
     dim3 grid(grid_for((total + 255) / 256)), block(256);
     if (depth == 8)
         hipLaunchKernelGGL((extend_border_kernel<uint8_t>), grid, block, 0, as_stream(stream), (uint8_t*)picOrigin, stride, picW, picH, marginX, marginY);
@@ -563,6 +576,68 @@ int sa8d_levels(int depth, const void* planeA, int64_t strideA, const void* plan
     else
         hipLaunchKernelGGL((sa8d_levels_kernel<uint16_t>), dim3(blocks), dim3(256), 0, st, (const uint16_t*)planeA, strideA, (const uint16_t*)planeB, strideB, lv);
     XH_LAUNCH_CHECK("sa8d_levels_kernel");
+    return X265HIP_OK;
+}
+} // namespace xh
+
+// ---- border extension of up to three planes (Y, Cb, Cr) in one launch (frame pass step 5) -----------------------------------
+namespace xh {
+struct BorderPlanes { void* pic[3]; int64_t stride[3]; int w[3], h[3], mx[3], my[3]; long long first[4]; };
+
+template <typename P>
+__global__ __launch_bounds__(256) void extend_border3_kernel(BorderPlanes bp)
+{
+    const long long total = bp.first[3];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    {
+        const int pl = i >= bp.first[2] ? 2 : (i >= bp.first[1] ? 1 : 0);
+        const long long k0 = i - bp.first[pl];
+        const int W = bp.w[pl], H = bp.h[pl], MX = bp.mx[pl], MY = bp.my[pl], fullW = W + 2 * MX;
+        const long long bands = 2LL * MY * fullW;
+        int x, y;
+        if (k0 < bands)
+        {
+            const int row = (int)(k0 / fullW);
+            y = row < MY ? row - MY : H + (row - MY);
+            x = (int)(k0 % fullW) - MX;
+        }
+        else
+        {
+            const long long k = k0 - bands;
+            const int xx = (int)(k % (2 * MX));
+            y = (int)(k / (2 * MX));
+            x = xx < MX ? xx - MX : W + (xx - MX);
+        }
+        const int sy = y < 0 ? 0 : (y >= H ? H - 1 : y), sx = x < 0 ? 0 : (x >= W ? W - 1 : x);
+        P* pic = (P*)bp.pic[pl];
+        pic[(int64_t)y * bp.stride[pl] + x] = pic[(int64_t)sy * bp.stride[pl] + sx];
+    }
+}
+
+int extend_border_planes(int depth, int nPlanes, void* const* pics, const int64_t* strides, const int* w, const int* h, const int* mx, const int* my,
+                         hipStream_t st)
+{
+    BorderPlanes bp{};
+    long long total = 0;
+    for (int i = 0; i < 3; i++)
+    {
+        bp.first[i] = total;
+        if (i < nPlanes)
+        {
+            bp.pic[i] = pics[i]; bp.stride[i] = strides[i]; bp.w[i] = w[i]; bp.h[i] = h[i]; bp.mx[i] = mx[i]; bp.my[i] = my[i];
+            total += 2LL * my[i] * (w[i] + 2 * mx[i]) + 2LL * mx[i] * h[i];
+        }
+        else
+        {
+            bp.w[i] = bp.h[i] = 1;
+        }
+    }
+    bp.first[3] = total;
+    for (int i = nPlanes; i < 3; i++) bp.first[i] = total;
+    dim3 grid(grid_for((total + 255) / 256)), block(256);
+    if (depth == 8) hipLaunchKernelGGL((extend_border3_kernel<uint8_t>), grid, block, 0, st, bp);
+    else hipLaunchKernelGGL((extend_border3_kernel<uint16_t>), grid, block, 0, st, bp);
+    XH_LAUNCH_CHECK("extend_border3_kernel");
     return X265HIP_OK;
 }
 } // namespace xh
