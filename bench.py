@@ -84,7 +84,7 @@ def pmc_traffic(stage):
     names = {"planes": "subpel_planes_kernel", "me64": "motion2_kernel<unsigned char, 64", "me32": "motion3_kernel<unsigned char, 32",
              "me16": "motion3_kernel<unsigned char, 16", "me8": "motion3_kernel<unsigned char, 8", "pred8": "pred_from_planes_kernel",
              "chain32": "residual_chain_kernel<unsigned char, 32", "chain8": "residual_chain_kernel<unsigned char, 8",
-             "sa8d": "sa8d_levels_kernel", "border": "extend_border_kernel", "chroma": "pred_chroma_kernel"}
+             "sa8d": "sa8d_levels_kernel", "border": "extend_border3_kernel", "chroma": "pred_chroma_kernel"}
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_bytes.txt")))
     if not files:
