@@ -16,6 +16,8 @@
 #include "lowres.h"
 #include "yuv.h"
 #include "x265.h"
+#include "picyuv.h"
+#include "slicetype.h"
 
 using namespace X265_NS;
 
@@ -154,6 +156,66 @@ int ref_motion_estimate(pixel* refPlane, pixel* fencPlane, intptr_t stride, int 
     outQMv[0] = out.x;
     outQMv[1] = out.y;
     return cost;
+}
+
+/* ---- intra prediction primitives (common/intrapred.cpp via the C table), cu = log2(size) - 2 ---- */
+void ref_intra_filter(int cu, const pixel* nb, pixel* out) { T().cu[cu].intra_filter(nb, out); }
+void ref_intra_pred(int cu, int mode, pixel* dst, intptr_t ds, const pixel* nb, int bFilter) { T().cu[cu].intra_pred[mode](dst, ds, nb, mode, bFilter); }
+void ref_intra_allangs(int cu, pixel* dest, pixel* nb, pixel* nbf, int bLuma) { T().cu[cu].intra_pred_allangs(dest, nb, nbf, bLuma); }
+int ref_intra_filter_flags(int mode) { return g_intraFilterFlags[mode]; }
+void ref_frame_init_lowres(const pixel* src, pixel* d0, pixel* dh, pixel* dv, pixel* dc, intptr_t ss, intptr_t ds, int w, int h)
+{ T().frameInitLowres(src, d0, dh, dv, dc, ss, ds, w, h); }
+
+/* ---- the real Lowres::create/init (common/lowres.cpp:50,259) + LookaheadTLD::lowresIntraEstimate
+ * (encoder/slicetype.cpp:696) on a caller-owned source plane with extended margins.  AQ off (invQscaleFactor NULL).
+ * geom[0..3] = lumaStride, width, lines, planesize; planes receives the four padded hpel planes (4*planesize).
+ * Returns costEst[0][0], or -1 if the buffers are too small (cap = elements available in `planes`). */
+int ref_lowres_intra_estimate(pixel* picOrg, intptr_t stride, int w, int h, int marginX, int marginY,
+                              int64_t* geom, pixel* planes, int64_t cap, int32_t* intraCost, uint8_t* intraMode, int32_t* rowSatd)
+{
+    T();
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = w;
+    param->sourceHeight = h;
+    param->rc.aqMode = 0;
+    param->rc.hevcAq = 0;
+    param->bAQMotion = 0;
+    param->bEnableHME = 0;
+    PicYuv pic;
+    pic.m_picWidth = w;
+    pic.m_picHeight = h;
+    pic.m_lumaMarginX = marginX;
+    pic.m_lumaMarginY = marginY;
+    pic.m_stride = stride;
+    pic.m_picOrg[0] = picOrg;
+    pic.m_param = param;
+    Lowres lr;
+    memset((void*)&lr, 0, sizeof(lr));
+    int ret = -1;
+    if (lr.create(param, &pic, param->rc.qgSize))
+    {
+        size_t planesize = lr.lumaStride * (lr.lines + 2 * marginY);
+        geom[0] = lr.lumaStride; geom[1] = lr.width; geom[2] = lr.lines; geom[3] = (int64_t)planesize;
+        if ((int64_t)(4 * planesize) <= cap)
+        {
+            lr.init(&pic, 0);
+            LookaheadTLD tld;
+            tld.init(lr.maxBlocksInRow, lr.maxBlocksInCol, lr.maxBlocksInRow * lr.maxBlocksInCol);
+            tld.lowresIntraEstimate(lr, param->rc.qgSize);
+            memcpy(planes, lr.buffer[0], 4 * planesize * sizeof(pixel));
+            int ncu = lr.maxBlocksInRow * lr.maxBlocksInCol;
+            memcpy(intraCost, lr.intraCost, ncu * sizeof(int32_t));
+            memcpy(intraMode, lr.intraMode, ncu);
+            memcpy(rowSatd, lr.rowSatds[0][0], lr.maxBlocksInCol * sizeof(int32_t));
+            ret = lr.costEst[0][0];
+        }
+    }
+    lr.destroy();
+    pic.m_picOrg[0] = NULL;
+    pic.m_param = NULL;
+    x265_param_free(param);
+    return ret;
 }
 
 } // extern "C"

@@ -110,6 +110,24 @@ void orc_pred_inter_chroma_##SFX(const P* ref, intptr_t rs, P* dst, intptr_t ds,
 ORC_DECL_FRAME(uint8_t, 8)
 ORC_DECL_FRAME(uint16_t, 16)
 
+/* ---- intra prediction, lowres init, lookahead intra estimate (x265_oracle_intra.c) ---------------------------- */
+#define ORC_DECL_INTRA(P, SFX) \
+/* common/intrapred.cpp:32 intraFilter<N> */ \
+void orc_intra_filter_##SFX(int n, const P* nb, P* out); \
+/* common/intrapred.cpp:57-222 intra_pred[35]: planar (0), DC (1), angular 2..34 */ \
+void orc_intra_pred_##SFX(int n, int mode, P* dst, intptr_t ds, const P* nb, int bFilter, int depth); \
+/* common/constants.cpp:561 g_intraFilterFlags[mode] & n */ \
+int orc_intra_uses_filtered_##SFX(int n, int mode); \
+/* common/intrapred.cpp:224 all_angs_pred_c */ \
+void orc_intra_allangs_##SFX(int n, P* dest, const P* nb, const P* nbFiltered, int bLuma, int depth); \
+/* common/pixel.cpp:604 frame_init_lowres_core */ \
+void orc_frame_init_lowres_##SFX(const P* src, P* d0, P* dh, P* dv, P* dc, intptr_t ss, intptr_t dstStride, int width, int height); \
+/* encoder/slicetype.cpp:696 LookaheadTLD::lowresIntraEstimate */ \
+int orc_lowres_intra_estimate_##SFX(const P* plane, intptr_t stride, int widthInCU, int heightInCU, int depth, \
+                                    int32_t* intraCost, uint8_t* intraMode, int32_t* rowSatd);
+ORC_DECL_INTRA(uint8_t, 8)
+ORC_DECL_INTRA(uint16_t, 16)
+
 /* ---- int16 block helpers (pixel-type independent) ------------------------------------------------------ */
 /* common/pixel.cpp:167 sse<..,int16_t,int16_t> */
 uint64_t orc_sse_ss(const int16_t* a, intptr_t sa, const int16_t* b, intptr_t sb, int w, int h);

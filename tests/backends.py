@@ -245,6 +245,48 @@ class Orc(_Base):
                                            po.vp(cost.ctypes.data + 2 * po.MVCOST_CENTRE), self.depth, ptr(out))
         return c, (int(out[0]), int(out[1]))
 
+    # ---- intra prediction / lookahead lowres
+    def intra_filter(self, n, nb):
+        out = np.zeros(4 * n + 1, self.pix)
+        self._f("orc_intra_filter")(n, ptr(nb), ptr(out))
+        return out
+
+    def intra_pred(self, n, mode, nb, bfilter):
+        out = np.zeros((n, n), self.pix)
+        self._f("orc_intra_pred")(n, mode, ptr(out), n, ptr(nb), bfilter, self.depth)
+        return out
+
+    def intra_uses_filtered(self, n, mode):
+        return self._f("orc_intra_uses_filtered")(n, mode)
+
+    def intra_allangs(self, n, nb, nbf, bluma):
+        out = np.zeros((33, n, n), self.pix)
+        self._f("orc_intra_allangs")(n, po.vp(out.ctypes.data), ptr(nb), ptr(nbf), bluma, self.depth)
+        return out
+
+    def frame_init_lowres(self, src, origin, w, h):
+        """src: padded 2-D plane, origin = (y, x) of the picture; w, h = lowres size. Returns four (h, w) planes."""
+        out = [np.zeros((h, w), self.pix) for _ in range(4)]
+        self._f("orc_frame_init_lowres")(ptr(src, *origin), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), src.shape[1], w, w, h)
+        return tuple(out)
+
+    def lowres_pass(self, src, origin, w, h, mx, my):
+        """Lowres::init restated: downscale, extend the four planes, intra estimate. Same returns as Ref.lowres_pass."""
+        lw, lh = ((w // 2 + 7) // 8) * 8, ((h // 2 + 7) // 8) * 8
+        stride = lw + 2 * mx
+        stride += (32 - stride % 32) % 32
+        planes = [np.ascontiguousarray(np.pad(p, ((my, my), (mx, stride - lw - mx)), mode="edge"))
+                  for p in self.frame_init_lowres(src, origin, lw, lh)]
+        est, cost, mode, rows = self.lowres_intra_estimate(planes[0], (my, mx), lw // 8, lh // 8)
+        return est, cost, mode, rows, planes, (stride, lw, lh)
+
+    def lowres_intra_estimate(self, plane, origin, wcu, hcu):
+        cost = np.zeros(wcu * hcu, np.int32)
+        mode = np.zeros(wcu * hcu, np.uint8)
+        rows = np.zeros(hcu, np.int32)
+        est = self._f("orc_lowres_intra_estimate")(ptr(plane, *origin), plane.shape[1], wcu, hcu, self.depth, ptr(cost), ptr(mode), ptr(rows))
+        return est, cost, mode, rows
+
 
 class Ref(_Base):
     name = "reference"
@@ -448,6 +490,49 @@ class Ref(_Base):
                                        ptr(a[0]), ptr(a[1]), ptr(a[2]), len(mvc), ptr(cand) if len(mvc) else None,
                                        merange, method, subme, qp, ptr(out))
         return c, (int(out[0]), int(out[1]))
+
+    # ---- intra prediction / lookahead lowres
+    def intra_filter(self, n, nb):
+        out = np.zeros(4 * n + 1, self.pix)
+        self.L.ref_intra_filter(cu_of(n), ptr(nb), ptr(out))
+        return out
+
+    def intra_pred(self, n, mode, nb, bfilter):
+        out = np.zeros((n, n), self.pix)
+        self.L.ref_intra_pred(cu_of(n), mode, ptr(out), n, ptr(nb), bfilter)
+        return out
+
+    def intra_uses_filtered(self, n, mode):
+        return 1 if self.L.ref_intra_filter_flags(mode) & n else 0
+
+    def intra_allangs(self, n, nb, nbf, bluma):
+        out = np.zeros((33, n, n), self.pix)
+        self.L.ref_intra_allangs(cu_of(n), po.vp(out.ctypes.data), ptr(nb), ptr(nbf), bluma)
+        return out
+
+    def frame_init_lowres(self, src, origin, w, h):
+        out = [np.zeros((h, w), self.pix) for _ in range(4)]
+        self.L.ref_frame_init_lowres(ptr(src, *origin), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]), src.shape[1], w, w, h)
+        return tuple(out)
+
+    def lowres_pass(self, src, origin, w, h, mx, my):
+        """The real Lowres::create/init + LookaheadTLD::lowresIntraEstimate on a padded source plane.
+        Returns (costEst, intraCost, intraMode, rowSatds, planes[4] padded 2-D, (lumaStride, width, lines))."""
+        geom = np.zeros(4, np.int64)
+        lw, lh = ((w // 2 + 7) // 8) * 8, ((h // 2 + 7) // 8) * 8
+        stride = lw + 2 * mx
+        stride += (32 - stride % 32) % 32
+        planesize = stride * (lh + 2 * my)
+        planes = np.zeros(4 * planesize, self.pix)
+        ncu = (lw // 8) * (lh // 8)
+        cost = np.zeros(ncu, np.int32)
+        mode = np.zeros(ncu, np.uint8)
+        rows = np.zeros(lh // 8, np.int32)
+        est = self.L.ref_lowres_intra_estimate(ptr(src, *origin), src.shape[1], w, h, mx, my, ptr(geom), ptr(planes), planes.size,
+                                               ptr(cost), ptr(mode), ptr(rows))
+        assert est >= 0 and (int(geom[0]), int(geom[1]), int(geom[2]), int(geom[3])) == (stride, lw, lh, planesize), geom
+        pl = [planes[i * planesize:(i + 1) * planesize].reshape(lh + 2 * my, stride) for i in range(4)]
+        return est, cost, mode, rows, pl, (stride, lw, lh)
 
 
 def same(x, y):

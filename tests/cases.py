@@ -154,6 +154,22 @@ def gen_cases(depth, seed=1234, reps=2):
                     yield ("hvpp %s" % lab, "interp", ("hvpp", chroma, w, h, p, so, max(idx, 1), idy))
 
 
+    # intra prediction (source/test/intrapredharness.cpp: random neighbour lines, every mode, bFilter 0/1) and the lowres
+    # downscale — appended last so the cases above keep their rng stream (and their golden digests)
+    for mode in ["rand"] * reps + ["min", "max"]:
+        for n in TU_SIZES:
+            nb = pix_buf(rng, mode, (4 * n + 1,), depth)
+            nbf = pix_buf(rng, mode, (4 * n + 1,), depth)
+            yield ("intra_filter %d %s" % (n, mode), "intra_filter", (n, nb))
+            for m in range(35):
+                for bf in (0, 1):
+                    yield ("intra_pred %d m%d f%d %s" % (n, m, bf, mode), "intra_pred", (n, m, nb, bf))
+            for bl in (0, 1):
+                yield ("intra_allangs %d l%d %s" % (n, bl, mode), "intra_allangs", (n, nb, nbf, bl))
+        src = pix_buf(rng, mode, (70, 2 * 40 + 8), depth)
+        yield ("frame_init_lowres %s" % mode, "frame_init_lowres", (src, (2, 1), 40, 33))
+
+
 def textured_frame(rng, h, w, depth, sigma=3.0):
     """Low-pass random texture + noise: SADs then have a meaningful minimum (BASELINE.md §3 generator, scaled down)."""
     pmax = (1 << depth) - 1
@@ -199,3 +215,10 @@ def digest(result):
             h.update(b"i" + str(int(x)).encode())
     feed(result)
     return h.hexdigest()[:16]
+
+
+def lowres_scene(depth, seed, H=136, W=200, margin=80):
+    """A source plane with PicYuv-style extended margins (the lookahead's downscale reads past the picture edge)."""
+    rng = np.random.default_rng(seed)
+    pic = textured_frame(rng, H, W, depth, sigma=4.0)
+    return np.ascontiguousarray(np.pad(pic, ((margin, margin), (margin, margin + 8)), mode="edge")), margin

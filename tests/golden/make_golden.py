@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import numpy as np  # noqa: E402
 from backends import Ref  # noqa: E402
-from cases import gen_cases, me_scene, digest  # noqa: E402
+from cases import gen_cases, me_scene, lowres_scene, digest  # noqa: E402
 
 ME_CASES = [  # (method, subme, w, h, bx_off, by_off, merange, qmvp, mvc, qp)
     (1, 2, 16, 16, 16, 24, 57, (5, -7), [(12, 8), (-20, 4)], 28),
@@ -42,6 +42,26 @@ def me_digests(backend_cls, depth):
     return out
 
 
+LOWRES_CASES = [(200, 136), (176, 144), (66, 50)]   # (W, H) of the full-resolution picture
+
+
+def lowres_results(backend_cls, depth):
+    """Lowres::init + LookaheadTLD::lowresIntraEstimate per case: (costEst, intraCost, intraMode, rowSatds, planes)."""
+    b = backend_cls(depth)
+    out = {}
+    for i, (w, h) in enumerate(LOWRES_CASES):
+        src, m = lowres_scene(depth, 300 + depth + i, h, w)
+        est, cost, mode, rows, planes, (stride, lw, lh) = b.lowres_pass(src, (m, m), w, h, m, m)
+        if i == 0:   # the rows to the right of the picture margin are allocator padding in the reference: compare the defined area
+            assert stride >= lw + 2 * m
+        out["lowres#%d" % i] = (est, cost, mode, rows) + tuple(np.ascontiguousarray(p[:, :lw + 2 * m]) for p in planes)
+    return out
+
+
+def lowres_digests(backend_cls, depth):
+    return {k: digest(v) for k, v in lowres_results(backend_cls, depth).items()}
+
+
 def prim_digests(backend_cls, depth):
     b = backend_cls(depth)
     out = {}
@@ -58,7 +78,7 @@ def prim_digests(backend_cls, depth):
 if __name__ == "__main__":
     gold = {}
     for depth in (8, 10):
-        gold[str(depth)] = {"prims": prim_digests(Ref, depth), "me": me_digests(Ref, depth),
+        gold[str(depth)] = {"prims": prim_digests(Ref, depth), "me": me_digests(Ref, depth), "lowres": lowres_digests(Ref, depth),
                             "mvcost": {str(qp): digest(Ref(depth).mvcost_table(qp)) for qp in (12, 28, 37, 51)}}
     path = os.path.join(HERE, "primitives_golden.json")
     with open(path, "w") as f:

@@ -33,6 +33,11 @@ def test_oracle_motion_estimate_matches_golden(depth):
 
 
 @pytest.mark.parametrize("depth", [8, 10])
+def test_oracle_lowres_pass_matches_golden(depth):
+    assert make_golden.lowres_digests(Orc, depth) == GOLD[str(depth)]["lowres"]
+
+
+@pytest.mark.parametrize("depth", [8, 10])
 def test_oracle_mvcost_matches_golden(depth):
     for qp, d in GOLD[str(depth)]["mvcost"].items():
         assert digest(Orc(depth).mvcost_table(int(qp))) == d

@@ -79,3 +79,26 @@ def test_motion_estimate_matches_reference(depth, method):
                 assert a == b, (depth, method, subme, w, h, bx, by, qmvp, mvmin, mvmax, mvc, a, b)
                 n += 1
     assert n >= 60
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_lowres_pass_matches_reference(depth):
+    """Lowres::create/init + LookaheadTLD::lowresIntraEstimate of the real reference vs the restatement: the four hpel planes
+    with their borders, every block's intra cost and mode, the row sums and the frame estimate."""
+    _need_ref(depth)
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    a, b = make_golden.lowres_results(Orc, depth), make_golden.lowres_results(Ref, depth)
+    assert set(a) == set(b)
+    for k in a:
+        assert same(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_intra_filter_flags_match_reference(depth):
+    _need_ref(depth)
+    o, r = Orc(depth), Ref(depth)
+    for n in (4, 8, 16, 32):
+        for mode in range(35):
+            assert o.intra_uses_filtered(n, mode) == r.intra_uses_filtered(n, mode), (n, mode)

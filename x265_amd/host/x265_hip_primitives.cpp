@@ -185,6 +185,11 @@ template <int N, int CU> static void sub_ps_hip(int16_t* d, intptr_t ds, const p
 {
     if (x265hip_call_sub_ps(D, N, N, d, ds, a, b, sa, sb)) g_c.cu[CU].sub_ps(d, ds, a, b, sa, sb);
 }
+/* calcresidual_t (primitives.h:157, getResidual pixel.cpp:472): sub_ps with one stride for all three blocks */
+template <int N, int CU> static void calcres_hip(const pixel* fenc, const pixel* pred, int16_t* resi, intptr_t stride)
+{
+    if (x265hip_call_sub_ps(D, N, N, resi, stride, fenc, pred, stride, stride)) g_c.cu[CU].calcresidual[NONALIGNED](fenc, pred, resi, stride);
+}
 template <int N, int CU> static void add_ps_hip(pixel* d, intptr_t ds, const pixel* a, const int16_t* r, intptr_t sa, intptr_t sr)
 {
     if (x265hip_call_add_ps(D, N, N, d, ds, a, r, sa, sr)) g_c.cu[CU].add_ps[NONALIGNED](d, ds, a, r, sa, sr);
@@ -323,6 +328,8 @@ template <int W, int H, int PART> static void c_vss_hip(const int16_t* s, intptr
         p.cu[cu].ssd_s[NONALIGNED] = ssd_s_hip<N, BLOCK_ ## N ## x ## N>; \
         p.cu[cu].ssd_s[ALIGNED] = ssd_s_hip<N, BLOCK_ ## N ## x ## N>; \
         p.cu[cu].sub_ps = sub_ps_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[cu].calcresidual[NONALIGNED] = calcres_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[cu].calcresidual[ALIGNED] = calcres_hip<N, BLOCK_ ## N ## x ## N>; \
         p.cu[cu].add_ps[NONALIGNED] = add_ps_hip<N, BLOCK_ ## N ## x ## N>; \
         p.cu[cu].add_ps[ALIGNED] = add_ps_hip<N, BLOCK_ ## N ## x ## N>; \
         p.cu[cu].copy_sp = copy_sp_hip<N, BLOCK_ ## N ## x ## N>; \
