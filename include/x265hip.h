@@ -273,6 +273,37 @@ int x265hip_framepass_output(x265hip_framepass* fp, int which, int level, void**
 int x265hip_framepass_set_profiling(x265hip_framepass* fp, int enable);
 int x265hip_framepass_stage_ms(x265hip_framepass* fp, float* ms11);
 
+/* ---------------------------------------------------------------- intra prediction + lookahead lowres ------- */
+/* The L-shaped neighbour line of an N x N block is x265's array: line[0] = top-left, line[1..2N] = top + top-right,
+ * line[2N+1..4N] = left + bottom-left (Predict::initAdiPattern, predict.cpp; intrapred.cpp).  N = 4, 8, 16, 32.
+ *
+ * intra_pred_t (primitives.h:143; cu[].intra_pred[35]: planar_pred_c intrapred.cpp:88, intra_pred_dc_c :71,
+ * intra_pred_ang_c :106): job i predicts mode (modes[i] & 255) with bFilter = (modes[i] >> 8) & 1 from the line at
+ * lines + lineOff[i] into dst + dstOff[i] (row pitch dstStride). */
+int x265hip_intra_pred_batch(int depth, int n, const void* lines, const int32_t* lineOff, const int32_t* modes,
+                             void* dst, const int32_t* dstOff, int64_t dstStride, int count, void* stream);
+/* intra_allangs_t (primitives.h:144, all_angs_pred_c intrapred.cpp:224): per block the 33 angular modes back to back
+ * (dest[(i*33 + mode-2) * N*N], horizontal modes stored transposed), each from the raw or the filtered line as
+ * g_intraFilterFlags says (constants.cpp:561). */
+int x265hip_intra_allangs_batch(int depth, int n, const void* lines, const int32_t* lineOff, const int32_t* filteredOff,
+                                int bLuma, void* dest, int count, void* stream);
+/* intra_filter_t (primitives.h:145, intraFilter<N> intrapred.cpp:32): [1 2 1]/4 along the line, both ends kept */
+int x265hip_intra_filter_batch(int depth, int n, const void* in, const int32_t* inOff, void* out, const int32_t* outOff,
+                               int count, void* stream);
+/* downscale_t (primitives.h:168; frameInitLowres = frame_init_lowres_core pixel.cpp:604): the half-resolution picture and
+ * its H / V / diagonal half-pel companions; reads src rows 0..2*height and columns 0..2*width (the source margins). */
+int x265hip_frame_init_lowres(int depth, const void* src, int64_t srcStride, void* dst0, void* dstH, void* dstV, void* dstC,
+                              int64_t dstStride, int width, int height, void* stream);
+/* Lowres::init (lowres.cpp:297-305): frameInitLowres + extendPicBorder of the four planes (planes[i] = picture origins) */
+int x265hip_lowres_init(int depth, const void* src, int64_t srcStride, void* const planes[4], int64_t dstStride,
+                        int width, int height, int marginX, int marginY, void* stream);
+/* LookaheadTLD::lowresIntraEstimate (slicetype.cpp:696-802) over a border-extended lowres plane: for every 8x8 block the
+ * cheapest of DC, planar and the coarse-to-fine angular scan by SATD, + 5*lambda(lookahead QP) + 4.  intraCost /
+ * intraMode are [heightInCU*widthInCU]; rowSatd[heightInCU] and costEst[1] (sum over the non-edge blocks) are optional
+ * (both NULL to skip).  No AQ scaling (invQscaleFactor == NULL in the reference). */
+int x265hip_lowres_intra_estimate(int depth, const void* plane, int64_t stride, int widthInCU, int heightInCU,
+                                  int32_t* intraCost, uint8_t* intraMode, int32_t* rowSatd, int32_t* costEst, void* stream);
+
 /* ---------------------------------------------------------------- per-call entry points (host pointers) ----- */
 /* What the reference-side table shims bind (x265_amd/host/x265_hip_primitives.cpp).  Arguments are the slot's own
  * arguments (HOST pointers, caller-owned, valid only during the call — primitives.h:133-234); each call stages the
@@ -306,6 +337,12 @@ int x265hip_call_blockfill_s(int size, int16_t* dst, int64_t ds, int16_t val);
 int x265hip_call_denoise_dct(int16_t* dctCoef, uint32_t* resSum, const uint16_t* offset, int numCoeff);
 int x265hip_call_rdoq_cost(int kind, int size, int depth, const int16_t* resiDct, const int16_t* fencDct, int64_t* costUncoded,
                            int64_t* totalUncoded, int64_t* totalRd, const int64_t* psyScale, uint32_t blkPos);
+
+int x265hip_call_intra_pred(int depth, int n, int mode, int bFilter, void* dst, int64_t dstStride, const void* line);
+int x265hip_call_intra_allangs(int depth, int n, void* dest, const void* line, const void* filtered, int bLuma);
+int x265hip_call_intra_filter(int depth, int n, const void* line, void* filtered);
+int x265hip_call_frame_init_lowres(int depth, const void* src, int64_t srcStride, void* dst0, void* dstH, void* dstV, void* dstC,
+                                   int64_t dstStride, int width, int height);
 
 #ifdef __cplusplus
 }

@@ -280,3 +280,65 @@ class Hip:
         cost, mv = self.motion_estimate_batch(refplane, fencplane, w, h, [(bx, by)], [mvmin], [mvmax], [qmvp],
                                               [mvc] if len(mvc) else [], merange, method, subme, qp)
         return int(cost[0]), (int(mv[0, 0]), int(mv[0, 1]))
+
+    # ---- intra prediction / lookahead lowres
+    def intra_filter(self, n, nb):
+        din = DevBuf(nb)
+        out = DevBuf.zeros((4 * n + 1,), self.pix)
+        check(self.L.x265hip_intra_filter_batch(self.depth, n, din.ptr, _ip([0]), out.ptr, _ip([0]), 1, None))
+        return out.get()
+
+    def intra_pred(self, n, mode, nb, bfilter):
+        din = DevBuf(nb)
+        out = DevBuf.zeros((n, n), self.pix)
+        check(self.L.x265hip_intra_pred_batch(self.depth, n, din.ptr, _ip([0]), _ip([mode | (bfilter << 8)]), out.ptr, _ip([0]), n, 1, None))
+        return out.get()
+
+    def intra_pred_batch(self, n, lines, modes, bfilters):
+        """lines: (count, 4n+1) array; returns (count, n, n)"""
+        count = len(modes)
+        din = DevBuf(lines)
+        out = DevBuf.zeros((count, n, n), self.pix)
+        check(self.L.x265hip_intra_pred_batch(self.depth, n, din.ptr, _ip(np.arange(count, dtype=np.int32) * (4 * n + 1)),
+                                              _ip(np.asarray(modes, np.int32) | (np.asarray(bfilters, np.int32) << 8)),
+                                              out.ptr, _ip(np.arange(count, dtype=np.int32) * n * n), n, count, None))
+        return out.get()
+
+    def intra_allangs(self, n, nb, nbf, bluma):
+        both = DevBuf(np.concatenate([nb, nbf]))
+        out = DevBuf.zeros((33, n, n), self.pix)
+        check(self.L.x265hip_intra_allangs_batch(self.depth, n, both.ptr, _ip([0]), _ip([4 * n + 1]), bluma, out.ptr, 1, None))
+        return out.get()
+
+    def frame_init_lowres(self, src, origin, w, h):
+        ds = DevBuf(src)
+        outs = [DevBuf.zeros((h, w), self.pix) for _ in range(4)]
+        check(self.L.x265hip_frame_init_lowres(self.depth, ds.at(_off(src, origin)), src.shape[1], outs[0].ptr, outs[1].ptr, outs[2].ptr,
+                                               outs[3].ptr, w, w, h, None))
+        return tuple(o.get() for o in outs)
+
+    def lowres_intra_estimate(self, plane, origin, wcu, hcu):
+        dp = DevBuf(plane)
+        cost, mode = DevBuf.zeros((wcu * hcu,), np.int32), DevBuf.zeros((wcu * hcu,), np.uint8)
+        rows, est = DevBuf.zeros((hcu,), np.int32), DevBuf.zeros((1,), np.int32)
+        check(self.L.x265hip_lowres_intra_estimate(self.depth, dp.at(_off(plane, origin)), plane.shape[1], wcu, hcu, cost.ptr, mode.ptr,
+                                                   rows.ptr, est.ptr, None))
+        return int(est.get()[0]), cost.get(), mode.get(), rows.get()
+
+    def lowres_pass(self, src, origin, w, h, mx, my):
+        """Lowres::init + lowresIntraEstimate on the device; same returns as backends.Orc.lowres_pass."""
+        lw, lh = ((w // 2 + 7) // 8) * 8, ((h // 2 + 7) // 8) * 8
+        stride = lw + 2 * mx
+        stride += (32 - stride % 32) % 32
+        ds = DevBuf(src)
+        planes = DevBuf.zeros((4, lh + 2 * my, stride), self.pix)
+        pe = (lh + 2 * my) * stride
+        org = my * stride + mx
+        ptrs = (C.c_void_p * 4)(*[planes.at(i * pe + org) for i in range(4)])
+        check(self.L.x265hip_lowres_init(self.depth, ds.at(_off(src, origin)), src.shape[1], ptrs, stride, lw, lh, mx, my, None))
+        wcu, hcu = lw // 8, lh // 8
+        cost, mode = DevBuf.zeros((wcu * hcu,), np.int32), DevBuf.zeros((wcu * hcu,), np.uint8)
+        rows, est = DevBuf.zeros((hcu,), np.int32), DevBuf.zeros((1,), np.int32)
+        check(self.L.x265hip_lowres_intra_estimate(self.depth, planes.at(org), stride, wcu, hcu, cost.ptr, mode.ptr, rows.ptr, est.ptr, None))
+        pl = planes.get()
+        return int(est.get()[0]), cost.get(), mode.get(), rows.get(), [np.ascontiguousarray(pl[i]) for i in range(4)], (stride, lw, lh)

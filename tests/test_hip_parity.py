@@ -437,6 +437,51 @@ def test_misc_batches(hipmod, depth):
     _report(bad, 1)
 
 
+@pytest.mark.parametrize("depth", [8, 10, 12])
+def test_intra_pred_batch_all_modes(hipmod, depth):
+    """Every mode x bFilter of every size in ONE launch per size, lines from the TestBench distribution + extremes."""
+    o, g = Orc(depth), hipmod.Hip(depth)
+    rng = np.random.default_rng(41 + depth)
+    pmax = (1 << depth) - 1
+    for n in (4, 8, 16, 32):
+        lines, modes, bfs = [], [], []
+        for trial in range(6):
+            if trial == 0:
+                ln = np.full(4 * n + 1, pmax)
+            elif trial == 1:
+                ln = np.zeros(4 * n + 1)
+            else:
+                ln = rng.integers(0, pmax + 1, 4 * n + 1)
+            for m in range(35):
+                for bf in (0, 1):
+                    lines.append(ln.astype(o.pix)); modes.append(m); bfs.append(bf)
+        lines = np.ascontiguousarray(np.stack(lines))
+        got = g.intra_pred_batch(n, lines, modes, bfs)
+        hipmod._release()
+        for i in range(len(modes)):
+            assert np.array_equal(got[i], o.intra_pred(n, modes[i], lines[i], bfs[i])), (n, modes[i], bfs[i])
+
+
+@pytest.mark.parametrize("depth", [8, 10, 12])
+def test_lowres_pass_matches_oracle(hipmod, depth):
+    """Lowres::init (downscale + four extended planes) and the lookahead intra estimate: planes, per-block cost and mode,
+    row sums and frame estimate, bit for bit; odd sizes exercise the rounded-up lowres width and dead rows of the last team."""
+    from cases import lowres_scene
+    o, g = Orc(depth), hipmod.Hip(depth)
+    for i, (w, h) in enumerate([(200, 136), (176, 144), (66, 50), (1920, 1080)]):
+        src, m = lowres_scene(depth, 500 + depth + i, h, w)
+        a = o.lowres_pass(src, (m, m), w, h, m, m)
+        b = g.lowres_pass(src, (m, m), w, h, m, m)
+        hipmod._release()
+        lw = a[5][1]
+        assert a[5] == b[5]
+        assert a[0] == b[0], (w, h, a[0], b[0])
+        for k in (1, 2, 3):
+            assert np.array_equal(a[k], b[k]), (w, h, k, np.argwhere(a[k] != b[k])[:5])
+        for pa, pb in zip(a[4], b[4]):
+            assert np.array_equal(pa[:, :lw + 2 * m], pb[:, :lw + 2 * m]), (w, h)
+
+
 def test_twelve_bit_primitives_match_oracle(hipmod):
     """depth 12 (u16 pixels, the third X265_DEPTH): same sweep against the oracle restatement (the real-reference pin covers
     8 and 10 bit; the 12-bit arithmetic differs only in the shift / clip constants the oracle derives from `depth`)."""

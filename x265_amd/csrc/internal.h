@@ -14,7 +14,7 @@ int sa8d_levels(int depth, const void* planeA, int64_t strideA, const void* plan
 int pred_from_planes(int depth, int size, const void* planes, int64_t planeElems, int64_t strideR, void* dst, int64_t strideD,
                      const int32_t* pu_xy, const int32_t* qmv, int n, hipStream_t st);
 
-// border extension of up to three planes in one launch
+// border extension of up to four planes in one launch
 int extend_border_planes(int depth, int nPlanes, void* const* pics, const int64_t* strides, const int* w, const int* h, const int* mx, const int* my,
                          hipStream_t st);
 

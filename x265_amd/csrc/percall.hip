@@ -482,4 +482,78 @@ int x265hip_call_rdoq_cost(int kind, int size, int depth, const int16_t* resiDct
     return X265HIP_OK;
 }
 
+// intra_pred_t (primitives.h:143): one mode of one block from a caller-owned neighbour line
+int x265hip_call_intra_pred(int depth, int n, int mode, int bFilter, void* dst, int64_t dstStride, const void* line)
+{
+    const int B = depth == 8 ? 1 : 2;
+    if (mode < 0 || mode > 34) return set_error(X265HIP_EINVAL, "call_intra_pred: mode %d", mode);
+    const size_t lb = (size_t)(4 * n + 1) * B, db = (size_t)n * n * B;
+    PC_BEGIN(lb + db + 64);
+    const size_t oJ = carve(4 * sizeof(int32_t)), oL = carve(lb), oD = carve(db);
+    hostp<int32_t>(oJ)[0] = 0;                                // line offset
+    hostp<int32_t>(oJ)[1] = mode | ((bFilter ? 1 : 0) << 8);
+    hostp<int32_t>(oJ)[2] = 0;                                // dst offset
+    memcpy(hostp<char>(oL), line, lb);
+    PC_TRY(upload());
+    PC_TRY(x265hip_intra_pred_batch(depth, n, devp<char>(oL), devp<int32_t>(oJ), devp<int32_t>(oJ) + 1, devp<char>(oD), devp<int32_t>(oJ) + 2, n, 1, t_st.stream));
+    PC_TRY(download(oD, db));
+    unpack_rows(dst, dstStride, hostp<char>(oD), n, n, B);
+    return X265HIP_OK;
+}
+
+// intra_allangs_t (primitives.h:144): dest receives 33 * N * N samples
+int x265hip_call_intra_allangs(int depth, int n, void* dest, const void* line, const void* filtered, int bLuma)
+{
+    const int B = depth == 8 ? 1 : 2;
+    const size_t lb = (size_t)(4 * n + 1) * B, db = (size_t)33 * n * n * B;
+    PC_BEGIN(2 * lb + db + 64);
+    const size_t oJ = carve(4 * sizeof(int32_t)), oL = carve(2 * (size_t)(4 * n + 1) * B), oD = carve(db);
+    hostp<int32_t>(oJ)[0] = 0;
+    hostp<int32_t>(oJ)[1] = 4 * n + 1;
+    memcpy(hostp<char>(oL), line, lb);
+    memcpy(hostp<char>(oL) + lb, filtered, lb);
+    PC_TRY(upload());
+    PC_TRY(x265hip_intra_allangs_batch(depth, n, devp<char>(oL), devp<int32_t>(oJ), devp<int32_t>(oJ) + 1, bLuma, devp<char>(oD), 1, t_st.stream));
+    PC_TRY(download(oD, db));
+    memcpy(dest, hostp<char>(oD), db);
+    return X265HIP_OK;
+}
+
+// intra_filter_t (primitives.h:145): writes exactly 4N+1 samples
+int x265hip_call_intra_filter(int depth, int n, const void* line, void* filtered)
+{
+    const int B = depth == 8 ? 1 : 2;
+    const size_t lb = (size_t)(4 * n + 1) * B;
+    PC_BEGIN(2 * lb + 64);
+    const size_t oJ = carve(4 * sizeof(int32_t)), oL = carve(lb), oD = carve(lb);
+    hostp<int32_t>(oJ)[0] = 0;
+    hostp<int32_t>(oJ)[1] = 0;
+    memcpy(hostp<char>(oL), line, lb);
+    PC_TRY(upload());
+    PC_TRY(x265hip_intra_filter_batch(depth, n, devp<char>(oL), devp<int32_t>(oJ), devp<char>(oD), devp<int32_t>(oJ) + 1, 1, t_st.stream));
+    PC_TRY(download(oD, lb));
+    memcpy(filtered, hostp<char>(oD), lb);
+    return X265HIP_OK;
+}
+
+// downscale_t (primitives.h:168): src rows 0..2*height, columns 0..2*width are read (frame_init_lowres_core, pixel.cpp:604)
+int x265hip_call_frame_init_lowres(int depth, const void* src, int64_t srcStride, void* dst0, void* dstH, void* dstV, void* dstC,
+                                   int64_t dstStride, int width, int height)
+{
+    const int B = depth == 8 ? 1 : 2;
+    const int sw = 2 * width + 1, sh = 2 * height + 1;
+    const size_t sb = (size_t)sw * sh * B, db = (size_t)width * height * B;
+    PC_BEGIN(sb + 4 * db + 128);
+    const size_t oS = carve(sb + 16), oD = carve(4 * db);
+    pack_rows(hostp<char>(oS), src, srcStride, sw, sh, B);
+    PC_TRY(upload());
+    char* d = devp<char>(oD);
+    PC_TRY(x265hip_frame_init_lowres(depth, devp<char>(oS), sw, d, d + db, d + 2 * db, d + 3 * db, width, width, height, t_st.stream));
+    PC_TRY(download(oD, 4 * db));
+    void* outs[4] = { dst0, dstH, dstV, dstC };
+    for (int i = 0; i < 4; i++)
+        unpack_rows(outs[i], dstStride, hostp<char>(oD) + i * db, width, height, B);
+    return X265HIP_OK;
+}
+
 } // extern "C"

@@ -580,17 +580,17 @@ int sa8d_levels(int depth, const void* planeA, int64_t strideA, const void* plan
 }
 } // namespace xh
 
-// ---- border extension of up to three planes (Y, Cb, Cr) in one launch (frame pass step 5) -----------------------------------
+// ---- border extension of up to four planes (Y, Cb, Cr; the four lowres hpel planes) in one launch (frame pass step 5) -----------------------------------
 namespace xh {
-struct BorderPlanes { void* pic[3]; int64_t stride[3]; int w[3], h[3], mx[3], my[3]; long long first[4]; };
+struct BorderPlanes { void* pic[4]; int64_t stride[4]; int w[4], h[4], mx[4], my[4]; long long first[5]; };
 
 template <typename P>
 __global__ __launch_bounds__(256) void extend_border3_kernel(BorderPlanes bp)
 {
-    const long long total = bp.first[3];
+    const long long total = bp.first[4];
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
     {
-        const int pl = i >= bp.first[2] ? 2 : (i >= bp.first[1] ? 1 : 0);
+        const int pl = i >= bp.first[3] ? 3 : (i >= bp.first[2] ? 2 : (i >= bp.first[1] ? 1 : 0));
         const long long k0 = i - bp.first[pl];
         const int W = bp.w[pl], H = bp.h[pl], MX = bp.mx[pl], MY = bp.my[pl], fullW = W + 2 * MX;
         const long long bands = 2LL * MY * fullW;
@@ -619,7 +619,9 @@ int extend_border_planes(int depth, int nPlanes, void* const* pics, const int64_
 {
     BorderPlanes bp{};
     long long total = 0;
-    for (int i = 0; i < 3; i++)
+    if (nPlanes < 1 || nPlanes > 4)
+        return set_error(X265HIP_EINVAL, "extend_border_planes: %d planes", nPlanes);
+    for (int i = 0; i < 4; i++)
     {
         bp.first[i] = total;
         if (i < nPlanes)
@@ -632,8 +634,8 @@ int extend_border_planes(int depth, int nPlanes, void* const* pics, const int64_
             bp.w[i] = bp.h[i] = 1;
         }
     }
-    bp.first[3] = total;
-    for (int i = nPlanes; i < 3; i++) bp.first[i] = total;
+    bp.first[4] = total;
+    for (int i = nPlanes; i < 4; i++) bp.first[i] = total;
     dim3 grid(grid_for((total + 255) / 256)), block(256);
     if (depth == 8) hipLaunchKernelGGL((extend_border3_kernel<uint8_t>), grid, block, 0, st, bp);
     else hipLaunchKernelGGL((extend_border3_kernel<uint16_t>), grid, block, 0, st, bp);

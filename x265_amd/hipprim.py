@@ -99,6 +99,16 @@ PROTOTYPES = {
     "x265hip_call_blockfill_s": (i32, [i32, vp, i64, C.c_int16]),
     "x265hip_call_denoise_dct": (i32, [vp, vp, vp, i32]),
     "x265hip_call_rdoq_cost": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, u32]),
+    "x265hip_intra_pred_batch": (i32, [i32, i32, vp, vp, vp, vp, vp, i64, i32, vp]),
+    "x265hip_intra_allangs_batch": (i32, [i32, i32, vp, vp, vp, i32, vp, i32, vp]),
+    "x265hip_intra_filter_batch": (i32, [i32, i32, vp, vp, vp, vp, i32, vp]),
+    "x265hip_frame_init_lowres": (i32, [i32, vp, i64, vp, vp, vp, vp, i64, i32, i32, vp]),
+    "x265hip_lowres_init": (i32, [i32, vp, i64, C.POINTER(vp), i64, i32, i32, i32, i32, vp]),
+    "x265hip_lowres_intra_estimate": (i32, [i32, vp, i64, i32, i32, vp, vp, vp, vp, vp]),
+    "x265hip_call_intra_pred": (i32, [i32, i32, i32, i32, vp, i64, vp]),
+    "x265hip_call_intra_allangs": (i32, [i32, i32, vp, vp, vp, i32]),
+    "x265hip_call_intra_filter": (i32, [i32, i32, vp, vp]),
+    "x265hip_call_frame_init_lowres": (i32, [i32, vp, i64, vp, vp, vp, vp, i64, i32, i32]),
 }
 
 CMP_SAD, CMP_SATD, CMP_SA8D, CMP_SA8D8, CMP_PSY = 0, 1, 2, 3, 4

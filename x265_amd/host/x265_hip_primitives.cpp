@@ -355,6 +355,42 @@ template <int W, int H, int PART> static void c_vss_hip(const int16_t* s, intptr
         p.cu[BLOCK_ ## N ## x ## N].psyRdoQuant_2p = psy_rdoq_2p_hip<N, BLOCK_ ## N ## x ## N>; \
     } while (0)
 
+/* ---- intra prediction (primitives.h:143-145, intrapred.cpp) and the lookahead downscale (primitives.h:168) ---- */
+template <int N, int CU> static void intra_pred_hip(pixel* dst, intptr_t ds, const pixel* line, int mode, int bFilter)
+{
+    if (x265hip_call_intra_pred(X265_DEPTH, N, mode, bFilter, dst, ds, line)) g_c.cu[CU].intra_pred[mode](dst, ds, line, mode, bFilter);
+}
+template <int N, int CU> static void intra_planar_hip(pixel* dst, intptr_t ds, const pixel* line, int, int bFilter)
+{
+    if (x265hip_call_intra_pred(X265_DEPTH, N, PLANAR_IDX, bFilter, dst, ds, line)) g_c.cu[CU].intra_pred[PLANAR_IDX](dst, ds, line, PLANAR_IDX, bFilter);
+}
+template <int N, int CU> static void intra_dc_hip(pixel* dst, intptr_t ds, const pixel* line, int, int bFilter)
+{
+    if (x265hip_call_intra_pred(X265_DEPTH, N, DC_IDX, bFilter, dst, ds, line)) g_c.cu[CU].intra_pred[DC_IDX](dst, ds, line, DC_IDX, bFilter);
+}
+template <int N, int CU> static void intra_allangs_hip(pixel* dest, pixel* line, pixel* filtered, int bLuma)
+{
+    if (x265hip_call_intra_allangs(X265_DEPTH, N, dest, line, filtered, bLuma)) g_c.cu[CU].intra_pred_allangs(dest, line, filtered, bLuma);
+}
+template <int N, int CU> static void intra_filter_hip(const pixel* line, pixel* filtered)
+{
+    if (x265hip_call_intra_filter(X265_DEPTH, N, line, filtered)) g_c.cu[CU].intra_filter(line, filtered);
+}
+static void frame_init_lowres_hip(const pixel* src, pixel* d0, pixel* dh, pixel* dv, pixel* dc, intptr_t ss, intptr_t ds, int w, int h)
+{
+    if (x265hip_call_frame_init_lowres(X265_DEPTH, src, ss, d0, dh, dv, dc, ds, w, h)) g_c.frameInitLowres(src, d0, dh, dv, dc, ss, ds, w, h);
+}
+
+#define HIP_INTRA(N) do { \
+        const int cu = BLOCK_ ## N ## x ## N; \
+        p.cu[cu].intra_pred[PLANAR_IDX] = intra_planar_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[cu].intra_pred[DC_IDX] = intra_dc_hip<N, BLOCK_ ## N ## x ## N>; \
+        for (int m = 2; m < NUM_INTRA_MODE; m++) \
+            p.cu[cu].intra_pred[m] = intra_pred_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[cu].intra_pred_allangs = intra_allangs_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[cu].intra_filter = intra_filter_hip<N, BLOCK_ ## N ## x ## N>; \
+    } while (0)
+
 static void report_calls()
 {
     fprintf(stderr, "x265hip: %llu primitive calls served by the GPU\n", x265hip_call_count());
@@ -401,6 +437,8 @@ void setupAssemblyPrimitives(EncoderPrimitives& p, int /* cpuMask: CPU ISA bits,
     p.dequant_normal = dequant_normal_hip;
     p.dequant_scaling = dequant_scaling_hip;
     p.denoiseDct = denoise_hip;
+    HIP_INTRA(4); HIP_INTRA(8); HIP_INTRA(16); HIP_INTRA(32);
+    p.frameInitLowres = frame_init_lowres_hip;
 }
 
 } // namespace X265_NS
