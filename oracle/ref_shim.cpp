@@ -218,4 +218,115 @@ int ref_lowres_intra_estimate(pixel* picOrg, intptr_t stride, int w, int h, int 
     return ret;
 }
 
+/* ---- the real lookahead P-frame cost: Lowres::create/init of two pictures, LookaheadTLD::lowresIntraEstimate of the
+ * second, then CostEstimateGroup::estimateCUCost (encoder/slicetype.cpp:3218) over every 8x8 block of frame 1 with frame 0
+ * as its reference.  numSlices == 1 goes through the reference's own singleCost() -> estimateFrameCost() serial loop
+ * (:3021, :3170-3179); numSlices > 1 repeats the cooperative-slice row loop of processTasks (:3092-3104, which needs a
+ * thread pool to be reached) around the reference's estimateCUCost, and adds the slice sums as :3152-3158 does.
+ * AQ, weighted prediction and HME are off.  Outputs are frame 1's lowresMvs[0][1], lowresMvCosts[0][1], lowresCosts[1][0],
+ * rowSatds[1][0], intraMbs[1], intraCost.  Returns costEst[1][0]. */
+namespace {
+struct CostProbeGroup : public CostEstimateGroup
+{
+    CostProbeGroup(Lookahead& l, Lowres** f) : CostEstimateGroup(l, f) {}
+    void cu(LookaheadTLD& tld, int x, int y, bool doSearch[2], bool lastRow, int slice) { estimateCUCost(tld, x, y, 0, 1, 1, doSearch, lastRow, slice, 0); }
+};
+}
+
+int64_t ref_lookahead_cost_p(pixel* pic0, pixel* pic1, intptr_t stride, int w, int h, int marginX, int marginY,
+                             int numRowsPerSlice, int numSlices,
+                             int32_t* mvs, int32_t* mvCosts, uint16_t* lowresCosts, int32_t* rowSatds, int32_t* intraMbs, int32_t* intraCost)
+{
+    T();
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = w;
+    param->sourceHeight = h;
+    param->rc.aqMode = 0;
+    param->rc.hevcAq = 0;
+    param->bAQMotion = 0;
+    param->bEnableHME = 0;
+    param->bEnableWeightedPred = 0;
+    param->bEnableWeightedBiPred = 0;
+    param->lookaheadSlices = 0;
+    PicYuv pics[2];
+    Lowres lr[2];
+    pixel* org[2] = { pic0, pic1 };
+    int64_t ret = -1;
+    bool ok = true;
+    for (int i = 0; i < 2; i++)
+    {
+        pics[i].m_picWidth = w;
+        pics[i].m_picHeight = h;
+        pics[i].m_lumaMarginX = marginX;
+        pics[i].m_lumaMarginY = marginY;
+        pics[i].m_stride = stride;
+        pics[i].m_picOrg[0] = org[i];
+        pics[i].m_param = param;
+        memset((void*)&lr[i], 0, sizeof(Lowres));
+        ok = ok && lr[i].create(param, &pics[i], param->rc.qgSize);
+    }
+    if (ok)
+    {
+        lr[0].init(&pics[0], 0);
+        lr[1].init(&pics[1], 1);
+        Lookahead la(param, NULL);
+        la.create();
+        LookaheadTLD& tld = la.m_tld[0];
+        tld.lowresIntraEstimate(lr[1], param->rc.qgSize);
+        Lowres* frames[2] = { &lr[0], &lr[1] };
+        CostProbeGroup g(la, frames);
+        Lowres* fenc = frames[1];
+        const int W = la.m_8x8Width, H = la.m_8x8Height, ncu = W * H;
+        if (numSlices <= 1)
+            ret = g.singleCost(0, 1, 1, false);
+        else
+        {
+            bool doSearch[2] = { true, false };
+            fenc->weightedRef[1].isWeighted = false;
+            fenc->costEst[1][0] = 0;
+            fenc->costEstAq[1][0] = 0;
+            memset(g.m_slice, 0, sizeof(g.m_slice));
+            for (int sl = 0; sl < numSlices; sl++)
+            {
+                int firstY = numRowsPerSlice * sl;
+                int lastY = sl == numSlices - 1 ? H - 1 : numRowsPerSlice * (sl + 1) - 1;
+                bool lastRow = true;
+                for (int cuY = lastY; cuY >= firstY; cuY--)
+                {
+                    fenc->rowSatds[1][0][cuY] = 0;
+                    for (int cuX = W - 1; cuX >= 0; cuX--)
+                        g.cu(tld, cuX, cuY, doSearch, lastRow, sl);
+                    lastRow = false;
+                }
+            }
+            for (int sl = 0; sl < numSlices; sl++)
+            {
+                fenc->costEst[1][0] += g.m_slice[sl].costEst;
+                fenc->intraMbs[1] += g.m_slice[sl].intraMbs;
+            }
+            ret = fenc->costEst[1][0];
+        }
+        for (int i = 0; i < ncu; i++)
+        {
+            mvs[2 * i] = fenc->lowresMvs[0][1][i].x;
+            mvs[2 * i + 1] = fenc->lowresMvs[0][1][i].y;
+        }
+        memcpy(mvCosts, fenc->lowresMvCosts[0][1], ncu * sizeof(int32_t));
+        memcpy(lowresCosts, fenc->lowresCosts[1][0], ncu * sizeof(uint16_t));
+        memcpy(rowSatds, fenc->rowSatds[1][0], H * sizeof(int32_t));
+        memcpy(intraCost, fenc->intraCost, ncu * sizeof(int32_t));
+        *intraMbs = fenc->intraMbs[1];
+        la.destroy();
+    }
+    for (int i = 0; i < 2; i++)
+    {
+        lr[i].destroy();
+        pics[i].m_picOrg[0] = NULL;
+        pics[i].m_param = NULL;
+    }
+    x265_param_free(param);
+    return ret;
+}
+
 } // extern "C"

@@ -93,6 +93,13 @@ ORC_DECL_PIXEL(uint16_t, 16)
 /* encoder/search.cpp:2724 Search::setSearchRange + common/cudata.cpp:1915 CUData::clipMv */
 void orc_set_search_range(int picW, int picH, int maxCUSize, int merange, int refLagPixels, int cuX, int cuY,
                           const int32_t qmvp[2], int32_t mvmin[2], int32_t mvmax[2]);
+#define ORC_DECL_LOOKAHEAD(P, SFX) \
+/* encoder/slicetype.cpp:3218 CostEstimateGroup::estimateCUCost over a whole P frame (lowres motionEstimate: motion.cpp:775, :1471) */ \
+int64_t orc_lookahead_cost_p_##SFX(const P* fencPlane, const P* const* ref, intptr_t stride, int widthInCU, int heightInCU, \
+                                   int numRowsPerSlice, int numSlices, int depth, const int32_t* intraCost, const uint16_t* mvcost, \
+                                   int32_t* mvs, int32_t* mvCosts, uint16_t* lowresCosts, int32_t* rowSatds, int32_t* intraMbs);
+ORC_DECL_LOOKAHEAD(uint8_t, 8)
+ORC_DECL_LOOKAHEAD(uint16_t, 16)
 #define ORC_DECL_FRAME(P, SFX) \
 /* common/predict.cpp:245 Predict::predInterLumaPixel */ \
 void orc_pred_inter_luma_##SFX(const P* ref, intptr_t rs, P* dst, intptr_t ds, int bx, int by, int w, int h, int qx, int qy, int depth); \

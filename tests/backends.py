@@ -287,6 +287,22 @@ class Orc(_Base):
         est = self._f("orc_lowres_intra_estimate")(ptr(plane, *origin), plane.shape[1], wcu, hcu, self.depth, ptr(cost), ptr(mode), ptr(rows))
         return est, cost, mode, rows
 
+    def lookahead_cost_p(self, src0, src1, origin, w, h, mx, my, rows_per_slice, num_slices):
+        """Lowres::init of both pictures, intra estimate of the second, then the P-frame cost pass (frame 1 referencing frame 0).
+        Returns (costEst, mvs[ncu,2], mvCosts, lowresCosts, rowSatds, intraMbs, intraCost)."""
+        import ctypes as C
+        _, _, _, _, pl0, (stride, lw, lh) = self.lowres_pass(src0, origin, w, h, mx, my)
+        _, icost, _, _, pl1, _ = self.lowres_pass(src1, origin, w, h, mx, my)
+        wcu, hcu = lw // 8, lh // 8
+        ncu = wcu * hcu
+        mvs, mvc = np.zeros((ncu, 2), np.int32), np.zeros(ncu, np.int32)
+        lc, rows, imb = np.zeros(ncu, np.uint16), np.zeros(hcu, np.int32), np.zeros(1, np.int32)
+        tab = po.mvcost_table(12 + 6 * (self.depth - 8), self.depth)
+        refs = (C.c_void_p * 4)(*[ptr(p, my, mx).value for p in pl0])
+        est = self._f("orc_lookahead_cost_p")(ptr(pl1[0], my, mx), refs, stride, wcu, hcu, rows_per_slice, num_slices, self.depth,
+                                              ptr(icost), po.vp(tab.ctypes.data + 2 * po.MVCOST_CENTRE), ptr(mvs), ptr(mvc), ptr(lc), ptr(rows), ptr(imb))
+        return int(est), mvs, mvc, lc, rows, int(imb[0]), icost
+
 
 class Ref(_Base):
     name = "reference"
@@ -533,6 +549,18 @@ class Ref(_Base):
         assert est >= 0 and (int(geom[0]), int(geom[1]), int(geom[2]), int(geom[3])) == (stride, lw, lh, planesize), geom
         pl = [planes[i * planesize:(i + 1) * planesize].reshape(lh + 2 * my, stride) for i in range(4)]
         return est, cost, mode, rows, pl, (stride, lw, lh)
+
+    def lookahead_cost_p(self, src0, src1, origin, w, h, mx, my, rows_per_slice, num_slices):
+        lw, lh = ((w // 2 + 7) // 8) * 8, ((h // 2 + 7) // 8) * 8
+        wcu, hcu = lw // 8, lh // 8
+        ncu = wcu * hcu
+        mvs, mvc = np.zeros((ncu, 2), np.int32), np.zeros(ncu, np.int32)
+        lc, rows, imb = np.zeros(ncu, np.uint16), np.zeros(hcu, np.int32), np.zeros(1, np.int32)
+        icost = np.zeros(ncu, np.int32)
+        assert src0.shape == src1.shape
+        est = self.L.ref_lookahead_cost_p(ptr(src0, *origin), ptr(src1, *origin), src0.shape[1], w, h, mx, my, rows_per_slice, num_slices,
+                                          ptr(mvs), ptr(mvc), ptr(lc), ptr(rows), ptr(imb), ptr(icost))
+        return int(est), mvs, mvc, lc, rows, int(imb[0]), icost
 
 
 def same(x, y):

@@ -222,3 +222,22 @@ def lowres_scene(depth, seed, H=136, W=200, margin=80):
     rng = np.random.default_rng(seed)
     pic = textured_frame(rng, H, W, depth, sigma=4.0)
     return np.ascontiguousarray(np.pad(pic, ((margin, margin), (margin, margin + 8)), mode="edge")), margin
+
+
+def lookahead_scene(depth, seed, H=136, W=200, margin=80):
+    """Two padded source pictures: the second is the first moved per 48x40 tile (vectors in [-9, 9]^2) plus noise — what the
+    lookahead's lowres search sees between consecutive frames."""
+    rng = np.random.default_rng(seed)
+    pmax = (1 << depth) - 1
+    big = textured_frame(rng, H + 32, W + 32, depth, sigma=2.0)
+    p0 = big[16:16 + H, 16:16 + W]
+    p1 = np.zeros_like(p0)
+    th, tw = 40, 48
+    for y0 in range(0, H, th):
+        for x0 in range(0, W, tw):
+            dy, dx = int(rng.integers(-9, 10)), int(rng.integers(-9, 10))
+            y1, x1 = min(y0 + th, H), min(x0 + tw, W)
+            p1[y0:y1, x0:x1] = big[16 + y0 + dy:16 + y1 + dy, 16 + x0 + dx:16 + x1 + dx]
+    p1 = np.clip(np.rint(p1.astype(np.float64) + rng.normal(0, 2.0 * (pmax / 255.0), p1.shape)), 0, pmax).astype(p0.dtype)
+    pad = ((margin, margin), (margin, margin + 8))
+    return np.ascontiguousarray(np.pad(p0, pad, mode="edge")), np.ascontiguousarray(np.pad(p1, pad, mode="edge")), margin

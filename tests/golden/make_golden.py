@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import numpy as np  # noqa: E402
 from backends import Ref  # noqa: E402
-from cases import gen_cases, me_scene, lowres_scene, digest  # noqa: E402
+from cases import gen_cases, me_scene, lowres_scene, lookahead_scene, digest  # noqa: E402
 
 ME_CASES = [  # (method, subme, w, h, bx_off, by_off, merange, qmvp, mvc, qp)
     (1, 2, 16, 16, 16, 24, 57, (5, -7), [(12, 8), (-20, 4)], 28),
@@ -62,6 +62,23 @@ def lowres_digests(backend_cls, depth):
     return {k: digest(v) for k, v in lowres_results(backend_cls, depth).items()}
 
 
+LOOKAHEAD_CASES = [(200, 136, 9, 1), (200, 136, 3, 3), (176, 144, 9, 1), (66, 50, 4, 1), (320, 200, 5, 2)]   # W, H, rows/slice, slices
+
+
+def lookahead_results(backend_cls, depth):
+    """The lookahead's P-frame cost pass per case: (costEst, mvs, mvCosts, lowresCosts, rowSatds, intraMbs, intraCost)."""
+    b = backend_cls(depth)
+    out = {}
+    for i, (w, h, rps, ns) in enumerate(LOOKAHEAD_CASES):
+        s0, s1, m = lookahead_scene(depth, 700 + depth + w, h, w)
+        out["lookahead#%d" % i] = b.lookahead_cost_p(s0, s1, (m, m), w, h, m, m, rps, ns)
+    return out
+
+
+def lookahead_digests(backend_cls, depth):
+    return {k: digest(v) for k, v in lookahead_results(backend_cls, depth).items()}
+
+
 def prim_digests(backend_cls, depth):
     b = backend_cls(depth)
     out = {}
@@ -78,7 +95,7 @@ def prim_digests(backend_cls, depth):
 if __name__ == "__main__":
     gold = {}
     for depth in (8, 10):
-        gold[str(depth)] = {"prims": prim_digests(Ref, depth), "me": me_digests(Ref, depth), "lowres": lowres_digests(Ref, depth),
+        gold[str(depth)] = {"prims": prim_digests(Ref, depth), "me": me_digests(Ref, depth), "lowres": lowres_digests(Ref, depth), "lookahead": lookahead_digests(Ref, depth),
                             "mvcost": {str(qp): digest(Ref(depth).mvcost_table(qp)) for qp in (12, 28, 37, 51)}}
     path = os.path.join(HERE, "primitives_golden.json")
     with open(path, "w") as f:

@@ -38,6 +38,11 @@ def test_oracle_lowres_pass_matches_golden(depth):
 
 
 @pytest.mark.parametrize("depth", [8, 10])
+def test_oracle_lookahead_cost_matches_golden(depth):
+    assert make_golden.lookahead_digests(Orc, depth) == GOLD[str(depth)]["lookahead"]
+
+
+@pytest.mark.parametrize("depth", [8, 10])
 def test_oracle_mvcost_matches_golden(depth):
     for qp, d in GOLD[str(depth)]["mvcost"].items():
         assert digest(Orc(depth).mvcost_table(int(qp))) == d

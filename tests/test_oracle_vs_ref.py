@@ -102,3 +102,17 @@ def test_intra_filter_flags_match_reference(depth):
     for n in (4, 8, 16, 32):
         for mode in range(35):
             assert o.intra_uses_filtered(n, mode) == r.intra_uses_filtered(n, mode), (n, mode)
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_lookahead_p_cost_matches_reference(depth):
+    """The real Lookahead / CostEstimateGroup::estimateCUCost (lowres motionEstimate, reverse-order MV prediction, intra
+    fallback, frame score) over whole frames, serial and in cooperative row slices, vs the restatement."""
+    _need_ref(depth)
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    a, b = make_golden.lookahead_results(Orc, depth), make_golden.lookahead_results(Ref, depth)
+    assert set(a) == set(b)
+    for k in a:
+        assert same(a[k], b[k]), k
