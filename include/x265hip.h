@@ -304,6 +304,32 @@ int x265hip_lowres_init(int depth, const void* src, int64_t srcStride, void* con
 int x265hip_lowres_intra_estimate(int depth, const void* plane, int64_t stride, int widthInCU, int heightInCU,
                                   int32_t* intraCost, uint8_t* intraMode, int32_t* rowSatd, int32_t* costEst, void* stream);
 
+/* The lookahead's P-frame cost pass for a batch of (frame, reference) pairs — CostEstimateGroup::estimateCUCost
+ * (slicetype.cpp:3218-3385) for b == p1 over every 8x8 block of the lowres frame, i.e. per block: SATD of the already
+ * known neighbour vectors (right, below, below-left, below-right; :3271-3307) -> start vector, the lowres flavour of
+ * MotionEstimate::motionEstimate (HEX, merange 16, subpel refine 1: motion.cpp:775, :855-944, :1471-1501 with
+ * Lowres::lowresQPelCost, lowres.h:94), + 4 against the block's intra cost, frame score over the non-edge blocks.
+ * Rows are walked bottom-up in `numSlices` independent slices of `numRowsPerSlice` rows (the reference's cooperative
+ * lookahead slices, :3092-3104; 1 slice = the serial loop :3170-3179).  No AQ, no weighted reference, no HME.
+ * All pairs share the geometry; planes are border-extended lowres planes (x265hip_lowres_init), `ref` = hpel plane 0 of
+ * the reference with planes 1..3 `planeElems` elements apart.  `sync` is ncu u64 of scratch per pair, zeroed once when
+ * allocated; `epoch` must be non-zero and differ from every earlier call that used the same scratch.
+ * `pairs` is a DEVICE array.  costEst[i] = { costEst, intraMbs } of pair i. */
+typedef struct x265hip_lookahead_pair
+{
+    const void*    fenc;         /* lowresPlane[0] origin of the frame being costed */
+    const void*    ref;          /* reference frame: hpel plane 0 origin */
+    const int32_t* intraCost;    /* [ncu] of the frame being costed (x265hip_lowres_intra_estimate) */
+    int32_t*       mvs;          /* out [ncu][2]  lowresMvs[0][b-p0], quarter-pel */
+    int32_t*       mvCosts;      /* out [ncu]     lowresMvCosts[0][b-p0] */
+    uint16_t*      lowresCosts;  /* out [ncu]     min(cost, 16383) | listused << 14 */
+    int32_t*       rowSatds;     /* out [heightInCU] */
+    uint64_t*      sync;         /* scratch [ncu] */
+} x265hip_lookahead_pair;
+int x265hip_lookahead_cost_p_batch(int depth, const x265hip_lookahead_pair* pairs, int nPairs, int64_t stride, int64_t planeElems,
+                                   int widthInCU, int heightInCU, int numRowsPerSlice, int numSlices,
+                                   const uint16_t* mvcost, uint32_t epoch, int32_t* costEst, void* stream);
+
 /* ---------------------------------------------------------------- per-call entry points (host pointers) ----- */
 /* What the reference-side table shims bind (x265_amd/host/x265_hip_primitives.cpp).  Arguments are the slot's own
  * arguments (HOST pointers, caller-owned, valid only during the call — primitives.h:133-234); each call stages the

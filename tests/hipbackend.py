@@ -342,3 +342,52 @@ class Hip:
         check(self.L.x265hip_lowres_intra_estimate(self.depth, planes.at(org), stride, wcu, hcu, cost.ptr, mode.ptr, rows.ptr, est.ptr, None))
         pl = planes.get()
         return int(est.get()[0]), cost.get(), mode.get(), rows.get(), [np.ascontiguousarray(pl[i]) for i in range(4)], (stride, lw, lh)
+
+    _epoch = [0]
+
+    def lookahead_cost_p_batch(self, pairs, origin, w, h, mx, my, rows_per_slice, num_slices):
+        """pairs: list of (src0, src1) padded pictures of one geometry; the whole chain on the device: Lowres::init of both,
+        intra estimate of the second, P-frame cost pass of all pairs in ONE launch.  Returns a list of backends.Orc.lookahead_cost_p tuples."""
+        lw, lh = ((w // 2 + 7) // 8) * 8, ((h // 2 + 7) // 8) * 8
+        stride = lw + 2 * mx
+        stride += (32 - stride % 32) % 32
+        pe = (lh + 2 * my) * stride
+        org = my * stride + mx
+        wcu, hcu = lw // 8, lh // 8
+        ncu = wcu * hcu
+        n = len(pairs)
+        keep, descs, outs = [], (hp.LookaheadPair * n)(), []
+        qp = 12 + 6 * (self.depth - 8)
+        if qp not in self._mvcost:
+            tab = np.zeros(2 * MVCOST_HALF + 1, np.uint16)
+            check(self.L.x265hip_mvcost_table(qp, self.depth, tab.ctypes.data, MVCOST_HALF))
+            self._mvcost[qp] = DevBuf(tab)
+        for i, (s0, s1) in enumerate(pairs):
+            planes = []
+            for src in (s0, s1):
+                ds = DevBuf(src)
+                pl = DevBuf.zeros((4, lh + 2 * my, stride), self.pix)
+                ptrs = (C.c_void_p * 4)(*[pl.at(k * pe + org) for k in range(4)])
+                check(self.L.x265hip_lowres_init(self.depth, ds.at(_off(src, origin)), src.shape[1], ptrs, stride, lw, lh, mx, my, None))
+                planes.append(pl)
+                keep.append(ds)
+            icost, imode = DevBuf.zeros((ncu,), np.int32), DevBuf.zeros((ncu,), np.uint8)
+            check(self.L.x265hip_lowres_intra_estimate(self.depth, planes[1].at(org), stride, wcu, hcu, icost.ptr, imode.ptr, None, None, None))
+            o = dict(mvs=DevBuf.zeros((ncu, 2), np.int32), mvc=DevBuf.zeros((ncu,), np.int32), lc=DevBuf.zeros((ncu,), np.uint16),
+                     rows=DevBuf.zeros((hcu,), np.int32), sync=DevBuf.zeros((ncu,), np.uint64), icost=icost)
+            d = descs[i]
+            d.fenc, d.ref, d.intraCost = planes[1].at(org), planes[0].at(org), icost.ptr
+            d.mvs, d.mvCosts, d.lowresCosts, d.rowSatds, d.sync = o["mvs"].ptr, o["mvc"].ptr, o["lc"].ptr, o["rows"].ptr, o["sync"].ptr
+            keep += planes + [imode]
+            outs.append(o)
+        ddesc = DevBuf(np.frombuffer(bytes(descs), np.uint8))
+        est = DevBuf.zeros((n, 2), np.int32)
+        for rep in range(2):      # twice on the same scratch: the second launch must not see the first one's handshake words
+            self._epoch[0] += 1
+            check(self.L.x265hip_lookahead_cost_p_batch(self.depth, ddesc.ptr, n, stride, pe, wcu, hcu, rows_per_slice, num_slices,
+                                                        self._mvcost[qp].at(MVCOST_HALF), self._epoch[0], est.ptr, None))
+        e = est.get()
+        return [(int(e[i, 0]), o["mvs"].get(), o["mvc"].get(), o["lc"].get(), o["rows"].get(), int(e[i, 1]), o["icost"].get()) for i, o in enumerate(outs)]
+
+    def lookahead_cost_p(self, src0, src1, origin, w, h, mx, my, rows_per_slice, num_slices):
+        return self.lookahead_cost_p_batch([(src0, src1)], origin, w, h, mx, my, rows_per_slice, num_slices)[0]

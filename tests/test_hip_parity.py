@@ -4,6 +4,8 @@ The per-primitive sweep reuses the TestBench-shaped seeded cases of tests/cases.
 buffers, unaligned origins, stride 96) — the same cases that pin the oracle to the real reference and to the golden
 digests — and reports EVERY mismatch (grouped), not just the first, so one GPU run tells the whole story."""
 import collections
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -480,6 +482,33 @@ def test_lowres_pass_matches_oracle(hipmod, depth):
             assert np.array_equal(a[k], b[k]), (w, h, k, np.argwhere(a[k] != b[k])[:5])
         for pa, pb in zip(a[4], b[4]):
             assert np.array_equal(pa[:, :lw + 2 * m], pb[:, :lw + 2 * m]), (w, h)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_lookahead_p_cost_matches_oracle(hipmod, depth):
+    """The lookahead's P-frame cost pass (lowres init -> intra estimate -> estimateCUCost over the frame) on the GPU vs the
+    restatement: every block's vector, cost, packed lowresCost, the row sums, the frame score and the intra count; serial and
+    sliced; 11 pairs in one launch (not a multiple of the 8 XCDs), run twice on the same handshake scratch."""
+    from cases import lookahead_scene
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    o, g = Orc(depth), hipmod.Hip(depth)
+    for (w, h, rps, ns) in make_golden.LOOKAHEAD_CASES:
+        s0, s1, m = lookahead_scene(depth, 700 + depth + w, h, w)
+        a = o.lookahead_cost_p(s0, s1, (m, m), w, h, m, m, rps, ns)
+        b = g.lookahead_cost_p(s0, s1, (m, m), w, h, m, m, rps, ns)
+        hipmod._release()
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert same(x, y), (w, h, rps, ns, k)
+    w, h = 320, 200
+    scenes = [lookahead_scene(depth, 900 + depth + i, h, w) for i in range(11)]
+    m = scenes[0][2]
+    got = g.lookahead_cost_p_batch([(s[0], s[1]) for s in scenes], (m, m), w, h, m, m, 4, 3)
+    hipmod._release()
+    for i, sc in enumerate(scenes):
+        want = o.lookahead_cost_p(sc[0], sc[1], (m, m), w, h, m, m, 4, 3)
+        for k, (x, y) in enumerate(zip(want, got[i])):
+            assert same(x, y), (i, k)
 
 
 def test_twelve_bit_primitives_match_oracle(hipmod):
