@@ -255,16 +255,27 @@ def main():
     if rank == 0:
         ab = algorithmic_bytes(W, H, DEPTH, MERANGE)
         dom = max(STAGES, key=lambda s: stage_ms[s])
-        # the dominant stage is a motion-search level: algorithmic bytes = source + reference picture once each (every
-        # PU of a level tiles the picture and the search windows overlap: compulsory traffic is the two pictures) + I/O arrays
+        # A motion-search level is a chain of the reference's sad / sad_x3 / sad_x4 / interpolate + satd slot calls.  ALGORITHMIC bytes per
+        # launch = SURVEY.md §8d's per-call figures (sad 2WHB, sad_x3 4WHB, sad_x4 5WHB, an interpolated candidate adds the filter's
+        # in + out bytes) summed over the calls the reference's search issues per PU on THIS workload, counted with the pinned CPU
+        # oracle by tools/count_me_units.py (the search is bit-exact, so the GPU walks the same candidates), x the PUs of the launch.
+        # The unique footprint (source + reference window once + 44 B per PU), which is all HBM must deliver when caches work, is
+        # reported next to it as `unique_footprint`.
         n_by_stage = {"me64": 480, "me32": 1980, "me16": 8040, "me8": 32400}
+        ME_BYTES_PER_PU = {"me64": 283422.6, "me32": 64257.7, "me16": 15408.4, "me8": 4067.6}   # tools/count_me_units.py, seed 4321
+        ME_CALLS_PER_PU = {"me64": 17.58, "me32": 16.23, "me16": 15.15, "me8": 15.09}
         S_, R_ = W + 2 * MARGIN, H + 2 * MARGIN
+        unique = None
         if dom in n_by_stage:
             n = n_by_stage[dom]
-            dom_bytes = W * H + (W + 2 * (MERANGE + 4)) * (H + 2 * (MERANGE + 4)) + n * (12 + 32)
+            dom_bytes = int(ME_BYTES_PER_PU[dom] * n)
+            ub = W * H + (W + 2 * (MERANGE + 4)) * (H + 2 * (MERANGE + 4)) + n * (12 + 32)
+            unique = {"bytes_per_launch": ub, "achieved": round(ub / (stage_ms[dom] * 1e-3) / 1e9, 2),
+                      "frac": round(ub / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}
             names = {"me64": "motion2_kernel<u8,64,4,planes>", "me32": "motion3_kernel<u8,32,64>", "me16": "motion3_kernel<u8,16,16>",
                      "me8": "motion3_kernel<u8,8,16>"}
-            kernel = "%s (%s: %d PUs; compulsory bytes = source + reference window once + 44 B per PU)" % (names[dom], dom, n)
+            kernel = "%s (%s: %d PUs x %.0f B = %.1f reference slot calls per PU, SURVEY 8d per-call bytes)" % (
+                names[dom], dom, n, ME_BYTES_PER_PU[dom], ME_CALLS_PER_PU[dom])
         elif dom == "planes":
             dom_bytes = 17 * S_ * R_                       # read the padded reference once, write 16 planes
             kernel = "subpel_planes_kernel<u8> (16 quarter-pel planes of the padded reference)"
@@ -285,7 +296,7 @@ def main():
                        "frames_per_step": world * F, "frames_in_flight_per_gpu": F, "pus_per_frame": 42900, "tus_per_frame": 8100},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": stage_ms[dom]},
+                         "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": stage_ms[dom], "unique_footprint": unique},
             "stage_ms": stage_ms,
         }
         if world == 1 and args.cpu_frames > 0:

@@ -190,6 +190,11 @@ const int16_t* orc_dct_matrix(int log2n);    /* N*N row-major */
 void orc_mvcost_table(int qp, int depth, uint16_t* table);
 /* common/primitives.cpp lumaPartitionMapTable via partitionFromSizes (primitives.h:435): LumaPU enum or -1 */
 int orc_partition_from_sizes(int w, int h);
+/* per-call traffic accounting of orc_motion_estimate (SURVEY.md §8d figures); out = { bytes, primitive calls } */
+void orc_me_stats_reset(void);
+void orc_me_stats(uint64_t out[2]);
+/* per motion-search level of the last orc_frame_pass_*: { bytes, primitive calls, PUs } x 4 */
+void orc_frame_pass_me_stats(uint64_t out[12]);
 
 #ifdef __cplusplus
 }

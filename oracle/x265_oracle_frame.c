@@ -28,6 +28,10 @@ void orc_set_search_range(int picW, int picH, int maxCUSize, int merange, int re
     mvmin[0] = mn[0]; mvmin[1] = mn[1]; mvmax[0] = mx[0]; mvmax[1] = mx[1];
 }
 
+/* { bytes, primitive calls, PUs } of each motion-search level of the last orc_frame_pass_* call (see orc_me_stats) */
+static uint64_t g_frame_me_stats[4][3];
+void orc_frame_pass_me_stats(uint64_t out[12]) { memcpy(out, g_frame_me_stats, sizeof(g_frame_me_stats)); }
+
 #define PIX uint8_t
 #define FN(x) x##_8
 #include "x265_oracle_frame.inc"
