@@ -88,6 +88,7 @@ def oracle():
         f("orc_p2s", None, [vp, ip, vp, ip, i32, i32, i32])
         f("orc_motion_estimate", i32, [vp, ip, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, vp, i32, vp])
         f("orc_subpel_compare", i32, [vp, ip, i32, i32, vp, i32, i32, i32, i32, i32, i32])
+        f("orc_motion_estimate_chroma", i32, [vp, ip, vp, vp, ip, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, vp, i32, vp])
         f("orc_intra_filter", None, [i32, vp, vp])
         f("orc_intra_pred", None, [i32, i32, vp, ip, vp, i32, i32])
         f("orc_intra_uses_filtered", i32, [i32, i32])
@@ -208,6 +209,7 @@ def ref(depth):
     g("ref_partition_from_sizes", i32, [i32, i32])
     g("ref_mvcost_table", None, [i32, vp])
     g("ref_motion_estimate", i32, [vp, vp, ip, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp])
+    g("ref_motion_estimate_chroma", i32, [vp, vp, vp, vp, vp, vp, ip, ip, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp])
     g("ref_intra_filter", None, [i32, vp, vp])
     g("ref_intra_pred", None, [i32, i32, vp, ip, vp, i32])
     g("ref_intra_allangs", None, [i32, vp, vp, vp, i32])

@@ -329,4 +329,69 @@ int64_t ref_lookahead_cost_p(pixel* pic0, pixel* pic1, intptr_t stride, int w, i
     return ret;
 }
 
+/* ---- the real MotionEstimate::motionEstimate with the chroma SATD term of subpelCompare (encoder/motion.cpp:1601-1660), the
+ * way Search::predInterSearch runs it on a 4:2:0 picture.  The search, subpelCompare and every primitive are the reference's;
+ * only the PU set-up is done here (what setSourcePU(const Yuv&, ...) does at motion.cpp:196-224, without needing a CTU-sized
+ * Yuv and the encoder's z-scan tables): luma through the lookahead-style setSourcePU, chroma source copied into the PU cache,
+ * bChromaSATD = subme > 2 && chromaSatd (:212), and a one-entry offset table so ReferencePlanes::getCbAddr / getLumaAddr
+ * resolve to the PU position. */
+namespace {
+struct ChromaME : public MotionEstimate
+{
+    void arm(int subme, const pixel* fencCb, const pixel* fencCr, intptr_t fencStrideC, int w, int h)
+    {
+        chromaSatd = primitives.chroma[X265_CSP_I420].pu[partEnum].satd;
+        bChromaSATD = subme > 2 && chromaSatd;
+        for (int y = 0; y < h / 2; y++)
+        {
+            memcpy(fencPUYuv.m_buf[1] + y * fencPUYuv.m_csize, fencCb + y * fencStrideC, (w / 2) * sizeof(pixel));
+            memcpy(fencPUYuv.m_buf[2] + y * fencPUYuv.m_csize, fencCr + y * fencStrideC, (w / 2) * sizeof(pixel));
+        }
+        ctuAddr = 0;
+        absPartIdx = 0;
+    }
+};
+}
+
+int ref_motion_estimate_chroma(pixel* refY, pixel* refCb, pixel* refCr, pixel* fencY, pixel* fencCb, pixel* fencCr, intptr_t stride, intptr_t strideC,
+                               int bx, int by, int w, int h, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp,
+                               int numCand, const int32_t* mvc, int merange, int method, int subme, int qp, int32_t* outQMv)
+{
+    T();
+    ChromaME me;
+    me.init(X265_CSP_I420);
+    me.setQP(qp);
+    me.setSourcePU(fencY, stride, bx + (intptr_t)by * stride, w, h, method, method, method, subme);
+    me.arm(subme, fencCb + (bx >> 1) + (intptr_t)(by >> 1) * strideC, fencCr + (bx >> 1) + (intptr_t)(by >> 1) * strideC, strideC, w, h);
+    PicYuv recon;
+    intptr_t zero = 0, offY = bx + (intptr_t)by * stride, offC = (bx >> 1) + (intptr_t)(by >> 1) * strideC;
+    recon.m_cuOffsetY = &zero;
+    recon.m_cuOffsetC = &zero;
+    recon.m_buOffsetY = &offY;
+    recon.m_buOffsetC = &offC;
+    recon.m_picOrg[0] = refY;
+    recon.m_picOrg[1] = refCb;
+    recon.m_picOrg[2] = refCr;
+    recon.m_stride = stride;
+    recon.m_strideC = strideC;
+    ReferencePlanes ref;
+    ref.fpelPlane[0] = refY;
+    ref.fpelPlane[1] = refCb;
+    ref.fpelPlane[2] = refCr;
+    ref.reconPic = &recon;
+    ref.lumaStride = stride;
+    ref.chromaStride = strideC;
+    MV cands[16];
+    for (int i = 0; i < numCand && i < 16; i++)
+        cands[i] = MV(mvc[2 * i], mvc[2 * i + 1]);
+    MV out(0, 0);
+    int cost = me.motionEstimate(&ref, MV(mvmin[0], mvmin[1]), MV(mvmax[0], mvmax[1]), MV(qmvp[0], qmvp[1]),
+                                 numCand, cands, merange, out, 1, 0);
+    outQMv[0] = out.x;
+    outQMv[1] = out.y;
+    recon.m_picOrg[0] = recon.m_picOrg[1] = recon.m_picOrg[2] = NULL;
+    recon.m_cuOffsetY = recon.m_cuOffsetC = recon.m_buOffsetY = recon.m_buOffsetC = NULL;
+    return cost;
+}
+
 } // extern "C"

@@ -81,6 +81,12 @@ int orc_motion_estimate_##SFX(const P* plane, intptr_t stride, int bx, int by, c
                               const int32_t mvmin[2], const int32_t mvmax[2], const int32_t qmvp[2], \
                               int numCand, const int32_t* mvc, int merange, int method, int subme, \
                               const uint16_t* cost, int depth, int32_t outQMv[2]); \
+/* encoder/motion.cpp:739 with the chroma SATD term of subpelCompare (:1601-1660) as Search::predInterSearch runs it on 4:2:0 */ \
+int orc_motion_estimate_chroma_##SFX(const P* plane, intptr_t stride, const P* cbPlane, const P* crPlane, intptr_t strideC, int bx, int by, \
+                            const P* fenc, const P* fencCb, const P* fencCr, int w, int h, \
+                            const int32_t mvmin[2], const int32_t mvmax[2], const int32_t qmvp[2], \
+                            int numCand, const int32_t* mvc, int merange, int method, int subme, \
+                            const uint16_t* cost, int depth, int32_t outQMv[2]); \
 /* encoder/motion.cpp:1571 MotionEstimate::subpelCompare (luma only); cmp: 0 = sad, 1 = satd */ \
 int orc_subpel_compare_##SFX(const P* plane, intptr_t stride, int bx, int by, const P* fenc, int w, int h, \
                              int qmvx, int qmvy, int cmp, int depth);

@@ -303,6 +303,23 @@ class Orc(_Base):
                                               ptr(icost), po.vp(tab.ctypes.data + 2 * po.MVCOST_CENTRE), ptr(mvs), ptr(mvc), ptr(lc), ptr(rows), ptr(imb))
         return int(est), mvs, mvc, lc, rows, int(imb[0]), icost
 
+    def motion_estimate_chroma(self, ref, src, bx, by, w, h, mvmin, mvmax, qmvp, mvc, merange, method, subme, qp):
+        """ref / src: (Y, Cb, Cr) padded planes (chroma at half size, half margins); (bx, by) luma position in the padded plane."""
+        fenc = np.zeros((64, 64), self.pix)
+        fenc[:h, :w] = src[0][by:by + h, bx:bx + w]
+        fc = [np.zeros((32, 32), self.pix) for _ in range(2)]
+        for k in range(2):
+            fc[k][:h // 2, :w // 2] = src[1 + k][by // 2:by // 2 + h // 2, bx // 2:bx // 2 + w // 2]
+        cost = self.mvcost_table(qp)
+        a = [np.array(v, np.int32) for v in (mvmin, mvmax, qmvp)]
+        cand = np.array(mvc, np.int32).reshape(-1)
+        out = np.zeros(2, np.int32)
+        c = self._f("orc_motion_estimate_chroma")(ptr(ref[0]), ref[0].shape[1], ptr(ref[1]), ptr(ref[2]), ref[1].shape[1], bx, by,
+                                                  ptr(fenc), ptr(fc[0]), ptr(fc[1]), w, h, ptr(a[0]), ptr(a[1]), ptr(a[2]),
+                                                  len(mvc), ptr(cand) if len(mvc) else None, merange, method, subme,
+                                                  po.vp(cost.ctypes.data + 2 * po.MVCOST_CENTRE), self.depth, ptr(out))
+        return c, (int(out[0]), int(out[1]))
+
 
 class Ref(_Base):
     name = "reference"
@@ -561,6 +578,16 @@ class Ref(_Base):
         est = self.L.ref_lookahead_cost_p(ptr(src0, *origin), ptr(src1, *origin), src0.shape[1], w, h, mx, my, rows_per_slice, num_slices,
                                           ptr(mvs), ptr(mvc), ptr(lc), ptr(rows), ptr(imb), ptr(icost))
         return int(est), mvs, mvc, lc, rows, int(imb[0]), icost
+
+    def motion_estimate_chroma(self, ref, src, bx, by, w, h, mvmin, mvmax, qmvp, mvc, merange, method, subme, qp):
+        a = [np.array(v, np.int32) for v in (mvmin, mvmax, qmvp)]
+        cand = np.array(mvc, np.int32).reshape(-1)
+        out = np.zeros(2, np.int32)
+        assert ref[0].shape == src[0].shape and ref[1].shape == src[1].shape
+        c = self.L.ref_motion_estimate_chroma(ptr(ref[0]), ptr(ref[1]), ptr(ref[2]), ptr(src[0]), ptr(src[1]), ptr(src[2]),
+                                              ref[0].shape[1], ref[1].shape[1], bx, by, w, h, ptr(a[0]), ptr(a[1]), ptr(a[2]),
+                                              len(mvc), ptr(cand) if len(mvc) else None, merange, method, subme, qp, ptr(out))
+        return c, (int(out[0]), int(out[1]))
 
 
 def same(x, y):

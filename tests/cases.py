@@ -241,3 +241,17 @@ def lookahead_scene(depth, seed, H=136, W=200, margin=80):
     p1 = np.clip(np.rint(p1.astype(np.float64) + rng.normal(0, 2.0 * (pmax / 255.0), p1.shape)), 0, pmax).astype(p0.dtype)
     pad = ((margin, margin), (margin, margin + 8))
     return np.ascontiguousarray(np.pad(p0, pad, mode="edge")), np.ascontiguousarray(np.pad(p1, pad, mode="edge")), margin
+
+
+def me_scene_yuv(depth, seed, H=160, W=192, margin=80):
+    """me_scene plus Cb / Cr planes at half resolution (half margins) that move with the luma."""
+    ref, src, m = me_scene(depth, seed, H, W, margin)
+    rng = np.random.default_rng(seed + 5)
+    mid = 1 << (depth - 1)
+    pmax = (1 << depth) - 1
+
+    def chroma(y, gain):
+        sub = (y[0::2, 0::2].astype(np.int64) + y[1::2, 0::2] + y[0::2, 1::2] + y[1::2, 1::2] + 2) >> 2
+        c = mid + np.rint(gain * (sub - mid)).astype(np.int64) + rng.integers(-2, 3, sub.shape) * (1 << (depth - 8))
+        return np.ascontiguousarray(np.clip(c, 0, pmax).astype(y.dtype))
+    return (ref, chroma(ref, 0.6), chroma(ref, -0.5)), (src, chroma(src, 0.6), chroma(src, -0.5)), m

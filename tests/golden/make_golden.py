@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import numpy as np  # noqa: E402
 from backends import Ref  # noqa: E402
-from cases import gen_cases, me_scene, lowres_scene, lookahead_scene, digest  # noqa: E402
+from cases import gen_cases, me_scene, me_scene_yuv, lowres_scene, lookahead_scene, digest  # noqa: E402
 
 ME_CASES = [  # (method, subme, w, h, bx_off, by_off, merange, qmvp, mvc, qp)
     (1, 2, 16, 16, 16, 24, 57, (5, -7), [(12, 8), (-20, 4)], 28),
@@ -39,6 +39,37 @@ def me_digests(backend_cls, depth):
         mvmax = ((qmvp[0] >> 2) + mr, (qmvp[1] >> 2) + mr)
         cost, mv = b.motion_estimate(refp, srcp, m + bx, m + by, w, h, mvmin, mvmax, qmvp, mvc, mr, method, subme, qp)
         out["me#%d" % i] = [int(cost), int(mv[0]), int(mv[1])]
+    return out
+
+
+def chroma_me_cases():
+    """(w, h, bx, by, method, subme, qmvp, mvc): every PU shape x {DIA, HEX, STAR} x subme {2,3,4,5,7}, seeded positions."""
+    from backends import PU_SIZES
+    rng = np.random.default_rng(9)
+    out = []
+    for (w, h) in PU_SIZES:
+        if (w, h) == (4, 4):
+            continue
+        for method in (0, 1, 3):
+            for subme in (2, 3, 4, 5, 7):
+                bx, by = int(rng.integers(0, 192 - w) // 2 * 2), int(rng.integers(0, 160 - h) // 2 * 2)
+                qmvp = (int(rng.integers(-20, 21)), int(rng.integers(-20, 21)))
+                mvc = [(int(rng.integers(-30, 31)), int(rng.integers(-30, 31)))] if rng.integers(0, 2) else []
+                out.append((w, h, bx, by, method, subme, qmvp, mvc))
+    return out
+
+
+def chroma_me_results(backend_cls, depth, stride=1):
+    """motionEstimate with the chroma SATD term of subpelCompare (subme > 2, 4:2:0): [cost, mvx, mvy] per case."""
+    b = backend_cls(depth)
+    ref, src, m = me_scene_yuv(depth, 321 + depth)
+    out = {}
+    for i, (w, h, bx, by, method, subme, qmvp, mvc) in enumerate(chroma_me_cases()[::stride]):
+        mr = 16
+        mvmin = ((qmvp[0] >> 2) - mr, (qmvp[1] >> 2) - mr)
+        mvmax = ((qmvp[0] >> 2) + mr, (qmvp[1] >> 2) + mr)
+        cost, mv = b.motion_estimate_chroma(ref, src, m + bx, m + by, w, h, mvmin, mvmax, qmvp, mvc, mr, method, subme, 28)
+        out["cme#%d" % i] = [int(cost), int(mv[0]), int(mv[1])]
     return out
 
 
@@ -95,7 +126,7 @@ def prim_digests(backend_cls, depth):
 if __name__ == "__main__":
     gold = {}
     for depth in (8, 10):
-        gold[str(depth)] = {"prims": prim_digests(Ref, depth), "me": me_digests(Ref, depth), "lowres": lowres_digests(Ref, depth), "lookahead": lookahead_digests(Ref, depth),
+        gold[str(depth)] = {"prims": prim_digests(Ref, depth), "me": me_digests(Ref, depth), "chroma_me": chroma_me_results(Ref, depth), "lowres": lowres_digests(Ref, depth), "lookahead": lookahead_digests(Ref, depth),
                             "mvcost": {str(qp): digest(Ref(depth).mvcost_table(qp)) for qp in (12, 28, 37, 51)}}
     path = os.path.join(HERE, "primitives_golden.json")
     with open(path, "w") as f:

@@ -33,6 +33,11 @@ def test_oracle_motion_estimate_matches_golden(depth):
 
 
 @pytest.mark.parametrize("depth", [8, 10])
+def test_oracle_chroma_motion_estimate_matches_golden(depth):
+    assert make_golden.chroma_me_results(Orc, depth) == GOLD[str(depth)]["chroma_me"]
+
+
+@pytest.mark.parametrize("depth", [8, 10])
 def test_oracle_lowres_pass_matches_golden(depth):
     assert make_golden.lowres_digests(Orc, depth) == GOLD[str(depth)]["lowres"]
 

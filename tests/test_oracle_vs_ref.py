@@ -116,3 +116,16 @@ def test_lookahead_p_cost_matches_reference(depth):
     assert set(a) == set(b)
     for k in a:
         assert same(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_chroma_motion_estimate_matches_reference(depth):
+    """The real MotionEstimate with bChromaSATD (subpelCompare's Cb + Cr SATD term, motion.cpp:1601-1660) vs the restatement:
+    every PU shape x DIA / HEX / STAR x subme 2..7."""
+    _need_ref(depth)
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    a, b = make_golden.chroma_me_results(Orc, depth), make_golden.chroma_me_results(Ref, depth)
+    assert a == b, [k for k in a if a[k] != b[k]][:10]
+    assert len(a) == 360
