@@ -189,6 +189,16 @@ int x265hip_motion_estimate_planes_batch(int depth, int w, int h,
                                          int numCand, const int32_t* mvc, int merange, int searchMethod, int subme,
                                          const uint16_t* mvcost, int mvcostHalf,
                                          int n, int32_t* outMv, int32_t* outCost, void* stream);
+/* The same search as Search::predInterSearch runs it on a 4:2:0 picture (setSourcePU with bChroma, motion.cpp:196-224): for
+ * subme > 2 and chroma blocks of whole 4x4 tiles every subpelCompare call adds the SATD of the Cb and Cr blocks predicted at
+ * the candidate vector (motion.cpp:1601-1660; 4-tap filters, eighth-pel).  Chroma planes are picture origins at half
+ * resolution; pu_xy stays in luma samples (even).  Other shapes / subme <= 2 fall through to the luma-only search. */
+int x265hip_motion_estimate_chroma_batch(int depth, int w, int h, const void* fencPlane, int64_t strideF, const void* fencCb,
+                                         const void* fencCr, int64_t strideFC, const void* refPlane, int64_t strideR,
+                                         const void* refCb, const void* refCr, int64_t strideRC,
+                                         const int32_t* pu_xy, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp,
+                                         int numCand, const int32_t* mvc, int merange, int searchMethod, int subme,
+                                         const uint16_t* mvcost, int mvcostHalf, int n, int32_t* outMv, int32_t* outCost, void* stream);
 
 /* Search::setSearchRange (reference: source/encoder/search.cpp:2724-2770) with CUData::clipMv (cudata.cpp:1915-1928) for n
  * CUs at cu_xy [n][2]: qmvp[i] = mvSrc[srcIdx[i]] (quarter-pel; (0,0) when mvSrc is NULL or srcIdx[i] < 0), then

@@ -391,3 +391,26 @@ class Hip:
 
     def lookahead_cost_p(self, src0, src1, origin, w, h, mx, my, rows_per_slice, num_slices):
         return self.lookahead_cost_p_batch([(src0, src1)], origin, w, h, mx, my, rows_per_slice, num_slices)[0]
+
+    def motion_estimate_chroma_batch(self, ref, src, w, h, pu_xy, mvmin, mvmax, qmvp, mvc, merange, method, subme, qp):
+        """ref / src = (Y, Cb, Cr) padded planes; the chroma origin is the plane origin (positions are absolute, even)."""
+        n = len(pu_xy)
+        numCand = len(mvc[0]) if n and len(mvc) else 0
+        d = [DevBuf(p) for p in (ref[0], ref[1], ref[2], src[0], src[1], src[2])]
+        tab = self._mvcost[qp]
+        outmv, outcost = DevBuf.zeros((n, 2), np.int32), DevBuf.zeros((n,), np.int32)
+        cand = dev_i32(np.asarray(mvc, np.int32).reshape(-1)) if numCand else None
+        check(self.L.x265hip_motion_estimate_chroma_batch(
+            self.depth, w, h, d[3].ptr, src[0].shape[1], d[4].ptr, d[5].ptr, src[1].shape[1], d[0].ptr, ref[0].shape[1], d[1].ptr, d[2].ptr,
+            ref[1].shape[1], _ip(np.asarray(pu_xy, np.int32)), _ip(np.asarray(mvmin, np.int32)), _ip(np.asarray(mvmax, np.int32)),
+            _ip(np.asarray(qmvp, np.int32)), numCand, cand.ptr if cand else None, merange, method, subme,
+            tab.at(MVCOST_HALF), MVCOST_HALF, n, outmv.ptr, outcost.ptr, None))
+        return outcost.get(), outmv.get()
+
+    def motion_estimate_chroma(self, ref, src, bx, by, w, h, mvmin, mvmax, qmvp, mvc, merange, method, subme, qp):
+        if qp not in self._mvcost:
+            from backends import Orc
+            self.set_mvcost_table(qp, Orc(self.depth).mvcost_table(qp))
+        cost, mv = self.motion_estimate_chroma_batch(ref, src, w, h, [(bx, by)], [mvmin], [mvmax], [qmvp], [mvc] if len(mvc) else [],
+                                                     merange, method, subme, qp)
+        return int(cost[0]), (int(mv[0, 0]), int(mv[0, 1]))

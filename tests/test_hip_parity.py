@@ -484,6 +484,32 @@ def test_lowres_pass_matches_oracle(hipmod, depth):
             assert np.array_equal(pa[:, :lw + 2 * m], pb[:, :lw + 2 * m]), (w, h)
 
 
+@pytest.mark.parametrize("depth", [8, 10, 12])
+def test_chroma_motion_estimate_matches_oracle(hipmod, depth):
+    """motionEstimate with the chroma SATD term of subpelCompare (subme > 2, 4:2:0): every PU shape x DIA / HEX / STAR x subme
+    2..7 one by one, then a frame-shaped batch of 16x16 PUs at subme 3 (BASELINE configs[2])."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    from cases import me_scene_yuv
+    want = make_golden.chroma_me_results(Orc, depth)
+    got = make_golden.chroma_me_results(hipmod.Hip, depth)
+    hipmod._release()
+    bad = [k for k in want if want[k] != got[k]]
+    assert not bad, (len(bad), bad[:8], [(want[k], got[k]) for k in bad[:4]])
+    o, g = Orc(depth), hipmod.Hip(depth)
+    ref, src, m = me_scene_yuv(depth, 321 + depth)
+    pus = [(m + x, m + y) for y in range(0, 160, 16) for x in range(0, 192, 16)]
+    qmvp = [((i * 7) % 23 - 11, (i * 5) % 19 - 9) for i in range(len(pus))]
+    mvmin = [((q[0] >> 2) - 16, (q[1] >> 2) - 16) for q in qmvp]
+    mvmax = [((q[0] >> 2) + 16, (q[1] >> 2) + 16) for q in qmvp]
+    g.motion_estimate_chroma(ref, src, pus[0][0], pus[0][1], 16, 16, mvmin[0], mvmax[0], qmvp[0], [], 16, 3, 3, 28)   # loads the cost table
+    cost, mv = g.motion_estimate_chroma_batch(ref, src, 16, 16, pus, mvmin, mvmax, qmvp, [], 16, 3, 3, 28)
+    hipmod._release()
+    for i, (bx, by) in enumerate(pus):
+        c, v = o.motion_estimate_chroma(ref, src, bx, by, 16, 16, mvmin[i], mvmax[i], qmvp[i], [], 16, 3, 3, 28)
+        assert (int(cost[i]), int(mv[i, 0]), int(mv[i, 1])) == (c, v[0], v[1]), i
+
+
 @pytest.mark.parametrize("depth", [8, 10])
 def test_lookahead_p_cost_matches_oracle(hipmod, depth):
     """The lookahead's P-frame cost pass (lowres init -> intra estimate -> estimateCUCost over the frame) on the GPU vs the

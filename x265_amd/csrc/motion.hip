@@ -60,6 +60,12 @@ struct MeCtx
     int w, h, depth, lane;
     int quadsX, quads;                   // quads = (w/4) * h groups of 4 horizontally adjacent pixels
     int gs, ngroups;                     // lanes per candidate group, groups per wave
+    bool chroma;                         // bChromaSATD (motion.cpp:212): subme > 2 and the 4:2:0 chroma block is whole 4x4 tiles
+    const P* crefCb;                     // reference chroma planes at the PU's chroma origin
+    const P* crefCr;
+    int64_t strideC;
+    P* fencCb;                           // LDS, (w/2) x (h/2) each
+    P* fencCr;
 
     __device__ __forceinline__ int mvcost(int qx, int qy) const
     {
@@ -113,36 +119,39 @@ struct MeCtx
         }
     }
 
-    // ---- W x H block at `r` (integer position in the reference plane) filtered to phase (xFrac, yFrac) into dst:
-    // copy / luma_hpp / luma_vpp / luma_hvpp exactly as subpelCompare (motion.cpp:1571-1600) and
+    // ---- bw x bh block at `r` (integer position in a reference plane of pitch rs) filtered to phase (xFrac, yFrac) into dst:
+    // copy / hpp / vpp / hps + vsp exactly as subpelCompare (motion.cpp:1571-1600 luma 8-tap, :1626-1658 chroma 4-tap) and
     // Predict::predInterLumaPixel (predict.cpp:245-266) select them.  dst may be LDS or global.
-    __device__ __forceinline__ void interp_block(const P* r, int xFrac, int yFrac, P* dst, int64_t ds) const
+    template <int NT>
+    __device__ __forceinline__ void interp_blk(const P* r, int64_t rs, int xFrac, int yFrac, P* dst, int64_t ds, int bw, int bh) const
     {
+        constexpr int HALF = NT / 2 - 1, SPAN = 4 + NT - 1;
+        const int qX = bw >> 2, nq = qX * bh;
         if (!(xFrac | yFrac))
         {
-            for (int q = lane; q < quads; q += 64)
+            for (int q = lane; q < nq; q += 64)
             {
-                const int row = q / quadsX, c4 = (q - row * quadsX) * 4;
-                st_unaligned<Q>(dst + row * ds + c4, ld_unaligned<Q>(r + (int64_t)row * stride + c4));
+                const int row = q / qX, c4 = (q - row * qX) * 4;
+                st_unaligned<Q>(dst + row * ds + c4, ld_unaligned<Q>(r + (int64_t)row * rs + c4));
             }
         }
         else if (!yFrac)
         {
             const Stage st = stage_for(IF_HPP, depth);
-            int c[8];
+            int c[NT];
 #pragma unroll
-            for (int i = 0; i < 8; i++) c[i] = kLumaFilter[xFrac][i];
-            for (int q = lane; q < quads; q += 64)
+            for (int i = 0; i < NT; i++) c[i] = filter_tap<NT>(xFrac, i);
+            for (int q = lane; q < nq; q += 64)
             {
-                const int row = q / quadsX, c4 = (q - row * quadsX) * 4;
-                int v[11], out[4];
-                load_span<11>(r + (int64_t)row * stride + c4 - 3, v);
+                const int row = q / qX, c4 = (q - row * qX) * 4;
+                int v[SPAN], out[4];
+                load_span<SPAN>(r + (int64_t)row * rs + c4 - HALF, v);
 #pragma unroll
                 for (int o = 0; o < 4; o++)
                 {
                     int sum = 0;
 #pragma unroll
-                    for (int i = 0; i < 8; i++) sum += v[o + i] * c[i];
+                    for (int i = 0; i < NT; i++) sum += v[o + i] * c[i];
                     out[o] = finish(sum, st);
                 }
                 store4(dst + row * ds + c4, out);
@@ -151,18 +160,18 @@ struct MeCtx
         else if (!xFrac)
         {
             const Stage st = stage_for(IF_VPP, depth);
-            int c[8];
+            int c[NT];
 #pragma unroll
-            for (int i = 0; i < 8; i++) c[i] = kLumaFilter[yFrac][i];
-            for (int q = lane; q < quads; q += 64)
+            for (int i = 0; i < NT; i++) c[i] = filter_tap<NT>(yFrac, i);
+            for (int q = lane; q < nq; q += 64)
             {
-                const int row = q / quadsX, c4 = (q - row * quadsX) * 4;
+                const int row = q / qX, c4 = (q - row * qX) * 4;
                 int sum[4] = { 0, 0, 0, 0 }, out[4];
 #pragma unroll
-                for (int i = 0; i < 8; i++)
+                for (int i = 0; i < NT; i++)
                 {
                     int v[4];
-                    load4(r + (int64_t)(row + i - 3) * stride + c4, v);
+                    load4(r + (int64_t)(row + i - HALF) * rs + c4, v);
 #pragma unroll
                     for (int o = 0; o < 4; o++) sum[o] += v[o] * c[i];
                 }
@@ -174,36 +183,36 @@ struct MeCtx
         else
         {
             const Stage s1 = stage_for(IF_HPS, depth), s2 = stage_for(IF_VSP, depth);
-            int c1[8], c2[8];
+            int c1[NT], c2[NT];
 #pragma unroll
-            for (int i = 0; i < 8; i++) { c1[i] = kLumaFilter[xFrac][i]; c2[i] = kLumaFilter[yFrac][i]; }
-            const int quads1 = quadsX * (h + 7);
+            for (int i = 0; i < NT; i++) { c1[i] = filter_tap<NT>(xFrac, i); c2[i] = filter_tap<NT>(yFrac, i); }
+            const int quads1 = qX * (bh + NT - 1);
             for (int q = lane; q < quads1; q += 64)
             {
-                const int row = q / quadsX, c4 = (q - row * quadsX) * 4;
-                int v[11], out[4];
-                load_span<11>(r + (int64_t)(row - 3) * stride + c4 - 3, v);
+                const int row = q / qX, c4 = (q - row * qX) * 4;
+                int v[SPAN], out[4];
+                load_span<SPAN>(r + (int64_t)(row - HALF) * rs + c4 - HALF, v);
 #pragma unroll
                 for (int o = 0; o < 4; o++)
                 {
                     int sum = 0;
 #pragma unroll
-                    for (int i = 0; i < 8; i++) sum += v[o + i] * c1[i];
+                    for (int i = 0; i < NT; i++) sum += v[o + i] * c1[i];
                     out[o] = finish(sum, s1);
                 }
-                store4(tmp + row * w + c4, out);
+                store4(tmp + row * bw + c4, out);
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
-            for (int q = lane; q < quads; q += 64)
+            for (int q = lane; q < nq; q += 64)
             {
-                const int row = q / quadsX, c4 = (q - row * quadsX) * 4;
+                const int row = q / qX, c4 = (q - row * qX) * 4;
                 int sum[4] = { 0, 0, 0, 0 }, out[4];
 #pragma unroll
-                for (int i = 0; i < 8; i++)
+                for (int i = 0; i < NT; i++)
                 {
                     int v[4];
-                    load4(tmp + (row + i) * w + c4, v);
+                    load4(tmp + (row + i) * bw + c4, v);
 #pragma unroll
                     for (int o = 0; o < 4; o++) sum[o] += v[o] * c2[i];
                 }
@@ -214,6 +223,10 @@ struct MeCtx
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void interp_block(const P* r, int xFrac, int yFrac, P* dst, int64_t ds) const
+    {
+        interp_blk<8>(r, stride, xFrac, yFrac, dst, ds, w, h);
     }
 
     __device__ __forceinline__ void build_pred(int qx, int qy) const
@@ -230,29 +243,53 @@ struct MeCtx
     }
 
     // pixel.cpp:263-297 satd tilers, see pixel.hip for the per-tile >> 1 argument
-    __device__ __forceinline__ int satd_pred() const
+    __device__ __forceinline__ int satd_blocks(const P* a, int sa, const P* b, int sb, int bw, int bh) const
     {
-        const int tilesX = w >> 2, tiles = tilesX * (h >> 2);
+        const int tilesX = bw >> 2, tiles = tilesX * (bh >> 2);
         int acc = 0;
         for (int t = lane; t < tiles; t += 64)
         {
             const int ty = t / tilesX, tx = t - ty * tilesX;
             int m[16];
-            tile_diff(fenc + ty * 4 * w + tx * 4, (int64_t)w, pred + ty * 4 * w + tx * 4, (int64_t)w, m);
+            tile_diff(a + ty * 4 * sa + tx * 4, (int64_t)sa, b + ty * 4 * sb + tx * 4, (int64_t)sb, m);
             hadamard4x4(m);
             acc += abs_sum16(m) >> 1;
         }
         return uni(wave_sum(acc));
     }
+    __device__ __forceinline__ int satd_pred() const { return satd_blocks(fenc, w, pred, w, w, h); }
 
-    // MotionEstimate::subpelCompare (luma): cmp 0 = sad, 1 = satd
+    // the chroma part of subpelCompare (motion.cpp:1601-1660, 4:2:0): SATD of the Cb and Cr blocks predicted at the same
+    // vector, eighth-pel in chroma samples; `pred` is free again once the luma cost has been summed
+    __device__ __forceinline__ int chroma_term(Mv q) const
+    {
+        const int cw = w >> 1, ch = h >> 1;
+        const int64_t off = (int64_t)(q.y >> 3) * strideC + (q.x >> 3);
+        int cost = 0;
+#pragma unroll 1
+        for (int pl = 0; pl < 2; pl++)
+        {
+            interp_blk<4>((pl ? crefCr : crefCb) + off, strideC, q.x & 7, q.y & 7, pred, (int64_t)cw, cw, ch);
+            cost += satd_blocks(pl ? fencCr : fencCb, cw, pred, cw, cw, ch);
+            __builtin_amdgcn_wave_barrier();
+        }
+        return cost;
+    }
+
+    // MotionEstimate::subpelCompare: cmp 0 = sad, 1 = satd (luma), + the chroma SATD term when bChromaSATD
     __device__ __forceinline__ int subpel(Mv q, int cmp) const
     {
+        int v;
         if (!cmp && !((q.x | q.y) & 3))
-            return sad_at(q.x >> 2, q.y >> 2);
-        build_pred(q.x, q.y);
-        const int v = cmp ? satd_pred() : sad_pred();
-        __builtin_amdgcn_wave_barrier();
+            v = sad_at(q.x >> 2, q.y >> 2);
+        else
+        {
+            build_pred(q.x, q.y);
+            v = cmp ? satd_pred() : sad_pred();
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (chroma)
+            v += chroma_term(q);
         return v;
     }
 };
@@ -273,6 +310,9 @@ __device__ __constant__ const int8_t kSquare1[9][2] = { {0,0}, {0,-1}, {0,1}, {-
 // motion.cpp:48-58 workload[subme] = { hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd }
 __device__ __constant__ const uint8_t kWorkload[8][5] = { {1,4,0,4,0}, {1,4,1,4,0}, {1,4,1,4,1}, {2,4,1,4,1}, {2,4,2,4,1}, {1,8,1,8,1}, {2,8,1,8,1}, {2,8,2,8,1} };
 
+// bChromaSATD inputs (4:2:0): source and reference chroma planes at the picture origin
+struct ChromaPlanes { const void* fencCb; const void* fencCr; int64_t strideFC; const void* refCb; const void* refCr; int64_t strideRC; int enable; };
+
 template <typename P>
 __global__ __launch_bounds__(256) void motion_kernel(const P* __restrict__ fencPlane, int64_t strideF,
                                                      const P* __restrict__ refPlane, int64_t strideR,
@@ -280,7 +320,7 @@ __global__ __launch_bounds__(256) void motion_kernel(const P* __restrict__ fencP
                                                      const int32_t* __restrict__ mvmaxA, const int32_t* __restrict__ qmvpA,
                                                      int numCand, const int32_t* __restrict__ mvcA, int merange, int method, int subme,
                                                      const uint16_t* __restrict__ mvcost, int w, int h, int depth, int n,
-                                                     int perWaveBytes, int32_t* __restrict__ outMv, int32_t* __restrict__ outCost)
+                                                     int perWaveBytes, int32_t* __restrict__ outMv, int32_t* __restrict__ outCost, ChromaPlanes cp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wv = threadIdx.x >> 6;
@@ -294,6 +334,10 @@ __global__ __launch_bounds__(256) void motion_kernel(const P* __restrict__ fencP
     c.fenc = reinterpret_cast<P*>(base);
     c.pred = reinterpret_cast<P*>(base + (size_t)w * h * sizeof(P));
     c.tmp = reinterpret_cast<int16_t*>(base + 2 * (size_t)w * h * sizeof(P));
+    c.chroma = cp.enable != 0;
+    c.strideC = cp.strideRC;
+    c.fencCb = reinterpret_cast<P*>(base + 2 * (size_t)w * h * sizeof(P) + (size_t)(h + 7) * w * 2);
+    c.fencCr = c.fencCb + (w >> 1) * (h >> 1);
     c.stride = strideR;
     c.cost = mvcost;
     typedef typename MeCtx<P>::Q Q;
@@ -315,6 +359,19 @@ __global__ __launch_bounds__(256) void motion_kernel(const P* __restrict__ fencP
             {
                 const int row = q / c.quadsX, c4 = (q - row * c.quadsX) * 4;
                 *reinterpret_cast<Q*>(c.fenc + row * w + c4) = ld_unaligned<Q>(f + (int64_t)row * strideF + c4);
+            }
+            if (c.chroma)
+            {
+                const int64_t coff = (int64_t)(by >> 1) * cp.strideFC + (bx >> 1);
+                const int cw = w >> 1, cq = (cw >> 2) * (h >> 1);
+                c.crefCb = (const P*)cp.refCb + (int64_t)(by >> 1) * cp.strideRC + (bx >> 1);
+                c.crefCr = (const P*)cp.refCr + (int64_t)(by >> 1) * cp.strideRC + (bx >> 1);
+                for (int q = c.lane; q < cq; q += 64)
+                {
+                    const int row = q / (cw >> 2), c4 = (q - row * (cw >> 2)) * 4;
+                    *reinterpret_cast<Q*>(c.fencCb + row * cw + c4) = ld_unaligned<Q>((const P*)cp.fencCb + coff + (int64_t)row * cp.strideFC + c4);
+                    *reinterpret_cast<Q*>(c.fencCr + row * cw + c4) = ld_unaligned<Q>((const P*)cp.fencCr + coff + (int64_t)row * cp.strideFC + c4);
+                }
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
@@ -573,6 +630,41 @@ extern "C" int x265hip_motion_estimate_batch(int depth, int w, int h, const void
                                                 numCand, mvc, merange, searchMethod, subme, mvcost, mvcostHalf, n, outMv, outCost, stream);
 }
 
+namespace xh {
+static int launch_motion_v1(int depth, int w, int h, const void* fencPlane, int64_t strideF, const void* refPlane, int64_t strideR,
+                            const int32_t* pu_xy, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp, int numCand, const int32_t* mvc,
+                            int merange, int searchMethod, int subme, const uint16_t* mvcost, int n, int32_t* outMv, int32_t* outCost,
+                            const ChromaPlanes& cp, hipStream_t st)
+{
+    const int B = depth == 8 ? 1 : 2;
+    int perWave = 2 * w * h * B + (h + 7) * w * 2 + (cp.enable ? 2 * (w >> 1) * (h >> 1) * B : 0);
+    perWave = (perWave + 15) & ~15;
+    // dynamic LDS is kept under 64 KiB per workgroup: big PUs at 16-bit run 2 waves per workgroup instead of 4
+    const int wpg = perWave * 4 <= 65536 ? 4 : (perWave * 2 <= 65536 ? 2 : 1);
+    dim3 grid(grid_for((n + wpg - 1) / wpg, 256 * 8)), block(64 * wpg);
+    if (depth == 8)
+        hipLaunchKernelGGL((motion_kernel<uint8_t>), grid, block, wpg * perWave, st, (const uint8_t*)fencPlane, strideF,
+                           (const uint8_t*)refPlane, strideR, pu_xy, mvmin, mvmax, qmvp, numCand, mvc, merange, searchMethod, subme,
+                           mvcost, w, h, depth, n, perWave, outMv, outCost, cp);
+    else
+        hipLaunchKernelGGL((motion_kernel<uint16_t>), grid, block, wpg * perWave, st, (const uint16_t*)fencPlane, strideF,
+                           (const uint16_t*)refPlane, strideR, pu_xy, mvmin, mvmax, qmvp, numCand, mvc, merange, searchMethod, subme,
+                           mvcost, w, h, depth, n, perWave, outMv, outCost, cp);
+    XH_LAUNCH_CHECK("motion_kernel");
+    return X265HIP_OK;
+}
+static int check_me_args(const char* who, int depth, int w, int h, int n, int searchMethod, int subme, int numCand, int merange, int mvcostHalf)
+{
+    if (!valid_depth(depth) || !valid_block(w, h) || (w & 3) || (h & 3) || (w == 4 && h == 4) || n < 0)
+        return set_error(X265HIP_EINVAL, "%s: depth %d PU %dx%d n %d", who, depth, w, h, n);
+    if (searchMethod != 0 && searchMethod != 1 && searchMethod != 3 && searchMethod != 5)
+        return set_error(X265HIP_EINVAL, "%s: searchMethod %d not implemented (DIA 0, HEX 1, STAR 3, FULL 5)", who, searchMethod);
+    if (subme < 0 || subme > 7 || numCand < 0 || merange < 1 || mvcostHalf < 4 * (merange + 64))
+        return set_error(X265HIP_EINVAL, "%s: subme %d numCand %d merange %d mvcostHalf %d", who, subme, numCand, merange, mvcostHalf);
+    return X265HIP_OK;
+}
+} // namespace xh
+
 extern "C" int x265hip_motion_estimate_planes_batch(int depth, int w, int h, const void* fencPlane, int64_t strideF,
                                                     const void* refPlane, int64_t strideR, const void* subpelPlanes, int64_t planeElems,
                                                     const int32_t* pu_xy, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp,
@@ -581,12 +673,8 @@ extern "C" int x265hip_motion_estimate_planes_batch(int depth, int w, int h, con
                                                     int32_t* outCost, void* stream)
 {
     XH_CHECK_DEV();
-    if (!valid_depth(depth) || !valid_block(w, h) || (w & 3) || (h & 3) || (w == 4 && h == 4) || n < 0)
-        return set_error(X265HIP_EINVAL, "motion_estimate: depth %d PU %dx%d n %d", depth, w, h, n);
-    if (searchMethod != 0 && searchMethod != 1 && searchMethod != 3 && searchMethod != 5)
-        return set_error(X265HIP_EINVAL, "motion_estimate: searchMethod %d not implemented (DIA 0, HEX 1, STAR 3, FULL 5)", searchMethod);
-    if (subme < 0 || subme > 7 || numCand < 0 || merange < 1 || mvcostHalf < 4 * (merange + 64))
-        return set_error(X265HIP_EINVAL, "motion_estimate: subme %d numCand %d merange %d mvcostHalf %d", subme, numCand, merange, mvcostHalf);
+    int e = check_me_args("motion_estimate", depth, w, h, n, searchMethod, subme, numCand, merange, mvcostHalf);
+    if (e) return e;
     if (!n) return X265HIP_OK;
     // square 8..64 PUs run on the team kernel of motion2.hip; everything else (and X265HIP_ME_V1=1) on the generic one
     static const bool forceV1 = getenv("X265HIP_ME_V1") != nullptr;
@@ -594,22 +682,32 @@ extern "C" int x265hip_motion_estimate_planes_batch(int depth, int w, int h, con
     if (!forceV1 && motion2_dispatch(depth, w, h, fencPlane, strideF, refPlane, strideR, pu_xy, mvmin, mvmax, qmvp, numCand, mvc, merange,
                                      searchMethod, subme, mvcost, n, subpelPlanes, planeElems, outMv, outCost, as_stream(stream), &rc2))
         return rc2;
-    const int B = depth == 8 ? 1 : 2;
-    int perWave = 2 * w * h * B + (h + 7) * w * 2;
-    perWave = (perWave + 15) & ~15;
-    // dynamic LDS is kept under 64 KiB per workgroup: big PUs at 16-bit run 2 waves per workgroup instead of 4
-    const int wpg = perWave * 4 <= 65536 ? 4 : (perWave * 2 <= 65536 ? 2 : 1);
-    dim3 grid(grid_for((n + wpg - 1) / wpg, 256 * 8)), block(64 * wpg);
-    if (depth == 8)
-        hipLaunchKernelGGL((motion_kernel<uint8_t>), grid, block, wpg * perWave, as_stream(stream), (const uint8_t*)fencPlane, strideF,
-                           (const uint8_t*)refPlane, strideR, pu_xy, mvmin, mvmax, qmvp, numCand, mvc, merange, searchMethod, subme,
-                           mvcost, w, h, depth, n, perWave, outMv, outCost);
-    else
-        hipLaunchKernelGGL((motion_kernel<uint16_t>), grid, block, wpg * perWave, as_stream(stream), (const uint16_t*)fencPlane, strideF,
-                           (const uint16_t*)refPlane, strideR, pu_xy, mvmin, mvmax, qmvp, numCand, mvc, merange, searchMethod, subme,
-                           mvcost, w, h, depth, n, perWave, outMv, outCost);
-    XH_LAUNCH_CHECK("motion_kernel");
-    return X265HIP_OK;
+    const ChromaPlanes none{};
+    return launch_motion_v1(depth, w, h, fencPlane, strideF, refPlane, strideR, pu_xy, mvmin, mvmax, qmvp, numCand, mvc, merange, searchMethod,
+                            subme, mvcost, n, outMv, outCost, none, as_stream(stream));
+}
+
+extern "C" int x265hip_motion_estimate_chroma_batch(int depth, int w, int h, const void* fencPlane, int64_t strideF, const void* fencCb,
+                                                    const void* fencCr, int64_t strideFC, const void* refPlane, int64_t strideR,
+                                                    const void* refCb, const void* refCr, int64_t strideRC,
+                                                    const int32_t* pu_xy, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp,
+                                                    int numCand, const int32_t* mvc, int merange, int searchMethod, int subme,
+                                                    const uint16_t* mvcost, int mvcostHalf, int n, int32_t* outMv, int32_t* outCost, void* stream)
+{
+    XH_CHECK_DEV();
+    int e = check_me_args("motion_estimate_chroma", depth, w, h, n, searchMethod, subme, numCand, merange, mvcostHalf);
+    if (e) return e;
+    if (!n) return X265HIP_OK;
+    // motion.cpp:212: bChromaSATD = subpelRefine > 2 && chromaSatd != NULL (the 4:2:0 block must be whole 4x4 tiles, pixel.cpp:1200-1226)
+    const bool on = subme > 2 && !((w >> 1) & 3) && !((h >> 1) & 3);
+    if (!on)
+        return x265hip_motion_estimate_planes_batch(depth, w, h, fencPlane, strideF, refPlane, strideR, nullptr, 0, pu_xy, mvmin, mvmax, qmvp,
+                                                    numCand, mvc, merange, searchMethod, subme, mvcost, mvcostHalf, n, outMv, outCost, stream);
+    if (!fencCb || !fencCr || !refCb || !refCr)
+        return set_error(X265HIP_EINVAL, "motion_estimate_chroma: chroma planes missing");
+    const ChromaPlanes cp{ fencCb, fencCr, strideFC, refCb, refCr, strideRC, 1 };
+    return launch_motion_v1(depth, w, h, fencPlane, strideF, refPlane, strideR, pu_xy, mvmin, mvmax, qmvp, numCand, mvc, merange, searchMethod,
+                            subme, mvcost, n, outMv, outCost, cp, as_stream(stream));
 }
 
 // ======================================================================================================================
@@ -653,6 +751,7 @@ __global__ __launch_bounds__(256) void pred_inter_luma_kernel(const P* __restric
     c.w = w; c.h = h; c.depth = depth;
     c.quadsX = w >> 2; c.quads = c.quadsX * h;
     c.stride = strideR;
+    c.chroma = false;
     c.tmp = reinterpret_cast<int16_t*>(smem + (size_t)wv * perWaveBytes);
     const int wavesPerWg = blockDim.x >> 6;
     for (int pu = blockIdx.x * wavesPerWg + wv; pu < n; pu += gridDim.x * wavesPerWg)

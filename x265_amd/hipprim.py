@@ -105,6 +105,8 @@ PROTOTYPES = {
     "x265hip_frame_init_lowres": (i32, [i32, vp, i64, vp, vp, vp, vp, i64, i32, i32, vp]),
     "x265hip_lowres_init": (i32, [i32, vp, i64, C.POINTER(vp), i64, i32, i32, i32, i32, vp]),
     "x265hip_lowres_intra_estimate": (i32, [i32, vp, i64, i32, i32, vp, vp, vp, vp, vp]),
+    "x265hip_motion_estimate_chroma_batch": (i32, [i32, i32, i32, vp, i64, vp, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, i32, vp, i32, i32, i32,
+                                                   vp, i32, i32, vp, vp, vp]),
     "x265hip_lookahead_cost_p_batch": (i32, [i32, vp, i32, i64, i64, i32, i32, i32, i32, vp, u32, vp, vp]),
     "x265hip_call_intra_pred": (i32, [i32, i32, i32, i32, vp, i64, vp]),
     "x265hip_call_intra_allangs": (i32, [i32, i32, vp, vp, vp, i32]),
