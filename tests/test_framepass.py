@@ -156,6 +156,20 @@ def test_yuv_frame_pass_is_bit_exact(fpmod, w, h, depth, qp, subme):
     assert sum(int(x.sum()) for x in want["cnumSig"]) > 0
 
 
+@pytest.mark.parametrize("w,h,depth,qp,method,subme", [(200, 136, 8, 28, 3, 3), (328, 200, 10, 30, 1, 4), (640, 360, 8, 26, 3, 3)])
+def test_yuv_frame_pass_with_chroma_satd_search(fpmod, w, h, depth, qp, method, subme):
+    """BASELINE configs[2]/[3] shape of the search: STAR / HEX at subme 3-4 on a 4:2:0 picture, where every sub-pel comparison of
+    motionEstimate carries the chroma SATD term — the whole pass against the C restatement."""
+    sc = make_scene_yuv(w, h, depth=depth, seed=77 + qp, tile=48, sigma=3.0 * (1 if depth == 8 else 4))
+    fp = fpmod.FramePass(w, h, depth=depth, qp=qp, method=method, subme=subme)
+    got = fp.run_host_yuv(sc)
+    want = oracle_frame_pass(sc["src"], sc["ref"], depth=depth, qp=qp, method=method, subme=subme, src_c=(sc["src_cb"], sc["src_cr"]),
+                             ref_c=(sc["ref_cb"], sc["ref_cr"]))
+    assert same_results(got, want) == []
+    luma_only = oracle_frame_pass(sc["src"], sc["ref"], depth=depth, qp=qp, method=method, subme=subme)
+    assert any(not np.array_equal(a, b) for a, b in zip(want["mv"], luma_only["mv"]))      # the chroma term does steer the search
+
+
 @pytest.mark.parametrize("depth", [8, 10])
 def test_pred_inter_chroma_matches_oracle(fpmod, depth):
     from oracle import pyoracle as po

@@ -294,6 +294,17 @@ static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t st
         dr.picW = fp->width; dr.picH = fp->height; dr.maxCUSize = 64;
         dr.refLagPixels = fp->height;                     // -F1: m_refLagPixels = sourceHeight (search.cpp:92)
         dr.qmvpO = fp->qmvp[l]; dr.mvminO = fp->mvmin[l]; dr.mvmaxO = fp->mvmax[l];
+        if (ca && fp->subme > 2)
+        {
+            // 4:2:0 picture at subme > 2: every sub-pel comparison carries the chroma SATD term (motion.cpp:212, :1601) -> the generic
+            // kernel with its 4-tap chroma path, search ranges from their own launch
+            FP_TRY(x265hip_set_search_range_batch(fp->width, fp->height, 64, fp->merange, fp->height, fp->puXY[l], dr.mvSrc, dr.srcIdx, n,
+                                                  fp->qmvp[l], fp->mvmin[l], fp->mvmax[l], stream));
+            FP_TRY(x265hip_motion_estimate_chroma_batch(depth, sz, sz, src, strideS, ca->srcCb, ca->srcCr, ca->sS, ref, strideR, ca->refCb, ca->refCr,
+                                                        ca->sR, fp->puXY[l], fp->mvmin[l], fp->mvmax[l], fp->qmvp[l], 0, nullptr, fp->merange,
+                                                        fp->method, fp->subme, fp->mvcost + kMvHalf, kMvHalf, n, fp->mv[l], fp->cost[l], stream));
+            continue;
+        }
         FP_TRY(motion_estimate_fused(depth, sz, src, strideS, ref, strideR, planesOrigin, fp->planeElems, fp->puXY[l], dr, fp->merange,
                                      fp->method, fp->subme, fp->mvcost + kMvHalf, n, fp->mv[l], fp->cost[l], as_stream(stream)));
     }
