@@ -95,6 +95,7 @@ def oracle():
         f("orc_intra_allangs", None, [i32, vp, vp, vp, i32, i32])
         f("orc_frame_init_lowres", None, [vp, vp, vp, vp, vp, ip, ip, i32, i32])
         f("orc_lowres_intra_estimate", i32, [vp, ip, i32, i32, i32, vp, vp, vp])
+        f("orc_lookahead_cost_b", i64, [vp, vp, vp, ip, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp])
         f("orc_lookahead_cost_p", i64, [vp, vp, ip, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp])
 
     def g(name, res, args):
@@ -216,6 +217,7 @@ def ref(depth):
     g("ref_intra_filter_flags", i32, [i32])
     g("ref_frame_init_lowres", None, [vp, vp, vp, vp, vp, ip, ip, i32, i32])
     g("ref_lowres_intra_estimate", i32, [vp, ip, i32, i32, i32, i32, vp, vp, i64, vp, vp, vp])
+    g("ref_lookahead_cost_b", i64, [vp, vp, vp, ip, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp])
     g("ref_lookahead_cost_p", i64, [vp, vp, ip, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp])
     assert L.ref_depth() == key
     _refs[key] = L

@@ -394,4 +394,114 @@ int ref_motion_estimate_chroma(pixel* refY, pixel* refCb, pixel* refCr, pixel* f
     return cost;
 }
 
+/* ---- the real lookahead B-frame cost: three pictures p0 = 0, b = 1, p1 = 2; CostEstimateGroup::singleCost(0, 2, 1)
+ * (numSlices == 1) or the cooperative-slice row loop around estimateCUCost as in ref_lookahead_cost_p.  prefillL0 != 0 first
+ * runs the P estimate (0, 1, 1) so list 0 is already searched (bDoSearch[0] false, slicetype.cpp:3126) and its stored costs are
+ * reused.  Outputs are frame 1's lowresMvs / lowresMvCosts of both lists at distance 1, lowresCosts[1][1], rowSatds[1][1].
+ * Returns costEst[1][1], i.e. the raw sum scaled by 100 / (130 + bFrameBias) (:3183-3186). */
+int64_t ref_lookahead_cost_b(pixel* pic0, pixel* pic1, pixel* pic2, intptr_t stride, int w, int h, int marginX, int marginY,
+                             int numRowsPerSlice, int numSlices, int prefillL0,
+                             int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1, uint16_t* lowresCosts, int32_t* rowSatds)
+{
+    T();
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = w;
+    param->sourceHeight = h;
+    param->rc.aqMode = 0;
+    param->rc.hevcAq = 0;
+    param->bAQMotion = 0;
+    param->bEnableHME = 0;
+    param->bEnableWeightedPred = 0;
+    param->bEnableWeightedBiPred = 0;
+    param->lookaheadSlices = 0;
+    PicYuv pics[3];
+    Lowres lr[3];
+    pixel* org[3] = { pic0, pic1, pic2 };
+    int64_t ret = -1;
+    bool ok = true;
+    for (int i = 0; i < 3; i++)
+    {
+        pics[i].m_picWidth = w;
+        pics[i].m_picHeight = h;
+        pics[i].m_lumaMarginX = marginX;
+        pics[i].m_lumaMarginY = marginY;
+        pics[i].m_stride = stride;
+        pics[i].m_picOrg[0] = org[i];
+        pics[i].m_param = param;
+        memset((void*)&lr[i], 0, sizeof(Lowres));
+        ok = ok && lr[i].create(param, &pics[i], param->rc.qgSize);
+    }
+    if (ok)
+    {
+        for (int i = 0; i < 3; i++)
+            lr[i].init(&pics[i], i);
+        Lookahead la(param, NULL);
+        la.create();
+        LookaheadTLD& tld = la.m_tld[0];
+        tld.lowresIntraEstimate(lr[1], param->rc.qgSize);
+        Lowres* frames[3] = { &lr[0], &lr[1], &lr[2] };
+        Lowres* fenc = frames[1];
+        const int W = la.m_8x8Width, H = la.m_8x8Height, ncu = W * H;
+        if (prefillL0)
+        {
+            CostProbeGroup g0(la, frames);
+            g0.singleCost(0, 1, 1, false);
+        }
+        if (numSlices <= 1)
+        {
+            CostProbeGroup g(la, frames);
+            ret = g.singleCost(0, 2, 1, false);
+        }
+        else
+        {
+            struct BGroup : public CostEstimateGroup
+            {
+                BGroup(Lookahead& l, Lowres** f) : CostEstimateGroup(l, f) {}
+                void cu(LookaheadTLD& t, int x, int y, bool ds[2], bool lastRow, int slice) { estimateCUCost(t, x, y, 0, 2, 1, ds, lastRow, slice, 0); }
+            } g(la, frames);
+            bool doSearch[2] = { fenc->lowresMvs[0][1][0].x == 0x7FFF, fenc->lowresMvs[1][1][0].x == 0x7FFF };
+            fenc->weightedRef[1].isWeighted = false;
+            fenc->costEst[1][1] = 0;
+            fenc->costEstAq[1][1] = 0;
+            memset(g.m_slice, 0, sizeof(g.m_slice));
+            for (int sl = 0; sl < numSlices; sl++)
+            {
+                int firstY = numRowsPerSlice * sl;
+                int lastY = sl == numSlices - 1 ? H - 1 : numRowsPerSlice * (sl + 1) - 1;
+                bool lastRow = true;
+                for (int cuY = lastY; cuY >= firstY; cuY--)
+                {
+                    fenc->rowSatds[1][1][cuY] = 0;
+                    for (int cuX = W - 1; cuX >= 0; cuX--)
+                        g.cu(tld, cuX, cuY, doSearch, lastRow, sl);
+                    lastRow = false;
+                }
+            }
+            int64_t score = 0;
+            for (int sl = 0; sl < numSlices; sl++)
+                score += g.m_slice[sl].costEst;
+            ret = score * 100 / (130 + param->bFrameBias);
+        }
+        for (int i = 0; i < ncu; i++)
+        {
+            mvs0[2 * i] = fenc->lowresMvs[0][1][i].x; mvs0[2 * i + 1] = fenc->lowresMvs[0][1][i].y;
+            mvs1[2 * i] = fenc->lowresMvs[1][1][i].x; mvs1[2 * i + 1] = fenc->lowresMvs[1][1][i].y;
+        }
+        memcpy(mvCosts0, fenc->lowresMvCosts[0][1], ncu * sizeof(int32_t));
+        memcpy(mvCosts1, fenc->lowresMvCosts[1][1], ncu * sizeof(int32_t));
+        memcpy(lowresCosts, fenc->lowresCosts[1][1], ncu * sizeof(uint16_t));
+        memcpy(rowSatds, fenc->rowSatds[1][1], H * sizeof(int32_t));
+        la.destroy();
+    }
+    for (int i = 0; i < 3; i++)
+    {
+        lr[i].destroy();
+        pics[i].m_picOrg[0] = NULL;
+        pics[i].m_param = NULL;
+    }
+    x265_param_free(param);
+    return ret;
+}
+
 } // extern "C"

@@ -320,6 +320,34 @@ class Orc(_Base):
                                                   po.vp(cost.ctypes.data + 2 * po.MVCOST_CENTRE), self.depth, ptr(out))
         return c, (int(out[0]), int(out[1]))
 
+    def lookahead_cost_b(self, src0, src1, src2, origin, w, h, mx, my, rows_per_slice, num_slices, prefill_l0):
+        """B-frame cost of picture 1 between pictures 0 and 2 (estimateFrameCost(p0=0, p1=2, b=1)).  prefill_l0: list 0 was already
+        searched by the P estimate (0, 1, 1) and is reused.  Returns (costEst scaled by 100/130, mvs0, mvCosts0, mvs1, mvCosts1,
+        lowresCosts, rowSatds)."""
+        import ctypes as C
+        pl = [self.lowres_pass(s_, origin, w, h, mx, my) for s_ in (src0, src1, src2)]
+        stride, lw, lh = pl[0][5]
+        icost = pl[1][1]
+        wcu, hcu = lw // 8, lh // 8
+        ncu = wcu * hcu
+        mvs = [np.zeros((ncu, 2), np.int32) for _ in range(2)]
+        mvc = [np.zeros(ncu, np.int32) for _ in range(2)]
+        lc, rows, imb = np.zeros(ncu, np.uint16), np.zeros(hcu, np.int32), np.zeros(1, np.int32)
+        tab = po.mvcost_table(12 + 6 * (self.depth - 8), self.depth)
+        tabp = po.vp(tab.ctypes.data + 2 * po.MVCOST_CENTRE)
+        refs0 = (C.c_void_p * 4)(*[ptr(p, my, mx).value for p in pl[0][4]])
+        refs1 = (C.c_void_p * 4)(*[ptr(p, my, mx).value for p in pl[2][4]])
+        fenc = ptr(pl[1][4][0], my, mx)
+        do = np.array([1, 1], np.int32)
+        if prefill_l0:
+            # (the reference shim pre-fills through singleCost(), i.e. the serial, unsliced loop)
+            self._f("orc_lookahead_cost_p")(fenc, refs0, stride, wcu, hcu, hcu, 1, self.depth, ptr(icost), tabp,
+                                            ptr(mvs[0]), ptr(mvc[0]), ptr(lc), ptr(rows), ptr(imb))
+            do[0] = 0
+        est = self._f("orc_lookahead_cost_b")(fenc, refs0, refs1, stride, wcu, hcu, rows_per_slice, num_slices, self.depth, tabp, ptr(do),
+                                              ptr(mvs[0]), ptr(mvc[0]), ptr(mvs[1]), ptr(mvc[1]), ptr(lc), ptr(rows))
+        return int(est) * 100 // 130, mvs[0], mvc[0], mvs[1], mvc[1], lc, rows
+
 
 class Ref(_Base):
     name = "reference"
@@ -588,6 +616,18 @@ class Ref(_Base):
                                               ref[0].shape[1], ref[1].shape[1], bx, by, w, h, ptr(a[0]), ptr(a[1]), ptr(a[2]),
                                               len(mvc), ptr(cand) if len(mvc) else None, merange, method, subme, qp, ptr(out))
         return c, (int(out[0]), int(out[1]))
+
+    def lookahead_cost_b(self, src0, src1, src2, origin, w, h, mx, my, rows_per_slice, num_slices, prefill_l0):
+        lw, lh = ((w // 2 + 7) // 8) * 8, ((h // 2 + 7) // 8) * 8
+        wcu, hcu = lw // 8, lh // 8
+        ncu = wcu * hcu
+        mvs = [np.zeros((ncu, 2), np.int32) for _ in range(2)]
+        mvc = [np.zeros(ncu, np.int32) for _ in range(2)]
+        lc, rows = np.zeros(ncu, np.uint16), np.zeros(hcu, np.int32)
+        est = self.L.ref_lookahead_cost_b(ptr(src0, *origin), ptr(src1, *origin), ptr(src2, *origin), src0.shape[1], w, h, mx, my,
+                                          rows_per_slice, num_slices, int(prefill_l0), ptr(mvs[0]), ptr(mvc[0]), ptr(mvs[1]), ptr(mvc[1]),
+                                          ptr(lc), ptr(rows))
+        return int(est), mvs[0], mvc[0], mvs[1], mvc[1], lc, rows
 
 
 def same(x, y):

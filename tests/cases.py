@@ -255,3 +255,21 @@ def me_scene_yuv(depth, seed, H=160, W=192, margin=80):
         c = mid + np.rint(gain * (sub - mid)).astype(np.int64) + rng.integers(-2, 3, sub.shape) * (1 << (depth - 8))
         return np.ascontiguousarray(np.clip(c, 0, pmax).astype(y.dtype))
     return (ref, chroma(ref, 0.6), chroma(ref, -0.5)), (src, chroma(src, 0.6), chroma(src, -0.5)), m
+
+
+def lookahead_scene3(depth, seed, H=136, W=200, margin=80):
+    """Three consecutive padded pictures (constant per-tile motion across them) for the B-frame cost pass."""
+    rng = np.random.default_rng(seed)
+    pmax = (1 << depth) - 1
+    big = textured_frame(rng, H + 64, W + 64, depth, sigma=2.0)
+    th, tw = 40, 48
+    vec = {(y0, x0): (int(rng.integers(-7, 8)), int(rng.integers(-7, 8))) for y0 in range(0, H, th) for x0 in range(0, W, tw)}
+    pics = []
+    for t in range(3):
+        p = np.zeros((H, W), big.dtype)
+        for (y0, x0), (dy, dx) in vec.items():
+            y1, x1 = min(y0 + th, H), min(x0 + tw, W)
+            p[y0:y1, x0:x1] = big[32 + y0 + t * dy:32 + y1 + t * dy, 32 + x0 + t * dx:32 + x1 + t * dx]
+        p = np.clip(np.rint(p.astype(np.float64) + rng.normal(0, 2.0 * (pmax / 255.0), p.shape)), 0, pmax).astype(big.dtype)
+        pics.append(np.ascontiguousarray(np.pad(p, ((margin, margin), (margin, margin + 8)), mode="edge")))
+    return pics, margin

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import numpy as np  # noqa: E402
 from backends import Ref  # noqa: E402
-from cases import gen_cases, me_scene, me_scene_yuv, lowres_scene, lookahead_scene, digest  # noqa: E402
+from cases import gen_cases, me_scene, me_scene_yuv, lowres_scene, lookahead_scene, lookahead_scene3, digest  # noqa: E402
 
 ME_CASES = [  # (method, subme, w, h, bx_off, by_off, merange, qmvp, mvc, qp)
     (1, 2, 16, 16, 16, 24, 57, (5, -7), [(12, 8), (-20, 4)], 28),
@@ -106,6 +106,19 @@ def lookahead_results(backend_cls, depth):
     return out
 
 
+LOOKAHEAD_B_CASES = [(200, 136, 9, 1, 0), (200, 136, 9, 1, 1), (200, 136, 3, 3, 0), (176, 144, 9, 1, 0), (320, 200, 5, 2, 1), (66, 50, 4, 1, 0)]
+
+
+def lookahead_b_results(backend_cls, depth):
+    """B-frame cost pass per case (W, H, rows/slice, slices, list 0 pre-searched): (costEst, mvs0, mvCosts0, mvs1, mvCosts1, lowresCosts, rowSatds)."""
+    b = backend_cls(depth)
+    out = {}
+    for i, (w, h, rps, ns, pre) in enumerate(LOOKAHEAD_B_CASES):
+        pics, m = lookahead_scene3(depth, 800 + depth + w, h, w)
+        out["lookahead_b#%d" % i] = b.lookahead_cost_b(pics[0], pics[1], pics[2], (m, m), w, h, m, m, rps, ns, pre)
+    return out
+
+
 def lookahead_digests(backend_cls, depth):
     return {k: digest(v) for k, v in lookahead_results(backend_cls, depth).items()}
 
@@ -127,6 +140,7 @@ if __name__ == "__main__":
     gold = {}
     for depth in (8, 10):
         gold[str(depth)] = {"prims": prim_digests(Ref, depth), "me": me_digests(Ref, depth), "chroma_me": chroma_me_results(Ref, depth), "lowres": lowres_digests(Ref, depth), "lookahead": lookahead_digests(Ref, depth),
+                            "lookahead_b": {k: digest(v) for k, v in lookahead_b_results(Ref, depth).items()},
                             "mvcost": {str(qp): digest(Ref(depth).mvcost_table(qp)) for qp in (12, 28, 37, 51)}}
     path = os.path.join(HERE, "primitives_golden.json")
     with open(path, "w") as f:

@@ -48,6 +48,11 @@ def test_oracle_lookahead_cost_matches_golden(depth):
 
 
 @pytest.mark.parametrize("depth", [8, 10])
+def test_oracle_lookahead_b_cost_matches_golden(depth):
+    assert {k: digest(v) for k, v in make_golden.lookahead_b_results(Orc, depth).items()} == GOLD[str(depth)]["lookahead_b"]
+
+
+@pytest.mark.parametrize("depth", [8, 10])
 def test_oracle_mvcost_matches_golden(depth):
     for qp, d in GOLD[str(depth)]["mvcost"].items():
         assert digest(Orc(depth).mvcost_table(int(qp))) == d

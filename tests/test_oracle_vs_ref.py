@@ -129,3 +129,16 @@ def test_chroma_motion_estimate_matches_reference(depth):
     a, b = make_golden.chroma_me_results(Orc, depth), make_golden.chroma_me_results(Ref, depth)
     assert a == b, [k for k in a if a[k] != b[k]][:10]
     assert len(a) == 360
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_lookahead_b_cost_matches_reference(depth):
+    """estimateCUCost for a B frame through the real Lookahead (both lists searched or list 0 reused, bidir average and co-located
+    candidates, the skip rule, 100/130 frame scaling), serial and sliced, vs the restatement."""
+    _need_ref(depth)
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    a, b = make_golden.lookahead_b_results(Orc, depth), make_golden.lookahead_b_results(Ref, depth)
+    for k in a:
+        assert same(a[k], b[k]), k
