@@ -335,10 +335,32 @@ typedef struct x265hip_lookahead_pair
     uint16_t*      lowresCosts;  /* out [ncu]     min(cost, 16383) | listused << 14 */
     int32_t*       rowSatds;     /* out [heightInCU] */
     uint64_t*      sync;         /* scratch [ncu] */
+    int32_t        bidirList;    /* 0: P frame (everything above).  1: one list of a B frame: the search applies the bidir skip rule
+                                    (slicetype.cpp:3303-3317) and only mvs / mvCosts are written; finish with x265hip_lookahead_bidir_batch */
+    int32_t        reserved;
 } x265hip_lookahead_pair;
 int x265hip_lookahead_cost_p_batch(int depth, const x265hip_lookahead_pair* pairs, int nPairs, int64_t stride, int64_t planeElems,
                                    int widthInCU, int heightInCU, int numRowsPerSlice, int numSlices,
                                    const uint16_t* mvcost, uint32_t epoch, int32_t* costEst, void* stream);
+
+/* B frames (p0 < b < p1): run the two list searches as pairs with bidirList = 1 (a list that was searched before keeps its stored
+ * vectors and costs, slicetype.cpp:3126-3127, :3260-3264), then this pass over every block: cheapest of the two lists, the average
+ * of the two motion-compensated blocks and the co-located average by SATD (:3320-3338), + 4, packed lowresCosts, rowSatds, and
+ * costEst[i] = raw sum over the non-edge blocks (the caller scales by 100 / (130 + bFrameBias), :3183-3186).  `frames` is a DEVICE array. */
+typedef struct x265hip_lookahead_bframe
+{
+    const void*    fenc;         /* lowresPlane[0] origin of the B frame */
+    const void*    ref0;         /* past reference, hpel plane 0 origin */
+    const void*    ref1;         /* future reference, hpel plane 0 origin */
+    const int32_t* mvs0;         /* [ncu][2] lowresMvs[0][b-p0] */
+    const int32_t* mvs1;         /* [ncu][2] lowresMvs[1][p1-b] */
+    const int32_t* mvCosts0;     /* [ncu] */
+    const int32_t* mvCosts1;     /* [ncu] */
+    uint16_t*      lowresCosts;  /* out [ncu] */
+    int32_t*       rowSatds;     /* out [heightInCU] */
+} x265hip_lookahead_bframe;
+int x265hip_lookahead_bidir_batch(int depth, const x265hip_lookahead_bframe* frames, int nFrames, int64_t stride, int64_t planeElems,
+                                  int widthInCU, int heightInCU, int32_t* costEst, void* stream);
 
 /* ---------------------------------------------------------------- per-call entry points (host pointers) ----- */
 /* What the reference-side table shims bind (x265_amd/host/x265_hip_primitives.cpp).  Arguments are the slot's own

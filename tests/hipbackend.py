@@ -414,3 +414,61 @@ class Hip:
         cost, mv = self.motion_estimate_chroma_batch(ref, src, w, h, [(bx, by)], [mvmin], [mvmax], [qmvp], [mvc] if len(mvc) else [],
                                                      merange, method, subme, qp)
         return int(cost[0]), (int(mv[0, 0]), int(mv[0, 1]))
+
+    def lookahead_cost_b(self, src0, src1, src2, origin, w, h, mx, my, rows_per_slice, num_slices, prefill_l0):
+        """B-frame cost of picture 1 between 0 and 2, all on the device; same returns as backends.Orc.lookahead_cost_b."""
+        lw, lh = ((w // 2 + 7) // 8) * 8, ((h // 2 + 7) // 8) * 8
+        stride = lw + 2 * mx
+        stride += (32 - stride % 32) % 32
+        pe = (lh + 2 * my) * stride
+        org = my * stride + mx
+        wcu, hcu = lw // 8, lh // 8
+        ncu = wcu * hcu
+        qp = 12 + 6 * (self.depth - 8)
+        if qp not in self._mvcost:
+            tab = np.zeros(2 * MVCOST_HALF + 1, np.uint16)
+            check(self.L.x265hip_mvcost_table(qp, self.depth, tab.ctypes.data, MVCOST_HALF))
+            self._mvcost[qp] = DevBuf(tab)
+        planes, keep = [], []
+        for src in (src0, src1, src2):
+            ds = DevBuf(src)
+            pl = DevBuf.zeros((4, lh + 2 * my, stride), self.pix)
+            ptrs = (C.c_void_p * 4)(*[pl.at(k * pe + org) for k in range(4)])
+            check(self.L.x265hip_lowres_init(self.depth, ds.at(_off(src, origin)), src.shape[1], ptrs, stride, lw, lh, mx, my, None))
+            planes.append(pl)
+            keep.append(ds)
+        icost, imode = DevBuf.zeros((ncu,), np.int32), DevBuf.zeros((ncu,), np.uint8)
+        check(self.L.x265hip_lowres_intra_estimate(self.depth, planes[1].at(org), stride, wcu, hcu, icost.ptr, imode.ptr, None, None, None))
+        mvs = [DevBuf.zeros((ncu, 2), np.int32) for _ in range(2)]
+        mvc = [DevBuf.zeros((ncu,), np.int32) for _ in range(2)]
+        lc, rows = DevBuf.zeros((ncu,), np.uint16), DevBuf.zeros((hcu,), np.int32)
+        sync = [DevBuf.zeros((ncu,), np.uint64) for _ in range(2)]
+        est2 = DevBuf.zeros((2, 2), np.int32)
+
+        def pair(lst, bidir):
+            d = hp.LookaheadPair()
+            d.fenc, d.ref, d.intraCost = planes[1].at(org), planes[0 if lst == 0 else 2].at(org), icost.ptr
+            d.mvs, d.mvCosts, d.lowresCosts, d.rowSatds, d.sync = mvs[lst].ptr, mvc[lst].ptr, lc.ptr, rows.ptr, sync[lst].ptr
+            d.bidirList = bidir
+            return d
+
+        def launch(descs, rps, ns):
+            arr = (hp.LookaheadPair * len(descs))(*descs)
+            dd = DevBuf(np.frombuffer(bytes(arr), np.uint8))
+            self._epoch[0] += 1
+            check(self.L.x265hip_lookahead_cost_p_batch(self.depth, dd.ptr, len(descs), stride, pe, wcu, hcu, rps, ns,
+                                                        self._mvcost[qp].at(MVCOST_HALF), self._epoch[0], est2.ptr, None))
+            check(self.L.x265hip_stream_sync(None))
+
+        if prefill_l0:
+            launch([pair(0, 0)], hcu, 1)                       # the P estimate (0, 1, 1), serial like the reference shim
+            launch([pair(1, 1)], rows_per_slice, num_slices)
+        else:
+            launch([pair(0, 1), pair(1, 1)], rows_per_slice, num_slices)
+        bf = hp.LookaheadBFrame()
+        bf.fenc, bf.ref0, bf.ref1 = planes[1].at(org), planes[0].at(org), planes[2].at(org)
+        bf.mvs0, bf.mvs1, bf.mvCosts0, bf.mvCosts1, bf.lowresCosts, bf.rowSatds = mvs[0].ptr, mvs[1].ptr, mvc[0].ptr, mvc[1].ptr, lc.ptr, rows.ptr
+        dbf = DevBuf(np.frombuffer(bytes(bf), np.uint8))
+        est = DevBuf.zeros((1,), np.int32)
+        check(self.L.x265hip_lookahead_bidir_batch(self.depth, dbf.ptr, 1, stride, pe, wcu, hcu, est.ptr, None))
+        return int(est.get()[0]) * 100 // 130, mvs[0].get(), mvc[0].get(), mvs[1].get(), mvc[1].get(), lc.get(), rows.get()

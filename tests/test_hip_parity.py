@@ -537,6 +537,20 @@ def test_lookahead_p_cost_matches_oracle(hipmod, depth):
             assert same(x, y), (i, k)
 
 
+@pytest.mark.parametrize("depth", [8, 10])
+def test_lookahead_b_cost_matches_oracle(hipmod, depth):
+    """B-frame cost pass: both list searches with the skip rule in one launch (or list 0 reused from the P estimate), then the
+    bidir / co-located candidates — vectors and costs of both lists, packed lowresCosts, row sums, frame score."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    want = make_golden.lookahead_b_results(Orc, depth)
+    got = make_golden.lookahead_b_results(hipmod.Hip, depth)
+    hipmod._release()
+    for k in want:
+        for j, (x, y) in enumerate(zip(want[k], got[k])):
+            assert same(x, y), (k, j)
+
+
 def test_twelve_bit_primitives_match_oracle(hipmod):
     """depth 12 (u16 pixels, the third X265_DEPTH): same sweep against the oracle restatement (the real-reference pin covers
     8 and 10 bit; the 12-bit arithmetic differs only in the shift / clip constants the oracle derives from `depth`)."""

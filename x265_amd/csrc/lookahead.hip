@@ -79,10 +79,12 @@ struct LaCtx
         return LaPk<P>::avg(ld_unaligned<Q>(a), ld_unaligned<Q>(b));
     }
     __device__ __forceinline__ int sad(int qx, int qy) const { return la_row_allsum((int)LaPk<P>::sad(fetch(qx, qy), fq)); }
-    __device__ __forceinline__ int satd(int qx, int qy) const
+    __device__ __forceinline__ int satd(int qx, int qy) const { return satd_of(fetch(qx, qy)); }
+    // 8x8 SATD of the source block against a predicted block held one packed quad per lane
+    __device__ __forceinline__ int satd_of(Q blk) const
     {
         int p[4];
-        LaPk<P>::unpack(fetch(qx, qy), p);
+        LaPk<P>::unpack(blk, p);
         const int d0 = fu[0] - p[0], d1 = fu[1] - p[1], d2 = fu[2] - p[2], d3 = fu[3] - p[3];
         const int s01 = d0 + d1, e01 = d0 - d1, s23 = d2 + d3, e23 = d2 - d3;
         int m[4] = { s01 + s23, s01 - s23, e01 + e23, e01 - e23 };
@@ -149,6 +151,7 @@ __global__ __launch_bounds__(64) void lookahead_p_kernel(const LaPair* __restric
         return;
     const int cuY = H - 1 - (k % H);
     const LaPair pr = pairs[pairIdx];
+    const bool bidirList = pr.bidirList != 0;
     int slice = cuY / rowsPerSlice;
     if (slice > numSlices - 1) slice = numSlices - 1;
     const int lastY = slice == numSlices - 1 ? H - 1 : rowsPerSlice * (slice + 1) - 1;
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(64) void lookahead_p_kernel(const LaPair* __restric
             if (cuX > 0) { la_unpack(la_load(below + cuX - 1), mx[numc], my[numc]); numc++; }
             if (cuX < W - 1) { la_unpack(la_load(below + cuX + 1), mx[numc], my[numc]); numc++; }
         }
-        int mvpX = 0, mvpY = 0;
+        int mvpX = 0, mvpY = 0, skipCost = 0x7fffffff;
         c.px = 0; c.py = 0;
         if (numc)
         {
@@ -206,7 +209,12 @@ __global__ __launch_bounds__(64) void lookahead_p_kernel(const LaPair* __restric
             int mvpcost = 1 << 28;                                // MotionEstimate::COST_MAX (motion.h:65)
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                if (i < numc && d[i] < mvpcost) { mvpcost = d[i]; mvpX = mx[i]; mvpY = my[i]; }
+                if (i < numc)
+                {
+                    if (d[i] < mvpcost) { mvpcost = d[i]; mvpX = mx[i]; mvpY = my[i]; }
+                    if (bidirList && !(mvpX | mvpY))              // slicetype.cpp:3303-3305: this candidate's cost while the best so far is zero
+                        skipCost = d[i];
+                }
         }
         c.px = mvpX; c.py = mvpY;
 
@@ -364,12 +372,28 @@ __global__ __launch_bounds__(64) void lookahead_p_kernel(const LaPair* __restric
         }
 #undef YOK
 #undef LT1
+        if (bidirList && skipCost < 64 && skipCost < bcost)      // slicetype.cpp:3313-3317
+        {
+            bcost = skipCost;
+            bmvX = 0; bmvY = 0;
+        }
         // ---- publish, then the block's bookkeeping (slicetype.cpp:3318-3384, P frame: inter + 4 against intra) ----
         if (lane == 0)
             __hip_atomic_store(mine + cuX, ((uint64_t)epoch << 32) | (uint32_t)(uint16_t)bmvX | ((uint32_t)(uint16_t)bmvY << 16),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         prevX = bmvX; prevY = bmvY;
         const int fencCost = bcost;
+        if (bidirList)
+        {
+            // one list of a B frame: only the vector and its cost; x265hip_lookahead_bidir_batch does the rest
+            if (lane == 0)
+            {
+                pr.mvs[2 * cuXY] = bmvX;
+                pr.mvs[2 * cuXY + 1] = bmvY;
+                pr.mvCosts[cuXY] = fencCost;
+            }
+            continue;
+        }
         int cuCost = fencCost + 4, listused = 1;
         const int ic = sfl(pr.intraCost[cuXY]);
         if (ic < cuCost) { cuCost = ic; listused = 0; }
@@ -388,11 +412,73 @@ __global__ __launch_bounds__(64) void lookahead_p_kernel(const LaPair* __restric
             pr.lowresCosts[cuXY] = (uint16_t)((cuCost < 16383 ? cuCost : 16383) | (listused << 14));
         }
     }
-    if (lane == 0)
+    if (lane == 0 && !bidirList)
     {
         pr.rowSatds[cuY] = rowSum;
         atomicAdd(costEst + 2 * pairIdx, scoreSum);
         atomicAdd(costEst + 2 * pairIdx + 1, intraCnt);
+    }
+}
+
+// ---- B frames: the part of estimateCUCost after the two list searches (slicetype.cpp:3320-3338, :3353-3384) ----------------
+// One wave per block row; its four DPP rows take four neighbouring blocks at a time.  No dependencies between blocks.
+template <typename P>
+__global__ __launch_bounds__(64) void lookahead_bidir_kernel(const x265hip_lookahead_bframe* __restrict__ frames, int64_t stride, int64_t planeElems,
+                                                             int W, int H, int32_t* __restrict__ costEst)
+{
+    typedef LaCtx<P> C;
+    typedef typename C::Q Q;
+    constexpr int N = 8;
+    const int f = blockIdx.x / H, cuY = blockIdx.x % H;
+    const x265hip_lookahead_bframe fr = frames[f];
+    const int lane = threadIdx.x, s = lane & 15, slot = lane >> 4;
+    const int t = s >> 2, r = s & 3;
+    const int qrow = (t >> 1) * 4 + r, qcol = (t & 1) * 4;
+    C c0, c1;
+    c0.slot = c1.slot = slot;
+    c0.hi1 = c1.hi1 = s & 1;
+    c0.hi2 = c1.hi2 = s & 2;
+    c0.stride = c1.stride = (int)stride;
+    c0.planeElems = c1.planeElems = planeElems;
+    const int64_t rowOff = (int64_t)(cuY * N + qrow) * stride + qcol;
+    int rowSum = 0, scoreSum = 0;
+#pragma unroll 1
+    for (int x0 = 0; x0 < W; x0 += 4)
+    {
+        const int cuX = x0 + slot;
+        const bool live = cuX < W;
+        const int cx = live ? cuX : W - 1;
+        const int cuXY = cuY * W + cx;
+        c0.fq = ld_unaligned<Q>((const P*)fr.fenc + rowOff + cx * N);
+        LaPk<P>::unpack(c0.fq, c0.fu);
+        c0.ref0 = (const P*)fr.ref0 + rowOff + cx * N;
+        c1.ref0 = (const P*)fr.ref1 + rowOff + cx * N;
+        int bcost = 1 << 28, listused = 0;
+        const int m0 = fr.mvCosts0[cuXY], m1 = fr.mvCosts1[cuXY];
+        if (m0 < bcost) { bcost = m0; listused = 1; }
+        if (m1 < bcost) { bcost = m1; listused = 2; }
+        // avg(l0-mv, l1-mv), then the co-located average (pixelavg_pp of the two motion-compensated blocks)
+        const Q a = LaPk<P>::avg(c0.fetch(fr.mvs0[2 * cuXY], fr.mvs0[2 * cuXY + 1]), c1.fetch(fr.mvs1[2 * cuXY], fr.mvs1[2 * cuXY + 1]));
+        const Q b = LaPk<P>::avg(c0.fetch(0, 0), c1.fetch(0, 0));
+        const int ca = c0.satd_of(a), cb = c0.satd_of(b);
+        if (ca < bcost) { bcost = ca; listused = 3; }
+        if (cb < bcost) { bcost = cb; listused = 3; }
+        bcost += 4;                                               // lowresPenalty
+        if (live && s == 0)
+        {
+            fr.lowresCosts[cuXY] = (uint16_t)((bcost < 16383 ? bcost : 16383) | (listused << 14));
+            rowSum += bcost;
+            if ((cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2)
+                scoreSum += bcost;
+        }
+    }
+    // lanes 0, 16, 32, 48 hold the partial sums of their slots
+    rowSum = __builtin_amdgcn_readlane(rowSum, 0) + __builtin_amdgcn_readlane(rowSum, 16) + __builtin_amdgcn_readlane(rowSum, 32) + __builtin_amdgcn_readlane(rowSum, 48);
+    scoreSum = __builtin_amdgcn_readlane(scoreSum, 0) + __builtin_amdgcn_readlane(scoreSum, 16) + __builtin_amdgcn_readlane(scoreSum, 32) + __builtin_amdgcn_readlane(scoreSum, 48);
+    if (lane == 0)
+    {
+        fr.rowSatds[cuY] = rowSum;
+        atomicAdd(costEst + f, scoreSum);
     }
 }
 
@@ -421,5 +507,23 @@ extern "C" int x265hip_lookahead_cost_p_batch(int depth, const x265hip_lookahead
         hipLaunchKernelGGL((lookahead_p_kernel<uint16_t>), grid, block, 0, as_stream(stream), pairs, nPairs, stride, planeElems, widthInCU, heightInCU,
                            numRowsPerSlice, numSlices, mvcost, epoch, costEst);
     XH_LAUNCH_CHECK("lookahead_p_kernel");
+    return X265HIP_OK;
+}
+
+extern "C" int x265hip_lookahead_bidir_batch(int depth, const x265hip_lookahead_bframe* frames, int nFrames, int64_t stride, int64_t planeElems,
+                                             int widthInCU, int heightInCU, int32_t* costEst, void* stream)
+{
+    XH_CHECK_DEV();
+    if (!valid_depth(depth) || nFrames < 0 || widthInCU < 1 || heightInCU < 1)
+        return set_error(X265HIP_EINVAL, "lookahead_bidir_batch: depth %d frames %d grid %dx%d", depth, nFrames, widthInCU, heightInCU);
+    if (nFrames == 0) return X265HIP_OK;
+    int e = check_hip(hipMemsetAsync(costEst, 0, (size_t)nFrames * sizeof(int32_t), as_stream(stream)), "lookahead memset");
+    if (e) return e;
+    dim3 grid((unsigned)(nFrames * heightInCU)), block(64);
+    if (depth == 8)
+        hipLaunchKernelGGL((lookahead_bidir_kernel<uint8_t>), grid, block, 0, as_stream(stream), frames, stride, planeElems, widthInCU, heightInCU, costEst);
+    else
+        hipLaunchKernelGGL((lookahead_bidir_kernel<uint16_t>), grid, block, 0, as_stream(stream), frames, stride, planeElems, widthInCU, heightInCU, costEst);
+    XH_LAUNCH_CHECK("lookahead_bidir_kernel");
     return X265HIP_OK;
 }

@@ -108,6 +108,7 @@ PROTOTYPES = {
     "x265hip_motion_estimate_chroma_batch": (i32, [i32, i32, i32, vp, i64, vp, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, i32, vp, i32, i32, i32,
                                                    vp, i32, i32, vp, vp, vp]),
     "x265hip_lookahead_cost_p_batch": (i32, [i32, vp, i32, i64, i64, i32, i32, i32, i32, vp, u32, vp, vp]),
+    "x265hip_lookahead_bidir_batch": (i32, [i32, vp, i32, i64, i64, i32, i32, vp, vp]),
     "x265hip_call_intra_pred": (i32, [i32, i32, i32, i32, vp, i64, vp]),
     "x265hip_call_intra_allangs": (i32, [i32, i32, vp, vp, vp, i32]),
     "x265hip_call_intra_filter": (i32, [i32, i32, vp, vp]),
@@ -119,7 +120,14 @@ CMP_SAD, CMP_SATD, CMP_SA8D, CMP_SA8D8, CMP_PSY = 0, 1, 2, 3, 4
 
 class LookaheadPair(C.Structure):
     """x265hip_lookahead_pair (include/x265hip.h)"""
-    _fields_ = [("fenc", vp), ("ref", vp), ("intraCost", vp), ("mvs", vp), ("mvCosts", vp), ("lowresCosts", vp), ("rowSatds", vp), ("sync", vp)]
+    _fields_ = [("fenc", vp), ("ref", vp), ("intraCost", vp), ("mvs", vp), ("mvCosts", vp), ("lowresCosts", vp), ("rowSatds", vp), ("sync", vp),
+                ("bidirList", C.c_int32), ("reserved", C.c_int32)]
+
+
+class LookaheadBFrame(C.Structure):
+    """x265hip_lookahead_bframe (include/x265hip.h)"""
+    _fields_ = [("fenc", vp), ("ref0", vp), ("ref1", vp), ("mvs0", vp), ("mvs1", vp), ("mvCosts0", vp), ("mvCosts1", vp), ("lowresCosts", vp),
+                ("rowSatds", vp)]
 IF_HPP, IF_HPS, IF_VPP, IF_VPS, IF_VSP, IF_VSS, IF_HVPP = range(7)
 DIA_SEARCH, HEX_SEARCH, STAR_SEARCH, FULL_SEARCH = 0, 1, 3, 5      # x265.h X265_*_SEARCH
 
