@@ -259,7 +259,9 @@ int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t stride
 /* The same pass on a 4:2:0 picture: additionally Predict::predInterChromaPixel (predict.cpp:306-352) from the 8x8 vectors and
  * the residual chain on Cb and Cr (16x16 TUs under the 32x32 luma TUs, 4x4 under the 8x8 ones) with the chroma QpParam of
  * Quant::setChromaQP (quant.cpp:233-243), and border extension of the chroma reconstruction.  Plane pointers address pixel
- * (0,0); chroma margins are marginX/2, marginY/2. */
+ * (0,0); chroma margins are marginX/2, marginY/2.  The Cb and Cr planes of one picture must lie within 2^31 elements of each
+ * other (one launch covers both, Cr is addressed from the Cb pointer with 32-bit offsets): allocate a picture's planes in one
+ * buffer, as x265's PicYuv does; otherwise X265HIP_EINVAL. */
 typedef struct x265hip_yuv { void* y; void* cb; void* cr; int64_t strideY; int64_t strideC; } x265hip_yuv;
 int x265hip_framepass_run_yuv(x265hip_framepass* fp, const x265hip_yuv* src, const x265hip_yuv* ref, const x265hip_yuv* pred,
                               const x265hip_yuv* recon, int marginX, int marginY, void* stream);

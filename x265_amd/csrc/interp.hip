@@ -8,6 +8,7 @@
 // One lane produces V (4, or 2 for the 2/6-wide chroma shapes) horizontally adjacent outputs of one row.  The
 // separable hv filter keeps its 14-bit intermediate in LDS (one wave per block), never in HBM.
 #include "common.h"
+#include <cstdlib>
 #include "filters.h"
 #include "internal.h"
 
@@ -313,6 +314,168 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const P* __restrict_
     }
 }
 
+
+// ---- 8-bit specialisation: the same planes with packed dot products ---------------------------------------------------------
+// Pixels are staged biased by -128 (xor 0x80) so that v_dot4_i32_i8 applies: sum(c * p) = dot4(c, p - 128) + 128 * sum(c) and
+// sum(c) = 64 for every phase, i.e. "+ 8192" — which is exactly the -8192 offset of the 14-bit intermediate (ipfilter.cpp:124-126),
+// so at 8 bit the hps value IS the biased dot product.  Horizontal windows come from v_alignbyte_b32, the vertical pass
+// transposes 4x4 bytes with v_perm_b32, and the second (vertical, 14-bit) stage runs on v_dot2_i32_i16 over row pairs.
+constexpr int pack4c(int a, int b, int c, int d) { return (a & 255) | ((b & 255) << 8) | ((c & 255) << 16) | (int)((unsigned)(d & 255) << 24); }
+constexpr int pack2c(int a, int b) { return (a & 0xffff) | (int)((unsigned)(b & 0xffff) << 16); }
+struct LumaPacked
+{
+    int lo4[4], hi4[4];          // taps 0-3 / 4-7 as signed bytes, per phase
+    int pr[4][4];                // tap pairs (0,1) (2,3) (4,5) (6,7) as signed shorts, per phase
+};
+constexpr LumaPacked make_luma_packed()
+{
+    const int f[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 }, { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+    LumaPacked t{};
+    for (int p = 0; p < 4; p++)
+    {
+        t.lo4[p] = pack4c(f[p][0], f[p][1], f[p][2], f[p][3]);
+        t.hi4[p] = pack4c(f[p][4], f[p][5], f[p][6], f[p][7]);
+        for (int k = 0; k < 4; k++)
+            t.pr[p][k] = pack2c(f[p][2 * k], f[p][2 * k + 1]);
+    }
+    return t;
+}
+constexpr LumaPacked kLumaPk = make_luma_packed();
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int dot4(int a, int b, int acc) { return __builtin_amdgcn_sdot4(a, b, acc, false); }
+__device__ __forceinline__ int dot2(int a, int b, int acc)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), acc, false);
+}
+// four values >> SH, saturated to u8 and packed: gfx950's v_ashr_pk_u8_i32 does two at a time; v_perm_b32 joins the halves.
+// (Written with the builtin on purpose: left to pattern matching, this compiler emits the same instruction WITHOUT masking the
+// undefined upper half and corrupts bytes 2-3 whenever the first value is negative.)
+template <int SH>
+__device__ __forceinline__ uint32_t sat_pack4(int a, int b, int c, int d)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ashr_pk_u8_i32(a, b, SH), hi = (uint32_t)__builtin_amdgcn_ashr_pk_u8_i32(c, d, SH);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
+__global__ __launch_bounds__(256) void subpel_planes8_kernel(const uint8_t* __restrict__ ref, int64_t stride, uint8_t* __restrict__ planes, int64_t planeElems,
+                                                             int x0, int y0, int x1, int y1)
+{
+    const int xlo = x0 - 4, xhi = x1 + 4, ylo = y0 - 4, yhi = y1 + 4;
+    constexpr int TW = 64, TH = 16, IWD = 18, IH = TH + 7;              // staged row: 18 dwords = columns bx-4 .. bx+67
+    __shared__ uint32_t in[IH][IWD];                                     // biased pixels (p ^ 0x80)
+    __shared__ __attribute__((aligned(8))) int16_t im[3][IH][TW];
+    const int tilesX = (x1 - x0 + TW - 1) / TW;
+    const int bx = x0 + (blockIdx.x % tilesX) * TW, by = y0 + (blockIdx.x / tilesX) * TH;
+    const int t = threadIdx.x;
+    for (int i = t; i < IH * IWD; i += 256)
+    {
+        const int r = i / IWD, q = i % IWD;
+        const int yy = min(max(by - 3 + r, ylo), yhi - 1), xs = bx - 4 + 4 * q;
+        const uint8_t* row = ref + (int64_t)yy * stride;
+        uint32_t v;
+        if (xs >= xlo && xs + 3 < xhi)
+            v = ld_unaligned<uint32_t>(row + xs);
+        else
+        {
+            v = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v |= (uint32_t)row[min(max(xs + e, xlo), xhi - 1)] << (8 * e);
+        }
+        in[r][q] = v ^ 0x80808080u;
+    }
+    __syncthreads();
+    // ---- phase A: the three horizontal phases of one staged row quad per item
+    for (int i = t; i < IH * (TW / 4); i += 256)
+    {
+        const int r = i / (TW / 4), q = i % (TW / 4);
+        const uint32_t d0 = in[r][q], d1 = in[r][q + 1], d2 = in[r][q + 2];
+        // output o (column bx + 4q + o) needs bytes 4q + 1 + o .. + 8 of the staged row
+        uint32_t wl[4], wh[4];
+        wl[0] = __builtin_amdgcn_alignbyte(d1, d0, 1); wh[0] = __builtin_amdgcn_alignbyte(d2, d1, 1);
+        wl[1] = __builtin_amdgcn_alignbyte(d1, d0, 2); wh[1] = __builtin_amdgcn_alignbyte(d2, d1, 2);
+        wl[2] = __builtin_amdgcn_alignbyte(d1, d0, 3); wh[2] = __builtin_amdgcn_alignbyte(d2, d1, 3);
+        wl[3] = d1; wh[3] = d2;
+        const int y = by + r - 3, x = bx + 4 * q;
+        const bool out = r >= 3 && r < 3 + TH && y < y1 && x < x1;
+#pragma unroll
+        for (int xf = 1; xf < 4; xf++)
+        {
+            int h[4];
+#pragma unroll
+            for (int o = 0; o < 4; o++)
+                h[o] = dot4((int)wl[o], kLumaPk.lo4[xf], dot4((int)wh[o], kLumaPk.hi4[xf], 0));     // = true sum - 8192 = the hps value
+            uint2 hv;
+            hv.x = (uint32_t)(h[0] & 0xffff) | ((uint32_t)h[1] << 16);
+            hv.y = (uint32_t)(h[2] & 0xffff) | ((uint32_t)h[3] << 16);
+            *reinterpret_cast<uint2*>(&im[xf - 1][r][4 * q]) = hv;
+            if (out)
+                st_unaligned<uint32_t>(planes + (int64_t)xf * planeElems + (int64_t)y * stride + x,
+                                       sat_pack4<6>(h[0] + 8224, h[1] + 8224, h[2] + 8224, h[3] + 8224));           // (sum + 32) >> 6, clipped
+        }
+    }
+    __syncthreads();
+    // ---- phase B: plane 0, the vertical planes and the nine hv planes of one output quad per thread
+    {
+        const int r = t / (TW / 4), q = t % (TW / 4);
+        const int y = by + r, x = bx + 4 * q;
+        if (y < y1 && x < x1)
+        {
+            uint32_t R[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) R[k] = in[r + k][q + 1];                // rows y-3 .. y+4 at columns x .. x+3 (biased)
+            st_unaligned<uint32_t>(planes + (int64_t)y * stride + x, R[3] ^ 0x80808080u);
+            uint32_t cl[4], ch[4];                                               // column o: rows 0-3 / rows 4-7 as bytes
+            {
+                const uint32_t t0 = __builtin_amdgcn_perm(R[1], R[0], 0x05010400u), t1 = __builtin_amdgcn_perm(R[1], R[0], 0x07030602u);
+                const uint32_t u0 = __builtin_amdgcn_perm(R[3], R[2], 0x05010400u), u1 = __builtin_amdgcn_perm(R[3], R[2], 0x07030602u);
+                cl[0] = __builtin_amdgcn_perm(u0, t0, 0x05040100u); cl[1] = __builtin_amdgcn_perm(u0, t0, 0x07060302u);
+                cl[2] = __builtin_amdgcn_perm(u1, t1, 0x05040100u); cl[3] = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
+                const uint32_t t2 = __builtin_amdgcn_perm(R[5], R[4], 0x05010400u), t3 = __builtin_amdgcn_perm(R[5], R[4], 0x07030602u);
+                const uint32_t u2 = __builtin_amdgcn_perm(R[7], R[6], 0x05010400u), u3 = __builtin_amdgcn_perm(R[7], R[6], 0x07030602u);
+                ch[0] = __builtin_amdgcn_perm(u2, t2, 0x05040100u); ch[1] = __builtin_amdgcn_perm(u2, t2, 0x07060302u);
+                ch[2] = __builtin_amdgcn_perm(u3, t3, 0x05040100u); ch[3] = __builtin_amdgcn_perm(u3, t3, 0x07060302u);
+            }
+#pragma unroll
+            for (int yf = 1; yf < 4; yf++)
+            {
+                int o4[4];
+#pragma unroll
+                for (int o = 0; o < 4; o++)
+                    o4[o] = dot4((int)cl[o], kLumaPk.lo4[yf], dot4((int)ch[o], kLumaPk.hi4[yf], 8192 + 32));
+                st_unaligned<uint32_t>(planes + (int64_t)(yf * 4) * planeElems + (int64_t)y * stride + x, sat_pack4<6>(o4[0], o4[1], o4[2], o4[3]));
+            }
+#pragma unroll
+            for (int xf = 1; xf < 4; xf++)
+            {
+                uint32_t pr[4][4];                                               // [row pair][column]: (h[2j][o], h[2j+1][o])
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                {
+                    const uint2 a = *reinterpret_cast<const uint2*>(&im[xf - 1][r + 2 * j][4 * q]);
+                    const uint2 b = *reinterpret_cast<const uint2*>(&im[xf - 1][r + 2 * j + 1][4 * q]);
+                    pr[j][0] = __builtin_amdgcn_perm(b.x, a.x, 0x05040100u); pr[j][1] = __builtin_amdgcn_perm(b.x, a.x, 0x07060302u);
+                    pr[j][2] = __builtin_amdgcn_perm(b.y, a.y, 0x05040100u); pr[j][3] = __builtin_amdgcn_perm(b.y, a.y, 0x07060302u);
+                }
+#pragma unroll
+                for (int yf = 1; yf < 4; yf++)
+                {
+                    int o4[4];
+#pragma unroll
+                    for (int o = 0; o < 4; o++)
+                    {
+                        int sum = (1 << 11) + (8192 << 6);                               // interp_vert_sp at depth 8: offset, shift 12 (ipfilter.cpp:244-246)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) sum = dot2((int)pr[j][o], kLumaPk.pr[yf][j], sum);
+                        o4[o] = sum;
+                    }
+                    st_unaligned<uint32_t>(planes + (int64_t)(yf * 4 + xf) * planeElems + (int64_t)y * stride + x, sat_pack4<12>(o4[0], o4[1], o4[2], o4[3]));
+                }
+            }
+        }
+    }
+}
+
 } // namespace xh
 
 extern "C" int x265hip_build_subpel_planes(int depth, const void* refOrigin, int64_t stride, int picW, int picH, int marginX, int marginY,
@@ -325,7 +488,11 @@ extern "C" int x265hip_build_subpel_planes(int depth, const void* refOrigin, int
     const int x0 = -marginX + 4, y0 = -marginY + 4, x1 = picW + marginX - 4, y1 = picH + marginY - 4;
     const int tilesX = (x1 - x0 + 63) / 64, tilesY = (y1 - y0 + 15) / 16;
     dim3 grid(tilesX * tilesY), block(256);
-    if (depth == 8)
+    static const bool generic8 = getenv("X265HIP_PLANES_GENERIC") != nullptr;
+    if (depth == 8 && !generic8)
+        hipLaunchKernelGGL(subpel_planes8_kernel, grid, block, 0, as_stream(stream), (const uint8_t*)refOrigin, stride, (uint8_t*)planesOrigin, planeElems,
+                           x0, y0, x1, y1);
+    else if (depth == 8)
         hipLaunchKernelGGL((subpel_planes_kernel<uint8_t>), grid, block, 0, as_stream(stream), (const uint8_t*)refOrigin, stride,
                            (uint8_t*)planesOrigin, planeElems, x0, y0, x1, y1, depth);
     else

@@ -22,27 +22,31 @@ def padded(plane, margin=MARGIN):
 
 
 class Plane:
-    """A padded picture plane in device memory."""
+    """A padded picture plane in device memory (its own allocation, or a window of a shared one: `store` = (DevBuf, element offset))."""
 
-    def __init__(self, width, height, depth, host=None, margin=MARGIN):
+    def __init__(self, width, height, depth, host=None, margin=MARGIN, store=None):
         self.width, self.height, self.depth, self.margin = width, height, depth, margin
         self.stride = width + 2 * margin
         self.rows = height + 2 * margin
-        dt = hp.pix_dtype(depth)
-        if host is not None:
-            assert host.shape == (height, width) and host.dtype == dt
-            self.buf = DevBuf(padded(host, margin))
+        self.dtype = hp.pix_dtype(depth)
+        if store is not None:
+            self.buf, self.base = store
         else:
-            self.buf = DevBuf.zeros((self.rows, self.stride), dt)
-        self.origin = self.buf.at(margin * self.stride + margin)
+            self.buf, self.base = DevBuf.zeros((self.rows * self.stride,), self.dtype), 0
+        self.ptr = self.buf.at(self.base)
+        self.origin = self.buf.at(self.base + margin * self.stride + margin)
+        if host is not None:
+            assert host.shape == (height, width) and host.dtype == self.dtype
+            self.upload(host)
 
     def upload(self, host):
         p = padded(host, self.margin)
-        check(hp.lib().x265hip_memcpy_h2d(self.buf.ptr, p.ctypes.data, p.nbytes, None))
+        check(hp.lib().x265hip_memcpy_h2d(self.ptr, p.ctypes.data, p.nbytes, None))
         check(hp.lib().x265hip_stream_sync(None))
 
     def get(self, with_margins=False):
-        a = self.buf.get()
+        a = np.empty((self.rows, self.stride), self.dtype)
+        check(hp.lib().x265hip_memcpy_d2h(a.ctypes.data, self.ptr, a.nbytes, None))
         m = self.margin
         return a if with_margins else np.ascontiguousarray(a[m:m + self.height, m:m + self.width])
 
@@ -52,12 +56,18 @@ class YuvStruct(C.Structure):
 
 
 class Picture:
-    """A 4:2:0 picture in device memory: luma Plane + two chroma Planes (half size, half margins)."""
+    """A 4:2:0 picture in device memory: luma Plane + two chroma Planes (half size, half margins) in ONE allocation — the frame pass
+    addresses Cr from the Cb pointer with 32-bit element offsets (include/x265hip.h), so the planes of a picture must sit together."""
 
     def __init__(self, width, height, depth, y=None, cb=None, cr=None, margin=MARGIN):
-        self.y = Plane(width, height, depth, y, margin)
-        self.cb = Plane(width // 2, height // 2, depth, cb, margin // 2)
-        self.cr = Plane(width // 2, height // 2, depth, cr, margin // 2)
+        ny = (width + 2 * margin) * (height + 2 * margin)
+        nc = (width // 2 + margin) * (height // 2 + margin)
+        ny = (ny + 63) & ~63
+        nc = (nc + 63) & ~63
+        self.store = DevBuf.zeros((ny + 2 * nc,), hp.pix_dtype(depth))
+        self.y = Plane(width, height, depth, y, margin, store=(self.store, 0))
+        self.cb = Plane(width // 2, height // 2, depth, cb, margin // 2, store=(self.store, ny))
+        self.cr = Plane(width // 2, height // 2, depth, cr, margin // 2, store=(self.store, ny + nc))
 
     def struct(self):
         return YuvStruct(self.y.origin, self.cb.origin, self.cr.origin, self.y.stride, self.cb.stride)
