@@ -81,7 +81,7 @@ def reference_encoder(frames=12):
 def pmc_traffic(stage):
     """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
     in separate runs of this same command; FETCH doubled per the gfx950 correction of MI355X_MICROARCH.md).  None if absent."""
-    names = {"planes": "subpel_planes_kernel", "me64": "motion2_kernel<unsigned char, 64", "me32": "motion3_kernel<unsigned char, 32",
+    names = {"planes": "subpel_planes", "me64": "motion2_kernel<unsigned char, 64", "me32": "motion3_kernel<unsigned char, 32",
              "me16": "motion3_kernel<unsigned char, 16", "me8": "motion3_kernel<unsigned char, 8", "pred8": "pred_from_planes_kernel",
              "chain32": "residual_chain_kernel<unsigned char, 32", "chain8": "residual_chain_kernel<unsigned char, 8",
              "sa8d": "sa8d_levels_kernel", "border": "extend_border3_kernel", "chroma": "pred_chroma_kernel"}

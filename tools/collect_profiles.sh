@@ -16,6 +16,7 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $ou
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/${tag}_write -o b -- $cmd > $out/${tag}_write.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES \
     --kernel-trace --output-format csv -d $out/${tag}_sq -o b -- $cmd > $out/${tag}_sq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_lookahead -o b -- env CPU=0 PAIRS=64 python $root/tools/lookahead_bench.py > $out/${tag}_lookahead.log 2>&1
 cd $root
 python bench.py > $out/${tag}_bench_line.json 2> $out/${tag}_bench.err
 tail -c 600 $out/${tag}_bench_line.json

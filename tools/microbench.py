@@ -94,6 +94,20 @@ def main():
             ms = timeit(lambda: check(L.x265hip_interp_batch(kind, 8, depth, bs, bs, da.ptr, S, out.ptr, bs, d_o.ptr, d_od.ptr, co.ptr, 0, n, None)))
             res.append({"kernel": "luma_%s %dx%d" % (name, bs, bs), "n": n, "ms": ms, "GBps": n * (ext + bs * bs) * B / ms / 1e6})
 
+    # intra prediction: all 35 modes of every block of the frame (35 x n jobs), neighbour lines random
+    for size in (4, 8, 16, 32):
+        nblk = (W // size) * (H // size)
+        if size == 4:
+            nblk //= 4                      # 4x4 x 35 modes of a whole 1080p frame would be 4.5 M jobs; a quarter of them
+        lines = DevBuf(rng.integers(0, 1 << depth, size=(nblk, 4 * size + 1)).astype(dt))
+        n = nblk * 35
+        lo = dev_i32(np.repeat(np.arange(nblk) * (4 * size + 1), 35))
+        md = dev_i32(np.tile(np.arange(35), nblk) | (1 << 8))
+        do = dev_i32(np.arange(n, dtype=np.int64) * size * size)
+        out = DevBuf.empty((n, size, size), dt)
+        ms = timeit(lambda: check(L.x265hip_intra_pred_batch(depth, size, lines.ptr, lo.ptr, md.ptr, out.ptr, do.ptr, size, n, None)), iters=10)
+        res.append({"kernel": "intra_pred %dx%d x35" % (size, size), "n": n, "ms": ms, "GBps": n * ((4 * size + 1) + size * size) * B / ms / 1e6})
+
     for r in res:
         print("%-22s n=%-7d %8.3f ms  %9.1f GB/s (algorithmic)" % (r["kernel"], r["n"], r["ms"], r["GBps"]))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -39,6 +39,15 @@ stats = find("stats", "kernel_stats.csv")
 if stats:
     shutil.copy(stats, os.path.join(P, f"{tag}_bench_kernel_stats.csv"))
 
+la = find("lookahead", "kernel_stats.csv")
+if la:
+    shutil.copy(la, os.path.join(P, f"{tag}_lookahead_kernel_stats.csv"))
+    log = os.path.join(G, f"{tag}_lookahead.log")
+    if os.path.exists(log):
+        lines = [l for l in open(log) if l.startswith("{")]
+        if lines:
+            open(os.path.join(P, f"{tag}_lookahead_bench_line.json"), "w").write(lines[-1])
+
 fv, grid = per_kernel("fetch")
 wv, _ = per_kernel("write")
 with open(os.path.join(P, f"{tag}_pmc_hbm_bytes.txt"), "w") as o:

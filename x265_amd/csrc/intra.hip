@@ -342,37 +342,30 @@ __global__ __launch_bounds__(256) void lowres_intra_kernel(const P* __restrict__
     }
 }
 
-// rowSatds[0][0][cy] = sum of the row's costs; costEst = sum over the non-edge blocks (slicetype.cpp:777-800, AQ off)
-__global__ __launch_bounds__(256) void lowres_intra_sums_kernel(const int32_t* __restrict__ intraCost, int widthInCU, int heightInCU,
-                                                                int32_t* __restrict__ rowSatd, int32_t* __restrict__ costEst)
+// rowSatds[0][0][cy] = sum of the row's costs; costEst = sum over the non-edge blocks (slicetype.cpp:777-800, AQ off).  One wave per row.
+__global__ __launch_bounds__(64) void lowres_intra_sums_kernel(const int32_t* __restrict__ intraCost, int widthInCU, int heightInCU,
+                                                               int32_t* __restrict__ rowSatd, int32_t* __restrict__ costEst)
 {
-    __shared__ int part[4];
     const bool all = widthInCU <= 2 || heightInCU <= 2;
-    int est = 0;
-    for (int cy = threadIdx.x >> 6; cy < heightInCU; cy += 4)     // one wave per row, grid = 1 workgroup (a lowres frame has < 200 rows)
+    const int cy = blockIdx.x;
+    int row = 0, in = 0;
+    for (int cx = threadIdx.x; cx < widthInCU; cx += 64)
     {
-        int row = 0, in = 0;
-        for (int cx = threadIdx.x & 63; cx < widthInCU; cx += 64)
-        {
-            const int c = intraCost[cy * widthInCU + cx];
-            row += c;
-            if (all || (cx > 0 && cx < widthInCU - 1 && cy > 0 && cy < heightInCU - 1))
-                in += c;
-        }
-        for (int o = 32; o; o >>= 1)
-        {
-            row += __shfl_xor(row, o);
-            in += __shfl_xor(in, o);
-        }
-        if ((threadIdx.x & 63) == 0)
-            rowSatd[cy] = row;
-        est += in;
+        const int c = intraCost[cy * widthInCU + cx];
+        row += c;
+        if (all || (cx > 0 && cx < widthInCU - 1 && cy > 0 && cy < heightInCU - 1))
+            in += c;
     }
-    if ((threadIdx.x & 63) == 0)
-        part[threadIdx.x >> 6] = est;
-    __syncthreads();
+    for (int o = 32; o; o >>= 1)
+    {
+        row += __shfl_xor(row, o);
+        in += __shfl_xor(in, o);
+    }
     if (threadIdx.x == 0)
-        *costEst = part[0] + part[1] + part[2] + part[3];
+    {
+        rowSatd[cy] = row;
+        if (in) atomicAdd(costEst, in);
+    }
 }
 
 static bool valid_intra_size(int n) { return n == 4 || n == 8 || n == 16 || n == 32; }
@@ -481,7 +474,9 @@ int x265hip_lowres_intra_estimate(int depth, const void* plane, int64_t stride, 
     XH_LAUNCH_CHECK("lowres_intra_kernel");
     if (rowSatd && costEst)
     {
-        hipLaunchKernelGGL(lowres_intra_sums_kernel, dim3(1), dim3(256), 0, as_stream(stream), intraCost, widthInCU, heightInCU, rowSatd, costEst);
+        int e = check_hip(hipMemsetAsync(costEst, 0, sizeof(int32_t), as_stream(stream)), "lowres_intra memset");
+        if (e) return e;
+        hipLaunchKernelGGL(lowres_intra_sums_kernel, dim3(heightInCU), dim3(64), 0, as_stream(stream), intraCost, widthInCU, heightInCU, rowSatd, costEst);
         XH_LAUNCH_CHECK("lowres_intra_sums_kernel");
     }
     return X265HIP_OK;
