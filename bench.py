@@ -183,15 +183,33 @@ def main():
 
     state["last"] = None                  # recon of the last chain of the previous step, still to be handed to the next rank
 
+    # Dependencies between the F chains are per picture, tracked with events (no per-step join of all streams):
+    #   done[j][k & 1]  chain j finished its pass of step k (its recon is complete)
+    #   got[k & 1]      the reference for chain 0 of step k has arrived (the exchange of step k finished)
+    done = [[torch.cuda.Event(), torch.cuda.Event()] for _ in range(F)]
+    got = [torch.cuda.Event(), torch.cuda.Event()]
+
     def launch(j, k, recs):
         src, rec = pool[(k + j) % NPOOL], recons[j][k & 1]
         recs[j] = rec
-        if streams[j] is not None:
-            streams[j].wait_stream(torch.cuda.current_stream())
-            sh = streams[j].cuda_stream
+        st = streams[j]
+        if st is None:                                          # F == 1: everything in order on the current stream
+            run_pass(fps_[j].h, src, state["refs"][j], preds[j], rec, stream)
+            return
+        p = (k - 1) & 1
+        if k == 0:
+            st.wait_stream(torch.cuda.current_stream())          # input upload
         else:
-            sh = stream
-        run_pass(fps_[j].h, src, state["refs"][j], preds[j], rec, sh)
+            st.wait_event(got[k & 1] if j == 0 else done[j - 1][p])          # producer of this pass's reference
+        if k > 1:
+            # `rec` was the reference of the next chain (or went through the exchange) at step k-1: its reader must be done
+            if j < F - 1:
+                st.wait_event(done[j + 1][p])
+            else:
+                st.wait_event(got[p])
+                st.wait_event(done[0][p])                        # single rank: chain 0 read it in place
+        run_pass(fps_[j].h, src, state["refs"][j], preds[j], rec, st.cuda_stream)
+        done[j][k & 1].record(st)
 
     def step():
         # reconstructed-reference hand-over: chain j+1 takes chain j's recon of the previous step (same device, pointer swap); the
@@ -201,15 +219,15 @@ def main():
         cur = torch.cuda.current_stream()
         recs = [None] * F
         if state["last"] is not None:
+            if streams[0] is not None:
+                cur.wait_event(done[F - 1][(k - 1) & 1])         # the picture to hand over is complete
             ring.begin(state["last"])
         for j in range(1, F):
             launch(j, k, recs)
         if state["last"] is not None:
             state["refs"][0] = ring.finish()
+            got[k & 1].record(cur)
         launch(0, k, recs)
-        for j in range(F):
-            if streams[j] is not None:
-                cur.wait_stream(streams[j])
         state["refs"] = [state["refs"][0]] + recs[:F - 1]
         state["last"] = recs[F - 1]
         state["k"] = k + 1
@@ -230,6 +248,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_dt = time.perf_counter() - t0                     # host time to enqueue the steps (launch-bound check)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -297,7 +316,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": stage_ms[dom], "unique_footprint": unique},
-            "stage_ms": stage_ms,
+            "stage_ms": stage_ms, "host_enqueue_ms_per_step": round(host_dt * 1e3 / args.steps, 4),
         }
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_frames)
