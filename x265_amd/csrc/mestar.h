@@ -1,6 +1,8 @@
 // mestar.h — X265_STAR_SEARCH (reference: source/encoder/motion.cpp:1132-1240, StarPatternSearch :362-604, COST_MV_PT_DIST
 // :224-236, offsets[] :74-84), shared by the three motion kernels.  `C` provides
 //     int fullpel_cost(int mx, int my, int shift)   =  sad(block at full-pel (mx, my)) + mvcost((mx, my) << shift)
+//     void fullpel_costs<K>(mx[K], my[K], out[K])   =  the same for K points at once, shift 2
+//     int mvcost(int qx, int qy)
 // The reference evaluates the points of one distance either in sad_x4 groups (all in range) or one by one behind per-point
 // range checks; the order is the same and a point's check is implied by the group check, so: for each point in reference
 // order, if its own check holds, evaluate it and update (bcost, bmv, bPointNr, bDistance) on a strict improvement.
@@ -11,8 +13,25 @@ namespace xh {
 
 struct StarState { int bx, by, bcost, bPointNr, bDistance; };
 
-#define XH_STAR_PT(mx_, my_, cond_, point_, dist_) do { if (cond_) { const int c_ = c.fullpel_cost((mx_), (my_), 2); \
-        if (c_ < st.bcost) { st.bcost = c_; st.bx = (mx_); st.by = (my_); st.bPointNr = (point_); st.bDistance = (dist_); } } } while (0)
+// K points of one ring measured together and replayed in reference order.  A point's cost does not depend on the running best, so
+// batching them (all loads of the ring in flight at once) changes nothing but the latency.  Points that fail their range check are
+// measured at the ring centre instead (always inside the range, so inside the padded plane) and ignored.
+template <int K, class C>
+__device__ __forceinline__ void star_points(C& c, StarState& st, int ox, int oy, const int (&px)[K], const int (&py)[K], const bool (&ok)[K],
+                                            const int (&pnr)[K], const int (&dst)[K])
+{
+    int ex[K], ey[K], cost[K];
+#pragma unroll
+    for (int i = 0; i < K; i++)
+    {
+        ex[i] = ok[i] ? px[i] : ox;
+        ey[i] = ok[i] ? py[i] : oy;
+    }
+    c.template fullpel_costs<K>(ex, ey, cost);
+#pragma unroll
+    for (int i = 0; i < K; i++)
+        if (ok[i] && cost[i] < st.bcost) { st.bcost = cost[i]; st.bx = px[i]; st.by = py[i]; st.bPointNr = pnr[i]; st.bDistance = dst[i]; }
+}
 
 template <class C>
 __device__ __forceinline__ void star_pattern_search(C& c, int minx, int miny, int maxx, int maxy, StarState& st, int earlyExitIters, int merange)
@@ -22,51 +41,60 @@ __device__ __forceinline__ void star_pattern_search(C& c, int minx, int miny, in
     {
         const int dist = 1;
         const int top = oy - dist, bottom = oy + dist, left = ox - dist, right = ox + dist;
-        XH_STAR_PT(ox, top, top >= miny, 2, dist);
-        XH_STAR_PT(left, oy, left >= minx, 4, dist);
-        XH_STAR_PT(right, oy, right <= maxx, 5, dist);
-        XH_STAR_PT(ox, bottom, bottom <= maxy, 7, dist);
+        const int px[4] = { ox, left, right, ox }, py[4] = { top, oy, oy, bottom };
+        const bool ok[4] = { top >= miny, left >= minx, right <= maxx, bottom <= maxy };
+        const int pnr[4] = { 2, 4, 5, 7 }, dst[4] = { dist, dist, dist, dist };
+        star_points<4>(c, st, ox, oy, px, py, ok, pnr, dst);
         if (st.bcost < saved) rounds = 0;
         else if (++rounds >= earlyExitIters) return;
     }
+#pragma unroll 1
     for (int dist = 2; dist <= 8; dist <<= 1)
     {
         const int top = oy - dist, bottom = oy + dist, left = ox - dist, right = ox + dist;
         const int top2 = oy - (dist >> 1), bottom2 = oy + (dist >> 1), left2 = ox - (dist >> 1), right2 = ox + (dist >> 1);
         saved = st.bcost;
-        XH_STAR_PT(ox, top, top >= miny, 2, dist);
-        XH_STAR_PT(left2, top2, top2 >= miny && left2 >= minx, 1, dist >> 1);
-        XH_STAR_PT(right2, top2, top2 >= miny && right2 <= maxx, 3, dist >> 1);
-        XH_STAR_PT(left, oy, left >= minx, 4, dist);
-        XH_STAR_PT(right, oy, right <= maxx, 5, dist);
-        XH_STAR_PT(left2, bottom2, bottom2 <= maxy && left2 >= minx, 6, dist >> 1);
-        XH_STAR_PT(right2, bottom2, bottom2 <= maxy && right2 <= maxx, 8, dist >> 1);
-        XH_STAR_PT(ox, bottom, bottom <= maxy, 7, dist);
+        const int px[8] = { ox, left2, right2, left, right, left2, right2, ox };
+        const int py[8] = { top, top2, top2, oy, oy, bottom2, bottom2, bottom };
+        const bool ok[8] = { top >= miny, top2 >= miny && left2 >= minx, top2 >= miny && right2 <= maxx, left >= minx, right <= maxx,
+                             bottom2 <= maxy && left2 >= minx, bottom2 <= maxy && right2 <= maxx, bottom <= maxy };
+        const int pnr[8] = { 2, 1, 3, 4, 5, 6, 8, 7 };
+        const int dst[8] = { dist, dist >> 1, dist >> 1, dist, dist, dist >> 1, dist >> 1, dist };
+        star_points<8>(c, st, ox, oy, px, py, ok, pnr, dst);
         if (st.bcost < saved) rounds = 0;
         else if (++rounds >= earlyExitIters) return;
     }
+#pragma unroll 1
     for (int dist = 16; dist <= (int)(int16_t)merange; dist <<= 1)
     {
         const int top = oy - dist, bottom = oy + dist, left = ox - dist, right = ox + dist;
         saved = st.bcost;
-        XH_STAR_PT(ox, top, top >= miny, 0, dist);
-        XH_STAR_PT(left, oy, left >= minx, 0, dist);
-        XH_STAR_PT(right, oy, right <= maxx, 0, dist);
-        XH_STAR_PT(ox, bottom, bottom <= maxy, 0, dist);
-        for (int index = 1; index < 4; index++)
+        const int q = dist >> 2;
+        // reference order: the four axis points, then for index 1..3 the four diagonal-side points (motion.cpp:560-600)
         {
-            const int posYT = top + ((dist >> 2) * index), posYB = bottom - ((dist >> 2) * index);
-            const int posXL = ox - ((dist >> 2) * index), posXR = ox + ((dist >> 2) * index);
-            XH_STAR_PT(posXL, posYT, posYT >= miny && posXL >= minx, 0, dist);
-            XH_STAR_PT(posXR, posYT, posYT >= miny && posXR <= maxx, 0, dist);
-            XH_STAR_PT(posXL, posYB, posYB <= maxy && posXL >= minx, 0, dist);
-            XH_STAR_PT(posXR, posYB, posYB <= maxy && posXR <= maxx, 0, dist);
+            const int px[8] = { ox, left, right, ox, ox - q, ox + q, ox - q, ox + q };
+            const int py[8] = { top, oy, oy, bottom, top + q, top + q, bottom - q, bottom - q };
+            const bool ok[8] = { top >= miny, left >= minx, right <= maxx, bottom <= maxy,
+                                 top + q >= miny && ox - q >= minx, top + q >= miny && ox + q <= maxx,
+                                 bottom - q <= maxy && ox - q >= minx, bottom - q <= maxy && ox + q <= maxx };
+            const int pnr[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, dst[8] = { dist, dist, dist, dist, dist, dist, dist, dist };
+            star_points<8>(c, st, ox, oy, px, py, ok, pnr, dst);
+        }
+        {
+            const int a = 2 * q, b = 3 * q;
+            const int px[8] = { ox - a, ox + a, ox - a, ox + a, ox - b, ox + b, ox - b, ox + b };
+            const int py[8] = { top + a, top + a, bottom - a, bottom - a, top + b, top + b, bottom - b, bottom - b };
+            const bool ok[8] = { top + a >= miny && ox - a >= minx, top + a >= miny && ox + a <= maxx,
+                                 bottom - a <= maxy && ox - a >= minx, bottom - a <= maxy && ox + a <= maxx,
+                                 top + b >= miny && ox - b >= minx, top + b >= miny && ox + b <= maxx,
+                                 bottom - b <= maxy && ox - b >= minx, bottom - b <= maxy && ox + b <= maxx };
+            const int pnr[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, dst[8] = { dist, dist, dist, dist, dist, dist, dist, dist };
+            star_points<8>(c, st, ox, oy, px, py, ok, pnr, dst);
         }
         if (st.bcost < saved) rounds = 0;
         else if (++rounds >= earlyExitIters) return;
     }
 }
-#undef XH_STAR_PT
 
 __device__ __constant__ const int8_t kStarOffsets[16][2] = { {-1,0}, {0,-1}, {-1,-1}, {1,-1}, {-1,0}, {1,0}, {-1,1}, {-1,-1},
                                                               {1,-1}, {1,1}, {-1,0}, {0,1}, {-1,1}, {1,1}, {1,0}, {0,1} };   // motion.cpp:74-84
@@ -106,10 +134,15 @@ __device__ __forceinline__ void star_search(C& c, int minx, int miny, int maxx, 
                 {
                     if (tx + 15 <= maxx)
                     {
-                        XH_TRY(tx, ty, 2);
-                        XH_TRY(tx + 5, ty, 2);
-                        XH_TRY(tx + 10, ty, 2);
-                        XH_TRY(tx + 15, ty, 3);                                // the reference adds mvcost(tmv << 3) here (:1195)
+                        // one sad_x4 of the reference: four points measured together
+                        const int px[4] = { tx, tx + 5, tx + 10, tx + 15 }, py[4] = { ty, ty, ty, ty };
+                        int cost[4];
+                        c.template fullpel_costs<4>(px, py, cost);
+                        // the reference adds mvcost(tmv << 3) to the fourth (:1195)
+                        cost[3] += c.mvcost((tx + 15) << 3, ty << 3) - c.mvcost((tx + 15) << 2, ty << 2);
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            if (cost[i] < st.bcost) { st.bcost = cost[i]; st.bx = px[i]; st.by = py[i]; }
                         tx += 15;
                     }
                     else

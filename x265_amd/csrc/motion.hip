@@ -87,6 +87,12 @@ struct MeCtx
 
     // mestar.h contract
     __device__ __forceinline__ int fullpel_cost(int mx, int my, int shift) const { return sad_at(mx, my) + mvcost(mx << shift, my << shift); }
+    template <int K>
+    __device__ __forceinline__ void fullpel_costs(const int (&mx)[K], const int (&my)[K], int (&out)[K]) const
+    {
+#pragma unroll 1
+        for (int k = 0; k < K; k++) out[k] = fullpel_cost(mx[k], my[k], 2);
+    }
 
     // K (<= 4) candidates; costs[k] = SAD only.  Small PUs run all candidates side by side in lane groups.
     __device__ __forceinline__ void sad_multi(int K, const Mv* mvs, int* costs) const

@@ -320,6 +320,15 @@ struct Team
         for (int k = 0; k < K; k++) costs[k] += __builtin_amdgcn_readlane(mvc, k);
     }
 
+    // mestar.h contract: K points at once on the candidate-parallel path (shift 2)
+    template <int K>
+    __device__ __forceinline__ void fullpel_costs(const int (&mx)[K], const int (&my)[K], int (&out)[K])
+    {
+        Mv2 cd[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) cd[k] = Mv2{ mx[k], my[k] };
+        eval_sad<K>(cd, out);
+    }
     // mestar.h contract: sad + mvcost((mx, my) << shift)
     __device__ __forceinline__ int fullpel_cost(int mx, int my, int shift)
     {

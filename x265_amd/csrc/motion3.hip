@@ -134,7 +134,26 @@ struct RowTeam
         // every tile's |H D H^T| sum is even (pixel.hip), so one >> 1 over the block equals the per-tile >> 1 of pixel.cpp:235
         return team_allsum<TEAM>(acc) >> 1;
     }
-    // mestar.h contract
+    // mestar.h contract: K full-pel points measured together (all their loads in flight before the first reduction)
+    template <int K>
+    __device__ __forceinline__ void fullpel_costs(const int (&mx)[K], const int (&my)[K], int (&out)[K]) const
+    {
+        unsigned acc[K];
+        int mvc[K];
+#pragma unroll
+        for (int k = 0; k < K; k++)
+        {
+            const P* r = plane0 + my[k] * stride + mx[k];
+            acc[k] = 0;
+#pragma unroll
+            for (int j = 0; j < IPT; j++)
+                acc[k] = Pk3<P>::sad(ld_unaligned<Q>(r + qoff[j]), fq[j], acc[k]);
+            mvc[k] = mvcost(mx[k] * 4, my[k] * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++)
+            out[k] = team_allsum<TEAM>((int)acc[k]) + mvc[k];
+    }
     __device__ __forceinline__ int fullpel_cost(int mx, int my, int shift) const
     {
         return sad_q(Mv3{ mx * 4, my * 4 }) + mvcost(mx << shift, my << shift);
