@@ -302,6 +302,14 @@ int x265hip_intra_allangs_batch(int depth, int n, const void* lines, const int32
 /* intra_filter_t (primitives.h:145, intraFilter<N> intrapred.cpp:32): [1 2 1]/4 along the line, both ends kept */
 int x265hip_intra_filter_batch(int depth, int n, const void* in, const int32_t* inOff, void* out, const int32_t* outOff,
                                int count, void* stream);
+/* The distortion half of the intra mode decision (Search::checkIntraInInter search.cpp:1291-1452, estIntraPredQT :1509-1696): for
+ * each block the cu[].sa8d cost (satd_4x4 at N = 4) of all 35 predictions against the source block fenc + fencOff[i] (row pitch
+ * fencStride): costs[i*35 + mode].  DC is edge-smoothed when N <= 16, planar and the angles take the raw or the filtered line as
+ * g_intraFilterFlags says, the mode 10 / 26 edge gradient is on when N <= 16 — exactly the calls the reference makes; the mode
+ * bits and the argmin stay with the caller (they need the entropy coder's state).  64x64 CUs are scanned at 32x32 by the
+ * reference after a 2:1 downscale (:1327-1345), which is the caller's business too. */
+int x265hip_intra_scan_batch(int depth, int n, const void* lines, const int32_t* lineOff, const int32_t* filteredOff, const void* fenc,
+                             int64_t fencStride, const int32_t* fencOff, int count, int32_t* costs, void* stream);
 /* downscale_t (primitives.h:168; frameInitLowres = frame_init_lowres_core pixel.cpp:604): the half-resolution picture and
  * its H / V / diagonal half-pel companions; reads src rows 0..2*height and columns 0..2*width (the source margins). */
 int x265hip_frame_init_lowres(int depth, const void* src, int64_t srcStride, void* dst0, void* dstH, void* dstV, void* dstC,

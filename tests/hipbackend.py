@@ -472,3 +472,15 @@ class Hip:
         est = DevBuf.zeros((1,), np.int32)
         check(self.L.x265hip_lookahead_bidir_batch(self.depth, dbf.ptr, 1, stride, pe, wcu, hcu, est.ptr, None))
         return int(est.get()[0]) * 100 // 130, mvs[0].get(), mvc[0].get(), mvs[1].get(), mvc[1].get(), lc.get(), rows.get()
+
+    def intra_scan(self, n, lines, filtered, fenc_plane, fenc_xy):
+        """lines / filtered: (count, 4n+1); fenc_plane 2-D, fenc_xy list of (y, x).  Returns (count, 35) sa8d costs."""
+        count = len(fenc_xy)
+        dl = DevBuf(np.concatenate([lines.reshape(-1), filtered.reshape(-1)]))
+        df = DevBuf(fenc_plane)
+        out = DevBuf.zeros((count, 35), np.int32)
+        ln = 4 * n + 1
+        check(self.L.x265hip_intra_scan_batch(self.depth, n, dl.ptr, _ip(np.arange(count, dtype=np.int32) * ln),
+                                              _ip(np.arange(count, dtype=np.int32) * ln + count * ln), df.ptr, fenc_plane.shape[1],
+                                              _ip([y * fenc_plane.shape[1] + x for (y, x) in fenc_xy]), count, out.ptr, None))
+        return out.get()

@@ -465,6 +465,37 @@ def test_intra_pred_batch_all_modes(hipmod, depth):
 
 
 @pytest.mark.parametrize("depth", [8, 10, 12])
+def test_intra_mode_scan_matches_oracle(hipmod, depth):
+    """x265hip_intra_scan_batch = for every block and each of the 35 modes: intra_pred (raw / filtered line and bFilter as
+    Search::checkIntraInInter chooses them) followed by cu[].sa8d against the source block — composed here from the two pinned
+    oracle primitives."""
+    from cases import textured_frame
+    o, g = Orc(depth), hipmod.Hip(depth)
+    rng = np.random.default_rng(61 + depth)
+    plane = textured_frame(rng, 160, 224, depth)
+    for n in (4, 8, 16, 32):
+        count = 23
+        xy = [(int(rng.integers(1, 160 - n)), int(rng.integers(1, 224 - 2 * n))) for _ in range(count)]
+        lines = np.zeros((count, 4 * n + 1), o.pix)
+        for i, (y, x) in enumerate(xy):
+            if i % 5 == 4:
+                lines[i] = rng.integers(0, o.pmax + 1, 4 * n + 1)            # unrelated neighbours: large costs, clipping edge gradients
+            else:
+                lines[i, 0] = plane[y - 1, x - 1]
+                lines[i, 1:2 * n + 1] = np.resize(plane[y - 1, x:x + 2 * n], 2 * n)
+                lines[i, 2 * n + 1:] = np.resize(plane[y:y + 2 * n, x - 1], 2 * n)
+        filt = np.stack([o.intra_filter(n, lines[i]) for i in range(count)])
+        got = g.intra_scan(n, lines, filt, plane, xy)
+        hipmod._release()
+        for i, (y, x) in enumerate(xy):
+            for mode in range(35):
+                src = filt[i] if o.intra_uses_filtered(n, mode) else lines[i]
+                pred = o.intra_pred(n, mode, src, 1 if n <= 16 else 0)
+                want = o.sa8d(n, plane, (y, x), pred, (0, 0)) if n > 4 else o.satd(4, 4, plane, (y, x), pred, (0, 0))
+                assert got[i, mode] == want, (n, i, mode, int(got[i, mode]), want)
+
+
+@pytest.mark.parametrize("depth", [8, 10, 12])
 def test_lowres_pass_matches_oracle(hipmod, depth):
     """Lowres::init (downscale + four extended planes) and the lookahead intra estimate: planes, per-block cost and mode,
     row sums and frame estimate, bit for bit; odd sizes exercise the rounded-up lowres width and dead rows of the last team."""

@@ -108,6 +108,19 @@ def main():
         ms = timeit(lambda: check(L.x265hip_intra_pred_batch(depth, size, lines.ptr, lo.ptr, md.ptr, out.ptr, do.ptr, size, n, None)), iters=10)
         res.append({"kernel": "intra_pred %dx%d x35" % (size, size), "n": n, "ms": ms, "GBps": n * ((4 * size + 1) + size * size) * B / ms / 1e6})
 
+    # intra mode scan: sa8d of all 35 modes for every block of the frame, predictions never materialised
+    for size in (8, 16, 32):
+        oa, _ = grid(size)
+        nblk = oa.size
+        lines = DevBuf(rng.integers(0, 1 << depth, size=(2 * nblk, 4 * size + 1)).astype(dt))
+        lo = dev_i32(np.arange(nblk) * (4 * size + 1))
+        fo = dev_i32((np.arange(nblk) + nblk) * (4 * size + 1))
+        d_o = dev_i32(oa)
+        costs = DevBuf.empty((nblk, 35), np.int32)
+        ms = timeit(lambda: check(L.x265hip_intra_scan_batch(depth, size, lines.ptr, lo.ptr, fo.ptr, da.ptr, S, d_o.ptr, nblk, costs.ptr, None)), iters=10)
+        # per-call traffic of the reference for the same work: 35 x (intra_pred writes N^2 + sa8d reads 2 N^2)
+        res.append({"kernel": "intra_scan %dx%d x35" % (size, size), "n": nblk * 35, "ms": ms, "GBps": nblk * 35 * 3 * size * size * B / ms / 1e6})
+
     for r in res:
         print("%-22s n=%-7d %8.3f ms  %9.1f GB/s (algorithmic)" % (r["kernel"], r["n"], r["ms"], r["GBps"]))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

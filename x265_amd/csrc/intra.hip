@@ -16,6 +16,7 @@
 //    the 4 refinements never leave the wave.
 #include "common.h"
 #include "internal.h"
+#include "tiles.h"
 
 namespace xh {
 
@@ -368,6 +369,80 @@ __global__ __launch_bounds__(64) void lowres_intra_sums_kernel(const int32_t* __
     }
 }
 
+// ---- intra mode scan: sa8d(source block, prediction of mode m) for all 35 modes of a block -----------------------------------------
+// The distortion half of Search::checkIntraInInter / estIntraPredQT (search.cpp:1344-1420, :1568-1640): DC (edge-smoothed when N <= 16),
+// planar (filtered line when N >= 8), the 33 angles each from the raw or filtered line per g_intraFilterFlags; cost = cu[].sa8d (satd_4x4 for
+// 4x4, sa8d_8x8, one rounding per 16x16 above).  The reference compares horizontal modes transposed (allangs buffer layout, :1388-1391);
+// a 2-D Hadamard magnitude sum is transpose-invariant, so every mode is measured upright here.  Lane = one 4x4 tile whose 16 predicted
+// samples are generated in registers — no prediction buffer exists; an 8x8 Hadamard spans a DPP quad as in pixel.hip.
+template <typename P>
+__global__ __launch_bounds__(256) void intra_scan_kernel(const P* __restrict__ lines, const int32_t* __restrict__ lineOff, const int32_t* __restrict__ filtOff,
+                                                         const P* __restrict__ fenc, int64_t fs, const int32_t* __restrict__ fencOff,
+                                                         int n, int log2n, int depth, long long jobs, int32_t* __restrict__ costs)
+{
+    const int lane = threadIdx.x & 63;
+    const int tiles = (n >> 2) * (n >> 2);
+    const int T = tiles >= 64 ? 64 : tiles;
+    const int jpw = 64 / T, sub = lane & (T - 1);
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long job = wave * jpw + lane / T;
+    const bool ok = job < jobs;
+    const long long jc = ok ? job : jobs - 1;
+    const int b = (int)(jc / 35), mode = (int)(jc % 35);
+    const int maxv = (1 << depth) - 1;
+    const int bFilter = n <= 16;
+    const GlobalLine<P> ln{ lines + (intra_uses_filtered(n, mode) ? filtOff[b] : lineOff[b]), 2 * n };
+    int dc = 0;
+    if (mode == 1)
+    {
+        dc = n;
+        for (int i = 1; i <= n; i++)
+            dc += ln.at(i) + ln.at(-i);
+        dc >>= log2n + 1;
+    }
+    // tile order as in pixel.hip: 16x16 blocks in raster order, inside them 8x8 blocks, inside them the four 4x4 quadrants (one DPP quad)
+    const int n16x = n >= 16 ? (n >> 4) : 1;
+    const int b16 = sub >> 4, b8 = (sub >> 2) & 3, q = sub & 3;
+    int x, y;
+    if (n >= 8)
+    {
+        x = (b16 % n16x) * 16 + (b8 & 1) * 8 + (q & 1) * 4;
+        y = (b16 / n16x) * 16 + (b8 >> 1) * 8 + (q >> 1) * 4;
+        if (n == 8) { x = (q & 1) * 4; y = (q >> 1) * 4; }
+    }
+    else
+        x = y = 0;
+    const P* f = fenc + fencOff[b] + (int64_t)y * fs + x;
+    int m[16];
+#pragma unroll
+    for (int yy = 0; yy < 4; yy++)
+    {
+        int v[4];
+        load4(f + yy * fs, v);
+#pragma unroll
+        for (int xx = 0; xx < 4; xx++)
+            m[4 * yy + xx] = v[xx] - intra_sample(ln, n, log2n, mode, bFilter, x + xx, y + yy, maxv, dc);
+    }
+    hadamard4x4(m);
+    int acc;
+    if (n == 4)
+        acc = abs_sum16(m) >> 1;                              // satd_4x4 (pixel.cpp:210-237), cu[BLOCK_4x4].sa8d alias
+    else
+    {
+        const int raw8 = quad_sa8d_raw(m, lane);
+        if (n >= 16)
+        {
+            const int s16 = group_sum((lane & 3) == 0 ? raw8 : 0, 16);
+            acc = (lane & 15) == 0 ? ((s16 + 2) >> 2) : 0;     // sa8d_16x16: four raw 8x8, one rounding (pixel.cpp:341-350)
+        }
+        else
+            acc = (lane & 3) == 0 ? ((raw8 + 2) >> 2) : 0;     // sa8d_8x8 (pixel.cpp:336)
+        acc = group_sum(acc, T);
+    }
+    if (ok && sub == 0)
+        costs[job] = acc;
+}
+
 static bool valid_intra_size(int n) { return n == 4 || n == 8 || n == 16 || n == 32; }
 static int log2_of(int n) { return n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5; }
 
@@ -425,6 +500,27 @@ int x265hip_intra_filter_batch(int depth, int n, const void* in, const int32_t* 
     else
         hipLaunchKernelGGL((intra_filter_kernel<uint16_t>), grid, block, 0, as_stream(stream), (const uint16_t*)in, inOff, (uint16_t*)out, outOff, n, total);
     XH_LAUNCH_CHECK("intra_filter_kernel");
+    return X265HIP_OK;
+}
+
+int x265hip_intra_scan_batch(int depth, int n, const void* lines, const int32_t* lineOff, const int32_t* filteredOff, const void* fenc,
+                             int64_t fencStride, const int32_t* fencOff, int count, int32_t* costs, void* stream)
+{
+    XH_CHECK_DEV();
+    if (!valid_depth(depth) || !valid_intra_size(n) || count < 0)
+        return set_error(X265HIP_EINVAL, "intra_scan_batch: depth %d size %d count %d", depth, n, count);
+    if (count == 0) return X265HIP_OK;
+    const long long jobs = (long long)count * 35;
+    const int tiles = (n / 4) * (n / 4), T = tiles >= 64 ? 64 : tiles;
+    const long long waves = (jobs + 64 / T - 1) / (64 / T);
+    dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    if (depth == 8)
+        hipLaunchKernelGGL((intra_scan_kernel<uint8_t>), grid, block, 0, as_stream(stream), (const uint8_t*)lines, lineOff, filteredOff, (const uint8_t*)fenc,
+                           fencStride, fencOff, n, log2_of(n), depth, jobs, costs);
+    else
+        hipLaunchKernelGGL((intra_scan_kernel<uint16_t>), grid, block, 0, as_stream(stream), (const uint16_t*)lines, lineOff, filteredOff, (const uint16_t*)fenc,
+                           fencStride, fencOff, n, log2_of(n), depth, jobs, costs);
+    XH_LAUNCH_CHECK("intra_scan_kernel");
     return X265HIP_OK;
 }
 
