@@ -3,6 +3,7 @@
 // BitCost::setQP (bitcost.cpp:32-60) because the MVD cost table is float host math in the reference too.
 #include "common.h"
 #include "internal.h"
+#include <cstdlib>
 #include <cmath>
 #include <vector>
 
@@ -296,8 +297,17 @@ static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t st
         dr.qmvpO = fp->qmvp[l]; dr.mvminO = fp->mvmin[l]; dr.mvmaxO = fp->mvmax[l];
         if (ca && fp->subme > 2)
         {
-            // 4:2:0 picture at subme > 2: every sub-pel comparison carries the chroma SATD term (motion.cpp:212, :1601) -> the generic
-            // kernel with its 4-tap chroma path, search ranges from their own launch
+            // 4:2:0 picture at subme > 2: every sub-pel comparison carries the chroma SATD term (motion.cpp:212, :1601).  8 / 16 / 32 PUs:
+            // the plane-based row-team kernel with an in-register 4-tap chroma path; 64x64: the generic kernel, ranges from their own launch.
+            const ChromaPlanes cpl{ ca->srcCb, ca->srcCr, ca->sS, ca->refCb, ca->refCr, ca->sR, 1 };
+            int rc = X265HIP_OK;
+            static const bool genericChroma = getenv("X265HIP_CHROMA_ME_GENERIC") != nullptr;
+            if (!genericChroma && motion_estimate_fused_chroma(depth, sz, src, strideS, strideR, planesOrigin, fp->planeElems, cpl, fp->puXY[l], dr, fp->merange,
+                                                               fp->method, fp->subme, fp->mvcost + kMvHalf, n, fp->mv[l], fp->cost[l], as_stream(stream), &rc))
+            {
+                FP_TRY(rc);
+                continue;
+            }
             FP_TRY(x265hip_set_search_range_batch(fp->width, fp->height, 64, fp->merange, fp->height, fp->puXY[l], dr.mvSrc, dr.srcIdx, n,
                                                   fp->qmvp[l], fp->mvmin[l], fp->mvmax[l], stream));
             FP_TRY(x265hip_motion_estimate_chroma_batch(depth, sz, sz, src, strideS, ca->srcCb, ca->srcCr, ca->sS, ref, strideR, ca->refCb, ca->refCr,

@@ -316,9 +316,6 @@ __device__ __constant__ const int8_t kSquare1[9][2] = { {0,0}, {0,-1}, {0,1}, {-
 // motion.cpp:48-58 workload[subme] = { hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd }
 __device__ __constant__ const uint8_t kWorkload[8][5] = { {1,4,0,4,0}, {1,4,1,4,0}, {1,4,1,4,1}, {2,4,1,4,1}, {2,4,2,4,1}, {1,8,1,8,1}, {2,8,1,8,1}, {2,8,2,8,1} };
 
-// bChromaSATD inputs (4:2:0): source and reference chroma planes at the picture origin
-struct ChromaPlanes { const void* fencCb; const void* fencCr; int64_t strideFC; const void* refCb; const void* refCr; int64_t strideRC; int enable; };
-
 template <typename P>
 __global__ __launch_bounds__(256) void motion_kernel(const P* __restrict__ fencPlane, int64_t strideF,
                                                      const P* __restrict__ refPlane, int64_t strideR,

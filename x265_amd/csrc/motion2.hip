@@ -839,7 +839,7 @@ static int launch_motion2(const void* fencPlane, int64_t strideF, const void* re
 int motion3_dispatch(int depth, int size, const void* fencPlane, int64_t strideF, int64_t strideR, const int32_t* pu_xy,
                      const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp, int numCand, const int32_t* mvc, int merange,
                      int method, int subme, const uint16_t* mvcost, int n, const void* planes, int64_t planeElems, const DeriveRange* drp,
-                     int32_t* outMv, int32_t* outCost, hipStream_t st, int* rc);
+                     int32_t* outMv, int32_t* outCost, hipStream_t st, int* rc, const ChromaPlanes* cpp = nullptr);
 
 // returns 1 when the shape is handled here, 0 when the caller should use the generic kernel of motion.hip
 int motion2_dispatch(int depth, int w, int h, const void* fencPlane, int64_t strideF, const void* refPlane, int64_t strideR,
@@ -880,6 +880,16 @@ int motion_estimate_fused(int depth, int size, const void* fencPlane, int64_t st
                           method, subme, mvcost, n, planes, planeElems, outMv, outCost, st, &rc, &dr))
         return set_error(X265HIP_EINVAL, "motion_estimate_fused: PU size %d is not a team-kernel shape", size);
     return rc;
+}
+
+int motion_estimate_fused_chroma(int depth, int size, const void* fencPlane, int64_t strideF, int64_t strideR, const void* planes, int64_t planeElems,
+                                 const ChromaPlanes& cp, const int32_t* pu_xy, const DeriveRange& dr, int merange, int method, int subme,
+                                 const uint16_t* mvcost, int n, int32_t* outMv, int32_t* outCost, hipStream_t st, int* rc)
+{
+    *rc = X265HIP_OK;
+    if (!n) return 1;
+    return motion3_dispatch(depth, size, fencPlane, strideF, strideR, pu_xy, dr.mvminO, dr.mvmaxO, dr.qmvpO, 0, nullptr, merange, method, subme,
+                            mvcost, n, planes, planeElems, &dr, outMv, outCost, st, rc, &cp);
 }
 
 } // namespace xh

@@ -15,6 +15,7 @@
 #include "common.h"
 #include "searchrange.h"
 #include "mestar.h"
+#include "filters.h"
 
 namespace xh {
 
@@ -71,7 +72,7 @@ __device__ __forceinline__ int team_allsum(int v)
     return v;
 }
 
-template <typename P, int N, int TEAM>
+template <typename P, int N, int TEAM, bool CHROMA = false>
 struct RowTeam
 {
     typedef typename Pk3<P>::T Q;
@@ -86,6 +87,13 @@ struct RowTeam
     int qoff[IPT];                                     // element offset of this lane's quads inside the PU (row * stride + col)
     Q fq[IPT];
     int fu[IPT][4];
+    // bChromaSATD (4:2:0): the chroma block is (N/2)^2 per plane = N*N/16 quads; a lane holds one quad per pass.  8x8 PUs put Cb in
+    // lanes 0-3 and Cr in lanes 4-7 of one pass, 16x16 / 32x32 PUs take one pass per plane with every lane busy.
+    static constexpr int CPASS = N == 8 ? 1 : 2;
+    const P* cref[CPASS];                               // reference chroma plane at this lane's quad (mv (0,0))
+    int strideC, depth;
+    int fuc[CPASS][4];
+    bool cact;                                          // lane takes part in the chroma term
 
     __device__ __forceinline__ int mvcost(int qx, int qy) const { return (int)(uint16_t)(cost[qx - qmvp.x] + cost[qy - qmvp.y]); }
 
@@ -134,6 +142,73 @@ struct RowTeam
         // every tile's |H D H^T| sum is even (pixel.hip), so one >> 1 over the block equals the per-tile >> 1 of pixel.cpp:235
         return team_allsum<TEAM>(acc) >> 1;
     }
+    // one quad of the chroma prediction at eighth-pel vector (mvx, mvy): 4-tap H to the 14-bit intermediate, 4-tap V back to pixels.
+    // This hv form reproduces the reference's four cases exactly (copy / filter_hpp / filter_vpp / filter_hps + filter_vsp,
+    // motion.cpp:1618-1658): with a zero fraction the filter is {0, 64, 0, 0}, the intermediate is 64 p - offset without loss, and
+    // (64 (S >> s1) + round) >> s2 == (S + 32) >> 6 because s1 + s2 = 12 and the inner floor nests inside the outer one.
+    __device__ __forceinline__ void chroma_quad(const P* r, int mvx, int mvy, int out[4]) const
+    {
+        const int xF = mvx & 7, yF = mvy & 7;
+        const P* base = r + (mvy >> 3) * strideC + (mvx >> 3);
+        const Stage s1 = stage_for(IF_HPS, depth), s2 = stage_for(IF_VSP, depth);
+        int c1[4], c2[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { c1[i] = kChromaFilter[xF][i]; c2[i] = kChromaFilter[yF][i]; }
+        int sum[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            int v[8];
+            const P* row = base + (k - 1) * strideC - 1;
+            load4(row, v);
+            load4(row + 4, v + 4);
+#pragma unroll
+            for (int o = 0; o < 4; o++)
+            {
+                const int h = finish(v[o] * c1[0] + v[o + 1] * c1[1] + v[o + 2] * c1[2] + v[o + 3] * c1[3], s1);
+                sum[o] += h * c2[k];
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; o++) out[o] = finish(sum[o], s2);
+    }
+    // SATD of the Cb and Cr blocks predicted at quarter-pel luma vector q (= eighth-pel chroma), the chroma part of subpelCompare
+    __device__ __forceinline__ int chroma_term(Mv3 q) const
+    {
+        const bool hi1 = s & 1, hi2 = s & 2;
+        int acc = 0;
+#pragma unroll
+        for (int ps = 0; ps < CPASS; ps++)
+        {
+            int p[4];
+            chroma_quad(cref[ps], q.x, q.y, p);
+            const int d0 = fuc[ps][0] - p[0], d1 = fuc[ps][1] - p[1], d2 = fuc[ps][2] - p[2], d3 = fuc[ps][3] - p[3];
+            const int s01 = d0 + d1, e01 = d0 - d1, s23 = d2 + d3, e23 = d2 - d3;
+            int m[4] = { s01 + s23, s01 - s23, e01 + e23, e01 - e23 };
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                const int pr = __builtin_amdgcn_mov_dpp(m[i], 0xB1, 0xF, 0xF, true);
+                m[i] = hi1 ? pr - m[i] : m[i] + pr;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                const int pr = __builtin_amdgcn_mov_dpp(m[i], 0x4E, 0xF, 0xF, true);
+                m[i] = hi2 ? pr - m[i] : m[i] + pr;
+            }
+            const int a = iabs(m[0]) + iabs(m[1]) + iabs(m[2]) + iabs(m[3]);
+            acc += cact ? a : 0;
+        }
+        return team_allsum<TEAM>(acc) >> 1;                 // every 4x4 tile sum is even: one shift equals the per-tile >> 1 of satd_4x4
+    }
+    // MotionEstimate::subpelCompare: luma sad / satd + (bChromaSATD) the chroma SATD term
+    __device__ __forceinline__ int sub_q(Mv3 q, int satd) const
+    {
+        const int v = satd ? satd_q(q) : sad_q(q);
+        return CHROMA ? v + chroma_term(q) : v;
+    }
+
     // mestar.h contract: K full-pel points measured together (all their loads in flight before the first reduction)
     template <int K>
     __device__ __forceinline__ void fullpel_costs(const int (&mx)[K], const int (&my)[K], int (&out)[K]) const
@@ -171,16 +246,16 @@ __device__ __forceinline__ Mv3 mv_clip3(Mv3 v, Mv3 lo, Mv3 hi)
 __device__ __forceinline__ bool mv_in3(Mv3 v, Mv3 lo, Mv3 hi) { return v.x >= lo.x && v.x <= hi.x && v.y >= lo.y && v.y <= hi.y; }
 __device__ __forceinline__ int sext2c(int v) { return (v & 2) ? (v | ~3) : v; }
 
-template <typename P, int N, int TEAM>
+template <typename P, int N, int TEAM, bool CHROMA>
 __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fencPlane, int64_t strideF, int64_t strideR,
                                                       const int32_t* __restrict__ pu_xy, const int32_t* __restrict__ mvminA,
                                                       const int32_t* __restrict__ mvmaxA, const int32_t* __restrict__ qmvpA,
                                                       int numCand, const int32_t* __restrict__ mvcA, int merange, int method, int subme,
                                                       const uint16_t* __restrict__ mvcostTab, int n,
                                                       const P* __restrict__ planes, int64_t planeElems, DeriveRange dr,
-                                                      int32_t* __restrict__ outMv, int32_t* __restrict__ outCost)
+                                                      int32_t* __restrict__ outMv, int32_t* __restrict__ outCost, ChromaPlanes cp, int depth)
 {
-    typedef RowTeam<P, N, TEAM> RT;
+    typedef RowTeam<P, N, TEAM, CHROMA> RT;
     typedef typename RT::Q Q;
     constexpr int TPB = 256 / TEAM;                         // PUs per workgroup
     RT c;
@@ -233,6 +308,26 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
             Pk3<P>::unpack(c.fq[j], c.fu[j]);
         }
     }
+    if (CHROMA)
+    {
+        c.strideC = (int)cp.strideRC;
+        c.depth = depth;
+        constexpr int TXC = N / 8;                              // 4x4 tiles per row of the chroma block
+        const int t = c.s >> 2, r = c.s & 3;
+        const int cbx = bx >> 1, cby = by >> 1;
+#pragma unroll
+        for (int ps = 0; ps < RT::CPASS; ps++)
+        {
+            // 8x8 PU: tile 0 = Cb, tile 1 = Cr, tiles 2-3 idle; larger PUs: pass 0 = Cb, pass 1 = Cr, tile t of the plane
+            const int plane = N == 8 ? (t & 1) : ps;
+            const int tt = N == 8 ? 0 : t;
+            const int row = (tt / TXC) * 4 + r, col = (tt % TXC) * 4;
+            const P* fc = (const P*)(plane ? cp.fencCr : cp.fencCb) + (int64_t)(cby + row) * cp.strideFC + cbx + col;
+            load4(fc, c.fuc[ps]);
+            c.cref[ps] = (const P*)(plane ? cp.refCr : cp.refCb) + (int64_t)(cby + row) * cp.strideRC + cbx + col;
+        }
+        c.cact = N == 8 ? (t < 2) : true;
+    }
 
 #define YOK(yy) (((yy) >= mvmin.y) & ((yy) <= mvmax.y))
 #define LT1(v) do { const int v_ = (v); if (v_ < bcost) bcost = v_; } while (0)
@@ -240,7 +335,7 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
     // ---- predictor, zero and candidates (motion.cpp:761-812)
     const Mv3 pmv = mv_clip3(qmvp, qmvmin, qmvmax);
     Mv3 bestpre = pmv;
-    int bprecost = c.sad_q(pmv);
+    int bprecost = c.sub_q(pmv, 0);
     Mv3 bmv = { (pmv.x + 2) >> 2, (pmv.y + 2) >> 2 };
     int bcost = bprecost;
     if ((pmv.x & 3) | (pmv.y & 3))
@@ -261,7 +356,7 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
         const Mv3 m = mv_clip3(raw, qmvmin, qmvmax);
         if ((m.x | m.y) && !(m.x == pmv.x && m.y == pmv.y) && !(m.x == bestpre.x && m.y == bestpre.y))
         {
-            const int cst = c.sad_q(m) + c.mvcost(m.x, m.y);
+            const int cst = c.sub_q(m, 0) + c.mvcost(m.x, m.y);
             if (cst < bprecost)
             {
                 bprecost = cst;
@@ -395,7 +490,7 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
         int hpelcomp = 0;
         if (hpelSatd)
         {
-            bcost = c.satd_q(bmv) + c.mvcost(bmv.x, bmv.y);
+            bcost = c.sub_q(bmv, 1) + c.mvcost(bmv.x, bmv.y);
             hpelcomp = 1;
         }
         for (int iter = 0; iter < hpelIters; iter++)
@@ -406,7 +501,7 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
                 const Mv3 q = { bmv.x + sq1xC(i) * 2, bmv.y + sq1yC(i) * 2 };
                 if ((q.y < qmvmin.y) | (q.y > qmvmax.y))
                     continue;
-                const int cst = c.cmp_q(q, hpelcomp) + c.mvcost(q.x, q.y);
+                const int cst = c.sub_q(q, hpelcomp) + c.mvcost(q.x, q.y);
                 if (cst < bcost) { bcost = cst; bdir = i; }
             }
             if (bdir)
@@ -418,7 +513,7 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
                 break;
         }
         if (!hpelSatd)
-            bcost = c.satd_q(bmv) + c.mvcost(bmv.x, bmv.y);
+            bcost = c.sub_q(bmv, 1) + c.mvcost(bmv.x, bmv.y);
         for (int iter = 0; iter < qpelIters; iter++)
         {
             int bdir = 0;
@@ -427,7 +522,7 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
                 const Mv3 q = { bmv.x + sq1xC(i), bmv.y + sq1yC(i) };
                 if ((q.y < qmvmin.y) | (q.y > qmvmax.y))
                     continue;
-                const int cst = c.satd_q(q) + c.mvcost(q.x, q.y);
+                const int cst = c.sub_q(q, 1) + c.mvcost(q.x, q.y);
                 if (cst < bcost) { bcost = cst; bdir = i; }
             }
             if (bdir)
@@ -454,7 +549,7 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
 int motion3_dispatch(int depth, int size, const void* fencPlane, int64_t strideF, int64_t strideR, const int32_t* pu_xy,
                      const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp, int numCand, const int32_t* mvc, int merange,
                      int method, int subme, const uint16_t* mvcost, int n, const void* planes, int64_t planeElems, const DeriveRange* drp,
-                     int32_t* outMv, int32_t* outCost, hipStream_t st, int* rc)
+                     int32_t* outMv, int32_t* outCost, hipStream_t st, int* rc, const ChromaPlanes* cpp)
 {
     // 64x64 stays on the 4-wave team kernel of motion2.hip: one wave per 64x64 PU measured slower (58 vs 38 us per level)
     if (!planes || (size != 8 && size != 16 && size != 32) || strideR > 0x3fffffff)
@@ -464,10 +559,15 @@ int motion3_dispatch(int depth, int size, const void* fencPlane, int64_t strideF
     const int tpb = size <= 16 ? 16 : 4;                     // 16-lane teams for 8x8 / 16x16, one wave per PU for 32x32 / 64x64
     const int blocks = (((n + tpb - 1) / tpb) + 7) & ~7;
     dim3 grid(blocks), block(256);
-#define M3(P, N, TEAM) hipLaunchKernelGGL((motion3_kernel<P, N, TEAM>), grid, block, 0, st, (const P*)fencPlane, strideF, strideR, pu_xy, mvmin, mvmax, qmvp, \
-                                    numCand, mvc, merange, method, subme, mvcost, n, (const P*)planes, planeElems, dr, outMv, outCost)
-    if (depth == 8) { if (size == 8) M3(uint8_t, 8, 16); else if (size == 16) M3(uint8_t, 16, 16); else if (size == 32) M3(uint8_t, 32, 64); else M3(uint8_t, 64, 64); }
-    else            { if (size == 8) M3(uint16_t, 8, 16); else if (size == 16) M3(uint16_t, 16, 16); else if (size == 32) M3(uint16_t, 32, 64); else M3(uint16_t, 64, 64); }
+    ChromaPlanes cpn{};
+    const bool chroma = cpp && cpp->enable;
+    if (chroma) cpn = *cpp;
+#define M3C(P, N, TEAM, CH) hipLaunchKernelGGL((motion3_kernel<P, N, TEAM, CH>), grid, block, 0, st, (const P*)fencPlane, strideF, strideR, pu_xy, mvmin, mvmax, qmvp, \
+                                    numCand, mvc, merange, method, subme, mvcost, n, (const P*)planes, planeElems, dr, outMv, outCost, cpn, depth)
+#define M3(P, N, TEAM) do { if (chroma) M3C(P, N, TEAM, true); else M3C(P, N, TEAM, false); } while (0)
+    if (depth == 8) { if (size == 8) M3(uint8_t, 8, 16); else if (size == 16) M3(uint8_t, 16, 16); else M3(uint8_t, 32, 64); }
+    else            { if (size == 8) M3(uint16_t, 8, 16); else if (size == 16) M3(uint16_t, 16, 16); else M3(uint16_t, 32, 64); }
+#undef M3C
 #undef M3
     hipError_t e = hipGetLastError();
     *rc = e == hipSuccess ? X265HIP_OK : check_hip(e, "motion3_kernel");

@@ -37,6 +37,15 @@ struct DeriveRange
     int32_t *qmvpO, *mvminO, *mvmaxO;       // also written, so the arrays hold what the separate entry point would produce
 };
 
+// bChromaSATD inputs (4:2:0): source and reference chroma planes at the picture origin (motion.cpp:212, :1601-1660)
+struct ChromaPlanes { const void* fencCb; const void* fencCr; int64_t strideFC; const void* refCb; const void* refCr; int64_t strideRC; int enable; };
+
+// the same with the chroma SATD term on every sub-pel comparison: 8x8 / 16x16 / 32x32 PUs on the plane-based row-team kernel.
+// Returns 1 when handled (rc = status), 0 when the caller must use the generic path.
+int motion_estimate_fused_chroma(int depth, int size, const void* fencPlane, int64_t strideF, int64_t strideR, const void* planes, int64_t planeElems,
+                                 const ChromaPlanes& cp, const int32_t* pu_xy, const DeriveRange& dr, int merange, int method, int subme,
+                                 const uint16_t* mvcost, int n, int32_t* outMv, int32_t* outCost, hipStream_t st, int* rc);
+
 // internal (framepass.hip): x265hip_set_search_range_batch + x265hip_motion_estimate_planes_batch in ONE launch, square PUs only
 int motion_estimate_fused(int depth, int size, const void* fencPlane, int64_t strideF, const void* refPlane, int64_t strideR,
                           const void* planes, int64_t planeElems, const int32_t* pu_xy, const DeriveRange& dr, int merange, int method,
