@@ -100,6 +100,24 @@ def pmc_traffic(stage):
     return None, None
 
 
+def valu_per_frame():
+    """VALU wave-instructions of one frame pass = sum over its kernels of SQ_INSTS_VALU per launch, from the committed rocprofv3 SQ pass
+    (profiles/r*_pmc_sq.txt; every kernel of the pass is launched once per frame).  None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.txt")))
+    if not files:
+        return None, None
+    total = 0
+    for line in open(files[-1]):
+        if line.startswith("#") or "{" not in line:
+            continue
+        try:
+            total += json.loads(line[line.index("{"):])["SQ_INSTS_VALU"]
+        except (ValueError, KeyError):
+            continue
+    return (total or None), os.path.relpath(files[-1], ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -304,6 +322,14 @@ def main():
             kernel = dom
         achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(dom)
+        # second roofline that actually binds at F frames in flight: VALU issue.  256 CUs x 4 SIMDs, one wave64 VALU instruction per
+        # 4 cycles per SIMD, 2.4 GHz (MI355X_MICROARCH.md) = 614 G wave-instructions / s.
+        vpf, vsrc = valu_per_frame()
+        valu = None
+        if vpf:
+            peak = 256 * 4 / 4 * 2.4e9
+            valu = {"wave_instr_per_frame": vpf, "source": vsrc, "peak_wave_instr_per_s": peak, "achieved_wave_instr_per_s": round(vpf * fps),
+                    "frac": round(vpf * fps / peak, 4)}
         out = {
             "metric": "encode fps (1080p preset medium hot path: frame passes per second)", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -316,6 +342,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": stage_ms[dom], "unique_footprint": unique},
+            "valu_issue": valu,
             "stage_ms": stage_ms, "host_enqueue_ms_per_step": round(host_dt * 1e3 / args.steps, 4),
         }
         if world == 1 and args.cpu_frames > 0:
