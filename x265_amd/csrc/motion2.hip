@@ -190,7 +190,7 @@ __device__ __forceinline__ int sq1xB(int i) { return (int)((0x997797888ull >> (4
 __device__ __forceinline__ int sq1yB(int i) { return (int)((0x979788978ull >> (4 * i)) & 15) - 8; }     // {0,-1,1,0,0,-1,1,-1,1}
 
 // ---- the team context ------------------------------------------------------------------------------------------------------
-template <typename P, int N, int WAVES, bool PLANES>
+template <typename P, int N, int WAVES, bool PLANES, bool CHROMA = false>
 struct Team
 {
     typedef typename Pk<P>::T Q;
@@ -212,6 +212,27 @@ struct Team
     int* part;                      // LDS [2][8][WAVES] team partial sums (WAVES > 1)
     int phase;                      // alternates the partial buffer
     Q fq[IPT];                      // this thread's quads of the source block
+    // bChromaSATD (64x64 PU, 4:2:0): the 32x32 chroma block of a plane is 256 quads = one per thread; tile-major (4 threads = 4 rows of a tile)
+    const P* cref[2];
+    int strideC;
+    int fuc[2][4];
+
+    // the chroma part of subpelCompare (motion.cpp:1601-1660): SATD of the Cb and Cr blocks predicted at vector q, over the team
+    __device__ __forceinline__ int chroma_cost(Mv2 q)
+    {
+        int acc = 0;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+        {
+            int p[4];
+            chroma_quad_hv(cref[j], strideC, q.x, q.y, depth, p);
+            const int d[4] = { fuc[j][0] - p[0], fuc[j][1] - p[1], fuc[j][2] - p[2], fuc[j][3] - p[3] };
+            acc += quad_row_hadamard_abs(d, lane & 1, lane & 2);
+        }
+        int v[1] = { wave64_sum_l63(acc) };
+        team_combine<1>(v);
+        return v[0] >> 1;                               // every tile sum is even (pixel.hip): one shift = the per-tile >> 1 of satd_4x4
+    }
 
     __device__ __forceinline__ void team_barrier() const { if (WAVES > 1) __syncthreads(); }
 
@@ -460,7 +481,7 @@ struct Team
     }
 };
 
-template <typename P, int N, int WAVES, bool PLANES>
+template <typename P, int N, int WAVES, bool PLANES, bool CHROMA = false>
 __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __restrict__ fencPlane, int64_t strideF,
                                                              const P* __restrict__ refPlane, int64_t strideR,
                                                              const int32_t* __restrict__ pu_xy, const int32_t* __restrict__ mvminA,
@@ -468,9 +489,10 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
                                                              int numCand, const int32_t* __restrict__ mvcA, int merange, int method, int subme,
                                                              const uint16_t* __restrict__ mvcostTab, int depth, int n,
                                                              const P* __restrict__ planes, int64_t planeElems, DeriveRange dr,
-                                                             int32_t* __restrict__ outMv, int32_t* __restrict__ outCost)
+                                                             int32_t* __restrict__ outMv, int32_t* __restrict__ outCost, ChromaPlanes cp)
 {
-    typedef Team<P, N, WAVES, PLANES> TM;
+    static_assert(!CHROMA || (N == 64 && WAVES == 4 && PLANES), "the chroma SATD term lives in the 64x64 team configuration (smaller PUs: motion3.hip)");
+    typedef Team<P, N, WAVES, PLANES, CHROMA> TM;
     typedef typename TM::Q Q;
     constexpr int TPB = (WAVES > 1) ? 1 : 4;                           // teams per workgroup
     __shared__ __attribute__((aligned(16))) P fencS[TPB][N * N];
@@ -537,6 +559,18 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
                     *reinterpret_cast<Q*>(c.fencL + row * N + c4) = c.fq[j];
             }
         }
+        if (CHROMA)
+        {
+            const int t = c.tid >> 2, r = c.tid & 3;                    // 64 tiles of the 32x32 chroma block, 4 threads = the 4 rows of a tile
+            const int row = (t >> 3) * 4 + r, col = (t & 7) * 4;
+            const int64_t offF = (int64_t)((by >> 1) + row) * cp.strideFC + (bx >> 1) + col;
+            const int64_t offR = (int64_t)((by >> 1) + row) * cp.strideRC + (bx >> 1) + col;
+            c.strideC = (int)cp.strideRC;
+            load4((const P*)cp.fencCb + offF, c.fuc[0]);
+            load4((const P*)cp.fencCr + offF, c.fuc[1]);
+            c.cref[0] = (const P*)cp.refCb + offR;
+            c.cref[1] = (const P*)cp.refCr + offR;
+        }
         if (WAVES > 1)
             __syncthreads();
         else
@@ -560,6 +594,7 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
             int cs[3];
             c.template eval_sad<3, true>(q3, cs);
             bprecost = cs[0] - c.mvcost(pmv.x, pmv.y);
+            if (CHROMA) bprecost += c.chroma_cost(pmv);
             bcost = bprecost;
             if ((pmv.x & 3) | (pmv.y & 3))
                 bcost = cs[1];
@@ -593,7 +628,8 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
             const Mv2 m = mv_clip2(raw, qmvmin, qmvmax);
             if ((m.x | m.y) && !(m.x == pmv.x && m.y == pmv.y) && !(m.x == bestpre.x && m.y == bestpre.y))
             {
-                const int cst = c.subpel_one(m, 0);
+                int cst = c.subpel_one(m, 0);
+                if (CHROMA) cst += c.chroma_cost(m);
                 if (cst < bprecost)
                 {
                     bprecost = cst;
@@ -755,6 +791,12 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
                         ok[k + 1] = !((q[k + 1].y < qmvmin.y) | (q[k + 1].y > qmvmax.y));
                     }
                     c.template eval_subpel<5>(q, ok, 1, cs);
+                    if (CHROMA)
+                    {
+#pragma unroll
+                        for (int k = 0; k < 5; k++)
+                            if (ok[k]) cs[k] += c.chroma_cost(q[k]);
+                    }
                     bcost = cs[0];
                     int bdir = 0;
 #pragma unroll
@@ -770,7 +812,10 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
                         hpelcomp = 3;                   // satd + "first iteration found nothing: stop half-pel iterations"
                 }
                 else
+                {
                     bcost = c.subpel_one(bmv, 1);
+                    if (CHROMA) bcost += c.chroma_cost(bmv);
+                }
             }
 #define REFINE(ITERS, DIRS, STEP, CMP) \
             for (int iter = 0; iter < (ITERS); iter++) \
@@ -785,6 +830,7 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
                         ok[k] = !((q[k].y < qmvmin.y) | (q[k].y > qmvmax.y)); \
                     } \
                     c.template eval_subpel<4>(q, ok, (CMP), cs); \
+                    if (CHROMA) { _Pragma("unroll") for (int k = 0; k < 4; k++) if (ok[k]) cs[k] += c.chroma_cost(q[k]); } \
                     _Pragma("unroll") for (int k = 0; k < 4; k++) \
                         if (ok[k] && cs[k] < bcost) { bcost = cs[k]; bdir = d0 + k; } \
                 } \
@@ -802,7 +848,10 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
                 REFINE(itersLeft, hpelDirs, 2, cmpH)
             }
             if (!hpelSatd)
+            {
                 bcost = c.subpel_one(bmv, 1);
+                if (CHROMA) bcost += c.chroma_cost(bmv);
+            }
             REFINE(qpelIters, qpelDirs, 1, 1)
 #undef REFINE
         }
@@ -828,11 +877,25 @@ static int launch_motion2(const void* fencPlane, int64_t strideF, const void* re
     dim3 grid(blocks), block(64 * (WAVES > 1 ? WAVES : 4));
     if (planes)
         hipLaunchKernelGGL((motion2_kernel<P, N, WAVES, true>), grid, block, 0, st, (const P*)fencPlane, strideF, (const P*)refPlane, strideR, pu_xy,
-                           mvmin, mvmax, qmvp, numCand, mvc, merange, method, subme, mvcost, depth, n, (const P*)planes, planeElems, dr, outMv, outCost);
+                           mvmin, mvmax, qmvp, numCand, mvc, merange, method, subme, mvcost, depth, n, (const P*)planes, planeElems, dr, outMv, outCost, ChromaPlanes{});
     else
         hipLaunchKernelGGL((motion2_kernel<P, N, WAVES, false>), grid, block, 0, st, (const P*)fencPlane, strideF, (const P*)refPlane, strideR, pu_xy,
-                           mvmin, mvmax, qmvp, numCand, mvc, merange, method, subme, mvcost, depth, n, (const P*)planes, planeElems, dr, outMv, outCost);
+                           mvmin, mvmax, qmvp, numCand, mvc, merange, method, subme, mvcost, depth, n, (const P*)planes, planeElems, dr, outMv, outCost, ChromaPlanes{});
     XH_LAUNCH_CHECK("motion2_kernel");
+    return X265HIP_OK;
+}
+
+// 64x64 PUs with the chroma SATD term (bChromaSATD): the 4-wave team kernel on planes
+template <typename P>
+static int launch_motion2_chroma64(const void* fencPlane, int64_t strideF, int64_t strideR, const int32_t* pu_xy, int merange, int method, int subme,
+                                   const uint16_t* mvcost, int depth, int n, const void* planes, int64_t planeElems, const DeriveRange& dr,
+                                   const ChromaPlanes& cp, int32_t* outMv, int32_t* outCost, hipStream_t st)
+{
+    const int blocks = (grid_for(n, 256 * 32) + 7) & ~7;
+    hipLaunchKernelGGL((motion2_kernel<P, 64, 4, true, true>), dim3(blocks), dim3(256), 0, st, (const P*)fencPlane, strideF, (const P*)planes, strideR, pu_xy,
+                       dr.mvminO, dr.mvmaxO, dr.qmvpO, 0, (const int32_t*)nullptr, merange, method, subme, mvcost, depth, n, (const P*)planes, planeElems, dr,
+                       outMv, outCost, cp);
+    XH_LAUNCH_CHECK("motion2_kernel(chroma)");
     return X265HIP_OK;
 }
 
@@ -888,6 +951,14 @@ int motion_estimate_fused_chroma(int depth, int size, const void* fencPlane, int
 {
     *rc = X265HIP_OK;
     if (!n) return 1;
+    if (size == 64 && planes && dr.enable)
+    {
+        *rc = depth == 8 ? launch_motion2_chroma64<uint8_t>(fencPlane, strideF, strideR, pu_xy, merange, method, subme, mvcost, depth, n, planes, planeElems, dr, cp,
+                                                            outMv, outCost, st)
+                         : launch_motion2_chroma64<uint16_t>(fencPlane, strideF, strideR, pu_xy, merange, method, subme, mvcost, depth, n, planes, planeElems, dr, cp,
+                                                             outMv, outCost, st);
+        return 1;
+    }
     return motion3_dispatch(depth, size, fencPlane, strideF, strideR, pu_xy, dr.mvminO, dr.mvmaxO, dr.qmvpO, 0, nullptr, merange, method, subme,
                             mvcost, n, planes, planeElems, &dr, outMv, outCost, st, rc, &cp);
 }

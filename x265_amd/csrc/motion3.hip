@@ -142,36 +142,6 @@ struct RowTeam
         // every tile's |H D H^T| sum is even (pixel.hip), so one >> 1 over the block equals the per-tile >> 1 of pixel.cpp:235
         return team_allsum<TEAM>(acc) >> 1;
     }
-    // one quad of the chroma prediction at eighth-pel vector (mvx, mvy): 4-tap H to the 14-bit intermediate, 4-tap V back to pixels.
-    // This hv form reproduces the reference's four cases exactly (copy / filter_hpp / filter_vpp / filter_hps + filter_vsp,
-    // motion.cpp:1618-1658): with a zero fraction the filter is {0, 64, 0, 0}, the intermediate is 64 p - offset without loss, and
-    // (64 (S >> s1) + round) >> s2 == (S + 32) >> 6 because s1 + s2 = 12 and the inner floor nests inside the outer one.
-    __device__ __forceinline__ void chroma_quad(const P* r, int mvx, int mvy, int out[4]) const
-    {
-        const int xF = mvx & 7, yF = mvy & 7;
-        const P* base = r + (mvy >> 3) * strideC + (mvx >> 3);
-        const Stage s1 = stage_for(IF_HPS, depth), s2 = stage_for(IF_VSP, depth);
-        int c1[4], c2[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) { c1[i] = kChromaFilter[xF][i]; c2[i] = kChromaFilter[yF][i]; }
-        int sum[4] = { 0, 0, 0, 0 };
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-        {
-            int v[8];
-            const P* row = base + (k - 1) * strideC - 1;
-            load4(row, v);
-            load4(row + 4, v + 4);
-#pragma unroll
-            for (int o = 0; o < 4; o++)
-            {
-                const int h = finish(v[o] * c1[0] + v[o + 1] * c1[1] + v[o + 2] * c1[2] + v[o + 3] * c1[3], s1);
-                sum[o] += h * c2[k];
-            }
-        }
-#pragma unroll
-        for (int o = 0; o < 4; o++) out[o] = finish(sum[o], s2);
-    }
     // SATD of the Cb and Cr blocks predicted at quarter-pel luma vector q (= eighth-pel chroma), the chroma part of subpelCompare
     __device__ __forceinline__ int chroma_term(Mv3 q) const
     {
@@ -181,23 +151,9 @@ struct RowTeam
         for (int ps = 0; ps < CPASS; ps++)
         {
             int p[4];
-            chroma_quad(cref[ps], q.x, q.y, p);
-            const int d0 = fuc[ps][0] - p[0], d1 = fuc[ps][1] - p[1], d2 = fuc[ps][2] - p[2], d3 = fuc[ps][3] - p[3];
-            const int s01 = d0 + d1, e01 = d0 - d1, s23 = d2 + d3, e23 = d2 - d3;
-            int m[4] = { s01 + s23, s01 - s23, e01 + e23, e01 - e23 };
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-            {
-                const int pr = __builtin_amdgcn_mov_dpp(m[i], 0xB1, 0xF, 0xF, true);
-                m[i] = hi1 ? pr - m[i] : m[i] + pr;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-            {
-                const int pr = __builtin_amdgcn_mov_dpp(m[i], 0x4E, 0xF, 0xF, true);
-                m[i] = hi2 ? pr - m[i] : m[i] + pr;
-            }
-            const int a = iabs(m[0]) + iabs(m[1]) + iabs(m[2]) + iabs(m[3]);
+            chroma_quad_hv(cref[ps], strideC, q.x, q.y, depth, p);
+            const int d[4] = { fuc[ps][0] - p[0], fuc[ps][1] - p[1], fuc[ps][2] - p[2], fuc[ps][3] - p[3] };
+            const int a = quad_row_hadamard_abs(d, hi1, hi2);
             acc += cact ? a : 0;
         }
         return team_allsum<TEAM>(acc) >> 1;                 // every 4x4 tile sum is even: one shift equals the per-tile >> 1 of satd_4x4
