@@ -541,7 +541,7 @@ def test_chroma_motion_estimate_matches_oracle(hipmod, depth):
         assert (int(cost[i]), int(mv[i, 0]), int(mv[i, 1])) == (c, v[0], v[1]), i
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", [8, 10, 12])
 def test_lookahead_p_cost_matches_oracle(hipmod, depth):
     """The lookahead's P-frame cost pass (lowres init -> intra estimate -> estimateCUCost over the frame) on the GPU vs the
     restatement: every block's vector, cost, packed lowresCost, the row sums, the frame score and the intra count; serial and
@@ -568,7 +568,7 @@ def test_lookahead_p_cost_matches_oracle(hipmod, depth):
             assert same(x, y), (i, k)
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", [8, 10, 12])
 def test_lookahead_b_cost_matches_oracle(hipmod, depth):
     """B-frame cost pass: both list searches with the skip rule in one launch (or list 0 reused from the P estimate), then the
     bidir / co-located candidates — vectors and costs of both lists, packed lowresCosts, row sums, frame score."""
