@@ -239,6 +239,8 @@ def main():
         if state["last"] is not None:
             if streams[0] is not None:
                 cur.wait_event(done[F - 1][(k - 1) & 1])         # the picture to hand over is complete
+                if k >= 2:
+                    cur.wait_event(done[0][k & 1])               # chain 0 of step k-2 has finished reading the inbox being refilled
             ring.begin(state["last"])
         for j in range(1, F):
             launch(j, k, recs)
