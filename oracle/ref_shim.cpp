@@ -18,6 +18,8 @@
 #include "x265.h"
 #include "picyuv.h"
 #include "slicetype.h"
+#include "predict.h"
+#include "shortyuv.h"
 
 using namespace X265_NS;
 
@@ -502,6 +504,50 @@ int64_t ref_lookahead_cost_b(pixel* pic0, pixel* pic1, pixel* pic2, intptr_t str
     }
     x265_param_free(param);
     return ret;
+}
+
+/* ---- the real bi-predictive motion compensation pieces: Predict::predInterLumaShort / predInterChromaShort (common/predict.cpp:268, :364)
+ * for both references and Yuv::addAvg (common/yuv.cpp:189), i.e. what Predict::motionCompensation does for an unweighted bi-predicted PU
+ * (:131-199).  One-entry offset tables place the PU at (bx, by) of caller-owned planes, as in ref_motion_estimate_chroma. */
+void ref_pred_inter_bi(pixel* r0y, pixel* r0cb, pixel* r0cr, pixel* r1y, pixel* r1cb, pixel* r1cr, intptr_t stride, intptr_t strideC,
+                       int bx, int by, int w, int h, const int32_t* mv0, const int32_t* mv1, pixel* dstY, pixel* dstCb, pixel* dstCr)
+{
+    T();
+    Predict pr;
+    pr.allocBuffers(X265_CSP_I420);
+    ShortYuv s[2];
+    Yuv out;
+    s[0].create(MAX_CU_SIZE, X265_CSP_I420);
+    s[1].create(MAX_CU_SIZE, X265_CSP_I420);
+    out.create(MAX_CU_SIZE, X265_CSP_I420);
+    intptr_t zero = 0, offY = bx + (intptr_t)by * stride, offC = (bx >> 1) + (intptr_t)(by >> 1) * strideC;
+    pixel* planes[2][3] = { { r0y, r0cb, r0cr }, { r1y, r1cb, r1cr } };
+    const int32_t* mvs[2] = { mv0, mv1 };
+    /* PredictionUnit only has the (CUData, CUGeom, puIdx) constructor; it is five plain fields, filled here directly */
+    alignas(PredictionUnit) unsigned char puRaw[sizeof(PredictionUnit)];
+    PredictionUnit& pu = *reinterpret_cast<PredictionUnit*>(puRaw);
+    pu.ctuAddr = 0; pu.cuAbsPartIdx = 0; pu.puAbsPartIdx = 0; pu.width = w; pu.height = h;
+    for (int l = 0; l < 2; l++)
+    {
+        PicYuv ref;
+        ref.m_cuOffsetY = &zero; ref.m_cuOffsetC = &zero; ref.m_buOffsetY = &offY; ref.m_buOffsetC = &offC;
+        ref.m_picOrg[0] = planes[l][0]; ref.m_picOrg[1] = planes[l][1]; ref.m_picOrg[2] = planes[l][2];
+        ref.m_stride = stride; ref.m_strideC = strideC;
+        MV mv(mvs[l][0], mvs[l][1]);
+        pr.predInterLumaShort(pu, s[l], ref, mv);
+        pr.predInterChromaShort(pu, s[l], ref, mv);
+        ref.m_picOrg[0] = ref.m_picOrg[1] = ref.m_picOrg[2] = NULL;
+        ref.m_cuOffsetY = ref.m_cuOffsetC = ref.m_buOffsetY = ref.m_buOffsetC = NULL;
+    }
+    out.addAvg(s[0], s[1], 0, w, h, true, true);
+    for (int y = 0; y < h; y++)
+        memcpy(dstY + y * w, out.m_buf[0] + y * out.m_size, w * sizeof(pixel));
+    for (int y = 0; y < h / 2; y++)
+    {
+        memcpy(dstCb + y * (w / 2), out.m_buf[1] + y * out.m_csize, (w / 2) * sizeof(pixel));
+        memcpy(dstCr + y * (w / 2), out.m_buf[2] + y * out.m_csize, (w / 2) * sizeof(pixel));
+    }
+    s[0].destroy(); s[1].destroy(); out.destroy();
 }
 
 } // extern "C"

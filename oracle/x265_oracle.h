@@ -122,6 +122,9 @@ void orc_frame_pass_##SFX(int width, int height, int depth, int qp, int merange,
                           const P* const srcC[2], const P* const refC[2], P* const predC[2], P* const reconC[2], \
                           intptr_t ssC, intptr_t rsC, intptr_t psC, intptr_t csC, \
                           int16_t* clevel[4], uint32_t* cnumSig[4], uint64_t* cdist[4]); \
+/* common/predict.cpp:131-199 bi-predictive motion compensation: predInterLumaShort / predInterChromaShort of both lists + addAvg */ \
+void orc_pred_inter_bi_##SFX(const P* const ref0[3], const P* const ref1[3], intptr_t rs, intptr_t rsC, int bx, int by, int w, int h, \
+                             const int32_t mv0[2], const int32_t mv1[2], P* dstY, intptr_t dsY, P* dstCb, P* dstCr, intptr_t dsC, int depth); \
 /* common/predict.cpp:306 Predict::predInterChromaPixel (4:2:0) */ \
 void orc_pred_inter_chroma_##SFX(const P* ref, intptr_t rs, P* dst, intptr_t ds, int bx, int by, int lumaW, int lumaH, int qx, int qy, int depth);
 ORC_DECL_FRAME(uint8_t, 8)

@@ -348,6 +348,20 @@ class Orc(_Base):
                                               ptr(mvs[0]), ptr(mvc[0]), ptr(mvs[1]), ptr(mvc[1]), ptr(lc), ptr(rows))
         return int(est) * 100 // 130, mvs[0], mvc[0], mvs[1], mvc[1], lc, rows
 
+    def pred_inter_bi(self, ref0, ref1, bx, by, w, h, mv0, mv1):
+        """ref0 / ref1 = (Y, Cb, Cr) padded planes; (bx, by) absolute luma position.  Returns (Y[h,w], Cb, Cr)."""
+        import ctypes as C
+        L = po.oracle()
+        fn = getattr(L, "orc_pred_inter_bi_%s" % self.s)
+        fn.restype = None
+        fn.argtypes = [po.vp, po.vp, po.ip, po.ip, po.i32, po.i32, po.i32, po.i32, po.vp, po.vp, po.vp, po.ip, po.vp, po.vp, po.ip, po.i32]
+        r0 = (C.c_void_p * 3)(*[ptr(p).value for p in ref0])
+        r1 = (C.c_void_p * 3)(*[ptr(p).value for p in ref1])
+        y, cb, cr = np.zeros((h, w), self.pix), np.zeros((h // 2, w // 2), self.pix), np.zeros((h // 2, w // 2), self.pix)
+        fn(r0, r1, ref0[0].shape[1], ref0[1].shape[1], bx, by, w, h, ptr(np.array(mv0, np.int32)), ptr(np.array(mv1, np.int32)),
+           ptr(y), w, ptr(cb), ptr(cr), w // 2, self.depth)
+        return y, cb, cr
+
 
 class Ref(_Base):
     name = "reference"
@@ -628,6 +642,12 @@ class Ref(_Base):
                                           rows_per_slice, num_slices, int(prefill_l0), ptr(mvs[0]), ptr(mvc[0]), ptr(mvs[1]), ptr(mvc[1]),
                                           ptr(lc), ptr(rows))
         return int(est), mvs[0], mvc[0], mvs[1], mvc[1], lc, rows
+
+    def pred_inter_bi(self, ref0, ref1, bx, by, w, h, mv0, mv1):
+        y, cb, cr = np.zeros((h, w), self.pix), np.zeros((h // 2, w // 2), self.pix), np.zeros((h // 2, w // 2), self.pix)
+        self.L.ref_pred_inter_bi(ptr(ref0[0]), ptr(ref0[1]), ptr(ref0[2]), ptr(ref1[0]), ptr(ref1[1]), ptr(ref1[2]), ref0[0].shape[1],
+                                 ref0[1].shape[1], bx, by, w, h, ptr(np.array(mv0, np.int32)), ptr(np.array(mv1, np.int32)), ptr(y), ptr(cb), ptr(cr))
+        return y, cb, cr
 
 
 def same(x, y):

@@ -73,6 +73,31 @@ def chroma_me_results(backend_cls, depth, stride=1):
     return out
 
 
+def bipred_results(backend_cls, depth):
+    """Bi-predictive motion compensation (predInterLumaShort / predInterChromaShort of both references + addAvg) for every PU shape,
+    six vector pairs each (full-pel, half and quarter fractions in either direction): (Y, Cb, Cr) per case."""
+    from backends import PU_SIZES
+    b = backend_cls(depth)
+    ref, src, m = me_scene_yuv(depth, 55 + depth)
+    rng = np.random.default_rng(3)
+    out = {}
+    for (w, h) in PU_SIZES:
+        if (w, h) == (4, 4):
+            continue
+        for t in range(6):
+            bx, by = m + int(rng.integers(0, 192 - w) // 2 * 2), m + int(rng.integers(0, 160 - h) // 2 * 2)
+            mv0 = (int(rng.integers(-40, 41)), int(rng.integers(-40, 41)))
+            mv1 = (int(rng.integers(-40, 41)), int(rng.integers(-40, 41)))
+            if t == 0:
+                mv0 = (mv0[0] & ~3, mv0[1] & ~3)
+            if t == 1:
+                mv1 = (mv1[0] & ~7, mv1[1])
+            if t == 2:
+                mv0 = (mv0[0], mv0[1] & ~7)
+            out["bi %dx%d #%d" % (w, h, t)] = b.pred_inter_bi(ref, src, bx, by, w, h, mv0, mv1)
+    return out
+
+
 LOWRES_CASES = [(200, 136), (176, 144), (66, 50)]   # (W, H) of the full-resolution picture
 
 
@@ -139,7 +164,8 @@ def prim_digests(backend_cls, depth):
 if __name__ == "__main__":
     gold = {}
     for depth in (8, 10):
-        gold[str(depth)] = {"prims": prim_digests(Ref, depth), "me": me_digests(Ref, depth), "chroma_me": chroma_me_results(Ref, depth), "lowres": lowres_digests(Ref, depth), "lookahead": lookahead_digests(Ref, depth),
+        gold[str(depth)] = {"prims": prim_digests(Ref, depth), "me": me_digests(Ref, depth), "chroma_me": chroma_me_results(Ref, depth),
+                            "bipred": {k: digest(v) for k, v in bipred_results(Ref, depth).items()}, "lowres": lowres_digests(Ref, depth), "lookahead": lookahead_digests(Ref, depth),
                             "lookahead_b": {k: digest(v) for k, v in lookahead_b_results(Ref, depth).items()},
                             "mvcost": {str(qp): digest(Ref(depth).mvcost_table(qp)) for qp in (12, 28, 37, 51)}}
     path = os.path.join(HERE, "primitives_golden.json")

@@ -38,6 +38,11 @@ def test_oracle_chroma_motion_estimate_matches_golden(depth):
 
 
 @pytest.mark.parametrize("depth", [8, 10])
+def test_oracle_bipred_matches_golden(depth):
+    assert {k: digest(v) for k, v in make_golden.bipred_results(Orc, depth).items()} == GOLD[str(depth)]["bipred"]
+
+
+@pytest.mark.parametrize("depth", [8, 10])
 def test_oracle_lowres_pass_matches_golden(depth):
     assert make_golden.lowres_digests(Orc, depth) == GOLD[str(depth)]["lowres"]
 

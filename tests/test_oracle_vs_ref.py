@@ -142,3 +142,16 @@ def test_lookahead_b_cost_matches_reference(depth):
     a, b = make_golden.lookahead_b_results(Orc, depth), make_golden.lookahead_b_results(Ref, depth)
     for k in a:
         assert same(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_bipred_matches_reference(depth):
+    """Predict::predInterLumaShort / predInterChromaShort of two references + Yuv::addAvg (the unweighted bi-pred branch of
+    Predict::motionCompensation) vs the restatement, every PU shape."""
+    _need_ref(depth)
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    a, b = make_golden.bipred_results(Orc, depth), make_golden.bipred_results(Ref, depth)
+    for k in a:
+        assert same(a[k], b[k]), k
