@@ -263,6 +263,12 @@ int x265hip_framepass_run(x265hip_framepass* fp, const void* src, int64_t stride
  * other (one launch covers both, Cr is addressed from the Cb pointer with 32-bit offsets): allocate a picture's planes in one
  * buffer, as x265's PicYuv does; otherwise X265HIP_EINVAL. */
 typedef struct x265hip_yuv { void* y; void* cb; void* cr; int64_t strideY; int64_t strideC; } x265hip_yuv;
+/* Predict::motionCompensation for an unweighted bi-predicted PU (predict.cpp:131-199): predInterLumaShort / predInterChromaShort of
+ * both references (:268-306, :364-420: convert_p2s / hps / vps / hps + vss by the vector's fractions, 14-bit) combined by Yuv::addAvg
+ * (yuv.cpp:189-211, pixel.cpp:842-862) — luma, Cb and Cr of n PUs of one shape (w multiple of 4) in one launch, written at the PU
+ * positions of `dst`.  pu_xy in luma samples; mv0 / mv1 quarter-pel luma vectors (eighth-pel for the 4:2:0 chroma). */
+int x265hip_pred_inter_bi_batch(int depth, int w, int h, const x265hip_yuv* ref0, const x265hip_yuv* ref1, const x265hip_yuv* dst,
+                                const int32_t* pu_xy, const int32_t* mv0, const int32_t* mv1, int n, void* stream);
 int x265hip_framepass_run_yuv(x265hip_framepass* fp, const x265hip_yuv* src, const x265hip_yuv* ref, const x265hip_yuv* pred,
                               const x265hip_yuv* recon, int marginX, int marginY, void* stream);
 /* device pointers to the results of the last run (owned by fp).  `level`: 0..3 = CU size 64, 32, 16, 8 for the ME

@@ -358,8 +358,8 @@ class Orc(_Base):
         r0 = (C.c_void_p * 3)(*[ptr(p).value for p in ref0])
         r1 = (C.c_void_p * 3)(*[ptr(p).value for p in ref1])
         y, cb, cr = np.zeros((h, w), self.pix), np.zeros((h // 2, w // 2), self.pix), np.zeros((h // 2, w // 2), self.pix)
-        fn(r0, r1, ref0[0].shape[1], ref0[1].shape[1], bx, by, w, h, ptr(np.array(mv0, np.int32)), ptr(np.array(mv1, np.int32)),
-           ptr(y), w, ptr(cb), ptr(cr), w // 2, self.depth)
+        a0, a1 = np.array(mv0, np.int32), np.array(mv1, np.int32)          # named: a temporary would be freed before the call reads it
+        fn(r0, r1, ref0[0].shape[1], ref0[1].shape[1], bx, by, w, h, ptr(a0), ptr(a1), ptr(y), w, ptr(cb), ptr(cr), w // 2, self.depth)
         return y, cb, cr
 
 
@@ -645,8 +645,9 @@ class Ref(_Base):
 
     def pred_inter_bi(self, ref0, ref1, bx, by, w, h, mv0, mv1):
         y, cb, cr = np.zeros((h, w), self.pix), np.zeros((h // 2, w // 2), self.pix), np.zeros((h // 2, w // 2), self.pix)
+        a0, a1 = np.array(mv0, np.int32), np.array(mv1, np.int32)
         self.L.ref_pred_inter_bi(ptr(ref0[0]), ptr(ref0[1]), ptr(ref0[2]), ptr(ref1[0]), ptr(ref1[1]), ptr(ref1[2]), ref0[0].shape[1],
-                                 ref0[1].shape[1], bx, by, w, h, ptr(np.array(mv0, np.int32)), ptr(np.array(mv1, np.int32)), ptr(y), ptr(cb), ptr(cr))
+                                 ref0[1].shape[1], bx, by, w, h, ptr(a0), ptr(a1), ptr(y), ptr(cb), ptr(cr))
         return y, cb, cr
 
 

@@ -484,3 +484,20 @@ class Hip:
                                               _ip(np.arange(count, dtype=np.int32) * ln + count * ln), df.ptr, fenc_plane.shape[1],
                                               _ip([y * fenc_plane.shape[1] + x for (y, x) in fenc_xy]), count, out.ptr, None))
         return out.get()
+
+    def pred_inter_bi_batch(self, ref0, ref1, w, h, pu_xy, mv0, mv1):
+        """ref0 / ref1 = (Y, Cb, Cr) padded planes.  Returns the three destination planes (same shapes, zero outside the PUs)."""
+        from x265_amd.framepass import YuvStruct
+        d = [DevBuf(p) for p in (ref0[0], ref0[1], ref0[2], ref1[0], ref1[1], ref1[2])]
+        out = [DevBuf.zeros(p.shape, self.pix) for p in ref0]
+        sy, sc = ref0[0].shape[1], ref0[1].shape[1]
+        a, b, c = YuvStruct(d[0].ptr, d[1].ptr, d[2].ptr, sy, sc), YuvStruct(d[3].ptr, d[4].ptr, d[5].ptr, sy, sc), YuvStruct(out[0].ptr, out[1].ptr, out[2].ptr, sy, sc)
+        n = len(pu_xy)
+        check(self.L.x265hip_pred_inter_bi_batch(self.depth, w, h, C.byref(a), C.byref(b), C.byref(c), _ip(np.asarray(pu_xy, np.int32)),
+                                                 _ip(np.asarray(mv0, np.int32)), _ip(np.asarray(mv1, np.int32)), n, None))
+        return [o.get() for o in out]
+
+    def pred_inter_bi(self, ref0, ref1, bx, by, w, h, mv0, mv1):
+        y, cb, cr = self.pred_inter_bi_batch(ref0, ref1, w, h, [(bx, by)], [mv0], [mv1])
+        return (np.ascontiguousarray(y[by:by + h, bx:bx + w]), np.ascontiguousarray(cb[by // 2:by // 2 + h // 2, bx // 2:bx // 2 + w // 2]),
+                np.ascontiguousarray(cr[by // 2:by // 2 + h // 2, bx // 2:bx // 2 + w // 2]))

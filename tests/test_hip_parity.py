@@ -542,6 +542,35 @@ def test_chroma_motion_estimate_matches_oracle(hipmod, depth):
 
 
 @pytest.mark.parametrize("depth", [8, 10, 12])
+def test_bipred_matches_oracle(hipmod, depth):
+    """Bi-predictive motion compensation (two 14-bit predictions + addAvg; luma, Cb, Cr): every PU shape one by one (the golden case
+    list), then a frame-shaped batch of 16x16 PUs with per-PU vector pairs, nothing written outside the PUs."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    from cases import me_scene_yuv
+    want = make_golden.bipred_results(Orc, depth)
+    got = make_golden.bipred_results(hipmod.Hip, depth)
+    hipmod._release()
+    bad = [k for k in want if not same(want[k], got[k])]
+    assert not bad, (len(bad), bad[:8])
+    o, g = Orc(depth), hipmod.Hip(depth)
+    ref, src, m = me_scene_yuv(depth, 55 + depth)
+    rng = np.random.default_rng(12)
+    pus = [(m + x, m + y) for y in range(0, 160, 16) for x in range(0, 192, 16)]
+    mv0 = [(int(rng.integers(-30, 31)), int(rng.integers(-30, 31))) for _ in pus]
+    mv1 = [(int(rng.integers(-30, 31)), int(rng.integers(-30, 31))) for _ in pus]
+    y, cb, cr = g.pred_inter_bi_batch(ref, src, 16, 16, pus, mv0, mv1)
+    hipmod._release()
+    wy, wcb, wcr = np.zeros_like(y), np.zeros_like(cb), np.zeros_like(cr)
+    for (bx, by), a, b in zip(pus, mv0, mv1):
+        py, pcb, pcr = o.pred_inter_bi(ref, src, bx, by, 16, 16, a, b)
+        wy[by:by + 16, bx:bx + 16] = py
+        wcb[by // 2:by // 2 + 8, bx // 2:bx // 2 + 8] = pcb
+        wcr[by // 2:by // 2 + 8, bx // 2:bx // 2 + 8] = pcr
+    assert np.array_equal(y, wy) and np.array_equal(cb, wcb) and np.array_equal(cr, wcr)
+
+
+@pytest.mark.parametrize("depth", [8, 10, 12])
 def test_lookahead_p_cost_matches_oracle(hipmod, depth):
     """The lookahead's P-frame cost pass (lowres init -> intra estimate -> estimateCUCost over the frame) on the GPU vs the
     restatement: every block's vector, cost, packed lowresCost, the row sums, the frame score and the intra count; serial and

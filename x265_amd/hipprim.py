@@ -102,6 +102,7 @@ PROTOTYPES = {
     "x265hip_intra_pred_batch": (i32, [i32, i32, vp, vp, vp, vp, vp, i64, i32, vp]),
     "x265hip_intra_allangs_batch": (i32, [i32, i32, vp, vp, vp, i32, vp, i32, vp]),
     "x265hip_intra_filter_batch": (i32, [i32, i32, vp, vp, vp, vp, i32, vp]),
+    "x265hip_pred_inter_bi_batch": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
     "x265hip_intra_scan_batch": (i32, [i32, i32, vp, vp, vp, vp, i64, vp, i32, vp, vp]),
     "x265hip_frame_init_lowres": (i32, [i32, vp, i64, vp, vp, vp, vp, i64, i32, i32, vp]),
     "x265hip_lowres_init": (i32, [i32, vp, i64, C.POINTER(vp), i64, i32, i32, i32, i32, vp]),
