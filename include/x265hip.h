@@ -271,6 +271,12 @@ int x265hip_pred_inter_bi_batch(int depth, int w, int h, const x265hip_yuv* ref0
                                 const int32_t* pu_xy, const int32_t* mv0, const int32_t* mv1, int n, void* stream);
 int x265hip_framepass_run_yuv(x265hip_framepass* fp, const x265hip_yuv* src, const x265hip_yuv* ref, const x265hip_yuv* pred,
                               const x265hip_yuv* recon, int marginX, int marginY, void* stream);
+/* The B-frame variant: a second (future) reference of the same geometry.  Both lists are searched at every level (list 1's vectors
+ * and costs: x265hip_framepass_output levels 4..7 of X265HIP_FP_MV / X265HIP_FP_MECOST), and the prediction is the unweighted
+ * bi-predictive average of the two lists' 8x8 vectors (x265hip_pred_inter_bi_batch, Predict::motionCompensation B-slice branch)
+ * for luma and chroma; the residual chains, sa8d costs and borders follow as in the P pass. */
+int x265hip_framepass_run_yuv_b(x265hip_framepass* fp, const x265hip_yuv* src, const x265hip_yuv* ref0, const x265hip_yuv* ref1,
+                                const x265hip_yuv* pred, const x265hip_yuv* recon, int marginX, int marginY, void* stream);
 /* device pointers to the results of the last run (owned by fp).  `level`: 0..3 = CU size 64, 32, 16, 8 for the ME
  * outputs; for the transform outputs 0..1 = luma TU size 32, 8 and (after run_yuv) 2..3 = Cb 16x16, 4x4, 4..5 = Cr 16x16, 4x4.
  * *count = number of PUs / TUs. */

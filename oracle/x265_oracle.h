@@ -121,7 +121,8 @@ void orc_frame_pass_##SFX(int width, int height, int depth, int qp, int merange,
                           int16_t* level[2], uint32_t* numSig[2], uint64_t* dist[2], \
                           const P* const srcC[2], const P* const refC[2], P* const predC[2], P* const reconC[2], \
                           intptr_t ssC, intptr_t rsC, intptr_t psC, intptr_t csC, \
-                          int16_t* clevel[4], uint32_t* cnumSig[4], uint64_t* cdist[4]); \
+                          int16_t* clevel[4], uint32_t* cnumSig[4], uint64_t* cdist[4], \
+                          const P* ref1, const P* const ref1C[2], int32_t* mv1[4], int32_t* mecost1[4]); \
 /* common/predict.cpp:131-199 bi-predictive motion compensation: predInterLumaShort / predInterChromaShort of both lists + addAvg */ \
 void orc_pred_inter_bi_##SFX(const P* const ref0[3], const P* const ref1[3], intptr_t rs, intptr_t rsC, int bx, int by, int w, int h, \
                              const int32_t mv0[2], const int32_t mv1[2], P* dstY, intptr_t dsY, P* dstCb, P* dstCr, intptr_t dsC, int depth); \

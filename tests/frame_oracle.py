@@ -26,13 +26,14 @@ def _proto(L, depth):
     fn = getattr(L, "orc_frame_pass_%s" % po.sfx(depth))
     pp = C.POINTER(C.c_void_p)
     fn.restype = None
-    fn.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_ssize_t] * 4 + [C.c_int, C.c_int] + [pp] * 6 + [pp] * 4 + [C.c_ssize_t] * 4 + [pp] * 3
+    fn.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_ssize_t] * 4 + [C.c_int, C.c_int] + [pp] * 6 + [pp] * 4 + [C.c_ssize_t] * 4 + [pp] * 3 + [C.c_void_p, pp, pp, pp]
     return fn
 
 
-def oracle_frame_pass(src, ref, depth=8, qp=28, merange=57, method=1, subme=2, src_c=None, ref_c=None):
+def oracle_frame_pass(src, ref, depth=8, qp=28, merange=57, method=1, subme=2, src_c=None, ref_c=None, ref1=None, ref1_c=None):
     """Run the C restatement of the frame pass; returns the same dict x265_amd.framepass.FramePass.run_host returns.
-    src_c / ref_c: optional (cb, cr) 4:2:0 planes -> the YUV pass (chroma prediction, chroma residual chain)."""
+    src_c / ref_c: optional (cb, cr) 4:2:0 planes -> the YUV pass (chroma prediction, chroma residual chain).
+    ref1 (/ ref1_c): a second reference -> the B pass: list-1 search (outputs mv1 / cost1) and bi-predictive prediction."""
     L = po.oracle()
     h, w = src.shape
     m = MARGIN
@@ -67,10 +68,19 @@ def oracle_frame_pass(src, ref, depth=8, qp=28, merange=57, method=1, subme=2, s
         cargs = [(C.c_void_p * 2)(*[corg(a) for a in lst]) for lst in (psc, prc, ppc, pcc)] + [Sc, Sc, Sc, Sc, arr(clevel), arr(cns), arr(cdist)]
     else:
         cargs = [None, None, None, None, 0, 0, 0, 0, None, None, None]
+    bargs = [None, None, None, None]
+    if ref1 is not None:
+        pref1 = np.ascontiguousarray(np.pad(ref1, m, mode="edge"))
+        mv1 = [np.zeros((n, 2), np.int32) for n in ncu]
+        cost1 = [np.zeros(n, np.int32) for n in ncu]
+        pr1c = [np.ascontiguousarray(np.pad(p, mc, mode="edge")) for p in ref1_c] if yuv else None
+        bargs = [org(pref1), (C.c_void_p * 2)(*[corg(a) for a in pr1c]) if yuv else None, arr(mv1), arr(cost1)]
     _proto(L, depth)(w, h, depth, qp, merange, method, subme, org(psrc), S, org(pref), S, org(pred), S, org(recon), S, m, m,
-                     arr(mv), arr(cost), arr(sa8d), arr(level), arr(numsig), arr(dist), *cargs)
+                     arr(mv), arr(cost), arr(sa8d), arr(level), arr(numsig), arr(dist), *cargs, *bargs)
     out = {"mv": mv, "cost": cost, "sa8d": sa8d, "level": level, "numSig": numsig, "dist": dist,
            "pred": np.ascontiguousarray(pred[m:m + h, m:m + w]), "recon": recon}
+    if ref1 is not None:
+        out.update({"mv1": mv1, "cost1": cost1})
     if yuv:
         out.update({"clevel": clevel, "cnumSig": cns, "cdist": cdist,
                     "pred_c": [np.ascontiguousarray(p[mc:mc + h // 2, mc:mc + w // 2]) for p in ppc], "recon_c": pcc})
@@ -80,7 +90,7 @@ def oracle_frame_pass(src, ref, depth=8, qp=28, merange=57, method=1, subme=2, s
 def same_results(got, want):
     """List of the output names that differ (empty = bit-exact)."""
     bad = []
-    for k in ("mv", "cost", "sa8d", "level", "numSig", "dist"):
+    for k in ("mv", "cost", "sa8d", "level", "numSig", "dist") + (("mv1", "cost1") if "mv1" in want else ()):
         for i, (a, b) in enumerate(zip(got[k], want[k])):
             if not np.array_equal(a, b):
                 bad.append("%s[%d] (%d of %d rows differ)" % (k, i, int(np.any(a.reshape(len(a), -1) != b.reshape(len(b), -1), axis=1).sum()), len(a)))

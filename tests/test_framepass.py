@@ -170,6 +170,22 @@ def test_yuv_frame_pass_with_chroma_satd_search(fpmod, w, h, depth, qp, method, 
     assert any(not np.array_equal(a, b) for a, b in zip(want["mv"], luma_only["mv"]))      # the chroma term does steer the search
 
 
+@pytest.mark.parametrize("w,h,depth,qp,method,subme", [(200, 136, 8, 28, 1, 2), (328, 200, 10, 30, 1, 3), (200, 136, 8, 35, 3, 2), (1920, 1080, 8, 28, 1, 2)])
+def test_b_frame_pass_is_bit_exact(fpmod, w, h, depth, qp, method, subme):
+    """The B variant: both lists searched at every level (list 1 against the next picture), bi-predictive prediction of luma and chroma from
+    the two lists' 8x8 vectors (two 14-bit predictions + addAvg), then the usual chains — every output incl. list 1's vectors / costs."""
+    sc = make_scene_yuv(w, h, depth=depth, seed=91 + qp, tile=48 if w < 1000 else 96, sigma=3.0 * (1 if depth == 8 else 4))
+    nxt = make_scene_yuv(w, h, depth=depth, seed=91 + qp, tile=48 if w < 1000 else 96, sigma=5.0 * (1 if depth == 8 else 4), vmax=5)
+    # the "future" reference: the same content generator with other motion / noise (the source of that scene)
+    r1 = (nxt["src"], nxt["src_cb"], nxt["src_cr"])
+    fp = fpmod.FramePass(w, h, depth=depth, qp=qp, method=method, subme=subme)
+    got = fp.run_host_yuv_b(sc, *r1)
+    want = oracle_frame_pass(sc["src"], sc["ref"], depth=depth, qp=qp, method=method, subme=subme, src_c=(sc["src_cb"], sc["src_cr"]),
+                             ref_c=(sc["ref_cb"], sc["ref_cr"]), ref1=r1[0], ref1_c=(r1[1], r1[2]))
+    assert same_results(got, want) == []
+    assert any(int(np.abs(m).sum()) for m in want["mv1"])
+
+
 @pytest.mark.parametrize("depth", [8, 10])
 def test_pred_inter_chroma_matches_oracle(fpmod, depth):
     from oracle import pyoracle as po

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--qp", type=int, default=28)
     ap.add_argument("--frames-in-flight", type=int, default=3)
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--b", action="store_true", help="B pass: second reference, both lists searched, bi-predictive prediction")
     a = ap.parse_args()
     L = hp.lib()
     check(L.x265hip_init(0))
@@ -55,7 +56,10 @@ def main():
     def step(k):
         for j in range(F):
             rec = recs[j][k & 1]
-            fps[j].run_yuv(pool[(k + j) % NPOOL], cur[j], preds[j], rec, streams[j])
+            if a.b:
+                fps[j].run_yuv_b(pool[(k + j) % NPOOL], cur[j], pool[(k + j + 1) % NPOOL], preds[j], rec, streams[j])    # "future" reference: the next source
+            else:
+                fps[j].run_yuv(pool[(k + j) % NPOOL], cur[j], preds[j], rec, streams[j])
             cur[j] = rec                                             # each chain references its own previous reconstruction
 
     def sync():
@@ -70,7 +74,7 @@ def main():
         step(k)
     sync()
     dt = time.perf_counter() - t0
-    print(json.dumps({"config": "%dx%d %d-bit 4:2:0 me %d subme %d merange %d qp %d" % (w, h, d, a.me, a.subme, a.merange, a.qp),
+    print(json.dumps({"config": "%dx%d %d-bit 4:2:0 me %d subme %d merange %d qp %d%s" % (w, h, d, a.me, a.subme, a.merange, a.qp, " B pass" if a.b else ""),
                       "frames_in_flight": F, "steps": a.steps, "frames_per_s": round(F * a.steps / dt, 1), "ms_per_frame": round(dt * 1e3 / (F * a.steps), 4)}))
 
 

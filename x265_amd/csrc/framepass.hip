@@ -35,6 +35,9 @@ struct x265hip_framepass
     uint64_t* cdist[2][2];
     int32_t* cquantCoeff[2];
     std::vector<int32_t> hCtuXY[2];
+    // B pass: list-1 search state and the second reference's planes, allocated on the first B run
+    int32_t *qmvp1[4], *mvmin1[4], *mvmax1[4], *mv1[4], *cost1[4];
+    void* planes1;
     void* planes;                  // 16 sub-pel planes of the current reference (device), sized on first run
     int64_t planeElems, planeStride;
     int planeMarginX, planeMarginY;
@@ -224,6 +227,12 @@ int x265hip_framepass_destroy(x265hip_framepass* fp)
     }
     if (fp->mvcost) (void)hipFree(fp->mvcost);
     if (fp->planes) (void)hipFree(fp->planes);
+    if (fp->planes1) (void)hipFree(fp->planes1);
+    for (int l = 0; l < 4; l++)
+    {
+        void* ptrs[] = { fp->qmvp1[l], fp->mvmin1[l], fp->mvmax1[l], fp->mv1[l], fp->cost1[l] };
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+    }
     for (int i = 0; i < 12; i++) (void)hipEventDestroy(fp->ev[i]);
     delete fp;
     return X265HIP_OK;
@@ -232,10 +241,11 @@ int x265hip_framepass_destroy(x265hip_framepass* fp)
 } // extern "C"
 
 struct ChromaArgs { const void *srcCb, *srcCr, *refCb, *refCr; void *predCb, *predCr, *recCb, *recCr; int64_t sS, sR, sP, sRec; };
+struct BArgs { const void *ref1, *ref1Cb, *ref1Cr; };       // second reference of a B pass (same strides and margins as the first)
 
 static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t strideS, const void* ref, int64_t strideR,
                               void* pred, int64_t strideP, void* recon, int64_t strideRec, int marginX, int marginY, const ChromaArgs* ca,
-                              void* stream)
+                              void* stream, const BArgs* ba = nullptr)
 {
     XH_CHECK_DEV();
     if (!fp || !src || !ref || !pred || !recon)
@@ -274,6 +284,22 @@ static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t st
         const size_t B = depth == 8 ? 1 : 2;
         FP_TRY(check_hip(hipMalloc(&fp->planes, (size_t)fp->planeElems * 16 * B), "hipMalloc(subpel planes)"));
         FP_TRY(check_hip(hipMemsetAsync(fp->planes, 0, (size_t)fp->planeElems * 16 * B, as_stream(stream)), "hipMemset(subpel planes)"));
+        if (fp->planes1) (void)hipFree(fp->planes1);
+        fp->planes1 = nullptr;
+    }
+    if (ba && !fp->planes1)
+    {
+        FP_TRY(check_hip(hipStreamSynchronize(as_stream(stream)), "framepass sync"));
+        const size_t B = depth == 8 ? 1 : 2;
+        FP_TRY(check_hip(hipMalloc(&fp->planes1, (size_t)fp->planeElems * 16 * B), "hipMalloc(subpel planes, list 1)"));
+        FP_TRY(check_hip(hipMemsetAsync(fp->planes1, 0, (size_t)fp->planeElems * 16 * B, as_stream(stream)), "hipMemset(subpel planes)"));
+        for (int l = 0; l < 4; l++)
+            if (!fp->mv1[l])
+            {
+                const size_t n = (size_t)fp->nLevel[l];
+                FP_TRY(dev_alloc(&fp->qmvp1[l], 2 * n)); FP_TRY(dev_alloc(&fp->mvmin1[l], 2 * n)); FP_TRY(dev_alloc(&fp->mvmax1[l], 2 * n));
+                FP_TRY(dev_alloc(&fp->mv1[l], 2 * n)); FP_TRY(dev_alloc(&fp->cost1[l], n));
+            }
     }
     const size_t Bp = depth == 8 ? 1 : 2;
     void* planesOrigin = (char*)fp->planes + ((int64_t)marginY * strideR + marginX) * Bp;
@@ -281,46 +307,72 @@ static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t st
     // 0. the 16 quarter-pel planes of this reference
     FP_MARK(0);
     FP_TRY(x265hip_build_subpel_planes(depth, ref, strideR, fp->width, fp->height, marginX, marginY, planesOrigin, fp->planeElems, stream));
+    void* planes1Origin = ba ? (char*)fp->planes1 + ((int64_t)marginY * strideR + marginX) * Bp : nullptr;
+    if (ba)
+        FP_TRY(x265hip_build_subpel_planes(depth, ba->ref1, strideR, fp->width, fp->height, marginX, marginY, planes1Origin, fp->planeElems, stream));
     // 1. top-down motion search
     for (int l = 0; l < 4; l++)
     {
         const int n = fp->nLevel[l], sz = kCuSize[l];
         FP_MARK(1 + l);
         if (!n) continue;
-        // setSearchRange + motionEstimate in one launch (searchrange.h); qmvp / mvmin / mvmax arrays are still produced
-        DeriveRange dr{};
-        dr.enable = 1;
-        dr.mvSrc = l ? fp->mv[l - 1] : nullptr;
-        dr.srcIdx = fp->parent[l];
-        dr.picW = fp->width; dr.picH = fp->height; dr.maxCUSize = 64;
-        dr.refLagPixels = fp->height;                     // -F1: m_refLagPixels = sourceHeight (search.cpp:92)
-        dr.qmvpO = fp->qmvp[l]; dr.mvminO = fp->mvmin[l]; dr.mvmaxO = fp->mvmax[l];
-        if (ca && fp->subme > 2)
+        // per list (one for a P pass, two for a B pass): setSearchRange + motionEstimate, children around their own list's parent vector
+        for (int list = 0; list < (ba ? 2 : 1); list++)
         {
-            // 4:2:0 picture at subme > 2: every sub-pel comparison carries the chroma SATD term (motion.cpp:212, :1601).  8 / 16 / 32 PUs:
-            // the plane-based row-team kernel with an in-register 4-tap chroma path; 64x64: the generic kernel, ranges from their own launch.
-            const ChromaPlanes cpl{ ca->srcCb, ca->srcCr, ca->sS, ca->refCb, ca->refCr, ca->sR, 1 };
-            int rc = X265HIP_OK;
-            static const bool genericChroma = getenv("X265HIP_CHROMA_ME_GENERIC") != nullptr;
-            if (!genericChroma && motion_estimate_fused_chroma(depth, sz, src, strideS, strideR, planesOrigin, fp->planeElems, cpl, fp->puXY[l], dr, fp->merange,
-                                                               fp->method, fp->subme, fp->mvcost + kMvHalf, n, fp->mv[l], fp->cost[l], as_stream(stream), &rc))
-            {
-                FP_TRY(rc);
-                continue;
-            }
-            FP_TRY(x265hip_set_search_range_batch(fp->width, fp->height, 64, fp->merange, fp->height, fp->puXY[l], dr.mvSrc, dr.srcIdx, n,
-                                                  fp->qmvp[l], fp->mvmin[l], fp->mvmax[l], stream));
-            FP_TRY(x265hip_motion_estimate_chroma_batch(depth, sz, sz, src, strideS, ca->srcCb, ca->srcCr, ca->sS, ref, strideR, ca->refCb, ca->refCr,
-                                                        ca->sR, fp->puXY[l], fp->mvmin[l], fp->mvmax[l], fp->qmvp[l], 0, nullptr, fp->merange,
-                                                        fp->method, fp->subme, fp->mvcost + kMvHalf, kMvHalf, n, fp->mv[l], fp->cost[l], stream));
-            continue;
+            int32_t** MV = list ? fp->mv1 : fp->mv; int32_t** COST = list ? fp->cost1 : fp->cost;
+            int32_t** QMVP = list ? fp->qmvp1 : fp->qmvp; int32_t** MVMIN = list ? fp->mvmin1 : fp->mvmin; int32_t** MVMAX = list ? fp->mvmax1 : fp->mvmax;
+            const void* REFY = list ? ba->ref1 : ref;
+            const void* REFCB = list ? ba->ref1Cb : (ca ? ca->refCb : nullptr);
+            const void* REFCR = list ? ba->ref1Cr : (ca ? ca->refCr : nullptr);
+            void* PLANES = list ? planes1Origin : planesOrigin;
+            auto search = [&]() -> int {
+                // setSearchRange + motionEstimate in one launch (searchrange.h); qmvp / mvmin / mvmax arrays are still produced
+                DeriveRange dr{};
+                dr.enable = 1;
+                dr.mvSrc = l ? MV[l - 1] : nullptr;
+                dr.srcIdx = fp->parent[l];
+                dr.picW = fp->width; dr.picH = fp->height; dr.maxCUSize = 64;
+                dr.refLagPixels = fp->height;                     // -F1: m_refLagPixels = sourceHeight (search.cpp:92)
+                dr.qmvpO = QMVP[l]; dr.mvminO = MVMIN[l]; dr.mvmaxO = MVMAX[l];
+                if (ca && fp->subme > 2)
+                {
+                    // 4:2:0 picture at subme > 2: every sub-pel comparison carries the chroma SATD term (motion.cpp:212, :1601).  8 / 16 / 32 PUs:
+                    // the plane-based row-team kernel with an in-register 4-tap chroma path; 64x64: the generic kernel, ranges from their own launch.
+                    const ChromaPlanes cpl{ ca->srcCb, ca->srcCr, ca->sS, REFCB, REFCR, ca->sR, 1 };
+                    int rc = X265HIP_OK;
+                    static const bool genericChroma = getenv("X265HIP_CHROMA_ME_GENERIC") != nullptr;
+                    if (!genericChroma && motion_estimate_fused_chroma(depth, sz, src, strideS, strideR, PLANES, fp->planeElems, cpl, fp->puXY[l], dr, fp->merange,
+                                                                       fp->method, fp->subme, fp->mvcost + kMvHalf, n, MV[l], COST[l], as_stream(stream), &rc))
+                    {
+                        FP_TRY(rc);
+                        return X265HIP_OK;
+                    }
+                    FP_TRY(x265hip_set_search_range_batch(fp->width, fp->height, 64, fp->merange, fp->height, fp->puXY[l], dr.mvSrc, dr.srcIdx, n,
+                                                          QMVP[l], MVMIN[l], MVMAX[l], stream));
+                    FP_TRY(x265hip_motion_estimate_chroma_batch(depth, sz, sz, src, strideS, ca->srcCb, ca->srcCr, ca->sS, REFY, strideR, REFCB, REFCR,
+                                                                ca->sR, fp->puXY[l], MVMIN[l], MVMAX[l], QMVP[l], 0, nullptr, fp->merange,
+                                                                fp->method, fp->subme, fp->mvcost + kMvHalf, kMvHalf, n, MV[l], COST[l], stream));
+                    return X265HIP_OK;
+                }
+                FP_TRY(motion_estimate_fused(depth, sz, src, strideS, REFY, strideR, PLANES, fp->planeElems, fp->puXY[l], dr, fp->merange,
+                                             fp->method, fp->subme, fp->mvcost + kMvHalf, n, MV[l], COST[l], as_stream(stream)));
+    
+                return X265HIP_OK;
+            };
+            FP_TRY(search());
         }
-        FP_TRY(motion_estimate_fused(depth, sz, src, strideS, ref, strideR, planesOrigin, fp->planeElems, fp->puXY[l], dr, fp->merange,
-                                     fp->method, fp->subme, fp->mvcost + kMvHalf, n, fp->mv[l], fp->cost[l], as_stream(stream)));
     }
     FP_MARK(5);
     // 2. prediction from the 8x8 vectors
-    FP_TRY(pred_from_planes(depth, 8, planesOrigin, fp->planeElems, strideR, pred, strideP, fp->puXY[3], fp->mv[3], fp->nLevel[3], as_stream(stream)));
+    if (ba)
+    {
+        // B pass: bi-predictive motion compensation from the two lists' 8x8 vectors, luma and chroma in one launch (bipred.hip)
+        const x265hip_yuv r0{ (void*)ref, (void*)ca->refCb, (void*)ca->refCr, strideR, ca->sR }, r1{ (void*)ba->ref1, (void*)ba->ref1Cb, (void*)ba->ref1Cr, strideR, ca->sR };
+        const x265hip_yuv pd{ pred, ca->predCb, ca->predCr, strideP, ca->sP };
+        FP_TRY(x265hip_pred_inter_bi_batch(depth, 8, 8, &r0, &r1, &pd, fp->puXY[3], fp->mv[3], fp->mv1[3], fp->nLevel[3], stream));
+    }
+    else
+        FP_TRY(pred_from_planes(depth, 8, planesOrigin, fp->planeElems, strideR, pred, strideP, fp->puXY[3], fp->mv[3], fp->nLevel[3], as_stream(stream)));
     // 3. residual chain
     const int qp = fp->qp + 6 * (depth - 8);                                            // QpParam.qp = slice qp + QP_BD_OFFSET (quant.cpp:224)
     static const int invQuantScales[6] = { 40, 45, 51, 57, 64, 72 };                     // scalinglist.cpp:130
@@ -382,8 +434,9 @@ static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t st
             fp->cStrideF = ca->sS; fp->cStrideP = ca->sP; fp->cStrideR = ca->sRec;
             fp->cDeltaF = dF; fp->cDeltaP = dP; fp->cDeltaR = dR;
         }
-        FP_TRY(x265hip_pred_inter_chroma_batch(depth, 8, 8, ca->refCb, ca->refCr, ca->sR, ca->predCb, ca->predCr, ca->sP, fp->puXY[3], fp->mv[3],
-                                               fp->nLevel[3], stream));
+        if (!ba)
+            FP_TRY(x265hip_pred_inter_chroma_batch(depth, 8, 8, ca->refCb, ca->refCr, ca->sR, ca->predCb, ca->predCr, ca->sP, fp->puXY[3], fp->mv[3],
+                                                   fp->nLevel[3], stream));
         const int bd = 6 * (depth - 8);
         int qpc = fp->qp < -bd ? -bd : (fp->qp > 57 ? 57 : fp->qp);
         if (qpc >= 30) qpc = kChromaScale[qpc];
@@ -434,6 +487,21 @@ int x265hip_framepass_run_yuv(x265hip_framepass* fp, const x265hip_yuv* src, con
     return framepass_run_impl(fp, src->y, src->strideY, ref->y, ref->strideY, pred->y, pred->strideY, recon->y, recon->strideY, marginX, marginY, &ca, stream);
 }
 
+int x265hip_framepass_run_yuv_b(x265hip_framepass* fp, const x265hip_yuv* src, const x265hip_yuv* ref0, const x265hip_yuv* ref1, const x265hip_yuv* pred,
+                                const x265hip_yuv* recon, int marginX, int marginY, void* stream)
+{
+    if (!fp || !src || !ref0 || !ref1 || !pred || !recon || !src->cb || !src->cr || !ref0->cb || !ref0->cr || !ref1->y || !ref1->cb || !ref1->cr || !pred->cb ||
+        !pred->cr || !recon->cb || !recon->cr)
+        return set_error(X265HIP_EINVAL, "framepass_run_yuv_b: null plane");
+    if ((marginX & 1) || (marginY & 1))
+        return set_error(X265HIP_EINVAL, "framepass_run_yuv_b: margins must be even (4:2:0)");
+    if (ref0->strideY != ref1->strideY || ref0->strideC != ref1->strideC)
+        return set_error(X265HIP_EINVAL, "framepass_run_yuv_b: the two references must share their strides");
+    ChromaArgs ca = { src->cb, src->cr, ref0->cb, ref0->cr, pred->cb, pred->cr, recon->cb, recon->cr, src->strideC, ref0->strideC, pred->strideC, recon->strideC };
+    BArgs ba = { ref1->y, ref1->cb, ref1->cr };
+    return framepass_run_impl(fp, src->y, src->strideY, ref0->y, ref0->strideY, pred->y, pred->strideY, recon->y, recon->strideY, marginX, marginY, &ca, stream, &ba);
+}
+
 int x265hip_framepass_set_profiling(x265hip_framepass* fp, int enable)
 {
     if (!fp) return set_error(X265HIP_EINVAL, "framepass_set_profiling: null handle");
@@ -456,6 +524,15 @@ int x265hip_framepass_output(x265hip_framepass* fp, int which, int level, void**
     if (!fp || !devPtr || !count)
         return set_error(X265HIP_EINVAL, "framepass_output: null argument");
     const bool cuLevel = which <= X265HIP_FP_SA8D;
+    if (cuLevel && level >= 4 && level < 8 && (which == X265HIP_FP_MV || which == X265HIP_FP_MECOST))
+    {
+        // list 1 of the last B pass (x265hip_framepass_run_yuv_b): levels 4..7 = CU size 64, 32, 16, 8
+        if (!fp->mv1[level - 4])
+            return set_error(X265HIP_EINVAL, "framepass_output: no B pass has run on this handle");
+        *devPtr = which == X265HIP_FP_MV ? (void*)fp->mv1[level - 4] : (void*)fp->cost1[level - 4];
+        *count = fp->nLevel[level - 4];
+        return X265HIP_OK;
+    }
     if (level < 0 || level >= (cuLevel ? 4 : 6))
         return set_error(X265HIP_EINVAL, "framepass_output: level %d for output %d", level, which);
     if (!cuLevel && level >= 2)

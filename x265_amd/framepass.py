@@ -92,6 +92,11 @@ class FramePass:
         a, b, c, d = src.struct(), ref.struct(), pred.struct(), recon.struct()
         check(self.L.x265hip_framepass_run_yuv(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), recon.y.margin, recon.y.margin, stream))
 
+    def run_yuv_b(self, src, ref0, ref1, pred, recon, stream=None):
+        """B pass: two references; bi-predictive prediction from both lists' 8x8 vectors."""
+        a, b, b1, c, d = src.struct(), ref0.struct(), ref1.struct(), pred.struct(), recon.struct()
+        check(self.L.x265hip_framepass_run_yuv_b(self.h, C.byref(a), C.byref(b), C.byref(b1), C.byref(c), C.byref(d), recon.y.margin, recon.y.margin, stream))
+
     def output(self, which, level):
         p, n = C.c_void_p(), C.c_int()
         check(self.L.x265hip_framepass_output(self.h, which, level, C.byref(p), C.byref(n)))
@@ -134,6 +139,25 @@ class FramePass:
         r = self.results()
         r["pred"] = pp.get()
         r["recon"] = pc.get(with_margins=True)
+        return r
+
+    def run_host_yuv_b(self, sc, ref1, ref1_cb, ref1_cr):
+        """run_host_yuv with a second reference picture (host arrays): the B pass; adds mv1 / cost1 (list 1)."""
+        w, h, d = self.width, self.height, self.depth
+        ps = Picture(w, h, d, sc["src"], sc["src_cb"], sc["src_cr"])
+        pr = Picture(w, h, d, sc["ref"], sc["ref_cb"], sc["ref_cr"])
+        pr1 = Picture(w, h, d, ref1, ref1_cb, ref1_cr)
+        pp, pc = Picture(w, h, d), Picture(w, h, d)
+        self.run_yuv_b(ps, pr, pr1, pp, pc)
+        r = self.results()
+        r["mv1"] = [self.fetch(FP_MV, 4 + l) for l in range(4)]
+        r["cost1"] = [self.fetch(FP_MECOST, 4 + l) for l in range(4)]
+        r["pred"], r["recon"] = pp.y.get(), pc.y.get(with_margins=True)
+        r["clevel"] = [self.fetch(FP_LEVEL, 2 + i) for i in range(4)]
+        r["cnumSig"] = [self.fetch(FP_NUMSIG, 2 + i) for i in range(4)]
+        r["cdist"] = [self.fetch(FP_DIST, 2 + i) for i in range(4)]
+        r["pred_c"] = [pp.cb.get(), pp.cr.get()]
+        r["recon_c"] = [pc.cb.get(with_margins=True), pc.cr.get(with_margins=True)]
         return r
 
     def run_host_yuv(self, sc):

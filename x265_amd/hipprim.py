@@ -69,6 +69,7 @@ PROTOTYPES = {
     "x265hip_mvcost_table": (i32, [i32, i32, vp, i32]),
     "x265hip_framepass_create": (i32, [i32, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]),
     "x265hip_framepass_destroy": (i32, [vp]),
+    "x265hip_framepass_run_yuv_b": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "x265hip_framepass_run": (i32, [vp, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, vp]),
     "x265hip_framepass_run_yuv": (i32, [vp, vp, vp, vp, vp, i32, i32, vp]),
     "x265hip_pred_inter_chroma_batch": (i32, [i32, i32, i32, vp, vp, i64, vp, vp, i64, vp, vp, i32, vp]),
