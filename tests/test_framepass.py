@@ -214,3 +214,42 @@ def test_pred_inter_chroma_matches_oracle(fpmod, depth):
                 if not np.array_equal(dd[pl].get(), want):
                     bad.append((lw, lh, i, pl))
         assert not bad, bad[:5]
+
+
+def test_graph_replay_matches_plain_launches(fpmod):
+    """X265HIP_GRAPH=1: the frame pass captured as a hipGraph (after the first plain run) and replayed must leave the same outputs as plain
+    launches — a chain of four passes alternating two reconstruction buffers, in a subprocess because the switch is read once per process."""
+    import subprocess, sys, os, hashlib
+    code = r"""
+import ctypes as C, hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from x265_amd import hipprim as hp
+from x265_amd.framepass import FramePass, Picture
+from x265_amd.synth import make_scene_yuv
+L = hp.lib(); hp.check(L.x265hip_init(0))
+w, h = 328, 200
+sc = make_scene_yuv(w, h, depth=8, seed=5, tile=48)
+src = Picture(w, h, 8, sc["src"], sc["src_cb"], sc["src_cr"]); ref = Picture(w, h, 8, sc["ref"], sc["ref_cb"], sc["ref_cr"])
+pred = Picture(w, h, 8); rec = [Picture(w, h, 8), Picture(w, h, 8)]
+fp = FramePass(w, h, depth=8, qp=30)
+st = C.c_void_p(); hp.check(L.x265hip_stream_create(C.byref(st)))
+cur = ref
+hsh = hashlib.sha256()
+for k in range(6):
+    fp.run_yuv(src, cur, pred, rec[k & 1], st)
+    hp.check(L.x265hip_stream_sync(st))
+    cur = rec[k & 1]
+    hsh.update(cur.y.get(True).tobytes()); hsh.update(cur.cb.get(True).tobytes()); hsh.update(fp.fetch(1, 3).tobytes())
+print(hsh.hexdigest())
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for graph in (False, True):
+        env = dict(os.environ)
+        env.pop("X265HIP_GRAPH", None)
+        if graph:
+            env["X265HIP_GRAPH"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] and len(outs[0]) == 64
