@@ -297,6 +297,21 @@ int x265hip_framepass_output(x265hip_framepass* fp, int which, int level, void**
 int x265hip_framepass_set_profiling(x265hip_framepass* fp, int enable);
 int x265hip_framepass_stage_ms(x265hip_framepass* fp, float* ms11);
 
+/* ---------------------------------------------------------------- small primitives around the path ----------- */
+/* var_t (primitives.h:173, pixel_var pixel.cpp:704): out[i] = sum | (sum of squares) << 32 of the size x size block, 32-bit wrap as in the reference */
+int x265hip_var_batch(int depth, int size, const void* plane, int64_t stride, const int32_t* off, int n, uint64_t* out, void* stream);
+/* weightp_pp_t / weightp_sp_t (primitives.h:164-165, pixel.cpp:518 / :493): explicit weighted prediction of a width x height region —
+ * from pixels (reference-plane weighting, MotionReference::applyWeight) or from the 14-bit intermediate (Predict::addWeightUni) */
+int x265hip_weight_pp(int depth, const void* src, void* dst, int64_t stride, int width, int height, int w0, int round, int shift, int offset, void* stream);
+int x265hip_weight_sp(int depth, const int16_t* src, void* dst, int64_t srcStride, int64_t dstStride, int width, int height, int w0, int round, int shift,
+                      int offset, void* stream);
+/* scale1D_t / scale2D_t (primitives.h:166-167, pixel.cpp:559 / :585): the 2:1 downscales of the 64x64 intra mode scan (search.cpp:1327-1345):
+ * n neighbour lines of 128 + 128 samples -> 64 + 64; n 64x64 blocks -> dense 32x32 */
+int x265hip_scale1d_128to64_batch(int depth, const void* src, void* dst, int n, void* stream);
+int x265hip_scale2d_64to32_batch(int depth, const void* plane, int64_t stride, const int32_t* off, void* dst, int n, void* stream);
+/* transpose_t (primitives.h:158, pixel.cpp:485): n size x size blocks -> dense transposed blocks */
+int x265hip_transpose_batch(int depth, int size, const void* plane, int64_t stride, const int32_t* off, void* dst, int n, void* stream);
+
 /* ---------------------------------------------------------------- intra prediction + lookahead lowres ------- */
 /* The L-shaped neighbour line of an N x N block is x265's array: line[0] = top-left, line[1..2N] = top + top-right,
  * line[2N+1..4N] = left + bottom-left (Predict::initAdiPattern, predict.cpp; intrapred.cpp).  N = 4, 8, 16, 32.
@@ -418,6 +433,12 @@ int x265hip_call_denoise_dct(int16_t* dctCoef, uint32_t* resSum, const uint16_t*
 int x265hip_call_rdoq_cost(int kind, int size, int depth, const int16_t* resiDct, const int16_t* fencDct, int64_t* costUncoded,
                            int64_t* totalUncoded, int64_t* totalRd, const int64_t* psyScale, uint32_t blkPos);
 
+int x265hip_call_var(int depth, int size, const void* pix, int64_t stride, uint64_t* result);
+int x265hip_call_weight_pp(int depth, const void* src, void* dst, int64_t stride, int width, int height, int w0, int round, int shift, int offset);
+int x265hip_call_weight_sp(int depth, const int16_t* src, void* dst, int64_t srcStride, int64_t dstStride, int width, int height, int w0, int round, int shift, int offset);
+int x265hip_call_scale1d_128to64(int depth, void* dst, const void* src);
+int x265hip_call_scale2d_64to32(int depth, void* dst, const void* src, int64_t stride);
+int x265hip_call_transpose(int depth, int size, void* dst, const void* src, int64_t stride);
 int x265hip_call_intra_pred(int depth, int n, int mode, int bFilter, void* dst, int64_t dstStride, const void* line);
 int x265hip_call_intra_allangs(int depth, int n, void* dest, const void* line, const void* filtered, int bLuma);
 int x265hip_call_intra_filter(int depth, int n, const void* line, void* filtered);

@@ -71,6 +71,11 @@ def oracle():
         f("orc_sse_pp", u64, [vp, ip, vp, ip, i32, i32])
         f("orc_psy_cost_pp", i32, [vp, ip, vp, ip, i32])
         f("orc_var", u64, [vp, ip, i32])
+        f("orc_weight_pp", None, [vp, vp, ip, i32, i32, i32, i32, i32, i32, i32])
+        f("orc_weight_sp", None, [vp, vp, ip, ip, i32, i32, i32, i32, i32, i32, i32])
+        f("orc_scale1d_128to64", None, [vp, vp])
+        f("orc_scale2d_64to32", None, [vp, vp, ip])
+        f("orc_transpose", None, [vp, vp, ip, i32])
         f("orc_sub_ps", None, [vp, ip, vp, vp, ip, ip, i32, i32])
         f("orc_add_ps", None, [vp, ip, vp, vp, ip, ip, i32, i32, i32])
         f("orc_calcresidual", None, [vp, vp, vp, ip, i32])
@@ -167,6 +172,11 @@ def ref(depth):
     g("ref_ssd_s", u64, [i32, vp, ip])
     g("ref_psy_cost_pp", i32, [i32, vp, ip, vp, ip])
     g("ref_var", u64, [i32, vp, ip])
+    g("ref_weight_pp", None, [vp, vp, ip, i32, i32, i32, i32, i32, i32])
+    g("ref_weight_sp", None, [vp, vp, ip, ip, i32, i32, i32, i32, i32, i32])
+    g("ref_scale1d_128to64", None, [vp, vp])
+    g("ref_scale2d_64to32", None, [vp, vp, ip])
+    g("ref_transpose", None, [i32, vp, vp, ip])
     g("ref_sub_ps", None, [i32, vp, ip, vp, vp, ip, ip])
     g("ref_add_ps", None, [i32, vp, ip, vp, vp, ip, ip])
     g("ref_calcresidual", None, [i32, vp, vp, vp, ip])

@@ -69,6 +69,11 @@ uint64_t ref_sse_ss(int cu, const int16_t* a, intptr_t sa, const int16_t* b, int
 uint64_t ref_ssd_s(int cu, const int16_t* a, intptr_t sa) { return T().cu[cu].ssd_s[NONALIGNED](a, sa); }
 int ref_psy_cost_pp(int cu, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb) { return T().cu[cu].psy_cost_pp(a, sa, b, sb); }
 uint64_t ref_var(int cu, const pixel* a, intptr_t sa) { return T().cu[cu].var(a, sa); }
+void ref_weight_pp(const pixel* s, pixel* d, intptr_t stride, int w, int h, int w0, int round, int shift, int offset) { T().weight_pp(s, d, stride, w, h, w0, round, shift, offset); }
+void ref_weight_sp(const int16_t* s, pixel* d, intptr_t ss, intptr_t ds, int w, int h, int w0, int round, int shift, int offset) { T().weight_sp(s, d, ss, ds, w, h, w0, round, shift, offset); }
+void ref_scale1d_128to64(pixel* d, const pixel* s) { T().scale1D_128to64[NONALIGNED](d, s); }
+void ref_scale2d_64to32(pixel* d, const pixel* s, intptr_t stride) { T().scale2D_64to32(d, s, stride); }
+void ref_transpose(int cu, pixel* d, const pixel* s, intptr_t stride) { T().cu[cu].transpose(d, s, stride); }
 
 /* ---- block arithmetic / copies ---- */
 void ref_sub_ps(int cu, int16_t* d, intptr_t ds, const pixel* a, const pixel* b, intptr_t sa, intptr_t sb) { T().cu[cu].sub_ps(d, ds, a, b, sa, sb); }

@@ -43,6 +43,13 @@ uint64_t orc_sse_pp_##SFX(const P* a, intptr_t sa, const P* b, intptr_t sb, int 
 int orc_psy_cost_pp_##SFX(const P* src, intptr_t ss, const P* rec, intptr_t rs, int dim); \
 /* common/pixel.cpp:704 pixel_var<size> */ \
 uint64_t orc_var_##SFX(const P* p, intptr_t s, int size); \
+/* common/pixel.cpp:518 weight_pp_c, :493 weight_sp_c */ \
+void orc_weight_pp_##SFX(const P* src, P* dst, intptr_t stride, int width, int height, int w0, int round, int shift, int offset, int depth); \
+void orc_weight_sp_##SFX(const int16_t* src, P* dst, intptr_t ss, intptr_t ds, int width, int height, int w0, int round, int shift, int offset, int depth); \
+/* common/pixel.cpp:559 scale1D_128to64, :585 scale2D_64to32, :485 transpose<size> */ \
+void orc_scale1d_128to64_##SFX(P* dst, const P* src); \
+void orc_scale2d_64to32_##SFX(P* dst, const P* src, intptr_t stride); \
+void orc_transpose_##SFX(P* dst, const P* src, intptr_t stride, int size); \
 /* common/pixel.cpp:815 pixel_sub_ps_c */ \
 void orc_sub_ps_##SFX(int16_t* d, intptr_t ds, const P* a, const P* b, intptr_t sa, intptr_t sb, int w, int h); \
 /* common/pixel.cpp:829 pixel_add_ps_c */ \

@@ -362,6 +362,32 @@ class Orc(_Base):
         fn(r0, r1, ref0[0].shape[1], ref0[1].shape[1], bx, by, w, h, ptr(a0), ptr(a1), ptr(y), w, ptr(cb), ptr(cr), w // 2, self.depth)
         return y, cb, cr
 
+    # ---- weighted prediction, downscales, transpose
+    def weight_pp(self, a, ao, w, h, w0, rnd, shift, offset):
+        d = np.zeros_like(a)
+        self._f("orc_weight_pp")(ptr(a, *ao), ptr(d, *ao), a.shape[1], w, h, w0, rnd, shift, offset, self.depth)
+        return np.ascontiguousarray(d[ao[0]:ao[0] + h, ao[1]:ao[1] + w])
+
+    def weight_sp(self, a, ao, w, h, w0, rnd, shift, offset):
+        d = np.zeros((h, w), self.pix)
+        self._f("orc_weight_sp")(ptr(a, *ao), ptr(d), a.shape[1], w, w, h, w0, rnd, shift, offset, self.depth)
+        return d
+
+    def scale1d_128to64(self, line):
+        d = np.zeros(128, self.pix)
+        self._f("orc_scale1d_128to64")(ptr(d), ptr(line))
+        return d
+
+    def scale2d_64to32(self, a, ao):
+        d = np.zeros((32, 32), self.pix)
+        self._f("orc_scale2d_64to32")(ptr(d), ptr(a, *ao), a.shape[1])
+        return d
+
+    def transpose(self, size, a, ao):
+        d = np.zeros((size, size), self.pix)
+        self._f("orc_transpose")(ptr(d), ptr(a, *ao), a.shape[1], size)
+        return d
+
 
 class Ref(_Base):
     name = "reference"
@@ -649,6 +675,32 @@ class Ref(_Base):
         self.L.ref_pred_inter_bi(ptr(ref0[0]), ptr(ref0[1]), ptr(ref0[2]), ptr(ref1[0]), ptr(ref1[1]), ptr(ref1[2]), ref0[0].shape[1],
                                  ref0[1].shape[1], bx, by, w, h, ptr(a0), ptr(a1), ptr(y), ptr(cb), ptr(cr))
         return y, cb, cr
+
+    # ---- weighted prediction, downscales, transpose
+    def weight_pp(self, a, ao, w, h, w0, rnd, shift, offset):
+        d = np.zeros_like(a)
+        self.L.ref_weight_pp(ptr(a, *ao), ptr(d, *ao), a.shape[1], w, h, w0, rnd, shift, offset)
+        return np.ascontiguousarray(d[ao[0]:ao[0] + h, ao[1]:ao[1] + w])
+
+    def weight_sp(self, a, ao, w, h, w0, rnd, shift, offset):
+        d = np.zeros((h, w), self.pix)
+        self.L.ref_weight_sp(ptr(a, *ao), ptr(d), a.shape[1], w, w, h, w0, rnd, shift, offset)
+        return d
+
+    def scale1d_128to64(self, line):
+        d = np.zeros(128, self.pix)
+        self.L.ref_scale1d_128to64(ptr(d), ptr(line))
+        return d
+
+    def scale2d_64to32(self, a, ao):
+        d = np.zeros((32, 32), self.pix)
+        self.L.ref_scale2d_64to32(ptr(d), ptr(a, *ao), a.shape[1])
+        return d
+
+    def transpose(self, size, a, ao):
+        d = np.zeros((size, size), self.pix)
+        self.L.ref_transpose(cu_of(size), ptr(d), ptr(a, *ao), a.shape[1])
+        return d
 
 
 def same(x, y):

@@ -170,6 +170,25 @@ def gen_cases(depth, seed=1234, reps=2):
         yield ("frame_init_lowres %s" % mode, "frame_init_lowres", (src, (2, 1), 40, 33))
 
 
+    # weighted prediction (pixelharness.cpp check_weightp / check_weightpUni: w0 in [0, 127], shift includes the 14-bit correction),
+    # the 64x64 intra-scan downscales and transposes — appended last like the intra cases
+    for mode in ["rand"] * reps + ["min", "max"]:
+        p = pix_buf(rng, mode, (S + 80, S), depth)
+        sh = short_buf(rng, mode, (S + 80, S), -8192, 8191)
+        corr = 14 - depth
+        for (w, h) in ((16, 16), (64, 24), (48, 64), (32, 7)):
+            ao = origin(room=64)
+            w0, shift, offset = int(rng.integers(1, 128)), int(rng.integers(0, 7)) + corr, int(rng.integers(-20, 21)) * (1 << (depth - 8))
+            rnd = (1 << (shift - 1)) if shift else 0
+            yield ("weight_pp %dx%d %s" % (w, h, mode), "weight_pp", (p, ao, w, h, w0, rnd, shift, offset))
+            yield ("weight_sp %dx%d %s" % (w, h, mode), "weight_sp", (sh, ao, w, h, w0, rnd, shift, offset))
+        yield ("scale1D %s" % mode, "scale1d_128to64", (pix_buf(rng, mode, (256,), depth),))
+        big = pix_buf(rng, mode, (S + 80, S), depth)
+        yield ("scale2D %s" % mode, "scale2d_64to32", (big, origin(room=64)))
+        for size in (4, 8, 16, 32, 64):
+            yield ("transpose %d %s" % (size, mode), "transpose", (size, big, origin(room=64)))
+
+
 def textured_frame(rng, h, w, depth, sigma=3.0):
     """Low-pass random texture + noise: SADs then have a meaningful minimum (BASELINE.md §3 generator, scaled down)."""
     pmax = (1 << depth) - 1

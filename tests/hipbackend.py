@@ -501,3 +501,37 @@ class Hip:
         y, cb, cr = self.pred_inter_bi_batch(ref0, ref1, w, h, [(bx, by)], [mv0], [mv1])
         return (np.ascontiguousarray(y[by:by + h, bx:bx + w]), np.ascontiguousarray(cb[by // 2:by // 2 + h // 2, bx // 2:bx // 2 + w // 2]),
                 np.ascontiguousarray(cr[by // 2:by // 2 + h // 2, bx // 2:bx // 2 + w // 2]))
+
+    # ---- small primitives: var, weighted prediction, downscales, transpose
+    def var(self, size, a, ao):
+        da = DevBuf(a)
+        out = DevBuf.zeros((1,), np.uint64)
+        check(self.L.x265hip_var_batch(self.depth, size, da.ptr, a.shape[1], _ip([_off(a, ao)]), 1, out.ptr, None))
+        return int(out.get()[0])
+
+    def weight_pp(self, a, ao, w, h, w0, rnd, shift, offset):
+        da, dd = DevBuf(a), DevBuf.zeros(a.shape, self.pix)
+        o = _off(a, ao)
+        check(self.L.x265hip_weight_pp(self.depth, da.at(o), dd.at(o), a.shape[1], w, h, w0, rnd, shift, offset, None))
+        d = dd.get()
+        return np.ascontiguousarray(d[ao[0]:ao[0] + h, ao[1]:ao[1] + w])
+
+    def weight_sp(self, a, ao, w, h, w0, rnd, shift, offset):
+        da, dd = DevBuf(a), DevBuf.zeros((h, w), self.pix)
+        check(self.L.x265hip_weight_sp(self.depth, da.at(_off(a, ao)), dd.ptr, a.shape[1], w, w, h, w0, rnd, shift, offset, None))
+        return dd.get()
+
+    def scale1d_128to64(self, line):
+        ds, dd = DevBuf(line), DevBuf.zeros((128,), self.pix)
+        check(self.L.x265hip_scale1d_128to64_batch(self.depth, ds.ptr, dd.ptr, 1, None))
+        return dd.get()
+
+    def scale2d_64to32(self, a, ao):
+        da, dd = DevBuf(a), DevBuf.zeros((32, 32), self.pix)
+        check(self.L.x265hip_scale2d_64to32_batch(self.depth, da.ptr, a.shape[1], _ip([_off(a, ao)]), dd.ptr, 1, None))
+        return dd.get()
+
+    def transpose(self, size, a, ao):
+        da, dd = DevBuf(a), DevBuf.zeros((size, size), self.pix)
+        check(self.L.x265hip_transpose_batch(self.depth, size, da.ptr, a.shape[1], _ip([_off(a, ao)]), dd.ptr, 1, None))
+        return dd.get()

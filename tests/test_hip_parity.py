@@ -16,7 +16,7 @@ from cases import gen_cases, me_scene, pix_buf, short_buf
 pytestmark = pytest.mark.gpu
 
 DEPTHS = [8, 10]
-NOT_ON_GPU = {"var"}     # pixel_var is lookahead / AQ material, not on the §8 path
+NOT_ON_GPU = set()        # every primitive of tests/cases.py has a HIP entry point
 
 
 @pytest.fixture(scope="module")

@@ -556,4 +556,96 @@ int x265hip_call_frame_init_lowres(int depth, const void* src, int64_t srcStride
     return X265HIP_OK;
 }
 
+// var_t (primitives.h:173)
+int x265hip_call_var(int depth, int size, const void* pix, int64_t stride, uint64_t* result)
+{
+    const int B = depth == 8 ? 1 : 2;
+    const size_t nb = (size_t)size * size * B;
+    PC_BEGIN(nb + 64);
+    const size_t oJ = carve(4 * sizeof(int32_t)), oP = carve(nb), oR = carve(8);
+    hostp<int32_t>(oJ)[0] = 0;
+    pack_rows(hostp<char>(oP), pix, stride, size, size, B);
+    PC_TRY(upload());
+    PC_TRY(x265hip_var_batch(depth, size, devp<char>(oP), size, devp<int32_t>(oJ), 1, devp<uint64_t>(oR), t_st.stream));
+    PC_TRY(download(oR, 8));
+    *result = *hostp<uint64_t>(oR);
+    return X265HIP_OK;
+}
+
+// weightp_pp_t (primitives.h:164): src and dst share one stride
+int x265hip_call_weight_pp(int depth, const void* src, void* dst, int64_t stride, int width, int height, int w0, int round, int shift, int offset)
+{
+    const int B = depth == 8 ? 1 : 2;
+    const size_t nb = (size_t)width * height * B;
+    PC_BEGIN(2 * nb + 64);
+    const size_t oS = carve(nb), oD = carve(nb);
+    pack_rows(hostp<char>(oS), src, stride, width, height, B);
+    PC_TRY(upload());
+    // dense staging: source and destination both at pitch `width` (the slot has one stride for both)
+    PC_TRY(x265hip_weight_pp(depth, devp<char>(oS), devp<char>(oD), width, width, height, w0, round, shift, offset, t_st.stream));
+    PC_TRY(download(oD, nb));
+    unpack_rows(dst, stride, hostp<char>(oD), width, height, B);
+    return X265HIP_OK;
+}
+
+// weightp_sp_t (primitives.h:165)
+int x265hip_call_weight_sp(int depth, const int16_t* src, void* dst, int64_t srcStride, int64_t dstStride, int width, int height, int w0, int round, int shift, int offset)
+{
+    const int B = depth == 8 ? 1 : 2;
+    const size_t ns = (size_t)width * height * 2, nd = (size_t)width * height * B;
+    PC_BEGIN(ns + nd + 64);
+    const size_t oS = carve(ns), oD = carve(nd);
+    pack_rows(hostp<char>(oS), src, srcStride, width, height, 2);
+    PC_TRY(upload());
+    PC_TRY(x265hip_weight_sp(depth, devp<int16_t>(oS), devp<char>(oD), width, width, width, height, w0, round, shift, offset, t_st.stream));
+    PC_TRY(download(oD, nd));
+    unpack_rows(dst, dstStride, hostp<char>(oD), width, height, B);
+    return X265HIP_OK;
+}
+
+// scale1D_t (primitives.h:166): 256 samples in, 128 out
+int x265hip_call_scale1d_128to64(int depth, void* dst, const void* src)
+{
+    const int B = depth == 8 ? 1 : 2;
+    PC_BEGIN((size_t)384 * B + 64);
+    const size_t oS = carve(256 * B), oD = carve(128 * B);
+    memcpy(hostp<char>(oS), src, 256 * B);
+    PC_TRY(upload());
+    PC_TRY(x265hip_scale1d_128to64_batch(depth, devp<char>(oS), devp<char>(oD), 1, t_st.stream));
+    PC_TRY(download(oD, 128 * B));
+    memcpy(dst, hostp<char>(oD), 128 * B);
+    return X265HIP_OK;
+}
+
+// scale2D_t (primitives.h:167): 64x64 at `stride` in, dense 32x32 out
+int x265hip_call_scale2d_64to32(int depth, void* dst, const void* src, int64_t stride)
+{
+    const int B = depth == 8 ? 1 : 2;
+    PC_BEGIN((size_t)(4096 + 1024) * B + 64);
+    const size_t oJ = carve(4 * sizeof(int32_t)), oS = carve(4096 * B), oD = carve(1024 * B);
+    hostp<int32_t>(oJ)[0] = 0;
+    pack_rows(hostp<char>(oS), src, stride, 64, 64, B);
+    PC_TRY(upload());
+    PC_TRY(x265hip_scale2d_64to32_batch(depth, devp<char>(oS), 64, devp<int32_t>(oJ), devp<char>(oD), 1, t_st.stream));
+    PC_TRY(download(oD, 1024 * B));
+    memcpy(dst, hostp<char>(oD), 1024 * B);
+    return X265HIP_OK;
+}
+
+// transpose_t (primitives.h:158)
+int x265hip_call_transpose(int depth, int size, void* dst, const void* src, int64_t stride)
+{
+    const int B = depth == 8 ? 1 : 2;
+    const size_t nb = (size_t)size * size * B;
+    PC_BEGIN(2 * nb + 64);
+    const size_t oJ = carve(4 * sizeof(int32_t)), oS = carve(nb), oD = carve(nb);
+    hostp<int32_t>(oJ)[0] = 0;
+    pack_rows(hostp<char>(oS), src, stride, size, size, B);
+    PC_TRY(upload());
+    PC_TRY(x265hip_transpose_batch(depth, size, devp<char>(oS), size, devp<int32_t>(oJ), devp<char>(oD), 1, t_st.stream));
+    PC_TRY(download(oD, nb));
+    memcpy(dst, hostp<char>(oD), nb);
+    return X265HIP_OK;
+}
+
 } // extern "C"

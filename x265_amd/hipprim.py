@@ -100,6 +100,18 @@ PROTOTYPES = {
     "x265hip_call_blockfill_s": (i32, [i32, vp, i64, C.c_int16]),
     "x265hip_call_denoise_dct": (i32, [vp, vp, vp, i32]),
     "x265hip_call_rdoq_cost": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, u32]),
+    "x265hip_var_batch": (i32, [i32, i32, vp, i64, vp, i32, vp, vp]),
+    "x265hip_weight_pp": (i32, [i32, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
+    "x265hip_weight_sp": (i32, [i32, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, vp]),
+    "x265hip_scale1d_128to64_batch": (i32, [i32, vp, vp, i32, vp]),
+    "x265hip_scale2d_64to32_batch": (i32, [i32, vp, i64, vp, vp, i32, vp]),
+    "x265hip_transpose_batch": (i32, [i32, i32, vp, i64, vp, vp, i32, vp]),
+    "x265hip_call_var": (i32, [i32, i32, vp, i64, vp]),
+    "x265hip_call_weight_pp": (i32, [i32, vp, vp, i64, i32, i32, i32, i32, i32, i32]),
+    "x265hip_call_weight_sp": (i32, [i32, vp, vp, i64, i64, i32, i32, i32, i32, i32, i32]),
+    "x265hip_call_scale1d_128to64": (i32, [i32, vp, vp]),
+    "x265hip_call_scale2d_64to32": (i32, [i32, vp, vp, i64]),
+    "x265hip_call_transpose": (i32, [i32, i32, vp, vp, i64]),
     "x265hip_intra_pred_batch": (i32, [i32, i32, vp, vp, vp, vp, vp, i64, i32, vp]),
     "x265hip_intra_allangs_batch": (i32, [i32, i32, vp, vp, vp, i32, vp, i32, vp]),
     "x265hip_intra_filter_batch": (i32, [i32, i32, vp, vp, vp, vp, i32, vp]),

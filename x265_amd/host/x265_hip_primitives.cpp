@@ -391,6 +391,39 @@ static void frame_init_lowres_hip(const pixel* src, pixel* d0, pixel* dh, pixel*
         p.cu[cu].intra_filter = intra_filter_hip<N, BLOCK_ ## N ## x ## N>; \
     } while (0)
 
+/* ---- small primitives around the path: var, explicit weighting, the 64x64 intra-scan downscales, transpose ---- */
+template <int N, int CU> static uint64_t var_hip(const pixel* pix, intptr_t stride)
+{
+    uint64_t r = 0;
+    if (x265hip_call_var(X265_DEPTH, N, pix, stride, &r)) return g_c.cu[CU].var(pix, stride);
+    return r;
+}
+template <int N, int CU> static void transpose_hip(pixel* dst, const pixel* src, intptr_t stride)
+{
+    if (x265hip_call_transpose(X265_DEPTH, N, dst, src, stride)) g_c.cu[CU].transpose(dst, src, stride);
+}
+static void weight_pp_hip(const pixel* src, pixel* dst, intptr_t stride, int width, int height, int w0, int round, int shift, int offset)
+{
+    if (x265hip_call_weight_pp(X265_DEPTH, src, dst, stride, width, height, w0, round, shift, offset)) g_c.weight_pp(src, dst, stride, width, height, w0, round, shift, offset);
+}
+static void weight_sp_hip(const int16_t* src, pixel* dst, intptr_t ss, intptr_t ds, int width, int height, int w0, int round, int shift, int offset)
+{
+    if (x265hip_call_weight_sp(X265_DEPTH, src, dst, ss, ds, width, height, w0, round, shift, offset)) g_c.weight_sp(src, dst, ss, ds, width, height, w0, round, shift, offset);
+}
+static void scale1d_hip(pixel* dst, const pixel* src)
+{
+    if (x265hip_call_scale1d_128to64(X265_DEPTH, dst, src)) g_c.scale1D_128to64[NONALIGNED](dst, src);
+}
+static void scale2d_hip(pixel* dst, const pixel* src, intptr_t stride)
+{
+    if (x265hip_call_scale2d_64to32(X265_DEPTH, dst, src, stride)) g_c.scale2D_64to32(dst, src, stride);
+}
+
+#define HIP_SMALL(N) do { \
+        p.cu[BLOCK_ ## N ## x ## N].var = var_hip<N, BLOCK_ ## N ## x ## N>; \
+        p.cu[BLOCK_ ## N ## x ## N].transpose = transpose_hip<N, BLOCK_ ## N ## x ## N>; \
+    } while (0)
+
 static void report_calls()
 {
     fprintf(stderr, "x265hip: %llu primitive calls served by the GPU\n", x265hip_call_count());
@@ -439,6 +472,13 @@ void setupAssemblyPrimitives(EncoderPrimitives& p, int /* cpuMask: CPU ISA bits,
     p.denoiseDct = denoise_hip;
     HIP_INTRA(4); HIP_INTRA(8); HIP_INTRA(16); HIP_INTRA(32);
     p.frameInitLowres = frame_init_lowres_hip;
+    HIP_SMALL(8); HIP_SMALL(16); HIP_SMALL(32); HIP_SMALL(64);
+    p.cu[BLOCK_4x4].transpose = transpose_hip<4, BLOCK_4x4>;
+    p.weight_pp = weight_pp_hip;
+    p.weight_sp = weight_sp_hip;
+    p.scale1D_128to64[NONALIGNED] = scale1d_hip;
+    p.scale1D_128to64[ALIGNED] = scale1d_hip;
+    p.scale2D_64to32 = scale2d_hip;
 }
 
 } // namespace X265_NS
