@@ -74,8 +74,9 @@ struct LaCtx
         const int ia = (qy & 2) | ((qx & 2) >> 1);
         const int rx = qx + (qx & 1), ry = qy + (qy & 1);
         const int ib = (ry & 2) | ((rx & 2) >> 1);
-        const P* a = ref0 + ia * planeElems + (qy >> 2) * stride + (qx >> 2);
-        const P* b = ref0 + ib * planeElems + (ry >> 2) * stride + (rx >> 2);
+        // 24-bit full-rate multiplies (lowres planes are far below 2^24 elements, strides below 2^23: checked at the entry point)
+        const P* a = ref0 + (__umul24(ia, (int)planeElems) + __mul24(qy >> 2, stride) + (qx >> 2));
+        const P* b = ref0 + (__umul24(ib, (int)planeElems) + __mul24(ry >> 2, stride) + (rx >> 2));
         return LaPk<P>::avg(ld_unaligned<Q>(a), ld_unaligned<Q>(b));
     }
     __device__ __forceinline__ int sad(int qx, int qy) const { return la_row_allsum((int)LaPk<P>::sad(fetch(qx, qy), fq)); }
@@ -492,6 +493,7 @@ extern "C" int x265hip_lookahead_cost_p_batch(int depth, const x265hip_lookahead
 {
     XH_CHECK_DEV();
     if (!valid_depth(depth) || nPairs < 0 || widthInCU < 1 || heightInCU < 1 || numSlices < 1 || numRowsPerSlice < 1 || epoch == 0 ||
+        stride >= (1 << 23) || planeElems >= (1 << 22) || planeElems < 0 ||
         (long long)numRowsPerSlice * (numSlices - 1) >= heightInCU)
         return set_error(X265HIP_EINVAL, "lookahead_cost_p_batch: depth %d pairs %d grid %dx%d slices %d x %d rows epoch %u", depth, nPairs, widthInCU,
                          heightInCU, numSlices, numRowsPerSlice, epoch);
@@ -514,7 +516,7 @@ extern "C" int x265hip_lookahead_bidir_batch(int depth, const x265hip_lookahead_
                                              int widthInCU, int heightInCU, int32_t* costEst, void* stream)
 {
     XH_CHECK_DEV();
-    if (!valid_depth(depth) || nFrames < 0 || widthInCU < 1 || heightInCU < 1)
+    if (!valid_depth(depth) || nFrames < 0 || widthInCU < 1 || heightInCU < 1 || stride >= (1 << 23) || planeElems >= (1 << 22) || planeElems < 0)
         return set_error(X265HIP_EINVAL, "lookahead_bidir_batch: depth %d frames %d grid %dx%d", depth, nFrames, widthInCU, heightInCU);
     if (nFrames == 0) return X265HIP_OK;
     int e = check_hip(hipMemsetAsync(costEst, 0, (size_t)nFrames * sizeof(int32_t), as_stream(stream)), "lookahead memset");

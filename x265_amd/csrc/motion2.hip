@@ -243,8 +243,13 @@ struct Team
     __device__ __forceinline__ const P* cand_ptr(Mv2 m) const
     {
         if (QPEL)
-            return plane0 + (int64_t)((m.y & 3) * 4 + (m.x & 3)) * planeElems + (int64_t)(m.y >> 2) * stride + (m.x >> 2);
-        return fref + (int64_t)m.y * stride + m.x;
+        {
+            // 24-bit full-rate multiplies on the candidate chain (stride < 2^23 is checked at dispatch; planes below 2^24 elements up to 4K)
+            const int ph = (m.y & 3) * 4 + (m.x & 3);
+            const int64_t po = planeElems < (1 << 24) ? (int64_t)__umul24(ph, (int)planeElems) : (int64_t)ph * planeElems;
+            return plane0 + po + (__mul24(m.y >> 2, (int)stride) + (m.x >> 2));
+        }
+        return fref + (__mul24(m.y, (int)stride) + m.x);
     }
 
     // combine K per-wave values (valid in lane 63 of each wave) over the team; every thread gets the K totals
@@ -305,7 +310,7 @@ struct Team
                 for (int j = 0; j < IPT; j++)
                 {
                     const int q = tid + j * GS, row = q / QX, c4 = (q % QX) * 4;
-                    acc[k] = Pk<P>::sad(ld_unaligned<Q>(r + (int64_t)row * stride + c4), fq[j], acc[k]);
+                    acc[k] = Pk<P>::sad(ld_unaligned<Q>(r + (__mul24(row, (int)stride) + c4)), fq[j], acc[k]);
                 }
             }
 #pragma unroll
@@ -917,7 +922,7 @@ int motion2_dispatch(int depth, int w, int h, const void* fencPlane, int64_t str
         return 1;
     DeriveRange dr{};
     if (drp) dr = *drp;
-    if (w != h || !(w == 8 || w == 16 || w == 32 || w == 64))
+    if (w != h || !(w == 8 || w == 16 || w == 32 || w == 64) || strideR >= (1 << 23))
         return 0;
 #define M2(P, N, WV) *rc = launch_motion2<P, N, WV>(fencPlane, strideF, refPlane, strideR, pu_xy, mvmin, mvmax, qmvp, numCand, mvc, merange, \
                                                     method, subme, mvcost, depth, n, planes, planeElems, dr, outMv, outCost, st)

@@ -80,6 +80,7 @@ struct RowTeam
     static constexpr int TX = N / 4;                   // tiles per row
     const P* plane0;                                   // phase plane 0 at the PU origin
     int64_t planeElems;
+    bool smallPlane;                                   // planeElems < 2^24: the phase offset fits a 24-bit multiply
     int stride;
     const uint16_t* cost;
     Mv3 qmvp;
@@ -99,7 +100,11 @@ struct RowTeam
 
     __device__ __forceinline__ const P* cand(Mv3 q) const
     {
-        return plane0 + (int64_t)((q.y & 3) * 4 + (q.x & 3)) * planeElems + (q.y >> 2) * stride + (q.x >> 2);
+        // full-rate 24-bit multiplies instead of v_mul_lo_u32 / v_mad_u64_u32 (quarter rate) on the candidate chain: the stride is below
+        // 2^23 (checked at dispatch), the phase index is 0..15 and the plane size is below 2^24 elements up to 4K (smallPlane)
+        const int ph = (q.y & 3) * 4 + (q.x & 3);
+        const int64_t po = smallPlane ? (int64_t)__umul24(ph, (int)planeElems) : (int64_t)ph * planeElems;
+        return plane0 + po + (__mul24(q.y >> 2, stride) + (q.x >> 2));
     }
     // subpelCompare(..., sad) (motion.cpp:1571) / sad() of the block at quarter-pel vector q, WITHOUT mv cost
     __device__ __forceinline__ int sad_q(Mv3 q) const
@@ -174,7 +179,7 @@ struct RowTeam
 #pragma unroll
         for (int k = 0; k < K; k++)
         {
-            const P* r = plane0 + my[k] * stride + mx[k];
+            const P* r = plane0 + (__mul24(my[k], stride) + mx[k]);
             acc[k] = 0;
 #pragma unroll
             for (int j = 0; j < IPT; j++)
@@ -218,6 +223,7 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
     c.s = threadIdx.x & (TEAM - 1);
     c.stride = (int)strideR;
     c.planeElems = planeElems;
+    c.smallPlane = planeElems < (1 << 24);
     c.cost = mvcostTab;
     // XCD-aware block order (see motion2.hip): XCD x works on the x-th contiguous eighth of the raster-ordered PU list
     const int chunk = gridDim.x >> 3;
@@ -508,7 +514,7 @@ int motion3_dispatch(int depth, int size, const void* fencPlane, int64_t strideF
                      int32_t* outMv, int32_t* outCost, hipStream_t st, int* rc, const ChromaPlanes* cpp)
 {
     // 64x64 stays on the 4-wave team kernel of motion2.hip: one wave per 64x64 PU measured slower (58 vs 38 us per level)
-    if (!planes || (size != 8 && size != 16 && size != 32) || strideR > 0x3fffffff)
+    if (!planes || (size != 8 && size != 16 && size != 32) || strideR >= (1 << 23))
         return 0;
     DeriveRange dr{};
     if (drp) dr = *drp;
