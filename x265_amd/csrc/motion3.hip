@@ -13,6 +13,7 @@
 //   * every candidate, integer or sub-pel, is a block read from the pre-filtered quarter-pel planes
 //     (x265hip_build_subpel_planes; plane 0 is the picture), so the serial chain contains no filtering.
 #include "common.h"
+#include <cstdlib>
 #include "searchrange.h"
 #include "mestar.h"
 #include "filters.h"
@@ -66,6 +67,14 @@ __device__ __forceinline__ int sq1yC(int i) { return (int)((0x979788978ull >> (4
 template <int TEAM>
 __device__ __forceinline__ int team_allsum(int v)
 {
+    if (TEAM == 8)
+    {
+        // eight lanes = half a DPP row: butterflies inside the quad, then the mirrored half (lane i <-> 7 - i sits in the other quad)
+        v += dpp_all<0xB1>(v);          // quad_perm [1,0,3,2]
+        v += dpp_all<0x4E>(v);          // quad_perm [2,3,0,1]
+        v += dpp_all<0x141>(v);         // row_half_mirror
+        return v;
+    }
     v = row_allsum(v);
     if (TEAM == 64)
         v = __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
@@ -518,7 +527,10 @@ int motion3_dispatch(int depth, int size, const void* fencPlane, int64_t strideF
         return 0;
     DeriveRange dr{};
     if (drp) dr = *drp;
-    const int tpb = size <= 16 ? 16 : 4;                     // 16-lane teams for 8x8 / 16x16, one wave per PU for 32x32 / 64x64
+    // 8x8: eight PUs per wave (8-lane teams, a lane = two quads: all per-candidate control and address work is shared by twice as many PUs as
+    // with 16-lane teams); 16x16: four PUs per wave; 32x32: one wave per PU
+    static const bool team16 = getenv("X265HIP_ME8_TEAM16") != nullptr;
+    const int tpb = size == 8 ? (team16 ? 16 : 32) : (size == 16 ? 16 : 4);     // (16x16 on 8-lane teams measured slower: 35 vs 28 us)
     const int blocks = (((n + tpb - 1) / tpb) + 7) & ~7;
     dim3 grid(blocks), block(256);
     ChromaPlanes cpn{};
@@ -527,8 +539,18 @@ int motion3_dispatch(int depth, int size, const void* fencPlane, int64_t strideF
 #define M3C(P, N, TEAM, CH) hipLaunchKernelGGL((motion3_kernel<P, N, TEAM, CH>), grid, block, 0, st, (const P*)fencPlane, strideF, strideR, pu_xy, mvmin, mvmax, qmvp, \
                                     numCand, mvc, merange, method, subme, mvcost, n, (const P*)planes, planeElems, dr, outMv, outCost, cpn, depth)
 #define M3(P, N, TEAM) do { if (chroma) M3C(P, N, TEAM, true); else M3C(P, N, TEAM, false); } while (0)
-    if (depth == 8) { if (size == 8) M3(uint8_t, 8, 16); else if (size == 16) M3(uint8_t, 16, 16); else M3(uint8_t, 32, 64); }
-    else            { if (size == 8) M3(uint16_t, 8, 16); else if (size == 16) M3(uint16_t, 16, 16); else M3(uint16_t, 32, 64); }
+    if (depth == 8)
+    {
+        if (size == 8) { if (team16) M3(uint8_t, 8, 16); else M3(uint8_t, 8, 8); }
+        else if (size == 16) M3(uint8_t, 16, 16);
+        else M3(uint8_t, 32, 64);
+    }
+    else
+    {
+        if (size == 8) { if (team16) M3(uint16_t, 8, 16); else M3(uint16_t, 8, 8); }
+        else if (size == 16) M3(uint16_t, 16, 16);
+        else M3(uint16_t, 32, 64);
+    }
 #undef M3C
 #undef M3
     hipError_t e = hipGetLastError();
