@@ -403,10 +403,16 @@ static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t st
     FP_MARK(8);
     // 4. mode costs
     {
-        Sa8dLevel lv[4];
-        for (int l = 0; l < 4; l++)
-            lv[l] = Sa8dLevel{ fp->cuOff[l], fp->cuOffP[l], fp->sa8d[l], fp->nLevel[l], kCuSize[l] };
-        FP_TRY(sa8d_levels(depth, src, strideS, pred, strideP, lv, 4, as_stream(stream)));
+        static const bool perLevel = getenv("X265HIP_SA8D_LEVELS") != nullptr;       // the first version: one Hadamard pass per CU size
+        if (perLevel)
+        {
+            Sa8dLevel lv[4];
+            for (int l = 0; l < 4; l++)
+                lv[l] = Sa8dLevel{ fp->cuOff[l], fp->cuOffP[l], fp->sa8d[l], fp->nLevel[l], kCuSize[l] };
+            FP_TRY(sa8d_levels(depth, src, strideS, pred, strideP, lv, 4, as_stream(stream)));
+        }
+        else
+            FP_TRY(sa8d_pyramid(depth, src, strideS, pred, strideP, fp->width, fp->height, fp->sa8d, as_stream(stream)));
     }
     FP_MARK(9);
     // 4b. chroma (4:2:0), when the caller passed Cb / Cr planes: predInterChromaPixel from the 8x8 vectors, then the same residual

@@ -10,6 +10,9 @@ struct Sa8dLevel { const int32_t* offA; const int32_t* offB; int32_t* out; int n
 int sa8d_levels(int depth, const void* planeA, int64_t strideA, const void* planeB, int64_t strideB, const Sa8dLevel* levels, int nLevels,
                 hipStream_t st);
 
+// the same four costs (out[l] for CU size 64 >> l, raster order of the complete CUs inside a W x H picture) from one Hadamard pass
+int sa8d_pyramid(int depth, const void* planeA, int64_t strideA, const void* planeB, int64_t strideB, int W, int H, int32_t* const out[4], hipStream_t st);
+
 // Predict::predInterLumaPixel for 8x8 PUs reading the pre-filtered quarter-pel planes (a phase-selected block copy)
 int pred_from_planes(int depth, int size, const void* planes, int64_t planeElems, int64_t strideR, void* dst, int64_t strideD,
                      const int32_t* pu_xy, const int32_t* qmv, int n, hipStream_t st);

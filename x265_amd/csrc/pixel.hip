@@ -580,6 +580,72 @@ int sa8d_levels(int depth, const void* planeA, int64_t strideA, const void* plan
 }
 } // namespace xh
 
+// ---- sa8d pyramid: the four CU sizes' costs from ONE Hadamard pass over the picture (frame pass step 4) ------------------------------
+// cu[].sa8d of a 16x16 block is ((sum of its four raw 8x8 Hadamard sums) + 2) >> 2 and the 32x32 / 64x64 costs are sums of 16x16 costs
+// (pixel.cpp:336-376), so every level derives from the raw 8x8 sums: a lane takes a 4x4 tile, a DPP quad an 8x8, sixteen lanes a 16x16 block.  CU lists are the raster-ordered complete
+// CUs of each size inside the picture (what framepass.hip builds), so indices are computed, not looked up.
+namespace xh {
+template <typename P>
+__global__ __launch_bounds__(256) void sa8d_pyramid_kernel(const P* __restrict__ A, int64_t sA, const P* __restrict__ B, int64_t sB, int W, int H,
+                                                           int32_t* __restrict__ o64, int32_t* __restrict__ o32, int32_t* __restrict__ o16, int32_t* __restrict__ o8)
+{
+    // one wave = one 64x64 region of the 64-aligned grid, four passes of one 32x32 quadrant each (16 lanes = a 16x16 block): the 32 and 64
+    // totals are wave-local sums, so nothing needs zeroing or atomics
+    const int lane = threadIdx.x & 63;
+    const int rw = (W + 63) >> 6, rh = (H + 63) >> 6;
+    const int region = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (region >= rw * rh)
+        return;
+    const int x64 = (region % rw) * 64, y64 = (region / rw) * 64;
+    const int sub = lane & 15, b8 = sub >> 2, q = sub & 3, blk = lane >> 4;
+    int raw8[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++)
+    {
+        const int x16 = x64 + (it & 1) * 32 + (blk & 1) * 16, y16 = y64 + (it >> 1) * 32 + (blk >> 1) * 16;
+        const int x = x16 + (b8 & 1) * 8 + (q & 1) * 4, y = y16 + (b8 >> 1) * 8 + (q >> 1) * 4;
+        int m[16];
+        // tiles past the picture edge read the margins (or, far outside, a clamped position); their sums are dropped below
+        const int cx = x < W ? x : W - 4, cy = y < H ? y : H - 4;
+        tile_diff(A + (int64_t)cy * sA + cx, sA, B + (int64_t)cy * sB + cx, sB, m);
+        hadamard4x4(m);
+        raw8[it] = quad_sa8d_raw(m, lane);
+    }
+    int s64 = 0;
+#pragma unroll
+    for (int it = 0; it < 4; it++)
+    {
+        const int x16 = x64 + (it & 1) * 32 + (blk & 1) * 16, y16 = y64 + (it >> 1) * 32 + (blk >> 1) * 16;
+        const int x8 = x16 + (b8 & 1) * 8, y8 = y16 + (b8 >> 1) * 8;
+        if (q == 0 && x8 + 8 <= W && y8 + 8 <= H)
+            o8[(y8 >> 3) * (W >> 3) + (x8 >> 3)] = (raw8[it] + 2) >> 2;
+        const int s16 = group_sum(q == 0 ? raw8[it] : 0, 16);
+        const int c16 = (s16 + 2) >> 2;
+        if (sub == 0 && x16 + 16 <= W && y16 + 16 <= H)
+            o16[(y16 >> 4) * (W >> 4) + (x16 >> 4)] = c16;
+        const int s32 = __builtin_amdgcn_readlane(c16, 0) + __builtin_amdgcn_readlane(c16, 16) + __builtin_amdgcn_readlane(c16, 32) + __builtin_amdgcn_readlane(c16, 48);
+        const int x32 = x64 + (it & 1) * 32, y32 = y64 + (it >> 1) * 32;
+        if (lane == 0 && x32 + 32 <= W && y32 + 32 <= H)
+            o32[(y32 >> 5) * (W >> 5) + (x32 >> 5)] = s32;
+        s64 += s32;
+    }
+    if (lane == 0 && x64 + 64 <= W && y64 + 64 <= H)
+        o64[(y64 >> 6) * (W >> 6) + (x64 >> 6)] = s64;
+}
+
+int sa8d_pyramid(int depth, const void* planeA, int64_t strideA, const void* planeB, int64_t strideB, int W, int H, int32_t* const out[4], hipStream_t st)
+{
+    const int regions = ((W + 63) >> 6) * ((H + 63) >> 6);
+    dim3 grid((unsigned)((regions + 3) / 4)), block(256);
+    if (depth == 8)
+        hipLaunchKernelGGL((sa8d_pyramid_kernel<uint8_t>), grid, block, 0, st, (const uint8_t*)planeA, strideA, (const uint8_t*)planeB, strideB, W, H, out[0], out[1], out[2], out[3]);
+    else
+        hipLaunchKernelGGL((sa8d_pyramid_kernel<uint16_t>), grid, block, 0, st, (const uint16_t*)planeA, strideA, (const uint16_t*)planeB, strideB, W, H, out[0], out[1], out[2], out[3]);
+    XH_LAUNCH_CHECK("sa8d_pyramid_kernel");
+    return X265HIP_OK;
+}
+} // namespace xh
+
 // ---- border extension of up to four planes (Y, Cb, Cr; the four lowres hpel planes) in one launch (frame pass step 5) -----------------------------------
 namespace xh {
 struct BorderPlanes { void* pic[4]; int64_t stride[4]; int w[4], h[4], mx[4], my[4]; long long first[5]; };
