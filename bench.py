@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=30, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-ref-encoder", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="independent frame passes per GPU per step, each on its own HIP stream (x265 --frame-threads inside one device)")
