@@ -123,6 +123,18 @@ __device__ __constant__ const int8_t kLumaFilter[4][8] = {
 __device__ __constant__ const int8_t kChromaFilter[8][4] = {
     { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 }, { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
 
+// ---- DPP all-reduce over a 16-lane row: the sum lands in all 16 lanes (row_ror:8,4,2,1), no LDS, no readlane -------------------
+template <int CTRL>
+__device__ __forceinline__ int dpp_all(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ int row_allsum(int v)
+{
+    v += dpp_all<0x128>(v);
+    v += dpp_all<0x124>(v);
+    v += dpp_all<0x122>(v);
+    v += dpp_all<0x121>(v);
+    return v;
+}
+
 // filter tap i of phase idx; NT = 8 (luma) or 4 (chroma)
 template <int NT>
 __device__ __forceinline__ int filter_tap(int idx, int i)

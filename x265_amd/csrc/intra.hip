@@ -236,17 +236,6 @@ __global__ __launch_bounds__(256) void lowres_init_kernel(const P* __restrict__ 
 }
 
 // ---- lookahead: intra cost of every 8x8 block of a lowres plane ----------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ int dppi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
-__device__ __forceinline__ int row16_allsum(int v)
-{
-    v += dppi<0x128>(v);
-    v += dppi<0x124>(v);
-    v += dppi<0x122>(v);
-    v += dppi<0x121>(v);
-    return v;
-}
-
 template <typename P>
 __global__ __launch_bounds__(256) void lowres_intra_kernel(const P* __restrict__ plane, int64_t stride, int widthInCU, int heightInCU, int depth,
                                                            int32_t* __restrict__ intraCost, uint8_t* __restrict__ intraMode)
@@ -288,7 +277,7 @@ __global__ __launch_bounds__(256) void lowres_intra_kernel(const P* __restrict__
     int fe[4];
     load4(cur + (int64_t)py * stride + px, fe);
     const bool hi1 = s & 1, hi2 = s & 2;
-    const int dc = (row16_allsum(s < 8 ? (int)raw[s + 1] : (int)raw[-(s - 8 + 1)]) + N) >> 4;
+    const int dc = (row_allsum(s < 8 ? (int)raw[s + 1] : (int)raw[-(s - 8 + 1)]) + N) >> 4;
 
     auto cost_of = [&](int mode) -> int {
         const LdsLine ln{ intra_uses_filtered(N, mode) ? flt : raw };
@@ -311,7 +300,7 @@ __global__ __launch_bounds__(256) void lowres_intra_kernel(const P* __restrict__
             m[i] = hi2 ? pr - m[i] : m[i] + pr;
         }
         // satd 8x8 = four 4x4 tiles, each >> 1 (pixel.cpp:210-297); every tile sum is even, so one shift of the total
-        return row16_allsum(iabs(m[0]) + iabs(m[1]) + iabs(m[2]) + iabs(m[3])) >> 1;
+        return row_allsum(iabs(m[0]) + iabs(m[1]) + iabs(m[2]) + iabs(m[3])) >> 1;
     };
 
     int best = cost_of(1), bestMode = 1;                       // DC first, planar only if strictly cheaper (slicetype.cpp:741-747)

@@ -42,16 +42,6 @@ template <> struct LaPk<uint16_t>
     static __device__ __forceinline__ void unpack(T a, int v[4]) { v[0] = a.x & 0xffff; v[1] = a.x >> 16; v[2] = a.y & 0xffff; v[3] = a.y >> 16; }
 };
 
-template <int CTRL>
-__device__ __forceinline__ int la_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
-__device__ __forceinline__ int la_row_allsum(int v)
-{
-    v += la_dpp<0x128>(v);
-    v += la_dpp<0x124>(v);
-    v += la_dpp<0x122>(v);
-    v += la_dpp<0x121>(v);
-    return v;
-}
 __device__ __forceinline__ int sfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 template <typename P>
@@ -79,7 +69,7 @@ struct LaCtx
         const P* b = ref0 + (__umul24(ib, (int)planeElems) + __mul24(ry >> 2, stride) + (rx >> 2));
         return LaPk<P>::avg(ld_unaligned<Q>(a), ld_unaligned<Q>(b));
     }
-    __device__ __forceinline__ int sad(int qx, int qy) const { return la_row_allsum((int)LaPk<P>::sad(fetch(qx, qy), fq)); }
+    __device__ __forceinline__ int sad(int qx, int qy) const { return row_allsum((int)LaPk<P>::sad(fetch(qx, qy), fq)); }
     __device__ __forceinline__ int satd(int qx, int qy) const { return satd_of(fetch(qx, qy)); }
     // 8x8 SATD of the source block against a predicted block held one packed quad per lane
     __device__ __forceinline__ int satd_of(Q blk) const
@@ -101,7 +91,7 @@ struct LaCtx
             const int pr = __builtin_amdgcn_mov_dpp(m[i], 0x4E, 0xF, 0xF, true);
             m[i] = hi2 ? pr - m[i] : m[i] + pr;
         }
-        return la_row_allsum(iabs(m[0]) + iabs(m[1]) + iabs(m[2]) + iabs(m[3])) >> 1;
+        return row_allsum(iabs(m[0]) + iabs(m[1]) + iabs(m[2]) + iabs(m[3])) >> 1;
     }
     __device__ __forceinline__ int mvcost(int qx, int qy) const { return (int)(uint16_t)(cost[qx - px] + cost[qy - py]); }
 

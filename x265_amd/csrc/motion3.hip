@@ -40,17 +40,7 @@ template <> struct Pk3<uint16_t>
     static __device__ __forceinline__ void unpack(T a, int v[4]) { v[0] = a.x & 0xffff; v[1] = a.x >> 16; v[2] = a.y & 0xffff; v[3] = a.y >> 16; }
 };
 
-template <int CTRL>
-__device__ __forceinline__ int dpp_all(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
-// sum over the 16 lanes of a DPP row, result in every lane (row_ror:8,4,2,1)
-__device__ __forceinline__ int row_allsum(int v)
-{
-    v += dpp_all<0x128>(v);
-    v += dpp_all<0x124>(v);
-    v += dpp_all<0x122>(v);
-    v += dpp_all<0x121>(v);
-    return v;
-}
+// dpp_all / row_allsum (16-lane DPP all-reduce) live in common.h
 
 __device__ __constant__ const uint8_t kWorkloadC[8][5] = { {1,4,0,4,0}, {1,4,1,4,0}, {1,4,1,4,1}, {2,4,1,4,1}, {2,4,2,4,1}, {1,8,1,8,1}, {2,8,1,8,1}, {2,8,2,8,1} }; // motion.cpp:48-58
 
