@@ -193,13 +193,12 @@ def main():
     fps_ = [FramePass(W, H, depth=DEPTH, qp=QP, merange=MERANGE, method=hp.HEX_SEARCH, subme=SUBME) for _ in range(F)]
     fp = fps_[0]
 
-    state = {"refs": [ring.current] + [ref0] * (F - 1), "k": 0}
+    from x265_amd.exchange import FrameChains
+    chains = FrameChains(ring, F, [ring.current] + [ref0] * (F - 1))
 
     def run_pass(h, src, ref, pred, rec, sh):
         a, b, c, d = yuv(src), yuv(ref), yuv(pred), yuv(rec)
         hp.check(L.x265hip_framepass_run_yuv(h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), MARGIN, MARGIN, sh))
-
-    state["last"] = None                  # recon of the last chain of the previous step, still to be handed to the next rank
 
     # Dependencies between the F chains are per picture, tracked with events (no per-step join of all streams):
     #   done[j][k & 1]  chain j finished its pass of step k (its recon is complete)
@@ -207,13 +206,12 @@ def main():
     done = [[torch.cuda.Event(), torch.cuda.Event()] for _ in range(F)]
     got = [torch.cuda.Event(), torch.cuda.Event()]
 
-    def launch(j, k, recs):
+    def launch(j, k, ref):
         src, rec = pool[(k + j) % NPOOL], recons[j][k & 1]
-        recs[j] = rec
         st = streams[j]
         if st is None:                                          # F == 1: everything in order on the current stream
-            run_pass(fps_[j].h, src, state["refs"][j], preds[j], rec, stream)
-            return
+            run_pass(fps_[j].h, src, ref, preds[j], rec, stream)
+            return rec
         p = (k - 1) & 1
         if k == 0:
             st.wait_stream(torch.cuda.current_stream())          # input upload
@@ -226,36 +224,29 @@ def main():
             else:
                 st.wait_event(got[p])
                 st.wait_event(done[0][p])                        # single rank: chain 0 read it in place
-        run_pass(fps_[j].h, src, state["refs"][j], preds[j], rec, st.cuda_stream)
+        run_pass(fps_[j].h, src, ref, preds[j], rec, st.cuda_stream)
         done[j][k & 1].record(st)
+        return rec
+
+    def before_exchange(k):
+        # the transfer reads the last chain's reconstruction of step k-1 and refills the inbox chain 0 read at step k-2
+        if streams[0] is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(done[F - 1][(k - 1) & 1])
+            if k >= 2:
+                cur.wait_event(done[0][k & 1])
+
+    def after_exchange(k):
+        got[k & 1].record(torch.cuda.current_stream())
 
     def step():
-        # reconstructed-reference hand-over: chain j+1 takes chain j's recon of the previous step (same device, pointer swap); the
-        # last chain's recon goes to chain 0 of rank+1 through the RCCL send/recv ring (at N = 1 it wraps around locally).  The
-        # transfer is started first and only chain 0 waits for it: chains 1..F-1 run on their own streams meanwhile.
-        k = state["k"]
-        cur = torch.cuda.current_stream()
-        recs = [None] * F
-        if state["last"] is not None:
-            if streams[0] is not None:
-                cur.wait_event(done[F - 1][(k - 1) & 1])         # the picture to hand over is complete
-                if k >= 2:
-                    cur.wait_event(done[0][k & 1])               # chain 0 of step k-2 has finished reading the inbox being refilled
-            ring.begin(state["last"])
-        for j in range(1, F):
-            launch(j, k, recs)
-        if state["last"] is not None:
-            state["refs"][0] = ring.finish()
-            got[k & 1].record(cur)
-        launch(0, k, recs)
-        state["refs"] = [state["refs"][0]] + recs[:F - 1]
-        state["last"] = recs[F - 1]
-        state["k"] = k + 1
+        # x265_amd/exchange.py FrameChains: start the hand-over, launch chains 1..F-1, wait for the incoming reference, launch chain 0
+        chains.step(launch, before_exchange, after_exchange)
 
     def profile_step():
-        k = state["k"]
-        run_pass(fp.h, pool[k % NPOOL], state["refs"][0], preds[0], recons[0][k & 1], stream)
-        state["k"] = k + 1
+        k = chains.k
+        run_pass(fp.h, pool[k % NPOOL], chains.refs[0], preds[0], recons[0][k & 1], stream)
+        chains.k = k + 1
 
     def fence():
         if world > 1:

@@ -56,6 +56,23 @@ def _worker(rank, world, port, out):
         produced.append(rec.numpy().copy())
         ref = ring.exchange(rec)
     np.save(os.path.join(out, "rank%d.npy" % rank), np.stack(produced))
+    # 3. bench.py's schedule with F = 2 frame passes in flight per rank (FrameChains: hand-over started first, chain 1 launched while it is
+    #    in flight, chain 0 after the incoming reference arrived)
+    from x265_amd.exchange import FrameChains
+    F = 2
+    firsts = [torch.from_numpy(_scene(2000 + 10 * rank + j)["ref"].copy()) for j in range(F)]
+    ring2 = ReferenceRing(firsts[0], torch.empty_like(firsts[0]), rank, world)
+    chains = FrameChains(ring2, F, [ring2.current] + firsts[1:])
+    order, out2 = [], []
+
+    def launch(j, k, ref):
+        order.append(j)
+        sc = _scene((k * world + rank) * F + j)
+        return torch.from_numpy(_recon(sc["src"], ref.numpy()))
+    for s in range(STEPS + 1):
+        out2.append(np.stack([r.numpy().copy() for r in chains.step(launch)]))
+    assert order == [1, 0] * (STEPS + 1)                     # chain 0 (the one that needs the transfer) is always launched last
+    np.save(os.path.join(out, "chains%d.npy" % rank), np.stack(out2))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -73,6 +90,23 @@ def test_ring_exchange_two_ranks_matches_sequential_schedule(tmp_path):
             recs.append(_recon(sc["src"], refs[r]))
             assert np.array_equal(got[r][s], recs[r]), (s, r)
         refs = [recs[(r - 1) % world] for r in range(world)]
+
+
+def test_frame_chains_two_ranks_match_the_reference_relation(tmp_path):
+    """F = 2 chains per rank, 2 ranks: every reconstruction equals what the dependency rule gives — chain j references chain j-1 of the same
+    rank one step earlier, chain 0 references the last chain of the previous rank one step earlier."""
+    world, F = 2, 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(os.path.join(str(tmp_path), "chains%d.npy" % r)) for r in range(world)]       # [step][chain]
+    prev = [[_scene(2000 + 10 * r + j)["ref"] for j in range(F)] for r in range(world)]           # references of step 0
+    for s in range(STEPS + 1):
+        recs = [[None] * F for _ in range(world)]
+        for r in range(world):
+            for j in range(F):
+                sc = _scene((s * world + r) * F + j)
+                recs[r][j] = _recon(sc["src"], prev[r][j])
+                assert np.array_equal(got[r][s][j], recs[r][j]), (s, r, j)
+        prev = [[recs[(r - 1) % world][F - 1]] + recs[r][:F - 1] for r in range(world)]
 
 
 def test_single_rank_ring_is_identity():

@@ -75,3 +75,39 @@ class ReferenceRing:
     def exchange(self, recon):
         self.begin(recon)
         return self.finish()
+
+
+class FrameChains:
+    """The frame schedule of one rank with F frame passes in flight (bench.py; x265 runs several frame encoders per device the same way).
+
+    Chain j of rank g encodes frame (step * N + g) * F + j.  Its reference is the reconstruction chain j-1 produced one step earlier; chain 0
+    takes the last chain of rank g-1 through the ring.  `step(launch)` drives one step: the hand-over of the previous step's last
+    reconstruction is STARTED first, chains 1..F-1 (whose references are local) are launched while it is in flight, and only chain 0 waits
+    for the incoming picture.  `launch(j, k, ref)` runs chain j of step k against `ref` and returns its reconstruction; `before_exchange(k)`
+    / `after_exchange(k)` are optional hooks around the transfer (bench.py orders its HIP streams there)."""
+
+    def __init__(self, ring, frames_in_flight, first_refs):
+        assert frames_in_flight >= 1 and len(first_refs) == frames_in_flight
+        self.ring, self.F = ring, frames_in_flight
+        self.refs = list(first_refs)
+        self.last = None               # reconstruction of the last chain of the previous step, still to be handed to the next rank
+        self.k = 0
+
+    def step(self, launch, before_exchange=None, after_exchange=None):
+        k, F = self.k, self.F
+        recs = [None] * F
+        if self.last is not None:
+            if before_exchange:
+                before_exchange(k)
+            self.ring.begin(self.last)
+        for j in range(1, F):
+            recs[j] = launch(j, k, self.refs[j])
+        if self.last is not None:
+            self.refs[0] = self.ring.finish()
+            if after_exchange:
+                after_exchange(k)
+        recs[0] = launch(0, k, self.refs[0])
+        self.refs = [self.refs[0]] + recs[:F - 1]
+        self.last = recs[F - 1]
+        self.k = k + 1
+        return recs
