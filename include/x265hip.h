@@ -361,7 +361,8 @@ int x265hip_lowres_intra_estimate(int depth, const void* plane, int64_t stride, 
  * All pairs share the geometry; planes are border-extended lowres planes (x265hip_lowres_init), `ref` = hpel plane 0 of
  * the reference with planes 1..3 `planeElems` elements apart.  `sync` is ncu u64 of scratch per pair, zeroed once when
  * allocated; `epoch` must be non-zero and differ from every earlier call that used the same scratch.
- * `pairs` is a DEVICE array.  costEst[i] = { costEst, intraMbs } of pair i. */
+ * `pairs` is a DEVICE array.  costEst[i] = { costEst, intraMbs } of pair i; a negative intraMbs means the row handshake timed out (stale
+ * `sync` scratch or a reused epoch) and the pair's outputs are invalid. */
 typedef struct x265hip_lookahead_pair
 {
     const void*    fenc;         /* lowresPlane[0] origin of the frame being costed */

@@ -166,6 +166,7 @@ __global__ __launch_bounds__(64) void lookahead_p_kernel(const LaPair* __restric
     const int mvminY = -cuY * N - 8, mvmaxY = (H - cuY - 1) * N + 8;
     int rowSum = 0, scoreSum = 0, intraCnt = 0;
     int prevX = 0, prevY = 0;
+    bool stuck = false;
 
 #pragma unroll 1
     for (int cuX = W - 1; cuX >= 0; cuX--)
@@ -184,8 +185,15 @@ __global__ __launch_bounds__(64) void lookahead_p_kernel(const LaPair* __restric
         if (!lastRow)
         {
             const int waitIdx = cuX > 0 ? cuX - 1 : cuX;          // the row below moves right to left: this one is done last
-            while ((uint32_t)sfl((int)(la_load(below + waitIdx) >> 32)) != epoch)
-                __builtin_amdgcn_s_sleep(2);
+            // (bounded: the row below is always dispatched earlier, so this normally takes microseconds; if the handshake word never
+            // arrives — a stale `sync` buffer or an epoch reused by the caller — give up after ~2 s instead of hanging the device and
+            // report it through a negative costEst[2 i + 1])
+            int spins = 0;
+            while (!stuck && (uint32_t)sfl((int)(la_load(below + waitIdx) >> 32)) != epoch)
+            {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 22)) stuck = true;            // sticky: the rest of the row no longer waits
+            }
             la_unpack(la_load(below + cuX), mx[numc], my[numc]);
             numc++;
             if (cuX > 0) { la_unpack(la_load(below + cuX - 1), mx[numc], my[numc]); numc++; }
@@ -409,6 +417,8 @@ __global__ __launch_bounds__(64) void lookahead_p_kernel(const LaPair* __restric
         atomicAdd(costEst + 2 * pairIdx, scoreSum);
         atomicAdd(costEst + 2 * pairIdx + 1, intraCnt);
     }
+    if (lane == 0 && stuck)
+        atomicAdd(costEst + 2 * pairIdx + 1, -(1 << 30));        // intraMbs far below zero: the handshake timed out, outputs are invalid
 }
 
 // ---- B frames: the part of estimateCUCost after the two list searches (slicetype.cpp:3320-3338, :3353-3384) ----------------
