@@ -159,7 +159,7 @@ int x265hip_interp_batch(int kind, int taps, int depth, int w, int h,
 
 /* ---------------------------------------------------------------- fused hot loops --------------------------- */
 /* MotionEstimate::motionEstimate (reference: source/encoder/motion.cpp:739-1569) for n PUs of one shape in one
- * launch: predictor / zero / candidate tests, integer search (searchMethod X265_DIA_SEARCH 0, X265_HEX_SEARCH 1,
+ * launch: predictor / zero / candidate tests, integer search (searchMethod X265_DIA_SEARCH 0, X265_HEX_SEARCH 1, X265_UMH_SEARCH 2,
  * X265_STAR_SEARCH 3, X265_FULL_SEARCH 5; x265.h), then the sub-pel refine of workload[subme] (motion.cpp:48-58) with luma_hpp/vpp/hvpp
  * + sad/satd (subpelCompare, motion.cpp:1571).  Luma only (bChromaSATD == false, i.e. subme <= 2 semantics for chroma).
  *   fencPlane/refPlane: source and (padded) reconstructed reference luma planes; PU i sits at pu_xy[2i], pu_xy[2i+1]

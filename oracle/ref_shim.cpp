@@ -32,6 +32,7 @@ EncoderPrimitives& T()
         /* fill the GLOBAL table too: MotionEstimate and the hv filters read it */
         setupCPrimitives(primitives);
         setupAliasPrimitives(primitives);
+        MotionEstimate::initScales();      /* as Encoder::create does (encoder.cpp:123): the UMH search reads sizeScale[] */
         done = true;
     }
     return primitives;

@@ -292,3 +292,70 @@ def lookahead_scene3(depth, seed, H=136, W=200, margin=80):
         p = np.clip(np.rint(p.astype(np.float64) + rng.normal(0, 2.0 * (pmax / 255.0), p.shape)), 0, pmax).astype(big.dtype)
         pics.append(np.ascontiguousarray(np.pad(p, ((margin, margin), (margin, margin + 8)), mode="edge")))
     return pics, margin
+
+
+def umh_scenes(depth):
+    """Scenes that reach every branch of the UMH search (encoder/motion.cpp:946-1130): the early-termination tests need blocks that match
+    well at the predictor (SAD_THRESH), the `cross_start = range + 2` branch needs a cost that is flat under the radius-1 diamond and the
+    radius-2 octagon but better a few pixels along an axis (stripes of period 3..6), and the adaptive range needs poor matches too.
+    Yields (ref, src, margin, H, W, (dy, dx) true shift)."""
+    pmax = (1 << depth) - 1
+    sc = 1 << (depth - 8)
+    dt = np.uint8 if depth == 8 else np.uint16
+    m, H, W = 96, 160, 192
+    yy, xx = np.mgrid[0:H + 2 * m, 0:W + 2 * m]
+    for k, sigma in enumerate((0.0, 0.7, 3.0, 25.0)):                      # smooth blocks + noise of growing strength
+        rng = np.random.default_rng(4000 + 10 * depth + k)
+        base = rng.integers(0, 256, size=((H + 2 * m) // 8 + 2, (W + 2 * m) // 8 + 2)).astype(np.float64)
+        big = np.kron(base, np.ones((8, 8)))[:H + 2 * m, :W + 2 * m]
+        big = (big + np.roll(big, 1, 0) + np.roll(big, 1, 1) + np.roll(big, 3, 0) + np.roll(big, 3, 1)) / 5
+        ref = np.clip(np.rint((big + rng.normal(0, 2, big.shape)) * sc), 0, pmax)
+        shift = (int(rng.integers(-9, 10)), int(rng.integers(-9, 10)))
+        src = np.clip(np.rint(np.roll(ref, shift, (0, 1)) + rng.normal(0, sigma * sc, ref.shape)), 0, pmax)
+        yield np.ascontiguousarray(ref.astype(dt)), np.ascontiguousarray(src.astype(dt)), m, H, W, shift
+    for k, (per, axis) in enumerate(((3, 0), (3, 1), (5, 0), (4, 1))):      # stripes: local minima every `per` pixels along one axis
+        rng = np.random.default_rng(4100 + 10 * depth + k)
+        stripes = (((xx if axis == 0 else yy) % per) == 0) * 60.0
+        smooth = 100 + 20 * np.sin(xx / 37.0) + 20 * np.cos(yy / 29.0)
+        ref = np.clip(np.rint((smooth + stripes) * sc), 0, pmax)
+        shift = [0, 0]
+        shift[1 - axis] = per * int(rng.choice([-2, -1, 1, 2]))
+        src = np.clip(np.rint(np.roll(ref, tuple(shift), (0, 1)) + rng.normal(0, 0.6 * sc, ref.shape)), 0, pmax)
+        yield np.ascontiguousarray(ref.astype(dt)), np.ascontiguousarray(src.astype(dt)), m, H, W, (shift[0], shift[1], per, axis)
+
+
+def umh_groups(depth, groups_per_scene=6, npu=8):
+    """Batches of PUs for the scenes above: each group is one (w, h, merange, subme, qp, numCand) with npu PUs, predictors near the true
+    motion half of the time.  Yields (scene_index, ref, src, group dict)."""
+    sizes = [(8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (32, 16), (8, 16), (64, 32), (24, 32), (16, 12)]
+    for si, (ref, src, m, H, W, info) in enumerate(umh_scenes(depth)):
+        rng = np.random.default_rng(4200 + 100 * depth + si)
+        dy, dx = info[0], info[1]
+        per = info[2] if len(info) == 4 else 0
+        for gi in range(groups_per_scene):
+            w, h = sizes[int(rng.integers(0, len(sizes)))]
+            merange = int(rng.choice([8, 16, 32, 57]))
+            numCand = int(rng.integers(0, 4))
+            g = dict(w=w, h=h, merange=merange, subme=int(rng.choice([0, 2, 3, 7])), qp=int(rng.choice([22, 37])), numCand=numCand,
+                     pus=[], mins=[], maxs=[], mvps=[], cands=[])
+            for _ in range(npu):
+                bx = m + int(rng.integers(0, (W - w) // 4 + 1)) * 4
+                by = m + int(rng.integers(0, (H - h) // 4 + 1)) * 4
+                if per:                                 # predictor a whole number of periods away from the truth (or on it)
+                    off = per * int(rng.integers(-1, 2))
+                    qmvp = (-dx * 4 + (4 * off if info[3] == 0 else 0), -dy * 4 + (4 * off if info[3] == 1 else 0))
+                elif rng.integers(0, 2):
+                    qmvp = (-dx * 4 + int(rng.integers(-6, 7)), -dy * 4 + int(rng.integers(-6, 7)))
+                else:
+                    qmvp = (int(rng.integers(-40, 41)), int(rng.integers(-40, 41)))
+                mvmin = [(qmvp[0] >> 2) - merange, (qmvp[1] >> 2) - merange]
+                mvmax = [(qmvp[0] >> 2) + merange, (qmvp[1] >> 2) + merange]
+                k = int(rng.integers(0, 4))
+                if k == 0:
+                    mvmax[1] = max(min(mvmax[1], int(rng.integers(0, 6))), mvmin[1])        # frame-parallel row lag
+                if k == 1:
+                    mvmin[1] = min(max(mvmin[1], int(rng.integers(-3, 4))), mvmax[1])
+                g["pus"].append((bx, by)); g["mins"].append(tuple(mvmin)); g["maxs"].append(tuple(mvmax)); g["mvps"].append(qmvp)
+                g["cands"].append([((-dx * 4 + int(rng.integers(-8, 9)), -dy * 4 + int(rng.integers(-8, 9))) if rng.integers(0, 2)
+                                    else (int(rng.integers(-60, 61)), int(rng.integers(-60, 61)))) for _ in range(numCand)])
+            yield si, ref, src, g

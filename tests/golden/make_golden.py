@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import numpy as np  # noqa: E402
 from backends import Ref  # noqa: E402
-from cases import gen_cases, me_scene, me_scene_yuv, lowres_scene, lookahead_scene, lookahead_scene3, digest  # noqa: E402
+from cases import gen_cases, umh_groups, me_scene, me_scene_yuv, lowres_scene, lookahead_scene, lookahead_scene3, digest  # noqa: E402
 
 ME_CASES = [  # (method, subme, w, h, bx_off, by_off, merange, qmvp, mvc, qp)
     (1, 2, 16, 16, 16, 24, 57, (5, -7), [(12, 8), (-20, 4)], 28),
@@ -39,6 +39,18 @@ def me_digests(backend_cls, depth):
         mvmax = ((qmvp[0] >> 2) + mr, (qmvp[1] >> 2) + mr)
         cost, mv = b.motion_estimate(refp, srcp, m + bx, m + by, w, h, mvmin, mvmax, qmvp, mvc, mr, method, subme, qp)
         out["me#%d" % i] = [int(cost), int(mv[0]), int(mv[1])]
+    return out
+
+
+def umh_results(backend_cls, depth):
+    """X265_UMH_SEARCH (method 2) over tests/cases.py umh_groups: one [cost, mvx, mvy] per PU, keyed scene/group/PU."""
+    b = backend_cls(depth)
+    out = {}
+    for gi, (si, ref, src, g) in enumerate(umh_groups(depth)):
+        for i in range(len(g["pus"])):
+            cost, mv = b.motion_estimate(ref, src, g["pus"][i][0], g["pus"][i][1], g["w"], g["h"], g["mins"][i], g["maxs"][i], g["mvps"][i],
+                                         g["cands"][i], g["merange"], 2, g["subme"], g["qp"])
+            out["umh#%d.%d.%d" % (si, gi, i)] = [int(cost), int(mv[0]), int(mv[1])]
     return out
 
 
@@ -164,7 +176,7 @@ def prim_digests(backend_cls, depth):
 if __name__ == "__main__":
     gold = {}
     for depth in (8, 10):
-        gold[str(depth)] = {"prims": prim_digests(Ref, depth), "me": me_digests(Ref, depth), "chroma_me": chroma_me_results(Ref, depth),
+        gold[str(depth)] = {"prims": prim_digests(Ref, depth), "me": me_digests(Ref, depth), "umh": umh_results(Ref, depth), "chroma_me": chroma_me_results(Ref, depth),
                             "bipred": {k: digest(v) for k, v in bipred_results(Ref, depth).items()}, "lowres": lowres_digests(Ref, depth), "lookahead": lookahead_digests(Ref, depth),
                             "lookahead_b": {k: digest(v) for k, v in lookahead_b_results(Ref, depth).items()},
                             "mvcost": {str(qp): digest(Ref(depth).mvcost_table(qp)) for qp in (12, 28, 37, 51)}}

@@ -17,7 +17,7 @@ def fpmod():
     return framepass
 
 
-@pytest.mark.parametrize("depth,method,subme,qp", [(8, 1, 2, 28), (10, 1, 2, 30), (8, 0, 3, 22), (8, 1, 5, 35), (10, 1, 7, 24), (8, 3, 3, 28), (10, 3, 2, 26)])
+@pytest.mark.parametrize("depth,method,subme,qp", [(8, 1, 2, 28), (10, 1, 2, 30), (8, 0, 3, 22), (8, 1, 5, 35), (10, 1, 7, 24), (8, 3, 3, 28), (10, 3, 2, 26), (8, 2, 2, 28), (10, 2, 3, 30)])
 def test_small_frame_pass_is_bit_exact(fpmod, depth, method, subme, qp):
     sc = make_scene(200, 136, depth=depth, seed=11 + qp, tile=48, sigma=3.0 * (1 if depth == 8 else 4))
     fp = fpmod.FramePass(200, 136, depth=depth, qp=qp, merange=57, method=method, subme=subme)
@@ -156,7 +156,7 @@ def test_yuv_frame_pass_is_bit_exact(fpmod, w, h, depth, qp, subme):
     assert sum(int(x.sum()) for x in want["cnumSig"]) > 0
 
 
-@pytest.mark.parametrize("w,h,depth,qp,method,subme", [(200, 136, 8, 28, 3, 3), (328, 200, 10, 30, 1, 4), (640, 360, 8, 26, 3, 3)])
+@pytest.mark.parametrize("w,h,depth,qp,method,subme", [(200, 136, 8, 28, 3, 3), (328, 200, 10, 30, 1, 4), (640, 360, 8, 26, 3, 3), (200, 136, 8, 28, 2, 3)])
 def test_yuv_frame_pass_with_chroma_satd_search(fpmod, w, h, depth, qp, method, subme):
     """BASELINE configs[2]/[3] shape of the search: STAR / HEX at subme 3-4 on a 4:2:0 picture, where every sub-pel comparison of
     motionEstimate carries the chroma SATD term — the whole pass against the C restatement."""

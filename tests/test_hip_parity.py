@@ -318,7 +318,7 @@ def dev_keep(values):
 # ---- motion estimation ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("planes", [0, 1], ids=["filter", "planes"])
 @pytest.mark.parametrize("depth", DEPTHS)
-@pytest.mark.parametrize("method", [0, 1, 3, 5])
+@pytest.mark.parametrize("method", [0, 1, 2, 3, 5])
 def test_motion_estimate_matches_oracle(hipmod, depth, method, planes):
     o, g = Orc(depth), hipmod.Hip(depth)
     rng = np.random.default_rng(77 + depth + method)
@@ -353,6 +353,34 @@ def test_motion_estimate_matches_oracle(hipmod, depth, method, planes):
                 total += 1
                 if (int(cost[i]), (int(mv[i, 0]), int(mv[i, 1]))) != want:
                     bad.append("me%d %dx%d subme%d got %s want %s" % (method, w, h, subme, (int(cost[i]), tuple(int(v) for v in mv[i])), want))
+    _report(bad, total)
+
+
+@pytest.mark.parametrize("planes", [0, 1], ids=["filter", "planes"])
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_umh_search_matches_oracle_and_golden(hipmod, depth, planes):
+    """X265_UMH_SEARCH on the scenes that reach its early-termination, cross and adaptive-range branches (tests/cases.py umh_scenes),
+    against the oracle and against the vectors of the real reference committed in tests/golden."""
+    import json
+    import os
+    from cases import umh_groups
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "primitives_golden.json")))["golden"][str(depth)]["umh"]
+    o, g = Orc(depth), hipmod.Hip(depth)
+    for qp in (22, 37):
+        g.set_mvcost_table(qp, o.mvcost_table(qp))
+    bad, total = [], 0
+    for gi, (si, refp, srcp, grp) in enumerate(umh_groups(depth)):
+        w, h, numCand = grp["w"], grp["h"], grp["numCand"]
+        cost, mv = g.motion_estimate_batch(refp, srcp, w, h, grp["pus"], grp["mins"], grp["maxs"], grp["mvps"], grp["cands"] if numCand else [],
+                                           grp["merange"], 2, grp["subme"], grp["qp"], planes_margin=96 if planes else 0)
+        hipmod._release()
+        for i in range(len(grp["pus"])):
+            want = o.motion_estimate(refp, srcp, grp["pus"][i][0], grp["pus"][i][1], w, h, grp["mins"][i], grp["maxs"][i], grp["mvps"][i],
+                                     grp["cands"][i], grp["merange"], 2, grp["subme"], grp["qp"])
+            got = (int(cost[i]), (int(mv[i, 0]), int(mv[i, 1])))
+            total += 1
+            if got != want or [got[0], got[1][0], got[1][1]] != gold["umh#%d.%d.%d" % (si, gi, i)]:
+                bad.append("umh scene %d %dx%d subme%d got %s want %s" % (si, w, h, grp["subme"], got, want))
     _report(bad, total)
 
 

@@ -30,6 +30,7 @@ def test_oracle_primitives_match_golden(depth):
 @pytest.mark.parametrize("depth", [8, 10])
 def test_oracle_motion_estimate_matches_golden(depth):
     assert make_golden.me_digests(Orc, depth) == GOLD[str(depth)]["me"]
+    assert make_golden.umh_results(Orc, depth) == GOLD[str(depth)]["umh"]
 
 
 @pytest.mark.parametrize("depth", [8, 10])

@@ -51,7 +51,19 @@ def test_every_primitive_matches_reference(depth):
 
 
 @pytest.mark.parametrize("depth", DEPTHS)
-@pytest.mark.parametrize("method", [0, 1, 3, 5])     # DIA, HEX, STAR, FULL (x265.h X265_*_SEARCH)
+def test_umh_search_matches_reference(depth):
+    """X265_UMH_SEARCH on scenes built to reach its early-termination, cross and adaptive-range branches (tests/cases.py umh_scenes)."""
+    _need_ref(depth)
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    a, b = make_golden.umh_results(Orc, depth), make_golden.umh_results(Ref, depth)
+    assert len(a) >= 300
+    assert a == b, [k for k in a if a[k] != b[k]][:8]
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+@pytest.mark.parametrize("method", [0, 1, 2, 3, 5])     # DIA, HEX, UMH, STAR, FULL (x265.h X265_*_SEARCH)
 def test_motion_estimate_matches_reference(depth, method):
     _need_ref(depth)
     o, r = Orc(depth), Ref(depth)

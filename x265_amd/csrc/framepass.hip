@@ -119,7 +119,7 @@ int x265hip_framepass_create(int width, int height, int depth, int qp, int meran
 {
     XH_CHECK_DEV();
     if (!out || width < 8 || height < 8 || (width & 7) || (height & 7) || !valid_depth(depth) || qp < 0 || qp > 51 ||
-        merange < 1 || merange > 256 || subme < 0 || subme > 7 || (searchMethod != 0 && searchMethod != 1 && searchMethod != 3 && searchMethod != 5))
+        merange < 1 || merange > 256 || subme < 0 || subme > 7 || (searchMethod != 0 && searchMethod != 1 && searchMethod != 2 && searchMethod != 3 && searchMethod != 5))
         return set_error(X265HIP_EINVAL, "framepass_create: %dx%d depth %d qp %d merange %d me %d subme %d", width, height, depth, qp,
                          merange, searchMethod, subme);
     x265hip_framepass* fp = new x265hip_framepass();

@@ -22,6 +22,7 @@
 #include "filters.h"
 #include "searchrange.h"
 #include "mestar.h"
+#include "meumh.h"
 #include <cstdlib>
 
 namespace xh {
@@ -427,7 +428,12 @@ __global__ __launch_bounds__(256) void motion_kernel(const P* __restrict__ fencP
             c.sad_multi(4, cand, costs); \
             for (int k_ = 0; k_ < 4; k_++) costs[k_] += c.mvcost(cand[k_].x * 4, cand[k_].y * 4); } while (0)
 
-        if (method == 0)
+        // X265_UMH_SEARCH (meumh.h) ends either for good or in the hexagon refine of X265_HEX_SEARCH (goto me_hex2, motion.cpp:1127)
+        int meth = method, hexRange = merange;       // UMH scales the range the hexagon refine then runs with (motion.cpp:1039)
+        if (meth == 2)
+            meth = umh_search(c, mvmin.x, mvmin.y, mvmax.x, mvmax.y, hexRange, bmv.x, bmv.y, bcost, (pmv.x + 2) >> 2, (pmv.y + 2) >> 2, numCand,
+                              mvcA + (int64_t)pu * numCand * 2, qmvp.x, qmvp.y, w, h) ? 1 : -1;
+        if (meth == 0)
         {
             // X265_DIA_SEARCH, motion.cpp:831-852
             bcost <<= 4;
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(256) void motion_kernel(const P* __restrict__ fencP
             while (--i && mv_in_range(bmv, mvmin, mvmax));
             bcost >>= 4;
         }
-        else if (method == 1)
+        else if (meth == 1)
         {
             // X265_HEX_SEARCH, motion.cpp:855-944
             DIRS3(-2, 0, -1, 2, 1, 2);
@@ -473,7 +479,7 @@ __global__ __launch_bounds__(256) void motion_kernel(const P* __restrict__ fencP
                 {
                     bmv.x += kHex2[dir + 1][0];
                     bmv.y += kHex2[dir + 1][1];
-                    for (int i = (merange >> 1) - 1; i > 0 && mv_in_range(bmv, mvmin, mvmax); i--)
+                    for (int i = (hexRange >> 1) - 1; i > 0 && mv_in_range(bmv, mvmin, mvmax); i--)
                     {
                         DIRS3(kHex2[dir + 0][0], kHex2[dir + 0][1], kHex2[dir + 1][0], kHex2[dir + 1][1], kHex2[dir + 2][0], kHex2[dir + 2][1]);
                         bcost &= ~7;
@@ -505,9 +511,9 @@ __global__ __launch_bounds__(256) void motion_kernel(const P* __restrict__ fencP
             bmv.x += kSquare1[dir][0];
             bmv.y += kSquare1[dir][1];
         }
-        else if (method == 3)
+        else if (meth == 3)
             star_search(c, mvmin.x, mvmin.y, mvmax.x, mvmax.y, merange, bmv.x, bmv.y, bcost);  // X265_STAR_SEARCH (mestar.h)
-        else
+        else if (meth == 5)
         {
             // X265_FULL_SEARCH, motion.cpp:1397-1441: raster order, strict '<' keeps the first minimum
             for (int ty = mvmin.y; ty <= mvmax.y; ty++)
@@ -660,8 +666,8 @@ static int check_me_args(const char* who, int depth, int w, int h, int n, int se
 {
     if (!valid_depth(depth) || !valid_block(w, h) || (w & 3) || (h & 3) || (w == 4 && h == 4) || n < 0)
         return set_error(X265HIP_EINVAL, "%s: depth %d PU %dx%d n %d", who, depth, w, h, n);
-    if (searchMethod != 0 && searchMethod != 1 && searchMethod != 3 && searchMethod != 5)
-        return set_error(X265HIP_EINVAL, "%s: searchMethod %d not implemented (DIA 0, HEX 1, STAR 3, FULL 5)", who, searchMethod);
+    if (searchMethod != 0 && searchMethod != 1 && searchMethod != 2 && searchMethod != 3 && searchMethod != 5)
+        return set_error(X265HIP_EINVAL, "%s: searchMethod %d not implemented (DIA 0, HEX 1, UMH 2, STAR 3, FULL 5)", who, searchMethod);
     if (subme < 0 || subme > 7 || numCand < 0 || merange < 1 || mvcostHalf < 4 * (merange + 64))
         return set_error(X265HIP_EINVAL, "%s: subme %d numCand %d merange %d mvcostHalf %d", who, subme, numCand, merange, mvcostHalf);
     return X265HIP_OK;

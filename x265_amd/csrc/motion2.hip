@@ -22,6 +22,7 @@
 #include "filters.h"
 #include "searchrange.h"
 #include "mestar.h"
+#include "meumh.h"
 #include <cstdlib>
 
 #ifndef ME2_MIN_WAVES
@@ -643,7 +644,12 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
             }
         }
 
-        if (method == 0)
+        // X265_UMH_SEARCH (meumh.h) ends either for good or in the hexagon refine of X265_HEX_SEARCH (goto me_hex2, motion.cpp:1127)
+        int meth = method, hexRange = merange;       // UMH scales the range the hexagon refine then runs with (motion.cpp:1039)
+        if (meth == 2)
+            meth = umh_search(c, mvmin.x, mvmin.y, mvmax.x, mvmax.y, hexRange, bmv.x, bmv.y, bcost, (pmv.x + 2) >> 2, (pmv.y + 2) >> 2, numCand,
+                              mvcA + (int64_t)pu * numCand * 2, qmvp.x, qmvp.y, N, N) ? 1 : -1;
+        if (meth == 0)
         {
             // X265_DIA_SEARCH, motion.cpp:831-852
             bcost <<= 4;
@@ -666,7 +672,7 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
             while (--i && mv_in_range2(bmv, mvmin, mvmax));
             bcost >>= 4;
         }
-        else if (method == 1)
+        else if (meth == 1)
         {
             // X265_HEX_SEARCH, motion.cpp:855-944
             {
@@ -696,7 +702,7 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
                 {
                     bmv.x += hex2xB(dir + 1);
                     bmv.y += hex2yB(dir + 1);
-                    for (int i = (merange >> 1) - 1; i > 0 && mv_in_range2(bmv, mvmin, mvmax); i--)
+                    for (int i = (hexRange >> 1) - 1; i > 0 && mv_in_range2(bmv, mvmin, mvmax); i--)
                     {
                         const Mv2 cd[3] = { { bmv.x + hex2xB(dir + 0), bmv.y + hex2yB(dir + 0) },
                                             { bmv.x + hex2xB(dir + 1), bmv.y + hex2yB(dir + 1) },
@@ -737,9 +743,9 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
             bmv.x += sq1xB(dir);
             bmv.y += sq1yB(dir);
         }
-        else if (method == 3)
+        else if (meth == 3)
             star_search(c, mvmin.x, mvmin.y, mvmax.x, mvmax.y, merange, bmv.x, bmv.y, bcost);  // X265_STAR_SEARCH (mestar.h)
-        else
+        else if (meth == 5)
         {
             // X265_FULL_SEARCH, motion.cpp:1397-1441: raster order, strict '<' keeps the first minimum
             for (int ty = mvmin.y; ty <= mvmax.y; ty++)

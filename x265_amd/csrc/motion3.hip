@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include "searchrange.h"
 #include "mestar.h"
+#include "meumh.h"
 #include "filters.h"
 
 namespace xh {
@@ -326,7 +327,12 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
         }
     }
 
-    if (method == 0)
+    // X265_UMH_SEARCH (meumh.h) ends either for good or in the hexagon refine of X265_HEX_SEARCH (goto me_hex2, motion.cpp:1127)
+    int meth = method, hexRange = merange;       // UMH scales the range the hexagon refine then runs with (motion.cpp:1039)
+    if (meth == 2)
+        meth = umh_search(c, mvmin.x, mvmin.y, mvmax.x, mvmax.y, hexRange, bmv.x, bmv.y, bcost, (pmv.x + 2) >> 2, (pmv.y + 2) >> 2, numCand,
+                          mvcA + (int64_t)pu * numCand * 2, qmvp.x, qmvp.y, N, N) ? 1 : -1;
+    if (meth == 0)
     {
         // X265_DIA_SEARCH, motion.cpp:831-852
         bcost <<= 4;
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
         while (--i && mv_in3(bmv, mvmin, mvmax));
         bcost >>= 4;
     }
-    else if (method == 1)
+    else if (meth == 1)
     {
         // X265_HEX_SEARCH, motion.cpp:855-944
         {
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
             {
                 bmv.x += hex2xC(dir + 1);
                 bmv.y += hex2yC(dir + 1);
-                for (int i = (merange >> 1) - 1; i > 0 && mv_in3(bmv, mvmin, mvmax); i--)
+                for (int i = (hexRange >> 1) - 1; i > 0 && mv_in3(bmv, mvmin, mvmax); i--)
                 {
                     const Mv3 a = { bmv.x + hex2xC(dir + 0), bmv.y + hex2yC(dir + 0) };
                     const Mv3 b = { bmv.x + hex2xC(dir + 1), bmv.y + hex2yC(dir + 1) };
@@ -411,9 +417,9 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
         bmv.x += sq1xC(dir);
         bmv.y += sq1yC(dir);
     }
-    else if (method == 3)
+    else if (meth == 3)
         star_search(c, mvmin.x, mvmin.y, mvmax.x, mvmax.y, merange, bmv.x, bmv.y, bcost);      // X265_STAR_SEARCH (mestar.h)
-    else
+    else if (meth == 5)
     {
         // X265_FULL_SEARCH, motion.cpp:1397-1441: raster order, strict '<' keeps the first minimum
         for (int ty = mvmin.y; ty <= mvmax.y; ty++)

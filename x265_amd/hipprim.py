@@ -144,7 +144,7 @@ class LookaheadBFrame(C.Structure):
     _fields_ = [("fenc", vp), ("ref0", vp), ("ref1", vp), ("mvs0", vp), ("mvs1", vp), ("mvCosts0", vp), ("mvCosts1", vp), ("lowresCosts", vp),
                 ("rowSatds", vp)]
 IF_HPP, IF_HPS, IF_VPP, IF_VPS, IF_VSP, IF_VSS, IF_HVPP = range(7)
-DIA_SEARCH, HEX_SEARCH, STAR_SEARCH, FULL_SEARCH = 0, 1, 3, 5      # x265.h X265_*_SEARCH
+DIA_SEARCH, HEX_SEARCH, UMH_SEARCH, STAR_SEARCH, FULL_SEARCH = 0, 1, 2, 3, 5      # x265.h X265_*_SEARCH
 
 
 class HipError(RuntimeError):
