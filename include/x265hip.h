@@ -269,6 +269,17 @@ typedef struct x265hip_yuv { void* y; void* cb; void* cr; int64_t strideY; int64
  * positions of `dst`.  pu_xy in luma samples; mv0 / mv1 quarter-pel luma vectors (eighth-pel for the 4:2:0 chroma). */
 int x265hip_pred_inter_bi_batch(int depth, int w, int h, const x265hip_yuv* ref0, const x265hip_yuv* ref1, const x265hip_yuv* dst,
                                 const int32_t* pu_xy, const int32_t* mv0, const int32_t* mv1, int n, void* stream);
+/* Predict::motionCompensation, every branch (predict.cpp:77-266), for n PUs of one shape of a 4:2:0 picture:
+ *   ref1 == NULL  uni-prediction from ref0 with mv0 (a P slice :84-119, or a B-slice PU that uses one list :201-265): weighted when
+ *                 wp0 && wp0[0].wtPresent -> predInter*Short + addWeightUni (:525-576, weight_sp); else predInterLumaPixel / ChromaPixel
+ *   both given    bi-prediction (:176-199): weighted when wp0 && wp1 && (wp0[0].wtPresent || wp1[0].wtPresent) -> addWeightBi (:411-522);
+ *                 else Yuv::addAvg (the same result as x265hip_pred_inter_bi_batch)
+ * wp0 / wp1: the slice's WeightParam entries (slice.h:295) of the reference in each list, [Y, Cb, Cr], or NULL when the PPS has
+ * weighted (bi-)prediction off.  Vectors are used as given (the caller applies CUData::clipMv).  Host pointers for wp*. */
+typedef struct x265hip_weight_param { int32_t inputWeight; int32_t inputOffset; int32_t log2WeightDenom; int32_t wtPresent; } x265hip_weight_param;
+int x265hip_motion_compensation_batch(int depth, int w, int h, const x265hip_yuv* ref0, const x265hip_yuv* ref1, const x265hip_yuv* dst,
+                                      const int32_t* pu_xy, const int32_t* mv0, const int32_t* mv1, int n,
+                                      const x265hip_weight_param* wp0, const x265hip_weight_param* wp1, void* stream);
 int x265hip_framepass_run_yuv(x265hip_framepass* fp, const x265hip_yuv* src, const x265hip_yuv* ref, const x265hip_yuv* pred,
                               const x265hip_yuv* recon, int marginX, int marginY, void* stream);
 /* The B-frame variant: a second (future) reference of the same geometry.  Both lists are searched at every level (list 1's vectors

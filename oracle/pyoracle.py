@@ -222,6 +222,7 @@ def ref(depth):
     g("ref_motion_estimate", i32, [vp, vp, ip, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp])
     g("ref_motion_estimate_chroma", i32, [vp, vp, vp, vp, vp, vp, ip, ip, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp])
     g("ref_pred_inter_bi", None, [vp, vp, vp, vp, vp, vp, ip, ip, i32, i32, i32, i32, vp, vp, vp, vp, vp])
+    g("ref_motion_compensation", None, [vp, vp, vp, vp, vp, vp, ip, ip, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp])
     g("ref_intra_filter", None, [i32, vp, vp])
     g("ref_intra_pred", None, [i32, i32, vp, ip, vp, i32])
     g("ref_intra_allangs", None, [i32, vp, vp, vp, i32])

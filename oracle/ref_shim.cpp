@@ -20,6 +20,8 @@
 #include "slicetype.h"
 #include "predict.h"
 #include "shortyuv.h"
+#include "framedata.h"
+#include "cudata.h"
 
 using namespace X265_NS;
 
@@ -554,6 +556,88 @@ void ref_pred_inter_bi(pixel* r0y, pixel* r0cb, pixel* r0cr, pixel* r1y, pixel* 
         memcpy(dstCr + y * (w / 2), out.m_buf[2] + y * out.m_csize, (w / 2) * sizeof(pixel));
     }
     s[0].destroy(); s[1].destroy(); out.destroy();
+}
+
+/* ---- the real Predict::motionCompensation (common/predict.cpp:77-266), every branch: a one-PU CUData / Slice / PPS around caller-owned
+ * planes.  r1y == NULL: uni-prediction (sliceP: a P slice; else a B slice whose only reference sits in list `uniList`); wp0 / wp1: three
+ * {inputWeight, inputOffset, log2WeightDenom, wtPresent} per list or NULL = weighted prediction off in the PPS.  dst* = h x w blocks. */
+void ref_motion_compensation(pixel* r0y, pixel* r0cb, pixel* r0cr, pixel* r1y, pixel* r1cb, pixel* r1cr, intptr_t stride, intptr_t strideC,
+                             int bx, int by, int w, int h, const int32_t* mv0, const int32_t* mv1, const int32_t* wp0, const int32_t* wp1,
+                             int sliceP, int uniList, pixel* dstY, pixel* dstCb, pixel* dstCr)
+{
+    T();
+    Predict pr;
+    pr.allocBuffers(X265_CSP_I420);
+    Yuv out;
+    out.create(MAX_CU_SIZE, X265_CSP_I420);
+    x265_param param;
+    memset(&param, 0, sizeof(param));
+    param.maxCUSize = 64;
+    FrameData enc;
+    enc.m_param = &param;
+    alignas(SPS) unsigned char spsRaw[sizeof(SPS)];
+    alignas(PPS) unsigned char ppsRaw[sizeof(PPS)];
+    memset(spsRaw, 0, sizeof(spsRaw));
+    memset(ppsRaw, 0, sizeof(ppsRaw));
+    SPS& sps = *reinterpret_cast<SPS*>(spsRaw);
+    PPS& pps = *reinterpret_cast<PPS*>(ppsRaw);
+    sps.picWidthInLumaSamples = 1 << 16;                  /* clipMv (cudata.cpp:1915) leaves the test vectors alone */
+    sps.picHeightInLumaSamples = 1 << 16;
+    const bool bi = r1y != NULL;
+    pps.bUseWeightPred = wp0 != NULL;
+    pps.bUseWeightedBiPred = bi ? (wp0 != NULL && wp1 != NULL) : (wp0 != NULL);
+    Slice slice;
+    slice.m_sps = &sps;
+    slice.m_pps = &pps;
+    slice.m_sliceType = sliceP ? P_SLICE : B_SLICE;
+    slice.m_numRefIdx[0] = slice.m_numRefIdx[1] = 1;
+    intptr_t zero = 0, offY = bx + (intptr_t)by * stride, offC = (bx >> 1) + (intptr_t)(by >> 1) * strideC;
+    PicYuv pics[2];
+    pixel* planes[2][3] = { { r0y, r0cb, r0cr }, { r1y, r1cb, r1cr } };
+    const int32_t* mvIn[2] = { mv0, mv1 };
+    const int32_t* wpIn[2] = { wp0, wp1 };
+    int8_t refIdx[2][1] = { { -1 }, { -1 } };
+    MV mvs[2][1];
+    CUData cu;
+    cu.m_slice = &slice;
+    cu.m_encData = &enc;
+    for (int k = 0; k < (bi ? 2 : 1); k++)
+    {
+        const int list = bi ? k : (sliceP ? 0 : uniList);  /* input k goes to this list */
+        PicYuv& ref = pics[list];
+        ref.m_cuOffsetY = &zero; ref.m_cuOffsetC = &zero; ref.m_buOffsetY = &offY; ref.m_buOffsetC = &offC;
+        ref.m_picOrg[0] = planes[k][0]; ref.m_picOrg[1] = planes[k][1]; ref.m_picOrg[2] = planes[k][2];
+        ref.m_stride = stride; ref.m_strideC = strideC;
+        slice.m_refReconPicList[list][0] = &ref;
+        refIdx[list][0] = 0;
+        mvs[list][0] = MV(mvIn[k][0], mvIn[k][1]);
+        if (wpIn[k])
+            for (int pl = 0; pl < 3; pl++)
+            {
+                WeightParam& p = slice.m_weightPredTable[list][0][pl];
+                p.inputWeight = wpIn[k][4 * pl]; p.inputOffset = wpIn[k][4 * pl + 1];
+                p.log2WeightDenom = (uint32_t)wpIn[k][4 * pl + 2]; p.wtPresent = wpIn[k][4 * pl + 3];
+            }
+    }
+    cu.m_refIdx[0] = refIdx[0]; cu.m_refIdx[1] = refIdx[1];
+    cu.m_mv[0] = mvs[0]; cu.m_mv[1] = mvs[1];
+    alignas(PredictionUnit) unsigned char puRaw[sizeof(PredictionUnit)];
+    PredictionUnit& pu = *reinterpret_cast<PredictionUnit*>(puRaw);
+    pu.ctuAddr = 0; pu.cuAbsPartIdx = 0; pu.puAbsPartIdx = 0; pu.width = w; pu.height = h;
+    pr.motionCompensation(cu, pu, out, true, true);
+    for (int y = 0; y < h; y++)
+        memcpy(dstY + y * w, out.m_buf[0] + y * out.m_size, w * sizeof(pixel));
+    for (int y = 0; y < h / 2; y++)
+    {
+        memcpy(dstCb + y * (w / 2), out.m_buf[1] + y * out.m_csize, (w / 2) * sizeof(pixel));
+        memcpy(dstCr + y * (w / 2), out.m_buf[2] + y * out.m_csize, (w / 2) * sizeof(pixel));
+    }
+    for (int l = 0; l < 2; l++)
+    {
+        pics[l].m_picOrg[0] = pics[l].m_picOrg[1] = pics[l].m_picOrg[2] = NULL;
+        pics[l].m_cuOffsetY = pics[l].m_cuOffsetC = pics[l].m_buOffsetY = pics[l].m_buOffsetC = NULL;
+    }
+    out.destroy();
 }
 
 } // extern "C"

@@ -362,6 +362,27 @@ class Orc(_Base):
         fn(r0, r1, ref0[0].shape[1], ref0[1].shape[1], bx, by, w, h, ptr(a0), ptr(a1), ptr(y), w, ptr(cb), ptr(cr), w // 2, self.depth)
         return y, cb, cr
 
+    def motion_compensation(self, ref0, ref1, bx, by, w, h, mv0, mv1, wp0, wp1, sliceP=0, uniList=0):
+        """Predict::motionCompensation for one PU: ref1 None = uni-prediction; wp = [(inputWeight, inputOffset, log2WeightDenom, wtPresent)] * 3
+        per list or None (weighted prediction off).  Returns (Y[h,w], Cb, Cr)."""
+        import ctypes as C
+        L = po.oracle()
+        fn = getattr(L, "orc_motion_compensation_%s" % self.s)
+        fn.restype = None
+        fn.argtypes = [po.vp, po.vp, po.ip, po.ip, po.i32, po.i32, po.i32, po.i32, po.vp, po.vp, po.vp, po.vp, po.vp, po.ip, po.vp, po.vp, po.ip, po.i32]
+        r0 = (C.c_void_p * 3)(*[ptr(p).value for p in ref0])
+        r1 = (C.c_void_p * 3)(*[ptr(p).value for p in ref1]) if ref1 is not None else None
+        H, S = ref0[0].shape
+        y, cb, cr = np.zeros((H, S), self.pix), np.zeros(ref0[1].shape, self.pix), np.zeros(ref0[1].shape, self.pix)
+        a0 = np.array(mv0, np.int32)
+        a1 = np.array(mv1 if mv1 is not None else (0, 0), np.int32)
+        w0 = np.array(wp0, np.int32).reshape(-1) if wp0 is not None else None
+        w1 = np.array(wp1, np.int32).reshape(-1) if wp1 is not None else None
+        fn(r0, r1, S, ref0[1].shape[1], bx, by, w, h, ptr(a0), ptr(a1), ptr(w0) if w0 is not None else None, ptr(w1) if w1 is not None else None,
+           ptr(y), S, ptr(cb), ptr(cr), ref0[1].shape[1], self.depth)
+        return (np.ascontiguousarray(y[by:by + h, bx:bx + w]), np.ascontiguousarray(cb[by // 2:(by + h) // 2, bx // 2:(bx + w) // 2]),
+                np.ascontiguousarray(cr[by // 2:(by + h) // 2, bx // 2:(bx + w) // 2]))
+
     # ---- weighted prediction, downscales, transpose
     def weight_pp(self, a, ao, w, h, w0, rnd, shift, offset):
         d = np.zeros_like(a)
@@ -674,6 +695,18 @@ class Ref(_Base):
         a0, a1 = np.array(mv0, np.int32), np.array(mv1, np.int32)
         self.L.ref_pred_inter_bi(ptr(ref0[0]), ptr(ref0[1]), ptr(ref0[2]), ptr(ref1[0]), ptr(ref1[1]), ptr(ref1[2]), ref0[0].shape[1],
                                  ref0[1].shape[1], bx, by, w, h, ptr(a0), ptr(a1), ptr(y), ptr(cb), ptr(cr))
+        return y, cb, cr
+
+    def motion_compensation(self, ref0, ref1, bx, by, w, h, mv0, mv1, wp0, wp1, sliceP=0, uniList=0):
+        y, cb, cr = np.zeros((h, w), self.pix), np.zeros((h // 2, w // 2), self.pix), np.zeros((h // 2, w // 2), self.pix)
+        a0 = np.array(mv0, np.int32)
+        a1 = np.array(mv1 if mv1 is not None else (0, 0), np.int32)
+        w0 = np.array(wp0, np.int32).reshape(-1) if wp0 is not None else None
+        w1 = np.array(wp1, np.int32).reshape(-1) if wp1 is not None else None
+        r1 = [ptr(p) for p in ref1] if ref1 is not None else [None, None, None]
+        self.L.ref_motion_compensation(ptr(ref0[0]), ptr(ref0[1]), ptr(ref0[2]), r1[0], r1[1], r1[2], ref0[0].shape[1], ref0[1].shape[1],
+                                       bx, by, w, h, ptr(a0), ptr(a1), ptr(w0) if w0 is not None else None, ptr(w1) if w1 is not None else None,
+                                       int(sliceP), int(uniList), ptr(y), ptr(cb), ptr(cr))
         return y, cb, cr
 
     # ---- weighted prediction, downscales, transpose

@@ -110,6 +110,64 @@ def bipred_results(backend_cls, depth):
     return out
 
 
+def mc_cases(depth):
+    """Predict::motionCompensation cases: (label, w, h, bx, by, mv0, mv1 or None, wp0, wp1, sliceP, uniList); every branch of
+    predict.cpp:77-266 — P / B-uni from either list / bi, each with weighted prediction off, on-but-absent for the reference, and
+    present (weights and offsets over the ranges weightAnalyse produces, denominators 0..7, all three planes different)."""
+    from backends import PU_SIZES
+    rng = np.random.default_rng(31 + depth)
+    out = []
+
+    def wp(present):
+        denom = int(rng.integers(0, 8))
+        return [(int(rng.integers(max(1, (1 << denom) // 2), min(127, 2 * (1 << denom)) + 1)), int(rng.integers(-40, 41)), denom, present)] + \
+               [(int(rng.integers(max(1, (1 << d) // 2), min(127, 2 * (1 << d)) + 1)), int(rng.integers(-20, 21)), d, int(rng.integers(0, 2)))
+                for d in (int(rng.integers(0, 8)), int(rng.integers(0, 8)))]
+    for (w, h) in PU_SIZES:
+        if (w, h) == (4, 4):
+            continue
+        for t in range(10):
+            bx, by = int(rng.integers(0, 192 - w) // 2 * 2), int(rng.integers(0, 160 - h) // 2 * 2)
+            mv0 = (int(rng.integers(-40, 41)), int(rng.integers(-40, 41)))
+            mv1 = (int(rng.integers(-40, 41)), int(rng.integers(-40, 41)))
+            if t % 5 == 0:
+                mv0 = (mv0[0] & ~7, mv0[1] & ~7)
+            if t % 5 == 1:
+                mv0, mv1 = (mv0[0] & ~7, mv0[1]), (mv1[0], mv1[1] & ~7)
+            kind = t % 10
+            if kind == 0:
+                out.append(("P plain", w, h, bx, by, mv0, None, None, None, 1, 0))
+            elif kind == 1:
+                out.append(("P weighted", w, h, bx, by, mv0, None, wp(1), None, 1, 0))
+            elif kind == 2:
+                out.append(("P absent", w, h, bx, by, mv0, None, wp(0), None, 1, 0))
+            elif kind == 3:
+                out.append(("B uni0 weighted", w, h, bx, by, mv0, None, wp(1), None, 0, 0))
+            elif kind == 4:
+                out.append(("B uni1 weighted", w, h, bx, by, mv0, None, wp(1), None, 0, 1))
+            elif kind == 5:
+                out.append(("B uni1 plain", w, h, bx, by, mv0, None, None, None, 0, 1))
+            elif kind == 6:
+                out.append(("B bi plain", w, h, bx, by, mv0, mv1, None, None, 0, 0))
+            elif kind == 7:
+                out.append(("B bi weighted", w, h, bx, by, mv0, mv1, wp(1), wp(1), 0, 0))
+            elif kind == 8:
+                out.append(("B bi one-sided", w, h, bx, by, mv0, mv1, wp(0), wp(1), 0, 0))
+            else:
+                out.append(("B bi absent", w, h, bx, by, mv0, mv1, wp(0), wp(0), 0, 0))
+    return out
+
+
+def mc_results(backend_cls, depth):
+    b = backend_cls(depth)
+    ref, src, m = me_scene_yuv(depth, 58 + depth)
+    out = {}
+    for i, (label, w, h, bx, by, mv0, mv1, wp0, wp1, sliceP, uniList) in enumerate(mc_cases(depth)):
+        out["mc %s %dx%d #%d" % (label, w, h, i)] = b.motion_compensation(ref, src if mv1 is not None else None, m + bx, m + by, w, h, mv0, mv1,
+                                                                           wp0, wp1, sliceP, uniList)
+    return out
+
+
 LOWRES_CASES = [(200, 136), (176, 144), (66, 50)]   # (W, H) of the full-resolution picture
 
 
@@ -177,7 +235,8 @@ if __name__ == "__main__":
     gold = {}
     for depth in (8, 10):
         gold[str(depth)] = {"prims": prim_digests(Ref, depth), "me": me_digests(Ref, depth), "umh": umh_results(Ref, depth), "chroma_me": chroma_me_results(Ref, depth),
-                            "bipred": {k: digest(v) for k, v in bipred_results(Ref, depth).items()}, "lowres": lowres_digests(Ref, depth), "lookahead": lookahead_digests(Ref, depth),
+                            "bipred": {k: digest(v) for k, v in bipred_results(Ref, depth).items()},
+                            "mc": {k: digest(v) for k, v in mc_results(Ref, depth).items()}, "lowres": lowres_digests(Ref, depth), "lookahead": lookahead_digests(Ref, depth),
                             "lookahead_b": {k: digest(v) for k, v in lookahead_b_results(Ref, depth).items()},
                             "mvcost": {str(qp): digest(Ref(depth).mvcost_table(qp)) for qp in (12, 28, 37, 51)}}
     path = os.path.join(HERE, "primitives_golden.json")

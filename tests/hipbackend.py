@@ -502,6 +502,29 @@ class Hip:
         return (np.ascontiguousarray(y[by:by + h, bx:bx + w]), np.ascontiguousarray(cb[by // 2:by // 2 + h // 2, bx // 2:bx // 2 + w // 2]),
                 np.ascontiguousarray(cr[by // 2:by // 2 + h // 2, bx // 2:bx // 2 + w // 2]))
 
+    def motion_compensation_batch(self, ref0, ref1, w, h, pu_xy, mv0, mv1, wp0, wp1):
+        """x265hip_motion_compensation_batch: ref1 None = uni-prediction.  Returns the three destination planes."""
+        from x265_amd.framepass import YuvStruct
+        from x265_amd.hipprim import WeightParam
+        d0 = [DevBuf(p) for p in ref0]
+        d1 = [DevBuf(p) for p in ref1] if ref1 is not None else None
+        out = [DevBuf.zeros(p.shape, self.pix) for p in ref0]
+        sy, sc = ref0[0].shape[1], ref0[1].shape[1]
+        a = YuvStruct(d0[0].ptr, d0[1].ptr, d0[2].ptr, sy, sc)
+        b = YuvStruct(d1[0].ptr, d1[1].ptr, d1[2].ptr, sy, sc) if d1 else None
+        c = YuvStruct(out[0].ptr, out[1].ptr, out[2].ptr, sy, sc)
+        w0 = (WeightParam * 3)(*[WeightParam(*t) for t in wp0]) if wp0 is not None else None
+        w1 = (WeightParam * 3)(*[WeightParam(*t) for t in wp1]) if wp1 is not None else None
+        check(self.L.x265hip_motion_compensation_batch(self.depth, w, h, C.byref(a), C.byref(b) if b else None, C.byref(c),
+                                                       _ip(np.asarray(pu_xy, np.int32)), _ip(np.asarray(mv0, np.int32)),
+                                                       _ip(np.asarray(mv1, np.int32)) if ref1 is not None else None, len(pu_xy), w0, w1, None))
+        return [o.get() for o in out]
+
+    def motion_compensation(self, ref0, ref1, bx, by, w, h, mv0, mv1, wp0, wp1, sliceP=0, uniList=0):
+        y, cb, cr = self.motion_compensation_batch(ref0, ref1, w, h, [(bx, by)], [mv0], [mv1] if mv1 is not None else None, wp0, wp1)
+        return (np.ascontiguousarray(y[by:by + h, bx:bx + w]), np.ascontiguousarray(cb[by // 2:by // 2 + h // 2, bx // 2:bx // 2 + w // 2]),
+                np.ascontiguousarray(cr[by // 2:by // 2 + h // 2, bx // 2:bx // 2 + w // 2]))
+
     # ---- small primitives: var, weighted prediction, downscales, transpose
     def var(self, size, a, ao):
         da = DevBuf(a)

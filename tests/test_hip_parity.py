@@ -598,6 +598,39 @@ def test_bipred_matches_oracle(hipmod, depth):
     assert np.array_equal(y, wy) and np.array_equal(cb, wcb) and np.array_equal(cr, wcr)
 
 
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_motion_compensation_matches_oracle_and_golden(hipmod, depth):
+    """Predict::motionCompensation, every branch (P / B-uni / bi x weighted prediction off, on-but-absent, present) for every PU shape
+    against the oracle and the committed vectors of the real reference; then a frame-shaped weighted bi-predictive batch."""
+    import json
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    from cases import me_scene_yuv, digest
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "primitives_golden.json")))["golden"][str(depth)]["mc"]
+    want = make_golden.mc_results(Orc, depth)
+    got = make_golden.mc_results(hipmod.Hip, depth)
+    hipmod._release()
+    bad = [k for k in want if not same(want[k], got[k]) or digest(got[k]) != gold[k]]
+    assert len(want) >= 240 and not bad, (len(bad), bad[:8])
+    o, g = Orc(depth), hipmod.Hip(depth)
+    ref, src, m = me_scene_yuv(depth, 58 + depth)
+    rng = np.random.default_rng(13)
+    pus = [(m + x, m + y) for y in range(0, 160, 16) for x in range(0, 192, 16)]
+    mv0 = [(int(rng.integers(-30, 31)), int(rng.integers(-30, 31))) for _ in pus]
+    mv1 = [(int(rng.integers(-30, 31)), int(rng.integers(-30, 31))) for _ in pus]
+    wp0, wp1 = [(70, 5, 6, 1), (60, -3, 6, 1), (33, 2, 5, 0)], [(61, -7, 6, 0), (64, 0, 6, 0), (29, 1, 5, 1)]
+    for r1, v1, w1 in ((src, mv1, wp1), (None, None, None)):
+        y, cb, cr = g.motion_compensation_batch(ref, r1, 16, 16, pus, mv0, v1, wp0, w1)
+        hipmod._release()
+        wy, wcb, wcr = np.zeros_like(y), np.zeros_like(cb), np.zeros_like(cr)
+        for i, (bx, by) in enumerate(pus):
+            py, pcb, pcr = o.motion_compensation(ref, r1, bx, by, 16, 16, mv0[i], v1[i] if v1 else None, wp0, w1)
+            wy[by:by + 16, bx:bx + 16] = py
+            wcb[by // 2:by // 2 + 8, bx // 2:bx // 2 + 8] = pcb
+            wcr[by // 2:by // 2 + 8, bx // 2:bx // 2 + 8] = pcr
+        assert np.array_equal(y, wy) and np.array_equal(cb, wcb) and np.array_equal(cr, wcr)
+
+
 @pytest.mark.parametrize("depth", [8, 10, 12])
 def test_lookahead_p_cost_matches_oracle(hipmod, depth):
     """The lookahead's P-frame cost pass (lowres init -> intra estimate -> estimateCUCost over the frame) on the GPU vs the

@@ -39,6 +39,11 @@ def test_oracle_chroma_motion_estimate_matches_golden(depth):
 
 
 @pytest.mark.parametrize("depth", [8, 10])
+def test_oracle_motion_compensation_matches_golden(depth):
+    assert {k: digest(v) for k, v in make_golden.mc_results(Orc, depth).items()} == GOLD[str(depth)]["mc"]
+
+
+@pytest.mark.parametrize("depth", [8, 10])
 def test_oracle_bipred_matches_golden(depth):
     assert {k: digest(v) for k, v in make_golden.bipred_results(Orc, depth).items()} == GOLD[str(depth)]["bipred"]
 

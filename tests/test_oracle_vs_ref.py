@@ -51,6 +51,19 @@ def test_every_primitive_matches_reference(depth):
 
 
 @pytest.mark.parametrize("depth", DEPTHS)
+def test_motion_compensation_matches_reference(depth):
+    """The real Predict::motionCompensation (one-PU CUData / Slice / PPS around the test planes) vs the restatement, every branch."""
+    _need_ref(depth)
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    a, b = make_golden.mc_results(Orc, depth), make_golden.mc_results(Ref, depth)
+    assert len(a) >= 240
+    bad = [k for k in a if not same(a[k], b[k])]
+    assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_umh_search_matches_reference(depth):
     """X265_UMH_SEARCH on scenes built to reach its early-termination, cross and adaptive-range branches (tests/cases.py umh_scenes)."""
     _need_ref(depth)

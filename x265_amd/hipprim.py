@@ -116,6 +116,7 @@ PROTOTYPES = {
     "x265hip_intra_allangs_batch": (i32, [i32, i32, vp, vp, vp, i32, vp, i32, vp]),
     "x265hip_intra_filter_batch": (i32, [i32, i32, vp, vp, vp, vp, i32, vp]),
     "x265hip_pred_inter_bi_batch": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "x265hip_motion_compensation_batch": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
     "x265hip_intra_scan_batch": (i32, [i32, i32, vp, vp, vp, vp, i64, vp, i32, vp, vp]),
     "x265hip_frame_init_lowres": (i32, [i32, vp, i64, vp, vp, vp, vp, i64, i32, i32, vp]),
     "x265hip_lowres_init": (i32, [i32, vp, i64, C.POINTER(vp), i64, i32, i32, i32, i32, vp]),
@@ -131,6 +132,11 @@ PROTOTYPES = {
 }
 
 CMP_SAD, CMP_SATD, CMP_SA8D, CMP_SA8D8, CMP_PSY = 0, 1, 2, 3, 4
+
+
+class WeightParam(C.Structure):
+    """x265hip_weight_param (include/x265hip.h): one plane's WeightParam of the slice header"""
+    _fields_ = [("inputWeight", C.c_int32), ("inputOffset", C.c_int32), ("log2WeightDenom", C.c_int32), ("wtPresent", C.c_int32)]
 
 
 class LookaheadPair(C.Structure):
