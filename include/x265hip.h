@@ -139,6 +139,44 @@ int x265hip_denoise_dct_batch(int16_t* dctCoef, uint32_t* resSum, const uint16_t
 int x265hip_rdoq_cost_batch(int kind, int size, int depth, const int16_t* resiDct, const int16_t* fencDct, const int64_t* psyScale,
                             const int32_t* tu, const int32_t* blkPos, int n, int64_t* costUncoded, int64_t* cgUncoded, int64_t* cgRd, void* stream);
 
+/* ---- coefficient-scan cost primitives of the RDOQ / bit-estimation loop (dct.cpp:757-1006; callers quant.cpp:610-1420, entropy.cpp
+ * codeCoeffNxN).  scanType: SCAN_DIAG 0, SCAN_HOR 1, SCAN_VER 2 (common.h:404-407; 16x16 and 32x32 units are always scanned diagonally).
+ * The scan orders (constants.cpp g_scanOrder / g_scan4x4) are built in the library by the rule of the standard.  The CABAC cost table is
+ * the encoder's data: upload x265_entropyStateBits[128] (constants.cpp) once before the two cost calls that read it (host pointer). */
+int x265hip_set_entropy_state_bits(const uint32_t* bits128);
+/* scanPosLast_t (primitives.h:217; dct.cpp:757): TU i = coeff[i << (2 log2TrSize) ...] (dense), every TU must hold at least one non-zero
+ * coefficient for lastPos to mean what the reference's does (an all-zero TU gives 0); numSig of the reference is implied by the data.
+ * Outputs per TU: coeffSign / coeffFlag / coeffNum [64] (MLS_GRP_NUM) and the last significant scan position. */
+int x265hip_scan_pos_last_batch(int log2TrSize, int scanType, const int16_t* coeff, int n, uint16_t* coeffSign, uint16_t* coeffFlag,
+                                uint8_t* coeffNum, int32_t* lastPos, void* stream);
+/* findPosFirstLast_t (primitives.h:218; dct.cpp:795): job i is the 4x4 group at coeff + cgOffsets[i] of a unit with row pitch trSize;
+ * out = (absSumSign << 31) | (lastNZPosInCG << 8) | firstNZPosInCG.  Undefined for an all-zero group, as in the reference. */
+int x265hip_find_pos_first_last_batch(const int16_t* coeff, const int64_t* cgOffsets, int64_t trSize, int scanType, int n, uint32_t* out,
+                                      void* stream);
+/* costCoeffNxN_t (primitives.h:220; dct.cpp:841): the significance flags of one 4x4 group from scanPosSigOff down to 0.  Job fields are
+ * the reference's arguments (scanType selects its `scan` = g_scan4x4[type]); baseCtx + i * ctxStride is job i's private copy of the
+ * significance contexts (read and advanced), absCoeff + 16 i receives the levels as the reference's absCoeff does, bits[i] the sum. */
+typedef struct x265hip_coeff_group_job
+{
+    int64_t coeffOffset;         /* the group's top-left coefficient, in elements from `coeff` */
+    int32_t trSize;              /* row pitch of the unit */
+    int32_t scanType;
+    uint32_t scanFlagMask;
+    int32_t offset;
+    int32_t scanPosSigOff;
+    int32_t subPosBase;
+    uint8_t tabSigCtx[16];
+} x265hip_coeff_group_job;
+int x265hip_cost_coeff_nxn_batch(const int16_t* coeff, const x265hip_coeff_group_job* jobs, int n, uint8_t* baseCtx, int ctxStride,
+                                 uint16_t* absCoeff, uint32_t* bits, void* stream);
+/* costCoeffRemain_t (primitives.h:221; dct.cpp:901): job i = levels absCoeff[16 i ...], numNonZero[i], first index firstIdx[i] */
+int x265hip_cost_coeff_remain_batch(const uint16_t* absCoeff, const int32_t* numNonZero, const int32_t* firstIdx, int n, uint32_t* bits,
+                                    void* stream);
+/* costC1C2Flag_t (primitives.h:222; dct.cpp:949): job i = levels absCoeff[16 i ...], numC1Flag[i] (1..8); baseCtxMod + i * ctxStride is
+ * the job's greater-than-1 context set (4 bytes, advanced) with its greater-than-2 context at [ctxOffset]. */
+int x265hip_cost_c1c2_flag_batch(const uint16_t* absCoeff, const int32_t* numC1Flag, uint8_t* baseCtxMod, int ctxStride, int ctxOffset, int n,
+                                 uint32_t* out, void* stream);
+
 /* ---------------------------------------------------------------- interpolation ----------------------------- */
 /* filter_pp_t / filter_hps_t / filter_ps_t / filter_sp_t / filter_ss_t / filter_hv_pp_t (primitives.h:176-183;
  * ipfilter.cpp:79-369).  taps = 8 (luma) or 4 (chroma).  One job = one W x H block:
@@ -451,6 +489,15 @@ int x265hip_call_weight_sp(int depth, const int16_t* src, void* dst, int64_t src
 int x265hip_call_scale1d_128to64(int depth, void* dst, const void* src);
 int x265hip_call_scale2d_64to32(int depth, void* dst, const void* src, int64_t stride);
 int x265hip_call_transpose(int depth, int size, void* dst, const void* src, int64_t stride);
+/* scanPosLast_t / findPosFirstLast_t / costCoeffNxN_t / costCoeffRemain_t / costC1C2Flag_t (primitives.h:217-222) on host buffers;
+ * `scanType` is what the caller's scan-table pointer identifies (the shim compares it with g_scanOrder / g_scan4x4). */
+int x265hip_call_scan_pos_last(int log2TrSize, int scanType, const int16_t* coeff, uint16_t* coeffSign, uint16_t* coeffFlag, uint8_t* coeffNum,
+                               int numSig, int* lastPos);
+int x265hip_call_find_pos_first_last(const int16_t* dstCoeff, int64_t trSize, int scanType, uint32_t* result);
+int x265hip_call_cost_coeff_nxn(int scanType, const int16_t* coeff, int64_t trSize, uint16_t* absCoeff, const uint8_t* tabSigCtx,
+                                uint32_t scanFlagMask, uint8_t* baseCtx, int offset, int scanPosSigOff, int subPosBase, uint32_t* result);
+int x265hip_call_cost_coeff_remain(const uint16_t* absCoeff, int numNonZero, int idx, uint32_t* result);
+int x265hip_call_cost_c1c2_flag(const uint16_t* absCoeff, int64_t numC1Flag, uint8_t* baseCtxMod, int64_t ctxOffset, uint32_t* result);
 int x265hip_call_intra_pred(int depth, int n, int mode, int bFilter, void* dst, int64_t dstStride, const void* line);
 int x265hip_call_intra_allangs(int depth, int n, void* dest, const void* line, const void* filtered, int bLuma);
 int x265hip_call_intra_filter(int depth, int n, const void* line, void* filtered);

@@ -222,6 +222,15 @@ def ref(depth):
     g("ref_motion_estimate", i32, [vp, vp, ip, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp])
     g("ref_motion_estimate_chroma", i32, [vp, vp, vp, vp, vp, vp, ip, ip, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp])
     g("ref_pred_inter_bi", None, [vp, vp, vp, vp, vp, vp, ip, ip, i32, i32, i32, i32, vp, vp, vp, vp, vp])
+    u16p = u8p = vp
+    g("ref_scan_order", None, [i32, i32, vp])
+    g("ref_scan4x4", None, [i32, vp])
+    g("ref_entropy_state_bits", None, [vp])
+    g("ref_scanPosLast", i32, [vp, vp, vp, vp, vp, i32, vp, i32])
+    g("ref_findPosFirstLast", C.c_uint32, [vp, ip, vp])
+    g("ref_costCoeffNxN", C.c_uint32, [vp, vp, ip, vp, vp, C.c_uint32, vp, i32, i32, i32])
+    g("ref_costCoeffRemain", C.c_uint32, [vp, i32, i32])
+    g("ref_costC1C2Flag", C.c_uint32, [vp, ip, vp, ip])
     g("ref_motion_compensation", None, [vp, vp, vp, vp, vp, vp, ip, ip, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp])
     g("ref_intra_filter", None, [i32, vp, vp])
     g("ref_intra_pred", None, [i32, i32, vp, ip, vp, i32])

@@ -21,6 +21,8 @@
 #include "predict.h"
 #include "shortyuv.h"
 #include "framedata.h"
+#include "constants.h"
+#include "contexts.h"
 #include "cudata.h"
 
 using namespace X265_NS;
@@ -639,5 +641,22 @@ void ref_motion_compensation(pixel* r0y, pixel* r0cb, pixel* r0cr, pixel* r1y, p
     }
     out.destroy();
 }
+
+/* ---- coefficient-scan cost primitives (common/dct.cpp:757-1006 via the C table) and the tables they walk (constants.cpp) ---- */
+void ref_scan_order(int type, int sizeIdx, uint16_t* out) { memcpy(out, g_scanOrder[type][sizeIdx], (size_t)(16 << (2 * sizeIdx)) * sizeof(uint16_t)); }
+void ref_scan4x4(int type, uint16_t* out) { memcpy(out, g_scan4x4[type], 16 * sizeof(uint16_t)); }
+void ref_entropy_state_bits(uint32_t* out) { memcpy(out, PFX(entropyStateBits), 128 * sizeof(uint32_t)); }
+int ref_scanPosLast(const uint16_t* scan, const coeff_t* coeff, uint16_t* sign, uint16_t* flag, uint8_t* num, int numSig, const uint16_t* cg4x4, int trSize)
+{
+    return T().scanPosLast(scan, coeff, sign, flag, num, numSig, cg4x4, trSize);
+}
+uint32_t ref_findPosFirstLast(const int16_t* c, intptr_t trSize, const uint16_t* scanTbl) { return T().findPosFirstLast(c, trSize, scanTbl); }
+uint32_t ref_costCoeffNxN(const uint16_t* scan, const coeff_t* coeff, intptr_t trSize, uint16_t* absCoeff, const uint8_t* tabSigCtx, uint32_t mask,
+                          uint8_t* baseCtx, int offset, int scanPosSigOff, int subPosBase)
+{
+    return T().costCoeffNxN(scan, coeff, trSize, absCoeff, tabSigCtx, mask, baseCtx, offset, scanPosSigOff, subPosBase);
+}
+uint32_t ref_costCoeffRemain(uint16_t* absCoeff, int numNonZero, int idx) { return T().costCoeffRemain(absCoeff, numNonZero, idx); }
+uint32_t ref_costC1C2Flag(uint16_t* absCoeff, intptr_t n, uint8_t* ctx, intptr_t ctxOffset) { return T().costC1C2Flag(absCoeff, n, ctx, ctxOffset); }
 
 } // extern "C"

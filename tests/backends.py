@@ -34,6 +34,60 @@ class _Base:
         self.pmax = (1 << depth) - 1
 
 
+def entropy_state_bits_fixture():
+    """x265_entropyStateBits[128] as dumped from the reference build by tests/golden/make_golden.py (data, not an algorithm)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "entropy_state_bits.json")
+    return np.array(json.load(open(path))["entropyStateBits"], np.uint32)
+
+
+def scan_order_py(stype, log2):
+    """The scan of a (1 << log2) TU by the rule of the standard (4x4 groups in `stype` order, 16x16 / 32x32 always diagonal); used by the
+    test wrappers to place jobs, and checked against the oracle / reference tables in the tests."""
+    def pos(t, n):
+        out = []
+        if t == 0:
+            x = y = 0
+            while len(out) < n * n:
+                while y >= 0:
+                    if x < n and y < n:
+                        out.append((x, y))
+                    y -= 1
+                    x += 1
+                y, x = x, 0
+        elif t == 1:
+            out = [(x, y) for y in range(n) for x in range(n)]
+        else:
+            out = [(x, y) for x in range(n) for y in range(n)]
+        return out
+    size = 1 << log2
+    t = 0 if log2 > 3 else stype
+    cg = pos(t, size // 4) if size > 4 else [(0, 0)]
+    inner = pos(t, 4)
+    return np.array([(cy * 4 + py) * size + cx * 4 + px for (cx, cy) in cg for (px, py) in inner], np.uint16)
+
+
+def sig_ctx_table(log2, pattern):
+    """tabSigCtx of codeCoeffNxN (entropy.cpp table_cnt; HEVC 9.3.4.2.5): the significance-context increment of each position of a 4x4
+    group — the fixed map of a 4x4 TU, otherwise by which neighbouring groups are coded (pattern bit 0: right, bit 1: below)."""
+    if log2 == 2:
+        return np.array([0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8], np.uint8)
+    t = np.zeros(16, np.uint8)
+    for y in range(4):
+        for x in range(4):
+            if pattern == 0:
+                v = 2 if x + y == 0 else (1 if x + y < 3 else 0)
+            elif pattern == 1:
+                v = 2 if y == 0 else (1 if y == 1 else 0)
+            elif pattern == 2:
+                v = 2 if x == 0 else (1 if x == 1 else 0)
+            else:
+                v = 2
+            t[y * 4 + x] = v
+    return t
+
+
 class Orc(_Base):
     name = "oracle"
 
@@ -383,6 +437,67 @@ class Orc(_Base):
         return (np.ascontiguousarray(y[by:by + h, bx:bx + w]), np.ascontiguousarray(cb[by // 2:(by + h) // 2, bx // 2:(bx + w) // 2]),
                 np.ascontiguousarray(cr[by // 2:(by + h) // 2, bx // 2:(bx + w) // 2]))
 
+    # ---- coefficient-scan cost primitives (dct.cpp:757-1006)
+    def _cf(self, name, restype, argtypes):
+        import ctypes as C
+        fn = getattr(po.oracle(), name)
+        fn.restype, fn.argtypes = restype, argtypes
+        return fn
+
+    def scan_order(self, stype, log2):
+        out = np.zeros(1 << (2 * log2), np.uint16)
+        self._cf("orc_scan_order", None, [po.i32, po.i32, po.vp])(stype, log2, ptr(out))
+        return out
+
+    def scan4x4(self, stype):
+        return self.scan_order(stype, 2)
+
+    def entropy_state_bits(self):
+        return entropy_state_bits_fixture()
+
+    def scan_pos_last(self, log2, stype, coeff):
+        import ctypes as C
+        scan = self.scan_order(stype, log2)
+        sign, flag, num = np.zeros(64, np.uint16), np.zeros(64, np.uint16), np.zeros(64, np.uint8)
+        c = np.ascontiguousarray(coeff, np.int16).reshape(-1)
+        last = self._cf("orc_scanPosLast", po.i32, [po.vp, po.vp, po.vp, po.vp, po.vp, po.i32])(ptr(scan), ptr(c), ptr(sign), ptr(flag), ptr(num),
+                                                                                              int(np.count_nonzero(c)))
+        return int(last), sign, flag, num
+
+    def find_pos_first_last(self, tu, cgx, cgy, stype):
+        import ctypes as C
+        tu = np.ascontiguousarray(tu, np.int16)
+        scan = self.scan4x4(stype)
+        return int(self._cf("orc_findPosFirstLast", C.c_uint32, [po.vp, po.ip, po.vp])(ptr(tu, cgy * 4, cgx * 4), tu.shape[1], ptr(scan)))
+
+    def cost_coeff_nxn(self, tu, log2, stype, cgIdx, scanPosSigOff, pattern, offset, ctx):
+        """One coefficient group (the cgIdx-th of the TU's scan) from scanPosSigOff down: (bits, absCoeff[16] with the unwritten tail zero, ctx after)."""
+        import ctypes as C
+        tu = np.ascontiguousarray(tu, np.int16)
+        scan, scan4 = self.scan_order(stype, log2), self.scan4x4(stype if log2 <= 3 else 0)
+        base = int(scan[cgIdx * 16])
+        mask = 0
+        for k in range(scanPosSigOff + 1):
+            mask = mask * 2 + int(tu.reshape(-1)[scan[cgIdx * 16 + k]] != 0)
+        absC, ctx2 = np.zeros(16, np.uint16), np.array(ctx, np.uint8)
+        tab = sig_ctx_table(log2, pattern)
+        bits = self._cf("orc_costCoeffNxN", C.c_uint32, [po.vp, po.vp, po.ip, po.vp, po.vp, C.c_uint32, po.vp, po.i32, po.i32, po.i32, po.vp])
+        sb = self.entropy_state_bits()
+        first = 1 if scanPosSigOff < 15 else 0
+        r = bits(ptr(scan4), ptr(tu.reshape(-1), 0, base), tu.shape[1], ptr(absC, 0, first), ptr(tab), mask, ptr(ctx2), offset, scanPosSigOff, cgIdx * 16, ptr(sb))
+        return int(r), absC, ctx2
+
+    def cost_coeff_remain(self, absCoeff, numNonZero, idx):
+        import ctypes as C
+        a = np.ascontiguousarray(absCoeff, np.uint16)
+        return int(self._cf("orc_costCoeffRemain", C.c_uint32, [po.vp, po.i32, po.i32])(ptr(a), numNonZero, idx))
+
+    def cost_c1c2_flag(self, absCoeff, numC1Flag, ctx, ctxOffset):
+        import ctypes as C
+        a, ctx2, sb = np.ascontiguousarray(absCoeff, np.uint16), np.array(ctx, np.uint8), self.entropy_state_bits()
+        r = self._cf("orc_costC1C2Flag", C.c_uint32, [po.vp, po.ip, po.vp, po.ip, po.vp])(ptr(a), numC1Flag, ptr(ctx2), ctxOffset, ptr(sb))
+        return int(r), ctx2
+
     # ---- weighted prediction, downscales, transpose
     def weight_pp(self, a, ao, w, h, w0, rnd, shift, offset):
         d = np.zeros_like(a)
@@ -708,6 +823,57 @@ class Ref(_Base):
                                        bx, by, w, h, ptr(a0), ptr(a1), ptr(w0) if w0 is not None else None, ptr(w1) if w1 is not None else None,
                                        int(sliceP), int(uniList), ptr(y), ptr(cb), ptr(cr))
         return y, cb, cr
+
+    # ---- coefficient-scan cost primitives (dct.cpp:757-1006)
+    def scan_order(self, stype, log2):
+        out = np.zeros(1 << (2 * log2), np.uint16)
+        self.L.ref_scan_order(stype, log2 - 2, ptr(out))
+        return out
+
+    def scan4x4(self, stype):
+        out = np.zeros(16, np.uint16)
+        self.L.ref_scan4x4(stype, ptr(out))
+        return out
+
+    def entropy_state_bits(self):
+        out = np.zeros(128, np.uint32)
+        self.L.ref_entropy_state_bits(ptr(out))
+        return out
+
+    def scan_pos_last(self, log2, stype, coeff):
+        scan, scan4 = self.scan_order(stype, log2), self.scan4x4(stype if log2 <= 3 else 0)
+        sign, flag, num = np.zeros(64, np.uint16), np.zeros(64, np.uint16), np.zeros(64, np.uint8)
+        c = np.ascontiguousarray(coeff, np.int16).reshape(-1)
+        last = self.L.ref_scanPosLast(ptr(scan), ptr(c), ptr(sign), ptr(flag), ptr(num), int(np.count_nonzero(c)), ptr(scan4), 1 << log2)
+        return int(last), sign, flag, num
+
+    def find_pos_first_last(self, tu, cgx, cgy, stype):
+        tu = np.ascontiguousarray(tu, np.int16)
+        scan = self.scan4x4(stype)
+        return int(self.L.ref_findPosFirstLast(ptr(tu, cgy * 4, cgx * 4), tu.shape[1], ptr(scan)))
+
+    def cost_coeff_nxn(self, tu, log2, stype, cgIdx, scanPosSigOff, pattern, offset, ctx):
+        tu = np.ascontiguousarray(tu, np.int16)
+        scan, scan4 = self.scan_order(stype, log2), self.scan4x4(stype if log2 <= 3 else 0)
+        base = int(scan[cgIdx * 16])
+        mask = 0
+        for k in range(scanPosSigOff + 1):
+            mask = mask * 2 + int(tu.reshape(-1)[scan[cgIdx * 16 + k]] != 0)
+        absC, ctx2 = np.zeros(16, np.uint16), np.array(ctx, np.uint8)
+        tab = sig_ctx_table(log2, pattern)
+        first = 1 if scanPosSigOff < 15 else 0
+        r = self.L.ref_costCoeffNxN(ptr(scan4), ptr(tu.reshape(-1), 0, base), tu.shape[1], ptr(absC, 0, first), ptr(tab), mask, ptr(ctx2), offset, scanPosSigOff,
+                                    cgIdx * 16)
+        return int(r), absC, ctx2
+
+    def cost_coeff_remain(self, absCoeff, numNonZero, idx):
+        a = np.ascontiguousarray(absCoeff, np.uint16)
+        return int(self.L.ref_costCoeffRemain(ptr(a), numNonZero, idx))
+
+    def cost_c1c2_flag(self, absCoeff, numC1Flag, ctx, ctxOffset):
+        a, ctx2 = np.ascontiguousarray(absCoeff, np.uint16), np.array(ctx, np.uint8)
+        r = self.L.ref_costC1C2Flag(ptr(a), numC1Flag, ptr(ctx2), ctxOffset)
+        return int(r), ctx2
 
     # ---- weighted prediction, downscales, transpose
     def weight_pp(self, a, ao, w, h, w0, rnd, shift, offset):

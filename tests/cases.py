@@ -359,3 +359,64 @@ def umh_groups(depth, groups_per_scene=6, npu=8):
                 g["cands"].append([((-dx * 4 + int(rng.integers(-8, 9)), -dy * 4 + int(rng.integers(-8, 9))) if rng.integers(0, 2)
                                     else (int(rng.integers(-60, 61)), int(rng.integers(-60, 61)))) for _ in range(numCand)])
             yield si, ref, src, g
+
+
+def coef_cases(seed=77):
+    """Cases for the coefficient-scan cost primitives, drawn as test/pixelharness.cpp:1705-2060 draws them (two thirds zeros, mostly negative
+    levels, every scan type and TU size, random CABAC states 2..124).  Yields (label, method, args) for Orc / Ref / Hip methods."""
+    rng = np.random.default_rng(seed)
+
+    def coeffs(n, density):
+        v = rng.integers(1, 0x7FFF, size=n).astype(np.int32)
+        v[rng.random(n) >= density] = 0
+        v[rng.random(n) < 0.8] *= -1
+        small = rng.random(n) < 0.5
+        v[small] = np.sign(v[small]) * rng.integers(1, 4, size=int(small.sum()))
+        return v.astype(np.int16)
+    for stype in range(3):
+        for log2 in (2, 3, 4, 5):
+            size = 1 << log2
+            for rep in range(6):
+                density = [0.33, 0.05, 0.6, 0.01, 0.2, 1.0][rep]
+                tu = coeffs(size * size, density).reshape(size, size)
+                if not tu.any():
+                    tu[-1, -1] = -1
+                if rep == 3:                                   # a single coefficient somewhere
+                    tu[:] = 0
+                    tu[int(rng.integers(0, size)), int(rng.integers(0, size))] = int(rng.choice([-1, 1, 300, -32768]))
+                yield ("scanPosLast t%d %dx%d #%d" % (stype, size, size, rep), "scan_pos_last", (log2, stype, tu.copy()))
+                ncg = (size // 4) ** 2
+                for k in range(3):
+                    cgx, cgy = int(rng.integers(0, size // 4)), int(rng.integers(0, size // 4))
+                    if tu[cgy * 4:cgy * 4 + 4, cgx * 4:cgx * 4 + 4].any():
+                        yield ("findPosFirstLast t%d %dx%d #%d.%d" % (stype, size, size, rep, k), "find_pos_first_last", (tu.copy(), cgx, cgy, stype))
+                    cg = int(rng.integers(0, ncg))
+                    off = int(rng.integers(0, 16))
+                    ctx = rng.integers(2, 125, size=64).astype(np.uint8)
+                    offset = 0 if log2 == 2 else (9 if log2 == 3 else 12)
+                    yield ("costCoeffNxN t%d %dx%d #%d.%d" % (stype, size, size, rep, k), "cost_coeff_nxn",
+                           (tu.copy(), log2, stype, cg, off, int(rng.integers(0, 4)), offset, ctx))
+    for rep in range(120):
+        a = rng.integers(0, 0x8000, size=16).astype(np.uint16)
+        a[rng.random(16) < 0.6] = 1
+        if rep % 3 == 0:
+            a = np.minimum(a, rng.integers(1, 60, size=16)).astype(np.uint16)
+        nnz = int(rng.integers(1, 17))
+        first = 0
+        while first < 8 and a[first] < 2:
+            first += 1
+        if first < nnz or rep % 2:
+            yield ("costCoeffRemain #%d" % rep, "cost_coeff_remain", (a.copy(), max(nnz, min(first, 15) + 1), min(first, 15)))
+    for rep in range(120):
+        vals = []
+        for _ in range(8):
+            v = int(rng.integers(0, 0x8000))
+            v = 0 if v < 0x7FFF // 3 else (1 if v < 0x7FFF * 2 // 3 else (2 if v < 0x7FFF * 3 // 4 else v))
+            if v:
+                vals.append(v)
+        if not vals:
+            vals = [1]
+        a = np.zeros(16, np.uint16)
+        a[:len(vals)] = vals
+        ctx = rng.integers(2, 125, size=8).astype(np.uint8)
+        yield ("costC1C2Flag #%d" % rep, "cost_c1c2_flag", (a, len(vals), ctx, int(rng.integers(0, 4)) + 4))

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import numpy as np  # noqa: E402
 from backends import Ref  # noqa: E402
-from cases import gen_cases, umh_groups, me_scene, me_scene_yuv, lowres_scene, lookahead_scene, lookahead_scene3, digest  # noqa: E402
+from cases import gen_cases, coef_cases, umh_groups, me_scene, me_scene_yuv, lowres_scene, lookahead_scene, lookahead_scene3, digest  # noqa: E402
 
 ME_CASES = [  # (method, subme, w, h, bx_off, by_off, merange, qmvp, mvc, qp)
     (1, 2, 16, 16, 16, 24, 57, (5, -7), [(12, 8), (-20, 4)], 28),
@@ -107,6 +107,16 @@ def bipred_results(backend_cls, depth):
             if t == 2:
                 mv0 = (mv0[0], mv0[1] & ~7)
             out["bi %dx%d #%d" % (w, h, t)] = b.pred_inter_bi(ref, src, bx, by, w, h, mv0, mv1)
+    return out
+
+
+def coef_digests(backend_cls):
+    """The coefficient-scan cost primitives (scanPosLast … costC1C2Flag) over tests/cases.py coef_cases, plus the scan orders themselves."""
+    b = backend_cls(8)
+    out = {label: digest(getattr(b, fn)(*args)) for label, fn, args in coef_cases()}
+    for t in range(3):
+        for log2 in (2, 3, 4, 5):
+            out["scanOrder t%d log2 %d" % (t, log2)] = digest(b.scan_order(t, log2))
     return out
 
 
@@ -239,8 +249,13 @@ if __name__ == "__main__":
                             "mc": {k: digest(v) for k, v in mc_results(Ref, depth).items()}, "lowres": lowres_digests(Ref, depth), "lookahead": lookahead_digests(Ref, depth),
                             "lookahead_b": {k: digest(v) for k, v in lookahead_b_results(Ref, depth).items()},
                             "mvcost": {str(qp): digest(Ref(depth).mvcost_table(qp)) for qp in (12, 28, 37, 51)}}
+    # the CABAC cost table is data of the reference: dump it for the tests and for the GPU box, where /root/reference does not exist
+    with open(os.path.join(HERE, "entropy_state_bits.json"), "w") as f:
+        json.dump({"source": "x265_entropyStateBits (common/constants.cpp) of the reference build, dumped by tests/golden/make_golden.py",
+                   "entropyStateBits": [int(v) for v in Ref(8).entropy_state_bits()]}, f)
+    gold["coef"] = coef_digests(Ref)
     path = os.path.join(HERE, "primitives_golden.json")
     with open(path, "w") as f:
         json.dump({"source": "x265 3.4+28 C primitives ([noasm]), /root/reference/source via oracle/Makefile",
                    "generator": "tests/golden/make_golden.py", "golden": gold}, f, indent=0, sort_keys=True)
-    print("wrote", path, {d: len(g["prims"]) for d, g in gold.items()})
+    print("wrote", path, {d: len(g["prims"]) for d, g in gold.items() if "prims" in g})

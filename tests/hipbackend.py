@@ -525,6 +525,93 @@ class Hip:
         return (np.ascontiguousarray(y[by:by + h, bx:bx + w]), np.ascontiguousarray(cb[by // 2:by // 2 + h // 2, bx // 2:bx // 2 + w // 2]),
                 np.ascontiguousarray(cr[by // 2:by // 2 + h // 2, bx // 2:bx // 2 + w // 2]))
 
+    # ---- coefficient-scan cost primitives (n = 1 batches of the batched entries)
+    def _coef_ready(self):
+        if not getattr(Hip, "_state_bits_set", False):
+            from backends import entropy_state_bits_fixture
+            sb = entropy_state_bits_fixture()
+            check(self.L.x265hip_set_entropy_state_bits(sb.ctypes.data_as(C.c_void_p)))
+            Hip._state_bits_set = True
+
+    def scan_pos_last_batch(self, log2, stype, tus):
+        """tus: [n, size, size] int16.  Returns (last[n], sign[n,64], flag[n,64], num[n,64])."""
+        n = len(tus)
+        d = DevBuf(np.ascontiguousarray(tus, np.int16))
+        sign, flag, num, last = DevBuf.zeros((n, 64), np.uint16), DevBuf.zeros((n, 64), np.uint16), DevBuf.zeros((n, 64), np.uint8), DevBuf.zeros((n,), np.int32)
+        check(self.L.x265hip_scan_pos_last_batch(log2, stype, d.ptr, n, sign.ptr, flag.ptr, num.ptr, last.ptr, None))
+        return last.get(), sign.get(), flag.get(), num.get()
+
+    def scan_pos_last(self, log2, stype, coeff):
+        last, sign, flag, num = self.scan_pos_last_batch(log2, stype, np.ascontiguousarray(coeff, np.int16)[None])
+        return int(last[0]), sign[0], flag[0], num[0]
+
+    def find_pos_first_last_batch(self, tu, cgs, stype):
+        tu = np.ascontiguousarray(tu, np.int16)
+        d = DevBuf(tu)
+        offs = DevBuf(np.array([cy * 4 * tu.shape[1] + cx * 4 for (cx, cy) in cgs], np.int64))
+        out = DevBuf.zeros((len(cgs),), np.uint32)
+        check(self.L.x265hip_find_pos_first_last_batch(d.ptr, offs.ptr, tu.shape[1], stype, len(cgs), out.ptr, None))
+        return out.get()
+
+    def find_pos_first_last(self, tu, cgx, cgy, stype):
+        return int(self.find_pos_first_last_batch(tu, [(cgx, cgy)], stype)[0])
+
+    def cost_coeff_nxn_batch(self, tu, log2, stype, jobs):
+        """jobs: list of (cgIdx, scanPosSigOff, pattern, offset, ctx[64]).  Returns (bits[n], absCoeff[n,16], ctx[n,64])."""
+        from backends import sig_ctx_table, scan_order_py
+        from x265_amd.hipprim import CoeffGroupJob
+        self._coef_ready()
+        tu = np.ascontiguousarray(tu, np.int16)
+        scan = scan_order_py(stype, log2)
+        n = len(jobs)
+        arr = (CoeffGroupJob * n)()
+        ctxs = np.zeros((n, 64), np.uint8)
+        for i, (cg, off, pattern, offset, ctx) in enumerate(jobs):
+            mask = 0
+            for k in range(off + 1):
+                mask = mask * 2 + int(tu.reshape(-1)[scan[cg * 16 + k]] != 0)
+            arr[i].coeffOffset = int(scan[cg * 16]); arr[i].trSize = tu.shape[1]; arr[i].scanType = stype if log2 <= 3 else 0
+            arr[i].scanFlagMask = mask; arr[i].offset = offset; arr[i].scanPosSigOff = off; arr[i].subPosBase = cg * 16
+            arr[i].tabSigCtx[:] = [int(v) for v in sig_ctx_table(log2, pattern)]
+            ctxs[i, :len(ctx)] = ctx
+        dj = DevBuf(np.frombuffer(bytes(arr), np.uint8).copy())
+        d, dc = DevBuf(tu), DevBuf(ctxs)
+        absC, bits = DevBuf.zeros((n, 16), np.uint16), DevBuf.zeros((n,), np.uint32)
+        check(self.L.x265hip_cost_coeff_nxn_batch(d.ptr, dj.ptr, n, dc.ptr, 64, absC.ptr, bits.ptr, None))
+        return bits.get(), absC.get(), dc.get()
+
+    def cost_coeff_nxn(self, tu, log2, stype, cgIdx, scanPosSigOff, pattern, offset, ctx):
+        bits, absC, ctxs = self.cost_coeff_nxn_batch(tu, log2, stype, [(cgIdx, scanPosSigOff, pattern, offset, ctx)])
+        # the Orc / Ref wrappers hand the reference `buffer + first` as the harness does (pixelharness.cpp:1964); same view here
+        first = 1 if scanPosSigOff < 15 else 0
+        full = np.zeros(16, np.uint16)
+        full[first:] = absC[0][:16 - first]
+        return int(bits[0]), full, ctxs[0][:len(ctx)].copy()
+
+    def cost_coeff_remain_batch(self, absCoeffs, nnz, idx):
+        n = len(nnz)
+        a = DevBuf(np.ascontiguousarray(absCoeffs, np.uint16).reshape(n, 16))
+        dn, di, out = DevBuf(np.asarray(nnz, np.int32)), DevBuf(np.asarray(idx, np.int32)), DevBuf.zeros((n,), np.uint32)
+        check(self.L.x265hip_cost_coeff_remain_batch(a.ptr, dn.ptr, di.ptr, n, out.ptr, None))
+        return out.get()
+
+    def cost_coeff_remain(self, absCoeff, numNonZero, idx):
+        return int(self.cost_coeff_remain_batch(np.asarray(absCoeff)[None], [numNonZero], [idx])[0])
+
+    def cost_c1c2_flag_batch(self, absCoeffs, counts, ctxs, ctxOffset):
+        self._coef_ready()
+        n = len(counts)
+        a = DevBuf(np.ascontiguousarray(absCoeffs, np.uint16).reshape(n, 16))
+        c = np.zeros((n, 16), np.uint8)
+        c[:, :np.asarray(ctxs).shape[1]] = ctxs
+        dc, dn, out = DevBuf(c), DevBuf(np.asarray(counts, np.int32)), DevBuf.zeros((n,), np.uint32)
+        check(self.L.x265hip_cost_c1c2_flag_batch(a.ptr, dn.ptr, dc.ptr, 16, ctxOffset, n, out.ptr, None))
+        return out.get(), dc.get()
+
+    def cost_c1c2_flag(self, absCoeff, numC1Flag, ctx, ctxOffset):
+        out, c = self.cost_c1c2_flag_batch(np.asarray(absCoeff)[None], [numC1Flag], np.asarray(ctx)[None], ctxOffset)
+        return int(out[0]), c[0][:len(ctx)].copy()
+
     # ---- small primitives: var, weighted prediction, downscales, transpose
     def var(self, size, a, ao):
         da = DevBuf(a)

@@ -598,6 +598,65 @@ def test_bipred_matches_oracle(hipmod, depth):
     assert np.array_equal(y, wy) and np.array_equal(cb, wcb) and np.array_equal(cr, wcr)
 
 
+def test_coefficient_scan_primitives_match_oracle_and_golden(hipmod):
+    """scanPosLast / findPosFirstLast / costCoeffNxN / costCoeffRemain / costC1C2Flag: every case one by one against the oracle and the
+    committed digests of the reference, then many jobs per launch (a launch of 300 TUs per size, 256-job cost batches with private
+    context copies) against per-job oracle results."""
+    import json
+    from cases import coef_cases, digest
+    from backends import scan_order_py
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "primitives_golden.json")))["golden"]["coef"]
+    o, g = Orc(8), hipmod.Hip(8)
+    bad, total = [], 0
+    for label, fn, args in coef_cases():
+        want, got = getattr(o, fn)(*args), getattr(g, fn)(*args)
+        total += 1
+        if not same(want, got) or digest(got) != gold[label]:
+            bad.append(label)
+    hipmod._release()
+    _report(bad, total)
+    rng = np.random.default_rng(5)
+    for log2 in (2, 3, 4, 5):
+        size = 1 << log2
+        for stype in range(3):
+            tus = rng.integers(-300, 301, size=(300, size, size)).astype(np.int16)
+            tus[rng.random(tus.shape) < 0.8] = 0
+            tus[:, -1, -1] |= 1                                  # at least one coefficient each
+            tus[7] = 0
+            tus[7, 0, 0] = -5
+            last, sign, flag, num = g.scan_pos_last_batch(log2, stype, tus)
+            for i in range(0, 300, 7):
+                w = o.scan_pos_last(log2, stype, tus[i])
+                assert (int(last[i]), sign[i].tolist(), flag[i].tolist(), num[i].tolist()) == (w[0], w[1].tolist(), w[2].tolist(), w[3].tolist()), (log2, stype, i)
+            tu = tus[3]
+            cgs = [(x, y) for y in range(size // 4) for x in range(size // 4) if tu[y * 4:y * 4 + 4, x * 4:x * 4 + 4].any()]
+            if cgs:
+                got = g.find_pos_first_last_batch(tu, cgs, stype)
+                assert [int(v) for v in got] == [o.find_pos_first_last(tu, x, y, stype) for (x, y) in cgs]
+            ncg = (size // 4) ** 2
+            jobs = [(int(rng.integers(0, ncg)), int(rng.integers(0, 16)), int(rng.integers(0, 4)), 0 if log2 == 2 else (9 if log2 == 3 else 12),
+                     rng.integers(2, 125, size=64).astype(np.uint8)) for _ in range(256)]
+            bits, absC, ctxs = g.cost_coeff_nxn_batch(tu, log2, stype, jobs)
+            for i in range(0, 256, 5):
+                w = o.cost_coeff_nxn(tu, log2, stype, *jobs[i])
+                first = 1 if jobs[i][1] < 15 else 0             # the oracle wrapper's buffer starts `first` slots earlier (see hipbackend)
+                assert (int(bits[i]), absC[i][:16 - first].tolist(), ctxs[i].tolist()) == (w[0], w[1][first:].tolist(), w[2].tolist()), (log2, stype, i)
+    hipmod._release()
+    a = rng.integers(1, 200, size=(512, 16)).astype(np.uint16)
+    a[rng.random(a.shape) < 0.5] = 1
+    nnz = rng.integers(1, 17, size=512)
+    idx = np.array([int(rng.integers(0, n)) for n in nnz])
+    got = g.cost_coeff_remain_batch(a, nnz, idx)
+    assert [int(v) for v in got] == [o.cost_coeff_remain(a[i], int(nnz[i]), int(idx[i])) for i in range(512)]
+    cnt = rng.integers(1, 9, size=512)
+    ctx = rng.integers(2, 125, size=(512, 8)).astype(np.uint8)
+    a = rng.integers(1, 5, size=(512, 16)).astype(np.uint16)
+    out, c2 = g.cost_c1c2_flag_batch(a, cnt, ctx, 5)
+    for i in range(512):
+        w = o.cost_c1c2_flag(a[i], int(cnt[i]), ctx[i], 5)
+        assert (int(out[i]), c2[i][:8].tolist()) == (w[0], w[1].tolist()), i
+
+
 @pytest.mark.parametrize("depth", DEPTHS)
 def test_motion_compensation_matches_oracle_and_golden(hipmod, depth):
     """Predict::motionCompensation, every branch (P / B-uni / bi x weighted prediction off, on-but-absent, present) for every PU shape

@@ -38,6 +38,12 @@ def test_oracle_chroma_motion_estimate_matches_golden(depth):
     assert make_golden.chroma_me_results(Orc, depth) == GOLD[str(depth)]["chroma_me"]
 
 
+def test_oracle_coefficient_scan_primitives_match_golden():
+    got = make_golden.coef_digests(Orc)
+    want = GOLD["coef"]
+    assert len(want) >= 600 and got == want, [k for k in want if got.get(k) != want[k]][:8]
+
+
 @pytest.mark.parametrize("depth", [8, 10])
 def test_oracle_motion_compensation_matches_golden(depth):
     assert {k: digest(v) for k, v in make_golden.mc_results(Orc, depth).items()} == GOLD[str(depth)]["mc"]

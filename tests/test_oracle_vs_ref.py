@@ -50,6 +50,25 @@ def test_every_primitive_matches_reference(depth):
     assert n > 2000
 
 
+def test_coefficient_scan_primitives_match_reference():
+    """scanPosLast / findPosFirstLast / costCoeffNxN / costCoeffRemain / costC1C2Flag of the reference's C table and its scan-order tables vs the
+    restatement, on inputs drawn like test/pixelharness.cpp draws them; and the committed CABAC cost table is the reference's."""
+    _need_ref(8)
+    from cases import coef_cases
+    from backends import entropy_state_bits_fixture, scan_order_py
+    o, r = Orc(8), Ref(8)
+    assert np.array_equal(entropy_state_bits_fixture(), r.entropy_state_bits())
+    for t in range(3):
+        assert np.array_equal(o.scan4x4(t), r.scan4x4(t))
+        for log2 in (2, 3, 4, 5):
+            assert np.array_equal(o.scan_order(t, log2), r.scan_order(t, log2)) and np.array_equal(scan_order_py(t, log2), r.scan_order(t, log2))
+    n = 0
+    for label, fn, args in coef_cases():
+        assert same(getattr(o, fn)(*args), getattr(r, fn)(*args)), label
+        n += 1
+    assert n >= 600
+
+
 @pytest.mark.parametrize("depth", DEPTHS)
 def test_motion_compensation_matches_reference(depth):
     """The real Predict::motionCompensation (one-PU CUData / Slice / PPS around the test planes) vs the restatement, every branch."""

@@ -648,4 +648,112 @@ int x265hip_call_transpose(int depth, int size, void* dst, const void* src, int6
     return X265HIP_OK;
 }
 
+// scanPosLast_t (primitives.h:217).  The reference stops after numSig non-zero coefficients; the batch entry walks to the last non-zero
+// one of the unit, which is the same place when numSig is the unit's count — what every caller passes (quant.cpp, entropy.cpp).
+int x265hip_call_scan_pos_last(int log2TrSize, int scanType, const int16_t* coeff, uint16_t* coeffSign, uint16_t* coeffFlag, uint8_t* coeffNum,
+                               int numSig, int* lastPos)
+{
+    const size_t nc = (size_t)1 << (2 * log2TrSize);
+    PC_BEGIN(nc * 2 + 64 * 5 + 64);
+    const size_t oC = carve(nc * 2), oS = carve(128), oF = carve(128), oN = carve(64), oL = carve(4);
+    memcpy(hostp<char>(oC), coeff, nc * 2);
+    (void)numSig;
+    PC_TRY(upload());
+    PC_TRY(x265hip_scan_pos_last_batch(log2TrSize, scanType, devp<int16_t>(oC), 1, devp<uint16_t>(oS), devp<uint16_t>(oF), devp<uint8_t>(oN),
+                                       devp<int32_t>(oL), t_st.stream));
+    PC_TRY(download(oS, oL + 4 - oS));
+    memcpy(coeffSign, hostp<char>(oS), 128);
+    memcpy(coeffFlag, hostp<char>(oF), 128);
+    memcpy(coeffNum, hostp<char>(oN), 64);
+    *lastPos = *hostp<int32_t>(oL);
+    return X265HIP_OK;
+}
+
+// findPosFirstLast_t (primitives.h:218)
+int x265hip_call_find_pos_first_last(const int16_t* dstCoeff, int64_t trSize, int scanType, uint32_t* result)
+{
+    PC_BEGIN(128);
+    const size_t oO = carve(8), oC = carve(32), oR = carve(4);
+    *hostp<int64_t>(oO) = 0;
+    for (int y = 0; y < 4; y++)
+        memcpy(hostp<int16_t>(oC) + 4 * y, dstCoeff + y * trSize, 8);
+    PC_TRY(upload());
+    PC_TRY(x265hip_find_pos_first_last_batch(devp<int16_t>(oC), devp<int64_t>(oO), 4, scanType, 1, devp<uint32_t>(oR), t_st.stream));
+    PC_TRY(download(oR, 4));
+    *result = *hostp<uint32_t>(oR);
+    return X265HIP_OK;
+}
+
+// costCoeffNxN_t (primitives.h:220).  The significance contexts the call can touch are baseCtx[0 .. max(tabSigCtx) + offset] (at most
+// 8 + 12) and travel both ways.
+int x265hip_call_cost_coeff_nxn(int scanType, const int16_t* coeff, int64_t trSize, uint16_t* absCoeff, const uint8_t* tabSigCtx,
+                                uint32_t scanFlagMask, uint8_t* baseCtx, int offset, int scanPosSigOff, int subPosBase, uint32_t* result)
+{
+    int top = 0;
+    for (int i = 0; i < 16; i++)
+        top = tabSigCtx[i] > top ? tabSigCtx[i] : top;
+    const int nctx = top + offset + 1;
+    if (nctx > 64 || offset < 0)
+        return X265HIP_EINVAL;
+    PC_BEGIN(512);
+    const size_t oJ = carve(sizeof(x265hip_coeff_group_job)), oC = carve(32), oX = carve(64), oA = carve(32), oR = carve(4);
+    x265hip_coeff_group_job* jb = hostp<x265hip_coeff_group_job>(oJ);
+    jb->coeffOffset = 0; jb->trSize = 4; jb->scanType = scanType; jb->scanFlagMask = scanFlagMask; jb->offset = offset;
+    jb->scanPosSigOff = scanPosSigOff; jb->subPosBase = subPosBase;
+    memcpy(jb->tabSigCtx, tabSigCtx, 16);
+    for (int y = 0; y < 4; y++)
+        memcpy(hostp<int16_t>(oC) + 4 * y, coeff + y * trSize, 8);
+    memcpy(hostp<char>(oX), baseCtx, (size_t)nctx);
+    PC_TRY(upload());
+    PC_TRY(x265hip_cost_coeff_nxn_batch(devp<int16_t>(oC), devp<x265hip_coeff_group_job>(oJ), 1, devp<uint8_t>(oX), 64, devp<uint16_t>(oA),
+                                        devp<uint32_t>(oR), t_st.stream));
+    PC_TRY(download(oX, oR + 4 - oX));
+    memcpy(baseCtx, hostp<char>(oX), (size_t)nctx);
+    // the reference leaves absCoeff[0 .. number of flags seen] written (one slot past the last significant level at most)
+    int nsig = 0;
+    for (int k = 0; k <= scanPosSigOff; k++)
+        nsig += (scanFlagMask >> k) & 1;
+    const int slots = nsig + ((scanFlagMask >> scanPosSigOff) & 1 ? 0 : 1);      // last write lands on slot nsig unless position 0 was significant
+    memcpy(absCoeff, hostp<char>(oA), (size_t)(slots > 16 ? 16 : slots) * 2);
+    *result = *hostp<uint32_t>(oR);
+    return X265HIP_OK;
+}
+
+// costCoeffRemain_t (primitives.h:221)
+int x265hip_call_cost_coeff_remain(const uint16_t* absCoeff, int numNonZero, int idx, uint32_t* result)
+{
+    PC_BEGIN(128);
+    const size_t oA = carve(32), oN = carve(4), oI = carve(4), oR = carve(4);
+    const int cnt = numNonZero > idx + 1 ? numNonZero : idx + 1;                 // the do-while reads absCoeff[idx] at least
+    memset(hostp<char>(oA), 0, 32);
+    memcpy(hostp<char>(oA), absCoeff, (size_t)(cnt > 16 ? 16 : cnt) * 2);
+    *hostp<int32_t>(oN) = numNonZero; *hostp<int32_t>(oI) = idx;
+    PC_TRY(upload());
+    PC_TRY(x265hip_cost_coeff_remain_batch(devp<uint16_t>(oA), devp<int32_t>(oN), devp<int32_t>(oI), 1, devp<uint32_t>(oR), t_st.stream));
+    PC_TRY(download(oR, 4));
+    *result = *hostp<uint32_t>(oR);
+    return X265HIP_OK;
+}
+
+// costC1C2Flag_t (primitives.h:222): contexts [0..3] and [ctxOffset] travel
+int x265hip_call_cost_c1c2_flag(const uint16_t* absCoeff, int64_t numC1Flag, uint8_t* baseCtxMod, int64_t ctxOffset, uint32_t* result)
+{
+    if (ctxOffset < 0 || ctxOffset >= 60 || numC1Flag < 1 || numC1Flag > 16)
+        return X265HIP_EINVAL;
+    PC_BEGIN(256);
+    const size_t oA = carve(32), oN = carve(4), oX = carve(64), oR = carve(4);
+    memset(hostp<char>(oA), 0, 32);
+    memcpy(hostp<char>(oA), absCoeff, (size_t)numC1Flag * 2);
+    *hostp<int32_t>(oN) = (int32_t)numC1Flag;
+    memcpy(hostp<char>(oX), baseCtxMod, 4);
+    hostp<uint8_t>(oX)[ctxOffset] = baseCtxMod[ctxOffset];
+    PC_TRY(upload());
+    PC_TRY(x265hip_cost_c1c2_flag_batch(devp<uint16_t>(oA), devp<int32_t>(oN), devp<uint8_t>(oX), 64, (int)ctxOffset, 1, devp<uint32_t>(oR), t_st.stream));
+    PC_TRY(download(oX, oR + 4 - oX));
+    memcpy(baseCtxMod, hostp<char>(oX), 4);
+    baseCtxMod[ctxOffset] = hostp<uint8_t>(oX)[ctxOffset];
+    *result = *hostp<uint32_t>(oR);
+    return X265HIP_OK;
+}
+
 } // extern "C"

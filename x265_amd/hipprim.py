@@ -116,6 +116,17 @@ PROTOTYPES = {
     "x265hip_intra_allangs_batch": (i32, [i32, i32, vp, vp, vp, i32, vp, i32, vp]),
     "x265hip_intra_filter_batch": (i32, [i32, i32, vp, vp, vp, vp, i32, vp]),
     "x265hip_pred_inter_bi_batch": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "x265hip_set_entropy_state_bits": (i32, [vp]),
+    "x265hip_scan_pos_last_batch": (i32, [i32, i32, vp, i32, vp, vp, vp, vp, vp]),
+    "x265hip_find_pos_first_last_batch": (i32, [vp, vp, i64, i32, i32, vp, vp]),
+    "x265hip_cost_coeff_nxn_batch": (i32, [vp, vp, i32, vp, i32, vp, vp, vp]),
+    "x265hip_cost_coeff_remain_batch": (i32, [vp, vp, vp, i32, vp, vp]),
+    "x265hip_cost_c1c2_flag_batch": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
+    "x265hip_call_scan_pos_last": (i32, [i32, i32, vp, vp, vp, vp, i32, vp]),
+    "x265hip_call_find_pos_first_last": (i32, [vp, i64, i32, vp]),
+    "x265hip_call_cost_coeff_nxn": (i32, [i32, vp, i64, vp, vp, C.c_uint32, vp, i32, i32, i32, vp]),
+    "x265hip_call_cost_coeff_remain": (i32, [vp, i32, i32, vp]),
+    "x265hip_call_cost_c1c2_flag": (i32, [vp, i64, vp, i64, vp]),
     "x265hip_motion_compensation_batch": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
     "x265hip_intra_scan_batch": (i32, [i32, i32, vp, vp, vp, vp, i64, vp, i32, vp, vp]),
     "x265hip_frame_init_lowres": (i32, [i32, vp, i64, vp, vp, vp, vp, i64, i32, i32, vp]),
@@ -132,6 +143,12 @@ PROTOTYPES = {
 }
 
 CMP_SAD, CMP_SATD, CMP_SA8D, CMP_SA8D8, CMP_PSY = 0, 1, 2, 3, 4
+
+
+class CoeffGroupJob(C.Structure):
+    """x265hip_coeff_group_job (include/x265hip.h)"""
+    _fields_ = [("coeffOffset", C.c_int64), ("trSize", C.c_int32), ("scanType", C.c_int32), ("scanFlagMask", C.c_uint32), ("offset", C.c_int32),
+                ("scanPosSigOff", C.c_int32), ("subPosBase", C.c_int32), ("tabSigCtx", C.c_uint8 * 16)]
 
 
 class WeightParam(C.Structure):

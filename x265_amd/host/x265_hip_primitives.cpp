@@ -15,6 +15,8 @@
 // `cpuMask` is ignored: the GPU path is selected by the environment variable X265HIP (default on, "0" disables).
 #include "common.h"
 #include "primitives.h"
+#include "constants.h"
+#include "contexts.h"
 #include "x265hip.h"
 
 #include <cstdio>
@@ -419,6 +421,60 @@ static void scale2d_hip(pixel* dst, const pixel* src, intptr_t stride)
     if (x265hip_call_scale2d_64to32(X265_DEPTH, dst, src, stride)) g_c.scale2D_64to32(dst, src, stride);
 }
 
+// ---- coefficient-scan cost primitives (dct.cpp:757-1006).  The table passes scan orders as pointers into constants.cpp; the library
+// builds the same orders itself, so the pointer only has to be recognised.
+static int scan_type_of(const uint16_t* scan, int sizeIdx)
+{
+    for (int t = 0; t < NUM_SCAN_TYPE; t++)
+        if (scan == g_scanOrder[t][sizeIdx]) return t;
+    return -1;
+}
+static int scan4_type_of(const uint16_t* scan)
+{
+    for (int t = 0; t < NUM_SCAN_TYPE; t++)
+        if (scan == g_scan4x4[t]) return t;
+    return -1;
+}
+static int scanPosLast_hip(const uint16_t* scan, const coeff_t* coeff, uint16_t* coeffSign, uint16_t* coeffFlag, uint8_t* coeffNum, int numSig,
+                           const uint16_t* scanCG4x4, const int trSize)
+{
+    const int log2 = trSize == 4 ? 2 : trSize == 8 ? 3 : trSize == 16 ? 4 : 5;
+    const int t = scan_type_of(scan, log2 - 2);
+    int last = 0;
+    if (t < 0 || x265hip_call_scan_pos_last(log2, t, coeff, coeffSign, coeffFlag, coeffNum, numSig, &last))
+        return g_c.scanPosLast(scan, coeff, coeffSign, coeffFlag, coeffNum, numSig, scanCG4x4, trSize);
+    return last;
+}
+static uint32_t findPosFirstLast_hip(const int16_t* dstCoeff, const intptr_t trSize, const uint16_t scanTbl[16])
+{
+    const int t = scan4_type_of(scanTbl);
+    uint32_t r = 0;
+    if (t < 0 || x265hip_call_find_pos_first_last(dstCoeff, trSize, t, &r))
+        return g_c.findPosFirstLast(dstCoeff, trSize, scanTbl);
+    return r;
+}
+static uint32_t costCoeffNxN_hip(const uint16_t* scan, const coeff_t* coeff, intptr_t trSize, uint16_t* absCoeff, const uint8_t* tabSigCtx,
+                                 uint32_t scanFlagMask, uint8_t* baseCtx, int offset, int scanPosSigOff, int subPosBase)
+{
+    const int t = scan4_type_of(scan);
+    uint32_t r = 0;
+    if (t < 0 || x265hip_call_cost_coeff_nxn(t, coeff, trSize, absCoeff, tabSigCtx, scanFlagMask, baseCtx, offset, scanPosSigOff, subPosBase, &r))
+        return g_c.costCoeffNxN(scan, coeff, trSize, absCoeff, tabSigCtx, scanFlagMask, baseCtx, offset, scanPosSigOff, subPosBase);
+    return r;
+}
+static uint32_t costCoeffRemain_hip(uint16_t* absCoeff, int numNonZero, int idx)
+{
+    uint32_t r = 0;
+    if (x265hip_call_cost_coeff_remain(absCoeff, numNonZero, idx, &r)) return g_c.costCoeffRemain(absCoeff, numNonZero, idx);
+    return r;
+}
+static uint32_t costC1C2Flag_hip(uint16_t* absCoeff, intptr_t numC1Flag, uint8_t* baseCtxMod, intptr_t ctxOffset)
+{
+    uint32_t r = 0;
+    if (x265hip_call_cost_c1c2_flag(absCoeff, numC1Flag, baseCtxMod, ctxOffset, &r)) return g_c.costC1C2Flag(absCoeff, numC1Flag, baseCtxMod, ctxOffset);
+    return r;
+}
+
 #define HIP_SMALL(N) do { \
         p.cu[BLOCK_ ## N ## x ## N].var = var_hip<N, BLOCK_ ## N ## x ## N>; \
         p.cu[BLOCK_ ## N ## x ## N].transpose = transpose_hip<N, BLOCK_ ## N ## x ## N>; \
@@ -479,6 +535,15 @@ void setupAssemblyPrimitives(EncoderPrimitives& p, int /* cpuMask: CPU ISA bits,
     p.scale1D_128to64[NONALIGNED] = scale1d_hip;
     p.scale1D_128to64[ALIGNED] = scale1d_hip;
     p.scale2D_64to32 = scale2d_hip;
+    if (!x265hip_set_entropy_state_bits(PFX(entropyStateBits)))
+    {
+        // the coefficient-scan cost helpers of RDOQ and of the bit estimation (the CABAC cost table is the encoder's own data)
+        p.scanPosLast = scanPosLast_hip;
+        p.findPosFirstLast = findPosFirstLast_hip;
+        p.costCoeffNxN = costCoeffNxN_hip;
+        p.costCoeffRemain = costCoeffRemain_hip;
+        p.costC1C2Flag = costC1C2Flag_hip;
+    }
 }
 
 } // namespace X265_NS
