@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--me", type=int, default=1, help="0 dia, 1 hex, 3 star, 5 full")
+    ap.add_argument("--me", type=int, default=1, help="0 dia, 1 hex, 2 umh, 3 star, 5 full")
     ap.add_argument("--subme", type=int, default=2)
     ap.add_argument("--merange", type=int, default=57)
     ap.add_argument("--qp", type=int, default=28)
