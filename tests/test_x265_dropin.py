@@ -48,14 +48,30 @@ def test_reference_testbench_passes_with_gpu_primitives(bits):
     assert out.count("Testing primitives:") >= 1
 
 
-def test_qcif_bitstream_identical_to_c_primitives(tmp_path):
-    c_exe, g_exe = _need("x265_8bit"), _need("x265_hip_8bit")
+ENCODES = {
+    # BASELINE.json configs[0]: QCIF all-intra, preset ultrafast, 8 frames
+    "intra-ultrafast": (8, 8, ["--preset", "ultrafast", "--keyint", "1"]),
+    # P frames: motion search, interpolation, residual coding of inter CUs
+    "p-ultrafast": (8, 6, ["--preset", "ultrafast", "--bframes", "0", "--keyint", "6"]),
+    # the shape of configs[1] on a small picture: preset medium (hex, subme 2, rd 3, RDOQ off … weightp, B frames with the lookahead)
+    "b-medium": (8, 6, ["--preset", "medium", "--keyint", "6", "--rc-lookahead", "4", "--bframes", "2"]),
+    # Main10 build of the same
+    "b-medium-main10": (10, 6, ["--preset", "medium", "--keyint", "6", "--rc-lookahead", "4", "--bframes", "2"]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(ENCODES))
+def test_qcif_bitstream_identical_to_c_primitives(tmp_path, name):
+    """The reference encoder with the GPU table vs with its own C table: the same bytes out (the reference's regression
+    criterion), for intra, P and B / lookahead encodes, 8-bit and Main10."""
+    bits, frames, extra = ENCODES[name]
+    c_exe, g_exe = _need("x265_%dbit" % bits), _need("x265_hip_%dbit" % bits)
     sys.path.insert(0, ROOT)
     from x265_amd.synth import make_clip
     yuv = str(tmp_path / "qcif.yuv")
-    make_clip(yuv, 176, 144, 8, seed=99, tile=48)
-    args = ["--input", yuv, "--input-res", "176x144", "--fps", "30", "--preset", "ultrafast", "--keyint", "1",
-            "--frames", "8", "--pools", "none", "-F", "1", "--hash", "1"]
+    make_clip(yuv, 176, 144, frames, seed=99, tile=48)
+    args = ["--input", yuv, "--input-res", "176x144", "--input-depth", "8", "--fps", "30", "--frames", str(frames), "--pools", "none", "-F", "1",
+            "--hash", "1"] + extra
     outs = {}
     for tag, exe in (("c", c_exe), ("gpu", g_exe)):
         o = str(tmp_path / (tag + ".hevc"))
