@@ -57,6 +57,12 @@ ENCODES = {
     "b-medium": (8, 6, ["--preset", "medium", "--keyint", "6", "--rc-lookahead", "4", "--bframes", "2"]),
     # Main10 build of the same
     "b-medium-main10": (10, 6, ["--preset", "medium", "--keyint", "6", "--rc-lookahead", "4", "--bframes", "2"]),
+    # the shape of configs[2]: preset slow --me star --merange 57 (star search, subme 3 with the chroma SATD term, rect / amp PUs, RDOQ)
+    "slow-star": (8, 4, ["--preset", "slow", "--me", "star", "--merange", "57", "--keyint", "4", "--rc-lookahead", "3", "--bframes", "1"]),
+    # the shape of configs[3]: Main10 preset slower --rd 6 (RDOQ level 2 and its coefficient-scan cost helpers, psy-rdoq, subme 4)
+    "slower-rd6-main10": (10, 4, ["--preset", "slower", "--rd", "6", "--keyint", "4", "--rc-lookahead", "3", "--bframes", "1"]),
+    # uneven multi-hexagon search
+    "umh-medium": (8, 4, ["--preset", "medium", "--me", "umh", "--keyint", "4", "--rc-lookahead", "3", "--bframes", "1"]),
 }
 
 
