@@ -177,6 +177,36 @@ int x265hip_cost_coeff_remain_batch(const uint16_t* absCoeff, const int32_t* num
 int x265hip_cost_c1c2_flag_batch(const uint16_t* absCoeff, const int32_t* numC1Flag, uint8_t* baseCtxMod, int ctxStride, int ctxOffset, int n,
                                  uint32_t* out, void* stream);
 
+/* ---- in-loop filter primitives.  One job = one call of the reference's primitive.
+ * pelFilterLumaStrong_t / pelFilterChroma_t (primitives.h:224-225; loopfilter.cpp:139-185): job i filters the four lines starting at
+ * plane + off[i] (line step srcStep, sample step across the edge `offset`: EDGE_VER = (stride, 1), EDGE_HOR = (1, stride)). */
+int x265hip_pel_filter_luma_strong_batch(int depth, void* plane, const int64_t* off, int64_t srcStep, int64_t offset, const int32_t* tcP,
+                                         const int32_t* tcQ, int n, void* stream);
+int x265hip_pel_filter_chroma_batch(int depth, void* plane, const int64_t* off, int64_t srcStep, int64_t offset, const int32_t* tc,
+                                    const int32_t* maskP, const int32_t* maskQ, int n, void* stream);
+/* sign_t (primitives.h:206; loopfilter.cpp:38): dst[i] = sign(src1[i] - src2[i]) */
+int x265hip_sao_sign(int depth, int8_t* dst, const void* src1, const void* src2, int n, void* stream);
+/* saoCuOrgE0 / E1 / E1_2Rows / E2 / E3 / B0 (primitives.h:194-198; loopfilter.cpp:44-137).  kind 0..5 in that order.  Sign buffers live in
+ * the int8 array `aux` at element offsets aux0 / aux1: E1, E1_2Rows: aux0 = upBuff1 (read and updated); E2: aux0 = bufft (written at
+ * [1 .. width]), aux1 = buff1 (read); E3: aux0 = upBuff1 (read at [startX + 1, endX), written one to the left), width = endX.
+ * offsets = offsetEo[5] (or the 32 band offsets of B0); signLeft for E0; height for B0 (E0 and E1_2Rows cover two rows, the rest one).
+ * Jobs of one launch must not touch each other's samples; width <= 256. */
+typedef struct x265hip_sao_job
+{
+    int64_t recOff, aux0, aux1;
+    int32_t width, height, startX;
+    int8_t offsets[32];
+    int8_t signLeft[2];
+    int8_t reserved[2];
+} x265hip_sao_job;
+int x265hip_sao_apply_batch(int depth, int kind, void* plane, int64_t stride, int8_t* aux, const x265hip_sao_job* jobs, int n, void* stream);
+/* saoCuStatsBO / E0 / E1 / E2 / E3 (primitives.h:200-204; sao.cpp:1762-1925): kind 0..4.  Job i: diff + diffOff (pitch 64 = MAX_CU_SIZE),
+ * plane + recOff, endX x endY samples; aux0 = upBuff1 (E1, E2, E3: read for the first row, left as the reference leaves it), aux1 =
+ * upBufft (E2).  stats / count: [n][32] int32, ADDED to (BO uses 32 classes, the edge kinds entries 0..4 folded by SAO::s_eoTable). */
+typedef struct x265hip_sao_stats_job { int64_t diffOff, recOff, aux0, aux1; int32_t endX, endY; } x265hip_sao_stats_job;
+int x265hip_sao_stats_batch(int depth, int kind, const int16_t* diff, const void* plane, int64_t stride, int8_t* aux,
+                            const x265hip_sao_stats_job* jobs, int n, int32_t* stats, int32_t* count, void* stream);
+
 /* ---------------------------------------------------------------- interpolation ----------------------------- */
 /* filter_pp_t / filter_hps_t / filter_ps_t / filter_sp_t / filter_ss_t / filter_hv_pp_t (primitives.h:176-183;
  * ipfilter.cpp:79-369).  taps = 8 (luma) or 4 (chroma).  One job = one W x H block:
@@ -498,6 +528,16 @@ int x265hip_call_cost_coeff_nxn(int scanType, const int16_t* coeff, int64_t trSi
                                 uint32_t scanFlagMask, uint8_t* baseCtx, int offset, int scanPosSigOff, int subPosBase, uint32_t* result);
 int x265hip_call_cost_coeff_remain(const uint16_t* absCoeff, int numNonZero, int idx, uint32_t* result);
 int x265hip_call_cost_c1c2_flag(const uint16_t* absCoeff, int64_t numC1Flag, uint8_t* baseCtxMod, int64_t ctxOffset, uint32_t* result);
+/* pelFilterLumaStrong_t / pelFilterChroma_t / sign_t / saoCuOrg* / saoCuStats* (primitives.h:194-206, 224-225) on host buffers.
+ * sao_apply: kind 0..5 = E0, E1, E1_2Rows, E2, E3, B0; a = width (endX for E3), b = height (B0) or startX (E3); aux0 / aux1 = the
+ * primitive's sign buffers in argument order.  sao_stats: kind 0..4 = BO, E0..E3; up1 / upt = upBuff1 / upBufft. */
+int x265hip_call_pel_filter_luma_strong(int depth, void* src, int64_t srcStep, int64_t offset, int32_t tcP, int32_t tcQ);
+int x265hip_call_pel_filter_chroma(int depth, void* src, int64_t srcStep, int64_t offset, int32_t tc, int32_t maskP, int32_t maskQ);
+int x265hip_call_sao_sign(int depth, int8_t* dst, const void* src1, const void* src2, int endX);
+int x265hip_call_sao_apply(int depth, int kind, void* rec, int64_t stride, int a, int b, int8_t* aux0, int8_t* aux1, const int8_t* offsets,
+                           const int8_t* signLeft);
+int x265hip_call_sao_stats(int depth, int kind, const int16_t* diff, const void* rec, int64_t stride, int8_t* up1, int8_t* upt, int endX, int endY,
+                           int32_t* stats, int32_t* count);
 int x265hip_call_intra_pred(int depth, int n, int mode, int bFilter, void* dst, int64_t dstStride, const void* line);
 int x265hip_call_intra_allangs(int depth, int n, void* dest, const void* line, const void* filtered, int bLuma);
 int x265hip_call_intra_filter(int depth, int n, const void* line, void* filtered);

@@ -231,6 +231,19 @@ def ref(depth):
     g("ref_costCoeffNxN", C.c_uint32, [vp, vp, ip, vp, vp, C.c_uint32, vp, i32, i32, i32])
     g("ref_costCoeffRemain", C.c_uint32, [vp, i32, i32])
     g("ref_costC1C2Flag", C.c_uint32, [vp, ip, vp, ip])
+    g("ref_pelFilterLumaStrong", None, [i32, vp, ip, ip, i32, i32])
+    g("ref_pelFilterChroma", None, [i32, vp, ip, ip, i32, i32, i32])
+    g("ref_saoSign", None, [vp, vp, vp, i32])
+    g("ref_saoCuOrgE0", None, [vp, vp, i32, vp, ip])
+    g("ref_saoCuOrgE1", None, [vp, vp, vp, ip, i32, i32])
+    g("ref_saoCuOrgE2", None, [vp, vp, vp, vp, i32, ip])
+    g("ref_saoCuOrgE3", None, [vp, vp, vp, ip, i32, i32])
+    g("ref_saoCuOrgB0", None, [vp, vp, i32, i32, ip])
+    g("ref_saoCuStatsBO", None, [vp, vp, ip, i32, i32, vp, vp])
+    g("ref_saoCuStatsE0", None, [vp, vp, ip, i32, i32, vp, vp])
+    g("ref_saoCuStatsE1", None, [vp, vp, ip, vp, i32, i32, vp, vp])
+    g("ref_saoCuStatsE2", None, [vp, vp, ip, vp, vp, i32, i32, vp, vp])
+    g("ref_saoCuStatsE3", None, [vp, vp, ip, vp, i32, i32, vp, vp])
     g("ref_motion_compensation", None, [vp, vp, vp, vp, vp, vp, ip, ip, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp])
     g("ref_intra_filter", None, [i32, vp, vp])
     g("ref_intra_pred", None, [i32, i32, vp, ip, vp, i32])

@@ -659,4 +659,23 @@ uint32_t ref_costCoeffNxN(const uint16_t* scan, const coeff_t* coeff, intptr_t t
 uint32_t ref_costCoeffRemain(uint16_t* absCoeff, int numNonZero, int idx) { return T().costCoeffRemain(absCoeff, numNonZero, idx); }
 uint32_t ref_costC1C2Flag(uint16_t* absCoeff, intptr_t n, uint8_t* ctx, intptr_t ctxOffset) { return T().costC1C2Flag(absCoeff, n, ctx, ctxOffset); }
 
+/* ---- in-loop filter primitives through the C table (common/loopfilter.cpp, encoder/sao.cpp:1762-1925) ---- */
+void ref_pelFilterLumaStrong(int dir, pixel* src, intptr_t srcStep, intptr_t offset, int32_t tcP, int32_t tcQ) { T().pelFilterLumaStrong[dir](src, srcStep, offset, tcP, tcQ); }
+void ref_pelFilterChroma(int dir, pixel* src, intptr_t srcStep, intptr_t offset, int32_t tc, int32_t maskP, int32_t maskQ) { T().pelFilterChroma[dir](src, srcStep, offset, tc, maskP, maskQ); }
+void ref_saoSign(int8_t* dst, const pixel* a, const pixel* b, int endX) { T().sign(dst, a, b, endX); }
+void ref_saoCuOrgE0(pixel* rec, int8_t* offsetEo, int width, int8_t* signLeft, intptr_t stride) { T().saoCuOrgE0(rec, offsetEo, width, signLeft, stride); }
+void ref_saoCuOrgE1(pixel* rec, int8_t* upBuff1, int8_t* offsetEo, intptr_t stride, int width, int rows)
+{
+    if (rows == 2) T().saoCuOrgE1_2Rows(rec, upBuff1, offsetEo, stride, width);
+    else T().saoCuOrgE1(rec, upBuff1, offsetEo, stride, width);
+}
+void ref_saoCuOrgE2(pixel* rec, int8_t* bufft, int8_t* buff1, int8_t* offsetEo, int width, intptr_t stride) { T().saoCuOrgE2[width > 16](rec, bufft, buff1, offsetEo, width, stride); }
+void ref_saoCuOrgE3(pixel* rec, int8_t* upBuff1, int8_t* offsetEo, intptr_t stride, int startX, int endX) { T().saoCuOrgE3[(endX - startX) > 16](rec, upBuff1, offsetEo, stride, startX, endX); }
+void ref_saoCuOrgB0(pixel* rec, const int8_t* offset, int w, int h, intptr_t stride) { T().saoCuOrgB0(rec, offset, w, h, stride); }
+void ref_saoCuStatsBO(const int16_t* diff, const pixel* rec, intptr_t stride, int endX, int endY, int32_t* stats, int32_t* count) { T().saoCuStatsBO(diff, rec, stride, endX, endY, stats, count); }
+void ref_saoCuStatsE0(const int16_t* diff, const pixel* rec, intptr_t stride, int endX, int endY, int32_t* stats, int32_t* count) { T().saoCuStatsE0(diff, rec, stride, endX, endY, stats, count); }
+void ref_saoCuStatsE1(const int16_t* diff, const pixel* rec, intptr_t stride, int8_t* up, int endX, int endY, int32_t* stats, int32_t* count) { T().saoCuStatsE1(diff, rec, stride, up, endX, endY, stats, count); }
+void ref_saoCuStatsE2(const int16_t* diff, const pixel* rec, intptr_t stride, int8_t* up, int8_t* upt, int endX, int endY, int32_t* stats, int32_t* count) { T().saoCuStatsE2(diff, rec, stride, up, upt, endX, endY, stats, count); }
+void ref_saoCuStatsE3(const int16_t* diff, const pixel* rec, intptr_t stride, int8_t* up, int endX, int endY, int32_t* stats, int32_t* count) { T().saoCuStatsE3(diff, rec, stride, up, endX, endY, stats, count); }
+
 } // extern "C"

@@ -498,6 +498,72 @@ class Orc(_Base):
         r = self._cf("orc_costC1C2Flag", C.c_uint32, [po.vp, po.ip, po.vp, po.ip, po.vp])(ptr(a), numC1Flag, ptr(ctx2), ctxOffset, ptr(sb))
         return int(r), ctx2
 
+    # ---- in-loop filter primitives (loopfilter.cpp, sao.cpp:1762-1925).  pos = (y, x) of the primitive's `rec` / `src` pointer in `plane`
+    def _lf(self, name, argtypes):
+        fn = getattr(po.oracle(), "%s_%s" % (name, self.s))
+        fn.restype, fn.argtypes = None, argtypes
+        return fn
+
+    def pel_filter_luma_strong(self, plane, pos, edgeDir, tcP, tcQ):
+        p = plane.copy()
+        step, off = (p.shape[1], 1) if edgeDir == 0 else (1, p.shape[1])
+        self._lf("orc_pelFilterLumaStrong", [po.vp, po.ip, po.ip, po.i32, po.i32])(ptr(p, *pos), step, off, tcP, tcQ)
+        return p
+
+    def pel_filter_chroma(self, plane, pos, edgeDir, tc, maskP, maskQ):
+        p = plane.copy()
+        step, off = (p.shape[1], 1) if edgeDir == 0 else (1, p.shape[1])
+        self._lf("orc_pelFilterChroma", [po.vp, po.ip, po.ip, po.i32, po.i32, po.i32, po.i32])(ptr(p, *pos), step, off, tc, maskP, maskQ, self.depth)
+        return p
+
+    def sao_sign(self, a, b):
+        d = np.zeros(len(a), np.int8)
+        self._lf("orc_saoSign", [po.vp, po.vp, po.vp, po.i32])(ptr(d), ptr(a), ptr(b), len(a))
+        return d
+
+    def sao_e0(self, plane, pos, offsetEo, width, signLeft):
+        p, eo, sl = plane.copy(), np.array(offsetEo, np.int8), np.array(signLeft, np.int8)
+        self._lf("orc_saoCuOrgE0", [po.vp, po.vp, po.i32, po.vp, po.ip, po.i32])(ptr(p, *pos), ptr(eo), width, ptr(sl), p.shape[1], self.depth)
+        return p
+
+    def sao_e1(self, plane, pos, up, offsetEo, width, rows):
+        p, eo, u = plane.copy(), np.array(offsetEo, np.int8), np.array(up, np.int8)
+        self._lf("orc_saoCuOrgE1", [po.vp, po.vp, po.vp, po.ip, po.i32, po.i32, po.i32])(ptr(p, *pos), ptr(u), ptr(eo), p.shape[1], width, rows, self.depth)
+        return p, u
+
+    def sao_e2(self, plane, pos, bufft, buff1, offsetEo, width):
+        p, eo, bt, b1 = plane.copy(), np.array(offsetEo, np.int8), np.array(bufft, np.int8), np.array(buff1, np.int8)
+        self._lf("orc_saoCuOrgE2", [po.vp, po.vp, po.vp, po.vp, po.i32, po.ip, po.i32])(ptr(p, *pos), ptr(bt), ptr(b1), ptr(eo), width, p.shape[1], self.depth)
+        return p, bt
+
+    def sao_e3(self, plane, pos, upfull, offsetEo, startX, endX):
+        p, eo, u = plane.copy(), np.array(offsetEo, np.int8), np.array(upfull, np.int8)
+        self._lf("orc_saoCuOrgE3", [po.vp, po.vp, po.vp, po.ip, po.i32, po.i32, po.i32])(ptr(p, *pos), ptr(u, 0, 1), ptr(eo), p.shape[1], startX, endX, self.depth)
+        return p, u
+
+    def sao_b0(self, plane, pos, offset32, w, h):
+        p, o = plane.copy(), np.array(offset32, np.int8)
+        self._lf("orc_saoCuOrgB0", [po.vp, po.vp, po.i32, po.i32, po.ip, po.i32])(ptr(p, *pos), ptr(o), w, h, p.shape[1], self.depth)
+        return p
+
+    def sao_stats(self, kind, diff, plane, pos, endX, endY, stats, count, up1full, uptfull):
+        """kind 0 BO, 1..4 E0..E3; diff [64, 64] int16; up*full carry one element before index 0.  Returns (stats, count, up1full, uptfull)."""
+        st, ct, u1, ut = np.array(stats, np.int32), np.array(count, np.int32), np.array(up1full, np.int8), np.array(uptfull, np.int8)
+        d = np.ascontiguousarray(diff, np.int16)
+        S = plane.shape[1]
+        if kind == 0:
+            self._lf("orc_saoCuStatsBO", [po.vp, po.vp, po.ip, po.i32, po.i32, po.vp, po.vp, po.i32])(ptr(d), ptr(plane, *pos), S, endX, endY, ptr(st), ptr(ct), self.depth)
+        elif kind == 1:
+            self._lf("orc_saoCuStatsE0", [po.vp, po.vp, po.ip, po.i32, po.i32, po.vp, po.vp])(ptr(d), ptr(plane, *pos), S, endX, endY, ptr(st), ptr(ct))
+        elif kind == 2:
+            self._lf("orc_saoCuStatsE1", [po.vp, po.vp, po.ip, po.vp, po.i32, po.i32, po.vp, po.vp])(ptr(d), ptr(plane, *pos), S, ptr(u1, 0, 1), endX, endY, ptr(st), ptr(ct))
+        elif kind == 3:
+            self._lf("orc_saoCuStatsE2", [po.vp, po.vp, po.ip, po.vp, po.vp, po.i32, po.i32, po.vp, po.vp])(ptr(d), ptr(plane, *pos), S, ptr(u1, 0, 1), ptr(ut, 0, 1), endX, endY,
+                                                                                                          ptr(st), ptr(ct))
+        else:
+            self._lf("orc_saoCuStatsE3", [po.vp, po.vp, po.ip, po.vp, po.i32, po.i32, po.vp, po.vp])(ptr(d), ptr(plane, *pos), S, ptr(u1, 0, 1), endX, endY, ptr(st), ptr(ct))
+        return st, ct, u1, ut
+
     # ---- weighted prediction, downscales, transpose
     def weight_pp(self, a, ao, w, h, w0, rnd, shift, offset):
         d = np.zeros_like(a)
@@ -874,6 +940,65 @@ class Ref(_Base):
         a, ctx2 = np.ascontiguousarray(absCoeff, np.uint16), np.array(ctx, np.uint8)
         r = self.L.ref_costC1C2Flag(ptr(a), numC1Flag, ptr(ctx2), ctxOffset)
         return int(r), ctx2
+
+    # ---- in-loop filter primitives
+    def pel_filter_luma_strong(self, plane, pos, edgeDir, tcP, tcQ):
+        p = plane.copy()
+        step, off = (p.shape[1], 1) if edgeDir == 0 else (1, p.shape[1])
+        self.L.ref_pelFilterLumaStrong(edgeDir, ptr(p, *pos), step, off, tcP, tcQ)
+        return p
+
+    def pel_filter_chroma(self, plane, pos, edgeDir, tc, maskP, maskQ):
+        p = plane.copy()
+        step, off = (p.shape[1], 1) if edgeDir == 0 else (1, p.shape[1])
+        self.L.ref_pelFilterChroma(edgeDir, ptr(p, *pos), step, off, tc, maskP, maskQ)
+        return p
+
+    def sao_sign(self, a, b):
+        d = np.zeros(len(a), np.int8)
+        self.L.ref_saoSign(ptr(d), ptr(a), ptr(b), len(a))
+        return d
+
+    def sao_e0(self, plane, pos, offsetEo, width, signLeft):
+        p, eo, sl = plane.copy(), np.array(offsetEo, np.int8), np.array(signLeft, np.int8)
+        self.L.ref_saoCuOrgE0(ptr(p, *pos), ptr(eo), width, ptr(sl), p.shape[1])
+        return p
+
+    def sao_e1(self, plane, pos, up, offsetEo, width, rows):
+        p, eo, u = plane.copy(), np.array(offsetEo, np.int8), np.array(up, np.int8)
+        self.L.ref_saoCuOrgE1(ptr(p, *pos), ptr(u), ptr(eo), p.shape[1], width, rows)
+        return p, u
+
+    def sao_e2(self, plane, pos, bufft, buff1, offsetEo, width):
+        p, eo, bt, b1 = plane.copy(), np.array(offsetEo, np.int8), np.array(bufft, np.int8), np.array(buff1, np.int8)
+        self.L.ref_saoCuOrgE2(ptr(p, *pos), ptr(bt), ptr(b1), ptr(eo), width, p.shape[1])
+        return p, bt
+
+    def sao_e3(self, plane, pos, upfull, offsetEo, startX, endX):
+        p, eo, u = plane.copy(), np.array(offsetEo, np.int8), np.array(upfull, np.int8)
+        self.L.ref_saoCuOrgE3(ptr(p, *pos), ptr(u, 0, 1), ptr(eo), p.shape[1], startX, endX)
+        return p, u
+
+    def sao_b0(self, plane, pos, offset32, w, h):
+        p, o = plane.copy(), np.array(offset32, np.int8)
+        self.L.ref_saoCuOrgB0(ptr(p, *pos), ptr(o), w, h, p.shape[1])
+        return p
+
+    def sao_stats(self, kind, diff, plane, pos, endX, endY, stats, count, up1full, uptfull):
+        st, ct, u1, ut = np.array(stats, np.int32), np.array(count, np.int32), np.array(up1full, np.int8), np.array(uptfull, np.int8)
+        d = np.ascontiguousarray(diff, np.int16)
+        S = plane.shape[1]
+        if kind == 0:
+            self.L.ref_saoCuStatsBO(ptr(d), ptr(plane, *pos), S, endX, endY, ptr(st), ptr(ct))
+        elif kind == 1:
+            self.L.ref_saoCuStatsE0(ptr(d), ptr(plane, *pos), S, endX, endY, ptr(st), ptr(ct))
+        elif kind == 2:
+            self.L.ref_saoCuStatsE1(ptr(d), ptr(plane, *pos), S, ptr(u1, 0, 1), endX, endY, ptr(st), ptr(ct))
+        elif kind == 3:
+            self.L.ref_saoCuStatsE2(ptr(d), ptr(plane, *pos), S, ptr(u1, 0, 1), ptr(ut, 0, 1), endX, endY, ptr(st), ptr(ct))
+        else:
+            self.L.ref_saoCuStatsE3(ptr(d), ptr(plane, *pos), S, ptr(u1, 0, 1), endX, endY, ptr(st), ptr(ct))
+        return st, ct, u1, ut
 
     # ---- weighted prediction, downscales, transpose
     def weight_pp(self, a, ao, w, h, w0, rnd, shift, offset):

@@ -420,3 +420,50 @@ def coef_cases(seed=77):
         a[:len(vals)] = vals
         ctx = rng.integers(2, 125, size=8).astype(np.uint8)
         yield ("costC1C2Flag #%d" % rep, "cost_c1c2_flag", (a, len(vals), ctx, int(rng.integers(0, 4)) + 4))
+
+
+def loop_cases(depth, seed=91):
+    """Cases for the in-loop filter primitives, drawn as test/pixelharness.cpp draws them (random pictures incl. all-min / all-max, tc and
+    masks over their ranges, sign buffers in {-1, 0, 1}, CTU-sized statistics blocks with ragged ends).  Yields (label, method, args)."""
+    rng = np.random.default_rng(seed + depth)
+    pmax = (1 << depth) - 1
+    dt = np.uint8 if depth == 8 else np.uint16
+    H, W = 96, 112
+
+    def pic(mode):
+        if mode == "rand":
+            return rng.integers(0, pmax + 1, size=(H, W)).astype(dt)
+        if mode == "smooth":                        # neighbouring samples often equal or one apart: every edge class occurs
+            base = rng.integers(0, pmax - 8, size=(H // 4 + 1, W // 4 + 1))
+            return (np.kron(base, np.ones((4, 4), np.int64))[:H, :W] + rng.integers(0, 3, size=(H, W))).astype(dt)
+        return np.full((H, W), 0 if mode == "min" else pmax, dt)
+    signs = lambda n: rng.integers(-1, 2, size=n).astype(np.int8)      # noqa: E731
+    eo = lambda: rng.integers(-7, 8, size=5).astype(np.int8)           # noqa: E731
+    for mi, kind_of_picture in enumerate(("rand", "smooth", "rand", "smooth", "min", "max")):
+        p = pic(kind_of_picture)
+        mode = "%s%d" % (kind_of_picture, mi)
+        for rep in range(4):
+            pos = (int(rng.integers(8, 16)), int(rng.integers(8, 16)))
+            tc = int(rng.integers(0, pmax))
+            for d in (0, 1):
+                yield ("pelFilterLumaStrong dir%d %s #%d" % (d, mode, rep), "pel_filter_luma_strong", (p, pos, d, tc & int(rng.integers(-1, pmax)), tc & int(rng.integers(-1, pmax))))
+                yield ("pelFilterChroma dir%d %s #%d" % (d, mode, rep), "pel_filter_chroma", (p, pos, d, int(rng.integers(0, 30)) << (depth - 8), -int(rng.integers(0, 2)), -int(rng.integers(0, 2))))
+            w = int(rng.choice([8, 16, 17, 32, 33, 48, 64]))
+            yield ("sign %s #%d" % (mode, rep), "sao_sign", (np.ascontiguousarray(p[pos[0], :w + 5]), np.ascontiguousarray(p[pos[0] + 1, :w + 5])))
+            yield ("saoCuOrgE0 %s w%d #%d" % (mode, w, rep), "sao_e0", (p, pos, eo(), w, signs(2)))
+            yield ("saoCuOrgE1 %s w%d #%d" % (mode, w, rep), "sao_e1", (p, pos, signs(w), eo(), w, 1))
+            yield ("saoCuOrgE1_2Rows %s w%d #%d" % (mode, w, rep), "sao_e1", (p, pos, signs(w), eo(), w, 2))
+            yield ("saoCuOrgE2 %s w%d #%d" % (mode, w, rep), "sao_e2", (p, pos, signs(w + 1), signs(w), eo(), w))
+            s0 = int(rng.integers(0, 2))
+            yield ("saoCuOrgE3 %s w%d #%d" % (mode, w, rep), "sao_e3", (p, pos, signs(w + 1), eo(), s0, w - int(rng.integers(0, 2))))
+            yield ("saoCuOrgB0 %s w%d #%d" % (mode, w, rep), "sao_b0", (p, pos, rng.integers(-7, 8, size=32).astype(np.int8), w, int(rng.integers(1, 65))))
+            diff = rng.integers(-pmax, pmax + 1, size=(64, 64)).astype(np.int16)
+            for kind in range(5):
+                endX = 64 - int(rng.integers(0, 5)) - (1 if kind >= 3 else 0)
+                endY = 64 - int(rng.integers(0, 4)) - (1 if kind >= 1 else 0)
+                if rep == 3:
+                    endX, endY = int(rng.integers(1, 20)), int(rng.integers(1, 6))
+                ncls = 32 if kind == 0 else 5
+                yield ("saoCuStats%s %s %dx%d #%d" % (["BO", "E0", "E1", "E2", "E3"][kind], mode, endX, endY, rep), "sao_stats",
+                       (kind, diff, p, pos, endX, endY, rng.integers(0, 1 << 20, size=ncls).astype(np.int32), rng.integers(0, 1 << 20, size=ncls).astype(np.int32),
+                        signs(endX + 2), signs(endX + 2)))

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import numpy as np  # noqa: E402
 from backends import Ref  # noqa: E402
-from cases import gen_cases, coef_cases, umh_groups, me_scene, me_scene_yuv, lowres_scene, lookahead_scene, lookahead_scene3, digest  # noqa: E402
+from cases import gen_cases, coef_cases, loop_cases, umh_groups, me_scene, me_scene_yuv, lowres_scene, lookahead_scene, lookahead_scene3, digest  # noqa: E402
 
 ME_CASES = [  # (method, subme, w, h, bx_off, by_off, merange, qmvp, mvc, qp)
     (1, 2, 16, 16, 16, 24, 57, (5, -7), [(12, 8), (-20, 4)], 28),
@@ -118,6 +118,12 @@ def coef_digests(backend_cls):
         for log2 in (2, 3, 4, 5):
             out["scanOrder t%d log2 %d" % (t, log2)] = digest(b.scan_order(t, log2))
     return out
+
+
+def loop_digests(backend_cls, depth):
+    """The in-loop filter primitives (deblocking edge filters, SAO offset application and statistics) over tests/cases.py loop_cases."""
+    b = backend_cls(depth)
+    return {label: digest(getattr(b, fn)(*args)) for label, fn, args in loop_cases(depth)}
 
 
 def mc_cases(depth):
@@ -246,7 +252,8 @@ if __name__ == "__main__":
     for depth in (8, 10):
         gold[str(depth)] = {"prims": prim_digests(Ref, depth), "me": me_digests(Ref, depth), "umh": umh_results(Ref, depth), "chroma_me": chroma_me_results(Ref, depth),
                             "bipred": {k: digest(v) for k, v in bipred_results(Ref, depth).items()},
-                            "mc": {k: digest(v) for k, v in mc_results(Ref, depth).items()}, "lowres": lowres_digests(Ref, depth), "lookahead": lookahead_digests(Ref, depth),
+                            "mc": {k: digest(v) for k, v in mc_results(Ref, depth).items()},
+                            "loop": loop_digests(Ref, depth), "lowres": lowres_digests(Ref, depth), "lookahead": lookahead_digests(Ref, depth),
                             "lookahead_b": {k: digest(v) for k, v in lookahead_b_results(Ref, depth).items()},
                             "mvcost": {str(qp): digest(Ref(depth).mvcost_table(qp)) for qp in (12, 28, 37, 51)}}
     # the CABAC cost table is data of the reference: dump it for the tests and for the GPU box, where /root/reference does not exist

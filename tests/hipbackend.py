@@ -612,6 +612,79 @@ class Hip:
         out, c = self.cost_c1c2_flag_batch(np.asarray(absCoeff)[None], [numC1Flag], np.asarray(ctx)[None], ctxOffset)
         return int(out[0]), c[0][:len(ctx)].copy()
 
+    # ---- in-loop filter primitives (n = 1 batches; pos = (y, x) of the primitive's pointer)
+    def pel_filter_luma_strong(self, plane, pos, edgeDir, tcP, tcQ):
+        d = DevBuf(plane)
+        S = plane.shape[1]
+        step, off = (S, 1) if edgeDir == 0 else (1, S)
+        o, a, b = DevBuf(np.array([pos[0] * S + pos[1]], np.int64)), dev_i32([tcP]), dev_i32([tcQ])
+        check(self.L.x265hip_pel_filter_luma_strong_batch(self.depth, d.ptr, o.ptr, step, off, a.ptr, b.ptr, 1, None))
+        return d.get()
+
+    def pel_filter_chroma(self, plane, pos, edgeDir, tc, maskP, maskQ):
+        d = DevBuf(plane)
+        S = plane.shape[1]
+        step, off = (S, 1) if edgeDir == 0 else (1, S)
+        o, a, b, c = DevBuf(np.array([pos[0] * S + pos[1]], np.int64)), dev_i32([tc]), dev_i32([maskP]), dev_i32([maskQ])
+        check(self.L.x265hip_pel_filter_chroma_batch(self.depth, d.ptr, o.ptr, step, off, a.ptr, b.ptr, c.ptr, 1, None))
+        return d.get()
+
+    def sao_sign(self, a, b):
+        da, db, dd = DevBuf(a), DevBuf(b), DevBuf.zeros((len(a),), np.int8)
+        check(self.L.x265hip_sao_sign(self.depth, dd.ptr, da.ptr, db.ptr, len(a), None))
+        return dd.get()
+
+    def _sao_apply(self, kind, plane, pos, jobfields, aux):
+        from x265_amd.hipprim import SaoJob
+        d = DevBuf(plane)
+        jb = SaoJob()
+        jb.recOff = pos[0] * plane.shape[1] + pos[1]
+        for k, v in jobfields.items():
+            if k in ("offsets", "signLeft"):
+                arr = getattr(jb, k)
+                for i, x in enumerate(v):
+                    arr[i] = int(x)
+            else:
+                setattr(jb, k, v)
+        dj = DevBuf(np.frombuffer(bytes(jb), np.uint8).copy())
+        da = DevBuf(np.ascontiguousarray(aux, np.int8)) if aux is not None else None
+        check(self.L.x265hip_sao_apply_batch(self.depth, kind, d.ptr, plane.shape[1], da.ptr if da else None, dj.ptr, 1, None))
+        return d.get(), (da.get() if da else None)
+
+    def sao_e0(self, plane, pos, offsetEo, width, signLeft):
+        return self._sao_apply(0, plane, pos, dict(width=width, offsets=offsetEo, signLeft=signLeft), None)[0]
+
+    def sao_e1(self, plane, pos, up, offsetEo, width, rows):
+        return self._sao_apply(1 if rows == 1 else 2, plane, pos, dict(width=width, offsets=offsetEo, aux0=0), np.array(up, np.int8))
+
+    def sao_e2(self, plane, pos, bufft, buff1, offsetEo, width):
+        aux = np.concatenate([np.array(bufft, np.int8), np.array(buff1, np.int8)])
+        p, a = self._sao_apply(3, plane, pos, dict(width=width, offsets=offsetEo, aux0=0, aux1=len(bufft)), aux)
+        return p, a[:len(bufft)].copy()
+
+    def sao_e3(self, plane, pos, upfull, offsetEo, startX, endX):
+        return self._sao_apply(4, plane, pos, dict(width=endX, startX=startX, offsets=offsetEo, aux0=1), np.array(upfull, np.int8))
+
+    def sao_b0(self, plane, pos, offset32, w, h):
+        return self._sao_apply(5, plane, pos, dict(width=w, height=h, offsets=offset32), None)[0]
+
+    def sao_stats(self, kind, diff, plane, pos, endX, endY, stats, count, up1full, uptfull):
+        from x265_amd.hipprim import SaoStatsJob
+        d, dd = DevBuf(plane), DevBuf(np.ascontiguousarray(diff, np.int16))
+        n1 = len(up1full)
+        aux = np.concatenate([np.array(up1full, np.int8), np.array(uptfull, np.int8)])
+        da = DevBuf(aux)
+        jb = SaoStatsJob()
+        jb.diffOff, jb.recOff, jb.aux0, jb.aux1, jb.endX, jb.endY = 0, pos[0] * plane.shape[1] + pos[1], 1, n1 + 1, endX, endY
+        dj = DevBuf(np.frombuffer(bytes(jb), np.uint8).copy())
+        st, ct = np.zeros(32, np.int32), np.zeros(32, np.int32)
+        st[:len(stats)] = stats
+        ct[:len(count)] = count
+        ds, dc = DevBuf(st), DevBuf(ct)
+        check(self.L.x265hip_sao_stats_batch(self.depth, kind, dd.ptr, d.ptr, plane.shape[1], da.ptr, dj.ptr, 1, ds.ptr, dc.ptr, None))
+        a = da.get()
+        return ds.get()[:len(stats)].copy(), dc.get()[:len(count)].copy(), a[:n1].copy(), a[n1:].copy()
+
     # ---- small primitives: var, weighted prediction, downscales, transpose
     def var(self, size, a, ao):
         da = DevBuf(a)

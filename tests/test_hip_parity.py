@@ -598,6 +598,68 @@ def test_bipred_matches_oracle(hipmod, depth):
     assert np.array_equal(y, wy) and np.array_equal(cb, wcb) and np.array_equal(cr, wcr)
 
 
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_loop_filter_primitives_match_oracle_and_golden(hipmod, depth):
+    """Deblocking edge filters, SAO offset application and SAO statistics: every case against the oracle and the committed digests of the
+    reference; then whole-picture launches — every vertical luma edge segment of a picture in one launch, band offset and statistics of
+    every CTU in one launch — against per-call oracle results."""
+    import json
+    from cases import loop_cases, digest
+    from x265_amd.hipprim import DevBuf, check, dev_i32, SaoJob, SaoStatsJob
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "primitives_golden.json")))["golden"][str(depth)]["loop"]
+    o, g = Orc(depth), hipmod.Hip(depth)
+    bad, total = [], 0
+    for label, fn, args in loop_cases(depth):
+        want, got = getattr(o, fn)(*args), getattr(g, fn)(*args)
+        hipmod._release()
+        total += 1
+        if not same(want, got) or digest(got) != gold[label]:
+            bad.append(label)
+    _report(bad, total)
+    rng = np.random.default_rng(17 + depth)
+    H, W = 136, 200
+    pic = (np.kron(rng.integers(0, (1 << depth) - 8, size=(H // 4, W // 4)), np.ones((4, 4), np.int64)) + rng.integers(0, 3, size=(H, W))).astype(g.pix)
+    L = g.L
+    # all vertical edges on the 8-sample grid, four lines each: disjoint jobs, one launch
+    segs = [(y, x) for y in range(0, H, 4) for x in range(8, W, 8)]
+    tcP, tcQ = rng.integers(0, 20, size=len(segs)).astype(np.int32), rng.integers(0, 20, size=len(segs)).astype(np.int32)
+    d, doff, dp, dq = DevBuf(pic), DevBuf(np.array([y * W + x for (y, x) in segs], np.int64)), dev_i32(tcP), dev_i32(tcQ)   # named: launches are asynchronous
+    check(L.x265hip_pel_filter_luma_strong_batch(depth, d.ptr, doff.ptr, W, 1, dp.ptr, dq.ptr, len(segs), None))
+    want = pic
+    for i, (y, x) in enumerate(segs):
+        want = o.pel_filter_luma_strong(want, (y, x), 0, int(tcP[i]), int(tcQ[i]))
+    assert np.array_equal(d.get(), want)
+    # band offset and BO / E0 statistics of every 64x64 CTU (ragged right and bottom ones) in one launch each
+    ctus = [(y, x, min(64, W - 1 - x), min(64, H - 1 - y)) for y in range(1, H - 1, 64) for x in range(1, W - 1, 64)]
+    jobs = (SaoJob * len(ctus))()
+    band = rng.integers(-7, 8, size=(len(ctus), 32)).astype(np.int8)
+    for i, (y, x, w, h) in enumerate(ctus):
+        jobs[i].recOff, jobs[i].width, jobs[i].height = y * W + x, w, h
+        for k in range(32):
+            jobs[i].offsets[k] = int(band[i, k])
+    d, dj = DevBuf(pic), DevBuf(np.frombuffer(bytes(jobs), np.uint8).copy())
+    check(L.x265hip_sao_apply_batch(depth, 5, d.ptr, W, None, dj.ptr, len(ctus), None))
+    want = pic
+    for i, (y, x, w, h) in enumerate(ctus):
+        want = o.sao_b0(want, (y, x), band[i], w, h)
+    assert np.array_equal(d.get(), want)
+    diff = rng.integers(-200, 201, size=(len(ctus), 64, 64)).astype(np.int16)
+    for kind in (0, 1):
+        sj = (SaoStatsJob * len(ctus))()
+        for i, (y, x, w, h) in enumerate(ctus):
+            sj[i].diffOff, sj[i].recOff, sj[i].endX, sj[i].endY = i * 4096, y * W + x, w, h
+        ds, dc = DevBuf.zeros((len(ctus), 32), np.int32), DevBuf.zeros((len(ctus), 32), np.int32)
+        dd, dpic, dsj = DevBuf(diff), DevBuf(pic), DevBuf(np.frombuffer(bytes(sj), np.uint8).copy())
+        check(L.x265hip_sao_stats_batch(depth, kind, dd.ptr, dpic.ptr, W, None, dsj.ptr, len(ctus), ds.ptr, dc.ptr, None))
+        st, ct = ds.get(), dc.get()
+        ncls = 32 if kind == 0 else 5
+        for i, (y, x, w, h) in enumerate(ctus):
+            ws, wc, _, _ = o.sao_stats(kind, diff[i], pic, (y, x), w, h, np.zeros(ncls, np.int32), np.zeros(ncls, np.int32), np.zeros(w + 2, np.int8),
+                                       np.zeros(w + 2, np.int8))
+            assert st[i][:ncls].tolist() == ws.tolist() and ct[i][:ncls].tolist() == wc.tolist(), (kind, i)
+    hipmod._release()
+
+
 def test_coefficient_scan_primitives_match_oracle_and_golden(hipmod):
     """scanPosLast / findPosFirstLast / costCoeffNxN / costCoeffRemain / costC1C2Flag: every case one by one against the oracle and the
     committed digests of the reference, then many jobs per launch (a launch of 300 TUs per size, 256-job cost batches with private

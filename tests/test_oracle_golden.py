@@ -38,6 +38,12 @@ def test_oracle_chroma_motion_estimate_matches_golden(depth):
     assert make_golden.chroma_me_results(Orc, depth) == GOLD[str(depth)]["chroma_me"]
 
 
+@pytest.mark.parametrize("depth", [8, 10])
+def test_oracle_loop_filter_primitives_match_golden(depth):
+    got, want = make_golden.loop_digests(Orc, depth), GOLD[str(depth)]["loop"]
+    assert len(want) >= 380 and got == want, [k for k in want if got.get(k) != want[k]][:8]
+
+
 def test_oracle_coefficient_scan_primitives_match_golden():
     got = make_golden.coef_digests(Orc)
     want = GOLD["coef"]

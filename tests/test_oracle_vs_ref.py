@@ -50,6 +50,19 @@ def test_every_primitive_matches_reference(depth):
     assert n > 2000
 
 
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_loop_filter_primitives_match_reference(depth):
+    """pelFilterLumaStrong / pelFilterChroma, calSign, saoCuOrgE0..E3 / B0 and saoCuStatsBO / E0..E3 of the reference's C table vs the restatement."""
+    _need_ref(depth)
+    from cases import loop_cases
+    o, r = Orc(depth), Ref(depth)
+    n = 0
+    for label, fn, args in loop_cases(depth):
+        assert same(getattr(o, fn)(*args), getattr(r, fn)(*args)), label
+        n += 1
+    assert n >= 380
+
+
 def test_coefficient_scan_primitives_match_reference():
     """scanPosLast / findPosFirstLast / costCoeffNxN / costCoeffRemain / costC1C2Flag of the reference's C table and its scan-order tables vs the
     restatement, on inputs drawn like test/pixelharness.cpp draws them; and the committed CABAC cost table is the reference's."""

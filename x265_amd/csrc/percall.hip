@@ -756,4 +756,147 @@ int x265hip_call_cost_c1c2_flag(const uint16_t* absCoeff, int64_t numC1Flag, uin
     return X265HIP_OK;
 }
 
+// ---- in-loop filter primitives.  Only the samples the reference's function itself touches are staged (it is handed pointers into the
+// middle of pictures and of small test buffers alike).
+
+// pelFilterLumaStrong_t (primitives.h:224): four lines x eight samples across the edge, staged densely (line step 8, sample step 1)
+int x265hip_call_pel_filter_luma_strong(int depth, void* src, int64_t srcStep, int64_t offset, int32_t tcP, int32_t tcQ)
+{
+    const int B = depth == 8 ? 1 : 2;
+    PC_BEGIN(256);
+    const size_t oO = carve(8), oT = carve(8), oW = carve(32 * 2);
+    *hostp<int64_t>(oO) = 4;
+    hostp<int32_t>(oT)[0] = tcP; hostp<int32_t>(oT)[1] = tcQ;
+    for (int l = 0; l < 4; l++)
+        for (int k = -4; k < 4; k++)
+            memcpy(hostp<char>(oW) + (l * 8 + k + 4) * B, (const char*)src + (l * srcStep + k * offset) * B, B);
+    PC_TRY(upload());
+    PC_TRY(x265hip_pel_filter_luma_strong_batch(depth, devp<char>(oW), devp<int64_t>(oO), 8, 1, devp<int32_t>(oT), devp<int32_t>(oT) + 1, 1, t_st.stream));
+    PC_TRY(download(oW, 64));
+    for (int l = 0; l < 4; l++)
+        for (int k = -3; k < 3; k++)
+            memcpy((char*)src + (l * srcStep + k * offset) * B, hostp<char>(oW) + (l * 8 + k + 4) * B, B);
+    return X265HIP_OK;
+}
+
+// pelFilterChroma_t (primitives.h:225): samples -2 .. +1 of four lines
+int x265hip_call_pel_filter_chroma(int depth, void* src, int64_t srcStep, int64_t offset, int32_t tc, int32_t maskP, int32_t maskQ)
+{
+    const int B = depth == 8 ? 1 : 2;
+    PC_BEGIN(256);
+    const size_t oO = carve(8), oT = carve(16), oW = carve(16 * 2);
+    *hostp<int64_t>(oO) = 2;
+    hostp<int32_t>(oT)[0] = tc; hostp<int32_t>(oT)[1] = maskP; hostp<int32_t>(oT)[2] = maskQ;
+    for (int l = 0; l < 4; l++)
+        for (int k = -2; k < 2; k++)
+            memcpy(hostp<char>(oW) + (l * 4 + k + 2) * B, (const char*)src + (l * srcStep + k * offset) * B, B);
+    PC_TRY(upload());
+    PC_TRY(x265hip_pel_filter_chroma_batch(depth, devp<char>(oW), devp<int64_t>(oO), 4, 1, devp<int32_t>(oT), devp<int32_t>(oT) + 1, devp<int32_t>(oT) + 2, 1,
+                                           t_st.stream));
+    PC_TRY(download(oW, 32));
+    for (int l = 0; l < 4; l++)
+        for (int k = -1; k < 1; k++)
+            memcpy((char*)src + (l * srcStep + k * offset) * B, hostp<char>(oW) + (l * 4 + k + 2) * B, B);
+    return X265HIP_OK;
+}
+
+// sign_t (primitives.h:206)
+int x265hip_call_sao_sign(int depth, int8_t* dst, const void* src1, const void* src2, int endX)
+{
+    if (endX <= 0) return X265HIP_OK;
+    const int B = depth == 8 ? 1 : 2;
+    PC_BEGIN((size_t)endX * (2 * B + 1) + 64);
+    const size_t oA = carve((size_t)endX * B), oB = carve((size_t)endX * B), oD = carve((size_t)endX);
+    memcpy(hostp<char>(oA), src1, (size_t)endX * B);
+    memcpy(hostp<char>(oB), src2, (size_t)endX * B);
+    PC_TRY(upload());
+    PC_TRY(x265hip_sao_sign(depth, devp<int8_t>(oD), devp<char>(oA), devp<char>(oB), endX, t_st.stream));
+    PC_TRY(download(oD, (size_t)endX));
+    memcpy(dst, hostp<char>(oD), (size_t)endX);
+    return X265HIP_OK;
+}
+
+// saoCuOrgE0 / E1 / E1_2Rows / E2 / E3 / B0 (primitives.h:194-198), kind 0..5.  a = width (endX for E3), b = height (B0) or startX (E3).
+int x265hip_call_sao_apply(int depth, int kind, void* rec, int64_t stride, int a, int b, int8_t* aux0, int8_t* aux1, const int8_t* offsets,
+                           const int8_t* signLeft)
+{
+    const int B = depth == 8 ? 1 : 2;
+    const int width = a;
+    // rows and columns of the picture the reference reads / writes
+    const int wrRows = kind == 5 ? b : ((kind == 0 || kind == 2) ? 2 : 1);
+    const int rdRows = kind == 5 ? b : (kind == 0 ? 2 : wrRows + 1);
+    const int x0 = kind == 4 ? b + 1 : 0;
+    const int wrCols = width, rdCols = (kind == 0 || kind == 3) ? width + 1 : width;
+    if (width <= x0 || width > 256 || wrRows < 1)
+        return kind == 4 && width <= x0 ? X265HIP_OK : X265HIP_EINVAL;
+    const int pitch = rdCols;
+    PC_BEGIN((size_t)rdRows * pitch * B + 1024);
+    const size_t oJ = carve(sizeof(x265hip_sao_job)), oX = carve(2 * (size_t)(width + 4)), oW = carve((size_t)rdRows * pitch * B);
+    x265hip_sao_job* jb = hostp<x265hip_sao_job>(oJ);
+    memset(jb, 0, sizeof(*jb));
+    jb->recOff = 0; jb->width = width; jb->height = b; jb->startX = b;
+    memcpy(jb->offsets, offsets, kind == 5 ? 32 : 5);
+    if (kind == 0) { jb->signLeft[0] = signLeft[0]; jb->signLeft[1] = signLeft[1]; }
+    int8_t* ax = hostp<int8_t>(oX);
+    memset(ax, 0, 2 * (size_t)(width + 4));
+    // aux staging: first array at [1 ..], second at [width + 5 ..] (one spare element before each for E3's write to [x - 1])
+    jb->aux0 = 1; jb->aux1 = width + 5;
+    if (kind == 1 || kind == 2) memcpy(ax + 1, aux0, (size_t)width);
+    if (kind == 3) memcpy(ax + width + 5, aux1, (size_t)width);                 // buff1 is read, bufft only written
+    if (kind == 4) memcpy(ax + 1 + x0, aux0 + x0, (size_t)(width - x0));
+    for (int y = 0; y < rdRows; y++)
+        memcpy(hostp<char>(oW) + ((size_t)y * pitch + x0) * B, (const char*)rec + (y * stride + x0) * B, (size_t)(rdCols - x0) * B);
+    PC_TRY(upload());
+    PC_TRY(x265hip_sao_apply_batch(depth, kind, devp<char>(oW), pitch, devp<int8_t>(oX), devp<x265hip_sao_job>(oJ), 1, t_st.stream));
+    PC_TRY(download(oX, oW + (size_t)rdRows * pitch * B - oX));
+    for (int y = 0; y < wrRows; y++)
+        memcpy((char*)rec + (y * stride + x0) * B, hostp<char>(oW) + ((size_t)y * pitch + x0) * B, (size_t)(wrCols - x0) * B);
+    if (kind == 1 || kind == 2) memcpy(aux0, ax + 1, (size_t)width);
+    if (kind == 3) memcpy(aux0 + 1, ax + 2, (size_t)width);                     // bufft[x + 1]
+    if (kind == 4) memcpy(aux0 + x0 - 1, ax + x0, (size_t)(width - x0));         // upBuff1[x - 1]
+    return X265HIP_OK;
+}
+
+// saoCuStatsBO / E0 / E1 / E2 / E3 (primitives.h:200-204), kind 0..4
+int x265hip_call_sao_stats(int depth, int kind, const int16_t* diff, const void* rec, int64_t stride, int8_t* up1, int8_t* upt, int endX, int endY,
+                           int32_t* stats, int32_t* count)
+{
+    if (endX <= 0 || endY <= 0 || endX > 64 || endY > 64)
+        return X265HIP_EINVAL;
+    const int B = depth == 8 ? 1 : 2;
+    const int cl = (kind == 1 || kind == 3 || kind == 4) ? -1 : 0, cr = (kind == 0 || kind == 2) ? endX : endX + 1;   // columns read: [cl, cr)
+    const int rows = (kind <= 1) ? endY : endY + 1;
+    const int pitch = 66;
+    PC_BEGIN(64 * 64 * 2 + (size_t)65 * pitch * 2 + 1024);
+    const size_t oJ = carve(sizeof(x265hip_sao_stats_job)), oS = carve(128), oC = carve(128), oX = carve(2 * 68), oD = carve((size_t)endY * 64 * 2),
+                 oW = carve((size_t)rows * pitch * B);
+    x265hip_sao_stats_job* jb = hostp<x265hip_sao_stats_job>(oJ);
+    jb->diffOff = 0; jb->recOff = 1; jb->aux0 = 1; jb->aux1 = 69; jb->endX = endX; jb->endY = endY;
+    const int ncls = kind == 0 ? 32 : 5;
+    memset(hostp<char>(oS), 0, 256);
+    memcpy(hostp<int32_t>(oS), stats, (size_t)ncls * 4);
+    memcpy(hostp<int32_t>(oC), count, (size_t)ncls * 4);
+    int8_t* ax = hostp<int8_t>(oX);
+    memset(ax, 0, 2 * 68);
+    if (kind >= 2) memcpy(ax + 1, up1, (size_t)endX);
+    memcpy(hostp<char>(oD), diff, (size_t)endY * 64 * 2);
+    for (int y = 0; y < rows; y++)
+        memcpy(hostp<char>(oW) + ((size_t)y * pitch + 1 + cl) * B, (const char*)rec + (y * stride + cl) * B, (size_t)(cr - cl) * B);
+    PC_TRY(upload());
+    PC_TRY(x265hip_sao_stats_batch(depth, kind, devp<int16_t>(oD), devp<char>(oW), pitch, devp<int8_t>(oX), devp<x265hip_sao_stats_job>(oJ), 1,
+                                   devp<int32_t>(oS), devp<int32_t>(oC), t_st.stream));
+    PC_TRY(download(oS, oD - oS));
+    memcpy(stats, hostp<int32_t>(oS), (size_t)ncls * 4);
+    memcpy(count, hostp<int32_t>(oC), (size_t)ncls * 4);
+    if (kind == 2) memcpy(up1, ax + 1, (size_t)endX);
+    if (kind == 3)
+    {
+        // row y writes [0 .. endX] of upBufft (y even) or upBuff1 (y odd); the buffer the last row wrote, and the one before if there was one
+        if (endY >= 2 || !((endY - 1) & 1)) memcpy(upt, ax + 69, (size_t)endX + 1);
+        if (endY >= 2 || ((endY - 1) & 1)) memcpy(up1, ax + 1, (size_t)endX + 1);
+    }
+    if (kind == 4) memcpy(up1 - 1, ax, (size_t)endX + 1);                       // [-1 .. endX - 1]
+    return X265HIP_OK;
+}
+
 } // extern "C"

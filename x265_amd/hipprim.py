@@ -127,6 +127,16 @@ PROTOTYPES = {
     "x265hip_call_cost_coeff_nxn": (i32, [i32, vp, i64, vp, vp, C.c_uint32, vp, i32, i32, i32, vp]),
     "x265hip_call_cost_coeff_remain": (i32, [vp, i32, i32, vp]),
     "x265hip_call_cost_c1c2_flag": (i32, [vp, i64, vp, i64, vp]),
+    "x265hip_pel_filter_luma_strong_batch": (i32, [i32, vp, vp, i64, i64, vp, vp, i32, vp]),
+    "x265hip_pel_filter_chroma_batch": (i32, [i32, vp, vp, i64, i64, vp, vp, vp, i32, vp]),
+    "x265hip_sao_sign": (i32, [i32, vp, vp, vp, i32, vp]),
+    "x265hip_sao_apply_batch": (i32, [i32, i32, vp, i64, vp, vp, i32, vp]),
+    "x265hip_sao_stats_batch": (i32, [i32, i32, vp, vp, i64, vp, vp, i32, vp, vp, vp]),
+    "x265hip_call_pel_filter_luma_strong": (i32, [i32, vp, i64, i64, i32, i32]),
+    "x265hip_call_pel_filter_chroma": (i32, [i32, vp, i64, i64, i32, i32, i32]),
+    "x265hip_call_sao_sign": (i32, [i32, vp, vp, vp, i32]),
+    "x265hip_call_sao_apply": (i32, [i32, i32, vp, i64, i32, i32, vp, vp, vp, vp]),
+    "x265hip_call_sao_stats": (i32, [i32, i32, vp, vp, i64, vp, vp, i32, i32, vp, vp]),
     "x265hip_motion_compensation_batch": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
     "x265hip_intra_scan_batch": (i32, [i32, i32, vp, vp, vp, vp, i64, vp, i32, vp, vp]),
     "x265hip_frame_init_lowres": (i32, [i32, vp, i64, vp, vp, vp, vp, i64, i32, i32, vp]),
@@ -143,6 +153,17 @@ PROTOTYPES = {
 }
 
 CMP_SAD, CMP_SATD, CMP_SA8D, CMP_SA8D8, CMP_PSY = 0, 1, 2, 3, 4
+
+
+class SaoJob(C.Structure):
+    """x265hip_sao_job (include/x265hip.h)"""
+    _fields_ = [("recOff", C.c_int64), ("aux0", C.c_int64), ("aux1", C.c_int64), ("width", C.c_int32), ("height", C.c_int32), ("startX", C.c_int32),
+                ("offsets", C.c_int8 * 32), ("signLeft", C.c_int8 * 2), ("reserved", C.c_int8 * 2)]
+
+
+class SaoStatsJob(C.Structure):
+    """x265hip_sao_stats_job (include/x265hip.h)"""
+    _fields_ = [("diffOff", C.c_int64), ("recOff", C.c_int64), ("aux0", C.c_int64), ("aux1", C.c_int64), ("endX", C.c_int32), ("endY", C.c_int32)]
 
 
 class CoeffGroupJob(C.Structure):

@@ -475,6 +475,68 @@ static uint32_t costC1C2Flag_hip(uint16_t* absCoeff, intptr_t numC1Flag, uint8_t
     return r;
 }
 
+// ---- in-loop filter primitives (loopfilter.cpp, sao.cpp:1762-1925)
+static void pelFilterLumaStrong_hip(pixel* src, intptr_t srcStep, intptr_t offset, int32_t tcP, int32_t tcQ)
+{
+    if (x265hip_call_pel_filter_luma_strong(X265_DEPTH, src, srcStep, offset, tcP, tcQ)) g_c.pelFilterLumaStrong[0](src, srcStep, offset, tcP, tcQ);
+}
+static void pelFilterChroma_hip(pixel* src, intptr_t srcStep, intptr_t offset, int32_t tc, int32_t maskP, int32_t maskQ)
+{
+    if (x265hip_call_pel_filter_chroma(X265_DEPTH, src, srcStep, offset, tc, maskP, maskQ)) g_c.pelFilterChroma[0](src, srcStep, offset, tc, maskP, maskQ);
+}
+static void saoSign_hip(int8_t* dst, const pixel* src1, const pixel* src2, const int endX)
+{
+    if (x265hip_call_sao_sign(X265_DEPTH, dst, src1, src2, endX)) g_c.sign(dst, src1, src2, endX);
+}
+static void saoCuOrgE0_hip(pixel* rec, int8_t* offsetEo, int width, int8_t* signLeft, intptr_t stride)
+{
+    if (x265hip_call_sao_apply(X265_DEPTH, 0, rec, stride, width, 0, NULL, NULL, offsetEo, signLeft)) g_c.saoCuOrgE0(rec, offsetEo, width, signLeft, stride);
+}
+static void saoCuOrgE1_hip(pixel* rec, int8_t* upBuff1, int8_t* offsetEo, intptr_t stride, int width)
+{
+    if (x265hip_call_sao_apply(X265_DEPTH, 1, rec, stride, width, 0, upBuff1, NULL, offsetEo, NULL)) g_c.saoCuOrgE1(rec, upBuff1, offsetEo, stride, width);
+}
+static void saoCuOrgE1_2Rows_hip(pixel* rec, int8_t* upBuff1, int8_t* offsetEo, intptr_t stride, int width)
+{
+    if (x265hip_call_sao_apply(X265_DEPTH, 2, rec, stride, width, 0, upBuff1, NULL, offsetEo, NULL)) g_c.saoCuOrgE1_2Rows(rec, upBuff1, offsetEo, stride, width);
+}
+static void saoCuOrgE2_hip(pixel* rec, int8_t* bufft, int8_t* buff1, int8_t* offsetEo, int width, intptr_t stride)
+{
+    if (x265hip_call_sao_apply(X265_DEPTH, 3, rec, stride, width, 0, bufft, buff1, offsetEo, NULL)) g_c.saoCuOrgE2[0](rec, bufft, buff1, offsetEo, width, stride);
+}
+static void saoCuOrgE3_hip(pixel* rec, int8_t* upBuff1, int8_t* offsetEo, intptr_t stride, int startX, int endX)
+{
+    if (x265hip_call_sao_apply(X265_DEPTH, 4, rec, stride, endX, startX, upBuff1, NULL, offsetEo, NULL)) g_c.saoCuOrgE3[0](rec, upBuff1, offsetEo, stride, startX, endX);
+}
+static void saoCuOrgB0_hip(pixel* rec, const int8_t* offset, int ctuWidth, int ctuHeight, intptr_t stride)
+{
+    if (x265hip_call_sao_apply(X265_DEPTH, 5, rec, stride, ctuWidth, ctuHeight, NULL, NULL, offset, NULL)) g_c.saoCuOrgB0(rec, offset, ctuWidth, ctuHeight, stride);
+}
+static void saoCuStatsBO_hip(const int16_t* diff, const pixel* rec, intptr_t stride, int endX, int endY, int32_t* stats, int32_t* count)
+{
+    if (x265hip_call_sao_stats(X265_DEPTH, 0, diff, rec, stride, NULL, NULL, endX, endY, stats, count)) g_c.saoCuStatsBO(diff, rec, stride, endX, endY, stats, count);
+}
+static void saoCuStatsE0_hip(const int16_t* diff, const pixel* rec, intptr_t stride, int endX, int endY, int32_t* stats, int32_t* count)
+{
+    if (x265hip_call_sao_stats(X265_DEPTH, 1, diff, rec, stride, NULL, NULL, endX, endY, stats, count)) g_c.saoCuStatsE0(diff, rec, stride, endX, endY, stats, count);
+}
+static void saoCuStatsE1_hip(const int16_t* diff, const pixel* rec, intptr_t stride, int8_t* upBuff1, int endX, int endY, int32_t* stats, int32_t* count)
+{
+    if (x265hip_call_sao_stats(X265_DEPTH, 2, diff, rec, stride, upBuff1, NULL, endX, endY, stats, count))
+        g_c.saoCuStatsE1(diff, rec, stride, upBuff1, endX, endY, stats, count);
+}
+static void saoCuStatsE2_hip(const int16_t* diff, const pixel* rec, intptr_t stride, int8_t* upBuff1, int8_t* upBufft, int endX, int endY, int32_t* stats,
+                             int32_t* count)
+{
+    if (x265hip_call_sao_stats(X265_DEPTH, 3, diff, rec, stride, upBuff1, upBufft, endX, endY, stats, count))
+        g_c.saoCuStatsE2(diff, rec, stride, upBuff1, upBufft, endX, endY, stats, count);
+}
+static void saoCuStatsE3_hip(const int16_t* diff, const pixel* rec, intptr_t stride, int8_t* upBuff1, int endX, int endY, int32_t* stats, int32_t* count)
+{
+    if (x265hip_call_sao_stats(X265_DEPTH, 4, diff, rec, stride, upBuff1, NULL, endX, endY, stats, count))
+        g_c.saoCuStatsE3(diff, rec, stride, upBuff1, endX, endY, stats, count);
+}
+
 #define HIP_SMALL(N) do { \
         p.cu[BLOCK_ ## N ## x ## N].var = var_hip<N, BLOCK_ ## N ## x ## N>; \
         p.cu[BLOCK_ ## N ## x ## N].transpose = transpose_hip<N, BLOCK_ ## N ## x ## N>; \
@@ -535,6 +597,22 @@ void setupAssemblyPrimitives(EncoderPrimitives& p, int /* cpuMask: CPU ISA bits,
     p.scale1D_128to64[NONALIGNED] = scale1d_hip;
     p.scale1D_128to64[ALIGNED] = scale1d_hip;
     p.scale2D_64to32 = scale2d_hip;
+    // in-loop filters: deblocking edge filters, SAO offset application and statistics (the C code is the same for both edge directions
+    // and both width classes, loopfilter.cpp:187-205)
+    p.pelFilterLumaStrong[0] = p.pelFilterLumaStrong[1] = pelFilterLumaStrong_hip;
+    p.pelFilterChroma[0] = p.pelFilterChroma[1] = pelFilterChroma_hip;
+    p.sign = saoSign_hip;
+    p.saoCuOrgE0 = saoCuOrgE0_hip;
+    p.saoCuOrgE1 = saoCuOrgE1_hip;
+    p.saoCuOrgE1_2Rows = saoCuOrgE1_2Rows_hip;
+    p.saoCuOrgE2[0] = p.saoCuOrgE2[1] = saoCuOrgE2_hip;
+    p.saoCuOrgE3[0] = p.saoCuOrgE3[1] = saoCuOrgE3_hip;
+    p.saoCuOrgB0 = saoCuOrgB0_hip;
+    p.saoCuStatsBO = saoCuStatsBO_hip;
+    p.saoCuStatsE0 = saoCuStatsE0_hip;
+    p.saoCuStatsE1 = saoCuStatsE1_hip;
+    p.saoCuStatsE2 = saoCuStatsE2_hip;
+    p.saoCuStatsE3 = saoCuStatsE3_hip;
     if (!x265hip_set_entropy_state_bits(PFX(entropyStateBits)))
     {
         // the coefficient-scan cost helpers of RDOQ and of the bit estimation (the CABAC cost table is the encoder's own data)
