@@ -826,7 +826,7 @@ def test_empty_batches_and_bad_arguments(hipmod):
     assert L.x265hip_dct_batch(64, 0, 8, None, 64, None, None, 1, None) == -1                                  # no 64-point transform
     assert L.x265hip_dct_batch(8, 1, 8, None, 8, None, None, 1, None) == -1                                    # DST is 4x4 only
     assert L.x265hip_motion_estimate_batch(8, 4, 4, None, 0, None, 0, None, None, None, None, 0, None, 57, 1, 2, None, 65536, 1, None, None, None) == -1
-    assert L.x265hip_motion_estimate_batch(8, 8, 8, None, 0, None, 0, None, None, None, None, 0, None, 57, 2, 2, None, 65536, 1, None, None, None) == -1   # UMH
+    assert L.x265hip_motion_estimate_batch(8, 8, 8, None, 0, None, 0, None, None, None, None, 0, None, 57, 4, 2, None, 65536, 1, None, None, None) == -1   # SEA (needs the integral planes) is not implemented
     assert L.x265hip_interp_batch(hp.IF_HVPP, 4, 8, 8, 8, None, 0, None, 0, None, None, None, 0, 1, None) == -1          # hv_pp is a luma slot
     from x265_amd.framepass import FramePass
     with pytest.raises(hp.HipError):
