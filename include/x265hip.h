@@ -184,6 +184,17 @@ int x265hip_pel_filter_luma_strong_batch(int depth, void* plane, const int64_t* 
                                          const int32_t* tcQ, int n, void* stream);
 int x265hip_pel_filter_chroma_batch(int depth, void* plane, const int64_t* off, int64_t srcStep, int64_t offset, const int32_t* tc,
                                     const int32_t* maskP, const int32_t* maskQ, int n, void* stream);
+/* Deblock::edgeFilterLuma / edgeFilterChroma (deblock.cpp:317-513), the whole per-unit work: job i is one 4-line unit of an edge whose first
+ * Q-side sample sits at (xy[2i], xy[2i+1]) of the plane (chroma: of the chroma planes, 4:2:0); dir 0 = vertical edge (EDGE_VER), 1 =
+ * horizontal.  bs = the unit's boundary strength (0 skips; chroma filters bs 2 only), qpP / qpQ the QPs of the two sides, bypass [n][2]
+ * the cu_transquant_bypass flags of P and Q or NULL (pps bTransquantBypassEnabled off).  beta / tc from Table 8-12 with the slice's
+ * offsets, the decisions from lines 0 and 3, then pelFilterLumaStrong or the normal filter (deblock.cpp:276-314); chroma: tc from the
+ * mapped chroma QP, then pelFilterChroma on Cb and Cr.  All vertical edges of a picture may go in one launch, then all horizontal ones. */
+int x265hip_deblock_luma_batch(int depth, void* plane, int64_t stride, int dir, const int32_t* xy, const uint8_t* bs, const int8_t* qpP,
+                               const int8_t* qpQ, const uint8_t* bypass, int betaOffsetDiv2, int tcOffsetDiv2, int n, void* stream);
+int x265hip_deblock_chroma_batch(int depth, void* cb, void* cr, int64_t strideC, int dir, const int32_t* xy, const uint8_t* bs,
+                                 const int8_t* qpP, const int8_t* qpQ, const uint8_t* bypass, int tcOffsetDiv2, int cbQpOffset, int crQpOffset,
+                                 int n, void* stream);
 /* sign_t (primitives.h:206; loopfilter.cpp:38): dst[i] = sign(src1[i] - src2[i]) */
 int x265hip_sao_sign(int depth, int8_t* dst, const void* src1, const void* src2, int n, void* stream);
 /* saoCuOrgE0 / E1 / E1_2Rows / E2 / E3 / B0 (primitives.h:194-198; loopfilter.cpp:44-137).  kind 0..5 in that order.  Sign buffers live in

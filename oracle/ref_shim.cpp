@@ -21,6 +21,7 @@
 #include "predict.h"
 #include "shortyuv.h"
 #include "framedata.h"
+#include "deblock.h"
 #include "constants.h"
 #include "contexts.h"
 #include "cudata.h"
@@ -677,5 +678,76 @@ void ref_saoCuStatsE0(const int16_t* diff, const pixel* rec, intptr_t stride, in
 void ref_saoCuStatsE1(const int16_t* diff, const pixel* rec, intptr_t stride, int8_t* up, int endX, int endY, int32_t* stats, int32_t* count) { T().saoCuStatsE1(diff, rec, stride, up, endX, endY, stats, count); }
 void ref_saoCuStatsE2(const int16_t* diff, const pixel* rec, intptr_t stride, int8_t* up, int8_t* upt, int endX, int endY, int32_t* stats, int32_t* count) { T().saoCuStatsE2(diff, rec, stride, up, upt, endX, endY, stats, count); }
 void ref_saoCuStatsE3(const int16_t* diff, const pixel* rec, intptr_t stride, int8_t* up, int endX, int endY, int32_t* stats, int32_t* count) { T().saoCuStatsE3(diff, rec, stride, up, endX, endY, stats, count); }
+
+/* ---- the real Deblock::edgeFilterLuma / edgeFilterChroma (common/deblock.cpp:317-513) on one 64x64 CTU whose inner edges are filtered:
+ * a CUData that is its own picture (one CTU), block strengths / QPs / lossless flags given per 4x4 unit in RASTER order (16 x 16).
+ * y / cb / cr point at the CTU's top-left sample inside caller-owned planes.  edge: in 4-sample units from the CTU's left / top (1..15). */
+struct DeblockProbe : public Deblock
+{
+    static void luma(const CUData* cu, int dir, int edge, const uint8_t* bs) { edgeFilterLuma(cu, 0, 0, dir, edge, bs); }
+    static void chroma(const CUData* cu, int dir, int edge, const uint8_t* bs) { edgeFilterChroma(cu, 0, 0, dir, edge, bs); }
+};
+void ref_deblock_ctu_edge(pixel* y, pixel* cb, pixel* cr, intptr_t stride, intptr_t strideC, int dir, int edge, const uint8_t* bsRaster,
+                          const int8_t* qpRaster, const uint8_t* bypassRaster, int betaOffsetDiv2, int tcOffsetDiv2, int cbQpOffset, int crQpOffset,
+                          int doLuma, int doChroma)
+{
+    T();
+    x265_param param;
+    memset(&param, 0, sizeof(param));
+    param.maxCUSize = 64;
+    alignas(SPS) unsigned char spsRaw[sizeof(SPS)];
+    alignas(PPS) unsigned char ppsRaw[sizeof(PPS)];
+    memset(spsRaw, 0, sizeof(spsRaw));
+    memset(ppsRaw, 0, sizeof(ppsRaw));
+    SPS& sps = *reinterpret_cast<SPS*>(spsRaw);
+    PPS& pps = *reinterpret_cast<PPS*>(ppsRaw);
+    sps.numPartInCUSize = 16;
+    sps.numPartitions = 256;
+    pps.deblockingFilterBetaOffsetDiv2 = betaOffsetDiv2;
+    pps.deblockingFilterTcOffsetDiv2 = tcOffsetDiv2;
+    pps.chromaQpOffset[0] = cbQpOffset;
+    pps.chromaQpOffset[1] = crQpOffset;
+    pps.bTransquantBypassEnabled = bypassRaster != NULL;
+    Slice slice;
+    slice.m_sps = &sps;
+    slice.m_pps = &pps;
+    /* offsets of the 256 units inside the CTU, z-order -> sample offset (PicYuv::createOffsets does the same from the sps) */
+    intptr_t zero = 0, buY[256], buC[256];
+    uint8_t bs[256], bypass[256];
+    int8_t qp[256];
+    for (int r = 0; r < 256; r++)
+    {
+        const uint32_t z = g_rasterToZscan[r];
+        const int ux = r & 15, uy = r >> 4;
+        buY[z] = (intptr_t)uy * 4 * stride + ux * 4;
+        buC[z] = (intptr_t)uy * 2 * strideC + ux * 2;
+        bs[z] = bsRaster[r];
+        qp[z] = qpRaster[r];
+        bypass[z] = bypassRaster ? bypassRaster[r] : 0;
+    }
+    PicYuv pic;
+    pic.m_cuOffsetY = &zero; pic.m_cuOffsetC = &zero; pic.m_buOffsetY = buY; pic.m_buOffsetC = buC;
+    pic.m_picOrg[0] = y; pic.m_picOrg[1] = cb; pic.m_picOrg[2] = cr;
+    pic.m_stride = stride; pic.m_strideC = strideC;
+    FrameData enc;
+    enc.m_param = &param;
+    enc.m_reconPic = &pic;
+    CUData cu;
+    enc.m_picCTU = &cu;
+    cu.m_encData = &enc;
+    cu.m_slice = &slice;
+    cu.m_cuAddr = 0;
+    cu.m_absIdxInCTU = 0;
+    cu.m_chromaFormat = X265_CSP_I420;
+    cu.m_hChromaShift = cu.m_vChromaShift = 1;
+    cu.m_qp = qp;
+    cu.m_tqBypass = bypass;
+    cu.s_numPartInCUSize = 16;
+    if (doLuma) DeblockProbe::luma(&cu, dir, edge, bs);
+    if (doChroma) DeblockProbe::chroma(&cu, dir, edge, bs);
+    pic.m_picOrg[0] = pic.m_picOrg[1] = pic.m_picOrg[2] = NULL;
+    pic.m_cuOffsetY = pic.m_cuOffsetC = pic.m_buOffsetY = pic.m_buOffsetC = NULL;
+    enc.m_picCTU = NULL;
+}
 
 } // extern "C"

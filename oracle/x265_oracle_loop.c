@@ -2,6 +2,7 @@
  * (SURVEY.md §8f rank 4), restated on the CPU. */
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 #define PIX uint8_t
 #define FN(x) x##_8

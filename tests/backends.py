@@ -504,6 +504,30 @@ class Orc(_Base):
         fn.restype, fn.argtypes = None, argtypes
         return fn
 
+    def deblock_ctu_edge(self, planes, ctu, edgeDir, edge, bs, qp, bypass, betaDiv2, tcDiv2, cbOff, crOff, doLuma=1, doChroma=1):
+        """One inner edge of the 64x64 CTU at luma position ctu = (y, x): bs / qp / bypass are [16, 16] arrays per 4x4 unit (raster).
+        Restated as the unit loops of Deblock::edgeFilterLuma / edgeFilterChroma over the per-unit oracle functions."""
+        y, cb, cr = [p.copy() for p in planes]
+        S, SC = y.shape[1], cb.shape[1]
+        fl = self._lf("orc_deblock_luma_unit", [po.vp, po.ip, po.ip] + [po.i32] * 9)
+        fc = self._lf("orc_deblock_chroma_unit", [po.vp, po.vp, po.ip, po.ip] + [po.i32] * 10)
+        chk = 0 if bypass is None else 1
+        byp = bypass if bypass is not None else np.zeros((16, 16), np.uint8)
+        if doLuma:
+            for idx in range(16):
+                (qx, qy), (px, py) = ((edge, idx), (edge - 1, idx)) if edgeDir == 0 else ((idx, edge), (idx, edge - 1))
+                pos = (ctu[0] + qy * 4, ctu[1] + qx * 4)
+                step, off = (S, 1) if edgeDir == 0 else (1, S)
+                fl(ptr(y, *pos), step, off, int(bs[qy, qx]), int(qp[py, px]), int(qp[qy, qx]), chk, int(byp[py, px]), int(byp[qy, qx]), betaDiv2, tcDiv2, self.depth)
+        if doChroma:
+            for idx in range(8):
+                (qx, qy), (px, py) = ((edge, 2 * idx), (edge - 1, 2 * idx)) if edgeDir == 0 else ((2 * idx, edge), (2 * idx, edge - 1))
+                pos = (ctu[0] // 2 + (idx * 4 if edgeDir == 0 else edge * 2), ctu[1] // 2 + (edge * 2 if edgeDir == 0 else idx * 4))
+                step, off = (SC, 1) if edgeDir == 0 else (1, SC)
+                fc(ptr(cb, *pos), ptr(cr, *pos), step, off, int(bs[qy, qx]), int(qp[py, px]), int(qp[qy, qx]), chk, int(byp[py, px]), int(byp[qy, qx]), tcDiv2,
+                   cbOff, crOff, self.depth)
+        return y, cb, cr
+
     def pel_filter_luma_strong(self, plane, pos, edgeDir, tcP, tcQ):
         p = plane.copy()
         step, off = (p.shape[1], 1) if edgeDir == 0 else (1, p.shape[1])
@@ -942,6 +966,14 @@ class Ref(_Base):
         return int(r), ctx2
 
     # ---- in-loop filter primitives
+    def deblock_ctu_edge(self, planes, ctu, edgeDir, edge, bs, qp, bypass, betaDiv2, tcDiv2, cbOff, crOff, doLuma=1, doChroma=1):
+        y, cb, cr = [p.copy() for p in planes]
+        b8, q8 = np.ascontiguousarray(bs, np.uint8), np.ascontiguousarray(qp, np.int8)
+        t8 = np.ascontiguousarray(bypass, np.uint8) if bypass is not None else None
+        self.L.ref_deblock_ctu_edge(ptr(y, *ctu), ptr(cb, ctu[0] // 2, ctu[1] // 2), ptr(cr, ctu[0] // 2, ctu[1] // 2), y.shape[1], cb.shape[1], edgeDir, edge,
+                                    ptr(b8), ptr(q8), ptr(t8) if t8 is not None else None, betaDiv2, tcDiv2, cbOff, crOff, doLuma, doChroma)
+        return y, cb, cr
+
     def pel_filter_luma_strong(self, plane, pos, edgeDir, tcP, tcQ):
         p = plane.copy()
         step, off = (p.shape[1], 1) if edgeDir == 0 else (1, p.shape[1])

@@ -467,3 +467,30 @@ def loop_cases(depth, seed=91):
                 yield ("saoCuStats%s %s %dx%d #%d" % (["BO", "E0", "E1", "E2", "E3"][kind], mode, endX, endY, rep), "sao_stats",
                        (kind, diff, p, pos, endX, endY, rng.integers(0, 1 << 20, size=ncls).astype(np.int32), rng.integers(0, 1 << 20, size=ncls).astype(np.int32),
                         signs(endX + 2), signs(endX + 2)))
+
+
+def deblock_cases(depth, seed=55):
+    """Inner edges of one 64x64 CTU for Deblock::edgeFilterLuma / edgeFilterChroma: pictures that are smooth across the edge (so the beta / strong
+    decisions go both ways), random boundary strengths, QPs 10..51 per unit, slice offsets, optional lossless flags.  Yields (label, method, args)."""
+    rng = np.random.default_rng(seed + depth)
+    pmax = (1 << depth) - 1
+    dt = np.uint8 if depth == 8 else np.uint16
+    H, W = 96, 112
+    sc = 1 << (depth - 8)
+    for rep in range(10):
+        # blocky content: 8x8 blocks of nearly flat values with small steps between neighbours, plus a little noise
+        step = [2, 6, 15, 40][rep % 4]
+        base = np.cumsum(rng.integers(-step, step + 1, size=(H // 8 + 1, W // 8 + 1)), axis=1) + 128
+        y = np.clip((np.kron(base, np.ones((8, 8), np.int64))[:H, :W] + rng.integers(-1, 2, size=(H, W)) * (rep % 3 == 0)) * sc, 0, pmax).astype(dt)
+        cb = np.clip((np.kron(base[:H // 16 + 1, :W // 16 + 1], np.ones((8, 8), np.int64))[:H // 2, :W // 2] + rng.integers(-2, 3, size=(H // 2, W // 2))) * sc, 0, pmax).astype(dt)
+        cr = np.clip(pmax - cb.astype(np.int64) + rng.integers(-3, 4, size=cb.shape) * sc, 0, pmax).astype(dt)
+        ctu = (16, 24)
+        for edgeDir in (0, 1):
+            for edge in (2, 4, 8, 14):
+                bs = rng.integers(0, 3, size=(16, 16)).astype(np.uint8)
+                qp = rng.integers(10, 52, size=(16, 16)).astype(np.int8) if rep % 2 else np.full((16, 16), int(rng.integers(20, 45)), np.int8)
+                bypass = rng.integers(0, 2, size=(16, 16)).astype(np.uint8) if rep % 5 == 4 else None
+                offs = (int(rng.integers(-3, 4)), int(rng.integers(-3, 4)), int(rng.integers(-6, 7)), int(rng.integers(-6, 7))) if rep % 3 == 2 else (0, 0, 0, 0)
+                chroma = 1 if edge % 4 == 0 else 0                 # chroma edges sit on the 8-sample chroma grid
+                yield ("deblock dir%d edge%d #%d" % (edgeDir, edge, rep), "deblock_ctu_edge",
+                       ((y, cb, cr), ctu, edgeDir, edge, bs, qp, bypass, offs[0], offs[1], offs[2], offs[3], 1, chroma))

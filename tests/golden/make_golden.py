@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import numpy as np  # noqa: E402
 from backends import Ref  # noqa: E402
-from cases import gen_cases, coef_cases, loop_cases, umh_groups, me_scene, me_scene_yuv, lowres_scene, lookahead_scene, lookahead_scene3, digest  # noqa: E402
+from cases import gen_cases, coef_cases, loop_cases, deblock_cases, umh_groups, me_scene, me_scene_yuv, lowres_scene, lookahead_scene, lookahead_scene3, digest  # noqa: E402
 
 ME_CASES = [  # (method, subme, w, h, bx_off, by_off, merange, qmvp, mvc, qp)
     (1, 2, 16, 16, 16, 24, 57, (5, -7), [(12, 8), (-20, 4)], 28),
@@ -123,7 +123,9 @@ def coef_digests(backend_cls):
 def loop_digests(backend_cls, depth):
     """The in-loop filter primitives (deblocking edge filters, SAO offset application and statistics) over tests/cases.py loop_cases."""
     b = backend_cls(depth)
-    return {label: digest(getattr(b, fn)(*args)) for label, fn, args in loop_cases(depth)}
+    out = {label: digest(getattr(b, fn)(*args)) for label, fn, args in loop_cases(depth)}
+    out.update({label: digest(getattr(b, fn)(*args)) for label, fn, args in deblock_cases(depth)})      # the real Deblock::edgeFilterLuma / Chroma
+    return out
 
 
 def mc_cases(depth):

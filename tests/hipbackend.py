@@ -613,6 +613,42 @@ class Hip:
         return int(out[0]), c[0][:len(ctx)].copy()
 
     # ---- in-loop filter primitives (n = 1 batches; pos = (y, x) of the primitive's pointer)
+    def deblock_ctu_edge(self, planes, ctu, edgeDir, edge, bs, qp, bypass, betaDiv2, tcDiv2, cbOff, crOff, doLuma=1, doChroma=1):
+        """The same CTU edge through the batched entries: 16 luma units, 8 chroma units."""
+        d = [DevBuf(p) for p in planes]
+        S, SC = planes[0].shape[1], planes[1].shape[1]
+        keep = []
+
+        def run(units, chroma):
+            xy = dev_i32(np.array([u[0] for u in units], np.int32).reshape(-1))
+            dbs = DevBuf(np.array([u[1] for u in units], np.uint8))
+            dqp, dqq = DevBuf(np.array([u[2] for u in units], np.int8)), DevBuf(np.array([u[3] for u in units], np.int8))
+            dby = DevBuf(np.array([[u[4], u[5]] for u in units], np.uint8).reshape(-1)) if bypass is not None else None
+            keep.extend([xy, dbs, dqp, dqq, dby])
+            if chroma:
+                check(self.L.x265hip_deblock_chroma_batch(self.depth, d[1].ptr, d[2].ptr, SC, edgeDir, xy.ptr, dbs.ptr, dqp.ptr, dqq.ptr, dby.ptr if dby else None,
+                                                          tcDiv2, cbOff, crOff, len(units), None))
+            else:
+                check(self.L.x265hip_deblock_luma_batch(self.depth, d[0].ptr, S, edgeDir, xy.ptr, dbs.ptr, dqp.ptr, dqq.ptr, dby.ptr if dby else None,
+                                                        betaDiv2, tcDiv2, len(units), None))
+        byp = bypass if bypass is not None else np.zeros((16, 16), np.uint8)
+        if doLuma:
+            units = []
+            for idx in range(16):
+                (qx, qy), (px, py) = ((edge, idx), (edge - 1, idx)) if edgeDir == 0 else ((idx, edge), (idx, edge - 1))
+                units.append(((ctu[1] + qx * 4, ctu[0] + qy * 4), int(bs[qy, qx]), int(qp[py, px]), int(qp[qy, qx]), int(byp[py, px]), int(byp[qy, qx])))
+            run(units, False)
+        if doChroma:
+            units = []
+            for idx in range(8):
+                (qx, qy), (px, py) = ((edge, 2 * idx), (edge - 1, 2 * idx)) if edgeDir == 0 else ((2 * idx, edge), (2 * idx, edge - 1))
+                pos = (ctu[1] // 2 + (edge * 2 if edgeDir == 0 else idx * 4), ctu[0] // 2 + (idx * 4 if edgeDir == 0 else edge * 2))
+                units.append((pos, int(bs[qy, qx]), int(qp[py, px]), int(qp[qy, qx]), int(byp[py, px]), int(byp[qy, qx])))
+            run(units, True)
+        out = tuple(x.get() for x in d)
+        del keep
+        return out
+
     def pel_filter_luma_strong(self, plane, pos, edgeDir, tcP, tcQ):
         d = DevBuf(plane)
         S = plane.shape[1]

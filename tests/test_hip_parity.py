@@ -604,12 +604,13 @@ def test_loop_filter_primitives_match_oracle_and_golden(hipmod, depth):
     reference; then whole-picture launches — every vertical luma edge segment of a picture in one launch, band offset and statistics of
     every CTU in one launch — against per-call oracle results."""
     import json
-    from cases import loop_cases, digest
+    import itertools
+    from cases import loop_cases, deblock_cases, digest
     from x265_amd.hipprim import DevBuf, check, dev_i32, SaoJob, SaoStatsJob
     gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "primitives_golden.json")))["golden"][str(depth)]["loop"]
     o, g = Orc(depth), hipmod.Hip(depth)
     bad, total = [], 0
-    for label, fn, args in loop_cases(depth):
+    for label, fn, args in itertools.chain(loop_cases(depth), deblock_cases(depth)):
         want, got = getattr(o, fn)(*args), getattr(g, fn)(*args)
         hipmod._release()
         total += 1
@@ -629,6 +630,25 @@ def test_loop_filter_primitives_match_oracle_and_golden(hipmod, depth):
     for i, (y, x) in enumerate(segs):
         want = o.pel_filter_luma_strong(want, (y, x), 0, int(tcP[i]), int(tcQ[i]))
     assert np.array_equal(d.get(), want)
+    # the deblocking of a whole picture in two launches: every unit of every vertical edge of the 8-sample grid, then every horizontal one,
+    # with per-unit boundary strengths and QPs — against the per-unit restatement applied in the same order
+    from oracle import pyoracle as po
+    fl = o._lf("orc_deblock_luma_unit", [po.vp, po.ip, po.ip] + [po.i32] * 9)
+    blocky = (np.kron(np.cumsum(rng.integers(-6, 7, size=(H // 8, W // 8)), axis=1) + 120, np.ones((8, 8), np.int64)) << (depth - 8)).astype(g.pix)
+    blocky = np.clip(blocky.astype(np.int64) + rng.integers(-1, 2, size=blocky.shape), 0, (1 << depth) - 1).astype(g.pix)
+    d, want = DevBuf(blocky), blocky.copy()
+    for edgeDir in (0, 1):
+        units = [(x, y) for y in range(0, H, 4) for x in range(8, W, 8)] if edgeDir == 0 else [(x, y) for y in range(8, H, 8) for x in range(0, W, 4)]
+        bs = rng.integers(0, 3, size=len(units)).astype(np.uint8)
+        qpP, qpQ = rng.integers(18, 46, size=len(units)).astype(np.int8), rng.integers(18, 46, size=len(units)).astype(np.int8)
+        dxy, dbs, dp_, dq_ = dev_i32(np.array(units, np.int32).reshape(-1)), DevBuf(bs), DevBuf(qpP), DevBuf(qpQ)
+        check(L.x265hip_deblock_luma_batch(depth, d.ptr, W, edgeDir, dxy.ptr, dbs.ptr, dp_.ptr, dq_.ptr, None, 1, -1, len(units), None))
+        step, off = (W, 1) if edgeDir == 0 else (1, W)
+        for i, (x, y) in enumerate(units):
+            fl(o_ptr(want, y, x), step, off, int(bs[i]), int(qpP[i]), int(qpQ[i]), 0, 0, 0, 1, -1, depth)
+        got = d.get()
+        assert np.array_equal(got, want), (edgeDir, int((got != want).sum()))
+    assert not np.array_equal(want, blocky)
     # band offset and BO / E0 statistics of every 64x64 CTU (ragged right and bottom ones) in one launch each
     ctus = [(y, x, min(64, W - 1 - x), min(64, H - 1 - y)) for y in range(1, H - 1, 64) for x in range(1, W - 1, 64)]
     jobs = (SaoJob * len(ctus))()

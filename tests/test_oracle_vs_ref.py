@@ -54,10 +54,12 @@ def test_every_primitive_matches_reference(depth):
 def test_loop_filter_primitives_match_reference(depth):
     """pelFilterLumaStrong / pelFilterChroma, calSign, saoCuOrgE0..E3 / B0 and saoCuStatsBO / E0..E3 of the reference's C table vs the restatement."""
     _need_ref(depth)
-    from cases import loop_cases
+    from cases import loop_cases, deblock_cases
+    import itertools
     o, r = Orc(depth), Ref(depth)
     n = 0
-    for label, fn, args in loop_cases(depth):
+    # deblock_cases: the real Deblock::edgeFilterLuma / edgeFilterChroma on a one-CTU CUData vs the per-unit restatement
+    for label, fn, args in itertools.chain(loop_cases(depth), deblock_cases(depth)):
         assert same(getattr(o, fn)(*args), getattr(r, fn)(*args)), label
         n += 1
     assert n >= 380

@@ -61,6 +61,121 @@ __global__ __launch_bounds__(256) void sao_sign_kernel(int8_t* __restrict__ dst,
         dst[i] = (int8_t)sgn((int)a[i] - (int)b[i]);
 }
 
+// ---- Deblock::edgeFilterLuma / edgeFilterChroma (deblock.cpp:317-513): the whole per-unit decision (boundary strength and QPs in, beta / tc
+// from Table 8-12, the d / strong / side decisions from lines 0 and 3, then the strong or the normal filter) — one thread per line, four
+// threads per 4-line unit; every thread reads lines 0 and 3 of its unit for the decisions, so no exchange is needed.  All vertical edges
+// of a picture are independent of each other (8-sample grid, at most 3 samples modified either side), and so are all horizontal ones:
+// a frame is two launches.
+__device__ __forceinline__ int db_beta(int q) { return q < 16 ? 0 : (q < 29 ? q - 10 : 2 * q - 38); }
+__device__ __forceinline__ int db_tc(int q)
+{
+    // tc' of Table 8-12 for Q = 18 .. 53, two entries per byte would not fit 24: one byte each, packed in four 64-bit words + tail
+    const uint8_t tail[36] = { 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24 };
+    return q < 18 ? 0 : tail[q - 18];
+}
+__device__ __forceinline__ int db_chroma_qp(int qp)
+{
+    const uint8_t map[14] = { 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37 };           // Table 8-10, qPi 30..43
+    return qp < 30 ? qp : (qp > 43 ? qp - 6 : map[qp - 30]);
+}
+
+template <typename P>
+__global__ __launch_bounds__(256) void deblock_luma_kernel(P* __restrict__ plane, int64_t stride, int dir, const int32_t* __restrict__ xy,
+                                                           const uint8_t* __restrict__ bsA, const int8_t* __restrict__ qpPA, const int8_t* __restrict__ qpQA,
+                                                           const uint8_t* __restrict__ bypass, int betaOffsetDiv2, int tcOffsetDiv2, int n, int depth)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, j = t >> 2, line = t & 3;
+    if (j >= n)
+        return;
+    const int bs = bsA[j];
+    if (!bs)
+        return;
+    int maskP = -1, maskQ = -1;
+    if (bypass)
+    {
+        maskP = (int)bypass[2 * j] - 1;
+        maskQ = (int)bypass[2 * j + 1] - 1;
+        if (!(maskP | maskQ))
+            return;
+    }
+    const int64_t srcStep = dir == 0 ? stride : 1, offset = dir == 0 ? 1 : stride;
+    P* u = plane + (int64_t)xy[2 * j + 1] * stride + xy[2 * j];
+    const int qp = ((int)qpPA[j] + (int)qpQA[j] + 1) >> 1, shift = depth - 8, maxv = (1 << depth) - 1;
+    const int beta = db_beta(lf_clip3(0, 51, qp + 2 * betaOffsetDiv2)) << shift;
+    auto dP = [&](const P* s) { return abs((int)s[-offset * 3] - 2 * (int)s[-offset * 2] + (int)s[-offset]); };
+    auto dQ = [&](const P* s) { return abs((int)s[0] - 2 * (int)s[offset] + (int)s[offset * 2]); };
+    const P* l0 = u;
+    const P* l3 = u + srcStep * 3;
+    const int dp0 = dP(l0), dq0 = dQ(l0), dp3 = dP(l3), dq3 = dQ(l3);
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+    if (d0 + d3 >= beta)
+        return;
+    const int tc = db_tc(lf_clip3(0, 53, qp + 2 * (bs - 1) + 2 * tcOffsetDiv2)) << shift;
+    auto strong = [&](const P* s) {
+        return (abs((int)s[-offset * 4] - (int)s[-offset]) + abs((int)s[offset * 3] - (int)s[0]) < (beta >> 3)) &&
+               (abs((int)s[-offset] - (int)s[0]) < ((tc * 5 + 1) >> 1));
+    };
+    P* src = u + srcStep * line;
+    const int m4 = src[0], m3 = src[-offset], m5 = src[offset], m2 = src[-offset * 2], m6 = src[offset * 2], m1 = src[-offset * 3];
+    if (2 * d0 < (beta >> 2) && 2 * d3 < (beta >> 2) && strong(l0) && strong(l3))
+    {
+        const int m7 = src[offset * 3], m0 = src[-offset * 4], tcP = (2 * tc) & maskP, tcQ = (2 * tc) & maskQ;
+        // the decisions above read lines 0 and 3 of this unit, which their owner threads are about to modify: all four threads of a unit
+        // sit in one wave and have taken the same branches, so the reads are complete before any of these stores issues (program order
+        // within the wave); the compiler must not sink the loads below the stores of another lane, which it cannot (same instruction stream)
+        src[-offset * 3] = (P)(lf_clip3(-tcP, tcP, ((2 * m0 + 3 * m1 + m2 + m3 + m4 + 4) >> 3) - m1) + m1);
+        src[-offset * 2] = (P)(lf_clip3(-tcP, tcP, ((m1 + m2 + m3 + m4 + 2) >> 2) - m2) + m2);
+        src[-offset] = (P)(lf_clip3(-tcP, tcP, ((m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4) >> 3) - m3) + m3);
+        src[0] = (P)(lf_clip3(-tcQ, tcQ, ((m2 + 2 * m3 + 2 * m4 + 2 * m5 + m6 + 4) >> 3) - m4) + m4);
+        src[offset] = (P)(lf_clip3(-tcQ, tcQ, ((m3 + m4 + m5 + m6 + 2) >> 2) - m5) + m5);
+        src[offset * 2] = (P)(lf_clip3(-tcQ, tcQ, ((m3 + m4 + m5 + 3 * m6 + 2 * m7 + 4) >> 3) - m6) + m6);
+        return;
+    }
+    // pelFilterLuma (deblock.cpp:276-314)
+    const int side = (beta + (beta >> 1)) >> 3;
+    const int maskP1 = (dp0 + dp3 < side ? -1 : 0) & maskP, maskQ1 = (dq0 + dq3 < side ? -1 : 0) & maskQ;
+    int delta = (9 * (m4 - m3) - 3 * (m5 - m2) + 8) >> 4;
+    if (abs(delta) < tc * 10)
+    {
+        const int tc2 = tc >> 1;
+        delta = lf_clip3(-tc, tc, delta);
+        src[-offset] = clip_pix<P>(m3 + (delta & maskP), maxv);
+        src[0] = clip_pix<P>(m4 - (delta & maskQ), maxv);
+        if (maskP1)
+            src[-offset * 2] = clip_pix<P>(m2 + lf_clip3(-tc2, tc2, ((((m1 + m3 + 1) >> 1) - m2 + delta) >> 1)), maxv);
+        if (maskQ1)
+            src[offset] = clip_pix<P>(m5 + lf_clip3(-tc2, tc2, ((((m6 + m4 + 1) >> 1) - m5 - delta) >> 1)), maxv);
+    }
+}
+
+template <typename P>
+__global__ __launch_bounds__(256) void deblock_chroma_kernel(P* __restrict__ cb, P* __restrict__ cr, int64_t stride, int dir, const int32_t* __restrict__ xy,
+                                                             const uint8_t* __restrict__ bsA, const int8_t* __restrict__ qpPA,
+                                                             const int8_t* __restrict__ qpQA, const uint8_t* __restrict__ bypass, int tcOffsetDiv2,
+                                                             int cbQpOffset, int crQpOffset, int n, int depth)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, j = t >> 3, line = t & 3, c = (t >> 2) & 1;
+    if (j >= n || bsA[j] <= 1)
+        return;
+    int maskP = -1, maskQ = -1;
+    if (bypass)
+    {
+        maskP = bypass[2 * j] ? 0 : -1;
+        maskQ = bypass[2 * j + 1] ? 0 : -1;
+        if (!(maskP | maskQ))
+            return;
+    }
+    const int64_t srcStep = dir == 0 ? stride : 1, offset = dir == 0 ? 1 : stride;
+    P* src = (c ? cr : cb) + (int64_t)xy[2 * j + 1] * stride + xy[2 * j] + srcStep * line;
+    const int qpA = ((int)qpPA[j] + (int)qpQA[j] + 1) >> 1;
+    const int qp = db_chroma_qp(qpA + (c ? crQpOffset : cbQpOffset));
+    const int tc = db_tc(lf_clip3(0, 53, qp + 2 + 2 * tcOffsetDiv2)) << (depth - 8), maxv = (1 << depth) - 1;
+    const int m4 = src[0], m3 = src[-offset], m5 = src[offset], m2 = src[-offset * 2];
+    const int delta = lf_clip3(-tc, tc, (((m4 - m3) * 4) + m2 - m5 + 4) >> 3);
+    src[-offset] = clip_pix<P>(m3 + (delta & maskP), maxv);
+    src[0] = clip_pix<P>(m4 - (delta & maskQ), maxv);
+}
+
 // ---- SAO offset application: one workgroup per job
 enum { SAO_E0 = 0, SAO_E1 = 1, SAO_E1_2ROWS = 2, SAO_E2 = 3, SAO_E3 = 4, SAO_B0 = 5 };
 
@@ -317,5 +432,43 @@ extern "C" int x265hip_sao_stats_batch(int depth, int kind, const int16_t* diff,
         hipLaunchKernelGGL((sao_stats_kernel<uint16_t>), grid, block, 0, as_stream(stream), kind, diff, (const uint16_t*)plane, stride, aux, jobs, stats, count,
                            depth - 5);
     XH_LAUNCH_CHECK("sao_stats_kernel");
+    return X265HIP_OK;
+}
+
+extern "C" int x265hip_deblock_luma_batch(int depth, void* plane, int64_t stride, int dir, const int32_t* xy, const uint8_t* bs, const int8_t* qpP,
+                                          const int8_t* qpQ, const uint8_t* bypass, int betaOffsetDiv2, int tcOffsetDiv2, int n, void* stream)
+{
+    XH_CHECK_DEV();
+    if (!valid_depth(depth) || (dir != 0 && dir != 1) || n < 0 || betaOffsetDiv2 < -6 || betaOffsetDiv2 > 6 || tcOffsetDiv2 < -6 || tcOffsetDiv2 > 6)
+        return set_error(X265HIP_EINVAL, "deblock_luma: depth %d dir %d n %d offsets %d %d", depth, dir, n, betaOffsetDiv2, tcOffsetDiv2);
+    if (!n) return X265HIP_OK;
+    dim3 grid((4 * n + 255) / 256), block(256);
+    if (depth == 8)
+        hipLaunchKernelGGL((deblock_luma_kernel<uint8_t>), grid, block, 0, as_stream(stream), (uint8_t*)plane, stride, dir, xy, bs, qpP, qpQ, bypass,
+                           betaOffsetDiv2, tcOffsetDiv2, n, depth);
+    else
+        hipLaunchKernelGGL((deblock_luma_kernel<uint16_t>), grid, block, 0, as_stream(stream), (uint16_t*)plane, stride, dir, xy, bs, qpP, qpQ, bypass,
+                           betaOffsetDiv2, tcOffsetDiv2, n, depth);
+    XH_LAUNCH_CHECK("deblock_luma_kernel");
+    return X265HIP_OK;
+}
+
+extern "C" int x265hip_deblock_chroma_batch(int depth, void* cb, void* cr, int64_t strideC, int dir, const int32_t* xy, const uint8_t* bs,
+                                            const int8_t* qpP, const int8_t* qpQ, const uint8_t* bypass, int tcOffsetDiv2, int cbQpOffset, int crQpOffset,
+                                            int n, void* stream)
+{
+    XH_CHECK_DEV();
+    if (!valid_depth(depth) || (dir != 0 && dir != 1) || n < 0 || tcOffsetDiv2 < -6 || tcOffsetDiv2 > 6 || cbQpOffset < -12 || cbQpOffset > 12 ||
+        crQpOffset < -12 || crQpOffset > 12)
+        return set_error(X265HIP_EINVAL, "deblock_chroma: depth %d dir %d n %d offsets %d %d %d", depth, dir, n, tcOffsetDiv2, cbQpOffset, crQpOffset);
+    if (!n) return X265HIP_OK;
+    dim3 grid((8 * n + 255) / 256), block(256);
+    if (depth == 8)
+        hipLaunchKernelGGL((deblock_chroma_kernel<uint8_t>), grid, block, 0, as_stream(stream), (uint8_t*)cb, (uint8_t*)cr, strideC, dir, xy, bs, qpP, qpQ,
+                           bypass, tcOffsetDiv2, cbQpOffset, crQpOffset, n, depth);
+    else
+        hipLaunchKernelGGL((deblock_chroma_kernel<uint16_t>), grid, block, 0, as_stream(stream), (uint16_t*)cb, (uint16_t*)cr, strideC, dir, xy, bs, qpP, qpQ,
+                           bypass, tcOffsetDiv2, cbQpOffset, crQpOffset, n, depth);
+    XH_LAUNCH_CHECK("deblock_chroma_kernel");
     return X265HIP_OK;
 }

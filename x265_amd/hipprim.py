@@ -130,6 +130,8 @@ PROTOTYPES = {
     "x265hip_pel_filter_luma_strong_batch": (i32, [i32, vp, vp, i64, i64, vp, vp, i32, vp]),
     "x265hip_pel_filter_chroma_batch": (i32, [i32, vp, vp, i64, i64, vp, vp, vp, i32, vp]),
     "x265hip_sao_sign": (i32, [i32, vp, vp, vp, i32, vp]),
+    "x265hip_deblock_luma_batch": (i32, [i32, vp, i64, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "x265hip_deblock_chroma_batch": (i32, [i32, vp, vp, i64, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "x265hip_sao_apply_batch": (i32, [i32, i32, vp, i64, vp, vp, i32, vp]),
     "x265hip_sao_stats_batch": (i32, [i32, i32, vp, vp, i64, vp, vp, i32, vp, vp, vp]),
     "x265hip_call_pel_filter_luma_strong": (i32, [i32, vp, i64, i64, i32, i32]),
