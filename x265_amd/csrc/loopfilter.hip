@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void sao_sign_kernel(int8_t* __restrict__ dst,
 __device__ __forceinline__ int db_beta(int q) { return q < 16 ? 0 : (q < 29 ? q - 10 : 2 * q - 38); }
 __device__ __forceinline__ int db_tc(int q)
 {
-    // tc' of Table 8-12 for Q = 18 .. 53, two entries per byte would not fit 24: one byte each, packed in four 64-bit words + tail
+    // tc' of Table 8-12 for Q = 18 .. 53 (zero below)
     const uint8_t tail[36] = { 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24 };
     return q < 18 ? 0 : tail[q - 18];
 }
@@ -120,9 +120,8 @@ __global__ __launch_bounds__(256) void deblock_luma_kernel(P* __restrict__ plane
     if (2 * d0 < (beta >> 2) && 2 * d3 < (beta >> 2) && strong(l0) && strong(l3))
     {
         const int m7 = src[offset * 3], m0 = src[-offset * 4], tcP = (2 * tc) & maskP, tcQ = (2 * tc) & maskQ;
-        // the decisions above read lines 0 and 3 of this unit, which their owner threads are about to modify: all four threads of a unit
-        // sit in one wave and have taken the same branches, so the reads are complete before any of these stores issues (program order
-        // within the wave); the compiler must not sink the loads below the stores of another lane, which it cannot (same instruction stream)
+        // the decisions above read lines 0 and 3, which their owner threads now modify: the four threads of a unit sit in one wave and
+        // took the same branches, so every such load was issued before any of these stores (one instruction stream, in-order memory issue)
         src[-offset * 3] = (P)(lf_clip3(-tcP, tcP, ((2 * m0 + 3 * m1 + m2 + m3 + m4 + 4) >> 3) - m1) + m1);
         src[-offset * 2] = (P)(lf_clip3(-tcP, tcP, ((m1 + m2 + m3 + m4 + 2) >> 2) - m2) + m2);
         src[-offset] = (P)(lf_clip3(-tcP, tcP, ((m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4) >> 3) - m3) + m3);
