@@ -359,6 +359,23 @@ typedef struct x265hip_weight_param { int32_t inputWeight; int32_t inputOffset; 
 int x265hip_motion_compensation_batch(int depth, int w, int h, const x265hip_yuv* ref0, const x265hip_yuv* ref1, const x265hip_yuv* dst,
                                       const int32_t* pu_xy, const int32_t* mv0, const int32_t* mv1, int n,
                                       const x265hip_weight_param* wp0, const x265hip_weight_param* wp1, void* stream);
+/* ---- the lookahead's weighted-prediction analysis.
+ * LookaheadTLD::weightCostLuma (slicetype.cpp:807-840) for n candidate weights in one launch: fencPlane / refPlane are the lowres planes of
+ * the frame and of its reference (plane origins, same stride, padded as Lowres pads them), width x lines the lowres size, intraCost the
+ * frame's per-8x8 intra costs; costs[i] (device) = sum over blocks of min(satd8x8(weighted reference, frame), intraCost).  wp: host array;
+ * an entry with wtPresent == 0 measures the unweighted reference. */
+int x265hip_lookahead_weight_cost_batch(int depth, const void* fencPlane, const void* refPlane, int64_t stride, int width, int lines,
+                                        const int32_t* intraCost, const x265hip_weight_param* wp, int n, uint32_t* costs, void* stream);
+/* LookaheadTLD::weightsAnalyse (slicetype.cpp:860-960): the scale / offset guess from the frames' statistics (wp_ssd[0], wp_sum[0] of the
+ * two Lowres), its two cost evaluations, the 0.2 % test, and the weighting of the reference's four lowres planes.  refBuffers /
+ * weightedBuffers: four padded buffers of planeElems elements each, one after the other (Lowres::buffer[0..3], LookaheadTLD::wbuffer);
+ * padOffset = plane origin inside a buffer (Lowres::lowresPlane[0] - buffer[0]).  Blocks until done: *isWeighted and *chosen (host) are
+ * ReferencePlanes::isWeighted and the weight the reference keeps only inside the weighted planes. */
+int x265hip_lookahead_weights_analyse(int depth, const void* fencPlane, const void* refBuffers, int64_t planeElems, int64_t stride, int64_t padOffset,
+                                      int paddedLines, int width, int lines, const int32_t* intraCost, uint64_t fencSsd, uint64_t fencSum,
+                                      uint64_t refSsd, uint64_t refSum, void* weightedBuffers, x265hip_weight_param* chosen, int* isWeighted,
+                                      void* stream);
+
 int x265hip_framepass_run_yuv(x265hip_framepass* fp, const x265hip_yuv* src, const x265hip_yuv* ref, const x265hip_yuv* pred,
                               const x265hip_yuv* recon, int marginX, int marginY, void* stream);
 /* The B-frame variant: a second (future) reference of the same geometry.  Both lists are searched at every level (list 1's vectors

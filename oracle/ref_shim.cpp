@@ -750,4 +750,69 @@ void ref_deblock_ctu_edge(pixel* y, pixel* cb, pixel* cr, intptr_t stride, intpt
     enc.m_picCTU = NULL;
 }
 
+/* ---- the real LookaheadTLD::weightsAnalyse (encoder/slicetype.cpp:860-960; weightCostLuma :807-840) on real Lowres objects: pic0 is the
+ * reference (frame 0), pic1 the frame being weighted against it (frame 1); wp_ssd / wp_sum as AQ would have left them.  Outputs: the four
+ * weighted lowres buffers (planes: 4 x planesize elements, only written when the function decides to weight) and weightedCostDelta.
+ * Returns weightedRef[1].isWeighted, or -1. */
+int ref_weights_analyse(pixel* pic0, pixel* pic1, intptr_t stride, int w, int h, int marginX, int marginY, uint64_t fencSsd, uint64_t fencSum,
+                        uint64_t refSsd, uint64_t refSum, pixel* planes, int64_t planesCap, double* costDelta)
+{
+    T();
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = w;
+    param->sourceHeight = h;
+    param->rc.aqMode = 0;
+    param->rc.hevcAq = 0;
+    param->bAQMotion = 0;
+    param->bEnableHME = 0;
+    param->lookaheadSlices = 0;
+    PicYuv pics[2];
+    Lowres lr[2];
+    pixel* org[2] = { pic0, pic1 };
+    int ret = -1;
+    bool ok = true;
+    for (int i = 0; i < 2; i++)
+    {
+        pics[i].m_picWidth = w;
+        pics[i].m_picHeight = h;
+        pics[i].m_lumaMarginX = marginX;
+        pics[i].m_lumaMarginY = marginY;
+        pics[i].m_stride = stride;
+        pics[i].m_picOrg[0] = org[i];
+        pics[i].m_param = param;
+        memset((void*)&lr[i], 0, sizeof(Lowres));
+        ok = ok && lr[i].create(param, &pics[i], param->rc.qgSize);
+    }
+    if (ok)
+    {
+        lr[0].init(&pics[0], 0);
+        lr[1].init(&pics[1], 1);
+        Lookahead la(param, NULL);
+        la.create();
+        LookaheadTLD& tld = la.m_tld[0];
+        tld.lowresIntraEstimate(lr[1], param->rc.qgSize);
+        lr[1].wp_ssd[0] = fencSsd; lr[1].wp_sum[0] = fencSum;
+        lr[0].wp_ssd[0] = refSsd; lr[0].wp_sum[0] = refSum;
+        lr[1].weightedRef[1].isWeighted = false;
+        lr[1].weightedCostDelta[1] = -1.0;
+        tld.weightsAnalyse(lr[1], lr[0]);
+        ret = lr[1].weightedRef[1].isWeighted ? 1 : 0;
+        *costDelta = lr[1].weightedCostDelta[1];
+        const intptr_t planesize = lr[1].buffer[1] - lr[1].buffer[0];
+        if (ret == 1 && 4 * planesize <= planesCap)
+            for (int i = 0; i < 4; i++)
+                memcpy(planes + i * planesize, tld.wbuffer[i], planesize * sizeof(pixel));
+        la.destroy();
+    }
+    for (int i = 0; i < 2; i++)
+    {
+        lr[i].destroy();
+        pics[i].m_picOrg[0] = NULL;
+        pics[i].m_param = NULL;
+    }
+    x265_param_free(param);
+    return ret;
+}
+
 } // extern "C"

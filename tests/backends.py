@@ -341,6 +341,25 @@ class Orc(_Base):
         est = self._f("orc_lowres_intra_estimate")(ptr(plane, *origin), plane.shape[1], wcu, hcu, self.depth, ptr(cost), ptr(mode), ptr(rows))
         return est, cost, mode, rows
 
+    def weights_analyse(self, src0, src1, origin, w, h, mx, my, fencSsd, fencSum, refSsd, refSum):
+        """LookaheadTLD::weightsAnalyse for frame 1 (src1) against frame 0 (src0).  Returns (isWeighted, [4 weighted padded lowres planes]);
+        the chosen (scale, denominator, offset) are left in self.last_weights."""
+        import ctypes as C
+        _, _, _, _, pl0, (stride, lw, lh) = self.lowres_pass(src0, origin, w, h, mx, my)
+        _, icost, _, _, pl1, _ = self.lowres_pass(src1, origin, w, h, mx, my)
+        out = [np.zeros_like(p) for p in pl0]
+        chosen = np.zeros(3, np.int32)
+        fn = self._f("orc_weights_analyse")
+        fn.restype = po.i32
+        fn.argtypes = [po.vp, po.vp, po.vp, po.ip, po.ip, po.i32, po.i32, po.i32, po.vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, po.vp, po.i32]
+        rb = (C.c_void_p * 4)(*[ptr(p).value for p in pl0])
+        ob = (C.c_void_p * 4)(*[ptr(p).value for p in out])
+        isw = fn(ptr(pl1[0], my, mx), rb, ob, stride, my * stride + mx, lh + 2 * my, lw, lh, ptr(icost), fencSsd, fencSum, refSsd, refSum, ptr(chosen), self.depth)
+        self.last_weights = tuple(int(v) for v in chosen)
+        for p in out:
+            p[:, lw + 2 * mx:] = 0                      # the stride-alignment tail of a row is not part of the padded plane
+        return int(isw), out
+
     def lookahead_cost_p(self, src0, src1, origin, w, h, mx, my, rows_per_slice, num_slices):
         """Lowres::init of both pictures, intra estimate of the second, then the P-frame cost pass (frame 1 referencing frame 0).
         Returns (costEst, mvs[ncu,2], mvCosts, lowresCosts, rowSatds, intraMbs, intraCost)."""
@@ -860,6 +879,22 @@ class Ref(_Base):
         assert est >= 0 and (int(geom[0]), int(geom[1]), int(geom[2]), int(geom[3])) == (stride, lw, lh, planesize), geom
         pl = [planes[i * planesize:(i + 1) * planesize].reshape(lh + 2 * my, stride) for i in range(4)]
         return est, cost, mode, rows, pl, (stride, lw, lh)
+
+    def weights_analyse(self, src0, src1, origin, w, h, mx, my, fencSsd, fencSum, refSsd, refSum):
+        lw, lh = ((w // 2 + 7) // 8) * 8, ((h // 2 + 7) // 8) * 8
+        stride = lw + 2 * mx
+        stride += (32 - stride % 32) % 32
+        planesize = stride * (lh + 2 * my)
+        planes = np.zeros(4 * planesize, self.pix)
+        delta = np.zeros(1, np.float64)
+        isw = self.L.ref_weights_analyse(ptr(src0, *origin), ptr(src1, *origin), src0.shape[1], w, h, mx, my, fencSsd, fencSum, refSsd, refSum,
+                                         ptr(planes), planes.size, ptr(delta))
+        assert isw >= 0
+        self.last_cost_delta = float(delta[0])
+        out = [planes[i * planesize:(i + 1) * planesize].reshape(lh + 2 * my, stride).copy() for i in range(4)]
+        for p in out:
+            p[:, lw + 2 * mx:] = 0
+        return int(isw), out
 
     def lookahead_cost_p(self, src0, src1, origin, w, h, mx, my, rows_per_slice, num_slices):
         lw, lh = ((w // 2 + 7) // 8) * 8, ((h // 2 + 7) // 8) * 8

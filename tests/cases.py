@@ -494,3 +494,23 @@ def deblock_cases(depth, seed=55):
                 chroma = 1 if edge % 4 == 0 else 0                 # chroma edges sit on the 8-sample chroma grid
                 yield ("deblock dir%d edge%d #%d" % (edgeDir, edge, rep), "deblock_ctu_edge",
                        ((y, cb, cr), ctu, edgeDir, edge, bs, qp, bypass, offs[0], offs[1], offs[2], offs[3], 1, chroma))
+
+
+def weight_scenes(depth, seed=300):
+    """Pairs of pictures for the lookahead's weighted-prediction analysis: the second is the first faded (gain / offset) and moved a little,
+    plus pairs that should NOT be weighted (same brightness).  Yields (label, src0, src1, margin, H, W, (fencSsd, fencSum, refSsd, refSum))."""
+    for k, (gain, off, H, W) in enumerate(((0.8, 6, 136, 200), (1.25, -10, 136, 200), (1.0, 0, 136, 200), (0.6, 30, 144, 176), (1.0, 12, 66, 50),
+                                           (0.3, 90, 200, 320), (1.9, -60, 136, 200), (1.02, 0, 136, 200))):
+        s0, s1, m = lookahead_scene(depth, seed + 10 * depth + k, H, W)
+        sc = 1 << (depth - 8)
+        pmax = (1 << depth) - 1
+        f = np.clip(np.rint(s1.astype(np.float64) * gain + off * sc), 0, pmax).astype(s1.dtype)
+        stats = []
+        for pic in (f, s0):
+            core = pic[m:m + H, m:m + W].astype(np.int64)
+            n = core.size
+            sm, sq = int(core.sum()), int((core * core).sum())
+            stats += [(sq - (sm * sm + n // 2) // n) // 4, sm // 4]
+        # the statistics are inputs of the analysis (AQ leaves them in the Lowres); weightsAnalyse divides the sum by the LOWRES area
+        # (slicetype.cpp:892), so sums of that scale are what lets the test reach its weighting branch
+        yield ("fade gain %.2f off %d %dx%d" % (gain, off, W, H), s0, f, m, H, W, tuple(stats))

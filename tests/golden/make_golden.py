@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import numpy as np  # noqa: E402
 from backends import Ref  # noqa: E402
-from cases import gen_cases, coef_cases, loop_cases, deblock_cases, umh_groups, me_scene, me_scene_yuv, lowres_scene, lookahead_scene, lookahead_scene3, digest  # noqa: E402
+from cases import gen_cases, coef_cases, loop_cases, deblock_cases, weight_scenes, umh_groups, me_scene, me_scene_yuv, lowres_scene, lookahead_scene, lookahead_scene3, digest  # noqa: E402
 
 ME_CASES = [  # (method, subme, w, h, bx_off, by_off, merange, qmvp, mvc, qp)
     (1, 2, 16, 16, 16, 24, 57, (5, -7), [(12, 8), (-20, 4)], 28),
@@ -125,6 +125,16 @@ def loop_digests(backend_cls, depth):
     b = backend_cls(depth)
     out = {label: digest(getattr(b, fn)(*args)) for label, fn, args in loop_cases(depth)}
     out.update({label: digest(getattr(b, fn)(*args)) for label, fn, args in deblock_cases(depth)})      # the real Deblock::edgeFilterLuma / Chroma
+    return out
+
+
+def weightp_results(backend_cls, depth):
+    """LookaheadTLD::weightsAnalyse per scene of tests/cases.py weight_scenes: (isWeighted, the four weighted lowres planes)."""
+    b = backend_cls(depth)
+    out = {}
+    for label, s0, s1, m, H, W, st in weight_scenes(depth):
+        isw, planes = b.weights_analyse(s0, s1, (m, m), W, H, m, m, *st)
+        out["weightp " + label] = (isw, planes[0], planes[1], planes[2], planes[3])
     return out
 
 
@@ -255,7 +265,8 @@ if __name__ == "__main__":
         gold[str(depth)] = {"prims": prim_digests(Ref, depth), "me": me_digests(Ref, depth), "umh": umh_results(Ref, depth), "chroma_me": chroma_me_results(Ref, depth),
                             "bipred": {k: digest(v) for k, v in bipred_results(Ref, depth).items()},
                             "mc": {k: digest(v) for k, v in mc_results(Ref, depth).items()},
-                            "loop": loop_digests(Ref, depth), "lowres": lowres_digests(Ref, depth), "lookahead": lookahead_digests(Ref, depth),
+                            "loop": loop_digests(Ref, depth),
+                            "weightp": {k: digest(v) for k, v in weightp_results(Ref, depth).items()}, "lowres": lowres_digests(Ref, depth), "lookahead": lookahead_digests(Ref, depth),
                             "lookahead_b": {k: digest(v) for k, v in lookahead_b_results(Ref, depth).items()},
                             "mvcost": {str(qp): digest(Ref(depth).mvcost_table(qp)) for qp in (12, 28, 37, 51)}}
     # the CABAC cost table is data of the reference: dump it for the tests and for the GPU box, where /root/reference does not exist

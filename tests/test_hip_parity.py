@@ -773,6 +773,45 @@ def test_motion_compensation_matches_oracle_and_golden(hipmod, depth):
 
 
 @pytest.mark.parametrize("depth", [8, 10, 12])
+def test_weightp_analysis_matches_oracle_and_golden(hipmod, depth):
+    """The lookahead's weighted-prediction analysis on the device (lowres planes, intra costs, the two weightCostLuma evaluations, the
+    decision, the weighted planes) vs the restatement and (8 / 10 bit) the committed results of the real weightsAnalyse; then a batch of
+    candidate weights in one launch against per-candidate oracle costs."""
+    import json
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    from cases import weight_scenes, digest
+    from x265_amd.hipprim import DevBuf, check, WeightParam
+    want = make_golden.weightp_results(Orc, depth)
+    got = make_golden.weightp_results(hipmod.Hip, depth)
+    hipmod._release()
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "primitives_golden.json")))["golden"].get(str(depth), {}).get("weightp")
+    for k in want:
+        assert same(want[k], got[k]), k
+        if gold:
+            assert digest(got[k]) == gold[k], k
+    assert sum(v[0] for v in want.values()) >= 3
+    o, g = Orc(depth), hipmod.Hip(depth)
+    label, s0, s1, m, H, W, st = next(iter(weight_scenes(depth)))
+    _, icost, _, _, pl1, (stride, lw, lh) = o.lowres_pass(s1, (m, m), W, H, m, m)
+    _, _, _, _, pl0, _ = o.lowres_pass(s0, (m, m), W, H, m, m)
+    rng = np.random.default_rng(3)
+    cands = [(int(rng.integers(1, 128)), int(rng.integers(-60, 61)), int(rng.integers(0, 8)), int(rng.integers(0, 2))) for _ in range(24)]
+    arr = (WeightParam * len(cands))(*[WeightParam(*c) for c in cands])
+    df, dr, di, dc = DevBuf(pl1[0]), DevBuf(pl0[0]), DevBuf(icost), DevBuf.zeros((len(cands),), np.uint32)
+    org = m * stride + m
+    check(g.L.x265hip_lookahead_weight_cost_batch(depth, df.at(org), dr.at(org), stride, lw, lh, di.ptr, arr, len(cands), dc.ptr, None))
+    costs = dc.get()
+    import ctypes as C
+    from oracle import pyoracle as po
+    fn = o._f("orc_weight_cost_luma")
+    fn.restype = C.c_uint32
+    fn.argtypes = [po.vp, po.vp, po.ip, po.i32, po.i32, po.vp, po.i32, po.i32, po.i32, po.i32, po.i32]
+    for i, (w_, o_, d_, p_) in enumerate(cands):
+        assert int(costs[i]) == fn(o_ptr(pl1[0], m, m), o_ptr(pl0[0], m, m), stride, lw, lh, o_ptr(icost, 0, 0), p_, w_, o_, d_, depth), (i, cands[i])
+
+
+@pytest.mark.parametrize("depth", [8, 10, 12])
 def test_lookahead_p_cost_matches_oracle(hipmod, depth):
     """The lookahead's P-frame cost pass (lowres init -> intra estimate -> estimateCUCost over the frame) on the GPU vs the
     restatement: every block's vector, cost, packed lowresCost, the row sums, the frame score and the intra count; serial and

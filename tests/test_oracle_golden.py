@@ -44,6 +44,12 @@ def test_oracle_loop_filter_primitives_match_golden(depth):
     assert len(want) >= 380 and got == want, [k for k in want if got.get(k) != want[k]][:8]
 
 
+@pytest.mark.parametrize("depth", [8, 10])
+def test_oracle_weightp_analysis_matches_golden(depth):
+    got = {k: digest(v) for k, v in make_golden.weightp_results(Orc, depth).items()}
+    assert len(got) == 8 and got == GOLD[str(depth)]["weightp"]
+
+
 def test_oracle_coefficient_scan_primitives_match_golden():
     got = make_golden.coef_digests(Orc)
     want = GOLD["coef"]

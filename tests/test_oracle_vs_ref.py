@@ -65,6 +65,20 @@ def test_loop_filter_primitives_match_reference(depth):
     assert n >= 380
 
 
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_weightp_analysis_matches_reference(depth):
+    """The real LookaheadTLD::weightsAnalyse (real Lowres objects, the lookahead's own weightCostLuma) vs the restatement: the decision and,
+    where it weights, the four weighted lowres planes; fades that must be weighted and pairs that must not."""
+    _need_ref(depth)
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    a, b = make_golden.weightp_results(Orc, depth), make_golden.weightp_results(Ref, depth)
+    assert sum(v[0] for v in b.values()) >= 4 and sum(1 - v[0] for v in b.values()) >= 2
+    for k in a:
+        assert same(a[k], b[k]), k
+
+
 def test_coefficient_scan_primitives_match_reference():
     """scanPosLast / findPosFirstLast / costCoeffNxN / costCoeffRemain / costC1C2Flag of the reference's C table and its scan-order tables vs the
     restatement, on inputs drawn like test/pixelharness.cpp draws them; and the committed CABAC cost table is the reference's."""
