@@ -246,9 +246,10 @@ struct CostProbeGroup : public CostEstimateGroup
 };
 }
 
-int64_t ref_lookahead_cost_p(pixel* pic0, pixel* pic1, intptr_t stride, int w, int h, int marginX, int marginY,
-                             int numRowsPerSlice, int numSlices,
-                             int32_t* mvs, int32_t* mvCosts, uint16_t* lowresCosts, int32_t* rowSatds, int32_t* intraMbs, int32_t* intraCost)
+static int64_t lookahead_cost_p_impl(pixel* pic0, pixel* pic1, intptr_t stride, int w, int h, int marginX, int marginY,
+                                     int numRowsPerSlice, int numSlices,
+                                     int32_t* mvs, int32_t* mvCosts, uint16_t* lowresCosts, int32_t* rowSatds, int32_t* intraMbs, int32_t* intraCost,
+                                     const uint64_t* wpStats, int* isWeighted)
 {
     T();
     x265_param* param = x265_param_alloc();
@@ -259,7 +260,7 @@ int64_t ref_lookahead_cost_p(pixel* pic0, pixel* pic1, intptr_t stride, int w, i
     param->rc.hevcAq = 0;
     param->bAQMotion = 0;
     param->bEnableHME = 0;
-    param->bEnableWeightedPred = 0;
+    param->bEnableWeightedPred = wpStats ? 1 : 0;      /* estimateFrameCost then runs weightsAnalyse and searches list 0 on the weighted planes (:3136-3138, :3222) */
     param->bEnableWeightedBiPred = 0;
     param->lookaheadSlices = 0;
     PicYuv pics[2];
@@ -287,6 +288,11 @@ int64_t ref_lookahead_cost_p(pixel* pic0, pixel* pic1, intptr_t stride, int w, i
         la.create();
         LookaheadTLD& tld = la.m_tld[0];
         tld.lowresIntraEstimate(lr[1], param->rc.qgSize);
+        if (wpStats)
+        {
+            lr[1].wp_ssd[0] = wpStats[0]; lr[1].wp_sum[0] = wpStats[1];
+            lr[0].wp_ssd[0] = wpStats[2]; lr[0].wp_sum[0] = wpStats[3];
+        }
         Lowres* frames[2] = { &lr[0], &lr[1] };
         CostProbeGroup g(la, frames);
         Lowres* fenc = frames[1];
@@ -330,6 +336,7 @@ int64_t ref_lookahead_cost_p(pixel* pic0, pixel* pic1, intptr_t stride, int w, i
         memcpy(rowSatds, fenc->rowSatds[1][0], H * sizeof(int32_t));
         memcpy(intraCost, fenc->intraCost, ncu * sizeof(int32_t));
         *intraMbs = fenc->intraMbs[1];
+        if (isWeighted) *isWeighted = fenc->weightedRef[1].isWeighted ? 1 : 0;
         la.destroy();
     }
     for (int i = 0; i < 2; i++)
@@ -340,6 +347,23 @@ int64_t ref_lookahead_cost_p(pixel* pic0, pixel* pic1, intptr_t stride, int w, i
     }
     x265_param_free(param);
     return ret;
+}
+
+int64_t ref_lookahead_cost_p(pixel* pic0, pixel* pic1, intptr_t stride, int w, int h, int marginX, int marginY,
+                             int numRowsPerSlice, int numSlices,
+                             int32_t* mvs, int32_t* mvCosts, uint16_t* lowresCosts, int32_t* rowSatds, int32_t* intraMbs, int32_t* intraCost)
+{
+    return lookahead_cost_p_impl(pic0, pic1, stride, w, h, marginX, marginY, numRowsPerSlice, numSlices, mvs, mvCosts, lowresCosts, rowSatds, intraMbs,
+                                 intraCost, NULL, NULL);
+}
+
+/* the same with --weightp on (serial path only): wpStats = { fenc wp_ssd, fenc wp_sum, ref wp_ssd, ref wp_sum } */
+int64_t ref_lookahead_cost_p_weightp(pixel* pic0, pixel* pic1, intptr_t stride, int w, int h, int marginX, int marginY, const uint64_t* wpStats,
+                                     int32_t* mvs, int32_t* mvCosts, uint16_t* lowresCosts, int32_t* rowSatds, int32_t* intraMbs, int32_t* intraCost,
+                                     int* isWeighted)
+{
+    return lookahead_cost_p_impl(pic0, pic1, stride, w, h, marginX, marginY, 1 << 20, 1, mvs, mvCosts, lowresCosts, rowSatds, intraMbs, intraCost, wpStats,
+                                 isWeighted);
 }
 
 /* ---- the real MotionEstimate::motionEstimate with the chroma SATD term of subpelCompare (encoder/motion.cpp:1601-1660), the

@@ -341,6 +341,25 @@ class Orc(_Base):
         est = self._f("orc_lowres_intra_estimate")(ptr(plane, *origin), plane.shape[1], wcu, hcu, self.depth, ptr(cost), ptr(mode), ptr(rows))
         return est, cost, mode, rows
 
+    def lookahead_cost_p_weightp(self, src0, src1, origin, w, h, mx, my, stats):
+        """The P-frame cost pass with --weightp: weightsAnalyse, then the pass against the weighted planes when it decided to weight.
+        Returns lookahead_cost_p's tuple + (isWeighted,)."""
+        import ctypes as C
+        isw, wpl = self.weights_analyse(src0, src1, origin, w, h, mx, my, *stats)
+        _, _, _, _, pl0, (stride, lw, lh) = self.lowres_pass(src0, origin, w, h, mx, my)
+        _, icost, _, _, pl1, _ = self.lowres_pass(src1, origin, w, h, mx, my)
+        if isw:
+            pl0 = wpl
+        wcu, hcu = lw // 8, lh // 8
+        ncu = wcu * hcu
+        mvs, mvc = np.zeros((ncu, 2), np.int32), np.zeros(ncu, np.int32)
+        lc, rows, imb = np.zeros(ncu, np.uint16), np.zeros(hcu, np.int32), np.zeros(1, np.int32)
+        tab = po.mvcost_table(12 + 6 * (self.depth - 8), self.depth)
+        refs = (C.c_void_p * 4)(*[ptr(p, my, mx).value for p in pl0])
+        est = self._f("orc_lookahead_cost_p")(ptr(pl1[0], my, mx), refs, stride, wcu, hcu, hcu, 1, self.depth,
+                                              ptr(icost), po.vp(tab.ctypes.data + 2 * po.MVCOST_CENTRE), ptr(mvs), ptr(mvc), ptr(lc), ptr(rows), ptr(imb))
+        return int(est), mvs, mvc, lc, rows, int(imb[0]), icost, int(isw)
+
     def weights_analyse(self, src0, src1, origin, w, h, mx, my, fencSsd, fencSum, refSsd, refSum):
         """LookaheadTLD::weightsAnalyse for frame 1 (src1) against frame 0 (src0).  Returns (isWeighted, [4 weighted padded lowres planes]);
         the chosen (scale, denominator, offset) are left in self.last_weights."""
@@ -879,6 +898,18 @@ class Ref(_Base):
         assert est >= 0 and (int(geom[0]), int(geom[1]), int(geom[2]), int(geom[3])) == (stride, lw, lh, planesize), geom
         pl = [planes[i * planesize:(i + 1) * planesize].reshape(lh + 2 * my, stride) for i in range(4)]
         return est, cost, mode, rows, pl, (stride, lw, lh)
+
+    def lookahead_cost_p_weightp(self, src0, src1, origin, w, h, mx, my, stats):
+        lw, lh = ((w // 2 + 7) // 8) * 8, ((h // 2 + 7) // 8) * 8
+        wcu, hcu = lw // 8, lh // 8
+        ncu = wcu * hcu
+        mvs, mvc = np.zeros((ncu, 2), np.int32), np.zeros(ncu, np.int32)
+        lc, rows, imb = np.zeros(ncu, np.uint16), np.zeros(hcu, np.int32), np.zeros(1, np.int32)
+        icost, isw = np.zeros(ncu, np.int32), np.zeros(1, np.int32)
+        st = np.array(stats, np.uint64)
+        est = self.L.ref_lookahead_cost_p_weightp(ptr(src0, *origin), ptr(src1, *origin), src0.shape[1], w, h, mx, my, ptr(st), ptr(mvs), ptr(mvc), ptr(lc),
+                                                  ptr(rows), ptr(imb), ptr(icost), ptr(isw))
+        return int(est), mvs, mvc, lc, rows, int(imb[0]), icost, int(isw[0])
 
     def weights_analyse(self, src0, src1, origin, w, h, mx, my, fencSsd, fencSum, refSsd, refSum):
         lw, lh = ((w // 2 + 7) // 8) * 8, ((h // 2 + 7) // 8) * 8

@@ -138,6 +138,13 @@ def weightp_results(backend_cls, depth):
     return out
 
 
+def lookahead_weightp_results(backend_cls, depth):
+    """The P-frame cost pass with --weightp (weightsAnalyse, then list 0 searched on the weighted planes) per weight scene:
+    lookahead_cost_p's tuple + isWeighted."""
+    b = backend_cls(depth)
+    return {"lookahead weightp " + label: b.lookahead_cost_p_weightp(s0, s1, (m, m), W, H, m, m, st) for label, s0, s1, m, H, W, st in weight_scenes(depth)}
+
+
 def mc_cases(depth):
     """Predict::motionCompensation cases: (label, w, h, bx, by, mv0, mv1 or None, wp0, wp1, sliceP, uniList); every branch of
     predict.cpp:77-266 — P / B-uni from either list / bi, each with weighted prediction off, on-but-absent for the reference, and
@@ -266,7 +273,8 @@ if __name__ == "__main__":
                             "bipred": {k: digest(v) for k, v in bipred_results(Ref, depth).items()},
                             "mc": {k: digest(v) for k, v in mc_results(Ref, depth).items()},
                             "loop": loop_digests(Ref, depth),
-                            "weightp": {k: digest(v) for k, v in weightp_results(Ref, depth).items()}, "lowres": lowres_digests(Ref, depth), "lookahead": lookahead_digests(Ref, depth),
+                            "weightp": {k: digest(v) for k, v in weightp_results(Ref, depth).items()},
+                            "lookahead_weightp": {k: digest(v) for k, v in lookahead_weightp_results(Ref, depth).items()}, "lowres": lowres_digests(Ref, depth), "lookahead": lookahead_digests(Ref, depth),
                             "lookahead_b": {k: digest(v) for k, v in lookahead_b_results(Ref, depth).items()},
                             "mvcost": {str(qp): digest(Ref(depth).mvcost_table(qp)) for qp in (12, 28, 37, 51)}}
     # the CABAC cost table is data of the reference: dump it for the tests and for the GPU box, where /root/reference does not exist

@@ -375,7 +375,7 @@ class Hip:
 
     _epoch = [0]
 
-    def lookahead_cost_p_batch(self, pairs, origin, w, h, mx, my, rows_per_slice, num_slices):
+    def lookahead_cost_p_batch(self, pairs, origin, w, h, mx, my, rows_per_slice, num_slices, wp_stats=None):
         """pairs: list of (src0, src1) padded pictures of one geometry; the whole chain on the device: Lowres::init of both,
         intra estimate of the second, P-frame cost pass of all pairs in ONE launch.  Returns a list of backends.Orc.lookahead_cost_p tuples."""
         lw, lh = ((w // 2 + 7) // 8) * 8, ((h // 2 + 7) // 8) * 8
@@ -406,9 +406,23 @@ class Hip:
             o = dict(mvs=DevBuf.zeros((ncu, 2), np.int32), mvc=DevBuf.zeros((ncu,), np.int32), lc=DevBuf.zeros((ncu,), np.uint16),
                      rows=DevBuf.zeros((hcu,), np.int32), sync=DevBuf.zeros((ncu,), np.uint64), icost=icost)
             d = descs[i]
-            d.fenc, d.ref, d.intraCost = planes[1].at(org), planes[0].at(org), icost.ptr
+            refplanes = planes[0]
+            if wp_stats is not None:
+                # --weightp: LookaheadTLD::weightsAnalyse first; list 0 then searches the weighted planes (slicetype.cpp:3136-3138, :3222)
+                from x265_amd.hipprim import WeightParam
+                wbuf = DevBuf.zeros((4, lh + 2 * my, stride), self.pix)
+                chosen, isw = WeightParam(), C.c_int(0)
+                check(self.L.x265hip_lookahead_weights_analyse(self.depth, planes[1].at(org), planes[0].ptr, pe, stride, org, lh + 2 * my, lw, lh, icost.ptr,
+                                                               *wp_stats[i], wbuf.ptr, C.byref(chosen), C.byref(isw), None))
+                o_isw = int(isw.value)
+                if o_isw:
+                    refplanes = wbuf
+                keep.append(wbuf)
+            d.fenc, d.ref, d.intraCost = planes[1].at(org), refplanes.at(org), icost.ptr
             d.mvs, d.mvCosts, d.lowresCosts, d.rowSatds, d.sync = o["mvs"].ptr, o["mvc"].ptr, o["lc"].ptr, o["rows"].ptr, o["sync"].ptr
             keep += planes + [imode]
+            if wp_stats is not None:
+                o["isw"] = o_isw
             outs.append(o)
         ddesc = DevBuf(np.frombuffer(bytes(descs), np.uint8))
         est = DevBuf.zeros((n, 2), np.int32)
@@ -417,10 +431,15 @@ class Hip:
             check(self.L.x265hip_lookahead_cost_p_batch(self.depth, ddesc.ptr, n, stride, pe, wcu, hcu, rows_per_slice, num_slices,
                                                         self._mvcost[qp].at(MVCOST_HALF), self._epoch[0], est.ptr, None))
         e = est.get()
-        return [(int(e[i, 0]), o["mvs"].get(), o["mvc"].get(), o["lc"].get(), o["rows"].get(), int(e[i, 1]), o["icost"].get()) for i, o in enumerate(outs)]
+        return [(int(e[i, 0]), o["mvs"].get(), o["mvc"].get(), o["lc"].get(), o["rows"].get(), int(e[i, 1]), o["icost"].get()) + ((o["isw"],) if "isw" in o else ())
+                for i, o in enumerate(outs)]
 
     def lookahead_cost_p(self, src0, src1, origin, w, h, mx, my, rows_per_slice, num_slices):
         return self.lookahead_cost_p_batch([(src0, src1)], origin, w, h, mx, my, rows_per_slice, num_slices)[0]
+
+    def lookahead_cost_p_weightp(self, src0, src1, origin, w, h, mx, my, stats):
+        hcu = ((h // 2 + 7) // 8)
+        return self.lookahead_cost_p_batch([(src0, src1)], origin, w, h, mx, my, hcu, 1, wp_stats=[stats])[0]
 
     def motion_estimate_chroma_batch(self, ref, src, w, h, pu_xy, mvmin, mvmax, qmvp, mvc, merange, method, subme, qp):
         """ref / src = (Y, Cb, Cr) padded planes; the chroma origin is the plane origin (positions are absolute, even)."""

@@ -791,6 +791,15 @@ def test_weightp_analysis_matches_oracle_and_golden(hipmod, depth):
         if gold:
             assert digest(got[k]) == gold[k], k
     assert sum(v[0] for v in want.values()) >= 3
+    # the P-frame cost pass with --weightp, everything on the device: analysis, then the pass with the weighted planes as list 0
+    want = make_golden.lookahead_weightp_results(Orc, depth)
+    got = make_golden.lookahead_weightp_results(hipmod.Hip, depth)
+    hipmod._release()
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "primitives_golden.json")))["golden"].get(str(depth), {}).get("lookahead_weightp")
+    for k in want:
+        assert len(want[k]) == len(got[k]) and all(same(x, y) for x, y in zip(want[k], got[k])), k
+        if gold:
+            assert digest(got[k]) == gold[k], k
     o, g = Orc(depth), hipmod.Hip(depth)
     label, s0, s1, m, H, W, st = next(iter(weight_scenes(depth)))
     _, icost, _, _, pl1, (stride, lw, lh) = o.lowres_pass(s1, (m, m), W, H, m, m)

@@ -48,6 +48,8 @@ def test_oracle_loop_filter_primitives_match_golden(depth):
 def test_oracle_weightp_analysis_matches_golden(depth):
     got = {k: digest(v) for k, v in make_golden.weightp_results(Orc, depth).items()}
     assert len(got) == 8 and got == GOLD[str(depth)]["weightp"]
+    got = {k: digest(v) for k, v in make_golden.lookahead_weightp_results(Orc, depth).items()}
+    assert len(got) == 8 and got == GOLD[str(depth)]["lookahead_weightp"]
 
 
 def test_oracle_coefficient_scan_primitives_match_golden():

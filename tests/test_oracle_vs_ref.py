@@ -77,6 +77,11 @@ def test_weightp_analysis_matches_reference(depth):
     assert sum(v[0] for v in b.values()) >= 4 and sum(1 - v[0] for v in b.values()) >= 2
     for k in a:
         assert same(a[k], b[k]), k
+    # and the whole P-frame estimate with --weightp: the reference's estimateFrameCost (weightsAnalyse inside, list 0 on the weighted planes)
+    a, b = make_golden.lookahead_weightp_results(Orc, depth), make_golden.lookahead_weightp_results(Ref, depth)
+    for k in a:
+        assert all(same(x, y) for x, y in zip(a[k], b[k])) and len(a[k]) == len(b[k]), k
+    assert sum(v[-1] for v in b.values()) >= 4
 
 
 def test_coefficient_scan_primitives_match_reference():
