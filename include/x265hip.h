@@ -377,6 +377,18 @@ int x265hip_lookahead_weights_analyse(int depth, const void* fencPlane, const vo
                                       uint64_t refSsd, uint64_t refSum, void* weightedBuffers, x265hip_weight_param* chosen, int* isWeighted,
                                       void* stream);
 
+/* ---- adaptive quantisation of the lookahead: LookaheadTLD::calcAdaptiveQuantFrame (slicetype.cpp:444-700), 4:2:0, aqMode 0..3 (X265_AQ_NONE,
+ * VARIANCE, AUTO_VARIANCE, AUTO_VARIANCE_BIASED; no hevc-aq / HDR10 / user offsets / edge mode).
+ * x265hip_aq_block_energy: the device part — energy[i] (device) = acEnergyCu of the i-th qgSize x qgSize block in raster order
+ * (ceil(width / qgSize) per row; blocks past the edge read the picture's padding), sums[0..2] / [3..5] (device, ADDED to) the frame's
+ * pixel sums and squared sums per plane.  x265hip_lookahead_aq_frame: the whole function — energies on the device, the per-block offsets
+ * in double precision on the host side in the reference's order; outputs are host arrays sized like Lowres allocates them (blockCount
+ * entries; invQscaleFactor8x8 only for qgSize 8): qpAqOffset (= qpCuTreeOffset), invQscaleFactor, wpStats = { wp_sum[3], wp_ssd[3] }
+ * (final, as weightsAnalyse reads them; only meaningful with weightp).  Blocks until done. */
+int x265hip_aq_block_energy(int depth, const x265hip_yuv* pic, int width, int height, int qgSize, uint32_t* energy, uint64_t* sums, void* stream);
+int x265hip_lookahead_aq_frame(int depth, const x265hip_yuv* pic, int width, int height, int qgSize, int aqMode, double aqStrength, int weightp,
+                               double* qpAqOffset, int32_t* invQscaleFactor, int32_t* invQscaleFactor8x8, uint64_t* wpStats, int* blockCount,
+                               void* stream);
 int x265hip_framepass_run_yuv(x265hip_framepass* fp, const x265hip_yuv* src, const x265hip_yuv* ref, const x265hip_yuv* pred,
                               const x265hip_yuv* recon, int marginX, int marginY, void* stream);
 /* The B-frame variant: a second (future) reference of the same geometry.  Both lists are searched at every level (list 1's vectors

@@ -20,6 +20,7 @@
 #include "slicetype.h"
 #include "predict.h"
 #include "shortyuv.h"
+#include "frame.h"
 #include "framedata.h"
 #include "deblock.h"
 #include "constants.h"
@@ -834,6 +835,74 @@ int ref_weights_analyse(pixel* pic0, pixel* pic1, intptr_t stride, int w, int h,
         lr[i].destroy();
         pics[i].m_picOrg[0] = NULL;
         pics[i].m_param = NULL;
+    }
+    x265_param_free(param);
+    return ret;
+}
+
+/* ---- the real LookaheadTLD::calcAdaptiveQuantFrame (encoder/slicetype.cpp:444-700) on a Frame whose source picture is the caller's planes:
+ * per-block AQ offsets (aqMode 0..3; 4 needs the edge pictures and is not driven), invQscaleFactor, and the frame statistics weightsAnalyse
+ * reads (wp_sum / wp_ssd, all three planes).  Returns the number of AQ blocks, or -1. */
+int ref_aq_frame(pixel* y, pixel* cb, pixel* cr, intptr_t stride, intptr_t strideC, int w, int h, int marginX, int marginY, int qgSize, int aqMode,
+                 double aqStrength, int weightp, double* qpAqOffset, int32_t* invQscaleFactor, int32_t* invQscaleFactor8x8, uint64_t* wpStats)
+{
+    T();
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = w;
+    param->sourceHeight = h;
+    param->internalCsp = X265_CSP_I420;
+    param->rc.aqMode = aqMode;
+    param->rc.aqStrength = aqStrength;
+    param->rc.qgSize = qgSize;
+    param->rc.hevcAq = 0;
+    param->rc.cuTree = 0;
+    param->bAQMotion = 0;
+    param->bEnableHME = 0;
+    param->bEnableWeightedPred = weightp;
+    param->bEnableWeightedBiPred = 0;
+    param->bHDR10Opt = 0;
+    param->bDynamicRefine = 0;
+    param->bEnableFades = 0;
+    param->lookaheadSlices = 0;
+    int ret = -1;
+    {
+        PicYuv pic;
+        pic.m_picWidth = w; pic.m_picHeight = h;
+        pic.m_lumaMarginX = marginX; pic.m_lumaMarginY = marginY;
+        pic.m_chromaMarginX = marginX / 2; pic.m_chromaMarginY = marginY / 2;
+        pic.m_stride = stride; pic.m_strideC = strideC;
+        pic.m_picOrg[0] = y; pic.m_picOrg[1] = cb; pic.m_picOrg[2] = cr;
+        pic.m_picCsp = X265_CSP_I420;
+        pic.m_hChromaShift = pic.m_vChromaShift = 1;
+        pic.m_param = param;
+        Frame* frame = new Frame;
+        frame->m_param = param;
+        frame->m_fencPic = &pic;
+        if (frame->m_lowres.create(param, &pic, qgSize))
+        {
+            Lookahead la(param, NULL);
+            la.create();
+            LookaheadTLD& tld = la.m_tld[0];
+            tld.calcAdaptiveQuantFrame(frame, param);
+            Lowres& lr = frame->m_lowres;
+            const int blocks = qgSize == 8 ? lr.maxBlocksInRowFullRes * lr.maxBlocksInColFullRes : lr.maxBlocksInRow * lr.maxBlocksInCol;
+            ret = blocks;
+            if (lr.qpAqOffset)
+            {
+                memcpy(qpAqOffset, lr.qpAqOffset, blocks * sizeof(double));
+                memcpy(invQscaleFactor, lr.invQscaleFactor, blocks * sizeof(int));
+                if (qgSize == 8 && lr.invQscaleFactor8x8)
+                    memcpy(invQscaleFactor8x8, lr.invQscaleFactor8x8, lr.maxBlocksInRow * lr.maxBlocksInCol * sizeof(int));
+            }
+            for (int i = 0; i < 3; i++) { wpStats[i] = lr.wp_sum[i]; wpStats[3 + i] = lr.wp_ssd[i]; }
+            la.destroy();
+        }
+        frame->m_lowres.destroy();
+        frame->m_fencPic = NULL;
+        delete frame;
+        pic.m_picOrg[0] = pic.m_picOrg[1] = pic.m_picOrg[2] = NULL;
+        pic.m_param = NULL;
     }
     x265_param_free(param);
     return ret;

@@ -341,6 +341,20 @@ class Orc(_Base):
         est = self._f("orc_lowres_intra_estimate")(ptr(plane, *origin), plane.shape[1], wcu, hcu, self.depth, ptr(cost), ptr(mode), ptr(rows))
         return est, cost, mode, rows
 
+    def aq_frame(self, yuv, origin, w, h, qgSize, aqMode, aqStrength, weightp):
+        """LookaheadTLD::calcAdaptiveQuantFrame on a padded 4:2:0 picture yuv = (Y, Cb, Cr), luma origin (y, x) (chroma at half).
+        Returns (blockCount, qpAqOffset float64[], invQscaleFactor int32[], invQscaleFactor8x8 int32[], wpStats uint64[6])."""
+        import ctypes as C
+        lw, lh = ((w // 2 + 7) // 8) * 8, ((h // 2 + 7) // 8) * 8
+        nmax = (lw // 8) * (lh // 8) * 4
+        qp, inv, inv8, st = np.zeros(nmax, np.float64), np.zeros(nmax, np.int32), np.zeros(nmax, np.int32), np.zeros(6, np.uint64)
+        fn = self._f("orc_aq_frame")
+        fn.restype = po.i32
+        fn.argtypes = [po.vp, po.vp, po.vp, po.ip, po.ip, po.i32, po.i32, po.i32, po.i32, C.c_double, po.i32, po.vp, po.vp, po.vp, po.vp, po.i32]
+        n = fn(ptr(yuv[0], *origin), ptr(yuv[1], origin[0] // 2, origin[1] // 2), ptr(yuv[2], origin[0] // 2, origin[1] // 2), yuv[0].shape[1], yuv[1].shape[1],
+               w, h, qgSize, aqMode, aqStrength, weightp, ptr(qp), ptr(inv), ptr(inv8), ptr(st), self.depth)
+        return int(n), qp, inv, inv8, st
+
     def lookahead_cost_p_weightp(self, src0, src1, origin, w, h, mx, my, stats):
         """The P-frame cost pass with --weightp: weightsAnalyse, then the pass against the weighted planes when it decided to weight.
         Returns lookahead_cost_p's tuple + (isWeighted,)."""
@@ -898,6 +912,14 @@ class Ref(_Base):
         assert est >= 0 and (int(geom[0]), int(geom[1]), int(geom[2]), int(geom[3])) == (stride, lw, lh, planesize), geom
         pl = [planes[i * planesize:(i + 1) * planesize].reshape(lh + 2 * my, stride) for i in range(4)]
         return est, cost, mode, rows, pl, (stride, lw, lh)
+
+    def aq_frame(self, yuv, origin, w, h, qgSize, aqMode, aqStrength, weightp):
+        lw, lh = ((w // 2 + 7) // 8) * 8, ((h // 2 + 7) // 8) * 8
+        nmax = (lw // 8) * (lh // 8) * 4
+        qp, inv, inv8, st = np.zeros(nmax, np.float64), np.zeros(nmax, np.int32), np.zeros(nmax, np.int32), np.zeros(6, np.uint64)
+        n = self.L.ref_aq_frame(ptr(yuv[0], *origin), ptr(yuv[1], origin[0] // 2, origin[1] // 2), ptr(yuv[2], origin[0] // 2, origin[1] // 2), yuv[0].shape[1],
+                                yuv[1].shape[1], w, h, origin[1], origin[0], qgSize, aqMode, float(aqStrength), weightp, ptr(qp), ptr(inv), ptr(inv8), ptr(st))
+        return int(n), qp, inv, inv8, st
 
     def lookahead_cost_p_weightp(self, src0, src1, origin, w, h, mx, my, stats):
         lw, lh = ((w // 2 + 7) // 8) * 8, ((h // 2 + 7) // 8) * 8

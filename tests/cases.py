@@ -514,3 +514,17 @@ def weight_scenes(depth, seed=300):
         # the statistics are inputs of the analysis (AQ leaves them in the Lowres); weightsAnalyse divides the sum by the LOWRES area
         # (slicetype.cpp:892), so sums of that scale are what lets the test reach its weighting branch
         yield ("fade gain %.2f off %d %dx%d" % (gain, off, W, H), s0, f, m, H, W, tuple(stats))
+
+
+def aq_cases(depth):
+    """calcAdaptiveQuantFrame cases: (label, yuv planes, origin, w, h, qgSize, aqMode, aqStrength, weightp) over picture sizes with ragged
+    block edges, both quantisation-group sizes, the three AQ modes, strengths incl. 0, and the statistics-only path (AQ off, weightp on)."""
+    out = []
+    k = 0
+    for (w, h) in ((200, 136), (176, 144), (66, 50), (320, 200)):
+        (ry, rcb, rcr), (sy, scb, scr), m = me_scene_yuv(depth, 900 + depth + w, H=h, W=w, margin=80)
+        for (qg, mode, strength, wp) in ((16, 1, 1.0, 1), (16, 2, 1.0, 1), (16, 3, 0.8, 0), (8, 2, 1.0, 1), (8, 1, 1.5, 0), (8, 3, 0.6, 1), (16, 0, 0.0, 1),
+                                         (16, 2, 0.0, 1)):
+            out.append(("aq %dx%d qg%d mode%d s%.1f wp%d" % (w, h, qg, mode, strength, wp), (sy, scb, scr), (m, m), w, h, qg, mode, strength, wp))
+            k += 1
+    return out

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import numpy as np  # noqa: E402
 from backends import Ref  # noqa: E402
-from cases import gen_cases, coef_cases, loop_cases, deblock_cases, weight_scenes, umh_groups, me_scene, me_scene_yuv, lowres_scene, lookahead_scene, lookahead_scene3, digest  # noqa: E402
+from cases import gen_cases, coef_cases, loop_cases, deblock_cases, weight_scenes, aq_cases, umh_groups, me_scene, me_scene_yuv, lowres_scene, lookahead_scene, lookahead_scene3, digest  # noqa: E402
 
 ME_CASES = [  # (method, subme, w, h, bx_off, by_off, merange, qmvp, mvc, qp)
     (1, 2, 16, 16, 16, 24, 57, (5, -7), [(12, 8), (-20, 4)], 28),
@@ -145,6 +145,12 @@ def lookahead_weightp_results(backend_cls, depth):
     return {"lookahead weightp " + label: b.lookahead_cost_p_weightp(s0, s1, (m, m), W, H, m, m, st) for label, s0, s1, m, H, W, st in weight_scenes(depth)}
 
 
+def aq_results(backend_cls, depth):
+    """LookaheadTLD::calcAdaptiveQuantFrame per case of tests/cases.py aq_cases: (blockCount, qpAqOffset, invQscaleFactor, invQscaleFactor8x8, wpStats)."""
+    b = backend_cls(depth)
+    return {c[0]: b.aq_frame(*c[1:]) for c in aq_cases(depth)}
+
+
 def mc_cases(depth):
     """Predict::motionCompensation cases: (label, w, h, bx, by, mv0, mv1 or None, wp0, wp1, sliceP, uniList); every branch of
     predict.cpp:77-266 — P / B-uni from either list / bi, each with weighted prediction off, on-but-absent for the reference, and
@@ -274,6 +280,7 @@ if __name__ == "__main__":
                             "mc": {k: digest(v) for k, v in mc_results(Ref, depth).items()},
                             "loop": loop_digests(Ref, depth),
                             "weightp": {k: digest(v) for k, v in weightp_results(Ref, depth).items()},
+                            "aq": {k: digest(v) for k, v in aq_results(Ref, depth).items()},
                             "lookahead_weightp": {k: digest(v) for k, v in lookahead_weightp_results(Ref, depth).items()}, "lowres": lowres_digests(Ref, depth), "lookahead": lookahead_digests(Ref, depth),
                             "lookahead_b": {k: digest(v) for k, v in lookahead_b_results(Ref, depth).items()},
                             "mvcost": {str(qp): digest(Ref(depth).mvcost_table(qp)) for qp in (12, 28, 37, 51)}}

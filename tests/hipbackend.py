@@ -373,6 +373,23 @@ class Hip:
             p[:, lw + 2 * mx:] = 0
         return int(isw.value), res
 
+    def aq_frame(self, yuv, origin, w, h, qgSize, aqMode, aqStrength, weightp):
+        """x265hip_lookahead_aq_frame; same returns as backends.Orc.aq_frame."""
+        from x265_amd.framepass import YuvStruct
+        d = [DevBuf(p) for p in yuv]
+        S, SC = yuv[0].shape[1], yuv[1].shape[1]
+        isz = np.dtype(self.pix).itemsize
+        pic = YuvStruct(d[0].ptr + (origin[0] * S + origin[1]) * isz, d[1].ptr + ((origin[0] // 2) * SC + origin[1] // 2) * isz,
+                        d[2].ptr + ((origin[0] // 2) * SC + origin[1] // 2) * isz, S, SC)
+        lw, lh = ((w // 2 + 7) // 8) * 8, ((h // 2 + 7) // 8) * 8
+        nmax = (lw // 8) * (lh // 8) * 4
+        qp, inv, inv8, st = np.zeros(nmax, np.float64), np.zeros(nmax, np.int32), np.zeros(nmax, np.int32), np.zeros(6, np.uint64)
+        n = C.c_int(0)
+        vpp = lambda a: a.ctypes.data_as(C.c_void_p)      # noqa: E731
+        check(self.L.x265hip_lookahead_aq_frame(self.depth, C.byref(pic), w, h, qgSize, aqMode, float(aqStrength), weightp, vpp(qp), vpp(inv), vpp(inv8), vpp(st),
+                                                C.byref(n), None))
+        return int(n.value), qp, inv, inv8, st
+
     _epoch = [0]
 
     def lookahead_cost_p_batch(self, pairs, origin, w, h, mx, my, rows_per_slice, num_slices, wp_stats=None):

@@ -775,7 +775,8 @@ def test_motion_compensation_matches_oracle_and_golden(hipmod, depth):
 @pytest.mark.parametrize("depth", [8, 10, 12])
 def test_weightp_analysis_matches_oracle_and_golden(hipmod, depth):
     """The lookahead's weighted-prediction analysis on the device (lowres planes, intra costs, the two weightCostLuma evaluations, the
-    decision, the weighted planes) vs the restatement and (8 / 10 bit) the committed results of the real weightsAnalyse; then a batch of
+    decision, the weighted planes), the P-frame cost pass on the weighted planes and the adaptive-quantisation frame pass
+    (calcAdaptiveQuantFrame) vs the restatement and (8 / 10 bit) the committed results of the real weightsAnalyse; then a batch of
     candidate weights in one launch against per-candidate oracle costs."""
     import json
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
@@ -798,6 +799,15 @@ def test_weightp_analysis_matches_oracle_and_golden(hipmod, depth):
     gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "primitives_golden.json")))["golden"].get(str(depth), {}).get("lookahead_weightp")
     for k in want:
         assert len(want[k]) == len(got[k]) and all(same(x, y) for x, y in zip(want[k], got[k])), k
+        if gold:
+            assert digest(got[k]) == gold[k], k
+    # adaptive quantisation (energies on the device, the offsets in double precision on the host side of the library)
+    want = make_golden.aq_results(Orc, depth)
+    got = make_golden.aq_results(hipmod.Hip, depth)
+    hipmod._release()
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "primitives_golden.json")))["golden"].get(str(depth), {}).get("aq")
+    for k in want:
+        assert want[k][0] == got[k][0] and all(np.array_equal(x, y) for x, y in zip(want[k][1:], got[k][1:])), k
         if gold:
             assert digest(got[k]) == gold[k], k
     o, g = Orc(depth), hipmod.Hip(depth)

@@ -50,6 +50,8 @@ def test_oracle_weightp_analysis_matches_golden(depth):
     assert len(got) == 8 and got == GOLD[str(depth)]["weightp"]
     got = {k: digest(v) for k, v in make_golden.lookahead_weightp_results(Orc, depth).items()}
     assert len(got) == 8 and got == GOLD[str(depth)]["lookahead_weightp"]
+    got = {k: digest(v) for k, v in make_golden.aq_results(Orc, depth).items()}
+    assert len(got) == 32 and got == GOLD[str(depth)]["aq"]
 
 
 def test_oracle_coefficient_scan_primitives_match_golden():

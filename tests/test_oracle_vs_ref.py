@@ -82,6 +82,10 @@ def test_weightp_analysis_matches_reference(depth):
     for k in a:
         assert all(same(x, y) for x, y in zip(a[k], b[k])) and len(a[k]) == len(b[k]), k
     assert sum(v[-1] for v in b.values()) >= 4
+    # adaptive quantisation: the real calcAdaptiveQuantFrame (a Frame around the test planes) — doubles, ints and the frame statistics
+    a, b = make_golden.aq_results(Orc, depth), make_golden.aq_results(Ref, depth)
+    for k in a:
+        assert a[k][0] == b[k][0] and all(np.array_equal(x, y) for x, y in zip(a[k][1:], b[k][1:])), k
 
 
 def test_coefficient_scan_primitives_match_reference():

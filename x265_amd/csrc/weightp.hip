@@ -11,6 +11,7 @@
 // four lowres planes (x265hip_weight_pp over the padded buffers).
 #include "common.h"
 #include <cmath>
+#include <vector>
 
 namespace xh {
 
@@ -220,5 +221,176 @@ extern "C" int x265hip_lookahead_weights_analyse(int depth, const void* fencPlan
         if (e) return e;
     }
     *isWeighted = 1;
+    return X265HIP_OK;
+}
+
+// ---- adaptive quantisation of the lookahead: LookaheadTLD::calcAdaptiveQuantFrame (slicetype.cpp:444-700), 4:2:0, aqMode 0..3.
+// The device computes what is data-parallel — the AC energy of every qgSize block (acEnergyCu :256: luma block + the two half-size chroma
+// blocks, var = (sum, ssd), energy = ssd - (sum^2 >> shift) per plane, 32-bit wrap-around like the reference) and the frame sums the
+// weighted-prediction analysis reads; one wave per block.  The per-block offsets are a few double-precision expressions with a running
+// average between two passes: they run on the host side of the library in the reference's order (same libm), from the downloaded energies.
+namespace xh {
+
+template <typename P>
+__global__ __launch_bounds__(256) void aq_energy_kernel(const P* __restrict__ y, const P* __restrict__ cb, const P* __restrict__ cr, int64_t stride,
+                                                        int64_t strideC, int blocksX, int nblocks, int qg, uint32_t* __restrict__ energy,
+                                                        unsigned long long* __restrict__ sums)
+{
+    const int lane = threadIdx.x & 63, blk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (blk >= nblocks)
+        return;
+    const int by = (blk / blocksX) * qg, bx = (blk % blocksX) * qg;
+    uint32_t var = 0;
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+    {
+        const int n = p ? qg >> 1 : qg;                                  // block edge in this plane
+        const int shift = p ? (qg == 8 ? 4 : 6) : (qg == 8 ? 6 : 8);
+        const P* src = p == 0 ? y + (int64_t)by * stride + bx : (p == 1 ? cb : cr) + (int64_t)(by >> 1) * strideC + (bx >> 1);
+        const int64_t ss = p ? strideC : stride;
+        uint32_t sum = 0, ssd = 0;
+        for (int i = lane; i < n * n; i += 64)
+        {
+            const uint32_t v = src[(int64_t)(i / n) * ss + (i % n)];
+            sum += v;
+            ssd += v * v;
+        }
+        sum = (uint32_t)wave_sum((int)sum);
+        ssd = (uint32_t)wave_sum((int)ssd);
+        if (!lane)
+        {
+            atomicAdd(&sums[p], (unsigned long long)sum);
+            atomicAdd(&sums[3 + p], (unsigned long long)ssd);
+        }
+        var += ssd - (uint32_t)(((uint64_t)sum * sum) >> shift);
+    }
+    if (!lane)
+        energy[blk] = var;
+}
+
+static int aq_exp2fix8(double x)
+{
+    const int i = (int)(x * (-64.f / 6.f) + 512.5f);
+    if (i < 0) return 0;
+    if (i > 1023) return 0xffff;
+    const int lut = (int)(256.0 * (pow(2.0, (i & 63) / 64.0) - 1.0) + 0.5);       // x265_exp2_lut[i & 63] (constants.cpp)
+    return (lut + 256) << (i >> 6) >> 8;
+}
+
+} // namespace xh
+
+extern "C" int x265hip_aq_block_energy(int depth, const x265hip_yuv* pic, int width, int height, int qgSize, uint32_t* energy, uint64_t* sums, void* stream)
+{
+    XH_CHECK_DEV();
+    if (!valid_depth(depth) || !pic || width < 1 || height < 1 || (qgSize != 8 && qgSize != 16))
+        return set_error(X265HIP_EINVAL, "aq_block_energy: depth %d %dx%d qgSize %d", depth, width, height, qgSize);
+    const int bxs = (width + qgSize - 1) / qgSize, bys = (height + qgSize - 1) / qgSize, n = bxs * bys;
+    dim3 grid((n + 3) / 4), block(256);
+    if (depth == 8)
+        hipLaunchKernelGGL((aq_energy_kernel<uint8_t>), grid, block, 0, as_stream(stream), (const uint8_t*)pic->y, (const uint8_t*)pic->cb, (const uint8_t*)pic->cr,
+                           pic->strideY, pic->strideC, bxs, n, qgSize, energy, (unsigned long long*)sums);
+    else
+        hipLaunchKernelGGL((aq_energy_kernel<uint16_t>), grid, block, 0, as_stream(stream), (const uint16_t*)pic->y, (const uint16_t*)pic->cb,
+                           (const uint16_t*)pic->cr, pic->strideY, pic->strideC, bxs, n, qgSize, energy, (unsigned long long*)sums);
+    XH_LAUNCH_CHECK("aq_energy_kernel");
+    return X265HIP_OK;
+}
+
+extern "C" int x265hip_lookahead_aq_frame(int depth, const x265hip_yuv* pic, int width, int height, int qgSize, int aqMode, double aqStrength, int weightp,
+                                          double* qpAqOffset, int32_t* invQscaleFactor, int32_t* invQscaleFactor8x8, uint64_t* wpStats, int* blockCountOut,
+                                          void* stream)
+{
+    XH_CHECK_DEV();
+    if (!valid_depth(depth) || !pic || width < 16 || height < 16 || (qgSize != 8 && qgSize != 16) || aqMode < 0 || aqMode > 3 || !wpStats || !blockCountOut ||
+        (aqMode && (!qpAqOffset || !invQscaleFactor || (qgSize == 8 && !invQscaleFactor8x8))))
+        return set_error(X265HIP_EINVAL, "lookahead_aq_frame: depth %d %dx%d qgSize %d aqMode %d", depth, width, height, qgSize, aqMode);
+    hipStream_t st = as_stream(stream);
+    const int lw = ((width / 2 + 7) >> 3) << 3, lh = ((height / 2 + 7) >> 3) << 3, wcu = lw >> 3, hcu = lh >> 3;
+    const int incr = qgSize == 8 ? 8 : 16;
+    const int blockCount = qgSize == 8 ? (wcu * 2) * (hcu * 2) : wcu * hcu;
+    const int bxs = (width + incr - 1) / incr, bys = (height + incr - 1) / incr, n = bxs * bys;       // the blocks the reference's loops visit
+    *blockCountOut = blockCount;
+    if (n > blockCount)
+        return set_error(X265HIP_EINVAL, "lookahead_aq_frame: %d blocks visited, %d allocated by the reference", n, blockCount);
+    uint64_t sums[6] = { 0, 0, 0, 0, 0, 0 };
+    std::vector<uint32_t> energy((size_t)n);
+    const bool needEnergy = (aqMode != 0 && aqStrength != 0) || weightp;
+    if (needEnergy)
+    {
+        uint32_t* dE = nullptr;
+        uint64_t* dS = nullptr;
+        if (hipMalloc((void**)&dE, sizeof(uint32_t) * n + 64) != hipSuccess)
+            return set_error(X265HIP_ENOMEM, "lookahead_aq_frame: scratch");
+        dS = (uint64_t*)((char*)dE + (((size_t)sizeof(uint32_t) * n + 15) & ~(size_t)15));
+        int e = hipMemsetAsync(dS, 0, 48, st) == hipSuccess ? X265HIP_OK : X265HIP_EHIP;
+        if (!e) e = x265hip_aq_block_energy(depth, pic, width, height, qgSize, dE, dS, stream);
+        if (!e && (hipMemcpyAsync(energy.data(), dE, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                   hipMemcpyAsync(sums, dS, 48, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
+            e = set_error(X265HIP_EHIP, "lookahead_aq_frame: readback");
+        (void)hipFree(dE);
+        if (e) return e;
+    }
+    const float modeOneConst = qgSize == 8 ? 11.427f : 14.427f, modeTwoConst = qgSize == 8 ? 8.f : 11.f;
+    if (aqMode == 0 || aqStrength == 0)
+    {
+        if (aqMode && aqStrength == 0)
+            for (int i = 0; i < blockCount; i++) { qpAqOffset[i] = 0; invQscaleFactor[i] = 256; }
+        // with AQ off the energies are only computed for the statistics (:497-503); in mode VARIANCE each block is measured once (second
+        // loop), in the AUTO modes once (first loop): the sums above count every block exactly once in all three cases
+    }
+    else
+    {
+        // slicetype.cpp:514-632, double arithmetic in the reference's order
+        double avg_adj_pow2 = 0, avg_adj = 0, qp_adj = 0, bias_strength = 0.f, strength = 0.f;
+        if (aqMode == 2 || aqMode == 3)
+        {
+            const double bit_depth_correction = 1.f / (1 << (2 * (depth - 8)));
+            for (int i = 0; i < n; i++)
+            {
+                qp_adj = pow(energy[i] * bit_depth_correction + 1, 0.1);
+                qpAqOffset[i] = qp_adj;
+                avg_adj += qp_adj;
+                avg_adj_pow2 += qp_adj * qp_adj;
+            }
+            avg_adj /= blockCount;
+            avg_adj_pow2 /= blockCount;
+            strength = aqStrength * avg_adj;
+            avg_adj = avg_adj - 0.5f * (avg_adj_pow2 - modeTwoConst) / avg_adj;
+            bias_strength = aqStrength;
+        }
+        else
+            strength = aqStrength * 1.0397f;
+        for (int i = 0; i < n; i++)
+        {
+            if (aqMode == 3)
+            {
+                qp_adj = qpAqOffset[i];
+                qp_adj = strength * (qp_adj - avg_adj) + bias_strength * (1.f - modeTwoConst / (qp_adj * qp_adj));
+            }
+            else if (aqMode == 2)
+            {
+                qp_adj = qpAqOffset[i];
+                qp_adj = strength * (qp_adj - avg_adj);
+            }
+            else
+                qp_adj = strength * (log2((double)(energy[i] > 1 ? energy[i] : 1)) - (modeOneConst + 2 * (depth - 8)));
+            qpAqOffset[i] = qp_adj;
+            invQscaleFactor[i] = aq_exp2fix8(qp_adj);
+        }
+    }
+    if (qgSize == 8 && aqMode)
+        for (int cuY = 0; cuY < hcu; cuY++)
+            for (int cuX = 0; cuX < wcu; cuX++)
+                invQscaleFactor8x8[cuX + cuY * wcu] = (invQscaleFactor[cuX * 2 + cuY * wcu * 4] + invQscaleFactor[cuX * 2 + cuY * wcu * 4 + 1] +
+                                                       invQscaleFactor[cuX * 2 + cuY * wcu * 4 + wcu * 2] + invQscaleFactor[cuX * 2 + cuY * wcu * 4 + wcu * 2 + 1]) / 4;
+    if (weightp)
+    {
+        // :662-676
+        const int maxCol = ((width + 8) >> 4) << 4, maxRow = ((height + 8) >> 4) << 4;
+        const int w3[3] = { maxCol, maxCol >> 1, maxCol >> 1 }, h3[3] = { maxRow, maxRow >> 1, maxRow >> 1 };
+        for (int i = 0; i < 3; i++)
+            sums[3 + i] = sums[3 + i] - (sums[i] * sums[i] + (uint64_t)((w3[i] * h3[i]) / 2)) / (uint64_t)(w3[i] * h3[i]);
+    }
+    for (int i = 0; i < 6; i++) wpStats[i] = sums[i];
     return X265HIP_OK;
 }
