@@ -389,6 +389,15 @@ int x265hip_aq_block_energy(int depth, const x265hip_yuv* pic, int width, int he
 int x265hip_lookahead_aq_frame(int depth, const x265hip_yuv* pic, int width, int height, int qgSize, int aqMode, double aqStrength, int weightp,
                                double* qpAqOffset, int32_t* invQscaleFactor, int32_t* invQscaleFactor8x8, uint64_t* wpStats, int* blockCount,
                                void* stream);
+/* CU-tree: Lookahead::estimateCUPropagate (slicetype.cpp:2641-2750) with the propagateCost primitive (pixel.cpp:914-940) for frame b between
+ * p0 and p1 (a P frame: p1MinusP0 == bMinusP0, list 1 unused).  All arrays are device arrays per 8x8 lowres block of frame b: its own
+ * propagateCost (ignored when !referenced), intraCost, lowresCosts[b-p0][p1-b], invQscaleFactor (invQscaleFactor8x8 for qgSize 8), the two
+ * lists' vectors; refCosts0 / refCosts1 = the reference frames' propagateCost, updated (saturating at 65535).  scratch: 2 * blocks uint64.
+ * cuTreeFinish (the log2 of the ratio, :2889-2937) stays host logic. */
+int x265hip_cutree_propagate(int widthInCU, int heightInCU, int fpsNum, int fpsDenom, double averageDuration, int bMinusP0, int p1MinusP0,
+                             int referenced, int weightedBiPred, const uint16_t* propagateIn, const int32_t* intraCost, const uint16_t* lowresCosts,
+                             const int32_t* invQscale, const int32_t* mvs0, const int32_t* mvs1, uint16_t* refCosts0, uint16_t* refCosts1,
+                             uint64_t* scratch, void* stream);
 int x265hip_framepass_run_yuv(x265hip_framepass* fp, const x265hip_yuv* src, const x265hip_yuv* ref, const x265hip_yuv* pred,
                               const x265hip_yuv* recon, int marginX, int marginY, void* stream);
 /* The B-frame variant: a second (future) reference of the same geometry.  Both lists are searched at every level (list 1's vectors

@@ -232,6 +232,7 @@ def ref(depth):
     g("ref_costCoeffRemain", C.c_uint32, [vp, i32, i32])
     g("ref_costC1C2Flag", C.c_uint32, [vp, ip, vp, ip])
     g("ref_lookahead_cost_p_weightp", C.c_int64, [vp, vp, ip, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp])
+    g("ref_cutree_propagate", i32, [vp, ip, i32, i32, i32, i32, i32, i32, i32, C.c_double, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, C.c_double, vp, vp, i32])
     g("ref_aq_frame", i32, [vp, vp, vp, ip, ip, i32, i32, i32, i32, i32, i32, C.c_double, i32, vp, vp, vp, vp])
     g("ref_weights_analyse", i32, [vp, vp, ip, i32, i32, i32, i32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, vp, C.c_int64, vp])
     g("ref_deblock_ctu_edge", None, [vp, vp, vp, ip, ip, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32])

@@ -908,4 +908,94 @@ int ref_aq_frame(pixel* y, pixel* cb, pixel* cr, intptr_t stride, intptr_t strid
     return ret;
 }
 
+/* ---- the real Lookahead::estimateCUPropagate (+ cuTreeFinish when vbv is set; encoder/slicetype.cpp:2641-2750, :2889-2937) on three real
+ * Lowres objects (frames 0, 1, 2 = p0, b, p1; isP: p1 = b = 1).  Frame b's per-8x8 inputs are given; the reference frames' propagateCost
+ * arrays are read and updated.  pic: any padded picture of the right size (Lowres::create wants one).  Returns the 8x8 block count. */
+namespace {
+struct LookaheadProbe : public Lookahead
+{
+    LookaheadProbe(x265_param* p) : Lookahead(p, NULL) {}
+    void propagate(Lowres** f, double dur, int p0, int p1, int b, int referenced) { estimateCUPropagate(f, dur, p0, p1, b, referenced); }
+    void finish(Lowres* f, double dur, int ref0Distance) { cuTreeFinish(f, dur, ref0Distance); }
+};
+}
+int ref_cutree_propagate(pixel* pic, intptr_t stride, int w, int h, int marginX, int marginY, int qgSize, int fpsNum, int fpsDenom, double averageDuration,
+                         int isP, int referenced, int weightedBiPred, const uint16_t* propagateIn, const int32_t* intraCost, const uint16_t* lowresCosts,
+                         const int32_t* invQscale, const int32_t* mvs0, const int32_t* mvs1, uint16_t* refCosts0, uint16_t* refCosts1,
+                         int doFinish, double qCompress, const double* qpAqOffset, double* qpCuTreeOffset, int aqBlocks)
+{
+    T();
+    x265_param* param = x265_param_alloc();
+    x265_param_default(param);
+    param->sourceWidth = w;
+    param->sourceHeight = h;
+    param->rc.aqMode = 2;
+    param->rc.qgSize = qgSize;
+    param->rc.hevcAq = 0;
+    param->rc.cuTree = 1;
+    param->rc.qCompress = qCompress;
+    param->bAQMotion = 0;
+    param->bEnableHME = 0;
+    param->bEnableWeightedBiPred = weightedBiPred;
+    param->fpsNum = fpsNum;
+    param->fpsDenom = fpsDenom;
+    param->lookaheadSlices = 0;
+    PicYuv pics[3];
+    Lowres lr[3];
+    int ret = -1;
+    bool ok = true;
+    for (int i = 0; i < 3; i++)
+    {
+        pics[i].m_picWidth = w; pics[i].m_picHeight = h;
+        pics[i].m_lumaMarginX = marginX; pics[i].m_lumaMarginY = marginY;
+        pics[i].m_stride = stride;
+        pics[i].m_picOrg[0] = pic;
+        pics[i].m_param = param;
+        memset((void*)&lr[i], 0, sizeof(Lowres));
+        ok = ok && lr[i].create(param, &pics[i], qgSize);
+    }
+    if (ok)
+    {
+        LookaheadProbe la(param);
+        la.create();
+        const int ncu = la.m_8x8Width * la.m_8x8Height;
+        const int p0 = 0, b = 1, p1 = isP ? 1 : 2;
+        Lowres* frames[3] = { &lr[0], &lr[1], &lr[2] };
+        Lowres& fb = lr[b];
+        memcpy(fb.propagateCost, propagateIn, ncu * sizeof(uint16_t));
+        memcpy(fb.intraCost, intraCost, ncu * sizeof(int32_t));
+        memcpy(fb.lowresCosts[b - p0][p1 - b], lowresCosts, ncu * sizeof(uint16_t));
+        if (qgSize == 8) memcpy(fb.invQscaleFactor8x8, invQscale, ncu * sizeof(int));
+        else memcpy(fb.invQscaleFactor, invQscale, ncu * sizeof(int));
+        for (int i = 0; i < ncu; i++)
+        {
+            fb.lowresMvs[0][b - p0][i] = MV(mvs0[2 * i], mvs0[2 * i + 1]);
+            if (!isP) fb.lowresMvs[1][p1 - b][i] = MV(mvs1[2 * i], mvs1[2 * i + 1]);
+        }
+        memcpy(lr[p0].propagateCost, refCosts0, ncu * sizeof(uint16_t));
+        if (!isP) memcpy(lr[p1].propagateCost, refCosts1, ncu * sizeof(uint16_t));
+        la.propagate(frames, averageDuration, p0, p1, b, referenced);
+        memcpy(refCosts0, lr[p0].propagateCost, ncu * sizeof(uint16_t));
+        if (!isP) memcpy(refCosts1, lr[p1].propagateCost, ncu * sizeof(uint16_t));
+        if (doFinish)
+        {
+            memcpy(fb.qpAqOffset, qpAqOffset, aqBlocks * sizeof(double));
+            memcpy(fb.qpCuTreeOffset, qpAqOffset, aqBlocks * sizeof(double));
+            fb.weightedCostDelta[0] = 0;
+            la.finish(&fb, averageDuration, isP ? 1 : 0);
+            memcpy(qpCuTreeOffset, fb.qpCuTreeOffset, aqBlocks * sizeof(double));
+        }
+        ret = ncu;
+        la.destroy();
+    }
+    for (int i = 0; i < 3; i++)
+    {
+        lr[i].destroy();
+        pics[i].m_picOrg[0] = NULL;
+        pics[i].m_param = NULL;
+    }
+    x265_param_free(param);
+    return ret;
+}
+
 } // extern "C"

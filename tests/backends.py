@@ -341,6 +341,26 @@ class Orc(_Base):
         est = self._f("orc_lowres_intra_estimate")(ptr(plane, *origin), plane.shape[1], wcu, hcu, self.depth, ptr(cost), ptr(mode), ptr(rows))
         return est, cost, mode, rows
 
+    def cutree_propagate(self, w, h, qgSize, fps, avgDuration, isP, referenced, wbp, propIn, intra, lowresCosts, invq, mvs0, mvs1, ref0, ref1, qCompress, qpAq):
+        """Lookahead::estimateCUPropagate then cuTreeFinish for frame b.  Arrays per 8x8 lowres block; qpAq per quantisation group.
+        Returns (refCosts0, refCosts1, qpCuTreeOffset)."""
+        import ctypes as C
+        L = po.oracle()
+        wcu, hcu = (w // 2 + 7) // 8, (h // 2 + 7) // 8
+        r0, r1 = np.array(ref0, np.uint16), np.array(ref1, np.uint16)
+        f = L.orc_cutree_propagate
+        f.restype, f.argtypes = None, [po.i32] * 4 + [C.c_double] + [po.i32] * 4 + [po.vp] * 8
+        f(wcu, hcu, fps[0], fps[1], avgDuration, 1, 1 if isP else 2, referenced, wbp, ptr(propIn), ptr(intra), ptr(lowresCosts), ptr(invq), ptr(mvs0), ptr(mvs1),
+          ptr(r0), ptr(r1))
+        out = np.array(qpAq, np.float64)
+        pfin = np.array(propIn, np.uint16)
+        if not referenced:
+            pfin[:wcu] = 0                 # the reference zeroes (and re-uses) the first row of an unreferenced frame's propagateCost (:2656-2658)
+        g = L.orc_cutree_finish
+        g.restype, g.argtypes = None, [po.i32] * 5 + [C.c_double] * 3 + [po.vp] * 5
+        g(wcu, hcu, qgSize, fps[0], fps[1], avgDuration, qCompress, 0.0, ptr(intra), ptr(invq), ptr(pfin), ptr(qpAq), ptr(out))
+        return r0, r1, out
+
     def aq_frame(self, yuv, origin, w, h, qgSize, aqMode, aqStrength, weightp):
         """LookaheadTLD::calcAdaptiveQuantFrame on a padded 4:2:0 picture yuv = (Y, Cb, Cr), luma origin (y, x) (chroma at half).
         Returns (blockCount, qpAqOffset float64[], invQscaleFactor int32[], invQscaleFactor8x8 int32[], wpStats uint64[6])."""
@@ -912,6 +932,17 @@ class Ref(_Base):
         assert est >= 0 and (int(geom[0]), int(geom[1]), int(geom[2]), int(geom[3])) == (stride, lw, lh, planesize), geom
         pl = [planes[i * planesize:(i + 1) * planesize].reshape(lh + 2 * my, stride) for i in range(4)]
         return est, cost, mode, rows, pl, (stride, lw, lh)
+
+    def cutree_propagate(self, w, h, qgSize, fps, avgDuration, isP, referenced, wbp, propIn, intra, lowresCosts, invq, mvs0, mvs1, ref0, ref1, qCompress, qpAq):
+        m = 80
+        pic = np.zeros((h + 2 * m, w + 2 * m), self.pix)
+        r0, r1 = np.array(ref0, np.uint16), np.array(ref1, np.uint16)
+        out = np.zeros(len(qpAq), np.float64)
+        n = self.L.ref_cutree_propagate(ptr(pic, m, m), pic.shape[1], w, h, m, m, qgSize, fps[0], fps[1], float(avgDuration), int(isP), int(referenced), int(wbp),
+                                        ptr(propIn), ptr(intra), ptr(lowresCosts), ptr(invq), ptr(mvs0), ptr(mvs1), ptr(r0), ptr(r1), 1, float(qCompress),
+                                        ptr(qpAq), ptr(out), len(qpAq))
+        assert n == len(intra)
+        return r0, r1, out
 
     def aq_frame(self, yuv, origin, w, h, qgSize, aqMode, aqStrength, weightp):
         lw, lh = ((w // 2 + 7) // 8) * 8, ((h // 2 + 7) // 8) * 8

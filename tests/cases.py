@@ -528,3 +528,35 @@ def aq_cases(depth):
             out.append(("aq %dx%d qg%d mode%d s%.1f wp%d" % (w, h, qg, mode, strength, wp), (sy, scb, scr), (m, m), w, h, qg, mode, strength, wp))
             k += 1
     return out
+
+
+def cutree_cases(seed=70):
+    """Inputs for the CU-tree propagation step: random per-block costs (some blocks intra: inter cost >= intra cost), vectors that land
+    inside, on the edge of and outside the frame, P and B (both lists, one list), referenced or not, saturating reference costs.
+    Yields (label, args of Orc / Ref / Hip .cutree_propagate)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k, (w, h) in enumerate(((200, 136), (176, 144), (66, 50), (320, 200), (1920, 1080))):
+        for rep in range(4):
+            wcu, hcu = (w // 2 + 7) // 8, (h // 2 + 7) // 8
+            ncu = wcu * hcu
+            qg = 16 if rep != 2 else 8
+            isP = rep % 2
+            intra = rng.integers(1, 4000, size=ncu).astype(np.int32)
+            inter = np.minimum(rng.integers(0, 5000, size=ncu), 0x3FFF)
+            lists = rng.integers(1, 4, size=ncu) if not isP else np.ones(ncu, np.int64)
+            lowres = (inter | (lists << 14)).astype(np.uint16)
+            invq = rng.integers(60, 1200, size=ncu).astype(np.int32)
+            span = 40 if rep < 3 else 3000
+            mvs0 = rng.integers(-span, span + 1, size=(ncu, 2)).astype(np.int32)
+            mvs1 = rng.integers(-span, span + 1, size=(ncu, 2)).astype(np.int32)
+            mvs0[rng.random(ncu) < 0.3] = 0
+            propIn = rng.integers(0, 30000, size=ncu).astype(np.uint16)
+            ref0 = rng.integers(0, 65535 if rep == 1 else 20000, size=ncu).astype(np.uint16)
+            ref1 = rng.integers(0, 20000, size=ncu).astype(np.uint16)
+            nq = ncu * (4 if qg == 8 else 1)
+            qpAq = rng.normal(0, 2, size=nq)
+            out.append(("cutree %dx%d #%d" % (w, h, rep),
+                        (w, h, qg, (30000, 1001) if rep % 2 else (25, 1), [0.04, 0.0333, 1.5, 0.001][rep], isP, 0 if rep == 3 else 1, 1 if rep == 0 else 0,
+                         propIn, intra, lowres, invq, mvs0, mvs1, ref0, ref1, 0.6, qpAq)))
+    return out

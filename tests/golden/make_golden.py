@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import numpy as np  # noqa: E402
 from backends import Ref  # noqa: E402
-from cases import gen_cases, coef_cases, loop_cases, deblock_cases, weight_scenes, aq_cases, umh_groups, me_scene, me_scene_yuv, lowres_scene, lookahead_scene, lookahead_scene3, digest  # noqa: E402
+from cases import gen_cases, coef_cases, loop_cases, deblock_cases, weight_scenes, aq_cases, cutree_cases, umh_groups, me_scene, me_scene_yuv, lowres_scene, lookahead_scene, lookahead_scene3, digest  # noqa: E402
 
 ME_CASES = [  # (method, subme, w, h, bx_off, by_off, merange, qmvp, mvc, qp)
     (1, 2, 16, 16, 16, 24, 57, (5, -7), [(12, 8), (-20, 4)], 28),
@@ -149,6 +149,12 @@ def aq_results(backend_cls, depth):
     """LookaheadTLD::calcAdaptiveQuantFrame per case of tests/cases.py aq_cases: (blockCount, qpAqOffset, invQscaleFactor, invQscaleFactor8x8, wpStats)."""
     b = backend_cls(depth)
     return {c[0]: b.aq_frame(*c[1:]) for c in aq_cases(depth)}
+
+
+def cutree_results(backend_cls):
+    """Lookahead::estimateCUPropagate (+ cuTreeFinish where the backend has it) per case of tests/cases.py cutree_cases."""
+    b = backend_cls(8)
+    return {label: b.cutree_propagate(*args) for label, args in cutree_cases()}
 
 
 def mc_cases(depth):
@@ -289,6 +295,7 @@ if __name__ == "__main__":
         json.dump({"source": "x265_entropyStateBits (common/constants.cpp) of the reference build, dumped by tests/golden/make_golden.py",
                    "entropyStateBits": [int(v) for v in Ref(8).entropy_state_bits()]}, f)
     gold["coef"] = coef_digests(Ref)
+    gold["cutree"] = {k: [digest(v[0]), digest(v[1]), digest(v[2])] for k, v in cutree_results(Ref).items()}
     path = os.path.join(HERE, "primitives_golden.json")
     with open(path, "w") as f:
         json.dump({"source": "x265 3.4+28 C primitives ([noasm]), /root/reference/source via oracle/Makefile",

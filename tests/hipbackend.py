@@ -390,6 +390,15 @@ class Hip:
                                                 C.byref(n), None))
         return int(n.value), qp, inv, inv8, st
 
+    def cutree_propagate(self, w, h, qgSize, fps, avgDuration, isP, referenced, wbp, propIn, intra, lowresCosts, invq, mvs0, mvs1, ref0, ref1, qCompress, qpAq):
+        """x265hip_cutree_propagate; returns (refCosts0, refCosts1) — cuTreeFinish is host logic and not part of the library."""
+        wcu, hcu = (w // 2 + 7) // 8, (h // 2 + 7) // 8
+        d = [DevBuf(np.ascontiguousarray(a)) for a in (propIn, intra, lowresCosts, invq, mvs0, mvs1, np.array(ref0, np.uint16), np.array(ref1, np.uint16))]
+        scratch = DevBuf.zeros((2 * wcu * hcu,), np.uint64)
+        check(self.L.x265hip_cutree_propagate(wcu, hcu, fps[0], fps[1], float(avgDuration), 1, 1 if isP else 2, int(referenced), int(wbp), d[0].ptr, d[1].ptr,
+                                              d[2].ptr, d[3].ptr, d[4].ptr, None if isP else d[5].ptr, d[6].ptr, None if isP else d[7].ptr, scratch.ptr, None))
+        return d[6].get(), d[7].get()
+
     _epoch = [0]
 
     def lookahead_cost_p_batch(self, pairs, origin, w, h, mx, my, rows_per_slice, num_slices, wp_stats=None):

@@ -772,6 +772,22 @@ def test_motion_compensation_matches_oracle_and_golden(hipmod, depth):
         assert np.array_equal(y, wy) and np.array_equal(cb, wcb) and np.array_equal(cr, wcr)
 
 
+def test_cutree_propagate_matches_oracle_and_golden(hipmod):
+    """Lookahead::estimateCUPropagate on the device (double-precision amounts, scatter into the references with saturation) vs the restatement
+    and the committed results of the real function, up to the block grid of a 1080p frame."""
+    import json
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    from cases import digest
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "primitives_golden.json")))["golden"]["cutree"]
+    want = make_golden.cutree_results(Orc)
+    got = make_golden.cutree_results(hipmod.Hip)
+    hipmod._release()
+    for k in want:
+        assert np.array_equal(want[k][0], got[k][0]) and np.array_equal(want[k][1], got[k][1]), k
+        assert [digest(got[k][0]), digest(got[k][1])] == gold[k][:2], k
+
+
 @pytest.mark.parametrize("depth", [8, 10, 12])
 def test_weightp_analysis_matches_oracle_and_golden(hipmod, depth):
     """The lookahead's weighted-prediction analysis on the device (lowres planes, intra costs, the two weightCostLuma evaluations, the

@@ -54,6 +54,11 @@ def test_oracle_weightp_analysis_matches_golden(depth):
     assert len(got) == 32 and got == GOLD[str(depth)]["aq"]
 
 
+def test_oracle_cutree_matches_golden():
+    got = {k: [digest(v[0]), digest(v[1]), digest(v[2])] for k, v in make_golden.cutree_results(Orc).items()}
+    assert len(got) == 20 and got == GOLD["cutree"]
+
+
 def test_oracle_coefficient_scan_primitives_match_golden():
     got = make_golden.coef_digests(Orc)
     want = GOLD["coef"]

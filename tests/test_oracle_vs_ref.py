@@ -88,6 +88,18 @@ def test_weightp_analysis_matches_reference(depth):
         assert a[k][0] == b[k][0] and all(np.array_equal(x, y) for x, y in zip(a[k][1:], b[k][1:])), k
 
 
+def test_cutree_matches_reference():
+    """The real Lookahead::estimateCUPropagate and cuTreeFinish on real Lowres objects vs the restatement: the references' propagateCost after
+    the step (incl. saturation and vectors leaving the frame) and the frame's qpCuTreeOffset."""
+    _need_ref(8)
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    a, b = make_golden.cutree_results(Orc), make_golden.cutree_results(Ref)
+    for k in a:
+        assert all(np.array_equal(x, y) for x, y in zip(a[k], b[k])), k
+
+
 def test_coefficient_scan_primitives_match_reference():
     """scanPosLast / findPosFirstLast / costCoeffNxN / costCoeffRemain / costC1C2Flag of the reference's C table and its scan-order tables vs the
     restatement, on inputs drawn like test/pixelharness.cpp draws them; and the committed CABAC cost table is the reference's."""

@@ -394,3 +394,101 @@ extern "C" int x265hip_lookahead_aq_frame(int depth, const x265hip_yuv* pic, int
     for (int i = 0; i < 6; i++) wpStats[i] = sums[i];
     return X265HIP_OK;
 }
+
+// ---- CU-tree: Lookahead::estimateCUPropagate (slicetype.cpp:2641-2750) with its primitive estimateCUPropagateCost (pixel.cpp:914-940).
+// One lane per 8x8 block of frame b: the amount it passes on (double precision, the reference's operations one by one — explicit _rn
+// intrinsics so that nothing is contracted into an FMA), split over the lists it used and over the four blocks its vector points at in
+// each reference.  The reference adds into the references' uint16 propagateCost with saturation, block after block; every addend is
+// non-negative, so the saturated result is min(initial + sum of addends, 65535) in any order: addends go to 64-bit accumulators with
+// atomics, a second kernel folds them in.
+namespace xh {
+
+__global__ __launch_bounds__(256) void cutree_propagate_kernel(int W, int H, double fps, int referenced, int bw0, int bw1,
+                                                               const uint16_t* __restrict__ propagateIn, const int32_t* __restrict__ intraCost,
+                                                               const uint16_t* __restrict__ lowresCosts, const int32_t* __restrict__ invQscale,
+                                                               const int32_t* __restrict__ mvs0, const int32_t* __restrict__ mvs1,
+                                                               unsigned long long* __restrict__ acc)
+{
+    const int cu = blockIdx.x * blockDim.x + threadIdx.x, ncu = W * H;
+    if (cu >= ncu)
+        return;
+    const int by = cu / W, bx = cu - by * W;
+    const int ic = intraCost[cu], lc = lowresCosts[cu];
+    const int interCost = min(ic, lc & 0x3FFF);
+    const double propagateIntra = __dmul_rn((double)ic, (double)invQscale[cu]);           // int * int in the reference, converted: same value (< 2^53)
+    const double propagateAmount = __dadd_rn((double)(referenced ? propagateIn[cu] : 0), __dmul_rn(propagateIntra, fps));
+    const double num = (double)(ic - interCost);
+    const int amount = (int)__dadd_rn(__ddiv_rn(__dmul_rn(propagateAmount, num), (double)ic), 0.5);
+    if (amount <= 0)
+        return;
+    const int lists = lc >> 14;
+#pragma unroll
+    for (int list = 0; list < 2; list++)
+    {
+        if (!((lists >> list) & 1))
+            continue;
+        int la = amount;
+        if (lists == 3)
+            la = (la * (list ? bw1 : bw0) + 32) >> 6;
+        const int32_t* mv = list ? mvs1 : mvs0;
+        unsigned long long* a = acc + (size_t)list * ncu;
+        int x = mv[2 * cu], y = mv[2 * cu + 1];
+        if (!(x | y))
+        {
+            atomicAdd(&a[cu], (unsigned long long)la);
+            continue;
+        }
+        const int cux = (x >> 5) + bx, cuy = (y >> 5) + by, i0 = cux + cuy * W;
+        x &= 31;
+        y &= 31;
+        const int w0 = (32 - y) * (32 - x), w1 = (32 - y) * x, w2 = y * (32 - x), w3 = y * x;
+        const bool xin = cux >= 0 && cux < W, x1in = cux + 1 >= 0 && cux + 1 < W, yin = cuy >= 0 && cuy < H, y1in = cuy + 1 >= 0 && cuy + 1 < H;
+        if (xin && yin) atomicAdd(&a[i0], (unsigned long long)((la * w0 + 512) >> 10));
+        if (x1in && yin) atomicAdd(&a[i0 + 1], (unsigned long long)((la * w1 + 512) >> 10));
+        if (xin && y1in) atomicAdd(&a[i0 + W], (unsigned long long)((la * w2 + 512) >> 10));
+        if (x1in && y1in) atomicAdd(&a[i0 + W + 1], (unsigned long long)((la * w3 + 512) >> 10));
+    }
+}
+
+__global__ __launch_bounds__(256) void cutree_fold_kernel(int ncu, const unsigned long long* __restrict__ acc, uint16_t* __restrict__ ref0, uint16_t* __restrict__ ref1)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncu)
+        return;
+    const unsigned long long a0 = acc[i] + ref0[i];
+    ref0[i] = (uint16_t)(a0 < 65535ull ? a0 : 65535ull);
+    if (ref1)
+    {
+        const unsigned long long a1 = acc[ncu + i] + ref1[i];
+        ref1[i] = (uint16_t)(a1 < 65535ull ? a1 : 65535ull);
+    }
+}
+
+} // namespace xh
+
+extern "C" int x265hip_cutree_propagate(int widthInCU, int heightInCU, int fpsNum, int fpsDenom, double averageDuration, int bMinusP0, int p1MinusP0,
+                                        int referenced, int weightedBiPred, const uint16_t* propagateIn, const int32_t* intraCost, const uint16_t* lowresCosts,
+                                        const int32_t* invQscale, const int32_t* mvs0, const int32_t* mvs1, uint16_t* refCosts0, uint16_t* refCosts1,
+                                        uint64_t* scratch, void* stream)
+{
+    XH_CHECK_DEV();
+    if (widthInCU < 1 || heightInCU < 1 || fpsNum < 1 || fpsDenom < 1 || bMinusP0 < 1 || p1MinusP0 < bMinusP0 || !scratch || !refCosts0 ||
+        (p1MinusP0 > bMinusP0 && (!refCosts1 || !mvs1)))
+        return set_error(X265HIP_EINVAL, "cutree_propagate: %dx%d fps %d/%d distances %d %d", widthInCU, heightInCU, fpsNum, fpsDenom, bMinusP0, p1MinusP0);
+    hipStream_t st = as_stream(stream);
+    const int ncu = widthInCU * heightInCU;
+    auto clipd = [](double f) { return f < 0.01 ? 0.01 : (f > 1.00 ? 1.00 : f); };                 // CLIP_DURATION (ratecontrol.h:42-47)
+    const double fpsFactor = clipd((double)fpsDenom / fpsNum) / clipd(averageDuration);
+    const double fps = fpsFactor / 256;
+    const int dsf = ((bMinusP0 << 8) + (p1MinusP0 >> 1)) / p1MinusP0;
+    const int bw = weightedBiPred ? 64 - (dsf >> 2) : 32;
+    if (hipMemsetAsync(scratch, 0, sizeof(uint64_t) * 2 * (size_t)ncu, st) != hipSuccess)
+        return set_error(X265HIP_EHIP, "cutree_propagate: memset");
+    dim3 grid((ncu + 255) / 256), block(256);
+    hipLaunchKernelGGL(cutree_propagate_kernel, grid, block, 0, st, widthInCU, heightInCU, fps, referenced, bw, 64 - bw, propagateIn, intraCost, lowresCosts, invQscale,
+                       mvs0, mvs1 ? mvs1 : mvs0, (unsigned long long*)scratch);
+    XH_LAUNCH_CHECK("cutree_propagate_kernel");
+    hipLaunchKernelGGL(cutree_fold_kernel, grid, block, 0, st, ncu, (const unsigned long long*)scratch, refCosts0, p1MinusP0 > bMinusP0 ? refCosts1 : (uint16_t*)nullptr);
+    XH_LAUNCH_CHECK("cutree_fold_kernel");
+    return X265HIP_OK;
+}

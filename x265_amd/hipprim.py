@@ -141,6 +141,7 @@ PROTOTYPES = {
     "x265hip_call_sao_stats": (i32, [i32, i32, vp, vp, i64, vp, vp, i32, i32, vp, vp]),
     "x265hip_lookahead_weight_cost_batch": (i32, [i32, vp, vp, i64, i32, i32, vp, vp, i32, vp, vp]),
     "x265hip_lookahead_weights_analyse": (i32, [i32, vp, vp, i64, i64, i64, i32, i32, i32, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, vp, vp, vp, vp]),
+    "x265hip_cutree_propagate": (i32, [i32, i32, i32, i32, C.c_double, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "x265hip_aq_block_energy": (i32, [i32, vp, i32, i32, i32, vp, vp, vp]),
     "x265hip_lookahead_aq_frame": (i32, [i32, vp, i32, i32, i32, i32, C.c_double, i32, vp, vp, vp, vp, vp, vp]),
     "x265hip_motion_compensation_batch": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
