@@ -132,7 +132,22 @@ __device__ __forceinline__ void star_search(C& c, int minx, int miny, int maxx, 
             for (int ty = miny; ty <= maxy; ty += 5)
                 for (int tx = minx; tx <= maxx; tx += 5)
                 {
-                    if (tx + 15 <= maxx)
+                    if (tx + 35 <= maxx)
+                    {
+                        // two consecutive sad_x4 groups of the reference measured together (eight loads in flight instead of four: the
+                        // raster is a chain of dependent-latency batches, not of arithmetic), replayed in the same order
+                        int px[8], py[8], cost[8];
+#pragma unroll
+                        for (int i = 0; i < 8; i++) { px[i] = tx + 5 * i; py[i] = ty; }
+                        c.template fullpel_costs<8>(px, py, cost);
+                        cost[3] += c.mvcost((tx + 15) << 3, ty << 3) - c.mvcost((tx + 15) << 2, ty << 2);      // the fourth of each group (:1195)
+                        cost[7] += c.mvcost((tx + 35) << 3, ty << 3) - c.mvcost((tx + 35) << 2, ty << 2);
+#pragma unroll
+                        for (int i = 0; i < 8; i++)
+                            if (cost[i] < st.bcost) { st.bcost = cost[i]; st.bx = px[i]; st.by = py[i]; }
+                        tx += 35;
+                    }
+                    else if (tx + 15 <= maxx)
                     {
                         // one sad_x4 of the reference: four points measured together
                         const int px[4] = { tx, tx + 5, tx + 10, tx + 15 }, py[4] = { ty, ty, ty, ty };
