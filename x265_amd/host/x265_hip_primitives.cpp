@@ -183,6 +183,10 @@ template <int W, int H, int PART> static void p2s_hip(const pixel* s, intptr_t s
 {
     if (x265hip_call_p2s(D, W, H, s, ss, d, ds)) g_c.pu[PART].convert_p2s[NONALIGNED](s, ss, d, ds);
 }
+template <int W, int H, int PART> static void c_p2s_hip(const pixel* s, intptr_t ss, int16_t* d, intptr_t ds)
+{
+    if (x265hip_call_p2s(D, W / 2, H / 2, s, ss, d, ds)) g_c.chroma[X265_CSP_I420].pu[PART].p2s[NONALIGNED](s, ss, d, ds);
+}
 template <int N, int CU> static void sub_ps_hip(int16_t* d, intptr_t ds, const pixel* a, const pixel* b, intptr_t sa, intptr_t sb)
 {
     if (x265hip_call_sub_ps(D, N, N, d, ds, a, b, sa, sb)) g_c.cu[CU].sub_ps(d, ds, a, b, sa, sb);
@@ -319,6 +323,8 @@ template <int W, int H, int PART> static void c_vss_hip(const int16_t* s, intptr
         p.chroma[X265_CSP_I420].pu[part].filter_vps = c_vps_hip<W, H, LUMA_ ## W ## x ## H>; \
         p.chroma[X265_CSP_I420].pu[part].filter_vsp = c_vsp_hip<W, H, LUMA_ ## W ## x ## H>; \
         p.chroma[X265_CSP_I420].pu[part].filter_vss = c_vss_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.chroma[X265_CSP_I420].pu[part].p2s[NONALIGNED] = c_p2s_hip<W, H, LUMA_ ## W ## x ## H>; \
+        p.chroma[X265_CSP_I420].pu[part].p2s[ALIGNED] = c_p2s_hip<W, H, LUMA_ ## W ## x ## H>; \
     } while (0)
 
 #define HIP_CU(N) do { \
