@@ -11,6 +11,7 @@
 // four lowres planes (x265hip_weight_pp over the padded buffers).
 #include "common.h"
 #include <cmath>
+#include <algorithm>
 #include <vector>
 
 namespace xh {
@@ -236,36 +237,46 @@ __global__ __launch_bounds__(256) void aq_energy_kernel(const P* __restrict__ y,
                                                         int64_t strideC, int blocksX, int nblocks, int qg, uint32_t* __restrict__ energy,
                                                         unsigned long long* __restrict__ sums)
 {
-    const int lane = threadIdx.x & 63, blk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (blk >= nblocks)
-        return;
-    const int by = (blk / blocksX) * qg, bx = (blk % blocksX) * qg;
-    uint32_t var = 0;
-#pragma unroll
-    for (int p = 0; p < 3; p++)
+    // a wave walks over blocks (grid-stride) and keeps the frame sums in registers; the workgroup's four waves meet in LDS and issue one
+    // atomic per plane and quantity — thousands of atomics on six addresses would serialise the whole launch
+    __shared__ unsigned long long sAcc[4][6];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wavesTotal = gridDim.x * 4;
+    unsigned long long acc[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int blk = blockIdx.x * 4 + wv; blk < nblocks; blk += wavesTotal)
     {
-        const int n = p ? qg >> 1 : qg;                                  // block edge in this plane
-        const int shift = p ? (qg == 8 ? 4 : 6) : (qg == 8 ? 6 : 8);
-        const P* src = p == 0 ? y + (int64_t)by * stride + bx : (p == 1 ? cb : cr) + (int64_t)(by >> 1) * strideC + (bx >> 1);
-        const int64_t ss = p ? strideC : stride;
-        uint32_t sum = 0, ssd = 0;
-        for (int i = lane; i < n * n; i += 64)
+        const int by = (blk / blocksX) * qg, bx = (blk % blocksX) * qg;
+        uint32_t var = 0;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
         {
-            const uint32_t v = src[(int64_t)(i / n) * ss + (i % n)];
-            sum += v;
-            ssd += v * v;
+            const int n = p ? qg >> 1 : qg;                              // block edge in this plane
+            const int shift = p ? (qg == 8 ? 4 : 6) : (qg == 8 ? 6 : 8);
+            const P* src = p == 0 ? y + (int64_t)by * stride + bx : (p == 1 ? cb : cr) + (int64_t)(by >> 1) * strideC + (bx >> 1);
+            const int64_t ss = p ? strideC : stride;
+            uint32_t sum = 0, ssd = 0;
+            for (int i = lane; i < n * n; i += 64)
+            {
+                const uint32_t v = src[(int64_t)(i / n) * ss + (i % n)];
+                sum += v;
+                ssd += v * v;
+            }
+            sum = (uint32_t)wave_sum((int)sum);
+            ssd = (uint32_t)wave_sum((int)ssd);
+            acc[p] += sum;
+            acc[3 + p] += ssd;
+            var += ssd - (uint32_t)(((uint64_t)sum * sum) >> shift);
         }
-        sum = (uint32_t)wave_sum((int)sum);
-        ssd = (uint32_t)wave_sum((int)ssd);
         if (!lane)
-        {
-            atomicAdd(&sums[p], (unsigned long long)sum);
-            atomicAdd(&sums[3 + p], (unsigned long long)ssd);
-        }
-        var += ssd - (uint32_t)(((uint64_t)sum * sum) >> shift);
+            energy[blk] = var;
     }
     if (!lane)
-        energy[blk] = var;
+    {
+#pragma unroll
+        for (int k = 0; k < 6; k++) sAcc[wv][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6)
+        atomicAdd(&sums[threadIdx.x], sAcc[0][threadIdx.x] + sAcc[1][threadIdx.x] + sAcc[2][threadIdx.x] + sAcc[3][threadIdx.x]);
 }
 
 static int aq_exp2fix8(double x)
@@ -285,7 +296,7 @@ extern "C" int x265hip_aq_block_energy(int depth, const x265hip_yuv* pic, int wi
     if (!valid_depth(depth) || !pic || width < 1 || height < 1 || (qgSize != 8 && qgSize != 16))
         return set_error(X265HIP_EINVAL, "aq_block_energy: depth %d %dx%d qgSize %d", depth, width, height, qgSize);
     const int bxs = (width + qgSize - 1) / qgSize, bys = (height + qgSize - 1) / qgSize, n = bxs * bys;
-    dim3 grid((n + 3) / 4), block(256);
+    dim3 grid(std::min((n + 3) / 4, 512)), block(256);
     if (depth == 8)
         hipLaunchKernelGGL((aq_energy_kernel<uint8_t>), grid, block, 0, as_stream(stream), (const uint8_t*)pic->y, (const uint8_t*)pic->cb, (const uint8_t*)pic->cr,
                            pic->strideY, pic->strideC, bxs, n, qgSize, energy, (unsigned long long*)sums);
