@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from backends import Orc, PU_SIZES, same          # noqa: E402
-from cases import gen_cases, me_scene             # noqa: E402
+from cases import gen_cases, me_scene, coef_cases, loop_cases, deblock_cases, cutree_cases             # noqa: E402
 import hipbackend                                 # noqa: E402
 from x265_amd import hipprim as hp                # noqa: E402
 
@@ -26,6 +26,27 @@ def main():
     hp.check(hp.lib().x265hip_init(0))
     bad, n, t0 = [], 0, time.time()
     for seed in range(a.first_seed, a.first_seed + a.seeds):
+        # the "next" rows: coefficient-scan helpers, in-loop filter primitives, deblocking edges, CU-tree step
+        o8, g8 = Orc(8), hipbackend.Hip(8)
+        for label, fn, args in coef_cases(seed=seed):
+            n += 1
+            if not same(getattr(o8, fn)(*args), getattr(g8, fn)(*args)):
+                bad.append("seed %d %s" % (seed, label))
+            hipbackend._release()
+        for label, args in cutree_cases(seed=seed):
+            w_, g_ = o8.cutree_propagate(*args), g8.cutree_propagate(*args)
+            n += 1
+            if not (np.array_equal(w_[0], g_[0]) and np.array_equal(w_[1], g_[1])):
+                bad.append("seed %d %s" % (seed, label))
+            hipbackend._release()
+        for depth in (8, 10, 12):
+            o, g = Orc(depth), hipbackend.Hip(depth)
+            import itertools
+            for label, fn, args in itertools.chain(loop_cases(depth, seed=seed), deblock_cases(depth, seed=seed)):
+                n += 1
+                if not same(getattr(o, fn)(*args), getattr(g, fn)(*args)):
+                    bad.append("seed %d depth %d %s" % (seed, depth, label))
+                hipbackend._release()
         for depth in (8, 10, 12):
             o, g = Orc(depth), hipbackend.Hip(depth)
             if depth != 12:
