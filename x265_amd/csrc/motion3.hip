@@ -78,7 +78,14 @@ struct RowTeam
     typedef typename Pk3<P>::T Q;
     static constexpr int IPT = N * N / 4 / TEAM;       // quads per lane: 1 (8x8), 4 (16x16 on 16 lanes, 32x32 on 64), 16 (64x64 on 64)
     static constexpr int TX = N / 4;                   // tiles per row
-    const P* plane0;                                   // phase plane 0 at the PU origin
+    // Candidate blocks are addressed as (uniform base) + (32-bit unsigned byte offset): the loads then take the scalar-base form
+    // (global_load v, voffset, s[base]) and the per-load 64-bit pointer arithmetic disappears.  The base is the plane pointer moved back
+    // by kBias elements so that offsets of candidates above / left of the picture origin stay non-negative; nothing is read at the base.
+    static constexpr uint32_t kBias = 1u << 22;
+    const char* base;                                  // (const char*)(planes - kBias), the same for every lane
+    uint32_t org;                                      // byte offset of phase plane 0 at the PU origin from `base`
+    const char* costBase;                              // (const char*)(mvcost centre - kCostBias)
+    static constexpr uint32_t kCostBias = 1u << 16;
     int64_t planeElems;
     bool smallPlane;                                   // planeElems < 2^24: the phase offset fits a 24-bit multiply
     int stride;
@@ -96,37 +103,39 @@ struct RowTeam
     int fuc[CPASS][4];
     bool cact;                                          // lane takes part in the chroma term
 
-    __device__ __forceinline__ int mvcost(int qx, int qy) const { return (int)(uint16_t)(cost[qx - qmvp.x] + cost[qy - qmvp.y]); }
+    __device__ __forceinline__ uint16_t cost_at(int i) const { return *reinterpret_cast<const uint16_t*>(costBase + (size_t)(((uint32_t)i + kCostBias) * 2u)); }
+    __device__ __forceinline__ int mvcost(int qx, int qy) const { return (int)(uint16_t)(cost_at(qx - qmvp.x) + cost_at(qy - qmvp.y)); }
+    template <typename T> __device__ __forceinline__ T ld_off(uint32_t byteOff) const { return ld_unaligned<T>(base + (size_t)byteOff); }
 
-    __device__ __forceinline__ const P* cand(Mv3 q) const
+    __device__ __forceinline__ uint32_t cand(Mv3 q) const
     {
         // full-rate 24-bit multiplies instead of v_mul_lo_u32 / v_mad_u64_u32 (quarter rate) on the candidate chain: the stride is below
         // 2^23 (checked at dispatch), the phase index is 0..15 and the plane size is below 2^24 elements up to 4K (smallPlane)
         const int ph = (q.y & 3) * 4 + (q.x & 3);
-        const int64_t po = smallPlane ? (int64_t)__umul24(ph, (int)planeElems) : (int64_t)ph * planeElems;
-        return plane0 + po + (__mul24(q.y >> 2, stride) + (q.x >> 2));
+        const uint32_t po = smallPlane ? (uint32_t)__umul24(ph, (int)planeElems) : (uint32_t)ph * (uint32_t)planeElems;
+        return org + (po + (uint32_t)(__mul24(q.y >> 2, stride) + (q.x >> 2))) * (uint32_t)sizeof(P);
     }
     // subpelCompare(..., sad) (motion.cpp:1571) / sad() of the block at quarter-pel vector q, WITHOUT mv cost
     __device__ __forceinline__ int sad_q(Mv3 q) const
     {
-        const P* r = cand(q);
+        const uint32_t r = cand(q);
         unsigned acc = 0;
 #pragma unroll
         for (int j = 0; j < IPT; j++)
-            acc = Pk3<P>::sad(ld_unaligned<Q>(r + qoff[j]), fq[j], acc);
+            acc = Pk3<P>::sad(ld_off<Q>(r + (uint32_t)qoff[j]), fq[j], acc);
         return team_allsum<TEAM>((int)acc);
     }
     // subpelCompare(..., satd): 4x4 Hadamard tiles, rows of a tile in the 4 lanes of a DPP quad
     __device__ __forceinline__ int satd_q(Mv3 q) const
     {
-        const P* r = cand(q);
+        const uint32_t r = cand(q);
         const bool hi1 = s & 1, hi2 = s & 2;
         int acc = 0;
 #pragma unroll
         for (int j = 0; j < IPT; j++)
         {
             int p[4];
-            Pk3<P>::unpack(ld_unaligned<Q>(r + qoff[j]), p);
+            Pk3<P>::unpack(ld_off<Q>(r + (uint32_t)qoff[j]), p);
             const int d0 = fu[j][0] - p[0], d1 = fu[j][1] - p[1], d2 = fu[j][2] - p[2], d3 = fu[j][3] - p[3];
             const int s01 = d0 + d1, e01 = d0 - d1, s23 = d2 + d3, e23 = d2 - d3;
             int m[4] = { s01 + s23, s01 - s23, e01 + e23, e01 - e23 };
@@ -179,11 +188,11 @@ struct RowTeam
 #pragma unroll
         for (int k = 0; k < K; k++)
         {
-            const P* r = plane0 + (__mul24(my[k], stride) + mx[k]);
+            const uint32_t r = org + (uint32_t)(__mul24(my[k], stride) + mx[k]) * (uint32_t)sizeof(P);
             acc[k] = 0;
 #pragma unroll
             for (int j = 0; j < IPT; j++)
-                acc[k] = Pk3<P>::sad(ld_unaligned<Q>(r + qoff[j]), fq[j], acc[k]);
+                acc[k] = Pk3<P>::sad(ld_off<Q>(r + (uint32_t)qoff[j]), fq[j], acc[k]);
             mvc[k] = mvcost(mx[k] * 4, my[k] * 4);
         }
 #pragma unroll
@@ -225,6 +234,8 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
     c.planeElems = planeElems;
     c.smallPlane = planeElems < (1 << 24);
     c.cost = mvcostTab;
+    c.costBase = reinterpret_cast<const char*>(mvcostTab) - (size_t)RT::kCostBias * 2;
+    c.base = reinterpret_cast<const char*>(planes) - (size_t)RT::kBias * sizeof(P);
     // XCD-aware block order (see motion2.hip): XCD x works on the x-th contiguous eighth of the raster-ordered PU list
     const int chunk = gridDim.x >> 3;
     const int lblock = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
     }
     const Mv3 qmvmin = { mvmin.x * 4, mvmin.y * 4 }, qmvmax = { mvmax.x * 4, mvmax.y * 4 };
     c.qmvp = qmvp;
-    c.plane0 = planes + (int64_t)by * strideR + bx;
+    c.org = (RT::kBias + (uint32_t)(by * (int)strideR + bx)) * (uint32_t)sizeof(P);
     {
         const P* f = fencPlane + (int64_t)by * strideF + bx;
 #pragma unroll
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
         {
             const int t = j * (TEAM / 4) + (c.s >> 2), r = c.s & 3;     // tile-major: 4 consecutive lanes = the 4 rows of tile t
             const int row = (t / RT::TX) * 4 + r, col = (t % RT::TX) * 4;
-            c.qoff[j] = row * (int)strideR + col;
+            c.qoff[j] = (row * (int)strideR + col) * (int)sizeof(P);          // bytes
             c.fq[j] = ld_unaligned<Q>(f + (int64_t)row * strideF + col);
             Pk3<P>::unpack(c.fq[j], c.fu[j]);
         }
