@@ -204,6 +204,13 @@ struct Team
 
     const P* fref;
     const P* plane0;                // sub-pel planes at the PU origin (plane p at plane0 + p * planeElems), or NULL
+    // candidate SADs and MVD costs address memory as (uniform base) + (32-bit unsigned byte offset), see motion3.hip: scalar-base loads
+    static constexpr uint32_t kBias = 1u << 22, kCostBias = 1u << 16;
+    const char* baseF;              // (const char*)(refPlane - kBias)
+    const char* baseP;              // (const char*)(planes - kBias)
+    const char* costBase;           // (const char*)(mvcost centre - kCostBias)
+    uint32_t org;                   // byte offset of the PU origin from either base (both planes share the geometry)
+    uint32_t qoffB[IPT];            // byte offset of this thread's j-th quad inside the block
     int64_t planeElems;
     int64_t stride;
     const uint16_t* cost;
@@ -237,7 +244,19 @@ struct Team
 
     __device__ __forceinline__ void team_barrier() const { if (WAVES > 1) __syncthreads(); }
 
-    __device__ __forceinline__ int mvcost_lane(int qx, int qy) const { return (int)(uint16_t)(cost[qx - qmvp.x] + cost[qy - qmvp.y]); }
+    __device__ __forceinline__ uint16_t cost_at(int i) const { return *reinterpret_cast<const uint16_t*>(costBase + (size_t)(((uint32_t)i + kCostBias) * 2u)); }
+    __device__ __forceinline__ int mvcost_lane(int qx, int qy) const { return (int)(uint16_t)(cost_at(qx - qmvp.x) + cost_at(qy - qmvp.y)); }
+    template <bool QPEL>
+    __device__ __forceinline__ uint32_t cand_off(Mv2 m) const
+    {
+        if (QPEL)
+        {
+            const int ph = (m.y & 3) * 4 + (m.x & 3);
+            const uint32_t po = planeElems < (1 << 24) ? (uint32_t)__umul24(ph, (int)planeElems) : (uint32_t)ph * (uint32_t)planeElems;
+            return org + (po + (uint32_t)(__mul24(m.y >> 2, (int)stride) + (m.x >> 2))) * (uint32_t)sizeof(P);
+        }
+        return org + (uint32_t)(__mul24(m.y, (int)stride) + m.x) * (uint32_t)sizeof(P);
+    }
     __device__ __forceinline__ int mvcost(int qx, int qy) const { return uni2(mvcost_lane(qx, qy)); }
 
     template <bool QPEL>
@@ -306,13 +325,11 @@ struct Team
             for (int k = 0; k < K; k++)
             {
                 acc[k] = 0;
-                const P* r = cand_ptr<QPEL>(c[k]);
+                const uint32_t r = cand_off<QPEL>(c[k]);
+                const char* b = QPEL ? baseP : baseF;
 #pragma unroll
                 for (int j = 0; j < IPT; j++)
-                {
-                    const int q = tid + j * GS, row = q / QX, c4 = (q % QX) * 4;
-                    acc[k] = Pk<P>::sad(ld_unaligned<Q>(r + (__mul24(row, (int)stride) + c4)), fq[j], acc[k]);
-                }
+                    acc[k] = Pk<P>::sad(ld_unaligned<Q>(b + (size_t)(r + qoffB[j])), fq[j], acc[k]);
             }
 #pragma unroll
             for (int k = 0; k < K; k++) costs[k] = wave64_sum_l63((int)acc[k]);
@@ -511,6 +528,9 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
     c.depth = depth;
     c.stride = strideR;
     c.cost = mvcostTab;
+    c.costBase = reinterpret_cast<const char*>(mvcostTab) - (size_t)TM::kCostBias * 2;
+    c.baseF = reinterpret_cast<const char*>(refPlane) - (size_t)TM::kBias * sizeof(P);
+    c.baseP = reinterpret_cast<const char*>(planes) - (size_t)TM::kBias * sizeof(P);
     c.fencL = fencS[team];
     c.part = partS[team];
     c.phase = 0;
@@ -552,6 +572,7 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
         c.fref = refPlane + (int64_t)by * strideR + bx;
         c.plane0 = PLANES ? planes + (int64_t)by * strideR + bx : nullptr;
         c.planeElems = planeElems;
+        c.org = (TM::kBias + (uint32_t)(by * (int)strideR + bx)) * (uint32_t)sizeof(P);
         // source block: registers (SAD mapping) + LDS (tile stage)
         c.team_barrier();                                               // previous PU's tile reads are done
         {
@@ -561,6 +582,7 @@ __global__ __launch_bounds__(256, ME2_MIN_WAVES) void motion2_kernel(const P* __
             {
                 const int q = (TM::NG == 1 ? c.tid : (c.lane & 15)) + j * TM::GS, row = q / TM::QX, c4 = (q % TM::QX) * 4;
                 c.fq[j] = ld_unaligned<Q>(f + (int64_t)row * strideF + c4);
+                c.qoffB[j] = (uint32_t)(row * (int)strideR + c4) * (uint32_t)sizeof(P);
                 if (TM::NG == 1 || c.lane < 16)
                     *reinterpret_cast<Q*>(c.fencL + row * N + c4) = c.fq[j];
             }
