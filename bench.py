@@ -49,6 +49,58 @@ def cpu_baseline(frames):
             "sample": "%d frame passes of the same 1920x1080 workload (oracle/x265_oracle_frame.c, gcc -O2, 1 thread, %.1f s)" % (frames, dt)}
 
 
+def _cpu_chain(frames, start_at=0.0):
+    """One independent chain of `frames` oracle frame passes in a worker process, started at wall-clock time `start_at` (so that all workers
+    run at the same time); returns (start, end) wall-clock times."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from frame_oracle import oracle_frame_pass
+    from x265_amd.synth import make_scene_yuv
+    sc = make_scene_yuv(W, H, depth=DEPTH, seed=4321 + os.getpid() % 7)
+    crop = lambda a, hh, ww: np.ascontiguousarray(a[:hh, :ww])  # noqa: E731
+    oracle_frame_pass(crop(sc["src"], 136, 200), crop(sc["ref"], 136, 200), depth=DEPTH, qp=QP,
+                      src_c=(crop(sc["src_cb"], 68, 100), crop(sc["src_cr"], 68, 100)),
+                      ref_c=(crop(sc["ref_cb"], 68, 100), crop(sc["ref_cr"], 68, 100)))
+    while time.time() < start_at:
+        time.sleep(0.01)
+    t0 = time.time()
+    ref, ref_c = sc["ref"], (sc["ref_cb"], sc["ref_cr"])
+    for _ in range(frames):
+        r = oracle_frame_pass(sc["src"], ref, depth=DEPTH, qp=QP, merange=MERANGE, method=1, subme=SUBME,
+                              src_c=(sc["src_cb"], sc["src_cr"]), ref_c=ref_c)
+        ref = np.ascontiguousarray(r["recon"][96:96 + H, 96:96 + W])
+        ref_c = tuple(np.ascontiguousarray(p[48:48 + H // 2, 48:48 + W // 2]) for p in r["recon_c"])
+    return t0, time.time()
+
+
+def cpu_baseline_parallel(frames_per_chain=4, max_procs=64, timeout_s=120):
+    """The same port on many host cores: one independent frame chain per worker process (frame-level parallelism, like the GPU's chains);
+    throughput = all frames / (last end - first start).  Context beside the single-core figure.  Plain subprocesses with a hard timeout:
+    this leg must never be able to hang the bench."""
+    procs = max(1, min(max_procs, (os.cpu_count() or 1)))
+    start_at = time.time() + 10.0                      # workers build their scene first (a few seconds), then all start together
+    code = "import sys; sys.path.insert(0, %r); import bench; print('SPAN %%.6f %%.6f' %% bench._cpu_chain(%d, %.3f))" % (ROOT, frames_per_chain, start_at)
+    env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="")
+    ps = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(procs)]
+    spans, deadline = [], time.time() + timeout_s
+    for p in ps:
+        try:
+            out, _ = p.communicate(timeout=max(1.0, deadline - time.time()))
+            for line in out.splitlines():
+                if line.startswith("SPAN"):
+                    spans.append(tuple(float(v) for v in line.split()[1:3]))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.communicate()
+    if not spans:
+        return {"error": "no worker finished within %d s" % timeout_s}
+    wall = max(e for _, e in spans) - min(s for s, _ in spans)
+    late = sum(1 for s0, _ in spans if s0 > start_at + 0.5)
+    return {"value": len(spans) * frames_per_chain / wall, "unit": "frames/s", "cores": len(spans), "kind": "port",
+            "sample": "%d processes x %d chained frame passes of the same workload started together, %.1f s%s"
+                      % (len(spans), frames_per_chain, wall, (" (%d workers started late)" % late) if late else "")}
+
+
 def reference_encoder(frames=12):
     """Context only: the REAL reference CLI ([noasm] C path, built into oracle/_ref by oracle/Makefile) encoding the same
     kind of clip at 1080p preset medium --me hex on all host cores.  A full encoder, not the same workload."""
@@ -340,6 +392,7 @@ def main():
         }
         if world == 1 and args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_frames)
+            out["cpu_baseline_parallel"] = cpu_baseline_parallel()
             if not args.no_ref_encoder:
                 out["reference_encoder"] = reference_encoder()
         print(json.dumps(out), flush=True)
