@@ -143,12 +143,12 @@ _refs = {}
 
 
 def ref_available(depth):
-    return os.path.exists(os.path.join(REF_DIR, "libx265ref%d.so" % (8 if depth == 8 else 10)))
+    return os.path.exists(os.path.join(REF_DIR, "libx265ref%d.so" % (depth if depth in (8, 10, 12) else 10)))
 
 
 def ref(depth):
-    """The real reference build for `depth` (8 or 10). Raises FileNotFoundError if oracle/_ref was not built."""
-    key = 8 if depth == 8 else 10
+    """The real reference build for `depth` (8, 10 or 12). Raises FileNotFoundError if oracle/_ref was not built."""
+    key = depth if depth in (8, 10, 12) else 10
     if key in _refs:
         return _refs[key]
     path = os.path.join(REF_DIR, "libx265ref%d.so" % key)

@@ -888,8 +888,8 @@ def test_lookahead_b_cost_matches_oracle(hipmod, depth):
 
 
 def test_twelve_bit_primitives_match_oracle(hipmod):
-    """depth 12 (u16 pixels, the third X265_DEPTH): same sweep against the oracle restatement (the real-reference pin covers
-    8 and 10 bit; the 12-bit arithmetic differs only in the shift / clip constants the oracle derives from `depth`)."""
+    """depth 12 (u16 pixels, the third X265_DEPTH): same sweep against the oracle restatement, whose 12-bit arithmetic is pinned to a Main12
+    build of the reference on the CPU side (oracle/Makefile ref12, tests/test_oracle_vs_ref.py DEPTHS)."""
     o, g = Orc(12), hipmod.Hip(12)
     bad, n = [], 0
     for label, fn, args in gen_cases(12, seed=777, reps=1):

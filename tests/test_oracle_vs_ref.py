@@ -8,7 +8,7 @@ from backends import Orc, Ref, same
 from cases import gen_cases, me_scene
 from oracle import pyoracle as po
 
-DEPTHS = [8, 10]
+DEPTHS = [8, 10, 12]          # Main, Main10, Main12 builds of the reference (oracle/Makefile ref8 / ref10 / ref12)
 
 
 def _need_ref(depth):
