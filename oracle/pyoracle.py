@@ -1,7 +1,7 @@
 """pyoracle — TEST INFRASTRUCTURE ONLY.
 
 ctypes loaders for (1) oracle/libx265oracle.so, our plain-C restatement of the x265 C primitives, and
-(2) oracle/_ref/libx265ref{8,10}.so, the REAL reference compiled by oracle/Makefile.  Only tests/,
+(2) oracle/_ref/libx265ref{8,10,12}.so, the REAL reference compiled by oracle/Makefile.  Only tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; nothing under x265_amd/ does.
 """
 import ctypes as C

@@ -5,7 +5,7 @@
  * leg may load this library; the product path (x265_amd/, libx265hip.so) never does.
  *
  * Parity status: PINNED — every function here is checked bit-for-bit against the real reference
- * (oracle/_ref/libx265ref{8,10}.so, compiled from /root/reference/source by oracle/Makefile) in
+ * (oracle/_ref/libx265ref{8,10,12}.so, compiled from /root/reference/source by oracle/Makefile) in
  * tests/test_oracle_vs_ref.py, and against digests of reference outputs committed under tests/golden/.
  *
  * Conventions: strides are in ELEMENTS (as in x265). `depth` is the internal bit depth (8, 10 or 12);
