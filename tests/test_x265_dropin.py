@@ -26,7 +26,7 @@ def _need(name):
     return p
 
 
-@pytest.mark.parametrize("bits", [8, 10])
+@pytest.mark.parametrize("bits", [8, 10, 12])
 def test_reference_testbench_passes_with_gpu_primitives(bits):
     exe = _need("TestBench_hip%d" % bits)
     env = dict(os.environ, X265HIP_VERBOSE="1")
@@ -61,6 +61,8 @@ ENCODES = {
     "slow-star": (8, 4, ["--preset", "slow", "--me", "star", "--merange", "57", "--keyint", "4", "--rc-lookahead", "3", "--bframes", "1"]),
     # the shape of configs[3]: Main10 preset slower --rd 6 (RDOQ level 2 and its coefficient-scan cost helpers, psy-rdoq, subme 4)
     "slower-rd6-main10": (10, 4, ["--preset", "slower", "--rd", "6", "--keyint", "4", "--rc-lookahead", "3", "--bframes", "1"]),
+    # Main12 build
+    "b-medium-main12": (12, 4, ["--preset", "medium", "--keyint", "4", "--rc-lookahead", "3", "--bframes", "1"]),
     # uneven multi-hexagon search
     "umh-medium": (8, 4, ["--preset", "medium", "--me", "umh", "--keyint", "4", "--rc-lookahead", "3", "--bframes", "1"]),
 }
