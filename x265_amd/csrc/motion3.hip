@@ -41,6 +41,27 @@ template <> struct Pk3<uint16_t>
     static __device__ __forceinline__ void unpack(T a, int v[4]) { v[0] = a.x & 0xffff; v[1] = a.x >> 16; v[2] = a.y & 0xffff; v[3] = a.y >> 16; }
 };
 
+// ---- packed 16-bit SATD arithmetic.  Every value of a 4x4 Hadamard of pixel differences is at most 16 * (2^depth - 1): 4080 at 8 bit,
+// 16368 at 10 bit — inside int16 — so two values share a register (v_pk_add / v_pk_sub / v_pk_mad / v_pk_max, one DPP move for two),
+// which halves the instruction count of the sub-pel comparisons.  12-bit pixels (65520) keep the 32-bit path.
+typedef short s2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s2v as_s2(uint32_t v) { return __builtin_bit_cast(s2v, v); }
+__device__ __forceinline__ uint32_t as_u(s2v v) { return __builtin_bit_cast(uint32_t, v); }
+template <typename P> struct Pk16;
+template <> struct Pk16<uint8_t>
+{
+    // bytes 0,1 -> (lo, hi) halves of one register, bytes 2,3 -> the other (v_perm_b32; selector 0x0c = constant zero byte)
+    static __device__ __forceinline__ void split(uint32_t a, s2v& p01, s2v& p23)
+    {
+        p01 = as_s2(__builtin_amdgcn_perm(0u, a, 0x0c010c00u));
+        p23 = as_s2(__builtin_amdgcn_perm(0u, a, 0x0c030c02u));
+    }
+};
+template <> struct Pk16<uint16_t>
+{
+    static __device__ __forceinline__ void split(uint2 a, s2v& p01, s2v& p23) { p01 = as_s2(a.x); p23 = as_s2(a.y); }
+};
+
 // dpp_all / row_allsum (16-lane DPP all-reduce) live in common.h
 
 __device__ __constant__ const uint8_t kWorkloadC[8][5] = { {1,4,0,4,0}, {1,4,1,4,0}, {1,4,1,4,1}, {2,4,1,4,1}, {2,4,2,4,1}, {1,8,1,8,1}, {2,8,1,8,1}, {2,8,2,8,1} }; // motion.cpp:48-58
@@ -95,6 +116,8 @@ struct RowTeam
     int qoff[IPT];                                     // element offset of this lane's quads inside the PU (row * stride + col)
     Q fq[IPT];
     int fu[IPT][4];
+    s2v fp[IPT][2];                                    // the same source samples as packed pairs (0,1) and (2,3)
+    bool pk16;                                         // depth <= 10: packed 16-bit SATD
     // bChromaSATD (4:2:0): the chroma block is (N/2)^2 per plane = N*N/16 quads; a lane holds one quad per pass.  8x8 PUs put Cb in
     // lanes 0-3 and Cr in lanes 4-7 of one pass, 16x16 / 32x32 PUs take one pass per plane with every lane busy.
     static constexpr int CPASS = N == 8 ? 1 : 2;
@@ -131,6 +154,32 @@ struct RowTeam
         const uint32_t r = cand(q);
         const bool hi1 = s & 1, hi2 = s & 2;
         int acc = 0;
+        if (sizeof(P) == 1 || pk16)                  // 8-bit: always (the 32-bit path below is not even compiled in)
+        {
+            const s2v one = { 1, 1 }, kh = { 1, -1 };
+            const s2v k1 = hi1 ? -one : one, k2 = hi2 ? -one : one;
+#pragma unroll
+            for (int j = 0; j < IPT; j++)
+            {
+                s2v p01, p23;
+                Pk16<P>::split(ld_off<Q>(r + (uint32_t)qoff[j]), p01, p23);
+                const s2v d01 = fp[j][0] - p01, d23 = fp[j][1] - p23;
+                const s2v A = d01 + d23, B = d01 - d23;                          // (d0+d2, d1+d3), (d0-d2, d1-d3)
+                const s2v Ar = as_s2(__builtin_amdgcn_alignbit(as_u(A), as_u(A), 16)), Br = as_s2(__builtin_amdgcn_alignbit(as_u(B), as_u(B), 16));
+                s2v m01 = Ar * kh + A, m23 = Br * kh + B;                        // (h0, -h1), (h2, -h3): signs do not matter below
+                s2v pr = as_s2((uint32_t)__builtin_amdgcn_mov_dpp((int)as_u(m01), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+                m01 = m01 * k1 + pr;
+                pr = as_s2((uint32_t)__builtin_amdgcn_mov_dpp((int)as_u(m23), 0xB1, 0xF, 0xF, true));
+                m23 = m23 * k1 + pr;
+                pr = as_s2((uint32_t)__builtin_amdgcn_mov_dpp((int)as_u(m01), 0x4E, 0xF, 0xF, true));         // quad_perm [2,3,0,1]
+                m01 = m01 * k2 + pr;
+                pr = as_s2((uint32_t)__builtin_amdgcn_mov_dpp((int)as_u(m23), 0x4E, 0xF, 0xF, true));
+                m23 = m23 * k2 + pr;
+                acc = __builtin_amdgcn_sdot2(__builtin_elementwise_max(m01, -m01), one, acc, false);
+                acc = __builtin_amdgcn_sdot2(__builtin_elementwise_max(m23, -m23), one, acc, false);
+            }
+            return team_allsum<TEAM>(acc) >> 1;
+        }
 #pragma unroll
         for (int j = 0; j < IPT; j++)
         {
@@ -234,6 +283,7 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
     c.planeElems = planeElems;
     c.smallPlane = planeElems < (1 << 24);
     c.cost = mvcostTab;
+    c.pk16 = depth <= 10;
     c.costBase = reinterpret_cast<const char*>(mvcostTab) - (size_t)RT::kCostBias * 2;
     c.base = reinterpret_cast<const char*>(planes) - (size_t)RT::kBias * sizeof(P);
     // XCD-aware block order (see motion2.hip): XCD x works on the x-th contiguous eighth of the raster-ordered PU list
@@ -279,6 +329,8 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
             c.qoff[j] = (row * (int)strideR + col) * (int)sizeof(P);          // bytes
             c.fq[j] = ld_unaligned<Q>(f + (int64_t)row * strideF + col);
             Pk3<P>::unpack(c.fq[j], c.fu[j]);
+            c.fp[j][0] = s2v{ (short)c.fu[j][0], (short)c.fu[j][1] };
+            c.fp[j][1] = s2v{ (short)c.fu[j][2], (short)c.fu[j][3] };
         }
     }
     if (CHROMA)
