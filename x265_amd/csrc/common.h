@@ -44,6 +44,27 @@ __device__ __forceinline__ void st_unaligned(P* p, T v)
     __builtin_memcpy(p, &v, sizeof(T));
 }
 
+// ---- packed 16-bit SATD arithmetic.  Every value of a 4x4 Hadamard of pixel differences is at most 16 * (2^depth - 1): 4080 at 8 bit,
+// 16368 at 10 bit — inside int16 — so two values share a register (v_pk_add / v_pk_sub / v_pk_mad / v_pk_max, one DPP move for two),
+// which halves the instruction count of the sub-pel comparisons.  12-bit pixels (65520) keep the 32-bit path.
+typedef short s2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s2v as_s2(uint32_t v) { return __builtin_bit_cast(s2v, v); }
+__device__ __forceinline__ uint32_t as_u(s2v v) { return __builtin_bit_cast(uint32_t, v); }
+template <typename P> struct Pk16;
+template <> struct Pk16<uint8_t>
+{
+    // bytes 0,1 -> (lo, hi) halves of one register, bytes 2,3 -> the other (v_perm_b32; selector 0x0c = constant zero byte)
+    static __device__ __forceinline__ void split(uint32_t a, s2v& p01, s2v& p23)
+    {
+        p01 = as_s2(__builtin_amdgcn_perm(0u, a, 0x0c010c00u));
+        p23 = as_s2(__builtin_amdgcn_perm(0u, a, 0x0c030c02u));
+    }
+};
+template <> struct Pk16<uint16_t>
+{
+    static __device__ __forceinline__ void split(uint2 a, s2v& p01, s2v& p23) { p01 = as_s2(a.x); p23 = as_s2(a.y); }
+};
+
 // 4 horizontally adjacent pixels as ints
 __device__ __forceinline__ void load4(const uint8_t* p, int v[4])
 {

@@ -398,6 +398,42 @@ struct Team
         for (int t = s; t < TILES; t += G)
         {
             const int ty = t / TX, tx = t % TX;
+            if (PLANES && sizeof(P) == 1 && cmp)
+            {
+                // 8-bit SATD of one 4x4 tile on packed 16-bit pairs (see common.h): rows as ((c0, c1), (c2, c3)); the vertical butterflies
+                // are plain packed adds across the four row registers, the horizontal ones rotate a register by 16 bits
+                const P* pp = plane0 + (int64_t)(yFrac * 4 + xFrac) * planeElems + (int64_t)((q.y >> 2) + ty * 4) * stride + (q.x >> 2) + tx * 4;
+                s2v a[4], b[4];
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+                {
+                    s2v p01, p23, f01, f23;
+                    Pk16<uint8_t>::split(ld_unaligned<uint32_t>(pp + y * stride), p01, p23);
+                    Pk16<uint8_t>::split(*reinterpret_cast<const uint32_t*>(fencL + (ty * 4 + y) * N + tx * 4), f01, f23);
+                    a[y] = f01 - p01;
+                    b[y] = f23 - p23;
+                }
+                const s2v one = { 1, 1 }, kh = { 1, -1 };
+                int tile = 0;
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                {
+                    s2v* v = h ? b : a;
+                    const s2v s0 = v[0] + v[1], e0 = v[0] - v[1], s1 = v[2] + v[3], e1 = v[2] - v[3];
+                    v[0] = s0 + s1; v[1] = e0 + e1; v[2] = s0 - s1; v[3] = e0 - e1;
+                }
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+                {
+                    const s2v A = a[y] + b[y], B = a[y] - b[y];
+                    const s2v Ar = as_s2(__builtin_amdgcn_alignbit(as_u(A), as_u(A), 16)), Br = as_s2(__builtin_amdgcn_alignbit(as_u(B), as_u(B), 16));
+                    const s2v m01 = Ar * kh + A, m23 = Br * kh + B;
+                    tile = __builtin_amdgcn_sdot2(__builtin_elementwise_max(m01, -m01), one, tile, false);
+                    tile = __builtin_amdgcn_sdot2(__builtin_elementwise_max(m23, -m23), one, tile, false);
+                }
+                acc += tile >> 1;
+                continue;
+            }
             int p[16], f[16];
             if (PLANES)
             {

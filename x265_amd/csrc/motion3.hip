@@ -41,27 +41,7 @@ template <> struct Pk3<uint16_t>
     static __device__ __forceinline__ void unpack(T a, int v[4]) { v[0] = a.x & 0xffff; v[1] = a.x >> 16; v[2] = a.y & 0xffff; v[3] = a.y >> 16; }
 };
 
-// ---- packed 16-bit SATD arithmetic.  Every value of a 4x4 Hadamard of pixel differences is at most 16 * (2^depth - 1): 4080 at 8 bit,
-// 16368 at 10 bit — inside int16 — so two values share a register (v_pk_add / v_pk_sub / v_pk_mad / v_pk_max, one DPP move for two),
-// which halves the instruction count of the sub-pel comparisons.  12-bit pixels (65520) keep the 32-bit path.
-typedef short s2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ s2v as_s2(uint32_t v) { return __builtin_bit_cast(s2v, v); }
-__device__ __forceinline__ uint32_t as_u(s2v v) { return __builtin_bit_cast(uint32_t, v); }
-template <typename P> struct Pk16;
-template <> struct Pk16<uint8_t>
-{
-    // bytes 0,1 -> (lo, hi) halves of one register, bytes 2,3 -> the other (v_perm_b32; selector 0x0c = constant zero byte)
-    static __device__ __forceinline__ void split(uint32_t a, s2v& p01, s2v& p23)
-    {
-        p01 = as_s2(__builtin_amdgcn_perm(0u, a, 0x0c010c00u));
-        p23 = as_s2(__builtin_amdgcn_perm(0u, a, 0x0c030c02u));
-    }
-};
-template <> struct Pk16<uint16_t>
-{
-    static __device__ __forceinline__ void split(uint2 a, s2v& p01, s2v& p23) { p01 = as_s2(a.x); p23 = as_s2(a.y); }
-};
-
+// packed 16-bit SATD helpers (s2v, Pk16) live in common.h
 // dpp_all / row_allsum (16-lane DPP all-reduce) live in common.h
 
 __device__ __constant__ const uint8_t kWorkloadC[8][5] = { {1,4,0,4,0}, {1,4,1,4,0}, {1,4,1,4,1}, {2,4,1,4,1}, {2,4,2,4,1}, {1,8,1,8,1}, {2,8,1,8,1}, {2,8,2,8,1} }; // motion.cpp:48-58
