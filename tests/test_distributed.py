@@ -1,4 +1,4 @@
-"""world_size-2 gloo tests (CPU) of the frame-parallel path: the ring exchange itself, and a two-rank emulation of the
+"""world_size-2 and -3 gloo tests (CPU) of the frame-parallel path: the ring exchange itself, and a two-rank emulation of the
 bench loop in which the oracle stands in for the GPU frame pass — the frames each rank produces must equal the frames a
 single process produces when it follows the same reference schedule."""
 import os
@@ -77,8 +77,8 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_ring_exchange_two_ranks_matches_sequential_schedule(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_ring_exchange_two_ranks_matches_sequential_schedule(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     got = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r)) for r in range(world)]
     # single-process emulation of the same schedule
@@ -92,10 +92,11 @@ def test_ring_exchange_two_ranks_matches_sequential_schedule(tmp_path):
         refs = [recs[(r - 1) % world] for r in range(world)]
 
 
-def test_frame_chains_two_ranks_match_the_reference_relation(tmp_path):
-    """F = 2 chains per rank, 2 ranks: every reconstruction equals what the dependency rule gives — chain j references chain j-1 of the same
-    rank one step earlier, chain 0 references the last chain of the previous rank one step earlier."""
-    world, F = 2, 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_frame_chains_two_ranks_match_the_reference_relation(tmp_path, world):
+    """F = 2 chains per rank, 2 (and 3: an odd ring) ranks: every reconstruction equals what the dependency rule gives — chain j references
+    chain j-1 of the same rank one step earlier, chain 0 references the last chain of the previous rank one step earlier."""
+    F = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     got = [np.load(os.path.join(str(tmp_path), "chains%d.npy" % r)) for r in range(world)]       # [step][chain]
     prev = [[_scene(2000 + 10 * r + j)["ref"] for j in range(F)] for r in range(world)]           # references of step 0
