@@ -73,12 +73,12 @@ def _cpu_chain(frames, start_at=0.0):
     return t0, time.time()
 
 
-def cpu_baseline_parallel(frames_per_chain=4, max_procs=64, timeout_s=120):
+def cpu_baseline_parallel(frames_per_chain=4, max_procs=64, timeout_s=120, start_delay_s=10.0):
     """The same port on many host cores: one independent frame chain per worker process (frame-level parallelism, like the GPU's chains);
     throughput = all frames / (last end - first start).  Context beside the single-core figure.  Plain subprocesses with a hard timeout:
     this leg must never be able to hang the bench."""
     procs = max(1, min(max_procs, (os.cpu_count() or 1)))
-    start_at = time.time() + 10.0                      # workers build their scene first (a few seconds), then all start together
+    start_at = time.time() + start_delay_s             # workers build their scene first (a few seconds), then all start together
     code = "import sys; sys.path.insert(0, %r); import bench; print('SPAN %%.6f %%.6f' %% bench._cpu_chain(%d, %.3f))" % (ROOT, frames_per_chain, start_at)
     env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="")
     ps = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(procs)]

@@ -38,3 +38,18 @@ def test_oracle_frame_pass_properties():
     still = oracle_frame_pass(sc["ref"], sc["ref"])
     assert all(not x.any() for x in still["mv"]) and all(not x.any() for x in still["numSig"])
     assert np.array_equal(still["recon"][m:-m, m:-m], sc["ref"])
+
+
+def test_bench_parallel_cpu_baseline_leg_runs_and_is_bounded():
+    """bench.py's multi-process CPU leg (plain subprocesses with a hard timeout): two workers, one frame pass each, finishes and reports."""
+    import os
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    t0 = time.time()
+    r = bench.cpu_baseline_parallel(frames_per_chain=1, max_procs=2, timeout_s=90, start_delay_s=6.0)
+    assert "error" not in r, r
+    assert r["cores"] == 2 and r["value"] > 0 and r["kind"] == "port"
+    assert time.time() - t0 < 90
+
