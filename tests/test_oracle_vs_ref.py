@@ -133,6 +133,52 @@ def test_motion_compensation_matches_reference(depth):
 
 
 @pytest.mark.parametrize("depth", DEPTHS)
+@pytest.mark.parametrize("method", [1, 2, 3])
+def test_search_methods_random_stress_matches_reference(depth, method):
+    """HEX / UMH / STAR on smooth scenes with noise from none to heavy (so that the SAD thresholds of UMH and the early exits of STAR go both
+    ways), small and large ranges, tight vertical bounds, predictors near and far from the true motion: 240 random PUs per case."""
+    _need_ref(depth)
+    o, r = Orc(depth), Ref(depth)
+    sc = 1 << (depth - 8)
+    pmax = (1 << depth) - 1
+    n = 0
+    for seed in range(6):
+        rng = np.random.default_rng(7000 + 10 * seed + method)
+        sigma = [0, 0.5, 1, 3, 8, 30][seed] * sc
+        shift = (int(rng.integers(-9, 10)), int(rng.integers(-9, 10)))
+        m, H, W = 96, 192, 192
+        base = rng.integers(0, 256, size=((H + 2 * m) // 8 + 2, (W + 2 * m) // 8 + 2)).astype(np.float64)
+        big = np.kron(base, np.ones((8, 8)))[:H + 2 * m, :W + 2 * m]
+        big = (big + np.roll(big, 1, 0) + np.roll(big, 1, 1) + np.roll(big, 3, 0) + np.roll(big, 3, 1)) / 5
+        refp = np.clip(np.rint((big + rng.normal(0, 2, big.shape)) * sc), 0, pmax).astype(o.pix)
+        srcp = np.clip(np.rint(np.roll(refp.astype(np.float64), shift, (0, 1)) + rng.normal(0, sigma, big.shape)), 0, pmax).astype(o.pix)
+        for _ in range(40):
+            w, h = [(8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 24), (64, 32), (24, 32), (4, 8), (8, 4), (16, 12)][int(rng.integers(0, 12))]
+            bx = m + int(rng.integers(0, (W - w) // 4 + 1)) * 4
+            by = m + int(rng.integers(0, (H - h) // 4 + 1)) * 4
+            merange = int(rng.choice([4, 8, 16, 32, 57]))
+            if rng.integers(0, 2):
+                qmvp = (int(-shift[1] * 4 + rng.integers(-6, 7)), int(-shift[0] * 4 + rng.integers(-6, 7)))
+            else:
+                qmvp = (int(rng.integers(-40, 41)), int(rng.integers(-40, 41)))
+            mvmin = [(qmvp[0] >> 2) - merange, (qmvp[1] >> 2) - merange]
+            mvmax = [(qmvp[0] >> 2) + merange, (qmvp[1] >> 2) + merange]
+            k = int(rng.integers(0, 4))
+            if k == 0:
+                mvmax[1] = max(min(mvmax[1], int(rng.integers(0, 6))), mvmin[1])
+            if k == 1:
+                mvmin[1] = min(max(mvmin[1], int(rng.integers(-3, 4))), mvmax[1])
+            mvc = [((int(-shift[1] * 4 + rng.integers(-8, 9)), int(-shift[0] * 4 + rng.integers(-8, 9))) if rng.integers(0, 2)
+                    else (int(rng.integers(-60, 61)), int(rng.integers(-60, 61)))) for _ in range(int(rng.integers(0, 5)))]
+            subme, qp = int(rng.choice([0, 2, 3, 7])), int(rng.choice([22, 28, 37]))
+            a = o.motion_estimate(refp, srcp, bx, by, w, h, tuple(mvmin), tuple(mvmax), qmvp, mvc, merange, method, subme, qp)
+            b = r.motion_estimate(refp, srcp, bx, by, w, h, tuple(mvmin), tuple(mvmax), qmvp, mvc, merange, method, subme, qp)
+            assert a == b, (depth, method, seed, w, h, bx, by, merange, qmvp, mvmin, mvmax, mvc, subme, a, b)
+            n += 1
+    assert n == 240
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_umh_search_matches_reference(depth):
     """X265_UMH_SEARCH on scenes built to reach its early-termination, cross and adaptive-range branches (tests/cases.py umh_scenes)."""
     _need_ref(depth)
