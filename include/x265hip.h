@@ -484,14 +484,18 @@ int x265hip_lowres_intra_estimate(int depth, const void* plane, int64_t stride, 
  * (slicetype.cpp:3218-3385) for b == p1 over every 8x8 block of the lowres frame, i.e. per block: SATD of the already
  * known neighbour vectors (right, below, below-left, below-right; :3271-3307) -> start vector, the lowres flavour of
  * MotionEstimate::motionEstimate (HEX, merange 16, subpel refine 1: motion.cpp:775, :855-944, :1471-1501 with
- * Lowres::lowresQPelCost, lowres.h:94), + 4 against the block's intra cost, frame score over the non-edge blocks.
+ * Lowres::lowresQPelCost, lowres.h:94), + 4 against the block's intra cost, frame score over the non-edge blocks, and the
+ * AQ-scaled flavour of the score and of the row sums when `invQscale` is given (:3353-3384).
  * Rows are walked bottom-up in `numSlices` independent slices of `numRowsPerSlice` rows (the reference's cooperative
- * lookahead slices, :3092-3104; 1 slice = the serial loop :3170-3179).  No AQ, no weighted reference, no HME.
+ * lookahead slices, :3092-3104; 1 slice = the serial loop :3170-3179).  No HME.  A weighted reference (weightp) is the same
+ * pass with `ref` pointing at the weighted planes (x265hip_lookahead_weights_analyse).
  * All pairs share the geometry; planes are border-extended lowres planes (x265hip_lowres_init), `ref` = hpel plane 0 of
  * the reference with planes 1..3 `planeElems` elements apart.  `sync` is ncu u64 of scratch per pair, zeroed once when
- * allocated; `epoch` must be non-zero and differ from every earlier call that used the same scratch.
- * `pairs` is a DEVICE array.  costEst[i] = { costEst, intraMbs } of pair i; a negative intraMbs means the row handshake timed out (stale
- * `sync` scratch or a reused epoch) and the pair's outputs are invalid. */
+ * allocated; `epoch` must be non-zero and differ from every earlier call that used the same scratch (the caller owns that
+ * rule: a reused epoch is NOT detected — stale handshake words would be taken for this call's; x265hip_la_* below owns its
+ * scratch and epochs).  `pairs` is a DEVICE array.
+ * est[4 i ..] = { costEst, costEstAq, intraMbs, status } of pair i (int64 each); status != 0 means the row handshake timed
+ * out (a `sync` scratch that was not zeroed) and the pair's outputs are invalid. */
 typedef struct x265hip_lookahead_pair
 {
     const void*    fenc;         /* lowresPlane[0] origin of the frame being costed */
@@ -502,18 +506,23 @@ typedef struct x265hip_lookahead_pair
     uint16_t*      lowresCosts;  /* out [ncu]     min(cost, 16383) | listused << 14 */
     int32_t*       rowSatds;     /* out [heightInCU] */
     uint64_t*      sync;         /* scratch [ncu] */
+    const int32_t* invQscale;    /* [ncu] Lowres::invQscaleFactor (invQscaleFactor8x8 for qg-size 8) of the frame being costed, or NULL: no AQ */
     int32_t        bidirList;    /* 0: P frame (everything above).  1: one list of a B frame: the search applies the bidir skip rule
                                     (slicetype.cpp:3303-3317) and only mvs / mvCosts are written; finish with x265hip_lookahead_bidir_batch */
     int32_t        reserved;
 } x265hip_lookahead_pair;
 int x265hip_lookahead_cost_p_batch(int depth, const x265hip_lookahead_pair* pairs, int nPairs, int64_t stride, int64_t planeElems,
                                    int widthInCU, int heightInCU, int numRowsPerSlice, int numSlices,
-                                   const uint16_t* mvcost, uint32_t epoch, int32_t* costEst, void* stream);
+                                   const uint16_t* mvcost, uint32_t epoch, int64_t* est, void* stream);
+/* The same bookkeeping for a P estimate whose list-0 search was done before (bDoSearch[0] == false, slicetype.cpp:3260-3264): cost from the
+ * stored mvCosts (an INPUT here; mvs / sync / ref unused) + 4 against intra, packed lowresCosts, rowSatds, est as above. */
+int x265hip_lookahead_pcost_batch(const x265hip_lookahead_pair* pairs, int nPairs, int widthInCU, int heightInCU, int64_t* est, void* stream);
 
 /* B frames (p0 < b < p1): run the two list searches as pairs with bidirList = 1 (a list that was searched before keeps its stored
  * vectors and costs, slicetype.cpp:3126-3127, :3260-3264), then this pass over every block: cheapest of the two lists, the average
  * of the two motion-compensated blocks and the co-located average by SATD (:3320-3338), + 4, packed lowresCosts, rowSatds, and
- * costEst[i] = raw sum over the non-edge blocks (the caller scales by 100 / (130 + bFrameBias), :3183-3186).  `frames` is a DEVICE array. */
+ * est[2 i ..] = { raw sum over the non-edge blocks, its AQ-scaled flavour } (int64; the caller scales costEst by 100 / (130 + bFrameBias),
+ * :3183-3186).  `frames` is a DEVICE array. */
 typedef struct x265hip_lookahead_bframe
 {
     const void*    fenc;         /* lowresPlane[0] origin of the B frame */
@@ -525,9 +534,64 @@ typedef struct x265hip_lookahead_bframe
     const int32_t* mvCosts1;     /* [ncu] */
     uint16_t*      lowresCosts;  /* out [ncu] */
     int32_t*       rowSatds;     /* out [heightInCU] */
+    const int32_t* invQscale;    /* [ncu] or NULL, as in x265hip_lookahead_pair */
 } x265hip_lookahead_bframe;
 int x265hip_lookahead_bidir_batch(int depth, const x265hip_lookahead_bframe* frames, int nFrames, int64_t stride, int64_t planeElems,
-                                  int widthInCU, int heightInCU, int32_t* costEst, void* stream);
+                                  int widthInCU, int heightInCU, int64_t* est, void* stream);
+
+/* ---------------------------------------------------------------- the lookahead session (x265's batching seam) ---- */
+/* What an x265 build binds where the reference itself batches lookahead work: CostEstimateGroup::add / finishBatch
+ * (slicetype.cpp:3027-3048, up to 512 estimates per batch) and estimateFrameCost (:3115-3214).  The session mirrors x265's Lowres
+ * (common/lowres.h:152) in HBM: a frame SLOT holds the four padded half-resolution planes, the per-8x8 intra costs and AQ factors,
+ * and per (list, distance) the vectors and costs of every motion search done so far.  One estimate = slot indices + which lists to
+ * search; a batch = one launch of every list search, one of every P bookkeeping pass, one of every B pass, one copy back.
+ * x265_amd/host/x265_hip_lookahead.cpp is the x265-side binding.  All pointers are HOST pointers;
+ * calls block until their results are in host memory; a session serialises its callers. */
+typedef struct x265hip_la x265hip_la;
+typedef struct x265hip_la_config
+{
+    int32_t depth;                   /* 8 / 10 / 12 */
+    int32_t width, lines;            /* Lowres::width, Lowres::lines (lowres picture, pixels) */
+    int64_t stride;                  /* Lowres::lumaStride */
+    int64_t planeElems;              /* Lowres::buffer[1] - buffer[0] (padded plane, elements) */
+    int64_t padOffset;               /* Lowres::lowresPlane[0] - buffer[0] */
+    int32_t widthInCU, heightInCU;   /* Lookahead::m_8x8Width, m_8x8Height */
+    int32_t maxDist;                 /* bframes + 2: (list, distance) entries per frame (lowres.cpp:135-150) */
+    int32_t numSlots;                /* frames resident at once (lookahead depth + bframes + the reference's slack) */
+} x265hip_la_config;
+x265hip_la* x265hip_la_create(const x265hip_la_config* cfg);          /* NULL on failure: x265hip_last_error() */
+void x265hip_la_destroy(x265hip_la* la);
+/* Lowres::init + lowresIntraEstimate + calcAdaptiveQuantFrame results of a frame entering the lookahead: `buffers` = the four padded
+ * planes, contiguous (Lowres::buffer[0], 4 * planeElems pixels); intraCost [ncu]; invQscale [ncu] (invQscaleFactor, or
+ * invQscaleFactor8x8 for qg-size 8) or NULL when the encoder allocates none.  Forgets every vector stored for the slot. */
+int x265hip_la_set_frame(x265hip_la* la, int slot, const void* buffers, const int32_t* intraCost, const int32_t* invQscale);
+/* vectors of a search the session has not seen (done by another path): mvs [ncu][2] quarter-pel, mvCosts [ncu] */
+int x265hip_la_put_vectors(x265hip_la* la, int slot, int list, int dist, const int32_t* mvs, const int32_t* mvCosts);
+int x265hip_la_has_vectors(x265hip_la* la, int slot, int list, int dist);
+/* LookaheadTLD::weightsAnalyse (slicetype.cpp:860-960) of frame slotB against slotRef from the frames' wp_ssd[0] / wp_sum[0]: *isWeighted,
+ * *chosen, and — when weighted — *weightedId naming the weighted planes for the NEXT x265hip_la_estimate_batch (they live until that call
+ * returns, like the reference's per-thread wbuffer lives until the next analysis). */
+int x265hip_la_weights_analyse(x265hip_la* la, int slotB, int slotRef, uint64_t fencSsd, uint64_t fencSum, uint64_t refSsd, uint64_t refSum,
+                               x265hip_weight_param* chosen, int* isWeighted, int* weightedId);
+typedef struct x265hip_la_estimate
+{
+    int32_t   b, p0, p1;             /* slots; p1 == b: P estimate */
+    int32_t   dist0, dist1;          /* b - p0, p1 - b in frames */
+    int32_t   search0, search1;      /* bDoSearch[] (slicetype.cpp:3125-3127); a list that is not searched uses the session's stored vectors */
+    int32_t   weightedId;            /* -1, or x265hip_la_weights_analyse's id: list 0 searches the weighted planes */
+    int32_t*  mvs0;                  /* out when search0: Lowres::lowresMvs[0][dist0] ([ncu] MV = 2 x int32) */
+    int32_t*  mvCosts0;              /* out when search0: lowresMvCosts[0][dist0] */
+    int32_t*  mvs1;                  /* out when search1 */
+    int32_t*  mvCosts1;
+    uint16_t* lowresCosts;           /* out: lowresCosts[dist0][dist1] */
+    int32_t*  rowSatds;              /* out: rowSatds[dist0][dist1] */
+    int64_t   costEst, costEstAq;    /* out: sums over the non-edge blocks, before the B-frame scaling (:3183-3186) */
+    int32_t   intraMbs, reserved;    /* out (P estimates) */
+} x265hip_la_estimate;
+/* numRowsPerSlice / numSlices: the cooperative-slice geometry the reference would use for these estimates (1 slice of heightInCU rows in
+ * batch mode, m_numCoopSlices otherwise, :3141-3180) */
+int x265hip_la_estimate_batch(x265hip_la* la, x265hip_la_estimate* est, int n, int numRowsPerSlice, int numSlices);
+int x265hip_la_stats(x265hip_la* la, uint64_t* batches, uint64_t* estimates, uint64_t* searches);
 
 /* ---------------------------------------------------------------- per-call entry points (host pointers) ----- */
 /* What the reference-side table shims bind (x265_amd/host/x265_hip_primitives.cpp).  Arguments are the slot's own

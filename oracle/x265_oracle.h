@@ -111,6 +111,15 @@ void orc_set_search_range(int picW, int picH, int maxCUSize, int merange, int re
 int64_t orc_lookahead_cost_p_##SFX(const P* fencPlane, const P* const* ref, intptr_t stride, int widthInCU, int heightInCU, \
                                    int numRowsPerSlice, int numSlices, int depth, const int32_t* intraCost, const uint16_t* mvcost, \
                                    int32_t* mvs, int32_t* mvCosts, uint16_t* lowresCosts, int32_t* rowSatds, int32_t* intraMbs); \
+/* the two passes with the AQ-scaled sums (slicetype.cpp:3362-3384) and, for P, the reuse of a stored search (:3260-3264) */ \
+int64_t orc_lookahead_cost_p_aq_##SFX(const P* fencPlane, const P* const* ref, intptr_t stride, int widthInCU, int heightInCU, \
+                                      int numRowsPerSlice, int numSlices, int depth, const int32_t* intraCost, const uint16_t* mvcost, \
+                                      int32_t* mvs, int32_t* mvCosts, uint16_t* lowresCosts, int32_t* rowSatds, int32_t* intraMbs, \
+                                      const int32_t* invQscale, int doSearch, int64_t* costEstAq); \
+int64_t orc_lookahead_cost_b_aq_##SFX(const P* fencPlane, const P* const* ref0, const P* const* ref1, intptr_t stride, int widthInCU, int heightInCU, \
+                                      int numRowsPerSlice, int numSlices, int depth, const uint16_t* mvcost, const int32_t doSearch[2], \
+                                      int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1, uint16_t* lowresCosts, int32_t* rowSatds, \
+                                      const int32_t* invQscale, int64_t* costEstAq); \
 /* the same for a B frame (p0 < b < p1): two lists + the two bi-predictive candidates (slicetype.cpp:3254-3350) */ \
 int64_t orc_lookahead_cost_b_##SFX(const P* fencPlane, const P* const* ref0, const P* const* ref1, intptr_t stride, int widthInCU, int heightInCU, \
                                    int numRowsPerSlice, int numSlices, int depth, const uint16_t* mvcost, const int32_t doSearch[2], \

@@ -1,0 +1,206 @@
+/* la_emul.c — TEST INFRASTRUCTURE ONLY.  The lookahead-session part of the C ABI (include/x265hip.h, x265hip_la_*) implemented on the CPU
+ * with the oracle's restatement (oracle/x265_oracle*.c), built into tests/support/libx265hip_emul.so.  It exists so that the x265-side binding
+ * (x265_amd/host/x265_hip_lookahead.cpp: slot management, batching, what is written back into x265's Lowres arrays) can be proven
+ * byte-identical against the unmodified reference encoder in this GPU-less container: oracle/_ref/x265_emul_8bit = reference objects + the
+ * binding + THIS library, compared with oracle/_ref/x265_8bit by tests/test_lookahead_binding.py.  It is never linked into, loaded by or
+ * shipped with the product (x265_amd/libx265hip.so); on a GPU the same binding runs on the HIP kernels (tests/test_x265_dropin.py). */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/x265hip.h"
+#include "../../oracle/x265_oracle.h"
+
+/* oracle/x265_oracle_pix.inc (LookaheadTLD::weightsAnalyse); exported by the oracle library, not listed in its header */
+int orc_weights_analyse_8(const uint8_t* fenc, const uint8_t* const refBuf[4], uint8_t* const outBuf[4], intptr_t stride, intptr_t padOffset, int paddedLines,
+                          int width, int lines, const int32_t* intraCost, uint64_t fencSsd, uint64_t fencSum, uint64_t refSsd, uint64_t refSum,
+                          int32_t chosen[3], int depth);
+int orc_weights_analyse_16(const uint16_t* fenc, const uint16_t* const refBuf[4], uint16_t* const outBuf[4], intptr_t stride, intptr_t padOffset, int paddedLines,
+                           int width, int lines, const int32_t* intraCost, uint64_t fencSsd, uint64_t fencSum, uint64_t refSsd, uint64_t refSum,
+                           int32_t chosen[3], int depth);
+
+typedef struct slot
+{
+    void*    buffers;
+    int32_t* intraCost;
+    int32_t* invQscale;
+    int32_t* store;        /* [2][maxDist][3 ncu] */
+    uint8_t  valid[2 * 18];
+    int      live, hasInvQ;
+} slot;
+
+struct x265hip_la
+{
+    x265hip_la_config c;
+    int B, ncu;
+    slot* slots;
+    void* wbuf[64];
+    int wbufsUsed;
+    uint16_t* mvcost;
+    uint64_t batches, estimates, searches;
+};
+
+static char g_err[256] = "";
+int x265hip_device_count(void) { return 1; }
+int x265hip_init(int device) { (void)device; return 0; }
+const char* x265hip_last_error(void) { return g_err; }
+
+x265hip_la* x265hip_la_create(const x265hip_la_config* cfg)
+{
+    x265hip_la* la = (x265hip_la*)calloc(1, sizeof(*la));
+    la->c = *cfg;
+    la->B = cfg->depth == 8 ? 1 : 2;
+    la->ncu = cfg->widthInCU * cfg->heightInCU;
+    la->slots = (slot*)calloc(cfg->numSlots, sizeof(slot));
+    la->mvcost = (uint16_t*)malloc((4 * 32768 + 1) * sizeof(uint16_t));
+    orc_mvcost_table(12 + 6 * (cfg->depth - 8), cfg->depth, la->mvcost);
+    return la;
+}
+
+void x265hip_la_destroy(x265hip_la* la)
+{
+    if (!la) return;
+    for (int i = 0; i < la->c.numSlots; i++)
+    {
+        free(la->slots[i].buffers); free(la->slots[i].intraCost); free(la->slots[i].invQscale); free(la->slots[i].store);
+    }
+    for (int i = 0; i < 64; i++) free(la->wbuf[i]);
+    free(la->slots); free(la->mvcost); free(la);
+}
+
+int x265hip_la_set_frame(x265hip_la* la, int slotIdx, const void* buffers, const int32_t* intraCost, const int32_t* invQscale)
+{
+    slot* s = &la->slots[slotIdx];
+    const size_t pb = (size_t)4 * la->c.planeElems * la->B, cb = (size_t)la->ncu * 4;
+    if (!s->buffers)
+    {
+        s->buffers = malloc(pb); s->intraCost = (int32_t*)malloc(cb); s->invQscale = (int32_t*)malloc(cb);
+        s->store = (int32_t*)malloc((size_t)2 * la->c.maxDist * 3 * cb);
+    }
+    memcpy(s->buffers, buffers, pb);
+    memcpy(s->intraCost, intraCost, cb);
+    s->hasInvQ = invQscale != NULL;
+    if (invQscale) memcpy(s->invQscale, invQscale, cb);
+    memset(s->valid, 0, sizeof(s->valid));
+    s->live = 1;
+    return 0;
+}
+
+static int32_t* store_of(x265hip_la* la, slot* s, int list, int dist) { return s->store + ((size_t)list * la->c.maxDist + dist) * 3 * la->ncu; }
+
+int x265hip_la_put_vectors(x265hip_la* la, int slotIdx, int list, int dist, const int32_t* mvs, const int32_t* mvCosts)
+{
+    slot* s = &la->slots[slotIdx];
+    int32_t* d = store_of(la, s, list, dist);
+    memcpy(d, mvs, (size_t)la->ncu * 8);
+    memcpy(d + 2 * la->ncu, mvCosts, (size_t)la->ncu * 4);
+    s->valid[list * la->c.maxDist + dist] = 1;
+    return 0;
+}
+
+int x265hip_la_has_vectors(x265hip_la* la, int slotIdx, int list, int dist) { return la->slots[slotIdx].live && la->slots[slotIdx].valid[list * la->c.maxDist + dist]; }
+
+#define PLANES(T, buf, out) do { for (int k_ = 0; k_ < 4; k_++) (out)[k_] = (const T*)(buf) + (size_t)k_ * la->c.planeElems + la->c.padOffset; } while (0)
+
+int x265hip_la_weights_analyse(x265hip_la* la, int slotB, int slotRef, uint64_t fencSsd, uint64_t fencSum, uint64_t refSsd, uint64_t refSum,
+                               x265hip_weight_param* chosen, int* isWeighted, int* weightedId)
+{
+    const x265hip_la_config* c = &la->c;
+    slot* fb = &la->slots[slotB];
+    slot* fr = &la->slots[slotRef];
+    if (la->wbufsUsed >= 64) { snprintf(g_err, sizeof(g_err), "emul: too many weighted references in one batch"); return X265HIP_EINVAL; }
+    if (!la->wbuf[la->wbufsUsed]) la->wbuf[la->wbufsUsed] = malloc((size_t)4 * c->planeElems * la->B);
+    void* w = la->wbuf[la->wbufsUsed];
+    const int paddedLines = (int)(c->planeElems / c->stride);
+    int32_t ch[3];
+    int r;
+    if (c->depth == 8)
+    {
+        const uint8_t* rb[4]; uint8_t* ob[4];
+        for (int k = 0; k < 4; k++) { rb[k] = (const uint8_t*)fr->buffers + (size_t)k * c->planeElems; ob[k] = (uint8_t*)w + (size_t)k * c->planeElems; }
+        r = orc_weights_analyse_8((const uint8_t*)fb->buffers + c->padOffset, rb, ob, c->stride, c->padOffset, paddedLines, c->width, c->lines, fb->intraCost,
+                                  fencSsd, fencSum, refSsd, refSum, ch, c->depth);
+    }
+    else
+    {
+        const uint16_t* rb[4]; uint16_t* ob[4];
+        for (int k = 0; k < 4; k++) { rb[k] = (const uint16_t*)fr->buffers + (size_t)k * c->planeElems; ob[k] = (uint16_t*)w + (size_t)k * c->planeElems; }
+        r = orc_weights_analyse_16((const uint16_t*)fb->buffers + c->padOffset, rb, ob, c->stride, c->padOffset, paddedLines, c->width, c->lines, fb->intraCost,
+                                   fencSsd, fencSum, refSsd, refSum, ch, c->depth);
+    }
+    *isWeighted = r;
+    chosen->inputWeight = ch[0]; chosen->log2WeightDenom = ch[1]; chosen->inputOffset = ch[2]; chosen->wtPresent = r;
+    *weightedId = r ? la->wbufsUsed++ : -1;
+    return 0;
+}
+
+int x265hip_la_estimate_batch(x265hip_la* la, x265hip_la_estimate* est, int n, int numRowsPerSlice, int numSlices)
+{
+    const x265hip_la_config* c = &la->c;
+    const int ncu = la->ncu, W = c->widthInCU, H = c->heightInCU;
+    for (int i = 0; i < n; i++)
+    {
+        x265hip_la_estimate* q = &est[i];
+        slot* fb = &la->slots[q->b];
+        const int bidir = q->p1 != q->b;
+        const int32_t* invQ = fb->hasInvQ ? fb->invQscale : NULL;
+        int32_t* st0 = store_of(la, fb, 0, q->dist0);
+        int32_t* st1 = bidir ? store_of(la, fb, 1, q->dist1) : NULL;
+        if ((!q->search0 && !fb->valid[q->dist0]) || (bidir && !q->search1 && !fb->valid[c->maxDist + q->dist1]))
+        {
+            snprintf(g_err, sizeof(g_err), "emul: estimate %d reuses vectors the session has not seen", i);
+            return X265HIP_EINVAL;
+        }
+        const void* ref0buf = q->weightedId >= 0 ? la->wbuf[q->weightedId] : la->slots[q->p0].buffers;
+        int64_t aq = 0;
+        int32_t intraMbs = 0;
+        int64_t cost;
+        const int32_t ds[2] = { q->search0, q->search1 };
+#define RUN(T, SFX) do { \
+            const T* r0[4]; const T* r0u[4]; const T* r1[4]; \
+            PLANES(T, ref0buf, r0); PLANES(T, la->slots[q->p0].buffers, r0u); PLANES(T, la->slots[q->p1].buffers, r1); \
+            const T* fenc = (const T*)fb->buffers + c->padOffset; \
+            if (!bidir) \
+                cost = orc_lookahead_cost_p_aq_##SFX(fenc, r0, c->stride, W, H, numRowsPerSlice, numSlices, c->depth, fb->intraCost, la->mvcost + 2 * 32768, \
+                                                     st0, st0 + 2 * ncu, q->lowresCosts, q->rowSatds, &intraMbs, invQ, q->search0, &aq); \
+            else \
+            { \
+                /* list 0 searches the weighted planes when there are any; the bi-predictive candidates use the unweighted ones (slicetype.cpp:3322): \
+                 * the oracle's B pass takes one plane set per list, so a weighted list 0 is searched first as its own pass */ \
+                int32_t dsl[2] = { ds[0], ds[1] }; \
+                if (q->weightedId >= 0 && ds[0]) \
+                { \
+                    uint16_t* lc = (uint16_t*)malloc((size_t)ncu * 2); int32_t* rs = (int32_t*)malloc((size_t)H * 4); \
+                    int32_t* m1 = (int32_t*)malloc((size_t)ncu * 12); \
+                    const int32_t only0[2] = { 1, 0 }; \
+                    memset(m1, 0, (size_t)ncu * 12); \
+                    orc_lookahead_cost_b_aq_##SFX(fenc, r0, r1, c->stride, W, H, numRowsPerSlice, numSlices, c->depth, la->mvcost + 2 * 32768, only0, \
+                                                  st0, st0 + 2 * ncu, m1, m1 + 2 * ncu, lc, rs, NULL, NULL); \
+                    free(lc); free(rs); free(m1); \
+                    dsl[0] = 0; \
+                } \
+                cost = orc_lookahead_cost_b_aq_##SFX(fenc, r0u, r1, c->stride, W, H, numRowsPerSlice, numSlices, c->depth, la->mvcost + 2 * 32768, dsl, \
+                                                     st0, st0 + 2 * ncu, st1, st1 + 2 * ncu, q->lowresCosts, q->rowSatds, invQ, &aq); \
+            } \
+        } while (0)
+        if (c->depth == 8) RUN(uint8_t, 8); else RUN(uint16_t, 16);
+#undef RUN
+        if (q->search0) { memcpy(q->mvs0, st0, (size_t)ncu * 8); memcpy(q->mvCosts0, st0 + 2 * ncu, (size_t)ncu * 4); fb->valid[q->dist0] = 1; la->searches++; }
+        if (bidir && q->search1) { memcpy(q->mvs1, st1, (size_t)ncu * 8); memcpy(q->mvCosts1, st1 + 2 * ncu, (size_t)ncu * 4); fb->valid[c->maxDist + q->dist1] = 1; la->searches++; }
+        q->costEst = cost;
+        q->costEstAq = aq;
+        q->intraMbs = bidir ? 0 : intraMbs;
+    }
+    la->wbufsUsed = 0;
+    la->batches++;
+    la->estimates += n;
+    return 0;
+}
+
+int x265hip_la_stats(x265hip_la* la, uint64_t* batches, uint64_t* estimates, uint64_t* searches)
+{
+    if (batches) *batches = la->batches;
+    if (estimates) *estimates = la->estimates;
+    if (searches) *searches = la->searches;
+    return 0;
+}

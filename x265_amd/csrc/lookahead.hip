@@ -128,10 +128,12 @@ __device__ __forceinline__ void la_unpack(uint64_t w, int& x, int& y)
     y = sfl((int)(int16_t)(uint16_t)((w >> 16) & 0xffff));
 }
 
+__device__ __forceinline__ void la_add64(int64_t* p, int v) { atomicAdd((unsigned long long*)p, (unsigned long long)(long long)v); }
+
 template <typename P>
 __global__ __launch_bounds__(64) void lookahead_p_kernel(const LaPair* __restrict__ pairs, int nPairs, int64_t stride, int64_t planeElems, int W, int H,
                                                          int rowsPerSlice, int numSlices, const uint16_t* __restrict__ costTab, uint32_t epoch,
-                                                         int32_t* __restrict__ costEst)
+                                                         int64_t* __restrict__ est)
 {
     typedef LaCtx<P> C;
     typedef typename C::Q Q;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(64) void lookahead_p_kernel(const LaPair* __restric
     uint64_t* mine = pr.sync + (int64_t)cuY * W;
 
     const int mvminY = -cuY * N - 8, mvmaxY = (H - cuY - 1) * N + 8;
-    int rowSum = 0, scoreSum = 0, intraCnt = 0;
+    int rowSum = 0, scoreSum = 0, scoreAq = 0, intraCnt = 0;
     int prevX = 0, prevY = 0;
     bool stuck = false;
 
@@ -184,20 +186,29 @@ __global__ __launch_bounds__(64) void lookahead_p_kernel(const LaPair* __restric
         if (cuX < W - 1) { mx[0] = prevX; my[0] = prevY; numc = 1; }
         if (!lastRow)
         {
-            const int waitIdx = cuX > 0 ? cuX - 1 : cuX;          // the row below moves right to left: this one is done last
-            // (bounded: the row below is always dispatched earlier, so this normally takes microseconds; if the handshake word never
-            // arrives — a stale `sync` buffer or an epoch reused by the caller — give up after ~2 s instead of hanging the device and
-            // report it through a negative costEst[2 i + 1])
+            // The row below moves right to left, so its below-left block (cuX - 1) is published last.  Every word carries the epoch next to
+            // the vector and is written / read by ONE 64-bit agent-scope atomic, so each of the (up to) three words is validated on its own:
+            // no ordering between different words is assumed.  Bounded: the row below is always dispatched earlier, so this normally takes
+            // microseconds; if a word never arrives (a `sync` scratch that was not zeroed) give up after ~2 s instead of hanging the device
+            // and report it through est[4 i + 3].
+            const int lo = cuX > 0 ? cuX - 1 : cuX, hi = cuX < W - 1 ? cuX + 1 : cuX;
+            uint64_t w0 = 0, w1 = 0, w2 = 0;
             int spins = 0;
-            while (!stuck && (uint32_t)sfl((int)(la_load(below + waitIdx) >> 32)) != epoch)
+            for (;;)
             {
+                w0 = la_load(below + cuX);
+                w1 = la_load(below + lo);
+                w2 = la_load(below + hi);
+                const bool ok = (uint32_t)sfl((int)(w0 >> 32)) == epoch && (uint32_t)sfl((int)(w1 >> 32)) == epoch && (uint32_t)sfl((int)(w2 >> 32)) == epoch;
+                if (ok || stuck)
+                    break;
                 __builtin_amdgcn_s_sleep(8);
                 if (++spins > (1 << 22)) stuck = true;            // sticky: the rest of the row no longer waits
             }
-            la_unpack(la_load(below + cuX), mx[numc], my[numc]);
+            la_unpack(w0, mx[numc], my[numc]);
             numc++;
-            if (cuX > 0) { la_unpack(la_load(below + cuX - 1), mx[numc], my[numc]); numc++; }
-            if (cuX < W - 1) { la_unpack(la_load(below + cuX + 1), mx[numc], my[numc]); numc++; }
+            if (cuX > 0) { la_unpack(w1, mx[numc], my[numc]); numc++; }
+            if (cuX < W - 1) { la_unpack(w2, mx[numc], my[numc]); numc++; }
         }
         int mvpX = 0, mvpY = 0, skipCost = 0x7fffffff;
         c.px = 0; c.py = 0;
@@ -397,12 +408,16 @@ __global__ __launch_bounds__(64) void lookahead_p_kernel(const LaPair* __restric
         const int ic = sfl(pr.intraCost[cuXY]);
         if (ic < cuCost) { cuCost = ic; listused = 0; }
         const bool scored = (cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2;
+        int cuCostAq = cuCost;
         if (scored)
         {
+            if (pr.invQscale)
+                cuCostAq = (cuCost * sfl(pr.invQscale[cuXY]) + 128) >> 8;
             scoreSum += cuCost;
+            scoreAq += cuCostAq;
             intraCnt += !listused;
         }
-        rowSum += cuCost;
+        rowSum += cuCostAq;
         if (lane == 0)
         {
             pr.mvs[2 * cuXY] = bmvX;
@@ -414,18 +429,57 @@ __global__ __launch_bounds__(64) void lookahead_p_kernel(const LaPair* __restric
     if (lane == 0 && !bidirList)
     {
         pr.rowSatds[cuY] = rowSum;
-        atomicAdd(costEst + 2 * pairIdx, scoreSum);
-        atomicAdd(costEst + 2 * pairIdx + 1, intraCnt);
+        la_add64(est + 4 * pairIdx, scoreSum);
+        la_add64(est + 4 * pairIdx + 1, scoreAq);
+        la_add64(est + 4 * pairIdx + 2, intraCnt);
     }
     if (lane == 0 && stuck)
-        atomicAdd(costEst + 2 * pairIdx + 1, -(1 << 30));        // intraMbs far below zero: the handshake timed out, outputs are invalid
+        atomicOr((unsigned long long*)(est + 4 * pairIdx + 3), 1ull);   // idempotent: any number of stuck rows leaves the same mark
+}
+
+// ---- a P estimate whose search was done before (bDoSearch[0] == false): only the bookkeeping of estimateCUCost ---------------
+__global__ __launch_bounds__(64) void lookahead_pcost_kernel(const LaPair* __restrict__ pairs, int W, int H, int64_t* __restrict__ est)
+{
+    const int pairIdx = blockIdx.x / H, cuY = blockIdx.x % H;
+    const LaPair pr = pairs[pairIdx];
+    int rowSum = 0, scoreSum = 0, scoreAq = 0, intraCnt = 0;
+    for (int cuX = threadIdx.x; cuX < W; cuX += 64)
+    {
+        const int cuXY = cuY * W + cuX;
+        int cuCost = pr.mvCosts[cuXY] + 4, listused = 1;
+        const int ic = pr.intraCost[cuXY];
+        if (ic < cuCost) { cuCost = ic; listused = 0; }
+        const bool scored = (cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2;
+        int cuCostAq = cuCost;
+        if (scored)
+        {
+            if (pr.invQscale)
+                cuCostAq = (cuCost * pr.invQscale[cuXY] + 128) >> 8;
+            scoreSum += cuCost;
+            scoreAq += cuCostAq;
+            intraCnt += !listused;
+        }
+        rowSum += cuCostAq;
+        pr.lowresCosts[cuXY] = (uint16_t)((cuCost < 16383 ? cuCost : 16383) | (listused << 14));
+    }
+    rowSum = wave_sum(rowSum);
+    scoreSum = wave_sum(scoreSum);
+    scoreAq = wave_sum(scoreAq);
+    intraCnt = wave_sum(intraCnt);
+    if (threadIdx.x == 0)
+    {
+        pr.rowSatds[cuY] = rowSum;
+        la_add64(est + 4 * pairIdx, scoreSum);
+        la_add64(est + 4 * pairIdx + 1, scoreAq);
+        la_add64(est + 4 * pairIdx + 2, intraCnt);
+    }
 }
 
 // ---- B frames: the part of estimateCUCost after the two list searches (slicetype.cpp:3320-3338, :3353-3384) ----------------
 // One wave per block row; its four DPP rows take four neighbouring blocks at a time.  No dependencies between blocks.
 template <typename P>
 __global__ __launch_bounds__(64) void lookahead_bidir_kernel(const x265hip_lookahead_bframe* __restrict__ frames, int64_t stride, int64_t planeElems,
-                                                             int W, int H, int32_t* __restrict__ costEst)
+                                                             int W, int H, int64_t* __restrict__ est)
 {
     typedef LaCtx<P> C;
     typedef typename C::Q Q;
@@ -442,7 +496,7 @@ __global__ __launch_bounds__(64) void lookahead_bidir_kernel(const x265hip_looka
     c0.stride = c1.stride = (int)stride;
     c0.planeElems = c1.planeElems = planeElems;
     const int64_t rowOff = (int64_t)(cuY * N + qrow) * stride + qcol;
-    int rowSum = 0, scoreSum = 0;
+    int rowSum = 0, scoreSum = 0, scoreAq = 0;
 #pragma unroll 1
     for (int x0 = 0; x0 < W; x0 += 4)
     {
@@ -468,18 +522,26 @@ __global__ __launch_bounds__(64) void lookahead_bidir_kernel(const x265hip_looka
         if (live && s == 0)
         {
             fr.lowresCosts[cuXY] = (uint16_t)((bcost < 16383 ? bcost : 16383) | (listused << 14));
-            rowSum += bcost;
+            int bcostAq = bcost;
             if ((cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2)
+            {
+                if (fr.invQscale)
+                    bcostAq = (bcost * fr.invQscale[cuXY] + 128) >> 8;
                 scoreSum += bcost;
+                scoreAq += bcostAq;
+            }
+            rowSum += bcostAq;
         }
     }
     // lanes 0, 16, 32, 48 hold the partial sums of their slots
     rowSum = __builtin_amdgcn_readlane(rowSum, 0) + __builtin_amdgcn_readlane(rowSum, 16) + __builtin_amdgcn_readlane(rowSum, 32) + __builtin_amdgcn_readlane(rowSum, 48);
     scoreSum = __builtin_amdgcn_readlane(scoreSum, 0) + __builtin_amdgcn_readlane(scoreSum, 16) + __builtin_amdgcn_readlane(scoreSum, 32) + __builtin_amdgcn_readlane(scoreSum, 48);
+    scoreAq = __builtin_amdgcn_readlane(scoreAq, 0) + __builtin_amdgcn_readlane(scoreAq, 16) + __builtin_amdgcn_readlane(scoreAq, 32) + __builtin_amdgcn_readlane(scoreAq, 48);
     if (lane == 0)
     {
         fr.rowSatds[cuY] = rowSum;
-        atomicAdd(costEst + f, scoreSum);
+        la_add64(est + 2 * f, scoreSum);
+        la_add64(est + 2 * f + 1, scoreAq);
     }
 }
 
@@ -489,43 +551,56 @@ using namespace xh;
 
 extern "C" int x265hip_lookahead_cost_p_batch(int depth, const x265hip_lookahead_pair* pairs, int nPairs, int64_t stride, int64_t planeElems,
                                               int widthInCU, int heightInCU, int numRowsPerSlice, int numSlices,
-                                              const uint16_t* mvcost, uint32_t epoch, int32_t* costEst, void* stream)
+                                              const uint16_t* mvcost, uint32_t epoch, int64_t* est, void* stream)
 {
     XH_CHECK_DEV();
     if (!valid_depth(depth) || nPairs < 0 || widthInCU < 1 || heightInCU < 1 || numSlices < 1 || numRowsPerSlice < 1 || epoch == 0 ||
-        stride >= (1 << 23) || planeElems >= (1 << 22) || planeElems < 0 ||
+        stride >= (1 << 23) || planeElems >= (1 << 24) || planeElems < 0 || !est ||
         (long long)numRowsPerSlice * (numSlices - 1) >= heightInCU)
         return set_error(X265HIP_EINVAL, "lookahead_cost_p_batch: depth %d pairs %d grid %dx%d slices %d x %d rows epoch %u", depth, nPairs, widthInCU,
                          heightInCU, numSlices, numRowsPerSlice, epoch);
     if (nPairs == 0) return X265HIP_OK;
-    int e = check_hip(hipMemsetAsync(costEst, 0, (size_t)nPairs * 2 * sizeof(int32_t), as_stream(stream)), "lookahead memset");
+    int e = check_hip(hipMemsetAsync(est, 0, (size_t)nPairs * 4 * sizeof(int64_t), as_stream(stream)), "lookahead memset");
     if (e) return e;
     const int groups = (nPairs + 7) / 8;
     dim3 grid((unsigned)(groups * heightInCU * 8)), block(64);
     if (depth == 8)
         hipLaunchKernelGGL((lookahead_p_kernel<uint8_t>), grid, block, 0, as_stream(stream), pairs, nPairs, stride, planeElems, widthInCU, heightInCU,
-                           numRowsPerSlice, numSlices, mvcost, epoch, costEst);
+                           numRowsPerSlice, numSlices, mvcost, epoch, est);
     else
         hipLaunchKernelGGL((lookahead_p_kernel<uint16_t>), grid, block, 0, as_stream(stream), pairs, nPairs, stride, planeElems, widthInCU, heightInCU,
-                           numRowsPerSlice, numSlices, mvcost, epoch, costEst);
+                           numRowsPerSlice, numSlices, mvcost, epoch, est);
     XH_LAUNCH_CHECK("lookahead_p_kernel");
     return X265HIP_OK;
 }
 
 extern "C" int x265hip_lookahead_bidir_batch(int depth, const x265hip_lookahead_bframe* frames, int nFrames, int64_t stride, int64_t planeElems,
-                                             int widthInCU, int heightInCU, int32_t* costEst, void* stream)
+                                             int widthInCU, int heightInCU, int64_t* est, void* stream)
 {
     XH_CHECK_DEV();
-    if (!valid_depth(depth) || nFrames < 0 || widthInCU < 1 || heightInCU < 1 || stride >= (1 << 23) || planeElems >= (1 << 22) || planeElems < 0)
+    if (!valid_depth(depth) || nFrames < 0 || widthInCU < 1 || heightInCU < 1 || stride >= (1 << 23) || planeElems >= (1 << 24) || planeElems < 0 || !est)
         return set_error(X265HIP_EINVAL, "lookahead_bidir_batch: depth %d frames %d grid %dx%d", depth, nFrames, widthInCU, heightInCU);
     if (nFrames == 0) return X265HIP_OK;
-    int e = check_hip(hipMemsetAsync(costEst, 0, (size_t)nFrames * sizeof(int32_t), as_stream(stream)), "lookahead memset");
+    int e = check_hip(hipMemsetAsync(est, 0, (size_t)nFrames * 2 * sizeof(int64_t), as_stream(stream)), "lookahead memset");
     if (e) return e;
     dim3 grid((unsigned)(nFrames * heightInCU)), block(64);
     if (depth == 8)
-        hipLaunchKernelGGL((lookahead_bidir_kernel<uint8_t>), grid, block, 0, as_stream(stream), frames, stride, planeElems, widthInCU, heightInCU, costEst);
+        hipLaunchKernelGGL((lookahead_bidir_kernel<uint8_t>), grid, block, 0, as_stream(stream), frames, stride, planeElems, widthInCU, heightInCU, est);
     else
-        hipLaunchKernelGGL((lookahead_bidir_kernel<uint16_t>), grid, block, 0, as_stream(stream), frames, stride, planeElems, widthInCU, heightInCU, costEst);
+        hipLaunchKernelGGL((lookahead_bidir_kernel<uint16_t>), grid, block, 0, as_stream(stream), frames, stride, planeElems, widthInCU, heightInCU, est);
     XH_LAUNCH_CHECK("lookahead_bidir_kernel");
+    return X265HIP_OK;
+}
+
+extern "C" int x265hip_lookahead_pcost_batch(const x265hip_lookahead_pair* pairs, int nPairs, int widthInCU, int heightInCU, int64_t* est, void* stream)
+{
+    XH_CHECK_DEV();
+    if (nPairs < 0 || widthInCU < 1 || heightInCU < 1 || !est)
+        return set_error(X265HIP_EINVAL, "lookahead_pcost_batch: pairs %d grid %dx%d", nPairs, widthInCU, heightInCU);
+    if (nPairs == 0) return X265HIP_OK;
+    int e = check_hip(hipMemsetAsync(est, 0, (size_t)nPairs * 4 * sizeof(int64_t), as_stream(stream)), "lookahead memset");
+    if (e) return e;
+    hipLaunchKernelGGL(lookahead_pcost_kernel, dim3((unsigned)(nPairs * heightInCU)), dim3(64), 0, as_stream(stream), pairs, widthInCU, heightInCU, est);
+    XH_LAUNCH_CHECK("lookahead_pcost_kernel");
     return X265HIP_OK;
 }

@@ -1,0 +1,294 @@
+// x265_hip_lookahead.cpp — the second translation unit a maintainer adds to an x265 build: it binds the lookahead's own batching seam,
+// CostEstimateGroup::finishBatch / estimateFrameCost (reference source/encoder/slicetype.cpp:3041-3048, :3115-3214), to the device-resident
+// lookahead session of libx265hip.so (include/x265hip.h, x265hip_la_*).
+//
+// x265 already groups lookahead work there: slicetypeAnalyse queues every missing motion search and frame cost of the mini-GOP candidates
+// (up to 512 estimates, :1942-2008) and then runs them over the thread pool, one estimateFrameCost per worker.  Here the whole queue is ONE
+// call: the session holds each queued frame's half-resolution planes, intra costs and AQ factors in HBM, searches every (frame, reference)
+// pair of the batch in one launch, and returns exactly what estimateCUCost leaves in the Lowres arrays (lowresMvs, lowresMvCosts,
+// lowresCosts, rowSatds, costEst, costEstAq, intraMbs) — so everything downstream (scenecut, slicetypePath, cuTree, rate control) runs
+// unchanged on identical numbers and the bitstream is byte-identical.
+//
+// How it is linked (oracle/Makefile): in a source tree a maintainer would add two `if (x265hip_lookahead(...)) return;`
+// lines.  Against the read-only reference the same effect is obtained at link time: the two symbols are weakened in slicetype.o
+// (objcopy --weaken-symbol) so the definitions below win, and the reference's original bodies stay reachable as CostEstimateGroupRef::*
+// (slicetype.cpp compiled a second time with -DCostEstimateGroup=CostEstimateGroupRef, every other symbol of that object localised).  This
+// file restates none of the reference's control flow: when the cache test says "not computed yet" it computes on the GPU and fills the
+// Lowres arrays, then ALWAYS finishes through the reference's own estimateFrameCost, which finds its cache filled (:3121-3122).
+//
+// Without a usable device, or with X265HIP_LOOKAHEAD=0, or for configurations the device pass does not cover (HME, aq-motion), every call
+// goes to the reference's original code.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#define protected public
+#define private public
+#include "common.h"
+#include "frame.h"
+#include "lowres.h"
+#include "slicetype.h"
+#undef protected
+#undef private
+
+#include "x265hip.h"
+
+namespace X265_NS {
+
+// the reference's original bodies (slicetype.cpp compiled as CostEstimateGroupRef; `this` is the first argument in the Itanium C++ ABI)
+#define X265HIP_STR2(x) #x
+#define X265HIP_STR(x) X265HIP_STR2(x)
+#define X265HIP_NSLEN sizeof(X265HIP_STR(X265_NS)) - 1
+// mangled: _ZN <len><ns> 20CostEstimateGroupRef ...  — the namespace is `x265` in every build of oracle/Makefile (checked below)
+extern int64_t refEstimateFrameCost(CostEstimateGroup* self, LookaheadTLD& tld, int p0, int p1, int b, bool bIntraPenalty)
+    asm("_ZN4x26520CostEstimateGroupRef17estimateFrameCostERNS_12LookaheadTLDEiiib");
+extern void refFinishBatch(CostEstimateGroup* self) asm("_ZN4x26520CostEstimateGroupRef11finishBatchEv");
+static_assert(sizeof(X265HIP_STR(X265_NS)) == sizeof("x265"), "the asm labels above assume -DX265_NS=x265");
+
+namespace {
+
+struct SlotEntry { const Lowres* lowres; int frameNum; uint64_t stamp; };
+
+struct Session
+{
+    const Lookahead* owner = NULL;
+    x265hip_la* la = NULL;
+    std::vector<SlotEntry> slots;
+    uint64_t stamp = 0;
+    uint64_t uploads = 0;
+};
+
+std::mutex g_lock;
+Session g_session;
+int g_state = 0;                 // 0 = not decided, 1 = on, -1 = off
+bool g_verbose = false;
+
+void report()
+{
+    if (!g_session.la)
+        return;
+    uint64_t batches = 0, estimates = 0, searches = 0;
+    x265hip_la_stats(g_session.la, &batches, &estimates, &searches);
+    fprintf(stderr, "x265hip: lookahead: %llu frame-cost estimates (%llu motion-search passes over %llu lowres frames) served by the GPU in %llu batches\n",
+            (unsigned long long)estimates, (unsigned long long)searches, (unsigned long long)g_session.uploads, (unsigned long long)batches);
+}
+
+bool enabled()
+{
+    if (!g_state)
+    {
+        const char* env = getenv("X265HIP_LOOKAHEAD");
+        const char* all = getenv("X265HIP");
+        g_verbose = getenv("X265HIP_VERBOSE") != NULL;
+        if ((env && !strcmp(env, "0")) || (all && !strcmp(all, "0")) || x265hip_device_count() < 1)
+            g_state = -1;
+        else
+        {
+            g_state = 1;
+            if (g_verbose)
+                atexit(report);
+        }
+    }
+    return g_state > 0;
+}
+
+[[noreturn]] void die(const char* what)
+{
+    // the product path fails loudly: results after a failed device call would no longer be the reference's
+    fprintf(stderr, "x265hip: lookahead: %s: %s\n", what, x265hip_last_error());
+    abort();
+}
+
+bool covered(const Lookahead& l, const Lowres* fenc)
+{
+    const x265_param* p = l.m_param;
+    return !p->bEnableHME && !p->bAQMotion && fenc->buffer[0] && (fenc->buffer[1] - fenc->buffer[0]) < (1 << 24) && p->bframes + 2 <= 18;
+}
+
+Session& session_for(const Lookahead& l, const Lowres* f)
+{
+    Session& s = g_session;
+    if (s.la && s.owner == &l)
+        return s;
+    if (s.la)
+    {
+        x265hip_la_destroy(s.la);           // a new encoder in the same process
+        s.la = NULL;
+    }
+    x265hip_la_config c;
+    memset(&c, 0, sizeof(c));
+    c.depth = X265_DEPTH;
+    c.width = f->width;
+    c.lines = f->lines;
+    c.stride = f->lumaStride;
+    c.planeElems = f->buffer[1] - f->buffer[0];
+    c.padOffset = f->lowresPlane[0] - f->buffer[0];
+    c.widthInCU = l.m_8x8Width;
+    c.heightInCU = l.m_8x8Height;
+    c.maxDist = l.m_param->bframes + 2;
+    c.numSlots = l.m_param->lookaheadDepth + l.m_param->bframes + 10;
+    s.la = x265hip_la_create(&c);
+    if (!s.la)
+        die("session");
+    s.owner = &l;
+    s.slots.assign(c.numSlots, SlotEntry{ NULL, 0, 0 });
+    s.stamp = 0;
+    return s;
+}
+
+int slot_of(Session& s, const Lookahead& l, const Lowres* f)
+{
+    int victim = -1;
+    for (size_t i = 0; i < s.slots.size(); i++)
+    {
+        SlotEntry& e = s.slots[i];
+        if (e.lowres == f && e.frameNum == f->frameNum)
+        {
+            e.stamp = s.stamp;
+            return (int)i;
+        }
+        if (e.lowres == f || !e.lowres)
+        {
+            if (victim < 0 || s.slots[victim].lowres)
+                victim = (int)i;            // the frame's old picture, or a free slot
+        }
+    }
+    if (victim < 0)
+    {
+        for (size_t i = 0; i < s.slots.size(); i++)
+            if (s.slots[i].stamp < s.stamp && (victim < 0 || s.slots[i].stamp < s.slots[victim].stamp))
+                victim = (int)i;
+        if (victim < 0)
+        {
+            fprintf(stderr, "x265hip: lookahead: more than %d frames in one batch\n", (int)s.slots.size());
+            abort();
+        }
+    }
+    const int32_t* invq = f->invQscaleFactor ? (l.m_param->rc.qgSize == 8 ? f->invQscaleFactor8x8 : f->invQscaleFactor) : NULL;
+    if (x265hip_la_set_frame(s.la, victim, f->buffer[0], f->intraCost, invq))
+        die("frame upload");
+    s.slots[victim] = SlotEntry{ f, f->frameNum, s.stamp };
+    s.uploads++;
+    return victim;
+}
+
+struct Job { int p0, p1, b; };
+
+// the missing results of `jobs` on the device, left in the Lowres arrays exactly as estimateCUCost leaves them (slicetype.cpp:3129-3207)
+void compute(CostEstimateGroup& g, const Job* jobs, int n, bool coop)
+{
+    const Lookahead& l = g.m_lookahead;
+    const x265_param* param = l.m_param;
+    std::lock_guard<std::mutex> guard(g_lock);
+    Session& s = session_for(l, g.m_frames[jobs[0].b]);
+    s.stamp++;
+    std::vector<x265hip_la_estimate> est(n);
+    for (int i = 0; i < n; i++)
+    {
+        const Job& j = jobs[i];
+        Lowres* fenc = g.m_frames[j.b];
+        Lowres* ref0 = g.m_frames[j.p0];
+        Lowres* ref1 = g.m_frames[j.p1];
+        x265hip_la_estimate& e = est[i];
+        memset(&e, 0, sizeof(e));
+        e.b = slot_of(s, l, fenc);
+        e.p0 = slot_of(s, l, ref0);
+        e.p1 = j.p1 == j.b ? e.b : slot_of(s, l, ref1);
+        e.dist0 = j.b - j.p0;
+        e.dist1 = j.p1 - j.b;
+        e.search0 = fenc->lowresMvs[0][e.dist0][0].x == 0x7FFF;
+        e.search1 = j.p1 > j.b && fenc->lowresMvs[1][e.dist1][0].x == 0x7FFF;
+        e.weightedId = -1;
+        fenc->weightedRef[e.dist0].isWeighted = false;
+        if (param->bEnableWeightedPred && e.search0)
+        {
+            x265hip_weight_param chosen;
+            int isWeighted = 0;
+            if (x265hip_la_weights_analyse(s.la, e.b, e.p0, fenc->wp_ssd[0], fenc->wp_sum[0], ref0->wp_ssd[0], ref0->wp_sum[0], &chosen, &isWeighted, &e.weightedId))
+                die("weights analysis");
+            // the weighted planes only ever serve this estimate's list-0 search (slicetype.cpp:3222, :3269), which runs on the device:
+            // the host-side ReferencePlanes stay unweighted.  weightedCostDelta = minscore / origscore is an integer division of a
+            // smaller by a larger unsigned (:945): 0, the value Lowres::init left there.
+        }
+        // lists that are not searched must already be in the session (they are, unless another path produced them)
+        for (int list = 0; list < (j.p1 > j.b ? 2 : 1); list++)
+        {
+            const int dist = list ? e.dist1 : e.dist0;
+            if (!(list ? e.search1 : e.search0) && !x265hip_la_has_vectors(s.la, e.b, list, dist))
+                if (x265hip_la_put_vectors(s.la, e.b, list, dist, (const int32_t*)fenc->lowresMvs[list][dist], fenc->lowresMvCosts[list][dist]))
+                    die("vector upload");
+        }
+        e.mvs0 = (int32_t*)fenc->lowresMvs[0][e.dist0];
+        e.mvCosts0 = fenc->lowresMvCosts[0][e.dist0];
+        e.mvs1 = (int32_t*)fenc->lowresMvs[1][e.dist1];
+        e.mvCosts1 = fenc->lowresMvCosts[1][e.dist1];
+        e.lowresCosts = fenc->lowresCosts[e.dist0][e.dist1];
+        e.rowSatds = fenc->rowSatds[e.dist0][e.dist1];
+    }
+    // batch mode never uses cooperative slices; a single estimate does when the pool allows and it has something to search or is a B estimate
+    int rows = l.m_8x8Height, slices = 1;
+    if (coop)
+    {
+        rows = l.m_numRowsPerSlice;
+        slices = l.m_numCoopSlices;
+    }
+    if (x265hip_la_estimate_batch(s.la, est.data(), n, rows, slices))
+        die("estimate batch");
+    for (int i = 0; i < n; i++)
+    {
+        const Job& j = jobs[i];
+        Lowres* fenc = g.m_frames[j.b];
+        const x265hip_la_estimate& e = est[i];
+        int64_t score = e.costEst;
+        if (j.b != j.p1)
+            score = score * 100 / (130 + param->bFrameBias);
+        else
+            fenc->intraMbs[e.dist0] += e.intraMbs;
+        fenc->costEst[e.dist0][e.dist1] = score;
+        fenc->costEstAq[e.dist0][e.dist1] = e.costEstAq;
+    }
+}
+
+inline bool cached(const Lowres* fenc, int p0, int p1, int b)
+{
+    return fenc->costEst[b - p0][p1 - b] >= 0 && fenc->rowSatds[b - p0][p1 - b][0] != -1;
+}
+
+} // namespace
+
+int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, int b, bool bIntraPenalty)
+{
+    Lowres* fenc = m_frames[b];
+    if (!cached(fenc, p0, p1, b) && enabled() && covered(m_lookahead, fenc))
+    {
+        const bool search0 = fenc->lowresMvs[0][b - p0][0].x == 0x7FFF;
+        const bool search1 = p1 > b && fenc->lowresMvs[1][p1 - b][0].x == 0x7FFF;
+        const bool coop = !m_batchMode && m_lookahead.m_numCoopSlices > 1 && (p1 > b || search0 || search1);
+        const Job j = { p0, p1, b };
+        compute(*this, &j, 1, coop);
+    }
+    return refEstimateFrameCost(this, tld, p0, p1, b, bIntraPenalty);
+}
+
+void CostEstimateGroup::finishBatch()
+{
+    if (m_jobTotal > 0 && enabled() && covered(m_lookahead, m_frames[m_estimates[0].b]))
+    {
+        std::vector<Job> jobs;
+        jobs.reserve(m_jobTotal);
+        for (int i = 0; i < m_jobTotal; i++)
+        {
+            const Estimate& e = m_estimates[i];
+            if (!cached(m_frames[e.b], e.p0, e.p1, e.b))
+                jobs.push_back(Job{ e.p0, e.p1, e.b });
+        }
+        if (!jobs.empty())
+            compute(*this, jobs.data(), (int)jobs.size(), false);
+        // every estimate of the queue is now cached; the reference's own loop (below) only reads the scores back
+    }
+    refFinishBatch(this);
+}
+
+} // namespace X265_NS
