@@ -451,13 +451,14 @@ class Hip:
                 o["isw"] = o_isw
             outs.append(o)
         ddesc = DevBuf(np.frombuffer(bytes(descs), np.uint8))
-        est = DevBuf.zeros((n, 2), np.int32)
+        est = DevBuf.zeros((n, 4), np.int64)
         for rep in range(2):      # twice on the same scratch: the second launch must not see the first one's handshake words
             self._epoch[0] += 1
             check(self.L.x265hip_lookahead_cost_p_batch(self.depth, ddesc.ptr, n, stride, pe, wcu, hcu, rows_per_slice, num_slices,
                                                         self._mvcost[qp].at(MVCOST_HALF), self._epoch[0], est.ptr, None))
         e = est.get()
-        return [(int(e[i, 0]), o["mvs"].get(), o["mvc"].get(), o["lc"].get(), o["rows"].get(), int(e[i, 1]), o["icost"].get()) + ((o["isw"],) if "isw" in o else ())
+        assert not e[:, 3].any(), "row handshake timed out"
+        return [(int(e[i, 0]), o["mvs"].get(), o["mvc"].get(), o["lc"].get(), o["rows"].get(), int(e[i, 2]), o["icost"].get()) + ((o["isw"],) if "isw" in o else ())
                 for i, o in enumerate(outs)]
 
     def lookahead_cost_p(self, src0, src1, origin, w, h, mx, my, rows_per_slice, num_slices):
@@ -518,7 +519,7 @@ class Hip:
         mvc = [DevBuf.zeros((ncu,), np.int32) for _ in range(2)]
         lc, rows = DevBuf.zeros((ncu,), np.uint16), DevBuf.zeros((hcu,), np.int32)
         sync = [DevBuf.zeros((ncu,), np.uint64) for _ in range(2)]
-        est2 = DevBuf.zeros((2, 2), np.int32)
+        est2 = DevBuf.zeros((2, 4), np.int64)
 
         def pair(lst, bidir):
             d = hp.LookaheadPair()
@@ -544,9 +545,9 @@ class Hip:
         bf.fenc, bf.ref0, bf.ref1 = planes[1].at(org), planes[0].at(org), planes[2].at(org)
         bf.mvs0, bf.mvs1, bf.mvCosts0, bf.mvCosts1, bf.lowresCosts, bf.rowSatds = mvs[0].ptr, mvs[1].ptr, mvc[0].ptr, mvc[1].ptr, lc.ptr, rows.ptr
         dbf = DevBuf(np.frombuffer(bytes(bf), np.uint8))
-        est = DevBuf.zeros((1,), np.int32)
+        est = DevBuf.zeros((1, 2), np.int64)
         check(self.L.x265hip_lookahead_bidir_batch(self.depth, dbf.ptr, 1, stride, pe, wcu, hcu, est.ptr, None))
-        return int(est.get()[0]) * 100 // 130, mvs[0].get(), mvc[0].get(), mvs[1].get(), mvc[1].get(), lc.get(), rows.get()
+        return int(est.get()[0, 0]) * 100 // 130, mvs[0].get(), mvc[0].get(), mvs[1].get(), mvc[1].get(), lc.get(), rows.get()
 
     def intra_scan(self, n, lines, filtered, fenc_plane, fenc_xy):
         """lines / filtered: (count, 4n+1); fenc_plane 2-D, fenc_xy list of (y, x).  Returns (count, 35) sa8d costs."""

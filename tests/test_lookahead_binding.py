@@ -1,0 +1,56 @@
+"""The x265-side binding of the lookahead seam (x265_amd/host/x265_hip_lookahead.cpp) proven on the CPU tier: the reference encoder linked with
+the binding and with tests/support/libx265hip_emul.so — the x265hip_la_* ABI implemented by the ORACLE, test infrastructure — must produce the
+same bytes as the unmodified reference encoder.  That pins, against the real x265, (a) the binding's plumbing (slot management, what is batched,
+what is written back into the Lowres arrays, the cooperative-slice rule) and (b) the oracle's restatement of estimateCUCost with AQ, weightp,
+B frames, cu-tree and scenecuts downstream of it.  On a GPU the same binding runs on the HIP kernels: tests/test_x265_dropin.py."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+sys.path.insert(0, ROOT)
+
+
+def _need(name):
+    p = os.path.join(REF, name)
+    if not os.path.exists(p):
+        pytest.skip("%s not built (needs /root/reference at build time: make -C oracle ref emul)" % name)
+    return p
+
+
+CASES = {
+    # 720p: cooperative lookahead slices are on (height >= 720), b-adapt 2 batches, AQ 2, cu-tree, weightp
+    "720p-medium": (8, 1280, 720, 14, ["--preset", "medium", "--me", "hex"]),
+    # a fade: the weighted-prediction analysis picks weights, list 0 searches the weighted planes
+    "720p-fade": (8, 1280, 720, 12, ["--preset", "medium", "--bframes", "2"]),
+    # Main10, fewer B frames, b-adapt 1 (no batches: every estimate is a single cooperative call)
+    "main10-badapt1": (10, 1280, 720, 10, ["--preset", "fast", "--b-adapt", "1"]),
+    # small picture: no slices, no pool batches
+    "cif-slow": (8, 352, 288, 16, ["--preset", "slow", "--rc-lookahead", "10"]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_binding_with_emulated_abi_is_byte_identical(tmp_path, name):
+    bits, w, h, frames, extra = CASES[name]
+    ref, emul = _need("x265_%dbit" % bits), _need("x265_emul_%dbit" % bits)
+    from x265_amd.synth import make_clip
+    yuv = str(tmp_path / "clip.yuv")
+    make_clip(yuv, w, h, frames, seed=77, fade=("fade" in name))
+    args = ["--input", yuv, "--input-res", "%dx%d" % (w, h), "--input-depth", "8", "--fps", "30", "--frames", str(frames), "--pools", "4", "-F", "2",
+            "--hash", "1"] + extra
+    outs = {}
+    for tag, exe in (("ref", ref), ("emul", emul)):
+        o = str(tmp_path / (tag + ".hevc"))
+        r = subprocess.run([exe] + args + ["-o", o], capture_output=True, text=True, timeout=900, env=dict(os.environ, X265HIP_VERBOSE="1"))
+        assert r.returncode == 0, r.stderr[-800:]
+        outs[tag] = (open(o, "rb").read(), r.stderr)
+    assert len(outs["ref"][0]) > 1000
+    assert outs["ref"][0] == outs["emul"][0], "bitstreams differ"
+    served = [l for l in outs["emul"][1].splitlines() if "frame-cost estimates" in l]
+    assert served and int(served[0].split()[2]) >= frames - 2, outs["emul"][1][-600:]
+    if "fade" in name:
+        assert "Weighted P-Frames: Y:0.0%" not in outs["ref"][1], "the fade clip was meant to exercise weightp"

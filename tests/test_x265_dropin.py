@@ -29,7 +29,7 @@ def _need(name):
 @pytest.mark.parametrize("bits", [8, 10, 12])
 def test_reference_testbench_passes_with_gpu_primitives(bits):
     exe = _need("TestBench_hip%d" % bits)
-    env = dict(os.environ, X265HIP_VERBOSE="1")
+    env = dict(os.environ, X265HIP_VERBOSE="1", X265HIP_TABLE="percall")
     p = subprocess.Popen([exe, "--cpuid", "SSE2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
     lines, t0, done = [], time.time(), False
     try:
@@ -83,7 +83,7 @@ def test_qcif_bitstream_identical_to_c_primitives(tmp_path, name):
     outs = {}
     for tag, exe in (("c", c_exe), ("gpu", g_exe)):
         o = str(tmp_path / (tag + ".hevc"))
-        env = dict(os.environ, X265HIP_VERBOSE="1")
+        env = dict(os.environ, X265HIP_VERBOSE="1", X265HIP_TABLE="percall")
         r = subprocess.run([exe] + args + ["-o", o], capture_output=True, text=True, timeout=900, env=env)
         assert r.returncode == 0, r.stderr[-800:]
         outs[tag] = (open(o, "rb").read(), r.stderr)
@@ -91,3 +91,28 @@ def test_qcif_bitstream_identical_to_c_primitives(tmp_path, name):
     assert outs["c"][0] == outs["gpu"][0], "bitstreams differ"
     served = [l for l in outs["gpu"][1].splitlines() if "primitive calls served by the GPU" in l]
     assert served and int(served[0].split()[1]) > 1000, outs["gpu"][1][-600:]
+
+
+@pytest.mark.parametrize("case", ["1080p-medium-hex", "720p-main10-fade"])
+def test_lookahead_seam_on_gpu_is_byte_identical(case):
+    """BASELINE.json configs[1] through the drop-in as it is meant to be used: the reference encoder + x265_hip_primitives.cpp +
+    x265_hip_lookahead.cpp + libx265hip.so, default settings (C slots stay, the lookahead's batched cost estimates run on the GPU —
+    INTEGRATION.md §5), all host cores.  Same bytes as the unmodified encoder, and the estimates were really served by the device."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import encode_fps
+    if case == "1080p-medium-hex":
+        r = encode_fps.measure(frames=24, width=1920, height=1080, bits=8, preset="medium", extra=("--me", "hex"))
+    else:
+        from x265_amd.synth import make_clip
+        clip = "/tmp/x265hip_fade_%d.yuv" % os.getpid()
+        make_clip(clip, 1280, 720, 16, seed=77, fade=True)
+        try:
+            r = encode_fps.measure(frames=16, width=1280, height=720, bits=10, preset="medium", extra=("--bframes", "2"), clip=clip)
+        finally:
+            os.remove(clip)
+    if "error" in r and "not built" in r["error"]:
+        pytest.skip(r["error"])
+    assert "error" not in r, r
+    assert r["byte_identical"], r
+    served = [l for l in r["gpu"]["served"] if "frame-cost estimates" in l]
+    assert served and int(served[0].split()[2]) > 10, r

@@ -76,7 +76,7 @@ def main():
         d.mvs, d.mvCosts, d.lowresCosts, d.rowSatds, d.sync = [b.ptr for b in o]
         keep.append(o)
     ddesc = DevBuf(np.frombuffer(bytes(descs), np.uint8))
-    estp = DevBuf.zeros((NP, 2), np.int32)
+    estp = DevBuf.zeros((NP, 4), np.int64)
     qp = 12 + 6 * (depth - 8)
     half = 2 * 32768
     tab = np.zeros(2 * half + 1, np.uint16)

@@ -12,7 +12,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libx265hip.so")
 
-vp, i32, i64, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32
+vp, i32, i64, u32, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64
 
 # name -> (restype, argtypes); mirrors include/x265hip.h one to one (tests/test_abi.py checks the header against this)
 PROTOTYPES = {
@@ -153,6 +153,15 @@ PROTOTYPES = {
                                                    vp, i32, i32, vp, vp, vp]),
     "x265hip_lookahead_cost_p_batch": (i32, [i32, vp, i32, i64, i64, i32, i32, i32, i32, vp, u32, vp, vp]),
     "x265hip_lookahead_bidir_batch": (i32, [i32, vp, i32, i64, i64, i32, i32, vp, vp]),
+    "x265hip_lookahead_pcost_batch": (i32, [vp, i32, i32, i32, vp, vp]),
+    "x265hip_la_create": (vp, [vp]),
+    "x265hip_la_destroy": (None, [vp]),
+    "x265hip_la_set_frame": (i32, [vp, i32, vp, vp, vp]),
+    "x265hip_la_put_vectors": (i32, [vp, i32, i32, i32, vp, vp]),
+    "x265hip_la_has_vectors": (i32, [vp, i32, i32, i32]),
+    "x265hip_la_weights_analyse": (i32, [vp, i32, i32, u64, u64, u64, u64, vp, vp, vp]),
+    "x265hip_la_estimate_batch": (i32, [vp, vp, i32, i32, i32]),
+    "x265hip_la_stats": (i32, [vp, vp, vp, vp]),
     "x265hip_call_intra_pred": (i32, [i32, i32, i32, i32, vp, i64, vp]),
     "x265hip_call_intra_allangs": (i32, [i32, i32, vp, vp, vp, i32]),
     "x265hip_call_intra_filter": (i32, [i32, i32, vp, vp]),
@@ -187,13 +196,26 @@ class WeightParam(C.Structure):
 class LookaheadPair(C.Structure):
     """x265hip_lookahead_pair (include/x265hip.h)"""
     _fields_ = [("fenc", vp), ("ref", vp), ("intraCost", vp), ("mvs", vp), ("mvCosts", vp), ("lowresCosts", vp), ("rowSatds", vp), ("sync", vp),
-                ("bidirList", C.c_int32), ("reserved", C.c_int32)]
+                ("invQscale", vp), ("bidirList", C.c_int32), ("reserved", C.c_int32)]
+
+
+class LaConfig(C.Structure):
+    """x265hip_la_config (include/x265hip.h)"""
+    _fields_ = [("depth", C.c_int32), ("width", C.c_int32), ("lines", C.c_int32), ("stride", C.c_int64), ("planeElems", C.c_int64), ("padOffset", C.c_int64),
+                ("widthInCU", C.c_int32), ("heightInCU", C.c_int32), ("maxDist", C.c_int32), ("numSlots", C.c_int32)]
+
+
+class LaEstimate(C.Structure):
+    """x265hip_la_estimate (include/x265hip.h)"""
+    _fields_ = [("b", C.c_int32), ("p0", C.c_int32), ("p1", C.c_int32), ("dist0", C.c_int32), ("dist1", C.c_int32), ("search0", C.c_int32),
+                ("search1", C.c_int32), ("weightedId", C.c_int32), ("mvs0", vp), ("mvCosts0", vp), ("mvs1", vp), ("mvCosts1", vp), ("lowresCosts", vp),
+                ("rowSatds", vp), ("costEst", C.c_int64), ("costEstAq", C.c_int64), ("intraMbs", C.c_int32), ("reserved", C.c_int32)]
 
 
 class LookaheadBFrame(C.Structure):
     """x265hip_lookahead_bframe (include/x265hip.h)"""
     _fields_ = [("fenc", vp), ("ref0", vp), ("ref1", vp), ("mvs0", vp), ("mvs1", vp), ("mvCosts0", vp), ("mvCosts1", vp), ("lowresCosts", vp),
-                ("rowSatds", vp)]
+                ("rowSatds", vp), ("invQscale", vp)]
 IF_HPP, IF_HPS, IF_VPP, IF_VPS, IF_VSP, IF_VSS, IF_HVPP = range(7)
 DIA_SEARCH, HEX_SEARCH, UMH_SEARCH, STAR_SEARCH, FULL_SEARCH = 0, 1, 2, 3, 5      # x265.h X265_*_SEARCH
 

@@ -12,7 +12,8 @@
 // Every shim is a synchronous call on caller-owned host memory, exactly the slot's signature; it forwards to the
 // per-call entry point x265hip_call_* and, if the GPU path reports an error, to the reference's own C implementation
 // (a private table filled by setupCPrimitives) — never garbage, never abort (SURVEY.md §8b "Errors").
-// `cpuMask` is ignored: the GPU path is selected by the environment variable X265HIP (default on, "0" disables).
+// `cpuMask` is ignored: the GPU path is selected by the environment variables X265HIP (default on, "0" disables everything) and
+// X265HIP_TABLE (see setupAssemblyPrimitives).
 #include "common.h"
 #include "primitives.h"
 #include "constants.h"
@@ -559,6 +560,14 @@ void setupAssemblyPrimitives(EncoderPrimitives& p, int /* cpuMask: CPU ISA bits,
 {
     const char* env = getenv("X265HIP");
     if (env && !strcmp(env, "0"))
+        return;
+    // X265HIP_TABLE selects what the table holds:
+    //   percall   every slot below becomes its per-call shim (one slot call = one 1-job launch + sync): the bit-exactness proof of each
+    //             kernel under the reference's own TestBench and encoder, ~1000x slower than the C code
+    //   (default) the C slots stay; the GPU serves the encoder where x265 batches work itself — the lookahead seam,
+    //             x265_hip_lookahead.cpp — which is the configuration encode fps is measured on
+    const char* mode = getenv("X265HIP_TABLE");
+    if (!mode || strcmp(mode, "percall"))
         return;
     if (x265hip_device_count() < 1 || x265hip_init(0))
         return;                                     // no usable GPU: leave the table alone (C path stays)

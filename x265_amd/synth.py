@@ -29,9 +29,10 @@ def make_scene(width, height, depth=8, seed=4321, tile=96, vmax=9, sigma=3.0):
     return {"src": np.clip(np.rint(src), 0, pmax).astype(dt), "ref": np.clip(np.rint(ref), 0, pmax).astype(dt)}
 
 
-def make_clip(path, width, height, frames, seed=4321, tile=96, vmax=9, sigma=3.0):
+def make_clip(path, width, height, frames, seed=4321, tile=96, vmax=9, sigma=3.0, fade=False):
     """Write an 8-bit I420 clip: a textured background whose tiles keep moving with their own constant velocity
-    (half rate) + per-frame noise; chroma = 128 + 0.3 * (luma - 128) subsampled."""
+    (half rate) + per-frame noise; chroma = 128 + 0.3 * (luma - 128) subsampled.  fade: the picture fades in from
+    40 % to full brightness over the clip (weighted prediction has something to find)."""
     rng = np.random.default_rng(seed)
     pad = vmax * frames // 2 + 16
     big = make_scene(width + 2 * pad, height + 2 * pad, 8, seed, tile, 0, 0.0)["ref"].astype(np.float64)
@@ -46,6 +47,8 @@ def make_clip(path, width, height, frames, seed=4321, tile=96, vmax=9, sigma=3.0
                     y0, x0 = j * tile, i * tile
                     y1, x1 = min(y0 + tile, height), min(x0 + tile, width)
                     luma[y0:y1, x0:x1] = big[pad + y0 + dy:pad + y1 + dy, pad + x0 + dx:pad + x1 + dx]
+            if fade:
+                luma = luma * (0.4 + 0.6 * t / max(frames - 1, 1))
             luma = np.clip(np.rint(luma + rng.normal(0, sigma, luma.shape)), 0, 255)
             f.write(luma.astype(np.uint8).tobytes())
             c = np.clip(np.rint(128 + 0.3 * (luma[::2, ::2] - 128)), 0, 255).astype(np.uint8)
