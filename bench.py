@@ -1,14 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py — the contract bench.  One "step" = one frame pass (the P-frame hot path: top-down HEX motion search,
-prediction, residual chain, sa8d costs, border extension — include/x265hip.h "frame pass") over one 1920x1080 synthetic
-frame per GPU (BASELINE.json configs[1]: 1080p, --me hex, merange 57, subme 2, 8-bit).  Frames shard across ranks the way
-x265's frame threads do: rank g owns frames g, g+N, ...; after every step each rank sends its border-extended
-reconstruction to rank g+1 (RCCL send/recv ring shift) where it is the reference of that rank's next frame.
+"""bench.py — the contract bench (BASELINE.json metric: encode fps, 1080p preset medium, --me hex).
 
-  python bench.py --gpus 1 --steps 200 --warmup 20
+`value` is REAL encode fps: the reference encoder's own binary with the two added translation units (x265_amd/host/*.cpp) and
+libx265hip.so behind them — oracle/_ref/x265_hip_8bit — encoding a synthetic 1920x1080 clip with `--preset medium --me hex`; the GPU serves
+the lookahead's batched frame-cost estimates, everything else is the reference's host code.  One "step" = one chunk of
+CHUNK = 12 frames of the clip; K steps are encoded in one run of the encoder, bracketed by barrier + synchronize, wall clock of this process
+(the encoder's own "encoded N frames in Xs" figure is reported beside it as `cli_fps`).  At N = 1 the same clip is also encoded by the
+unmodified reference encoder (oracle/_ref/x265_8bit, `cpu_baseline`, kind "reference") and the two bitstreams must be byte-identical.
+With N ranks every rank encodes its own clip on its own GPU (chunk-parallel, the way x265 is scaled out in practice; the host cores are
+split between the ranks): weak scaling, no data-path collective.
+
+Beside it, `frame_pass` keeps the device-resident hot path of round 1 (quarter-pel planes, top-down motion search, prediction, residual
+chains, sa8d, borders on HBM-resident pictures, F frame chains per GPU, recon exchanged over RCCL when N > 1) with its own roofline.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (see DESIGN.md §5 for every field)."""
+Rank 0 prints ONE JSON line (DESIGN.md §5 explains every field)."""
 import argparse
 import ctypes as C
 import json
@@ -22,6 +30,8 @@ sys.path.insert(0, ROOT)
 
 W, H, DEPTH, QP, MERANGE, SUBME = 1920, 1080, 8, 28, 57, 2
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MIN_TIMED_S = 0.5                 # every timed region lasts at least this long, whatever --steps says
+CHUNK = 12                        # frames per step of the real encode
 STAGES = ["planes", "me64", "me32", "me16", "me8", "pred8", "chain32", "chain8", "sa8d", "chroma", "border"]
 
 
@@ -101,55 +111,53 @@ def cpu_baseline_parallel(frames_per_chain=4, max_procs=64, timeout_s=120, start
                       % (len(spans), frames_per_chain, wall, (" (%d workers started late)" % late) if late else "")}
 
 
-def reference_encoder(frames=12):
-    """Context only: the REAL reference CLI ([noasm] C path, built into oracle/_ref by oracle/Makefile) encoding the same
-    kind of clip at 1080p preset medium --me hex on all host cores.  A full encoder, not the same workload."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "x265_8bit")
-    if not os.path.exists(exe):
-        return None
-    import numpy as np
-    from x265_amd.synth import make_clip
-    path = "/tmp/x265hip_bench_%d.yuv" % os.getpid()
-    try:
-        make_clip(path, W, H, frames, seed=4321)
-        cmd = [exe, "--input", path, "--input-res", "%dx%d" % (W, H), "--fps", "30", "--preset", "medium", "--me", "hex",
-               "--frames", str(frames), "-o", "/dev/null"]
-        t0 = time.perf_counter()
-        p = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
-        dt = time.perf_counter() - t0
-        fps = None
-        for line in (p.stderr + p.stdout).splitlines():
-            if "encoded" in line and "fps" in line:
-                fps = float(line.split("(")[1].split("fps")[0])
-        return {"fps": fps, "cores": os.cpu_count(), "frames": frames, "wall_s": round(dt, 1), "cmd": " ".join(cmd[3:]),
-                "note": "full x265 encoder, [noasm] C primitives (no nasm in the image); reported for context, not the same workload"}
-    except Exception as e:  # noqa: BLE001
-        return {"error": str(e)[:200]}
-    finally:
-        if os.path.exists(path):
-            os.remove(path)
+def _pmc_file():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_bytes.txt")))
+    return files[-1] if files else None
+
+
+PMC_KERNELS = {"planes": "subpel_planes", "me64": "motion2_kernel<unsigned char, 64", "me32": "motion3_kernel<unsigned char, 32",
+               "me16": "motion3_kernel<unsigned char, 16", "me8": "motion3_kernel<unsigned char, 8", "pred8": "pred_from_planes_kernel",
+               "chain32": "residual_chain_kernel<unsigned char, 32", "chain8": "residual_chain_kernel<unsigned char, 8",
+               "sa8d": "sa8d_pyramid_kernel", "border": "extend_border3_kernel", "chroma": "pred_chroma_kernel"}
 
 
 def pmc_traffic(stage):
-    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
-    in separate runs of this same command; FETCH doubled per the gfx950 correction of MI355X_MICROARCH.md).  None if absent."""
-    names = {"planes": "subpel_planes", "me64": "motion2_kernel<unsigned char, 64", "me32": "motion3_kernel<unsigned char, 32",
-             "me16": "motion3_kernel<unsigned char, 16", "me8": "motion3_kernel<unsigned char, 8", "pred8": "pred_from_planes_kernel",
-             "chain32": "residual_chain_kernel<unsigned char, 32", "chain8": "residual_chain_kernel<unsigned char, 8",
-             "sa8d": "sa8d_levels_kernel", "border": "extend_border3_kernel", "chroma": "pred_chroma_kernel"}
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_bytes.txt")))
-    if not files:
-        return None, None
-    for line in open(files[-1]):
-        if names[stage] in line:
+    """HBM bytes per launch of the stage's kernel from the newest COMMITTED rocprofv3 PMC passes (tools/collect_profiles.sh: FETCH_SIZE and
+    WRITE_SIZE in separate runs of this same workload; the file says which FETCH correction it applies, see tools/pmc_calibrate).
+    (bytes, file, note) or (None, None, None)."""
+    f = _pmc_file()
+    if not f:
+        return None, None, None
+    note = "from the committed profile, not collected in this run"
+    for line in open(f):
+        if line.startswith("# fetch_correction"):
+            note += "; " + line[1:].strip()
+        if PMC_KERNELS[stage] in line:
             cols = line.split()
             try:
-                fetch2_kib, write_kib = float(cols[-2]), float(cols[-1])
-                return int((fetch2_kib + write_kib) * 1024), os.path.relpath(files[-1], ROOT)
+                return int((float(cols[-2]) + float(cols[-1])) * 1024), os.path.relpath(f, ROOT), note
             except ValueError:
                 continue
-    return None, None
+    return None, None, None
+
+
+def pmc_frame_bytes():
+    """Sum over the frame pass's kernels (each launched once per frame) of PMC FETCH + WRITE bytes per launch."""
+    f = _pmc_file()
+    if not f:
+        return None, None
+    total = 0
+    for line in open(f):
+        if line.startswith("#"):
+            continue
+        cols = line.split()
+        try:
+            total += int((float(cols[-2]) + float(cols[-1])) * 1024)
+        except (ValueError, IndexError):
+            continue
+    return (total or None), os.path.relpath(f, ROOT)
 
 
 def valu_per_frame():
@@ -170,41 +178,15 @@ def valu_per_frame():
     return (total or None), os.path.relpath(files[-1], ROOT)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--cpu-frames", type=int, default=30, help="frames of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--no-ref-encoder", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, default=3,
-                    help="independent frame passes per GPU per step, each on its own HIP stream (x265 --frame-threads inside one device)")
-    args = ap.parse_args()
-
+def frame_pass_bench(args, rank, local_rank, world, steps, warmup):
+    """The device-resident hot path (round 1's headline): F frame passes per GPU per step on HBM-resident pictures, recon exchanged over
+    RCCL when N > 1.  The timed loop is repeated until it has run for at least MIN_TIMED_S.  Returns the `frame_pass` object (rank 0) or None."""
     import numpy as np
     import torch
     import torch.distributed as dist
     from x265_amd import hipprim as hp
     from x265_amd.framepass import FramePass, MARGIN, algorithmic_bytes
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: libx265hip has no CPU fallback")
-    # X265HIP_BENCH_SAME_DEVICE=1 is a debugging aid for 1-GPU boxes: every rank uses cuda:0 and the exchange runs over gloo
-    same_dev = os.environ.get("X265HIP_BENCH_SAME_DEVICE") == "1"
-    if same_dev:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
     L = hp.lib()
-    hp.check(L.x265hip_init(local_rank))
-    if world > 1:
-        if same_dev:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.current_stream().cuda_stream or None
 
@@ -305,11 +287,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     fence()
+    # the timed region lasts at least MIN_TIMED_S whatever --steps says: `steps` is raised (on every rank alike) from a first estimate
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(10):
+        step()
+    fence()
+    est = (time.perf_counter() - t0) / 10
+    if world > 1:
+        t = torch.tensor([est], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        est = float(t.item())
+    steps = max(steps, int(MIN_TIMED_S / max(est, 1e-6)) + 1)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
         step()
     host_dt = time.perf_counter() - t0                     # host time to enqueue the steps (launch-bound check)
     fence()
@@ -318,14 +312,26 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    ms_per_step = dt * 1e3 / args.steps
-    fps = world * F * args.steps / dt
+    ms_per_step = dt * 1e3 / steps
+    fps = world * F * steps / dt
+
+    # ---- the dominant kernel's duration UNDER THE SAME LOAD as `fps` (F chains in flight): HIP events of chain 0's own stream
+    hp.check(L.x265hip_framepass_set_profiling(fp.h, 1))
+    acc_l = np.zeros(11)
+    nload = 30
+    ms9 = (C.c_float * 11)()
+    for _ in range(nload):
+        step()
+        hp.check(L.x265hip_framepass_stage_ms(fp.h, ms9))
+        acc_l += np.array(list(ms9))
+    hp.check(L.x265hip_framepass_set_profiling(fp.h, 0))
+    stage_ms_loaded = dict(zip(STAGES, (acc_l / nload).round(5).tolist()))
+    fence()
 
     # ---- roofline of the dominant kernel: same workload, same stream, HIP events at the stage boundaries
     hp.check(L.x265hip_framepass_set_profiling(fp.h, 1))
     acc = np.zeros(11)
-    nprof = max(10, min(args.steps, 50))
-    ms9 = (C.c_float * 11)()
+    nprof = max(10, min(steps, 50))
     for _ in range(nprof):
         profile_step()
         hp.check(L.x265hip_framepass_stage_ms(fp.h, ms9))
@@ -334,67 +340,288 @@ def main():
     stage_ms = dict(zip(STAGES, (acc / nprof).round(5).tolist()))
     fence()
 
-    if rank == 0:
-        ab = algorithmic_bytes(W, H, DEPTH, MERANGE)
-        dom = max(STAGES, key=lambda s: stage_ms[s])
-        # A motion-search level is a chain of the reference's sad / sad_x3 / sad_x4 / interpolate + satd slot calls.  ALGORITHMIC bytes per
-        # launch = SURVEY.md §8d's per-call figures (sad 2WHB, sad_x3 4WHB, sad_x4 5WHB, an interpolated candidate adds the filter's
-        # in + out bytes) summed over the calls the reference's search issues per PU on THIS workload, counted with the pinned CPU
-        # oracle by tools/count_me_units.py (the search is bit-exact, so the GPU walks the same candidates), x the PUs of the launch.
-        # The unique footprint (source + reference window once + 44 B per PU), which is all HBM must deliver when caches work, is
-        # reported next to it as `unique_footprint`.
-        n_by_stage = {"me64": 480, "me32": 1980, "me16": 8040, "me8": 32400}
-        ME_BYTES_PER_PU = {"me64": 283422.6, "me32": 64257.7, "me16": 15408.4, "me8": 4067.6}   # tools/count_me_units.py, seed 4321
-        ME_CALLS_PER_PU = {"me64": 17.58, "me32": 16.23, "me16": 15.15, "me8": 15.09}
-        S_, R_ = W + 2 * MARGIN, H + 2 * MARGIN
-        unique = None
-        if dom in n_by_stage:
-            n = n_by_stage[dom]
-            dom_bytes = int(ME_BYTES_PER_PU[dom] * n)
-            ub = W * H + (W + 2 * (MERANGE + 4)) * (H + 2 * (MERANGE + 4)) + n * (12 + 32)
-            unique = {"bytes_per_launch": ub, "achieved": round(ub / (stage_ms[dom] * 1e-3) / 1e9, 2),
-                      "frac": round(ub / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}
-            names = {"me64": "motion2_kernel<u8,64,4,planes>", "me32": "motion3_kernel<u8,32,64>", "me16": "motion3_kernel<u8,16,16>",
-                     "me8": "motion3_kernel<u8,8,16>"}
-            kernel = "%s (%s: %d PUs x %.0f B = %.1f reference slot calls per PU, SURVEY 8d per-call bytes)" % (
-                names[dom], dom, n, ME_BYTES_PER_PU[dom], ME_CALLS_PER_PU[dom])
-        elif dom == "planes":
-            dom_bytes = 17 * S_ * R_                       # read the padded reference once, write 16 planes
-            kernel = "subpel_planes_kernel<u8> (16 quarter-pel planes of the padded reference)"
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        return None
+    ab = algorithmic_bytes(W, H, DEPTH, MERANGE)
+    dom = max(STAGES, key=lambda s: stage_ms_loaded[s])
+    # A motion-search level is a chain of the reference's sad / sad_x3 / sad_x4 / interpolate + satd slot calls.  ALGORITHMIC bytes per
+    # launch = SURVEY.md §8d's per-call figures (sad 2WHB, sad_x3 4WHB, sad_x4 5WHB, an interpolated candidate adds the filter's
+    # in + out bytes) summed over the calls the reference's search issues per PU on THIS workload, counted with the pinned CPU
+    # oracle by tools/count_me_units.py (the search is bit-exact, so the GPU walks the same candidates), x the PUs of the launch.
+    # These per-call bytes are mostly served by L2 / MALL (a candidate re-reads its neighbour's pixels); what HBM must deliver is the
+    # unique footprint (source + reference window once + 44 B per PU), reported as `unique_footprint`, and what it did deliver is the
+    # PMC figure `traffic` / `hbm_counter_frac`.
+    n_by_stage = {"me64": 480, "me32": 1980, "me16": 8040, "me8": 32400}
+    ME_BYTES_PER_PU = {"me64": 283422.6, "me32": 64257.7, "me16": 15408.4, "me8": 4067.6}   # tools/count_me_units.py, seed 4321
+    ME_CALLS_PER_PU = {"me64": 17.58, "me32": 16.23, "me16": 15.15, "me8": 15.09}
+    S_, R_ = W + 2 * MARGIN, H + 2 * MARGIN
+    launch_ms = stage_ms_loaded[dom]                       # measured with F chains in flight, i.e. under the load `value` is measured under
+    unique = None
+    if dom in n_by_stage:
+        n = n_by_stage[dom]
+        dom_bytes = int(ME_BYTES_PER_PU[dom] * n)
+        ub = W * H + (W + 2 * (MERANGE + 4)) * (H + 2 * (MERANGE + 4)) + n * (12 + 32)
+        unique = {"bytes_per_launch": ub, "achieved": round(ub / (launch_ms * 1e-3) / 1e9, 2),
+                  "frac": round(ub / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}
+        names = {"me64": "motion2_kernel<u8,64,4,planes>", "me32": "motion3_kernel<u8,32,64>", "me16": "motion3_kernel<u8,16,16>",
+                 "me8": "motion3_kernel<u8,8,16>"}
+        kernel = "%s (%s: %d PUs x %.0f B = %.1f reference slot calls per PU, SURVEY 8d per-call bytes — cache-served, see unique_footprint / hbm_counter_frac)" % (
+            names[dom], dom, n, ME_BYTES_PER_PU[dom], ME_CALLS_PER_PU[dom])
+    elif dom == "planes":
+        dom_bytes = 17 * S_ * R_                       # read the padded reference once, write 16 planes
+        kernel = "subpel_planes_kernel<u8> (16 quarter-pel planes of the padded reference)"
+    else:
+        dom_bytes = {"pred8": ab["pred"], "chain32": ab["chain"], "chain8": ab["chain"], "sa8d": ab["sa8d"], "border": ab["border"],
+                     "chroma": ab["chain"] // 2 + ab["pred"] // 2}[dom]
+        kernel = dom
+    achieved = dom_bytes / (launch_ms * 1e-3) / 1e9
+    traffic, traffic_src, traffic_note = pmc_traffic(dom)
+    frame_bytes, _ = pmc_frame_bytes()
+    # second roofline that actually binds at F frames in flight: VALU issue.  256 CUs x 4 SIMDs, one wave64 VALU instruction per
+    # 4 cycles per SIMD, 2.4 GHz (MI355X_MICROARCH.md) = 614 G wave-instructions / s.
+    vpf, vsrc = valu_per_frame()
+    valu = None
+    if vpf:
+        peak = 256 * 4 / 4 * 2.4e9
+        valu = {"wave_instr_per_frame": vpf, "source": vsrc, "peak_wave_instr_per_s": peak, "achieved_wave_instr_per_s": round(vpf * fps),
+                "frac": round(vpf * fps / peak, 4)}
+    out = {
+        "value": round(fps, 2), "unit": "frame passes/s", "steps": steps, "ms_per_step": round(ms_per_step, 4), "timed_s": round(dt, 3),
+        "workload": "1920x1080 8-bit 4:2:0, --me hex --merange 57 --subme 2, qp 28: frame pass = quarter-pel planes + top-down 2Nx2N "
+                    "motion search (64/32/16/8) + luma/chroma prediction + dct/quant/dequant/idct/recon/sse chain (Y, Cb, Cr) + sa8d + borders; "
+                    "F independent frame passes per GPU per step on F streams (x265 frame threads), each referencing the previous chain's recon; "
+                    "the last chain's recon goes to the next rank (RCCL send/recv) when N > 1.  A builder-defined composition of reference "
+                    "call sequences, not the encoder's own decisions (DESIGN.md §5)",
+        "frames_per_step": world * F, "frames_in_flight_per_gpu": F, "pus_per_frame": 42900, "tus_per_frame": 8100,
+        "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
+                     "hbm_counter_frac": round(traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if traffic else None,
+                     "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": launch_ms, "launch_ms_solo": stage_ms[dom],
+                     "launch_ms_note": "HIP events on the kernel's own stream with F chains in flight (solo single-stream figure beside it)",
+                     "unique_footprint": unique},
+        "whole_pass": {"pmc_bytes_per_frame": frame_bytes, "achieved": round(frame_bytes * fps / 1e9, 1) if frame_bytes else None,
+                       "frac": round(frame_bytes * fps / 1e9 / HBM_PEAK_GBPS, 4) if frame_bytes else None,
+                       "note": "sum over the pass's kernels of PMC FETCH + WRITE bytes per launch (committed profile) x frame passes/s of this run"},
+        "valu_issue": valu,
+        "stage_ms": stage_ms_loaded, "stage_ms_solo": stage_ms, "host_enqueue_ms_per_step": round(host_dt * 1e3 / steps, 4),
+    }
+    if world == 1 and args.cpu_frames > 0:
+        out["cpu_port"] = cpu_baseline(args.cpu_frames)
+        if not args.quick:
+            out["cpu_port_parallel"] = cpu_baseline_parallel()
+    return out
+
+
+def lookahead_kernel_probe(L, hp, np_mod, pairs=8):
+    """The GPU kernel that dominates the encode's device work, lookahead_p_kernel (CostEstimateGroup::estimateCUCost for a batch of (frame,
+    reference) pairs), launched live on its own stream with HIP events around it: `pairs` pairs of the 960x544 lowres geometry of a 1080p
+    source, one slice (x265's batch mode).  Returns (ms per launch, blocks per launch)."""
+    np = np_mod
+    from x265_amd.hipprim import DevBuf, LookaheadPair, check
+    from x265_amd.synth import make_scene
+    sc = make_scene(W, H, DEPTH, seed=4321)
+    M = 96
+    lw, lh = ((W // 2 + 7) // 8) * 8, ((H // 2 + 7) // 8) * 8
+    ls = lw + 2 * 32
+    ls += (32 - ls % 32) % 32
+    mx = my = 32
+    pe = (lh + 2 * my) * ls
+    org = my * ls + mx
+    wcu, hcu = lw // 8, lh // 8
+    ncu = wcu * hcu
+    st = C.c_void_p()
+    check(L.x265hip_stream_create(C.byref(st)))
+    planes = []
+    for key in ("ref", "src"):
+        src = np.ascontiguousarray(np.pad(sc[key], ((M, M), (M, M + 8)), mode="edge"))
+        ds = DevBuf(src)
+        pl = DevBuf.zeros((4, lh + 2 * my, ls), src.dtype)
+        ptrs = (C.c_void_p * 4)(*[pl.at(k * pe + org) for k in range(4)])
+        check(L.x265hip_lowres_init(DEPTH, ds.at(M * src.shape[1] + M), src.shape[1], ptrs, ls, lw, lh, mx, my, st))
+        planes.append((pl, ds))
+    icost, imode = DevBuf.zeros((ncu,), np.int32), DevBuf.zeros((ncu,), np.uint8)
+    check(L.x265hip_lowres_intra_estimate(DEPTH, planes[1][0].at(org), ls, wcu, hcu, icost.ptr, imode.ptr, None, None, st))
+    descs, keep = (LookaheadPair * pairs)(), []
+    for i in range(pairs):
+        o = [DevBuf.zeros((ncu, 2), np.int32), DevBuf.zeros((ncu,), np.int32), DevBuf.zeros((ncu,), np.uint16), DevBuf.zeros((hcu,), np.int32),
+             DevBuf.zeros((ncu,), np.uint64)]
+        d = descs[i]
+        d.fenc, d.ref, d.intraCost = planes[1][0].at(org), planes[0][0].at(org), icost.ptr
+        d.mvs, d.mvCosts, d.lowresCosts, d.rowSatds, d.sync = [b.ptr for b in o]
+        keep.append(o)
+    ddesc = DevBuf(np.frombuffer(bytes(descs), np.uint8))
+    est = DevBuf.zeros((pairs, 4), np.int64)
+    half = 2 * 32768
+    tab = np.zeros(2 * half + 1, np.uint16)
+    check(L.x265hip_mvcost_table(12, DEPTH, tab.ctypes.data, half))
+    dtab = DevBuf(tab)
+    ev0, ev1 = C.c_void_p(), C.c_void_p()
+    check(L.x265hip_event_create(C.byref(ev0)))
+    check(L.x265hip_event_create(C.byref(ev1)))
+    epoch, total, reps = 0, 0.0, 0
+    for it in range(3 + 20):
+        epoch += 1
+        check(L.x265hip_event_record(ev0, st))
+        check(L.x265hip_lookahead_cost_p_batch(DEPTH, ddesc.ptr, pairs, ls, pe, wcu, hcu, hcu, 1, dtab.at(half), epoch, est.ptr, st))
+        check(L.x265hip_event_record(ev1, st))
+        ms = C.c_float()
+        check(L.x265hip_event_elapsed_ms(ev0, ev1, C.byref(ms)))
+        if it >= 3:
+            total += ms.value
+            reps += 1
+    check(L.x265hip_stream_sync(st))
+    assert not est.get()[:, 3].any()
+    L.x265hip_event_destroy(ev0)
+    L.x265hip_event_destroy(ev1)
+    L.x265hip_stream_destroy(st)
+    return total / reps, pairs * ncu
+
+
+def encode_bench(args, rank, local_rank, world, fence):
+    """Real encode fps: oracle/_ref/x265_hip_8bit on this rank's own synthetic 1080p clip (K * CHUNK frames after a W * CHUNK warm-up run),
+    wall clock of this process between two fences; at N = 1 the unmodified reference encoder on the same clip beside it."""
+    import hashlib
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import encode_fps as ef
+    ref, hip = os.path.join(ef.REF, "x265_8bit"), os.path.join(ef.REF, "x265_hip_8bit")
+    if not (os.path.exists(ref) and os.path.exists(hip)):
+        raise SystemExit("bench.py: oracle/_ref/x265_8bit and x265_hip_8bit are missing — build them where /root/reference exists "
+                         "(python -c 'import __graft_entry__ as g; g.build()'); they travel to the GPU box with the tree")
+    from x265_amd.synth import make_clip
+    frames, wframes = args.steps * CHUNK, max(args.warmup, 0) * CHUNK
+    total = max(frames, wframes)
+    clip = "/tmp/x265hip_bench_%d_r%d.yuv" % (os.getpid(), rank)
+    make_clip(clip, W, H, total, seed=4321 + 101 * rank)
+    cores = os.cpu_count() or 1
+    per_rank = max(4, cores // world)
+    base = ["--input", clip, "--input-res", "%dx%d" % (W, H), "--input-depth", "8", "--fps", "30", "--preset", "medium", "--me", "hex", "--hash", "1"]
+    if world > 1:
+        base += ["--pools", str(per_rank)]                   # the ranks share the host: each encoder gets its share of the cores
+    visible = os.environ.get("HIP_VISIBLE_DEVICES")
+    env = dict(os.environ, X265HIP_VERBOSE="1", HIP_VISIBLE_DEVICES=visible.split(",")[local_rank] if visible else str(local_rank))
+    out_hip, out_ref = clip + ".gpu.hevc", clip + ".ref.hevc"
+    res = {}
+    try:
+        if wframes:
+            ef._run(hip, base + ["--frames", str(wframes)], out_hip, env=env)
+        fence()
+        t0 = time.perf_counter()
+        r = ef._run(hip, base + ["--frames", str(frames)], out_hip, env=env)
+        fence()
+        dt = time.perf_counter() - t0
+        if r["rc"]:
+            raise SystemExit("bench.py: x265_hip_8bit failed: " + r["tail"])
+        res = {"dt": dt, "frames": frames, "cli_fps": r["fps"], "served": r["served"], "pools": per_rank if world > 1 else cores}
+        if rank == 0 and world == 1 and not args.no_ref_encoder:
+            r0 = ef._run(ref, base + ["--frames", str(frames)], out_ref)
+            same = hashlib.sha256(open(out_ref, "rb").read()).digest() == hashlib.sha256(open(out_hip, "rb").read()).digest()
+            res["reference"] = {"cli_fps": r0["fps"], "wall_s": r0["wall_s"], "rc": r0["rc"], "byte_identical": bool(same),
+                                "bitstream_bytes": os.path.getsize(out_ref)}
+    finally:
+        for p in (clip, out_hip, out_ref):
+            if os.path.exists(p):
+                os.remove(p)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10, help="timed steps; one step = one %d-frame chunk of the encode" % CHUNK)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--cpu-frames", type=int, default=10, help="frame passes of the CPU port sample inside `frame_pass` (0 = skip)")
+    ap.add_argument("--no-ref-encoder", action="store_true")
+    ap.add_argument("--no-frame-pass", action="store_true", help="skip the device-resident frame-pass block")
+    ap.add_argument("--quick", action="store_true", help="skip the multi-process CPU port leg")
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="frame pass: independent passes per GPU per step, each on its own HIP stream (x265 --frame-threads inside one device)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from x265_amd import hipprim as hp
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libx265hip has no CPU fallback")
+    # X265HIP_BENCH_SAME_DEVICE=1 is a debugging aid for 1-GPU boxes: every rank uses cuda:0 and the exchange runs over gloo
+    same_dev = os.environ.get("X265HIP_BENCH_SAME_DEVICE") == "1"
+    if same_dev:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    L = hp.lib()
+    hp.check(L.x265hip_init(local_rank))
+    if world > 1:
+        if same_dev:
+            dist.init_process_group("gloo")
         else:
-            dom_bytes = {"pred8": ab["pred"], "chain32": ab["chain"], "chain8": ab["chain"], "sa8d": ab["sa8d"], "border": ab["border"],
-                         "chroma": ab["chain"] // 2 + ab["pred"] // 2}[dom]
-            kernel = dom
-        achieved = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(dom)
-        # second roofline that actually binds at F frames in flight: VALU issue.  256 CUs x 4 SIMDs, one wave64 VALU instruction per
-        # 4 cycles per SIMD, 2.4 GHz (MI355X_MICROARCH.md) = 614 G wave-instructions / s.
-        vpf, vsrc = valu_per_frame()
-        valu = None
-        if vpf:
-            peak = 256 * 4 / 4 * 2.4e9
-            valu = {"wave_instr_per_frame": vpf, "source": vsrc, "peak_wave_instr_per_s": peak, "achieved_wave_instr_per_s": round(vpf * fps),
-                    "frac": round(vpf * fps / peak, 4)}
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    enc = encode_bench(args, rank, local_rank, world, fence)
+    dt = enc["dt"]
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    fps = world * enc["frames"] / dt
+
+    fpb = None
+    if not args.no_frame_pass:
+        fpb = frame_pass_bench(args, rank, local_rank, world, max(args.steps, 20), max(args.warmup, 5))
+
+    if rank == 0:
+        la_ms, la_blocks = lookahead_kernel_probe(L, hp, np)
+        # ALGORITHMIC bytes per 8x8 lowres block of the P cost pass: SURVEY.md §8d per-call figures (sad / satd 2WHB, a quarter-pel candidate
+        # adds the two half-pel blocks and the averaged one) over the calls the reference issues per block on this clip geometry, counted
+        # with the pinned oracle (tools/count_lookahead_units.py: 19.77 calls, 3978 B per block, seed 4321)
+        LA_BYTES_PER_BLOCK, LA_CALLS_PER_BLOCK = 3978.0, 19.77
+        la_bytes = LA_BYTES_PER_BLOCK * la_blocks
+        ach = la_bytes / (la_ms * 1e-3) / 1e9
+        # what HBM has to deliver when caches work: the frame's plane + the reference's four half-pel planes once per pair, 22 B of results per block
+        uniq = (la_blocks // 8160) * 5 * 1024 * 608 + la_blocks * 22
         out = {
-            "metric": "encode fps (1080p preset medium hot path: frame passes per second)", "value": round(fps, 2), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "metric": "encode fps (1080p preset medium)", "value": round(fps, 3), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "1920x1080 8-bit 4:2:0, --me hex --merange 57 --subme 2, qp 28: frame pass = quarter-pel planes + top-down 2Nx2N "
-                                   "motion search (64/32/16/8) + luma/chroma prediction + dct/quant/dequant/idct/recon/sse chain (Y, Cb, Cr) + sa8d + borders; "
-                                   "F independent frame passes per GPU per step on F streams (x265 frame threads), each referencing the previous chain's recon; "
-                                   "the last chain's recon goes to the next rank (RCCL send/recv) when N > 1",
-                       "frames_per_step": world * F, "frames_in_flight_per_gpu": F, "pus_per_frame": 42900, "tus_per_frame": 8100},
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": dom_bytes, "launch_ms": stage_ms[dom], "unique_footprint": unique},
-            "valu_issue": valu,
-            "stage_ms": stage_ms, "host_enqueue_ms_per_step": round(host_dt * 1e3 / args.steps, 4),
+            "config": {"workload": "x265 --preset medium --me hex, 1920x1080 8-bit 4:2:0 synthetic clip (x265_amd/synth.make_clip: 96x96 tiles with their own "
+                                   "velocities + noise, seed 4321 + 101 * rank), %d frames per rank per timed run (one step = %d frames); the reference "
+                                   "encoder's binary + x265_amd/host/*.cpp + libx265hip.so (oracle/_ref/x265_hip_8bit): lookahead frame-cost estimates "
+                                   "batched on the GPU, C primitive slots, all host cores; N ranks = N encoders on N GPUs, each on its own clip"
+                                   % (enc["frames"], CHUNK),
+                       "frames_per_step": world * CHUNK, "encoder_cli_fps_rank0": enc["cli_fps"], "served_by_gpu": enc["served"],
+                       "host_cores": os.cpu_count(), "pool_threads_per_encoder": enc["pools"], "timed_s": round(dt, 2)},
+            "roofline": {"bound": "hbm", "kernel": "lookahead_p_kernel<u8> (%d (frame, reference) pairs of 960x544 lowres = %d 8x8 blocks x %.0f B = %.1f "
+                                                     "reference slot calls per block, SURVEY 8d per-call bytes; a latency-bound dependent chain, see DESIGN.md §5)"
+                                                     % (la_blocks // 8160, la_blocks, LA_BYTES_PER_BLOCK, LA_CALLS_PER_BLOCK),
+                         "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(la_bytes), "launch_ms": round(la_ms, 4),
+                         "launch_ms_note": "HIP events on the kernel's own stream, measured in this run",
+                         "unique_footprint": {"bytes_per_launch": uniq, "achieved": round(uniq / (la_ms * 1e-3) / 1e9, 2),
+                                              "frac": round(uniq / (la_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}},
         }
-        if world == 1 and args.cpu_frames > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_frames)
-            out["cpu_baseline_parallel"] = cpu_baseline_parallel()
-            if not args.no_ref_encoder:
-                out["reference_encoder"] = reference_encoder()
+        if "reference" in enc:
+            r0 = enc["reference"]
+            out["cpu_baseline"] = {"value": r0["cli_fps"], "unit": "frames/s", "cores": os.cpu_count(), "kind": "reference",
+                                   "sample": "the same %d-frame clip and arguments through oracle/_ref/x265_8bit (unmodified reference, [noasm] C primitives — "
+                                             "no nasm in the image, so the AVX2 / AVX-512 path cannot be built), its own fps line; wall %.1f s; pool = all host "
+                                             "cores, of which x265 keeps roughly 15 busy at this size" % (enc["frames"], r0["wall_s"]),
+                                   "byte_identical_to_gpu_path": r0["byte_identical"], "bitstream_bytes": r0["bitstream_bytes"]}
+            if not r0["byte_identical"]:
+                out["error"] = "the GPU-path bitstream differs from the reference encoder's"
+        if fpb:
+            out["frame_pass"] = fpb
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

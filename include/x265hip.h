@@ -370,8 +370,7 @@ int x265hip_lookahead_weight_cost_batch(int depth, const void* fencPlane, const 
  * two Lowres), its two cost evaluations, the 0.2 % test, and the weighting of the reference's four lowres planes.  refBuffers /
  * weightedBuffers: four padded buffers of planeElems elements each, one after the other (Lowres::buffer[0..3], LookaheadTLD::wbuffer);
  * padOffset = plane origin inside a buffer (Lowres::lowresPlane[0] - buffer[0]).  Blocks until done: *isWeighted and *chosen (host) are
- * ReferencePlanes::isWeighted and the weight the reference keeps only inside the weighted planes.  Both weight entries keep a small
- * device scratch per process: call them from one thread at a time. */
+ * ReferencePlanes::isWeighted and the weight the reference keeps only inside the weighted planes.  Re-entrant: scratch is per call / per thread. */
 int x265hip_lookahead_weights_analyse(int depth, const void* fencPlane, const void* refBuffers, int64_t planeElems, int64_t stride, int64_t padOffset,
                                       int paddedLines, int width, int lines, const int32_t* intraCost, uint64_t fencSsd, uint64_t fencSum,
                                       uint64_t refSsd, uint64_t refSum, void* weightedBuffers, x265hip_weight_param* chosen, int* isWeighted,

@@ -1,6 +1,9 @@
 """GPU parity of the frame pass (x265hip_framepass_*): every output bit-exact against the C restatement
 (oracle/x265_oracle_frame.c), from a 200x136 picture with 8x8 TU strips up to the BASELINE 1080p configuration, and a
 two-frame chain where the second frame searches the first frame's border-extended reconstruction."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -253,3 +256,30 @@ print(hsh.hexdigest())
         assert r.returncode == 0, r.stderr[-1500:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1] and len(outs[0]) == 64
+
+
+def _golden_cases():
+    import json
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "framepass_configs_golden.json")
+    return json.load(open(p))["cases"]
+
+
+@pytest.mark.parametrize("name", sorted(_golden_cases()))
+def test_baseline_configs_match_golden(fpmod, name):
+    """BASELINE.json configs[2], [3] and [4] AS CONFIGURED — 3840x2160 STAR merange 57 subme 3 with the chroma SATD term, 3840x2160 Main10 STAR
+    subme 4, 7680x4320 HEX — plus the 1080p B pass and two Main12 cases: the HIP frame pass on the seeded scene, every output hashed and compared
+    with the digests the pinned CPU oracle produced (tests/golden/make_framepass_golden.py; the oracle needs minutes per case, the GPU test only hashes)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_framepass_golden as mg
+    case = _golden_cases()[name]
+    p = case["params"]
+    key = tuple(p[k] for k in ("width", "height", "depth", "qp", "method", "merange", "subme", "seed", "pass"))
+    assert mg.CASES[name] == key, "golden file and generator disagree: regenerate"
+    sc, nxt = mg.scene(key)
+    fp = fpmod.FramePass(p["width"], p["height"], depth=p["depth"], qp=p["qp"], merange=p["merange"], method=p["method"], subme=p["subme"])
+    got = fp.run_host_yuv_b(sc, *nxt) if nxt else fp.run_host_yuv(sc)
+    dg = mg.digest(got)
+    bad = sorted(k for k in case["digests"] if dg.get(k) != case["digests"][k])
+    assert not bad, bad
+    assert set(dg) == set(case["digests"])
+    fp.close()

@@ -94,3 +94,19 @@ def test_oracle_lookahead_b_cost_matches_golden(depth):
 def test_oracle_mvcost_matches_golden(depth):
     for qp, d in GOLD[str(depth)]["mvcost"].items():
         assert digest(Orc(depth).mvcost_table(int(qp))) == d
+
+
+def test_framepass_config_golden_is_reproducible_on_the_cpu_tier():
+    """tests/golden/framepass_configs_golden.json (the digests the GPU tier compares BASELINE configs[2..4] against) is what the oracle produces:
+    the small case is re-derived here, and the file holds every case of the generator with matching parameters."""
+    import json
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_framepass_golden as mg
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "framepass_configs_golden.json")))["cases"]
+    assert sorted(gold) == sorted(mg.CASES)
+    for name, case in gold.items():
+        assert tuple(case["params"][k] for k in ("width", "height", "depth", "qp", "method", "merange", "subme", "seed", "pass")) == mg.CASES[name]
+        assert case["info"]["nonzero_mvs"] > 0 and case["info"]["numSig"] > 0
+    small = [n for n in mg.CASES if n.startswith("small")][0]
+    _, dg, _ = mg.run_oracle(small)
+    assert dg == gold[small]["digests"]

@@ -12,12 +12,28 @@
 // reference's serial walk stops at that same position (numSig reaching zero), so the words are identical.  The other four are short serial
 // walks through a CABAC context array, one lane per job.
 #include "common.h"
+#include <cstring>
+#include <mutex>
 
 namespace xh {
 
 __device__ uint32_t g_stateBits[128];
 __device__ uint16_t g_scanTab[3][16 + 64 + 256 + 1024];          // [type][offset(log2)..]
-static bool s_stateBitsSet = false, s_scanSet = false;
+// __device__ symbols exist once PER DEVICE: which devices hold the tables is tracked per device id, under a mutex (slot calls arrive from
+// every pool worker of the encoder, and a process may drive several GPUs)
+static constexpr int kMaxDevices = 64;
+static std::mutex s_tabLock;
+static bool s_scanSet[kMaxDevices] = {}, s_stateBitsOn[kMaxDevices] = {};
+static bool s_haveStateBits = false;
+static uint32_t s_stateBitsHost[128];
+
+static int current_device()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices)
+        return -1;
+    return d;
+}
 
 __host__ __device__ constexpr int scan_off(int log2) { return log2 == 2 ? 0 : log2 == 3 ? 16 : log2 == 4 ? 80 : 336; }
 
@@ -49,7 +65,11 @@ static void scan_positions(int type, int n, int* xs, int* ys)
 
 static int ensure_scan_tables()
 {
-    if (s_scanSet)
+    const int dev = current_device();
+    if (dev < 0)
+        return set_error(X265HIP_EHIP, "coefscan: no current device");
+    std::lock_guard<std::mutex> g(s_tabLock);
+    if (s_scanSet[dev])
         return X265HIP_OK;
     static uint16_t tab[3][16 + 64 + 256 + 1024];
     for (int type = 0; type < 3; type++)
@@ -66,7 +86,7 @@ static int ensure_scan_tables()
         }
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_scanTab), tab, sizeof(tab)) != hipSuccess)
         return set_error(X265HIP_EHIP, "coefscan: scan table upload failed");
-    s_scanSet = true;
+    s_scanSet[dev] = true;
     return X265HIP_OK;
 }
 
@@ -265,10 +285,21 @@ __global__ __launch_bounds__(256) void cost_c1c2_kernel(const uint16_t* __restri
     out[j] = (sum & 0x00FFFFFF) + (c1 << 26) + (firstC2Idx << 28);
 }
 
+// the CABAC table reaches each device the first time a cost kernel is about to run there
 static int need_state_bits(const char* who)
 {
-    if (!s_stateBitsSet)
+    const int dev = current_device();
+    if (dev < 0)
+        return set_error(X265HIP_EHIP, "%s: no current device", who);
+    std::lock_guard<std::mutex> g(s_tabLock);
+    if (!s_haveStateBits)
         return set_error(X265HIP_EINVAL, "%s: x265hip_set_entropy_state_bits has not been called", who);
+    if (!s_stateBitsOn[dev])
+    {
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stateBits), s_stateBitsHost, sizeof(s_stateBitsHost)) != hipSuccess)
+            return set_error(X265HIP_EHIP, "%s: CABAC table upload failed", who);
+        s_stateBitsOn[dev] = true;
+    }
     return X265HIP_OK;
 }
 
@@ -281,9 +312,11 @@ extern "C" int x265hip_set_entropy_state_bits(const uint32_t* bits)
     XH_CHECK_DEV();
     if (!bits)
         return set_error(X265HIP_EINVAL, "set_entropy_state_bits: null table");
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stateBits), bits, 128 * sizeof(uint32_t)) != hipSuccess)
-        return set_error(X265HIP_EHIP, "set_entropy_state_bits: upload failed");
-    s_stateBitsSet = true;
+    std::lock_guard<std::mutex> g(s_tabLock);
+    memcpy(s_stateBitsHost, bits, sizeof(s_stateBitsHost));
+    s_haveStateBits = true;
+    for (int d = 0; d < kMaxDevices; d++)
+        s_stateBitsOn[d] = false;                  // every device re-uploads before its next cost kernel (need_state_bits)
     return X265HIP_OK;
 }
 

@@ -114,6 +114,8 @@ int x265hip_mvcost_table(int qp, int depth, uint16_t* table, int half)
     return X265HIP_OK;
 }
 
+int x265hip_framepass_destroy(x265hip_framepass* fp);
+
 int x265hip_framepass_create(int width, int height, int depth, int qp, int merange, int searchMethod, int subme,
                              x265hip_framepass** out)
 {
@@ -123,6 +125,8 @@ int x265hip_framepass_create(int width, int height, int depth, int qp, int meran
         return set_error(X265HIP_EINVAL, "framepass_create: %dx%d depth %d qp %d merange %d me %d subme %d", width, height, depth, qp,
                          merange, searchMethod, subme);
     x265hip_framepass* fp = new x265hip_framepass();
+    // an error below releases everything allocated so far
+#define FP_TRYC(x) do { int e_ = (x); if (e_) { x265hip_framepass_destroy(fp); return e_; } } while (0)
     fp->width = width; fp->height = height; fp->depth = depth; fp->qp = qp;
     fp->merange = merange; fp->method = searchMethod; fp->subme = subme;
     fp->cuOffStrideS = fp->cuOffStrideP = fp->tuStrideF = fp->tuStrideP = fp->tuStrideR = -1;
@@ -131,7 +135,7 @@ int x265hip_framepass_create(int width, int height, int depth, int qp, int meran
     fp->planeElems = fp->planeStride = 0;
     fp->planeMarginX = fp->planeMarginY = 0;
     for (int i = 0; i < 12; i++)
-        FP_TRY(check_hip(hipEventCreate(&fp->ev[i]), "hipEventCreate(framepass)"));
+        FP_TRYC(check_hip(hipEventCreate(&fp->ev[i]), "hipEventCreate(framepass)"));
     for (int l = 0; l < 4; l++)
     {
         const int sz = kCuSize[l];
@@ -153,14 +157,14 @@ int x265hip_framepass_create(int width, int height, int depth, int qp, int meran
             }
         const int n = (int)par.size();
         fp->nLevel[l] = n;
-        FP_TRY(dev_upload(&fp->puXY[l], fp->hCuXY[l]));
-        FP_TRY(dev_upload(&fp->parent[l], par));
-        FP_TRY(dev_alloc(&fp->qmvp[l], 2 * (size_t)n));
-        FP_TRY(dev_alloc(&fp->mvmin[l], 2 * (size_t)n));
-        FP_TRY(dev_alloc(&fp->mvmax[l], 2 * (size_t)n));
-        FP_TRY(dev_alloc(&fp->mv[l], 2 * (size_t)n));
-        FP_TRY(dev_alloc(&fp->cost[l], (size_t)n));
-        FP_TRY(dev_alloc(&fp->sa8d[l], (size_t)n));
+        FP_TRYC(dev_upload(&fp->puXY[l], fp->hCuXY[l]));
+        FP_TRYC(dev_upload(&fp->parent[l], par));
+        FP_TRYC(dev_alloc(&fp->qmvp[l], 2 * (size_t)n));
+        FP_TRYC(dev_alloc(&fp->mvmin[l], 2 * (size_t)n));
+        FP_TRYC(dev_alloc(&fp->mvmax[l], 2 * (size_t)n));
+        FP_TRYC(dev_alloc(&fp->mv[l], 2 * (size_t)n));
+        FP_TRYC(dev_alloc(&fp->cost[l], (size_t)n));
+        FP_TRYC(dev_alloc(&fp->sa8d[l], (size_t)n));
         fp->cuOff[l] = fp->cuOffP[l] = nullptr;
     }
     // TUs: 32x32 over the 32-aligned area, 8x8 over the remaining right / bottom strips
@@ -175,12 +179,12 @@ int x265hip_framepass_create(int width, int height, int depth, int qp, int meran
     {
         const int n = (int)fp->hTuXY[t].size() / 2, nc = kTuSize[t] * kTuSize[t];
         fp->nTu[t] = n;
-        FP_TRY(dev_upload(&fp->tuXY[t], fp->hTuXY[t]));
-        FP_TRY(dev_alloc(&fp->level[t], (size_t)n * nc));
-        FP_TRY(dev_alloc(&fp->numSig[t], (size_t)n));
-        FP_TRY(dev_alloc(&fp->dist[t], (size_t)n));
+        FP_TRYC(dev_upload(&fp->tuXY[t], fp->hTuXY[t]));
+        FP_TRYC(dev_alloc(&fp->level[t], (size_t)n * nc));
+        FP_TRYC(dev_alloc(&fp->numSig[t], (size_t)n));
+        FP_TRYC(dev_alloc(&fp->dist[t], (size_t)n));
         std::vector<int32_t> qc(nc, quantScales[(qp + 6 * (depth - 8)) % 6]);       // QpParam: qp + QP_BD_OFFSET (quant.cpp:224)
-        FP_TRY(dev_upload(&fp->quantCoeff[t], qc));
+        FP_TRYC(dev_upload(&fp->quantCoeff[t], qc));
         fp->tuOffF[t] = fp->tuOffP[t] = fp->tuOffR[t] = nullptr;
     }
     // chroma TUs mirror the luma TU lists at half resolution; QpParam of chroma: Quant::setChromaQP (quant.cpp:233-243)
@@ -195,11 +199,11 @@ int x265hip_framepass_create(int width, int height, int depth, int qp, int meran
                 fp->hCtuXY[t].push_back(fp->hTuXY[t][i] >> 1);
             const int n = fp->nTu[t], nc = kCTuSize[t] * kCTuSize[t];
             std::vector<int32_t> qc(nc, quantScales[qpc % 6]);
-            FP_TRY(dev_upload(&fp->cquantCoeff[t], qc));
+            FP_TRYC(dev_upload(&fp->cquantCoeff[t], qc));
             // Cb and Cr outputs are one allocation each ([2n]: Cb then Cr) so both planes go through ONE chain launch
-            FP_TRY(dev_alloc(&fp->clevel[0][t], (size_t)2 * n * nc));
-            FP_TRY(dev_alloc(&fp->cnumSig[0][t], (size_t)2 * n));
-            FP_TRY(dev_alloc(&fp->cdist[0][t], (size_t)2 * n));
+            FP_TRYC(dev_alloc(&fp->clevel[0][t], (size_t)2 * n * nc));
+            FP_TRYC(dev_alloc(&fp->cnumSig[0][t], (size_t)2 * n));
+            FP_TRYC(dev_alloc(&fp->cdist[0][t], (size_t)2 * n));
             fp->clevel[1][t] = fp->clevel[0][t] + (size_t)n * nc;
             fp->cnumSig[1][t] = fp->cnumSig[0][t] + n;
             fp->cdist[1][t] = fp->cdist[0][t] + n;
@@ -209,9 +213,10 @@ int x265hip_framepass_create(int width, int height, int depth, int qp, int meran
         fp->cDeltaF = fp->cDeltaP = fp->cDeltaR = 0;
     }
     std::vector<uint16_t> tab(2 * kMvHalf + 1);
-    FP_TRY(x265hip_mvcost_table(qp, depth, tab.data(), kMvHalf));
-    FP_TRY(dev_upload(&fp->mvcost, tab));
+    FP_TRYC(x265hip_mvcost_table(qp, depth, tab.data(), kMvHalf));
+    FP_TRYC(dev_upload(&fp->mvcost, tab));
     *out = fp;
+#undef FP_TRYC
     return X265HIP_OK;
 }
 
@@ -253,6 +258,14 @@ int x265hip_framepass_destroy(x265hip_framepass* fp)
 struct ChromaArgs { const void *srcCb, *srcCr, *refCb, *refCr; void *predCb, *predCr, *recCb, *recCr; int64_t sS, sR, sP, sRec; };
 struct BArgs { const void *ref1, *ref1Cb, *ref1Cr; };       // second reference of a B pass (same strides and margins as the first)
 
+// cached graphs reference the offset tables / plane buffers of the geometry they were captured with
+static void drop_graphs(x265hip_framepass* fp)
+{
+    for (auto& g : fp->graphs) (void)hipGraphExecDestroy(g.exec);
+    fp->graphs.clear();
+    fp->plainRuns = 0;
+}
+
 static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t strideS, const void* ref, int64_t strideR,
                               void* pred, int64_t strideP, void* recon, int64_t strideRec, int marginX, int marginY, const ChromaArgs* ca,
                               void* stream, const BArgs* ba = nullptr)
@@ -264,6 +277,7 @@ static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t st
     // offset tables depend on the caller's strides: (re)build them when the strides change (first run, normally once)
     if (fp->cuOffStrideS != strideS || fp->cuOffStrideP != strideP)
     {
+        drop_graphs(fp);
         FP_TRY(check_hip(hipStreamSynchronize(as_stream(stream)), "framepass sync"));
         for (int l = 0; l < 4; l++)
         {
@@ -274,6 +288,7 @@ static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t st
     }
     if (fp->tuStrideF != strideS || fp->tuStrideP != strideP || fp->tuStrideR != strideRec)
     {
+        drop_graphs(fp);
         FP_TRY(check_hip(hipStreamSynchronize(as_stream(stream)), "framepass sync"));
         for (int t = 0; t < 2; t++)
         {
@@ -286,6 +301,7 @@ static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t st
     // sub-pel planes of this reference (16 x padded picture, e.g. 43 MB at 1080p 8-bit): allocated once per geometry
     if (!fp->planes || fp->planeStride != strideR || fp->planeMarginX != marginX || fp->planeMarginY != marginY)
     {
+        drop_graphs(fp);
         FP_TRY(check_hip(hipStreamSynchronize(as_stream(stream)), "framepass sync"));
         if (fp->planes) (void)hipFree(fp->planes);
         fp->planes = nullptr;
@@ -427,6 +443,7 @@ static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t st
             return set_error(X265HIP_EINVAL, "framepass_run_yuv: Cb and Cr planes are more than 2^31 elements apart");
         if (fp->cStrideF != ca->sS || fp->cStrideP != ca->sP || fp->cStrideR != ca->sRec || fp->cDeltaF != dF || fp->cDeltaP != dP || fp->cDeltaR != dR)
         {
+            drop_graphs(fp);
             FP_TRY(check_hip(hipStreamSynchronize(as_stream(stream)), "framepass sync"));
             for (int t = 0; t < 2; t++)
             {
@@ -547,9 +564,13 @@ int x265hip_framepass_run_yuv(x265hip_framepass* fp, const x265hip_yuv* src, con
     const hipError_t ce = hipStreamEndCapture(as_stream(stream), &graph);
     if (rc || ce != hipSuccess || !graph)
     {
+        // the capture is over either way; whatever went wrong inside it (an allocation or a synchronize is illegal while capturing), the
+        // pass itself is still owed: run it plainly
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
-        return rc ? rc : plain();
+        const int rp = plain();
+        if (!rp) { fp->plainRuns++; fp->lastPlain = key; }
+        return rp;
     }
     hipGraphExec_t exec = nullptr;
     const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);

@@ -88,14 +88,11 @@ __global__ __launch_bounds__(256) void weight_cost_kernel(const P* __restrict__ 
 static int launch_weight_costs(int depth, const void* fenc, const void* ref, int64_t stride, int width, int lines, const int32_t* intraCost,
                                const x265hip_weight_param* wp, int n, uint32_t* costs, hipStream_t st)
 {
-    static WeightCand* dCand = nullptr;
-    static int cap = 0;
-    if (n > cap)
-    {
-        if (dCand) (void)hipFree(dCand);
-        cap = n < 16 ? 16 : n;
-        if (hipMalloc((void**)&dCand, sizeof(WeightCand) * cap) != hipSuccess) { cap = 0; dCand = nullptr; return set_error(X265HIP_ENOMEM, "weight_cost: candidates"); }
-    }
+    // candidates live in a stream-ordered allocation of this call (freed on the stream behind the kernel): no process-wide scratch, so
+    // any thread, any device, any stream
+    WeightCand* dCand = nullptr;
+    if (hipMallocAsync((void**)&dCand, sizeof(WeightCand) * n, st) != hipSuccess)
+        return set_error(X265HIP_ENOMEM, "weight_cost: candidates");
     const int correction = 14 - depth;
     WeightCand* h = (WeightCand*)alloca(sizeof(WeightCand) * n);
     for (int i = 0; i < n; i++)
@@ -120,6 +117,7 @@ static int launch_weight_costs(int depth, const void* fenc, const void* ref, int
         hipLaunchKernelGGL((weight_cost_kernel<uint16_t>), grid, block, 0, st, (const uint16_t*)fenc, (const uint16_t*)ref, stride, wcu, ncu, intraCost, dCand, costs,
                            (1 << depth) - 1, correction);
     XH_LAUNCH_CHECK("weight_cost_kernel");
+    (void)hipFreeAsync(dCand, st);
     return X265HIP_OK;
 }
 
@@ -153,9 +151,14 @@ extern "C" int x265hip_lookahead_weights_analyse(int depth, const void* fencPlan
     const char* ref0 = (const char*)refBuffers + padOffset * B;
     *isWeighted = 0;
     chosen->inputWeight = chosen->inputOffset = chosen->log2WeightDenom = chosen->wtPresent = 0;
-    static uint32_t* dCost = nullptr;
-    if (!dCost && hipMalloc((void**)&dCost, sizeof(uint32_t) * 4) != hipSuccess)
+    // four words of device scratch per (thread, device): the function blocks, so a thread never has two calls in flight
+    static thread_local uint32_t* t_cost[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return set_error(X265HIP_EHIP, "lookahead_weights_analyse: no current device");
+    if (!t_cost[dev] && hipMalloc((void**)&t_cost[dev], sizeof(uint32_t) * 4) != hipSuccess)
         return set_error(X265HIP_ENOMEM, "lookahead_weights_analyse: scratch");
+    uint32_t* dCost = t_cost[dev];
     auto cost_of = [&](const x265hip_weight_param& wp, unsigned int* out) -> int {
         int e = launch_weight_costs(depth, fencPlane, ref0, stride, width, lines, intraCost, &wp, 1, dCost, st);
         if (e) return e;
