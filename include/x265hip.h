@@ -592,6 +592,30 @@ typedef struct x265hip_la_estimate
 int x265hip_la_estimate_batch(x265hip_la* la, x265hip_la_estimate* est, int n, int numRowsPerSlice, int numSlices);
 int x265hip_la_stats(x265hip_la* la, uint64_t* batches, uint64_t* estimates, uint64_t* searches);
 
+/* ---------------------------------------------------------------- reference-picture mirrors (lookup face) --------- */
+/* The sub-pel filters the encoder applies to a reference picture (luma_hpp / luma_vpp / luma_hvpp from MotionEstimate::subpelCompare,
+ * motion.cpp:1571-1600, and Predict::predInterLumaPixel, predict.cpp:245-266) are per-pixel functions of that picture, so a mirrored
+ * picture gets all 15 fractional planes computed once, as its CTU rows are published, and the table slots serve a filter call as a block
+ * copy (x265_amd/host/x265_hip_refplanes.cpp).  Everything here is asynchronous to the encoder: rows_final() queues work
+ * for a worker thread and returns; readers use only what rows_ready() has published and compute the rest themselves.
+ * Geometry = PicYuv's (picyuv.cpp:87-128): hostBase = m_picBuf[0], bufRows rows of `stride` elements, picture origin at
+ * (marginY, marginX).  The buffer stays the caller's and must outlive the refpic. */
+typedef struct x265hip_refpic x265hip_refpic;
+x265hip_refpic* x265hip_refpic_create(int depth, int picW, int picH, int64_t stride, int marginX, int marginY, int bufRows, const void* hostBase);
+void x265hip_refpic_destroy(x265hip_refpic* rp);
+/* a new picture is about to be reconstructed into the buffer: nothing is valid any more; queued work of the old picture is dropped */
+int x265hip_refpic_reset(x265hip_refpic* rp);
+/* picture rows [0, rowsFinal) are final in the buffer together with their left / right margins and the top margin (rowsFinal >= picH:
+ * the whole padded picture) — what FrameFilter::processPostRow guarantees when it sets m_reconRowFlag (framefilter.cpp:664) */
+int x265hip_refpic_rows_final(x265hip_refpic* rp, int rowsFinal);
+/* host plane of phase p = yFrac * 4 + xFrac (1..15): same layout as the buffer — element offset of a pixel in hostBase == in the plane */
+const void* x265hip_refpic_plane(x265hip_refpic* rp, int phase);
+/* r: the planes hold picture rows [-(marginY - 4), r) (r <= picH + marginY - 4 once the picture is complete); columns
+ * [-(marginX - 4), picW + marginX - 4).  *_ptr: the same int for readers that poll it per call (load it with acquire semantics). */
+int x265hip_refpic_rows_ready(x265hip_refpic* rp);
+const int* x265hip_refpic_rows_ready_ptr(x265hip_refpic* rp);
+int x265hip_refpic_wait(x265hip_refpic* rp);        /* blocks until the worker has nothing queued for rp; reports a worker failure */
+
 /* ---------------------------------------------------------------- per-call entry points (host pointers) ----- */
 /* What the reference-side table shims bind (x265_amd/host/x265_hip_primitives.cpp).  Arguments are the slot's own
  * arguments (HOST pointers, caller-owned, valid only during the call — primitives.h:133-234); each call stages the

@@ -204,3 +204,67 @@ int x265hip_la_stats(x265hip_la* la, uint64_t* batches, uint64_t* estimates, uin
     if (searches) *searches = la->searches;
     return 0;
 }
+
+/* ---------------------------------------------------------------- reference-picture mirrors, emulated ------------------------------- *
+ * Synchronous: rows_final() filters the newly final band with the oracle's luma filters (orc_interp_*_pp, the restatement of
+ * ipfilter.cpp:79-369) before it returns.  Same contract as the device implementation otherwise. */
+struct x265hip_refpic
+{
+    int depth, B, picW, picH, marginX, marginY, bufRows;
+    int64_t stride, planeElems;
+    const char* hostBase;
+    char* planes;        /* 15 planes */
+    int phaseDone;       /* buffer rows */
+    int rowsReady;
+};
+
+x265hip_refpic* x265hip_refpic_create(int depth, int picW, int picH, int64_t stride, int marginX, int marginY, int bufRows, const void* hostBase)
+{
+    x265hip_refpic* rp = (x265hip_refpic*)calloc(1, sizeof(*rp));
+    rp->depth = depth; rp->B = depth == 8 ? 1 : 2; rp->picW = picW; rp->picH = picH; rp->marginX = marginX; rp->marginY = marginY; rp->bufRows = bufRows;
+    rp->stride = stride; rp->planeElems = stride * bufRows; rp->hostBase = (const char*)hostBase;
+    rp->planes = (char*)calloc((size_t)15 * rp->planeElems, rp->B);
+    rp->phaseDone = 4;
+    rp->rowsReady = -(1 << 30);
+    return rp;
+}
+void x265hip_refpic_destroy(x265hip_refpic* rp) { if (rp) { free(rp->planes); free(rp); } }
+int x265hip_refpic_reset(x265hip_refpic* rp) { rp->phaseDone = 4; __atomic_store_n(&rp->rowsReady, -(1 << 30), __ATOMIC_RELEASE); return 0; }
+const void* x265hip_refpic_plane(x265hip_refpic* rp, int phase) { return rp->planes + (size_t)(phase - 1) * rp->planeElems * rp->B; }
+int x265hip_refpic_rows_ready(x265hip_refpic* rp) { return __atomic_load_n(&rp->rowsReady, __ATOMIC_ACQUIRE); }
+const int* x265hip_refpic_rows_ready_ptr(x265hip_refpic* rp) { return &rp->rowsReady; }
+int x265hip_refpic_wait(x265hip_refpic* rp) { (void)rp; return 0; }
+
+int x265hip_refpic_rows_final(x265hip_refpic* rp, int rowsFinal)
+{
+    const int complete = rowsFinal >= rp->picH;
+    const int finalRows = complete ? rp->marginY + rp->picH + rp->marginY : rp->marginY + rowsFinal;
+    const int phaseEnd = finalRows - 4;
+    if (phaseEnd <= rp->phaseDone) return 0;
+    const int w = rp->picW + 2 * rp->marginX - 8, h = phaseEnd - rp->phaseDone;
+    const size_t off = (size_t)rp->phaseDone * rp->stride + 4;            /* first computed element of the band (buffer coordinates) */
+    for (int yf = 0; yf < 4; yf++)
+        for (int xf = 0; xf < 4; xf++)
+        {
+            if (!(xf | yf)) continue;
+            char* dst = rp->planes + ((size_t)(yf * 4 + xf - 1) * rp->planeElems + off) * rp->B;
+            const char* src = rp->hostBase + off * rp->B;
+#define FILT(T, SFX) do { \
+                /* the oracle's filters work on PU-sized blocks (their intermediate buffer holds 64 x 71 samples): tile the band */ \
+                for (int ty = 0; ty < h; ty += 64) \
+                    for (int tx = 0; tx < w; tx += 64) \
+                    { \
+                        const int bw = w - tx < 64 ? w - tx : 64, bh = h - ty < 64 ? h - ty : 64; \
+                        const T* s_ = (const T*)src + (size_t)ty * rp->stride + tx; \
+                        T* d_ = (T*)dst + (size_t)ty * rp->stride + tx; \
+                        if (!yf) orc_interp_horiz_pp_##SFX(8, s_, rp->stride, d_, rp->stride, bw, bh, xf, rp->depth); \
+                        else if (!xf) orc_interp_vert_pp_##SFX(8, s_, rp->stride, d_, rp->stride, bw, bh, yf, rp->depth); \
+                        else orc_interp_hv_pp_##SFX(8, s_, rp->stride, d_, rp->stride, bw, bh, xf, yf, rp->depth); \
+                    } } while (0)
+            if (rp->depth == 8) FILT(uint8_t, 8); else FILT(uint16_t, 16);
+#undef FILT
+        }
+    rp->phaseDone = phaseEnd;
+    __atomic_store_n(&rp->rowsReady, phaseEnd - rp->marginY, __ATOMIC_RELEASE);
+    return 0;
+}

@@ -1,4 +1,5 @@
-"""The x265-side binding of the lookahead seam (x265_amd/host/x265_hip_lookahead.cpp) proven on the CPU tier: the reference encoder linked with
+"""The x265-side bindings of the two seams — the lookahead (x265_amd/host/x265_hip_lookahead.cpp) and the reference-picture mirrors with their lookup
+slots (x265_amd/host/x265_hip_refplanes.cpp) — proven on the CPU tier: the reference encoder linked with
 the binding and with tests/support/libx265hip_emul.so — the x265hip_la_* ABI implemented by the ORACLE, test infrastructure — must produce the
 same bytes as the unmodified reference encoder.  That pins, against the real x265, (a) the binding's plumbing (slot management, what is batched,
 what is written back into the Lowres arrays, the cooperative-slice rule) and (b) the oracle's restatement of estimateCUCost with AQ, weightp,
@@ -52,5 +53,8 @@ def test_binding_with_emulated_abi_is_byte_identical(tmp_path, name):
     assert outs["ref"][0] == outs["emul"][0], "bitstreams differ"
     served = [l for l in outs["emul"][1].splitlines() if "frame-cost estimates" in l]
     assert served and int(served[0].split()[2]) >= frames - 2, outs["emul"][1][-600:]
+    # the reference-picture mirrors (x265_hip_refplanes.cpp): luma sub-pel filter calls answered out of the (emulated) planes
+    planes = [l for l in outs["emul"][1].splitlines() if "x265hip: refplanes:" in l]
+    assert planes and int(planes[0].split()[2]) > 1000, outs["emul"][1][-600:]
     if "fade" in name:
         assert "Weighted P-Frames: Y:0.0%" not in outs["ref"][1], "the fade clip was meant to exercise weightp"

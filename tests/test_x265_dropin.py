@@ -116,3 +116,5 @@ def test_lookahead_seam_on_gpu_is_byte_identical(case):
     assert r["byte_identical"], r
     served = [l for l in r["gpu"]["served"] if "frame-cost estimates" in l]
     assert served and int(served[0].split()[2]) > 10, r
+    planes = [l for l in r["gpu"]["served"] if "refplanes:" in l]
+    assert planes and int(planes[0].split()[2]) > 10000, r

@@ -478,6 +478,28 @@ __global__ __launch_bounds__(256) void subpel_planes8_kernel(const uint8_t* __re
 
 } // namespace xh
 
+namespace xh {
+// the region [x0, x1) x [y0, y1) (picture coordinates) of all 15 fractional planes + plane 0; reads rows y0 - 3 .. y1 + 3 and columns
+// x0 - 4 .. x1 + 3 of the reference.  The whole picture is one call; a band of rows is the same launch with a smaller y range (refpic.hip).
+int build_subpel_rows(int depth, const void* refOrigin, int64_t stride, int x0, int x1, int y0, int y1, void* planesOrigin, int64_t planeElems, hipStream_t st)
+{
+    if (x1 <= x0 || y1 <= y0) return X265HIP_OK;
+    const int tilesX = (x1 - x0 + 63) / 64, tilesY = (y1 - y0 + 15) / 16;
+    dim3 grid(tilesX * tilesY), block(256);
+    static const bool generic8 = getenv("X265HIP_PLANES_GENERIC") != nullptr;
+    if (depth == 8 && !generic8)
+        hipLaunchKernelGGL(subpel_planes8_kernel, grid, block, 0, st, (const uint8_t*)refOrigin, stride, (uint8_t*)planesOrigin, planeElems, x0, y0, x1, y1);
+    else if (depth == 8)
+        hipLaunchKernelGGL((subpel_planes_kernel<uint8_t>), grid, block, 0, st, (const uint8_t*)refOrigin, stride, (uint8_t*)planesOrigin, planeElems, x0, y0, x1, y1,
+                           depth);
+    else
+        hipLaunchKernelGGL((subpel_planes_kernel<uint16_t>), grid, block, 0, st, (const uint16_t*)refOrigin, stride, (uint16_t*)planesOrigin, planeElems, x0, y0, x1,
+                           y1, depth);
+    XH_LAUNCH_CHECK("subpel_planes_kernel");
+    return X265HIP_OK;
+}
+} // namespace xh
+
 extern "C" int x265hip_build_subpel_planes(int depth, const void* refOrigin, int64_t stride, int picW, int picH, int marginX, int marginY,
                                            void* planesOrigin, int64_t planeElems, void* stream)
 {
@@ -485,21 +507,8 @@ extern "C" int x265hip_build_subpel_planes(int depth, const void* refOrigin, int
     if (!valid_depth(depth) || picW < 8 || picH < 8 || marginX < 8 || marginY < 8 || (picW & 3) || (marginX & 3))
         return set_error(X265HIP_EINVAL, "build_subpel_planes: depth %d pic %dx%d margins %d,%d", depth, picW, picH, marginX, marginY);
     // the 8-tap support needs 3 / 4 pixels around every output: compute everything except the outermost 4 columns / rows
-    const int x0 = -marginX + 4, y0 = -marginY + 4, x1 = picW + marginX - 4, y1 = picH + marginY - 4;
-    const int tilesX = (x1 - x0 + 63) / 64, tilesY = (y1 - y0 + 15) / 16;
-    dim3 grid(tilesX * tilesY), block(256);
-    static const bool generic8 = getenv("X265HIP_PLANES_GENERIC") != nullptr;
-    if (depth == 8 && !generic8)
-        hipLaunchKernelGGL(subpel_planes8_kernel, grid, block, 0, as_stream(stream), (const uint8_t*)refOrigin, stride, (uint8_t*)planesOrigin, planeElems,
-                           x0, y0, x1, y1);
-    else if (depth == 8)
-        hipLaunchKernelGGL((subpel_planes_kernel<uint8_t>), grid, block, 0, as_stream(stream), (const uint8_t*)refOrigin, stride,
-                           (uint8_t*)planesOrigin, planeElems, x0, y0, x1, y1, depth);
-    else
-        hipLaunchKernelGGL((subpel_planes_kernel<uint16_t>), grid, block, 0, as_stream(stream), (const uint16_t*)refOrigin, stride,
-                           (uint16_t*)planesOrigin, planeElems, x0, y0, x1, y1, depth);
-    XH_LAUNCH_CHECK("subpel_planes_kernel");
-    return X265HIP_OK;
+    return xh::build_subpel_rows(depth, refOrigin, stride, -marginX + 4, picW + marginX - 4, -marginY + 4, picH + marginY - 4, planesOrigin, planeElems,
+                                 as_stream(stream));
 }
 
 // ---- prediction out of the quarter-pel planes: predInterLumaPixel (predict.cpp:245-266) becomes a phase-selected block copy ----

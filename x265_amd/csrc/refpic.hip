@@ -1,0 +1,237 @@
+// refpic.hip — reference-picture mirrors behind x265hip_refpic_* (include/x265hip.h): the "lookup" face of the boundary.
+//
+// x265's sub-pel work on a reference picture — every luma_hpp / luma_vpp / luma_hvpp call of MotionEstimate::subpelCompare
+// (motion.cpp:1571-1600) and of Predict::predInterLumaPixel (predict.cpp:245-266) — is a per-pixel function of the reconstructed
+// picture alone: value = f(picture, x, y, xFrac, yFrac).  A reference picture therefore needs it computed ONCE, not once per candidate
+// of every PU of every frame that references it.  A refpic mirrors one reconstructed luma picture of the DPB on the device; as the
+// encoder publishes finished CTU rows (FrameFilter::processPostRow, framefilter.cpp:654-664) a worker thread
+//     uploads the new rows (copied into a page-locked staging plane first: the encoder's buffer is ordinary memory the encoder may free),
+//     filters every phase row whose 8-tap support is final — all 15 fractional phases in one launch of the sub-pel plane kernel
+//       (interp.hip; plane[yFrac * 4 + xFrac](x, y) == what the reference's filter returns for that pixel),
+//     brings the 15 band slices back into page-locked host planes with ONE 2-D copy, and publishes `rowsReady`.
+// The table slots then serve a filter call on a mirrored picture as a W x H block copy out of the right plane
+// (x265_amd/host/x265_hip_refplanes.cpp); rows not yet published fall through to the C filter — same values either way, so the
+// bitstream is identical whatever the timing.  The encoder never waits for this module.
+#include "common.h"
+#include "internal.h"
+#include <atomic>
+#include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
+struct x265hip_refpic
+{
+    int depth = 8, B = 1, picW = 0, picH = 0, marginX = 0, marginY = 0, bufRows = 0, device = 0;
+    int64_t stride = 0, planeElems = 0;
+    const char* hostBase = nullptr;          // the encoder's buffer (PicYuv::m_picBuf[0])
+    char* hStage = nullptr;                   // page-locked staging copy of the rows on their way up
+    char* dPic = nullptr;                     // device copy of the padded picture
+    char* dPlanes = nullptr;                  // 16 planes (plane 0 unused), planeElems apart
+    char* hPlanes = nullptr;                  // page-locked host planes 1..15 at (p - 1) * planeElems
+    hipStream_t st = nullptr;
+    // progress (buffer rows: 0 = first row of the top margin)
+    int uploaded = 0;                         // rows [0, uploaded) of the buffer are on the device   (worker only)
+    int phaseDone = 4;                        // phase rows [4, phaseDone) are in hPlanes             (worker only)
+    std::atomic<int> rowsReady{ -(1 << 30) }; // published: phase rows of PICTURE rows [-(marginY - 4), rowsReady) are valid
+    std::atomic<uint32_t> epoch{ 0 };         // bumped by reset(): queued work of an older picture is dropped
+    std::atomic<int> pending{ 0 };            // queued + running jobs
+    std::atomic<int> failed{ 0 };
+};
+
+namespace xh {
+
+struct RefJob { x265hip_refpic* rp; int rowsFinal; uint32_t epoch; };
+
+struct RefWorker
+{
+    std::mutex m;
+    std::condition_variable cv, idle;
+    std::deque<RefJob> q;
+    std::thread th;
+    bool started = false, stop = false;
+
+    void start()
+    {
+        std::lock_guard<std::mutex> g(m);
+        if (started) return;
+        started = true;
+        th = std::thread([this] { run(); });
+        atexit([] { worker().shutdown(); });
+    }
+    void shutdown()
+    {
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (!started || stop) return;
+            stop = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+    void push(const RefJob& j)
+    {
+        j.rp->pending.fetch_add(1);
+        {
+            std::lock_guard<std::mutex> g(m);
+            q.push_back(j);
+        }
+        cv.notify_one();
+    }
+    static RefWorker& worker() { static RefWorker* w = new RefWorker; return *w; }      // leaked on purpose: lives as long as the process
+    void run();
+};
+
+int build_subpel_rows(int depth, const void* refOrigin, int64_t stride, int x0, int x1, int y0, int y1, void* planesOrigin, int64_t planeElems, hipStream_t st);
+
+static void process(const RefJob& j)
+{
+    x265hip_refpic* rp = j.rp;
+    if (j.epoch != rp->epoch.load() || rp->failed.load())
+        return;
+    if (hipSetDevice(rp->device) != hipSuccess) { rp->failed = 1; return; }
+    const int B = rp->B;
+    // buffer rows that are final: top margin + picture rows [0, rowsFinal); the whole buffer once the picture is complete
+    const bool complete = j.rowsFinal >= rp->picH;
+    const int finalRows = complete ? rp->marginY + rp->picH + rp->marginY : rp->marginY + j.rowsFinal;
+    if (finalRows <= rp->uploaded)
+        return;
+    const size_t off = (size_t)rp->uploaded * rp->stride * B, bytes = (size_t)(finalRows - rp->uploaded) * rp->stride * B;
+    memcpy(rp->hStage + off, rp->hostBase + off, bytes);                  // final rows: nobody writes them any more
+    if (hipMemcpyAsync(rp->dPic + off, rp->hStage + off, bytes, hipMemcpyHostToDevice, rp->st) != hipSuccess) { rp->failed = 1; return; }
+    rp->uploaded = finalRows;
+    // phase rows whose support (rows y - 3 .. y + 4) is final; the outermost 4 rows of the buffer are never computed
+    const int phaseEnd = finalRows - 4;
+    if (phaseEnd > rp->phaseDone)
+    {
+        const int y0 = rp->phaseDone - rp->marginY, y1 = phaseEnd - rp->marginY;       // picture coordinates
+        const char* org = rp->dPic + ((size_t)rp->marginY * rp->stride + rp->marginX) * B;
+        char* porg = rp->dPlanes + ((size_t)rp->marginY * rp->stride + rp->marginX) * B;
+        if (build_subpel_rows(rp->depth, org, rp->stride, -rp->marginX + 4, rp->picW + rp->marginX - 4, y0, y1, porg, rp->planeElems, rp->st))
+        { rp->failed = 1; return; }
+        // planes 1..15, rows [phaseDone, phaseEnd): one 2-D copy — "row" = the band of one plane, pitch = one plane
+        const size_t bandOff = (size_t)rp->phaseDone * rp->stride * B, bandBytes = (size_t)(phaseEnd - rp->phaseDone) * rp->stride * B;
+        const size_t pitch = (size_t)rp->planeElems * B;
+        if (hipMemcpy2DAsync(rp->hPlanes + bandOff, pitch, rp->dPlanes + pitch + bandOff, pitch, bandBytes, 15, hipMemcpyDeviceToHost, rp->st) != hipSuccess)
+        { rp->failed = 1; return; }
+        if (hipStreamSynchronize(rp->st) != hipSuccess) { rp->failed = 1; return; }
+        rp->phaseDone = phaseEnd;
+        if (j.epoch == rp->epoch.load())
+            rp->rowsReady.store(phaseEnd - rp->marginY, std::memory_order_release);
+    }
+    else if (hipStreamSynchronize(rp->st) != hipSuccess)
+        rp->failed = 1;
+}
+
+void RefWorker::run()
+{
+    for (;;)
+    {
+        RefJob j;
+        {
+            std::unique_lock<std::mutex> g(m);
+            cv.wait(g, [this] { return stop || !q.empty(); });
+            if (q.empty())
+                return;
+            j = q.front();
+            q.pop_front();
+        }
+        process(j);
+        if (j.rp->pending.fetch_sub(1) == 1)
+        {
+            std::lock_guard<std::mutex> g(m);
+            idle.notify_all();
+        }
+    }
+}
+
+} // namespace xh
+
+using namespace xh;
+
+extern "C" {
+
+x265hip_refpic* x265hip_refpic_create(int depth, int picW, int picH, int64_t stride, int marginX, int marginY, int bufRows, const void* hostBase)
+{
+    if (ensure_device()) return nullptr;
+    if (!valid_depth(depth) || picW < 8 || picH < 8 || (picW & 3) || (marginX & 3) || marginX < 8 || marginY < 8 || stride < picW + 2 * marginX ||
+        bufRows < picH + 2 * marginY || !hostBase)
+    {
+        set_error(X265HIP_EINVAL, "x265hip_refpic_create: depth %d pic %dx%d stride %lld margins %d,%d rows %d", depth, picW, picH, (long long)stride, marginX, marginY, bufRows);
+        return nullptr;
+    }
+    x265hip_refpic* rp = new x265hip_refpic;
+    rp->depth = depth; rp->B = depth == 8 ? 1 : 2;
+    rp->picW = picW; rp->picH = picH; rp->marginX = marginX; rp->marginY = marginY; rp->bufRows = bufRows;
+    rp->stride = stride; rp->planeElems = stride * (int64_t)bufRows;
+    rp->hostBase = (const char*)hostBase;
+    (void)hipGetDevice(&rp->device);
+    const size_t planeBytes = (size_t)rp->planeElems * rp->B;
+    bool ok = hipStreamCreateWithFlags(&rp->st, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc((void**)&rp->dPic, planeBytes) == hipSuccess && hipMalloc((void**)&rp->dPlanes, planeBytes * 16) == hipSuccess &&
+              hipHostMalloc((void**)&rp->hPlanes, planeBytes * 15, hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void**)&rp->hStage, planeBytes, hipHostMallocDefault) == hipSuccess;
+    if (!ok)
+    {
+        set_error(X265HIP_ENOMEM, "x265hip_refpic_create: %zu bytes per plane", planeBytes);
+        x265hip_refpic_destroy(rp);
+        return nullptr;
+    }
+    RefWorker::worker().start();
+    return rp;
+}
+
+int x265hip_refpic_wait(x265hip_refpic* rp)
+{
+    if (!rp) return set_error(X265HIP_EINVAL, "x265hip_refpic_wait: null");
+    RefWorker& w = RefWorker::worker();
+    std::unique_lock<std::mutex> g(w.m);
+    w.idle.wait(g, [rp] { return rp->pending.load() == 0; });
+    return rp->failed.load() ? set_error(X265HIP_EHIP, "x265hip_refpic: a device operation of the worker failed") : X265HIP_OK;
+}
+
+void x265hip_refpic_destroy(x265hip_refpic* rp)
+{
+    if (!rp) return;
+    rp->epoch.fetch_add(1);
+    if (rp->st) (void)x265hip_refpic_wait(rp);
+    (void)hipSetDevice(rp->device);
+    if (rp->hStage) (void)hipHostFree(rp->hStage);
+    if (rp->dPic) (void)hipFree(rp->dPic);
+    if (rp->dPlanes) (void)hipFree(rp->dPlanes);
+    if (rp->hPlanes) (void)hipHostFree(rp->hPlanes);
+    if (rp->st) (void)hipStreamDestroy(rp->st);
+    delete rp;
+}
+
+int x265hip_refpic_reset(x265hip_refpic* rp)
+{
+    if (!rp) return set_error(X265HIP_EINVAL, "x265hip_refpic_reset: null");
+    rp->rowsReady.store(-(1 << 30), std::memory_order_release);     // nothing is valid: readers fall through to the C filter
+    rp->epoch.fetch_add(1);                                           // whatever is queued for the old picture is dropped
+    int e = x265hip_refpic_wait(rp);                                  // the worker owns uploaded / phaseDone: take them over only when it is idle
+    rp->uploaded = 0;
+    rp->phaseDone = 4;
+    return e;
+}
+
+int x265hip_refpic_rows_final(x265hip_refpic* rp, int rowsFinal)
+{
+    if (!rp || rowsFinal < 0) return set_error(X265HIP_EINVAL, "x265hip_refpic_rows_final: rows %d", rowsFinal);
+    if (rp->failed.load()) return set_error(X265HIP_EHIP, "x265hip_refpic: a device operation of the worker failed");
+    RefWorker::worker().push(RefJob{ rp, rowsFinal > rp->picH ? rp->picH : rowsFinal, rp->epoch.load() });
+    return X265HIP_OK;
+}
+
+const void* x265hip_refpic_plane(x265hip_refpic* rp, int phase)
+{
+    if (!rp || phase < 1 || phase > 15) return nullptr;
+    return rp->hPlanes + (size_t)(phase - 1) * rp->planeElems * rp->B;
+}
+
+int x265hip_refpic_rows_ready(x265hip_refpic* rp) { return rp ? rp->rowsReady.load(std::memory_order_acquire) : -(1 << 30); }
+
+const int* x265hip_refpic_rows_ready_ptr(x265hip_refpic* rp) { return rp ? reinterpret_cast<const int*>(&rp->rowsReady) : nullptr; }
+
+} // extern "C"

@@ -162,6 +162,14 @@ PROTOTYPES = {
     "x265hip_la_weights_analyse": (i32, [vp, i32, i32, u64, u64, u64, u64, vp, vp, vp]),
     "x265hip_la_estimate_batch": (i32, [vp, vp, i32, i32, i32]),
     "x265hip_la_stats": (i32, [vp, vp, vp, vp]),
+    "x265hip_refpic_create": (vp, [i32, i32, i32, i64, i32, i32, i32, vp]),
+    "x265hip_refpic_destroy": (None, [vp]),
+    "x265hip_refpic_reset": (i32, [vp]),
+    "x265hip_refpic_rows_final": (i32, [vp, i32]),
+    "x265hip_refpic_plane": (vp, [vp, i32]),
+    "x265hip_refpic_rows_ready": (i32, [vp]),
+    "x265hip_refpic_rows_ready_ptr": (vp, [vp]),
+    "x265hip_refpic_wait": (i32, [vp]),
     "x265hip_call_intra_pred": (i32, [i32, i32, i32, i32, vp, i64, vp]),
     "x265hip_call_intra_allangs": (i32, [i32, i32, vp, vp, vp, i32]),
     "x265hip_call_intra_filter": (i32, [i32, i32, vp, vp]),

@@ -549,6 +549,8 @@ static void saoCuStatsE3_hip(const int16_t* diff, const pixel* rec, intptr_t str
         p.cu[BLOCK_ ## N ## x ## N].transpose = transpose_hip<N, BLOCK_ ## N ## x ## N>; \
     } while (0)
 
+void x265hip_install_lookup_slots(EncoderPrimitives& p);        // x265_hip_refplanes.cpp
+
 static void report_calls()
 {
     fprintf(stderr, "x265hip: %llu primitive calls served by the GPU\n", x265hip_call_count());
@@ -564,11 +566,15 @@ void setupAssemblyPrimitives(EncoderPrimitives& p, int /* cpuMask: CPU ISA bits,
     // X265HIP_TABLE selects what the table holds:
     //   percall   every slot below becomes its per-call shim (one slot call = one 1-job launch + sync): the bit-exactness proof of each
     //             kernel under the reference's own TestBench and encoder, ~1000x slower than the C code
-    //   (default) the C slots stay; the GPU serves the encoder where x265 batches work itself — the lookahead seam,
-    //             x265_hip_lookahead.cpp — which is the configuration encode fps is measured on
+    //   (default) the C slots stay, except the luma sub-pel filters, which look their result up in planes the GPU built once per reference
+    //             picture (x265_hip_refplanes.cpp); beside the table the GPU serves the lookahead's batched cost estimates
+    //             (x265_hip_lookahead.cpp).  This is the configuration encode fps is measured on
     const char* mode = getenv("X265HIP_TABLE");
     if (!mode || strcmp(mode, "percall"))
+    {
+        x265hip_install_lookup_slots(p);            // x265_hip_refplanes.cpp: luma sub-pel filters served from GPU-built planes
         return;
+    }
     if (x265hip_device_count() < 1 || x265hip_init(0))
         return;                                     // no usable GPU: leave the table alone (C path stays)
     ensure_c_table();

@@ -1,0 +1,268 @@
+// x265_hip_refplanes.cpp — the third translation unit of the drop-in: reference-picture mirrors and the lookup slots they feed
+// (include/x265hip.h, x265hip_refpic_*).
+//
+// Every luma_hpp / luma_vpp / luma_hvpp call the encoder makes on a reconstructed reference picture — the sub-pel candidates of
+// MotionEstimate::subpelCompare (reference source/encoder/motion.cpp:1571-1600) and Predict::predInterLumaPixel (common/predict.cpp:245-266)
+// — asks for values that depend on the picture and the position only.  The GPU computes them once per reference picture (all 15 fractional
+// planes, as CTU rows are published), and the table slot becomes a block copy out of the right plane.  Two seams:
+//   * FrameFilter::processPostRow (encoder/framefilter.cpp:654-664), where x265 itself tells other frame encoders that a CTU row of
+//     reconstructed pixels is final: the definition below runs the reference's own body, then hands the finished rows to the picture's
+//     mirror (x265hip_refpic_rows_final, asynchronous);
+//   * the three table slots per PU size, installed by x265hip_install_lookup_slots() from setupAssemblyPrimitives: a call whose source
+//     pointer lies inside a mirrored picture and whose rows the mirror has published is served by memcpy; anything else — rows still on
+//     their way, weighted reference copies, lowres planes, the TestBench's own buffers — goes to the C function the slot held before.
+// Same values either way (tests/test_framepass.py::test_subpel_planes_match_reference_filters pins plane == filter), so the bitstream
+// does not depend on how far the mirror has got.  The encoder never waits here.
+//
+// Linked like the lookahead seam: the reference's processPostRow is weakened in framefilter.o, and its original body stays reachable as
+// FrameFilterRef::processPostRow from a second compile of framefilter.cpp (oracle/Makefile).
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#define protected public
+#define private public
+#include "common.h"
+#include "frame.h"
+#include "framedata.h"
+#include "picyuv.h"
+#include "primitives.h"
+#include "slice.h"
+#include "framefilter.h"
+#undef protected
+#undef private
+
+#include "x265hip.h"
+
+namespace X265_NS {
+
+extern void refProcessPostRow(FrameFilter* self, int row) asm("_ZN4x26514FrameFilterRef14processPostRowEi");
+static_assert(sizeof("" "x265") == 5, "");
+
+namespace {
+
+struct Mirror
+{
+    const pixel* lo;            // PicYuv::m_picBuf[0]
+    const pixel* hi;            // one past the buffer
+    intptr_t stride;
+    int picW, picH, marginX, marginY;
+    const pixel* plane[16];     // host planes, same layout as the buffer ([0] unused)
+    const int* rowsReady;       // published by the worker (acquire)
+    x265hip_refpic* rp;
+    // writer side (frame filter threads)
+    std::mutex lock;
+    int poc;
+    bool tracking;              // the picture now in the buffer is a reference picture whose rows we publish
+    uint64_t rowDone[4];        // CTU rows whose processPostRow has run (slices may finish out of order)
+    int prefix;                 // CTU rows [0, prefix) are done
+};
+
+const int kMaxMirrors = 64;
+Mirror g_mirror[kMaxMirrors];
+std::atomic<int> g_count(0);
+std::mutex g_createLock;
+int g_state = 0;                 // 0 undecided, 1 on, -1 off
+EncoderPrimitives g_c;           // the slots' previous contents
+std::atomic<uint64_t> g_served[64], g_missed[64], g_foreign[64];
+std::atomic<int> g_nextShard(0);
+thread_local int t_shard = -1;
+
+inline int shard()
+{
+    if (t_shard < 0) t_shard = g_nextShard.fetch_add(1) & 63;
+    return t_shard;
+}
+
+void report()
+{
+    uint64_t s = 0, m = 0, f = 0;
+    for (int i = 0; i < 64; i++) { s += g_served[i]; m += g_missed[i]; f += g_foreign[i]; }
+    fprintf(stderr, "x265hip: refplanes: %llu luma sub-pel filter calls served from GPU-built planes of %d mirrored pictures, %llu on mirrored pictures before "
+                    "their rows arrived and %llu on other memory computed on the host\n", (unsigned long long)s, g_count.load(), (unsigned long long)m,
+            (unsigned long long)f);
+}
+
+bool enabled()
+{
+    if (!g_state)
+    {
+        std::lock_guard<std::mutex> g(g_createLock);
+        if (!g_state)
+        {
+            const char* env = getenv("X265HIP_REFPLANES");
+            const char* all = getenv("X265HIP");
+            const char* table = getenv("X265HIP_TABLE");
+            if ((env && !strcmp(env, "0")) || (all && !strcmp(all, "0")) || (table && !strcmp(table, "percall")) || x265hip_device_count() < 1)
+                g_state = -1;
+            else
+            {
+                g_state = 1;
+                if (getenv("X265HIP_VERBOSE"))
+                    atexit(report);
+            }
+        }
+    }
+    return g_state > 0;
+}
+
+inline const Mirror* find(const pixel* p)
+{
+    const int n = g_count.load(std::memory_order_acquire);
+    for (int i = 0; i < n; i++)
+        if (p >= g_mirror[i].lo && p < g_mirror[i].hi)
+            return &g_mirror[i];
+    return NULL;
+}
+
+Mirror* mirror_of(PicYuv* pic)
+{
+    const pixel* lo = pic->m_picBuf[0];
+    const int n = g_count.load(std::memory_order_acquire);
+    for (int i = 0; i < n; i++)
+        if (g_mirror[i].lo == lo)
+            return &g_mirror[i];
+    std::lock_guard<std::mutex> g(g_createLock);
+    const int n2 = g_count.load();
+    for (int i = n; i < n2; i++)
+        if (g_mirror[i].lo == lo)
+            return &g_mirror[i];
+    if (n2 == kMaxMirrors)
+        return NULL;
+    Mirror& m = g_mirror[n2];
+    const int maxCU = pic->m_param->maxCUSize;
+    const int bufRows = (int)(((pic->m_picHeight + maxCU - 1) / maxCU) * maxCU + 2 * pic->m_lumaMarginY);       // picyuv.cpp:95-98
+    m.rp = x265hip_refpic_create(X265_DEPTH, pic->m_picWidth, pic->m_picHeight, pic->m_stride, pic->m_lumaMarginX, pic->m_lumaMarginY, bufRows, lo);
+    if (!m.rp)
+    {
+        fprintf(stderr, "x265hip: refplanes: %s\n", x265hip_last_error());
+        abort();                                   // the product path fails loudly
+    }
+    m.lo = lo;
+    m.hi = lo + (size_t)pic->m_stride * bufRows;
+    m.stride = pic->m_stride;
+    m.picW = pic->m_picWidth; m.picH = pic->m_picHeight; m.marginX = pic->m_lumaMarginX; m.marginY = pic->m_lumaMarginY;
+    m.plane[0] = NULL;
+    for (int p = 1; p < 16; p++)
+        m.plane[p] = (const pixel*)x265hip_refpic_plane(m.rp, p);
+    m.rowsReady = x265hip_refpic_rows_ready_ptr(m.rp);
+    m.poc = -1;
+    m.tracking = false;
+    m.prefix = 0;
+    memset(m.rowDone, 0, sizeof(m.rowDone));
+    g_count.store(n2 + 1, std::memory_order_release);
+    return &m;
+}
+
+// W x H block of phase plane `phase` at `src`, if `src` lies in a mirrored picture whose rows have arrived
+template <int W, int H>
+inline bool serve(const pixel* src, intptr_t srcStride, pixel* dst, intptr_t dstStride, int phase)
+{
+    const Mirror* m = find(src);
+    if (!m)
+    {
+        g_foreign[shard()].fetch_add(1, std::memory_order_relaxed);
+        return false;
+    }
+    const ptrdiff_t off = src - m->lo;
+    const int by = (int)(off / m->stride), bx = (int)(off - (ptrdiff_t)by * m->stride);
+    const int y = by - m->marginY, x = bx - m->marginX;
+    if (srcStride != m->stride || x < -(m->marginX - 4) || x + W > m->picW + m->marginX - 4 || y < -(m->marginY - 4) ||
+        y + H > __atomic_load_n(m->rowsReady, __ATOMIC_ACQUIRE))
+    {
+        g_missed[shard()].fetch_add(1, std::memory_order_relaxed);
+        return false;
+    }
+    const pixel* p = m->plane[phase] + off;
+    for (int r = 0; r < H; r++)
+        memcpy(dst + r * dstStride, p + r * m->stride, W * sizeof(pixel));
+    g_served[shard()].fetch_add(1, std::memory_order_relaxed);
+    return true;
+}
+
+template <int W, int H, int PART> void hpp_lookup(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int c)
+{
+    if (!c || !serve<W, H>(s, ss, d, ds, c)) g_c.pu[PART].luma_hpp(s, ss, d, ds, c);
+}
+template <int W, int H, int PART> void vpp_lookup(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int c)
+{
+    if (!c || !serve<W, H>(s, ss, d, ds, 4 * c)) g_c.pu[PART].luma_vpp(s, ss, d, ds, c);
+}
+template <int W, int H, int PART> void hvpp_lookup(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int cx, int cy)
+{
+    if (!cx || !cy || !serve<W, H>(s, ss, d, ds, 4 * cy + cx)) g_c.pu[PART].luma_hvpp(s, ss, d, ds, cx, cy);
+}
+
+} // namespace
+
+#define LOOKUP_PU(W, H) do { \
+        p.pu[LUMA_ ## W ## x ## H].luma_hpp = hpp_lookup<W, H, LUMA_ ## W ## x ## H>; \
+        p.pu[LUMA_ ## W ## x ## H].luma_vpp = vpp_lookup<W, H, LUMA_ ## W ## x ## H>; \
+        p.pu[LUMA_ ## W ## x ## H].luma_hvpp = hvpp_lookup<W, H, LUMA_ ## W ## x ## H>; \
+    } while (0)
+
+// called by setupAssemblyPrimitives (x265_hip_primitives.cpp) in the default table mode
+void x265hip_install_lookup_slots(EncoderPrimitives& p)
+{
+    if (!enabled())
+        return;
+    g_c = p;                                        // what the slots did before (the C functions)
+    LOOKUP_PU(4, 4);   LOOKUP_PU(8, 8);   LOOKUP_PU(16, 16); LOOKUP_PU(32, 32); LOOKUP_PU(64, 64);
+    LOOKUP_PU(8, 4);   LOOKUP_PU(4, 8);   LOOKUP_PU(16, 8);  LOOKUP_PU(8, 16);  LOOKUP_PU(32, 16); LOOKUP_PU(16, 32);
+    LOOKUP_PU(64, 32); LOOKUP_PU(32, 64); LOOKUP_PU(16, 12); LOOKUP_PU(12, 16); LOOKUP_PU(16, 4);  LOOKUP_PU(4, 16);
+    LOOKUP_PU(32, 24); LOOKUP_PU(24, 32); LOOKUP_PU(32, 8);  LOOKUP_PU(8, 32);  LOOKUP_PU(64, 48); LOOKUP_PU(48, 64);
+    LOOKUP_PU(64, 16); LOOKUP_PU(16, 64);
+}
+
+void FrameFilter::processPostRow(int row)
+{
+    Mirror* m = NULL;
+    if (enabled() && m_frame && m_frame->m_reconPic && m_numRows <= 256)
+    {
+        // before the reference's body announces the row (m_reconRowFlag, framefilter.cpp:664): a buffer that starts a new picture must not
+        // keep serving the old picture's planes
+        m = mirror_of(m_frame->m_reconPic);
+        if (m)
+        {
+            std::lock_guard<std::mutex> g(m->lock);
+            if (m->poc != m_frame->m_poc)
+            {
+                if (x265hip_refpic_reset(m->rp))
+                {
+                    fprintf(stderr, "x265hip: refplanes: %s\n", x265hip_last_error());
+                    abort();
+                }
+                m->poc = m_frame->m_poc;
+                m->tracking = IS_REFERENCED(m_frame);           // unreferenced B pictures are never searched: nothing to build
+                m->prefix = 0;
+                memset(m->rowDone, 0, sizeof(m->rowDone));
+            }
+        }
+    }
+    refProcessPostRow(this, row);
+    if (m)
+    {
+        std::lock_guard<std::mutex> g(m->lock);
+        if (m->tracking && m->poc == m_frame->m_poc)
+        {
+            m->rowDone[row >> 6] |= 1ull << (row & 63);
+            int prefix = m->prefix;
+            while (prefix < m_numRows && (m->rowDone[prefix >> 6] >> (prefix & 63) & 1))
+                prefix++;
+            if (prefix > m->prefix)
+            {
+                m->prefix = prefix;
+                const int rows = prefix == m_numRows ? m->picH : prefix * (int)m_param->maxCUSize;
+                if (x265hip_refpic_rows_final(m->rp, rows))
+                {
+                    fprintf(stderr, "x265hip: refplanes: %s\n", x265hip_last_error());
+                    abort();
+                }
+            }
+        }
+    }
+}
+
+} // namespace X265_NS
