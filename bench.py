@@ -534,6 +534,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=10, help="frame passes of the CPU port sample inside `frame_pass` (0 = skip)")
     ap.add_argument("--no-ref-encoder", action="store_true")
     ap.add_argument("--no-frame-pass", action="store_true", help="skip the device-resident frame-pass block")
+    ap.add_argument("--frame-pass-only", action="store_true", help="profiling aid (tools/collect_profiles.sh): only the frame-pass block, printed as the line")
     ap.add_argument("--quick", action="store_true", help="skip the multi-process CPU port leg")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="frame pass: independent passes per GPU per step, each on its own HIP stream (x265 --frame-threads inside one device)")
@@ -569,6 +570,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.frame_pass_only:
+        fpb = frame_pass_bench(args, rank, local_rank, world, 10, 2)
+        if rank == 0:
+            print(json.dumps({"frame_pass": fpb}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     enc = encode_bench(args, rank, local_rank, world, fence)
     dt = enc["dt"]
     if world > 1:

@@ -48,17 +48,39 @@ if la:
         if lines:
             open(os.path.join(P, f"{tag}_lookahead_bench_line.json"), "w").write(lines[-1])
 
+# correction factors of the byte counters in OUR access patterns (tools/pmc_calibrate.py; 4-byte unaligned loads for the 8-bit kernels)
+calib = os.path.join(P, f"{tag}_pmc_calibration.txt")
+import subprocess
+subprocess.call([sys.executable, os.path.join(ROOT, "tools", "pmc_calibrate.py"), "--summarise", G, calib])
+ffac, wfac = 2.0, 1.0
+if os.path.exists(calib):
+    for line in open(calib):
+        c = line.split()
+        if len(c) == 6 and c[0] == "FETCH_SIZE" and c[1] == "calib_read4u" and c[5] != "nan":
+            ffac = float(c[5])
+        if len(c) == 6 and c[0] == "WRITE_SIZE" and c[1] == "calib_write4" and c[5] != "nan":
+            wfac = float(c[5])
+
 fv, grid = per_kernel("fetch")
 wv, _ = per_kernel("write")
 with open(os.path.join(P, f"{tag}_pmc_hbm_bytes.txt"), "w") as o:
-    o.write(f"# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on: python bench.py --steps 10 --warmup 2 --cpu-frames 0   {note}\n")
-    o.write("# per-launch averages in KiB as reported; gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md), see doubled column\n")
-    o.write(f"{'kernel':<72}{'grid':>9}{'launches':>9}{'FETCH_KiB':>13}{'FETCHx2_KiB':>13}{'WRITE_KiB':>13}\n")
+    o.write(f"# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on the frame pass (bench.py --frame-pass-only)   {note}\n")
+    o.write(f"# fetch_correction {ffac:.3f} write_correction {wfac:.3f}: measured on known byte counts in this access pattern ({tag}_pmc_calibration.txt); "
+            "per-launch averages in KiB, raw and corrected\n")
+    o.write(f"{'kernel':<72}{'grid':>9}{'launches':>9}{'FETCH_raw':>13}{'WRITE_raw':>13}{'FETCH_KiB':>13}{'WRITE_KiB':>13}\n")
     for k in sorted(fv):
         f = fv[k]["FETCH_SIZE"]
         w = wv.get(k, {}).get("WRITE_SIZE", [0.0])
         fa, wa = sum(f) / len(f), sum(w) / len(w)
-        o.write(f"{k:<72}{grid[k]:>9}{len(f):>9}{fa:>13.1f}{2 * fa:>13.1f}{wa:>13.1f}\n")
+        o.write(f"{k:<72}{grid[k]:>9}{len(f):>9}{fa:>13.1f}{wa:>13.1f}{ffac * fa:>13.1f}{wfac * wa:>13.1f}\n")
+
+enc = find("encode", "kernel_stats.csv")
+if enc:
+    shutil.copy(enc, os.path.join(P, f"{tag}_encode_kernel_stats.csv"))
+    log = os.path.join(G, f"{tag}_encode.log")
+    if os.path.exists(log):
+        keep = [l for l in open(log, errors="replace") if l.startswith(("encoded", "x265hip:"))]
+        open(os.path.join(P, f"{tag}_encode_log.txt"), "w").writelines(keep)
 
 sv, _ = per_kernel("sq")
 with open(os.path.join(P, f"{tag}_pmc_sq.txt"), "w") as o:
