@@ -56,7 +56,10 @@ ffac, wfac = 2.0, 1.0
 if os.path.exists(calib):
     for line in open(calib):
         c = line.split()
-        if len(c) == 6 and c[0] == "FETCH_SIZE" and c[1] == "calib_read4u" and c[5] != "nan":
+        # the counter's own scale comes from the ALIGNED pattern, where bytes fetched == bytes asked for (factor 2.000: the counter tallies
+        # 128-byte requests as 64); the unaligned 4-byte pattern of the motion kernels then shows 1.125x over-fetch (each wave's 256-byte
+        # span straddles one extra 32-byte sector), which is real traffic and stays in the corrected figure
+        if len(c) == 6 and c[0] == "FETCH_SIZE" and c[1] == "calib_read16" and c[5] != "nan":
             ffac = float(c[5])
         if len(c) == 6 and c[0] == "WRITE_SIZE" and c[1] == "calib_write4" and c[5] != "nan":
             wfac = float(c[5])
@@ -65,7 +68,7 @@ fv, grid = per_kernel("fetch")
 wv, _ = per_kernel("write")
 with open(os.path.join(P, f"{tag}_pmc_hbm_bytes.txt"), "w") as o:
     o.write(f"# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on the frame pass (bench.py --frame-pass-only)   {note}\n")
-    o.write(f"# fetch_correction {ffac:.3f} write_correction {wfac:.3f}: measured on known byte counts in this access pattern ({tag}_pmc_calibration.txt); "
+    o.write(f"# fetch_correction {ffac:.3f} write_correction {wfac:.3f}: measured on known byte counts ({tag}_pmc_calibration.txt: the counter reports half the fetched bytes; 4-byte unaligned loads over-fetch 1.125x on top); "
             "per-launch averages in KiB, raw and corrected\n")
     o.write(f"{'kernel':<72}{'grid':>9}{'launches':>9}{'FETCH_raw':>13}{'WRITE_raw':>13}{'FETCH_KiB':>13}{'WRITE_KiB':>13}\n")
     for k in sorted(fv):
