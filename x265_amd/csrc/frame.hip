@@ -11,6 +11,7 @@
 // transform (HEVC conformance), so running the full path gives the same recon.
 #include "common.h"
 #include "dctcore.h"
+#include "internal.h"
 
 namespace xh {
 
@@ -19,18 +20,20 @@ template <typename P> __device__ __forceinline__ void store8(P* p, const int v[8
 
 struct QParams { int qBits, add, dqScale, dqShift, maxVal; };
 
+typedef int16_t ChainLds[4][2][1024];
+
 template <typename P, int N>
-__global__ __launch_bounds__(256) void residual_chain_kernel(const P* __restrict__ fenc, int64_t sF, const P* __restrict__ pred, int64_t sP,
-                                                             P* __restrict__ recon, int64_t sR,
-                                                             const int32_t* __restrict__ offF, const int32_t* __restrict__ offP,
-                                                             const int32_t* __restrict__ offR, const int32_t* __restrict__ quantCoeff,
-                                                             QParams qp, int s1f, int s2f, int s1i, int s2i,
-                                                             int16_t* __restrict__ level, uint32_t* __restrict__ numSig,
-                                                             uint64_t* __restrict__ dist, int n)
+__device__ __forceinline__ void residual_chain_body(ChainLds& lds, int block, int blocks,
+                                                    const P* __restrict__ fenc, int64_t sF, const P* __restrict__ pred, int64_t sP,
+                                                    P* __restrict__ recon, int64_t sR,
+                                                    const int32_t* __restrict__ offF, const int32_t* __restrict__ offP,
+                                                    const int32_t* __restrict__ offR, const int32_t* __restrict__ quantCoeff,
+                                                    QParams qp, int s1f, int s2f, int s1i, int s2i,
+                                                    int16_t* __restrict__ level, uint32_t* __restrict__ numSig,
+                                                    uint64_t* __restrict__ dist, int n)
 {
     constexpr int G = (32 / N) * (32 / N);
     constexpr int LPT = N * N / 16;             // lanes per TU (each lane owns 16 elements)
-    __shared__ __attribute__((aligned(16))) int16_t lds[4][2][1024];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int16_t* buf0 = lds[wv][0];
     int16_t* buf1 = lds[wv][1];
@@ -40,8 +43,8 @@ __global__ __launch_bounds__(256) void residual_chain_kernel(const P* __restrict
     make_b_operand<N, true>(lane, bI, corrI);
 
     const int groups = (n + G - 1) / G;
-    const int wavesTotal = gridDim.x * 4;
-    for (int grp = blockIdx.x * 4 + wv; grp < groups; grp += wavesTotal)
+    const int wavesTotal = blocks * 4;
+    for (int grp = block * 4 + wv; grp < groups; grp += wavesTotal)
     {
         const int tu0 = grp * G;
         int fv[16], pv[16];
@@ -137,18 +140,32 @@ __global__ __launch_bounds__(256) void residual_chain_kernel(const P* __restrict
     }
 }
 
+template <typename P, int N>
+__global__ __launch_bounds__(256) void residual_chain_kernel(const P* __restrict__ fenc, int64_t sF, const P* __restrict__ pred, int64_t sP,
+                                                             P* __restrict__ recon, int64_t sR,
+                                                             const int32_t* __restrict__ offF, const int32_t* __restrict__ offP,
+                                                             const int32_t* __restrict__ offR, const int32_t* __restrict__ quantCoeff,
+                                                             QParams qp, int s1f, int s2f, int s1i, int s2i,
+                                                             int16_t* __restrict__ level, uint32_t* __restrict__ numSig,
+                                                             uint64_t* __restrict__ dist, int n)
+{
+    __shared__ __attribute__((aligned(16))) ChainLds lds;
+    residual_chain_body<P, N>(lds, blockIdx.x, gridDim.x, fenc, sF, pred, sP, recon, sR, offF, offP, offR, quantCoeff, qp, s1f, s2f, s1i, s2i, level, numSig, dist, n);
+}
+
 // 4x4 TUs: one lane per TU, the whole chain in registers (DCT4; the DST variant is intra-luma only and not part of
 // the inter residual chain this entry point serves)
 template <typename P>
-__global__ __launch_bounds__(256) void residual_chain4_kernel(const P* __restrict__ fenc, int64_t sF, const P* __restrict__ pred, int64_t sP,
-                                                              P* __restrict__ recon, int64_t sR,
-                                                              const int32_t* __restrict__ offF, const int32_t* __restrict__ offP,
-                                                              const int32_t* __restrict__ offR, const int32_t* __restrict__ quantCoeff,
-                                                              QParams qp, int s1f, int s2f, int s1i, int s2i,
-                                                              int16_t* __restrict__ level, uint32_t* __restrict__ numSig,
-                                                              uint64_t* __restrict__ dist, int n)
+__device__ __forceinline__ void residual_chain4_body(int block, int blocks,
+                                                     const P* __restrict__ fenc, int64_t sF, const P* __restrict__ pred, int64_t sP,
+                                                     P* __restrict__ recon, int64_t sR,
+                                                     const int32_t* __restrict__ offF, const int32_t* __restrict__ offP,
+                                                     const int32_t* __restrict__ offR, const int32_t* __restrict__ quantCoeff,
+                                                     QParams qp, int s1f, int s2f, int s1i, int s2i,
+                                                     int16_t* __restrict__ level, uint32_t* __restrict__ numSig,
+                                                     uint64_t* __restrict__ dist, int n)
 {
-    for (int tu = blockIdx.x * blockDim.x + threadIdx.x; tu < n; tu += gridDim.x * blockDim.x)
+    for (int tu = block * blockDim.x + threadIdx.x; tu < n; tu += blocks * blockDim.x)
     {
         int f[16], p[16], x[16], t[16];
 #pragma unroll
@@ -235,6 +252,54 @@ __global__ __launch_bounds__(256) void residual_chain4_kernel(const P* __restric
 }
 
 template <typename P>
+__global__ __launch_bounds__(256) void residual_chain4_kernel(const P* __restrict__ fenc, int64_t sF, const P* __restrict__ pred, int64_t sP,
+                                                              P* __restrict__ recon, int64_t sR,
+                                                              const int32_t* __restrict__ offF, const int32_t* __restrict__ offP,
+                                                              const int32_t* __restrict__ offR, const int32_t* __restrict__ quantCoeff,
+                                                              QParams qp, int s1f, int s2f, int s1i, int s2i,
+                                                              int16_t* __restrict__ level, uint32_t* __restrict__ numSig,
+                                                              uint64_t* __restrict__ dist, int n)
+{
+    residual_chain4_body<P>(blockIdx.x, gridDim.x, fenc, sF, pred, sP, recon, sR, offF, offP, offR, quantCoeff, qp, s1f, s2f, s1i, s2i, level, numSig, dist, n);
+}
+
+// ---- several chains in ONE launch: the frame pass runs luma 32x32, luma 8x8, chroma 16x16 and chroma 4x4 TUs back to back; as separate
+// launches the three small ones are ~10 us of pure latency each.  A workgroup finds its segment from its block index; segments may differ in
+// planes, strides, TU size and quantiser.
+struct ChainSeg
+{
+    const void* fenc; const void* pred; void* recon;
+    int64_t sF, sP, sR;
+    const int32_t* offF; const int32_t* offP; const int32_t* offR; const int32_t* quantCoeff;
+    QParams qp;
+    int s1f, s2f, s1i, s2i;
+    int16_t* level; uint32_t* numSig; uint64_t* dist;
+    int n, size, firstBlock, blocks;
+};
+struct ChainSegs { ChainSeg s[4]; int count; };
+
+template <typename P>
+__global__ __launch_bounds__(256) void residual_chain_multi_kernel(ChainSegs segs)
+{
+    __shared__ __attribute__((aligned(16))) ChainLds lds;
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        if (i < segs.count && (int)blockIdx.x >= segs.s[i].firstBlock) k = i;
+    const ChainSeg& g = segs.s[k];
+    const int block = blockIdx.x - g.firstBlock;
+    const P* f = (const P*)g.fenc;
+    const P* p = (const P*)g.pred;
+    P* r = (P*)g.recon;
+#define CH_ARGS f, g.sF, p, g.sP, r, g.sR, g.offF, g.offP, g.offR, g.quantCoeff, g.qp, g.s1f, g.s2f, g.s1i, g.s2i, g.level, g.numSig, g.dist, g.n
+    if (g.size == 32) residual_chain_body<P, 32>(lds, block, g.blocks, CH_ARGS);
+    else if (g.size == 16) residual_chain_body<P, 16>(lds, block, g.blocks, CH_ARGS);
+    else if (g.size == 8) residual_chain_body<P, 8>(lds, block, g.blocks, CH_ARGS);
+    else residual_chain4_body<P>(block, g.blocks, CH_ARGS);
+#undef CH_ARGS
+}
+
+template <typename P>
 static int launch_chain(int size, int depth, const void* fenc, int64_t sF, const void* pred, int64_t sP, void* recon, int64_t sR,
                         const int32_t* offF, const int32_t* offP, const int32_t* offR, const int32_t* quantCoeff,
                         QParams qp, int16_t* level, uint32_t* numSig, uint64_t* dist, int n, hipStream_t st)
@@ -261,6 +326,41 @@ static int launch_chain(int size, int depth, const void* fenc, int64_t sF, const
             hipLaunchKernelGGL((residual_chain_kernel<P, 32>), grid, block, 0, st, f, sF, p, sP, r, sR, offF, offP, offR, quantCoeff, qp, s1f, s2f, s1i, s2i, level, numSig, dist, n);
     }
     XH_LAUNCH_CHECK("residual_chain_kernel");
+    return X265HIP_OK;
+}
+
+// internal (framepass.hip): up to four chains of different TU sizes / planes / quantisers in one launch
+int residual_chain_multi(int depth, const ChainJob* jobs, int count, hipStream_t st)
+{
+    if (count < 1 || count > 4)
+        return set_error(X265HIP_EINVAL, "residual_chain_multi: %d segments", count);
+    ChainSegs segs{};
+    int blocks = 0, used = 0;
+    for (int i = 0; i < count; i++)
+    {
+        const ChainJob& j = jobs[i];
+        if (!j.n) continue;
+        if (!(j.size == 4 || j.size == 8 || j.size == 16 || j.size == 32) || j.qBits < 1 || j.dqShift < 1)
+            return set_error(X265HIP_EINVAL, "residual_chain_multi: segment %d size %d", i, j.size);
+        ChainSeg& g = segs.s[used++];
+        const int log2n = j.size == 4 ? 2 : j.size == 8 ? 3 : j.size == 16 ? 4 : 5;
+        g.fenc = j.fenc; g.pred = j.pred; g.recon = j.recon; g.sF = j.sF; g.sP = j.sP; g.sR = j.sR;
+        g.offF = j.offF; g.offP = j.offP; g.offR = j.offR; g.quantCoeff = j.quantCoeff;
+        g.qp = QParams{ j.qBits, j.add, j.dqScale, j.dqShift, (1 << depth) - 1 };
+        g.s1f = log2n - 1 + depth - 8; g.s2f = log2n + 6; g.s1i = 7; g.s2i = 12 - (depth - 8);
+        g.level = j.level; g.numSig = j.numSig; g.dist = j.dist; g.n = j.n; g.size = j.size;
+        const int G = j.size == 4 ? 1 : (32 / j.size) * (32 / j.size);
+        g.blocks = j.size == 4 ? grid_for((j.n + 255) / 256) : grid_for(((j.n + G - 1) / G + 3) / 4);
+        g.firstBlock = blocks;
+        blocks += g.blocks;
+    }
+    segs.count = used;
+    if (!used) return X265HIP_OK;
+    if (depth == 8)
+        hipLaunchKernelGGL((residual_chain_multi_kernel<uint8_t>), dim3(blocks), dim3(256), 0, st, segs);
+    else
+        hipLaunchKernelGGL((residual_chain_multi_kernel<uint16_t>), dim3(blocks), dim3(256), 0, st, segs);
+    XH_LAUNCH_CHECK("residual_chain_multi_kernel");
     return X265HIP_OK;
 }
 

@@ -337,6 +337,7 @@ static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t st
     if (ba)
         FP_TRY(x265hip_build_subpel_planes(depth, ba->ref1, strideR, fp->width, fp->height, marginX, marginY, planes1Origin, fp->planeElems, stream));
     // 1. top-down motion search
+    int predDone = 0;
     for (int l = 0; l < 4; l++)
     {
         const int n = fp->nLevel[l], sz = kCuSize[l];
@@ -360,6 +361,11 @@ static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t st
                 dr.picW = fp->width; dr.picH = fp->height; dr.maxCUSize = 64;
                 dr.refLagPixels = fp->height;                     // -F1: m_refLagPixels = sourceHeight (search.cpp:92)
                 dr.qmvpO = QMVP[l]; dr.mvminO = MVMIN[l]; dr.mvmaxO = MVMAX[l];
+                if (l == 3 && !ba)
+                {
+                    // P pass: the 8x8 level writes the luma prediction itself (row-team kernel epilogue); predDone stays 0 on the other kernels
+                    dr.predOut = pred; dr.predStride = strideP; dr.predDone = &predDone;
+                }
                 if (ca && fp->subme > 2)
                 {
                     // 4:2:0 picture at subme > 2: every sub-pel comparison carries the chroma SATD term (motion.cpp:212, :1601).  8 / 16 / 32 PUs:
@@ -397,42 +403,10 @@ static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t st
         const x265hip_yuv pd{ pred, ca->predCb, ca->predCr, strideP, ca->sP };
         FP_TRY(x265hip_pred_inter_bi_batch(depth, 8, 8, &r0, &r1, &pd, fp->puXY[3], fp->mv[3], fp->mv1[3], fp->nLevel[3], stream));
     }
-    else
+    else if (!predDone)
         FP_TRY(pred_from_planes(depth, 8, planesOrigin, fp->planeElems, strideR, pred, strideP, fp->puXY[3], fp->mv[3], fp->nLevel[3], as_stream(stream)));
-    // 3. residual chain
-    const int qp = fp->qp + 6 * (depth - 8);                                            // QpParam.qp = slice qp + QP_BD_OFFSET (quant.cpp:224)
-    static const int invQuantScales[6] = { 40, 45, 51, 57, 64, 72 };                     // scalinglist.cpp:130
-    for (int t = 0; t < 2; t++)
-    {
-        FP_MARK(6 + t);
-        if (!fp->nTu[t]) continue;
-        const int log2n = kTuSize[t] == 32 ? 5 : 3;
-        const int transformShift = 15 - depth - log2n;                                   // MAX_TR_DYNAMIC_RANGE - X265_DEPTH - log2TrSize (quant.cpp:408)
-        const int qBits = 14 + qp / 6 + transformShift;                                  // QUANT_SHIFT + per + transformShift (quant.cpp:465)
-        const int add = 85 << (qBits - 9);                                               // inter rounding (quant.cpp:466)
-        const int dqShift = 20 - 14 - transformShift;                                    // QUANT_IQUANT_SHIFT - QUANT_SHIFT - transformShift (quant.cpp:552)
-        const int dqScale = invQuantScales[qp % 6] << (qp / 6);                          // quant.cpp:567
-        FP_TRY(x265hip_residual_chain_batch(kTuSize[t], depth, src, strideS, pred, strideP, recon, strideRec, fp->tuOffF[t], fp->tuOffP[t],
-                                            fp->tuOffR[t], fp->quantCoeff[t], qBits, add, dqScale, dqShift, fp->level[t], fp->numSig[t],
-                                            fp->dist[t], fp->nTu[t], stream));
-    }
-    FP_MARK(8);
-    // 4. mode costs
-    {
-        static const bool perLevel = getenv("X265HIP_SA8D_LEVELS") != nullptr;       // the first version: one Hadamard pass per CU size
-        if (perLevel)
-        {
-            Sa8dLevel lv[4];
-            for (int l = 0; l < 4; l++)
-                lv[l] = Sa8dLevel{ fp->cuOff[l], fp->cuOffP[l], fp->sa8d[l], fp->nLevel[l], kCuSize[l] };
-            FP_TRY(sa8d_levels(depth, src, strideS, pred, strideP, lv, 4, as_stream(stream)));
-        }
-        else
-            FP_TRY(sa8d_pyramid(depth, src, strideS, pred, strideP, fp->width, fp->height, fp->sa8d, as_stream(stream)));
-    }
-    FP_MARK(9);
-    // 4b. chroma (4:2:0), when the caller passed Cb / Cr planes: predInterChromaPixel from the 8x8 vectors, then the same residual
-    //     chain with 16x16 / 4x4 TUs and the chroma QpParam
+    // 3. chroma prediction (4:2:0, when the caller passed Cb / Cr planes): predInterChromaPixel from the 8x8 vectors (the B pass has
+    //    already predicted chroma in its bi-predictive launch)
     if (ca)
     {
         const int64_t B = depth == 8 ? 1 : 2;
@@ -470,25 +444,74 @@ static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t st
         if (!ba)
             FP_TRY(x265hip_pred_inter_chroma_batch(depth, 8, 8, ca->refCb, ca->refCr, ca->sR, ca->predCb, ca->predCr, ca->sP, fp->puXY[3], fp->mv[3],
                                                    fp->nLevel[3], stream));
-        const int bd = 6 * (depth - 8);
-        int qpc = fp->qp < -bd ? -bd : (fp->qp > 57 ? 57 : fp->qp);
-        if (qpc >= 30) qpc = kChromaScale[qpc];
-        qpc += bd;
+    }
+    FP_MARK(6);
+    // 4. residual chains: luma 32x32 TUs on the 32-aligned area + 8x8 TUs on the rest, chroma 16x16 + 4x4 (Cb and Cr together: Cr TUs are
+    //    addressed from the Cb base pointers through the offset tables above) with the chroma QpParam — ONE launch (frame.hip)
+    const int qp = fp->qp + 6 * (depth - 8);                                            // QpParam.qp = slice qp + QP_BD_OFFSET (quant.cpp:224)
+    static const int invQuantScales[6] = { 40, 45, 51, 57, 64, 72 };                     // scalinglist.cpp:130
+    {
+        ChainJob jobs[4];
+        int nj = 0;
         for (int t = 0; t < 2; t++)
         {
             if (!fp->nTu[t]) continue;
-            const int log2n = kCTuSize[t] == 16 ? 4 : 2;
-            const int transformShift = 15 - depth - log2n;
-            const int qBits = 14 + qpc / 6 + transformShift, add = 85 << (qBits - 9);
-            const int dqShift = 20 - 14 - transformShift, dqScale = invQuantScales[qpc % 6] << (qpc / 6);
-            // Cb and Cr in one launch: Cr TUs are addressed from the Cb base pointers (offset tables above)
-            FP_TRY(x265hip_residual_chain_batch(kCTuSize[t], depth, ca->srcCb, ca->sS, ca->predCb, ca->sP, ca->recCb, ca->sRec, fp->ctuOffF[t],
-                                                fp->ctuOffP[t], fp->ctuOffR[t], fp->cquantCoeff[t], qBits, add, dqScale, dqShift, fp->clevel[0][t],
-                                                fp->cnumSig[0][t], fp->cdist[0][t], 2 * fp->nTu[t], stream));
+            const int log2n = kTuSize[t] == 32 ? 5 : 3;
+            const int transformShift = 15 - depth - log2n;                               // MAX_TR_DYNAMIC_RANGE - X265_DEPTH - log2TrSize (quant.cpp:408)
+            const int qBits = 14 + qp / 6 + transformShift;                              // QUANT_SHIFT + per + transformShift (quant.cpp:465)
+            jobs[nj++] = ChainJob{ kTuSize[t], src, strideS, pred, strideP, recon, strideRec, fp->tuOffF[t], fp->tuOffP[t], fp->tuOffR[t], fp->quantCoeff[t],
+                                   qBits, 85 << (qBits - 9),                             // inter rounding (quant.cpp:466)
+                                   invQuantScales[qp % 6] << (qp / 6),                   // quant.cpp:567
+                                   20 - 14 - transformShift,                             // QUANT_IQUANT_SHIFT - QUANT_SHIFT - transformShift (quant.cpp:552)
+                                   fp->level[t], fp->numSig[t], fp->dist[t], fp->nTu[t] };
         }
+        if (ca)
+        {
+            const int bd = 6 * (depth - 8);
+            int qpc = fp->qp < -bd ? -bd : (fp->qp > 57 ? 57 : fp->qp);
+            if (qpc >= 30) qpc = kChromaScale[qpc];
+            qpc += bd;
+            for (int t = 0; t < 2; t++)
+            {
+                if (!fp->nTu[t]) continue;
+                const int log2n = kCTuSize[t] == 16 ? 4 : 2;
+                const int transformShift = 15 - depth - log2n;
+                const int qBits = 14 + qpc / 6 + transformShift;
+                jobs[nj++] = ChainJob{ kCTuSize[t], ca->srcCb, ca->sS, ca->predCb, ca->sP, ca->recCb, ca->sRec, fp->ctuOffF[t], fp->ctuOffP[t], fp->ctuOffR[t],
+                                       fp->cquantCoeff[t], qBits, 85 << (qBits - 9), invQuantScales[qpc % 6] << (qpc / 6), 20 - 14 - transformShift,
+                                       fp->clevel[0][t], fp->cnumSig[0][t], fp->cdist[0][t], 2 * fp->nTu[t] };
+            }
+        }
+        static const bool separate = getenv("X265HIP_CHAIN_SEPARATE") != nullptr;       // A/B switch: one launch per chain, as in round 1
+        if (!separate)
+            FP_TRY(residual_chain_multi(depth, jobs, nj, as_stream(stream)));
+        else
+            for (int k = 0; k < nj; k++)
+            {
+                const ChainJob& j = jobs[k];
+                FP_TRY(x265hip_residual_chain_batch(j.size, depth, j.fenc, j.sF, j.pred, j.sP, j.recon, j.sR, j.offF, j.offP, j.offR, j.quantCoeff, j.qBits, j.add,
+                                                    j.dqScale, j.dqShift, j.level, j.numSig, j.dist, j.n, stream));
+            }
     }
+    FP_MARK(7);
+    FP_MARK(8);
+    // 5. mode costs
+    // 4. mode costs
+    {
+        static const bool perLevel = getenv("X265HIP_SA8D_LEVELS") != nullptr;       // the first version: one Hadamard pass per CU size
+        if (perLevel)
+        {
+            Sa8dLevel lv[4];
+            for (int l = 0; l < 4; l++)
+                lv[l] = Sa8dLevel{ fp->cuOff[l], fp->cuOffP[l], fp->sa8d[l], fp->nLevel[l], kCuSize[l] };
+            FP_TRY(sa8d_levels(depth, src, strideS, pred, strideP, lv, 4, as_stream(stream)));
+        }
+        else
+            FP_TRY(sa8d_pyramid(depth, src, strideS, pred, strideP, fp->width, fp->height, fp->sa8d, as_stream(stream)));
+    }
+    FP_MARK(9);
     FP_MARK(10);
-    // 5. the reconstructed picture becomes a reference
+    // 6. the reconstructed picture becomes a reference
     {
         void* pics[3] = { recon, ca ? ca->recCb : nullptr, ca ? ca->recCr : nullptr };
         const int64_t strides[3] = { strideRec, ca ? ca->sRec : 0, ca ? ca->sRec : 0 };

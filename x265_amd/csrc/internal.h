@@ -17,6 +17,17 @@ int sa8d_pyramid(int depth, const void* planeA, int64_t strideA, const void* pla
 int pred_from_planes(int depth, int size, const void* planes, int64_t planeElems, int64_t strideR, void* dst, int64_t strideD,
                      const int32_t* pu_xy, const int32_t* qmv, int n, hipStream_t st);
 
+// up to four residual chains (x265hip_residual_chain_batch) of different TU sizes / planes / quantisers in ONE launch (frame.hip)
+struct ChainJob
+{
+    int size;
+    const void* fenc; int64_t sF; const void* pred; int64_t sP; void* recon; int64_t sR;
+    const int32_t* offF; const int32_t* offP; const int32_t* offR; const int32_t* quantCoeff;
+    int qBits, add, dqScale, dqShift;
+    int16_t* level; uint32_t* numSig; uint64_t* dist; int n;
+};
+int residual_chain_multi(int depth, const ChainJob* jobs, int count, hipStream_t st);
+
 // border extension of up to four planes in one launch
 int extend_border_planes(int depth, int nPlanes, void* const* pics, const int64_t* strides, const int* w, const int* h, const int* mx, const int* my,
                          hipStream_t st);

@@ -553,6 +553,20 @@ __global__ __launch_bounds__(256) void motion3_kernel(const P* __restrict__ fenc
         outMv[2 * pu + 1] = bmv.y;
         outCost[pu] = bcost;
     }
+    if (dr.predOut)
+    {
+        // Predict::predInterLumaPixel (predict.cpp:245-266) at the winner: copy / hpp / vpp / hvpp of the block == the block of phase plane
+        // (y & 3) * 4 + (x & 3) at the full-pel part of the vector; each lane moves the quads it has been comparing all along
+        const uint32_t r = c.cand(bmv);
+        P* pd = (P*)dr.predOut + (int64_t)by * dr.predStride + bx;
+#pragma unroll
+        for (int j = 0; j < RT::IPT; j++)
+        {
+            const int t = j * (TEAM / 4) + (c.s >> 2), rr = c.s & 3;
+            const int row = (t / RT::TX) * 4 + rr, col = (t % RT::TX) * 4;
+            st_unaligned<Q>(pd + (int64_t)row * dr.predStride + col, c.template ld_off<Q>(r + (uint32_t)c.qoff[j]));
+        }
+    }
 }
 
 // returns 1 when handled (square PUs with planes), 0 otherwise
@@ -594,6 +608,8 @@ int motion3_dispatch(int depth, int size, const void* fencPlane, int64_t strideF
 #undef M3
     hipError_t e = hipGetLastError();
     *rc = e == hipSuccess ? X265HIP_OK : check_hip(e, "motion3_kernel");
+    if (dr.predOut && dr.predDone && e == hipSuccess)
+        *dr.predDone = 1;
     return 1;
 }
 

@@ -35,6 +35,12 @@ struct DeriveRange
     const int32_t* srcIdx;
     int picW, picH, maxCUSize, refLagPixels;
     int32_t *qmvpO, *mvminO, *mvmaxO;       // also written, so the arrays hold what the separate entry point would produce
+    // optional (row-team kernel, motion3.hip): write the PU's prediction — predInterLumaPixel at the winning vector, i.e. the block of the
+    // winning vector's phase plane — to predOut at the PU position.  The search has just walked those cache lines; a separate copy kernel
+    // over the whole frame re-fetches 13-27 MB for 2 MB of 8x8 blocks (r01 PMC).  *predDone (host) is set when the kernel honoured it.
+    void* predOut;
+    int64_t predStride;
+    int* predDone;
 };
 
 // bChromaSATD inputs (4:2:0): source and reference chroma planes at the picture origin (motion.cpp:212, :1601-1660)
