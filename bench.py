@@ -32,7 +32,9 @@ W, H, DEPTH, QP, MERANGE, SUBME = 1920, 1080, 8, 28, 57, 2
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MIN_TIMED_S = 0.5                 # every timed region lasts at least this long, whatever --steps says
 CHUNK = 12                        # frames per step of the real encode
-STAGES = ["planes", "me64", "me32", "me16", "me8", "pred8", "chain32", "chain8", "sa8d", "chroma", "border"]
+# frame-pass stages between the 12 HIP events of x265hip_framepass_stage_ms: quarter-pel planes, the four search levels (the 8x8 level also writes
+# the luma prediction), chroma prediction, ALL residual chains (one launch: Y 32x32 + 8x8, Cb / Cr 16x16 + 4x4), sa8d, borders; "-" = unused slots
+STAGES = ["planes", "me64", "me32", "me16", "me8", "pred_c", "chains", "-", "sa8d", "--", "border"]
 
 
 def cpu_baseline(frames):
@@ -118,9 +120,8 @@ def _pmc_file():
 
 
 PMC_KERNELS = {"planes": "subpel_planes", "me64": "motion2_kernel<unsigned char, 64", "me32": "motion3_kernel<unsigned char, 32",
-               "me16": "motion3_kernel<unsigned char, 16", "me8": "motion3_kernel<unsigned char, 8", "pred8": "pred_from_planes_kernel",
-               "chain32": "residual_chain_kernel<unsigned char, 32", "chain8": "residual_chain_kernel<unsigned char, 8",
-               "sa8d": "sa8d_pyramid_kernel", "border": "extend_border3_kernel", "chroma": "pred_chroma_kernel"}
+               "me16": "motion3_kernel<unsigned char, 16", "me8": "motion3_kernel<unsigned char, 8", "pred_c": "pred_chroma_kernel",
+               "chains": "residual_chain_multi_kernel", "sa8d": "sa8d_pyramid_kernel", "border": "extend_border3_kernel", "-": "\0", "--": "\0"}
 
 
 def pmc_traffic(stage):
@@ -373,8 +374,7 @@ def frame_pass_bench(args, rank, local_rank, world, steps, warmup):
         dom_bytes = 17 * S_ * R_                       # read the padded reference once, write 16 planes
         kernel = "subpel_planes_kernel<u8> (16 quarter-pel planes of the padded reference)"
     else:
-        dom_bytes = {"pred8": ab["pred"], "chain32": ab["chain"], "chain8": ab["chain"], "sa8d": ab["sa8d"], "border": ab["border"],
-                     "chroma": ab["chain"] // 2 + ab["pred"] // 2}[dom]
+        dom_bytes = {"pred_c": ab["pred"] // 2, "chains": ab["chain"] * 3 // 2, "sa8d": ab["sa8d"], "border": ab["border"], "-": 0, "--": 0}[dom]
         kernel = dom
     achieved = dom_bytes / (launch_ms * 1e-3) / 1e9
     traffic, traffic_src, traffic_note = pmc_traffic(dom)

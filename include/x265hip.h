@@ -253,6 +253,19 @@ int x265hip_motion_estimate_batch(int depth, int w, int h,
                                   const uint16_t* mvcost, int mvcostHalf,
                                   int n, int32_t* outMv, int32_t* outCost, void* stream);
 
+/* --me sea (X265_SEA, motion.cpp:1242-1395).  x265hip_build_integral_planes: the twelve window-sum planes FrameFilter::computeMEIntegral
+ * keeps per reference picture (framefilter.cpp:684-830; FrameData::m_meIntegral, framedata.h:171: 32x32 32x24 32x8 24x32 16x16 16x12 16x4 12x16 8x32
+ * 8x8 4x16 4x4) over a whole padded picture buffer (bufBase = first sample of the buffer, rows x stride): planes[k * planeElems + y * stride + x]
+ * = sum of the w_k x h_k window at (x, y), 0 where the window leaves the buffer and in row 0.  scratch: 6 * planeElems uint32.
+ * x265hip_motion_estimate_sea_batch: motionEstimate with the SEA search; refPlane / integralPlanes address the same sample (the picture
+ * origin or the buffer start) so that pu_xy applies to both; merange <= 126.  Everything else as x265hip_motion_estimate_batch. */
+int x265hip_build_integral_planes(int depth, const void* bufBase, int64_t stride, int rows, uint32_t* planes, int64_t planeElems, uint32_t* scratch,
+                                  void* stream);
+int x265hip_motion_estimate_sea_batch(int depth, int w, int h, const void* fencPlane, int64_t strideF, const void* refPlane, int64_t strideR,
+                                      const uint32_t* integralPlanes, int64_t planeElems, const int32_t* pu_xy, const int32_t* mvmin,
+                                      const int32_t* mvmax, const int32_t* qmvp, int numCand, const int32_t* mvc, int merange, int subme,
+                                      const uint16_t* mvcost, int mvcostHalf, int n, int32_t* outMv, int32_t* outCost, void* stream);
+
 /* All 16 quarter-pel phases of a whole (padded) reference picture, computed once per reference: plane[yFrac*4 + xFrac](x,y)
  * is exactly what luma_hpp / luma_vpp / luma_hvpp (ipfilter.cpp:79-369) produce for that pixel, plane 0 is the picture.
  * planesOrigin addresses pixel (0,0) of plane 0; plane p starts planeElems elements later; same stride and margins as the

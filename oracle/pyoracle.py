@@ -92,6 +92,8 @@ def oracle():
         f("orc_interp_hv_pp", None, [i32, vp, ip, vp, ip, i32, i32, i32, i32, i32])
         f("orc_p2s", None, [vp, ip, vp, ip, i32, i32, i32])
         f("orc_motion_estimate", i32, [vp, ip, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, vp, i32, vp])
+        f("orc_integral_plane", None, [vp, ip, i32, i32, i32, vp])
+        f("orc_motion_estimate_sea", i32, [vp, ip, vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, vp, i32, vp])
         f("orc_subpel_compare", i32, [vp, ip, i32, i32, vp, i32, i32, i32, i32, i32, i32])
         f("orc_motion_estimate_chroma", i32, [vp, ip, vp, vp, ip, i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, vp, i32, vp])
         f("orc_intra_filter", None, [i32, vp, vp])
@@ -220,6 +222,8 @@ def ref(depth):
     g("ref_partition_from_sizes", i32, [i32, i32])
     g("ref_mvcost_table", None, [i32, vp])
     g("ref_motion_estimate", i32, [vp, vp, ip, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp])
+    g("ref_integral_planes", None, [vp, ip, i32, i32, i32, vp, i64])
+    g("ref_motion_estimate_sea", i32, [vp, vp, ip, vp, i64, i32, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, vp])
     g("ref_motion_estimate_chroma", i32, [vp, vp, vp, vp, vp, vp, ip, ip, i32, i32, i32, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp])
     g("ref_pred_inter_bi", None, [vp, vp, vp, vp, vp, vp, ip, ip, i32, i32, i32, i32, vp, vp, vp, vp, vp])
     u16p = u8p = vp

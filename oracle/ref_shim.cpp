@@ -172,6 +172,56 @@ int ref_motion_estimate(pixel* refPlane, pixel* fencPlane, intptr_t stride, int 
     return cost;
 }
 
+/* ---- the real window-sum planes of --me sea: FrameFilter::computeMEIntegral (encoder/framefilter.cpp:684-830) needs a whole FrameEncoder; this
+ * drives the reference's own integral_inith / integral_initv primitives over all rows of a padded picture in the order that function does
+ * (row y: horizontal running sums accumulated onto row y + 1 of every plane, then the vertical difference h rows up).  planes = 12 buffers of
+ * planeElems uint32 (zeroed by the caller), laid out like the picture buffer (origin at padY * stride + padX).  rows = maxHeight + 2 * padY. */
+void ref_integral_planes(pixel* picOrg, intptr_t stride, int maxHeight, int padX, int padY, uint32_t* planes, int64_t planeElems)
+{
+    EncoderPrimitives& p = T();
+    static const int win[12][2] = { {32,32},{32,24},{32,8},{24,32},{16,16},{16,12},{16,4},{12,16},{8,32},{8,8},{4,16},{4,4} };
+    auto idx = [](int v) { return v == 4 ? INTEGRAL_4 : v == 8 ? INTEGRAL_8 : v == 12 ? INTEGRAL_12 : v == 16 ? INTEGRAL_16 : v == 24 ? INTEGRAL_24 : INTEGRAL_32; };
+    for (int y = -padY; y < maxHeight + padY - 1; y++)
+    {
+        pixel* pix = picOrg + (intptr_t)y * stride - padX;
+        for (int k = 0; k < 12; k++)
+        {
+            uint32_t* org = planes + (int64_t)k * planeElems + (intptr_t)padY * stride + padX;
+            uint32_t* sum = org + (intptr_t)(y + 1) * stride - padX;
+            p.integral_inith[idx(win[k][0])](sum, pix, stride);
+            if (y >= win[k][1] - padY)
+                p.integral_initv[idx(win[k][1])](sum - (intptr_t)win[k][1] * stride, stride);
+        }
+    }
+}
+
+/* the real MotionEstimate::motionEstimate with X265_SEA (motion.cpp:1242-1395); `planes` as ref_integral_planes left them */
+int ref_motion_estimate_sea(pixel* refPlane, pixel* fencPlane, intptr_t stride, uint32_t* planes, int64_t planeElems, int padX, int padY, int bx, int by, int w, int h,
+                            const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp, int numCand, const int32_t* mvc,
+                            int merange, int subme, int qp, int32_t* outQMv)
+{
+    T();
+    MotionEstimate me;
+    me.init(X265_CSP_I400);
+    me.setQP(qp);
+    me.setSourcePU(fencPlane, stride, bx + (intptr_t)by * stride, w, h, X265_SEA, X265_SEA, X265_SEA, subme);
+    for (int k = 0; k < INTEGRAL_PLANE_NUM; k++)
+        me.integral[k] = planes + (int64_t)k * planeElems + (intptr_t)padY * stride + padX + bx + (intptr_t)by * stride;     /* search.cpp: planes moved to the PU */
+    ReferencePlanes ref;
+    ref.fpelPlane[0] = refPlane;
+    ref.lumaStride = stride;
+    ref.isLowres = false;
+    ref.isHMELowres = false;
+    MV cands[16];
+    for (int i = 0; i < numCand && i < 16; i++)
+        cands[i] = MV(mvc[2 * i], mvc[2 * i + 1]);
+    MV out(0, 0);
+    int cost = me.motionEstimate(&ref, MV(mvmin[0], mvmin[1]), MV(mvmax[0], mvmax[1]), MV(qmvp[0], qmvp[1]), numCand, cands, merange, out, 1, 0);
+    outQMv[0] = out.x;
+    outQMv[1] = out.y;
+    return cost;
+}
+
 /* ---- intra prediction primitives (common/intrapred.cpp via the C table), cu = log2(size) - 2 ---- */
 void ref_intra_filter(int cu, const pixel* nb, pixel* out) { T().cu[cu].intra_filter(nb, out); }
 void ref_intra_pred(int cu, int mode, pixel* dst, intptr_t ds, const pixel* nb, int bFilter) { T().cu[cu].intra_pred[mode](dst, ds, nb, mode, bFilter); }

@@ -111,6 +111,11 @@ void orc_set_search_range(int picW, int picH, int maxCUSize, int merange, int re
 int64_t orc_lookahead_cost_p_##SFX(const P* fencPlane, const P* const* ref, intptr_t stride, int widthInCU, int heightInCU, \
                                    int numRowsPerSlice, int numSlices, int depth, const int32_t* intraCost, const uint16_t* mvcost, \
                                    int32_t* mvs, int32_t* mvCosts, uint16_t* lowresCosts, int32_t* rowSatds, int32_t* intraMbs); \
+/* --me sea (motion.cpp:1242-1395): window-sum planes (framefilter.cpp:684-830) + the search */ \
+void orc_integral_plane_##SFX(const P* buf, intptr_t stride, int rows, int w, int h, uint32_t* out); \
+int orc_motion_estimate_sea_##SFX(const P* plane, intptr_t stride, const uint32_t* const* integral, int bx, int by, const P* fenc, int w, int h, \
+                                  const int32_t mvmin[2], const int32_t mvmax[2], const int32_t qmvp[2], int numCand, const int32_t* mvc, \
+                                  int merange, int subme, const uint16_t* cost, int depth, int32_t outQMv[2]); \
 /* the two passes with the AQ-scaled sums (slicetype.cpp:3362-3384) and, for P, the reuse of a stored search (:3260-3264) */ \
 int64_t orc_lookahead_cost_p_aq_##SFX(const P* fencPlane, const P* const* ref, intptr_t stride, int widthInCU, int heightInCU, \
                                       int numRowsPerSlice, int numSlices, int depth, const int32_t* intraCost, const uint16_t* mvcost, \

@@ -299,6 +299,35 @@ class Orc(_Base):
                                            po.vp(cost.ctypes.data + 2 * po.MVCOST_CENTRE), self.depth, ptr(out))
         return c, (int(out[0]), int(out[1]))
 
+    SEA_WINDOWS = ((32, 32), (32, 24), (32, 8), (24, 32), (16, 16), (16, 12), (16, 4), (12, 16), (8, 32), (8, 8), (4, 16), (4, 4))
+
+    def integral_planes(self, buf, pad=None):
+        """The twelve window-sum planes of --me sea over a padded picture buffer: plane[k][y, x] = sum of the w_k x h_k window at (x, y)."""
+        out = []
+        for (w, h) in self.SEA_WINDOWS:
+            o = np.zeros(buf.shape, np.uint32)
+            self._f("orc_integral_plane")(ptr(buf), buf.shape[1], buf.shape[0], w, h, ptr(o))
+            out.append(o)
+        return out
+
+    def motion_estimate_sea(self, refplane, fencplane, bx, by, w, h, mvmin, mvmax, qmvp, mvc, merange, subme, qp, planes=None):
+        import ctypes as C
+        fenc = np.zeros((64, 64), self.pix)
+        fenc[:h, :w] = fencplane[by:by + h, bx:bx + w]
+        # the reference's source cache is the CU's 64x64 block: what lies right of / below the PU is the picture (AMP shapes read it)
+        blk = fencplane[by:by + 64, bx:bx + 64]
+        fenc[:blk.shape[0], :blk.shape[1]] = blk
+        cost = self.mvcost_table(qp)
+        planes = planes if planes is not None else self.integral_planes(refplane)
+        arr = (C.c_void_p * 12)(*[p.ctypes.data for p in planes])
+        a = [np.array(v, np.int32) for v in (mvmin, mvmax, qmvp)]
+        cand = np.array(mvc, np.int32).reshape(-1)
+        out = np.zeros(2, np.int32)
+        c = self._f("orc_motion_estimate_sea")(ptr(refplane), refplane.shape[1], arr, bx, by, ptr(fenc), w, h, ptr(a[0]), ptr(a[1]), ptr(a[2]),
+                                               len(mvc), ptr(cand) if len(mvc) else None, merange, subme,
+                                               po.vp(cost.ctypes.data + 2 * po.MVCOST_CENTRE), self.depth, ptr(out))
+        return c, (int(out[0]), int(out[1]))
+
     # ---- intra prediction / lookahead lowres
     def intra_filter(self, n, nb):
         out = np.zeros(4 * n + 1, self.pix)
@@ -888,6 +917,28 @@ class Ref(_Base):
         c = self.L.ref_motion_estimate(ptr(refplane), ptr(fencplane), refplane.shape[1], bx, by, w, h,
                                        ptr(a[0]), ptr(a[1]), ptr(a[2]), len(mvc), ptr(cand) if len(mvc) else None,
                                        merange, method, subme, qp, ptr(out))
+        return c, (int(out[0]), int(out[1]))
+
+    def integral_planes(self, buf, pad):
+        """The reference's own integral_inith / integral_initv primitives driven as FrameFilter::computeMEIntegral drives them; pad = (padY, padX)."""
+        pady, padx = pad
+        planes = np.zeros((12,) + buf.shape, np.uint32)
+        self.L.ref_integral_planes(ptr(buf, pady, padx), buf.shape[1], buf.shape[0] - 2 * pady, padx, pady, ptr(planes), buf.shape[0] * buf.shape[1])
+        return [planes[k] for k in range(12)]
+
+    def motion_estimate_sea(self, refplane, fencplane, bx, by, w, h, mvmin, mvmax, qmvp, mvc, merange, subme, qp, planes=None, pad=(80, 96)):
+        assert refplane.shape == fencplane.shape
+        pady, padx = pad
+        if planes is None:
+            planes = self.integral_planes(refplane, pad)
+        pl = np.ascontiguousarray(np.stack(planes))
+        a = [np.array(v, np.int32) for v in (mvmin, mvmax, qmvp)]
+        cand = np.array(mvc, np.int32).reshape(-1)
+        out = np.zeros(2, np.int32)
+        # the shim addresses planes from the picture origin: hand it origin-relative PU coordinates
+        c = self.L.ref_motion_estimate_sea(ptr(refplane, pady, padx), ptr(fencplane, pady, padx), refplane.shape[1], ptr(pl), refplane.shape[0] * refplane.shape[1],
+                                           padx, pady, bx - padx, by - pady, w, h, ptr(a[0]), ptr(a[1]), ptr(a[2]), len(mvc), ptr(cand) if len(mvc) else None,
+                                           merange, subme, qp, ptr(out))
         return c, (int(out[0]), int(out[1]))
 
     # ---- intra prediction / lookahead lowres

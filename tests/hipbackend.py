@@ -276,6 +276,32 @@ class Hip:
             tab.at(MVCOST_HALF), MVCOST_HALF, n, outmv.ptr, outcost.ptr, None))
         return outcost.get(), outmv.get()
 
+    def integral_planes(self, buf):
+        """x265hip_build_integral_planes over a padded picture buffer: list of 12 (rows, stride) uint32 arrays."""
+        R, S = buf.shape
+        db = DevBuf(buf)
+        planes, scratch = DevBuf.zeros((12, R, S), np.uint32), DevBuf.zeros((6, R, S), np.uint32)
+        check(self.L.x265hip_build_integral_planes(self.depth, db.ptr, S, R, planes.ptr, R * S, scratch.ptr, None))
+        a = planes.get()
+        return [a[k] for k in range(12)]
+
+    def motion_estimate_sea_batch(self, refplane, fencplane, w, h, pu_xy, mvmin, mvmax, qmvp, mvc, merange, subme, qp):
+        """--me sea: window-sum planes of the reference built on the device, then the search for every PU in one launch."""
+        n = len(pu_xy)
+        numCand = len(mvc[0]) if n and len(mvc) else 0
+        R, S = refplane.shape
+        dr, df = DevBuf(refplane), DevBuf(fencplane)
+        planes, scratch = DevBuf.zeros((12, R, S), np.uint32), DevBuf.zeros((6, R, S), np.uint32)
+        check(self.L.x265hip_build_integral_planes(self.depth, dr.ptr, S, R, planes.ptr, R * S, scratch.ptr, None))
+        tab = self._mvcost[qp]
+        outmv, outcost = DevBuf.zeros((n, 2), np.int32), DevBuf.zeros((n,), np.int32)
+        cand = dev_i32(np.asarray(mvc, np.int32).reshape(-1)) if numCand else None
+        check(self.L.x265hip_motion_estimate_sea_batch(
+            self.depth, w, h, df.ptr, fencplane.shape[1], dr.ptr, S, planes.ptr, R * S, _ip(np.asarray(pu_xy, np.int32)), _ip(np.asarray(mvmin, np.int32)),
+            _ip(np.asarray(mvmax, np.int32)), _ip(np.asarray(qmvp, np.int32)), numCand, cand.ptr if cand else None, merange, subme,
+            tab.at(MVCOST_HALF), MVCOST_HALF, n, outmv.ptr, outcost.ptr, None))
+        return outcost.get(), outmv.get()
+
     def motion_estimate(self, refplane, fencplane, bx, by, w, h, mvmin, mvmax, qmvp, mvc, merange, method, subme, qp):
         cost, mv = self.motion_estimate_batch(refplane, fencplane, w, h, [(bx, by)], [mvmin], [mvmax], [qmvp],
                                               [mvc] if len(mvc) else [], merange, method, subme, qp)

@@ -316,6 +316,54 @@ def dev_keep(values):
 
 
 # ---- motion estimation ---------------------------------------------------------------------------------------------------
+SEA_SHAPES = [(8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 16), (16, 32), (64, 32), (32, 64), (32, 24), (24, 32), (64, 48), (48, 64), (64, 16), (16, 64),
+              (16, 12), (12, 16), (16, 4), (4, 16)]      # the shapes whose four sub-blocks lie inside the PU (the others read the reference's stale source cache)
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_sea_search_matches_oracle(hipmod, depth):
+    """--me sea (X265_SEA, motion.cpp:1242-1395): the twelve window-sum planes built on the device equal the oracle's (itself pinned to the
+    reference's integral_init* primitives), and the search — DC lower-bound elimination per row against the running best, survivors SAD-ed in
+    threes, with the reference's cost arithmetic as it stands — returns the oracle's vector and cost for every PU of a batch."""
+    o, g = Orc(depth), hipmod.Hip(depth)
+    rng = np.random.default_rng(377 + depth)
+    refp, srcp, m = me_scene(depth, 199 + depth)
+    H, W = refp.shape[0] - 2 * m, refp.shape[1] - 2 * m
+    want_planes, got_planes = o.integral_planes(refp), g.integral_planes(refp)
+    for k, (w, h) in enumerate(Orc.SEA_WINDOWS):
+        assert np.array_equal(want_planes[k], got_planes[k]), (k, w, h)
+    bad, total = [], 0
+    for qp in (22, 37):
+        g.set_mvcost_table(qp, o.mvcost_table(qp))
+    for subme in (0, 2, 3):
+        for (w, h) in SEA_SHAPES:
+            npu = 8
+            merange = int(rng.choice([8, 16, 57]))
+            qp = int(rng.choice([22, 37]))
+            numCand = int(rng.integers(0, 3))
+            pus, mins, maxs, mvps, cands = [], [], [], [], []
+            for _ in range(npu):
+                bx = m + int(rng.integers(0, (W - w) // 4 + 1)) * 4
+                by = m + int(rng.integers(0, (H - h) // 4 + 1)) * 4
+                qmvp = (int(rng.integers(-40, 41)), int(rng.integers(-40, 41)))
+                mr = min(merange, 20)                      # keep every window (incl. the rounding up to 4) inside the 80-pixel margin
+                mvmin = ((qmvp[0] >> 2) - mr, (qmvp[1] >> 2) - mr)
+                mvmax = ((qmvp[0] >> 2) + mr, (qmvp[1] >> 2) + mr)
+                if rng.integers(0, 3) == 0:
+                    mvmax = (mvmax[0], min(mvmax[1], int(rng.integers(0, 6))))
+                pus.append((bx, by)); mins.append(mvmin); maxs.append(mvmax); mvps.append(qmvp)
+                cands.append([(int(rng.integers(-60, 61)), int(rng.integers(-60, 61))) for _ in range(numCand)])
+            cost, mv = g.motion_estimate_sea_batch(refp, srcp, w, h, pus, mins, maxs, mvps, cands if numCand else [], merange, subme, qp)
+            for i in range(npu):
+                a = o.motion_estimate_sea(refp, srcp, pus[i][0], pus[i][1], w, h, mins[i], maxs[i], mvps[i], cands[i], merange, subme, qp, planes=want_planes)
+                b = (int(cost[i]), (int(mv[i, 0]), int(mv[i, 1])))
+                total += 1
+                if a != b:
+                    bad.append((subme, w, h, pus[i], mvps[i], a, b))
+    assert not bad, (len(bad), total, bad[:5])
+    assert total >= 400
+
+
 @pytest.mark.parametrize("planes", [0, 1], ids=["filter", "planes"])
 @pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("method", [0, 1, 2, 3, 5])

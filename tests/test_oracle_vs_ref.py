@@ -222,6 +222,43 @@ def test_motion_estimate_matches_reference(depth, method):
 
 
 @pytest.mark.parametrize("depth", DEPTHS)
+def test_sea_search_matches_reference(depth):
+    """--me sea: the restated window-sum planes against the reference's own integral_inith / integral_initv primitives driven as
+    FrameFilter::computeMEIntegral drives them, and the restated search against the real MotionEstimate::motionEstimate with X265_SEA on those
+    planes (shapes whose sub-blocks lie inside the PU: the reference reads its 64x64 source cache beyond the PU for the others)."""
+    _need_ref(depth)
+    o, r = Orc(depth), Ref(depth)
+    rng = np.random.default_rng(177 + depth)
+    refp, srcp, m = me_scene(depth, 99 + depth)
+    H, W = refp.shape[0] - 2 * m, refp.shape[1] - 2 * m
+    pady, padx = 80, 96                                     # PicYuv margins at CTU 64 (picyuv.cpp:87-88)
+    refp = np.ascontiguousarray(np.pad(refp[m:m + H, m:m + W], ((pady, pady), (padx, padx)), mode="edge"))
+    srcp = np.ascontiguousarray(np.pad(srcp[m:m + H, m:m + W], ((pady, pady), (padx, padx)), mode="edge"))
+    po_, pr = o.integral_planes(refp), r.integral_planes(refp, (pady, padx))
+    for k, (w, h) in enumerate(Orc.SEA_WINDOWS):
+        assert np.array_equal(po_[k][:refp.shape[0] - h - 1, :refp.shape[1] - w], pr[k][:refp.shape[0] - h - 1, :refp.shape[1] - w]), (k, w, h)
+    sizes = [(8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 16), (16, 32), (64, 32), (32, 64), (32, 24), (24, 32), (64, 48), (48, 64), (64, 16), (16, 64),
+             (16, 12), (12, 16), (16, 4), (4, 16)]
+    n = 0
+    for subme in (0, 2, 3):
+        for (w, h) in sizes:
+            for _ in range(2):
+                bx = padx + int(rng.integers(0, (W - w) // 4 + 1)) * 4
+                by = pady + int(rng.integers(0, (H - h) // 4 + 1)) * 4
+                merange = int(rng.choice([8, 16, 24]))
+                qmvp = (int(rng.integers(-40, 41)), int(rng.integers(-40, 41)))
+                mvmin = ((qmvp[0] >> 2) - merange, (qmvp[1] >> 2) - merange)
+                mvmax = ((qmvp[0] >> 2) + merange, (qmvp[1] >> 2) + merange)
+                mvc = [(int(rng.integers(-60, 61)), int(rng.integers(-60, 61))) for _ in range(int(rng.integers(0, 4)))]
+                qp = int(rng.choice([22, 28, 37]))
+                a = o.motion_estimate_sea(refp, srcp, bx, by, w, h, mvmin, mvmax, qmvp, mvc, merange, subme, qp, planes=po_)
+                b = r.motion_estimate_sea(refp, srcp, bx, by, w, h, mvmin, mvmax, qmvp, mvc, merange, subme, qp, planes=pr, pad=(pady, padx))
+                assert a == b, (depth, subme, w, h, bx, by, qmvp, mvmin, mvmax, mvc, a, b)
+                n += 1
+    assert n >= 100
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_lowres_pass_matches_reference(depth):
     """Lowres::create/init + LookaheadTLD::lowresIntraEstimate of the real reference vs the restatement: the four hpel planes
     with their borders, every block's intra cost and mode, the row sums and the frame estimate."""

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void motion_kernel(const P* __restrict__ fencP
                                                      const int32_t* __restrict__ mvmaxA, const int32_t* __restrict__ qmvpA,
                                                      int numCand, const int32_t* __restrict__ mvcA, int merange, int method, int subme,
                                                      const uint16_t* __restrict__ mvcost, int w, int h, int depth, int n,
-                                                     int perWaveBytes, int32_t* __restrict__ outMv, int32_t* __restrict__ outCost, ChromaPlanes cp)
+                                                     int perWaveBytes, int32_t* __restrict__ outMv, int32_t* __restrict__ outCost, ChromaPlanes cp, SeaPlanes sea)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wv = threadIdx.x >> 6;
@@ -513,6 +513,122 @@ __global__ __launch_bounds__(256) void motion_kernel(const P* __restrict__ fencP
         }
         else if (meth == 3)
             star_search(c, mvmin.x, mvmin.y, mvmax.x, mvmax.y, merange, bmv.x, bmv.y, bcost);  // X265_STAR_SEARCH (mestar.h)
+        else if (meth == 4)
+        {
+            // X265_SEA, motion.cpp:1242-1395.  A row of the window is one step: every lane forms the DC lower bound of its position (ads_x4 / x2 / x1,
+            // pixel.cpp:121-166: |sum of the PU's quarters - window sums of the reference| + the position's x cost) against the row-start best;
+            // a ballot is the list of survivors in x order; survivors are SAD-ed three at a time and compared in order (COST_MV_X3_ABS), the
+            // last one or two of the row with the ordinary cost (COST_MV).  The arithmetic is the reference's as it stands (see the oracle).
+            const int minX = max(bmv.x - merange, mvmin.x), minY = max(bmv.y - merange, mvmin.y);
+            const int maxX = min(bmv.x + merange, mvmax.x), maxY = min(bmv.y + merange, mvmax.y);
+            const int meRangeWidth = (maxX - minX + 3) & ~3;
+            int deltaX = w <= 8 ? w : w >> 1;
+            int64_t deltaY = h <= 8 ? h : h >> 1;
+            const int wh = (w << 8) | h;
+            auto is = [wh](int a, int b) { return wh == ((a << 8) | b); };
+            const bool isSmall = is(4, 4) || is(16, 12) || is(12, 16) || is(16, 4) || is(4, 16);
+            const bool isV = is(32, 64) || is(16, 32) || is(8, 16) || is(4, 8), isH = is(64, 32) || is(32, 16) || is(16, 8) || is(8, 4);
+            const bool isAsym = is(12, 16) || is(4, 16) || is(24, 32) || is(8, 32) || is(48, 64) || is(16, 64) || is(16, 12) || is(16, 4) || is(32, 24) ||
+                                is(32, 8) || is(64, 48) || is(64, 16);
+            int tw, th;
+            if (isV) { tw = w; th = h >> 1; }
+            else if (isH) { tw = w >> 1; th = h; }
+            else if (isAsym) { tw = isSmall ? w : w >> 1; th = isSmall ? h : h >> 1; }
+            else { tw = w <= 8 ? w : w >> 1; th = w <= 8 ? h : h >> 1; }
+            // sums of the four sub-blocks of the source PU (sad_x4 against zeros, :1306-1312); blocks that leave the PU (shapes for which the
+            // reference reads whatever its 64x64 source cache holds there) are clamped to the PU: those shapes have no defined result
+            int encDC[4];
+#pragma unroll 1
+            for (int k = 0; k < 4; k++)
+            {
+                const int ox = (k & 1) ? deltaX : 0, oy = (k & 2) ? (int)deltaY : 0;
+                int sum = 0;
+                for (int e = c.lane; e < tw * th; e += 64)
+                {
+                    const int yy = min(oy + e / tw, h - 1), xx = min(ox + e % tw, w - 1);
+                    sum += (int)c.fenc[yy * w + xx];
+                }
+                encDC[k] = uni(wave_sum(sum));
+            }
+            int plane;
+            switch (deltaX)
+            {
+            case 32: plane = (deltaY % 24 == 0) ? 1 : (deltaY == 8 ? 2 : 0); break;
+            case 24: plane = 3; break;
+            case 16: plane = (deltaY % 12 == 0) ? 5 : (deltaY == 4 ? 6 : 4); break;
+            case 12: plane = 7; break;
+            case 8: plane = deltaY == 32 ? 8 : 9; break;
+            case 4: plane = deltaY == 16 ? 10 : 11; break;
+            default: plane = 11; break;
+            }
+            const uint32_t* sumsBase = sea.base + (int64_t)plane * sea.planeElems + (int64_t)by * strideR + bx;
+            const bool strided = is(64, 64) || is(32, 32) || is(16, 16) || is(32, 64) || is(16, 32) || is(8, 16) || is(4, 8) || is(12, 16) || is(4, 16) ||
+                                 is(24, 32) || is(8, 32) || is(48, 64) || is(16, 64);
+            if (strided) deltaY *= strideR;
+            if (isV) encDC[1] = encDC[2];
+            if (isH) deltaY = deltaX;
+            const int kind = (is(4, 4) || is(8, 8) || is(16, 12) || is(12, 16) || is(16, 4) || is(4, 16)) ? 1
+                           : ((is(8, 4) || is(4, 8) || is(16, 8) || is(8, 16) || is(32, 16) || is(16, 32) || is(64, 32) || is(32, 64)) ? 2 : 4);
+            const int chunks = (meRangeWidth + 63) >> 6;                 // <= 4: merange <= 126 (checked at the entry point)
+#pragma unroll 1
+            for (int ty = minY; ty <= maxY; ty++)
+            {
+                const int ycost = uni((int)c.cost[ty - 2 * qmvp.y]) << 2;
+                if (bcost <= ycost)
+                    continue;
+                bcost -= ycost;
+                unsigned long long keep[4] = { 0, 0, 0, 0 };
+                const uint32_t* sums = sumsBase + minX + (int64_t)ty * strideR;
+#pragma unroll
+                for (int ch = 0; ch < 4; ch++)
+                {
+                    const int i = ch * 64 + c.lane;
+                    bool k = false;
+                    if (ch < chunks && i < meRangeWidth)
+                    {
+                        long long a = llabs((long long)encDC[0] - (long long)sums[i]);
+                        if (kind == 4)
+                            a += llabs((long long)encDC[1] - (long long)sums[i + (w >> 1)]) + llabs((long long)encDC[2] - (long long)sums[i + deltaY]) +
+                                 llabs((long long)encDC[3] - (long long)sums[i + deltaY + (w >> 1)]);
+                        else if (kind == 2)
+                            a += llabs((long long)encDC[1] - (long long)sums[i + deltaY]);
+                        k = (int)(a + c.cost[4 * (minX + i) - qmvp.x]) < bcost;
+                    }
+                    keep[ch] = __ballot(k);
+                }
+                // survivors in x order, three at a time
+                int px[3], np = 0;
+#pragma unroll 1
+                for (int ch = 0; ch < chunks; ch++)
+                {
+                    unsigned long long m = keep[ch];
+                    while (m)
+                    {
+                        const int bit = __builtin_ctzll(m);
+                        m &= m - 1;
+                        px[np++] = minX + ch * 64 + bit;
+                        if (np == 3)
+                        {
+                            cand[0] = Mv{ px[0], ty }; cand[1] = Mv{ px[1], ty }; cand[2] = Mv{ px[2], ty }; cand[3] = cand[2];
+                            c.sad_multi(3, cand, costs);
+#pragma unroll
+                            for (int k3 = 0; k3 < 3; k3++)
+                            {
+                                const int cst = costs[k3] + uni((int)c.cost[4 * px[k3] - 2 * qmvp.x]);      // x cost only, predictor taken off twice (:307-309)
+                                if (cst < bcost) { bcost = cst; bmv.x = px[k3]; bmv.y = ty; }
+                            }
+                            np = 0;
+                        }
+                    }
+                }
+                bcost += ycost;
+                for (int k3 = 0; k3 < np; k3++)                                                              // COST_MV
+                {
+                    const int cst = c.sad_at(px[k3], ty) + c.mvcost(px[k3] * 4, ty * 4);
+                    if (cst < bcost) { bcost = cst; bmv.x = px[k3]; bmv.y = ty; }
+                }
+            }
+        }
         else if (meth == 5)
         {
             // X265_FULL_SEARCH, motion.cpp:1397-1441: raster order, strict '<' keeps the first minimum
@@ -643,7 +759,7 @@ namespace xh {
 static int launch_motion_v1(int depth, int w, int h, const void* fencPlane, int64_t strideF, const void* refPlane, int64_t strideR,
                             const int32_t* pu_xy, const int32_t* mvmin, const int32_t* mvmax, const int32_t* qmvp, int numCand, const int32_t* mvc,
                             int merange, int searchMethod, int subme, const uint16_t* mvcost, int n, int32_t* outMv, int32_t* outCost,
-                            const ChromaPlanes& cp, hipStream_t st)
+                            const ChromaPlanes& cp, hipStream_t st, const SeaPlanes& sea = SeaPlanes{})
 {
     const int B = depth == 8 ? 1 : 2;
     int perWave = 2 * w * h * B + (h + 7) * w * 2 + (cp.enable ? 2 * (w >> 1) * (h >> 1) * B : 0);
@@ -654,11 +770,11 @@ static int launch_motion_v1(int depth, int w, int h, const void* fencPlane, int6
     if (depth == 8)
         hipLaunchKernelGGL((motion_kernel<uint8_t>), grid, block, wpg * perWave, st, (const uint8_t*)fencPlane, strideF,
                            (const uint8_t*)refPlane, strideR, pu_xy, mvmin, mvmax, qmvp, numCand, mvc, merange, searchMethod, subme,
-                           mvcost, w, h, depth, n, perWave, outMv, outCost, cp);
+                           mvcost, w, h, depth, n, perWave, outMv, outCost, cp, sea);
     else
         hipLaunchKernelGGL((motion_kernel<uint16_t>), grid, block, wpg * perWave, st, (const uint16_t*)fencPlane, strideF,
                            (const uint16_t*)refPlane, strideR, pu_xy, mvmin, mvmax, qmvp, numCand, mvc, merange, searchMethod, subme,
-                           mvcost, w, h, depth, n, perWave, outMv, outCost, cp);
+                           mvcost, w, h, depth, n, perWave, outMv, outCost, cp, sea);
     XH_LAUNCH_CHECK("motion_kernel");
     return X265HIP_OK;
 }
@@ -667,7 +783,8 @@ static int check_me_args(const char* who, int depth, int w, int h, int n, int se
     if (!valid_depth(depth) || !valid_block(w, h) || (w & 3) || (h & 3) || (w == 4 && h == 4) || n < 0)
         return set_error(X265HIP_EINVAL, "%s: depth %d PU %dx%d n %d", who, depth, w, h, n);
     if (searchMethod != 0 && searchMethod != 1 && searchMethod != 2 && searchMethod != 3 && searchMethod != 5)
-        return set_error(X265HIP_EINVAL, "%s: searchMethod %d not implemented (DIA 0, HEX 1, UMH 2, STAR 3, FULL 5)", who, searchMethod);
+        return set_error(X265HIP_EINVAL, "%s: searchMethod %d not available here (DIA 0, HEX 1, UMH 2, STAR 3, FULL 5; SEA 4 needs the window-sum planes: "
+                         "x265hip_motion_estimate_sea_batch)", who, searchMethod);
     if (subme < 0 || subme > 7 || numCand < 0 || merange < 1 || mvcostHalf < 4 * (merange + 64))
         return set_error(X265HIP_EINVAL, "%s: subme %d numCand %d merange %d mvcostHalf %d", who, subme, numCand, merange, mvcostHalf);
     return X265HIP_OK;
@@ -717,6 +834,91 @@ extern "C" int x265hip_motion_estimate_chroma_batch(int depth, int w, int h, con
     const ChromaPlanes cp{ fencCb, fencCr, strideFC, refCb, refCr, strideRC, 1 };
     return launch_motion_v1(depth, w, h, fencPlane, strideF, refPlane, strideR, pu_xy, mvmin, mvmax, qmvp, numCand, mvc, merange, searchMethod,
                             subme, mvcost, n, outMv, outCost, cp, as_stream(stream));
+}
+
+// ---- --me sea: window-sum planes of a reference picture + the search --------------------------------------------------------------------
+namespace xh {
+// horizontal window sums of widths 4, 8, 12, 16, 24, 32 for every position of a padded picture buffer (one pass over 32 pixels gives all six)
+template <typename P>
+__global__ __launch_bounds__(256) void integral_h_kernel(const P* __restrict__ buf, int64_t stride, int rows, uint32_t* __restrict__ hsum, int64_t planeElems)
+{
+    const int64_t total = stride * (int64_t)rows;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256)
+    {
+        const int x = (int)(idx % stride);
+        const P* p = buf + idx;
+        uint32_t s = 0, out[6];
+#pragma unroll
+        for (int i = 0; i < 32; i++)
+        {
+            s += (x + i < stride) ? (uint32_t)p[i] : 0u;
+            if (i == 3) out[0] = s;
+            if (i == 7) out[1] = s;
+            if (i == 11) out[2] = s;
+            if (i == 15) out[3] = s;
+            if (i == 23) out[4] = s;
+            if (i == 31) out[5] = s;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            hsum[(int64_t)k * planeElems + idx] = out[k];
+    }
+}
+// plane k (w_k x h_k): vertical sum of h_k rows of the width-w_k horizontal sums; zero where the window leaves the buffer and in row 0, the
+// base row of the reference's running sums (framefilter.cpp:768-790)
+__global__ __launch_bounds__(256) void integral_v_kernel(const uint32_t* __restrict__ hsum, int64_t stride, int rows, int64_t planeElems, uint32_t* __restrict__ planes)
+{
+    const int kW[12] = { 32, 32, 32, 24, 16, 16, 16, 12, 8, 8, 4, 4 }, kH[12] = { 32, 24, 8, 32, 16, 12, 4, 16, 32, 8, 16, 4 };
+    const int k = blockIdx.y, w = kW[k], h = kH[k];
+    const int hw = w == 4 ? 0 : w == 8 ? 1 : w == 12 ? 2 : w == 16 ? 3 : w == 24 ? 4 : 5;
+    const uint32_t* src = hsum + (int64_t)hw * planeElems;
+    uint32_t* dst = planes + (int64_t)k * planeElems;
+    const int64_t total = stride * (int64_t)rows;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256)
+    {
+        const int x = (int)(idx % stride), y = (int)(idx / stride);
+        uint32_t s = 0;
+        if (y >= 1 && y + h <= rows && x + w <= stride)
+            for (int j = 0; j < h; j++)
+                s += src[idx + (int64_t)j * stride];
+        dst[idx] = s;
+    }
+}
+} // namespace xh
+
+extern "C" int x265hip_build_integral_planes(int depth, const void* bufBase, int64_t stride, int rows, uint32_t* planes, int64_t planeElems, uint32_t* scratch,
+                                             void* stream)
+{
+    XH_CHECK_DEV();
+    if (!valid_depth(depth) || !bufBase || !planes || !scratch || stride < 64 || rows < 64 || planeElems < stride * rows)
+        return set_error(X265HIP_EINVAL, "build_integral_planes: depth %d stride %lld rows %d", depth, (long long)stride, rows);
+    const int64_t total = stride * (int64_t)rows;
+    dim3 block(256), grid(grid_for((total + 255) / 256, 256 * 32));
+    if (depth == 8)
+        hipLaunchKernelGGL((integral_h_kernel<uint8_t>), grid, block, 0, as_stream(stream), (const uint8_t*)bufBase, stride, rows, scratch, planeElems);
+    else
+        hipLaunchKernelGGL((integral_h_kernel<uint16_t>), grid, block, 0, as_stream(stream), (const uint16_t*)bufBase, stride, rows, scratch, planeElems);
+    XH_LAUNCH_CHECK("integral_h_kernel");
+    hipLaunchKernelGGL(integral_v_kernel, dim3(grid.x, 12), block, 0, as_stream(stream), scratch, stride, rows, planeElems, planes);
+    XH_LAUNCH_CHECK("integral_v_kernel");
+    return X265HIP_OK;
+}
+
+extern "C" int x265hip_motion_estimate_sea_batch(int depth, int w, int h, const void* fencPlane, int64_t strideF, const void* refPlane, int64_t strideR,
+                                                 const uint32_t* integralPlanes, int64_t planeElems, const int32_t* pu_xy, const int32_t* mvmin,
+                                                 const int32_t* mvmax, const int32_t* qmvp, int numCand, const int32_t* mvc, int merange, int subme,
+                                                 const uint16_t* mvcost, int mvcostHalf, int n, int32_t* outMv, int32_t* outCost, void* stream)
+{
+    XH_CHECK_DEV();
+    int e = check_me_args("motion_estimate_sea", depth, w, h, n, 5, subme, numCand, merange, mvcostHalf);
+    if (e) return e;
+    if (!integralPlanes || merange > 126)
+        return set_error(X265HIP_EINVAL, "motion_estimate_sea: window-sum planes missing or merange %d > 126", merange);
+    if (!n) return X265HIP_OK;
+    const ChromaPlanes none{};
+    const SeaPlanes sea{ integralPlanes, planeElems, 1 };
+    return launch_motion_v1(depth, w, h, fencPlane, strideF, refPlane, strideR, pu_xy, mvmin, mvmax, qmvp, numCand, mvc, merange, 4, subme, mvcost, n, outMv,
+                            outCost, none, as_stream(stream), sea);
 }
 
 // ======================================================================================================================

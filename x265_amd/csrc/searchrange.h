@@ -43,6 +43,9 @@ struct DeriveRange
     int* predDone;
 };
 
+// --me sea: the twelve window-sum planes of the reference picture (picture-origin pointers, the picture's stride), planeElems apart
+struct SeaPlanes { const uint32_t* base; int64_t planeElems; int enable; };
+
 // bChromaSATD inputs (4:2:0): source and reference chroma planes at the picture origin (motion.cpp:212, :1601-1660)
 struct ChromaPlanes { const void* fencCb; const void* fencCr; int64_t strideFC; const void* refCb; const void* refCr; int64_t strideRC; int enable; };
 

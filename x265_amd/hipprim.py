@@ -154,6 +154,8 @@ PROTOTYPES = {
     "x265hip_lookahead_cost_p_batch": (i32, [i32, vp, i32, i64, i64, i32, i32, i32, i32, vp, u32, vp, vp]),
     "x265hip_lookahead_bidir_batch": (i32, [i32, vp, i32, i64, i64, i32, i32, vp, vp]),
     "x265hip_lookahead_pcost_batch": (i32, [vp, i32, i32, i32, vp, vp]),
+    "x265hip_build_integral_planes": (i32, [i32, vp, i64, i32, vp, i64, vp, vp]),
+    "x265hip_motion_estimate_sea_batch": (i32, [i32, i32, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, vp, i32, i32, vp, i32, i32, vp, vp, vp]),
     "x265hip_la_create": (vp, [vp]),
     "x265hip_la_destroy": (None, [vp]),
     "x265hip_la_set_frame": (i32, [vp, i32, vp, vp, vp]),
