@@ -118,3 +118,32 @@ def test_lookahead_seam_on_gpu_is_byte_identical(case):
     assert served and int(served[0].split()[2]) > 10, r
     planes = [l for l in r["gpu"]["served"] if "refplanes:" in l]
     assert planes and int(planes[0].split()[2]) > 10000, r
+
+
+BASELINE_ENCODES = {
+    # BASELINE.json configs[2]: 3840x2160 preset slow --me star --merange 57
+    "configs[2] 4K slow star": (8, 3840, 2160, 8, "slow", ("--me", "star", "--merange", "57")),
+    # configs[3]: 3840x2160 Main10 preset slower --rd 6
+    "configs[3] 4K main10 slower rd6": (10, 3840, 2160, 6, "slower", ("--rd", "6")),
+    # configs[4]: 7680x4320 preset medium (one encoder; the 8-GPU form is N of these)
+    "configs[4] 8K medium": (8, 7680, 4320, 6, "medium", ()),
+}
+
+
+@pytest.mark.parametrize("name", sorted(BASELINE_ENCODES))
+def test_baseline_configs_encode_byte_identical_through_the_seams(name):
+    """BASELINE.json configs[2], [3], [4] as real encodes: the reference encoder with the lookahead session and the reference-picture mirrors on the
+    GPU (4K: 32 400 lowres blocks per estimate, 8.7 M-sample planes; 8K: 130 k blocks, 35 M-sample planes) against the unmodified encoder — same
+    bytes, and both seams really served."""
+    bits, w, h, frames, preset, extra = BASELINE_ENCODES[name]
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import encode_fps
+    r = encode_fps.measure(frames=frames, width=w, height=h, bits=bits, preset=preset, extra=extra, seed=31)
+    if "error" in r and "not built" in r["error"]:
+        pytest.skip(r["error"])
+    assert "error" not in r, r
+    assert r["byte_identical"], r
+    served = [l for l in r["gpu"]["served"] if "frame-cost estimates" in l]
+    assert served and int(served[0].split()[2]) >= 3, r
+    planes = [l for l in r["gpu"]["served"] if "refplanes:" in l]
+    assert planes and int(planes[0].split()[2]) > 1000, r

@@ -122,7 +122,10 @@ def main():
         res.append({"kernel": "intra_scan %dx%d x35" % (size, size), "n": nblk * 35, "ms": ms, "GBps": nblk * 35 * 3 * size * size * B / ms / 1e6})
 
     for r in res:
-        print("%-22s n=%-7d %8.3f ms  %9.1f GB/s (algorithmic)" % (r["kernel"], r["n"], r["ms"], r["GBps"]))
+        # per-call algorithmic bytes over the launch time: a figure above the HBM peak (8 TB/s spec, 6.3 TB/s achievable) can only come from
+        # cache hits — candidates of one PU overlap, so L2 / MALL serve most of the per-call bytes — and is labelled as such
+        tag = "GB/s (algorithmic)" if r["GBps"] <= 6300 else "GB/s (algorithmic, cache-served: above what HBM can deliver)"
+        print("%-22s n=%-7d %8.3f ms  %9.1f %s" % (r["kernel"], r["n"], r["ms"], r["GBps"], tag))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "microbench_d%d.json" % depth), "w") as f:
         json.dump(res, f, indent=1)

@@ -17,6 +17,8 @@
 namespace xh {
 
 struct WeightCand { int present, w0, round, shift, offset; };
+constexpr int kCandsPerLaunch = 16;
+struct WeightCands { WeightCand c[kCandsPerLaunch]; };
 
 __device__ __forceinline__ int had4_abs_sum(const int (&d)[4][4])
 {
@@ -39,11 +41,11 @@ __device__ __forceinline__ int had4_abs_sum(const int (&d)[4][4])
 
 template <typename P>
 __global__ __launch_bounds__(256) void weight_cost_kernel(const P* __restrict__ fenc, const P* __restrict__ ref, int64_t stride, int widthInCU, int ncu,
-                                                          const int32_t* __restrict__ intraCost, const WeightCand* __restrict__ cands,
+                                                          const int32_t* __restrict__ intraCost, WeightCands cands,
                                                           uint32_t* __restrict__ costs, int maxv, int correction)
 {
     const int c = blockIdx.y;
-    const WeightCand k = cands[c];
+    const WeightCand k = cands.c[c];
     const int mb = blockIdx.x * blockDim.x + threadIdx.x;
     int cost = 0;
     if (mb < ncu)
@@ -88,36 +90,33 @@ __global__ __launch_bounds__(256) void weight_cost_kernel(const P* __restrict__ 
 static int launch_weight_costs(int depth, const void* fenc, const void* ref, int64_t stride, int width, int lines, const int32_t* intraCost,
                                const x265hip_weight_param* wp, int n, uint32_t* costs, hipStream_t st)
 {
-    // candidates live in a stream-ordered allocation of this call (freed on the stream behind the kernel): no process-wide scratch, so
-    // any thread, any device, any stream
-    WeightCand* dCand = nullptr;
-    if (hipMallocAsync((void**)&dCand, sizeof(WeightCand) * n, st) != hipSuccess)
-        return set_error(X265HIP_ENOMEM, "weight_cost: candidates");
+    // the candidates travel as kernel arguments, sixteen per launch: no scratch buffer to own, so any thread, any device, any stream
     const int correction = 14 - depth;
-    WeightCand* h = (WeightCand*)alloca(sizeof(WeightCand) * n);
-    for (int i = 0; i < n; i++)
-    {
-        const int denom = wp[i].log2WeightDenom;
-        h[i].present = wp[i].wtPresent;
-        h[i].w0 = wp[i].inputWeight;
-        h[i].round = (denom ? 1 << (denom - 1) : 0) << correction;
-        h[i].shift = denom + correction;
-        h[i].offset = wp[i].inputOffset << (depth - 8);
-    }
-    if (hipMemcpyAsync(dCand, h, sizeof(WeightCand) * n, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)   // h is on this stack
-        return set_error(X265HIP_EHIP, "weight_cost: candidate upload");
     if (hipMemsetAsync(costs, 0, sizeof(uint32_t) * n, st) != hipSuccess)
         return set_error(X265HIP_EHIP, "weight_cost: memset");
     const int wcu = (width + 7) >> 3, hcu = (lines + 7) >> 3, ncu = wcu * hcu;
-    dim3 grid((ncu + 255) / 256, n), block(256);
-    if (depth == 8)
-        hipLaunchKernelGGL((weight_cost_kernel<uint8_t>), grid, block, 0, st, (const uint8_t*)fenc, (const uint8_t*)ref, stride, wcu, ncu, intraCost, dCand, costs,
-                           (1 << depth) - 1, correction);
-    else
-        hipLaunchKernelGGL((weight_cost_kernel<uint16_t>), grid, block, 0, st, (const uint16_t*)fenc, (const uint16_t*)ref, stride, wcu, ncu, intraCost, dCand, costs,
-                           (1 << depth) - 1, correction);
-    XH_LAUNCH_CHECK("weight_cost_kernel");
-    (void)hipFreeAsync(dCand, st);
+    for (int i0 = 0; i0 < n; i0 += kCandsPerLaunch)
+    {
+        const int m = n - i0 < kCandsPerLaunch ? n - i0 : kCandsPerLaunch;
+        WeightCands h{};
+        for (int i = 0; i < m; i++)
+        {
+            const int denom = wp[i0 + i].log2WeightDenom;
+            h.c[i].present = wp[i0 + i].wtPresent;
+            h.c[i].w0 = wp[i0 + i].inputWeight;
+            h.c[i].round = (denom ? 1 << (denom - 1) : 0) << correction;
+            h.c[i].shift = denom + correction;
+            h.c[i].offset = wp[i0 + i].inputOffset << (depth - 8);
+        }
+        dim3 grid((ncu + 255) / 256, m), block(256);
+        if (depth == 8)
+            hipLaunchKernelGGL((weight_cost_kernel<uint8_t>), grid, block, 0, st, (const uint8_t*)fenc, (const uint8_t*)ref, stride, wcu, ncu, intraCost, h, costs + i0,
+                               (1 << depth) - 1, correction);
+        else
+            hipLaunchKernelGGL((weight_cost_kernel<uint16_t>), grid, block, 0, st, (const uint16_t*)fenc, (const uint16_t*)ref, stride, wcu, ncu, intraCost, h,
+                               costs + i0, (1 << depth) - 1, correction);
+        XH_LAUNCH_CHECK("weight_cost_kernel");
+    }
     return X265HIP_OK;
 }
 
