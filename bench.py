@@ -559,10 +559,12 @@ def main():
     L = hp.lib()
     hp.check(L.x265hip_init(local_rank))
     if world > 1:
+        import datetime
+        tmo = datetime.timedelta(seconds=300)              # a wedged collective must end the run with an error, not hang the box
         if same_dev:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
     dev = torch.device("cuda", local_rank)
 
     def fence():
@@ -587,7 +589,10 @@ def main():
 
     fpb = None
     if not args.no_frame_pass:
-        fpb = frame_pass_bench(args, rank, local_rank, world, max(args.steps, 20), max(args.warmup, 5))
+        try:
+            fpb = frame_pass_bench(args, rank, local_rank, world, max(args.steps, 20), max(args.warmup, 5))
+        except Exception as e:  # noqa: BLE001  — the secondary block must never cost the run its headline
+            fpb = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
     if rank == 0:
         la_ms, la_blocks = lookahead_kernel_probe(L, hp, np)
