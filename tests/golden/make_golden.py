@@ -278,9 +278,44 @@ def prim_digests(backend_cls, depth):
     return out
 
 
+SEA_SHAPES = [(8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 16), (16, 32), (64, 32), (32, 64), (32, 24), (24, 32), (64, 48), (48, 64), (64, 16), (16, 64),
+              (16, 12), (12, 16), (16, 4), (4, 16)]
+
+
+def sea_results(B, depth):
+    """--me sea on fixed cases (the shapes whose sub-blocks lie inside the PU): [cost, mvx, mvy] per case + a digest of the twelve window-sum planes
+    over the region where the reference defines them."""
+    from cases import me_scene
+    b = B(depth)
+    rng = np.random.default_rng(977 + depth)
+    refp, srcp, m = me_scene(depth, 299 + depth)
+    H, W = refp.shape[0] - 2 * m, refp.shape[1] - 2 * m
+    pady, padx = 80, 96
+    refp = np.ascontiguousarray(np.pad(refp[m:m + H, m:m + W], ((pady, pady), (padx, padx)), mode="edge"))
+    srcp = np.ascontiguousarray(np.pad(srcp[m:m + H, m:m + W], ((pady, pady), (padx, padx)), mode="edge"))
+    is_ref = B is Ref
+    planes = b.integral_planes(refp, (pady, padx)) if is_ref else b.integral_planes(refp)
+    wins = ((32, 32), (32, 24), (32, 8), (24, 32), (16, 16), (16, 12), (16, 4), (12, 16), (8, 32), (8, 8), (4, 16), (4, 4))
+    out = {"planes": digest(tuple(np.ascontiguousarray(planes[k][:refp.shape[0] - h - 1, :refp.shape[1] - w]) for k, (w, h) in enumerate(wins))), "cases": []}
+    for subme in (0, 2, 3):
+        for (w, h) in SEA_SHAPES:
+            bx = padx + int(rng.integers(0, (W - w) // 4 + 1)) * 4
+            by = pady + int(rng.integers(0, (H - h) // 4 + 1)) * 4
+            merange = int(rng.choice([8, 16, 24]))
+            qmvp = (int(rng.integers(-40, 41)), int(rng.integers(-40, 41)))
+            mvmin = ((qmvp[0] >> 2) - merange, (qmvp[1] >> 2) - merange)
+            mvmax = ((qmvp[0] >> 2) + merange, (qmvp[1] >> 2) + merange)
+            mvc = [(int(rng.integers(-60, 61)), int(rng.integers(-60, 61))) for _ in range(int(rng.integers(0, 4)))]
+            qp = int(rng.choice([22, 28, 37]))
+            kw = dict(planes=planes, pad=(pady, padx)) if is_ref else dict(planes=planes)
+            c, mv = b.motion_estimate_sea(refp, srcp, bx, by, w, h, mvmin, mvmax, qmvp, mvc, merange, subme, qp, **kw)
+            out["cases"].append([int(c), int(mv[0]), int(mv[1])])
+    return out
+
+
 if __name__ == "__main__":
     gold = {}
-    for depth in (8, 10):
+    for depth in (8, 10, 12):
         gold[str(depth)] = {"prims": prim_digests(Ref, depth), "me": me_digests(Ref, depth), "umh": umh_results(Ref, depth), "chroma_me": chroma_me_results(Ref, depth),
                             "bipred": {k: digest(v) for k, v in bipred_results(Ref, depth).items()},
                             "mc": {k: digest(v) for k, v in mc_results(Ref, depth).items()},
@@ -289,7 +324,8 @@ if __name__ == "__main__":
                             "aq": {k: digest(v) for k, v in aq_results(Ref, depth).items()},
                             "lookahead_weightp": {k: digest(v) for k, v in lookahead_weightp_results(Ref, depth).items()}, "lowres": lowres_digests(Ref, depth), "lookahead": lookahead_digests(Ref, depth),
                             "lookahead_b": {k: digest(v) for k, v in lookahead_b_results(Ref, depth).items()},
-                            "mvcost": {str(qp): digest(Ref(depth).mvcost_table(qp)) for qp in (12, 28, 37, 51)}}
+                            "mvcost": {str(qp): digest(Ref(depth).mvcost_table(qp)) for qp in (12, 28, 37, 51)},
+                            "sea": sea_results(Ref, depth)}
     # the CABAC cost table is data of the reference: dump it for the tests and for the GPU box, where /root/reference does not exist
     with open(os.path.join(HERE, "entropy_state_bits.json"), "w") as f:
         json.dump({"source": "x265_entropyStateBits (common/constants.cpp) of the reference build, dumped by tests/golden/make_golden.py",
