@@ -58,3 +58,49 @@ def test_binding_with_emulated_abi_is_byte_identical(tmp_path, name):
     assert planes and int(planes[0].split()[2]) > 1000, outs["emul"][1][-600:]
     if "fade" in name:
         assert "Weighted P-Frames: Y:0.0%" not in outs["ref"][1], "the fade clip was meant to exercise weightp"
+
+
+OPTION_SETS = {
+    # rate control that asks the lookahead for more: VBV plans ahead through vbvLookahead / vbvFrameCost (slicetype.cpp:1786-1877)
+    "vbv": (1280, 720, 12, ["--preset", "medium", "--vbv-bufsize", "4000", "--vbv-maxrate", "3000", "--bitrate", "2500"]),
+    # slices: CTU rows of a picture finish out of order (FrameFilter::processPostRow per slice): the mirrors publish the contiguous prefix only
+    "slices": (1280, 720, 10, ["--preset", "medium", "--slices", "4"]),
+    "no-wpp-F1": (640, 360, 12, ["--preset", "medium", "--no-wpp", "-F", "1"]),
+    "bframes0": (640, 360, 12, ["--preset", "medium", "--bframes", "0"]),
+    "badapt0-long-lookahead": (640, 360, 40, ["--preset", "faster", "--b-adapt", "0", "--rc-lookahead", "30", "--bframes", "3"]),
+    "no-cutree-no-aq": (640, 360, 12, ["--preset", "medium", "--no-cutree", "--aq-mode", "0"]),
+    "qg8-aq3": (640, 360, 12, ["--preset", "medium", "--aq-mode", "3", "--qg-size", "8"]),
+    "lookahead-slices4": (1280, 720, 10, ["--preset", "medium", "--lookahead-slices", "4"]),
+    "weightb-ref4": (640, 360, 14, ["--preset", "slow", "--weightb", "--ref", "4"]),
+    # not covered by the device pass: the binding must step aside and leave the reference's code in charge
+    "hme-falls-back": (1280, 720, 8, ["--preset", "medium", "--hme"]),
+    "aq-motion-falls-back": (640, 360, 10, ["--preset", "medium", "--aq-motion"]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(OPTION_SETS))
+def test_binding_across_encoder_options(tmp_path, name):
+    """The two seams under the encoder options that change what they see — VBV lookahead costs, slices (rows published out of order), no WPP / one
+    frame thread, no B frames, fixed B pattern with a long lookahead, AQ / CU-tree off, qg-size 8, lookahead slices, weighted B prediction, and the two
+    options the device pass does not cover (HME, aq-motion) — byte-identical to the unmodified reference every time."""
+    w, h, frames, extra = OPTION_SETS[name]
+    ref, emul = _need("x265_8bit"), _need("x265_emul_8bit")
+    from x265_amd.synth import make_clip
+    yuv = str(tmp_path / "clip.yuv")
+    make_clip(yuv, w, h, frames, seed=131, fade=("weightb" in name))
+    args = ["--input", yuv, "--input-res", "%dx%d" % (w, h), "--input-depth", "8", "--fps", "30", "--frames", str(frames), "--pools", "4", "--hash", "1"] + extra
+    if "-F" not in extra:
+        args += ["-F", "2"]
+    outs = {}
+    for tag, exe in (("ref", ref), ("emul", emul)):
+        o = str(tmp_path / (tag + ".hevc"))
+        r = subprocess.run([exe] + args + ["-o", o], capture_output=True, text=True, timeout=900, env=dict(os.environ, X265HIP_VERBOSE="1"))
+        assert r.returncode == 0, r.stderr[-800:]
+        outs[tag] = (open(o, "rb").read(), r.stderr)
+    assert len(outs["ref"][0]) > 1000
+    assert outs["ref"][0] == outs["emul"][0], "bitstreams differ"
+    served = [l for l in outs["emul"][1].splitlines() if "frame-cost estimates" in l]
+    if "falls-back" in name:
+        assert not served or int(served[0].split()[2]) == 0, outs["emul"][1][-400:]
+    else:
+        assert served and int(served[0].split()[2]) > 0, outs["emul"][1][-600:]
