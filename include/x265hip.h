@@ -629,6 +629,13 @@ int x265hip_refpic_rows_ready(x265hip_refpic* rp);
 const int* x265hip_refpic_rows_ready_ptr(x265hip_refpic* rp);
 int x265hip_refpic_wait(x265hip_refpic* rp);        /* blocks until the worker has nothing queued for rp; reports a worker failure */
 
+/* ---------------------------------------------------------------- source-picture energy planes (lookup face) ------- */
+/* The source half of psyCost_pp (pixel.cpp:726-757) for every aligned block of a SOURCE plane: e8[by * (width / 8) + bx] =
+ * sa8d_8x8(block, 0) - (sum(block) >> 2) of the 8x8 block at (8 bx, 8 by); e4[...] the same with satd_4x4 for every 4x4 block
+ * (row pitch width / 8 * 2).  Host pointers, blocks until the planes are in host memory; one call per plane of a picture entering the
+ * encoder.  x265_amd/host/x265_hip_srcplanes.cpp serves cu[].psy_cost_pp from them. */
+int x265hip_source_energy(int depth, const void* hostPlane, int64_t stride, int width, int height, int32_t* hostE8, int32_t* hostE4);
+
 /* ---------------------------------------------------------------- per-call entry points (host pointers) ----- */
 /* What the reference-side table shims bind (x265_amd/host/x265_hip_primitives.cpp).  Arguments are the slot's own
  * arguments (HOST pointers, caller-owned, valid only during the call — primitives.h:133-234); each call stages the

@@ -7,8 +7,9 @@
 
 namespace X265_NS {
 void x265hip_install_lookup_slots(EncoderPrimitives& p);        // x265_amd/host/x265_hip_refplanes.cpp
+void x265hip_install_psy_slots(EncoderPrimitives& p);           // x265_amd/host/x265_hip_srcplanes.cpp
 void setupInstrinsicPrimitives(EncoderPrimitives&, int) {}
-void setupAssemblyPrimitives(EncoderPrimitives& p, int) { x265hip_install_lookup_slots(p); }
+void setupAssemblyPrimitives(EncoderPrimitives& p, int) { x265hip_install_lookup_slots(p); x265hip_install_psy_slots(p); }
 }
 extern "C" {
 int PFX(cpu_cpuid_test)(void) { return 0; }

@@ -268,3 +268,31 @@ int x265hip_refpic_rows_final(x265hip_refpic* rp, int rowsFinal)
     __atomic_store_n(&rp->rowsReady, phaseEnd - rp->marginY, __ATOMIC_RELEASE);
     return 0;
 }
+
+
+/* ---------------------------------------------------------------- source-picture energy planes, emulated ------------------------------ *
+ * the source half of psyCost_pp (pixel.cpp:726-757) with the oracle's sa8d / satd restatements against a zero block */
+int x265hip_source_energy(int depth, const void* hostPlane, int64_t stride, int width, int height, int32_t* hostE8, int32_t* hostE4)
+{
+    const int bw = width >> 3, bh = height >> 3;
+    static const uint16_t zero[64];
+    for (int by = 0; by < bh; by++)
+        for (int bx = 0; bx < bw; bx++)
+        {
+#define ENERGY(T, SFX) do { \
+            const T* p = (const T*)hostPlane + (int64_t)by * 8 * stride + bx * 8; \
+            int sum = 0; \
+            for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) sum += p[y * stride + x]; \
+            hostE8[by * bw + bx] = orc_sa8d_##SFX(p, stride, (const T*)zero, 0, 8) - (sum >> 2); \
+            for (int q = 0; q < 4; q++) \
+            { \
+                const T* p4 = p + (q >> 1) * 4 * stride + (q & 1) * 4; \
+                int s4 = 0; \
+                for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) s4 += p4[y * stride + x]; \
+                hostE4[(by * 2 + (q >> 1)) * (bw * 2) + bx * 2 + (q & 1)] = orc_satd_##SFX(p4, stride, (const T*)zero, 0, 4, 4) - (s4 >> 2); \
+            } } while (0)
+            if (depth == 8) ENERGY(uint8_t, 8); else ENERGY(uint16_t, 16);
+#undef ENERGY
+        }
+    return 0;
+}

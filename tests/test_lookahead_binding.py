@@ -56,6 +56,9 @@ def test_binding_with_emulated_abi_is_byte_identical(tmp_path, name):
     # the reference-picture mirrors (x265_hip_refplanes.cpp): luma sub-pel filter calls answered out of the (emulated) planes
     planes = [l for l in outs["emul"][1].splitlines() if "x265hip: refplanes:" in l]
     assert planes and int(planes[0].split()[2]) > 1000, outs["emul"][1][-600:]
+    # the source-picture energy planes (x265_hip_srcplanes.cpp): the source half of psy_cost_pp looked up, every block verified against the picture
+    psy = [l for l in outs["emul"][1].splitlines() if "x265hip: srcplanes:" in l]
+    assert psy and int(psy[0].split()[5]) > 1000, outs["emul"][1][-600:]
     if "fade" in name:
         assert "Weighted P-Frames: Y:0.0%" not in outs["ref"][1], "the fade clip was meant to exercise weightp"
 

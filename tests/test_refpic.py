@@ -78,3 +78,35 @@ def test_rows_arrive_band_by_band_and_match_the_filters(depth, w, h):
             assert np.array_equal(planes[p][4:my + ready, 4:S - 4], want2[p][4:my + ready, 4:S - 4]), p
     finally:
         L.x265hip_refpic_destroy(rp)
+
+
+@pytest.mark.parametrize("depth,w,h", [(8, 200, 136), (10, 72, 64), (12, 328, 200)])
+def test_source_energy_planes_match_the_oracle(depth, w, h):
+    """x265hip_source_energy: the source half of psyCost_pp (pixel.cpp:726-757) for every aligned 8x8 and 4x4 block of a plane — sa8d_8x8 / satd_4x4
+    against a zero block minus a quarter of the block sum — against the oracle's restatements, on random and on extreme pictures."""
+    from backends import Orc
+    from x265_amd import hipprim as hp
+    L = hp.lib()
+    hp.check(L.x265hip_init(0))
+    o = Orc(depth)
+    rng = np.random.default_rng(11 + depth)
+    dt = hp.pix_dtype(depth)
+    S = w + 24
+    for kind in ("random", "max", "checker"):
+        if kind == "random":
+            pic = rng.integers(0, 1 << depth, size=(h + 3, S)).astype(dt)
+        elif kind == "max":
+            pic = np.full((h + 3, S), (1 << depth) - 1, dt)
+        else:
+            pic = (((np.add.outer(np.arange(h + 3), np.arange(S)) & 1) * ((1 << depth) - 1))).astype(dt)
+        bw, bh = w // 8, h // 8
+        e8, e4 = np.zeros((bh, bw), np.int32), np.zeros((bh * 2, bw * 2), np.int32)
+        hp.check(L.x265hip_source_energy(depth, pic.ctypes.data, S, w, h, e8.ctypes.data, e4.ctypes.data))
+        zero = np.zeros((8, 8), dt)
+        for by in range(bh):
+            for bx in range(bw):
+                blk = np.ascontiguousarray(pic[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8])
+                assert e8[by, bx] == o.sa8d(8, blk, (0, 0), zero, (0, 0)) - (int(blk.sum()) >> 2), (kind, bx, by)
+                for q in range(4):
+                    b4 = np.ascontiguousarray(blk[(q >> 1) * 4:(q >> 1) * 4 + 4, (q & 1) * 4:(q & 1) * 4 + 4])
+                    assert e4[by * 2 + (q >> 1), bx * 2 + (q & 1)] == o.satd(4, 4, b4, (0, 0), zero, (0, 0)) - (int(b4.sum()) >> 2), (kind, bx, by, q)

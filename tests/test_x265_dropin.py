@@ -118,6 +118,8 @@ def test_lookahead_seam_on_gpu_is_byte_identical(case):
     assert served and int(served[0].split()[2]) > 10, r
     planes = [l for l in r["gpu"]["served"] if "refplanes:" in l]
     assert planes and int(planes[0].split()[2]) > 10000, r
+    psy = [l for l in r["gpu"]["served"] if "srcplanes:" in l]
+    assert psy and int(psy[0].split()[5]) > 10000, r
 
 
 BASELINE_ENCODES = {

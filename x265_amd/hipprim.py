@@ -164,6 +164,7 @@ PROTOTYPES = {
     "x265hip_la_weights_analyse": (i32, [vp, i32, i32, u64, u64, u64, u64, vp, vp, vp]),
     "x265hip_la_estimate_batch": (i32, [vp, vp, i32, i32, i32]),
     "x265hip_la_stats": (i32, [vp, vp, vp, vp]),
+    "x265hip_source_energy": (i32, [i32, vp, i64, i32, i32, vp, vp]),
     "x265hip_refpic_create": (vp, [i32, i32, i32, i64, i32, i32, i32, vp]),
     "x265hip_refpic_destroy": (None, [vp]),
     "x265hip_refpic_reset": (i32, [vp]),

@@ -550,6 +550,7 @@ static void saoCuStatsE3_hip(const int16_t* diff, const pixel* rec, intptr_t str
     } while (0)
 
 void x265hip_install_lookup_slots(EncoderPrimitives& p);        // x265_hip_refplanes.cpp
+void x265hip_install_psy_slots(EncoderPrimitives& p);           // x265_hip_srcplanes.cpp
 
 static void report_calls()
 {
@@ -573,6 +574,7 @@ void setupAssemblyPrimitives(EncoderPrimitives& p, int /* cpuMask: CPU ISA bits,
     if (!mode || strcmp(mode, "percall"))
     {
         x265hip_install_lookup_slots(p);            // x265_hip_refplanes.cpp: luma sub-pel filters served from GPU-built planes
+        x265hip_install_psy_slots(p);               // x265_hip_srcplanes.cpp: the source half of psy_cost_pp from GPU-built energy planes
         return;
     }
     if (x265hip_device_count() < 1 || x265hip_init(0))
