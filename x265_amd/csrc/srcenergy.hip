@@ -7,6 +7,7 @@
 // it is computed once per picture: one launch per plane gives the energy of every aligned 8x8 and 4x4 block; the table slot
 // (x265_amd/host/x265_hip_srcplanes.cpp) then looks the source half up and only computes the reconstruction half.
 #include "common.h"
+#include <cstring>
 
 namespace xh {
 
@@ -94,6 +95,18 @@ __global__ __launch_bounds__(128) void source_energy_kernel(const P* __restrict_
 
 using namespace xh;
 
+namespace xh {
+// per calling thread: a stream, a device buffer and page-locked staging, kept between calls (a picture's worth of planes arrives per frame)
+struct EnergyScratch
+{
+    hipStream_t st = nullptr;
+    char* d = nullptr; char* h = nullptr;
+    size_t cap = 0;
+    int device = -1;
+};
+static thread_local EnergyScratch t_es;
+}
+
 extern "C" int x265hip_source_energy(int depth, const void* hostPlane, int64_t stride, int width, int height, int32_t* hostE8, int32_t* hostE4)
 {
     XH_CHECK_DEV();
@@ -101,32 +114,36 @@ extern "C" int x265hip_source_energy(int depth, const void* hostPlane, int64_t s
         return set_error(X265HIP_EINVAL, "source_energy: depth %d %dx%d stride %lld", depth, width, height, (long long)stride);
     // complete 8x8 blocks only (what psyCost_pp can be asked about: CUs and TUs are aligned to their size)
     const int bw = width >> 3, bh = height >> 3, B = depth == 8 ? 1 : 2;
-    const size_t planeBytes = (size_t)stride * (bh * 8) * B, e8Bytes = (size_t)bw * bh * 4, e4Bytes = e8Bytes * 4;
-    hipStream_t st = nullptr;
-    char* d = nullptr;
-    int rc = X265HIP_OK;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
-        return set_error(X265HIP_EHIP, "source_energy: stream");
-    if (hipMalloc((void**)&d, planeBytes + e8Bytes + e4Bytes) != hipSuccess)
-        rc = set_error(X265HIP_ENOMEM, "source_energy: %zu bytes", planeBytes + e8Bytes + e4Bytes);
-    if (!rc && hipMemcpyAsync(d, hostPlane, planeBytes, hipMemcpyHostToDevice, st) != hipSuccess)
-        rc = set_error(X265HIP_EHIP, "source_energy: upload");
-    if (!rc)
+    const size_t planeBytes = (size_t)stride * (bh * 8) * B, e8Bytes = (size_t)bw * bh * 4, e4Bytes = e8Bytes * 4, need = planeBytes + e8Bytes + e4Bytes;
+    EnergyScratch& es = t_es;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (es.device != dev || es.cap < need)
     {
-        int32_t* dE8 = (int32_t*)(d + planeBytes);
-        int32_t* dE4 = dE8 + (size_t)bw * bh;
-        const dim3 grid((bw * bh + 127) / 128), block(128);
-        if (depth == 8)
-            hipLaunchKernelGGL((source_energy_kernel<uint8_t>), grid, block, 0, st, (const uint8_t*)d, stride, bw, bh, dE8, dE4);
-        else
-            hipLaunchKernelGGL((source_energy_kernel<uint16_t>), grid, block, 0, st, (const uint16_t*)d, stride, bw, bh, dE8, dE4);
-        if (hipGetLastError() != hipSuccess)
-            rc = set_error(X265HIP_EHIP, "source_energy: launch");
-        if (!rc && (hipMemcpyAsync(hostE8, dE8, e8Bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                    hipMemcpyAsync(hostE4, dE4, e4Bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
-            rc = set_error(X265HIP_EHIP, "source_energy: download");
+        if (es.d) (void)hipFree(es.d);
+        if (es.h) (void)hipHostFree(es.h);
+        if (es.st && es.device != dev) { (void)hipStreamDestroy(es.st); es.st = nullptr; }
+        es.d = es.h = nullptr; es.cap = 0; es.device = dev;
+        if (!es.st && hipStreamCreateWithFlags(&es.st, hipStreamNonBlocking) != hipSuccess)
+            return set_error(X265HIP_EHIP, "source_energy: stream");
+        if (hipMalloc((void**)&es.d, need) != hipSuccess || hipHostMalloc((void**)&es.h, need, hipHostMallocDefault) != hipSuccess)
+            return set_error(X265HIP_ENOMEM, "source_energy: %zu bytes", need);
+        es.cap = need;
     }
-    if (d) (void)hipFree(d);
-    (void)hipStreamDestroy(st);
-    return rc;
+    memcpy(es.h, hostPlane, planeBytes);
+    if (hipMemcpyAsync(es.d, es.h, planeBytes, hipMemcpyHostToDevice, es.st) != hipSuccess)
+        return set_error(X265HIP_EHIP, "source_energy: upload");
+    int32_t* dE8 = (int32_t*)(es.d + planeBytes);
+    int32_t* dE4 = dE8 + (size_t)bw * bh;
+    const dim3 grid((bw * bh + 127) / 128), block(128);
+    if (depth == 8)
+        hipLaunchKernelGGL((source_energy_kernel<uint8_t>), grid, block, 0, es.st, (const uint8_t*)es.d, stride, bw, bh, dE8, dE4);
+    else
+        hipLaunchKernelGGL((source_energy_kernel<uint16_t>), grid, block, 0, es.st, (const uint16_t*)es.d, stride, bw, bh, dE8, dE4);
+    XH_LAUNCH_CHECK("source_energy_kernel");
+    if (hipMemcpyAsync(es.h + planeBytes, dE8, e8Bytes + e4Bytes, hipMemcpyDeviceToHost, es.st) != hipSuccess || hipStreamSynchronize(es.st) != hipSuccess)
+        return set_error(X265HIP_EHIP, "source_energy: download");
+    memcpy(hostE8, es.h + planeBytes, e8Bytes);
+    memcpy(hostE4, es.h + planeBytes + e8Bytes, e4Bytes);
+    return X265HIP_OK;
 }

@@ -66,9 +66,10 @@ std::atomic<int> g_count(0);
 std::mutex g_createLock;
 int g_state = 0;                 // 0 undecided, 1 on, -1 off
 EncoderPrimitives g_c;           // the slots' previous contents
-std::atomic<uint64_t> g_served[64], g_missed[64], g_foreign[64];
+struct alignas(64) Counter { std::atomic<uint64_t> v; };            // one cache line each: the slots run on every pool worker at once
+Counter g_served[64], g_missed[64], g_foreign[64];
 std::atomic<int> g_nextShard(0);
-thread_local int t_shard = -1;
+__attribute__((tls_model("initial-exec"))) thread_local int t_shard = -1;
 
 inline int shard()
 {
@@ -79,7 +80,7 @@ inline int shard()
 void report()
 {
     uint64_t s = 0, m = 0, f = 0;
-    for (int i = 0; i < 64; i++) { s += g_served[i]; m += g_missed[i]; f += g_foreign[i]; }
+    for (int i = 0; i < 64; i++) { s += g_served[i].v; m += g_missed[i].v; f += g_foreign[i].v; }
     fprintf(stderr, "x265hip: refplanes: %llu luma sub-pel filter calls served from GPU-built planes of %d mirrored pictures, %llu on mirrored pictures before "
                     "their rows arrived and %llu on other memory computed on the host\n", (unsigned long long)s, g_count.load(), (unsigned long long)m,
             (unsigned long long)f);
@@ -163,7 +164,7 @@ inline bool serve(const pixel* src, intptr_t srcStride, pixel* dst, intptr_t dst
     const Mirror* m = find(src);
     if (!m)
     {
-        g_foreign[shard()].fetch_add(1, std::memory_order_relaxed);
+        g_foreign[shard()].v.fetch_add(1, std::memory_order_relaxed);
         return false;
     }
     const ptrdiff_t off = src - m->lo;
@@ -172,13 +173,13 @@ inline bool serve(const pixel* src, intptr_t srcStride, pixel* dst, intptr_t dst
     if (srcStride != m->stride || x < -(m->marginX - 4) || x + W > m->picW + m->marginX - 4 || y < -(m->marginY - 4) ||
         y + H > __atomic_load_n(m->rowsReady, __ATOMIC_ACQUIRE))
     {
-        g_missed[shard()].fetch_add(1, std::memory_order_relaxed);
+        g_missed[shard()].v.fetch_add(1, std::memory_order_relaxed);
         return false;
     }
     const pixel* p = m->plane[phase] + off;
     for (int r = 0; r < H; r++)
         memcpy(dst + r * dstStride, p + r * m->stride, W * sizeof(pixel));
-    g_served[shard()].fetch_add(1, std::memory_order_relaxed);
+    g_served[shard()].v.fetch_add(1, std::memory_order_relaxed);
     return true;
 }
 

@@ -19,7 +19,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
+#include <thread>
 
 #define protected public
 #define private public
@@ -58,21 +61,22 @@ std::atomic<int> g_npics(0);
 std::mutex g_lock;
 int g_state = 0;
 EncoderPrimitives g_c;
-std::atomic<uint64_t> g_hit[64], g_miss[64];
+struct alignas(64) Counter { std::atomic<uint64_t> v; };            // one cache line each: the slots run on every pool worker at once
+Counter g_hit[64], g_miss[64];
 std::atomic<int> g_shardNext(0);
-thread_local int t_shard = -1;
+__attribute__((tls_model("initial-exec"))) thread_local int t_shard = -1;
 inline int shard() { if (t_shard < 0) t_shard = g_shardNext.fetch_add(1) & 63; return t_shard; }
 
 // per thread: which source-cache buffers hold which part of which picture
 struct CacheMap { const pixel* buf[3]; uint32_t size, csize; SrcPic* sp; uint32_t version; int x, y; };
-const int kMaps = 16;
-thread_local CacheMap t_map[kMaps];
-thread_local int t_mapNext = 0;
+const int kMaps = 8;
+__attribute__((tls_model("initial-exec"))) thread_local CacheMap t_map[kMaps];
+__attribute__((tls_model("initial-exec"))) thread_local int t_mapNext = 0;
 
 void report()
 {
     uint64_t h = 0, m = 0;
-    for (int i = 0; i < 64; i++) { h += g_hit[i]; m += g_miss[i]; }
+    for (int i = 0; i < 64; i++) { h += g_hit[i].v; m += g_miss[i].v; }
     fprintf(stderr, "x265hip: srcplanes: source half of %llu psy-cost calls served from GPU-built energy planes of %d source buffers, %llu computed on the host\n",
             (unsigned long long)h, g_npics.load(), (unsigned long long)m);
 }
@@ -124,15 +128,13 @@ SrcPic* find_pic(const PicYuv* pic, bool create)
     return &s;
 }
 
-// the planes of the picture now in the buffer; blocks the first caller for one upload + three small launches, others go on without them
-void build(SrcPic* sp, const PicYuv& pic)
+// the planes of the picture now in the buffer (worker thread: a picture enters the encoder a whole lookahead before its first CTU is analysed)
+void build(SrcPic* sp, uint32_t v)
 {
-    const uint32_t v = sp->version.load();
-    if (sp->built.load(std::memory_order_acquire) == v)
-        return;
-    std::unique_lock<std::mutex> g(sp->lock, std::try_to_lock);
-    if (!g.owns_lock() || sp->built.load() == v)
-        return;
+    const PicYuv& pic = *sp->pic.load();
+    if (sp->version.load() != v)
+        return;                                        // a newer picture is already on its way into the buffer
+    std::lock_guard<std::mutex> g(sp->lock);
     const int planes = pic.m_picCsp == X265_CSP_I400 ? 1 : 3;
     for (int k = 0; k < planes; k++)
     {
@@ -154,8 +156,45 @@ void build(SrcPic* sp, const PicYuv& pic)
             abort();                                   // the product path fails loudly
         }
     }
-    if (sp->version.load() == v)                        // a newer picture may have arrived meanwhile: then these planes are simply never used
+    if (sp->version.load() == v)                        // otherwise these planes are simply never used
         sp->built.store(v, std::memory_order_release);
+}
+
+struct Job { SrcPic* sp; uint32_t version; };
+// the queue lives on the heap and is never destroyed: the worker is detached and may be waiting on it while the process runs its static
+// destructors at exit (destroying a condition variable somebody waits on hangs)
+struct Queue { std::mutex lock; std::condition_variable cv; std::deque<Job> jobs; bool workerUp = false; };
+Queue& queue() { static Queue* q = new Queue; return *q; }
+
+void worker()
+{
+    Queue& q = queue();
+    for (;;)
+    {
+        Job j;
+        {
+            std::unique_lock<std::mutex> g(q.lock);
+            q.cv.wait(g, [&q] { return !q.jobs.empty(); });
+            j = q.jobs.front();
+            q.jobs.pop_front();
+        }
+        build(j.sp, j.version);
+    }
+}
+
+void enqueue(SrcPic* sp, uint32_t version)
+{
+    Queue& q = queue();
+    {
+        std::lock_guard<std::mutex> g(q.lock);
+        if (!q.workerUp)
+        {
+            q.workerUp = true;
+            std::thread(worker).detach();              // lives as long as the process; idle when no pictures arrive
+        }
+        q.jobs.push_back(Job{ sp, version });
+    }
+    q.cv.notify_one();
 }
 
 inline void remember(const Yuv* y, SrcPic* sp, uint32_t version, int px, int py)
@@ -221,10 +260,10 @@ template <int N, int CU> int psy_lookup(const pixel* source, intptr_t sstride, c
     Located L;
     if (!locate<N>(source, sstride, L))
     {
-        g_miss[shard()].fetch_add(1, std::memory_order_relaxed);
+        g_miss[shard()].v.fetch_add(1, std::memory_order_relaxed);
         return g_c.cu[CU].psy_cost_pp(source, sstride, recon, rstride);
     }
-    g_hit[shard()].fetch_add(1, std::memory_order_relaxed);
+    g_hit[shard()].v.fetch_add(1, std::memory_order_relaxed);
     if (N == 4)
     {
         const int src = L.e4[(size_t)L.by8 * (L.bw * 2) + L.bx8];
@@ -261,13 +300,13 @@ void x265hip_install_psy_slots(EncoderPrimitives& p)
 
 void PicYuv::copyFromPicture(const x265_picture& pic, const x265_param& param, int padx, int pady)
 {
-    if (enabled())
-    {
-        SrcPic* sp = find_pic(this, true);
-        if (sp)
-            sp->version.fetch_add(1);                  // before the pixels change: nobody may trust the old planes from here on
-    }
+    SrcPic* sp = enabled() ? find_pic(this, true) : NULL;
+    uint32_t v = 0;
+    if (sp)
+        v = sp->version.fetch_add(1) + 1;              // before the pixels change: nobody may trust the old planes from here on
     refCopyFromPicture(this, pic, param, padx, pady);
+    if (sp)
+        enqueue(sp, v);                                 // the picture is complete (padding included): its planes are built in the background
 }
 
 void Yuv::copyFromPicYuv(const PicYuv& srcPic, uint32_t cuAddr, uint32_t absPartIdx)
@@ -278,7 +317,6 @@ void Yuv::copyFromPicYuv(const PicYuv& srcPic, uint32_t cuAddr, uint32_t absPart
     SrcPic* sp = find_pic(&srcPic, false);             // only buffers that went through copyFromPicture are source pictures
     if (!sp)
         return;
-    build(sp, srcPic);
     const ptrdiff_t off = srcPic.getLumaAddr(cuAddr, absPartIdx) - srcPic.m_picOrg[0];
     remember(this, sp, sp->version.load(), (int)(off % srcPic.m_stride), (int)(off / srcPic.m_stride));
 }
@@ -295,10 +333,8 @@ void Yuv::copyPartToYuv(Yuv& dstYuv, uint32_t absPartIdx) const
             remember(&dstYuv, m.sp, m.version, m.x + g_zscanToPelX[absPartIdx], m.y + g_zscanToPelY[absPartIdx]);
             return;
         }
-    // the source is not a mapped source cache (prediction / reconstruction buffers use this function too): whatever dstYuv held is gone
-    for (int i = 0; i < kMaps; i++)
-        if (t_map[i].buf[0] == dstYuv.m_buf[0])
-            t_map[i].buf[0] = NULL;
+    // not a mapped source cache: prediction / reconstruction buffers use this function too.  A stale entry for dstYuv does no harm — the slot
+    // verifies the bytes before it uses a plane value
 }
 
 } // namespace X265_NS
