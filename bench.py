@@ -611,7 +611,8 @@ def main():
             "config": {"workload": "x265 --preset medium --me hex, 1920x1080 8-bit 4:2:0 synthetic clip (x265_amd/synth.make_clip: 96x96 tiles with their own "
                                    "velocities + noise, seed 4321 + 101 * rank), %d frames per rank per timed run (one step = %d frames); the reference "
                                    "encoder's binary + x265_amd/host/*.cpp + libx265hip.so (oracle/_ref/x265_hip_8bit): lookahead frame-cost estimates "
-                                   "batched on the GPU, C primitive slots, all host cores; N ranks = N encoders on N GPUs, each on its own clip"
+                                   "batched on the GPU, luma sub-pel filter slots served from GPU-built fractional planes of each reference picture, "
+                                   "psy-cost source halves from GPU-built energy planes, C slots otherwise, all host cores; N ranks = N encoders on N GPUs, each on its own clip"
                                    % (enc["frames"], CHUNK),
                        "frames_per_step": world * CHUNK, "encoder_cli_fps_rank0": enc["cli_fps"], "served_by_gpu": enc["served"],
                        "host_cores": os.cpu_count(), "pool_threads_per_encoder": enc["pools"], "timed_s": round(dt, 2)},
@@ -630,6 +631,8 @@ def main():
                                    "sample": "the same %d-frame clip and arguments through oracle/_ref/x265_8bit (unmodified reference, [noasm] C primitives — "
                                              "no nasm in the image, so the AVX2 / AVX-512 path cannot be built), its own fps line; wall %.1f s; pool = all host "
                                              "cores, of which x265 keeps roughly 15 busy at this size" % (enc["frames"], r0["wall_s"]),
+                                   "wall_fps": round(enc["frames"] / r0["wall_s"], 3) if r0["wall_s"] else None,
+                                   "wall_fps_note": "frames / process wall time, the way `value` is measured (start-up and clip reading included)",
                                    "byte_identical_to_gpu_path": r0["byte_identical"], "bitstream_bytes": r0["bitstream_bytes"]}
             if not r0["byte_identical"]:
                 out["error"] = "the GPU-path bitstream differs from the reference encoder's"
