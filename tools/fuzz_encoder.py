@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Random encoder-option sets through the x265-side bindings: for each seed draw a picture size, a chroma format, a preset and a handful of
+options that change what the four seams see, encode the same synthetic clip with the unmodified reference encoder and with
+the bound one, and compare the bitstreams byte for byte.
+
+  python tools/fuzz_encoder.py --seeds 0-39                # CPU tier: oracle/_ref/x265_emul_8bit (the ABI emulated by the oracle, test infra)
+  python tools/fuzz_encoder.py --seeds 0-39 --gpu          # GPU box:  oracle/_ref/x265_hip_8bit  (libx265hip.so)
+
+The draw is a pure function of the seed, so a failing seed is a reproducible test case (tests/test_encoder_fuzz.py pins a list of them)."""
+import argparse
+import json
+import os
+import random
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+SIZES = [(176, 144), (320, 180), (352, 288), (416, 240), (200, 136), (330, 250), (640, 360), (256, 64), (72, 200)]
+PRESETS = ["ultrafast", "superfast", "veryfast", "faster", "fast", "medium", "medium", "medium", "slow", "slower", "veryslow"]
+# (option words, weight) — every entry is independent of the others unless `conflicts` says otherwise
+OPTIONS = [
+    (["--me", "dia"], 2), (["--me", "hex"], 3), (["--me", "umh"], 2), (["--me", "star"], 2), (["--me", "sea"], 1), (["--me", "full", "--merange", "12"], 1),
+    (["--subme", "0"], 1), (["--subme", "1"], 1), (["--subme", "3"], 2), (["--subme", "5"], 1), (["--subme", "7"], 1),
+    (["--merange", "16"], 1), (["--merange", "92"], 1),
+    (["--ref", "1"], 1), (["--ref", "4"], 2), (["--ref", "6", "--limit-refs", "0"], 1),
+    (["--bframes", "0"], 1), (["--bframes", "2"], 1), (["--bframes", "8"], 1), (["--b-adapt", "0"], 1), (["--b-adapt", "1"], 1), (["--no-b-pyramid"], 1),
+    (["--weightb"], 2), (["--no-weightp"], 1),
+    (["--rc-lookahead", "8"], 1), (["--rc-lookahead", "40"], 1), (["--lookahead-slices", "0"], 1), (["--lookahead-slices", "3"], 1),
+    (["--no-cutree"], 1), (["--aq-mode", "0"], 1), (["--aq-mode", "1"], 1), (["--aq-mode", "3"], 1), (["--aq-mode", "4"], 1), (["--qg-size", "16"], 1),
+    (["--hevc-aq"], 1), (["--aq-strength", "2.0"], 1),
+    (["--psy-rd", "0"], 2), (["--psy-rd", "4.0"], 1), (["--psy-rdoq", "5.0"], 1), (["--rdoq-level", "0"], 1), (["--rdoq-level", "2"], 1),
+    (["--rd", "2"], 1), (["--rd", "4"], 1), (["--rd", "5"], 1), (["--rd", "6"], 1),
+    (["--rect"], 1), (["--rect", "--amp"], 1), (["--tskip"], 1), (["--cu-lossless"], 1), (["--no-early-skip"], 1), (["--rskip", "2"], 1), (["--rskip", "0"], 1),
+    (["--ctu", "32"], 2), (["--ctu", "16"], 1), (["--ctu", "32", "--min-cu-size", "16"], 1), (["--max-tu-size", "16"], 1), (["--tu-intra-depth", "3", "--tu-inter-depth", "3"], 1),
+    (["--no-sao"], 1), (["--no-deblock"], 1), (["--deblock", "-2:2"], 1), (["--sao-non-deblock"], 1), (["--limit-sao"], 1), (["--selective-sao", "2"], 1),
+    (["--slices", "2"], 1), (["--no-wpp"], 1), (["--pmode"], 1), (["--pme"], 1),
+    (["--keyint", "5", "--min-keyint", "5"], 1), (["--open-gop"], 1), (["--no-open-gop"], 1), (["--no-scenecut"], 1), (["--intra-refresh"], 1), (["--radl", "2"], 1),
+    (["--crf", "18"], 1), (["--crf", "36"], 1), (["--qp", "22"], 1), (["--qp", "40"], 1), (["--bitrate", "300"], 1),
+    (["--bitrate", "400", "--vbv-bufsize", "500", "--vbv-maxrate", "500"], 1), (["--lossless"], 1), (["--strict-cbr", "--bitrate", "300", "--vbv-bufsize", "300", "--vbv-maxrate", "300"], 1),
+    (["--tune", "grain"], 1), (["--tune", "psnr"], 1), (["--tune", "ssim"], 1), (["--tune", "zerolatency"], 1), (["--tune", "fastdecode"], 1), (["--tune", "animation"], 1),
+    (["--nr-intra", "100", "--nr-inter", "200"], 1), (["--constrained-intra"], 1), (["--signhide"], 1), (["--no-signhide"], 1), (["--max-merge", "5"], 1),
+    (["--temporal-layers", "2"], 1), (["--hme", "--hme-search", "hex,umh,umh"], 1), (["--aq-motion"], 1), (["--scenecut-aware-qp", "1", "--bitrate", "500"], 0),
+    (["--hist-scenecut"], 1), (["--fades"], 1), (["--cbqpoffs", "3", "--crqpoffs", "-3"], 1), (["--scaling-list", "default"], 1), (["--ssim-rd"], 1),
+    (["--interlace", "tff"], 1), (["--frame-dup"], 0), (["--dynamic-rd", "2", "--bitrate", "300", "--vbv-bufsize", "400", "--vbv-maxrate", "400"], 1),
+    (["--limit-modes"], 1), (["--limit-tu", "2"], 1), (["--early-skip"], 1), (["--fast-intra"], 1), (["--b-intra"], 1), (["--analyze-src-pics"], 1),
+    (["--opt-qp-pps", "--opt-ref-list-length-pps"], 1), (["--opt-cu-delta-qp"], 1), (["--multi-pass-opt-distortion"], 0), (["--cll"], 0), (["--hrd", "--bitrate", "400", "--vbv-bufsize", "500", "--vbv-maxrate", "500"], 1),
+]
+
+
+def _key(words):
+    return words[0]
+
+
+def draw(seed):
+    """The test case of `seed`: dict(width, height, frames, csp, fade, args)."""
+    rng = random.Random(0x265 * 1000003 + seed)
+    w, h = rng.choice(SIZES)
+    csp = rng.choices(["i420", "i420", "i420", "i444", "i422", "i400"], k=1)[0]
+    frames = rng.choice([6, 8, 10, 12, 16])
+    preset = rng.choice(PRESETS)
+    n = rng.choice([0, 1, 2, 2, 3, 3, 4, 5])
+    picked, keys = [], set()
+    pool = [o for o, wgt in OPTIONS for _ in range(wgt)]
+    guard = 0
+    while len(picked) < n and guard < 100:
+        guard += 1
+        o = rng.choice(pool)
+        ks = {x for x in o if x.startswith("--")}
+        ks = {"--rc" if k in ("--crf", "--qp", "--bitrate", "--lossless", "--strict-cbr", "--vbv-bufsize") else k for k in ks}
+        if ks & keys:
+            continue
+        keys |= ks
+        picked.append(o)
+    args = ["--preset", preset]
+    for o in picked:
+        args += o
+    args += ["-F", str(rng.choice([1, 2, 3, 4])), "--pools", str(rng.choice([2, 4, 6]))]
+    return {"width": w, "height": h, "frames": frames, "csp": csp, "fade": rng.random() < 0.25, "args": args, "seed": seed}
+
+
+def run_case(case, bound_exe, ref_exe, workdir, timeout=900):
+    from x265_amd.synth import make_clip
+    yuv = os.path.join(workdir, "fuzz_%d.yuv" % case["seed"])
+    make_clip(yuv, case["width"], case["height"], case["frames"], seed=1000 + case["seed"], tile=48, vmax=7, fade=case["fade"], csp=case["csp"])
+    base = ["--input", yuv, "--input-res", "%dx%d" % (case["width"], case["height"]), "--input-depth", "8", "--input-csp", case["csp"], "--fps", "30",
+            "--frames", str(case["frames"]), "--hash", "1"] + case["args"]
+    res = {"seed": case["seed"], "cmd": " ".join(base[2:])}
+    outs = {}
+    try:
+        for tag, exe in (("ref", ref_exe), ("bound", bound_exe)):
+            o = os.path.join(workdir, "fuzz_%d_%s.hevc" % (case["seed"], tag))
+            t0 = time.time()
+            r = subprocess.run([exe] + base + ["-o", o], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, X265HIP_VERBOSE="1"))
+            res[tag + "_s"] = round(time.time() - t0, 2)
+            res[tag + "_rc"] = r.returncode
+            outs[tag] = open(o, "rb").read() if os.path.exists(o) else b""
+            if tag == "bound":
+                res["served"] = [l for l in r.stderr.splitlines() if l.startswith("x265hip:")]
+            if r.returncode:
+                res[tag + "_tail"] = r.stderr[-300:]
+            if os.path.exists(o):
+                os.remove(o)
+    finally:
+        if os.path.exists(yuv):
+            os.remove(yuv)
+    res["bytes"] = len(outs.get("ref", b""))
+    # an option set the reference itself rejects is not a test case; it must be rejected by both alike
+    res["ok"] = res.get("ref_rc") == res.get("bound_rc") and outs.get("ref") == outs.get("bound")
+    res["encoded"] = res.get("ref_rc") == 0 and res["bytes"] > 0
+    return res
+
+
+def parse_seeds(s):
+    out = []
+    for part in s.split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            out += list(range(int(a), int(b) + 1))
+        else:
+            out.append(int(part))
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", default="0-19")
+    ap.add_argument("--gpu", action="store_true", help="x265_hip_8bit (needs an MI355X) instead of the emulated ABI")
+    ap.add_argument("--json", default=None)
+    a = ap.parse_args()
+    bound = os.path.join(REF, "x265_hip_8bit" if a.gpu else "x265_emul_8bit")
+    ref = os.path.join(REF, "x265_8bit")
+    results = []
+    with tempfile.TemporaryDirectory() as d:
+        for seed in parse_seeds(a.seeds):
+            r = run_case(draw(seed), bound, ref, d)
+            results.append(r)
+            print("%s seed %3d  %6d B  ref %5.1fs bound %5.1fs  %s" % ("ok  " if r["ok"] else "FAIL", seed, r["bytes"], r.get("ref_s", 0), r.get("bound_s", 0), r["cmd"][60:]),
+                  flush=True)
+    bad = [r for r in results if not r["ok"]]
+    print("%d cases, %d encoded, %d mismatches%s" % (len(results), sum(r["encoded"] for r in results), len(bad), (": seeds " + ",".join(str(r["seed"]) for r in bad)) if bad else ""))
+    if a.json:
+        json.dump(results, open(a.json, "w"), indent=1)
+    sys.exit(1 if bad else 0)

@@ -38,6 +38,16 @@ __device__ __forceinline__ T ld_unaligned(const P* p)
     __builtin_memcpy(&v, p, sizeof(T));
     return v;
 }
+// the same through a pointer the compiler cannot prove to be global memory (one read out of a descriptor in memory): the address-space cast
+// turns flat_load (aperture check, both wait counters) into global_load
+#define XH_GLOBAL_AS __attribute__((address_space(1)))
+template <typename T, typename P>
+__device__ __forceinline__ T ld_global_unaligned(const P* p)
+{
+    T v;
+    __builtin_memcpy(&v, (const XH_GLOBAL_AS char*)p, sizeof(T));
+    return v;
+}
 template <typename T, typename P>
 __device__ __forceinline__ void st_unaligned(P* p, T v)
 {

@@ -54,6 +54,7 @@ struct LaCtx
     const uint16_t* cost;     // centred MVD cost row
     int px, py;               // mvp (scalar, quarter-pel)
     int slot;                 // candidate slot of this lane (0..3)
+    int sel[4];               // sel[j] = slot == j ? ~0 : 0
     bool hi1, hi2;
     Q fq;
     int fu[4];
@@ -67,7 +68,7 @@ struct LaCtx
         // 24-bit full-rate multiplies (lowres planes are far below 2^24 elements, strides below 2^23: checked at the entry point)
         const P* a = ref0 + (__umul24(ia, (int)planeElems) + __mul24(qy >> 2, stride) + (qx >> 2));
         const P* b = ref0 + (__umul24(ib, (int)planeElems) + __mul24(ry >> 2, stride) + (rx >> 2));
-        return LaPk<P>::avg(ld_unaligned<Q>(a), ld_unaligned<Q>(b));
+        return LaPk<P>::avg(ld_global_unaligned<Q>(a), ld_global_unaligned<Q>(b));
     }
     __device__ __forceinline__ int sad(int qx, int qy) const { return row_allsum((int)LaPk<P>::sad(fetch(qx, qy), fq)); }
     __device__ __forceinline__ int satd(int qx, int qy) const { return satd_of(fetch(qx, qy)); }
@@ -104,8 +105,9 @@ struct LaCtx
 #pragma unroll
         for (int k = 0; k < K; k++)
         {
-            const int qx = slot == 0 ? cx[4 * k] : (slot == 1 ? cx[4 * k + 1] : (slot == 2 ? cx[4 * k + 2] : cx[4 * k + 3]));
-            const int qy = slot == 0 ? cy[4 * k] : (slot == 1 ? cy[4 * k + 1] : (slot == 2 ? cy[4 * k + 2] : cy[4 * k + 3]));
+            // this lane's candidate out of four wave-uniform values: mask-and-or (branch-free; the ?: chain compiled to exec-mask branches)
+            const int qx = (cx[4 * k] & sel[0]) | (cx[4 * k + 1] & sel[1]) | (cx[4 * k + 2] & sel[2]) | (cx[4 * k + 3] & sel[3]);
+            const int qy = (cy[4 * k] & sel[0]) | (cy[4 * k + 1] & sel[1]) | (cy[4 * k + 2] & sel[2]) | (cy[4 * k + 3] & sel[3]);
             vd[k] = useSatd ? satd(qx, qy) : sad(qx, qy);
             vm[k] = mvcost(qx, qy);
         }
@@ -121,7 +123,7 @@ struct LaCtx
 };
 
 __device__ __forceinline__ int la_clip(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-__device__ __forceinline__ uint64_t la_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t la_load(const uint64_t* p) { return __hip_atomic_load((const XH_GLOBAL_AS uint64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void la_unpack(uint64_t w, int& x, int& y)
 {
     x = sfl((int)(int16_t)(uint16_t)(w & 0xffff));
@@ -155,6 +157,9 @@ __global__ __launch_bounds__(64) void lookahead_p_kernel(const LaPair* __restric
     const int qrow = (t >> 1) * 4 + r, qcol = (t & 1) * 4;       // tile-major: the 4 rows of a 4x4 tile in one DPP quad
     C c;
     c.slot = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        c.sel[j] = c.slot == j ? -1 : 0;
     c.hi1 = s & 1;
     c.hi2 = s & 2;
     c.stride = (int)stride;
@@ -174,16 +179,21 @@ __global__ __launch_bounds__(64) void lookahead_p_kernel(const LaPair* __restric
     for (int cuX = W - 1; cuX >= 0; cuX--)
     {
         const int cuXY = cuY * W + cuX;
-        c.fq = ld_unaligned<Q>(fencRow + cuX * N);
+        c.fq = ld_global_unaligned<Q>(fencRow + cuX * N);
         LaPk<P>::unpack(c.fq, c.fu);
         c.ref0 = refRow + cuX * N;
         const int mvminX = -cuX * N - 8, mvmaxX = (W - cuX - 1) * N + 8;
         const int qminX = mvminX * 4, qmaxX = mvmaxX * 4, qminY = mvminY * 4, qmaxY = mvmaxY * 4;
 
         // ---- reverse-order MV prediction (slicetype.cpp:3271-3307): SATD of each neighbour vector, cheapest wins ----
+        // candidate order: right neighbour (cuX < W - 1), then below, below-left (cuX > 0), below-right (cuX < W - 1) when there is a row below.
+        // Built with wave-uniform selects only: a dynamically indexed array would live in scratch memory, one more round trip per block.
         int mx[4] = { 0, 0, 0, 0 }, my[4] = { 0, 0, 0, 0 };
         int numc = 0;
-        if (cuX < W - 1) { mx[0] = prevX; my[0] = prevY; numc = 1; }
+        const bool hasRight = cuX < W - 1, hasLeft = cuX > 0;
+        // the bookkeeping inputs of this block, requested now and used after the search (off the dependent chain)
+        const int icLoad = bidirList ? 0 : ld_global_unaligned<int>(pr.intraCost + cuXY);
+        const int iqLoad = (!bidirList && pr.invQscale) ? ld_global_unaligned<int>(pr.invQscale + cuXY) : 256;
         if (!lastRow)
         {
             // The row below moves right to left, so its below-left block (cuX - 1) is published last.  Every word carries the epoch next to
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(64) void lookahead_p_kernel(const LaPair* __restric
             // no ordering between different words is assumed.  Bounded: the row below is always dispatched earlier, so this normally takes
             // microseconds; if a word never arrives (a `sync` scratch that was not zeroed) give up after ~2 s instead of hanging the device
             // and report it through est[4 i + 3].
-            const int lo = cuX > 0 ? cuX - 1 : cuX, hi = cuX < W - 1 ? cuX + 1 : cuX;
+            const int lo = hasLeft ? cuX - 1 : cuX, hi = hasRight ? cuX + 1 : cuX;
             uint64_t w0 = 0, w1 = 0, w2 = 0;
             int spins = 0;
             for (;;)
@@ -205,10 +215,29 @@ __global__ __launch_bounds__(64) void lookahead_p_kernel(const LaPair* __restric
                 __builtin_amdgcn_s_sleep(8);
                 if (++spins > (1 << 22)) stuck = true;            // sticky: the rest of the row no longer waits
             }
-            la_unpack(w0, mx[numc], my[numc]);
-            numc++;
-            if (cuX > 0) { la_unpack(w1, mx[numc], my[numc]); numc++; }
-            if (cuX < W - 1) { la_unpack(w2, mx[numc], my[numc]); numc++; }
+            int bx, by, lx, ly, rx, ry;
+            la_unpack(w0, bx, by);
+            la_unpack(w1, lx, ly);
+            la_unpack(w2, rx, ry);
+            if (hasRight)
+            {
+                mx[0] = prevX; my[0] = prevY;
+                mx[1] = bx; my[1] = by;
+                mx[2] = hasLeft ? lx : rx; my[2] = hasLeft ? ly : ry;
+                mx[3] = rx; my[3] = ry;                               // only counted when hasLeft
+                numc = hasLeft ? 4 : 3;
+            }
+            else
+            {
+                mx[0] = bx; my[0] = by;
+                mx[1] = lx; my[1] = ly;                               // only counted when hasLeft
+                numc = hasLeft ? 2 : 1;
+            }
+        }
+        else if (hasRight)
+        {
+            mx[0] = prevX; my[0] = prevY;
+            numc = 1;
         }
         int mvpX = 0, mvpY = 0, skipCost = 0x7fffffff;
         c.px = 0; c.py = 0;
@@ -405,14 +434,14 @@ __global__ __launch_bounds__(64) void lookahead_p_kernel(const LaPair* __restric
             continue;
         }
         int cuCost = fencCost + 4, listused = 1;
-        const int ic = sfl(pr.intraCost[cuXY]);
+        const int ic = sfl(icLoad);
         if (ic < cuCost) { cuCost = ic; listused = 0; }
         const bool scored = (cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2;
         int cuCostAq = cuCost;
         if (scored)
         {
             if (pr.invQscale)
-                cuCostAq = (cuCost * sfl(pr.invQscale[cuXY]) + 128) >> 8;
+                cuCostAq = (cuCost * sfl(iqLoad) + 128) >> 8;
             scoreSum += cuCost;
             scoreAq += cuCostAq;
             intraCnt += !listused;

@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <vector>
 
@@ -58,6 +59,7 @@ struct Session
     std::vector<SlotEntry> slots;
     uint64_t stamp = 0;
     uint64_t uploads = 0;
+    uint64_t waitNs = 0;          // wall time the lookahead thread spent inside compute() (descriptor build + device pass + write-back)
 };
 
 std::mutex g_lock;
@@ -71,8 +73,9 @@ void report()
         return;
     uint64_t batches = 0, estimates = 0, searches = 0;
     x265hip_la_stats(g_session.la, &batches, &estimates, &searches);
-    fprintf(stderr, "x265hip: lookahead: %llu frame-cost estimates (%llu motion-search passes over %llu lowres frames) served by the GPU in %llu batches\n",
-            (unsigned long long)estimates, (unsigned long long)searches, (unsigned long long)g_session.uploads, (unsigned long long)batches);
+    fprintf(stderr, "x265hip: lookahead: %llu frame-cost estimates (%llu motion-search passes over %llu lowres frames) served by the GPU in %llu batches, %.3f s inside the seam\n",
+            (unsigned long long)estimates, (unsigned long long)searches, (unsigned long long)g_session.uploads, (unsigned long long)batches,
+            g_session.waitNs * 1e-9);
 }
 
 bool enabled()
@@ -182,6 +185,7 @@ void compute(CostEstimateGroup& g, const Job* jobs, int n, bool coop)
     const Lookahead& l = g.m_lookahead;
     const x265_param* param = l.m_param;
     std::lock_guard<std::mutex> guard(g_lock);
+    const auto t0 = std::chrono::steady_clock::now();
     Session& s = session_for(l, g.m_frames[jobs[0].b]);
     s.stamp++;
     std::vector<x265hip_la_estimate> est(n);
@@ -249,6 +253,7 @@ void compute(CostEstimateGroup& g, const Job* jobs, int n, bool coop)
         fenc->costEst[e.dist0][e.dist1] = score;
         fenc->costEstAq[e.dist0][e.dist1] = e.costEstAq;
     }
+    s.waitNs += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
 }
 
 inline bool cached(const Lowres* fenc, int p0, int p1, int b)

@@ -29,11 +29,13 @@ def make_scene(width, height, depth=8, seed=4321, tile=96, vmax=9, sigma=3.0):
     return {"src": np.clip(np.rint(src), 0, pmax).astype(dt), "ref": np.clip(np.rint(ref), 0, pmax).astype(dt)}
 
 
-def make_clip(path, width, height, frames, seed=4321, tile=96, vmax=9, sigma=3.0, fade=False):
+def make_clip(path, width, height, frames, seed=4321, tile=96, vmax=9, sigma=3.0, fade=False, csp="i420"):
     """Write an 8-bit I420 clip: a textured background whose tiles keep moving with their own constant velocity
     (half rate) + per-frame noise; chroma = 128 + 0.3 * (luma - 128) subsampled.  fade: the picture fades in from
-    40 % to full brightness over the clip (weighted prediction has something to find)."""
+    40 % to full brightness over the clip (weighted prediction has something to find).  csp: "i420" (default), "i422", "i444" or "i400"
+    (x265 --input-csp): how the two chroma planes are subsampled / whether they exist."""
     rng = np.random.default_rng(seed)
+    sy, sx = {"i420": (2, 2), "i422": (1, 2), "i444": (1, 1), "i400": (0, 0)}[csp]
     pad = vmax * frames // 2 + 16
     big = make_scene(width + 2 * pad, height + 2 * pad, 8, seed, tile, 0, 0.0)["ref"].astype(np.float64)
     ty, tx = (height + tile - 1) // tile, (width + tile - 1) // tile
@@ -51,9 +53,10 @@ def make_clip(path, width, height, frames, seed=4321, tile=96, vmax=9, sigma=3.0
                 luma = luma * (0.4 + 0.6 * t / max(frames - 1, 1))
             luma = np.clip(np.rint(luma + rng.normal(0, sigma, luma.shape)), 0, 255)
             f.write(luma.astype(np.uint8).tobytes())
-            c = np.clip(np.rint(128 + 0.3 * (luma[::2, ::2] - 128)), 0, 255).astype(np.uint8)
-            f.write(c.tobytes())
-            f.write(c.tobytes())
+            if sy:
+                c = np.clip(np.rint(128 + 0.3 * (luma[::sy, ::sx] - 128)), 0, 255).astype(np.uint8)
+                f.write(c.tobytes())
+                f.write(np.ascontiguousarray(255 - c if csp != "i420" else c).tobytes())
 
 
 def chroma_of(luma, depth, gain):
