@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <unistd.h>
 
 #define protected public
 #define private public
@@ -65,6 +66,7 @@ Mirror g_mirror[kMaxMirrors];
 std::atomic<int> g_count(0);
 std::mutex g_createLock;
 int g_state = 0;                 // 0 undecided, 1 on, -1 off
+bool g_verify = false;           // X265HIP_VERIFY=1: served blocks are recomputed with the C filter and compared (debugging self-check)
 EncoderPrimitives g_c;           // the slots' previous contents
 struct alignas(64) Counter { std::atomic<uint64_t> v; };            // one cache line each: the slots run on every pool worker at once
 Counter g_served[64], g_missed[64], g_foreign[64];
@@ -101,6 +103,7 @@ bool enabled()
             else
             {
                 g_state = 1;
+                g_verify = getenv("X265HIP_VERIFY") != NULL;
                 if (getenv("X265HIP_VERBOSE"))
                     atexit(report);
             }
@@ -183,17 +186,35 @@ inline bool serve(const pixel* src, intptr_t srcStride, pixel* dst, intptr_t dst
     return true;
 }
 
+// X265HIP_VERIFY=1: every served block is recomputed with the C filter and compared (self-check for debugging; off by default)
+template <int W, int H>
+void verify(const char* what, const pixel* s, pixel* d, intptr_t ds, const pixel* want, int cx, int cy)
+{
+    for (int r = 0; r < H; r++)
+        if (memcmp(d + r * ds, want + r * W, W * sizeof(pixel)))
+        {
+            const Mirror* m = find(s);
+            const ptrdiff_t off = s - m->lo;
+            const int by = (int)(off / m->stride), bx = (int)(off - (ptrdiff_t)by * m->stride);
+            fprintf(stderr, "x265hip: refplanes: VERIFY FAILED %s %dx%d phase (%d, %d) at x %d y %d row %d of poc %d (rowsReady %d, picH %d)\n", what, W, H, cx, cy,
+                    bx - m->marginX, by - m->marginY, r, m->poc, *m->rowsReady, m->picH);
+            abort();
+        }
+}
 template <int W, int H, int PART> void hpp_lookup(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int c)
 {
-    if (!c || !serve<W, H>(s, ss, d, ds, c)) g_c.pu[PART].luma_hpp(s, ss, d, ds, c);
+    if (!c || !serve<W, H>(s, ss, d, ds, c)) { g_c.pu[PART].luma_hpp(s, ss, d, ds, c); return; }
+    if (g_verify) { pixel t[W * H]; g_c.pu[PART].luma_hpp(s, ss, t, W, c); verify<W, H>("hpp", s, d, ds, t, c, 0); }
 }
 template <int W, int H, int PART> void vpp_lookup(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int c)
 {
-    if (!c || !serve<W, H>(s, ss, d, ds, 4 * c)) g_c.pu[PART].luma_vpp(s, ss, d, ds, c);
+    if (!c || !serve<W, H>(s, ss, d, ds, 4 * c)) { g_c.pu[PART].luma_vpp(s, ss, d, ds, c); return; }
+    if (g_verify) { pixel t[W * H]; g_c.pu[PART].luma_vpp(s, ss, t, W, c); verify<W, H>("vpp", s, d, ds, t, 0, c); }
 }
 template <int W, int H, int PART> void hvpp_lookup(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int cx, int cy)
 {
-    if (!cx || !cy || !serve<W, H>(s, ss, d, ds, 4 * cy + cx)) g_c.pu[PART].luma_hvpp(s, ss, d, ds, cx, cy);
+    if (!cx || !cy || !serve<W, H>(s, ss, d, ds, 4 * cy + cx)) { g_c.pu[PART].luma_hvpp(s, ss, d, ds, cx, cy); return; }
+    if (g_verify) { pixel t[W * H]; g_c.pu[PART].luma_hvpp(s, ss, t, W, cx, cy); verify<W, H>("hvpp", s, d, ds, t, cx, cy); }
 }
 
 } // namespace
@@ -220,6 +241,10 @@ void x265hip_install_lookup_slots(EncoderPrimitives& p)
 void FrameFilter::processPostRow(int row)
 {
     Mirror* m = NULL;
+    // X265HIP_DEBUG_DELAY_US=n: sleep n microseconds here, seams on or off.  A diagnostic: the reference encoder's own output depends on thread
+    // timing in a few corner configurations (tools/fuzz_encoder.py uses this to tell those from real mismatches)
+    static const int delayUs = getenv("X265HIP_DEBUG_DELAY_US") ? atoi(getenv("X265HIP_DEBUG_DELAY_US")) : 0;
+    if (delayUs > 0) usleep(delayUs);
     if (enabled() && m_frame && m_frame->m_reconPic && m_numRows <= 256)
     {
         // before the reference's body announces the row (m_reconRowFlag, framefilter.cpp:664): a buffer that starts a new picture must not
