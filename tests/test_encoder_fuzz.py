@@ -26,9 +26,9 @@ def _need(name):
     return p
 
 
-def _check(seed, bound, tmp_path):
+def _check(seed, bound, tmp_path, bits=8):
     import fuzz_encoder as fz
-    r = fz.run_case(fz.draw(seed), bound, _need("x265_8bit"), str(tmp_path))
+    r = fz.run_case(fz.draw(seed), bound, _need("x265_%dbit" % bits), str(tmp_path))
     assert r["encoded"], "seed %d is pinned as a case the reference encodes: %s" % (seed, r)
     assert r["ok"] and "reference_timing_dependent" not in r, "seed %d: bitstreams differ\n%s" % (seed, r["cmd"])
     return r
@@ -37,6 +37,20 @@ def _check(seed, bound, tmp_path):
 @pytest.mark.parametrize("seed", CPU_SEEDS)
 def test_random_option_set_is_byte_identical_with_emulated_abi(tmp_path, seed):
     _check(seed, _need("x265_emul_8bit"), tmp_path)
+
+
+MAIN10_SEEDS = [202, 203, 205, 206, 207, 209, 210, 213, 214, 217]
+
+
+@pytest.mark.parametrize("seed", MAIN10_SEEDS)
+def test_random_option_set_main10_with_emulated_abi(tmp_path, seed):
+    _check(seed, _need("x265_emul_10bit"), tmp_path, bits=10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", MAIN10_SEEDS[:6])
+def test_random_option_set_main10_on_gpu(tmp_path, seed):
+    _check(seed, _need("x265_hip_10bit"), tmp_path, bits=10)
 
 
 def test_draw_is_a_pure_function_of_the_seed():

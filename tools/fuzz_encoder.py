@@ -153,9 +153,10 @@ if __name__ == "__main__":
     ap.add_argument("--seeds", default="0-19")
     ap.add_argument("--gpu", action="store_true", help="x265_hip_8bit (needs an MI355X) instead of the emulated ABI")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--bits", type=int, default=8, help="internal bit depth of the encoder build (8 or 10; the clip stays 8-bit input)")
     a = ap.parse_args()
-    bound = os.path.join(REF, "x265_hip_8bit" if a.gpu else "x265_emul_8bit")
-    ref = os.path.join(REF, "x265_8bit")
+    bound = os.path.join(REF, ("x265_hip_%dbit" if a.gpu else "x265_emul_%dbit") % a.bits)
+    ref = os.path.join(REF, "x265_%dbit" % a.bits)
     results = []
     with tempfile.TemporaryDirectory() as d:
         for seed in parse_seeds(a.seeds):
