@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """bench.py — the contract bench (BASELINE.json metric: encode fps, 1080p preset medium, --me hex).
 
-`value` is REAL encode fps: the reference encoder's own binary with the two added translation units (x265_amd/host/*.cpp) and
+`value` is REAL encode fps: the reference encoder's own binary with the four added translation units (x265_amd/host/*.cpp) and
 libx265hip.so behind them — oracle/_ref/x265_hip_8bit — encoding a synthetic 1920x1080 clip with `--preset medium --me hex`; the GPU serves
-the lookahead's batched frame-cost estimates, everything else is the reference's host code.  One "step" = one chunk of
+the lookahead's batched frame-cost estimates, the luma sub-pel filter calls on reference pictures (fractional planes built per picture) and the
+source half of the psy costs (energy planes built per source picture); everything else is the reference's host code.  One "step" = one chunk of
 CHUNK = 12 frames of the clip; K steps are encoded in one run of the encoder, bracketed by barrier + synchronize, wall clock of this process
 (the encoder's own "encoded N frames in Xs" figure is reported beside it as `cli_fps`).  At N = 1 the same clip is also encoded by the
 unmodified reference encoder (oracle/_ref/x265_8bit, `cpu_baseline`, kind "reference") and the two bitstreams must be byte-identical.
