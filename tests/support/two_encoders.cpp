@@ -1,0 +1,95 @@
+// two_encoders.cpp — the x265 API driven the way a long-lived process drives it: several encoders opened and closed one after another, with
+// different picture sizes, in ONE process.  Test infrastructure for the lifetime rules of the x265-side bindings (x265_amd/host/*.cpp): a closed
+// encoder's picture buffers are freed, malloc hands the same addresses to the next encoder's buffers, and neither a reference-picture mirror
+// nor a source-picture entry of the first may answer for them (PicYuv::destroy seam).
+// Linked three ways by oracle/Makefile (reference objects only / + bindings + emulated ABI / + bindings + libx265hip.so); the outputs must agree.
+//
+//   two_encoders <out-prefix>     writes <out-prefix>_<k>.hevc for each session k
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "x265.h"
+
+struct Session { int w, h, frames, seed; const char* preset; int bframes; };
+
+// a textured scene that moves: deterministic, no files
+static void make_frame(std::vector<uint8_t>& buf, int w, int h, int t, uint32_t seed)
+{
+    buf.resize((size_t)w * h * 3 / 2);
+    uint32_t s = seed * 2654435761u + (uint32_t)t * 40503u;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            const int sx = x + 3 * t, sy = y + t;
+            int v = 96 + ((sx * 7 + sy * 13) & 63) + (((sx >> 4) ^ (sy >> 4)) & 1) * 48 + ((sx / 24 + sy / 40) % 3) * 9;
+            s = s * 1664525u + 1013904223u;
+            v += (int)((s >> 28) & 7) - 3;
+            buf[(size_t)y * w + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+    uint8_t* cb = buf.data() + (size_t)w * h;
+    uint8_t* cr = cb + (size_t)(w / 2) * (h / 2);
+    for (int y = 0; y < h / 2; y++)
+        for (int x = 0; x < w / 2; x++)
+        {
+            cb[(size_t)y * (w / 2) + x] = (uint8_t)(128 + (((x + t) >> 3) & 7) * 3);
+            cr[(size_t)y * (w / 2) + x] = (uint8_t)(120 + (((y + 2 * t) >> 3) & 7) * 4);
+        }
+}
+
+static bool run(const Session& ss, const char* path)
+{
+    x265_param* p = x265_param_alloc();
+    if (x265_param_default_preset(p, ss.preset, NULL) < 0) return false;
+    p->sourceWidth = ss.w; p->sourceHeight = ss.h; p->fpsNum = 30; p->fpsDenom = 1; p->internalCsp = X265_CSP_I420;
+    p->totalFrames = ss.frames; p->bframes = ss.bframes; p->frameNumThreads = 2; p->decodedPictureHashSEI = 1;
+    p->logLevel = X265_LOG_ERROR; p->bRepeatHeaders = 1;
+    x265_param_parse(p, "pools", "4");
+    x265_encoder* enc = x265_encoder_open(p);
+    if (!enc) { fprintf(stderr, "two_encoders: open failed\n"); return false; }
+    FILE* f = fopen(path, "wb");
+    if (!f) return false;
+    x265_picture* pic = x265_picture_alloc();
+    x265_picture_init(p, pic);
+    std::vector<uint8_t> buf;
+    x265_nal* nal; uint32_t nnal;
+    for (int t = 0; t < ss.frames; t++)
+    {
+        make_frame(buf, ss.w, ss.h, t, (uint32_t)ss.seed);
+        pic->planes[0] = buf.data(); pic->planes[1] = buf.data() + (size_t)ss.w * ss.h; pic->planes[2] = (uint8_t*)pic->planes[1] + (size_t)(ss.w / 2) * (ss.h / 2);
+        pic->stride[0] = ss.w; pic->stride[1] = pic->stride[2] = ss.w / 2;
+        pic->bitDepth = 8; pic->colorSpace = X265_CSP_I420; pic->pts = t;
+        if (x265_encoder_encode(enc, &nal, &nnal, pic, NULL) < 0) return false;
+        for (uint32_t i = 0; i < nnal; i++) fwrite(nal[i].payload, 1, nal[i].sizeBytes, f);
+    }
+    while (x265_encoder_encode(enc, &nal, &nnal, NULL, NULL) > 0)
+        for (uint32_t i = 0; i < nnal; i++) fwrite(nal[i].payload, 1, nal[i].sizeBytes, f);
+    fclose(f);
+    x265_picture_free(pic);
+    x265_encoder_close(enc);
+    x265_param_free(p);
+    return true;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: two_encoders <out-prefix>\n"); return 2; }
+    // sizes chosen so that freed buffers of one session are likely to be handed out again in the next, whole or in part
+    const Session sessions[] = {
+        { 352, 288, 10, 11, "medium", 3 },
+        { 640, 360, 8, 22, "fast", 2 },
+        { 352, 288, 10, 33, "medium", 3 },     // the first geometry again: same allocation sizes, other pictures
+        { 176, 144, 12, 44, "slow", 4 },
+        { 640, 368, 8, 55, "medium", 0 },
+    };
+    for (size_t k = 0; k < sizeof(sessions) / sizeof(sessions[0]); k++)
+    {
+        char path[512];
+        snprintf(path, sizeof(path), "%s_%d.hevc", argv[1], (int)k);
+        if (!run(sessions[k], path)) { fprintf(stderr, "two_encoders: session %d failed\n", (int)k); return 1; }
+    }
+    x265_cleanup();
+    return 0;
+}

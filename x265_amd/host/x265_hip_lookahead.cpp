@@ -46,6 +46,7 @@ namespace X265_NS {
 extern int64_t refEstimateFrameCost(CostEstimateGroup* self, LookaheadTLD& tld, int p0, int p1, int b, bool bIntraPenalty)
     asm("_ZN4x26520CostEstimateGroupRef17estimateFrameCostERNS_12LookaheadTLDEiiib");
 extern void refFinishBatch(CostEstimateGroup* self) asm("_ZN4x26520CostEstimateGroupRef11finishBatchEv");
+extern void refLookaheadDestroy(Lookahead* self) asm("_ZN4x26512LookaheadRef7destroyEv");
 static_assert(sizeof(X265HIP_STR(X265_NS)) == sizeof("x265"), "the asm labels above assume -DX265_NS=x265");
 
 namespace {
@@ -67,12 +68,34 @@ Session g_session;
 int g_state = 0;                 // 0 = not decided, 1 = on, -1 = off
 bool g_verbose = false;
 
-void report()
+// totals of the sessions that were closed with their encoders (Lookahead::destroy below)
+uint64_t g_pastBatches = 0, g_pastEstimates = 0, g_pastSearches = 0, g_pastUploads = 0, g_pastWaitNs = 0;
+
+void retire_session()
 {
-    if (!g_session.la)
+    Session& s = g_session;
+    if (!s.la)
         return;
     uint64_t batches = 0, estimates = 0, searches = 0;
-    x265hip_la_stats(g_session.la, &batches, &estimates, &searches);
+    x265hip_la_stats(s.la, &batches, &estimates, &searches);
+    g_pastBatches += batches; g_pastEstimates += estimates; g_pastSearches += searches; g_pastUploads += s.uploads; g_pastWaitNs += s.waitNs;
+    x265hip_la_destroy(s.la);
+    s.la = NULL;
+    s.owner = NULL;
+    s.slots.clear();
+    s.uploads = 0;
+    s.waitNs = 0;
+}
+
+void report()
+{
+    uint64_t batches = 0, estimates = 0, searches = 0;
+    if (g_session.la)
+        x265hip_la_stats(g_session.la, &batches, &estimates, &searches);
+    batches += g_pastBatches; estimates += g_pastEstimates; searches += g_pastSearches;
+    g_session.uploads += g_pastUploads; g_session.waitNs += g_pastWaitNs;
+    if (!batches && !g_session.la)
+        return;
     fprintf(stderr, "x265hip: lookahead: %llu frame-cost estimates (%llu motion-search passes over %llu lowres frames) served by the GPU in %llu batches, %.3f s inside the seam\n",
             (unsigned long long)estimates, (unsigned long long)searches, (unsigned long long)g_session.uploads, (unsigned long long)batches,
             g_session.waitNs * 1e-9);
@@ -115,11 +138,7 @@ Session& session_for(const Lookahead& l, const Lowres* f)
     Session& s = g_session;
     if (s.la && s.owner == &l)
         return s;
-    if (s.la)
-    {
-        x265hip_la_destroy(s.la);           // a new encoder in the same process
-        s.la = NULL;
-    }
+    retire_session();                       // another encoder in the same process (several at once take turns: the session follows the caller)
     x265hip_la_config c;
     memset(&c, 0, sizeof(c));
     c.depth = X265_DEPTH;
@@ -262,6 +281,19 @@ inline bool cached(const Lowres* fenc, int p0, int p1, int b)
 }
 
 } // namespace
+
+// The encoder is being closed: its Lowres objects and its Lookahead are about to be freed, and a later encoder of the same process may get the
+// same addresses back from malloc — the session's slots are keyed by them, so the session must not outlive them (tests/support/two_encoders.cpp).
+void Lookahead::destroy()
+{
+    if (g_state > 0)
+    {
+        std::lock_guard<std::mutex> guard(g_lock);
+        if (g_session.owner == this)
+            retire_session();
+    }
+    refLookaheadDestroy(this);
+}
 
 int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, int b, bool bIntraPenalty)
 {

@@ -116,8 +116,11 @@ inline const Mirror* find(const pixel* p)
 {
     const int n = g_count.load(std::memory_order_acquire);
     for (int i = 0; i < n; i++)
-        if (p >= g_mirror[i].lo && p < g_mirror[i].hi)
+    {
+        const pixel* lo = __atomic_load_n(&g_mirror[i].lo, __ATOMIC_ACQUIRE);     // NULL: a retired entry (or one being set up: lo is stored last)
+        if (lo && p >= lo && p < g_mirror[i].hi)
             return &g_mirror[i];
+    }
     return NULL;
 }
 
@@ -133,9 +136,16 @@ Mirror* mirror_of(PicYuv* pic)
     for (int i = n; i < n2; i++)
         if (g_mirror[i].lo == lo)
             return &g_mirror[i];
-    if (n2 == kMaxMirrors)
+    int slot = n2;
+    for (int i = 0; i < n2; i++)
+        if (!g_mirror[i].lo && !g_mirror[i].rp)
+        {
+            slot = i;                              // the entry of a destroyed buffer (x265hip_refplanes_retire)
+            break;
+        }
+    if (slot == kMaxMirrors)
         return NULL;
-    Mirror& m = g_mirror[n2];
+    Mirror& m = g_mirror[slot];
     const int maxCU = pic->m_param->maxCUSize;
     const int bufRows = (int)(((pic->m_picHeight + maxCU - 1) / maxCU) * maxCU + 2 * pic->m_lumaMarginY);       // picyuv.cpp:95-98
     m.rp = x265hip_refpic_create(X265_DEPTH, pic->m_picWidth, pic->m_picHeight, pic->m_stride, pic->m_lumaMarginX, pic->m_lumaMarginY, bufRows, lo);
@@ -144,7 +154,6 @@ Mirror* mirror_of(PicYuv* pic)
         fprintf(stderr, "x265hip: refplanes: %s\n", x265hip_last_error());
         abort();                                   // the product path fails loudly
     }
-    m.lo = lo;
     m.hi = lo + (size_t)pic->m_stride * bufRows;
     m.stride = pic->m_stride;
     m.picW = pic->m_picWidth; m.picH = pic->m_picHeight; m.marginX = pic->m_lumaMarginX; m.marginY = pic->m_lumaMarginY;
@@ -156,7 +165,9 @@ Mirror* mirror_of(PicYuv* pic)
     m.tracking = false;
     m.prefix = 0;
     memset(m.rowDone, 0, sizeof(m.rowDone));
-    g_count.store(n2 + 1, std::memory_order_release);
+    __atomic_store_n(&m.lo, lo, __ATOMIC_RELEASE);         // last: find() matches an entry by [lo, hi)
+    if (slot == n2)
+        g_count.store(n2 + 1, std::memory_order_release);
     return &m;
 }
 
@@ -224,6 +235,30 @@ template <int W, int H, int PART> void hvpp_lookup(const pixel* s, intptr_t ss, 
         p.pu[LUMA_ ## W ## x ## H].luma_vpp = vpp_lookup<W, H, LUMA_ ## W ## x ## H>; \
         p.pu[LUMA_ ## W ## x ## H].luma_hvpp = hvpp_lookup<W, H, LUMA_ ## W ## x ## H>; \
     } while (0)
+
+// PicYuv::destroy (x265_hip_srcplanes.cpp): the buffer at `lo` is about to be freed.  Its mirror must stop answering for that address range
+// before malloc can hand it to anybody else; nobody reads a picture that is being destroyed, so no reader is inside the entry.
+void x265hip_refplanes_retire(const pixel* lo)
+{
+    if (g_state <= 0)
+        return;
+    std::lock_guard<std::mutex> g(g_createLock);
+    const int n = g_count.load();
+    for (int i = 0; i < n; i++)
+        if (g_mirror[i].lo == lo)
+        {
+            Mirror& m = g_mirror[i];
+            std::lock_guard<std::mutex> g2(m.lock);
+            __atomic_store_n(&m.lo, (const pixel*)NULL, __ATOMIC_RELEASE);
+            m.hi = NULL;
+            m.rowsReady = NULL;
+            m.tracking = false;
+            m.poc = -1;
+            x265hip_refpic_destroy(m.rp);           // waits for the worker's queued bands of this picture
+            m.rp = NULL;
+            return;
+        }
+}
 
 // called by setupAssemblyPrimitives (x265_hip_primitives.cpp) in the default table mode
 void x265hip_install_lookup_slots(EncoderPrimitives& p)

@@ -39,6 +39,8 @@ namespace X265_NS {
 
 extern void refCopyFromPicture(PicYuv* self, const x265_picture& pic, const x265_param& param, int padx, int pady)
     asm("_ZN4x2659PicYuvRef15copyFromPictureERK12x265_pictureRK10x265_paramii");
+extern void refDestroy(PicYuv* self) asm("_ZN4x2659PicYuvRef7destroyEv");
+void x265hip_refplanes_retire(const pixel* lo);     // x265_hip_refplanes.cpp
 extern void refCopyFromPicYuv(Yuv* self, const PicYuv& srcPic, uint32_t cuAddr, uint32_t absPartIdx) asm("_ZN4x2656YuvRef14copyFromPicYuvERKNS_6PicYuvEjj");
 extern void refCopyPartToYuv(const Yuv* self, Yuv& dstYuv, uint32_t absPartIdx) asm("_ZNK4x2656YuvRef13copyPartToYuvERS0_j");
 
@@ -117,6 +119,12 @@ SrcPic* find_pic(const PicYuv* pic, bool create)
     for (int i = n; i < n2; i++)
         if (g_pics[i].pic.load() == pic)
             return &g_pics[i];
+    for (int i = 0; i < n2; i++)
+        if (!g_pics[i].pic.load())                     // the entry of a destroyed buffer (retire() below): its planes are reused or resized by build()
+        {
+            g_pics[i].pic.store(pic);
+            return &g_pics[i];
+        }
     if (n2 == kMaxPics)
         return NULL;
     SrcPic& s = g_pics[n2];
@@ -131,10 +139,11 @@ SrcPic* find_pic(const PicYuv* pic, bool create)
 // the planes of the picture now in the buffer (worker thread: a picture enters the encoder a whole lookahead before its first CTU is analysed)
 void build(SrcPic* sp, uint32_t v)
 {
-    const PicYuv& pic = *sp->pic.load();
-    if (sp->version.load() != v)
-        return;                                        // a newer picture is already on its way into the buffer
-    std::lock_guard<std::mutex> g(sp->lock);
+    std::lock_guard<std::mutex> g(sp->lock);           // PicYuv::destroy waits here for a build in progress
+    const PicYuv* picp = sp->pic.load();
+    if (!picp || sp->version.load() != v)
+        return;                                        // the buffer is gone, or a newer picture is already on its way into it
+    const PicYuv& pic = *picp;
     const int planes = pic.m_picCsp == X265_CSP_I400 ? 1 : 3;
     for (int k = 0; k < planes; k++)
     {
@@ -307,6 +316,23 @@ void PicYuv::copyFromPicture(const x265_picture& pic, const x265_param& param, i
     refCopyFromPicture(this, pic, param, padx, pady);
     if (sp)
         enqueue(sp, v);                                 // the picture is complete (padding included): its planes are built in the background
+}
+
+// the buffer goes away (encoder close; a process may open another encoder afterwards, with other picture sizes, and malloc may hand the same
+// addresses out again): nothing may keep pointing into it — neither the source-picture entry nor a reference-picture mirror
+void PicYuv::destroy()
+{
+    if (g_state > 0)
+        if (SrcPic* sp = find_pic(this, false))
+        {
+            std::lock_guard<std::mutex> g(sp->lock);
+            sp->version.fetch_add(1);                   // queued builds and remembered cache positions of this buffer are void
+            sp->built.store(0);
+            sp->pic.store(nullptr);
+        }
+    if (m_picBuf[0])
+        x265hip_refplanes_retire(m_picBuf[0]);
+    refDestroy(this);
 }
 
 void Yuv::copyFromPicYuv(const PicYuv& srcPic, uint32_t cuAddr, uint32_t absPartIdx)
