@@ -4,11 +4,13 @@
 // nor a source-picture entry of the first may answer for them (PicYuv::destroy seam).
 // Linked three ways by oracle/Makefile (reference objects only / + bindings + emulated ABI / + bindings + libx265hip.so); the outputs must agree.
 //
-//   two_encoders <out-prefix>     writes <out-prefix>_<k>.hevc for each session k
+//   two_encoders <out-prefix> [par]   writes <out-prefix>_<k>.hevc for each session k; `par`: sessions run two (then three) at a time on
+//                                     their own threads — encoders alive at the same time, the way an ABR ladder runs them
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "x265.h"
@@ -84,12 +86,28 @@ int main(int argc, char** argv)
         { 176, 144, 12, 44, "slow", 4 },
         { 640, 368, 8, 55, "medium", 0 },
     };
-    for (size_t k = 0; k < sizeof(sessions) / sizeof(sessions[0]); k++)
-    {
+    const int n = (int)(sizeof(sessions) / sizeof(sessions[0]));
+    const bool par = argc > 2 && !strcmp(argv[2], "par");
+    bool ok[n];
+    auto one = [&](int k) {
         char path[512];
-        snprintf(path, sizeof(path), "%s_%d.hevc", argv[1], (int)k);
-        if (!run(sessions[k], path)) { fprintf(stderr, "two_encoders: session %d failed\n", (int)k); return 1; }
+        snprintf(path, sizeof(path), "%s_%d.hevc", argv[1], k);
+        ok[k] = run(sessions[k], path);
+    };
+    if (par)
+    {
+        const int groups[2][2] = { { 0, 2 }, { 2, 5 } };
+        for (const auto& g : groups)
+        {
+            std::vector<std::thread> ts;
+            for (int k = g[0]; k < g[1]; k++) ts.emplace_back(one, k);
+            for (auto& t : ts) t.join();
+        }
     }
+    else
+        for (int k = 0; k < n; k++) one(k);
+    for (int k = 0; k < n; k++)
+        if (!ok[k]) { fprintf(stderr, "two_encoders: session %d failed\n", k); return 1; }
     x265_cleanup();
     return 0;
 }

@@ -20,15 +20,15 @@ def _need(name):
     return p
 
 
-def _run(exe, prefix, env=None):
-    r = subprocess.run([exe, prefix], capture_output=True, text=True, timeout=900, env=dict(os.environ, X265HIP_VERBOSE="1", **(env or {})))
+def _run(exe, prefix, env=None, par=False):
+    r = subprocess.run([exe, prefix] + (["par"] if par else []), capture_output=True, text=True, timeout=900, env=dict(os.environ, X265HIP_VERBOSE="1", **(env or {})))
     assert r.returncode == 0, "%s: rc %d\n%s" % (os.path.basename(exe), r.returncode, r.stderr[-600:])
     return [open("%s_%d.hevc" % (prefix, k), "rb").read() for k in range(SESSIONS)], r.stderr
 
 
-def _compare(bound, tmp_path):
+def _compare(bound, tmp_path, par=False):
     ref, _ = _run(_need("two_encoders_ref8"), str(tmp_path / "ref"))
-    got, log = _run(bound, str(tmp_path / "bound"))
+    got, log = _run(bound, str(tmp_path / "bound"), par=par)
     assert all(len(b) > 1000 for b in ref)
     for k in range(SESSIONS):
         assert ref[k] == got[k], "session %d differs from the reference" % k
@@ -43,6 +43,17 @@ def test_sequential_encoders_in_one_process_with_emulated_abi(tmp_path):
     _compare(_need("two_encoders_emul8"), tmp_path)
 
 
+def test_concurrent_encoders_in_one_process_with_emulated_abi(tmp_path):
+    """two, then three encoders alive at the same time (an ABR ladder's shape): one lookahead session per live encoder, mirrors and source
+    entries per buffer; the outputs equal the sequential reference run's"""
+    _compare(_need("two_encoders_emul8"), tmp_path, par=True)
+
+
 @pytest.mark.gpu
 def test_sequential_encoders_in_one_process_on_gpu(tmp_path):
     _compare(_need("two_encoders_hip8"), tmp_path)
+
+
+@pytest.mark.gpu
+def test_concurrent_encoders_in_one_process_on_gpu(tmp_path):
+    _compare(_need("two_encoders_hip8"), tmp_path, par=True)

@@ -61,19 +61,21 @@ struct Session
     uint64_t stamp = 0;
     uint64_t uploads = 0;
     uint64_t waitNs = 0;          // wall time the lookahead thread spent inside compute() (descriptor build + device pass + write-back)
+    uint64_t lastUse = 0;
 };
 
 std::mutex g_lock;
-Session g_session;
+const int kMaxSessions = 4;        // encoders of one process that run at the same time (an ABR ladder); more than that take turns
+Session g_sessions[kMaxSessions];
+uint64_t g_useClock = 0;
 int g_state = 0;                 // 0 = not decided, 1 = on, -1 = off
 bool g_verbose = false;
 
 // totals of the sessions that were closed with their encoders (Lookahead::destroy below)
 uint64_t g_pastBatches = 0, g_pastEstimates = 0, g_pastSearches = 0, g_pastUploads = 0, g_pastWaitNs = 0;
 
-void retire_session()
+void retire_session(Session& s)
 {
-    Session& s = g_session;
     if (!s.la)
         return;
     uint64_t batches = 0, estimates = 0, searches = 0;
@@ -89,16 +91,21 @@ void retire_session()
 
 void report()
 {
-    uint64_t batches = 0, estimates = 0, searches = 0;
-    if (g_session.la)
-        x265hip_la_stats(g_session.la, &batches, &estimates, &searches);
-    batches += g_pastBatches; estimates += g_pastEstimates; searches += g_pastSearches;
-    g_session.uploads += g_pastUploads; g_session.waitNs += g_pastWaitNs;
-    if (!batches && !g_session.la)
+    uint64_t batches = g_pastBatches, estimates = g_pastEstimates, searches = g_pastSearches, uploads = g_pastUploads, waitNs = g_pastWaitNs;
+    bool any = batches != 0;
+    for (Session& s : g_sessions)
+        if (s.la)
+        {
+            uint64_t b = 0, e = 0, m = 0;
+            x265hip_la_stats(s.la, &b, &e, &m);
+            batches += b; estimates += e; searches += m; uploads += s.uploads; waitNs += s.waitNs;
+            any = true;
+        }
+    if (!any)
         return;
     fprintf(stderr, "x265hip: lookahead: %llu frame-cost estimates (%llu motion-search passes over %llu lowres frames) served by the GPU in %llu batches, %.3f s inside the seam\n",
-            (unsigned long long)estimates, (unsigned long long)searches, (unsigned long long)g_session.uploads, (unsigned long long)batches,
-            g_session.waitNs * 1e-9);
+            (unsigned long long)estimates, (unsigned long long)searches, (unsigned long long)uploads, (unsigned long long)batches,
+            waitNs * 1e-9);
 }
 
 bool enabled()
@@ -135,10 +142,24 @@ bool covered(const Lookahead& l, const Lowres* fenc)
 
 Session& session_for(const Lookahead& l, const Lowres* f)
 {
-    Session& s = g_session;
-    if (s.la && s.owner == &l)
-        return s;
-    retire_session();                       // another encoder in the same process (several at once take turns: the session follows the caller)
+    Session* pick = NULL;
+    for (Session& c : g_sessions)
+        if (c.la && c.owner == &l)
+        {
+            c.lastUse = ++g_useClock;
+            return c;
+        }
+    for (Session& c : g_sessions)
+        if (!c.la) { pick = &c; break; }
+    if (!pick)
+    {
+        pick = &g_sessions[0];                  // more live encoders than sessions: the least recently used one gives way (correct, only slower)
+        for (Session& c : g_sessions)
+            if (c.lastUse < pick->lastUse) pick = &c;
+        retire_session(*pick);
+    }
+    Session& s = *pick;
+    s.lastUse = ++g_useClock;
     x265hip_la_config c;
     memset(&c, 0, sizeof(c));
     c.depth = X265_DEPTH;
@@ -289,8 +310,9 @@ void Lookahead::destroy()
     if (g_state > 0)
     {
         std::lock_guard<std::mutex> guard(g_lock);
-        if (g_session.owner == this)
-            retire_session();
+        for (Session& c : g_sessions)
+            if (c.owner == this)
+                retire_session(c);
     }
     refLookaheadDestroy(this);
 }
