@@ -501,7 +501,7 @@ def encode_bench(args, rank, local_rank, world, fence):
     if world > 1:
         base += ["--pools", str(per_rank)]                   # the ranks share the host: each encoder gets its share of the cores
     visible = os.environ.get("HIP_VISIBLE_DEVICES")
-    env = dict(os.environ, X265HIP_VERBOSE="1", HIP_VISIBLE_DEVICES=visible.split(",")[local_rank] if visible else str(local_rank))
+    env = dict(os.environ, X265HIP_VERBOSE="1", X265HIP="require", HIP_VISIBLE_DEVICES=visible.split(",")[local_rank] if visible else str(local_rank))
     out_hip, out_ref = clip + ".gpu.hevc", clip + ".ref.hevc"
     res = {}
     try:

@@ -21,7 +21,7 @@ def _need(name):
 
 
 def _run(exe, prefix, env=None, par=False):
-    r = subprocess.run([exe, prefix] + (["par"] if par else []), capture_output=True, text=True, timeout=900, env=dict(os.environ, X265HIP_VERBOSE="1", **(env or {})))
+    r = subprocess.run([exe, prefix] + (["par"] if par else []), capture_output=True, text=True, timeout=900, env=dict(os.environ, X265HIP_VERBOSE="1", X265HIP="require", **(env or {})))
     assert r.returncode == 0, "%s: rc %d\n%s" % (os.path.basename(exe), r.returncode, r.stderr[-600:])
     return [open("%s_%d.hevc" % (prefix, k), "rb").read() for k in range(SESSIONS)], r.stderr
 

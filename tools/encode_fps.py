@@ -45,7 +45,7 @@ def measure(frames=60, width=1920, height=1080, bits=8, preset="medium", extra=(
            "host_cores": os.cpu_count()}
     try:
         runs_ref = [_run(ref, args, o_ref) for _ in range(repeat)]
-        runs_hip = [_run(hip, args, o_hip, env=dict(os.environ, X265HIP_VERBOSE="1")) for _ in range(repeat)]
+        runs_hip = [_run(hip, args, o_hip, env=dict(os.environ, X265HIP_VERBOSE="1", X265HIP="require")) for _ in range(repeat)]
         best = lambda rs: max(rs, key=lambda r: r["fps"] or 0)  # noqa: E731
         r_ref, r_hip = best(runs_ref), best(runs_hip)
         res["reference"] = {k: r_ref[k] for k in ("fps", "wall_s", "rc")}

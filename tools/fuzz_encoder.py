@@ -96,7 +96,7 @@ def run_case(case, bound_exe, ref_exe, workdir, timeout=240):
             o = os.path.join(workdir, "fuzz_%d_%s.hevc" % (case["seed"], tag))
             t0 = time.time()
             try:
-                r = subprocess.run([exe] + base + ["-o", o], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, X265HIP_VERBOSE="1"))
+                r = subprocess.run([exe] + base + ["-o", o], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, X265HIP_VERBOSE="1", X265HIP="require"))
             except subprocess.TimeoutExpired:
                 r = subprocess.CompletedProcess([], -9, "", "timeout after %d s" % timeout)
             res[tag + "_s"] = round(time.time() - t0, 2)

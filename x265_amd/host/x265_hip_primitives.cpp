@@ -564,6 +564,20 @@ void setupAssemblyPrimitives(EncoderPrimitives& p, int /* cpuMask: CPU ISA bits,
     const char* env = getenv("X265HIP");
     if (env && !strcmp(env, "0"))
         return;
+    // No device: never silent.  The bindings switch themselves off and the reference's own host code runs (an encoder must still encode), but it says
+    // so; X265HIP=require turns that into an error (bench.py and the GPU tests run with it: a number measured on a silent fallback is worthless).
+    static bool probed = false;
+    if (!probed)
+    {
+        probed = true;
+        if (x265hip_device_count() < 1)
+        {
+            fprintf(stderr, "x265hip: no HIP device visible: GPU bindings are OFF, the encoder runs the reference's host code only%s\n",
+                    env && !strcmp(env, "require") ? "" : " (X265HIP=0 silences this, X265HIP=require makes it fatal)");
+            if (env && !strcmp(env, "require"))
+                abort();
+        }
+    }
     // X265HIP_TABLE selects what the table holds:
     //   percall   every slot below becomes its per-call shim (one slot call = one 1-job launch + sync): the bit-exactness proof of each
     //             kernel under the reference's own TestBench and encoder, ~1000x slower than the C code
