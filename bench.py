@@ -145,6 +145,26 @@ def pmc_traffic(stage):
     return None, None, None
 
 
+def pmc_lookahead():
+    """HBM bytes per launch of lookahead_p_kernel from the newest committed PMC passes of `bench.py --lookahead-probe-only`
+    (profiles/r*_pmc_lookahead.txt; FETCH_SIZE and WRITE_SIZE in separate runs, corrected as the file says).  (bytes, file, note) or Nones."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_lookahead.txt")))
+    if not files:
+        return None, None, None
+    note = "from the committed profile of this same probe, not collected in this run"
+    for line in open(files[-1]):
+        if line.startswith("# fetch_correction"):
+            note += "; " + line[1:].strip()
+        if "lookahead_p_kernel" in line and not line.startswith("#"):
+            cols = line.split()
+            try:
+                return int((float(cols[-2]) + float(cols[-1])) * 1024), os.path.relpath(files[-1], ROOT), note
+            except ValueError:
+                continue
+    return None, None, None
+
+
 def pmc_frame_bytes():
     """Sum over the frame pass's kernels (each launched once per frame) of PMC FETCH + WRITE bytes per launch."""
     f = _pmc_file()
@@ -537,6 +557,8 @@ def main():
     ap.add_argument("--no-frame-pass", action="store_true", help="skip the device-resident frame-pass block")
     ap.add_argument("--frame-pass-only", action="store_true", help="profiling aid (tools/collect_profiles.sh): only the frame-pass block, printed as the line")
     ap.add_argument("--quick", action="store_true", help="skip the multi-process CPU port leg")
+    ap.add_argument("--lookahead-probe-only", action="store_true",
+                    help="profiling aid (tools/collect_profiles.sh): only the lookahead_p_kernel probe of the roofline block, so that PMC passes see exactly its launches")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="frame pass: independent passes per GPU per step, each on its own HIP stream (x265 --frame-threads inside one device)")
     args = ap.parse_args()
@@ -559,6 +581,10 @@ def main():
     torch.cuda.set_device(local_rank)
     L = hp.lib()
     hp.check(L.x265hip_init(local_rank))
+    if args.lookahead_probe_only:
+        la_ms, la_blocks = lookahead_kernel_probe(L, hp, np)
+        print(json.dumps({"lookahead_probe": {"launch_ms": round(la_ms, 4), "blocks": la_blocks, "pairs": la_blocks // 8160}}), flush=True)
+        return
     if world > 1:
         import datetime
         tmo = datetime.timedelta(seconds=300)              # a wedged collective must end the run with an error, not hang the box
@@ -605,6 +631,7 @@ def main():
         ach = la_bytes / (la_ms * 1e-3) / 1e9
         # what HBM has to deliver when caches work: the frame's plane + the reference's four half-pel planes once per pair, 22 B of results per block
         uniq = (la_blocks // 8160) * 5 * 1024 * 608 + la_blocks * 22
+        la_traffic, la_tfile, la_tnote = pmc_lookahead()
         out = {
             "metric": "encode fps (1080p preset medium)", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 3),
@@ -620,7 +647,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "lookahead_p_kernel<u8> (%d (frame, reference) pairs of 960x544 lowres = %d 8x8 blocks x %.0f B = %.1f "
                                                      "reference slot calls per block, SURVEY 8d per-call bytes; a latency-bound dependent chain, see DESIGN.md §5)"
                                                      % (la_blocks // 8160, la_blocks, LA_BYTES_PER_BLOCK, LA_CALLS_PER_BLOCK),
-                         "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": la_traffic,
+                         "traffic_source": la_tfile, "traffic_note": la_tnote,
+                         "hbm_counter_frac": round(la_traffic / (la_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if la_traffic else None,
                          "algorithmic_bytes_per_launch": int(la_bytes), "launch_ms": round(la_ms, 4),
                          "launch_ms_note": "HIP events on the kernel's own stream, measured in this run",
                          "unique_footprint": {"bytes_per_launch": uniq, "achieved": round(uniq / (la_ms * 1e-3) / 1e9, 2),

@@ -77,6 +77,29 @@ with open(os.path.join(P, f"{tag}_pmc_hbm_bytes.txt"), "w") as o:
         fa, wa = sum(f) / len(f), sum(w) / len(w)
         o.write(f"{k:<72}{grid[k]:>9}{len(f):>9}{fa:>13.1f}{wa:>13.1f}{ffac * fa:>13.1f}{wfac * wa:>13.1f}\n")
 
+# bench.py's lookahead_p_kernel probe (python bench.py --lookahead-probe-only): duration, byte counters, SQ counters of exactly those launches
+lfv, lgrid = per_kernel("lafetch")
+lwv, _ = per_kernel("lawrite")
+lsv, _ = per_kernel("lasq")
+lst = find("lastats", "kernel_stats.csv")
+if lfv:
+    with open(os.path.join(P, f"{tag}_pmc_lookahead.txt"), "w") as o:
+        o.write(f"# rocprofv3 on `python bench.py --lookahead-probe-only` (lookahead_p_kernel, 8 (frame, reference) pairs of 960x544 per launch): --kernel-trace --stats, then --pmc FETCH_SIZE, --pmc WRITE_SIZE and the SQ counters, each in its own pass   {note}\n")
+        o.write(f"# fetch_correction {ffac:.3f} write_correction {wfac:.3f} ({tag}_pmc_calibration.txt); per-launch averages in KiB, raw and corrected\n")
+        if lst:
+            for r in csv.DictReader(open(lst)):
+                if "lookahead_p_kernel" in r["Name"]:
+                    o.write(f"# kernel stats: {r['Calls']} launches, average {float(r['AverageNs']) / 1e3:.1f} us (min {float(r['MinNs']) / 1e3:.1f}, max {float(r['MaxNs']) / 1e3:.1f})\n")
+        o.write(f"{'kernel':<72}{'grid':>9}{'launches':>9}{'FETCH_raw':>13}{'WRITE_raw':>13}{'FETCH_KiB':>13}{'WRITE_KiB':>13}\n")
+        for k in sorted(lfv):
+            f = lfv[k]["FETCH_SIZE"]
+            w = lwv.get(k, {}).get("WRITE_SIZE", [0.0])
+            fa, wa = sum(f) / len(f), sum(w) / len(w)
+            o.write(f"{k:<72}{lgrid[k]:>9}{len(f):>9}{fa:>13.1f}{wa:>13.1f}{ffac * fa:>13.1f}{wfac * wa:>13.1f}\n")
+        for k in lsv:
+            o.write("# SQ per launch  " + f"{k:<60}" + json.dumps({c: int(sum(v) / len(v)) for c, v in sorted(lsv[k].items())}) + "\n")
+    print(open(os.path.join(P, f"{tag}_pmc_lookahead.txt")).read())
+
 enc = find("encode", "kernel_stats.csv")
 if enc:
     shutil.copy(enc, os.path.join(P, f"{tag}_encode_kernel_stats.csv"))
