@@ -2,12 +2,31 @@
 // The product's x265_hip_primitives.cpp also carries the per-call shims of every slot, which bind the whole device library; the emulation
 // build only exercises the two seams that do not need a GPU to be checked for plumbing — the lookahead session and the reference-picture
 // mirrors — against tests/support/libx265hip_emul.so, so its table setup is just the lookup slots.
+#include <cstring>
+#include <mutex>
+
 #include "common.h"
 #include "primitives.h"
 
 namespace X265_NS {
 void x265hip_install_lookup_slots(EncoderPrimitives& p);        // x265_amd/host/x265_hip_refplanes.cpp
 void x265hip_install_psy_slots(EncoderPrimitives& p);           // x265_amd/host/x265_hip_srcplanes.cpp
+// the reference's C table for the bindings' "what the slot did before" (same function as in the product's x265_hip_primitives.cpp)
+const EncoderPrimitives& x265hip_c_table()
+{
+    static EncoderPrimitives c;
+    static bool ready = false;
+    static std::mutex once;
+    std::lock_guard<std::mutex> g(once);
+    if (!ready)
+    {
+        memset(&c, 0, sizeof(c));
+        setupCPrimitives(c);
+        setupAliasPrimitives(c);
+        ready = true;
+    }
+    return c;
+}
 void setupInstrinsicPrimitives(EncoderPrimitives&, int) {}
 void setupAssemblyPrimitives(EncoderPrimitives& p, int) { x265hip_install_lookup_slots(p); x265hip_install_psy_slots(p); }
 }

@@ -12,6 +12,11 @@
 #include <cstring>
 #include <thread>
 #include <vector>
+#include <dirent.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include "x265.h"
 
@@ -75,8 +80,48 @@ static bool run(const Session& ss, const char* path)
     return true;
 }
 
+// TWO_ENCODERS_WATCHDOG=<seconds>: if the program is still running after that long, every thread prints its stack (module + offset,
+// resolvable with addr2line against the binaries as built) and the process exits with code 9 — a hang on the GPU box must leave evidence
+static void dump_stack(int)
+{
+    void* frames[48];
+    const int n = backtrace(frames, 48);
+    char head[64];
+    const int len = snprintf(head, sizeof(head), "---- thread %ld\n", (long)syscall(SYS_gettid));
+    if (write(2, head, len) < 0) {}
+    backtrace_symbols_fd(frames, n, 2);
+}
+static void watchdog(int seconds)
+{
+    sleep(seconds);
+    fprintf(stderr, "two_encoders: watchdog after %d s, stacks of all threads:\n", seconds);
+    const long self = (long)syscall(SYS_gettid);
+    for (int round = 0; round < 3; round++)             // three snapshots half a second apart: stuck or merely slow?
+    {
+        fprintf(stderr, "==== snapshot %d\n", round);
+        DIR* d = opendir("/proc/self/task");
+        for (dirent* e = d ? readdir(d) : NULL; e; e = readdir(d))
+        {
+            const long tid = atol(e->d_name);
+            if (tid > 0 && tid != self)
+            {
+                syscall(SYS_tgkill, getpid(), tid, SIGUSR1);
+                usleep(20000);
+            }
+        }
+        if (d) closedir(d);
+        usleep(500000);
+    }
+    _exit(9);
+}
+
 int main(int argc, char** argv)
 {
+    if (const char* w = getenv("TWO_ENCODERS_WATCHDOG"))
+    {
+        signal(SIGUSR1, dump_stack);
+        std::thread(watchdog, atoi(w)).detach();
+    }
     if (argc < 2) { fprintf(stderr, "usage: two_encoders <out-prefix>\n"); return 2; }
     // sizes chosen so that freed buffers of one session are likely to be handed out again in the next, whole or in part
     const Session sessions[] = {

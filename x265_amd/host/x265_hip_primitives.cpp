@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace X265_NS {
 
@@ -31,6 +32,8 @@ static bool g_cReady = false;
 
 static void ensure_c_table()
 {
+    static std::mutex once;                         // encoders opened at the same time both come through x265_setup_primitives
+    std::lock_guard<std::mutex> g(once);
     if (!g_cReady)
     {
         memset(&g_c, 0, sizeof(g_c));
@@ -38,6 +41,14 @@ static void ensure_c_table()
         setupAliasPrimitives(g_c);
         g_cReady = true;
     }
+}
+
+// the reference's C table, built here (setupCPrimitives + setupAliasPrimitives) rather than copied from whatever table is being set up: the other
+// binding TUs take their "what the slot did before" functions from it, complete and free of anybody's wrappers
+const EncoderPrimitives& x265hip_c_table()
+{
+    ensure_c_table();
+    return g_c;
 }
 
 #define D X265_DEPTH

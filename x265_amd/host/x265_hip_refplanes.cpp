@@ -39,6 +39,8 @@
 
 namespace X265_NS {
 
+const EncoderPrimitives& x265hip_c_table();          // x265_hip_primitives.cpp
+
 extern void refProcessPostRow(FrameFilter* self, int row) asm("_ZN4x26514FrameFilterRef14processPostRowEi");
 static_assert(sizeof("" "x265") == 5, "");
 
@@ -265,7 +267,20 @@ void x265hip_install_lookup_slots(EncoderPrimitives& p)
 {
     if (!enabled())
         return;
-    g_c = p;                                        // what the slots did before (the C functions)
+    // What the slots did before: the reference's C functions, from a table built for the purpose (x265hip_c_table, x265_hip_primitives.cpp), once.
+    // Not a copy of `p`: x265_setup_primitives is not serialised between encoders opened at the same time (primitives.cpp:
+    // `if (!primitives.pu[0].sad)`), so `p` may be half filled by another thread or already hold these very wrappers — a wrapper that
+    // captured itself would call itself for ever (tests/test_encoder_lifetime.py, concurrent sessions).
+    {
+        static std::mutex once;
+        static bool have = false;
+        std::lock_guard<std::mutex> g(once);
+        if (!have)
+        {
+            g_c = x265hip_c_table();
+            have = true;
+        }
+    }
     LOOKUP_PU(4, 4);   LOOKUP_PU(8, 8);   LOOKUP_PU(16, 16); LOOKUP_PU(32, 32); LOOKUP_PU(64, 64);
     LOOKUP_PU(8, 4);   LOOKUP_PU(4, 8);   LOOKUP_PU(16, 8);  LOOKUP_PU(8, 16);  LOOKUP_PU(32, 16); LOOKUP_PU(16, 32);
     LOOKUP_PU(64, 32); LOOKUP_PU(32, 64); LOOKUP_PU(16, 12); LOOKUP_PU(12, 16); LOOKUP_PU(16, 4);  LOOKUP_PU(4, 16);

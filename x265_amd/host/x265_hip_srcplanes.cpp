@@ -37,6 +37,8 @@
 
 namespace X265_NS {
 
+const EncoderPrimitives& x265hip_c_table();          // x265_hip_primitives.cpp
+
 extern void refCopyFromPicture(PicYuv* self, const x265_picture& pic, const x265_param& param, int padx, int pady)
     asm("_ZN4x2659PicYuvRef15copyFromPictureERK12x265_pictureRK10x265_paramii");
 extern void refDestroy(PicYuv* self) asm("_ZN4x2659PicYuvRef7destroyEv");
@@ -298,7 +300,20 @@ void x265hip_install_psy_slots(EncoderPrimitives& p)
 {
     if (!enabled())
         return;
-    g_c = p;
+    // What the slots did before: the reference's C functions, from a table built for the purpose (x265hip_c_table, x265_hip_primitives.cpp), once.
+    // Not a copy of `p`: x265_setup_primitives is not serialised between encoders opened at the same time (primitives.cpp:
+    // `if (!primitives.pu[0].sad)`), so `p` may be half filled by another thread or already hold these very wrappers — a wrapper that
+    // captured itself would call itself for ever (tests/test_encoder_lifetime.py, concurrent sessions).
+    {
+        static std::mutex once;
+        static bool have = false;
+        std::lock_guard<std::mutex> g(once);
+        if (!have)
+        {
+            g_c = x265hip_c_table();
+            have = true;
+        }
+    }
     // cu[BLOCK_4x4].sa8d is aliased to satd_4x4 only later (setupAliasPrimitives, primitives.cpp:139); the lookups call the pu[] slots directly
     p.cu[BLOCK_4x4].psy_cost_pp = psy_lookup<4, BLOCK_4x4>;
     p.cu[BLOCK_8x8].psy_cost_pp = psy_lookup<8, BLOCK_8x8>;
