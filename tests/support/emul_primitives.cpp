@@ -28,7 +28,7 @@ const EncoderPrimitives& x265hip_c_table()
     return c;
 }
 void setupInstrinsicPrimitives(EncoderPrimitives&, int) {}
-void setupAssemblyPrimitives(EncoderPrimitives& p, int) { x265hip_install_lookup_slots(p); x265hip_install_psy_slots(p); }
+void setupAssemblyPrimitives(EncoderPrimitives& p, int) { setupAliasPrimitives(p); x265hip_install_lookup_slots(p); x265hip_install_psy_slots(p); }
 }
 extern "C" {
 int PFX(cpu_cpuid_test)(void) { return 0; }

@@ -15,6 +15,7 @@
 #include <dirent.h>
 #include <execinfo.h>
 #include <signal.h>
+#include <ucontext.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 
@@ -120,6 +121,23 @@ int main(int argc, char** argv)
     if (const char* w = getenv("TWO_ENCODERS_WATCHDOG"))
     {
         signal(SIGUSR1, dump_stack);
+        struct sigaction sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.sa_flags = SA_SIGINFO;
+        sa.sa_sigaction = [](int, siginfo_t* si, void* ucv) {
+            // a call through a null pointer leaves nothing for the unwinder: print where it came from (the return address on top of the stack)
+            ucontext_t* uc = (ucontext_t*)ucv;
+            const uintptr_t rip = (uintptr_t)uc->uc_mcontext.gregs[REG_RIP], rsp = (uintptr_t)uc->uc_mcontext.gregs[REG_RSP];
+            void* ret[1] = { rip ? (void*)rip : *(void**)rsp };
+            char head[128];
+            const int len = snprintf(head, sizeof(head), "---- SIGSEGV at %p (fault address %p), thread %ld, called from:\n", (void*)rip, si->si_addr, (long)syscall(SYS_gettid));
+            if (write(2, head, len) < 0) {}
+            backtrace_symbols_fd(ret, 1, 2);
+            dump_stack(0);
+            _exit(11);
+        };
+        sigaction(SIGSEGV, &sa, NULL);
+        signal(SIGABRT, [](int) { dump_stack(0); _exit(12); });
         std::thread(watchdog, atoi(w)).detach();
     }
     if (argc < 2) { fprintf(stderr, "usage: two_encoders <out-prefix>\n"); return 2; }

@@ -575,6 +575,11 @@ void setupAssemblyPrimitives(EncoderPrimitives& p, int /* cpuMask: CPU ISA bits,
     const char* env = getenv("X265HIP");
     if (env && !strcmp(env, "0"))
         return;
+    // x265_setup_primitives (primitives.cpp) is not serialised: an encoder opened on another thread sees `primitives.pu[0].sad` set, skips the
+    // set-up and starts using the table while this call is still running — and this call can take long (the first one initialises the HIP
+    // runtime).  The reference closes the table with setupAliasPrimitives AFTER this function; do it first as well, so that the table is complete
+    // (every slot a C function) for the whole time spent here.  Without it a second encoder called through null alias slots on the GPU box.
+    setupAliasPrimitives(p);
     // No device: never silent.  The bindings switch themselves off and the reference's own host code runs (an encoder must still encode), but it says
     // so; X265HIP=require turns that into an error (bench.py and the GPU tests run with it: a number measured on a silent fallback is worthless).
     static bool probed = false;
