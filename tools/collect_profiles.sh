@@ -27,7 +27,7 @@ lacmd="python $root/bench.py --lookahead-probe-only"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_lastats -o b -- $lacmd > $out/${tag}_lastats.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${tag}_lafetch -o b -- $lacmd > $out/${tag}_lafetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/${tag}_lawrite -o b -- $lacmd > $out/${tag}_lawrite.log 2>&1
-timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES \
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES \
     --kernel-trace --output-format csv -d $out/${tag}_lasq -o b -- $lacmd > $out/${tag}_lasq.log 2>&1
 rm -rf $out/calib_fetch $out/calib_write
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/calib_fetch -o c -- python $root/tools/pmc_calibrate.py > $out/${tag}_calib_fetch.log 2>&1
