@@ -57,3 +57,44 @@ def test_sequential_encoders_in_one_process_on_gpu(tmp_path):
 @pytest.mark.gpu
 def test_concurrent_encoders_in_one_process_on_gpu(tmp_path):
     _compare(_need("two_encoders_hip8"), tmp_path, par=True)
+
+
+def _ladder(exe, tmp_path, tag, clips):
+    rungs = [("r1", clips[0], "352x288", "medium", 2), ("r2", clips[1], "640x360", "fast", 2), ("r3", clips[2], "416x240", "slow", 1)]
+    cfg = tmp_path / ("ladder_%s.txt" % tag)
+    outs = []
+    with open(cfg, "w") as f:
+        for name, clip, res, preset, ft in rungs:
+            o = str(tmp_path / ("%s_%s.hevc" % (tag, name)))
+            outs.append(o)
+            f.write("[%s:0:nil] --input %s --input-res %s --fps 30 --frames 12 --preset %s --pools 4 -F %d --hash 1 -o %s\n" % (name, clip, res, preset, ft, o))
+    r = subprocess.run([exe, "--abr-ladder", str(cfg)], capture_output=True, text=True, timeout=900, env=dict(os.environ, X265HIP_VERBOSE="1", X265HIP="require"))
+    assert r.returncode == 0, r.stderr[-600:]
+    return [open(o, "rb").read() for o in outs], r.stderr
+
+
+def _abr_ladder(bound, tmp_path):
+    """the CLI's own way of running several encoders at once in one process: --abr-ladder (abrEncApp.cpp), three rungs of different sizes"""
+    import sys
+    sys.path.insert(0, ROOT)
+    from x265_amd.synth import make_clip
+    clips = []
+    for i, (w, h) in enumerate(((352, 288), (640, 360), (416, 240))):
+        p = str(tmp_path / ("clip%d.yuv" % i))
+        make_clip(p, w, h, 12, seed=5 + i, tile=48)
+        clips.append(p)
+    ref, _ = _ladder(_need("x265_8bit"), tmp_path, "ref", clips)
+    got, log = _ladder(bound, tmp_path, "bound", clips)
+    assert all(len(b) > 1000 for b in ref)
+    for k in range(3):
+        assert ref[k] == got[k], "rung %d differs from the reference" % k
+    assert "x265hip: lookahead:" in log and "x265hip: refplanes:" in log, log[-600:]
+
+
+def test_abr_ladder_with_emulated_abi(tmp_path):
+    _abr_ladder(_need("x265_emul_8bit"), tmp_path)
+
+
+@pytest.mark.gpu
+def test_abr_ladder_on_gpu(tmp_path):
+    _abr_ladder(_need("x265_hip_8bit"), tmp_path)
