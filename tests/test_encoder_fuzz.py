@@ -28,7 +28,7 @@ def _need(name):
 
 def _check(seed, bound, tmp_path, bits=8):
     import fuzz_encoder as fz
-    r = fz.run_case(fz.draw(seed), bound, _need("x265_%dbit" % bits), str(tmp_path))
+    r = fz.run_case(fz.draw(seed), bound, _need("x265_%dbit" % bits), str(tmp_path), bits=bits)
     assert r["encoded"], "seed %d is pinned as a case the reference encodes: %s" % (seed, r)
     if "reference_timing_dependent" in r:
         pytest.skip("seed %d: the reference's own output moved under a timing perturbation with every seam off (%s)" % (seed, r["reference_timing_dependent"]))

@@ -98,3 +98,37 @@ def test_abr_ladder_with_emulated_abi(tmp_path):
 @pytest.mark.gpu
 def test_abr_ladder_on_gpu(tmp_path):
     _abr_ladder(_need("x265_hip_8bit"), tmp_path)
+
+
+def _multi_pass(bound, tmp_path):
+    """encodes that feed each other through files: analysis save -> load (reuse level 10: the second encode skips most of its own analysis and the
+    lookahead sees loaded data), and two-pass rate control (pass 2 reads pass 1's statistics)"""
+    import sys
+    sys.path.insert(0, ROOT)
+    from x265_amd.synth import make_clip
+    clip = str(tmp_path / "clip.yuv")
+    make_clip(clip, 640, 360, 12, seed=6, tile=48)
+    base = ["--input", clip, "--input-res", "640x360", "--fps", "30", "--frames", "12", "--preset", "medium", "--pools", "4", "-F", "2", "--hash", "1"]
+    outs = {}
+    for tag, exe in (("ref", _need("x265_8bit")), ("bound", bound)):
+        an, st = str(tmp_path / (tag + ".analysis")), str(tmp_path / (tag + ".stats"))
+        steps = [("save", ["--analysis-save", an, "--analysis-save-reuse-level", "10"]), ("load", ["--analysis-load", an, "--analysis-load-reuse-level", "10"]),
+                 ("pass1", ["--pass", "1", "--stats", st, "--bitrate", "500"]), ("pass2", ["--pass", "2", "--stats", st, "--bitrate", "500"])]
+        for name, extra in steps:
+            o = str(tmp_path / ("%s_%s.hevc" % (tag, name)))
+            r = subprocess.run([exe] + base + extra + ["-o", o], capture_output=True, text=True, timeout=900, env=dict(os.environ, X265HIP_VERBOSE="1", X265HIP="require"))
+            assert r.returncode == 0, r.stderr[-600:]
+            outs[(tag, name)] = open(o, "rb").read()
+        outs[(tag, "analysis")] = open(an, "rb").read()
+    for name in ("save", "load", "pass1", "pass2", "analysis"):
+        assert len(outs[("ref", name)]) > 1000
+        assert outs[("ref", name)] == outs[("bound", name)], "%s differs from the reference" % name
+
+
+def test_analysis_reuse_and_two_pass_with_emulated_abi(tmp_path):
+    _multi_pass(_need("x265_emul_8bit"), tmp_path)
+
+
+@pytest.mark.gpu
+def test_analysis_reuse_and_two_pass_on_gpu(tmp_path):
+    _multi_pass(_need("x265_hip_8bit"), tmp_path)

@@ -86,11 +86,15 @@ def draw(seed):
     return {"width": w, "height": h, "frames": frames, "csp": csp, "fade": rng.random() < 0.25, "args": args, "seed": seed}
 
 
-def run_case(case, bound_exe, ref_exe, workdir, timeout=240):
+def run_case(case, bound_exe, ref_exe, workdir, timeout=240, bits=8):
     from x265_amd.synth import make_clip
     yuv = os.path.join(workdir, "fuzz_%d.yuv" % case["seed"])
-    make_clip(yuv, case["width"], case["height"], case["frames"], seed=1000 + case["seed"], tile=48, vmax=7, fade=case["fade"], csp=case["csp"])
-    base = ["--input", yuv, "--input-res", "%dx%d" % (case["width"], case["height"]), "--input-depth", "8", "--input-csp", case["csp"], "--fps", "30",
+    # a Main10 build gets 10-bit input for every odd seed (PicYuv::copyFromPicture takes another path for 16-bit samples)
+    in_depth = 10 if bits == 10 and case["seed"] % 2 else 8
+    mk = lambda: make_clip(yuv, case["width"], case["height"], case["frames"], seed=1000 + case["seed"], tile=48, vmax=7, fade=case["fade"], csp=case["csp"],   # noqa: E731
+                           depth=in_depth)
+    mk()
+    base = ["--input", yuv, "--input-res", "%dx%d" % (case["width"], case["height"]), "--input-depth", str(in_depth), "--input-csp", case["csp"], "--fps", "30",
             "--frames", str(case["frames"]), "--hash", "1"] + case["args"]
     res = {"seed": case["seed"], "cmd": " ".join(base[2:])}
     outs = {}
@@ -122,7 +126,7 @@ def run_case(case, bound_exe, ref_exe, workdir, timeout=240):
     if not res["ok"] and res.get("bound_rc") == 0:
         # Is the REFERENCE's output a function of its input here?  The bound binary with every seam off (X265HIP=0) is the reference's code path;
         # perturb its thread timing (a sleep in FrameFilter::processPostRow) and see whether the bytes move.  If they do, the case cannot tell anything.
-        make_clip(yuv, case["width"], case["height"], case["frames"], seed=1000 + case["seed"], tile=48, vmax=7, fade=case["fade"], csp=case["csp"])
+        mk()
         try:
             for us in (500, 2000, 8000):
                 o = os.path.join(workdir, "fuzz_%d_perturbed.hevc" % case["seed"])
@@ -163,7 +167,7 @@ if __name__ == "__main__":
     results = []
     with tempfile.TemporaryDirectory() as d:
         for seed in parse_seeds(a.seeds):
-            r = run_case(draw(seed), bound, ref, d)
+            r = run_case(draw(seed), bound, ref, d, bits=a.bits)
             results.append(r)
             print("%s seed %3d  %6d B  ref %5.1fs bound %5.1fs  %s" % (("ndet" if "reference_timing_dependent" in r else "ok  " if r["encoded"] else "n/a ") if r["ok"] else "FAIL", seed, r["bytes"], r.get("ref_s", 0), r.get("bound_s", 0), r["cmd"][60:]),
                   flush=True)

@@ -29,11 +29,12 @@ def make_scene(width, height, depth=8, seed=4321, tile=96, vmax=9, sigma=3.0):
     return {"src": np.clip(np.rint(src), 0, pmax).astype(dt), "ref": np.clip(np.rint(ref), 0, pmax).astype(dt)}
 
 
-def make_clip(path, width, height, frames, seed=4321, tile=96, vmax=9, sigma=3.0, fade=False, csp="i420"):
+def make_clip(path, width, height, frames, seed=4321, tile=96, vmax=9, sigma=3.0, fade=False, csp="i420", depth=8):
     """Write an 8-bit I420 clip: a textured background whose tiles keep moving with their own constant velocity
     (half rate) + per-frame noise; chroma = 128 + 0.3 * (luma - 128) subsampled.  fade: the picture fades in from
     40 % to full brightness over the clip (weighted prediction has something to find).  csp: "i420" (default), "i422", "i444" or "i400"
-    (x265 --input-csp): how the two chroma planes are subsampled / whether they exist."""
+    (x265 --input-csp): how the two chroma planes are subsampled / whether they exist.  depth 10: 16-bit little-endian samples (x265
+    --input-depth 10), the 8-bit picture times four plus two more bits of noise."""
     rng = np.random.default_rng(seed)
     sy, sx = {"i420": (2, 2), "i422": (1, 2), "i444": (1, 1), "i400": (0, 0)}[csp]
     pad = vmax * frames // 2 + 16
@@ -52,11 +53,15 @@ def make_clip(path, width, height, frames, seed=4321, tile=96, vmax=9, sigma=3.0
             if fade:
                 luma = luma * (0.4 + 0.6 * t / max(frames - 1, 1))
             luma = np.clip(np.rint(luma + rng.normal(0, sigma, luma.shape)), 0, 255)
-            f.write(luma.astype(np.uint8).tobytes())
+            if depth == 8:
+                out = lambda a: a.astype(np.uint8).tobytes()                                      # noqa: E731
+            else:
+                out = lambda a: (a.astype(np.uint16) * 4 + rng.integers(0, 4, a.shape, dtype=np.uint16)).astype("<u2").tobytes()   # noqa: E731
+            f.write(out(luma))
             if sy:
-                c = np.clip(np.rint(128 + 0.3 * (luma[::sy, ::sx] - 128)), 0, 255).astype(np.uint8)
-                f.write(c.tobytes())
-                f.write(np.ascontiguousarray(255 - c if csp != "i420" else c).tobytes())
+                c = np.clip(np.rint(128 + 0.3 * (luma[::sy, ::sx] - 128)), 0, 255)
+                f.write(out(c))
+                f.write(out(np.ascontiguousarray(255 - c if csp != "i420" else c)))
 
 
 def chroma_of(luma, depth, gain):
