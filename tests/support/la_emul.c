@@ -34,7 +34,7 @@ struct x265hip_la
     x265hip_la_config c;
     int B, ncu;
     slot* slots;
-    void* wbuf[64];
+    void* wbuf[1024];        /* as many weighted plane sets as one batch can ask for (x265 queues up to 512 estimates) */
     int wbufsUsed;
     uint16_t* mvcost;
     uint64_t batches, estimates, searches;
@@ -64,7 +64,7 @@ void x265hip_la_destroy(x265hip_la* la)
     {
         free(la->slots[i].buffers); free(la->slots[i].intraCost); free(la->slots[i].invQscale); free(la->slots[i].store);
     }
-    for (int i = 0; i < 64; i++) free(la->wbuf[i]);
+    for (int i = 0; i < 1024; i++) free(la->wbuf[i]);
     free(la->slots); free(la->mvcost); free(la);
 }
 
@@ -108,7 +108,7 @@ int x265hip_la_weights_analyse(x265hip_la* la, int slotB, int slotRef, uint64_t 
     const x265hip_la_config* c = &la->c;
     slot* fb = &la->slots[slotB];
     slot* fr = &la->slots[slotRef];
-    if (la->wbufsUsed >= 64) { snprintf(g_err, sizeof(g_err), "emul: too many weighted references in one batch"); return X265HIP_EINVAL; }
+    if (la->wbufsUsed >= 1024) { snprintf(g_err, sizeof(g_err), "emul: too many weighted references in one batch"); return X265HIP_EINVAL; }
     if (!la->wbuf[la->wbufsUsed]) la->wbuf[la->wbufsUsed] = malloc((size_t)4 * c->planeElems * la->B);
     void* w = la->wbuf[la->wbufsUsed];
     const int paddedLines = (int)(c->planeElems / c->stride);

@@ -79,6 +79,11 @@ def draw(seed):
     args = ["--preset", preset]
     for o in picked:
         args += o
+    if h <= 64 and "--no-weightp" not in args:
+        # A picture of ONE CTU row: MotionReference::applyWeight (reference.cpp:119-123) returns before it has weighted anything
+        # (finishedRows == 0), so the reference searches a weighted plane that is uninitialised heap memory — its output then depends on
+        # the allocator's history.  Found by this fuzzer (seeds 110, 412, 440); not a test case for a binding.
+        args += ["--no-weightp"]
     ft = rng.choice([1, 2, 3, 4])
     if "--vbv-bufsize" in args:
         ft = 1          # x265 documents VBV with frame threads as non-deterministic (rate control reads row statistics as they happen to arrive)

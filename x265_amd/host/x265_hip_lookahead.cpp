@@ -23,6 +23,7 @@
 #include <cstring>
 #include <chrono>
 #include <mutex>
+#include <unistd.h>
 #include <vector>
 
 #define protected public
@@ -69,7 +70,7 @@ const int kMaxSessions = 4;        // encoders of one process that run at the sa
 Session g_sessions[kMaxSessions];
 uint64_t g_useClock = 0;
 int g_state = 0;                 // 0 = not decided, 1 = on, -1 = off
-bool g_verbose = false;
+bool g_verbose = false, g_trace = false;
 
 // totals of the sessions that were closed with their encoders (Lookahead::destroy below)
 uint64_t g_pastBatches = 0, g_pastEstimates = 0, g_pastSearches = 0, g_pastUploads = 0, g_pastWaitNs = 0;
@@ -115,6 +116,7 @@ bool enabled()
         const char* env = getenv("X265HIP_LOOKAHEAD");
         const char* all = getenv("X265HIP");
         g_verbose = getenv("X265HIP_VERBOSE") != NULL;
+        g_trace = getenv("X265HIP_DEBUG_TRACE") != NULL;
         if ((env && !strcmp(env, "0")) || (all && !strcmp(all, "0")) || x265hip_device_count() < 1)
             g_state = -1;
         else
@@ -292,6 +294,23 @@ void compute(CostEstimateGroup& g, const Job* jobs, int n, bool coop)
             fenc->intraMbs[e.dist0] += e.intraMbs;
         fenc->costEst[e.dist0][e.dist1] = score;
         fenc->costEstAq[e.dist0][e.dist1] = e.costEstAq;
+        if (g_trace)
+        {
+            // X265HIP_DEBUG_TRACE=1: one line per estimate — what was asked and what came back (sums of the arrays), for diffing two runs
+            auto sum32 = [](const int32_t* p, int n) { uint64_t h = 1469598103934665603ull; for (int k = 0; k < n; k++) { h ^= (uint32_t)p[k]; h *= 1099511628211ull; } return h; };
+            const int ncu = l.m_8x8Width * l.m_8x8Height;
+            fprintf(stderr, "x265hip-trace: b %d p0 %d p1 %d search %d%d weighted %d coop %d -> cost %lld aq %lld intra %d mvs0 %016llx mvc0 %016llx mvs1 %016llx mvc1 %016llx lc %016llx rows %016llx intraMbsAcc %d in: intraCost %016llx planes %016llx ref %016llx\n",
+                    fenc->frameNum, g.m_frames[j.p0]->frameNum, g.m_frames[j.p1]->frameNum, e.search0, e.search1, e.weightedId, (int)coop,
+                    (long long)e.costEst, (long long)e.costEstAq, e.intraMbs, (unsigned long long)sum32((const int32_t*)fenc->lowresMvs[0][e.dist0], 2 * ncu),
+                    (unsigned long long)sum32(fenc->lowresMvCosts[0][e.dist0], ncu),
+                    (unsigned long long)(j.p1 > j.b ? sum32((const int32_t*)fenc->lowresMvs[1][e.dist1], 2 * ncu) : 0),
+                    (unsigned long long)(j.p1 > j.b ? sum32(fenc->lowresMvCosts[1][e.dist1], ncu) : 0),
+                    (unsigned long long)sum32((const int32_t*)fenc->lowresCosts[e.dist0][e.dist1], ncu / 2),
+                    (unsigned long long)sum32(fenc->rowSatds[e.dist0][e.dist1], l.m_8x8Height), fenc->intraMbs[e.dist0],
+                    (unsigned long long)sum32(fenc->intraCost, ncu),
+                    (unsigned long long)sum32((const int32_t*)fenc->buffer[0], (int)((fenc->buffer[1] - fenc->buffer[0]) * sizeof(pixel) / 4)),
+                    (unsigned long long)sum32((const int32_t*)g.m_frames[j.p0]->buffer[0], (int)((fenc->buffer[1] - fenc->buffer[0]) * sizeof(pixel) / 4)));
+        }
     }
     s.waitNs += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -317,8 +336,18 @@ void Lookahead::destroy()
     refLookaheadDestroy(this);
 }
 
+// X265HIP_DEBUG_DELAY_US (see x265_hip_refplanes.cpp): the same diagnostic sleep on the lookahead's side, seams on or off — the reference's output
+// depends on how fast its lookahead is relative to its input in a few corner cases (clips shorter than the lookahead, tiny pictures)
+static void debug_delay()
+{
+    static const int delayUs = getenv("X265HIP_DEBUG_DELAY_US") ? atoi(getenv("X265HIP_DEBUG_DELAY_US")) : 0;
+    if (delayUs > 0)
+        usleep(delayUs);
+}
+
 int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, int b, bool bIntraPenalty)
 {
+    debug_delay();
     Lowres* fenc = m_frames[b];
     if (!cached(fenc, p0, p1, b) && enabled() && covered(m_lookahead, fenc))
     {
@@ -333,6 +362,7 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
 
 void CostEstimateGroup::finishBatch()
 {
+    debug_delay();
     if (m_jobTotal > 0 && enabled() && covered(m_lookahead, m_frames[m_estimates[0].b]))
     {
         std::vector<Job> jobs;
