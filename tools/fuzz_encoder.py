@@ -178,6 +178,7 @@ if __name__ == "__main__":
     ap.add_argument("--seeds", default="0-19")
     ap.add_argument("--gpu", action="store_true", help="x265_hip_8bit (needs an MI355X) instead of the emulated ABI")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--summary", default=None, help="compact summary (counts, non-cases, per-seed command and size) for profiles/")
     ap.add_argument("--bits", type=int, default=8, help="internal bit depth of the encoder build (8 or 10; the clip stays 8-bit input)")
     a = ap.parse_args()
     bound = os.path.join(REF, ("x265_hip_%dbit" if a.gpu else "x265_emul_%dbit") % a.bits)
@@ -193,4 +194,10 @@ if __name__ == "__main__":
     print("%d cases, %d encoded, %d mismatches%s" % (len(results), sum(r["encoded"] for r in results), len(bad), (": seeds " + ",".join(str(r["seed"]) for r in bad)) if bad else ""))
     if a.json:
         json.dump(results, open(a.json, "w"), indent=1)
+    if a.summary:
+        json.dump({"what": "tools/fuzz_encoder.py --seeds %s%s --bits %d: %s vs %s, byte comparison of the bitstreams" % (a.seeds, " --gpu" if a.gpu else "", a.bits, os.path.basename(ref), os.path.basename(bound)),
+                   "cases": len(results), "encoded": sum(r["encoded"] for r in results), "mismatches": [r["seed"] for r in bad],
+                   "rejected_by_reference": [r["seed"] for r in results if not r["encoded"]],
+                   "reference_timing_dependent": {str(r["seed"]): r["reference_timing_dependent"] for r in results if "reference_timing_dependent" in r},
+                   "results": [{"seed": r["seed"], "cmd": r["cmd"], "bytes": r["bytes"], "ok": r["ok"]} for r in results]}, open(a.summary, "w"), indent=0)
     sys.exit(1 if bad else 0)
