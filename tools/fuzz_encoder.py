@@ -95,7 +95,7 @@ def draw(seed):
     return {"width": w, "height": h, "frames": frames, "csp": csp, "fade": rng.random() < 0.25, "args": args, "seed": seed}
 
 
-def run_case(case, bound_exe, ref_exe, workdir, timeout=90, bits=8):
+def run_case(case, bound_exe, ref_exe, workdir, timeout=120, bits=8):
     from x265_amd.synth import make_clip
     yuv = os.path.join(workdir, "fuzz_%d.yuv" % case["seed"])
     # a Main10 build gets 10-bit input for every odd seed (PicYuv::copyFromPicture takes another path for 16-bit samples)
@@ -111,8 +111,9 @@ def run_case(case, bound_exe, ref_exe, workdir, timeout=90, bits=8):
         for tag, exe in (("ref", ref_exe), ("bound", bound_exe)):
             o = os.path.join(workdir, "fuzz_%d_%s.hevc" % (case["seed"], tag))
             t0 = time.time()
+            limit = timeout if tag == "ref" else max(timeout, 5 * res["ref_s"] + 60)     # the bound encoder gets time in proportion to the reference's
             try:
-                r = subprocess.run([exe] + base + ["-o", o], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, X265HIP_VERBOSE="1", X265HIP="require"))
+                r = subprocess.run([exe] + base + ["-o", o], capture_output=True, text=True, timeout=limit, env=dict(os.environ, X265HIP_VERBOSE="1", X265HIP="require"))
             except subprocess.TimeoutExpired:
                 r = subprocess.CompletedProcess([], -9, "", "timeout after %d s" % timeout)
             res[tag + "_s"] = round(time.time() - t0, 2)
