@@ -79,6 +79,11 @@ def draw(seed):
     args = ["--preset", preset]
     for o in picked:
         args += o
+    # the reference rejects a lookahead that is not deeper than the B-frame run — and its CLI then hangs or crashes instead of exiting
+    la_default = {"ultrafast": 5, "superfast": 10, "veryfast": 15, "faster": 15, "fast": 15, "medium": 20, "slow": 25, "slower": 40, "veryslow": 40}[preset]
+    la = int(args[args.index("--rc-lookahead") + 1]) if "--rc-lookahead" in args else la_default
+    if "--bframes" in args and la <= int(args[args.index("--bframes") + 1]):
+        args += ["--rc-lookahead", str(int(args[args.index("--bframes") + 1]) + 3)]
     if h <= 64 and "--no-weightp" not in args:
         # A picture of ONE CTU row: MotionReference::applyWeight (reference.cpp:119-123) returns before it has weighted anything
         # (finishedRows == 0), so the reference searches a weighted plane that is uninitialised heap memory — its output then depends on
