@@ -55,6 +55,14 @@ def test_random_option_set_main10_on_gpu(tmp_path, seed):
     _check(seed, _need("x265_hip_10bit"), tmp_path, bits=10)
 
 
+MAIN12_SEEDS = [700, 703, 705, 709, 713, 717, 719]
+
+
+@pytest.mark.parametrize("seed", MAIN12_SEEDS)
+def test_random_option_set_main12_with_emulated_abi(tmp_path, seed):
+    _check(seed, _need("x265_emul_12bit"), tmp_path, bits=12)
+
+
 def test_draw_is_a_pure_function_of_the_seed():
     import fuzz_encoder as fz
     assert fz.draw(7) == fz.draw(7) and fz.draw(7) != fz.draw(8)
