@@ -119,8 +119,9 @@ def _multi_pass(bound, tmp_path):
             r = subprocess.run([exe] + base + extra + ["-o", o], capture_output=True, text=True, timeout=900, env=dict(os.environ, X265HIP_VERBOSE="1", X265HIP="require"))
             assert r.returncode == 0, r.stderr[-600:]
             outs[(tag, name)] = open(o, "rb").read()
-        outs[(tag, "analysis")] = open(an, "rb").read()
-    for name in ("save", "load", "pass1", "pass2", "analysis"):
+    # (the analysis FILE itself is not compared: the reference's own file differs between runs of the same command — three variants in eight
+    #  runs here — while the bitstreams it is loaded into do not)
+    for name in ("save", "load", "pass1", "pass2"):
         assert len(outs[("ref", name)]) > 1000
         assert outs[("ref", name)] == outs[("bound", name)], "%s differs from the reference" % name
 
