@@ -188,6 +188,7 @@ if __name__ == "__main__":
     ap.add_argument("--seeds", default="0-19")
     ap.add_argument("--gpu", action="store_true", help="x265_hip_8bit (needs an MI355X) instead of the emulated ABI")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--size", default=None, help="WxH for every case instead of the drawn size (e.g. 1280x720: cooperative lookahead slices, bigger batches)")
     ap.add_argument("--summary", default=None, help="compact summary (counts, non-cases, per-seed command and size) for profiles/")
     ap.add_argument("--bits", type=int, default=8, help="internal bit depth of the encoder build (8 or 10; the clip stays 8-bit input)")
     a = ap.parse_args()
@@ -196,7 +197,11 @@ if __name__ == "__main__":
     results = []
     with tempfile.TemporaryDirectory() as d:
         for seed in parse_seeds(a.seeds):
-            r = run_case(draw(seed), bound, ref, d, bits=a.bits)
+            case = draw(seed)
+            if a.size:
+                case["width"], case["height"] = (int(v) for v in a.size.split("x"))
+                case["frames"] = min(case["frames"], 10)
+            r = run_case(case, bound, ref, d, bits=a.bits)
             results.append(r)
             print("%s seed %3d  %6d B  ref %5.1fs bound %5.1fs  %s" % (("ndet" if "reference_timing_dependent" in r else "ok  " if r["encoded"] else "n/a ") if r["ok"] else "FAIL", seed, r["bytes"], r.get("ref_s", 0), r.get("bound_s", 0), r["cmd"][60:]),
                   flush=True)
