@@ -68,6 +68,18 @@ def test_draw_is_a_pure_function_of_the_seed():
     assert fz.draw(7) == fz.draw(7) and fz.draw(7) != fz.draw(8)
     kinds = {fz.draw(s)["csp"] for s in range(60)}
     assert kinds == {"i420", "i422", "i444", "i400"}
+    # the rules that keep draws inside what the reference encodes deterministically (tools/fuzz_encoder.py explains each)
+    for s in range(1200):
+        c = fz.draw(s)
+        a = c["args"]
+        if c["height"] <= 64:
+            assert "--no-weightp" in a and ("--weightb" not in a or "--no-weightb" in a), (s, a)
+        if "--vbv-bufsize" in a:
+            assert a[a.index("-F") + 1] == "1" and "--no-wpp" in a, (s, a)
+        if "--bframes" in a:
+            la = [int(a[i + 1]) for i, w in enumerate(a) if w == "--rc-lookahead"]
+            default = {"ultrafast": 5, "superfast": 10, "veryfast": 15, "faster": 15, "fast": 15, "medium": 20, "slow": 25, "slower": 40, "veryslow": 40}[a[1]]
+            assert (la[-1] if la else default) > int(a[a.index("--bframes") + 1]), (s, a)
 
 
 @pytest.mark.gpu
