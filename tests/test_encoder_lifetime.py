@@ -26,8 +26,8 @@ def _run(exe, prefix, env=None, par=False):
     return [open("%s_%d.hevc" % (prefix, k), "rb").read() for k in range(SESSIONS)], r.stderr
 
 
-def _compare(bound, tmp_path, par=False):
-    ref, _ = _run(_need("two_encoders_ref8"), str(tmp_path / "ref"))
+def _compare(bound, tmp_path, par=False, bits=8):
+    ref, _ = _run(_need("two_encoders_ref%d" % bits), str(tmp_path / "ref"))
     got, log = _run(bound, str(tmp_path / "bound"), par=par)
     assert all(len(b) > 1000 for b in ref)
     for k in range(SESSIONS):
@@ -47,6 +47,10 @@ def test_concurrent_encoders_in_one_process_with_emulated_abi(tmp_path):
     """two, then three encoders alive at the same time (an ABR ladder's shape): one lookahead session per live encoder, mirrors and source
     entries per buffer; the outputs equal the sequential reference run's"""
     _compare(_need("two_encoders_emul8"), tmp_path, par=True)
+
+
+def test_concurrent_main10_encoders_in_one_process_with_emulated_abi(tmp_path):
+    _compare(_need("two_encoders_emul10"), tmp_path, par=True, bits=10)
 
 
 @pytest.mark.gpu
