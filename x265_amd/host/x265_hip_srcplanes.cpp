@@ -295,6 +295,29 @@ template <int N, int CU> int psy_lookup(const pixel* source, intptr_t sstride, c
 
 } // namespace
 
+// x265_hip_sadplanes.cpp (MotionEstimate::setSourcePU): which source picture buffer, and where in it, does this thread's source cache `y` hold?
+// *pic / *version name the picture (a buffer is reused for later pictures: the version tells them apart), (*x, *y) the luma position of the
+// cache's first sample.  false: not a source cache this thread filled through the seams below.
+bool x265hip_srcplanes_where(const Yuv& y, const PicYuv** pic, uint32_t* version, int* px, int* py)
+{
+    if (g_state <= 0)
+        return false;
+    for (int i = 0; i < kMaps; i++)
+    {
+        const CacheMap& m = t_map[i];
+        if (m.buf[0] && m.buf[0] == y.m_buf[0] && m.size == y.m_size)
+        {
+            if (m.sp->version.load(std::memory_order_relaxed) != m.version)
+                return false;
+            *pic = m.sp->pic.load(std::memory_order_relaxed);
+            *version = m.version;
+            *px = m.x; *py = m.y;
+            return *pic != NULL;
+        }
+    }
+    return false;
+}
+
 // called by setupAssemblyPrimitives in the default table mode, after the C table is complete
 void x265hip_install_psy_slots(EncoderPrimitives& p)
 {
