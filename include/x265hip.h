@@ -521,7 +521,8 @@ typedef struct x265hip_lookahead_pair
     const int32_t* invQscale;    /* [ncu] Lowres::invQscaleFactor (invQscaleFactor8x8 for qg-size 8) of the frame being costed, or NULL: no AQ */
     int32_t        bidirList;    /* 0: P frame (everything above).  1: one list of a B frame: the search applies the bidir skip rule
                                     (slicetype.cpp:3303-3317) and only mvs / mvCosts are written; finish with x265hip_lookahead_bidir_batch */
-    int32_t        reserved;
+    int32_t        sliceGeom;    /* 0: the launch's numRowsPerSlice / numSlices.  Otherwise numRowsPerSlice | numSlices << 16 of THIS pair: estimates of
+                                    different cooperative-slice geometries (batch mode = 1 slice, single estimates = m_numCoopSlices) share a launch */
 } x265hip_lookahead_pair;
 int x265hip_lookahead_cost_p_batch(int depth, const x265hip_lookahead_pair* pairs, int nPairs, int64_t stride, int64_t planeElems,
                                    int widthInCU, int heightInCU, int numRowsPerSlice, int numSlices,
@@ -603,7 +604,31 @@ typedef struct x265hip_la_estimate
 /* numRowsPerSlice / numSlices: the cooperative-slice geometry the reference would use for these estimates (1 slice of heightInCU rows in
  * batch mode, m_numCoopSlices otherwise, :3141-3180) */
 int x265hip_la_estimate_batch(x265hip_la* la, x265hip_la_estimate* est, int n, int numRowsPerSlice, int numSlices);
+/* Searches AHEAD of the reference's request.  One list search of estimateCUCost — the vectors and vector costs of (frame b, list, dist) —
+ * is a function of the two frames (plus the list-0 weights), of whether it runs inside a P or a B estimate (`bidir`: the zero-vector skip rule,
+ * slicetype.cpp:3303-3317) and of the cooperative-slice geometry (a slice's last row has no row below, :3274-3281).  x265 asks for most of
+ * them one at a time (slicetypePathCost / scenecut / cuTree -> singleCost), which leaves the device > 90 % empty; a binding that can see
+ * which searches are still missing in the lookahead window hands them over WITH a batch that has to run anyway, each tagged with the variant
+ * the reference will ask for.  They ride in the same lookahead_p_kernel launch; their results stay in the session, keyed by
+ * (slot, list, dist, bidir, geometry).  A later estimate that needs exactly that search (search0 / search1 set, same variant, and — list 0 —
+ * the same weighting decision, which is a function of the frame pair too) is served from there: no search launch, the vectors are copied
+ * to the estimate's outputs as if it had searched.  Anything never asked for is simply dropped with the slot.  Exact by construction.
+ * weightedId: as in x265hip_la_estimate (list 0 only). */
+typedef struct x265hip_la_search
+{
+    int32_t b, ref;                  /* slots: the frame and the reference of this list */
+    int32_t list, dist;              /* 0 / 1; |b - ref| in frames */
+    int32_t bidir;                   /* 0: as inside a P estimate, 1: as inside a B estimate */
+    int32_t weightedId;              /* -1, or x265hip_la_weights_analyse's id (list 0) */
+    int32_t numRowsPerSlice, numSlices;
+} x265hip_la_search;
+int x265hip_la_estimate_batch_ahead(x265hip_la* la, x265hip_la_estimate* est, int n, int numRowsPerSlice, int numSlices,
+                                    const x265hip_la_search* ahead, int nAhead);
+/* 1 when the session holds that search ahead of its request (so the binding can skip the weights analysis that would precede it) */
+int x265hip_la_has_ahead(x265hip_la* la, int slot, int list, int dist, int bidir, int numRowsPerSlice, int numSlices);
 int x265hip_la_stats(x265hip_la* la, uint64_t* batches, uint64_t* estimates, uint64_t* searches);
+/* searches launched ahead of their request / of those, how many an estimate later used / lookahead_p_kernel launches / pairs in them */
+int x265hip_la_stats_ahead(x265hip_la* la, uint64_t* launchedAhead, uint64_t* usedAhead, uint64_t* searchLaunches, uint64_t* searchPairs);
 
 /* ---------------------------------------------------------------- reference-picture mirrors (lookup face) --------- */
 /* The sub-pel filters the encoder applies to a reference picture (luma_hpp / luma_vpp / luma_hvpp from MotionEstimate::subpelCompare,

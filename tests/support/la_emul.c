@@ -27,6 +27,9 @@ typedef struct slot
     int32_t* store;        /* [2][maxDist][3 ncu] */
     uint8_t  valid[2 * 18];
     int      live, hasInvQ;
+    int32_t* ahead;        /* [2][maxDist][4][3 ncu]: searches done ahead of their request (x265hip_la_search) */
+    uint8_t  aheadValid[2 * 18 * 4];
+    int32_t  aheadRows[2 * 18 * 4], aheadSlices[2 * 18 * 4];
 } slot;
 
 struct x265hip_la
@@ -37,7 +40,7 @@ struct x265hip_la
     void* wbuf[1024];        /* as many weighted plane sets as one batch can ask for (x265 queues up to 512 estimates) */
     int wbufsUsed;
     uint16_t* mvcost;
-    uint64_t batches, estimates, searches;
+    uint64_t batches, estimates, searches, aheadLaunched, aheadUsed, searchLaunches, searchPairs;
 };
 
 static char g_err[256] = "";
@@ -63,6 +66,7 @@ void x265hip_la_destroy(x265hip_la* la)
     for (int i = 0; i < la->c.numSlots; i++)
     {
         free(la->slots[i].buffers); free(la->slots[i].intraCost); free(la->slots[i].invQscale); free(la->slots[i].store);
+        free(la->slots[i].ahead);
     }
     for (int i = 0; i < 1024; i++) free(la->wbuf[i]);
     free(la->slots); free(la->mvcost); free(la);
@@ -82,6 +86,7 @@ int x265hip_la_set_frame(x265hip_la* la, int slotIdx, const void* buffers, const
     s->hasInvQ = invQscale != NULL;
     if (invQscale) memcpy(s->invQscale, invQscale, cb);
     memset(s->valid, 0, sizeof(s->valid));
+    memset(s->aheadValid, 0, sizeof(s->aheadValid));
     s->live = 1;
     return 0;
 }
@@ -134,10 +139,59 @@ int x265hip_la_weights_analyse(x265hip_la* la, int slotB, int slotRef, uint64_t 
     return 0;
 }
 
-int x265hip_la_estimate_batch(x265hip_la* la, x265hip_la_estimate* est, int n, int numRowsPerSlice, int numSlices)
+static int ahead_index(const x265hip_la* la, int list, int dist, int bidir, int slices) { return ((list * la->c.maxDist + dist) * 2 + (bidir ? 1 : 0)) * 2 + (slices > 1 ? 1 : 0); }
+static int32_t* ahead_of(x265hip_la* la, slot* s, int idx)
+{
+    if (!s->ahead) s->ahead = (int32_t*)calloc((size_t)2 * la->c.maxDist * 4 * 3 * la->ncu, 4);
+    return s->ahead + (size_t)idx * 3 * la->ncu;
+}
+
+int x265hip_la_has_ahead(x265hip_la* la, int slotIdx, int list, int dist, int bidir, int numRowsPerSlice, int numSlices)
+{
+    const slot* s = &la->slots[slotIdx];
+    const int idx = ahead_index(la, list, dist, bidir, numSlices);
+    return s->live && s->aheadValid[idx] && s->aheadRows[idx] == numRowsPerSlice && s->aheadSlices[idx] == numSlices;
+}
+
+/* one list search in the variant asked for, into dst ([3 ncu]); the oracle's P / B passes with only that list searched */
+static void search_ahead(x265hip_la* la, const x265hip_la_search* a, int32_t* dst)
 {
     const x265hip_la_config* c = &la->c;
     const int ncu = la->ncu, W = c->widthInCU, H = c->heightInCU;
+    slot* fb = &la->slots[a->b];
+    const void* refbuf = (!a->list && a->weightedId >= 0) ? la->wbuf[a->weightedId] : la->slots[a->ref].buffers;
+    uint16_t* lc = (uint16_t*)malloc((size_t)ncu * 2); int32_t* rs = (int32_t*)malloc((size_t)H * 4);
+    int32_t* other = (int32_t*)calloc((size_t)ncu * 3, 4);
+    int32_t intraMbs = 0; int64_t aq = 0;
+#define AHEAD(T, SFX) do { \
+        const T* r[4]; PLANES(T, refbuf, r); \
+        const T* fenc = (const T*)fb->buffers + c->padOffset; \
+        if (!a->bidir) \
+            orc_lookahead_cost_p_aq_##SFX(fenc, r, c->stride, W, H, a->numRowsPerSlice, a->numSlices, c->depth, fb->intraCost, la->mvcost + 2 * 32768, \
+                                          dst, dst + 2 * ncu, lc, rs, &intraMbs, NULL, 1, &aq); \
+        else \
+        { \
+            const int32_t ds[2] = { !a->list, a->list }; \
+            orc_lookahead_cost_b_aq_##SFX(fenc, r, r, c->stride, W, H, a->numRowsPerSlice, a->numSlices, c->depth, la->mvcost + 2 * 32768, ds, \
+                                          a->list ? other : dst, (a->list ? other : dst) + 2 * ncu, a->list ? dst : other, (a->list ? dst : other) + 2 * ncu, \
+                                          lc, rs, NULL, NULL); \
+        } } while (0)
+    if (c->depth == 8) AHEAD(uint8_t, 8); else AHEAD(uint16_t, 16);
+#undef AHEAD
+    free(lc); free(rs); free(other);
+}
+
+int x265hip_la_estimate_batch(x265hip_la* la, x265hip_la_estimate* est, int n, int numRowsPerSlice, int numSlices)
+{
+    return x265hip_la_estimate_batch_ahead(la, est, n, numRowsPerSlice, numSlices, NULL, 0);
+}
+
+int x265hip_la_estimate_batch_ahead(x265hip_la* la, x265hip_la_estimate* est, int n, int numRowsPerSlice, int numSlices,
+                                    const x265hip_la_search* ahead, int nAhead)
+{
+    const x265hip_la_config* c = &la->c;
+    const int ncu = la->ncu, W = c->widthInCU, H = c->heightInCU;
+    int anySearch = 0;
     for (int i = 0; i < n; i++)
     {
         x265hip_la_estimate* q = &est[i];
@@ -151,18 +205,28 @@ int x265hip_la_estimate_batch(x265hip_la* la, x265hip_la_estimate* est, int n, i
             snprintf(g_err, sizeof(g_err), "emul: estimate %d reuses vectors the session has not seen", i);
             return X265HIP_EINVAL;
         }
-        const void* ref0buf = q->weightedId >= 0 ? la->wbuf[q->weightedId] : la->slots[q->p0].buffers;
+        /* searched ahead of this request in the same variant: the vectors are the search's result (the device copies them the same way) */
+        int served0 = 0, served1 = 0;
+        for (int l = 0; l < (bidir ? 2 : 1); l++)
+        {
+            const int dist = l ? q->dist1 : q->dist0;
+            if (!(l ? q->search1 : q->search0) || !x265hip_la_has_ahead(la, q->b, l, dist, bidir, numRowsPerSlice, numSlices)) continue;
+            memcpy(l ? st1 : st0, ahead_of(la, fb, ahead_index(la, l, dist, bidir, numSlices)), (size_t)ncu * 12);
+            if (l) served1 = 1; else served0 = 1;
+            la->aheadUsed++;
+        }
+        const void* ref0buf = q->weightedId >= 0 && !served0 ? la->wbuf[q->weightedId] : la->slots[q->p0].buffers;
         int64_t aq = 0;
         int32_t intraMbs = 0;
         int64_t cost;
-        const int32_t ds[2] = { q->search0, q->search1 };
+        const int32_t ds[2] = { q->search0 && !served0, q->search1 && !served1 };
 #define RUN(T, SFX) do { \
             const T* r0[4]; const T* r0u[4]; const T* r1[4]; \
             PLANES(T, ref0buf, r0); PLANES(T, la->slots[q->p0].buffers, r0u); PLANES(T, la->slots[q->p1].buffers, r1); \
             const T* fenc = (const T*)fb->buffers + c->padOffset; \
             if (!bidir) \
                 cost = orc_lookahead_cost_p_aq_##SFX(fenc, r0, c->stride, W, H, numRowsPerSlice, numSlices, c->depth, fb->intraCost, la->mvcost + 2 * 32768, \
-                                                     st0, st0 + 2 * ncu, q->lowresCosts, q->rowSatds, &intraMbs, invQ, q->search0, &aq); \
+                                                     st0, st0 + 2 * ncu, q->lowresCosts, q->rowSatds, &intraMbs, invQ, ds[0], &aq); \
             else \
             { \
                 /* list 0 searches the weighted planes when there are any; the bi-predictive candidates use the unweighted ones (slicetype.cpp:3322): \
@@ -185,15 +249,28 @@ int x265hip_la_estimate_batch(x265hip_la* la, x265hip_la_estimate* est, int n, i
         } while (0)
         if (c->depth == 8) RUN(uint8_t, 8); else RUN(uint16_t, 16);
 #undef RUN
-        if (q->search0) { memcpy(q->mvs0, st0, (size_t)ncu * 8); memcpy(q->mvCosts0, st0 + 2 * ncu, (size_t)ncu * 4); fb->valid[q->dist0] = 1; la->searches++; }
-        if (bidir && q->search1) { memcpy(q->mvs1, st1, (size_t)ncu * 8); memcpy(q->mvCosts1, st1 + 2 * ncu, (size_t)ncu * 4); fb->valid[c->maxDist + q->dist1] = 1; la->searches++; }
+        if (q->search0) { memcpy(q->mvs0, st0, (size_t)ncu * 8); memcpy(q->mvCosts0, st0 + 2 * ncu, (size_t)ncu * 4); fb->valid[q->dist0] = 1; la->searches += !served0; }
+        if (bidir && q->search1) { memcpy(q->mvs1, st1, (size_t)ncu * 8); memcpy(q->mvCosts1, st1 + 2 * ncu, (size_t)ncu * 4); fb->valid[c->maxDist + q->dist1] = 1; la->searches += !served1; }
+        if (ds[0] || ds[1]) { anySearch = 1; la->searchPairs += ds[0] + ds[1]; }
         q->costEst = cost;
         q->costEstAq = aq;
         q->intraMbs = bidir ? 0 : intraMbs;
     }
+    for (int j = 0; j < nAhead; j++)
+    {
+        const x265hip_la_search* a = &ahead[j];
+        slot* fb = &la->slots[a->b];
+        const int idx = ahead_index(la, a->list, a->dist, a->bidir, a->numSlices);
+        if (fb->valid[a->list * c->maxDist + a->dist] || (fb->aheadValid[idx] && fb->aheadRows[idx] == a->numRowsPerSlice && fb->aheadSlices[idx] == a->numSlices))
+            continue;
+        search_ahead(la, a, ahead_of(la, fb, idx));
+        fb->aheadValid[idx] = 1; fb->aheadRows[idx] = a->numRowsPerSlice; fb->aheadSlices[idx] = a->numSlices;
+        la->aheadLaunched++; la->searchPairs++; anySearch = 1;
+    }
     la->wbufsUsed = 0;
-    la->batches++;
+    la->batches += n > 0;
     la->estimates += n;
+    la->searchLaunches += anySearch;
     return 0;
 }
 
@@ -202,6 +279,15 @@ int x265hip_la_stats(x265hip_la* la, uint64_t* batches, uint64_t* estimates, uin
     if (batches) *batches = la->batches;
     if (estimates) *estimates = la->estimates;
     if (searches) *searches = la->searches;
+    return 0;
+}
+
+int x265hip_la_stats_ahead(x265hip_la* la, uint64_t* launchedAhead, uint64_t* usedAhead, uint64_t* searchLaunches, uint64_t* searchPairs)
+{
+    if (launchedAhead) *launchedAhead = la->aheadLaunched;
+    if (usedAhead) *usedAhead = la->aheadUsed;
+    if (searchLaunches) *searchLaunches = la->searchLaunches;
+    if (searchPairs) *searchPairs = la->searchPairs;
     return 0;
 }
 

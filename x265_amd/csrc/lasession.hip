@@ -28,6 +28,10 @@ struct LaSlot
     int32_t* store = nullptr;        // [2][maxDist][3 * ncu]: mvs (2 ncu) then mvCosts (ncu)
     bool     live = false, hasInvQ = false;
     std::vector<uint8_t> valid;      // [2 * maxDist]
+    // searches done ahead of their request (x265hip_la_search): [2][maxDist][4 variants = bidir * 2 + (numSlices > 1)][3 * ncu], allocated on first use
+    int32_t* ahead = nullptr;
+    struct AheadInfo { uint8_t valid = 0; int32_t rows = 0, slices = 0; };
+    std::vector<AheadInfo> aheadInfo; // [2 * maxDist * 4]
 };
 
 struct ScatterJob { const int32_t* src; int32_t* dst; };
@@ -51,6 +55,7 @@ struct x265hip_la
     uint64_t* dSync = nullptr;                                               // [2 capEst][ncu]
     char* dDesc = nullptr; char* hDesc = nullptr; size_t descBytes = 0;     // pairs / pcost pairs / bframes / scatter jobs
     uint64_t statBatches = 0, statEstimates = 0, statSearches = 0;
+    uint64_t statAheadLaunched = 0, statAheadUsed = 0, statSearchLaunches = 0, statSearchPairs = 0;
 };
 
 namespace xh {
@@ -83,7 +88,7 @@ static int la_grow(x265hip_la* la, int n)
     la->dOut = la->hOut = la->dDesc = la->hDesc = nullptr; la->dSync = nullptr; la->capEst = 0;
     const size_t blk = est_block_bytes(la);
     la->outBytes = blk * cap + (size_t)cap * 3 * 4 * sizeof(int64_t);        // + est words of the three kernels
-    la->descBytes = (size_t)cap * (2 * sizeof(x265hip_lookahead_pair) + sizeof(x265hip_lookahead_pair) + sizeof(x265hip_lookahead_bframe) + 2 * sizeof(ScatterJob));
+    la->descBytes = (size_t)cap * (2 * sizeof(x265hip_lookahead_pair) + sizeof(x265hip_lookahead_pair) + sizeof(x265hip_lookahead_bframe) + 4 * sizeof(ScatterJob));
     int e;
     if ((e = check_hip(hipMalloc((void**)&la->dOut, la->outBytes), "la out"))) return e;
     if ((e = check_hip(hipHostMalloc((void**)&la->hOut, la->outBytes, hipHostMallocDefault), "la out pinned"))) return e;
@@ -107,6 +112,12 @@ static inline int32_t* store_of(const x265hip_la* la, const LaSlot& s, int list,
     return s.store + ((size_t)list * la->cfg.maxDist + dist) * 3 * la->ncu;
 }
 
+static inline int ahead_index(const x265hip_la* la, int list, int dist, int bidir, int slices)
+{
+    return ((list * la->cfg.maxDist + dist) * 2 + (bidir ? 1 : 0)) * 2 + (slices > 1 ? 1 : 0);
+}
+static inline int32_t* ahead_of(const x265hip_la* la, const LaSlot& s, int idx) { return s.ahead + (size_t)idx * 3 * la->ncu; }
+
 } // namespace xh
 
 using namespace xh;
@@ -129,7 +140,7 @@ x265hip_la* x265hip_la_create(const x265hip_la_config* cfg)
     la->ncu = cfg->widthInCU * cfg->heightInCU;
     (void)hipGetDevice(&la->device);
     la->slots.resize(cfg->numSlots);
-    for (auto& s : la->slots) s.valid.assign(2 * cfg->maxDist, 0);
+    for (auto& s : la->slots) { s.valid.assign(2 * cfg->maxDist, 0); s.aheadInfo.assign(2 * cfg->maxDist * 4, xh::LaSlot::AheadInfo()); }
     bool ok = hipStreamCreateWithFlags(&la->st, hipStreamNonBlocking) == hipSuccess;
     // BitCost row of the lookahead QP (X265_LOOKAHEAD_QP = 12 + 6 * (depth - 8), common.h:232)
     std::vector<uint16_t> tab(2 * kMvcostHalf + 1);
@@ -156,6 +167,7 @@ void x265hip_la_destroy(x265hip_la* la)
         if (s.intraCost) (void)hipFree(s.intraCost);
         if (s.invQscale) (void)hipFree(s.invQscale);
         if (s.store) (void)hipFree(s.store);
+        if (s.ahead) (void)hipFree(s.ahead);
     }
     for (char* w : la->wbufs) (void)hipFree(w);
     if (la->mvcost) (void)hipFree(la->mvcost);
@@ -191,6 +203,7 @@ int x265hip_la_set_frame(x265hip_la* la, int slot, const void* buffers, const in
     // the caller's arrays are pageable and may change after we return
     if ((e = check_hip(hipStreamSynchronize(la->st), "la set_frame sync"))) return e;
     std::fill(s.valid.begin(), s.valid.end(), 0);            // Lowres::init resets every search (lowres.cpp:289-295)
+    std::fill(s.aheadInfo.begin(), s.aheadInfo.end(), LaSlot::AheadInfo());
     s.live = true;
     return X265HIP_OK;
 }
@@ -249,14 +262,30 @@ int x265hip_la_weights_analyse(x265hip_la* la, int slotB, int slotRef, uint64_t 
 
 int x265hip_la_estimate_batch(x265hip_la* la, x265hip_la_estimate* est, int n, int numRowsPerSlice, int numSlices)
 {
+    return x265hip_la_estimate_batch_ahead(la, est, n, numRowsPerSlice, numSlices, nullptr, 0);
+}
+
+int x265hip_la_has_ahead(x265hip_la* la, int slot, int list, int dist, int bidir, int numRowsPerSlice, int numSlices)
+{
+    if (!la || slot < 0 || slot >= (int)la->slots.size() || list < 0 || list > 1 || dist < 1 || dist >= la->cfg.maxDist) return 0;
+    std::lock_guard<std::mutex> g(la->lock);
+    const LaSlot& s = la->slots[slot];
+    const LaSlot::AheadInfo& a = s.aheadInfo[ahead_index(la, list, dist, bidir, numSlices)];
+    return s.live && a.valid && a.rows == numRowsPerSlice && a.slices == numSlices;
+}
+
+int x265hip_la_estimate_batch_ahead(x265hip_la* la, x265hip_la_estimate* est, int n, int numRowsPerSlice, int numSlices,
+                                    const x265hip_la_search* ahead, int nAhead)
+{
     int e = la_enter(la);
     if (e) return e;
-    if (n < 0 || (n && !est) || numSlices < 1 || numRowsPerSlice < 1 || (long long)numRowsPerSlice * (numSlices - 1) >= la->cfg.heightInCU)
-        return set_error(X265HIP_EINVAL, "x265hip_la_estimate_batch: n %d slices %d x %d", n, numSlices, numRowsPerSlice);
+    if (n < 0 || (n && !est) || nAhead < 0 || (nAhead && !ahead) || numSlices < 1 || numRowsPerSlice < 1 ||
+        (long long)numRowsPerSlice * (numSlices - 1) >= la->cfg.heightInCU)
+        return set_error(X265HIP_EINVAL, "x265hip_la_estimate_batch: n %d ahead %d slices %d x %d", n, nAhead, numSlices, numRowsPerSlice);
     std::lock_guard<std::mutex> g(la->lock);
     struct Release { x265hip_la* l; ~Release() { l->wbufsUsed = 0; } } release{ la };
-    if (!n) return X265HIP_OK;
-    if ((e = la_grow(la, n))) return e;
+    if (!n && !nAhead) return X265HIP_OK;
+    if ((e = la_grow(la, n + nAhead))) return e;
     const x265hip_la_config& c = la->cfg;
     const int ncu = la->ncu, H = c.heightInCU, W = c.widthInCU, B = la->B;
     const size_t blk = est_block_bytes(la);
@@ -264,13 +293,20 @@ int x265hip_la_estimate_batch(x265hip_la* la, x265hip_la_estimate* est, int n, i
     x265hip_lookahead_pair* hPairs = (x265hip_lookahead_pair*)la->hDesc;                      // [2 cap] searches
     x265hip_lookahead_pair* hPcost = hPairs + 2 * la->capEst;                                 // [cap]
     x265hip_lookahead_bframe* hBf = (x265hip_lookahead_bframe*)(hPcost + la->capEst);         // [cap]
-    ScatterJob* hSc = (ScatterJob*)(hBf + la->capEst);                                        // [2 cap]
+    ScatterJob* hSc = (ScatterJob*)(hBf + la->capEst);                                        // [4 cap]
     auto dev_of = [&](const void* h) { return la->dDesc + ((const char*)h - la->hDesc); };
     // est words live in the tail of dOut (3 * cap * 4 int64 reserved): [nPairs][4] search pairs, then [nPcost][4], then [nBf][2]; the worst
-    // case (all B, both lists searched) is 8 + 2 words per estimate
+    // case (all B, both lists searched, + the searches ahead) is 8 + 2 words per estimate and 4 per search ahead
     int64_t* dEstSearch = (int64_t*)(la->dOut + blk * la->capEst);
     int nPairs = 0, nPcost = 0, nBf = 0, nSc = 0;
     std::vector<int> pairOfEst(n, -1), pcostOfEst(n, -1), bfOfEst(n, -1);
+    // vectors this call produces: they become visible to later calls (valid[] / aheadInfo[]) only after the final synchronise succeeded, and
+    // a later estimate of THIS call that reuses them reads the producer's block directly (the slot store is filled by the scatter at the end)
+    struct Produced { int slot, list, dist; const int32_t* where; };
+    std::vector<Produced> produced;
+    struct AheadDone { int slot, idx, rows, slices; };
+    std::vector<AheadDone> aheadDone;
+    auto slice_geom = [&](int rows, int slices) { return (rows == numRowsPerSlice && slices == numSlices) ? 0 : (rows | slices << 16); };
     for (int i = 0; i < n; i++)
     {
         x265hip_la_estimate& q = est[i];
@@ -289,16 +325,32 @@ int x265hip_la_estimate_batch(x265hip_la* la, x265hip_la_estimate* est, int n, i
         const char* fencOrg = fb.buffers + c.padOffset * B;
         const int32_t* invQ = fb.hasInvQ ? fb.invQscale : nullptr;
         const int32_t* useMvs[2] = { nullptr, nullptr };
+        bool searchedHere0 = false;
         for (int l = 0; l < (bidir ? 2 : 1); l++)
         {
             const int dist = l ? q.dist1 : q.dist0, search = l ? q.search1 : q.search0;
             int32_t* st = store_of(la, fb, l, dist);
             if (!search)
             {
-                if (!fb.valid[l * c.maxDist + dist])
+                const int32_t* where = fb.valid[l * c.maxDist + dist] ? st : nullptr;
+                for (const Produced& pr : produced)
+                    if (pr.slot == q.b && pr.list == l && pr.dist == dist) where = pr.where;
+                if (!where)
                     return set_error(X265HIP_EINVAL, "x265hip_la_estimate_batch: estimate %d reuses list %d distance %d which the session has not seen "
                                      "(x265hip_la_put_vectors)", i, l, dist);
-                useMvs[l] = st;
+                useMvs[l] = where;
+                continue;
+            }
+            const LaSlot::AheadInfo& ai = fb.aheadInfo[ahead_index(la, l, dist, bidir, numSlices)];
+            if (fb.ahead && ai.valid && ai.rows == numRowsPerSlice && ai.slices == numSlices)
+            {
+                // searched ahead of this request, same variant: the estimate gets the vectors as if it had searched
+                const int32_t* src = ahead_of(la, fb, ahead_index(la, l, dist, bidir, numSlices));
+                useMvs[l] = src;
+                hSc[nSc].src = src; hSc[nSc].dst = st; nSc++;
+                hSc[nSc].src = src; hSc[nSc].dst = oMvs[l]; nSc++;
+                produced.push_back(Produced{ q.b, l, dist, src });
+                la->statAheadUsed++;
                 continue;
             }
             const LaSlot& fr = la->slots[l ? q.p1 : q.p0];
@@ -315,13 +367,13 @@ int x265hip_la_estimate_batch(x265hip_la* la, x265hip_la_estimate* est, int n, i
             p.sync = la->dSync + (size_t)nPairs * ncu;
             p.invQscale = invQ;
             p.bidirList = bidir ? 1 : 0;
-            if (!bidir) pairOfEst[i] = nPairs;
+            if (!bidir) { pairOfEst[i] = nPairs; searchedHere0 = true; }
             nPairs++;
             useMvs[l] = oMvs[l];
             hSc[nSc].src = oMvs[l];
             hSc[nSc].dst = st;
             nSc++;
-            fb.valid[l * c.maxDist + dist] = 1;
+            produced.push_back(Produced{ q.b, l, dist, oMvs[l] });
             la->statSearches++;
         }
         if (bidir)
@@ -337,7 +389,7 @@ int x265hip_la_estimate_batch(x265hip_la* la, x265hip_la_estimate* est, int n, i
             f.invQscale = invQ;
             bfOfEst[i] = nBf++;
         }
-        else if (!q.search0)
+        else if (!searchedHere0)
         {
             x265hip_lookahead_pair& p = hPcost[nPcost];
             memset(&p, 0, sizeof(p));
@@ -349,6 +401,42 @@ int x265hip_la_estimate_batch(x265hip_la* la, x265hip_la_estimate* est, int n, i
             pcostOfEst[i] = nPcost++;
         }
     }
+    // the searches ahead: same kernel, same launch; vectors go straight into the slot's ahead store, the rest of a pair's outputs into a scratch block
+    for (int j = 0; j < nAhead; j++)
+    {
+        const x265hip_la_search& a = ahead[j];
+        if (a.b < 0 || a.b >= (int)la->slots.size() || a.ref < 0 || a.ref >= (int)la->slots.size() || !la->slots[a.b].live || !la->slots[a.ref].live ||
+            a.list < 0 || a.list > 1 || a.dist < 1 || a.dist >= c.maxDist || a.numSlices < 1 || a.numRowsPerSlice < 1 || a.numRowsPerSlice > 0xffff ||
+            a.numSlices > 0x7fff || (long long)a.numRowsPerSlice * (a.numSlices - 1) >= H || a.weightedId >= la->wbufsUsed || (a.weightedId >= 0 && a.list))
+            return set_error(X265HIP_EINVAL, "x265hip_la_estimate_batch: search ahead %d (b %d ref %d list %d dist %d)", j, a.b, a.ref, a.list, a.dist);
+        LaSlot& fb = la->slots[a.b];
+        const int idx = ahead_index(la, a.list, a.dist, a.bidir, a.numSlices);
+        if (fb.valid[a.list * c.maxDist + a.dist] || (fb.aheadInfo[idx].valid && fb.aheadInfo[idx].rows == a.numRowsPerSlice && fb.aheadInfo[idx].slices == a.numSlices))
+            continue;                          // already there
+        bool dup = false;
+        for (const AheadDone& d : aheadDone) dup = dup || (d.slot == a.b && d.idx == idx);
+        if (dup) continue;
+        if (!fb.ahead && (e = check_hip(hipMalloc((void**)&fb.ahead, (size_t)2 * c.maxDist * 4 * 3 * ncu * 4), "la slot searches ahead"))) return e;
+        char* scratchBlk = la->dOut + blk * (n + j);
+        int32_t* oRows = (int32_t*)scratchBlk + 6 * ncu;
+        int32_t* dst = ahead_of(la, fb, idx);
+        x265hip_lookahead_pair& p = hPairs[nPairs];
+        memset(&p, 0, sizeof(p));
+        p.fenc = fb.buffers + c.padOffset * B;
+        p.ref = ((!a.list && a.weightedId >= 0) ? la->wbufs[a.weightedId] : la->slots[a.ref].buffers) + c.padOffset * B;
+        p.intraCost = fb.intraCost;
+        p.mvs = dst;
+        p.mvCosts = dst + 2 * ncu;
+        p.lowresCosts = (uint16_t*)(oRows + H);
+        p.rowSatds = oRows;
+        p.sync = la->dSync + (size_t)nPairs * ncu;
+        p.invQscale = fb.hasInvQ ? fb.invQscale : nullptr;
+        p.bidirList = a.bidir ? 1 : 0;
+        p.sliceGeom = slice_geom(a.numRowsPerSlice, a.numSlices);
+        nPairs++;
+        aheadDone.push_back(AheadDone{ a.b, idx, a.numRowsPerSlice, a.numSlices });
+        la->statAheadLaunched++;
+    }
     int64_t* dEstPcost = dEstSearch + (size_t)nPairs * 4;
     int64_t* dEstBf = dEstPcost + (size_t)nPcost * 4;
     if ((e = check_hip(hipMemcpyAsync(la->dDesc, la->hDesc, la->descBytes, hipMemcpyHostToDevice, la->st), "la desc h2d"))) return e;
@@ -358,9 +446,14 @@ int x265hip_la_estimate_batch(x265hip_la* la, x265hip_la_estimate* est, int n, i
         if ((e = check_hip(hipMemsetAsync(la->dSync, 0, (size_t)2 * la->capEst * ncu * sizeof(uint64_t), la->st), "la sync zero"))) return e;
         la->epoch = 1;
     }
-    if (nPairs && (e = x265hip_lookahead_cost_p_batch(c.depth, (const x265hip_lookahead_pair*)dev_of(hPairs), nPairs, c.stride, c.planeElems, W, H, numRowsPerSlice,
-                                                      numSlices, la->mvcost + kMvcostHalf, la->epoch, dEstSearch, la->st)))
-        return e;
+    if (nPairs)
+    {
+        if ((e = x265hip_lookahead_cost_p_batch(c.depth, (const x265hip_lookahead_pair*)dev_of(hPairs), nPairs, c.stride, c.planeElems, W, H, numRowsPerSlice,
+                                                numSlices, la->mvcost + kMvcostHalf, la->epoch, dEstSearch, la->st)))
+            return e;
+        la->statSearchLaunches++;
+        la->statSearchPairs += nPairs;
+    }
     if (nPcost && (e = x265hip_lookahead_pcost_batch((const x265hip_lookahead_pair*)dev_of(hPcost), nPcost, W, H, dEstPcost, la->st)))
         return e;
     if (nBf && (e = x265hip_lookahead_bidir_batch(c.depth, (const x265hip_lookahead_bframe*)dev_of(hBf), nBf, c.stride, c.planeElems, W, H, dEstBf, la->st)))
@@ -371,7 +464,7 @@ int x265hip_la_estimate_batch(x265hip_la* la, x265hip_la_estimate* est, int n, i
         XH_LAUNCH_CHECK("la_scatter_kernel");
     }
     const size_t used = blk * n, estWords = (size_t)(nPairs + nPcost) * 4 + (size_t)nBf * 2;
-    if ((e = check_hip(hipMemcpyAsync(la->hOut, la->dOut, used, hipMemcpyDeviceToHost, la->st), "la out d2h"))) return e;
+    if (used && (e = check_hip(hipMemcpyAsync(la->hOut, la->dOut, used, hipMemcpyDeviceToHost, la->st), "la out d2h"))) return e;
     if ((e = check_hip(hipMemcpyAsync(la->hOut + blk * la->capEst, dEstSearch, estWords * 8, hipMemcpyDeviceToHost, la->st), "la est d2h"))) return e;
     if ((e = check_hip(hipStreamSynchronize(la->st), "la batch sync"))) return e;
     const int64_t* hEst = (const int64_t*)(la->hOut + blk * la->capEst);
@@ -380,6 +473,14 @@ int x265hip_la_estimate_batch(x265hip_la* la, x265hip_la_estimate* est, int n, i
     for (int i = 0; i < nPairs; i++)
         if (hEst[4 * i + 3])
             return set_error(X265HIP_EHIP, "x265hip_la_estimate_batch: row handshake of search %d timed out", i);
+    // everything arrived: the produced vectors are now the session's
+    for (const Produced& pr : produced)
+        la->slots[pr.slot].valid[pr.list * c.maxDist + pr.dist] = 1;
+    for (const AheadDone& d : aheadDone)
+    {
+        LaSlot::AheadInfo& ai = la->slots[d.slot].aheadInfo[d.idx];
+        ai.valid = 1; ai.rows = d.rows; ai.slices = d.slices;
+    }
     for (int i = 0; i < n; i++)
     {
         x265hip_la_estimate& q = est[i];
@@ -405,7 +506,7 @@ int x265hip_la_estimate_batch(x265hip_la* la, x265hip_la_estimate* est, int n, i
             q.intraMbs = (int32_t)w[2];
         }
     }
-    la->statBatches++;
+    if (n) la->statBatches++;
     la->statEstimates += n;
     return X265HIP_OK;
 }
@@ -417,6 +518,17 @@ int x265hip_la_stats(x265hip_la* la, uint64_t* batches, uint64_t* estimates, uin
     if (batches) *batches = la->statBatches;
     if (estimates) *estimates = la->statEstimates;
     if (searches) *searches = la->statSearches;
+    return X265HIP_OK;
+}
+
+int x265hip_la_stats_ahead(x265hip_la* la, uint64_t* launchedAhead, uint64_t* usedAhead, uint64_t* searchLaunches, uint64_t* searchPairs)
+{
+    if (!la) return set_error(X265HIP_EINVAL, "x265hip_la_stats_ahead: null session");
+    std::lock_guard<std::mutex> g(la->lock);
+    if (launchedAhead) *launchedAhead = la->statAheadLaunched;
+    if (usedAhead) *usedAhead = la->statAheadUsed;
+    if (searchLaunches) *searchLaunches = la->statSearchLaunches;
+    if (searchPairs) *searchPairs = la->statSearchPairs;
     return X265HIP_OK;
 }
 

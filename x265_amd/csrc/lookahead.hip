@@ -147,6 +147,12 @@ __global__ __launch_bounds__(64) void lookahead_p_kernel(const LaPair* __restric
     const int cuY = H - 1 - (k % H);
     const LaPair pr = pairs[pairIdx];
     const bool bidirList = pr.bidirList != 0;
+    if (pr.sliceGeom)
+    {
+        // this pair's own cooperative-slice geometry (x265hip_lookahead_pair::sliceGeom): batch-mode and single estimates share a launch
+        rowsPerSlice = pr.sliceGeom & 0xffff;
+        numSlices = pr.sliceGeom >> 16;
+    }
     int slice = cuY / rowsPerSlice;
     if (slice > numSlices - 1) slice = numSlices - 1;
     const int lastY = slice == numSlices - 1 ? H - 1 : rowsPerSlice * (slice + 1) - 1;

@@ -163,7 +163,10 @@ PROTOTYPES = {
     "x265hip_la_has_vectors": (i32, [vp, i32, i32, i32]),
     "x265hip_la_weights_analyse": (i32, [vp, i32, i32, u64, u64, u64, u64, vp, vp, vp]),
     "x265hip_la_estimate_batch": (i32, [vp, vp, i32, i32, i32]),
+    "x265hip_la_estimate_batch_ahead": (i32, [vp, vp, i32, i32, i32, vp, i32]),
+    "x265hip_la_has_ahead": (i32, [vp, i32, i32, i32, i32, i32, i32]),
     "x265hip_la_stats": (i32, [vp, vp, vp, vp]),
+    "x265hip_la_stats_ahead": (i32, [vp, vp, vp, vp, vp]),
     "x265hip_source_energy": (i32, [i32, vp, i64, i32, i32, vp, vp]),
     "x265hip_refpic_create": (vp, [i32, i32, i32, i64, i32, i32, i32, vp]),
     "x265hip_refpic_destroy": (None, [vp]),
@@ -207,7 +210,7 @@ class WeightParam(C.Structure):
 class LookaheadPair(C.Structure):
     """x265hip_lookahead_pair (include/x265hip.h)"""
     _fields_ = [("fenc", vp), ("ref", vp), ("intraCost", vp), ("mvs", vp), ("mvCosts", vp), ("lowresCosts", vp), ("rowSatds", vp), ("sync", vp),
-                ("invQscale", vp), ("bidirList", C.c_int32), ("reserved", C.c_int32)]
+                ("invQscale", vp), ("bidirList", C.c_int32), ("sliceGeom", C.c_int32)]
 
 
 class LaConfig(C.Structure):
@@ -221,6 +224,12 @@ class LaEstimate(C.Structure):
     _fields_ = [("b", C.c_int32), ("p0", C.c_int32), ("p1", C.c_int32), ("dist0", C.c_int32), ("dist1", C.c_int32), ("search0", C.c_int32),
                 ("search1", C.c_int32), ("weightedId", C.c_int32), ("mvs0", vp), ("mvCosts0", vp), ("mvs1", vp), ("mvCosts1", vp), ("lowresCosts", vp),
                 ("rowSatds", vp), ("costEst", C.c_int64), ("costEstAq", C.c_int64), ("intraMbs", C.c_int32), ("reserved", C.c_int32)]
+
+
+class LaSearch(C.Structure):
+    """x265hip_la_search (include/x265hip.h): a list search handed over ahead of the reference's request"""
+    _fields_ = [("b", C.c_int32), ("ref", C.c_int32), ("list", C.c_int32), ("dist", C.c_int32), ("bidir", C.c_int32), ("weightedId", C.c_int32),
+                ("numRowsPerSlice", C.c_int32), ("numSlices", C.c_int32)]
 
 
 class LookaheadBFrame(C.Structure):

@@ -71,9 +71,11 @@ Session g_sessions[kMaxSessions];
 uint64_t g_useClock = 0;
 int g_state = 0;                 // 0 = not decided, 1 = on, -1 = off
 bool g_verbose = false, g_trace = false;
+bool g_ahead = true;             // X265HIP_LOOKAHEAD_AHEAD=0: no searches ahead of the reference's requests (for A/B measurements)
 
 // totals of the sessions that were closed with their encoders (Lookahead::destroy below)
 uint64_t g_pastBatches = 0, g_pastEstimates = 0, g_pastSearches = 0, g_pastUploads = 0, g_pastWaitNs = 0;
+uint64_t g_pastAhead[4] = { 0, 0, 0, 0 };      // x265hip_la_stats_ahead: launched ahead, used, search launches, pairs in them
 
 void retire_session(Session& s)
 {
@@ -81,6 +83,9 @@ void retire_session(Session& s)
         return;
     uint64_t batches = 0, estimates = 0, searches = 0;
     x265hip_la_stats(s.la, &batches, &estimates, &searches);
+    uint64_t ah[4] = { 0, 0, 0, 0 };
+    x265hip_la_stats_ahead(s.la, &ah[0], &ah[1], &ah[2], &ah[3]);
+    for (int i = 0; i < 4; i++) g_pastAhead[i] += ah[i];
     g_pastBatches += batches; g_pastEstimates += estimates; g_pastSearches += searches; g_pastUploads += s.uploads; g_pastWaitNs += s.waitNs;
     x265hip_la_destroy(s.la);
     s.la = NULL;
@@ -93,13 +98,16 @@ void retire_session(Session& s)
 void report()
 {
     uint64_t batches = g_pastBatches, estimates = g_pastEstimates, searches = g_pastSearches, uploads = g_pastUploads, waitNs = g_pastWaitNs;
+    uint64_t ahead[4] = { g_pastAhead[0], g_pastAhead[1], g_pastAhead[2], g_pastAhead[3] };
     bool any = batches != 0;
     for (Session& s : g_sessions)
         if (s.la)
         {
-            uint64_t b = 0, e = 0, m = 0;
+            uint64_t b = 0, e = 0, m = 0, ah[4] = { 0, 0, 0, 0 };
             x265hip_la_stats(s.la, &b, &e, &m);
+            x265hip_la_stats_ahead(s.la, &ah[0], &ah[1], &ah[2], &ah[3]);
             batches += b; estimates += e; searches += m; uploads += s.uploads; waitNs += s.waitNs;
+            for (int i = 0; i < 4; i++) ahead[i] += ah[i];
             any = true;
         }
     if (!any)
@@ -107,6 +115,8 @@ void report()
     fprintf(stderr, "x265hip: lookahead: %llu frame-cost estimates (%llu motion-search passes over %llu lowres frames) served by the GPU in %llu batches, %.3f s inside the seam\n",
             (unsigned long long)estimates, (unsigned long long)searches, (unsigned long long)uploads, (unsigned long long)batches,
             waitNs * 1e-9);
+    fprintf(stderr, "x265hip: lookahead: %llu searches launched ahead of their request, %llu of them used; %llu search launches of %.1f (frame, reference) pairs on average\n",
+            (unsigned long long)ahead[0], (unsigned long long)ahead[1], (unsigned long long)ahead[2], ahead[2] ? (double)ahead[3] / ahead[2] : 0.0);
 }
 
 bool enabled()
@@ -117,6 +127,8 @@ bool enabled()
         const char* all = getenv("X265HIP");
         g_verbose = getenv("X265HIP_VERBOSE") != NULL;
         g_trace = getenv("X265HIP_DEBUG_TRACE") != NULL;
+        const char* ahead = getenv("X265HIP_LOOKAHEAD_AHEAD");
+        g_ahead = !(ahead && !strcmp(ahead, "0"));
         if ((env && !strcmp(env, "0")) || (all && !strcmp(all, "0")) || x265hip_device_count() < 1)
             g_state = -1;
         else
@@ -221,6 +233,82 @@ int slot_of(Session& s, const Lookahead& l, const Lowres* f)
 
 struct Job { int p0, p1, b; };
 
+// Searches the reference has not asked for yet but, by the shape of its own control flow, will: slicetypeAnalyse batches the list-0 searches of
+// frames 2 .. numFrames-1 and the list-1 search at the SAME distance when that frame already exists (slicetype.cpp:1942-1968); every other search —
+// list 1 of a frame whose partner arrived later, list 0 of the first and of the newest frame — is asked for one estimate at a time from
+// slicetypePathCost / scenecut / slicetypeDecide (singleCost -> estimateFrameCost), which runs cooperative slices (:3141-3166).  Each of those is
+// a function of the two frames, of the P / B flavour and of the slice geometry only (x265hip_la_search), so it can ride along with a launch that
+// happens anyway and be picked up when the request comes.  Frames are taken from the group's own NULL-terminated array (slicetype.cpp:1408-1411).
+const int kMaxAhead = 160;
+void plan_ahead(Session& s, CostEstimateGroup& g, const Job* jobs, int n, const std::vector<x265hip_la_estimate>& est, std::vector<x265hip_la_search>& out)
+{
+    const Lookahead& l = g.m_lookahead;
+    const x265_param* param = l.m_param;
+    int lo = jobs[0].p0, hi = jobs[0].p1;
+    for (int i = 0; i < n; i++)
+    {
+        lo = X265_MIN(lo, jobs[i].p0);
+        hi = X265_MAX(hi, X265_MAX(jobs[i].p1, jobs[i].b));
+    }
+    const int bound = X265_LOOKAHEAD_MAX + X265_BFRAME_MAX + 2;          // the array has bound + 2 entries, zero-filled behind the last frame
+    while (hi + 1 <= bound && g.m_frames[hi + 1])
+        hi++;
+    const int coopSlices = X265_MAX(1, l.m_numCoopSlices), coopRows = coopSlices > 1 ? l.m_numRowsPerSlice : l.m_8x8Height;
+    auto real = [&](int b, int list, int dist) {
+        for (int i = 0; i < n; i++)
+            if (jobs[i].b == b && (list ? (est[i].search1 && est[i].dist1 == dist) : (est[i].search0 && est[i].dist0 == dist)))
+                return true;
+        return false;
+    };
+    for (int b = X265_MAX(lo, 1); b <= hi && (int)out.size() < kMaxAhead; b++)
+    {
+        Lowres* fenc = g.m_frames[b];
+        if (!covered(l, fenc))
+            return;
+        int slotB = -1;
+        for (int dist = 1; dist <= param->bframes + 1; dist++)
+        {
+            // list 1 (B flavour only): the partner frame exists now
+            if (dist <= param->bframes && b + dist <= hi && fenc->lowresMvs[1][dist][0].x == 0x7FFF && !real(b, 1, dist))
+            {
+                if (slotB < 0) slotB = slot_of(s, l, fenc);
+                if (!x265hip_la_has_ahead(s.la, slotB, 1, dist, 1, coopRows, coopSlices))
+                {
+                    x265hip_la_search a = { slotB, slot_of(s, l, g.m_frames[b + dist]), 1, dist, 1, -1, coopRows, coopSlices };
+                    out.push_back(a);
+                }
+            }
+            // list 0: with batched motion searches only the frames the batch leaves out (the first and the newest); both flavours otherwise
+            const bool batched = l.m_bBatchMotionSearch && b != 1 && b != hi;
+            if (b - dist >= lo && g.m_frames[b - dist] && !batched && fenc->lowresMvs[0][dist][0].x == 0x7FFF && !real(b, 0, dist))
+            {
+                if (slotB < 0) slotB = slot_of(s, l, fenc);
+                const int slotR = slot_of(s, l, g.m_frames[b - dist]);
+                int weightedId = -2;
+                for (int bidir = 0; bidir <= (l.m_bBatchMotionSearch ? 0 : 1); bidir++)
+                {
+                    if (x265hip_la_has_ahead(s.la, slotB, 0, dist, bidir, coopRows, coopSlices))
+                        continue;
+                    if (weightedId == -2)
+                    {
+                        weightedId = -1;
+                        if (param->bEnableWeightedPred)
+                        {
+                            x265hip_weight_param chosen;
+                            int isWeighted = 0;
+                            Lowres* ref0 = g.m_frames[b - dist];
+                            if (x265hip_la_weights_analyse(s.la, slotB, slotR, fenc->wp_ssd[0], fenc->wp_sum[0], ref0->wp_ssd[0], ref0->wp_sum[0], &chosen, &isWeighted, &weightedId))
+                                die("weights analysis (ahead)");
+                        }
+                    }
+                    x265hip_la_search a = { slotB, slotR, 0, dist, bidir, weightedId, coopRows, coopSlices };
+                    out.push_back(a);
+                }
+            }
+        }
+    }
+}
+
 // the missing results of `jobs` on the device, left in the Lowres arrays exactly as estimateCUCost leaves them (slicetype.cpp:3129-3207)
 void compute(CostEstimateGroup& g, const Job* jobs, int n, bool coop)
 {
@@ -248,7 +336,8 @@ void compute(CostEstimateGroup& g, const Job* jobs, int n, bool coop)
         e.search1 = j.p1 > j.b && fenc->lowresMvs[1][e.dist1][0].x == 0x7FFF;
         e.weightedId = -1;
         fenc->weightedRef[e.dist0].isWeighted = false;
-        if (param->bEnableWeightedPred && e.search0)
+        const int estRows = coop ? l.m_numRowsPerSlice : l.m_8x8Height, estSlices = coop ? l.m_numCoopSlices : 1;
+        if (param->bEnableWeightedPred && e.search0 && !x265hip_la_has_ahead(s.la, e.b, 0, e.dist0, j.p1 != j.b, estRows, estSlices))
         {
             x265hip_weight_param chosen;
             int isWeighted = 0;
@@ -280,7 +369,10 @@ void compute(CostEstimateGroup& g, const Job* jobs, int n, bool coop)
         rows = l.m_numRowsPerSlice;
         slices = l.m_numCoopSlices;
     }
-    if (x265hip_la_estimate_batch(s.la, est.data(), n, rows, slices))
+    std::vector<x265hip_la_search> ahead;
+    if (g_ahead)
+        plan_ahead(s, g, jobs, n, est, ahead);
+    if (x265hip_la_estimate_batch_ahead(s.la, est.data(), n, rows, slices, ahead.data(), (int)ahead.size()))
         die("estimate batch");
     for (int i = 0; i < n; i++)
     {
