@@ -661,6 +661,51 @@ int x265hip_refpic_wait(x265hip_refpic* rp);        /* blocks until the worker h
  * encoder.  x265_amd/host/x265_hip_srcplanes.cpp serves cu[].psy_cost_pp from them. */
 int x265hip_source_energy(int depth, const void* hostPlane, int64_t stride, int width, int height, int32_t* hostE8, int32_t* hostE4);
 
+/* ---------------------------------------------------------------- SAD surfaces (lookup face) ----------------------- */
+/* The integer-pel candidates of MotionEstimate::motionEstimate are sad(fenc, FENC_STRIDE, fref + mx + my * stride, stride) (motion.cpp:246-330
+ * macros; HEX :770-944, STAR :1132-1240) with fenc a copy of the SOURCE picture's PU (setSourcePU, :194-222) and fref the finished reference
+ * picture at the PU's position (:752-756).  Which candidates a search visits depends on the decisions before it; what a candidate costs does
+ * not — it is a function of (source picture, reference picture, position, vector).  A sadsurf holds those values for every aligned N x N block
+ * (N = 8 << level) of one (source picture, reference picture) pair over a WIN x WIN window of vectors per block, built on the device as the
+ * reference picture's rows become final, and mirrored into page-locked host memory; x265_amd/host/x265_hip_sadplanes.cpp swaps a
+ * MotionEstimate's sad / sad_x3 / sad_x4 pointers for table loads while the search of a covered PU runs.
+ * Where a block's window lies is decided on the device, per 64 x 64 region top down over the block sizes 64, 32, 16: every vector of
+ * [-searchRange, searchRange)^2 that keeps the block inside the padded reference picture is measured (the search-window kernel: source CTU and
+ * reference window staged in LDS, 16x16 SADs of all candidates by v_qsad_pk_u16_u8 kept in LDS, folded to 32 / 64), the cheapest by
+ * SAD + (lambda20 * (bits(4 |vx - px|) + bits(4 |vy - py|)) + 10) / 20 (bits(d) = 2 floor(log2(d + 1)) + 1; p = the parent block's best vector,
+ * (0, 0) at the top; ties: smaller vy, then smaller vx) is the block's best, and its window starts at best - WIN / 2, clamped into the range
+ * and into the padded picture.  That choice only decides how many lookups hit — every entry is the exact SAD, and a vector outside the window is
+ * computed by the C function as before.  lambda20 = 20 x the encoder's lambda (SAD units per bit of vector cost). */
+#define X265HIP_SADSURF_WIN 16
+#define X265HIP_SADSURF_LEVELS 4
+typedef struct x265hip_srcpic x265hip_srcpic;        /* the luma plane of a source picture, resident on the device */
+x265hip_srcpic* x265hip_srcpic_create(int depth, int width, int height);
+int x265hip_srcpic_upload(x265hip_srcpic* sp, const void* hostLuma, int64_t stride);          /* blocks until the copy is on the device */
+void x265hip_srcpic_destroy(x265hip_srcpic* sp);
+typedef struct x265hip_sadsurf x265hip_sadsurf;
+typedef struct x265hip_sadsurf_level
+{
+    int32_t        blocksX, blocksY;     /* width / N, height / N (blocks that lie inside the picture) */
+    int32_t        entryBytes;           /* 2 (uint16: N * N * pixel max < 65536) or 4 (uint32) */
+    int32_t        reserved;
+    const int16_t* origin;               /* [blocksY * blocksX][2]: the vector (ox, oy) of window entry (0, 0), full-pel; NULL: level not built */
+    const void*    table;                /* [blocksY * blocksX][WIN * WIN]: entry j * WIN + i = SAD against the reference at vector (ox + i, oy + j) */
+} x265hip_sadsurf_level;
+typedef struct x265hip_sadsurf_view
+{
+    x265hip_sadsurf_level level[X265HIP_SADSURF_LEVELS];
+    const int* ctuRowsReady;             /* rows of 64 picture lines: origins and tables of every block above line 64 * (*ctuRowsReady) are in host
+                                            memory (load with acquire semantics); grows as the reference picture's rows become final */
+} x265hip_sadsurf_view;
+/* Levels 1..3 (N = 16, 32, 64) are built; level 0 is reserved (origin == NULL).  searchRange: 8..32, a multiple of 4.  The surface follows `ref`'s progress (x265hip_refpic_rows_final) by itself: rows that are
+ * final already are built at once, the others as they arrive; x265hip_refpic_reset / _destroy of `ref` ends it (no further rows are published;
+ * the handle stays valid until it is released).  `src` must stay unchanged and alive until the release.  NULL on failure. */
+x265hip_sadsurf* x265hip_sadsurf_attach(x265hip_srcpic* src, x265hip_refpic* ref, int searchRange, int lambda20);
+const x265hip_sadsurf_view* x265hip_sadsurf_get_view(x265hip_sadsurf* ss);
+void x265hip_sadsurf_release(x265hip_sadsurf* ss);
+/* per process: surfaces attached, CTU rows built, device time is in the profiles */
+int x265hip_sadsurf_stats(uint64_t* attached, uint64_t* ctuRows);
+
 /* ---------------------------------------------------------------- per-call entry points (host pointers) ----- */
 /* What the reference-side table shims bind (x265_amd/host/x265_hip_primitives.cpp).  Arguments are the slot's own
  * arguments (HOST pointers, caller-owned, valid only during the call — primitives.h:133-234); each call stages the

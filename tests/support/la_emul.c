@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 #include "../../include/x265hip.h"
 #include "../../oracle/x265_oracle.h"
 
@@ -302,7 +303,11 @@ struct x265hip_refpic
     char* planes;        /* 15 planes */
     int phaseDone;       /* buffer rows */
     int rowsReady;
+    int rowsFinal;       /* picture rows the caller declared final (the whole padded picture once >= picH) */
+    struct x265hip_sadsurf* surfaces;      /* attached SAD surfaces (singly linked) */
 };
+static void sadsurf_progress(struct x265hip_sadsurf* ss);
+static void sadsurf_detach_all(x265hip_refpic* rp);
 
 x265hip_refpic* x265hip_refpic_create(int depth, int picW, int picH, int64_t stride, int marginX, int marginY, int bufRows, const void* hostBase)
 {
@@ -314,15 +319,25 @@ x265hip_refpic* x265hip_refpic_create(int depth, int picW, int picH, int64_t str
     rp->rowsReady = -(1 << 30);
     return rp;
 }
-void x265hip_refpic_destroy(x265hip_refpic* rp) { if (rp) { free(rp->planes); free(rp); } }
-int x265hip_refpic_reset(x265hip_refpic* rp) { rp->phaseDone = 4; __atomic_store_n(&rp->rowsReady, -(1 << 30), __ATOMIC_RELEASE); return 0; }
+void x265hip_refpic_destroy(x265hip_refpic* rp) { if (rp) { sadsurf_detach_all(rp); free(rp->planes); free(rp); } }
+int x265hip_refpic_reset(x265hip_refpic* rp)
+{
+    sadsurf_detach_all(rp);
+    rp->phaseDone = 4; rp->rowsFinal = 0;
+    __atomic_store_n(&rp->rowsReady, -(1 << 30), __ATOMIC_RELEASE);
+    return 0;
+}
 const void* x265hip_refpic_plane(x265hip_refpic* rp, int phase) { return rp->planes + (size_t)(phase - 1) * rp->planeElems * rp->B; }
 int x265hip_refpic_rows_ready(x265hip_refpic* rp) { return __atomic_load_n(&rp->rowsReady, __ATOMIC_ACQUIRE); }
 const int* x265hip_refpic_rows_ready_ptr(x265hip_refpic* rp) { return &rp->rowsReady; }
 int x265hip_refpic_wait(x265hip_refpic* rp) { (void)rp; return 0; }
 
+static void sadsurf_progress_all(x265hip_refpic* rp);
+
 int x265hip_refpic_rows_final(x265hip_refpic* rp, int rowsFinal)
 {
+    if (rowsFinal > rp->rowsFinal) rp->rowsFinal = rowsFinal;
+    sadsurf_progress_all(rp);
     const int complete = rowsFinal >= rp->picH;
     const int finalRows = complete ? rp->marginY + rp->picH + rp->marginY : rp->marginY + rowsFinal;
     const int phaseEnd = finalRows - 4;
@@ -380,5 +395,154 @@ int x265hip_source_energy(int depth, const void* hostPlane, int64_t stride, int 
             if (depth == 8) ENERGY(uint8_t, 8); else ENERGY(uint16_t, 16);
 #undef ENERGY
         }
+    return 0;
+}
+
+
+/* ---------------------------------------------------------------- SAD surfaces, emulated ------------------------------------------------- *
+ * Synchronous: attach() and the reference picture's rows_final() build every CTU row whose reference rows are final with the oracle
+ * (oracle/x265_oracle_sadsurf.inc) before they return.  Same contract as the device implementation otherwise. */
+void orc_sadsurf_rows_8(const uint8_t* src, intptr_t srcStride, const uint8_t* ref, intptr_t refStride, int picW, int picH, int marginX, int marginY,
+                        int S, int lambda20, int row0, int row1, int16_t* const origin[4], uint32_t* const table[4]);
+void orc_sadsurf_rows_16(const uint16_t* src, intptr_t srcStride, const uint16_t* ref, intptr_t refStride, int picW, int picH, int marginX, int marginY,
+                         int S, int lambda20, int row0, int row1, int16_t* const origin[4], uint32_t* const table[4]);
+
+struct x265hip_srcpic { int depth, B, w, h; char* luma; };
+
+x265hip_srcpic* x265hip_srcpic_create(int depth, int width, int height)
+{
+    x265hip_srcpic* sp = (x265hip_srcpic*)calloc(1, sizeof(*sp));
+    sp->depth = depth; sp->B = depth == 8 ? 1 : 2; sp->w = width; sp->h = height;
+    sp->luma = (char*)malloc((size_t)width * height * sp->B);
+    return sp;
+}
+int x265hip_srcpic_upload(x265hip_srcpic* sp, const void* hostLuma, int64_t stride)
+{
+    for (int y = 0; y < sp->h; y++)
+        memcpy(sp->luma + (size_t)y * sp->w * sp->B, (const char*)hostLuma + (size_t)y * stride * sp->B, (size_t)sp->w * sp->B);
+    return 0;
+}
+void x265hip_srcpic_destroy(x265hip_srcpic* sp) { if (sp) { free(sp->luma); free(sp); } }
+
+struct x265hip_sadsurf
+{
+    x265hip_srcpic* src;
+    x265hip_refpic* ref;                 /* NULL once the reference picture has gone (reset / destroy) */
+    struct x265hip_sadsurf* next;
+    int S, lambda20, levelMask, ctuRows, ctuRowsReady;
+    uint32_t* wide[X265HIP_SADSURF_LEVELS];      /* the oracle's uint32 tables (the views narrow them where the ABI says uint16) */
+    x265hip_sadsurf_view view;
+    int16_t* origin[X265HIP_SADSURF_LEVELS];
+    void* table[X265HIP_SADSURF_LEVELS];
+};
+static uint64_t g_ssAttached, g_ssRows;
+
+static void sadsurf_progress(x265hip_sadsurf* ss)
+{
+    x265hip_refpic* rp = ss->ref;
+    if (!rp) return;
+    const int complete = rp->rowsFinal >= rp->picH;
+    while (ss->ctuRowsReady < ss->ctuRows)
+    {
+        const int r = ss->ctuRowsReady;
+        if (!complete && 64 * (r + 1) + ss->S > rp->rowsFinal)      /* the lowest reference line a candidate of this row touches */
+            break;
+        const char* refOrg = rp->hostBase + ((size_t)rp->marginY * rp->stride + rp->marginX) * rp->B;
+        if (rp->depth == 8)
+            orc_sadsurf_rows_8((const uint8_t*)ss->src->luma, ss->src->w, (const uint8_t*)refOrg, rp->stride, rp->picW, rp->picH, rp->marginX, rp->marginY,
+                               ss->S, ss->lambda20, r, r + 1, ss->origin, ss->wide);
+        else
+            orc_sadsurf_rows_16((const uint16_t*)ss->src->luma, ss->src->w, (const uint16_t*)refOrg, rp->stride, rp->picW, rp->picH, rp->marginX, rp->marginY,
+                                ss->S, ss->lambda20, r, r + 1, ss->origin, ss->wide);
+        for (int l = 1; l < X265HIP_SADSURF_LEVELS; l++)
+        {
+            const int log2n = 3 + l;
+            const int bx = ss->src->w >> log2n, byTotal = ss->src->h >> log2n;
+            int by0 = (64 * r) >> log2n, by1 = (64 * (r + 1)) >> log2n;
+            if (by1 > byTotal) by1 = byTotal;
+            if (ss->view.level[l].entryBytes == 2)
+                for (size_t i = (size_t)by0 * bx * 256; i < (size_t)by1 * bx * 256; i++)
+                    ((uint16_t*)ss->table[l])[i] = (uint16_t)ss->wide[l][i];
+        }
+        g_ssRows++;
+        __atomic_store_n(&ss->ctuRowsReady, r + 1, __ATOMIC_RELEASE);
+    }
+}
+
+/* rows_final() runs on the encoder's frame-filter threads, attach() / release() on its analysis threads: one lock around the lists (the device
+ * implementation serialises the same operations on its worker thread) */
+static pthread_mutex_t g_ssLock = PTHREAD_MUTEX_INITIALIZER;
+static void sadsurf_progress_all(x265hip_refpic* rp)
+{
+    pthread_mutex_lock(&g_ssLock);
+    for (x265hip_sadsurf* s = rp->surfaces; s; s = s->next) sadsurf_progress(s);
+    pthread_mutex_unlock(&g_ssLock);
+}
+static void sadsurf_detach_all(x265hip_refpic* rp)
+{
+    pthread_mutex_lock(&g_ssLock);
+    for (x265hip_sadsurf* s = rp->surfaces; s; )
+    {
+        x265hip_sadsurf* n = s->next;
+        s->ref = NULL; s->next = NULL;
+        s = n;
+    }
+    rp->surfaces = NULL;
+    pthread_mutex_unlock(&g_ssLock);
+}
+
+x265hip_sadsurf* x265hip_sadsurf_attach(x265hip_srcpic* src, x265hip_refpic* ref, int searchRange, int lambda20)
+{
+    const int levelMask = 14;
+    if (!src || !ref || src->depth != ref->depth || src->w != ref->picW || src->h != ref->picH || searchRange < 8 || searchRange > 32 || (searchRange & 3) ||
+        lambda20 < 0 || lambda20 > (1 << 20))
+    {
+        snprintf(g_err, sizeof(g_err), "emul: sadsurf_attach: mismatched pictures or range %d", searchRange);
+        return NULL;
+    }
+    x265hip_sadsurf* ss = (x265hip_sadsurf*)calloc(1, sizeof(*ss));
+    ss->src = src; ss->ref = ref; ss->S = searchRange; ss->lambda20 = lambda20; ss->levelMask = levelMask;
+    ss->ctuRows = (src->h + 63) / 64;
+    for (int l = 0; l < X265HIP_SADSURF_LEVELS; l++)
+    {
+        if (!(ss->levelMask >> l & 1)) continue;
+        const int log2n = 3 + l, N = 1 << log2n;
+        x265hip_sadsurf_level* v = &ss->view.level[l];
+        v->blocksX = src->w >> log2n; v->blocksY = src->h >> log2n;
+        v->entryBytes = (uint64_t)N * N * ((1u << src->depth) - 1) < 65536 ? 2 : 4;
+        const size_t nb = (size_t)v->blocksX * v->blocksY;
+        ss->origin[l] = (int16_t*)calloc(nb ? nb : 1, 4);
+        ss->wide[l] = (uint32_t*)calloc(nb ? nb : 1, (size_t)256 * 4);
+        ss->table[l] = v->entryBytes == 4 ? (void*)ss->wide[l] : calloc(nb ? nb : 1, (size_t)256 * 2);
+        v->origin = ss->origin[l]; v->table = ss->table[l];
+    }
+    ss->view.ctuRowsReady = &ss->ctuRowsReady;
+    pthread_mutex_lock(&g_ssLock);
+    ss->next = ref->surfaces;
+    ref->surfaces = ss;
+    g_ssAttached++;
+    sadsurf_progress(ss);
+    pthread_mutex_unlock(&g_ssLock);
+    return ss;
+}
+const x265hip_sadsurf_view* x265hip_sadsurf_get_view(x265hip_sadsurf* ss) { return ss ? &ss->view : NULL; }
+void x265hip_sadsurf_release(x265hip_sadsurf* ss)
+{
+    if (!ss) return;
+    pthread_mutex_lock(&g_ssLock);
+    if (ss->ref)
+    {
+        x265hip_sadsurf** pp = &ss->ref->surfaces;
+        while (*pp && *pp != ss) pp = &(*pp)->next;
+        if (*pp) *pp = ss->next;
+    }
+    pthread_mutex_unlock(&g_ssLock);
+    for (int l = 0; l < X265HIP_SADSURF_LEVELS; l++) { free(ss->origin[l]); if (ss->table[l] != (void*)ss->wide[l]) free(ss->table[l]); free(ss->wide[l]); }
+    free(ss);
+}
+int x265hip_sadsurf_stats(uint64_t* attached, uint64_t* ctuRows)
+{
+    if (attached) *attached = g_ssAttached;
+    if (ctuRows) *ctuRows = g_ssRows;
     return 0;
 }

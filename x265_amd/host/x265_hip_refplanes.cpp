@@ -58,6 +58,7 @@ struct Mirror
     // writer side (frame filter threads)
     std::mutex lock;
     int poc;
+    std::atomic<uint32_t> generation;   // bumped whenever the buffer starts a new picture (x265_hip_sadplanes.cpp keys its surfaces on it)
     bool tracking;              // the picture now in the buffer is a reference picture whose rows we publish
     uint64_t rowDone[4];        // CTU rows whose processPostRow has run (slices may finish out of order)
     int prefix;                 // CTU rows [0, prefix) are done
@@ -238,6 +239,27 @@ template <int W, int H, int PART> void hvpp_lookup(const pixel* s, intptr_t ss, 
         p.pu[LUMA_ ## W ## x ## H].luma_hvpp = hvpp_lookup<W, H, LUMA_ ## W ## x ## H>; \
     } while (0)
 
+// x265_hip_sadplanes.cpp: the device mirror of the reconstructed picture in `recon` and the generation of the picture it holds now
+x265hip_refpic* x265hip_refplanes_device(const PicYuv* recon, uint32_t* generation)
+{
+    if (g_state <= 0)
+        return NULL;
+    const pixel* lo = recon->m_picBuf[0];
+    const int n = g_count.load(std::memory_order_acquire);
+    for (int i = 0; i < n; i++)
+        if (__atomic_load_n(&g_mirror[i].lo, __ATOMIC_ACQUIRE) == lo)
+        {
+            *generation = g_mirror[i].generation.load(std::memory_order_acquire);
+            return g_mirror[i].tracking ? g_mirror[i].rp : NULL;
+        }
+    return NULL;
+}
+bool x265hip_refplanes_current(const PicYuv* recon, uint32_t generation)
+{
+    uint32_t g = 0;
+    return x265hip_refplanes_device(recon, &g) && g == generation;
+}
+
 // PicYuv::destroy (x265_hip_srcplanes.cpp): the buffer at `lo` is about to be freed.  Its mirror must stop answering for that address range
 // before malloc can hand it to anybody else; nobody reads a picture that is being destroyed, so no reader is inside the entry.
 void x265hip_refplanes_retire(const pixel* lo)
@@ -256,6 +278,7 @@ void x265hip_refplanes_retire(const pixel* lo)
             m.rowsReady = NULL;
             m.tracking = false;
             m.poc = -1;
+            m.generation.fetch_add(1, std::memory_order_release);
             x265hip_refpic_destroy(m.rp);           // waits for the worker's queued bands of this picture
             m.rp = NULL;
             return;
@@ -311,6 +334,7 @@ void FrameFilter::processPostRow(int row)
                     abort();
                 }
                 m->poc = m_frame->m_poc;
+                m->generation.fetch_add(1, std::memory_order_release);
                 m->tracking = IS_REFERENCED(m_frame);           // unreferenced B pictures are never searched: nothing to build
                 m->prefix = 0;
                 memset(m->rowDone, 0, sizeof(m->rowDone));

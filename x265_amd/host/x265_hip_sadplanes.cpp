@@ -1,23 +1,31 @@
-// x265_hip_sadplanes.cpp — the fifth translation unit of the drop-in: integer-pel SAD served from GPU-built SAD surfaces
-// (include/x265hip.h, x265hip_sadsurf_*).
+// x265_hip_sadplanes.cpp — the fifth translation unit of the drop-in: the integer-pel SADs of the motion search served from GPU-built SAD
+// surfaces (include/x265hip.h, x265hip_sadsurf_*).
 //
 // MotionEstimate::motionEstimate (reference source/encoder/motion.cpp:739-1569) measures its integer-pel candidates as
-//     sad(fenc, FENC_STRIDE, fref + mx + my * stride, stride)                                  (:246-330 macros, :770-944 HEX, :1132-1240 STAR)
-// where fenc = fencPUYuv.m_buf[0] is a copy of the SOURCE picture's PU (setSourcePU, :194-222) and fref = ref->fpelPlane[0] + blockOffset
-// a position in the finished reference picture (:752-756).  Which candidates the search visits depends on the decisions before it; what a
-// candidate costs does not: SAD(source block at (x, y), reference block at (x + mx, y + my)) is a function of the two pictures and the position.
-// ...
+//     sad(fenc, FENC_STRIDE, fref + mx + my * stride, stride)                (macros :246-330; HEX :770-944, STAR :1132-1240, square refine :1430-1450)
+// where fenc = fencPUYuv.m_buf[0] is a copy of the SOURCE picture's PU (setSourcePU, :194-222) and fref = ref->fpelPlane[0] + blockOffset a
+// position in the finished reference picture (:752-756).  Which candidates a search visits depends on the decisions before it (the predictors
+// come from the neighbours' vectors); what a candidate costs does not: SAD(source block at (x, y), reference block at (x + mx, y + my)) is a
+// function of the two pictures, the position and the vector.  The GPU computes those values per (source picture, reference picture) pair for
+// every aligned 16 / 32 / 64 block over a 16 x 16 window of vectors per block, placed around the block's own best match of an exhaustive
+// +-32 search (x265hip_sadsurf, x265_amd/csrc/sadsurf.hip), as the reference picture's rows become final; a search then reads a candidate's
+// SAD out of the table when the vector lies in the block's window and computes it with the C function otherwise.  Same value either way, so the
+// bitstream does not depend on what has arrived or on where the windows lie.  Measured before it was built (every eligible
+// call computed twice): the eligible calls are 9.8 % of the bound encoder's critical path at 1080p preset medium.
 //
 // Two seams on motion.o (same link technique as the other seams, oracle/Makefile):
-//   MotionEstimate::setSourcePU     (analysis variant): remembers, per MotionEstimate object of this thread, which source picture the PU came
-//                                   from (x265hip_srcplanes_where) and verifies the copied block against that picture byte for byte;
-//   MotionEstimate::motionEstimate  runs the reference's own body with this object's sad / sad_x3 / sad_x4 pointers swapped for lookups
-//                                   when the (source picture, reference picture) pair has a surface that covers this PU.
+//   MotionEstimate::setSourcePU     (analysis variant): notes, per MotionEstimate object of this thread, which source picture and position the
+//                                   PU came from (x265hip_srcplanes_where) and compares the copied block with that picture byte for byte —
+//                                   equal bytes have equal SADs: this comparison, not the bookkeeping, is what makes a lookup exact;
+//   MotionEstimate::motionEstimate  runs the reference's own body with this object's sad / sad_x3 / sad_x4 pointers swapped for the lookups
+//                                   while the (source picture, reference picture) pair has a surface whose rows cover this PU.
+// Surfaces are attached on first use (the first search of a frame against a reference) and retired when either picture's buffer moves on.
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #define protected public
 #define private public
@@ -39,6 +47,10 @@ namespace X265_NS {
 
 const EncoderPrimitives& x265hip_c_table();          // x265_hip_primitives.cpp
 bool x265hip_srcplanes_where(const Yuv& y, const PicYuv** pic, uint32_t* version, int* px, int* py);     // x265_hip_srcplanes.cpp
+x265hip_srcpic* x265hip_srcplanes_device(const PicYuv* pic, uint32_t version);
+bool x265hip_srcplanes_current(const PicYuv* pic, uint32_t version);
+x265hip_refpic* x265hip_refplanes_device(const PicYuv* recon, uint32_t* generation);                    // x265_hip_refplanes.cpp
+bool x265hip_refplanes_current(const PicYuv* recon, uint32_t generation);
 
 extern void refSetSourcePU(MotionEstimate* self, const Yuv& srcFencYuv, int ctuAddr, int cuPartIdx, int puPartIdx, int pwidth, int pheight, const int method,
                            const int refine, bool bChroma) asm("_ZN4x26517MotionEstimateRef11setSourcePUERKNS_3YuvEiiiiiiib");
@@ -55,177 +67,230 @@ extern void refInitScales() asm("_ZN4x26517MotionEstimateRef10initScalesEv");
 
 namespace {
 
+const int WIN = X265HIP_SADSURF_WIN;
+
 int g_state = 0;                 // 0 undecided, 1 on, -1 off
-int g_exp = 0;                   // X265HIP_DEBUG_SADEXP: 1 = statistics of the eligible calls, 2 = eligible calls are computed twice (cost doubling)
+int g_exp = 0;                   // X265HIP_DEBUG_SADEXP=2: every eligible call is computed twice and nothing is looked up (the cost-doubling measurement)
+int g_levels = 14;               // X265HIP_SADPLANES_LEVELS: bit l = blocks of 8 << l are looked up (16, 32, 64 are built)
+int g_range = 32;                // X265HIP_SADPLANES_RANGE: the exhaustive search that places the windows covers [-range, range)^2
 EncoderPrimitives g_c;
 std::mutex g_lock;
 
-struct alignas(64) Counter { std::atomic<uint64_t> v[8]; };
-// [size class 0..3 = 8, 16, 32, 64][bucket]: |mv - centre| <= 8, 12, 16, 24, 32, more; [6] = mv == 0 outside 16; [7] = calls
-Counter g_hist[4][64], g_histOwn[4][64];     // centre = the CTU's first vector / the vector this very search ends on
+struct alignas(64) Counter { std::atomic<uint64_t> hit, miss, unserved; };
+Counter g_count[64];
 std::atomic<int> g_nextShard(0);
 __attribute__((tls_model("initial-exec"))) thread_local int t_shard = -1;
 inline int shard() { if (t_shard < 0) t_shard = g_nextShard.fetch_add(1) & 63; return t_shard; }
 
 // what this thread's MotionEstimate objects hold (setSourcePU)
-struct PuInfo { const MotionEstimate* me; const PicYuv* srcPic; uint32_t version; int x, y, w, h; };
+struct PuInfo { const MotionEstimate* me; const PicYuv* srcPic; uint32_t version; int x, y, w; };
 const int kPu = 4;
 __attribute__((tls_model("initial-exec"))) thread_local PuInfo t_pu[kPu];
 __attribute__((tls_model("initial-exec"))) thread_local int t_puNext = 0;
+
+// one (source picture, reference picture) pair
+struct Pair
+{
+    const PicYuv* srcPic; uint32_t version;
+    const PicYuv* recon; uint32_t generation;
+    x265hip_sadsurf* ss;
+    const x265hip_sadsurf_view* view;
+};
+std::vector<Pair*> g_pairs;          // under g_lock
+uint64_t g_attached = 0, g_retired = 0;
+
+// per thread: the pairs it met last (a frame encoder's workers keep asking for the same few)
+const int kCache = 8;
+__attribute__((tls_model("initial-exec"))) thread_local Pair t_cache[kCache];
+__attribute__((tls_model("initial-exec"))) thread_local int t_cacheNext = 0;
 
 // the lookup context of the motionEstimate call in progress on this thread
 struct Ctx
 {
     const pixel* fenc;           // fencPUYuv.m_buf[0]
-    const pixel* fref;           // reference position of mv (0, 0)
+    const pixel* winBase;        // reference position of window entry (0, 0)
     intptr_t stride;
-    int sizeClass;
-    int cx, cy;                  // window centre (experiment: the first vector found for this CTU and reference)
-    bool haveCentre;
+    size_t span;                 // (WIN - 1) * stride + WIN: pointers at or beyond winBase + span are outside the window
+    const void* tab;             // the block's WIN * WIN entries
+    uint32_t hit, miss;
 };
 __attribute__((tls_model("initial-exec"))) thread_local Ctx t_ctx;
 
-// experiment: the centre a device search would pick per (CTU, reference) is approximated by the first motionEstimate result in that CTU
-struct CentreMemo { const PicYuv* ref; int ctu; int cx, cy; };
-__attribute__((tls_model("initial-exec"))) thread_local CentreMemo t_centre[8];
-__attribute__((tls_model("initial-exec"))) thread_local int t_centreNext = 0;
-
 void report()
 {
-    static const char* names[4] = { "8x8", "16x16", "32x32", "64x64" };
-    for (int c = 0; c < 8; c++)
-    {
-        uint64_t b[8] = { 0 };
-        for (int s = 0; s < 64; s++)
-            for (int k = 0; k < 8; k++)
-                b[k] += (c < 4 ? g_hist[c][s] : g_histOwn[c - 4][s]).v[k];
-        if (!b[7])
-            continue;
-        fprintf(stderr, c < 4 ? "x265hip: sadplanes: experiment %s: %llu eligible candidate SADs; distance from the CTU's first vector <=8: %.1f%% <=12: %.1f%% <=16: %.1f%% <=24: %.1f%% <=32: %.1f%% "
-                        "more: %.1f%% (of which mv 0: %.1f%%)\n" : "x265hip: sadplanes: experiment %s: %llu eligible candidate SADs; distance from this search's own result <=8: %.1f%% <=12: %.1f%% <=16: %.1f%% <=24: %.1f%% <=32: %.1f%% "
-                        "more: %.1f%% (of which mv 0: %.1f%%)\n", names[c & 3], (unsigned long long)b[7], 100.0 * b[0] / b[7], 100.0 * (b[0] + b[1]) / b[7],
-                100.0 * (b[0] + b[1] + b[2]) / b[7], 100.0 * (b[0] + b[1] + b[2] + b[3]) / b[7], 100.0 * (b[0] + b[1] + b[2] + b[3] + b[4]) / b[7], 100.0 * b[5] / b[7],
-                100.0 * b[6] / b[7]);
-    }
+    uint64_t h = 0, m = 0, un = 0;
+    for (int i = 0; i < 64; i++) { h += g_count[i].hit; m += g_count[i].miss; un += g_count[i].unserved; }
+    uint64_t attached = 0, rows = 0;
+    x265hip_sadsurf_stats(&attached, &rows);
+    fprintf(stderr, "x265hip: sadplanes: %llu integer-pel SADs of the motion search served from GPU-built SAD surfaces (%llu surfaces, %llu CTU rows), %llu of the same "
+                    "searches outside their block's window and %llu searches without a surface computed on the host\n", (unsigned long long)h,
+            (unsigned long long)attached, (unsigned long long)rows, (unsigned long long)m, (unsigned long long)un);
 }
 
-bool enabled()
+bool decide()
 {
+    std::lock_guard<std::mutex> g(g_lock);
     if (!g_state)
     {
-        std::lock_guard<std::mutex> g(g_lock);
-        if (!g_state)
+        const char* env = getenv("X265HIP_SADPLANES");
+        const char* all = getenv("X265HIP");
+        const char* table = getenv("X265HIP_TABLE");
+        const char* exp = getenv("X265HIP_DEBUG_SADEXP");
+        g_exp = exp ? atoi(exp) : 0;
+        if (getenv("X265HIP_SADPLANES_LEVELS")) g_levels = atoi(getenv("X265HIP_SADPLANES_LEVELS")) & 14;
+        if (getenv("X265HIP_SADPLANES_RANGE")) g_range = atoi(getenv("X265HIP_SADPLANES_RANGE"));
+        if (g_range < 8) g_range = 8;
+        if (g_range > 32) g_range = 32;
+        g_range &= ~3;
+        // 8-bit builds only for now: the search-window kernel is built on v_qsad_pk_u16_u8
+        if ((env && !strcmp(env, "0")) || (all && !strcmp(all, "0")) || (table && !strcmp(table, "percall")) || X265_DEPTH != 8 || !g_levels ||
+            x265hip_device_count() < 1)
+            g_state = -1;
+        else
         {
-            const char* env = getenv("X265HIP_SADPLANES");
-            const char* all = getenv("X265HIP");
-            const char* table = getenv("X265HIP_TABLE");
-            const char* exp = getenv("X265HIP_DEBUG_SADEXP");
-            g_exp = exp ? atoi(exp) : 0;
-            if ((env && !strcmp(env, "0")) || (all && !strcmp(all, "0")) || (table && !strcmp(table, "percall")) || x265hip_device_count() < 1)
-                g_state = -1;
-            else
-            {
-                g_c = x265hip_c_table();
-                refInitScales();            // the reference body's own file-static table (motion.cpp:60, :120-160): its copy in the second object
-                g_state = 1;
-                if (g_exp == 1)
-                    atexit(report);
-            }
+            g_c = x265hip_c_table();
+            refInitScales();            // the reference body's own file-static table (motion.cpp:60, :120-160): its copy in the second object
+            g_state = 1;
+            if (getenv("X265HIP_VERBOSE"))
+                atexit(report);
         }
     }
     return g_state > 0;
 }
 
-__attribute__((tls_model("initial-exec"))) thread_local int16_t t_cand[1024][2];
-__attribute__((tls_model("initial-exec"))) thread_local int t_ncand = 0;
+inline bool enabled() { return g_state ? g_state > 0 : decide(); }
 
-inline void bucket(Counter& h, int mx, int my, int cx, int cy)
+// the pair's surface: this thread's cache, then the table; attached on first use.  NULL: no device copy of one of the pictures (yet)
+const Pair* pair_of(const PicYuv* srcPic, uint32_t version, const PicYuv* recon, int lambda20)
 {
-    const int dx = abs(mx - cx), dy = abs(my - cy), d = dx > dy ? dx : dy;
-    const int k = d <= 8 ? 0 : d <= 12 ? 1 : d <= 16 ? 2 : d <= 24 ? 3 : d <= 32 ? 4 : 5;
-    h.v[k].fetch_add(1, std::memory_order_relaxed);
-    h.v[7].fetch_add(1, std::memory_order_relaxed);
-    if (d > 16 && !mx && !my)
-        h.v[6].fetch_add(1, std::memory_order_relaxed);
-}
-
-inline void account(int mx, int my)
-{
-    const Ctx& c = t_ctx;
-    if (g_exp != 1)
-        return;
-    if (t_ncand < 1024) { t_cand[t_ncand][0] = (int16_t)mx; t_cand[t_ncand][1] = (int16_t)my; t_ncand++; }
-    if (c.haveCentre)
-        bucket(g_hist[c.sizeClass][shard()], mx, my, c.cx, c.cy);
-}
-
-inline bool decode(const pixel* p, int& mx, int& my)
-{
-    const Ctx& c = t_ctx;
-    const ptrdiff_t d = p - c.fref + 128 * c.stride + 128;          // candidates within +-128 of the block position
-    if (d < 0)
-        return false;
-    my = (int)(d / c.stride);
-    mx = (int)(d - my * c.stride);
-    if (my > 256 || mx > 256)
-        return false;
-    mx -= 128; my -= 128;
-    return true;
-}
-
-template <int PART> int sad_exp(const pixel* fenc, intptr_t fs, const pixel* ref, intptr_t rs)
-{
-    int mx, my;
-    if (fenc == t_ctx.fenc && rs == t_ctx.stride && decode(ref, mx, my))
+    uint32_t generation = 0;
+    x265hip_refpic* rp = x265hip_refplanes_device(recon, &generation);
+    if (!rp)
+        return NULL;
+    for (int i = 0; i < kCache; i++)
     {
-        account(mx, my);
-        if (g_exp == 2)
+        const Pair& c = t_cache[i];
+        if (c.srcPic == srcPic && c.version == version && c.recon == recon && c.generation == generation)
+            return &c;
+    }
+    std::lock_guard<std::mutex> g(g_lock);
+    Pair* found = NULL;
+    for (size_t i = 0; i < g_pairs.size();)
+    {
+        Pair* p = g_pairs[i];
+        if (p->srcPic == srcPic && p->version == version && p->recon == recon && p->generation == generation)
+            found = p;
+        else if (!x265hip_srcplanes_current(p->srcPic, p->version) || !x265hip_refplanes_current(p->recon, p->generation))
         {
-            volatile int sink = g_c.pu[PART].sad(fenc, fs, ref, rs);
-            (void)sink;
+            // one of the two buffers holds another picture by now: the frame this surface served is finished, nobody reads it any more
+            x265hip_sadsurf_release(p->ss);
+            delete p;
+            g_pairs[i] = g_pairs.back();
+            g_pairs.pop_back();
+            g_retired++;
+            continue;
         }
+        i++;
+    }
+    if (!found)
+    {
+        x265hip_srcpic* sp = x265hip_srcplanes_device(srcPic, version);
+        if (!sp)
+            return NULL;                     // the source picture's upload has not finished: the next search asks again
+        x265hip_sadsurf* ss = x265hip_sadsurf_attach(sp, rp, g_range, lambda20);
+        if (!ss)
+        {
+            fprintf(stderr, "x265hip: sadplanes: %s\n", x265hip_last_error());
+            abort();                         // the product path fails loudly
+        }
+        found = new Pair{ srcPic, version, recon, generation, ss, x265hip_sadsurf_get_view(ss) };
+        g_pairs.push_back(found);
+        g_attached++;
+    }
+    Pair& c = t_cache[t_cacheNext];
+    t_cacheNext = (t_cacheNext + 1) % kCache;
+    c = *found;
+    return &c;
+}
+
+// entry of `p` in the window of the search in progress, or -1
+inline int locate(const Ctx& c, const pixel* p)
+{
+    const size_t d = (size_t)(p - c.winBase);        // below the window: wraps to a huge value
+    if (d >= c.span)
+        return -1;
+    const unsigned dy = (unsigned)d / (unsigned)c.stride, dx = (unsigned)d - dy * (unsigned)c.stride;
+    return dx < (unsigned)WIN ? (int)(dy * WIN + dx) : -1;
+}
+
+template <int PART, typename E> int sad_lookup(const pixel* fenc, intptr_t fs, const pixel* ref, intptr_t rs)
+{
+    Ctx& c = t_ctx;
+    if (fenc == c.fenc && rs == c.stride)
+    {
+        const int k = locate(c, ref);
+        if (k >= 0) { c.hit++; return (int)((const E*)c.tab)[k]; }
+        c.miss++;
     }
     return g_c.pu[PART].sad(fenc, fs, ref, rs);
 }
-template <int PART> void sad_x3_exp(const pixel* fenc, const pixel* r0, const pixel* r1, const pixel* r2, intptr_t rs, int32_t* res)
+template <int PART, typename E> void sad_x3_lookup(const pixel* fenc, const pixel* r0, const pixel* r1, const pixel* r2, intptr_t rs, int32_t* res)
 {
-    int mx, my;
-    if (fenc == t_ctx.fenc && rs == t_ctx.stride && decode(r0, mx, my))
-    {
-        account(mx, my);
-        if (decode(r1, mx, my)) account(mx, my);
-        if (decode(r2, mx, my)) account(mx, my);
-        if (g_exp == 2)
-        {
-            int32_t tmp[3];
-            g_c.pu[PART].sad_x3(fenc, r0, r1, r2, rs, tmp);
-            volatile int sink = tmp[0] + tmp[1] + tmp[2];
-            (void)sink;
-        }
-    }
+    Ctx& c = t_ctx;
+    if (fenc != c.fenc || rs != c.stride) { g_c.pu[PART].sad_x3(fenc, r0, r1, r2, rs, res); return; }
+    const int k0 = locate(c, r0), k1 = locate(c, r1), k2 = locate(c, r2);
+    if ((k0 | k1 | k2) < 0 && k0 < 0 && k1 < 0 && k2 < 0) { c.miss += 3; g_c.pu[PART].sad_x3(fenc, r0, r1, r2, rs, res); return; }
+    const E* t = (const E*)c.tab;
+    // sad_x3 is three independent sad<lx, ly> (pixel.cpp:74-95): a candidate outside the window is measured on its own
+    res[0] = k0 >= 0 ? (int32_t)t[k0] : g_c.pu[PART].sad(fenc, FENC_STRIDE, r0, rs);
+    res[1] = k1 >= 0 ? (int32_t)t[k1] : g_c.pu[PART].sad(fenc, FENC_STRIDE, r1, rs);
+    res[2] = k2 >= 0 ? (int32_t)t[k2] : g_c.pu[PART].sad(fenc, FENC_STRIDE, r2, rs);
+    const int h = (k0 >= 0) + (k1 >= 0) + (k2 >= 0);
+    c.hit += h; c.miss += 3 - h;
+}
+template <int PART, typename E> void sad_x4_lookup(const pixel* fenc, const pixel* r0, const pixel* r1, const pixel* r2, const pixel* r3, intptr_t rs, int32_t* res)
+{
+    Ctx& c = t_ctx;
+    if (fenc != c.fenc || rs != c.stride) { g_c.pu[PART].sad_x4(fenc, r0, r1, r2, r3, rs, res); return; }
+    const int k0 = locate(c, r0), k1 = locate(c, r1), k2 = locate(c, r2), k3 = locate(c, r3);
+    if (k0 < 0 && k1 < 0 && k2 < 0 && k3 < 0) { c.miss += 4; g_c.pu[PART].sad_x4(fenc, r0, r1, r2, r3, rs, res); return; }
+    const E* t = (const E*)c.tab;
+    res[0] = k0 >= 0 ? (int32_t)t[k0] : g_c.pu[PART].sad(fenc, FENC_STRIDE, r0, rs);
+    res[1] = k1 >= 0 ? (int32_t)t[k1] : g_c.pu[PART].sad(fenc, FENC_STRIDE, r1, rs);
+    res[2] = k2 >= 0 ? (int32_t)t[k2] : g_c.pu[PART].sad(fenc, FENC_STRIDE, r2, rs);
+    res[3] = k3 >= 0 ? (int32_t)t[k3] : g_c.pu[PART].sad(fenc, FENC_STRIDE, r3, rs);
+    const int h = (k0 >= 0) + (k1 >= 0) + (k2 >= 0) + (k3 >= 0);
+    c.hit += h; c.miss += 4 - h;
+}
+
+// X265HIP_DEBUG_SADEXP=2: the measurement that preceded this file — every call a lookup could serve is computed twice
+template <int PART> int sad_twice(const pixel* fenc, intptr_t fs, const pixel* ref, intptr_t rs)
+{
+    if (fenc == t_ctx.fenc && rs == t_ctx.stride) { volatile int sink = g_c.pu[PART].sad(fenc, fs, ref, rs); (void)sink; }
+    return g_c.pu[PART].sad(fenc, fs, ref, rs);
+}
+template <int PART> void sad_x3_twice(const pixel* fenc, const pixel* r0, const pixel* r1, const pixel* r2, intptr_t rs, int32_t* res)
+{
+    if (fenc == t_ctx.fenc && rs == t_ctx.stride) { int32_t tmp[3]; g_c.pu[PART].sad_x3(fenc, r0, r1, r2, rs, tmp); volatile int sink = tmp[0] + tmp[1] + tmp[2]; (void)sink; }
     g_c.pu[PART].sad_x3(fenc, r0, r1, r2, rs, res);
 }
-template <int PART> void sad_x4_exp(const pixel* fenc, const pixel* r0, const pixel* r1, const pixel* r2, const pixel* r3, intptr_t rs, int32_t* res)
+template <int PART> void sad_x4_twice(const pixel* fenc, const pixel* r0, const pixel* r1, const pixel* r2, const pixel* r3, intptr_t rs, int32_t* res)
 {
-    int mx, my;
-    if (fenc == t_ctx.fenc && rs == t_ctx.stride && decode(r0, mx, my))
-    {
-        account(mx, my);
-        if (decode(r1, mx, my)) account(mx, my);
-        if (decode(r2, mx, my)) account(mx, my);
-        if (decode(r3, mx, my)) account(mx, my);
-        if (g_exp == 2)
-        {
-            int32_t tmp[4];
-            g_c.pu[PART].sad_x4(fenc, r0, r1, r2, r3, rs, tmp);
-            volatile int sink = tmp[0] + tmp[1] + tmp[2] + tmp[3];
-            (void)sink;
-        }
-    }
+    if (fenc == t_ctx.fenc && rs == t_ctx.stride) { int32_t tmp[4]; g_c.pu[PART].sad_x4(fenc, r0, r1, r2, r3, rs, tmp); volatile int sink = tmp[0] + tmp[1] + tmp[2] + tmp[3]; (void)sink; }
     g_c.pu[PART].sad_x4(fenc, r0, r1, r2, r3, rs, res);
 }
 
+template <int PART> inline void install(MotionEstimate* me, int entryBytes)
+{
+    if (g_exp == 2) { me->sad = sad_twice<PART>; me->sad_x3 = sad_x3_twice<PART>; me->sad_x4 = sad_x4_twice<PART>; }
+    else if (entryBytes == 2) { me->sad = sad_lookup<PART, uint16_t>; me->sad_x3 = sad_x3_lookup<PART, uint16_t>; me->sad_x4 = sad_x4_lookup<PART, uint16_t>; }
+    else { me->sad = sad_lookup<PART, uint32_t>; me->sad_x3 = sad_x3_lookup<PART, uint32_t>; me->sad_x4 = sad_x4_lookup<PART, uint32_t>; }
+}
+
 } // namespace
+
+// x265_hip_srcplanes.cpp keeps a device copy of every source picture only when this returns true
+bool x265hip_sadplanes_wanted() { return enabled() && g_exp != 2; }
 
 void MotionEstimate::setSourcePU(const Yuv& srcFencYuv, int _ctuAddr, int cuPartIdx, int puPartIdx, int pwidth, int pheight, const int method, const int refine,
                                  bool bChroma)
@@ -241,7 +306,8 @@ void MotionEstimate::setSourcePU(const Yuv& srcFencYuv, int _ctuAddr, int cuPart
     u.me = this;
     u.srcPic = NULL;
     const PicYuv* pic; uint32_t version; int cx, cy;
-    if (pwidth != pheight || pwidth < 8 || !x265hip_srcplanes_where(srcFencYuv, &pic, &version, &cx, &cy))
+    if (pwidth != pheight || pwidth < 8 || !(g_levels >> (pwidth == 8 ? 0 : pwidth == 16 ? 1 : pwidth == 32 ? 2 : 3) & 1) ||
+        !x265hip_srcplanes_where(srcFencYuv, &pic, &version, &cx, &cy))
         return;
     const int x = cx + g_zscanToPelX[puPartIdx], y = cy + g_zscanToPelY[puPartIdx];
     if ((x | y) & (pwidth - 1) || x + pwidth > (int)pic->m_picWidth || y + pheight > (int)pic->m_picHeight)
@@ -252,7 +318,7 @@ void MotionEstimate::setSourcePU(const Yuv& srcFencYuv, int _ctuAddr, int cuPart
     for (int r = 0; r < pheight; r++)
         if (memcmp(f + r * FENC_STRIDE, p + r * pic->m_stride, pwidth * sizeof(pixel)))
             return;
-    u.srcPic = pic; u.version = version; u.x = x; u.y = y; u.w = pwidth; u.h = pheight;
+    u.srcPic = pic; u.version = version; u.x = x; u.y = y; u.w = pwidth;
 }
 
 int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const MV& mvmax, const MV& qmvp, int numCandidates, const MV* mvc, int merange,
@@ -263,39 +329,81 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
     const PuInfo* u = NULL;
     for (int i = 0; i < kPu; i++)
         if (t_pu[i].me == this && t_pu[i].srcPic) { u = &t_pu[i]; break; }
-    if (!u || !g_exp)
+    if (!u)
         return refMotionEstimate(this, ref, mvmin, mvmax, qmvp, numCandidates, mvc, merange, outQMv, maxSlices, srcReferencePlane);
-    // experiment modes
     Ctx& c = t_ctx;
-    c.fenc = fencPUYuv.m_buf[0];
-    c.fref = ref->fpelPlane[0] + ref->reconPic->m_cuOffsetY[ctuAddr] + ref->reconPic->m_buOffsetY[absPartIdx];
-    c.stride = ref->lumaStride;
-    c.sizeClass = u->w == 8 ? 0 : u->w == 16 ? 1 : u->w == 32 ? 2 : 3;
-    c.haveCentre = false;
-    t_ncand = 0;
-    CentreMemo* memo = NULL;
-    for (int i = 0; i < 8; i++)
-        if (t_centre[i].ref == ref->reconPic && t_centre[i].ctu == ctuAddr) { memo = &t_centre[i]; break; }
-    if (memo) { c.cx = memo->cx; c.cy = memo->cy; c.haveCentre = true; }
-    const pixelcmp_t s1 = sad; const pixelcmp_x3_t s3 = sad_x3; const pixelcmp_x4_t s4 = sad_x4;
-    switch (c.sizeClass)
+    const int level = u->w == 8 ? 0 : u->w == 16 ? 1 : u->w == 32 ? 2 : 3;
+    int entryBytes = 0;
+    if (g_exp != 2)
     {
-    case 0: sad = sad_exp<LUMA_8x8>; sad_x3 = sad_x3_exp<LUMA_8x8>; sad_x4 = sad_x4_exp<LUMA_8x8>; break;
-    case 1: sad = sad_exp<LUMA_16x16>; sad_x3 = sad_x3_exp<LUMA_16x16>; sad_x4 = sad_x4_exp<LUMA_16x16>; break;
-    case 2: sad = sad_exp<LUMA_32x32>; sad_x3 = sad_x3_exp<LUMA_32x32>; sad_x4 = sad_x4_exp<LUMA_32x32>; break;
-    default: sad = sad_exp<LUMA_64x64>; sad_x3 = sad_x3_exp<LUMA_64x64>; sad_x4 = sad_x4_exp<LUMA_64x64>; break;
+        // 20 x lambda out of this search's own vector-cost table: m_cost[i] = lambda * (2 log2(i + 1) + 0.718) (bitcost.cpp:48-70), log2(1025) = 10.0
+        const int lambda20 = (int)m_cost[1024] - (int)m_cost[0];
+        const Pair* pr = pair_of(u->srcPic, u->version, ref->reconPic, lambda20);
+        const x265hip_sadsurf_level* lv = pr ? &pr->view->level[level] : NULL;
+        if (!lv || !lv->origin || (u->y >> 6) >= __atomic_load_n(pr->view->ctuRowsReady, __ATOMIC_ACQUIRE))
+        {
+            g_count[shard()].unserved.fetch_add(1, std::memory_order_relaxed);
+            return refMotionEstimate(this, ref, mvmin, mvmax, qmvp, numCandidates, mvc, merange, outQMv, maxSlices, srcReferencePlane);
+        }
+        // the position the reference will search from (motion.cpp:752-756) must be the one the source block was verified at
+        const intptr_t off = ref->reconPic->m_cuOffsetY[ctuAddr] + ref->reconPic->m_buOffsetY[absPartIdx];
+        if (off != (intptr_t)u->y * ref->lumaStride + u->x || u->x / u->w >= lv->blocksX || u->y / u->w >= lv->blocksY)
+            return refMotionEstimate(this, ref, mvmin, mvmax, qmvp, numCandidates, mvc, merange, outQMv, maxSlices, srcReferencePlane);
+        const size_t b = (size_t)(u->y / u->w) * lv->blocksX + u->x / u->w;
+        const int ox = lv->origin[2 * b], oy = lv->origin[2 * b + 1];
+        entryBytes = lv->entryBytes;
+        c.tab = (const char*)lv->table + b * WIN * WIN * entryBytes;
+        c.stride = ref->lumaStride;
+        c.winBase = ref->fpelPlane[0] + off + (intptr_t)oy * c.stride + ox;
+        c.span = (size_t)(WIN - 1) * c.stride + WIN;
+    }
+    else
+        c.stride = ref->lumaStride;
+    c.fenc = fencPUYuv.m_buf[0];
+    c.hit = c.miss = 0;
+    const pixelcmp_t s1 = sad; const pixelcmp_x3_t s3 = sad_x3; const pixelcmp_x4_t s4 = sad_x4;
+    switch (level)
+    {
+    case 0: install<LUMA_8x8>(this, entryBytes); break;
+    case 1: install<LUMA_16x16>(this, entryBytes); break;
+    case 2: install<LUMA_32x32>(this, entryBytes); break;
+    default: install<LUMA_64x64>(this, entryBytes); break;
     }
     const int r = refMotionEstimate(this, ref, mvmin, mvmax, qmvp, numCandidates, mvc, merange, outQMv, maxSlices, srcReferencePlane);
     sad = s1; sad_x3 = s3; sad_x4 = s4;
     c.fenc = NULL;
-    for (int i = 0; i < t_ncand; i++)
-        bucket(g_histOwn[c.sizeClass][shard()], t_cand[i][0], t_cand[i][1], outQMv.x >> 2, outQMv.y >> 2);
-    if (!memo)
+    if (g_exp == 3 && entryBytes)
     {
-        CentreMemo& m = t_centre[t_centreNext];
-        t_centreNext = (t_centreNext + 1) & 7;
-        m.ref = ref->reconPic; m.ctu = ctuAddr; m.cx = outQMv.x >> 2; m.cy = outQMv.y >> 2;
+        // X265HIP_DEBUG_SADEXP=3: where did the search end relative to the window the device chose?
+        const intptr_t off0 = c.winBase - (ref->fpelPlane[0] + ref->reconPic->m_cuOffsetY[ctuAddr] + ref->reconPic->m_buOffsetY[absPartIdx]);
+        int oy = (int)((off0 + 256 * c.stride + 256) / c.stride) - 256, ox = (int)(off0 - (intptr_t)oy * c.stride);
+        const int dx = abs((outQMv.x >> 2) - (ox + WIN / 2)), dy = abs((outQMv.y >> 2) - (oy + WIN / 2)), d = dx > dy ? dx : dy;
+        static std::atomic<uint64_t> hist[4][6], hm[4][6][2];
+        const int b = d <= 2 ? 0 : d <= 4 ? 1 : d <= 7 ? 2 : d <= 16 ? 3 : d <= 32 ? 4 : 5;
+        hist[level][b]++; hm[level][b][0] += c.hit; hm[level][b][1] += c.miss;
+        static std::atomic<int> shown(0);
+        if (d > 16 && level == 3 && shown.fetch_add(1) < 60)
+        {
+            const uint32_t atCentre = entryBytes == 2 ? ((const uint16_t*)c.tab)[8 * WIN + 8] : ((const uint32_t*)c.tab)[8 * WIN + 8];
+            const pixel* fr = ref->fpelPlane[0] + ref->reconPic->m_cuOffsetY[ctuAddr] + ref->reconPic->m_buOffsetY[absPartIdx];
+            const int atResult = g_c.pu[LUMA_64x64].sad(fencPUYuv.m_buf[0], FENC_STRIDE, fr + (outQMv.x >> 2) + (outQMv.y >> 2) * c.stride, c.stride);
+            fprintf(stderr, "far: pos %d,%d window centre %d,%d (sad %u) result %d,%d (sad %d, cost %d) mvp %d,%d merange %d mvmin %d,%d mvmax %d,%d\n", u->x, u->y, ox + 8, oy + 8, atCentre,
+                    outQMv.x >> 2, outQMv.y >> 2, atResult, r, qmvp.x >> 2, qmvp.y >> 2, merange, mvmin.x, mvmin.y, mvmax.x, mvmax.y);
+        }
+        static std::atomic<int> once(0);
+        if (!once.exchange(1))
+            atexit([] {
+                for (int l = 1; l < 4; l++)
+                {
+                    fprintf(stderr, "x265hip: sadplanes: level %d: |search result - window centre| <=2 / <=4 / <=7 / <=16 / <=32 / more:", l);
+                    for (int k = 0; k < 6; k++) fprintf(stderr, " %llu (hit %llu miss %llu)", (unsigned long long)hist[l][k].load(), (unsigned long long)hm[l][k][0].load(), (unsigned long long)hm[l][k][1].load());
+                    fprintf(stderr, "\n");
+                }
+            });
     }
+    Counter& k = g_count[shard()];
+    k.hit.fetch_add(c.hit, std::memory_order_relaxed);
+    k.miss.fetch_add(c.miss, std::memory_order_relaxed);
     return r;
 }
 

@@ -43,6 +43,7 @@ extern void refCopyFromPicture(PicYuv* self, const x265_picture& pic, const x265
     asm("_ZN4x2659PicYuvRef15copyFromPictureERK12x265_pictureRK10x265_paramii");
 extern void refDestroy(PicYuv* self) asm("_ZN4x2659PicYuvRef7destroyEv");
 void x265hip_refplanes_retire(const pixel* lo);     // x265_hip_refplanes.cpp
+bool x265hip_sadplanes_wanted();                    // x265_hip_sadplanes.cpp: source pictures are kept on the device for the SAD surfaces
 extern void refCopyFromPicYuv(Yuv* self, const PicYuv& srcPic, uint32_t cuAddr, uint32_t absPartIdx) asm("_ZN4x2656YuvRef14copyFromPicYuvERKNS_6PicYuvEjj");
 extern void refCopyPartToYuv(const Yuv* self, Yuv& dstYuv, uint32_t absPartIdx) asm("_ZNK4x2656YuvRef13copyPartToYuvERS0_j");
 
@@ -57,6 +58,8 @@ struct SrcPic                        // one source picture buffer and its energy
     int32_t* e8[3];
     int32_t* e4[3];
     int bw[3], bh[3];                // 8x8 blocks per row / column of each plane
+    x265hip_srcpic* dev;             // the luma plane on the device (x265_hip_sadplanes.cpp attaches SAD surfaces to it); version `built`
+    int devW, devH;
 };
 
 const int kMaxPics = 128;
@@ -134,6 +137,7 @@ SrcPic* find_pic(const PicYuv* pic, bool create)
     s.version = 1;
     s.built = 0;
     for (int k = 0; k < 3; k++) { s.e8[k] = s.e4[k] = NULL; s.bw[k] = s.bh[k] = 0; }
+    s.dev = NULL; s.devW = s.devH = 0;
     g_npics.store(n2 + 1, std::memory_order_release);
     return &s;
 }
@@ -165,6 +169,24 @@ void build(SrcPic* sp, uint32_t v)
         {
             fprintf(stderr, "x265hip: srcplanes: %s\n", x265hip_last_error());
             abort();                                   // the product path fails loudly
+        }
+    }
+    if (x265hip_sadplanes_wanted())
+    {
+        if (sp->dev && (sp->devW != (int)pic.m_picWidth || sp->devH != (int)pic.m_picHeight))
+        {
+            x265hip_srcpic_destroy(sp->dev);
+            sp->dev = NULL;
+        }
+        if (!sp->dev)
+        {
+            sp->dev = x265hip_srcpic_create(X265_DEPTH, pic.m_picWidth, pic.m_picHeight);
+            sp->devW = pic.m_picWidth; sp->devH = pic.m_picHeight;
+        }
+        if (!sp->dev || x265hip_srcpic_upload(sp->dev, pic.m_picOrg[0], pic.m_stride))
+        {
+            fprintf(stderr, "x265hip: srcplanes: %s\n", x265hip_last_error());
+            abort();
         }
     }
     if (sp->version.load() == v)                        // otherwise these planes are simply never used
@@ -316,6 +338,22 @@ bool x265hip_srcplanes_where(const Yuv& y, const PicYuv** pic, uint32_t* version
         }
     }
     return false;
+}
+
+// x265_hip_sadplanes.cpp: the device copy of source picture `pic` in its version `version` (NULL: not built, or the buffer has moved on)
+x265hip_srcpic* x265hip_srcplanes_device(const PicYuv* pic, uint32_t version)
+{
+    SrcPic* sp = find_pic(pic, false);
+    if (!sp || sp->built.load(std::memory_order_acquire) != version || sp->version.load(std::memory_order_relaxed) != version)
+        return NULL;
+    return sp->dev;
+}
+
+// is `version` still the picture in `pic`'s buffer?  (x265_hip_sadplanes.cpp retires the surfaces of pictures that have left)
+bool x265hip_srcplanes_current(const PicYuv* pic, uint32_t version)
+{
+    SrcPic* sp = find_pic(pic, false);
+    return sp && sp->version.load(std::memory_order_relaxed) == version;
 }
 
 // called by setupAssemblyPrimitives in the default table mode, after the C table is complete
