@@ -687,15 +687,21 @@ typedef struct x265hip_sadsurf_level
 {
     int32_t        blocksX, blocksY;     /* width / N, height / N (blocks that lie inside the picture) */
     int32_t        entryBytes;           /* 2 (uint16: N * N * pixel max < 65536) or 4 (uint32) */
-    int32_t        reserved;
-    const int16_t* origin;               /* [blocksY * blocksX][2]: the vector (ox, oy) of window entry (0, 0), full-pel; NULL: level not built */
-    const void*    table;                /* [blocksY * blocksX][WIN * WIN]: entry j * WIN + i = SAD against the reference at vector (ox + i, oy + j) */
+    int32_t        blocksPerCtuRow;      /* 64 / N block rows per row of 64 picture lines */
+    /* Results are laid out per row of 64 picture lines (one device-to-host copy per band): block (bx, by) lives in chunk r = by / blocksPerCtuRow
+     * at index k = (by % blocksPerCtuRow) * blocksX + bx:
+     *   origin  (const int16_t*)((const char*)origin + r * ctuRowPitch) + 2 k      (ox, oy) = the vector of window entry (0, 0), full-pel
+     *   table   (const char*)table + r * ctuRowPitch + k * WIN * WIN * entryBytes   entry j * WIN + i = SAD at vector (ox + i, oy + j)
+     * origin == NULL: level not built */
+    const int16_t* origin;
+    const void*    table;
 } x265hip_sadsurf_level;
 typedef struct x265hip_sadsurf_view
 {
     x265hip_sadsurf_level level[X265HIP_SADSURF_LEVELS];
-    const int* ctuRowsReady;             /* rows of 64 picture lines: origins and tables of every block above line 64 * (*ctuRowsReady) are in host
-                                            memory (load with acquire semantics); grows as the reference picture's rows become final */
+    int64_t    ctuRowPitch;              /* bytes between the chunks of consecutive rows of 64 picture lines */
+    const int* ctuRowsReady;             /* origins and tables of every block above picture line 64 * (*ctuRowsReady) are in host memory (load with
+                                            acquire semantics); grows as the reference picture's rows become final */
 } x265hip_sadsurf_view;
 /* Levels 1..3 (N = 16, 32, 64) are built; level 0 is reserved (origin == NULL).  searchRange: 8..32, a multiple of 4.  The surface follows `ref`'s progress (x265hip_refpic_rows_final) by itself: rows that are
  * final already are built at once, the others as they arrive; x265hip_refpic_reset / _destroy of `ref` ends it (no further rows are published;

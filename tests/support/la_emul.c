@@ -429,11 +429,12 @@ struct x265hip_sadsurf
     x265hip_srcpic* src;
     x265hip_refpic* ref;                 /* NULL once the reference picture has gone (reset / destroy) */
     struct x265hip_sadsurf* next;
-    int S, lambda20, levelMask, ctuRows, ctuRowsReady;
-    uint32_t* wide[X265HIP_SADSURF_LEVELS];      /* the oracle's uint32 tables (the views narrow them where the ABI says uint16) */
+    int S, lambda20, ctuRows, ctuRowsReady;
     x265hip_sadsurf_view view;
-    int16_t* origin[X265HIP_SADSURF_LEVELS];
-    void* table[X265HIP_SADSURF_LEVELS];
+    int64_t originOff[X265HIP_SADSURF_LEVELS], tableOff[X265HIP_SADSURF_LEVELS];
+    char* buf;                                   /* ctuRows chunks of view.ctuRowPitch bytes, the layout of x265hip_sadsurf_level */
+    int16_t* origin[X265HIP_SADSURF_LEVELS];     /* the oracle's whole-picture arrays */
+    uint32_t* wide[X265HIP_SADSURF_LEVELS];
 };
 static uint64_t g_ssAttached, g_ssRows;
 
@@ -454,15 +455,23 @@ static void sadsurf_progress(x265hip_sadsurf* ss)
         else
             orc_sadsurf_rows_16((const uint16_t*)ss->src->luma, ss->src->w, (const uint16_t*)refOrg, rp->stride, rp->picW, rp->picH, rp->marginX, rp->marginY,
                                 ss->S, ss->lambda20, r, r + 1, ss->origin, ss->wide);
+        char* chunk = ss->buf + (size_t)r * ss->view.ctuRowPitch;
         for (int l = 1; l < X265HIP_SADSURF_LEVELS; l++)
         {
-            const int log2n = 3 + l;
-            const int bx = ss->src->w >> log2n, byTotal = ss->src->h >> log2n;
-            int by0 = (64 * r) >> log2n, by1 = (64 * (r + 1)) >> log2n;
-            if (by1 > byTotal) by1 = byTotal;
-            if (ss->view.level[l].entryBytes == 2)
-                for (size_t i = (size_t)by0 * bx * 256; i < (size_t)by1 * bx * 256; i++)
-                    ((uint16_t*)ss->table[l])[i] = (uint16_t)ss->wide[l][i];
+            const x265hip_sadsurf_level* v = &ss->view.level[l];
+            for (int j = 0; j < v->blocksPerCtuRow; j++)
+            {
+                const int by = r * v->blocksPerCtuRow + j;
+                if (by >= v->blocksY) break;
+                for (int bx = 0; bx < v->blocksX; bx++)
+                {
+                    const size_t b = (size_t)by * v->blocksX + bx, k = (size_t)j * v->blocksX + bx;
+                    memcpy(chunk + ss->originOff[l] + k * 4, ss->origin[l] + 2 * b, 4);
+                    for (int e = 0; e < 256; e++)
+                        if (v->entryBytes == 2) ((uint16_t*)(chunk + ss->tableOff[l]))[k * 256 + e] = (uint16_t)ss->wide[l][b * 256 + e];
+                        else ((uint32_t*)(chunk + ss->tableOff[l]))[k * 256 + e] = ss->wide[l][b * 256 + e];
+                }
+            }
         }
         g_ssRows++;
         __atomic_store_n(&ss->ctuRowsReady, r + 1, __ATOMIC_RELEASE);
@@ -493,7 +502,6 @@ static void sadsurf_detach_all(x265hip_refpic* rp)
 
 x265hip_sadsurf* x265hip_sadsurf_attach(x265hip_srcpic* src, x265hip_refpic* ref, int searchRange, int lambda20)
 {
-    const int levelMask = 14;
     if (!src || !ref || src->depth != ref->depth || src->w != ref->picW || src->h != ref->picH || searchRange < 8 || searchRange > 32 || (searchRange & 3) ||
         lambda20 < 0 || lambda20 > (1 << 20))
     {
@@ -501,20 +509,27 @@ x265hip_sadsurf* x265hip_sadsurf_attach(x265hip_srcpic* src, x265hip_refpic* ref
         return NULL;
     }
     x265hip_sadsurf* ss = (x265hip_sadsurf*)calloc(1, sizeof(*ss));
-    ss->src = src; ss->ref = ref; ss->S = searchRange; ss->lambda20 = lambda20; ss->levelMask = levelMask;
+    ss->src = src; ss->ref = ref; ss->S = searchRange; ss->lambda20 = lambda20;
     ss->ctuRows = (src->h + 63) / 64;
-    for (int l = 0; l < X265HIP_SADSURF_LEVELS; l++)
+    int64_t off = 0;
+    for (int l = 1; l < X265HIP_SADSURF_LEVELS; l++)
     {
-        if (!(ss->levelMask >> l & 1)) continue;
         const int log2n = 3 + l, N = 1 << log2n;
         x265hip_sadsurf_level* v = &ss->view.level[l];
-        v->blocksX = src->w >> log2n; v->blocksY = src->h >> log2n;
+        v->blocksX = src->w >> log2n; v->blocksY = src->h >> log2n; v->blocksPerCtuRow = 64 / N;
         v->entryBytes = (uint64_t)N * N * ((1u << src->depth) - 1) < 65536 ? 2 : 4;
         const size_t nb = (size_t)v->blocksX * v->blocksY;
         ss->origin[l] = (int16_t*)calloc(nb ? nb : 1, 4);
         ss->wide[l] = (uint32_t*)calloc(nb ? nb : 1, (size_t)256 * 4);
-        ss->table[l] = v->entryBytes == 4 ? (void*)ss->wide[l] : calloc(nb ? nb : 1, (size_t)256 * 2);
-        v->origin = ss->origin[l]; v->table = ss->table[l];
+        ss->originOff[l] = off; off += (int64_t)v->blocksPerCtuRow * v->blocksX * 4;
+        ss->tableOff[l] = off; off += (int64_t)v->blocksPerCtuRow * v->blocksX * 256 * v->entryBytes;
+    }
+    ss->view.ctuRowPitch = off;
+    ss->buf = (char*)calloc((size_t)ss->ctuRows, (size_t)off);
+    for (int l = 1; l < X265HIP_SADSURF_LEVELS; l++)
+    {
+        ss->view.level[l].origin = (const int16_t*)(ss->buf + ss->originOff[l]);
+        ss->view.level[l].table = ss->buf + ss->tableOff[l];
     }
     ss->view.ctuRowsReady = &ss->ctuRowsReady;
     pthread_mutex_lock(&g_ssLock);
@@ -537,7 +552,8 @@ void x265hip_sadsurf_release(x265hip_sadsurf* ss)
         if (*pp) *pp = ss->next;
     }
     pthread_mutex_unlock(&g_ssLock);
-    for (int l = 0; l < X265HIP_SADSURF_LEVELS; l++) { free(ss->origin[l]); if (ss->table[l] != (void*)ss->wide[l]) free(ss->table[l]); free(ss->wide[l]); }
+    for (int l = 0; l < X265HIP_SADSURF_LEVELS; l++) { free(ss->origin[l]); free(ss->wide[l]); }
+    free(ss->buf);
     free(ss);
 }
 int x265hip_sadsurf_stats(uint64_t* attached, uint64_t* ctuRows)

@@ -1,0 +1,164 @@
+"""SAD surfaces (include/x265hip.h x265hip_sadsurf_*; x265_amd/csrc/sadsurf.hip): the integer-pel SADs of MotionEstimate::motionEstimate
+(reference source/encoder/motion.cpp:246-330, :752-756) as tables built on the device.
+
+CPU tier: the restatement (oracle/x265_oracle_sadsurf.inc, driven through the emulated ABI of tests/support/libx265hip_emul.so) against the
+REAL reference's sad<N, N> (oracle/_ref/libx265ref8.so through backends.Ref; the pinned oracle primitive where /root/reference was not
+available at build time) — sampled entries of every window — and the windows' legality.  GPU tier: the device surfaces against the
+restatement, origin for origin and entry for entry, on pictures with ragged edges, with the reference picture arriving in bands before and
+after the surface is attached, and several surfaces on one reference."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+EMUL = os.path.join(ROOT, "tests", "support", "libx265hip_emul.so")
+MX, MY = 96, 80            # PicYuv's luma margins at CTU 64 (picyuv.cpp:87-89)
+WIN = 16
+
+
+def _emul(hp):
+    if not os.path.exists(EMUL):
+        pytest.skip("tests/support/libx265hip_emul.so not built (make -C oracle emul)")
+    em = C.CDLL(EMUL)
+    for name, (res, args) in hp.PROTOTYPES.items():
+        if name.startswith(("x265hip_refpic_", "x265hip_srcpic_", "x265hip_sadsurf_")) or name == "x265hip_last_error":
+            fn = getattr(em, name)
+            fn.restype, fn.argtypes = res, args
+    return em
+
+
+def _pictures(w, h, seed, count=2):
+    """A padded reference picture (as the encoder's recon buffer: margins replicated) and `count` source pictures = the reference moved per
+    48 x 40 tile by up to +-20 pixels plus noise."""
+    rng = np.random.default_rng(seed)
+    from cases import textured_frame
+    big = textured_frame(rng, h + 128, w + 128, 8, sigma=2.0)
+    ref = big[64:64 + h, 64:64 + w]
+    rows = ((h + 63) // 64) * 64 + 2 * MY
+    stride = ((w + 2 * MX + 63) // 64) * 64
+    buf = np.zeros((rows, stride), np.uint8)
+    buf[:h + 2 * MY, :w + 2 * MX] = np.pad(ref, ((MY, MY), (MX, MX)), mode="edge")
+    srcs = []
+    for k in range(count):
+        s = np.zeros_like(ref)
+        for y0 in range(0, h, 40):
+            for x0 in range(0, w, 48):
+                dy, dx = int(rng.integers(-20, 21)), int(rng.integers(-20, 21))
+                y1, x1 = min(y0 + 40, h), min(x0 + 48, w)
+                s[y0:y1, x0:x1] = big[64 + y0 + dy:64 + y1 + dy, 64 + x0 + dx:64 + x1 + dx]
+        srcs.append(np.ascontiguousarray(np.clip(np.rint(s + rng.normal(0, 2.0, s.shape)), 0, 255).astype(np.uint8)))
+    return buf, stride, rows, srcs
+
+
+def _read_view(hp, L, ss, w, h):
+    """{level: (origins [by][bx][2] int16, tables [by][bx][256] uint32)} out of the chunked host layout."""
+    v = C.cast(L.x265hip_sadsurf_get_view(ss), C.POINTER(hp.SadSurfView)).contents
+    assert v.ctuRowsReady[0] == (h + 63) // 64, v.ctuRowsReady[0]
+    out = {}
+    for l in (1, 2, 3):
+        lv = v.level[l]
+        n = 8 << l
+        assert (lv.blocksX, lv.blocksY, lv.blocksPerCtuRow) == (w // n, h // n, 64 // n)
+        org = np.zeros((lv.blocksY, lv.blocksX, 2), np.int16)
+        tab = np.zeros((lv.blocksY, lv.blocksX, WIN * WIN), np.uint32)
+        et = np.uint16 if lv.entryBytes == 2 else np.uint32
+        for by in range(lv.blocksY):
+            r, j = divmod(by, lv.blocksPerCtuRow)
+            k0 = j * lv.blocksX
+            o = (C.c_int16 * (2 * lv.blocksX)).from_address(lv.origin + r * v.ctuRowPitch + 4 * k0)
+            org[by] = np.frombuffer(o, np.int16).reshape(lv.blocksX, 2)
+            t = (C.c_char * (lv.blocksX * WIN * WIN * lv.entryBytes)).from_address(lv.table + r * v.ctuRowPitch + k0 * WIN * WIN * lv.entryBytes)
+            tab[by] = np.frombuffer(t, et).reshape(lv.blocksX, WIN * WIN)
+        out[l] = (org, tab)
+    return out
+
+
+def _run(hp, L, w, h, seed, S, lam, bands, attach_after):
+    """Drive one library: reference rows arrive in `bands` (picture rows); source k is attached after band attach_after[k] (-1: before any)."""
+    buf, stride, rows, srcs = _pictures(w, h, seed, count=len(attach_after))
+    rp = L.x265hip_refpic_create(8, w, h, stride, MX, MY, rows, buf.ctypes.data)
+    assert rp, L.x265hip_last_error()
+    sps, sss = [], [None] * len(srcs)
+    for s in srcs:
+        sp = L.x265hip_srcpic_create(8, w, h)
+        assert sp, L.x265hip_last_error()
+        assert L.x265hip_srcpic_upload(sp, s.ctypes.data, s.shape[1]) == 0
+        sps.append(sp)
+
+    def attach(k):
+        sss[k] = L.x265hip_sadsurf_attach(sps[k], rp, S, lam)
+        assert sss[k], L.x265hip_last_error()
+
+    for k, a in enumerate(attach_after):
+        if a < 0:
+            attach(k)
+    for i, r in enumerate(bands):
+        assert L.x265hip_refpic_rows_final(rp, r) == 0
+        for k, a in enumerate(attach_after):
+            if a == i:
+                attach(k)
+    assert L.x265hip_refpic_wait(rp) == 0, L.x265hip_last_error()
+    views = [_read_view(hp, L, ss, w, h) for ss in sss]
+    for ss in sss:
+        L.x265hip_sadsurf_release(ss)
+    L.x265hip_refpic_wait(rp)
+    L.x265hip_refpic_destroy(rp)
+    for sp in sps:
+        L.x265hip_srcpic_destroy(sp)
+    return views, buf, stride, srcs
+
+
+def test_restatement_entries_are_the_reference_sad_and_windows_are_legal():
+    import x265_amd.hipprim as hp
+    import backends
+    em = _emul(hp)
+    try:
+        o = backends.Ref(8)            # the real sad<N, N> (pixel.cpp:40-55) out of oracle/_ref/libx265ref8.so
+    except Exception:
+        o = backends.Orc(8)            # pinned to it by tests/test_oracle_vs_ref.py
+    w, h, S = 200, 136, 16
+    views, buf, stride, srcs = _run(hp, em, w, h, 5, S, 9 * 20, [64, 128, h], [-1])
+    rng = np.random.default_rng(1)
+    for l, (org, tab) in views[0].items():
+        n = 8 << l
+        for by in range(org.shape[0]):
+            for bx in range(org.shape[1]):
+                ox, oy = int(org[by, bx, 0]), int(org[by, bx, 1])
+                x, y = bx * n, by * n
+                assert -S <= ox <= S - WIN and -S <= oy <= S - WIN
+                assert x + ox >= -MX and x + ox + WIN - 1 + n <= w + MX and y + oy >= -MY and y + oy + WIN - 1 + n <= h + MY
+                for k in rng.integers(0, WIN * WIN, 24):
+                    j, i = divmod(int(k), WIN)
+                    want = o.sad(n, n, srcs[0], (y, x), buf, (MY + y + oy + j, MX + x + ox + i))
+                    assert tab[by, bx, k] == want, (l, bx, by, i, j)
+
+
+GPU_CASES = [
+    # w, h, seed, S, lambda20, bands (picture rows final), attach_after per source
+    (200, 136, 11, 32, 180, [64, 128, 136], [-1, 1]),
+    (416, 240, 12, 32, 0, [240], [-1, 0]),
+    (352, 288, 13, 16, 400, [64, 128, 192, 256, 288], [0, 2, 4]),
+    (72, 200, 14, 32, 180, [128, 200], [-1]),
+    (1280, 720, 15, 32, 180, [192, 448, 720], [1]),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(len(GPU_CASES)))
+def test_device_surfaces_match_restatement(case):
+    import x265_amd.hipprim as hp
+    L = hp.lib()
+    hp.check(L.x265hip_init(0))
+    em = _emul(hp)
+    w, h, seed, S, lam, bands, attach_after = GPU_CASES[case]
+    got, *_ = _run(hp, L, w, h, seed, S, lam, bands, attach_after)
+    want, *_ = _run(hp, em, w, h, seed, S, lam, bands, attach_after)
+    for k in range(len(attach_after)):
+        for l in (1, 2, 3):
+            assert np.array_equal(got[k][l][0], want[k][l][0]), ("origins", k, l)
+            assert np.array_equal(got[k][l][1], want[k][l][1]), ("tables", k, l)

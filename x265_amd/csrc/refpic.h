@@ -1,0 +1,87 @@
+// refpic.h — the reference-picture mirror's state and its worker thread, shared by refpic.hip (sub-pel planes) and sadsurf.hip (SAD surfaces
+// that follow a mirror's progress).  Not part of the C ABI.
+#pragma once
+#include "common.h"
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+struct x265hip_sadsurf;
+
+struct x265hip_refpic
+{
+    int depth = 8, B = 1, picW = 0, picH = 0, marginX = 0, marginY = 0, bufRows = 0, device = 0;
+    int64_t stride = 0, planeElems = 0;
+    const char* hostBase = nullptr;          // the encoder's buffer (PicYuv::m_picBuf[0])
+    char* hStage = nullptr;                   // page-locked staging copy of the rows on their way up
+    char* dPic = nullptr;                     // device copy of the padded picture
+    char* dPlanes = nullptr;                  // 16 planes (plane 0 unused), planeElems apart
+    char* hPlanes = nullptr;                  // page-locked host planes 1..15 at (p - 1) * planeElems
+    hipStream_t st = nullptr;
+    // progress (buffer rows: 0 = first row of the top margin)
+    int uploaded = 0;                         // rows [0, uploaded) of the buffer are on the device   (worker only)
+    int phaseDone = 4;                        // phase rows [4, phaseDone) are in hPlanes             (worker only)
+    std::atomic<int> rowsReady{ -(1 << 30) }; // published: phase rows of PICTURE rows [-(marginY - 4), rowsReady) are valid
+    std::atomic<uint32_t> epoch{ 0 };         // bumped by reset(): queued work of an older picture is dropped
+    std::atomic<int> pending{ 0 };            // queued + running jobs
+    std::atomic<int> failed{ 0 };
+    std::vector<x265hip_sadsurf*> surfaces;   // SAD surfaces attached to this picture (worker only; sadsurf.hip)
+};
+
+namespace xh {
+
+// kind 0: rows [0, rowsFinal) of rp's picture are final.  kind 1 / 2: attach / release the SAD surface `ss` (sadsurf.hip); rp may be null for a
+// release whose picture has gone
+struct RefJob { x265hip_refpic* rp; int rowsFinal; uint32_t epoch; int kind = 0; x265hip_sadsurf* ss = nullptr; };
+
+struct RefWorker
+{
+    std::mutex m;
+    std::condition_variable cv, idle;
+    std::deque<RefJob> q;
+    std::thread th;
+    bool started = false, stop = false;
+
+    void start()
+    {
+        std::lock_guard<std::mutex> g(m);
+        if (started) return;
+        started = true;
+        th = std::thread([this] { run(); });
+        atexit([] { worker().shutdown(); });
+    }
+    void shutdown()
+    {
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (!started || stop) return;
+            stop = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+    void push(const RefJob& j)
+    {
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (stop)
+                return;                 // the process is exiting (atexit joined the worker): nobody would run the job, and wait() must not block on it
+            if (j.rp) j.rp->pending.fetch_add(1);
+            q.push_back(j);
+        }
+        cv.notify_one();
+    }
+    static RefWorker& worker() { static RefWorker* w = new RefWorker; return *w; }      // leaked on purpose: lives as long as the process
+    void run();
+};
+
+
+// sadsurf.hip, called on the worker thread
+void sadsurf_rows_arrived(x265hip_refpic* rp);            // after a band of rp has been uploaded (and its planes published)
+void sadsurf_job(const RefJob& j);                        // kinds 1 and 2
+void sadsurf_detach_all(x265hip_refpic* rp);              // rp is being reset or destroyed (worker idle for rp)
+
+} // namespace xh

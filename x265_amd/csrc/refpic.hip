@@ -14,79 +14,20 @@
 // bitstream is identical whatever the timing.  The encoder never waits for this module.
 #include "common.h"
 #include "internal.h"
-#include <atomic>
+#include "refpic.h"
 #include <cstring>
-#include <condition_variable>
-#include <deque>
-#include <mutex>
-#include <thread>
-
-struct x265hip_refpic
-{
-    int depth = 8, B = 1, picW = 0, picH = 0, marginX = 0, marginY = 0, bufRows = 0, device = 0;
-    int64_t stride = 0, planeElems = 0;
-    const char* hostBase = nullptr;          // the encoder's buffer (PicYuv::m_picBuf[0])
-    char* hStage = nullptr;                   // page-locked staging copy of the rows on their way up
-    char* dPic = nullptr;                     // device copy of the padded picture
-    char* dPlanes = nullptr;                  // 16 planes (plane 0 unused), planeElems apart
-    char* hPlanes = nullptr;                  // page-locked host planes 1..15 at (p - 1) * planeElems
-    hipStream_t st = nullptr;
-    // progress (buffer rows: 0 = first row of the top margin)
-    int uploaded = 0;                         // rows [0, uploaded) of the buffer are on the device   (worker only)
-    int phaseDone = 4;                        // phase rows [4, phaseDone) are in hPlanes             (worker only)
-    std::atomic<int> rowsReady{ -(1 << 30) }; // published: phase rows of PICTURE rows [-(marginY - 4), rowsReady) are valid
-    std::atomic<uint32_t> epoch{ 0 };         // bumped by reset(): queued work of an older picture is dropped
-    std::atomic<int> pending{ 0 };            // queued + running jobs
-    std::atomic<int> failed{ 0 };
-};
 
 namespace xh {
-
-struct RefJob { x265hip_refpic* rp; int rowsFinal; uint32_t epoch; };
-
-struct RefWorker
-{
-    std::mutex m;
-    std::condition_variable cv, idle;
-    std::deque<RefJob> q;
-    std::thread th;
-    bool started = false, stop = false;
-
-    void start()
-    {
-        std::lock_guard<std::mutex> g(m);
-        if (started) return;
-        started = true;
-        th = std::thread([this] { run(); });
-        atexit([] { worker().shutdown(); });
-    }
-    void shutdown()
-    {
-        {
-            std::lock_guard<std::mutex> g(m);
-            if (!started || stop) return;
-            stop = true;
-        }
-        cv.notify_all();
-        if (th.joinable()) th.join();
-    }
-    void push(const RefJob& j)
-    {
-        j.rp->pending.fetch_add(1);
-        {
-            std::lock_guard<std::mutex> g(m);
-            q.push_back(j);
-        }
-        cv.notify_one();
-    }
-    static RefWorker& worker() { static RefWorker* w = new RefWorker; return *w; }      // leaked on purpose: lives as long as the process
-    void run();
-};
 
 int build_subpel_rows(int depth, const void* refOrigin, int64_t stride, int x0, int x1, int y0, int y1, void* planesOrigin, int64_t planeElems, hipStream_t st);
 
 static void process(const RefJob& j)
 {
+    if (j.kind)
+    {
+        sadsurf_job(j);
+        return;
+    }
     x265hip_refpic* rp = j.rp;
     if (j.epoch != rp->epoch.load() || rp->failed.load())
         return;
@@ -122,6 +63,9 @@ static void process(const RefJob& j)
     }
     else if (hipStreamSynchronize(rp->st) != hipSuccess)
         rp->failed = 1;
+    // the SAD surfaces that follow this picture: after the planes, which the encoder needs first
+    if (!rp->failed.load() && j.epoch == rp->epoch.load())
+        sadsurf_rows_arrived(rp);
 }
 
 void RefWorker::run()
@@ -138,7 +82,7 @@ void RefWorker::run()
             q.pop_front();
         }
         process(j);
-        if (j.rp->pending.fetch_sub(1) == 1)
+        if (j.rp && j.rp->pending.fetch_sub(1) == 1)
         {
             std::lock_guard<std::mutex> g(m);
             idle.notify_all();
@@ -196,6 +140,7 @@ void x265hip_refpic_destroy(x265hip_refpic* rp)
     if (!rp) return;
     rp->epoch.fetch_add(1);
     if (rp->st) (void)x265hip_refpic_wait(rp);
+    sadsurf_detach_all(rp);                                           // the worker is idle for rp: nobody else touches the list
     (void)hipSetDevice(rp->device);
     if (rp->hStage) (void)hipHostFree(rp->hStage);
     if (rp->dPic) (void)hipFree(rp->dPic);
@@ -211,6 +156,10 @@ int x265hip_refpic_reset(x265hip_refpic* rp)
     rp->rowsReady.store(-(1 << 30), std::memory_order_release);     // nothing is valid: readers fall through to the C filter
     rp->epoch.fetch_add(1);                                           // whatever is queued for the old picture is dropped
     int e = x265hip_refpic_wait(rp);                                  // the worker owns uploaded / phaseDone: take them over only when it is idle
+    // a band the worker was finishing when the epoch moved may have published its rows after the store above (it checks the epoch before
+    // it publishes, not atomically with it): nothing of the old picture may stay visible
+    rp->rowsReady.store(-(1 << 30), std::memory_order_release);
+    sadsurf_detach_all(rp);
     rp->uploaded = 0;
     rp->phaseDone = 4;
     return e;

@@ -1,0 +1,569 @@
+// sadsurf.hip — SAD surfaces behind x265hip_sadsurf_* (include/x265hip.h): the integer-pel candidates of the encoder's motion search as table loads.
+//
+// MotionEstimate::motionEstimate (reference source/encoder/motion.cpp:739-1569) measures an integer-pel candidate as
+// sad(fenc, FENC_STRIDE, fref + mx + my * stride, stride) (:246-330) — a function of the source picture, the finished reference picture, the
+// block's position and the vector, and of nothing the encoder decides.  One surface = one (source picture, reference picture) pair: for every
+// aligned 16 / 32 / 64 block a 16 x 16 window of vectors, built here as the reference picture's rows arrive (the refpic worker calls
+// sadsurf_rows_arrived after each band) and mirrored into page-locked host memory, where x265_amd/host/x265_hip_sadplanes.cpp reads them.
+//
+// The kernel is the search-window kernel of the design: one workgroup per 64 x 64 region (CTU), 16 waves.
+//   stage    the source CTU (4 KB) and the reference window (64 + 2S)^2 around it (16 KB at S = 32) go to LDS once;
+//   measure  wave b owns 16x16 block b of the CTU: its 256 source pixels sit in registers, and every vector of [-S, S)^2 is measured four at a
+//            time with v_qsad_pk_u16_u8 (four SADs of 4 source pixels against a sliding 8-byte window of the reference row: 16 absolute
+//            differences per lane and instruction, no alignment work), 64 instructions per four candidates; the 16 x (2S)^2 results
+//            (u16, 128 KB at S = 32) stay in LDS — the exhaustive search's unique footprint per CTU is 4 KB + 16 KB in, nothing out;
+//   decide   top down 64 -> 32 -> 16: a block's SAD at a vector is the sum of its 16x16 parts; cost = SAD + vector cost around the parent's
+//            best vector; wave / workgroup minimum (DPP + LDS);
+//   emit     the 16 x 16 window around each block's best vector is gathered out of the LDS surface (no second SAD pass) and written with the
+//            block's origin into the CTU row's chunk of the table buffer.
+// Values are pinned to the oracle (oracle/x265_oracle_sadsurf.inc: entries == sad<N, N> of the reference, pixel.cpp:40-55; origins == the same
+// rule) by tests/test_sadsurf.py.  8-bit pictures only: v_qsad_pk_u16_u8 is a byte instruction (16-bit builds keep the C slots).
+#include "common.h"
+#include "internal.h"
+#include "refpic.h"
+#include <cstring>
+#include <map>
+
+struct x265hip_srcpic
+{
+    int depth = 8, w = 0, h = 0, device = 0;
+    int64_t pitch = 0;                  // bytes between rows of dLuma
+    char* dLuma = nullptr;
+    char* hStage = nullptr;             // page-locked staging copy (the encoder's buffer is ordinary memory)
+    hipStream_t st = nullptr;
+};
+
+namespace xh {
+
+constexpr int kWin = X265HIP_SADSURF_WIN;
+
+struct SurfLayout
+{
+    int blocksX[4], blocksY[4], per[4], entryBytes[4];
+    int64_t originOff[4], tableOff[4];   // byte offsets inside a CTU row's chunk
+    int64_t pitch;                        // bytes per CTU row
+    int ctuCols, ctuRows;
+};
+
+struct SurfArgs
+{
+    const uint8_t* src; int64_t srcPitch;
+    const uint8_t* ref; int64_t refStride;       // reference pixel (0, 0)
+    int picW, picH, marginX, marginY;
+    int S, lambda20, row0;
+    char* out;                                    // device table buffer (chunk of CTU row 0 first)
+    int64_t pitch;
+    int64_t originOff[4], tableOff[4];
+    int blocksX[4];
+};
+
+} // namespace xh
+
+struct x265hip_sadsurf
+{
+    x265hip_srcpic* src = nullptr;
+    x265hip_refpic* ref = nullptr;       // null once the reference picture has gone (under g_ssLock)
+    int S = 32, lambda20 = 0;
+    xh::SurfLayout lay;
+    char* dBuf = nullptr;                // ctuRows * pitch
+    char* hBuf = nullptr;                // page-locked mirror, same layout
+    size_t bytes = 0;
+    int rowsBuilt = 0;                   // worker only
+    std::atomic<int> ctuRowsReady{ 0 };
+    x265hip_sadsurf_view view;
+    std::atomic<bool> released{ false };
+};
+
+namespace xh {
+
+static std::mutex g_ssLock;              // the surfaces lists of the mirrors and x265hip_sadsurf::ref
+static std::mutex g_poolLock;
+struct PoolEntry { char* d; char* h; };
+static std::multimap<size_t, PoolEntry> g_pool;      // table buffers of finished surfaces, by size (pinned allocations are expensive: ~ms)
+static std::atomic<uint64_t> g_statAttached{ 0 }, g_statRows{ 0 };
+
+static void layout_for(int w, int h, int depth, SurfLayout& L)
+{
+    memset(&L, 0, sizeof(L));
+    L.ctuCols = (w + 63) / 64; L.ctuRows = (h + 63) / 64;
+    int64_t off = 0;
+    for (int l = 1; l < 4; l++)
+    {
+        const int N = 8 << l;
+        L.blocksX[l] = w / N; L.blocksY[l] = h / N; L.per[l] = 64 / N;
+        L.entryBytes[l] = (uint64_t)N * N * ((1u << depth) - 1) < 65536 ? 2 : 4;
+        L.originOff[l] = off; off += (int64_t)L.per[l] * L.blocksX[l] * 4;
+        off = (off + 15) & ~(int64_t)15;
+        L.tableOff[l] = off; off += (int64_t)L.per[l] * L.blocksX[l] * kWin * kWin * L.entryBytes[l];
+        off = (off + 15) & ~(int64_t)15;
+    }
+    L.pitch = (off + 255) & ~(int64_t)255;
+}
+
+// ---- the kernel ---------------------------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int ss_bits(int d) { return 2 * (31 - __clz(d + 1)) + 1; }          // 2 floor(log2(d + 1)) + 1
+__device__ __forceinline__ uint64_t u64_min(uint64_t a, uint64_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        const uint32_t lo = __shfl_xor((uint32_t)v, off), hi = __shfl_xor((uint32_t)(v >> 32), off);
+        v = u64_min(v, ((uint64_t)hi << 32) | lo);
+    }
+    return v;
+}
+
+// the cheapest vector of one block: `sum(c)` = the block's SAD at candidate c (index dyIdx * 2S + dxIdx).  Called by `threads` consecutive
+// threads (a multiple of 64) that scan the candidates `first`, `first + threads`, ...; returns the packed key of this thread's best
+template <typename F>
+__device__ __forceinline__ uint64_t ss_scan(F sum, int S, int first, int threads, int xlo, int xhi, int ylo, int yhi, int px, int py, int lambda20)
+{
+    const int D = 2 * S;
+    uint64_t best = ~(uint64_t)0;
+    for (int c = first; c < D * D; c += threads)
+    {
+        const int dyI = c / D, dxI = c - dyI * D;
+        const int vx = dxI - S, vy = dyI - S;
+        if (vx < xlo || vx > xhi || vy < ylo || vy > yhi)
+            continue;
+        const uint32_t cost = sum(c) + (uint32_t)((lambda20 * (ss_bits(4 * abs(vx - px)) + ss_bits(4 * abs(vy - py))) + 10) / 20);
+        best = u64_min(best, ((uint64_t)cost << 12) | (uint32_t)c);          // ties: the smaller candidate index = smaller vy, then smaller vx
+    }
+    return best;
+}
+
+__device__ __forceinline__ void ss_origin(uint64_t key, int S, int xlo, int xhi, int ylo, int yhi, int& bx, int& by, int& ox, int& oy)
+{
+    const int D = 2 * S;
+    int c = (int)(key & 4095);
+    if (key == ~(uint64_t)0) c = S * D + S;               // no legal candidate (cannot happen with margins >= S): vector (0, 0)
+    by = c / D - S; bx = c - (c / D) * D - S;
+    ox = bx - kWin / 2; oy = by - kWin / 2;
+    if (ox > S - kWin) ox = S - kWin;
+    if (ox < -S) ox = -S;
+    if (oy > S - kWin) oy = S - kWin;
+    if (oy < -S) oy = -S;
+    if (ox > xhi - (kWin - 1)) ox = xhi - (kWin - 1);
+    if (ox < xlo) ox = xlo;
+    if (oy > yhi - (kWin - 1)) oy = yhi - (kWin - 1);
+    if (oy < ylo) oy = ylo;
+}
+
+__global__ __launch_bounds__(1024) void sadsurf_ctu_kernel(SurfArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int S = a.S, D = 2 * S;
+    const int RW = 64 + D + 8;                                   // reference window row pitch (bytes): + 4 for the last 8-byte window, multiple of 8
+    uint8_t* sSrc = smem;                                        // [64][64]
+    uint8_t* sRef = smem + 4096;                                 // [64 + D][RW]
+    uint16_t* sSurf = (uint16_t*)(smem + 4096 + (size_t)(64 + D) * RW);      // [16][D][D]
+    __shared__ uint64_t sRed[16];
+    __shared__ int sBest[4][16][2];                              // [level][block][vx, vy]
+    __shared__ int sOrg[4][16][2];
+
+    const int cx = blockIdx.x, cy = a.row0 + blockIdx.y;
+    const int x0 = cx * 64, y0 = cy * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- stage ----
+    for (int i = tid; i < 64 * 16; i += 1024)
+    {
+        const int r = i >> 4, c4 = (i & 15) * 4;
+        uint32_t v = 0;
+        if (y0 + r < a.picH && x0 + c4 + 3 < a.picW)
+            v = ld_global_unaligned<uint32_t>(a.src + (int64_t)(y0 + r) * a.srcPitch + x0 + c4);
+        else if (y0 + r < a.picH)
+            for (int k = 0; k < 4; k++)
+                if (x0 + c4 + k < a.picW) v |= (uint32_t)a.src[(int64_t)(y0 + r) * a.srcPitch + x0 + c4 + k] << (8 * k);
+        *(uint32_t*)(sSrc + r * 64 + c4) = v;
+    }
+    {
+        const int dw = RW / 4;
+        for (int i = tid; i < (64 + D) * dw; i += 1024)
+        {
+            const int r = i / dw, c4 = (i - r * dw) * 4;
+            *(uint32_t*)(sRef + r * RW + c4) = ld_global_unaligned<uint32_t>(a.ref + (int64_t)(y0 - S + r) * a.refStride + (x0 - S + c4));
+        }
+    }
+    __syncthreads();
+
+    // ---- measure: wave b <-> 16x16 block b ----
+    {
+        const int b = wave, bx = b & 3, by = b >> 2;
+        const bool inside = x0 + bx * 16 + 16 <= a.picW && y0 + by * 16 + 16 <= a.picH;
+        if (inside)
+        {
+            uint32_t s[16][4];
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    s[r][k] = *(const uint32_t*)(sSrc + (by * 16 + r) * 64 + bx * 16 + 4 * k);
+            const int Q = D / 4;
+            for (int item = lane; item < Q * D; item += 64)
+            {
+                const int dyI = item / Q, q = item - dyI * Q;
+                const uint8_t* rp = sRef + (by * 16 + dyI) * RW + bx * 16 + 4 * q;
+                uint64_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                {
+                    const uint32_t* w = (const uint32_t*)(rp + r * RW);
+                    const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
+                    acc0 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)d1 << 32) | d0, s[r][0], acc0);
+                    acc1 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)d2 << 32) | d1, s[r][1], acc1);
+                    acc2 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)d3 << 32) | d2, s[r][2], acc2);
+                    acc3 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)d4 << 32) | d3, s[r][3], acc3);
+                }
+                // four u16 lanes each at most 64 * 255: the sum of the four stays below 65536 per lane (16 * 16 * 255 = 65280), no carry between them
+                *(uint64_t*)(sSurf + ((size_t)b * D + dyI) * D + 4 * q) = acc0 + acc1 + acc2 + acc3;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- decide, top down ----
+    const int DD = D * D;
+    // level 3: the whole CTU, all 1024 threads
+    const bool have3 = x0 + 64 <= a.picW && y0 + 64 <= a.picH;
+    if (have3)
+    {
+        const int xlo = -a.marginX - x0, xhi = a.picW + a.marginX - 64 - x0, ylo = -a.marginY - y0, yhi = a.picH + a.marginY - 64 - y0;
+        uint64_t k = ss_scan([&](int c) { uint32_t t = 0;
+#pragma unroll
+                                          for (int b = 0; b < 16; b++) t += sSurf[b * DD + c];
+                                          return t; }, S, tid, 1024, xlo, xhi, ylo, yhi, 0, 0, a.lambda20);
+        k = wave_min_u64(k);
+        if (lane == 0) sRed[wave] = k;
+        __syncthreads();
+        if (tid == 0)
+        {
+            uint64_t m = sRed[0];
+            for (int i = 1; i < 16; i++) m = u64_min(m, sRed[i]);
+            int bx, by, ox, oy;
+            ss_origin(m, S, xlo, xhi, ylo, yhi, bx, by, ox, oy);
+            sBest[3][0][0] = bx; sBest[3][0][1] = by; sOrg[3][0][0] = ox; sOrg[3][0][1] = oy;
+        }
+    }
+    __syncthreads();
+    // level 2: 32x32 block g <-> threads [256 g, 256 g + 256)
+    {
+        const int g = tid >> 8, t = tid & 255, gx = g & 1, gy = g >> 1;
+        const int x = x0 + gx * 32, y = y0 + gy * 32;
+        const bool have = x + 32 <= a.picW && y + 32 <= a.picH;
+        const int xlo = -a.marginX - x, xhi = a.picW + a.marginX - 32 - x, ylo = -a.marginY - y, yhi = a.picH + a.marginY - 32 - y;
+        uint64_t k = ~(uint64_t)0;
+        if (have)
+        {
+            const int px = have3 ? sBest[3][0][0] : 0, py = have3 ? sBest[3][0][1] : 0;
+            const int b0 = (gy * 2) * 4 + gx * 2;
+            k = ss_scan([&](int c) { return (uint32_t)sSurf[b0 * DD + c] + sSurf[(b0 + 1) * DD + c] + sSurf[(b0 + 4) * DD + c] + sSurf[(b0 + 5) * DD + c]; },
+                        S, t, 256, xlo, xhi, ylo, yhi, px, py, a.lambda20);
+            k = wave_min_u64(k);
+        }
+        if (lane == 0) sRed[wave] = k;
+        __syncthreads();
+        if (have && t == 0)
+        {
+            uint64_t m = u64_min(u64_min(sRed[4 * g], sRed[4 * g + 1]), u64_min(sRed[4 * g + 2], sRed[4 * g + 3]));
+            int bx, by, ox, oy;
+            ss_origin(m, S, xlo, xhi, ylo, yhi, bx, by, ox, oy);
+            sBest[2][g][0] = bx; sBest[2][g][1] = by; sOrg[2][g][0] = ox; sOrg[2][g][1] = oy;
+        }
+    }
+    __syncthreads();
+    // level 1: 16x16 block b <-> wave b
+    {
+        const int b = wave, bx16 = b & 3, by16 = b >> 2;
+        const int x = x0 + bx16 * 16, y = y0 + by16 * 16;
+        const bool have = x + 16 <= a.picW && y + 16 <= a.picH;
+        if (have)
+        {
+            const int g = (by16 >> 1) * 2 + (bx16 >> 1);
+            const bool haveParent = x0 + (bx16 >> 1) * 32 + 32 <= a.picW && y0 + (by16 >> 1) * 32 + 32 <= a.picH;
+            const int px = haveParent ? sBest[2][g][0] : 0, py = haveParent ? sBest[2][g][1] : 0;
+            const int xlo = -a.marginX - x, xhi = a.picW + a.marginX - 16 - x, ylo = -a.marginY - y, yhi = a.picH + a.marginY - 16 - y;
+            uint64_t k = ss_scan([&](int c) { return (uint32_t)sSurf[b * DD + c]; }, S, lane, 64, xlo, xhi, ylo, yhi, px, py, a.lambda20);
+            k = wave_min_u64(k);
+            if (lane == 0)
+            {
+                int vx, vy, ox, oy;
+                ss_origin(k, S, xlo, xhi, ylo, yhi, vx, vy, ox, oy);
+                sOrg[1][b][0] = ox; sOrg[1][b][1] = oy;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- emit: origins and the 16 x 16 windows, gathered from the LDS surface ----
+    char* chunk = a.out + (int64_t)cy * a.pitch;
+    // level 1: wave b, 4 entries per lane
+    {
+        const int b = wave, bx16 = b & 3, by16 = b >> 2;
+        if (x0 + bx16 * 16 + 16 <= a.picW && y0 + by16 * 16 + 16 <= a.picH)
+        {
+            const int ox = sOrg[1][b][0], oy = sOrg[1][b][1];
+            const int64_t idx = (int64_t)by16 * a.blocksX[1] + cx * 4 + bx16;
+            if (lane == 0)
+                *(uint32_t*)(chunk + a.originOff[1] + idx * 4) = (uint32_t)(uint16_t)(int16_t)ox | ((uint32_t)(uint16_t)(int16_t)oy << 16);
+            uint16_t* tab = (uint16_t*)(chunk + a.tableOff[1]) + idx * (kWin * kWin);
+            const int j = lane >> 2, i4 = (lane & 3) * 4;
+            const uint16_t* p = sSurf + ((size_t)b * D + (oy + S + j)) * D + (ox + S + i4);
+            uint16_t v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+            *(uint2*)(tab + j * kWin + i4) = make_uint2((uint32_t)v0 | ((uint32_t)v1 << 16), (uint32_t)v2 | ((uint32_t)v3 << 16));
+        }
+    }
+    // level 2: group g, one entry per thread
+    {
+        const int g = tid >> 8, t = tid & 255, gx = g & 1, gy = g >> 1;
+        if (x0 + gx * 32 + 32 <= a.picW && y0 + gy * 32 + 32 <= a.picH)
+        {
+            const int ox = sOrg[2][g][0], oy = sOrg[2][g][1];
+            const int64_t idx = (int64_t)gy * a.blocksX[2] + cx * 2 + gx;
+            if (t == 0)
+                *(uint32_t*)(chunk + a.originOff[2] + idx * 4) = (uint32_t)(uint16_t)(int16_t)ox | ((uint32_t)(uint16_t)(int16_t)oy << 16);
+            const int j = t >> 4, i = t & 15, b0 = (gy * 2) * 4 + gx * 2;
+            const size_t c = (size_t)(oy + S + j) * D + (ox + S + i);
+            ((uint32_t*)(chunk + a.tableOff[2]))[idx * (kWin * kWin) + t] =
+                (uint32_t)sSurf[b0 * DD + c] + sSurf[(b0 + 1) * DD + c] + sSurf[(b0 + 4) * DD + c] + sSurf[(b0 + 5) * DD + c];
+        }
+    }
+    // level 3: threads 0..255
+    if (have3 && tid < 256)
+    {
+        const int ox = sOrg[3][0][0], oy = sOrg[3][0][1];
+        const int64_t idx = cx;
+        if (tid == 0)
+            *(uint32_t*)(chunk + a.originOff[3] + idx * 4) = (uint32_t)(uint16_t)(int16_t)ox | ((uint32_t)(uint16_t)(int16_t)oy << 16);
+        const int j = tid >> 4, i = tid & 15;
+        const size_t c = (size_t)(oy + S + j) * D + (ox + S + i);
+        uint32_t t = 0;
+#pragma unroll
+        for (int b = 0; b < 16; b++) t += sSurf[b * DD + c];
+        ((uint32_t*)(chunk + a.tableOff[3]))[idx * (kWin * kWin) + tid] = t;
+    }
+}
+
+static size_t surf_lds_bytes(int S)
+{
+    const int D = 2 * S, RW = 64 + D + 8;
+    return 4096 + (size_t)(64 + D) * RW + (size_t)16 * D * D * 2;
+}
+
+// build CTU rows [r0, r1) of `ss` on its reference's stream and bring them to the host (worker thread)
+static int build_rows(x265hip_sadsurf* ss, int r0, int r1)
+{
+    x265hip_refpic* rp = ss->ref;
+    SurfArgs a;
+    memset(&a, 0, sizeof(a));
+    a.src = (const uint8_t*)ss->src->dLuma; a.srcPitch = ss->src->pitch;
+    a.ref = (const uint8_t*)rp->dPic + (size_t)rp->marginY * rp->stride + rp->marginX; a.refStride = rp->stride;
+    a.picW = rp->picW; a.picH = rp->picH; a.marginX = rp->marginX; a.marginY = rp->marginY;
+    a.S = ss->S; a.lambda20 = ss->lambda20; a.row0 = r0;
+    a.out = ss->dBuf; a.pitch = ss->lay.pitch;
+    for (int l = 1; l < 4; l++) { a.originOff[l] = ss->lay.originOff[l]; a.tableOff[l] = ss->lay.tableOff[l]; a.blocksX[l] = ss->lay.blocksX[l]; }
+    const size_t lds = surf_lds_bytes(ss->S);
+    static std::atomic<int> attrSet{ 0 };
+    if (!attrSet.load())
+    {
+        if (hipFuncSetAttribute((const void*)sadsurf_ctu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)surf_lds_bytes(32)) != hipSuccess)
+            return set_error(X265HIP_EHIP, "sadsurf: cannot raise the dynamic LDS limit");
+        attrSet = 1;
+    }
+    hipLaunchKernelGGL(sadsurf_ctu_kernel, dim3(ss->lay.ctuCols, r1 - r0), dim3(1024), lds, rp->st, a);
+    XH_LAUNCH_CHECK("sadsurf_ctu_kernel");
+    const size_t off = (size_t)r0 * ss->lay.pitch, bytes = (size_t)(r1 - r0) * ss->lay.pitch;
+    int e;
+    if ((e = check_hip(hipMemcpyAsync(ss->hBuf + off, ss->dBuf + off, bytes, hipMemcpyDeviceToHost, rp->st), "sadsurf d2h"))) return e;
+    if ((e = check_hip(hipStreamSynchronize(rp->st), "sadsurf sync"))) return e;
+    return X265HIP_OK;
+}
+
+// rows of `ss` that the reference's uploaded rows allow now
+static void progress(x265hip_sadsurf* ss)
+{
+    x265hip_refpic* rp = ss->ref;
+    if (!rp || rp->failed.load() || ss->released)
+        return;
+    const bool complete = rp->uploaded >= rp->marginY + rp->picH + rp->marginY;
+    const int finalPic = rp->uploaded - rp->marginY;           // picture rows [.., finalPic) are on the device
+    int r1 = ss->rowsBuilt;
+    while (r1 < ss->lay.ctuRows && (complete || 64 * (r1 + 1) + ss->S <= finalPic))
+        r1++;
+    if (r1 == ss->rowsBuilt)
+        return;
+    if (build_rows(ss, ss->rowsBuilt, r1)) { rp->failed = 1; return; }
+    g_statRows += r1 - ss->rowsBuilt;
+    ss->rowsBuilt = r1;
+    ss->ctuRowsReady.store(r1, std::memory_order_release);
+}
+
+void sadsurf_rows_arrived(x265hip_refpic* rp)
+{
+    std::vector<x265hip_sadsurf*> list;
+    {
+        std::lock_guard<std::mutex> g(g_ssLock);
+        list = rp->surfaces;
+    }
+    for (x265hip_sadsurf* ss : list)
+        progress(ss);
+}
+
+static void free_surface(x265hip_sadsurf* ss)
+{
+    {
+        std::lock_guard<std::mutex> g(g_poolLock);
+        g_pool.insert({ ss->bytes, PoolEntry{ ss->dBuf, ss->hBuf } });
+    }
+    delete ss;
+}
+
+void sadsurf_job(const RefJob& j)
+{
+    x265hip_sadsurf* ss = j.ss;
+    if (j.kind == 1)
+    {
+        // attach: the worker has seen every band queued before this job, so `uploaded` is what the surface can start from
+        if (ss->ref && j.epoch == ss->ref->epoch.load() && hipSetDevice(ss->ref->device) == hipSuccess)
+            progress(ss);
+        return;
+    }
+    // release
+    {
+        std::lock_guard<std::mutex> g(g_ssLock);
+        if (ss->ref)
+        {
+            auto& v = ss->ref->surfaces;
+            for (size_t i = 0; i < v.size(); i++)
+                if (v[i] == ss) { v[i] = v.back(); v.pop_back(); break; }
+            ss->ref = nullptr;
+        }
+    }
+    free_surface(ss);
+}
+
+void sadsurf_detach_all(x265hip_refpic* rp)
+{
+    std::lock_guard<std::mutex> g(g_ssLock);
+    for (x265hip_sadsurf* ss : rp->surfaces)
+        ss->ref = nullptr;
+    rp->surfaces.clear();
+}
+
+} // namespace xh
+
+using namespace xh;
+
+extern "C" {
+
+x265hip_srcpic* x265hip_srcpic_create(int depth, int width, int height)
+{
+    if (ensure_device()) return nullptr;
+    if (depth != 8 || width < 16 || height < 16 || width > 16384 || height > 16384)
+    {
+        set_error(X265HIP_EINVAL, "x265hip_srcpic_create: depth %d %dx%d (8-bit pictures only)", depth, width, height);
+        return nullptr;
+    }
+    x265hip_srcpic* sp = new x265hip_srcpic;
+    sp->depth = depth; sp->w = width; sp->h = height;
+    sp->pitch = (width + 255) & ~255;
+    (void)hipGetDevice(&sp->device);
+    const size_t bytes = (size_t)sp->pitch * height;
+    if (hipStreamCreateWithFlags(&sp->st, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&sp->dLuma, bytes + 256) != hipSuccess ||
+        hipHostMalloc((void**)&sp->hStage, bytes, hipHostMallocDefault) != hipSuccess)
+    {
+        set_error(X265HIP_ENOMEM, "x265hip_srcpic_create: %zu bytes", bytes);
+        x265hip_srcpic_destroy(sp);
+        return nullptr;
+    }
+    return sp;
+}
+
+int x265hip_srcpic_upload(x265hip_srcpic* sp, const void* hostLuma, int64_t stride)
+{
+    if (!sp || !hostLuma || stride < sp->w) return set_error(X265HIP_EINVAL, "x265hip_srcpic_upload: bad arguments");
+    int e = check_hip(hipSetDevice(sp->device), "hipSetDevice");
+    if (e) return e;
+    for (int y = 0; y < sp->h; y++)
+        memcpy(sp->hStage + (size_t)y * sp->pitch, (const char*)hostLuma + (size_t)y * stride, sp->w);
+    if ((e = check_hip(hipMemcpyAsync(sp->dLuma, sp->hStage, (size_t)sp->pitch * sp->h, hipMemcpyHostToDevice, sp->st), "srcpic h2d"))) return e;
+    return check_hip(hipStreamSynchronize(sp->st), "srcpic sync");
+}
+
+void x265hip_srcpic_destroy(x265hip_srcpic* sp)
+{
+    if (!sp) return;
+    (void)hipSetDevice(sp->device);
+    if (sp->st) { (void)hipStreamSynchronize(sp->st); (void)hipStreamDestroy(sp->st); }
+    if (sp->dLuma) (void)hipFree(sp->dLuma);
+    if (sp->hStage) (void)hipHostFree(sp->hStage);
+    delete sp;
+}
+
+x265hip_sadsurf* x265hip_sadsurf_attach(x265hip_srcpic* src, x265hip_refpic* ref, int searchRange, int lambda20)
+{
+    if (ensure_device()) return nullptr;
+    if (!src || !ref || src->depth != 8 || ref->depth != 8 || src->w != ref->picW || src->h != ref->picH || searchRange < 8 || searchRange > 32 || (searchRange & 3) ||
+        lambda20 < 0 || lambda20 > (1 << 20) || ref->marginX < searchRange + 8 || ref->marginY < searchRange || src->device != ref->device)
+    {
+        set_error(X265HIP_EINVAL, "x265hip_sadsurf_attach: pictures do not match, or range %d / lambda %d / margins out of bounds", searchRange, lambda20);
+        return nullptr;
+    }
+    x265hip_sadsurf* ss = new x265hip_sadsurf;
+    ss->src = src; ss->ref = ref; ss->S = searchRange; ss->lambda20 = lambda20;
+    layout_for(src->w, src->h, 8, ss->lay);
+    ss->bytes = (size_t)ss->lay.pitch * ss->lay.ctuRows;
+    {
+        std::lock_guard<std::mutex> g(g_poolLock);
+        auto it = g_pool.find(ss->bytes);
+        if (it != g_pool.end()) { ss->dBuf = it->second.d; ss->hBuf = it->second.h; g_pool.erase(it); }
+    }
+    if (!ss->dBuf)
+    {
+        (void)hipSetDevice(ref->device);
+        if (hipMalloc((void**)&ss->dBuf, ss->bytes) != hipSuccess || hipHostMalloc((void**)&ss->hBuf, ss->bytes, hipHostMallocDefault) != hipSuccess)
+        {
+            set_error(X265HIP_ENOMEM, "x265hip_sadsurf_attach: %zu bytes", ss->bytes);
+            if (ss->dBuf) (void)hipFree(ss->dBuf);
+            delete ss;
+            return nullptr;
+        }
+    }
+    memset(&ss->view, 0, sizeof(ss->view));
+    for (int l = 1; l < 4; l++)
+    {
+        x265hip_sadsurf_level& v = ss->view.level[l];
+        v.blocksX = ss->lay.blocksX[l]; v.blocksY = ss->lay.blocksY[l]; v.entryBytes = ss->lay.entryBytes[l]; v.blocksPerCtuRow = ss->lay.per[l];
+        v.origin = (const int16_t*)(ss->hBuf + ss->lay.originOff[l]);
+        v.table = ss->hBuf + ss->lay.tableOff[l];
+    }
+    ss->view.ctuRowPitch = ss->lay.pitch;
+    ss->view.ctuRowsReady = reinterpret_cast<const int*>(&ss->ctuRowsReady);
+    {
+        std::lock_guard<std::mutex> g(g_ssLock);
+        ref->surfaces.push_back(ss);
+    }
+    g_statAttached++;
+    RefWorker::worker().push(RefJob{ ref, 0, ref->epoch.load(), 1, ss });
+    return ss;
+}
+
+const x265hip_sadsurf_view* x265hip_sadsurf_get_view(x265hip_sadsurf* ss) { return ss ? &ss->view : nullptr; }
+
+void x265hip_sadsurf_release(x265hip_sadsurf* ss)
+{
+    if (!ss) return;
+    ss->released = true;
+    RefWorker::worker().push(RefJob{ nullptr, 0, 0, 2, ss });
+}
+
+int x265hip_sadsurf_stats(uint64_t* attached, uint64_t* ctuRows)
+{
+    if (attached) *attached = g_statAttached.load();
+    if (ctuRows) *ctuRows = g_statRows.load();
+    return X265HIP_OK;
+}
+
+} // extern "C"

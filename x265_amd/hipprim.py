@@ -176,6 +176,13 @@ PROTOTYPES = {
     "x265hip_refpic_rows_ready": (i32, [vp]),
     "x265hip_refpic_rows_ready_ptr": (vp, [vp]),
     "x265hip_refpic_wait": (i32, [vp]),
+    "x265hip_srcpic_create": (vp, [i32, i32, i32]),
+    "x265hip_srcpic_upload": (i32, [vp, vp, i64]),
+    "x265hip_srcpic_destroy": (None, [vp]),
+    "x265hip_sadsurf_attach": (vp, [vp, vp, i32, i32]),
+    "x265hip_sadsurf_get_view": (vp, [vp]),
+    "x265hip_sadsurf_release": (None, [vp]),
+    "x265hip_sadsurf_stats": (i32, [vp, vp]),
     "x265hip_call_intra_pred": (i32, [i32, i32, i32, i32, vp, i64, vp]),
     "x265hip_call_intra_allangs": (i32, [i32, i32, vp, vp, vp, i32]),
     "x265hip_call_intra_filter": (i32, [i32, i32, vp, vp]),
@@ -224,6 +231,16 @@ class LaEstimate(C.Structure):
     _fields_ = [("b", C.c_int32), ("p0", C.c_int32), ("p1", C.c_int32), ("dist0", C.c_int32), ("dist1", C.c_int32), ("search0", C.c_int32),
                 ("search1", C.c_int32), ("weightedId", C.c_int32), ("mvs0", vp), ("mvCosts0", vp), ("mvs1", vp), ("mvCosts1", vp), ("lowresCosts", vp),
                 ("rowSatds", vp), ("costEst", C.c_int64), ("costEstAq", C.c_int64), ("intraMbs", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SadSurfLevel(C.Structure):
+    """x265hip_sadsurf_level (include/x265hip.h)"""
+    _fields_ = [("blocksX", C.c_int32), ("blocksY", C.c_int32), ("entryBytes", C.c_int32), ("blocksPerCtuRow", C.c_int32), ("origin", vp), ("table", vp)]
+
+
+class SadSurfView(C.Structure):
+    """x265hip_sadsurf_view (include/x265hip.h)"""
+    _fields_ = [("level", SadSurfLevel * 4), ("ctuRowPitch", C.c_int64), ("ctuRowsReady", C.POINTER(C.c_int))]
 
 
 class LaSearch(C.Structure):

@@ -349,10 +349,13 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
         const intptr_t off = ref->reconPic->m_cuOffsetY[ctuAddr] + ref->reconPic->m_buOffsetY[absPartIdx];
         if (off != (intptr_t)u->y * ref->lumaStride + u->x || u->x / u->w >= lv->blocksX || u->y / u->w >= lv->blocksY)
             return refMotionEstimate(this, ref, mvmin, mvmax, qmvp, numCandidates, mvc, merange, outQMv, maxSlices, srcReferencePlane);
-        const size_t b = (size_t)(u->y / u->w) * lv->blocksX + u->x / u->w;
-        const int ox = lv->origin[2 * b], oy = lv->origin[2 * b + 1];
+        // x265hip_sadsurf_level: results are laid out per row of 64 picture lines
+        const int by = u->y / u->w, cr = by / lv->blocksPerCtuRow;
+        const size_t k = (size_t)(by - cr * lv->blocksPerCtuRow) * lv->blocksX + u->x / u->w;
+        const int16_t* org = (const int16_t*)((const char*)lv->origin + (size_t)cr * pr->view->ctuRowPitch) + 2 * k;
+        const int ox = org[0], oy = org[1];
         entryBytes = lv->entryBytes;
-        c.tab = (const char*)lv->table + b * WIN * WIN * entryBytes;
+        c.tab = (const char*)lv->table + (size_t)cr * pr->view->ctuRowPitch + k * WIN * WIN * entryBytes;
         c.stride = ref->lumaStride;
         c.winBase = ref->fpelPlane[0] + off + (intptr_t)oy * c.stride + ox;
         c.span = (size_t)(WIN - 1) * c.stride + WIN;
