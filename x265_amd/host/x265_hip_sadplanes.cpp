@@ -72,6 +72,9 @@ const int WIN = X265HIP_SADSURF_WIN;
 int g_state = 0;                 // 0 undecided, 1 on, -1 off
 int g_exp = 0;                   // X265HIP_DEBUG_SADEXP=2: every eligible call is computed twice and nothing is looked up (the cost-doubling measurement)
 int g_levels = 14;               // X265HIP_SADPLANES_LEVELS: bit l = blocks of 8 << l are looked up (16, 32, 64 are built)
+int g_time = 0;                  // X265HIP_DEBUG_SADTIME=1: cycles inside the reference's motionEstimate for the PUs a surface could serve, by block size;
+                                 // =2: the same with the lookups switched off (the pair of runs measures what the lookups save)
+std::atomic<uint64_t> g_cycles[4], g_timed[4];
 int g_range = 32;                // X265HIP_SADPLANES_RANGE: the exhaustive search that places the windows covers [-range, range)^2
 EncoderPrimitives g_c;
 std::mutex g_lock;
@@ -115,6 +118,7 @@ struct Ctx
     uint32_t hit, miss;
 };
 __attribute__((tls_model("initial-exec"))) thread_local Ctx t_ctx;
+__attribute__((tls_model("initial-exec"))) thread_local uint64_t t_hit = 0, t_miss = 0, t_searches = 0;      // up to 255 searches per thread stay unreported at exit
 
 void report()
 {
@@ -122,6 +126,10 @@ void report()
     for (int i = 0; i < 64; i++) { h += g_count[i].hit; m += g_count[i].miss; un += g_count[i].unserved; }
     uint64_t attached = 0, rows = 0;
     x265hip_sadsurf_stats(&attached, &rows);
+    if (g_time)
+        for (int l = 1; l < 4; l++)
+            fprintf(stderr, "x265hip: sadplanes: block size %d: %llu searches, %.0f cycles each inside the reference's motionEstimate (%s)\n", 8 << l,
+                    (unsigned long long)g_timed[l].load(), g_timed[l] ? (double)g_cycles[l].load() / g_timed[l].load() : 0.0, g_time == 2 ? "lookups off" : "lookups on");
     fprintf(stderr, "x265hip: sadplanes: %llu integer-pel SADs of the motion search served from GPU-built SAD surfaces (%llu surfaces, %llu CTU rows), %llu of the same "
                     "searches outside their block's window and %llu searches without a surface computed on the host\n", (unsigned long long)h,
             (unsigned long long)attached, (unsigned long long)rows, (unsigned long long)m, (unsigned long long)un);
@@ -137,6 +145,7 @@ bool decide()
         const char* table = getenv("X265HIP_TABLE");
         const char* exp = getenv("X265HIP_DEBUG_SADEXP");
         g_exp = exp ? atoi(exp) : 0;
+        g_time = getenv("X265HIP_DEBUG_SADTIME") ? atoi(getenv("X265HIP_DEBUG_SADTIME")) : 0;
         if (getenv("X265HIP_SADPLANES_LEVELS")) g_levels = atoi(getenv("X265HIP_SADPLANES_LEVELS")) & 14;
         if (getenv("X265HIP_SADPLANES_RANGE")) g_range = atoi(getenv("X265HIP_SADPLANES_RANGE"));
         if (g_range < 8) g_range = 8;
@@ -347,11 +356,11 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
         }
         // the position the reference will search from (motion.cpp:752-756) must be the one the source block was verified at
         const intptr_t off = ref->reconPic->m_cuOffsetY[ctuAddr] + ref->reconPic->m_buOffsetY[absPartIdx];
-        if (off != (intptr_t)u->y * ref->lumaStride + u->x || u->x / u->w >= lv->blocksX || u->y / u->w >= lv->blocksY)
+        if (off != (intptr_t)u->y * ref->lumaStride + u->x || (u->x >> (3 + level)) >= lv->blocksX || (u->y >> (3 + level)) >= lv->blocksY)
             return refMotionEstimate(this, ref, mvmin, mvmax, qmvp, numCandidates, mvc, merange, outQMv, maxSlices, srcReferencePlane);
         // x265hip_sadsurf_level: results are laid out per row of 64 picture lines
-        const int by = u->y / u->w, cr = by / lv->blocksPerCtuRow;
-        const size_t k = (size_t)(by - cr * lv->blocksPerCtuRow) * lv->blocksX + u->x / u->w;
+        const int sh = 3 + level, by = u->y >> sh, cr = u->y >> 6;
+        const size_t k = (size_t)(by - (cr << (3 - level))) * lv->blocksX + (u->x >> sh);
         const int16_t* org = (const int16_t*)((const char*)lv->origin + (size_t)cr * pr->view->ctuRowPitch) + 2 * k;
         const int ox = org[0], oy = org[1];
         entryBytes = lv->entryBytes;
@@ -359,54 +368,41 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
         c.stride = ref->lumaStride;
         c.winBase = ref->fpelPlane[0] + off + (intptr_t)oy * c.stride + ox;
         c.span = (size_t)(WIN - 1) * c.stride + WIN;
+        // the block's entries were written by the device a moment ago: bring them in while the search sets itself up
+        for (int i = 0; i < WIN * WIN * entryBytes; i += 64)
+            __builtin_prefetch((const char*)c.tab + i);
     }
     else
         c.stride = ref->lumaStride;
     c.fenc = fencPUYuv.m_buf[0];
     c.hit = c.miss = 0;
     const pixelcmp_t s1 = sad; const pixelcmp_x3_t s3 = sad_x3; const pixelcmp_x4_t s4 = sad_x4;
-    switch (level)
-    {
-    case 0: install<LUMA_8x8>(this, entryBytes); break;
-    case 1: install<LUMA_16x16>(this, entryBytes); break;
-    case 2: install<LUMA_32x32>(this, entryBytes); break;
-    default: install<LUMA_64x64>(this, entryBytes); break;
-    }
+    if (g_time != 2)
+        switch (level)
+        {
+        case 0: install<LUMA_8x8>(this, entryBytes); break;
+        case 1: install<LUMA_16x16>(this, entryBytes); break;
+        case 2: install<LUMA_32x32>(this, entryBytes); break;
+        default: install<LUMA_64x64>(this, entryBytes); break;
+        }
+    const uint64_t t0 = g_time ? __builtin_ia32_rdtsc() : 0;
     const int r = refMotionEstimate(this, ref, mvmin, mvmax, qmvp, numCandidates, mvc, merange, outQMv, maxSlices, srcReferencePlane);
+    if (g_time)
+    {
+        g_cycles[level].fetch_add(__builtin_ia32_rdtsc() - t0, std::memory_order_relaxed);
+        g_timed[level].fetch_add(1, std::memory_order_relaxed);
+    }
     sad = s1; sad_x3 = s3; sad_x4 = s4;
     c.fenc = NULL;
-    if (g_exp == 3 && entryBytes)
+    // counters: per thread, flushed to the shared ones now and then (an atomic per search would be felt)
+    t_hit += c.hit; t_miss += c.miss;
+    if (((++t_searches) & 255) == 0)
     {
-        // X265HIP_DEBUG_SADEXP=3: where did the search end relative to the window the device chose?
-        const intptr_t off0 = c.winBase - (ref->fpelPlane[0] + ref->reconPic->m_cuOffsetY[ctuAddr] + ref->reconPic->m_buOffsetY[absPartIdx]);
-        int oy = (int)((off0 + 256 * c.stride + 256) / c.stride) - 256, ox = (int)(off0 - (intptr_t)oy * c.stride);
-        const int dx = abs((outQMv.x >> 2) - (ox + WIN / 2)), dy = abs((outQMv.y >> 2) - (oy + WIN / 2)), d = dx > dy ? dx : dy;
-        static std::atomic<uint64_t> hist[4][6], hm[4][6][2];
-        const int b = d <= 2 ? 0 : d <= 4 ? 1 : d <= 7 ? 2 : d <= 16 ? 3 : d <= 32 ? 4 : 5;
-        hist[level][b]++; hm[level][b][0] += c.hit; hm[level][b][1] += c.miss;
-        static std::atomic<int> shown(0);
-        if (d > 16 && level == 3 && shown.fetch_add(1) < 60)
-        {
-            const uint32_t atCentre = entryBytes == 2 ? ((const uint16_t*)c.tab)[8 * WIN + 8] : ((const uint32_t*)c.tab)[8 * WIN + 8];
-            const pixel* fr = ref->fpelPlane[0] + ref->reconPic->m_cuOffsetY[ctuAddr] + ref->reconPic->m_buOffsetY[absPartIdx];
-            const int atResult = g_c.pu[LUMA_64x64].sad(fencPUYuv.m_buf[0], FENC_STRIDE, fr + (outQMv.x >> 2) + (outQMv.y >> 2) * c.stride, c.stride);
-            fprintf(stderr, "far: pos %d,%d window centre %d,%d (sad %u) result %d,%d (sad %d, cost %d) mvp %d,%d merange %d mvmin %d,%d mvmax %d,%d\n", u->x, u->y, ox + 8, oy + 8, atCentre,
-                    outQMv.x >> 2, outQMv.y >> 2, atResult, r, qmvp.x >> 2, qmvp.y >> 2, merange, mvmin.x, mvmin.y, mvmax.x, mvmax.y);
-        }
-        static std::atomic<int> once(0);
-        if (!once.exchange(1))
-            atexit([] {
-                for (int l = 1; l < 4; l++)
-                {
-                    fprintf(stderr, "x265hip: sadplanes: level %d: |search result - window centre| <=2 / <=4 / <=7 / <=16 / <=32 / more:", l);
-                    for (int k = 0; k < 6; k++) fprintf(stderr, " %llu (hit %llu miss %llu)", (unsigned long long)hist[l][k].load(), (unsigned long long)hm[l][k][0].load(), (unsigned long long)hm[l][k][1].load());
-                    fprintf(stderr, "\n");
-                }
-            });
+        Counter& k = g_count[shard()];
+        k.hit.fetch_add(t_hit, std::memory_order_relaxed);
+        k.miss.fetch_add(t_miss, std::memory_order_relaxed);
+        t_hit = t_miss = 0;
     }
-    Counter& k = g_count[shard()];
-    k.hit.fetch_add(c.hit, std::memory_order_relaxed);
-    k.miss.fetch_add(c.miss, std::memory_order_relaxed);
     return r;
 }
 
