@@ -23,6 +23,7 @@
 #include <cstring>
 #include <chrono>
 #include <mutex>
+#include <pthread.h>
 #include <unistd.h>
 #include <vector>
 
@@ -48,6 +49,7 @@ extern int64_t refEstimateFrameCost(CostEstimateGroup* self, LookaheadTLD& tld, 
     asm("_ZN4x26520CostEstimateGroupRef17estimateFrameCostERNS_12LookaheadTLDEiiib");
 extern void refFinishBatch(CostEstimateGroup* self) asm("_ZN4x26520CostEstimateGroupRef11finishBatchEv");
 extern void refLookaheadDestroy(Lookahead* self) asm("_ZN4x26512LookaheadRef7destroyEv");
+extern void refPreLookahead(PreLookaheadGroup* self, int workerThreadID) asm("_ZN4x26520PreLookaheadGroupRef12processTasksEi");
 static_assert(sizeof(X265HIP_STR(X265_NS)) == sizeof("x265"), "the asm labels above assume -DX265_NS=x265");
 
 namespace {
@@ -432,14 +434,55 @@ void Lookahead::destroy()
 // depends on how fast its lookahead is relative to its input in a few corner cases (clips shorter than the lookahead, tiny pictures)
 static void debug_delay()
 {
-    static const int delayUs = getenv("X265HIP_DEBUG_DELAY_US") ? atoi(getenv("X265HIP_DEBUG_DELAY_US")) : 0;
+    // X265HIP_DEBUG_LA_DELAY_US: the same on this side only — how sensitive is the encode to the lookahead's speed?
+    static const int delayUs = getenv("X265HIP_DEBUG_LA_DELAY_US") ? atoi(getenv("X265HIP_DEBUG_LA_DELAY_US")) :
+                               getenv("X265HIP_DEBUG_DELAY_US") ? atoi(getenv("X265HIP_DEBUG_DELAY_US")) : 0;
     if (delayUs > 0)
         usleep(delayUs);
 }
 
+// X265HIP_DEBUG_LA_TIMELINE=file: one line per call of the two seams — enter / exit (ns since the first call), thread, what was asked, whether it was
+// cached.  The gaps between the lines are the lookahead's own host work (pre-lookahead, path search, CU-tree): where a lookahead-bound encode spends
+// its time (tools/la_timeline.py)
+struct Timeline
+{
+    FILE* f = NULL;
+    std::chrono::steady_clock::time_point t0;
+    std::mutex m;
+    Timeline()
+    {
+        const char* path = getenv("X265HIP_DEBUG_LA_TIMELINE");
+        if (path) { f = fopen(path, "w"); t0 = std::chrono::steady_clock::now(); }
+    }
+    long long now() const { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+    void line(long long a, long long z, const char* what, int p0, int p1, int b, int cached, int n)
+    {
+        std::lock_guard<std::mutex> g(m);
+        fprintf(f, "%lld %lld %lx %s %d %d %d %d %d\n", a, z, (unsigned long)pthread_self(), what, p0, p1, b, cached, n);
+    }
+};
+static Timeline& timeline() { static Timeline* t = new Timeline; return *t; }
+
 int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, int b, bool bIntraPenalty)
 {
     debug_delay();
+    if (timeline().f)
+    {
+        const long long a = timeline().now();
+        const int wasCached = cached(m_frames[b], p0, p1, b);
+        if (!wasCached && enabled() && covered(m_lookahead, m_frames[b]))
+        {
+            Lowres* fenc = m_frames[b];
+            const bool search0 = fenc->lowresMvs[0][b - p0][0].x == 0x7FFF;
+            const bool search1 = p1 > b && fenc->lowresMvs[1][p1 - b][0].x == 0x7FFF;
+            const bool coop = !m_batchMode && m_lookahead.m_numCoopSlices > 1 && (p1 > b || search0 || search1);
+            const Job j = { p0, p1, b };
+            compute(*this, &j, 1, coop);
+        }
+        const int64_t r = refEstimateFrameCost(this, tld, p0, p1, b, bIntraPenalty);
+        timeline().line(a, timeline().now(), m_batchMode ? "estB" : "est", p0, p1, m_frames[b]->frameNum, wasCached, 1);
+        return r;
+    }
     Lowres* fenc = m_frames[b];
     if (!cached(fenc, p0, p1, b) && enabled() && covered(m_lookahead, fenc))
     {
@@ -452,9 +495,21 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
     return refEstimateFrameCost(this, tld, p0, p1, b, bIntraPenalty);
 }
 
+// The pre-lookahead of the frames that entered since the last slice-type decision (slicetype.cpp:1380-1402): Lowres::init, adaptive quantisation,
+// the intra estimate — one frame per bonded worker.
+void PreLookaheadGroup::processTasks(int workerThreadID)
+{
+    const long long a = timeline().f ? timeline().now() : 0;
+    refPreLookahead(this, workerThreadID);
+    if (timeline().f)
+        timeline().line(a, timeline().now(), "pre", 0, 0, 0, 0, m_jobTotal);
+}
+
 void CostEstimateGroup::finishBatch()
 {
     debug_delay();
+    const long long tlA = timeline().f ? timeline().now() : 0;
+    struct TlExit { long long a; int n; ~TlExit() { if (timeline().f) timeline().line(a, timeline().now(), "batch", 0, 0, 0, 0, n); } } tlExit{ tlA, m_jobTotal };
     if (m_jobTotal > 0 && enabled() && covered(m_lookahead, m_frames[m_estimates[0].b]))
     {
         std::vector<Job> jobs;
