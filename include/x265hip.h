@@ -709,8 +709,9 @@ typedef struct x265hip_sadsurf_view
 x265hip_sadsurf* x265hip_sadsurf_attach(x265hip_srcpic* src, x265hip_refpic* ref, int searchRange, int lambda20);
 const x265hip_sadsurf_view* x265hip_sadsurf_get_view(x265hip_sadsurf* ss);
 void x265hip_sadsurf_release(x265hip_sadsurf* ss);
-/* per process: surfaces attached, CTU rows built, device time is in the profiles */
-int x265hip_sadsurf_stats(uint64_t* attached, uint64_t* ctuRows);
+/* per process: surfaces attached, CTU rows built, kernel launches that built them (rows of several surfaces of one reference picture share a launch)
+ * and the device time of those launches (HIP events around each launch on the stream it runs on), nanoseconds */
+int x265hip_sadsurf_stats(uint64_t* attached, uint64_t* ctuRows, uint64_t* launches, uint64_t* kernelNs);
 
 /* ---------------------------------------------------------------- per-call entry points (host pointers) ----- */
 /* What the reference-side table shims bind (x265_amd/host/x265_hip_primitives.cpp).  Arguments are the slot's own

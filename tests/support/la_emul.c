@@ -556,8 +556,10 @@ void x265hip_sadsurf_release(x265hip_sadsurf* ss)
     free(ss->buf);
     free(ss);
 }
-int x265hip_sadsurf_stats(uint64_t* attached, uint64_t* ctuRows)
+int x265hip_sadsurf_stats(uint64_t* attached, uint64_t* ctuRows, uint64_t* launches, uint64_t* kernelNs)
 {
+    if (kernelNs) *kernelNs = 0;
+    if (launches) *launches = 0;
     if (attached) *attached = g_ssAttached;
     if (ctuRows) *ctuRows = g_ssRows;
     return 0;

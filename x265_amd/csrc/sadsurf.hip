@@ -16,8 +16,8 @@
 //            best vector; wave / workgroup minimum (DPP + LDS);
 //   emit     the 16 x 16 window around each block's best vector is gathered out of the LDS surface (no second SAD pass) and written with the
 //            block's origin into the CTU row's chunk of the table buffer.
-// Values are pinned to the oracle (oracle/x265_oracle_sadsurf.inc: entries == sad<N, N> of the reference, pixel.cpp:40-55; origins == the same
-// rule) by tests/test_sadsurf.py.  8-bit pictures only: v_qsad_pk_u16_u8 is a byte instruction (16-bit builds keep the C slots).
+// Values are pinned by tests/test_sadsurf.py (entries == sad<N, N> of the reference, pixel.cpp:40-55; origins == the same rule restated on the
+// CPU by the test tier).  8-bit pictures only: v_qsad_pk_u16_u8 is a byte instruction (16-bit builds keep the C slots).
 #include "common.h"
 #include "internal.h"
 #include "refpic.h"
@@ -45,16 +45,25 @@ struct SurfLayout
     int ctuCols, ctuRows;
 };
 
-struct SurfArgs
+// one surface's share of a launch: rows [row0, row0 + rows) of its table
+struct SurfJob
 {
     const uint8_t* src; int64_t srcPitch;
+    char* out;                                    // device table buffer (chunk of CTU row 0 first)
+    int S, lambda20, row0, rows;
+};
+constexpr int kMaxJobs = 8;
+
+// one launch: rows of up to kMaxJobs surfaces that share the reference picture (and with it the geometry and the table layout)
+struct SurfArgs
+{
     const uint8_t* ref; int64_t refStride;       // reference pixel (0, 0)
     int picW, picH, marginX, marginY;
-    int S, lambda20, row0;
-    char* out;                                    // device table buffer (chunk of CTU row 0 first)
     int64_t pitch;
     int64_t originOff[4], tableOff[4];
     int blocksX[4];
+    int nJobs;
+    SurfJob job[kMaxJobs];
 };
 
 } // namespace xh
@@ -80,7 +89,7 @@ static std::mutex g_ssLock;              // the surfaces lists of the mirrors an
 static std::mutex g_poolLock;
 struct PoolEntry { char* d; char* h; };
 static std::multimap<size_t, PoolEntry> g_pool;      // table buffers of finished surfaces, by size (pinned allocations are expensive: ~ms)
-static std::atomic<uint64_t> g_statAttached{ 0 }, g_statRows{ 0 };
+static std::atomic<uint64_t> g_statAttached{ 0 }, g_statRows{ 0 }, g_statLaunches{ 0 }, g_statKernelNs{ 0 };
 
 static void layout_for(int w, int h, int depth, SurfLayout& L)
 {
@@ -102,7 +111,7 @@ static void layout_for(int w, int h, int depth, SurfLayout& L)
 
 // ---- the kernel ---------------------------------------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ int ss_bits(int d) { return 2 * (31 - __clz(d + 1)) + 1; }          // 2 floor(log2(d + 1)) + 1
+__device__ __forceinline__ int ss_log(int d) { return 31 - __clz(4 * d + 1); }                  // floor(log2(4 d + 1)): bits(4 d) = 2 ss_log(d) + 1
 __device__ __forceinline__ uint64_t u64_min(uint64_t a, uint64_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
 {
@@ -115,23 +124,44 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
     return v;
 }
 
-// the cheapest vector of one block: `sum(c)` = the block's SAD at candidate c (index dyIdx * 2S + dxIdx).  Called by `threads` consecutive
-// threads (a multiple of 64) that scan the candidates `first`, `first + threads`, ...; returns the packed key of this thread's best
+// The scan of one block's candidates by a team of threads, four neighbouring vectors per step.  A thread owns the column group q (vectors
+// vx = 4 q - S .. + 3) and the rows first, first + step, ...: its four horizontal terms are computed once.  `sums(c, s)` = the block's SADs at
+// the candidates c .. c + 3.  cost = SAD + sVc[log(|vx - px|) + log(|vy - py|)] (the vector-cost table of this CTU's lambda), illegal vectors cost
+// UINT_MAX; the thread's candidates are visited in ascending index, so `<` keeps the smallest index among equals.  Returns cost << 12 | index.
 template <typename F>
-__device__ __forceinline__ uint64_t ss_scan(F sum, int S, int first, int threads, int xlo, int xhi, int ylo, int yhi, int px, int py, int lambda20)
+__device__ __forceinline__ uint64_t ss_scan4(F sums, const uint32_t* sVc, int S, int q, int first, int step, int xlo, int xhi, int ylo, int yhi, int px, int py)
 {
     const int D = 2 * S;
-    uint64_t best = ~(uint64_t)0;
-    for (int c = first; c < D * D; c += threads)
+    uint32_t best = 0xFFFFFFFFu, bestC = 0;
+    if (4 * q < D)
     {
-        const int dyI = c / D, dxI = c - dyI * D;
-        const int vx = dxI - S, vy = dyI - S;
-        if (vx < xlo || vx > xhi || vy < ylo || vy > yhi)
-            continue;
-        const uint32_t cost = sum(c) + (uint32_t)((lambda20 * (ss_bits(4 * abs(vx - px)) + ss_bits(4 * abs(vy - py))) + 10) / 20);
-        best = u64_min(best, ((uint64_t)cost << 12) | (uint32_t)c);          // ties: the smaller candidate index = smaller vy, then smaller vx
+        int lx[4];
+        bool okx[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+        {
+            const int vx = 4 * q + e - S;
+            lx[e] = ss_log(abs(vx - px));
+            okx[e] = vx >= xlo && vx <= xhi;
+        }
+        for (int dyI = first; dyI < D; dyI += step)
+        {
+            const int vy = dyI - S;
+            if (vy < ylo || vy > yhi)
+                continue;
+            const int ly = ss_log(abs(vy - py));
+            const int c = dyI * D + 4 * q;
+            uint32_t s[4];
+            sums(c, s);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+            {
+                const uint32_t cost = okx[e] ? s[e] + sVc[lx[e] + ly] : 0xFFFFFFFFu;
+                if (cost < best) { best = cost; bestC = (uint32_t)(c + e); }
+            }
+        }
     }
-    return best;
+    return best == 0xFFFFFFFFu ? ~(uint64_t)0 : ((uint64_t)best << 12) | bestC;
 }
 
 __device__ __forceinline__ void ss_origin(uint64_t key, int S, int xlo, int xhi, int ylo, int yhi, int& bx, int& by, int& ox, int& oy)
@@ -151,19 +181,31 @@ __device__ __forceinline__ void ss_origin(uint64_t key, int S, int xlo, int xhi,
     if (oy < ylo) oy = ylo;
 }
 
+// four u16 SADs of one 16x16 block at the candidates c .. c + 3 (c a multiple of 4: one 8-byte LDS read), added to s[]
+__device__ __forceinline__ void ss_add4(const uint16_t* surf, int c, uint32_t* s)
+{
+    const uint2 v = *(const uint2*)(surf + c);
+    s[0] += v.x & 0xFFFFu; s[1] += v.x >> 16; s[2] += v.y & 0xFFFFu; s[3] += v.y >> 16;
+}
+
 __global__ __launch_bounds__(1024) void sadsurf_ctu_kernel(SurfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int S = a.S, D = 2 * S;
-    const int RW = 64 + D + 8;                                   // reference window row pitch (bytes): + 4 for the last 8-byte window, multiple of 8
-    uint8_t* sSrc = smem;                                        // [64][64]
-    uint8_t* sRef = smem + 4096;                                 // [64 + D][RW]
-    uint16_t* sSurf = (uint16_t*)(smem + 4096 + (size_t)(64 + D) * RW);      // [16][D][D]
     __shared__ uint64_t sRed[16];
     __shared__ int sBest[4][16][2];                              // [level][block][vx, vy]
     __shared__ int sOrg[4][16][2];
+    __shared__ uint32_t sVc[32];                                 // vector cost by log(|dx|) + log(|dy|)
 
-    const int cx = blockIdx.x, cy = a.row0 + blockIdx.y;
+    int jn = 0, rowIn = blockIdx.y;
+    while (jn + 1 < a.nJobs && rowIn >= a.job[jn].rows) { rowIn -= a.job[jn].rows; jn++; }
+    const SurfJob& jb = a.job[jn];
+    const int S = jb.S, D = 2 * S, DD = D * D;
+    const int RW = 64 + D + 8;                                   // reference window row pitch (bytes): room for the last 24-byte read, multiple of 8
+    uint8_t* sSrc = smem;                                        // [64][64]
+    uint8_t* sRef = smem + 4096;                                 // [64 + D][RW]
+    uint16_t* sSurf = (uint16_t*)(smem + 4096 + (size_t)(64 + D) * RW);      // [16][D][D]
+
+    const int cx = blockIdx.x, cy = jb.row0 + rowIn;
     const int x0 = cx * 64, y0 = cy * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -173,10 +215,10 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu_kernel(SurfArgs a)
         const int r = i >> 4, c4 = (i & 15) * 4;
         uint32_t v = 0;
         if (y0 + r < a.picH && x0 + c4 + 3 < a.picW)
-            v = ld_global_unaligned<uint32_t>(a.src + (int64_t)(y0 + r) * a.srcPitch + x0 + c4);
+            v = ld_global_unaligned<uint32_t>(jb.src + (int64_t)(y0 + r) * jb.srcPitch + x0 + c4);
         else if (y0 + r < a.picH)
             for (int k = 0; k < 4; k++)
-                if (x0 + c4 + k < a.picW) v |= (uint32_t)a.src[(int64_t)(y0 + r) * a.srcPitch + x0 + c4 + k] << (8 * k);
+                if (x0 + c4 + k < a.picW) v |= (uint32_t)jb.src[(int64_t)(y0 + r) * jb.srcPitch + x0 + c4 + k] << (8 * k);
         *(uint32_t*)(sSrc + r * 64 + c4) = v;
     }
     {
@@ -187,9 +229,12 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu_kernel(SurfArgs a)
             *(uint32_t*)(sRef + r * RW + c4) = ld_global_unaligned<uint32_t>(a.ref + (int64_t)(y0 - S + r) * a.refStride + (x0 - S + c4));
         }
     }
+    if (tid < 32)
+        sVc[tid] = (uint32_t)((jb.lambda20 * (2 * tid + 2) + 10) / 20);          // bits(4 |dx|) + bits(4 |dy|) = 2 (log + log) + 2
     __syncthreads();
 
-    // ---- measure: wave b <-> 16x16 block b ----
+    // ---- measure: wave b <-> 16x16 block b.  A lane owns an 8 x 8 patch of vectors: 16 accumulators of four u16 SADs each.  Reference row j of
+    // the patch (24 bytes) is read once and meets source row j - dy for each of the patch's eight dy: 64 v_qsad_pk_u16_u8 per 24 bytes of LDS ----
     {
         const int b = wave, bx = b & 3, by = b >> 2;
         const bool inside = x0 + bx * 16 + 16 <= a.picW && y0 + by * 16 + 16 <= a.picH;
@@ -198,43 +243,60 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu_kernel(SurfArgs a)
             uint32_t s[16][4];
 #pragma unroll
             for (int r = 0; r < 16; r++)
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    s[r][k] = *(const uint32_t*)(sSrc + (by * 16 + r) * 64 + bx * 16 + 4 * k);
-            const int Q = D / 4;
-            for (int item = lane; item < Q * D; item += 64)
             {
-                const int dyI = item / Q, q = item - dyI * Q;
-                const uint8_t* rp = sRef + (by * 16 + dyI) * RW + bx * 16 + 4 * q;
-                uint64_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+                // the block's pixels are the same for every lane of the wave: scalar registers, the qsad's second operand
+                const uint4 v = *(const uint4*)(sSrc + (by * 16 + r) * 64 + bx * 16);
+                s[r][0] = __builtin_amdgcn_readfirstlane(v.x); s[r][1] = __builtin_amdgcn_readfirstlane(v.y);
+                s[r][2] = __builtin_amdgcn_readfirstlane(v.z); s[r][3] = __builtin_amdgcn_readfirstlane(v.w);
+            }
+            const int G = D / 8;
+            for (int item = lane; item < G * G; item += 64)
+            {
+                const int dyg = item / G, xs = item - dyg * G;
+                const uint8_t* base = sRef + (by * 16 + 8 * dyg) * RW + bx * 16 + 8 * xs;
+                uint64_t acc[8][2];
 #pragma unroll
-                for (int r = 0; r < 16; r++)
+                for (int i = 0; i < 8; i++) acc[i][0] = acc[i][1] = 0;
+#pragma unroll
+                for (int j = 0; j < 23; j++)
                 {
-                    const uint32_t* w = (const uint32_t*)(rp + r * RW);
-                    const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
-                    acc0 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)d1 << 32) | d0, s[r][0], acc0);
-                    acc1 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)d2 << 32) | d1, s[r][1], acc1);
-                    acc2 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)d3 << 32) | d2, s[r][2], acc2);
-                    acc3 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)d4 << 32) | d3, s[r][3], acc3);
+                    const uint2* p = (const uint2*)(base + j * RW);
+                    const uint2 p0 = p[0], p1 = p[1], p2 = p[2];
+                    const uint32_t d[6] = { p0.x, p0.y, p1.x, p1.y, p2.x, p2.y };
+#pragma unroll
+                    for (int dyo = 0; dyo < 8; dyo++)
+                    {
+                        const int r = j - dyo;
+                        if (r < 0 || r > 15)
+                            continue;
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                        {
+                            acc[dyo][0] = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)d[k + 1] << 32) | d[k], s[r][k], acc[dyo][0]);
+                            acc[dyo][1] = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)d[k + 2] << 32) | d[k + 1], s[r][k], acc[dyo][1]);
+                        }
+                    }
                 }
-                // four u16 lanes each at most 64 * 255: the sum of the four stays below 65536 per lane (16 * 16 * 255 = 65280), no carry between them
-                *(uint64_t*)(sSurf + ((size_t)b * D + dyI) * D + 4 * q) = acc0 + acc1 + acc2 + acc3;
+                // an accumulator's u16 lanes hold at most 16 * 16 * 255 = 65280: no carry between them
+                uint16_t* o = sSurf + ((size_t)b * D + 8 * dyg) * D + 8 * xs;
+#pragma unroll
+                for (int dyo = 0; dyo < 8; dyo++)
+                    *(uint4*)(o + dyo * D) = make_uint4((uint32_t)acc[dyo][0], (uint32_t)(acc[dyo][0] >> 32), (uint32_t)acc[dyo][1], (uint32_t)(acc[dyo][1] >> 32));
             }
         }
     }
     __syncthreads();
 
     // ---- decide, top down ----
-    const int DD = D * D;
-    // level 3: the whole CTU, all 1024 threads
+    // level 3: the whole CTU, all 1024 threads: column group tid & 15, rows tid >> 4, + 64, ...
     const bool have3 = x0 + 64 <= a.picW && y0 + 64 <= a.picH;
     if (have3)
     {
         const int xlo = -a.marginX - x0, xhi = a.picW + a.marginX - 64 - x0, ylo = -a.marginY - y0, yhi = a.picH + a.marginY - 64 - y0;
-        uint64_t k = ss_scan([&](int c) { uint32_t t = 0;
+        uint64_t k = ss_scan4([&](int c, uint32_t* s) { s[0] = s[1] = s[2] = s[3] = 0;
 #pragma unroll
-                                          for (int b = 0; b < 16; b++) t += sSurf[b * DD + c];
-                                          return t; }, S, tid, 1024, xlo, xhi, ylo, yhi, 0, 0, a.lambda20);
+                                                       for (int b = 0; b < 16; b++) ss_add4(sSurf + b * DD, c, s); },
+                              sVc, S, tid & 15, tid >> 4, 64, xlo, xhi, ylo, yhi, 0, 0);
         k = wave_min_u64(k);
         if (lane == 0) sRed[wave] = k;
         __syncthreads();
@@ -258,9 +320,10 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu_kernel(SurfArgs a)
         if (have)
         {
             const int px = have3 ? sBest[3][0][0] : 0, py = have3 ? sBest[3][0][1] : 0;
-            const int b0 = (gy * 2) * 4 + gx * 2;
-            k = ss_scan([&](int c) { return (uint32_t)sSurf[b0 * DD + c] + sSurf[(b0 + 1) * DD + c] + sSurf[(b0 + 4) * DD + c] + sSurf[(b0 + 5) * DD + c]; },
-                        S, t, 256, xlo, xhi, ylo, yhi, px, py, a.lambda20);
+            const uint16_t* s0 = sSurf + ((gy * 2) * 4 + gx * 2) * DD;
+            k = ss_scan4([&](int c, uint32_t* s) { s[0] = s[1] = s[2] = s[3] = 0;
+                                                   ss_add4(s0, c, s); ss_add4(s0 + DD, c, s); ss_add4(s0 + 4 * DD, c, s); ss_add4(s0 + 5 * DD, c, s); },
+                         sVc, S, t & 15, t >> 4, 16, xlo, xhi, ylo, yhi, px, py);
             k = wave_min_u64(k);
         }
         if (lane == 0) sRed[wave] = k;
@@ -285,7 +348,9 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu_kernel(SurfArgs a)
             const bool haveParent = x0 + (bx16 >> 1) * 32 + 32 <= a.picW && y0 + (by16 >> 1) * 32 + 32 <= a.picH;
             const int px = haveParent ? sBest[2][g][0] : 0, py = haveParent ? sBest[2][g][1] : 0;
             const int xlo = -a.marginX - x, xhi = a.picW + a.marginX - 16 - x, ylo = -a.marginY - y, yhi = a.picH + a.marginY - 16 - y;
-            uint64_t k = ss_scan([&](int c) { return (uint32_t)sSurf[b * DD + c]; }, S, lane, 64, xlo, xhi, ylo, yhi, px, py, a.lambda20);
+            const uint16_t* s0 = sSurf + b * DD;
+            uint64_t k = ss_scan4([&](int c, uint32_t* s) { s[0] = s[1] = s[2] = s[3] = 0; ss_add4(s0, c, s); },
+                                  sVc, S, lane & 15, lane >> 4, 4, xlo, xhi, ylo, yhi, px, py);
             k = wave_min_u64(k);
             if (lane == 0)
             {
@@ -298,7 +363,7 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu_kernel(SurfArgs a)
     __syncthreads();
 
     // ---- emit: origins and the 16 x 16 windows, gathered from the LDS surface ----
-    char* chunk = a.out + (int64_t)cy * a.pitch;
+    char* chunk = jb.out + (int64_t)cy * a.pitch;
     // level 1: wave b, 4 entries per lane
     {
         const int b = wave, bx16 = b & 3, by16 = b >> 2;
@@ -352,52 +417,95 @@ static size_t surf_lds_bytes(int S)
     return 4096 + (size_t)(64 + D) * RW + (size_t)16 * D * D * 2;
 }
 
-// build CTU rows [r0, r1) of `ss` on its reference's stream and bring them to the host (worker thread)
-static int build_rows(x265hip_sadsurf* ss, int r0, int r1)
-{
-    x265hip_refpic* rp = ss->ref;
-    SurfArgs a;
-    memset(&a, 0, sizeof(a));
-    a.src = (const uint8_t*)ss->src->dLuma; a.srcPitch = ss->src->pitch;
-    a.ref = (const uint8_t*)rp->dPic + (size_t)rp->marginY * rp->stride + rp->marginX; a.refStride = rp->stride;
-    a.picW = rp->picW; a.picH = rp->picH; a.marginX = rp->marginX; a.marginY = rp->marginY;
-    a.S = ss->S; a.lambda20 = ss->lambda20; a.row0 = r0;
-    a.out = ss->dBuf; a.pitch = ss->lay.pitch;
-    for (int l = 1; l < 4; l++) { a.originOff[l] = ss->lay.originOff[l]; a.tableOff[l] = ss->lay.tableOff[l]; a.blocksX[l] = ss->lay.blocksX[l]; }
-    const size_t lds = surf_lds_bytes(ss->S);
-    static std::atomic<int> attrSet{ 0 };
-    if (!attrSet.load())
-    {
-        if (hipFuncSetAttribute((const void*)sadsurf_ctu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)surf_lds_bytes(32)) != hipSuccess)
-            return set_error(X265HIP_EHIP, "sadsurf: cannot raise the dynamic LDS limit");
-        attrSet = 1;
-    }
-    hipLaunchKernelGGL(sadsurf_ctu_kernel, dim3(ss->lay.ctuCols, r1 - r0), dim3(1024), lds, rp->st, a);
-    XH_LAUNCH_CHECK("sadsurf_ctu_kernel");
-    const size_t off = (size_t)r0 * ss->lay.pitch, bytes = (size_t)(r1 - r0) * ss->lay.pitch;
-    int e;
-    if ((e = check_hip(hipMemcpyAsync(ss->hBuf + off, ss->dBuf + off, bytes, hipMemcpyDeviceToHost, rp->st), "sadsurf d2h"))) return e;
-    if ((e = check_hip(hipStreamSynchronize(rp->st), "sadsurf sync"))) return e;
-    return X265HIP_OK;
-}
-
-// rows of `ss` that the reference's uploaded rows allow now
-static void progress(x265hip_sadsurf* ss)
+// rows of `ss` that the reference's uploaded rows allow now: [ss->rowsBuilt, returned value)
+static int rows_possible(x265hip_sadsurf* ss)
 {
     x265hip_refpic* rp = ss->ref;
     if (!rp || rp->failed.load() || ss->released)
-        return;
+        return ss->rowsBuilt;
     const bool complete = rp->uploaded >= rp->marginY + rp->picH + rp->marginY;
     const int finalPic = rp->uploaded - rp->marginY;           // picture rows [.., finalPic) are on the device
     int r1 = ss->rowsBuilt;
     while (r1 < ss->lay.ctuRows && (complete || 64 * (r1 + 1) + ss->S <= finalPic))
         r1++;
-    if (r1 == ss->rowsBuilt)
-        return;
-    if (build_rows(ss, ss->rowsBuilt, r1)) { rp->failed = 1; return; }
-    g_statRows += r1 - ss->rowsBuilt;
-    ss->rowsBuilt = r1;
-    ss->ctuRowsReady.store(r1, std::memory_order_release);
+    return r1;
+}
+
+// build what the reference's rows allow of every surface in `list` (all attached to rp) in one launch on rp's stream, bring the rows to the
+// host, publish them (worker thread)
+static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& list)
+{
+    size_t i = 0;
+    while (i < list.size())
+    {
+        SurfArgs a;
+        memset(&a, 0, sizeof(a));
+        x265hip_sadsurf* in[kMaxJobs];
+        int upto[kMaxJobs], rows = 0, maxS = 0;
+        for (; i < list.size() && a.nJobs < kMaxJobs; i++)
+        {
+            x265hip_sadsurf* ss = list[i];
+            if (ss->ref != rp)
+                continue;
+            const int r1 = rows_possible(ss);
+            if (r1 == ss->rowsBuilt)
+                continue;
+            SurfJob& j = a.job[a.nJobs];
+            j.src = (const uint8_t*)ss->src->dLuma; j.srcPitch = ss->src->pitch;
+            j.out = ss->dBuf; j.S = ss->S; j.lambda20 = ss->lambda20; j.row0 = ss->rowsBuilt; j.rows = r1 - ss->rowsBuilt;
+            in[a.nJobs] = ss; upto[a.nJobs] = r1;
+            rows += j.rows;
+            if (ss->S > maxS) maxS = ss->S;
+            a.nJobs++;
+        }
+        if (!a.nJobs)
+            return;
+        const SurfLayout& lay = in[0]->lay;                   // same picture size: same layout
+        a.ref = (const uint8_t*)rp->dPic + (size_t)rp->marginY * rp->stride + rp->marginX; a.refStride = rp->stride;
+        a.picW = rp->picW; a.picH = rp->picH; a.marginX = rp->marginX; a.marginY = rp->marginY;
+        a.pitch = lay.pitch;
+        for (int l = 1; l < 4; l++) { a.originOff[l] = lay.originOff[l]; a.tableOff[l] = lay.tableOff[l]; a.blocksX[l] = lay.blocksX[l]; }
+        static std::atomic<int> attrSet{ 0 };
+        if (!attrSet.load())
+        {
+            if (hipFuncSetAttribute((const void*)sadsurf_ctu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)surf_lds_bytes(32)) != hipSuccess)
+            {
+                set_error(X265HIP_EHIP, "sadsurf: cannot raise the dynamic LDS limit");
+                rp->failed = 1;
+                return;
+            }
+            attrSet = 1;
+        }
+        // the launch between two events of its own stream: the kernel's device time, summed for x265hip_sadsurf_stats (worker thread only)
+        static thread_local hipEvent_t ev[2] = { nullptr, nullptr };
+        if (!ev[0] && (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess))
+            ev[0] = ev[1] = nullptr;
+        if (ev[0]) (void)hipEventRecord(ev[0], rp->st);
+        hipLaunchKernelGGL(sadsurf_ctu_kernel, dim3(lay.ctuCols, rows), dim3(1024), surf_lds_bytes(maxS), rp->st, a);
+        bool bad = hipGetLastError() != hipSuccess;
+        if (ev[0]) (void)hipEventRecord(ev[1], rp->st);
+        for (int k = 0; k < a.nJobs && !bad; k++)
+        {
+            const size_t off = (size_t)a.job[k].row0 * lay.pitch, bytes = (size_t)a.job[k].rows * lay.pitch;
+            bad = hipMemcpyAsync(in[k]->hBuf + off, in[k]->dBuf + off, bytes, hipMemcpyDeviceToHost, rp->st) != hipSuccess;
+        }
+        if (bad || hipStreamSynchronize(rp->st) != hipSuccess)
+        {
+            set_error(X265HIP_EHIP, "sadsurf: launch, copy or synchronisation failed");
+            rp->failed = 1;
+            return;
+        }
+        float ms = 0;
+        if (ev[0] && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess)
+            g_statKernelNs += (uint64_t)(ms * 1e6);
+        g_statRows += rows;
+        g_statLaunches++;
+        for (int k = 0; k < a.nJobs; k++)
+        {
+            in[k]->rowsBuilt = upto[k];
+            in[k]->ctuRowsReady.store(upto[k], std::memory_order_release);
+        }
+    }
 }
 
 void sadsurf_rows_arrived(x265hip_refpic* rp)
@@ -407,8 +515,7 @@ void sadsurf_rows_arrived(x265hip_refpic* rp)
         std::lock_guard<std::mutex> g(g_ssLock);
         list = rp->surfaces;
     }
-    for (x265hip_sadsurf* ss : list)
-        progress(ss);
+    progress(rp, list);
 }
 
 static void free_surface(x265hip_sadsurf* ss)
@@ -427,7 +534,7 @@ void sadsurf_job(const RefJob& j)
     {
         // attach: the worker has seen every band queued before this job, so `uploaded` is what the surface can start from
         if (ss->ref && j.epoch == ss->ref->epoch.load() && hipSetDevice(ss->ref->device) == hipSuccess)
-            progress(ss);
+            progress(ss->ref, std::vector<x265hip_sadsurf*>{ ss });
         return;
     }
     // release
@@ -559,8 +666,10 @@ void x265hip_sadsurf_release(x265hip_sadsurf* ss)
     RefWorker::worker().push(RefJob{ nullptr, 0, 0, 2, ss });
 }
 
-int x265hip_sadsurf_stats(uint64_t* attached, uint64_t* ctuRows)
+int x265hip_sadsurf_stats(uint64_t* attached, uint64_t* ctuRows, uint64_t* launches, uint64_t* kernelNs)
 {
+    if (kernelNs) *kernelNs = g_statKernelNs.load();
+    if (launches) *launches = g_statLaunches.load();
     if (attached) *attached = g_statAttached.load();
     if (ctuRows) *ctuRows = g_statRows.load();
     return X265HIP_OK;

@@ -182,7 +182,7 @@ PROTOTYPES = {
     "x265hip_sadsurf_attach": (vp, [vp, vp, i32, i32]),
     "x265hip_sadsurf_get_view": (vp, [vp]),
     "x265hip_sadsurf_release": (None, [vp]),
-    "x265hip_sadsurf_stats": (i32, [vp, vp]),
+    "x265hip_sadsurf_stats": (i32, [vp, vp, vp, vp]),
     "x265hip_call_intra_pred": (i32, [i32, i32, i32, i32, vp, i64, vp]),
     "x265hip_call_intra_allangs": (i32, [i32, i32, vp, vp, vp, i32]),
     "x265hip_call_intra_filter": (i32, [i32, i32, vp, vp]),

@@ -124,15 +124,15 @@ void report()
 {
     uint64_t h = 0, m = 0, un = 0;
     for (int i = 0; i < 64; i++) { h += g_count[i].hit; m += g_count[i].miss; un += g_count[i].unserved; }
-    uint64_t attached = 0, rows = 0;
-    x265hip_sadsurf_stats(&attached, &rows);
+    uint64_t attached = 0, rows = 0, launches = 0, kernelNs = 0;
+    x265hip_sadsurf_stats(&attached, &rows, &launches, &kernelNs);
     if (g_time)
         for (int l = 1; l < 4; l++)
             fprintf(stderr, "x265hip: sadplanes: block size %d: %llu searches, %.0f cycles each inside the reference's motionEstimate (%s)\n", 8 << l,
                     (unsigned long long)g_timed[l].load(), g_timed[l] ? (double)g_cycles[l].load() / g_timed[l].load() : 0.0, g_time == 2 ? "lookups off" : "lookups on");
-    fprintf(stderr, "x265hip: sadplanes: %llu integer-pel SADs of the motion search served from GPU-built SAD surfaces (%llu surfaces, %llu CTU rows), %llu of the same "
+    fprintf(stderr, "x265hip: sadplanes: %llu integer-pel SADs of the motion search served from GPU-built SAD surfaces (%llu surfaces, %llu CTU rows in %llu launches, %.3f ms of device time), %llu of the same "
                     "searches outside their block's window and %llu searches without a surface computed on the host\n", (unsigned long long)h,
-            (unsigned long long)attached, (unsigned long long)rows, (unsigned long long)m, (unsigned long long)un);
+            (unsigned long long)attached, (unsigned long long)rows, (unsigned long long)launches, kernelNs * 1e-6, (unsigned long long)m, (unsigned long long)un);
 }
 
 bool decide()
