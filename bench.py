@@ -6,10 +6,12 @@ libx265hip.so behind them — oracle/_ref/x265_hip_8bit — encoding a synthetic
 the lookahead's batched frame-cost estimates, the luma sub-pel filter calls on reference pictures (fractional planes built per picture) and the
 source half of the psy costs (energy planes built per source picture); everything else is the reference's host code.  One "step" = one chunk of
 CHUNK = 12 frames of the clip; K steps are encoded in one run of the encoder, bracketed by barrier + synchronize, wall clock of this process
-(the encoder's own "encoded N frames in Xs" figure is reported beside it as `cli_fps`).  At N = 1 the same clip is also encoded by the
-unmodified reference encoder (oracle/_ref/x265_8bit, `cpu_baseline`, kind "reference") and the two bitstreams must be byte-identical.
-With N ranks every rank encodes its own clip on its own GPU (chunk-parallel, the way x265 is scaled out in practice; the host cores are
-split between the ranks): weak scaling, no data-path collective.
+(the encoder's own "encoded N frames in Xs" figure is reported beside it as `cli_fps`).  The workload is ONE clip: the K * CHUNK-frame segment repeated N times; rank r
+encodes repetition r as a closed-GOP chunk on GPU r (chunk-parallel, the way x265 is scaled out over a long clip; the host cores are split between
+the ranks): weak scaling, no data-path collective, and an N-rank value is N times the N = 1 job.  At every N the same chunks are then encoded by the
+unmodified reference encoder, N at a time (oracle/_ref/x265_8bit, `cpu_baseline`, kind "reference"), and every chunk's two bitstreams must be
+byte-identical.  `roofline` is the kernel with the most device time in the timed encode, priced from the library's own HIP events around every launch
+(x265hip_device_time); `rooflines` holds the other named kernels and the stand-alone probes; `gpu_duty_cycle` = device time / wall clock.
 
 Beside it, `frame_pass` keeps the device-resident hot path of round 1 (quarter-pel planes, top-down motion search, prediction, residual
 chains, sa8d, borders on HBM-resident pictures, F frame chains per GPU, recon exchanged over RCCL when N > 1) with its own roofline.
@@ -500,9 +502,33 @@ def lookahead_kernel_probe(L, hp, np_mod, pairs=8):
     return total / reps, pairs * ncu
 
 
-def encode_bench(args, rank, local_rank, world, fence):
-    """Real encode fps: oracle/_ref/x265_hip_8bit on this rank's own synthetic 1080p clip (K * CHUNK frames after a W * CHUNK warm-up run),
-    wall clock of this process between two fences; at N = 1 the unmodified reference encoder on the same clip beside it."""
+def parse_served(lines):
+    """The encoder's X265HIP_VERBOSE lines (x265_amd/host/*.cpp) as numbers: the device-time ledger of x265hip_device_time per clock, the SAD
+    surfaces' rows and launches, the lookahead's search launches and pairs."""
+    import re
+    out = {"clocks": {}}
+    for l in lines:
+        if "device time" in l:
+            for m in re.finditer(r"(lookahead searches|other lookahead kernels|sub-pel plane bands|SAD surfaces|source energy planes) ([\d.]+) ms in (\d+) launch groups \((\d+) algorithmic bytes\)", l):
+                out["clocks"][m.group(1)] = {"ms": float(m.group(2)), "launch_groups": int(m.group(3)), "algorithmic_bytes": int(m.group(4))}
+            m = re.search(r"total ([\d.]+) ms", l)
+            if m:
+                out["device_ms"] = float(m.group(1))
+        m = re.search(r"\((\d+) surfaces, (\d+) CTU rows in (\d+) launches", l)
+        if m:
+            out["surfaces"], out["ctu_rows"], out["surface_launches"] = int(m.group(1)), int(m.group(2)), int(m.group(3))
+        m = re.search(r"(\d+) search launches of ([\d.]+) \(frame, reference\) pairs", l)
+        if m:
+            out["search_launches"], out["pairs_per_launch"] = int(m.group(1)), float(m.group(2))
+    return out
+
+
+def encode_bench(args, rank, local_rank, world, fence, allmax):
+    """Real encode fps.  The workload is ONE clip: the K * CHUNK-frame segment of make_clip(seed 4321) repeated N times; rank r encodes repetition r as
+    a closed-GOP chunk (its own run of oracle/_ref/x265_hip_8bit on its own GPU, the way x265 is scaled out over a long clip), so the N-rank job is N
+    times the N = 1 job and every chunk's bitstream must equal the reference encoder's bitstream of the segment.  Timed: wall clock of this process
+    between two fences around the encoder run (after a W * CHUNK-frame warm-up run); afterwards, with the same fences, the unmodified reference
+    encoder on the same chunks, N at a time, with the same share of the host cores (`cpu_baseline` at every N)."""
     import hashlib
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import encode_fps as ef
@@ -514,7 +540,7 @@ def encode_bench(args, rank, local_rank, world, fence):
     frames, wframes = args.steps * CHUNK, max(args.warmup, 0) * CHUNK
     total = max(frames, wframes)
     clip = "/tmp/x265hip_bench_%d_r%d.yuv" % (os.getpid(), rank)
-    make_clip(clip, W, H, total, seed=4321 + 101 * rank)
+    make_clip(clip, W, H, total, seed=4321)                  # every rank's chunk is a repetition of the same segment
     cores = os.cpu_count() or 1
     per_rank = max(4, cores // world)
     base = ["--input", clip, "--input-res", "%dx%d" % (W, H), "--input-depth", "8", "--fps", "30", "--preset", "medium", "--me", "hex", "--hash", "1"]
@@ -535,16 +561,69 @@ def encode_bench(args, rank, local_rank, world, fence):
         if r["rc"]:
             raise SystemExit("bench.py: x265_hip_8bit failed: " + r["tail"])
         res = {"dt": dt, "frames": frames, "cli_fps": r["fps"], "served": r["served"], "pools": per_rank if world > 1 else cores}
-        if rank == 0 and world == 1 and not args.no_ref_encoder:
+        if not args.no_ref_encoder:
+            fence()
+            t0 = time.perf_counter()
             r0 = ef._run(ref, base + ["--frames", str(frames)], out_ref)
-            same = hashlib.sha256(open(out_ref, "rb").read()).digest() == hashlib.sha256(open(out_hip, "rb").read()).digest()
-            res["reference"] = {"cli_fps": r0["fps"], "wall_s": r0["wall_s"], "rc": r0["rc"], "byte_identical": bool(same),
-                                "bitstream_bytes": os.path.getsize(out_ref)}
+            fence()
+            dt_ref = allmax(time.perf_counter() - t0)
+            same = r0["rc"] == 0 and hashlib.sha256(open(out_ref, "rb").read()).digest() == hashlib.sha256(open(out_hip, "rb").read()).digest()
+            differing = allmax(0.0 if same else 1.0)
+            res["reference"] = {"cli_fps": r0["fps"], "wall_s": round(dt_ref, 2), "rc": r0["rc"], "byte_identical": differing == 0.0,
+                                "bitstream_bytes": os.path.getsize(out_ref) if r0["rc"] == 0 else 0}
     finally:
         for p in (clip, out_hip, out_ref):
             if os.path.exists(p):
                 os.remove(p)
     return res
+
+
+def sadsurf_probe(np_mod):
+    """tools/sadsurf_bench.py's `frame` mode inside this process: the search-window kernel on whole 1080p pictures (510 CTUs per launch), timed by
+    the library's own HIP events around each launch."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sadsurf_bench as sb
+    import x265_amd.hipprim as hp
+    L = hp.lib()
+    buf, stride, rows, srcs = sb.pictures(W, H, 2, 4321)
+    r = sb.run_mode(hp, L, "frame", W, H, 2, 32, 4, buf, stride, rows, srcs)
+    r["algorithmic_bytes_per_ctu"] = sb.unit_bytes(32)
+    return r
+
+
+def source_digest(*names):
+    """sha256 over kernel sources: profiles/ files carry it, and a profile is only quoted when it was collected from the sources of this tree"""
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        h.update(open(os.path.join(ROOT, "x265_amd", "csrc", n), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_profile(pattern, kernel, digest):
+    """(HBM bytes per launch, file, note) of `kernel` from the newest committed PMC summary matching `pattern` whose `# sources` stamp equals `digest`
+    (tools/collect_profiles.sh writes the stamp); (None, file, why) when there is none for these sources."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if not files:
+        return None, None, "no committed PMC profile"
+    f = files[-1]
+    stamp, note = None, "from the committed profile, not collected in this run"
+    val = None
+    for line in open(f):
+        if line.startswith("# sources"):
+            stamp = line.split()[-1]
+        if line.startswith("# fetch_correction"):
+            note += "; " + line[1:].strip()
+        if kernel in line and not line.startswith("#"):
+            cols = line.split()
+            try:
+                val = int((float(cols[-2]) + float(cols[-1])) * 1024)
+            except ValueError:
+                continue
+    if stamp != digest:
+        return None, os.path.relpath(f, ROOT), "the committed profile was collected from other kernel sources (stamp %s, tree %s): not quoted" % (stamp, digest)
+    return val, os.path.relpath(f, ROOT), note
 
 
 def main():
@@ -559,6 +638,7 @@ def main():
     ap.add_argument("--quick", action="store_true", help="skip the multi-process CPU port leg")
     ap.add_argument("--lookahead-probe-only", action="store_true",
                     help="profiling aid (tools/collect_profiles.sh): only the lookahead_p_kernel probe of the roofline block, so that PMC passes see exactly its launches")
+    ap.add_argument("--probe-pairs", type=int, default=8, help="--lookahead-probe-only: (frame, reference) pairs per launch")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="frame pass: independent passes per GPU per step, each on its own HIP stream (x265 --frame-threads inside one device)")
     args = ap.parse_args()
@@ -582,7 +662,7 @@ def main():
     L = hp.lib()
     hp.check(L.x265hip_init(local_rank))
     if args.lookahead_probe_only:
-        la_ms, la_blocks = lookahead_kernel_probe(L, hp, np)
+        la_ms, la_blocks = lookahead_kernel_probe(L, hp, np, pairs=args.probe_pairs)
         print(json.dumps({"lookahead_probe": {"launch_ms": round(la_ms, 4), "blocks": la_blocks, "pairs": la_blocks // 8160}}), flush=True)
         return
     if world > 1:
@@ -606,12 +686,15 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
-    enc = encode_bench(args, rank, local_rank, world, fence)
-    dt = enc["dt"]
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    def allmax(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
+
+    enc = encode_bench(args, rank, local_rank, world, fence, allmax)
+    dt = allmax(enc["dt"])
     fps = world * enc["frames"] / dt
 
     fpb = None
@@ -622,50 +705,122 @@ def main():
             fpb = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
     if rank == 0:
-        la_ms, la_blocks = lookahead_kernel_probe(L, hp, np)
+        served = parse_served(enc["served"])
+        clocks = served.get("clocks", {})
+        ctu_cols = (W + 63) // 64
+        # ---- SAD surfaces: the search-window kernel, live in the timed encode (the library's HIP events around every launch) -------------------------
+        ss = clocks.get("SAD surfaces", {})
+        ss_digest = source_digest("sadsurf.hip")
+        ss_traffic, ss_tfile, ss_tnote = pmc_profile("r*_pmc_sadsurf.txt", "sadsurf_ctu_kernel", ss_digest)
+        ss_block = None
+        if ss.get("ms") and served.get("surface_launches"):
+            secs, n = ss["ms"] * 1e-3, served["surface_launches"]
+            ctus = served["ctu_rows"] * ctu_cols
+            ach = ss["algorithmic_bytes"] / secs / 1e9
+            comp = ctus * (64 * 64 + 128 * 128 + 16 * 516 + 4 * 1028 + 1028)
+            ss_block = {"bound": "hbm", "kernel": "sadsurf_ctu_kernel, live in the timed encode: %d launches building %d CTU rows (%.1f CTUs per launch) of %d SAD surfaces; per CTU "
+                                                  "16 + 4 + 1 exhaustive block searches over 64 x 64 vectors, SURVEY 8d unique-footprint bytes per block search (508 437 B per "
+                                                  "complete CTU); VALU-bound on v_qsad_pk_u16_u8, see valu_sad" % (n, served["ctu_rows"], ctus / n, served["surfaces"]),
+                        "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
+                        "traffic": ss_traffic, "traffic_source": ss_tfile, "traffic_note": ss_tnote,
+                        "algorithmic_bytes_per_launch": int(ss["algorithmic_bytes"] / n), "launch_ms": round(ss["ms"] / n, 5),
+                        "launch_ms_note": "HIP events around every launch on the stream it runs on, inside libx265hip.so, summed over the timed encode (x265hip_device_time)",
+                        "compulsory": {"bytes_per_launch": int(comp / n), "achieved": round(comp / secs / 1e9, 2),
+                                       "note": "what the kernel must move: source CTU + reference window in, windows and origins out"},
+                        "valu_sad": {"abs_diff_per_s_T": round(ctus * 16 * 4096 * 256 / secs / 1e12, 2), "ceiling_T": 95.2,
+                                     "ceiling_note": "v_qsad_pk_u16_u8 issue rate of the whole chip measured by tools/micro/qsad_rate (profiles/r03_v2_sadsurf_kernel.txt)"}}
+        probe_block = None
+        try:
+            pr = sadsurf_probe(np)
+            secs = pr["kernel_ns"] * 1e-9
+            ach = pr["ctus"] * pr["algorithmic_bytes_per_ctu"] / secs / 1e9
+            probe_block = {"bound": "hbm", "kernel": "sadsurf_ctu_kernel on whole 1080p pictures (tools/sadsurf_bench.py frame mode: %d launches of %d CTUs)" % (pr["launches"], pr["ctus_per_launch"]),
+                           "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": ss_traffic,
+                           "traffic_source": ss_tfile, "traffic_note": ss_tnote,
+                           "algorithmic_bytes_per_launch": int(pr["ctus_per_launch"] * pr["algorithmic_bytes_per_ctu"]), "launch_ms": round(pr["us_per_launch"] * 1e-3, 5),
+                           "valu_sad": {"abs_diff_per_s_T": round(pr["ctus"] * 16 * 4096 * 256 / secs / 1e12, 2), "ceiling_T": 95.2}}
+        except Exception as e:  # noqa: BLE001
+            probe_block = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        # ---- lookahead searches: live in the encode, and the probe at the encode's launch size ---------------------------------------------------------
         # ALGORITHMIC bytes per 8x8 lowres block of the P cost pass: SURVEY.md §8d per-call figures (sad / satd 2WHB, a quarter-pel candidate
         # adds the two half-pel blocks and the averaged one) over the calls the reference issues per block on this clip geometry, counted
         # with the pinned oracle (tools/count_lookahead_units.py: 19.77 calls, 3978 B per block, seed 4321)
-        LA_BYTES_PER_BLOCK, LA_CALLS_PER_BLOCK = 3978.0, 19.77
+        LA_BYTES_PER_BLOCK, LA_CALLS_PER_BLOCK, LA_BLOCKS = 3978.0, 19.77, 8160
+        la = clocks.get("lookahead searches", {})
+        la_digest = source_digest("lookahead.hip", "lasession.hip")
+        la_traffic, la_tfile, la_tnote = pmc_profile("r*_pmc_lookahead.txt", "lookahead_p_kernel", la_digest)
+        la_live = None
+        if la.get("ms") and served.get("search_launches"):
+            pairs = served["search_launches"] * served["pairs_per_launch"]
+            secs = la["ms"] * 1e-3
+            ach = pairs * LA_BLOCKS * LA_BYTES_PER_BLOCK / secs / 1e9
+            la_live = {"bound": "hbm", "kernel": "lookahead_p_kernel<u8>, live in the timed encode: %d launches of %.1f (frame, reference) pairs of 960x544 lowres = %d 8x8 blocks "
+                                                 "x %.0f B each (%.1f reference slot calls per block, SURVEY 8d per-call bytes); a latency-bound dependent chain, see DESIGN.md §5"
+                                                 % (served["search_launches"], served["pairs_per_launch"], LA_BLOCKS, LA_BYTES_PER_BLOCK, LA_CALLS_PER_BLOCK),
+                       "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
+                       "traffic": None, "algorithmic_bytes_per_launch": int(served["pairs_per_launch"] * LA_BLOCKS * LA_BYTES_PER_BLOCK),
+                       "launch_ms": round(la["ms"] / served["search_launches"], 4), "launch_ms_note": "HIP events around each launch, summed over the timed encode"}
+        probe_pairs = int(min(64, max(1, round(served.get("pairs_per_launch", 8)))))
+        la_ms, la_blocks = lookahead_kernel_probe(L, hp, np, pairs=probe_pairs)
         la_bytes = LA_BYTES_PER_BLOCK * la_blocks
         ach = la_bytes / (la_ms * 1e-3) / 1e9
         # what HBM has to deliver when caches work: the frame's plane + the reference's four half-pel planes once per pair, 22 B of results per block
-        uniq = (la_blocks // 8160) * 5 * 1024 * 608 + la_blocks * 22
-        la_traffic, la_tfile, la_tnote = pmc_lookahead()
+        uniq = (la_blocks // LA_BLOCKS) * 5 * 1024 * 608 + la_blocks * 22
+        la_probe = {"bound": "hbm", "kernel": "lookahead_p_kernel<u8> probe: %d identical (frame, reference) pairs per launch (the encode's average launch size), %d blocks x %.0f B"
+                                              % (la_blocks // LA_BLOCKS, la_blocks, LA_BYTES_PER_BLOCK),
+                    "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
+                    "traffic": la_traffic if probe_pairs == 8 else None, "traffic_source": la_tfile, "traffic_note": la_tnote,
+                    "algorithmic_bytes_per_launch": int(la_bytes), "launch_ms": round(la_ms, 4),
+                    "launch_ms_note": "HIP events on the kernel's own stream, measured in this run",
+                    "unique_footprint": {"bytes_per_launch": uniq, "achieved": round(uniq / (la_ms * 1e-3) / 1e9, 2),
+                                         "frac": round(uniq / (la_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}}
+        # ---- sub-pel plane bands: the one kernel of the encode that is bandwidth-shaped ------------------------------------------------------------------
+        pl = clocks.get("sub-pel plane bands", {})
+        pl_block = None
+        if pl.get("ms") and pl.get("launch_groups"):
+            secs = pl["ms"] * 1e-3
+            ach = pl["algorithmic_bytes"] / secs / 1e9
+            pl_block = {"bound": "hbm", "kernel": "subpel_planes8_kernel (+ nothing else in the span), live in the timed encode: %d bands; bytes = rows x padded width x (1 picture + 15 "
+                                                  "phase planes)" % pl["launch_groups"],
+                        "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": None,
+                        "algorithmic_bytes_per_launch": int(pl["algorithmic_bytes"] / pl["launch_groups"]), "launch_ms": round(pl["ms"] / pl["launch_groups"], 5),
+                        "launch_ms_note": "HIP events around each band's launch; bands are one CTU row each (launch-latency sized)"}
+        # the dominant kernel of the timed region = the clock with the most device time
+        named = [(ss.get("ms", 0.0), ss_block), (la.get("ms", 0.0), la_live)]
+        named = [b for _, b in sorted(named, key=lambda t: -t[0]) if b]
+        dominant = named[0] if named else la_probe
+        others = [b for b in (ss_block, probe_block, la_live, la_probe, pl_block) if b and b is not dominant]
         out = {
             "metric": "encode fps (1080p preset medium)", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "x265 --preset medium --me hex, 1920x1080 8-bit 4:2:0 synthetic clip (x265_amd/synth.make_clip: 96x96 tiles with their own "
-                                   "velocities + noise, seed 4321 + 101 * rank), %d frames per rank per timed run (one step = %d frames); the reference "
-                                   "encoder's binary + x265_amd/host/*.cpp + libx265hip.so (oracle/_ref/x265_hip_8bit): lookahead frame-cost estimates "
-                                   "batched on the GPU, luma sub-pel filter slots served from GPU-built fractional planes of each reference picture, "
-                                   "psy-cost source halves from GPU-built energy planes, C slots otherwise, all host cores; N ranks = N encoders on N GPUs, each on its own clip"
-                                   % (enc["frames"], CHUNK),
+            "config": {"workload": "x265 --preset medium --me hex, 1920x1080 8-bit 4:2:0; ONE synthetic clip = the %d-frame segment of x265_amd/synth.make_clip (96x96 tiles with "
+                                   "their own velocities + noise, seed 4321) repeated N times, rank r encodes repetition r as a closed-GOP chunk on GPU r (one step = %d frames "
+                                   "per rank); the reference encoder's binary + x265_amd/host/*.cpp + libx265hip.so (oracle/_ref/x265_hip_8bit): lookahead frame-cost "
+                                   "estimates batched on the GPU, integer-pel SADs of the motion search looked up in GPU-built SAD surfaces, luma sub-pel filter slots "
+                                   "served from GPU-built fractional planes of each reference picture, psy-cost source halves from GPU-built energy planes, C slots "
+                                   "otherwise; the host cores are split between the ranks" % (enc["frames"], CHUNK),
                        "frames_per_step": world * CHUNK, "encoder_cli_fps_rank0": enc["cli_fps"], "served_by_gpu": enc["served"],
                        "host_cores": os.cpu_count(), "pool_threads_per_encoder": enc["pools"], "timed_s": round(dt, 2)},
-            "roofline": {"bound": "hbm", "kernel": "lookahead_p_kernel<u8> (%d (frame, reference) pairs of 960x544 lowres = %d 8x8 blocks x %.0f B = %.1f "
-                                                     "reference slot calls per block, SURVEY 8d per-call bytes; a latency-bound dependent chain, see DESIGN.md §5)"
-                                                     % (la_blocks // 8160, la_blocks, LA_BYTES_PER_BLOCK, LA_CALLS_PER_BLOCK),
-                         "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": la_traffic,
-                         "traffic_source": la_tfile, "traffic_note": la_tnote,
-                         "hbm_counter_frac": round(la_traffic / (la_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) if la_traffic else None,
-                         "algorithmic_bytes_per_launch": int(la_bytes), "launch_ms": round(la_ms, 4),
-                         "launch_ms_note": "HIP events on the kernel's own stream, measured in this run",
-                         "unique_footprint": {"bytes_per_launch": uniq, "achieved": round(uniq / (la_ms * 1e-3) / 1e9, 2),
-                                              "frac": round(uniq / (la_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}},
+            "roofline": dominant,
+            "rooflines": others,
+            "gpu_duty_cycle": {"device_ms": served.get("device_ms"), "timed_s": round(dt, 2),
+                               "frac": round(served["device_ms"] * 1e-3 / dt, 4) if served.get("device_ms") else None,
+                               "by_clock_ms": {k: v["ms"] for k, v in clocks.items()},
+                               "note": "rank 0's encoder: sum of the device time of every launch group of the bound modules (x265hip_device_time) / wall clock of the timed "
+                                       "region; the weight analysis of the lookahead (about 1 % of the device time) is not inside a span"},
         }
         if "reference" in enc:
             r0 = enc["reference"]
-            out["cpu_baseline"] = {"value": r0["cli_fps"], "unit": "frames/s", "cores": os.cpu_count(), "kind": "reference",
-                                   "sample": "the same %d-frame clip and arguments through oracle/_ref/x265_8bit (unmodified reference, [noasm] C primitives — "
-                                             "no nasm in the image, so the AVX2 / AVX-512 path cannot be built), its own fps line; wall %.1f s; pool = all host "
-                                             "cores, of which x265 keeps roughly 15 busy at this size" % (enc["frames"], r0["wall_s"]),
-                                   "wall_fps": round(enc["frames"] / r0["wall_s"], 3) if r0["wall_s"] else None,
-                                   "wall_fps_note": "frames / process wall time, the way `value` is measured (start-up and clip reading included)",
+            ref_fps = world * enc["frames"] / r0["wall_s"] if r0["wall_s"] else None
+            out["cpu_baseline"] = {"value": round(ref_fps, 3) if ref_fps else None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "reference",
+                                   "sample": "the same %d chunk(s) of %d frames, same arguments (and the same --pools share at N > 1), through oracle/_ref/x265_8bit — the unmodified "
+                                             "reference, [noasm] C primitives: no nasm in the image, so the AVX2 / AVX-512 path cannot be built — %d encoder(s) at the same time, "
+                                             "measured like `value`: all frames / wall clock between two fences (%.1f s)" % (world, enc["frames"], world, r0["wall_s"]),
+                                   "cli_fps_rank0": r0["cli_fps"],
                                    "byte_identical_to_gpu_path": r0["byte_identical"], "bitstream_bytes": r0["bitstream_bytes"]}
             if not r0["byte_identical"]:
-                out["error"] = "the GPU-path bitstream differs from the reference encoder's"
+                out["error"] = "a chunk's GPU-path bitstream differs from the reference encoder's"
         if fpb:
             out["frame_pass"] = fpb
         print(json.dumps(out), flush=True)

@@ -54,6 +54,21 @@ int  x265hip_event_destroy(void* ev);
 int  x265hip_event_record(void* ev, void* stream);
 int  x265hip_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
 
+/* Device-time ledger of the modules the bound encoder uses (lookahead session, reference-picture mirrors, SAD surfaces, source energy planes): every
+ * launch group of those modules runs between two HIP events of its own stream; after the stream synchronisation that the module performs anyway the
+ * elapsed time is added to its clock.  Per process.  bench.py derives the encode's device duty cycle and the live launch durations of the
+ * roofline block from it (x265_amd/host prints the clocks at exit under X265HIP_VERBOSE). */
+#define X265HIP_CLK_LA_SEARCH  0   /* lookahead_p_kernel launches of the session (x265hip_la_estimate_batch*)                         */
+#define X265HIP_CLK_LA_OTHER   1   /* the session's other kernels: P cost, bidir, scatter, weight analysis, lowres planes + intra      */
+#define X265HIP_CLK_PLANES     2   /* sub-pel plane bands of the reference-picture mirrors                                             */
+#define X265HIP_CLK_SADSURF    3   /* search-window kernel of the SAD surfaces                                                         */
+#define X265HIP_CLK_ENERGY     4   /* source energy planes                                                                             */
+#define X265HIP_CLK_COUNT      5
+/* algorithmicBytes: SURVEY.md §8d bytes of the work inside the spans where the module can state them itself — SAD surfaces: per block of a built CTU
+ * the exhaustive search's unique footprint W H B + (W + R - 1)(H + R - 1) B + 4 R^2 (R = 2 searchRange); plane bands: rows x (padded width) x
+ * (1 picture + 15 phase planes) x B; 0 for the other clocks (bench.py prices the lookahead searches per 8x8 block from its own count). */
+int  x265hip_device_time(int clock, uint64_t* spans, uint64_t* nanoseconds, uint64_t* algorithmicBytes);
+
 /* ---------------------------------------------------------------- pixel comparisons ------------------------- */
 /* pixelcmp_t  (primitives.h:133): pu[].sad, pu[].satd, cu[].sa8d, chroma sa8d; out[i] = cmp(A+offA[i], B+offB[i]) */
 #define X265HIP_CMP_SAD    0   /* pixel.cpp:40   sad<lx,ly>                                  */

@@ -373,6 +373,15 @@ int x265hip_refpic_rows_final(x265hip_refpic* rp, int rowsFinal)
 
 /* ---------------------------------------------------------------- source-picture energy planes, emulated ------------------------------ *
  * the source half of psyCost_pp (pixel.cpp:726-757) with the oracle's sa8d / satd restatements against a zero block */
+int x265hip_device_time(int clock, uint64_t* spans, uint64_t* nanoseconds, uint64_t* algorithmicBytes)
+{
+    (void)clock;
+    if (algorithmicBytes) *algorithmicBytes = 0;
+    if (spans) *spans = 0;
+    if (nanoseconds) *nanoseconds = 0;
+    return 0;                           /* no device: nothing to time */
+}
+
 int x265hip_source_energy(int depth, const void* hostPlane, int64_t stride, int width, int height, int32_t* hostE8, int32_t* hostE4)
 {
     const int bw = width >> 3, bh = height >> 3;

@@ -21,6 +21,17 @@ bool valid_block(int w, int h);            // multiples of 2 up to 64 (luma PU s
 #define XH_CHECK_DEV()      do { int e_ = xh::ensure_device(); if (e_) return e_; } while (0)
 #define XH_LAUNCH_CHECK(nm) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return xh::check_hip(e_, nm); } while (0)
 
+// ---- device-time ledger (x265hip_device_time): a span = the launches between begin() and end() on one stream; commit() after that stream has been
+// synchronised adds the elapsed time to the clock.  Events are per thread and per clock; a span that could not get its events measures nothing.
+struct DevSpan
+{
+    int clk; hipStream_t st; hipEvent_t e0 = nullptr, e1 = nullptr;
+    uint64_t bytes = 0;                              // SURVEY.md §8d algorithmic bytes of the span's work, where the module states them
+    DevSpan(int clock, hipStream_t stream);          // records the first event
+    void end();                                      // records the second event
+    void commit();                                   // after the stream's synchronisation
+};
+
 // grid sizing for batch kernels: enough 256-thread workgroups to fill 256 CUs several times over, grid-stride beyond
 inline int grid_for(long long workgroups_needed, int cap = 256 * 16)
 {

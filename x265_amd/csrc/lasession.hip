@@ -446,6 +446,7 @@ int x265hip_la_estimate_batch_ahead(x265hip_la* la, x265hip_la_estimate* est, in
         if ((e = check_hip(hipMemsetAsync(la->dSync, 0, (size_t)2 * la->capEst * ncu * sizeof(uint64_t), la->st), "la sync zero"))) return e;
         la->epoch = 1;
     }
+    DevSpan spanSearch(X265HIP_CLK_LA_SEARCH, la->st);
     if (nPairs)
     {
         if ((e = x265hip_lookahead_cost_p_batch(c.depth, (const x265hip_lookahead_pair*)dev_of(hPairs), nPairs, c.stride, c.planeElems, W, H, numRowsPerSlice,
@@ -454,6 +455,8 @@ int x265hip_la_estimate_batch_ahead(x265hip_la* la, x265hip_la_estimate* est, in
         la->statSearchLaunches++;
         la->statSearchPairs += nPairs;
     }
+    spanSearch.end();
+    DevSpan spanOther(X265HIP_CLK_LA_OTHER, la->st);
     if (nPcost && (e = x265hip_lookahead_pcost_batch((const x265hip_lookahead_pair*)dev_of(hPcost), nPcost, W, H, dEstPcost, la->st)))
         return e;
     if (nBf && (e = x265hip_lookahead_bidir_batch(c.depth, (const x265hip_lookahead_bframe*)dev_of(hBf), nBf, c.stride, c.planeElems, W, H, dEstBf, la->st)))
@@ -463,10 +466,13 @@ int x265hip_la_estimate_batch_ahead(x265hip_la* la, x265hip_la_estimate* est, in
         hipLaunchKernelGGL(la_scatter_kernel, dim3(8, nSc), dim3(256), 0, la->st, (const ScatterJob*)dev_of(hSc), 3 * ncu);
         XH_LAUNCH_CHECK("la_scatter_kernel");
     }
+    spanOther.end();
     const size_t used = blk * n, estWords = (size_t)(nPairs + nPcost) * 4 + (size_t)nBf * 2;
     if (used && (e = check_hip(hipMemcpyAsync(la->hOut, la->dOut, used, hipMemcpyDeviceToHost, la->st), "la out d2h"))) return e;
     if ((e = check_hip(hipMemcpyAsync(la->hOut + blk * la->capEst, dEstSearch, estWords * 8, hipMemcpyDeviceToHost, la->st), "la est d2h"))) return e;
     if ((e = check_hip(hipStreamSynchronize(la->st), "la batch sync"))) return e;
+    if (nPairs) spanSearch.commit();
+    if (nPcost || nBf || nSc) spanOther.commit();
     const int64_t* hEst = (const int64_t*)(la->hOut + blk * la->capEst);
     const int64_t* hEstPcost = hEst + (size_t)nPairs * 4;
     const int64_t* hEstBf = hEstPcost + (size_t)nPcost * 4;

@@ -49,14 +49,18 @@ static void process(const RefJob& j)
         const int y0 = rp->phaseDone - rp->marginY, y1 = phaseEnd - rp->marginY;       // picture coordinates
         const char* org = rp->dPic + ((size_t)rp->marginY * rp->stride + rp->marginX) * B;
         char* porg = rp->dPlanes + ((size_t)rp->marginY * rp->stride + rp->marginX) * B;
+        DevSpan span(X265HIP_CLK_PLANES, rp->st);
         if (build_subpel_rows(rp->depth, org, rp->stride, -rp->marginX + 4, rp->picW + rp->marginX - 4, y0, y1, porg, rp->planeElems, rp->st))
         { rp->failed = 1; return; }
+        span.end();
+        span.bytes = (uint64_t)(y1 - y0) * (uint64_t)(rp->picW + 2 * rp->marginX - 8) * 16 * B;
         // planes 1..15, rows [phaseDone, phaseEnd): one 2-D copy — "row" = the band of one plane, pitch = one plane
         const size_t bandOff = (size_t)rp->phaseDone * rp->stride * B, bandBytes = (size_t)(phaseEnd - rp->phaseDone) * rp->stride * B;
         const size_t pitch = (size_t)rp->planeElems * B;
         if (hipMemcpy2DAsync(rp->hPlanes + bandOff, pitch, rp->dPlanes + pitch + bandOff, pitch, bandBytes, 15, hipMemcpyDeviceToHost, rp->st) != hipSuccess)
         { rp->failed = 1; return; }
         if (hipStreamSynchronize(rp->st) != hipSuccess) { rp->failed = 1; return; }
+        span.commit();
         rp->phaseDone = phaseEnd;
         if (j.epoch == rp->epoch.load())
             rp->rowsReady.store(phaseEnd - rp->marginY, std::memory_order_release);

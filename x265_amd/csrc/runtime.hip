@@ -2,6 +2,7 @@
 // There is deliberately no CPU fallback anywhere in this library: without a gfx950-class device every entry point
 // returns X265HIP_ENODEV.
 #include "common.h"
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -75,6 +76,48 @@ int ensure_device()
     return init_device(cur);
 }
 
+static std::atomic<uint64_t> g_clkSpans[X265HIP_CLK_COUNT], g_clkNs[X265HIP_CLK_COUNT], g_clkBytes[X265HIP_CLK_COUNT];
+
+DevSpan::DevSpan(int clock, hipStream_t stream) : clk(clock), st(stream)
+{
+    static thread_local hipEvent_t ev[X265HIP_CLK_COUNT][2];
+    static thread_local int evDevice[X265HIP_CLK_COUNT];
+    static thread_local bool have[X265HIP_CLK_COUNT];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (have[clk] && evDevice[clk] != dev)
+    {
+        (void)hipEventDestroy(ev[clk][0]); (void)hipEventDestroy(ev[clk][1]);
+        have[clk] = false;
+    }
+    if (!have[clk])
+    {
+        if (hipEventCreate(&ev[clk][0]) != hipSuccess || hipEventCreate(&ev[clk][1]) != hipSuccess) { (void)hipGetLastError(); return; }
+        have[clk] = true; evDevice[clk] = dev;
+    }
+    e0 = ev[clk][0]; e1 = ev[clk][1];
+    if (hipEventRecord(e0, st) != hipSuccess) { (void)hipGetLastError(); e0 = e1 = nullptr; }
+}
+
+void DevSpan::end()
+{
+    if (e1 && hipEventRecord(e1, st) != hipSuccess) { (void)hipGetLastError(); e0 = e1 = nullptr; }
+}
+
+void DevSpan::commit()
+{
+    float ms = 0;
+    if (e0 && e1 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess)
+    {
+        g_clkNs[clk] += (uint64_t)((double)ms * 1e6);
+        g_clkSpans[clk]++;
+        g_clkBytes[clk] += bytes;
+    }
+    else
+        (void)hipGetLastError();
+    e0 = e1 = nullptr;
+}
+
 bool valid_depth(int depth) { return depth == 8 || depth == 10 || depth == 12; }
 bool valid_block(int w, int h) { return w >= 2 && h >= 2 && w <= 64 && h <= 64 && !(w & 1) && !(h & 1); }
 
@@ -98,6 +141,15 @@ int x265hip_device_count(void)
 }
 
 const char* x265hip_last_error(void) { return t_err; }
+
+int x265hip_device_time(int clock, uint64_t* spans, uint64_t* nanoseconds, uint64_t* algorithmicBytes)
+{
+    if (clock >= 0 && clock < X265HIP_CLK_COUNT && algorithmicBytes) *algorithmicBytes = g_clkBytes[clock].load();
+    if (clock < 0 || clock >= X265HIP_CLK_COUNT) return set_error(X265HIP_EINVAL, "x265hip_device_time: clock %d", clock);
+    if (spans) *spans = g_clkSpans[clock].load();
+    if (nanoseconds) *nanoseconds = g_clkNs[clock].load();
+    return X265HIP_OK;
+}
 const char* x265hip_version(void) { return "x265hip 0.1 (gfx950)"; }
 
 int x265hip_malloc(void** dptr, size_t bytes)

@@ -89,7 +89,7 @@ static std::mutex g_ssLock;              // the surfaces lists of the mirrors an
 static std::mutex g_poolLock;
 struct PoolEntry { char* d; char* h; };
 static std::multimap<size_t, PoolEntry> g_pool;      // table buffers of finished surfaces, by size (pinned allocations are expensive: ~ms)
-static std::atomic<uint64_t> g_statAttached{ 0 }, g_statRows{ 0 }, g_statLaunches{ 0 }, g_statKernelNs{ 0 };
+static std::atomic<uint64_t> g_statAttached{ 0 }, g_statRows{ 0 }, g_statLaunches{ 0 };
 
 static void layout_for(int w, int h, int depth, SurfLayout& L)
 {
@@ -476,14 +476,25 @@ static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& li
             }
             attrSet = 1;
         }
-        // the launch between two events of its own stream: the kernel's device time, summed for x265hip_sadsurf_stats (worker thread only)
-        static thread_local hipEvent_t ev[2] = { nullptr, nullptr };
-        if (!ev[0] && (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess))
-            ev[0] = ev[1] = nullptr;
-        if (ev[0]) (void)hipEventRecord(ev[0], rp->st);
+        // the launch between two events of its own stream: the kernel's device time (x265hip_device_time, x265hip_sadsurf_stats)
+        DevSpan span(X265HIP_CLK_SADSURF, rp->st);
         hipLaunchKernelGGL(sadsurf_ctu_kernel, dim3(lay.ctuCols, rows), dim3(1024), surf_lds_bytes(maxS), rp->st, a);
         bool bad = hipGetLastError() != hipSuccess;
-        if (ev[0]) (void)hipEventRecord(ev[1], rp->st);
+        span.end();
+        for (int k = 0; k < a.nJobs; k++)
+        {
+            // one W x H block over an R x R window = W H B + (W + R - 1)(H + R - 1) B + 4 R^2 (B = 1, R = 2 S), per block built
+            const int64_t R = 2 * a.job[k].S;
+            for (int l = 1; l < 4; l++)
+            {
+                const int64_t N = 8 << l, unit = N * N + (N + R - 1) * (N + R - 1) + 4 * R * R;
+                int blockRows = 0;
+                for (int r = a.job[k].row0; r < a.job[k].row0 + a.job[k].rows; r++)
+                    for (int j = 0; j < lay.per[l]; j++)
+                        blockRows += r * lay.per[l] + j < lay.blocksY[l];
+                span.bytes += (uint64_t)(unit * blockRows * lay.blocksX[l]);
+            }
+        }
         for (int k = 0; k < a.nJobs && !bad; k++)
         {
             const size_t off = (size_t)a.job[k].row0 * lay.pitch, bytes = (size_t)a.job[k].rows * lay.pitch;
@@ -495,9 +506,7 @@ static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& li
             rp->failed = 1;
             return;
         }
-        float ms = 0;
-        if (ev[0] && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess)
-            g_statKernelNs += (uint64_t)(ms * 1e6);
+        span.commit();
         g_statRows += rows;
         g_statLaunches++;
         for (int k = 0; k < a.nJobs; k++)
@@ -668,7 +677,7 @@ void x265hip_sadsurf_release(x265hip_sadsurf* ss)
 
 int x265hip_sadsurf_stats(uint64_t* attached, uint64_t* ctuRows, uint64_t* launches, uint64_t* kernelNs)
 {
-    if (kernelNs) *kernelNs = g_statKernelNs.load();
+    if (kernelNs) (void)x265hip_device_time(X265HIP_CLK_SADSURF, nullptr, kernelNs, nullptr);
     if (launches) *launches = g_statLaunches.load();
     if (attached) *attached = g_statAttached.load();
     if (ctuRows) *ctuRows = g_statRows.load();

@@ -136,13 +136,16 @@ extern "C" int x265hip_source_energy(int depth, const void* hostPlane, int64_t s
     int32_t* dE8 = (int32_t*)(es.d + planeBytes);
     int32_t* dE4 = dE8 + (size_t)bw * bh;
     const dim3 grid((bw * bh + 127) / 128), block(128);
+    DevSpan span(X265HIP_CLK_ENERGY, es.st);
     if (depth == 8)
         hipLaunchKernelGGL((source_energy_kernel<uint8_t>), grid, block, 0, es.st, (const uint8_t*)es.d, stride, bw, bh, dE8, dE4);
     else
         hipLaunchKernelGGL((source_energy_kernel<uint16_t>), grid, block, 0, es.st, (const uint16_t*)es.d, stride, bw, bh, dE8, dE4);
     XH_LAUNCH_CHECK("source_energy_kernel");
+    span.end();
     if (hipMemcpyAsync(es.h + planeBytes, dE8, e8Bytes + e4Bytes, hipMemcpyDeviceToHost, es.st) != hipSuccess || hipStreamSynchronize(es.st) != hipSuccess)
         return set_error(X265HIP_EHIP, "source_energy: download");
+    span.commit();
     memcpy(hostE8, es.h + planeBytes, e8Bytes);
     memcpy(hostE4, es.h + planeBytes + e8Bytes, e4Bytes);
     return X265HIP_OK;

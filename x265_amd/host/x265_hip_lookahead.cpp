@@ -37,6 +37,7 @@
 #undef private
 
 #include "x265hip.h"
+#include "x265_hip_debug.h"
 
 namespace X265_NS {
 
@@ -188,7 +189,9 @@ Session& session_for(const Lookahead& l, const Lowres* f)
     c.heightInCU = l.m_8x8Height;
     c.maxDist = l.m_param->bframes + 2;
     c.numSlots = l.m_param->lookaheadDepth + l.m_param->bframes + 10;
+    x265hip_debug_mark("create: lookahead session");
     s.la = x265hip_la_create(&c);
+    x265hip_debug_mark("created: lookahead session");
     if (!s.la)
         die("session");
     s.owner = &l;

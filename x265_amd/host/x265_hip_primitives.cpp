@@ -19,11 +19,14 @@
 #include "constants.h"
 #include "contexts.h"
 #include "x265hip.h"
+#include "x265_hip_debug.h"
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <mutex>
+#include <unistd.h>
 
 namespace X265_NS {
 
@@ -568,6 +571,25 @@ static void report_calls()
     fprintf(stderr, "x265hip: %llu primitive calls served by the GPU\n", x265hip_call_count());
 }
 
+// X265HIP_VERBOSE: the device-time ledger of the bound modules (include/x265hip.h, x265hip_device_time) — what the GPU was busy with, in total
+static void report_device_time()
+{
+    static const char* const names[X265HIP_CLK_COUNT] = { "lookahead searches", "other lookahead kernels", "sub-pel plane bands", "SAD surfaces", "source energy planes" };
+    uint64_t total = 0;
+    char line[1024];
+    int n = 0;
+    for (int c = 0; c < X265HIP_CLK_COUNT; c++)
+    {
+        uint64_t spans = 0, ns = 0, bytes = 0;
+        x265hip_device_time(c, &spans, &ns, &bytes);
+        total += ns;
+        n += snprintf(line + n, sizeof(line) - n, "%s%s %.3f ms in %llu launch groups (%llu algorithmic bytes)", c ? ", " : "", names[c], ns * 1e-6,
+                      (unsigned long long)spans, (unsigned long long)bytes);
+    }
+    fprintf(stderr, "x265hip: device time (HIP events around every launch group): %s; total %.3f ms\n", line, total * 1e-6);
+    x265hip_debug_mark("last exit handler of the bindings");
+}
+
 void setupInstrinsicPrimitives(EncoderPrimitives&, int) {}
 
 void setupAssemblyPrimitives(EncoderPrimitives& p, int /* cpuMask: CPU ISA bits, meaningless for a GPU path */)
@@ -575,6 +597,8 @@ void setupAssemblyPrimitives(EncoderPrimitives& p, int /* cpuMask: CPU ISA bits,
     const char* env = getenv("X265HIP");
     if (env && !strcmp(env, "0"))
         return;
+    x265hip_debug_mark("setupAssemblyPrimitives enters");
+    struct MarkExit { ~MarkExit() { x265hip_debug_mark("setupAssemblyPrimitives returns"); } } markExit;
     // x265_setup_primitives (primitives.cpp) is not serialised: an encoder opened on another thread sees `primitives.pu[0].sad` set, skips the
     // set-up and starts using the table while this call is still running — and this call can take long (the first one initialises the HIP
     // runtime).  The reference closes the table with setupAliasPrimitives AFTER this function; do it first as well, so that the table is complete
@@ -586,7 +610,9 @@ void setupAssemblyPrimitives(EncoderPrimitives& p, int /* cpuMask: CPU ISA bits,
     if (!probed)
     {
         probed = true;
-        if (x265hip_device_count() < 1)
+        const int devices = x265hip_device_count();
+        x265hip_debug_mark("device count known (HIP runtime initialised)");
+        if (devices < 1)
         {
             fprintf(stderr, "x265hip: no HIP device visible: GPU bindings are OFF, the encoder runs the reference's host code only%s\n",
                     env && !strcmp(env, "require") ? "" : " (X265HIP=0 silences this, X265HIP=require makes it fatal)");
@@ -603,6 +629,12 @@ void setupAssemblyPrimitives(EncoderPrimitives& p, int /* cpuMask: CPU ISA bits,
     const char* mode = getenv("X265HIP_TABLE");
     if (!mode || strcmp(mode, "percall"))
     {
+        static bool timeReport = false;
+        if (!timeReport && getenv("X265HIP_VERBOSE") && x265hip_device_count() > 0)
+        {
+            timeReport = true;
+            atexit(report_device_time);
+        }
         x265hip_install_lookup_slots(p);            // x265_hip_refplanes.cpp: luma sub-pel filters served from GPU-built planes
         x265hip_install_psy_slots(p);               // x265_hip_srcplanes.cpp: the source half of psy_cost_pp from GPU-built energy planes
         return;

@@ -36,6 +36,7 @@
 #undef private
 
 #include "x265hip.h"
+#include "x265_hip_debug.h"
 
 namespace X265_NS {
 
@@ -151,7 +152,9 @@ Mirror* mirror_of(PicYuv* pic)
     Mirror& m = g_mirror[slot];
     const int maxCU = pic->m_param->maxCUSize;
     const int bufRows = (int)(((pic->m_picHeight + maxCU - 1) / maxCU) * maxCU + 2 * pic->m_lumaMarginY);       // picyuv.cpp:95-98
+    x265hip_debug_mark("create: reference-picture mirror");
     m.rp = x265hip_refpic_create(X265_DEPTH, pic->m_picWidth, pic->m_picHeight, pic->m_stride, pic->m_lumaMarginX, pic->m_lumaMarginY, bufRows, lo);
+    x265hip_debug_mark("created: reference-picture mirror");
     if (!m.rp)
     {
         fprintf(stderr, "x265hip: refplanes: %s\n", x265hip_last_error());

@@ -34,6 +34,7 @@
 #undef private
 
 #include "x265hip.h"
+#include "x265_hip_debug.h"
 
 namespace X265_NS {
 
@@ -180,7 +181,9 @@ void build(SrcPic* sp, uint32_t v)
         }
         if (!sp->dev)
         {
+            x265hip_debug_mark("create: device copy of a source picture");
             sp->dev = x265hip_srcpic_create(X265_DEPTH, pic.m_picWidth, pic.m_picHeight);
+            x265hip_debug_mark("created: device copy of a source picture");
             sp->devW = pic.m_picWidth; sp->devH = pic.m_picHeight;
         }
         if (!sp->dev || x265hip_srcpic_upload(sp->dev, pic.m_picOrg[0], pic.m_stride))
