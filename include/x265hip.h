@@ -54,6 +54,16 @@ int  x265hip_event_destroy(void* ev);
 int  x265hip_event_record(void* ev, void* stream);
 int  x265hip_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
 
+/* Several GPUs in one encoder (x265's frame-thread model, SURVEY.md §8e: frames <-> GPUs).  A PLACE is where a picture's device copy lives: place p
+ * is on HIP device devices[p] (several places may share a device — that is how the exchange is exercised on a one-GPU box).  Reference-picture
+ * mirrors and source pictures are created at a place (x265hip_refpic_create_at, x265hip_srcpic_create_at); a SAD surface is built at its SOURCE
+ * picture's place, and when the reference picture's mirror lives elsewhere the library keeps a replica of the reconstructed picture at the source's
+ * place: every band of rows the owner uploads is pushed device to device (hipMemcpyPeerAsync — xGMI between the GPUs of a node; no host round trip) —
+ * the reconstructed-reference exchange of frame-parallel encoding (reference frameencoder.cpp:848-861 waits on the rows, framefilter.cpp:654-664
+ * publishes them).  Objects created without a place (x265hip_refpic_create, x265hip_srcpic_create) live on the calling thread's device. */
+int  x265hip_places(int n, const int* devices);                        /* places can be added later, not moved */
+int  x265hip_peer_stats(uint64_t* replicas, uint64_t* bands, uint64_t* bytes);   /* per process: replicas created, bands pushed, bytes pushed */
+
 /* Device-time ledger of the modules the bound encoder uses (lookahead session, reference-picture mirrors, SAD surfaces, source energy planes): every
  * launch group of those modules runs between two HIP events of its own stream; after the stream synchronisation that the module performs anyway the
  * elapsed time is added to its clock.  Per process.  bench.py derives the encode's device duty cycle and the live launch durations of the
@@ -655,6 +665,7 @@ int x265hip_la_stats_ahead(x265hip_la* la, uint64_t* launchedAhead, uint64_t* us
  * (marginY, marginX).  The buffer stays the caller's and must outlive the refpic. */
 typedef struct x265hip_refpic x265hip_refpic;
 x265hip_refpic* x265hip_refpic_create(int depth, int picW, int picH, int64_t stride, int marginX, int marginY, int bufRows, const void* hostBase);
+x265hip_refpic* x265hip_refpic_create_at(int place, int depth, int picW, int picH, int64_t stride, int marginX, int marginY, int bufRows, const void* hostBase);   /* x265hip_places */
 void x265hip_refpic_destroy(x265hip_refpic* rp);
 /* a new picture is about to be reconstructed into the buffer: nothing is valid any more; queued work of the old picture is dropped */
 int x265hip_refpic_reset(x265hip_refpic* rp);
@@ -695,6 +706,7 @@ int x265hip_source_energy(int depth, const void* hostPlane, int64_t stride, int 
 #define X265HIP_SADSURF_LEVELS 4
 typedef struct x265hip_srcpic x265hip_srcpic;        /* the luma plane of a source picture, resident on the device */
 x265hip_srcpic* x265hip_srcpic_create(int depth, int width, int height);
+x265hip_srcpic* x265hip_srcpic_create_at(int place, int depth, int width, int height);       /* x265hip_places */
 int x265hip_srcpic_upload(x265hip_srcpic* sp, const void* hostLuma, int64_t stride);          /* blocks until the copy is on the device */
 void x265hip_srcpic_destroy(x265hip_srcpic* sp);
 typedef struct x265hip_sadsurf x265hip_sadsurf;
@@ -718,10 +730,14 @@ typedef struct x265hip_sadsurf_view
     const int* ctuRowsReady;             /* origins and tables of every block above picture line 64 * (*ctuRowsReady) are in host memory (load with
                                             acquire semantics); grows as the reference picture's rows become final */
 } x265hip_sadsurf_view;
-/* Levels 1..3 (N = 16, 32, 64) are built; level 0 is reserved (origin == NULL).  searchRange: 8..32, a multiple of 4.  The surface follows `ref`'s progress (x265hip_refpic_rows_final) by itself: rows that are
+/* Levels 1..3 (N = 16, 32, 64) are searched; level 0 (N = 8; x265hip_sadsurf_attach_levels, origin == NULL when it is not built) takes its window from the parent 16 x 16 block (same origin; its SADs are measured after
+ * the parent's window is known); an 8 x 8 block whose parent does not lie inside the picture has no window: origin (-32768, -32768), never look it up.  searchRange: 8..32, a multiple of 4.  The surface follows `ref`'s progress (x265hip_refpic_rows_final) by itself: rows that are
  * final already are built at once, the others as they arrive; x265hip_refpic_reset / _destroy of `ref` ends it (no further rows are published;
  * the handle stays valid until it is released).  `src` must stay unchanged and alive until the release.  NULL on failure. */
-x265hip_sadsurf* x265hip_sadsurf_attach(x265hip_srcpic* src, x265hip_refpic* ref, int searchRange, int lambda20);
+x265hip_sadsurf* x265hip_sadsurf_attach(x265hip_srcpic* src, x265hip_refpic* ref, int searchRange, int lambda20);          /* levels 1..3 */
+/* levels: bit l = level l is built; bits 1..3 must be set, bit 0 adds the 8 x 8 windows (2.5 times the table bytes: on the 1080p bench clip only a
+ * third of the 8 x 8 searches stay inside their parent's window, so x265_amd/host leaves it off unless X265HIP_SADPLANES_LEVELS says otherwise) */
+x265hip_sadsurf* x265hip_sadsurf_attach_levels(x265hip_srcpic* src, x265hip_refpic* ref, int searchRange, int lambda20, int levels);
 const x265hip_sadsurf_view* x265hip_sadsurf_get_view(x265hip_sadsurf* ss);
 void x265hip_sadsurf_release(x265hip_sadsurf* ss);
 /* per process: surfaces attached, CTU rows built, kernel launches that built them (rows of several surfaces of one reference picture share a launch)

@@ -305,7 +305,26 @@ struct x265hip_refpic
     int rowsReady;
     int rowsFinal;       /* picture rows the caller declared final (the whole padded picture once >= picH) */
     struct x265hip_sadsurf* surfaces;      /* attached SAD surfaces (singly linked) */
+    int place;                             /* x265hip_refpic_create_at; -1 for x265hip_refpic_create */
+    int repPlace[16], repCopied[16], nRep; /* emulated replicas at other places: how many buffer rows each has been "pushed" */
 };
+/* places (x265hip_places): the emulation has no devices; it keeps the bookkeeping of the exchange — which replicas exist, how many bands and bytes
+ * the device implementation would have pushed from GPU to GPU — so that the binding's placement logic can be tested on the CPU tier */
+static int g_nPlaces;
+static uint64_t g_peerReplicas, g_peerBands, g_peerBytes;
+int x265hip_places(int n, const int* devices)
+{
+    if (n < 1 || n > 64 || !devices || n < g_nPlaces) { snprintf(g_err, sizeof(g_err), "emul: x265hip_places: %d", n); return -1; }
+    g_nPlaces = n;
+    return 0;
+}
+int x265hip_peer_stats(uint64_t* replicas, uint64_t* bands, uint64_t* bytes)
+{
+    if (replicas) *replicas = g_peerReplicas;
+    if (bands) *bands = g_peerBands;
+    if (bytes) *bytes = g_peerBytes;
+    return 0;
+}
 static void sadsurf_progress(struct x265hip_sadsurf* ss);
 static void sadsurf_detach_all(x265hip_refpic* rp);
 
@@ -317,12 +336,21 @@ x265hip_refpic* x265hip_refpic_create(int depth, int picW, int picH, int64_t str
     rp->planes = (char*)calloc((size_t)15 * rp->planeElems, rp->B);
     rp->phaseDone = 4;
     rp->rowsReady = -(1 << 30);
+    rp->place = -1;
+    return rp;
+}
+x265hip_refpic* x265hip_refpic_create_at(int place, int depth, int picW, int picH, int64_t stride, int marginX, int marginY, int bufRows, const void* hostBase)
+{
+    if (place < 0 || place >= g_nPlaces) { snprintf(g_err, sizeof(g_err), "emul: no place %d", place); return NULL; }
+    x265hip_refpic* rp = x265hip_refpic_create(depth, picW, picH, stride, marginX, marginY, bufRows, hostBase);
+    if (rp) rp->place = place;
     return rp;
 }
 void x265hip_refpic_destroy(x265hip_refpic* rp) { if (rp) { sadsurf_detach_all(rp); free(rp->planes); free(rp); } }
 int x265hip_refpic_reset(x265hip_refpic* rp)
 {
     sadsurf_detach_all(rp);
+    for (int i = 0; i < rp->nRep; i++) rp->repCopied[i] = 0;
     rp->phaseDone = 4; rp->rowsFinal = 0;
     __atomic_store_n(&rp->rowsReady, -(1 << 30), __ATOMIC_RELEASE);
     return 0;
@@ -416,13 +444,21 @@ void orc_sadsurf_rows_8(const uint8_t* src, intptr_t srcStride, const uint8_t* r
 void orc_sadsurf_rows_16(const uint16_t* src, intptr_t srcStride, const uint16_t* ref, intptr_t refStride, int picW, int picH, int marginX, int marginY,
                          int S, int lambda20, int row0, int row1, int16_t* const origin[4], uint32_t* const table[4]);
 
-struct x265hip_srcpic { int depth, B, w, h; char* luma; };
+struct x265hip_srcpic { int depth, B, w, h; char* luma; int place; };
 
 x265hip_srcpic* x265hip_srcpic_create(int depth, int width, int height)
 {
     x265hip_srcpic* sp = (x265hip_srcpic*)calloc(1, sizeof(*sp));
     sp->depth = depth; sp->B = depth == 8 ? 1 : 2; sp->w = width; sp->h = height;
     sp->luma = (char*)malloc((size_t)width * height * sp->B);
+    sp->place = -1;
+    return sp;
+}
+x265hip_srcpic* x265hip_srcpic_create_at(int place, int depth, int width, int height)
+{
+    if (place < 0 || place >= g_nPlaces) { snprintf(g_err, sizeof(g_err), "emul: no place %d", place); return NULL; }
+    x265hip_srcpic* sp = x265hip_srcpic_create(depth, width, height);
+    if (sp) sp->place = place;
     return sp;
 }
 int x265hip_srcpic_upload(x265hip_srcpic* sp, const void* hostLuma, int64_t stride)
@@ -438,7 +474,7 @@ struct x265hip_sadsurf
     x265hip_srcpic* src;
     x265hip_refpic* ref;                 /* NULL once the reference picture has gone (reset / destroy) */
     struct x265hip_sadsurf* next;
-    int S, lambda20, ctuRows, ctuRowsReady;
+    int S, lambda20, ctuRows, ctuRowsReady, levels;
     x265hip_sadsurf_view view;
     int64_t originOff[X265HIP_SADSURF_LEVELS], tableOff[X265HIP_SADSURF_LEVELS];
     char* buf;                                   /* ctuRows chunks of view.ctuRowPitch bytes, the layout of x265hip_sadsurf_level */
@@ -452,6 +488,20 @@ static void sadsurf_progress(x265hip_sadsurf* ss)
     x265hip_refpic* rp = ss->ref;
     if (!rp) return;
     const int complete = rp->rowsFinal >= rp->picH;
+    if (ss->src->place != rp->place && ss->ctuRowsReady < ss->ctuRows && (complete || 64 * (ss->ctuRowsReady + 1) + ss->S <= rp->rowsFinal))
+    {
+        /* the device implementation builds this surface from a replica of the picture at the source's place: rows pushed GPU to GPU */
+        int k = 0;
+        while (k < rp->nRep && rp->repPlace[k] != ss->src->place) k++;
+        if (k == rp->nRep && k < 16) { rp->repPlace[k] = ss->src->place; rp->repCopied[k] = 0; rp->nRep++; g_peerReplicas++; }
+        const int uploaded = complete ? rp->picH + 2 * rp->marginY : rp->marginY + rp->rowsFinal;
+        if (k < 16 && rp->repCopied[k] < uploaded)
+        {
+            g_peerBands++;
+            g_peerBytes += (uint64_t)(uploaded - rp->repCopied[k]) * rp->stride * rp->B;
+            rp->repCopied[k] = uploaded;
+        }
+    }
     while (ss->ctuRowsReady < ss->ctuRows)
     {
         const int r = ss->ctuRowsReady;
@@ -465,8 +515,9 @@ static void sadsurf_progress(x265hip_sadsurf* ss)
             orc_sadsurf_rows_16((const uint16_t*)ss->src->luma, ss->src->w, (const uint16_t*)refOrg, rp->stride, rp->picW, rp->picH, rp->marginX, rp->marginY,
                                 ss->S, ss->lambda20, r, r + 1, ss->origin, ss->wide);
         char* chunk = ss->buf + (size_t)r * ss->view.ctuRowPitch;
-        for (int l = 1; l < X265HIP_SADSURF_LEVELS; l++)
+        for (int l = 0; l < X265HIP_SADSURF_LEVELS; l++)
         {
+            if (!(ss->levels >> l & 1)) continue;
             const x265hip_sadsurf_level* v = &ss->view.level[l];
             for (int j = 0; j < v->blocksPerCtuRow; j++)
             {
@@ -511,18 +562,23 @@ static void sadsurf_detach_all(x265hip_refpic* rp)
 
 x265hip_sadsurf* x265hip_sadsurf_attach(x265hip_srcpic* src, x265hip_refpic* ref, int searchRange, int lambda20)
 {
+    return x265hip_sadsurf_attach_levels(src, ref, searchRange, lambda20, 14);
+}
+x265hip_sadsurf* x265hip_sadsurf_attach_levels(x265hip_srcpic* src, x265hip_refpic* ref, int searchRange, int lambda20, int levels)
+{
     if (!src || !ref || src->depth != ref->depth || src->w != ref->picW || src->h != ref->picH || searchRange < 8 || searchRange > 32 || (searchRange & 3) ||
-        lambda20 < 0 || lambda20 > (1 << 20))
+        lambda20 < 0 || lambda20 > (1 << 20) || (levels & ~15) || (levels & 14) != 14)
     {
         snprintf(g_err, sizeof(g_err), "emul: sadsurf_attach: mismatched pictures or range %d", searchRange);
         return NULL;
     }
     x265hip_sadsurf* ss = (x265hip_sadsurf*)calloc(1, sizeof(*ss));
-    ss->src = src; ss->ref = ref; ss->S = searchRange; ss->lambda20 = lambda20;
+    ss->src = src; ss->ref = ref; ss->S = searchRange; ss->lambda20 = lambda20; ss->levels = levels;
     ss->ctuRows = (src->h + 63) / 64;
     int64_t off = 0;
-    for (int l = 1; l < X265HIP_SADSURF_LEVELS; l++)
+    for (int l = 0; l < X265HIP_SADSURF_LEVELS; l++)
     {
+        if (!(levels >> l & 1)) continue;         /* not built: origin == NULL in the view, NULL arrays for the oracle */
         const int log2n = 3 + l, N = 1 << log2n;
         x265hip_sadsurf_level* v = &ss->view.level[l];
         v->blocksX = src->w >> log2n; v->blocksY = src->h >> log2n; v->blocksPerCtuRow = 64 / N;
@@ -535,8 +591,9 @@ x265hip_sadsurf* x265hip_sadsurf_attach(x265hip_srcpic* src, x265hip_refpic* ref
     }
     ss->view.ctuRowPitch = off;
     ss->buf = (char*)calloc((size_t)ss->ctuRows, (size_t)off);
-    for (int l = 1; l < X265HIP_SADSURF_LEVELS; l++)
+    for (int l = 0; l < X265HIP_SADSURF_LEVELS; l++)
     {
+        if (!(levels >> l & 1)) continue;
         ss->view.level[l].origin = (const int16_t*)(ss->buf + ss->originOff[l]);
         ss->view.level[l].table = ss->buf + ss->tableOff[l];
     }

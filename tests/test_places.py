@@ -1,0 +1,133 @@
+"""Several GPUs in one encoder (include/x265hip.h: x265hip_places, *_create_at; X265HIP_DEVICES in x265_amd/host/x265_hip_debug.h): reference-picture
+mirrors and source pictures take their places in turn, a SAD surface is built where its source picture lives from a replica of the reference
+picture that the library feeds device to device — the reconstructed-reference exchange of frame-parallel encoding (reference
+frameencoder.cpp:848-861, framefilter.cpp:654-664).
+
+CPU tier: the bound encoder on the emulated ABI (tests/support/libx265hip_emul.so keeps the exchange's bookkeeping) with two and three places is
+byte-identical to the unmodified reference encoder, and the exchange happened.  GPU tier: two places on the one GPU of the box (the exchange is then a
+device-to-device copy inside one GPU, every other line of the path is the multi-GPU one): the device surfaces built from a replica equal the
+restatement entry for entry, and the bound encoder with X265HIP_DEVICES=0,0 is byte-identical to the reference."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _need(name):
+    p = os.path.join(REF, name)
+    if not os.path.exists(p):
+        pytest.skip("%s not built (needs /root/reference at build time)" % name)
+    return p
+
+
+def _encode(exe, yuv, w, h, frames, out, env, extra=()):
+    args = ["--input", yuv, "--input-res", "%dx%d" % (w, h), "--input-depth", "8", "--fps", "30", "--frames", str(frames), "--pools", "4", "-F", "3", "--hash", "1",
+            "--preset", "medium", "--me", "hex"] + list(extra)
+    r = subprocess.run([exe] + args + ["-o", out], capture_output=True, text=True, timeout=900, env=dict(os.environ, X265HIP_VERBOSE="1", **env))
+    assert r.returncode == 0, r.stderr[-800:]
+    return open(out, "rb").read(), r.stderr
+
+
+def _exchange(stderr):
+    m = re.search(r"x265hip: places: (\d+) .*; (\d+) replicas of reference pictures at other places, (\d+) bands of reconstructed rows \(([\d.]+) MB\)", stderr)
+    assert m, stderr[-800:]
+    return int(m.group(1)), int(m.group(2)), int(m.group(3)), float(m.group(4))
+
+
+@pytest.mark.parametrize("devices", ["0,1", "0,1,2"])
+def test_bound_encoder_with_places_is_byte_identical_on_the_emulation(tmp_path, devices):
+    ref, emul = _need("x265_8bit"), _need("x265_emul_8bit")
+    from x265_amd.synth import make_clip
+    yuv = str(tmp_path / "clip.yuv")
+    w, h, frames = 416, 240, 14
+    make_clip(yuv, w, h, frames, seed=31)
+    want, _ = _encode(ref, yuv, w, h, frames, str(tmp_path / "ref.hevc"), {})
+    got, err = _encode(emul, yuv, w, h, frames, str(tmp_path / "emul.hevc"), {"X265HIP_DEVICES": devices})
+    assert got == want, "bitstreams differ"
+    places, replicas, bands, mb = _exchange(err)
+    assert places == len(devices.split(",")) and replicas > 0 and bands >= replicas and mb > 0
+    served = [l for l in err.splitlines() if "x265hip: sadplanes:" in l]
+    assert served and int(served[0].split()[2]) > 1000, err[-600:]
+
+
+@pytest.mark.gpu
+def test_surface_built_from_a_replica_matches_restatement():
+    import x265_amd.hipprim as hp
+    import test_sadsurf as ts
+    L = hp.lib()
+    hp.check(L.x265hip_init(0))
+    em = ts._emul(hp)
+    for lib in (L, em):
+        for name in ("x265hip_places", "x265hip_peer_stats", "x265hip_refpic_create_at", "x265hip_srcpic_create_at"):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = hp.PROTOTYPES[name]
+        devs = (C.c_int * 2)(0, 0)
+        assert lib.x265hip_places(2, devs) == 0, lib.x265hip_last_error()
+    w, h, S, lam = 416, 240, 32, 180
+    buf, stride, rows, srcs = ts._pictures(w, h, 21, count=3)
+    bands = [64, 128, 192, h]
+
+    def run(lib):
+        rp = lib.x265hip_refpic_create_at(0, 8, w, h, stride, ts.MX, ts.MY, rows, buf.ctypes.data)
+        assert rp, lib.x265hip_last_error()
+        sps, sss = [], []
+        for k, s in enumerate(srcs):
+            sp = lib.x265hip_srcpic_create_at(k % 2, 8, w, h)          # sources 0 and 2 live with the mirror, source 1 at the other place
+            assert sp, lib.x265hip_last_error()
+            assert lib.x265hip_srcpic_upload(sp, s.ctypes.data, s.shape[1]) == 0
+            sps.append(sp)
+        sss.append(lib.x265hip_sadsurf_attach(sps[0], rp, S, lam))
+        sss.append(lib.x265hip_sadsurf_attach(sps[1], rp, S, lam))
+        for i, r in enumerate(bands):
+            assert lib.x265hip_refpic_rows_final(rp, r) == 0
+            if i == 1:
+                sss.append(lib.x265hip_sadsurf_attach(sps[2], rp, S, lam))
+        assert all(sss), lib.x265hip_last_error()
+        assert lib.x265hip_refpic_wait(rp) == 0, lib.x265hip_last_error()
+        views = [ts._read_view(hp, lib, ss, w, h) for ss in sss]
+        for ss in sss:
+            lib.x265hip_sadsurf_release(ss)
+        lib.x265hip_refpic_wait(rp)
+        lib.x265hip_refpic_destroy(rp)
+        for sp in sps:
+            lib.x265hip_srcpic_destroy(sp)
+        return views
+
+    st0 = [C.c_uint64() for _ in range(3)]
+    L.x265hip_peer_stats(*[C.byref(x) for x in st0])
+    got, want = run(L), run(em)
+    st1 = [C.c_uint64() for _ in range(3)]
+    L.x265hip_peer_stats(*[C.byref(x) for x in st1])
+    for k in range(3):
+        for l in (1, 2, 3):
+            assert np.array_equal(got[k][l][0], want[k][l][0]), ("origins", k, l)
+            assert np.array_equal(got[k][l][1], want[k][l][1]), ("tables", k, l)
+    # one replica (for source 1), fed band by band: every uploaded row of the padded picture exactly once
+    assert st1[0].value - st0[0].value == 1
+    assert st1[1].value - st0[1].value >= 2
+    assert st1[2].value - st0[2].value == (h + 2 * ts.MY) * stride
+
+
+@pytest.mark.gpu
+def test_bound_encoder_with_two_places_on_one_gpu_is_byte_identical(tmp_path):
+    ref, hip = _need("x265_8bit"), _need("x265_hip_8bit")
+    from x265_amd.synth import make_clip
+    yuv = str(tmp_path / "clip.yuv")
+    w, h, frames = 640, 360, 20
+    make_clip(yuv, w, h, frames, seed=32)
+    want, _ = _encode(ref, yuv, w, h, frames, str(tmp_path / "ref.hevc"), {})
+    got, err = _encode(hip, yuv, w, h, frames, str(tmp_path / "hip.hevc"), {"X265HIP_DEVICES": "0,0", "X265HIP": "require"})
+    assert got == want, "bitstreams differ"
+    places, replicas, bands, mb = _exchange(err)
+    assert places == 2 and replicas > 0 and bands >= replicas and mb > 0
+    served = [l for l in err.splitlines() if "x265hip: sadplanes:" in l]
+    assert served and int(served[0].split()[2]) > 1000, err[-600:]

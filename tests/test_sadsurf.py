@@ -26,7 +26,7 @@ def _emul(hp):
         pytest.skip("tests/support/libx265hip_emul.so not built (make -C oracle emul)")
     em = C.CDLL(EMUL)
     for name, (res, args) in hp.PROTOTYPES.items():
-        if name.startswith(("x265hip_refpic_", "x265hip_srcpic_", "x265hip_sadsurf_")) or name == "x265hip_last_error":
+        if name.startswith(("x265hip_refpic_", "x265hip_srcpic_", "x265hip_sadsurf_")) or name in ("x265hip_last_error", "x265hip_places", "x265hip_peer_stats"):
             fn = getattr(em, name)
             fn.restype, fn.argtypes = res, args
     return em
@@ -60,8 +60,10 @@ def _read_view(hp, L, ss, w, h):
     v = C.cast(L.x265hip_sadsurf_get_view(ss), C.POINTER(hp.SadSurfView)).contents
     assert v.ctuRowsReady[0] == (h + 63) // 64, v.ctuRowsReady[0]
     out = {}
-    for l in (1, 2, 3):
+    for l in (0, 1, 2, 3):
         lv = v.level[l]
+        if not lv.origin:
+            continue                   # level not built
         n = 8 << l
         assert (lv.blocksX, lv.blocksY, lv.blocksPerCtuRow) == (w // n, h // n, 64 // n)
         org = np.zeros((lv.blocksY, lv.blocksX, 2), np.int16)
@@ -78,7 +80,7 @@ def _read_view(hp, L, ss, w, h):
     return out
 
 
-def _run(hp, L, w, h, seed, S, lam, bands, attach_after):
+def _run(hp, L, w, h, seed, S, lam, bands, attach_after, levels=15):
     """Drive one library: reference rows arrive in `bands` (picture rows); source k is attached after band attach_after[k] (-1: before any)."""
     buf, stride, rows, srcs = _pictures(w, h, seed, count=len(attach_after))
     rp = L.x265hip_refpic_create(8, w, h, stride, MX, MY, rows, buf.ctypes.data)
@@ -91,7 +93,7 @@ def _run(hp, L, w, h, seed, S, lam, bands, attach_after):
         sps.append(sp)
 
     def attach(k):
-        sss[k] = L.x265hip_sadsurf_attach(sps[k], rp, S, lam)
+        sss[k] = L.x265hip_sadsurf_attach_levels(sps[k], rp, S, lam, levels)
         assert sss[k], L.x265hip_last_error()
 
     for k, a in enumerate(attach_after):
@@ -130,6 +132,11 @@ def test_restatement_entries_are_the_reference_sad_and_windows_are_legal():
             for bx in range(org.shape[1]):
                 ox, oy = int(org[by, bx, 0]), int(org[by, bx, 1])
                 x, y = bx * n, by * n
+                if l == 0 and (x // 16 >= w // 16 or y // 16 >= h // 16):
+                    assert (ox, oy) == (-32768, -32768)          # no 16x16 parent inside the picture: no window
+                    continue
+                if l == 0:
+                    assert (ox, oy) == tuple(int(v) for v in views[0][1][0][by // 2, bx // 2])       # the parent's window
                 assert -S <= ox <= S - WIN and -S <= oy <= S - WIN
                 assert x + ox >= -MX and x + ox + WIN - 1 + n <= w + MX and y + oy >= -MY and y + oy + WIN - 1 + n <= h + MY
                 for k in rng.integers(0, WIN * WIN, 24):
@@ -156,9 +163,11 @@ def test_device_surfaces_match_restatement(case):
     hp.check(L.x265hip_init(0))
     em = _emul(hp)
     w, h, seed, S, lam, bands, attach_after = GPU_CASES[case]
-    got, *_ = _run(hp, L, w, h, seed, S, lam, bands, attach_after)
-    want, *_ = _run(hp, em, w, h, seed, S, lam, bands, attach_after)
+    levels = 14 if case == 1 else 15                 # one case without the 8x8 windows (the layout of the product's default)
+    got, *_ = _run(hp, L, w, h, seed, S, lam, bands, attach_after, levels)
+    want, *_ = _run(hp, em, w, h, seed, S, lam, bands, attach_after, levels)
     for k in range(len(attach_after)):
-        for l in (1, 2, 3):
+        assert sorted(got[k]) == sorted(want[k]) == ([1, 2, 3] if levels == 14 else [0, 1, 2, 3])
+        for l in got[k]:
             assert np.array_equal(got[k][l][0], want[k][l][0]), ("origins", k, l)
             assert np.array_equal(got[k][l][1], want[k][l][1]), ("tables", k, l)

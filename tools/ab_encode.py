@@ -53,7 +53,7 @@ def main():
     cfgs = []
     for c in a.configs:
         name, _, rest = c.partition(":")
-        env = dict(kv.split("=", 1) for kv in rest.split(",") if kv)
+        env = dict(kv.split("=", 1) for kv in rest.split(";" if ";" in rest or rest.count("=") == 1 else ",") if kv)
         cfgs.append((name, env))
     res = {name: [] for name, _ in cfgs}
     for r in range(a.rounds):

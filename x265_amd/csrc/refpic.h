@@ -11,9 +11,19 @@
 
 struct x265hip_sadsurf;
 
+namespace xh {
+// A copy of a mirrored picture on another place (another GPU of the encoder): rows are pushed device to device (hipMemcpyPeerAsync, xGMI between
+// the GPUs of a node) as the owner uploads them; the SAD surfaces of source pictures that live on that place are built from it, on its device.
+struct Replica { int place = 0, device = 0; char* dPic = nullptr; hipStream_t st = nullptr; int copied = 0; };
+int place_device(int place);                 // runtime.hip: the HIP device of a place (x265hip_places), -1 if there is no such place
+int place_of_device(int device);             // the anonymous place of objects created without one: -(device + 1)
+}
+
 struct x265hip_refpic
 {
     int depth = 8, B = 1, picW = 0, picH = 0, marginX = 0, marginY = 0, bufRows = 0, device = 0;
+    int place = -1;                           // x265hip_refpic_create_at; -(device + 1) for x265hip_refpic_create
+    std::vector<xh::Replica*> replicas;       // worker only
     int64_t stride = 0, planeElems = 0;
     const char* hostBase = nullptr;          // the encoder's buffer (PicYuv::m_picBuf[0])
     char* hStage = nullptr;                   // page-locked staging copy of the rows on their way up

@@ -100,9 +100,35 @@ using namespace xh;
 
 extern "C" {
 
+static x265hip_refpic* refpic_create(int place, int depth, int picW, int picH, int64_t stride, int marginX, int marginY, int bufRows, const void* hostBase);
+
 x265hip_refpic* x265hip_refpic_create(int depth, int picW, int picH, int64_t stride, int marginX, int marginY, int bufRows, const void* hostBase)
 {
     if (ensure_device()) return nullptr;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return refpic_create(place_of_device(dev), depth, picW, picH, stride, marginX, marginY, bufRows, hostBase);
+}
+
+x265hip_refpic* x265hip_refpic_create_at(int place, int depth, int picW, int picH, int64_t stride, int marginX, int marginY, int bufRows, const void* hostBase)
+{
+    const int dev = place >= 0 ? place_device(place) : -1;
+    if (dev < 0)
+    {
+        set_error(X265HIP_EINVAL, "x265hip_refpic_create_at: no place %d (x265hip_places)", place);
+        return nullptr;
+    }
+    // the mirror's memory and stream belong to the place's device; the calling thread's own device is restored
+    int cur = 0;
+    const bool had = hipGetDevice(&cur) == hipSuccess;
+    if (hipSetDevice(dev) != hipSuccess) { set_error(X265HIP_EHIP, "x265hip_refpic_create_at: hipSetDevice(%d)", dev); return nullptr; }
+    x265hip_refpic* rp = refpic_create(place, depth, picW, picH, stride, marginX, marginY, bufRows, hostBase);
+    if (had) (void)hipSetDevice(cur);
+    return rp;
+}
+
+static x265hip_refpic* refpic_create(int place, int depth, int picW, int picH, int64_t stride, int marginX, int marginY, int bufRows, const void* hostBase)
+{
     if (!valid_depth(depth) || picW < 8 || picH < 8 || (picW & 3) || (marginX & 3) || marginX < 8 || marginY < 8 || stride < picW + 2 * marginX ||
         bufRows < picH + 2 * marginY || !hostBase)
     {
@@ -115,6 +141,7 @@ x265hip_refpic* x265hip_refpic_create(int depth, int picW, int picH, int64_t str
     rp->stride = stride; rp->planeElems = stride * (int64_t)bufRows;
     rp->hostBase = (const char*)hostBase;
     (void)hipGetDevice(&rp->device);
+    rp->place = place;
     const size_t planeBytes = (size_t)rp->planeElems * rp->B;
     bool ok = hipStreamCreateWithFlags(&rp->st, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc((void**)&rp->dPic, planeBytes) == hipSuccess && hipMalloc((void**)&rp->dPlanes, planeBytes * 16) == hipSuccess &&
@@ -145,6 +172,16 @@ void x265hip_refpic_destroy(x265hip_refpic* rp)
     rp->epoch.fetch_add(1);
     if (rp->st) (void)x265hip_refpic_wait(rp);
     sadsurf_detach_all(rp);                                           // the worker is idle for rp: nobody else touches the list
+    int cur = 0;
+    const bool had = hipGetDevice(&cur) == hipSuccess;
+    for (Replica* r : rp->replicas)
+    {
+        (void)hipSetDevice(r->device);
+        if (r->st) { (void)hipStreamSynchronize(r->st); (void)hipStreamDestroy(r->st); }
+        if (r->dPic) (void)hipFree(r->dPic);
+        delete r;
+    }
+    rp->replicas.clear();
     (void)hipSetDevice(rp->device);
     if (rp->hStage) (void)hipHostFree(rp->hStage);
     if (rp->dPic) (void)hipFree(rp->dPic);
@@ -152,6 +189,7 @@ void x265hip_refpic_destroy(x265hip_refpic* rp)
     if (rp->hPlanes) (void)hipHostFree(rp->hPlanes);
     if (rp->st) (void)hipStreamDestroy(rp->st);
     delete rp;
+    if (had) (void)hipSetDevice(cur);
 }
 
 int x265hip_refpic_reset(x265hip_refpic* rp)
@@ -164,6 +202,8 @@ int x265hip_refpic_reset(x265hip_refpic* rp)
     // it publishes, not atomically with it): nothing of the old picture may stay visible
     rp->rowsReady.store(-(1 << 30), std::memory_order_release);
     sadsurf_detach_all(rp);
+    for (Replica* r : rp->replicas)
+        r->copied = 0;                                                // the replicas stay (same picture size), their rows are the old picture's
     rp->uploaded = 0;
     rp->phaseDone = 4;
     return e;

@@ -76,6 +76,16 @@ int ensure_device()
     return init_device(cur);
 }
 
+// places (x265hip_places): place p lives on HIP device g_places[p]; several places may share a device
+static int g_places[64];
+static std::atomic<int> g_nPlaces{ 0 };
+int place_device(int place)
+{
+    if (place < 0) return -(place + 1);
+    return place < g_nPlaces.load() ? g_places[place] : -1;
+}
+int place_of_device(int device) { return -(device + 1); }
+
 static std::atomic<uint64_t> g_clkSpans[X265HIP_CLK_COUNT], g_clkNs[X265HIP_CLK_COUNT], g_clkBytes[X265HIP_CLK_COUNT];
 
 DevSpan::DevSpan(int clock, hipStream_t stream) : clk(clock), st(stream)
@@ -141,6 +151,28 @@ int x265hip_device_count(void)
 }
 
 const char* x265hip_last_error(void) { return t_err; }
+
+int x265hip_places(int n, const int* devices)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1)
+    {
+        (void)hipGetLastError();
+        return set_error(X265HIP_ENODEV, "x265hip_places: no HIP device available; there is no CPU fallback");
+    }
+    if (n < 1 || n > 64 || !devices) return set_error(X265HIP_EINVAL, "x265hip_places: %d places", n);
+    for (int i = 0; i < n; i++)
+        if (devices[i] < 0 || devices[i] >= count)
+            return set_error(X265HIP_EINVAL, "x265hip_places: place %d on device %d (have %d)", i, devices[i], count);
+    if (g_nPlaces.load() > n) return set_error(X265HIP_EINVAL, "x265hip_places: places can be added, not removed");
+    for (int i = 0; i < n; i++)
+    {
+        if (i < g_nPlaces.load() && g_places[i] != devices[i]) return set_error(X265HIP_EINVAL, "x265hip_places: place %d is on device %d already", i, g_places[i]);
+        g_places[i] = devices[i];
+    }
+    g_nPlaces = n;
+    return X265HIP_OK;
+}
 
 int x265hip_device_time(int clock, uint64_t* spans, uint64_t* nanoseconds, uint64_t* algorithmicBytes)
 {

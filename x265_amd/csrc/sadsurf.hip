@@ -23,10 +23,12 @@
 #include "refpic.h"
 #include <cstring>
 #include <map>
+#include <utility>
 
 struct x265hip_srcpic
 {
     int depth = 8, w = 0, h = 0, device = 0;
+    int place = -1;                     // x265hip_srcpic_create_at; -(device + 1) for x265hip_srcpic_create
     int64_t pitch = 0;                  // bytes between rows of dLuma
     char* dLuma = nullptr;
     char* hStage = nullptr;             // page-locked staging copy (the encoder's buffer is ordinary memory)
@@ -51,6 +53,7 @@ struct SurfJob
     const uint8_t* src; int64_t srcPitch;
     char* out;                                    // device table buffer (chunk of CTU row 0 first)
     int S, lambda20, row0, rows;
+    int level0;                                   // the 8x8 windows are wanted
 };
 constexpr int kMaxJobs = 8;
 
@@ -62,6 +65,7 @@ struct SurfArgs
     int64_t pitch;
     int64_t originOff[4], tableOff[4];
     int blocksX[4];
+    int blocksY0;                                 // 8x8 blocks inside the picture, vertically
     int nJobs;
     SurfJob job[kMaxJobs];
 };
@@ -72,7 +76,8 @@ struct x265hip_sadsurf
 {
     x265hip_srcpic* src = nullptr;
     x265hip_refpic* ref = nullptr;       // null once the reference picture has gone (under g_ssLock)
-    int S = 32, lambda20 = 0;
+    xh::Replica* rep = nullptr;          // the reference picture's replica at the source's place; null: the mirror itself (same place).  Worker only
+    int S = 32, lambda20 = 0, levels = 14;
     xh::SurfLayout lay;
     char* dBuf = nullptr;                // ctuRows * pitch
     char* hBuf = nullptr;                // page-locked mirror, same layout
@@ -88,16 +93,19 @@ namespace xh {
 static std::mutex g_ssLock;              // the surfaces lists of the mirrors and x265hip_sadsurf::ref
 static std::mutex g_poolLock;
 struct PoolEntry { char* d; char* h; };
-static std::multimap<size_t, PoolEntry> g_pool;      // table buffers of finished surfaces, by size (pinned allocations are expensive: ~ms)
+static std::multimap<std::pair<size_t, int>, PoolEntry> g_pool;      // key: (bytes, device of d)      // table buffers of finished surfaces, by size (pinned allocations are expensive: ~ms)
 static std::atomic<uint64_t> g_statAttached{ 0 }, g_statRows{ 0 }, g_statLaunches{ 0 };
+static std::atomic<uint64_t> g_statReplicas{ 0 }, g_statPeerBands{ 0 }, g_statPeerBytes{ 0 };
 
-static void layout_for(int w, int h, int depth, SurfLayout& L)
+static void layout_for(int w, int h, int depth, int levels, SurfLayout& L)
 {
     memset(&L, 0, sizeof(L));
     L.ctuCols = (w + 63) / 64; L.ctuRows = (h + 63) / 64;
     int64_t off = 0;
-    for (int l = 1; l < 4; l++)
+    for (int l = 0; l < 4; l++)
     {
+        if (!(levels >> l & 1))
+            continue;                             // level not built: no room in the chunks, blocksX = 0
         const int N = 8 << l;
         L.blocksX[l] = w / N; L.blocksY[l] = h / N; L.per[l] = 64 / N;
         L.entryBytes[l] = (uint64_t)N * N * ((1u << depth) - 1) < 65536 ? 2 : 4;
@@ -380,6 +388,50 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu_kernel(SurfArgs a)
             *(uint2*)(tab + j * kWin + i4) = make_uint2((uint32_t)v0 | ((uint32_t)v1 << 16), (uint32_t)v2 | ((uint32_t)v3 << 16));
         }
     }
+    // level 0: the four 8x8 blocks of wave b's 16x16 block take their parent's window; their SADs are measured now, 4 vectors per lane (one row of
+    // the window = 4 lanes): per source row two v_qsad_pk_u16_u8 on a 12-byte stretch of the reference row, brought to byte alignment with
+    // v_alignbyte (the window's origin is arbitrary).  An 8x8 block whose parent is not inside the picture has no window: origin (-32768, -32768)
+    {
+        const int b = wave, bx16 = b & 3, by16 = b >> 2;
+        const bool parent = x0 + bx16 * 16 + 16 <= a.picW && y0 + by16 * 16 + 16 <= a.picH;
+        const int ox = parent ? sOrg[1][b][0] : 0, oy = parent ? sOrg[1][b][1] : 0;
+#pragma unroll 1
+        for (int q = 0; q < (jb.level0 ? 4 : 0); q++)
+        {
+            const int qx = q & 1, qy = q >> 1;
+            const int x = x0 + bx16 * 16 + qx * 8, y = y0 + by16 * 16 + qy * 8;
+            if (x + 8 > a.picW || y + 8 > a.picH)
+                continue;
+            const int64_t idx = (int64_t)(by16 * 2 + qy) * a.blocksX[0] + cx * 8 + bx16 * 2 + qx;
+            if (!parent)
+            {
+                if (lane == 0)
+                    *(uint32_t*)(chunk + a.originOff[0] + idx * 4) = 0x80008000u;
+                *(uint2*)((uint16_t*)(chunk + a.tableOff[0]) + idx * (kWin * kWin) + lane * 4) = make_uint2(0, 0);
+                continue;
+            }
+            if (lane == 0)
+                *(uint32_t*)(chunk + a.originOff[0] + idx * 4) = (uint32_t)(uint16_t)(int16_t)ox | ((uint32_t)(uint16_t)(int16_t)oy << 16);
+            const int j = lane >> 2, i4 = (lane & 3) * 4;
+            const int col = bx16 * 16 + qx * 8 + ox + S + i4, sh = col & 3;
+            const uint8_t* rp0 = sRef + (by16 * 16 + qy * 8 + oy + S + j) * RW + (col - sh);
+            const uint8_t* sp0 = sSrc + (by16 * 16 + qy * 8) * 64 + bx16 * 16 + qx * 8;
+            uint64_t acc = 0;
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+            {
+                const uint2 sv = *(const uint2*)(sp0 + r * 64);
+                const uint32_t s0 = __builtin_amdgcn_readfirstlane(sv.x), s1 = __builtin_amdgcn_readfirstlane(sv.y);
+                const uint32_t* w = (const uint32_t*)(rp0 + r * RW);
+                const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3];
+                const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh), w2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+                acc = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w1 << 32) | w0, s0, acc);
+                acc = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)w2 << 32) | w1, s1, acc);
+            }
+            uint16_t* tab = (uint16_t*)(chunk + a.tableOff[0]) + idx * (kWin * kWin);
+            *(uint2*)(tab + j * kWin + i4) = make_uint2((uint32_t)acc, (uint32_t)(acc >> 32));
+        }
+    }
     // level 2: group g, one entry per thread
     {
         const int g = tid >> 8, t = tid & 255, gx = g & 1, gy = g >> 1;
@@ -431,90 +483,165 @@ static int rows_possible(x265hip_sadsurf* ss)
     return r1;
 }
 
-// build what the reference's rows allow of every surface in `list` (all attached to rp) in one launch on rp's stream, bring the rows to the
-// host, publish them (worker thread)
+// the replica of rp at `place`, created on first use (worker thread)
+static Replica* replica_at(x265hip_refpic* rp, int place)
+{
+    for (Replica* r : rp->replicas)
+        if (r->place == place) return r;
+    const int dev = place_device(place);
+    if (dev < 0 || hipSetDevice(dev) != hipSuccess)
+        return nullptr;
+    Replica* r = new Replica;
+    r->place = place; r->device = dev;
+    const size_t bytes = (size_t)rp->planeElems * rp->B;
+    if (hipStreamCreateWithFlags(&r->st, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&r->dPic, bytes) != hipSuccess)
+    {
+        if (r->st) (void)hipStreamDestroy(r->st);
+        delete r;
+        (void)hipSetDevice(rp->device);
+        return nullptr;
+    }
+    if (dev != rp->device)
+    {
+        // direct access between the two GPUs where the fabric offers it (xGMI inside a node); hipMemcpyPeerAsync works either way
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dev, rp->device) == hipSuccess && can && hipDeviceEnablePeerAccess(rp->device, 0) != hipSuccess)
+            (void)hipGetLastError();                       // already enabled
+    }
+    (void)hipSetDevice(rp->device);
+    rp->replicas.push_back(r);
+    g_statReplicas++;
+    return r;
+}
+
+// build what the reference's rows allow of every surface in `list` (all attached to rp): per place one launch on that place's stream — the mirror's
+// own for surfaces whose source lives where the mirror does, the replica's otherwise, after the rows the replica does not have yet have been pushed
+// device to device — then the rows come to the host and are published (worker thread; the band's upload has been synchronised)
 static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& list)
 {
-    size_t i = 0;
-    while (i < list.size())
-    {
-        SurfArgs a;
-        memset(&a, 0, sizeof(a));
-        x265hip_sadsurf* in[kMaxJobs];
-        int upto[kMaxJobs], rows = 0, maxS = 0;
-        for (; i < list.size() && a.nJobs < kMaxJobs; i++)
+    std::vector<Replica*> places(1, nullptr);                // nullptr = the mirror's own place
+    for (x265hip_sadsurf* ss : list)
+        if (ss->ref == rp && ss->rep)
         {
-            x265hip_sadsurf* ss = list[i];
-            if (ss->ref != rp)
-                continue;
-            const int r1 = rows_possible(ss);
-            if (r1 == ss->rowsBuilt)
-                continue;
-            SurfJob& j = a.job[a.nJobs];
-            j.src = (const uint8_t*)ss->src->dLuma; j.srcPitch = ss->src->pitch;
-            j.out = ss->dBuf; j.S = ss->S; j.lambda20 = ss->lambda20; j.row0 = ss->rowsBuilt; j.rows = r1 - ss->rowsBuilt;
-            in[a.nJobs] = ss; upto[a.nJobs] = r1;
-            rows += j.rows;
-            if (ss->S > maxS) maxS = ss->S;
-            a.nJobs++;
+            bool seen = false;
+            for (Replica* r : places) seen = seen || r == ss->rep;
+            if (!seen) places.push_back(ss->rep);
         }
-        if (!a.nJobs)
-            return;
-        const SurfLayout& lay = in[0]->lay;                   // same picture size: same layout
-        a.ref = (const uint8_t*)rp->dPic + (size_t)rp->marginY * rp->stride + rp->marginX; a.refStride = rp->stride;
-        a.picW = rp->picW; a.picH = rp->picH; a.marginX = rp->marginX; a.marginY = rp->marginY;
-        a.pitch = lay.pitch;
-        for (int l = 1; l < 4; l++) { a.originOff[l] = lay.originOff[l]; a.tableOff[l] = lay.tableOff[l]; a.blocksX[l] = lay.blocksX[l]; }
-        static std::atomic<int> attrSet{ 0 };
-        if (!attrSet.load())
+    for (Replica* rep : places)
+    {
+        const int dev = rep ? rep->device : rp->device;
+        hipStream_t st = rep ? rep->st : rp->st;
+        const char* dPic = rep ? rep->dPic : rp->dPic;
+        bool pushed = !rep;
+        size_t i = 0;
+        while (i < list.size())
         {
-            if (hipFuncSetAttribute((const void*)sadsurf_ctu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)surf_lds_bytes(32)) != hipSuccess)
+            SurfArgs a;
+            memset(&a, 0, sizeof(a));
+            x265hip_sadsurf* in[kMaxJobs];
+            int upto[kMaxJobs], rows = 0, maxS = 0;
+            for (; i < list.size() && a.nJobs < kMaxJobs; i++)
             {
-                set_error(X265HIP_EHIP, "sadsurf: cannot raise the dynamic LDS limit");
+                x265hip_sadsurf* ss = list[i];
+                if (ss->ref != rp || ss->rep != rep)
+                    continue;
+                if (a.nJobs && ss->levels != in[0]->levels)
+                    break;                                    // another table layout: the next launch
+                const int r1 = rows_possible(ss);
+                if (r1 == ss->rowsBuilt)
+                    continue;
+                SurfJob& j = a.job[a.nJobs];
+                j.src = (const uint8_t*)ss->src->dLuma; j.srcPitch = ss->src->pitch;
+                j.out = ss->dBuf; j.S = ss->S; j.lambda20 = ss->lambda20; j.row0 = ss->rowsBuilt; j.rows = r1 - ss->rowsBuilt;
+                j.level0 = ss->levels & 1;
+                in[a.nJobs] = ss; upto[a.nJobs] = r1;
+                rows += j.rows;
+                if (ss->S > maxS) maxS = ss->S;
+                a.nJobs++;
+            }
+            if (!a.nJobs)
+                break;
+            if (hipSetDevice(dev) != hipSuccess) { rp->failed = 1; return; }
+            if (!pushed)
+            {
+                // the reconstructed rows the replica lacks, straight from the owner's device memory
+                if (rep->copied < rp->uploaded)
+                {
+                    const size_t off = (size_t)rep->copied * rp->stride * rp->B, bytes = (size_t)(rp->uploaded - rep->copied) * rp->stride * rp->B;
+                    if (hipMemcpyPeerAsync(rep->dPic + off, rep->device, rp->dPic + off, rp->device, bytes, st) != hipSuccess)
+                    {
+                        set_error(X265HIP_EHIP, "sadsurf: device-to-device push of reference rows failed");
+                        rp->failed = 1;
+                        (void)hipSetDevice(rp->device);
+                        return;
+                    }
+                    g_statPeerBands++;
+                    g_statPeerBytes += bytes;
+                    rep->copied = rp->uploaded;
+                }
+                pushed = true;
+            }
+            const SurfLayout& lay = in[0]->lay;               // same picture size: same layout
+            a.ref = (const uint8_t*)dPic + (size_t)rp->marginY * rp->stride + rp->marginX; a.refStride = rp->stride;
+            a.picW = rp->picW; a.picH = rp->picH; a.marginX = rp->marginX; a.marginY = rp->marginY;
+            a.pitch = lay.pitch;
+            for (int l = 0; l < 4; l++) { a.originOff[l] = lay.originOff[l]; a.tableOff[l] = lay.tableOff[l]; a.blocksX[l] = lay.blocksX[l]; }
+            a.blocksY0 = lay.blocksY[0];
+            // the dynamic LDS limit is a per-device attribute of the kernel
+            static std::atomic<uint64_t> attrSet{ 0 };
+            if (!(attrSet.load() >> dev & 1))
+            {
+                if (hipFuncSetAttribute((const void*)sadsurf_ctu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)surf_lds_bytes(32)) != hipSuccess)
+                {
+                    set_error(X265HIP_EHIP, "sadsurf: cannot raise the dynamic LDS limit");
+                    rp->failed = 1;
+                    (void)hipSetDevice(rp->device);
+                    return;
+                }
+                attrSet |= (uint64_t)1 << dev;
+            }
+            // the launch between two events of its own stream: the kernel's device time (x265hip_device_time, x265hip_sadsurf_stats)
+            DevSpan span(X265HIP_CLK_SADSURF, st);
+            hipLaunchKernelGGL(sadsurf_ctu_kernel, dim3(lay.ctuCols, rows), dim3(1024), surf_lds_bytes(maxS), st, a);
+            bool bad = hipGetLastError() != hipSuccess;
+            span.end();
+            for (int k = 0; k < a.nJobs; k++)
+            {
+                // one W x H block over an R x R window = W H B + (W + R - 1)(H + R - 1) B + 4 R^2 (B = 1, R = 2 S), per block built
+                const int64_t R = 2 * a.job[k].S;
+                for (int l = 1; l < 4; l++)
+                {
+                    const int64_t N = 8 << l, unit = N * N + (N + R - 1) * (N + R - 1) + 4 * R * R;
+                    int blockRows = 0;
+                    for (int r = a.job[k].row0; r < a.job[k].row0 + a.job[k].rows; r++)
+                        for (int j = 0; j < lay.per[l]; j++)
+                            blockRows += r * lay.per[l] + j < lay.blocksY[l];
+                    span.bytes += (uint64_t)(unit * blockRows * lay.blocksX[l]);
+                }
+            }
+            for (int k = 0; k < a.nJobs && !bad; k++)
+            {
+                const size_t off = (size_t)a.job[k].row0 * lay.pitch, bytes = (size_t)a.job[k].rows * lay.pitch;
+                bad = hipMemcpyAsync(in[k]->hBuf + off, in[k]->dBuf + off, bytes, hipMemcpyDeviceToHost, st) != hipSuccess;
+            }
+            if (bad || hipStreamSynchronize(st) != hipSuccess)
+            {
+                set_error(X265HIP_EHIP, "sadsurf: launch, copy or synchronisation failed");
                 rp->failed = 1;
+                (void)hipSetDevice(rp->device);
                 return;
             }
-            attrSet = 1;
-        }
-        // the launch between two events of its own stream: the kernel's device time (x265hip_device_time, x265hip_sadsurf_stats)
-        DevSpan span(X265HIP_CLK_SADSURF, rp->st);
-        hipLaunchKernelGGL(sadsurf_ctu_kernel, dim3(lay.ctuCols, rows), dim3(1024), surf_lds_bytes(maxS), rp->st, a);
-        bool bad = hipGetLastError() != hipSuccess;
-        span.end();
-        for (int k = 0; k < a.nJobs; k++)
-        {
-            // one W x H block over an R x R window = W H B + (W + R - 1)(H + R - 1) B + 4 R^2 (B = 1, R = 2 S), per block built
-            const int64_t R = 2 * a.job[k].S;
-            for (int l = 1; l < 4; l++)
+            span.commit();
+            g_statRows += rows;
+            g_statLaunches++;
+            for (int k = 0; k < a.nJobs; k++)
             {
-                const int64_t N = 8 << l, unit = N * N + (N + R - 1) * (N + R - 1) + 4 * R * R;
-                int blockRows = 0;
-                for (int r = a.job[k].row0; r < a.job[k].row0 + a.job[k].rows; r++)
-                    for (int j = 0; j < lay.per[l]; j++)
-                        blockRows += r * lay.per[l] + j < lay.blocksY[l];
-                span.bytes += (uint64_t)(unit * blockRows * lay.blocksX[l]);
+                in[k]->rowsBuilt = upto[k];
+                in[k]->ctuRowsReady.store(upto[k], std::memory_order_release);
             }
         }
-        for (int k = 0; k < a.nJobs && !bad; k++)
-        {
-            const size_t off = (size_t)a.job[k].row0 * lay.pitch, bytes = (size_t)a.job[k].rows * lay.pitch;
-            bad = hipMemcpyAsync(in[k]->hBuf + off, in[k]->dBuf + off, bytes, hipMemcpyDeviceToHost, rp->st) != hipSuccess;
-        }
-        if (bad || hipStreamSynchronize(rp->st) != hipSuccess)
-        {
-            set_error(X265HIP_EHIP, "sadsurf: launch, copy or synchronisation failed");
-            rp->failed = 1;
-            return;
-        }
-        span.commit();
-        g_statRows += rows;
-        g_statLaunches++;
-        for (int k = 0; k < a.nJobs; k++)
-        {
-            in[k]->rowsBuilt = upto[k];
-            in[k]->ctuRowsReady.store(upto[k], std::memory_order_release);
-        }
     }
+    (void)hipSetDevice(rp->device);
 }
 
 void sadsurf_rows_arrived(x265hip_refpic* rp)
@@ -531,7 +658,7 @@ static void free_surface(x265hip_sadsurf* ss)
 {
     {
         std::lock_guard<std::mutex> g(g_poolLock);
-        g_pool.insert({ ss->bytes, PoolEntry{ ss->dBuf, ss->hBuf } });
+        g_pool.insert({ { ss->bytes, ss->src->device }, PoolEntry{ ss->dBuf, ss->hBuf } });
     }
     delete ss;
 }
@@ -543,7 +670,15 @@ void sadsurf_job(const RefJob& j)
     {
         // attach: the worker has seen every band queued before this job, so `uploaded` is what the surface can start from
         if (ss->ref && j.epoch == ss->ref->epoch.load() && hipSetDevice(ss->ref->device) == hipSuccess)
+        {
+            if (ss->src->place != ss->ref->place && !(ss->rep = replica_at(ss->ref, ss->src->place)))
+            {
+                set_error(X265HIP_ENOMEM, "sadsurf: no replica of the reference picture at place %d", ss->src->place);
+                ss->ref->failed = 1;
+                return;
+            }
             progress(ss->ref, std::vector<x265hip_sadsurf*>{ ss });
+        }
         return;
     }
     // release
@@ -574,9 +709,34 @@ using namespace xh;
 
 extern "C" {
 
+static x265hip_srcpic* srcpic_create(int place, int depth, int width, int height);
+
 x265hip_srcpic* x265hip_srcpic_create(int depth, int width, int height)
 {
     if (ensure_device()) return nullptr;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return srcpic_create(place_of_device(dev), depth, width, height);
+}
+
+x265hip_srcpic* x265hip_srcpic_create_at(int place, int depth, int width, int height)
+{
+    const int dev = place >= 0 ? place_device(place) : -1;
+    if (dev < 0)
+    {
+        set_error(X265HIP_EINVAL, "x265hip_srcpic_create_at: no place %d (x265hip_places)", place);
+        return nullptr;
+    }
+    int cur = 0;
+    const bool had = hipGetDevice(&cur) == hipSuccess;
+    if (hipSetDevice(dev) != hipSuccess) { set_error(X265HIP_EHIP, "x265hip_srcpic_create_at: hipSetDevice(%d)", dev); return nullptr; }
+    x265hip_srcpic* sp = srcpic_create(place, depth, width, height);
+    if (had) (void)hipSetDevice(cur);
+    return sp;
+}
+
+static x265hip_srcpic* srcpic_create(int place, int depth, int width, int height)
+{
     if (depth != 8 || width < 16 || height < 16 || width > 16384 || height > 16384)
     {
         set_error(X265HIP_EINVAL, "x265hip_srcpic_create: depth %d %dx%d (8-bit pictures only)", depth, width, height);
@@ -586,6 +746,7 @@ x265hip_srcpic* x265hip_srcpic_create(int depth, int width, int height)
     sp->depth = depth; sp->w = width; sp->h = height;
     sp->pitch = (width + 255) & ~255;
     (void)hipGetDevice(&sp->device);
+    sp->place = place;
     const size_t bytes = (size_t)sp->pitch * height;
     if (hipStreamCreateWithFlags(&sp->st, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&sp->dLuma, bytes + 256) != hipSuccess ||
         hipHostMalloc((void**)&sp->hStage, bytes, hipHostMallocDefault) != hipSuccess)
@@ -600,46 +761,63 @@ x265hip_srcpic* x265hip_srcpic_create(int depth, int width, int height)
 int x265hip_srcpic_upload(x265hip_srcpic* sp, const void* hostLuma, int64_t stride)
 {
     if (!sp || !hostLuma || stride < sp->w) return set_error(X265HIP_EINVAL, "x265hip_srcpic_upload: bad arguments");
+    int cur = 0;
+    const bool had = hipGetDevice(&cur) == hipSuccess;
     int e = check_hip(hipSetDevice(sp->device), "hipSetDevice");
     if (e) return e;
     for (int y = 0; y < sp->h; y++)
         memcpy(sp->hStage + (size_t)y * sp->pitch, (const char*)hostLuma + (size_t)y * stride, sp->w);
-    if ((e = check_hip(hipMemcpyAsync(sp->dLuma, sp->hStage, (size_t)sp->pitch * sp->h, hipMemcpyHostToDevice, sp->st), "srcpic h2d"))) return e;
-    return check_hip(hipStreamSynchronize(sp->st), "srcpic sync");
+    if (!(e = check_hip(hipMemcpyAsync(sp->dLuma, sp->hStage, (size_t)sp->pitch * sp->h, hipMemcpyHostToDevice, sp->st), "srcpic h2d")))
+        e = check_hip(hipStreamSynchronize(sp->st), "srcpic sync");
+    if (had && cur != sp->device) (void)hipSetDevice(cur);
+    return e;
 }
 
 void x265hip_srcpic_destroy(x265hip_srcpic* sp)
 {
     if (!sp) return;
+    int cur = 0;
+    const bool had = hipGetDevice(&cur) == hipSuccess;
     (void)hipSetDevice(sp->device);
     if (sp->st) { (void)hipStreamSynchronize(sp->st); (void)hipStreamDestroy(sp->st); }
     if (sp->dLuma) (void)hipFree(sp->dLuma);
     if (sp->hStage) (void)hipHostFree(sp->hStage);
+    if (had && cur != sp->device) (void)hipSetDevice(cur);
     delete sp;
 }
 
 x265hip_sadsurf* x265hip_sadsurf_attach(x265hip_srcpic* src, x265hip_refpic* ref, int searchRange, int lambda20)
 {
+    return x265hip_sadsurf_attach_levels(src, ref, searchRange, lambda20, 14);
+}
+
+x265hip_sadsurf* x265hip_sadsurf_attach_levels(x265hip_srcpic* src, x265hip_refpic* ref, int searchRange, int lambda20, int levels)
+{
     if (ensure_device()) return nullptr;
     if (!src || !ref || src->depth != 8 || ref->depth != 8 || src->w != ref->picW || src->h != ref->picH || searchRange < 8 || searchRange > 32 || (searchRange & 3) ||
-        lambda20 < 0 || lambda20 > (1 << 20) || ref->marginX < searchRange + 8 || ref->marginY < searchRange || src->device != ref->device)
+        lambda20 < 0 || lambda20 > (1 << 20) || ref->marginX < searchRange + 8 || ref->marginY < searchRange || (levels & ~15) || (levels & 14) != 14)
     {
         set_error(X265HIP_EINVAL, "x265hip_sadsurf_attach: pictures do not match, or range %d / lambda %d / margins out of bounds", searchRange, lambda20);
         return nullptr;
     }
     x265hip_sadsurf* ss = new x265hip_sadsurf;
-    ss->src = src; ss->ref = ref; ss->S = searchRange; ss->lambda20 = lambda20;
-    layout_for(src->w, src->h, 8, ss->lay);
+    ss->src = src; ss->ref = ref; ss->S = searchRange; ss->lambda20 = lambda20; ss->levels = levels;
+    layout_for(src->w, src->h, 8, levels, ss->lay);
     ss->bytes = (size_t)ss->lay.pitch * ss->lay.ctuRows;
     {
         std::lock_guard<std::mutex> g(g_poolLock);
-        auto it = g_pool.find(ss->bytes);
+        auto it = g_pool.find({ ss->bytes, src->device });
         if (it != g_pool.end()) { ss->dBuf = it->second.d; ss->hBuf = it->second.h; g_pool.erase(it); }
     }
     if (!ss->dBuf)
     {
-        (void)hipSetDevice(ref->device);
-        if (hipMalloc((void**)&ss->dBuf, ss->bytes) != hipSuccess || hipHostMalloc((void**)&ss->hBuf, ss->bytes, hipHostMallocDefault) != hipSuccess)
+        // the table is written by the kernel that runs where the SOURCE picture lives
+        int cur = 0;
+        const bool had = hipGetDevice(&cur) == hipSuccess;
+        (void)hipSetDevice(src->device);
+        const bool ok = hipMalloc((void**)&ss->dBuf, ss->bytes) == hipSuccess && hipHostMalloc((void**)&ss->hBuf, ss->bytes, hipHostMallocDefault) == hipSuccess;
+        if (had && cur != src->device) (void)hipSetDevice(cur);
+        if (!ok)
         {
             set_error(X265HIP_ENOMEM, "x265hip_sadsurf_attach: %zu bytes", ss->bytes);
             if (ss->dBuf) (void)hipFree(ss->dBuf);
@@ -648,9 +826,11 @@ x265hip_sadsurf* x265hip_sadsurf_attach(x265hip_srcpic* src, x265hip_refpic* ref
         }
     }
     memset(&ss->view, 0, sizeof(ss->view));
-    for (int l = 1; l < 4; l++)
+    for (int l = 0; l < 4; l++)
     {
         x265hip_sadsurf_level& v = ss->view.level[l];
+        if (!(levels >> l & 1))
+            continue;                             // origin == NULL: level not built
         v.blocksX = ss->lay.blocksX[l]; v.blocksY = ss->lay.blocksY[l]; v.entryBytes = ss->lay.entryBytes[l]; v.blocksPerCtuRow = ss->lay.per[l];
         v.origin = (const int16_t*)(ss->hBuf + ss->lay.originOff[l]);
         v.table = ss->hBuf + ss->lay.tableOff[l];
@@ -673,6 +853,14 @@ void x265hip_sadsurf_release(x265hip_sadsurf* ss)
     if (!ss) return;
     ss->released = true;
     RefWorker::worker().push(RefJob{ nullptr, 0, 0, 2, ss });
+}
+
+int x265hip_peer_stats(uint64_t* replicas, uint64_t* bands, uint64_t* bytes)
+{
+    if (replicas) *replicas = g_statReplicas.load();
+    if (bands) *bands = g_statPeerBands.load();
+    if (bytes) *bytes = g_statPeerBytes.load();
+    return X265HIP_OK;
 }
 
 int x265hip_sadsurf_stats(uint64_t* attached, uint64_t* ctuRows, uint64_t* launches, uint64_t* kernelNs)

@@ -184,6 +184,11 @@ PROTOTYPES = {
     "x265hip_sadsurf_release": (None, [vp]),
     "x265hip_sadsurf_stats": (i32, [vp, vp, vp, vp]),
     "x265hip_device_time": (i32, [i32, vp, vp, vp]),
+    "x265hip_sadsurf_attach_levels": (vp, [vp, vp, i32, i32, i32]),
+    "x265hip_places": (i32, [i32, vp]),
+    "x265hip_peer_stats": (i32, [vp, vp, vp]),
+    "x265hip_refpic_create_at": (vp, [i32, i32, i32, i32, i64, i32, i32, i32, vp]),
+    "x265hip_srcpic_create_at": (vp, [i32, i32, i32, i32]),
     "x265hip_call_intra_pred": (i32, [i32, i32, i32, i32, vp, i64, vp]),
     "x265hip_call_intra_allangs": (i32, [i32, i32, vp, vp, vp, i32]),
     "x265hip_call_intra_filter": (i32, [i32, i32, vp, vp]),

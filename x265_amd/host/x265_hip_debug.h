@@ -4,7 +4,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 #include <unistd.h>
+#include "x265hip.h"
 
 namespace X265_NS {
 
@@ -40,6 +42,41 @@ inline void x265hip_debug_mark(const char* what)
         }
     }
     fprintf(stderr, "x265hip-startup: %8.1f ms  %s\n", (now - procStart) * 1e3, what);
+}
+
+// X265HIP_DEVICES=0,1,2,3: the encoder's device work is spread over several GPUs — place p (include/x265hip.h, x265hip_places) lives on the p-th
+// device of the list; the same device may be listed more than once (two places on one GPU: the way the exchange is exercised on a one-GPU box).
+// Reference-picture mirrors and source pictures take their places in turn (x265's frame encoders work on consecutive frames at the same time:
+// consecutive pictures -> different GPUs); a SAD surface is built where its source picture lives, from a replica of the reference picture that the
+// library feeds device to device.  Returns the number of places (0: the variable is not set — everything lives on the calling thread's device).
+inline int x265hip_places_configured()
+{
+    static int n = -1;
+    static std::mutex lock;
+    std::lock_guard<std::mutex> g(lock);
+    if (n >= 0)
+        return n;
+    n = 0;
+    const char* env = getenv("X265HIP_DEVICES");
+    if (!env || !*env)
+        return 0;
+    int devs[64], count = 0;
+    for (const char* p = env; *p && count < 64;)
+    {
+        char* end;
+        const long v = strtol(p, &end, 10);
+        if (end == p) break;
+        devs[count++] = (int)v;
+        p = *end == ',' ? end + 1 : end;
+        if (*end && *end != ',') break;
+    }
+    if (count < 1 || x265hip_places(count, devs))
+    {
+        fprintf(stderr, "x265hip: X265HIP_DEVICES=%s: %s\n", env, count < 1 ? "not a list of device numbers" : x265hip_last_error());
+        abort();                                   // the product path fails loudly
+    }
+    n = count;
+    return n;
 }
 
 } // namespace X265_NS

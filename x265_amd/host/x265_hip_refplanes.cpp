@@ -153,7 +153,9 @@ Mirror* mirror_of(PicYuv* pic)
     const int maxCU = pic->m_param->maxCUSize;
     const int bufRows = (int)(((pic->m_picHeight + maxCU - 1) / maxCU) * maxCU + 2 * pic->m_lumaMarginY);       // picyuv.cpp:95-98
     x265hip_debug_mark("create: reference-picture mirror");
-    m.rp = x265hip_refpic_create(X265_DEPTH, pic->m_picWidth, pic->m_picHeight, pic->m_stride, pic->m_lumaMarginX, pic->m_lumaMarginY, bufRows, lo);
+    const int places = x265hip_places_configured();
+    m.rp = places ? x265hip_refpic_create_at(slot % places, X265_DEPTH, pic->m_picWidth, pic->m_picHeight, pic->m_stride, pic->m_lumaMarginX, pic->m_lumaMarginY, bufRows, lo)
+                  : x265hip_refpic_create(X265_DEPTH, pic->m_picWidth, pic->m_picHeight, pic->m_stride, pic->m_lumaMarginX, pic->m_lumaMarginY, bufRows, lo);
     x265hip_debug_mark("created: reference-picture mirror");
     if (!m.rp)
     {

@@ -7,7 +7,7 @@
 // position in the finished reference picture (:752-756).  Which candidates a search visits depends on the decisions before it (the predictors
 // come from the neighbours' vectors); what a candidate costs does not: SAD(source block at (x, y), reference block at (x + mx, y + my)) is a
 // function of the two pictures, the position and the vector.  The GPU computes those values per (source picture, reference picture) pair for
-// every aligned 16 / 32 / 64 block over a 16 x 16 window of vectors per block, placed around the block's own best match of an exhaustive
+// every aligned 8 / 16 / 32 / 64 block over a 16 x 16 window of vectors per block, placed around the block's own best match of an exhaustive
 // +-32 search (x265hip_sadsurf, x265_amd/csrc/sadsurf.hip), as the reference picture's rows become final; a search then reads a candidate's
 // SAD out of the table when the vector lies in the block's window and computes it with the C function otherwise.  Same value either way, so the
 // bitstream does not depend on what has arrived or on where the windows lie.  Measured before it was built (every eligible
@@ -42,6 +42,7 @@
 #undef private
 
 #include "x265hip.h"
+#include "x265_hip_debug.h"
 
 namespace X265_NS {
 
@@ -71,7 +72,7 @@ const int WIN = X265HIP_SADSURF_WIN;
 
 int g_state = 0;                 // 0 undecided, 1 on, -1 off
 int g_exp = 0;                   // X265HIP_DEBUG_SADEXP=2: every eligible call is computed twice and nothing is looked up (the cost-doubling measurement)
-int g_levels = 14;               // X265HIP_SADPLANES_LEVELS: bit l = blocks of 8 << l are looked up (16, 32, 64 are built)
+int g_levels = 14;               // X265HIP_SADPLANES_LEVELS: bit l = blocks of 8 << l are looked up (8x8: only a third of the searches stay in the parent's window — off)
 int g_time = 0;                  // X265HIP_DEBUG_SADTIME=1: cycles inside the reference's motionEstimate for the PUs a surface could serve, by block size;
                                  // =2: the same with the lookups switched off (the pair of runs measures what the lookups save)
 std::atomic<uint64_t> g_cycles[4], g_timed[4];
@@ -118,7 +119,21 @@ struct Ctx
     uint32_t hit, miss;
 };
 __attribute__((tls_model("initial-exec"))) thread_local Ctx t_ctx;
-__attribute__((tls_model("initial-exec"))) thread_local uint64_t t_hit = 0, t_miss = 0, t_searches = 0;      // up to 255 searches per thread stay unreported at exit
+__attribute__((tls_model("initial-exec"))) thread_local uint64_t t_hit = 0, t_miss = 0, t_searches = 0;
+// what a thread has not reported yet goes to the shared counters when the thread ends (the pool's workers end with the encoder)
+struct FlushAtThreadExit
+{
+    ~FlushAtThreadExit()
+    {
+        if (t_hit | t_miss)
+        {
+            g_count[0].hit.fetch_add(t_hit, std::memory_order_relaxed);
+            g_count[0].miss.fetch_add(t_miss, std::memory_order_relaxed);
+            t_hit = t_miss = 0;
+        }
+    }
+};
+thread_local FlushAtThreadExit t_flushAtExit;
 
 void report()
 {
@@ -127,12 +142,20 @@ void report()
     uint64_t attached = 0, rows = 0, launches = 0, kernelNs = 0;
     x265hip_sadsurf_stats(&attached, &rows, &launches, &kernelNs);
     if (g_time)
-        for (int l = 1; l < 4; l++)
+        for (int l = 0; l < 4; l++)
             fprintf(stderr, "x265hip: sadplanes: block size %d: %llu searches, %.0f cycles each inside the reference's motionEstimate (%s)\n", 8 << l,
                     (unsigned long long)g_timed[l].load(), g_timed[l] ? (double)g_cycles[l].load() / g_timed[l].load() : 0.0, g_time == 2 ? "lookups off" : "lookups on");
     fprintf(stderr, "x265hip: sadplanes: %llu integer-pel SADs of the motion search served from GPU-built SAD surfaces (%llu surfaces, %llu CTU rows in %llu launches, %.3f ms of device time), %llu of the same "
                     "searches outside their block's window and %llu searches without a surface computed on the host\n", (unsigned long long)h,
             (unsigned long long)attached, (unsigned long long)rows, (unsigned long long)launches, kernelNs * 1e-6, (unsigned long long)m, (unsigned long long)un);
+    const int places = x265hip_places_configured();
+    if (places)
+    {
+        uint64_t replicas = 0, bands = 0, bytes = 0;
+        x265hip_peer_stats(&replicas, &bands, &bytes);
+        fprintf(stderr, "x265hip: places: %d (X265HIP_DEVICES=%s); %llu replicas of reference pictures at other places, %llu bands of reconstructed rows (%.1f MB) "
+                        "pushed device to device\n", places, getenv("X265HIP_DEVICES"), (unsigned long long)replicas, (unsigned long long)bands, bytes * 1e-6);
+    }
 }
 
 bool decide()
@@ -146,7 +169,7 @@ bool decide()
         const char* exp = getenv("X265HIP_DEBUG_SADEXP");
         g_exp = exp ? atoi(exp) : 0;
         g_time = getenv("X265HIP_DEBUG_SADTIME") ? atoi(getenv("X265HIP_DEBUG_SADTIME")) : 0;
-        if (getenv("X265HIP_SADPLANES_LEVELS")) g_levels = atoi(getenv("X265HIP_SADPLANES_LEVELS")) & 14;
+        if (getenv("X265HIP_SADPLANES_LEVELS")) g_levels = atoi(getenv("X265HIP_SADPLANES_LEVELS")) & 15;
         if (getenv("X265HIP_SADPLANES_RANGE")) g_range = atoi(getenv("X265HIP_SADPLANES_RANGE"));
         if (g_range < 8) g_range = 8;
         if (g_range > 32) g_range = 32;
@@ -206,7 +229,7 @@ const Pair* pair_of(const PicYuv* srcPic, uint32_t version, const PicYuv* recon,
         x265hip_srcpic* sp = x265hip_srcplanes_device(srcPic, version);
         if (!sp)
             return NULL;                     // the source picture's upload has not finished: the next search asks again
-        x265hip_sadsurf* ss = x265hip_sadsurf_attach(sp, rp, g_range, lambda20);
+        x265hip_sadsurf* ss = x265hip_sadsurf_attach_levels(sp, rp, g_range, lambda20, g_levels | 14);
         if (!ss)
         {
             fprintf(stderr, "x265hip: sadplanes: %s\n", x265hip_last_error());
@@ -363,6 +386,12 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
         const size_t k = (size_t)(by - (cr << (3 - level))) * lv->blocksX + (u->x >> sh);
         const int16_t* org = (const int16_t*)((const char*)lv->origin + (size_t)cr * pr->view->ctuRowPitch) + 2 * k;
         const int ox = org[0], oy = org[1];
+        if (ox == -32768)
+        {
+            // an 8x8 block without a window (its 16x16 parent does not lie inside the picture)
+            g_count[shard()].unserved.fetch_add(1, std::memory_order_relaxed);
+            return refMotionEstimate(this, ref, mvmin, mvmax, qmvp, numCandidates, mvc, merange, outQMv, maxSlices, srcReferencePlane);
+        }
         entryBytes = lv->entryBytes;
         c.tab = (const char*)lv->table + (size_t)cr * pr->view->ctuRowPitch + k * WIN * WIN * entryBytes;
         c.stride = ref->lumaStride;
@@ -396,6 +425,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
     c.fenc = NULL;
     // counters: per thread, flushed to the shared ones now and then (an atomic per search would be felt)
     t_hit += c.hit; t_miss += c.miss;
+    (void)&t_flushAtExit;            // constructed on this thread's first search, destroyed (and flushed) when the thread ends
     if (((++t_searches) & 255) == 0)
     {
         Counter& k = g_count[shard()];

@@ -182,7 +182,10 @@ void build(SrcPic* sp, uint32_t v)
         if (!sp->dev)
         {
             x265hip_debug_mark("create: device copy of a source picture");
-            sp->dev = x265hip_srcpic_create(X265_DEPTH, pic.m_picWidth, pic.m_picHeight);
+            static std::atomic<int> nextPlace(0);
+            const int places = x265hip_places_configured();
+            sp->dev = places ? x265hip_srcpic_create_at(nextPlace.fetch_add(1) % places, X265_DEPTH, pic.m_picWidth, pic.m_picHeight)
+                             : x265hip_srcpic_create(X265_DEPTH, pic.m_picWidth, pic.m_picHeight);
             x265hip_debug_mark("created: device copy of a source picture");
             sp->devW = pic.m_picWidth; sp->devH = pic.m_picHeight;
         }
