@@ -32,6 +32,7 @@
 #include "primitives.h"
 #include "slice.h"
 #include "framefilter.h"
+#include "reference.h"
 #undef protected
 #undef private
 
@@ -43,6 +44,11 @@ namespace X265_NS {
 const EncoderPrimitives& x265hip_c_table();          // x265_hip_primitives.cpp
 
 extern void refProcessPostRow(FrameFilter* self, int row) asm("_ZN4x26514FrameFilterRef14processPostRowEi");
+// the reference's MotionReference (reference.cpp compiled a second time as MotionReferenceRef): the weighted copies of reference pictures
+extern int refMrInit(MotionReference* self, PicYuv* recPic, WeightParam* wp, const x265_param& p) asm("_ZN4x26518MotionReferenceRef4initEPNS_6PicYuvEPNS_11WeightParamERK10x265_param");
+extern void refMrApplyWeight(MotionReference* self, uint32_t finishedRows, uint32_t maxNumRows, uint32_t maxNumRowsInSlice, uint32_t sliceId)
+    asm("_ZN4x26518MotionReferenceRef11applyWeightEjjjj");
+extern void refMrDestruct(MotionReference* self) asm("_ZN4x26518MotionReferenceRefD2Ev");
 static_assert(sizeof("" "x265") == 5, "");
 
 namespace {
@@ -67,6 +73,10 @@ struct Mirror
 
 const int kMaxMirrors = 64;
 Mirror g_mirror[kMaxMirrors];
+// [lo, hi) of every entry once more, side by side: what a filter call scans to find its picture (the entries themselves are several cache lines each)
+struct Range { const pixel* lo; const pixel* hi; };
+Range g_range[kMaxMirrors];
+uint64_t g_weightedMirrors = 0;  // under g_createLock
 std::atomic<int> g_count(0);
 std::mutex g_createLock;
 int g_state = 0;                 // 0 undecided, 1 on, -1 off
@@ -90,6 +100,9 @@ void report()
     fprintf(stderr, "x265hip: refplanes: %llu luma sub-pel filter calls served from GPU-built planes of %d mirrored pictures, %llu on mirrored pictures before "
                     "their rows arrived and %llu on other memory computed on the host\n", (unsigned long long)s, g_count.load(), (unsigned long long)m,
             (unsigned long long)f);
+    if (g_weightedMirrors)
+        fprintf(stderr, "x265hip: refplanes: %llu of the mirrored pictures are weighted copies of reference pictures (MotionReference::applyWeight)\n",
+                (unsigned long long)g_weightedMirrors);
 }
 
 bool enabled()
@@ -121,16 +134,17 @@ inline const Mirror* find(const pixel* p)
     const int n = g_count.load(std::memory_order_acquire);
     for (int i = 0; i < n; i++)
     {
-        const pixel* lo = __atomic_load_n(&g_mirror[i].lo, __ATOMIC_ACQUIRE);     // NULL: a retired entry (or one being set up: lo is stored last)
-        if (lo && p >= lo && p < g_mirror[i].hi)
+        const pixel* lo = __atomic_load_n(&g_range[i].lo, __ATOMIC_ACQUIRE);      // NULL: a retired entry (or one being set up: lo is stored last)
+        if (lo && p >= lo && p < g_range[i].hi)
             return &g_mirror[i];
     }
     return NULL;
 }
 
-Mirror* mirror_of(PicYuv* pic)
+// the mirror of the padded luma picture that starts at `lo` (a PicYuv's buffer, or a MotionReference's weighted copy of one: same geometry), created
+// on first use; `create` false: only an existing one
+Mirror* mirror_at(const pixel* lo, const PicYuv* pic, bool weighted, bool create = true)
 {
-    const pixel* lo = pic->m_picBuf[0];
     const int n = g_count.load(std::memory_order_acquire);
     for (int i = 0; i < n; i++)
         if (g_mirror[i].lo == lo)
@@ -140,6 +154,8 @@ Mirror* mirror_of(PicYuv* pic)
     for (int i = n; i < n2; i++)
         if (g_mirror[i].lo == lo)
             return &g_mirror[i];
+    if (!create)
+        return NULL;
     int slot = n2;
     for (int i = 0; i < n2; i++)
         if (!g_mirror[i].lo && !g_mirror[i].rp)
@@ -163,6 +179,8 @@ Mirror* mirror_of(PicYuv* pic)
         abort();                                   // the product path fails loudly
     }
     m.hi = lo + (size_t)pic->m_stride * bufRows;
+    g_range[slot].hi = m.hi;
+    g_weightedMirrors += weighted;
     m.stride = pic->m_stride;
     m.picW = pic->m_picWidth; m.picH = pic->m_picHeight; m.marginX = pic->m_lumaMarginX; m.marginY = pic->m_lumaMarginY;
     m.plane[0] = NULL;
@@ -173,11 +191,14 @@ Mirror* mirror_of(PicYuv* pic)
     m.tracking = false;
     m.prefix = 0;
     memset(m.rowDone, 0, sizeof(m.rowDone));
-    __atomic_store_n(&m.lo, lo, __ATOMIC_RELEASE);         // last: find() matches an entry by [lo, hi)
+    m.lo = lo;
+    __atomic_store_n(&g_range[slot].lo, lo, __ATOMIC_RELEASE);       // last: find() matches an entry by [lo, hi)
     if (slot == n2)
         g_count.store(n2 + 1, std::memory_order_release);
     return &m;
 }
+
+Mirror* mirror_of(PicYuv* pic) { return mirror_at(pic->m_picBuf[0], pic, false); }
 
 // W x H block of phase plane `phase` at `src`, if `src` lies in a mirrored picture whose rows have arrived
 template <int W, int H>
@@ -278,7 +299,9 @@ void x265hip_refplanes_retire(const pixel* lo)
         {
             Mirror& m = g_mirror[i];
             std::lock_guard<std::mutex> g2(m.lock);
-            __atomic_store_n(&m.lo, (const pixel*)NULL, __ATOMIC_RELEASE);
+            __atomic_store_n(&g_range[i].lo, (const pixel*)NULL, __ATOMIC_RELEASE);
+            g_range[i].hi = NULL;
+            m.lo = NULL;
             m.hi = NULL;
             m.rowsReady = NULL;
             m.tracking = false;
@@ -368,6 +391,68 @@ void FrameFilter::processPostRow(int row)
             }
         }
     }
+}
+
+// ---- weighted reference pictures -------------------------------------------------------------------------------------------------------------
+// With weighted prediction the motion search of a frame measures its candidates against a WEIGHTED copy of the reference picture
+// (MotionReference::init points fpelPlane[0] at weightBuffer[0], reference.cpp:86-103; applyWeight fills it row by row as the reference picture's
+// rows become available, :119-186), so the sub-pel filter calls of subpelCompare read that copy — memory no recon mirror covers.  The copy is a
+// padded picture of the same geometry whose rows become final in order: it gets a mirror of its own, reset whenever the MotionReference is
+// initialised for another frame, fed after every applyWeight; the lookup slots then serve it like any other picture.  One slice per picture only
+// (with several, rows are weighted per slice).
+int MotionReference::init(PicYuv* recPic, WeightParam* wp, const x265_param& p)
+{
+    const int r = refMrInit(this, recPic, wp, p);
+    if (r || !enabled() || !weightBuffer[0])
+        return r;
+    const bool lumaWeighted = isWeighted && fpelPlane[0] != recPic->m_picOrg[0] && p.maxSlices == 1;
+    Mirror* m = mirror_at(weightBuffer[0], recPic, true, lumaWeighted);
+    if (m)
+    {
+        std::lock_guard<std::mutex> g(m->lock);
+        if (x265hip_refpic_reset(m->rp))
+        {
+            fprintf(stderr, "x265hip: refplanes: %s\n", x265hip_last_error());
+            abort();
+        }
+        m->generation.fetch_add(1, std::memory_order_release);
+        m->poc = -2;
+        m->tracking = lumaWeighted;
+        m->prefix = 0;
+    }
+    return r;
+}
+
+void MotionReference::applyWeight(uint32_t finishedRows, uint32_t maxNumRows, uint32_t maxNumRowsInSlice, uint32_t sliceId)
+{
+    refMrApplyWeight(this, finishedRows, maxNumRows, maxNumRowsInSlice, sliceId);
+    if (g_state <= 0 || !isWeighted || sliceId || !weightBuffer[0] || fpelPlane[0] == reconPic->m_picOrg[0])
+        return;
+    Mirror* m = mirror_at(weightBuffer[0], reconPic, true, false);
+    if (!m)
+        return;
+    std::lock_guard<std::mutex> g(m->lock);
+    if (!m->tracking)
+        return;
+    // CTU rows [0, numSliceWeightedRows) are weighted; the call that reaches the last but one row does the last one with it, and the bottom margin
+    const int done = (int)numSliceWeightedRows[0];
+    const int rows = done >= (int)maxNumRows - 1 ? m->picH : done * (int)reconPic->m_param->maxCUSize;
+    if (rows > m->prefix)
+    {
+        m->prefix = rows;
+        if (x265hip_refpic_rows_final(m->rp, rows))
+        {
+            fprintf(stderr, "x265hip: refplanes: %s\n", x265hip_last_error());
+            abort();
+        }
+    }
+}
+
+MotionReference::~MotionReference()
+{
+    if (weightBuffer[0])
+        x265hip_refplanes_retire(weightBuffer[0]);          // before the reference's body frees the buffer
+    refMrDestruct(this);
 }
 
 } // namespace X265_NS
