@@ -722,7 +722,8 @@ def main():
                                                   "16 + 4 + 1 exhaustive block searches over 64 x 64 vectors, SURVEY 8d unique-footprint bytes per block search (508 437 B per "
                                                   "complete CTU); VALU-bound on v_qsad_pk_u16_u8, see valu_sad" % (n, served["ctu_rows"], ctus / n, served["surfaces"]),
                         "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
-                        "traffic": ss_traffic, "traffic_source": ss_tfile, "traffic_note": ss_tnote,
+                        "traffic": int(ss_traffic * (ctus / n) / 510.0) if ss_traffic else None, "traffic_source": ss_tfile,
+                        "traffic_note": (ss_tnote + "; the profile's launches build 510 CTUs each: scaled to this run's CTUs per launch") if ss_traffic else ss_tnote,
                         "algorithmic_bytes_per_launch": int(ss["algorithmic_bytes"] / n), "launch_ms": round(ss["ms"] / n, 5),
                         "launch_ms_note": "HIP events around every launch on the stream it runs on, inside libx265hip.so, summed over the timed encode (x265hip_device_time)",
                         "compulsory": {"bytes_per_launch": int(comp / n), "achieved": round(comp / secs / 1e9, 2),
@@ -758,7 +759,9 @@ def main():
                                                  "x %.0f B each (%.1f reference slot calls per block, SURVEY 8d per-call bytes); a latency-bound dependent chain, see DESIGN.md §5"
                                                  % (served["search_launches"], served["pairs_per_launch"], LA_BLOCKS, LA_BYTES_PER_BLOCK, LA_CALLS_PER_BLOCK),
                        "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
-                       "traffic": None, "algorithmic_bytes_per_launch": int(served["pairs_per_launch"] * LA_BLOCKS * LA_BYTES_PER_BLOCK),
+                       "traffic": int(la_traffic * served["pairs_per_launch"] / 35.0) if la_traffic else None, "traffic_source": la_tfile,
+                       "traffic_note": (la_tnote + "; the profile's launches hold 35 pairs each: scaled to this run's pairs per launch") if la_traffic else la_tnote,
+                       "algorithmic_bytes_per_launch": int(served["pairs_per_launch"] * LA_BLOCKS * LA_BYTES_PER_BLOCK),
                        "launch_ms": round(la["ms"] / served["search_launches"], 4), "launch_ms_note": "HIP events around each launch, summed over the timed encode"}
         probe_pairs = int(min(64, max(1, round(served.get("pairs_per_launch", 8)))))
         la_ms, la_blocks = lookahead_kernel_probe(L, hp, np, pairs=probe_pairs)
@@ -769,7 +772,7 @@ def main():
         la_probe = {"bound": "hbm", "kernel": "lookahead_p_kernel<u8> probe: %d identical (frame, reference) pairs per launch (the encode's average launch size), %d blocks x %.0f B"
                                               % (la_blocks // LA_BLOCKS, la_blocks, LA_BYTES_PER_BLOCK),
                     "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
-                    "traffic": la_traffic if probe_pairs == 8 else None, "traffic_source": la_tfile, "traffic_note": la_tnote,
+                    "traffic": la_traffic if probe_pairs == 35 else None, "traffic_source": la_tfile, "traffic_note": la_tnote,
                     "algorithmic_bytes_per_launch": int(la_bytes), "launch_ms": round(la_ms, 4),
                     "launch_ms_note": "HIP events on the kernel's own stream, measured in this run",
                     "unique_footprint": {"bytes_per_launch": uniq, "achieved": round(uniq / (la_ms * 1e-3) / 1e9, 2),

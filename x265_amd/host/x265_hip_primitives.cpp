@@ -25,7 +25,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <unistd.h>
 
 namespace X265_NS {
@@ -586,7 +588,8 @@ static void report_device_time()
         n += snprintf(line + n, sizeof(line) - n, "%s%s %.3f ms in %llu launch groups (%llu algorithmic bytes)", c ? ", " : "", names[c], ns * 1e-6,
                       (unsigned long long)spans, (unsigned long long)bytes);
     }
-    fprintf(stderr, "x265hip: device time (HIP events around every launch group): %s; total %.3f ms\n", line, total * 1e-6);
+    if (total)
+        fprintf(stderr, "x265hip: device time (HIP events around every launch group): %s; total %.3f ms\n", line, total * 1e-6);
     x265hip_debug_mark("last exit handler of the bindings");
 }
 
@@ -606,20 +609,39 @@ void setupAssemblyPrimitives(EncoderPrimitives& p, int /* cpuMask: CPU ISA bits,
     setupAliasPrimitives(p);
     // No device: never silent.  The bindings switch themselves off and the reference's own host code runs (an encoder must still encode), but it says
     // so; X265HIP=require turns that into an error (bench.py and the GPU tests run with it: a number measured on a silent fallback is worthless).
-    static bool probed = false;
-    if (!probed)
+    // The probe runs beside the rest of x265_encoder_open (thread pools, frame encoders, lookahead: ~0.1 s at 1080p) instead of in front of it: the
+    // first HIP call of a process initialises the runtime and the device (50-160 ms on the MI355X box), and nothing needs the answer before the
+    // first picture arrives — the seams ask x265hip_device_count() themselves, which waits for the same initialisation if it is still running.
+    static std::once_flag probeOnce;
+    const bool require = env && !strcmp(env, "require");
+    const bool percall = getenv("X265HIP_TABLE") && !strcmp(getenv("X265HIP_TABLE"), "percall");
+    static std::atomic<bool> probeDone(false);
+    auto probe = [require]
     {
-        probed = true;
+        struct Done { ~Done() { probeDone = true; } } done;
         const int devices = x265hip_device_count();
         x265hip_debug_mark("device count known (HIP runtime initialised)");
         if (devices < 1)
         {
             fprintf(stderr, "x265hip: no HIP device visible: GPU bindings are OFF, the encoder runs the reference's host code only%s\n",
-                    env && !strcmp(env, "require") ? "" : " (X265HIP=0 silences this, X265HIP=require makes it fatal)");
-            if (env && !strcmp(env, "require"))
+                    require ? "" : " (X265HIP=0 silences this, X265HIP=require makes it fatal)");
+            if (require)
                 abort();
+            return;
         }
-    }
+        // the device's context and its first stream are the other slow first-time steps: take them here as well
+        void* st = NULL;
+        if (!x265hip_init(0) && !x265hip_stream_create(&st))
+            x265hip_stream_destroy(st);
+        x265hip_debug_mark("device context warm");
+    };
+    std::call_once(probeOnce, [&]
+    {
+        if (percall) { probe(); return; }
+        std::thread(probe).detach();
+        // a process that ends while the runtime is still initialising must not run the runtime's exit handlers underneath it
+        atexit([] { while (!probeDone) usleep(1000); });
+    });
     // X265HIP_TABLE selects what the table holds:
     //   percall   every slot below becomes its per-call shim (one slot call = one 1-job launch + sync): the bit-exactness proof of each
     //             kernel under the reference's own TestBench and encoder, ~1000x slower than the C code
@@ -630,7 +652,7 @@ void setupAssemblyPrimitives(EncoderPrimitives& p, int /* cpuMask: CPU ISA bits,
     if (!mode || strcmp(mode, "percall"))
     {
         static bool timeReport = false;
-        if (!timeReport && getenv("X265HIP_VERBOSE") && x265hip_device_count() > 0)
+        if (!timeReport && getenv("X265HIP_VERBOSE"))
         {
             timeReport = true;
             atexit(report_device_time);

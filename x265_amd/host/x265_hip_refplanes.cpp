@@ -58,6 +58,7 @@ struct Mirror
     const pixel* lo;            // PicYuv::m_picBuf[0]
     const pixel* hi;            // one past the buffer
     intptr_t stride;
+    uint64_t recip;             // 2^40 / stride + 1
     int picW, picH, marginX, marginY;
     const pixel* plane[16];     // host planes, same layout as the buffer ([0] unused)
     const int* rowsReady;       // published by the worker (acquire)
@@ -92,6 +93,19 @@ inline int shard()
     if (t_shard < 0) t_shard = g_nextShard.fetch_add(1) & 63;
     return t_shard;
 }
+// the slots count in plain thread-local integers (an atomic add per filter call is felt at 20 million calls); a thread's share goes to the shared
+// counters when the thread ends — the pool's workers end with their encoder, before the exit handlers print
+struct ThreadCounts
+{
+    uint64_t served = 0, missed = 0, foreign = 0;
+    ~ThreadCounts()
+    {
+        g_served[shard()].v.fetch_add(served, std::memory_order_relaxed);
+        g_missed[shard()].v.fetch_add(missed, std::memory_order_relaxed);
+        g_foreign[shard()].v.fetch_add(foreign, std::memory_order_relaxed);
+    }
+};
+thread_local ThreadCounts t_counts;
 
 void report()
 {
@@ -103,6 +117,14 @@ void report()
     if (g_weightedMirrors)
         fprintf(stderr, "x265hip: refplanes: %llu of the mirrored pictures are weighted copies of reference pictures (MotionReference::applyWeight)\n",
                 (unsigned long long)g_weightedMirrors);
+}
+
+bool switched_on()
+{
+    const char* env = getenv("X265HIP_REFPLANES");
+    const char* all = getenv("X265HIP");
+    const char* table = getenv("X265HIP_TABLE");
+    return !((env && !strcmp(env, "0")) || (all && !strcmp(all, "0")) || (table && !strcmp(table, "percall")));
 }
 
 bool enabled()
@@ -182,6 +204,7 @@ Mirror* mirror_at(const pixel* lo, const PicYuv* pic, bool weighted, bool create
     g_range[slot].hi = m.hi;
     g_weightedMirrors += weighted;
     m.stride = pic->m_stride;
+    m.recip = ((uint64_t)1 << 40) / (uint64_t)pic->m_stride + 1;
     m.picW = pic->m_picWidth; m.picH = pic->m_picHeight; m.marginX = pic->m_lumaMarginX; m.marginY = pic->m_lumaMarginY;
     m.plane[0] = NULL;
     for (int p = 1; p < 16; p++)
@@ -207,22 +230,24 @@ inline bool serve(const pixel* src, intptr_t srcStride, pixel* dst, intptr_t dst
     const Mirror* m = find(src);
     if (!m)
     {
-        g_foreign[shard()].v.fetch_add(1, std::memory_order_relaxed);
+        t_counts.foreign++;
         return false;
     }
     const ptrdiff_t off = src - m->lo;
-    const int by = (int)(off / m->stride), bx = (int)(off - (ptrdiff_t)by * m->stride);
+    // off / stride without a division: off < 2^26, stride < 2^14, recip = 2^40 / stride + 1 — the estimate's error is below 2^-14 of a row, less than
+    // the distance of any off / stride from the next integer (1 / stride)
+    const int by = (int)(((uint64_t)off * m->recip) >> 40), bx = (int)(off - (ptrdiff_t)by * m->stride);
     const int y = by - m->marginY, x = bx - m->marginX;
     if (srcStride != m->stride || x < -(m->marginX - 4) || x + W > m->picW + m->marginX - 4 || y < -(m->marginY - 4) ||
         y + H > __atomic_load_n(m->rowsReady, __ATOMIC_ACQUIRE))
     {
-        g_missed[shard()].v.fetch_add(1, std::memory_order_relaxed);
+        t_counts.missed++;
         return false;
     }
     const pixel* p = m->plane[phase] + off;
     for (int r = 0; r < H; r++)
         memcpy(dst + r * dstStride, p + r * m->stride, W * sizeof(pixel));
-    g_served[shard()].v.fetch_add(1, std::memory_order_relaxed);
+    t_counts.served++;
     return true;
 }
 
@@ -316,7 +341,9 @@ void x265hip_refplanes_retire(const pixel* lo)
 // called by setupAssemblyPrimitives (x265_hip_primitives.cpp) in the default table mode
 void x265hip_install_lookup_slots(EncoderPrimitives& p)
 {
-    if (!enabled())
+    // decided by the switches alone: whether a device exists is known a moment later (setupAssemblyPrimitives probes beside the encoder's own set-up),
+    // and without one the wrappers find nothing to serve and call the C functions
+    if (!switched_on())
         return;
     // What the slots did before: the reference's C functions, from a table built for the purpose (x265hip_c_table, x265_hip_primitives.cpp), once.
     // Not a copy of `p`: x265_setup_primitives is not serialised between encoders opened at the same time (primitives.cpp:

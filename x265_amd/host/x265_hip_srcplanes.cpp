@@ -89,6 +89,14 @@ void report()
             (unsigned long long)h, g_npics.load(), (unsigned long long)m);
 }
 
+bool switched_on()
+{
+    const char* env = getenv("X265HIP_SRCPLANES");
+    const char* all = getenv("X265HIP");
+    const char* table = getenv("X265HIP_TABLE");
+    return !((env && !strcmp(env, "0")) || (all && !strcmp(all, "0")) || (table && !strcmp(table, "percall")));
+}
+
 bool enabled()
 {
     if (!g_state)
@@ -365,7 +373,9 @@ bool x265hip_srcplanes_current(const PicYuv* pic, uint32_t version)
 // called by setupAssemblyPrimitives in the default table mode, after the C table is complete
 void x265hip_install_psy_slots(EncoderPrimitives& p)
 {
-    if (!enabled())
+    // decided by the switches alone: whether a device exists is known a moment later (setupAssemblyPrimitives probes beside the encoder's own set-up),
+    // and without one the wrappers find nothing to serve and call the C functions
+    if (!switched_on())
         return;
     // What the slots did before: the reference's C functions, from a table built for the purpose (x265hip_c_table, x265_hip_primitives.cpp), once.
     // Not a copy of `p`: x265_setup_primitives is not serialised between encoders opened at the same time (primitives.cpp:
