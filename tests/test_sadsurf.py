@@ -32,14 +32,14 @@ def _emul(hp):
     return em
 
 
-def _pictures(w, h, seed, count=2):
+def _pictures(w, h, seed, count=2, MX=MX, MY=MY, ctu=64):
     """A padded reference picture (as the encoder's recon buffer: margins replicated) and `count` source pictures = the reference moved per
     48 x 40 tile by up to +-20 pixels plus noise."""
     rng = np.random.default_rng(seed)
     from cases import textured_frame
     big = textured_frame(rng, h + 128, w + 128, 8, sigma=2.0)
     ref = big[64:64 + h, 64:64 + w]
-    rows = ((h + 63) // 64) * 64 + 2 * MY
+    rows = ((h + ctu - 1) // ctu) * ctu + 2 * MY          # picyuv.cpp:95-98
     stride = ((w + 2 * MX + 63) // 64) * 64
     buf = np.zeros((rows, stride), np.uint8)
     buf[:h + 2 * MY, :w + 2 * MX] = np.pad(ref, ((MY, MY), (MX, MX)), mode="edge")
@@ -80,9 +80,9 @@ def _read_view(hp, L, ss, w, h):
     return out
 
 
-def _run(hp, L, w, h, seed, S, lam, bands, attach_after, levels=15):
+def _run(hp, L, w, h, seed, S, lam, bands, attach_after, levels=15, MX=MX, MY=MY, ctu=64):
     """Drive one library: reference rows arrive in `bands` (picture rows); source k is attached after band attach_after[k] (-1: before any)."""
-    buf, stride, rows, srcs = _pictures(w, h, seed, count=len(attach_after))
+    buf, stride, rows, srcs = _pictures(w, h, seed, count=len(attach_after), MX=MX, MY=MY, ctu=ctu)
     rp = L.x265hip_refpic_create(8, w, h, stride, MX, MY, rows, buf.ctypes.data)
     assert rp, L.x265hip_last_error()
     sps, sss = [], [None] * len(srcs)
@@ -152,6 +152,10 @@ GPU_CASES = [
     (352, 288, 13, 16, 400, [64, 128, 192, 256, 288], [0, 2, 4]),
     (72, 200, 14, 32, 180, [128, 200], [-1]),
     (1280, 720, 15, 32, 180, [192, 448, 720], [1]),
+    # --ctu 16: PicYuv pads 48 x 32 only and its buffer ends 32 rows below the picture — the search window reaches beyond both (fuzz seed 59: a GPU
+    # memory fault before the staging loads were clamped into the buffer)
+    (200, 136, 16, 32, 180, [48, 96, 136], [-1, 1], 48, 32, 16),
+    (72, 40, 17, 24, 180, [16, 40], [-1], 48, 32, 16),
 ]
 
 
@@ -162,10 +166,11 @@ def test_device_surfaces_match_restatement(case):
     L = hp.lib()
     hp.check(L.x265hip_init(0))
     em = _emul(hp)
-    w, h, seed, S, lam, bands, attach_after = GPU_CASES[case]
+    w, h, seed, S, lam, bands, attach_after, *geom = GPU_CASES[case]
+    geom = dict(zip(("MX", "MY", "ctu"), geom))
     levels = 14 if case == 1 else 15                 # one case without the 8x8 windows (the layout of the product's default)
-    got, *_ = _run(hp, L, w, h, seed, S, lam, bands, attach_after, levels)
-    want, *_ = _run(hp, em, w, h, seed, S, lam, bands, attach_after, levels)
+    got, *_ = _run(hp, L, w, h, seed, S, lam, bands, attach_after, levels, **geom)
+    want, *_ = _run(hp, em, w, h, seed, S, lam, bands, attach_after, levels, **geom)
     for k in range(len(attach_after)):
         assert sorted(got[k]) == sorted(want[k]) == ([1, 2, 3] if levels == 14 else [0, 1, 2, 3])
         for l in got[k]:

@@ -62,6 +62,7 @@ struct SurfArgs
 {
     const uint8_t* ref; int64_t refStride;       // reference pixel (0, 0)
     int picW, picH, marginX, marginY;
+    int bufRows;                                  // rows of the padded picture in device memory (marginY above picture row 0)
     int64_t pitch;
     int64_t originOff[4], tableOff[4];
     int blocksX[4];
@@ -231,10 +232,14 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu_kernel(SurfArgs a)
     }
     {
         const int dw = RW / 4;
+        // the window may reach beyond the padded picture (small margins: CTU 16 pads 48 x 32; the last CTU row and column of any picture): those
+        // positions belong to illegal vectors only — whatever is staged for them is never looked at — but the loads must stay inside the buffer
+        const int yMax = a.bufRows - a.marginY - 1, xMax = a.picW + a.marginX - 4;
         for (int i = tid; i < (64 + D) * dw; i += 1024)
         {
             const int r = i / dw, c4 = (i - r * dw) * 4;
-            *(uint32_t*)(sRef + r * RW + c4) = ld_global_unaligned<uint32_t>(a.ref + (int64_t)(y0 - S + r) * a.refStride + (x0 - S + c4));
+            const int y = min(max(y0 - S + r, -a.marginY), yMax), x = min(max(x0 - S + c4, -a.marginX), xMax);
+            *(uint32_t*)(sRef + r * RW + c4) = ld_global_unaligned<uint32_t>(a.ref + (int64_t)y * a.refStride + x);
         }
     }
     if (tid < 32)
@@ -583,7 +588,7 @@ static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& li
             }
             const SurfLayout& lay = in[0]->lay;               // same picture size: same layout
             a.ref = (const uint8_t*)dPic + (size_t)rp->marginY * rp->stride + rp->marginX; a.refStride = rp->stride;
-            a.picW = rp->picW; a.picH = rp->picH; a.marginX = rp->marginX; a.marginY = rp->marginY;
+            a.picW = rp->picW; a.picH = rp->picH; a.marginX = rp->marginX; a.marginY = rp->marginY; a.bufRows = rp->bufRows;
             a.pitch = lay.pitch;
             for (int l = 0; l < 4; l++) { a.originOff[l] = lay.originOff[l]; a.tableOff[l] = lay.tableOff[l]; a.blocksX[l] = lay.blocksX[l]; }
             a.blocksY0 = lay.blocksY[0];

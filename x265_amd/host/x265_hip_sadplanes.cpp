@@ -76,6 +76,7 @@ int g_levels = 14;               // X265HIP_SADPLANES_LEVELS: bit l = blocks of 
 int g_time = 0;                  // X265HIP_DEBUG_SADTIME=1: cycles inside the reference's motionEstimate for the PUs a surface could serve, by block size;
                                  // =2: the same with the lookups switched off (the pair of runs measures what the lookups save)
 std::atomic<uint64_t> g_cycles[4], g_timed[4];
+bool g_verify = false;           // X265HIP_VERIFY=1: every looked-up SAD is recomputed with the C function and compared (debugging self-check)
 int g_range = 32;                // X265HIP_SADPLANES_RANGE: the exhaustive search that places the windows covers [-range, range)^2
 EncoderPrimitives g_c;
 std::mutex g_lock;
@@ -117,6 +118,7 @@ struct Ctx
     size_t span;                 // (WIN - 1) * stride + WIN: pointers at or beyond winBase + span are outside the window
     const void* tab;             // the block's WIN * WIN entries
     uint32_t hit, miss;
+    int x, y, w, ox, oy;         // for X265HIP_VERIFY's message
 };
 __attribute__((tls_model("initial-exec"))) thread_local Ctx t_ctx;
 __attribute__((tls_model("initial-exec"))) thread_local uint64_t t_hit = 0, t_miss = 0, t_searches = 0;
@@ -169,6 +171,7 @@ bool decide()
         const char* exp = getenv("X265HIP_DEBUG_SADEXP");
         g_exp = exp ? atoi(exp) : 0;
         g_time = getenv("X265HIP_DEBUG_SADTIME") ? atoi(getenv("X265HIP_DEBUG_SADTIME")) : 0;
+        g_verify = getenv("X265HIP_VERIFY") != NULL;
         if (getenv("X265HIP_SADPLANES_LEVELS")) g_levels = atoi(getenv("X265HIP_SADPLANES_LEVELS")) & 15;
         if (getenv("X265HIP_SADPLANES_RANGE")) g_range = atoi(getenv("X265HIP_SADPLANES_RANGE"));
         if (g_range < 8) g_range = 8;
@@ -255,13 +258,30 @@ inline int locate(const Ctx& c, const pixel* p)
     return dx < (unsigned)WIN ? (int)(dy * WIN + dx) : -1;
 }
 
+// X265HIP_VERIFY=1: the table entry against the C function
+template <int PART> void verify_entry(const Ctx& c, const pixel* fenc, const pixel* ref, intptr_t rs, int k, int got)
+{
+    const int want = g_c.pu[PART].sad(fenc, FENC_STRIDE, ref, rs);
+    if (want != got)
+    {
+        fprintf(stderr, "x265hip: sadplanes: VERIFY FAILED block %dx%d at (%d, %d), window origin (%d, %d), entry (%d, %d): table %d, sad() %d\n", c.w, c.w, c.x, c.y, c.ox, c.oy,
+                k % WIN, k / WIN, got, want);
+        abort();
+    }
+}
+
 template <int PART, typename E> int sad_lookup(const pixel* fenc, intptr_t fs, const pixel* ref, intptr_t rs)
 {
     Ctx& c = t_ctx;
     if (fenc == c.fenc && rs == c.stride)
     {
         const int k = locate(c, ref);
-        if (k >= 0) { c.hit++; return (int)((const E*)c.tab)[k]; }
+        if (k >= 0)
+        {
+            c.hit++;
+            if (g_verify) verify_entry<PART>(c, fenc, ref, rs, k, (int)((const E*)c.tab)[k]);
+            return (int)((const E*)c.tab)[k];
+        }
         c.miss++;
     }
     return g_c.pu[PART].sad(fenc, fs, ref, rs);
@@ -279,6 +299,12 @@ template <int PART, typename E> void sad_x3_lookup(const pixel* fenc, const pixe
     res[2] = k2 >= 0 ? (int32_t)t[k2] : g_c.pu[PART].sad(fenc, FENC_STRIDE, r2, rs);
     const int h = (k0 >= 0) + (k1 >= 0) + (k2 >= 0);
     c.hit += h; c.miss += 3 - h;
+    if (g_verify)
+    {
+        if (k0 >= 0) verify_entry<PART>(c, fenc, r0, rs, k0, res[0]);
+        if (k1 >= 0) verify_entry<PART>(c, fenc, r1, rs, k1, res[1]);
+        if (k2 >= 0) verify_entry<PART>(c, fenc, r2, rs, k2, res[2]);
+    }
 }
 template <int PART, typename E> void sad_x4_lookup(const pixel* fenc, const pixel* r0, const pixel* r1, const pixel* r2, const pixel* r3, intptr_t rs, int32_t* res)
 {
@@ -293,6 +319,13 @@ template <int PART, typename E> void sad_x4_lookup(const pixel* fenc, const pixe
     res[3] = k3 >= 0 ? (int32_t)t[k3] : g_c.pu[PART].sad(fenc, FENC_STRIDE, r3, rs);
     const int h = (k0 >= 0) + (k1 >= 0) + (k2 >= 0) + (k3 >= 0);
     c.hit += h; c.miss += 4 - h;
+    if (g_verify)
+    {
+        if (k0 >= 0) verify_entry<PART>(c, fenc, r0, rs, k0, res[0]);
+        if (k1 >= 0) verify_entry<PART>(c, fenc, r1, rs, k1, res[1]);
+        if (k2 >= 0) verify_entry<PART>(c, fenc, r2, rs, k2, res[2]);
+        if (k3 >= 0) verify_entry<PART>(c, fenc, r3, rs, k3, res[3]);
+    }
 }
 
 // X265HIP_DEBUG_SADEXP=2: the measurement that preceded this file — every call a lookup could serve is computed twice
@@ -397,6 +430,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
         c.stride = ref->lumaStride;
         c.winBase = ref->fpelPlane[0] + off + (intptr_t)oy * c.stride + ox;
         c.span = (size_t)(WIN - 1) * c.stride + WIN;
+        c.x = u->x; c.y = u->y; c.w = u->w; c.ox = ox; c.oy = oy;
         // the block's entries were written by the device a moment ago: bring them in while the search sets itself up
         for (int i = 0; i < WIN * WIN * entryBytes; i += 64)
             __builtin_prefetch((const char*)c.tab + i);
