@@ -584,7 +584,10 @@ int x265hip_lookahead_bidir_batch(int depth, const x265hip_lookahead_bframe* fra
  * and per (list, distance) the vectors and costs of every motion search done so far.  One estimate = slot indices + which lists to
  * search; a batch = one launch of every list search, one of every P bookkeeping pass, one of every B pass, one copy back.
  * x265_amd/host/x265_hip_lookahead.cpp is the x265-side binding.  All pointers are HOST pointers;
- * calls block until their results are in host memory; a session serialises its callers. */
+ * calls block until their results are in host memory; a session serialises its callers.  The weighted plane sets are a two-call protocol:
+ * x265hip_la_weights_analyse hands out a weightedId that stays reserved until the NEXT x265hip_la_estimate_batch* call of the session returns
+ * (whatever it returns) — so the thread that analysed must be the one that sends the batch, with no other batch of the session in between: use one
+ * thread per session (the x265 binding holds its lock across both calls).  After a batch the session keeps at most 8 plane sets for reuse. */
 typedef struct x265hip_la x265hip_la;
 typedef struct x265hip_la_config
 {

@@ -283,7 +283,16 @@ int x265hip_la_estimate_batch_ahead(x265hip_la* la, x265hip_la_estimate* est, in
         (long long)numRowsPerSlice * (numSlices - 1) >= la->cfg.heightInCU)
         return set_error(X265HIP_EINVAL, "x265hip_la_estimate_batch: n %d ahead %d slices %d x %d", n, nAhead, numSlices, numRowsPerSlice);
     std::lock_guard<std::mutex> g(la->lock);
-    struct Release { x265hip_la* l; ~Release() { l->wbufsUsed = 0; } } release{ la };
+    // the weighted plane sets of this batch go back to the pool when the call ends; a big batch on a fade must not pin its peak for the session's life
+    struct Release
+    {
+        x265hip_la* l;
+        ~Release()
+        {
+            l->wbufsUsed = 0;
+            while (l->wbufs.size() > 8) { (void)hipFree(l->wbufs.back()); l->wbufs.pop_back(); }
+        }
+    } release{ la };
     if (!n && !nAhead) return X265HIP_OK;
     if ((e = la_grow(la, n + nAhead))) return e;
     const x265hip_la_config& c = la->cfg;
