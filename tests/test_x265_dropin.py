@@ -149,3 +149,24 @@ def test_baseline_configs_encode_byte_identical_through_the_seams(name):
     assert served and int(served[0].split()[2]) >= 3, r
     planes = [l for l in r["gpu"]["served"] if "refplanes:" in l]
     assert planes and int(planes[0].split()[2]) > 1000, r
+
+
+def test_8k_encode_with_two_places_is_byte_identical(monkeypatch):
+    """BASELINE.json configs[4] names the multi-GPU form: 7680x4320 preset medium, frame-parallel, reconstructed reference pictures exchanged between
+    the GPUs.  Inside one encoder that is X265HIP_DEVICES: mirrors and source pictures take the places in turn, SAD surfaces are built
+    from replicas fed device to device.  Here with two places on the one GPU of the box — every line of the path except the xGMI hop itself — against
+    the unmodified encoder: same bytes, and the exchange happened."""
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import encode_fps
+    monkeypatch.setenv("X265HIP_DEVICES", "0,0")
+    r = encode_fps.measure(frames=5, width=7680, height=4320, bits=8, preset="medium", extra=(), seed=33)
+    if "error" in r and "not built" in r["error"]:
+        pytest.skip(r["error"])
+    assert "error" not in r, r
+    assert r["byte_identical"], r
+    ex = [l for l in r["gpu"]["served"] if "x265hip: places:" in l]
+    m = ex and re.search(r"(\d+) replicas of reference pictures at other places, (\d+) bands of reconstructed rows \(([\d.]+) MB\)", ex[0])
+    assert m and int(m.group(1)) > 0 and int(m.group(2)) > 0 and float(m.group(3)) > 10.0, r["gpu"]["served"]
+    sad = [l for l in r["gpu"]["served"] if "x265hip: sadplanes:" in l]
+    assert sad and int(sad[0].split()[2]) > 10000, r["gpu"]["served"]

@@ -66,9 +66,10 @@ struct Session
     uint64_t uploads = 0;
     uint64_t waitNs = 0;          // wall time the lookahead thread spent inside compute() (descriptor build + device pass + write-back)
     uint64_t lastUse = 0;
+    std::mutex m;                 // held across a compute(): the encoders of an ABR ladder have a session each and do not wait for one another
 };
 
-std::mutex g_lock;
+std::mutex g_lock;               // the session table (who owns which entry, eviction) and the totals below; order: g_lock, then a session's m
 const int kMaxSessions = 4;        // encoders of one process that run at the same time (an ABR ladder); more than that take turns
 Session g_sessions[kMaxSessions];
 uint64_t g_useClock = 0;
@@ -173,6 +174,7 @@ Session& session_for(const Lookahead& l, const Lowres* f)
         pick = &g_sessions[0];                  // more live encoders than sessions: the least recently used one gives way (correct, only slower)
         for (Session& c : g_sessions)
             if (c.lastUse < pick->lastUse) pick = &c;
+        std::lock_guard<std::mutex> busy(pick->m);      // its own encoder may be inside a batch
         retire_session(*pick);
     }
     Session& s = *pick;
@@ -319,9 +321,11 @@ void compute(CostEstimateGroup& g, const Job* jobs, int n, bool coop)
 {
     const Lookahead& l = g.m_lookahead;
     const x265_param* param = l.m_param;
-    std::lock_guard<std::mutex> guard(g_lock);
+    std::unique_lock<std::mutex> table(g_lock);
     const auto t0 = std::chrono::steady_clock::now();
     Session& s = session_for(l, g.m_frames[jobs[0].b]);
+    std::lock_guard<std::mutex> guard(s.m);              // free: a session is used by its own encoder's lookahead only, and evictions hold g_lock
+    table.unlock();
     s.stamp++;
     std::vector<x265hip_la_estimate> est(n);
     for (int i = 0; i < n; i++)
@@ -428,7 +432,10 @@ void Lookahead::destroy()
         std::lock_guard<std::mutex> guard(g_lock);
         for (Session& c : g_sessions)
             if (c.owner == this)
+            {
+                std::lock_guard<std::mutex> busy(c.m);
                 retire_session(c);
+            }
     }
     refLookaheadDestroy(this);
 }

@@ -76,6 +76,8 @@ int g_levels = 14;               // X265HIP_SADPLANES_LEVELS: bit l = blocks of 
 int g_time = 0;                  // X265HIP_DEBUG_SADTIME=1: cycles inside the reference's motionEstimate for the PUs a surface could serve, by block size;
                                  // =2: the same with the lookups switched off (the pair of runs measures what the lookups save)
 std::atomic<uint64_t> g_cycles[4], g_timed[4];
+bool g_missHist = false;         // X265HIP_DEBUG_SADMISS=1: how far outside their window do the misses lie, by block size (report at exit)
+std::atomic<uint64_t> g_missBy[4][4];   // [level][0: within 8 of the window, 1: within 16, 2: within 32, 3: farther]
 bool g_verify = false;           // X265HIP_VERIFY=1: every looked-up SAD is recomputed with the C function and compared (debugging self-check)
 int g_range = 32;                // X265HIP_SADPLANES_RANGE: the exhaustive search that places the windows covers [-range, range)^2
 EncoderPrimitives g_c;
@@ -150,6 +152,10 @@ void report()
     fprintf(stderr, "x265hip: sadplanes: %llu integer-pel SADs of the motion search served from GPU-built SAD surfaces (%llu surfaces, %llu CTU rows in %llu launches, %.3f ms of device time), %llu of the same "
                     "searches outside their block's window and %llu searches without a surface computed on the host\n", (unsigned long long)h,
             (unsigned long long)attached, (unsigned long long)rows, (unsigned long long)launches, kernelNs * 1e-6, (unsigned long long)m, (unsigned long long)un);
+    if (g_missHist)
+        for (int l = 0; l < 4; l++)
+            fprintf(stderr, "x265hip: sadplanes: block size %d: misses within 8 / 16 / 32 vectors of the window and farther: %llu / %llu / %llu / %llu\n", 8 << l,
+                    (unsigned long long)g_missBy[l][0].load(), (unsigned long long)g_missBy[l][1].load(), (unsigned long long)g_missBy[l][2].load(), (unsigned long long)g_missBy[l][3].load());
     const int places = x265hip_places_configured();
     if (places)
     {
@@ -172,6 +178,7 @@ bool decide()
         g_exp = exp ? atoi(exp) : 0;
         g_time = getenv("X265HIP_DEBUG_SADTIME") ? atoi(getenv("X265HIP_DEBUG_SADTIME")) : 0;
         g_verify = getenv("X265HIP_VERIFY") != NULL;
+        g_missHist = getenv("X265HIP_DEBUG_SADMISS") != NULL;
         if (getenv("X265HIP_SADPLANES_LEVELS")) g_levels = atoi(getenv("X265HIP_SADPLANES_LEVELS")) & 15;
         if (getenv("X265HIP_SADPLANES_RANGE")) g_range = atoi(getenv("X265HIP_SADPLANES_RANGE"));
         if (g_range < 8) g_range = 8;
@@ -258,6 +265,18 @@ inline int locate(const Ctx& c, const pixel* p)
     return dx < (unsigned)WIN ? (int)(dy * WIN + dx) : -1;
 }
 
+// X265HIP_DEBUG_SADMISS=1: a candidate outside the window — how far outside?
+void count_miss(const Ctx& c, const pixel* p)
+{
+    const ptrdiff_t d = p - c.winBase;
+    ptrdiff_t dy = d / c.stride, dx = d - dy * c.stride;
+    if (dx > c.stride / 2) { dx -= c.stride; dy++; }
+    if (dx < -c.stride / 2) { dx += c.stride; dy--; }
+    const int ox = dx < 0 ? (int)-dx : dx >= WIN ? (int)(dx - WIN + 1) : 0, oy = dy < 0 ? (int)-dy : dy >= WIN ? (int)(dy - WIN + 1) : 0;
+    const int out = ox > oy ? ox : oy, level = c.w == 8 ? 0 : c.w == 16 ? 1 : c.w == 32 ? 2 : 3;
+    g_missBy[level][out <= 8 ? 0 : out <= 16 ? 1 : out <= 32 ? 2 : 3].fetch_add(1, std::memory_order_relaxed);
+}
+
 // X265HIP_VERIFY=1: the table entry against the C function
 template <int PART> void verify_entry(const Ctx& c, const pixel* fenc, const pixel* ref, intptr_t rs, int k, int got)
 {
@@ -283,6 +302,7 @@ template <int PART, typename E> int sad_lookup(const pixel* fenc, intptr_t fs, c
             return (int)((const E*)c.tab)[k];
         }
         c.miss++;
+        if (g_missHist) count_miss(c, ref);
     }
     return g_c.pu[PART].sad(fenc, fs, ref, rs);
 }
@@ -291,7 +311,13 @@ template <int PART, typename E> void sad_x3_lookup(const pixel* fenc, const pixe
     Ctx& c = t_ctx;
     if (fenc != c.fenc || rs != c.stride) { g_c.pu[PART].sad_x3(fenc, r0, r1, r2, rs, res); return; }
     const int k0 = locate(c, r0), k1 = locate(c, r1), k2 = locate(c, r2);
-    if ((k0 | k1 | k2) < 0 && k0 < 0 && k1 < 0 && k2 < 0) { c.miss += 3; g_c.pu[PART].sad_x3(fenc, r0, r1, r2, rs, res); return; }
+    if (k0 < 0 && k1 < 0 && k2 < 0)
+    {
+        c.miss += 3;
+        if (g_missHist) { count_miss(c, r0); count_miss(c, r1); count_miss(c, r2); }
+        g_c.pu[PART].sad_x3(fenc, r0, r1, r2, rs, res);
+        return;
+    }
     const E* t = (const E*)c.tab;
     // sad_x3 is three independent sad<lx, ly> (pixel.cpp:74-95): a candidate outside the window is measured on its own
     res[0] = k0 >= 0 ? (int32_t)t[k0] : g_c.pu[PART].sad(fenc, FENC_STRIDE, r0, rs);
@@ -299,6 +325,7 @@ template <int PART, typename E> void sad_x3_lookup(const pixel* fenc, const pixe
     res[2] = k2 >= 0 ? (int32_t)t[k2] : g_c.pu[PART].sad(fenc, FENC_STRIDE, r2, rs);
     const int h = (k0 >= 0) + (k1 >= 0) + (k2 >= 0);
     c.hit += h; c.miss += 3 - h;
+    if (g_missHist) { if (k0 < 0) count_miss(c, r0); if (k1 < 0) count_miss(c, r1); if (k2 < 0) count_miss(c, r2); }
     if (g_verify)
     {
         if (k0 >= 0) verify_entry<PART>(c, fenc, r0, rs, k0, res[0]);
@@ -311,7 +338,13 @@ template <int PART, typename E> void sad_x4_lookup(const pixel* fenc, const pixe
     Ctx& c = t_ctx;
     if (fenc != c.fenc || rs != c.stride) { g_c.pu[PART].sad_x4(fenc, r0, r1, r2, r3, rs, res); return; }
     const int k0 = locate(c, r0), k1 = locate(c, r1), k2 = locate(c, r2), k3 = locate(c, r3);
-    if (k0 < 0 && k1 < 0 && k2 < 0 && k3 < 0) { c.miss += 4; g_c.pu[PART].sad_x4(fenc, r0, r1, r2, r3, rs, res); return; }
+    if (k0 < 0 && k1 < 0 && k2 < 0 && k3 < 0)
+    {
+        c.miss += 4;
+        if (g_missHist) { count_miss(c, r0); count_miss(c, r1); count_miss(c, r2); count_miss(c, r3); }
+        g_c.pu[PART].sad_x4(fenc, r0, r1, r2, r3, rs, res);
+        return;
+    }
     const E* t = (const E*)c.tab;
     res[0] = k0 >= 0 ? (int32_t)t[k0] : g_c.pu[PART].sad(fenc, FENC_STRIDE, r0, rs);
     res[1] = k1 >= 0 ? (int32_t)t[k1] : g_c.pu[PART].sad(fenc, FENC_STRIDE, r1, rs);
@@ -319,6 +352,7 @@ template <int PART, typename E> void sad_x4_lookup(const pixel* fenc, const pixe
     res[3] = k3 >= 0 ? (int32_t)t[k3] : g_c.pu[PART].sad(fenc, FENC_STRIDE, r3, rs);
     const int h = (k0 >= 0) + (k1 >= 0) + (k2 >= 0) + (k3 >= 0);
     c.hit += h; c.miss += 4 - h;
+    if (g_missHist) { if (k0 < 0) count_miss(c, r0); if (k1 < 0) count_miss(c, r1); if (k2 < 0) count_miss(c, r2); if (k3 < 0) count_miss(c, r3); }
     if (g_verify)
     {
         if (k0 >= 0) verify_entry<PART>(c, fenc, r0, rs, k0, res[0]);
