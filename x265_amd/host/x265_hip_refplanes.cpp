@@ -290,32 +290,6 @@ template <int W, int H, int PART> void hvpp_lookup(const pixel* s, intptr_t ss, 
         p.pu[LUMA_ ## W ## x ## H].luma_hvpp = hvpp_lookup<W, H, LUMA_ ## W ## x ## H>; \
     } while (0)
 
-// x265_hip_sadplanes.cpp (the subpelCompare seam): where in the host planes does the filtered W x H block of phase `phase` at `src` lie?  The same
-// conditions as serve<W, H>() — a mirrored picture, the block inside the computed area, its rows arrived — but no copy: the caller compares straight
-// against the plane (row pitch = the picture's stride).  NULL: compute it.
-const pixel* x265hip_refplanes_block(const pixel* src, intptr_t srcStride, int W, int H, int phase)
-{
-    if (g_state <= 0)
-        return NULL;
-    const Mirror* m = find(src);
-    if (!m)
-    {
-        t_counts.foreign++;
-        return NULL;
-    }
-    const ptrdiff_t off = src - m->lo;
-    const int by = (int)(((uint64_t)off * m->recip) >> 40), bx = (int)(off - (ptrdiff_t)by * m->stride);
-    const int y = by - m->marginY, x = bx - m->marginX;
-    if (srcStride != m->stride || x < -(m->marginX - 4) || x + W > m->picW + m->marginX - 4 || y < -(m->marginY - 4) ||
-        y + H > __atomic_load_n(m->rowsReady, __ATOMIC_ACQUIRE))
-    {
-        t_counts.missed++;
-        return NULL;
-    }
-    t_counts.served++;
-    return m->plane[phase] + off;
-}
-
 // x265_hip_sadplanes.cpp: the device mirror of the reconstructed picture in `recon` and the generation of the picture it holds now
 x265hip_refpic* x265hip_refplanes_device(const PicYuv* recon, uint32_t* generation)
 {

@@ -65,15 +65,6 @@ extern int refMotionEstimate(MotionEstimate* self, ReferencePlanes* ref, const M
     asm("_ZN4x26517MotionEstimateRef14motionEstimateEPNS_15ReferencePlanesERKNS_2MVES5_S5_iPS4_iRS3_jPt");
 #endif
 extern void refInitScales() asm("_ZN4x26517MotionEstimateRef10initScalesEv");
-// MotionEstimateRef::subpelCompare: the body the reference's motionEstimate calls for every sub-pel candidate (motion.cpp:1571-1668) — reachable under an
-// alias (oracle/Makefile), while the name itself resolves to subpel_compare_seam below
-extern int refSubpelCompare(MotionEstimate* self, ReferencePlanes* ref, const MV& qmv, pixelcmp_t cmp) asm("x265hip_ref_subpelCompare");
-const pixel* x265hip_refplanes_block(const pixel* src, intptr_t srcStride, int W, int H, int phase);      // x265_hip_refplanes.cpp
-#if X265_DEPTH == 8
-int subpel_compare_seam(MotionEstimate* self, ReferencePlanes* ref, const MV& qmv, pixelcmp_t cmp) asm("_ZN4x26517MotionEstimateRef13subpelCompareEPNS_15ReferencePlanesERKNS_2MVEPFiPKhlS7_lE");
-#else
-int subpel_compare_seam(MotionEstimate* self, ReferencePlanes* ref, const MV& qmv, pixelcmp_t cmp) asm("_ZN4x26517MotionEstimateRef13subpelCompareEPNS_15ReferencePlanesERKNS_2MVEPFiPKtlS7_lE");
-#endif
 
 namespace {
 
@@ -511,38 +502,6 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
         t_hit = t_miss = 0;
     }
     return r;
-}
-
-// MotionEstimate::subpelCompare (motion.cpp:1571-1668), as the reference's motionEstimate body calls it for every sub-pel candidate: filter the reference block
-// into a stack buffer (luma_hpp / vpp / hvpp, :1591-1597), compare the source PU with the buffer (:1598).  On a mirrored picture the filtered block already
-// exists in a host plane, and the comparison functions take any row pitch: compare with the plane itself and skip the copy the lookup slot would make.
-// Luma-only searches (bChromaSATD: subme > 2 adds chroma terms — the reference's body does those) with a fractional vector; everything else, and any block
-// the planes cannot serve, goes to the reference's body.  X265HIP_SUBPEL_DIRECT=0 switches it off; X265HIP_VERIFY=1 runs both and compares.
-int subpel_compare_seam(MotionEstimate* self, ReferencePlanes* ref, const MV& qmv, pixelcmp_t cmp)
-{
-    static const bool direct = !(getenv("X265HIP_SUBPEL_DIRECT") && !strcmp(getenv("X265HIP_SUBPEL_DIRECT"), "0"));
-    // the PU's height by its partition (the object keeps the width only; enum LumaPU, primitives.h:41-55)
-    static const uint8_t kHeight[NUM_PU_SIZES] = { 4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 12, 16, 4, 16, 24, 32, 8, 32, 48, 64, 16, 64 };
-    static const uint8_t kWidth[NUM_PU_SIZES] = { 4, 8, 16, 32, 64, 8, 4, 16, 8, 32, 16, 64, 32, 16, 12, 16, 4, 32, 24, 32, 8, 64, 48, 64, 16 };
-    const int xFrac = qmv.x & 3, yFrac = qmv.y & 3;
-    if (direct && !self->bChromaSATD && (xFrac | yFrac) && (unsigned)self->partEnum < NUM_PU_SIZES && kWidth[self->partEnum] == self->blockwidth)
-    {
-        const int blockheight = kHeight[self->partEnum];
-        const intptr_t refStride = ref->lumaStride;
-        const pixel* fref = ref->fpelPlane[0] + self->blockOffset + (qmv.x >> 2) + (qmv.y >> 2) * refStride;                 // :1574
-        const pixel* p = x265hip_refplanes_block(fref, refStride, self->blockwidth, blockheight, 4 * yFrac + xFrac);
-        if (p)
-        {
-            const int cost = cmp(self->fencPUYuv.m_buf[0], FENC_STRIDE, p, refStride);
-            if (g_verify && cost != refSubpelCompare(self, ref, qmv, cmp))
-            {
-                fprintf(stderr, "x265hip: sadplanes: VERIFY FAILED subpelCompare %dx%d qmv (%d, %d)\n", self->blockwidth, blockheight, qmv.x, qmv.y);
-                abort();
-            }
-            return cost;
-        }
-    }
-    return refSubpelCompare(self, ref, qmv, cmp);
 }
 
 } // namespace X265_NS
