@@ -16,6 +16,8 @@
 #include "internal.h"
 #include "refpic.h"
 #include <cstring>
+#include <map>
+#include <utility>
 
 namespace xh {
 
@@ -102,6 +104,15 @@ extern "C" {
 
 static x265hip_refpic* refpic_create(int place, int depth, int picW, int picH, int64_t stride, int marginX, int marginY, int bufRows, const void* hostBase);
 
+// The buffers of destroyed mirrors, kept for the next mirror of the same size on the same device: page-locking 42 MB per mirror is the slow part of
+// creating one (10-15 ms) and unlocking it the slow part of destroying one — an encoder that closes hands its mirrors to the next encoder of the
+// process, and a process that ends leaves them to the runtime's own teardown.
+namespace {
+struct MirrorBufs { char* dPic; char* dPlanes; char* hPlanes; char* hStage; hipStream_t st; };
+std::mutex g_bufLock;
+std::multimap<std::pair<size_t, int>, MirrorBufs> g_bufPool;        // key: (bytes of one padded plane, device)
+}
+
 x265hip_refpic* x265hip_refpic_create(int depth, int picW, int picH, int64_t stride, int marginX, int marginY, int bufRows, const void* hostBase)
 {
     if (ensure_device()) return nullptr;
@@ -143,10 +154,22 @@ static x265hip_refpic* refpic_create(int place, int depth, int picW, int picH, i
     (void)hipGetDevice(&rp->device);
     rp->place = place;
     const size_t planeBytes = (size_t)rp->planeElems * rp->B;
-    bool ok = hipStreamCreateWithFlags(&rp->st, hipStreamNonBlocking) == hipSuccess &&
-              hipMalloc((void**)&rp->dPic, planeBytes) == hipSuccess && hipMalloc((void**)&rp->dPlanes, planeBytes * 16) == hipSuccess &&
-              hipHostMalloc((void**)&rp->hPlanes, planeBytes * 15, hipHostMallocDefault) == hipSuccess &&
-              hipHostMalloc((void**)&rp->hStage, planeBytes, hipHostMallocDefault) == hipSuccess;
+    bool ok = false;
+    {
+        std::lock_guard<std::mutex> g(g_bufLock);
+        auto it = g_bufPool.find({ planeBytes, rp->device });
+        if (it != g_bufPool.end())
+        {
+            rp->dPic = it->second.dPic; rp->dPlanes = it->second.dPlanes; rp->hPlanes = it->second.hPlanes; rp->hStage = it->second.hStage; rp->st = it->second.st;
+            g_bufPool.erase(it);
+            ok = true;
+        }
+    }
+    if (!ok)
+        ok = hipStreamCreateWithFlags(&rp->st, hipStreamNonBlocking) == hipSuccess &&
+             hipMalloc((void**)&rp->dPic, planeBytes) == hipSuccess && hipMalloc((void**)&rp->dPlanes, planeBytes * 16) == hipSuccess &&
+             hipHostMalloc((void**)&rp->hPlanes, planeBytes * 15, hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc((void**)&rp->hStage, planeBytes, hipHostMallocDefault) == hipSuccess;
     if (!ok)
     {
         set_error(X265HIP_ENOMEM, "x265hip_refpic_create: %zu bytes per plane", planeBytes);
@@ -183,11 +206,21 @@ void x265hip_refpic_destroy(x265hip_refpic* rp)
     }
     rp->replicas.clear();
     (void)hipSetDevice(rp->device);
-    if (rp->hStage) (void)hipHostFree(rp->hStage);
-    if (rp->dPic) (void)hipFree(rp->dPic);
-    if (rp->dPlanes) (void)hipFree(rp->dPlanes);
-    if (rp->hPlanes) (void)hipHostFree(rp->hPlanes);
-    if (rp->st) (void)hipStreamDestroy(rp->st);
+    if (rp->st && rp->dPic && rp->dPlanes && rp->hPlanes && rp->hStage)
+    {
+        // complete set: to the pool (the worker is idle for rp and its stream has been synchronised by the wait above)
+        (void)hipStreamSynchronize(rp->st);
+        std::lock_guard<std::mutex> g(g_bufLock);
+        g_bufPool.insert({ { (size_t)rp->planeElems * rp->B, rp->device }, MirrorBufs{ rp->dPic, rp->dPlanes, rp->hPlanes, rp->hStage, rp->st } });
+    }
+    else
+    {
+        if (rp->hStage) (void)hipHostFree(rp->hStage);
+        if (rp->dPic) (void)hipFree(rp->dPic);
+        if (rp->dPlanes) (void)hipFree(rp->dPlanes);
+        if (rp->hPlanes) (void)hipHostFree(rp->hPlanes);
+        if (rp->st) (void)hipStreamDestroy(rp->st);
+    }
     delete rp;
     if (had) (void)hipSetDevice(cur);
 }

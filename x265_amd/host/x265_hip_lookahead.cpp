@@ -427,6 +427,7 @@ inline bool cached(const Lowres* fenc, int p0, int p1, int b)
 // same addresses back from malloc — the session's slots are keyed by them, so the session must not outlive them (tests/support/two_encoders.cpp).
 void Lookahead::destroy()
 {
+    x265hip_debug_mark("Lookahead::destroy (the encoder is being closed)");
     if (g_state > 0)
     {
         std::lock_guard<std::mutex> guard(g_lock);
@@ -438,6 +439,7 @@ void Lookahead::destroy()
             }
     }
     refLookaheadDestroy(this);
+    x265hip_debug_mark("Lookahead::destroy returns");
 }
 
 // X265HIP_DEBUG_DELAY_US (see x265_hip_refplanes.cpp): the same diagnostic sleep on the lookahead's side, seams on or off — the reference's output

@@ -423,7 +423,11 @@ void PicYuv::destroy()
             sp->pic.store(nullptr);
         }
     if (m_picBuf[0])
+    {
+        x265hip_debug_mark("PicYuv::destroy: retire");
         x265hip_refplanes_retire(m_picBuf[0]);
+        x265hip_debug_mark("PicYuv::destroy: retired");
+    }
     refDestroy(this);
 }
 
