@@ -704,7 +704,9 @@ int x265hip_source_energy(int depth, const void* hostPlane, int64_t stride, int 
  * SAD + (lambda20 * (bits(4 |vx - px|) + bits(4 |vy - py|)) + 10) / 20 (bits(d) = 2 floor(log2(d + 1)) + 1; p = the parent block's best vector,
  * (0, 0) at the top; ties: smaller vy, then smaller vx) is the block's best, and its window starts at best - WIN / 2, clamped into the range
  * and into the padded picture.  That choice only decides how many lookups hit — every entry is the exact SAD, and a vector outside the window is
- * computed by the C function as before.  lambda20 = 20 x the encoder's lambda (SAD units per bit of vector cost). */
+ * computed by the C function as before.  lambda20 = 20 x the encoder's lambda (SAD units per bit of vector cost).
+ * 8-bit pictures: searchRange up to 32, v_qsad_pk_u16_u8, u16 surface in LDS; 16-bit pictures (depth 10 / 12): searchRange up to 16 (the u32 surface of a
+ * CTU must fit LDS), v_sad_u16, every table u32, no 8 x 8 level.  Strides count samples. */
 #define X265HIP_SADSURF_WIN 16
 #define X265HIP_SADSURF_LEVELS 4
 typedef struct x265hip_srcpic x265hip_srcpic;        /* the luma plane of a source picture, resident on the device */

@@ -32,7 +32,7 @@ def _emul(hp):
     return em
 
 
-def _pictures(w, h, seed, count=2, MX=MX, MY=MY, ctu=64):
+def _pictures(w, h, seed, count=2, MX=MX, MY=MY, ctu=64, depth=8):
     """A padded reference picture (as the encoder's recon buffer: margins replicated) and `count` source pictures = the reference moved per
     48 x 40 tile by up to +-20 pixels plus noise."""
     rng = np.random.default_rng(seed)
@@ -52,6 +52,12 @@ def _pictures(w, h, seed, count=2, MX=MX, MY=MY, ctu=64):
                 y1, x1 = min(y0 + 40, h), min(x0 + 48, w)
                 s[y0:y1, x0:x1] = big[64 + y0 + dy:64 + y1 + dy, 64 + x0 + dx:64 + x1 + dx]
         srcs.append(np.ascontiguousarray(np.clip(np.rint(s + rng.normal(0, 2.0, s.shape)), 0, 255).astype(np.uint8)))
+    if depth > 8:
+        # the same pictures with `depth` bits per sample: scaled up, the new low bits random
+        sh = depth - 8
+        buf = (buf.astype(np.uint16) << sh) | rng.integers(0, 1 << sh, buf.shape, dtype=np.uint16)
+        buf[:h + 2 * MY, :w + 2 * MX] = np.pad(buf[MY:MY + h, MX:MX + w], ((MY, MY), (MX, MX)), mode="edge")
+        srcs = [np.ascontiguousarray((s.astype(np.uint16) << sh) | rng.integers(0, 1 << sh, s.shape, dtype=np.uint16)) for s in srcs]
     return buf, stride, rows, srcs
 
 
@@ -80,14 +86,14 @@ def _read_view(hp, L, ss, w, h):
     return out
 
 
-def _run(hp, L, w, h, seed, S, lam, bands, attach_after, levels=15, MX=MX, MY=MY, ctu=64):
+def _run(hp, L, w, h, seed, S, lam, bands, attach_after, levels=15, MX=MX, MY=MY, ctu=64, depth=8):
     """Drive one library: reference rows arrive in `bands` (picture rows); source k is attached after band attach_after[k] (-1: before any)."""
-    buf, stride, rows, srcs = _pictures(w, h, seed, count=len(attach_after), MX=MX, MY=MY, ctu=ctu)
-    rp = L.x265hip_refpic_create(8, w, h, stride, MX, MY, rows, buf.ctypes.data)
+    buf, stride, rows, srcs = _pictures(w, h, seed, count=len(attach_after), MX=MX, MY=MY, ctu=ctu, depth=depth)
+    rp = L.x265hip_refpic_create(depth, w, h, stride, MX, MY, rows, buf.ctypes.data)
     assert rp, L.x265hip_last_error()
     sps, sss = [], [None] * len(srcs)
     for s in srcs:
-        sp = L.x265hip_srcpic_create(8, w, h)
+        sp = L.x265hip_srcpic_create(depth, w, h)
         assert sp, L.x265hip_last_error()
         assert L.x265hip_srcpic_upload(sp, s.ctypes.data, s.shape[1]) == 0
         sps.append(sp)
@@ -115,16 +121,17 @@ def _run(hp, L, w, h, seed, S, lam, bands, attach_after, levels=15, MX=MX, MY=MY
     return views, buf, stride, srcs
 
 
-def test_restatement_entries_are_the_reference_sad_and_windows_are_legal():
+@pytest.mark.parametrize("depth", [8, 10])
+def test_restatement_entries_are_the_reference_sad_and_windows_are_legal(depth):
     import x265_amd.hipprim as hp
     import backends
     em = _emul(hp)
     try:
-        o = backends.Ref(8)            # the real sad<N, N> (pixel.cpp:40-55) out of oracle/_ref/libx265ref8.so
+        o = backends.Ref(depth)        # the real sad<N, N> (pixel.cpp:40-55) out of oracle/_ref/libx265ref{8,10}.so
     except Exception:
-        o = backends.Orc(8)            # pinned to it by tests/test_oracle_vs_ref.py
+        o = backends.Orc(depth)        # pinned to it by tests/test_oracle_vs_ref.py
     w, h, S = 200, 136, 16
-    views, buf, stride, srcs = _run(hp, em, w, h, 5, S, 9 * 20, [64, 128, h], [-1])
+    views, buf, stride, srcs = _run(hp, em, w, h, 5, S, 9 * 20, [64, 128, h], [-1], levels=15 if depth == 8 else 14, depth=depth)
     rng = np.random.default_rng(1)
     for l, (org, tab) in views[0].items():
         n = 8 << l
@@ -156,6 +163,11 @@ GPU_CASES = [
     # memory fault before the staging loads were clamped into the buffer)
     (200, 136, 16, 32, 180, [48, 96, 136], [-1, 1], 48, 32, 16),
     (72, 40, 17, 24, 180, [16, 40], [-1], 48, 32, 16),
+    # 16-bit pictures (Main10 / Main12 builds): the v_sad_u16 kernel, u32 surfaces, range <= 16
+    (200, 136, 18, 16, 180, [64, 128, 136], [-1, 1], 96, 80, 64, 10),
+    (416, 240, 19, 16, 0, [240], [-1, 0], 96, 80, 64, 12),
+    (200, 136, 20, 12, 400, [48, 96, 136], [0], 48, 32, 16, 10),
+    (1280, 720, 21, 16, 180, [192, 448, 720], [1], 96, 80, 64, 10),
 ]
 
 
@@ -167,8 +179,8 @@ def test_device_surfaces_match_restatement(case):
     hp.check(L.x265hip_init(0))
     em = _emul(hp)
     w, h, seed, S, lam, bands, attach_after, *geom = GPU_CASES[case]
-    geom = dict(zip(("MX", "MY", "ctu"), geom))
-    levels = 14 if case == 1 else 15                 # one case without the 8x8 windows (the layout of the product's default)
+    geom = dict(zip(("MX", "MY", "ctu", "depth"), geom))
+    levels = 14 if case == 1 or geom.get("depth", 8) > 8 else 15       # one 8-bit case without the 8x8 windows (the product's default layout); 16-bit never has them
     got, *_ = _run(hp, L, w, h, seed, S, lam, bands, attach_after, levels, **geom)
     want, *_ = _run(hp, em, w, h, seed, S, lam, bands, attach_after, levels, **geom)
     for k in range(len(attach_after)):

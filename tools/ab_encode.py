@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--preset", default="medium")
     ap.add_argument("--extra", default="--me hex")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--bits", type=int, default=8, help="encoder build: 8, 10 or 12 (x265_<bits>bit / x265_hip_<bits>bit); the clip stays 8-bit input")
     a = ap.parse_args()
     w, h = map(int, a.res.split("x"))
     from x265_amd.synth import make_clip
@@ -49,7 +50,7 @@ def main():
     if not os.path.exists(clip):
         make_clip(clip, w, h, a.frames, seed=4321)
     args = ["--input", clip, "--input-res", a.res, "--input-depth", "8", "--fps", "30", "--frames", str(a.frames), "--preset", a.preset, "--hash", "1"] + a.extra.split()
-    ref = run(os.path.join(REF, "x265_8bit"), args, "/tmp/ab_ref.hevc", dict(os.environ))
+    ref = run(os.path.join(REF, "x265_%dbit" % a.bits), args, "/tmp/ab_ref.hevc", dict(os.environ))
     cfgs = []
     for c in a.configs:
         name, _, rest = c.partition(":")
@@ -59,7 +60,7 @@ def main():
     for r in range(a.rounds):
         for name, env in (cfgs if r % 2 == 0 else cfgs[::-1]):
             e = dict(os.environ, X265HIP="require", X265HIP_VERBOSE="1", **env)
-            res[name].append(run(os.path.join(REF, "x265_hip_8bit"), args, "/tmp/ab_%s.hevc" % name, e))
+            res[name].append(run(os.path.join(REF, "x265_hip_%dbit" % a.bits), args, "/tmp/ab_%s.hevc" % name, e))
     summary = {"clip": "%s %d frames preset %s %s" % (a.res, a.frames, a.preset, a.extra), "reference": {"fps": ref["fps"], "user": round(ref["user"], 1)}, "configs": {}}
     print("reference: %.2f fps, user %.1f s" % (ref["fps"], ref["user"]))
     for name, env in cfgs:

@@ -17,7 +17,7 @@
 //   emit     the 16 x 16 window around each block's best vector is gathered out of the LDS surface (no second SAD pass) and written with the
 //            block's origin into the CTU row's chunk of the table buffer.
 // Values are pinned by tests/test_sadsurf.py (entries == sad<N, N> of the reference, pixel.cpp:40-55; origins == the same rule restated on the
-// CPU by the test tier).  8-bit pictures only: v_qsad_pk_u16_u8 is a byte instruction (16-bit builds keep the C slots).
+// CPU by the test tier).  16-bit pictures (Main10 / Main12 builds) have a kernel of their own below: v_sad_u16, u32 surfaces, range <= 16.
 #include "common.h"
 #include "internal.h"
 #include "refpic.h"
@@ -197,13 +197,171 @@ __device__ __forceinline__ void ss_add4(const uint16_t* surf, int c, uint32_t* s
     s[0] += v.x & 0xFFFFu; s[1] += v.x >> 16; s[2] += v.y & 0xFFFFu; s[3] += v.y >> 16;
 }
 
+// the same for the u32 surfaces of 16-bit pictures (one 16-byte LDS read)
+__device__ __forceinline__ void ss_add4(const uint32_t* surf, int c, uint32_t* s)
+{
+    const uint4 v = *(const uint4*)(surf + c);
+    s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+}
+
+// what the phases of a workgroup share besides the surface
+struct SsShared
+{
+    uint64_t red[16];
+    int best[4][16][2];                                          // [level][block][vx, vy]
+    int org[4][16][2];
+    uint32_t vc[32];                                             // vector cost by log(|dx|) + log(|dy|)
+};
+
+// decide (top down 64 -> 32 -> 16) and emit the windows of levels 1..3 out of the LDS surface `sSurf` ([16][D][D], ST = u16 for 8-bit pictures, u32 for
+// 16-bit ones); called by all 1024 threads of the workgroup after the surface is complete.  Leaves the level-1 origins in sh.org[1] (the 8x8 pass of
+// the 8-bit kernel takes them from there).
+template <typename ST>
+__device__ __forceinline__ void ss_decide_emit(const SurfArgs& a, const SurfJob& jb, const ST* sSurf, SsShared& sh, int S, int x0, int y0, int cx, int cy)
+{
+    const int D = 2 * S, DD = D * D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t* sRed = sh.red;
+    int (*sBest)[16][2] = sh.best;
+    int (*sOrg)[16][2] = sh.org;
+    const uint32_t* sVc = sh.vc;
+    // ---- decide, top down ----
+    // level 3: the whole CTU, all 1024 threads: column group tid & 15, rows tid >> 4, + 64, ...
+    const bool have3 = x0 + 64 <= a.picW && y0 + 64 <= a.picH;
+    if (have3)
+    {
+        const int xlo = -a.marginX - x0, xhi = a.picW + a.marginX - 64 - x0, ylo = -a.marginY - y0, yhi = a.picH + a.marginY - 64 - y0;
+        uint64_t k = ss_scan4([&](int c, uint32_t* s) { s[0] = s[1] = s[2] = s[3] = 0;
+#pragma unroll
+                                                       for (int b = 0; b < 16; b++) ss_add4(sSurf + b * DD, c, s); },
+                              sVc, S, tid & 15, tid >> 4, 64, xlo, xhi, ylo, yhi, 0, 0);
+        k = wave_min_u64(k);
+        if (lane == 0) sRed[wave] = k;
+        __syncthreads();
+        if (tid == 0)
+        {
+            uint64_t m = sRed[0];
+            for (int i = 1; i < 16; i++) m = u64_min(m, sRed[i]);
+            int bx, by, ox, oy;
+            ss_origin(m, S, xlo, xhi, ylo, yhi, bx, by, ox, oy);
+            sBest[3][0][0] = bx; sBest[3][0][1] = by; sOrg[3][0][0] = ox; sOrg[3][0][1] = oy;
+        }
+    }
+    __syncthreads();
+    // level 2: 32x32 block g <-> threads [256 g, 256 g + 256)
+    {
+        const int g = tid >> 8, t = tid & 255, gx = g & 1, gy = g >> 1;
+        const int x = x0 + gx * 32, y = y0 + gy * 32;
+        const bool have = x + 32 <= a.picW && y + 32 <= a.picH;
+        const int xlo = -a.marginX - x, xhi = a.picW + a.marginX - 32 - x, ylo = -a.marginY - y, yhi = a.picH + a.marginY - 32 - y;
+        uint64_t k = ~(uint64_t)0;
+        if (have)
+        {
+            const int px = have3 ? sBest[3][0][0] : 0, py = have3 ? sBest[3][0][1] : 0;
+            const ST* s0 = sSurf + ((gy * 2) * 4 + gx * 2) * DD;
+            k = ss_scan4([&](int c, uint32_t* s) { s[0] = s[1] = s[2] = s[3] = 0;
+                                                   ss_add4(s0, c, s); ss_add4(s0 + DD, c, s); ss_add4(s0 + 4 * DD, c, s); ss_add4(s0 + 5 * DD, c, s); },
+                         sVc, S, t & 15, t >> 4, 16, xlo, xhi, ylo, yhi, px, py);
+            k = wave_min_u64(k);
+        }
+        if (lane == 0) sRed[wave] = k;
+        __syncthreads();
+        if (have && t == 0)
+        {
+            uint64_t m = u64_min(u64_min(sRed[4 * g], sRed[4 * g + 1]), u64_min(sRed[4 * g + 2], sRed[4 * g + 3]));
+            int bx, by, ox, oy;
+            ss_origin(m, S, xlo, xhi, ylo, yhi, bx, by, ox, oy);
+            sBest[2][g][0] = bx; sBest[2][g][1] = by; sOrg[2][g][0] = ox; sOrg[2][g][1] = oy;
+        }
+    }
+    __syncthreads();
+    // level 1: 16x16 block b <-> wave b
+    {
+        const int b = wave, bx16 = b & 3, by16 = b >> 2;
+        const int x = x0 + bx16 * 16, y = y0 + by16 * 16;
+        const bool have = x + 16 <= a.picW && y + 16 <= a.picH;
+        if (have)
+        {
+            const int g = (by16 >> 1) * 2 + (bx16 >> 1);
+            const bool haveParent = x0 + (bx16 >> 1) * 32 + 32 <= a.picW && y0 + (by16 >> 1) * 32 + 32 <= a.picH;
+            const int px = haveParent ? sBest[2][g][0] : 0, py = haveParent ? sBest[2][g][1] : 0;
+            const int xlo = -a.marginX - x, xhi = a.picW + a.marginX - 16 - x, ylo = -a.marginY - y, yhi = a.picH + a.marginY - 16 - y;
+            const ST* s0 = sSurf + b * DD;
+            uint64_t k = ss_scan4([&](int c, uint32_t* s) { s[0] = s[1] = s[2] = s[3] = 0; ss_add4(s0, c, s); },
+                                  sVc, S, lane & 15, lane >> 4, 4, xlo, xhi, ylo, yhi, px, py);
+            k = wave_min_u64(k);
+            if (lane == 0)
+            {
+                int vx, vy, ox, oy;
+                ss_origin(k, S, xlo, xhi, ylo, yhi, vx, vy, ox, oy);
+                sOrg[1][b][0] = ox; sOrg[1][b][1] = oy;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- emit: origins and the 16 x 16 windows, gathered from the LDS surface ----
+    char* chunk = jb.out + (int64_t)cy * a.pitch;
+    // level 1: wave b, 4 entries per lane
+    {
+        const int b = wave, bx16 = b & 3, by16 = b >> 2;
+        if (x0 + bx16 * 16 + 16 <= a.picW && y0 + by16 * 16 + 16 <= a.picH)
+        {
+            const int ox = sOrg[1][b][0], oy = sOrg[1][b][1];
+            const int64_t idx = (int64_t)by16 * a.blocksX[1] + cx * 4 + bx16;
+            if (lane == 0)
+                *(uint32_t*)(chunk + a.originOff[1] + idx * 4) = (uint32_t)(uint16_t)(int16_t)ox | ((uint32_t)(uint16_t)(int16_t)oy << 16);
+            const int j = lane >> 2, i4 = (lane & 3) * 4;
+            const ST* p = sSurf + ((size_t)b * D + (oy + S + j)) * D + (ox + S + i4);
+            const ST v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+            if (sizeof(ST) == 2)
+            {
+                uint16_t* tab = (uint16_t*)(chunk + a.tableOff[1]) + idx * (kWin * kWin);
+                *(uint2*)(tab + j * kWin + i4) = make_uint2((uint32_t)v0 | ((uint32_t)v1 << 16), (uint32_t)v2 | ((uint32_t)v3 << 16));
+            }
+            else
+            {
+                uint32_t* tab = (uint32_t*)(chunk + a.tableOff[1]) + idx * (kWin * kWin);
+                *(uint4*)(tab + j * kWin + i4) = make_uint4((uint32_t)v0, (uint32_t)v1, (uint32_t)v2, (uint32_t)v3);
+            }
+        }
+    }
+    // level 2: group g, one entry per thread
+    {
+        const int g = tid >> 8, t = tid & 255, gx = g & 1, gy = g >> 1;
+        if (x0 + gx * 32 + 32 <= a.picW && y0 + gy * 32 + 32 <= a.picH)
+        {
+            const int ox = sOrg[2][g][0], oy = sOrg[2][g][1];
+            const int64_t idx = (int64_t)gy * a.blocksX[2] + cx * 2 + gx;
+            if (t == 0)
+                *(uint32_t*)(chunk + a.originOff[2] + idx * 4) = (uint32_t)(uint16_t)(int16_t)ox | ((uint32_t)(uint16_t)(int16_t)oy << 16);
+            const int j = t >> 4, i = t & 15, b0 = (gy * 2) * 4 + gx * 2;
+            const size_t c = (size_t)(oy + S + j) * D + (ox + S + i);
+            ((uint32_t*)(chunk + a.tableOff[2]))[idx * (kWin * kWin) + t] =
+                (uint32_t)sSurf[b0 * DD + c] + sSurf[(b0 + 1) * DD + c] + sSurf[(b0 + 4) * DD + c] + sSurf[(b0 + 5) * DD + c];
+        }
+    }
+    // level 3: threads 0..255
+    if (have3 && tid < 256)
+    {
+        const int ox = sOrg[3][0][0], oy = sOrg[3][0][1];
+        const int64_t idx = cx;
+        if (tid == 0)
+            *(uint32_t*)(chunk + a.originOff[3] + idx * 4) = (uint32_t)(uint16_t)(int16_t)ox | ((uint32_t)(uint16_t)(int16_t)oy << 16);
+        const int j = tid >> 4, i = tid & 15;
+        const size_t c = (size_t)(oy + S + j) * D + (ox + S + i);
+        uint32_t t = 0;
+#pragma unroll
+        for (int b = 0; b < 16; b++) t += sSurf[b * DD + c];
+        ((uint32_t*)(chunk + a.tableOff[3]))[idx * (kWin * kWin) + tid] = t;
+    }
+
+}
+
 __global__ __launch_bounds__(1024) void sadsurf_ctu_kernel(SurfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint64_t sRed[16];
-    __shared__ int sBest[4][16][2];                              // [level][block][vx, vy]
-    __shared__ int sOrg[4][16][2];
-    __shared__ uint32_t sVc[32];                                 // vector cost by log(|dx|) + log(|dy|)
+    __shared__ SsShared sh;
 
     int jn = 0, rowIn = blockIdx.y;
     while (jn + 1 < a.nJobs && rowIn >= a.job[jn].rows) { rowIn -= a.job[jn].rows; jn++; }
@@ -243,7 +401,7 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu_kernel(SurfArgs a)
         }
     }
     if (tid < 32)
-        sVc[tid] = (uint32_t)((jb.lambda20 * (2 * tid + 2) + 10) / 20);          // bits(4 |dx|) + bits(4 |dy|) = 2 (log + log) + 2
+        sh.vc[tid] = (uint32_t)((jb.lambda20 * (2 * tid + 2) + 10) / 20);        // bits(4 |dx|) + bits(4 |dy|) = 2 (log + log) + 2
     __syncthreads();
 
     // ---- measure: wave b <-> 16x16 block b.  A lane owns an 8 x 8 patch of vectors: 16 accumulators of four u16 SADs each.  Reference row j of
@@ -300,99 +458,9 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu_kernel(SurfArgs a)
     }
     __syncthreads();
 
-    // ---- decide, top down ----
-    // level 3: the whole CTU, all 1024 threads: column group tid & 15, rows tid >> 4, + 64, ...
-    const bool have3 = x0 + 64 <= a.picW && y0 + 64 <= a.picH;
-    if (have3)
-    {
-        const int xlo = -a.marginX - x0, xhi = a.picW + a.marginX - 64 - x0, ylo = -a.marginY - y0, yhi = a.picH + a.marginY - 64 - y0;
-        uint64_t k = ss_scan4([&](int c, uint32_t* s) { s[0] = s[1] = s[2] = s[3] = 0;
-#pragma unroll
-                                                       for (int b = 0; b < 16; b++) ss_add4(sSurf + b * DD, c, s); },
-                              sVc, S, tid & 15, tid >> 4, 64, xlo, xhi, ylo, yhi, 0, 0);
-        k = wave_min_u64(k);
-        if (lane == 0) sRed[wave] = k;
-        __syncthreads();
-        if (tid == 0)
-        {
-            uint64_t m = sRed[0];
-            for (int i = 1; i < 16; i++) m = u64_min(m, sRed[i]);
-            int bx, by, ox, oy;
-            ss_origin(m, S, xlo, xhi, ylo, yhi, bx, by, ox, oy);
-            sBest[3][0][0] = bx; sBest[3][0][1] = by; sOrg[3][0][0] = ox; sOrg[3][0][1] = oy;
-        }
-    }
-    __syncthreads();
-    // level 2: 32x32 block g <-> threads [256 g, 256 g + 256)
-    {
-        const int g = tid >> 8, t = tid & 255, gx = g & 1, gy = g >> 1;
-        const int x = x0 + gx * 32, y = y0 + gy * 32;
-        const bool have = x + 32 <= a.picW && y + 32 <= a.picH;
-        const int xlo = -a.marginX - x, xhi = a.picW + a.marginX - 32 - x, ylo = -a.marginY - y, yhi = a.picH + a.marginY - 32 - y;
-        uint64_t k = ~(uint64_t)0;
-        if (have)
-        {
-            const int px = have3 ? sBest[3][0][0] : 0, py = have3 ? sBest[3][0][1] : 0;
-            const uint16_t* s0 = sSurf + ((gy * 2) * 4 + gx * 2) * DD;
-            k = ss_scan4([&](int c, uint32_t* s) { s[0] = s[1] = s[2] = s[3] = 0;
-                                                   ss_add4(s0, c, s); ss_add4(s0 + DD, c, s); ss_add4(s0 + 4 * DD, c, s); ss_add4(s0 + 5 * DD, c, s); },
-                         sVc, S, t & 15, t >> 4, 16, xlo, xhi, ylo, yhi, px, py);
-            k = wave_min_u64(k);
-        }
-        if (lane == 0) sRed[wave] = k;
-        __syncthreads();
-        if (have && t == 0)
-        {
-            uint64_t m = u64_min(u64_min(sRed[4 * g], sRed[4 * g + 1]), u64_min(sRed[4 * g + 2], sRed[4 * g + 3]));
-            int bx, by, ox, oy;
-            ss_origin(m, S, xlo, xhi, ylo, yhi, bx, by, ox, oy);
-            sBest[2][g][0] = bx; sBest[2][g][1] = by; sOrg[2][g][0] = ox; sOrg[2][g][1] = oy;
-        }
-    }
-    __syncthreads();
-    // level 1: 16x16 block b <-> wave b
-    {
-        const int b = wave, bx16 = b & 3, by16 = b >> 2;
-        const int x = x0 + bx16 * 16, y = y0 + by16 * 16;
-        const bool have = x + 16 <= a.picW && y + 16 <= a.picH;
-        if (have)
-        {
-            const int g = (by16 >> 1) * 2 + (bx16 >> 1);
-            const bool haveParent = x0 + (bx16 >> 1) * 32 + 32 <= a.picW && y0 + (by16 >> 1) * 32 + 32 <= a.picH;
-            const int px = haveParent ? sBest[2][g][0] : 0, py = haveParent ? sBest[2][g][1] : 0;
-            const int xlo = -a.marginX - x, xhi = a.picW + a.marginX - 16 - x, ylo = -a.marginY - y, yhi = a.picH + a.marginY - 16 - y;
-            const uint16_t* s0 = sSurf + b * DD;
-            uint64_t k = ss_scan4([&](int c, uint32_t* s) { s[0] = s[1] = s[2] = s[3] = 0; ss_add4(s0, c, s); },
-                                  sVc, S, lane & 15, lane >> 4, 4, xlo, xhi, ylo, yhi, px, py);
-            k = wave_min_u64(k);
-            if (lane == 0)
-            {
-                int vx, vy, ox, oy;
-                ss_origin(k, S, xlo, xhi, ylo, yhi, vx, vy, ox, oy);
-                sOrg[1][b][0] = ox; sOrg[1][b][1] = oy;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- emit: origins and the 16 x 16 windows, gathered from the LDS surface ----
+    ss_decide_emit<uint16_t>(a, jb, sSurf, sh, S, x0, y0, cx, cy);
     char* chunk = jb.out + (int64_t)cy * a.pitch;
-    // level 1: wave b, 4 entries per lane
-    {
-        const int b = wave, bx16 = b & 3, by16 = b >> 2;
-        if (x0 + bx16 * 16 + 16 <= a.picW && y0 + by16 * 16 + 16 <= a.picH)
-        {
-            const int ox = sOrg[1][b][0], oy = sOrg[1][b][1];
-            const int64_t idx = (int64_t)by16 * a.blocksX[1] + cx * 4 + bx16;
-            if (lane == 0)
-                *(uint32_t*)(chunk + a.originOff[1] + idx * 4) = (uint32_t)(uint16_t)(int16_t)ox | ((uint32_t)(uint16_t)(int16_t)oy << 16);
-            uint16_t* tab = (uint16_t*)(chunk + a.tableOff[1]) + idx * (kWin * kWin);
-            const int j = lane >> 2, i4 = (lane & 3) * 4;
-            const uint16_t* p = sSurf + ((size_t)b * D + (oy + S + j)) * D + (ox + S + i4);
-            uint16_t v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
-            *(uint2*)(tab + j * kWin + i4) = make_uint2((uint32_t)v0 | ((uint32_t)v1 << 16), (uint32_t)v2 | ((uint32_t)v3 << 16));
-        }
-    }
+    const auto& sOrg = sh.org;
     // level 0: the four 8x8 blocks of wave b's 16x16 block take their parent's window; their SADs are measured now, 4 vectors per lane (one row of
     // the window = 4 lanes): per source row two v_qsad_pk_u16_u8 on a 12-byte stretch of the reference row, brought to byte alignment with
     // v_alignbyte (the window's origin is arbitrary).  An 8x8 block whose parent is not inside the picture has no window: origin (-32768, -32768)
@@ -437,35 +505,140 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu_kernel(SurfArgs a)
             *(uint2*)(tab + j * kWin + i4) = make_uint2((uint32_t)acc, (uint32_t)(acc >> 32));
         }
     }
-    // level 2: group g, one entry per thread
+}
+
+// ---- the same kernel for 16-bit pictures (Main10 / Main12 builds) --------------------------------------------------------------------------
+// v_qsad_pk_u16_u8 is a byte instruction; 16-bit samples are measured with v_sad_u16 (two absolute differences per lane and instruction), and a 16x16
+// SAD no longer fits 16 bits, so the surface holds u32 — 16 x (2 S)^2 x 4 bytes: S <= 16 keeps it in LDS (64 KB).  The reference window is staged twice,
+// once as it is and once shifted by one sample, so that odd vectors read aligned dwords too.  A lane owns a 4 x 4 patch of vectors; the block's source
+// rows go through scalar registers eight at a time.  Decide and emit are the shared template.
+__global__ __launch_bounds__(1024) void sadsurf_ctu16_kernel(SurfArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ SsShared sh;
+
+    int jn = 0, rowIn = blockIdx.y;
+    while (jn + 1 < a.nJobs && rowIn >= a.job[jn].rows) { rowIn -= a.job[jn].rows; jn++; }
+    const SurfJob& jb = a.job[jn];
+    const int S = jb.S, D = 2 * S;
+    const int RWD = (64 + D) / 2 + 4;                            // window row pitch in dwords (two samples each): room for the last 9-dword read, even
+    uint32_t* sSrc = (uint32_t*)smem;                            // [64][32] dwords
+    uint32_t* sRefA = sSrc + 64 * 32;                            // [64 + D][RWD]: dword k = samples (2k, 2k + 1) of the window row
+    uint32_t* sRefB = sRefA + (64 + D) * RWD;                    // the same shifted by one sample: dword k = samples (2k + 1, 2k + 2)
+    uint32_t* sSurf = sRefB + (64 + D) * RWD;                    // [16][D][D]
+
+    const int cx = blockIdx.x, cy = jb.row0 + rowIn;
+    const int x0 = cx * 64, y0 = cy * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint16_t* src = (const uint16_t*)jb.src;
+    const uint16_t* ref = (const uint16_t*)a.ref;
+    const int64_t srcPitch = jb.srcPitch / 2;                    // samples
+
+    // ---- stage ----
+    for (int i = tid; i < 64 * 32; i += 1024)
     {
-        const int g = tid >> 8, t = tid & 255, gx = g & 1, gy = g >> 1;
-        if (x0 + gx * 32 + 32 <= a.picW && y0 + gy * 32 + 32 <= a.picH)
+        const int r = i >> 5, c2 = (i & 31) * 2;
+        uint32_t v = 0;
+        if (y0 + r < a.picH)
         {
-            const int ox = sOrg[2][g][0], oy = sOrg[2][g][1];
-            const int64_t idx = (int64_t)gy * a.blocksX[2] + cx * 2 + gx;
-            if (t == 0)
-                *(uint32_t*)(chunk + a.originOff[2] + idx * 4) = (uint32_t)(uint16_t)(int16_t)ox | ((uint32_t)(uint16_t)(int16_t)oy << 16);
-            const int j = t >> 4, i = t & 15, b0 = (gy * 2) * 4 + gx * 2;
-            const size_t c = (size_t)(oy + S + j) * D + (ox + S + i);
-            ((uint32_t*)(chunk + a.tableOff[2]))[idx * (kWin * kWin) + t] =
-                (uint32_t)sSurf[b0 * DD + c] + sSurf[(b0 + 1) * DD + c] + sSurf[(b0 + 4) * DD + c] + sSurf[(b0 + 5) * DD + c];
+            if (x0 + c2 < a.picW) v = src[(int64_t)(y0 + r) * srcPitch + x0 + c2];
+            if (x0 + c2 + 1 < a.picW) v |= (uint32_t)src[(int64_t)(y0 + r) * srcPitch + x0 + c2 + 1] << 16;
+        }
+        sSrc[r * 32 + c2 / 2] = v;
+    }
+    {
+        // positions outside the padded picture's buffer belong to illegal vectors only: the loads are clamped into the buffer (see the 8-bit kernel)
+        // (sample pairs start at even positions and the padded width is even: a pair is inside or outside as a whole; the third sample is clamped alone)
+        const int yMax = a.bufRows - a.marginY - 1, xEnd = a.picW + a.marginX;
+        for (int i = tid; i < (64 + D) * RWD; i += 1024)
+        {
+            const int r = i / RWD, k = i - r * RWD;
+            const int y = min(max(y0 - S + r, -a.marginY), yMax), x = min(max(x0 - S + 2 * k, -a.marginX), xEnd - 2);
+            const uint16_t* p = ref + (int64_t)y * a.refStride;
+            const uint32_t s0 = p[x], s1 = p[x + 1], s2 = p[min(x + 2, xEnd - 1)];
+            sRefA[r * RWD + k] = s0 | (s1 << 16);
+            sRefB[r * RWD + k] = s1 | (s2 << 16);
         }
     }
-    // level 3: threads 0..255
-    if (have3 && tid < 256)
+    if (tid < 32)
+        sh.vc[tid] = (uint32_t)((jb.lambda20 * (2 * tid + 2) + 10) / 20);
+    __syncthreads();
+
+    // ---- measure: wave b <-> 16x16 block b; a lane owns 4 x 4 vectors (16 u32 accumulators); source rows eight at a time in scalar registers ----
     {
-        const int ox = sOrg[3][0][0], oy = sOrg[3][0][1];
-        const int64_t idx = cx;
-        if (tid == 0)
-            *(uint32_t*)(chunk + a.originOff[3] + idx * 4) = (uint32_t)(uint16_t)(int16_t)ox | ((uint32_t)(uint16_t)(int16_t)oy << 16);
-        const int j = tid >> 4, i = tid & 15;
-        const size_t c = (size_t)(oy + S + j) * D + (ox + S + i);
-        uint32_t t = 0;
+        const int b = wave, bx = b & 3, by = b >> 2;
+        const bool inside = x0 + bx * 16 + 16 <= a.picW && y0 + by * 16 + 16 <= a.picH;
+        if (inside)
+        {
+            const int G = D / 4;
+            for (int item = lane; item < G * G; item += 64)
+            {
+                const int py4 = item / G, px4 = item - py4 * G;
+                uint32_t acc[4][4];
 #pragma unroll
-        for (int b = 0; b < 16; b++) t += sSurf[b * DD + c];
-        ((uint32_t*)(chunk + a.tableOff[3]))[idx * (kWin * kWin) + tid] = t;
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) acc[i][c] = 0;
+#pragma unroll 1
+                for (int h = 0; h < 2; h++)
+                {
+                    uint32_t s[8][8];
+#pragma unroll
+                    for (int r = 0; r < 8; r++)
+                    {
+                        const uint4 v0 = *(const uint4*)(sSrc + (by * 16 + 8 * h + r) * 32 + bx * 8), v1 = *(const uint4*)(sSrc + (by * 16 + 8 * h + r) * 32 + bx * 8 + 4);
+                        s[r][0] = __builtin_amdgcn_readfirstlane(v0.x); s[r][1] = __builtin_amdgcn_readfirstlane(v0.y);
+                        s[r][2] = __builtin_amdgcn_readfirstlane(v0.z); s[r][3] = __builtin_amdgcn_readfirstlane(v0.w);
+                        s[r][4] = __builtin_amdgcn_readfirstlane(v1.x); s[r][5] = __builtin_amdgcn_readfirstlane(v1.y);
+                        s[r][6] = __builtin_amdgcn_readfirstlane(v1.z); s[r][7] = __builtin_amdgcn_readfirstlane(v1.w);
+                    }
+                    const int base = (by * 16 + 8 * h + 4 * py4) * RWD + bx * 8 + 2 * px4;
+#pragma unroll
+                    for (int j = 0; j < 11; j++)
+                    {
+                        const uint32_t* pa = sRefA + base + j * RWD;
+                        const uint32_t* pb = sRefB + base + j * RWD;
+                        uint32_t da[9], db[9];
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                        {
+                            const uint2 va = *(const uint2*)(pa + 2 * k), vb = *(const uint2*)(pb + 2 * k);
+                            da[2 * k] = va.x; da[2 * k + 1] = va.y; db[2 * k] = vb.x; db[2 * k + 1] = vb.y;
+                        }
+                        da[8] = pa[8]; db[8] = pb[8];
+#pragma unroll
+                        for (int dyo = 0; dyo < 4; dyo++)
+                        {
+                            const int r = j - dyo;
+                            if (r < 0 || r > 7)
+                                continue;
+#pragma unroll
+                            for (int k = 0; k < 8; k++)
+                            {
+                                acc[dyo][0] = __builtin_amdgcn_sad_u16(da[k], s[r][k], acc[dyo][0]);
+                                acc[dyo][1] = __builtin_amdgcn_sad_u16(db[k], s[r][k], acc[dyo][1]);
+                                acc[dyo][2] = __builtin_amdgcn_sad_u16(da[k + 1], s[r][k], acc[dyo][2]);
+                                acc[dyo][3] = __builtin_amdgcn_sad_u16(db[k + 1], s[r][k], acc[dyo][3]);
+                            }
+                        }
+                    }
+                }
+                uint32_t* o = sSurf + ((size_t)b * D + 4 * py4) * D + 4 * px4;
+#pragma unroll
+                for (int dyo = 0; dyo < 4; dyo++)
+                    *(uint4*)(o + dyo * D) = make_uint4(acc[dyo][0], acc[dyo][1], acc[dyo][2], acc[dyo][3]);
+            }
+        }
     }
+    __syncthreads();
+
+    ss_decide_emit<uint32_t>(a, jb, sSurf, sh, S, x0, y0, cx, cy);
+}
+
+static size_t surf16_lds_bytes(int S)
+{
+    const int D = 2 * S, RWD = (64 + D) / 2 + 4;
+    return (size_t)64 * 32 * 4 + (size_t)2 * (64 + D) * RWD * 4 + (size_t)16 * D * D * 4;
 }
 
 static size_t surf_lds_bytes(int S)
@@ -558,7 +731,7 @@ static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& li
                 SurfJob& j = a.job[a.nJobs];
                 j.src = (const uint8_t*)ss->src->dLuma; j.srcPitch = ss->src->pitch;
                 j.out = ss->dBuf; j.S = ss->S; j.lambda20 = ss->lambda20; j.row0 = ss->rowsBuilt; j.rows = r1 - ss->rowsBuilt;
-                j.level0 = ss->levels & 1;
+                j.level0 = (ss->levels & 1) && rp->depth == 8;
                 in[a.nJobs] = ss; upto[a.nJobs] = r1;
                 rows += j.rows;
                 if (ss->S > maxS) maxS = ss->S;
@@ -587,7 +760,7 @@ static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& li
                 pushed = true;
             }
             const SurfLayout& lay = in[0]->lay;               // same picture size: same layout
-            a.ref = (const uint8_t*)dPic + (size_t)rp->marginY * rp->stride + rp->marginX; a.refStride = rp->stride;
+            a.ref = (const uint8_t*)dPic + ((size_t)rp->marginY * rp->stride + rp->marginX) * rp->B; a.refStride = rp->stride;        // stride in samples
             a.picW = rp->picW; a.picH = rp->picH; a.marginX = rp->marginX; a.marginY = rp->marginY; a.bufRows = rp->bufRows;
             a.pitch = lay.pitch;
             for (int l = 0; l < 4; l++) { a.originOff[l] = lay.originOff[l]; a.tableOff[l] = lay.tableOff[l]; a.blocksX[l] = lay.blocksX[l]; }
@@ -596,7 +769,8 @@ static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& li
             static std::atomic<uint64_t> attrSet{ 0 };
             if (!(attrSet.load() >> dev & 1))
             {
-                if (hipFuncSetAttribute((const void*)sadsurf_ctu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)surf_lds_bytes(32)) != hipSuccess)
+                if (hipFuncSetAttribute((const void*)sadsurf_ctu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)surf_lds_bytes(32)) != hipSuccess ||
+                    hipFuncSetAttribute((const void*)sadsurf_ctu16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)surf16_lds_bytes(16)) != hipSuccess)
                 {
                     set_error(X265HIP_EHIP, "sadsurf: cannot raise the dynamic LDS limit");
                     rp->failed = 1;
@@ -607,16 +781,19 @@ static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& li
             }
             // the launch between two events of its own stream: the kernel's device time (x265hip_device_time, x265hip_sadsurf_stats)
             DevSpan span(X265HIP_CLK_SADSURF, st);
-            hipLaunchKernelGGL(sadsurf_ctu_kernel, dim3(lay.ctuCols, rows), dim3(1024), surf_lds_bytes(maxS), st, a);
+            if (rp->depth == 8)
+                hipLaunchKernelGGL(sadsurf_ctu_kernel, dim3(lay.ctuCols, rows), dim3(1024), surf_lds_bytes(maxS), st, a);
+            else
+                hipLaunchKernelGGL(sadsurf_ctu16_kernel, dim3(lay.ctuCols, rows), dim3(1024), surf16_lds_bytes(maxS), st, a);
             bool bad = hipGetLastError() != hipSuccess;
             span.end();
             for (int k = 0; k < a.nJobs; k++)
             {
-                // one W x H block over an R x R window = W H B + (W + R - 1)(H + R - 1) B + 4 R^2 (B = 1, R = 2 S), per block built
+                // one W x H block over an R x R window = W H B + (W + R - 1)(H + R - 1) B + 4 R^2 (R = 2 S), per block built
                 const int64_t R = 2 * a.job[k].S;
                 for (int l = 1; l < 4; l++)
                 {
-                    const int64_t N = 8 << l, unit = N * N + (N + R - 1) * (N + R - 1) + 4 * R * R;
+                    const int64_t N = 8 << l, unit = (N * N + (N + R - 1) * (N + R - 1)) * rp->B + 4 * R * R;
                     int blockRows = 0;
                     for (int r = a.job[k].row0; r < a.job[k].row0 + a.job[k].rows; r++)
                         for (int j = 0; j < lay.per[l]; j++)
@@ -742,14 +919,14 @@ x265hip_srcpic* x265hip_srcpic_create_at(int place, int depth, int width, int he
 
 static x265hip_srcpic* srcpic_create(int place, int depth, int width, int height)
 {
-    if (depth != 8 || width < 16 || height < 16 || width > 16384 || height > 16384)
+    if (!valid_depth(depth) || width < 16 || height < 16 || width > 16384 || height > 16384)
     {
-        set_error(X265HIP_EINVAL, "x265hip_srcpic_create: depth %d %dx%d (8-bit pictures only)", depth, width, height);
+        set_error(X265HIP_EINVAL, "x265hip_srcpic_create: depth %d %dx%d", depth, width, height);
         return nullptr;
     }
     x265hip_srcpic* sp = new x265hip_srcpic;
     sp->depth = depth; sp->w = width; sp->h = height;
-    sp->pitch = (width + 255) & ~255;
+    sp->pitch = ((int64_t)width * (depth == 8 ? 1 : 2) + 255) & ~(int64_t)255;
     (void)hipGetDevice(&sp->device);
     sp->place = place;
     const size_t bytes = (size_t)sp->pitch * height;
@@ -770,8 +947,9 @@ int x265hip_srcpic_upload(x265hip_srcpic* sp, const void* hostLuma, int64_t stri
     const bool had = hipGetDevice(&cur) == hipSuccess;
     int e = check_hip(hipSetDevice(sp->device), "hipSetDevice");
     if (e) return e;
+    const size_t B = sp->depth == 8 ? 1 : 2;                 // `stride` counts samples, like every stride of the ABI
     for (int y = 0; y < sp->h; y++)
-        memcpy(sp->hStage + (size_t)y * sp->pitch, (const char*)hostLuma + (size_t)y * stride, sp->w);
+        memcpy(sp->hStage + (size_t)y * sp->pitch, (const char*)hostLuma + (size_t)y * stride * B, sp->w * B);
     if (!(e = check_hip(hipMemcpyAsync(sp->dLuma, sp->hStage, (size_t)sp->pitch * sp->h, hipMemcpyHostToDevice, sp->st), "srcpic h2d")))
         e = check_hip(hipStreamSynchronize(sp->st), "srcpic sync");
     if (had && cur != sp->device) (void)hipSetDevice(cur);
@@ -799,15 +977,15 @@ x265hip_sadsurf* x265hip_sadsurf_attach(x265hip_srcpic* src, x265hip_refpic* ref
 x265hip_sadsurf* x265hip_sadsurf_attach_levels(x265hip_srcpic* src, x265hip_refpic* ref, int searchRange, int lambda20, int levels)
 {
     if (ensure_device()) return nullptr;
-    if (!src || !ref || src->depth != 8 || ref->depth != 8 || src->w != ref->picW || src->h != ref->picH || searchRange < 8 || searchRange > 32 || (searchRange & 3) ||
-        lambda20 < 0 || lambda20 > (1 << 20) || ref->marginX < searchRange + 8 || ref->marginY < searchRange || (levels & ~15) || (levels & 14) != 14)
+    if (!src || !ref || src->depth != ref->depth || src->w != ref->picW || src->h != ref->picH || searchRange < 8 || searchRange > (src->depth == 8 ? 32 : 16) || (searchRange & 3) ||
+        lambda20 < 0 || lambda20 > (1 << 20) || ref->marginX < searchRange + 8 || ref->marginY < searchRange || (levels & ~15) || (levels & 14) != 14 || ((levels & 1) && src->depth != 8))
     {
-        set_error(X265HIP_EINVAL, "x265hip_sadsurf_attach: pictures do not match, or range %d / lambda %d / margins out of bounds", searchRange, lambda20);
+        set_error(X265HIP_EINVAL, "x265hip_sadsurf_attach: pictures do not match, or range %d (8..32 for 8-bit pictures, 8..16 for 16-bit ones) / lambda %d / margins out of bounds", searchRange, lambda20);
         return nullptr;
     }
     x265hip_sadsurf* ss = new x265hip_sadsurf;
     ss->src = src; ss->ref = ref; ss->S = searchRange; ss->lambda20 = lambda20; ss->levels = levels;
-    layout_for(src->w, src->h, 8, levels, ss->lay);
+    layout_for(src->w, src->h, src->depth, levels, ss->lay);
     ss->bytes = (size_t)ss->lay.pitch * ss->lay.ctuRows;
     {
         std::lock_guard<std::mutex> g(g_poolLock);

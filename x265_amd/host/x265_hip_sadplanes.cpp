@@ -184,8 +184,13 @@ bool decide()
         if (g_range < 8) g_range = 8;
         if (g_range > 32) g_range = 32;
         g_range &= ~3;
-        // 8-bit builds only for now: the search-window kernel is built on v_qsad_pk_u16_u8
-        if ((env && !strcmp(env, "0")) || (all && !strcmp(all, "0")) || (table && !strcmp(table, "percall")) || X265_DEPTH != 8 || !g_levels ||
+        // 16-bit builds (Main10 / Main12): the device keeps a CTU's u32 surface in LDS up to a range of 16, and has no 8x8 level
+        if (X265_DEPTH != 8)
+        {
+            if (g_range > 16) g_range = 16;
+            g_levels &= 14;
+        }
+        if ((env && !strcmp(env, "0")) || (all && !strcmp(all, "0")) || (table && !strcmp(table, "percall")) || !g_levels ||
             x265hip_device_count() < 1)
             g_state = -1;
         else
