@@ -53,3 +53,39 @@ def test_bench_parallel_cpu_baseline_leg_runs_and_is_bounded():
     assert r["cores"] == 2 and r["value"] > 0 and r["kind"] == "port"
     assert time.time() - t0 < 90
 
+
+
+def test_bench_parses_the_encoders_ledger_lines_and_matches_profiles_by_source_hash(tmp_path, monkeypatch):
+    """bench.py prices its roofline blocks from the X265HIP_VERBOSE lines of the timed encode (x265_amd/host/*.cpp) and quotes PMC traffic only from a
+    committed profile whose `# sources` stamp equals the sha256 of the tree's kernel sources."""
+    import bench
+    lines = [
+        "x265hip: lookahead: 2362 frame-cost estimates (556 motion-search passes over 120 lowres frames) served by the GPU in 603 batches, 0.236 s inside the seam",
+        "x265hip: lookahead: 504 searches launched ahead of their request, 399 of them used; 30 search launches of 35.3 (frame, reference) pairs on average",
+        "x265hip: sadplanes: 7998027 integer-pel SADs of the motion search served from GPU-built SAD surfaces (436 surfaces, 7412 CTU rows in 1322 launches, 88.648 ms of device time), "
+        "3836338 of the same searches outside their block's window and 1344 searches without a surface computed on the host",
+        "x265hip: device time (HIP events around every launch group): lookahead searches 40.355 ms in 30 launch groups (0 algorithmic bytes), other lookahead kernels 23.703 ms in 603 "
+        "launch groups (0 algorithmic bytes), sub-pel plane bands 14.269 ms in 1173 launch groups (2861709312 algorithmic bytes), SAD surfaces 88.648 ms in 1322 launch groups "
+        "(110688584400 algorithmic bytes), source energy planes 4.132 ms in 360 launch groups (0 algorithmic bytes); total 171.107 ms",
+    ]
+    s = bench.parse_served(lines)
+    assert s["surfaces"] == 436 and s["ctu_rows"] == 7412 and s["surface_launches"] == 1322
+    assert s["search_launches"] == 30 and abs(s["pairs_per_launch"] - 35.3) < 1e-9
+    assert abs(s["device_ms"] - 171.107) < 1e-9
+    assert s["clocks"]["SAD surfaces"] == {"ms": 88.648, "launch_groups": 1322, "algorithmic_bytes": 110688584400}
+    assert s["clocks"]["sub-pel plane bands"]["algorithmic_bytes"] == 2861709312
+    # 7412 rows of 30 CTUs at 508 437 bytes, minus the blocks of the ragged last row (1080 = 16 * 64 + 56): the ledger's figure is the library's
+    assert 0.95 < s["clocks"]["SAD surfaces"]["algorithmic_bytes"] / (7412 * 30 * 508437.0) <= 1.0
+
+    # profile matching: stamp equal -> quoted, stamp different -> not quoted, and says why
+    digest = bench.source_digest("sadsurf.hip")
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    body = ("# sources sadsurf.hip %s\n# fetch_correction 2.000 write_correction 1.000 (x); per-launch averages in KiB, raw and corrected\n"
+            "xh::sadsurf_ctu_kernel   522240   16   8577.6   6588.8   17155.1   6588.8\n")
+    (prof / "r99_v1_pmc_sadsurf.txt").write_text(body % digest)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    val, f, note = bench.pmc_profile("r*_pmc_sadsurf.txt", "sadsurf_ctu_kernel", digest)
+    assert val == int((17155.1 + 6588.8) * 1024) and f.endswith("r99_v1_pmc_sadsurf.txt") and "fetch_correction" in note
+    val, f, note = bench.pmc_profile("r*_pmc_sadsurf.txt", "sadsurf_ctu_kernel", "0" * 16)
+    assert val is None and "not quoted" in note
