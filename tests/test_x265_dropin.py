@@ -140,7 +140,8 @@ def test_baseline_configs_encode_byte_identical_through_the_seams(name):
     bits, w, h, frames, preset, extra = BASELINE_ENCODES[name]
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import encode_fps
-    r = encode_fps.measure(frames=frames, width=w, height=h, bits=bits, preset=preset, extra=extra, seed=31)
+    # the Main10 configuration is fed 10-bit samples (BASELINE.json configs[3] is a 10-bit encode of 10-bit material)
+    r = encode_fps.measure(frames=frames, width=w, height=h, bits=bits, preset=preset, extra=extra, seed=31, input_depth=10 if bits == 10 else 8)
     if "error" in r and "not built" in r["error"]:
         pytest.skip(r["error"])
     assert "error" not in r, r

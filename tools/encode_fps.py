@@ -30,15 +30,16 @@ def _run(exe, args, out, env=None, timeout=1200):
     return {"rc": p.returncode, "fps": fps, "wall_s": round(wall, 2), "served": served, "tail": log[-400:] if p.returncode else ""}
 
 
-def measure(frames=60, width=1920, height=1080, bits=8, preset="medium", extra=("--me", "hex"), seed=4321, keep=False, clip=None, repeat=1):
+def measure(frames=60, width=1920, height=1080, bits=8, preset="medium", extra=("--me", "hex"), seed=4321, keep=False, clip=None, repeat=1, input_depth=8):
+    """input_depth 10: the clip holds 16-bit little-endian samples with 10 significant bits (PicYuv::copyFromPicture takes its 16-bit path; Main10 / Main12 builds)."""
     ref, hip = os.path.join(REF, "x265_%dbit" % bits), os.path.join(REF, "x265_hip_%dbit" % bits)
     if not (os.path.exists(ref) and os.path.exists(hip)):
         return {"error": "oracle/_ref/x265_%dbit / x265_hip_%dbit not built (make -C oracle ref hip where /root/reference exists)" % (bits, bits)}
     from x265_amd.synth import make_clip
-    path = clip or "/tmp/x265hip_clip_%dx%d_%d_%d.yuv" % (width, height, frames, seed)
+    path = clip or "/tmp/x265hip_clip_%dx%d_%d_%d_d%d.yuv" % (width, height, frames, seed, input_depth)
     if not os.path.exists(path):
-        make_clip(path, width, height, frames, seed=seed)
-    args = ["--input", path, "--input-res", "%dx%d" % (width, height), "--input-depth", "8", "--fps", "30", "--frames", str(frames), "--preset", preset,
+        make_clip(path, width, height, frames, seed=seed, depth=input_depth)
+    args = ["--input", path, "--input-res", "%dx%d" % (width, height), "--input-depth", str(input_depth), "--fps", "30", "--frames", str(frames), "--preset", preset,
             "--hash", "1"] + list(extra)
     o_ref, o_hip = "/tmp/x265hip_ref_%d.hevc" % os.getpid(), "/tmp/x265hip_gpu_%d.hevc" % os.getpid()
     res = {"clip": "%dx%d %d-bit-encode, %d synthetic frames (make_clip seed %d)" % (width, height, bits, frames, seed), "cmd": " ".join(args[2:]),
