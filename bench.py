@@ -591,6 +591,16 @@ def sadsurf_probe(np_mod):
     return r
 
 
+def host_cpu_quota():
+    """CPUs the container may use: the cgroup-v2 quota (cpu.max: "<quota> <period>" or "max ...") — on the MI355X box 16 of the 256 cores the kernel shows.
+    None when there is no quota."""
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(float(q) / float(period), 2)
+    except (OSError, ValueError):
+        return None
+
+
 def source_digest(*names):
     """sha256 over kernel sources: profiles/ files carry it, and a profile is only quoted when it was collected from the sources of this tree"""
     import hashlib
@@ -804,7 +814,9 @@ def main():
                                    "served from GPU-built fractional planes of each reference picture, psy-cost source halves from GPU-built energy planes, C slots "
                                    "otherwise; the host cores are split between the ranks" % (enc["frames"], CHUNK),
                        "frames_per_step": world * CHUNK, "encoder_cli_fps_rank0": enc["cli_fps"], "served_by_gpu": enc["served"],
-                       "host_cores": os.cpu_count(), "pool_threads_per_encoder": enc["pools"], "timed_s": round(dt, 2)},
+                       "host_cores": os.cpu_count(), "host_cpu_quota": host_cpu_quota(), "pool_threads_per_encoder": enc["pools"], "timed_s": round(dt, 2),
+                       "host_note": "host_cpu_quota = CPUs the container's cgroup grants (cpu.max); when it is far below host_cores both encoders are bound by CPU seconds per "
+                                    "frame and N encoders share the same budget (DESIGN.md §4c)"},
             "roofline": dominant,
             "rooflines": others,
             "gpu_duty_cycle": {"device_ms": served.get("device_ms"), "timed_s": round(dt, 2),
@@ -816,7 +828,11 @@ def main():
         if "reference" in enc:
             r0 = enc["reference"]
             ref_fps = world * enc["frames"] / r0["wall_s"] if r0["wall_s"] else None
-            out["cpu_baseline"] = {"value": round(ref_fps, 3) if ref_fps else None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "reference",
+            quota = host_cpu_quota()
+            out["cpu_baseline"] = {"value": round(ref_fps, 3) if ref_fps else None, "unit": "frames/s",
+                                   "cores": int(min(os.cpu_count() or 1, quota)) if quota else os.cpu_count(), "kind": "reference",
+                                   "cores_note": "CPUs the process tree can use at once: min(cores the kernel shows = %s, cgroup quota = %s); x265 starts one pool thread per shown core"
+                                                 % (os.cpu_count(), quota),
                                    "sample": "the same %d chunk(s) of %d frames, same arguments (and the same --pools share at N > 1), through oracle/_ref/x265_8bit — the unmodified "
                                              "reference, [noasm] C primitives: no nasm in the image, so the AVX2 / AVX-512 path cannot be built — %d encoder(s) at the same time, "
                                              "measured like `value`: all frames / wall clock between two fences (%.1f s)" % (world, enc["frames"], world, r0["wall_s"]),
