@@ -585,9 +585,18 @@ def sadsurf_probe(np_mod):
     import sadsurf_bench as sb
     import x265_amd.hipprim as hp
     L = hp.lib()
+    def planes_clock():
+        v = [C.c_uint64() for _ in range(3)]
+        L.x265hip_device_time(2, C.byref(v[0]), C.byref(v[1]), C.byref(v[2]))          # X265HIP_CLK_PLANES
+        return [x.value for x in v]
     buf, stride, rows, srcs = sb.pictures(W, H, 2, 4321)
+    sb.run_mode(hp, L, "frame", W, H, 1, 32, 1, buf, stride, rows, srcs[:1])           # warm-up: kernels loaded, buffers pooled
+    p0 = planes_clock()
     r = sb.run_mode(hp, L, "frame", W, H, 2, 32, 4, buf, stride, rows, srcs)
+    p1 = planes_clock()
     r["algorithmic_bytes_per_ctu"] = sb.unit_bytes(32)
+    # in frame mode the whole reference picture becomes final at once: the sub-pel plane kernel runs over a whole padded picture per repetition
+    r["planes"] = {"spans": p1[0] - p0[0], "ns": p1[1] - p0[1], "bytes": p1[2] - p0[2]}
     return r
 
 
@@ -740,7 +749,7 @@ def main():
                                        "note": "what the kernel must move: source CTU + reference window in, windows and origins out"},
                         "valu_sad": {"abs_diff_per_s_T": round(ctus * 16 * 4096 * 256 / secs / 1e12, 2), "ceiling_T": 95.2,
                                      "ceiling_note": "v_qsad_pk_u16_u8 issue rate of the whole chip measured by tools/micro/qsad_rate (profiles/r03_v2_sadsurf_kernel.txt)"}}
-        probe_block = None
+        probe_block, planes_probe = None, None
         try:
             pr = sadsurf_probe(np)
             secs = pr["kernel_ns"] * 1e-9
@@ -750,6 +759,14 @@ def main():
                            "traffic_source": ss_tfile, "traffic_note": ss_tnote,
                            "algorithmic_bytes_per_launch": int(pr["ctus_per_launch"] * pr["algorithmic_bytes_per_ctu"]), "launch_ms": round(pr["us_per_launch"] * 1e-3, 5),
                            "valu_sad": {"abs_diff_per_s_T": round(pr["ctus"] * 16 * 4096 * 256 / secs / 1e12, 2), "ceiling_T": 95.2}}
+            pp = pr.get("planes") or {}
+            if pp.get("spans") and pp.get("ns"):
+                psecs = pp["ns"] * 1e-9
+                planes_probe = {"bound": "hbm", "kernel": "subpel_planes8_kernel on whole padded 1080p pictures (%d launches inside the same probe): bytes = rows x padded width x (1 picture + 15 "
+                                                          "phase planes)" % pp["spans"],
+                                "achieved": round(pp["bytes"] / psecs / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(pp["bytes"] / psecs / 1e9 / HBM_PEAK_GBPS, 5),
+                                "traffic": None, "algorithmic_bytes_per_launch": int(pp["bytes"] / pp["spans"]), "launch_ms": round(pp["ns"] / pp["spans"] * 1e-6, 5),
+                                "launch_ms_note": "HIP events around each launch (x265hip_device_time), after a warm-up repetition"}
         except Exception as e:  # noqa: BLE001
             probe_block = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         # ---- lookahead searches: live in the encode, and the probe at the encode's launch size ---------------------------------------------------------
@@ -802,7 +819,7 @@ def main():
         named = [(ss.get("ms", 0.0), ss_block), (la.get("ms", 0.0), la_live)]
         named = [b for _, b in sorted(named, key=lambda t: -t[0]) if b]
         dominant = named[0] if named else la_probe
-        others = [b for b in (ss_block, probe_block, la_live, la_probe, pl_block) if b and b is not dominant]
+        others = [b for b in (ss_block, probe_block, la_live, la_probe, pl_block, planes_probe) if b and b is not dominant]
         out = {
             "metric": "encode fps (1080p preset medium)", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 3),
