@@ -1,4 +1,6 @@
 #!/bin/bash
+# (experiment of round 3: an opt-in _exit() at the end of the bindings' exit handlers; wall - CLI time 0.55 s either way, so the switch was removed again —
+# the script stays as the record of how profiles/r03_v5_exit_experiment.txt was produced)
 set -u
 python3 -c "
 import sys; sys.path.insert(0, '.')
