@@ -73,7 +73,8 @@ int  x265hip_peer_stats(uint64_t* replicas, uint64_t* bands, uint64_t* bytes);  
 #define X265HIP_CLK_PLANES     2   /* sub-pel plane bands of the reference-picture mirrors                                             */
 #define X265HIP_CLK_SADSURF    3   /* search-window kernel of the SAD surfaces                                                         */
 #define X265HIP_CLK_ENERGY     4   /* source energy planes                                                                             */
-#define X265HIP_CLK_COUNT      5
+#define X265HIP_CLK_CUSERVE    5   /* CU residual quad-tree jobs (x265hip_cuserve_*)                                                   */
+#define X265HIP_CLK_COUNT      6
 /* algorithmicBytes: SURVEY.md §8d bytes of the work inside the spans where the module can state them itself — SAD surfaces: per block of a built CTU
  * the exhaustive search's unique footprint W H B + (W + R - 1)(H + R - 1) B + 4 R^2 (R = 2 searchRange); plane bands: rows x (padded width) x
  * (1 picture + 15 phase planes) x B; 0 for the other clocks (bench.py prices the lookahead searches per 8x8 block from its own count). */
@@ -813,6 +814,94 @@ int x265hip_call_intra_allangs(int depth, int n, void* dest, const void* line, c
 int x265hip_call_intra_filter(int depth, int n, const void* line, void* filtered);
 int x265hip_call_frame_init_lowres(int depth, const void* src, int64_t srcStride, void* dst0, void* dstH, void* dstV, void* dstC,
                                    int64_t dstStride, int width, int height);
+
+/* ---------------------------------------------------------------- CU residual quad-tree jobs ----------------------- */
+/* One job = the transform arithmetic of one inter CU's residual quad-tree, everything Search::estimateResidualQT (reference
+ * source/encoder/search.cpp:3178-3560) asks of Quant::transformNxN (common/quant.cpp:397-470: cu[].dct -> quant -> signBitHidingHDQ
+ * :246-395) and Quant::invtransformNxN (:543-603: dequant_normal -> cu[].idct) for the luma transform sizes 32 and 16 the tree may
+ * try (4:2:0 chroma 16 and 8), plus the two sse_pp distortions of every unit (search.cpp:3269, :3295).  The caller (x265_amd/host/
+ * x265_hip_cuserve.cpp) keeps the entropy coder and every decision.  Jobs travel through mailbox SLOTS in page-locked host memory
+ * that the device reads and writes directly: the caller fills the slot's job header and pixel block, submits, and polls the
+ * per-unit `ready` words (each unit is published as soon as it is done: luma first).  Flat quantiser only (no scaling lists), no
+ * transform skip, no transquant bypass, no noise reduction, no RDOQ: the caller does not submit such CUs.
+ *
+ * Pixel block: source Y (N x N, N = 1 << log2CUSize), source Cb, Cr (N/2 x N/2 each, 4:2:0; absent when chroma == 0), then the
+ * prediction in the same order; rows contiguous; elements uint8_t (bitDepth 8) or uint16_t.
+ * Levels: luma transform sizes s from sHi = min(5, log2TrMax, log2CUSize) down to sLo = max(4, log2TrMin); no level when sHi < sLo.
+ * Units of a level: plane 0 (Y), then 1 (Cb), 2 (Cr); within a plane raster order of the (N >> s)^2 units. */
+typedef struct x265hip_cujob
+{
+    uint32_t log2CUSize;          /* 4..6 */
+    uint32_t log2TrMax, log2TrMin;/* the luma transform sizes the tree may try (Search::estimateResidualQT's depthRange, largest first) */
+    uint32_t chroma;              /* 1: 4:2:0 Cb and Cr blocks are part of the job */
+    uint32_t bitDepth;            /* 8, 10, 12 */
+    uint32_t quantOffset;         /* 171 (I slice) or 85: quant.cpp:466 `add = offset << (qbits - 9)` */
+    uint32_t signHide;            /* pps->bSignHideEnabled: signBitHidingHDQ runs on units with numSig >= 2 */
+    uint32_t reserved;
+    int32_t  qpRem[3], qpPer[3];  /* Quant::m_qpParam[Y, Cb, Cr] */
+    int32_t  quantScale[3];       /* the flat m_quantCoef entry of each plane's rem (scalinglist.cpp:386) */
+    int32_t  dequantScale[3];     /* s_invQuantScales[rem] (scalinglist.cpp:130); dequant_normal's scale = dequantScale << per */
+} x265hip_cujob;
+typedef struct x265hip_cujob_unit
+{
+    uint32_t ready;               /* == the job's sequence number once this unit's numSig / distortions / levels / residual are in place */
+    uint32_t numSig;              /* transformNxN's return value (after sign-bit hiding) */
+    uint64_t zeroDist;            /* sse_pp(source, prediction) */
+    uint64_t codedDist;           /* sse_pp(source, clip(prediction + reconstructed residual)); defined when numSig != 0 */
+    uint64_t reserved;
+} x265hip_cujob_unit;
+#define X265HIP_CUJOB_MAX_UNITS   60                       /* 64x64, sizes 32 + 16: 3 * (4 + 16) */
+#define X265HIP_CUJOB_MAX_ELEMS   (2 * 6144)               /* int16 entries of `levels` (and of `resi`) of the largest job */
+#define X265HIP_CUJOB_PIXEL_BYTES (2 * 6144 * 2)           /* source + prediction of a 64x64 4:2:0 CU at 16 bit */
+/* inline layout helpers (x265hipi_*: not exported symbols) shared by the library, the bindings and the checkers */
+#if defined(__HIPCC__)
+#define X265HIP_HD __host__ __device__
+#else
+#define X265HIP_HD
+#endif
+X265HIP_HD static inline int x265hipi_cujob_levels(const x265hip_cujob* j, int* sHi, int* sLo)
+{
+    int hi = j->log2TrMax < 5 ? (int)j->log2TrMax : 5, lo = j->log2TrMin > 4 ? (int)j->log2TrMin : 4;
+    if (hi > (int)j->log2CUSize) hi = (int)j->log2CUSize;
+    *sHi = hi; *sLo = lo;
+    return hi - lo + 1;
+}
+/* index of unit (s, plane, tuX, tuY) in the slot's `units` array; s = log2 of the LUMA transform size of the level */
+X265HIP_HD static inline int x265hipi_cujob_unit_index(const x265hip_cujob* j, int sHi, int s, int plane, int tuX, int tuY)
+{
+    const int planes = j->chroma ? 3 : 1;
+    int base = 0;
+    for (int k = sHi; k > s; k--)
+        base += planes << (2 * ((int)j->log2CUSize - k));
+    const int n = 1 << ((int)j->log2CUSize - s);
+    return base + plane * n * n + tuY * n + tuX;
+}
+/* offset (int16 entries) of the same unit's block in the slot's `levels` and `resi` arrays: (size of the unit)^2 entries, rows contiguous */
+X265HIP_HD static inline int x265hipi_cujob_elem_offset(const x265hip_cujob* j, int sHi, int s, int plane, int tuX, int tuY)
+{
+    const int N2 = 1 << (2 * (int)j->log2CUSize), n = 1 << ((int)j->log2CUSize - s);
+    const int perLevel = j->chroma ? N2 + N2 / 2 : N2;
+    const int t = tuY * n + tuX;
+    int off = (sHi - s) * perLevel;
+    if (plane == 0) return off + (t << (2 * s));
+    off += N2 + (plane == 2 ? N2 / 4 : 0);
+    return off + (t << (2 * (s - 1)));
+}
+typedef struct x265hip_cuserve x265hip_cuserve;
+/* mode 0: a resident server kernel per slot group polls the slots' doorbells (started on demand, ends by itself after `idle
+ * microseconds` without work so that nothing in the process ever waits on it for long); mode 1: one launch per job on the slot's own
+ * stream.  Either way completion is signalled through the units' `ready` words, never through a stream synchronisation. */
+int x265hip_cuserve_open(int slots, int mode, x265hip_cuserve** out);
+int x265hip_cuserve_close(x265hip_cuserve* cs);
+/* the slot's memory: the caller writes *job and *pixels, reads units / levels / resi */
+int x265hip_cuserve_slot(x265hip_cuserve* cs, int slot, x265hip_cujob** job, void** pixels, const x265hip_cujob_unit** units,
+                         const int16_t** levels, const int16_t** resi);
+/* hands the slot's job to the device; *seq = the value the units' `ready` words take */
+int x265hip_cuserve_submit(x265hip_cuserve* cs, int slot, uint32_t* seq);
+/* to be called now and then by a caller that is still waiting (mode 0: restarts a server that has gone idle meanwhile); returns
+ * X265HIP_EHIP when the device reported a failure: the caller gives up the job and computes on the host */
+int x265hip_cuserve_poke(x265hip_cuserve* cs, int slot);
+int x265hip_cuserve_stats(x265hip_cuserve* cs, uint64_t* jobs, uint64_t* serverStarts, uint64_t* deviceNs);
 
 #ifdef __cplusplus
 }

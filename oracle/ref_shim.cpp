@@ -26,6 +26,9 @@
 #include "constants.h"
 #include "contexts.h"
 #include "cudata.h"
+#include "scalinglist.h"
+#include "entropy.h"
+#include "quant.h"
 
 using namespace X265_NS;
 
@@ -1048,4 +1051,88 @@ int ref_cutree_propagate(pixel* pic, intptr_t stride, int w, int h, int marginX,
     return ret;
 }
 
+
+/* ---- the real Quant::transformNxN / ::invtransformNxN (common/quant.cpp:397-470, :543-603) on an inter unit: a Quant object with flat
+ * quantiser matrices (ScalingList::setupQuantMatrices with m_bEnabled = false), RDOQ and noise reduction off, a one-partition inter CUData
+ * whose slice is I (sliceI: rounding offset 171) or P (85) and whose PPS enables sign hiding or not.  qp: the QpParam value of the plane
+ * (Quant::m_qpParam[ttype].setQpParam argument, i.e. qp + QP_BD_OFFSET).  resiDct (may be NULL) receives Quant::m_resiDctCoeff. */
+namespace {
+struct QuantProbe : public Quant                 /* the fields are protected */
+{
+    void plain() { m_rdoqLevel = 0; m_nr = NULL; }
+    void setQp(int ttype, int qp) { m_qpParam[ttype].setQpParam(qp); }
+    const int16_t* resiDct() const { return m_resiDctCoeff; }
+};
+struct QuantRig
+{
+    ScalingList sl;
+    Entropy entropy;
+    QuantProbe q;
+    bool ok;
+    QuantRig()
+    {
+        T();
+        ok = sl.init();
+        sl.m_bEnabled = false;
+        sl.m_bDataPresent = false;
+        sl.setupQuantMatrices(X265_CSP_I420);
+        ok = ok && q.init(0.0, sl, entropy);
+        q.plain();
+    }
+};
+QuantRig& rig() { static QuantRig r; return r; }
+struct InterCU
+{
+    CUData cu;
+    Slice slice;
+    unsigned char ppsRaw[sizeof(PPS)];
+    uint8_t tqBypass[256], predMode[256];
+    InterCU(int sliceI, int signHide)
+    {
+        memset(ppsRaw, 0, sizeof(ppsRaw));
+        PPS& pps = *reinterpret_cast<PPS*>(ppsRaw);
+        pps.bSignHideEnabled = !!signHide;
+        slice.m_pps = &pps;
+        slice.m_sliceType = sliceI ? I_SLICE : P_SLICE;
+        memset(tqBypass, 0, sizeof(tqBypass));
+        memset(predMode, MODE_INTER, sizeof(predMode));
+        cu.m_slice = &slice;
+        cu.m_tqBypass = tqBypass;
+        cu.m_predMode = predMode;
+        cu.m_chromaFormat = X265_CSP_I420;
+        cu.m_hChromaShift = cu.m_vChromaShift = 1;
+    }
+};
+}
+uint32_t ref_transform_nxn(const int16_t* residual, uint32_t resiStride, int16_t* coeff, int16_t* resiDct, int log2TrSize, int ttype, int qp, int sliceI,
+                           int signHide)
+{
+    QuantRig& r = rig();
+    if (!r.ok) return 0xffffffffu;
+    InterCU c(sliceI, signHide);
+    r.q.setQp(ttype, qp);
+    pixel fenc[4] = { 0, 0, 0, 0 };                 /* only read for psy-rdoq, which is off */
+    const uint32_t numSig = r.q.transformNxN(c.cu, fenc, 2, residual, resiStride, coeff, (uint32_t)log2TrSize, (TextType)ttype, 0, false);
+    if (resiDct)
+        memcpy(resiDct, r.q.resiDct(), sizeof(int16_t) << (2 * log2TrSize));
+    return numSig;
+}
+void ref_invtransform_nxn(int16_t* residual, uint32_t resiStride, const int16_t* coeff, int log2TrSize, int ttype, int qp, uint32_t numSig)
+{
+    QuantRig& r = rig();
+    if (!r.ok) return;
+    InterCU c(0, 0);
+    r.q.setQp(ttype, qp);
+    r.q.invtransformNxN(c.cu, residual, resiStride, coeff, (uint32_t)log2TrSize, (TextType)ttype, false, false, numSig);
+}
+/* the QpParam fields and flat matrix entries the job header carries, as the reference computes them */
+void ref_qp_param(int qp, int32_t* out) /* rem, per, quantScale, dequantScale */
+{
+    QuantRig& r = rig();
+    QpParam p;
+    p.setQpParam(qp);
+    out[0] = p.rem; out[1] = p.per;
+    out[2] = r.sl.m_quantCoef[3][3][p.rem][0];
+    out[3] = ScalingList::s_invQuantScales[p.rem];
+}
 } // extern "C"

@@ -1,0 +1,172 @@
+/* x265_oracle_rqt.c — TEST INFRASTRUCTURE ONLY (see x265_oracle.h): the transform arithmetic of an inter CU's residual quad-tree, i.e. what
+ * Search::estimateResidualQT (reference source/encoder/search.cpp:3178-3560) asks of Quant::transformNxN and Quant::invtransformNxN, restated
+ * on the CPU from the pinned primitives of x265_oracle.c, and the CU job built from them (include/x265hip.h, x265hip_cujob: the checker of
+ * x265_amd/csrc/cuserve.hip and the engine of tests/support/la_emul.c).
+ * Pinned: tests/test_oracle_vs_ref.py runs orc_transform_nxn / orc_invtransform_nxn against the real Quant class (oracle/ref_shim.cpp
+ * ref_transform_nxn / ref_invtransform_nxn) over sizes, planes, QPs, slice types and sign hiding on / off. */
+#include <stdint.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+#include "x265_oracle.h"
+#include "../include/x265hip.h"
+
+void orc_scan_order(int type, int log2, uint16_t* out);                                                  /* x265_oracle_coef.c */
+int orc_scanPosLast(const uint16_t* scan, const int16_t* coeff, uint16_t* coeffSign, uint16_t* coeffFlag, uint8_t* coeffNum, int numSig);
+
+/* common/quant.cpp:246-395 Quant::signBitHidingHDQ: per 4x4 coefficient group of the scan (last to first) whose first and last non-zero
+ * levels lie at least SBH_THRESHOLD (4) scan positions apart, the parity of the sum of levels must equal the sign of the first one; where it
+ * does not, the level whose change costs least (deltaU: the quantiser's rounding remainder) moves by one.  resiDct: the transform coefficients
+ * (Quant::m_resiDctCoeff) — the sign a zero level would take.  Returns the new numSig. */
+uint32_t orc_sign_hide_hdq(int16_t* coeff, const int32_t* deltaU, const int16_t* resiDct, uint32_t numSig, int log2TrSize, int scanType)
+{
+    uint16_t scan[1024];
+    uint8_t coeffNum[64];
+    uint16_t coeffSign[64], coeffFlag[64];
+    orc_scan_order(scanType, log2TrSize, scan);
+    const int lastScanPos = orc_scanPosLast(scan, coeff, coeffSign, coeffFlag, coeffNum, (int)numSig);
+    const int cgLastScanPos = lastScanPos >> 4;
+    const uint32_t correctOffset = 0x0F & (lastScanPos ^ 0xF);              /* :268: the last group was left-aligned only as far as it was walked */
+    coeffFlag[cgLastScanPos] = (uint16_t)(coeffFlag[cgLastScanPos] << correctOffset);
+    for (int cg = cgLastScanPos; cg >= 0; cg--)
+    {
+        const int cgStartPos = cg << 4;
+        if (!coeffNum[cg])
+            continue;
+        /* bit (15 - n) of coeffFlag = scan position n of the group holds a non-zero level */
+        int firstNZ = 0, lastNZ = 15;
+        while (!(coeffFlag[cg] & (0x8000 >> firstNZ))) firstNZ++;
+        while (!(coeffFlag[cg] & (0x8000 >> lastNZ))) lastNZ--;
+        if (lastNZ - firstNZ < 4)
+            continue;
+        const uint32_t signbit = coeff[scan[cgStartPos + firstNZ]] > 0 ? 0 : 1;
+        uint32_t absSum = 0;
+        for (int n = firstNZ; n <= lastNZ; n++)
+            absSum += (uint32_t)(int32_t)coeff[scan[n + cgStartPos]];
+        if (signbit == (absSum & 1))
+            continue;
+        int minCostInc = INT32_MAX, minPos = -1, curCost = INT32_MAX;
+        int32_t finalChange = 0, curChange = 0;
+        uint32_t cgFlags = coeffFlag[cg];
+        if (cg == cgLastScanPos)
+            cgFlags >>= correctOffset;
+        for (int n = (cg == cgLastScanPos ? lastNZ : 15); n >= 0; --n)
+        {
+            const uint32_t blkPos = scan[n + cgStartPos];
+            if (cgFlags & 1)
+            {
+                if (deltaU[blkPos] > 0) { curCost = -deltaU[blkPos]; curChange = 1; }
+                else if (cgFlags == 1 && abs(coeff[blkPos]) == 1) curCost = INT32_MAX;     /* the group's first level may not vanish */
+                else { curCost = deltaU[blkPos]; curChange = -1; }
+            }
+            else if (cgFlags == 0)
+            {
+                /* before the first non-zero level: a new level here becomes the first one and its sign is the hidden bit */
+                const uint32_t thisSignBit = resiDct[blkPos] >= 0 ? 0 : 1;
+                if (thisSignBit != signbit) curCost = INT32_MAX;
+                else { curCost = -deltaU[blkPos]; curChange = 1; }
+            }
+            else { curCost = -deltaU[blkPos]; curChange = 1; }
+            if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minPos = (int)blkPos; }
+            cgFlags >>= 1;
+        }
+        if (minPos < 0)
+            continue;
+        if (coeff[minPos] == 32767 || coeff[minPos] == -32768)
+            finalChange = -1;
+        if (!coeff[minPos]) numSig++;
+        else if (finalChange == -1 && abs(coeff[minPos]) == 1) numSig--;
+        const int16_t sigMask = (int16_t)(resiDct[minPos] >> 15);
+        coeff[minPos] = (int16_t)(coeff[minPos] + (((int16_t)finalChange ^ sigMask) - sigMask));
+    }
+    return numSig;
+}
+
+/* common/quant.cpp:397-470 Quant::transformNxN for an inter unit without transform skip / bypass / noise reduction / RDOQ and with flat
+ * quantiser matrices: cu[].dct -> quant (:455-461: qbits = 14 + per + transformShift, add = offset << (qbits - 9)) -> signBitHidingHDQ when
+ * numSig >= 2 and the PPS enables it (inter units scan diagonally, cudata.cpp:2088).  resiDct (N * N) receives the transform coefficients. */
+uint32_t orc_transform_nxn(const int16_t* residual, intptr_t resiStride, int16_t* coeff, int16_t* resiDct, int log2TrSize, int depth, int rem, int per,
+                           int quantScale, int quantOffset, int signHide)
+{
+    const int n = 1 << (2 * log2TrSize), transformShift = 15 - depth - log2TrSize;
+    int32_t deltaU[1024], quantCoeff[1024];
+    (void)rem;
+    orc_dct(log2TrSize, residual, resiDct, resiStride, depth);
+    for (int i = 0; i < n; i++) quantCoeff[i] = quantScale;
+    const int qbits = 14 + per + transformShift;
+    const int add = quantOffset << (qbits - 9);
+    uint32_t numSig = orc_quant(resiDct, quantCoeff, deltaU, coeff, qbits, add, n);
+    if (numSig >= 2 && signHide)
+        numSig = orc_sign_hide_hdq(coeff, deltaU, resiDct, numSig, log2TrSize, 0);
+    return numSig;
+}
+
+/* common/quant.cpp:543-603 Quant::invtransformNxN, same restrictions: dequant_normal (scale = invQuantScales[rem] << per, shift = 20 - 14 -
+ * transformShift) -> cu[].idct; a lone DC level takes the short cut of :586-596 (blockfill of the value the full transform would give) */
+void orc_invtransform_nxn(int16_t* residual, intptr_t resiStride, const int16_t* coeff, int log2TrSize, int depth, int per, int dequantScale, uint32_t numSig)
+{
+    const int n = 1 << (2 * log2TrSize), size = 1 << log2TrSize, transformShift = 15 - depth - log2TrSize;
+    int16_t dq[1024];
+    orc_dequant_normal(coeff, dq, n, dequantScale << per, 20 - 14 - transformShift);
+    if (numSig == 1 && coeff[0] != 0)
+    {
+        const int shift_1st = 7 - 6, add_1st = 1 << (shift_1st - 1), shift_2nd = 12 - (depth - 8) - 3, add_2nd = 1 << (shift_2nd - 1);
+        const int dc_val = (((dq[0] * (64 >> 6) + add_1st) >> shift_1st) * (64 >> 3) + add_2nd) >> shift_2nd;
+        orc_blockfill_s(residual, resiStride, (int16_t)dc_val, size);
+        return;
+    }
+    orc_idct(log2TrSize, dq, residual, resiStride, depth);
+}
+
+/* ---- the CU job (include/x265hip.h): every unit of every level; returns the number of units written -------------------------------------------- */
+#define ORC_CUJOB(P, SFX) \
+int orc_cujob_run_##SFX(const x265hip_cujob* j, const P* pixels, x265hip_cujob_unit* units, int16_t* levels, int16_t* resi, uint32_t seq) \
+{ \
+    int sHi, sLo, done = 0; \
+    const int nl = x265hipi_cujob_levels(j, &sHi, &sLo); \
+    const int N = 1 << j->log2CUSize, N2 = N * N, planeElems = j->chroma ? N2 + N2 / 2 : N2, depth = (int)j->bitDepth; \
+    const P* src = pixels; \
+    const P* prd = pixels + planeElems; \
+    for (int lv = 0; lv < nl; lv++) \
+    { \
+        const int s = sHi - lv, perRow = 1 << ((int)j->log2CUSize - s); \
+        for (int plane = 0; plane < (j->chroma ? 3 : 1); plane++) \
+        { \
+            const int log2n = plane ? s - 1 : s, n = 1 << log2n, pw = plane ? N / 2 : N; \
+            const P* ps = src + (plane == 0 ? 0 : plane == 1 ? N2 : N2 + N2 / 4); \
+            const P* pp = prd + (plane == 0 ? 0 : plane == 1 ? N2 : N2 + N2 / 4); \
+            for (int ty = 0; ty < perRow; ty++) \
+                for (int tx = 0; tx < perRow; tx++) \
+                { \
+                    x265hip_cujob_unit* u = units + x265hipi_cujob_unit_index(j, sHi, s, plane, tx, ty); \
+                    const int eo = x265hipi_cujob_elem_offset(j, sHi, s, plane, tx, ty); \
+                    const P* f = ps + (ty * n) * pw + tx * n; \
+                    const P* p = pp + (ty * n) * pw + tx * n; \
+                    int16_t r[1024], dct[1024], back[1024]; \
+                    P rec[1024]; \
+                    orc_sub_ps_##SFX(r, n, f, p, pw, pw, n, n); \
+                    u->numSig = orc_transform_nxn(r, n, levels + eo, dct, log2n, depth, j->qpRem[plane], j->qpPer[plane], j->quantScale[plane], (int)j->quantOffset, \
+                                                  (int)j->signHide); \
+                    u->zeroDist = orc_sse_pp_##SFX(f, pw, p, pw, n, n); \
+                    if (u->numSig) \
+                    { \
+                        orc_invtransform_nxn(back, n, levels + eo, log2n, depth, j->qpPer[plane], j->dequantScale[plane], u->numSig); \
+                        orc_add_ps_##SFX(rec, n, p, back, pw, n, n, n, depth); \
+                        u->codedDist = orc_sse_pp_##SFX(f, pw, rec, n, n, n); \
+                        memcpy(resi + eo, back, sizeof(int16_t) * n * n); \
+                    } \
+                    else \
+                    { \
+                        u->codedDist = u->zeroDist; \
+                        memset(resi + eo, 0, sizeof(int16_t) * n * n); \
+                    } \
+                    u->reserved = 0; \
+                    __atomic_store_n(&u->ready, seq, __ATOMIC_RELEASE); \
+                    done++; \
+                } \
+        } \
+    } \
+    return done; \
+}
+ORC_CUJOB(uint8_t, 8)
+ORC_CUJOB(uint16_t, 16)

@@ -630,3 +630,66 @@ int x265hip_sadsurf_stats(uint64_t* attached, uint64_t* ctuRows, uint64_t* launc
     if (ctuRows) *ctuRows = g_ssRows;
     return 0;
 }
+
+/* ---- CU residual quad-tree jobs (include/x265hip.h, x265hip_cuserve_*): the restatement (oracle/x265_oracle_rqt.c) behind the same slot / submit /
+ * ready-word protocol; the job is done inside x265hip_cuserve_submit.  X265HIP_EMUL_CUSERVE_FAIL=open | submit makes the respective call fail
+ * (the bindings must then compute on the host and still produce the reference's bytes: tests/test_fallback.py). */
+int orc_cujob_run_8(const x265hip_cujob* j, const uint8_t* pixels, x265hip_cujob_unit* units, int16_t* levels, int16_t* resi, uint32_t seq);
+int orc_cujob_run_16(const x265hip_cujob* j, const uint16_t* pixels, x265hip_cujob_unit* units, int16_t* levels, int16_t* resi, uint32_t seq);
+typedef struct cu_slot
+{
+    x265hip_cujob job;
+    x265hip_cujob_unit units[X265HIP_CUJOB_MAX_UNITS];
+    _Alignas(64) unsigned char pixels[X265HIP_CUJOB_PIXEL_BYTES];
+    _Alignas(64) int16_t levels[X265HIP_CUJOB_MAX_ELEMS];
+    _Alignas(64) int16_t resi[X265HIP_CUJOB_MAX_ELEMS];
+    uint32_t seq;
+} cu_slot;
+struct x265hip_cuserve { int slots, mode; cu_slot* slot; uint64_t jobs; };
+int x265hip_cuserve_open(int slots, int mode, x265hip_cuserve** out)
+{
+    const char* fail = getenv("X265HIP_EMUL_CUSERVE_FAIL");
+    if (fail && !strcmp(fail, "open")) { snprintf(g_err, sizeof(g_err), "emulated failure of x265hip_cuserve_open"); return X265HIP_ENOMEM; }
+    if (!out || slots < 1 || slots > 256) return X265HIP_EINVAL;
+    x265hip_cuserve* cs = (x265hip_cuserve*)calloc(1, sizeof(*cs));
+    cs->slots = slots; cs->mode = mode;
+    cs->slot = (cu_slot*)aligned_alloc(64, sizeof(cu_slot) * slots);
+    memset(cs->slot, 0, sizeof(cu_slot) * slots);
+    *out = cs;
+    return 0;
+}
+int x265hip_cuserve_close(x265hip_cuserve* cs) { if (cs) { free(cs->slot); free(cs); } return 0; }
+int x265hip_cuserve_slot(x265hip_cuserve* cs, int slot, x265hip_cujob** job, void** pixels, const x265hip_cujob_unit** units, const int16_t** levels,
+                         const int16_t** resi)
+{
+    if (!cs || slot < 0 || slot >= cs->slots) return X265HIP_EINVAL;
+    cu_slot* s = cs->slot + slot;
+    if (job) *job = &s->job;
+    if (pixels) *pixels = s->pixels;
+    if (units) *units = s->units;
+    if (levels) *levels = s->levels;
+    if (resi) *resi = s->resi;
+    return 0;
+}
+int x265hip_cuserve_submit(x265hip_cuserve* cs, int slot, uint32_t* seq)
+{
+    const char* fail = getenv("X265HIP_EMUL_CUSERVE_FAIL");
+    if (fail && !strcmp(fail, "submit")) { snprintf(g_err, sizeof(g_err), "emulated failure of x265hip_cuserve_submit"); return X265HIP_EHIP; }
+    if (!cs || slot < 0 || slot >= cs->slots || !seq) return X265HIP_EINVAL;
+    cu_slot* s = cs->slot + slot;
+    int sHi, sLo;
+    if (s->job.log2CUSize < 4 || s->job.log2CUSize > 6 || x265hipi_cujob_levels(&s->job, &sHi, &sLo) < 1) return X265HIP_EINVAL;
+    *seq = ++s->seq;
+    __atomic_fetch_add(&cs->jobs, 1, __ATOMIC_RELAXED);
+    if (s->job.bitDepth == 8) orc_cujob_run_8(&s->job, s->pixels, s->units, s->levels, s->resi, *seq);
+    else orc_cujob_run_16(&s->job, (const uint16_t*)s->pixels, s->units, s->levels, s->resi, *seq);
+    return 0;
+}
+int x265hip_cuserve_poke(x265hip_cuserve* cs, int slot) { (void)cs; (void)slot; return 0; }
+int x265hip_cuserve_stats(x265hip_cuserve* cs, uint64_t* jobs, uint64_t* serverStarts, uint64_t* deviceNs)
+{
+    if (jobs) *jobs = cs ? cs->jobs : 0;
+    if (serverStarts) *serverStarts = 0;
+    if (deviceNs) *deviceNs = 0;
+    return 0;
+}

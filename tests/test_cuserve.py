@@ -1,0 +1,288 @@
+"""CU residual quad-tree jobs (include/x265hip.h x265hip_cuserve_*; x265_amd/csrc/cuserve.hip): the transform arithmetic of an inter CU —
+Quant::transformNxN (reference source/common/quant.cpp:397-470, with signBitHidingHDQ :246-395) and Quant::invtransformNxN (:543-603) for
+every transform unit Search::estimateResidualQT (encoder/search.cpp:3178-3560) may try — as ONE job handed to the device.
+
+CPU tier: the restatement (oracle/x265_oracle_rqt.c) against the REAL Quant class of the reference (oracle/_ref/libx265ref*.so, ref_shim.cpp
+ref_transform_nxn / ref_invtransform_nxn): sizes 8-32, Y / Cb / Cr QPs, I and P rounding offsets, sign hiding on and off, residuals from
+noise-like to nearly empty; the job built from it through the emulated ABI (tests/support/libx265hip_emul.so).
+GPU tier: the device's job against the restatement's, unit for unit (numSig, levels, reconstructed residual, both distortions), CU 16 / 32 /
+64, 8 / 10 / 12 bit, with and without chroma, one or two transform sizes, resident-server and launch-per-job hand-off."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import pyoracle as po   # noqa: E402  (checker only)
+
+EMUL = os.path.join(ROOT, "tests", "support", "libx265hip_emul.so")
+vp, i32, u32 = C.c_void_p, C.c_int, C.c_uint32
+
+
+def _orc():
+    L = po.oracle()
+    L.orc_transform_nxn.restype, L.orc_transform_nxn.argtypes = u32, [vp, C.c_ssize_t, vp, vp, i32, i32, i32, i32, i32, i32, i32]
+    L.orc_invtransform_nxn.restype, L.orc_invtransform_nxn.argtypes = None, [vp, C.c_ssize_t, vp, i32, i32, i32, i32, u32]
+    for sfx in ("8", "16"):
+        f = getattr(L, "orc_cujob_run_" + sfx)
+        f.restype, f.argtypes = i32, [vp, vp, vp, vp, vp, u32]
+    return L
+
+
+def _ref(depth):
+    if not po.ref_available(depth):
+        pytest.skip("oracle/_ref/libx265ref%d.so not built (make -C oracle ref)" % depth)
+    R = po.ref(depth)
+    R.ref_transform_nxn.restype, R.ref_transform_nxn.argtypes = u32, [vp, u32, vp, vp, i32, i32, i32, i32, i32]
+    R.ref_invtransform_nxn.restype, R.ref_invtransform_nxn.argtypes = None, [vp, u32, vp, i32, i32, i32, u32]
+    R.ref_qp_param.restype, R.ref_qp_param.argtypes = None, [i32, vp]
+    return R
+
+
+def _residual(rng, n, depth, kind):
+    pmax = (1 << depth) - 1
+    if kind == 0:      # TestBench's distribution (mbdstharness.cpp:63-77): uniform over the whole range
+        r = rng.integers(-pmax, pmax + 1, (n, n))
+    elif kind == 1:    # what a good prediction leaves: small noise
+        r = np.rint(rng.normal(0, 3 << (depth - 8), (n, n)))
+    elif kind == 2:    # smooth ramp + a few spikes: a handful of low-frequency levels
+        yy, xx = np.mgrid[0:n, 0:n]
+        r = ((xx - n / 2) * rng.uniform(-2, 2) + (yy - n / 2) * rng.uniform(-2, 2)) * (1 << (depth - 8))
+        k = rng.integers(0, n, (4, 2))
+        r[k[:, 0], k[:, 1]] += rng.integers(-40, 41, 4) * (1 << (depth - 8))
+    else:              # a single step edge
+        r = np.zeros((n, n))
+        r[:, rng.integers(1, n):] = rng.integers(-30, 31) * (1 << (depth - 8))
+    return np.ascontiguousarray(np.clip(r, -pmax, pmax).astype(np.int16))
+
+
+@pytest.mark.parametrize("depth", [8, 10, 12])
+def test_transform_restatement_matches_the_reference_quant_class(depth):
+    """orc_transform_nxn / orc_invtransform_nxn == Quant::transformNxN / ::invtransformNxN of the reference, bit for bit."""
+    O, R = _orc(), _ref(depth)
+    rng = np.random.default_rng(100 + depth)
+    bdOff = 6 * (depth - 8)
+    n_cases = hidden = 0
+    for log2n in (3, 4, 5):
+        n = 1 << log2n
+        for ttype in (0, 1, 2):
+            for qp in (bdOff + 4, bdOff + 17, bdOff + 22, bdOff + 27, bdOff + 32, bdOff + 38, bdOff + 45, bdOff + 51):
+                qparam = (C.c_int32 * 4)()
+                R.ref_qp_param(qp, qparam)
+                rem, per, qs, dqs = qparam[0], qparam[1], qparam[2], qparam[3]
+                assert (rem, per) == (qp % 6, qp // 6)
+                for sliceI in (0, 1):
+                    for signHide in (0, 1):
+                        for kind in (0, 1, 2, 3):
+                            stride = n + 8 * int(rng.integers(0, 3))
+                            resi = np.zeros((n, stride), np.int16)
+                            resi[:, :n] = _residual(rng, n, depth, kind)
+                            c_o, c_r = np.zeros(n * n, np.int16), np.zeros(n * n, np.int16)
+                            d_o, d_r = np.zeros(n * n, np.int16), np.zeros(n * n, np.int16)
+                            ns_r = R.ref_transform_nxn(resi.ctypes.data, stride, c_r.ctypes.data, d_r.ctypes.data, log2n, ttype, qp, sliceI, signHide)
+                            ns_o = O.orc_transform_nxn(resi.ctypes.data, stride, c_o.ctypes.data, d_o.ctypes.data, log2n, depth, rem, per, qs, 171 if sliceI else 85,
+                                                       signHide)
+                            label = (log2n, ttype, qp, sliceI, signHide, kind)
+                            assert ns_o == ns_r and np.array_equal(c_o, c_r) and np.array_equal(d_o, d_r), label
+                            assert ns_o == int(np.count_nonzero(c_o)), label
+                            if signHide:
+                                c_plain = np.zeros(n * n, np.int16)
+                                O.orc_transform_nxn(resi.ctypes.data, stride, c_plain.ctypes.data, d_o.ctypes.data, log2n, depth, rem, per, qs, 171 if sliceI else 85, 0)
+                                hidden += int(not np.array_equal(c_plain, c_o))
+                            if ns_r:
+                                b_o, b_r = np.full((n, stride), 77, np.int16), np.full((n, stride), 77, np.int16)
+                                R.ref_invtransform_nxn(b_r.ctypes.data, stride, c_r.ctypes.data, log2n, ttype, qp, ns_r)
+                                O.orc_invtransform_nxn(b_o.ctypes.data, stride, c_o.ctypes.data, log2n, depth, per, dqs, ns_o)
+                                assert np.array_equal(b_o, b_r), label
+                            n_cases += 1
+    assert n_cases == 3 * 3 * 8 * 2 * 2 * 4
+    assert hidden > 100, hidden          # the sign-hiding branch really moved levels
+
+
+# ---- jobs ------------------------------------------------------------------------------------------------------------------------------------
+
+def _job_header(hp, log2cu, tr_max, tr_min, chroma, depth, qps, sliceI, signHide):
+    j = hp.CuJob()
+    j.log2CUSize, j.log2TrMax, j.log2TrMin, j.chroma, j.bitDepth = log2cu, tr_max, tr_min, chroma, depth
+    j.quantOffset, j.signHide = (171 if sliceI else 85), signHide
+    quant = [26214, 23302, 20560, 18396, 16384, 14564]      # the flat matrix entries (scalinglist.cpp:129-130; checked against the reference above)
+    dequant = [40, 45, 51, 57, 64, 72]
+    for p in range(3):
+        j.qpRem[p], j.qpPer[p] = qps[p] % 6, qps[p] // 6
+        j.quantScale[p], j.dequantScale[p] = quant[qps[p] % 6], dequant[qps[p] % 6]
+    return j
+
+
+def _job_pixels(rng, log2cu, chroma, depth, kind):
+    """source + prediction, Y then Cb, Cr, as the job's pixel block"""
+    N = 1 << log2cu
+    pmax = (1 << depth) - 1
+    dt = np.uint8 if depth == 8 else np.uint16
+    planes = [(N, N)] + ([(N // 2, N // 2)] * 2 if chroma else [])
+    src, prd = [], []
+    for (h, w) in planes:
+        base = rng.integers(0, pmax + 1, (h, w)) if kind == 0 else np.clip(np.rint(rng.normal(pmax / 2, pmax / 6, (h, w))), 0, pmax)
+        if kind == 0:
+            p = rng.integers(0, pmax + 1, (h, w))
+        else:
+            p = np.clip(base + np.rint(rng.normal(0, (2 + 3 * kind) * (1 << (depth - 8)), (h, w))), 0, pmax)
+        src.append(base.astype(dt).ravel())
+        prd.append(p.astype(dt).ravel())
+    return np.ascontiguousarray(np.concatenate(src + prd))
+
+
+def _layout(hp, j):
+    """[(s, plane, tx, ty, unitIndex, elemOffset, n)] exactly as include/x265hip.h's inline helpers lay a job out"""
+    hi, lo = min(5, j.log2TrMax, j.log2CUSize), max(4, j.log2TrMin)
+    planes = 3 if j.chroma else 1
+    N2 = 1 << (2 * j.log2CUSize)
+    per_level = N2 + N2 // 2 if j.chroma else N2
+    out, base = [], 0
+    for s in range(hi, lo - 1, -1):
+        per = 1 << (j.log2CUSize - s)
+        for plane in range(planes):
+            n = 1 << (s - 1 if plane else s)
+            for ty in range(per):
+                for tx in range(per):
+                    t = ty * per + tx
+                    eo = (hi - s) * per_level + (t * n * n if plane == 0 else N2 + (N2 // 4 if plane == 2 else 0) + t * n * n)
+                    out.append((s, plane, tx, ty, base + plane * per * per + t, eo, n))
+        base += planes * per * per
+    return out
+
+
+def _oracle_job(hp, O, j, pix):
+    units = (hp.CuJobUnit * hp.CUJOB_MAX_UNITS)()
+    levels, resi = np.zeros(hp.CUJOB_MAX_ELEMS, np.int16), np.zeros(hp.CUJOB_MAX_ELEMS, np.int16)
+    fn = O.orc_cujob_run_8 if j.bitDepth == 8 else O.orc_cujob_run_16
+    done = fn(C.byref(j), pix.ctypes.data, C.byref(units), levels.ctypes.data, resi.ctypes.data, 1)
+    return done, units, levels, resi
+
+
+def _run_on(hp, L, cs, slot, j, pix, timeout=20.0):
+    job, pixels, units, levels, resi = vp(), vp(), vp(), vp(), vp()
+    hp.check(L.x265hip_cuserve_slot(cs, slot, C.byref(job), C.byref(pixels), C.byref(units), C.byref(levels), C.byref(resi)))
+    C.memmove(job, C.byref(j), C.sizeof(j))
+    C.memmove(pixels, pix.ctypes.data, pix.nbytes)
+    seq = u32()
+    hp.check(L.x265hip_cuserve_submit(cs, slot, C.byref(seq)))
+    lay = _layout(hp, j)
+    un = C.cast(units, C.POINTER(hp.CuJobUnit))
+    t0 = time.time()
+    while any(un[k[4]].ready != seq.value for k in lay):
+        hp.check(L.x265hip_cuserve_poke(cs, slot))
+        assert time.time() - t0 < timeout, "job not finished after %.0f s" % timeout
+    lv = np.ctypeslib.as_array(C.cast(levels, C.POINTER(C.c_int16)), (hp.CUJOB_MAX_ELEMS,)).copy()
+    rs = np.ctypeslib.as_array(C.cast(resi, C.POINTER(C.c_int16)), (hp.CUJOB_MAX_ELEMS,)).copy()
+    return [(un[k[4]].numSig, un[k[4]].zeroDist, un[k[4]].codedDist) for k in lay], lv, rs
+
+
+def _compare(hp, j, got, want_units, want_levels, want_resi, label):
+    heads, lv, rs = got
+    n_units = coded = 0
+    for k, (s, plane, tx, ty, ui, eo, n) in enumerate(_layout(hp, j)):
+        w = want_units[ui]
+        assert heads[k][0] == w.numSig, (label, "numSig", s, plane, tx, ty, heads[k][0], w.numSig)
+        assert heads[k][1] == w.zeroDist, (label, "zeroDist", s, plane, tx, ty)
+        assert np.array_equal(lv[eo:eo + n * n], want_levels[eo:eo + n * n]), (label, "levels", s, plane, tx, ty)
+        if w.numSig:
+            assert heads[k][2] == w.codedDist, (label, "codedDist", s, plane, tx, ty)
+            assert np.array_equal(rs[eo:eo + n * n], want_resi[eo:eo + n * n]), (label, "resi", s, plane, tx, ty)
+            coded += 1
+        n_units += 1
+    return n_units, coded
+
+
+JOB_SHAPES = [  # log2CU, trMax, trMin, chroma
+    (5, 5, 5, 1), (6, 5, 5, 1), (4, 5, 4, 1), (5, 5, 4, 1), (6, 5, 4, 1), (5, 5, 2, 0), (6, 5, 5, 0), (4, 4, 2, 1), (6, 4, 4, 1)]
+
+
+def _cases(depth, seed):
+    rng = np.random.default_rng(seed)
+    bd = 6 * (depth - 8)
+    for shape in JOB_SHAPES:
+        for kind in (0, 1, 2):
+            for rep in range(2):
+                qy = int(rng.integers(bd + 10, bd + 46))
+                qps = (qy, max(0, qy - int(rng.integers(0, 7))), max(0, qy - int(rng.integers(0, 7))))
+                yield shape, kind, qps, int(rng.integers(0, 2)), int(rng.integers(0, 4) > 0), rng
+
+
+def test_emulated_jobs_are_the_restatement():
+    """tests/support/libx265hip_emul.so's cuserve (what the CPU-tier encodes of test_x265_dropin.py / test_encoder_fuzz.py run on) through the same
+    submit / poll protocol as the device."""
+    from x265_amd import hipprim as hp
+    if not os.path.exists(EMUL):
+        pytest.skip("tests/support/libx265hip_emul.so not built (make -C oracle emul)")
+    em = C.CDLL(EMUL)
+    for name, (res, args) in hp.PROTOTYPES.items():
+        if name.startswith("x265hip_cuserve_"):
+            fn = getattr(em, name)
+            fn.restype, fn.argtypes = res, args
+    em.x265hip_last_error.restype = C.c_char_p
+    O = _orc()
+    cs = vp()
+    assert em.x265hip_cuserve_open(3, 0, C.byref(cs)) == 0
+    total = 0
+    for depth in (8, 10):
+        for shape, kind, qps, sliceI, signHide, rng in _cases(depth, 7 + depth):
+            j = _job_header(hp, *shape, depth, qps, sliceI, signHide)
+            pix = _job_pixels(rng, shape[0], shape[3], depth, kind)
+            done, wu, wl, wr = _oracle_job(hp, O, j, pix)
+            n, coded = _compare(hp, j, _run_on(_Chk, em, cs, total % 3, j, pix), wu, wl, wr, (depth, shape, kind, qps))
+            assert n == done
+            total += 1
+    assert em.x265hip_cuserve_close(cs) == 0
+    assert total == 2 * len(JOB_SHAPES) * 6
+
+
+class _Chk:
+    """hp-like holder for _run_on over the emulated library (no HipError there)"""
+    from x265_amd import hipprim as _hp
+    CuJobUnit, CUJOB_MAX_ELEMS = _hp.CuJobUnit, _hp.CUJOB_MAX_ELEMS
+
+    @staticmethod
+    def check(rc):
+        assert rc == 0, rc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 0])
+def test_device_jobs_match_the_restatement(mode):
+    """every unit of every job: numSig, levels, reconstructed residual, both distortions; 8 / 10 / 12 bit; slots reused, sequence numbers running"""
+    from x265_amd import hipprim as hp
+    L = hp.lib()
+    hp.check(L.x265hip_init(0))
+    O = _orc()
+    cs = vp()
+    hp.check(L.x265hip_cuserve_open(4, mode, C.byref(cs)))
+    try:
+        total = units = coded = 0
+        for depth in (8, 10, 12):
+            for shape, kind, qps, sliceI, signHide, rng in _cases(depth, 40 + depth):
+                j = _job_header(hp, *shape, depth, qps, sliceI, signHide)
+                pix = _job_pixels(rng, shape[0], shape[3], depth, kind)
+                done, wu, wl, wr = _oracle_job(hp, O, j, pix)
+                n, c = _compare(hp, j, _run_on(hp, L, cs, total % 4, j, pix), wu, wl, wr, (mode, depth, shape, kind, qps, sliceI, signHide))
+                assert n == done
+                total += 1; units += n; coded += c
+        jobs, starts, ns = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        hp.check(L.x265hip_cuserve_stats(cs, C.byref(jobs), C.byref(starts), C.byref(ns)))
+        assert jobs.value == total and ns.value > 0
+        assert coded > units // 3
+        if mode == 0:
+            # the resident server leaves by itself when idle and comes back for the next job
+            time.sleep(0.05)
+            j = _job_header(hp, 5, 5, 5, 1, 8, (30, 29, 29), 0, 1)
+            pix = _job_pixels(np.random.default_rng(5), 5, 1, 8, 1)
+            done, wu, wl, wr = _oracle_job(hp, O, j, pix)
+            _compare(hp, j, _run_on(hp, L, cs, 0, j, pix), wu, wl, wr, "after idling")
+            hp.check(L.x265hip_cuserve_stats(cs, C.byref(jobs), C.byref(starts), C.byref(ns)))
+            assert starts.value >= 2, starts.value
+    finally:
+        hp.check(L.x265hip_cuserve_close(cs))

@@ -1,0 +1,640 @@
+// cuserve.hip — CU residual quad-tree jobs (include/x265hip.h, x265hip_cuserve_*): the transform arithmetic of one inter CU handed over by a
+// host thread that WAITS for it, so the figure of merit is the round trip, not throughput.
+//
+// Reference arithmetic (per transform unit; search.cpp:3178-3560 is the caller on the host):
+//   Quant::transformNxN    quant.cpp:397-470   cu[].dct (dct.cpp:459-525) -> quant_c (dct.cpp:664-686) -> signBitHidingHDQ (quant.cpp:246-395,
+//                                              with scanPosLast_c dct.cpp:757-788 on the up-right diagonal scan: inter units always scan diagonally,
+//                                              cudata.cpp:2088)
+//   Quant::invtransformNxN quant.cpp:543-603   dequant_normal (dct.cpp:612-630) -> cu[].idct (dct.cpp:544-610); the DC-only shortcut (:586-596) is
+//                                              an arithmetic identity of the full inverse transform
+//   sse_pp(source, prediction), sse_pp(source, clip(prediction + residual'))   pixel.cpp:167-186, add_ps :829
+//
+// Hand-off: a SLOT is a block of page-locked, host-coherent memory (job header + pixel block in, unit headers + levels + reconstructed residual
+// out).  The device reads and writes it directly over PCIe; there is no staging copy, no stream synchronisation and no event on the path:
+//   mode 0 (resident)   one workgroup per slot, started on the server stream, polls the slot's doorbell word (system-scope atomic load,
+//                       s_sleep between polls); a host thread submits by storing the next sequence number.  A server that has seen no work for
+//                       `idleUs` ends by itself (nothing in the process may wait on it for long: hipFree synchronises every stream) and is
+//                       started again by the next submitter that finds it gone.
+//   mode 1 (launch)     one 1-workgroup launch per job on the slot's own stream.
+// Completion: every unit's `ready` word takes the job's sequence number when its results are in host memory (released with a system-scope
+// fence); luma units of the largest size first, so the host's entropy coder can start while chroma is still on the device.
+//
+// One workgroup = 4 waves; a wave owns a 32x32 MFMA tile = one 32x32 unit, four 16x16 or sixteen 8x8 units of ONE plane (dctcore.h); the CU's
+// source and prediction are staged in LDS once (every level re-reads them).  Sign-bit hiding: one lane per 4x4 coefficient group (64 per tile).
+#include "common.h"
+#include "dctcore.h"
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+namespace xh {
+
+void clock_add(int clk, uint64_t spans, uint64_t ns, uint64_t bytes);     // runtime.hip
+
+namespace {
+
+constexpr int kInts = X265HIP_CUJOB_MAX_ELEMS;
+
+struct Slot                                      // host-coherent page-locked memory; one per submitting host thread
+{
+    uint32_t doorbell;                           // host -> device: sequence number of the job below (mode 0)
+    uint32_t pad0[15];
+    uint32_t failed;                             // device -> host: a job the device could not do (never expected)
+    uint32_t pad1[15];
+    x265hip_cujob job;
+    x265hip_cujob_unit units[X265HIP_CUJOB_MAX_UNITS];
+    alignas(64) unsigned char pixels[X265HIP_CUJOB_PIXEL_BYTES];
+    alignas(64) int16_t levels[kInts];
+    alignas(64) int16_t resi[kInts];
+};
+
+// ---- up-right diagonal scans (6.5.3): position k of the scan of an n x n grid -> (x, y) ---------------------------------------------------------
+struct DiagScans { uint8_t s2[4], s4[16], s8[64]; };      // value = y * n + x
+constexpr DiagScans make_diag()
+{
+    DiagScans d{};
+    for (int which = 0; which < 3; which++)
+    {
+        const int n = which == 0 ? 2 : which == 1 ? 4 : 8;
+        int i = 0, x = 0, y = 0;
+        while (i < n * n)
+        {
+            while (y >= 0)
+            {
+                if (x < n && y < n)
+                {
+                    const uint8_t v = (uint8_t)(y * n + x);
+                    if (which == 0) d.s2[i] = v; else if (which == 1) d.s4[i] = v; else d.s8[i] = v;
+                    i++;
+                }
+                y--; x++;
+            }
+            y = x; x = 0;
+        }
+    }
+    return d;
+}
+__device__ __constant__ const DiagScans kDiag = make_diag();
+
+struct HostCtl                                    // host-coherent page-locked memory, one per x265hip_cuserve
+{
+    uint32_t serverState;                        // 0: no server; 0x80000000 | g: generation g is being started; g: generation g is polling
+};
+struct DevCtl                                     // device memory
+{
+    uint32_t quit;                               // set by the workgroup that finds the server idle (or told to leave): every workgroup leaves at its next poll
+    uint32_t left;                               // workgroups that have left
+    uint64_t lastWork;                           // wall_clock64() of the last job any workgroup has taken
+    uint64_t busyTicks[256];                     // per slot: 100 MHz ticks spent on its jobs
+};
+
+struct TileLds { int16_t a[1024], b[1024], c[1024]; };            // per wave: transform ping-pong + deltaU
+struct JobLds
+{
+    x265hip_cujob job;
+    uint32_t seq;
+    alignas(16) unsigned char pix[X265HIP_CUJOB_PIXEL_BYTES];
+    alignas(16) TileLds tile[4];
+};
+
+struct PlaneParams { int qBits, add, quantScale, dqScale, dqShift, s1f, s2f, s1i, s2i, maxVal; };
+
+__device__ __forceinline__ PlaneParams plane_params(const x265hip_cujob& j, int plane, int log2n)
+{
+    // quant.cpp:408 transformShift = MAX_TR_DYNAMIC_RANGE(15) - depth - log2TrSize; :461 qbits = QUANT_SHIFT(14) + per + transformShift;
+    // :466 add = offset << (qbits - 9); :556 shift = QUANT_IQUANT_SHIFT(20) - QUANT_SHIFT - transformShift; :567 scale = invQuantScales[rem] << per
+    // dct.cpp:459-525: forward shifts log2n - 1 + (depth - 8), log2n + 6; :544-610 inverse shifts 7, 12 - (depth - 8)
+    PlaneParams p;
+    const int depth = (int)j.bitDepth, transformShift = 15 - depth - log2n;
+    p.qBits = 14 + j.qpPer[plane] + transformShift;
+    p.add = (int)j.quantOffset << (p.qBits - 9);
+    p.quantScale = j.quantScale[plane];
+    p.dqScale = j.dequantScale[plane] << j.qpPer[plane];
+    p.dqShift = 20 - 14 - transformShift;
+    p.s1f = log2n - 1 + (depth - 8); p.s2f = log2n + 6;
+    p.s1i = 7; p.s2i = 12 - (depth - 8);
+    p.maxVal = (1 << depth) - 1;
+    return p;
+}
+
+// One tile: units u0 .. u0 + G - 1 (G = (32 / N)^2, raster order, `count` of them exist) of size N x N of one plane.
+//   src / prd: the plane's source and prediction in LDS, `pw` elements per row; the plane has (pw / N)^2 units
+template <typename P, int N>
+__device__ __forceinline__ void tile_chain(TileLds& t, const P* src, const P* prd, int pw, int u0, int count, const PlaneParams qp, bool signHide,
+                                           x265hip_cujob_unit* units, int unitBase, int16_t* levels, int16_t* resi, int elemBase, uint32_t seq)
+{
+    constexpr int G = (32 / N) * (32 / N);
+    constexpr int LPT = N * N / 16;              // lanes per unit: 16 coefficients each in the quantiser, one 4x4 group each in the sign hiding
+    constexpr int CGW = N / 4;                   // coefficient groups per row of a unit
+    const int lane = threadIdx.x & 63;
+    const int perRow = pw / N;
+    v4i bF, bI;
+    int corrF, corrI;
+    make_b_operand<N, false>(lane, bF, corrF);
+    make_b_operand<N, true>(lane, bI, corrI);
+
+    // ---- residual = source - prediction (two runs of 8 per lane; kept in registers for the distortions)
+    int fv[16], pv[16];
+#pragma unroll
+    for (int half = 0; half < 2; half++)
+    {
+        const int e = lane * 16 + half * 8;
+        const int g = e / (N * N), rr = (e % (N * N)) / N, cc = e % N;
+        int r[8];
+        if (g < count)
+        {
+            const int u = u0 + g, ux = u % perRow, uy = u / perRow;
+            const int off = (uy * N + rr) * pw + ux * N + cc;
+            load4(src + off, &fv[8 * half]); load4(src + off + 4, &fv[8 * half + 4]);
+            load4(prd + off, &pv[8 * half]); load4(prd + off + 4, &pv[8 * half + 4]);
+        }
+        else
+        {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { fv[8 * half + i] = 0; pv[8 * half + i] = 0; }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) r[i] = fv[8 * half + i] - pv[8 * half + i];
+        store4(t.a + e, r); store4(t.a + e + 4, r + 4);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    // ---- forward transform: a -> b -> a
+    mfma_pass<N, false>(t.a, t.b, lane, bF, corrF, qp.s1f);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    mfma_pass<N, false>(t.b, t.a, lane, bF, corrF, qp.s2f);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    // ---- quant (quant_c): levels -> b, deltaU -> c; the transform coefficients stay in a (sign hiding reads their signs)
+    int cnt = 0;
+    const int qBits8 = qp.qBits - 8;
+#pragma unroll
+    for (int half = 0; half < 2; half++)
+    {
+        const int e = lane * 16 + half * 8;
+        int cf[8], lv[8], du[8];
+        load4(t.a + e, cf); load4(t.a + e + 4, cf + 4);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+        {
+            const int tmp = iabs(cf[i]) * qp.quantScale;
+            const int l = (tmp + qp.add) >> qp.qBits;
+            du[i] = (tmp - (l << qp.qBits)) >> qBits8;
+            cnt += l != 0;
+            lv[i] = clip3i(-32768, 32767, cf[i] < 0 ? -l : l);
+        }
+        store4(t.b + e, lv); store4(t.b + e + 4, lv + 4);
+        store4(t.c + e, du); store4(t.c + e + 4, du + 4);
+    }
+    int numSig = group_sum(cnt, LPT);                       // of the unit this lane belongs to (lanes g * LPT .. g * LPT + LPT - 1)
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    // ---- sign-bit hiding (signBitHidingHDQ): lane = coefficient group `cg` (scan order) of unit lane / LPT
+    {
+        const int g = lane / LPT, cg = lane % LPT;
+        const int cgPos = CGW == 2 ? kDiag.s2[cg] : CGW == 4 ? kDiag.s4[cg] : kDiag.s8[cg];
+        const int cgx = cgPos % CGW, cgy = cgPos / CGW;
+        const int base = g * N * N + (cgy * 4) * N + cgx * 4;
+        int lv[16];
+        uint32_t flags = 0;                                  // bit (15 - n) = level at scan position n of the group is non-zero
+#pragma unroll
+        for (int n = 0; n < 16; n++)
+        {
+            const int p4 = kDiag.s4[n];
+            lv[n] = t.b[base + (p4 >> 2) * N + (p4 & 3)];
+            flags |= (uint32_t)(lv[n] != 0) << (15 - n);
+        }
+        // the unit's last non-zero group in scan order (scanPosLast_c walks the scan until numSig non-zero levels were seen)
+        const unsigned long long nz = __ballot(flags != 0);
+        unsigned long long mine = nz;
+        if constexpr (LPT < 64) mine = (nz >> (g * LPT)) & ((1ull << LPT) - 1);
+        const int cgLast = mine ? 63 - __builtin_clzll(mine) : -1;
+        int delta = 0;
+        if (signHide && numSig >= 2 && flags && cg <= cgLast)
+        {
+            const int firstNZ = 15 ^ (31 - __builtin_clz(flags));            // quant.cpp:303-307
+            const int lastNZ = 15 ^ __builtin_ctz(flags);
+            if (lastNZ - firstNZ >= 4)                                       // SBH_THRESHOLD
+            {
+                const uint32_t signbit = lv[firstNZ] > 0 ? 0 : 1;
+                int absSum = 0;
+#pragma unroll
+                for (int n = 0; n < 16; n++)
+                    if (n >= firstNZ && n <= lastNZ) absSum += lv[n];
+                if (signbit != ((uint32_t)absSum & 1))
+                {
+                    int minCostInc = 0x7fffffff, minN = -1, finalChange = 0, curChange = 0;
+                    const int start = cg == cgLast ? lastNZ : 15;
+                    uint32_t cgFlags = flags >> (15 - start);               // bit 0 = position `start`
+#pragma unroll
+                    for (int n = 15; n >= 0; n--)
+                    {
+                        if (n > start) continue;
+                        const int p4 = kDiag.s4[n];
+                        const int at = base + (p4 >> 2) * N + (p4 & 3);
+                        const int dU = t.c[at];
+                        int curCost;
+                        if (cgFlags & 1)
+                        {
+                            if (dU > 0) { curCost = -dU; curChange = 1; }
+                            else if (cgFlags == 1 && iabs(lv[n]) == 1) curCost = 0x7fffffff;
+                            else { curCost = dU; curChange = -1; }
+                        }
+                        else if (cgFlags == 0)
+                        {
+                            const uint32_t thisSignBit = t.a[at] >= 0 ? 0 : 1;
+                            if (thisSignBit != signbit) curCost = 0x7fffffff;
+                            else { curCost = -dU; curChange = 1; }
+                        }
+                        else { curCost = -dU; curChange = 1; }
+                        if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minN = n; }
+                        cgFlags >>= 1;
+                    }
+                    if (minN >= 0)
+                    {
+                        const int p4 = kDiag.s4[minN];
+                        const int at = base + (p4 >> 2) * N + (p4 & 3);
+                        int v = t.b[at];
+                        if (v == 32767 || v == -32768) finalChange = -1;
+                        if (!v) delta = 1;
+                        else if (finalChange == -1 && iabs(v) == 1) delta = -1;
+                        const int sigMask = t.a[at] < 0 ? -1 : 0;
+                        v += (finalChange ^ sigMask) - sigMask;
+                        t.b[at] = (int16_t)v;
+                    }
+                }
+            }
+        }
+        numSig += group_sum(delta, LPT);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    // ---- levels out (16 contiguous per lane), dequant_normal -> a
+    const int gL = (lane * 16) / (N * N);
+    const bool okL = gL < count;
+    {
+        const int dqAdd = 1 << (qp.dqShift - 1);
+#pragma unroll
+        for (int half = 0; half < 2; half++)
+        {
+            const int e = lane * 16 + half * 8;
+            int lv[8], dq[8];
+            load4(t.b + e, lv); load4(t.b + e + 4, lv + 4);
+#pragma unroll
+            for (int i = 0; i < 8; i++) dq[i] = clip3i(-32768, 32767, (lv[i] * qp.dqScale + dqAdd) >> qp.dqShift);
+            if (okL)
+                *reinterpret_cast<uint4*>(levels + elemBase + (u0 + gL) * N * N + (e % (N * N))) = *reinterpret_cast<const uint4*>(t.b + e);
+            store4(t.a + e, dq); store4(t.a + e + 4, dq + 4);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    // ---- inverse transform: a -> b -> a
+    mfma_pass<N, true>(t.a, t.b, lane, bI, corrI, qp.s1i);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    mfma_pass<N, true>(t.b, t.a, lane, bI, corrI, qp.s2i);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    // ---- reconstructed residual out; distortions
+    unsigned long long zero = 0, coded = 0;
+#pragma unroll
+    for (int half = 0; half < 2; half++)
+    {
+        const int e = lane * 16 + half * 8;
+        int r[8];
+        load4(t.a + e, r); load4(t.a + e + 4, r + 4);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+        {
+            const int f = fv[8 * half + i], p = pv[8 * half + i];
+            const unsigned d0 = (unsigned)(f - p), d1 = (unsigned)(f - clip3i(0, qp.maxVal, p + r[i]));
+            zero += (unsigned long long)d0 * d0;
+            coded += (unsigned long long)d1 * d1;
+        }
+        if (okL)
+            *reinterpret_cast<uint4*>(resi + elemBase + (u0 + gL) * N * N + (e % (N * N))) = *reinterpret_cast<const uint4*>(t.a + e);
+    }
+    zero = group_sum64(zero, LPT);
+    coded = group_sum64(coded, LPT);
+    x265hip_cujob_unit* un = units + unitBase + u0 + gL;
+    const bool writer = okL && (lane & (LPT - 1)) == 0;
+    if (writer)
+    {
+        un->numSig = (uint32_t)numSig;
+        un->zeroDist = zero;
+        un->codedDist = coded;
+    }
+    __threadfence_system();                                                  // the unit's data before its ready word
+    if (writer)
+        __hip_atomic_store(&un->ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+}
+
+template <typename P>
+__device__ __forceinline__ void run_job(Slot* s, JobLds& L, uint32_t seq, uint64_t* busyTicks)
+{
+    const int tid = threadIdx.x, wv = tid >> 6;
+    const uint64_t t0 = wall_clock64();
+    // ---- job header and pixel block: host memory -> LDS
+    if (tid < (int)(sizeof(x265hip_cujob) / 4))
+        reinterpret_cast<uint32_t*>(&L.job)[tid] = reinterpret_cast<const uint32_t*>(&s->job)[tid];
+    __syncthreads();
+    const x265hip_cujob& j = L.job;
+    const int N = 1 << j.log2CUSize, NC = N >> 1;
+    const int lumaElems = N * N, planeElems = j.chroma ? lumaElems + lumaElems / 2 : lumaElems;
+    const int bytes = 2 * planeElems * (int)sizeof(P);
+    for (int i = tid * 16; i < bytes; i += 256 * 16)
+        *reinterpret_cast<uint4*>(L.pix + i) = *reinterpret_cast<const uint4*>(s->pixels + i);
+    __syncthreads();
+    const P* src = reinterpret_cast<const P*>(L.pix);
+    const P* prd = src + planeElems;
+    int sHi, sLo;
+    const int levels = x265hipi_cujob_levels(&j, &sHi, &sLo);
+    // ---- tiles, largest size first, luma before chroma; wave w takes tiles w, w + 4, ...
+    int tile = 0;
+    for (int lv = 0; lv < levels; lv++)
+    {
+        const int sz = sHi - lv;
+        const int perRow = 1 << ((int)j.log2CUSize - sz), nUnits = perRow * perRow;
+        for (int plane = 0; plane < (j.chroma ? 3 : 1); plane++)
+        {
+            const int log2n = plane ? sz - 1 : sz;                          // 5, 4 (luma) or 4, 3 (chroma)
+            const int G = 1 << (2 * (5 - log2n));
+            const int tiles = (nUnits + G - 1) / G;
+            const P* ps = plane == 0 ? src : plane == 1 ? src + lumaElems : src + lumaElems + lumaElems / 4;
+            const P* pp = plane == 0 ? prd : plane == 1 ? prd + lumaElems : prd + lumaElems + lumaElems / 4;
+            const int pw = plane ? NC : N;
+            const PlaneParams qp = plane_params(j, plane, log2n);
+            const int unitBase = x265hipi_cujob_unit_index(&j, sHi, sz, plane, 0, 0);
+            const int elemBase = x265hipi_cujob_elem_offset(&j, sHi, sz, plane, 0, 0);
+            for (int k = 0; k < tiles; k++, tile++)
+            {
+                if ((tile & 3) != wv) continue;
+                const int u0 = k * G, count = nUnits - u0 < G ? nUnits - u0 : G;
+                if (log2n == 5) tile_chain<P, 32>(L.tile[wv], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq);
+                else if (log2n == 4) tile_chain<P, 16>(L.tile[wv], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq);
+                else tile_chain<P, 8>(L.tile[wv], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0)
+        *busyTicks += wall_clock64() - t0;
+}
+
+__device__ __forceinline__ void run_job_any(Slot* s, JobLds& L, uint32_t seq, uint64_t* busyTicks)
+{
+    // bitDepth selects the pixel type; read it from the slot (uniform)
+    const uint32_t depth = __hip_atomic_load(&s->job.bitDepth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (depth == 8) run_job<uint8_t>(s, L, seq, busyTicks);
+    else run_job<uint16_t>(s, L, seq, busyTicks);
+}
+
+// mode 1: one job, one launch
+__global__ __launch_bounds__(256) void cu_job_kernel(Slot* s, uint32_t seq, uint64_t* busyTicks)
+{
+    __shared__ JobLds L;
+    run_job_any(s, L, seq, busyTicks);
+}
+
+// mode 0: workgroup b serves slot b.  The server as a whole leaves when no workgroup has taken a job for `idleTicks` (100 MHz) or the host rings
+// 0xffffffff on any slot: the workgroup that notices sets ctl->quit, every workgroup leaves at its next poll, the last one tells the host.
+__global__ __launch_bounds__(256) void cu_server_kernel(Slot* slots, HostCtl* hostCtl, DevCtl* ctl, uint32_t generation, uint64_t idleTicks)
+{
+    __shared__ JobLds L;
+    Slot* s = slots + blockIdx.x;
+    uint32_t last = 0;
+    if (threadIdx.x == 0)
+    {
+        last = __hip_atomic_load(&s->doorbell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // a job rung while no server was there has not been done: its first unit is not ready
+        if (last && last != 0xffffffffu && __hip_atomic_load(&s->units[0].ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != last)
+            last--;
+        if (blockIdx.x == 0)
+        {
+            __hip_atomic_store(&ctl->lastWork, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&hostCtl->serverState, generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    for (;;)
+    {
+        if (threadIdx.x == 0)
+        {
+            uint32_t v;
+            int polls = 0;
+            for (;;)
+            {
+                v = __hip_atomic_load(&s->doorbell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (v == 0xffffffffu) { __hip_atomic_store(&ctl->quit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if (__hip_atomic_load(&ctl->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { v = 0xffffffffu; break; }
+                if (v != last) break;
+                if ((++polls & 15) == 0 &&
+                    wall_clock64() - __hip_atomic_load(&ctl->lastWork, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > idleTicks)
+                {
+                    __hip_atomic_store(&ctl->quit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = 0xffffffffu;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (v != 0xffffffffu)
+                __hip_atomic_store(&ctl->lastWork, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            L.seq = v;
+        }
+        __syncthreads();
+        const uint32_t v = L.seq;
+        __syncthreads();
+        if (v == 0xffffffffu)
+        {
+            // the last workgroup out tells the host; a submitter that rang in between finds serverState == 0 while it waits and starts the next server
+            if (threadIdx.x == 0 && __hip_atomic_fetch_add(&ctl->left, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
+                __hip_atomic_store(&hostCtl->serverState, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        last = v;
+        run_job_any(s, L, v, &ctl->busyTicks[blockIdx.x]);
+    }
+}
+
+} // namespace
+} // namespace xh
+
+using namespace xh;
+
+struct x265hip_cuserve
+{
+    int slots = 0, mode = 0, device = 0;
+    Slot* host = nullptr;                         // page-locked, coherent
+    Slot* dev = nullptr;                          // the same memory as the device addresses it
+    HostCtl* hostCtl = nullptr; HostCtl* devHostCtl = nullptr;
+    DevCtl* ctl = nullptr;                        // device memory
+    hipStream_t serverStream = nullptr;
+    hipStream_t* jobStreams = nullptr;            // mode 1
+    std::atomic<uint32_t>* seq = nullptr;         // per slot
+    std::atomic<uint32_t> generation{ 0 };
+    std::mutex launchLock;
+    std::atomic<uint64_t> jobs{ 0 }, starts{ 0 };
+    uint64_t idleUs = 2000;
+};
+
+static int start_server(x265hip_cuserve* cs)
+{
+    std::lock_guard<std::mutex> g(cs->launchLock);
+    if (__atomic_load_n(&cs->hostCtl->serverState, __ATOMIC_ACQUIRE) != 0)
+        return X265HIP_OK;                                                   // someone else has started one meanwhile
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != cs->device && hipSetDevice(cs->device) != hipSuccess)
+        return set_error(X265HIP_EHIP, "cuserve: hipSetDevice(%d) failed", cs->device);
+    const uint32_t gen = (cs->generation.fetch_add(1) + 1) & 0x7fffffffu;
+    // the device writes the word when the server runs; "being started" keeps other submitters from starting a second one
+    __atomic_store_n(&cs->hostCtl->serverState, 0x80000000u | gen, __ATOMIC_RELEASE);
+    // quit / left back to zero in stream order (the previous server, if any, has left: it was the one that cleared serverState)
+    hipError_t e = hipMemsetAsync(cs->ctl, 0, 8, cs->serverStream);
+    if (e == hipSuccess)
+    {
+        hipLaunchKernelGGL(cu_server_kernel, dim3(cs->slots), dim3(256), 0, cs->serverStream, cs->dev, cs->devHostCtl, cs->ctl, gen ? gen : 1u, cs->idleUs * 100);
+        e = hipGetLastError();
+    }
+    if (cur >= 0 && cur != cs->device) (void)hipSetDevice(cur);
+    if (e != hipSuccess)
+    {
+        __atomic_store_n(&cs->hostCtl->serverState, 0u, __ATOMIC_RELEASE);
+        return check_hip(e, "cu_server_kernel");
+    }
+    cs->starts++;
+    return X265HIP_OK;
+}
+
+extern "C" {
+
+int x265hip_cuserve_open(int slots, int mode, x265hip_cuserve** out)
+{
+    XH_CHECK_DEV();
+    if (!out || slots < 1 || slots > 256 || mode < 0 || mode > 1)
+        return set_error(X265HIP_EINVAL, "x265hip_cuserve_open: slots %d mode %d", slots, mode);
+    x265hip_cuserve* cs = new (std::nothrow) x265hip_cuserve;
+    if (!cs) return set_error(X265HIP_ENOMEM, "x265hip_cuserve_open: out of memory");
+    cs->slots = slots; cs->mode = mode;
+    (void)hipGetDevice(&cs->device);
+    if (const char* env = getenv("X265HIP_CUSERVE_IDLE_US")) cs->idleUs = (uint64_t)atoll(env);
+    int e = check_hip(hipHostMalloc((void**)&cs->host, sizeof(Slot) * slots, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc(cuserve slots)");
+    if (!e) { memset(cs->host, 0, sizeof(Slot) * slots); e = check_hip(hipHostGetDevicePointer((void**)&cs->dev, cs->host, 0), "hipHostGetDevicePointer(cuserve)"); }
+    if (!e) e = check_hip(hipHostMalloc((void**)&cs->hostCtl, 64, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc(cuserve control)");
+    if (!e) { memset(cs->hostCtl, 0, 64); e = check_hip(hipHostGetDevicePointer((void**)&cs->devHostCtl, cs->hostCtl, 0), "hipHostGetDevicePointer(cuserve control)"); }
+    if (!e) e = check_hip(hipMalloc((void**)&cs->ctl, sizeof(DevCtl)), "hipMalloc(cuserve control)");
+    // the server stream gets the highest priority: HIP maps priorities to separate hardware queues, so the resident kernel never sits in front of
+    // another stream's packets in the same queue
+    int lo = 0, hi = 0;
+    if (!e) { (void)hipDeviceGetStreamPriorityRange(&lo, &hi); e = check_hip(hipStreamCreateWithPriority(&cs->serverStream, hipStreamNonBlocking, hi), "hipStreamCreateWithPriority(cuserve)"); }
+    if (!e) e = check_hip(hipMemsetAsync(cs->ctl, 0, sizeof(DevCtl), cs->serverStream), "hipMemsetAsync(cuserve control)");
+    if (!e) e = check_hip(hipStreamSynchronize(cs->serverStream), "hipStreamSynchronize(cuserve)");
+    if (!e)
+    {
+        cs->seq = new (std::nothrow) std::atomic<uint32_t>[slots];
+        cs->jobStreams = new (std::nothrow) hipStream_t[slots];
+        if (!cs->seq || !cs->jobStreams) e = set_error(X265HIP_ENOMEM, "x265hip_cuserve_open: out of memory");
+        else
+            for (int i = 0; i < slots; i++) { cs->seq[i] = 0; cs->jobStreams[i] = nullptr; }
+    }
+    if (!e && mode == 1)
+        for (int i = 0; i < slots && !e; i++)
+            e = check_hip(hipStreamCreateWithFlags(&cs->jobStreams[i], hipStreamNonBlocking), "hipStreamCreate(cuserve job)");
+    if (e) { x265hip_cuserve_close(cs); return e; }
+    *out = cs;
+    return X265HIP_OK;
+}
+
+static uint64_t device_ticks(x265hip_cuserve* cs)
+{
+    if (!cs->ctl) return 0;
+    static thread_local uint64_t buf[256];
+    // a plain copy on the null stream would wait for the resident server: copy on a stream of its own
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    uint64_t ticks = 0;
+    if (hipMemcpyAsync(buf, (char*)cs->ctl + offsetof(DevCtl, busyTicks), sizeof(uint64_t) * cs->slots, hipMemcpyDeviceToHost, st) == hipSuccess &&
+        hipStreamSynchronize(st) == hipSuccess)
+        for (int i = 0; i < cs->slots; i++) ticks += buf[i];
+    else
+        (void)hipGetLastError();
+    (void)hipStreamDestroy(st);
+    return ticks;
+}
+
+int x265hip_cuserve_close(x265hip_cuserve* cs)
+{
+    if (!cs) return X265HIP_OK;
+    if (cs->host)
+    {
+        __atomic_store_n(&cs->host[0].doorbell, 0xffffffffu, __ATOMIC_RELEASE);           // a resident server leaves at its next poll
+        if (cs->serverStream) (void)hipStreamSynchronize(cs->serverStream);
+        if (cs->jobStreams)
+            for (int i = 0; i < cs->slots; i++)
+                if (cs->jobStreams[i]) { (void)hipStreamSynchronize(cs->jobStreams[i]); (void)hipStreamDestroy(cs->jobStreams[i]); }
+        clock_add(X265HIP_CLK_CUSERVE, cs->jobs.load(), device_ticks(cs) * 10, 0);
+        (void)hipHostFree(cs->host);
+    }
+    if (cs->hostCtl) (void)hipHostFree(cs->hostCtl);
+    if (cs->ctl) (void)hipFree(cs->ctl);
+    if (cs->serverStream) (void)hipStreamDestroy(cs->serverStream);
+    delete[] cs->seq; delete[] cs->jobStreams;
+    delete cs;
+    return X265HIP_OK;
+}
+
+int x265hip_cuserve_slot(x265hip_cuserve* cs, int slot, x265hip_cujob** job, void** pixels, const x265hip_cujob_unit** units, const int16_t** levels,
+                         const int16_t** resi)
+{
+    if (!cs || slot < 0 || slot >= cs->slots) return set_error(X265HIP_EINVAL, "x265hip_cuserve_slot: slot %d", slot);
+    Slot* s = cs->host + slot;
+    if (job) *job = &s->job;
+    if (pixels) *pixels = s->pixels;
+    if (units) *units = s->units;
+    if (levels) *levels = s->levels;
+    if (resi) *resi = s->resi;
+    return X265HIP_OK;
+}
+
+int x265hip_cuserve_submit(x265hip_cuserve* cs, int slot, uint32_t* seqOut)
+{
+    if (!cs || slot < 0 || slot >= cs->slots || !seqOut) return set_error(X265HIP_EINVAL, "x265hip_cuserve_submit: slot %d", slot);
+    Slot* s = cs->host + slot;
+    const x265hip_cujob& j = s->job;
+    int sHi, sLo;
+    if (j.log2CUSize < 4 || j.log2CUSize > 6 || x265hipi_cujob_levels(&j, &sHi, &sLo) < 1 || !valid_depth((int)j.bitDepth))
+        return set_error(X265HIP_EINVAL, "x265hip_cuserve_submit: CU 2^%u, transform sizes 2^%u..2^%u, depth %u", j.log2CUSize, j.log2TrMin, j.log2TrMax, j.bitDepth);
+    uint32_t seq = cs->seq[slot].load(std::memory_order_relaxed) + 1;                       // a slot has one submitter at a time
+    if (seq >= 0xfffffff0u) seq = 1;
+    cs->seq[slot].store(seq, std::memory_order_relaxed);
+    *seqOut = seq;
+    cs->jobs.fetch_add(1, std::memory_order_relaxed);
+    if (cs->mode == 1)
+    {
+        std::atomic_thread_fence(std::memory_order_release);
+        hipLaunchKernelGGL(cu_job_kernel, dim3(1), dim3(256), 0, cs->jobStreams[slot], cs->dev + slot, seq, &cs->ctl->busyTicks[slot]);
+        XH_LAUNCH_CHECK("cu_job_kernel");
+        return X265HIP_OK;
+    }
+    __atomic_store_n(&s->doorbell, seq, __ATOMIC_RELEASE);
+    if (__atomic_load_n(&cs->hostCtl->serverState, __ATOMIC_ACQUIRE) == 0)
+        return start_server(cs);
+    return X265HIP_OK;
+}
+
+int x265hip_cuserve_poke(x265hip_cuserve* cs, int slot)
+{
+    if (!cs || slot < 0 || slot >= cs->slots) return set_error(X265HIP_EINVAL, "x265hip_cuserve_poke: slot %d", slot);
+    if (__atomic_load_n(&cs->host[slot].failed, __ATOMIC_ACQUIRE)) return set_error(X265HIP_EHIP, "cuserve: the device gave up a job of slot %d", slot);
+    if (cs->mode == 0 && __atomic_load_n(&cs->hostCtl->serverState, __ATOMIC_ACQUIRE) == 0)
+        return start_server(cs);
+    return X265HIP_OK;
+}
+
+int x265hip_cuserve_stats(x265hip_cuserve* cs, uint64_t* jobs, uint64_t* serverStarts, uint64_t* deviceNs)
+{
+    if (!cs) return set_error(X265HIP_EINVAL, "x265hip_cuserve_stats: null");
+    if (jobs) *jobs = cs->jobs.load();
+    if (serverStarts) *serverStarts = cs->starts.load();
+    if (deviceNs) *deviceNs = device_ticks(cs) * 10;
+    return X265HIP_OK;
+}
+
+} // extern "C"

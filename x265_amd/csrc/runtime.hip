@@ -88,6 +88,12 @@ int place_of_device(int device) { return -(device + 1); }
 
 static std::atomic<uint64_t> g_clkSpans[X265HIP_CLK_COUNT], g_clkNs[X265HIP_CLK_COUNT], g_clkBytes[X265HIP_CLK_COUNT];
 
+void clock_add(int clk, uint64_t spans, uint64_t ns, uint64_t bytes)
+{
+    if (clk < 0 || clk >= X265HIP_CLK_COUNT) return;
+    g_clkSpans[clk] += spans; g_clkNs[clk] += ns; g_clkBytes[clk] += bytes;
+}
+
 DevSpan::DevSpan(int clock, hipStream_t stream) : clk(clock), st(stream)
 {
     static thread_local hipEvent_t ev[X265HIP_CLK_COUNT][2];

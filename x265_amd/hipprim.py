@@ -183,6 +183,12 @@ PROTOTYPES = {
     "x265hip_sadsurf_get_view": (vp, [vp]),
     "x265hip_sadsurf_release": (None, [vp]),
     "x265hip_sadsurf_stats": (i32, [vp, vp, vp, vp]),
+    "x265hip_cuserve_open": (i32, [i32, i32, C.POINTER(vp)]),
+    "x265hip_cuserve_close": (i32, [vp]),
+    "x265hip_cuserve_slot": (i32, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+    "x265hip_cuserve_submit": (i32, [vp, i32, C.POINTER(u32)]),
+    "x265hip_cuserve_poke": (i32, [vp, i32]),
+    "x265hip_cuserve_stats": (i32, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
     "x265hip_device_time": (i32, [i32, vp, vp, vp]),
     "x265hip_sadsurf_attach_levels": (vp, [vp, vp, i32, i32, i32]),
     "x265hip_places": (i32, [i32, vp]),
@@ -247,6 +253,22 @@ class SadSurfLevel(C.Structure):
 class SadSurfView(C.Structure):
     """x265hip_sadsurf_view (include/x265hip.h)"""
     _fields_ = [("level", SadSurfLevel * 4), ("ctuRowPitch", C.c_int64), ("ctuRowsReady", C.POINTER(C.c_int))]
+
+
+class CuJob(C.Structure):
+    """x265hip_cujob (include/x265hip.h): the header of a CU residual quad-tree job"""
+    _fields_ = [("log2CUSize", u32), ("log2TrMax", u32), ("log2TrMin", u32), ("chroma", u32), ("bitDepth", u32), ("quantOffset", u32), ("signHide", u32),
+                ("reserved", u32), ("qpRem", C.c_int32 * 3), ("qpPer", C.c_int32 * 3), ("quantScale", C.c_int32 * 3), ("dequantScale", C.c_int32 * 3)]
+
+
+class CuJobUnit(C.Structure):
+    """x265hip_cujob_unit (include/x265hip.h): one transform unit's result header"""
+    _fields_ = [("ready", u32), ("numSig", u32), ("zeroDist", u64), ("codedDist", u64), ("reserved", u64)]
+
+
+CUJOB_MAX_UNITS = 60
+CUJOB_MAX_ELEMS = 2 * 6144
+CUJOB_PIXEL_BYTES = 2 * 6144 * 2
 
 
 class LaSearch(C.Structure):

@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 
 #define protected public
 #define private public
@@ -35,6 +36,7 @@
 #include "shortyuv.h"
 #include "cudata.h"
 #include "quant.h"
+#include "scalinglist.h"
 #include "search.h"
 #undef protected
 #undef private
@@ -66,13 +68,48 @@ extern void refInvtransformNxN(Quant* self, const CUData& cu, int16_t* residual,
 namespace {
 
 int g_state = 0;                 // 0 undecided, 1 on, -1 off
-int g_time = 0;                  // X265HIP_DEBUG_CUTIME=1: cycles inside the functions a job could replace, by block size (report at exit)
+int g_time = 0;                  // X265HIP_DEBUG_CUTIME=1: cycles inside the functions a job could replace, by block size (report at exit);
+                                 // =2: the same with the jobs running (the pair of runs measures what the jobs save and what the waiting costs)
+int g_minLog2 = 5;               // X265HIP_CUSERVE_MIN: smallest CU (log2) whose residual quad-tree becomes a job
+int g_mode = 1;                  // X265HIP_CUSERVE_MODE: 0 resident server (mailbox), 1 one launch per job
+int g_slots = 64;                // X265HIP_CUSERVE_SLOTS: host threads that can have a job in flight
+bool g_verify = false;           // X265HIP_VERIFY=1: every served unit is recomputed by the reference's function and compared
+bool g_require = false;          // X265HIP=require: a device failure is fatal instead of falling back
 std::mutex g_lock;
+x265hip_cuserve* g_cs = NULL;
+std::atomic<int> g_nextSlot(0);
+std::atomic<bool> g_dead(false); // the device failed once: every later CU is computed on the host
 
 // X265HIP_DEBUG_CUTIME: [0..3] transformNxN by log2TrSize - 2, [4..7] invtransformNxN, [8..12] top-level estimateResidualQT by log2CUSize - 2,
 // [13..17] checkIntraInInter by log2CUSize - 2; second index: 0 inside a top-level estimateResidualQT of this thread, 1 elsewhere
 std::atomic<uint64_t> g_cycles[18][2], g_calls[18][2];
 __attribute__((tls_model("initial-exec"))) thread_local int t_inRqt = 0;
+
+struct alignas(64) Counters { std::atomic<uint64_t> jobs, fwd, inv, fwdMiss, invMiss, waitCycles, waits, skipped; };
+Counters g_count[64];
+std::atomic<int> g_nextShard(0);
+__attribute__((tls_model("initial-exec"))) thread_local int t_shard = -1;
+inline Counters& counters() { if (t_shard < 0) t_shard = g_nextShard.fetch_add(1) & 63; return g_count[t_shard]; }
+
+// the job of the top-level estimateResidualQT in progress on this thread
+struct Job
+{
+    bool active;
+    const Quant* quant;                  // the Search object's quantiser: only its calls are looked at
+    const int16_t* resi[3]; uint32_t resiStride[3];      // the CU's residual blocks (ShortYuv): what identifies a unit
+    uint32_t log2CU;
+    int sHi, sLo;
+    uint32_t seq;
+    int slot;
+    x265hip_cujob* job;
+    const x265hip_cujob_unit* units;
+    const int16_t* levels;
+    const int16_t* resiOut;
+};
+__attribute__((tls_model("initial-exec"))) thread_local Job t_job;
+struct SlotMem { x265hip_cujob* job; void* pixels; const x265hip_cujob_unit* units; const int16_t* levels; const int16_t* resi; };
+__attribute__((tls_model("initial-exec"))) thread_local int t_slot = -2;           // -2: not asked yet, -1: none left
+__attribute__((tls_model("initial-exec"))) thread_local SlotMem t_mem;
 
 void report_time()
 {
@@ -88,6 +125,25 @@ void report_time()
     }
 }
 
+void report()
+{
+    uint64_t jobs = 0, fwd = 0, inv = 0, fm = 0, im = 0, wc = 0, w = 0, sk = 0;
+    for (int i = 0; i < 64; i++)
+    {
+        jobs += g_count[i].jobs; fwd += g_count[i].fwd; inv += g_count[i].inv; fm += g_count[i].fwdMiss; im += g_count[i].invMiss;
+        wc += g_count[i].waitCycles; w += g_count[i].waits; sk += g_count[i].skipped;
+    }
+    uint64_t devJobs = 0, starts = 0, ns = 0;
+    if (g_cs) x265hip_cuserve_stats(g_cs, &devJobs, &starts, &ns);
+    fprintf(stderr, "x265hip: cuserve: %llu CU residual quad-trees (CU >= %d) handed to the GPU as jobs (%s, %.3f ms of device time%s): %llu forward "
+                    "transform+quant units and %llu inverse units served, %llu + %llu calls of those CUs computed on the host; %llu waits of %.0f cycles on average; "
+                    "%llu CUs not submitted%s\n",
+            (unsigned long long)jobs, 1 << g_minLog2, g_mode ? "one launch per job" : "resident server", ns * 1e-6,
+            g_mode ? "" : (std::string(", ") + std::to_string(starts) + " server starts").c_str(), (unsigned long long)fwd, (unsigned long long)inv,
+            (unsigned long long)fm, (unsigned long long)im, (unsigned long long)w, w ? (double)wc / w : 0.0, (unsigned long long)sk,
+            g_dead.load() ? "; THE DEVICE FAILED during the run, the rest was computed on the host" : "");
+}
+
 bool decide()
 {
     std::lock_guard<std::mutex> g(g_lock);
@@ -96,12 +152,103 @@ bool decide()
         g_time = getenv("X265HIP_DEBUG_CUTIME") ? atoi(getenv("X265HIP_DEBUG_CUTIME")) : 0;
         if (g_time)
             atexit(report_time);
-        g_state = -1;
+        const char* env = getenv("X265HIP_CUSERVE");
+        const char* all = getenv("X265HIP");
+        const char* table = getenv("X265HIP_TABLE");
+        g_require = all && !strcmp(all, "require");
+        g_verify = getenv("X265HIP_VERIFY") != NULL;
+        if (getenv("X265HIP_CUSERVE_MIN")) { const int v = atoi(getenv("X265HIP_CUSERVE_MIN")); g_minLog2 = v >= 64 ? 6 : v >= 32 ? 5 : 4; }
+        if (getenv("X265HIP_CUSERVE_MODE")) g_mode = atoi(getenv("X265HIP_CUSERVE_MODE")) ? 1 : 0;
+        if (getenv("X265HIP_CUSERVE_SLOTS")) g_slots = atoi(getenv("X265HIP_CUSERVE_SLOTS"));
+        if (g_slots < 1) g_slots = 1;
+        if (g_slots > 256) g_slots = 256;
+        if ((env && !strcmp(env, "0")) || (all && !strcmp(all, "0")) || (table && !strcmp(table, "percall")) || g_time == 1)
+            g_state = -1;
+        else
+            g_state = 1;
     }
     return g_state > 0;
 }
-inline bool enabled() { return g_state ? g_state > 0 : decide(); }
-struct DecideAtLoad { DecideAtLoad() { decide(); } } g_decideAtLoad;        // the Quant seams read g_time without asking
+struct DecideAtLoad { DecideAtLoad() { decide(); } } g_decideAtLoad;        // the Quant seams read g_time / g_state without asking
+
+// a device failure: said once, fatal under X265HIP=require, otherwise every later CU is computed by the reference's functions (SURVEY §8b "Errors")
+void device_failed(const char* what)
+{
+    if (!g_dead.exchange(true))
+        fprintf(stderr, "x265hip: cuserve: %s: %s — CU jobs are OFF from here on, the host computes\n", what, x265hip_last_error());
+    if (g_require)
+        abort();
+}
+
+// this thread's slot; opens the service on first use
+bool my_slot()
+{
+    if (t_slot >= 0) return true;
+    if (t_slot == -1 || g_dead.load(std::memory_order_relaxed)) return false;
+    t_slot = -1;
+    {
+        std::lock_guard<std::mutex> g(g_lock);
+        if (!g_cs && !g_dead.load())
+        {
+            if (x265hip_device_count() < 1) { g_dead = true; return false; }       // said by setupAssemblyPrimitives already
+            if (x265hip_cuserve_open(g_slots, g_mode, &g_cs)) { g_cs = NULL; device_failed("x265hip_cuserve_open"); return false; }
+            if (getenv("X265HIP_VERBOSE"))
+                atexit(report);
+        }
+        if (!g_cs) return false;
+    }
+    const int s = g_nextSlot.fetch_add(1);
+    if (s >= g_slots) return false;
+    if (x265hip_cuserve_slot(g_cs, s, &t_mem.job, &t_mem.pixels, &t_mem.units, &t_mem.levels, &t_mem.resi)) return false;
+    t_slot = s;
+    return true;
+}
+
+template <typename T> inline void pack_rows(T*& dst, const T* src, uint32_t stride, int n)
+{
+    if ((int)stride == n) { memcpy(dst, src, sizeof(T) * n * n); dst += n * n; return; }
+    for (int y = 0; y < n; y++, dst += n) memcpy(dst, src + (size_t)y * stride, sizeof(T) * n);
+}
+
+// unit of this thread's job a residual block belongs to, or -1
+inline int locate(const Job& j, const int16_t* residual, uint32_t resiStride, uint32_t log2TrSize, int ttype, int* elemOff)
+{
+    const int s = ttype ? (int)log2TrSize + 1 : (int)log2TrSize;
+    if (s > j.sHi || s < j.sLo || resiStride != j.resiStride[ttype]) return -1;
+    const ptrdiff_t d = residual - j.resi[ttype];
+    const int N = (1 << j.log2CU) >> (ttype ? 1 : 0), n = 1 << log2TrSize;
+    if (d < 0 || d >= (ptrdiff_t)resiStride * N) return -1;
+    const int y = (int)(d / resiStride), x = (int)(d % resiStride);
+    if (x >= N || (x & (n - 1)) || (y & (n - 1))) return -1;
+    *elemOff = x265hipi_cujob_elem_offset(j.job, j.sHi, s, ttype, x >> log2TrSize, y >> log2TrSize);
+    return x265hipi_cujob_unit_index(j.job, j.sHi, s, ttype, x >> log2TrSize, y >> log2TrSize);
+}
+
+// waits for unit u of this thread's job; false: the device did not deliver (the job is abandoned)
+inline bool wait_unit(Job& j, int u)
+{
+    const uint32_t* ready = &j.units[u].ready;
+    if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == j.seq) return true;
+    const uint64_t t0 = __builtin_ia32_rdtsc();
+    uint64_t spins = 0;
+    while (__atomic_load_n(ready, __ATOMIC_ACQUIRE) != j.seq)
+    {
+        __builtin_ia32_pause();
+        if ((++spins & 255) == 0)
+        {
+            if (x265hip_cuserve_poke(g_cs, j.slot) || __builtin_ia32_rdtsc() - t0 > 3000000000ull)      // ~1 s: not a latency, a failure
+            {
+                j.active = false;
+                device_failed("a job did not come back");
+                return false;
+            }
+        }
+    }
+    Counters& c = counters();
+    c.waitCycles.fetch_add(__builtin_ia32_rdtsc() - t0, std::memory_order_relaxed);
+    c.waits.fetch_add(1, std::memory_order_relaxed);
+    return true;
+}
 
 struct Timed
 {
@@ -115,26 +262,85 @@ struct Timed
     }
 };
 
+// the job of one CU: header + pixels into this thread's slot, submit
+bool submit(Search* se, Mode& mode, const CUGeom& cuGeom, ShortYuv& resiYuv, const uint32_t depthRange[2])
+{
+    const CUData& cu = mode.cu;
+    const Quant& q = se->m_quant;
+    const int csp = se->m_csp;
+    const bool codeChroma = csp != X265_CSP_I400 && se->m_frame->m_fencPic->m_picCsp != X265_CSP_I400;
+    if (cu.m_tqBypass[0] || q.m_rdoqLevel || (q.m_nr && q.m_nr->offset) || q.m_scalingList->m_bEnabled || (csp != X265_CSP_I420 && csp != X265_CSP_I400) ||
+        (csp == X265_CSP_I420) != codeChroma)
+        return false;
+    x265hip_cujob hdr;
+    hdr.log2CUSize = cuGeom.log2CUSize; hdr.log2TrMax = depthRange[1]; hdr.log2TrMin = depthRange[0];
+    hdr.chroma = codeChroma; hdr.bitDepth = X265_DEPTH;
+    hdr.quantOffset = cu.m_slice->m_sliceType == I_SLICE ? 171 : 85;
+    hdr.signHide = cu.m_slice->m_pps->bSignHideEnabled;
+    hdr.reserved = 0;
+    int sHi, sLo;
+    if (x265hipi_cujob_levels(&hdr, &sHi, &sLo) < 1 || !my_slot())
+        return false;
+    for (int p = 0; p < 3; p++)
+    {
+        const QpParam& qp = q.m_qpParam[p];
+        hdr.qpRem[p] = qp.rem; hdr.qpPer[p] = qp.per;
+        hdr.quantScale[p] = q.m_scalingList->m_quantCoef[3][3 + p][qp.rem][0];          // flat: every entry of every size and list is s_quantScales[rem]
+        hdr.dequantScale[p] = ScalingList::s_invQuantScales[qp.rem];
+    }
+    const int N = 1 << cuGeom.log2CUSize;
+    const Yuv* fenc = mode.fencYuv;
+    const Yuv* pred = &mode.predYuv;
+    *t_mem.job = hdr;
+    pixel* dst = (pixel*)t_mem.pixels;
+    pack_rows(dst, fenc->m_buf[0], fenc->m_size, N);
+    if (codeChroma) { pack_rows(dst, fenc->m_buf[1], fenc->m_csize, N / 2); pack_rows(dst, fenc->m_buf[2], fenc->m_csize, N / 2); }
+    pack_rows(dst, pred->m_buf[0], pred->m_size, N);
+    if (codeChroma) { pack_rows(dst, pred->m_buf[1], pred->m_csize, N / 2); pack_rows(dst, pred->m_buf[2], pred->m_csize, N / 2); }
+    Job& j = t_job;
+    if (x265hip_cuserve_submit(g_cs, t_slot, &j.seq))
+    {
+        device_failed("x265hip_cuserve_submit");
+        return false;
+    }
+    j.quant = &q;
+    for (int p = 0; p < 3; p++) { j.resi[p] = resiYuv.m_buf[p]; j.resiStride[p] = p ? resiYuv.m_csize : resiYuv.m_size; }
+    if (!codeChroma) j.resi[1] = j.resi[2] = NULL;
+    j.log2CU = cuGeom.log2CUSize; j.sHi = sHi; j.sLo = sLo; j.slot = t_slot;
+    j.job = t_mem.job; j.units = t_mem.units; j.levels = t_mem.levels; j.resiOut = t_mem.resi;
+    j.active = true;
+    counters().jobs.fetch_add(1, std::memory_order_relaxed);
+    return true;
+}
+
 } // namespace
 
 void Search::estimateResidualQT(Mode& mode, const CUGeom& cuGeom, uint32_t absPartIdx, uint32_t tuDepth, ShortYuv& resiYuv, Cost& outCosts, const uint32_t depthRange[2],
                                 int32_t splitMore)
 {
-    enabled();
+    // only the top-level call arrives here (the reference body recurses into its own copy)
+    const bool serve = g_state > 0 && !g_dead.load(std::memory_order_relaxed) && (int)cuGeom.log2CUSize >= g_minLog2 && !t_job.active && !tuDepth && !absPartIdx;
+    bool submitted = false;
+    if (serve)
+    {
+        submitted = submit(this, mode, cuGeom, resiYuv, depthRange);
+        if (!submitted) counters().skipped.fetch_add(1, std::memory_order_relaxed);
+    }
     if (g_time)
     {
         Timed t(8 + cuGeom.log2CUSize - 2);
         t_inRqt++;
         refEstimateResidualQT(this, mode, cuGeom, absPartIdx, tuDepth, resiYuv, outCosts, depthRange, splitMore);
         t_inRqt--;
-        return;
     }
-    refEstimateResidualQT(this, mode, cuGeom, absPartIdx, tuDepth, resiYuv, outCosts, depthRange, splitMore);
+    else
+        refEstimateResidualQT(this, mode, cuGeom, absPartIdx, tuDepth, resiYuv, outCosts, depthRange, splitMore);
+    if (submitted)
+        t_job.active = false;
 }
 
 void Search::checkIntraInInter(Mode& intraMode, const CUGeom& cuGeom)
 {
-    enabled();
     if (g_time)
     {
         Timed t(13 + cuGeom.log2CUSize - 2);
@@ -147,6 +353,42 @@ void Search::checkIntraInInter(Mode& intraMode, const CUGeom& cuGeom)
 uint32_t Quant::transformNxN(const CUData& cu, const pixel* fenc, uint32_t fencStride, const int16_t* residual, uint32_t resiStride, coeff_t* coeff, uint32_t log2TrSize,
                              TextType ttype, uint32_t absPartIdx, bool useTransformSkip)
 {
+    Job& j = t_job;
+    if (j.active && j.quant == this && !useTransformSkip)
+    {
+        int eo = 0;
+        const int u = locate(j, residual, resiStride, log2TrSize, (int)ttype, &eo);
+        if (u >= 0)
+        {
+            const uint64_t t0 = g_time ? __builtin_ia32_rdtsc() : 0;
+            if (wait_unit(j, u))
+            {
+                const int n2 = 1 << (2 * log2TrSize);
+                memcpy(coeff, j.levels + eo, sizeof(coeff_t) * n2);
+                const uint32_t numSig = j.units[u].numSig;
+                if (g_verify)
+                {
+                    coeff_t want[1024];
+                    const uint32_t ns = refTransformNxN(this, cu, fenc, fencStride, residual, resiStride, want, log2TrSize, ttype, absPartIdx, useTransformSkip);
+                    if (ns != numSig || memcmp(want, coeff, sizeof(coeff_t) * n2))
+                    {
+                        fprintf(stderr, "x265hip: cuserve: VERIFY FAILED transformNxN %dx%d plane %d: numSig %u (device) vs %u\n", 1 << log2TrSize, 1 << log2TrSize, (int)ttype,
+                                numSig, ns);
+                        abort();
+                    }
+                }
+                counters().fwd.fetch_add(1, std::memory_order_relaxed);
+                if (g_time)
+                {
+                    g_cycles[log2TrSize - 2][0].fetch_add(__builtin_ia32_rdtsc() - t0, std::memory_order_relaxed);
+                    g_calls[log2TrSize - 2][0].fetch_add(1, std::memory_order_relaxed);
+                }
+                return numSig;
+            }
+        }
+        else
+            counters().fwdMiss.fetch_add(1, std::memory_order_relaxed);
+    }
     if (g_time)
     {
         Timed t(log2TrSize - 2);
@@ -158,6 +400,46 @@ uint32_t Quant::transformNxN(const CUData& cu, const pixel* fenc, uint32_t fencS
 void Quant::invtransformNxN(const CUData& cu, int16_t* residual, uint32_t resiStride, const coeff_t* coeff, uint32_t log2TrSize, TextType ttype, bool bIntra,
                             bool useTransformSkip, uint32_t numSig)
 {
+    Job& j = t_job;
+    if (j.active && j.quant == this && !useTransformSkip && !bIntra)
+    {
+        // which unit?  the one of this size and plane whose levels these are: equal levels have equal inverse transforms, so the comparison — not
+        // any bookkeeping — is what makes the copy exact.  The tree asks for a unit's inverse right after its forward transform: look there first.
+        const int s = ttype ? (int)log2TrSize + 1 : (int)log2TrSize;
+        if (s <= j.sHi && s >= j.sLo && (ttype == TEXT_LUMA || j.resi[ttype]))
+        {
+            const uint64_t t0 = g_time ? __builtin_ia32_rdtsc() : 0;
+            const int per = 1 << (j.log2CU - s), n = 1 << log2TrSize, n2 = n * n;
+            const int first = x265hipi_cujob_unit_index(j.job, j.sHi, s, (int)ttype, 0, 0), eo0 = x265hipi_cujob_elem_offset(j.job, j.sHi, s, (int)ttype, 0, 0);
+            for (int t = 0; t < per * per; t++)
+            {
+                const x265hip_cujob_unit& un = j.units[first + t];
+                if (__atomic_load_n(&un.ready, __ATOMIC_ACQUIRE) != j.seq || un.numSig != numSig || memcmp(coeff, j.levels + eo0 + t * n2, sizeof(coeff_t) * n2))
+                    continue;
+                const int16_t* src = j.resiOut + eo0 + t * n2;
+                for (int y = 0; y < n; y++)
+                    memcpy(residual + (size_t)y * resiStride, src + y * n, sizeof(int16_t) * n);
+                if (g_verify)
+                {
+                    int16_t want[1024];
+                    refInvtransformNxN(this, cu, want, n, coeff, log2TrSize, ttype, bIntra, useTransformSkip, numSig);
+                    if (memcmp(want, src, sizeof(int16_t) * n2))
+                    {
+                        fprintf(stderr, "x265hip: cuserve: VERIFY FAILED invtransformNxN %dx%d plane %d numSig %u\n", n, n, (int)ttype, numSig);
+                        abort();
+                    }
+                }
+                counters().inv.fetch_add(1, std::memory_order_relaxed);
+                if (g_time)
+                {
+                    g_cycles[4 + log2TrSize - 2][0].fetch_add(__builtin_ia32_rdtsc() - t0, std::memory_order_relaxed);
+                    g_calls[4 + log2TrSize - 2][0].fetch_add(1, std::memory_order_relaxed);
+                }
+                return;
+            }
+            counters().invMiss.fetch_add(1, std::memory_order_relaxed);
+        }
+    }
     if (g_time)
     {
         Timed t(4 + log2TrSize - 2);
