@@ -1,0 +1,93 @@
+// cuserve_rt.cpp — round trip of the PRODUCT's CU residual quad-tree jobs through the C ABI (include/x265hip.h, x265hip_cuserve_*): a host thread
+// fills its slot, submits, and spins on the units' ready words, as x265_amd/host/x265_hip_cuserve.cpp does.  (measurement aid)
+//   cuserve_rt <mode 0|1> [iters]        1, 4 and 16 submitting threads; 32x32 and 64x64 CUs (4:2:0, 8 bit, one transform size)
+#include <atomic>
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include "../../include/x265hip.h"
+
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char** argv)
+{
+    const int mode = argc > 1 ? atoi(argv[1]) : 1, iters = argc > 2 ? atoi(argv[2]) : 3000;
+    if (x265hip_device_count() < 1 || x265hip_init(0)) { fprintf(stderr, "no device: %s\n", x265hip_last_error()); return 2; }
+    x265hip_cuserve* cs = NULL;
+    if (x265hip_cuserve_open(16, mode, &cs)) { fprintf(stderr, "open: %s\n", x265hip_last_error()); return 2; }
+    std::atomic<bool> failed(false);
+    for (int log2cu = 5; log2cu <= 6; log2cu++)
+        for (int T : { 1, 4, 16 })
+        {
+            std::vector<std::vector<double>> lat(T), first(T);
+            std::atomic<int> go(0);
+            auto body = [&](int t)
+            {
+                x265hip_init(0);
+                x265hip_cujob* job; void* pixels; const x265hip_cujob_unit* units; const int16_t* levels; const int16_t* resi;
+                x265hip_cuserve_slot(cs, t, &job, &pixels, &units, &levels, &resi);
+                const int N = 1 << log2cu, bytes = 2 * (N * N + N * N / 2);
+                std::vector<unsigned char> src(bytes);
+                uint32_t s = 1234 + t;
+                for (auto& b : src) { s = s * 1664525u + 1013904223u; b = (unsigned char)(128 + ((s >> 24) & 15)); }
+                while (!go.load()) {}
+                for (int i = 0; i < iters + 100 && !failed; i++)
+                {
+                    src[i % bytes] ^= 3;
+                    const double t0 = now_us();
+                    memset(job, 0, sizeof(*job));
+                    job->log2CUSize = log2cu; job->log2TrMax = 5; job->log2TrMin = 5; job->chroma = 1; job->bitDepth = 8; job->quantOffset = 85; job->signHide = 1;
+                    for (int p = 0; p < 3; p++) { job->qpRem[p] = 2; job->qpPer[p] = 5; job->quantScale[p] = 20560; job->dequantScale[p] = 51; }
+                    memcpy(pixels, src.data(), bytes);
+                    uint32_t seq = 0;
+                    if (x265hip_cuserve_submit(cs, t, &seq)) { fprintf(stderr, "submit: %s\n", x265hip_last_error()); failed = true; break; }
+                    int sHi, sLo;
+                    x265hipi_cujob_levels(job, &sHi, &sLo);
+                    const int per = 1 << (log2cu - 5), nUnits = 3 * per * per;
+                    double tFirst = 0;
+                    for (int u = 0; u < nUnits && !failed; u++)
+                    {
+                        uint64_t spins = 0;
+                        while (__atomic_load_n(&units[u].ready, __ATOMIC_ACQUIRE) != seq)
+                        {
+                            __builtin_ia32_pause();
+                            if ((++spins & 1023) == 0)
+                            {
+                                if (x265hip_cuserve_poke(cs, t)) { fprintf(stderr, "poke: %s\n", x265hip_last_error()); failed = true; break; }
+                                if (now_us() - t0 > 2e6) { fprintf(stderr, "job %d of thread %d: unit %d not ready after 2 s\n", i, t, u); failed = true; break; }
+                            }
+                        }
+                        if (u == 0) tFirst = now_us() - t0;
+                    }
+                    volatile int16_t sink = levels[0] + resi[0]; (void)sink;
+                    const double t1 = now_us();
+                    if (i >= 100) { lat[t].push_back(t1 - t0); first[t].push_back(tFirst); }
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; t++) th.emplace_back(body, t);
+            const double w0 = now_us();
+            go = 1;
+            for (auto& x : th) x.join();
+            const double wall = now_us() - w0;
+            if (failed) { printf("FAILED (mode %d, CU %d, %d threads)\n", mode, 1 << log2cu, T); x265hip_cuserve_close(cs); return 1; }
+            std::vector<double> all, f;
+            for (auto& v : lat) all.insert(all.end(), v.begin(), v.end());
+            for (auto& v : first) f.insert(f.end(), v.begin(), v.end());
+            std::sort(all.begin(), all.end()); std::sort(f.begin(), f.end());
+            double sum = 0; for (double x : all) sum += x;
+            printf("%s, %dx%d CU (4:2:0, 8 bit, 32x32 transforms), %2d thread%s: whole job mean %6.1f us, median %6.1f, p99 %6.1f; first luma unit median %6.1f us; %.0f jobs/s in total\n",
+                   mode ? "one launch per job" : "resident server   ", 1 << log2cu, 1 << log2cu, T, T > 1 ? "s" : " ", sum / all.size(), all[all.size() / 2],
+                   all[(size_t)(all.size() * 0.99)], f[f.size() / 2], (double)T * (iters + 100) / (wall * 1e-6));
+            fflush(stdout);
+        }
+    uint64_t jobs = 0, starts = 0, ns = 0;
+    x265hip_cuserve_stats(cs, &jobs, &starts, &ns);
+    printf("%llu jobs, %llu server starts, %.1f us of device time per job\n", (unsigned long long)jobs, (unsigned long long)starts, jobs ? ns * 1e-3 / jobs : 0.0);
+    x265hip_cuserve_close(cs);
+    return 0;
+}
