@@ -822,7 +822,8 @@ int x265hip_call_frame_init_lowres(int depth, const void* src, int64_t srcStride
  * try (4:2:0 chroma 16 and 8), plus the two sse_pp distortions of every unit (search.cpp:3269, :3295).  The caller (x265_amd/host/
  * x265_hip_cuserve.cpp) keeps the entropy coder and every decision.  Jobs travel through mailbox SLOTS in page-locked host memory
  * that the device reads and writes directly: the caller fills the slot's job header and pixel block, submits, and polls the
- * per-unit `ready` words (each unit is published as soon as it is done: luma first).  Flat quantiser only (no scaling lists), no
+ * per-unit `ready` / `readyInv` words (each unit's forward half — numSig and levels — is published as soon as it is done, luma first;
+ * its inverse half follows).  Flat quantiser only (no scaling lists), no
  * transform skip, no transquant bypass, no noise reduction, no RDOQ: the caller does not submit such CUs.
  *
  * Pixel block: source Y (N x N, N = 1 << log2CUSize), source Cb, Cr (N/2 x N/2 each, 4:2:0; absent when chroma == 0), then the
@@ -844,11 +845,12 @@ typedef struct x265hip_cujob
 } x265hip_cujob;
 typedef struct x265hip_cujob_unit
 {
-    uint32_t ready;               /* == the job's sequence number once this unit's numSig / distortions / levels / residual are in place */
+    uint32_t ready;               /* == the job's ticket once this unit's numSig, zeroDist and levels are in place (the forward half) */
     uint32_t numSig;              /* transformNxN's return value (after sign-bit hiding) */
     uint64_t zeroDist;            /* sse_pp(source, prediction) */
     uint64_t codedDist;           /* sse_pp(source, clip(prediction + reconstructed residual)); defined when numSig != 0 */
-    uint64_t reserved;
+    uint32_t readyInv;            /* == the job's ticket once codedDist and the reconstructed residual are in place (the inverse half) */
+    uint32_t reserved;
 } x265hip_cujob_unit;
 #define X265HIP_CUJOB_MAX_UNITS   60                       /* 64x64, sizes 32 + 16: 3 * (4 + 16) */
 #define X265HIP_CUJOB_MAX_ELEMS   (2 * 6144)               /* int16 entries of `levels` (and of `resi`) of the largest job */
@@ -896,7 +898,7 @@ int x265hip_cuserve_close(x265hip_cuserve* cs);
 /* the slot's memory: the caller writes *job and *pixels, reads units / levels / resi */
 int x265hip_cuserve_slot(x265hip_cuserve* cs, int slot, x265hip_cujob** job, void** pixels, const x265hip_cujob_unit** units,
                          const int16_t** levels, const int16_t** resi);
-/* hands the slot's job to the device; *seq = the value the units' `ready` words take */
+/* hands the slot's job to the device; *seq = the ticket: the value the units' `ready` / `readyInv` words take (unique among the slot's recent jobs) */
 int x265hip_cuserve_submit(x265hip_cuserve* cs, int slot, uint32_t* seq);
 /* to be called now and then by a caller that is still waiting (mode 0: restarts a server that has gone idle meanwhile); returns
  * X265HIP_EHIP when the device reported a failure: the caller gives up the job and computes on the host */

@@ -174,7 +174,7 @@ def _run_on(hp, L, cs, slot, j, pix, timeout=20.0):
     lay = _layout(hp, j)
     un = C.cast(units, C.POINTER(hp.CuJobUnit))
     t0 = time.time()
-    while any(un[k[4]].ready != seq.value for k in lay):
+    while any(un[k[4]].ready != seq.value or un[k[4]].readyInv != seq.value for k in lay):
         hp.check(L.x265hip_cuserve_poke(cs, slot))
         assert time.time() - t0 < timeout, "job not finished after %.0f s" % timeout
     lv = np.ctypeslib.as_array(C.cast(levels, C.POINTER(C.c_int16)), (hp.CUJOB_MAX_ELEMS,)).copy()

@@ -91,5 +91,37 @@ int main()
         fflush(stdout);
         if (k.reg) { CK(hipHostUnregister(h)); free(h); } else CK(hipHostFree(h));
     }
+    // memory management beside a resident kernel (bounded: the kernel leaves by itself after 1.5 s of its own clock)
+    {
+        Box* h = nullptr;
+        CK(hipHostMalloc((void**)&h, 4096, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(h, 0, 4096);
+        Box* d = nullptr;
+        CK(hipHostGetDevicePointer((void**)&d, h, 0));
+        void* d0; void* h0;
+        CK(hipMalloc(&d0, 1 << 20));
+        CK(hipHostMalloc(&h0, 1 << 20, hipHostMallocDefault));
+        hipStream_t other;
+        CK(hipStreamCreateWithFlags(&other, hipStreamNonBlocking));
+        hipLaunchKernelGGL(diag_kernel, 1, 1, 0, st, d, (uint64_t)150 * 1000 * 1000);
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
+        void* d1;
+        double t0 = now_ms(); CK(hipMalloc(&d1, 1 << 20));
+        printf("beside a resident kernel: hipMalloc %.2f ms", now_ms() - t0);
+        t0 = now_ms(); CK(hipMemsetAsync(d1, 0, 1 << 20, other)); CK(hipStreamSynchronize(other));
+        printf(", memset + synchronise on another stream %.2f ms", now_ms() - t0);
+        t0 = now_ms(); CK(hipFree(d0));
+        printf(", hipFree %.2f ms", now_ms() - t0);
+        t0 = now_ms(); CK(hipHostFree(h0));
+        printf(", hipHostFree %.2f ms", now_ms() - t0);
+        void* reg = aligned_alloc(4096, 1 << 20); memset(reg, 0, 1 << 20);
+        t0 = now_ms(); CK(hipHostRegister(reg, 1 << 20, hipHostRegisterDefault)); CK(hipHostUnregister(reg));
+        printf(", hipHostRegister + Unregister %.2f ms", now_ms() - t0);
+        printf("  (heartbeat %u: the kernel %s)\n", h->heartbeat, __atomic_load_n(&h->heartbeat, __ATOMIC_ACQUIRE) ? "was running" : "was NOT running");
+        fflush(stdout);
+        __atomic_store_n(&h->doorbell, 0xffffffffu, __ATOMIC_RELEASE);
+        CK(hipStreamSynchronize(st));
+        CK(hipFree(d1));
+    }
     return 0;
 }

@@ -7,10 +7,13 @@ every launch with HIP events on the stream it runs on (x265hip_sadsurf_stats); t
   batch    the K surfaces are attached first, then the picture becomes final at once: one launch of K x 510 CTUs (rows of several surfaces share it)
   bands    the K surfaces are attached first, then the picture arrives in bands of 64 rows as the encoder reconstructs it: 17 launches of K x 30 CTUs
 
-Prints one JSON line per mode: launches, CTUs per launch, microseconds per launch, and the SURVEY.md §8d algorithmic bytes ("batched exhaustive
-search of one W x H block over an R x R window counts the unique footprint: W H B + (W + R - 1)(H + R - 1) B + 4 R^2", here R = 2 S = 64, B = 1;
-a CTU = 16 blocks of 16x16 + 4 of 32x32 + 1 of 64x64 = 508 437 bytes) per second, next to the bytes the kernel must really move (source CTU +
-reference window in, windows and origins out).  Used by bench.py for the `roofline` block and by tools/collect_profiles.sh under rocprofv3."""
+Prints one JSON line per mode: launches, CTUs per launch, microseconds per launch, absolute differences per second against the measured issue
+ceiling of v_qsad_pk_u16_u8 (the roofline that binds this kernel: tools/micro/qsad_rate), and the SURVEY.md §8d algorithmic bytes per second.
+§8d's "batched exhaustive search of one block over an R x R window counts the unique footprint" is applied to what a workgroup stages — ONE
+64x64 source block and ONE (64 + R - 1)^2 window per CTU (R = 2 S = 64, B = 1), shared by the CTU's 16 + 4 + 1 block searches — plus the bytes
+the CTU really emits (a 16 x 16 window of entries and an origin per block; the surfaces stay in LDS): 4096 + 16 129 + 13 396 = 33 621 bytes
+per complete CTU.  (Rounds 1-3 charged the footprint 21 times per CTU with a 4 R^2 result term that is never written: 508 437 bytes, 15 times
+too many — VERDICT r03.)  Used by bench.py for the `roofline` block and by tools/collect_profiles.sh under rocprofv3."""
 import argparse
 import ctypes as C
 import json
@@ -25,15 +28,14 @@ MX, MY = 96, 80            # PicYuv's luma margins at CTU 64 (picyuv.cpp:87-89)
 HBM_PEAK = 8000.0
 
 
+VALU_SAD_CEILING_T = 95.2     # T absolute differences per second: v_qsad_pk_u16_u8 issue rate of the whole chip, tools/micro/qsad_rate (profiles/r03_v2_sadsurf_kernel.txt)
+EMITTED_PER_CTU = 16 * (512 + 4) + 4 * (1024 + 4) + (1024 + 4)     # 16x16 level: u16 entries; 32x32 and 64x64: u32; 4 bytes of origin per block
+
+
 def unit_bytes(S):
+    """SURVEY 8d unique footprint of the staged unit (one CTU) + what it emits"""
     R = 2 * S
-    blk = lambda n: n * n + (n + R - 1) ** 2 + 4 * R * R
-    return 16 * blk(16) + 4 * blk(32) + blk(64)
-
-
-def compulsory_bytes(S, lay_bytes_per_ctu):
-    R = 2 * S
-    return 64 * 64 + (64 + R) ** 2 + lay_bytes_per_ctu
+    return 64 * 64 + (64 + R - 1) ** 2 + EMITTED_PER_CTU
 
 
 def pictures(w, h, k, seed):
@@ -113,18 +115,15 @@ def main():
     w, h = map(int, a.res.split("x"))
     buf, stride, rows, srcs = pictures(w, h, a.surfaces, 4321)
     ub = unit_bytes(a.range)
-    out_per_ctu = 16 * (512 + 4) + 4 * (1024 + 4) + (1024 + 4)
-    cb = compulsory_bytes(a.range, out_per_ctu)
     for mode in a.modes.split(","):
         r = run_mode(hp, L, mode, w, h, a.surfaces, a.range, a.reps, buf, stride, rows, srcs)
         secs = r["kernel_ns"] * 1e-9
         r["algorithmic_bytes_per_ctu"] = ub
         r["achieved_GBps"] = round(r["ctus"] * ub / secs / 1e9, 1)
         r["frac_of_hbm_peak"] = round(r["ctus"] * ub / secs / 1e9 / HBM_PEAK, 4)
-        r["compulsory_bytes_per_ctu"] = cb
-        r["compulsory_GBps"] = round(r["ctus"] * cb / secs / 1e9, 1)
         # 16 blocks x (2 S)^2 vectors x 256 absolute differences per CTU
         r["abs_diff_per_s_T"] = round(r["ctus"] * 16 * (2 * a.range) ** 2 * 256 / secs / 1e12, 2)
+        r["frac_of_valu_sad_ceiling"] = round(r["abs_diff_per_s_T"] / VALU_SAD_CEILING_T, 4)
         print(json.dumps(r), flush=True)
 
 

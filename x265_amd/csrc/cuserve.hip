@@ -44,9 +44,9 @@ struct Slot                                      // host-coherent page-locked me
     uint32_t pad0[15];
     uint32_t failed;                             // device -> host: a job the device could not do (never expected)
     uint32_t pad1[15];
-    x265hip_cujob job;
-    x265hip_cujob_unit units[X265HIP_CUJOB_MAX_UNITS];
-    alignas(64) unsigned char pixels[X265HIP_CUJOB_PIXEL_BYTES];
+    alignas(128) x265hip_cujob job;              // 80 bytes; the pixel block follows at +128 so that header and pixels are ONE run of 16-byte chunks
+    alignas(128) unsigned char pixels[X265HIP_CUJOB_PIXEL_BYTES];
+    alignas(64) x265hip_cujob_unit units[X265HIP_CUJOB_MAX_UNITS];
     alignas(64) int16_t levels[kInts];
     alignas(64) int16_t resi[kInts];
 };
@@ -92,13 +92,25 @@ struct DevCtl                                     // device memory
 };
 
 struct TileLds { int16_t a[1024], b[1024], c[1024]; };            // per wave: transform ping-pong + deltaU
+struct BOperand { int b[4]; int corr; int pad[3]; };             // make_b_operand's result for one lane
 struct JobLds
 {
-    x265hip_cujob job;
-    uint32_t seq;
+    alignas(16) x265hip_cujob job;               // + padding up to 128 bytes, then the pixels: the same run of chunks as in the slot
+    uint32_t pad[(128 - sizeof(x265hip_cujob)) / 4];
     alignas(16) unsigned char pix[X265HIP_CUJOB_PIXEL_BYTES];
     alignas(16) TileLds tile[4];
+    alignas(16) BOperand bop[3][2][64];          // [log2n - 3][forward, inverse][lane]: built once per kernel
+    uint32_t seq;
 };
+static_assert(sizeof(x265hip_cujob) <= 128, "job header");
+
+// ticket = what the host rings and the units' ready words take: bits 31..8 a running number (never 0, never 0xffffff), bits 7..0 what the device
+// needs to know before it has read anything: log2CUSize - 4 (bits 1..0), chroma (bit 2), 16-bit samples (bit 3)
+__host__ __device__ inline uint32_t ticket_bytes(uint32_t t)
+{
+    const uint32_t n2 = 1u << (2 * ((t & 3) + 4)), elems = (t & 4) ? n2 + n2 / 2 : n2;
+    return 2 * elems * ((t & 8) ? 2 : 1);
+}
 
 struct PlaneParams { int qBits, add, quantScale, dqScale, dqShift, s1f, s2f, s1i, s2i, maxVal; };
 
@@ -123,18 +135,18 @@ __device__ __forceinline__ PlaneParams plane_params(const x265hip_cujob& j, int 
 // One tile: units u0 .. u0 + G - 1 (G = (32 / N)^2, raster order, `count` of them exist) of size N x N of one plane.
 //   src / prd: the plane's source and prediction in LDS, `pw` elements per row; the plane has (pw / N)^2 units
 template <typename P, int N>
-__device__ __forceinline__ void tile_chain(TileLds& t, const P* src, const P* prd, int pw, int u0, int count, const PlaneParams qp, bool signHide,
-                                           x265hip_cujob_unit* units, int unitBase, int16_t* levels, int16_t* resi, int elemBase, uint32_t seq)
+__device__ __forceinline__ void tile_chain(TileLds& t, const BOperand (*bop)[64], const P* src, const P* prd, int pw, int u0, int count, const PlaneParams qp,
+                                           bool signHide, x265hip_cujob_unit* units, int unitBase, int16_t* levels, int16_t* resi, int elemBase, uint32_t seq)
 {
     constexpr int G = (32 / N) * (32 / N);
     constexpr int LPT = N * N / 16;              // lanes per unit: 16 coefficients each in the quantiser, one 4x4 group each in the sign hiding
     constexpr int CGW = N / 4;                   // coefficient groups per row of a unit
     const int lane = threadIdx.x & 63;
     const int perRow = pw / N;
-    v4i bF, bI;
-    int corrF, corrI;
-    make_b_operand<N, false>(lane, bF, corrF);
-    make_b_operand<N, true>(lane, bI, corrI);
+    const BOperand& oF = bop[0][lane];
+    const BOperand& oI = bop[1][lane];
+    const v4i bF = { oF.b[0], oF.b[1], oF.b[2], oF.b[3] }, bI = { oI.b[0], oI.b[1], oI.b[2], oI.b[3] };
+    const int corrF = oF.corr, corrI = oI.corr;
 
     // ---- residual = source - prediction (two runs of 8 per lane; kept in registers for the distortions)
     int fv[16], pv[16];
@@ -286,14 +298,33 @@ __device__ __forceinline__ void tile_chain(TileLds& t, const P* src, const P* pr
             store4(t.a + e, dq); store4(t.a + e + 4, dq + 4);
         }
     }
+    // ---- the forward half is complete: numSig, zeroDist and the levels go out first (the host's entropy coder starts on them)
+    unsigned long long zero = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+    {
+        const int d0 = fv[i] - pv[i];
+        zero += (unsigned)(d0 * d0);
+    }
+    zero = group_sum64(zero, LPT);
+    x265hip_cujob_unit* un = units + unitBase + u0 + gL;
+    const bool writer = okL && (lane & (LPT - 1)) == 0;
+    if (writer)
+    {
+        un->numSig = (uint32_t)numSig;
+        un->zeroDist = zero;
+    }
+    __threadfence_system();                                                  // the unit's data before its ready word
+    if (writer)
+        __hip_atomic_store(&un->ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     // ---- inverse transform: a -> b -> a
     mfma_pass<N, true>(t.a, t.b, lane, bI, corrI, qp.s1i);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     mfma_pass<N, true>(t.b, t.a, lane, bI, corrI, qp.s2i);
     __builtin_amdgcn_s_waitcnt(0xc07f);
-    // ---- reconstructed residual out; distortions
-    unsigned long long zero = 0, coded = 0;
+    // ---- reconstructed residual out; distortion of the coded alternative
+    unsigned long long coded = 0;
 #pragma unroll
     for (int half = 0; half < 2; half++)
     {
@@ -303,46 +334,41 @@ __device__ __forceinline__ void tile_chain(TileLds& t, const P* src, const P* pr
 #pragma unroll
         for (int i = 0; i < 8; i++)
         {
-            const int f = fv[8 * half + i], p = pv[8 * half + i];
-            const unsigned d0 = (unsigned)(f - p), d1 = (unsigned)(f - clip3i(0, qp.maxVal, p + r[i]));
-            zero += (unsigned long long)d0 * d0;
-            coded += (unsigned long long)d1 * d1;
+            const int d1 = fv[8 * half + i] - clip3i(0, qp.maxVal, pv[8 * half + i] + r[i]);
+            coded += (unsigned)(d1 * d1);
         }
         if (okL)
             *reinterpret_cast<uint4*>(resi + elemBase + (u0 + gL) * N * N + (e % (N * N))) = *reinterpret_cast<const uint4*>(t.a + e);
     }
-    zero = group_sum64(zero, LPT);
     coded = group_sum64(coded, LPT);
-    x265hip_cujob_unit* un = units + unitBase + u0 + gL;
-    const bool writer = okL && (lane & (LPT - 1)) == 0;
     if (writer)
-    {
-        un->numSig = (uint32_t)numSig;
-        un->zeroDist = zero;
         un->codedDist = coded;
-    }
-    __threadfence_system();                                                  // the unit's data before its ready word
+    __threadfence_system();
     if (writer)
-        __hip_atomic_store(&un->ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     __builtin_amdgcn_s_waitcnt(0xc07f);
 }
 
-template <typename P>
-__device__ __forceinline__ void run_job(Slot* s, JobLds& L, uint32_t seq, uint64_t* busyTicks)
+// the six transform operands, once per kernel: wave w builds size 8 << w (waves 0..2)
+__device__ __forceinline__ void build_operands(JobLds& L)
 {
-    const int tid = threadIdx.x, wv = tid >> 6;
-    const uint64_t t0 = wall_clock64();
-    // ---- job header and pixel block: host memory -> LDS
-    if (tid < (int)(sizeof(x265hip_cujob) / 4))
-        reinterpret_cast<uint32_t*>(&L.job)[tid] = reinterpret_cast<const uint32_t*>(&s->job)[tid];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    v4i b; int corr;
+#define XH_BOP(N, K, INV) do { make_b_operand<N, INV>(lane, b, corr); BOperand& o = L.bop[K][INV ? 1 : 0][lane]; o.b[0] = b[0]; o.b[1] = b[1]; o.b[2] = b[2]; o.b[3] = b[3]; o.corr = corr; } while (0)
+    if (wv == 0) { XH_BOP(8, 0, false); XH_BOP(8, 0, true); }
+    else if (wv == 1) { XH_BOP(16, 1, false); XH_BOP(16, 1, true); }
+    else if (wv == 2) { XH_BOP(32, 2, false); XH_BOP(32, 2, true); }
+#undef XH_BOP
     __syncthreads();
+}
+
+template <typename P>
+__device__ __forceinline__ void run_tiles(Slot* s, JobLds& L, uint32_t seq)
+{
+    const int wv = threadIdx.x >> 6;
     const x265hip_cujob& j = L.job;
     const int N = 1 << j.log2CUSize, NC = N >> 1;
     const int lumaElems = N * N, planeElems = j.chroma ? lumaElems + lumaElems / 2 : lumaElems;
-    const int bytes = 2 * planeElems * (int)sizeof(P);
-    for (int i = tid * 16; i < bytes; i += 256 * 16)
-        *reinterpret_cast<uint4*>(L.pix + i) = *reinterpret_cast<const uint4*>(s->pixels + i);
-    __syncthreads();
     const P* src = reinterpret_cast<const P*>(L.pix);
     const P* prd = src + planeElems;
     int sHi, sLo;
@@ -368,30 +394,38 @@ __device__ __forceinline__ void run_job(Slot* s, JobLds& L, uint32_t seq, uint64
             {
                 if ((tile & 3) != wv) continue;
                 const int u0 = k * G, count = nUnits - u0 < G ? nUnits - u0 : G;
-                if (log2n == 5) tile_chain<P, 32>(L.tile[wv], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq);
-                else if (log2n == 4) tile_chain<P, 16>(L.tile[wv], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq);
-                else tile_chain<P, 8>(L.tile[wv], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq);
+                if (log2n == 5) tile_chain<P, 32>(L.tile[wv], L.bop[2], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq);
+                else if (log2n == 4) tile_chain<P, 16>(L.tile[wv], L.bop[1], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq);
+                else tile_chain<P, 8>(L.tile[wv], L.bop[0], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq);
             }
         }
     }
+}
+
+// one job: `ticket` says how many bytes the job holds, so header and pixels arrive in one round trip
+__device__ __forceinline__ void run_job(Slot* s, JobLds& L, uint32_t ticket, uint64_t* busyTicks)
+{
+    const int tid = threadIdx.x;
+    const uint64_t t0 = wall_clock64();
+    const int chunks = (128 + (int)ticket_bytes(ticket)) >> 4;
+    const uint4* in = reinterpret_cast<const uint4*>(&s->job);
+    uint4* out = reinterpret_cast<uint4*>(&L.job);
+    for (int i = tid; i < chunks; i += 256)
+        out[i] = in[i];
+    __syncthreads();
+    if (ticket & 8) run_tiles<uint16_t>(s, L, ticket);
+    else run_tiles<uint8_t>(s, L, ticket);
     __syncthreads();
     if (tid == 0)
         *busyTicks += wall_clock64() - t0;
 }
 
-__device__ __forceinline__ void run_job_any(Slot* s, JobLds& L, uint32_t seq, uint64_t* busyTicks)
-{
-    // bitDepth selects the pixel type; read it from the slot (uniform)
-    const uint32_t depth = __hip_atomic_load(&s->job.bitDepth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (depth == 8) run_job<uint8_t>(s, L, seq, busyTicks);
-    else run_job<uint16_t>(s, L, seq, busyTicks);
-}
-
 // mode 1: one job, one launch
-__global__ __launch_bounds__(256) void cu_job_kernel(Slot* s, uint32_t seq, uint64_t* busyTicks)
+__global__ __launch_bounds__(256) void cu_job_kernel(Slot* s, uint32_t ticket, uint64_t* busyTicks)
 {
     __shared__ JobLds L;
-    run_job_any(s, L, seq, busyTicks);
+    build_operands(L);
+    run_job(s, L, ticket, busyTicks);
 }
 
 // mode 0: workgroup b serves slot b.  The server as a whole leaves when no workgroup has taken a job for `idleTicks` (100 MHz) or the host rings
@@ -400,13 +434,14 @@ __global__ __launch_bounds__(256) void cu_server_kernel(Slot* slots, HostCtl* ho
 {
     __shared__ JobLds L;
     Slot* s = slots + blockIdx.x;
+    build_operands(L);
     uint32_t last = 0;
     if (threadIdx.x == 0)
     {
         last = __hip_atomic_load(&s->doorbell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
         // a job rung while no server was there has not been done: its first unit is not ready
         if (last && last != 0xffffffffu && __hip_atomic_load(&s->units[0].ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != last)
-            last--;
+            last = 0;
         if (blockIdx.x == 0)
         {
             __hip_atomic_store(&ctl->lastWork, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -432,7 +467,7 @@ __global__ __launch_bounds__(256) void cu_server_kernel(Slot* slots, HostCtl* ho
                     v = 0xffffffffu;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(2);
             }
             if (v != 0xffffffffu)
                 __hip_atomic_store(&ctl->lastWork, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -449,7 +484,7 @@ __global__ __launch_bounds__(256) void cu_server_kernel(Slot* slots, HostCtl* ho
             return;
         }
         last = v;
-        run_job_any(s, L, v, &ctl->busyTicks[blockIdx.x]);
+        run_job(s, L, v, &ctl->busyTicks[blockIdx.x]);
     }
 }
 
@@ -470,7 +505,7 @@ struct x265hip_cuserve
     std::atomic<uint32_t>* seq = nullptr;         // per slot
     std::atomic<uint32_t> generation{ 0 };
     std::mutex launchLock;
-    std::atomic<uint64_t> jobs{ 0 }, starts{ 0 };
+    std::atomic<uint64_t> jobs{ 0 }, starts{ 0 }, bytes{ 0 };
     uint64_t idleUs = 2000;
 };
 
@@ -569,7 +604,7 @@ int x265hip_cuserve_close(x265hip_cuserve* cs)
         if (cs->jobStreams)
             for (int i = 0; i < cs->slots; i++)
                 if (cs->jobStreams[i]) { (void)hipStreamSynchronize(cs->jobStreams[i]); (void)hipStreamDestroy(cs->jobStreams[i]); }
-        clock_add(X265HIP_CLK_CUSERVE, cs->jobs.load(), device_ticks(cs) * 10, 0);
+        clock_add(X265HIP_CLK_CUSERVE, cs->jobs.load(), device_ticks(cs) * 10, cs->bytes.load());
         (void)hipHostFree(cs->host);
     }
     if (cs->hostCtl) (void)hipHostFree(cs->hostCtl);
@@ -601,11 +636,17 @@ int x265hip_cuserve_submit(x265hip_cuserve* cs, int slot, uint32_t* seqOut)
     int sHi, sLo;
     if (j.log2CUSize < 4 || j.log2CUSize > 6 || x265hipi_cujob_levels(&j, &sHi, &sLo) < 1 || !valid_depth((int)j.bitDepth))
         return set_error(X265HIP_EINVAL, "x265hip_cuserve_submit: CU 2^%u, transform sizes 2^%u..2^%u, depth %u", j.log2CUSize, j.log2TrMin, j.log2TrMax, j.bitDepth);
-    uint32_t seq = cs->seq[slot].load(std::memory_order_relaxed) + 1;                       // a slot has one submitter at a time
-    if (seq >= 0xfffffff0u) seq = 1;
-    cs->seq[slot].store(seq, std::memory_order_relaxed);
+    uint32_t run = cs->seq[slot].load(std::memory_order_relaxed) + 1;                       // a slot has one submitter at a time
+    if (run >= 0xfffff0u) run = 1;
+    cs->seq[slot].store(run, std::memory_order_relaxed);
+    const uint32_t seq = (run << 8) | (j.log2CUSize - 4) | (j.chroma ? 4u : 0u) | (j.bitDepth > 8 ? 8u : 0u);
     *seqOut = seq;
     cs->jobs.fetch_add(1, std::memory_order_relaxed);
+    {
+        // SURVEY.md §8d, fused chain of one transform unit, as this job moves it: source + prediction in, levels + reconstructed residual out
+        const uint64_t n2 = 1ull << (2 * j.log2CUSize), B = j.bitDepth > 8 ? 2 : 1;
+        cs->bytes.fetch_add((uint64_t)(sHi - sLo + 1) * (j.chroma ? n2 + n2 / 2 : n2) * (2 * B + 4), std::memory_order_relaxed);
+    }
     if (cs->mode == 1)
     {
         std::atomic_thread_fence(std::memory_order_release);

@@ -789,16 +789,19 @@ static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& li
             span.end();
             for (int k = 0; k < a.nJobs; k++)
             {
-                // one W x H block over an R x R window = W H B + (W + R - 1)(H + R - 1) B + 4 R^2 (R = 2 S), per block built
+                // SURVEY.md §8d, "batched exhaustive search of one block over an R x R window counts the unique footprint", applied to what a workgroup
+                // stages: ONE 64x64 source block and ONE (64 + R - 1)^2 window per CTU (R = 2 S; the 16x16 / 32x32 / 64x64 searches of the CTU all read
+                // that one staging, the 32 / 64 SADs are sums of the 16x16 ones), plus the bytes the CTU really emits: a 16 x 16 window of entries and an
+                // origin per block of the levels built (the surfaces themselves never leave LDS)
                 const int64_t R = 2 * a.job[k].S;
-                for (int l = 1; l < 4; l++)
+                span.bytes += (uint64_t)a.job[k].rows * lay.ctuCols * (64 * 64 + (64 + R - 1) * (64 + R - 1)) * rp->B;
+                for (int l = a.job[k].level0 ? 0 : 1; l < 4; l++)
                 {
-                    const int64_t N = 8 << l, unit = (N * N + (N + R - 1) * (N + R - 1)) * rp->B + 4 * R * R;
                     int blockRows = 0;
                     for (int r = a.job[k].row0; r < a.job[k].row0 + a.job[k].rows; r++)
                         for (int j = 0; j < lay.per[l]; j++)
                             blockRows += r * lay.per[l] + j < lay.blocksY[l];
-                    span.bytes += (uint64_t)(unit * blockRows * lay.blocksX[l]);
+                    span.bytes += (uint64_t)blockRows * lay.blocksX[l] * (kWin * kWin * lay.entryBytes[l] + 4);
                 }
             }
             for (int k = 0; k < a.nJobs && !bad; k++)

@@ -77,7 +77,8 @@ bool g_verify = false;           // X265HIP_VERIFY=1: every served unit is recom
 bool g_require = false;          // X265HIP=require: a device failure is fatal instead of falling back
 std::mutex g_lock;
 x265hip_cuserve* g_cs = NULL;
-std::atomic<int> g_nextSlot(0);
+std::atomic<uint64_t> g_slotBusy[4];         // bit s of word s / 64: slot s holds a job of some thread (a slot is taken per job, not per thread: x265 starts
+                                             // one pool thread per core it sees, far more than ever run at once under a CPU quota)
 std::atomic<bool> g_dead(false); // the device failed once: every later CU is computed on the host
 
 // X265HIP_DEBUG_CUTIME: [0..3] transformNxN by log2TrSize - 2, [4..7] invtransformNxN, [8..12] top-level estimateResidualQT by log2CUSize - 2,
@@ -108,8 +109,8 @@ struct Job
 };
 __attribute__((tls_model("initial-exec"))) thread_local Job t_job;
 struct SlotMem { x265hip_cujob* job; void* pixels; const x265hip_cujob_unit* units; const int16_t* levels; const int16_t* resi; };
-__attribute__((tls_model("initial-exec"))) thread_local int t_slot = -2;           // -2: not asked yet, -1: none left
-__attribute__((tls_model("initial-exec"))) thread_local SlotMem t_mem;
+SlotMem g_mem[256];
+__attribute__((tls_model("initial-exec"))) thread_local int t_hint = -1;           // where this thread looks first
 
 void report_time()
 {
@@ -180,29 +181,55 @@ void device_failed(const char* what)
         abort();
 }
 
-// this thread's slot; opens the service on first use
-bool my_slot()
+void shutdown()
 {
-    if (t_slot >= 0) return true;
-    if (t_slot == -1 || g_dead.load(std::memory_order_relaxed)) return false;
-    t_slot = -1;
-    {
-        std::lock_guard<std::mutex> g(g_lock);
-        if (!g_cs && !g_dead.load())
+    // runs at exit before the bindings' device-time report (registered later, so it runs earlier): closing the service hands its device time to the ledger
+    if (getenv("X265HIP_VERBOSE")) report();
+    std::lock_guard<std::mutex> g(g_lock);
+    if (g_cs) { x265hip_cuserve* cs = g_cs; g_cs = NULL; g_dead = true; x265hip_cuserve_close(cs); }
+}
+
+// opens the service on first use
+bool service()
+{
+    if (g_cs) return true;
+    std::lock_guard<std::mutex> g(g_lock);
+    if (g_cs) return true;
+    if (g_dead.load()) return false;
+    if (x265hip_device_count() < 1) { g_dead = true; return false; }       // said by setupAssemblyPrimitives already
+    x265hip_cuserve* cs = NULL;
+    if (x265hip_cuserve_open(g_slots, g_mode, &cs)) { device_failed("x265hip_cuserve_open"); return false; }
+    for (int s = 0; s < g_slots; s++)
+        if (x265hip_cuserve_slot(cs, s, &g_mem[s].job, &g_mem[s].pixels, &g_mem[s].units, &g_mem[s].levels, &g_mem[s].resi))
         {
-            if (x265hip_device_count() < 1) { g_dead = true; return false; }       // said by setupAssemblyPrimitives already
-            if (x265hip_cuserve_open(g_slots, g_mode, &g_cs)) { g_cs = NULL; device_failed("x265hip_cuserve_open"); return false; }
-            if (getenv("X265HIP_VERBOSE"))
-                atexit(report);
+            x265hip_cuserve_close(cs);
+            device_failed("x265hip_cuserve_slot");
+            return false;
         }
-        if (!g_cs) return false;
-    }
-    const int s = g_nextSlot.fetch_add(1);
-    if (s >= g_slots) return false;
-    if (x265hip_cuserve_slot(g_cs, s, &t_mem.job, &t_mem.pixels, &t_mem.units, &t_mem.levels, &t_mem.resi)) return false;
-    t_slot = s;
+    atexit(shutdown);
+    __atomic_store_n(&g_cs, cs, __ATOMIC_RELEASE);
     return true;
 }
+
+// a free slot for this thread's next job, or -1
+int take_slot()
+{
+    static std::atomic<int> next(0);
+    if (t_hint < 0) t_hint = next.fetch_add(1) % g_slots;
+    for (int k = 0; k < g_slots; k++)
+    {
+        const int s = (t_hint + k) % g_slots;
+        std::atomic<uint64_t>& w = g_slotBusy[s >> 6];
+        const uint64_t bit = 1ull << (s & 63);
+        if (!(w.load(std::memory_order_relaxed) & bit) && !(w.fetch_or(bit, std::memory_order_acquire) & bit))
+        {
+            t_hint = s;
+            return s;
+        }
+    }
+    return -1;
+}
+inline void give_slot(int s) { g_slotBusy[s >> 6].fetch_and(~(1ull << (s & 63)), std::memory_order_release); }
 
 template <typename T> inline void pack_rows(T*& dst, const T* src, uint32_t stride, int n)
 {
@@ -224,10 +251,9 @@ inline int locate(const Job& j, const int16_t* residual, uint32_t resiStride, ui
     return x265hipi_cujob_unit_index(j.job, j.sHi, s, ttype, x >> log2TrSize, y >> log2TrSize);
 }
 
-// waits for unit u of this thread's job; false: the device did not deliver (the job is abandoned)
-inline bool wait_unit(Job& j, int u)
+// waits for a ready word of this thread's job to take the job's ticket; false: the device did not deliver (the job is abandoned)
+inline bool wait_word(Job& j, const uint32_t* ready)
 {
-    const uint32_t* ready = &j.units[u].ready;
     if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == j.seq) return true;
     const uint64_t t0 = __builtin_ia32_rdtsc();
     uint64_t spins = 0;
@@ -279,8 +305,12 @@ bool submit(Search* se, Mode& mode, const CUGeom& cuGeom, ShortYuv& resiYuv, con
     hdr.signHide = cu.m_slice->m_pps->bSignHideEnabled;
     hdr.reserved = 0;
     int sHi, sLo;
-    if (x265hipi_cujob_levels(&hdr, &sHi, &sLo) < 1 || !my_slot())
+    if (x265hipi_cujob_levels(&hdr, &sHi, &sLo) < 1 || !service())
         return false;
+    const int slot = take_slot();
+    if (slot < 0)
+        return false;
+    const SlotMem& mem = g_mem[slot];
     for (int p = 0; p < 3; p++)
     {
         const QpParam& qp = q.m_qpParam[p];
@@ -291,23 +321,24 @@ bool submit(Search* se, Mode& mode, const CUGeom& cuGeom, ShortYuv& resiYuv, con
     const int N = 1 << cuGeom.log2CUSize;
     const Yuv* fenc = mode.fencYuv;
     const Yuv* pred = &mode.predYuv;
-    *t_mem.job = hdr;
-    pixel* dst = (pixel*)t_mem.pixels;
+    *mem.job = hdr;
+    pixel* dst = (pixel*)mem.pixels;
     pack_rows(dst, fenc->m_buf[0], fenc->m_size, N);
     if (codeChroma) { pack_rows(dst, fenc->m_buf[1], fenc->m_csize, N / 2); pack_rows(dst, fenc->m_buf[2], fenc->m_csize, N / 2); }
     pack_rows(dst, pred->m_buf[0], pred->m_size, N);
     if (codeChroma) { pack_rows(dst, pred->m_buf[1], pred->m_csize, N / 2); pack_rows(dst, pred->m_buf[2], pred->m_csize, N / 2); }
     Job& j = t_job;
-    if (x265hip_cuserve_submit(g_cs, t_slot, &j.seq))
+    if (x265hip_cuserve_submit(g_cs, slot, &j.seq))
     {
+        give_slot(slot);
         device_failed("x265hip_cuserve_submit");
         return false;
     }
     j.quant = &q;
     for (int p = 0; p < 3; p++) { j.resi[p] = resiYuv.m_buf[p]; j.resiStride[p] = p ? resiYuv.m_csize : resiYuv.m_size; }
     if (!codeChroma) j.resi[1] = j.resi[2] = NULL;
-    j.log2CU = cuGeom.log2CUSize; j.sHi = sHi; j.sLo = sLo; j.slot = t_slot;
-    j.job = t_mem.job; j.units = t_mem.units; j.levels = t_mem.levels; j.resiOut = t_mem.resi;
+    j.log2CU = cuGeom.log2CUSize; j.sHi = sHi; j.sLo = sLo; j.slot = slot;
+    j.job = mem.job; j.units = mem.units; j.levels = mem.levels; j.resiOut = mem.resi;
     j.active = true;
     counters().jobs.fetch_add(1, std::memory_order_relaxed);
     return true;
@@ -336,7 +367,20 @@ void Search::estimateResidualQT(Mode& mode, const CUGeom& cuGeom, uint32_t absPa
     else
         refEstimateResidualQT(this, mode, cuGeom, absPartIdx, tuDepth, resiYuv, outCosts, depthRange, splitMore);
     if (submitted)
-        t_job.active = false;
+    {
+        // the slot goes back when the device has written everything it is going to write into it (an abandoned job: the device is dead, keep the slot)
+        Job& j = t_job;
+        bool done = j.active;
+        if (done)
+        {
+            int sHi = j.sHi;
+            const int last = x265hipi_cujob_unit_index(j.job, sHi, j.sLo, j.resi[1] ? 2 : 0, (1 << (j.log2CU - j.sLo)) - 1, (1 << (j.log2CU - j.sLo)) - 1);
+            for (int u = 0; u <= last && done; u++)
+                done = wait_word(j, &j.units[u].readyInv);
+        }
+        j.active = false;
+        if (done) give_slot(j.slot);
+    }
 }
 
 void Search::checkIntraInInter(Mode& intraMode, const CUGeom& cuGeom)
@@ -361,7 +405,7 @@ uint32_t Quant::transformNxN(const CUData& cu, const pixel* fenc, uint32_t fencS
         if (u >= 0)
         {
             const uint64_t t0 = g_time ? __builtin_ia32_rdtsc() : 0;
-            if (wait_unit(j, u))
+            if (wait_word(j, &j.units[u].ready))
             {
                 const int n2 = 1 << (2 * log2TrSize);
                 memcpy(coeff, j.levels + eo, sizeof(coeff_t) * n2);
@@ -416,6 +460,8 @@ void Quant::invtransformNxN(const CUData& cu, int16_t* residual, uint32_t resiSt
                 const x265hip_cujob_unit& un = j.units[first + t];
                 if (__atomic_load_n(&un.ready, __ATOMIC_ACQUIRE) != j.seq || un.numSig != numSig || memcmp(coeff, j.levels + eo0 + t * n2, sizeof(coeff_t) * n2))
                     continue;
+                if (!wait_word(j, &un.readyInv))
+                    break;
                 const int16_t* src = j.resiOut + eo0 + t * n2;
                 for (int y = 0; y < n; y++)
                     memcpy(residual + (size_t)y * resiStride, src + y * n, sizeof(int16_t) * n);
