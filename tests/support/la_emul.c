@@ -45,12 +45,42 @@ struct x265hip_la
 };
 
 static char g_err[256] = "";
+/* X265HIP_EMUL_FAIL=<entry point>[:<n>]: the named entry point fails from its n-th call on (n = 1 when omitted), the way a device that runs out of
+ * memory or is lost fails — the bindings must then carry on with the reference's own host code and still produce the reference's bytes
+ * (tests/test_fallback.py; SURVEY.md §8b "Errors").  Entry points: la_create, la_set_frame, la_weights, la_put_vectors, la_estimate, refpic_create,
+ * refpic_reset, rows_final, source_energy, srcpic_create, srcpic_upload, sadsurf_attach, cuserve_open, cuserve_submit. */
+static int fail_now(const char* name)
+{
+    static const char* spec = NULL;
+    static int asked = 0, from = 1, calls = 0;
+    static char want[32];
+    if (!asked)
+    {
+        asked = 1;
+        spec = getenv("X265HIP_EMUL_FAIL");
+        if (spec)
+        {
+            const char* c = strchr(spec, ':');
+            size_t n = c ? (size_t)(c - spec) : strlen(spec);
+            if (n > 31) n = 31;
+            memcpy(want, spec, n); want[n] = 0;
+            if (c) from = atoi(c + 1);
+        }
+    }
+    if (!spec || strcmp(want, name))
+        return 0;
+    if (__atomic_add_fetch(&calls, 1, __ATOMIC_RELAXED) < from)
+        return 0;
+    snprintf(g_err, sizeof(g_err), "emulated failure of %s (X265HIP_EMUL_FAIL)", name);
+    return 1;
+}
 int x265hip_device_count(void) { return 1; }
 int x265hip_init(int device) { (void)device; return 0; }
 const char* x265hip_last_error(void) { return g_err; }
 
 x265hip_la* x265hip_la_create(const x265hip_la_config* cfg)
 {
+    if (fail_now("la_create")) return NULL;
     x265hip_la* la = (x265hip_la*)calloc(1, sizeof(*la));
     la->c = *cfg;
     la->B = cfg->depth == 8 ? 1 : 2;
@@ -75,6 +105,7 @@ void x265hip_la_destroy(x265hip_la* la)
 
 int x265hip_la_set_frame(x265hip_la* la, int slotIdx, const void* buffers, const int32_t* intraCost, const int32_t* invQscale)
 {
+    if (fail_now("la_set_frame")) return X265HIP_EHIP;
     slot* s = &la->slots[slotIdx];
     const size_t pb = (size_t)4 * la->c.planeElems * la->B, cb = (size_t)la->ncu * 4;
     if (!s->buffers)
@@ -96,6 +127,7 @@ static int32_t* store_of(x265hip_la* la, slot* s, int list, int dist) { return s
 
 int x265hip_la_put_vectors(x265hip_la* la, int slotIdx, int list, int dist, const int32_t* mvs, const int32_t* mvCosts)
 {
+    if (fail_now("la_put_vectors")) return X265HIP_EHIP;
     slot* s = &la->slots[slotIdx];
     int32_t* d = store_of(la, s, list, dist);
     memcpy(d, mvs, (size_t)la->ncu * 8);
@@ -111,6 +143,7 @@ int x265hip_la_has_vectors(x265hip_la* la, int slotIdx, int list, int dist) { re
 int x265hip_la_weights_analyse(x265hip_la* la, int slotB, int slotRef, uint64_t fencSsd, uint64_t fencSum, uint64_t refSsd, uint64_t refSum,
                                x265hip_weight_param* chosen, int* isWeighted, int* weightedId)
 {
+    if (fail_now("la_weights")) return X265HIP_EHIP;
     const x265hip_la_config* c = &la->c;
     slot* fb = &la->slots[slotB];
     slot* fr = &la->slots[slotRef];
@@ -190,6 +223,7 @@ int x265hip_la_estimate_batch(x265hip_la* la, x265hip_la_estimate* est, int n, i
 int x265hip_la_estimate_batch_ahead(x265hip_la* la, x265hip_la_estimate* est, int n, int numRowsPerSlice, int numSlices,
                                     const x265hip_la_search* ahead, int nAhead)
 {
+    if (fail_now("la_estimate")) return X265HIP_EHIP;
     const x265hip_la_config* c = &la->c;
     const int ncu = la->ncu, W = c->widthInCU, H = c->heightInCU;
     int anySearch = 0;
@@ -330,6 +364,7 @@ static void sadsurf_detach_all(x265hip_refpic* rp);
 
 x265hip_refpic* x265hip_refpic_create(int depth, int picW, int picH, int64_t stride, int marginX, int marginY, int bufRows, const void* hostBase)
 {
+    if (fail_now("refpic_create")) return NULL;
     x265hip_refpic* rp = (x265hip_refpic*)calloc(1, sizeof(*rp));
     rp->depth = depth; rp->B = depth == 8 ? 1 : 2; rp->picW = picW; rp->picH = picH; rp->marginX = marginX; rp->marginY = marginY; rp->bufRows = bufRows;
     rp->stride = stride; rp->planeElems = stride * bufRows; rp->hostBase = (const char*)hostBase;
@@ -349,6 +384,7 @@ x265hip_refpic* x265hip_refpic_create_at(int place, int depth, int picW, int pic
 void x265hip_refpic_destroy(x265hip_refpic* rp) { if (rp) { sadsurf_detach_all(rp); free(rp->planes); free(rp); } }
 int x265hip_refpic_reset(x265hip_refpic* rp)
 {
+    if (fail_now("refpic_reset")) return X265HIP_EHIP;
     sadsurf_detach_all(rp);
     for (int i = 0; i < rp->nRep; i++) rp->repCopied[i] = 0;
     rp->phaseDone = 4; rp->rowsFinal = 0;
@@ -364,6 +400,7 @@ static void sadsurf_progress_all(x265hip_refpic* rp);
 
 int x265hip_refpic_rows_final(x265hip_refpic* rp, int rowsFinal)
 {
+    if (fail_now("rows_final")) return X265HIP_EHIP;
     if (rowsFinal > rp->rowsFinal) rp->rowsFinal = rowsFinal;
     sadsurf_progress_all(rp);
     const int complete = rowsFinal >= rp->picH;
@@ -412,6 +449,7 @@ int x265hip_device_time(int clock, uint64_t* spans, uint64_t* nanoseconds, uint6
 
 int x265hip_source_energy(int depth, const void* hostPlane, int64_t stride, int width, int height, int32_t* hostE8, int32_t* hostE4)
 {
+    if (fail_now("source_energy")) return X265HIP_EHIP;
     const int bw = width >> 3, bh = height >> 3;
     static const uint16_t zero[64];
     for (int by = 0; by < bh; by++)
@@ -444,14 +482,17 @@ void orc_sadsurf_rows_8(const uint8_t* src, intptr_t srcStride, const uint8_t* r
 void orc_sadsurf_rows_16(const uint16_t* src, intptr_t srcStride, const uint16_t* ref, intptr_t refStride, int picW, int picH, int marginX, int marginY,
                          int S, int lambda20, int row0, int row1, int16_t* const origin[4], uint32_t* const table[4]);
 
-struct x265hip_srcpic { int depth, B, w, h; char* luma; int place; };
+struct x265hip_srcpic { int depth, B, w, h; char* luma; int place; int refs; };     /* refs: the creator + the surfaces attached (as in the library) */
+static void srcpic_unref(x265hip_srcpic* sp) { if (__atomic_sub_fetch(&sp->refs, 1, __ATOMIC_ACQ_REL) == 0) { free(sp->luma); free(sp); } }
 
 x265hip_srcpic* x265hip_srcpic_create(int depth, int width, int height)
 {
+    if (fail_now("srcpic_create")) return NULL;
     x265hip_srcpic* sp = (x265hip_srcpic*)calloc(1, sizeof(*sp));
     sp->depth = depth; sp->B = depth == 8 ? 1 : 2; sp->w = width; sp->h = height;
     sp->luma = (char*)malloc((size_t)width * height * sp->B);
     sp->place = -1;
+    sp->refs = 1;
     return sp;
 }
 x265hip_srcpic* x265hip_srcpic_create_at(int place, int depth, int width, int height)
@@ -463,11 +504,12 @@ x265hip_srcpic* x265hip_srcpic_create_at(int place, int depth, int width, int he
 }
 int x265hip_srcpic_upload(x265hip_srcpic* sp, const void* hostLuma, int64_t stride)
 {
+    if (fail_now("srcpic_upload")) return X265HIP_EHIP;
     for (int y = 0; y < sp->h; y++)
         memcpy(sp->luma + (size_t)y * sp->w * sp->B, (const char*)hostLuma + (size_t)y * stride * sp->B, (size_t)sp->w * sp->B);
     return 0;
 }
-void x265hip_srcpic_destroy(x265hip_srcpic* sp) { if (sp) { free(sp->luma); free(sp); } }
+void x265hip_srcpic_destroy(x265hip_srcpic* sp) { if (sp) srcpic_unref(sp); }
 
 struct x265hip_sadsurf
 {
@@ -566,6 +608,7 @@ x265hip_sadsurf* x265hip_sadsurf_attach(x265hip_srcpic* src, x265hip_refpic* ref
 }
 x265hip_sadsurf* x265hip_sadsurf_attach_levels(x265hip_srcpic* src, x265hip_refpic* ref, int searchRange, int lambda20, int levels)
 {
+    if (fail_now("sadsurf_attach")) return NULL;
     if (!src || !ref || src->depth != ref->depth || src->w != ref->picW || src->h != ref->picH || searchRange < 8 || searchRange > 32 || (searchRange & 3) ||
         lambda20 < 0 || lambda20 > (1 << 20) || (levels & ~15) || (levels & 14) != 14)
     {
@@ -574,6 +617,7 @@ x265hip_sadsurf* x265hip_sadsurf_attach_levels(x265hip_srcpic* src, x265hip_refp
     }
     x265hip_sadsurf* ss = (x265hip_sadsurf*)calloc(1, sizeof(*ss));
     ss->src = src; ss->ref = ref; ss->S = searchRange; ss->lambda20 = lambda20; ss->levels = levels;
+    __atomic_add_fetch(&src->refs, 1, __ATOMIC_ACQ_REL);
     ss->ctuRows = (src->h + 63) / 64;
     int64_t off = 0;
     for (int l = 0; l < X265HIP_SADSURF_LEVELS; l++)
@@ -620,6 +664,7 @@ void x265hip_sadsurf_release(x265hip_sadsurf* ss)
     pthread_mutex_unlock(&g_ssLock);
     for (int l = 0; l < X265HIP_SADSURF_LEVELS; l++) { free(ss->origin[l]); free(ss->wide[l]); }
     free(ss->buf);
+    srcpic_unref(ss->src);
     free(ss);
 }
 int x265hip_sadsurf_stats(uint64_t* attached, uint64_t* ctuRows, uint64_t* launches, uint64_t* kernelNs)
@@ -632,8 +677,8 @@ int x265hip_sadsurf_stats(uint64_t* attached, uint64_t* ctuRows, uint64_t* launc
 }
 
 /* ---- CU residual quad-tree jobs (include/x265hip.h, x265hip_cuserve_*): the restatement (oracle/x265_oracle_rqt.c) behind the same slot / submit /
- * ready-word protocol; the job is done inside x265hip_cuserve_submit.  X265HIP_EMUL_CUSERVE_FAIL=open | submit makes the respective call fail
- * (the bindings must then compute on the host and still produce the reference's bytes: tests/test_fallback.py). */
+ * ready-word protocol; the job is done inside x265hip_cuserve_submit.  X265HIP_EMUL_FAIL=cuserve_open | cuserve_submit[:n] makes
+ * the respective call fail (fail_now above). */
 int orc_cujob_run_8(const x265hip_cujob* j, const uint8_t* pixels, x265hip_cujob_unit* units, int16_t* levels, int16_t* resi, uint32_t seq);
 int orc_cujob_run_16(const x265hip_cujob* j, const uint16_t* pixels, x265hip_cujob_unit* units, int16_t* levels, int16_t* resi, uint32_t seq);
 typedef struct cu_slot
@@ -648,8 +693,7 @@ typedef struct cu_slot
 struct x265hip_cuserve { int slots, mode; cu_slot* slot; uint64_t jobs; };
 int x265hip_cuserve_open(int slots, int mode, x265hip_cuserve** out)
 {
-    const char* fail = getenv("X265HIP_EMUL_CUSERVE_FAIL");
-    if (fail && !strcmp(fail, "open")) { snprintf(g_err, sizeof(g_err), "emulated failure of x265hip_cuserve_open"); return X265HIP_ENOMEM; }
+    if (fail_now("cuserve_open")) return X265HIP_ENOMEM;
     if (!out || slots < 1 || slots > 256) return X265HIP_EINVAL;
     x265hip_cuserve* cs = (x265hip_cuserve*)calloc(1, sizeof(*cs));
     cs->slots = slots; cs->mode = mode;
@@ -673,8 +717,7 @@ int x265hip_cuserve_slot(x265hip_cuserve* cs, int slot, x265hip_cujob** job, voi
 }
 int x265hip_cuserve_submit(x265hip_cuserve* cs, int slot, uint32_t* seq)
 {
-    const char* fail = getenv("X265HIP_EMUL_CUSERVE_FAIL");
-    if (fail && !strcmp(fail, "submit")) { snprintf(g_err, sizeof(g_err), "emulated failure of x265hip_cuserve_submit"); return X265HIP_EHIP; }
+    if (fail_now("cuserve_submit")) return X265HIP_EHIP;
     if (!cs || slot < 0 || slot >= cs->slots || !seq) return X265HIP_EINVAL;
     cu_slot* s = cs->slot + slot;
     int sHi, sLo;

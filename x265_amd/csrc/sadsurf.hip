@@ -33,7 +33,10 @@ struct x265hip_srcpic
     char* dLuma = nullptr;
     char* hStage = nullptr;             // page-locked staging copy (the encoder's buffer is ordinary memory)
     hipStream_t st = nullptr;
+    std::atomic<int> refs{ 1 };         // the creator's + one per SAD surface attached: a surface reads dLuma and files its buffers under `device` until it is freed,
+                                        // so x265hip_srcpic_destroy only drops the creator's reference (a resized source buffer used to free under them)
 };
+static void srcpic_unref(x265hip_srcpic* sp);
 
 namespace xh {
 
@@ -841,11 +844,13 @@ void sadsurf_rows_arrived(x265hip_refpic* rp)
 
 static void free_surface(x265hip_sadsurf* ss)
 {
+    x265hip_srcpic* src = ss->src;
     {
         std::lock_guard<std::mutex> g(g_poolLock);
-        g_pool.insert({ { ss->bytes, ss->src->device }, PoolEntry{ ss->dBuf, ss->hBuf } });
+        g_pool.insert({ { ss->bytes, src->device }, PoolEntry{ ss->dBuf, ss->hBuf } });
     }
     delete ss;
+    ::srcpic_unref(src);
 }
 
 void sadsurf_job(const RefJob& j)
@@ -961,7 +966,13 @@ int x265hip_srcpic_upload(x265hip_srcpic* sp, const void* hostLuma, int64_t stri
 
 void x265hip_srcpic_destroy(x265hip_srcpic* sp)
 {
-    if (!sp) return;
+    if (sp) srcpic_unref(sp);
+}
+
+} // extern "C"
+static void srcpic_unref(x265hip_srcpic* sp)
+{
+    if (sp->refs.fetch_sub(1) != 1) return;
     int cur = 0;
     const bool had = hipGetDevice(&cur) == hipSuccess;
     (void)hipSetDevice(sp->device);
@@ -971,6 +982,7 @@ void x265hip_srcpic_destroy(x265hip_srcpic* sp)
     if (had && cur != sp->device) (void)hipSetDevice(cur);
     delete sp;
 }
+extern "C" {
 
 x265hip_sadsurf* x265hip_sadsurf_attach(x265hip_srcpic* src, x265hip_refpic* ref, int searchRange, int lambda20)
 {
@@ -1011,6 +1023,7 @@ x265hip_sadsurf* x265hip_sadsurf_attach_levels(x265hip_srcpic* src, x265hip_refp
             return nullptr;
         }
     }
+    src->refs.fetch_add(1);
     memset(&ss->view, 0, sizeof(ss->view));
     for (int l = 0; l < 4; l++)
     {

@@ -44,6 +44,35 @@ inline void x265hip_debug_mark(const char* what)
     fprintf(stderr, "x265hip-startup: %8.1f ms  %s\n", (now - procStart) * 1e3, what);
 }
 
+// SURVEY.md §8b "Errors": a failing GPU call must never take the encoder down — every seam has the reference's own host function one branch away, and
+// that is where it goes: the failing module says so ONCE, switches itself (or the object concerned) off, and the encode continues with the reference's
+// bytes.  X265HIP=require (what bench.py, the tools and the GPU tests run with) makes the same event fatal: a number measured on a fallback is worthless.
+inline bool x265hip_required()
+{
+    static const bool r = getenv("X265HIP") && !strcmp(getenv("X265HIP"), "require");
+    return r;
+}
+inline void x265hip_device_failure(const char* module, const char* what)
+{
+    static std::mutex lock;
+    static char said[8][32];
+    static int n = 0;
+    {
+        std::lock_guard<std::mutex> g(lock);
+        bool first = true;
+        for (int i = 0; i < n; i++)
+            if (!strncmp(said[i], module, 31)) first = false;
+        if (first)
+        {
+            if (n < 8) { strncpy(said[n], module, 31); said[n][31] = 0; n++; }
+            fprintf(stderr, "x265hip: %s: %s: %s — this part of the GPU path is OFF from here on, the encoder's own host code takes over%s\n", module, what, x265hip_last_error(),
+                    x265hip_required() ? " (X265HIP=require: fatal)" : "");
+        }
+    }
+    if (x265hip_required())
+        abort();
+}
+
 // X265HIP_DEVICES=0,1,2,3: the encoder's device work is spread over several GPUs — place p (include/x265hip.h, x265hip_places) lives on the p-th
 // device of the list; the same device may be listed more than once (two places on one GPU: the way the exchange is exercised on a one-GPU box).
 // Reference-picture mirrors and source pictures take their places in turn (x265's frame encoders work on consecutive frames at the same time:
@@ -72,8 +101,11 @@ inline int x265hip_places_configured()
     }
     if (count < 1 || x265hip_places(count, devs))
     {
-        fprintf(stderr, "x265hip: X265HIP_DEVICES=%s: %s\n", env, count < 1 ? "not a list of device numbers" : x265hip_last_error());
-        abort();                                   // the product path fails loudly
+        // a configuration error, not a device failure: places stay unconfigured (everything lives on one device) unless the run requires the GPU path
+        fprintf(stderr, "x265hip: X265HIP_DEVICES=%s: %s — ignored, one device is used\n", env, count < 1 ? "not a list of device numbers" : x265hip_last_error());
+        if (x265hip_required())
+            abort();
+        return 0;
     }
     n = count;
     return n;

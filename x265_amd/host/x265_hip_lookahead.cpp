@@ -145,12 +145,9 @@ bool enabled()
     return g_state > 0;
 }
 
-[[noreturn]] void die(const char* what)
-{
-    // the product path fails loudly: results after a failed device call would no longer be the reference's
-    fprintf(stderr, "x265hip: lookahead: %s: %s\n", what, x265hip_last_error());
-    abort();
-}
+// a device call of the estimate path failed: thrown up to compute_guarded(), which hands the estimates back to the reference's own functions
+struct DeviceFailure { const char* what; };
+[[noreturn]] void die(const char* what) { throw DeviceFailure{ what }; }
 
 bool covered(const Lookahead& l, const Lowres* fenc)
 {
@@ -225,10 +222,7 @@ int slot_of(Session& s, const Lookahead& l, const Lowres* f)
             if (s.slots[i].stamp < s.stamp && (victim < 0 || s.slots[i].stamp < s.slots[victim].stamp))
                 victim = (int)i;
         if (victim < 0)
-        {
-            fprintf(stderr, "x265hip: lookahead: more than %d frames in one batch\n", (int)s.slots.size());
-            abort();
-        }
+            die("more frames in one batch than the session has slots");
     }
     const int32_t* invq = f->invQscaleFactor ? (l.m_param->rc.qgSize == 8 ? f->invQscaleFactor8x8 : f->invQscaleFactor) : NULL;
     if (x265hip_la_set_frame(s.la, victim, f->buffer[0], f->intraCost, invq))
@@ -421,6 +415,38 @@ inline bool cached(const Lowres* fenc, int p0, int p1, int b)
     return fenc->costEst[b - p0][p1 - b] >= 0 && fenc->rowSatds[b - p0][p1 - b][0] != -1;
 }
 
+// compute(), or — when a device call fails on the way — nothing: the seam switches itself off, whatever the failed batch may have half-written
+// into the Lowres arrays is marked "not searched / not estimated" again, and the reference's own estimateFrameCost computes it (SURVEY §8b "Errors")
+void compute_guarded(CostEstimateGroup& g, const Job* jobs, int n, bool coop)
+{
+    struct Before { bool search0, search1; };
+    std::vector<Before> before(n);
+    for (int i = 0; i < n; i++)
+    {
+        const Lowres* fenc = g.m_frames[jobs[i].b];
+        before[i].search0 = fenc->lowresMvs[0][jobs[i].b - jobs[i].p0][0].x == 0x7FFF;
+        before[i].search1 = jobs[i].p1 > jobs[i].b && fenc->lowresMvs[1][jobs[i].p1 - jobs[i].b][0].x == 0x7FFF;
+    }
+    try
+    {
+        compute(g, jobs, n, coop);
+    }
+    catch (const DeviceFailure& f)
+    {
+        g_state = -1;
+        for (int i = 0; i < n; i++)
+        {
+            Lowres* fenc = g.m_frames[jobs[i].b];
+            const int d0 = jobs[i].b - jobs[i].p0, d1 = jobs[i].p1 - jobs[i].b;
+            if (before[i].search0) fenc->lowresMvs[0][d0][0].x = 0x7FFF;
+            if (before[i].search1) fenc->lowresMvs[1][d1][0].x = 0x7FFF;
+            fenc->costEst[d0][d1] = -1;
+            fenc->rowSatds[d0][d1][0] = -1;
+        }
+        x265hip_device_failure("lookahead", f.what);
+    }
+}
+
 } // namespace
 
 // The encoder is being closed: its Lowres objects and its Lookahead are about to be freed, and a later encoder of the same process may get the
@@ -489,7 +515,7 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
             const bool search1 = p1 > b && fenc->lowresMvs[1][p1 - b][0].x == 0x7FFF;
             const bool coop = !m_batchMode && m_lookahead.m_numCoopSlices > 1 && (p1 > b || search0 || search1);
             const Job j = { p0, p1, b };
-            compute(*this, &j, 1, coop);
+            compute_guarded(*this, &j, 1, coop);
         }
         const int64_t r = refEstimateFrameCost(this, tld, p0, p1, b, bIntraPenalty);
         timeline().line(a, timeline().now(), m_batchMode ? "estB" : "est", p0, p1, m_frames[b]->frameNum, wasCached, 1);
@@ -502,7 +528,7 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
         const bool search1 = p1 > b && fenc->lowresMvs[1][p1 - b][0].x == 0x7FFF;
         const bool coop = !m_batchMode && m_lookahead.m_numCoopSlices > 1 && (p1 > b || search0 || search1);
         const Job j = { p0, p1, b };
-        compute(*this, &j, 1, coop);
+        compute_guarded(*this, &j, 1, coop);
     }
     return refEstimateFrameCost(this, tld, p0, p1, b, bIntraPenalty);
 }
@@ -533,7 +559,7 @@ void CostEstimateGroup::finishBatch()
                 jobs.push_back(Job{ e.p0, e.p1, e.b });
         }
         if (!jobs.empty())
-            compute(*this, jobs.data(), (int)jobs.size(), false);
+            compute_guarded(*this, jobs.data(), (int)jobs.size(), false);
         // every estimate of the queue is now cached; the reference's own loop (below) only reads the scores back
     }
     refFinishBatch(this);

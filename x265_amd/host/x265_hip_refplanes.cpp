@@ -70,6 +70,7 @@ struct Mirror
     bool tracking;              // the picture now in the buffer is a reference picture whose rows we publish
     uint64_t rowDone[4];        // CTU rows whose processPostRow has run (slices may finish out of order)
     int prefix;                 // CTU rows [0, prefix) are done
+    bool dead;                  // a device call on this mirror failed: nothing is served from it any more (kill_mirror)
 };
 
 const int kMaxMirrors = 64;
@@ -78,6 +79,7 @@ Mirror g_mirror[kMaxMirrors];
 struct Range { const pixel* lo; const pixel* hi; };
 Range g_range[kMaxMirrors];
 uint64_t g_weightedMirrors = 0;  // under g_createLock
+std::atomic<bool> g_noNewMirrors(false);   // a mirror could not be created: no further attempts (x265hip_device_failure said why)
 std::atomic<int> g_count(0);
 std::mutex g_createLock;
 int g_state = 0;                 // 0 undecided, 1 on, -1 off
@@ -176,7 +178,7 @@ Mirror* mirror_at(const pixel* lo, const PicYuv* pic, bool weighted, bool create
     for (int i = n; i < n2; i++)
         if (g_mirror[i].lo == lo)
             return &g_mirror[i];
-    if (!create)
+    if (!create || g_noNewMirrors.load(std::memory_order_relaxed))
         return NULL;
     int slot = n2;
     for (int i = 0; i < n2; i++)
@@ -197,8 +199,10 @@ Mirror* mirror_at(const pixel* lo, const PicYuv* pic, bool weighted, bool create
     x265hip_debug_mark("created: reference-picture mirror");
     if (!m.rp)
     {
-        fprintf(stderr, "x265hip: refplanes: %s\n", x265hip_last_error());
-        abort();                                   // the product path fails loudly
+        // no mirror for this buffer (nor for any later one: the device is out of memory or gone): its filter calls are "on other memory" -> the C filters
+        g_noNewMirrors.store(true);
+        x265hip_device_failure("refplanes", "reference-picture mirror");
+        return NULL;
     }
     m.hi = lo + (size_t)pic->m_stride * bufRows;
     g_range[slot].hi = m.hi;
@@ -211,6 +215,7 @@ Mirror* mirror_at(const pixel* lo, const PicYuv* pic, bool weighted, bool create
         m.plane[p] = (const pixel*)x265hip_refpic_plane(m.rp, p);
     m.rowsReady = x265hip_refpic_rows_ready_ptr(m.rp);
     m.poc = -1;
+    m.dead = false;
     m.tracking = false;
     m.prefix = 0;
     memset(m.rowDone, 0, sizeof(m.rowDone));
@@ -222,6 +227,16 @@ Mirror* mirror_at(const pixel* lo, const PicYuv* pic, bool weighted, bool create
 }
 
 Mirror* mirror_of(PicYuv* pic) { return mirror_at(pic->m_picBuf[0], pic, false); }
+
+// a device call on this mirror failed: nothing of it is served any more (its "rows ready" count reads 0 for good), the C filters take over
+const int g_noRows = -(1 << 30);      // the library's own "nothing is valid" value (refpic.hip)
+void kill_mirror(Mirror* m, const char* what)
+{
+    m->rowsReady = &g_noRows;
+    m->tracking = false;
+    m->dead = true;
+    x265hip_device_failure("refplanes", what);
+}
 
 // W x H block of phase plane `phase` at `src`, if `src` lies in a mirrored picture whose rows have arrived
 template <int W, int H>
@@ -238,8 +253,9 @@ inline bool serve(const pixel* src, intptr_t srcStride, pixel* dst, intptr_t dst
     // the distance of any off / stride from the next integer (1 / stride)
     const int by = (int)(((uint64_t)off * m->recip) >> 40), bx = (int)(off - (ptrdiff_t)by * m->stride);
     const int y = by - m->marginY, x = bx - m->marginX;
+    // a block that lies entirely in the top margin needs the first band too (the margin's planes are built with it): at least one row must have arrived
     if (srcStride != m->stride || x < -(m->marginX - 4) || x + W > m->picW + m->marginX - 4 || y < -(m->marginY - 4) ||
-        y + H > __atomic_load_n(m->rowsReady, __ATOMIC_ACQUIRE))
+        (y + H > 1 ? y + H : 1) > __atomic_load_n(m->rowsReady, __ATOMIC_ACQUIRE))
     {
         t_counts.missed++;
         return false;
@@ -383,14 +399,11 @@ void FrameFilter::processPostRow(int row)
             std::lock_guard<std::mutex> g(m->lock);
             if (m->poc != m_frame->m_poc)
             {
-                if (x265hip_refpic_reset(m->rp))
-                {
-                    fprintf(stderr, "x265hip: refplanes: %s\n", x265hip_last_error());
-                    abort();
-                }
+                if (!m->dead && x265hip_refpic_reset(m->rp))
+                    kill_mirror(m, "x265hip_refpic_reset");
                 m->poc = m_frame->m_poc;
                 m->generation.fetch_add(1, std::memory_order_release);
-                m->tracking = IS_REFERENCED(m_frame);           // unreferenced B pictures are never searched: nothing to build
+                m->tracking = !m->dead && IS_REFERENCED(m_frame);           // unreferenced B pictures are never searched: nothing to build
                 m->prefix = 0;
                 memset(m->rowDone, 0, sizeof(m->rowDone));
             }
@@ -411,10 +424,7 @@ void FrameFilter::processPostRow(int row)
                 m->prefix = prefix;
                 const int rows = prefix == m_numRows ? m->picH : prefix * (int)m_param->maxCUSize;
                 if (x265hip_refpic_rows_final(m->rp, rows))
-                {
-                    fprintf(stderr, "x265hip: refplanes: %s\n", x265hip_last_error());
-                    abort();
-                }
+                    kill_mirror(m, "x265hip_refpic_rows_final");
             }
         }
     }
@@ -437,14 +447,11 @@ int MotionReference::init(PicYuv* recPic, WeightParam* wp, const x265_param& p)
     if (m)
     {
         std::lock_guard<std::mutex> g(m->lock);
-        if (x265hip_refpic_reset(m->rp))
-        {
-            fprintf(stderr, "x265hip: refplanes: %s\n", x265hip_last_error());
-            abort();
-        }
+        if (!m->dead && x265hip_refpic_reset(m->rp))
+            kill_mirror(m, "x265hip_refpic_reset");
         m->generation.fetch_add(1, std::memory_order_release);
         m->poc = -2;
-        m->tracking = lumaWeighted;
+        m->tracking = !m->dead && lumaWeighted;
         m->prefix = 0;
     }
     return r;
@@ -468,10 +475,7 @@ void MotionReference::applyWeight(uint32_t finishedRows, uint32_t maxNumRows, ui
     {
         m->prefix = rows;
         if (x265hip_refpic_rows_final(m->rp, rows))
-        {
-            fprintf(stderr, "x265hip: refplanes: %s\n", x265hip_last_error());
-            abort();
-        }
+            kill_mirror(m, "x265hip_refpic_rows_final");
     }
 }
 

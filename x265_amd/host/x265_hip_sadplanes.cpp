@@ -247,8 +247,10 @@ const Pair* pair_of(const PicYuv* srcPic, uint32_t version, const PicYuv* recon,
         x265hip_sadsurf* ss = x265hip_sadsurf_attach_levels(sp, rp, g_range, lambda20, g_levels | 14);
         if (!ss)
         {
-            fprintf(stderr, "x265hip: sadplanes: %s\n", x265hip_last_error());
-            abort();                         // the product path fails loudly
+            // no table for this pair, nor for later ones (out of memory, or the device is gone): every search measures its candidates with the C functions
+            g_state = -1;
+            x265hip_device_failure("sadplanes", "x265hip_sadsurf_attach");
+            return NULL;
         }
         found = new Pair{ srcPic, version, recon, generation, ss, x265hip_sadsurf_get_view(ss) };
         g_pairs.push_back(found);

@@ -68,6 +68,7 @@ SrcPic g_pics[kMaxPics];
 std::atomic<int> g_npics(0);
 std::mutex g_lock;
 int g_state = 0;
+std::atomic<bool> g_noDeviceCopies(false);   // a source picture could not be copied to the device: no further attempts
 EncoderPrimitives g_c;
 struct alignas(64) Counter { std::atomic<uint64_t> v; };            // one cache line each: the slots run on every pool worker at once
 Counter g_hit[64], g_miss[64];
@@ -176,11 +177,13 @@ void build(SrcPic* sp, uint32_t v)
         }
         if (x265hip_source_energy(X265_DEPTH, pic.m_picOrg[k], k ? pic.m_strideC : pic.m_stride, w, h, sp->e8[k], sp->e4[k]))
         {
-            fprintf(stderr, "x265hip: srcplanes: %s\n", x265hip_last_error());
-            abort();                                   // the product path fails loudly
+            // these planes are never marked built: the psy slots compute the source half themselves; no further attempts
+            g_state = -1;
+            x265hip_device_failure("srcplanes", "x265hip_source_energy");
+            return;
         }
     }
-    if (x265hip_sadplanes_wanted())
+    if (x265hip_sadplanes_wanted() && !g_noDeviceCopies.load(std::memory_order_relaxed))
     {
         if (sp->dev && (sp->devW != (int)pic.m_picWidth || sp->devH != (int)pic.m_picHeight))
         {
@@ -199,8 +202,10 @@ void build(SrcPic* sp, uint32_t v)
         }
         if (!sp->dev || x265hip_srcpic_upload(sp->dev, pic.m_picOrg[0], pic.m_stride))
         {
-            fprintf(stderr, "x265hip: srcplanes: %s\n", x265hip_last_error());
-            abort();
+            // no device copy of this source picture (nor of later ones): no SAD surfaces can be attached to it, the searches use the C functions
+            if (sp->dev) { x265hip_srcpic_destroy(sp->dev); sp->dev = NULL; }
+            g_noDeviceCopies.store(true);
+            x265hip_device_failure("srcplanes", "device copy of a source picture");
         }
     }
     if (sp->version.load() == v)                        // otherwise these planes are simply never used
