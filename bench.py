@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 W, H, DEPTH, QP, MERANGE, SUBME = 1920, 1080, 8, 28, 57, 2
 VALU_SAD_CEILING_T = 95.2          # T absolute differences/s: v_qsad_pk_u16_u8 on the whole chip (tools/micro/qsad_rate)
+PCIE_PEAK_GBPS = 64.0            # PCIe Gen5 x16, one direction
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MIN_TIMED_S = 0.5                 # every timed region lasts at least this long, whatever --steps says
 CHUNK = 12                        # frames per step of the real encode
@@ -510,7 +511,7 @@ def parse_served(lines):
     out = {"clocks": {}}
     for l in lines:
         if "device time" in l:
-            for m in re.finditer(r"(lookahead searches|other lookahead kernels|sub-pel plane bands|SAD surfaces|source energy planes) ([\d.]+) ms in (\d+) launch groups \((\d+) algorithmic bytes\)", l):
+            for m in re.finditer(r"(lookahead searches|other lookahead kernels|sub-pel plane bands|SAD surfaces|source energy planes|CU residual quad-tree jobs) ([\d.]+) ms in (\d+) launch groups \((\d+) algorithmic bytes\)", l):
                 out["clocks"][m.group(1)] = {"ms": float(m.group(2)), "launch_groups": int(m.group(3)), "algorithmic_bytes": int(m.group(4))}
             m = re.search(r"total ([\d.]+) ms", l)
             if m:
@@ -521,6 +522,12 @@ def parse_served(lines):
         m = re.search(r"(\d+) search launches of ([\d.]+) \(frame, reference\) pairs", l)
         if m:
             out["search_launches"], out["pairs_per_launch"] = int(m.group(1)), float(m.group(2))
+        m = re.search(r"cuserve: (\d+) CU residual quad-trees \(CU >= (\d+)\) handed to the GPU as jobs \(([^,]+), ([\d.]+) ms of device time.*?: (\d+) forward transform\+quant units and "
+                      r"(\d+) inverse units served, (\d+) \+ (\d+) calls of those CUs computed on the host; (\d+) waits of (\d+) cycles on average; (\d+) CUs not submitted", l)
+        if m:
+            out["cu"] = {"jobs": int(m.group(1)), "min_cu": int(m.group(2)), "handoff": m.group(3), "device_ms": float(m.group(4)), "forward_units": int(m.group(5)),
+                         "inverse_units": int(m.group(6)), "host_computed": int(m.group(7)) + int(m.group(8)), "waits": int(m.group(9)), "wait_cycles": int(m.group(10)),
+                         "not_submitted": int(m.group(11))}
     return out
 
 
@@ -572,6 +579,28 @@ def encode_bench(args, rank, local_rank, world, fence, allmax):
             differing = allmax(0.0 if same else 1.0)
             res["reference"] = {"cli_fps": r0["fps"], "wall_s": round(dt_ref, 2), "rc": r0["rc"], "byte_identical": differing == 0.0,
                                 "bitstream_bytes": os.path.getsize(out_ref) if r0["rc"] == 0 else 0}
+        if world > 1:
+            # ---- BASELINE configs[4]'s form beside the chunk form: ONE encoder whose device work is spread over the N GPUs (X265HIP_DEVICES: reference-picture
+            # mirrors and source pictures take their places in turn, SAD surfaces are built where the source lives from replicas fed device to device, every
+            # place runs its own worker thread and its own CU-job server).  Outside the timed region; rank 0 only, the other ranks wait at the fence.
+            fence()
+            if rank == 0:
+                all_devs = visible.split(",") if visible else [str(i) for i in range(world)]
+                env1 = dict(os.environ, X265HIP_VERBOSE="1", X265HIP="require", HIP_VISIBLE_DEVICES=",".join(all_devs[:world]),
+                            X265HIP_DEVICES=",".join(str(i) for i in range(world)))
+                out_one = clip + ".places.hevc"
+                t0 = time.perf_counter()
+                r1 = ef._run(hip, [a for a in base if a not in ("--pools", str(per_rank))] + ["--frames", str(frames)], out_one, env=env1)
+                dt1 = time.perf_counter() - t0
+                same1 = r1["rc"] == 0 and os.path.exists(out_hip) and open(out_one, "rb").read() == open(out_hip, "rb").read()
+                res["one_encoder"] = {"places": world, "fps": round(frames / dt1, 3) if r1["rc"] == 0 else None, "cli_fps": r1["fps"], "rc": r1["rc"],
+                                      "byte_identical_to_chunk_path": same1,
+                                      "exchange": [l for l in r1["served"] if "places:" in l or "cuserve:" in l],
+                                      "note": "one x265 encoder using all %d GPUs (frames <-> GPUs inside the encoder, reconstructed rows pushed device to device); it has the whole "
+                                              "host to itself while the chunk form splits the host between %d encoders" % (world, world)}
+                if os.path.exists(out_one):
+                    os.remove(out_one)
+            fence()
     finally:
         for p in (clip, out_hip, out_ref):
             if os.path.exists(p):
@@ -653,7 +682,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-frames", type=int, default=10, help="frame passes of the CPU port sample inside `frame_pass` (0 = skip)")
     ap.add_argument("--no-ref-encoder", action="store_true")
-    ap.add_argument("--no-frame-pass", action="store_true", help="skip the device-resident frame-pass block")
+    ap.add_argument("--no-frame-pass", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--frame-pass", action="store_true",
+                    help="also run the device-resident frame-pass harness (`frame_pass` block: rounds 1-2's pipeline of the kernels on HBM-resident pictures with its CPU port leg); "
+                         "no product consumes it, so the default run spends the driver's time on the encode only (VERDICT r03)")
     ap.add_argument("--frame-pass-only", action="store_true", help="profiling aid (tools/collect_profiles.sh): only the frame-pass block, printed as the line")
     ap.add_argument("--quick", action="store_true", help="skip the multi-process CPU port leg")
     ap.add_argument("--lookahead-probe-only", action="store_true",
@@ -718,7 +750,7 @@ def main():
     fps = world * enc["frames"] / dt
 
     fpb = None
-    if not args.no_frame_pass:
+    if args.frame_pass and not args.no_frame_pass:
         try:
             fpb = frame_pass_bench(args, rank, local_rank, world, max(args.steps, 20), max(args.warmup, 5))
         except Exception as e:  # noqa: BLE001  — the secondary block must never cost the run its headline
@@ -820,11 +852,29 @@ def main():
                         "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": None,
                         "algorithmic_bytes_per_launch": int(pl["algorithmic_bytes"] / pl["launch_groups"]), "launch_ms": round(pl["ms"] / pl["launch_groups"], 5),
                         "launch_ms_note": "HIP events around each band's launch; bands are one CTU row each (launch-latency sized)"}
+        # ---- CU residual quad-tree jobs: a host thread WAITS for each, so the path is built for round trip, not for bytes per second ------------------------------
+        cu = clocks.get("CU residual quad-tree jobs", {})
+        cu_block = None
+        if cu.get("ms") and served.get("cu"):
+            c = served["cu"]
+            secs = cu["ms"] * 1e-3
+            ach = cu["algorithmic_bytes"] / secs / 1e9
+            cu_block = {"bound": "latency", "kernel": "cu_server_kernel, live in the timed encode (%s): %d jobs = the transform arithmetic (MFMA dct -> quant -> sign-bit hiding -> dequant -> MFMA "
+                                                      "idct -> two SSEs) of the residual quad-trees of %d CUs >= %dx%d, %d forward and %d inverse units served to Quant::transformNxN / "
+                                                      "invtransformNxN; one workgroup per mailbox slot, data path host memory -> LDS -> host memory over PCIe (never HBM)"
+                                                      % (c["handoff"], c["jobs"], c["jobs"], c["min_cu"], c["min_cu"], c["forward_units"], c["inverse_units"]),
+                        "achieved": round(ach, 3), "peak": PCIE_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / PCIE_PEAK_GBPS, 5), "traffic": None,
+                        "peak_note": "PCIe Gen5 x16, one direction; the job is a dependent chain (doorbell -> one read round trip -> four MFMA passes -> write -> fence -> ready "
+                                     "word) and its figure of merit is the round trip: profiles/r04_*_cuserve_rt.txt (9.7 us to the first luma unit, 14.7 us per 32x32 CU job)",
+                        "busy_us_per_job": round(cu["ms"] * 1e3 / c["jobs"], 2), "algorithmic_bytes_per_job": int(cu["algorithmic_bytes"] / c["jobs"]),
+                        "hbm": {"achieved": round(ach, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 6),
+                                "note": "SURVEY 8d fused-chain bytes of the units (source + prediction in, levels + reconstructed residual out) / busy time of ONE workgroup"},
+                        "host_waits": {"count": c["waits"], "mean_cycles": c["wait_cycles"]}}
         # the dominant kernel of the timed region = the clock with the most device time
-        named = [(ss.get("ms", 0.0), ss_block), (la.get("ms", 0.0), la_live)]
+        named = [(ss.get("ms", 0.0), ss_block), (la.get("ms", 0.0), la_live), (cu.get("ms", 0.0), cu_block)]
         named = [b for _, b in sorted(named, key=lambda t: -t[0]) if b]
         dominant = named[0] if named else la_probe
-        others = [b for b in (ss_block, probe_block, la_live, la_probe, pl_block, planes_probe) if b and b is not dominant]
+        others = [b for b in (ss_block, probe_block, cu_block, la_live, la_probe, pl_block, planes_probe) if b and b is not dominant]
         out = {
             "metric": "encode fps (1080p preset medium)", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 3),
@@ -832,7 +882,8 @@ def main():
             "config": {"workload": "x265 --preset medium --me hex, 1920x1080 8-bit 4:2:0; ONE synthetic clip = the %d-frame segment of x265_amd/synth.make_clip (96x96 tiles with "
                                    "their own velocities + noise, seed 4321) repeated N times, rank r encodes repetition r as a closed-GOP chunk on GPU r (one step = %d frames "
                                    "per rank); the reference encoder's binary + x265_amd/host/*.cpp + libx265hip.so (oracle/_ref/x265_hip_8bit): lookahead frame-cost "
-                                   "estimates batched on the GPU, integer-pel SADs of the motion search looked up in GPU-built SAD surfaces, luma sub-pel filter slots "
+                                   "estimates batched on the GPU, the residual quad-trees of CUs >= 32x32 (MFMA dct / quant / sign hiding / dequant / idct) as mailbox jobs to a resident GPU "
+                                   "server, integer-pel SADs of the motion search looked up in GPU-built SAD surfaces, luma sub-pel filter slots "
                                    "served from GPU-built fractional planes of each reference picture, psy-cost source halves from GPU-built energy planes, C slots "
                                    "otherwise; the host cores are split between the ranks" % (enc["frames"], CHUNK),
                        "frames_per_step": world * CHUNK, "encoder_cli_fps_rank0": enc["cli_fps"], "served_by_gpu": enc["served"],
@@ -843,9 +894,13 @@ def main():
             "rooflines": others,
             "gpu_duty_cycle": {"device_ms": served.get("device_ms"), "timed_s": round(dt, 2),
                                "frac": round(served["device_ms"] * 1e-3 / dt, 4) if served.get("device_ms") else None,
+                               "launch_groups_frac": round((served["device_ms"] - cu.get("ms", 0.0)) * 1e-3 / dt, 4) if served.get("device_ms") else None,
+                               "cu_job_workgroup_seconds_per_second": round(cu.get("ms", 0.0) * 1e-3 / dt, 4),
                                "by_clock_ms": {k: v["ms"] for k, v in clocks.items()},
                                "note": "rank 0's encoder: sum of the device time of every launch group of the bound modules (x265hip_device_time) / wall clock of the timed "
-                                       "region; the weight analysis of the lookahead (about 1 % of the device time) is not inside a span"},
+                                       "region (launch_groups_frac), plus the busy time of the CU-job server's workgroups — each a one-CU job, several at a time, so `frac` can "
+                                       "exceed 1: it is workgroup-seconds per second, i.e. CUs kept busy on average; the weight analysis of the lookahead (about 1 % of the "
+                                       "device time) is not inside a span"},
         }
         if "reference" in enc:
             r0 = enc["reference"]
@@ -862,6 +917,8 @@ def main():
                                    "byte_identical_to_gpu_path": r0["byte_identical"], "bitstream_bytes": r0["bitstream_bytes"]}
             if not r0["byte_identical"]:
                 out["error"] = "a chunk's GPU-path bitstream differs from the reference encoder's"
+        if enc.get("one_encoder"):
+            out["one_encoder_all_gpus"] = enc["one_encoder"]
         if fpb:
             out["frame_pass"] = fpb
         print(json.dumps(out), flush=True)

@@ -894,6 +894,8 @@ typedef struct x265hip_cuserve x265hip_cuserve;
  * microseconds` without work so that nothing in the process ever waits on it for long); mode 1: one launch per job on the slot's own
  * stream.  Either way completion is signalled through the units' `ready` words, never through a stream synchronisation. */
 int x265hip_cuserve_open(int slots, int mode, x265hip_cuserve** out);
+/* the same service at place `place` (x265hip_places): its slots are served by that place's device */
+int x265hip_cuserve_open_at(int place, int slots, int mode, x265hip_cuserve** out);
 int x265hip_cuserve_close(x265hip_cuserve* cs);
 /* the slot's memory: the caller writes *job and *pixels, reads units / levels / resi */
 int x265hip_cuserve_slot(x265hip_cuserve* cs, int slot, x265hip_cujob** job, void** pixels, const x265hip_cujob_unit** units,

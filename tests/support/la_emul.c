@@ -702,6 +702,11 @@ int x265hip_cuserve_open(int slots, int mode, x265hip_cuserve** out)
     *out = cs;
     return 0;
 }
+int x265hip_cuserve_open_at(int place, int slots, int mode, x265hip_cuserve** out)
+{
+    if (place < 0 || place >= g_nPlaces) { snprintf(g_err, sizeof(g_err), "emul: no place %d", place); return X265HIP_EINVAL; }
+    return x265hip_cuserve_open(slots, mode, out);
+}
 int x265hip_cuserve_close(x265hip_cuserve* cs) { if (cs) { free(cs->slot); free(cs); } return 0; }
 int x265hip_cuserve_slot(x265hip_cuserve* cs, int slot, x265hip_cujob** job, void** pixels, const x265hip_cujob_unit** units, const int16_t** levels,
                          const int16_t** resi)

@@ -131,3 +131,31 @@ def test_bound_encoder_with_two_places_on_one_gpu_is_byte_identical(tmp_path):
     assert places == 2 and replicas > 0 and bands >= replicas and mb > 0
     served = [l for l in err.splitlines() if "x265hip: sadplanes:" in l]
     assert served and int(served[0].split()[2]) > 1000, err[-600:]
+
+
+def _physical_devices():
+    import x265_amd.hipprim as hp
+    return hp.lib().x265hip_device_count()
+
+
+@pytest.mark.gpu
+def test_bound_encoder_on_two_physical_gpus_is_byte_identical(tmp_path):
+    """X265HIP_DEVICES=0,1 on a node with at least two GPUs: hipDeviceEnablePeerAccess, the cross-device hipMemcpyPeerAsync of reconstructed bands
+    (x265_amd/csrc/sadsurf.hip replica_at / progress) and the CU-job servers of both places really run between two devices.  Skipped on a one-GPU box
+    (the round-end 1-GPU tier); the driver's 8-GPU node runs it."""
+    n = _physical_devices()
+    if n < 2:
+        pytest.skip("one HIP device visible: the cross-device branch needs two (the two-places-on-one-GPU test above covers the logic)")
+    ref, hip = _need("x265_8bit"), _need("x265_hip_8bit")
+    from x265_amd.synth import make_clip
+    yuv = str(tmp_path / "clip.yuv")
+    w, h, frames = 1280, 720, 24
+    make_clip(yuv, w, h, frames, seed=33)
+    want, _ = _encode(ref, yuv, w, h, frames, str(tmp_path / "ref.hevc"), {})
+    devices = ",".join(str(i) for i in range(min(n, 4)))
+    got, err = _encode(hip, yuv, w, h, frames, str(tmp_path / "hip.hevc"), {"X265HIP_DEVICES": devices, "X265HIP": "require"})
+    assert got == want, "bitstreams differ"
+    places, replicas, bands, mb = _exchange(err)
+    assert places == min(n, 4) and replicas > 0 and bands >= replicas and mb > 0
+    served = [l for l in err.splitlines() if "x265hip: sadplanes:" in l]
+    assert served and int(served[0].split()[2]) > 1000, err[-600:]

@@ -14,6 +14,11 @@ constexpr int kWave = 64;
 int set_error(int code, const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 int ensure_device();                       // lazy hipSetDevice + capability check; X265HIP_ENODEV when absent
+// hipFree synchronises EVERY stream of the device (measured: 1.45 s beside a resident kernel, tools/micro/mailbox_diag), so the library never calls it
+// directly: device_free() first asks the resident CU-job servers (cuserve.hip) to leave, frees, and lets the next submitter start them again.
+hipError_t device_free(void* p);
+void servers_pause();                      // cuserve.hip
+void servers_resume();
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 bool valid_depth(int depth);
 bool valid_block(int w, int h);            // multiples of 2 up to 64 (luma PU shapes and their chroma halves)

@@ -33,6 +33,7 @@
 namespace xh {
 
 void clock_add(int clk, uint64_t spans, uint64_t ns, uint64_t bytes);     // runtime.hip
+int place_device(int place);
 
 namespace {
 
@@ -82,6 +83,8 @@ __device__ __constant__ const DiagScans kDiag = make_diag();
 struct HostCtl                                    // host-coherent page-locked memory, one per x265hip_cuserve
 {
     uint32_t serverState;                        // 0: no server; 0x80000000 | g: generation g is being started; g: generation g is polling
+    uint32_t pad[15];
+    uint32_t leave;                              // host -> device: the server is asked to leave (somebody has to synchronise the device: servers_pause)
 };
 struct DevCtl                                     // device memory
 {
@@ -457,7 +460,12 @@ __global__ __launch_bounds__(256) void cu_server_kernel(Slot* slots, HostCtl* ho
             for (;;)
             {
                 v = __hip_atomic_load(&s->doorbell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (v == 0xffffffffu) { __hip_atomic_store(&ctl->quit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if (v == 0xffffffffu || (blockIdx.x == 0 && __hip_atomic_load(&hostCtl->leave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)))
+                {
+                    __hip_atomic_store(&ctl->quit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = 0xffffffffu;
+                    break;
+                }
                 if (__hip_atomic_load(&ctl->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { v = 0xffffffffu; break; }
                 if (v != last) break;
                 if ((++polls & 15) == 0 &&
@@ -506,14 +514,17 @@ struct x265hip_cuserve
     std::atomic<uint32_t> generation{ 0 };
     std::mutex launchLock;
     std::atomic<uint64_t> jobs{ 0 }, starts{ 0 }, bytes{ 0 };
+    std::atomic<int> paused{ 0 };                 // servers_pause() callers in progress: no server is started meanwhile
     uint64_t idleUs = 2000;
 };
+static std::mutex g_openLock;
+static x265hip_cuserve* g_open[16];               // the services with a resident server (mode 0)
 
 static int start_server(x265hip_cuserve* cs)
 {
     std::lock_guard<std::mutex> g(cs->launchLock);
-    if (__atomic_load_n(&cs->hostCtl->serverState, __ATOMIC_ACQUIRE) != 0)
-        return X265HIP_OK;                                                   // someone else has started one meanwhile
+    if (__atomic_load_n(&cs->hostCtl->serverState, __ATOMIC_ACQUIRE) != 0 || cs->paused.load() > 0)
+        return X265HIP_OK;                                                   // someone else has started one meanwhile / a device synchronisation is going on
     int cur = -1;
     (void)hipGetDevice(&cur);
     if (cur != cs->device && hipSetDevice(cs->device) != hipSuccess)
@@ -537,6 +548,33 @@ static int start_server(x265hip_cuserve* cs)
     cs->starts++;
     return X265HIP_OK;
 }
+
+namespace xh {
+void servers_pause()
+{
+    std::lock_guard<std::mutex> g(g_openLock);
+    for (x265hip_cuserve* cs : g_open)
+    {
+        if (!cs) continue;
+        std::lock_guard<std::mutex> l(cs->launchLock);                       // no start_server between the test and the flag
+        cs->paused++;
+        __atomic_store_n(&cs->hostCtl->leave, 1u, __ATOMIC_RELEASE);
+    }
+    // the servers leave at their next poll (a job in progress is finished first): wait for that, briefly — hipFree would wait anyway
+    const auto t0 = std::chrono::steady_clock::now();
+    for (x265hip_cuserve* cs : g_open)
+        while (cs && __atomic_load_n(&cs->hostCtl->serverState, __ATOMIC_ACQUIRE) != 0 &&
+               std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(200))
+            __builtin_ia32_pause();
+}
+void servers_resume()
+{
+    std::lock_guard<std::mutex> g(g_openLock);
+    for (x265hip_cuserve* cs : g_open)
+        if (cs && --cs->paused == 0)
+            __atomic_store_n(&cs->hostCtl->leave, 0u, __ATOMIC_RELEASE);
+}
+} // namespace xh
 
 extern "C" {
 
@@ -573,6 +611,12 @@ int x265hip_cuserve_open(int slots, int mode, x265hip_cuserve** out)
         for (int i = 0; i < slots && !e; i++)
             e = check_hip(hipStreamCreateWithFlags(&cs->jobStreams[i], hipStreamNonBlocking), "hipStreamCreate(cuserve job)");
     if (e) { x265hip_cuserve_close(cs); return e; }
+    if (mode == 0)
+    {
+        std::lock_guard<std::mutex> g(g_openLock);
+        for (x265hip_cuserve*& slot : g_open)
+            if (!slot) { slot = cs; break; }
+    }
     *out = cs;
     return X265HIP_OK;
 }
@@ -594,9 +638,26 @@ static uint64_t device_ticks(x265hip_cuserve* cs)
     return ticks;
 }
 
+int x265hip_cuserve_open_at(int place, int slots, int mode, x265hip_cuserve** out)
+{
+    const int dev = place >= 0 ? place_device(place) : -1;
+    if (dev < 0) return set_error(X265HIP_EINVAL, "x265hip_cuserve_open_at: no place %d (x265hip_places)", place);
+    int cur = 0;
+    const bool had = hipGetDevice(&cur) == hipSuccess;
+    if (hipSetDevice(dev) != hipSuccess) return set_error(X265HIP_EHIP, "x265hip_cuserve_open_at: hipSetDevice(%d)", dev);
+    const int e = x265hip_cuserve_open(slots, mode, out);
+    if (had) (void)hipSetDevice(cur);
+    return e;
+}
+
 int x265hip_cuserve_close(x265hip_cuserve* cs)
 {
     if (!cs) return X265HIP_OK;
+    {
+        std::lock_guard<std::mutex> g(g_openLock);
+        for (x265hip_cuserve*& slot : g_open)
+            if (slot == cs) slot = nullptr;
+    }
     if (cs->host)
     {
         __atomic_store_n(&cs->host[0].doorbell, 0xffffffffu, __ATOMIC_RELEASE);           // a resident server leaves at its next poll
@@ -608,7 +669,7 @@ int x265hip_cuserve_close(x265hip_cuserve* cs)
         (void)hipHostFree(cs->host);
     }
     if (cs->hostCtl) (void)hipHostFree(cs->hostCtl);
-    if (cs->ctl) (void)hipFree(cs->ctl);
+    if (cs->ctl) (void)device_free(cs->ctl);
     if (cs->serverStream) (void)hipStreamDestroy(cs->serverStream);
     delete[] cs->seq; delete[] cs->jobStreams;
     delete cs;
@@ -650,8 +711,13 @@ int x265hip_cuserve_submit(x265hip_cuserve* cs, int slot, uint32_t* seqOut)
     if (cs->mode == 1)
     {
         std::atomic_thread_fence(std::memory_order_release);
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != cs->device) (void)hipSetDevice(cs->device);
         hipLaunchKernelGGL(cu_job_kernel, dim3(1), dim3(256), 0, cs->jobStreams[slot], cs->dev + slot, seq, &cs->ctl->busyTicks[slot]);
-        XH_LAUNCH_CHECK("cu_job_kernel");
+        const hipError_t le = hipGetLastError();
+        if (cur >= 0 && cur != cs->device) (void)hipSetDevice(cur);
+        if (le != hipSuccess) return check_hip(le, "cu_job_kernel");
         return X265HIP_OK;
     }
     __atomic_store_n(&s->doorbell, seq, __ATOMIC_RELEASE);

@@ -81,7 +81,7 @@ static int upload_offsets(int32_t** d, const std::vector<int32_t>& xy, int64_t s
     std::vector<int32_t> off(xy.size() / 2);
     for (size_t i = 0; i < off.size(); i++)
         off[i] = (int32_t)((int64_t)xy[2 * i + 1] * stride + xy[2 * i]);
-    if (*d) (void)hipFree(*d);
+    if (*d) (void)device_free(*d);
     *d = nullptr;
     return dev_upload(d, off);
 }
@@ -226,27 +226,27 @@ int x265hip_framepass_destroy(x265hip_framepass* fp)
     for (int l = 0; l < 4; l++)
     {
         void* ptrs[] = { fp->puXY[l], fp->parent[l], fp->qmvp[l], fp->mvmin[l], fp->mvmax[l], fp->mv[l], fp->cost[l], fp->sa8d[l], fp->cuOff[l], fp->cuOffP[l] };
-        for (void* p : ptrs) if (p) (void)hipFree(p);
+        for (void* p : ptrs) if (p) (void)device_free(p);
     }
     for (int t = 0; t < 2; t++)
     {
         void* ptrs[] = { fp->tuXY[t], fp->tuOffF[t], fp->tuOffP[t], fp->tuOffR[t], fp->level[t], fp->numSig[t], fp->dist[t], fp->quantCoeff[t] };
-        for (void* p : ptrs) if (p) (void)hipFree(p);
+        for (void* p : ptrs) if (p) (void)device_free(p);
     }
     for (int t = 0; t < 2; t++)
     {
         void* ptrs[] = { fp->ctuOffF[t], fp->ctuOffP[t], fp->ctuOffR[t], fp->cquantCoeff[t], fp->clevel[0][t], fp->cnumSig[0][t], fp->cdist[0][t] };
-        for (void* p : ptrs) if (p) (void)hipFree(p);
+        for (void* p : ptrs) if (p) (void)device_free(p);
     }
-    if (fp->mvcost) (void)hipFree(fp->mvcost);
+    if (fp->mvcost) (void)device_free(fp->mvcost);
     for (auto& g : fp->graphs) (void)hipGraphExecDestroy(g.exec);
     fp->graphs.clear();
-    if (fp->planes) (void)hipFree(fp->planes);
-    if (fp->planes1) (void)hipFree(fp->planes1);
+    if (fp->planes) (void)device_free(fp->planes);
+    if (fp->planes1) (void)device_free(fp->planes1);
     for (int l = 0; l < 4; l++)
     {
         void* ptrs[] = { fp->qmvp1[l], fp->mvmin1[l], fp->mvmax1[l], fp->mv1[l], fp->cost1[l] };
-        for (void* p : ptrs) if (p) (void)hipFree(p);
+        for (void* p : ptrs) if (p) (void)device_free(p);
     }
     for (int i = 0; i < 12; i++) (void)hipEventDestroy(fp->ev[i]);
     delete fp;
@@ -303,14 +303,14 @@ static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t st
     {
         drop_graphs(fp);
         FP_TRY(check_hip(hipStreamSynchronize(as_stream(stream)), "framepass sync"));
-        if (fp->planes) (void)hipFree(fp->planes);
+        if (fp->planes) (void)device_free(fp->planes);
         fp->planes = nullptr;
         fp->planeStride = strideR; fp->planeMarginX = marginX; fp->planeMarginY = marginY;
         fp->planeElems = strideR * (int64_t)(fp->height + 2 * marginY);
         const size_t B = depth == 8 ? 1 : 2;
         FP_TRY(check_hip(hipMalloc(&fp->planes, (size_t)fp->planeElems * 16 * B), "hipMalloc(subpel planes)"));
         FP_TRY(check_hip(hipMemsetAsync(fp->planes, 0, (size_t)fp->planeElems * 16 * B, as_stream(stream)), "hipMemset(subpel planes)"));
-        if (fp->planes1) (void)hipFree(fp->planes1);
+        if (fp->planes1) (void)device_free(fp->planes1);
         fp->planes1 = nullptr;
     }
     if (ba && !fp->planes1)
@@ -433,7 +433,7 @@ static int framepass_run_impl(x265hip_framepass* fp, const void* src, int64_t st
                         off[i] = (int32_t)o;
                         off[n + i] = (int32_t)(o + deltas[k]);
                     }
-                    if (*dst[k]) (void)hipFree(*dst[k]);
+                    if (*dst[k]) (void)device_free(*dst[k]);
                     *dst[k] = nullptr;
                     FP_TRY(dev_upload(dst[k], off));
                 }

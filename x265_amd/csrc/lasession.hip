@@ -80,10 +80,10 @@ static int la_grow(x265hip_la* la, int n)
     if (n <= la->capEst) return X265HIP_OK;
     int cap = la->capEst ? la->capEst : 16;
     while (cap < n) cap *= 2;
-    if (la->dOut) (void)hipFree(la->dOut);
+    if (la->dOut) (void)device_free(la->dOut);
     if (la->hOut) (void)hipHostFree(la->hOut);
-    if (la->dSync) (void)hipFree(la->dSync);
-    if (la->dDesc) (void)hipFree(la->dDesc);
+    if (la->dSync) (void)device_free(la->dSync);
+    if (la->dDesc) (void)device_free(la->dDesc);
     if (la->hDesc) (void)hipHostFree(la->hDesc);
     la->dOut = la->hOut = la->dDesc = la->hDesc = nullptr; la->dSync = nullptr; la->capEst = 0;
     const size_t blk = est_block_bytes(la);
@@ -163,18 +163,18 @@ void x265hip_la_destroy(x265hip_la* la)
     if (la->st) (void)hipStreamSynchronize(la->st);
     for (auto& s : la->slots)
     {
-        if (s.buffers) (void)hipFree(s.buffers);
-        if (s.intraCost) (void)hipFree(s.intraCost);
-        if (s.invQscale) (void)hipFree(s.invQscale);
-        if (s.store) (void)hipFree(s.store);
-        if (s.ahead) (void)hipFree(s.ahead);
+        if (s.buffers) (void)device_free(s.buffers);
+        if (s.intraCost) (void)device_free(s.intraCost);
+        if (s.invQscale) (void)device_free(s.invQscale);
+        if (s.store) (void)device_free(s.store);
+        if (s.ahead) (void)device_free(s.ahead);
     }
-    for (char* w : la->wbufs) (void)hipFree(w);
-    if (la->mvcost) (void)hipFree(la->mvcost);
-    if (la->dOut) (void)hipFree(la->dOut);
+    for (char* w : la->wbufs) (void)device_free(w);
+    if (la->mvcost) (void)device_free(la->mvcost);
+    if (la->dOut) (void)device_free(la->dOut);
     if (la->hOut) (void)hipHostFree(la->hOut);
-    if (la->dSync) (void)hipFree(la->dSync);
-    if (la->dDesc) (void)hipFree(la->dDesc);
+    if (la->dSync) (void)device_free(la->dSync);
+    if (la->dDesc) (void)device_free(la->dDesc);
     if (la->hDesc) (void)hipHostFree(la->hDesc);
     if (la->st) (void)hipStreamDestroy(la->st);
     delete la;
@@ -290,7 +290,7 @@ int x265hip_la_estimate_batch_ahead(x265hip_la* la, x265hip_la_estimate* est, in
         ~Release()
         {
             l->wbufsUsed = 0;
-            while (l->wbufs.size() > 8) { (void)hipFree(l->wbufs.back()); l->wbufs.pop_back(); }
+            while (l->wbufs.size() > 8) { (void)device_free(l->wbufs.back()); l->wbufs.pop_back(); }
         }
     } release{ la };
     if (!n && !nAhead) return X265HIP_OK;

@@ -36,7 +36,7 @@ static int staging_reserve(size_t bytes)
     if (bytes > s.cap)
     {
         if (s.host) (void)hipHostFree(s.host);
-        if (s.dev) (void)hipFree(s.dev);
+        if (s.dev) (void)device_free(s.dev);
         s.host = s.dev = nullptr;
         s.cap = 0;
         size_t cap = 1 << 16;

@@ -61,7 +61,8 @@ struct RefWorker
         if (started) return;
         started = true;
         th = std::thread([this] { run(); });
-        atexit([] { worker().shutdown(); });
+        static std::once_flag once;
+        std::call_once(once, [] { atexit([] { for (int p = 0; p < kWorkers; p++) if (workers()[p]) workers()[p]->shutdown(); }); });
     }
     void shutdown()
     {
@@ -84,7 +85,19 @@ struct RefWorker
         }
         cv.notify_one();
     }
-    static RefWorker& worker() { static RefWorker* w = new RefWorker; return *w; }      // leaked on purpose: lives as long as the process
+    // one worker per place (a GPU of the encoder): the bands, surfaces and replicas of the pictures that live there are driven by their own thread, so
+    // the devices of one encoder do not queue behind one another; objects without a place share worker 0.  Leaked on purpose:
+    // the workers live as long as the process.
+    static constexpr int kWorkers = 16;
+    static RefWorker** workers() { static RefWorker* w[kWorkers] = {}; return w; }
+    static RefWorker& worker(int place)
+    {
+        static std::mutex lock;
+        const int p = place >= 0 ? place % kWorkers : 0;
+        std::lock_guard<std::mutex> g(lock);
+        if (!workers()[p]) workers()[p] = new RefWorker;
+        return *workers()[p];
+    }
     void run();
 };
 

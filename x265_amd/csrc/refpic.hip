@@ -176,14 +176,14 @@ static x265hip_refpic* refpic_create(int place, int depth, int picW, int picH, i
         x265hip_refpic_destroy(rp);
         return nullptr;
     }
-    RefWorker::worker().start();
+    RefWorker::worker(rp->place).start();
     return rp;
 }
 
 int x265hip_refpic_wait(x265hip_refpic* rp)
 {
     if (!rp) return set_error(X265HIP_EINVAL, "x265hip_refpic_wait: null");
-    RefWorker& w = RefWorker::worker();
+    RefWorker& w = RefWorker::worker(rp->place);
     std::unique_lock<std::mutex> g(w.m);
     w.idle.wait(g, [rp] { return rp->pending.load() == 0; });
     return rp->failed.load() ? set_error(X265HIP_EHIP, "x265hip_refpic: a device operation of the worker failed") : X265HIP_OK;
@@ -201,7 +201,7 @@ void x265hip_refpic_destroy(x265hip_refpic* rp)
     {
         (void)hipSetDevice(r->device);
         if (r->st) { (void)hipStreamSynchronize(r->st); (void)hipStreamDestroy(r->st); }
-        if (r->dPic) (void)hipFree(r->dPic);
+        if (r->dPic) (void)device_free(r->dPic);
         delete r;
     }
     rp->replicas.clear();
@@ -216,8 +216,8 @@ void x265hip_refpic_destroy(x265hip_refpic* rp)
     else
     {
         if (rp->hStage) (void)hipHostFree(rp->hStage);
-        if (rp->dPic) (void)hipFree(rp->dPic);
-        if (rp->dPlanes) (void)hipFree(rp->dPlanes);
+        if (rp->dPic) (void)device_free(rp->dPic);
+        if (rp->dPlanes) (void)device_free(rp->dPlanes);
         if (rp->hPlanes) (void)hipHostFree(rp->hPlanes);
         if (rp->st) (void)hipStreamDestroy(rp->st);
     }
@@ -246,7 +246,7 @@ int x265hip_refpic_rows_final(x265hip_refpic* rp, int rowsFinal)
 {
     if (!rp || rowsFinal < 0) return set_error(X265HIP_EINVAL, "x265hip_refpic_rows_final: rows %d", rowsFinal);
     if (rp->failed.load()) return set_error(X265HIP_EHIP, "x265hip_refpic: a device operation of the worker failed");
-    RefWorker::worker().push(RefJob{ rp, rowsFinal > rp->picH ? rp->picH : rowsFinal, rp->epoch.load() });
+    RefWorker::worker(rp->place).push(RefJob{ rp, rowsFinal > rp->picH ? rp->picH : rowsFinal, rp->epoch.load() });
     return X265HIP_OK;
 }
 

@@ -88,6 +88,15 @@ int place_of_device(int device) { return -(device + 1); }
 
 static std::atomic<uint64_t> g_clkSpans[X265HIP_CLK_COUNT], g_clkNs[X265HIP_CLK_COUNT], g_clkBytes[X265HIP_CLK_COUNT];
 
+hipError_t device_free(void* p)
+{
+    if (!p) return hipSuccess;
+    servers_pause();
+    const hipError_t e = hipFree(p);
+    servers_resume();
+    return e;
+}
+
 void clock_add(int clk, uint64_t spans, uint64_t ns, uint64_t bytes)
 {
     if (clk < 0 || clk >= X265HIP_CLK_COUNT) return;
@@ -199,7 +208,7 @@ int x265hip_malloc(void** dptr, size_t bytes)
 int x265hip_free(void* dptr)
 {
     XH_CHECK_DEV();
-    return check_hip(hipFree(dptr), "hipFree");
+    return check_hip(device_free(dptr), "hipFree");
 }
 int x265hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream)
 {

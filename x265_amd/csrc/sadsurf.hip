@@ -80,6 +80,7 @@ struct x265hip_sadsurf
 {
     x265hip_srcpic* src = nullptr;
     x265hip_refpic* ref = nullptr;       // null once the reference picture has gone (under g_ssLock)
+    int workerPlace = -1;                // the worker that drives this surface (its reference picture's place)
     xh::Replica* rep = nullptr;          // the reference picture's replica at the source's place; null: the mirror itself (same place).  Worker only
     int S = 32, lambda20 = 0, levels = 14;
     xh::SurfLayout lay;
@@ -977,7 +978,7 @@ static void srcpic_unref(x265hip_srcpic* sp)
     const bool had = hipGetDevice(&cur) == hipSuccess;
     (void)hipSetDevice(sp->device);
     if (sp->st) { (void)hipStreamSynchronize(sp->st); (void)hipStreamDestroy(sp->st); }
-    if (sp->dLuma) (void)hipFree(sp->dLuma);
+    if (sp->dLuma) (void)device_free(sp->dLuma);
     if (sp->hStage) (void)hipHostFree(sp->hStage);
     if (had && cur != sp->device) (void)hipSetDevice(cur);
     delete sp;
@@ -1018,7 +1019,7 @@ x265hip_sadsurf* x265hip_sadsurf_attach_levels(x265hip_srcpic* src, x265hip_refp
         if (!ok)
         {
             set_error(X265HIP_ENOMEM, "x265hip_sadsurf_attach: %zu bytes", ss->bytes);
-            if (ss->dBuf) (void)hipFree(ss->dBuf);
+            if (ss->dBuf) (void)device_free(ss->dBuf);
             delete ss;
             return nullptr;
         }
@@ -1041,7 +1042,8 @@ x265hip_sadsurf* x265hip_sadsurf_attach_levels(x265hip_srcpic* src, x265hip_refp
         ref->surfaces.push_back(ss);
     }
     g_statAttached++;
-    RefWorker::worker().push(RefJob{ ref, 0, ref->epoch.load(), 1, ss });
+    ss->workerPlace = ref->place;                 // the release must queue behind the attach: same worker
+    RefWorker::worker(ref->place).push(RefJob{ ref, 0, ref->epoch.load(), 1, ss });
     return ss;
 }
 
@@ -1051,7 +1053,7 @@ void x265hip_sadsurf_release(x265hip_sadsurf* ss)
 {
     if (!ss) return;
     ss->released = true;
-    RefWorker::worker().push(RefJob{ nullptr, 0, 0, 2, ss });
+    RefWorker::worker(ss->workerPlace).push(RefJob{ nullptr, 0, 0, 2, ss });
 }
 
 int x265hip_peer_stats(uint64_t* replicas, uint64_t* bands, uint64_t* bytes)

@@ -120,7 +120,7 @@ extern "C" int x265hip_source_energy(int depth, const void* hostPlane, int64_t s
     (void)hipGetDevice(&dev);
     if (es.device != dev || es.cap < need)
     {
-        if (es.d) (void)hipFree(es.d);
+        if (es.d) (void)device_free(es.d);
         if (es.h) (void)hipHostFree(es.h);
         if (es.st && es.device != dev) { (void)hipStreamDestroy(es.st); es.st = nullptr; }
         es.d = es.h = nullptr; es.cap = 0; es.device = dev;

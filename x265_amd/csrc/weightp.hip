@@ -340,7 +340,7 @@ extern "C" int x265hip_lookahead_aq_frame(int depth, const x265hip_yuv* pic, int
         if (!e && (hipMemcpyAsync(energy.data(), dE, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st) != hipSuccess ||
                    hipMemcpyAsync(sums, dS, 48, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
             e = set_error(X265HIP_EHIP, "lookahead_aq_frame: readback");
-        (void)hipFree(dE);
+        (void)device_free(dE);
         if (e) return e;
     }
     const float modeOneConst = qgSize == 8 ? 11.427f : 14.427f, modeTwoConst = qgSize == 8 ? 8.f : 11.f;

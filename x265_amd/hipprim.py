@@ -184,6 +184,7 @@ PROTOTYPES = {
     "x265hip_sadsurf_release": (None, [vp]),
     "x265hip_sadsurf_stats": (i32, [vp, vp, vp, vp]),
     "x265hip_cuserve_open": (i32, [i32, i32, C.POINTER(vp)]),
+    "x265hip_cuserve_open_at": (i32, [i32, i32, i32, C.POINTER(vp)]),
     "x265hip_cuserve_close": (i32, [vp]),
     "x265hip_cuserve_slot": (i32, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     "x265hip_cuserve_submit": (i32, [vp, i32, C.POINTER(u32)]),

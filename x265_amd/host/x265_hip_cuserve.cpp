@@ -71,14 +71,22 @@ int g_state = 0;                 // 0 undecided, 1 on, -1 off
 int g_time = 0;                  // X265HIP_DEBUG_CUTIME=1: cycles inside the functions a job could replace, by block size (report at exit);
                                  // =2: the same with the jobs running (the pair of runs measures what the jobs save and what the waiting costs)
 int g_minLog2 = 5;               // X265HIP_CUSERVE_MIN: smallest CU (log2) whose residual quad-tree becomes a job
-int g_mode = 1;                  // X265HIP_CUSERVE_MODE: 0 resident server (mailbox), 1 one launch per job
+int g_mode = 0;                  // X265HIP_CUSERVE_MODE: 0 resident server (mailbox), 1 one launch per job
 int g_slots = 64;                // X265HIP_CUSERVE_SLOTS: host threads that can have a job in flight
 bool g_verify = false;           // X265HIP_VERIFY=1: every served unit is recomputed by the reference's function and compared
 bool g_require = false;          // X265HIP=require: a device failure is fatal instead of falling back
 std::mutex g_lock;
-x265hip_cuserve* g_cs = NULL;
-std::atomic<uint64_t> g_slotBusy[4];         // bit s of word s / 64: slot s holds a job of some thread (a slot is taken per job, not per thread: x265 starts
+struct SlotMem { x265hip_cujob* job; void* pixels; const x265hip_cujob_unit* units; const int16_t* levels; const int16_t* resi; };
+// one job service per place (X265HIP_DEVICES; one on the calling thread's device when no places are configured): every GPU of the encoder serves CU jobs
+struct Service
+{
+    x265hip_cuserve* cs;
+    SlotMem mem[256];
+    std::atomic<uint64_t> busy[4];           // bit s of word s / 64: slot s holds a job of some thread (a slot is taken per job, not per thread: x265 starts
                                              // one pool thread per core it sees, far more than ever run at once under a CPU quota)
+};
+Service g_svc[16];
+std::atomic<int> g_nsvc(0);                  // services open (published last)
 std::atomic<bool> g_dead(false); // the device failed once: every later CU is computed on the host
 
 // X265HIP_DEBUG_CUTIME: [0..3] transformNxN by log2TrSize - 2, [4..7] invtransformNxN, [8..12] top-level estimateResidualQT by log2CUSize - 2,
@@ -102,14 +110,13 @@ struct Job
     int sHi, sLo;
     uint32_t seq;
     int slot;
+    Service* svc;
     x265hip_cujob* job;
     const x265hip_cujob_unit* units;
     const int16_t* levels;
     const int16_t* resiOut;
 };
 __attribute__((tls_model("initial-exec"))) thread_local Job t_job;
-struct SlotMem { x265hip_cujob* job; void* pixels; const x265hip_cujob_unit* units; const int16_t* levels; const int16_t* resi; };
-SlotMem g_mem[256];
 __attribute__((tls_model("initial-exec"))) thread_local int t_hint = -1;           // where this thread looks first
 
 void report_time()
@@ -135,11 +142,16 @@ void report()
         wc += g_count[i].waitCycles; w += g_count[i].waits; sk += g_count[i].skipped;
     }
     uint64_t devJobs = 0, starts = 0, ns = 0;
-    if (g_cs) x265hip_cuserve_stats(g_cs, &devJobs, &starts, &ns);
-    fprintf(stderr, "x265hip: cuserve: %llu CU residual quad-trees (CU >= %d) handed to the GPU as jobs (%s, %.3f ms of device time%s): %llu forward "
+    for (int k = 0; k < g_nsvc.load(); k++)
+    {
+        uint64_t a = 0, b = 0, c = 0;
+        if (g_svc[k].cs && !x265hip_cuserve_stats(g_svc[k].cs, &a, &b, &c)) { devJobs += a; starts += b; ns += c; }
+    }
+    fprintf(stderr, "x265hip: cuserve: %llu CU residual quad-trees (CU >= %d) handed to the GPU as jobs (%s%s, %.3f ms of device time%s): %llu forward "
                     "transform+quant units and %llu inverse units served, %llu + %llu calls of those CUs computed on the host; %llu waits of %.0f cycles on average; "
                     "%llu CUs not submitted%s\n",
-            (unsigned long long)jobs, 1 << g_minLog2, g_mode ? "one launch per job" : "resident server", ns * 1e-6,
+            (unsigned long long)jobs, 1 << g_minLog2, g_mode ? "one launch per job" : "resident server",
+            g_nsvc.load() > 1 ? (std::string(" at each of ") + std::to_string(g_nsvc.load()) + " places").c_str() : "", ns * 1e-6,
             g_mode ? "" : (std::string(", ") + std::to_string(starts) + " server starts").c_str(), (unsigned long long)fwd, (unsigned long long)inv,
             (unsigned long long)fm, (unsigned long long)im, (unsigned long long)w, w ? (double)wc / w : 0.0, (unsigned long long)sk,
             g_dead.load() ? "; THE DEVICE FAILED during the run, the rest was computed on the host" : "");
@@ -183,53 +195,69 @@ void device_failed(const char* what)
 
 void shutdown()
 {
-    // runs at exit before the bindings' device-time report (registered later, so it runs earlier): closing the service hands its device time to the ledger
+    // runs at exit before the bindings' device-time report (registered later, so it runs earlier): closing the services hands their device time to the ledger
     if (getenv("X265HIP_VERBOSE")) report();
     std::lock_guard<std::mutex> g(g_lock);
-    if (g_cs) { x265hip_cuserve* cs = g_cs; g_cs = NULL; g_dead = true; x265hip_cuserve_close(cs); }
+    g_dead = true;
+    const int n = g_nsvc.exchange(0);
+    for (int k = 0; k < n; k++)
+        if (g_svc[k].cs) { x265hip_cuserve_close(g_svc[k].cs); g_svc[k].cs = NULL; }
 }
 
-// opens the service on first use
+// opens the services on first use
 bool service()
 {
-    if (g_cs) return true;
+    if (g_nsvc.load(std::memory_order_acquire)) return true;
     std::lock_guard<std::mutex> g(g_lock);
-    if (g_cs) return true;
+    if (g_nsvc.load()) return true;
     if (g_dead.load()) return false;
     if (x265hip_device_count() < 1) { g_dead = true; return false; }       // said by setupAssemblyPrimitives already
-    x265hip_cuserve* cs = NULL;
-    if (x265hip_cuserve_open(g_slots, g_mode, &cs)) { device_failed("x265hip_cuserve_open"); return false; }
-    for (int s = 0; s < g_slots; s++)
-        if (x265hip_cuserve_slot(cs, s, &g_mem[s].job, &g_mem[s].pixels, &g_mem[s].units, &g_mem[s].levels, &g_mem[s].resi))
+    const int places = x265hip_places_configured();
+    const int n = places > 16 ? 16 : places > 0 ? places : 1;
+    for (int k = 0; k < n; k++)
+    {
+        Service& sv = g_svc[k];
+        const int e = places ? x265hip_cuserve_open_at(k, g_slots, g_mode, &sv.cs) : x265hip_cuserve_open(g_slots, g_mode, &sv.cs);
+        bool ok = !e;
+        for (int s = 0; ok && s < g_slots; s++)
+            ok = !x265hip_cuserve_slot(sv.cs, s, &sv.mem[s].job, &sv.mem[s].pixels, &sv.mem[s].units, &sv.mem[s].levels, &sv.mem[s].resi);
+        if (!ok)
         {
-            x265hip_cuserve_close(cs);
-            device_failed("x265hip_cuserve_slot");
+            for (int j = 0; j <= k; j++)
+                if (g_svc[j].cs) { x265hip_cuserve_close(g_svc[j].cs); g_svc[j].cs = NULL; }
+            device_failed("x265hip_cuserve_open");
             return false;
         }
+    }
     atexit(shutdown);
-    __atomic_store_n(&g_cs, cs, __ATOMIC_RELEASE);
+    g_nsvc.store(n, std::memory_order_release);
     return true;
 }
 
-// a free slot for this thread's next job, or -1
-int take_slot()
+// a free slot for this thread's next job (at the service this thread is attached to: threads spread over the places), or -1
+int take_slot(Service** svc)
 {
     static std::atomic<int> next(0);
-    if (t_hint < 0) t_hint = next.fetch_add(1) % g_slots;
+    const int nsvc = g_nsvc.load(std::memory_order_relaxed);
+    if (nsvc < 1) return -1;
+    if (t_hint < 0) t_hint = next.fetch_add(1) % (g_slots * nsvc);
+    Service& sv = g_svc[(t_hint / g_slots) % nsvc];
+    const int h = t_hint % g_slots;
     for (int k = 0; k < g_slots; k++)
     {
-        const int s = (t_hint + k) % g_slots;
-        std::atomic<uint64_t>& w = g_slotBusy[s >> 6];
+        const int s = (h + k) % g_slots;
+        std::atomic<uint64_t>& w = sv.busy[s >> 6];
         const uint64_t bit = 1ull << (s & 63);
         if (!(w.load(std::memory_order_relaxed) & bit) && !(w.fetch_or(bit, std::memory_order_acquire) & bit))
         {
-            t_hint = s;
+            t_hint = (t_hint / g_slots) * g_slots + s;
+            *svc = &sv;
             return s;
         }
     }
     return -1;
 }
-inline void give_slot(int s) { g_slotBusy[s >> 6].fetch_and(~(1ull << (s & 63)), std::memory_order_release); }
+inline void give_slot(Service* sv, int s) { sv->busy[s >> 6].fetch_and(~(1ull << (s & 63)), std::memory_order_release); }
 
 template <typename T> inline void pack_rows(T*& dst, const T* src, uint32_t stride, int n)
 {
@@ -262,7 +290,7 @@ inline bool wait_word(Job& j, const uint32_t* ready)
         __builtin_ia32_pause();
         if ((++spins & 255) == 0)
         {
-            if (x265hip_cuserve_poke(g_cs, j.slot) || __builtin_ia32_rdtsc() - t0 > 3000000000ull)      // ~1 s: not a latency, a failure
+            if (x265hip_cuserve_poke(j.svc->cs, j.slot) || __builtin_ia32_rdtsc() - t0 > 3000000000ull)      // ~1 s: not a latency, a failure
             {
                 j.active = false;
                 device_failed("a job did not come back");
@@ -307,10 +335,11 @@ bool submit(Search* se, Mode& mode, const CUGeom& cuGeom, ShortYuv& resiYuv, con
     int sHi, sLo;
     if (x265hipi_cujob_levels(&hdr, &sHi, &sLo) < 1 || !service())
         return false;
-    const int slot = take_slot();
+    Service* svc = NULL;
+    const int slot = take_slot(&svc);
     if (slot < 0)
         return false;
-    const SlotMem& mem = g_mem[slot];
+    const SlotMem& mem = svc->mem[slot];
     for (int p = 0; p < 3; p++)
     {
         const QpParam& qp = q.m_qpParam[p];
@@ -328,16 +357,16 @@ bool submit(Search* se, Mode& mode, const CUGeom& cuGeom, ShortYuv& resiYuv, con
     pack_rows(dst, pred->m_buf[0], pred->m_size, N);
     if (codeChroma) { pack_rows(dst, pred->m_buf[1], pred->m_csize, N / 2); pack_rows(dst, pred->m_buf[2], pred->m_csize, N / 2); }
     Job& j = t_job;
-    if (x265hip_cuserve_submit(g_cs, slot, &j.seq))
+    if (x265hip_cuserve_submit(svc->cs, slot, &j.seq))
     {
-        give_slot(slot);
+        give_slot(svc, slot);
         device_failed("x265hip_cuserve_submit");
         return false;
     }
     j.quant = &q;
     for (int p = 0; p < 3; p++) { j.resi[p] = resiYuv.m_buf[p]; j.resiStride[p] = p ? resiYuv.m_csize : resiYuv.m_size; }
     if (!codeChroma) j.resi[1] = j.resi[2] = NULL;
-    j.log2CU = cuGeom.log2CUSize; j.sHi = sHi; j.sLo = sLo; j.slot = slot;
+    j.log2CU = cuGeom.log2CUSize; j.sHi = sHi; j.sLo = sLo; j.slot = slot; j.svc = svc;
     j.job = mem.job; j.units = mem.units; j.levels = mem.levels; j.resiOut = mem.resi;
     j.active = true;
     counters().jobs.fetch_add(1, std::memory_order_relaxed);
@@ -379,7 +408,7 @@ void Search::estimateResidualQT(Mode& mode, const CUGeom& cuGeom, uint32_t absPa
                 done = wait_word(j, &j.units[u].readyInv);
         }
         j.active = false;
-        if (done) give_slot(j.slot);
+        if (done) give_slot(j.svc, j.slot);
     }
 }
 
