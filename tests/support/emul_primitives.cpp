@@ -11,6 +11,7 @@
 namespace X265_NS {
 void x265hip_install_lookup_slots(EncoderPrimitives& p);        // x265_amd/host/x265_hip_refplanes.cpp
 void x265hip_install_psy_slots(EncoderPrimitives& p);           // x265_amd/host/x265_hip_srcplanes.cpp
+void x265hip_install_cuserve_slots(EncoderPrimitives& p);       // x265_amd/host/x265_hip_cuserve.cpp
 // the reference's C table for the bindings' "what the slot did before" (same function as in the product's x265_hip_primitives.cpp)
 const EncoderPrimitives& x265hip_c_table()
 {
@@ -28,7 +29,7 @@ const EncoderPrimitives& x265hip_c_table()
     return c;
 }
 void setupInstrinsicPrimitives(EncoderPrimitives&, int) {}
-void setupAssemblyPrimitives(EncoderPrimitives& p, int) { setupAliasPrimitives(p); x265hip_install_lookup_slots(p); x265hip_install_psy_slots(p); }
+void setupAssemblyPrimitives(EncoderPrimitives& p, int) { setupAliasPrimitives(p); x265hip_install_lookup_slots(p); x265hip_install_psy_slots(p); x265hip_install_cuserve_slots(p); }
 }
 extern "C" {
 int PFX(cpu_cpuid_test)(void) { return 0; }

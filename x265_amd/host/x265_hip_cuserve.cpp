@@ -16,8 +16,14 @@
 // against the reference's); anything the job does not cover (transform skip, transquant bypass, scaling lists, noise reduction, RDOQ,
 // 4:2:2 / 4:4:4) runs the reference's functions as before.
 //
+// Beside the transforms the job answers the distortions of the same blocks — cu[].sse_pp(source, prediction) and cu[].sse_pp(source, reconstruction)
+// of every unit (search.cpp:3269, :3295, and again at CU level :2872-2877) — and the time a thread spends waiting for the device goes into
+// psy_cost_pp(source, prediction) of the unit it waits for, which the tree asks for next (:3272) and encodeResAndCalcRdInterCU asks for again
+// (:2888): both are remembered for the scope of that one encodeResAndCalcRdInterCU call, keyed by the blocks' addresses in the mode's source /
+// prediction / reconstruction buffers, which nobody writes inside that scope.
+//
 // Seams (same link technique as the other seams, oracle/Makefile): Search::estimateResidualQT, Search::checkIntraInInter on search.o;
-// Quant::transformNxN, Quant::invtransformNxN on quant.o.
+// Quant::transformNxN, Quant::invtransformNxN on quant.o; Search::encodeResAndCalcRdInterCU (the scope) with the reference's body renamed in place.
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -52,6 +58,7 @@ extern void refEstimateResidualQT(Search* self, Mode& mode, const CUGeom& cuGeom
                                   const uint32_t depthRange[2], int32_t splitMore)
     asm("_ZN4x2659SearchRef18estimateResidualQTERNS_4ModeERKNS_6CUGeomEjjRNS_8ShortYuvERNS0_4CostEPKji");
 extern void refCheckIntraInInter(Search* self, Mode& intraMode, const CUGeom& cuGeom) asm("_ZN4x2659SearchRef17checkIntraInInterERNS_4ModeERKNS_6CUGeomE");
+extern void refEncodeResAndCalcRdInterCU(Search* self, Mode& interMode, const CUGeom& cuGeom) asm("_ZN4x2656Search29encodeResAndCalcRdInterCUBodyERNS_4ModeERKNS_6CUGeomE");
 #if X265_DEPTH == 8
 extern uint32_t refTransformNxN(Quant* self, const CUData& cu, const pixel* fenc, uint32_t fencStride, const int16_t* residual, uint32_t resiStride, coeff_t* coeff,
                                 uint32_t log2TrSize, TextType ttype, uint32_t absPartIdx, bool useTransformSkip)
@@ -94,7 +101,7 @@ std::atomic<bool> g_dead(false); // the device failed once: every later CU is co
 std::atomic<uint64_t> g_cycles[18][2], g_calls[18][2];
 __attribute__((tls_model("initial-exec"))) thread_local int t_inRqt = 0;
 
-struct alignas(64) Counters { std::atomic<uint64_t> jobs, fwd, inv, fwdMiss, invMiss, waitCycles, waits, skipped; };
+struct alignas(64) Counters { std::atomic<uint64_t> jobs, fwd, inv, fwdMiss, invMiss, waitCycles, waits, skipped, dist, psyHit, psyAhead; };
 Counters g_count[64];
 std::atomic<int> g_nextShard(0);
 __attribute__((tls_model("initial-exec"))) thread_local int t_shard = -1;
@@ -108,6 +115,14 @@ struct Job
     const int16_t* resi[3]; uint32_t resiStride[3];      // the CU's residual blocks (ShortYuv): what identifies a unit
     uint32_t log2CU;
     int sHi, sLo;
+    bool inTree;                         // inside the top-level estimateResidualQT: transform units are looked up (afterwards only the remembered values serve)
+    const Search* search;
+    const pixel* fenc[3]; uint32_t fencStride[3];        // the mode's source and prediction blocks (Yuv): what identifies an sse / psy question
+    const pixel* pred[3]; uint32_t predStride[3];
+    bool psyRd;
+    uint8_t invServed[X265HIP_CUJOB_MAX_UNITS];          // the unit's reconstructed residual came from the device (so its reconstruction is pred + that)
+    uint8_t energyKnown[X265HIP_CUJOB_MAX_UNITS];        // psy_cost_pp(source, prediction) of the unit has been computed on this thread
+    int32_t energy[X265HIP_CUJOB_MAX_UNITS];
     uint32_t seq;
     int slot;
     Service* svc;
@@ -117,8 +132,13 @@ struct Job
     const int16_t* resiOut;
 };
 __attribute__((tls_model("initial-exec"))) thread_local Job t_job;
+__attribute__((tls_model("initial-exec"))) thread_local int t_inEncodeRes = 0;
+EncoderPrimitives g_prev;            // the table as it was when the cuserve slots were installed (C functions + the psy lookups of x265_hip_srcplanes.cpp)
+bool g_slots_installed = false;
+int g_serveDist = 1;                 // X265HIP_CUSERVE_DIST=0: transforms only
 __attribute__((tls_model("initial-exec"))) thread_local int t_hint = -1;           // where this thread looks first
 
+void end_job();
 void report_time()
 {
     static const char* const what[4] = { "Quant::transformNxN", "Quant::invtransformNxN", "Search::estimateResidualQT (top level, whole tree)", "Search::checkIntraInInter" };
@@ -135,11 +155,11 @@ void report_time()
 
 void report()
 {
-    uint64_t jobs = 0, fwd = 0, inv = 0, fm = 0, im = 0, wc = 0, w = 0, sk = 0;
+    uint64_t jobs = 0, fwd = 0, inv = 0, fm = 0, im = 0, wc = 0, w = 0, sk = 0, di = 0, ph = 0, pa = 0;
     for (int i = 0; i < 64; i++)
     {
         jobs += g_count[i].jobs; fwd += g_count[i].fwd; inv += g_count[i].inv; fm += g_count[i].fwdMiss; im += g_count[i].invMiss;
-        wc += g_count[i].waitCycles; w += g_count[i].waits; sk += g_count[i].skipped;
+        wc += g_count[i].waitCycles; w += g_count[i].waits; sk += g_count[i].skipped; di += g_count[i].dist; ph += g_count[i].psyHit; pa += g_count[i].psyAhead;
     }
     uint64_t devJobs = 0, starts = 0, ns = 0;
     for (int k = 0; k < g_nsvc.load(); k++)
@@ -155,6 +175,8 @@ void report()
             g_mode ? "" : (std::string(", ") + std::to_string(starts) + " server starts").c_str(), (unsigned long long)fwd, (unsigned long long)inv,
             (unsigned long long)fm, (unsigned long long)im, (unsigned long long)w, w ? (double)wc / w : 0.0, (unsigned long long)sk,
             g_dead.load() ? "; THE DEVICE FAILED during the run, the rest was computed on the host" : "");
+    fprintf(stderr, "x265hip: cuserve: %llu sse_pp answers out of the jobs; %llu psy-cost (source, prediction) values computed while waiting for the device, %llu psy-cost calls "
+                    "answered from values remembered within their encodeResAndCalcRdInterCU\n", (unsigned long long)di, (unsigned long long)pa, (unsigned long long)ph);
 }
 
 bool decide()
@@ -173,6 +195,7 @@ bool decide()
         if (getenv("X265HIP_CUSERVE_MIN")) { const int v = atoi(getenv("X265HIP_CUSERVE_MIN")); g_minLog2 = v >= 64 ? 6 : v >= 32 ? 5 : 4; }
         if (getenv("X265HIP_CUSERVE_MODE")) g_mode = atoi(getenv("X265HIP_CUSERVE_MODE")) ? 1 : 0;
         if (getenv("X265HIP_CUSERVE_SLOTS")) g_slots = atoi(getenv("X265HIP_CUSERVE_SLOTS"));
+        if (getenv("X265HIP_CUSERVE_DIST")) g_serveDist = atoi(getenv("X265HIP_CUSERVE_DIST"));
         if (g_slots < 1) g_slots = 1;
         if (g_slots > 256) g_slots = 256;
         if ((env && !strcmp(env, "0")) || (all && !strcmp(all, "0")) || (table && !strcmp(table, "percall")) || g_time == 1)
@@ -364,8 +387,18 @@ bool submit(Search* se, Mode& mode, const CUGeom& cuGeom, ShortYuv& resiYuv, con
         return false;
     }
     j.quant = &q;
-    for (int p = 0; p < 3; p++) { j.resi[p] = resiYuv.m_buf[p]; j.resiStride[p] = p ? resiYuv.m_csize : resiYuv.m_size; }
-    if (!codeChroma) j.resi[1] = j.resi[2] = NULL;
+    j.search = se;
+    for (int p = 0; p < 3; p++)
+    {
+        j.resi[p] = resiYuv.m_buf[p]; j.resiStride[p] = p ? resiYuv.m_csize : resiYuv.m_size;
+        j.fenc[p] = fenc->m_buf[p]; j.fencStride[p] = p ? fenc->m_csize : fenc->m_size;
+        j.pred[p] = pred->m_buf[p]; j.predStride[p] = p ? pred->m_csize : pred->m_size;
+    }
+    if (!codeChroma) { j.resi[1] = j.resi[2] = NULL; j.fenc[1] = j.fenc[2] = j.pred[1] = j.pred[2] = NULL; }
+    j.psyRd = se->m_rdCost.m_psyRd != 0;
+    memset(j.invServed, 0, sizeof(j.invServed));
+    memset(j.energyKnown, 0, sizeof(j.energyKnown));
+    j.inTree = true;
     j.log2CU = cuGeom.log2CUSize; j.sHi = sHi; j.sLo = sLo; j.slot = slot; j.svc = svc;
     j.job = mem.job; j.units = mem.units; j.levels = mem.levels; j.resiOut = mem.resi;
     j.active = true;
@@ -373,7 +406,175 @@ bool submit(Search* se, Mode& mode, const CUGeom& cuGeom, ShortYuv& resiYuv, con
     return true;
 }
 
+// the job's scope ends: the slot goes back when the device has written everything it is going to write into it (an abandoned job: the device is
+// dead, the slot is kept)
+void end_job()
+{
+    Job& j = t_job;
+    bool done = j.active;
+    if (done)
+    {
+        const int last = x265hipi_cujob_unit_index(j.job, j.sHi, j.sLo, j.resi[1] ? 2 : 0, (1 << (j.log2CU - j.sLo)) - 1, (1 << (j.log2CU - j.sLo)) - 1);
+        for (int u = 0; u <= last && done; u++)
+            done = wait_word(j, &j.units[u].readyInv);
+    }
+    j.active = false;
+    j.inTree = false;
+    if (done) give_slot(j.svc, j.slot);
+}
+
+// ---- what the job knows about (source, other) blocks ---------------------------------------------------------------------------------------------
+// the unit (or, for a block of the CU's own size above the largest transform, the units) a block of the mode's source Yuv covers
+struct Where { int plane, x, y, n, s; };
+inline bool where_in_source(const Job& j, const pixel* src, intptr_t stride, int n, Where& w)
+{
+    for (int p = 0; p < 3; p++)
+    {
+        if (!j.fenc[p] || (uint32_t)stride != j.fencStride[p]) continue;
+        const ptrdiff_t d = src - j.fenc[p];
+        const int N = (1 << j.log2CU) >> (p ? 1 : 0);
+        if (d < 0 || d >= (ptrdiff_t)stride * N) continue;
+        const int y = (int)(d / stride), x = (int)(d % stride);
+        if (x >= N || (x & (n - 1)) || (y & (n - 1)) || x + n > N || y + n > N) return false;
+        int lg = 0;
+        while ((1 << lg) < n) lg++;
+        w.plane = p; w.x = x; w.y = y; w.n = n; w.s = p ? lg + 1 : lg;
+        return true;
+    }
+    return false;
+}
+
+// sse_pp(source block, other block) out of the job, or false
+inline bool job_sse(Job& j, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb, int n, uint64_t& out)
+{
+    Where w;
+    if (!where_in_source(j, a, sa, n, w)) return false;
+    const bool vsPred = (uint32_t)sb == j.predStride[w.plane] && b == j.pred[w.plane] + (size_t)w.y * sb + w.x;
+    if (vsPred)
+    {
+        // the unit itself, or — a block above the largest transform size (a 64x64 CU) — the sum over the units it is made of (sse is additive)
+        const int s = w.s > j.sHi ? j.sHi : w.s;
+        if (s < j.sLo) return false;
+        const int k = 1 << (w.s - s), sh = w.plane ? s - 1 : s;
+        uint64_t sum = 0;
+        for (int ty = 0; ty < k; ty++)
+            for (int tx = 0; tx < k; tx++)
+            {
+                const int u = x265hipi_cujob_unit_index(j.job, j.sHi, s, w.plane, (w.x >> sh) + tx, (w.y >> sh) + ty);
+                if (!wait_word(j, &j.units[u].ready)) return false;
+                sum += j.units[u].zeroDist;
+            }
+        out = sum;
+        return true;
+    }
+    if (w.s > j.sHi || w.s < j.sLo) return false;
+    // against the tree's reconstruction of the unit (search.cpp:3293-3295: add_ps(recon, pred, inverse-transformed residual), then sse_pp(source, recon))
+    const Yuv& rq = j.search->m_rqt[(w.plane ? w.s - 1 : w.s) - 2].reconQtYuv;
+    const uint32_t rs = w.plane ? rq.m_csize : rq.m_size;
+    if ((uint32_t)sb != rs || b != rq.m_buf[w.plane] + (size_t)w.y * rs + w.x) return false;
+    const int sh = w.plane ? w.s - 1 : w.s;
+    const int u = x265hipi_cujob_unit_index(j.job, j.sHi, w.s, w.plane, w.x >> sh, w.y >> sh);
+    if (!j.invServed[u] || !wait_word(j, &j.units[u].readyInv)) return false;
+    out = j.units[u].codedDist;
+    return true;
+}
+
+template <int CU, int N, bool CHROMA> sse_t sse_slot(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
+{
+    Job& j = t_job;
+    if (j.active)
+    {
+        uint64_t v;
+        if (job_sse(j, a, sa, b, sb, N, v))
+        {
+            if (g_verify)
+            {
+                const sse_t want = CHROMA ? g_prev.chroma[X265_CSP_I420].cu[CU].sse_pp(a, sa, b, sb) : g_prev.cu[CU].sse_pp(a, sa, b, sb);
+                if ((uint64_t)want != v) { fprintf(stderr, "x265hip: cuserve: VERIFY FAILED sse_pp %dx%d: %llu (job) vs %llu\n", N, N, (unsigned long long)v, (unsigned long long)want); abort(); }
+            }
+            counters().dist.fetch_add(1, std::memory_order_relaxed);
+            return (sse_t)v;
+        }
+    }
+    return CHROMA ? g_prev.chroma[X265_CSP_I420].cu[CU].sse_pp(a, sa, b, sb) : g_prev.cu[CU].sse_pp(a, sa, b, sb);
+}
+
+// psy_cost_pp(source block, prediction block): remembered per unit within the job's scope; a block above the largest transform size is the sum of its
+// units' values (psyCost_pp sums over 8x8 blocks, pixel.cpp:739-748)
+template <int CU, int N> int psy_slot(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
+{
+    Job& j = t_job;
+    Where w;
+    if (j.active && N >= 8 && where_in_source(j, a, sa, N, w) && (uint32_t)sb == j.predStride[w.plane] && b == j.pred[w.plane] + (size_t)w.y * sb + w.x)
+    {
+        const int s = w.s > j.sHi ? j.sHi : w.s;
+        if (s >= j.sLo)
+        {
+            const int k = 1 << (w.s - s), sh = w.plane ? s - 1 : s;
+            bool all = true;
+            int64_t sum = 0;
+            for (int ty = 0; ty < k && all; ty++)
+                for (int tx = 0; tx < k && all; tx++)
+                {
+                    const int u = x265hipi_cujob_unit_index(j.job, j.sHi, s, w.plane, (w.x >> sh) + tx, (w.y >> sh) + ty);
+                    all = j.energyKnown[u];
+                    sum += j.energy[u];
+                }
+            if (all)
+            {
+                if (g_verify && g_prev.cu[CU].psy_cost_pp(a, sa, b, sb) != (int)sum) { fprintf(stderr, "x265hip: cuserve: VERIFY FAILED psy_cost_pp %dx%d\n", N, N); abort(); }
+                counters().psyHit.fetch_add(1, std::memory_order_relaxed);
+                return (int)sum;
+            }
+            const int v = g_prev.cu[CU].psy_cost_pp(a, sa, b, sb);
+            if (k == 1)
+            {
+                const int u = x265hipi_cujob_unit_index(j.job, j.sHi, s, w.plane, w.x >> sh, w.y >> sh);
+                j.energy[u] = v; j.energyKnown[u] = 1;
+            }
+            return v;
+        }
+    }
+    return g_prev.cu[CU].psy_cost_pp(a, sa, b, sb);
+}
+
+// while this thread waits for unit u's forward half: the psy-cost of (source, prediction) of the same unit, which the tree asks for right after
+// (search.cpp:3272 luma, :3345 chroma) and encodeResAndCalcRdInterCU once more (:2888)
+inline void psy_ahead(Job& j, int u, int plane, int x, int y, int n)
+{
+    if (!j.psyRd || !g_slots_installed || j.energyKnown[u] || n < 8) return;
+    const pixel* a = j.fenc[plane] + (size_t)y * j.fencStride[plane] + x;
+    const pixel* b = j.pred[plane] + (size_t)y * j.predStride[plane] + x;
+    const int cu = n == 8 ? BLOCK_8x8 : n == 16 ? BLOCK_16x16 : BLOCK_32x32;
+    j.energy[u] = g_prev.cu[cu].psy_cost_pp(a, j.fencStride[plane], b, j.predStride[plane]);
+    j.energyKnown[u] = 1;
+    counters().psyAhead.fetch_add(1, std::memory_order_relaxed);
+}
+
 } // namespace
+
+// called by setupAssemblyPrimitives in the default table mode, after the psy lookups of x265_hip_srcplanes.cpp are in the table
+void x265hip_install_cuserve_slots(EncoderPrimitives& p)
+{
+    decide();
+    if (g_state <= 0 || !g_serveDist || g_slots_installed)
+        return;
+    g_prev = p;
+    g_verify = getenv("X265HIP_VERIFY") != NULL;
+    p.cu[BLOCK_8x8].sse_pp = sse_slot<BLOCK_8x8, 8, false>;
+    p.cu[BLOCK_16x16].sse_pp = sse_slot<BLOCK_16x16, 16, false>;
+    p.cu[BLOCK_32x32].sse_pp = sse_slot<BLOCK_32x32, 32, false>;
+    p.cu[BLOCK_64x64].sse_pp = sse_slot<BLOCK_64x64, 64, false>;
+    // 4:2:0: chroma[].cu[i] is the chroma block of luma CU i (primitives.h:80-90)
+    p.chroma[X265_CSP_I420].cu[BLOCK_16x16].sse_pp = sse_slot<BLOCK_16x16, 8, true>;
+    p.chroma[X265_CSP_I420].cu[BLOCK_32x32].sse_pp = sse_slot<BLOCK_32x32, 16, true>;
+    p.chroma[X265_CSP_I420].cu[BLOCK_64x64].sse_pp = sse_slot<BLOCK_64x64, 32, true>;
+    p.cu[BLOCK_8x8].psy_cost_pp = psy_slot<BLOCK_8x8, 8>;
+    p.cu[BLOCK_16x16].psy_cost_pp = psy_slot<BLOCK_16x16, 16>;
+    p.cu[BLOCK_32x32].psy_cost_pp = psy_slot<BLOCK_32x32, 32>;
+    p.cu[BLOCK_64x64].psy_cost_pp = psy_slot<BLOCK_64x64, 64>;
+    g_slots_installed = true;
+}
 
 void Search::estimateResidualQT(Mode& mode, const CUGeom& cuGeom, uint32_t absPartIdx, uint32_t tuDepth, ShortYuv& resiYuv, Cost& outCosts, const uint32_t depthRange[2],
                                 int32_t splitMore)
@@ -397,19 +598,21 @@ void Search::estimateResidualQT(Mode& mode, const CUGeom& cuGeom, uint32_t absPa
         refEstimateResidualQT(this, mode, cuGeom, absPartIdx, tuDepth, resiYuv, outCosts, depthRange, splitMore);
     if (submitted)
     {
-        // the slot goes back when the device has written everything it is going to write into it (an abandoned job: the device is dead, keep the slot)
-        Job& j = t_job;
-        bool done = j.active;
-        if (done)
-        {
-            int sHi = j.sHi;
-            const int last = x265hipi_cujob_unit_index(j.job, sHi, j.sLo, j.resi[1] ? 2 : 0, (1 << (j.log2CU - j.sLo)) - 1, (1 << (j.log2CU - j.sLo)) - 1);
-            for (int u = 0; u <= last && done; u++)
-                done = wait_word(j, &j.units[u].readyInv);
-        }
-        j.active = false;
-        if (done) give_slot(j.svc, j.slot);
+        t_job.inTree = false;
+        if (!t_inEncodeRes)
+            end_job();                 // not expected (estimateResidualQT has one caller), but then nothing is remembered beyond the tree
     }
+}
+
+// The scope of a job's remembered values: one call of encodeResAndCalcRdInterCU (reference search.cpp:2822-2975).  Inside it nobody writes the mode's
+// source or prediction block, nor — after the tree — the tree's reconstruction buffers.  The reference's body runs under its renamed symbol.
+void Search::encodeResAndCalcRdInterCU(Mode& interMode, const CUGeom& cuGeom)
+{
+    t_inEncodeRes++;
+    refEncodeResAndCalcRdInterCU(this, interMode, cuGeom);
+    t_inEncodeRes--;
+    if (t_job.active)
+        end_job();
 }
 
 void Search::checkIntraInInter(Mode& intraMode, const CUGeom& cuGeom)
@@ -427,13 +630,19 @@ uint32_t Quant::transformNxN(const CUData& cu, const pixel* fenc, uint32_t fencS
                              TextType ttype, uint32_t absPartIdx, bool useTransformSkip)
 {
     Job& j = t_job;
-    if (j.active && j.quant == this && !useTransformSkip)
+    if (j.active && j.inTree && j.quant == this && !useTransformSkip)
     {
         int eo = 0;
         const int u = locate(j, residual, resiStride, log2TrSize, (int)ttype, &eo);
         if (u >= 0)
         {
             const uint64_t t0 = g_time ? __builtin_ia32_rdtsc() : 0;
+            if (__atomic_load_n(&j.units[u].ready, __ATOMIC_ACQUIRE) != j.seq)
+            {
+                // not there yet: do something the tree needs next anyway instead of spinning
+                const ptrdiff_t d = residual - j.resi[ttype];
+                psy_ahead(j, u, (int)ttype, (int)(d % resiStride), (int)(d / resiStride), 1 << log2TrSize);
+            }
             if (wait_word(j, &j.units[u].ready))
             {
                 const int n2 = 1 << (2 * log2TrSize);
@@ -474,7 +683,7 @@ void Quant::invtransformNxN(const CUData& cu, int16_t* residual, uint32_t resiSt
                             bool useTransformSkip, uint32_t numSig)
 {
     Job& j = t_job;
-    if (j.active && j.quant == this && !useTransformSkip && !bIntra)
+    if (j.active && j.inTree && j.quant == this && !useTransformSkip && !bIntra)
     {
         // which unit?  the one of this size and plane whose levels these are: equal levels have equal inverse transforms, so the comparison — not
         // any bookkeeping — is what makes the copy exact.  The tree asks for a unit's inverse right after its forward transform: look there first.
@@ -504,6 +713,7 @@ void Quant::invtransformNxN(const CUData& cu, int16_t* residual, uint32_t resiSt
                         abort();
                     }
                 }
+                j.invServed[first + t] = 1;
                 counters().inv.fetch_add(1, std::memory_order_relaxed);
                 if (g_time)
                 {

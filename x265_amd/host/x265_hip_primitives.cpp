@@ -567,6 +567,7 @@ static void saoCuStatsE3_hip(const int16_t* diff, const pixel* rec, intptr_t str
 
 void x265hip_install_lookup_slots(EncoderPrimitives& p);        // x265_hip_refplanes.cpp
 void x265hip_install_psy_slots(EncoderPrimitives& p);           // x265_hip_srcplanes.cpp
+void x265hip_install_cuserve_slots(EncoderPrimitives& p);       // x265_hip_cuserve.cpp
 
 static void report_calls()
 {
@@ -659,6 +660,7 @@ void setupAssemblyPrimitives(EncoderPrimitives& p, int /* cpuMask: CPU ISA bits,
         }
         x265hip_install_lookup_slots(p);            // x265_hip_refplanes.cpp: luma sub-pel filters served from GPU-built planes
         x265hip_install_psy_slots(p);               // x265_hip_srcplanes.cpp: the source half of psy_cost_pp from GPU-built energy planes
+        x265hip_install_cuserve_slots(p);           // x265_hip_cuserve.cpp: sse_pp / psy_cost_pp answers out of the CU residual quad-tree jobs
         return;
     }
     if (x265hip_device_count() < 1 || x265hip_init(0))
