@@ -160,7 +160,7 @@ int orc_cujob_run_##SFX(const x265hip_cujob* j, const P* pixels, x265hip_cujob_u
                         u->codedDist = u->zeroDist; \
                         memset(resi + eo, 0, sizeof(int16_t) * n * n); \
                     } \
-                    u->reserved = 0; \
+                    u->fwdTicks = 0; \
                     __atomic_store_n(&u->readyInv, seq, __ATOMIC_RELEASE); \
                     __atomic_store_n(&u->ready, seq, __ATOMIC_RELEASE); \
                     done++; \

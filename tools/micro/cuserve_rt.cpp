@@ -23,7 +23,7 @@ int main(int argc, char** argv)
     for (int log2cu = 5; log2cu <= 6; log2cu++)
         for (int T : { 1, 4, 16 })
         {
-            std::vector<std::vector<double>> lat(T), first(T);
+            std::vector<std::vector<double>> lat(T), first(T), dev(T);
             std::atomic<int> go(0);
             auto body = [&](int t)
             {
@@ -70,7 +70,7 @@ int main(int argc, char** argv)
                     }
                     volatile int16_t sink = levels[0] + resi[0]; (void)sink;
                     const double t1 = now_us();
-                    if (i >= 100) { lat[t].push_back(t1 - t0); first[t].push_back(tFirst); }
+                    if (i >= 100) { lat[t].push_back(t1 - t0); first[t].push_back(tFirst); dev[t].push_back(units[0].fwdTicks * 0.01); }
                 }
             };
             std::vector<std::thread> th;
@@ -80,14 +80,16 @@ int main(int argc, char** argv)
             for (auto& x : th) x.join();
             const double wall = now_us() - w0;
             if (failed) { printf("FAILED (mode %d, CU %d, %d threads)\n", mode, 1 << log2cu, T); x265hip_cuserve_close(cs); return 1; }
-            std::vector<double> all, f;
+            std::vector<double> all, f, dv;
             for (auto& v : lat) all.insert(all.end(), v.begin(), v.end());
             for (auto& v : first) f.insert(f.end(), v.begin(), v.end());
+            for (auto& v : dev) dv.insert(dv.end(), v.begin(), v.end());
+            std::sort(dv.begin(), dv.end());
             std::sort(all.begin(), all.end()); std::sort(f.begin(), f.end());
             double sum = 0; for (double x : all) sum += x;
-            printf("%s, %dx%d CU (4:2:0, 8 bit, 32x32 transforms), %2d thread%s: whole job mean %6.1f us, median %6.1f, p99 %6.1f; first luma unit forward half median %6.1f us; %.0f jobs/s in total\n",
+            printf("%s, %dx%d CU (4:2:0, 8 bit, 32x32 transforms), %2d thread%s: whole job mean %6.1f us, median %6.1f, p99 %6.1f; first luma unit forward half median %6.1f us (%4.1f us of it on the device, doorbell seen -> ready word issued); %.0f jobs/s in total\n",
                    mode ? "one launch per job" : "resident server   ", 1 << log2cu, 1 << log2cu, T, T > 1 ? "s" : " ", sum / all.size(), all[all.size() / 2],
-                   all[(size_t)(all.size() * 0.99)], f[f.size() / 2], (double)T * (iters + 100) / (wall * 1e-6));
+                   all[(size_t)(all.size() * 0.99)], f[f.size() / 2], dv[dv.size() / 2], (double)T * (iters + 100) / (wall * 1e-6));
             fflush(stdout);
         }
     uint64_t jobs = 0, starts = 0, ns = 0;

@@ -139,7 +139,7 @@ __device__ __forceinline__ PlaneParams plane_params(const x265hip_cujob& j, int 
 //   src / prd: the plane's source and prediction in LDS, `pw` elements per row; the plane has (pw / N)^2 units
 template <typename P, int N>
 __device__ __forceinline__ void tile_chain(TileLds& t, const BOperand (*bop)[64], const P* src, const P* prd, int pw, int u0, int count, const PlaneParams qp,
-                                           bool signHide, x265hip_cujob_unit* units, int unitBase, int16_t* levels, int16_t* resi, int elemBase, uint32_t seq)
+                                           bool signHide, x265hip_cujob_unit* units, int unitBase, int16_t* levels, int16_t* resi, int elemBase, uint32_t seq, uint64_t t0)
 {
     constexpr int G = (32 / N) * (32 / N);
     constexpr int LPT = N * N / 16;              // lanes per unit: 16 coefficients each in the quantiser, one 4x4 group each in the sign hiding
@@ -317,9 +317,13 @@ __device__ __forceinline__ void tile_chain(TileLds& t, const BOperand (*bop)[64]
         un->numSig = (uint32_t)numSig;
         un->zeroDist = zero;
     }
-    __threadfence_system();                                                  // the unit's data before its ready word
+    // the unit's data before its ready word: the release store waits for every store this wave has issued (s_waitcnt vmcnt(0) is per wave) — no
+    // separate __threadfence_system(), whose L2 invalidate is of no use here (the slot is uncached host memory) and costs the other kernels their lines
     if (writer)
+    {
+        un->fwdTicks = (uint32_t)(wall_clock64() - t0);                      // 100 MHz ticks from the job's start to this unit's forward half
         __hip_atomic_store(&un->ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     // ---- inverse transform: a -> b -> a
     mfma_pass<N, true>(t.a, t.b, lane, bI, corrI, qp.s1i);
@@ -345,10 +349,10 @@ __device__ __forceinline__ void tile_chain(TileLds& t, const BOperand (*bop)[64]
     }
     coded = group_sum64(coded, LPT);
     if (writer)
+    {
         un->codedDist = coded;
-    __threadfence_system();
-    if (writer)
         __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __builtin_amdgcn_s_waitcnt(0xc07f);
 }
 
@@ -366,7 +370,7 @@ __device__ __forceinline__ void build_operands(JobLds& L)
 }
 
 template <typename P>
-__device__ __forceinline__ void run_tiles(Slot* s, JobLds& L, uint32_t seq)
+__device__ __forceinline__ void run_tiles(Slot* s, JobLds& L, uint32_t seq, uint64_t t0)
 {
     const int wv = threadIdx.x >> 6;
     const x265hip_cujob& j = L.job;
@@ -397,9 +401,9 @@ __device__ __forceinline__ void run_tiles(Slot* s, JobLds& L, uint32_t seq)
             {
                 if ((tile & 3) != wv) continue;
                 const int u0 = k * G, count = nUnits - u0 < G ? nUnits - u0 : G;
-                if (log2n == 5) tile_chain<P, 32>(L.tile[wv], L.bop[2], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq);
-                else if (log2n == 4) tile_chain<P, 16>(L.tile[wv], L.bop[1], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq);
-                else tile_chain<P, 8>(L.tile[wv], L.bop[0], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq);
+                if (log2n == 5) tile_chain<P, 32>(L.tile[wv], L.bop[2], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0);
+                else if (log2n == 4) tile_chain<P, 16>(L.tile[wv], L.bop[1], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0);
+                else tile_chain<P, 8>(L.tile[wv], L.bop[0], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0);
             }
         }
     }
@@ -416,8 +420,8 @@ __device__ __forceinline__ void run_job(Slot* s, JobLds& L, uint32_t ticket, uin
     for (int i = tid; i < chunks; i += 256)
         out[i] = in[i];
     __syncthreads();
-    if (ticket & 8) run_tiles<uint16_t>(s, L, ticket);
-    else run_tiles<uint8_t>(s, L, ticket);
+    if (ticket & 8) run_tiles<uint16_t>(s, L, ticket, t0);
+    else run_tiles<uint8_t>(s, L, ticket, t0);
     __syncthreads();
     if (tid == 0)
         *busyTicks += wall_clock64() - t0;
@@ -441,15 +445,15 @@ __global__ __launch_bounds__(256) void cu_server_kernel(Slot* slots, HostCtl* ho
     uint32_t last = 0;
     if (threadIdx.x == 0)
     {
+        // "the server has had work" starts now for every workgroup, whichever gets on the chip first (the word still holds the previous server's time)
+        __hip_atomic_fetch_max(&ctl->lastWork, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = __hip_atomic_load(&s->doorbell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
         // a job rung while no server was there has not been done: its first unit is not ready
         if (last && last != 0xffffffffu && __hip_atomic_load(&s->units[0].ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != last)
             last = 0;
+        // serverState has ONE writer, workgroup 0 (two workgroups' stores to the same host word may arrive in either order)
         if (blockIdx.x == 0)
-        {
-            __hip_atomic_store(&ctl->lastWork, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&hostCtl->serverState, generation, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
     }
     for (;;)
     {
@@ -468,17 +472,22 @@ __global__ __launch_bounds__(256) void cu_server_kernel(Slot* slots, HostCtl* ho
                 }
                 if (__hip_atomic_load(&ctl->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { v = 0xffffffffu; break; }
                 if (v != last) break;
-                if ((++polls & 15) == 0 &&
-                    wall_clock64() - __hip_atomic_load(&ctl->lastWork, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > idleTicks)
+                if ((++polls & 15) == 0)
                 {
-                    __hip_atomic_store(&ctl->quit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    v = 0xffffffffu;
-                    break;
+                    // read the word first, the clock second: another workgroup may store a later time in between, never an earlier one
+                    const uint64_t lw = __hip_atomic_load(&ctl->lastWork, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint64_t now = wall_clock64();
+                    if (now > lw && now - lw > idleTicks)
+                    {
+                        __hip_atomic_store(&ctl->quit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v = 0xffffffffu;
+                        break;
+                    }
                 }
                 __builtin_amdgcn_s_sleep(2);
             }
             if (v != 0xffffffffu)
-                __hip_atomic_store(&ctl->lastWork, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_max(&ctl->lastWork, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             L.seq = v;
         }
         __syncthreads();
@@ -486,9 +495,19 @@ __global__ __launch_bounds__(256) void cu_server_kernel(Slot* slots, HostCtl* ho
         __syncthreads();
         if (v == 0xffffffffu)
         {
-            // the last workgroup out tells the host; a submitter that rang in between finds serverState == 0 while it waits and starts the next server
-            if (threadIdx.x == 0 && __hip_atomic_fetch_add(&ctl->left, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
-                __hip_atomic_store(&hostCtl->serverState, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // everybody leaves; workgroup 0 leaves last and tells the host (a submitter that rang in between finds serverState == 0 while it waits and
+            // starts the next server, which takes the pending job)
+            if (threadIdx.x == 0)
+            {
+                if (blockIdx.x != 0)
+                    __hip_atomic_fetch_add(&ctl->left, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                else
+                {
+                    while (__hip_atomic_load(&ctl->left, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x - 1)
+                        __builtin_amdgcn_s_sleep(2);
+                    __hip_atomic_store(&hostCtl->serverState, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
             return;
         }
         last = v;

@@ -33,6 +33,7 @@ struct x265hip_refpic
     hipStream_t st = nullptr;
     // progress (buffer rows: 0 = first row of the top margin)
     int uploaded = 0;                         // rows [0, uploaded) of the buffer are on the device   (worker only)
+    int ssDeferred = 0;                       // bands whose SAD-surface rows are waiting for company (sadsurf_rows_arrived; worker only)
     int phaseDone = 4;                        // phase rows [4, phaseDone) are in hPlanes             (worker only)
     std::atomic<int> rowsReady{ -(1 << 30) }; // published: phase rows of PICTURE rows [-(marginY - 4), rowsReady) are valid
     std::atomic<uint32_t> epoch{ 0 };         // bumped by reset(): queued work of an older picture is dropped

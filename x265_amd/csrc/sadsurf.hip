@@ -840,6 +840,25 @@ void sadsurf_rows_arrived(x265hip_refpic* rp)
         std::lock_guard<std::mutex> g(g_ssLock);
         list = rp->surfaces;
     }
+    // One workgroup per CTU on 256 CUs: a band of one CTU row of one or two surfaces fills a fraction of the chip for the same ~54 us as a full one.
+    // Rows therefore wait for company — until the pending CTUs reach X265HIP_SADSURF_BATCH (default 224), the picture is complete, or two bands
+    // have gone by (the searches of a frame start at least the reference-lag rows behind the band, so nobody is waiting for the newest rows yet;
+    // a search that does arrive early measures its candidates on the host, same values).
+    static const int batch = getenv("X265HIP_SADSURF_BATCH") ? atoi(getenv("X265HIP_SADSURF_BATCH")) : 224;
+    if (batch > 0)
+    {
+        const bool complete = rp->uploaded >= rp->marginY + rp->picH + rp->marginY;
+        int pending = 0;
+        for (x265hip_sadsurf* ss : list)
+            if (ss->ref == rp)
+                pending += (rows_possible(ss) - ss->rowsBuilt) * ss->lay.ctuCols;
+        if (!complete && pending < batch && rp->ssDeferred < 2)
+        {
+            if (pending) rp->ssDeferred++;
+            return;
+        }
+        rp->ssDeferred = 0;
+    }
     progress(rp, list);
 }
 
