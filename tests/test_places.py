@@ -113,7 +113,7 @@ def test_surface_built_from_a_replica_matches_restatement():
             assert np.array_equal(got[k][l][1], want[k][l][1]), ("tables", k, l)
     # one replica (for source 1), fed band by band: every uploaded row of the padded picture exactly once
     assert st1[0].value - st0[0].value == 1
-    assert st1[1].value - st0[1].value >= 2
+    assert st1[1].value - st0[1].value >= 1          # rows wait for company (X265HIP_SADSURF_BATCH): bands may be pushed together
     assert st1[2].value - st0[2].value == (h + 2 * ts.MY) * stride
 
 

@@ -78,6 +78,9 @@ int g_time = 0;                  // X265HIP_DEBUG_SADTIME=1: cycles inside the r
 std::atomic<uint64_t> g_cycles[4], g_timed[4];
 bool g_missHist = false;         // X265HIP_DEBUG_SADMISS=1: how far outside their window do the misses lie, by block size (report at exit)
 std::atomic<uint64_t> g_missBy[4][4];   // [level][0: within 8 of the window, 1: within 16, 2: within 32, 3: farther]
+bool g_subpelHit = false;        // X265HIP_DEBUG_SUBPELHIT=1: how many served searches end within +-3 quarter-pels of the surface's own best vector (what a
+                                 // table of sub-pel SATDs around that vector could serve at most), by block size (report at exit)
+std::atomic<uint64_t> g_spHit[4], g_spAll[4];
 bool g_verify = false;           // X265HIP_VERIFY=1: every looked-up SAD is recomputed with the C function and compared (debugging self-check)
 int g_range = 32;                // X265HIP_SADPLANES_RANGE: the exhaustive search that places the windows covers [-range, range)^2
 EncoderPrimitives g_c;
@@ -152,6 +155,10 @@ void report()
     fprintf(stderr, "x265hip: sadplanes: %llu integer-pel SADs of the motion search served from GPU-built SAD surfaces (%llu surfaces, %llu CTU rows in %llu launches, %.3f ms of device time), %llu of the same "
                     "searches outside their block's window and %llu searches without a surface computed on the host\n", (unsigned long long)h,
             (unsigned long long)attached, (unsigned long long)rows, (unsigned long long)launches, kernelNs * 1e-6, (unsigned long long)m, (unsigned long long)un);
+    if (g_subpelHit)
+        for (int l = 1; l < 4; l++)
+            fprintf(stderr, "x265hip: sadplanes: block size %d: %llu of %llu served searches end within 3 quarter-pels of the surface's own best vector (%.1f %%)\n", 8 << l,
+                    (unsigned long long)g_spHit[l].load(), (unsigned long long)g_spAll[l].load(), g_spAll[l] ? 100.0 * g_spHit[l].load() / g_spAll[l].load() : 0.0);
     if (g_missHist)
         for (int l = 0; l < 4; l++)
             fprintf(stderr, "x265hip: sadplanes: block size %d: misses within 8 / 16 / 32 vectors of the window and farther: %llu / %llu / %llu / %llu\n", 8 << l,
@@ -179,6 +186,7 @@ bool decide()
         g_time = getenv("X265HIP_DEBUG_SADTIME") ? atoi(getenv("X265HIP_DEBUG_SADTIME")) : 0;
         g_verify = getenv("X265HIP_VERIFY") != NULL;
         g_missHist = getenv("X265HIP_DEBUG_SADMISS") != NULL;
+        g_subpelHit = getenv("X265HIP_DEBUG_SUBPELHIT") != NULL;
         if (getenv("X265HIP_SADPLANES_LEVELS")) g_levels = atoi(getenv("X265HIP_SADPLANES_LEVELS")) & 15;
         if (getenv("X265HIP_SADPLANES_RANGE")) g_range = atoi(getenv("X265HIP_SADPLANES_RANGE"));
         if (g_range < 8) g_range = 8;
@@ -498,6 +506,12 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
     }
     sad = s1; sad_x3 = s3; sad_x4 = s4;
     c.fenc = NULL;
+    if (g_subpelHit && g_exp != 2)
+    {
+        const int dx = outQMv.x - 4 * (c.ox + WIN / 2), dy = outQMv.y - 4 * (c.oy + WIN / 2);
+        g_spAll[level].fetch_add(1, std::memory_order_relaxed);
+        if (dx >= -3 && dx <= 3 && dy >= -3 && dy <= 3) g_spHit[level].fetch_add(1, std::memory_order_relaxed);
+    }
     // counters: per thread, flushed to the shared ones now and then (an atomic per search would be felt)
     t_hit += c.hit; t_miss += c.miss;
     (void)&t_flushAtExit;            // constructed on this thread's first search, destroyed (and flushed) when the thread ends
