@@ -511,7 +511,7 @@ def parse_served(lines):
     out = {"clocks": {}}
     for l in lines:
         if "device time" in l:
-            for m in re.finditer(r"(lookahead searches|other lookahead kernels|sub-pel plane bands|SAD surfaces|source energy planes|CU residual quad-tree jobs) ([\d.]+) ms in (\d+) launch groups \((\d+) algorithmic bytes\)", l):
+            for m in re.finditer(r"(lookahead searches|other lookahead kernels|sub-pel plane bands|SAD surfaces|source energy planes|CU residual quad-tree jobs|sub-pel SATD tables) ([\d.]+) ms in (\d+) launch groups \((\d+) algorithmic bytes\)", l):
                 out["clocks"][m.group(1)] = {"ms": float(m.group(2)), "launch_groups": int(m.group(3)), "algorithmic_bytes": int(m.group(4))}
             m = re.search(r"total ([\d.]+) ms", l)
             if m:

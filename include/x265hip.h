@@ -74,7 +74,8 @@ int  x265hip_peer_stats(uint64_t* replicas, uint64_t* bands, uint64_t* bytes);  
 #define X265HIP_CLK_SADSURF    3   /* search-window kernel of the SAD surfaces                                                         */
 #define X265HIP_CLK_ENERGY     4   /* source energy planes                                                                             */
 #define X265HIP_CLK_CUSERVE    5   /* CU residual quad-tree jobs (x265hip_cuserve_*)                                                   */
-#define X265HIP_CLK_COUNT      6
+#define X265HIP_CLK_SUBPEL     6   /* sub-pel SATD tables of the SAD surfaces                                                          */
+#define X265HIP_CLK_COUNT      7
 /* algorithmicBytes: SURVEY.md §8d bytes of the work inside the spans where the module can state them itself — SAD surfaces: per block of a built CTU
  * the exhaustive search's unique footprint W H B + (W + R - 1)(H + R - 1) B + 4 R^2 (R = 2 searchRange); plane bands: rows x (padded width) x
  * (1 picture + 15 phase planes) x B; 0 for the other clocks (bench.py prices the lookahead searches per 8x8 block from its own count). */
@@ -728,7 +729,15 @@ typedef struct x265hip_sadsurf_level
      * origin == NULL: level not built */
     const int16_t* origin;
     const void*    table;
+    /* Sub-pel SATDs around the window's centre c = (ox + WIN / 2, oy + WIN / 2) (round 4; levels 1..3, requested with bit 4 of `levels`, built
+     * where the reference picture's sub-pel planes live): what MotionEstimate::subpelCompare (reference encoder/motion.cpp:1571-1600) measures with
+     * the satd comparison at the 7 x 7 quarter-pel vectors q = 4 c + (dx, dy), dx, dy in -3..3 — every position the sub-pel refinement of a
+     * search that ends its integer stage at c can visit:
+     *   entries (const uint32_t*)((const char*)subpel + r * ctuRowPitch) + k * X265HIP_SADSURF_SUBPEL, entry (dy + 3) * 7 + (dx + 3)
+     * NULL: not built */
+    const uint32_t* subpel;
 } x265hip_sadsurf_level;
+#define X265HIP_SADSURF_SUBPEL 49
 typedef struct x265hip_sadsurf_view
 {
     x265hip_sadsurf_level level[X265HIP_SADSURF_LEVELS];
@@ -741,7 +750,7 @@ typedef struct x265hip_sadsurf_view
  * final already are built at once, the others as they arrive; x265hip_refpic_reset / _destroy of `ref` ends it (no further rows are published;
  * the handle stays valid until it is released).  `src` must stay unchanged and alive until the release.  NULL on failure. */
 x265hip_sadsurf* x265hip_sadsurf_attach(x265hip_srcpic* src, x265hip_refpic* ref, int searchRange, int lambda20);          /* levels 1..3 */
-/* levels: bit l = level l is built; bits 1..3 must be set, bit 0 adds the 8 x 8 windows (2.5 times the table bytes: on the 1080p bench clip only a
+/* levels: bit l = level l is built; bits 1..3 must be set, bit 4 adds the sub-pel SATD tables of levels 1..3, bit 0 adds the 8 x 8 windows (2.5 times the table bytes: on the 1080p bench clip only a
  * third of the 8 x 8 searches stay inside their parent's window, so x265_amd/host leaves it off unless X265HIP_SADPLANES_LEVELS says otherwise) */
 x265hip_sadsurf* x265hip_sadsurf_attach_levels(x265hip_srcpic* src, x265hip_refpic* ref, int searchRange, int lambda20, int levels);
 const x265hip_sadsurf_view* x265hip_sadsurf_get_view(x265hip_sadsurf* ss);

@@ -4,6 +4,7 @@
 #include <stddef.h>
 #include <stdlib.h>
 #include "../include/x265hip.h"
+#include "x265_oracle.h"
 
 #define PIX uint8_t
 #define FN(x) x##_8

@@ -482,6 +482,11 @@ void orc_sadsurf_rows_8(const uint8_t* src, intptr_t srcStride, const uint8_t* r
 void orc_sadsurf_rows_16(const uint16_t* src, intptr_t srcStride, const uint16_t* ref, intptr_t refStride, int picW, int picH, int marginX, int marginY,
                          int S, int lambda20, int row0, int row1, int16_t* const origin[4], uint32_t* const table[4]);
 
+void orc_sadsurf_subpel_rows_8(const uint8_t* src, intptr_t srcStride, const uint8_t* ref, intptr_t refStride, int picW, int picH, int depth, int row0, int row1,
+                               int16_t* const origin[4], uint32_t* const subpel[4]);
+void orc_sadsurf_subpel_rows_16(const uint16_t* src, intptr_t srcStride, const uint16_t* ref, intptr_t refStride, int picW, int picH, int depth, int row0, int row1,
+                                int16_t* const origin[4], uint32_t* const subpel[4]);
+
 struct x265hip_srcpic { int depth, B, w, h; char* luma; int place; int refs; };     /* refs: the creator + the surfaces attached (as in the library) */
 static void srcpic_unref(x265hip_srcpic* sp) { if (__atomic_sub_fetch(&sp->refs, 1, __ATOMIC_ACQ_REL) == 0) { free(sp->luma); free(sp); } }
 
@@ -522,6 +527,8 @@ struct x265hip_sadsurf
     char* buf;                                   /* ctuRows chunks of view.ctuRowPitch bytes, the layout of x265hip_sadsurf_level */
     int16_t* origin[X265HIP_SADSURF_LEVELS];     /* the oracle's whole-picture arrays */
     uint32_t* wide[X265HIP_SADSURF_LEVELS];
+    uint32_t* subpel[X265HIP_SADSURF_LEVELS];    /* [blocks][49] when the sub-pel tables are built */
+    int64_t subpelOff[X265HIP_SADSURF_LEVELS];
 };
 static uint64_t g_ssAttached, g_ssRows;
 
@@ -556,6 +563,15 @@ static void sadsurf_progress(x265hip_sadsurf* ss)
         else
             orc_sadsurf_rows_16((const uint16_t*)ss->src->luma, ss->src->w, (const uint16_t*)refOrg, rp->stride, rp->picW, rp->picH, rp->marginX, rp->marginY,
                                 ss->S, ss->lambda20, r, r + 1, ss->origin, ss->wide);
+        if (ss->levels & 16)
+        {
+            if (rp->depth == 8)
+                orc_sadsurf_subpel_rows_8((const uint8_t*)ss->src->luma, ss->src->w, (const uint8_t*)refOrg, rp->stride, rp->picW, rp->picH, rp->depth, r, r + 1,
+                                          ss->origin, ss->subpel);
+            else
+                orc_sadsurf_subpel_rows_16((const uint16_t*)ss->src->luma, ss->src->w, (const uint16_t*)refOrg, rp->stride, rp->picW, rp->picH, rp->depth, r, r + 1,
+                                           ss->origin, ss->subpel);
+        }
         char* chunk = ss->buf + (size_t)r * ss->view.ctuRowPitch;
         for (int l = 0; l < X265HIP_SADSURF_LEVELS; l++)
         {
@@ -572,6 +588,8 @@ static void sadsurf_progress(x265hip_sadsurf* ss)
                     for (int e = 0; e < 256; e++)
                         if (v->entryBytes == 2) ((uint16_t*)(chunk + ss->tableOff[l]))[k * 256 + e] = (uint16_t)ss->wide[l][b * 256 + e];
                         else ((uint32_t*)(chunk + ss->tableOff[l]))[k * 256 + e] = ss->wide[l][b * 256 + e];
+                    if (ss->subpel[l])
+                        memcpy(chunk + ss->subpelOff[l] + k * X265HIP_SADSURF_SUBPEL * 4, ss->subpel[l] + b * X265HIP_SADSURF_SUBPEL, X265HIP_SADSURF_SUBPEL * 4);
                 }
             }
         }
@@ -610,10 +628,17 @@ x265hip_sadsurf* x265hip_sadsurf_attach_levels(x265hip_srcpic* src, x265hip_refp
 {
     if (fail_now("sadsurf_attach")) return NULL;
     if (!src || !ref || src->depth != ref->depth || src->w != ref->picW || src->h != ref->picH || searchRange < 8 || searchRange > 32 || (searchRange & 3) ||
-        lambda20 < 0 || lambda20 > (1 << 20) || (levels & ~15) || (levels & 14) != 14)
+        lambda20 < 0 || lambda20 > (1 << 20) || (levels & ~31) || (levels & 14) != 14)
     {
         snprintf(g_err, sizeof(g_err), "emul: sadsurf_attach: mismatched pictures or range %d", searchRange);
         return NULL;
+    }
+    /* the sub-pel tables: as the library, only where the mirror lives; and — this is the scalar restatement, 49 filtered comparisons per block — only for
+     * pictures the CPU tier's clips have (X265HIP_EMUL_SUBPEL_MAX_PIXELS, default 640 x 384); beyond that the level's `subpel` stays NULL */
+    {
+        const char* lim = getenv("X265HIP_EMUL_SUBPEL_MAX_PIXELS");
+        const long maxPix = lim ? atol(lim) : 640L * 384L;
+        if (src->place != ref->place || (long)src->w * src->h > maxPix) levels &= ~16;
     }
     x265hip_sadsurf* ss = (x265hip_sadsurf*)calloc(1, sizeof(*ss));
     ss->src = src; ss->ref = ref; ss->S = searchRange; ss->lambda20 = lambda20; ss->levels = levels;
@@ -632,6 +657,11 @@ x265hip_sadsurf* x265hip_sadsurf_attach_levels(x265hip_srcpic* src, x265hip_refp
         ss->wide[l] = (uint32_t*)calloc(nb ? nb : 1, (size_t)256 * 4);
         ss->originOff[l] = off; off += (int64_t)v->blocksPerCtuRow * v->blocksX * 4;
         ss->tableOff[l] = off; off += (int64_t)v->blocksPerCtuRow * v->blocksX * 256 * v->entryBytes;
+        if (l && (levels & 16))
+        {
+            ss->subpel[l] = (uint32_t*)calloc(nb ? nb : 1, (size_t)X265HIP_SADSURF_SUBPEL * 4);
+            ss->subpelOff[l] = off; off += (int64_t)v->blocksPerCtuRow * v->blocksX * X265HIP_SADSURF_SUBPEL * 4;
+        }
     }
     ss->view.ctuRowPitch = off;
     ss->buf = (char*)calloc((size_t)ss->ctuRows, (size_t)off);
@@ -640,6 +670,7 @@ x265hip_sadsurf* x265hip_sadsurf_attach_levels(x265hip_srcpic* src, x265hip_refp
         if (!(levels >> l & 1)) continue;
         ss->view.level[l].origin = (const int16_t*)(ss->buf + ss->originOff[l]);
         ss->view.level[l].table = ss->buf + ss->tableOff[l];
+        ss->view.level[l].subpel = ss->subpel[l] ? (const uint32_t*)(ss->buf + ss->subpelOff[l]) : NULL;
     }
     ss->view.ctuRowsReady = &ss->ctuRowsReady;
     pthread_mutex_lock(&g_ssLock);
@@ -662,7 +693,7 @@ void x265hip_sadsurf_release(x265hip_sadsurf* ss)
         if (*pp) *pp = ss->next;
     }
     pthread_mutex_unlock(&g_ssLock);
-    for (int l = 0; l < X265HIP_SADSURF_LEVELS; l++) { free(ss->origin[l]); free(ss->wide[l]); }
+    for (int l = 0; l < X265HIP_SADSURF_LEVELS; l++) { free(ss->origin[l]); free(ss->wide[l]); free(ss->subpel[l]); }
     free(ss->buf);
     srcpic_unref(ss->src);
     free(ss);

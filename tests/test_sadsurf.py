@@ -82,7 +82,15 @@ def _read_view(hp, L, ss, w, h):
             org[by] = np.frombuffer(o, np.int16).reshape(lv.blocksX, 2)
             t = (C.c_char * (lv.blocksX * WIN * WIN * lv.entryBytes)).from_address(lv.table + r * v.ctuRowPitch + k0 * WIN * WIN * lv.entryBytes)
             tab[by] = np.frombuffer(t, et).reshape(lv.blocksX, WIN * WIN)
-        out[l] = (org, tab)
+        sub = None
+        if lv.subpel:
+            sub = np.zeros((lv.blocksY, lv.blocksX, 49), np.uint32)
+            for by in range(lv.blocksY):
+                r, j = divmod(by, lv.blocksPerCtuRow)
+                k0 = j * lv.blocksX
+                t = (C.c_uint32 * (lv.blocksX * 49)).from_address(lv.subpel + r * v.ctuRowPitch + k0 * 49 * 4)
+                sub[by] = np.frombuffer(t, np.uint32).reshape(lv.blocksX, 49)
+        out[l] = (org, tab, sub)
     return out
 
 
@@ -133,7 +141,7 @@ def test_restatement_entries_are_the_reference_sad_and_windows_are_legal(depth):
     w, h, S = 200, 136, 16
     views, buf, stride, srcs = _run(hp, em, w, h, 5, S, 9 * 20, [64, 128, h], [-1], levels=15 if depth == 8 else 14, depth=depth)
     rng = np.random.default_rng(1)
-    for l, (org, tab) in views[0].items():
+    for l, (org, tab, _) in views[0].items():
         n = 8 << l
         for by in range(org.shape[0]):
             for bx in range(org.shape[1]):
@@ -188,3 +196,68 @@ def test_device_surfaces_match_restatement(case):
         for l in got[k]:
             assert np.array_equal(got[k][l][0], want[k][l][0]), ("origins", k, l)
             assert np.array_equal(got[k][l][1], want[k][l][1]), ("tables", k, l)
+
+
+# ---- sub-pel SATD tables (round 4) ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_subpel_entries_are_the_reference_filters_and_satd(depth):
+    """The restatement's sub-pel entries (oracle/x265_oracle_sadsurf.inc orc_sadsurf_subpel_rows, through the emulated ABI) against what
+    MotionEstimate::subpelCompare (reference encoder/motion.cpp:1571-1600) does with the REAL primitives of oracle/_ref: the block itself (integer
+    vector) or luma_hpp / luma_vpp / luma_hvpp of it, then satd against the source block."""
+    import x265_amd.hipprim as hp
+    import backends
+    em = _emul(hp)
+    try:
+        o = backends.Ref(depth)
+    except Exception:
+        o = backends.Orc(depth)
+    w, h, S = 200, 136, 16
+    views, buf, stride, srcs = _run(hp, em, w, h, 9, S, 9 * 20, [64, 128, h], [-1], levels=30, depth=depth)
+    rng = np.random.default_rng(2)
+    checked = 0
+    for l in (1, 2, 3):
+        org, tab, sub = views[0][l]
+        assert sub is not None
+        n = 8 << l
+        for by in range(org.shape[0]):
+            for bx in range(org.shape[1]):
+                cx, cy = int(org[by, bx, 0]) + WIN // 2, int(org[by, bx, 1]) + WIN // 2
+                for v in rng.choice(49, 4, replace=False):
+                    qx, qy = 4 * cx + int(v) % 7 - 3, 4 * cy + int(v) // 7 - 3
+                    ry, rx = MY + by * n + (qy >> 2), MX + bx * n + (qx >> 2)
+                    fx, fy = qx & 3, qy & 3
+                    if not (fx | fy):
+                        blk = np.ascontiguousarray(buf[ry:ry + n, rx:rx + n])
+                    elif not fy:
+                        blk = o.interp("hpp", 0, n, n, buf, (ry, rx), fx)
+                    elif not fx:
+                        blk = o.interp("vpp", 0, n, n, buf, (ry, rx), fy)
+                    else:
+                        blk = o.interp("hvpp", 0, n, n, buf, (ry, rx), fx, fy)
+                    want = o.satd(n, n, srcs[0], (by * n, bx * n), blk, (0, 0))
+                    assert int(sub[by, bx, int(v)]) == want, (l, bx, by, int(v), int(sub[by, bx, int(v)]), want)
+                    checked += 1
+    assert checked > 400
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(8, 200, 136, 32, [64, 128, 136]), (8, 416, 240, 32, [240]), (10, 200, 136, 16, [64, 136]), (12, 136, 72, 16, [72])])
+def test_device_subpel_tables_match_restatement(case):
+    """x265_amd/csrc/sadsurf.hip subpel_satd_kernel against the restatement, every entry of every block of levels 1..3; the reference picture in bands and
+    whole; two source pictures, one attached late."""
+    import x265_amd.hipprim as hp
+    depth, w, h, S, bands = case
+    L = hp.lib()
+    hp.check(L.x265hip_init(0))
+    em = _emul(hp)
+    got, *_ = _run(hp, L, w, h, 23, S, 200, bands, [-1, len(bands) - 1 if len(bands) > 1 else -1], levels=30, depth=depth)
+    want, *_ = _run(hp, em, w, h, 23, S, 200, bands, [-1, len(bands) - 1 if len(bands) > 1 else -1], levels=30, depth=depth)
+    n = 0
+    for k in range(2):
+        for l in (1, 2, 3):
+            assert np.array_equal(got[k][l][0], want[k][l][0]) and np.array_equal(got[k][l][1], want[k][l][1]), ("windows", k, l)
+            assert got[k][l][2] is not None and want[k][l][2] is not None
+            assert np.array_equal(got[k][l][2], want[k][l][2]), ("sub-pel", k, l, np.argwhere(got[k][l][2] != want[k][l][2])[:4])
+            n += got[k][l][2].size
+    assert n > 1000

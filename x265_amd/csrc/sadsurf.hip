@@ -21,6 +21,7 @@
 #include "common.h"
 #include "internal.h"
 #include "refpic.h"
+#include "tiles.h"
 #include <cstring>
 #include <map>
 #include <utility>
@@ -46,6 +47,7 @@ struct SurfLayout
 {
     int blocksX[4], blocksY[4], per[4], entryBytes[4];
     int64_t originOff[4], tableOff[4];   // byte offsets inside a CTU row's chunk
+    int64_t subpelOff[4];                 // sub-pel SATD tables (levels 1..3 when bit 4 of `levels` is set; 0 = not built)
     int64_t pitch;                        // bytes per CTU row
     int ctuCols, ctuRows;
 };
@@ -118,6 +120,11 @@ static void layout_for(int w, int h, int depth, int levels, SurfLayout& L)
         off = (off + 15) & ~(int64_t)15;
         L.tableOff[l] = off; off += (int64_t)L.per[l] * L.blocksX[l] * kWin * kWin * L.entryBytes[l];
         off = (off + 15) & ~(int64_t)15;
+        if (l && (levels & 16))
+        {
+            L.subpelOff[l] = off; off += (int64_t)L.per[l] * L.blocksX[l] * X265HIP_SADSURF_SUBPEL * 4;
+            off = (off + 15) & ~(int64_t)15;
+        }
     }
     L.pitch = (off + 255) & ~(int64_t)255;
 }
@@ -639,6 +646,68 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu16_kernel(SurfArgs a)
     ss_decide_emit<uint32_t>(a, jb, sSurf, sh, S, x0, y0, cx, cy);
 }
 
+
+// ---- sub-pel SATD tables (round 4) ---------------------------------------------------------------------------------------------------------------
+// What MotionEstimate::subpelCompare (reference encoder/motion.cpp:1571-1600) computes with the satd comparison — satd(source block, reference block
+// at quarter-pel vector q), the reference block being the picture itself (q integer) or luma_hpp / vpp / hvpp of it, i.e. the mirror's phase plane
+// 4 fy + fx — for the 7 x 7 vectors q = 4 c + (dx, dy) around the window's centre c = origin + WIN / 2 of every block of levels 1..3.  A job = one
+// (block, vector); a wave runs 64 / T jobs at once, T = lanes per job (one 4x4 tile each per step), as pixcmp_kernel<SATD> does (pixel.hip); the SATD of
+// a 16x16 / 32x32 / 64x64 block is the sum over its 4x4 tiles of (sum |H d H^T|) >> 1 (pixel.cpp:210-297: satd8<w, h> over satd_8x4).
+struct SubpelArgs
+{
+    const void* pic; const void* planes; int64_t stride, planeElems;        // reference: pixel (0, 0) of the picture / of plane 0; planes 1..15 follow
+    const void* src; int64_t srcPitch;                                      // source luma, bytes per row
+    char* out;                                                              // the surface's device chunks
+    int64_t pitch, originOff[4], subpelOff[4];
+    int blocksX[4], blocksY[4], per[4];
+    int row0, rows;
+    int jobs[4];                                                            // (block, vector) jobs of levels 1..3 in this launch: prefix sums
+};
+template <typename P>
+__global__ __launch_bounds__(256) void subpel_satd_kernel(SubpelArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int gwave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), wavesTotal = gridDim.x * (blockDim.x >> 6);
+    const P* pic = (const P*)a.pic;
+    const P* planes = (const P*)a.planes;
+    for (int l = 1; l < 4; l++)
+    {
+        const int N = 8 << l, tiles = (N >> 2) * (N >> 2), T = tiles >= 64 ? 64 : tiles, bpw = 64 / T, iters = tiles / T;
+        const int n = a.jobs[l] - a.jobs[l - 1], sub = lane & (T - 1);
+        const int rowBlocks = a.per[l] * a.blocksX[l];
+        for (int job0 = gwave * bpw; job0 < n; job0 += wavesTotal * bpw)
+        {
+            const int job = job0 + lane / T;
+            const bool ok = job < n;
+            const int jc = ok ? job : n - 1;
+            const int v = jc % X265HIP_SADSURF_SUBPEL, b = jc / X265HIP_SADSURF_SUBPEL;     // b: block index inside the launch's rows of this level
+            const int cr = a.row0 + b / rowBlocks, k = b % rowBlocks;                       // chunk (row of 64 lines), index inside the chunk
+            const int by = cr * a.per[l] + k / a.blocksX[l], bx = k % a.blocksX[l];
+            const bool inPic = by < a.blocksY[l];
+            char* chunk = a.out + (int64_t)cr * a.pitch;
+            const int16_t* org = (const int16_t*)(chunk + a.originOff[l]) + 2 * k;
+            const int cx = org[0] + kWin / 2, cy = org[1] + kWin / 2;
+            const int qx = 4 * cx + v % 7 - 3, qy = 4 * cy + v / 7 - 3;
+            const int phase = 4 * (qy & 3) + (qx & 3);
+            const P* ref = (phase ? planes + (int64_t)phase * a.planeElems : pic) + (int64_t)(by * N + (qy >> 2)) * a.stride + bx * N + (qx >> 2);
+            const P* srcB = (const P*)((const char*)a.src + (int64_t)(by * N) * a.srcPitch) + bx * N;
+            const int64_t srcStride = a.srcPitch / (int64_t)sizeof(P);
+            int acc = 0;
+            for (int it = 0; it < iters; it++)
+            {
+                const int t = sub + it * T, ty = (t / (N >> 2)) * 4, tx = (t % (N >> 2)) * 4;
+                int m[16];
+                tile_diff(srcB + ty * srcStride + tx, srcStride, ref + ty * a.stride + tx, a.stride, m);
+                hadamard4x4(m);
+                acc += abs_sum16(m) >> 1;
+            }
+            acc = group_sum(acc, T);
+            if (ok && inPic && sub == 0)
+                ((uint32_t*)(chunk + a.subpelOff[l]))[(int64_t)k * X265HIP_SADSURF_SUBPEL + v] = (uint32_t)acc;
+        }
+    }
+}
+
 static size_t surf16_lds_bytes(int S)
 {
     const int D = 2 * S, RWD = (64 + D) / 2 + 4;
@@ -791,6 +860,37 @@ static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& li
                 hipLaunchKernelGGL(sadsurf_ctu16_kernel, dim3(lay.ctuCols, rows), dim3(1024), surf16_lds_bytes(maxS), st, a);
             bool bad = hipGetLastError() != hipSuccess;
             span.end();
+            DevSpan span2(X265HIP_CLK_SUBPEL, st);
+            // the sub-pel SATD tables of the rows just built (same stream: the origins are there); surfaces at the mirror's own place only
+            for (int k = 0; k < a.nJobs && !bad && !rep; k++)
+            {
+                if (!(in[k]->levels & 16))
+                    continue;
+                SubpelArgs sa;
+                memset(&sa, 0, sizeof(sa));
+                sa.pic = dPic + ((size_t)rp->marginY * rp->stride + rp->marginX) * rp->B;
+                sa.planes = rp->dPlanes + ((size_t)rp->marginY * rp->stride + rp->marginX) * rp->B;
+                sa.stride = rp->stride; sa.planeElems = rp->planeElems;
+                sa.src = a.job[k].src; sa.srcPitch = a.job[k].srcPitch;
+                sa.out = a.job[k].out; sa.pitch = lay.pitch;
+                sa.row0 = a.job[k].row0; sa.rows = a.job[k].rows;
+                for (int l = 1; l < 4; l++)
+                {
+                    sa.originOff[l] = lay.originOff[l]; sa.subpelOff[l] = lay.subpelOff[l];
+                    sa.blocksX[l] = lay.blocksX[l]; sa.blocksY[l] = lay.blocksY[l]; sa.per[l] = lay.per[l];
+                    sa.jobs[l] = sa.jobs[l - 1] + sa.rows * lay.per[l] * lay.blocksX[l] * X265HIP_SADSURF_SUBPEL;
+                }
+                const int waves = (sa.jobs[1] + 3) / 4 + (sa.jobs[2] - sa.jobs[1]) + (sa.jobs[3] - sa.jobs[2]);
+                const int grid = waves / 4 + 1 < 4096 ? waves / 4 + 1 : 4096;
+                if (rp->depth == 8)
+                    hipLaunchKernelGGL(subpel_satd_kernel<uint8_t>, dim3(grid), dim3(256), 0, st, sa);
+                else
+                    hipLaunchKernelGGL(subpel_satd_kernel<uint16_t>, dim3(grid), dim3(256), 0, st, sa);
+                bad = hipGetLastError() != hipSuccess;
+                // satd W x H = 2 W H B per call
+                span2.bytes += (uint64_t)sa.rows * lay.ctuCols * 3 * 64 * 64 * X265HIP_SADSURF_SUBPEL * 2 * rp->B;
+            }
+            span2.end();
             for (int k = 0; k < a.nJobs; k++)
             {
                 // SURVEY.md §8d, "batched exhaustive search of one block over an R x R window counts the unique footprint", applied to what a workgroup
@@ -821,6 +921,7 @@ static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& li
                 return;
             }
             span.commit();
+            if (span2.bytes) span2.commit();
             g_statRows += rows;
             g_statLaunches++;
             for (int k = 0; k < a.nJobs; k++)
@@ -1013,11 +1114,13 @@ x265hip_sadsurf* x265hip_sadsurf_attach_levels(x265hip_srcpic* src, x265hip_refp
 {
     if (ensure_device()) return nullptr;
     if (!src || !ref || src->depth != ref->depth || src->w != ref->picW || src->h != ref->picH || searchRange < 8 || searchRange > (src->depth == 8 ? 32 : 16) || (searchRange & 3) ||
-        lambda20 < 0 || lambda20 > (1 << 20) || ref->marginX < searchRange + 8 || ref->marginY < searchRange || (levels & ~15) || (levels & 14) != 14 || ((levels & 1) && src->depth != 8))
+        lambda20 < 0 || lambda20 > (1 << 20) || ref->marginX < searchRange + 8 || ref->marginY < searchRange || (levels & ~31) || (levels & 14) != 14 || ((levels & 1) && src->depth != 8))
     {
         set_error(X265HIP_EINVAL, "x265hip_sadsurf_attach: pictures do not match, or range %d (8..32 for 8-bit pictures, 8..16 for 16-bit ones) / lambda %d / margins out of bounds", searchRange, lambda20);
         return nullptr;
     }
+    if (src->place != ref->place)
+        levels &= ~16;                            // the sub-pel planes live with the mirror: a surface built from a replica elsewhere has no sub-pel tables
     x265hip_sadsurf* ss = new x265hip_sadsurf;
     ss->src = src; ss->ref = ref; ss->S = searchRange; ss->lambda20 = lambda20; ss->levels = levels;
     layout_for(src->w, src->h, src->depth, levels, ss->lay);
@@ -1053,6 +1156,7 @@ x265hip_sadsurf* x265hip_sadsurf_attach_levels(x265hip_srcpic* src, x265hip_refp
         v.blocksX = ss->lay.blocksX[l]; v.blocksY = ss->lay.blocksY[l]; v.entryBytes = ss->lay.entryBytes[l]; v.blocksPerCtuRow = ss->lay.per[l];
         v.origin = (const int16_t*)(ss->hBuf + ss->lay.originOff[l]);
         v.table = ss->hBuf + ss->lay.tableOff[l];
+        v.subpel = ss->lay.subpelOff[l] ? (const uint32_t*)(ss->hBuf + ss->lay.subpelOff[l]) : nullptr;
     }
     ss->view.ctuRowPitch = ss->lay.pitch;
     ss->view.ctuRowsReady = reinterpret_cast<const int*>(&ss->ctuRowsReady);

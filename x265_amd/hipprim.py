@@ -248,7 +248,7 @@ class LaEstimate(C.Structure):
 
 class SadSurfLevel(C.Structure):
     """x265hip_sadsurf_level (include/x265hip.h)"""
-    _fields_ = [("blocksX", C.c_int32), ("blocksY", C.c_int32), ("entryBytes", C.c_int32), ("blocksPerCtuRow", C.c_int32), ("origin", vp), ("table", vp)]
+    _fields_ = [("blocksX", C.c_int32), ("blocksY", C.c_int32), ("entryBytes", C.c_int32), ("blocksPerCtuRow", C.c_int32), ("origin", vp), ("table", vp), ("subpel", vp)]
 
 
 class SadSurfView(C.Structure):

@@ -577,7 +577,7 @@ static void report_calls()
 // X265HIP_VERBOSE: the device-time ledger of the bound modules (include/x265hip.h, x265hip_device_time) — what the GPU was busy with, in total
 static void report_device_time()
 {
-    static const char* const names[X265HIP_CLK_COUNT] = { "lookahead searches", "other lookahead kernels", "sub-pel plane bands", "SAD surfaces", "source energy planes", "CU residual quad-tree jobs" };
+    static const char* const names[X265HIP_CLK_COUNT] = { "lookahead searches", "other lookahead kernels", "sub-pel plane bands", "SAD surfaces", "source energy planes", "CU residual quad-tree jobs", "sub-pel SATD tables" };
     uint64_t total = 0;
     char line[1024];
     int n = 0;

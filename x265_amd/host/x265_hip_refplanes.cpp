@@ -51,6 +51,9 @@ extern void refMrApplyWeight(MotionReference* self, uint32_t finishedRows, uint3
 extern void refMrDestruct(MotionReference* self) asm("_ZN4x26518MotionReferenceRefD2Ev");
 static_assert(sizeof("" "x265") == 5, "");
 
+typedef void (*x265hip_filter_body)(const pixel* src, intptr_t srcStride, pixel* dst, intptr_t dstStride, int fx, int fy);
+bool x265hip_sadplanes_subpel(const pixel* src, intptr_t srcStride, pixel* dst, intptr_t dstStride, int w, int h, int fx, int fy, x265hip_filter_body body);    // x265_hip_sadplanes.cpp
+
 namespace {
 
 struct Mirror
@@ -282,20 +285,38 @@ void verify(const char* what, const pixel* s, pixel* d, intptr_t ds, const pixel
             abort();
         }
 }
-template <int W, int H, int PART> void hpp_lookup(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int c)
+// the lookups proper: (cx, cy) = the fractional position; hpp uses cx, vpp cy
+template <int W, int H, int PART> void hpp_body(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int c, int)
 {
     if (!c || !serve<W, H>(s, ss, d, ds, c)) { g_c.pu[PART].luma_hpp(s, ss, d, ds, c); return; }
     if (g_verify) { pixel t[W * H]; g_c.pu[PART].luma_hpp(s, ss, t, W, c); verify<W, H>("hpp", s, d, ds, t, c, 0); }
 }
-template <int W, int H, int PART> void vpp_lookup(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int c)
+template <int W, int H, int PART> void vpp_body(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int, int c)
 {
     if (!c || !serve<W, H>(s, ss, d, ds, 4 * c)) { g_c.pu[PART].luma_vpp(s, ss, d, ds, c); return; }
     if (g_verify) { pixel t[W * H]; g_c.pu[PART].luma_vpp(s, ss, t, W, c); verify<W, H>("vpp", s, d, ds, t, 0, c); }
 }
-template <int W, int H, int PART> void hvpp_lookup(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int cx, int cy)
+template <int W, int H, int PART> void hvpp_body(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int cx, int cy)
 {
     if (!cx || !cy || !serve<W, H>(s, ss, d, ds, 4 * cy + cx)) { g_c.pu[PART].luma_hvpp(s, ss, d, ds, cx, cy); return; }
     if (g_verify) { pixel t[W * H]; g_c.pu[PART].luma_hvpp(s, ss, t, W, cx, cy); verify<W, H>("hvpp", s, d, ds, t, cx, cy); }
+}
+// the table slots: a square block of 16 and up may be the sub-pel candidate of a motion search whose SATD table holds the answer
+// (x265hip_sadplanes_subpel: the block is then not produced at all unless somebody turns out to need it — it gets the body to do that)
+template <int W, int H, int PART> void hpp_lookup(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int c)
+{
+    if (W == H && W >= 16 && x265hip_sadplanes_subpel(s, ss, d, ds, W, H, c, 0, hpp_body<W, H, PART>)) return;
+    hpp_body<W, H, PART>(s, ss, d, ds, c, 0);
+}
+template <int W, int H, int PART> void vpp_lookup(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int c)
+{
+    if (W == H && W >= 16 && x265hip_sadplanes_subpel(s, ss, d, ds, W, H, 0, c, vpp_body<W, H, PART>)) return;
+    vpp_body<W, H, PART>(s, ss, d, ds, 0, c);
+}
+template <int W, int H, int PART> void hvpp_lookup(const pixel* s, intptr_t ss, pixel* d, intptr_t ds, int cx, int cy)
+{
+    if (W == H && W >= 16 && x265hip_sadplanes_subpel(s, ss, d, ds, W, H, cx, cy, hvpp_body<W, H, PART>)) return;
+    hvpp_body<W, H, PART>(s, ss, d, ds, cx, cy);
 }
 
 } // namespace

@@ -126,6 +126,29 @@ struct Ctx
     int x, y, w, ox, oy;         // for X265HIP_VERIFY's message
 };
 __attribute__((tls_model("initial-exec"))) thread_local Ctx t_ctx;
+
+// the sub-pel SATD context of the motionEstimate call in progress on this thread (round 4): MotionEstimate::subpelCompare (motion.cpp:1571-1600)
+// measures a quarter-pel candidate as satd(fenc, luma_hpp / vpp / hvpp(fref + integer part)) — first a filter slot, then this object's satd.  While a
+// context is active, the filter lookups of x265_hip_refplanes.cpp ask x265hip_sadplanes_subpel() first: a candidate within +-3 quarter-pels of the
+// window's centre is in the block's table, so the filtered block is not even copied and the satd that follows returns the table's value.
+struct SubCtx
+{
+    const uint32_t* tab;         // the block's 49 entries; NULL: no context
+    const pixel* fenc;
+    const pixel* centre;         // reference position of the centre vector c
+    intptr_t stride;
+    int n;                       // block size
+    const pixel* dst;            // the buffer the last intercepted filter call was asked to fill (its satd comes next)
+    int val, lastK;
+    // what that filter call was, in case the comparison that follows is not the satd (a predictor measured with SAD, motion.cpp:778): then the block is
+    // produced after all
+    void (*body)(const pixel*, intptr_t, pixel*, intptr_t, int, int);
+    const pixel* src; intptr_t dstStride; int fx, fy;
+    uint32_t hit, miss;
+};
+__attribute__((tls_model("initial-exec"))) thread_local SubCtx t_sub;
+int g_subpel = 1;                // X265HIP_SADPLANES_SUBPEL=0: integer-pel lookups only
+std::atomic<uint64_t> g_subHit(0), g_subMiss(0);
 __attribute__((tls_model("initial-exec"))) thread_local uint64_t t_hit = 0, t_miss = 0, t_searches = 0;
 // what a thread has not reported yet goes to the shared counters when the thread ends (the pool's workers end with the encoder)
 struct FlushAtThreadExit
@@ -155,6 +178,8 @@ void report()
     fprintf(stderr, "x265hip: sadplanes: %llu integer-pel SADs of the motion search served from GPU-built SAD surfaces (%llu surfaces, %llu CTU rows in %llu launches, %.3f ms of device time), %llu of the same "
                     "searches outside their block's window and %llu searches without a surface computed on the host\n", (unsigned long long)h,
             (unsigned long long)attached, (unsigned long long)rows, (unsigned long long)launches, kernelNs * 1e-6, (unsigned long long)m, (unsigned long long)un);
+    fprintf(stderr, "x265hip: sadplanes: %llu sub-pel SATDs of the motion search (filter + satd) served from GPU-built tables around the windows' centres, %llu of the same "
+                    "searches elsewhere computed on the host\n", (unsigned long long)g_subHit.load(), (unsigned long long)g_subMiss.load());
     if (g_subpelHit)
         for (int l = 1; l < 4; l++)
             fprintf(stderr, "x265hip: sadplanes: block size %d: %llu of %llu served searches end within 3 quarter-pels of the surface's own best vector (%.1f %%)\n", 8 << l,
@@ -189,6 +214,7 @@ bool decide()
         g_subpelHit = getenv("X265HIP_DEBUG_SUBPELHIT") != NULL;
         if (getenv("X265HIP_SADPLANES_LEVELS")) g_levels = atoi(getenv("X265HIP_SADPLANES_LEVELS")) & 15;
         if (getenv("X265HIP_SADPLANES_RANGE")) g_range = atoi(getenv("X265HIP_SADPLANES_RANGE"));
+        if (getenv("X265HIP_SADPLANES_SUBPEL")) g_subpel = atoi(getenv("X265HIP_SADPLANES_SUBPEL"));
         if (g_range < 8) g_range = 8;
         if (g_range > 32) g_range = 32;
         g_range &= ~3;
@@ -252,7 +278,7 @@ const Pair* pair_of(const PicYuv* srcPic, uint32_t version, const PicYuv* recon,
         x265hip_srcpic* sp = x265hip_srcplanes_device(srcPic, version);
         if (!sp)
             return NULL;                     // the source picture's upload has not finished: the next search asks again
-        x265hip_sadsurf* ss = x265hip_sadsurf_attach_levels(sp, rp, g_range, lambda20, g_levels | 14);
+        x265hip_sadsurf* ss = x265hip_sadsurf_attach_levels(sp, rp, g_range, lambda20, g_levels | 14 | (g_subpel ? 16 : 0));
         if (!ss)
         {
             // no table for this pair, nor for later ones (out of memory, or the device is gone): every search measures its candidates with the C functions
@@ -306,6 +332,14 @@ template <int PART> void verify_entry(const Ctx& c, const pixel* fenc, const pix
 
 template <int PART, typename E> int sad_lookup(const pixel* fenc, intptr_t fs, const pixel* ref, intptr_t rs)
 {
+    if (t_sub.dst && ref == t_sub.dst)
+    {
+        // the filtered block a table-held candidate did not produce is wanted after all: a SAD comparison (motion.cpp:778, :805)
+        SubCtx& sc = t_sub;
+        sc.dst = NULL;
+        if (!g_verify) sc.body(sc.src, sc.stride, const_cast<pixel*>(ref), sc.dstStride, sc.fx, sc.fy);
+        return g_c.pu[PART].sad(fenc, fs, ref, rs);
+    }
     Ctx& c = t_ctx;
     if (fenc == c.fenc && rs == c.stride)
     {
@@ -394,6 +428,59 @@ template <int PART> void sad_x4_twice(const pixel* fenc, const pixel* r0, const 
     g_c.pu[PART].sad_x4(fenc, r0, r1, r2, r3, rs, res);
 }
 
+// entry of the quarter-pel vector (integer position p, fractions fx, fy) in the context's table, or -1
+inline int sub_locate(const SubCtx& c, const pixel* p, intptr_t stride, int fx, int fy)
+{
+    if (stride != c.stride) return -1;
+    const ptrdiff_t d = p - c.centre;
+    // |dx| <= 1 here for anything of interest: split d = dy * stride + dx with dx in (-stride / 2, stride / 2]
+    ptrdiff_t dy = (d + stride / 2) / stride;
+    if (d + stride / 2 < 0) dy = -((-(d + stride / 2) + stride - 1) / stride);
+    const ptrdiff_t dx = d - dy * stride;
+    const long qx = 4 * (long)dx + fx, qy = 4 * (long)dy + fy;
+    if (qx < -3 || qx > 3 || qy < -3 || qy > 3) return -1;
+    return (int)((qy + 3) * 7 + qx + 3);
+}
+
+template <int PART> int satd_lookup(const pixel* fenc, intptr_t fs, const pixel* ref, intptr_t rs)
+{
+    SubCtx& c = t_sub;
+    if (c.tab && fenc == c.fenc)
+    {
+        if (ref == c.dst)
+        {
+            // the block the filter lookup was asked for a moment ago (and did not copy)
+            c.dst = NULL;
+            c.hit++;
+            if (g_verify)
+            {
+                const int want = g_c.pu[PART].satd(fenc, fs, ref, rs);
+                if (want != c.val)
+                {
+                    fprintf(stderr, "x265hip: sadplanes: VERIFY FAILED sub-pel satd %dx%d: table %d, satd() %d (entry %d; the table:", c.n, c.n, c.val, want, c.lastK);
+                    for (int i = 0; i < 49; i++) fprintf(stderr, " %u", c.tab[i]);
+                    fprintf(stderr, ")\n");
+                    abort();
+                }
+            }
+            return c.val;
+        }
+        const int k = sub_locate(c, ref, rs, 0, 0);          // an integer candidate measured with satd (the search's best integer vector, motion.cpp:1514)
+        if (k >= 0)
+        {
+            c.hit++;
+            if (g_verify)
+            {
+                const int want = g_c.pu[PART].satd(fenc, fs, ref, rs);
+                if (want != (int)c.tab[k]) { fprintf(stderr, "x265hip: sadplanes: VERIFY FAILED integer satd %dx%d: table %u, satd() %d\n", c.n, c.n, c.tab[k], want); abort(); }
+            }
+            return (int)c.tab[k];
+        }
+        c.miss++;
+    }
+    return g_c.pu[PART].satd(fenc, fs, ref, rs);
+}
+
 template <int PART> inline void install(MotionEstimate* me, int entryBytes)
 {
     if (g_exp == 2) { me->sad = sad_twice<PART>; me->sad_x3 = sad_x3_twice<PART>; me->sad_x4 = sad_x4_twice<PART>; }
@@ -402,6 +489,27 @@ template <int PART> inline void install(MotionEstimate* me, int entryBytes)
 }
 
 } // namespace
+
+// x265_hip_refplanes.cpp's filter lookups, before they copy anything: is this the sub-pel candidate of a search whose table holds its satd?  true: the
+// value is remembered for the satd call that follows, `dst` is NOT filled (nobody else reads subpelCompare's buffer)
+bool x265hip_sadplanes_subpel(const pixel* src, intptr_t srcStride, pixel* dst, intptr_t dstStride, int w, int h, int fx, int fy,
+                              void (*body)(const pixel*, intptr_t, pixel*, intptr_t, int, int))
+{
+    SubCtx& c = t_sub;
+    if (!c.tab || w != c.n || h != c.n)
+        return false;
+    // whatever an earlier candidate left behind is void now (a predictor measured with SAD goes through the filter slot too, motion.cpp:770, and
+    // nobody consumes its value)
+    c.dst = NULL;
+    const int k = sub_locate(c, src, srcStride, fx, fy);
+    if (k < 0)
+        return false;
+    c.dst = dst;
+    c.val = (int)c.tab[k];
+    c.lastK = k;
+    c.body = body; c.src = src; c.dstStride = dstStride; c.fx = fx; c.fy = fy;
+    return !g_verify;                // X265HIP_VERIFY: the block is filtered as usual and the satd that follows compares
+}
 
 // x265_hip_srcplanes.cpp keeps a device copy of every source picture only when this returns true
 bool x265hip_sadplanes_wanted() { return enabled() && g_exp != 2; }
@@ -448,6 +556,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
     Ctx& c = t_ctx;
     const int level = u->w == 8 ? 0 : u->w == 16 ? 1 : u->w == 32 ? 2 : 3;
     int entryBytes = 0;
+    const uint32_t* subTab = NULL;
     if (g_exp != 2)
     {
         // 20 x lambda out of this search's own vector-cost table: m_cost[i] = lambda * (2 log2(i + 1) + 0.718) (bitcost.cpp:48-70), log2(1025) = 10.0
@@ -476,6 +585,8 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
         }
         entryBytes = lv->entryBytes;
         c.tab = (const char*)lv->table + (size_t)cr * pr->view->ctuRowPitch + k * WIN * WIN * entryBytes;
+        if (lv->subpel && level >= 1)
+            subTab = (const uint32_t*)((const char*)lv->subpel + (size_t)cr * pr->view->ctuRowPitch) + k * X265HIP_SADSURF_SUBPEL;
         c.stride = ref->lumaStride;
         c.winBase = ref->fpelPlane[0] + off + (intptr_t)oy * c.stride + ox;
         c.span = (size_t)(WIN - 1) * c.stride + WIN;
@@ -488,6 +599,21 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
         c.stride = ref->lumaStride;
     c.fenc = fencPUYuv.m_buf[0];
     c.hit = c.miss = 0;
+    SubCtx& sc = t_sub;
+    sc.tab = NULL;
+    const pixelcmp_t sSatd = satd;
+    if (g_exp != 2 && g_time != 2 && subTab)
+    {
+        sc.tab = subTab; sc.fenc = c.fenc; sc.stride = c.stride; sc.n = u->w;
+        sc.centre = c.winBase + (intptr_t)(WIN / 2) * c.stride + WIN / 2;
+        sc.dst = NULL; sc.hit = sc.miss = 0;
+        switch (level)
+        {
+        case 1: satd = satd_lookup<LUMA_16x16>; break;
+        case 2: satd = satd_lookup<LUMA_32x32>; break;
+        default: satd = satd_lookup<LUMA_64x64>; break;
+        }
+    }
     const pixelcmp_t s1 = sad; const pixelcmp_x3_t s3 = sad_x3; const pixelcmp_x4_t s4 = sad_x4;
     if (g_time != 2)
         switch (level)
@@ -505,6 +631,12 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
         g_timed[level].fetch_add(1, std::memory_order_relaxed);
     }
     sad = s1; sad_x3 = s3; sad_x4 = s4;
+    satd = sSatd;
+    if (sc.tab)
+    {
+        sc.tab = NULL;
+        if (sc.hit | sc.miss) { g_subHit.fetch_add(sc.hit, std::memory_order_relaxed); g_subMiss.fetch_add(sc.miss, std::memory_order_relaxed); }
+    }
     c.fenc = NULL;
     if (g_subpelHit && g_exp != 2)
     {
