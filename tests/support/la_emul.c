@@ -634,10 +634,10 @@ x265hip_sadsurf* x265hip_sadsurf_attach_levels(x265hip_srcpic* src, x265hip_refp
         return NULL;
     }
     /* the sub-pel tables: as the library, only where the mirror lives; and — this is the scalar restatement, 49 filtered comparisons per block — only for
-     * pictures the CPU tier's clips have (X265HIP_EMUL_SUBPEL_MAX_PIXELS, default 640 x 384); beyond that the level's `subpel` stays NULL */
+     * pictures the CPU tier's clips have (X265HIP_EMUL_SUBPEL_MAX_PIXELS, default 416 x 240); beyond that the level's `subpel` stays NULL */
     {
         const char* lim = getenv("X265HIP_EMUL_SUBPEL_MAX_PIXELS");
-        const long maxPix = lim ? atol(lim) : 640L * 384L;
+        const long maxPix = lim ? atol(lim) : 416L * 240L;
         if (src->place != ref->place || (long)src->w * src->h > maxPix) levels &= ~16;
     }
     x265hip_sadsurf* ss = (x265hip_sadsurf*)calloc(1, sizeof(*ss));

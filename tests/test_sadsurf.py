@@ -261,3 +261,21 @@ def test_device_subpel_tables_match_restatement(case):
             assert np.array_equal(got[k][l][2], want[k][l][2]), ("sub-pel", k, l, np.argwhere(got[k][l][2] != want[k][l][2])[:4])
             n += got[k][l][2].size
     assert n > 1000
+
+
+def test_bound_encoder_serves_subpel_candidates_from_the_tables(tmp_path):
+    """CPU tier: the motion-search seam with the emulated ABI's sub-pel tables (pictures up to 416 x 240 there): filter + satd pairs of subpelCompare answered
+    from the tables, every answer recomputed by the reference's functions (X265HIP_VERIFY), bitstream identical to the unmodified reference's."""
+    import re
+    import test_places as tp
+    ref, emul = tp._need("x265_8bit"), tp._need("x265_emul_8bit")
+    from x265_amd.synth import make_clip
+    yuv = str(tmp_path / "clip.yuv")
+    w, h, frames = 416, 240, 12
+    make_clip(yuv, w, h, frames, seed=41)
+    want, _ = tp._encode(ref, yuv, w, h, frames, str(tmp_path / "ref.hevc"), {})
+    for env in ({"X265HIP_VERIFY": "1"}, {}):
+        got, err = tp._encode(emul, yuv, w, h, frames, str(tmp_path / "emul.hevc"), env)
+        assert got == want, "bitstreams differ (%s)" % env
+        m = re.search(r"sadplanes: (\d+) sub-pel SATDs of the motion search", err)
+        assert m and int(m.group(1)) > 2000, err[-800:]

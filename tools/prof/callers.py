@@ -65,7 +65,7 @@ def name_of(pc):
     va = pc - a + off if pie[path] else pc
     j = bisect.bisect_right(addrs, va) - 1
     nm = names[j] if j >= 0 else "?"
-    return "%s[%s]" % (re.sub(r"\(.*", "", nm)[:60], path.rsplit("/", 1)[-1][:24])
+    return "%s[%s]" % (re.sub(r"\(.*", "", nm.replace("(anonymous namespace)", "anon"))[:60], path.rsplit("/", 1)[-1][:24])
 
 
 chains = collections.Counter()

@@ -678,12 +678,17 @@ __global__ __launch_bounds__(256) void subpel_satd_kernel(SubpelArgs a)
         for (int job0 = gwave * bpw; job0 < n; job0 += wavesTotal * bpw)
         {
             const int job = job0 + lane / T;
-            const bool ok = job < n;
-            const int jc = ok ? job : n - 1;
-            const int v = jc % X265HIP_SADSURF_SUBPEL, b = jc / X265HIP_SADSURF_SUBPEL;     // b: block index inside the launch's rows of this level
-            const int cr = a.row0 + b / rowBlocks, k = b % rowBlocks;                       // chunk (row of 64 lines), index inside the chunk
-            const int by = cr * a.per[l] + k / a.blocksX[l], bx = k % a.blocksX[l];
-            const bool inPic = by < a.blocksY[l];
+            int jc = job < n ? job : n - 1;
+            int v = jc % X265HIP_SADSURF_SUBPEL, b = jc / X265HIP_SADSURF_SUBPEL;           // b: block index inside the launch's rows of this level
+            int cr = a.row0 + b / rowBlocks, k = b % rowBlocks;                             // chunk (row of 64 lines), index inside the chunk
+            int by = cr * a.per[l] + k / a.blocksX[l];
+            // block rows below the picture (a last CTU row that is not 64 lines tall) exist in the chunk's layout but not in the pictures: such lanes
+            // (and the lanes past the last job) measure the picture's first block instead (its origin was written by this launch or an earlier one) and
+            // store nothing
+            const bool ok = job < n && by < a.blocksY[l];
+            if (!ok) { v = 0; cr = 0; k = 0; by = 0; }
+            const int bx = k % a.blocksX[l];
+            const bool inPic = ok;
             char* chunk = a.out + (int64_t)cr * a.pitch;
             const int16_t* org = (const int16_t*)(chunk + a.originOff[l]) + 2 * k;
             const int cx = org[0] + kWin / 2, cy = org[1] + kWin / 2;
