@@ -279,3 +279,21 @@ def test_bound_encoder_serves_subpel_candidates_from_the_tables(tmp_path):
         assert got == want, "bitstreams differ (%s)" % env
         m = re.search(r"sadplanes: (\d+) sub-pel SATDs of the motion search", err)
         assert m and int(m.group(1)) > 2000, err[-800:]
+
+
+def test_bound_encoder_serves_rectangular_pus_as_sums_of_squares(tmp_path):
+    """CPU tier: --rect --amp searches (presets slow / slower): a 32x16 ... 48x64 PU's integer-pel SADs as sums of its 16x16 / 32x32 squares' window entries,
+    each sum recomputed by the reference's sad (X265HIP_VERIFY), bitstream identical."""
+    import re
+    import test_places as tp
+    ref, emul = tp._need("x265_8bit"), tp._need("x265_emul_8bit")
+    from x265_amd.synth import make_clip
+    yuv = str(tmp_path / "clip.yuv")
+    w, h, frames = 416, 240, 6
+    make_clip(yuv, w, h, frames, seed=43)
+    extra = ["--rect", "--amp", "--me", "star", "--subme", "3", "--no-weightp"]
+    want, _ = tp._encode(ref, yuv, w, h, frames, str(tmp_path / "ref.hevc"), {}, extra)
+    got, err = tp._encode(emul, yuv, w, h, frames, str(tmp_path / "emul.hevc"), {"X265HIP_VERIFY": "1"}, extra)
+    assert got == want, "bitstreams differ"
+    m = re.search(r"rectangular / asymmetric PUs: (\d+) searches, (\d+) integer-pel SADs served", err)
+    assert m and int(m.group(1)) > 500 and int(m.group(2)) > 5000, err[-800:]

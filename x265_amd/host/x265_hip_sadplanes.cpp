@@ -93,7 +93,7 @@ __attribute__((tls_model("initial-exec"))) thread_local int t_shard = -1;
 inline int shard() { if (t_shard < 0) t_shard = g_nextShard.fetch_add(1) & 63; return t_shard; }
 
 // what this thread's MotionEstimate objects hold (setSourcePU)
-struct PuInfo { const MotionEstimate* me; const PicYuv* srcPic; uint32_t version; int x, y, w; };
+struct PuInfo { const MotionEstimate* me; const PicYuv* srcPic; uint32_t version; int x, y, w, h; };
 const int kPu = 4;
 __attribute__((tls_model("initial-exec"))) thread_local PuInfo t_pu[kPu];
 __attribute__((tls_model("initial-exec"))) thread_local int t_puNext = 0;
@@ -148,6 +148,8 @@ struct SubCtx
 };
 __attribute__((tls_model("initial-exec"))) thread_local SubCtx t_sub;
 int g_subpel = 1;                // X265HIP_SADPLANES_SUBPEL=0: integer-pel lookups only
+int g_rect = 1;                  // X265HIP_SADPLANES_RECT=0: square PUs only
+std::atomic<uint64_t> g_rectHit(0), g_rectMiss(0), g_rectSearches(0);
 std::atomic<uint64_t> g_subHit(0), g_subMiss(0);
 __attribute__((tls_model("initial-exec"))) thread_local uint64_t t_hit = 0, t_miss = 0, t_searches = 0;
 // what a thread has not reported yet goes to the shared counters when the thread ends (the pool's workers end with the encoder)
@@ -180,6 +182,9 @@ void report()
             (unsigned long long)attached, (unsigned long long)rows, (unsigned long long)launches, kernelNs * 1e-6, (unsigned long long)m, (unsigned long long)un);
     fprintf(stderr, "x265hip: sadplanes: %llu sub-pel SATDs of the motion search (filter + satd) served from GPU-built tables around the windows' centres, %llu of the same "
                     "searches elsewhere computed on the host\n", (unsigned long long)g_subHit.load(), (unsigned long long)g_subMiss.load());
+    if (g_rectSearches.load())
+        fprintf(stderr, "x265hip: sadplanes: rectangular / asymmetric PUs: %llu searches, %llu integer-pel SADs served as sums of their squares' entries, %llu with a square's "
+                        "window elsewhere computed on the host\n", (unsigned long long)g_rectSearches.load(), (unsigned long long)g_rectHit.load(), (unsigned long long)g_rectMiss.load());
     if (g_subpelHit)
         for (int l = 1; l < 4; l++)
             fprintf(stderr, "x265hip: sadplanes: block size %d: %llu of %llu served searches end within 3 quarter-pels of the surface's own best vector (%.1f %%)\n", 8 << l,
@@ -215,6 +220,7 @@ bool decide()
         if (getenv("X265HIP_SADPLANES_LEVELS")) g_levels = atoi(getenv("X265HIP_SADPLANES_LEVELS")) & 15;
         if (getenv("X265HIP_SADPLANES_RANGE")) g_range = atoi(getenv("X265HIP_SADPLANES_RANGE"));
         if (getenv("X265HIP_SADPLANES_SUBPEL")) g_subpel = atoi(getenv("X265HIP_SADPLANES_SUBPEL"));
+        if (getenv("X265HIP_SADPLANES_RECT")) g_rect = atoi(getenv("X265HIP_SADPLANES_RECT"));
         if (g_range < 8) g_range = 8;
         if (g_range > 32) g_range = 32;
         g_range &= ~3;
@@ -411,6 +417,76 @@ template <int PART, typename E> void sad_x4_lookup(const pixel* fenc, const pixe
     }
 }
 
+
+// ---- rectangular and asymmetric PUs (round 4; preset slow and slower: --rect, --amp) -------------------------------------------------------------
+// A W x H PU made of aligned 16x16 / 32x32 squares (32x16, 16x32, 64x32, 32x64, 64x16, 16x64, 64x48, 48x64): its SAD at a vector is the sum of its
+// squares' SADs at that vector (pixel.cpp:40-55 sums over the block's pixels), and every square has a window of its own in the surface — placed around
+// ITS best vector, so the lookup serves a candidate only when it lies in all of them (halves that move together: usually); otherwise the C function.
+struct RectPart { const void* tab; const pixel* winBase; int entryBytes; };
+struct RectCtx { const pixel* fenc; intptr_t stride; size_t span; int n; RectPart part[6]; uint32_t hit, miss; };
+__attribute__((tls_model("initial-exec"))) thread_local RectCtx t_rect;
+
+inline int rect_sum(const RectCtx& c, const pixel* p)
+{
+    int sum = 0;
+    for (int i = 0; i < c.n; i++)
+    {
+        const RectPart& q = c.part[i];
+        const size_t d = (size_t)(p - q.winBase);
+        if (d >= c.span) return -1;
+        const unsigned dy = (unsigned)d / (unsigned)c.stride, dx = (unsigned)d - dy * (unsigned)c.stride;
+        if (dx >= (unsigned)WIN) return -1;
+        const int k = (int)(dy * WIN + dx);
+        sum += q.entryBytes == 2 ? (int)((const uint16_t*)q.tab)[k] : (int)((const uint32_t*)q.tab)[k];
+    }
+    return sum;
+}
+template <int PART> inline int rect_one(RectCtx& c, const pixel* fenc, const pixel* ref, intptr_t rs)
+{
+    const int v = rect_sum(c, ref);
+    if (v < 0) { c.miss++; return g_c.pu[PART].sad(fenc, FENC_STRIDE, ref, rs); }
+    c.hit++;
+    if (g_verify)
+    {
+        const int want = g_c.pu[PART].sad(fenc, FENC_STRIDE, ref, rs);
+        if (want != v) { fprintf(stderr, "x265hip: sadplanes: VERIFY FAILED rectangular PU (%d squares): tables %d, sad() %d\n", c.n, v, want); abort(); }
+    }
+    return v;
+}
+template <int PART> int sad_rect(const pixel* fenc, intptr_t fs, const pixel* ref, intptr_t rs)
+{
+    RectCtx& c = t_rect;
+    if (fenc == c.fenc && rs == c.stride && fs == FENC_STRIDE) return rect_one<PART>(c, fenc, ref, rs);
+    return g_c.pu[PART].sad(fenc, fs, ref, rs);
+}
+template <int PART> void sad_x3_rect(const pixel* fenc, const pixel* r0, const pixel* r1, const pixel* r2, intptr_t rs, int32_t* res)
+{
+    RectCtx& c = t_rect;
+    if (fenc != c.fenc || rs != c.stride) { g_c.pu[PART].sad_x3(fenc, r0, r1, r2, rs, res); return; }
+    res[0] = rect_one<PART>(c, fenc, r0, rs); res[1] = rect_one<PART>(c, fenc, r1, rs); res[2] = rect_one<PART>(c, fenc, r2, rs);
+}
+template <int PART> void sad_x4_rect(const pixel* fenc, const pixel* r0, const pixel* r1, const pixel* r2, const pixel* r3, intptr_t rs, int32_t* res)
+{
+    RectCtx& c = t_rect;
+    if (fenc != c.fenc || rs != c.stride) { g_c.pu[PART].sad_x4(fenc, r0, r1, r2, r3, rs, res); return; }
+    res[0] = rect_one<PART>(c, fenc, r0, rs); res[1] = rect_one<PART>(c, fenc, r1, rs); res[2] = rect_one<PART>(c, fenc, r2, rs); res[3] = rect_one<PART>(c, fenc, r3, rs);
+}
+template <int PART> inline void install_rect(MotionEstimate* me) { me->sad = sad_rect<PART>; me->sad_x3 = sad_x3_rect<PART>; me->sad_x4 = sad_x4_rect<PART>; }
+inline bool install_rect_for(MotionEstimate* me, int w, int h)
+{
+    if (w == 32 && h == 16) install_rect<LUMA_32x16>(me); else if (w == 16 && h == 32) install_rect<LUMA_16x32>(me);
+    else if (w == 64 && h == 32) install_rect<LUMA_64x32>(me); else if (w == 32 && h == 64) install_rect<LUMA_32x64>(me);
+    else if (w == 64 && h == 16) install_rect<LUMA_64x16>(me); else if (w == 16 && h == 64) install_rect<LUMA_16x64>(me);
+    else if (w == 64 && h == 48) install_rect<LUMA_64x48>(me); else if (w == 48 && h == 64) install_rect<LUMA_48x64>(me);
+    else return false;
+    return true;
+}
+inline bool rect_shape(int w, int h)
+{
+    return (w == 32 && h == 16) || (w == 16 && h == 32) || (w == 64 && h == 32) || (w == 32 && h == 64) || (w == 64 && h == 16) || (w == 16 && h == 64) ||
+           (w == 64 && h == 48) || (w == 48 && h == 64);
+}
+
 // X265HIP_DEBUG_SADEXP=2: the measurement that preceded this file — every call a lookup could serve is computed twice
 template <int PART> int sad_twice(const pixel* fenc, intptr_t fs, const pixel* ref, intptr_t rs)
 {
@@ -528,11 +604,14 @@ void MotionEstimate::setSourcePU(const Yuv& srcFencYuv, int _ctuAddr, int cuPart
     u.me = this;
     u.srcPic = NULL;
     const PicYuv* pic; uint32_t version; int cx, cy;
-    if (pwidth != pheight || pwidth < 8 || !(g_levels >> (pwidth == 8 ? 0 : pwidth == 16 ? 1 : pwidth == 32 ? 2 : 3) & 1) ||
-        !x265hip_srcplanes_where(srcFencYuv, &pic, &version, &cx, &cy))
+    const bool rect = pwidth != pheight;
+    if (rect ? !(g_rect && rect_shape(pwidth, pheight)) : (pwidth < 8 || !(g_levels >> (pwidth == 8 ? 0 : pwidth == 16 ? 1 : pwidth == 32 ? 2 : 3) & 1)))
         return;
+    if (!x265hip_srcplanes_where(srcFencYuv, &pic, &version, &cx, &cy))
+        return;
+    // puPartIdx: the PU's offset inside the CU's source cache (the second PU of a 2NxN / Nx2N / AMP CU does not start at the CU's corner)
     const int x = cx + g_zscanToPelX[puPartIdx], y = cy + g_zscanToPelY[puPartIdx];
-    if ((x | y) & (pwidth - 1) || x + pwidth > (int)pic->m_picWidth || y + pheight > (int)pic->m_picHeight)
+    if ((x | y) & ((rect ? 16 : pwidth) - 1) || x + pwidth > (int)pic->m_picWidth || y + pheight > (int)pic->m_picHeight)
         return;
     // equal bytes have equal SADs: this comparison, not the bookkeeping, is what makes a lookup exact
     const pixel* p = pic->m_picOrg[0] + (intptr_t)y * pic->m_stride + x;
@@ -540,7 +619,7 @@ void MotionEstimate::setSourcePU(const Yuv& srcFencYuv, int _ctuAddr, int cuPart
     for (int r = 0; r < pheight; r++)
         if (memcmp(f + r * FENC_STRIDE, p + r * pic->m_stride, pwidth * sizeof(pixel)))
             return;
-    u.srcPic = pic; u.version = version; u.x = x; u.y = y; u.w = pwidth;
+    u.srcPic = pic; u.version = version; u.x = x; u.y = y; u.w = pwidth; u.h = pheight;
 }
 
 int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const MV& mvmax, const MV& qmvp, int numCandidates, const MV* mvc, int merange,
@@ -553,6 +632,64 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
         if (t_pu[i].me == this && t_pu[i].srcPic) { u = &t_pu[i]; break; }
     if (!u)
         return refMotionEstimate(this, ref, mvmin, mvmax, qmvp, numCandidates, mvc, merange, outQMv, maxSlices, srcReferencePlane);
+    if (u->w != u->h)
+    {
+        // ---- a rectangular / asymmetric PU: the sum of its aligned squares' entries (largest squares first: 32x32 where one fits on a 32-grid)
+        if (g_exp == 2 || g_time == 2)
+            return refMotionEstimate(this, ref, mvmin, mvmax, qmvp, numCandidates, mvc, merange, outQMv, maxSlices, srcReferencePlane);
+        const int lambda20 = (int)m_cost[1024] - (int)m_cost[0];
+        const Pair* pr = pair_of(u->srcPic, u->version, ref->reconPic, lambda20);
+        const intptr_t off = ref->reconPic->m_cuOffsetY[ctuAddr] + ref->reconPic->m_buOffsetY[absPartIdx];
+        if (!pr || off != (intptr_t)u->y * ref->lumaStride + u->x || ((u->y + u->h - 1) >> 6) >= __atomic_load_n(pr->view->ctuRowsReady, __ATOMIC_ACQUIRE))
+        {
+            g_count[shard()].unserved.fetch_add(1, std::memory_order_relaxed);
+            return refMotionEstimate(this, ref, mvmin, mvmax, qmvp, numCandidates, mvc, merange, outQMv, maxSlices, srcReferencePlane);
+        }
+        RectCtx& rc = t_rect;
+        rc.n = 0;
+        rc.stride = ref->lumaStride;
+        rc.span = (size_t)(WIN - 1) * rc.stride + WIN;
+        const pixel* puRef = ref->fpelPlane[0] + off;
+        bool ok = true;
+        uint8_t done[4][4] = {};                       // 16x16 cells of the PU
+        for (int cy16 = 0; cy16 < u->h / 16 && ok; cy16++)
+            for (int cx16 = 0; cx16 < u->w / 16 && ok; cx16++)
+            {
+                if (done[cy16][cx16]) continue;
+                const int bx = u->x + 16 * cx16, by = u->y + 16 * cy16;
+                int lvl = 1;
+                if (!((bx | by) & 31) && 16 * cx16 + 32 <= u->w && 16 * cy16 + 32 <= u->h)
+                {
+                    lvl = 2;
+                    done[cy16][cx16 + 1] = done[cy16 + 1][cx16] = done[cy16 + 1][cx16 + 1] = 1;
+                }
+                const x265hip_sadsurf_level* lv = &pr->view->level[lvl];
+                const int sh = 3 + lvl, qx = bx >> sh, qy = by >> sh, cr = by >> 6;
+                if (!lv->origin || qx >= lv->blocksX || qy >= lv->blocksY || rc.n >= 6) { ok = false; break; }
+                const size_t k = (size_t)(qy - (cr << (3 - lvl))) * lv->blocksX + qx;
+                const int16_t* org = (const int16_t*)((const char*)lv->origin + (size_t)cr * pr->view->ctuRowPitch) + 2 * k;
+                RectPart& q = rc.part[rc.n++];
+                q.entryBytes = lv->entryBytes;
+                q.tab = (const char*)lv->table + (size_t)cr * pr->view->ctuRowPitch + k * WIN * WIN * lv->entryBytes;
+                // reference position of this square's window entry (0, 0), shifted back to the PU's corner: candidate pointers are PU pointers
+                q.winBase = puRef + (intptr_t)org[1] * rc.stride + org[0];
+                // (the square sits at (16 cx16, 16 cy16) inside the PU both in the source and in the reference, so the offsets cancel)
+            }
+        if (!ok || !rc.n)
+            return refMotionEstimate(this, ref, mvmin, mvmax, qmvp, numCandidates, mvc, merange, outQMv, maxSlices, srcReferencePlane);
+        rc.fenc = fencPUYuv.m_buf[0];
+        rc.hit = rc.miss = 0;
+        const pixelcmp_t s1 = sad; const pixelcmp_x3_t s3 = sad_x3; const pixelcmp_x4_t s4 = sad_x4;
+        if (!install_rect_for(this, u->w, u->h))
+            return refMotionEstimate(this, ref, mvmin, mvmax, qmvp, numCandidates, mvc, merange, outQMv, maxSlices, srcReferencePlane);
+        const int r = refMotionEstimate(this, ref, mvmin, mvmax, qmvp, numCandidates, mvc, merange, outQMv, maxSlices, srcReferencePlane);
+        sad = s1; sad_x3 = s3; sad_x4 = s4;
+        rc.fenc = NULL;
+        g_rectSearches.fetch_add(1, std::memory_order_relaxed);
+        g_rectHit.fetch_add(rc.hit, std::memory_order_relaxed);
+        g_rectMiss.fetch_add(rc.miss, std::memory_order_relaxed);
+        return r;
+    }
     Ctx& c = t_ctx;
     const int level = u->w == 8 ? 0 : u->w == 16 ? 1 : u->w == 32 ? 2 : 3;
     int entryBytes = 0;
