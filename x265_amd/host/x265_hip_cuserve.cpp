@@ -579,14 +579,19 @@ void x265hip_install_cuserve_slots(EncoderPrimitives& p)
 void Search::estimateResidualQT(Mode& mode, const CUGeom& cuGeom, uint32_t absPartIdx, uint32_t tuDepth, ShortYuv& resiYuv, Cost& outCosts, const uint32_t depthRange[2],
                                 int32_t splitMore)
 {
-    // only the top-level call arrives here (the reference body recurses into its own copy)
-    const bool serve = g_state > 0 && !g_dead.load(std::memory_order_relaxed) && (int)cuGeom.log2CUSize >= g_minLog2 && !t_job.active && !tuDepth && !absPartIdx;
-    bool submitted = false;
-    if (serve)
+    // only the top-level call arrives here (the reference body recurses into its own copy).  Normally the job is already on its way: it was submitted
+    // when encodeResAndCalcRdInterCU was entered (below), before the host even computed the residual
+    Job& j = t_job;
+    bool mine = j.active && !tuDepth && !absPartIdx && j.resi[0] == resiYuv.m_buf[0] && (int)j.job->log2TrMax == (int)depthRange[1] &&
+                (int)j.job->log2TrMin == (int)depthRange[0];
+    if (j.active && !mine)
+        end_job();                      // a tree this job was not made for (never seen): nothing of it is used
+    if (!mine && g_state > 0 && !g_dead.load(std::memory_order_relaxed) && (int)cuGeom.log2CUSize >= g_minLog2 && !tuDepth && !absPartIdx)
     {
-        submitted = submit(this, mode, cuGeom, resiYuv, depthRange);
-        if (!submitted) counters().skipped.fetch_add(1, std::memory_order_relaxed);
+        mine = submit(this, mode, cuGeom, resiYuv, depthRange);
+        if (!mine) counters().skipped.fetch_add(1, std::memory_order_relaxed);
     }
+    if (mine) j.inTree = true;
     if (g_time)
     {
         Timed t(8 + cuGeom.log2CUSize - 2);
@@ -596,9 +601,9 @@ void Search::estimateResidualQT(Mode& mode, const CUGeom& cuGeom, uint32_t absPa
     }
     else
         refEstimateResidualQT(this, mode, cuGeom, absPartIdx, tuDepth, resiYuv, outCosts, depthRange, splitMore);
-    if (submitted)
+    if (mine)
     {
-        t_job.inTree = false;
+        j.inTree = false;
         if (!t_inEncodeRes)
             end_job();                 // not expected (estimateResidualQT has one caller), but then nothing is remembered beyond the tree
     }
@@ -609,6 +614,16 @@ void Search::estimateResidualQT(Mode& mode, const CUGeom& cuGeom, uint32_t absPa
 void Search::encodeResAndCalcRdInterCU(Mode& interMode, const CUGeom& cuGeom)
 {
     t_inEncodeRes++;
+    if (g_state > 0 && !g_dead.load(std::memory_order_relaxed) && (int)cuGeom.log2CUSize >= g_minLog2 && !t_job.active)
+    {
+        // the job leaves now: the device fetches source and prediction while this thread still subtracts them (search.cpp:2838) and sets the tree up
+        uint32_t range[2];
+        interMode.cu.getInterTUQtDepthRange(range, 0);
+        if (!submit(this, interMode, cuGeom, m_rqt[cuGeom.depth].tmpResiYuv, range))
+            counters().skipped.fetch_add(1, std::memory_order_relaxed);
+        else
+            t_job.inTree = false;
+    }
     refEncodeResAndCalcRdInterCU(this, interMode, cuGeom);
     t_inEncodeRes--;
     if (t_job.active)
@@ -639,9 +654,14 @@ uint32_t Quant::transformNxN(const CUData& cu, const pixel* fenc, uint32_t fencS
             const uint64_t t0 = g_time ? __builtin_ia32_rdtsc() : 0;
             if (__atomic_load_n(&j.units[u].ready, __ATOMIC_ACQUIRE) != j.seq)
             {
-                // not there yet: do something the tree needs next anyway instead of spinning
+                // not there yet: do something the tree needs next anyway instead of spinning — this unit's psy-cost, then (a luma unit: chroma follows
+                // it in the tree, search.cpp:3314-3345) the psy-costs of the chroma units under it
                 const ptrdiff_t d = residual - j.resi[ttype];
-                psy_ahead(j, u, (int)ttype, (int)(d % resiStride), (int)(d / resiStride), 1 << log2TrSize);
+                const int x = (int)(d % resiStride), y = (int)(d / resiStride), n = 1 << log2TrSize;
+                psy_ahead(j, u, (int)ttype, x, y, n);
+                if (ttype == TEXT_LUMA && j.resi[1] && n >= 16)
+                    for (int p = 1; p <= 2 && __atomic_load_n(&j.units[u].ready, __ATOMIC_ACQUIRE) != j.seq; p++)
+                        psy_ahead(j, x265hipi_cujob_unit_index(j.job, j.sHi, (int)log2TrSize, p, x >> log2TrSize, y >> log2TrSize), p, x >> 1, y >> 1, n >> 1);
             }
             if (wait_word(j, &j.units[u].ready))
             {
