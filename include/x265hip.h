@@ -860,6 +860,8 @@ typedef struct x265hip_cujob_unit
     uint64_t codedDist;           /* sse_pp(source, clip(prediction + reconstructed residual)); defined when numSig != 0 */
     uint32_t readyInv;            /* == the job's ticket once codedDist and the reconstructed residual are in place (the inverse half) */
     uint32_t fwdTicks;            /* diagnostic: 100 MHz device ticks from the job's start to this unit's forward half */
+    uint32_t codedEnergy;         /* psy_cost_pp(source, clip(prediction + reconstructed residual)) (reference common/pixel.cpp:726-748); with readyInv, when numSig != 0 */
+    uint32_t reserved[3];
 } x265hip_cujob_unit;
 #define X265HIP_CUJOB_MAX_UNITS   60                       /* 64x64, sizes 32 + 16: 3 * (4 + 16) */
 #define X265HIP_CUJOB_MAX_ELEMS   (2 * 6144)               /* int16 entries of `levels` (and of `resi`) of the largest job */

@@ -153,11 +153,13 @@ int orc_cujob_run_##SFX(const x265hip_cujob* j, const P* pixels, x265hip_cujob_u
                         orc_invtransform_nxn(back, n, levels + eo, log2n, depth, j->qpPer[plane], j->dequantScale[plane], u->numSig); \
                         orc_add_ps_##SFX(rec, n, p, back, pw, n, n, n, depth); \
                         u->codedDist = orc_sse_pp_##SFX(f, pw, rec, n, n, n); \
+                        u->codedEnergy = (uint32_t)orc_psy_cost_pp_##SFX(f, pw, rec, n, n); \
                         memcpy(resi + eo, back, sizeof(int16_t) * n * n); \
                     } \
                     else \
                     { \
                         u->codedDist = u->zeroDist; \
+                        u->codedEnergy = 0; \
                         memset(resi + eo, 0, sizeof(int16_t) * n * n); \
                     } \
                     u->fwdTicks = 0; \

@@ -179,7 +179,7 @@ def _run_on(hp, L, cs, slot, j, pix, timeout=20.0):
         assert time.time() - t0 < timeout, "job not finished after %.0f s" % timeout
     lv = np.ctypeslib.as_array(C.cast(levels, C.POINTER(C.c_int16)), (hp.CUJOB_MAX_ELEMS,)).copy()
     rs = np.ctypeslib.as_array(C.cast(resi, C.POINTER(C.c_int16)), (hp.CUJOB_MAX_ELEMS,)).copy()
-    return [(un[k[4]].numSig, un[k[4]].zeroDist, un[k[4]].codedDist) for k in lay], lv, rs
+    return [(un[k[4]].numSig, un[k[4]].zeroDist, un[k[4]].codedDist, un[k[4]].codedEnergy) for k in lay], lv, rs
 
 
 def _compare(hp, j, got, want_units, want_levels, want_resi, label):
@@ -192,6 +192,7 @@ def _compare(hp, j, got, want_units, want_levels, want_resi, label):
         assert np.array_equal(lv[eo:eo + n * n], want_levels[eo:eo + n * n]), (label, "levels", s, plane, tx, ty)
         if w.numSig:
             assert heads[k][2] == w.codedDist, (label, "codedDist", s, plane, tx, ty)
+            assert heads[k][3] == w.codedEnergy, (label, "codedEnergy", s, plane, tx, ty, heads[k][3], w.codedEnergy)
             assert np.array_equal(rs[eo:eo + n * n], want_resi[eo:eo + n * n]), (label, "resi", s, plane, tx, ty)
             coded += 1
         n_units += 1

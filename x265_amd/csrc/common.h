@@ -17,6 +17,8 @@ int ensure_device();                       // lazy hipSetDevice + capability che
 // hipFree synchronises EVERY stream of the device (measured: 1.45 s beside a resident kernel, tools/micro/mailbox_diag), so the library never calls it
 // directly: device_free() first asks the resident CU-job servers (cuserve.hip) to leave, frees, and lets the next submitter start them again.
 hipError_t device_free(void* p);
+hipError_t pinned_alloc(void** out, size_t bytes);      // runtime.hip: page-locked host memory for the big buffers (huge pages + hipHostRegister)
+hipError_t pinned_free(void* p);
 void servers_pause();                      // cuserve.hip
 void servers_resume();
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

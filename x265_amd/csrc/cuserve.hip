@@ -23,6 +23,7 @@
 // source and prediction are staged in LDS once (every level re-reads them).  Sign-bit hiding: one lane per 4x4 coefficient group (64 per tile).
 #include "common.h"
 #include "dctcore.h"
+#include "tiles.h"
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -348,9 +349,42 @@ __device__ __forceinline__ void tile_chain(TileLds& t, const BOperand (*bop)[64]
             *reinterpret_cast<uint4*>(resi + elemBase + (u0 + gL) * N * N + (e % (N * N))) = *reinterpret_cast<const uint4*>(t.a + e);
     }
     coded = group_sum64(coded, LPT);
+    // ---- psy_cost_pp(source, reconstruction) (pixel.cpp:726-748): per 8x8 block |E(source) - E(reconstruction)|, E = sa8d_8x8 against zero - (sum >> 2).
+    // The reconstruction goes to LDS as int16; the lanes then take 4x4 tiles, four consecutive lanes = the quadrants of one 8x8 block
+    // (quad_sa8d_raw: the 8x8 Hadamard across the DPP quad), LPT tiles = one unit, exactly one pass
+#pragma unroll
+    for (int half = 0; half < 2; half++)
+    {
+        const int e = lane * 16 + half * 8;
+        int r[8], rec[8];
+        load4(t.a + e, r); load4(t.a + e + 4, r + 4);
+#pragma unroll
+        for (int i = 0; i < 8; i++) rec[i] = clip3i(0, qp.maxVal, pv[8 * half + i] + r[i]);
+        store4(t.b + e, rec); store4(t.b + e + 4, rec + 4);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    int energy;
+    {
+        constexpr int B8 = N / 8;                                            // 8x8 blocks per row of a unit
+        const int g2 = lane / LPT, tt = lane % LPT, b8 = tt >> 2, q = tt & 3;
+        const int tx = (b8 % B8) * 8 + (q & 1) * 4, ty = (b8 / B8) * 8 + (q >> 1) * 4;
+        const int u = u0 + (g2 < count ? g2 : 0), ux = u % perRow, uy = u / perRow;
+        int ms[16], mr[16];
+        tile_load(src + (uy * N + ty) * pw + ux * N + tx, (int64_t)pw, ms);
+        tile_load(t.b + g2 * N * N + ty * N + tx, (int64_t)N, mr);
+        int sumS = 0, sumR = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { sumS += ms[i]; sumR += mr[i]; }
+        hadamard4x4(ms);
+        hadamard4x4(mr);
+        const int rawS = quad_sa8d_raw(ms, lane), rawR = quad_sa8d_raw(mr, lane);
+        const int es = ((rawS + 2) >> 2) - (quad_sum(sumS) >> 2), er = ((rawR + 2) >> 2) - (quad_sum(sumR) >> 2);
+        energy = group_sum((lane & 3) == 0 ? iabs(es - er) : 0, LPT);
+    }
     if (writer)
     {
         un->codedDist = coded;
+        un->codedEnergy = (uint32_t)energy;
         __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);

@@ -168,8 +168,8 @@ static x265hip_refpic* refpic_create(int place, int depth, int picW, int picH, i
     if (!ok)
         ok = hipStreamCreateWithFlags(&rp->st, hipStreamNonBlocking) == hipSuccess &&
              hipMalloc((void**)&rp->dPic, planeBytes) == hipSuccess && hipMalloc((void**)&rp->dPlanes, planeBytes * 16) == hipSuccess &&
-             hipHostMalloc((void**)&rp->hPlanes, planeBytes * 15, hipHostMallocDefault) == hipSuccess &&
-             hipHostMalloc((void**)&rp->hStage, planeBytes, hipHostMallocDefault) == hipSuccess;
+             pinned_alloc((void**)&rp->hPlanes, planeBytes * 15) == hipSuccess &&
+             pinned_alloc((void**)&rp->hStage, planeBytes) == hipSuccess;
     if (!ok)
     {
         set_error(X265HIP_ENOMEM, "x265hip_refpic_create: %zu bytes per plane", planeBytes);
@@ -215,10 +215,10 @@ void x265hip_refpic_destroy(x265hip_refpic* rp)
     }
     else
     {
-        if (rp->hStage) (void)hipHostFree(rp->hStage);
+        if (rp->hStage) (void)pinned_free(rp->hStage);
         if (rp->dPic) (void)device_free(rp->dPic);
         if (rp->dPlanes) (void)device_free(rp->dPlanes);
-        if (rp->hPlanes) (void)hipHostFree(rp->hPlanes);
+        if (rp->hPlanes) (void)pinned_free(rp->hPlanes);
         if (rp->st) (void)hipStreamDestroy(rp->st);
     }
     delete rp;

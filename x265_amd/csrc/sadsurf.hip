@@ -1065,7 +1065,7 @@ static x265hip_srcpic* srcpic_create(int place, int depth, int width, int height
     sp->place = place;
     const size_t bytes = (size_t)sp->pitch * height;
     if (hipStreamCreateWithFlags(&sp->st, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&sp->dLuma, bytes + 256) != hipSuccess ||
-        hipHostMalloc((void**)&sp->hStage, bytes, hipHostMallocDefault) != hipSuccess)
+        pinned_alloc((void**)&sp->hStage, bytes) != hipSuccess)
     {
         set_error(X265HIP_ENOMEM, "x265hip_srcpic_create: %zu bytes", bytes);
         x265hip_srcpic_destroy(sp);
@@ -1104,7 +1104,7 @@ static void srcpic_unref(x265hip_srcpic* sp)
     (void)hipSetDevice(sp->device);
     if (sp->st) { (void)hipStreamSynchronize(sp->st); (void)hipStreamDestroy(sp->st); }
     if (sp->dLuma) (void)device_free(sp->dLuma);
-    if (sp->hStage) (void)hipHostFree(sp->hStage);
+    if (sp->hStage) (void)pinned_free(sp->hStage);
     if (had && cur != sp->device) (void)hipSetDevice(cur);
     delete sp;
 }
@@ -1141,7 +1141,7 @@ x265hip_sadsurf* x265hip_sadsurf_attach_levels(x265hip_srcpic* src, x265hip_refp
         int cur = 0;
         const bool had = hipGetDevice(&cur) == hipSuccess;
         (void)hipSetDevice(src->device);
-        const bool ok = hipMalloc((void**)&ss->dBuf, ss->bytes) == hipSuccess && hipHostMalloc((void**)&ss->hBuf, ss->bytes, hipHostMallocDefault) == hipSuccess;
+        const bool ok = hipMalloc((void**)&ss->dBuf, ss->bytes) == hipSuccess && pinned_alloc((void**)&ss->hBuf, ss->bytes) == hipSuccess;
         if (had && cur != src->device) (void)hipSetDevice(cur);
         if (!ok)
         {

@@ -264,7 +264,7 @@ class CuJob(C.Structure):
 
 class CuJobUnit(C.Structure):
     """x265hip_cujob_unit (include/x265hip.h): one transform unit's result header"""
-    _fields_ = [("ready", u32), ("numSig", u32), ("zeroDist", u64), ("codedDist", u64), ("readyInv", u32), ("fwdTicks", u32)]
+    _fields_ = [("ready", u32), ("numSig", u32), ("zeroDist", u64), ("codedDist", u64), ("readyInv", u32), ("fwdTicks", u32), ("codedEnergy", u32), ("reserved", u32 * 3)]
 
 
 CUJOB_MAX_UNITS = 60

@@ -101,7 +101,7 @@ std::atomic<bool> g_dead(false); // the device failed once: every later CU is co
 std::atomic<uint64_t> g_cycles[18][2], g_calls[18][2];
 __attribute__((tls_model("initial-exec"))) thread_local int t_inRqt = 0;
 
-struct alignas(64) Counters { std::atomic<uint64_t> jobs, fwd, inv, fwdMiss, invMiss, waitCycles, waits, skipped, dist, psyHit, psyAhead; };
+struct alignas(64) Counters { std::atomic<uint64_t> jobs, fwd, inv, fwdMiss, invMiss, waitCycles, waits, skipped, dist, psyHit, psyAhead, psyCoded; };
 Counters g_count[64];
 std::atomic<int> g_nextShard(0);
 __attribute__((tls_model("initial-exec"))) thread_local int t_shard = -1;
@@ -155,11 +155,11 @@ void report_time()
 
 void report()
 {
-    uint64_t jobs = 0, fwd = 0, inv = 0, fm = 0, im = 0, wc = 0, w = 0, sk = 0, di = 0, ph = 0, pa = 0;
+    uint64_t jobs = 0, fwd = 0, inv = 0, fm = 0, im = 0, wc = 0, w = 0, sk = 0, di = 0, ph = 0, pa = 0, pc = 0;
     for (int i = 0; i < 64; i++)
     {
         jobs += g_count[i].jobs; fwd += g_count[i].fwd; inv += g_count[i].inv; fm += g_count[i].fwdMiss; im += g_count[i].invMiss;
-        wc += g_count[i].waitCycles; w += g_count[i].waits; sk += g_count[i].skipped; di += g_count[i].dist; ph += g_count[i].psyHit; pa += g_count[i].psyAhead;
+        wc += g_count[i].waitCycles; w += g_count[i].waits; sk += g_count[i].skipped; di += g_count[i].dist; ph += g_count[i].psyHit; pa += g_count[i].psyAhead; pc += g_count[i].psyCoded;
     }
     uint64_t devJobs = 0, starts = 0, ns = 0;
     for (int k = 0; k < g_nsvc.load(); k++)
@@ -175,8 +175,9 @@ void report()
             g_mode ? "" : (std::string(", ") + std::to_string(starts) + " server starts").c_str(), (unsigned long long)fwd, (unsigned long long)inv,
             (unsigned long long)fm, (unsigned long long)im, (unsigned long long)w, w ? (double)wc / w : 0.0, (unsigned long long)sk,
             g_dead.load() ? "; THE DEVICE FAILED during the run, the rest was computed on the host" : "");
-    fprintf(stderr, "x265hip: cuserve: %llu sse_pp answers out of the jobs; %llu psy-cost (source, prediction) values computed while waiting for the device, %llu psy-cost calls "
-                    "answered from values remembered within their encodeResAndCalcRdInterCU\n", (unsigned long long)di, (unsigned long long)pa, (unsigned long long)ph);
+    fprintf(stderr, "x265hip: cuserve: %llu sse_pp and %llu psy-cost (source, reconstruction) answers out of the jobs; %llu psy-cost (source, prediction) values computed while waiting "
+                    "for the device, %llu psy-cost calls answered from values remembered within their encodeResAndCalcRdInterCU\n", (unsigned long long)di, (unsigned long long)pc,
+            (unsigned long long)pa, (unsigned long long)ph);
 }
 
 bool decide()
@@ -505,6 +506,24 @@ template <int CU, int N> int psy_slot(const pixel* a, intptr_t sa, const pixel* 
 {
     Job& j = t_job;
     Where w;
+    if (j.active && N >= 8 && where_in_source(j, a, sa, N, w) && w.s <= j.sHi && w.s >= j.sLo)
+    {
+        // against the tree's reconstruction of a unit whose residual came from the device (search.cpp:3299, :3373): the job measured it
+        const Yuv& rq = j.search->m_rqt[(w.plane ? w.s - 1 : w.s) - 2].reconQtYuv;
+        const uint32_t rs = w.plane ? rq.m_csize : rq.m_size;
+        if ((uint32_t)sb == rs && b == rq.m_buf[w.plane] + (size_t)w.y * rs + w.x)
+        {
+            const int sh = w.plane ? w.s - 1 : w.s;
+            const int u = x265hipi_cujob_unit_index(j.job, j.sHi, w.s, w.plane, w.x >> sh, w.y >> sh);
+            if (j.invServed[u] && wait_word(j, &j.units[u].readyInv))
+            {
+                const int v = (int)j.units[u].codedEnergy;
+                if (g_verify && g_prev.cu[CU].psy_cost_pp(a, sa, b, sb) != v) { fprintf(stderr, "x265hip: cuserve: VERIFY FAILED psy_cost_pp(source, reconstruction) %dx%d\n", N, N); abort(); }
+                counters().psyCoded.fetch_add(1, std::memory_order_relaxed);
+                return v;
+            }
+        }
+    }
     if (j.active && N >= 8 && where_in_source(j, a, sa, N, w) && (uint32_t)sb == j.predStride[w.plane] && b == j.pred[w.plane] + (size_t)w.y * sb + w.x)
     {
         const int s = w.s > j.sHi ? j.sHi : w.s;
