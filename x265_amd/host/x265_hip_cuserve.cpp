@@ -115,6 +115,7 @@ struct Job
     const int16_t* resi[3]; uint32_t resiStride[3];      // the CU's residual blocks (ShortYuv): what identifies a unit
     uint32_t log2CU;
     int sHi, sLo;
+    const Mode* mode;                    // the mode whose residual this is (its cbf flags and final reconstruction are looked at after the tree)
     bool inTree;                         // inside the top-level estimateResidualQT: transform units are looked up (afterwards only the remembered values serve)
     const Search* search;
     const pixel* fenc[3]; uint32_t fencStride[3];        // the mode's source and prediction blocks (Yuv): what identifies an sse / psy question
@@ -389,6 +390,7 @@ bool submit(Search* se, Mode& mode, const CUGeom& cuGeom, ShortYuv& resiYuv, con
     }
     j.quant = &q;
     j.search = se;
+    j.mode = &mode;
     for (int p = 0; p < 3; p++)
     {
         j.resi[p] = resiYuv.m_buf[p]; j.resiStride[p] = p ? resiYuv.m_csize : resiYuv.m_size;
@@ -480,13 +482,65 @@ inline bool job_sse(Job& j, const pixel* a, intptr_t sa, const pixel* b, intptr_
     return true;
 }
 
+// After the tree, encodeResAndCalcRdInterCU measures the CU's FINAL reconstruction (search.cpp:2940-2956: reconYuv = clip(pred + the residual the tree
+// kept), then sse_pp and psyCost of the whole CU against it).  With one transform size in the job that reconstruction is, unit by unit, either the
+// tree's coded reconstruction (the unit's cbf survived) or the prediction (cbf 0): the job and this thread know both answers.  `coded` / `zero` pick
+// the per-unit values; false when anything is missing.
+template <typename F> inline bool final_sum(Job& j, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb, int n, F unit_value, int64_t& out)
+{
+    Where w;
+    if (j.inTree || j.sHi != j.sLo || !where_in_source(j, a, sa, n, w) || w.x || w.y) return false;
+    const int N = (1 << j.log2CU) >> (w.plane ? 1 : 0);
+    if (n != N) return false;
+    const Yuv& ry = j.mode->reconYuv;
+    if ((uint32_t)sb != (w.plane ? ry.m_csize : ry.m_size) || b != ry.m_buf[w.plane]) return false;
+    const int s = j.sHi, k = 1 << (j.log2CU - s), sh = w.plane ? s - 1 : s, tuDepth = (int)j.log2CU - s;
+    const CUData& cu = j.mode->cu;
+    int64_t sum = 0;
+    for (int ty = 0; ty < k; ty++)
+        for (int tx = 0; tx < k; tx++)
+        {
+            const int u = x265hipi_cujob_unit_index(j.job, j.sHi, s, w.plane, tx, ty);
+            const uint32_t absPartIdx = g_rasterToZscan[((ty << s) >> 2) * 16 + ((tx << s) >> 2)];
+            const bool cbf = (cu.m_cbf[w.plane][absPartIdx] >> tuDepth) & 1;
+            int64_t v;
+            if (!unit_value(u, cbf, v)) return false;
+            sum += v;
+        }
+    (void)sh;
+    out = sum;
+    return true;
+}
+inline bool final_sse(Job& j, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb, int n, uint64_t& out)
+{
+    int64_t v;
+    if (!final_sum(j, a, sa, b, sb, n, [&j](int u, bool cbf, int64_t& val) {
+            if (cbf) { if (!j.invServed[u] || !wait_word(j, &j.units[u].readyInv)) return false; val = (int64_t)j.units[u].codedDist; }
+            else { if (!wait_word(j, &j.units[u].ready)) return false; val = (int64_t)j.units[u].zeroDist; }
+            return true; }, v))
+        return false;
+    out = (uint64_t)v;
+    return true;
+}
+inline bool final_psy(Job& j, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb, int n, int& out)
+{
+    int64_t v;
+    if (!final_sum(j, a, sa, b, sb, n, [&j](int u, bool cbf, int64_t& val) {
+            if (cbf) { if (!j.invServed[u] || !wait_word(j, &j.units[u].readyInv)) return false; val = (int64_t)j.units[u].codedEnergy; }
+            else { if (!j.energyKnown[u]) return false; val = j.energy[u]; }
+            return true; }, v))
+        return false;
+    out = (int)v;
+    return true;
+}
+
 template <int CU, int N, bool CHROMA> sse_t sse_slot(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
 {
     Job& j = t_job;
     if (j.active)
     {
         uint64_t v;
-        if (job_sse(j, a, sa, b, sb, N, v))
+        if (job_sse(j, a, sa, b, sb, N, v) || final_sse(j, a, sa, b, sb, N, v))
         {
             if (g_verify)
             {
@@ -506,6 +560,13 @@ template <int CU, int N> int psy_slot(const pixel* a, intptr_t sa, const pixel* 
 {
     Job& j = t_job;
     Where w;
+    int fin;
+    if (j.active && N >= 8 && final_psy(j, a, sa, b, sb, N, fin))
+    {
+        if (g_verify && g_prev.cu[CU].psy_cost_pp(a, sa, b, sb) != fin) { fprintf(stderr, "x265hip: cuserve: VERIFY FAILED psy_cost_pp(source, final reconstruction) %dx%d\n", N, N); abort(); }
+        counters().psyCoded.fetch_add(1, std::memory_order_relaxed);
+        return fin;
+    }
     if (j.active && N >= 8 && where_in_source(j, a, sa, N, w) && w.s <= j.sHi && w.s >= j.sLo)
     {
         // against the tree's reconstruction of a unit whose residual came from the device (search.cpp:3299, :3373): the job measured it
