@@ -908,7 +908,10 @@ int x265hip_cuserve_open(int slots, int mode, x265hip_cuserve** out);
 /* the same service at place `place` (x265hip_places): its slots are served by that place's device */
 int x265hip_cuserve_open_at(int place, int slots, int mode, x265hip_cuserve** out);
 int x265hip_cuserve_close(x265hip_cuserve* cs);
-/* the slot's memory: the caller writes *job and *pixels, reads units / levels / resi */
+/* the slot's memory: the caller fills *job (ordinary memory: it may read it back; submit copies it into the mailbox) and WRITES *pixels, front to
+ * back — when the device has a large BAR that block is device memory mapped write-combined into the process (the server then reads the job from its
+ * own HBM instead of over PCIe; X265HIP_CUSERVE_MAILBOX=host|device overrides the choice), so never read it — and reads units / levels / resi
+ * (page-locked host memory the device writes) */
 int x265hip_cuserve_slot(x265hip_cuserve* cs, int slot, x265hip_cujob** job, void** pixels, const x265hip_cujob_unit** units,
                          const int16_t** levels, const int16_t** resi);
 /* hands the slot's job to the device; *seq = the ticket: the value the units' `ready` / `readyInv` words take (unique among the slot's recent jobs) */

@@ -17,6 +17,10 @@ int ensure_device();                       // lazy hipSetDevice + capability che
 // hipFree synchronises EVERY stream of the device (measured: 1.45 s beside a resident kernel, tools/micro/mailbox_diag), so the library never calls it
 // directly: device_free() first asks the resident CU-job servers (cuserve.hip) to leave, frees, and lets the next submitter start them again.
 hipError_t device_free(void* p);
+// runtime.hip: a non-blocking stream of `device` for the duration of one operation.  hipStreamCreateWithFlags takes 3.9 ms on the MI355X box
+// (tools/micro/create_cost): short-lived users share a pool instead of owning one each; streams go back, they are never destroyed.
+hipStream_t stream_lease(int device);
+void stream_return(int device, hipStream_t st);
 hipError_t pinned_alloc(void** out, size_t bytes);      // runtime.hip: page-locked host memory for the big buffers (huge pages + hipHostRegister)
 hipError_t pinned_free(void* p);
 void servers_pause();                      // cuserve.hip

@@ -40,14 +40,24 @@ namespace {
 
 constexpr int kInts = X265HIP_CUJOB_MAX_ELEMS;
 
-struct Slot                                      // host-coherent page-locked memory; one per submitting host thread
+// A slot = a mailbox of two halves, each living where its READER is:
+//   SlotIn   host -> device.  DEVICE memory (uncached for the GPU's L2: hipDeviceMallocUncached) that the host writes through the large BAR — posted
+//            writes, no round trip; the server polls the doorbell and fetches header + pixels from its own HBM.  Against a mailbox in host memory the
+//            hand-off loses two PCIe read round trips (tools/micro/bar_mailbox: doorbell -> echo 10.6 us -> 6.6 us on the MI355X box).  The host never
+//            READS this half (a load through the BAR is a microsecond): x265hip_cuserve_slot hands out a shadow header in ordinary memory.
+//            Without a large BAR (or X265HIP_CUSERVE_MAILBOX=host): host-coherent page-locked memory, as in the first version.
+//   SlotOut  device -> host.  Host-coherent page-locked memory: the device's stores are posted writes as well, the host polls its own memory.
+struct SlotIn
 {
     uint32_t doorbell;                           // host -> device: sequence number of the job below (mode 0)
-    uint32_t pad0[15];
-    uint32_t failed;                             // device -> host: a job the device could not do (never expected)
-    uint32_t pad1[15];
+    uint32_t pad0[31];
     alignas(128) x265hip_cujob job;              // 80 bytes; the pixel block follows at +128 so that header and pixels are ONE run of 16-byte chunks
     alignas(128) unsigned char pixels[X265HIP_CUJOB_PIXEL_BYTES];
+};
+struct SlotOut
+{
+    uint32_t failed;                             // device -> host: a job the device could not do (never expected)
+    uint32_t pad1[15];
     alignas(64) x265hip_cujob_unit units[X265HIP_CUJOB_MAX_UNITS];
     alignas(64) int16_t levels[kInts];
     alignas(64) int16_t resi[kInts];
@@ -404,7 +414,7 @@ __device__ __forceinline__ void build_operands(JobLds& L)
 }
 
 template <typename P>
-__device__ __forceinline__ void run_tiles(Slot* s, JobLds& L, uint32_t seq, uint64_t t0)
+__device__ __forceinline__ void run_tiles(SlotOut* s, JobLds& L, uint32_t seq, uint64_t t0)
 {
     const int wv = threadIdx.x >> 6;
     const x265hip_cujob& j = L.job;
@@ -444,12 +454,12 @@ __device__ __forceinline__ void run_tiles(Slot* s, JobLds& L, uint32_t seq, uint
 }
 
 // one job: `ticket` says how many bytes the job holds, so header and pixels arrive in one round trip
-__device__ __forceinline__ void run_job(Slot* s, JobLds& L, uint32_t ticket, uint64_t* busyTicks)
+__device__ __forceinline__ void run_job(const SlotIn* sin, SlotOut* s, JobLds& L, uint32_t ticket, uint64_t* busyTicks)
 {
     const int tid = threadIdx.x;
     const uint64_t t0 = wall_clock64();
     const int chunks = (128 + (int)ticket_bytes(ticket)) >> 4;
-    const uint4* in = reinterpret_cast<const uint4*>(&s->job);
+    const uint4* in = reinterpret_cast<const uint4*>(&sin->job);
     uint4* out = reinterpret_cast<uint4*>(&L.job);
     for (int i = tid; i < chunks; i += 256)
         out[i] = in[i];
@@ -462,26 +472,27 @@ __device__ __forceinline__ void run_job(Slot* s, JobLds& L, uint32_t ticket, uin
 }
 
 // mode 1: one job, one launch
-__global__ __launch_bounds__(256) void cu_job_kernel(Slot* s, uint32_t ticket, uint64_t* busyTicks)
+__global__ __launch_bounds__(256) void cu_job_kernel(const SlotIn* sin, SlotOut* s, uint32_t ticket, uint64_t* busyTicks)
 {
     __shared__ JobLds L;
     build_operands(L);
-    run_job(s, L, ticket, busyTicks);
+    run_job(sin, s, L, ticket, busyTicks);
 }
 
 // mode 0: workgroup b serves slot b.  The server as a whole leaves when no workgroup has taken a job for `idleTicks` (100 MHz) or the host rings
 // 0xffffffff on any slot: the workgroup that notices sets ctl->quit, every workgroup leaves at its next poll, the last one tells the host.
-__global__ __launch_bounds__(256) void cu_server_kernel(Slot* slots, HostCtl* hostCtl, DevCtl* ctl, uint32_t generation, uint64_t idleTicks)
+__global__ __launch_bounds__(256) void cu_server_kernel(const SlotIn* ins, SlotOut* outs, HostCtl* hostCtl, DevCtl* ctl, uint32_t generation, uint64_t idleTicks)
 {
     __shared__ JobLds L;
-    Slot* s = slots + blockIdx.x;
+    const SlotIn* sin = ins + blockIdx.x;
+    SlotOut* s = outs + blockIdx.x;
     build_operands(L);
     uint32_t last = 0;
     if (threadIdx.x == 0)
     {
         // "the server has had work" starts now for every workgroup, whichever gets on the chip first (the word still holds the previous server's time)
         __hip_atomic_fetch_max(&ctl->lastWork, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = __hip_atomic_load(&s->doorbell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        last = __hip_atomic_load(&sin->doorbell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
         // a job rung while no server was there has not been done: its first unit is not ready
         if (last && last != 0xffffffffu && __hip_atomic_load(&s->units[0].ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != last)
             last = 0;
@@ -497,7 +508,7 @@ __global__ __launch_bounds__(256) void cu_server_kernel(Slot* slots, HostCtl* ho
             int polls = 0;
             for (;;)
             {
-                v = __hip_atomic_load(&s->doorbell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                v = __hip_atomic_load(&sin->doorbell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (v == 0xffffffffu || (blockIdx.x == 0 && __hip_atomic_load(&hostCtl->leave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)))
                 {
                     __hip_atomic_store(&ctl->quit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -545,7 +556,7 @@ __global__ __launch_bounds__(256) void cu_server_kernel(Slot* slots, HostCtl* ho
             return;
         }
         last = v;
-        run_job(s, L, v, &ctl->busyTicks[blockIdx.x]);
+        run_job(sin, s, L, v, &ctl->busyTicks[blockIdx.x]);
     }
 }
 
@@ -554,11 +565,23 @@ __global__ __launch_bounds__(256) void cu_server_kernel(Slot* slots, HostCtl* ho
 
 using namespace xh;
 
+// sfence: stores to write-combining memory (the BAR) become globally visible in program order across it, and the buffers are drained
+static inline void store_fence()
+{
+#if !defined(__HIP_DEVICE_COMPILE__)
+    __asm__ __volatile__("sfence" ::: "memory");
+#endif
+}
+
 struct x265hip_cuserve
 {
     int slots = 0, mode = 0, device = 0;
-    Slot* host = nullptr;                         // page-locked, coherent
-    Slot* dev = nullptr;                          // the same memory as the device addresses it
+    SlotIn* in = nullptr;                         // as the host addresses it: device memory through the BAR (inDevice) or page-locked host memory
+    SlotIn* inDev = nullptr;                      // as the device addresses it
+    bool inDevice = false;
+    SlotOut* out = nullptr;                       // page-locked, coherent
+    SlotOut* outDev = nullptr;                    // the same memory as the device addresses it
+    x265hip_cujob* shadow = nullptr;              // per slot: the header as the submitter fills (and reads) it; copied into the mailbox by submit
     HostCtl* hostCtl = nullptr; HostCtl* devHostCtl = nullptr;
     DevCtl* ctl = nullptr;                        // device memory
     hipStream_t serverStream = nullptr;
@@ -589,7 +612,7 @@ static int start_server(x265hip_cuserve* cs)
     hipError_t e = hipMemsetAsync(cs->ctl, 0, 8, cs->serverStream);
     if (e == hipSuccess)
     {
-        hipLaunchKernelGGL(cu_server_kernel, dim3(cs->slots), dim3(256), 0, cs->serverStream, cs->dev, cs->devHostCtl, cs->ctl, gen ? gen : 1u, cs->idleUs * 100);
+        hipLaunchKernelGGL(cu_server_kernel, dim3(cs->slots), dim3(256), 0, cs->serverStream, cs->inDev, cs->outDev, cs->devHostCtl, cs->ctl, gen ? gen : 1u, cs->idleUs * 100);
         e = hipGetLastError();
     }
     if (cur >= 0 && cur != cs->device) (void)hipSetDevice(cur);
@@ -641,8 +664,35 @@ int x265hip_cuserve_open(int slots, int mode, x265hip_cuserve** out)
     cs->slots = slots; cs->mode = mode;
     (void)hipGetDevice(&cs->device);
     if (const char* env = getenv("X265HIP_CUSERVE_IDLE_US")) cs->idleUs = (uint64_t)atoll(env);
-    int e = check_hip(hipHostMalloc((void**)&cs->host, sizeof(Slot) * slots, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc(cuserve slots)");
-    if (!e) { memset(cs->host, 0, sizeof(Slot) * slots); e = check_hip(hipHostGetDevicePointer((void**)&cs->dev, cs->host, 0), "hipHostGetDevicePointer(cuserve)"); }
+    int e = check_hip(hipHostMalloc((void**)&cs->out, sizeof(SlotOut) * slots, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc(cuserve slots)");
+    if (!e) { memset(cs->out, 0, sizeof(SlotOut) * slots); e = check_hip(hipHostGetDevicePointer((void**)&cs->outDev, cs->out, 0), "hipHostGetDevicePointer(cuserve)"); }
+    if (!e)
+    {
+        // the host -> device half: device memory when the host can write it (large BAR), see SlotIn
+        int largeBar = 0;
+        (void)hipDeviceGetAttribute(&largeBar, hipDeviceAttributeIsLargeBar, cs->device);
+        const char* where = getenv("X265HIP_CUSERVE_MAILBOX");
+        const bool wantDevice = where ? !strcmp(where, "device") : largeBar != 0;
+        if (wantDevice && hipExtMallocWithFlags((void**)&cs->inDev, sizeof(SlotIn) * slots, hipDeviceMallocUncached) == hipSuccess &&
+            hipMemset(cs->inDev, 0, sizeof(SlotIn) * slots) == hipSuccess && hipDeviceSynchronize() == hipSuccess)
+        {
+            cs->in = cs->inDev;
+            cs->inDevice = true;
+        }
+        else
+        {
+            (void)hipGetLastError();
+            if (cs->inDev) { (void)hipFree(cs->inDev); cs->inDev = nullptr; }
+            e = check_hip(hipHostMalloc((void**)&cs->in, sizeof(SlotIn) * slots, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc(cuserve mailbox)");
+            if (!e) { memset(cs->in, 0, sizeof(SlotIn) * slots); e = check_hip(hipHostGetDevicePointer((void**)&cs->inDev, cs->in, 0), "hipHostGetDevicePointer(cuserve mailbox)"); }
+        }
+    }
+    if (!e)
+    {
+        cs->shadow = new (std::nothrow) x265hip_cujob[slots];
+        if (!cs->shadow) e = set_error(X265HIP_ENOMEM, "x265hip_cuserve_open: out of memory");
+        else memset(cs->shadow, 0, sizeof(x265hip_cujob) * slots);
+    }
     if (!e) e = check_hip(hipHostMalloc((void**)&cs->hostCtl, 64, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc(cuserve control)");
     if (!e) { memset(cs->hostCtl, 0, 64); e = check_hip(hipHostGetDevicePointer((void**)&cs->devHostCtl, cs->hostCtl, 0), "hipHostGetDevicePointer(cuserve control)"); }
     if (!e) e = check_hip(hipMalloc((void**)&cs->ctl, sizeof(DevCtl)), "hipMalloc(cuserve control)");
@@ -711,16 +761,19 @@ int x265hip_cuserve_close(x265hip_cuserve* cs)
         for (x265hip_cuserve*& slot : g_open)
             if (slot == cs) slot = nullptr;
     }
-    if (cs->host)
+    if (cs->in)
     {
-        __atomic_store_n(&cs->host[0].doorbell, 0xffffffffu, __ATOMIC_RELEASE);           // a resident server leaves at its next poll
+        __atomic_store_n(&cs->in[0].doorbell, 0xffffffffu, __ATOMIC_RELEASE);             // a resident server leaves at its next poll
+        store_fence();
         if (cs->serverStream) (void)hipStreamSynchronize(cs->serverStream);
         if (cs->jobStreams)
             for (int i = 0; i < cs->slots; i++)
                 if (cs->jobStreams[i]) { (void)hipStreamSynchronize(cs->jobStreams[i]); (void)hipStreamDestroy(cs->jobStreams[i]); }
         clock_add(X265HIP_CLK_CUSERVE, cs->jobs.load(), device_ticks(cs) * 10, cs->bytes.load());
-        (void)hipHostFree(cs->host);
+        if (cs->inDevice) (void)device_free(cs->in); else (void)hipHostFree(cs->in);
     }
+    if (cs->out) (void)hipHostFree(cs->out);
+    delete[] cs->shadow;
     if (cs->hostCtl) (void)hipHostFree(cs->hostCtl);
     if (cs->ctl) (void)device_free(cs->ctl);
     if (cs->serverStream) (void)hipStreamDestroy(cs->serverStream);
@@ -733,9 +786,9 @@ int x265hip_cuserve_slot(x265hip_cuserve* cs, int slot, x265hip_cujob** job, voi
                          const int16_t** resi)
 {
     if (!cs || slot < 0 || slot >= cs->slots) return set_error(X265HIP_EINVAL, "x265hip_cuserve_slot: slot %d", slot);
-    Slot* s = cs->host + slot;
-    if (job) *job = &s->job;
-    if (pixels) *pixels = s->pixels;
+    SlotOut* s = cs->out + slot;
+    if (job) *job = cs->shadow + slot;
+    if (pixels) *pixels = cs->in[slot].pixels;
     if (units) *units = s->units;
     if (levels) *levels = s->levels;
     if (resi) *resi = s->resi;
@@ -745,8 +798,8 @@ int x265hip_cuserve_slot(x265hip_cuserve* cs, int slot, x265hip_cujob** job, voi
 int x265hip_cuserve_submit(x265hip_cuserve* cs, int slot, uint32_t* seqOut)
 {
     if (!cs || slot < 0 || slot >= cs->slots || !seqOut) return set_error(X265HIP_EINVAL, "x265hip_cuserve_submit: slot %d", slot);
-    Slot* s = cs->host + slot;
-    const x265hip_cujob& j = s->job;
+    SlotIn* s = cs->in + slot;
+    const x265hip_cujob& j = cs->shadow[slot];
     int sHi, sLo;
     if (j.log2CUSize < 4 || j.log2CUSize > 6 || x265hipi_cujob_levels(&j, &sHi, &sLo) < 1 || !valid_depth((int)j.bitDepth))
         return set_error(X265HIP_EINVAL, "x265hip_cuserve_submit: CU 2^%u, transform sizes 2^%u..2^%u, depth %u", j.log2CUSize, j.log2TrMin, j.log2TrMax, j.bitDepth);
@@ -761,19 +814,22 @@ int x265hip_cuserve_submit(x265hip_cuserve* cs, int slot, uint32_t* seqOut)
         const uint64_t n2 = 1ull << (2 * j.log2CUSize), B = j.bitDepth > 8 ? 2 : 1;
         cs->bytes.fetch_add((uint64_t)(sHi - sLo + 1) * (j.chroma ? n2 + n2 / 2 : n2) * (2 * B + 4), std::memory_order_relaxed);
     }
+    memcpy(&s->job, &j, sizeof(j));
+    store_fence();                                                                           // header and pixels leave the core before the doorbell does
     if (cs->mode == 1)
     {
         std::atomic_thread_fence(std::memory_order_release);
         int cur = -1;
         (void)hipGetDevice(&cur);
         if (cur != cs->device) (void)hipSetDevice(cs->device);
-        hipLaunchKernelGGL(cu_job_kernel, dim3(1), dim3(256), 0, cs->jobStreams[slot], cs->dev + slot, seq, &cs->ctl->busyTicks[slot]);
+        hipLaunchKernelGGL(cu_job_kernel, dim3(1), dim3(256), 0, cs->jobStreams[slot], cs->inDev + slot, cs->outDev + slot, seq, &cs->ctl->busyTicks[slot]);
         const hipError_t le = hipGetLastError();
         if (cur >= 0 && cur != cs->device) (void)hipSetDevice(cur);
         if (le != hipSuccess) return check_hip(le, "cu_job_kernel");
         return X265HIP_OK;
     }
     __atomic_store_n(&s->doorbell, seq, __ATOMIC_RELEASE);
+    store_fence();                                                                           // ... and the doorbell leaves now, not when its write-combining buffer is evicted
     if (__atomic_load_n(&cs->hostCtl->serverState, __ATOMIC_ACQUIRE) == 0)
         return start_server(cs);
     return X265HIP_OK;
@@ -782,7 +838,7 @@ int x265hip_cuserve_submit(x265hip_cuserve* cs, int slot, uint32_t* seqOut)
 int x265hip_cuserve_poke(x265hip_cuserve* cs, int slot)
 {
     if (!cs || slot < 0 || slot >= cs->slots) return set_error(X265HIP_EINVAL, "x265hip_cuserve_poke: slot %d", slot);
-    if (__atomic_load_n(&cs->host[slot].failed, __ATOMIC_ACQUIRE)) return set_error(X265HIP_EHIP, "cuserve: the device gave up a job of slot %d", slot);
+    if (__atomic_load_n(&cs->out[slot].failed, __ATOMIC_ACQUIRE)) return set_error(X265HIP_EHIP, "cuserve: the device gave up a job of slot %d", slot);
     if (cs->mode == 0 && __atomic_load_n(&cs->hostCtl->serverState, __ATOMIC_ACQUIRE) == 0)
         return start_server(cs);
     return X265HIP_OK;

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <vector>
 #include <mutex>
 #include <sys/mman.h>
 
@@ -90,6 +91,27 @@ int place_device(int place)
 int place_of_device(int device) { return -(device + 1); }
 
 static std::atomic<uint64_t> g_clkSpans[X265HIP_CLK_COUNT], g_clkNs[X265HIP_CLK_COUNT], g_clkBytes[X265HIP_CLK_COUNT];
+
+static std::mutex g_streamLock;
+static std::vector<hipStream_t> g_streamPool[64];
+hipStream_t stream_lease(int device)
+{
+    if (device < 0 || device >= 64) return nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_streamLock);
+        auto& v = g_streamPool[device];
+        if (!v.empty()) { hipStream_t st = v.back(); v.pop_back(); return st; }
+    }
+    hipStream_t st = nullptr;                       // the caller has made `device` current
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return st;
+}
+void stream_return(int device, hipStream_t st)
+{
+    if (!st || device < 0 || device >= 64) return;
+    std::lock_guard<std::mutex> g(g_streamLock);
+    g_streamPool[device].push_back(st);
+}
 
 hipError_t device_free(void* p)
 {

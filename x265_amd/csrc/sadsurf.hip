@@ -33,7 +33,7 @@ struct x265hip_srcpic
     int64_t pitch = 0;                  // bytes between rows of dLuma
     char* dLuma = nullptr;
     char* hStage = nullptr;             // page-locked staging copy (the encoder's buffer is ordinary memory)
-    hipStream_t st = nullptr;
+    // (no stream: x265hip_srcpic_upload leases one from the pool, runtime.hip stream_lease)
     std::atomic<int> refs{ 1 };         // the creator's + one per SAD surface attached: a surface reads dLuma and files its buffers under `device` until it is freed,
                                         // so x265hip_srcpic_destroy only drops the creator's reference (a resized source buffer used to free under them)
 };
@@ -773,8 +773,10 @@ static Replica* replica_at(x265hip_refpic* rp, int place)
 // build what the reference's rows allow of every surface in `list` (all attached to rp): per place one launch on that place's stream — the mirror's
 // own for surfaces whose source lives where the mirror does, the replica's otherwise, after the rows the replica does not have yet have been pushed
 // device to device — then the rows come to the host and are published (worker thread; the band's upload has been synchronised)
-static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& list)
+// rowBudget > 0: at most that many CTU rows in all (whole waves of workgroups, sadsurf_rows_arrived); the rest stays pending
+static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& list, int rowBudget = 0)
 {
+    int budget = rowBudget > 0 ? rowBudget : 1 << 30;
     std::vector<Replica*> places(1, nullptr);                // nullptr = the mirror's own place
     for (x265hip_sadsurf* ss : list)
         if (ss->ref == rp && ss->rep)
@@ -803,9 +805,11 @@ static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& li
                     continue;
                 if (a.nJobs && ss->levels != in[0]->levels)
                     break;                                    // another table layout: the next launch
-                const int r1 = rows_possible(ss);
+                int r1 = rows_possible(ss);
+                if (r1 - ss->rowsBuilt > budget) r1 = ss->rowsBuilt + budget;
                 if (r1 == ss->rowsBuilt)
                     continue;
+                budget -= r1 - ss->rowsBuilt;
                 SurfJob& j = a.job[a.nJobs];
                 j.src = (const uint8_t*)ss->src->dLuma; j.srcPitch = ss->src->pitch;
                 j.out = ss->dBuf; j.S = ss->S; j.lambda20 = ss->lambda20; j.row0 = ss->rowsBuilt; j.rows = r1 - ss->rowsBuilt;
@@ -964,6 +968,19 @@ void sadsurf_rows_arrived(x265hip_refpic* rp)
             return;
         }
         rp->ssDeferred = 0;
+        // 148 KB of LDS = one workgroup per CU: a launch takes ceil(CTUs / 256) rounds of the same ~54 us whatever the last round holds (287 CTUs, the
+        // live average of round 4's first measurement, = 2 rounds for 1.12 rounds of work).  While the picture is still arriving, launch whole rounds
+        // only; the newest rows — the ones no search is waiting for yet — stay pending and go with the next band.
+        const int cols = list.empty() ? 0 : list[0]->lay.ctuCols;
+        if (!complete && cols > 0 && cols <= 256 && pending > 256)
+        {
+            const int rowsPerRound = 256 / cols, rows = pending / cols;
+            if (rows >= rowsPerRound && (rows % rowsPerRound) * 4 < rowsPerRound * 3)      // a last round under 3/4 full is not worth its time now
+            {
+                progress(rp, list, rows / rowsPerRound * rowsPerRound);
+                return;
+            }
+        }
     }
     progress(rp, list);
 }
@@ -1064,7 +1081,8 @@ static x265hip_srcpic* srcpic_create(int place, int depth, int width, int height
     (void)hipGetDevice(&sp->device);
     sp->place = place;
     const size_t bytes = (size_t)sp->pitch * height;
-    if (hipStreamCreateWithFlags(&sp->st, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&sp->dLuma, bytes + 256) != hipSuccess ||
+    // no stream of its own (3.9 ms each, ~40 source pictures alive in a 1080p encoder): the upload leases one
+    if (hipMalloc((void**)&sp->dLuma, bytes + 256) != hipSuccess ||
         pinned_alloc((void**)&sp->hStage, bytes) != hipSuccess)
     {
         set_error(X265HIP_ENOMEM, "x265hip_srcpic_create: %zu bytes", bytes);
@@ -1084,8 +1102,14 @@ int x265hip_srcpic_upload(x265hip_srcpic* sp, const void* hostLuma, int64_t stri
     const size_t B = sp->depth == 8 ? 1 : 2;                 // `stride` counts samples, like every stride of the ABI
     for (int y = 0; y < sp->h; y++)
         memcpy(sp->hStage + (size_t)y * sp->pitch, (const char*)hostLuma + (size_t)y * stride * B, sp->w * B);
-    if (!(e = check_hip(hipMemcpyAsync(sp->dLuma, sp->hStage, (size_t)sp->pitch * sp->h, hipMemcpyHostToDevice, sp->st), "srcpic h2d")))
-        e = check_hip(hipStreamSynchronize(sp->st), "srcpic sync");
+    hipStream_t st = stream_lease(sp->device);
+    if (!st) e = set_error(X265HIP_EHIP, "x265hip_srcpic_upload: no stream");
+    else
+    {
+        if (!(e = check_hip(hipMemcpyAsync(sp->dLuma, sp->hStage, (size_t)sp->pitch * sp->h, hipMemcpyHostToDevice, st), "srcpic h2d")))
+            e = check_hip(hipStreamSynchronize(st), "srcpic sync");
+        stream_return(sp->device, st);
+    }
     if (had && cur != sp->device) (void)hipSetDevice(cur);
     return e;
 }
@@ -1102,7 +1126,6 @@ static void srcpic_unref(x265hip_srcpic* sp)
     int cur = 0;
     const bool had = hipGetDevice(&cur) == hipSuccess;
     (void)hipSetDevice(sp->device);
-    if (sp->st) { (void)hipStreamSynchronize(sp->st); (void)hipStreamDestroy(sp->st); }
     if (sp->dLuma) (void)device_free(sp->dLuma);
     if (sp->hStage) (void)pinned_free(sp->hStage);
     if (had && cur != sp->device) (void)hipSetDevice(cur);

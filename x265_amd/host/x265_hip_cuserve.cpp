@@ -101,7 +101,7 @@ std::atomic<bool> g_dead(false); // the device failed once: every later CU is co
 std::atomic<uint64_t> g_cycles[18][2], g_calls[18][2];
 __attribute__((tls_model("initial-exec"))) thread_local int t_inRqt = 0;
 
-struct alignas(64) Counters { std::atomic<uint64_t> jobs, fwd, inv, fwdMiss, invMiss, waitCycles, waits, skipped, dist, psyHit, psyAhead, psyCoded; };
+struct alignas(64) Counters { std::atomic<uint64_t> jobs, fwd, inv, fwdMiss, invMiss, waitCycles, waits, skipped, dist, psyHit, psyAhead, psyCoded, deadSub, deadAdd, lateSub, lateAdd; };
 Counters g_count[64];
 std::atomic<int> g_nextShard(0);
 __attribute__((tls_model("initial-exec"))) thread_local int t_shard = -1;
@@ -124,6 +124,12 @@ struct Job
     uint8_t invServed[X265HIP_CUJOB_MAX_UNITS];          // the unit's reconstructed residual came from the device (so its reconstruction is pred + that)
     uint8_t energyKnown[X265HIP_CUJOB_MAX_UNITS];        // psy_cost_pp(source, prediction) of the unit has been computed on this thread
     int32_t energy[X265HIP_CUJOB_MAX_UNITS];
+    // work of the reference's body whose result no one reads once the job answers (X265HIP_CUSERVE_DIST >= 3): the CU's residual (read only by the
+    // transformNxN calls the job serves) and the tree's reconstructions (read only by the sse_pp / psy-cost calls the job answers).  The call is
+    // remembered, not run; whoever turns out to need the result after all (a unit the job does not serve, a failed device) runs it first.
+    struct PendSub { bool pending; int16_t* dst; intptr_t ds; const pixel* a; const pixel* b; intptr_t sa, sb; pixel_sub_ps_t fn; } pendSub[3];
+    struct PendAdd { bool pending; pixel* dst; intptr_t ds; const pixel* a; const int16_t* b; intptr_t sa, sb; pixel_add_ps_t fn; } pendAdd[X265HIP_CUJOB_MAX_UNITS];
+    bool anyPendAdd, treeMine;
     uint32_t seq;
     int slot;
     Service* svc;
@@ -136,7 +142,7 @@ __attribute__((tls_model("initial-exec"))) thread_local Job t_job;
 __attribute__((tls_model("initial-exec"))) thread_local int t_inEncodeRes = 0;
 EncoderPrimitives g_prev;            // the table as it was when the cuserve slots were installed (C functions + the psy lookups of x265_hip_srcplanes.cpp)
 bool g_slots_installed = false;
-int g_serveDist = 1;                 // X265HIP_CUSERVE_DIST=0: transforms only
+int g_serveDist = 1;                 // X265HIP_CUSERVE_DIST=0: transforms only; 1: + the tree's distortions; 2: + the CU's final sse_pp / psy cost; 3 (default): + the body's sub_ps / add_ps calls nobody reads any more are not run
 __attribute__((tls_model("initial-exec"))) thread_local int t_hint = -1;           // where this thread looks first
 
 void end_job();
@@ -156,11 +162,12 @@ void report_time()
 
 void report()
 {
-    uint64_t jobs = 0, fwd = 0, inv = 0, fm = 0, im = 0, wc = 0, w = 0, sk = 0, di = 0, ph = 0, pa = 0, pc = 0;
+    uint64_t jobs = 0, fwd = 0, inv = 0, fm = 0, im = 0, wc = 0, w = 0, sk = 0, di = 0, ph = 0, pa = 0, pc = 0, dsb = 0, dad = 0, lsb = 0, lad = 0;
     for (int i = 0; i < 64; i++)
     {
         jobs += g_count[i].jobs; fwd += g_count[i].fwd; inv += g_count[i].inv; fm += g_count[i].fwdMiss; im += g_count[i].invMiss;
         wc += g_count[i].waitCycles; w += g_count[i].waits; sk += g_count[i].skipped; di += g_count[i].dist; ph += g_count[i].psyHit; pa += g_count[i].psyAhead; pc += g_count[i].psyCoded;
+        dsb += g_count[i].deadSub; dad += g_count[i].deadAdd; lsb += g_count[i].lateSub; lad += g_count[i].lateAdd;
     }
     uint64_t devJobs = 0, starts = 0, ns = 0;
     for (int k = 0; k < g_nsvc.load(); k++)
@@ -179,6 +186,9 @@ void report()
     fprintf(stderr, "x265hip: cuserve: %llu sse_pp and %llu psy-cost (source, reconstruction) answers out of the jobs; %llu psy-cost (source, prediction) values computed while waiting "
                     "for the device, %llu psy-cost calls answered from values remembered within their encodeResAndCalcRdInterCU\n", (unsigned long long)di, (unsigned long long)pc,
             (unsigned long long)pa, (unsigned long long)ph);
+    if (dsb || dad)
+        fprintf(stderr, "x265hip: cuserve: %llu sub_ps and %llu add_ps calls of those CUs put off because only the job's answers read their results (%llu + %llu run after all)\n",
+                (unsigned long long)dsb, (unsigned long long)dad, (unsigned long long)lsb, (unsigned long long)lad);
 }
 
 bool decide()
@@ -197,7 +207,7 @@ bool decide()
         if (getenv("X265HIP_CUSERVE_MIN")) { const int v = atoi(getenv("X265HIP_CUSERVE_MIN")); g_minLog2 = v >= 64 ? 6 : v >= 32 ? 5 : 4; }
         if (getenv("X265HIP_CUSERVE_MODE")) g_mode = atoi(getenv("X265HIP_CUSERVE_MODE")) ? 1 : 0;
         if (getenv("X265HIP_CUSERVE_SLOTS")) g_slots = atoi(getenv("X265HIP_CUSERVE_SLOTS"));
-        if (getenv("X265HIP_CUSERVE_DIST")) g_serveDist = atoi(getenv("X265HIP_CUSERVE_DIST"));
+        g_serveDist = getenv("X265HIP_CUSERVE_DIST") ? atoi(getenv("X265HIP_CUSERVE_DIST")) : 3;
         if (g_slots < 1) g_slots = 1;
         if (g_slots > 256) g_slots = 256;
         if ((env && !strcmp(env, "0")) || (all && !strcmp(all, "0")) || (table && !strcmp(table, "percall")) || g_time == 1)
@@ -304,6 +314,37 @@ inline int locate(const Job& j, const int16_t* residual, uint32_t resiStride, ui
     return x265hipi_cujob_unit_index(j.job, j.sHi, s, ttype, x >> log2TrSize, y >> log2TrSize);
 }
 
+inline void flush_sub(Job& j)
+{
+    for (int p = 0; p < 3; p++)
+        if (j.pendSub[p].pending)
+        {
+            Job::PendSub& s = j.pendSub[p];
+            s.pending = false;
+            s.fn(s.dst, s.ds, s.a, s.b, s.sa, s.sb);
+            counters().lateSub.fetch_add(1, std::memory_order_relaxed);
+        }
+}
+inline void flush_add(Job& j, int u)
+{
+    Job::PendAdd& a = j.pendAdd[u];
+    if (a.pending)
+    {
+        a.pending = false;
+        a.fn(a.dst, a.ds, a.a, a.b, a.sa, a.sb);
+        counters().lateAdd.fetch_add(1, std::memory_order_relaxed);
+    }
+}
+// the job stops answering (device failure): everything put off is run now, the reference's body goes on as if the job had never been
+inline void abandon(Job& j)
+{
+    flush_sub(j);
+    if (j.anyPendAdd)
+        for (int u = 0; u < X265HIP_CUJOB_MAX_UNITS; u++) flush_add(j, u);
+    j.anyPendAdd = false;
+    j.active = false;
+}
+
 // waits for a ready word of this thread's job to take the job's ticket; false: the device did not deliver (the job is abandoned)
 inline bool wait_word(Job& j, const uint32_t* ready)
 {
@@ -317,7 +358,7 @@ inline bool wait_word(Job& j, const uint32_t* ready)
         {
             if (x265hip_cuserve_poke(j.svc->cs, j.slot) || __builtin_ia32_rdtsc() - t0 > 3000000000ull)      // ~1 s: not a latency, a failure
             {
-                j.active = false;
+                abandon(j);
                 device_failed("a job did not come back");
                 return false;
             }
@@ -401,6 +442,10 @@ bool submit(Search* se, Mode& mode, const CUGeom& cuGeom, ShortYuv& resiYuv, con
     j.psyRd = se->m_rdCost.m_psyRd != 0;
     memset(j.invServed, 0, sizeof(j.invServed));
     memset(j.energyKnown, 0, sizeof(j.energyKnown));
+    j.pendSub[0].pending = j.pendSub[1].pending = j.pendSub[2].pending = false;
+    if (j.anyPendAdd) for (int u = 0; u < X265HIP_CUJOB_MAX_UNITS; u++) j.pendAdd[u].pending = false;
+    j.anyPendAdd = false;
+    j.treeMine = false;
     j.inTree = true;
     j.log2CU = cuGeom.log2CUSize; j.sHi = sHi; j.sLo = sLo; j.slot = slot; j.svc = svc;
     j.job = mem.job; j.units = mem.units; j.levels = mem.levels; j.resiOut = mem.resi;
@@ -415,6 +460,9 @@ void end_job()
 {
     Job& j = t_job;
     bool done = j.active;
+    if (done && !j.treeMine)
+        flush_sub(j);                  // the tree this job was made for never ran: whoever runs instead reads the residual
+    j.pendSub[0].pending = j.pendSub[1].pending = j.pendSub[2].pending = false;
     if (done)
     {
         const int last = x265hipi_cujob_unit_index(j.job, j.sHi, j.sLo, j.resi[1] ? 2 : 0, (1 << (j.log2CU - j.sLo)) - 1, (1 << (j.log2CU - j.sLo)) - 1);
@@ -472,12 +520,12 @@ inline bool job_sse(Job& j, const pixel* a, intptr_t sa, const pixel* b, intptr_
     }
     if (w.s > j.sHi || w.s < j.sLo) return false;
     // against the tree's reconstruction of the unit (search.cpp:3293-3295: add_ps(recon, pred, inverse-transformed residual), then sse_pp(source, recon))
-    const Yuv& rq = j.search->m_rqt[(w.plane ? w.s - 1 : w.s) - 2].reconQtYuv;
+    const Yuv& rq = j.search->m_rqt[w.s - 2].reconQtYuv;
     const uint32_t rs = w.plane ? rq.m_csize : rq.m_size;
     if ((uint32_t)sb != rs || b != rq.m_buf[w.plane] + (size_t)w.y * rs + w.x) return false;
     const int sh = w.plane ? w.s - 1 : w.s;
     const int u = x265hipi_cujob_unit_index(j.job, j.sHi, w.s, w.plane, w.x >> sh, w.y >> sh);
-    if (!j.invServed[u] || !wait_word(j, &j.units[u].readyInv)) return false;
+    if (!j.invServed[u] || !wait_word(j, &j.units[u].readyInv)) { flush_add(j, u); return false; }
     out = j.units[u].codedDist;
     return true;
 }
@@ -489,7 +537,7 @@ inline bool job_sse(Job& j, const pixel* a, intptr_t sa, const pixel* b, intptr_
 template <typename F> inline bool final_sum(Job& j, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb, int n, F unit_value, int64_t& out)
 {
     Where w;
-    if (j.inTree || j.sHi != j.sLo || !where_in_source(j, a, sa, n, w) || w.x || w.y) return false;
+    if (g_serveDist < 2 || j.inTree || j.sHi != j.sLo || !where_in_source(j, a, sa, n, w) || w.x || w.y) return false;
     const int N = (1 << j.log2CU) >> (w.plane ? 1 : 0);
     if (n != N) return false;
     const Yuv& ry = j.mode->reconYuv;
@@ -570,7 +618,7 @@ template <int CU, int N> int psy_slot(const pixel* a, intptr_t sa, const pixel* 
     if (j.active && N >= 8 && where_in_source(j, a, sa, N, w) && w.s <= j.sHi && w.s >= j.sLo)
     {
         // against the tree's reconstruction of a unit whose residual came from the device (search.cpp:3299, :3373): the job measured it
-        const Yuv& rq = j.search->m_rqt[(w.plane ? w.s - 1 : w.s) - 2].reconQtYuv;
+        const Yuv& rq = j.search->m_rqt[w.s - 2].reconQtYuv;
         const uint32_t rs = w.plane ? rq.m_csize : rq.m_size;
         if ((uint32_t)sb == rs && b == rq.m_buf[w.plane] + (size_t)w.y * rs + w.x)
         {
@@ -583,6 +631,7 @@ template <int CU, int N> int psy_slot(const pixel* a, intptr_t sa, const pixel* 
                 counters().psyCoded.fetch_add(1, std::memory_order_relaxed);
                 return v;
             }
+            flush_add(j, u);            // the reconstruction is read on the host after all
         }
     }
     if (j.active && N >= 8 && where_in_source(j, a, sa, N, w) && (uint32_t)sb == j.predStride[w.plane] && b == j.pred[w.plane] + (size_t)w.y * sb + w.x)
@@ -616,6 +665,56 @@ template <int CU, int N> int psy_slot(const pixel* a, intptr_t sa, const pixel* 
         }
     }
     return g_prev.cu[CU].psy_cost_pp(a, sa, b, sb);
+}
+
+
+// the CU's residual = source - prediction (encodeResAndCalcRdInterCU, search.cpp:2838 through ShortYuv::subtract): its only readers are the tree's
+// transformNxN calls, which the job serves from its own copy of source and prediction.  Put off (flush_sub) instead of run.
+template <int CU, int N, bool CHROMA> void sub_ps_slot(int16_t* dst, intptr_t ds, const pixel* a, const pixel* b, intptr_t sa, intptr_t sb)
+{
+    Job& j = t_job;
+    const pixel_sub_ps_t fn = CHROMA ? g_prev.chroma[X265_CSP_I420].cu[CU].sub_ps : g_prev.cu[CU].sub_ps;
+    if (j.active && !j.inTree && !j.treeMine && t_inEncodeRes && g_serveDist >= 3 && !g_verify && (N << (CHROMA ? 1 : 0)) == (1 << j.log2CU))
+        for (int p = CHROMA ? 1 : 0; p < (CHROMA ? 3 : 1); p++)
+            if (dst == j.resi[p] && (uint32_t)ds == j.resiStride[p] && a == j.fenc[p] && (uint32_t)sa == j.fencStride[p] && b == j.pred[p] && (uint32_t)sb == j.predStride[p])
+            {
+                j.pendSub[p] = Job::PendSub{ true, dst, ds, a, b, sa, sb, fn };
+                counters().deadSub.fetch_add(1, std::memory_order_relaxed);
+                return;
+            }
+    fn(dst, ds, a, b, sa, sb);
+}
+
+// a unit's reconstruction in the tree = prediction + the residual the device sent (search.cpp:3314 luma, :3433 chroma): its only readers are the
+// sse_pp and psy-cost calls right after, which the job answers.  Put off (flush_add) instead of run.
+template <int CU, int N, int AL> void add_ps_slot(pixel* dst, intptr_t ds, const pixel* a, const int16_t* b, intptr_t sa, intptr_t sb)
+{
+    Job& j = t_job;
+    if (j.active && j.inTree && g_serveDist >= 3 && !g_verify && !j.search->m_rdCost.m_ssimRd)
+        for (int p = 0; p < 3; p++)
+        {
+            if (!j.pred[p] || (uint32_t)sa != j.predStride[p]) continue;
+            const ptrdiff_t d = a - j.pred[p];
+            const int W = (1 << j.log2CU) >> (p ? 1 : 0);
+            if (d < 0 || d >= (ptrdiff_t)sa * W) continue;
+            const int y = (int)(d / sa), x = (int)(d % sa);
+            if (x >= W || (x & (N - 1)) || (y & (N - 1))) break;
+            int lg = 0;
+            while ((1 << lg) < N) lg++;
+            const int s = p ? lg + 1 : lg;
+            if (s > j.sHi || s < j.sLo) break;
+            const Yuv& rq = j.search->m_rqt[s - 2].reconQtYuv;
+            const ShortYuv& rs = j.search->m_rqt[s - 2].resiQtYuv;
+            const uint32_t rqs = p ? rq.m_csize : rq.m_size, rss = p ? rs.m_csize : rs.m_size;
+            if ((uint32_t)ds != rqs || dst != rq.m_buf[p] + (size_t)y * rqs + x || (uint32_t)sb != rss || b != rs.m_buf[p] + (size_t)y * rss + x) break;
+            const int u = x265hipi_cujob_unit_index(j.job, j.sHi, s, p, x >> lg, y >> lg);
+            if (!j.invServed[u]) break;
+            j.pendAdd[u] = Job::PendAdd{ true, dst, ds, a, b, sa, sb, g_prev.cu[CU].add_ps[AL] };
+            j.anyPendAdd = true;
+            counters().deadAdd.fetch_add(1, std::memory_order_relaxed);
+            return;
+        }
+    g_prev.cu[CU].add_ps[AL](dst, ds, a, b, sa, sb);
 }
 
 // while this thread waits for unit u's forward half: the psy-cost of (source, prediction) of the same unit, which the tree asks for right after
@@ -653,6 +752,16 @@ void x265hip_install_cuserve_slots(EncoderPrimitives& p)
     p.cu[BLOCK_16x16].psy_cost_pp = psy_slot<BLOCK_16x16, 16>;
     p.cu[BLOCK_32x32].psy_cost_pp = psy_slot<BLOCK_32x32, 32>;
     p.cu[BLOCK_64x64].psy_cost_pp = psy_slot<BLOCK_64x64, 64>;
+    if (g_serveDist >= 3)
+    {
+        p.cu[BLOCK_32x32].sub_ps = sub_ps_slot<BLOCK_32x32, 32, false>;
+        p.cu[BLOCK_64x64].sub_ps = sub_ps_slot<BLOCK_64x64, 64, false>;
+        p.chroma[X265_CSP_I420].cu[BLOCK_32x32].sub_ps = sub_ps_slot<BLOCK_32x32, 16, true>;
+        p.chroma[X265_CSP_I420].cu[BLOCK_64x64].sub_ps = sub_ps_slot<BLOCK_64x64, 32, true>;
+        p.cu[BLOCK_8x8].add_ps[0] = add_ps_slot<BLOCK_8x8, 8, 0>;     p.cu[BLOCK_8x8].add_ps[1] = add_ps_slot<BLOCK_8x8, 8, 1>;
+        p.cu[BLOCK_16x16].add_ps[0] = add_ps_slot<BLOCK_16x16, 16, 0>; p.cu[BLOCK_16x16].add_ps[1] = add_ps_slot<BLOCK_16x16, 16, 1>;
+        p.cu[BLOCK_32x32].add_ps[0] = add_ps_slot<BLOCK_32x32, 32, 0>; p.cu[BLOCK_32x32].add_ps[1] = add_ps_slot<BLOCK_32x32, 32, 1>;
+    }
     g_slots_installed = true;
 }
 
@@ -671,7 +780,7 @@ void Search::estimateResidualQT(Mode& mode, const CUGeom& cuGeom, uint32_t absPa
         mine = submit(this, mode, cuGeom, resiYuv, depthRange);
         if (!mine) counters().skipped.fetch_add(1, std::memory_order_relaxed);
     }
-    if (mine) j.inTree = true;
+    if (mine) { j.inTree = true; j.treeMine = true; }
     if (g_time)
     {
         Timed t(8 + cuGeom.log2CUSize - 2);
@@ -771,6 +880,8 @@ uint32_t Quant::transformNxN(const CUData& cu, const pixel* fenc, uint32_t fencS
         else
             counters().fwdMiss.fetch_add(1, std::memory_order_relaxed);
     }
+    if (j.active && j.quant == this)
+        flush_sub(j);                   // this call reads the CU's residual on the host after all
     if (g_time)
     {
         Timed t(log2TrSize - 2);
