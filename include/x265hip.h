@@ -847,7 +847,7 @@ typedef struct x265hip_cujob
     uint32_t bitDepth;            /* 8, 10, 12 */
     uint32_t quantOffset;         /* 171 (I slice) or 85: quant.cpp:466 `add = offset << (qbits - 9)` */
     uint32_t signHide;            /* pps->bSignHideEnabled: signBitHidingHDQ runs on units with numSig >= 2 */
-    uint32_t reserved;
+    uint32_t reserved;            /* 0; non-zero: diagnostic stage stamps in the units' reserved words (tools/micro/cuserve_rt) */
     int32_t  qpRem[3], qpPer[3];  /* Quant::m_qpParam[Y, Cb, Cr] */
     int32_t  quantScale[3];       /* the flat m_quantCoef entry of each plane's rem (scalinglist.cpp:386) */
     int32_t  dequantScale[3];     /* s_invQuantScales[rem] (scalinglist.cpp:130); dequant_normal's scale = dequantScale << per */
@@ -861,7 +861,8 @@ typedef struct x265hip_cujob_unit
     uint32_t readyInv;            /* == the job's ticket once codedDist and the reconstructed residual are in place (the inverse half) */
     uint32_t fwdTicks;            /* diagnostic: 100 MHz device ticks from the job's start to this unit's forward half */
     uint32_t codedEnergy;         /* psy_cost_pp(source, clip(prediction + reconstructed residual)) (reference common/pixel.cpp:726-748); with readyInv, when numSig != 0 */
-    uint32_t reserved[3];
+    uint32_t reserved[3];         /* diagnostic (job.reserved != 0): 16-bit 100 MHz ticks since the job's start, low | high half: [0] chain starts | forward transform
+                                   * done, [1] quantised | sign hiding done, [2] inverse transform done | readyInv issued */
 } x265hip_cujob_unit;
 #define X265HIP_CUJOB_MAX_UNITS   60                       /* 64x64, sizes 32 + 16: 3 * (4 + 16) */
 #define X265HIP_CUJOB_MAX_ELEMS   (2 * 6144)               /* int16 entries of `levels` (and of `resi`) of the largest job */

@@ -48,7 +48,9 @@ static char g_err[256] = "";
 /* X265HIP_EMUL_FAIL=<entry point>[:<n>]: the named entry point fails from its n-th call on (n = 1 when omitted), the way a device that runs out of
  * memory or is lost fails — the bindings must then carry on with the reference's own host code and still produce the reference's bytes
  * (tests/test_fallback.py; SURVEY.md §8b "Errors").  Entry points: la_create, la_set_frame, la_weights, la_put_vectors, la_estimate, refpic_create,
- * refpic_reset, rows_final, source_energy, srcpic_create, srcpic_upload, sadsurf_attach, cuserve_open, cuserve_submit. */
+ * refpic_reset, rows_final, source_energy, srcpic_create, srcpic_upload, sadsurf_attach, cuserve_open, cuserve_submit, cuserve_job (from its n-th job
+ * on the service accepts jobs and never does them: the ready words stay as they are and x265hip_cuserve_poke reports the failure — a device that
+ * dies while a CU is in flight). */
 static int fail_now(const char* name)
 {
     static const char* spec = NULL;
@@ -721,7 +723,7 @@ typedef struct cu_slot
     _Alignas(64) int16_t resi[X265HIP_CUJOB_MAX_ELEMS];
     uint32_t seq;
 } cu_slot;
-struct x265hip_cuserve { int slots, mode; cu_slot* slot; uint64_t jobs; };
+struct x265hip_cuserve { int slots, mode; cu_slot* slot; uint64_t jobs; int lost; };
 int x265hip_cuserve_open(int slots, int mode, x265hip_cuserve** out)
 {
     if (fail_now("cuserve_open")) return X265HIP_ENOMEM;
@@ -760,11 +762,16 @@ int x265hip_cuserve_submit(x265hip_cuserve* cs, int slot, uint32_t* seq)
     if (s->job.log2CUSize < 4 || s->job.log2CUSize > 6 || x265hipi_cujob_levels(&s->job, &sHi, &sLo) < 1) return X265HIP_EINVAL;
     *seq = ++s->seq;
     __atomic_fetch_add(&cs->jobs, 1, __ATOMIC_RELAXED);
+    if (__atomic_load_n(&cs->lost, __ATOMIC_RELAXED) || fail_now("cuserve_job"))
+    {
+        __atomic_store_n(&cs->lost, 1, __ATOMIC_RELAXED);
+        return 0;                       /* accepted, never done */
+    }
     if (s->job.bitDepth == 8) orc_cujob_run_8(&s->job, s->pixels, s->units, s->levels, s->resi, *seq);
     else orc_cujob_run_16(&s->job, (const uint16_t*)s->pixels, s->units, s->levels, s->resi, *seq);
     return 0;
 }
-int x265hip_cuserve_poke(x265hip_cuserve* cs, int slot) { (void)cs; (void)slot; return 0; }
+int x265hip_cuserve_poke(x265hip_cuserve* cs, int slot) { (void)slot; return cs && __atomic_load_n(&cs->lost, __ATOMIC_RELAXED) ? X265HIP_EHIP : 0; }
 int x265hip_cuserve_stats(x265hip_cuserve* cs, uint64_t* jobs, uint64_t* serverStarts, uint64_t* deviceNs)
 {
     if (jobs) *jobs = cs ? cs->jobs : 0;

@@ -25,7 +25,7 @@ POINTS = {
     "refpic_create": ("refplanes", [1, 3]), "refpic_reset": ("refplanes", [1, 4]), "rows_final": ("refplanes", [1, 17]),
     "source_energy": ("srcplanes", [1, 8]), "srcpic_create": ("srcplanes", [1, 3]), "srcpic_upload": ("srcplanes", [1, 5]),
     "sadsurf_attach": ("sadplanes", [1, 4]),
-    "cuserve_open": ("cuserve", [1]), "cuserve_submit": ("cuserve", [1, 50]),
+    "cuserve_open": ("cuserve", [1]), "cuserve_submit": ("cuserve", [1, 50]), "cuserve_job": ("cuserve", [1, 37]),
 }
 OPTIONAL = {"la_put_vectors", "la_weights"}          # not reached by every clip: the byte comparison still counts, the message is not demanded
 

@@ -1,6 +1,7 @@
 // cuserve_rt.cpp — round trip of the PRODUCT's CU residual quad-tree jobs through the C ABI (include/x265hip.h, x265hip_cuserve_*): a host thread
 // fills its slot, submits, and spins on the units' ready words, as x265_amd/host/x265_hip_cuserve.cpp does.  (measurement aid)
-//   cuserve_rt <mode 0|1> [iters]        1, 4 and 16 submitting threads; 32x32 and 64x64 CUs (4:2:0, 8 bit, one transform size)
+//   cuserve_rt <mode 0|1> [iters] [stamps 0|1]   1, 4 and 16 submitting threads; 32x32 and 64x64 CUs (4:2:0, 8 bit, one transform size);
+//                                                stamps 1: the chain's stage stamps (job.reserved, x265hip_cujob_unit::reserved) of the first luma and the first Cb unit
 #include <atomic>
 #include <algorithm>
 #include <chrono>
@@ -15,7 +16,7 @@ static double now_us() { return std::chrono::duration<double, std::micro>(std::c
 
 int main(int argc, char** argv)
 {
-    const int mode = argc > 1 ? atoi(argv[1]) : 1, iters = argc > 2 ? atoi(argv[2]) : 3000;
+    const int mode = argc > 1 ? atoi(argv[1]) : 1, iters = argc > 2 ? atoi(argv[2]) : 3000, stamps = argc > 3 ? atoi(argv[3]) : 0;
     if (x265hip_device_count() < 1 || x265hip_init(0)) { fprintf(stderr, "no device: %s\n", x265hip_last_error()); return 2; }
     x265hip_cuserve* cs = NULL;
     if (x265hip_cuserve_open(16, mode, &cs)) { fprintf(stderr, "open: %s\n", x265hip_last_error()); return 2; }
@@ -24,6 +25,8 @@ int main(int argc, char** argv)
         for (int T : { 1, 4, 16 })
         {
             std::vector<std::vector<double>> lat(T), first(T), dev(T);
+            std::vector<std::vector<double>> st[2][7];
+            for (auto& a : st) for (auto& b : a) b.resize(T);
             std::atomic<int> go(0);
             auto body = [&](int t)
             {
@@ -40,7 +43,7 @@ int main(int argc, char** argv)
                     src[i % bytes] ^= 3;
                     const double t0 = now_us();
                     memset(job, 0, sizeof(*job));
-                    job->log2CUSize = log2cu; job->log2TrMax = 5; job->log2TrMin = 5; job->chroma = 1; job->bitDepth = 8; job->quantOffset = 85; job->signHide = 1;
+                    job->log2CUSize = log2cu; job->log2TrMax = 5; job->log2TrMin = 5; job->chroma = 1; job->bitDepth = 8; job->quantOffset = 85; job->signHide = 1; job->reserved = stamps;
                     for (int p = 0; p < 3; p++) { job->qpRem[p] = 2; job->qpPer[p] = 5; job->quantScale[p] = 20560; job->dequantScale[p] = 51; }
                     memcpy(pixels, src.data(), bytes);
                     uint32_t seq = 0;
@@ -71,6 +74,14 @@ int main(int argc, char** argv)
                     volatile int16_t sink = levels[0] + resi[0]; (void)sink;
                     const double t1 = now_us();
                     if (i >= 100) { lat[t].push_back(t1 - t0); first[t].push_back(tFirst); dev[t].push_back(units[0].fwdTicks * 0.01); }
+                    if (i >= 100 && stamps)
+                        for (int w = 0; w < 2; w++)
+                        {
+                            const x265hip_cujob_unit& un = units[w ? per * per : 0];
+                            const uint32_t v[7] = { un.reserved[0] & 0xffff, un.reserved[0] >> 16, un.reserved[1] & 0xffff, un.reserved[1] >> 16, un.fwdTicks, un.reserved[2] & 0xffff,
+                                                    un.reserved[2] >> 16 };
+                            for (int k = 0; k < 7; k++) st[w][k][t].push_back(v[k] * 0.01);
+                        }
                 }
             };
             std::vector<std::thread> th;
@@ -90,6 +101,20 @@ int main(int argc, char** argv)
             printf("%s, %dx%d CU (4:2:0, 8 bit, 32x32 transforms), %2d thread%s: whole job mean %6.1f us, median %6.1f, p99 %6.1f; first luma unit forward half median %6.1f us (%4.1f us of it on the device, doorbell seen -> ready word issued); %.0f jobs/s in total\n",
                    mode ? "one launch per job" : "resident server   ", 1 << log2cu, 1 << log2cu, T, T > 1 ? "s" : " ", sum / all.size(), all[all.size() / 2],
                    all[(size_t)(all.size() * 0.99)], f[f.size() / 2], dv[dv.size() / 2], (double)T * (iters + 100) / (wall * 1e-6));
+            if (stamps)
+                for (int w = 0; w < 2; w++)
+                {
+                    double med[7];
+                    for (int k = 0; k < 7; k++)
+                    {
+                        std::vector<double> a;
+                        for (auto& v : st[w][k]) a.insert(a.end(), v.begin(), v.end());
+                        std::sort(a.begin(), a.end());
+                        med[k] = a.empty() ? 0 : a[a.size() / 2];
+                    }
+                    printf("      %s unit, us since the doorbell was seen (medians): chain starts %.2f, forward transform done %.2f, quantised %.2f, sign hiding done %.2f, ready issued %.2f, "
+                           "inverse transform done %.2f, readyInv issued %.2f\n", w ? "first Cb  " : "first luma", med[0], med[1], med[2], med[3], med[4], med[5], med[6]);
+                }
             fflush(stdout);
         }
     uint64_t jobs = 0, starts = 0, ns = 0;

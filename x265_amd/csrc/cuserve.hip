@@ -150,8 +150,12 @@ __device__ __forceinline__ PlaneParams plane_params(const x265hip_cujob& j, int 
 //   src / prd: the plane's source and prediction in LDS, `pw` elements per row; the plane has (pw / N)^2 units
 template <typename P, int N>
 __device__ __forceinline__ void tile_chain(TileLds& t, const BOperand (*bop)[64], const P* src, const P* prd, int pw, int u0, int count, const PlaneParams qp,
-                                           bool signHide, x265hip_cujob_unit* units, int unitBase, int16_t* levels, int16_t* resi, int elemBase, uint32_t seq, uint64_t t0)
+                                           bool signHide, x265hip_cujob_unit* units, int unitBase, int16_t* levels, int16_t* resi, int elemBase, uint32_t seq, uint64_t t0, bool stamps)
 {
+    // job.reserved != 0 (tools/micro/cuserve_rt): 100 MHz ticks since the doorbell was seen at six points of the chain, two per reserved word of the unit
+    uint32_t stamp[6] = { 0, 0, 0, 0, 0, 0 };
+#define XH_STAMP(i) do { if (stamps) stamp[i] = (uint32_t)(wall_clock64() - t0) & 0xffffu; } while (0)
+    XH_STAMP(0);
     constexpr int G = (32 / N) * (32 / N);
     constexpr int LPT = N * N / 16;              // lanes per unit: 16 coefficients each in the quantiser, one 4x4 group each in the sign hiding
     constexpr int CGW = N / 4;                   // coefficient groups per row of a unit
@@ -192,6 +196,7 @@ __device__ __forceinline__ void tile_chain(TileLds& t, const BOperand (*bop)[64]
     __builtin_amdgcn_s_waitcnt(0xc07f);
     mfma_pass<N, false>(t.b, t.a, lane, bF, corrF, qp.s2f);
     __builtin_amdgcn_s_waitcnt(0xc07f);
+    XH_STAMP(1);
     // ---- quant (quant_c): levels -> b, deltaU -> c; the transform coefficients stay in a (sign hiding reads their signs)
     int cnt = 0;
     const int qBits8 = qp.qBits - 8;
@@ -215,6 +220,7 @@ __device__ __forceinline__ void tile_chain(TileLds& t, const BOperand (*bop)[64]
     }
     int numSig = group_sum(cnt, LPT);                       // of the unit this lane belongs to (lanes g * LPT .. g * LPT + LPT - 1)
     __builtin_amdgcn_s_waitcnt(0xc07f);
+    XH_STAMP(2);
     // ---- sign-bit hiding (signBitHidingHDQ): lane = coefficient group `cg` (scan order) of unit lane / LPT
     {
         const int g = lane / LPT, cg = lane % LPT;
@@ -294,6 +300,7 @@ __device__ __forceinline__ void tile_chain(TileLds& t, const BOperand (*bop)[64]
         numSig += group_sum(delta, LPT);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
+    XH_STAMP(3);
     // ---- levels out (16 contiguous per lane), dequant_normal -> a
     const int gL = (lane * 16) / (N * N);
     const bool okL = gL < count;
@@ -335,12 +342,23 @@ __device__ __forceinline__ void tile_chain(TileLds& t, const BOperand (*bop)[64]
         un->fwdTicks = (uint32_t)(wall_clock64() - t0);                      // 100 MHz ticks from the job's start to this unit's forward half
         __hip_atomic_store(&un->ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    // no level left in any unit of the tile (the common case of chroma at everyday QPs): nobody asks for these units' inverse half — Quant::invtransformNxN
+    // is only called on a unit with a coded block flag, and codedDist / codedEnergy / the reconstructed residual are defined for numSig != 0 only — so
+    // the half is declared done at once (the host's end-of-scope wait and the next tile of this wave start ~3 us earlier)
+    if (__ballot(okL && numSig != 0) == 0)
+    {
+        if (writer)
+            __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        return;
+    }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     // ---- inverse transform: a -> b -> a
     mfma_pass<N, true>(t.a, t.b, lane, bI, corrI, qp.s1i);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     mfma_pass<N, true>(t.b, t.a, lane, bI, corrI, qp.s2i);
     __builtin_amdgcn_s_waitcnt(0xc07f);
+    XH_STAMP(4);
     // ---- reconstructed residual out; distortion of the coded alternative
     unsigned long long coded = 0;
 #pragma unroll
@@ -395,6 +413,8 @@ __device__ __forceinline__ void tile_chain(TileLds& t, const BOperand (*bop)[64]
     {
         un->codedDist = coded;
         un->codedEnergy = (uint32_t)energy;
+        XH_STAMP(5);
+        if (stamps) { un->reserved[0] = stamp[0] | (stamp[1] << 16); un->reserved[1] = stamp[2] | (stamp[3] << 16); un->reserved[2] = stamp[4] | (stamp[5] << 16); }
         __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -445,9 +465,9 @@ __device__ __forceinline__ void run_tiles(SlotOut* s, JobLds& L, uint32_t seq, u
             {
                 if ((tile & 3) != wv) continue;
                 const int u0 = k * G, count = nUnits - u0 < G ? nUnits - u0 : G;
-                if (log2n == 5) tile_chain<P, 32>(L.tile[wv], L.bop[2], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0);
-                else if (log2n == 4) tile_chain<P, 16>(L.tile[wv], L.bop[1], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0);
-                else tile_chain<P, 8>(L.tile[wv], L.bop[0], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0);
+                if (log2n == 5) tile_chain<P, 32>(L.tile[wv], L.bop[2], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0, j.reserved != 0);
+                else if (log2n == 4) tile_chain<P, 16>(L.tile[wv], L.bop[1], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0, j.reserved != 0);
+                else tile_chain<P, 8>(L.tile[wv], L.bop[0], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0, j.reserved != 0);
             }
         }
     }
@@ -509,7 +529,8 @@ __global__ __launch_bounds__(256) void cu_server_kernel(const SlotIn* ins, SlotO
             for (;;)
             {
                 v = __hip_atomic_load(&sin->doorbell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (v == 0xffffffffu || (blockIdx.x == 0 && __hip_atomic_load(&hostCtl->leave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)))
+                // `leave` lives in host memory (a PCIe read of ~1.5 us): workgroup 0 looks at it every 8th poll only, its doorbell every time
+                if (v == 0xffffffffu || (blockIdx.x == 0 && (polls & 7) == 7 && __hip_atomic_load(&hostCtl->leave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)))
                 {
                     __hip_atomic_store(&ctl->quit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     v = 0xffffffffu;

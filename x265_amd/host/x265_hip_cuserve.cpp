@@ -59,6 +59,7 @@ extern void refEstimateResidualQT(Search* self, Mode& mode, const CUGeom& cuGeom
     asm("_ZN4x2659SearchRef18estimateResidualQTERNS_4ModeERKNS_6CUGeomEjjRNS_8ShortYuvERNS0_4CostEPKji");
 extern void refCheckIntraInInter(Search* self, Mode& intraMode, const CUGeom& cuGeom) asm("_ZN4x2659SearchRef17checkIntraInInterERNS_4ModeERKNS_6CUGeomE");
 extern void refEncodeResAndCalcRdInterCU(Search* self, Mode& interMode, const CUGeom& cuGeom) asm("_ZN4x2656Search29encodeResAndCalcRdInterCUBodyERNS_4ModeERKNS_6CUGeomE");
+extern void refEncodeResAndCalcRdSkipCU(Search* self, Mode& interMode) asm("_ZN4x2656Search28encodeResAndCalcRdSkipCUBodyERNS_4ModeE");
 #if X265_DEPTH == 8
 extern uint32_t refTransformNxN(Quant* self, const CUData& cu, const pixel* fenc, uint32_t fencStride, const int16_t* residual, uint32_t resiStride, coeff_t* coeff,
                                 uint32_t log2TrSize, TextType ttype, uint32_t absPartIdx, bool useTransformSkip)
@@ -101,7 +102,7 @@ std::atomic<bool> g_dead(false); // the device failed once: every later CU is co
 std::atomic<uint64_t> g_cycles[18][2], g_calls[18][2];
 __attribute__((tls_model("initial-exec"))) thread_local int t_inRqt = 0;
 
-struct alignas(64) Counters { std::atomic<uint64_t> jobs, fwd, inv, fwdMiss, invMiss, waitCycles, waits, skipped, dist, psyHit, psyAhead, psyCoded, deadSub, deadAdd, lateSub, lateAdd; };
+struct alignas(64) Counters { std::atomic<uint64_t> jobs, fwd, inv, fwdMiss, invMiss, waitCycles, waits, skipped, dist, psyHit, psyAhead, psyCoded, deadSub, deadAdd, lateSub, lateAdd, siteWaits[6], siteCycles[6], spec, specHit, psySkip; };
 Counters g_count[64];
 std::atomic<int> g_nextShard(0);
 __attribute__((tls_model("initial-exec"))) thread_local int t_shard = -1;
@@ -130,6 +131,10 @@ struct Job
     struct PendSub { bool pending; int16_t* dst; intptr_t ds; const pixel* a; const pixel* b; intptr_t sa, sb; pixel_sub_ps_t fn; } pendSub[3];
     struct PendAdd { bool pending; pixel* dst; intptr_t ds; const pixel* a; const int16_t* b; intptr_t sa, sb; pixel_add_ps_t fn; } pendAdd[X265HIP_CUJOB_MAX_UNITS];
     bool anyPendAdd, treeMine;
+    // 0: submitted ahead of its encodeResAndCalcRdInterCU (from encodeResAndCalcRdSkipCU, see there): nothing is answered yet; 1: inside the scope
+    int phase;
+    const Yuv* fencYuv;                  // the source Yuv the pixels were taken from
+    x265hip_cujob hdr;                   // what was submitted (an adopted job must be the job the scope would submit itself)
     uint32_t seq;
     int slot;
     Service* svc;
@@ -142,6 +147,7 @@ __attribute__((tls_model("initial-exec"))) thread_local Job t_job;
 __attribute__((tls_model("initial-exec"))) thread_local int t_inEncodeRes = 0;
 EncoderPrimitives g_prev;            // the table as it was when the cuserve slots were installed (C functions + the psy lookups of x265_hip_srcplanes.cpp)
 bool g_slots_installed = false;
+bool g_spec = true;                  // X265HIP_CUSERVE_SPEC=0: no job is submitted ahead of its scope
 int g_serveDist = 1;                 // X265HIP_CUSERVE_DIST=0: transforms only; 1: + the tree's distortions; 2: + the CU's final sse_pp / psy cost; 3 (default): + the body's sub_ps / add_ps calls nobody reads any more are not run
 __attribute__((tls_model("initial-exec"))) thread_local int t_hint = -1;           // where this thread looks first
 
@@ -162,12 +168,12 @@ void report_time()
 
 void report()
 {
-    uint64_t jobs = 0, fwd = 0, inv = 0, fm = 0, im = 0, wc = 0, w = 0, sk = 0, di = 0, ph = 0, pa = 0, pc = 0, dsb = 0, dad = 0, lsb = 0, lad = 0;
+    uint64_t jobs = 0, fwd = 0, inv = 0, fm = 0, im = 0, wc = 0, w = 0, sk = 0, di = 0, ph = 0, pa = 0, pc = 0, dsb = 0, dad = 0, lsb = 0, lad = 0, spc = 0, sph = 0, pss = 0;
     for (int i = 0; i < 64; i++)
     {
         jobs += g_count[i].jobs; fwd += g_count[i].fwd; inv += g_count[i].inv; fm += g_count[i].fwdMiss; im += g_count[i].invMiss;
         wc += g_count[i].waitCycles; w += g_count[i].waits; sk += g_count[i].skipped; di += g_count[i].dist; ph += g_count[i].psyHit; pa += g_count[i].psyAhead; pc += g_count[i].psyCoded;
-        dsb += g_count[i].deadSub; dad += g_count[i].deadAdd; lsb += g_count[i].lateSub; lad += g_count[i].lateAdd;
+        dsb += g_count[i].deadSub; dad += g_count[i].deadAdd; lsb += g_count[i].lateSub; lad += g_count[i].lateAdd; spc += g_count[i].spec; sph += g_count[i].specHit; pss += g_count[i].psySkip;
     }
     uint64_t devJobs = 0, starts = 0, ns = 0;
     for (int k = 0; k < g_nsvc.load(); k++)
@@ -186,6 +192,22 @@ void report()
     fprintf(stderr, "x265hip: cuserve: %llu sse_pp and %llu psy-cost (source, reconstruction) answers out of the jobs; %llu psy-cost (source, prediction) values computed while waiting "
                     "for the device, %llu psy-cost calls answered from values remembered within their encodeResAndCalcRdInterCU\n", (unsigned long long)di, (unsigned long long)pc,
             (unsigned long long)pa, (unsigned long long)ph);
+    {
+        static const char* const site[6] = { "luma forward half", "chroma forward half", "luma inverse half", "chroma inverse half", "distortion / psy answers", "end of the CU's scope" };
+        char line[512];
+        int n = 0;
+        for (int k = 0; k < 6; k++)
+        {
+            uint64_t ws = 0, cy = 0;
+            for (int i = 0; i < 64; i++) { ws += g_count[i].siteWaits[k]; cy += g_count[i].siteCycles[k]; }
+            n += snprintf(line + n, sizeof(line) - n, "%s%s %llu x %.0f", k ? ", " : "", site[k], (unsigned long long)ws, ws ? (double)cy / ws : 0.0);
+        }
+        if (w) fprintf(stderr, "x265hip: cuserve: waits by what was waited for (count x cycles): %s\n", line);
+    }
+    if (spc)
+        fprintf(stderr, "x265hip: cuserve: %llu jobs left ahead of their scope, when the merge candidate's skip evaluation started; %llu of them were the job their "
+                        "encodeResAndCalcRdInterCU wanted, %llu psy-costs of the skip evaluation served the tree as well\n", (unsigned long long)spc, (unsigned long long)sph,
+                (unsigned long long)pss);
     if (dsb || dad)
         fprintf(stderr, "x265hip: cuserve: %llu sub_ps and %llu add_ps calls of those CUs put off because only the job's answers read their results (%llu + %llu run after all)\n",
                 (unsigned long long)dsb, (unsigned long long)dad, (unsigned long long)lsb, (unsigned long long)lad);
@@ -207,6 +229,7 @@ bool decide()
         if (getenv("X265HIP_CUSERVE_MIN")) { const int v = atoi(getenv("X265HIP_CUSERVE_MIN")); g_minLog2 = v >= 64 ? 6 : v >= 32 ? 5 : 4; }
         if (getenv("X265HIP_CUSERVE_MODE")) g_mode = atoi(getenv("X265HIP_CUSERVE_MODE")) ? 1 : 0;
         if (getenv("X265HIP_CUSERVE_SLOTS")) g_slots = atoi(getenv("X265HIP_CUSERVE_SLOTS"));
+        if (getenv("X265HIP_CUSERVE_SPEC")) g_spec = atoi(getenv("X265HIP_CUSERVE_SPEC")) != 0;
         g_serveDist = getenv("X265HIP_CUSERVE_DIST") ? atoi(getenv("X265HIP_CUSERVE_DIST")) : 3;
         if (g_slots < 1) g_slots = 1;
         if (g_slots > 256) g_slots = 256;
@@ -346,7 +369,9 @@ inline void abandon(Job& j)
 }
 
 // waits for a ready word of this thread's job to take the job's ticket; false: the device did not deliver (the job is abandoned)
-inline bool wait_word(Job& j, const uint32_t* ready)
+// site: 0 luma forward half (transformNxN), 1 chroma forward half, 2 luma inverse half (invtransformNxN), 3 chroma inverse half, 4 a distortion / psy answer,
+// 5 the end of the job's scope (every unit's inverse half, so that the slot can go back)
+inline bool wait_word(Job& j, const uint32_t* ready, int site)
 {
     if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == j.seq) return true;
     const uint64_t t0 = __builtin_ia32_rdtsc();
@@ -365,8 +390,11 @@ inline bool wait_word(Job& j, const uint32_t* ready)
         }
     }
     Counters& c = counters();
-    c.waitCycles.fetch_add(__builtin_ia32_rdtsc() - t0, std::memory_order_relaxed);
+    const uint64_t dt = __builtin_ia32_rdtsc() - t0;
+    c.waitCycles.fetch_add(dt, std::memory_order_relaxed);
     c.waits.fetch_add(1, std::memory_order_relaxed);
+    c.siteCycles[site].fetch_add(dt, std::memory_order_relaxed);
+    c.siteWaits[site].fetch_add(1, std::memory_order_relaxed);
     return true;
 }
 
@@ -382,8 +410,8 @@ struct Timed
     }
 };
 
-// the job of one CU: header + pixels into this thread's slot, submit
-bool submit(Search* se, Mode& mode, const CUGeom& cuGeom, ShortYuv& resiYuv, const uint32_t depthRange[2])
+// the header of the job this CU's residual quad-tree is; false: not a CU the device serves
+bool make_header(Search* se, const Mode& mode, uint32_t log2CUSize, const uint32_t depthRange[2], x265hip_cujob& hdr)
 {
     const CUData& cu = mode.cu;
     const Quant& q = se->m_quant;
@@ -392,12 +420,30 @@ bool submit(Search* se, Mode& mode, const CUGeom& cuGeom, ShortYuv& resiYuv, con
     if (cu.m_tqBypass[0] || q.m_rdoqLevel || (q.m_nr && q.m_nr->offset) || q.m_scalingList->m_bEnabled || (csp != X265_CSP_I420 && csp != X265_CSP_I400) ||
         (csp == X265_CSP_I420) != codeChroma)
         return false;
-    x265hip_cujob hdr;
-    hdr.log2CUSize = cuGeom.log2CUSize; hdr.log2TrMax = depthRange[1]; hdr.log2TrMin = depthRange[0];
+    memset(&hdr, 0, sizeof(hdr));
+    hdr.log2CUSize = log2CUSize; hdr.log2TrMax = depthRange[1]; hdr.log2TrMin = depthRange[0];
     hdr.chroma = codeChroma; hdr.bitDepth = X265_DEPTH;
     hdr.quantOffset = cu.m_slice->m_sliceType == I_SLICE ? 171 : 85;
     hdr.signHide = cu.m_slice->m_pps->bSignHideEnabled;
     hdr.reserved = 0;
+    for (int p = 0; p < 3; p++)
+    {
+        const QpParam& qp = q.m_qpParam[p];
+        hdr.qpRem[p] = qp.rem; hdr.qpPer[p] = qp.per;
+        hdr.quantScale[p] = q.m_scalingList->m_quantCoef[3][3 + p][qp.rem][0];          // flat: every entry of every size and list is s_quantScales[rem]
+        hdr.dequantScale[p] = ScalingList::s_invQuantScales[qp.rem];
+    }
+    return true;
+}
+
+// the job of one CU: header + pixels into this thread's slot, submit
+bool submit(Search* se, Mode& mode, uint32_t log2CUSize, ShortYuv& resiYuv, const uint32_t depthRange[2])
+{
+    const Quant& q = se->m_quant;
+    x265hip_cujob hdr;
+    if (!make_header(se, mode, log2CUSize, depthRange, hdr))
+        return false;
+    const bool codeChroma = hdr.chroma != 0;
     int sHi, sLo;
     if (x265hipi_cujob_levels(&hdr, &sHi, &sLo) < 1 || !service())
         return false;
@@ -406,14 +452,7 @@ bool submit(Search* se, Mode& mode, const CUGeom& cuGeom, ShortYuv& resiYuv, con
     if (slot < 0)
         return false;
     const SlotMem& mem = svc->mem[slot];
-    for (int p = 0; p < 3; p++)
-    {
-        const QpParam& qp = q.m_qpParam[p];
-        hdr.qpRem[p] = qp.rem; hdr.qpPer[p] = qp.per;
-        hdr.quantScale[p] = q.m_scalingList->m_quantCoef[3][3 + p][qp.rem][0];          // flat: every entry of every size and list is s_quantScales[rem]
-        hdr.dequantScale[p] = ScalingList::s_invQuantScales[qp.rem];
-    }
-    const int N = 1 << cuGeom.log2CUSize;
+    const int N = 1 << log2CUSize;
     const Yuv* fenc = mode.fencYuv;
     const Yuv* pred = &mode.predYuv;
     *mem.job = hdr;
@@ -432,6 +471,9 @@ bool submit(Search* se, Mode& mode, const CUGeom& cuGeom, ShortYuv& resiYuv, con
     j.quant = &q;
     j.search = se;
     j.mode = &mode;
+    j.phase = 1;
+    j.fencYuv = fenc;
+    j.hdr = hdr;
     for (int p = 0; p < 3; p++)
     {
         j.resi[p] = resiYuv.m_buf[p]; j.resiStride[p] = p ? resiYuv.m_csize : resiYuv.m_size;
@@ -447,7 +489,7 @@ bool submit(Search* se, Mode& mode, const CUGeom& cuGeom, ShortYuv& resiYuv, con
     j.anyPendAdd = false;
     j.treeMine = false;
     j.inTree = true;
-    j.log2CU = cuGeom.log2CUSize; j.sHi = sHi; j.sLo = sLo; j.slot = slot; j.svc = svc;
+    j.log2CU = log2CUSize; j.sHi = sHi; j.sLo = sLo; j.slot = slot; j.svc = svc;
     j.job = mem.job; j.units = mem.units; j.levels = mem.levels; j.resiOut = mem.resi;
     j.active = true;
     counters().jobs.fetch_add(1, std::memory_order_relaxed);
@@ -467,7 +509,7 @@ void end_job()
     {
         const int last = x265hipi_cujob_unit_index(j.job, j.sHi, j.sLo, j.resi[1] ? 2 : 0, (1 << (j.log2CU - j.sLo)) - 1, (1 << (j.log2CU - j.sLo)) - 1);
         for (int u = 0; u <= last && done; u++)
-            done = wait_word(j, &j.units[u].readyInv);
+            done = wait_word(j, &j.units[u].readyInv, 5);
     }
     j.active = false;
     j.inTree = false;
@@ -512,7 +554,7 @@ inline bool job_sse(Job& j, const pixel* a, intptr_t sa, const pixel* b, intptr_
             for (int tx = 0; tx < k; tx++)
             {
                 const int u = x265hipi_cujob_unit_index(j.job, j.sHi, s, w.plane, (w.x >> sh) + tx, (w.y >> sh) + ty);
-                if (!wait_word(j, &j.units[u].ready)) return false;
+                if (!wait_word(j, &j.units[u].ready, 4)) return false;
                 sum += j.units[u].zeroDist;
             }
         out = sum;
@@ -525,7 +567,7 @@ inline bool job_sse(Job& j, const pixel* a, intptr_t sa, const pixel* b, intptr_
     if ((uint32_t)sb != rs || b != rq.m_buf[w.plane] + (size_t)w.y * rs + w.x) return false;
     const int sh = w.plane ? w.s - 1 : w.s;
     const int u = x265hipi_cujob_unit_index(j.job, j.sHi, w.s, w.plane, w.x >> sh, w.y >> sh);
-    if (!j.invServed[u] || !wait_word(j, &j.units[u].readyInv)) { flush_add(j, u); return false; }
+    if (!j.invServed[u] || !wait_word(j, &j.units[u].readyInv, 4)) { flush_add(j, u); return false; }
     out = j.units[u].codedDist;
     return true;
 }
@@ -563,8 +605,8 @@ inline bool final_sse(Job& j, const pixel* a, intptr_t sa, const pixel* b, intpt
 {
     int64_t v;
     if (!final_sum(j, a, sa, b, sb, n, [&j](int u, bool cbf, int64_t& val) {
-            if (cbf) { if (!j.invServed[u] || !wait_word(j, &j.units[u].readyInv)) return false; val = (int64_t)j.units[u].codedDist; }
-            else { if (!wait_word(j, &j.units[u].ready)) return false; val = (int64_t)j.units[u].zeroDist; }
+            if (cbf) { if (!j.invServed[u] || !wait_word(j, &j.units[u].readyInv, 4)) return false; val = (int64_t)j.units[u].codedDist; }
+            else { if (!wait_word(j, &j.units[u].ready, 4)) return false; val = (int64_t)j.units[u].zeroDist; }
             return true; }, v))
         return false;
     out = (uint64_t)v;
@@ -574,7 +616,7 @@ inline bool final_psy(Job& j, const pixel* a, intptr_t sa, const pixel* b, intpt
 {
     int64_t v;
     if (!final_sum(j, a, sa, b, sb, n, [&j](int u, bool cbf, int64_t& val) {
-            if (cbf) { if (!j.invServed[u] || !wait_word(j, &j.units[u].readyInv)) return false; val = (int64_t)j.units[u].codedEnergy; }
+            if (cbf) { if (!j.invServed[u] || !wait_word(j, &j.units[u].readyInv, 4)) return false; val = (int64_t)j.units[u].codedEnergy; }
             else { if (!j.energyKnown[u]) return false; val = j.energy[u]; }
             return true; }, v))
         return false;
@@ -585,7 +627,7 @@ inline bool final_psy(Job& j, const pixel* a, intptr_t sa, const pixel* b, intpt
 template <int CU, int N, bool CHROMA> sse_t sse_slot(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
 {
     Job& j = t_job;
-    if (j.active)
+    if (j.active && j.phase)
     {
         uint64_t v;
         if (job_sse(j, a, sa, b, sb, N, v) || final_sse(j, a, sa, b, sb, N, v))
@@ -609,6 +651,20 @@ template <int CU, int N> int psy_slot(const pixel* a, intptr_t sa, const pixel* 
     Job& j = t_job;
     Where w;
     int fin;
+    if (j.active && !j.phase)
+    {
+        // inside the encodeResAndCalcRdSkipCU the job was submitted from: its psy-cost of (source, reconstruction = a copy of the prediction,
+        // search.cpp:2786) is the value the residual quad-tree asks for again as (source, prediction) of the CU's only luma unit (search.cpp:3290)
+        if (N == (1 << j.log2CU) && j.sHi == (int)j.log2CU && j.psyRd && a == j.fenc[0] && (uint32_t)sa == j.fencStride[0] && b == j.mode->reconYuv.m_buf[0] &&
+            (uint32_t)sb == j.mode->reconYuv.m_size)
+        {
+            const int v = g_prev.cu[CU].psy_cost_pp(a, sa, b, sb);
+            const int u = x265hipi_cujob_unit_index(j.job, j.sHi, j.sHi, 0, 0, 0);
+            j.energy[u] = v; j.energyKnown[u] = 2;
+            return v;
+        }
+        return g_prev.cu[CU].psy_cost_pp(a, sa, b, sb);
+    }
     if (j.active && N >= 8 && final_psy(j, a, sa, b, sb, N, fin))
     {
         if (g_verify && g_prev.cu[CU].psy_cost_pp(a, sa, b, sb) != fin) { fprintf(stderr, "x265hip: cuserve: VERIFY FAILED psy_cost_pp(source, final reconstruction) %dx%d\n", N, N); abort(); }
@@ -624,7 +680,7 @@ template <int CU, int N> int psy_slot(const pixel* a, intptr_t sa, const pixel* 
         {
             const int sh = w.plane ? w.s - 1 : w.s;
             const int u = x265hipi_cujob_unit_index(j.job, j.sHi, w.s, w.plane, w.x >> sh, w.y >> sh);
-            if (j.invServed[u] && wait_word(j, &j.units[u].readyInv))
+            if (j.invServed[u] && wait_word(j, &j.units[u].readyInv, 4))
             {
                 const int v = (int)j.units[u].codedEnergy;
                 if (g_verify && g_prev.cu[CU].psy_cost_pp(a, sa, b, sb) != v) { fprintf(stderr, "x265hip: cuserve: VERIFY FAILED psy_cost_pp(source, reconstruction) %dx%d\n", N, N); abort(); }
@@ -771,13 +827,13 @@ void Search::estimateResidualQT(Mode& mode, const CUGeom& cuGeom, uint32_t absPa
     // only the top-level call arrives here (the reference body recurses into its own copy).  Normally the job is already on its way: it was submitted
     // when encodeResAndCalcRdInterCU was entered (below), before the host even computed the residual
     Job& j = t_job;
-    bool mine = j.active && !tuDepth && !absPartIdx && j.resi[0] == resiYuv.m_buf[0] && (int)j.job->log2TrMax == (int)depthRange[1] &&
+    bool mine = j.active && j.phase && !tuDepth && !absPartIdx && j.resi[0] == resiYuv.m_buf[0] && (int)j.job->log2TrMax == (int)depthRange[1] &&
                 (int)j.job->log2TrMin == (int)depthRange[0];
     if (j.active && !mine)
         end_job();                      // a tree this job was not made for (never seen): nothing of it is used
     if (!mine && g_state > 0 && !g_dead.load(std::memory_order_relaxed) && (int)cuGeom.log2CUSize >= g_minLog2 && !tuDepth && !absPartIdx)
     {
-        mine = submit(this, mode, cuGeom, resiYuv, depthRange);
+        mine = submit(this, mode, cuGeom.log2CUSize, resiYuv, depthRange);
         if (!mine) counters().skipped.fetch_add(1, std::memory_order_relaxed);
     }
     if (mine) { j.inTree = true; j.treeMine = true; }
@@ -800,15 +856,76 @@ void Search::estimateResidualQT(Mode& mode, const CUGeom& cuGeom, uint32_t absPa
 
 // The scope of a job's remembered values: one call of encodeResAndCalcRdInterCU (reference search.cpp:2822-2975).  Inside it nobody writes the mode's
 // source or prediction block, nor — after the tree — the tree's reconstruction buffers.  The reference's body runs under its renamed symbol.
+// is the job submitted ahead (phase 0) the job this scope would submit?  Same search object, source Yuv, residual buffer and header, and a prediction with
+// the same samples as the one the job took (the merge path hands encodeResAndCalcRdInterCU a COPY of it, analysis.cpp:2864): then it becomes this scope's job
+bool adopt(Search* se, Mode& mode, const CUGeom& cuGeom)
+{
+    Job& j = t_job;
+    uint32_t range[2];
+    mode.cu.getInterTUQtDepthRange(range, 0);
+    x265hip_cujob hdr;
+    if (j.search != se || j.fencYuv != mode.fencYuv || j.log2CU != cuGeom.log2CUSize || j.resi[0] != se->m_rqt[cuGeom.depth].tmpResiYuv.m_buf[0] ||
+        !make_header(se, mode, cuGeom.log2CUSize, range, hdr) || memcmp(&hdr, &j.hdr, sizeof(hdr)))
+        return false;
+    const Yuv& pred = mode.predYuv;
+    const int N = 1 << j.log2CU;
+    for (int p = 0; p < (j.pred[1] ? 3 : 1); p++)
+    {
+        const int n = p ? N / 2 : N;
+        const uint32_t st = p ? pred.m_csize : pred.m_size;
+        if (pred.m_buf[p] != j.pred[p])
+            for (int y = 0; y < n; y++)
+                if (memcmp(pred.m_buf[p] + (size_t)y * st, j.pred[p] + (size_t)y * j.predStride[p], sizeof(pixel) * n))
+                    return false;
+    }
+    for (int p = 0; p < (j.pred[1] ? 3 : 1); p++) { j.pred[p] = pred.m_buf[p]; j.predStride[p] = p ? pred.m_csize : pred.m_size; }
+    j.mode = &mode;
+    j.phase = 1;
+    // an energy remembered from the skip evaluation is the (source, prediction) energy now
+    for (int u = 0; u < X265HIP_CUJOB_MAX_UNITS; u++) if (j.energyKnown[u] == 2) { j.energyKnown[u] = 1; counters().psySkip.fetch_add(1, std::memory_order_relaxed); }
+    return true;
+}
+
+// Merge candidates at rd levels 1..4 (Analysis::checkMerge2Nx2N_rd0_4, analysis.cpp:2846-2866): the best candidate is evaluated as a skip —
+// encodeResAndCalcRdSkipCU, a few microseconds of distortions, psy-cost and bits — and then ALWAYS with its residual, encodeResAndCalcRdInterCU on a copy
+// of the same prediction.  The prediction is final when the skip evaluation starts: the job leaves there, and the device works on it while this thread
+// evaluates the skip.  Nothing is answered from the job before its own scope starts (phase 0); a job whose scope never comes is dropped at the next
+// call of either function.
+void Search::encodeResAndCalcRdSkipCU(Mode& interMode)
+{
+    Job& j = t_job;
+    if (j.active && !t_inEncodeRes)
+        end_job();
+    const uint32_t log2CU = interMode.cu.m_log2CUSize[0];
+    if (g_spec && g_state > 0 && !g_dead.load(std::memory_order_relaxed) && (int)log2CU >= g_minLog2 && !j.active && !t_inEncodeRes && m_param->rdLevel >= 1 &&
+        m_param->rdLevel <= 4 && !m_param->bLossless && !m_param->interRefine && !m_param->bDynamicRefine)
+    {
+        uint32_t range[2];
+        interMode.cu.getInterTUQtDepthRange(range, 0);
+        if (submit(this, interMode, log2CU, m_rqt[interMode.cu.m_cuDepth[0]].tmpResiYuv, range))
+        {
+            j.inTree = false;
+            j.phase = 0;
+            counters().spec.fetch_add(1, std::memory_order_relaxed);
+        }
+    }
+    refEncodeResAndCalcRdSkipCU(this, interMode);
+}
+
 void Search::encodeResAndCalcRdInterCU(Mode& interMode, const CUGeom& cuGeom)
 {
     t_inEncodeRes++;
+    if (t_job.active && !t_job.phase)
+    {
+        if (adopt(this, interMode, cuGeom)) counters().specHit.fetch_add(1, std::memory_order_relaxed);
+        else end_job();
+    }
     if (g_state > 0 && !g_dead.load(std::memory_order_relaxed) && (int)cuGeom.log2CUSize >= g_minLog2 && !t_job.active)
     {
         // the job leaves now: the device fetches source and prediction while this thread still subtracts them (search.cpp:2838) and sets the tree up
         uint32_t range[2];
         interMode.cu.getInterTUQtDepthRange(range, 0);
-        if (!submit(this, interMode, cuGeom, m_rqt[cuGeom.depth].tmpResiYuv, range))
+        if (!submit(this, interMode, cuGeom.log2CUSize, m_rqt[cuGeom.depth].tmpResiYuv, range))
             counters().skipped.fetch_add(1, std::memory_order_relaxed);
         else
             t_job.inTree = false;
@@ -852,7 +969,7 @@ uint32_t Quant::transformNxN(const CUData& cu, const pixel* fenc, uint32_t fencS
                     for (int p = 1; p <= 2 && __atomic_load_n(&j.units[u].ready, __ATOMIC_ACQUIRE) != j.seq; p++)
                         psy_ahead(j, x265hipi_cujob_unit_index(j.job, j.sHi, (int)log2TrSize, p, x >> log2TrSize, y >> log2TrSize), p, x >> 1, y >> 1, n >> 1);
             }
-            if (wait_word(j, &j.units[u].ready))
+            if (wait_word(j, &j.units[u].ready, ttype == TEXT_LUMA ? 0 : 1))
             {
                 const int n2 = 1 << (2 * log2TrSize);
                 memcpy(coeff, j.levels + eo, sizeof(coeff_t) * n2);
@@ -909,7 +1026,7 @@ void Quant::invtransformNxN(const CUData& cu, int16_t* residual, uint32_t resiSt
                 const x265hip_cujob_unit& un = j.units[first + t];
                 if (__atomic_load_n(&un.ready, __ATOMIC_ACQUIRE) != j.seq || un.numSig != numSig || memcmp(coeff, j.levels + eo0 + t * n2, sizeof(coeff_t) * n2))
                     continue;
-                if (!wait_word(j, &un.readyInv))
+                if (!wait_word(j, &un.readyInv, ttype == TEXT_LUMA ? 2 : 3))
                     break;
                 const int16_t* src = j.resiOut + eo0 + t * n2;
                 for (int y = 0; y < n; y++)
