@@ -861,11 +861,15 @@ def main():
             ach = cu["algorithmic_bytes"] / secs / 1e9
             cu_block = {"bound": "latency", "kernel": "cu_server_kernel, live in the timed encode (%s): %d jobs = the transform arithmetic (MFMA dct -> quant -> sign-bit hiding -> dequant -> MFMA "
                                                       "idct -> two SSEs) of the residual quad-trees of %d CUs >= %dx%d, %d forward and %d inverse units served to Quant::transformNxN / "
-                                                      "invtransformNxN; one workgroup per mailbox slot, data path host memory -> LDS -> host memory over PCIe (never HBM)"
+                                                      "invtransformNxN; one workgroup per mailbox slot; data path: the host writes header + pixels into the slot's device-memory half through the large BAR (posted PCIe writes), "
+                                                      "the workgroup reads them HBM -> LDS, results go LDS -> page-locked host memory (posted writes again)"
                                                       % (c["handoff"], c["jobs"], c["jobs"], c["min_cu"], c["min_cu"], c["forward_units"], c["inverse_units"]),
                         "achieved": round(ach, 3), "peak": PCIE_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / PCIE_PEAK_GBPS, 5), "traffic": None,
-                        "peak_note": "PCIe Gen5 x16, one direction; the job is a dependent chain (doorbell -> one read round trip -> four MFMA passes -> write -> fence -> ready "
-                                     "word) and its figure of merit is the round trip: profiles/r04_*_cuserve_rt.txt (9.7 us to the first luma unit, 14.7 us per 32x32 CU job)",
+                        "peak_note": "PCIe Gen5 x16, one direction; the job is a dependent chain (doorbell seen -> header + pixels from HBM -> two MFMA passes -> quantise -> sign hiding "
+                                     "-> levels out -> ready word -> two MFMA passes -> reconstruction, SSE, psy energy -> ready word) run by one wave per transform unit, and its "
+                                     "figure of merit is the round trip, not bytes per second: profiles/r04_*_cuserve_rt*.txt (7.6 us from submit to the first luma unit's forward "
+                                     "half, 4.0 us of it on the device; 12.2 us per 32x32 CU job; stage by stage in *_cuserve_rt_stamps.txt), against a transport floor of 2.4-2.9 us "
+                                     "for an empty ping-pong on this box (profiles/r04_*_bar_mailbox_breakdown.txt)",
                         "busy_us_per_job": round(cu["ms"] * 1e3 / c["jobs"], 2), "algorithmic_bytes_per_job": int(cu["algorithmic_bytes"] / c["jobs"]),
                         "hbm": {"achieved": round(ach, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 6),
                                 "note": "SURVEY 8d fused-chain bytes of the units (source + prediction in, levels + reconstructed residual out) / busy time of ONE workgroup"},

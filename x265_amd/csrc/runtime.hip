@@ -92,6 +92,23 @@ int place_of_device(int device) { return -(device + 1); }
 
 static std::atomic<uint64_t> g_clkSpans[X265HIP_CLK_COUNT], g_clkNs[X265HIP_CLK_COUNT], g_clkBytes[X265HIP_CLK_COUNT];
 
+static std::atomic<int> g_residentWgs{ 0 };
+void resident_workgroups(int delta) { g_residentWgs += delta; }
+int free_compute_units(int device)
+{
+    static std::atomic<int> cus[64];
+    if (device < 0 || device >= 64) return 256;
+    int n = cus[device].load();
+    if (!n)
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v < 1) { (void)hipGetLastError(); v = 256; }
+        cus[device] = n = v;
+    }
+    const int left = n - g_residentWgs.load();
+    return left > n / 4 ? left : n / 4;
+}
+
 static std::mutex g_streamLock;
 static std::vector<hipStream_t> g_streamPool[64];
 hipStream_t stream_lease(int device)

@@ -773,10 +773,28 @@ static Replica* replica_at(x265hip_refpic* rp, int place)
 // build what the reference's rows allow of every surface in `list` (all attached to rp): per place one launch on that place's stream — the mirror's
 // own for surfaces whose source lives where the mirror does, the replica's otherwise, after the rows the replica does not have yet have been pushed
 // device to device — then the rows come to the host and are published (worker thread; the band's upload has been synchronised)
-// rowBudget > 0: at most that many CTU rows in all (whole waves of workgroups, sadsurf_rows_arrived); the rest stays pending
-static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& list, int rowBudget = 0)
+// 148 KB of LDS = one workgroup per CU: a launch takes ceil(CTUs / 256) rounds of the same ~54 us whatever the last round holds (287 CTUs, the live
+// average of round 4's first measurement, = 2 rounds for 1.12 rounds of work).  While the reference picture is still arriving, a launch therefore takes
+// whole rounds only (a last round at least 3/4 full counts as whole); the newest rows — the ones no search is waiting for yet — stay pending and go
+// with the next band, or with the picture's last band, which takes everything.  X265HIP_SADSURF_ROUNDS=0: every launch takes all it can.
+static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& list)
 {
-    int budget = rowBudget > 0 ? rowBudget : 1 << 30;
+    static const bool rounds = !(getenv("X265HIP_SADSURF_ROUNDS") && !atoi(getenv("X265HIP_SADSURF_ROUNDS")));
+    int budget = 1 << 30;
+    if (rounds && rp->uploaded < rp->marginY + rp->picH + rp->marginY)
+    {
+        int rows = 0, cols = 0;
+        for (x265hip_sadsurf* ss : list)
+            if (ss->ref == rp) { rows += rows_possible(ss) - ss->rowsBuilt; cols = ss->lay.ctuCols; }
+        // one workgroup per CU that is not held by a resident workgroup (the CU-job server's: 61 KB of LDS each, this kernel's 148 KB do not fit beside them)
+        const int cus = free_compute_units(rp->device);
+        if (cols > 0 && cols <= cus && rows * cols > cus)
+        {
+            const int rowsPerRound = cus / cols;
+            if ((rows % rowsPerRound) * 4 < rowsPerRound * 3)
+                budget = rows / rowsPerRound * rowsPerRound;
+        }
+    }
     std::vector<Replica*> places(1, nullptr);                // nullptr = the mirror's own place
     for (x265hip_sadsurf* ss : list)
         if (ss->ref == rp && ss->rep)
@@ -955,6 +973,9 @@ void sadsurf_rows_arrived(x265hip_refpic* rp)
     // have gone by (the searches of a frame start at least the reference-lag rows behind the band, so nobody is waiting for the newest rows yet;
     // a search that does arrive early measures its candidates on the host, same values).
     static const int batch = getenv("X265HIP_SADSURF_BATCH") ? atoi(getenv("X265HIP_SADSURF_BATCH")) : 224;
+    // bands a reference picture's pending rows may wait for company.  The searches that would use them run at least the reference lag behind; the
+    // encode of round 4's bench clip asks for a row that is not there yet 4 281 times in 12 million lookups at 2 bands, and ... at 8 (X265HIP_SADSURF_DEFER)
+    static const int maxDefer = getenv("X265HIP_SADSURF_DEFER") ? atoi(getenv("X265HIP_SADSURF_DEFER")) : 8;
     if (batch > 0)
     {
         const bool complete = rp->uploaded >= rp->marginY + rp->picH + rp->marginY;
@@ -962,25 +983,12 @@ void sadsurf_rows_arrived(x265hip_refpic* rp)
         for (x265hip_sadsurf* ss : list)
             if (ss->ref == rp)
                 pending += (rows_possible(ss) - ss->rowsBuilt) * ss->lay.ctuCols;
-        if (!complete && pending < batch && rp->ssDeferred < 2)
+        if (!complete && pending < batch && rp->ssDeferred < maxDefer)
         {
             if (pending) rp->ssDeferred++;
             return;
         }
         rp->ssDeferred = 0;
-        // 148 KB of LDS = one workgroup per CU: a launch takes ceil(CTUs / 256) rounds of the same ~54 us whatever the last round holds (287 CTUs, the
-        // live average of round 4's first measurement, = 2 rounds for 1.12 rounds of work).  While the picture is still arriving, launch whole rounds
-        // only; the newest rows — the ones no search is waiting for yet — stay pending and go with the next band.
-        const int cols = list.empty() ? 0 : list[0]->lay.ctuCols;
-        if (!complete && cols > 0 && cols <= 256 && pending > 256)
-        {
-            const int rowsPerRound = 256 / cols, rows = pending / cols;
-            if (rows >= rowsPerRound && (rows % rowsPerRound) * 4 < rowsPerRound * 3)      // a last round under 3/4 full is not worth its time now
-            {
-                progress(rp, list, rows / rowsPerRound * rowsPerRound);
-                return;
-            }
-        }
     }
     progress(rp, list);
 }
@@ -1010,7 +1018,9 @@ void sadsurf_job(const RefJob& j)
                 ss->ref->failed = 1;
                 return;
             }
-            progress(ss->ref, std::vector<x265hip_sadsurf*>{ ss });
+            // together with whatever rows the reference's other surfaces are waiting with (a reference picture that is complete — the usual case —
+            // gives the new surface all its rows at once)
+            sadsurf_rows_arrived(ss->ref);
         }
         return;
     }

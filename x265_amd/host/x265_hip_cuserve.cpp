@@ -47,6 +47,7 @@
 #undef protected
 #undef private
 
+#include <sched.h>
 #include "x265hip.h"
 #include "x265_hip_debug.h"
 
@@ -80,7 +81,7 @@ int g_time = 0;                  // X265HIP_DEBUG_CUTIME=1: cycles inside the fu
                                  // =2: the same with the jobs running (the pair of runs measures what the jobs save and what the waiting costs)
 int g_minLog2 = 5;               // X265HIP_CUSERVE_MIN: smallest CU (log2) whose residual quad-tree becomes a job
 int g_mode = 0;                  // X265HIP_CUSERVE_MODE: 0 resident server (mailbox), 1 one launch per job
-int g_slots = 64;                // X265HIP_CUSERVE_SLOTS: host threads that can have a job in flight
+int g_slots = 64;                // X265HIP_CUSERVE_SLOTS: jobs that can be in flight (default: twice the CPUs this process may use, 16..64)
 bool g_verify = false;           // X265HIP_VERIFY=1: every served unit is recomputed by the reference's function and compared
 bool g_require = false;          // X265HIP=require: a device failure is fatal instead of falling back
 std::mutex g_lock;
@@ -184,7 +185,7 @@ void report()
     fprintf(stderr, "x265hip: cuserve: %llu CU residual quad-trees (CU >= %d) handed to the GPU as jobs (%s%s, %.3f ms of device time%s): %llu forward "
                     "transform+quant units and %llu inverse units served, %llu + %llu calls of those CUs computed on the host; %llu waits of %.0f cycles on average; "
                     "%llu CUs not submitted%s\n",
-            (unsigned long long)jobs, 1 << g_minLog2, g_mode ? "one launch per job" : "resident server",
+            (unsigned long long)jobs, 1 << g_minLog2, g_mode ? "one launch per job" : (std::string("resident server of ") + std::to_string(g_slots) + " workgroups").c_str(),
             g_nsvc.load() > 1 ? (std::string(" at each of ") + std::to_string(g_nsvc.load()) + " places").c_str() : "", ns * 1e-6,
             g_mode ? "" : (std::string(", ") + std::to_string(starts) + " server starts").c_str(), (unsigned long long)fwd, (unsigned long long)inv,
             (unsigned long long)fm, (unsigned long long)im, (unsigned long long)w, w ? (double)wc / w : 0.0, (unsigned long long)sk,
@@ -229,6 +230,22 @@ bool decide()
         if (getenv("X265HIP_CUSERVE_MIN")) { const int v = atoi(getenv("X265HIP_CUSERVE_MIN")); g_minLog2 = v >= 64 ? 6 : v >= 32 ? 5 : 4; }
         if (getenv("X265HIP_CUSERVE_MODE")) g_mode = atoi(getenv("X265HIP_CUSERVE_MODE")) ? 1 : 0;
         if (getenv("X265HIP_CUSERVE_SLOTS")) g_slots = atoi(getenv("X265HIP_CUSERVE_SLOTS"));
+        else
+        {
+            // every slot is a resident workgroup that keeps a CU from the kernels that want a CU's whole LDS (the SAD surfaces): no more of them than jobs can
+            // be in flight — a job belongs to a running thread or to one preempted in the middle of its CU; CPUs = affinity mask capped by the cgroup's quota
+            cpu_set_t set;
+            int cpus = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : 64;
+            if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r"))
+            {
+                long long quota = 0, period = 0;
+                char q[32];
+                if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") && period > 0 && (quota = atoll(q)) > 0 && (quota + period - 1) / period < cpus)
+                    cpus = (int)((quota + period - 1) / period);
+                fclose(f);
+            }
+            g_slots = 2 * cpus < 16 ? 16 : 2 * cpus > 64 ? 64 : 2 * cpus;
+        }
         if (getenv("X265HIP_CUSERVE_SPEC")) g_spec = atoi(getenv("X265HIP_CUSERVE_SPEC")) != 0;
         g_serveDist = getenv("X265HIP_CUSERVE_DIST") ? atoi(getenv("X265HIP_CUSERVE_DIST")) : 3;
         if (g_slots < 1) g_slots = 1;
