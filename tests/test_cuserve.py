@@ -242,6 +242,42 @@ def test_emulated_jobs_are_the_restatement():
     assert total == 2 * len(JOB_SHAPES) * 6
 
 
+@pytest.mark.parametrize("bits", [8, 10])
+def test_bound_encoder_on_emulated_jobs_serves_and_stays_byte_identical(tmp_path, bits):
+    """The binding end to end on the CPU tier, at both pixel widths: jobs served, distortions answered out of them (Main10 / Main12: through cu[].sse_ss,
+    which x265_setup_primitives aliases the luma sse_pp to after the binding's table set-up — a wrapper on sse_pp alone is silently lost there, and the
+    reconstructions the binding no longer computes were then read stale: found by tests/test_encoder_fuzz.py seed 203 in round 4), the body's dead
+    sub_ps / add_ps calls put off, jobs submitted ahead at the merge candidate's skip evaluation adopted — and the reference's bytes, also with
+    X265HIP_VERIFY recomputing every served value."""
+    import re, subprocess, sys
+    sys.path.insert(0, ROOT)
+    ref, emul = os.path.join(ROOT, "oracle", "_ref", "x265_%dbit" % bits), os.path.join(ROOT, "oracle", "_ref", "x265_emul_%dbit" % bits)
+    if not (os.path.exists(ref) and os.path.exists(emul)):
+        pytest.skip("oracle/_ref encoders not built (make -C oracle ref emul)")
+    from x265_amd.synth import make_clip
+    yuv = str(tmp_path / "clip.yuv")
+    make_clip(yuv, 384, 256, 6, seed=77, depth=bits)
+    args = ["--input", yuv, "--input-res", "384x256", "--input-depth", str(bits), "--fps", "30", "--frames", "6", "--preset", "medium", "--hash", "1", "--pools", "4", "-F", "2"]
+    want = str(tmp_path / "ref.hevc")
+    assert subprocess.run([ref] + args + ["-o", want], capture_output=True, timeout=600).returncode == 0
+    for verify in (False, True):
+        got = str(tmp_path / ("emul%d.hevc" % verify))
+        env = dict(os.environ, X265HIP_VERBOSE="1")
+        env.pop("X265HIP", None)
+        if verify:
+            env["X265HIP_VERIFY"] = "1"
+        r = subprocess.run([emul] + args + ["-o", got], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-800:]
+        assert open(got, "rb").read() == open(want, "rb").read(), "bitstream differs (bits %d, verify %d)" % (bits, verify)
+        m = re.search(r"cuserve: (\d+) sse_pp and (\d+) psy-cost \(source, reconstruction\) answers", r.stderr)
+        assert m and int(m.group(1)) > 0 and int(m.group(2)) > 0, r.stderr[-1200:]
+        m = re.search(r"cuserve: (\d+) jobs left ahead of their scope.*?; (\d+) of them were the job", r.stderr)
+        assert m and int(m.group(1)) > 0 and m.group(1) == m.group(2), r.stderr[-1200:]
+        if not verify:
+            m = re.search(r"cuserve: (\d+) sub_ps and (\d+) add_ps calls of those CUs put off", r.stderr)
+            assert m and int(m.group(1)) > 0 and int(m.group(2)) > 0, r.stderr[-1200:]
+
+
 class _Chk:
     """hp-like holder for _run_on over the emulated library (no HipError there)"""
     from x265_amd import hipprim as _hp

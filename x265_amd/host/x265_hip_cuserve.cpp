@@ -644,6 +644,7 @@ inline bool final_psy(Job& j, const pixel* a, intptr_t sa, const pixel* b, intpt
 template <int CU, int N, bool CHROMA> sse_t sse_slot(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
 {
     Job& j = t_job;
+
     if (j.active && j.phase)
     {
         uint64_t v;
@@ -660,6 +661,27 @@ template <int CU, int N, bool CHROMA> sse_t sse_slot(const pixel* a, intptr_t sa
     }
     return CHROMA ? g_prev.chroma[X265_CSP_I420].cu[CU].sse_pp(a, sa, b, sb) : g_prev.cu[CU].sse_pp(a, sa, b, sb);
 }
+
+#if X265_DEPTH > 8
+// Main10 / Main12: pixel == uint16_t and x265_setup_primitives aliases the luma cu[].sse_pp to cu[].sse_ss AFTER setupAssemblyPrimitives has run
+// (setupAliasPrimitives, primitives.cpp:90-94) — a wrapper on sse_pp would be overwritten.  The slot the encoder really calls is sse_ss: wrapped here; a call
+// that is not a question about this thread's job (int16 residual pairs included) goes to the function that was there.
+template <int CU, int N> sse_t sse_ss_slot(const int16_t* a, intptr_t sa, const int16_t* b, intptr_t sb)
+{
+    Job& j = t_job;
+    if (j.active && j.phase)
+    {
+        uint64_t v;
+        if (job_sse(j, (const pixel*)a, sa, (const pixel*)b, sb, N, v) || final_sse(j, (const pixel*)a, sa, (const pixel*)b, sb, N, v))
+        {
+            if (g_verify && (uint64_t)g_prev.cu[CU].sse_ss(a, sa, b, sb) != v) { fprintf(stderr, "x265hip: cuserve: VERIFY FAILED sse_pp (as sse_ss) %dx%d\n", N, N); abort(); }
+            counters().dist.fetch_add(1, std::memory_order_relaxed);
+            return (sse_t)v;
+        }
+    }
+    return g_prev.cu[CU].sse_ss(a, sa, b, sb);
+}
+#endif
 
 // psy_cost_pp(source block, prediction block): remembered per unit within the job's scope; a block above the largest transform size is the sum of its
 // units' values (psyCost_pp sums over 8x8 blocks, pixel.cpp:739-748)
@@ -817,6 +839,12 @@ void x265hip_install_cuserve_slots(EncoderPrimitives& p)
     p.cu[BLOCK_16x16].sse_pp = sse_slot<BLOCK_16x16, 16, false>;
     p.cu[BLOCK_32x32].sse_pp = sse_slot<BLOCK_32x32, 32, false>;
     p.cu[BLOCK_64x64].sse_pp = sse_slot<BLOCK_64x64, 64, false>;
+#if X265_DEPTH > 8
+    p.cu[BLOCK_8x8].sse_ss = sse_ss_slot<BLOCK_8x8, 8>;
+    p.cu[BLOCK_16x16].sse_ss = sse_ss_slot<BLOCK_16x16, 16>;
+    p.cu[BLOCK_32x32].sse_ss = sse_ss_slot<BLOCK_32x32, 32>;
+    p.cu[BLOCK_64x64].sse_ss = sse_ss_slot<BLOCK_64x64, 64>;
+#endif
     // 4:2:0: chroma[].cu[i] is the chroma block of luma CU i (primitives.h:80-90)
     p.chroma[X265_CSP_I420].cu[BLOCK_16x16].sse_pp = sse_slot<BLOCK_16x16, 8, true>;
     p.chroma[X265_CSP_I420].cu[BLOCK_32x32].sse_pp = sse_slot<BLOCK_32x32, 16, true>;
@@ -825,12 +853,16 @@ void x265hip_install_cuserve_slots(EncoderPrimitives& p)
     p.cu[BLOCK_16x16].psy_cost_pp = psy_slot<BLOCK_16x16, 16>;
     p.cu[BLOCK_32x32].psy_cost_pp = psy_slot<BLOCK_32x32, 32>;
     p.cu[BLOCK_64x64].psy_cost_pp = psy_slot<BLOCK_64x64, 64>;
-    if (g_serveDist >= 3)
+    const int dead = getenv("X265HIP_CUSERVE_DEAD") ? atoi(getenv("X265HIP_CUSERVE_DEAD")) : 3;
+    if (g_serveDist >= 3 && (dead & 1))
     {
         p.cu[BLOCK_32x32].sub_ps = sub_ps_slot<BLOCK_32x32, 32, false>;
         p.cu[BLOCK_64x64].sub_ps = sub_ps_slot<BLOCK_64x64, 64, false>;
         p.chroma[X265_CSP_I420].cu[BLOCK_32x32].sub_ps = sub_ps_slot<BLOCK_32x32, 16, true>;
         p.chroma[X265_CSP_I420].cu[BLOCK_64x64].sub_ps = sub_ps_slot<BLOCK_64x64, 32, true>;
+    }
+    if (g_serveDist >= 3 && (dead & 2))
+    {
         p.cu[BLOCK_8x8].add_ps[0] = add_ps_slot<BLOCK_8x8, 8, 0>;     p.cu[BLOCK_8x8].add_ps[1] = add_ps_slot<BLOCK_8x8, 8, 1>;
         p.cu[BLOCK_16x16].add_ps[0] = add_ps_slot<BLOCK_16x16, 16, 0>; p.cu[BLOCK_16x16].add_ps[1] = add_ps_slot<BLOCK_16x16, 16, 1>;
         p.cu[BLOCK_32x32].add_ps[0] = add_ps_slot<BLOCK_32x32, 32, 0>; p.cu[BLOCK_32x32].add_ps[1] = add_ps_slot<BLOCK_32x32, 32, 1>;
