@@ -35,9 +35,9 @@ make_clip('/tmp/prof_clip.yuv', 1920, 1080, 120, seed=4321)"
 X265HIP=require X265HIP_VERBOSE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_encode -o e -- $root/oracle/_ref/x265_hip_8bit --input /tmp/prof_clip.yuv \
     --input-res 1920x1080 --fps 30 --preset medium --me hex --frames 120 -o /dev/null > $out/${tag}_encode.log 2>&1
 find $out/${tag}_encode -name "*kernel_trace.csv" -size +30M -delete
-# the same encoder with one launch per CU job (30 frames: ~10^5 launches): the per-job kernel duration as rocprofv3 sees it
-X265HIP=require X265HIP_VERBOSE=1 X265HIP_CUSERVE_MODE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_encode_mode1 -o e -- $root/oracle/_ref/x265_hip_8bit \
-    --input /tmp/prof_clip.yuv --input-res 1920x1080 --fps 30 --preset medium --me hex --frames 30 -o /dev/null > $out/${tag}_encode_mode1.log 2>&1
+# CU jobs with one launch each (tools/micro/cuserve_rt mode 1: 1 / 4 / 16 submitting threads, 32x32 and 64x64 CUs): the per-job kernel duration as rocprofv3
+# sees it, beside the resident server's own busy-time ledger (the bound encoder itself crashed inside the tool with ~10^5 launches from 16 threads)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_encode_mode1 -o e -- $root/tools/micro/cuserve_rt 1 400 > $out/${tag}_encode_mode1.log 2>&1
 find $out/${tag}_encode_mode1 -name "*kernel_trace.csv" -delete
 cd $root
 ls -d $out/${tag}_* | head -40

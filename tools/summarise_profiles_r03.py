@@ -92,12 +92,12 @@ if enc:
     if os.path.exists(log):
         keep = [l for l in open(log, errors="replace") if l.startswith(("encoded", "x265hip:"))]
         open(os.path.join(P, f"{tag}_encode_log.txt"), "w").writelines(keep)
-# round 4: the same encode with one launch per CU job (X265HIP_CUSERVE_MODE=1): rocprofv3's average duration of cu_job_kernel is the per-job device
-# time the resident server's own busy-time ledger reports (bench.py roofline.busy_us_per_job)
+# round 4: CU jobs with one launch each (tools/micro/cuserve_rt mode 1): rocprofv3's average duration of cu_job_kernel beside the per-job device time the
+# resident server's own busy-time ledger reports (bench.py roofline.busy_us_per_job)
 enc1 = find("encode_mode1", "kernel_stats.csv")
 if enc1:
     shutil.copy(enc1, os.path.join(P, f"{tag}_encode_mode1_kernel_stats.csv"))
     log = os.path.join(G, f"{tag}_encode_mode1.log")
     if os.path.exists(log):
-        keep = [l for l in open(log, errors="replace") if l.startswith(("encoded", "x265hip:"))]
+        keep = [l for l in open(log, errors="replace") if l.startswith(("one launch per job", "resident server")) or " jobs, " in l]
         open(os.path.join(P, f"{tag}_encode_mode1_log.txt"), "w").writelines(keep)

@@ -785,7 +785,13 @@ template <int CU, int N, bool CHROMA> void sub_ps_slot(int16_t* dst, intptr_t ds
 template <int CU, int N, int AL> void add_ps_slot(pixel* dst, intptr_t ds, const pixel* a, const int16_t* b, intptr_t sa, intptr_t sb)
 {
     Job& j = t_job;
-    if (j.active && j.inTree && g_serveDist >= 3 && !g_verify && !j.search->m_rdCost.m_ssimRd)
+    // ... which holds only while the table really carries the answering slots (see x265hip_install_cuserve_slots about two set-ups at once)
+    bool answered = primitives.cu[CU].psy_cost_pp == psy_slot<CU, N> && primitives.cu[CU].sse_pp == sse_slot<CU, N, false>;
+#if X265_DEPTH > 8
+    answered = primitives.cu[CU].psy_cost_pp == psy_slot<CU, N> &&
+               (primitives.cu[CU].sse_pp == sse_slot<CU, N, false> || primitives.cu[CU].sse_pp == (pixel_sse_t)sse_ss_slot<CU, N>);
+#endif
+    if (answered && j.active && j.inTree && g_serveDist >= 3 && !g_verify && !j.search->m_rdCost.m_ssimRd)
         for (int p = 0; p < 3; p++)
         {
             if (!j.pred[p] || (uint32_t)sa != j.predStride[p]) continue;
@@ -831,10 +837,19 @@ inline void psy_ahead(Job& j, int u, int plane, int x, int y, int n)
 void x265hip_install_cuserve_slots(EncoderPrimitives& p)
 {
     decide();
-    if (g_state <= 0 || !g_serveDist || g_slots_installed)
+    if (g_state <= 0 || !g_serveDist)
         return;
-    g_prev = p;
-    g_verify = getenv("X265HIP_VERIFY") != NULL;
+    // x265_setup_primitives is not serialised: two encoders opened at the same moment both find the table empty and both set it up, the second one's
+    // setupCPrimitives writing C functions over slots the first has already wrapped (tests/test_encoder_lifetime.py, parallel sessions: one run in ten ended
+    // with add_ps wrapped and sse_pp not).  So the wrappers are written on EVERY call — the table ends up wrapped whoever comes last — while "what was
+    // there" is taken once, from the first call (later calls may already see wrappers in the table).
+    static std::mutex once;
+    std::lock_guard<std::mutex> g(once);
+    if (!g_slots_installed)
+    {
+        g_prev = p;
+        g_verify = getenv("X265HIP_VERIFY") != NULL;
+    }
     p.cu[BLOCK_8x8].sse_pp = sse_slot<BLOCK_8x8, 8, false>;
     p.cu[BLOCK_16x16].sse_pp = sse_slot<BLOCK_16x16, 16, false>;
     p.cu[BLOCK_32x32].sse_pp = sse_slot<BLOCK_32x32, 32, false>;
