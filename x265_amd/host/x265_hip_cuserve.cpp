@@ -135,7 +135,8 @@ struct Job
     // 0: submitted ahead of its encodeResAndCalcRdInterCU (from encodeResAndCalcRdSkipCU, see there): nothing is answered yet; 1: inside the scope
     int phase;
     const Yuv* fencYuv;                  // the source Yuv the pixels were taken from
-    x265hip_cujob hdr;                   // what was submitted (an adopted job must be the job the scope would submit itself)
+    x265hip_cujob hdr;                   // what was submitted (an adopted job must be the job the scope would submit itself) ...
+    alignas(64) pixel sent[X265HIP_CUJOB_PIXEL_BYTES / sizeof(pixel)];       // ... header AND pixels: a job's answers are a function of exactly these
     uint32_t seq;
     int slot;
     Service* svc;
@@ -473,12 +474,15 @@ bool submit(Search* se, Mode& mode, uint32_t log2CUSize, ShortYuv& resiYuv, cons
     const Yuv* fenc = mode.fencYuv;
     const Yuv* pred = &mode.predYuv;
     *mem.job = hdr;
-    pixel* dst = (pixel*)mem.pixels;
+    Job& j = t_job;
+    // packed in this thread's own memory first (what encodeResAndCalcRdInterCU compares a job submitted ahead with), then one front-to-back copy into the
+    // mailbox — device memory behind a write-combining mapping likes that better than 16- and 32-byte rows anyway
+    pixel* dst = j.sent;
     pack_rows(dst, fenc->m_buf[0], fenc->m_size, N);
     if (codeChroma) { pack_rows(dst, fenc->m_buf[1], fenc->m_csize, N / 2); pack_rows(dst, fenc->m_buf[2], fenc->m_csize, N / 2); }
     pack_rows(dst, pred->m_buf[0], pred->m_size, N);
     if (codeChroma) { pack_rows(dst, pred->m_buf[1], pred->m_csize, N / 2); pack_rows(dst, pred->m_buf[2], pred->m_csize, N / 2); }
-    Job& j = t_job;
+    memcpy(mem.pixels, j.sent, (size_t)(dst - j.sent) * sizeof(pixel));
     if (x265hip_cuserve_submit(svc->cs, slot, &j.seq))
     {
         give_slot(svc, slot);
@@ -932,16 +936,22 @@ bool adopt(Search* se, Mode& mode, const CUGeom& cuGeom)
         !make_header(se, mode, cuGeom.log2CUSize, range, hdr) || memcmp(&hdr, &j.hdr, sizeof(hdr)))
         return false;
     const Yuv& pred = mode.predYuv;
+    const Yuv& fenc = *mode.fencYuv;
     const int N = 1 << j.log2CU;
-    for (int p = 0; p < (j.pred[1] ? 3 : 1); p++)
-    {
-        const int n = p ? N / 2 : N;
-        const uint32_t st = p ? pred.m_csize : pred.m_size;
-        if (pred.m_buf[p] != j.pred[p])
-            for (int y = 0; y < n; y++)
-                if (memcmp(pred.m_buf[p] + (size_t)y * st, j.pred[p] + (size_t)y * j.predStride[p], sizeof(pixel) * n))
+    // the samples the job was given against the samples this scope would give it: source first, prediction second, plane by plane (the layout of submit).
+    // Buffer addresses say nothing — the mode's Yuv buffers are reused from CU to CU (an analysis-load encode evaluates skips that no
+    // encodeResAndCalcRdInterCU follows, analysis.cpp:2547: the job then waits for the NEXT CU's call)
+    const pixel* sent = j.sent;
+    for (int half = 0; half < 2; half++)
+        for (int p = 0; p < (j.pred[1] ? 3 : 1); p++)
+        {
+            const Yuv& y = half ? pred : fenc;
+            const int n = p ? N / 2 : N;
+            const uint32_t st = p ? y.m_csize : y.m_size;
+            for (int r = 0; r < n; r++, sent += n)
+                if (memcmp(y.m_buf[p] + (size_t)r * st, sent, sizeof(pixel) * n))
                     return false;
-    }
+        }
     for (int p = 0; p < (j.pred[1] ? 3 : 1); p++) { j.pred[p] = pred.m_buf[p]; j.predStride[p] = p ? pred.m_csize : pred.m_size; }
     j.mode = &mode;
     j.phase = 1;
@@ -962,7 +972,8 @@ void Search::encodeResAndCalcRdSkipCU(Mode& interMode)
         end_job();
     const uint32_t log2CU = interMode.cu.m_log2CUSize[0];
     if (g_spec && g_state > 0 && !g_dead.load(std::memory_order_relaxed) && (int)log2CU >= g_minLog2 && !j.active && !t_inEncodeRes && m_param->rdLevel >= 1 &&
-        m_param->rdLevel <= 4 && !m_param->bLossless && !m_param->interRefine && !m_param->bDynamicRefine)
+        m_param->rdLevel <= 4 && !m_param->bLossless && !m_param->interRefine && !m_param->bDynamicRefine && !m_param->analysisLoad)       // (a loaded analysis
+        // evaluates skips that nothing follows, analysis.cpp:2547: a job sent from there would only be waited for and dropped)
     {
         uint32_t range[2];
         interMode.cu.getInterTUQtDepthRange(range, 0);
