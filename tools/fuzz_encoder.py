@@ -89,8 +89,8 @@ def draw(seed):
         # (finishedRows == 0), so the reference searches a weighted plane that is uninitialised heap memory — its output then depends on
         # the allocator's history.  Found by this fuzzer (seeds 110, 412, 440); not a test case for a binding.
         args += ["--no-weightp"]
-    if h <= 64 and "--weightb" in args:
-        args += ["--no-weightb"]            # the same plane, weighted B prediction (seed 905)
+    if h <= 64 and "--no-weightb" not in args:
+        args += ["--no-weightb"]            # the same plane, weighted B prediction (seed 905 by --weightb, seed 1018 by --preset veryslow, which implies it)
     ft = rng.choice([1, 2, 3, 4])
     if "--vbv-bufsize" in args:
         # x265 documents VBV with frame threads as non-deterministic; with wavefront rows it is too (the row-level controller reads the statistics of
