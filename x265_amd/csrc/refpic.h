@@ -106,6 +106,7 @@ struct RefWorker
 // sadsurf.hip, called on the worker thread
 void sadsurf_rows_arrived(x265hip_refpic* rp);            // after a band of rp has been uploaded (and its planes published)
 void sadsurf_job(const RefJob& j);                        // kinds 1 and 2
+void sadsurf_attach_batch(const std::vector<RefJob>& jobs);   // kind 1 jobs that were queued together
 void sadsurf_detach_all(x265hip_refpic* rp);              // rp is being reset or destroyed (worker idle for rp)
 
 } // namespace xh

@@ -15,6 +15,7 @@
 #include "common.h"
 #include "internal.h"
 #include "refpic.h"
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <utility>
@@ -86,6 +87,35 @@ void RefWorker::run()
                 return;
             j = q.front();
             q.pop_front();
+        }
+        if (j.kind == 1)
+        {
+            // a surface being attached: the first search of a frame against each of its reference pictures attaches one, microseconds apart — give the
+            // siblings X265HIP_SADSURF_GATHER_US (default 100) to arrive and build them all in one launch (sadsurf.hip progress_multi); the attach jobs at the front of the queue only,
+            // so that nothing overtakes a band
+            static const int gatherUs = getenv("X265HIP_SADSURF_GATHER_US") ? atoi(getenv("X265HIP_SADSURF_GATHER_US")) : 100;
+            std::vector<RefJob> batch(1, j);
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;)
+            {
+                {
+                    std::lock_guard<std::mutex> g(m);
+                    while (!q.empty() && q.front().kind == 1) { batch.push_back(q.front()); q.pop_front(); }
+                    if (!q.empty() || stop) break;
+                }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(gatherUs)) break;
+                __builtin_ia32_pause();
+            }
+            sadsurf_attach_batch(batch);
+            bool idleNow = false;
+            for (const RefJob& b : batch)
+                if (b.rp && b.rp->pending.fetch_sub(1) == 1) idleNow = true;
+            if (idleNow)
+            {
+                std::lock_guard<std::mutex> g(m);
+                idle.notify_all();
+            }
+            continue;
         }
         process(j);
         if (j.rp && j.rp->pending.fetch_sub(1) == 1)

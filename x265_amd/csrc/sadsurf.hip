@@ -55,17 +55,17 @@ struct SurfLayout
 // one surface's share of a launch: rows [row0, row0 + rows) of its table
 struct SurfJob
 {
+    const uint8_t* ref; int64_t refStride;       // the job's reference pixel (0, 0): the surfaces of one launch may follow different reference pictures
     const uint8_t* src; int64_t srcPitch;
     char* out;                                    // device table buffer (chunk of CTU row 0 first)
     int S, lambda20, row0, rows;
     int level0;                                   // the 8x8 windows are wanted
 };
-constexpr int kMaxJobs = 8;
+constexpr int kMaxJobs = 16;
 
-// one launch: rows of up to kMaxJobs surfaces that share the reference picture (and with it the geometry and the table layout)
+// one launch: rows of up to kMaxJobs surfaces that share the geometry and the table layout (same encoder, same levels) — of one reference picture or several
 struct SurfArgs
 {
-    const uint8_t* ref; int64_t refStride;       // reference pixel (0, 0)
     int picW, picH, marginX, marginY;
     int bufRows;                                  // rows of the padded picture in device memory (marginY above picture row 0)
     int64_t pitch;
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu_kernel(SurfArgs a)
         {
             const int r = i / dw, c4 = (i - r * dw) * 4;
             const int y = min(max(y0 - S + r, -a.marginY), yMax), x = min(max(x0 - S + c4, -a.marginX), xMax);
-            *(uint32_t*)(sRef + r * RW + c4) = ld_global_unaligned<uint32_t>(a.ref + (int64_t)y * a.refStride + x);
+            *(uint32_t*)(sRef + r * RW + c4) = ld_global_unaligned<uint32_t>(jb.ref + (int64_t)y * jb.refStride + x);
         }
     }
     if (tid < 32)
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu16_kernel(SurfArgs a)
     const int x0 = cx * 64, y0 = cy * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint16_t* src = (const uint16_t*)jb.src;
-    const uint16_t* ref = (const uint16_t*)a.ref;
+    const uint16_t* ref = (const uint16_t*)jb.ref;
     const int64_t srcPitch = jb.srcPitch / 2;                    // samples
 
     // ---- stage ----
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu16_kernel(SurfArgs a)
         {
             const int r = i / RWD, k = i - r * RWD;
             const int y = min(max(y0 - S + r, -a.marginY), yMax), x = min(max(x0 - S + 2 * k, -a.marginX), xEnd - 2);
-            const uint16_t* p = ref + (int64_t)y * a.refStride;
+            const uint16_t* p = ref + (int64_t)y * jb.refStride;
             const uint32_t s0 = p[x], s1 = p[x + 1], s2 = p[min(x + 2, xEnd - 1)];
             sRefA[r * RWD + k] = s0 | (s1 << 16);
             sRefB[r * RWD + k] = s1 | (s2 << 16);
@@ -770,98 +770,138 @@ static Replica* replica_at(x265hip_refpic* rp, int place)
     return r;
 }
 
-// build what the reference's rows allow of every surface in `list` (all attached to rp): per place one launch on that place's stream — the mirror's
-// own for surfaces whose source lives where the mirror does, the replica's otherwise, after the rows the replica does not have yet have been pushed
-// device to device — then the rows come to the host and are published (worker thread; the band's upload has been synchronised)
-// 148 KB of LDS = one workgroup per CU: a launch takes ceil(CTUs / 256) rounds of the same ~54 us whatever the last round holds (287 CTUs, the live
-// average of round 4's first measurement, = 2 rounds for 1.12 rounds of work).  While the reference picture is still arriving, a launch therefore takes
-// whole rounds only (a last round at least 3/4 full counts as whole); the newest rows — the ones no search is waiting for yet — stay pending and go
-// with the next band, or with the picture's last band, which takes everything.  X265HIP_SADSURF_ROUNDS=0: every launch takes all it can.
-static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& list)
+// Build what the references' rows allow of every surface attached to the pictures in `rps` (worker thread; the bands' uploads have been synchronised).
+// Surfaces that share geometry, table layout and the device they are built on go into ONE launch, whichever reference picture they follow (a job
+// carries its own reference pointer): the three surfaces a P frame attaches within microseconds of each other — one per reference picture — are
+// 1530 CTUs together, 7 rounds of the 224 CUs the job server leaves free at 0.98 fill, where three launches of 510 CTUs are 3 rounds each at 0.76.
+// Surfaces whose source lives at another place are built from the replica there, after the rows it lacks have been pushed device to device.
+//
+// 148 KB of LDS = one workgroup per CU: a launch takes ceil(CTUs / free CUs) rounds of the same ~54 us whatever the last round holds.  While a
+// reference picture is still arriving, its newest rows — the ones no search is waiting for yet — are left out when they would only open a round that
+// stays less than 3/4 full; they go with the next band, or with the picture's last band, which takes everything.  X265HIP_SADSURF_ROUNDS=0: every launch
+// takes all it can.
+struct SurfItem { x265hip_sadsurf* ss; x265hip_refpic* rp; Replica* rep; int dev; int take; bool arriving; };
+
+static void fail_refs(const std::vector<SurfItem>& items, size_t from, size_t to)
+{
+    for (size_t k = from; k < to; k++) items[k].rp->failed = 1;
+}
+
+static void progress_multi(const std::vector<x265hip_refpic*>& rps)
 {
     static const bool rounds = !(getenv("X265HIP_SADSURF_ROUNDS") && !atoi(getenv("X265HIP_SADSURF_ROUNDS")));
-    int budget = 1 << 30;
-    if (rounds && rp->uploaded < rp->marginY + rp->picH + rp->marginY)
+    std::vector<SurfItem> items;
+    for (x265hip_refpic* rp : rps)
     {
-        int rows = 0, cols = 0;
-        for (x265hip_sadsurf* ss : list)
-            if (ss->ref == rp) { rows += rows_possible(ss) - ss->rowsBuilt; cols = ss->lay.ctuCols; }
-        // one workgroup per CU that is not held by a resident workgroup (the CU-job server's: 61 KB of LDS each, this kernel's 148 KB do not fit beside them)
-        const int cus = free_compute_units(rp->device);
-        if (cols > 0 && cols <= cus && rows * cols > cus)
+        if (rp->failed.load()) continue;
+        std::vector<x265hip_sadsurf*> list;
         {
-            const int rowsPerRound = cus / cols;
-            if ((rows % rowsPerRound) * 4 < rowsPerRound * 3)
-                budget = rows / rowsPerRound * rowsPerRound;
+            std::lock_guard<std::mutex> g(g_ssLock);
+            list = rp->surfaces;
+        }
+        const bool arriving = rp->uploaded < rp->marginY + rp->picH + rp->marginY;
+        for (x265hip_sadsurf* ss : list)
+        {
+            if (ss->ref != rp) continue;
+            const int take = rows_possible(ss) - ss->rowsBuilt;
+            if (take > 0)
+                items.push_back(SurfItem{ ss, rp, ss->rep, ss->rep ? ss->rep->device : rp->device, take, arriving });
         }
     }
-    std::vector<Replica*> places(1, nullptr);                // nullptr = the mirror's own place
-    for (x265hip_sadsurf* ss : list)
-        if (ss->ref == rp && ss->rep)
-        {
-            bool seen = false;
-            for (Replica* r : places) seen = seen || r == ss->rep;
-            if (!seen) places.push_back(ss->rep);
-        }
-    for (Replica* rep : places)
+    if (items.empty())
+        return;
+    // same device, geometry and table layout next to each other (stable: the order of `rps` and of the surfaces inside a group is kept)
+    auto same_group = [](const SurfItem& x, const SurfItem& y) {
+        return x.dev == y.dev && x.ss->levels == y.ss->levels && x.rp->depth == y.rp->depth && x.rp->picW == y.rp->picW && x.rp->picH == y.rp->picH &&
+               x.rp->marginX == y.rp->marginX && x.rp->marginY == y.rp->marginY && x.rp->bufRows == y.rp->bufRows && x.ss->lay.pitch == y.ss->lay.pitch; };
     {
-        const int dev = rep ? rep->device : rp->device;
-        hipStream_t st = rep ? rep->st : rp->st;
-        const char* dPic = rep ? rep->dPic : rp->dPic;
-        bool pushed = !rep;
-        size_t i = 0;
-        while (i < list.size())
+        std::vector<SurfItem> sorted;
+        std::vector<bool> used(items.size(), false);
+        for (size_t a0 = 0; a0 < items.size(); a0++)
+        {
+            if (used[a0]) continue;
+            for (size_t b0 = a0; b0 < items.size(); b0++)
+                if (!used[b0] && same_group(items[a0], items[b0])) { used[b0] = true; sorted.push_back(items[b0]); }
+        }
+        items.swap(sorted);
+    }
+    size_t g0 = 0;
+    while (g0 < items.size())
+    {
+        size_t g1 = g0 + 1;
+        while (g1 < items.size() && same_group(items[g0], items[g1])) g1++;
+        // whole rounds: rows of pictures that are still arriving may stay behind
+        if (rounds)
+        {
+            const int cols = items[g0].ss->lay.ctuCols, cus = free_compute_units(items[g0].dev);
+            int rows = 0, spare = 0;
+            for (size_t k = g0; k < g1; k++) { rows += items[k].take; if (items[k].arriving) spare += items[k].take; }
+            if (cols > 0 && cols <= cus && rows * cols > cus)
+            {
+                const int rowsPerRound = cus / cols;
+                int excess = rows % rowsPerRound;
+                if (excess * 4 < rowsPerRound * 3 && excess <= spare)
+                    for (size_t k = g1; k-- > g0 && excess > 0;)
+                        if (items[k].arriving)
+                        {
+                            const int d = items[k].take < excess ? items[k].take : excess;
+                            items[k].take -= d; excess -= d;
+                        }
+            }
+        }
+        size_t i = g0;
+        while (i < g1)
         {
             SurfArgs a;
             memset(&a, 0, sizeof(a));
-            x265hip_sadsurf* in[kMaxJobs];
+            size_t in[kMaxJobs];
             int upto[kMaxJobs], rows = 0, maxS = 0;
-            for (; i < list.size() && a.nJobs < kMaxJobs; i++)
+            for (; i < g1 && a.nJobs < kMaxJobs; i++)
             {
-                x265hip_sadsurf* ss = list[i];
-                if (ss->ref != rp || ss->rep != rep)
+                const SurfItem& it = items[i];
+                if (it.take <= 0)
                     continue;
-                if (a.nJobs && ss->levels != in[0]->levels)
-                    break;                                    // another table layout: the next launch
-                int r1 = rows_possible(ss);
-                if (r1 - ss->rowsBuilt > budget) r1 = ss->rowsBuilt + budget;
-                if (r1 == ss->rowsBuilt)
-                    continue;
-                budget -= r1 - ss->rowsBuilt;
+                x265hip_sadsurf* ss = it.ss;
+                const char* dPic = it.rep ? it.rep->dPic : it.rp->dPic;
                 SurfJob& j = a.job[a.nJobs];
+                j.ref = (const uint8_t*)dPic + ((size_t)it.rp->marginY * it.rp->stride + it.rp->marginX) * it.rp->B; j.refStride = it.rp->stride;   // stride in samples
                 j.src = (const uint8_t*)ss->src->dLuma; j.srcPitch = ss->src->pitch;
-                j.out = ss->dBuf; j.S = ss->S; j.lambda20 = ss->lambda20; j.row0 = ss->rowsBuilt; j.rows = r1 - ss->rowsBuilt;
-                j.level0 = (ss->levels & 1) && rp->depth == 8;
-                in[a.nJobs] = ss; upto[a.nJobs] = r1;
+                j.out = ss->dBuf; j.S = ss->S; j.lambda20 = ss->lambda20; j.row0 = ss->rowsBuilt; j.rows = it.take;
+                j.level0 = (ss->levels & 1) && it.rp->depth == 8;
+                in[a.nJobs] = i; upto[a.nJobs] = ss->rowsBuilt + it.take;
                 rows += j.rows;
                 if (ss->S > maxS) maxS = ss->S;
                 a.nJobs++;
             }
             if (!a.nJobs)
                 break;
-            if (hipSetDevice(dev) != hipSuccess) { rp->failed = 1; return; }
-            if (!pushed)
+            const SurfItem& first = items[in[0]];
+            x265hip_refpic* rp0 = first.rp;
+            const int dev = first.dev;
+            hipStream_t st = first.rep ? first.rep->st : rp0->st;
+            if (hipSetDevice(dev) != hipSuccess) { fail_refs(items, g0, g1); return; }
+            // the reconstructed rows a replica lacks, straight from the owner's device memory (on the replica's stream, waited for: the launch below may
+            // run on another reference's stream)
+            for (int k = 0; k < a.nJobs; k++)
             {
-                // the reconstructed rows the replica lacks, straight from the owner's device memory
-                if (rep->copied < rp->uploaded)
+                const SurfItem& it = items[in[k]];
+                if (!it.rep || it.rep->copied >= it.rp->uploaded)
+                    continue;
+                const size_t off = (size_t)it.rep->copied * it.rp->stride * it.rp->B, bytes = (size_t)(it.rp->uploaded - it.rep->copied) * it.rp->stride * it.rp->B;
+                if (hipMemcpyPeerAsync(it.rep->dPic + off, it.rep->device, it.rp->dPic + off, it.rp->device, bytes, it.rep->st) != hipSuccess ||
+                    hipStreamSynchronize(it.rep->st) != hipSuccess)
                 {
-                    const size_t off = (size_t)rep->copied * rp->stride * rp->B, bytes = (size_t)(rp->uploaded - rep->copied) * rp->stride * rp->B;
-                    if (hipMemcpyPeerAsync(rep->dPic + off, rep->device, rp->dPic + off, rp->device, bytes, st) != hipSuccess)
-                    {
-                        set_error(X265HIP_EHIP, "sadsurf: device-to-device push of reference rows failed");
-                        rp->failed = 1;
-                        (void)hipSetDevice(rp->device);
-                        return;
-                    }
-                    g_statPeerBands++;
-                    g_statPeerBytes += bytes;
-                    rep->copied = rp->uploaded;
+                    set_error(X265HIP_EHIP, "sadsurf: device-to-device push of reference rows failed");
+                    fail_refs(items, g0, g1);
+                    (void)hipSetDevice(rp0->device);
+                    return;
                 }
-                pushed = true;
+                g_statPeerBands++;
+                g_statPeerBytes += bytes;
+                it.rep->copied = it.rp->uploaded;
             }
-            const SurfLayout& lay = in[0]->lay;               // same picture size: same layout
-            a.ref = (const uint8_t*)dPic + ((size_t)rp->marginY * rp->stride + rp->marginX) * rp->B; a.refStride = rp->stride;        // stride in samples
-            a.picW = rp->picW; a.picH = rp->picH; a.marginX = rp->marginX; a.marginY = rp->marginY; a.bufRows = rp->bufRows;
+            const SurfLayout& lay = first.ss->lay;            // same picture size and levels: same layout
+            a.picW = rp0->picW; a.picH = rp0->picH; a.marginX = rp0->marginX; a.marginY = rp0->marginY; a.bufRows = rp0->bufRows;
             a.pitch = lay.pitch;
             for (int l = 0; l < 4; l++) { a.originOff[l] = lay.originOff[l]; a.tableOff[l] = lay.tableOff[l]; a.blocksX[l] = lay.blocksX[l]; }
             a.blocksY0 = lay.blocksY[0];
@@ -873,29 +913,31 @@ static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& li
                     hipFuncSetAttribute((const void*)sadsurf_ctu16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)surf16_lds_bytes(16)) != hipSuccess)
                 {
                     set_error(X265HIP_EHIP, "sadsurf: cannot raise the dynamic LDS limit");
-                    rp->failed = 1;
-                    (void)hipSetDevice(rp->device);
+                    fail_refs(items, g0, g1);
+                    (void)hipSetDevice(rp0->device);
                     return;
                 }
                 attrSet |= (uint64_t)1 << dev;
             }
             // the launch between two events of its own stream: the kernel's device time (x265hip_device_time, x265hip_sadsurf_stats)
             DevSpan span(X265HIP_CLK_SADSURF, st);
-            if (rp->depth == 8)
+            if (rp0->depth == 8)
                 hipLaunchKernelGGL(sadsurf_ctu_kernel, dim3(lay.ctuCols, rows), dim3(1024), surf_lds_bytes(maxS), st, a);
             else
                 hipLaunchKernelGGL(sadsurf_ctu16_kernel, dim3(lay.ctuCols, rows), dim3(1024), surf16_lds_bytes(maxS), st, a);
             bool bad = hipGetLastError() != hipSuccess;
             span.end();
             DevSpan span2(X265HIP_CLK_SUBPEL, st);
-            // the sub-pel SATD tables of the rows just built (same stream: the origins are there); surfaces at the mirror's own place only
-            for (int k = 0; k < a.nJobs && !bad && !rep; k++)
+            // the sub-pel SATD tables of the rows just built (same stream: the origins are there); surfaces at their mirror's own place only
+            for (int k = 0; k < a.nJobs && !bad; k++)
             {
-                if (!(in[k]->levels & 16))
+                const SurfItem& it = items[in[k]];
+                if (!(it.ss->levels & 16) || it.rep)
                     continue;
+                x265hip_refpic* rp = it.rp;
                 SubpelArgs sa;
                 memset(&sa, 0, sizeof(sa));
-                sa.pic = dPic + ((size_t)rp->marginY * rp->stride + rp->marginX) * rp->B;
+                sa.pic = rp->dPic + ((size_t)rp->marginY * rp->stride + rp->marginX) * rp->B;
                 sa.planes = rp->dPlanes + ((size_t)rp->marginY * rp->stride + rp->marginX) * rp->B;
                 sa.stride = rp->stride; sa.planeElems = rp->planeElems;
                 sa.src = a.job[k].src; sa.srcPitch = a.job[k].srcPitch;
@@ -925,26 +967,27 @@ static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& li
                 // that one staging, the 32 / 64 SADs are sums of the 16x16 ones), plus the bytes the CTU really emits: a 16 x 16 window of entries and an
                 // origin per block of the levels built (the surfaces themselves never leave LDS)
                 const int64_t R = 2 * a.job[k].S;
-                span.bytes += (uint64_t)a.job[k].rows * lay.ctuCols * (64 * 64 + (64 + R - 1) * (64 + R - 1)) * rp->B;
+                span.bytes += (uint64_t)a.job[k].rows * lay.ctuCols * (64 * 64 + (64 + R - 1) * (64 + R - 1)) * rp0->B;
                 for (int l = a.job[k].level0 ? 0 : 1; l < 4; l++)
                 {
                     int blockRows = 0;
                     for (int r = a.job[k].row0; r < a.job[k].row0 + a.job[k].rows; r++)
-                        for (int j = 0; j < lay.per[l]; j++)
-                            blockRows += r * lay.per[l] + j < lay.blocksY[l];
+                        for (int jj = 0; jj < lay.per[l]; jj++)
+                            blockRows += r * lay.per[l] + jj < lay.blocksY[l];
                     span.bytes += (uint64_t)blockRows * lay.blocksX[l] * (kWin * kWin * lay.entryBytes[l] + 4);
                 }
             }
             for (int k = 0; k < a.nJobs && !bad; k++)
             {
+                x265hip_sadsurf* ss = items[in[k]].ss;
                 const size_t off = (size_t)a.job[k].row0 * lay.pitch, bytes = (size_t)a.job[k].rows * lay.pitch;
-                bad = hipMemcpyAsync(in[k]->hBuf + off, in[k]->dBuf + off, bytes, hipMemcpyDeviceToHost, st) != hipSuccess;
+                bad = hipMemcpyAsync(ss->hBuf + off, ss->dBuf + off, bytes, hipMemcpyDeviceToHost, st) != hipSuccess;
             }
             if (bad || hipStreamSynchronize(st) != hipSuccess)
             {
                 set_error(X265HIP_EHIP, "sadsurf: launch, copy or synchronisation failed");
-                rp->failed = 1;
-                (void)hipSetDevice(rp->device);
+                fail_refs(items, g0, g1);
+                (void)hipSetDevice(rp0->device);
                 return;
             }
             span.commit();
@@ -953,44 +996,50 @@ static void progress(x265hip_refpic* rp, const std::vector<x265hip_sadsurf*>& li
             g_statLaunches++;
             for (int k = 0; k < a.nJobs; k++)
             {
-                in[k]->rowsBuilt = upto[k];
-                in[k]->ctuRowsReady.store(upto[k], std::memory_order_release);
+                x265hip_sadsurf* ss = items[in[k]].ss;
+                ss->rowsBuilt = upto[k];
+                ss->ctuRowsReady.store(upto[k], std::memory_order_release);
             }
+            (void)hipSetDevice(rp0->device);
         }
+        g0 = g1;
     }
-    (void)hipSetDevice(rp->device);
 }
 
-void sadsurf_rows_arrived(x265hip_refpic* rp)
+// One workgroup per CTU: a band of one CTU row of one or two surfaces fills a fraction of the chip for the same ~54 us as a full one.  A picture that is
+// still arriving therefore lets its rows wait for company — until the pending CTUs reach X265HIP_SADSURF_BATCH (default 224), the picture is complete, or
+// X265HIP_SADSURF_DEFER bands (default 8) have gone by: the searches of a frame start at least the reference-lag rows behind the band, so nobody is waiting
+// for the newest rows yet; a search that does arrive early measures its candidates on the host, same values (round 4's bench clip: 6 k of 12 million
+// lookups at 2 bands, 20-25 k at 8 and at 16).  True: leave this picture's rows for later.
+static bool rows_wait(x265hip_refpic* rp)
 {
+    static const int batch = getenv("X265HIP_SADSURF_BATCH") ? atoi(getenv("X265HIP_SADSURF_BATCH")) : 224;
+    static const int maxDefer = getenv("X265HIP_SADSURF_DEFER") ? atoi(getenv("X265HIP_SADSURF_DEFER")) : 8;
+    if (batch <= 0)
+        return false;
     std::vector<x265hip_sadsurf*> list;
     {
         std::lock_guard<std::mutex> g(g_ssLock);
         list = rp->surfaces;
     }
-    // One workgroup per CTU on 256 CUs: a band of one CTU row of one or two surfaces fills a fraction of the chip for the same ~54 us as a full one.
-    // Rows therefore wait for company — until the pending CTUs reach X265HIP_SADSURF_BATCH (default 224), the picture is complete, or two bands
-    // have gone by (the searches of a frame start at least the reference-lag rows behind the band, so nobody is waiting for the newest rows yet;
-    // a search that does arrive early measures its candidates on the host, same values).
-    static const int batch = getenv("X265HIP_SADSURF_BATCH") ? atoi(getenv("X265HIP_SADSURF_BATCH")) : 224;
-    // bands a reference picture's pending rows may wait for company.  The searches that would use them run at least the reference lag behind; the
-    // encode of round 4's bench clip asks for a row that is not there yet 4 281 times in 12 million lookups at 2 bands, and ... at 8 (X265HIP_SADSURF_DEFER)
-    static const int maxDefer = getenv("X265HIP_SADSURF_DEFER") ? atoi(getenv("X265HIP_SADSURF_DEFER")) : 8;
-    if (batch > 0)
+    const bool complete = rp->uploaded >= rp->marginY + rp->picH + rp->marginY;
+    int pending = 0;
+    for (x265hip_sadsurf* ss : list)
+        if (ss->ref == rp)
+            pending += (rows_possible(ss) - ss->rowsBuilt) * ss->lay.ctuCols;
+    if (!complete && pending < batch && rp->ssDeferred < maxDefer)
     {
-        const bool complete = rp->uploaded >= rp->marginY + rp->picH + rp->marginY;
-        int pending = 0;
-        for (x265hip_sadsurf* ss : list)
-            if (ss->ref == rp)
-                pending += (rows_possible(ss) - ss->rowsBuilt) * ss->lay.ctuCols;
-        if (!complete && pending < batch && rp->ssDeferred < maxDefer)
-        {
-            if (pending) rp->ssDeferred++;
-            return;
-        }
-        rp->ssDeferred = 0;
+        if (pending) rp->ssDeferred++;
+        return true;
     }
-    progress(rp, list);
+    rp->ssDeferred = 0;
+    return false;
+}
+
+void sadsurf_rows_arrived(x265hip_refpic* rp)
+{
+    if (!rows_wait(rp))
+        progress_multi(std::vector<x265hip_refpic*>{ rp });
 }
 
 static void free_surface(x265hip_sadsurf* ss)
@@ -1004,24 +1053,39 @@ static void free_surface(x265hip_sadsurf* ss)
     ::srcpic_unref(src);
 }
 
+// attach jobs that reached the worker together (refpic.hip RefWorker::run): each surface is set up, then the reference pictures concerned make ONE
+// pass of progress_multi — the surfaces of one source picture against its two or three reference pictures share a launch
+void sadsurf_attach_batch(const std::vector<RefJob>& jobs)
+{
+    std::vector<x265hip_refpic*> rps;
+    for (const RefJob& j : jobs)
+    {
+        x265hip_sadsurf* ss = j.ss;
+        // the worker has seen every band queued before this job, so `uploaded` is what the surface can start from
+        if (!ss->ref || j.epoch != ss->ref->epoch.load() || hipSetDevice(ss->ref->device) != hipSuccess)
+            continue;
+        if (ss->src->place != ss->ref->place && !(ss->rep = replica_at(ss->ref, ss->src->place)))
+        {
+            set_error(X265HIP_ENOMEM, "sadsurf: no replica of the reference picture at place %d", ss->src->place);
+            ss->ref->failed = 1;
+            continue;
+        }
+        bool seen = false;
+        for (x265hip_refpic* rp : rps) seen = seen || rp == ss->ref;
+        // together with whatever rows the reference's other surfaces are waiting with (a reference picture that is complete — the usual case —
+        // gives the new surface all its rows at once)
+        if (!seen && !rows_wait(ss->ref)) rps.push_back(ss->ref);
+    }
+    if (!rps.empty())
+        progress_multi(rps);
+}
+
 void sadsurf_job(const RefJob& j)
 {
     x265hip_sadsurf* ss = j.ss;
     if (j.kind == 1)
     {
-        // attach: the worker has seen every band queued before this job, so `uploaded` is what the surface can start from
-        if (ss->ref && j.epoch == ss->ref->epoch.load() && hipSetDevice(ss->ref->device) == hipSuccess)
-        {
-            if (ss->src->place != ss->ref->place && !(ss->rep = replica_at(ss->ref, ss->src->place)))
-            {
-                set_error(X265HIP_ENOMEM, "sadsurf: no replica of the reference picture at place %d", ss->src->place);
-                ss->ref->failed = 1;
-                return;
-            }
-            // together with whatever rows the reference's other surfaces are waiting with (a reference picture that is complete — the usual case —
-            // gives the new surface all its rows at once)
-            sadsurf_rows_arrived(ss->ref);
-        }
+        sadsurf_attach_batch(std::vector<RefJob>{ j });
         return;
     }
     // release
