@@ -297,3 +297,64 @@ def test_bound_encoder_serves_rectangular_pus_as_sums_of_squares(tmp_path):
     assert got == want, "bitstreams differ"
     m = re.search(r"rectangular / asymmetric PUs: (\d+) searches, (\d+) integer-pel SADs served", err)
     assert m and int(m.group(1)) > 500 and int(m.group(2)) > 5000, err[-800:]
+
+
+# ---- surfaces of several reference pictures in one launch (round 4) --------------------------------------------------------------------------------
+def _two_reference_pictures(L, hp, w, h, S, lam, levels, seeds):
+    """one source picture per reference picture, both references complete, the surfaces attached back to back; -> (views, launches of this run)"""
+    refs, srcs, sss = [], [], []
+    before = (C.c_uint64 * 4)()
+    L.x265hip_sadsurf_stats(C.byref(before, 0), C.byref(before, 8), C.byref(before, 16), C.byref(before, 24))
+    for seed in seeds:
+        buf, stride, rows, s = _pictures(w, h, seed, count=1)
+        rp = L.x265hip_refpic_create(8, w, h, stride, MX, MY, rows, buf.ctypes.data)
+        assert rp, L.x265hip_last_error()
+        assert L.x265hip_refpic_rows_final(rp, h) == 0 and L.x265hip_refpic_wait(rp) == 0
+        sp = L.x265hip_srcpic_create(8, w, h)
+        assert sp and L.x265hip_srcpic_upload(sp, s[0].ctypes.data, s[0].shape[1]) == 0
+        refs.append((rp, buf)); srcs.append((sp, s[0]))
+    for (rp, _), (sp, _) in zip(refs, srcs):
+        ss = L.x265hip_sadsurf_attach_levels(sp, rp, S, lam, levels)
+        assert ss, L.x265hip_last_error()
+        sss.append(ss)
+    for rp, _ in refs:
+        assert L.x265hip_refpic_wait(rp) == 0, L.x265hip_last_error()
+    views = [_read_view(hp, L, ss, w, h) for ss in sss]
+    after = (C.c_uint64 * 4)()
+    L.x265hip_sadsurf_stats(C.byref(after, 0), C.byref(after, 8), C.byref(after, 16), C.byref(after, 24))
+    for ss in sss:
+        L.x265hip_sadsurf_release(ss)
+    for rp, _ in refs:
+        L.x265hip_refpic_wait(rp)
+        L.x265hip_refpic_destroy(rp)
+    for sp, _ in srcs:
+        L.x265hip_srcpic_destroy(sp)
+    return views, int(after[2] - before[2])
+
+
+@pytest.mark.gpu
+def test_device_surfaces_of_three_reference_pictures_share_a_launch():
+    """Attach jobs that reach the worker within X265HIP_SADSURF_GATHER_US are built by ONE launch whichever reference picture each follows (a job carries
+    its own reference pointer): same origins and tables as the restatement builds one surface at a time.  In a process of its own: the window is read
+    once per process."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "three-references"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, X265HIP_SADSURF_GATHER_US="300000"))
+    assert r.returncode == 0, (r.stdout[-600:], r.stderr[-1200:])
+    assert "launches 1" in r.stdout, r.stdout[-400:]
+
+
+if __name__ == "__main__" and sys.argv[1:] == ["three-references"]:
+    import x265_amd.hipprim as hp
+    L = hp.lib()
+    hp.check(L.x265hip_init(0))
+    em = _emul(hp)
+    w, h, S, lam, levels, seeds = 416, 240, 32, 180, 15, (31, 32, 33)
+    got, launches = _two_reference_pictures(L, hp, w, h, S, lam, levels, seeds)
+    want, _ = _two_reference_pictures(em, hp, w, h, S, lam, levels, seeds)
+    for k in range(len(seeds)):
+        assert sorted(got[k]) == sorted(want[k]) == [0, 1, 2, 3]
+        for l in got[k]:
+            assert np.array_equal(got[k][l][0], want[k][l][0]), ("origins", k, l)
+            assert np.array_equal(got[k][l][1], want[k][l][1]), ("tables", k, l)
+    print("three surfaces on three reference pictures: launches %d" % launches)
