@@ -141,6 +141,7 @@ namespace {
 struct MirrorBufs { char* dPic; char* dPlanes; char* hPlanes; char* hStage; hipStream_t st; };
 std::mutex g_bufLock;
 std::multimap<std::pair<size_t, int>, MirrorBufs> g_bufPool;        // key: (bytes of one padded plane, device)
+size_t g_bufPoolBytes = 0;                                           // what the pooled sets hold, device + page-locked
 }
 
 x265hip_refpic* x265hip_refpic_create(int depth, int picW, int picH, int64_t stride, int marginX, int marginY, int bufRows, const void* hostBase)
@@ -190,6 +191,7 @@ static x265hip_refpic* refpic_create(int place, int depth, int picW, int picH, i
         auto it = g_bufPool.find({ planeBytes, rp->device });
         if (it != g_bufPool.end())
         {
+            g_bufPoolBytes -= 33 * planeBytes;
             rp->dPic = it->second.dPic; rp->dPlanes = it->second.dPlanes; rp->hPlanes = it->second.hPlanes; rp->hStage = it->second.hStage; rp->st = it->second.st;
             g_bufPool.erase(it);
             ok = true;
@@ -240,8 +242,30 @@ void x265hip_refpic_destroy(x265hip_refpic* rp)
     {
         // complete set: to the pool (the worker is idle for rp and its stream has been synchronised by the wait above)
         (void)hipStreamSynchronize(rp->st);
-        std::lock_guard<std::mutex> g(g_bufLock);
-        g_bufPool.insert({ { (size_t)rp->planeElems * rp->B, rp->device }, MirrorBufs{ rp->dPic, rp->dPlanes, rp->hPlanes, rp->hStage, rp->st } });
+        const size_t planeBytes = (size_t)rp->planeElems * rp->B;
+        std::vector<MirrorBufs> evicted;
+        {
+            std::lock_guard<std::mutex> g(g_bufLock);
+            g_bufPool.insert({ { planeBytes, rp->device }, MirrorBufs{ rp->dPic, rp->dPlanes, rp->hPlanes, rp->hStage, rp->st } });
+            g_bufPoolBytes += 33 * planeBytes;             // picture + 16 planes on the device, 15 planes + staging page-locked
+            // the pool is for the NEXT mirror of the same size (it was never trimmed): beyond X265HIP_POOL_MB (default 4096) sets of other
+            // sizes go first, then the oldest of this size
+            static const size_t cap = (size_t)(getenv("X265HIP_POOL_MB") ? atoll(getenv("X265HIP_POOL_MB")) : 4096) << 20;
+            while (g_bufPoolBytes > cap && g_bufPool.size() > 1)
+            {
+                auto victim = g_bufPool.begin();
+                for (auto it = g_bufPool.begin(); it != g_bufPool.end(); ++it)
+                    if (it->first.first != planeBytes) { victim = it; break; }
+                evicted.push_back(victim->second);
+                g_bufPoolBytes -= 33 * victim->first.first;
+                g_bufPool.erase(victim);
+            }
+        }
+        for (const MirrorBufs& b : evicted)                   // (allocated on the device of their key; hipFree and friends take any current device)
+        {
+            (void)pinned_free(b.hStage); (void)device_free(b.dPic); (void)device_free(b.dPlanes); (void)pinned_free(b.hPlanes);
+            if (b.st) (void)hipStreamDestroy(b.st);
+        }
     }
     else
     {
