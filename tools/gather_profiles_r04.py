@@ -63,8 +63,8 @@ cat([("resident server vs launches, first binding (transforms only)", "r04_b/ab.
      ("SAD-surface rows waiting for company: 2 / 8 / 16 bands", "r04_s/ab1080.txt"), ("resident server workgroups: 32 (default on this box) / 64 / 20", "r04_t/ab1080.txt"),
      ("FINAL TREE: on vs the round-3 feature set (r3: jobs, sub-pel tables, rectangular PUs, row batching, huge pages off)", "r04_z/ab1080.txt")], "ab_1080p_medium.txt",
     "# tools/ab_encode.py, 1080p medium 120 frames, interleaved rounds, byte-identity against the unmodified reference checked in every run (column `identical`)")
-cp("r04_i/configs2_4k_slow_star_ab.txt", "configs2_4k_slow_star_ab.txt")
-cp("r04_j/configs3_4k_main10_slower_ab.txt", "configs3_4k_main10_slower_ab.txt")
+cp("r04_c23/configs2_4k_slow_star_ab.txt", "configs2_4k_slow_star_ab.txt")
+cp("r04_c23/configs3_4k_main10_slower_ab.txt", "configs3_4k_main10_slower_ab.txt")
 cp("r04_f/subpel_hit.txt", "subpel_hit.txt")
 cat([("ioctl / munmap / mmap", "r04_f/ioctl_callers.txt"), ("runtime libraries", "r04_f/runtime_callers.txt")], "binding_overhead_callers.txt",
     "# CPU sampler with call chains (tools/prof/cpusample.c X265HIP_CPUSAMPLE_STACK=1, tools/prof/callers.py): who calls the runtime's system calls")
