@@ -694,8 +694,20 @@ int x265hip_cuserve_open(int slots, int mode, x265hip_cuserve** out)
         (void)hipDeviceGetAttribute(&largeBar, hipDeviceAttributeIsLargeBar, cs->device);
         const char* where = getenv("X265HIP_CUSERVE_MAILBOX");
         const bool wantDevice = where ? !strcmp(where, "device") : largeBar != 0;
+        bool usable = false;
         if (wantDevice && hipExtMallocWithFlags((void**)&cs->inDev, sizeof(SlotIn) * slots, hipDeviceMallocUncached) == hipSuccess &&
             hipMemset(cs->inDev, 0, sizeof(SlotIn) * slots) == hipSuccess && hipDeviceSynchronize() == hipSuccess)
+        {
+            // does a store through the BAR arrive?  A pattern into the last slot's pixel block, read back with a device-to-host copy, then cleared
+            // (a mapping that silently drops the writes would otherwise show up as jobs that never come back)
+            uint32_t pattern[16], back[16];
+            for (int k = 0; k < 16; k++) pattern[k] = 0x9e3779b9u * (uint32_t)(k + 1);
+            memcpy(cs->inDev[slots - 1].pixels, pattern, sizeof(pattern));
+            store_fence();
+            usable = hipMemcpy(back, cs->inDev[slots - 1].pixels, sizeof(back), hipMemcpyDeviceToHost) == hipSuccess && !memcmp(back, pattern, sizeof(back)) &&
+                     hipMemset(cs->inDev[slots - 1].pixels, 0, sizeof(pattern)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+        }
+        if (usable)
         {
             cs->in = cs->inDev;
             cs->inDevice = true;
