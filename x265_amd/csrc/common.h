@@ -20,8 +20,8 @@ hipError_t device_free(void* p);
 // runtime.hip: a non-blocking stream of `device` for the duration of one operation.  hipStreamCreateWithFlags takes 3.9 ms on the MI355X box
 // (tools/micro/create_cost): short-lived users share a pool instead of owning one each; streams go back, they are never destroyed.
 // runtime.hip: workgroups that stay on the chip (the CU-job server's, one per mailbox slot, each alone on a CU as far as a kernel that needs most of a
-// CU's LDS is concerned): resident_workgroups(+n / -n) keeps the count, free_compute_units(device) = CUs of the device minus that count
-void resident_workgroups(int delta);
+// CU's LDS is concerned): resident_workgroups(device, +n / -n) keeps the count per device, free_compute_units(device) = CUs of the device minus that count
+void resident_workgroups(int device, int delta);
 int free_compute_units(int device);
 hipStream_t stream_lease(int device);
 void stream_return(int device, hipStream_t st);

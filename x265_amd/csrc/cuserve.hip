@@ -752,7 +752,7 @@ int x265hip_cuserve_open(int slots, int mode, x265hip_cuserve** out)
         std::lock_guard<std::mutex> g(g_openLock);
         for (x265hip_cuserve*& slot : g_open)
             if (!slot) { slot = cs; break; }
-        resident_workgroups(slots);
+        resident_workgroups(cs->device, slots);
     }
     *out = cs;
     return X265HIP_OK;
@@ -793,7 +793,7 @@ int x265hip_cuserve_close(x265hip_cuserve* cs)
     {
         std::lock_guard<std::mutex> g(g_openLock);
         for (x265hip_cuserve*& slot : g_open)
-            if (slot == cs) { slot = nullptr; resident_workgroups(-cs->slots); }
+            if (slot == cs) { slot = nullptr; resident_workgroups(cs->device, -cs->slots); }
     }
     if (cs->in)
     {

@@ -92,8 +92,8 @@ int place_of_device(int device) { return -(device + 1); }
 
 static std::atomic<uint64_t> g_clkSpans[X265HIP_CLK_COUNT], g_clkNs[X265HIP_CLK_COUNT], g_clkBytes[X265HIP_CLK_COUNT];
 
-static std::atomic<int> g_residentWgs{ 0 };
-void resident_workgroups(int delta) { g_residentWgs += delta; }
+static std::atomic<int> g_residentWgs[64];
+void resident_workgroups(int device, int delta) { if (device >= 0 && device < 64) g_residentWgs[device] += delta; }
 int free_compute_units(int device)
 {
     static std::atomic<int> cus[64];
@@ -105,7 +105,7 @@ int free_compute_units(int device)
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v < 1) { (void)hipGetLastError(); v = 256; }
         cus[device] = n = v;
     }
-    const int left = n - g_residentWgs.load();
+    const int left = n - g_residentWgs[device].load();
     return left > n / 4 ? left : n / 4;
 }
 
