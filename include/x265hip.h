@@ -917,8 +917,9 @@ int x265hip_cuserve_slot(x265hip_cuserve* cs, int slot, x265hip_cujob** job, voi
                          const int16_t** levels, const int16_t** resi);
 /* hands the slot's job to the device; *seq = the ticket: the value the units' `ready` / `readyInv` words take (unique among the slot's recent jobs) */
 int x265hip_cuserve_submit(x265hip_cuserve* cs, int slot, uint32_t* seq);
-/* to be called now and then by a caller that is still waiting (mode 0: restarts a server that has gone idle meanwhile); returns
- * X265HIP_EHIP when the device reported a failure: the caller gives up the job and computes on the host */
+/* to be called now and then by a caller that is still waiting (mode 0: restarts a server that has gone idle meanwhile).  Returns 0: wait on;
+ * 1: wait on, and do not count this time against your timeout — the servers are paused for a device synchronisation or the server is still on its
+ * way onto the chip; X265HIP_EHIP (negative): the device reported a failure, the caller gives up the job and computes on the host */
 int x265hip_cuserve_poke(x265hip_cuserve* cs, int slot);
 int x265hip_cuserve_stats(x265hip_cuserve* cs, uint64_t* jobs, uint64_t* serverStarts, uint64_t* deviceNs);
 

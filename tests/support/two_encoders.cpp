@@ -140,7 +140,7 @@ int main(int argc, char** argv)
         signal(SIGABRT, [](int) { dump_stack(0); _exit(12); });
         std::thread(watchdog, atoi(w)).detach();
     }
-    if (argc < 2) { fprintf(stderr, "usage: two_encoders <out-prefix>\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: two_encoders <out-prefix> [par]\n"); return 2; }
     // sizes chosen so that freed buffers of one session are likely to be handed out again in the next, whole or in part
     const Session sessions[] = {
         { 352, 288, 10, 11, "medium", 3 },
@@ -157,7 +157,13 @@ int main(int argc, char** argv)
         snprintf(path, sizeof(path), "%s_%d.hevc", argv[1], k);
         ok[k] = run(sessions[k], path);
     };
-    if (par)
+    // TWO_ENCODERS_ONLY=<k>: session k alone (telling an encoder's own timing dependence from interference between live encoders)
+    if (const char* only = getenv("TWO_ENCODERS_ONLY"))
+    {
+        for (int k = 0; k < n; k++) ok[k] = true;
+        one(atoi(only));
+    }
+    else if (par)
     {
         const int groups[2][2] = { { 0, 2 }, { 2, 5 } };
         for (const auto& g : groups)

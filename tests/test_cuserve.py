@@ -175,7 +175,9 @@ def _run_on(hp, L, cs, slot, j, pix, timeout=20.0):
     un = C.cast(units, C.POINTER(hp.CuJobUnit))
     t0 = time.time()
     while any(un[k[4]].ready != seq.value or un[k[4]].readyInv != seq.value for k in lay):
-        hp.check(L.x265hip_cuserve_poke(cs, slot))
+        pk = L.x265hip_cuserve_poke(cs, slot)              # 0 / 1: wait on (1: the server is on its way); negative: failed
+        if pk < 0:
+            hp.check(pk)
         assert time.time() - t0 < timeout, "job not finished after %.0f s" % timeout
     lv = np.ctypeslib.as_array(C.cast(levels, C.POINTER(C.c_int16)), (hp.CUJOB_MAX_ELEMS,)).copy()
     rs = np.ctypeslib.as_array(C.cast(resi, C.POINTER(C.c_int16)), (hp.CUJOB_MAX_ELEMS,)).copy()

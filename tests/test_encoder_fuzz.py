@@ -41,6 +41,39 @@ def test_random_option_set_is_byte_identical_with_emulated_abi(tmp_path, seed):
     _check(seed, _need("x265_emul_8bit"), tmp_path)
 
 
+# Explicit cases (not drawn): option COMBINATIONS the table only ever draws one at a time.  The first two are round 4's advisor finding — with
+# --max-tu-size 16 and --tu-inter-depth 3 / 4 a 32x32 CU's residual tree goes below the CU job's smallest transform size, and the CU's final sse / psy answers
+# must not be put together from the job's 16x16 units (x265_hip_cuserve.cpp final_sum); run under X265HIP_VERIFY, which aborts on a wrong served value.
+EXPLICIT = [
+    dict(width=416, height=240, frames=10, csp="i420", fade=False, seed=9001, args=["--preset", "medium", "--max-tu-size", "16", "--tu-inter-depth", "3", "--rdoq-level", "0", "-F", "2", "--pools", "4"]),
+    dict(width=416, height=240, frames=10, csp="i420", fade=False, seed=9002, args=["--preset", "medium", "--max-tu-size", "16", "--tu-inter-depth", "4", "--tu-intra-depth", "4", "-F", "2", "--pools", "4"]),
+    dict(width=352, height=288, frames=8, csp="i420", fade=False, seed=9003, args=["--preset", "fast", "--max-tu-size", "8", "--tu-inter-depth", "2", "-F", "1", "--pools", "4"]),
+    dict(width=416, height=240, frames=8, csp="i420", fade=False, seed=9004, args=["--preset", "medium", "--ctu", "32", "--max-tu-size", "16", "--tu-inter-depth", "2", "--psy-rd", "0", "-F", "2", "--pools", "4"]),
+]
+
+
+def _explicit(case, bound, tmp_path):
+    import fuzz_encoder as fz
+    os.environ["X265HIP_VERIFY"] = "1"
+    try:
+        r = fz.run_case(case, bound, _need("x265_8bit"), str(tmp_path), bits=8)
+    finally:
+        del os.environ["X265HIP_VERIFY"]
+    assert r["encoded"], r
+    assert r["ok"], "explicit case %d: bitstreams differ\n%s" % (case["seed"], r["cmd"])
+
+
+@pytest.mark.parametrize("case", EXPLICIT, ids=lambda c: str(c["seed"]))
+def test_explicit_option_combination_is_byte_identical_with_emulated_abi(tmp_path, case):
+    _explicit(case, _need("x265_emul_8bit"), tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", EXPLICIT, ids=lambda c: str(c["seed"]))
+def test_explicit_option_combination_is_byte_identical_on_gpu(tmp_path, case):
+    _explicit(case, _need("x265_hip_8bit"), tmp_path)
+
+
 MAIN10_SEEDS = [202, 203, 205, 206, 207, 209, 210, 213, 214, 217]
 
 

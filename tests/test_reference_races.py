@@ -1,0 +1,96 @@
+"""A place where the REFERENCE's output depends on what else its process has done — found while chasing "encoders running concurrently in one
+process intermittently emit a different bitstream" (round 4's review), shown here with the reference's objects alone, and closed for binaries that carry
+the bindings by x265_amd/host/x265_hip_refraces.cpp.
+
+Analysis::m_refineLevel is read uninitialised (analysis.cpp:1314, :2019; assigned only in recodeCU :2435-2437; the constructor :73-83 leaves it
+    out).  The Analysis objects are `new ThreadLocalData[numTLD]` (frameencoder.cpp:298) — zero pages in a process that never freed a large block,
+    recycled memory otherwise.  A stale 2 there with early skip off (presets slow / slower) changes the bitstream.  An allocator shim writes 2 into
+    exactly those four bytes: the unmodified reference's output moves, the bound encoder's does not."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+SLOW_SESSION = 3          # tests/support/two_encoders.cpp: 176x144, preset slow (early skip off), 12 frames
+POOL_WORKERS = 4          # its `pools 4`: numTLD (frameencoder.cpp:294-298)
+
+
+def _need(name):
+    p = os.path.join(REF, name)
+    if not os.path.exists(p):
+        pytest.skip("%s not built (needs /root/reference at build time: make -C oracle emul)" % name)
+    return p
+
+
+def _poison_env(word):
+    elem, off = (int(x) for x in subprocess.run([_need("tld_layout8")], capture_output=True, text=True, check=True).stdout.split())
+    return dict(LD_PRELOAD=_need("allocshim.so"), ALLOCSHIM_SIZE=str(8 + POOL_WORKERS * elem), ALLOCSHIM_ELEM=str(elem), ALLOCSHIM_OFFSET=str(off), ALLOCSHIM_WORD=str(word))
+
+
+def _encode(exe, prefix, env, only=None, par=False):
+    e = dict(os.environ, X265HIP="require", **env)
+    if only is not None:
+        e["TWO_ENCODERS_ONLY"] = str(only)
+    r = subprocess.run([exe, prefix] + (["par"] if par else []), capture_output=True, text=True, timeout=900, env=e)
+    assert r.returncode == 0, r.stderr[-600:]
+    return r
+
+
+def _bytes(prefix, k):
+    return open("%s_%d.hevc" % (prefix, k), "rb").read()
+
+
+def test_reference_reads_refine_level_uninitialised_and_the_bound_encoder_does_not(tmp_path):
+    ref, bound = _need("two_encoders_ref8"), _need("two_encoders_emul8")
+    _encode(ref, str(tmp_path / "clean"), {}, only=SLOW_SESSION)
+    clean = _bytes(str(tmp_path / "clean"), SLOW_SESSION)
+    assert len(clean) > 1000
+    # the member's canonical state — what a fresh mapping holds — written explicitly: nothing moves
+    _encode(ref, str(tmp_path / "zero"), _poison_env(0), only=SLOW_SESSION)
+    assert _bytes(str(tmp_path / "zero"), SLOW_SESSION) == clean
+    # the state recycled memory can leave it in: the reference's own output moves.  (Should a later reference initialise the member, this assertion is
+    # the one to delete — and with it Analysis::Analysis() in x265_hip_refraces.cpp.)
+    _encode(ref, str(tmp_path / "two"), _poison_env(2), only=SLOW_SESSION)
+    assert _bytes(str(tmp_path / "two"), SLOW_SESSION) != clean, "the reference no longer depends on the uninitialised Analysis::m_refineLevel"
+    # the bound encoder (bindings over the emulated ABI) under the same poison: the reference's clean output
+    _encode(bound, str(tmp_path / "bound"), _poison_env(2), only=SLOW_SESSION)
+    assert _bytes(str(tmp_path / "bound"), SLOW_SESSION) == clean
+
+
+def test_concurrent_encoders_stay_identical_with_poisoned_analysis_objects(tmp_path):
+    """the review's failing shape made deterministic: three encoders alive at once, every Analysis object of every encoder born with the stale value"""
+    _encode(_need("two_encoders_ref8"), str(tmp_path / "ref"), {})
+    env = _poison_env(2)
+    # (the other sessions' pools have four workers too: same block size, every session is poisoned)
+    _encode(_need("two_encoders_emul8"), str(tmp_path / "bound"), dict(env, X265HIP_SADPLANES_RANGE="12"), par=True)
+    for k in range(5):
+        assert _bytes(str(tmp_path / "ref"), k) == _bytes(str(tmp_path / "bound"), k), "session %d differs from the reference" % k
+
+
+def test_concurrent_encoders_stress_amplified(tmp_path):
+    """the review's amplified reproduction (X265HIP_REFPLANES=0, three encoders at a time), looped: 13 % of such runs differed before the fix"""
+    _encode(_need("two_encoders_ref8"), str(tmp_path / "ref"), {})
+    want = [_bytes(str(tmp_path / "ref"), k) for k in range(5)]
+    bound = _need("two_encoders_emul8")
+    loops, lanes = 10, 3                                 # 30 runs, three at a time (the load is part of the reproduction)
+    for i in range(loops):
+        procs = [subprocess.Popen([bound, str(tmp_path / ("b%d_%d" % (i, l))), "par"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                  env=dict(os.environ, X265HIP="require", X265HIP_REFPLANES="0", X265HIP_SADPLANES_RANGE="12")) for l in range(lanes)]
+        for l, p in enumerate(procs):
+            assert p.wait(timeout=900) == 0
+            for k in range(5):
+                assert _bytes(str(tmp_path / ("b%d_%d" % (i, l))), k) == want[k], "run %d.%d: session %d differs from the reference" % (i, l, k)
+
+
+@pytest.mark.gpu
+def test_concurrent_encoders_stress_on_gpu(tmp_path):
+    _encode(_need("two_encoders_ref8"), str(tmp_path / "ref"), {})
+    want = [_bytes(str(tmp_path / "ref"), k) for k in range(5)]
+    bound = _need("two_encoders_hip8")
+    for i in range(12):
+        env = _poison_env(2) if i % 2 else {}
+        _encode(bound, str(tmp_path / ("g%d" % i)), dict(env, X265HIP_REFPLANES="0" if i % 3 == 0 else "1"), par=True)
+        for k in range(5):
+            assert _bytes(str(tmp_path / ("g%d" % i)), k) == want[k], "run %d: session %d differs from the reference" % (i, k)

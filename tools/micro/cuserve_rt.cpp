@@ -66,7 +66,7 @@ int main(int argc, char** argv)
                             __builtin_ia32_pause();
                             if ((++spins & 1023) == 0)
                             {
-                                if (x265hip_cuserve_poke(cs, t)) { fprintf(stderr, "poke: %s\n", x265hip_last_error()); failed = true; break; }
+                                if (x265hip_cuserve_poke(cs, t) < 0) { fprintf(stderr, "poke: %s\n", x265hip_last_error()); failed = true; break; }
                                 if (now_us() - t0 > 2e6) { fprintf(stderr, "job %d of thread %d: unit %d not ready after 2 s\n", i, t, u); failed = true; break; }
                             }
                         }

@@ -616,6 +616,7 @@ struct x265hip_cuserve
 };
 static std::mutex g_openLock;
 static x265hip_cuserve* g_open[16];               // the services with a resident server (mode 0)
+static int g_pauseDepth;                          // servers_pause() calls without their servers_resume() yet (under g_openLock): a service opened meanwhile joins them
 
 static int start_server(x265hip_cuserve* cs)
 {
@@ -650,6 +651,7 @@ namespace xh {
 void servers_pause()
 {
     std::lock_guard<std::mutex> g(g_openLock);
+    g_pauseDepth++;
     for (x265hip_cuserve* cs : g_open)
     {
         if (!cs) continue;
@@ -667,8 +669,9 @@ void servers_pause()
 void servers_resume()
 {
     std::lock_guard<std::mutex> g(g_openLock);
+    if (g_pauseDepth > 0) g_pauseDepth--;
     for (x265hip_cuserve* cs : g_open)
-        if (cs && --cs->paused == 0)
+        if (cs && cs->paused.load() > 0 && --cs->paused == 0)
             __atomic_store_n(&cs->hostCtl->leave, 0u, __ATOMIC_RELEASE);
 }
 } // namespace xh
@@ -680,6 +683,23 @@ int x265hip_cuserve_open(int slots, int mode, x265hip_cuserve** out)
     XH_CHECK_DEV();
     if (!out || slots < 1 || slots > 256 || mode < 0 || mode > 1)
         return set_error(X265HIP_EINVAL, "x265hip_cuserve_open: slots %d mode %d", slots, mode);
+    if (mode == 0)
+    {
+        // every slot is a resident workgroup: all of them must fit on the chip at once, or the jobs of the ones that never get a CU are never done.  What fits is
+        // bounded by the LDS a workgroup holds (sizeof(JobLds)); a quarter of the CUs stays free for the kernels that are launched and finish
+        int dev = 0, cus = 0, lds = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 &&
+            hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) == hipSuccess && lds > 0)
+        {
+            const int perCu = lds / (int)sizeof(JobLds) > 0 ? lds / (int)sizeof(JobLds) : 1;
+            const int fit = (cus - cus / 4) * perCu;
+            if (slots > fit)
+                return set_error(X265HIP_EINVAL, "x265hip_cuserve_open: %d resident workgroups asked for, %d fit beside the other kernels (%d CUs, %d per CU)", slots, fit, cus, perCu);
+        }
+        else
+            (void)hipGetLastError();
+    }
     x265hip_cuserve* cs = new (std::nothrow) x265hip_cuserve;
     if (!cs) return set_error(X265HIP_ENOMEM, "x265hip_cuserve_open: out of memory");
     cs->slots = slots; cs->mode = mode;
@@ -750,8 +770,16 @@ int x265hip_cuserve_open(int slots, int mode, x265hip_cuserve** out)
     if (mode == 0)
     {
         std::lock_guard<std::mutex> g(g_openLock);
+        bool registered = false;
         for (x265hip_cuserve*& slot : g_open)
-            if (!slot) { slot = cs; break; }
+            if (!slot) { slot = cs; registered = true; break; }
+        if (!registered) { x265hip_cuserve_close(cs); return set_error(X265HIP_EINVAL, "x265hip_cuserve_open: more than %d services with a resident server", (int)(sizeof(g_open) / sizeof(g_open[0]))); }
+        // opened in the middle of somebody's device synchronisation: this service is paused with the others and resumes with them
+        if (g_pauseDepth > 0)
+        {
+            cs->paused = g_pauseDepth;
+            __atomic_store_n(&cs->hostCtl->leave, 1u, __ATOMIC_RELEASE);
+        }
         resident_workgroups(cs->device, slots);
     }
     *out = cs;
@@ -873,8 +901,15 @@ int x265hip_cuserve_poke(x265hip_cuserve* cs, int slot)
 {
     if (!cs || slot < 0 || slot >= cs->slots) return set_error(X265HIP_EINVAL, "x265hip_cuserve_poke: slot %d", slot);
     if (__atomic_load_n(&cs->out[slot].failed, __ATOMIC_ACQUIRE)) return set_error(X265HIP_EHIP, "cuserve: the device gave up a job of slot %d", slot);
-    if (cs->mode == 0 && __atomic_load_n(&cs->hostCtl->serverState, __ATOMIC_ACQUIRE) == 0)
-        return start_server(cs);
+    if (cs->mode == 0)
+    {
+        // 1: nothing is wrong and nothing can be expected yet — a device synchronisation has the servers paused (device_free), or the server is on its way
+        // onto the chip (started now, or "being started": the device clears the flag when the kernel runs).  The caller's timeout does not run meanwhile.
+        if (cs->paused.load() > 0) return 1;
+        const uint32_t st = __atomic_load_n(&cs->hostCtl->serverState, __ATOMIC_ACQUIRE);
+        if (st == 0) { const int e = start_server(cs); return e ? e : 1; }
+        if (st & 0x80000000u) return 1;
+    }
     return X265HIP_OK;
 }
 

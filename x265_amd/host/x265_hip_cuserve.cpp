@@ -25,6 +25,7 @@
 // Seams (same link technique as the other seams, oracle/Makefile): Search::estimateResidualQT, Search::checkIntraInInter on search.o;
 // Quant::transformNxN, Quant::invtransformNxN on quant.o; Search::encodeResAndCalcRdInterCU (the scope) with the reference's body renamed in place.
 #include <atomic>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -81,6 +82,8 @@ int g_time = 0;                  // X265HIP_DEBUG_CUTIME=1: cycles inside the fu
                                  // =2: the same with the jobs running (the pair of runs measures what the jobs save and what the waiting costs)
 int g_minLog2 = 5;               // X265HIP_CUSERVE_MIN: smallest CU (log2) whose residual quad-tree becomes a job
 int g_mode = 0;                  // X265HIP_CUSERVE_MODE: 0 resident server (mailbox), 1 one launch per job
+int64_t g_timeoutNs = 10000000000ll;            // X265HIP_CUSERVE_TIMEOUT_MS
+std::atomic<int> g_lateJobs(0);
 int g_slots = 64;                // X265HIP_CUSERVE_SLOTS: jobs that can be in flight (default: twice the CPUs this process may use, 16..64)
 bool g_verify = false;           // X265HIP_VERIFY=1: every served unit is recomputed by the reference's function and compared
 bool g_require = false;          // X265HIP=require: a device failure is fatal instead of falling back
@@ -230,6 +233,7 @@ bool decide()
         g_verify = getenv("X265HIP_VERIFY") != NULL;
         if (getenv("X265HIP_CUSERVE_MIN")) { const int v = atoi(getenv("X265HIP_CUSERVE_MIN")); g_minLog2 = v >= 64 ? 6 : v >= 32 ? 5 : 4; }
         if (getenv("X265HIP_CUSERVE_MODE")) g_mode = atoi(getenv("X265HIP_CUSERVE_MODE")) ? 1 : 0;
+        if (getenv("X265HIP_CUSERVE_TIMEOUT_MS") && atoll(getenv("X265HIP_CUSERVE_TIMEOUT_MS")) > 0) g_timeoutNs = atoll(getenv("X265HIP_CUSERVE_TIMEOUT_MS")) * 1000000ll;
         if (getenv("X265HIP_CUSERVE_SLOTS")) g_slots = atoi(getenv("X265HIP_CUSERVE_SLOTS"));
         else
         {
@@ -394,15 +398,28 @@ inline bool wait_word(Job& j, const uint32_t* ready, int site)
     if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == j.seq) return true;
     const uint64_t t0 = __builtin_ia32_rdtsc();
     uint64_t spins = 0;
+    int64_t waitedNs = 0, lastNs = -1;
     while (__atomic_load_n(ready, __ATOMIC_ACQUIRE) != j.seq)
     {
         __builtin_ia32_pause();
         if ((++spins & 255) == 0)
         {
-            if (x265hip_cuserve_poke(j.svc->cs, j.slot) || __builtin_ia32_rdtsc() - t0 > 3000000000ull)      // ~1 s: not a latency, a failure
+            // Not a latency, a failure — but only time the device could have used counts (wall clock; x265hip_cuserve_poke says 1 while the servers are
+            // paused for somebody's hipFree or the server is still on its way onto the chip), the bound is generous (X265HIP_CUSERVE_TIMEOUT_MS, default 10 s),
+            // and one late job costs that job only: the third one in an encode switches the offload off
+            const int pk = x265hip_cuserve_poke(j.svc->cs, j.slot);
+            timespec ts;
+            clock_gettime(CLOCK_MONOTONIC, &ts);
+            const int64_t nowNs = (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+            if (pk == 0 && lastNs >= 0) waitedNs += nowNs - lastNs;
+            lastNs = nowNs;
+            if (pk < 0 || waitedNs > g_timeoutNs)
             {
                 abandon(j);
-                device_failed("a job did not come back");
+                if (pk < 0 || g_lateJobs.fetch_add(1) + 1 >= 3)
+                    device_failed("a job did not come back");
+                else
+                    fprintf(stderr, "x265hip: cuserve: a job did not come back within %lld ms; this CU is computed on the host\n", (long long)(g_timeoutNs / 1000000));
                 return false;
             }
         }
@@ -600,7 +617,9 @@ inline bool job_sse(Job& j, const pixel* a, intptr_t sa, const pixel* b, intptr_
 template <typename F> inline bool final_sum(Job& j, const pixel* a, intptr_t sa, const pixel* b, intptr_t sb, int n, F unit_value, int64_t& out)
 {
     Where w;
-    if (g_serveDist < 2 || j.inTree || j.sHi != j.sLo || !where_in_source(j, a, sa, n, w) || w.x || w.y) return false;
+    // "one transform size in the job" must also mean "one transform size in the TREE": x265hipi_cujob_levels clamps the job's smallest size to 16, the tree
+    // may go below it (--max-tu-size 16 --tu-inter-depth 3: depthRange [3, 4]) and a unit split further has neither the job's coded nor its zero answer
+    if (g_serveDist < 2 || j.inTree || j.sHi != j.sLo || (int)j.job->log2TrMin < j.sLo || !where_in_source(j, a, sa, n, w) || w.x || w.y) return false;
     const int N = (1 << j.log2CU) >> (w.plane ? 1 : 0);
     if (n != N) return false;
     const Yuv& ry = j.mode->reconYuv;

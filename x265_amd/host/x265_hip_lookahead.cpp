@@ -394,8 +394,8 @@ void compute(CostEstimateGroup& g, const Job* jobs, int n, bool coop)
             // X265HIP_DEBUG_TRACE=1: one line per estimate — what was asked and what came back (sums of the arrays), for diffing two runs
             auto sum32 = [](const int32_t* p, int n) { uint64_t h = 1469598103934665603ull; for (int k = 0; k < n; k++) { h ^= (uint32_t)p[k]; h *= 1099511628211ull; } return h; };
             const int ncu = l.m_8x8Width * l.m_8x8Height;
-            fprintf(stderr, "x265hip-trace: b %d p0 %d p1 %d search %d%d weighted %d coop %d -> cost %lld aq %lld intra %d mvs0 %016llx mvc0 %016llx mvs1 %016llx mvc1 %016llx lc %016llx rows %016llx intraMbsAcc %d in: intraCost %016llx planes %016llx ref %016llx\n",
-                    fenc->frameNum, g.m_frames[j.p0]->frameNum, g.m_frames[j.p1]->frameNum, e.search0, e.search1, e.weightedId, (int)coop,
+            fprintf(stderr, "x265hip-trace: w %d b %d p0 %d p1 %d search %d%d weighted %d coop %d -> cost %lld aq %lld intra %d mvs0 %016llx mvc0 %016llx mvs1 %016llx mvc1 %016llx lc %016llx rows %016llx intraMbsAcc %d in: intraCost %016llx planes %016llx ref %016llx\n",
+                    fenc->width, fenc->frameNum, g.m_frames[j.p0]->frameNum, g.m_frames[j.p1]->frameNum, e.search0, e.search1, e.weightedId, (int)coop,
                     (long long)e.costEst, (long long)e.costEstAq, e.intraMbs, (unsigned long long)sum32((const int32_t*)fenc->lowresMvs[0][e.dist0], 2 * ncu),
                     (unsigned long long)sum32(fenc->lowresMvCosts[0][e.dist0], ncu),
                     (unsigned long long)(j.p1 > j.b ? sum32((const int32_t*)fenc->lowresMvs[1][e.dist1], 2 * ncu) : 0),

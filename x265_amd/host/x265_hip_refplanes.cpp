@@ -430,11 +430,46 @@ void FrameFilter::processPostRow(int row)
             }
         }
     }
+    // (before the body: its last statement lets the frame encoder go on to the next frame, framefilter.cpp:719-722, and m_frame changes under a reader)
+    // X265HIP_DEBUG_TRACE=1: one line per finished CTU row — picture width, POC, slice type and QP, and a hash of the row's reconstructed luma and chroma; the
+    // first line that differs between two runs names the first picture row whose reconstruction differs (seams on or off)
+    static const bool trace = getenv("X265HIP_DEBUG_TRACE") != NULL;
+    if (trace && m_frame && m_frame->m_reconPic && m_frame->m_encData)
+    {
+        const PicYuv* rec = m_frame->m_reconPic;
+        const int cs = (int)m_param->maxCUSize, y0 = row * cs, y1 = X265_MIN((int)rec->m_picHeight, y0 + cs);
+        uint64_t h = 1469598103934665603ull, hc = h;
+        for (int y = y0; y < y1; y++)
+            for (int x = 0; x < (int)rec->m_picWidth; x++) { h ^= rec->m_picOrg[0][(intptr_t)y * rec->m_stride + x]; h *= 1099511628211ull; }
+        if (rec->m_picCsp != X265_CSP_I400)
+            for (int k = 1; k < 3; k++)
+                for (int y = y0 >> rec->m_vChromaShift; y < (y1 >> rec->m_vChromaShift); y++)
+                    for (int x = 0; x < (int)(rec->m_picWidth >> rec->m_hChromaShift); x++) { hc ^= rec->m_picOrg[k][(intptr_t)y * rec->m_strideC + x]; hc *= 1099511628211ull; }
+        const Slice* sl = m_frame->m_encData->m_slice;
+        // ... and, per CTU of the row, of the decisions its analysis left in the picture's CU data (final once the row is analysed, unlike the pixels above,
+        // which the in-loop filters of the next row still touch)
+        const uint32_t wCtu = (rec->m_picWidth + cs - 1) / cs;
+        for (uint32_t c = 0; c < wCtu; c++)
+        {
+            const CUData* ctu = m_frame->m_encData->getPicCTU(row * wCtu + c);
+            const uint32_t np = ctu->m_numPartitions;
+            // vectors count only where the list is used (the other entries are whatever the buffer held)
+            auto hmv = [np, ctu](int list) { uint64_t x = 1469598103934665603ull; for (uint32_t i = 0; i < np; i++) if (ctu->m_predMode[i] != MODE_INTRA && ctu->m_refIdx[list][i] >= 0) { x ^= (uint32_t)ctu->m_mv[list][i].word; x *= 1099511628211ull; } return (unsigned)(x ^ (x >> 32)) & 0xffffff; };
+            auto hb = [np](const void* p, size_t el) { uint64_t x = 1469598103934665603ull; const uint8_t* b = (const uint8_t*)p; for (size_t i = 0; i < np * el; i++) { x ^= b[i]; x *= 1099511628211ull; } return (unsigned)(x ^ (x >> 32)) & 0xffffff; };
+            fprintf(stderr, "x265hip-trace: ctu w %d poc %d addr %u depth %06x pred %06x part %06x merge %06x skip %06x dir %06x ref0 %06x ref1 %06x mv0 %06x mv1 %06x mvp0 %06x mvp1 %06x tu %06x cbfY %06x cbfU %06x "
+                    "cbfV %06x qp %06x intra %06x\n", (int)rec->m_picWidth, m_frame->m_poc, row * wCtu + c, hb(ctu->m_cuDepth, 1), hb(ctu->m_predMode, 1), hb(ctu->m_partSize, 1), hb(ctu->m_mergeFlag, 1),
+                    hb(ctu->m_skipFlag[0], 1), hb(ctu->m_interDir, 1), hb(ctu->m_refIdx[0], 1), hb(ctu->m_refIdx[1], 1), hmv(0), hmv(1), hb(ctu->m_mvpIdx[0], 1),
+                    hb(ctu->m_mvpIdx[1], 1), hb(ctu->m_tuDepth, 1), hb(ctu->m_cbf[0], 1), hb(ctu->m_cbf[1], 1), hb(ctu->m_cbf[2], 1), hb(ctu->m_qp, 1), hb(ctu->m_lumaIntraDir, 1));
+        }
+    }
+    // the body's last statement counts the row as complete (framefilter.cpp:719-722): with the picture's last row the frame encoder goes on and
+    // m_frame may already be the NEXT picture when the body returns — whatever is needed afterwards is read now
+    const int pocOfRow = m_frame ? m_frame->m_poc : -1;
     refProcessPostRow(this, row);
     if (m)
     {
         std::lock_guard<std::mutex> g(m->lock);
-        if (m->tracking && m->poc == m_frame->m_poc)
+        if (m->tracking && m->poc == pocOfRow)
         {
             m->rowDone[row >> 6] |= 1ull << (row & 63);
             int prefix = m->prefix;

@@ -625,6 +625,25 @@ void MotionEstimate::setSourcePU(const Yuv& srcFencYuv, int _ctuAddr, int cuPart
 int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const MV& mvmax, const MV& qmvp, int numCandidates, const MV* mvc, int merange,
                                    MV& outQMv, uint32_t maxSlices, pixel* srcReferencePlane)
 {
+    // X265HIP_DEBUG_TRACE=2: one line per search — what went in (hashes of the source PU and of the reference block at the PU's position and around it,
+    // the predictor, the candidates, the range) and what came out; sorted, the lines of two runs of the same encode are equal or name the first search that differs
+    static const bool trace = getenv("X265HIP_DEBUG_TRACE") && atoi(getenv("X265HIP_DEBUG_TRACE")) >= 2;
+    if (trace && ctuAddr >= 0 && !ref->isLowres)
+    {
+        auto hb = [](const pixel* p, intptr_t stride, int w, int h) { uint64_t x = 1469598103934665603ull; for (int r = 0; r < h; r++) for (int c = 0; c < w; c++) { x ^= p[r * stride + c]; x *= 1099511628211ull; } return (unsigned)(x ^ (x >> 32)) & 0xffffff; };
+        const intptr_t off = ref->reconPic->m_cuOffsetY[ctuAddr] + ref->reconPic->m_buOffsetY[absPartIdx];
+        static const uint8_t puH[25] = { 4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 12, 16, 4, 16, 24, 32, 8, 32, 48, 64, 16, 64 };     // primitives.h:41-55 (blockheight is never set, motion.cpp:178)
+        const int blockheight = puH[partEnum];
+        const unsigned hs = hb(fencPUYuv.m_buf[0], FENC_STRIDE, blockwidth, blockheight), hr = hb(ref->fpelPlane[0] + off, ref->lumaStride, blockwidth, blockheight);
+        const unsigned hwin = hb(ref->fpelPlane[0] + off - 8 * ref->lumaStride - 8, ref->lumaStride, blockwidth + 16, blockheight + 16);
+        uint64_t hc = 1469598103934665603ull;
+        for (int i = 0; i < numCandidates; i++) { hc ^= (uint32_t)mvc[i].word; hc *= 1099511628211ull; }
+        const int r = refMotionEstimate(this, ref, mvmin, mvmax, qmvp, numCandidates, mvc, merange, outQMv, maxSlices, srcReferencePlane);
+        static std::atomic<uint64_t> seq(0);
+        fprintf(stderr, "x265hip-trace: me seq %llu w %d ctu %d part %d pu %dx%d weighted %d src %06x ref %06x win %06x mvp %d,%d cand %d %06x range %d,%d..%d,%d -> %d,%d cost %d\n", (unsigned long long)seq.fetch_add(1), (int)ref->reconPic->m_picWidth, ctuAddr,
+                absPartIdx, blockwidth, blockheight, (int)ref->isWeighted, hs, hr, hwin, qmvp.x, qmvp.y, numCandidates, (unsigned)(hc ^ (hc >> 32)) & 0xffffff, mvmin.x, mvmin.y, mvmax.x, mvmax.y, outQMv.x, outQMv.y, r);
+        return r;
+    }
     if (g_state <= 0 || ctuAddr < 0 || srcReferencePlane || ref->isWeighted || ref->isLowres)
         return refMotionEstimate(this, ref, mvmin, mvmax, qmvp, numCandidates, mvc, merange, outQMv, maxSlices, srcReferencePlane);
     const PuInfo* u = NULL;

@@ -382,6 +382,8 @@ void x265hip_install_psy_slots(EncoderPrimitives& p)
     // and without one the wrappers find nothing to serve and call the C functions
     if (!switched_on())
         return;
+    if (getenv("X265HIP_SRCPLANES_PSY") && !strcmp(getenv("X265HIP_SRCPLANES_PSY"), "0"))
+        return;                                        // the seams and the planes stay, the psy slots keep the C functions (a diagnostic)
     // What the slots did before: the reference's C functions, from a table built for the purpose (x265hip_c_table, x265_hip_primitives.cpp), once.
     // Not a copy of `p`: x265_setup_primitives is not serialised between encoders opened at the same time (primitives.cpp:
     // `if (!primitives.pu[0].sad)`), so `p` may be half filled by another thread or already hold these very wrappers — a wrapper that
