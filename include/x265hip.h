@@ -851,6 +851,12 @@ typedef struct x265hip_cujob
     int32_t  qpRem[3], qpPer[3];  /* Quant::m_qpParam[Y, Cb, Cr] */
     int32_t  quantScale[3];       /* the flat m_quantCoef entry of each plane's rem (scalinglist.cpp:386) */
     int32_t  dequantScale[3];     /* s_invQuantScales[rem] (scalinglist.cpp:130); dequant_normal's scale = dequantScale << per */
+    uint32_t coefMode;            /* 1: the host quantises (Quant::rdoQuant, quant.cpp:610-1420 — presets slow and slower; its decisions read the entropy coder's
+                                   * state).  A unit's `levels` block then receives the TRANSFORM COEFFICIENTS of its residual — cu[].dct's output, what
+                                   * Quant::transformNxN leaves in m_resiDctCoeff (quant.cpp:432) — numSig is 0, zeroDist as always, and there is no inverse half:
+                                   * readyInv is set with ready; codedDist / codedEnergy / the `resi` block of chroma units are not written */
+    uint32_t sourceDct;           /* with coefMode: 1 = a LUMA unit's `resi` block receives cu[].dct of the unit's SOURCE pixels — m_fencDctCoeff, which psy-rdoq
+                                   * compares the levels' reconstruction against (quant.cpp:436-442) */
 } x265hip_cujob;
 typedef struct x265hip_cujob_unit
 {
@@ -858,7 +864,7 @@ typedef struct x265hip_cujob_unit
     uint32_t numSig;              /* transformNxN's return value (after sign-bit hiding) */
     uint64_t zeroDist;            /* sse_pp(source, prediction) */
     uint64_t codedDist;           /* sse_pp(source, clip(prediction + reconstructed residual)); defined when numSig != 0 */
-    uint32_t readyInv;            /* == the job's ticket once codedDist and the reconstructed residual are in place (the inverse half) */
+    uint32_t readyInv;            /* == the job's ticket once codedDist and the reconstructed residual are in place (the inverse half; coefMode: set with ready) */
     uint32_t fwdTicks;            /* diagnostic: 100 MHz device ticks from the job's start to this unit's forward half */
     uint32_t codedEnergy;         /* psy_cost_pp(source, clip(prediction + reconstructed residual)) (reference common/pixel.cpp:726-748); with readyInv, when numSig != 0 */
     uint32_t reserved[3];         /* diagnostic (job.reserved != 0): 16-bit 100 MHz ticks since the job's start, low | high half: [0] chain starts | forward transform

@@ -145,6 +145,24 @@ int orc_cujob_run_##SFX(const x265hip_cujob* j, const P* pixels, x265hip_cujob_u
                     int16_t r[1024], dct[1024], back[1024]; \
                     P rec[1024]; \
                     orc_sub_ps_##SFX(r, n, f, p, pw, pw, n, n); \
+                    if (j->coefMode) \
+                    { \
+                        /* the host quantises (Quant::rdoQuant): what Quant::transformNxN has computed by quant.cpp:432 (m_resiDctCoeff) and :436-442 \
+                         * (m_fencDctCoeff: copy_ps of the source block, then the same cu[].dct) */ \
+                        orc_dct(log2n, r, levels + eo, n, depth); \
+                        if (j->sourceDct && plane == 0) \
+                        { \
+                            for (int y = 0; y < n; y++) for (int x = 0; x < n; x++) r[y * n + x] = (int16_t)f[y * pw + x]; \
+                            orc_dct(log2n, r, resi + eo, n, depth); \
+                        } \
+                        u->numSig = 0; \
+                        u->zeroDist = orc_sse_pp_##SFX(f, pw, p, pw, n, n); \
+                        u->fwdTicks = 0; \
+                        __atomic_store_n(&u->readyInv, seq, __ATOMIC_RELEASE); \
+                        __atomic_store_n(&u->ready, seq, __ATOMIC_RELEASE); \
+                        done++; \
+                        continue; \
+                    } \
                     u->numSig = orc_transform_nxn(r, n, levels + eo, dct, log2n, depth, j->qpRem[plane], j->qpPer[plane], j->quantScale[plane], (int)j->quantOffset, \
                                                   (int)j->signHide); \
                     u->zeroDist = orc_sse_pp_##SFX(f, pw, p, pw, n, n); \

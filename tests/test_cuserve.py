@@ -106,8 +106,9 @@ def test_transform_restatement_matches_the_reference_quant_class(depth):
 
 # ---- jobs ------------------------------------------------------------------------------------------------------------------------------------
 
-def _job_header(hp, log2cu, tr_max, tr_min, chroma, depth, qps, sliceI, signHide):
+def _job_header(hp, log2cu, tr_max, tr_min, chroma, depth, qps, sliceI, signHide, coef=0, source_dct=0):
     j = hp.CuJob()
+    j.coefMode, j.sourceDct = coef, source_dct
     j.log2CUSize, j.log2TrMax, j.log2TrMin, j.chroma, j.bitDepth = log2cu, tr_max, tr_min, chroma, depth
     j.quantOffset, j.signHide = (171 if sliceI else 85), signHide
     quant = [26214, 23302, 20560, 18396, 16384, 14564]      # the flat matrix entries (scalinglist.cpp:129-130; checked against the reference above)
@@ -192,7 +193,13 @@ def _compare(hp, j, got, want_units, want_levels, want_resi, label):
         assert heads[k][0] == w.numSig, (label, "numSig", s, plane, tx, ty, heads[k][0], w.numSig)
         assert heads[k][1] == w.zeroDist, (label, "zeroDist", s, plane, tx, ty)
         assert np.array_equal(lv[eo:eo + n * n], want_levels[eo:eo + n * n]), (label, "levels", s, plane, tx, ty)
-        if w.numSig:
+        if j.coefMode:
+            # the `levels` block holds the residual's transform coefficients; a luma unit's `resi` block the source block's (sourceDct)
+            assert w.numSig == 0
+            if j.sourceDct and plane == 0:
+                assert np.array_equal(rs[eo:eo + n * n], want_resi[eo:eo + n * n]), (label, "source transform", s, plane, tx, ty)
+                coded += 1
+        elif w.numSig:
             assert heads[k][2] == w.codedDist, (label, "codedDist", s, plane, tx, ty)
             assert heads[k][3] == w.codedEnergy, (label, "codedEnergy", s, plane, tx, ty, heads[k][3], w.codedEnergy)
             assert np.array_equal(rs[eo:eo + n * n], want_resi[eo:eo + n * n]), (label, "resi", s, plane, tx, ty)
@@ -234,7 +241,7 @@ def test_emulated_jobs_are_the_restatement():
     total = 0
     for depth in (8, 10):
         for shape, kind, qps, sliceI, signHide, rng in _cases(depth, 7 + depth):
-            j = _job_header(hp, *shape, depth, qps, sliceI, signHide)
+            j = _job_header(hp, *shape, depth, qps, sliceI, signHide, coef=int(total % 4 == 3), source_dct=int(total % 8 == 3))
             pix = _job_pixels(rng, shape[0], shape[3], depth, kind)
             done, wu, wl, wr = _oracle_job(hp, O, j, pix)
             n, coded = _compare(hp, j, _run_on(_Chk, em, cs, total % 3, j, pix), wu, wl, wr, (depth, shape, kind, qps))
@@ -278,6 +285,69 @@ def test_bound_encoder_on_emulated_jobs_serves_and_stays_byte_identical(tmp_path
         if not verify:
             m = re.search(r"cuserve: (\d+) sub_ps and (\d+) add_ps calls of those CUs put off", r.stderr)
             assert m and int(m.group(1)) > 0 and int(m.group(2)) > 0, r.stderr[-1200:]
+
+
+@pytest.mark.parametrize("depth", [8, 10, 12])
+def test_coefficient_mode_restatement_is_the_reference_transform(depth):
+    """coefMode jobs (RDOQ presets: the host quantises): a unit's `levels` block == the reference's cu[].dct of (source - prediction), a luma unit's
+    `resi` block == cu[].dct of the source block as int16 — what Quant::transformNxN leaves in m_resiDctCoeff / m_fencDctCoeff (quant.cpp:432, :436-442)"""
+    from x265_amd import hipprim as hp
+    O, R = _orc(), _ref(depth)
+    rng = np.random.default_rng(900 + depth)
+    checked = 0
+    for shape in ((5, 5, 4, 1), (6, 5, 5, 1), (4, 4, 4, 1)):
+        for kind in (0, 1, 2):
+            j = _job_header(hp, *shape, depth, (30 + 6 * (depth - 8),) * 3, 0, 1, coef=1, source_dct=1)
+            pix = _job_pixels(rng, shape[0], shape[3], depth, kind)
+            done, wu, wl, wr = _oracle_job(hp, O, j, pix)
+            N = 1 << shape[0]
+            planes = [N * N] + ([N * N // 4] * 2 if shape[3] else [])
+            half = sum(planes)
+            for (s, plane, tx, ty, ui, eo, n) in _layout(hp, j):
+                pw = N if plane == 0 else N // 2
+                base = sum(planes[:plane])
+                src = pix[base:base + pw * pw].reshape(pw, pw)[ty * n:(ty + 1) * n, tx * n:(tx + 1) * n].astype(np.int32)
+                prd = pix[half + base:half + base + pw * pw].reshape(pw, pw)[ty * n:(ty + 1) * n, tx * n:(tx + 1) * n].astype(np.int32)
+                resi = np.ascontiguousarray((src - prd).astype(np.int16))
+                want = np.zeros(n * n, np.int16)
+                R.ref_dct(int(np.log2(n)) - 2, resi.ctypes.data, want.ctypes.data, n)
+                assert np.array_equal(wl[eo:eo + n * n], want), (depth, shape, kind, s, plane, tx, ty)
+                assert wu[ui].numSig == 0 and wu[ui].zeroDist == int(((src - prd) ** 2).sum())
+                if plane == 0:
+                    s16 = np.ascontiguousarray(src.astype(np.int16))
+                    R.ref_dct(int(np.log2(n)) - 2, s16.ctypes.data, want.ctypes.data, n)
+                    assert np.array_equal(wr[eo:eo + n * n], want), (depth, shape, kind, "source", s, tx, ty)
+                checked += 1
+    assert checked >= 90
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 0])
+def test_device_coefficient_jobs_match_the_restatement(mode):
+    """coefMode jobs on the MI355X (what the RDOQ presets hand over: the MFMA transforms of every unit's residual, and of the luma units' source blocks for
+    psy-rdoq) against the restatement; 8 / 10 / 12 bit, with and without sourceDct, slots reused, mixed with ordinary jobs on the same service"""
+    from x265_amd import hipprim as hp
+    L = hp.lib()
+    hp.check(L.x265hip_init(0))
+    O = _orc()
+    cs = vp()
+    hp.check(L.x265hip_cuserve_open(4, mode, C.byref(cs)))
+    try:
+        total = units = sources = 0
+        for depth in (8, 10, 12):
+            for shape, kind, qps, sliceI, signHide, rng in _cases(depth, 60 + depth):
+                variant = total % 3                               # 0: coefficients + source transform, 1: coefficients only, 2: an ordinary job in between
+                j = _job_header(hp, *shape, depth, qps, sliceI, signHide, coef=int(variant != 2), source_dct=int(variant == 0))
+                pix = _job_pixels(rng, shape[0], shape[3], depth, kind)
+                done, wu, wl, wr = _oracle_job(hp, O, j, pix)
+                n, c = _compare(hp, j, _run_on(hp, L, cs, total % 4, j, pix), wu, wl, wr, (mode, depth, shape, kind, qps, variant))
+                assert n == done
+                total += 1; units += n
+                if variant == 0:
+                    sources += c
+        assert units > 1000 and sources > 100
+    finally:
+        hp.check(L.x265hip_cuserve_close(cs))
 
 
 class _Chk:

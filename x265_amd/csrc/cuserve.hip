@@ -150,7 +150,8 @@ __device__ __forceinline__ PlaneParams plane_params(const x265hip_cujob& j, int 
 //   src / prd: the plane's source and prediction in LDS, `pw` elements per row; the plane has (pw / N)^2 units
 template <typename P, int N>
 __device__ __forceinline__ void tile_chain(TileLds& t, const BOperand (*bop)[64], const P* src, const P* prd, int pw, int u0, int count, const PlaneParams qp,
-                                           bool signHide, x265hip_cujob_unit* units, int unitBase, int16_t* levels, int16_t* resi, int elemBase, uint32_t seq, uint64_t t0, bool stamps)
+                                           bool signHide, x265hip_cujob_unit* units, int unitBase, int16_t* levels, int16_t* resi, int elemBase, uint32_t seq, uint64_t t0, bool stamps,
+                                           int coef)
 {
     // job.reserved != 0 (tools/micro/cuserve_rt): 100 MHz ticks since the doorbell was seen at six points of the chain, two per reserved word of the unit
     uint32_t stamp[6] = { 0, 0, 0, 0, 0, 0 };
@@ -197,6 +198,66 @@ __device__ __forceinline__ void tile_chain(TileLds& t, const BOperand (*bop)[64]
     mfma_pass<N, false>(t.b, t.a, lane, bF, corrF, qp.s2f);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     XH_STAMP(1);
+    if (coef)
+    {
+        // ---- coefficient mode (x265hip_cujob::coefMode): the host quantises (Quant::rdoQuant).  The unit's transform coefficients go out where the levels
+        // would; coef & 2: the same transform of the unit's SOURCE pixels (m_fencDctCoeff, quant.cpp:436-442) goes out where the reconstructed residual would
+        const int gC = (lane * 16) / (N * N);
+        const bool okC = gC < count;
+        if (coef & 2)
+        {
+#pragma unroll
+            for (int half = 0; half < 2; half++)
+            {
+                const int e = lane * 16 + half * 8;
+                store4(t.c + e, &fv[8 * half]); store4(t.c + e + 4, &fv[8 * half + 4]);
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; half++)
+        {
+            const int e = lane * 16 + half * 8;
+            if (okC)
+                *reinterpret_cast<uint4*>(levels + elemBase + (u0 + gC) * N * N + (e % (N * N))) = *reinterpret_cast<const uint4*>(t.a + e);
+        }
+        if (coef & 2)
+        {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            mfma_pass<N, false>(t.c, t.b, lane, bF, corrF, qp.s1f);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            mfma_pass<N, false>(t.b, t.c, lane, bF, corrF, qp.s2f);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+            for (int half = 0; half < 2; half++)
+            {
+                const int e = lane * 16 + half * 8;
+                if (okC)
+                    *reinterpret_cast<uint4*>(resi + elemBase + (u0 + gC) * N * N + (e % (N * N))) = *reinterpret_cast<const uint4*>(t.c + e);
+            }
+        }
+        unsigned long long zeroC = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+        {
+            const int d0 = fv[i] - pv[i];
+            zeroC += (unsigned)(d0 * d0);
+        }
+        zeroC = group_sum64(zeroC, LPT);
+        x265hip_cujob_unit* unC = units + unitBase + u0 + gC;
+        if (okC && (lane & (LPT - 1)) == 0)
+        {
+            unC->numSig = 0;
+            unC->zeroDist = zeroC;
+            unC->fwdTicks = (uint32_t)(wall_clock64() - t0);
+            XH_STAMP(5);
+            if (stamps) { unC->reserved[0] = stamp[0] | (stamp[1] << 16); unC->reserved[1] = 0; unC->reserved[2] = stamp[5] << 16; }
+            // (the release store waits for every store this wave has issued: the blocks above are in host memory when either word is seen)
+            __hip_atomic_store(&unC->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&unC->ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        return;
+    }
     // ---- quant (quant_c): levels -> b, deltaU -> c; the transform coefficients stay in a (sign hiding reads their signs)
     int cnt = 0;
     const int qBits8 = qp.qBits - 8;
@@ -459,15 +520,16 @@ __device__ __forceinline__ void run_tiles(SlotOut* s, JobLds& L, uint32_t seq, u
             const P* pp = plane == 0 ? prd : plane == 1 ? prd + lumaElems : prd + lumaElems + lumaElems / 4;
             const int pw = plane ? NC : N;
             const PlaneParams qp = plane_params(j, plane, log2n);
+            const int coef = j.coefMode ? 1 | (j.sourceDct && plane == 0 ? 2 : 0) : 0;
             const int unitBase = x265hipi_cujob_unit_index(&j, sHi, sz, plane, 0, 0);
             const int elemBase = x265hipi_cujob_elem_offset(&j, sHi, sz, plane, 0, 0);
             for (int k = 0; k < tiles; k++, tile++)
             {
                 if ((tile & 3) != wv) continue;
                 const int u0 = k * G, count = nUnits - u0 < G ? nUnits - u0 : G;
-                if (log2n == 5) tile_chain<P, 32>(L.tile[wv], L.bop[2], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0, j.reserved != 0);
-                else if (log2n == 4) tile_chain<P, 16>(L.tile[wv], L.bop[1], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0, j.reserved != 0);
-                else tile_chain<P, 8>(L.tile[wv], L.bop[0], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0, j.reserved != 0);
+                if (log2n == 5) tile_chain<P, 32>(L.tile[wv], L.bop[2], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0, j.reserved != 0, coef);
+                else if (log2n == 4) tile_chain<P, 16>(L.tile[wv], L.bop[1], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0, j.reserved != 0, coef);
+                else tile_chain<P, 8>(L.tile[wv], L.bop[0], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0, j.reserved != 0, coef);
             }
         }
     }

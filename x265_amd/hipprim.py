@@ -259,7 +259,8 @@ class SadSurfView(C.Structure):
 class CuJob(C.Structure):
     """x265hip_cujob (include/x265hip.h): the header of a CU residual quad-tree job"""
     _fields_ = [("log2CUSize", u32), ("log2TrMax", u32), ("log2TrMin", u32), ("chroma", u32), ("bitDepth", u32), ("quantOffset", u32), ("signHide", u32),
-                ("reserved", u32), ("qpRem", C.c_int32 * 3), ("qpPer", C.c_int32 * 3), ("quantScale", C.c_int32 * 3), ("dequantScale", C.c_int32 * 3)]
+                ("reserved", u32), ("qpRem", C.c_int32 * 3), ("qpPer", C.c_int32 * 3), ("quantScale", C.c_int32 * 3), ("dequantScale", C.c_int32 * 3),
+                ("coefMode", u32), ("sourceDct", u32)]
 
 
 class CuJobUnit(C.Structure):

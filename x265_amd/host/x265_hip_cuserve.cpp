@@ -84,6 +84,7 @@ int g_minLog2 = 5;               // X265HIP_CUSERVE_MIN: smallest CU (log2) whos
 int g_mode = 0;                  // X265HIP_CUSERVE_MODE: 0 resident server (mailbox), 1 one launch per job
 int64_t g_timeoutNs = 10000000000ll;            // X265HIP_CUSERVE_TIMEOUT_MS
 std::atomic<int> g_lateJobs(0);
+int g_rdoqJobs = 1;              // X265HIP_CUSERVE_RDOQ=0: CUs quantised by Quant::rdoQuant are not handed over at all (round 4's behaviour)
 int g_slots = 64;                // X265HIP_CUSERVE_SLOTS: jobs that can be in flight (default: twice the CPUs this process may use, 16..64)
 bool g_verify = false;           // X265HIP_VERIFY=1: every served unit is recomputed by the reference's function and compared
 bool g_require = false;          // X265HIP=require: a device failure is fatal instead of falling back
@@ -233,6 +234,7 @@ bool decide()
         g_verify = getenv("X265HIP_VERIFY") != NULL;
         if (getenv("X265HIP_CUSERVE_MIN")) { const int v = atoi(getenv("X265HIP_CUSERVE_MIN")); g_minLog2 = v >= 64 ? 6 : v >= 32 ? 5 : 4; }
         if (getenv("X265HIP_CUSERVE_MODE")) g_mode = atoi(getenv("X265HIP_CUSERVE_MODE")) ? 1 : 0;
+        if (getenv("X265HIP_CUSERVE_RDOQ")) g_rdoqJobs = atoi(getenv("X265HIP_CUSERVE_RDOQ")) ? 1 : 0;
         if (getenv("X265HIP_CUSERVE_TIMEOUT_MS") && atoll(getenv("X265HIP_CUSERVE_TIMEOUT_MS")) > 0) g_timeoutNs = atoll(getenv("X265HIP_CUSERVE_TIMEOUT_MS")) * 1000000ll;
         if (getenv("X265HIP_CUSERVE_SLOTS")) g_slots = atoi(getenv("X265HIP_CUSERVE_SLOTS"));
         else
@@ -452,7 +454,9 @@ bool make_header(Search* se, const Mode& mode, uint32_t log2CUSize, const uint32
     const Quant& q = se->m_quant;
     const int csp = se->m_csp;
     const bool codeChroma = csp != X265_CSP_I400 && se->m_frame->m_fencPic->m_picCsp != X265_CSP_I400;
-    if (cu.m_tqBypass[0] || q.m_rdoqLevel || (q.m_nr && q.m_nr->offset) || q.m_scalingList->m_bEnabled || (csp != X265_CSP_I420 && csp != X265_CSP_I400) ||
+    // RDOQ (presets slow / slower): the quantiser is Quant::rdoQuant and stays on the host (its decisions read the entropy coder's state); the job then carries
+    // the transforms in front of it — coefficient mode, X265HIP_CUSERVE_RDOQ=0 switches that off
+    if (cu.m_tqBypass[0] || (q.m_rdoqLevel && !g_rdoqJobs) || (q.m_nr && q.m_nr->offset) || q.m_scalingList->m_bEnabled || (csp != X265_CSP_I420 && csp != X265_CSP_I400) ||
         (csp == X265_CSP_I420) != codeChroma)
         return false;
     memset(&hdr, 0, sizeof(hdr));
@@ -468,6 +472,8 @@ bool make_header(Search* se, const Mode& mode, uint32_t log2CUSize, const uint32
         hdr.quantScale[p] = q.m_scalingList->m_quantCoef[3][3 + p][qp.rem][0];          // flat: every entry of every size and list is s_quantScales[rem]
         hdr.dequantScale[p] = ScalingList::s_invQuantScales[qp.rem];
     }
+    hdr.coefMode = q.m_rdoqLevel ? 1 : 0;
+    hdr.sourceDct = q.m_rdoqLevel && q.m_psyRdoqScale ? 1 : 0;
     return true;
 }
 
@@ -857,9 +863,49 @@ inline void psy_ahead(Job& j, int u, int plane, int x, int y, int n)
 } // namespace
 
 // called by setupAssemblyPrimitives in the default table mode, after the psy lookups of x265_hip_srcplanes.cpp are in the table
+// X265HIP_DEBUG_CUTIME: the transform primitives themselves, timed (what of Quant::transformNxN / ::invtransformNxN is transform and what is the quantiser —
+// with RDOQ the quantiser is Quant::rdoQuant and stays on the host, so this is the share a job could take over there)
+dct_t g_timedDct[4]; idct_t g_timedIdct[4];
+std::atomic<uint64_t> g_primCycles[8][2], g_primCalls[8][2];
+template <int S> void dct_timed(const int16_t* src, int16_t* dst, intptr_t stride)
+{
+    const uint64_t t0 = __builtin_ia32_rdtsc();
+    g_timedDct[S](src, dst, stride);
+    g_primCycles[S][!t_inRqt].fetch_add(__builtin_ia32_rdtsc() - t0, std::memory_order_relaxed);
+    g_primCalls[S][!t_inRqt].fetch_add(1, std::memory_order_relaxed);
+}
+template <int S> void idct_timed(const int16_t* src, int16_t* dst, intptr_t stride)
+{
+    const uint64_t t0 = __builtin_ia32_rdtsc();
+    g_timedIdct[S](src, dst, stride);
+    g_primCycles[4 + S][!t_inRqt].fetch_add(__builtin_ia32_rdtsc() - t0, std::memory_order_relaxed);
+    g_primCalls[4 + S][!t_inRqt].fetch_add(1, std::memory_order_relaxed);
+}
+void report_prim_time()
+{
+    for (int k = 0; k < 8; k++)
+        for (int w = 0; w < 2; w++)
+            if (g_primCalls[k][w].load())
+                fprintf(stderr, "x265hip: cutime: %-52s %2dx%-2d %s: %9llu calls, %8.0f cycles each, %7.3f G cycles\n", k < 4 ? "cu[].dct (the primitive alone)" : "cu[].idct (the primitive alone)",
+                        4 << (k & 3), 4 << (k & 3), w ? "(elsewhere)           " : "(in estimateResidualQT)", (unsigned long long)g_primCalls[k][w].load(),
+                        (double)g_primCycles[k][w].load() / g_primCalls[k][w].load(), g_primCycles[k][w].load() * 1e-9);
+}
+
 void x265hip_install_cuserve_slots(EncoderPrimitives& p)
 {
     decide();
+    if (g_time)
+    {
+        static std::mutex onceT;
+        std::lock_guard<std::mutex> g(onceT);
+        if (!g_timedDct[0])
+        {
+            for (int k = 0; k < 4; k++) { g_timedDct[k] = p.cu[k].dct; g_timedIdct[k] = p.cu[k].idct; }
+            atexit(report_prim_time);
+        }
+        p.cu[0].dct = dct_timed<0>; p.cu[1].dct = dct_timed<1>; p.cu[2].dct = dct_timed<2>; p.cu[3].dct = dct_timed<3>;
+        p.cu[0].idct = idct_timed<0>; p.cu[1].idct = idct_timed<1>; p.cu[2].idct = idct_timed<2>; p.cu[3].idct = idct_timed<3>;
+    }
     if (g_state <= 0 || !g_serveDist)
         return;
     // x265_setup_primitives is not serialised: two encoders opened at the same moment both find the table empty and both set it up, the second one's
@@ -1063,6 +1109,44 @@ uint32_t Quant::transformNxN(const CUData& cu, const pixel* fenc, uint32_t fencS
                     for (int p = 1; p <= 2 && __atomic_load_n(&j.units[u].ready, __ATOMIC_ACQUIRE) != j.seq; p++)
                         psy_ahead(j, x265hipi_cujob_unit_index(j.job, j.sHi, (int)log2TrSize, p, x >> log2TrSize, y >> log2TrSize), p, x >> 1, y >> 1, n >> 1);
             }
+            if (j.hdr.coefMode)
+            {
+                // RDOQ: the device has transformed (residual -> m_resiDctCoeff, and for psy-rdoq source -> m_fencDctCoeff: quant.cpp:432, :436-442); the
+                // quantiser is the reference's own, called as Quant::transformNxN calls it (:454-455)
+                if (!wait_word(j, &j.units[u].ready, ttype == TEXT_LUMA ? 0 : 1))
+                    goto host;
+                const int n2 = 1 << (2 * log2TrSize);
+                const bool usePsy = m_psyRdoqScale && ttype == TEXT_LUMA;
+                memcpy(m_resiDctCoeff, j.levels + eo, sizeof(int16_t) * n2);
+                if (usePsy)
+                    memcpy(m_fencDctCoeff, j.resiOut + eo, sizeof(int16_t) * n2);
+                if (g_verify)
+                {
+                    int16_t gotR[1024], gotF[1024];
+                    memcpy(gotR, m_resiDctCoeff, sizeof(int16_t) * n2);
+                    if (usePsy) memcpy(gotF, m_fencDctCoeff, sizeof(int16_t) * n2);
+                    coeff_t want[1024];
+                    const uint32_t ns = refTransformNxN(this, cu, fenc, fencStride, residual, resiStride, want, log2TrSize, ttype, absPartIdx, useTransformSkip);
+                    if (memcmp(gotR, m_resiDctCoeff, sizeof(int16_t) * n2) || (usePsy && memcmp(gotF, m_fencDctCoeff, sizeof(int16_t) * n2)))
+                    {
+                        fprintf(stderr, "x265hip: cuserve: VERIFY FAILED transformNxN (RDOQ) %dx%d plane %d: the device's transform coefficients differ from cu[].dct's\n",
+                                1 << log2TrSize, 1 << log2TrSize, (int)ttype);
+                        abort();
+                    }
+                    const uint32_t numSigV = (this->*rdoQuant_func[log2TrSize - 2])(cu, coeff, ttype, absPartIdx, usePsy);
+                    if (ns != numSigV || memcmp(want, coeff, sizeof(coeff_t) * n2)) { fprintf(stderr, "x265hip: cuserve: VERIFY FAILED rdoQuant is not a function of its inputs?\n"); abort(); }
+                    counters().fwd.fetch_add(1, std::memory_order_relaxed);
+                    return numSigV;
+                }
+                const uint32_t numSigQ = (this->*rdoQuant_func[log2TrSize - 2])(cu, coeff, ttype, absPartIdx, usePsy);
+                counters().fwd.fetch_add(1, std::memory_order_relaxed);
+                if (g_time)
+                {
+                    g_cycles[log2TrSize - 2][0].fetch_add(__builtin_ia32_rdtsc() - t0, std::memory_order_relaxed);
+                    g_calls[log2TrSize - 2][0].fetch_add(1, std::memory_order_relaxed);
+                }
+                return numSigQ;
+            }
             if (wait_word(j, &j.units[u].ready, ttype == TEXT_LUMA ? 0 : 1))
             {
                 const int n2 = 1 << (2 * log2TrSize);
@@ -1091,6 +1175,7 @@ uint32_t Quant::transformNxN(const CUData& cu, const pixel* fenc, uint32_t fencS
         else
             counters().fwdMiss.fetch_add(1, std::memory_order_relaxed);
     }
+host:
     if (j.active && j.quant == this)
         flush_sub(j);                   // this call reads the CU's residual on the host after all
     if (g_time)
@@ -1105,7 +1190,7 @@ void Quant::invtransformNxN(const CUData& cu, int16_t* residual, uint32_t resiSt
                             bool useTransformSkip, uint32_t numSig)
 {
     Job& j = t_job;
-    if (j.active && j.inTree && j.quant == this && !useTransformSkip && !bIntra)
+    if (j.active && j.inTree && j.quant == this && !useTransformSkip && !bIntra && !j.hdr.coefMode)
     {
         // which unit?  the one of this size and plane whose levels these are: equal levels have equal inverse transforms, so the comparison — not
         // any bookkeeping — is what makes the copy exact.  The tree asks for a unit's inverse right after its forward transform: look there first.
