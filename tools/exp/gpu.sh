@@ -1,0 +1,55 @@
+#!/bin/bash
+# tools/exp/gpu.sh — ONE parameterised script for what is run on the MI355X box through gpurun (replaces the per-experiment r03_* / r04_* scripts; those
+# are in the history).  Everything lands under gpurun_out/<tag>/; summaries worth keeping are copied into profiles/.
+#
+#   tools/exp/gpu.sh <tag> <task> [task ...]
+#     tests [-k expr]      the GPU test tier (or a selection)
+#     bench                python bench.py (the contract line)
+#     configs23            BASELINE configs[2] / configs[3] at 4K: defaults vs X265HIP_CUSERVE_RDOQ=0 (round 4's behaviour: RDOQ CUs not handed over)
+#     ab <frames> <name:ENV=..,..> ...   interleaved A/B of the 1080p preset-medium bench encode
+#     rt                   tools/micro/cuserve_rt: the job round trip, with stage stamps
+#     stats                rocprofv3 --kernel-trace --stats of a 120-frame bound encode
+#     cpuprofile           the bound encoder under the CPU sampler (tools/prof), 2 x 240 frames
+set -u
+TAG=$1; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export X265HIP_VERBOSE=1
+clip() { python - "$1" "$2" <<'PY'
+import os, sys; sys.path.insert(0, '.')
+from x265_amd.synth import make_clip
+if not os.path.exists(sys.argv[1]): make_clip(sys.argv[1], 1920, 1080, int(sys.argv[2]), seed=4321)
+PY
+}
+while [ $# -gt 0 ]; do
+  task=$1; shift
+  case $task in
+    tests)
+      sel=(); if [ "${1:-}" = "-k" ]; then sel=(-k "$2"); shift 2; fi
+      timeout 1500 python -m pytest tests -m gpu -x -q "${sel[@]}" 2>&1 | tail -15 > $OUT/gputest.log; tail -3 $OUT/gputest.log ;;
+    bench)
+      timeout 600 python bench.py 2> $OUT/bench.err | tail -1 > $OUT/bench.json; cut -c1-300 $OUT/bench.json ;;
+    configs23)
+      OLD="X265HIP_CUSERVE_RDOQ=0"
+      timeout 1200 python tools/ab_encode.py --rounds 2 --frames 24 --res 3840x2160 --preset slow --extra "--me star --merange 57" base: r4:$OLD --out $OUT/configs2.json 2>&1 | tee $OUT/configs2_4k_slow_star_ab.txt | tail -12
+      timeout 1200 python tools/ab_encode.py --rounds 2 --frames 8 --res 3840x2160 --preset slower --extra "--rd 6" --bits 10 base: r4:$OLD --out $OUT/configs3.json 2>&1 | tee $OUT/configs3_4k_main10_slower_ab.txt | tail -12 ;;
+    ab)
+      frames=$1; shift; cfgs=(); while [ $# -gt 0 ] && [[ "$1" == *:* ]]; do cfgs+=("$1"); shift; done
+      timeout 1500 python tools/ab_encode.py --rounds 3 --frames $frames "${cfgs[@]}" --out $OUT/ab.json 2>&1 | tee $OUT/ab.txt | tail -14 ;;
+    rt)
+      timeout 300 tools/micro/cuserve_rt 2>&1 | tee $OUT/cuserve_rt.txt | tail -30 ;;
+    stats)
+      clip /tmp/bench120.yuv 120
+      HERE=$PWD
+      (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $HERE/$OUT/prof -- $HERE/oracle/_ref/x265_hip_8bit --input /tmp/bench120.yuv --input-res 1920x1080 --fps 30 --frames 120 --preset medium --me hex -o /tmp/s.hevc > $HERE/$OUT/stats_run.log 2>&1)
+      find $OUT/prof -name "*kernel_stats*" | head -2 ;;
+    cpuprofile)
+      clip /tmp/bench240.yuv 240
+      for k in 1 2; do
+        X265HIP_CPUSAMPLE_OUT=/tmp/s$k.bin LD_PRELOAD=tools/prof/libcpusample.so oracle/_ref/x265_hip_8bit --input /tmp/bench240.yuv --input-res 1920x1080 --fps 30 --frames 240 --preset medium --me hex -o /tmp/p.hevc 2>&1 | grep -E "encoded|x265hip" > $OUT/cpuprofile_run$k.log
+        python tools/prof/resolve.py /tmp/s$k.bin > $OUT/cpu_profile_bound_encoder_$k.txt 2>&1
+      done
+      head -45 $OUT/cpu_profile_bound_encoder_1.txt ;;
+    *) echo "unknown task $task"; exit 2 ;;
+  esac
+done
