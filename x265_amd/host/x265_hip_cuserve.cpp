@@ -84,7 +84,9 @@ int g_minLog2 = 5;               // X265HIP_CUSERVE_MIN: smallest CU (log2) whos
 int g_mode = 0;                  // X265HIP_CUSERVE_MODE: 0 resident server (mailbox), 1 one launch per job
 int64_t g_timeoutNs = 10000000000ll;            // X265HIP_CUSERVE_TIMEOUT_MS
 std::atomic<int> g_lateJobs(0);
-int g_rdoqJobs = 1;              // X265HIP_CUSERVE_RDOQ=0: CUs quantised by Quant::rdoQuant are not handed over at all (round 4's behaviour)
+int g_rdoqJobs = 0;              // X265HIP_CUSERVE_RDOQ=1: CUs quantised by Quant::rdoQuant are handed over as coefficient-mode jobs.  Off by default: measured on the
+                                 // MI355X box at BASELINE configs[2] / configs[3] (profiles/r05_v1_configs*_ab.txt) the jobs cost 1-3 % — a 16x16 cu[].dct is 0.8 us of
+                                 // CPU, a 32x32 one 6 us, against 8 us to the first unit of a job and a 2-4 KB copy per unit; the quantiser itself cannot move
 int g_slots = 64;                // X265HIP_CUSERVE_SLOTS: jobs that can be in flight (default: twice the CPUs this process may use, 16..64)
 bool g_verify = false;           // X265HIP_VERIFY=1: every served unit is recomputed by the reference's function and compared
 bool g_require = false;          // X265HIP=require: a device failure is fatal instead of falling back
@@ -454,8 +456,8 @@ bool make_header(Search* se, const Mode& mode, uint32_t log2CUSize, const uint32
     const Quant& q = se->m_quant;
     const int csp = se->m_csp;
     const bool codeChroma = csp != X265_CSP_I400 && se->m_frame->m_fencPic->m_picCsp != X265_CSP_I400;
-    // RDOQ (presets slow / slower): the quantiser is Quant::rdoQuant and stays on the host (its decisions read the entropy coder's state); the job then carries
-    // the transforms in front of it — coefficient mode, X265HIP_CUSERVE_RDOQ=0 switches that off
+    // RDOQ (presets slow / slower): the quantiser is Quant::rdoQuant and stays on the host (its decisions read the entropy coder's state); a job can only carry
+    // the transforms in front of it — coefficient mode, X265HIP_CUSERVE_RDOQ=1 (see g_rdoqJobs for why it is not the default)
     if (cu.m_tqBypass[0] || (q.m_rdoqLevel && !g_rdoqJobs) || (q.m_nr && q.m_nr->offset) || q.m_scalingList->m_bEnabled || (csp != X265_CSP_I420 && csp != X265_CSP_I400) ||
         (csp == X265_CSP_I420) != codeChroma)
         return false;
