@@ -929,6 +929,43 @@ int x265hip_cuserve_submit(x265hip_cuserve* cs, int slot, uint32_t* seq);
 int x265hip_cuserve_poke(x265hip_cuserve* cs, int slot);
 int x265hip_cuserve_stats(x265hip_cuserve* cs, uint64_t* jobs, uint64_t* serverStarts, uint64_t* deviceNs);
 
+/* ---- SAO statistics of one CTU as a job of the same service (round 5) ---------------------------------------------------------------------
+ * SAO::calcSaoStatsCTU (reference source/encoder/sao.cpp:735-917; called per plane from rdoSaoUnitCu :1293-1305) measures, for the deblocked CTU, the
+ * sums and counts of (source - reconstruction) per band (SAO_BO, saoCuStatsBO_c :1762) and per edge category of the four edge classes (saoCuStatsE0..E3_c
+ * :1780-1925): a function of the CTU's deblocked samples (with one row above and one column to the left), its source samples and, per class, the
+ * rectangle of samples the reference measures (what is not deblocked yet at the right / bottom is left out, :778-899).  The caller computes the
+ * rectangles exactly as the reference does and hands them over; the device measures all classes of all planes in one job, luma first.
+ *
+ * The slot's pixel block, per plane p (0 .. planes-1) in turn: the reconstruction block, (h + 1) rows of (w + 1) samples starting at the sample ABOVE-LEFT
+ * of the CTU's first one (row pitch w + 1), then the source block, h rows of w samples (row pitch w).  8-bit samples only (bitDepth 8).
+ * Results: the slot's `levels` block read as int32: stats[plane][class][32] (3 * 5 * 32 entries) followed by count[plane][class][32]; class order
+ * BO, EO_0, EO_1, EO_2, EO_3; an edge class fills entries 0..4 (the category order of SAO::s_eoTable: the values saoCuStatsE*_c add into their `stats`).
+ * units[p].ready == the ticket when plane p's numbers are in place. */
+typedef struct x265hip_saojob
+{
+    uint32_t bitDepth;            /* 8 */
+    uint32_t planes;              /* 1 or 3 */
+    uint32_t eo23;                /* 0: EO_2 and EO_3 are not measured (--limit-sao, sao.cpp:853-854): their entries are zero */
+    uint32_t reserved;
+    struct
+    {
+        uint16_t w, h;            /* the CTU's part of the plane */
+        uint8_t  x0[5], y0[5], x1[5], y1[5];   /* per class: samples [x0, x1) x [y0, y1) are measured */
+    } plane[3];
+} x265hip_saojob;
+#define X265HIP_SAOJOB_STATS_ENTRIES (3 * 5 * 32)
+/* bytes of the pixel block the job describes */
+X265HIP_HD static inline int x265hipi_saojob_pixel_bytes(const x265hip_saojob* j)
+{
+    int n = 0;
+    for (uint32_t p = 0; p < j->planes && p < 3; p++)
+        n += (j->plane[p].w + 1) * (j->plane[p].h + 1) + j->plane[p].w * j->plane[p].h;
+    return n;
+}
+/* hands the job to the device: `job` is copied into the mailbox in front of the pixel block the caller has written (x265hip_cuserve_slot's *pixels);
+ * *seq = the ticket */
+int x265hip_cuserve_submit_sao(x265hip_cuserve* cs, int slot, const x265hip_saojob* job, uint32_t* seq);
+
 #ifdef __cplusplus
 }
 #endif

@@ -191,3 +191,67 @@ int orc_cujob_run_##SFX(const x265hip_cujob* j, const P* pixels, x265hip_cujob_u
 }
 ORC_CUJOB(uint8_t, 8)
 ORC_CUJOB(uint16_t, 16)
+
+
+/* ---- the SAO statistics job (include/x265hip.h, x265hip_saojob): SAO::calcSaoStatsCTU (encoder/sao.cpp:735-917) for every plane of the job, the
+ * primitives called in the reference's order with the reference's arguments, on the job's blocks.  diff = source - reconstruction (pitch 64, :786-806). */
+void orc_saoSign_8(int8_t* dst, const uint8_t* src1, const uint8_t* src2, int endX);
+void orc_saoCuStatsBO_8(const int16_t* diff, const uint8_t* rec, intptr_t stride, int endX, int endY, int32_t* stats, int32_t* count, int depth);
+void orc_saoCuStatsE0_8(const int16_t* diff, const uint8_t* rec, intptr_t stride, int endX, int endY, int32_t* stats, int32_t* count);
+void orc_saoCuStatsE1_8(const int16_t* diff, const uint8_t* rec, intptr_t stride, int8_t* upBuff1, int endX, int endY, int32_t* stats, int32_t* count);
+void orc_saoCuStatsE2_8(const int16_t* diff, const uint8_t* rec, intptr_t stride, int8_t* upBuff1, int8_t* upBufft, int endX, int endY, int32_t* stats, int32_t* count);
+void orc_saoCuStatsE3_8(const int16_t* diff, const uint8_t* rec, intptr_t stride, int8_t* upBuff1, int endX, int endY, int32_t* stats, int32_t* count);
+
+int orc_saojob_run_8(const x265hip_saojob* j, const uint8_t* pixels, x265hip_cujob_unit* units, int32_t* out, uint32_t seq)
+{
+    int32_t* stats = out;
+    int32_t* count = out + X265HIP_SAOJOB_STATS_ENTRIES;
+    memset(out, 0, sizeof(int32_t) * 2 * X265HIP_SAOJOB_STATS_ENTRIES);
+    const uint8_t* at = pixels;
+    for (uint32_t p = 0; p < j->planes && p < 3; p++)
+    {
+        const int w = j->plane[p].w, h = j->plane[p].h, stride = w + 1;
+        const uint8_t* rec0 = at + stride + 1;                 /* the CTU's first sample */
+        const uint8_t* fenc0 = at + (w + 1) * (h + 1);
+        at = fenc0 + w * h;
+        int16_t diff[64 * 64];
+        int8_t _up[2 * (64 + 16 + 16)], *upBuff1 = _up + 16, *upBufft = upBuff1 + (64 + 16 + 16);
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++)
+                diff[y * 64 + x] = (int16_t)(fenc0[y * w + x] - rec0[y * stride + x]);
+#define R(c, f) (j->plane[p].f[c])
+        int32_t* st = stats + p * 5 * 32;
+        int32_t* ct = count + p * 5 * 32;
+        /* SAO_BO :810-823 */
+        orc_saoCuStatsBO_8(diff, rec0, stride, R(0, x1), R(0, y1), st, ct, 8);
+        /* SAO_EO_0 :826-839 */
+        orc_saoCuStatsE0_8(diff + R(1, x0), rec0 + R(1, x0), stride, R(1, x1) - R(1, x0), R(1, y1), st + 32, ct + 32);
+        /* SAO_EO_1 :841-861: sign of the first measured row against the row above it, then the rows */
+        {
+            const uint8_t* rec = rec0 + R(2, y0) * stride;
+            orc_saoSign_8(upBuff1, rec, rec - stride, w);
+            orc_saoCuStatsE1_8(diff + R(2, y0) * 64, rec0 + R(2, y0) * stride, stride, upBuff1, R(2, x1), R(2, y1) - R(2, y0), st + 64, ct + 64);
+        }
+        if (j->eo23)
+        {
+            /* SAO_EO_2 :865-888 */
+            {
+                const uint8_t* rec = rec0 + R(3, y0) * stride;
+                orc_saoSign_8(upBuff1, rec + R(3, x0), rec + R(3, x0) - stride - 1, R(3, x1) - R(3, x0));
+                orc_saoCuStatsE2_8(diff + R(3, x0) + R(3, y0) * 64, rec0 + R(3, x0) + R(3, y0) * stride, stride, upBuff1, upBufft, R(3, x1) - R(3, x0), R(3, y1) - R(3, y0),
+                                   st + 96, ct + 96);
+            }
+            /* SAO_EO_3 :889-914 */
+            {
+                const uint8_t* rec = rec0 + R(4, y0) * stride;
+                orc_saoSign_8(upBuff1, rec + R(4, x0) - 1, rec + R(4, x0) - 1 - stride + 1, R(4, x1) - R(4, x0) + 1);
+                orc_saoCuStatsE3_8(diff + R(4, x0) + R(4, y0) * 64, rec0 + R(4, x0) + R(4, y0) * stride, stride, upBuff1 + 1, R(4, x1) - R(4, x0), R(4, y1) - R(4, y0),
+                                   st + 128, ct + 128);
+            }
+        }
+#undef R
+        __atomic_store_n(&units[p].readyInv, seq, __ATOMIC_RELEASE);
+        __atomic_store_n(&units[p].ready, seq, __ATOMIC_RELEASE);
+    }
+    return (int)j->planes;
+}

@@ -48,7 +48,7 @@ static char g_err[256] = "";
 /* X265HIP_EMUL_FAIL=<entry point>[:<n>]: the named entry point fails from its n-th call on (n = 1 when omitted), the way a device that runs out of
  * memory or is lost fails — the bindings must then carry on with the reference's own host code and still produce the reference's bytes
  * (tests/test_fallback.py; SURVEY.md §8b "Errors").  Entry points: la_create, la_set_frame, la_weights, la_put_vectors, la_estimate, refpic_create,
- * refpic_reset, rows_final, source_energy, srcpic_create, srcpic_upload, sadsurf_attach, cuserve_open, cuserve_submit, cuserve_job (from its n-th job
+ * refpic_reset, rows_final, source_energy, srcpic_create, srcpic_upload, sadsurf_attach, cuserve_open, cuserve_submit, cuserve_submit_sao, cuserve_job, saostats_job (from its n-th job
  * on the service accepts jobs and never does them: the ready words stay as they are and x265hip_cuserve_poke reports the failure — a device that
  * dies while a CU is in flight). */
 static int fail_now(const char* name)
@@ -769,6 +769,24 @@ int x265hip_cuserve_submit(x265hip_cuserve* cs, int slot, uint32_t* seq)
     }
     if (s->job.bitDepth == 8) orc_cujob_run_8(&s->job, s->pixels, s->units, s->levels, s->resi, *seq);
     else orc_cujob_run_16(&s->job, (const uint16_t*)s->pixels, s->units, s->levels, s->resi, *seq);
+    return 0;
+}
+int orc_saojob_run_8(const x265hip_saojob* j, const uint8_t* pixels, x265hip_cujob_unit* units, int32_t* out, uint32_t seq);
+int x265hip_cuserve_submit_sao(x265hip_cuserve* cs, int slot, const x265hip_saojob* job, uint32_t* seq)
+{
+    if (fail_now("cuserve_submit_sao")) return X265HIP_EHIP;
+    if (!cs || slot < 0 || slot >= cs->slots || !job || !seq || job->bitDepth != 8 || job->planes < 1 || job->planes > 3 ||
+        x265hipi_saojob_pixel_bytes(job) > X265HIP_CUJOB_PIXEL_BYTES)
+        return X265HIP_EINVAL;
+    cu_slot* s = cs->slot + slot;
+    *seq = ++s->seq;
+    __atomic_fetch_add(&cs->jobs, 1, __ATOMIC_RELAXED);
+    if (__atomic_load_n(&cs->lost, __ATOMIC_RELAXED) || fail_now("saostats_job"))
+    {
+        __atomic_store_n(&cs->lost, 1, __ATOMIC_RELAXED);
+        return 0;
+    }
+    orc_saojob_run_8(job, s->pixels, s->units, (int32_t*)s->levels, *seq);
     return 0;
 }
 int x265hip_cuserve_poke(x265hip_cuserve* cs, int slot) { (void)slot; return cs && __atomic_load_n(&cs->lost, __ATOMIC_RELAXED) ? X265HIP_EHIP : 0; }

@@ -31,6 +31,7 @@ def _orc():
     for sfx in ("8", "16"):
         f = getattr(L, "orc_cujob_run_" + sfx)
         f.restype, f.argtypes = i32, [vp, vp, vp, vp, vp, u32]
+    L.orc_saojob_run_8.restype, L.orc_saojob_run_8.argtypes = i32, [vp, vp, vp, vp, u32]
     return L
 
 
@@ -41,6 +42,7 @@ def _ref(depth):
     R.ref_transform_nxn.restype, R.ref_transform_nxn.argtypes = u32, [vp, u32, vp, vp, i32, i32, i32, i32, i32]
     R.ref_invtransform_nxn.restype, R.ref_invtransform_nxn.argtypes = None, [vp, u32, vp, i32, i32, i32, u32]
     R.ref_qp_param.restype, R.ref_qp_param.argtypes = None, [i32, vp]
+    R.ref_dct.restype, R.ref_dct.argtypes = None, [i32, vp, vp, C.c_ssize_t]
     return R
 
 
@@ -350,10 +352,180 @@ def test_device_coefficient_jobs_match_the_restatement(mode):
         hp.check(L.x265hip_cuserve_close(cs))
 
 
+# ---- SAO statistics jobs (x265hip_saojob) ---------------------------------------------------------------------------------------------------------
+
+def _sao_job(hp, rng, planes, full):
+    """a job as SAO::calcSaoStatsCTU's seam would build it: plane sizes up to 64x64 (partial CTUs at the picture's edges), rectangles as the reference's
+    start / end expressions produce them (left / above unavailable: start 1; right / bottom edge or the not-yet-deblocked margin: end shortened)"""
+    j = hp.SaoJob()
+    j.bitDepth, j.planes, j.eo23 = 8, planes, int(rng.integers(0, 4) > 0)
+    blocks = []
+    for b in range(planes):
+        luma = b == 0 and planes != 2
+        w = (64 if luma else 32) if full else int(rng.integers(1, (64 if luma else 32) + 1))
+        h = (64 if luma else 32) if full else int(rng.integers(1, (64 if luma else 32) + 1))
+        po = 0 if luma else 2
+        right, bottom, left, above = (int(rng.integers(0, 3) == 0) for _ in range(4))
+        j.plane[b].w, j.plane[b].h = w, h
+        rects = [
+            (0, 0, w if right else w - 5 + po, h if bottom else h - 4 + po),
+            (left, 0, w - 1 if right else w - 5 + po, h - 4 + po),
+            (0, above, w if right else w - 5 + po, h - 1 if bottom else h - 4 + po),
+            (left, above, w - 1 if right else w - 5 + po, h - 1 if bottom else h - 4 + po),
+            (left, above, w - 1 if right else w - 5 + po, h - 1 if bottom else h - 4 + po)]
+        for c, (x0, y0, x1, y1) in enumerate(rects):
+            if x1 <= x0 or y1 <= y0:
+                x0 = y0 = x1 = y1 = 0
+            j.plane[b].x0[c], j.plane[b].y0[c], j.plane[b].x1[c], j.plane[b].y1[c] = x0, y0, x1, y1
+        kind = int(rng.integers(0, 3))
+        base = rng.integers(0, 256, (h + 1, w + 1)) if kind == 0 else np.clip(np.rint(rng.normal(128, 30, (h + 1, w + 1))), 0, 255)
+        if kind == 2:
+            base = (base // 16) * 16                                      # flat steps: many equal neighbours (the zero-sign category)
+        src = np.clip(base[1:, 1:] + np.rint(rng.normal(0, 4, (h, w))), 0, 255)
+        blocks += [base.astype(np.uint8).ravel(), src.astype(np.uint8).ravel()]
+    return j, np.ascontiguousarray(np.concatenate(blocks))
+
+
+def _oracle_sao(hp, O, j, pix):
+    units = (hp.CuJobUnit * hp.CUJOB_MAX_UNITS)()
+    out = np.zeros(2 * hp.SAOJOB_STATS_ENTRIES, np.int32)
+    assert O.orc_saojob_run_8(C.byref(j), pix.ctypes.data, C.byref(units), out.ctypes.data, 1) == j.planes
+    return out
+
+
+def _run_sao_on(hp, L, cs, slot, j, pix, timeout=20.0):
+    job, pixels, units, levels, resi = vp(), vp(), vp(), vp(), vp()
+    hp.check(L.x265hip_cuserve_slot(cs, slot, C.byref(job), C.byref(pixels), C.byref(units), C.byref(levels), C.byref(resi)))
+    C.memmove(pixels, pix.ctypes.data, pix.nbytes)
+    seq = u32()
+    hp.check(L.x265hip_cuserve_submit_sao(cs, slot, C.byref(j), C.byref(seq)))
+    un = C.cast(units, C.POINTER(hp.CuJobUnit))
+    t0 = time.time()
+    while any(un[b].ready != seq.value for b in range(j.planes)):
+        pk = L.x265hip_cuserve_poke(cs, slot)
+        if pk < 0:
+            hp.check(pk)
+        assert time.time() - t0 < timeout, "SAO job not finished after %.0f s" % timeout
+    return np.ctypeslib.as_array(C.cast(levels, C.POINTER(C.c_int32)), (2 * hp.SAOJOB_STATS_ENTRIES,)).copy()
+
+
+def _same_sao(j, got, want, label):
+    n = 160 * j.planes
+    E = 3 * 5 * 32
+    assert np.array_equal(got[:n], want[:n]), (label, "sums", np.nonzero(got[:n] != want[:n])[0][:8])
+    assert np.array_equal(got[E:E + n], want[E:E + n]), (label, "counts", np.nonzero(got[E:E + n] != want[E:E + n])[0][:8])
+    return int(want[E:E + n].sum())
+
+
+def test_sao_job_restatement_counts_what_the_reference_counts():
+    """orc_saojob_run_8 calls the pinned saoCuStats* restatements in SAO::calcSaoStatsCTU's order; here its numbers are checked against a direct statement of
+    what that is — per class, every sample of the rectangle classified by its two neighbours — so that the restatement and the device, which is written the
+    direct way, are not the same code twice.  (Against the REAL calcSaoStatsCTU: test_bound_encoder_sao_statistics_jobs..., under X265HIP_VERIFY.)"""
+    from x265_amd import hipprim as hp
+    O = _orc()
+    rng = np.random.default_rng(31)
+    eo = [1, 2, 0, 3, 4]
+    nb = {1: ((0, 1), (0, -1)), 2: ((1, 0), (-1, 0)), 3: ((1, 1), (-1, -1)), 4: ((1, -1), (-1, 1))}
+    for it in range(60):
+        j, pix = _sao_job(hp, rng, int(rng.integers(1, 4)), it % 4 == 0)
+        want = _oracle_sao(hp, O, j, pix)
+        at = 0
+        for b in range(j.planes):
+            w, h = j.plane[b].w, j.plane[b].h
+            rec = pix[at:at + (w + 1) * (h + 1)].reshape(h + 1, w + 1).astype(np.int32); at += (w + 1) * (h + 1)
+            src = pix[at:at + w * h].reshape(h, w).astype(np.int32); at += w * h
+            for c in range(5):
+                if c >= 3 and not j.eo23:
+                    assert not want[b * 160 + c * 32: b * 160 + c * 32 + 32].any()
+                    continue
+                sums, cnts = np.zeros(32, np.int64), np.zeros(32, np.int64)
+                for y in range(j.plane[b].y0[c], j.plane[b].y1[c]):
+                    for x in range(j.plane[b].x0[c], j.plane[b].x1[c]):
+                        v = rec[y + 1, x + 1]
+                        if c == 0:
+                            k = v >> 3
+                        else:
+                            (ay, ax), (by, bx) = nb[c]
+                            k = eo[int(np.sign(v - rec[y + 1 + ay, x + 1 + ax])) + int(np.sign(v - rec[y + 1 + by, x + 1 + bx])) + 2]
+                        sums[k] += src[y, x] - v
+                        cnts[k] += 1
+                assert np.array_equal(want[b * 160 + c * 32: b * 160 + c * 32 + 32], sums), (it, b, c)
+                assert np.array_equal(want[480 + b * 160 + c * 32: 480 + b * 160 + c * 32 + 32], cnts), (it, b, c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 0])
+def test_device_sao_jobs_match_the_restatement(mode):
+    """SAO statistics jobs on the MI355X against the restatement: 1-3 planes, full and partial CTUs, every availability pattern, eo23 on and off; mixed with
+    CU jobs on the same slots (the two job kinds share the resident server)"""
+    from x265_amd import hipprim as hp
+    L = hp.lib()
+    hp.check(L.x265hip_init(0))
+    O = _orc()
+    cs = vp()
+    hp.check(L.x265hip_cuserve_open(4, mode, C.byref(cs)))
+    try:
+        rng = np.random.default_rng(77 + mode)
+        measured = 0
+        for it in range(240):
+            if it % 5 == 4:
+                j = _job_header(hp, 5, 5, 4, 1, 8, (30, 29, 29), 0, 1)
+                pix = _job_pixels(rng, 5, 1, 8, 1)
+                done, wu, wl, wr = _oracle_job(hp, O, j, pix)
+                _compare(hp, j, _run_on(hp, L, cs, it % 4, j, pix), wu, wl, wr, ("cu job between SAO jobs", it))
+                continue
+            j, pix = _sao_job(hp, rng, int(rng.integers(1, 4)), it % 3 == 0)
+            measured += _same_sao(j, _run_sao_on(hp, L, cs, it % 4, j, pix), _oracle_sao(hp, O, j, pix), (mode, it))
+        assert measured > 500000
+    finally:
+        hp.check(L.x265hip_cuserve_close(cs))
+
+
+def test_emulated_sao_jobs_are_the_restatement():
+    from x265_amd import hipprim as hp
+    if not os.path.exists(EMUL):
+        pytest.skip("tests/support/libx265hip_emul.so not built (make -C oracle emul)")
+    em = C.CDLL(EMUL)
+    for name, (res, args) in hp.PROTOTYPES.items():
+        if name.startswith("x265hip_cuserve_"):
+            fn = getattr(em, name)
+            fn.restype, fn.argtypes = res, args
+    O = _orc()
+    cs = vp()
+    assert em.x265hip_cuserve_open(2, 0, C.byref(cs)) == 0
+    rng = np.random.default_rng(5)
+    for it in range(40):
+        j, pix = _sao_job(hp, rng, int(rng.integers(1, 4)), it % 3 == 0)
+        _same_sao(j, _run_sao_on(_Chk, em, cs, it % 2, j, pix), _oracle_sao(hp, O, j, pix), it)
+    assert em.x265hip_cuserve_close(cs) == 0
+
+
+@pytest.mark.parametrize("extra", [[], ["--limit-sao"], ["--sao-non-deblock"], ["--slices", "2"], ["--ctu", "32"], ["--preset", "slow"]], ids=lambda e: "-".join(x.strip("-") for x in e) or "medium")
+def test_bound_encoder_sao_statistics_jobs_stay_byte_identical(tmp_path, extra):
+    """SAO::calcSaoStatsCTU served by jobs (emulated ABI), 328x200: partial CTUs on the right and at the bottom.  X265HIP_VERIFY runs the reference's own body
+    beside every served plane and aborts on a different sum or count."""
+    import re, subprocess, sys
+    sys.path.insert(0, ROOT)
+    ref, emul = os.path.join(ROOT, "oracle", "_ref", "x265_8bit"), os.path.join(ROOT, "oracle", "_ref", "x265_emul_8bit")
+    if not (os.path.exists(ref) and os.path.exists(emul)):
+        pytest.skip("oracle/_ref encoders not built (make -C oracle ref emul)")
+    from x265_amd.synth import make_clip
+    yuv = str(tmp_path / "clip.yuv")
+    make_clip(yuv, 328, 200, 6, seed=78)
+    args = ["--input", yuv, "--input-res", "328x200", "--fps", "30", "--frames", "6", "--preset", "medium", "--hash", "1", "--pools", "4", "-F", "2"] + extra
+    want, got = str(tmp_path / "ref.hevc"), str(tmp_path / "emul.hevc")
+    assert subprocess.run([ref] + args + ["-o", want], capture_output=True, timeout=600).returncode == 0
+    r = subprocess.run([emul] + args + ["-o", got], capture_output=True, text=True, timeout=600, env=dict(os.environ, X265HIP="require", X265HIP_VERBOSE="1", X265HIP_VERIFY="1"))
+    assert r.returncode == 0, r.stderr[-800:]
+    assert open(got, "rb").read() == open(want, "rb").read()
+    m = re.search(r"saostats: SAO statistics of (\d+) CTU planes .*? in (\d+) jobs, (\d+) planes on the host", r.stderr)
+    assert m and int(m.group(1)) > 100 and int(m.group(3)) == 0, r.stderr[-800:]
+
+
 class _Chk:
     """hp-like holder for _run_on over the emulated library (no HipError there)"""
     from x265_amd import hipprim as _hp
-    CuJobUnit, CUJOB_MAX_ELEMS = _hp.CuJobUnit, _hp.CUJOB_MAX_ELEMS
+    CuJobUnit, CUJOB_MAX_ELEMS, SAOJOB_STATS_ENTRIES = _hp.CuJobUnit, _hp.CUJOB_MAX_ELEMS, _hp.SAOJOB_STATS_ENTRIES
 
     @staticmethod
     def check(rc):

@@ -120,8 +120,10 @@ static_assert(sizeof(x265hip_cujob) <= 128, "job header");
 
 // ticket = what the host rings and the units' ready words take: bits 31..8 a running number (never 0, never 0xffffff), bits 7..0 what the device
 // needs to know before it has read anything: log2CUSize - 4 (bits 1..0), chroma (bit 2), 16-bit samples (bit 3)
+// bits 1..0 == 3: an SAO statistics job (x265hip_saojob): bits 7..2 = the job's size, header included, in 512-byte steps
 __host__ __device__ inline uint32_t ticket_bytes(uint32_t t)
 {
+    if ((t & 3) == 3) return ((t >> 2) & 63u) * 512u - 128u;
     const uint32_t n2 = 1u << (2 * ((t & 3) + 4)), elems = (t & 4) ? n2 + n2 / 2 : n2;
     return 2 * elems * ((t & 8) ? 2 : 1);
 }
@@ -535,6 +537,85 @@ __device__ __forceinline__ void run_tiles(SlotOut* s, JobLds& L, uint32_t seq, u
     }
 }
 
+// ---- SAO statistics of one CTU (x265hip_saojob; reference sao.cpp:735-917 with saoCuStatsBO / E0..E3_c :1762-1925).  The reference walks each class's
+// rectangle with running sign buffers; an edge category is a function of a sample and two neighbours, so every sample is classified on its own here:
+//   E0: left / right    E1: above / below    E2: above-left / below-right    E3: above-right / below-left;   category = s_eoTable[sign + sign + 2]
+// Sums and counts go to LDS histograms (5 classes x 32 bins each), one plane at a time, luma first; wave 0 writes a plane's 320 numbers to the slot and
+// releases units[plane].ready behind them.
+static_assert(sizeof(x265hip_saojob) <= 128, "SAO job header");
+__device__ __forceinline__ int sgn3(int v) { return (v > 0) - (v < 0); }
+__device__ __forceinline__ void run_sao(SlotOut* s, JobLds& L, uint32_t seq, uint64_t t0)
+{
+    const x265hip_saojob& j = *reinterpret_cast<const x265hip_saojob*>(&L.job);
+    int* hist = reinterpret_cast<int*>(&L.tile[0]);                       // [0..159] sums of class c bin b at c * 32 + b, [160..319] counts
+    int32_t* out = reinterpret_cast<int32_t*>(s->levels);
+    const int tid = threadIdx.x, lx = tid & 63, ly = tid >> 6;
+    const unsigned char* at = L.pix;
+    const int eoCat[5] = { 1, 2, 0, 3, 4 };                               // SAO::s_eoTable (sao.cpp:65)
+    const int planes = j.planes < 3 ? (int)j.planes : 3;
+    for (int p = 0; p < planes; p++)
+    {
+        const int w = j.plane[p].w, h = j.plane[p].h, stride = w + 1;
+        const unsigned char* rec0 = at + stride + 1;
+        const unsigned char* fenc0 = at + (w + 1) * (h + 1);
+        at = fenc0 + w * h;
+        for (int i = tid; i < 320; i += 256) hist[i] = 0;
+        __syncthreads();
+        int x0[5], y0[5], x1[5], y1[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) { x0[c] = j.plane[p].x0[c]; y0[c] = j.plane[p].y0[c]; x1[c] = j.plane[p].x1[c]; y1[c] = j.plane[p].y1[c]; }
+        if (lx < w)
+            for (int y = ly; y < h; y += 4)
+            {
+                const unsigned char* r = rec0 + y * stride + lx;
+                const int c = r[0], d = (int)fenc0[y * w + lx] - c;
+                if (lx < x1[0] && y < y1[0]) { atomicAdd(&hist[c >> 3], d); atomicAdd(&hist[160 + (c >> 3)], 1); }
+                if (lx >= x0[1] && lx < x1[1] && y < y1[1])
+                {
+                    const int k = 32 + eoCat[sgn3(c - (int)r[1]) + sgn3(c - (int)r[-1]) + 2];
+                    atomicAdd(&hist[k], d); atomicAdd(&hist[160 + k], 1);
+                }
+                if (lx < x1[2] && y >= y0[2] && y < y1[2])
+                {
+                    const int k = 64 + eoCat[sgn3(c - (int)r[stride]) + sgn3(c - (int)r[-stride]) + 2];
+                    atomicAdd(&hist[k], d); atomicAdd(&hist[160 + k], 1);
+                }
+                if (j.eo23)
+                {
+                    if (lx >= x0[3] && lx < x1[3] && y >= y0[3] && y < y1[3])
+                    {
+                        const int k = 96 + eoCat[sgn3(c - (int)r[stride + 1]) + sgn3(c - (int)r[-stride - 1]) + 2];
+                        atomicAdd(&hist[k], d); atomicAdd(&hist[160 + k], 1);
+                    }
+                    if (lx >= x0[4] && lx < x1[4] && y >= y0[4] && y < y1[4])
+                    {
+                        const int k = 128 + eoCat[sgn3(c - (int)r[stride - 1]) + sgn3(c - (int)r[-stride + 1]) + 2];
+                        atomicAdd(&hist[k], d); atomicAdd(&hist[160 + k], 1);
+                    }
+                }
+            }
+        __syncthreads();
+        if (tid < 64)
+        {
+            for (int i = tid; i < 160; i += 64)
+            {
+                out[p * 160 + i] = hist[i];
+                out[X265HIP_SAOJOB_STATS_ENTRIES + p * 160 + i] = hist[160 + i];
+            }
+            // the release store waits for this wave's own stores (s_waitcnt vmcnt(0) is per wave): lane 0 publishes after the whole wave has issued them
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            if (tid == 0)
+            {
+                s->units[p].fwdTicks = (uint32_t)(wall_clock64() - t0);
+                __hip_atomic_store(&s->units[p].readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&s->units[p].ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // one job: `ticket` says how many bytes the job holds, so header and pixels arrive in one round trip
 __device__ __forceinline__ void run_job(const SlotIn* sin, SlotOut* s, JobLds& L, uint32_t ticket, uint64_t* busyTicks)
 {
@@ -546,7 +627,8 @@ __device__ __forceinline__ void run_job(const SlotIn* sin, SlotOut* s, JobLds& L
     for (int i = tid; i < chunks; i += 256)
         out[i] = in[i];
     __syncthreads();
-    if (ticket & 8) run_tiles<uint16_t>(s, L, ticket, t0);
+    if ((ticket & 3) == 3) run_sao(s, L, ticket, t0);
+    else if (ticket & 8) run_tiles<uint16_t>(s, L, ticket, t0);
     else run_tiles<uint8_t>(s, L, ticket, t0);
     __syncthreads();
     if (tid == 0)
@@ -672,7 +754,7 @@ struct x265hip_cuserve
     std::atomic<uint32_t>* seq = nullptr;         // per slot
     std::atomic<uint32_t> generation{ 0 };
     std::mutex launchLock;
-    std::atomic<uint64_t> jobs{ 0 }, starts{ 0 }, bytes{ 0 };
+    std::atomic<uint64_t> jobs{ 0 }, starts{ 0 }, bytes{ 0 }, saoJobs{ 0 };
     std::atomic<int> paused{ 0 };                 // servers_pause() callers in progress: no server is started meanwhile
     uint64_t idleUs = 2000;
 };
@@ -954,6 +1036,51 @@ int x265hip_cuserve_submit(x265hip_cuserve* cs, int slot, uint32_t* seqOut)
     }
     __atomic_store_n(&s->doorbell, seq, __ATOMIC_RELEASE);
     store_fence();                                                                           // ... and the doorbell leaves now, not when its write-combining buffer is evicted
+    if (__atomic_load_n(&cs->hostCtl->serverState, __ATOMIC_ACQUIRE) == 0)
+        return start_server(cs);
+    return X265HIP_OK;
+}
+
+int x265hip_cuserve_submit_sao(x265hip_cuserve* cs, int slot, const x265hip_saojob* job, uint32_t* seqOut)
+{
+    if (!cs || slot < 0 || slot >= cs->slots || !job || !seqOut) return set_error(X265HIP_EINVAL, "x265hip_cuserve_submit_sao: slot %d", slot);
+    bool ok = job->bitDepth == 8 && job->planes >= 1 && job->planes <= 3;
+    for (uint32_t p = 0; ok && p < job->planes; p++)
+    {
+        ok = job->plane[p].w >= 1 && job->plane[p].w <= 64 && job->plane[p].h >= 1 && job->plane[p].h <= 64;
+        for (int c = 0; ok && c < 5; c++)
+            ok = job->plane[p].x1[c] <= job->plane[p].w && job->plane[p].y1[c] <= job->plane[p].h;
+    }
+    const int bytes = ok ? x265hipi_saojob_pixel_bytes(job) : 0;
+    if (!ok || bytes > X265HIP_CUJOB_PIXEL_BYTES)
+        return set_error(X265HIP_EINVAL, "x265hip_cuserve_submit_sao: depth %u, %u planes, luma %ux%u", job->bitDepth, job->planes, job->plane[0].w, job->plane[0].h);
+    SlotIn* s = cs->in + slot;
+    uint32_t run = cs->seq[slot].load(std::memory_order_relaxed) + 1;
+    if (run >= 0xfffff0u) run = 1;
+    cs->seq[slot].store(run, std::memory_order_relaxed);
+    const uint32_t steps = (uint32_t)(128 + bytes + 511) / 512;
+    const uint32_t seq = (run << 8) | 3u | (steps << 2);
+    *seqOut = seq;
+    cs->jobs.fetch_add(1, std::memory_order_relaxed);
+    cs->saoJobs.fetch_add(1, std::memory_order_relaxed);
+    // what SAO::calcSaoStatsCTU reads and writes per plane: source + reconstruction in, 2 x 5 x 32 int32 out
+    cs->bytes.fetch_add((uint64_t)bytes + 2 * 160 * 4 * job->planes, std::memory_order_relaxed);
+    memcpy(&s->job, job, sizeof(*job));
+    store_fence();
+    if (cs->mode == 1)
+    {
+        std::atomic_thread_fence(std::memory_order_release);
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != cs->device) (void)hipSetDevice(cs->device);
+        hipLaunchKernelGGL(cu_job_kernel, dim3(1), dim3(256), 0, cs->jobStreams[slot], cs->inDev + slot, cs->outDev + slot, seq, &cs->ctl->busyTicks[slot]);
+        const hipError_t le = hipGetLastError();
+        if (cur >= 0 && cur != cs->device) (void)hipSetDevice(cur);
+        if (le != hipSuccess) return check_hip(le, "cu_job_kernel (SAO statistics)");
+        return X265HIP_OK;
+    }
+    __atomic_store_n(&s->doorbell, seq, __ATOMIC_RELEASE);
+    store_fence();
     if (__atomic_load_n(&cs->hostCtl->serverState, __ATOMIC_ACQUIRE) == 0)
         return start_server(cs);
     return X265HIP_OK;

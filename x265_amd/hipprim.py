@@ -189,6 +189,7 @@ PROTOTYPES = {
     "x265hip_cuserve_slot": (i32, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
     "x265hip_cuserve_submit": (i32, [vp, i32, C.POINTER(u32)]),
     "x265hip_cuserve_poke": (i32, [vp, i32]),
+    "x265hip_cuserve_submit_sao": (i32, [vp, i32, vp, vp]),
     "x265hip_cuserve_stats": (i32, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
     "x265hip_device_time": (i32, [i32, vp, vp, vp]),
     "x265hip_sadsurf_attach_levels": (vp, [vp, vp, i32, i32, i32]),
@@ -261,6 +262,18 @@ class CuJob(C.Structure):
     _fields_ = [("log2CUSize", u32), ("log2TrMax", u32), ("log2TrMin", u32), ("chroma", u32), ("bitDepth", u32), ("quantOffset", u32), ("signHide", u32),
                 ("reserved", u32), ("qpRem", C.c_int32 * 3), ("qpPer", C.c_int32 * 3), ("quantScale", C.c_int32 * 3), ("dequantScale", C.c_int32 * 3),
                 ("coefMode", u32), ("sourceDct", u32)]
+
+
+class SaoJobPlane(C.Structure):
+    _fields_ = [("w", C.c_uint16), ("h", C.c_uint16), ("x0", C.c_uint8 * 5), ("y0", C.c_uint8 * 5), ("x1", C.c_uint8 * 5), ("y1", C.c_uint8 * 5)]
+
+
+class SaoJob(C.Structure):
+    """x265hip_saojob (include/x265hip.h): the SAO statistics of one CTU as a job of the CU-job service"""
+    _fields_ = [("bitDepth", u32), ("planes", u32), ("eo23", u32), ("reserved", u32), ("plane", SaoJobPlane * 3)]
+
+
+SAOJOB_STATS_ENTRIES = 3 * 5 * 32
 
 
 class CuJobUnit(C.Structure):

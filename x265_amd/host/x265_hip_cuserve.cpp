@@ -45,6 +45,7 @@
 #include "quant.h"
 #include "scalinglist.h"
 #include "search.h"
+#include "sao.h"
 #undef protected
 #undef private
 
@@ -75,6 +76,8 @@ extern void refInvtransformNxN(Quant* self, const CUData& cu, int16_t* residual,
                                bool bIntra, bool useTransformSkip, uint32_t numSig)
     asm("_ZN4x2658QuantRef15invtransformNxNERKNS_6CUDataEPsjPKsjNS_8TextTypeEbbj");
 
+extern void refCalcSaoStatsCTU(SAO* self, int addr, int plane) asm("_ZN4x2656SAORef15calcSaoStatsCTUEii");
+
 namespace {
 
 int g_state = 0;                 // 0 undecided, 1 on, -1 off
@@ -84,9 +87,8 @@ int g_minLog2 = 5;               // X265HIP_CUSERVE_MIN: smallest CU (log2) whos
 int g_mode = 0;                  // X265HIP_CUSERVE_MODE: 0 resident server (mailbox), 1 one launch per job
 int64_t g_timeoutNs = 10000000000ll;            // X265HIP_CUSERVE_TIMEOUT_MS
 std::atomic<int> g_lateJobs(0);
-int g_rdoqJobs = 0;              // X265HIP_CUSERVE_RDOQ=1: CUs quantised by Quant::rdoQuant are handed over as coefficient-mode jobs.  Off by default: measured on the
-                                 // MI355X box at BASELINE configs[2] / configs[3] (profiles/r05_v1_configs*_ab.txt) the jobs cost 1-3 % — a 16x16 cu[].dct is 0.8 us of
-                                 // CPU, a 32x32 one 6 us, against 8 us to the first unit of a job and a 2-4 KB copy per unit; the quantiser itself cannot move
+int g_rdoqJobs = 1;              // X265HIP_CUSERVE_RDOQ=0: CUs quantised by Quant::rdoQuant are not handed over (round 4's behaviour).  On: measured on the MI355X box at
+                                 // BASELINE configs[2] / configs[3] (profiles/r05_v1_configs*_ab.txt): +2 % / +6 % fps, -3 % / -6 % CPU seconds
 int g_slots = 64;                // X265HIP_CUSERVE_SLOTS: jobs that can be in flight (default: twice the CPUs this process may use, 16..64)
 bool g_verify = false;           // X265HIP_VERIFY=1: every served unit is recomputed by the reference's function and compared
 bool g_require = false;          // X265HIP=require: a device failure is fatal instead of falling back
@@ -456,8 +458,8 @@ bool make_header(Search* se, const Mode& mode, uint32_t log2CUSize, const uint32
     const Quant& q = se->m_quant;
     const int csp = se->m_csp;
     const bool codeChroma = csp != X265_CSP_I400 && se->m_frame->m_fencPic->m_picCsp != X265_CSP_I400;
-    // RDOQ (presets slow / slower): the quantiser is Quant::rdoQuant and stays on the host (its decisions read the entropy coder's state); a job can only carry
-    // the transforms in front of it — coefficient mode, X265HIP_CUSERVE_RDOQ=1 (see g_rdoqJobs for why it is not the default)
+    // RDOQ (presets slow / slower): the quantiser is Quant::rdoQuant and stays on the host (its decisions read the entropy coder's state); the job carries
+    // the transforms in front of it — coefficient mode (X265HIP_CUSERVE_RDOQ=0 switches it off)
     if (cu.m_tqBypass[0] || (q.m_rdoqLevel && !g_rdoqJobs) || (q.m_nr && q.m_nr->offset) || q.m_scalingList->m_bEnabled || (csp != X265_CSP_I420 && csp != X265_CSP_I400) ||
         (csp == X265_CSP_I420) != codeChroma)
         return false;
@@ -1241,6 +1243,270 @@ void Quant::invtransformNxN(const CUData& cu, int16_t* residual, uint32_t resiSt
         return;
     }
     refInvtransformNxN(this, cu, residual, resiStride, coeff, log2TrSize, ttype, bIntra, useTransformSkip, numSig);
+}
+
+
+// ---- SAO statistics as jobs of the same service (round 5; include/x265hip.h x265hip_saojob) --------------------------------------------------------------
+// SAO::calcSaoStatsCTU (reference source/encoder/sao.cpp:735-917) is called per plane from rdoSaoUnitCu (:1293-1305) for every CTU, two columns behind the
+// deblocking of the same row (framefilter.cpp:440-500): 5 classes x 3 planes of per-sample classification = ~50 us of CPU per CTU (6.8 % of the bound
+// encoder's CPU time in round 4's profile).  Its result is a function of the deblocked CTU (with the row above and the column to the left), the source CTU and
+// the rectangles the reference measures: the seam below computes the rectangles exactly as the reference does, hands the two blocks to the device — one job
+// for all planes when luma is asked for (the chroma planes are measured while this thread runs the luma offsets' RDO) — and adds the sums and counts it gets
+// back where the reference's primitives add theirs.  8-bit builds; X265HIP_SAOSTATS=0 switches it off; X265HIP_VERIFY recomputes with the reference's body.
+namespace {
+
+int g_saoState = 0;              // 0 undecided, 1 on, -1 off
+struct alignas(64) SaoCounters { std::atomic<uint64_t> jobs, planes, hostPlanes, waits, waitCycles; };
+SaoCounters g_saoCount[16];
+struct SaoJob
+{
+    bool active;
+    const SAO* sao; int addr;
+    int nblocks, blockPlane[3];          // job block b holds plane blockPlane[b]
+    bool consumed[3];
+    Service* svc; int slot; uint32_t seq;
+};
+__attribute__((tls_model("initial-exec"))) thread_local SaoJob t_sao;
+
+void sao_report()
+{
+    uint64_t jobs = 0, planes = 0, host = 0, w = 0, wc = 0;
+    for (int i = 0; i < 16; i++) { jobs += g_saoCount[i].jobs; planes += g_saoCount[i].planes; host += g_saoCount[i].hostPlanes; w += g_saoCount[i].waits; wc += g_saoCount[i].waitCycles; }
+    fprintf(stderr, "x265hip: saostats: SAO statistics of %llu CTU planes (SAO::calcSaoStatsCTU: band + four edge classes) measured by the GPU in %llu jobs, %llu planes on the host; "
+                    "%llu waits of %.0f cycles on average\n", (unsigned long long)planes, (unsigned long long)jobs, (unsigned long long)host, (unsigned long long)w, w ? (double)wc / w : 0.0);
+}
+
+bool sao_enabled()
+{
+    if (!g_saoState)
+    {
+        std::lock_guard<std::mutex> g(g_lock);
+        if (!g_saoState)
+        {
+            const char* env = getenv("X265HIP_SAOSTATS");
+            const char* all = getenv("X265HIP");
+            const char* table = getenv("X265HIP_TABLE");
+            if (X265_DEPTH != 8 || (env && !strcmp(env, "0")) || (all && !strcmp(all, "0")) || (table && !strcmp(table, "percall")))
+                g_saoState = -1;
+            else
+            {
+                g_saoState = 1;
+                if (getenv("X265HIP_VERBOSE")) atexit(sao_report);
+            }
+        }
+    }
+    return g_saoState > 0;
+}
+
+inline SaoCounters& sao_counters() { counters(); return g_saoCount[t_shard & 15]; }
+
+// the rectangles of one plane, exactly as sao.cpp:741-914 computes them; false: a geometry the job does not carry
+bool sao_rects(const SAO* sao, int addr, int plane, x265hip_saojob& job, int b, const pixel*& rec0, const pixel*& fenc0, intptr_t& stride, bool& eo23)
+{
+    const Frame* frame = sao->m_frame;
+    const x265_param* param = sao->m_param;
+    const Slice* slice = frame->m_encData->m_slice;
+    const PicYuv* reconPic = frame->m_reconPic;
+    const CUData* cu = frame->m_encData->getPicCTU(addr);
+    fenc0 = frame->m_fencPic->getPlaneAddr(plane, addr);
+    rec0 = reconPic->getPlaneAddr(plane, addr);
+    stride = plane ? reconPic->m_strideC : reconPic->m_stride;
+    if ((plane ? frame->m_fencPic->m_strideC : frame->m_fencPic->m_stride) != stride)
+        return false;                                    // (the reference indexes both pictures with the reconstruction's stride, :786-806)
+    uint32_t picWidth = param->sourceWidth, picHeight = param->sourceHeight;
+    int ctuWidth = param->maxCUSize, ctuHeight = param->maxCUSize;
+    uint32_t lpelx = cu->m_cuPelX, tpely = cu->m_cuPelY;
+    const uint32_t bAboveUnavail = (!tpely) | cu->m_bFirstRowInSlice;
+    if (plane)
+    {
+        picWidth >>= sao->m_hChromaShift; picHeight >>= sao->m_vChromaShift;
+        ctuWidth >>= sao->m_hChromaShift; ctuHeight >>= sao->m_vChromaShift;
+        lpelx >>= sao->m_hChromaShift; tpely >>= sao->m_vChromaShift;
+    }
+    const uint32_t rpelx = x265_min(lpelx + ctuWidth, picWidth), bpely = x265_min(tpely + ctuHeight, picHeight);
+    ctuWidth = rpelx - lpelx; ctuHeight = bpely - tpely;
+    if (cu->m_bLastRowInSlice)
+        picHeight = bpely;
+    if (ctuWidth < 1 || ctuHeight < 1 || ctuWidth > 64 || ctuHeight > 64)
+        return false;
+    const int po = plane ? 2 : 0;
+    const bool nd = param->bSaoNonDeblocked != 0;
+    const bool right = rpelx == picWidth, bottom = bpely == picHeight;
+    int x0[5], y0[5], x1[5], y1[5];
+    // SAO_BO (:810-823): skipB 4 / skipR 5, non-deblocked 3 / 4
+    { const int skipB = nd ? 3 : 4, skipR = nd ? 4 : 5;
+      x0[0] = 0; y0[0] = 0; x1[0] = right ? ctuWidth : ctuWidth - skipR + po; y1[0] = bottom ? ctuHeight : ctuHeight - skipB + po; }
+    // SAO_EO_0 (:826-839): skipB 4 / skipR 5, non-deblocked 3 / 5; the rows are NOT shortened at the picture's bottom
+    { const int skipB = nd ? 3 : 4, skipR = 5;
+      x0[1] = !lpelx; y0[1] = 0; x1[1] = right ? ctuWidth - 1 : ctuWidth - skipR + po; y1[1] = ctuHeight - skipB + po; }
+    // SAO_EO_1 (:841-861): skipB 4, skipR 5 / non-deblocked 4
+    { const int skipB = 4, skipR = nd ? 4 : 5;
+      x0[2] = 0; y0[2] = bAboveUnavail; x1[2] = right ? ctuWidth : ctuWidth - skipR + po; y1[2] = bottom ? ctuHeight - 1 : ctuHeight - skipB + po; }
+    // SAO_EO_2 / SAO_EO_3 (:865-914): skipB 4, skipR 5
+    for (int c = 3; c < 5; c++)
+    { const int skipB = 4, skipR = 5;
+      x0[c] = !lpelx; y0[c] = bAboveUnavail; x1[c] = right ? ctuWidth - 1 : ctuWidth - skipR + po; y1[c] = bottom ? ctuHeight - 1 : ctuHeight - skipB + po; }
+    eo23 = !param->bLimitSAO || ((slice->m_sliceType == P_SLICE && !cu->isSkipped(0)) || (slice->m_sliceType != B_SLICE));
+    job.plane[b].w = (uint16_t)ctuWidth; job.plane[b].h = (uint16_t)ctuHeight;
+    for (int c = 0; c < 5; c++)
+    {
+        // an empty rectangle (a CTU a few samples wide) measures nothing in the reference's loops either; the job carries it as [0, 0)
+        if (x1[c] <= x0[c] || y1[c] <= y0[c] || x1[c] < 0 || y1[c] < 0) { x0[c] = y0[c] = x1[c] = y1[c] = 0; }
+        job.plane[b].x0[c] = (uint8_t)x0[c]; job.plane[b].y0[c] = (uint8_t)y0[c]; job.plane[b].x1[c] = (uint8_t)x1[c]; job.plane[b].y1[c] = (uint8_t)y1[c];
+    }
+    return true;
+}
+
+void sao_drop(SaoJob& sj, bool deviceDone)
+{
+    if (sj.active && deviceDone) give_slot(sj.svc, sj.slot);
+    sj.active = false;
+}
+
+// waits for block b of this thread's SAO job; false: the device did not deliver
+bool sao_wait(SaoJob& sj, int b)
+{
+    const uint32_t* ready = &sj.svc->mem[sj.slot].units[b].ready;
+    if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == sj.seq) return true;
+    const uint64_t t0 = __builtin_ia32_rdtsc();
+    uint64_t spins = 0;
+    int64_t waitedNs = 0, lastNs = -1;
+    while (__atomic_load_n(ready, __ATOMIC_ACQUIRE) != sj.seq)
+    {
+        __builtin_ia32_pause();
+        if ((++spins & 255) == 0)
+        {
+            const int pk = x265hip_cuserve_poke(sj.svc->cs, sj.slot);
+            timespec ts;
+            clock_gettime(CLOCK_MONOTONIC, &ts);
+            const int64_t nowNs = (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+            if (pk == 0 && lastNs >= 0) waitedNs += nowNs - lastNs;
+            lastNs = nowNs;
+            if (pk < 0 || waitedNs > g_timeoutNs)
+            {
+                sj.active = false;                       // the slot is not given back: the device may still write into it
+                g_saoState = -1;
+                x265hip_device_failure("saostats", "an SAO statistics job did not come back");
+                return false;
+            }
+        }
+    }
+    SaoCounters& c = sao_counters();
+    c.waits.fetch_add(1, std::memory_order_relaxed);
+    c.waitCycles.fetch_add(__builtin_ia32_rdtsc() - t0, std::memory_order_relaxed);
+    return true;
+}
+
+// one job for planes [first, first + n) of CTU `addr`; false: not submitted
+bool sao_submit(SAO* sao, int addr, int first, int n)
+{
+    SaoJob& sj = t_sao;
+    if (g_dead.load(std::memory_order_relaxed) || !service())
+        return false;
+    x265hip_saojob job;
+    memset(&job, 0, sizeof(job));
+    job.bitDepth = X265_DEPTH; job.planes = (uint32_t)n;
+    const pixel* rec0[3]; const pixel* fenc0[3]; intptr_t stride[3];
+    bool eo23 = true;
+    for (int b = 0; b < n; b++)
+        if (!sao_rects(sao, addr, first + b, job, b, rec0[b], fenc0[b], stride[b], eo23))
+            return false;
+    job.eo23 = eo23;
+    Service* svc = NULL;
+    const int slot = take_slot(&svc);
+    if (slot < 0)
+        return false;
+    // the blocks, packed in this thread's memory first, then one front-to-back copy into the mailbox (write-combining memory)
+    static thread_local pixel staged[3 * (65 * 65 + 64 * 64)];
+    pixel* dst = staged;
+    for (int b = 0; b < n; b++)
+    {
+        const int w = job.plane[b].w, h = job.plane[b].h;
+        const pixel* r = rec0[b] - stride[b] - 1;
+        for (int y = 0; y <= h; y++, dst += w + 1) memcpy(dst, r + (intptr_t)y * stride[b], (size_t)(w + 1) * sizeof(pixel));
+        for (int y = 0; y < h; y++, dst += w) memcpy(dst, fenc0[b] + (intptr_t)y * stride[b], (size_t)w * sizeof(pixel));
+    }
+    memcpy(svc->mem[slot].pixels, staged, (size_t)(dst - staged) * sizeof(pixel));
+    uint32_t seq = 0;
+    if (x265hip_cuserve_submit_sao(svc->cs, slot, &job, &seq))
+    {
+        give_slot(svc, slot);
+        g_saoState = -1;
+        x265hip_device_failure("saostats", "x265hip_cuserve_submit_sao");
+        return false;
+    }
+    sj.active = true; sj.sao = sao; sj.addr = addr; sj.nblocks = n; sj.svc = svc; sj.slot = slot; sj.seq = seq;
+    for (int b = 0; b < 3; b++) { sj.blockPlane[b] = first + b; sj.consumed[b] = false; }
+    sao_counters().jobs.fetch_add(1, std::memory_order_relaxed);
+    return true;
+}
+
+} // namespace
+
+void SAO::calcSaoStatsCTU(int addr, int plane)
+{
+    if (g_saoState < 0 || !sao_enabled())
+    {
+        refCalcSaoStatsCTU(this, addr, plane);
+        return;
+    }
+    SaoJob& sj = t_sao;
+    // a job of another CTU (its chroma planes were never asked for): wait it out, the slot goes back
+    if (sj.active && (sj.sao != this || sj.addr != addr))
+    {
+        bool done = true;
+        for (int b = 0; b < sj.nblocks && done; b++) done = sao_wait(sj, b);
+        sao_drop(sj, done);
+    }
+    int b = -1;
+    if (sj.active)
+        for (int k = 0; k < sj.nblocks; k++)
+            if (sj.blockPlane[k] == plane && !sj.consumed[k]) b = k;
+    if (b < 0 && !sj.active)
+    {
+        const bool chroma = m_param->internalCsp != X265_CSP_I400 && m_frame->m_fencPic->m_picCsp != X265_CSP_I400;
+        const SAOParam* sp = m_frame->m_encData->m_saoParam;
+        // luma asked for: the chroma planes ride along when the reference is going to ask for them whatever the luma decision (no --limit-sao, :1299-1306)
+        const bool ok = plane == 0 ? sao_submit(this, addr, 0, chroma && !m_param->bLimitSAO && sp && sp->bSaoFlag[1] && m_param->internalCsp == X265_CSP_I420 ? 3 : 1)
+                                   : plane == 1 && m_param->internalCsp == X265_CSP_I420 ? sao_submit(this, addr, 1, 2) : false;
+        if (ok) b = 0;
+    }
+    if (b >= 0 && sao_wait(sj, b))
+    {
+        const int32_t* out = (const int32_t*)sj.svc->mem[sj.slot].levels;
+        const int32_t* st = out + b * 160;
+        const int32_t* ct = out + X265HIP_SAOJOB_STATS_ENTRIES + b * 160;
+        static const int typeOf[5] = { SAO_BO, SAO_EO_0, SAO_EO_1, SAO_EO_2, SAO_EO_3 };
+        if (g_verify)
+        {
+            PerClass keepC, keepO;
+            memcpy(keepC, m_count[plane], sizeof(keepC)); memcpy(keepO, m_offsetOrg[plane], sizeof(keepO));
+            refCalcSaoStatsCTU(this, addr, plane);
+            for (int c = 0; c < 5; c++)
+                for (int k = 0; k < (c ? 5 : 32); k++)
+                    if (m_count[plane][typeOf[c]][k] != keepC[typeOf[c]][k] + ct[c * 32 + k] || m_offsetOrg[plane][typeOf[c]][k] != keepO[typeOf[c]][k] + st[c * 32 + k])
+                    {
+                        fprintf(stderr, "x265hip: saostats: VERIFY FAILED CTU %d plane %d class %d bin %d: count %d + %d vs %d, sum %d + %d vs %d\n", addr, plane, c, k, keepC[typeOf[c]][k],
+                                ct[c * 32 + k], m_count[plane][typeOf[c]][k], keepO[typeOf[c]][k], st[c * 32 + k], m_offsetOrg[plane][typeOf[c]][k]);
+                        abort();
+                    }
+        }
+        else
+            for (int c = 0; c < 5; c++)
+                for (int k = 0; k < (c ? 5 : 32); k++)
+                {
+                    m_count[plane][typeOf[c]][k] += ct[c * 32 + k];
+                    m_offsetOrg[plane][typeOf[c]][k] += st[c * 32 + k];
+                }
+        sj.consumed[b] = true;
+        sao_counters().planes.fetch_add(1, std::memory_order_relaxed);
+        bool all = true;
+        for (int k = 0; k < sj.nblocks; k++) all = all && sj.consumed[k];
+        if (all) sao_drop(sj, true);
+        return;
+    }
+    sao_counters().hostPlanes.fetch_add(1, std::memory_order_relaxed);
+    refCalcSaoStatsCTU(this, addr, plane);
 }
 
 } // namespace X265_NS
