@@ -854,7 +854,8 @@ typedef struct x265hip_cujob
     uint32_t coefMode;            /* 1: the host quantises (Quant::rdoQuant, quant.cpp:610-1420 — presets slow and slower; its decisions read the entropy coder's
                                    * state).  A unit's `levels` block then receives the TRANSFORM COEFFICIENTS of its residual — cu[].dct's output, what
                                    * Quant::transformNxN leaves in m_resiDctCoeff (quant.cpp:432) — numSig is 0, zeroDist as always, and there is no inverse half:
-                                   * readyInv is set with ready; codedDist / codedEnergy / the `resi` block of chroma units are not written */
+                                   * codedDist / codedEnergy / the `resi` block of chroma units are not written.  `ready`: the coefficients are in place; `readyInv`:
+                                   * so is everything else the unit will get (the luma units' source transform with sourceDct: it may arrive before or after) */
     uint32_t sourceDct;           /* with coefMode: 1 = a LUMA unit's `resi` block receives cu[].dct of the unit's SOURCE pixels — m_fencDctCoeff, which psy-rdoq
                                    * compares the levels' reconstruction against (quant.cpp:436-442) */
 } x265hip_cujob;

@@ -37,7 +37,7 @@ while [ $# -gt 0 ]; do
       frames=$1; shift; cfgs=(); while [ $# -gt 0 ] && [[ "$1" == *:* ]]; do cfgs+=("$1"); shift; done
       timeout 1500 python tools/ab_encode.py --rounds 3 --frames $frames "${cfgs[@]}" --out $OUT/ab.json 2>&1 | tee $OUT/ab.txt | tail -14 ;;
     rt)
-      timeout 300 tools/micro/cuserve_rt 2>&1 | tee $OUT/cuserve_rt.txt | tail -30 ;;
+      (timeout 200 tools/micro/cuserve_rt 0 3000 1; timeout 100 tools/micro/cuserve_rt 1 1000 0) 2>&1 | tee $OUT/cuserve_rt.txt | tail -30 ;;
     stats)
       clip /tmp/bench120.yuv 120
       HERE=$PWD

@@ -117,6 +117,60 @@ int main(int argc, char** argv)
                 }
             fflush(stdout);
         }
+    // ---- SAO statistics jobs (x265hip_saojob): a whole 64x64 CTU, three planes, every class; what SAO::calcSaoStatsCTU's seam hands over per CTU
+    for (int T : { 1, 4, 16 })
+    {
+        std::vector<std::vector<double>> luma(T), whole(T), dev0(T), dev2(T);
+        std::atomic<int> go(0);
+        auto body = [&](int t)
+        {
+            x265hip_init(0);
+            x265hip_cujob* job; void* pixels; const x265hip_cujob_unit* units; const int16_t* levels; const int16_t* resi;
+            x265hip_cuserve_slot(cs, t, &job, &pixels, &units, &levels, &resi);
+            x265hip_saojob sj;
+            memset(&sj, 0, sizeof(sj));
+            sj.bitDepth = 8; sj.planes = 3; sj.eo23 = 1;
+            for (int p = 0; p < 3; p++)
+            {
+                const int n = p ? 32 : 64, po = p ? 2 : 0;
+                sj.plane[p].w = sj.plane[p].h = (uint16_t)n;
+                for (int c = 0; c < 5; c++) { sj.plane[p].x0[c] = c == 1 || c >= 3; sj.plane[p].y0[c] = c >= 2; sj.plane[p].x1[c] = (uint8_t)(n - 5 + po); sj.plane[p].y1[c] = (uint8_t)(n - 4 + po); }
+            }
+            const int bytes = x265hipi_saojob_pixel_bytes(&sj);
+            std::vector<unsigned char> src(bytes);
+            uint32_t s = 99 + t;
+            for (auto& b : src) { s = s * 1664525u + 1013904223u; b = (unsigned char)(120 + ((s >> 24) & 31)); }
+            while (!go.load()) {}
+            for (int i = 0; i < iters + 100 && !failed; i++)
+            {
+                src[i % bytes] ^= 5;
+                const double t0 = now_us();
+                memcpy(pixels, src.data(), bytes);
+                uint32_t seq = 0;
+                if (x265hip_cuserve_submit_sao(cs, t, &sj, &seq)) { fprintf(stderr, "submit_sao: %s\n", x265hip_last_error()); failed = true; break; }
+                double tl = 0;
+                for (int p = 0; p < 3 && !failed; p++)
+                {
+                    uint64_t spins = 0;
+                    while (__atomic_load_n(&units[p].ready, __ATOMIC_ACQUIRE) != seq)
+                        if ((++spins & 1023) == 0 && x265hip_cuserve_poke(cs, t) < 0) { fprintf(stderr, "poke: %s\n", x265hip_last_error()); failed = true; break; }
+                    if (p == 0) tl = now_us() - t0;
+                }
+                const double tw = now_us() - t0;
+                if (i >= 100) { luma[t].push_back(tl); whole[t].push_back(tw); dev0[t].push_back(units[0].fwdTicks * 0.01); dev2[t].push_back(units[2].fwdTicks * 0.01); }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back(body, t);
+        const double w0 = now_us();
+        go = 1;
+        for (auto& x : th) x.join();
+        const double wall = now_us() - w0;
+        auto med = [](std::vector<std::vector<double>>& v) { std::vector<double> a; for (auto& x : v) a.insert(a.end(), x.begin(), x.end()); std::sort(a.begin(), a.end()); return a.empty() ? 0.0 : a[a.size() / 2]; };
+        printf("%s, SAO statistics of a 64x64 CTU (4:2:0, 8 bit, 5 classes x 3 planes), %2d thread%s: luma ready median %6.1f us (%4.1f us of it on the device), all planes %6.1f us (%4.1f on the device); "
+               "%.0f jobs/s in total\n", mode ? "one launch per job" : "resident server   ", T, T > 1 ? "s" : " ", med(luma), med(dev0), med(whole), med(dev2), (double)T * (iters + 100) / (wall * 1e-6));
+        fflush(stdout);
+    }
     uint64_t jobs = 0, starts = 0, ns = 0;
     x265hip_cuserve_stats(cs, &jobs, &starts, &ns);
     printf("%llu jobs, %llu server starts, %.1f us of device time per job\n", (unsigned long long)jobs, (unsigned long long)starts, jobs ? ns * 1e-3 / jobs : 0.0);

@@ -169,6 +169,9 @@ __device__ __forceinline__ void tile_chain(TileLds& t, const BOperand (*bop)[64]
     const v4i bF = { oF.b[0], oF.b[1], oF.b[2], oF.b[3] }, bI = { oI.b[0], oI.b[1], oI.b[2], oI.b[3] };
     const int corrF = oF.corr, corrI = oI.corr;
 
+    // coef (x265hip_cujob::coefMode): bit 0 the residual's transform coefficients go out, bit 1 the source block's; bit 2: the two parts are separate work
+    // items on different waves (the residual part releases `ready`, the source part `readyInv`)
+    const bool srcOnly = (coef & 3) == 2;
     // ---- residual = source - prediction (two runs of 8 per lane; kept in registers for the distortions)
     int fv[16], pv[16];
 #pragma unroll
@@ -189,8 +192,9 @@ __device__ __forceinline__ void tile_chain(TileLds& t, const BOperand (*bop)[64]
 #pragma unroll
             for (int i = 0; i < 8; i++) { fv[8 * half + i] = 0; pv[8 * half + i] = 0; }
         }
+        // (coefficient mode, source part: the SOURCE samples are transformed — m_fencDctCoeff, quant.cpp:436-442 — by the same two passes)
 #pragma unroll
-        for (int i = 0; i < 8; i++) r[i] = fv[8 * half + i] - pv[8 * half + i];
+        for (int i = 0; i < 8; i++) r[i] = srcOnly ? fv[8 * half + i] : fv[8 * half + i] - pv[8 * half + i];
         store4(t.a + e, r); store4(t.a + e + 4, r + 4);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -202,40 +206,27 @@ __device__ __forceinline__ void tile_chain(TileLds& t, const BOperand (*bop)[64]
     XH_STAMP(1);
     if (coef)
     {
-        // ---- coefficient mode (x265hip_cujob::coefMode): the host quantises (Quant::rdoQuant).  The unit's transform coefficients go out where the levels
-        // would; coef & 2: the same transform of the unit's SOURCE pixels (m_fencDctCoeff, quant.cpp:436-442) goes out where the reconstructed residual would
+        // ---- coefficient mode (x265hip_cujob::coefMode): the host quantises (Quant::rdoQuant).  The unit's transform coefficients go out where the levels would
+        // (residual part) or where the reconstructed residual would (source part: m_fencDctCoeff for psy-rdoq)
         const int gC = (lane * 16) / (N * N);
         const bool okC = gC < count;
-        if (coef & 2)
-        {
-#pragma unroll
-            for (int half = 0; half < 2; half++)
-            {
-                const int e = lane * 16 + half * 8;
-                store4(t.c + e, &fv[8 * half]); store4(t.c + e + 4, &fv[8 * half + 4]);
-            }
-        }
+        int16_t* dstC = srcOnly ? resi : levels;
 #pragma unroll
         for (int half = 0; half < 2; half++)
         {
             const int e = lane * 16 + half * 8;
             if (okC)
-                *reinterpret_cast<uint4*>(levels + elemBase + (u0 + gC) * N * N + (e % (N * N))) = *reinterpret_cast<const uint4*>(t.a + e);
+                *reinterpret_cast<uint4*>(dstC + elemBase + (u0 + gC) * N * N + (e % (N * N))) = *reinterpret_cast<const uint4*>(t.a + e);
         }
-        if (coef & 2)
+        x265hip_cujob_unit* unC = units + unitBase + u0 + gC;
+        const bool writerC = okC && (lane & (LPT - 1)) == 0;
+        if (srcOnly)
         {
+            // (the release store waits for every store this wave has issued: the block above is in host memory when the word is seen)
+            if (writerC)
+                __hip_atomic_store(&unC->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             __builtin_amdgcn_s_waitcnt(0xc07f);
-            mfma_pass<N, false>(t.c, t.b, lane, bF, corrF, qp.s1f);
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            mfma_pass<N, false>(t.b, t.c, lane, bF, corrF, qp.s2f);
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-#pragma unroll
-            for (int half = 0; half < 2; half++)
-            {
-                const int e = lane * 16 + half * 8;
-                if (okC)
-                    *reinterpret_cast<uint4*>(resi + elemBase + (u0 + gC) * N * N + (e % (N * N))) = *reinterpret_cast<const uint4*>(t.c + e);
-            }
+            return;
         }
         unsigned long long zeroC = 0;
 #pragma unroll
@@ -245,16 +236,15 @@ __device__ __forceinline__ void tile_chain(TileLds& t, const BOperand (*bop)[64]
             zeroC += (unsigned)(d0 * d0);
         }
         zeroC = group_sum64(zeroC, LPT);
-        x265hip_cujob_unit* unC = units + unitBase + u0 + gC;
-        if (okC && (lane & (LPT - 1)) == 0)
+        if (writerC)
         {
             unC->numSig = 0;
             unC->zeroDist = zeroC;
             unC->fwdTicks = (uint32_t)(wall_clock64() - t0);
             XH_STAMP(5);
             if (stamps) { unC->reserved[0] = stamp[0] | (stamp[1] << 16); unC->reserved[1] = 0; unC->reserved[2] = stamp[5] << 16; }
-            // (the release store waits for every store this wave has issued: the blocks above are in host memory when either word is seen)
-            __hip_atomic_store(&unC->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (!(coef & 4))
+                __hip_atomic_store(&unC->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&unC->ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -522,12 +512,16 @@ __device__ __forceinline__ void run_tiles(SlotOut* s, JobLds& L, uint32_t seq, u
             const P* pp = plane == 0 ? prd : plane == 1 ? prd + lumaElems : prd + lumaElems + lumaElems / 4;
             const int pw = plane ? NC : N;
             const PlaneParams qp = plane_params(j, plane, log2n);
-            const int coef = j.coefMode ? 1 | (j.sourceDct && plane == 0 ? 2 : 0) : 0;
+            // coefficient mode: a luma tile whose source block is wanted as well is TWO work items (residual part, source part) — on different waves, so that
+            // the first luma unit's two blocks arrive together instead of one behind the other
+            const int parts = j.coefMode && j.sourceDct && plane == 0 ? 2 : 1;
             const int unitBase = x265hipi_cujob_unit_index(&j, sHi, sz, plane, 0, 0);
             const int elemBase = x265hipi_cujob_elem_offset(&j, sHi, sz, plane, 0, 0);
-            for (int k = 0; k < tiles; k++, tile++)
+            for (int kk = 0; kk < tiles * parts; kk++, tile++)
             {
                 if ((tile & 3) != wv) continue;
+                const int k = kk / parts;
+                const int coef = !j.coefMode ? 0 : parts == 1 ? 1 : (kk % parts) == 0 ? 1 | 4 : 2 | 4;
                 const int u0 = k * G, count = nUnits - u0 < G ? nUnits - u0 : G;
                 if (log2n == 5) tile_chain<P, 32>(L.tile[wv], L.bop[2], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0, j.reserved != 0, coef);
                 else if (log2n == 4) tile_chain<P, 16>(L.tile[wv], L.bop[1], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0, j.reserved != 0, coef);
@@ -547,11 +541,12 @@ __device__ __forceinline__ int sgn3(int v) { return (v > 0) - (v < 0); }
 __device__ __forceinline__ void run_sao(SlotOut* s, JobLds& L, uint32_t seq, uint64_t t0)
 {
     const x265hip_saojob& j = *reinterpret_cast<const x265hip_saojob*>(&L.job);
-    int* hist = reinterpret_cast<int*>(&L.tile[0]);                       // [0..159] sums of class c bin b at c * 32 + b, [160..319] counts
+    // LDS: [0..159] sums of class c bin b at c * 32 + b, [160..319] counts — what goes out; [320..575] / [576..831] the waves' private band histograms
+    // (sums / counts, 64 entries per wave: 32 used)
+    int* hist = reinterpret_cast<int*>(&L.tile[0]);
     int32_t* out = reinterpret_cast<int32_t*>(s->levels);
     const int tid = threadIdx.x, lx = tid & 63, ly = tid >> 6;
     const unsigned char* at = L.pix;
-    const int eoCat[5] = { 1, 2, 0, 3, 4 };                               // SAO::s_eoTable (sao.cpp:65)
     const int planes = j.planes < 3 ? (int)j.planes : 3;
     for (int p = 0; p < planes; p++)
     {
@@ -559,41 +554,61 @@ __device__ __forceinline__ void run_sao(SlotOut* s, JobLds& L, uint32_t seq, uin
         const unsigned char* rec0 = at + stride + 1;
         const unsigned char* fenc0 = at + (w + 1) * (h + 1);
         at = fenc0 + w * h;
-        for (int i = tid; i < 320; i += 256) hist[i] = 0;
+        for (int i = tid; i < 832; i += 256) hist[i] = 0;
         __syncthreads();
         int x0[5], y0[5], x1[5], y1[5];
 #pragma unroll
         for (int c = 0; c < 5; c++) { x0[c] = j.plane[p].x0[c]; y0[c] = j.plane[p].y0[c]; x1[c] = j.plane[p].x1[c]; y1[c] = j.plane[p].y1[c]; }
+        // edge classes: five categories each — per lane in registers, count in the high and the (signed) sum in the low word of one 64-bit accumulator;
+        // the band class has 32 bins: the wave's private LDS histogram
+        long long acc[4][5];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) acc[c][k] = 0;
+        int* bandSum = hist + 320 + ly * 64;
+        int* bandCnt = hist + 576 + ly * 64;
+        const bool eo23 = j.eo23 != 0;
         if (lx < w)
             for (int y = ly; y < h; y += 4)
             {
                 const unsigned char* r = rec0 + y * stride + lx;
                 const int c = r[0], d = (int)fenc0[y * w + lx] - c;
-                if (lx < x1[0] && y < y1[0]) { atomicAdd(&hist[c >> 3], d); atomicAdd(&hist[160 + (c >> 3)], 1); }
-                if (lx >= x0[1] && lx < x1[1] && y < y1[1])
+                const long long one = (1ll << 32) + d;
+                if (lx < x1[0] && y < y1[0]) { atomicAdd(&bandSum[c >> 3], d); atomicAdd(&bandCnt[c >> 3], 1); }
+                // s_eoTable (sao.cpp:65) folds sign + sign + 2 = 0..4 into the categories 1, 2, 0, 3, 4
+#define XH_EO(cls, na, nb) do { const int e = sgn3(c - (int)(na)) + sgn3(c - (int)(nb)) + 2; const int k = e == 0 ? 1 : e == 1 ? 2 : e == 2 ? 0 : e; \
+                                _Pragma("unroll") for (int q = 0; q < 5; q++) acc[cls][q] += k == q ? one : 0; } while (0)
+                if (lx >= x0[1] && lx < x1[1] && y < y1[1]) XH_EO(0, r[1], r[-1]);
+                if (lx < x1[2] && y >= y0[2] && y < y1[2]) XH_EO(1, r[stride], r[-stride]);
+                if (eo23)
                 {
-                    const int k = 32 + eoCat[sgn3(c - (int)r[1]) + sgn3(c - (int)r[-1]) + 2];
-                    atomicAdd(&hist[k], d); atomicAdd(&hist[160 + k], 1);
+                    if (lx >= x0[3] && lx < x1[3] && y >= y0[3] && y < y1[3]) XH_EO(2, r[stride + 1], r[-stride - 1]);
+                    if (lx >= x0[4] && lx < x1[4] && y >= y0[4] && y < y1[4]) XH_EO(3, r[stride - 1], r[-stride + 1]);
                 }
-                if (lx < x1[2] && y >= y0[2] && y < y1[2])
+#undef XH_EO
+            }
+        // the waves' edge accumulators: reduced across the wave, lane 0 adds the wave's 20 pairs to the plane's table
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+            {
+                const long long v = (long long)group_sum64((unsigned long long)acc[c][k], kWave);
+                if (lx == 0 && v)
                 {
-                    const int k = 64 + eoCat[sgn3(c - (int)r[stride]) + sgn3(c - (int)r[-stride]) + 2];
-                    atomicAdd(&hist[k], d); atomicAdd(&hist[160 + k], 1);
-                }
-                if (j.eo23)
-                {
-                    if (lx >= x0[3] && lx < x1[3] && y >= y0[3] && y < y1[3])
-                    {
-                        const int k = 96 + eoCat[sgn3(c - (int)r[stride + 1]) + sgn3(c - (int)r[-stride - 1]) + 2];
-                        atomicAdd(&hist[k], d); atomicAdd(&hist[160 + k], 1);
-                    }
-                    if (lx >= x0[4] && lx < x1[4] && y >= y0[4] && y < y1[4])
-                    {
-                        const int k = 128 + eoCat[sgn3(c - (int)r[stride - 1]) + sgn3(c - (int)r[-stride + 1]) + 2];
-                        atomicAdd(&hist[k], d); atomicAdd(&hist[160 + k], 1);
-                    }
+                    const int sum = (int)(v & 0xffffffffll);
+                    const int cnt = (int)((v - sum) >> 32);
+                    atomicAdd(&hist[(c + 1) * 32 + k], sum);
+                    atomicAdd(&hist[160 + (c + 1) * 32 + k], cnt);
                 }
             }
+        __syncthreads();
+        if (tid < 32)
+        {
+            hist[tid] = hist[320 + tid] + hist[320 + 64 + tid] + hist[320 + 128 + tid] + hist[320 + 192 + tid];
+            hist[160 + tid] = hist[576 + tid] + hist[576 + 64 + tid] + hist[576 + 128 + tid] + hist[576 + 192 + tid];
+        }
         __syncthreads();
         if (tid < 64)
         {

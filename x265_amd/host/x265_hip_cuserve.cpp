@@ -1117,10 +1117,11 @@ uint32_t Quant::transformNxN(const CUData& cu, const pixel* fenc, uint32_t fencS
             {
                 // RDOQ: the device has transformed (residual -> m_resiDctCoeff, and for psy-rdoq source -> m_fencDctCoeff: quant.cpp:432, :436-442); the
                 // quantiser is the reference's own, called as Quant::transformNxN calls it (:454-455)
-                if (!wait_word(j, &j.units[u].ready, ttype == TEXT_LUMA ? 0 : 1))
+                const bool usePsy = m_psyRdoqScale && ttype == TEXT_LUMA;
+                // (the source block's transform is a work item of its own on the device and releases `readyInv`)
+                if (!wait_word(j, &j.units[u].ready, ttype == TEXT_LUMA ? 0 : 1) || (usePsy && !wait_word(j, &j.units[u].readyInv, 0)))
                     goto host;
                 const int n2 = 1 << (2 * log2TrSize);
-                const bool usePsy = m_psyRdoqScale && ttype == TEXT_LUMA;
                 memcpy(m_resiDctCoeff, j.levels + eo, sizeof(int16_t) * n2);
                 if (usePsy)
                     memcpy(m_fencDctCoeff, j.resiOut + eo, sizeof(int16_t) * n2);
