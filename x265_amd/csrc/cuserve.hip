@@ -538,6 +538,17 @@ __device__ __forceinline__ void run_tiles(SlotOut* s, JobLds& L, uint32_t seq, u
 // releases units[plane].ready behind them.
 static_assert(sizeof(x265hip_saojob) <= 128, "SAO job header");
 __device__ __forceinline__ int sgn3(int v) { return (v > 0) - (v < 0); }
+// the wave's total of v, valid in lane 63: six DPP adds (quad swaps, half-row and row mirrors, then the row broadcasts of gfx9), no LDS
+__device__ __forceinline__ int wave_total_lane63(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);       // quad_perm [1, 0, 3, 2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);       // quad_perm [2, 3, 0, 1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);      // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);      // row_mirror: every lane of a row holds the row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
 __device__ __forceinline__ void run_sao(SlotOut* s, JobLds& L, uint32_t seq, uint64_t t0)
 {
     const x265hip_saojob& j = *reinterpret_cast<const x265hip_saojob*>(&L.job);
@@ -559,9 +570,10 @@ __device__ __forceinline__ void run_sao(SlotOut* s, JobLds& L, uint32_t seq, uin
         int x0[5], y0[5], x1[5], y1[5];
 #pragma unroll
         for (int c = 0; c < 5; c++) { x0[c] = j.plane[p].x0[c]; y0[c] = j.plane[p].y0[c]; x1[c] = j.plane[p].x1[c]; y1[c] = j.plane[p].y1[c]; }
-        // edge classes: five categories each — per lane in registers, count in the high and the (signed) sum in the low word of one 64-bit accumulator;
+        // edge classes: five categories each — per lane in registers, count in the high and the (signed) sum in the low half of one 32-bit accumulator;
         // the band class has 32 bins: the wave's private LDS histogram
-        long long acc[4][5];
+        // (per lane at most 16 samples: the count fits the high half-word, the sum of differences, |d| <= 255, the low one)
+        int acc[4][5];
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
@@ -574,7 +586,7 @@ __device__ __forceinline__ void run_sao(SlotOut* s, JobLds& L, uint32_t seq, uin
             {
                 const unsigned char* r = rec0 + y * stride + lx;
                 const int c = r[0], d = (int)fenc0[y * w + lx] - c;
-                const long long one = (1ll << 32) + d;
+                const int one = (1 << 16) + d;
                 if (lx < x1[0] && y < y1[0]) { atomicAdd(&bandSum[c >> 3], d); atomicAdd(&bandCnt[c >> 3], 1); }
                 // s_eoTable (sao.cpp:65) folds sign + sign + 2 = 0..4 into the categories 1, 2, 0, 3, 4
 #define XH_EO(cls, na, nb) do { const int e = sgn3(c - (int)(na)) + sgn3(c - (int)(nb)) + 2; const int k = e == 0 ? 1 : e == 1 ? 2 : e == 2 ? 0 : e; \
@@ -588,17 +600,16 @@ __device__ __forceinline__ void run_sao(SlotOut* s, JobLds& L, uint32_t seq, uin
                 }
 #undef XH_EO
             }
-        // the waves' edge accumulators: reduced across the wave, lane 0 adds the wave's 20 pairs to the plane's table
+        // the waves' edge accumulators: unpacked, totalled across the wave without LDS, lane 63 adds the wave's 20 pairs to the plane's table
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
             for (int k = 0; k < 5; k++)
             {
-                const long long v = (long long)group_sum64((unsigned long long)acc[c][k], kWave);
-                if (lx == 0 && v)
+                const int sumL = (int)(short)(acc[c][k] & 0xffff), cntL = (acc[c][k] - sumL) >> 16;
+                const int sum = wave_total_lane63(sumL), cnt = wave_total_lane63(cntL);
+                if (lx == 63 && cnt)
                 {
-                    const int sum = (int)(v & 0xffffffffll);
-                    const int cnt = (int)((v - sum) >> 32);
                     atomicAdd(&hist[(c + 1) * 32 + k], sum);
                     atomicAdd(&hist[160 + (c + 1) * 32 + k], cnt);
                 }
@@ -639,8 +650,15 @@ __device__ __forceinline__ void run_job(const SlotIn* sin, SlotOut* s, JobLds& L
     const int chunks = (128 + (int)ticket_bytes(ticket)) >> 4;
     const uint4* in = reinterpret_cast<const uint4*>(&sin->job);
     uint4* out = reinterpret_cast<uint4*>(&L.job);
-    for (int i = tid; i < chunks; i += 256)
-        out[i] = in[i];
+    // (four loads in flight per thread before the first store: an SAO job is 800 chunks, a 64x64 CU job 1 544 — one HBM latency per round of 1 024)
+    for (int base = tid; base < chunks; base += 1024)
+    {
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (base + 256 * k < chunks) v[k] = in[base + 256 * k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (base + 256 * k < chunks) out[base + 256 * k] = v[k];
+    }
     __syncthreads();
     if ((ticket & 3) == 3) run_sao(s, L, ticket, t0);
     else if (ticket & 8) run_tiles<uint16_t>(s, L, ticket, t0);
