@@ -603,6 +603,9 @@ typedef struct x265hip_la_config
     int32_t numSlots;                /* frames resident at once (lookahead depth + bframes + the reference's slack) */
 } x265hip_la_config;
 x265hip_la* x265hip_la_create(const x265hip_la_config* cfg);          /* NULL on failure: x265hip_last_error() */
+/* the same session on the device of place `place` (x265hip_places): the sessions of one process take the places in turn (round 5; every call of the
+ * session switches the calling thread to the session's device, so it may be used from any thread) */
+x265hip_la* x265hip_la_create_at(int place, const x265hip_la_config* cfg);
 void x265hip_la_destroy(x265hip_la* la);
 /* Lowres::init + lowresIntraEstimate + calcAdaptiveQuantFrame results of a frame entering the lookahead: `buffers` = the four padded
  * planes, contiguous (Lowres::buffer[0], 4 * planeElems pixels); intraCost [ncu]; invQscale [ncu] (invQscaleFactor, or

@@ -80,6 +80,13 @@ int x265hip_device_count(void) { return 1; }
 int x265hip_init(int device) { (void)device; return 0; }
 const char* x265hip_last_error(void) { return g_err; }
 
+static int g_nPlaces;
+x265hip_la* x265hip_la_create(const x265hip_la_config* cfg);
+x265hip_la* x265hip_la_create_at(int place, const x265hip_la_config* cfg)
+{
+    if (place < 0 || place >= g_nPlaces) { snprintf(g_err, sizeof(g_err), "emul: no place %d", place); return NULL; }
+    return x265hip_la_create(cfg);
+}
 x265hip_la* x265hip_la_create(const x265hip_la_config* cfg)
 {
     if (fail_now("la_create")) return NULL;
@@ -346,7 +353,6 @@ struct x265hip_refpic
 };
 /* places (x265hip_places): the emulation has no devices; it keeps the bookkeeping of the exchange — which replicas exist, how many bands and bytes
  * the device implementation would have pushed from GPU to GPU — so that the binding's placement logic can be tested on the CPU tier */
-static int g_nPlaces;
 static uint64_t g_peerReplicas, g_peerBands, g_peerBytes;
 int x265hip_places(int n, const int* devices)
 {
@@ -640,7 +646,7 @@ x265hip_sadsurf* x265hip_sadsurf_attach_levels(x265hip_srcpic* src, x265hip_refp
     {
         const char* lim = getenv("X265HIP_EMUL_SUBPEL_MAX_PIXELS");
         const long maxPix = lim ? atol(lim) : 416L * 240L;
-        if (src->place != ref->place || (long)src->w * src->h > maxPix) levels &= ~16;
+        if ((long)src->w * src->h > maxPix) levels &= ~16;          /* (a surface built from a replica has sub-pel tables too: the replica computes its own planes) */
     }
     x265hip_sadsurf* ss = (x265hip_sadsurf*)calloc(1, sizeof(*ss));
     ss->src = src; ss->ref = ref; ss->S = searchRange; ss->lambda20 = lambda20; ss->levels = levels;

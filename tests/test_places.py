@@ -57,6 +57,16 @@ def test_bound_encoder_with_places_is_byte_identical_on_the_emulation(tmp_path, 
     assert places == len(devices.split(",")) and replicas > 0 and bands >= replicas and mb > 0
     served = [l for l in err.splitlines() if "x265hip: sadplanes:" in l]
     assert served and int(served[0].split()[2]) > 1000, err[-600:]
+    # with several places no less is served than with one: a surface built from a replica has sub-pel SATD tables too (the replica computes its own
+    # planes) — in round 4 half (two places) or two thirds (three) of the frames lost them
+    one, err1 = _encode(emul, yuv, w, h, frames, str(tmp_path / "emul1.hevc"), {})
+    assert one == want
+
+    def subpel(e):
+        m = re.search(r"sadplanes: (\d+) sub-pel SATDs of the motion search", e)
+        assert m, e[-600:]
+        return int(m.group(1))
+    assert subpel(err1) > 500 and subpel(err) >= 0.9 * subpel(err1), (subpel(err), subpel(err1))
 
 
 @pytest.mark.gpu
@@ -85,12 +95,14 @@ def test_surface_built_from_a_replica_matches_restatement():
             assert sp, lib.x265hip_last_error()
             assert lib.x265hip_srcpic_upload(sp, s.ctypes.data, s.shape[1]) == 0
             sps.append(sp)
-        sss.append(lib.x265hip_sadsurf_attach(sps[0], rp, S, lam))
-        sss.append(lib.x265hip_sadsurf_attach(sps[1], rp, S, lam))
+        # levels 14 | 16: 16 / 32 / 64 blocks and their sub-pel SATD tables — at the other place they come from the replica's own planes (round 5)
+        lib.x265hip_sadsurf_attach_levels.restype, lib.x265hip_sadsurf_attach_levels.argtypes = hp.PROTOTYPES["x265hip_sadsurf_attach_levels"]
+        sss.append(lib.x265hip_sadsurf_attach_levels(sps[0], rp, S, lam, 30))
+        sss.append(lib.x265hip_sadsurf_attach_levels(sps[1], rp, S, lam, 30))
         for i, r in enumerate(bands):
             assert lib.x265hip_refpic_rows_final(rp, r) == 0
             if i == 1:
-                sss.append(lib.x265hip_sadsurf_attach(sps[2], rp, S, lam))
+                sss.append(lib.x265hip_sadsurf_attach_levels(sps[2], rp, S, lam, 30))
         assert all(sss), lib.x265hip_last_error()
         assert lib.x265hip_refpic_wait(rp) == 0, lib.x265hip_last_error()
         views = [ts._read_view(hp, lib, ss, w, h) for ss in sss]
@@ -111,6 +123,8 @@ def test_surface_built_from_a_replica_matches_restatement():
         for l in (1, 2, 3):
             assert np.array_equal(got[k][l][0], want[k][l][0]), ("origins", k, l)
             assert np.array_equal(got[k][l][1], want[k][l][1]), ("tables", k, l)
+            assert got[k][l][2] is not None and want[k][l][2] is not None, ("no sub-pel tables", k, l)
+            assert np.array_equal(got[k][l][2], want[k][l][2]), ("sub-pel tables", k, l)
     # one replica (for source 1), fed band by band: every uploaded row of the padded picture exactly once
     assert st1[0].value - st0[0].value == 1
     assert st1[1].value - st0[1].value >= 1          # rows wait for company (X265HIP_SADSURF_BATCH): bands may be pushed together

@@ -61,6 +61,7 @@ struct x265hip_la
 
 namespace xh {
 
+int place_device(int place);                     // runtime.hip
 static constexpr int kMvcostHalf = 2 * 32768;    // x265's own row: 2 * BC_MAX_MV quarter-pels each side (bitcost.h:45)
 
 static int la_enter(x265hip_la* la)
@@ -154,6 +155,18 @@ x265hip_la* x265hip_la_create(const x265hip_la_config* cfg)
         x265hip_la_destroy(la);
         return nullptr;
     }
+    return la;
+}
+
+x265hip_la* x265hip_la_create_at(int place, const x265hip_la_config* cfg)
+{
+    const int dev = place >= 0 ? xh::place_device(place) : -1;
+    if (dev < 0) { set_error(X265HIP_EINVAL, "x265hip_la_create_at: no place %d (x265hip_places)", place); return nullptr; }
+    int cur = 0;
+    const bool had = hipGetDevice(&cur) == hipSuccess;
+    if (hipSetDevice(dev) != hipSuccess) { set_error(X265HIP_EHIP, "x265hip_la_create_at: hipSetDevice(%d)", dev); return nullptr; }
+    x265hip_la* la = x265hip_la_create(cfg);
+    if (had) (void)hipSetDevice(cur);
     return la;
 }
 

@@ -14,7 +14,11 @@ struct x265hip_sadsurf;
 namespace xh {
 // A copy of a mirrored picture on another place (another GPU of the encoder): rows are pushed device to device (hipMemcpyPeerAsync, xGMI between
 // the GPUs of a node) as the owner uploads them; the SAD surfaces of source pictures that live on that place are built from it, on its device.
-struct Replica { int place = 0, device = 0; char* dPic = nullptr; hipStream_t st = nullptr; int copied = 0; };
+// Round 5: a replica has sub-pel planes of its own, COMPUTED from the rows it has received (15 planes are not worth the fabric when the filters that make
+// them run at HBM speed next to the copy): the sub-pel SATD tables of surfaces built from a replica come from them, so a frame whose source picture lives
+// at another place than its reference is served like any other (round 4: integer-pel only).
+struct Replica { int place = 0, device = 0; char* dPic = nullptr; char* dPlanes = nullptr; hipStream_t st = nullptr; int copied = 0, phaseDone = 4; };
+int build_subpel_rows(int depth, const void* refOrigin, int64_t stride, int x0, int x1, int y0, int y1, void* planesOrigin, int64_t planeElems, hipStream_t st);   // refpic.hip
 int place_device(int place);                 // runtime.hip: the HIP device of a place (x265hip_places), -1 if there is no such place
 int place_of_device(int device);             // the anonymous place of objects created without one: -(device + 1)
 }

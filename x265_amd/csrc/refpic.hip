@@ -234,6 +234,7 @@ void x265hip_refpic_destroy(x265hip_refpic* rp)
         (void)hipSetDevice(r->device);
         if (r->st) { (void)hipStreamSynchronize(r->st); (void)hipStreamDestroy(r->st); }
         if (r->dPic) (void)device_free(r->dPic);
+        if (r->dPlanes) (void)device_free(r->dPlanes);
         delete r;
     }
     rp->replicas.clear();

@@ -750,6 +750,7 @@ static Replica* replica_at(x265hip_refpic* rp, int place)
     Replica* r = new Replica;
     r->place = place; r->device = dev;
     const size_t bytes = (size_t)rp->planeElems * rp->B;
+    // (the planes: 16 x the picture, plane 0 unused, as in the mirror itself; without them the replica serves integer-pel surfaces only)
     if (hipStreamCreateWithFlags(&r->st, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&r->dPic, bytes) != hipSuccess)
     {
         if (r->st) (void)hipStreamDestroy(r->st);
@@ -764,6 +765,7 @@ static Replica* replica_at(x265hip_refpic* rp, int place)
         if (hipDeviceCanAccessPeer(&can, dev, rp->device) == hipSuccess && can && hipDeviceEnablePeerAccess(rp->device, 0) != hipSuccess)
             (void)hipGetLastError();                       // already enabled
     }
+    if (hipMalloc((void**)&r->dPlanes, 16 * bytes) != hipSuccess) { (void)hipGetLastError(); r->dPlanes = nullptr; }
     (void)hipSetDevice(rp->device);
     rp->replicas.push_back(r);
     g_statReplicas++;
@@ -899,6 +901,28 @@ static void progress_multi(const std::vector<x265hip_refpic*>& rps)
                 g_statPeerBands++;
                 g_statPeerBytes += bytes;
                 it.rep->copied = it.rp->uploaded;
+                // the replica's own sub-pel planes of the rows whose support (y - 3 .. y + 4) has arrived — the same filter launch as the mirror's band
+                // (refpic.hip process()), on the replica's device and stream; waited for below with the stream the surfaces are built on
+                const int phaseEnd = it.rep->copied - 4;
+                if (it.rep->dPlanes && phaseEnd > it.rep->phaseDone)
+                {
+                    x265hip_refpic* rp = it.rp;
+                    const char* org = it.rep->dPic + ((size_t)rp->marginY * rp->stride + rp->marginX) * rp->B;
+                    char* porg = it.rep->dPlanes + ((size_t)rp->marginY * rp->stride + rp->marginX) * rp->B;
+                    DevSpan spanP(X265HIP_CLK_PLANES, it.rep->st);
+                    if (build_subpel_rows(rp->depth, org, rp->stride, -rp->marginX + 4, rp->picW + rp->marginX - 4, it.rep->phaseDone - rp->marginY, phaseEnd - rp->marginY, porg,
+                                          rp->planeElems, it.rep->st) || hipStreamSynchronize(it.rep->st) != hipSuccess)
+                    {
+                        set_error(X265HIP_EHIP, "sadsurf: sub-pel planes of a replica failed");
+                        fail_refs(items, g0, g1);
+                        (void)hipSetDevice(rp0->device);
+                        return;
+                    }
+                    spanP.end();
+                    spanP.bytes = (uint64_t)(phaseEnd - it.rep->phaseDone) * (uint64_t)(rp->picW + 2 * rp->marginX - 8) * 16 * rp->B;
+                    spanP.commit();
+                    it.rep->phaseDone = phaseEnd;
+                }
             }
             const SurfLayout& lay = first.ss->lay;            // same picture size and levels: same layout
             a.picW = rp0->picW; a.picH = rp0->picH; a.marginX = rp0->marginX; a.marginY = rp0->marginY; a.bufRows = rp0->bufRows;
@@ -928,17 +952,18 @@ static void progress_multi(const std::vector<x265hip_refpic*>& rps)
             bool bad = hipGetLastError() != hipSuccess;
             span.end();
             DevSpan span2(X265HIP_CLK_SUBPEL, st);
-            // the sub-pel SATD tables of the rows just built (same stream: the origins are there); surfaces at their mirror's own place only
+            // the sub-pel SATD tables of the rows just built (same stream: the origins are there)
             for (int k = 0; k < a.nJobs && !bad; k++)
             {
                 const SurfItem& it = items[in[k]];
-                if (!(it.ss->levels & 16) || it.rep)
+                if (!(it.ss->levels & 16) || (it.rep && !it.rep->dPlanes))
                     continue;
                 x265hip_refpic* rp = it.rp;
                 SubpelArgs sa;
                 memset(&sa, 0, sizeof(sa));
-                sa.pic = rp->dPic + ((size_t)rp->marginY * rp->stride + rp->marginX) * rp->B;
-                sa.planes = rp->dPlanes + ((size_t)rp->marginY * rp->stride + rp->marginX) * rp->B;
+                // (a surface at another place than its reference's mirror: the replica's rows and the replica's own planes)
+                sa.pic = (it.rep ? it.rep->dPic : rp->dPic) + ((size_t)rp->marginY * rp->stride + rp->marginX) * rp->B;
+                sa.planes = (it.rep ? it.rep->dPlanes : rp->dPlanes) + ((size_t)rp->marginY * rp->stride + rp->marginX) * rp->B;
                 sa.stride = rp->stride; sa.planeElems = rp->planeElems;
                 sa.src = a.job[k].src; sa.srcPitch = a.job[k].srcPitch;
                 sa.out = a.job[k].out; sa.pitch = lay.pitch;
@@ -1221,8 +1246,6 @@ x265hip_sadsurf* x265hip_sadsurf_attach_levels(x265hip_srcpic* src, x265hip_refp
         set_error(X265HIP_EINVAL, "x265hip_sadsurf_attach: pictures do not match, or range %d (8..32 for 8-bit pictures, 8..16 for 16-bit ones) / lambda %d / margins out of bounds", searchRange, lambda20);
         return nullptr;
     }
-    if (src->place != ref->place)
-        levels &= ~16;                            // the sub-pel planes live with the mirror: a surface built from a replica elsewhere has no sub-pel tables
     x265hip_sadsurf* ss = new x265hip_sadsurf;
     ss->src = src; ss->ref = ref; ss->S = searchRange; ss->lambda20 = lambda20; ss->levels = levels;
     layout_for(src->w, src->h, src->depth, levels, ss->lay);

@@ -157,6 +157,7 @@ PROTOTYPES = {
     "x265hip_build_integral_planes": (i32, [i32, vp, i64, i32, vp, i64, vp, vp]),
     "x265hip_motion_estimate_sea_batch": (i32, [i32, i32, i32, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, vp, i32, i32, vp, i32, i32, vp, vp, vp]),
     "x265hip_la_create": (vp, [vp]),
+    "x265hip_la_create_at": (vp, [i32, vp]),
     "x265hip_la_destroy": (None, [vp]),
     "x265hip_la_set_frame": (i32, [vp, i32, vp, vp, vp]),
     "x265hip_la_put_vectors": (i32, [vp, i32, i32, i32, vp, vp]),

@@ -67,6 +67,7 @@ struct Session
     uint64_t waitNs = 0;          // wall time the lookahead thread spent inside compute() (descriptor build + device pass + write-back)
     uint64_t lastUse = 0;
     std::mutex m;                 // held across a compute(): the encoders of an ABR ladder have a session each and do not wait for one another
+    int place = 0;
 };
 
 std::mutex g_lock;               // the session table (who owns which entry, eviction) and the totals below; order: g_lock, then a session's m
@@ -189,7 +190,22 @@ Session& session_for(const Lookahead& l, const Lowres* f)
     c.maxDist = l.m_param->bframes + 2;
     c.numSlots = l.m_param->lookaheadDepth + l.m_param->bframes + 10;
     x265hip_debug_mark("create: lookahead session");
-    s.la = x265hip_la_create(&c);
+    // several places (X265HIP_DEVICES): the sessions of the process take them in turn, the LAST place first — a lone encoder's lookahead then does not
+    // sit on place 0 beside the first mirror, the first source picture and the first job server
+    static int nextPlace = -1;                           // under g_lock (compute() holds it while it asks for the session)
+    const int places = x265hip_places_configured();
+    if (places > 1)
+    {
+        if (nextPlace < 0) nextPlace = places - 1;
+        s.la = x265hip_la_create_at(nextPlace, &c);
+        s.place = nextPlace;
+        nextPlace = (nextPlace + places - 1) % places;
+    }
+    else
+    {
+        s.la = x265hip_la_create(&c);
+        s.place = 0;
+    }
     x265hip_debug_mark("created: lookahead session");
     if (!s.la)
         die("session");
