@@ -121,6 +121,7 @@ int main(int argc, char** argv)
     for (int T : { 1, 4, 16 })
     {
         std::vector<std::vector<double>> luma(T), whole(T), dev0(T), dev2(T);
+        std::vector<double> sst[2][5];
         std::atomic<int> go(0);
         auto body = [&](int t)
         {
@@ -129,7 +130,7 @@ int main(int argc, char** argv)
             x265hip_cuserve_slot(cs, t, &job, &pixels, &units, &levels, &resi);
             x265hip_saojob sj;
             memset(&sj, 0, sizeof(sj));
-            sj.bitDepth = 8; sj.planes = 3; sj.eo23 = 1;
+            sj.bitDepth = 8; sj.planes = 3; sj.eo23 = 1; sj.reserved = stamps;
             for (int p = 0; p < 3; p++)
             {
                 const int n = p ? 32 : 64, po = p ? 2 : 0;
@@ -158,6 +159,10 @@ int main(int argc, char** argv)
                 }
                 const double tw = now_us() - t0;
                 if (i >= 100) { luma[t].push_back(tl); whole[t].push_back(tw); dev0[t].push_back(units[0].fwdTicks * 0.01); dev2[t].push_back(units[2].fwdTicks * 0.01); }
+                if (i >= 100 && stamps && t == 0)
+                    for (int p = 0; p < 3; p += 2)
+                        for (int k = 0; k < 5; k++)
+                            sst[p / 2][k].push_back(((units[p].reserved[k >> 1] >> (16 * (k & 1))) & 0xffff) * 0.01);
             }
         };
         std::vector<std::thread> th;
@@ -169,6 +174,14 @@ int main(int argc, char** argv)
         auto med = [](std::vector<std::vector<double>>& v) { std::vector<double> a; for (auto& x : v) a.insert(a.end(), x.begin(), x.end()); std::sort(a.begin(), a.end()); return a.empty() ? 0.0 : a[a.size() / 2]; };
         printf("%s, SAO statistics of a 64x64 CTU (4:2:0, 8 bit, 5 classes x 3 planes), %2d thread%s: luma ready median %6.1f us (%4.1f us of it on the device), all planes %6.1f us (%4.1f on the device); "
                "%.0f jobs/s in total\n", mode ? "one launch per job" : "resident server   ", T, T > 1 ? "s" : " ", med(luma), med(dev0), med(whole), med(dev2), (double)T * (iters + 100) / (wall * 1e-6));
+        if (stamps)
+            for (int w = 0; w < 2; w++)
+            {
+                double m[5];
+                for (int k = 0; k < 5; k++) { std::sort(sst[w][k].begin(), sst[w][k].end()); m[k] = sst[w][k].empty() ? 0 : sst[w][k][sst[w][k].size() / 2]; }
+                printf("      %s plane, us since the doorbell was seen (medians): plane starts %.2f, histograms cleared %.2f, samples classified %.2f, edge classes totalled %.2f, published %.2f\n",
+                       w ? "Cr  " : "luma", m[0], m[1], m[2], m[3], m[4]);
+            }
         fflush(stdout);
     }
     uint64_t jobs = 0, starts = 0, ns = 0;

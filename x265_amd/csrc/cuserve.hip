@@ -565,8 +565,12 @@ __device__ __forceinline__ void run_sao(SlotOut* s, JobLds& L, uint32_t seq, uin
         const unsigned char* rec0 = at + stride + 1;
         const unsigned char* fenc0 = at + (w + 1) * (h + 1);
         at = fenc0 + w * h;
+        uint32_t stamp[5] = { 0, 0, 0, 0, 0 };                         // job.reserved != 0 (tools/micro/cuserve_rt): 100 MHz ticks since the doorbell at five points
+#define XH_SSTAMP(i) do { if (j.reserved) stamp[i] = (uint32_t)(wall_clock64() - t0) & 0xffffu; } while (0)
+        XH_SSTAMP(0);
         for (int i = tid; i < 832; i += 256) hist[i] = 0;
         __syncthreads();
+        XH_SSTAMP(1);
         int x0[5], y0[5], x1[5], y1[5];
 #pragma unroll
         for (int c = 0; c < 5; c++) { x0[c] = j.plane[p].x0[c]; y0[c] = j.plane[p].y0[c]; x1[c] = j.plane[p].x1[c]; y1[c] = j.plane[p].y1[c]; }
@@ -619,6 +623,7 @@ __device__ __forceinline__ void run_sao(SlotOut* s, JobLds& L, uint32_t seq, uin
                 todo &= ~m;
             }
         }
+        XH_SSTAMP(2);
         // the waves' edge accumulators: unpacked, totalled across the wave without LDS, lane 63 adds the wave's 20 pairs to the plane's table
 #pragma unroll
         for (int c = 0; c < 4; c++)
@@ -633,6 +638,7 @@ __device__ __forceinline__ void run_sao(SlotOut* s, JobLds& L, uint32_t seq, uin
                     atomicAdd(&hist[160 + (c + 1) * 32 + k], cnt);
                 }
             }
+        XH_SSTAMP(3);
         __syncthreads();
         if (tid < 32)
         {
@@ -652,12 +658,15 @@ __device__ __forceinline__ void run_sao(SlotOut* s, JobLds& L, uint32_t seq, uin
             __builtin_amdgcn_wave_barrier();
             if (tid == 0)
             {
+                XH_SSTAMP(4);
+                if (j.reserved) { s->units[p].reserved[0] = stamp[0] | (stamp[1] << 16); s->units[p].reserved[1] = stamp[2] | (stamp[3] << 16); s->units[p].reserved[2] = stamp[4]; }
                 s->units[p].fwdTicks = (uint32_t)(wall_clock64() - t0);
                 __hip_atomic_store(&s->units[p].readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(&s->units[p].ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         __syncthreads();
+#undef XH_SSTAMP
     }
 }
 
