@@ -291,8 +291,10 @@ int x265hip_refpic_reset(x265hip_refpic* rp)
     rp->rowsReady.store(-(1 << 30), std::memory_order_release);
     sadsurf_detach_all(rp);
     for (Replica* r : rp->replicas)
+    {
         r->copied = 0;                                                // the replicas stay (same picture size), their rows are the old picture's
         r->phaseDone = 4;                                             // ... and so are their sub-pel planes
+    }
     rp->uploaded = 0;
     rp->phaseDone = 4;
     return e;
