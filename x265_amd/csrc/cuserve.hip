@@ -113,6 +113,7 @@ struct JobLds
     uint32_t pad[(128 - sizeof(x265hip_cujob)) / 4];
     alignas(16) unsigned char pix[X265HIP_CUJOB_PIXEL_BYTES];
     alignas(16) TileLds tile[4];
+    int saoExtra[3520];                          // directly behind tile[]: an SAO statistics job lays its histograms over both (run_sao: 9 664 ints)
     alignas(16) BOperand bop[3][2][64];          // [log2n - 3][forward, inverse][lane]: built once per kernel
     uint32_t seq;
 };
@@ -538,6 +539,15 @@ __device__ __forceinline__ void run_tiles(SlotOut* s, JobLds& L, uint32_t seq, u
 // releases units[plane].ready behind them.
 static_assert(sizeof(x265hip_saojob) <= 128, "SAO job header");
 __device__ __forceinline__ int sgn3(int v) { return (v > 0) - (v < 0); }
+// the total of v over each row of 16 lanes, valid in lane 15 of the row: four DPP adds
+__device__ __forceinline__ int row_total_lane15(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    return v;
+}
 // the wave's total of v, valid in lane 63: six DPP adds (quad swaps, half-row and row mirrors, then the row broadcasts of gfx9), no LDS
 __device__ __forceinline__ int wave_total_lane63(int v)
 {
@@ -552,8 +562,9 @@ __device__ __forceinline__ int wave_total_lane63(int v)
 __device__ __forceinline__ void run_sao(SlotOut* s, JobLds& L, uint32_t seq, uint64_t t0)
 {
     const x265hip_saojob& j = *reinterpret_cast<const x265hip_saojob*>(&L.job);
-    // LDS: [0..159] sums of class c bin b at c * 32 + b, [160..319] counts — what goes out; [320..575] / [576..831] the waves' private band histograms
-    // (sums / counts, 64 entries per wave: 32 used)
+    // LDS (over tile[] and saoExtra[]): [0..159] sums of class c bin b at c * 32 + b, [160..319] counts — what goes out; [832..1471] the edge classes' row
+    // totals; [1472..9663] the band class: a column of 32 bins per LANE (wave w, band b, lane l at 1472 + (w * 32 + b) * 64 + l), count in the high and sum in
+    // the low half of a word — every lane adds into its own column, so no two lanes ever meet on an address
     int* hist = reinterpret_cast<int*>(&L.tile[0]);
     int32_t* out = reinterpret_cast<int32_t*>(s->levels);
     const int tid = threadIdx.x, lx = tid & 63, ly = tid >> 6;
@@ -568,7 +579,8 @@ __device__ __forceinline__ void run_sao(SlotOut* s, JobLds& L, uint32_t seq, uin
         uint32_t stamp[5] = { 0, 0, 0, 0, 0 };                         // job.reserved != 0 (tools/micro/cuserve_rt): 100 MHz ticks since the doorbell at five points
 #define XH_SSTAMP(i) do { if (j.reserved) stamp[i] = (uint32_t)(wall_clock64() - t0) & 0xffffu; } while (0)
         XH_SSTAMP(0);
-        for (int i = tid; i < 832; i += 256) hist[i] = 0;
+        for (int i = tid; i < 320; i += 256) hist[i] = 0;                   // (the 640 row totals behind them are all written before they are read)
+        for (int i = tid; i < 8192; i += 256) hist[1472 + i] = 0;
         __syncthreads();
         XH_SSTAMP(1);
         int x0[5], y0[5], x1[5], y1[5];
@@ -582,68 +594,85 @@ __device__ __forceinline__ void run_sao(SlotOut* s, JobLds& L, uint32_t seq, uin
         for (int c = 0; c < 4; c++)
 #pragma unroll
             for (int k = 0; k < 5; k++) acc[c][k] = 0;
-        int* bandSum = hist + 320 + ly * 64;
-        int* bandCnt = hist + 576 + ly * 64;
+        int* bandCol = hist + 1472 + ly * 32 * 64 + lx;
         const bool eo23 = j.eo23 != 0;
         for (int y = ly; y < h; y += 4)
         {
             bool bo = false;
             int band = -1, dBo = 0;
-            if (lx < w)
             {
-                const unsigned char* r = rec0 + y * stride + lx;
-                const int c = r[0], d = (int)fenc0[y * w + lx] - c;
+                // branch-free: a lane outside the plane (or a sample outside a class's rectangle) adds zero; its loads stay inside the job's LDS block
+                const bool in = lx < w;
+                const unsigned char* r = rec0 + y * stride + (in ? lx : 0);
+                const int c = r[0], d = (int)fenc0[y * w + (in ? lx : 0)] - c;
                 const int one = (1 << 16) + d;
-                bo = lx < x1[0] && y < y1[0];
+                bo = in && lx < x1[0] && y < y1[0];
                 band = bo ? c >> 3 : -1;
                 dBo = d;
+                const int sR = sgn3(c - (int)r[1]), sL = sgn3(c - (int)r[-1]), sD = sgn3(c - (int)r[stride]), sU = sgn3(c - (int)r[-stride]);
+                const int sDR = sgn3(c - (int)r[stride + 1]), sUL = sgn3(c - (int)r[-stride - 1]), sDL = sgn3(c - (int)r[stride - 1]), sUR = sgn3(c - (int)r[-stride + 1]);
                 // s_eoTable (sao.cpp:65) folds sign + sign + 2 = 0..4 into the categories 1, 2, 0, 3, 4
-#define XH_EO(cls, na, nb) do { const int e = sgn3(c - (int)(na)) + sgn3(c - (int)(nb)) + 2; const int k = e == 0 ? 1 : e == 1 ? 2 : e == 2 ? 0 : e; \
-                                _Pragma("unroll") for (int q = 0; q < 5; q++) acc[cls][q] += k == q ? one : 0; } while (0)
-                if (lx >= x0[1] && lx < x1[1] && y < y1[1]) XH_EO(0, r[1], r[-1]);
-                if (lx < x1[2] && y >= y0[2] && y < y1[2]) XH_EO(1, r[stride], r[-stride]);
-                if (eo23)
-                {
-                    if (lx >= x0[3] && lx < x1[3] && y >= y0[3] && y < y1[3]) XH_EO(2, r[stride + 1], r[-stride - 1]);
-                    if (lx >= x0[4] && lx < x1[4] && y >= y0[4] && y < y1[4]) XH_EO(3, r[stride - 1], r[-stride + 1]);
-                }
+#define XH_EO(cls, e2, cond) do { const int e = (e2) + 2; const int k = e == 0 ? 1 : e == 1 ? 2 : e == 2 ? 0 : e; const int v = (cond) ? one : 0; \
+                                  _Pragma("unroll") for (int q = 0; q < 5; q++) acc[cls][q] += k == q ? v : 0; } while (0)
+                XH_EO(0, sR + sL, in && lx >= x0[1] && lx < x1[1] && y < y1[1]);
+                XH_EO(1, sD + sU, in && lx < x1[2] && y >= y0[2] && y < y1[2]);
+                XH_EO(2, sDR + sUL, in && eo23 && lx >= x0[3] && lx < x1[3] && y >= y0[3] && y < y1[3]);
+                XH_EO(3, sDL + sUR, in && eo23 && lx >= x0[4] && lx < x1[4] && y >= y0[4] && y < y1[4]);
 #undef XH_EO
             }
-            // the band class: neighbours in a row mostly share a band — 64 LDS atomics on one address cost what 64 serial ones do (measured: 0.45 us per
-            // row of a wave).  Instead the wave walks the DISTINCT bands of its row: ballot of the lanes in the band, their differences totalled by DPP,
-            // lane 63 adds the pair to the wave's private histogram (its only writer)
-            unsigned long long todo = __ballot(bo);
-            while (todo)
-            {
-                const int lead = __builtin_ctzll(todo);
-                const int b = __builtin_amdgcn_readlane(band, lead);
-                const unsigned long long m = __ballot(band == b);
-                const int dsum = wave_total_lane63(band == b ? dBo : 0);
-                if (lx == 63) { bandSum[b] += dsum; bandCnt[b] += __builtin_popcountll(m); }
-                todo &= ~m;
-            }
+            // the band class: into this lane's own column (neighbours in a row mostly share a band: 64 atomics on one address cost what 64 serial ones do)
+            if (bo) bandCol[band * 64] += (1 << 16) + dBo;
         }
         XH_SSTAMP(2);
-        // the waves' edge accumulators: unpacked, totalled across the wave without LDS, lane 63 adds the wave's 20 pairs to the plane's table
+        // the waves' edge accumulators: unpacked, totalled over each row of 16 lanes by four DPP adds (lane 15 of a row holds its total), the 16 row totals
+        // of the workgroup go through LDS: hist[832 + item * 16 + wave * 4 + row], item = (class * 5 + category) * 2 + (0 sum, 1 count); thread t < 40 adds up
+        // item t's sixteen numbers
+        {
+            int* part = hist + 832;
 #pragma unroll
-        for (int c = 0; c < 4; c++)
+            for (int c = 0; c < 4; c++)
 #pragma unroll
-            for (int k = 0; k < 5; k++)
-            {
-                const int sumL = (int)(short)(acc[c][k] & 0xffff), cntL = (acc[c][k] - sumL) >> 16;
-                const int sum = wave_total_lane63(sumL), cnt = wave_total_lane63(cntL);
-                if (lx == 63 && cnt)
+                for (int k = 0; k < 5; k++)
                 {
-                    atomicAdd(&hist[(c + 1) * 32 + k], sum);
-                    atomicAdd(&hist[160 + (c + 1) * 32 + k], cnt);
+                    const int sumL = (int)(short)(acc[c][k] & 0xffff), cntL = (acc[c][k] - sumL) >> 16;
+                    const int sr = row_total_lane15(sumL), cr = row_total_lane15(cntL);
+                    if ((lx & 15) == 15)
+                    {
+                        part[((c * 5 + k) * 2 + 0) * 16 + ly * 4 + (lx >> 4)] = sr;
+                        part[((c * 5 + k) * 2 + 1) * 16 + ly * 4 + (lx >> 4)] = cr;
+                    }
                 }
-            }
+        }
+        __syncthreads();
+        if (tid < 40)
+        {
+            const int* q = hist + 832 + tid * 16;
+            int t = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) t += q[i];
+            const int item = tid >> 1, c = item / 5, k = item - c * 5;
+            hist[(tid & 1) * 160 + (c + 1) * 32 + k] = t;
+        }
         XH_SSTAMP(3);
         __syncthreads();
-        if (tid < 32)
+        // the band class: thread t adds up 32 columns of band t / 8 (all four waves' columns of a band lie 2 048 entries apart), the eight threads of a
+        // band combine by DPP
         {
-            hist[tid] = hist[320 + tid] + hist[320 + 64 + tid] + hist[320 + 128 + tid] + hist[320 + 192 + tid];
-            hist[160 + tid] = hist[576 + tid] + hist[576 + 64 + tid] + hist[576 + 128 + tid] + hist[576 + 192 + tid];
+            const int bnd = tid >> 3, seg = tid & 7;                          // columns seg * 32 .. seg * 32 + 31 of the band's 256
+            const int* col = hist + 1472 + (seg >> 1) * 2048 + bnd * 64 + (seg & 1) * 32;
+            int sumB = 0, cntB = 0;
+#pragma unroll 8
+            for (int i = 0; i < 32; i++)
+            {
+                const int v = col[i];
+                const int sL = (int)(short)(v & 0xffff);
+                sumB += sL; cntB += (v - sL) >> 16;
+            }
+            // eight consecutive lanes: xor 1, 2 (quad DPP), then lane + 4 of the same row
+            sumB += __builtin_amdgcn_update_dpp(0, sumB, 0xB1, 0xf, 0xf, false); cntB += __builtin_amdgcn_update_dpp(0, cntB, 0xB1, 0xf, 0xf, false);
+            sumB += __builtin_amdgcn_update_dpp(0, sumB, 0x4E, 0xf, 0xf, false); cntB += __builtin_amdgcn_update_dpp(0, cntB, 0x4E, 0xf, 0xf, false);
+            sumB += __builtin_amdgcn_update_dpp(0, sumB, 0x104, 0xf, 0xf, false); cntB += __builtin_amdgcn_update_dpp(0, cntB, 0x104, 0xf, 0xf, false);   // row_shl:4
+            if (seg == 0) { hist[bnd] = sumB; hist[160 + bnd] = cntB; }
         }
         __syncthreads();
         if (tid < 64)

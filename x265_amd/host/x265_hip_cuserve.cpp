@@ -1257,15 +1257,20 @@ void Quant::invtransformNxN(const CUData& cu, int16_t* residual, uint32_t resiSt
 namespace {
 
 int g_saoState = 0;              // 0 undecided, 1 on, -1 off
+bool g_saoParts = true;          // X265HIP_SAOSTATS_PARTS=1: the luma plane is not split in two (one job per plane)
 struct alignas(64) SaoCounters { std::atomic<uint64_t> jobs, planes, hostPlanes, waits, waitCycles; };
 SaoCounters g_saoCount[16];
+// One CTU's statistics are up to four PARTS, each a job of one block on a slot of its own — the upper and lower half of the luma CTU, Cb, Cr — so that four
+// workgroups measure at the same time (a part is a dependent chain of ~10 us on the device; sums and counts of the halves add up).  When slots are short the
+// CTU goes as fewer parts, down to one.
+struct SaoPart { int plane, slot; uint32_t seq; Service* svc; };
 struct SaoJob
 {
     bool active;
     const SAO* sao; int addr;
-    int nblocks, blockPlane[3];          // job block b holds plane blockPlane[b]
-    bool consumed[3];
-    Service* svc; int slot; uint32_t seq;
+    int nparts; SaoPart part[4];
+    bool consumed[3];                    // per plane
+    bool wanted[3];                      // planes this job carries
 };
 __attribute__((tls_model("initial-exec"))) thread_local SaoJob t_sao;
 
@@ -1287,6 +1292,7 @@ bool sao_enabled()
             const char* env = getenv("X265HIP_SAOSTATS");
             const char* all = getenv("X265HIP");
             const char* table = getenv("X265HIP_TABLE");
+            if (getenv("X265HIP_SAOSTATS_PARTS")) g_saoParts = atoi(getenv("X265HIP_SAOSTATS_PARTS")) > 1;
             if (X265_DEPTH != 8 || (env && !strcmp(env, "0")) || (all && !strcmp(all, "0")) || (table && !strcmp(table, "percall")))
                 g_saoState = -1;
             else
@@ -1301,18 +1307,19 @@ bool sao_enabled()
 
 inline SaoCounters& sao_counters() { counters(); return g_saoCount[t_shard & 15]; }
 
-// the rectangles of one plane, exactly as sao.cpp:741-914 computes them; false: a geometry the job does not carry
-bool sao_rects(const SAO* sao, int addr, int plane, x265hip_saojob& job, int b, const pixel*& rec0, const pixel*& fenc0, intptr_t& stride, bool& eo23)
+// the rectangles of one plane, exactly as sao.cpp:741-914 computes them (x265hip_saojob's plane block); false: a geometry the job does not carry
+struct SaoPlane { int w, h, x0[5], y0[5], x1[5], y1[5]; const pixel* rec0; const pixel* fenc0; intptr_t stride; bool eo23; };
+bool sao_rects(const SAO* sao, int addr, int plane, SaoPlane& out)
 {
     const Frame* frame = sao->m_frame;
     const x265_param* param = sao->m_param;
     const Slice* slice = frame->m_encData->m_slice;
     const PicYuv* reconPic = frame->m_reconPic;
     const CUData* cu = frame->m_encData->getPicCTU(addr);
-    fenc0 = frame->m_fencPic->getPlaneAddr(plane, addr);
-    rec0 = reconPic->getPlaneAddr(plane, addr);
-    stride = plane ? reconPic->m_strideC : reconPic->m_stride;
-    if ((plane ? frame->m_fencPic->m_strideC : frame->m_fencPic->m_stride) != stride)
+    out.fenc0 = frame->m_fencPic->getPlaneAddr(plane, addr);
+    out.rec0 = reconPic->getPlaneAddr(plane, addr);
+    out.stride = plane ? reconPic->m_strideC : reconPic->m_stride;
+    if ((plane ? frame->m_fencPic->m_strideC : frame->m_fencPic->m_stride) != out.stride)
         return false;                                    // (the reference indexes both pictures with the reconstruction's stride, :786-806)
     uint32_t picWidth = param->sourceWidth, picHeight = param->sourceHeight;
     int ctuWidth = param->maxCUSize, ctuHeight = param->maxCUSize;
@@ -1333,7 +1340,7 @@ bool sao_rects(const SAO* sao, int addr, int plane, x265hip_saojob& job, int b, 
     const int po = plane ? 2 : 0;
     const bool nd = param->bSaoNonDeblocked != 0;
     const bool right = rpelx == picWidth, bottom = bpely == picHeight;
-    int x0[5], y0[5], x1[5], y1[5];
+    int* x0 = out.x0; int* y0 = out.y0; int* x1 = out.x1; int* y1 = out.y1;
     // SAO_BO (:810-823): skipB 4 / skipR 5, non-deblocked 3 / 4
     { const int skipB = nd ? 3 : 4, skipR = nd ? 4 : 5;
       x0[0] = 0; y0[0] = 0; x1[0] = right ? ctuWidth : ctuWidth - skipR + po; y1[0] = bottom ? ctuHeight : ctuHeight - skipB + po; }
@@ -1347,37 +1354,35 @@ bool sao_rects(const SAO* sao, int addr, int plane, x265hip_saojob& job, int b, 
     for (int c = 3; c < 5; c++)
     { const int skipB = 4, skipR = 5;
       x0[c] = !lpelx; y0[c] = bAboveUnavail; x1[c] = right ? ctuWidth - 1 : ctuWidth - skipR + po; y1[c] = bottom ? ctuHeight - 1 : ctuHeight - skipB + po; }
-    eo23 = !param->bLimitSAO || ((slice->m_sliceType == P_SLICE && !cu->isSkipped(0)) || (slice->m_sliceType != B_SLICE));
-    job.plane[b].w = (uint16_t)ctuWidth; job.plane[b].h = (uint16_t)ctuHeight;
+    out.eo23 = !param->bLimitSAO || ((slice->m_sliceType == P_SLICE && !cu->isSkipped(0)) || (slice->m_sliceType != B_SLICE));
+    out.w = ctuWidth; out.h = ctuHeight;
     for (int c = 0; c < 5; c++)
-    {
-        // an empty rectangle (a CTU a few samples wide) measures nothing in the reference's loops either; the job carries it as [0, 0)
-        if (x1[c] <= x0[c] || y1[c] <= y0[c] || x1[c] < 0 || y1[c] < 0) { x0[c] = y0[c] = x1[c] = y1[c] = 0; }
-        job.plane[b].x0[c] = (uint8_t)x0[c]; job.plane[b].y0[c] = (uint8_t)y0[c]; job.plane[b].x1[c] = (uint8_t)x1[c]; job.plane[b].y1[c] = (uint8_t)y1[c];
-    }
+        if (x1[c] <= x0[c] || y1[c] <= y0[c] || x1[c] < 0 || y1[c] < 0) { x0[c] = y0[c] = x1[c] = y1[c] = 0; }    // empty: the reference's loops measure nothing either
     return true;
 }
 
 void sao_drop(SaoJob& sj, bool deviceDone)
 {
-    if (sj.active && deviceDone) give_slot(sj.svc, sj.slot);
+    if (sj.active && deviceDone)
+        for (int k = 0; k < sj.nparts; k++) give_slot(sj.part[k].svc, sj.part[k].slot);
     sj.active = false;
 }
 
-// waits for block b of this thread's SAO job; false: the device did not deliver
-bool sao_wait(SaoJob& sj, int b)
+// waits for one part of this thread's SAO job; false: the device did not deliver
+bool sao_wait(SaoJob& sj, int k)
 {
-    const uint32_t* ready = &sj.svc->mem[sj.slot].units[b].ready;
-    if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == sj.seq) return true;
+    const SaoPart& pt = sj.part[k];
+    const uint32_t* ready = &pt.svc->mem[pt.slot].units[0].ready;
+    if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == pt.seq) return true;
     const uint64_t t0 = __builtin_ia32_rdtsc();
     uint64_t spins = 0;
     int64_t waitedNs = 0, lastNs = -1;
-    while (__atomic_load_n(ready, __ATOMIC_ACQUIRE) != sj.seq)
+    while (__atomic_load_n(ready, __ATOMIC_ACQUIRE) != pt.seq)
     {
         __builtin_ia32_pause();
         if ((++spins & 255) == 0)
         {
-            const int pk = x265hip_cuserve_poke(sj.svc->cs, sj.slot);
+            const int pk = x265hip_cuserve_poke(pt.svc->cs, pt.slot);
             timespec ts;
             clock_gettime(CLOCK_MONOTONIC, &ts);
             const int64_t nowNs = (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
@@ -1385,7 +1390,7 @@ bool sao_wait(SaoJob& sj, int b)
             lastNs = nowNs;
             if (pk < 0 || waitedNs > g_timeoutNs)
             {
-                sj.active = false;                       // the slot is not given back: the device may still write into it
+                sj.active = false;                       // the slots are not given back: the device may still write into them
                 g_saoState = -1;
                 x265hip_device_failure("saostats", "an SAO statistics job did not come back");
                 return false;
@@ -1398,35 +1403,33 @@ bool sao_wait(SaoJob& sj, int b)
     return true;
 }
 
-// one job for planes [first, first + n) of CTU `addr`; false: not submitted
-bool sao_submit(SAO* sao, int addr, int first, int n)
+// rows [ra, rb) of plane `pl` as a one-block job on a free slot; false: no slot / the device refused
+bool sao_submit_part(SaoJob& sj, const SaoPlane& pl, int plane, int ra, int rb)
 {
-    SaoJob& sj = t_sao;
-    if (g_dead.load(std::memory_order_relaxed) || !service())
-        return false;
-    x265hip_saojob job;
-    memset(&job, 0, sizeof(job));
-    job.bitDepth = X265_DEPTH; job.planes = (uint32_t)n;
-    const pixel* rec0[3]; const pixel* fenc0[3]; intptr_t stride[3];
-    bool eo23 = true;
-    for (int b = 0; b < n; b++)
-        if (!sao_rects(sao, addr, first + b, job, b, rec0[b], fenc0[b], stride[b], eo23))
-            return false;
-    job.eo23 = eo23;
     Service* svc = NULL;
     const int slot = take_slot(&svc);
     if (slot < 0)
         return false;
-    // the blocks, packed in this thread's memory first, then one front-to-back copy into the mailbox (write-combining memory)
-    static thread_local pixel staged[3 * (65 * 65 + 64 * 64)];
-    pixel* dst = staged;
-    for (int b = 0; b < n; b++)
+    // the block: rows ra - 1 .. min(rb, h - 1) — one row above the first measured row and, unless the part ends with the plane, one below the last
+    const int rowsBelow = rb < pl.h ? 1 : 0, hh = rb - ra + rowsBelow, w = pl.w;
+    x265hip_saojob job;
+    memset(&job, 0, sizeof(job));
+    job.bitDepth = X265_DEPTH; job.planes = 1; job.eo23 = pl.eo23;
+    job.plane[0].w = (uint16_t)w; job.plane[0].h = (uint16_t)hh;
+    for (int c = 0; c < 5; c++)
     {
-        const int w = job.plane[b].w, h = job.plane[b].h;
-        const pixel* r = rec0[b] - stride[b] - 1;
-        for (int y = 0; y <= h; y++, dst += w + 1) memcpy(dst, r + (intptr_t)y * stride[b], (size_t)(w + 1) * sizeof(pixel));
-        for (int y = 0; y < h; y++, dst += w) memcpy(dst, fenc0[b] + (intptr_t)y * stride[b], (size_t)w * sizeof(pixel));
+        int y0 = pl.y0[c] < ra ? ra : pl.y0[c], y1 = pl.y1[c] > rb ? rb : pl.y1[c];
+        int x0 = pl.x0[c], x1 = pl.x1[c];
+        if (y1 <= y0 || x1 <= x0) { x0 = x1 = 0; y0 = y1 = ra; }
+        job.plane[0].x0[c] = (uint8_t)x0; job.plane[0].x1[c] = (uint8_t)x1; job.plane[0].y0[c] = (uint8_t)(y0 - ra); job.plane[0].y1[c] = (uint8_t)(y1 - ra);
     }
+    static thread_local pixel staged[66 * 65 + 65 * 64];
+    pixel* dst = staged;
+    const pixel* r = pl.rec0 + (intptr_t)(ra - 1) * pl.stride - 1;
+    for (int y = 0; y <= hh; y++, dst += w + 1) memcpy(dst, r + (intptr_t)y * pl.stride, (size_t)(w + 1) * sizeof(pixel));
+    const pixel* f = pl.fenc0 + (intptr_t)ra * pl.stride;
+    // (the source rows of the extra row below are carried but never measured: its samples lie outside every rectangle)
+    for (int y = 0; y < hh; y++, dst += w) memcpy(dst, f + (intptr_t)y * pl.stride, (size_t)w * sizeof(pixel));
     memcpy(svc->mem[slot].pixels, staged, (size_t)(dst - staged) * sizeof(pixel));
     uint32_t seq = 0;
     if (x265hip_cuserve_submit_sao(svc->cs, slot, &job, &seq))
@@ -1436,9 +1439,49 @@ bool sao_submit(SAO* sao, int addr, int first, int n)
         x265hip_device_failure("saostats", "x265hip_cuserve_submit_sao");
         return false;
     }
-    sj.active = true; sj.sao = sao; sj.addr = addr; sj.nblocks = n; sj.svc = svc; sj.slot = slot; sj.seq = seq;
-    for (int b = 0; b < 3; b++) { sj.blockPlane[b] = first + b; sj.consumed[b] = false; }
+    SaoPart& pt = sj.part[sj.nparts++];
+    pt.plane = plane; pt.slot = slot; pt.seq = seq; pt.svc = svc;
     sao_counters().jobs.fetch_add(1, std::memory_order_relaxed);
+    return true;
+}
+
+// the parts for planes [first, first + n) of CTU `addr`; false: nothing was submitted
+bool sao_submit(SAO* sao, int addr, int first, int n)
+{
+    SaoJob& sj = t_sao;
+    if (g_dead.load(std::memory_order_relaxed) || !service())
+        return false;
+    SaoPlane pl[3];
+    for (int b = 0; b < n; b++)
+        if (!sao_rects(sao, addr, first + b, pl[b]))
+            return false;
+    sj.nparts = 0;
+    for (int p = 0; p < 3; p++) { sj.consumed[p] = false; sj.wanted[p] = false; }
+    for (int b = 0; b < n && g_saoState > 0; b++)
+    {
+        const int plane = first + b, h = pl[b].h;
+        // the luma plane in two halves when it is high enough to be worth a second workgroup
+        const int mid = plane == 0 && g_saoParts && h >= 32 ? (h / 2 + 3) & ~3 : h;
+        const int before = sj.nparts;
+        bool ok = sao_submit_part(sj, pl[b], plane, 0, mid) && (mid == h || sao_submit_part(sj, pl[b], plane, mid, h));
+        if (!ok)
+        {
+            // a plane is served whole or not at all: parts of it that did leave are waited out and dropped with the rest (below, by the caller's next call)
+            if (sj.nparts > before || b > 0) break;
+            return false;
+        }
+        sj.wanted[plane] = true;
+    }
+    // a plane whose second half found no slot: not wanted (its first half is still waited for before the slots go back)
+    for (int p = 0; p < 3; p++)
+    {
+        int have = 0;
+        for (int k = 0; k < sj.nparts; k++) have += sj.part[k].plane == p;
+        if (sj.wanted[p] && !have) sj.wanted[p] = false;
+    }
+    if (!sj.nparts)
+        return false;
+    sj.active = true; sj.sao = sao; sj.addr = addr;
     return true;
 }
 
@@ -1452,59 +1495,73 @@ void SAO::calcSaoStatsCTU(int addr, int plane)
         return;
     }
     SaoJob& sj = t_sao;
-    // a job of another CTU (its chroma planes were never asked for): wait it out, the slot goes back
+    // a job of another CTU (its chroma planes were never asked for): wait it out, the slots go back
     if (sj.active && (sj.sao != this || sj.addr != addr))
     {
         bool done = true;
-        for (int b = 0; b < sj.nblocks && done; b++) done = sao_wait(sj, b);
+        for (int k = 0; k < sj.nparts && done; k++) done = sao_wait(sj, k);
         sao_drop(sj, done);
     }
-    int b = -1;
-    if (sj.active)
-        for (int k = 0; k < sj.nblocks; k++)
-            if (sj.blockPlane[k] == plane && !sj.consumed[k]) b = k;
-    if (b < 0 && !sj.active)
+    if (!sj.active)
     {
         const bool chroma = m_param->internalCsp != X265_CSP_I400 && m_frame->m_fencPic->m_picCsp != X265_CSP_I400;
         const SAOParam* sp = m_frame->m_encData->m_saoParam;
         // luma asked for: the chroma planes ride along when the reference is going to ask for them whatever the luma decision (no --limit-sao, :1299-1306)
-        const bool ok = plane == 0 ? sao_submit(this, addr, 0, chroma && !m_param->bLimitSAO && sp && sp->bSaoFlag[1] && m_param->internalCsp == X265_CSP_I420 ? 3 : 1)
-                                   : plane == 1 && m_param->internalCsp == X265_CSP_I420 ? sao_submit(this, addr, 1, 2) : false;
-        if (ok) b = 0;
+        if (plane == 0)
+            sao_submit(this, addr, 0, chroma && !m_param->bLimitSAO && sp && sp->bSaoFlag[1] && m_param->internalCsp == X265_CSP_I420 ? 3 : 1);
+        else if (plane == 1 && m_param->internalCsp == X265_CSP_I420)
+            sao_submit(this, addr, 1, 2);
     }
-    if (b >= 0 && sao_wait(sj, b))
+    if (sj.active && g_saoState > 0 && sj.wanted[plane] && !sj.consumed[plane])
     {
-        const int32_t* out = (const int32_t*)sj.svc->mem[sj.slot].levels;
-        const int32_t* st = out + b * 160;
-        const int32_t* ct = out + X265HIP_SAOJOB_STATS_ENTRIES + b * 160;
-        static const int typeOf[5] = { SAO_BO, SAO_EO_0, SAO_EO_1, SAO_EO_2, SAO_EO_3 };
-        if (g_verify)
+        bool ok = true;
+        for (int k = 0; k < sj.nparts && ok; k++)
+            if (sj.part[k].plane == plane) ok = sao_wait(sj, k);
+        if (ok)
         {
-            PerClass keepC, keepO;
-            memcpy(keepC, m_count[plane], sizeof(keepC)); memcpy(keepO, m_offsetOrg[plane], sizeof(keepO));
-            refCalcSaoStatsCTU(this, addr, plane);
-            for (int c = 0; c < 5; c++)
-                for (int k = 0; k < (c ? 5 : 32); k++)
-                    if (m_count[plane][typeOf[c]][k] != keepC[typeOf[c]][k] + ct[c * 32 + k] || m_offsetOrg[plane][typeOf[c]][k] != keepO[typeOf[c]][k] + st[c * 32 + k])
-                    {
-                        fprintf(stderr, "x265hip: saostats: VERIFY FAILED CTU %d plane %d class %d bin %d: count %d + %d vs %d, sum %d + %d vs %d\n", addr, plane, c, k, keepC[typeOf[c]][k],
-                                ct[c * 32 + k], m_count[plane][typeOf[c]][k], keepO[typeOf[c]][k], st[c * 32 + k], m_offsetOrg[plane][typeOf[c]][k]);
-                        abort();
-                    }
-        }
-        else
-            for (int c = 0; c < 5; c++)
-                for (int k = 0; k < (c ? 5 : 32); k++)
+            static const int typeOf[5] = { SAO_BO, SAO_EO_0, SAO_EO_1, SAO_EO_2, SAO_EO_3 };
+            int32_t st[160], ct[160];
+            memset(st, 0, sizeof(st)); memset(ct, 0, sizeof(ct));
+            for (int k = 0; k < sj.nparts; k++)
+                if (sj.part[k].plane == plane)
                 {
-                    m_count[plane][typeOf[c]][k] += ct[c * 32 + k];
-                    m_offsetOrg[plane][typeOf[c]][k] += st[c * 32 + k];
+                    const int32_t* out = (const int32_t*)sj.part[k].svc->mem[sj.part[k].slot].levels;
+                    for (int i = 0; i < 160; i++) { st[i] += out[i]; ct[i] += out[X265HIP_SAOJOB_STATS_ENTRIES + i]; }
                 }
-        sj.consumed[b] = true;
-        sao_counters().planes.fetch_add(1, std::memory_order_relaxed);
-        bool all = true;
-        for (int k = 0; k < sj.nblocks; k++) all = all && sj.consumed[k];
-        if (all) sao_drop(sj, true);
-        return;
+            if (g_verify)
+            {
+                PerClass keepC, keepO;
+                memcpy(keepC, m_count[plane], sizeof(keepC)); memcpy(keepO, m_offsetOrg[plane], sizeof(keepO));
+                refCalcSaoStatsCTU(this, addr, plane);
+                for (int c = 0; c < 5; c++)
+                    for (int k = 0; k < (c ? 5 : 32); k++)
+                        if (m_count[plane][typeOf[c]][k] != keepC[typeOf[c]][k] + ct[c * 32 + k] || m_offsetOrg[plane][typeOf[c]][k] != keepO[typeOf[c]][k] + st[c * 32 + k])
+                        {
+                            fprintf(stderr, "x265hip: saostats: VERIFY FAILED CTU %d plane %d class %d bin %d: count %d + %d vs %d, sum %d + %d vs %d\n", addr, plane, c, k, keepC[typeOf[c]][k],
+                                    ct[c * 32 + k], m_count[plane][typeOf[c]][k], keepO[typeOf[c]][k], st[c * 32 + k], m_offsetOrg[plane][typeOf[c]][k]);
+                            abort();
+                        }
+            }
+            else
+                for (int c = 0; c < 5; c++)
+                    for (int k = 0; k < (c ? 5 : 32); k++)
+                    {
+                        m_count[plane][typeOf[c]][k] += ct[c * 32 + k];
+                        m_offsetOrg[plane][typeOf[c]][k] += st[c * 32 + k];
+                    }
+            sj.consumed[plane] = true;
+            sao_counters().planes.fetch_add(1, std::memory_order_relaxed);
+            bool all = true;
+            for (int p = 0; p < 3; p++) all = all && (!sj.wanted[p] || sj.consumed[p]);
+            if (all)
+            {
+                // (parts of planes that were dropped half-submitted are waited for like the rest)
+                bool done = true;
+                for (int k = 0; k < sj.nparts && done; k++) done = sao_wait(sj, k);
+                sao_drop(sj, done);
+            }
+            return;
+        }
     }
     sao_counters().hostPlanes.fetch_add(1, std::memory_order_relaxed);
     refCalcSaoStatsCTU(this, addr, plane);
