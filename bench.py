@@ -527,6 +527,9 @@ def parse_served(lines):
             out["cu"] = {"jobs": int(m.group(1)), "min_cu": int(m.group(2)), "handoff": m.group(3), "device_ms": float(m.group(4)), "forward_units": int(m.group(5)),
                          "inverse_units": int(m.group(6)), "host_computed": int(m.group(7)) + int(m.group(8)), "waits": int(m.group(9)), "wait_cycles": int(m.group(10)),
                          "not_submitted": int(m.group(11))}
+        m = re.search(r"saostats: SAO statistics of (\d+) CTU planes .*? measured by the GPU in (\d+) jobs, (\d+) planes on the host; (\d+) waits of (\d+) cycles", l)
+        if m:
+            out["sao"] = {"planes": int(m.group(1)), "jobs": int(m.group(2)), "host_planes": int(m.group(3)), "waits": int(m.group(4)), "wait_cycles": int(m.group(5))}
     return out
 
 
@@ -876,7 +879,11 @@ def main():
                                      "figure of merit is the round trip, not bytes per second: profiles/r04_*_cuserve_rt*.txt (7.6 us from submit to the first luma unit's forward "
                                      "half, 4.0 us of it on the device; 12.2 us per 32x32 CU job; stage by stage in *_cuserve_rt_stamps.txt), against a transport floor of 2.4-2.9 us "
                                      "for an empty ping-pong on this box (profiles/r04_*_bar_mailbox_breakdown.txt)",
-                        "busy_us_per_job": round(cu["ms"] * 1e3 / c["jobs"], 2), "algorithmic_bytes_per_job": int(cu["algorithmic_bytes"] / c["jobs"]),
+                        # the server's slots also carry the SAO statistics jobs (one per CTU plane: SAO::calcSaoStatsCTU's classification of a deblocked plane against
+                        # its source; bytes = the two blocks in + 2 x 5 x 32 int32 out): busy time and bytes are over both kinds
+                        "sao_statistics_jobs": served.get("sao"),
+                        "busy_us_per_job": round(cu["ms"] * 1e3 / (c["jobs"] + (served.get("sao") or {}).get("jobs", 0)), 2),
+                        "algorithmic_bytes_per_job": int(cu["algorithmic_bytes"] / (c["jobs"] + (served.get("sao") or {}).get("jobs", 0))),
                         "host_waits": {"count": c["waits"], "mean_cycles": c["wait_cycles"]}}
         # the dominant kernel of the timed region = the clock with the most device time
         named = [(ss.get("ms", 0.0), ss_block), (la.get("ms", 0.0), la_live), (cu.get("ms", 0.0), cu_block)]
