@@ -9,7 +9,7 @@
 #     ab <frames> <name:ENV=..,..> ...   interleaved A/B of the 1080p preset-medium bench encode
 #     rt                   tools/micro/cuserve_rt: the job round trip, with stage stamps
 #     stats                rocprofv3 --kernel-trace --stats of a 120-frame bound encode
-#     cpuprofile           the bound encoder under the CPU sampler (tools/prof), 2 x 240 frames
+#     cpuprofile           the bound encoder under the CPU sampler (tools/prof), 6 x 240 frames merged (> 10 k samples)
 set -u
 TAG=$1; shift
 OUT=gpurun_out/$TAG
@@ -45,11 +45,12 @@ while [ $# -gt 0 ]; do
       find $OUT/prof -name "*kernel_stats*" | head -2 ;;
     cpuprofile)
       clip /tmp/bench240.yuv 240
-      for k in 1 2; do
+      for k in 1 2 3 4 5 6; do
         X265HIP_CPUSAMPLE_OUT=/tmp/s$k.bin LD_PRELOAD=tools/prof/libcpusample.so oracle/_ref/x265_hip_8bit --input /tmp/bench240.yuv --input-res 1920x1080 --fps 30 --frames 240 --preset medium --me hex -o /tmp/p.hevc 2>&1 | grep -E "encoded|x265hip" > $OUT/cpuprofile_run$k.log
-        python tools/prof/resolve.py /tmp/s$k.bin > $OUT/cpu_profile_bound_encoder_$k.txt 2>&1
+        python tools/prof/resolve.py /tmp/s$k.bin 200 > $OUT/cpu_profile_run$k.txt 2>&1
       done
-      head -45 $OUT/cpu_profile_bound_encoder_1.txt ;;
+      python tools/prof/merge.py $OUT/cpu_profile_run?.txt > $OUT/cpu_profile_bound_encoder.txt
+      head -48 $OUT/cpu_profile_bound_encoder.txt ;;
     *) echo "unknown task $task"; exit 2 ;;
   esac
 done
