@@ -41,8 +41,8 @@ while [ $# -gt 0 ]; do
     stats)
       clip /tmp/bench120.yuv 120
       HERE=$PWD
-      (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $HERE/$OUT/prof -- $HERE/oracle/_ref/x265_hip_8bit --input /tmp/bench120.yuv --input-res 1920x1080 --fps 30 --frames 120 --preset medium --me hex -o /tmp/s.hevc > $HERE/$OUT/stats_run.log 2>&1)
-      find $OUT/prof -name "*kernel_stats*" | head -2 ;;
+      (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $HERE/$OUT/prof -o p -- $HERE/oracle/_ref/x265_hip_8bit --input /tmp/bench120.yuv --input-res 1920x1080 --fps 30 --frames 120 --preset medium --me hex -o /tmp/s.hevc > $HERE/$OUT/stats_run.log 2>&1)
+      find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -r head -12 | cut -c1-180 ;;
     cpuprofile)
       clip /tmp/bench240.yuv 240
       for k in 1 2 3 4 5 6; do

@@ -770,14 +770,15 @@ __global__ __launch_bounds__(256) void cu_server_kernel(const SlotIn* ins, SlotO
                     // read the word first, the clock second: another workgroup may store a later time in between, never an earlier one
                     const uint64_t lw = __hip_atomic_load(&ctl->lastWork, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const uint64_t now = wall_clock64();
-                    if (now > lw && now - lw > idleTicks)
+                    if (now > lw && now - lw > (idleTicks & ~(1ull << 63)))
                     {
                         __hip_atomic_store(&ctl->quit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         v = 0xffffffffu;
                         break;
                     }
                 }
-                __builtin_amdgcn_s_sleep(2);
+                // X265HIP_CUSERVE_SPIN=1 (bit 63 of idleTicks): no sleep between polls — an experiment: does a chip that sees busy CUs clock higher?
+                if (!(idleTicks >> 63)) __builtin_amdgcn_s_sleep(2);
             }
             if (v != 0xffffffffu)
                 __hip_atomic_fetch_max(&ctl->lastWork, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -861,7 +862,8 @@ static int start_server(x265hip_cuserve* cs)
     hipError_t e = hipMemsetAsync(cs->ctl, 0, 8, cs->serverStream);
     if (e == hipSuccess)
     {
-        hipLaunchKernelGGL(cu_server_kernel, dim3(cs->slots), dim3(256), 0, cs->serverStream, cs->inDev, cs->outDev, cs->devHostCtl, cs->ctl, gen ? gen : 1u, cs->idleUs * 100);
+        hipLaunchKernelGGL(cu_server_kernel, dim3(cs->slots), dim3(256), 0, cs->serverStream, cs->inDev, cs->outDev, cs->devHostCtl, cs->ctl, gen ? gen : 1u,
+                           cs->idleUs * 100 | (getenv("X265HIP_CUSERVE_SPIN") && atoi(getenv("X265HIP_CUSERVE_SPIN")) ? 1ull << 63 : 0ull));
         e = hipGetLastError();
     }
     if (cur >= 0 && cur != cs->device) (void)hipSetDevice(cur);
