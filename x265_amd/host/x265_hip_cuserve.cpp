@@ -86,6 +86,7 @@ int g_time = 0;                  // X265HIP_DEBUG_CUTIME=1: cycles inside the fu
 int g_minLog2 = 5;               // X265HIP_CUSERVE_MIN: smallest CU (log2) whose residual quad-tree becomes a job
 int g_mode = 0;                  // X265HIP_CUSERVE_MODE: 0 resident server (mailbox), 1 one launch per job
 int64_t g_timeoutNs = 10000000000ll;            // X265HIP_CUSERVE_TIMEOUT_MS
+int g_yieldAfter = 0;                            // X265HIP_CUSERVE_YIELD
 std::atomic<int> g_lateJobs(0);
 int g_rdoqJobs = 1;              // X265HIP_CUSERVE_RDOQ=0: CUs quantised by Quant::rdoQuant are not handed over (round 4's behaviour).  On: measured on the MI355X box at
                                  // BASELINE configs[2] / configs[3] (profiles/r05_v1_configs*_ab.txt): +2 % / +6 % fps, -3 % / -6 % CPU seconds
@@ -238,6 +239,7 @@ bool decide()
         g_verify = getenv("X265HIP_VERIFY") != NULL;
         if (getenv("X265HIP_CUSERVE_MIN")) { const int v = atoi(getenv("X265HIP_CUSERVE_MIN")); g_minLog2 = v >= 64 ? 6 : v >= 32 ? 5 : 4; }
         if (getenv("X265HIP_CUSERVE_MODE")) g_mode = atoi(getenv("X265HIP_CUSERVE_MODE")) ? 1 : 0;
+        if (getenv("X265HIP_CUSERVE_YIELD")) g_yieldAfter = atoi(getenv("X265HIP_CUSERVE_YIELD"));
         if (getenv("X265HIP_CUSERVE_RDOQ")) g_rdoqJobs = atoi(getenv("X265HIP_CUSERVE_RDOQ")) ? 1 : 0;
         if (getenv("X265HIP_CUSERVE_TIMEOUT_MS") && atoll(getenv("X265HIP_CUSERVE_TIMEOUT_MS")) > 0) g_timeoutNs = atoll(getenv("X265HIP_CUSERVE_TIMEOUT_MS")) * 1000000ll;
         if (getenv("X265HIP_CUSERVE_SLOTS")) g_slots = atoi(getenv("X265HIP_CUSERVE_SLOTS"));
@@ -408,6 +410,9 @@ inline bool wait_word(Job& j, const uint32_t* ready, int site)
     while (__atomic_load_n(ready, __ATOMIC_ACQUIRE) != j.seq)
     {
         __builtin_ia32_pause();
+        // X265HIP_CUSERVE_YIELD=n: after n polls the waiter gives its CPU away between polls (x265 starts a pool thread per core it SEES, the box gives the
+        // process 16 CPUs: a spinning waiter may be keeping a runnable row from running)
+        if (g_yieldAfter && spins >= (uint64_t)g_yieldAfter) sched_yield();
         if ((++spins & 255) == 0)
         {
             // Not a latency, a failure — but only time the device could have used counts (wall clock; x265hip_cuserve_poke says 1 while the servers are
@@ -1380,6 +1385,7 @@ bool sao_wait(SaoJob& sj, int k)
     while (__atomic_load_n(ready, __ATOMIC_ACQUIRE) != pt.seq)
     {
         __builtin_ia32_pause();
+        if (g_yieldAfter && spins >= (uint64_t)g_yieldAfter) sched_yield();
         if ((++spins & 255) == 0)
         {
             const int pk = x265hip_cuserve_poke(pt.svc->cs, pt.slot);
