@@ -357,7 +357,7 @@ def test_device_coefficient_jobs_match_the_restatement(mode):
 def _sao_job(hp, rng, planes, full):
     """a job as SAO::calcSaoStatsCTU's seam would build it: plane sizes up to 64x64 (partial CTUs at the picture's edges), rectangles as the reference's
     start / end expressions produce them (left / above unavailable: start 1; right / bottom edge or the not-yet-deblocked margin: end shortened)"""
-    j = hp.SaoJob()
+    j = hp.SaoCtuJob()
     j.bitDepth, j.planes, j.eo23 = 8, planes, int(rng.integers(0, 4) > 0)
     blocks = []
     for b in range(planes):

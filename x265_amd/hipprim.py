@@ -269,7 +269,7 @@ class SaoJobPlane(C.Structure):
     _fields_ = [("w", C.c_uint16), ("h", C.c_uint16), ("x0", C.c_uint8 * 5), ("y0", C.c_uint8 * 5), ("x1", C.c_uint8 * 5), ("y1", C.c_uint8 * 5)]
 
 
-class SaoJob(C.Structure):
+class SaoCtuJob(C.Structure):
     """x265hip_saojob (include/x265hip.h): the SAO statistics of one CTU as a job of the CU-job service"""
     _fields_ = [("bitDepth", u32), ("planes", u32), ("eo23", u32), ("reserved", u32), ("plane", SaoJobPlane * 3)]
 
