@@ -90,7 +90,7 @@ int g_yieldAfter = 0;                            // X265HIP_CUSERVE_YIELD
 std::atomic<int> g_lateJobs(0);
 int g_rdoqJobs = 1;              // X265HIP_CUSERVE_RDOQ=0: CUs quantised by Quant::rdoQuant are not handed over (round 4's behaviour).  On: measured on the MI355X box at
                                  // BASELINE configs[2] / configs[3] (profiles/r05_v1_configs*_ab.txt): +2 % / +6 % fps, -3 % / -6 % CPU seconds
-int g_slots = 64;                // X265HIP_CUSERVE_SLOTS: jobs that can be in flight (default: twice the CPUs this process may use, 16..64)
+int g_slots = 64;                // X265HIP_CUSERVE_SLOTS: jobs that can be in flight (default: three times the CPUs this process may use, 16..64)
 bool g_verify = false;           // X265HIP_VERIFY=1: every served unit is recomputed by the reference's function and compared
 bool g_require = false;          // X265HIP=require: a device failure is fatal instead of falling back
 std::mutex g_lock;
@@ -257,7 +257,8 @@ bool decide()
                     cpus = (int)((quota + period - 1) / period);
                 fclose(f);
             }
-            g_slots = 2 * cpus < 16 ? 16 : 2 * cpus > 64 ? 64 : 2 * cpus;
+            // (round 5: three per CPU — a thread in the SAO decision holds up to six slots, this CTU's planes and the next CTU's, submitted ahead)
+            g_slots = 3 * cpus < 16 ? 16 : 3 * cpus > 64 ? 64 : 3 * cpus;
         }
         if (getenv("X265HIP_CUSERVE_SPEC")) g_spec = atoi(getenv("X265HIP_CUSERVE_SPEC")) != 0;
         g_serveDist = getenv("X265HIP_CUSERVE_DIST") ? atoi(getenv("X265HIP_CUSERVE_DIST")) : 3;
@@ -900,9 +901,37 @@ void report_prim_time()
                         (double)g_primCycles[k][w].load() / g_primCalls[k][w].load(), g_primCycles[k][w].load() * 1e-9);
 }
 
+// X265HIP_DEBUG_SCANHIT=1: how much of scanPosLast (dct.cpp:757-788; called by Entropy::codeCoeffNxN, entropy.cpp:1856) runs on levels a CU job has just
+// delivered — the call right after a served Quant::transformNxN, same coefficient buffer — i.e. what a job that also shipped the scan's per-group arrays could
+// take over (a measurement for the next step, not a product path)
+scanPosLast_t g_scanPrev;
+std::atomic<uint64_t> g_scanCycles[2], g_scanCalls[2];
+__attribute__((tls_model("initial-exec"))) thread_local const coeff_t* t_lastServedCoeff = NULL;
+int scan_counted(const uint16_t* scan, const coeff_t* coeff, uint16_t* coeffSign, uint16_t* coeffFlag, uint8_t* coeffNum, int numSig, const uint16_t* scanCG4x4, const int trSize)
+{
+    const int k = coeff == t_lastServedCoeff ? 0 : 1;
+    const uint64_t t0 = __builtin_ia32_rdtsc();
+    const int r = g_scanPrev(scan, coeff, coeffSign, coeffFlag, coeffNum, numSig, scanCG4x4, trSize);
+    g_scanCycles[k].fetch_add(__builtin_ia32_rdtsc() - t0, std::memory_order_relaxed);
+    g_scanCalls[k].fetch_add(1, std::memory_order_relaxed);
+    return r;
+}
+void report_scanhit()
+{
+    fprintf(stderr, "x265hip: scanhit: scanPosLast on levels a CU job has just delivered: %llu calls, %.3f G cycles; elsewhere: %llu calls, %.3f G cycles\n",
+            (unsigned long long)g_scanCalls[0].load(), g_scanCycles[0].load() * 1e-9, (unsigned long long)g_scanCalls[1].load(), g_scanCycles[1].load() * 1e-9);
+}
+
 void x265hip_install_cuserve_slots(EncoderPrimitives& p)
 {
     decide();
+    if (getenv("X265HIP_DEBUG_SCANHIT"))
+    {
+        static std::mutex onceS;
+        std::lock_guard<std::mutex> g(onceS);
+        if (!g_scanPrev) { g_scanPrev = p.scanPosLast; atexit(report_scanhit); }
+        p.scanPosLast = scan_counted;
+    }
     if (g_time)
     {
         static std::mutex onceT;
@@ -1174,6 +1203,7 @@ uint32_t Quant::transformNxN(const CUData& cu, const pixel* fenc, uint32_t fencS
                     }
                 }
                 counters().fwd.fetch_add(1, std::memory_order_relaxed);
+                t_lastServedCoeff = coeff;
                 if (g_time)
                 {
                     g_cycles[log2TrSize - 2][0].fetch_add(__builtin_ia32_rdtsc() - t0, std::memory_order_relaxed);
@@ -1263,7 +1293,7 @@ namespace {
 
 int g_saoState = 0;              // 0 undecided, 1 on, -1 off
 bool g_saoParts = false;         // X265HIP_SAOSTATS_PARTS=4: the luma plane goes as two jobs (upper / lower half).  Measured: 3 jobs per CTU 33.2 fps, 4 jobs 32.6, SAO on the host 30.9
-struct alignas(64) SaoCounters { std::atomic<uint64_t> jobs, planes, hostPlanes, waits, waitCycles; };
+struct alignas(64) SaoCounters { std::atomic<uint64_t> jobs, planes, hostPlanes, waits, waitCycles, ahead; };
 SaoCounters g_saoCount[16];
 // One CTU's statistics are up to four PARTS, each a job of one block on a slot of its own — the upper and lower half of the luma CTU, Cb, Cr — so that four
 // workgroups measure at the same time (a part is a dependent chain of ~10 us on the device; sums and counts of the halves add up).  When slots are short the
@@ -1277,14 +1307,17 @@ struct SaoJob
     bool consumed[3];                    // per plane
     bool wanted[3];                      // planes this job carries
 };
-__attribute__((tls_model("initial-exec"))) thread_local SaoJob t_sao;
+// two per thread: the CTU whose statistics are being asked for, and the NEXT CTU of the row, submitted ahead (see SAO::calcSaoStatsCTU below)
+__attribute__((tls_model("initial-exec"))) thread_local SaoJob t_saoSet[2];
+bool g_saoAhead = true;              // X265HIP_SAOSTATS_AHEAD=0: no CTU is submitted ahead of its request
 
 void sao_report()
 {
-    uint64_t jobs = 0, planes = 0, host = 0, w = 0, wc = 0;
-    for (int i = 0; i < 16; i++) { jobs += g_saoCount[i].jobs; planes += g_saoCount[i].planes; host += g_saoCount[i].hostPlanes; w += g_saoCount[i].waits; wc += g_saoCount[i].waitCycles; }
+    uint64_t jobs = 0, planes = 0, host = 0, w = 0, wc = 0, ah = 0;
+    for (int i = 0; i < 16; i++) { jobs += g_saoCount[i].jobs; planes += g_saoCount[i].planes; host += g_saoCount[i].hostPlanes; w += g_saoCount[i].waits; wc += g_saoCount[i].waitCycles; ah += g_saoCount[i].ahead; }
     fprintf(stderr, "x265hip: saostats: SAO statistics of %llu CTU planes (SAO::calcSaoStatsCTU: band + four edge classes) measured by the GPU in %llu jobs, %llu planes on the host; "
-                    "%llu waits of %.0f cycles on average\n", (unsigned long long)planes, (unsigned long long)jobs, (unsigned long long)host, (unsigned long long)w, w ? (double)wc / w : 0.0);
+                    "%llu waits of %.0f cycles on average; %llu CTUs submitted one CTU ahead of their request\n", (unsigned long long)planes, (unsigned long long)jobs, (unsigned long long)host,
+            (unsigned long long)w, w ? (double)wc / w : 0.0, (unsigned long long)ah);
 }
 
 bool sao_enabled()
@@ -1298,6 +1331,7 @@ bool sao_enabled()
             const char* all = getenv("X265HIP");
             const char* table = getenv("X265HIP_TABLE");
             if (getenv("X265HIP_SAOSTATS_PARTS")) g_saoParts = atoi(getenv("X265HIP_SAOSTATS_PARTS")) > 3;
+            if (getenv("X265HIP_SAOSTATS_AHEAD")) g_saoAhead = atoi(getenv("X265HIP_SAOSTATS_AHEAD")) != 0;
             if (X265_DEPTH != 8 || (env && !strcmp(env, "0")) || (all && !strcmp(all, "0")) || (table && !strcmp(table, "percall")))
                 g_saoState = -1;
             else
@@ -1452,9 +1486,8 @@ bool sao_submit_part(SaoJob& sj, const SaoPlane& pl, int plane, int ra, int rb)
 }
 
 // the parts for planes [first, first + n) of CTU `addr`; false: nothing was submitted
-bool sao_submit(SAO* sao, int addr, int first, int n)
+bool sao_submit(SaoJob& sj, SAO* sao, int addr, int first, int n)
 {
-    SaoJob& sj = t_sao;
     if (g_dead.load(std::memory_order_relaxed) || !service())
         return false;
     SaoPlane pl[3];
@@ -1500,24 +1533,66 @@ void SAO::calcSaoStatsCTU(int addr, int plane)
         refCalcSaoStatsCTU(this, addr, plane);
         return;
     }
-    SaoJob& sj = t_sao;
-    // a job of another CTU (its chroma planes were never asked for): wait it out, the slots go back
-    if (sj.active && (sj.sao != this || sj.addr != addr))
+    // this thread's sets: the one of this CTU (submitted ahead during the previous CTU, or now), and one free for the next CTU.  A set of any other CTU
+    // (its chroma planes were never asked for, or the row ended) is waited out and its slots go back
+    const int numCuInWidth = m_numCuInWidth;
+    const bool nextInRow = (addr + 1) % numCuInWidth != 0;
+    SaoJob* cur = NULL;
+    for (SaoJob& t : t_saoSet)
     {
+        if (!t.active) continue;
+        if (t.sao == this && t.addr == addr) { cur = &t; continue; }
+        if (t.sao == this && t.addr == addr + 1 && nextInRow) continue;
         bool done = true;
-        for (int k = 0; k < sj.nparts && done; k++) done = sao_wait(sj, k);
-        sao_drop(sj, done);
+        for (int k = 0; k < t.nparts && done; k++) done = sao_wait(t, k);
+        sao_drop(t, done);
     }
-    if (!sj.active)
+    const bool chroma = m_param->internalCsp != X265_CSP_I400 && m_frame->m_fencPic->m_picCsp != X265_CSP_I400;
+    const SAOParam* sp = m_frame->m_encData->m_saoParam;
+    // luma asked for: the chroma planes ride along when the reference is going to ask for them whatever the luma decision (no --limit-sao, :1299-1306)
+    const int planesWithLuma = chroma && !m_param->bLimitSAO && sp && sp->bSaoFlag[1] && m_param->internalCsp == X265_CSP_I420 ? 3 : 1;
+    if (!cur)
     {
-        const bool chroma = m_param->internalCsp != X265_CSP_I400 && m_frame->m_fencPic->m_picCsp != X265_CSP_I400;
-        const SAOParam* sp = m_frame->m_encData->m_saoParam;
-        // luma asked for: the chroma planes ride along when the reference is going to ask for them whatever the luma decision (no --limit-sao, :1299-1306)
-        if (plane == 0)
-            sao_submit(this, addr, 0, chroma && !m_param->bLimitSAO && sp && sp->bSaoFlag[1] && m_param->internalCsp == X265_CSP_I420 ? 3 : 1);
-        else if (plane == 1 && m_param->internalCsp == X265_CSP_I420)
-            sao_submit(this, addr, 1, 2);
+        for (SaoJob& t : t_saoSet)
+            if (!t.active) { cur = &t; break; }
+        if (cur)
+        {
+            if (plane == 0)
+                sao_submit(*cur, this, addr, 0, planesWithLuma);
+            else if (plane == 1 && m_param->internalCsp == X265_CSP_I420)
+                sao_submit(*cur, this, addr, 1, 2);
+            if (!cur->active) cur = NULL;
+        }
     }
+    // The NEXT CTU of the row leaves now, while this thread decides this CTU's offsets.  Safe because of where the reference calls from
+    // (FrameFilter::ParallelFilter::processTasks, framefilter.cpp:463-500): rdoSaoUnitCu(col - 2) runs after deblockCTU(col, EDGE_VER) and
+    // deblockCTU(col - 1, EDGE_HOR) — CTU col - 1 is as deblocked as it will be when its own turn comes one column later (what deblockCTU(col + 1, VER) and
+    // (col, HOR) still change lies in CTU col and beyond; what the next CTU ROW's horizontal edges change lies in the 3 bottom rows every class leaves out),
+    // and the previous row's SAO is applied no further than column col - 3 before that turn (:495-499: processSaoCTU(col - 3) after this call), so the row
+    // above CTU col - 1 and its two corner samples are still the deblocked ones.  X265HIP_VERIFY compares every plane served this way with the reference's
+    // body at the reference's own time.
+    if (plane == 0 && g_saoAhead && nextInRow && g_saoState > 0 && sp && sp->bSaoFlag[0])
+    {
+        SaoJob* nxt = NULL;
+        bool have = false;
+        for (SaoJob& t : t_saoSet)
+        {
+            if (t.active && t.sao == this && t.addr == addr + 1) have = true;
+            else if (!t.active && &t != cur && !nxt) nxt = &t;
+        }
+        if (!have && nxt)
+        {
+            sao_submit(*nxt, this, addr + 1, 0, planesWithLuma);
+            if (nxt->active) sao_counters().ahead.fetch_add(1, std::memory_order_relaxed);
+        }
+    }
+    if (!cur)
+    {
+        sao_counters().hostPlanes.fetch_add(1, std::memory_order_relaxed);
+        refCalcSaoStatsCTU(this, addr, plane);
+        return;
+    }
+    SaoJob& sj = *cur;
     if (sj.active && g_saoState > 0 && sj.wanted[plane] && !sj.consumed[plane])
     {
         bool ok = true;
