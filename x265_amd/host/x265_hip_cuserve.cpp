@@ -90,7 +90,7 @@ int g_yieldAfter = 0;                            // X265HIP_CUSERVE_YIELD
 std::atomic<int> g_lateJobs(0);
 int g_rdoqJobs = 1;              // X265HIP_CUSERVE_RDOQ=0: CUs quantised by Quant::rdoQuant are not handed over (round 4's behaviour).  On: measured on the MI355X box at
                                  // BASELINE configs[2] / configs[3] (profiles/r05_v1_configs*_ab.txt): +2 % / +6 % fps, -3 % / -6 % CPU seconds
-int g_slots = 64;                // X265HIP_CUSERVE_SLOTS: jobs that can be in flight (default: three times the CPUs this process may use, 16..64)
+int g_slots = 64;                // X265HIP_CUSERVE_SLOTS: jobs that can be in flight (default: twice the CPUs this process may use, 16..64)
 bool g_verify = false;           // X265HIP_VERIFY=1: every served unit is recomputed by the reference's function and compared
 bool g_require = false;          // X265HIP=require: a device failure is fatal instead of falling back
 std::mutex g_lock;
@@ -257,8 +257,8 @@ bool decide()
                     cpus = (int)((quota + period - 1) / period);
                 fclose(f);
             }
-            // (round 5: three per CPU — a thread in the SAO decision holds up to six slots, this CTU's planes and the next CTU's, submitted ahead)
-            g_slots = 3 * cpus < 16 ? 16 : 3 * cpus > 64 ? 64 : 3 * cpus;
+            // (round 5: three per CPU was tried when the SAO statistics jobs arrived — a thread in the SAO decision holds up to six slots — and lost: 32.0 fps against 33.7 with two per CPU)
+            g_slots = 2 * cpus < 16 ? 16 : 2 * cpus > 64 ? 64 : 2 * cpus;
         }
         if (getenv("X265HIP_CUSERVE_SPEC")) g_spec = atoi(getenv("X265HIP_CUSERVE_SPEC")) != 0;
         g_serveDist = getenv("X265HIP_CUSERVE_DIST") ? atoi(getenv("X265HIP_CUSERVE_DIST")) : 3;
