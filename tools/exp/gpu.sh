@@ -5,7 +5,7 @@
 #   tools/exp/gpu.sh <tag> <task> [task ...]
 #     tests [-k expr]      the GPU test tier (or a selection)
 #     bench                python bench.py (the contract line)
-#     configs23            BASELINE configs[2] / configs[3] at 4K: defaults (RDOQ CUs stay on the host) vs X265HIP_CUSERVE_RDOQ=1 (coefficient-mode CU jobs)
+#     configs23            BASELINE configs[2] / configs[3] at 4K: defaults (coefficient-mode CU jobs) vs X265HIP_CUSERVE_RDOQ=0 (RDOQ CUs stay on the host)
 #     ab <frames> <name:ENV=..,..> ...   interleaved A/B of the 1080p preset-medium bench encode
 #     rt                   tools/micro/cuserve_rt: the job round trip, with stage stamps
 #     stats                rocprofv3 --kernel-trace --stats of a 120-frame bound encode
@@ -30,9 +30,9 @@ while [ $# -gt 0 ]; do
     bench)
       timeout 600 python bench.py 2> $OUT/bench.err | tail -1 > $OUT/bench.json; cut -c1-300 $OUT/bench.json ;;
     configs23)
-      ON="X265HIP_CUSERVE_RDOQ=1"
-      timeout 1200 python tools/ab_encode.py --rounds 2 --frames 24 --res 3840x2160 --preset slow --extra "--me star --merange 57" base: coefjobs:$ON --out $OUT/configs2.json 2>&1 | tee $OUT/configs2_4k_slow_star_ab.txt | tail -12
-      timeout 1200 python tools/ab_encode.py --rounds 2 --frames 8 --res 3840x2160 --preset slower --extra "--rd 6" --bits 10 base: coefjobs:$ON --out $OUT/configs3.json 2>&1 | tee $OUT/configs3_4k_main10_slower_ab.txt | tail -12 ;;
+      OFF="X265HIP_CUSERVE_RDOQ=0"
+      timeout 1200 python tools/ab_encode.py --rounds 2 --frames 24 --res 3840x2160 --preset slow --extra "--me star --merange 57" base: nocoef:$OFF --out $OUT/configs2.json 2>&1 | tee $OUT/configs2_4k_slow_star_ab.txt | tail -12
+      timeout 1200 python tools/ab_encode.py --rounds 2 --frames 8 --res 3840x2160 --preset slower --extra "--rd 6" --bits 10 base: nocoef:$OFF --out $OUT/configs3.json 2>&1 | tee $OUT/configs3_4k_main10_slower_ab.txt | tail -12 ;;
     ab)
       frames=$1; shift; cfgs=(); while [ $# -gt 0 ] && [[ "$1" == *:* ]]; do cfgs+=("$1"); shift; done
       timeout 1500 python tools/ab_encode.py --rounds 3 --frames $frames "${cfgs[@]}" --out $OUT/ab.json 2>&1 | tee $OUT/ab.txt | tail -14 ;;
