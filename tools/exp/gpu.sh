@@ -9,6 +9,9 @@
 #     ab <frames> <name:ENV=..,..> ...   interleaved A/B of the 1080p preset-medium bench encode
 #     rt                   tools/micro/cuserve_rt: the job round trip, with stage stamps
 #     stats                rocprofv3 --kernel-trace --stats of a 120-frame bound encode
+#     pmc                  FETCH_SIZE / WRITE_SIZE per job: cuserve_rt in launch mode (one dispatch = one job), one shape per pass, counters in their own passes
+#     stress <n>           two_encoders_hip8 par looped n times (encoders alive at the same time on the real library; every other run with poisoned Analysis
+#                          objects, every third with X265HIP_REFPLANES=0), each session's bitstream compared with the reference objects' (tests/test_reference_races.py)
 #     cpuprofile           the bound encoder under the CPU sampler (tools/prof), 6 x 240 frames merged (> 10 k samples)
 set -u
 TAG=$1; shift
@@ -43,6 +46,31 @@ while [ $# -gt 0 ]; do
       HERE=$PWD
       (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $HERE/$OUT/prof -o p -- $HERE/oracle/_ref/x265_hip_8bit --input /tmp/bench120.yuv --input-res 1920x1080 --fps 30 --frames 120 --preset medium --me hex -o /tmp/s.hevc > $HERE/$OUT/stats_run.log 2>&1)
       find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -r head -12 | cut -c1-180 ;;
+    stress)
+      n=$1; shift
+      R=oracle/_ref; D=/tmp/stress_$TAG; mkdir -p $D
+      X265HIP=require $R/two_encoders_ref8 $D/ref || { echo "reference run failed"; exit 1; }
+      read elem off < <($R/tld_layout8)
+      bad=0; t0=$(date +%s)
+      for i in $(seq 1 $n); do
+        envs=(X265HIP=require)
+        [ $((i % 2)) = 1 ] && envs+=(LD_PRELOAD=$R/allocshim.so ALLOCSHIM_SIZE=$((8 + 4 * elem)) ALLOCSHIM_ELEM=$elem ALLOCSHIM_OFFSET=$off ALLOCSHIM_WORD=2)
+        [ $((i % 3)) = 0 ] && envs+=(X265HIP_REFPLANES=0)
+        env "${envs[@]}" TWO_ENCODERS_WATCHDOG=120 timeout 200 $R/two_encoders_hip8 $D/g par > $D/run.log 2>&1 || { echo "run $i: exit $?"; tail -5 $D/run.log; bad=$((bad + 1)); continue; }
+        for k in 0 1 2 3 4; do cmp -s $D/ref_$k.hevc $D/g_$k.hevc || { echo "run $i: session $k differs"; bad=$((bad + 1)); }; done
+      done
+      echo "concurrent encoders on the MI355X: $n runs (5 sessions each, two then three alive at a time), $bad mismatches or failures, $(( $(date +%s) - t0 )) s" | tee $OUT/concurrent_stress.txt ;;
+    pmc)
+      HERE=$PWD
+      for shape in cu5 cu6 sao; do for c in fetch:FETCH_SIZE write:WRITE_SIZE; do
+        (cd /tmp && export TMPDIR=/tmp && CUSERVE_RT_ONLY=$shape CUSERVE_RT_THREADS=1 timeout 200 rocprofv3 --pmc ${c#*:} --kernel-trace --output-format csv -d $HERE/$OUT/pmc/${shape}_${c%%:*} -o p -- $HERE/tools/micro/cuserve_rt 1 400 0 > $HERE/$OUT/pmc_${shape}_${c%%:*}.log 2>&1)
+      done; done
+      # the resident server (one dispatch for the whole run, idle polling included): 3100 jobs of one shape from one thread
+      for c in fetch:FETCH_SIZE write:WRITE_SIZE; do
+        (cd /tmp && export TMPDIR=/tmp && CUSERVE_RT_ONLY=cu5 CUSERVE_RT_THREADS=1 timeout 200 rocprofv3 --pmc ${c#*:} --kernel-trace --output-format csv -d $HERE/$OUT/pmc/srv5_${c%%:*} -o p -- $HERE/tools/micro/cuserve_rt 0 3000 0 > $HERE/$OUT/pmc_srv5_${c%%:*}.log 2>&1)
+      done
+      # algorithmic bytes: pixels in; levels + residual + unit records out (CU jobs), 480 statistics words out (SAO)
+      python tools/prof/pmc_launches.py $OUT/pmc cu5:3200:6240 cu6:12416:24960 sao:12675:1920 srv5:3200:6240:3100 | tee $OUT/cuserve_pmc_per_job.txt ;;
     cpuprofile)
       clip /tmp/bench240.yuv 240
       for k in 1 2 3 4 5 6; do

@@ -21,9 +21,13 @@ int main(int argc, char** argv)
     x265hip_cuserve* cs = NULL;
     if (x265hip_cuserve_open(16, mode, &cs)) { fprintf(stderr, "open: %s\n", x265hip_last_error()); return 2; }
     std::atomic<bool> failed(false);
+    // CUSERVE_RT_ONLY=cu5|cu6|sao, CUSERVE_RT_THREADS=<n>: one job shape from one thread count — the counter passes (tools/exp/gpu.sh pmc) want launches of one kind
+    const char* only = getenv("CUSERVE_RT_ONLY");
+    const int onlyT = getenv("CUSERVE_RT_THREADS") ? atoi(getenv("CUSERVE_RT_THREADS")) : 0;
     for (int log2cu = 5; log2cu <= 6; log2cu++)
         for (int T : { 1, 4, 16 })
         {
+            if ((only && (only[0] != 'c' || only[2] != '0' + log2cu)) || (onlyT && T != onlyT)) continue;
             std::vector<std::vector<double>> lat(T), first(T), dev(T);
             std::vector<std::vector<double>> st[2][7];
             for (auto& a : st) for (auto& b : a) b.resize(T);
@@ -120,6 +124,7 @@ int main(int argc, char** argv)
     // ---- SAO statistics jobs (x265hip_saojob): a whole 64x64 CTU, three planes, every class; what SAO::calcSaoStatsCTU's seam hands over per CTU
     for (int T : { 1, 4, 16 })
     {
+        if ((only && only[0] != 's') || (onlyT && T != onlyT)) continue;
         std::vector<std::vector<double>> luma(T), whole(T), dev0(T), dev2(T);
         std::vector<double> sst[2][5];
         std::atomic<int> go(0);

@@ -63,6 +63,8 @@ extern void refEstimateResidualQT(Search* self, Mode& mode, const CUGeom& cuGeom
 extern void refCheckIntraInInter(Search* self, Mode& intraMode, const CUGeom& cuGeom) asm("_ZN4x2659SearchRef17checkIntraInInterERNS_4ModeERKNS_6CUGeomE");
 extern void refEncodeResAndCalcRdInterCU(Search* self, Mode& interMode, const CUGeom& cuGeom) asm("_ZN4x2656Search29encodeResAndCalcRdInterCUBodyERNS_4ModeERKNS_6CUGeomE");
 extern void refEncodeResAndCalcRdSkipCU(Search* self, Mode& interMode) asm("_ZN4x2656Search28encodeResAndCalcRdSkipCUBodyERNS_4ModeE");
+extern void refPredInterSearch(Search* self, Mode& interMode, const CUGeom& cuGeom, bool bChromaMC, uint32_t refMasks[2])
+    asm("_ZN4x2656Search19predInterSearchBodyERNS_4ModeERKNS_6CUGeomEbPj");
 #if X265_DEPTH == 8
 extern uint32_t refTransformNxN(Quant* self, const CUData& cu, const pixel* fenc, uint32_t fencStride, const int16_t* residual, uint32_t resiStride, coeff_t* coeff,
                                 uint32_t log2TrSize, TextType ttype, uint32_t absPartIdx, bool useTransformSkip)
@@ -112,7 +114,7 @@ std::atomic<bool> g_dead(false); // the device failed once: every later CU is co
 std::atomic<uint64_t> g_cycles[18][2], g_calls[18][2];
 __attribute__((tls_model("initial-exec"))) thread_local int t_inRqt = 0;
 
-struct alignas(64) Counters { std::atomic<uint64_t> jobs, fwd, inv, fwdMiss, invMiss, waitCycles, waits, skipped, dist, psyHit, psyAhead, psyCoded, deadSub, deadAdd, lateSub, lateAdd, siteWaits[6], siteCycles[6], spec, specHit, psySkip; };
+struct alignas(64) Counters { std::atomic<uint64_t> jobs, fwd, inv, fwdMiss, invMiss, waitCycles, waits, skipped, dist, psyHit, psyAhead, psyCoded, deadSub, deadAdd, lateSub, lateAdd, siteWaits[6], siteCycles[6], spec, specHit, psySkip, specInter, specInterHit; };
 Counters g_count[64];
 std::atomic<int> g_nextShard(0);
 __attribute__((tls_model("initial-exec"))) thread_local int t_shard = -1;
@@ -127,6 +129,7 @@ struct Job
     uint32_t log2CU;
     int sHi, sLo;
     const Mode* mode;                    // the mode whose residual this is (its cbf flags and final reconstruction are looked at after the tree)
+    bool specInter;                      // left ahead of its scope from predInterSearch (not from the merge candidate's skip evaluation): counted apart
     bool inTree;                         // inside the top-level estimateResidualQT: transform units are looked up (afterwards only the remembered values serve)
     const Search* search;
     const pixel* fenc[3]; uint32_t fencStride[3];        // the mode's source and prediction blocks (Yuv): what identifies an sse / psy question
@@ -158,6 +161,7 @@ __attribute__((tls_model("initial-exec"))) thread_local Job t_job;
 __attribute__((tls_model("initial-exec"))) thread_local int t_inEncodeRes = 0;
 EncoderPrimitives g_prev;            // the table as it was when the cuserve slots were installed (C functions + the psy lookups of x265_hip_srcplanes.cpp)
 bool g_slots_installed = false;
+bool g_specInter = true;             // X265HIP_CUSERVE_SPEC_INTER=0: the 2Nx2N inter candidate's job leaves at its own encodeResAndCalcRdInterCU (round 4's behaviour)
 bool g_spec = true;                  // X265HIP_CUSERVE_SPEC=0: no job is submitted ahead of its scope
 int g_serveDist = 1;                 // X265HIP_CUSERVE_DIST=0: transforms only; 1: + the tree's distortions; 2: + the CU's final sse_pp / psy cost; 3 (default): + the body's sub_ps / add_ps calls nobody reads any more are not run
 __attribute__((tls_model("initial-exec"))) thread_local int t_hint = -1;           // where this thread looks first
@@ -179,12 +183,12 @@ void report_time()
 
 void report()
 {
-    uint64_t jobs = 0, fwd = 0, inv = 0, fm = 0, im = 0, wc = 0, w = 0, sk = 0, di = 0, ph = 0, pa = 0, pc = 0, dsb = 0, dad = 0, lsb = 0, lad = 0, spc = 0, sph = 0, pss = 0;
+    uint64_t jobs = 0, fwd = 0, inv = 0, fm = 0, im = 0, wc = 0, w = 0, sk = 0, di = 0, ph = 0, pa = 0, pc = 0, dsb = 0, dad = 0, lsb = 0, lad = 0, spc = 0, sph = 0, pss = 0, spi = 0, sih = 0;
     for (int i = 0; i < 64; i++)
     {
         jobs += g_count[i].jobs; fwd += g_count[i].fwd; inv += g_count[i].inv; fm += g_count[i].fwdMiss; im += g_count[i].invMiss;
         wc += g_count[i].waitCycles; w += g_count[i].waits; sk += g_count[i].skipped; di += g_count[i].dist; ph += g_count[i].psyHit; pa += g_count[i].psyAhead; pc += g_count[i].psyCoded;
-        dsb += g_count[i].deadSub; dad += g_count[i].deadAdd; lsb += g_count[i].lateSub; lad += g_count[i].lateAdd; spc += g_count[i].spec; sph += g_count[i].specHit; pss += g_count[i].psySkip;
+        dsb += g_count[i].deadSub; dad += g_count[i].deadAdd; lsb += g_count[i].lateSub; lad += g_count[i].lateAdd; spc += g_count[i].spec; sph += g_count[i].specHit; pss += g_count[i].psySkip; spi += g_count[i].specInter; sih += g_count[i].specInterHit;
     }
     uint64_t devJobs = 0, starts = 0, ns = 0;
     for (int k = 0; k < g_nsvc.load(); k++)
@@ -219,6 +223,9 @@ void report()
         fprintf(stderr, "x265hip: cuserve: %llu jobs left ahead of their scope, when the merge candidate's skip evaluation started; %llu of them were the job their "
                         "encodeResAndCalcRdInterCU wanted, %llu psy-costs of the skip evaluation served the tree as well\n", (unsigned long long)spc, (unsigned long long)sph,
                 (unsigned long long)pss);
+    if (spi)
+        fprintf(stderr, "x265hip: cuserve: %llu jobs left ahead of their scope when predInterSearch returned the 2Nx2N inter candidate's prediction; %llu of them were the job their "
+                        "encodeResAndCalcRdInterCU wanted\n", (unsigned long long)spi, (unsigned long long)sih);
     if (dsb || dad)
         fprintf(stderr, "x265hip: cuserve: %llu sub_ps and %llu add_ps calls of those CUs put off because only the job's answers read their results (%llu + %llu run after all)\n",
                 (unsigned long long)dsb, (unsigned long long)dad, (unsigned long long)lsb, (unsigned long long)lad);
@@ -261,6 +268,7 @@ bool decide()
             g_slots = 2 * cpus < 16 ? 16 : 2 * cpus > 64 ? 64 : 2 * cpus;
         }
         if (getenv("X265HIP_CUSERVE_SPEC")) g_spec = atoi(getenv("X265HIP_CUSERVE_SPEC")) != 0;
+        if (getenv("X265HIP_CUSERVE_SPEC_INTER")) g_specInter = atoi(getenv("X265HIP_CUSERVE_SPEC_INTER")) != 0;
         g_serveDist = getenv("X265HIP_CUSERVE_DIST") ? atoi(getenv("X265HIP_CUSERVE_DIST")) : 3;
         if (g_slots < 1) g_slots = 1;
         if (g_slots > 256) g_slots = 256;
@@ -1084,10 +1092,39 @@ void Search::encodeResAndCalcRdSkipCU(Mode& interMode)
         {
             j.inTree = false;
             j.phase = 0;
+            j.specInter = false;
             counters().spec.fetch_add(1, std::memory_order_relaxed);
         }
     }
     refEncodeResAndCalcRdSkipCU(this, interMode);
+}
+
+// The 2Nx2N inter candidate at rd levels 3 and 4 without rectangular partitions (Analysis::compressInterCU_rd0_4, analysis.cpp:1421-1611): its prediction
+// is final when predInterSearch returns (luma and chroma compensated, search.cpp:2181-2560), and it is ALWAYS evaluated with its residual (:1609-1611,
+// bestInter = the only inter candidate) — after checkInter_rd0_4's sa8d of the three planes and, in a B slice, after checkBidir2Nx2N has built and
+// measured the bidirectional prediction.  The job leaves here and the device works on it while this thread does that; the same adoption rule as for the
+// merge candidate (sample for sample the job's blocks, or it is dropped).
+void Search::predInterSearch(Mode& interMode, const CUGeom& cuGeom, bool bChromaMC, uint32_t refMasks[2])
+{
+    refPredInterSearch(this, interMode, cuGeom, bChromaMC, refMasks);
+    Job& j = t_job;
+    if (g_specInter && g_spec && g_state > 0 && !g_dead.load(std::memory_order_relaxed) && (int)cuGeom.log2CUSize >= g_minLog2 && !t_inEncodeRes &&
+        interMode.cu.m_partSize[0] == SIZE_2Nx2N && (bChromaMC || m_csp == X265_CSP_I400) && m_param->rdLevel >= 3 && m_param->rdLevel <= 4 &&
+        !m_param->bEnableRectInter && !m_param->bEnableAMP && !m_param->bDistributeModeAnalysis && !m_param->bLossless && !m_param->interRefine &&
+        !m_param->bDynamicRefine && !m_param->analysisLoad && !m_param->analysisSave)
+    {
+        if (j.active)
+            end_job();
+        uint32_t range[2];
+        interMode.cu.getInterTUQtDepthRange(range, 0);
+        if (submit(this, interMode, cuGeom.log2CUSize, m_rqt[cuGeom.depth].tmpResiYuv, range))
+        {
+            j.inTree = false;
+            j.phase = 0;
+            j.specInter = true;
+            counters().specInter.fetch_add(1, std::memory_order_relaxed);
+        }
+    }
 }
 
 void Search::encodeResAndCalcRdInterCU(Mode& interMode, const CUGeom& cuGeom)
@@ -1095,7 +1132,7 @@ void Search::encodeResAndCalcRdInterCU(Mode& interMode, const CUGeom& cuGeom)
     t_inEncodeRes++;
     if (t_job.active && !t_job.phase)
     {
-        if (adopt(this, interMode, cuGeom)) counters().specHit.fetch_add(1, std::memory_order_relaxed);
+        if (adopt(this, interMode, cuGeom)) (t_job.specInter ? counters().specInterHit : counters().specHit).fetch_add(1, std::memory_order_relaxed);
         else end_job();
     }
     if (g_state > 0 && !g_dead.load(std::memory_order_relaxed) && (int)cuGeom.log2CUSize >= g_minLog2 && !t_job.active)
