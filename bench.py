@@ -552,10 +552,22 @@ def encode_bench(args, rank, local_rank, world, fence, allmax):
     clip = "/tmp/x265hip_bench_%d_r%d.yuv" % (os.getpid(), rank)
     make_clip(clip, W, H, total, seed=4321)                  # every rank's chunk is a repetition of the same segment
     cores = os.cpu_count() or 1
-    per_rank = max(4, cores // world)
+    quota = host_cpu_quota()
+    usable = int(min(cores, quota)) if quota else cores      # CPUs the container's cgroup grants (16 of the 256 shown on the MI355X box)
+    per_rank = max(4, usable // world)
     base = ["--input", clip, "--input-res", "%dx%d" % (W, H), "--input-depth", "8", "--fps", "30", "--preset", "medium", "--me", "hex", "--hash", "1"]
+    threads_note = "x265's defaults"
     if world > 1:
         base += ["--pools", str(per_rank)]                   # the ranks share the host: each encoder gets its share of the cores
+        threads_note = "--pools %d (the ranks share %d usable CPUs)" % (per_rank, usable)
+    elif usable < cores:
+        # x265 sizes its pool from the cores the kernel shows and does not see the cgroup's quota: 256 pool threads on 16 CPUs' worth of quota are throttled in
+        # bursts.  The pool is sized to the quota; frame parallelism stays what x265 picks on this host (ThreadPool::getFrameThreadsCount, threadpool.cpp:661-676,
+        # from the shown cores).  Both encoders get the same arguments (profiles/r05_v1_pool_size.txt: bound 31.6-33.8 -> 36.1-36.9 fps, reference 18.4-19.3 either way)
+        ft = 5 if cores >= 32 else 4 if cores >= 16 else 3 if cores >= 8 else 2 if cores >= 4 else 1
+        base += ["--pools", str(usable), "--frame-threads", str(ft)]
+        per_rank = usable
+        threads_note = "--pools %d --frame-threads %d: the pool sized to the cgroup's CPU quota (%s of %d shown cores), frame threads as x265 picks them on this host" % (usable, ft, quota, cores)
     visible = os.environ.get("HIP_VISIBLE_DEVICES")
     env = dict(os.environ, X265HIP_VERBOSE="1", X265HIP="require", HIP_VISIBLE_DEVICES=visible.split(",")[local_rank] if visible else str(local_rank))
     out_hip, out_ref = clip + ".gpu.hevc", clip + ".ref.hevc"
@@ -570,7 +582,7 @@ def encode_bench(args, rank, local_rank, world, fence, allmax):
         dt = time.perf_counter() - t0
         if r["rc"]:
             raise SystemExit("bench.py: x265_hip_8bit failed: " + r["tail"])
-        res = {"dt": dt, "frames": frames, "cli_fps": r["fps"], "served": r["served"], "pools": per_rank if world > 1 else cores}
+        res = {"dt": dt, "frames": frames, "cli_fps": r["fps"], "served": r["served"], "pools": per_rank if (world > 1 or usable < cores) else cores, "threads_note": threads_note}
         if not args.no_ref_encoder:
             fence()
             t0 = time.perf_counter()
@@ -857,6 +869,23 @@ def main():
         # ---- CU residual quad-tree jobs: a host thread WAITS for each, so the path is built for round trip, not for bytes per second ------------------------------
         cu = clocks.get("CU residual quad-tree jobs", {})
         cu_block = None
+        # HBM bytes of ONE 32x32 CU job on the resident server (tools/exp/gpu.sh pmc: FETCH_SIZE and WRITE_SIZE of the server's dispatch / the jobs it served)
+        cu_traffic, cu_tfile, cu_tnote = None, None, "no committed PMC profile"
+        import glob as _glob
+        for f in sorted(_glob.glob(os.path.join(ROOT, "profiles", "r*_cuserve_pmc_per_job.txt")))[-1:]:
+            cu_tfile = os.path.relpath(f, ROOT)
+            stamp = None
+            for line in open(f):
+                c = line.split()
+                if line.startswith("# sources"):
+                    stamp = c[-1]
+                if c and c[0] == "srv5" and len(c) >= 7:
+                    cu_traffic = int(float(c[3]) + float(c[4]))
+                    cu_tnote = ("one 32x32 CU job (4:2:0, 8 bit) on the resident server: corrected FETCH_SIZE %s + WRITE_SIZE %s bytes per job against %s algorithmic bytes in "
+                                "(levels, residual and unit records go to page-locked host memory and are not HBM writes); from the committed profile, not collected in this run"
+                                % (c[3], c[4], c[5]))
+            if stamp != source_digest("cuserve.hip"):
+                cu_traffic, cu_tnote = None, "the committed profile was collected from other kernel sources (stamp %s): not quoted" % stamp
         if cu.get("ms") and served.get("cu"):
             c = served["cu"]
             secs = cu["ms"] * 1e-3
@@ -869,7 +898,7 @@ def main():
                         # SURVEY.md 8d's roofline for this family: fused-chain bytes of the units / the server's wall time (the timed region: the resident
                         # kernel is on the chip for all of it) / HBM peak.  It is of the order of 1e-4 and will stay there: the path is a latency chain
                         "achieved": round(cu["algorithmic_bytes"] / dt / 1e9, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": round(cu["algorithmic_bytes"] / dt / 1e9 / HBM_PEAK_GBPS, 6), "traffic": None,
+                        "frac": round(cu["algorithmic_bytes"] / dt / 1e9 / HBM_PEAK_GBPS, 6), "traffic": cu_traffic, "traffic_source": cu_tfile, "traffic_note": cu_tnote,
                         "achieved_note": "fused-chain bytes (SURVEY 8d: source + prediction in, levels + reconstructed residual out) of every unit of every job / wall clock "
                                          "of the timed region; per busy workgroup-second instead of per wall second: see `busy`",
                         "busy": {"achieved": round(ach, 3), "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 6), "note": "the same bytes / busy time of ONE workgroup (jobs run one per "
@@ -902,7 +931,7 @@ def main():
                                    "served from GPU-built fractional planes of each reference picture, psy-cost source halves from GPU-built energy planes, C slots "
                                    "otherwise; the host cores are split between the ranks" % (enc["frames"], CHUNK),
                        "frames_per_step": world * CHUNK, "encoder_cli_fps_rank0": enc["cli_fps"], "served_by_gpu": enc["served"],
-                       "host_cores": os.cpu_count(), "host_cpu_quota": host_cpu_quota(), "pool_threads_per_encoder": enc["pools"], "timed_s": round(dt, 2),
+                       "host_cores": os.cpu_count(), "host_cpu_quota": host_cpu_quota(), "pool_threads_per_encoder": enc["pools"], "threads": enc["threads_note"], "timed_s": round(dt, 2),
                        "host_note": "host_cpu_quota = CPUs the container's cgroup grants (cpu.max); when it is far below host_cores both encoders are bound by CPU seconds per "
                                     "frame and N encoders share the same budget (DESIGN.md §4c)"},
             "roofline": dominant,
@@ -923,8 +952,8 @@ def main():
             quota = host_cpu_quota()
             out["cpu_baseline"] = {"value": round(ref_fps, 3) if ref_fps else None, "unit": "frames/s",
                                    "cores": int(min(os.cpu_count() or 1, quota)) if quota else os.cpu_count(), "kind": "reference",
-                                   "cores_note": "CPUs the process tree can use at once: min(cores the kernel shows = %s, cgroup quota = %s); x265 starts one pool thread per shown core"
-                                                 % (os.cpu_count(), quota),
+                                   "cores_note": "CPUs the process tree can use at once: min(cores the kernel shows = %s, cgroup quota = %s); encoder threads: %s (the same for both encoders)"
+                                                 % (os.cpu_count(), quota, enc["threads_note"]),
                                    "sample": "the same %d chunk(s) of %d frames, same arguments (and the same --pools share at N > 1), through oracle/_ref/x265_8bit — the unmodified "
                                              "reference, [noasm] C primitives: no nasm in the image, so the AVX2 / AVX-512 path cannot be built — %d encoder(s) at the same time, "
                                              "measured like `value`: all frames / wall clock between two fences (%.1f s)" % (world, enc["frames"], world, r0["wall_s"]),

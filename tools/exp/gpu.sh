@@ -12,6 +12,8 @@
 #     pmc                  FETCH_SIZE / WRITE_SIZE per job: cuserve_rt in launch mode (one dispatch = one job), one shape per pass, counters in their own passes
 #     stress <n>           two_encoders_hip8 par looped n times (encoders alive at the same time on the real library; every other run with poisoned Analysis
 #                          objects, every third with X265HIP_REFPLANES=0), each session's bitstream compared with the reference objects' (tests/test_reference_races.py)
+#     framestats           x265's own per-frame clocks (--csv-log-level 2: DecideWait, Row0Wait, Wall, Ref Wait Wall, Total CTU time, Stall, Avg WPP, Row Blocks)
+#                          of the bound encoder and of the reference on the bench clip: where a frame encoder's wall clock goes
 #     cpuprofile           the bound encoder under the CPU sampler (tools/prof), 6 x 240 frames merged (> 10 k samples)
 set -u
 TAG=$1; shift
@@ -60,6 +62,32 @@ while [ $# -gt 0 ]; do
         for k in 0 1 2 3 4; do cmp -s $D/ref_$k.hevc $D/g_$k.hevc || { echo "run $i: session $k differs"; bad=$((bad + 1)); }; done
       done
       echo "concurrent encoders on the MI355X: $n runs (5 sessions each, two then three alive at a time), $bad mismatches or failures, $(( $(date +%s) - t0 )) s" | tee $OUT/concurrent_stress.txt ;;
+    framestats)
+      clip /tmp/bench120.yuv 120
+      for b in hip ref; do
+        exe=oracle/_ref/x265_hip_8bit; [ $b = ref ] && exe=oracle/_ref/x265_8bit
+        X265HIP=require $exe --input /tmp/bench120.yuv --input-res 1920x1080 --fps 30 --frames 120 --preset medium --me hex --csv $OUT/framestats_$b.csv --csv-log-level 2 -o /tmp/f.hevc 2>&1 | grep -E "^encoded" | tee $OUT/framestats_$b.log
+      done
+      python - $OUT <<'PY' | tee $OUT/frame_clocks.txt
+import csv, sys
+for b in ("hip", "ref"):
+    rows = [r for r in csv.reader(open("%s/framestats_%s.csv" % (sys.argv[1], b)))]
+    head = [h.strip() for h in rows[0]]
+    cols = ["DecideWait (ms)", "Row0Wait (ms)", "Wall time (ms)", "Ref Wait Wall (ms)", "Total CTU time (ms)", "Stall Time (ms)", "Total frame time (ms)", "Avg WPP", "Row Blocks"]
+    body = [r for r in rows[1:] if len(r) >= len(head) and r[0].strip().isdigit()]
+    print(b, len(body), "frames; per-frame means:")
+    for c in cols:
+        if c in head:
+            i = head.index(c)
+            v = [float(r[i]) for r in body if r[i].strip()]
+            print("   %-24s %9.2f" % (c, sum(v) / max(1, len(v))))
+    for t in ("I-SLICE", "P-SLICE", "B-SLICE", "b-SLICE"):
+        i, j, k = head.index("Wall time (ms)"), head.index("Total CTU time (ms)"), head.index("Ref Wait Wall (ms)")
+        sel = [r for r in body if r[1].strip() == t]
+        if sel:
+            print("   %s x %d: wall %.1f ms, CTU time %.1f ms, ref wait wall %.1f ms" % (t, len(sel), sum(float(r[i]) for r in sel) / len(sel), sum(float(r[j]) for r in sel) / len(sel), sum(float(r[k]) for r in sel) / len(sel)))
+PY
+      ;;
     pmc)
       HERE=$PWD
       for shape in cu5 cu6 sao; do for c in fetch:FETCH_SIZE write:WRITE_SIZE; do

@@ -28,6 +28,9 @@ def launches(d, counter):
 
 def main():
     root = sys.argv[1]
+    import hashlib
+    here = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    print("# sources %s" % hashlib.sha256(open(os.path.join(here, "x265_amd", "csrc", "cuserve.hip"), "rb").read()).hexdigest()[:16])
     print("# per-launch HBM traffic of one CU job / one SAO statistics job (launch mode: one dispatch = one job), rocprofv3 --pmc, separate passes")
     print("# corrected = raw KiB x 1024 x factor (FETCH_SIZE x%.1f, WRITE_SIZE x%.1f: profiles/r04_v1_pmc_calibration.txt)" % (FETCH_FACTOR, WRITE_FACTOR))
     print("%-6s %-34s %9s %14s %14s %16s %16s" % ("shape", "kernel", "launches", "fetch_B/job", "write_B/job", "algorithmic_in_B", "algorithmic_out_B"))
