@@ -522,6 +522,33 @@ def test_bound_encoder_sao_statistics_jobs_stay_byte_identical(tmp_path, extra):
     assert m and int(m.group(1)) > 100 and int(m.group(3)) == 0, r.stderr[-800:]
 
 
+@pytest.mark.parametrize("extra", [[], ["--bframes", "0"], ["--rd", "4"], ["--preset", "slow"]], ids=lambda e: "-".join(x.strip("-") for x in e) or "medium")
+def test_bound_encoder_inter_candidate_jobs_ahead_stay_byte_identical(tmp_path, extra):
+    """X265HIP_CUSERVE_SPEC_INTER=1 (off by default): the 2Nx2N inter candidate's job leaves when Search::predInterSearch returns and is adopted by
+    encodeResAndCalcRdInterCU sample for sample (analysis.cpp:1421-1611).  Every such job must be the one wanted; with rectangular partitions (preset slow)
+    none may leave."""
+    import re, subprocess, sys
+    sys.path.insert(0, ROOT)
+    ref, emul = os.path.join(ROOT, "oracle", "_ref", "x265_8bit"), os.path.join(ROOT, "oracle", "_ref", "x265_emul_8bit")
+    if not (os.path.exists(ref) and os.path.exists(emul)):
+        pytest.skip("oracle/_ref encoders not built (make -C oracle ref emul)")
+    from x265_amd.synth import make_clip
+    yuv = str(tmp_path / "clip.yuv")
+    make_clip(yuv, 416, 240, 8, seed=79)
+    args = ["--input", yuv, "--input-res", "416x240", "--fps", "30", "--frames", "8", "--preset", "medium", "--hash", "1", "--pools", "4", "-F", "2"] + extra
+    want, got = str(tmp_path / "ref.hevc"), str(tmp_path / "emul.hevc")
+    assert subprocess.run([ref] + args + ["-o", want], capture_output=True, timeout=600).returncode == 0
+    r = subprocess.run([emul] + args + ["-o", got], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, X265HIP="require", X265HIP_VERBOSE="1", X265HIP_VERIFY="1", X265HIP_CUSERVE_SPEC_INTER="1"))
+    assert r.returncode == 0, r.stderr[-800:]
+    assert open(got, "rb").read() == open(want, "rb").read()
+    m = re.search(r"(\d+) jobs left ahead of their scope when predInterSearch returned .*?; (\d+) of them were the job", r.stderr)
+    if "slow" in extra:
+        assert not m, r.stderr[-800:]
+    else:
+        assert m and int(m.group(1)) > 50 and m.group(1) == m.group(2), r.stderr[-800:]
+
+
 class _Chk:
     """hp-like holder for _run_on over the emulated library (no HipError there)"""
     from x265_amd import hipprim as _hp
