@@ -970,6 +970,29 @@ X265HIP_HD static inline int x265hipi_saojob_pixel_bytes(const x265hip_saojob* j
  * *seq = the ticket */
 int x265hip_cuserve_submit_sao(x265hip_cuserve* cs, int slot, const x265hip_saojob* job, uint32_t* seq);
 
+/* Intra mode scan as a job of the same service: the distortion half of Search::checkIntraInInter (search.cpp:1291-1452) for ONE block —
+ * sa8d(source block, prediction of mode m) for all 35 modes, exactly the calls the reference makes (DC edge-smoothed when N <= 16, planar from the
+ * filtered line when N >= 8, each angle from the raw or the filtered line as g_intraFilterFlags says, the mode 10 / 26 edge gradient when N <= 16;
+ * cu[].sa8d: sa8d_8x8, one rounding per 16x16 above).  The arithmetic of x265hip_intra_scan_batch, one block per job, the round trip of a CU job.
+ * Pixel block (samples: bytes at 8 bit, uint16_t above): the unfiltered neighbour line in the reference's array layout (Predict::initAdiPattern:
+ * [0] corner, [1..2N] top + top-right, [2N+1..4N] left + bottom-left) at sample 0, the [1 2 1] filtered line at sample 4N + 16, the N x N source
+ * block (stride N) at sample 2 * (4N + 16).  Results: units[0].ready = units[0].readyInv = the ticket; the 35 costs as int32 at the start of
+ * the slot's `levels` block (cost of mode m at index m). */
+#define X265HIP_INTRAJOB_MARK 0x100u
+typedef struct x265hip_intrajob
+{
+    uint32_t bitDepth;      /* 8, 10 or 12 */
+    uint32_t mark;          /* X265HIP_INTRAJOB_MARK: where an SAO statistics job holds its plane count (both kinds travel under the same ticket class) */
+    uint32_t log2Size;      /* 3, 4 or 5 */
+    uint32_t reserved;
+} x265hip_intrajob;
+X265HIP_HD static inline int x265hipi_intrajob_line_samples(int log2Size) { return (4 << log2Size) + 16; }
+X265HIP_HD static inline int x265hipi_intrajob_pixel_bytes(const x265hip_intrajob* j)
+{
+    return (2 * x265hipi_intrajob_line_samples((int)j->log2Size) + (1 << (2 * j->log2Size))) * (j->bitDepth > 8 ? 2 : 1);
+}
+int x265hip_cuserve_submit_intra(x265hip_cuserve* cs, int slot, const x265hip_intrajob* job, uint32_t* seq);
+
 #ifdef __cplusplus
 }
 #endif

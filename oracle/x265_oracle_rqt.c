@@ -255,3 +255,39 @@ int orc_saojob_run_8(const x265hip_saojob* j, const uint8_t* pixels, x265hip_cuj
     }
     return (int)j->planes;
 }
+
+/* ---- intra mode scan jobs (include/x265hip.h, x265hip_intrajob): what Search::checkIntraInInter (search.cpp:1291-1452) measures for one block —
+ * for each of the 35 modes the prediction the reference would make (DC with edge smoothing when N <= 16, :1356; planar from the filtered line when
+ * N >= 8, :1363-1367; every angle from the line g_intraFilterFlags picks, with the mode 10 / 26 edge gradient when N <= 16, :1376 / :1388) and
+ * cu[].sa8d against the source block (:1357, :1368, :1383-1387).  Composed from the pinned primitives of x265_oracle_intra.c and x265_oracle.c. */
+int orc_intrajob_run(const x265hip_intrajob* j, const void* pixels, x265hip_cujob_unit* units, int32_t* out, uint32_t seq)
+{
+    const int n = 1 << j->log2Size, line = x265hipi_intrajob_line_samples((int)j->log2Size), bFilter = n <= 16;
+    if (j->bitDepth == 8)
+    {
+        const uint8_t* raw = (const uint8_t*)pixels;
+        const uint8_t* flt = raw + line;
+        const uint8_t* fenc = raw + 2 * line;
+        uint8_t pred[32 * 32];
+        for (int mode = 0; mode < 35; mode++)
+        {
+            orc_intra_pred_8(n, mode, pred, n, orc_intra_uses_filtered_8(n, mode) ? flt : raw, bFilter, 8);
+            out[mode] = orc_sa8d_8(fenc, n, pred, n, n);
+        }
+    }
+    else
+    {
+        const uint16_t* raw = (const uint16_t*)pixels;
+        const uint16_t* flt = raw + line;
+        const uint16_t* fenc = raw + 2 * line;
+        uint16_t pred[32 * 32];
+        for (int mode = 0; mode < 35; mode++)
+        {
+            orc_intra_pred_16(n, mode, pred, n, orc_intra_uses_filtered_16(n, mode) ? flt : raw, bFilter, (int)j->bitDepth);
+            out[mode] = orc_sa8d_16(fenc, n, pred, n, n);
+        }
+    }
+    units[0].readyInv = seq;
+    units[0].ready = seq;
+    return 35;
+}

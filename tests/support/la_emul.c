@@ -795,6 +795,24 @@ int x265hip_cuserve_submit_sao(x265hip_cuserve* cs, int slot, const x265hip_saoj
     orc_saojob_run_8(job, s->pixels, s->units, (int32_t*)s->levels, *seq);
     return 0;
 }
+int orc_intrajob_run(const x265hip_intrajob* j, const void* pixels, x265hip_cujob_unit* units, int32_t* out, uint32_t seq);
+int x265hip_cuserve_submit_intra(x265hip_cuserve* cs, int slot, const x265hip_intrajob* job, uint32_t* seq)
+{
+    if (fail_now("cuserve_submit_intra")) return X265HIP_EHIP;
+    if (!cs || slot < 0 || slot >= cs->slots || !job || !seq || (job->bitDepth != 8 && job->bitDepth != 10 && job->bitDepth != 12) ||
+        job->mark != X265HIP_INTRAJOB_MARK || job->log2Size < 3 || job->log2Size > 5)
+        return X265HIP_EINVAL;
+    cu_slot* s = cs->slot + slot;
+    *seq = ++s->seq;
+    __atomic_fetch_add(&cs->jobs, 1, __ATOMIC_RELAXED);
+    if (__atomic_load_n(&cs->lost, __ATOMIC_RELAXED) || fail_now("intrascan_job"))
+    {
+        __atomic_store_n(&cs->lost, 1, __ATOMIC_RELAXED);
+        return 0;
+    }
+    orc_intrajob_run(job, s->pixels, s->units, (int32_t*)s->levels, *seq);
+    return 0;
+}
 int x265hip_cuserve_poke(x265hip_cuserve* cs, int slot) { (void)slot; return cs && __atomic_load_n(&cs->lost, __ATOMIC_RELAXED) ? X265HIP_EHIP : 0; }
 int x265hip_cuserve_stats(x265hip_cuserve* cs, uint64_t* jobs, uint64_t* serverStarts, uint64_t* deviceNs)
 {

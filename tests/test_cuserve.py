@@ -32,6 +32,10 @@ def _orc():
         f = getattr(L, "orc_cujob_run_" + sfx)
         f.restype, f.argtypes = i32, [vp, vp, vp, vp, vp, u32]
     L.orc_saojob_run_8.restype, L.orc_saojob_run_8.argtypes = i32, [vp, vp, vp, vp, u32]
+    L.orc_intrajob_run.restype, L.orc_intrajob_run.argtypes = i32, [vp, vp, vp, vp, u32]
+    for sfx in ("8", "16"):
+        f = getattr(L, "orc_intra_filter_" + sfx)
+        f.restype, f.argtypes = None, [i32, vp, vp]
     return L
 
 
@@ -520,6 +524,163 @@ def test_bound_encoder_sao_statistics_jobs_stay_byte_identical(tmp_path, extra):
     assert open(got, "rb").read() == open(want, "rb").read()
     m = re.search(r"saostats: SAO statistics of (\d+) CTU planes .*? in (\d+) jobs, (\d+) planes on the host", r.stderr)
     assert m and int(m.group(1)) > 100 and int(m.group(3)) == 0, r.stderr[-800:]
+
+
+# ---- intra scan jobs (x265hip_intrajob) -----------------------------------------------------------------------------------------------------------
+
+def _intra_job(hp, rng, log2n, depth, wild):
+    """a job as Search::checkIntraInInter's seam builds it: the unfiltered neighbour line of a textured block (or, `wild`, unrelated samples: large costs,
+    clipping edge gradients), its [1 2 1] filtered twin (oracle primitive), the source block"""
+    n = 1 << log2n
+    pix = np.uint8 if depth == 8 else np.uint16
+    pmax = (1 << depth) - 1
+    line = 4 * n + 16
+    j = hp.IntraScanJob()
+    j.bitDepth, j.mark, j.log2Size = depth, hp.INTRAJOB_MARK, log2n
+    base = int(rng.integers(0, pmax - 40))
+    fenc = (base + rng.integers(0, 40, (n, n)) + np.add.outer(np.arange(n), np.arange(n)) // 3).clip(0, pmax).astype(pix)
+    raw = rng.integers(0, pmax + 1, 4 * n + 1).astype(pix) if wild else (base + rng.integers(0, 40, 4 * n + 1)).clip(0, pmax).astype(pix)
+    O = _orc()
+    flt = np.zeros(4 * n + 1, pix)
+    getattr(O, "orc_intra_filter_%d" % (8 if depth == 8 else 16))(n, raw.ctypes.data, flt.ctypes.data)
+    blob = np.zeros(2 * line + n * n, pix)
+    blob[:4 * n + 1] = raw
+    blob[line:line + 4 * n + 1] = flt
+    blob[2 * line:] = fenc.ravel()
+    return j, blob
+
+
+def _oracle_intra(hp, O, j, pix):
+    units = (hp.CuJobUnit * hp.CUJOB_MAX_UNITS)()
+    out = np.zeros(35, np.int32)
+    assert O.orc_intrajob_run(C.byref(j), pix.ctypes.data, C.byref(units), out.ctypes.data, 1) == 35
+    return out
+
+
+def _run_intra_on(hp, L, cs, slot, j, pix, timeout=20.0):
+    job, pixels, units, levels, resi = vp(), vp(), vp(), vp(), vp()
+    hp.check(L.x265hip_cuserve_slot(cs, slot, C.byref(job), C.byref(pixels), C.byref(units), C.byref(levels), C.byref(resi)))
+    C.memmove(pixels, pix.ctypes.data, pix.nbytes)
+    seq = u32()
+    hp.check(L.x265hip_cuserve_submit_intra(cs, slot, C.byref(j), C.byref(seq)))
+    un = C.cast(units, C.POINTER(hp.CuJobUnit))
+    t0 = time.time()
+    while un[0].ready != seq.value:
+        pk = L.x265hip_cuserve_poke(cs, slot)
+        if pk < 0:
+            hp.check(pk)
+        assert time.time() - t0 < timeout, "intra scan job not finished after %.0f s" % timeout
+    _intra_ticks.setdefault(j.log2Size, []).append(int(un[0].fwdTicks))
+    return np.ctypeslib.as_array(C.cast(levels, C.POINTER(C.c_int32)), (35,)).copy()
+
+
+_intra_ticks = {}    # log2 size -> the device's own clock, doorbell seen -> costs out (100 MHz ticks), of the jobs run so far
+
+
+def test_intra_job_restatement_is_the_pinned_primitives():
+    """orc_intrajob_run against the composition the table-primitive test pins (tests/test_hip_parity.py::test_intra_mode_scan_matches_oracle): prediction of
+    each mode from the line the filter flags pick, then sa8d — here through the numpy-facing oracle wrappers"""
+    from x265_amd import hipprim as hp
+    from backends import Orc
+    O = _orc()
+    rng = np.random.default_rng(5)
+    for depth in (8, 10):
+        o = Orc(depth)
+        for log2n in (3, 4, 5):
+            n = 1 << log2n
+            j, blob = _intra_job(hp, rng, log2n, depth, False)
+            got = _oracle_intra(hp, O, j, blob)
+            line = 4 * n + 16
+            raw, flt, fenc = blob[:4 * n + 1], blob[line:line + 4 * n + 1], blob[2 * line:].reshape(n, n)
+            for mode in range(35):
+                pred = o.intra_pred(n, mode, flt if o.intra_uses_filtered(n, mode) else raw, 1 if n <= 16 else 0)
+                assert got[mode] == o.sa8d(n, fenc, (0, 0), pred, (0, 0)), (depth, n, mode)
+
+
+def test_emulated_intra_jobs_are_the_restatement():
+    from x265_amd import hipprim as hp
+    if not os.path.exists(EMUL):
+        pytest.skip("tests/support/libx265hip_emul.so not built (make -C oracle emul)")
+    E = C.CDLL(EMUL)
+    for name, (res, args) in hp.PROTOTYPES.items():
+        if name.startswith("x265hip_cuserve_"):
+            fn = getattr(E, name)
+            fn.restype, fn.argtypes = res, args
+    O = _orc()
+    cs = vp()
+    assert E.x265hip_cuserve_open(2, 0, C.byref(cs)) == 0
+    try:
+        rng = np.random.default_rng(6)
+        for it in range(12):
+            j, blob = _intra_job(hp, rng, 3 + it % 3, (8, 10, 12)[it % 3 if it > 5 else 0], it % 4 == 3)
+            assert np.array_equal(_run_intra_on(_Chk, E, cs, it % 2, j, blob), _oracle_intra(hp, O, j, blob)), it
+    finally:
+        assert E.x265hip_cuserve_close(cs) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 0])
+def test_device_intra_jobs_match_the_restatement(mode):
+    """intra scan jobs on the MI355X against the restatement: 8x8 / 16x16 / 32x32, 8 / 10 / 12 bit, textured and unrelated neighbours; mixed with CU jobs
+    and SAO statistics jobs on the same slots"""
+    from x265_amd import hipprim as hp
+    L = hp.lib()
+    hp.check(L.x265hip_init(0))
+    O = _orc()
+    cs = vp()
+    hp.check(L.x265hip_cuserve_open(4, mode, C.byref(cs)))
+    try:
+        rng = np.random.default_rng(91 + mode)
+        scans = 0
+        for it in range(180):
+            if it % 7 == 5:
+                j = _job_header(hp, 5, 5, 4, 1, 8, (30, 29, 29), 0, 1)
+                pix = _job_pixels(rng, 5, 1, 8, 1)
+                done, wu, wl, wr = _oracle_job(hp, O, j, pix)
+                _compare(hp, j, _run_on(hp, L, cs, it % 4, j, pix), wu, wl, wr, ("cu job between intra jobs", it))
+                continue
+            if it % 7 == 6:
+                sj, spix = _sao_job(hp, rng, 3, True)
+                _same_sao(sj, _run_sao_on(hp, L, cs, it % 4, sj, spix), _oracle_sao(hp, O, sj, spix), ("sao job between intra jobs", it))
+                continue
+            j, blob = _intra_job(hp, rng, 3 + it % 3, (8, 10, 12)[(it // 3) % 3], it % 5 == 4)
+            got, want = _run_intra_on(hp, L, cs, it % 4, j, blob), _oracle_intra(hp, O, j, blob)
+            assert np.array_equal(got, want), (mode, it, j.log2Size, j.bitDepth, np.nonzero(got != want)[0][:6], got[:4], want[:4])
+            scans += 1
+        assert scans > 100
+        print("intra scan jobs, device time (doorbell seen -> costs out), mode %d: " % mode +
+              ", ".join("%dx%d median %.1f us" % (1 << k, 1 << k, sorted(v)[len(v) // 2] / 100.0) for k, v in sorted(_intra_ticks.items())))
+        _intra_ticks.clear()
+    finally:
+        hp.check(L.x265hip_cuserve_close(cs))
+
+
+@pytest.mark.parametrize("extra,env", [([], {}), (["--bframes", "0"], {}), (["--fast-intra"], {}), (["--constrained-intra"], {}), (["--no-strong-intra-smoothing", "--rd", "2"], {}),
+                                       (["--b-intra", "--preset", "slow"], {}), (["--ctu", "32"], {"X265HIP_INTRASCAN_AHEAD": "0", "X265HIP_INTRASCAN_SYNC_MIN": "4"})],
+                         ids=lambda v: ("-".join(x.strip("-") for x in v) or "medium") if isinstance(v, list) else ("sync" if v else "ahead"))
+def test_bound_encoder_intra_scan_jobs_stay_byte_identical(tmp_path, extra, env):
+    """Search::checkIntraInInter's 35-mode scan served by jobs (emulated ABI).  X265HIP_VERIFY: the table slots also do the reference's work and every cost
+    the job returns is compared with the sa8d the reference measures, mode by mode; jobs submitted ahead must be adopted whenever the intra try comes."""
+    import re, subprocess, sys
+    sys.path.insert(0, ROOT)
+    ref, emul = os.path.join(ROOT, "oracle", "_ref", "x265_8bit"), os.path.join(ROOT, "oracle", "_ref", "x265_emul_8bit")
+    if not (os.path.exists(ref) and os.path.exists(emul)):
+        pytest.skip("oracle/_ref encoders not built (make -C oracle ref emul)")
+    from x265_amd.synth import make_clip
+    yuv = str(tmp_path / "clip.yuv")
+    make_clip(yuv, 416, 240, 10, seed=80)
+    args = ["--input", yuv, "--input-res", "416x240", "--fps", "30", "--frames", "10", "--preset", "medium", "--hash", "1", "--pools", "4", "-F", "2"] + extra
+    want, got = str(tmp_path / "ref.hevc"), str(tmp_path / "emul.hevc")
+    assert subprocess.run([ref] + args + ["-o", want], capture_output=True, timeout=600).returncode == 0
+    for verify in ({"X265HIP_VERIFY": "1"}, {}):
+        r = subprocess.run([emul] + args + ["-o", got], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, X265HIP="require", X265HIP_VERBOSE="1", **verify, **env))
+        assert r.returncode == 0, r.stderr[-800:]
+        assert open(got, "rb").read() == open(want, "rb").read()
+        m = re.search(r"intrascan: the 35-mode sa8d scans of (\d+) blocks .*? in (\d+) jobs, .*?; (\d+) jobs left ahead when predInterSearch returned, (\d+) of them adopted", r.stderr)
+        assert m and int(m.group(1)) > 20, r.stderr[-800:]
+        if not env:
+            assert int(m.group(3)) >= int(m.group(1)) and m.group(4) == m.group(1), r.stderr[-800:]      # every intra try found its job ahead, and it was the right one
 
 
 @pytest.mark.parametrize("extra", [[], ["--bframes", "0"], ["--rd", "4"], ["--preset", "slow"]], ids=lambda e: "-".join(x.strip("-") for x in e) or "medium")

@@ -27,6 +27,7 @@ POINTS = {
     "sadsurf_attach": ("sadplanes", [1, 4]),
     "cuserve_open": ("cuserve", [1]), "cuserve_submit": ("cuserve", [1, 50]), "cuserve_job": ("cuserve", [1, 37]),
     "cuserve_submit_sao": ("saostats", [1, 20]), "saostats_job": ("saostats", [1, 11]),
+    "cuserve_submit_intra": ("intrascan", [1, 15]), "intrascan_job": ("intrascan", [1, 9]),
 }
 OPTIONAL = {"la_put_vectors", "la_weights"}          # not reached by every clip: the byte comparison still counts, the message is not demanded
 
@@ -66,7 +67,7 @@ def test_without_failures_the_seams_serve(clip_and_reference):
     yuv, want, d = clip_and_reference
     r, got = _encode(yuv, d, {}, "plain")
     assert r.returncode == 0 and got == want, r.stderr[-600:]
-    for word in ("lookahead:", "refplanes:", "srcplanes:", "sadplanes:", "cuserve:", "saostats:"):
+    for word in ("lookahead:", "refplanes:", "srcplanes:", "sadplanes:", "cuserve:", "saostats:", "intrascan:"):
         assert any(l.startswith("x265hip: " + word) for l in r.stderr.splitlines()), (word, r.stderr[-1200:])
     assert "OFF from here on" not in r.stderr
 

@@ -14,6 +14,7 @@
 #                          objects, every third with X265HIP_REFPLANES=0), each session's bitstream compared with the reference objects' (tests/test_reference_races.py)
 #     framestats           x265's own per-frame clocks (--csv-log-level 2: DecideWait, Row0Wait, Wall, Ref Wait Wall, Total CTU time, Stall, Avg WPP, Row Blocks)
 #                          of the bound encoder and of the reference on the bench clip: where a frame encoder's wall clock goes
+#     callers <regex>      who calls the functions matching <regex>: one 240-frame run under the sampler with call chains (X265HIP_CPUSAMPLE_STACK=1), tools/prof/callers.py
 #     cpuprofile           the bound encoder under the CPU sampler (tools/prof), 6 x 240 frames merged (> 10 k samples)
 set -u
 TAG=$1; shift
@@ -88,6 +89,11 @@ for b in ("hip", "ref"):
             print("   %s x %d: wall %.1f ms, CTU time %.1f ms, ref wait wall %.1f ms" % (t, len(sel), sum(float(r[i]) for r in sel) / len(sel), sum(float(r[j]) for r in sel) / len(sel), sum(float(r[k]) for r in sel) / len(sel)))
 PY
       ;;
+    callers)
+      pat=$1; shift
+      clip /tmp/bench240.yuv 240
+      X265HIP_CPUSAMPLE_STACK=1 X265HIP_CPUSAMPLE_OUT=/tmp/cs.bin LD_PRELOAD=tools/prof/libcpusample.so oracle/_ref/x265_hip_8bit --input /tmp/bench240.yuv --input-res 1920x1080 --fps 30 --frames 240 --preset medium --me hex --pools 16 -F 5 -o /tmp/p.hevc 2>&1 | grep -E "^encoded" > $OUT/callers_run.log
+      python tools/prof/callers.py /tmp/cs.bin "$pat" 25 > $OUT/callers.txt 2>&1; head -60 $OUT/callers.txt | cut -c1-250 ;;
     pmc)
       HERE=$PWD
       for shape in cu5 cu6 sao; do for c in fetch:FETCH_SIZE write:WRITE_SIZE; do

@@ -77,5 +77,15 @@ for k in range(min(n, ns)):
     fr = [name_of(x) for x in stacks[k * DEPTH:(k + 1) * DEPTH] if x]
     chains[" <- ".join(fr[:8])] += 1
 print("%d of %d samples match %s" % (hits, min(n, ns), sys.argv[2]))
+# by the first frame that does not itself match: the caller the matched leaf works for
+first = collections.Counter()
+for c, v in chains.items():
+    fr = c.split(" <- ")
+    who = next((f for f in fr if not pat.search(f)), "?")
+    first[who] += v
+print("by first caller outside the pattern:")
+for c, v in first.most_common(20):
+    print("%5d  %5.1f %%  %s" % (v, 100.0 * v / max(1, hits), c))
+print("call chains:")
 for c, v in chains.most_common(top):
     print("%5d  %s" % (v, c))

@@ -24,6 +24,7 @@
 #include "common.h"
 #include "dctcore.h"
 #include "tiles.h"
+#include "intra_dev.h"
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -699,6 +700,139 @@ __device__ __forceinline__ void run_sao(SlotOut* s, JobLds& L, uint32_t seq, uin
     }
 }
 
+// ---- intra mode scan jobs (x265hip_intrajob): sa8d of all 35 predictions of one block, intra.hip's intra_scan_kernel with the lines and the source block
+// in the job's LDS copy.  A lane = one 4x4 tile whose 16 predicted samples are made in registers; a 32x32 block is one mode per wave and pass (9 passes of
+// the workgroup), a 16x16 block four modes per wave (3 passes), an 8x8 block sixteen (1 pass).
+template <typename P>
+__device__ __forceinline__ void run_intra(SlotOut* s, JobLds& L, uint32_t seq, uint64_t t0)
+{
+    const x265hip_intrajob& j = *reinterpret_cast<const x265hip_intrajob*>(&L.job);
+    const int log2n = (int)j.log2Size, n = 1 << log2n, n2 = 2 * n, depth = (int)j.bitDepth, maxv = (1 << depth) - 1;
+    const int lineSamples = x265hipi_intrajob_line_samples(log2n);
+    const P* raw = reinterpret_cast<const P*>(L.pix);
+    const P* fenc = raw + 2 * lineSamples;
+    // LDS over tile[]: [0..34] the costs (ints); from byte 256 the two lines CENTRED — c[j], j in [-2N, 2N]: 0 the corner, +j top / top-right, -j left /
+    // bottom-left (intra_dev.h) — as 16-bit samples, the filtered line 320 entries behind the unfiltered one: every read below is one ds_read_u16, no select
+    int* costs = reinterpret_cast<int*>(&L.tile[0]);
+    uint16_t* cen = reinterpret_cast<uint16_t*>(&L.tile[0]) + 128;
+    constexpr int kFlt = 320;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * (4 * n + 1); i += 256)
+    {
+        const int which = i >= 4 * n + 1, e = which ? i - (4 * n + 1) : i, jj = e - n2;
+        cen[which * kFlt + e] = (uint16_t)raw[which * lineSamples + (jj >= 0 ? jj : n2 - jj)];
+    }
+    const int tiles = (n >> 2) * (n >> 2);
+    const int T = tiles >= 64 ? 64 : tiles;
+    const int jpw = 64 / T, sub = lane & (T - 1);
+    const bool bFilter = n <= 16;
+    // tile order as in pixel.hip: 16x16 blocks in raster order, inside them 8x8 blocks, inside them the four 4x4 quadrants (one DPP quad)
+    const int n16x = n >= 16 ? (n >> 4) : 1;
+    const int b16 = sub >> 4, b8 = (sub >> 2) & 3, q = sub & 3;
+    int x = (b16 % n16x) * 16 + (b8 & 1) * 8 + (q & 1) * 4;
+    int y = (b16 / n16x) * 16 + (b8 >> 1) * 8 + (q >> 1) * 4;
+    if (n == 8) { x = (q & 1) * 4; y = (q >> 1) * 4; }
+    int fe[16];
+#pragma unroll
+    for (int yy = 0; yy < 4; yy++)
+        load4(fenc + (y + yy) * n + x, &fe[4 * yy]);
+    __syncthreads();
+    const uint16_t* cr = cen + n2;                            // the unfiltered line, centred
+    int dcv = n;
+    for (int i = 1; i <= n; i++)
+        dcv += (int)cr[i] + (int)cr[-i];
+    dcv >>= log2n + 1;
+    for (int base = 0; base < 35; base += 4 * jpw)
+    {
+        const int want = base + wave * jpw + lane / T;
+        const bool ok = want < 35;
+        const int mode = ok ? want : 34;
+        int m[16];
+        // ---- the angular prediction of every lane's mode, branch-free (modes 0 and 1 run it as mode 2 and are overwritten below).  intra_dev.h's
+        // ang_sample with the f == 0 case folded into the interpolation — ((32 - 0) * s0 + 16) >> 5 == s0 — and the line read from the centred copy
+        {
+            const int am = mode < 2 ? 2 : mode;
+            const bool horiz = am < 18;
+            const int rel = horiz ? 10 - am : am - 26;
+            const int sgn = horiz ? -1 : 1;
+            const int angle = kIntraAngle[8 + rel];
+            const int inv = rel < 0 ? kIntraInvAngle[-rel - 1] : 0;
+            const uint16_t* c = cr + (intra_uses_filtered(n, am) ? kFlt : 0);
+            const bool edge = bFilter && angle == 0;
+            const int corner = (int)c[0];
+#pragma unroll
+            for (int yy = 0; yy < 4; yy++)
+#pragma unroll
+                for (int xx = 0; xx < 4; xx++)
+                {
+                    const int px = x + xx, py = y + yy;
+                    const int u = horiz ? py : px, v = horiz ? px : py;
+                    const int t = (v + 1) * angle;
+                    const int k = (t >> 5) + u + 1, f = t & 31;
+                    const int j0 = k >= 0 ? sgn * k : -sgn * ((128 - k * inv) >> 8);
+                    const int k1 = k + 1;
+                    const int j1 = k1 >= 0 ? sgn * k1 : -sgn * ((128 - k1 * inv) >> 8);
+                    int val = ((32 - f) * (int)c[j0] + f * (int)c[j1] + 16) >> 5;
+                    // pure vertical / horizontal with edge smoothing: the first column / row follows the gradient of the other arm (intrapred.cpp:146-151)
+                    const int g = (int)c[sgn] + (((int)c[-sgn * (v + 1)] - corner) >> 1);
+                    const int gc = g < 0 ? 0 : (g > maxv ? maxv : g);
+                    val = (edge && u == 0) ? gc : val;
+                    m[4 * yy + xx] = val;
+                }
+        }
+        // ---- planar and DC: two of the 35, taken only by the waves that hold them
+        if (__builtin_amdgcn_ballot_w64(mode < 2) != 0)
+        {
+            const uint16_t* cp = cr + (n >= 8 ? kFlt : 0);    // planar reads the filtered line when N >= 8 (search.cpp:1363-1365)
+#pragma unroll
+            for (int yy = 0; yy < 4; yy++)
+#pragma unroll
+                for (int xx = 0; xx < 4; xx++)
+                {
+                    const int px = x + xx, py = y + yy;
+                    const int planar = ((n - 1 - px) * (int)cp[-(py + 1)] + (px + 1) * (int)cp[n + 1] + (n - 1 - py) * (int)cp[px + 1] + (py + 1) * (int)cp[-(n + 1)] + n) >> (log2n + 1);
+                    int dc = dcv;
+                    if (bFilter && !(px && py))
+                        dc = (px == 0 && py == 0) ? ((int)cr[1] + (int)cr[-1] + 2 * dcv + 2) >> 2
+                                                  : ((py == 0 ? (int)cr[px + 1] : (int)cr[-(py + 1)]) + 3 * dcv + 2) >> 2;
+                    m[4 * yy + xx] = mode == 0 ? planar : mode == 1 ? dc : m[4 * yy + xx];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            m[i] = fe[i] - m[i];
+        hadamard4x4(m);
+        const int raw8 = quad_sa8d_raw(m, lane);
+        int acc;
+        if (n >= 16)
+        {
+            const int s16 = group_sum((lane & 3) == 0 ? raw8 : 0, 16);
+            acc = (lane & 15) == 0 ? ((s16 + 2) >> 2) : 0;     // sa8d_16x16: four raw 8x8, one rounding (pixel.cpp:341-350)
+        }
+        else
+            acc = (lane & 3) == 0 ? ((raw8 + 2) >> 2) : 0;     // sa8d_8x8 (pixel.cpp:336)
+        acc = group_sum(acc, T);
+        if (ok && sub == 0)
+            costs[mode] = acc;
+    }
+    __syncthreads();
+    if (tid < 64)
+    {
+        int32_t* out = reinterpret_cast<int32_t*>(s->levels);
+        if (tid < 35)
+            out[tid] = costs[tid];
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        if (tid == 0)
+        {
+            s->units[0].fwdTicks = (uint32_t)(wall_clock64() - t0);
+            __hip_atomic_store(&s->units[0].readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&s->units[0].ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    __syncthreads();
+}
+
 // one job: `ticket` says how many bytes the job holds, so header and pixels arrive in one round trip
 __device__ __forceinline__ void run_job(const SlotIn* sin, SlotOut* s, JobLds& L, uint32_t ticket, uint64_t* busyTicks)
 {
@@ -710,7 +844,13 @@ __device__ __forceinline__ void run_job(const SlotIn* sin, SlotOut* s, JobLds& L
     for (int i = tid; i < chunks; i += 256)
         out[i] = in[i];
     __syncthreads();
-    if ((ticket & 3) == 3) run_sao(s, L, ticket, t0);
+    if ((ticket & 3) == 3)
+    {
+        const x265hip_intrajob& ij = *reinterpret_cast<const x265hip_intrajob*>(&L.job);
+        if (!(ij.mark & X265HIP_INTRAJOB_MARK)) run_sao(s, L, ticket, t0);
+        else if (ij.bitDepth > 8) run_intra<uint16_t>(s, L, ticket, t0);
+        else run_intra<uint8_t>(s, L, ticket, t0);
+    }
     else if (ticket & 8) run_tiles<uint16_t>(s, L, ticket, t0);
     else run_tiles<uint8_t>(s, L, ticket, t0);
     __syncthreads();
@@ -838,7 +978,7 @@ struct x265hip_cuserve
     std::atomic<uint32_t>* seq = nullptr;         // per slot
     std::atomic<uint32_t> generation{ 0 };
     std::mutex launchLock;
-    std::atomic<uint64_t> jobs{ 0 }, starts{ 0 }, bytes{ 0 }, saoJobs{ 0 };
+    std::atomic<uint64_t> jobs{ 0 }, starts{ 0 }, bytes{ 0 }, saoJobs{ 0 }, intraJobs{ 0 };
     std::atomic<int> paused{ 0 };                 // servers_pause() callers in progress: no server is started meanwhile
     uint64_t idleUs = 2000;
 };
@@ -1162,6 +1302,44 @@ int x265hip_cuserve_submit_sao(x265hip_cuserve* cs, int slot, const x265hip_saoj
         const hipError_t le = hipGetLastError();
         if (cur >= 0 && cur != cs->device) (void)hipSetDevice(cur);
         if (le != hipSuccess) return check_hip(le, "cu_job_kernel (SAO statistics)");
+        return X265HIP_OK;
+    }
+    __atomic_store_n(&s->doorbell, seq, __ATOMIC_RELEASE);
+    store_fence();
+    if (__atomic_load_n(&cs->hostCtl->serverState, __ATOMIC_ACQUIRE) == 0)
+        return start_server(cs);
+    return X265HIP_OK;
+}
+
+int x265hip_cuserve_submit_intra(x265hip_cuserve* cs, int slot, const x265hip_intrajob* job, uint32_t* seqOut)
+{
+    if (!cs || slot < 0 || slot >= cs->slots || !job || !seqOut) return set_error(X265HIP_EINVAL, "x265hip_cuserve_submit_intra: slot %d", slot);
+    if ((job->bitDepth != 8 && job->bitDepth != 10 && job->bitDepth != 12) || job->mark != X265HIP_INTRAJOB_MARK || job->log2Size < 3 || job->log2Size > 5)
+        return set_error(X265HIP_EINVAL, "x265hip_cuserve_submit_intra: depth %u, mark %#x, log2 size %u", job->bitDepth, job->mark, job->log2Size);
+    const int bytes = x265hipi_intrajob_pixel_bytes(job);
+    SlotIn* s = cs->in + slot;
+    uint32_t run = cs->seq[slot].load(std::memory_order_relaxed) + 1;
+    if (run >= 0xfffff0u) run = 1;
+    cs->seq[slot].store(run, std::memory_order_relaxed);
+    const uint32_t steps = (uint32_t)(128 + bytes + 511) / 512;
+    const uint32_t seq = (run << 8) | 3u | (steps << 2);
+    *seqOut = seq;
+    cs->jobs.fetch_add(1, std::memory_order_relaxed);
+    cs->intraJobs.fetch_add(1, std::memory_order_relaxed);
+    // what the 35 sa8d calls of Search::checkIntraInInter read: the two lines + the source block in, 35 costs out
+    cs->bytes.fetch_add((uint64_t)bytes + 35 * 4, std::memory_order_relaxed);
+    memcpy(&s->job, job, sizeof(*job));
+    store_fence();
+    if (cs->mode == 1)
+    {
+        std::atomic_thread_fence(std::memory_order_release);
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != cs->device) (void)hipSetDevice(cs->device);
+        hipLaunchKernelGGL(cu_job_kernel, dim3(1), dim3(256), 0, cs->jobStreams[slot], cs->inDev + slot, cs->outDev + slot, seq, &cs->ctl->busyTicks[slot]);
+        const hipError_t le = hipGetLastError();
+        if (cur >= 0 && cur != cs->device) (void)hipSetDevice(cur);
+        if (le != hipSuccess) return check_hip(le, "cu_job_kernel (intra scan)");
         return X265HIP_OK;
     }
     __atomic_store_n(&s->doorbell, seq, __ATOMIC_RELEASE);

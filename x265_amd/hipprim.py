@@ -191,6 +191,7 @@ PROTOTYPES = {
     "x265hip_cuserve_submit": (i32, [vp, i32, C.POINTER(u32)]),
     "x265hip_cuserve_poke": (i32, [vp, i32]),
     "x265hip_cuserve_submit_sao": (i32, [vp, i32, vp, vp]),
+    "x265hip_cuserve_submit_intra": (i32, [vp, i32, vp, vp]),
     "x265hip_cuserve_stats": (i32, [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
     "x265hip_device_time": (i32, [i32, vp, vp, vp]),
     "x265hip_sadsurf_attach_levels": (vp, [vp, vp, i32, i32, i32]),
@@ -275,6 +276,14 @@ class SaoCtuJob(C.Structure):
 
 
 SAOJOB_STATS_ENTRIES = 3 * 5 * 32
+
+
+class IntraScanJob(C.Structure):
+    """x265hip_intrajob (include/x265hip.h): the 35-mode sa8d scan of one block as a job of the CU-job service"""
+    _fields_ = [("bitDepth", u32), ("mark", u32), ("log2Size", u32), ("reserved", u32)]
+
+
+INTRAJOB_MARK = 0x100
 
 
 class CuJobUnit(C.Structure):
