@@ -530,6 +530,11 @@ def parse_served(lines):
         m = re.search(r"saostats: SAO statistics of (\d+) CTU planes .*? measured by the GPU in (\d+) jobs, (\d+) planes on the host; (\d+) waits of (\d+) cycles", l)
         if m:
             out["sao"] = {"planes": int(m.group(1)), "jobs": int(m.group(2)), "host_planes": int(m.group(3)), "waits": int(m.group(4)), "wait_cycles": int(m.group(5))}
+        m = re.search(r"intrascan: the 35-mode sa8d scans of (\d+) blocks .*? measured by the GPU in (\d+) jobs, (\d+) scans on the host; (\d+) jobs left ahead when predInterSearch "
+                      r"returned, (\d+) of them adopted, (\d+) never asked for; (\d+) waits of (\d+) cycles", l)
+        if m:
+            out["intra"] = {"scans_served": int(m.group(1)), "jobs": int(m.group(2)), "host_scans": int(m.group(3)), "ahead": int(m.group(4)), "adopted": int(m.group(5)),
+                            "never_asked_for": int(m.group(6)), "waits": int(m.group(7)), "wait_cycles": int(m.group(8))}
     return out
 
 
@@ -889,6 +894,7 @@ def main():
         if cu.get("ms") and served.get("cu"):
             c = served["cu"]
             secs = cu["ms"] * 1e-3
+            all_jobs = c["jobs"] + (served.get("sao") or {}).get("jobs", 0) + (served.get("intra") or {}).get("jobs", 0)
             ach = cu["algorithmic_bytes"] / secs / 1e9
             cu_block = {"bound": "latency", "kernel": "cu_server_kernel, live in the timed encode (%s): %d jobs = the transform arithmetic (MFMA dct -> quant -> sign-bit hiding -> dequant -> MFMA "
                                                       "idct -> two SSEs) of the residual quad-trees of %d CUs >= %dx%d, %d forward and %d inverse units served to Quant::transformNxN / "
@@ -911,8 +917,11 @@ def main():
                         # the server's slots also carry the SAO statistics jobs (one per CTU plane: SAO::calcSaoStatsCTU's classification of a deblocked plane against
                         # its source; bytes = the two blocks in + 2 x 5 x 32 int32 out): busy time and bytes are over both kinds
                         "sao_statistics_jobs": served.get("sao"),
-                        "busy_us_per_job": round(cu["ms"] * 1e3 / (c["jobs"] + (served.get("sao") or {}).get("jobs", 0)), 2),
-                        "algorithmic_bytes_per_job": int(cu["algorithmic_bytes"] / (c["jobs"] + (served.get("sao") or {}).get("jobs", 0))),
+                        # ... and the intra mode scans of Search::checkIntraInInter (35 predictions + sa8d of one block per job; bytes = the two neighbour lines and
+                        # the source block in, 35 costs out)
+                        "intra_scan_jobs": served.get("intra"),
+                        "busy_us_per_job": round(cu["ms"] * 1e3 / all_jobs, 2),
+                        "algorithmic_bytes_per_job": int(cu["algorithmic_bytes"] / all_jobs),
                         "host_waits": {"count": c["waits"], "mean_cycles": c["wait_cycles"]}}
         # the dominant kernel of the timed region = the clock with the most device time
         named = [(ss.get("ms", 0.0), ss_block), (la.get("ms", 0.0), la_live), (cu.get("ms", 0.0), cu_block)]
