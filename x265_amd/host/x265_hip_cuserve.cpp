@@ -46,6 +46,7 @@
 #include "quant.h"
 #include "scalinglist.h"
 #include "search.h"
+#include "analysis.h"
 #include "sao.h"
 #undef protected
 #undef private
@@ -1704,8 +1705,9 @@ void SAO::calcSaoStatsCTU(int addr, int plane)
 int g_intraState = 0;                // X265HIP_INTRASCAN=0: off
 bool g_intraAhead = true;            // X265HIP_INTRASCAN_AHEAD=0: the job leaves when checkIntraInInter is entered
 int g_intraMinLog2 = 4;              // X265HIP_INTRASCAN_MIN=<log2>: smallest block handed over (an 8x8 scan is ~8 us of host code: less than a round trip)
+bool g_intraAheadPredict = true;     // X265HIP_INTRASCAN_AHEAD=2: no prediction of whether the intra try will come, every candidate CU's job leaves
 int g_intraSyncMinLog2 = 5;          // ... and the smallest one handed over when no job is ahead (the thread waits a whole round trip)
-struct alignas(64) IntraCounters { std::atomic<uint64_t> jobs, served, ahead, aheadHit, dropped, waits, waitCycles, host; };
+struct alignas(64) IntraCounters { std::atomic<uint64_t> jobs, served, ahead, aheadHit, dropped, waits, waitCycles, host, aheadBy[2]; };
 IntraCounters g_intraCount[16];
 constexpr int kIntraMaxSamples = 2 * (4 * 32 + 16) + 32 * 32;
 struct IntraJob
@@ -1724,9 +1726,10 @@ inline IntraCounters& intra_counters() { counters(); return g_intraCount[t_shard
 
 void intra_report()
 {
-    uint64_t jobs = 0, served = 0, ah = 0, hit = 0, dr = 0, w = 0, wc = 0, host = 0;
+    uint64_t jobs = 0, served = 0, ah = 0, hit = 0, dr = 0, w = 0, wc = 0, host = 0, ab[2] = { 0, 0 };
     for (int i = 0; i < 16; i++)
     {
+        for (int k = 0; k < 2; k++) ab[k] += g_intraCount[i].aheadBy[k];
         jobs += g_intraCount[i].jobs; served += g_intraCount[i].served; ah += g_intraCount[i].ahead; hit += g_intraCount[i].aheadHit; dr += g_intraCount[i].dropped;
         w += g_intraCount[i].waits; wc += g_intraCount[i].waitCycles; host += g_intraCount[i].host;
     }
@@ -1734,6 +1737,7 @@ void intra_report()
                     "left ahead when predInterSearch returned, %llu of them adopted, %llu never asked for; %llu waits of %.0f cycles on average\n",
             (unsigned long long)served, 1 << g_intraMinLog2, 1 << g_intraMinLog2, (unsigned long long)jobs, (unsigned long long)host, (unsigned long long)ah, (unsigned long long)hit,
             (unsigned long long)dr, (unsigned long long)w, w ? (double)wc / w : 0.0);
+    fprintf(stderr, "x265hip: intrascan: %llu candidate CUs sent no job ahead because no sub-CU of theirs had chosen intra (analysis.cpp:1633: --limit-refs)\n", (unsigned long long)ab[0]);
 }
 
 bool intra_enabled()
@@ -1746,7 +1750,7 @@ bool intra_enabled()
             const char* env = getenv("X265HIP_INTRASCAN");
             const char* all = getenv("X265HIP");
             const char* table = getenv("X265HIP_TABLE");
-            if (getenv("X265HIP_INTRASCAN_AHEAD")) g_intraAhead = atoi(getenv("X265HIP_INTRASCAN_AHEAD")) != 0;
+            if (getenv("X265HIP_INTRASCAN_AHEAD")) { g_intraAhead = atoi(getenv("X265HIP_INTRASCAN_AHEAD")) != 0; g_intraAheadPredict = atoi(getenv("X265HIP_INTRASCAN_AHEAD")) != 2; }
             if (getenv("X265HIP_INTRASCAN_MIN")) g_intraMinLog2 = x265_clip3(3, 5, atoi(getenv("X265HIP_INTRASCAN_MIN")));
             if (getenv("X265HIP_INTRASCAN_SYNC_MIN")) g_intraSyncMinLog2 = x265_clip3(3, 6, atoi(getenv("X265HIP_INTRASCAN_SYNC_MIN")));
             if ((env && !strcmp(env, "0")) || (all && !strcmp(all, "0")) || (table && !strcmp(table, "percall")))
@@ -1912,9 +1916,32 @@ void intra_ahead(Search* se, Mode& interMode, const CUGeom& cuGeom)
         !(slice->m_sliceType != B_SLICE || se->m_param->bIntraInBFrames) || se->m_param->rdLevel < 2 || se->m_param->rdLevel > 4 || se->m_param->bDistributeModeAnalysis ||
         se->m_param->analysisLoad || (se->m_param->bCTUInfo & 4))
         return;
+    // With --limit-refs (preset medium and slower) the intra try needs `splitIntra` (analysis.cpp:1633): no sub-CU recursion for this CU, or a sub-CU whose
+    // best mode is intra (:1182, :1353, :1369).  The recursion leaves its trace in the depth's split prediction — initSubCU to this CU (:1346), the sub-CUs'
+    // data copied in quadrant by quadrant (:1370) — so the flag can be read back; a stale trace only costs a job nobody asks for, or a scan on the host.
+    int likely = 1;
+    if (se->m_param->limitReferences && g_intraAheadPredict)
+    {
+        const CUData& sp = static_cast<Analysis*>(se)->m_modeDepth[cuGeom.depth].pred[Analysis::PRED_SPLIT].cu;
+        if (sp.m_cuAddr == interMode.cu.m_cuAddr && sp.m_absIdxInCTU == cuGeom.absPartIdx && sp.m_encData == interMode.cu.m_encData && cuGeom.log2CUSize > 3)
+        {
+            const uint32_t q = cuGeom.numPartitions >> 2;
+            likely = 0;
+            for (uint32_t k = 0; k < 4; k++)
+                likely |= sp.m_predMode[k * q] == MODE_INTRA;
+        }
+    }
+    if (!likely)
+    {
+        intra_counters().aheadBy[0].fetch_add(1, std::memory_order_relaxed);      // (not sent: counted to show what the prediction withholds)
+        return;
+    }
     const int samples = intra_pack(se, interMode.cu, cuGeom, *interMode.fencYuv, ij.sent);
     if (intra_submit(ij, ij.sent, samples, log2n))
+    {
         intra_counters().ahead.fetch_add(1, std::memory_order_relaxed);
+        intra_counters().aheadBy[1].fetch_add(1, std::memory_order_relaxed);
+    }
 }
 
 // ---- the table slots the reference's body calls for the block.  Which mode a cu[].sa8d call stands for: the mode of the intra_pred[] call before it (every
