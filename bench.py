@@ -531,7 +531,7 @@ def parse_served(lines):
         if m:
             out["sao"] = {"planes": int(m.group(1)), "jobs": int(m.group(2)), "host_planes": int(m.group(3)), "waits": int(m.group(4)), "wait_cycles": int(m.group(5))}
         m = re.search(r"intrascan: the 35-mode sa8d scans of (\d+) blocks .*? measured by the GPU in (\d+) jobs, (\d+) scans on the host; (\d+) jobs left ahead when predInterSearch "
-                      r"returned, (\d+) of them adopted, (\d+) never asked for; (\d+) waits of (\d+) cycles", l)
+                      r"(?:returned|was entered), (\d+) of them adopted, (\d+) never asked for; (\d+) waits of (\d+) cycles", l)
         if m:
             out["intra"] = {"scans_served": int(m.group(1)), "jobs": int(m.group(2)), "host_scans": int(m.group(3)), "ahead": int(m.group(4)), "adopted": int(m.group(5)),
                             "never_asked_for": int(m.group(6)), "waits": int(m.group(7)), "wait_cycles": int(m.group(8))}

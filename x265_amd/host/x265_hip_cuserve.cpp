@@ -1118,9 +1118,10 @@ void Search::encodeResAndCalcRdSkipCU(Mode& interMode)
 // merge candidate (sample for sample the job's blocks, or it is dropped).
 void Search::predInterSearch(Mode& interMode, const CUGeom& cuGeom, bool bChromaMC, uint32_t refMasks[2])
 {
-    refPredInterSearch(this, interMode, cuGeom, bChromaMC, refMasks);
+    // the intra scan of the same CU, should it be tried as intra (below): its inputs are final already — the job leaves before the motion search, not after it
     if (interMode.cu.m_partSize[0] == SIZE_2Nx2N)
-        intra_ahead(this, interMode, cuGeom);                  // the intra scan of the same CU, should it be tried as intra (below)
+        intra_ahead(this, interMode, cuGeom);
+    refPredInterSearch(this, interMode, cuGeom, bChromaMC, refMasks);
     Job& j = t_job;
     if (g_specInter && g_spec && g_state > 0 && !g_dead.load(std::memory_order_relaxed) && (int)cuGeom.log2CUSize >= g_minLog2 && !t_inEncodeRes &&
         interMode.cu.m_partSize[0] == SIZE_2Nx2N && (bChromaMC || m_csp == X265_CSP_I400) && m_param->rdLevel >= 3 && m_param->rdLevel <= 4 &&
@@ -1734,7 +1735,7 @@ void intra_report()
         w += g_intraCount[i].waits; wc += g_intraCount[i].waitCycles; host += g_intraCount[i].host;
     }
     fprintf(stderr, "x265hip: intrascan: the 35-mode sa8d scans of %llu blocks >= %dx%d (Search::checkIntraInInter) measured by the GPU in %llu jobs, %llu scans on the host; %llu jobs "
-                    "left ahead when predInterSearch returned, %llu of them adopted, %llu never asked for; %llu waits of %.0f cycles on average\n",
+                    "left ahead when predInterSearch was entered, %llu of them adopted, %llu never asked for; %llu waits of %.0f cycles on average\n",
             (unsigned long long)served, 1 << g_intraMinLog2, 1 << g_intraMinLog2, (unsigned long long)jobs, (unsigned long long)host, (unsigned long long)ah, (unsigned long long)hit,
             (unsigned long long)dr, (unsigned long long)w, w ? (double)wc / w : 0.0);
     fprintf(stderr, "x265hip: intrascan: %llu candidate CUs sent no job ahead because no sub-CU of theirs had chosen intra (analysis.cpp:1633: --limit-refs)\n", (unsigned long long)ab[0]);
