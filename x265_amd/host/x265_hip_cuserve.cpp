@@ -1701,7 +1701,7 @@ void SAO::calcSaoStatsCTU(int addr, int plane)
 // offset into the all-angles buffer, search.cpp:1356-1390).  X265HIP_VERIFY: the slots do their work as well and every cost is compared.
 //
 // The job leaves AHEAD: the neighbours of a CU are final when its analysis starts (they belong to CUs coded before it; the sub-CU recursion writes inside
-// the CU only), so Search::predInterSearch's seam — the 2Nx2N inter candidate, always before the intra try — submits it, and checkIntraInInter adopts it if
+// the CU only), so Search::predInterSearch's seam — the 2Nx2N inter candidate, always before the intra try — submits it on entry, and checkIntraInInter adopts it if
 // the lines and the source block it would send now compare equal to what was sent; a job nobody asks for is dropped at the next one.
 int g_intraState = 0;                // X265HIP_INTRASCAN=0: off
 bool g_intraAhead = true;            // X265HIP_INTRASCAN_AHEAD=0: the job leaves when checkIntraInInter is entered
