@@ -1866,8 +1866,33 @@ int intra_pack(Search* se, const CUData& cu, const CUGeom& cuGeom, const Yuv& fe
     return 2 * line + n * n;
 }
 
+// A thread that ends (x265's pool threads end with their encoder) hands back what it still holds — a job ahead nobody asked for, parked slots: in a process
+// that opens and closes encoders for days, slots kept by dead threads would starve the service (the CU jobs would quietly stay on the host)
+struct IntraThreadEnd
+{
+    ~IntraThreadEnd()
+    {
+        if (g_dead.load(std::memory_order_relaxed))
+            return;                                          // the services are closed (or failed): their slots are gone with them
+        if (t_intra.active)
+            intra_drop(t_intra);
+        for (IntraParked& z : t_parked)
+        {
+            if (!z.svc)
+                continue;
+            for (int spins = 0; spins < 200000 && !intra_ready(z.svc, z.slot, z.seq); spins++)     // a scan is tens of microseconds of device time
+                __builtin_ia32_pause();
+            if (intra_ready(z.svc, z.slot, z.seq))
+                give_slot(z.svc, z.slot);
+            z.svc = NULL;
+        }
+    }
+};
+thread_local IntraThreadEnd t_intraThreadEnd;
+
 bool intra_submit(IntraJob& ij, const pixel* blob, int samples, int log2n)
 {
+    (void)&t_intraThreadEnd;                                 // (constructed on first use: registers the destructor with this thread)
     intra_sweep();
     if (!service())
         return false;
