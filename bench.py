@@ -598,6 +598,24 @@ def encode_bench(args, rank, local_rank, world, fence, allmax):
             differing = allmax(0.0 if same else 1.0)
             res["reference"] = {"cli_fps": r0["fps"], "wall_s": round(dt_ref, 2), "rc": r0["rc"], "byte_identical": differing == 0.0,
                                 "bitstream_bytes": os.path.getsize(out_ref) if r0["rc"] == 0 else 0}
+            # second baseline leg: the reference with its own intrinsics path (source/common/vec: SSE3 idct8/16/32, SSSE3 dct16/32, SSE4.1 dequant_scaling;
+            # oracle/Makefile `vec`), --asm SSE4.1.  The nasm half (AVX2 / AVX-512 kernels) cannot be assembled in this image.  Rank 0, N = 1 only.
+            vec = os.path.join(ef.REF, "x265_vec_8bit")
+            if world == 1 and os.path.exists(vec):
+                out_vec = clip + ".vec.hevc"
+                try:
+                    # (--no-info on both sides of the comparison: the options SEI carries the cpuid and would differ by those bytes alone)
+                    t0 = time.perf_counter()
+                    rv = ef._run(vec, base + ["--frames", str(frames), "--asm", "SSE4.1", "--no-info"], out_vec)
+                    dt_vec = time.perf_counter() - t0
+                    rn = ef._run(ref, base + ["--frames", str(min(frames, 40)), "--no-info"], out_ref + ".ni")
+                    rm = ef._run(vec, base + ["--frames", str(min(frames, 40)), "--asm", "SSE4.1", "--no-info"], out_vec + ".ni")
+                    same_v = rn["rc"] == 0 and rm["rc"] == 0 and open(out_ref + ".ni", "rb").read() == open(out_vec + ".ni", "rb").read()
+                    res["reference_vec"] = {"cli_fps": rv["fps"], "wall_s": round(dt_vec, 2), "rc": rv["rc"], "same_bitstream_without_info_sei": same_v}
+                finally:
+                    for q in (out_vec, out_vec + ".ni", out_ref + ".ni"):
+                        if os.path.exists(q):
+                            os.remove(q)
         if world > 1:
             # ---- BASELINE configs[4]'s form beside the chunk form: ONE encoder whose device work is spread over the N GPUs (X265HIP_DEVICES: reference-picture
             # mirrors and source pictures take their places in turn, SAD surfaces are built where the source lives from replicas fed device to device, every
@@ -647,6 +665,18 @@ def sadsurf_probe(np_mod):
     # in frame mode the whole reference picture becomes final at once: the sub-pel plane kernel runs over a whole padded picture per repetition
     r["planes"] = {"spans": p1[0] - p0[0], "ns": p1[1] - p0[1], "bytes": p1[2] - p0[2]}
     return r
+
+
+def build_flags():
+    """oracle/_ref/build_flags.txt (written by oracle/Makefile): the flags every reference object — the CPU baseline's and the ones the bound encoder links —
+    and the binding's own TUs were compiled with"""
+    try:
+        d = dict(l.strip().split("=", 1) for l in open(os.path.join(ROOT, "oracle", "_ref", "build_flags.txt")) if "=" in l)
+    except OSError:
+        return None
+    return {"reference_objects": d.get("REF_OPT"), "binding_tus": d.get("HOST_OPT"), "compiler": d.get("CXX"),
+            "note": "the reference's own default build: CMake Release on GCC = -O3 -DNDEBUG (source/CMakeLists.txt:2-7) plus -ffast-math -mstackrealign -fno-exceptions "
+                    "(:307-319); the same objects are the CPU baseline, the pinned oracle library and what the bound encoder links (rounds 1-5 used -O2)"}
 
 
 def host_cpu_quota():
@@ -940,7 +970,7 @@ def main():
                                    "served from GPU-built fractional planes of each reference picture, psy-cost source halves from GPU-built energy planes, C slots "
                                    "otherwise; the host cores are split between the ranks" % (enc["frames"], CHUNK),
                        "frames_per_step": world * CHUNK, "encoder_cli_fps_rank0": enc["cli_fps"], "served_by_gpu": enc["served"],
-                       "host_cores": os.cpu_count(), "host_cpu_quota": host_cpu_quota(), "pool_threads_per_encoder": enc["pools"], "threads": enc["threads_note"], "timed_s": round(dt, 2),
+                       "build_flags": build_flags(), "host_cores": os.cpu_count(), "host_cpu_quota": host_cpu_quota(), "pool_threads_per_encoder": enc["pools"], "threads": enc["threads_note"], "timed_s": round(dt, 2),
                        "host_note": "host_cpu_quota = CPUs the container's cgroup grants (cpu.max); when it is far below host_cores both encoders are bound by CPU seconds per "
                                     "frame and N encoders share the same budget (DESIGN.md §4c)"},
             "roofline": dominant,
@@ -961,6 +991,7 @@ def main():
             quota = host_cpu_quota()
             out["cpu_baseline"] = {"value": round(ref_fps, 3) if ref_fps else None, "unit": "frames/s",
                                    "cores": int(min(os.cpu_count() or 1, quota)) if quota else os.cpu_count(), "kind": "reference",
+                                   "build_flags": (build_flags() or {}).get("reference_objects"),
                                    "cores_note": "CPUs the process tree can use at once: min(cores the kernel shows = %s, cgroup quota = %s); encoder threads: %s (the same for both encoders)"
                                                  % (os.cpu_count(), quota, enc["threads_note"]),
                                    "sample": "the same %d chunk(s) of %d frames, same arguments (and the same --pools share at N > 1), through oracle/_ref/x265_8bit — the unmodified "
@@ -970,6 +1001,14 @@ def main():
                                    "byte_identical_to_gpu_path": r0["byte_identical"], "bitstream_bytes": r0["bitstream_bytes"]}
             if not r0["byte_identical"]:
                 out["error"] = "a chunk's GPU-path bitstream differs from the reference encoder's"
+            rv = enc.get("reference_vec")
+            if rv and rv.get("wall_s") and rv["rc"] == 0:
+                out["cpu_baseline_vec"] = {"value": round(enc["frames"] / rv["wall_s"], 3), "unit": "frames/s", "cores": out["cpu_baseline"]["cores"], "kind": "reference+vec",
+                                           "build_flags": (build_flags() or {}).get("reference_objects"), "cli_fps": rv["cli_fps"],
+                                           "same_bitstream_without_info_sei": rv["same_bitstream_without_info_sei"],
+                                           "sample": "the same %d frames through oracle/_ref/x265_vec_8bit --asm SSE4.1: the reference with its own compiler-intrinsics transforms "
+                                                     "(source/common/vec: idct8/16/32 SSE3, dct16/32 SSSE3, dequant_scaling SSE4.1 — the reference's SIMD for the MFMA rows that needs "
+                                                     "no assembler); every other slot is the C primitive, as in `cpu_baseline` (the .asm kernels need nasm, absent from the image)" % enc["frames"]}
         if enc.get("one_encoder"):
             out["one_encoder_all_gpus"] = enc["one_encoder"]
         if fpb:

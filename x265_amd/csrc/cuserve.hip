@@ -1138,18 +1138,21 @@ int x265hip_cuserve_open(int slots, int mode, x265hip_cuserve** out)
     if (e) { x265hip_cuserve_close(cs); return e; }
     if (mode == 0)
     {
-        std::lock_guard<std::mutex> g(g_openLock);
         bool registered = false;
-        for (x265hip_cuserve*& slot : g_open)
-            if (!slot) { slot = cs; registered = true; break; }
-        if (!registered) { x265hip_cuserve_close(cs); return set_error(X265HIP_EINVAL, "x265hip_cuserve_open: more than %d services with a resident server", (int)(sizeof(g_open) / sizeof(g_open[0]))); }
-        // opened in the middle of somebody's device synchronisation: this service is paused with the others and resumes with them
-        if (g_pauseDepth > 0)
         {
-            cs->paused = g_pauseDepth;
-            __atomic_store_n(&cs->hostCtl->leave, 1u, __ATOMIC_RELEASE);
+            std::lock_guard<std::mutex> g(g_openLock);
+            for (x265hip_cuserve*& slot : g_open)
+                if (!slot) { slot = cs; registered = true; break; }
+            // opened in the middle of somebody's device synchronisation: this service is paused with the others and resumes with them
+            if (registered && g_pauseDepth > 0)
+            {
+                cs->paused = g_pauseDepth;
+                __atomic_store_n(&cs->hostCtl->leave, 1u, __ATOMIC_RELEASE);
+            }
+            if (registered) resident_workgroups(cs->device, slots);
         }
-        resident_workgroups(cs->device, slots);
+        // (closed outside the lock: x265hip_cuserve_close and the device_free() it reaches take g_openLock themselves)
+        if (!registered) { x265hip_cuserve_close(cs); return set_error(X265HIP_EINVAL, "x265hip_cuserve_open: more than %d services with a resident server", (int)(sizeof(g_open) / sizeof(g_open[0]))); }
     }
     *out = cs;
     return X265HIP_OK;

@@ -1333,7 +1333,7 @@ void Quant::invtransformNxN(const CUData& cu, int16_t* residual, uint32_t resiSt
 // back where the reference's primitives add theirs.  8-bit builds; X265HIP_SAOSTATS=0 switches it off; X265HIP_VERIFY recomputes with the reference's body.
 namespace {
 
-int g_saoState = 0;              // 0 undecided, 1 on, -1 off
+std::atomic<int> g_saoState(0);  // 0 undecided, 1 on, -1 off (written by whichever thread decides or sees the device fail)
 bool g_saoParts = false;         // X265HIP_SAOSTATS_PARTS=4: the luma plane goes as two jobs (upper / lower half).  Measured: 3 jobs per CTU 33.2 fps, 4 jobs 32.6, SAO on the host 30.9
 struct alignas(64) SaoCounters { std::atomic<uint64_t> jobs, planes, hostPlanes, waits, waitCycles, ahead; };
 SaoCounters g_saoCount[16];
@@ -1345,6 +1345,8 @@ struct SaoJob
 {
     bool active;
     const SAO* sao; int addr;
+    const void* encData; int poc;        // the picture the blocks were read from: a row's SAO object serves every frame its FrameEncoder codes, (sao, addr) alone
+                                         // would let a set orphaned in an earlier frame (ParallelFilter::processTasks hops between pool threads) be adopted
     int nparts; SaoPart part[4];
     bool consumed[3];                    // per plane
     bool wanted[3];                      // planes this job carries
@@ -1562,9 +1564,37 @@ bool sao_submit(SaoJob& sj, SAO* sao, int addr, int first, int n)
     }
     if (!sj.nparts)
         return false;
-    sj.active = true; sj.sao = sao; sj.addr = addr;
+    sj.active = true; sj.sao = sao; sj.addr = addr; sj.encData = sao->m_frame->m_encData; sj.poc = sao->m_frame->m_poc;
     return true;
 }
+
+// A pool thread that ends with sets still out (an ahead job whose CTU another thread served: up to four slots each) hands their slots back, like
+// IntraThreadEnd below: with 2 x CPUs slots in all, one closed encoder could otherwise leave most of them taken for the rest of the process
+struct SaoThreadEnd
+{
+    ~SaoThreadEnd()
+    {
+        std::lock_guard<std::mutex> g(g_lock);               // shutdown() closes the services under this lock
+        if (g_dead.load(std::memory_order_relaxed))
+            return;                                          // the services are closed (or failed): their slots are gone with them
+        for (SaoJob& t : t_saoSet)
+        {
+            if (!t.active)
+                continue;
+            bool done = true;
+            for (int k = 0; k < t.nparts && done; k++)
+            {
+                const SaoPart& pt = t.part[k];
+                const uint32_t* ready = &pt.svc->mem[pt.slot].units[0].ready;
+                for (int spins = 0; spins < 200000 && __atomic_load_n(ready, __ATOMIC_ACQUIRE) != pt.seq; spins++)     // a plane is ~15 us of device time
+                    __builtin_ia32_pause();
+                done = __atomic_load_n(ready, __ATOMIC_ACQUIRE) == pt.seq;
+            }
+            sao_drop(t, done);
+        }
+    }
+};
+thread_local SaoThreadEnd t_saoThreadEnd;
 
 } // namespace
 
@@ -1580,11 +1610,13 @@ void SAO::calcSaoStatsCTU(int addr, int plane)
     const int numCuInWidth = m_numCuInWidth;
     const bool nextInRow = (addr + 1) % numCuInWidth != 0;
     SaoJob* cur = NULL;
+    (void)&t_saoThreadEnd;                                   // (constructed on first use: registers the destructor with this thread)
     for (SaoJob& t : t_saoSet)
     {
         if (!t.active) continue;
-        if (t.sao == this && t.addr == addr) { cur = &t; continue; }
-        if (t.sao == this && t.addr == addr + 1 && nextInRow) continue;
+        const bool thisPicture = t.sao == this && t.encData == (const void*)m_frame->m_encData && t.poc == m_frame->m_poc;
+        if (thisPicture && t.addr == addr) { cur = &t; continue; }
+        if (thisPicture && t.addr == addr + 1 && nextInRow) continue;
         bool done = true;
         for (int k = 0; k < t.nparts && done; k++) done = sao_wait(t, k);
         sao_drop(t, done);
@@ -1619,7 +1651,7 @@ void SAO::calcSaoStatsCTU(int addr, int plane)
         bool have = false;
         for (SaoJob& t : t_saoSet)
         {
-            if (t.active && t.sao == this && t.addr == addr + 1) have = true;
+            if (t.active && t.sao == this && t.addr == addr + 1 && t.encData == (const void*)m_frame->m_encData && t.poc == m_frame->m_poc) have = true;
             else if (!t.active && &t != cur && !nxt) nxt = &t;
         }
         if (!have && nxt)
@@ -1703,7 +1735,7 @@ void SAO::calcSaoStatsCTU(int addr, int plane)
 // The job leaves AHEAD: the neighbours of a CU are final when its analysis starts (they belong to CUs coded before it; the sub-CU recursion writes inside
 // the CU only), so Search::predInterSearch's seam — the 2Nx2N inter candidate, always before the intra try — submits it on entry, and checkIntraInInter adopts it if
 // the lines and the source block it would send now compare equal to what was sent; a job nobody asks for is dropped at the next one.
-int g_intraState = 0;                // X265HIP_INTRASCAN=0: off
+std::atomic<int> g_intraState(0);    // X265HIP_INTRASCAN=0: off
 bool g_intraAhead = true;            // X265HIP_INTRASCAN_AHEAD=0: the job leaves when checkIntraInInter is entered
 int g_intraMinLog2 = 4;              // X265HIP_INTRASCAN_MIN=<log2>: smallest block handed over (an 8x8 scan is ~8 us of host code: less than a round trip)
 bool g_intraAheadPredict = true;     // X265HIP_INTRASCAN_AHEAD=2: no prediction of whether the intra try will come, every candidate CU's job leaves
@@ -1872,6 +1904,7 @@ struct IntraThreadEnd
 {
     ~IntraThreadEnd()
     {
+        std::lock_guard<std::mutex> g(g_lock);               // shutdown() sets g_dead and closes the services (their pinned memory) under this lock
         if (g_dead.load(std::memory_order_relaxed))
             return;                                          // the services are closed (or failed): their slots are gone with them
         if (t_intra.active)
@@ -1890,6 +1923,7 @@ struct IntraThreadEnd
 };
 thread_local IntraThreadEnd t_intraThreadEnd;
 
+bool intra_slots_in(const EncoderPrimitives& p, int log2n);
 bool intra_submit(IntraJob& ij, const pixel* blob, int samples, int log2n)
 {
     (void)&t_intraThreadEnd;                                 // (constructed on first use: registers the destructor with this thread)
@@ -1938,7 +1972,8 @@ void intra_ahead(Search* se, Mode& interMode, const CUGeom& cuGeom)
     }
     const int log2n = (int)cuGeom.log2CUSize;
     const Slice* slice = interMode.cu.m_slice;
-    if (!g_intraAhead || !intra_enabled() || log2n < g_intraMinLog2 || log2n > 5 || log2n == (int)g_log2Size[se->m_param->maxCUSize] ||
+    // (only sizes whose table slots are installed: a job checkIntraInInter could never adopt would only hold a slot)
+    if (!g_intraAhead || !intra_enabled() || log2n < g_intraMinLog2 || log2n > 5 || !intra_slots_in(primitives, log2n) || log2n == (int)g_log2Size[se->m_param->maxCUSize] ||
         !(slice->m_sliceType != B_SLICE || se->m_param->bIntraInBFrames) || se->m_param->rdLevel < 2 || se->m_param->rdLevel > 4 || se->m_param->bDistributeModeAnalysis ||
         se->m_param->analysisLoad || (se->m_param->bCTUInfo & 4))
         return;
