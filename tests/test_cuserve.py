@@ -756,3 +756,35 @@ def test_device_jobs_match_the_restatement(mode):
             assert starts.value >= 2, starts.value
     finally:
         hp.check(L.x265hip_cuserve_close(cs))
+
+
+@pytest.mark.gpu
+def test_a_seventeenth_resident_service_is_refused_not_deadlocked():
+    """x265hip_cuserve_open keeps at most sixteen services with a resident server: the next one is an error (it used to close the half-made service while
+    holding the lock that close takes: a deadlock instead of X265HIP_EINVAL), and the sixteen stay usable"""
+    import threading
+    from x265_amd import hipprim as hp
+    L = hp.lib()
+    hp.check(L.x265hip_init(0))
+    opened, result = [], {}
+    try:
+        for _ in range(16):
+            cs = vp()
+            hp.check(L.x265hip_cuserve_open(1, 0, C.byref(cs)))
+            opened.append(cs)
+        def one_more():
+            cs = vp()
+            result["rc"] = L.x265hip_cuserve_open(1, 0, C.byref(cs))
+        t = threading.Thread(target=one_more, daemon=True)
+        t.start()
+        t.join(20)
+        assert not t.is_alive(), "the seventeenth x265hip_cuserve_open never returned"
+        assert result["rc"] == -1, result                       # X265HIP_EINVAL
+        O = _orc()
+        j = _job_header(hp, 5, 5, 5, 1, 8, (30, 29, 29), 0, 1)
+        pix = _job_pixels(np.random.default_rng(11), 5, 1, 8, 1)
+        done, wu, wl, wr = _oracle_job(hp, O, j, pix)
+        _compare(hp, j, _run_on(hp, L, opened[-1], 0, j, pix), wu, wl, wr, "sixteenth service")
+    finally:
+        for cs in opened:
+            hp.check(L.x265hip_cuserve_close(cs))

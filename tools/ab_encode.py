@@ -60,7 +60,13 @@ def main():
     for r in range(a.rounds):
         for name, env in (cfgs if r % 2 == 0 else cfgs[::-1]):
             e = dict(os.environ, X265HIP="require", X265HIP_VERBOSE="1", **env)
-            res[name].append(run(os.path.join(REF, "x265_hip_%dbit" % a.bits), args, "/tmp/ab_%s.hevc" % name, e))
+            # a configuration named REF* is the unmodified reference encoder, VEC* the reference with its intrinsics transforms (--asm SSE4.1), interleaved like the rest
+            if name.startswith("REF"):
+                res[name].append(run(os.path.join(REF, "x265_%dbit" % a.bits), args, "/tmp/ab_%s.hevc" % name, e))
+            elif name.startswith("VEC"):
+                res[name].append(run(os.path.join(REF, "x265_vec_8bit"), args + ["--asm", "SSE4.1"], "/tmp/ab_%s.hevc" % name, e))
+            else:
+                res[name].append(run(os.path.join(REF, "x265_hip_%dbit" % a.bits), args, "/tmp/ab_%s.hevc" % name, e))
     summary = {"clip": "%s %d frames preset %s %s" % (a.res, a.frames, a.preset, a.extra), "reference": {"fps": ref["fps"], "user": round(ref["user"], 1)}, "configs": {}}
     print("reference: %.2f fps, user %.1f s" % (ref["fps"], ref["user"]))
     for name, env in cfgs:

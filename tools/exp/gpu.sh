@@ -41,7 +41,8 @@ while [ $# -gt 0 ]; do
       timeout 1200 python tools/ab_encode.py --rounds 2 --frames 8 --res 3840x2160 --preset slower --extra "--rd 6" --bits 10 base: nocoef:$OFF --out $OUT/configs3.json 2>&1 | tee $OUT/configs3_4k_main10_slower_ab.txt | tail -12 ;;
     ab)
       frames=$1; shift; cfgs=(); while [ $# -gt 0 ] && [[ "$1" == *:* ]]; do cfgs+=("$1"); shift; done
-      timeout 1500 python tools/ab_encode.py --rounds 3 --frames $frames "${cfgs[@]}" --out $OUT/ab.json 2>&1 | tee $OUT/ab.txt | tail -14 ;;
+      # AB_ROUNDS (default 3), AB_EXTRA (default "--me hex"; the bench line's arguments on the MI355X box are "--me hex --pools 16 --frame-threads 5"), AB_NAME (file stem)
+      timeout ${AB_TIMEOUT:-1500} python tools/ab_encode.py --rounds ${AB_ROUNDS:-3} --frames $frames --extra "${AB_EXTRA:---me hex}" "${cfgs[@]}" --out $OUT/${AB_NAME:-ab}.json 2>&1 | tee $OUT/${AB_NAME:-ab}.txt | tail -${AB_TAIL:-14} ;;
     rt)
       (timeout 200 tools/micro/cuserve_rt 0 3000 1; timeout 100 tools/micro/cuserve_rt 1 1000 0) 2>&1 | tee $OUT/cuserve_rt.txt | tail -30 ;;
     stats)

@@ -103,11 +103,22 @@ struct DevCtl                                     // device memory
     uint32_t quit;                               // set by the workgroup that finds the server idle (or told to leave): every workgroup leaves at its next poll
     uint32_t left;                               // workgroups that have left
     uint64_t lastWork;                           // wall_clock64() of the last job any workgroup has taken
-    uint64_t busyTicks[256];                     // per slot: 100 MHz ticks spent on its jobs
+    uint64_t busyTicks[512];                     // per workgroup (two per slot): 100 MHz ticks spent on its jobs
 };
 
 struct TileLds { int16_t a[1024], b[1024], c[1024]; };            // per wave: transform ping-pong + deltaU
 struct BOperand { int b[4]; int corr; int pad[3]; };             // make_b_operand's result for one lane
+// the team form of a 32x32 unit (team_chain32 below: the four waves of a workgroup on ONE unit): a wave's 16x16x32 coefficient operand, and the words the
+// waves exchange at the barriers
+struct TeamOperand { long b; int corr; int pad; };
+struct TeamLds
+{
+    TeamOperand op[2][256];                      // [forward, inverse][thread]: built once per kernel
+    uint32_t part[16];                           // per 16-lane row of the team: partial sums (significant levels, squared differences)
+    uint32_t part2[16];
+    int energy[2][16];                           // psy energies of the unit's sixteen 8x8 blocks: [source, reconstruction]
+    int numSig;
+};
 struct JobLds
 {
     alignas(16) x265hip_cujob job;               // + padding up to 128 bytes, then the pixels: the same run of chunks as in the slot
@@ -116,6 +127,7 @@ struct JobLds
     alignas(16) TileLds tile[4];
     int saoExtra[3520];                          // directly behind tile[]: an SAO statistics job lays its histograms over both (run_sao: 9 664 ints)
     alignas(16) BOperand bop[3][2][64];          // [log2n - 3][forward, inverse][lane]: built once per kernel
+    alignas(16) TeamLds team;
     uint32_t seq;
 };
 static_assert(sizeof(x265hip_cujob) <= 128, "job header");
@@ -475,6 +487,358 @@ __device__ __forceinline__ void tile_chain(TileLds& t, const BOperand (*bop)[64]
     __builtin_amdgcn_s_waitcnt(0xc07f);
 }
 
+// ---- the team form: the four waves of a workgroup on ONE 32x32 unit ---------------------------------------------------------------------------------
+// A 32x32 luma unit is what the submitting thread waits for first, and on one wave every stage of its chain is ~150 dependent VALU instructions at 16
+// coefficients per lane (tile_chain above: 2.8 us from the pixels in LDS to the ready word).  Here the unit is spread over the workgroup: every
+// elementwise stage works on FOUR coefficients per thread, a transform pass is one 16x16 output quadrant per wave (two v_mfma_i32_16x16x32_i8 with the same
+// exact high-byte / low-byte split as dctcore.h), the stages meet at workgroup barriers that wait for LDS only.  Sign-bit hiding stays one lane per 4x4
+// coefficient group (64 groups: one wave).  Same arithmetic, same LDS layouts, same results as tile_chain<P, 32>.
+__device__ __forceinline__ void team_barrier()
+{
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // this wave's LDS traffic (not its stores to host memory: those are waited for where a ready word follows)
+    __builtin_amdgcn_s_barrier();
+}
+
+// thread tid's operand of the 16x16x32 form: wave w makes output rows 16 * (w >> 1) .., columns 16 * (w & 1) ..; lane l holds column C0 + (l & 15) of the
+// coefficient matrix for the contraction indices 8 * (l >> 4) .. + 7
+template <bool INV>
+__device__ __forceinline__ void make_team_operand(int tid, TeamOperand& o)
+{
+    const int w = tid >> 6, lane = tid & 63;
+    const int n = 16 * (w & 1) + (lane & 15), k0 = 8 * (lane >> 4);
+    int sum = 0;
+    unsigned long long bits = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+    {
+        const int k = k0 + j;
+        const int v = INV ? dct_coef<32>(k, n) : dct_coef<32>(n, k);
+        sum += v;
+        bits |= (unsigned long long)(v & 255) << (8 * j);
+    }
+    sum += __shfl_xor(sum, 16, kWave);
+    sum += __shfl_xor(sum, 32, kWave);
+    o.b = (long)bits;
+    o.corr = 128 * sum;
+    o.pad = 0;
+}
+
+// one pass of the 32x32 transform by the team: mfma_pass<32, INV> with the output quadrants dealt to the waves; in / out as there
+template <bool INV>
+__device__ __forceinline__ void team_pass(const int16_t* in, int16_t* out, int tid, const TeamOperand& op, int shift)
+{
+    const int w = tid >> 6, lane = tid & 63;
+    const int i = 16 * (w >> 1) + (lane & 15), k0 = 8 * (lane >> 4);
+    uint32_t x[4];
+    if (!INV)
+    {
+        const uint4 v = *reinterpret_cast<const uint4*>(in + i * 32 + k0);
+        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+    }
+    else
+    {
+        const int16_t* p = in + k0 * 32 + i;
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+            x[m] = (uint32_t)(uint16_t)p[(2 * m) * 32] | ((uint32_t)(uint16_t)p[(2 * m + 1) * 32] << 16);
+    }
+    const uint32_t lo0 = __builtin_amdgcn_perm(x[1], x[0], 0x06040200u) ^ 0x80808080u, lo1 = __builtin_amdgcn_perm(x[3], x[2], 0x06040200u) ^ 0x80808080u;
+    const uint32_t hi0 = __builtin_amdgcn_perm(x[1], x[0], 0x07050301u), hi1 = __builtin_amdgcn_perm(x[3], x[2], 0x07050301u);
+    const long ahi = (long)((unsigned long long)hi0 | ((unsigned long long)hi1 << 32)), alo = (long)((unsigned long long)lo0 | ((unsigned long long)lo1 << 32));
+    v4i acc = { 0, 0, 0, 0 };
+    acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(ahi, op.b, acc, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        acc[q] <<= 8;
+    acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(alo, op.b, acc, 0, 0, 0);
+    // D[row][col]: col = lane & 15, row = 4 * (lane >> 4) + q
+    const int n = 16 * (w & 1) + (lane & 15), row0 = 16 * (w >> 1) + 4 * (lane >> 4);
+    const int add = (1 << (shift - 1)) + op.corr;
+    int v[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+    {
+        const int t = (acc[e] + add) >> shift;
+        v[e] = INV ? clip3i(-32768, 32767, t) : t;
+    }
+    if (!INV)
+        store4(out + n * 32 + row0, v);
+    else
+    {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            out[(row0 + e) * 32 + n] = (int16_t)v[e];
+    }
+}
+
+// the sum of v over the team, for every thread: 16-lane rows by DPP, the sixteen row totals through LDS (the caller's barrier follows the store)
+__device__ __forceinline__ void team_part(uint32_t* part, int tid, uint32_t v)
+{
+    const uint32_t r = (uint32_t)row_allsum((int)v);
+    if ((tid & 15) == 0) part[tid >> 4] = r;
+}
+__device__ __forceinline__ unsigned long long team_total(const uint32_t* part)
+{
+    unsigned long long t = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) t += part[i];
+    return t;
+}
+
+// unit `u` (raster order; `pw` elements per row of the plane in LDS) of a plane whose transform size is 32: tile_chain<P, 32>'s work for one unit
+template <typename P>
+__device__ __forceinline__ void team_chain32(TileLds& t, TeamLds& tm, const P* src, const P* prd, int pw, int u, const PlaneParams qp, bool signHide,
+                                             x265hip_cujob_unit* un, int16_t* levels, int16_t* resi, uint32_t seq, uint64_t t0, bool stamps, int coef)
+{
+    uint32_t stamp[6] = { 0, 0, 0, 0, 0, 0 };
+    XH_STAMP(0);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int perRow = pw / 32, ux = u % perRow, uy = u / perRow;
+    const TeamOperand& oF = tm.op[0][tid];
+    const TeamOperand& oI = tm.op[1][tid];
+    const bool srcOnly = (coef & 3) == 2;
+    // ---- residual: four consecutive samples of a row per thread, kept in registers for the distortions
+    const int e = tid * 4;
+    int fv[4], pv[4];
+    {
+        const int off = (uy * 32 + (e >> 5)) * pw + ux * 32 + (e & 31);
+        load4(src + off, fv);
+        load4(prd + off, pv);
+        int r[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = srcOnly ? fv[i] : fv[i] - pv[i];
+        store4(t.a + e, r);
+    }
+    uint32_t zeroP = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int d0 = fv[i] - pv[i]; zeroP += (uint32_t)(d0 * d0); }
+    team_part(tm.part2, tid, zeroP);             // (read after the barriers below; nothing else writes part2 before the forward half is published)
+    team_barrier();
+    // ---- forward transform: a -> b -> a
+    team_pass<false>(t.a, t.b, tid, oF, qp.s1f);
+    team_barrier();
+    team_pass<false>(t.b, t.a, tid, oF, qp.s2f);
+    team_barrier();
+    XH_STAMP(1);
+    if (coef)
+    {
+        // ---- coefficient mode (tile_chain): the transform coefficients go out where the levels would (residual part) or where the reconstructed residual would
+        // (source part)
+        int16_t* dstC = srcOnly ? resi : levels;
+        *reinterpret_cast<uint2*>(dstC + e) = *reinterpret_cast<const uint2*>(t.a + e);
+        // every wave's stores are in host memory before the ready word leaves: each waits for its own, then the barrier
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0)
+        {
+            if (srcOnly)
+                __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            else
+            {
+                un->numSig = 0;
+                un->zeroDist = team_total(tm.part2);
+                un->fwdTicks = (uint32_t)(wall_clock64() - t0);
+                XH_STAMP(5);
+                if (stamps) { un->reserved[0] = stamp[0] | (stamp[1] << 16); un->reserved[1] = 0; un->reserved[2] = stamp[5] << 16; }
+                if (!(coef & 4))
+                    __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&un->ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        team_barrier();                          // (part2 and the tile are free again)
+        return;
+    }
+    // ---- quant (quant_c): levels -> b, deltaU -> c; the coefficients stay in a
+    {
+        int cf[4], lv[4], du[4];
+        uint32_t cnt = 0;
+        const int qBits8 = qp.qBits - 8;
+        load4(t.a + e, cf);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const int tmp = iabs(cf[i]) * qp.quantScale;
+            const int l = (tmp + qp.add) >> qp.qBits;
+            du[i] = (tmp - (l << qp.qBits)) >> qBits8;
+            cnt += l != 0;
+            lv[i] = clip3i(-32768, 32767, cf[i] < 0 ? -l : l);
+        }
+        store4(t.b + e, lv);
+        store4(t.c + e, du);
+        team_part(tm.part, tid, cnt);
+    }
+    team_barrier();
+    XH_STAMP(2);
+    int numSig = (int)team_total(tm.part);
+    // ---- sign-bit hiding (signBitHidingHDQ): wave 0, lane = coefficient group (scan order); tile_chain's code for N = 32
+    if (signHide && numSig >= 2)
+    {
+        if (wv == 0)
+        {
+            constexpr int N = 32, CGW = 8;
+            const int cg = lane;
+            const int cgPos = kDiag.s8[cg];
+            const int cgx = cgPos % CGW, cgy = cgPos / CGW;
+            const int base = (cgy * 4) * N + cgx * 4;
+            int lv[16];
+            uint32_t flags = 0;
+#pragma unroll
+            for (int n = 0; n < 16; n++)
+            {
+                const int p4 = kDiag.s4[n];
+                lv[n] = t.b[base + (p4 >> 2) * N + (p4 & 3)];
+                flags |= (uint32_t)(lv[n] != 0) << (15 - n);
+            }
+            const unsigned long long nz = __ballot(flags != 0);
+            const int cgLast = nz ? 63 - __builtin_clzll(nz) : -1;
+            int delta = 0;
+            if (flags && cg <= cgLast)
+            {
+                const int firstNZ = 15 ^ (31 - __builtin_clz(flags));
+                const int lastNZ = 15 ^ __builtin_ctz(flags);
+                if (lastNZ - firstNZ >= 4)
+                {
+                    const uint32_t signbit = lv[firstNZ] > 0 ? 0 : 1;
+                    int absSum = 0;
+#pragma unroll
+                    for (int n = 0; n < 16; n++)
+                        if (n >= firstNZ && n <= lastNZ) absSum += lv[n];
+                    if (signbit != ((uint32_t)absSum & 1))
+                    {
+                        int minCostInc = 0x7fffffff, minN = -1, finalChange = 0, curChange = 0;
+                        const int start = cg == cgLast ? lastNZ : 15;
+                        uint32_t cgFlags = flags >> (15 - start);
+#pragma unroll
+                        for (int n = 15; n >= 0; n--)
+                        {
+                            if (n > start) continue;
+                            const int p4 = kDiag.s4[n];
+                            const int at = base + (p4 >> 2) * N + (p4 & 3);
+                            const int dU = t.c[at];
+                            int curCost;
+                            if (cgFlags & 1)
+                            {
+                                if (dU > 0) { curCost = -dU; curChange = 1; }
+                                else if (cgFlags == 1 && iabs(lv[n]) == 1) curCost = 0x7fffffff;
+                                else { curCost = dU; curChange = -1; }
+                            }
+                            else if (cgFlags == 0)
+                            {
+                                const uint32_t thisSignBit = t.a[at] >= 0 ? 0 : 1;
+                                if (thisSignBit != signbit) curCost = 0x7fffffff;
+                                else { curCost = -dU; curChange = 1; }
+                            }
+                            else { curCost = -dU; curChange = 1; }
+                            if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minN = n; }
+                            cgFlags >>= 1;
+                        }
+                        if (minN >= 0)
+                        {
+                            const int p4 = kDiag.s4[minN];
+                            const int at = base + (p4 >> 2) * N + (p4 & 3);
+                            int v = t.b[at];
+                            if (v == 32767 || v == -32768) finalChange = -1;
+                            if (!v) delta = 1;
+                            else if (finalChange == -1 && iabs(v) == 1) delta = -1;
+                            const int sigMask = t.a[at] < 0 ? -1 : 0;
+                            v += (finalChange ^ sigMask) - sigMask;
+                            t.b[at] = (int16_t)v;
+                        }
+                    }
+                }
+            }
+            const int d = wave_sum(delta);
+            if (lane == 0) tm.numSig = numSig + d;
+        }
+        team_barrier();
+        numSig = tm.numSig;
+    }
+    XH_STAMP(3);
+    // ---- levels out, dequant_normal -> a
+    {
+        int lv[4], dq[4];
+        const int dqAdd = 1 << (qp.dqShift - 1);
+        load4(t.b + e, lv);
+#pragma unroll
+        for (int i = 0; i < 4; i++) dq[i] = clip3i(-32768, 32767, (lv[i] * qp.dqScale + dqAdd) >> qp.dqShift);
+        *reinterpret_cast<uint2*>(levels + e) = *reinterpret_cast<const uint2*>(t.b + e);
+        store4(t.a + e, dq);
+    }
+    // ---- the forward half is complete: every wave's levels are in host memory (each waits for its own stores), then the ready word
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_s_barrier();
+    if (tid == 0)
+    {
+        un->numSig = (uint32_t)numSig;
+        un->zeroDist = team_total(tm.part2);
+        un->fwdTicks = (uint32_t)(wall_clock64() - t0);
+        __hip_atomic_store(&un->ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (numSig == 0)
+    {
+        // nobody asks for the inverse half of a unit without a level (tile_chain)
+        if (tid == 0)
+            __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        team_barrier();
+        return;
+    }
+    // ---- inverse transform: a -> b -> a
+    team_pass<true>(t.a, t.b, tid, oI, qp.s1i);
+    team_barrier();
+    team_pass<true>(t.b, t.a, tid, oI, qp.s2i);
+    team_barrier();
+    XH_STAMP(4);
+    // ---- reconstructed residual out; distortion of the coded alternative; the reconstruction to b as int16 for the energies
+    {
+        int r[4], rec[4];
+        uint32_t codedP = 0;
+        load4(t.a + e, r);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            rec[i] = clip3i(0, qp.maxVal, pv[i] + r[i]);
+            const int d1 = fv[i] - rec[i];
+            codedP += (uint32_t)(d1 * d1);
+        }
+        *reinterpret_cast<uint2*>(resi + e) = *reinterpret_cast<const uint2*>(t.a + e);
+        store4(t.b + e, rec);
+        team_part(tm.part, tid, codedP);
+    }
+    team_barrier();
+    // ---- psy_cost_pp(source, reconstruction): per 8x8 block |E(source) - E(reconstruction)| (tile_chain).  Wave 0 measures the reconstruction, wave 1 the
+    // source: a lane = one 4x4 tile, four consecutive lanes the quadrants of one 8x8 block
+    if (wv < 2)
+    {
+        const int b8 = lane >> 2, q = lane & 3;
+        const int tx = (b8 & 3) * 8 + (q & 1) * 4, ty = (b8 >> 2) * 8 + (q >> 1) * 4;
+        int m[16];
+        if (wv == 0) tile_load(t.b + ty * 32 + tx, (int64_t)32, m);
+        else tile_load(src + (uy * 32 + ty) * pw + ux * 32 + tx, (int64_t)pw, m);
+        int sum = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) sum += m[i];
+        hadamard4x4(m);
+        const int raw = quad_sa8d_raw(m, lane);
+        const int en = ((raw + 2) >> 2) - (quad_sum(sum) >> 2);
+        if (q == 0) tm.energy[wv == 0 ? 1 : 0][b8] = en;
+    }
+    // (the reconstructed residual of every wave is in host memory before the word below)
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_s_barrier();
+    if (tid == 0)
+    {
+        int energy = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) energy += iabs(tm.energy[0][i] - tm.energy[1][i]);
+        un->codedDist = team_total(tm.part);
+        un->codedEnergy = (uint32_t)energy;
+        XH_STAMP(5);
+        if (stamps) { un->reserved[0] = stamp[0] | (stamp[1] << 16); un->reserved[1] = stamp[2] | (stamp[3] << 16); un->reserved[2] = stamp[4] | (stamp[5] << 16); }
+        __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    team_barrier();                              // (the tile and the team's words are free for the next unit)
+}
+
 // the six transform operands, once per kernel: wave w builds size 8 << w (waves 0..2)
 __device__ __forceinline__ void build_operands(JobLds& L)
 {
@@ -485,11 +849,16 @@ __device__ __forceinline__ void build_operands(JobLds& L)
     else if (wv == 1) { XH_BOP(16, 1, false); XH_BOP(16, 1, true); }
     else if (wv == 2) { XH_BOP(32, 2, false); XH_BOP(32, 2, true); }
 #undef XH_BOP
+    make_team_operand<false>(threadIdx.x, L.team.op[0][threadIdx.x]);
+    make_team_operand<true>(threadIdx.x, L.team.op[1][threadIdx.x]);
     __syncthreads();
 }
 
+// A job is served by a PAIR of workgroups (two per slot, each alone on a compute unit): role 0 takes the luma units — the 32x32 ones as a team, one after the
+// other, because the submitting thread asks for them one after the other and waits for the first — role 1 the chroma units, a 32x32 tile per wave as before.
+// Every unit is written by exactly one workgroup and carries its own ready words, so the two never meet.
 template <typename P>
-__device__ __forceinline__ void run_tiles(SlotOut* s, JobLds& L, uint32_t seq, uint64_t t0)
+__device__ __forceinline__ void run_tiles(SlotOut* s, JobLds& L, uint32_t seq, uint64_t t0, int role, bool team)
 {
     const int wv = threadIdx.x >> 6;
     const x265hip_cujob& j = L.job;
@@ -499,13 +868,13 @@ __device__ __forceinline__ void run_tiles(SlotOut* s, JobLds& L, uint32_t seq, u
     const P* prd = src + planeElems;
     int sHi, sLo;
     const int levels = x265hipi_cujob_levels(&j, &sHi, &sLo);
-    // ---- tiles, largest size first, luma before chroma; wave w takes tiles w, w + 4, ...
+    // ---- tiles, largest size first; wave w takes the role's tiles w, w + 4, ... (team units are taken by all four waves together)
     int tile = 0;
     for (int lv = 0; lv < levels; lv++)
     {
         const int sz = sHi - lv;
         const int perRow = 1 << ((int)j.log2CUSize - sz), nUnits = perRow * perRow;
-        for (int plane = 0; plane < (j.chroma ? 3 : 1); plane++)
+        for (int plane = role ? 1 : 0; plane < (role ? (j.chroma ? 3 : 1) : 1); plane++)
         {
             const int log2n = plane ? sz - 1 : sz;                          // 5, 4 (luma) or 4, 3 (chroma)
             const int G = 1 << (2 * (5 - log2n));
@@ -514,11 +883,22 @@ __device__ __forceinline__ void run_tiles(SlotOut* s, JobLds& L, uint32_t seq, u
             const P* pp = plane == 0 ? prd : plane == 1 ? prd + lumaElems : prd + lumaElems + lumaElems / 4;
             const int pw = plane ? NC : N;
             const PlaneParams qp = plane_params(j, plane, log2n);
-            // coefficient mode: a luma tile whose source block is wanted as well is TWO work items (residual part, source part) — on different waves, so that
-            // the first luma unit's two blocks arrive together instead of one behind the other
+            // coefficient mode: a luma tile whose source block is wanted as well is TWO work items (residual part, source part)
             const int parts = j.coefMode && j.sourceDct && plane == 0 ? 2 : 1;
             const int unitBase = x265hipi_cujob_unit_index(&j, sHi, sz, plane, 0, 0);
             const int elemBase = x265hipi_cujob_elem_offset(&j, sHi, sz, plane, 0, 0);
+            if (plane == 0 && log2n == 5 && team)
+            {
+                // the team form: unit by unit (G == 1), both parts of a unit back to back
+                for (int u = 0; u < nUnits; u++)
+                    for (int part = 0; part < parts; part++)
+                    {
+                        const int coef = !j.coefMode ? 0 : parts == 1 ? 1 : part == 0 ? 1 | 4 : 2 | 4;
+                        team_chain32<P>(L.tile[0], L.team, ps, pp, pw, u, qp, j.signHide != 0, s->units + unitBase + u, s->levels + elemBase + u * 1024,
+                                        s->resi + elemBase + u * 1024, seq, t0, j.reserved != 0, coef);
+                    }
+                continue;
+            }
             for (int kk = 0; kk < tiles * parts; kk++, tile++)
             {
                 if ((tile & 3) != wv) continue;
@@ -563,12 +943,14 @@ __device__ __forceinline__ int wave_total_lane63(int v)
 __device__ __forceinline__ void run_sao(SlotOut* s, JobLds& L, uint32_t seq, uint64_t t0)
 {
     const x265hip_saojob& j = *reinterpret_cast<const x265hip_saojob*>(&L.job);
-    // LDS (over tile[] and saoExtra[]): [0..159] sums of class c bin b at c * 32 + b, [160..319] counts — what goes out; [832..1471] the edge classes' row
-    // totals; [1472..9663] the band class: a column of 32 bins per LANE (wave w, band b, lane l at 1472 + (w * 32 + b) * 64 + l), count in the high and sum in
-    // the low half of a word — every lane adds into its own column, so no two lanes ever meet on an address
+    // LDS (over tile[]): [0..159] sums of class c bin b at c * 32 + b, [160..319] counts — what goes out; [320..1599] the edge classes, [1600..3647] the band
+    // class: a COLUMN per lane for every bin (edge class c, sign sum e in 0..4: 320 + ((c * 5 + e) * 64 + lane); band b: 1600 + b * 64 + lane), count in the high
+    // and sum in the low half of a word.  A sample is ONE ds_add per class into its lane's column of the bin it falls in (a zero when it lies outside the class's
+    // rectangle): lanes never meet on an address, the four waves share the columns (the add is atomic), and nothing is selected or compared per bin
+    // (a column sees at most 64 samples: the count fits the high half-word, the sum of differences, |d| <= 255, the low one)
     int* hist = reinterpret_cast<int*>(&L.tile[0]);
     int32_t* out = reinterpret_cast<int32_t*>(s->levels);
-    const int tid = threadIdx.x, lx = tid & 63, ly = tid >> 6;
+    const int tid = threadIdx.x, lx = tid & 63, ly = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned char* at = L.pix;
     const int planes = j.planes < 3 ? (int)j.planes : 3;
     for (int p = 0; p < planes; p++)
@@ -580,90 +962,75 @@ __device__ __forceinline__ void run_sao(SlotOut* s, JobLds& L, uint32_t seq, uin
         uint32_t stamp[5] = { 0, 0, 0, 0, 0 };                         // job.reserved != 0 (tools/micro/cuserve_rt): 100 MHz ticks since the doorbell at five points
 #define XH_SSTAMP(i) do { if (j.reserved) stamp[i] = (uint32_t)(wall_clock64() - t0) & 0xffffu; } while (0)
         XH_SSTAMP(0);
-        for (int i = tid; i < 320; i += 256) hist[i] = 0;                   // (the 640 row totals behind them are all written before they are read)
-        for (int i = tid; i < 8192; i += 256) hist[1472 + i] = 0;
+        {
+            int4* h4 = reinterpret_cast<int4*>(hist);
+            for (int i = tid; i < 3648 / 4; i += 256) h4[i] = int4{ 0, 0, 0, 0 };
+        }
         __syncthreads();
         XH_SSTAMP(1);
         int x0[5], y0[5], x1[5], y1[5];
 #pragma unroll
         for (int c = 0; c < 5; c++) { x0[c] = j.plane[p].x0[c]; y0[c] = j.plane[p].y0[c]; x1[c] = j.plane[p].x1[c]; y1[c] = j.plane[p].y1[c]; }
-        // edge classes: five categories each — per lane in registers, count in the high and the (signed) sum in the low half of one 32-bit accumulator;
-        // the band class has 32 bins: the wave's private LDS histogram
-        // (per lane at most 16 samples: the count fits the high half-word, the sum of differences, |d| <= 255, the low one)
-        int acc[4][5];
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-#pragma unroll
-            for (int k = 0; k < 5; k++) acc[c][k] = 0;
-        int* bandCol = hist + 1472 + ly * 32 * 64 + lx;
         const bool eo23 = j.eo23 != 0;
-        for (int y = ly; y < h; y += 4)
+        const bool in = lx < w;
+        // the rectangles' column tests do not depend on the row
+        const bool cx0 = in && lx < x1[0], cx1 = in && lx >= x0[1] && lx < x1[1], cx2 = in && lx < x1[2];
+        const bool cx3 = in && eo23 && lx >= x0[3] && lx < x1[3], cx4 = in && eo23 && lx >= x0[4] && lx < x1[4];
+        int* edgeCol = hist + 320 + lx;
+        int* bandCol = hist + 1600 + lx;
+        const int xi = in ? lx : 0;                                         // a lane outside the plane reads column 0 and adds zeros
+        // two rows per trip (rows ly + 8k and ly + 8k + 4): the loads of both are in flight before the first is classified — a wave is alone on its SIMD, nothing
+        // else hides the LDS latency.  The second row of the last trip may lie below the plane: it is read from the first one's place and adds zeros
+        auto classify = [&](int y, bool valid) __attribute__((always_inline))
         {
-            bool bo = false;
-            int band = -1, dBo = 0;
-            {
-                // branch-free: a lane outside the plane (or a sample outside a class's rectangle) adds zero; its loads stay inside the job's LDS block
-                const bool in = lx < w;
-                const unsigned char* r = rec0 + y * stride + (in ? lx : 0);
-                const int c = r[0], d = (int)fenc0[y * w + (in ? lx : 0)] - c;
-                const int one = (1 << 16) + d;
-                bo = in && lx < x1[0] && y < y1[0];
-                band = bo ? c >> 3 : -1;
-                dBo = d;
-                const int sR = sgn3(c - (int)r[1]), sL = sgn3(c - (int)r[-1]), sD = sgn3(c - (int)r[stride]), sU = sgn3(c - (int)r[-stride]);
-                const int sDR = sgn3(c - (int)r[stride + 1]), sUL = sgn3(c - (int)r[-stride - 1]), sDL = sgn3(c - (int)r[stride - 1]), sUR = sgn3(c - (int)r[-stride + 1]);
-                // s_eoTable (sao.cpp:65) folds sign + sign + 2 = 0..4 into the categories 1, 2, 0, 3, 4
-#define XH_EO(cls, e2, cond) do { const int e = (e2) + 2; const int k = e == 0 ? 1 : e == 1 ? 2 : e == 2 ? 0 : e; const int v = (cond) ? one : 0; \
-                                  _Pragma("unroll") for (int q = 0; q < 5; q++) acc[cls][q] += k == q ? v : 0; } while (0)
-                XH_EO(0, sR + sL, in && lx >= x0[1] && lx < x1[1] && y < y1[1]);
-                XH_EO(1, sD + sU, in && lx < x1[2] && y >= y0[2] && y < y1[2]);
-                XH_EO(2, sDR + sUL, in && eo23 && lx >= x0[3] && lx < x1[3] && y >= y0[3] && y < y1[3]);
-                XH_EO(3, sDL + sUR, in && eo23 && lx >= x0[4] && lx < x1[4] && y >= y0[4] && y < y1[4]);
-#undef XH_EO
-            }
-            // the band class: into this lane's own column (neighbours in a row mostly share a band: 64 atomics on one address cost what 64 serial ones do)
-            if (bo) bandCol[band * 64] += (1 << 16) + dBo;
-        }
-        XH_SSTAMP(2);
-        // the waves' edge accumulators: unpacked, totalled over each row of 16 lanes by four DPP adds (lane 15 of a row holds its total), the 16 row totals
-        // of the workgroup go through LDS: hist[832 + item * 16 + wave * 4 + row], item = (class * 5 + category) * 2 + (0 sum, 1 count); thread t < 40 adds up
-        // item t's sixteen numbers
+            const unsigned char* r = rec0 + y * stride + xi;
+            const int c = r[0], d = (int)fenc0[y * w + xi] - c;
+            const int one = valid ? (1 << 16) + d : 0;
+            // sign(c - neighbour) = the difference clamped to [-1, 1] (v_med3_i32)
+            const int sR = clip3i(-1, 1, c - (int)r[1]), sL = clip3i(-1, 1, c - (int)r[-1]), sD = clip3i(-1, 1, c - (int)r[stride]), sU = clip3i(-1, 1, c - (int)r[-stride]);
+            const int sDR = clip3i(-1, 1, c - (int)r[stride + 1]), sUL = clip3i(-1, 1, c - (int)r[-stride - 1]);
+            const int sDL = clip3i(-1, 1, c - (int)r[stride - 1]), sUR = clip3i(-1, 1, c - (int)r[-stride + 1]);
+            // (the row tests are wave-uniform: y is)
+            const bool r0 = y < y1[0], r1 = y < y1[1], r2 = y >= y0[2] && y < y1[2], r3 = y >= y0[3] && y < y1[3], r4 = y >= y0[4] && y < y1[4];
+            __hip_atomic_fetch_add(bandCol + (c >> 3) * 64, cx0 && r0 ? one : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(edgeCol + (0 * 5 + sR + sL + 2) * 64, cx1 && r1 ? one : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(edgeCol + (1 * 5 + sD + sU + 2) * 64, cx2 && r2 ? one : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(edgeCol + (2 * 5 + sDR + sUL + 2) * 64, cx3 && r3 ? one : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(edgeCol + (3 * 5 + sDL + sUR + 2) * 64, cx4 && r4 ? one : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        for (int y = ly; y < h; y += 8)
         {
-            int* part = hist + 832;
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-#pragma unroll
-                for (int k = 0; k < 5; k++)
-                {
-                    const int sumL = (int)(short)(acc[c][k] & 0xffff), cntL = (acc[c][k] - sumL) >> 16;
-                    const int sr = row_total_lane15(sumL), cr = row_total_lane15(cntL);
-                    if ((lx & 15) == 15)
-                    {
-                        part[((c * 5 + k) * 2 + 0) * 16 + ly * 4 + (lx >> 4)] = sr;
-                        part[((c * 5 + k) * 2 + 1) * 16 + ly * 4 + (lx >> 4)] = cr;
-                    }
-                }
+            const bool second = y + 4 < h;
+            classify(y, true);
+            classify(second ? y + 4 : y, second);
         }
         __syncthreads();
-        if (tid < 40)
+        XH_SSTAMP(2);
+        // the edge classes: wave c totals class c's five columns sets (six DPP adds each for sums and counts); s_eoTable (sao.cpp:65) folds sign + sign + 2 =
+        // 0..4 into the categories 1, 2, 0, 3, 4
         {
-            const int* q = hist + 832 + tid * 16;
-            int t = 0;
 #pragma unroll
-            for (int i = 0; i < 16; i++) t += q[i];
-            const int item = tid >> 1, c = item / 5, k = item - c * 5;
-            hist[(tid & 1) * 160 + (c + 1) * 32 + k] = t;
+            for (int e = 0; e < 5; e++)
+            {
+                const int v = hist[320 + (ly * 5 + e) * 64 + lx];
+                const int sumL = (int)(short)(v & 0xffff), cntL = (v - sumL) >> 16;
+                const int ts = wave_total_lane63(sumL), tc = wave_total_lane63(cntL);
+                const int k = e == 0 ? 1 : e == 1 ? 2 : e == 2 ? 0 : e;
+                if (lx == 63)
+                {
+                    hist[(ly + 1) * 32 + k] = ts;
+                    hist[160 + (ly + 1) * 32 + k] = tc;
+                }
+            }
         }
         XH_SSTAMP(3);
-        __syncthreads();
-        // the band class: thread t adds up 32 columns of band t / 8 (all four waves' columns of a band lie 2 048 entries apart), the eight threads of a
-        // band combine by DPP
+        // the band class: thread t adds up eight columns of band t / 8, the eight threads of a band combine by DPP
         {
-            const int bnd = tid >> 3, seg = tid & 7;                          // columns seg * 32 .. seg * 32 + 31 of the band's 256
-            const int* col = hist + 1472 + (seg >> 1) * 2048 + bnd * 64 + (seg & 1) * 32;
+            const int bnd = tid >> 3, seg = tid & 7;
+            const int* col = hist + 1600 + bnd * 64 + seg * 8;
             int sumB = 0, cntB = 0;
-#pragma unroll 8
-            for (int i = 0; i < 32; i++)
+#pragma unroll
+            for (int i = 0; i < 8; i++)
             {
                 const int v = col[i];
                 const int sL = (int)(short)(v & 0xffff);
@@ -833,46 +1200,67 @@ __device__ __forceinline__ void run_intra(SlotOut* s, JobLds& L, uint32_t seq, u
     __syncthreads();
 }
 
-// one job: `ticket` says how many bytes the job holds, so header and pixels arrive in one round trip
-__device__ __forceinline__ void run_job(const SlotIn* sin, SlotOut* s, JobLds& L, uint32_t ticket, uint64_t* busyTicks)
+// one job: `ticket` says how many bytes the job holds, so header and pixels arrive in one round trip.  role 0 / 1: this workgroup's half of a CU job (luma /
+// chroma: each fetches the header and its own planes only); SAO statistics and intra scans are role 0's alone
+__device__ __forceinline__ void run_job(const SlotIn* sin, SlotOut* s, JobLds& L, uint32_t ticket, uint64_t* busyTicks, int role, bool team)
 {
     const int tid = threadIdx.x;
+    const bool cuJob = (ticket & 3) != 3;
+    if (role && (!cuJob || !(ticket & 4)))
+        return;                                                              // nothing of this job is role 1's (uniform over the workgroup)
     const uint64_t t0 = wall_clock64();
-    const int chunks = (128 + (int)ticket_bytes(ticket)) >> 4;
     const uint4* in = reinterpret_cast<const uint4*>(&sin->job);
     uint4* out = reinterpret_cast<uint4*>(&L.job);
-    for (int i = tid; i < chunks; i += 256)
-        out[i] = in[i];
+    if (!cuJob)
+    {
+        const int chunks = (128 + (int)ticket_bytes(ticket)) >> 4;
+        for (int i = tid; i < chunks; i += 256)
+            out[i] = in[i];
+    }
+    else
+    {
+        // header (8 chunks), then the role's planes of the source and of the prediction: luma n2 * B bytes at 0, chroma n2 / 2 * B bytes behind it, the
+        // prediction planeBytes further on (all multiples of 16)
+        const int B = (ticket & 8) ? 2 : 1, n2 = 1 << (2 * ((int)(ticket & 3) + 4));
+        const int planeBytes = ((ticket & 4) ? n2 + n2 / 2 : n2) * B;
+        const int first = (role ? n2 * B : 0) >> 4, count = (role ? (n2 / 2) * B : n2 * B) >> 4, pred = planeBytes >> 4;
+        for (int i = tid; i < 8 + 2 * count; i += 256)
+        {
+            const int k = i < 8 ? i : i < 8 + count ? 8 + first + (i - 8) : 8 + pred + first + (i - 8 - count);
+            out[k] = in[k];
+        }
+    }
     __syncthreads();
-    if ((ticket & 3) == 3)
+    if (!cuJob)
     {
         const x265hip_intrajob& ij = *reinterpret_cast<const x265hip_intrajob*>(&L.job);
         if (!(ij.mark & X265HIP_INTRAJOB_MARK)) run_sao(s, L, ticket, t0);
         else if (ij.bitDepth > 8) run_intra<uint16_t>(s, L, ticket, t0);
         else run_intra<uint8_t>(s, L, ticket, t0);
     }
-    else if (ticket & 8) run_tiles<uint16_t>(s, L, ticket, t0);
-    else run_tiles<uint8_t>(s, L, ticket, t0);
+    else if (ticket & 8) run_tiles<uint16_t>(s, L, ticket, t0, role, team);
+    else run_tiles<uint8_t>(s, L, ticket, t0, role, team);
     __syncthreads();
     if (tid == 0)
         *busyTicks += wall_clock64() - t0;
 }
 
-// mode 1: one job, one launch
-__global__ __launch_bounds__(256) void cu_job_kernel(const SlotIn* sin, SlotOut* s, uint32_t ticket, uint64_t* busyTicks)
+// mode 1: one job, one launch of the pair
+__global__ __launch_bounds__(256) void cu_job_kernel(const SlotIn* sin, SlotOut* s, uint32_t ticket, uint64_t* busyTicks, uint32_t team)
 {
     __shared__ JobLds L;
     build_operands(L);
-    run_job(sin, s, L, ticket, busyTicks);
+    run_job(sin, s, L, ticket, busyTicks + blockIdx.x, (int)blockIdx.x, team != 0);
 }
 
-// mode 0: workgroup b serves slot b.  The server as a whole leaves when no workgroup has taken a job for `idleTicks` (100 MHz) or the host rings
+// mode 0: workgroups 2b and 2b + 1 serve slot b (roles 0 and 1, run_tiles).  The server as a whole leaves when no workgroup has taken a job for `idleTicks` (100 MHz) or the host rings
 // 0xffffffff on any slot: the workgroup that notices sets ctl->quit, every workgroup leaves at its next poll, the last one tells the host.
 __global__ __launch_bounds__(256) void cu_server_kernel(const SlotIn* ins, SlotOut* outs, HostCtl* hostCtl, DevCtl* ctl, uint32_t generation, uint64_t idleTicks)
 {
     __shared__ JobLds L;
-    const SlotIn* sin = ins + blockIdx.x;
-    SlotOut* s = outs + blockIdx.x;
+    const int role = (int)(blockIdx.x & 1);
+    const SlotIn* sin = ins + (blockIdx.x >> 1);
+    SlotOut* s = outs + (blockIdx.x >> 1);
     build_operands(L);
     uint32_t last = 0;
     if (threadIdx.x == 0)
@@ -880,8 +1268,18 @@ __global__ __launch_bounds__(256) void cu_server_kernel(const SlotIn* ins, SlotO
         // "the server has had work" starts now for every workgroup, whichever gets on the chip first (the word still holds the previous server's time)
         __hip_atomic_fetch_max(&ctl->lastWork, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = __hip_atomic_load(&sin->doorbell, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-        // a job rung while no server was there has not been done: its first unit is not ready
-        if (last && last != 0xffffffffu && __hip_atomic_load(&s->units[0].ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != last)
+        // a job rung while no server was there has not been done: the first unit of this workgroup's share is not ready (role 1: the first chroma unit of a
+        // CU job with chroma — the units behind the largest level's luma units; the header of a rung job is in the slot)
+        int firstUnit = 0;
+        if (role && last && last != 0xffffffffu && (last & 3) != 3 && (last & 4))
+        {
+            const uint32_t log2cu = (last & 3) + 4, trMax = __hip_atomic_load(&sin->job.log2TrMax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const uint32_t sHi = trMax < 5 ? (trMax < log2cu ? trMax : log2cu) : (log2cu < 5 ? log2cu : 5);
+            firstUnit = 1 << (2 * (log2cu - sHi));
+        }
+        else if (role)
+            firstUnit = -1;                                                  // (not a job role 1 has a share in: nothing to look at)
+        if (firstUnit >= 0 && last && last != 0xffffffffu && __hip_atomic_load(&s->units[firstUnit].ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != last)
             last = 0;
         // serverState has ONE writer, workgroup 0 (two workgroups' stores to the same host word may arrive in either order)
         if (blockIdx.x == 0)
@@ -910,13 +1308,14 @@ __global__ __launch_bounds__(256) void cu_server_kernel(const SlotIn* ins, SlotO
                     // read the word first, the clock second: another workgroup may store a later time in between, never an earlier one
                     const uint64_t lw = __hip_atomic_load(&ctl->lastWork, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const uint64_t now = wall_clock64();
-                    if (now > lw && now - lw > (idleTicks & ~(1ull << 63)))
+                    if (now > lw && now - lw > (idleTicks & ~(3ull << 62)))
                     {
                         __hip_atomic_store(&ctl->quit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         v = 0xffffffffu;
                         break;
                     }
                 }
+                // (bit 62 of idleTicks: X265HIP_CUSERVE_TEAM=0, see team_off())
                 // X265HIP_CUSERVE_SPIN=1 (bit 63 of idleTicks): no sleep between polls — an experiment: does a chip that sees busy CUs clock higher?
                 if (!(idleTicks >> 63)) __builtin_amdgcn_s_sleep(2);
             }
@@ -945,7 +1344,7 @@ __global__ __launch_bounds__(256) void cu_server_kernel(const SlotIn* ins, SlotO
             return;
         }
         last = v;
-        run_job(sin, s, L, v, &ctl->busyTicks[blockIdx.x]);
+        run_job(sin, s, L, v, &ctl->busyTicks[blockIdx.x], role, !((idleTicks >> 62) & 1));
     }
 }
 
@@ -986,6 +1385,13 @@ static std::mutex g_openLock;
 static x265hip_cuserve* g_open[16];               // the services with a resident server (mode 0)
 static int g_pauseDepth;                          // servers_pause() calls without their servers_resume() yet (under g_openLock): a service opened meanwhile joins them
 
+// X265HIP_CUSERVE_TEAM=0: 32x32 luma units run on one wave each (rounds 4-5's form; A/B switch for the team form of round 6)
+static bool team_off()
+{
+    static const bool off = getenv("X265HIP_CUSERVE_TEAM") && !atoi(getenv("X265HIP_CUSERVE_TEAM"));
+    return off;
+}
+
 static int start_server(x265hip_cuserve* cs)
 {
     std::lock_guard<std::mutex> g(cs->launchLock);
@@ -1002,8 +1408,8 @@ static int start_server(x265hip_cuserve* cs)
     hipError_t e = hipMemsetAsync(cs->ctl, 0, 8, cs->serverStream);
     if (e == hipSuccess)
     {
-        hipLaunchKernelGGL(cu_server_kernel, dim3(cs->slots), dim3(256), 0, cs->serverStream, cs->inDev, cs->outDev, cs->devHostCtl, cs->ctl, gen ? gen : 1u,
-                           cs->idleUs * 100 | (getenv("X265HIP_CUSERVE_SPIN") && atoi(getenv("X265HIP_CUSERVE_SPIN")) ? 1ull << 63 : 0ull));
+        hipLaunchKernelGGL(cu_server_kernel, dim3(2 * cs->slots), dim3(256), 0, cs->serverStream, cs->inDev, cs->outDev, cs->devHostCtl, cs->ctl, gen ? gen : 1u,
+                           cs->idleUs * 100 | (getenv("X265HIP_CUSERVE_SPIN") && atoi(getenv("X265HIP_CUSERVE_SPIN")) ? 1ull << 63 : 0ull) | (team_off() ? 1ull << 62 : 0ull));
         e = hipGetLastError();
     }
     if (cur >= 0 && cur != cs->device) (void)hipSetDevice(cur);
@@ -1063,8 +1469,8 @@ int x265hip_cuserve_open(int slots, int mode, x265hip_cuserve** out)
         {
             const int perCu = lds / (int)sizeof(JobLds) > 0 ? lds / (int)sizeof(JobLds) : 1;
             const int fit = (cus - cus / 4) * perCu;
-            if (slots > fit)
-                return set_error(X265HIP_EINVAL, "x265hip_cuserve_open: %d resident workgroups asked for, %d fit beside the other kernels (%d CUs, %d per CU)", slots, fit, cus, perCu);
+            if (2 * slots > fit)
+                return set_error(X265HIP_EINVAL, "x265hip_cuserve_open: %d resident workgroups (two per slot) asked for, %d fit beside the other kernels (%d CUs, %d per CU)", 2 * slots, fit, cus, perCu);
         }
         else
             (void)hipGetLastError();
@@ -1149,7 +1555,7 @@ int x265hip_cuserve_open(int slots, int mode, x265hip_cuserve** out)
                 cs->paused = g_pauseDepth;
                 __atomic_store_n(&cs->hostCtl->leave, 1u, __ATOMIC_RELEASE);
             }
-            if (registered) resident_workgroups(cs->device, slots);
+            if (registered) resident_workgroups(cs->device, 2 * slots);
         }
         // (closed outside the lock: x265hip_cuserve_close and the device_free() it reaches take g_openLock themselves)
         if (!registered) { x265hip_cuserve_close(cs); return set_error(X265HIP_EINVAL, "x265hip_cuserve_open: more than %d services with a resident server", (int)(sizeof(g_open) / sizeof(g_open[0]))); }
@@ -1161,14 +1567,14 @@ int x265hip_cuserve_open(int slots, int mode, x265hip_cuserve** out)
 static uint64_t device_ticks(x265hip_cuserve* cs)
 {
     if (!cs->ctl) return 0;
-    static thread_local uint64_t buf[256];
+    static thread_local uint64_t buf[512];
     // a plain copy on the null stream would wait for the resident server: copy on a stream of its own
     hipStream_t st = nullptr;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return 0; }
     uint64_t ticks = 0;
-    if (hipMemcpyAsync(buf, (char*)cs->ctl + offsetof(DevCtl, busyTicks), sizeof(uint64_t) * cs->slots, hipMemcpyDeviceToHost, st) == hipSuccess &&
+    if (hipMemcpyAsync(buf, (char*)cs->ctl + offsetof(DevCtl, busyTicks), sizeof(uint64_t) * 2 * cs->slots, hipMemcpyDeviceToHost, st) == hipSuccess &&
         hipStreamSynchronize(st) == hipSuccess)
-        for (int i = 0; i < cs->slots; i++) ticks += buf[i];
+        for (int i = 0; i < 2 * cs->slots; i++) ticks += buf[i];
     else
         (void)hipGetLastError();
     (void)hipStreamDestroy(st);
@@ -1193,7 +1599,7 @@ int x265hip_cuserve_close(x265hip_cuserve* cs)
     {
         std::lock_guard<std::mutex> g(g_openLock);
         for (x265hip_cuserve*& slot : g_open)
-            if (slot == cs) { slot = nullptr; resident_workgroups(cs->device, -cs->slots); }
+            if (slot == cs) { slot = nullptr; resident_workgroups(cs->device, -2 * cs->slots); }
     }
     if (cs->in)
     {
@@ -1256,7 +1662,7 @@ int x265hip_cuserve_submit(x265hip_cuserve* cs, int slot, uint32_t* seqOut)
         int cur = -1;
         (void)hipGetDevice(&cur);
         if (cur != cs->device) (void)hipSetDevice(cs->device);
-        hipLaunchKernelGGL(cu_job_kernel, dim3(1), dim3(256), 0, cs->jobStreams[slot], cs->inDev + slot, cs->outDev + slot, seq, &cs->ctl->busyTicks[slot]);
+        hipLaunchKernelGGL(cu_job_kernel, dim3(2), dim3(256), 0, cs->jobStreams[slot], cs->inDev + slot, cs->outDev + slot, seq, &cs->ctl->busyTicks[2 * slot], team_off() ? 0u : 1u);
         const hipError_t le = hipGetLastError();
         if (cur >= 0 && cur != cs->device) (void)hipSetDevice(cur);
         if (le != hipSuccess) return check_hip(le, "cu_job_kernel");
@@ -1301,7 +1707,7 @@ int x265hip_cuserve_submit_sao(x265hip_cuserve* cs, int slot, const x265hip_saoj
         int cur = -1;
         (void)hipGetDevice(&cur);
         if (cur != cs->device) (void)hipSetDevice(cs->device);
-        hipLaunchKernelGGL(cu_job_kernel, dim3(1), dim3(256), 0, cs->jobStreams[slot], cs->inDev + slot, cs->outDev + slot, seq, &cs->ctl->busyTicks[slot]);
+        hipLaunchKernelGGL(cu_job_kernel, dim3(2), dim3(256), 0, cs->jobStreams[slot], cs->inDev + slot, cs->outDev + slot, seq, &cs->ctl->busyTicks[2 * slot], team_off() ? 0u : 1u);
         const hipError_t le = hipGetLastError();
         if (cur >= 0 && cur != cs->device) (void)hipSetDevice(cur);
         if (le != hipSuccess) return check_hip(le, "cu_job_kernel (SAO statistics)");
@@ -1339,7 +1745,7 @@ int x265hip_cuserve_submit_intra(x265hip_cuserve* cs, int slot, const x265hip_in
         int cur = -1;
         (void)hipGetDevice(&cur);
         if (cur != cs->device) (void)hipSetDevice(cs->device);
-        hipLaunchKernelGGL(cu_job_kernel, dim3(1), dim3(256), 0, cs->jobStreams[slot], cs->inDev + slot, cs->outDev + slot, seq, &cs->ctl->busyTicks[slot]);
+        hipLaunchKernelGGL(cu_job_kernel, dim3(2), dim3(256), 0, cs->jobStreams[slot], cs->inDev + slot, cs->outDev + slot, seq, &cs->ctl->busyTicks[2 * slot], team_off() ? 0u : 1u);
         const hipError_t le = hipGetLastError();
         if (cur >= 0 && cur != cs->device) (void)hipSetDevice(cur);
         if (le != hipSuccess) return check_hip(le, "cu_job_kernel (intra scan)");

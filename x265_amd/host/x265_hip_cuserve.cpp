@@ -24,65 +24,12 @@
 //
 // Seams (same link technique as the other seams, oracle/Makefile): Search::estimateResidualQT, Search::checkIntraInInter on search.o;
 // Quant::transformNxN, Quant::invtransformNxN on quant.o; Search::encodeResAndCalcRdInterCU (the scope) with the reference's body renamed in place.
-#include <atomic>
-#include <ctime>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
-#include <utility>
-#include <string>
-
-#define protected public
-#define private public
-#include "common.h"
-#include "frame.h"
-#include "framedata.h"
-#include "picyuv.h"
-#include "primitives.h"
-#include "yuv.h"
-#include "shortyuv.h"
-#include "cudata.h"
-#include "quant.h"
-#include "scalinglist.h"
-#include "search.h"
-#include "analysis.h"
-#include "sao.h"
-#undef protected
-#undef private
-
-#include <sched.h>
-#include "x265hip.h"
-#include "x265_hip_debug.h"
+#include "x265_hip_cuserve.h"
 
 namespace X265_NS {
 
-const EncoderPrimitives& x265hip_c_table();          // x265_hip_primitives.cpp
+namespace cusvc {
 
-extern void refEstimateResidualQT(Search* self, Mode& mode, const CUGeom& cuGeom, uint32_t absPartIdx, uint32_t tuDepth, ShortYuv& resiYuv, Search::Cost& outCosts,
-                                  const uint32_t depthRange[2], int32_t splitMore)
-    asm("_ZN4x2659SearchRef18estimateResidualQTERNS_4ModeERKNS_6CUGeomEjjRNS_8ShortYuvERNS0_4CostEPKji");
-extern void refCheckIntraInInter(Search* self, Mode& intraMode, const CUGeom& cuGeom) asm("_ZN4x2659SearchRef17checkIntraInInterERNS_4ModeERKNS_6CUGeomE");
-extern void refEncodeResAndCalcRdInterCU(Search* self, Mode& interMode, const CUGeom& cuGeom) asm("_ZN4x2656Search29encodeResAndCalcRdInterCUBodyERNS_4ModeERKNS_6CUGeomE");
-extern void refEncodeResAndCalcRdSkipCU(Search* self, Mode& interMode) asm("_ZN4x2656Search28encodeResAndCalcRdSkipCUBodyERNS_4ModeE");
-extern void refPredInterSearch(Search* self, Mode& interMode, const CUGeom& cuGeom, bool bChromaMC, uint32_t refMasks[2])
-    asm("_ZN4x2656Search19predInterSearchBodyERNS_4ModeERKNS_6CUGeomEbPj");
-#if X265_DEPTH == 8
-extern uint32_t refTransformNxN(Quant* self, const CUData& cu, const pixel* fenc, uint32_t fencStride, const int16_t* residual, uint32_t resiStride, coeff_t* coeff,
-                                uint32_t log2TrSize, TextType ttype, uint32_t absPartIdx, bool useTransformSkip)
-    asm("_ZN4x2658QuantRef12transformNxNERKNS_6CUDataEPKhjPKsjPsjNS_8TextTypeEjb");
-#else
-extern uint32_t refTransformNxN(Quant* self, const CUData& cu, const pixel* fenc, uint32_t fencStride, const int16_t* residual, uint32_t resiStride, coeff_t* coeff,
-                                uint32_t log2TrSize, TextType ttype, uint32_t absPartIdx, bool useTransformSkip)
-    asm("_ZN4x2658QuantRef12transformNxNERKNS_6CUDataEPKtjPKsjPsjNS_8TextTypeEjb");
-#endif
-extern void refInvtransformNxN(Quant* self, const CUData& cu, int16_t* residual, uint32_t resiStride, const coeff_t* coeff, uint32_t log2TrSize, TextType ttype,
-                               bool bIntra, bool useTransformSkip, uint32_t numSig)
-    asm("_ZN4x2658QuantRef15invtransformNxNERKNS_6CUDataEPsjPKsjNS_8TextTypeEbbj");
-
-extern void refCalcSaoStatsCTU(SAO* self, int addr, int plane) asm("_ZN4x2656SAORef15calcSaoStatsCTUEii");
-
-namespace {
 
 int g_state = 0;                 // 0 undecided, 1 on, -1 off
 int g_time = 0;                  // X265HIP_DEBUG_CUTIME=1: cycles inside the functions a job could replace, by block size (report at exit);
@@ -98,15 +45,6 @@ int g_slots = 64;                // X265HIP_CUSERVE_SLOTS: jobs that can be in f
 bool g_verify = false;           // X265HIP_VERIFY=1: every served unit is recomputed by the reference's function and compared
 bool g_require = false;          // X265HIP=require: a device failure is fatal instead of falling back
 std::mutex g_lock;
-struct SlotMem { x265hip_cujob* job; void* pixels; const x265hip_cujob_unit* units; const int16_t* levels; const int16_t* resi; };
-// one job service per place (X265HIP_DEVICES; one on the calling thread's device when no places are configured): every GPU of the encoder serves CU jobs
-struct Service
-{
-    x265hip_cuserve* cs;
-    SlotMem mem[256];
-    std::atomic<uint64_t> busy[4];           // bit s of word s / 64: slot s holds a job of some thread (a slot is taken per job, not per thread: x265 starts
-                                             // one pool thread per core it sees, far more than ever run at once under a CPU quota)
-};
 Service g_svc[16];
 std::atomic<int> g_nsvc(0);                  // services open (published last)
 std::atomic<bool> g_dead(false); // the device failed once: every later CU is computed on the host
@@ -121,6 +59,7 @@ Counters g_count[64];
 std::atomic<int> g_nextShard(0);
 __attribute__((tls_model("initial-exec"))) thread_local int t_shard = -1;
 inline Counters& counters() { if (t_shard < 0) t_shard = g_nextShard.fetch_add(1) & 63; return g_count[t_shard]; }
+void touch_shard() { counters(); }
 
 // the job of the top-level estimateResidualQT in progress on this thread
 struct Job
@@ -169,7 +108,6 @@ bool g_spec = true;                  // X265HIP_CUSERVE_SPEC=0: no job is submit
 int g_serveDist = 1;                 // X265HIP_CUSERVE_DIST=0: transforms only; 1: + the tree's distortions; 2: + the CU's final sse_pp / psy cost; 3 (default): + the body's sub_ps / add_ps calls nobody reads any more are not run
 __attribute__((tls_model("initial-exec"))) thread_local int t_hint = -1;           // where this thread looks first
 
-void end_job();
 void report_time()
 {
     static const char* const what[4] = { "Quant::transformNxN", "Quant::invtransformNxN", "Search::estimateResidualQT (top level, whole tree)", "Search::checkIntraInInter" };
@@ -357,13 +295,6 @@ int take_slot(Service** svc)
     }
     return -1;
 }
-inline void give_slot(Service* sv, int s) { sv->busy[s >> 6].fetch_and(~(1ull << (s & 63)), std::memory_order_release); }
-
-template <typename T> inline void pack_rows(T*& dst, const T* src, uint32_t stride, int n)
-{
-    if ((int)stride == n) { memcpy(dst, src, sizeof(T) * n * n); dst += n * n; return; }
-    for (int y = 0; y < n; y++, dst += n) memcpy(dst, src + (size_t)y * stride, sizeof(T) * n);
-}
 
 // unit of this thread's job a residual block belongs to, or -1
 inline int locate(const Job& j, const int16_t* residual, uint32_t resiStride, uint32_t log2TrSize, int ttype, int* elemOff)
@@ -456,17 +387,12 @@ inline bool wait_word(Job& j, const uint32_t* ready, int site)
     return true;
 }
 
-struct Timed
-{
-    int k; uint64_t t0;
-    Timed(int slot) : k(slot), t0(__builtin_ia32_rdtsc()) {}
-    ~Timed()
-    {
-        const int w = k < 8 ? !t_inRqt : 0;
-        g_cycles[k][w].fetch_add(__builtin_ia32_rdtsc() - t0, std::memory_order_relaxed);
-        g_calls[k][w].fetch_add(1, std::memory_order_relaxed);
-    }
-};
+
+
+} // namespace cusvc
+
+using namespace cusvc;
+namespace {
 
 // the header of the job this CU's residual quad-tree is; false: not a CU the device serves
 bool make_header(Search* se, const Mode& mode, uint32_t log2CUSize, const uint32_t depthRange[2], x265hip_cujob& hdr)
@@ -933,7 +859,6 @@ void report_scanhit()
             (unsigned long long)g_scanCalls[0].load(), g_scanCycles[0].load() * 1e-9, (unsigned long long)g_scanCalls[1].load(), g_scanCycles[1].load() * 1e-9);
 }
 
-void install_intra_slots(EncoderPrimitives& p);
 
 void x265hip_install_cuserve_slots(EncoderPrimitives& p)
 {
@@ -1082,10 +1007,7 @@ bool adopt(Search* se, Mode& mode, const CUGeom& cuGeom)
 // of the same prediction.  The prediction is final when the skip evaluation starts: the job leaves there, and the device works on it while this thread
 // evaluates the skip.  Nothing is answered from the job before its own scope starts (phase 0); a job whose scope never comes is dropped at the next
 // call of either function.
-void intra_ahead(Search* se, Mode& interMode, const CUGeom& cuGeom);
-void install_intra_slots(EncoderPrimitives& p);
 
-void intra_unasked();
 
 void Search::encodeResAndCalcRdSkipCU(Mode& interMode)
 {
@@ -1323,823 +1245,5 @@ void Quant::invtransformNxN(const CUData& cu, int16_t* residual, uint32_t resiSt
     refInvtransformNxN(this, cu, residual, resiStride, coeff, log2TrSize, ttype, bIntra, useTransformSkip, numSig);
 }
 
-
-// ---- SAO statistics as jobs of the same service (round 5; include/x265hip.h x265hip_saojob) --------------------------------------------------------------
-// SAO::calcSaoStatsCTU (reference source/encoder/sao.cpp:735-917) is called per plane from rdoSaoUnitCu (:1293-1305) for every CTU, two columns behind the
-// deblocking of the same row (framefilter.cpp:440-500): 5 classes x 3 planes of per-sample classification = ~50 us of CPU per CTU (6.8 % of the bound
-// encoder's CPU time in round 4's profile).  Its result is a function of the deblocked CTU (with the row above and the column to the left), the source CTU and
-// the rectangles the reference measures: the seam below computes the rectangles exactly as the reference does, hands the two blocks to the device — one job
-// for all planes when luma is asked for (the chroma planes are measured while this thread runs the luma offsets' RDO) — and adds the sums and counts it gets
-// back where the reference's primitives add theirs.  8-bit builds; X265HIP_SAOSTATS=0 switches it off; X265HIP_VERIFY recomputes with the reference's body.
-namespace {
-
-std::atomic<int> g_saoState(0);  // 0 undecided, 1 on, -1 off (written by whichever thread decides or sees the device fail)
-bool g_saoParts = false;         // X265HIP_SAOSTATS_PARTS=4: the luma plane goes as two jobs (upper / lower half).  Measured: 3 jobs per CTU 33.2 fps, 4 jobs 32.6, SAO on the host 30.9
-struct alignas(64) SaoCounters { std::atomic<uint64_t> jobs, planes, hostPlanes, waits, waitCycles, ahead; };
-SaoCounters g_saoCount[16];
-// One CTU's statistics are up to four PARTS, each a job of one block on a slot of its own — the upper and lower half of the luma CTU, Cb, Cr — so that four
-// workgroups measure at the same time (a part is a dependent chain of ~10 us on the device; sums and counts of the halves add up).  When slots are short the
-// CTU goes as fewer parts, down to one.
-struct SaoPart { int plane, slot; uint32_t seq; Service* svc; };
-struct SaoJob
-{
-    bool active;
-    const SAO* sao; int addr;
-    const void* encData; int poc;        // the picture the blocks were read from: a row's SAO object serves every frame its FrameEncoder codes, (sao, addr) alone
-                                         // would let a set orphaned in an earlier frame (ParallelFilter::processTasks hops between pool threads) be adopted
-    int nparts; SaoPart part[4];
-    bool consumed[3];                    // per plane
-    bool wanted[3];                      // planes this job carries
-};
-// two per thread: the CTU whose statistics are being asked for, and the NEXT CTU of the row, submitted ahead (see SAO::calcSaoStatsCTU below)
-__attribute__((tls_model("initial-exec"))) thread_local SaoJob t_saoSet[2];
-bool g_saoAhead = true;              // X265HIP_SAOSTATS_AHEAD=0: no CTU is submitted ahead of its request
-
-void sao_report()
-{
-    uint64_t jobs = 0, planes = 0, host = 0, w = 0, wc = 0, ah = 0;
-    for (int i = 0; i < 16; i++) { jobs += g_saoCount[i].jobs; planes += g_saoCount[i].planes; host += g_saoCount[i].hostPlanes; w += g_saoCount[i].waits; wc += g_saoCount[i].waitCycles; ah += g_saoCount[i].ahead; }
-    fprintf(stderr, "x265hip: saostats: SAO statistics of %llu CTU planes (SAO::calcSaoStatsCTU: band + four edge classes) measured by the GPU in %llu jobs, %llu planes on the host; "
-                    "%llu waits of %.0f cycles on average; %llu CTUs submitted one CTU ahead of their request\n", (unsigned long long)planes, (unsigned long long)jobs, (unsigned long long)host,
-            (unsigned long long)w, w ? (double)wc / w : 0.0, (unsigned long long)ah);
-}
-
-bool sao_enabled()
-{
-    if (!g_saoState)
-    {
-        std::lock_guard<std::mutex> g(g_lock);
-        if (!g_saoState)
-        {
-            const char* env = getenv("X265HIP_SAOSTATS");
-            const char* all = getenv("X265HIP");
-            const char* table = getenv("X265HIP_TABLE");
-            if (getenv("X265HIP_SAOSTATS_PARTS")) g_saoParts = atoi(getenv("X265HIP_SAOSTATS_PARTS")) > 3;
-            if (getenv("X265HIP_SAOSTATS_AHEAD")) g_saoAhead = atoi(getenv("X265HIP_SAOSTATS_AHEAD")) != 0;
-            if (X265_DEPTH != 8 || (env && !strcmp(env, "0")) || (all && !strcmp(all, "0")) || (table && !strcmp(table, "percall")))
-                g_saoState = -1;
-            else
-            {
-                g_saoState = 1;
-                if (getenv("X265HIP_VERBOSE")) atexit(sao_report);
-            }
-        }
-    }
-    return g_saoState > 0;
-}
-
-inline SaoCounters& sao_counters() { counters(); return g_saoCount[t_shard & 15]; }
-
-// the rectangles of one plane, exactly as sao.cpp:741-914 computes them (x265hip_saojob's plane block); false: a geometry the job does not carry
-struct SaoPlane { int w, h, x0[5], y0[5], x1[5], y1[5]; const pixel* rec0; const pixel* fenc0; intptr_t stride; bool eo23; };
-bool sao_rects(const SAO* sao, int addr, int plane, SaoPlane& out)
-{
-    const Frame* frame = sao->m_frame;
-    const x265_param* param = sao->m_param;
-    const Slice* slice = frame->m_encData->m_slice;
-    const PicYuv* reconPic = frame->m_reconPic;
-    const CUData* cu = frame->m_encData->getPicCTU(addr);
-    out.fenc0 = frame->m_fencPic->getPlaneAddr(plane, addr);
-    out.rec0 = reconPic->getPlaneAddr(plane, addr);
-    out.stride = plane ? reconPic->m_strideC : reconPic->m_stride;
-    if ((plane ? frame->m_fencPic->m_strideC : frame->m_fencPic->m_stride) != out.stride)
-        return false;                                    // (the reference indexes both pictures with the reconstruction's stride, :786-806)
-    uint32_t picWidth = param->sourceWidth, picHeight = param->sourceHeight;
-    int ctuWidth = param->maxCUSize, ctuHeight = param->maxCUSize;
-    uint32_t lpelx = cu->m_cuPelX, tpely = cu->m_cuPelY;
-    const uint32_t bAboveUnavail = (!tpely) | cu->m_bFirstRowInSlice;
-    if (plane)
-    {
-        picWidth >>= sao->m_hChromaShift; picHeight >>= sao->m_vChromaShift;
-        ctuWidth >>= sao->m_hChromaShift; ctuHeight >>= sao->m_vChromaShift;
-        lpelx >>= sao->m_hChromaShift; tpely >>= sao->m_vChromaShift;
-    }
-    const uint32_t rpelx = x265_min(lpelx + ctuWidth, picWidth), bpely = x265_min(tpely + ctuHeight, picHeight);
-    ctuWidth = rpelx - lpelx; ctuHeight = bpely - tpely;
-    if (cu->m_bLastRowInSlice)
-        picHeight = bpely;
-    if (ctuWidth < 1 || ctuHeight < 1 || ctuWidth > 64 || ctuHeight > 64)
-        return false;
-    const int po = plane ? 2 : 0;
-    const bool nd = param->bSaoNonDeblocked != 0;
-    const bool right = rpelx == picWidth, bottom = bpely == picHeight;
-    int* x0 = out.x0; int* y0 = out.y0; int* x1 = out.x1; int* y1 = out.y1;
-    // SAO_BO (:810-823): skipB 4 / skipR 5, non-deblocked 3 / 4
-    { const int skipB = nd ? 3 : 4, skipR = nd ? 4 : 5;
-      x0[0] = 0; y0[0] = 0; x1[0] = right ? ctuWidth : ctuWidth - skipR + po; y1[0] = bottom ? ctuHeight : ctuHeight - skipB + po; }
-    // SAO_EO_0 (:826-839): skipB 4 / skipR 5, non-deblocked 3 / 5; the rows are NOT shortened at the picture's bottom
-    { const int skipB = nd ? 3 : 4, skipR = 5;
-      x0[1] = !lpelx; y0[1] = 0; x1[1] = right ? ctuWidth - 1 : ctuWidth - skipR + po; y1[1] = ctuHeight - skipB + po; }
-    // SAO_EO_1 (:841-861): skipB 4, skipR 5 / non-deblocked 4
-    { const int skipB = 4, skipR = nd ? 4 : 5;
-      x0[2] = 0; y0[2] = bAboveUnavail; x1[2] = right ? ctuWidth : ctuWidth - skipR + po; y1[2] = bottom ? ctuHeight - 1 : ctuHeight - skipB + po; }
-    // SAO_EO_2 / SAO_EO_3 (:865-914): skipB 4, skipR 5
-    for (int c = 3; c < 5; c++)
-    { const int skipB = 4, skipR = 5;
-      x0[c] = !lpelx; y0[c] = bAboveUnavail; x1[c] = right ? ctuWidth - 1 : ctuWidth - skipR + po; y1[c] = bottom ? ctuHeight - 1 : ctuHeight - skipB + po; }
-    out.eo23 = !param->bLimitSAO || ((slice->m_sliceType == P_SLICE && !cu->isSkipped(0)) || (slice->m_sliceType != B_SLICE));
-    out.w = ctuWidth; out.h = ctuHeight;
-    for (int c = 0; c < 5; c++)
-        if (x1[c] <= x0[c] || y1[c] <= y0[c] || x1[c] < 0 || y1[c] < 0) { x0[c] = y0[c] = x1[c] = y1[c] = 0; }    // empty: the reference's loops measure nothing either
-    return true;
-}
-
-void sao_drop(SaoJob& sj, bool deviceDone)
-{
-    if (sj.active && deviceDone)
-        for (int k = 0; k < sj.nparts; k++) give_slot(sj.part[k].svc, sj.part[k].slot);
-    sj.active = false;
-}
-
-// waits for one part of this thread's SAO job; false: the device did not deliver
-bool sao_wait(SaoJob& sj, int k)
-{
-    const SaoPart& pt = sj.part[k];
-    const uint32_t* ready = &pt.svc->mem[pt.slot].units[0].ready;
-    if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == pt.seq) return true;
-    const uint64_t t0 = __builtin_ia32_rdtsc();
-    uint64_t spins = 0;
-    int64_t waitedNs = 0, lastNs = -1;
-    while (__atomic_load_n(ready, __ATOMIC_ACQUIRE) != pt.seq)
-    {
-        __builtin_ia32_pause();
-        if (g_yieldAfter && spins >= (uint64_t)g_yieldAfter) sched_yield();
-        if ((++spins & 255) == 0)
-        {
-            const int pk = x265hip_cuserve_poke(pt.svc->cs, pt.slot);
-            timespec ts;
-            clock_gettime(CLOCK_MONOTONIC, &ts);
-            const int64_t nowNs = (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
-            if (pk == 0 && lastNs >= 0) waitedNs += nowNs - lastNs;
-            lastNs = nowNs;
-            if (pk < 0 || waitedNs > g_timeoutNs)
-            {
-                sj.active = false;                       // the slots are not given back: the device may still write into them
-                g_saoState = -1;
-                x265hip_device_failure("saostats", "an SAO statistics job did not come back");
-                return false;
-            }
-        }
-    }
-    SaoCounters& c = sao_counters();
-    c.waits.fetch_add(1, std::memory_order_relaxed);
-    c.waitCycles.fetch_add(__builtin_ia32_rdtsc() - t0, std::memory_order_relaxed);
-    return true;
-}
-
-// rows [ra, rb) of plane `pl` as a one-block job on a free slot; false: no slot / the device refused
-bool sao_submit_part(SaoJob& sj, const SaoPlane& pl, int plane, int ra, int rb)
-{
-    Service* svc = NULL;
-    const int slot = take_slot(&svc);
-    if (slot < 0)
-        return false;
-    // the block: rows ra - 1 .. min(rb, h - 1) — one row above the first measured row and, unless the part ends with the plane, one below the last
-    const int rowsBelow = rb < pl.h ? 1 : 0, hh = rb - ra + rowsBelow, w = pl.w;
-    x265hip_saojob job;
-    memset(&job, 0, sizeof(job));
-    job.bitDepth = X265_DEPTH; job.planes = 1; job.eo23 = pl.eo23;
-    job.plane[0].w = (uint16_t)w; job.plane[0].h = (uint16_t)hh;
-    for (int c = 0; c < 5; c++)
-    {
-        int y0 = pl.y0[c] < ra ? ra : pl.y0[c], y1 = pl.y1[c] > rb ? rb : pl.y1[c];
-        int x0 = pl.x0[c], x1 = pl.x1[c];
-        if (y1 <= y0 || x1 <= x0) { x0 = x1 = 0; y0 = y1 = ra; }
-        job.plane[0].x0[c] = (uint8_t)x0; job.plane[0].x1[c] = (uint8_t)x1; job.plane[0].y0[c] = (uint8_t)(y0 - ra); job.plane[0].y1[c] = (uint8_t)(y1 - ra);
-    }
-    static thread_local pixel staged[66 * 65 + 65 * 64];
-    pixel* dst = staged;
-    const pixel* r = pl.rec0 + (intptr_t)(ra - 1) * pl.stride - 1;
-    for (int y = 0; y <= hh; y++, dst += w + 1) memcpy(dst, r + (intptr_t)y * pl.stride, (size_t)(w + 1) * sizeof(pixel));
-    const pixel* f = pl.fenc0 + (intptr_t)ra * pl.stride;
-    // (the source rows of the extra row below are carried but never measured: its samples lie outside every rectangle)
-    for (int y = 0; y < hh; y++, dst += w) memcpy(dst, f + (intptr_t)y * pl.stride, (size_t)w * sizeof(pixel));
-    memcpy(svc->mem[slot].pixels, staged, (size_t)(dst - staged) * sizeof(pixel));
-    uint32_t seq = 0;
-    if (x265hip_cuserve_submit_sao(svc->cs, slot, &job, &seq))
-    {
-        give_slot(svc, slot);
-        g_saoState = -1;
-        x265hip_device_failure("saostats", "x265hip_cuserve_submit_sao");
-        return false;
-    }
-    SaoPart& pt = sj.part[sj.nparts++];
-    pt.plane = plane; pt.slot = slot; pt.seq = seq; pt.svc = svc;
-    sao_counters().jobs.fetch_add(1, std::memory_order_relaxed);
-    return true;
-}
-
-// the parts for planes [first, first + n) of CTU `addr`; false: nothing was submitted
-bool sao_submit(SaoJob& sj, SAO* sao, int addr, int first, int n)
-{
-    if (g_dead.load(std::memory_order_relaxed) || !service())
-        return false;
-    SaoPlane pl[3];
-    for (int b = 0; b < n; b++)
-        if (!sao_rects(sao, addr, first + b, pl[b]))
-            return false;
-    sj.nparts = 0;
-    for (int p = 0; p < 3; p++) { sj.consumed[p] = false; sj.wanted[p] = false; }
-    for (int b = 0; b < n && g_saoState > 0; b++)
-    {
-        const int plane = first + b, h = pl[b].h;
-        // the luma plane in two halves when it is high enough to be worth a second workgroup
-        const int mid = plane == 0 && g_saoParts && h >= 32 ? (h / 2 + 3) & ~3 : h;
-        const int before = sj.nparts;
-        bool ok = sao_submit_part(sj, pl[b], plane, 0, mid) && (mid == h || sao_submit_part(sj, pl[b], plane, mid, h));
-        if (!ok)
-        {
-            // a plane is served whole or not at all: parts of it that did leave are waited out and dropped with the rest (below, by the caller's next call)
-            if (sj.nparts > before || b > 0) break;
-            return false;
-        }
-        sj.wanted[plane] = true;
-    }
-    // a plane whose second half found no slot: not wanted (its first half is still waited for before the slots go back)
-    for (int p = 0; p < 3; p++)
-    {
-        int have = 0;
-        for (int k = 0; k < sj.nparts; k++) have += sj.part[k].plane == p;
-        if (sj.wanted[p] && !have) sj.wanted[p] = false;
-    }
-    if (!sj.nparts)
-        return false;
-    sj.active = true; sj.sao = sao; sj.addr = addr; sj.encData = sao->m_frame->m_encData; sj.poc = sao->m_frame->m_poc;
-    return true;
-}
-
-// A pool thread that ends with sets still out (an ahead job whose CTU another thread served: up to four slots each) hands their slots back, like
-// IntraThreadEnd below: with 2 x CPUs slots in all, one closed encoder could otherwise leave most of them taken for the rest of the process
-struct SaoThreadEnd
-{
-    ~SaoThreadEnd()
-    {
-        std::lock_guard<std::mutex> g(g_lock);               // shutdown() closes the services under this lock
-        if (g_dead.load(std::memory_order_relaxed))
-            return;                                          // the services are closed (or failed): their slots are gone with them
-        for (SaoJob& t : t_saoSet)
-        {
-            if (!t.active)
-                continue;
-            bool done = true;
-            for (int k = 0; k < t.nparts && done; k++)
-            {
-                const SaoPart& pt = t.part[k];
-                const uint32_t* ready = &pt.svc->mem[pt.slot].units[0].ready;
-                for (int spins = 0; spins < 200000 && __atomic_load_n(ready, __ATOMIC_ACQUIRE) != pt.seq; spins++)     // a plane is ~15 us of device time
-                    __builtin_ia32_pause();
-                done = __atomic_load_n(ready, __ATOMIC_ACQUIRE) == pt.seq;
-            }
-            sao_drop(t, done);
-        }
-    }
-};
-thread_local SaoThreadEnd t_saoThreadEnd;
-
-} // namespace
-
-void SAO::calcSaoStatsCTU(int addr, int plane)
-{
-    if (g_saoState < 0 || !sao_enabled())
-    {
-        refCalcSaoStatsCTU(this, addr, plane);
-        return;
-    }
-    // this thread's sets: the one of this CTU (submitted ahead during the previous CTU, or now), and one free for the next CTU.  A set of any other CTU
-    // (its chroma planes were never asked for, or the row ended) is waited out and its slots go back
-    const int numCuInWidth = m_numCuInWidth;
-    const bool nextInRow = (addr + 1) % numCuInWidth != 0;
-    SaoJob* cur = NULL;
-    (void)&t_saoThreadEnd;                                   // (constructed on first use: registers the destructor with this thread)
-    for (SaoJob& t : t_saoSet)
-    {
-        if (!t.active) continue;
-        const bool thisPicture = t.sao == this && t.encData == (const void*)m_frame->m_encData && t.poc == m_frame->m_poc;
-        if (thisPicture && t.addr == addr) { cur = &t; continue; }
-        if (thisPicture && t.addr == addr + 1 && nextInRow) continue;
-        bool done = true;
-        for (int k = 0; k < t.nparts && done; k++) done = sao_wait(t, k);
-        sao_drop(t, done);
-    }
-    const bool chroma = m_param->internalCsp != X265_CSP_I400 && m_frame->m_fencPic->m_picCsp != X265_CSP_I400;
-    const SAOParam* sp = m_frame->m_encData->m_saoParam;
-    // luma asked for: the chroma planes ride along when the reference is going to ask for them whatever the luma decision (no --limit-sao, :1299-1306)
-    const int planesWithLuma = chroma && !m_param->bLimitSAO && sp && sp->bSaoFlag[1] && m_param->internalCsp == X265_CSP_I420 ? 3 : 1;
-    if (!cur)
-    {
-        for (SaoJob& t : t_saoSet)
-            if (!t.active) { cur = &t; break; }
-        if (cur)
-        {
-            if (plane == 0)
-                sao_submit(*cur, this, addr, 0, planesWithLuma);
-            else if (plane == 1 && m_param->internalCsp == X265_CSP_I420)
-                sao_submit(*cur, this, addr, 1, 2);
-            if (!cur->active) cur = NULL;
-        }
-    }
-    // The NEXT CTU of the row leaves now, while this thread decides this CTU's offsets.  Safe because of where the reference calls from
-    // (FrameFilter::ParallelFilter::processTasks, framefilter.cpp:463-500): rdoSaoUnitCu(col - 2) runs after deblockCTU(col, EDGE_VER) and
-    // deblockCTU(col - 1, EDGE_HOR) — CTU col - 1 is as deblocked as it will be when its own turn comes one column later (what deblockCTU(col + 1, VER) and
-    // (col, HOR) still change lies in CTU col and beyond; what the next CTU ROW's horizontal edges change lies in the 3 bottom rows every class leaves out),
-    // and the previous row's SAO is applied no further than column col - 3 before that turn (:495-499: processSaoCTU(col - 3) after this call), so the row
-    // above CTU col - 1 and its two corner samples are still the deblocked ones.  X265HIP_VERIFY compares every plane served this way with the reference's
-    // body at the reference's own time.
-    if (plane == 0 && g_saoAhead && nextInRow && g_saoState > 0 && sp && sp->bSaoFlag[0])
-    {
-        SaoJob* nxt = NULL;
-        bool have = false;
-        for (SaoJob& t : t_saoSet)
-        {
-            if (t.active && t.sao == this && t.addr == addr + 1 && t.encData == (const void*)m_frame->m_encData && t.poc == m_frame->m_poc) have = true;
-            else if (!t.active && &t != cur && !nxt) nxt = &t;
-        }
-        if (!have && nxt)
-        {
-            sao_submit(*nxt, this, addr + 1, 0, planesWithLuma);
-            if (nxt->active) sao_counters().ahead.fetch_add(1, std::memory_order_relaxed);
-        }
-    }
-    if (!cur)
-    {
-        sao_counters().hostPlanes.fetch_add(1, std::memory_order_relaxed);
-        refCalcSaoStatsCTU(this, addr, plane);
-        return;
-    }
-    SaoJob& sj = *cur;
-    if (sj.active && g_saoState > 0 && sj.wanted[plane] && !sj.consumed[plane])
-    {
-        bool ok = true;
-        for (int k = 0; k < sj.nparts && ok; k++)
-            if (sj.part[k].plane == plane) ok = sao_wait(sj, k);
-        if (ok)
-        {
-            static const int typeOf[5] = { SAO_BO, SAO_EO_0, SAO_EO_1, SAO_EO_2, SAO_EO_3 };
-            int32_t st[160], ct[160];
-            memset(st, 0, sizeof(st)); memset(ct, 0, sizeof(ct));
-            for (int k = 0; k < sj.nparts; k++)
-                if (sj.part[k].plane == plane)
-                {
-                    const int32_t* out = (const int32_t*)sj.part[k].svc->mem[sj.part[k].slot].levels;
-                    for (int i = 0; i < 160; i++) { st[i] += out[i]; ct[i] += out[X265HIP_SAOJOB_STATS_ENTRIES + i]; }
-                }
-            if (g_verify)
-            {
-                PerClass keepC, keepO;
-                memcpy(keepC, m_count[plane], sizeof(keepC)); memcpy(keepO, m_offsetOrg[plane], sizeof(keepO));
-                refCalcSaoStatsCTU(this, addr, plane);
-                for (int c = 0; c < 5; c++)
-                    for (int k = 0; k < (c ? 5 : 32); k++)
-                        if (m_count[plane][typeOf[c]][k] != keepC[typeOf[c]][k] + ct[c * 32 + k] || m_offsetOrg[plane][typeOf[c]][k] != keepO[typeOf[c]][k] + st[c * 32 + k])
-                        {
-                            fprintf(stderr, "x265hip: saostats: VERIFY FAILED CTU %d plane %d class %d bin %d: count %d + %d vs %d, sum %d + %d vs %d\n", addr, plane, c, k, keepC[typeOf[c]][k],
-                                    ct[c * 32 + k], m_count[plane][typeOf[c]][k], keepO[typeOf[c]][k], st[c * 32 + k], m_offsetOrg[plane][typeOf[c]][k]);
-                            abort();
-                        }
-            }
-            else
-                for (int c = 0; c < 5; c++)
-                    for (int k = 0; k < (c ? 5 : 32); k++)
-                    {
-                        m_count[plane][typeOf[c]][k] += ct[c * 32 + k];
-                        m_offsetOrg[plane][typeOf[c]][k] += st[c * 32 + k];
-                    }
-            sj.consumed[plane] = true;
-            sao_counters().planes.fetch_add(1, std::memory_order_relaxed);
-            bool all = true;
-            for (int p = 0; p < 3; p++) all = all && (!sj.wanted[p] || sj.consumed[p]);
-            if (all)
-            {
-                // (parts of planes that were dropped half-submitted are waited for like the rest)
-                bool done = true;
-                for (int k = 0; k < sj.nparts && done; k++) done = sao_wait(sj, k);
-                sao_drop(sj, done);
-            }
-            return;
-        }
-    }
-    sao_counters().hostPlanes.fetch_add(1, std::memory_order_relaxed);
-    refCalcSaoStatsCTU(this, addr, plane);
-}
-
-// ---- the intra mode scan of Search::checkIntraInInter as a job ------------------------------------------------------------------------------------------
-// In a P slice (or with --b-intra) every CU below 64x64 whose best inter mode has a residual is also tried as intra (analysis.cpp:1630-1663): 35 predictions
-// and 35 sa8d calls per block, 5-6 % of the bound encoder's CPU time and all of it in the frames the others wait for (call chains of tools/prof/callers.py,
-// profiles/r05_v1_sa8d_callers.txt).  The distortion half goes to the device as an x265hip_intrajob (include/x265hip.h): the two neighbour lines exactly as
-// Predict::initAdiPattern leaves them in intraNeighbourBuf (so strong intra smoothing, constrained intra and unavailable neighbours are the host's business,
-// not the device's) and the source block in, 35 costs out.  The reference's OWN body then runs — mode bits, costs, the comparison chain, fast-intra's subset —
-// and only the table slots it calls for this block answer from the job: intra_pred[DC / planar], transpose and intra_pred_allangs into the Search object's
-// scratch buffers do nothing, cu[].sa8d against those buffers returns the job's cost of the mode the call stands for (first call DC, second planar, then by
-// offset into the all-angles buffer, search.cpp:1356-1390).  X265HIP_VERIFY: the slots do their work as well and every cost is compared.
-//
-// The job leaves AHEAD: the neighbours of a CU are final when its analysis starts (they belong to CUs coded before it; the sub-CU recursion writes inside
-// the CU only), so Search::predInterSearch's seam — the 2Nx2N inter candidate, always before the intra try — submits it on entry, and checkIntraInInter adopts it if
-// the lines and the source block it would send now compare equal to what was sent; a job nobody asks for is dropped at the next one.
-std::atomic<int> g_intraState(0);    // X265HIP_INTRASCAN=0: off
-bool g_intraAhead = true;            // X265HIP_INTRASCAN_AHEAD=0: the job leaves when checkIntraInInter is entered
-int g_intraMinLog2 = 4;              // X265HIP_INTRASCAN_MIN=<log2>: smallest block handed over (an 8x8 scan is ~8 us of host code: less than a round trip)
-bool g_intraAheadPredict = true;     // X265HIP_INTRASCAN_AHEAD=2: no prediction of whether the intra try will come, every candidate CU's job leaves
-int g_intraSyncMinLog2 = 5;          // ... and the smallest one handed over when no job is ahead (the thread waits a whole round trip)
-struct alignas(64) IntraCounters { std::atomic<uint64_t> jobs, served, ahead, aheadHit, dropped, waits, waitCycles, host, aheadBy[2]; };
-IntraCounters g_intraCount[16];
-constexpr int kIntraMaxSamples = 2 * (4 * 32 + 16) + 32 * 32;
-struct IntraJob
-{
-    bool active;
-    Service* svc; int slot; uint32_t seq;
-    int log2n;
-    pixel sent[kIntraMaxSamples];     // what the device was given: raw line, filtered line, source block
-};
-// inside refCheckIntraInInter of a served block: what the table slots answer from
-struct IntraCtx { bool active, allangs, verify; const pixel* predBuf; const pixel* fencT; int n, lastMode; const int32_t* costs; };
-__attribute__((tls_model("initial-exec"))) thread_local IntraJob t_intra;
-__attribute__((tls_model("initial-exec"))) thread_local IntraCtx t_ictx;
-
-inline IntraCounters& intra_counters() { counters(); return g_intraCount[t_shard & 15]; }
-
-void intra_report()
-{
-    uint64_t jobs = 0, served = 0, ah = 0, hit = 0, dr = 0, w = 0, wc = 0, host = 0, ab[2] = { 0, 0 };
-    for (int i = 0; i < 16; i++)
-    {
-        for (int k = 0; k < 2; k++) ab[k] += g_intraCount[i].aheadBy[k];
-        jobs += g_intraCount[i].jobs; served += g_intraCount[i].served; ah += g_intraCount[i].ahead; hit += g_intraCount[i].aheadHit; dr += g_intraCount[i].dropped;
-        w += g_intraCount[i].waits; wc += g_intraCount[i].waitCycles; host += g_intraCount[i].host;
-    }
-    fprintf(stderr, "x265hip: intrascan: the 35-mode sa8d scans of %llu blocks >= %dx%d (Search::checkIntraInInter) measured by the GPU in %llu jobs, %llu scans on the host; %llu jobs "
-                    "left ahead when predInterSearch was entered, %llu of them adopted, %llu never asked for; %llu waits of %.0f cycles on average\n",
-            (unsigned long long)served, 1 << g_intraMinLog2, 1 << g_intraMinLog2, (unsigned long long)jobs, (unsigned long long)host, (unsigned long long)ah, (unsigned long long)hit,
-            (unsigned long long)dr, (unsigned long long)w, w ? (double)wc / w : 0.0);
-    fprintf(stderr, "x265hip: intrascan: %llu candidate CUs sent no job ahead because no sub-CU of theirs had chosen intra (analysis.cpp:1633: --limit-refs)\n", (unsigned long long)ab[0]);
-}
-
-bool intra_enabled()
-{
-    if (!g_intraState)
-    {
-        std::lock_guard<std::mutex> g(g_lock);
-        if (!g_intraState)
-        {
-            const char* env = getenv("X265HIP_INTRASCAN");
-            const char* all = getenv("X265HIP");
-            const char* table = getenv("X265HIP_TABLE");
-            if (getenv("X265HIP_INTRASCAN_AHEAD")) { g_intraAhead = atoi(getenv("X265HIP_INTRASCAN_AHEAD")) != 0; g_intraAheadPredict = atoi(getenv("X265HIP_INTRASCAN_AHEAD")) != 2; }
-            if (getenv("X265HIP_INTRASCAN_MIN")) g_intraMinLog2 = x265_clip3(3, 5, atoi(getenv("X265HIP_INTRASCAN_MIN")));
-            if (getenv("X265HIP_INTRASCAN_SYNC_MIN")) g_intraSyncMinLog2 = x265_clip3(3, 6, atoi(getenv("X265HIP_INTRASCAN_SYNC_MIN")));
-            if ((env && !strcmp(env, "0")) || (all && !strcmp(all, "0")) || (table && !strcmp(table, "percall")))
-                g_intraState = -1;
-            else
-            {
-                g_intraState = 1;
-                if (getenv("X265HIP_VERBOSE")) atexit(intra_report);
-            }
-        }
-    }
-    if (g_intraState > 0 && g_dead.load(std::memory_order_relaxed))
-    {
-        // the service the scans travel on has failed (a lost job of either kind takes the whole service down): said once, like every module that goes off
-        bool first = false;
-        {
-            std::lock_guard<std::mutex> g(g_lock);
-            if (g_intraState > 0) { g_intraState = -1; first = true; }
-        }
-        if (first) x265hip_device_failure("intrascan", "the CU-job service has failed");
-    }
-    return g_intraState > 0 && g_state > 0 && g_slots_installed;
-}
-
-// waits for this thread's intra job; false: the device did not deliver (the slot is kept: the device may still write into it)
-bool intra_wait(IntraJob& ij)
-{
-    const uint32_t* ready = &ij.svc->mem[ij.slot].units[0].ready;
-    if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == ij.seq) return true;
-    const uint64_t t0 = __builtin_ia32_rdtsc();
-    uint64_t spins = 0;
-    int64_t waitedNs = 0, lastNs = -1;
-    while (__atomic_load_n(ready, __ATOMIC_ACQUIRE) != ij.seq)
-    {
-        __builtin_ia32_pause();
-        if ((++spins & 255) == 0)
-        {
-            const int pk = x265hip_cuserve_poke(ij.svc->cs, ij.slot);
-            timespec ts;
-            clock_gettime(CLOCK_MONOTONIC, &ts);
-            const int64_t nowNs = (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
-            if (pk == 0 && lastNs >= 0) waitedNs += nowNs - lastNs;
-            lastNs = nowNs;
-            if (pk < 0 || waitedNs > g_timeoutNs)
-            {
-                ij.active = false;
-                g_intraState = -1;
-                x265hip_device_failure("intrascan", "an intra scan job did not come back");
-                return false;
-            }
-        }
-    }
-    IntraCounters& c = intra_counters();
-    c.waits.fetch_add(1, std::memory_order_relaxed);
-    c.waitCycles.fetch_add(__builtin_ia32_rdtsc() - t0, std::memory_order_relaxed);
-    return true;
-}
-
-// the job's scope ends (served, or never asked for): the slot goes back once the device has written what it is going to write.  Nobody waits for a job
-// that was never asked for: its slot is parked (two per thread) and handed back when a later call finds its ready word set
-struct IntraParked { Service* svc; int slot; uint32_t seq; int looks; };
-__attribute__((tls_model("initial-exec"))) thread_local IntraParked t_parked[2];
-inline bool intra_ready(Service* svc, int slot, uint32_t seq) { return __atomic_load_n(&svc->mem[slot].units[0].ready, __ATOMIC_ACQUIRE) == seq; }
-void intra_sweep()
-{
-    for (IntraParked& z : t_parked)
-    {
-        if (!z.svc)
-            continue;
-        if (intra_ready(z.svc, z.slot, z.seq)) { give_slot(z.svc, z.slot); z.svc = NULL; }
-        else if (++z.looks == 16 && x265hip_cuserve_poke(z.svc->cs, z.slot) < 0)
-        {
-            // a parked job that is still out after sixteen later jobs, on a service that reports a failure: it is not coming (the slot stays taken)
-            z.svc = NULL;
-            if (g_intraState > 0)
-            {
-                g_intraState = -1;
-                x265hip_device_failure("intrascan", "an intra scan job did not come back");
-            }
-        }
-    }
-}
-void intra_drop(IntraJob& ij)
-{
-    if (!ij.active)
-        return;
-    ij.active = false;
-    if (intra_ready(ij.svc, ij.slot, ij.seq)) { give_slot(ij.svc, ij.slot); return; }
-    intra_sweep();
-    for (IntraParked& z : t_parked)
-        if (!z.svc) { z.svc = ij.svc; z.slot = ij.slot; z.seq = ij.seq; z.looks = 0; return; }
-    ij.active = true;                                       // both places taken by jobs still on the device: wait for this one after all
-    if (intra_wait(ij))
-        give_slot(ij.svc, ij.slot);
-    ij.active = false;
-}
-
-// the block as checkIntraInInter sees it now: Predict::initIntraNeighbors + initAdiPattern exactly as search.cpp:1308-1310 calls them (they write
-// intraNeighbourBuf[0] and, for 8 / 16 / 32, [1] from the reconstructed picture; the reference's body repeats the call), packed the way the job carries it
-int intra_pack(Search* se, const CUData& cu, const CUGeom& cuGeom, const Yuv& fencYuv, pixel* dst)
-{
-    const int log2n = (int)cuGeom.log2CUSize, n = 1 << log2n, line = x265hipi_intrajob_line_samples(log2n);
-    Predict::IntraNeighbors nb;
-    se->initIntraNeighbors(cu, 0, 0, true, &nb);
-    se->initAdiPattern(cu, cuGeom, 0, nb, ALL_IDX);
-    memcpy(dst, se->intraNeighbourBuf[0], sizeof(pixel) * (4 * n + 1));
-    memset(dst + 4 * n + 1, 0, sizeof(pixel) * 15);
-    memcpy(dst + line, se->intraNeighbourBuf[1], sizeof(pixel) * (4 * n + 1));
-    memset(dst + line + 4 * n + 1, 0, sizeof(pixel) * 15);
-    pixel* f = dst + 2 * line;
-    pack_rows(f, fencYuv.m_buf[0], fencYuv.m_size, n);
-    return 2 * line + n * n;
-}
-
-// A thread that ends (x265's pool threads end with their encoder) hands back what it still holds — a job ahead nobody asked for, parked slots: in a process
-// that opens and closes encoders for days, slots kept by dead threads would starve the service (the CU jobs would quietly stay on the host)
-struct IntraThreadEnd
-{
-    ~IntraThreadEnd()
-    {
-        std::lock_guard<std::mutex> g(g_lock);               // shutdown() sets g_dead and closes the services (their pinned memory) under this lock
-        if (g_dead.load(std::memory_order_relaxed))
-            return;                                          // the services are closed (or failed): their slots are gone with them
-        if (t_intra.active)
-            intra_drop(t_intra);
-        for (IntraParked& z : t_parked)
-        {
-            if (!z.svc)
-                continue;
-            for (int spins = 0; spins < 200000 && !intra_ready(z.svc, z.slot, z.seq); spins++)     // a scan is tens of microseconds of device time
-                __builtin_ia32_pause();
-            if (intra_ready(z.svc, z.slot, z.seq))
-                give_slot(z.svc, z.slot);
-            z.svc = NULL;
-        }
-    }
-};
-thread_local IntraThreadEnd t_intraThreadEnd;
-
-bool intra_slots_in(const EncoderPrimitives& p, int log2n);
-bool intra_submit(IntraJob& ij, const pixel* blob, int samples, int log2n)
-{
-    (void)&t_intraThreadEnd;                                 // (constructed on first use: registers the destructor with this thread)
-    intra_sweep();
-    if (!service())
-        return false;
-    Service* svc = NULL;
-    const int slot = take_slot(&svc);
-    if (slot < 0)
-        return false;
-    x265hip_intrajob job;
-    job.bitDepth = X265_DEPTH; job.mark = X265HIP_INTRAJOB_MARK; job.log2Size = (uint32_t)log2n; job.reserved = 0;
-    memcpy(svc->mem[slot].pixels, blob, sizeof(pixel) * samples);
-    uint32_t seq = 0;
-    if (x265hip_cuserve_submit_intra(svc->cs, slot, &job, &seq))
-    {
-        give_slot(svc, slot);
-        g_intraState = -1;
-        x265hip_device_failure("intrascan", "x265hip_cuserve_submit_intra");
-        return false;
-    }
-    if (blob != ij.sent) memcpy(ij.sent, blob, sizeof(pixel) * samples);
-    ij.svc = svc; ij.slot = slot; ij.seq = seq; ij.log2n = log2n; ij.active = true;
-    intra_counters().jobs.fetch_add(1, std::memory_order_relaxed);
-    return true;
-}
-
-void intra_unasked()
-{
-    IntraJob& ij = t_intra;
-    if (ij.active)
-    {
-        intra_counters().dropped.fetch_add(1, std::memory_order_relaxed);
-        intra_drop(ij);
-    }
-}
-
-// called by Search::predInterSearch's seam for the 2Nx2N candidate: will this CU be tried as intra (analysis.cpp:1595)?  Then its scan leaves now.
-void intra_ahead(Search* se, Mode& interMode, const CUGeom& cuGeom)
-{
-    IntraJob& ij = t_intra;
-    if (ij.active)
-    {
-        intra_counters().dropped.fetch_add(1, std::memory_order_relaxed);
-        intra_drop(ij);
-    }
-    const int log2n = (int)cuGeom.log2CUSize;
-    const Slice* slice = interMode.cu.m_slice;
-    // (only sizes whose table slots are installed: a job checkIntraInInter could never adopt would only hold a slot)
-    if (!g_intraAhead || !intra_enabled() || log2n < g_intraMinLog2 || log2n > 5 || !intra_slots_in(primitives, log2n) || log2n == (int)g_log2Size[se->m_param->maxCUSize] ||
-        !(slice->m_sliceType != B_SLICE || se->m_param->bIntraInBFrames) || se->m_param->rdLevel < 2 || se->m_param->rdLevel > 4 || se->m_param->bDistributeModeAnalysis ||
-        se->m_param->analysisLoad || (se->m_param->bCTUInfo & 4))
-        return;
-    // With --limit-refs (preset medium and slower) the intra try needs `splitIntra` (analysis.cpp:1633): no sub-CU recursion for this CU, or a sub-CU whose
-    // best mode is intra (:1182, :1353, :1369).  The recursion leaves its trace in the depth's split prediction — initSubCU to this CU (:1346), the sub-CUs'
-    // data copied in quadrant by quadrant (:1370) — so the flag can be read back; a stale trace only costs a job nobody asks for, or a scan on the host.
-    int likely = 1;
-    if (se->m_param->limitReferences && g_intraAheadPredict)
-    {
-        const CUData& sp = static_cast<Analysis*>(se)->m_modeDepth[cuGeom.depth].pred[Analysis::PRED_SPLIT].cu;
-        if (sp.m_cuAddr == interMode.cu.m_cuAddr && sp.m_absIdxInCTU == cuGeom.absPartIdx && sp.m_encData == interMode.cu.m_encData && cuGeom.log2CUSize > 3)
-        {
-            const uint32_t q = cuGeom.numPartitions >> 2;
-            likely = 0;
-            for (uint32_t k = 0; k < 4; k++)
-                likely |= sp.m_predMode[k * q] == MODE_INTRA;
-        }
-    }
-    if (!likely)
-    {
-        intra_counters().aheadBy[0].fetch_add(1, std::memory_order_relaxed);      // (not sent: counted to show what the prediction withholds)
-        return;
-    }
-    const int samples = intra_pack(se, interMode.cu, cuGeom, *interMode.fencYuv, ij.sent);
-    if (intra_submit(ij, ij.sent, samples, log2n))
-    {
-        intra_counters().ahead.fetch_add(1, std::memory_order_relaxed);
-        intra_counters().aheadBy[1].fetch_add(1, std::memory_order_relaxed);
-    }
-}
-
-// ---- the table slots the reference's body calls for the block.  Which mode a cu[].sa8d call stands for: the mode of the intra_pred[] call before it (every
-// one of the 35 entries is a slot that notes its own index) — or, where the table carries intra_pred_allangs (x265_setup_primitives removes the C one,
-// primitives.cpp; an assembly table has it), the offset into the all-angles buffer (search.cpp:1383-1387)
-template <int CU>
-int sa8d_slot(const pixel* a, intptr_t sa, const pixel* b, intptr_t sb)
-{
-    IntraCtx& c = t_ictx;
-    if (c.active && b >= c.predBuf && b < c.predBuf + 33 * c.n * c.n && (1 << (CU + 2)) == c.n)
-    {
-        const int mode = c.allangs ? 2 + (int)((b - c.predBuf) / (c.n * c.n)) : c.lastMode;
-        const int v = c.costs[mode];
-        if (c.verify)
-        {
-            const int want = g_prev.cu[CU].sa8d(a, sa, b, sb);
-            if (want != v)
-            {
-                fprintf(stderr, "x265hip: VERIFY FAILED intra scan %dx%d mode %d: %d (job) vs %d\n", c.n, c.n, mode, v, want);
-                abort();
-            }
-        }
-        return v;
-    }
-    return g_prev.cu[CU].sa8d(a, sa, b, sb);
-}
-template <int CU, int MODE>
-void intra_pred_slot(pixel* dst, intptr_t dstStride, const pixel* srcPix, int dirMode, int bFilter)
-{
-    IntraCtx& c = t_ictx;
-    if (c.active && dst == c.predBuf && (1 << (CU + 2)) == c.n)
-    {
-        c.lastMode = MODE;
-        c.allangs = false;
-        if (!c.verify)
-            return;
-    }
-    g_prev.cu[CU].intra_pred[MODE](dst, dstStride, srcPix, dirMode, bFilter);
-}
-template <int CU>
-void allangs_slot(pixel* dst, pixel* refPix, pixel* filtPix, int bLuma)
-{
-    IntraCtx& c = t_ictx;
-    if (c.active && dst == c.predBuf && (1 << (CU + 2)) == c.n)
-    {
-        c.allangs = true;
-        if (!c.verify)
-            return;
-    }
-    g_prev.cu[CU].intra_pred_allangs(dst, refPix, filtPix, bLuma);
-}
-template <int CU>
-void transpose_slot(pixel* dst, const pixel* src, intptr_t stride)
-{
-    const IntraCtx& c = t_ictx;
-    if (c.active && !c.verify && dst == c.fencT && (1 << (CU + 2)) == c.n)
-        return;
-    g_prev.cu[CU].transpose(dst, src, stride);
-}
-template <int CU, int M>
-struct InstallPredSlots
-{
-    static void run(EncoderPrimitives& p) { p.cu[CU].intra_pred[M] = intra_pred_slot<CU, M>; InstallPredSlots<CU, M - 1>::run(p); }
-};
-template <int CU>
-struct InstallPredSlots<CU, -1> { static void run(EncoderPrimitives&) {} };
-template <int CU>
-void install_intra_slots_for(EncoderPrimitives& p)
-{
-    p.cu[CU].sa8d = sa8d_slot<CU>;
-    InstallPredSlots<CU, NUM_INTRA_MODE - 1>::run(p);
-    if (g_prev.cu[CU].intra_pred_allangs)
-    {
-        p.cu[CU].intra_pred_allangs = allangs_slot<CU>;
-        p.cu[CU].transpose = transpose_slot<CU>;
-    }
-}
-void install_intra_slots(EncoderPrimitives& p)
-{
-    const char* env = getenv("X265HIP_INTRASCAN");
-    if (env && !strcmp(env, "0"))
-        return;
-    install_intra_slots_for<BLOCK_16x16>(p);
-    install_intra_slots_for<BLOCK_32x32>(p);
-}
-bool intra_slots_in(const EncoderPrimitives& p, int log2n)
-{
-    return log2n == 4 ? p.cu[BLOCK_16x16].sa8d == sa8d_slot<BLOCK_16x16> : log2n == 5 ? p.cu[BLOCK_32x32].sa8d == sa8d_slot<BLOCK_32x32> : false;
-}
-
-void Search::checkIntraInInter(Mode& intraMode, const CUGeom& cuGeom)
-{
-    IntraJob& ij = t_intra;
-    const int log2n = (int)cuGeom.log2CUSize;
-    if (intra_enabled() && log2n >= g_intraMinLog2 && log2n <= 5 && intra_slots_in(primitives, log2n) && !t_ictx.active)
-    {
-        pixel cur[kIntraMaxSamples];
-        const int samples = intra_pack(this, intraMode.cu, cuGeom, *intraMode.fencYuv, cur);
-        if (ij.active)
-        {
-            if (ij.log2n == log2n && !memcmp(cur, ij.sent, sizeof(pixel) * samples))
-                intra_counters().aheadHit.fetch_add(1, std::memory_order_relaxed);
-            else
-            {
-                intra_counters().dropped.fetch_add(1, std::memory_order_relaxed);
-                intra_drop(ij);
-            }
-        }
-        if (!ij.active && log2n >= g_intraSyncMinLog2)
-            intra_submit(ij, cur, samples, log2n);
-        if (ij.active && intra_wait(ij))
-        {
-            IntraCtx& c = t_ictx;
-            c.active = true; c.allangs = false; c.predBuf = m_intraPredAngs; c.fencT = m_fencTransposed; c.n = 1 << log2n; c.lastMode = DC_IDX;
-            c.costs = reinterpret_cast<const int32_t*>(ij.svc->mem[ij.slot].levels); c.verify = g_verify;
-            if (g_time) { Timed t(13 + cuGeom.log2CUSize - 2); refCheckIntraInInter(this, intraMode, cuGeom); }
-            else refCheckIntraInInter(this, intraMode, cuGeom);
-            c.active = false;
-            give_slot(ij.svc, ij.slot);
-            ij.active = false;
-            intra_counters().served.fetch_add(1, std::memory_order_relaxed);
-            return;
-        }
-    }
-    else if (ij.active)
-    {
-        intra_counters().dropped.fetch_add(1, std::memory_order_relaxed);
-        intra_drop(ij);
-    }
-    intra_counters().host.fetch_add(1, std::memory_order_relaxed);
-    if (g_time)
-    {
-        Timed t(13 + cuGeom.log2CUSize - 2);
-        refCheckIntraInInter(this, intraMode, cuGeom);
-        return;
-    }
-    refCheckIntraInInter(this, intraMode, cuGeom);
-}
 
 } // namespace X265_NS
