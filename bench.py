@@ -1,19 +1,18 @@
 #!/usr/bin/env python3
 """bench.py — the contract bench (BASELINE.json metric: encode fps, 1080p preset medium, --me hex).
 
-`value` is REAL encode fps: the reference encoder's own binary with the four added translation units (x265_amd/host/*.cpp) and
-libx265hip.so behind them — oracle/_ref/x265_hip_8bit — encoding a synthetic 1920x1080 clip with `--preset medium --me hex`; the GPU serves
-the lookahead's batched frame-cost estimates, the luma sub-pel filter calls on reference pictures (fractional planes built per picture) and the
-source half of the psy costs (energy planes built per source picture); everything else is the reference's host code.  One "step" = one chunk of
-CHUNK = 12 frames of the clip; K steps are encoded in one run of the encoder, bracketed by barrier + synchronize, wall clock of this process
-(the encoder's own "encoded N frames in Xs" figure is reported beside it as `cli_fps`).  The workload is ONE clip: the K * CHUNK-frame segment repeated N times; rank r
-encodes repetition r as a closed-GOP chunk on GPU r (chunk-parallel, the way x265 is scaled out over a long clip; the host cores are split between
-the ranks): weak scaling, no data-path collective, and an N-rank value is N times the N = 1 job.  At every N the same chunks are then encoded by the
-unmodified reference encoder, N at a time (oracle/_ref/x265_8bit, `cpu_baseline`, kind "reference"), and every chunk's two bitstreams must be
-byte-identical.  `roofline` is the kernel with the most device time in the timed encode, priced from the library's own HIP events around every launch
-(x265hip_device_time); `rooflines` holds the other named kernels and the stand-alone probes; `gpu_duty_cycle` = device time / wall clock.
+`value` is REAL encode fps: the reference encoder's own objects with the binding's translation units (x265_amd/host/*.cpp) and libx265hip.so behind them —
+oracle/_ref/x265_hip_8bit — encoding a synthetic 1920x1080 clip with `--preset medium --me hex` (INTEGRATION.md says what the GPU serves).  One "step" = CHUNK = 12
+frames of the clip; K steps are encoded in one run of ONE encoder, bracketed by barrier + synchronize, wall clock of this process (the encoder's own "encoded N
+frames in Xs" figure is reported beside it as `cli_fps`).  At N > 1 the job is the same and the encoder is still one: its device work is spread over the N GPUs
+(X265HIP_DEVICES; rank 0 runs it, the other ranks wait at the fences) — strong scaling; the chunk form (N encoders, one per GPU) and BASELINE
+configs[4]'s 8K shape are reported beside it, outside the timed region.  The same clip is then encoded by the unmodified reference encoder with the same
+arguments (oracle/_ref/x265_8bit built with the reference's own Release flags: `cpu_baseline`, kind "reference"; `cpu_baseline_vec`: with its intrinsics
+transforms), and the bitstreams must be byte-identical.  `roofline` is the kernel with the most device time in the timed encode, priced from the library's own
+HIP events around every launch (x265hip_device_time); `rooflines` holds the other named kernels and the stand-alone probes; `gpu_duty_cycle` = device time /
+wall clock.
 
-Beside it, `frame_pass` keeps the device-resident hot path of round 1 (quarter-pel planes, top-down motion search, prediction, residual
+Beside it (--frame-pass), `frame_pass` keeps the device-resident hot path of round 1 (quarter-pel planes, top-down motion search, prediction, residual
 chains, sa8d, borders on HBM-resident pictures, F frame chains per GPU, recon exchanged over RCCL when N > 1) with its own roofline.
 
   python bench.py --gpus 1 --steps 20 --warmup 5
@@ -539,11 +538,14 @@ def parse_served(lines):
 
 
 def encode_bench(args, rank, local_rank, world, fence, allmax):
-    """Real encode fps.  The workload is ONE clip: the K * CHUNK-frame segment of make_clip(seed 4321) repeated N times; rank r encodes repetition r as
-    a closed-GOP chunk (its own run of oracle/_ref/x265_hip_8bit on its own GPU, the way x265 is scaled out over a long clip), so the N-rank job is N
-    times the N = 1 job and every chunk's bitstream must equal the reference encoder's bitstream of the segment.  Timed: wall clock of this process
-    between two fences around the encoder run (after a W * CHUNK-frame warm-up run); afterwards, with the same fences, the unmodified reference
-    encoder on the same chunks, N at a time, with the same share of the host cores (`cpu_baseline` at every N)."""
+    """Real encode fps of ONE encoder on ONE clip: the K * CHUNK-frame segment of make_clip(seed 4321), 1920x1080, --preset medium --me hex.
+    N = 1: oracle/_ref/x265_hip_8bit on GPU 0.  N > 1: the SAME job, one encoder whose device work is spread over the N GPUs of the node (X265HIP_DEVICES=0..N-1:
+    reference-picture mirrors and source pictures take the GPUs in turn, SAD surfaces are built where the source picture lives from replicas of the reference
+    pictures fed band by band device to device — x265's frame threads <-> GPUs, the reconstructed-reference exchange of BASELINE's north_star inside libx265hip.so),
+    run by rank 0 while the other ranks hold their GPUs and wait at the fences: strong scaling, total work fixed.  Timed: wall clock between two fences around the
+    encoder run (after a W * CHUNK-frame warm-up run).  Afterwards, outside the timed region: the unmodified reference encoder on the same clip with the same
+    arguments (`cpu_baseline`; byte-identity of the two bitstreams), the reference with its intrinsics transforms (`cpu_baseline_vec`), and at N > 1 the chunk
+    form (N encoders, one per GPU, each a closed-GOP repetition of the segment, the host cores split between them) and BASELINE configs[4]'s shape (7680x4320)."""
     import hashlib
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import encode_fps as ef
@@ -555,61 +557,60 @@ def encode_bench(args, rank, local_rank, world, fence, allmax):
     frames, wframes = args.steps * CHUNK, max(args.warmup, 0) * CHUNK
     total = max(frames, wframes)
     clip = "/tmp/x265hip_bench_%d_r%d.yuv" % (os.getpid(), rank)
-    make_clip(clip, W, H, total, seed=4321)                  # every rank's chunk is a repetition of the same segment
+    if rank == 0 or world > 1:
+        make_clip(clip, W, H, total, seed=4321)              # (every rank keeps a copy: the chunk form beside the timed leg encodes a repetition per rank)
     cores = os.cpu_count() or 1
     quota = host_cpu_quota()
     usable = int(min(cores, quota)) if quota else cores      # CPUs the container's cgroup grants (16 of the 256 shown on the MI355X box)
-    per_rank = max(4, usable // world)
     base = ["--input", clip, "--input-res", "%dx%d" % (W, H), "--input-depth", "8", "--fps", "30", "--preset", "medium", "--me", "hex", "--hash", "1"]
-    threads_note = "x265's defaults"
-    if world > 1:
-        base += ["--pools", str(per_rank)]                   # the ranks share the host: each encoder gets its share of the cores
-        threads_note = "--pools %d (the ranks share %d usable CPUs)" % (per_rank, usable)
-    elif usable < cores:
+    threads, threads_note, pools = [], "x265's defaults", cores
+    if usable < cores:
         # x265 sizes its pool from the cores the kernel shows and does not see the cgroup's quota: 256 pool threads on 16 CPUs' worth of quota are throttled in
-        # bursts.  The pool is sized to the quota; frame parallelism stays what x265 picks on this host (ThreadPool::getFrameThreadsCount, threadpool.cpp:661-676,
-        # from the shown cores).  Both encoders get the same arguments (profiles/r05_v1_pool_size.txt: bound 31.6-33.8 -> 36.1-36.9 fps, reference 18.4-19.3 either way)
-        ft = 5 if cores >= 32 else 4 if cores >= 16 else 3 if cores >= 8 else 2 if cores >= 4 else 1
-        base += ["--pools", str(usable), "--frame-threads", str(ft)]
-        per_rank = usable
-        threads_note = "--pools %d --frame-threads %d: the pool sized to the cgroup's CPU quota (%s of %d shown cores), frame threads as x265 picks them on this host" % (usable, ft, quota, cores)
+        # bursts.  Both encoders get the thread arguments at which the REFERENCE is fastest on this box (profiles/r06_v1_threads_sweep.txt, -O3 builds: the reference
+        # 28.8 fps at --pools 16 -F 5, 31.1-31.7 at pools 20-24 with -F 5-6; the bound encoder 45.7-46.7 in every one of those cells): a pool of 1.5 x the quota
+        # and six frame threads (ThreadPool::getFrameThreadsCount, threadpool.cpp:661-676, would pick 5 from the shown cores)
+        pools, ft = int(round(1.5 * usable)), 6
+        threads = ["--pools", str(pools), "--frame-threads", str(ft)]
+        threads_note = ("--pools %d --frame-threads %d: the reference's best thread arguments on this box (cgroup quota %s of %d shown cores; profiles/r06_v1_threads_sweep.txt), "
+                        "the same for both encoders" % (pools, ft, quota, cores))
     visible = os.environ.get("HIP_VISIBLE_DEVICES")
-    env = dict(os.environ, X265HIP_VERBOSE="1", X265HIP="require", HIP_VISIBLE_DEVICES=visible.split(",")[local_rank] if visible else str(local_rank))
+    all_devs = visible.split(",") if visible else [str(i) for i in range(world)]
+    same_dev = os.environ.get("X265HIP_BENCH_SAME_DEVICE") == "1"          # debugging aid for 1-GPU boxes: every place is device 0
+    env = dict(os.environ, X265HIP_VERBOSE="1", X265HIP="require", HIP_VISIBLE_DEVICES=all_devs[0] if (world == 1 or same_dev) else ",".join(all_devs[:world]))
+    if world > 1:
+        env["X265HIP_DEVICES"] = ",".join("0" if same_dev else str(i) for i in range(world))
     out_hip, out_ref = clip + ".gpu.hevc", clip + ".ref.hevc"
     res = {}
     try:
-        if wframes:
-            ef._run(hip, base + ["--frames", str(wframes)], out_hip, env=env)
+        if wframes and rank == 0:
+            ef._run(hip, base + threads + ["--frames", str(wframes)], out_hip, env=env)
         fence()
         t0 = time.perf_counter()
-        r = ef._run(hip, base + ["--frames", str(frames)], out_hip, env=env)
+        r = ef._run(hip, base + threads + ["--frames", str(frames)], out_hip, env=env) if rank == 0 else {"rc": 0, "fps": None, "served": []}
         fence()
         dt = time.perf_counter() - t0
         if r["rc"]:
             raise SystemExit("bench.py: x265_hip_8bit failed: " + r["tail"])
-        res = {"dt": dt, "frames": frames, "cli_fps": r["fps"], "served": r["served"], "pools": per_rank if (world > 1 or usable < cores) else cores, "threads_note": threads_note}
-        if not args.no_ref_encoder:
-            fence()
+        res = {"dt": dt, "frames": frames, "cli_fps": r["fps"], "served": r["served"], "pools": pools, "threads_note": threads_note}
+        if not args.no_ref_encoder and rank == 0:
             t0 = time.perf_counter()
-            r0 = ef._run(ref, base + ["--frames", str(frames)], out_ref)
-            fence()
-            dt_ref = allmax(time.perf_counter() - t0)
+            r0 = ef._run(ref, base + threads + ["--frames", str(frames)], out_ref)
+            dt_ref = time.perf_counter() - t0
             same = r0["rc"] == 0 and hashlib.sha256(open(out_ref, "rb").read()).digest() == hashlib.sha256(open(out_hip, "rb").read()).digest()
-            differing = allmax(0.0 if same else 1.0)
-            res["reference"] = {"cli_fps": r0["fps"], "wall_s": round(dt_ref, 2), "rc": r0["rc"], "byte_identical": differing == 0.0,
+            res["reference"] = {"cli_fps": r0["fps"], "wall_s": round(dt_ref, 2), "rc": r0["rc"], "byte_identical": same,
                                 "bitstream_bytes": os.path.getsize(out_ref) if r0["rc"] == 0 else 0}
             # second baseline leg: the reference with its own intrinsics path (source/common/vec: SSE3 idct8/16/32, SSSE3 dct16/32, SSE4.1 dequant_scaling;
-            # oracle/Makefile `vec`), --asm SSE4.1.  The nasm half (AVX2 / AVX-512 kernels) cannot be assembled in this image.  Rank 0, N = 1 only.
+            # oracle/Makefile `vec`), --asm SSE4.1.  The nasm half (AVX2 / AVX-512 kernels) cannot be assembled in this image.
             vec = os.path.join(ef.REF, "x265_vec_8bit")
-            if world == 1 and os.path.exists(vec):
+            if os.path.exists(vec):
                 out_vec = clip + ".vec.hevc"
                 try:
                     # (--no-info on both sides of the comparison: the options SEI carries the cpuid and would differ by those bytes alone)
                     t0 = time.perf_counter()
-                    rv = ef._run(vec, base + ["--frames", str(frames), "--asm", "SSE4.1", "--no-info"], out_vec)
+                    rv = ef._run(vec, base + threads + ["--frames", str(frames), "--asm", "SSE4.1", "--no-info"], out_vec)
                     dt_vec = time.perf_counter() - t0
-                    rn = ef._run(ref, base + ["--frames", str(min(frames, 40)), "--no-info"], out_ref + ".ni")
-                    rm = ef._run(vec, base + ["--frames", str(min(frames, 40)), "--asm", "SSE4.1", "--no-info"], out_vec + ".ni")
+                    rn = ef._run(ref, base + threads + ["--frames", str(min(frames, 40)), "--no-info"], out_ref + ".ni")
+                    rm = ef._run(vec, base + threads + ["--frames", str(min(frames, 40)), "--asm", "SSE4.1", "--no-info"], out_vec + ".ni")
                     same_v = rn["rc"] == 0 and rm["rc"] == 0 and open(out_ref + ".ni", "rb").read() == open(out_vec + ".ni", "rb").read()
                     res["reference_vec"] = {"cli_fps": rv["fps"], "wall_s": round(dt_vec, 2), "rc": rv["rc"], "same_bitstream_without_info_sei": same_v}
                 finally:
@@ -617,26 +618,42 @@ def encode_bench(args, rank, local_rank, world, fence, allmax):
                         if os.path.exists(q):
                             os.remove(q)
         if world > 1:
-            # ---- BASELINE configs[4]'s form beside the chunk form: ONE encoder whose device work is spread over the N GPUs (X265HIP_DEVICES: reference-picture
-            # mirrors and source pictures take their places in turn, SAD surfaces are built where the source lives from replicas fed device to device, every
-            # place runs its own worker thread and its own CU-job server).  Outside the timed region; rank 0 only, the other ranks wait at the fence.
             fence()
+            # ---- beside the timed leg, the chunk form: N encoders, one per GPU, each a closed-GOP repetition of the segment, the host's CPUs split between them
+            per_rank = max(4, usable // world)
+            envc = dict(os.environ, X265HIP_VERBOSE="1", X265HIP="require", HIP_VISIBLE_DEVICES=all_devs[0] if same_dev else all_devs[local_rank])
+            out_chunk = clip + ".chunk.hevc"
+            t0 = time.perf_counter()
+            rc_ = ef._run(hip, base + ["--pools", str(per_rank), "--frames", str(frames)], out_chunk, env=envc)
+            fence()
+            dtc = allmax(time.perf_counter() - t0)
+            bad = allmax(1.0 if rc_["rc"] else 0.0)
+            if os.path.exists(out_chunk):
+                os.remove(out_chunk)
+            res["chunk_form"] = {"encoders": world, "fps": round(world * frames / dtc, 3) if not bad else None, "wall_s": round(dtc, 2), "pools_per_encoder": per_rank,
+                                 "note": "%d encoders at the same time, one per GPU, each encoding a repetition of the segment as a closed-GOP chunk with --pools %d (the host's %d "
+                                         "usable CPUs split); all frames of all encoders / wall clock" % (world, per_rank, usable)}
+            # ---- ... and BASELINE configs[4]'s shape: 7680x4320 preset medium, one encoder over the N GPUs, with the reference beside it (a few frames: a reported
+            # shape, not the metric)
             if rank == 0:
-                all_devs = visible.split(",") if visible else [str(i) for i in range(world)]
-                env1 = dict(os.environ, X265HIP_VERBOSE="1", X265HIP="require", HIP_VISIBLE_DEVICES=",".join(all_devs[:world]),
-                            X265HIP_DEVICES=",".join(str(i) for i in range(world)))
-                out_one = clip + ".places.hevc"
-                t0 = time.perf_counter()
-                r1 = ef._run(hip, [a for a in base if a not in ("--pools", str(per_rank))] + ["--frames", str(frames)], out_one, env=env1)
-                dt1 = time.perf_counter() - t0
-                same1 = r1["rc"] == 0 and os.path.exists(out_hip) and open(out_one, "rb").read() == open(out_hip, "rb").read()
-                res["one_encoder"] = {"places": world, "fps": round(frames / dt1, 3) if r1["rc"] == 0 else None, "cli_fps": r1["fps"], "rc": r1["rc"],
-                                      "byte_identical_to_chunk_path": same1,
-                                      "exchange": [l for l in r1["served"] if "places:" in l or "cuserve:" in l],
-                                      "note": "one x265 encoder using all %d GPUs (frames <-> GPUs inside the encoder, reconstructed rows pushed device to device); it has the whole "
-                                              "host to itself while the chunk form splits the host between %d encoders" % (world, world)}
-                if os.path.exists(out_one):
-                    os.remove(out_one)
+                clip8 = "/tmp/x265hip_bench8k_%d.yuv" % os.getpid()
+                out8, out8r = clip8 + ".gpu.hevc", clip8 + ".ref.hevc"
+                try:
+                    f8 = 8
+                    make_clip(clip8, 7680, 4320, f8, seed=4321)
+                    a8 = ["--input", clip8, "--input-res", "7680x4320", "--input-depth", "8", "--fps", "30", "--preset", "medium", "--me", "hex", "--hash", "1", "--frames", str(f8)] + threads
+                    t0 = time.perf_counter(); r8 = ef._run(hip, a8, out8, env=env); d8 = time.perf_counter() - t0
+                    t0 = time.perf_counter(); r8r = ef._run(ref, a8, out8r); d8r = time.perf_counter() - t0
+                    same8 = r8["rc"] == 0 and r8r["rc"] == 0 and open(out8, "rb").read() == open(out8r, "rb").read()
+                    res["configs4_8k"] = {"frames": f8, "places": world, "fps": round(f8 / d8, 3) if r8["rc"] == 0 else None, "cli_fps": r8["fps"],
+                                          "reference_fps": round(f8 / d8r, 3) if r8r["rc"] == 0 else None, "reference_cli_fps": r8r["fps"], "byte_identical": same8,
+                                          "exchange": [l for l in r8["served"] if "places:" in l]}
+                except Exception as e:  # noqa: BLE001 — a secondary block must never cost the run its headline
+                    res["configs4_8k"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+                finally:
+                    for q in (clip8, out8, out8r):
+                        if os.path.exists(q):
+                            os.remove(q)
             fence()
     finally:
         for p in (clip, out_hip, out_ref):
@@ -727,7 +744,7 @@ def pmc_profile(pattern, kernel, digest):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10, help="timed steps; one step = one %d-frame chunk of the encode" % CHUNK)
+    ap.add_argument("--steps", type=int, default=20, help="timed steps; one step = one %d-frame chunk of the encode" % CHUNK)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-frames", type=int, default=10, help="frame passes of the CPU port sample inside `frame_pass` (0 = skip)")
     ap.add_argument("--no-ref-encoder", action="store_true")
@@ -796,7 +813,7 @@ def main():
 
     enc = encode_bench(args, rank, local_rank, world, fence, allmax)
     dt = allmax(enc["dt"])
-    fps = world * enc["frames"] / dt
+    fps = enc["frames"] / dt                                  # ONE encoder at every N: the same job, N GPUs (strong scaling)
 
     fpb = None
     if args.frame_pass and not args.no_frame_pass:
@@ -961,15 +978,18 @@ def main():
         out = {
             "metric": "encode fps (1080p preset medium)", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "x265 --preset medium --me hex, 1920x1080 8-bit 4:2:0; ONE synthetic clip = the %d-frame segment of x265_amd/synth.make_clip (96x96 tiles with "
-                                   "their own velocities + noise, seed 4321) repeated N times, rank r encodes repetition r as a closed-GOP chunk on GPU r (one step = %d frames "
-                                   "per rank); the reference encoder's binary + x265_amd/host/*.cpp + libx265hip.so (oracle/_ref/x265_hip_8bit): lookahead frame-cost "
+            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "x265 --preset medium --me hex, 1920x1080 8-bit 4:2:0 (BASELINE configs[1]); ONE synthetic clip = the %d-frame segment of x265_amd/synth.make_clip "
+                                   "(96x96 tiles with their own velocities + noise, seed 4321), encoded by ONE encoder (one step = %d frames): the reference encoder's objects + "
+                                   "x265_amd/host/*.cpp + libx265hip.so (oracle/_ref/x265_hip_8bit)%s: lookahead frame-cost "
                                    "estimates batched on the GPU, the residual quad-trees of CUs >= 32x32 (MFMA dct / quant / sign hiding / dequant / idct) as mailbox jobs to a resident GPU "
-                                   "server, integer-pel SADs of the motion search looked up in GPU-built SAD surfaces, luma sub-pel filter slots "
-                                   "served from GPU-built fractional planes of each reference picture, psy-cost source halves from GPU-built energy planes, C slots "
-                                   "otherwise; the host cores are split between the ranks" % (enc["frames"], CHUNK),
-                       "frames_per_step": world * CHUNK, "encoder_cli_fps_rank0": enc["cli_fps"], "served_by_gpu": enc["served"],
+                                   "server, SAO statistics and the 35-mode intra scans of inter slices as jobs of the same server, integer-pel SADs and sub-pel SATDs of the motion search "
+                                   "looked up in GPU-built SAD surfaces, luma sub-pel filter slots served from GPU-built fractional planes of each reference picture, psy-cost source halves "
+                                   "from GPU-built energy planes, C slots otherwise"
+                                   % (enc["frames"], CHUNK, "" if world == 1 else ", its device work spread over the %d GPUs of the node (X265HIP_DEVICES: places; reconstructed rows of "
+                                      "reference pictures pushed device to device with hipMemcpyPeerAsync over xGMI — a copy between two devices of one process, which is what the exchange "
+                                      "is; RCCL would need one process per GPU and the encoder is one process)" % world),
+                       "frames_per_step": CHUNK, "encoder_cli_fps_rank0": enc["cli_fps"], "served_by_gpu": enc["served"],
                        "build_flags": build_flags(), "host_cores": os.cpu_count(), "host_cpu_quota": host_cpu_quota(), "pool_threads_per_encoder": enc["pools"], "threads": enc["threads_note"], "timed_s": round(dt, 2),
                        "host_note": "host_cpu_quota = CPUs the container's cgroup grants (cpu.max); when it is far below host_cores both encoders are bound by CPU seconds per "
                                     "frame and N encoders share the same budget (DESIGN.md §4c)"},
@@ -987,16 +1007,16 @@ def main():
         }
         if "reference" in enc:
             r0 = enc["reference"]
-            ref_fps = world * enc["frames"] / r0["wall_s"] if r0["wall_s"] else None
+            ref_fps = enc["frames"] / r0["wall_s"] if r0["wall_s"] else None
             quota = host_cpu_quota()
             out["cpu_baseline"] = {"value": round(ref_fps, 3) if ref_fps else None, "unit": "frames/s",
                                    "cores": int(min(os.cpu_count() or 1, quota)) if quota else os.cpu_count(), "kind": "reference",
                                    "build_flags": (build_flags() or {}).get("reference_objects"),
                                    "cores_note": "CPUs the process tree can use at once: min(cores the kernel shows = %s, cgroup quota = %s); encoder threads: %s (the same for both encoders)"
                                                  % (os.cpu_count(), quota, enc["threads_note"]),
-                                   "sample": "the same %d chunk(s) of %d frames, same arguments (and the same --pools share at N > 1), through oracle/_ref/x265_8bit — the unmodified "
-                                             "reference, [noasm] C primitives: no nasm in the image, so the AVX2 / AVX-512 path cannot be built — %d encoder(s) at the same time, "
-                                             "measured like `value`: all frames / wall clock between two fences (%.1f s)" % (world, enc["frames"], world, r0["wall_s"]),
+                                   "sample": "the same %d frames, same arguments, through oracle/_ref/x265_8bit — the unmodified reference, [noasm] C primitives at the reference's "
+                                             "own Release flags: no nasm in the image, so the AVX2 / AVX-512 path cannot be built (cpu_baseline_vec: its intrinsics path) — measured "
+                                             "like `value`: all frames / wall clock of the run (%.1f s)" % (enc["frames"], r0["wall_s"]),
                                    "cli_fps_rank0": r0["cli_fps"],
                                    "byte_identical_to_gpu_path": r0["byte_identical"], "bitstream_bytes": r0["bitstream_bytes"]}
             if not r0["byte_identical"]:
@@ -1009,8 +1029,11 @@ def main():
                                            "sample": "the same %d frames through oracle/_ref/x265_vec_8bit --asm SSE4.1: the reference with its own compiler-intrinsics transforms "
                                                      "(source/common/vec: idct8/16/32 SSE3, dct16/32 SSSE3, dequant_scaling SSE4.1 — the reference's SIMD for the MFMA rows that needs "
                                                      "no assembler); every other slot is the C primitive, as in `cpu_baseline` (the .asm kernels need nasm, absent from the image)" % enc["frames"]}
-        if enc.get("one_encoder"):
-            out["one_encoder_all_gpus"] = enc["one_encoder"]
+        for k in ("chunk_form", "configs4_8k"):
+            if enc.get(k):
+                out[k] = enc[k]
+        if world > 1:
+            out["exchange"] = [l for l in enc["served"] if "places:" in l]
         if fpb:
             out["frame_pass"] = fpb
         print(json.dumps(out), flush=True)

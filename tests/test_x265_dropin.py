@@ -133,13 +133,17 @@ BASELINE_ENCODES = {
 
 
 @pytest.mark.parametrize("name", sorted(BASELINE_ENCODES))
-def test_baseline_configs_encode_byte_identical_through_the_seams(name):
-    """BASELINE.json configs[2], [3], [4] as real encodes: the reference encoder with the lookahead session and the reference-picture mirrors on the
-    GPU (4K: 32 400 lowres blocks per estimate, 8.7 M-sample planes; 8K: 130 k blocks, 35 M-sample planes) against the unmodified encoder — same
-    bytes, and both seams really served."""
+def test_baseline_configs_encode_byte_identical_through_the_seams(name, monkeypatch):
+    """BASELINE.json configs[2], [3], [4] as real encodes: the reference encoder with every bound module on the GPU (4K: 32 400 lowres blocks per estimate,
+    8.7 M-sample planes; 8K: 130 k blocks, 35 M-sample planes) against the unmodified encoder — same bytes, with X265HIP_VERIFY=1 (every served value is
+    recomputed by the reference's function beside it: a mismatch aborts the encoder), and every module that applies to the configuration really served:
+    the lookahead session, the reference-picture planes, the CU jobs (coefficient mode at the RDOQ presets of configs[2] / [3]: forward transform units
+    served), SAO statistics jobs (8-bit builds), intra scan jobs (rd levels 2-4)."""
+    import re
     bits, w, h, frames, preset, extra = BASELINE_ENCODES[name]
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import encode_fps
+    monkeypatch.setenv("X265HIP_VERIFY", "1")
     # the Main10 configuration is fed 10-bit samples (BASELINE.json configs[3] is a 10-bit encode of 10-bit material)
     r = encode_fps.measure(frames=frames, width=w, height=h, bits=bits, preset=preset, extra=extra, seed=31, input_depth=10 if bits == 10 else 8)
     if "error" in r and "not built" in r["error"]:
@@ -150,6 +154,17 @@ def test_baseline_configs_encode_byte_identical_through_the_seams(name):
     assert served and int(served[0].split()[2]) >= 3, r
     planes = [l for l in r["gpu"]["served"] if "refplanes:" in l]
     assert planes and int(planes[0].split()[2]) > 1000, r
+    text = "\n".join(r["gpu"]["served"])
+    m = re.search(r"cuserve: (\d+) CU residual quad-trees .*?: (\d+) forward transform\+quant units and (\d+) inverse units served", text)
+    assert m and int(m.group(1)) > 100 and int(m.group(2)) > 100, text            # (configs[2] / [3]: rdoQuant on the host, coefficient-mode jobs: forward units only)
+    if name.startswith("configs[4]"):
+        assert int(m.group(3)) > 100, text                                        # preset medium: the whole chain, inverse units too
+    m = re.search(r"saostats: SAO statistics of (\d+) CTU planes", text)
+    if bits == 8:
+        assert m and int(m.group(1)) > 100, text
+    m = re.search(r"intrascan: the 35-mode sa8d scans of (\d+) blocks", text)
+    if not name.startswith("configs[3]"):                                         # (--rd 6: checkIntraInInter is not on the path)
+        assert m and int(m.group(1)) > 10, text
 
 
 def test_8k_encode_with_two_places_is_byte_identical(monkeypatch):

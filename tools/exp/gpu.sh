@@ -36,9 +36,16 @@ while [ $# -gt 0 ]; do
     bench)
       timeout 600 python bench.py 2> $OUT/bench.err | tail -1 > $OUT/bench.json; cut -c1-300 $OUT/bench.json ;;
     configs23)
-      OFF="X265HIP_CUSERVE_RDOQ=0"
-      timeout 1200 python tools/ab_encode.py --rounds 2 --frames 24 --res 3840x2160 --preset slow --extra "--me star --merange 57" base: nocoef:$OFF --out $OUT/configs2.json 2>&1 | tee $OUT/configs2_4k_slow_star_ab.txt | tail -12
-      timeout 1200 python tools/ab_encode.py --rounds 2 --frames 8 --res 3840x2160 --preset slower --extra "--rd 6" --bits 10 base: nocoef:$OFF --out $OUT/configs3.json 2>&1 | tee $OUT/configs3_4k_main10_slower_ab.txt | tail -12 ;;
+      # BASELINE configs[2] / configs[3] as JSON lines shaped like bench.py's (value, cpu_baseline with build flags, byte identity, served counts): CFG_ROUNDS
+      # interleaved rounds (default 5), the bench line's thread arguments; then the coefficient-mode A/B (RDOQ CUs on the host vs as jobs)
+      TH="--pools 24 --frame-threads 6"
+      timeout 1500 python tools/config_bench.py --encode configs2 --rounds ${CFG_ROUNDS:-5} --threads "$TH" 2> $OUT/configs2.err | tail -1 > $OUT/configs2_line.json; cut -c1-400 $OUT/configs2_line.json
+      timeout 1500 python tools/config_bench.py --encode configs3 --rounds ${CFG_ROUNDS:-5} --threads "$TH" 2> $OUT/configs3.err | tail -1 > $OUT/configs3_line.json; cut -c1-400 $OUT/configs3_line.json
+      if [ "${CFG_AB:-1}" = 1 ]; then
+        OFF="X265HIP_CUSERVE_RDOQ=0"
+        timeout 1500 python tools/ab_encode.py --rounds ${CFG_ROUNDS:-5} --frames 24 --res 3840x2160 --preset slow --extra "--me star --merange 57 $TH" base: nocoef:$OFF --out $OUT/configs2.json 2>&1 | tee $OUT/configs2_4k_slow_star_ab.txt | tail -6
+        timeout 1500 python tools/ab_encode.py --rounds ${CFG_ROUNDS:-5} --frames 8 --res 3840x2160 --preset slower --extra "--rd 6 $TH" --bits 10 base: nocoef:$OFF --out $OUT/configs3.json 2>&1 | tee $OUT/configs3_4k_main10_slower_ab.txt | tail -6
+      fi ;;
     ab)
       frames=$1; shift; cfgs=(); while [ $# -gt 0 ] && [[ "$1" == *:* ]]; do cfgs+=("$1"); shift; done
       # AB_ROUNDS (default 3), AB_EXTRA (default "--me hex"; the bench line's arguments on the MI355X box are "--me hex --pools 16 --frame-threads 5"), AB_NAME (file stem)

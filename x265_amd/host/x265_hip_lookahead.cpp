@@ -50,7 +50,6 @@ extern int64_t refEstimateFrameCost(CostEstimateGroup* self, LookaheadTLD& tld, 
     asm("_ZN4x26520CostEstimateGroupRef17estimateFrameCostERNS_12LookaheadTLDEiiib");
 extern void refFinishBatch(CostEstimateGroup* self) asm("_ZN4x26520CostEstimateGroupRef11finishBatchEv");
 extern void refLookaheadDestroy(Lookahead* self) asm("_ZN4x26512LookaheadRef7destroyEv");
-extern void refPreLookahead(PreLookaheadGroup* self, int workerThreadID) asm("_ZN4x26520PreLookaheadGroupRef12processTasksEi");
 static_assert(sizeof(X265HIP_STR(X265_NS)) == sizeof("x265"), "the asm labels above assume -DX265_NS=x265");
 
 namespace {
@@ -549,15 +548,12 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
     return refEstimateFrameCost(this, tld, p0, p1, b, bIntraPenalty);
 }
 
-// The pre-lookahead of the frames that entered since the last slice-type decision (slicetype.cpp:1380-1402): Lowres::init, adaptive quantisation,
-// the intra estimate — one frame per bonded worker.
-void PreLookaheadGroup::processTasks(int workerThreadID)
-{
-    const long long a = timeline().f ? timeline().now() : 0;
-    refPreLookahead(this, workerThreadID);
-    if (timeline().f)
-        timeline().line(a, timeline().now(), "pre", 0, 0, 0, 0, m_jobTotal);
-}
+// (The pre-lookahead — PreLookaheadGroup::processTasks, slicetype.cpp:1380-1402: Lowres::init, adaptive quantisation, the intra estimate, one frame per bonded
+// worker — stays the reference's: rounds 3-5 carried a pass-through seam here that only timed it.  x265hip_lowres_init / x265hip_lowres_intra_estimate exist and
+// are pinned (tests/test_hip_parity.py), but the frame's lowres planes, intra costs and modes are read by host code in four places afterwards (AQ, weightp,
+// cuTree, the slice-type decision), so they would have to come back over PCIe for work that is 1.0 % of the bound encoder's CPU time
+// (profiles/r06_v1_cpu_profile_bound_encoder.txt: frame_init_lowres_core 0.34 %, the lookahead's intra predictors and satd below that) on threads that are not
+// on a frame encoder's critical path.  Row f1's other half is host by decision; the seam is gone.)
 
 void CostEstimateGroup::finishBatch()
 {
