@@ -862,6 +862,11 @@ typedef struct x265hip_cujob
     uint32_t sourceDct;           /* with coefMode: 1 = a LUMA unit's `resi` block receives cu[].dct of the unit's SOURCE pixels — m_fencDctCoeff, which psy-rdoq
                                    * compares the levels' reconstruction against (quant.cpp:436-442) */
 } x265hip_cujob;
+/* coefMode == X265HIP_CUJOB_INVERSE: the INVERSE half alone, for levels the host has made (Quant::rdoQuant): Quant::invtransformNxN (quant.cpp:543-603:
+ * dequant_normal -> cu[].idct) of ONE 32x32 luma unit and the measurements Search::estimateResidualQT takes behind it.  log2CUSize = log2TrMax = 5, chroma = 0;
+ * pixel block: the unit's source block, its prediction, then its 1 024 levels (int16, rows contiguous).  Results in units[0]: numSig (non-zero levels counted),
+ * zeroDist, codedDist, codedEnergy and the unit's `resi` block; readyInv, then ready. */
+#define X265HIP_CUJOB_INVERSE 8u
 typedef struct x265hip_cujob_unit
 {
     uint32_t ready;               /* == the job's ticket once this unit's numSig, zeroDist and levels are in place (the forward half) */

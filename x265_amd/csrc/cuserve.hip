@@ -133,7 +133,7 @@ struct JobLds
 static_assert(sizeof(x265hip_cujob) <= 128, "job header");
 
 // ticket = what the host rings and the units' ready words take: bits 31..8 a running number (never 0, never 0xffffff), bits 7..0 what the device
-// needs to know before it has read anything: log2CUSize - 4 (bits 1..0), chroma (bit 2), 16-bit samples (bit 3)
+// needs to know before it has read anything: log2CUSize - 4 (bits 1..0), chroma (bit 2), 16-bit samples (bit 3), an inverse job's levels block (bit 4)
 // bits 1..0 == 3: an SAO statistics job (x265hip_saojob): bits 7..2 = the job's size, header included, in 512-byte steps
 __host__ __device__ inline uint32_t ticket_bytes(uint32_t t)
 {
@@ -495,9 +495,16 @@ __device__ __forceinline__ void tile_chain(TileLds& t, const BOperand (*bop)[64]
 // coefficient group (64 groups: one wave).  Same arithmetic, same LDS layouts, same results as tile_chain<P, 32>.
 __device__ __forceinline__ void team_barrier()
 {
-    __builtin_amdgcn_s_waitcnt(0xc07f);          // this wave's LDS traffic (not its stores to host memory: those are waited for where a ready word follows)
+    // s_barrier alone orders nothing for the compiler (the intrinsic is IntrNoMem: loads and stores may move across it): LDS-only fences either side — this
+    // wave's LDS traffic is complete before the barrier and none of the next stage's is issued before it; stores to host memory are NOT waited for here
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
+// Stores to host memory are NEVER ordered by these barriers: a unit's blocks leave through wave 0 alone, whose release store of the ready word orders them.  (The
+// first team version let every wave store its quarter and wait for it — s_waitcnt vmcnt(0) — in front of a barrier and wave 0's ready word: X265HIP_VERIFY at
+// BASELINE configs[2] caught coefficients read by the host before another wave's quarter had landed, 5 runs of 7; a system-scope release fence per wave closes
+// it and costs 1.5 us of the chain: profiles/r06_v1_team_fence.txt)
 
 // thread tid's operand of the 16x16x32 form: wave w makes output rows 16 * (w >> 1) .., columns 16 * (w & 1) ..; lane l holds column C0 + (l & 15) of the
 // coefficient matrix for the contraction indices 8 * (l >> 4) .. + 7
@@ -585,6 +592,74 @@ __device__ __forceinline__ unsigned long long team_total(const uint32_t* part)
     return t;
 }
 
+// the inverse half of a team unit: the dequantised coefficients are in t.a, the unit's source and prediction samples of this thread in fv / pv
+template <typename P>
+__device__ __forceinline__ void team_inverse32(TileLds& t, TeamLds& tm, const P* src, int pw, int ux, int uy, const PlaneParams qp, const int fv[4], const int pv[4],
+                                               x265hip_cujob_unit* un, int16_t* resi, uint32_t seq, uint64_t t0, bool stamps, uint32_t stamp[6])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, e = tid * 4;
+    const TeamOperand& oI = tm.op[1][tid];
+    // ---- inverse transform: a -> b -> a
+    team_pass<true>(t.a, t.b, tid, oI, qp.s1i);
+    team_barrier();
+    team_pass<true>(t.b, t.a, tid, oI, qp.s2i);
+    team_barrier();
+    XH_STAMP(4);
+    // ---- distortion of the coded alternative; the reconstruction to b as int16 for the energies (the reconstructed residual stays in a)
+    {
+        int r[4], rec[4];
+        uint32_t codedP = 0;
+        load4(t.a + e, r);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            rec[i] = clip3i(0, qp.maxVal, pv[i] + r[i]);
+            const int d1 = fv[i] - rec[i];
+            codedP += (uint32_t)(d1 * d1);
+        }
+        store4(t.b + e, rec);
+        team_part(tm.part, tid, codedP);
+    }
+    team_barrier();
+    // ---- wave 0 carries the reconstructed residual out; psy_cost_pp(source, reconstruction) meanwhile: per 8x8 block |E(source) - E(reconstruction)| (tile_chain) —
+    // wave 2 measures the reconstruction, wave 3 the source: a lane = one 4x4 tile, four consecutive lanes the quadrants of one 8x8 block
+    if (wv == 0)
+    {
+        const uint4 r0 = *reinterpret_cast<const uint4*>(t.a + lane * 16), r1 = *reinterpret_cast<const uint4*>(t.a + lane * 16 + 8);
+        *reinterpret_cast<uint4*>(resi + lane * 16) = r0;
+        *reinterpret_cast<uint4*>(resi + lane * 16 + 8) = r1;
+    }
+    else if (wv >= 2)
+    {
+        const int b8 = lane >> 2, q = lane & 3;
+        const int tx = (b8 & 3) * 8 + (q & 1) * 4, ty = (b8 >> 2) * 8 + (q >> 1) * 4;
+        int m[16];
+        if (wv == 2) tile_load(t.b + ty * 32 + tx, (int64_t)32, m);
+        else tile_load(src + (uy * 32 + ty) * pw + ux * 32 + tx, (int64_t)pw, m);
+        int sum = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) sum += m[i];
+        hadamard4x4(m);
+        const int raw = quad_sa8d_raw(m, lane);
+        const int en = ((raw + 2) >> 2) - (quad_sum(sum) >> 2);
+        if (q == 0) tm.energy[wv == 2 ? 1 : 0][b8] = en;
+    }
+    team_barrier();
+    // (wave 0's release store orders its own stores of the residual in front of the word)
+    if (tid == 0)
+    {
+        int energy = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) energy += iabs(tm.energy[0][i] - tm.energy[1][i]);
+        un->codedDist = team_total(tm.part);
+        un->codedEnergy = (uint32_t)energy;
+        XH_STAMP(5);
+        if (stamps) { un->reserved[0] = stamp[0] | (stamp[1] << 16); un->reserved[1] = stamp[2] | (stamp[3] << 16); un->reserved[2] = stamp[4] | (stamp[5] << 16); }
+        __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    team_barrier();                              // (the tile and the team's words are free for the next unit)
+}
+
 // unit `u` (raster order; `pw` elements per row of the plane in LDS) of a plane whose transform size is 32: tile_chain<P, 32>'s work for one unit
 template <typename P>
 __device__ __forceinline__ void team_chain32(TileLds& t, TeamLds& tm, const P* src, const P* prd, int pw, int u, const PlaneParams qp, bool signHide,
@@ -625,24 +700,27 @@ __device__ __forceinline__ void team_chain32(TileLds& t, TeamLds& tm, const P* s
         // ---- coefficient mode (tile_chain): the transform coefficients go out where the levels would (residual part) or where the reconstructed residual would
         // (source part)
         int16_t* dstC = srcOnly ? resi : levels;
-        *reinterpret_cast<uint2*>(dstC + e) = *reinterpret_cast<const uint2*>(t.a + e);
-        // every wave's stores are in host memory before the ready word leaves: each waits for its own, then the barrier
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_s_barrier();
-        if (tid == 0)
+        // (one wave carries the block out and publishes behind it, see the forward half below)
+        if (wv == 0)
         {
-            if (srcOnly)
-                __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            else
+            const uint4 c0 = *reinterpret_cast<const uint4*>(t.a + lane * 16), c1 = *reinterpret_cast<const uint4*>(t.a + lane * 16 + 8);
+            *reinterpret_cast<uint4*>(dstC + lane * 16) = c0;
+            *reinterpret_cast<uint4*>(dstC + lane * 16 + 8) = c1;
+            if (lane == 0)
             {
-                un->numSig = 0;
-                un->zeroDist = team_total(tm.part2);
-                un->fwdTicks = (uint32_t)(wall_clock64() - t0);
-                XH_STAMP(5);
-                if (stamps) { un->reserved[0] = stamp[0] | (stamp[1] << 16); un->reserved[1] = 0; un->reserved[2] = stamp[5] << 16; }
-                if (!(coef & 4))
+                if (srcOnly)
                     __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(&un->ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                else
+                {
+                    un->numSig = 0;
+                    un->zeroDist = team_total(tm.part2);
+                    un->fwdTicks = (uint32_t)(wall_clock64() - t0);
+                    XH_STAMP(5);
+                    if (stamps) { un->reserved[0] = stamp[0] | (stamp[1] << 16); un->reserved[1] = 0; un->reserved[2] = stamp[5] << 16; }
+                    if (!(coef & 4))
+                        __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(&un->ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
         }
         team_barrier();                          // (part2 and the tile are free again)
@@ -754,89 +832,99 @@ __device__ __forceinline__ void team_chain32(TileLds& t, TeamLds& tm, const P* s
         numSig = tm.numSig;
     }
     XH_STAMP(3);
-    // ---- levels out, dequant_normal -> a
+    // ---- dequant_normal -> a (every thread its four); wave 0 takes the unit's levels into registers: they leave through ONE wave, whose release store of the ready
+    // word then orders them (stores of another wave are not ordered against it by anything cheaper than a system-scope release fence per wave: profiles/r06_v1_team_fence.txt)
+    uint4 keep0 = { 0, 0, 0, 0 }, keep1 = { 0, 0, 0, 0 };
     {
         int lv[4], dq[4];
         const int dqAdd = 1 << (qp.dqShift - 1);
         load4(t.b + e, lv);
 #pragma unroll
         for (int i = 0; i < 4; i++) dq[i] = clip3i(-32768, 32767, (lv[i] * qp.dqScale + dqAdd) >> qp.dqShift);
-        *reinterpret_cast<uint2*>(levels + e) = *reinterpret_cast<const uint2*>(t.b + e);
         store4(t.a + e, dq);
+        if (wv == 0)
+        {
+            keep0 = *reinterpret_cast<const uint4*>(t.b + lane * 16);
+            keep1 = *reinterpret_cast<const uint4*>(t.b + lane * 16 + 8);
+        }
     }
-    // ---- the forward half is complete: every wave's levels are in host memory (each waits for its own stores), then the ready word
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_s_barrier();
+    team_barrier();
+    // ---- the forward half is complete: levels, numSig, zeroDist, then the ready word (the other waves are already in the inverse passes)
+    if (wv == 0)
+    {
+        *reinterpret_cast<uint4*>(levels + lane * 16) = keep0;
+        *reinterpret_cast<uint4*>(levels + lane * 16 + 8) = keep1;
+        if (lane == 0)
+        {
+            un->numSig = (uint32_t)numSig;
+            un->zeroDist = team_total(tm.part2);
+            un->fwdTicks = (uint32_t)(wall_clock64() - t0);
+            __hip_atomic_store(&un->ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // nobody asks for the inverse half of a unit without a level (tile_chain)
+            if (numSig == 0)
+                __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (numSig == 0)
+    {
+        team_barrier();
+        return;
+    }
+    team_inverse32<P>(t, tm, src, pw, ux, uy, qp, fv, pv, un, resi, seq, t0, stamps, stamp);
+}
+
+// An INVERSE job (x265hip_cujob::coefMode == X265HIP_CUJOB_INVERSE): one 32x32 luma unit whose levels the host has made (Quant::rdoQuant) — dequant_normal ->
+// cu[].idct -> reconstructed residual, sse_pp and psy energy of the reconstruction, i.e. Quant::invtransformNxN (quant.cpp:543-603) and the two measurements
+// Search::estimateResidualQT takes behind it (search.cpp:3290-3300).  The levels follow the source and prediction blocks in the pixel block.
+template <typename P>
+__device__ __forceinline__ void team_inverse_job(SlotOut* s, JobLds& L, uint32_t seq, uint64_t t0)
+{
+    const x265hip_cujob& j = L.job;
+    TileLds& t = L.tile[0];
+    TeamLds& tm = L.team;
+    const P* src = reinterpret_cast<const P*>(L.pix);
+    const P* prd = src + 1024;
+    const int16_t* lvIn = reinterpret_cast<const int16_t*>(prd + 1024);
+    const PlaneParams qp = plane_params(j, 0, 5);
+    const bool stamps = j.reserved != 0;
+    uint32_t stamp[6] = { 0, 0, 0, 0, 0, 0 };
+    XH_STAMP(0);
+    const int tid = threadIdx.x, e = tid * 4;
+    x265hip_cujob_unit* un = s->units;
+    int fv[4], pv[4], lv[4], dq[4];
+    load4(src + e, fv);
+    load4(prd + e, pv);
+    load4(lvIn + e, lv);
+    uint32_t zeroP = 0, cnt = 0;
+    const int dqAdd = 1 << (qp.dqShift - 1);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        const int d0 = fv[i] - pv[i];
+        zeroP += (uint32_t)(d0 * d0);
+        cnt += lv[i] != 0;
+        dq[i] = clip3i(-32768, 32767, (lv[i] * qp.dqScale + dqAdd) >> qp.dqShift);
+    }
+    store4(t.a + e, dq);
+    team_part(tm.part2, tid, zeroP);
+    team_part(tm.part, tid, cnt);
+    team_barrier();
+    const int numSig = (int)team_total(tm.part);
     if (tid == 0)
     {
         un->numSig = (uint32_t)numSig;
         un->zeroDist = team_total(tm.part2);
-        un->fwdTicks = (uint32_t)(wall_clock64() - t0);
-        __hip_atomic_store(&un->ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (numSig == 0)
-    {
-        // nobody asks for the inverse half of a unit without a level (tile_chain)
-        if (tid == 0)
-            __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (numSig)
+        team_inverse32<P>(t, tm, src, 32, 0, 0, qp, fv, pv, un, s->resi, seq, t0, stamps, stamp);
+    else
         team_barrier();
-        return;
-    }
-    // ---- inverse transform: a -> b -> a
-    team_pass<true>(t.a, t.b, tid, oI, qp.s1i);
-    team_barrier();
-    team_pass<true>(t.b, t.a, tid, oI, qp.s2i);
-    team_barrier();
-    XH_STAMP(4);
-    // ---- reconstructed residual out; distortion of the coded alternative; the reconstruction to b as int16 for the energies
-    {
-        int r[4], rec[4];
-        uint32_t codedP = 0;
-        load4(t.a + e, r);
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-        {
-            rec[i] = clip3i(0, qp.maxVal, pv[i] + r[i]);
-            const int d1 = fv[i] - rec[i];
-            codedP += (uint32_t)(d1 * d1);
-        }
-        *reinterpret_cast<uint2*>(resi + e) = *reinterpret_cast<const uint2*>(t.a + e);
-        store4(t.b + e, rec);
-        team_part(tm.part, tid, codedP);
-    }
-    team_barrier();
-    // ---- psy_cost_pp(source, reconstruction): per 8x8 block |E(source) - E(reconstruction)| (tile_chain).  Wave 0 measures the reconstruction, wave 1 the
-    // source: a lane = one 4x4 tile, four consecutive lanes the quadrants of one 8x8 block
-    if (wv < 2)
-    {
-        const int b8 = lane >> 2, q = lane & 3;
-        const int tx = (b8 & 3) * 8 + (q & 1) * 4, ty = (b8 >> 2) * 8 + (q >> 1) * 4;
-        int m[16];
-        if (wv == 0) tile_load(t.b + ty * 32 + tx, (int64_t)32, m);
-        else tile_load(src + (uy * 32 + ty) * pw + ux * 32 + tx, (int64_t)pw, m);
-        int sum = 0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) sum += m[i];
-        hadamard4x4(m);
-        const int raw = quad_sa8d_raw(m, lane);
-        const int en = ((raw + 2) >> 2) - (quad_sum(sum) >> 2);
-        if (q == 0) tm.energy[wv == 0 ? 1 : 0][b8] = en;
-    }
-    // (the reconstructed residual of every wave is in host memory before the word below)
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_s_barrier();
     if (tid == 0)
     {
-        int energy = 0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) energy += iabs(tm.energy[0][i] - tm.energy[1][i]);
-        un->codedDist = team_total(tm.part);
-        un->codedEnergy = (uint32_t)energy;
-        XH_STAMP(5);
-        if (stamps) { un->reserved[0] = stamp[0] | (stamp[1] << 16); un->reserved[1] = stamp[2] | (stamp[3] << 16); un->reserved[2] = stamp[4] | (stamp[5] << 16); }
-        __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        un->fwdTicks = (uint32_t)(wall_clock64() - t0);
+        if (!numSig) __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&un->ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    team_barrier();                              // (the tile and the team's words are free for the next unit)
 }
 
 // the six transform operands, once per kernel: wave w builds size 8 << w (waves 0..2)
@@ -866,6 +954,11 @@ __device__ __forceinline__ void run_tiles(SlotOut* s, JobLds& L, uint32_t seq, u
     const int lumaElems = N * N, planeElems = j.chroma ? lumaElems + lumaElems / 2 : lumaElems;
     const P* src = reinterpret_cast<const P*>(L.pix);
     const P* prd = src + planeElems;
+    if (j.coefMode == X265HIP_CUJOB_INVERSE)
+    {
+        if (role == 0) team_inverse_job<P>(s, L, seq, t0);
+        return;
+    }
     int sHi, sLo;
     const int levels = x265hipi_cujob_levels(&j, &sHi, &sLo);
     // ---- tiles, largest size first; wave w takes the role's tiles w, w + 4, ... (team units are taken by all four waves together)
@@ -1224,9 +1317,11 @@ __device__ __forceinline__ void run_job(const SlotIn* sin, SlotOut* s, JobLds& L
         const int B = (ticket & 8) ? 2 : 1, n2 = 1 << (2 * ((int)(ticket & 3) + 4));
         const int planeBytes = ((ticket & 4) ? n2 + n2 / 2 : n2) * B;
         const int first = (role ? n2 * B : 0) >> 4, count = (role ? (n2 / 2) * B : n2 * B) >> 4, pred = planeBytes >> 4;
-        for (int i = tid; i < 8 + 2 * count; i += 256)
+        // (bit 4 of the ticket: an inverse job — 1 024 levels behind the two blocks)
+        const int extra = (ticket & 16) ? 128 : 0;
+        for (int i = tid; i < 8 + 2 * count + extra; i += 256)
         {
-            const int k = i < 8 ? i : i < 8 + count ? 8 + first + (i - 8) : 8 + pred + first + (i - 8 - count);
+            const int k = i < 8 ? i : i < 8 + count ? 8 + first + (i - 8) : i < 8 + 2 * count ? 8 + pred + first + (i - 8 - count) : 8 + 2 * pred + (i - 8 - 2 * count);
             out[k] = in[k];
         }
     }
@@ -1646,7 +1741,10 @@ int x265hip_cuserve_submit(x265hip_cuserve* cs, int slot, uint32_t* seqOut)
     uint32_t run = cs->seq[slot].load(std::memory_order_relaxed) + 1;                       // a slot has one submitter at a time
     if (run >= 0xfffff0u) run = 1;
     cs->seq[slot].store(run, std::memory_order_relaxed);
-    const uint32_t seq = (run << 8) | (j.log2CUSize - 4) | (j.chroma ? 4u : 0u) | (j.bitDepth > 8 ? 8u : 0u);
+    const bool inverseJob = j.coefMode == X265HIP_CUJOB_INVERSE;
+    if (inverseJob && (j.log2CUSize != 5 || j.chroma || sHi != 5))
+        return set_error(X265HIP_EINVAL, "x265hip_cuserve_submit: an inverse job is one 32x32 luma unit (CU 2^%u, chroma %u, transform 2^%d)", j.log2CUSize, j.chroma, sHi);
+    const uint32_t seq = (run << 8) | (j.log2CUSize - 4) | (j.chroma ? 4u : 0u) | (j.bitDepth > 8 ? 8u : 0u) | (inverseJob ? 16u : 0u);
     *seqOut = seq;
     cs->jobs.fetch_add(1, std::memory_order_relaxed);
     {
