@@ -127,6 +127,30 @@ int orc_cujob_run_##SFX(const x265hip_cujob* j, const P* pixels, x265hip_cujob_u
     const int N = 1 << j->log2CUSize, N2 = N * N, planeElems = j->chroma ? N2 + N2 / 2 : N2, depth = (int)j->bitDepth; \
     const P* src = pixels; \
     const P* prd = pixels + planeElems; \
+    if (j->coefMode == X265HIP_CUJOB_INVERSE) \
+    { \
+        /* the inverse half alone of ONE 32x32 luma unit, for levels made elsewhere (Quant::rdoQuant): Quant::invtransformNxN quant.cpp:543-603, then the \
+         * reconstruction's sse_pp and psy energy (search.cpp:3290-3300); the levels follow the two blocks in the pixel block */ \
+        const int16_t* lv = (const int16_t*)(pixels + 2 * 1024); \
+        int16_t back[1024]; \
+        P rec[1024]; \
+        uint32_t ns = 0; \
+        for (int i = 0; i < 1024; i++) ns += lv[i] != 0; \
+        units[0].numSig = ns; \
+        units[0].zeroDist = orc_sse_pp_##SFX(src, 32, prd, 32, 32, 32); \
+        if (ns) \
+        { \
+            orc_invtransform_nxn(back, 32, lv, 5, depth, j->qpPer[0], j->dequantScale[0], ns); \
+            orc_add_ps_##SFX(rec, 32, prd, back, 32, 32, 32, 32, depth); \
+            units[0].codedDist = orc_sse_pp_##SFX(src, 32, rec, 32, 32, 32); \
+            units[0].codedEnergy = (uint32_t)orc_psy_cost_pp_##SFX(src, 32, rec, 32, 32); \
+            memcpy(resi, back, sizeof(back)); \
+        } \
+        units[0].fwdTicks = 0; \
+        __atomic_store_n(&units[0].readyInv, seq, __ATOMIC_RELEASE); \
+        __atomic_store_n(&units[0].ready, seq, __ATOMIC_RELEASE); \
+        return 1; \
+    } \
     for (int lv = 0; lv < nl; lv++) \
     { \
         const int s = sHi - lv, perRow = 1 << ((int)j->log2CUSize - s); \

@@ -711,6 +711,40 @@ def test_bound_encoder_inter_candidate_jobs_ahead_stay_byte_identical(tmp_path, 
         assert m and int(m.group(1)) > 50 and m.group(1) == m.group(2), r.stderr[-800:]
 
 
+@pytest.mark.parametrize("extra,bits", [(["--preset", "slow"], 8), (["--preset", "slower", "--rd", "6"], 10), (["--preset", "slow", "--ctu", "32", "--psy-rdoq", "0"], 8)],
+                         ids=["slow", "slower-rd6-main10", "slow-ctu32-nopsyrdoq"])
+def test_bound_encoder_inverse_jobs_behind_rdoq_stay_byte_identical(tmp_path, extra, bits):
+    """the RDOQ presets (BASELINE configs[2] / [3]'s): Quant::rdoQuant makes a luma 32x32 unit's levels on the host, the unit's inverse half leaves as an
+    x265hip_cujob of its own (coefMode X265HIP_CUJOB_INVERSE) and Quant::invtransformNxN collects it — residual, sse_pp and psy energy of the reconstruction.
+    Here over the emulated ABI with X265HIP_VERIFY=1: same bytes as the unmodified encoder, jobs really left and were collected; and switched off
+    (X265HIP_CUSERVE_INVERSE=0) none leaves."""
+    import re, subprocess, sys
+    sys.path.insert(0, ROOT)
+    ref, emul = os.path.join(ROOT, "oracle", "_ref", "x265_%dbit" % bits), os.path.join(ROOT, "oracle", "_ref", "x265_emul_%dbit" % bits)
+    if not (os.path.exists(ref) and os.path.exists(emul)):
+        pytest.skip("oracle/_ref encoders not built (make -C oracle ref emul)")
+    from x265_amd.synth import make_clip
+    yuv = str(tmp_path / "clip.yuv")
+    make_clip(yuv, 416, 240, 6, seed=83)
+    args = ["--input", yuv, "--input-res", "416x240", "--fps", "30", "--frames", "6", "--hash", "1", "--pools", "4", "-F", "2"] + extra
+    want, got = str(tmp_path / "ref.hevc"), str(tmp_path / "emul.hevc")
+    assert subprocess.run([ref] + args + ["-o", want], capture_output=True, timeout=900).returncode == 0
+    for off in (False, True):
+        env = dict(os.environ, X265HIP="require", X265HIP_VERBOSE="1", X265HIP_VERIFY="1")
+        if off:
+            env["X265HIP_CUSERVE_INVERSE"] = "0"
+        r = subprocess.run([emul] + args + ["-o", got], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-800:]
+        assert open(got, "rb").read() == open(want, "rb").read()
+        m = re.search(r"cuserve: (\d+) inverse jobs .*? left when the levels were made, (\d+) never collected", r.stderr)
+        served = re.search(r"(\d+) forward transform\+quant units and (\d+) inverse units served", r.stderr)
+        if off:
+            assert not m and served and int(served.group(2)) == 0, r.stderr[-800:]
+        else:
+            assert m and int(m.group(1)) > 20 and int(m.group(2)) * 10 <= int(m.group(1)), r.stderr[-800:]
+            assert served and int(served.group(2)) == int(m.group(1)) - int(m.group(2)), r.stderr[-800:]
+
+
 class _Chk:
     """hp-like holder for _run_on over the emulated library (no HipError there)"""
     from x265_amd import hipprim as _hp
@@ -788,3 +822,62 @@ def test_a_seventeenth_resident_service_is_refused_not_deadlocked():
     finally:
         for cs in opened:
             hp.check(L.x265hip_cuserve_close(cs))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 0])
+def test_device_inverse_jobs_match_the_restatement(mode):
+    """x265hip_cujob::coefMode == X265HIP_CUJOB_INVERSE (what the RDOQ presets could hand over behind Quant::rdoQuant): the inverse half alone of one 32x32 luma
+    unit, for levels made elsewhere.  The levels are the restatement's own for a whole job on the same pixels; the inverse job's reconstructed residual, codedDist,
+    codedEnergy, zeroDist and numSig must be that job's (8 / 10 / 12 bit)."""
+    from x265_amd import hipprim as hp
+    L = hp.lib()
+    hp.check(L.x265hip_init(0))
+    O = _orc()
+    cs = vp()
+    hp.check(L.x265hip_cuserve_open(2, mode, C.byref(cs)))
+    try:
+        n_done = 0
+        for depth in (8, 10, 12):
+            rng = np.random.default_rng(900 + depth)
+            bd = 6 * (depth - 8)
+            for kind in (0, 1, 2, 1, 2, 1):
+                qy = int(rng.integers(bd + 12, bd + 40))
+                j = _job_header(hp, 5, 5, 5, 0, depth, (qy, qy, qy), 0, int(rng.integers(0, 2)))
+                pix = _job_pixels(rng, 5, 0, depth, kind)
+                done, wu, wl, wr = _oracle_job(hp, O, j, pix)
+                assert done == 1
+                if not wu[0].numSig:
+                    continue
+                ji = _job_header(hp, 5, 5, 5, 0, depth, (qy, qy, qy), 0, 0, coef=8)
+                blob = np.frombuffer(pix.tobytes() + wl[:1024].tobytes(), np.uint8).copy()
+                job, pixels, units, levels, resi = vp(), vp(), vp(), vp(), vp()
+                slot = n_done % 2
+                hp.check(L.x265hip_cuserve_slot(cs, slot, C.byref(job), C.byref(pixels), C.byref(units), C.byref(levels), C.byref(resi)))
+                C.memmove(job, C.byref(ji), C.sizeof(ji))
+                C.memmove(pixels, blob.ctypes.data, blob.nbytes)
+                seq = u32()
+                hp.check(L.x265hip_cuserve_submit(cs, slot, C.byref(seq)))
+                un = C.cast(units, C.POINTER(hp.CuJobUnit))
+                t0 = time.time()
+                while un[0].ready != seq.value or un[0].readyInv != seq.value:
+                    pk = L.x265hip_cuserve_poke(cs, slot)
+                    if pk < 0:
+                        hp.check(pk)
+                    assert time.time() - t0 < 20.0, "inverse job not finished"
+                rs = np.ctypeslib.as_array(C.cast(resi, C.POINTER(C.c_int16)), (1024,)).copy()
+                label = (mode, depth, kind, qy)
+                assert un[0].numSig == int(np.count_nonzero(wl[:1024])), label
+                assert un[0].zeroDist == wu[0].zeroDist and un[0].codedDist == wu[0].codedDist and un[0].codedEnergy == wu[0].codedEnergy, label
+                assert np.array_equal(rs, wr[:1024]), label
+                n_done += 1
+        assert n_done >= 9, n_done
+        # an inverse job is one 32x32 luma unit: anything else is refused
+        bad = _job_header(hp, 6, 5, 5, 0, 8, (30, 30, 30), 0, 0, coef=8)
+        job = vp()
+        hp.check(L.x265hip_cuserve_slot(cs, 0, C.byref(job), None, None, None, None))
+        C.memmove(job, C.byref(bad), C.sizeof(bad))
+        seq = u32()
+        assert L.x265hip_cuserve_submit(cs, 0, C.byref(seq)) == -1
+    finally:
+        hp.check(L.x265hip_cuserve_close(cs))

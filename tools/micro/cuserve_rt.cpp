@@ -189,6 +189,61 @@ int main(int argc, char** argv)
             }
         fflush(stdout);
     }
+    // ---- inverse jobs (x265hip_cujob::coefMode == X265HIP_CUJOB_INVERSE): one 32x32 luma unit's levels in, its reconstructed residual + distortions out — what
+    // Quant::invtransformNxN's seam would hand over behind Quant::rdoQuant.  Timed: packing (4 KB through the BAR), submit, the wait, the 2 KB copy back
+    for (int T : { 1, 4, 16 })
+    {
+        if ((only && only[0] != 'i') || (onlyT && T != onlyT)) continue;
+        std::vector<std::vector<double>> lat(T), dev(T);
+        std::atomic<int> go(0);
+        auto body = [&](int t)
+        {
+            x265hip_init(0);
+            x265hip_cujob* job; void* pixels; const x265hip_cujob_unit* units; const int16_t* levels; const int16_t* resi;
+            x265hip_cuserve_slot(cs, t, &job, &pixels, &units, &levels, &resi);
+            std::vector<unsigned char> blob(2048 + 2048);
+            uint32_t s = 4321 + t;
+            for (int i = 0; i < 2048; i++) { s = s * 1664525u + 1013904223u; blob[i] = (unsigned char)(128 + ((s >> 24) & 15)); }
+            int16_t* lv = (int16_t*)(blob.data() + 2048);
+            for (int i = 0; i < 1024; i++) { s = s * 1664525u + 1013904223u; lv[i] = (int16_t)(((i & 31) + (i >> 5) < 12 && (s >> 28) < 6) ? (int)((s >> 20) & 7) - 3 : 0); }
+            int16_t back[1024];
+            while (!go.load()) {}
+            for (int i = 0; i < iters + 100 && !failed; i++)
+            {
+                lv[0] = (int16_t)(1 + (i & 3));
+                const double t0 = now_us();
+                memset(job, 0, sizeof(*job));
+                job->log2CUSize = 5; job->log2TrMax = 5; job->log2TrMin = 5; job->chroma = 0; job->bitDepth = 8; job->quantOffset = 85; job->coefMode = X265HIP_CUJOB_INVERSE;
+                job->qpRem[0] = 2; job->qpPer[0] = 5; job->quantScale[0] = 20560; job->dequantScale[0] = 51;
+                memcpy(pixels, blob.data(), blob.size());
+                uint32_t seq = 0;
+                if (x265hip_cuserve_submit(cs, t, &seq)) { fprintf(stderr, "submit (inverse): %s\n", x265hip_last_error()); failed = true; break; }
+                uint64_t spins = 0;
+                while (__atomic_load_n(&units[0].readyInv, __ATOMIC_ACQUIRE) != seq)
+                {
+                    __builtin_ia32_pause();
+                    if ((++spins & 1023) == 0 && (x265hip_cuserve_poke(cs, t) < 0 || now_us() - t0 > 2e6)) { fprintf(stderr, "inverse job %d of thread %d did not come back\n", i, t); failed = true; break; }
+                }
+                memcpy(back, resi, sizeof(back));
+                volatile int16_t sink = back[5]; (void)sink;
+                const double t1 = now_us();
+                while (__atomic_load_n(&units[0].ready, __ATOMIC_ACQUIRE) != seq && now_us() - t0 < 2e6) __builtin_ia32_pause();
+                if (i >= 100) { lat[t].push_back(t1 - t0); dev[t].push_back(units[0].fwdTicks * 0.01); }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back(body, t);
+        go = 1;
+        for (auto& x : th) x.join();
+        if (failed) { printf("FAILED (mode %d, inverse jobs, %d threads)\n", mode, T); x265hip_cuserve_close(cs); return 1; }
+        std::vector<double> all, dv;
+        for (auto& v : lat) all.insert(all.end(), v.begin(), v.end());
+        for (auto& v : dev) dv.insert(dv.end(), v.begin(), v.end());
+        std::sort(all.begin(), all.end()); std::sort(dv.begin(), dv.end());
+        printf("%s, inverse job of a 32x32 luma unit (8 bit), %2d thread%s: pack + submit + wait + copy back median %6.1f us, p99 %6.1f (%4.1f us of it on the device)\n",
+               mode ? "one launch per job" : "resident server   ", T, T > 1 ? "s" : " ", all[all.size() / 2], all[(size_t)(all.size() * 0.99)], dv[dv.size() / 2]);
+        fflush(stdout);
+    }
     uint64_t jobs = 0, starts = 0, ns = 0;
     x265hip_cuserve_stats(cs, &jobs, &starts, &ns);
     printf("%llu jobs, %llu server starts, %.1f us of device time per job\n", (unsigned long long)jobs, (unsigned long long)starts, jobs ? ns * 1e-3 / jobs : 0.0);

@@ -39,6 +39,7 @@ int g_mode = 0;                  // X265HIP_CUSERVE_MODE: 0 resident server (mai
 int64_t g_timeoutNs = 10000000000ll;            // X265HIP_CUSERVE_TIMEOUT_MS
 int g_yieldAfter = 0;                            // X265HIP_CUSERVE_YIELD
 std::atomic<int> g_lateJobs(0);
+int g_invJobs = 1;               // X265HIP_CUSERVE_INVERSE=0: at the RDOQ presets the inverse half of luma 32x32 units stays on the host (round 5's behaviour)
 int g_rdoqJobs = 1;              // X265HIP_CUSERVE_RDOQ=0: CUs quantised by Quant::rdoQuant are not handed over (round 4's behaviour).  On: measured on the MI355X box at
                                  // BASELINE configs[2] / configs[3] (profiles/r05_v1_configs*_ab.txt): +2 % / +6 % fps, -3 % / -6 % CPU seconds
 int g_slots = 64;                // X265HIP_CUSERVE_SLOTS: jobs that can be in flight (default: twice the CPUs this process may use, 16..64)
@@ -54,7 +55,7 @@ std::atomic<bool> g_dead(false); // the device failed once: every later CU is co
 std::atomic<uint64_t> g_cycles[18][2], g_calls[18][2];
 __attribute__((tls_model("initial-exec"))) thread_local int t_inRqt = 0;
 
-struct alignas(64) Counters { std::atomic<uint64_t> jobs, fwd, inv, fwdMiss, invMiss, waitCycles, waits, skipped, dist, psyHit, psyAhead, psyCoded, deadSub, deadAdd, lateSub, lateAdd, siteWaits[6], siteCycles[6], spec, specHit, psySkip, specInter, specInterHit; };
+struct alignas(64) Counters { std::atomic<uint64_t> jobs, fwd, inv, fwdMiss, invMiss, waitCycles, waits, skipped, dist, psyHit, psyAhead, psyCoded, deadSub, deadAdd, lateSub, lateAdd, siteWaits[6], siteCycles[6], spec, specHit, psySkip, specInter, specInterHit, invJobs, invDropped; };
 Counters g_count[64];
 std::atomic<int> g_nextShard(0);
 __attribute__((tls_model("initial-exec"))) thread_local int t_shard = -1;
@@ -90,6 +91,10 @@ struct Job
     const Yuv* fencYuv;                  // the source Yuv the pixels were taken from
     x265hip_cujob hdr;                   // what was submitted (an adopted job must be the job the scope would submit itself) ...
     alignas(64) pixel sent[X265HIP_CUJOB_PIXEL_BYTES / sizeof(pixel)];       // ... header AND pixels: a job's answers are a function of exactly these
+    // coefficient-mode jobs (RDOQ presets): the inverse half of a luma 32x32 unit as a job of its own on a second slot (x265hip_cujob::coefMode ==
+    // X265HIP_CUJOB_INVERSE), submitted when Quant::rdoQuant has made the unit's levels and collected by Quant::invtransformNxN (the tree codes the levels'
+    // bits in between, search.cpp:3243-3262)
+    struct InvAhead { bool active; int unit; Service* svc; int slot; uint32_t seq; const x265hip_cujob_unit* units; const int16_t* resi; int16_t sent[1024]; } inv;
     uint32_t seq;
     int slot;
     Service* svc;
@@ -167,6 +172,13 @@ void report()
     if (spi)
         fprintf(stderr, "x265hip: cuserve: %llu jobs left ahead of their scope when predInterSearch returned the 2Nx2N inter candidate's prediction; %llu of them were the job their "
                         "encodeResAndCalcRdInterCU wanted\n", (unsigned long long)spi, (unsigned long long)sih);
+    {
+        uint64_t ij = 0, idr = 0;
+        for (int i = 0; i < 64; i++) { ij += g_count[i].invJobs; idr += g_count[i].invDropped; }
+        if (ij)
+            fprintf(stderr, "x265hip: cuserve: %llu inverse jobs (luma 32x32 units of coefficient-mode CUs: dequant -> MFMA idct -> sse / psy energy behind Quant::rdoQuant's levels) "
+                            "left when the levels were made, %llu never collected\n", (unsigned long long)ij, (unsigned long long)idr);
+    }
     if (dsb || dad)
         fprintf(stderr, "x265hip: cuserve: %llu sub_ps and %llu add_ps calls of those CUs put off because only the job's answers read their results (%llu + %llu run after all)\n",
                 (unsigned long long)dsb, (unsigned long long)dad, (unsigned long long)lsb, (unsigned long long)lad);
@@ -189,6 +201,7 @@ bool decide()
         if (getenv("X265HIP_CUSERVE_MODE")) g_mode = atoi(getenv("X265HIP_CUSERVE_MODE")) ? 1 : 0;
         if (getenv("X265HIP_CUSERVE_YIELD")) g_yieldAfter = atoi(getenv("X265HIP_CUSERVE_YIELD"));
         if (getenv("X265HIP_CUSERVE_RDOQ")) g_rdoqJobs = atoi(getenv("X265HIP_CUSERVE_RDOQ")) ? 1 : 0;
+        if (getenv("X265HIP_CUSERVE_INVERSE")) g_invJobs = atoi(getenv("X265HIP_CUSERVE_INVERSE")) ? 1 : 0;
         if (getenv("X265HIP_CUSERVE_TIMEOUT_MS") && atoll(getenv("X265HIP_CUSERVE_TIMEOUT_MS")) > 0) g_timeoutNs = atoll(getenv("X265HIP_CUSERVE_TIMEOUT_MS")) * 1000000ll;
         if (getenv("X265HIP_CUSERVE_SLOTS")) g_slots = atoi(getenv("X265HIP_CUSERVE_SLOTS"));
         else
@@ -339,6 +352,7 @@ inline void abandon(Job& j)
         for (int u = 0; u < X265HIP_CUJOB_MAX_UNITS; u++) flush_add(j, u);
     j.anyPendAdd = false;
     j.active = false;
+    j.inv.active = false;                // (a pending inverse job's slot is kept: the device may still write into it)
 }
 
 // waits for a ready word of this thread's job to take the job's ticket; false: the device did not deliver (the job is abandoned)
@@ -425,6 +439,88 @@ bool make_header(Search* se, const Mode& mode, uint32_t log2CUSize, const uint32
 }
 
 // the job of one CU: header + pixels into this thread's slot, submit
+// ---- inverse jobs behind Quant::rdoQuant -------------------------------------------------------------------------------------------------------------------
+// waits for the pending inverse job of this thread's job (its own slot, its own ticket); false: the device did not deliver
+bool inv_wait(Job& j)
+{
+    Job::InvAhead& a = j.inv;
+    const uint32_t* ready = &a.units[0].readyInv;
+    if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == a.seq) return true;
+    const uint64_t t0 = __builtin_ia32_rdtsc();
+    uint64_t spins = 0;
+    int64_t waitedNs = 0, lastNs = -1;
+    while (__atomic_load_n(ready, __ATOMIC_ACQUIRE) != a.seq)
+    {
+        __builtin_ia32_pause();
+        if ((++spins & 255) == 0)
+        {
+            const int pk = x265hip_cuserve_poke(a.svc->cs, a.slot);
+            timespec ts;
+            clock_gettime(CLOCK_MONOTONIC, &ts);
+            const int64_t nowNs = (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+            if (pk == 0 && lastNs >= 0) waitedNs += nowNs - lastNs;
+            lastNs = nowNs;
+            if (pk < 0 || waitedNs > g_timeoutNs)
+            {
+                a.active = false;                        // the slot is kept: the device may still write into it
+                device_failed("an inverse job did not come back");
+                return false;
+            }
+        }
+    }
+    Counters& c = counters();
+    const uint64_t dt = __builtin_ia32_rdtsc() - t0;
+    c.waitCycles.fetch_add(dt, std::memory_order_relaxed);
+    c.waits.fetch_add(1, std::memory_order_relaxed);
+    c.siteCycles[2].fetch_add(dt, std::memory_order_relaxed);
+    c.siteWaits[2].fetch_add(1, std::memory_order_relaxed);
+    return true;
+}
+// a pending inverse job nobody collected (the tree did not ask for the unit's inverse, or asked with other levels): its slot goes back when the device is done
+void inv_drop(Job& j)
+{
+    if (!j.inv.active)
+        return;
+    if (inv_wait(j))
+        give_slot(j.inv.svc, j.inv.slot);
+    j.inv.active = false;
+    counters().invDropped.fetch_add(1, std::memory_order_relaxed);
+}
+// the levels of luma unit `u` (32x32, at (x, y) of the CU) have just been made by Quant::rdoQuant: its inverse half leaves as a job of its own
+void inv_submit(Job& j, int u, int x, int y, const coeff_t* coeff)
+{
+    if (!g_invJobs || g_dead.load(std::memory_order_relaxed))
+        return;
+    inv_drop(j);
+    Service* svc = NULL;
+    const int slot = take_slot(&svc);
+    if (slot < 0)
+        return;
+    const int N = 1 << j.log2CU, planeElems = j.hdr.chroma ? N * N + N * N / 2 : N * N;
+    // the unit's source block, its prediction (out of this thread's copy of what the CU job was given), then its levels: one front-to-back copy into the mailbox
+    alignas(64) unsigned char staged[2 * 1024 * sizeof(pixel) + 2048];
+    pixel* dst = reinterpret_cast<pixel*>(staged);
+    pack_rows(dst, j.sent + (size_t)y * N + x, (uint32_t)N, 32);
+    pack_rows(dst, j.sent + planeElems + (size_t)y * N + x, (uint32_t)N, 32);
+    memcpy(dst, coeff, 2048);
+    x265hip_cujob hdr = j.hdr;
+    hdr.log2CUSize = 5; hdr.log2TrMax = 5; hdr.log2TrMin = 5; hdr.chroma = 0; hdr.coefMode = X265HIP_CUJOB_INVERSE; hdr.sourceDct = 0; hdr.reserved = 0;
+    *svc->mem[slot].job = hdr;
+    memcpy(svc->mem[slot].pixels, staged, sizeof(staged));
+    uint32_t seq = 0;
+    if (x265hip_cuserve_submit(svc->cs, slot, &seq))
+    {
+        give_slot(svc, slot);
+        device_failed("x265hip_cuserve_submit (inverse job)");
+        return;
+    }
+    Job::InvAhead& a = j.inv;
+    a.unit = u; a.svc = svc; a.slot = slot; a.seq = seq; a.units = svc->mem[slot].units; a.resi = svc->mem[slot].resi;
+    memcpy(a.sent, coeff, 2048);
+    a.active = true;
+    counters().invJobs.fetch_add(1, std::memory_order_relaxed);
+}
+
 bool submit(Search* se, Mode& mode, uint32_t log2CUSize, ShortYuv& resiYuv, const uint32_t depthRange[2])
 {
     const Quant& q = se->m_quant;
@@ -480,6 +576,7 @@ bool submit(Search* se, Mode& mode, uint32_t log2CUSize, ShortYuv& resiYuv, cons
     j.anyPendAdd = false;
     j.treeMine = false;
     j.inTree = true;
+    inv_drop(j);
     j.log2CU = log2CUSize; j.sHi = sHi; j.sLo = sLo; j.slot = slot; j.svc = svc;
     j.job = mem.job; j.units = mem.units; j.levels = mem.levels; j.resiOut = mem.resi;
     j.active = true;
@@ -492,6 +589,7 @@ bool submit(Search* se, Mode& mode, uint32_t log2CUSize, ShortYuv& resiYuv, cons
 void end_job()
 {
     Job& j = t_job;
+    inv_drop(j);
     bool done = j.active;
     if (done && !j.treeMine)
         flush_sub(j);                  // the tree this job was made for never ran: whoever runs instead reads the residual
@@ -1139,10 +1237,21 @@ uint32_t Quant::transformNxN(const CUData& cu, const pixel* fenc, uint32_t fencS
                     const uint32_t numSigV = (this->*rdoQuant_func[log2TrSize - 2])(cu, coeff, ttype, absPartIdx, usePsy);
                     if (ns != numSigV || memcmp(want, coeff, sizeof(coeff_t) * n2)) { fprintf(stderr, "x265hip: cuserve: VERIFY FAILED rdoQuant is not a function of its inputs?\n"); abort(); }
                     counters().fwd.fetch_add(1, std::memory_order_relaxed);
+                    if (numSigV && ttype == TEXT_LUMA && log2TrSize == 5)
+                    {
+                        const ptrdiff_t dI = residual - j.resi[0];
+                        inv_submit(j, u, (int)(dI % resiStride), (int)(dI / resiStride), coeff);
+                    }
                     return numSigV;
                 }
                 const uint32_t numSigQ = (this->*rdoQuant_func[log2TrSize - 2])(cu, coeff, ttype, absPartIdx, usePsy);
                 counters().fwd.fetch_add(1, std::memory_order_relaxed);
+                // the levels exist now; the tree codes their bits (search.cpp:3243-3262) and then asks for the unit's inverse: that half leaves here
+                if (numSigQ && ttype == TEXT_LUMA && log2TrSize == 5)
+                {
+                    const ptrdiff_t dI = residual - j.resi[0];
+                    inv_submit(j, u, (int)(dI % resiStride), (int)(dI / resiStride), coeff);
+                }
                 if (g_time)
                 {
                     g_cycles[log2TrSize - 2][0].fetch_add(__builtin_ia32_rdtsc() - t0, std::memory_order_relaxed);
@@ -1194,6 +1303,42 @@ void Quant::invtransformNxN(const CUData& cu, int16_t* residual, uint32_t resiSt
                             bool useTransformSkip, uint32_t numSig)
 {
     Job& j = t_job;
+    if (j.active && j.inTree && j.quant == this && j.inv.active)
+    {
+        // coefficient mode: the inverse job submitted behind rdoQuant — served only if these ARE the levels it was given (equal levels have equal inverses)
+        Job::InvAhead& a = j.inv;
+        if (!useTransformSkip && !bIntra && ttype == TEXT_LUMA && log2TrSize == 5 && !memcmp(coeff, a.sent, 2048) && inv_wait(j))
+        {
+            const uint64_t t0 = g_time ? __builtin_ia32_rdtsc() : 0;
+            for (int y = 0; y < 32; y++)
+                memcpy(residual + (size_t)y * resiStride, a.resi + y * 32, sizeof(int16_t) * 32);
+            if (g_verify)
+            {
+                int16_t want[1024];
+                refInvtransformNxN(this, cu, want, 32, coeff, log2TrSize, ttype, bIntra, useTransformSkip, numSig);
+                if (memcmp(want, a.resi, sizeof(want)) || a.units[0].numSig != numSig)
+                {
+                    fprintf(stderr, "x265hip: cuserve: VERIFY FAILED invtransformNxN (inverse job) 32x32 numSig %u (device counted %u)\n", numSig, a.units[0].numSig);
+                    abort();
+                }
+            }
+            // the unit's measurements behind the inverse (sse_pp and psy energy of the reconstruction) go where the answering slots look for them
+            x265hip_cujob_unit& un = const_cast<x265hip_cujob_unit&>(j.units[a.unit]);
+            un.codedDist = a.units[0].codedDist;
+            un.codedEnergy = a.units[0].codedEnergy;
+            j.invServed[a.unit] = 1;
+            give_slot(a.svc, a.slot);
+            a.active = false;
+            counters().inv.fetch_add(1, std::memory_order_relaxed);
+            if (g_time)
+            {
+                g_cycles[4 + log2TrSize - 2][0].fetch_add(__builtin_ia32_rdtsc() - t0, std::memory_order_relaxed);
+                g_calls[4 + log2TrSize - 2][0].fetch_add(1, std::memory_order_relaxed);
+            }
+            return;
+        }
+        if (a.active) inv_drop(j);
+    }
     if (j.active && j.inTree && j.quant == this && !useTransformSkip && !bIntra && !j.hdr.coefMode)
     {
         // which unit?  the one of this size and plane whose levels these are: equal levels have equal inverse transforms, so the comparison — not
