@@ -2,7 +2,7 @@
 """bench.py — the contract bench (BASELINE.json metric: encode fps, 1080p preset medium, --me hex).
 
 `value` is REAL encode fps: the reference encoder's own objects with the binding's translation units (x265_amd/host/*.cpp) and libx265hip.so behind them —
-oracle/_ref/x265_hip_8bit — encoding a synthetic 1920x1080 clip with `--preset medium --me hex` (INTEGRATION.md says what the GPU serves).  One "step" = CHUNK = 12
+integration/_build/x265_hip_8bit — encoding a synthetic 1920x1080 clip with `--preset medium --me hex` (INTEGRATION.md says what the GPU serves).  One "step" = CHUNK = 12
 frames of the clip; K steps are encoded in one run of ONE encoder, bracketed by barrier + synchronize, wall clock of this process (the encoder's own "encoded N
 frames in Xs" figure is reported beside it as `cli_fps`).  At N > 1 the job is the same and the encoder is still one: its device work is spread over the N GPUs
 (X265HIP_DEVICES; rank 0 runs it, the other ranks wait at the fences) — strong scaling; the chunk form (N encoders, one per GPU) and BASELINE
@@ -539,7 +539,7 @@ def parse_served(lines):
 
 def encode_bench(args, rank, local_rank, world, fence, allmax):
     """Real encode fps of ONE encoder on ONE clip: the K * CHUNK-frame segment of make_clip(seed 4321), 1920x1080, --preset medium --me hex.
-    N = 1: oracle/_ref/x265_hip_8bit on GPU 0.  N > 1: the SAME job, one encoder whose device work is spread over the N GPUs of the node (X265HIP_DEVICES=0..N-1:
+    N = 1: integration/_build/x265_hip_8bit on GPU 0.  N > 1: the SAME job, one encoder whose device work is spread over the N GPUs of the node (X265HIP_DEVICES=0..N-1:
     reference-picture mirrors and source pictures take the GPUs in turn, SAD surfaces are built where the source picture lives from replicas of the reference
     pictures fed band by band device to device — x265's frame threads <-> GPUs, the reconstructed-reference exchange of BASELINE's north_star inside libx265hip.so),
     run by rank 0 while the other ranks hold their GPUs and wait at the fences: strong scaling, total work fixed.  Timed: wall clock between two fences around the
@@ -549,9 +549,9 @@ def encode_bench(args, rank, local_rank, world, fence, allmax):
     import hashlib
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import encode_fps as ef
-    ref, hip = os.path.join(ef.REF, "x265_8bit"), os.path.join(ef.REF, "x265_hip_8bit")
+    ref, hip = os.path.join(ef.REF, "x265_8bit"), os.path.join(ef.INTEG, "x265_hip_8bit")
     if not (os.path.exists(ref) and os.path.exists(hip)):
-        raise SystemExit("bench.py: oracle/_ref/x265_8bit and x265_hip_8bit are missing — build them where /root/reference exists "
+        raise SystemExit("bench.py: oracle/_ref/x265_8bit and integration/_build/x265_hip_8bit are missing — build them where /root/reference exists "
                          "(python -c 'import __graft_entry__ as g; g.build()'); they travel to the GPU box with the tree")
     from x265_amd.synth import make_clip
     frames, wframes = args.steps * CHUNK, max(args.warmup, 0) * CHUNK
@@ -981,7 +981,7 @@ def main():
             "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "x265 --preset medium --me hex, 1920x1080 8-bit 4:2:0 (BASELINE configs[1]); ONE synthetic clip = the %d-frame segment of x265_amd/synth.make_clip "
                                    "(96x96 tiles with their own velocities + noise, seed 4321), encoded by ONE encoder (one step = %d frames): the reference encoder's objects + "
-                                   "x265_amd/host/*.cpp + libx265hip.so (oracle/_ref/x265_hip_8bit)%s: lookahead frame-cost "
+                                   "x265_amd/host/*.cpp + libx265hip.so (integration/_build/x265_hip_8bit)%s: lookahead frame-cost "
                                    "estimates batched on the GPU, the residual quad-trees of CUs >= 32x32 (MFMA dct / quant / sign hiding / dequant / idct) as mailbox jobs to a resident GPU "
                                    "server, SAO statistics and the 35-mode intra scans of inter slices as jobs of the same server, integer-pel SADs and sub-pel SATDs of the motion search "
                                    "looked up in GPU-built SAD surfaces, luma sub-pel filter slots served from GPU-built fractional planes of each reference picture, psy-cost source halves "

@@ -4,7 +4,7 @@ rate control, CTU / TU sizes, slices, WPP, tunes ...) and must produce the same 
 they cover and for running in about a second each; the whole sweep is clean (2 of 200 are not test cases: one the reference rejects, one where
 the reference's own output moves when a 2 ms sleep is added to FrameFilter::processPostRow with every seam off — the fuzzer detects both).
 
-CPU tier: oracle/_ref/x265_emul_8bit (the C ABI emulated by the oracle — test infrastructure).  GPU tier: oracle/_ref/x265_hip_8bit."""
+CPU tier: oracle/_ref/x265_emul_8bit (the C ABI emulated by the oracle — test infrastructure).  GPU tier: integration/_build/x265_hip_8bit."""
 import os
 import sys
 
@@ -20,9 +20,11 @@ GPU_SEEDS = [19, 29, 40, 45, 59, 61, 63, 64, 70, 74, 82, 84, 86, 95, 109, 130, 1
 
 
 def _need(name):
-    p = os.path.join(REF, name)
+    # the product's integration builds (reference objects + the binding + libx265hip.so) live in integration/_build, the reference alone and the
+    # emulated-ABI test binaries in oracle/_ref
+    p = os.path.join(ROOT, "integration", "_build", name) if "_hip" in name else os.path.join(REF, name)
     if not os.path.exists(p):
-        pytest.skip("%s not built (needs /root/reference at build time: make -C oracle ref emul hip)" % name)
+        pytest.skip("%s not built (needs /root/reference at build time: make -C oracle ref emul; make -C integration hip)" % name)
     return p
 
 

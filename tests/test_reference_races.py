@@ -18,7 +18,9 @@ POOL_WORKERS = 4          # its `pools 4`: numTLD (frameencoder.cpp:294-298)
 
 
 def _need(name):
-    p = os.path.join(REF, name)
+    # the product's integration builds (reference objects + the binding + libx265hip.so) live in integration/_build, the reference alone and the
+    # emulated-ABI test binaries in oracle/_ref
+    p = os.path.join(ROOT, "integration", "_build", name) if "_hip" in name else os.path.join(REF, name)
     if not os.path.exists(p):
         pytest.skip("%s not built (needs /root/reference at build time: make -C oracle emul)" % name)
     return p

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Interleaved A/B runs of the bound encoder (oracle/_ref/x265_hip_8bit) on the bench clip: every configuration (a set of X265HIP_* environment
+"""Interleaved A/B runs of the bound encoder (integration/_build/x265_hip_8bit) on the bench clip: every configuration (a set of X265HIP_* environment
 variables) is run once per round, rounds alternate, so that drift of the box hits all configurations alike.  Prints per configuration the mean /
 median / best fps (the CLI's own fps line), user CPU seconds, and whether every bitstream was byte-identical to the unmodified reference's.
     python tools/ab_encode.py --rounds 5 --frames 120 base: sad0:X265HIP_SADPLANES=0 l12:X265HIP_SADPLANES_LEVELS=12
@@ -17,6 +17,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 REF = os.path.join(ROOT, "oracle", "_ref")
+INTEG = os.path.join(ROOT, "integration", "_build")
 
 
 def run(exe, args, out, env):
@@ -66,7 +67,7 @@ def main():
             elif name.startswith("VEC"):
                 res[name].append(run(os.path.join(REF, "x265_vec_8bit"), args + ["--asm", "SSE4.1"], "/tmp/ab_%s.hevc" % name, e))
             else:
-                res[name].append(run(os.path.join(REF, "x265_hip_%dbit" % a.bits), args, "/tmp/ab_%s.hevc" % name, e))
+                res[name].append(run(os.path.join(INTEG, "x265_hip_%dbit" % a.bits), args, "/tmp/ab_%s.hevc" % name, e))
     summary = {"clip": "%s %d frames preset %s %s" % (a.res, a.frames, a.preset, a.extra), "reference": {"fps": ref["fps"], "user": round(ref["user"], 1)}, "configs": {}}
     print("reference: %.2f fps, user %.1f s" % (ref["fps"], ref["user"]))
     for name, env in cfgs:

@@ -6,7 +6,7 @@
 #   *_stats / _fetch / _write / _sq   the device-resident frame pass (bench.py's `frame_pass` block): python tools/framepass_profile_cmd.py
 #   *_lookahead                        the lookahead cost pass, 64 pairs per launch
 #   *_lastats / _lafetch / _lawrite / _lasq   bench.py's own lookahead_p_kernel probe (8 pairs per launch): python bench.py --lookahead-probe-only
-#   *_encode                           the real encode (oracle/_ref/x265_hip_8bit, 60 frames): which kernels the encoder's GPU work consists of
+#   *_encode                           the real encode (integration/_build/x265_hip_8bit, 60 frames): which kernels the encoder's GPU work consists of
 #   calib_fetch / calib_write          known-byte-count kernels (tools/pmc_calibrate.py) for the byte counters' correction factors
 set -u
 tag=${1:-prof}
@@ -36,7 +36,7 @@ python -c "
 import sys; sys.path.insert(0, '$root')
 from x265_amd.synth import make_clip
 make_clip('/tmp/prof_clip.yuv', 1920, 1080, 60, seed=4321)"
-X265HIP_VERBOSE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_encode -o e -- $root/oracle/_ref/x265_hip_8bit --input /tmp/prof_clip.yuv \
+X265HIP_VERBOSE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_encode -o e -- $root/integration/_build/x265_hip_8bit --input /tmp/prof_clip.yuv \
     --input-res 1920x1080 --fps 30 --preset medium --me hex --frames 60 -o /dev/null > $out/${tag}_encode.log 2>&1
 cd $root
 ls $out/${tag}_* | head -40

@@ -6,7 +6,7 @@
 # sha256 of the kernel sources, which bench.py compares with its own tree before it quotes a profile).
 #   *_ss*     the search-window kernel on whole pictures: python tools/sadsurf_bench.py --modes frame
 #   *_la*     lookahead_p_kernel at the encode's launch size: python bench.py --lookahead-probe-only --probe-pairs 35
-#   *_encode  the real encode (oracle/_ref/x265_hip_8bit, 120 frames): which kernels the encoder's GPU work consists of
+#   *_encode  the real encode (integration/_build/x265_hip_8bit, 120 frames): which kernels the encoder's GPU work consists of
 #   calib_*   known-byte-count kernels (tools/pmc_calibrate.py) for the byte counters' correction factors
 set -u
 tag=${1:-prof}
@@ -32,7 +32,7 @@ python -c "
 import sys; sys.path.insert(0, '$root')
 from x265_amd.synth import make_clip
 make_clip('/tmp/prof_clip.yuv', 1920, 1080, 120, seed=4321)"
-X265HIP=require X265HIP_VERBOSE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_encode -o e -- $root/oracle/_ref/x265_hip_8bit --input /tmp/prof_clip.yuv \
+X265HIP=require X265HIP_VERBOSE=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_encode -o e -- $root/integration/_build/x265_hip_8bit --input /tmp/prof_clip.yuv \
     --input-res 1920x1080 --fps 30 --preset medium --me hex --frames 120 -o /dev/null > $out/${tag}_encode.log 2>&1
 find $out/${tag}_encode -name "*kernel_trace.csv" -size +30M -delete
 # CU jobs with one launch each (tools/micro/cuserve_rt mode 1: 1 / 4 / 16 submitting threads, 32x32 and 64x64 CUs): the per-job kernel duration as rocprofv3

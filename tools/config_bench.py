@@ -43,7 +43,7 @@ def encode_line(which, rounds, frames, threads):
     if not os.path.exists(clip):
         make_clip(clip, w, h, frames, seed=4321, depth=c["input_depth"])
     args = ["--input", clip, "--input-res", c["res"], "--input-depth", str(c["input_depth"]), "--fps", "30", "--frames", str(frames), "--preset", c["preset"], "--hash", "1"] + c["extra"] + threads
-    hip, ref = os.path.join(ab.REF, "x265_hip_%dbit" % c["bits"]), os.path.join(ab.REF, "x265_%dbit" % c["bits"])
+    hip, ref = os.path.join(ab.INTEG, "x265_hip_%dbit" % c["bits"]), os.path.join(ab.REF, "x265_%dbit" % c["bits"])
     runs = {"hip": [], "ref": []}
     for r in range(rounds):
         for k in (("hip", "ref") if r % 2 == 0 else ("ref", "hip")):

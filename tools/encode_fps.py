@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE.json's metric as the reference reports it: the CLI's own "encoded N frames in Xs (Y fps)" line, for
   * oracle/_ref/x265_8bit      the unmodified reference encoder ([noasm] C primitives; no nasm in the image), and
-  * oracle/_ref/x265_hip_8bit  the same objects + x265_amd/host/*.cpp + libx265hip.so (the lookahead seam on the GPU),
+  * integration/_build/x265_hip_8bit  the same objects + x265_amd/host/*.cpp + libx265hip.so (the lookahead seam on the GPU),
 on the same synthetic 1080p clip (x265_amd/synth.make_clip, seed 4321), same arguments, all host cores; the two bitstreams must be
 byte-identical.  Used by bench.py (`encode_fps` / `reference_encoder` keys) and runnable on its own:
     python tools/encode_fps.py --frames 60 [--preset medium] [--res 1920x1080] [--extra "--me hex"]"""
@@ -15,7 +15,8 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-REF = os.path.join(ROOT, "oracle", "_ref")
+REF = os.path.join(ROOT, "oracle", "_ref")                 # the reference alone (CPU baseline) and the emulated-ABI test binaries
+INTEG = os.path.join(ROOT, "integration", "_build")     # the product: reference objects + x265_amd/host/*.cpp + libx265hip.so
 
 
 def _run(exe, args, out, env=None, timeout=1200):
@@ -32,9 +33,9 @@ def _run(exe, args, out, env=None, timeout=1200):
 
 def measure(frames=60, width=1920, height=1080, bits=8, preset="medium", extra=("--me", "hex"), seed=4321, keep=False, clip=None, repeat=1, input_depth=8):
     """input_depth 10: the clip holds 16-bit little-endian samples with 10 significant bits (PicYuv::copyFromPicture takes its 16-bit path; Main10 / Main12 builds)."""
-    ref, hip = os.path.join(REF, "x265_%dbit" % bits), os.path.join(REF, "x265_hip_%dbit" % bits)
+    ref, hip = os.path.join(REF, "x265_%dbit" % bits), os.path.join(INTEG, "x265_hip_%dbit" % bits)
     if not (os.path.exists(ref) and os.path.exists(hip)):
-        return {"error": "oracle/_ref/x265_%dbit / x265_hip_%dbit not built (make -C oracle ref hip where /root/reference exists)" % (bits, bits)}
+        return {"error": "oracle/_ref/x265_%dbit / integration/_build/x265_hip_%dbit not built (make -C oracle ref; make -C integration hip where /root/reference exists)" % (bits, bits)}
     from x265_amd.synth import make_clip
     path = clip or "/tmp/x265hip_clip_%dx%d_%d_%d_d%d.yuv" % (width, height, frames, seed, input_depth)
     if not os.path.exists(path):

@@ -42,9 +42,9 @@ while [ $# -gt 0 ]; do
       timeout 1500 python tools/config_bench.py --encode configs2 --rounds ${CFG_ROUNDS:-5} --threads "$TH" 2> $OUT/configs2.err | tail -1 > $OUT/configs2_line.json; cut -c1-400 $OUT/configs2_line.json
       timeout 1500 python tools/config_bench.py --encode configs3 --rounds ${CFG_ROUNDS:-5} --threads "$TH" 2> $OUT/configs3.err | tail -1 > $OUT/configs3_line.json; cut -c1-400 $OUT/configs3_line.json
       if [ "${CFG_AB:-1}" = 1 ]; then
-        OFF="X265HIP_CUSERVE_RDOQ=0"
-        timeout 1500 python tools/ab_encode.py --rounds ${CFG_ROUNDS:-5} --frames 24 --res 3840x2160 --preset slow --extra "--me star --merange 57 $TH" base: nocoef:$OFF --out $OUT/configs2.json 2>&1 | tee $OUT/configs2_4k_slow_star_ab.txt | tail -6
-        timeout 1500 python tools/ab_encode.py --rounds ${CFG_ROUNDS:-5} --frames 8 --res 3840x2160 --preset slower --extra "--rd 6 $TH" --bits 10 base: nocoef:$OFF --out $OUT/configs3.json 2>&1 | tee $OUT/configs3_4k_main10_slower_ab.txt | tail -6
+        OFF="X265HIP_CUSERVE_RDOQ=0"; NOINV="X265HIP_CUSERVE_INVERSE=0"
+        timeout 2400 python tools/ab_encode.py --rounds ${CFG_ROUNDS:-5} --frames 24 --res 3840x2160 --preset slow --extra "--me star --merange 57 $TH" base: noinv:$NOINV nocoef:$OFF --out $OUT/configs2.json 2>&1 | tee $OUT/configs2_4k_slow_star_ab.txt | tail -6
+        timeout 2400 python tools/ab_encode.py --rounds ${CFG_ROUNDS:-5} --frames 8 --res 3840x2160 --preset slower --extra "--rd 6 $TH" --bits 10 base: noinv:$NOINV nocoef:$OFF --out $OUT/configs3.json 2>&1 | tee $OUT/configs3_4k_main10_slower_ab.txt | tail -6
       fi ;;
     ab)
       frames=$1; shift; cfgs=(); while [ $# -gt 0 ] && [[ "$1" == *:* ]]; do cfgs+=("$1"); shift; done
@@ -55,7 +55,7 @@ while [ $# -gt 0 ]; do
     stats)
       clip /tmp/bench120.yuv 120
       HERE=$PWD
-      (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $HERE/$OUT/prof -o p -- $HERE/oracle/_ref/x265_hip_8bit --input /tmp/bench120.yuv --input-res 1920x1080 --fps 30 --frames 120 --preset medium --me hex -o /tmp/s.hevc > $HERE/$OUT/stats_run.log 2>&1)
+      (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $HERE/$OUT/prof -o p -- $HERE/integration/_build/x265_hip_8bit --input /tmp/bench120.yuv --input-res 1920x1080 --fps 30 --frames 120 --preset medium --me hex -o /tmp/s.hevc > $HERE/$OUT/stats_run.log 2>&1)
       find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -r head -12 | cut -c1-180 ;;
     stress)
       n=$1; shift
@@ -67,14 +67,14 @@ while [ $# -gt 0 ]; do
         envs=(X265HIP=require)
         [ $((i % 2)) = 1 ] && envs+=(LD_PRELOAD=$R/allocshim.so ALLOCSHIM_SIZE=$((8 + 4 * elem)) ALLOCSHIM_ELEM=$elem ALLOCSHIM_OFFSET=$off ALLOCSHIM_WORD=2)
         [ $((i % 3)) = 0 ] && envs+=(X265HIP_REFPLANES=0)
-        env "${envs[@]}" TWO_ENCODERS_WATCHDOG=120 timeout 200 $R/two_encoders_hip8 $D/g par > $D/run.log 2>&1 || { echo "run $i: exit $?"; tail -5 $D/run.log; bad=$((bad + 1)); continue; }
+        env "${envs[@]}" TWO_ENCODERS_WATCHDOG=120 timeout 200 integration/_build/two_encoders_hip8 $D/g par > $D/run.log 2>&1 || { echo "run $i: exit $?"; tail -5 $D/run.log; bad=$((bad + 1)); continue; }
         for k in 0 1 2 3 4; do cmp -s $D/ref_$k.hevc $D/g_$k.hevc || { echo "run $i: session $k differs"; bad=$((bad + 1)); }; done
       done
       echo "concurrent encoders on the MI355X: $n runs (5 sessions each, two then three alive at a time), $bad mismatches or failures, $(( $(date +%s) - t0 )) s" | tee $OUT/concurrent_stress.txt ;;
     framestats)
       clip /tmp/bench120.yuv 120
       for b in hip ref; do
-        exe=oracle/_ref/x265_hip_8bit; [ $b = ref ] && exe=oracle/_ref/x265_8bit
+        exe=integration/_build/x265_hip_8bit; [ $b = ref ] && exe=oracle/_ref/x265_8bit
         X265HIP=require $exe --input /tmp/bench120.yuv --input-res 1920x1080 --fps 30 --frames 120 --preset medium --me hex --csv $OUT/framestats_$b.csv --csv-log-level 2 -o /tmp/f.hevc 2>&1 | grep -E "^encoded" | tee $OUT/framestats_$b.log
       done
       python - $OUT <<'PY' | tee $OUT/frame_clocks.txt
@@ -100,7 +100,7 @@ PY
     callers)
       pat=$1; shift
       clip /tmp/bench240.yuv 240
-      X265HIP_CPUSAMPLE_STACK=1 X265HIP_CPUSAMPLE_OUT=/tmp/cs.bin LD_PRELOAD=tools/prof/libcpusample.so oracle/_ref/x265_hip_8bit --input /tmp/bench240.yuv --input-res 1920x1080 --fps 30 --frames 240 --preset medium --me hex --pools 16 -F 5 -o /tmp/p.hevc 2>&1 | grep -E "^encoded" > $OUT/callers_run.log
+      X265HIP_CPUSAMPLE_STACK=1 X265HIP_CPUSAMPLE_OUT=/tmp/cs.bin LD_PRELOAD=tools/prof/libcpusample.so integration/_build/x265_hip_8bit --input /tmp/bench240.yuv --input-res 1920x1080 --fps 30 --frames 240 --preset medium --me hex --pools 16 -F 5 -o /tmp/p.hevc 2>&1 | grep -E "^encoded" > $OUT/callers_run.log
       python tools/prof/callers.py /tmp/cs.bin "$pat" 25 > $OUT/callers.txt 2>&1; head -60 $OUT/callers.txt | cut -c1-250 ;;
     pmc)
       HERE=$PWD
@@ -116,7 +116,7 @@ PY
     cpuprofile)
       clip /tmp/bench240.yuv 240
       for k in 1 2 3 4 5 6; do
-        X265HIP_CPUSAMPLE_OUT=/tmp/s$k.bin LD_PRELOAD=tools/prof/libcpusample.so oracle/_ref/x265_hip_8bit --input /tmp/bench240.yuv --input-res 1920x1080 --fps 30 --frames 240 --preset medium --me hex -o /tmp/p.hevc 2>&1 | grep -E "encoded|x265hip" > $OUT/cpuprofile_run$k.log
+        X265HIP_CPUSAMPLE_OUT=/tmp/s$k.bin LD_PRELOAD=tools/prof/libcpusample.so integration/_build/x265_hip_8bit --input /tmp/bench240.yuv --input-res 1920x1080 --fps 30 --frames 240 --preset medium --me hex -o /tmp/p.hevc 2>&1 | grep -E "encoded|x265hip" > $OUT/cpuprofile_run$k.log
         python tools/prof/resolve.py /tmp/s$k.bin 200 > $OUT/cpu_profile_run$k.txt 2>&1
       done
       python tools/prof/merge.py $OUT/cpu_profile_run?.txt > $OUT/cpu_profile_bound_encoder.txt

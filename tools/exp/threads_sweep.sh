@@ -13,7 +13,7 @@ PY
 D=/tmp/sweep_$$; mkdir -p $D
 for k in $(seq 1 $RUNS); do for cell in $CELLS; do P=${cell%%:*}; F=${cell##*:}
   for b in hip ref; do
-    exe=oracle/_ref/x265_hip_8bit; [ $b = ref ] && exe=oracle/_ref/x265_8bit
+    exe=integration/_build/x265_hip_8bit; [ $b = ref ] && exe=oracle/_ref/x265_8bit
     f=$(X265HIP=require $exe --input /tmp/sweep120.yuv --input-res 1920x1080 --fps 30 --frames 120 --preset medium --me hex --pools $P --frame-threads $F -o $D/$b.hevc 2>&1 | grep -E "^encoded" | sed -E 's/.*\(([0-9.]+) fps\).*/\1/')
     echo "${f:-0} $(md5sum < $D/$b.hevc | cut -c1-8)" >> $D/${b}_${P}_${F}.txt
   done

@@ -4,7 +4,7 @@ options that change what the four seams see, encode th
 the bound one, and compare the bitstreams byte for byte.
 
   python tools/fuzz_encoder.py --seeds 0-39                # CPU tier: oracle/_ref/x265_emul_8bit (the ABI emulated by the oracle, test infra)
-  python tools/fuzz_encoder.py --seeds 0-39 --gpu          # GPU box:  oracle/_ref/x265_hip_8bit  (libx265hip.so)
+  python tools/fuzz_encoder.py --seeds 0-39 --gpu          # GPU box:  integration/_build/x265_hip_8bit  (libx265hip.so)
 
 The draw is a pure function of the seed, so a failing seed is a reproducible test case (tests/test_encoder_fuzz.py pins a list of them)."""
 import argparse
@@ -192,7 +192,7 @@ if __name__ == "__main__":
     ap.add_argument("--summary", default=None, help="compact summary (counts, non-cases, per-seed command and size) for profiles/")
     ap.add_argument("--bits", type=int, default=8, help="internal bit depth of the encoder build (8 or 10; the clip stays 8-bit input)")
     a = ap.parse_args()
-    bound = os.path.join(REF, ("x265_hip_%dbit" if a.gpu else "x265_emul_%dbit") % a.bits)
+    bound = os.path.join(os.path.dirname(os.path.dirname(REF)), "integration", "_build", "x265_hip_%dbit" % a.bits) if a.gpu else os.path.join(REF, "x265_emul_%dbit" % a.bits)
     ref = os.path.join(REF, "x265_%dbit" % a.bits)
     results = []
     with tempfile.TemporaryDirectory() as d:
