@@ -730,9 +730,8 @@ def test_bound_encoder_inverse_jobs_behind_rdoq_stay_byte_identical(tmp_path, ex
     want, got = str(tmp_path / "ref.hevc"), str(tmp_path / "emul.hevc")
     assert subprocess.run([ref] + args + ["-o", want], capture_output=True, timeout=900).returncode == 0
     for off in (False, True):
-        env = dict(os.environ, X265HIP="require", X265HIP_VERBOSE="1", X265HIP_VERIFY="1")
-        if off:
-            env["X265HIP_CUSERVE_INVERSE"] = "0"
+        # (the default is on for 8-bit builds only: profiles/r06_v1_configs3_4k_main10_slower_ab.txt; here both settings are explicit)
+        env = dict(os.environ, X265HIP="require", X265HIP_VERBOSE="1", X265HIP_VERIFY="1", X265HIP_CUSERVE_INVERSE="0" if off else "1")
         r = subprocess.run([emul] + args + ["-o", got], capture_output=True, text=True, timeout=900, env=env)
         assert r.returncode == 0, r.stderr[-800:]
         assert open(got, "rb").read() == open(want, "rb").read()

@@ -100,7 +100,7 @@ PY
     callers)
       pat=$1; shift
       clip /tmp/bench240.yuv 240
-      X265HIP_CPUSAMPLE_STACK=1 X265HIP_CPUSAMPLE_OUT=/tmp/cs.bin LD_PRELOAD=tools/prof/libcpusample.so integration/_build/x265_hip_8bit --input /tmp/bench240.yuv --input-res 1920x1080 --fps 30 --frames 240 --preset medium --me hex --pools 16 -F 5 -o /tmp/p.hevc 2>&1 | grep -E "^encoded" > $OUT/callers_run.log
+      X265HIP_CPUSAMPLE_STACK=1 X265HIP_CPUSAMPLE_OUT=/tmp/cs.bin LD_PRELOAD=tools/prof/libcpusample.so integration/_build/x265_hip_8bit --input /tmp/bench240.yuv --input-res 1920x1080 --fps 30 --frames 240 --preset medium --me hex --pools 24 -F 6 -o /tmp/p.hevc 2>&1 | grep -E "^encoded" > $OUT/callers_run.log
       python tools/prof/callers.py /tmp/cs.bin "$pat" 25 > $OUT/callers.txt 2>&1; head -60 $OUT/callers.txt | cut -c1-250 ;;
     pmc)
       HERE=$PWD
@@ -115,11 +115,11 @@ PY
       python tools/prof/pmc_launches.py $OUT/pmc cu5:3200:6240 cu6:12416:24960 sao:12675:1920 srv5:3200:6240:3100 | tee $OUT/cuserve_pmc_per_job.txt ;;
     cpuprofile)
       clip /tmp/bench240.yuv 240
-      for k in 1 2 3 4 5 6; do
-        X265HIP_CPUSAMPLE_OUT=/tmp/s$k.bin LD_PRELOAD=tools/prof/libcpusample.so integration/_build/x265_hip_8bit --input /tmp/bench240.yuv --input-res 1920x1080 --fps 30 --frames 240 --preset medium --me hex -o /tmp/p.hevc 2>&1 | grep -E "encoded|x265hip" > $OUT/cpuprofile_run$k.log
+      for k in 1 2 3 4 5 6 7 8 9 10; do
+        X265HIP_CPUSAMPLE_OUT=/tmp/s$k.bin LD_PRELOAD=tools/prof/libcpusample.so integration/_build/x265_hip_8bit --input /tmp/bench240.yuv --input-res 1920x1080 --fps 30 --frames 240 --preset medium --me hex --pools 24 -F 6 -o /tmp/p.hevc 2>&1 | grep -E "encoded|x265hip" > $OUT/cpuprofile_run$k.log
         python tools/prof/resolve.py /tmp/s$k.bin 200 > $OUT/cpu_profile_run$k.txt 2>&1
       done
-      python tools/prof/merge.py $OUT/cpu_profile_run?.txt > $OUT/cpu_profile_bound_encoder.txt
+      python tools/prof/merge.py $OUT/cpu_profile_run*.txt > $OUT/cpu_profile_bound_encoder.txt
       head -48 $OUT/cpu_profile_bound_encoder.txt ;;
     *) echo "unknown task $task"; exit 2 ;;
   esac

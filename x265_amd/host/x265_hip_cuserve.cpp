@@ -39,7 +39,11 @@ int g_mode = 0;                  // X265HIP_CUSERVE_MODE: 0 resident server (mai
 int64_t g_timeoutNs = 10000000000ll;            // X265HIP_CUSERVE_TIMEOUT_MS
 int g_yieldAfter = 0;                            // X265HIP_CUSERVE_YIELD
 std::atomic<int> g_lateJobs(0);
-int g_invJobs = 1;               // X265HIP_CUSERVE_INVERSE=0: at the RDOQ presets the inverse half of luma 32x32 units stays on the host (round 5's behaviour)
+// X265HIP_CUSERVE_INVERSE=0 / 1: at the RDOQ presets the inverse half of luma 32x32 units stays on the host / leaves as a job behind Quant::rdoQuant.  Measured on
+// the MI355X box, 6 interleaved rounds each (profiles/r06_v1_configs2_4k_slow_star_ab.txt, ..._configs3_4k_main10_slower_ab.txt): BASELINE configs[2] (8 bit)
+// 3.78 vs 3.76 fps, 91.1 vs 91.5 CPU seconds with the jobs (236 739 units served); configs[3] (Main10) 1.46 vs 1.48 fps, 78.4 vs 77.0 CPU seconds (342 252 units:
+// six kilobytes through the BAR per job instead of four, and the tree's bit count of the levels is shorter than the round trip).  On for 8-bit builds, off above
+int g_invJobs = X265_DEPTH == 8 ? 1 : 0;
 int g_rdoqJobs = 1;              // X265HIP_CUSERVE_RDOQ=0: CUs quantised by Quant::rdoQuant are not handed over (round 4's behaviour).  On: measured on the MI355X box at
                                  // BASELINE configs[2] / configs[3] (profiles/r05_v1_configs*_ab.txt): +2 % / +6 % fps, -3 % / -6 % CPU seconds
 int g_slots = 64;                // X265HIP_CUSERVE_SLOTS: jobs that can be in flight (default: twice the CPUs this process may use, 16..64)
