@@ -52,6 +52,14 @@ static int init_device(int device)
         t_dev_ready = -1;
         return check_hip(e, "hipSetDevice");
     }
+    // How the threads that wait for a stream wait (hipSetDeviceFlags): blocking — on the interrupt — by default.  HIP's own default (`auto`) spins while there are
+    // fewer contexts than CPUs, and on a host whose CPUs the encoder needs that spin is taken from the encoder: 1080p medium, 5 interleaved rounds on the MI355X
+    // box, 45.9 fps / 30.2 CPU-s blocking vs 45.1 / 30.8 auto, 45.6 yield, 45.1 spin (profiles/r06_v1_sync_ab.txt).  X265HIP_SYNC=auto | spin | yield | blocking
+    {
+        const char* how = getenv("X265HIP_SYNC");
+        const unsigned flag = !how || !strcmp(how, "blocking") ? hipDeviceScheduleBlockingSync : !strcmp(how, "spin") ? hipDeviceScheduleSpin : !strcmp(how, "yield") ? hipDeviceScheduleYield : hipDeviceScheduleAuto;
+        if (hipSetDeviceFlags(flag) != hipSuccess) (void)hipGetLastError();
+    }
     hipDeviceProp_t prop;
     e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess)
