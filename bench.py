@@ -918,6 +918,31 @@ def main():
                         "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": None,
                         "algorithmic_bytes_per_launch": int(pl["algorithmic_bytes"] / pl["launch_groups"]), "launch_ms": round(pl["ms"] / pl["launch_groups"], 5),
                         "launch_ms_note": "HIP events around each band's launch; bands are one CTU row each (launch-latency sized)"}
+        # ---- sub-pel SATD tables: the launch group with the most device time after the job server ------------------------------------------------------------------
+        # per CTU of a surface row, three block levels (16 / 32 / 64), 49 quarter-pel vectors around each block's window centre.  Per-call bytes (satd =
+        # 2 W H B per call) = 3 x 64 x 64 x 49 x 2 B per CTU = 1 204 224; what HBM has to deliver once (unique footprint): the CTU's source block + for every block
+        # of every level the (N + 6)^2 neighbourhood of its centre in each of the 16 phase planes (N + 2 would do for the 7 x 7 quarter-pel vectors; the rows are
+        # 4 bytes wider either side) + the tables written: 64 x 64 + 16 x (16 x 22 x 22 + 4 x 38 x 38 + 70 x 70) + 21 x 49 x 4 = 302 820 B per CTU
+        sp = clocks.get("sub-pel SATD tables", {})
+        sp_block = None
+        SP_CALL_BYTES_PER_CTU, SP_UNIQUE_BYTES_PER_CTU = 3 * 64 * 64 * 49 * 2, 64 * 64 + 16 * (16 * 22 * 22 + 4 * 38 * 38 + 70 * 70) + 21 * 49 * 4
+        sp_traffic, sp_tfile, sp_tnote = pmc_profile("r*_pmc_encode.txt", "subpel_satd_kernel", ss_digest)
+        if sp.get("ms") and sp.get("launch_groups"):
+            secs = sp["ms"] * 1e-3
+            ctus = sp["algorithmic_bytes"] / SP_CALL_BYTES_PER_CTU
+            ach = sp["algorithmic_bytes"] / secs / 1e9
+            uniq = ctus * SP_UNIQUE_BYTES_PER_CTU
+            sp_block = {"bound": "hbm", "kernel": "subpel_satd_kernel<u8>, live in the timed encode: %d launch groups (one launch per surface of the group) = the 7 x 7 quarter-pel "
+                                                  "SATDs around the window centre of every 16x16 / 32x32 / 64x64 block of %.0f CTUs, out of the mirrors' phase planes"
+                                                  % (sp["launch_groups"], ctus),
+                        "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
+                        "achieved_note": "SURVEY 8d per-call bytes (satd = 2 W H B per (block, vector) call): what the reference's calls would move; most of it is the "
+                                         "same phase-plane neighbourhoods read 49 times — served by L2 / MALL, see `unique_footprint`",
+                        "unique_footprint": {"bytes_per_ctu": SP_UNIQUE_BYTES_PER_CTU, "achieved": round(uniq / secs / 1e9, 2), "frac": round(uniq / secs / 1e9 / HBM_PEAK_GBPS, 5)},
+                        "traffic": sp_traffic, "traffic_source": sp_tfile,
+                        "traffic_note": (sp_tnote + "; per LAUNCH of the profile's run (one surface's rows per launch), not per launch group") if sp_traffic else sp_tnote,
+                        "algorithmic_bytes_per_launch": int(sp["algorithmic_bytes"] / sp["launch_groups"]), "launch_ms": round(sp["ms"] / sp["launch_groups"], 5),
+                        "launch_ms_note": "HIP events around each launch group on its stream (x265hip_device_time), summed over the timed encode"}
         # ---- CU residual quad-tree jobs: a host thread WAITS for each, so the path is built for round trip, not for bytes per second ------------------------------
         cu = clocks.get("CU residual quad-tree jobs", {})
         cu_block = None
@@ -945,7 +970,7 @@ def main():
             ach = cu["algorithmic_bytes"] / secs / 1e9
             cu_block = {"bound": "latency", "kernel": "cu_server_kernel, live in the timed encode (%s): %d jobs = the transform arithmetic (MFMA dct -> quant -> sign-bit hiding -> dequant -> MFMA "
                                                       "idct -> two SSEs) of the residual quad-trees of %d CUs >= %dx%d, %d forward and %d inverse units served to Quant::transformNxN / "
-                                                      "invtransformNxN; one workgroup per mailbox slot; data path: the host writes header + pixels into the slot's device-memory half through the large BAR (posted PCIe writes), "
+                                                      "invtransformNxN; a pair of workgroups per mailbox slot (luma: the four waves on one 32x32 unit at a time; chroma); data path: the host writes header + pixels into the slot's device-memory half through the large BAR (posted PCIe writes), "
                                                       "the workgroup reads them HBM -> LDS, results go LDS -> page-locked host memory (posted writes again)"
                                                       % (c["handoff"], c["jobs"], c["jobs"], c["min_cu"], c["min_cu"], c["forward_units"], c["inverse_units"]),
                         # SURVEY.md 8d's roofline for this family: fused-chain bytes of the units / the server's wall time (the timed region: the resident
@@ -954,13 +979,13 @@ def main():
                         "frac": round(cu["algorithmic_bytes"] / dt / 1e9 / HBM_PEAK_GBPS, 6), "traffic": cu_traffic, "traffic_source": cu_tfile, "traffic_note": cu_tnote,
                         "achieved_note": "fused-chain bytes (SURVEY 8d: source + prediction in, levels + reconstructed residual out) of every unit of every job / wall clock "
                                          "of the timed region; per busy workgroup-second instead of per wall second: see `busy`",
-                        "busy": {"achieved": round(ach, 3), "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 6), "note": "the same bytes / busy time of ONE workgroup (jobs run one per "
-                                 "workgroup, about one workgroup busy on average)"},
+                        "busy": {"achieved": round(ach, 3), "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 6), "note": "the same bytes / the workgroup-seconds spent on them "
+                                 "(a CU job keeps its luma and its chroma workgroup busy for different times; both count)"},
                         "peak_note": "HBM3E 8 TB/s (MI355X_MICROARCH.md).  The figure of merit of this kernel is not this fraction: the job is a dependent chain (doorbell seen -> header + pixels from HBM -> two MFMA passes -> quantise -> sign hiding "
-                                     "-> levels out -> ready word -> two MFMA passes -> reconstruction, SSE, psy energy -> ready word) run by one wave per transform unit, and its "
-                                     "figure of merit is the round trip, not bytes per second: profiles/r04_*_cuserve_rt*.txt (7.6 us from submit to the first luma unit's forward "
-                                     "half, 4.0 us of it on the device; 12.2 us per 32x32 CU job; stage by stage in *_cuserve_rt_stamps.txt), against a transport floor of 2.4-2.9 us "
-                                     "for an empty ping-pong on this box (profiles/r04_*_bar_mailbox_breakdown.txt)",
+                                     "-> levels out -> ready word -> two MFMA passes -> reconstruction, SSE, psy energy -> ready word) — the four waves of a workgroup on a 32x32 luma unit, "
+                                     "one wave per chroma tile — and its figure of merit is the round trip, not bytes per second: profiles/r06_v1_cuserve_rt_stamps.txt (7.3 us from submit "
+                                     "to the first luma unit's forward half, 3.1 us of it on the device; 9.8 us per 32x32 CU job; round 5: 8.4 / 4.3 / 11.4), against a transport floor of "
+                                     "2.4-2.9 us for an empty ping-pong on this box (profiles/r04_v1_bar_mailbox_breakdown.txt)",
                         # the server's slots also carry the SAO statistics jobs (one per CTU plane: SAO::calcSaoStatsCTU's classification of a deblocked plane against
                         # its source; bytes = the two blocks in + 2 x 5 x 32 int32 out): busy time and bytes are over both kinds
                         "sao_statistics_jobs": served.get("sao"),
@@ -974,7 +999,7 @@ def main():
         named = [(ss.get("ms", 0.0), ss_block), (la.get("ms", 0.0), la_live), (cu.get("ms", 0.0), cu_block)]
         named = [b for _, b in sorted(named, key=lambda t: -t[0]) if b]
         dominant = named[0] if named else la_probe
-        others = [b for b in (ss_block, probe_block, cu_block, la_live, la_probe, pl_block, planes_probe) if b and b is not dominant]
+        others = [b for b in (ss_block, probe_block, cu_block, sp_block, la_live, la_probe, pl_block, planes_probe) if b and b is not dominant]
         out = {
             "metric": "encode fps (1080p preset medium)", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 3),

@@ -15,6 +15,7 @@
 #     framestats           x265's own per-frame clocks (--csv-log-level 2: DecideWait, Row0Wait, Wall, Ref Wait Wall, Total CTU time, Stall, Avg WPP, Row Blocks)
 #                          of the bound encoder and of the reference on the bench clip: where a frame encoder's wall clock goes
 #     callers <regex>      who calls the functions matching <regex>: one 240-frame run under the sampler with call chains (X265HIP_CPUSAMPLE_STACK=1), tools/prof/callers.py
+#     pmc_encode           FETCH_SIZE / WRITE_SIZE per launch of the kernels launched in a 30-frame bound encode (job server off), one pass per counter
 #     cpuprofile           the bound encoder under the CPU sampler (tools/prof), 6 x 240 frames merged (> 10 k samples)
 set -u
 TAG=$1; shift
@@ -113,6 +114,17 @@ PY
       done
       # algorithmic bytes: pixels in; levels + residual + unit records out (CU jobs), 480 statistics words out (SAO)
       python tools/prof/pmc_launches.py $OUT/pmc cu5:3200:6240 cu6:12416:24960 sao:12675:1920 srv5:3200:6240:3100 | tee $OUT/cuserve_pmc_per_job.txt ;;
+    pmc_encode)
+      # HBM bytes per launch of the kernels that are LAUNCHED in the bound encode (SAD surfaces, sub-pel SATD tables, phase planes, energy planes, lookahead): two
+      # counter passes over a 30-frame encode with the resident job server off (a kernel that stays on the chip would hold up the serialised dispatches of a --pmc run)
+      clip /tmp/bench30.yuv 30
+      HERE=$PWD
+      for c in fetch:FETCH_SIZE write:WRITE_SIZE; do
+        (cd /tmp && export TMPDIR=/tmp && X265HIP=require X265HIP_CUSERVE=0 X265HIP_SAOSTATS=0 X265HIP_INTRASCAN=0 timeout 400 rocprofv3 --pmc ${c#*:} --kernel-trace --output-format csv -d $HERE/$OUT/pmc_encode/${c%%:*} -o p -- \
+           $HERE/integration/_build/x265_hip_8bit --input /tmp/bench30.yuv --input-res 1920x1080 --fps 30 --frames 30 --preset medium --me hex --pools 24 -F 6 -o /tmp/pe.hevc > $HERE/$OUT/pmc_encode_${c%%:*}.log 2>&1)
+      done
+      find $OUT/pmc_encode -name "*kernel_trace.csv" -delete
+      python tools/prof/pmc_kernels.py $OUT/pmc_encode "x265_hip_8bit, 30 frames 1080p preset medium --me hex, CU / SAO / intra jobs off" sadsurf.hip | tee $OUT/pmc_encode.txt | head -16 ;;
     cpuprofile)
       clip /tmp/bench240.yuv 240
       for k in 1 2 3 4 5 6 7 8 9 10; do

@@ -371,10 +371,16 @@ void install_intra_slots(EncoderPrimitives& p)
         return;
     install_intra_slots_for<BLOCK_16x16>(p);
     install_intra_slots_for<BLOCK_32x32>(p);
+    // 8x8 blocks (X265HIP_INTRASCAN_MIN=3): their scans only ever leave AHEAD (an 8x8 scan is less host work than a round trip), and the answering slots sit on
+    // cu[BLOCK_8x8].sa8d and its 35 predictors, which every other 8x8 caller then goes through as well
+    const char* mn = getenv("X265HIP_INTRASCAN_MIN");
+    if (mn && atoi(mn) <= 3)
+        install_intra_slots_for<BLOCK_8x8>(p);
 }
 bool intra_slots_in(const EncoderPrimitives& p, int log2n)
 {
-    return log2n == 4 ? p.cu[BLOCK_16x16].sa8d == sa8d_slot<BLOCK_16x16> : log2n == 5 ? p.cu[BLOCK_32x32].sa8d == sa8d_slot<BLOCK_32x32> : false;
+    return log2n == 3 ? p.cu[BLOCK_8x8].sa8d == sa8d_slot<BLOCK_8x8>
+         : log2n == 4 ? p.cu[BLOCK_16x16].sa8d == sa8d_slot<BLOCK_16x16> : log2n == 5 ? p.cu[BLOCK_32x32].sa8d == sa8d_slot<BLOCK_32x32> : false;
 }
 
 void Search::checkIntraInInter(Mode& intraMode, const CUGeom& cuGeom)
