@@ -922,7 +922,7 @@ def main():
         # per CTU of a surface row, three block levels (16 / 32 / 64), 49 quarter-pel vectors around each block's window centre.  Per-call bytes (satd =
         # 2 W H B per call) = 3 x 64 x 64 x 49 x 2 B per CTU = 1 204 224; what HBM has to deliver once (unique footprint): the CTU's source block + for every block
         # of every level the (N + 6)^2 neighbourhood of its centre in each of the 16 phase planes (N + 2 would do for the 7 x 7 quarter-pel vectors; the rows are
-        # 4 bytes wider either side) + the tables written: 64 x 64 + 16 x (16 x 22 x 22 + 4 x 38 x 38 + 70 x 70) + 21 x 49 x 4 = 302 820 B per CTU
+        # 4 bytes wider either side) + the tables written: 64 x 64 + 16 x (16 x 22 x 22 + 4 x 38 x 38 + 70 x 70) + 21 x 49 x 4 = 302 932 B per CTU
         sp = clocks.get("sub-pel SATD tables", {})
         sp_block = None
         SP_CALL_BYTES_PER_CTU, SP_UNIQUE_BYTES_PER_CTU = 3 * 64 * 64 * 49 * 2, 64 * 64 + 16 * (16 * 22 * 22 + 4 * 38 * 38 + 70 * 70) + 21 * 49 * 4
