@@ -89,3 +89,21 @@ def test_bench_parses_the_encoders_ledger_lines_and_matches_profiles_by_source_h
     assert val == int((17155.1 + 6588.8) * 1024) and f.endswith("r99_v1_pmc_sadsurf.txt") and "fetch_correction" in note
     val, f, note = bench.pmc_profile("r*_pmc_sadsurf.txt", "sadsurf_ctu_kernel", "0" * 16)
     assert val is None and "not quoted" in note
+
+
+def test_committed_counter_profiles_were_collected_from_this_tree():
+    """bench.py quotes `roofline.traffic` only from a committed counter profile whose `# sources` stamp is the hash of the kernel sources in the tree: the
+    newest committed profile of each kernel family must carry the current hash — a kernel edit without a re-collection turns the driver's line's traffic to null."""
+    import glob
+    import os
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for pattern, kernel, names in (("r*_pmc_sadsurf.txt", "sadsurf_ctu_kernel", ("sadsurf.hip",)),
+                                   ("r*_pmc_lookahead.txt", "lookahead_p_kernel", ("lookahead.hip", "lasession.hip")),
+                                   ("r*_pmc_encode.txt", "subpel_satd_kernel", ("sadsurf.hip",))):
+        val, f, note = bench.pmc_profile(pattern, kernel, bench.source_digest(*names))
+        assert val and val > 0, (pattern, f, note)
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*_cuserve_pmc_per_job.txt")))
+    assert files
+    stamp = [l.split()[-1] for l in open(files[-1]) if l.startswith("# sources")]
+    assert stamp and stamp[0] == bench.source_digest("cuserve.hip"), (files[-1], stamp)
