@@ -158,12 +158,22 @@ bool enabled()
 
 inline const Mirror* find(const pixel* p)
 {
+    // the picture the thread's previous call lay in, first: the candidates of one sub-pel refinement and the blocks of one PU's compensation share it
+    static __attribute__((tls_model("initial-exec"))) thread_local int t_last = 0;
+    {
+        const pixel* lo = __atomic_load_n(&g_range[t_last].lo, __ATOMIC_ACQUIRE);
+        if (lo && p >= lo && p < g_range[t_last].hi)
+            return &g_mirror[t_last];
+    }
     const int n = g_count.load(std::memory_order_acquire);
     for (int i = 0; i < n; i++)
     {
         const pixel* lo = __atomic_load_n(&g_range[i].lo, __ATOMIC_ACQUIRE);      // NULL: a retired entry (or one being set up: lo is stored last)
         if (lo && p >= lo && p < g_range[i].hi)
+        {
+            t_last = i;
             return &g_mirror[i];
+        }
     }
     return NULL;
 }
@@ -396,8 +406,12 @@ void x265hip_install_lookup_slots(EncoderPrimitives& p)
             have = true;
         }
     }
-    LOOKUP_PU(4, 4);   LOOKUP_PU(8, 8);   LOOKUP_PU(16, 16); LOOKUP_PU(32, 32); LOOKUP_PU(64, 64);
-    LOOKUP_PU(8, 4);   LOOKUP_PU(4, 8);   LOOKUP_PU(16, 8);  LOOKUP_PU(8, 16);  LOOKUP_PU(32, 16); LOOKUP_PU(16, 32);
+    // X265HIP_REFPLANES_SMALL=0: blocks of 64 samples and fewer keep the C filters (a measurement switch: is a lookup of an 8x8 block — eight cold lines of a
+    // page-locked plane — cheaper than filtering it out of the picture the search has just read?  profiles/r06_v1_refplanes_small_ab.txt: yes)
+    const bool small = !(getenv("X265HIP_REFPLANES_SMALL") && !atoi(getenv("X265HIP_REFPLANES_SMALL")));
+    if (small) { LOOKUP_PU(4, 4);   LOOKUP_PU(8, 8);   LOOKUP_PU(8, 4);   LOOKUP_PU(4, 8); }
+    LOOKUP_PU(16, 16); LOOKUP_PU(32, 32); LOOKUP_PU(64, 64);
+    LOOKUP_PU(16, 8);  LOOKUP_PU(8, 16);  LOOKUP_PU(32, 16); LOOKUP_PU(16, 32);
     LOOKUP_PU(64, 32); LOOKUP_PU(32, 64); LOOKUP_PU(16, 12); LOOKUP_PU(12, 16); LOOKUP_PU(16, 4);  LOOKUP_PU(4, 16);
     LOOKUP_PU(32, 24); LOOKUP_PU(24, 32); LOOKUP_PU(32, 8);  LOOKUP_PU(8, 32);  LOOKUP_PU(64, 48); LOOKUP_PU(48, 64);
     LOOKUP_PU(64, 16); LOOKUP_PU(16, 64);
