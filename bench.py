@@ -1009,8 +1009,8 @@ def main():
                                  "(a CU job keeps its luma and its chroma workgroup busy for different times; both count)"},
                         "peak_note": "HBM3E 8 TB/s (MI355X_MICROARCH.md).  The figure of merit of this kernel is not this fraction: the job is a dependent chain (doorbell seen -> header + pixels from HBM -> two MFMA passes -> quantise -> sign hiding "
                                      "-> levels out -> ready word -> two MFMA passes -> reconstruction, SSE, psy energy -> ready word) — the four waves of a workgroup on a 32x32 luma unit, "
-                                     "one wave per chroma tile — and its figure of merit is the round trip, not bytes per second: profiles/r06_v1_cuserve_rt_stamps.txt (7.3 us from submit "
-                                     "to the first luma unit's forward half, 3.1 us of it on the device; 9.8 us per 32x32 CU job; round 5: 8.4 / 4.3 / 11.4), against a transport floor of "
+                                     "one wave per chroma tile — and its figure of merit is the round trip, not bytes per second: profiles/r06_v1_cuserve_rt_stamps.txt (6.6 us from submit "
+                                     "to the first luma unit's forward half, 3.1 us of it on the device; 8.9 us per 32x32 CU job; round 5: 8.4 / 4.3 / 11.4), against a transport floor of "
                                      "2.4-2.9 us for an empty ping-pong on this box (profiles/r04_v1_bar_mailbox_breakdown.txt)",
                         # the server's slots also carry the SAO statistics jobs (one per CTU plane: SAO::calcSaoStatsCTU's classification of a deblocked plane against
                         # its source; bytes = the two blocks in + 2 x 5 x 32 int32 out): busy time and bytes are over both kinds

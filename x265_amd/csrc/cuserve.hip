@@ -114,6 +114,7 @@ struct TeamOperand { long b; int corr; int pad; };
 struct TeamLds
 {
     TeamOperand op[2][256];                      // [forward, inverse][thread]: built once per kernel
+    TeamOperand op16[2][64];                     // the same for a 16x16 unit on one wave (solo_chain16)
     uint32_t part[16];                           // per 16-lane row of the team: partial sums (significant levels, squared differences)
     uint32_t part2[16];
     int energy[2][16];                           // psy energies of the unit's sixteen 8x8 blocks: [source, reconstruction]
@@ -873,6 +874,297 @@ __device__ __forceinline__ void team_chain32(TileLds& t, TeamLds& tm, const P* s
     team_inverse32<P>(t, tm, src, pw, ux, uy, qp, fv, pv, un, resi, seq, t0, stamps, stamp);
 }
 
+// ---- a 16x16 unit on ONE wave, four coefficients per lane (the chroma units of a 32x32 CU: one unit per plane) ----------------------------------------------
+// tile_chain<P, 16> gives a wave a 32x32 MFMA tile = four 16x16 units; a 32x32 CU has ONE per chroma plane, and the wave then runs the whole tile's instruction
+// stream for a quarter of its data.  Here the unit is the wave's only work: a pass is two v_mfma_i32_16x16x32_i8 (the contraction index padded from 16 to 32
+// with zeros), every elementwise stage has four coefficients per lane, sign-bit hiding one lane per 4x4 group (16 lanes).  Same arithmetic and results.
+template <bool INV>
+__device__ __forceinline__ void make_solo16_operand(int lane, TeamOperand& o)
+{
+    const int n = lane & 15, k0 = 8 * (lane >> 4);
+    int sum = 0;
+    unsigned long long bits = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+    {
+        const int k = k0 + j;
+        const int v = k < 16 ? (INV ? dct_coef<16>(k, n) : dct_coef<16>(n, k)) : 0;
+        sum += v;
+        bits |= (unsigned long long)(v & 255) << (8 * j);
+    }
+    sum += __shfl_xor(sum, 16, kWave);
+    sum += __shfl_xor(sum, 32, kWave);
+    o.b = (long)bits;
+    o.corr = 128 * sum;
+    o.pad = 0;
+}
+template <bool INV>
+__device__ __forceinline__ void solo_pass16(const int16_t* in, int16_t* out, int lane, const TeamOperand& op, int shift)
+{
+    const int i = lane & 15, k0 = 8 * (lane >> 4);
+    uint32_t x[4] = { 0, 0, 0, 0 };
+    if (k0 < 16)
+    {
+        if (!INV)
+        {
+            const uint4 v = *reinterpret_cast<const uint4*>(in + i * 16 + k0);
+            x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+        }
+        else
+        {
+            const int16_t* p = in + k0 * 16 + i;
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+                x[m] = (uint32_t)(uint16_t)p[(2 * m) * 16] | ((uint32_t)(uint16_t)p[(2 * m + 1) * 16] << 16);
+        }
+    }
+    const uint32_t lo0 = __builtin_amdgcn_perm(x[1], x[0], 0x06040200u) ^ 0x80808080u, lo1 = __builtin_amdgcn_perm(x[3], x[2], 0x06040200u) ^ 0x80808080u;
+    const uint32_t hi0 = __builtin_amdgcn_perm(x[1], x[0], 0x07050301u), hi1 = __builtin_amdgcn_perm(x[3], x[2], 0x07050301u);
+    const long ahi = (long)((unsigned long long)hi0 | ((unsigned long long)hi1 << 32)), alo = (long)((unsigned long long)lo0 | ((unsigned long long)lo1 << 32));
+    v4i acc = { 0, 0, 0, 0 };
+    acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(ahi, op.b, acc, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        acc[q] <<= 8;
+    acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(alo, op.b, acc, 0, 0, 0);
+    const int n = lane & 15, row0 = 4 * (lane >> 4);
+    const int add = (1 << (shift - 1)) + op.corr;
+    int v[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+    {
+        const int t = (acc[e] + add) >> shift;
+        v[e] = INV ? clip3i(-32768, 32767, t) : t;
+    }
+    if (!INV)
+        store4(out + n * 16 + row0, v);
+    else
+    {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            out[(row0 + e) * 16 + n] = (int16_t)v[e];
+    }
+}
+// the sum of v over the wave (v <= 2^26 per lane): rows of 16 lanes by DPP, the four row totals through the scalar unit
+__device__ __forceinline__ unsigned long long solo_total(uint32_t v)
+{
+    const uint32_t r = (uint32_t)row_allsum((int)v);
+    return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)r, 0) + (uint32_t)__builtin_amdgcn_readlane((int)r, 16) +
+           (uint32_t)__builtin_amdgcn_readlane((int)r, 32) + (uint32_t)__builtin_amdgcn_readlane((int)r, 48);
+}
+
+template <typename P>
+__device__ __forceinline__ void solo_chain16(TileLds& t, const TeamOperand (*op)[64], const P* src, const P* prd, const PlaneParams qp, bool signHide,
+                                             x265hip_cujob_unit* un, int16_t* levels, int16_t* resi, uint32_t seq, uint64_t t0, bool stamps, int coef)
+{
+    uint32_t stamp[6] = { 0, 0, 0, 0, 0, 0 };
+    XH_STAMP(0);
+    const int lane = threadIdx.x & 63, e = lane * 4;
+    const TeamOperand& oF = op[0][lane];
+    const TeamOperand& oI = op[1][lane];
+    int fv[4], pv[4];
+    {
+        load4(src + e, fv);
+        load4(prd + e, pv);
+        int r[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = fv[i] - pv[i];
+        store4(t.a + e, r);
+    }
+    uint32_t zeroP = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int d0 = fv[i] - pv[i]; zeroP += (uint32_t)(d0 * d0); }
+    const unsigned long long zero = solo_total(zeroP);
+    // ---- forward transform: a -> b -> a
+    solo_pass16<false>(t.a, t.b, lane, oF, qp.s1f);
+    solo_pass16<false>(t.b, t.a, lane, oF, qp.s2f);
+    XH_STAMP(1);
+    if (coef)
+    {
+        // coefficient mode (chroma: the residual's coefficients only)
+        *reinterpret_cast<uint2*>(levels + e) = *reinterpret_cast<const uint2*>(t.a + e);
+        if (lane == 0)
+        {
+            un->numSig = 0;
+            un->zeroDist = zero;
+            un->fwdTicks = (uint32_t)(wall_clock64() - t0);
+            XH_STAMP(5);
+            if (stamps) { un->reserved[0] = stamp[0] | (stamp[1] << 16); un->reserved[1] = 0; un->reserved[2] = stamp[5] << 16; }
+            __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&un->ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    // ---- quant: levels -> b, deltaU -> c; the coefficients stay in a
+    uint32_t cnt = 0;
+    {
+        int cf[4], lv[4], du[4];
+        const int qBits8 = qp.qBits - 8;
+        load4(t.a + e, cf);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            const int tmp = iabs(cf[i]) * qp.quantScale;
+            const int l = (tmp + qp.add) >> qp.qBits;
+            du[i] = (tmp - (l << qp.qBits)) >> qBits8;
+            cnt += l != 0;
+            lv[i] = clip3i(-32768, 32767, cf[i] < 0 ? -l : l);
+        }
+        store4(t.b + e, lv);
+        store4(t.c + e, du);
+    }
+    int numSig = wave_sum((int)cnt);
+    XH_STAMP(2);
+    // ---- sign-bit hiding: lane = coefficient group (scan order), 16 groups; tile_chain's code for N = 16
+    if (signHide && numSig >= 2)
+    {
+        constexpr int N = 16, CGW = 4;
+        const bool mine = lane < 16;
+        const int cg = lane & 15;
+        const int cgPos = kDiag.s4[cg];
+        const int cgx = cgPos % CGW, cgy = cgPos / CGW;
+        const int base = (cgy * 4) * N + cgx * 4;
+        int lv[16];
+        uint32_t flags = 0;
+#pragma unroll
+        for (int n = 0; n < 16; n++)
+        {
+            const int p4 = kDiag.s4[n];
+            lv[n] = t.b[base + (p4 >> 2) * N + (p4 & 3)];
+            flags |= (uint32_t)(lv[n] != 0) << (15 - n);
+        }
+        if (!mine) flags = 0;
+        const unsigned long long nz = __ballot(flags != 0);
+        const int cgLast = nz ? 63 - __builtin_clzll(nz) : -1;
+        int delta = 0;
+        if (flags && cg <= cgLast)
+        {
+            const int firstNZ = 15 ^ (31 - __builtin_clz(flags));
+            const int lastNZ = 15 ^ __builtin_ctz(flags);
+            if (lastNZ - firstNZ >= 4)
+            {
+                const uint32_t signbit = lv[firstNZ] > 0 ? 0 : 1;
+                int absSum = 0;
+#pragma unroll
+                for (int n = 0; n < 16; n++)
+                    if (n >= firstNZ && n <= lastNZ) absSum += lv[n];
+                if (signbit != ((uint32_t)absSum & 1))
+                {
+                    int minCostInc = 0x7fffffff, minN = -1, finalChange = 0, curChange = 0;
+                    const int start = cg == cgLast ? lastNZ : 15;
+                    uint32_t cgFlags = flags >> (15 - start);
+#pragma unroll
+                    for (int n = 15; n >= 0; n--)
+                    {
+                        if (n > start) continue;
+                        const int p4 = kDiag.s4[n];
+                        const int at = base + (p4 >> 2) * N + (p4 & 3);
+                        const int dU = t.c[at];
+                        int curCost;
+                        if (cgFlags & 1)
+                        {
+                            if (dU > 0) { curCost = -dU; curChange = 1; }
+                            else if (cgFlags == 1 && iabs(lv[n]) == 1) curCost = 0x7fffffff;
+                            else { curCost = dU; curChange = -1; }
+                        }
+                        else if (cgFlags == 0)
+                        {
+                            const uint32_t thisSignBit = t.a[at] >= 0 ? 0 : 1;
+                            if (thisSignBit != signbit) curCost = 0x7fffffff;
+                            else { curCost = -dU; curChange = 1; }
+                        }
+                        else { curCost = -dU; curChange = 1; }
+                        if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minN = n; }
+                        cgFlags >>= 1;
+                    }
+                    if (minN >= 0)
+                    {
+                        const int p4 = kDiag.s4[minN];
+                        const int at = base + (p4 >> 2) * N + (p4 & 3);
+                        int v = t.b[at];
+                        if (v == 32767 || v == -32768) finalChange = -1;
+                        if (!v) delta = 1;
+                        else if (finalChange == -1 && iabs(v) == 1) delta = -1;
+                        const int sigMask = t.a[at] < 0 ? -1 : 0;
+                        v += (finalChange ^ sigMask) - sigMask;
+                        t.b[at] = (int16_t)v;
+                    }
+                }
+            }
+        }
+        numSig += wave_sum(delta);
+    }
+    XH_STAMP(3);
+    // ---- levels out, dequant_normal -> a; the forward half is published by this wave's release store behind its own stores
+    {
+        int lv[4], dq[4];
+        const int dqAdd = 1 << (qp.dqShift - 1);
+        load4(t.b + e, lv);
+#pragma unroll
+        for (int i = 0; i < 4; i++) dq[i] = clip3i(-32768, 32767, (lv[i] * qp.dqScale + dqAdd) >> qp.dqShift);
+        *reinterpret_cast<uint2*>(levels + e) = *reinterpret_cast<const uint2*>(t.b + e);
+        store4(t.a + e, dq);
+    }
+    if (lane == 0)
+    {
+        un->numSig = (uint32_t)numSig;
+        un->zeroDist = zero;
+        un->fwdTicks = (uint32_t)(wall_clock64() - t0);
+        __hip_atomic_store(&un->ready, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (numSig == 0)
+            __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (numSig == 0)
+        return;
+    // ---- inverse transform: a -> b -> a
+    solo_pass16<true>(t.a, t.b, lane, oI, qp.s1i);
+    solo_pass16<true>(t.b, t.a, lane, oI, qp.s2i);
+    XH_STAMP(4);
+    uint32_t codedP = 0;
+    {
+        int r[4], rec[4];
+        load4(t.a + e, r);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            rec[i] = clip3i(0, qp.maxVal, pv[i] + r[i]);
+            const int d1 = fv[i] - rec[i];
+            codedP += (uint32_t)(d1 * d1);
+        }
+        *reinterpret_cast<uint2*>(resi + e) = *reinterpret_cast<const uint2*>(t.a + e);
+        store4(t.b + e, rec);
+    }
+    const unsigned long long coded = solo_total(codedP);
+    // ---- psy energies of the unit's four 8x8 blocks: lanes 0..15 the reconstruction's 4x4 tiles, lanes 16..31 the source's (a quad = one 8x8 block)
+    int en = 0;
+    if (lane < 32)
+    {
+        const int tt = lane & 15, b8 = tt >> 2, q = tt & 3;
+        const int tx = (b8 & 1) * 8 + (q & 1) * 4, ty = (b8 >> 1) * 8 + (q >> 1) * 4;
+        int m[16];
+        if (lane < 16) tile_load(t.b + ty * 16 + tx, (int64_t)16, m);
+        else tile_load(src + ty * 16 + tx, (int64_t)16, m);
+        int sum = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) sum += m[i];
+        hadamard4x4(m);
+        const int raw = quad_sa8d_raw(m, lane);
+        en = ((raw + 2) >> 2) - (quad_sum(sum) >> 2);
+    }
+    int energy = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+        energy += iabs(__builtin_amdgcn_readlane(en, 16 + 4 * b) - __builtin_amdgcn_readlane(en, 4 * b));
+    if (lane == 0)
+    {
+        un->codedDist = coded;
+        un->codedEnergy = (uint32_t)energy;
+        XH_STAMP(5);
+        if (stamps) { un->reserved[0] = stamp[0] | (stamp[1] << 16); un->reserved[1] = stamp[2] | (stamp[3] << 16); un->reserved[2] = stamp[4] | (stamp[5] << 16); }
+        __hip_atomic_store(&un->readyInv, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // An INVERSE job (x265hip_cujob::coefMode == X265HIP_CUJOB_INVERSE): one 32x32 luma unit whose levels the host has made (Quant::rdoQuant) — dequant_normal ->
 // cu[].idct -> reconstructed residual, sse_pp and psy energy of the reconstruction, i.e. Quant::invtransformNxN (quant.cpp:543-603) and the two measurements
 // Search::estimateResidualQT takes behind it (search.cpp:3290-3300).  The levels follow the source and prediction blocks in the pixel block.
@@ -939,6 +1231,7 @@ __device__ __forceinline__ void build_operands(JobLds& L)
 #undef XH_BOP
     make_team_operand<false>(threadIdx.x, L.team.op[0][threadIdx.x]);
     make_team_operand<true>(threadIdx.x, L.team.op[1][threadIdx.x]);
+    if (wv == 3) { make_solo16_operand<false>(lane, L.team.op16[0][lane]); make_solo16_operand<true>(lane, L.team.op16[1][lane]); }
     __syncthreads();
 }
 
@@ -999,6 +1292,9 @@ __device__ __forceinline__ void run_tiles(SlotOut* s, JobLds& L, uint32_t seq, u
                 const int coef = !j.coefMode ? 0 : parts == 1 ? 1 : (kk % parts) == 0 ? 1 | 4 : 2 | 4;
                 const int u0 = k * G, count = nUnits - u0 < G ? nUnits - u0 : G;
                 if (log2n == 5) tile_chain<P, 32>(L.tile[wv], L.bop[2], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0, j.reserved != 0, coef);
+                else if (log2n == 4 && nUnits == 1 && plane && team)
+                    // (the chroma units of a 32x32 CU: one 16x16 unit per plane, the wave's only work)
+                    solo_chain16<P>(L.tile[wv], L.team.op16, ps, pp, qp, j.signHide != 0, s->units + unitBase, s->levels + elemBase, s->resi + elemBase, seq, t0, j.reserved != 0, coef);
                 else if (log2n == 4) tile_chain<P, 16>(L.tile[wv], L.bop[1], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0, j.reserved != 0, coef);
                 else tile_chain<P, 8>(L.tile[wv], L.bop[0], ps, pp, pw, u0, count, qp, j.signHide != 0, s->units, unitBase, s->levels, s->resi, elemBase, seq, t0, j.reserved != 0, coef);
             }
