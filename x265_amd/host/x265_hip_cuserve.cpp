@@ -149,7 +149,7 @@ void report()
     fprintf(stderr, "x265hip: cuserve: %llu CU residual quad-trees (CU >= %d) handed to the GPU as jobs (%s%s, %.3f ms of device time%s): %llu forward "
                     "transform+quant units and %llu inverse units served, %llu + %llu calls of those CUs computed on the host; %llu waits of %.0f cycles on average; "
                     "%llu CUs not submitted%s\n",
-            (unsigned long long)jobs, 1 << g_minLog2, g_mode ? "one launch per job" : (std::string("resident server of ") + std::to_string(g_slots) + " workgroups").c_str(),
+            (unsigned long long)jobs, 1 << g_minLog2, g_mode ? "one launch per job" : (std::string("resident server of ") + std::to_string(2 * g_slots) + " workgroups = two per slot").c_str(),
             g_nsvc.load() > 1 ? (std::string(" at each of ") + std::to_string(g_nsvc.load()) + " places").c_str() : "", ns * 1e-6,
             g_mode ? "" : (std::string(", ") + std::to_string(starts) + " server starts").c_str(), (unsigned long long)fwd, (unsigned long long)inv,
             (unsigned long long)fm, (unsigned long long)im, (unsigned long long)w, w ? (double)wc / w : 0.0, (unsigned long long)sk,
