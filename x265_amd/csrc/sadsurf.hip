@@ -662,12 +662,21 @@ struct SubpelArgs
     int blocksX[4], blocksY[4], per[4];
     int row0, rows;
     int jobs[4];                                                            // (block, vector) jobs of levels 1..3 in this launch: prefix sums
+    int xcd;                                                                // 1: XCD-aware job order (the grid is a multiple of 128)
 };
 template <typename P>
 __global__ __launch_bounds__(256) void subpel_satd_kernel(SubpelArgs a)
 {
     const int lane = threadIdx.x & 63;
-    const int gwave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), wavesTotal = gridDim.x * (blockDim.x >> 6);
+    // XCD-aware order: workgroups are dealt to the eight XCDs round-robin, each XCD has its own L2, and consecutive jobs — the 49 vectors of a block, then the next
+    // block of the row, whose phase-plane lines are the same 128-byte lines — want ONE L2.  The job order is cut into chunks of 16 workgroups, chunk c goes to
+    // XCD c % 8: workgroup b (XCD b % 8, its i-th there, i = b / 8) takes place ((i / 16) * 8 + b % 8) * 16 + i % 16.  Chunks rather than one contiguous eighth
+    // per XCD: the levels have few jobs each (64x64 blocks: 368 workgroups' worth per picture row set) and an eighth-per-XCD split leaves XCDs without work —
+    // measured 95.9 us per launch against 77.2 us in the plain order, with the HBM fetch already down 5.3 x.  The grid is a multiple of 128.
+    // X265HIP_SADSURF_XCD=0 (a.xcd == 0): the plain order
+    const int xi = (int)(blockIdx.x >> 3), xq = (int)(blockIdx.x & 7);
+    const int vblock = a.xcd ? (((xi >> 4) * 8 + xq) << 4) + (xi & 15) : (int)blockIdx.x;
+    const int gwave = vblock * (blockDim.x >> 6) + (threadIdx.x >> 6), wavesTotal = gridDim.x * (blockDim.x >> 6);
     const P* pic = (const P*)a.pic;
     const P* planes = (const P*)a.planes;
     for (int l = 1; l < 4; l++)
@@ -975,7 +984,9 @@ static void progress_multi(const std::vector<x265hip_refpic*>& rps)
                     sa.jobs[l] = sa.jobs[l - 1] + sa.rows * lay.per[l] * lay.blocksX[l] * X265HIP_SADSURF_SUBPEL;
                 }
                 const int waves = (sa.jobs[1] + 3) / 4 + (sa.jobs[2] - sa.jobs[1]) + (sa.jobs[3] - sa.jobs[2]);
-                const int grid = waves / 4 + 1 < 4096 ? waves / 4 + 1 : 4096;
+                static const bool xcdOrder = !(getenv("X265HIP_SADSURF_XCD") && !atoi(getenv("X265HIP_SADSURF_XCD")));
+                sa.xcd = xcdOrder ? 1 : 0;
+                const int grid = ((waves / 4 + 1 < 4096 ? waves / 4 + 1 : 4096) + 127) & ~127;
                 if (rp->depth == 8)
                     hipLaunchKernelGGL(subpel_satd_kernel<uint8_t>, dim3(grid), dim3(256), 0, st, sa);
                 else
