@@ -81,6 +81,7 @@ std::atomic<uint64_t> g_missBy[4][4];   // [level][0: within 8 of the window, 1:
 bool g_subpelHit = false;        // X265HIP_DEBUG_SUBPELHIT=1: how many served searches end within +-3 quarter-pels of the surface's own best vector (what a
                                  // table of sub-pel SATDs around that vector could serve at most), by block size (report at exit)
 std::atomic<uint64_t> g_spHit[4], g_spAll[4];
+std::atomic<uint64_t> g_spDist[4][5];
 bool g_verify = false;           // X265HIP_VERIFY=1: every looked-up SAD is recomputed with the C function and compared (debugging self-check)
 int g_range = 32;                // X265HIP_SADPLANES_RANGE: the exhaustive search that places the windows covers [-range, range)^2
 EncoderPrimitives g_c;
@@ -189,6 +190,11 @@ void report()
         for (int l = 1; l < 4; l++)
             fprintf(stderr, "x265hip: sadplanes: block size %d: %llu of %llu served searches end within 3 quarter-pels of the surface's own best vector (%.1f %%)\n", 8 << l,
                     (unsigned long long)g_spHit[l].load(), (unsigned long long)g_spAll[l].load(), g_spAll[l] ? 100.0 * g_spHit[l].load() / g_spAll[l].load() : 0.0);
+    if (g_subpelHit)
+        for (int l = 1; l < 4; l++)
+            fprintf(stderr, "x265hip: sadplanes: block size %d: searches ending within 3 / 7 / 11 / 19 quarter-pels of the centre and farther: %llu / %llu / %llu / %llu / %llu\n", 8 << l,
+                    (unsigned long long)g_spDist[l][0].load(), (unsigned long long)g_spDist[l][1].load(), (unsigned long long)g_spDist[l][2].load(),
+                    (unsigned long long)g_spDist[l][3].load(), (unsigned long long)g_spDist[l][4].load());
     if (g_missHist)
         for (int l = 0; l < 4; l++)
             fprintf(stderr, "x265hip: sadplanes: block size %d: misses within 8 / 16 / 32 vectors of the window and farther: %llu / %llu / %llu / %llu\n", 8 << l,
@@ -799,6 +805,9 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
         const int dx = outQMv.x - 4 * (c.ox + WIN / 2), dy = outQMv.y - 4 * (c.oy + WIN / 2);
         g_spAll[level].fetch_add(1, std::memory_order_relaxed);
         if (dx >= -3 && dx <= 3 && dy >= -3 && dy <= 3) g_spHit[level].fetch_add(1, std::memory_order_relaxed);
+        // (how far from the centre do the others end: what a table of +-7 / +-11 / +-19 quarter-pels would cover)
+        const int far = (dx < 0 ? -dx : dx) > (dy < 0 ? -dy : dy) ? (dx < 0 ? -dx : dx) : (dy < 0 ? -dy : dy);
+        g_spDist[level][far <= 3 ? 0 : far <= 7 ? 1 : far <= 11 ? 2 : far <= 19 ? 3 : 4].fetch_add(1, std::memory_order_relaxed);
     }
     // counters: per thread, flushed to the shared ones now and then (an atomic per search would be felt)
     t_hit += c.hit; t_miss += c.miss;
