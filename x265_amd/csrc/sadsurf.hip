@@ -73,8 +73,23 @@ struct SurfArgs
     int blocksX[4];
     int blocksY0;                                 // 8x8 blocks inside the picture, vertically
     int nJobs;
+    int xcd;                                      // 1: XCD-aware CTU order (surf_ctu below)
     SurfJob job[kMaxJobs];
 };
+
+// Which CTU of the launch a workgroup takes.  Workgroups are dealt to the eight XCDs round-robin in dispatch order (x fastest), and the windows of neighbouring
+// CTUs overlap by half either way: in the plain order a row's neighbours sit in eight different L2s and each fetches the shared half again.  XCD x instead walks a
+// contiguous run of CTUs: of the `total` workgroups it receives n_x = total / 8 + (x < total % 8) — the linear ids x, x + 8, ... — and its i-th takes CTU
+// start_x + i, start_x = x * (total / 8) + min(x, total % 8): a bijection for any grid, every workgroup the same work.
+__device__ __forceinline__ void surf_ctu(int xcd, int& cx, int& rowIn)
+{
+    cx = blockIdx.x; rowIn = blockIdx.y;
+    if (!xcd) return;
+    const int total = gridDim.x * gridDim.y, L = blockIdx.y * gridDim.x + blockIdx.x;
+    const int x = L & 7, i = L >> 3, per = total >> 3, rem = total & 7;
+    const int c = x * per + (x < rem ? x : rem) + i;
+    cx = c % (int)gridDim.x; rowIn = c / (int)gridDim.x;
+}
 
 } // namespace xh
 
@@ -374,7 +389,8 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu_kernel(SurfArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ SsShared sh;
 
-    int jn = 0, rowIn = blockIdx.y;
+    int jn = 0, rowIn, cx;
+    surf_ctu(a.xcd, cx, rowIn);
     while (jn + 1 < a.nJobs && rowIn >= a.job[jn].rows) { rowIn -= a.job[jn].rows; jn++; }
     const SurfJob& jb = a.job[jn];
     const int S = jb.S, D = 2 * S, DD = D * D;
@@ -383,7 +399,7 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu_kernel(SurfArgs a)
     uint8_t* sRef = smem + 4096;                                 // [64 + D][RW]
     uint16_t* sSurf = (uint16_t*)(smem + 4096 + (size_t)(64 + D) * RW);      // [16][D][D]
 
-    const int cx = blockIdx.x, cy = jb.row0 + rowIn;
+    const int cy = jb.row0 + rowIn;
     const int x0 = cx * 64, y0 = cy * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -528,7 +544,8 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu16_kernel(SurfArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ SsShared sh;
 
-    int jn = 0, rowIn = blockIdx.y;
+    int jn = 0, rowIn, cx;
+    surf_ctu(a.xcd, cx, rowIn);
     while (jn + 1 < a.nJobs && rowIn >= a.job[jn].rows) { rowIn -= a.job[jn].rows; jn++; }
     const SurfJob& jb = a.job[jn];
     const int S = jb.S, D = 2 * S;
@@ -538,7 +555,7 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu16_kernel(SurfArgs a)
     uint32_t* sRefB = sRefA + (64 + D) * RWD;                    // the same shifted by one sample: dword k = samples (2k + 1, 2k + 2)
     uint32_t* sSurf = sRefB + (64 + D) * RWD;                    // [16][D][D]
 
-    const int cx = blockIdx.x, cy = jb.row0 + rowIn;
+    const int cy = jb.row0 + rowIn;
     const int x0 = cx * 64, y0 = cy * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint16_t* src = (const uint16_t*)jb.src;
@@ -865,6 +882,8 @@ static void progress_multi(const std::vector<x265hip_refpic*>& rps)
         {
             SurfArgs a;
             memset(&a, 0, sizeof(a));
+            static const bool xcdOrderCtu = !(getenv("X265HIP_SADSURF_XCD") && !atoi(getenv("X265HIP_SADSURF_XCD")));
+            a.xcd = xcdOrderCtu ? 1 : 0;
             size_t in[kMaxJobs];
             int upto[kMaxJobs], rows = 0, maxS = 0;
             for (; i < g1 && a.nJobs < kMaxJobs; i++)
