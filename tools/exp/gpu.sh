@@ -125,6 +125,20 @@ PY
       done
       find $OUT/pmc_encode -name "*kernel_trace.csv" -delete
       python tools/prof/pmc_kernels.py $OUT/pmc_encode "x265_hip_8bit, 30 frames 1080p preset medium --me hex, CU / SAO / intra jobs off" sadsurf.hip | tee $OUT/pmc_encode.txt | head -16 ;;
+    startup)
+      # where the wall clock outside x265's own fps clock goes: X265HIP_DEBUG_STARTUP marks (ms since the process started), the process's wall clock as
+      # the shell sees it, the encoder's own line — bound encoder and reference, three runs each
+      clip /tmp/bench240.yuv 240
+      for k in 1 2 3; do for b in hip ref; do
+        exe=integration/_build/x265_hip_8bit; [ $b = ref ] && exe=oracle/_ref/x265_8bit
+        t0=$(date +%s%N)
+        X265HIP=require X265HIP_DEBUG_STARTUP=1 $exe --input /tmp/bench240.yuv --input-res 1920x1080 --fps 30 --frames 240 --preset medium --me hex --pools 24 -F 6 -o /tmp/su.hevc > $OUT/startup_${b}_$k.log 2>&1
+        t1=$(date +%s%N)
+        echo "$b run $k: wall $(( (t1 - t0) / 1000000 )) ms; $(grep -E '^encoded' $OUT/startup_${b}_$k.log)" | tee -a $OUT/startup.txt
+      done; done
+      grep -E "x265hip-startup" $OUT/startup_hip_3.log | grep -v -E "device copy of a source|reference-picture mirror" | tee -a $OUT/startup.txt | tail -30
+      grep -c "create: " $OUT/startup_hip_3.log | sed 's/^/creates: /' | tee -a $OUT/startup.txt
+      grep -E "x265hip-startup" $OUT/startup_hip_3.log | head -3; grep -E "x265hip-startup" $OUT/startup_hip_3.log | grep -E "create" | sed -n '1p;$p' ;;
     cpuprofile)
       clip /tmp/bench240.yuv 240
       for k in 1 2 3 4 5 6 7 8 9 10; do
