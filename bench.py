@@ -946,25 +946,33 @@ def main():
                         "launch_ms_note": "HIP events around each band's launch; bands are one CTU row each (launch-latency sized)"}
         # ---- sub-pel SATD tables: the launch group with the most device time after the job server ------------------------------------------------------------------
         # per CTU of a surface row, three block levels (16 / 32 / 64), 49 quarter-pel vectors around each block's window centre.  Per-call bytes (satd =
-        # 2 W H B per call) = 3 x 64 x 64 x 49 x 2 B per CTU = 1 204 224; what HBM has to deliver once (unique footprint): the CTU's source block + for every block
-        # of every level the (N + 6)^2 neighbourhood of its centre in each of the 16 phase planes (N + 2 would do for the 7 x 7 quarter-pel vectors; the rows are
-        # 4 bytes wider either side) + the tables written: 64 x 64 + 16 x (16 x 22 x 22 + 4 x 38 x 38 + 70 x 70) + 21 x 49 x 4 = 302 932 B per CTU
+        # 2 W H B per call) = 3 x 64 x 64 x 49 x 2 B per CTU = 1 204 224.  What the kernel asks L2 / HBM for ONCE (subpel_satd_kernel_lds, round 6: a block's
+        # footprint goes through LDS once for its 49 vectors): per block of Q x Q (Q = 16; 32 for the 32x32 blocks and the four quadrants of a 64x64 block) Q + 1
+        # rows of Q + 4 bytes in each of the 16 phase planes, the source block once per level, the tables written:
+        # 16 x 16 x 17 x 20 + 2 x 4 x 16 x 33 x 36 + 3 x 4096 + 21 x 49 x 4 = 255 508 B per CTU (the first form's figure was 302 932: rows 4 bytes wider either side).
+        # VALU: a lane measures one vector, 62 instructions per 4x4 tile (ISA count), 49 of 64 lanes at work: 3 levels x 256 tiles x 62 wave instructions x 64 lanes
         sp = clocks.get("sub-pel SATD tables", {})
         sp_block = None
-        SP_CALL_BYTES_PER_CTU, SP_UNIQUE_BYTES_PER_CTU = 3 * 64 * 64 * 49 * 2, 64 * 64 + 16 * (16 * 22 * 22 + 4 * 38 * 38 + 70 * 70) + 21 * 49 * 4
+        SP_CALL_BYTES_PER_CTU, SP_UNIQUE_BYTES_PER_CTU = 3 * 64 * 64 * 49 * 2, 16 * 16 * 17 * 20 + 2 * 4 * 16 * 33 * 36 + 3 * 4096 + 21 * 49 * 4
+        SP_LANE_INSTR_PER_CTU, VALU_PEAK_TLANE = 3 * 256 * 62 * 64, 256 * 4 * 16 * 2.4e9 / 1e12          # lane-instructions; 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
         sp_traffic, sp_tfile, sp_tnote = pmc_profile("r*_pmc_encode.txt", "subpel_satd_kernel", ss_digest)
         if sp.get("ms") and sp.get("launch_groups"):
             secs = sp["ms"] * 1e-3
             ctus = sp["algorithmic_bytes"] / SP_CALL_BYTES_PER_CTU
             ach = sp["algorithmic_bytes"] / secs / 1e9
             uniq = ctus * SP_UNIQUE_BYTES_PER_CTU
-            sp_block = {"bound": "hbm", "kernel": "subpel_satd_kernel<u8>, live in the timed encode: %d launch groups (one launch per surface of the group) = the 7 x 7 quarter-pel "
-                                                  "SATDs around the window centre of every 16x16 / 32x32 / 64x64 block of %.0f CTUs, out of the mirrors' phase planes"
+            sp_block = {"bound": "hbm", "kernel": "subpel_satd_kernel_lds (8 bit), live in the timed encode: %d launch groups (one launch per surface of the group) = the 7 x 7 quarter-pel "
+                                                  "SATDs around the window centre of every 16x16 / 32x32 / 64x64 block of %.0f CTUs, out of the mirrors' phase planes; a block's footprint "
+                                                  "staged in LDS once, a lane per vector, packed 16-bit Hadamard with v_sad_u16 against the source tile's transform"
                                                   % (sp["launch_groups"], ctus),
                         "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
                         "achieved_note": "SURVEY 8d per-call bytes (satd = 2 W H B per (block, vector) call): what the reference's calls would move; most of it is the "
                                          "same phase-plane neighbourhoods read 49 times — served by L2 / MALL, see `unique_footprint`",
                         "unique_footprint": {"bytes_per_ctu": SP_UNIQUE_BYTES_PER_CTU, "achieved": round(uniq / secs / 1e9, 2), "frac": round(uniq / secs / 1e9 / HBM_PEAK_GBPS, 5)},
+                        "valu": {"lane_instructions_per_ctu": SP_LANE_INSTR_PER_CTU, "achieved": round(ctus * SP_LANE_INSTR_PER_CTU / secs / 1e12, 2), "peak": round(VALU_PEAK_TLANE, 1),
+                                 "unit": "T lane-instructions/s", "frac": round(ctus * SP_LANE_INSTR_PER_CTU / secs / 1e12 / VALU_PEAK_TLANE, 4),
+                                 "note": "what binds the kernel: 62 VALU instructions per 4x4 tile and vector (ISA count), 64 lanes issued for 49 vectors; peak = 256 CUs x 4 SIMDs x "
+                                         "16 lanes x 2.4 GHz, of which the resident job server's workgroups hold 64 CUs; the time is the launch GROUP's (two or three launches)"},
                         "traffic": sp_traffic, "traffic_source": sp_tfile,
                         "traffic_note": (sp_tnote + "; per LAUNCH of the profile's run (one surface's rows per launch), not per launch group") if sp_traffic else sp_tnote,
                         "algorithmic_bytes_per_launch": int(sp["algorithmic_bytes"] / sp["launch_groups"]), "launch_ms": round(sp["ms"] / sp["launch_groups"], 5),

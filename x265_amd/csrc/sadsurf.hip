@@ -739,6 +739,219 @@ __global__ __launch_bounds__(256) void subpel_satd_kernel(SubpelArgs a)
     }
 }
 
+// ---- the same tables for 8-bit pictures, second form (round 6): the planes through LDS, the lanes are the vectors, packed 16-bit Hadamard --------------------
+// subpel_satd_kernel above measures a (block, vector) per group of lanes, a lane per 4x4 tile: eight scattered 4-byte global loads and ~160 VALU instructions per
+// tile and vector — the texture addresser and the VALU are both near their limits (ISA count; the planes' lines come out of L2).  Here a workgroup takes a
+// block: the block's footprint in the sixteen phase planes — (Q + 1) rows of Q + 1 pixels around the window's centre, whole dwords — is staged in LDS ONCE for
+// the 49 vectors, lane v measures vector v and walks the block's tiles: a tile's four rows are four ds_read2_b32 (the two dwords a row of four unaligned pixels
+// lies in) and two v_perm_b32 each with the lane's own byte selectors, which split them into 16-bit pairs at the same time.  The Hadamard runs on packed pairs
+// (|coefficients| <= 16 * 255; common.h), and it is LINEAR: the source tile's transform M s is made once per tile (64 lanes, one tile each, into LDS) and
+// a lane accumulates sum |M s - M r| with v_sad_u16 — two coefficients and the accumulation per instruction.  v_sad_u16 compares unsigned halves: both
+// transforms carry the same bias 0x4000 in their first sample, which reaches every coefficient as +-0x4000 and cancels in the difference.  M is the Hadamard up
+// to the sign of every other coefficient (the rotate-and-multiply butterfly below), the same for both sides.  ~57 VALU instructions per tile and vector
+// instead of ~160, no scattered global loads.  A tile's sum of magnitudes is even (it is congruent to the sum of the coefficients = 16 x the first sample), so
+// shifting the block's total once equals pixel.cpp:210-297's shift per 8x4.
+// Jobs of a launch, longest first: the 64x64 blocks (four 32x32 quadrants one after the other, sums kept in registers), the 32x32 blocks (the four waves take
+// 16 tiles each), the 16x16 blocks four to a workgroup (a block per wave).  X265HIP_SUBPEL_LDS=0: the first form.
+namespace sp8 {
+constexpr int kPitch16 = 16 / 4 + 1, kPlane16 = 17 * kPitch16, kBlock16 = 16 * kPlane16;      // dwords
+constexpr int kPitch32 = 32 / 4 + 1, kPlane32 = 33 * kPitch32, kBlock32 = 16 * kPlane32;
+constexpr int kRefDw = (4 * kBlock16 > kBlock32 ? 4 * kBlock16 : kBlock32) + 4;
+struct Geo { int ok, x0, y0, sx, sy, k, cr, pad; };      // footprint's first pixel (x0, y0) in the reference, the block's (quadrant's) first pixel (sx, sy) in the source
+}
+
+// rows as ((c0, c1), (c2, c3)) pairs in, M * tile out (see above)
+__device__ __forceinline__ void pk_hadamard4x4(s2v a[4], s2v b[4])
+{
+    const s2v kh = { 1, -1 };
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+    {
+        s2v* v = h ? b : a;
+        const s2v s0 = v[0] + v[1], e0 = v[0] - v[1], s1 = v[2] + v[3], e1 = v[2] - v[3];
+        v[0] = s0 + s1; v[1] = e0 + e1; v[2] = s0 - s1; v[3] = e0 - e1;
+    }
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+    {
+        const s2v A = a[y] + b[y], B = a[y] - b[y];
+        const s2v Ar = as_s2(__builtin_amdgcn_alignbit(as_u(A), as_u(A), 16)), Br = as_s2(__builtin_amdgcn_alignbit(as_u(B), as_u(B), 16));
+        a[y] = Ar * kh + A; b[y] = Br * kh + B;
+    }
+}
+
+// stage ONE block's footprint (Q x Q block) with a group of T threads (a wave or the workgroup), g = the thread's number in the group; (x0, y0) is uniform over
+// the group, so a load is a scalar base + a 32-bit offset.  Every thread issues ALL its loads before the first LDS store (a load -> wait -> store loop has one
+// 4-byte load in flight per thread: twenty round trips to L2 per staging).  The picture (plane 0) has an allocation of its own; planes 1..15 follow one another.
+template <int Q, int T>
+__device__ __forceinline__ void sp8_stage_ref(const SubpelArgs& a, int x0, int y0, int g, uint32_t* dst)
+{
+    constexpr int pitch = Q / 4 + 1, planeDw = (Q + 1) * pitch, n15 = 15 * planeDw, it0 = (planeDw + T - 1) / T, it15 = (n15 + T - 1) / T;
+    const int64_t first = (int64_t)y0 * a.stride + x0;
+    // buffer loads: the 128-bit descriptor of a group-uniform base in scalar registers + ONE 32-bit offset register per load (a flat address is two, and the
+    // compiler builds all of a batch's addresses before its first load: 157 registers with global_load, three waves per SIMD)
+    const __amdgpu_buffer_rsrc_t d0 = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)a.pic + (uintptr_t)first) & ~(uintptr_t)3), 0, (int)0xfffffff0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t d1 = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)a.planes + (uintptr_t)a.planeElems + (uintptr_t)first) & ~(uintptr_t)3), 0, (int)0xfffffff0u, 0x00020000);
+    const uint32_t stride = (uint32_t)a.stride, planeElems = (uint32_t)a.planeElems;
+    uint32_t v0[it0], v1[it15];
+#pragma unroll
+    for (int k = 0; k < it0; k++)
+    {
+        const int i0 = g + T * k, i = i0 < planeDw ? i0 : planeDw - 1, r = i / pitch, j = i - r * pitch;
+        v0[k] = __builtin_amdgcn_raw_buffer_load_b32(d0, (int)((uint32_t)r * stride + 4u * (uint32_t)j), 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < it15; k++)
+    {
+        const int i0 = g + T * k, i = i0 < n15 ? i0 : n15 - 1, pp = i / planeDw, r1 = i - pp * planeDw, r = r1 / pitch, j = r1 - r * pitch;
+        v1[k] = __builtin_amdgcn_raw_buffer_load_b32(d1, (int)((uint32_t)pp * planeElems + (uint32_t)r * stride + 4u * (uint32_t)j), 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < it0; k++)
+        if (g + T * k < planeDw) dst[g + T * k] = v0[k];
+#pragma unroll
+    for (int k = 0; k < it15; k++)
+        if (g + T * k < n15) dst[planeDw + g + T * k] = v1[k];
+}
+// the transform of one source tile per thread: tile t of the Q x Q block whose first pixel is (sx, sy)
+template <int Q>
+__device__ __forceinline__ void sp8_stage_src(const SubpelArgs& a, int sx, int sy, int t, uint32_t* o)
+{
+    constexpr int TX = Q / 4;
+    const int ty = t / TX, tx = t - ty * TX;
+    const uint8_t* s = (const uint8_t*)a.src + (int64_t)(sy + 4 * ty) * a.srcPitch + sx + 4 * tx;
+    s2v sa[4], sb[4];
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+        Pk16<uint8_t>::split(ld_global_unaligned<uint32_t>(s + (int64_t)y * a.srcPitch), sa[y], sb[y]);
+    sa[0] = as_s2(as_u(sa[0]) | 0x4000u);
+    pk_hadamard4x4(sa, sb);
+    *(uint4*)o = make_uint4(as_u(sa[0]), as_u(sa[1]), as_u(sa[2]), as_u(sa[3]));
+    *(uint4*)(o + 4) = make_uint4(as_u(sb[0]), as_u(sb[1]), as_u(sb[2]), as_u(sb[3]));
+}
+
+// sum over tiles [t0, t1) of a staged block of sum |M s - M r| for this lane's vector: `ref` = the lane's first dword in the staged footprint
+template <int Q>
+__device__ __forceinline__ uint32_t sp8_tiles(const uint32_t* ref, uint32_t selLo, uint32_t selHi, const uint32_t* hs, int t0, int t1)
+{
+    constexpr int pitch = Q / 4 + 1, TX = Q / 4;
+    uint32_t acc = 0;
+#pragma unroll 2
+    for (int t = t0; t < t1; t++)
+    {
+        const int ty = t / TX, tx = t - ty * TX;
+        const uint32_t* p = ref + 4 * ty * pitch + tx;
+        s2v ra[4], rb[4];
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+        {
+            const uint32_t d0 = p[y * pitch], d1 = p[y * pitch + 1];
+            ra[y] = as_s2(__builtin_amdgcn_perm(d1, d0, selLo));
+            rb[y] = as_s2(__builtin_amdgcn_perm(d1, d0, selHi));
+        }
+        ra[0] = as_s2(as_u(ra[0]) | 0x4000u);
+        pk_hadamard4x4(ra, rb);
+        const uint4 h0 = *(const uint4*)(hs + 8 * t), h1 = *(const uint4*)(hs + 8 * t + 4);
+        acc = __builtin_amdgcn_sad_u16(as_u(ra[0]), h0.x, acc); acc = __builtin_amdgcn_sad_u16(as_u(ra[1]), h0.y, acc);
+        acc = __builtin_amdgcn_sad_u16(as_u(ra[2]), h0.z, acc); acc = __builtin_amdgcn_sad_u16(as_u(ra[3]), h0.w, acc);
+        acc = __builtin_amdgcn_sad_u16(as_u(rb[0]), h1.x, acc); acc = __builtin_amdgcn_sad_u16(as_u(rb[1]), h1.y, acc);
+        acc = __builtin_amdgcn_sad_u16(as_u(rb[2]), h1.z, acc); acc = __builtin_amdgcn_sad_u16(as_u(rb[3]), h1.w, acc);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void subpel_satd_kernel_lds(SubpelArgs a)
+{
+    __shared__ uint32_t sRef[sp8::kRefDw];
+    __shared__ __attribute__((aligned(16))) uint32_t sHs[64 * 8];
+    __shared__ uint32_t sPart[4 * 64];
+    __shared__ sp8::Geo sGeo[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n1 = (a.jobs[1] - a.jobs[0]) / X265HIP_SADSURF_SUBPEL, n2 = (a.jobs[2] - a.jobs[1]) / X265HIP_SADSURF_SUBPEL, n3 = (a.jobs[3] - a.jobs[2]) / X265HIP_SADSURF_SUBPEL;
+    const int total = n3 + n2 + ((n1 + 3) >> 2);
+    // the lane's vector: quarter-pel offset (dx, dy) from the centre -> phase plane 4 fy + fx at the whole-pel offset (dx >> 2, dy >> 2) = -1 or 0
+    const int v = lane < X265HIP_SADSURF_SUBPEL ? lane : 0;
+    const int dx = v % 7 - 3, dy = v / 7 - 3, phase = 4 * (dy & 3) + (dx & 3);
+    // byte alignment of the footprint's first pixel: the planes share one (planeElems and the stride are multiples of 4), the picture has its own allocation
+    const int xi = (int)(blockIdx.x >> 3), xq = (int)(blockIdx.x & 7);
+    const int first = a.xcd ? (((xi >> 4) * 8 + xq) << 4) + (xi & 15) : (int)blockIdx.x;          // (subpel_satd_kernel: chunks of 16 workgroups per XCD)
+    for (int job = first; job < total; job += gridDim.x)
+    {
+        const int l = job < n3 ? 3 : job < n3 + n2 ? 2 : 1;
+        const int b0 = l == 3 ? job : l == 2 ? job - n3 : 4 * (job - n3 - n2);
+        const int nb = l == 1 ? (n1 - b0 < 4 ? n1 - b0 : 4) : 1, N = 8 << l;
+        const int rowBlocks = a.per[l] * a.blocksX[l];
+        __syncthreads();                                                             // the previous job's LDS is no longer read
+        uint32_t acc = 0;
+        for (int quad = 0; quad < (l == 3 ? 4 : 1); quad++)
+        {
+            if (quad)
+                __syncthreads();
+            if (tid < 4)
+            {
+                sp8::Geo g = { 0, 0, 0, 0, 0, 0, 0, 0 };
+                if (tid < nb)
+                {
+                    const int b = b0 + tid;
+                    g.cr = a.row0 + b / rowBlocks; g.k = b % rowBlocks;
+                    const int by = g.cr * a.per[l] + g.k / a.blocksX[l], bx = g.k % a.blocksX[l];
+                    g.ok = by < a.blocksY[l];
+                    if (g.ok)
+                    {
+                        const int16_t* org = (const int16_t*)(a.out + (int64_t)g.cr * a.pitch + a.originOff[l]) + 2 * g.k;
+                        g.sx = bx * N + 32 * (quad & 1); g.sy = by * N + 32 * (quad >> 1);
+                        g.x0 = g.sx + org[0] + kWin / 2 - 1; g.y0 = g.sy + org[1] + kWin / 2 - 1;
+                    }
+                }
+                sGeo[tid] = g;
+            }
+            __syncthreads();
+            {
+                // (blocks that do not exist carry the geometry of the picture's first block: valid addresses, nothing of them is kept)
+                const sp8::Geo& gs = sGeo[l == 1 ? wave : 0];
+                const int x0 = __builtin_amdgcn_readfirstlane(gs.x0), y0 = __builtin_amdgcn_readfirstlane(gs.y0);
+                if (l == 1) sp8_stage_ref<16, 64>(a, x0, y0, lane, sRef + wave * sp8::kBlock16);
+                else sp8_stage_ref<32, 256>(a, x0, y0, tid, sRef);
+                if (tid < 64)
+                {
+                    const sp8::Geo& gt = sGeo[l == 1 ? tid >> 4 : 0];
+                    if (gt.ok)
+                    {
+                        if (l == 1) sp8_stage_src<16>(a, gt.sx, gt.sy, tid & 15, sHs + 8 * tid);
+                        else sp8_stage_src<32>(a, gt.sx, gt.sy, tid, sHs + 8 * tid);
+                    }
+                }
+            }
+            __syncthreads();
+            const sp8::Geo& g = sGeo[l == 1 ? wave : 0];
+            if (g.ok)
+            {
+                const uint8_t* base = phase ? (const uint8_t*)a.planes : (const uint8_t*)a.pic;
+                const int col = (int)(((uintptr_t)base + (int64_t)g.y0 * a.stride + g.x0) & 3) + 1 + (dx >> 2), sh = col & 3;
+                const uint32_t selLo = (uint32_t)sh | 0x0c000c00u | ((uint32_t)(sh + 1) << 16), selHi = (uint32_t)(sh + 2) | 0x0c000c00u | ((uint32_t)(sh + 3) << 16);
+                if (l == 1)
+                    acc = sp8_tiles<16>(sRef + wave * sp8::kBlock16 + phase * sp8::kPlane16 + (1 + (dy >> 2)) * sp8::kPitch16 + (col >> 2), selLo, selHi, sHs + wave * 16 * 8, 0, 16);
+                else
+                    acc += sp8_tiles<32>(sRef + phase * sp8::kPlane32 + (1 + (dy >> 2)) * sp8::kPitch32 + (col >> 2), selLo, selHi, sHs, 16 * wave, 16 * wave + 16);
+            }
+        }
+        if (l == 1)
+        {
+            const sp8::Geo& g = sGeo[wave];
+            if (g.ok && lane < X265HIP_SADSURF_SUBPEL)
+                ((uint32_t*)(a.out + (int64_t)g.cr * a.pitch + a.subpelOff[l]))[(int64_t)g.k * X265HIP_SADSURF_SUBPEL + lane] = acc >> 1;
+        }
+        else
+        {
+            sPart[tid] = acc;
+            __syncthreads();
+            const sp8::Geo& g = sGeo[0];
+            if (g.ok && tid < X265HIP_SADSURF_SUBPEL)
+                ((uint32_t*)(a.out + (int64_t)g.cr * a.pitch + a.subpelOff[l]))[(int64_t)g.k * X265HIP_SADSURF_SUBPEL + tid] = (sPart[tid] + sPart[64 + tid] + sPart[128 + tid] + sPart[192 + tid]) >> 1;
+        }
+    }
+}
+
 static size_t surf16_lds_bytes(int S)
 {
     const int D = 2 * S, RWD = (64 + D) / 2 + 4;
@@ -1006,7 +1219,15 @@ static void progress_multi(const std::vector<x265hip_refpic*>& rps)
                 static const bool xcdOrder = !(getenv("X265HIP_SADSURF_XCD") && !atoi(getenv("X265HIP_SADSURF_XCD")));
                 sa.xcd = xcdOrder ? 1 : 0;
                 const int grid = ((waves / 4 + 1 < 4096 ? waves / 4 + 1 : 4096) + 127) & ~127;
-                if (rp->depth == 8)
+                static const bool ldsForm = !(getenv("X265HIP_SUBPEL_LDS") && !atoi(getenv("X265HIP_SUBPEL_LDS")));
+                if (rp->depth == 8 && ldsForm && rp->stride % 4 == 0 && rp->planeElems % 4 == 0)
+                {
+                    // a workgroup per 64x64 block, per 32x32 block, per four 16x16 blocks (subpel_satd_kernel_lds); a multiple of 128 for the XCD order
+                    const int blocks1 = sa.jobs[1] / X265HIP_SADSURF_SUBPEL, blocks2 = (sa.jobs[2] - sa.jobs[1]) / X265HIP_SADSURF_SUBPEL, blocks3 = (sa.jobs[3] - sa.jobs[2]) / X265HIP_SADSURF_SUBPEL;
+                    const int groups = blocks3 + blocks2 + (blocks1 + 3) / 4;
+                    hipLaunchKernelGGL(subpel_satd_kernel_lds, dim3(((groups < 16384 ? groups : 16384) + 127) & ~127), dim3(256), 0, st, sa);
+                }
+                else if (rp->depth == 8)
                     hipLaunchKernelGGL(subpel_satd_kernel<uint8_t>, dim3(grid), dim3(256), 0, st, sa);
                 else
                     hipLaunchKernelGGL(subpel_satd_kernel<uint16_t>, dim3(grid), dim3(256), 0, st, sa);
