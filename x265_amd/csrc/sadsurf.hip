@@ -74,6 +74,7 @@ struct SurfArgs
     int blocksY0;                                 // 8x8 blocks inside the picture, vertically
     int nJobs;
     int xcd;                                      // 1: XCD-aware CTU order (surf_ctu below)
+    int64_t subpelOff3;                           // >= 0: the CTU's 49 sub-pel SATD entries of the 64x64 level are zeroed (subpel_satd_kernel_lds adds four quadrants into them)
     SurfJob job[kMaxJobs];
 };
 
@@ -402,6 +403,8 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu_kernel(SurfArgs a)
     const int cy = jb.row0 + rowIn;
     const int x0 = cx * 64, y0 = cy * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.subpelOff3 >= 0 && cx < a.blocksX[3] && tid < X265HIP_SADSURF_SUBPEL)          // (blocksX: the blocks that lie inside the picture)
+        ((uint32_t*)(jb.out + (int64_t)cy * a.pitch + a.subpelOff3))[(int64_t)cx * X265HIP_SADSURF_SUBPEL + tid] = 0;
 
     // ---- stage ----
     for (int i = tid; i < 64 * 16; i += 1024)
@@ -751,8 +754,9 @@ __global__ __launch_bounds__(256) void subpel_satd_kernel(SubpelArgs a)
 // to the sign of every other coefficient (the rotate-and-multiply butterfly below), the same for both sides.  ~57 VALU instructions per tile and vector
 // instead of ~160, no scattered global loads.  A tile's sum of magnitudes is even (it is congruent to the sum of the coefficients = 16 x the first sample), so
 // shifting the block's total once equals pixel.cpp:210-297's shift per 8x4.
-// Jobs of a launch, longest first: the 64x64 blocks (four 32x32 quadrants one after the other, sums kept in registers), the 32x32 blocks (the four waves take
-// 16 tiles each), the 16x16 blocks four to a workgroup (a block per wave).  X265HIP_SUBPEL_LDS=0: the first form.
+// Jobs of a launch, all of one size (one staging, 16 tiles per wave): the four 32x32 quadrants of every 64x64 block (their halved sums meet in the entry by
+// atomicAdd; the window kernel zeroes those entries), the 32x32 blocks (the four waves take 16 tiles each), the 16x16 blocks four to a workgroup (a block per
+// wave).  X265HIP_SUBPEL_LDS=0: the first form.
 namespace sp8 {
 constexpr int kPitch16 = 16 / 4 + 1, kPlane16 = 17 * kPitch16, kBlock16 = 16 * kPlane16;      // dwords
 constexpr int kPitch32 = 32 / 4 + 1, kPlane32 = 33 * kPitch32, kBlock32 = 16 * kPlane32;
@@ -868,76 +872,73 @@ __global__ __launch_bounds__(256) void subpel_satd_kernel_lds(SubpelArgs a)
     __shared__ sp8::Geo sGeo[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n1 = (a.jobs[1] - a.jobs[0]) / X265HIP_SADSURF_SUBPEL, n2 = (a.jobs[2] - a.jobs[1]) / X265HIP_SADSURF_SUBPEL, n3 = (a.jobs[3] - a.jobs[2]) / X265HIP_SADSURF_SUBPEL;
-    const int total = n3 + n2 + ((n1 + 3) >> 2);
+    const int total = 4 * n3 + n2 + ((n1 + 3) >> 2);
     // the lane's vector: quarter-pel offset (dx, dy) from the centre -> phase plane 4 fy + fx at the whole-pel offset (dx >> 2, dy >> 2) = -1 or 0
     const int v = lane < X265HIP_SADSURF_SUBPEL ? lane : 0;
     const int dx = v % 7 - 3, dy = v / 7 - 3, phase = 4 * (dy & 3) + (dx & 3);
-    // byte alignment of the footprint's first pixel: the planes share one (planeElems and the stride are multiples of 4), the picture has its own allocation
     const int xi = (int)(blockIdx.x >> 3), xq = (int)(blockIdx.x & 7);
     const int first = a.xcd ? (((xi >> 4) * 8 + xq) << 4) + (xi & 15) : (int)blockIdx.x;          // (subpel_satd_kernel: chunks of 16 workgroups per XCD)
     for (int job = first; job < total; job += gridDim.x)
     {
-        const int l = job < n3 ? 3 : job < n3 + n2 ? 2 : 1;
-        const int b0 = l == 3 ? job : l == 2 ? job - n3 : 4 * (job - n3 - n2);
+        // a 64x64 block is four jobs, one per 32x32 quadrant: every job is ONE staging + 16 tiles per wave (a workgroup that walked the four quadrants itself was
+        // the launch's long pole: a launch is ~180 CTUs, two rounds of workgroups).  A quadrant's sum is even like a tile's, so the halves add up to the block's
+        // entry: atomicAdd into entries the window kernel of the same rows has zeroed (SurfArgs::subpelOff3)
+        const int l = job < 4 * n3 ? 3 : job < 4 * n3 + n2 ? 2 : 1;
+        const int b0 = l == 3 ? job >> 2 : l == 2 ? job - 4 * n3 : 4 * (job - 4 * n3 - n2), quad = l == 3 ? job & 3 : 0;
         const int nb = l == 1 ? (n1 - b0 < 4 ? n1 - b0 : 4) : 1, N = 8 << l;
         const int rowBlocks = a.per[l] * a.blocksX[l];
         __syncthreads();                                                             // the previous job's LDS is no longer read
-        uint32_t acc = 0;
-        for (int quad = 0; quad < (l == 3 ? 4 : 1); quad++)
+        if (tid < 4)
         {
-            if (quad)
-                __syncthreads();
-            if (tid < 4)
+            sp8::Geo g = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            if (tid < nb)
             {
-                sp8::Geo g = { 0, 0, 0, 0, 0, 0, 0, 0 };
-                if (tid < nb)
+                const int b = b0 + tid;
+                g.cr = a.row0 + b / rowBlocks; g.k = b % rowBlocks;
+                const int by = g.cr * a.per[l] + g.k / a.blocksX[l], bx = g.k % a.blocksX[l];
+                g.ok = by < a.blocksY[l];
+                if (g.ok)
                 {
-                    const int b = b0 + tid;
-                    g.cr = a.row0 + b / rowBlocks; g.k = b % rowBlocks;
-                    const int by = g.cr * a.per[l] + g.k / a.blocksX[l], bx = g.k % a.blocksX[l];
-                    g.ok = by < a.blocksY[l];
-                    if (g.ok)
-                    {
-                        const int16_t* org = (const int16_t*)(a.out + (int64_t)g.cr * a.pitch + a.originOff[l]) + 2 * g.k;
-                        g.sx = bx * N + 32 * (quad & 1); g.sy = by * N + 32 * (quad >> 1);
-                        g.x0 = g.sx + org[0] + kWin / 2 - 1; g.y0 = g.sy + org[1] + kWin / 2 - 1;
-                    }
-                }
-                sGeo[tid] = g;
-            }
-            __syncthreads();
-            {
-                // (blocks that do not exist carry the geometry of the picture's first block: valid addresses, nothing of them is kept)
-                const sp8::Geo& gs = sGeo[l == 1 ? wave : 0];
-                const int x0 = __builtin_amdgcn_readfirstlane(gs.x0), y0 = __builtin_amdgcn_readfirstlane(gs.y0);
-                if (l == 1) sp8_stage_ref<16, 64>(a, x0, y0, lane, sRef + wave * sp8::kBlock16);
-                else sp8_stage_ref<32, 256>(a, x0, y0, tid, sRef);
-                if (tid < 64)
-                {
-                    const sp8::Geo& gt = sGeo[l == 1 ? tid >> 4 : 0];
-                    if (gt.ok)
-                    {
-                        if (l == 1) sp8_stage_src<16>(a, gt.sx, gt.sy, tid & 15, sHs + 8 * tid);
-                        else sp8_stage_src<32>(a, gt.sx, gt.sy, tid, sHs + 8 * tid);
-                    }
+                    const int16_t* org = (const int16_t*)(a.out + (int64_t)g.cr * a.pitch + a.originOff[l]) + 2 * g.k;
+                    g.sx = bx * N + 32 * (quad & 1); g.sy = by * N + 32 * (quad >> 1);
+                    g.x0 = g.sx + org[0] + kWin / 2 - 1; g.y0 = g.sy + org[1] + kWin / 2 - 1;
                 }
             }
-            __syncthreads();
-            const sp8::Geo& g = sGeo[l == 1 ? wave : 0];
-            if (g.ok)
+            sGeo[tid] = g;
+        }
+        __syncthreads();
+        {
+            // (blocks that do not exist carry the geometry of the picture's first block: valid addresses, nothing of them is kept)
+            const sp8::Geo& gs = sGeo[l == 1 ? wave : 0];
+            const int x0 = __builtin_amdgcn_readfirstlane(gs.x0), y0 = __builtin_amdgcn_readfirstlane(gs.y0);
+            if (l == 1) sp8_stage_ref<16, 64>(a, x0, y0, lane, sRef + wave * sp8::kBlock16);
+            else sp8_stage_ref<32, 256>(a, x0, y0, tid, sRef);
+            if (tid < 64)
             {
-                const uint8_t* base = phase ? (const uint8_t*)a.planes : (const uint8_t*)a.pic;
-                const int col = (int)(((uintptr_t)base + (int64_t)g.y0 * a.stride + g.x0) & 3) + 1 + (dx >> 2), sh = col & 3;
-                const uint32_t selLo = (uint32_t)sh | 0x0c000c00u | ((uint32_t)(sh + 1) << 16), selHi = (uint32_t)(sh + 2) | 0x0c000c00u | ((uint32_t)(sh + 3) << 16);
-                if (l == 1)
-                    acc = sp8_tiles<16>(sRef + wave * sp8::kBlock16 + phase * sp8::kPlane16 + (1 + (dy >> 2)) * sp8::kPitch16 + (col >> 2), selLo, selHi, sHs + wave * 16 * 8, 0, 16);
-                else
-                    acc += sp8_tiles<32>(sRef + phase * sp8::kPlane32 + (1 + (dy >> 2)) * sp8::kPitch32 + (col >> 2), selLo, selHi, sHs, 16 * wave, 16 * wave + 16);
+                const sp8::Geo& gt = sGeo[l == 1 ? tid >> 4 : 0];
+                if (gt.ok)
+                {
+                    if (l == 1) sp8_stage_src<16>(a, gt.sx, gt.sy, tid & 15, sHs + 8 * tid);
+                    else sp8_stage_src<32>(a, gt.sx, gt.sy, tid, sHs + 8 * tid);
+                }
             }
+        }
+        __syncthreads();
+        const sp8::Geo& g = sGeo[l == 1 ? wave : 0];
+        uint32_t acc = 0;
+        if (g.ok)
+        {
+            // byte alignment of the footprint's first pixel: the planes share one (planeElems and the stride are multiples of 4), the picture has its own allocation
+            const uint8_t* base = phase ? (const uint8_t*)a.planes : (const uint8_t*)a.pic;
+            const int col = (int)(((uintptr_t)base + (int64_t)g.y0 * a.stride + g.x0) & 3) + 1 + (dx >> 2), sh = col & 3;
+            const uint32_t selLo = (uint32_t)sh | 0x0c000c00u | ((uint32_t)(sh + 1) << 16), selHi = (uint32_t)(sh + 2) | 0x0c000c00u | ((uint32_t)(sh + 3) << 16);
+            if (l == 1)
+                acc = sp8_tiles<16>(sRef + wave * sp8::kBlock16 + phase * sp8::kPlane16 + (1 + (dy >> 2)) * sp8::kPitch16 + (col >> 2), selLo, selHi, sHs + wave * 16 * 8, 0, 16);
+            else
+                acc = sp8_tiles<32>(sRef + phase * sp8::kPlane32 + (1 + (dy >> 2)) * sp8::kPitch32 + (col >> 2), selLo, selHi, sHs, 16 * wave, 16 * wave + 16);
         }
         if (l == 1)
         {
-            const sp8::Geo& g = sGeo[wave];
             if (g.ok && lane < X265HIP_SADSURF_SUBPEL)
                 ((uint32_t*)(a.out + (int64_t)g.cr * a.pitch + a.subpelOff[l]))[(int64_t)g.k * X265HIP_SADSURF_SUBPEL + lane] = acc >> 1;
         }
@@ -945,9 +946,13 @@ __global__ __launch_bounds__(256) void subpel_satd_kernel_lds(SubpelArgs a)
         {
             sPart[tid] = acc;
             __syncthreads();
-            const sp8::Geo& g = sGeo[0];
             if (g.ok && tid < X265HIP_SADSURF_SUBPEL)
-                ((uint32_t*)(a.out + (int64_t)g.cr * a.pitch + a.subpelOff[l]))[(int64_t)g.k * X265HIP_SADSURF_SUBPEL + tid] = (sPart[tid] + sPart[64 + tid] + sPart[128 + tid] + sPart[192 + tid]) >> 1;
+            {
+                uint32_t* o = (uint32_t*)(a.out + (int64_t)g.cr * a.pitch + a.subpelOff[l]) + (int64_t)g.k * X265HIP_SADSURF_SUBPEL + tid;
+                const uint32_t sum = (sPart[tid] + sPart[64 + tid] + sPart[128 + tid] + sPart[192 + tid]) >> 1;
+                if (l == 3) atomicAdd(o, sum);
+                else *o = sum;
+            }
         }
     }
 }
@@ -1170,6 +1175,8 @@ static void progress_multi(const std::vector<x265hip_refpic*>& rps)
             a.pitch = lay.pitch;
             for (int l = 0; l < 4; l++) { a.originOff[l] = lay.originOff[l]; a.tableOff[l] = lay.tableOff[l]; a.blocksX[l] = lay.blocksX[l]; }
             a.blocksY0 = lay.blocksY[0];
+            // (8-bit pictures with sub-pel tables: the window kernel zeroes the 64x64 level's entries, which subpel_satd_kernel_lds then adds into)
+            a.subpelOff3 = (first.ss->levels & 16) && rp0->depth == 8 ? lay.subpelOff[3] : -1;
             // the dynamic LDS limit is a per-device attribute of the kernel
             static std::atomic<uint64_t> attrSet{ 0 };
             if (!(attrSet.load() >> dev & 1))
@@ -1222,16 +1229,17 @@ static void progress_multi(const std::vector<x265hip_refpic*>& rps)
                 static const bool ldsForm = !(getenv("X265HIP_SUBPEL_LDS") && !atoi(getenv("X265HIP_SUBPEL_LDS")));
                 if (rp->depth == 8 && ldsForm && rp->stride % 4 == 0 && rp->planeElems % 4 == 0)
                 {
-                    // a workgroup per 64x64 block, per 32x32 block, per four 16x16 blocks (subpel_satd_kernel_lds); a multiple of 128 for the XCD order
+                    // a workgroup per 32x32 quadrant of a 64x64 block, per 32x32 block, per four 16x16 blocks (subpel_satd_kernel_lds); a multiple of 128 for the XCD order
                     const int blocks1 = sa.jobs[1] / X265HIP_SADSURF_SUBPEL, blocks2 = (sa.jobs[2] - sa.jobs[1]) / X265HIP_SADSURF_SUBPEL, blocks3 = (sa.jobs[3] - sa.jobs[2]) / X265HIP_SADSURF_SUBPEL;
-                    const int groups = blocks3 + blocks2 + (blocks1 + 3) / 4;
+                    const int groups = 4 * blocks3 + blocks2 + (blocks1 + 3) / 4;
+                    // (the entries of the 64x64 blocks are sums over four workgroups: the window kernel in front of this launch has zeroed them, a.subpelOff3)
                     hipLaunchKernelGGL(subpel_satd_kernel_lds, dim3(((groups < 16384 ? groups : 16384) + 127) & ~127), dim3(256), 0, st, sa);
                 }
                 else if (rp->depth == 8)
                     hipLaunchKernelGGL(subpel_satd_kernel<uint8_t>, dim3(grid), dim3(256), 0, st, sa);
                 else
                     hipLaunchKernelGGL(subpel_satd_kernel<uint16_t>, dim3(grid), dim3(256), 0, st, sa);
-                bad = hipGetLastError() != hipSuccess;
+                bad = bad || hipGetLastError() != hipSuccess;
                 // satd W x H = 2 W H B per call
                 span2.bytes += (uint64_t)sa.rows * lay.ctuCols * 3 * 64 * 64 * X265HIP_SADSURF_SUBPEL * 2 * rp->B;
             }
