@@ -686,7 +686,7 @@ def test_bound_encoder_intra_scan_jobs_stay_byte_identical(tmp_path, extra, env)
 
 @pytest.mark.parametrize("extra", [[], ["--bframes", "0", "--rd", "4"], ["--preset", "slow"]], ids=lambda e: "-".join(x.strip("-") for x in e) or "medium")
 def test_bound_encoder_inter_candidate_jobs_ahead_stay_byte_identical(tmp_path, extra):
-    """X265HIP_CUSERVE_SPEC_INTER=1 (off by default): the 2Nx2N inter candidate's job leaves when Search::predInterSearch returns and is adopted by
+    """X265HIP_CUSERVE_SPEC_INTER=1 (the default since round 6's second session): the 2Nx2N inter candidate's job leaves when Search::predInterSearch returns and is adopted by
     encodeResAndCalcRdInterCU sample for sample (analysis.cpp:1421-1611).  Every such job must be the one wanted; with rectangular partitions (preset slow)
     none may leave."""
     import re, subprocess, sys

@@ -111,8 +111,9 @@ __attribute__((tls_model("initial-exec"))) thread_local Job t_job;
 __attribute__((tls_model("initial-exec"))) thread_local int t_inEncodeRes = 0;
 EncoderPrimitives g_prev;            // the table as it was when the cuserve slots were installed (C functions + the psy lookups of x265_hip_srcplanes.cpp)
 bool g_slots_installed = false;
-bool g_specInter = false;            // X265HIP_CUSERVE_SPEC_INTER=1: the 2Nx2N inter candidate's job leaves when predInterSearch returns.  Off: every such job is adopted and the
-                                     // host's wait cycles fall 22 %, but over twelve interleaved rounds fps was 0.5 lower with it than without (profiles/r05_v1_spec_inter_ab.txt)
+bool g_specInter = true;             // X265HIP_CUSERVE_SPEC_INTER=0: the 2Nx2N inter candidate's job does NOT leave when predInterSearch returns.  Every such job is adopted, the host's
+                                     // wait cycles fall by a fifth.  Round 5 (one-wave device chain, -O2 host) measured no fps for it and left it off; on round 6's final tree, at the
+                                     // bench's thread arguments: +1.3 % / +1.9 % fps and -2 % CPU seconds over 2 x 8 interleaved rounds of 240 frames (profiles/r06_v2_spec_inter_ab.txt)
 bool g_spec = true;                  // X265HIP_CUSERVE_SPEC=0: no job is submitted ahead of its scope
 int g_serveDist = 1;                 // X265HIP_CUSERVE_DIST=0: transforms only; 1: + the tree's distortions; 2: + the CU's final sse_pp / psy cost; 3 (default): + the body's sub_ps / add_ps calls nobody reads any more are not run
 __attribute__((tls_model("initial-exec"))) thread_local int t_hint = -1;           // where this thread looks first
