@@ -114,6 +114,7 @@ bool g_slots_installed = false;
 bool g_specInter = true;             // X265HIP_CUSERVE_SPEC_INTER=0: the 2Nx2N inter candidate's job does NOT leave when predInterSearch returns.  Every such job is adopted, the host's
                                      // wait cycles fall by a fifth.  Round 5 (one-wave device chain, -O2 host) measured no fps for it and left it off; on round 6's final tree, at the
                                      // bench's thread arguments: +1.3 % / +1.9 % fps and -2 % CPU seconds over 2 x 8 interleaved rounds of 240 frames (profiles/r06_v2_spec_inter_ab.txt)
+std::atomic<uint64_t> g_lumaWait[2][2][2];      // luma forward waits that spun: [CU 32 / 64][the job's first luma unit / a later one][count / cycles] (report)
 bool g_spec = true;                  // X265HIP_CUSERVE_SPEC=0: no job is submitted ahead of its scope
 int g_serveDist = 1;                 // X265HIP_CUSERVE_DIST=0: transforms only; 1: + the tree's distortions; 2: + the CU's final sse_pp / psy cost; 3 (default): + the body's sub_ps / add_ps calls nobody reads any more are not run
 __attribute__((tls_model("initial-exec"))) thread_local int t_hint = -1;           // where this thread looks first
@@ -169,6 +170,12 @@ void report()
             n += snprintf(line + n, sizeof(line) - n, "%s%s %llu x %.0f", k ? ", " : "", site[k], (unsigned long long)ws, ws ? (double)cy / ws : 0.0);
         }
         if (w) fprintf(stderr, "x265hip: cuserve: waits by what was waited for (count x cycles): %s\n", line);
+        if (w && (g_lumaWait[0][0][0] || g_lumaWait[1][0][0]))
+            fprintf(stderr, "x265hip: cuserve: luma forward waits by CU size and unit (count x cycles): 32x32 CU %llu x %.0f; 64x64 CU first unit %llu x %.0f, later units %llu x %.0f\n",
+                    (unsigned long long)(g_lumaWait[0][0][0] + g_lumaWait[0][1][0]),
+                    (double)(g_lumaWait[0][0][1] + g_lumaWait[0][1][1]) / (double)(g_lumaWait[0][0][0] + g_lumaWait[0][1][0] ? g_lumaWait[0][0][0] + g_lumaWait[0][1][0] : 1),
+                    (unsigned long long)g_lumaWait[1][0][0], (double)g_lumaWait[1][0][1] / (double)(g_lumaWait[1][0][0] ? g_lumaWait[1][0][0].load() : 1),
+                    (unsigned long long)g_lumaWait[1][1][0], (double)g_lumaWait[1][1][1] / (double)(g_lumaWait[1][1][0] ? g_lumaWait[1][1][0].load() : 1));
     }
     if (spc)
         fprintf(stderr, "x265hip: cuserve: %llu jobs left ahead of their scope, when the merge candidate's skip evaluation started; %llu of them were the job their "
@@ -1264,8 +1271,16 @@ uint32_t Quant::transformNxN(const CUData& cu, const pixel* fenc, uint32_t fencS
                 }
                 return numSigQ;
             }
+            const bool lumaSpin = ttype == TEXT_LUMA && __atomic_load_n(&j.units[u].ready, __ATOMIC_ACQUIRE) != j.seq;
+            const uint64_t w0 = lumaSpin ? __builtin_ia32_rdtsc() : 0;
             if (wait_word(j, &j.units[u].ready, ttype == TEXT_LUMA ? 0 : 1))
             {
+                if (lumaSpin)
+                {
+                    std::atomic<uint64_t>* c = g_lumaWait[j.hdr.log2CUSize >= 6][u != 0];
+                    c[0].fetch_add(1, std::memory_order_relaxed);
+                    c[1].fetch_add(__builtin_ia32_rdtsc() - w0, std::memory_order_relaxed);
+                }
                 const int n2 = 1 << (2 * log2TrSize);
                 memcpy(coeff, j.levels + eo, sizeof(coeff_t) * n2);
                 const uint32_t numSig = j.units[u].numSig;
