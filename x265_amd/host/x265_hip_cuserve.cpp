@@ -59,7 +59,7 @@ std::atomic<bool> g_dead(false); // the device failed once: every later CU is co
 std::atomic<uint64_t> g_cycles[18][2], g_calls[18][2];
 __attribute__((tls_model("initial-exec"))) thread_local int t_inRqt = 0;
 
-struct alignas(64) Counters { std::atomic<uint64_t> jobs, fwd, inv, fwdMiss, invMiss, waitCycles, waits, skipped, dist, psyHit, psyAhead, psyCoded, deadSub, deadAdd, lateSub, lateAdd, siteWaits[6], siteCycles[6], spec, specHit, psySkip, specInter, specInterHit, invJobs, invDropped; };
+struct alignas(64) Counters { std::atomic<uint64_t> jobs, fwd, inv, fwdMiss, invMiss, waitCycles, waits, skipped, dist, psyHit, psyAhead, psyCoded, deadSub, deadAdd, lateSub, lateAdd, siteWaits[6], siteCycles[6], lumaHist[24], spec, specHit, psySkip, specInter, specInterHit, invJobs, invDropped; };
 Counters g_count[64];
 std::atomic<int> g_nextShard(0);
 __attribute__((tls_model("initial-exec"))) thread_local int t_shard = -1;
@@ -170,6 +170,21 @@ void report()
             n += snprintf(line + n, sizeof(line) - n, "%s%s %llu x %.0f", k ? ", " : "", site[k], (unsigned long long)ws, ws ? (double)cy / ws : 0.0);
         }
         if (w) fprintf(stderr, "x265hip: cuserve: waits by what was waited for (count x cycles): %s\n", line);
+        if (w)
+        {
+            // the same waits by length: floor(log2(cycles)) -> count (a waiter that loses its CPU meanwhile — more runnable threads than CPUs, the quota's throttling — shows up
+            // in the top buckets: time it did not spend spinning)
+            char hl[512];
+            int hn = 0;
+            for (int b = 8; b < 24; b++)
+            {
+                uint64_t cnt = 0;
+                for (int i = 0; i < 64; i++) cnt += g_count[i].lumaHist[b];
+                if (b == 8) for (int bb = 0; bb < 8; bb++) for (int i = 0; i < 64; i++) cnt += g_count[i].lumaHist[bb];
+                hn += snprintf(hl + hn, sizeof(hl) - hn, " 2^%d:%llu", b, (unsigned long long)cnt);
+            }
+            fprintf(stderr, "x265hip: cuserve: luma forward waits by length (floor(log2(cycles)) : count):%s\n", hl);
+        }
         if (w && (g_lumaWait[0][0][0] || g_lumaWait[1][0][0]))
             fprintf(stderr, "x265hip: cuserve: luma forward waits by CU size and unit (count x cycles): 32x32 CU %llu x %.0f; 64x64 CU first unit %llu x %.0f, later units %llu x %.0f\n",
                     (unsigned long long)(g_lumaWait[0][0][0] + g_lumaWait[0][1][0]),
@@ -410,6 +425,7 @@ inline bool wait_word(Job& j, const uint32_t* ready, int site)
     c.waits.fetch_add(1, std::memory_order_relaxed);
     c.siteCycles[site].fetch_add(dt, std::memory_order_relaxed);
     c.siteWaits[site].fetch_add(1, std::memory_order_relaxed);
+    if (!site) { int b = 63 - __builtin_clzll(dt | 1); c.lumaHist[b > 23 ? 23 : b].fetch_add(1, std::memory_order_relaxed); }
     return true;
 }
 
