@@ -23,6 +23,7 @@
 #include "refpic.h"
 #include "tiles.h"
 #include <cstring>
+#include <type_traits>
 #include <map>
 #include <utility>
 
@@ -561,6 +562,8 @@ __global__ __launch_bounds__(1024) void sadsurf_ctu16_kernel(SurfArgs a)
     const int cy = jb.row0 + rowIn;
     const int x0 = cx * 64, y0 = cy * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.subpelOff3 >= 0 && cx < a.blocksX[3] && tid < X265HIP_SADSURF_SUBPEL)          // (as in the 8-bit kernel: 10-bit pictures' tables are summed over quadrant jobs too)
+        ((uint32_t*)(jb.out + (int64_t)cy * a.pitch + a.subpelOff3))[(int64_t)cx * X265HIP_SADSURF_SUBPEL + tid] = 0;
     const uint16_t* src = (const uint16_t*)jb.src;
     const uint16_t* ref = (const uint16_t*)jb.ref;
     const int64_t srcPitch = jb.srcPitch / 2;                    // samples
@@ -758,9 +761,9 @@ __global__ __launch_bounds__(256) void subpel_satd_kernel(SubpelArgs a)
 // atomicAdd; the window kernel zeroes those entries), the 32x32 blocks (the four waves take 16 tiles each), the 16x16 blocks four to a workgroup (a block per
 // wave).  X265HIP_SUBPEL_LDS=0: the first form.
 namespace sp8 {
-constexpr int kPitch16 = 16 / 4 + 1, kPlane16 = 17 * kPitch16, kBlock16 = 16 * kPlane16;      // dwords
-constexpr int kPitch32 = 32 / 4 + 1, kPlane32 = 33 * kPitch32, kBlock32 = 16 * kPlane32;
-constexpr int kRefDw = (4 * kBlock16 > kBlock32 ? 4 * kBlock16 : kBlock32) + 4;
+// geometry of a staged block, in dwords: B bytes per pixel, Q x Q block -> Q + 1 rows of Q + 1 pixels starting at any pixel: whole dwords, Q B / 4 + 1 per row
+template <int B, int Q> struct Lay { static constexpr int pitch = Q * B / 4 + 1, plane = (Q + 1) * pitch, block = 16 * plane; };
+template <int B> constexpr int ref_dw() { return (4 * Lay<B, 16>::block > Lay<B, 32>::block ? 4 * Lay<B, 16>::block : Lay<B, 32>::block) + 4; }
 struct Geo { int ok, x0, y0, sx, sy, k, cr, pad; };      // footprint's first pixel (x0, y0) in the reference, the block's (quadrant's) first pixel (sx, sy) in the source
 }
 
@@ -784,19 +787,19 @@ __device__ __forceinline__ void pk_hadamard4x4(s2v a[4], s2v b[4])
     }
 }
 
-// stage ONE block's footprint (Q x Q block) with a group of T threads (a wave or the workgroup), g = the thread's number in the group; (x0, y0) is uniform over
-// the group, so a load is a scalar base + a 32-bit offset.  Every thread issues ALL its loads before the first LDS store (a load -> wait -> store loop has one
-// 4-byte load in flight per thread: twenty round trips to L2 per staging).  The picture (plane 0) has an allocation of its own; planes 1..15 follow one another.
-template <int Q, int T>
+// stage ONE block's footprint (Q x Q block, B bytes per pixel) with a group of T threads (a wave or the workgroup), g = the thread's number in the group; (x0, y0) is
+// uniform over the group, so a load is a scalar base + a 32-bit offset.  Every thread issues ALL its loads before the first LDS store (a load -> wait -> store loop
+// has one 4-byte load in flight per thread: twenty round trips to L2 per staging).  The picture (plane 0) has an allocation of its own; planes 1..15 follow one another.
+template <int B, int Q, int T>
 __device__ __forceinline__ void sp8_stage_ref(const SubpelArgs& a, int x0, int y0, int g, uint32_t* dst)
 {
-    constexpr int pitch = Q / 4 + 1, planeDw = (Q + 1) * pitch, n15 = 15 * planeDw, it0 = (planeDw + T - 1) / T, it15 = (n15 + T - 1) / T;
-    const int64_t first = (int64_t)y0 * a.stride + x0;
+    constexpr int pitch = sp8::Lay<B, Q>::pitch, planeDw = sp8::Lay<B, Q>::plane, n15 = 15 * planeDw, it0 = (planeDw + T - 1) / T, it15 = (n15 + T - 1) / T;
+    const int64_t first = ((int64_t)y0 * a.stride + x0) * B;
     // buffer loads: the 128-bit descriptor of a group-uniform base in scalar registers + ONE 32-bit offset register per load (a flat address is two, and the
     // compiler builds all of a batch's addresses before its first load: 157 registers with global_load, three waves per SIMD)
     const __amdgpu_buffer_rsrc_t d0 = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)a.pic + (uintptr_t)first) & ~(uintptr_t)3), 0, (int)0xfffffff0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t d1 = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)a.planes + (uintptr_t)a.planeElems + (uintptr_t)first) & ~(uintptr_t)3), 0, (int)0xfffffff0u, 0x00020000);
-    const uint32_t stride = (uint32_t)a.stride, planeElems = (uint32_t)a.planeElems;
+    const __amdgpu_buffer_rsrc_t d1 = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)a.planes + (uintptr_t)(a.planeElems * B) + (uintptr_t)first) & ~(uintptr_t)3), 0, (int)0xfffffff0u, 0x00020000);
+    const uint32_t stride = (uint32_t)a.stride * B, planeBytes = (uint32_t)a.planeElems * B;
     uint32_t v0[it0], v1[it15];
 #pragma unroll
     for (int k = 0; k < it0; k++)
@@ -808,7 +811,7 @@ __device__ __forceinline__ void sp8_stage_ref(const SubpelArgs& a, int x0, int y
     for (int k = 0; k < it15; k++)
     {
         const int i0 = g + T * k, i = i0 < n15 ? i0 : n15 - 1, pp = i / planeDw, r1 = i - pp * planeDw, r = r1 / pitch, j = r1 - r * pitch;
-        v1[k] = __builtin_amdgcn_raw_buffer_load_b32(d1, (int)((uint32_t)pp * planeElems + (uint32_t)r * stride + 4u * (uint32_t)j), 0, 0);
+        v1[k] = __builtin_amdgcn_raw_buffer_load_b32(d1, (int)((uint32_t)pp * planeBytes + (uint32_t)r * stride + 4u * (uint32_t)j), 0, 0);
     }
 #pragma unroll
     for (int k = 0; k < it0; k++)
@@ -818,40 +821,53 @@ __device__ __forceinline__ void sp8_stage_ref(const SubpelArgs& a, int x0, int y
         if (g + T * k < n15) dst[planeDw + g + T * k] = v1[k];
 }
 // the transform of one source tile per thread: tile t of the Q x Q block whose first pixel is (sx, sy)
-template <int Q>
+template <typename P, int Q>
 __device__ __forceinline__ void sp8_stage_src(const SubpelArgs& a, int sx, int sy, int t, uint32_t* o)
 {
+    typedef typename std::conditional<sizeof(P) == 1, uint32_t, uint2>::type Row;
     constexpr int TX = Q / 4;
     const int ty = t / TX, tx = t - ty * TX;
-    const uint8_t* s = (const uint8_t*)a.src + (int64_t)(sy + 4 * ty) * a.srcPitch + sx + 4 * tx;
+    const P* s = (const P*)((const char*)a.src + (int64_t)(sy + 4 * ty) * a.srcPitch) + sx + 4 * tx;
+    const int64_t srcStride = a.srcPitch / (int64_t)sizeof(P);
     s2v sa[4], sb[4];
 #pragma unroll
     for (int y = 0; y < 4; y++)
-        Pk16<uint8_t>::split(ld_global_unaligned<uint32_t>(s + (int64_t)y * a.srcPitch), sa[y], sb[y]);
+        Pk16<P>::split(ld_global_unaligned<Row>(s + y * srcStride), sa[y], sb[y]);
     sa[0] = as_s2(as_u(sa[0]) | 0x4000u);
     pk_hadamard4x4(sa, sb);
     *(uint4*)o = make_uint4(as_u(sa[0]), as_u(sa[1]), as_u(sa[2]), as_u(sa[3]));
     *(uint4*)(o + 4) = make_uint4(as_u(sb[0]), as_u(sb[1]), as_u(sb[2]), as_u(sb[3]));
 }
 
-// sum over tiles [t0, t1) of a staged block of sum |M s - M r| for this lane's vector: `ref` = the lane's first dword in the staged footprint
-template <int Q>
+// sum over tiles [t0, t1) of a staged block of sum |M s - M r| for this lane's vector: `ref` = the lane's first dword in the staged footprint.  8 bit: a row of
+// four pixels lies in two dwords, (selLo, selHi) pick its bytes into 16-bit pairs.  16 bit: in three, the pairs are dwords (d0, d1) or — an odd first pixel —
+// the middles of (d0, d1) and (d1, d2): ONE selector (selLo) for both v_perm_b32
+template <int B, int Q>
 __device__ __forceinline__ uint32_t sp8_tiles(const uint32_t* ref, uint32_t selLo, uint32_t selHi, const uint32_t* hs, int t0, int t1)
 {
-    constexpr int pitch = Q / 4 + 1, TX = Q / 4;
+    constexpr int pitch = sp8::Lay<B, Q>::pitch, TX = Q / 4;
     uint32_t acc = 0;
 #pragma unroll 2
     for (int t = t0; t < t1; t++)
     {
         const int ty = t / TX, tx = t - ty * TX;
-        const uint32_t* p = ref + 4 * ty * pitch + tx;
+        const uint32_t* p = ref + 4 * ty * pitch + tx * B;
         s2v ra[4], rb[4];
 #pragma unroll
         for (int y = 0; y < 4; y++)
         {
             const uint32_t d0 = p[y * pitch], d1 = p[y * pitch + 1];
-            ra[y] = as_s2(__builtin_amdgcn_perm(d1, d0, selLo));
-            rb[y] = as_s2(__builtin_amdgcn_perm(d1, d0, selHi));
+            if (B == 1)
+            {
+                ra[y] = as_s2(__builtin_amdgcn_perm(d1, d0, selLo));
+                rb[y] = as_s2(__builtin_amdgcn_perm(d1, d0, selHi));
+            }
+            else
+            {
+                const uint32_t d2 = p[y * pitch + 2];
+                ra[y] = as_s2(__builtin_amdgcn_perm(d1, d0, selLo));
+                rb[y] = as_s2(__builtin_amdgcn_perm(d2, d1, selLo));
+            }
         }
         ra[0] = as_s2(as_u(ra[0]) | 0x4000u);
         pk_hadamard4x4(ra, rb);
@@ -864,9 +880,14 @@ __device__ __forceinline__ uint32_t sp8_tiles(const uint32_t* ref, uint32_t selL
     return acc;
 }
 
+// P = uint8_t: 8-bit pictures; uint16_t: 10-bit pictures (|coefficients| <= 16 * 1023 = 16 368: inside 16 bits with the bias; 12-bit pictures keep the first form)
+template <typename P>
 __global__ __launch_bounds__(256) void subpel_satd_kernel_lds(SubpelArgs a)
 {
-    __shared__ uint32_t sRef[sp8::kRefDw];
+    constexpr int B = (int)sizeof(P);
+    typedef sp8::Lay<B, 16> L16;
+    typedef sp8::Lay<B, 32> L32;
+    __shared__ uint32_t sRef[sp8::ref_dw<B>()];
     __shared__ __attribute__((aligned(16))) uint32_t sHs[64 * 8];
     __shared__ uint32_t sPart[4 * 64];
     __shared__ sp8::Geo sGeo[4];
@@ -911,15 +932,15 @@ __global__ __launch_bounds__(256) void subpel_satd_kernel_lds(SubpelArgs a)
             // (blocks that do not exist carry the geometry of the picture's first block: valid addresses, nothing of them is kept)
             const sp8::Geo& gs = sGeo[l == 1 ? wave : 0];
             const int x0 = __builtin_amdgcn_readfirstlane(gs.x0), y0 = __builtin_amdgcn_readfirstlane(gs.y0);
-            if (l == 1) sp8_stage_ref<16, 64>(a, x0, y0, lane, sRef + wave * sp8::kBlock16);
-            else sp8_stage_ref<32, 256>(a, x0, y0, tid, sRef);
+            if (l == 1) sp8_stage_ref<B, 16, 64>(a, x0, y0, lane, sRef + wave * L16::block);
+            else sp8_stage_ref<B, 32, 256>(a, x0, y0, tid, sRef);
             if (tid < 64)
             {
                 const sp8::Geo& gt = sGeo[l == 1 ? tid >> 4 : 0];
                 if (gt.ok)
                 {
-                    if (l == 1) sp8_stage_src<16>(a, gt.sx, gt.sy, tid & 15, sHs + 8 * tid);
-                    else sp8_stage_src<32>(a, gt.sx, gt.sy, tid, sHs + 8 * tid);
+                    if (l == 1) sp8_stage_src<P, 16>(a, gt.sx, gt.sy, tid & 15, sHs + 8 * tid);
+                    else sp8_stage_src<P, 32>(a, gt.sx, gt.sy, tid, sHs + 8 * tid);
                 }
             }
         }
@@ -928,14 +949,18 @@ __global__ __launch_bounds__(256) void subpel_satd_kernel_lds(SubpelArgs a)
         uint32_t acc = 0;
         if (g.ok)
         {
-            // byte alignment of the footprint's first pixel: the planes share one (planeElems and the stride are multiples of 4), the picture has its own allocation
-            const uint8_t* base = phase ? (const uint8_t*)a.planes : (const uint8_t*)a.pic;
-            const int col = (int)(((uintptr_t)base + (int64_t)g.y0 * a.stride + g.x0) & 3) + 1 + (dx >> 2), sh = col & 3;
-            const uint32_t selLo = (uint32_t)sh | 0x0c000c00u | ((uint32_t)(sh + 1) << 16), selHi = (uint32_t)(sh + 2) | 0x0c000c00u | ((uint32_t)(sh + 3) << 16);
+            // alignment of the footprint's first pixel in its dword: the planes share one (planeElems and the stride are multiples of 4 bytes), the picture has its own
+            // allocation.  col = the lane's first pixel in the staged row, counted in pixels from the row's first dword
+            const uintptr_t base = phase ? (uintptr_t)a.planes : (uintptr_t)a.pic;
+            const int col = (int)(((base + (uintptr_t)(((int64_t)g.y0 * a.stride + g.x0) * B)) & 3) / B) + 1 + (dx >> 2);
+            constexpr int perDw = 4 / B;
+            const int sh = col & (perDw - 1), dw = col / perDw;
+            const uint32_t selLo = B == 1 ? ((uint32_t)sh | 0x0c000c00u | ((uint32_t)(sh + 1) << 16)) : (sh ? 0x05040302u : 0x03020100u);
+            const uint32_t selHi = (uint32_t)(sh + 2) | 0x0c000c00u | ((uint32_t)(sh + 3) << 16);
             if (l == 1)
-                acc = sp8_tiles<16>(sRef + wave * sp8::kBlock16 + phase * sp8::kPlane16 + (1 + (dy >> 2)) * sp8::kPitch16 + (col >> 2), selLo, selHi, sHs + wave * 16 * 8, 0, 16);
+                acc = sp8_tiles<B, 16>(sRef + wave * L16::block + phase * L16::plane + (1 + (dy >> 2)) * L16::pitch + dw, selLo, selHi, sHs + wave * 16 * 8, 0, 16);
             else
-                acc = sp8_tiles<32>(sRef + phase * sp8::kPlane32 + (1 + (dy >> 2)) * sp8::kPitch32 + (col >> 2), selLo, selHi, sHs, 16 * wave, 16 * wave + 16);
+                acc = sp8_tiles<B, 32>(sRef + phase * L32::plane + (1 + (dy >> 2)) * L32::pitch + dw, selLo, selHi, sHs, 16 * wave, 16 * wave + 16);
         }
         if (l == 1)
         {
@@ -1175,8 +1200,8 @@ static void progress_multi(const std::vector<x265hip_refpic*>& rps)
             a.pitch = lay.pitch;
             for (int l = 0; l < 4; l++) { a.originOff[l] = lay.originOff[l]; a.tableOff[l] = lay.tableOff[l]; a.blocksX[l] = lay.blocksX[l]; }
             a.blocksY0 = lay.blocksY[0];
-            // (8-bit pictures with sub-pel tables: the window kernel zeroes the 64x64 level's entries, which subpel_satd_kernel_lds then adds into)
-            a.subpelOff3 = (first.ss->levels & 16) && rp0->depth == 8 ? lay.subpelOff[3] : -1;
+            // (8- and 10-bit pictures with sub-pel tables: the window kernel zeroes the 64x64 level's entries, which subpel_satd_kernel_lds then adds into)
+            a.subpelOff3 = (first.ss->levels & 16) && (rp0->depth == 8 || rp0->depth == 10) ? lay.subpelOff[3] : -1;
             // the dynamic LDS limit is a per-device attribute of the kernel
             static std::atomic<uint64_t> attrSet{ 0 };
             if (!(attrSet.load() >> dev & 1))
@@ -1227,13 +1252,16 @@ static void progress_multi(const std::vector<x265hip_refpic*>& rps)
                 sa.xcd = xcdOrder ? 1 : 0;
                 const int grid = ((waves / 4 + 1 < 4096 ? waves / 4 + 1 : 4096) + 127) & ~127;
                 static const bool ldsForm = !(getenv("X265HIP_SUBPEL_LDS") && !atoi(getenv("X265HIP_SUBPEL_LDS")));
-                if (rp->depth == 8 && ldsForm && rp->stride % 4 == 0 && rp->planeElems % 4 == 0)
+                if ((rp->depth == 8 || rp->depth == 10) && ldsForm && rp->stride * rp->B % 4 == 0 && rp->planeElems * rp->B % 4 == 0)
                 {
                     // a workgroup per 32x32 quadrant of a 64x64 block, per 32x32 block, per four 16x16 blocks (subpel_satd_kernel_lds); a multiple of 128 for the XCD order
                     const int blocks1 = sa.jobs[1] / X265HIP_SADSURF_SUBPEL, blocks2 = (sa.jobs[2] - sa.jobs[1]) / X265HIP_SADSURF_SUBPEL, blocks3 = (sa.jobs[3] - sa.jobs[2]) / X265HIP_SADSURF_SUBPEL;
                     const int groups = 4 * blocks3 + blocks2 + (blocks1 + 3) / 4;
                     // (the entries of the 64x64 blocks are sums over four workgroups: the window kernel in front of this launch has zeroed them, a.subpelOff3)
-                    hipLaunchKernelGGL(subpel_satd_kernel_lds, dim3(((groups < 16384 ? groups : 16384) + 127) & ~127), dim3(256), 0, st, sa);
+                    if (rp->depth == 8)
+                        hipLaunchKernelGGL(subpel_satd_kernel_lds<uint8_t>, dim3(((groups < 16384 ? groups : 16384) + 127) & ~127), dim3(256), 0, st, sa);
+                    else
+                        hipLaunchKernelGGL(subpel_satd_kernel_lds<uint16_t>, dim3(((groups < 16384 ? groups : 16384) + 127) & ~127), dim3(256), 0, st, sa);
                 }
                 else if (rp->depth == 8)
                     hipLaunchKernelGGL(subpel_satd_kernel<uint8_t>, dim3(grid), dim3(256), 0, st, sa);
