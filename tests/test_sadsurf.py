@@ -265,14 +265,14 @@ def test_device_subpel_tables_match_restatement(case):
 
 @pytest.mark.gpu
 def test_device_subpel_tables_first_form_at_8_bit():
-    """8-bit pictures take subpel_satd_kernel_lds (round 6); the first form, subpel_satd_kernel<uint8_t>, stays reachable (X265HIP_SUBPEL_LDS=0, strides that are no
-    multiple of 4) and stays pinned: the 8-bit cases of the test above in a process of their own with the switch set (the library reads it once)."""
+    """8- and 10-bit pictures take subpel_satd_kernel_lds (round 6); the first form, subpel_satd_kernel<uint8_t / uint16_t at 10 bit>, stays reachable (X265HIP_SUBPEL_LDS=0, strides that are no
+    multiple of 4) and stays pinned: the 8- and 10-bit cases of the test above in a process of their own with the switch set (the library reads it once)."""
     import subprocess
     import sys
     env = dict(os.environ, X265HIP_SUBPEL_LDS="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "test_device_subpel_tables_match_restatement and (case0 or case1)",
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k", "test_device_subpel_tables_match_restatement and (case0 or case1 or case2)",
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and "3 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_bound_encoder_serves_subpel_candidates_from_the_tables(tmp_path):
