@@ -28,6 +28,9 @@ ENCODES = {
                      name="BASELINE configs[2]: 3840x2160 preset slow --me star --merange 57"),
     "configs3": dict(res="3840x2160", bits=10, preset="slower", extra=["--rd", "6"], frames=8, input_depth=10,
                      name="BASELINE configs[3]: 3840x2160 Main10 preset slower --rd 6"),
+    # (configs[4] names eight GPUs; this is its picture size and preset on ONE: the single-GPU point of that shape — bench.py --gpus N carries the N-GPU form)
+    "configs4": dict(res="7680x4320", bits=8, preset="medium", extra=["--me", "hex"], frames=8, input_depth=8,
+                     name="BASELINE configs[4]'s shape on one GPU: 7680x4320 preset medium --me hex"),
 }
 
 
