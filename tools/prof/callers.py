@@ -16,7 +16,7 @@ maps = data[:i].decode(errors="replace").splitlines()
 n = (len(data) - i - 4) // 8
 pcs = struct.unpack("<%dQ" % n, data[i + 4:i + 4 + n * 8])
 st = open(sys.argv[1] + ".stacks", "rb").read()
-DEPTH = 10
+DEPTH = 24
 ns = len(st) // (8 * DEPTH)
 stacks = struct.unpack("<%dQ" % (ns * DEPTH), st[:ns * DEPTH * 8])
 regions = []
@@ -85,6 +85,19 @@ for c, v in chains.items():
     first[who] += v
 print("by first caller outside the pattern:")
 for c, v in first.most_common(20):
+    print("%5d  %5.1f %%  %s" % (v, 100.0 * v / max(1, hits), c))
+# by the first frame outside the runtime's own libraries (libhsa, libamdhip, libc, the thunk): whose call the matched leaf works for; "(runtime thread)" when the
+# whole stack is the runtime's (its event / signal threads)
+rt = re.compile(r"libhsa|libamdhip|libc\.so|libhsakmt|libdrm|\[anon\]|\?$|^\?")
+owner = collections.Counter()
+for k in range(min(n, ns)):
+    if not pat.search(name_of(pcs[k])):
+        continue
+    fr = [name_of(x) for x in stacks[k * DEPTH:(k + 1) * DEPTH] if x]
+    who = next((f for f in fr if not rt.search(f)), "(runtime thread)")
+    owner[name_of(pcs[k]).split("[")[0][:40] + "  <=  " + who] += 1
+print("leaf  <=  first frame outside the runtime libraries:")
+for c, v in owner.most_common(25):
     print("%5d  %5.1f %%  %s" % (v, 100.0 * v / max(1, hits), c))
 print("call chains:")
 for c, v in chains.most_common(top):

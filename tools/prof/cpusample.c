@@ -21,7 +21,7 @@ static uint64_t* g_pc;
 static volatile uint32_t g_n;
 static const char* g_out;
 /* X265HIP_CPUSAMPLE_STACK=1: 10 return addresses per sample as well (backtrace(); file <out>.stacks): who calls the ioctls? */
-#define DEPTH 10
+#define DEPTH 24
 static uint64_t* g_stack;
 static int g_wantStack;
 
